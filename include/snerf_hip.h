@@ -1,0 +1,128 @@
+/* libsnerf_hip -- C ABI of the MI355X (gfx950) volumetric-render hot path.
+ *
+ * Drop-in boundary for the S-NeRF background renderer.
+ * The reference has exactly one native interface -- the pybind module of
+ * s-nerfpp/zipnerf/gridencoder (src/bindings.cpp:5-9, src/gridencoder.h:12-15)
+ * -- and otherwise runs PyTorch eager ops; every entry point below names the
+ * reference function (file:line under /root/reference) it replaces.
+ *
+ * Conventions
+ *   - plain C: raw DEVICE pointers, explicit sizes/strides (in elements),
+ *     `stream` is a hipStream_t passed as void* (0 = default stream);
+ *   - the caller allocates everything, the callee writes in place, nothing is
+ *     returned but a status: 0 ok, 1 bad argument, 2 launch failure; no
+ *     exceptions cross the ABI, no hidden global state, thread-safe per stream;
+ *   - `dtype`: 0 = fp32 activations/weights (exact-parity mode, fp32 MFMA),
+ *     1 = bf16 activations/weights with fp32 accumulation;
+ *   - all launches are asynchronous on `stream`.
+ */
+#ifndef SNERF_HIP_H
+#define SNERF_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SNERF_DT_F32 0
+#define SNERF_DT_BF16 1
+#define SNERF_ACT_NONE 0
+#define SNERF_ACT_RELU 1
+#define SNERF_ACT_MASK 2 /* y = aux > 0 ? y : 0 : ReLU backward fused into the data-gradient GEMM */
+
+int snerf_version(void);
+
+/* ---- tiny-MLP layers (MFMA GEMMs) ------------------------------------------------------------
+ * Y[M, n_store] = act(A[M,K] . W[N,K]^T + bias).  Replaces nn.Linear(+ReLU):
+ *   s-nerf/model/models.py:200-214 (DenseBlock), :232-255 (MLP), :307-315 (proposal),
+ *   s-nerf/model/run_nerf_helpers.py:86-126 (NeRF), called through run_network :460-474.
+ * W is the packed weight [N (multiple of 128), K] in `dtype`; K a multiple of 64 (bf16) / 32 (fp32)
+ * with zero padding; lda/ldw multiples of 8/4; Y is `dtype` or fp32 (out_f32).  With W := W^T the
+ * same entry computes the data gradient; ACT_MASK applies the ReLU mask from `aux` and `colsum`
+ * (fp32 [n_store], accumulated atomically) receives the column sums = bias gradient of the layer below.
+ * variant: 0 = 128x128 tile, 1 = 256x256 tile (bf16, N % 256 == 0). */
+int snerf_linear_fwd(const void* A, long lda, const void* W, long ldw, const float* bias, void* Y, long ldy,
+                     const void* aux, long ldaux, float* colsum, int M, int N, int K, int n_store, int act,
+                     int dtype, int out_f32, int variant, void* stream);
+
+/* dW[n_valid, k_valid] (fp32, ldw) += dZ[M,N]^T . X[M,K]  -- weight gradient of the same layers
+ * (autograd of nn.Linear in the reference; train.py:213 loss.backward()).  `zeros` = >=16 bytes of
+ * device zeros (source for rows past M). */
+int snerf_linear_wgrad(const void* Z, long ldz, const void* X, long ldx, float* dW, long ldw, const void* zeros,
+                       int M, int N, int K, int n_valid, int k_valid, int dtype, void* stream);
+
+/* ---- encoders ---------------------------------------------------------------------------------
+ * Classic positional encoding written straight into MLP operand buffers.
+ *   run_nerf_helpers.py:22-70 (Embedder.embed: [x, sin(2^k x), cos(2^k x)]_k) and the per-sample
+ *   broadcast of the view direction in run_network (:465-469).
+ * pts [M,3]; viewdirs [N,3] rows vd_stride apart (NULL = no view branch); S samples per ray.
+ * dst1/dst2 (dst2 optional) get w_pts columns (3+6L values + zero pad); dstv gets w_views columns. */
+int snerf_classic_embed(const float* pts, const float* viewdirs, int vd_stride, int S, long M, int L, int Lv,
+                        void* dst1, long ld1, void* dst2, long ld2, int w_pts, void* dstv, long ldv, int w_views,
+                        int dtype, void* stream);
+
+/* mip path: s -> t (mip.py:7-9) -> cast_rays cone/cylinder (mip.py:80-91, 56-77, 31-53) -> contraction
+ * fn2 + Jacobi_g (mip.py:343-374) -> diagonal of J diag(c) J^T (mip.py:381-395) -> integrated_pos_enc
+ * (mip.py:94-118, 24-28; math_ops.py:6-12), `width` >= 6*max_deg columns (zero padded) into dst1 (and dst2).
+ * means_out/covs_out: optional fp32 [N*S,3] copies of the contracted mean / covariance diagonal. */
+int snerf_mip_encode(const float* s_vals, const float* origins, const float* directions, const float* radii,
+                     const float* near, const float* far, long n_rays, int S, int cone, int transform_idx, int max_deg,
+                     void* dst1, long ld1, void* dst2, long ld2, int width, float* means_out, float* covs_out,
+                     int dtype, void* stream);
+
+/* mip.py:12-21 pos_enc(viewdirs, 0, deg, append_identity) tiled per sample (models.py:285-287). */
+int snerf_mip_viewenc(const float* viewdirs, long n_rays, int S, int deg, void* dst, long ld, int width, int dtype,
+                      void* stream);
+
+/* ---- samplers (bit-exact interval indices; fp64 sequential accumulation per ray) -----------------
+ * run_nerf_helpers.py:336-379 sample_pdf.  nc = number of bins = cdf entries, nc-1 weights (rows ld_w apart).
+ * mid_mode 1 = the render_rays call (render.py:378-380): `bins` is z_vals [N,nc+1] (bin j = mid of z[j],z[j+1]) and
+ * `weights` points at weights[:,1]; mid_mode 0: bins [N,nc] as given.  u [N,Nf] rows u_stride apart (0 = shared row).
+ * inds (int32, nullable) = searchsorted(cdf,u,right); z_std (nullable) = std(samples,-1,unbiased=False) (render.py:405). */
+int snerf_classic_sample_pdf(const float* bins, long ld_bins, int mid_mode, const float* weights, long ld_w, int nc,
+                             const float* u, long u_stride, long N, int Nf, float* samples, int* inds, float* z_std,
+                             void* stream);
+/* render.py:354/:385  pts = rays_o[...,None,:] + rays_d[...,None,:] * z_vals[...,:,None]; rays rows = [o3,d3,...]. */
+int snerf_classic_points(const float* rays, int ray_stride, const float* z_vals, long N, int S, float* pts, void* stream);
+/* render.py:383 torch.sort(torch.cat([z_vals, z_samples], -1), -1) */
+int snerf_classic_merge_sort(const float* a, int na, const float* b, int nb, long N, float* out, void* stream);
+/* mip.py:294-316 blur-pool + resample_padding, then math_ops.py:19-76 sorted_piecewise_constant_pdf.
+ * idx_out (int32, nullable) = #(u >= cdf) - 1. */
+int snerf_mip_resample(const float* s_vals, const float* weights, const float* u, long u_stride, long N, int S, int Nf,
+                       float resample_padding, float* out, int* idx_out, void* stream);
+/* render.py:330-352 (mode 0: z = near(1-t)+far t or disparity) / mip.py:268-288 (mode 1: s = t) with optional
+ * stratified jitter rnd [N,P]; base [P] = linspace(0,1,P). */
+int snerf_stratified(const float* base, const float* rnd, const float* near, const float* far, int nf_stride, long N,
+                     int P, int mode, int lindisp, float* out, void* stream);
+
+/* ---- compositing --------------------------------------------------------------------------------
+ * models.py:166-175 activations + mip.py:151-189 real_volumetric_rendering.  raw_rgb NULL = proposal level. */
+int snerf_mip_composite_fwd(const float* raw_rgb, long ld_rgb, const float* raw_density, long ld_den, const float* noise,
+                            const float* s_vals, const float* dirs, const float* near, const float* far, long N, int S,
+                            int transform_idx, int white, float rgb_padding, float density_bias, float* comp_rgb,
+                            float* distance, float* acc, float* weights, void* stream);
+int snerf_mip_composite_bwd(const float* raw_rgb, long ld_rgb, const float* raw_density, long ld_den, const float* noise,
+                            const float* s_vals, const float* dirs, const float* near, const float* far, long N, int S,
+                            int transform_idx, int white, float rgb_padding, float density_bias, const float* weights,
+                            const float* distance, const float* g_rgb, const float* g_dist, const float* g_acc,
+                            const float* g_w, float* d_raw_rgb, long ld_drgb, float* d_raw_density, long ld_dden,
+                            void* stream);
+/* run_nerf_helpers.py:381-424 raw2outputs */
+int snerf_classic_composite_fwd(const float* raw, long ld, const float* noise, const float* z_vals, const float* rays_d,
+                                int rd_stride, long N, int S, int white, float* rgb_map, float* disp_map, float* acc_map,
+                                float* weights, float* depth_map, void* stream);
+int snerf_classic_composite_bwd(const float* raw, long ld, const float* noise, const float* z_vals, const float* rays_d,
+                                int rd_stride, long N, int S, int white, const float* weights, const float* acc_map,
+                                const float* depth_map, const float* g_rgb, const float* g_disp, const float* g_acc,
+                                const float* g_depth, const float* g_w, float* d_raw, long ld_draw, void* stream);
+
+/* ---- training tail ------------------------------------------------------------------------------
+ * torch.optim.Adam step over a flat fp32 arena (model_utils.py:23-34 builds Adam); grad_scale folds the
+ * data-parallel 1/world_size; zero_grad clears g for the next step. */
+int snerf_adam_step(float* p, float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, int step,
+                    float grad_scale, int zero_grad, void* stream);
+int snerf_colsum_f32(const float* x, long ld, long M, int C, float* out, void* stream);
+int snerf_cast_pad(const float* src, long ld_src, long M, int C, int Cpad, void* dst, long ld_dst, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,68 @@
+"""ctypes binding of libsnerf_hip.so (the C-ABI declared in include/snerf_hip.h).
+
+The prototypes are parsed from the header itself, so the Python side cannot
+drift from the ABI.  There is NO fallback: if the shared library is missing
+``load()`` raises, and every op in ``snerf_amd`` goes through ``load()``.
+"""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_REPO = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_HERE, "lib", "libsnerf_hip.so")
+HEADER_PATH = os.path.join(_REPO, "include", "snerf_hip.h")
+
+_CTYPE = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float}
+_lib = None
+
+
+def parse_header(path: str = HEADER_PATH):
+    """-> {name: [(ctype, argname), ...]} for every ``int snerf_*(...)`` declaration."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\bint\s+(snerf_\w+)\s*\(([^)]*)\)\s*;", src):
+        name, args = m.group(1), m.group(2).strip()
+        sig = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = " ".join(a.split())
+                if "*" in a:
+                    sig.append((ctypes.c_void_p, a.split("*")[-1].strip()))
+                else:
+                    ty, an = a.rsplit(" ", 1)
+                    sig.append((_CTYPE[ty.replace("const ", "").strip()], an))
+        protos[name] = sig
+    return protos
+
+
+def load():
+    """Load (once) and return the ctypes library with argtypes/restype set."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"libsnerf_hip.so not found at {LIB_PATH}: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C snerf_amd/csrc`).  snerf_amd has no CPU/PyTorch fallback for its kernels.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, sig in parse_header().items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.argtypes = [t for t, _ in sig]
+        fn.restype = ctypes.c_int
+    _lib = lib
+    return lib
+
+
+class SnerfHipError(RuntimeError):
+    pass
+
+
+_STATUS = {1: "bad argument", 2: "kernel launch failure"}
+
+
+def call(name: str, *args):
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise SnerfHipError(f"{name} failed: status {rc} ({_STATUS.get(rc, 'unknown')})")

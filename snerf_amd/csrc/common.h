@@ -1,0 +1,61 @@
+// Shared device/host helpers for libsnerf_hip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SNERF_OK 0
+#define SNERF_ERR_ARG 1
+#define SNERF_ERR_LAUNCH 2
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define SNERF_DT_F32 0
+#define SNERF_DT_BF16 1
+
+static inline int snerf_check_launch() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? SNERF_OK : SNERF_ERR_LAUNCH;
+}
+
+// Bijective XCD-aware remap of a 1-D block id (MI355X: 8 XCDs, block b runs on
+// XCD b % 8).  Blocks that land on one XCD get a contiguous range of logical
+// ids so that neighbouring tiles share that XCD's L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// inclusive prefix sum across the 64 lanes of a wave
+__device__ __forceinline__ float wave_incl_scan_add(float v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    float t = __shfl_up(v, o, 64);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+
+__device__ __forceinline__ float wave_incl_scan_mul(float v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    float t = __shfl_up(v, o, 64);
+    if (lane >= o) v *= t;
+  }
+  return v;
+}
+
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ __bf16 from_f32<__bf16>(float v) { return (__bf16)v; }
+template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }

@@ -1,0 +1,235 @@
+// Sample -> feature encoders that write straight into the MLP's A-operand
+// buffers (row-major [M, ld], dtype fp32 or bf16, zero padded to the GEMM's
+// K granularity) so that encodings never make a separate HBM round trip.
+//
+//   snerf_classic_embed : run_nerf_helpers.py:22-70 (Embedder) + the viewdir
+//                         broadcast of run_network (run_nerf_helpers.py:465-469)
+//   snerf_mip_encode    : mip.py:381-395 (sample2enc: Transform -> cast_rays ->
+//                         contraction fn2 -> Jacobi_g -> J diag(c) J^T) fused with
+//                         mip.py:94-118 (integrated_pos_enc, full-cov branch, of
+//                         which only the diagonal is live) and mip.py:24-28.
+//   snerf_mip_viewenc   : mip.py:12-21 (pos_enc of the view direction), tiled
+//                         per sample like models.py:285-287.
+//
+// Compiled with -ffp-contract=off: products and sums round exactly like the
+// CPU oracle's separate fp32 operations.
+#include "common.h"
+
+template <typename T>
+__global__ __launch_bounds__(256) void classic_embed_kernel(const float* __restrict__ pts, const float* __restrict__ viewdirs,
+                                                            int vd_stride, int S, long M, int L, int Lv, T* dst1, long ld1,
+                                                            T* dst2, long ld2, int w_pts, T* dstv, long ldv, int w_views) {
+  // one thread per output element; columns [0, w_pts) = point embedding (+ zero pad),
+  // columns [w_pts, w_pts + w_views) = view embedding (+ zero pad)
+  const int wtot = w_pts + w_views;
+  const long total = M * wtot;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long m = e / wtot;
+    int col = (int)(e - m * wtot);
+    const bool is_view = col >= w_pts;
+    const float* src;
+    int nf;
+    if (is_view) { col -= w_pts; src = viewdirs + (m / S) * vd_stride; nf = Lv; }
+    else { src = pts + m * 3; nf = L; }
+    float v = 0.f;
+    if (col < 3) v = src[col];
+    else if (col < 3 + 6 * nf) {
+      const int j = col - 3, k = j / 6, w = j % 6;
+      const float x = src[w % 3] * (float)(1 << k);
+      v = w < 3 ? sinf(x) : cosf(x);
+    }
+    const T o = from_f32<T>(v);
+    if (is_view) dstv[m * ldv + col] = o;
+    else {
+      dst1[m * ld1 + col] = o;
+      if (dst2 != nullptr) dst2[m * ld2 + col] = o;
+    }
+  }
+}
+
+extern "C" int snerf_classic_embed(const float* pts, const float* viewdirs, int vd_stride, int S, long M, int L, int Lv,
+                                   void* dst1, long ld1, void* dst2, long ld2, int w_pts, void* dstv, long ldv, int w_views,
+                                   int dtype, void* stream) {
+  if (M <= 0) return SNERF_OK;
+  if (w_pts < 3 + 6 * L || (viewdirs != nullptr && w_views < 3 + 6 * Lv) || S <= 0) return SNERF_ERR_ARG;
+  if (viewdirs == nullptr) w_views = 0;
+  const long total = M * (long)(w_pts + w_views);
+  const int blocks = (int)((total + 255) / 256 < 65536 * 4 ? (total + 255) / 256 : 65536 * 4);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == SNERF_DT_F32)
+    hipLaunchKernelGGL(classic_embed_kernel<float>, dim3(blocks), dim3(256), 0, s, pts, viewdirs, vd_stride, S, M, L, Lv,
+                       (float*)dst1, ld1, (float*)dst2, ld2, w_pts, (float*)dstv, ldv, w_views);
+  else
+    hipLaunchKernelGGL(classic_embed_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, pts, viewdirs, vd_stride, S, M, L, Lv,
+                       (__bf16*)dst1, ld1, (__bf16*)dst2, ld2, w_pts, (__bf16*)dstv, ldv, w_views);
+  return snerf_check_launch();
+}
+
+// ---------------------------------------------------------------------------
+// mip path
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float mip_transform(float s, float near, float far, int idx) {
+  if (idx == 0) return near * expf(s * logf(far / near));      // mip.py:8
+  if (idx == 1) return 1.f / ((1.f - s) / near + s / far);     // mip.py:7
+  return near * (1.f - s) + far * s;                           // mip.py:9
+}
+
+__device__ __forceinline__ float safe_sin(float x) {            // math_ops.py:6-12
+  const float t = 314.15927f;                                   // float32(100 * pi)
+  if (!(fabsf(x) < t)) {
+    float r = fmodf(x, t);
+    if (r != 0.f && r < 0.f) r += t;                            // python-sign remainder
+    x = r;
+  }
+  return sinf(x);
+}
+
+struct MipEncArgs {
+  const float* s_vals; const float* origins; const float* directions; const float* radii; const float* near; const float* far;
+  int S;          // intervals per ray (s_vals row has S+1 posts)
+  long M;         // N * S
+  int cone, transform_idx, max_deg;
+  void* dst1; long ld1; void* dst2; long ld2; int width;  // width >= 6*max_deg, zero padded
+  float* means_out; float* covs_out;                       // optional [M,3] debug/parity outputs
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void mip_encode_kernel(MipEncArgs a) {
+  __shared__ float sm[256][6];
+  const long mbase = (long)blockIdx.x * 256;
+  const long m = mbase + threadIdx.x;
+  if (m < a.M) {
+    const long ray = m / a.S;
+    const int i = (int)(m - ray * a.S);
+    const float near = a.near[ray], far = a.far[ray];
+    const float t0 = mip_transform(a.s_vals[ray * (a.S + 1) + i], near, far, a.transform_idx);
+    const float t1 = mip_transform(a.s_vals[ray * (a.S + 1) + i + 1], near, far, a.transform_idx);
+    const float rad = a.radii[ray];
+    float t_mean, t_var, r_var;
+    if (a.cone) {  // conical_frustum_to_gaussian, stable form (mip.py:56-64)
+      const float mu = (t0 + t1) / 2.f, hw = (t1 - t0) / 2.f;
+      const float mu2 = mu * mu, hw2 = hw * hw, hw4 = hw2 * hw2;
+      const float den = 3.f * mu2 + hw2;
+      t_mean = mu + (2.f * mu * hw2) / den;
+      t_var = hw2 / 3.f - (4.f / 15.f) * ((hw4 * (12.f * mu2 - hw2)) / (den * den));
+      r_var = (rad * rad) * (mu2 / 4.f + (5.f / 12.f) * hw2 - (4.f / 15.f) * hw4 / den);
+    } else {       // cylinder_to_gaussian (mip.py:73-77)
+      t_mean = (t0 + t1) / 2.f;
+      r_var = rad * rad / 4.f;
+      t_var = (t1 - t0) * (t1 - t0) / 12.f;
+    }
+    float d[3], o[3], x[3], c[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { d[k] = a.directions[ray * 3 + k]; o[k] = a.origins[ray * 3 + k]; }
+    const float dmag = fmaxf(1e-10f, d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {   // lift_gaussian diag (mip.py:31-46)
+      x[k] = d[k] * t_mean + o[k];
+      const float dd = d[k] * d[k];
+      c[k] = t_var * dd + r_var * (1.f - dd / dmag);
+    }
+    // contraction fn2 (mip.py:371-374) and Jacobian (mip.py:343-364); radius hard-coded 3 (mip.py:386)
+    const float nrm = sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+    const float l = nrm + 1e-8f;
+    float fm[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) fm[k] = l > 3.f ? (2.f - 3.f / l) * x[k] / l : x[k] / 3.f;
+    const float lj = nrm + 1e-5f;
+    float fc[3];
+    if (lj >= 3.f) {
+      const float ln = 1.f / lj, ln2 = ln * ln;
+      const float p1 = -3.f * ln2 + 2.f * ln;
+      const float p2 = 2.f * 3.f * (ln2 * ln2) - 2.f * (ln2 * ln);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const float J = (r == k ? p1 : 0.f) + p2 * (x[r] * x[k]);
+          acc += (J * J) * c[k];
+        }
+        fc[r] = acc;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) fc[r] = ((1.f / 3.f) * (1.f / 3.f)) * c[r];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { sm[threadIdx.x][k] = fm[k]; sm[threadIdx.x][3 + k] = fc[k]; }
+    if (a.means_out != nullptr) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { a.means_out[m * 3 + k] = fm[k]; a.covs_out[m * 3 + k] = fc[k]; }
+    }
+  }
+  __syncthreads();
+  const int nfeat = 6 * a.max_deg, half = 3 * a.max_deg;
+  const long rows = a.M - mbase < 256 ? a.M - mbase : 256;
+  const long total = rows * a.width;
+  T* d1 = (T*)a.dst1; T* d2 = (T*)a.dst2;
+  for (long e = threadIdx.x; e < total; e += 256) {
+    const int row = (int)(e / a.width), col = (int)(e - (long)row * a.width);
+    float v = 0.f;
+    if (col < nfeat) {
+      const int ph = col >= half, j = ph ? col - half : col, deg = j / 3, dim = j - deg * 3;
+      const float sc = (float)(1 << deg);
+      float y = sm[row][dim] * sc;
+      const float yv = (sm[row][3 + dim] * sc) * sc;
+      if (ph) y = y + 1.5707964f;   // float32(0.5 * pi)
+      v = expf(-0.5f * yv) * safe_sin(y);
+    }
+    const T o = from_f32<T>(v);
+    d1[(mbase + row) * a.ld1 + col] = o;
+    if (d2 != nullptr) d2[(mbase + row) * a.ld2 + col] = o;
+  }
+}
+
+extern "C" int snerf_mip_encode(const float* s_vals, const float* origins, const float* directions, const float* radii,
+                                const float* near, const float* far, long n_rays, int S, int cone, int transform_idx, int max_deg,
+                                void* dst1, long ld1, void* dst2, long ld2, int width, float* means_out, float* covs_out,
+                                int dtype, void* stream) {
+  if (n_rays <= 0) return SNERF_OK;
+  if (S <= 0 || width < 6 * max_deg || max_deg > 30 || dst1 == nullptr) return SNERF_ERR_ARG;
+  MipEncArgs a{s_vals, origins, directions, radii, near, far, S, n_rays * (long)S, cone, transform_idx, max_deg,
+               dst1, ld1, dst2, ld2, width, means_out, covs_out};
+  const int blocks = (int)((a.M + 255) / 256);
+  if (dtype == SNERF_DT_F32) hipLaunchKernelGGL(mip_encode_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(mip_encode_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+  return snerf_check_launch();
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void mip_viewenc_kernel(const float* __restrict__ viewdirs, int S, long M, int deg, T* dst, long ld,
+                                                          int width) {
+  // [x, sin(2^i x) deg-major, sin(2^i x + pi/2)] per ray, replicated for each of the ray's S samples
+  const long total = M * width;
+  const int n3 = 3 * deg;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long m = e / width;
+    const int col = (int)(e - m * width);
+    const float* x = viewdirs + (m / S) * 3;
+    float v = 0.f;
+    if (col < 3) v = x[col];
+    else if (col < 3 + 2 * n3) {
+      int j = col - 3;
+      const int ph = j >= n3;
+      if (ph) j -= n3;
+      float y = x[j % 3] * (float)(1 << (j / 3));
+      if (ph) y = y + 1.5707964f;
+      v = sinf(y);
+    }
+    dst[m * ld + col] = from_f32<T>(v);
+  }
+}
+
+extern "C" int snerf_mip_viewenc(const float* viewdirs, long n_rays, int S, int deg, void* dst, long ld, int width, int dtype,
+                                 void* stream) {
+  if (n_rays <= 0) return SNERF_OK;
+  if (width < 3 + 6 * deg || S <= 0) return SNERF_ERR_ARG;
+  const long M = n_rays * (long)S, total = M * width;
+  const int blocks = (int)((total + 255) / 256 < 262144 ? (total + 255) / 256 : 262144);
+  if (dtype == SNERF_DT_F32)
+    hipLaunchKernelGGL(mip_viewenc_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, viewdirs, S, M, deg, (float*)dst, ld, width);
+  else
+    hipLaunchKernelGGL(mip_viewenc_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, viewdirs, S, M, deg, (__bf16*)dst, ld, width);
+  return snerf_check_launch();
+}

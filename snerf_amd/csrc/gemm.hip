@@ -1,0 +1,350 @@
+// MFMA GEMMs for the S-NeRF tiny-MLP layers (gfx950 / CDNA4).
+//
+//   snerf_linear_fwd : Y[M,n_store] = act( A[M,K] . W[N,K]^T + bias )        ("NT")
+//                      used for every forward layer (reference: nn.Linear + ReLU,
+//                      s-nerf/model/models.py:200-214, run_nerf_helpers.py:86-126) and,
+//                      with W := W^T packed by the host, for the data gradient.
+//   snerf_linear_wgrad: dW[N,K] += dZ[M,N]^T . X[M,K]   (fp32 atomics)         ("TN")
+//
+// Layout: every LDS tile row is 128 bytes (64 bf16 / 32 fp32 of the reduction
+// axis) and is filled by `global_load_lds_dwordx4` (wave-uniform LDS base +
+// lane*16).  The 16-byte chunk c of row r is stored at chunk position
+// c ^ ((r>>1)&7); the permutation is applied on the per-lane GLOBAL source
+// address (the LDS image stays lane-linear) and again on the ds_read_b128
+// address, which makes every 16-lane read group of a 32x32 MFMA fragment hit
+// 16 distinct 16-byte slots (conflict free).
+//
+// dtype f32 uses v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain: parity mode,
+// 157 TF/s peak); dtype bf16 uses v_mfma_f32_32x32x16_bf16 (2.5 PF/s peak),
+// fp32 accumulate in both.
+#include "common.h"
+
+#define ACT_NONE 0
+#define ACT_RELU 1
+#define ACT_MASK 2  // y = (aux > 0) ? y : 0   (ReLU backward fused into dgrad)
+
+struct GemmNT {
+  const void* A; long lda;
+  const void* W; long ldw;
+  const float* bias;
+  void* Y; long ldy;
+  const void* aux; long ldaux;
+  float* colsum;
+  int M, N, K, n_store, act, out_f32;
+};
+
+template <typename T> struct Frag;
+template <> struct Frag<float> { typedef f32x4 type; };
+template <> struct Frag<__bf16> { typedef bf16x8 type; };
+
+__device__ __forceinline__ void mma32(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma32(f32x16& acc, const f32x4& a, const f32x4& b) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+}
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+__device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)lds_wave_base, 16, 0, 0);
+}
+
+// ---------------------------------------------------------------------------
+// NT kernel: BM x BN output tile, WM x WN waves, each wave (BM/WM) x (BN/WN).
+// ---------------------------------------------------------------------------
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmNT p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef typename Frag<T>::type frag_t;
+  constexpr int NW = WM * WN;
+  constexpr int EPC = 16 / (int)sizeof(T);   // elements per 16-byte chunk
+  constexpr int BKE = 128 / (int)sizeof(T);  // reduction elements per tile row
+  constexpr int STAGE = (BM + BN) * 128;
+  constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
+  constexpr int LA = BM / 8 / NW, LB = BN / 8 / NW;  // glds instructions per wave per tile
+  static_assert(LA >= 1 && LB >= 1, "tile too small for the wave count");
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int tiles_n = p.N / BN;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int logical = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int m0 = (logical / tiles_n) * BM, n0 = (logical % tiles_n) * BN;
+  const T* __restrict__ A = (const T*)p.A;
+  const T* __restrict__ W = (const T*)p.W;
+  const int KT = p.K / BKE;
+
+  // per-lane source coordinates of the staging loads (constant over k)
+  const int lrow = lane >> 3, lsc = lane & 7;
+  long a_off[LA], b_off[LB];
+#pragma unroll
+  for (int i = 0; i < LA; ++i) {
+    const int row = (wave * LA + i) * 8 + lrow;
+    const int c = lsc ^ ((row >> 1) & 7);
+    int gr = m0 + row;
+    gr = gr < p.M ? gr : p.M - 1;
+    a_off[i] = (long)gr * p.lda + c * EPC;
+  }
+#pragma unroll
+  for (int i = 0; i < LB; ++i) {
+    const int row = (wave * LB + i) * 8 + lrow;
+    const int c = lsc ^ ((row >> 1) & 7);
+    b_off[i] = (long)(n0 + row) * p.ldw + c * EPC;
+  }
+
+  auto issue = [&](int kt, int stage) {
+    char* sA = smem + stage * STAGE;
+    char* sB = sA + BM * 128;
+    const long k0 = (long)kt * BKE;
+#pragma unroll
+    for (int i = 0; i < LA; ++i) glds16(A + a_off[i] + k0, sA + (wave * LA + i) * 1024);
+#pragma unroll
+    for (int i = 0; i < LB; ++i) glds16(W + b_off[i] + k0, sB + (wave * LB + i) * 1024);
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment read offsets (bytes inside a tile), constant over k except the chunk index
+  int ra[TM], rb[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) ra[i] = wm * WTM + i * 32 + (lane & 31);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) rb[j] = wn * WTN + j * 32 + (lane & 31);
+  const int chalf = lane >> 5;
+
+  issue(0, 0);
+  for (int kt = 0; kt < KT; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < KT) issue(kt + 1, (kt + 1) & 1);
+    const char* sA = smem + (kt & 1) * STAGE;
+    const char* sB = sA + BM * 128;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      frag_t a[TM], b[TN];
+      const int c = 2 * ks + chalf;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = *(const frag_t*)(sA + ra[i] * 128 + ((c ^ ((ra[i] >> 1) & 7)) << 4));
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = *(const frag_t*)(sB + rb[j] * 128 + ((c ^ ((rb[j] >> 1) & 7)) << 4));
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) mma32(acc[i][j], a[i], b[j]);
+    }
+  }
+
+  // epilogue: D[i][j], j = lane&31 (n), i = (r&3) + 8*(r>>2) + 4*(lane>>5) (m)
+  const T* __restrict__ aux = (const T*)p.aux;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * WTN + j * 32 + (lane & 31);
+    const bool nok = n < p.n_store;
+    const float bv = (p.bias != nullptr && nok) ? p.bias[n] : 0.f;
+    float csum = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        float v = acc[i][j][r] + bv;
+        if (p.act == ACT_RELU) v = v > 0.f ? v : 0.f;
+        if (m < p.M && nok) {
+          if (p.act == ACT_MASK) v = to_f32(aux[(long)m * p.ldaux + n]) > 0.f ? v : 0.f;
+          if (p.out_f32) ((float*)p.Y)[(long)m * p.ldy + n] = v;
+          else ((T*)p.Y)[(long)m * p.ldy + n] = from_f32<T>(v);
+          csum += v;
+        }
+      }
+    }
+    if (p.colsum != nullptr) {
+      csum += __shfl_xor(csum, 32, 64);
+      if (lane < 32 && nok) atomicAdd(p.colsum + n, csum);
+    }
+  }
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+static int launch_nt(const GemmNT& p, hipStream_t stream) {
+  constexpr int LDS = 2 * (BM + BN) * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)gemm_nt_kernel<T, BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
+  hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, WM, WN>), dim3(tiles), dim3(64 * WM * WN), LDS, stream, p);
+  return snerf_check_launch();
+}
+
+extern "C" int snerf_linear_fwd(const void* A, long lda, const void* W, long ldw, const float* bias, void* Y, long ldy,
+                                const void* aux, long ldaux, float* colsum, int M, int N, int K, int n_store, int act,
+                                int dtype, int out_f32, int variant, void* stream) {
+  if (M <= 0) return SNERF_OK;
+  if (N <= 0 || (N % 128) != 0 || K <= 0 || n_store <= 0 || n_store > N) return SNERF_ERR_ARG;
+  const int bke = dtype == SNERF_DT_F32 ? 32 : 64;
+  if (K % bke != 0 || lda % (bke / 8) != 0 || ldw % (bke / 8) != 0) return SNERF_ERR_ARG;
+  if (act == ACT_MASK && aux == nullptr) return SNERF_ERR_ARG;
+  GemmNT p{A, lda, W, ldw, bias, Y, ldy, aux, ldaux, colsum, M, N, K, n_store, act, out_f32};
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == SNERF_DT_F32) return launch_nt<float, 128, 128, 2, 2>(p, s);
+  if (dtype == SNERF_DT_BF16) {
+    if (variant == 1 && N % 256 == 0) return launch_nt<__bf16, 256, 256, 2, 4>(p, s);
+    return launch_nt<__bf16, 128, 128, 2, 2>(p, s);
+  }
+  return SNERF_ERR_ARG;
+}
+
+// ---------------------------------------------------------------------------
+// TN kernel (weight gradient): dW[n,k] += sum_m dZ[m,n] * X[m,k]
+// 128 x 128 output tile, 4 waves (2 x 2), M split into chunks across blockIdx.y.
+// fp32: LDS rows of 128 floats, ds_read_b32 per MFMA operand (conflict free).
+// bf16: LDS rows of 128 bf16, operands gathered with 16-bit LDS reads (the
+//       reduction axis is the row axis of both operands, so a lane's 8
+//       consecutive k values sit in 8 different rows).
+// Rows >= M of dZ are sourced from a zero page so that they contribute 0.
+// ---------------------------------------------------------------------------
+struct GemmTN {
+  const void* Z; long ldz;
+  const void* X; long ldx;
+  float* dW; long ldw;
+  const void* zeros;  // >= 16 bytes of zeros in device memory
+  int M, N, K, n_valid, k_valid, m_chunk;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int EPC = 16 / (int)sizeof(T);
+  constexpr int ROWB = 128 * (int)sizeof(T);         // bytes per LDS row (128 columns)
+  constexpr int MT = sizeof(T) == 4 ? 16 : 32;       // reduction rows per stage
+  constexpr int TILEB = MT * ROWB;                   // 8 KiB per operand per stage
+  constexpr int RPI = 1024 / ROWB;                   // rows covered by one glds instruction (2 or 4)
+  constexpr int LI = MT / RPI / 4;                   // instructions per wave per operand (2)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave >> 1, wk = wave & 1;
+  const int tiles_k = (p.K + 127) / 128;
+  const int n0 = (blockIdx.x / tiles_k) * 128, k0 = (blockIdx.x % tiles_k) * 128;
+  const int mbeg = blockIdx.y * p.m_chunk;
+  const int mend = min(p.M, mbeg + p.m_chunk);
+  const T* __restrict__ Z = (const T*)p.Z;
+  const T* __restrict__ X = (const T*)p.X;
+  const int steps = (mend - mbeg + MT - 1) / MT;
+
+  // staging: lane -> (row within instruction, 16-byte chunk within row)
+  constexpr int CPR = ROWB / 16;                     // chunks per row (32 fp32 / 16 bf16)
+  const int lrow = lane / CPR, lch = lane % CPR;
+  // clamp the column chunk so that partial tiles (N or K not a multiple of 128) stay in bounds
+  int zc = n0 + lch * EPC; zc = zc < p.N ? zc : p.N - EPC;
+  int xc = k0 + lch * EPC; xc = xc < p.K ? xc : p.K - EPC;
+
+  auto issue = [&](int st, int stage) {
+    char* sZ = smem + stage * 2 * TILEB;
+    char* sX = sZ + TILEB;
+#pragma unroll
+    for (int i = 0; i < LI; ++i) {
+      const int r = (wave * LI + i) * RPI + lrow;
+      const int m = mbeg + st * MT + r;
+      const T* gz = m < mend ? Z + (long)m * p.ldz + zc : (const T*)p.zeros;
+      const int mx = m < mend ? m : mend - 1;
+      glds16(gz, sZ + (wave * LI + i) * 1024);
+      glds16(X + (long)mx * p.ldx + xc, sX + (wave * LI + i) * 1024);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (steps > 0) issue(0, 0);
+  for (int st = 0; st < steps; ++st) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (st + 1 < steps) issue(st + 1, (st + 1) & 1);
+    const char* sZ = smem + (st & 1) * 2 * TILEB;
+    const char* sX = sZ + TILEB;
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+      for (int kk = 0; kk < MT / 2; ++kk) {
+        const int row = 2 * kk + (lane >> 5);
+        float a[2], b[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          a[t] = *(const float*)(sZ + row * ROWB + (wn * 64 + t * 32 + (lane & 31)) * 4);
+          b[t] = *(const float*)(sX + row * ROWB + (wk * 64 + t * 32 + (lane & 31)) * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < MT / 16; ++ks) {
+        const int rbase = ks * 16 + 8 * (lane >> 5);
+        union { bf16x8 v; unsigned short u[8]; } a[2], b[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int ca = (wn * 64 + t * 32 + (lane & 31)) * 2, cb = (wk * 64 + t * 32 + (lane & 31)) * 2;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            a[t].u[e] = *(const unsigned short*)(sZ + (rbase + e) * ROWB + ca);
+            b[t].u[e] = *(const unsigned short*)(sX + (rbase + e) * ROWB + cb);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i].v, b[j].v, acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+  // D[i = n][j = k]: j = lane&31, i = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = k0 + wk * 64 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (n < p.n_valid && k < p.k_valid) atomicAdd(p.dW + (long)n * p.ldw + k, acc[i][j][r]);
+      }
+    }
+}
+
+extern "C" int snerf_linear_wgrad(const void* Z, long ldz, const void* X, long ldx, float* dW, long ldw, const void* zeros,
+                                  int M, int N, int K, int n_valid, int k_valid, int dtype, void* stream) {
+  if (M <= 0) return SNERF_OK;
+  const int epc = dtype == SNERF_DT_F32 ? 4 : 8;
+  if (N < epc || K < epc || N % epc || K % epc || ldz % epc || ldx % epc || zeros == nullptr) return SNERF_ERR_ARG;
+  // split M so that the grid has a few thousand blocks but each block still amortises its atomics
+  const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
+  int chunks = (4096 + tiles - 1) / tiles;
+  int m_chunk = (M + chunks - 1) / chunks;
+  m_chunk = ((m_chunk + 255) / 256) * 256;
+  if (m_chunk < 1024) m_chunk = 1024;
+  chunks = (M + m_chunk - 1) / m_chunk;
+  GemmTN p{Z, ldz, X, ldx, dW, ldw, zeros, M, N, K, n_valid, k_valid, m_chunk};
+  const int lds = 2 * 2 * 8192;
+  dim3 grid(tiles, chunks);
+  if (dtype == SNERF_DT_F32) hipLaunchKernelGGL(gemm_tn_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, p);
+  else if (dtype == SNERF_DT_BF16) hipLaunchKernelGGL(gemm_tn_kernel<__bf16>, grid, dim3(256), lds, (hipStream_t)stream, p);
+  else return SNERF_ERR_ARG;
+  return snerf_check_launch();
+}

@@ -1,0 +1,218 @@
+"""Drop-in ``MipNerfModel`` (path A, the renderer s-nerf/train.py and eval.py
+actually run) backed by libsnerf_hip.so.
+
+Mirrors s-nerf/model/models.py:
+  MipNerfModel   :10-187   same constructor keywords, same ``state_dict`` keys/shapes
+                           (``mlp.layers.N.layers.0.weight`` ... ``proposal.density_layer.bias``),
+                           same forward signature and return layout
+  make_mipnerf   :190-197
+  render_image   :328-360
+
+Only the configuration the reference can actually run is accelerated (SURVEY.md
+section 0): warp sampling (``no_warp_sample=0``; the other branch raises NameError
+in the reference, models.py:82/178), contraction ``fn=1`` with radius 3, two levels,
+view directions on, no appearance embedding, no semantic head.  Anything else
+raises NotImplementedError -- there is no eager fallback.
+
+Per level the whole chain  sample -> encode -> MLP -> activations -> composite  runs
+as HIP kernels; one ``torch.autograd.Function`` spans both levels so that
+``loss.backward()`` in an unmodified training loop reaches the parameters.
+"""
+from collections import namedtuple
+
+import torch
+from torch import nn
+
+from . import ops
+from .classic import _ArenaModule, _dt
+from .mlp import MipNerfNet, MipProposalNet
+
+Rays = namedtuple("Rays", ("origins", "directions", "viewdirs", "radii", "lossmult", "near", "far", "app"))
+EPS32 = float(torch.finfo(torch.float32).eps)
+
+
+class MipNerfModel(_ArenaModule):
+    def __init__(self, n_samples: int = 128, n_levels: int = 2, resample_padding: float = 0.01, stop_level_grad: bool = True,
+                 use_viewdirs: bool = True, lindisp: bool = False, ray_shape: str = "cylinder", min_deg_point: int = 0,
+                 max_deg_point: int = 16, deg_view: int = 4, density_noise: float = 1., density_bias: float = -1.,
+                 rgb_padding: float = 0.001, disable_integration: bool = False, no_warp_sample=True, fn=None, radius=None,
+                 real=False, transform_idx=0, rgb_layer=1, hidden_layer=256, encode_appearance=False, N_vocab=100,
+                 proposal_hidden_layer=256, proposal_loss=False, N_fine=128, semantic=False, semantic_class_num=0,
+                 compute: str = "bf16", device="cuda", variant: int = 0):
+        super().__init__()
+        if no_warp_sample:
+            raise NotImplementedError("no_warp_sample=1 is broken in the reference itself (models.py:82 vs :178); only the warp branch exists")
+        if n_levels != 2 or not use_viewdirs or encode_appearance or semantic or disable_integration or min_deg_point != 0 or not stop_level_grad:
+            raise NotImplementedError("accelerated MipNerfModel: n_levels=2, use_viewdirs, stop_level_grad, no appearance/semantic heads")
+        if fn != 1:
+            raise NotImplementedError("only the contraction warp fn=1 (the shipped nuScenes config) is accelerated")
+        self.n_levels, self.n_samples, self.N_fine = n_levels, n_samples, N_fine
+        self.resample_padding, self.ray_shape, self.max_deg_point, self.deg_view = resample_padding, ray_shape, max_deg_point, deg_view
+        self.density_noise, self.density_bias, self.rgb_padding = density_noise, density_bias, rgb_padding
+        self.transform_idx, self.proposal_loss, self.lindisp = int(transform_idx), proposal_loss, lindisp
+        self.radius, self.fn, self.real, self.semantic, self.no_warp_sample, self.use_viewdirs = radius, fn, real, False, 0, True
+        self.compute = compute
+        fd = max_deg_point * 6
+        cd = 3 + 6 * deg_view
+        shapes = [("mlp." + n, s) for n, s in MipNerfNet.param_shapes(hidden_layer, 8, 4, fd, cd, rgb_layer, 128)]
+        shapes += [("proposal." + n, s) for n, s in MipProposalNet.param_shapes(proposal_hidden_layer, 4, fd)]
+        self._setup_arena(shapes, torch.device(device))
+        dt = _dt(compute)
+        self.dt = dt
+        self.nerf = MipNerfNet(self.arena, "mlp.", dt, hidden_layer, 8, 4, fd, cd, rgb_layer, 128, variant)
+        self.prop = MipProposalNet(self.arena, "proposal.", dt, proposal_hidden_layer, 4, fd, variant)
+        self.nerf.version_fn = self._param_version
+        self.prop.version_fn = self._param_version
+        with torch.no_grad():  # DenseBlock / heads: xavier-uniform weights (models.py:208,256-257), default-Linear biases
+            for n in self.arena.names:
+                p = self.arena.p[n]
+                if n.endswith(".weight"):
+                    nn.init.xavier_uniform_(p if p.dim() == 2 else p.view(1, -1))
+                else:
+                    fan_in = self.arena.p[n[:-4] + "weight"].shape[-1]
+                    nn.init.uniform_(p, -1.0 / fan_in ** 0.5, 1.0 / fan_in ** 0.5)
+
+    # ------------------------------------------------------------------ core ----
+    def _run(self, rays: Rays, keep: bool, white_bg: bool, s_rand, u, noise0, noise1):
+        """Both levels.  Returns (outs, ctx) with outs = (dist0, acc0, s0, w0, rgb1, dist1, acc1, s1, w1)."""
+        dev = self.arena.flat.device
+        f = lambda t: t.detach().to(dev, torch.float32).contiguous()
+        o, d, vd = f(rays.origins), f(rays.directions), f(rays.viewdirs)
+        radii, near, far = f(rays.radii).reshape(-1), f(rays.near).reshape(-1), f(rays.far).reshape(-1)
+        n = o.shape[0]
+        S0, P1 = self.n_samples, self.N_fine
+        S1 = P1 - 1
+        cone = self.ray_shape == "cone"
+        if self.ray_shape not in ("cone", "cylinder"):
+            raise ValueError(self.ray_shape)
+        # ---- level 0: stratified s, encode, proposal MLP, composite
+        base = torch.linspace(0., 1., S0 + 1).to(dev)
+        s0 = ops.stratified(base, s_rand, None, None, n, 1)
+        E0 = self.prop.buf(n * S0, self.prop.Ew)
+        ops.mip_encode(s0, o, d, radii, near, far, cone, self.transform_idx, self.max_deg_point, E0, None, self.prop.Ew, self.dt)
+        raw_d0, acts0 = self.prop.forward(E0, keep)
+        _, dist0, acc0, w0 = ops.mip_composite_fwd(None, raw_d0, noise0, s0, d, near, far, self.transform_idx, white_bg,
+                                                   self.rgb_padding, self.density_bias)
+        # ---- level 1: resample (no gradient: stop_level_grad), encode, NeRF MLP, composite
+        s1, _ = ops.mip_resample(s0, w0, u, self.resample_padding)
+        SKIP, CB = self.nerf.alloc_inputs(n * S1)
+        H = self.nerf.H
+        ops.mip_encode(s1, o, d, radii, near, far, cone, self.transform_idx, self.max_deg_point, SKIP[:, H:], None, self.nerf.Ew, self.dt)
+        ops.mip_viewenc(vd, S1, self.deg_view, CB[:, H:], self.nerf.Cw, self.dt)
+        raw_rgb, raw_d1, saved1 = self.nerf.forward(SKIP, CB, keep)
+        rgb1, dist1, acc1, w1 = ops.mip_composite_fwd(raw_rgb, raw_d1, noise1, s1, d, near, far, self.transform_idx, white_bg,
+                                                      self.rgb_padding, self.density_bias)
+        ctx = None
+        if keep:
+            ctx = dict(d=d, near=near, far=far, s0=s0, s1=s1, raw_d0=raw_d0, acts0=acts0, w0=w0, dist0=dist0, raw_rgb=raw_rgb,
+                       raw_d1=raw_d1, saved1=saved1, w1=w1, dist1=dist1, noise0=noise0, noise1=noise1, white=white_bg)
+        return (dist0, acc0, s0, w0, rgb1, dist1, acc1, s1, w1), ctx
+
+    def _backward(self, ctx, g_dist0, g_acc0, g_w0, g_rgb1, g_dist1, g_acc1, g_w1):
+        """Accumulates parameter gradients into the arena."""
+        c = ctx
+        n = c["s0"].shape[0]
+        S0, S1 = c["s0"].shape[1] - 1, c["s1"].shape[1] - 1
+        dev = c["s0"].device
+        cc = lambda t: None if t is None else t.contiguous().float()
+        if any(t is not None for t in (g_rgb1, g_dist1, g_acc1, g_w1)):
+            d_rgb = torch.empty(n * S1, 3, dtype=torch.float32, device=dev)
+            d_den = torch.empty(n * S1, 1, dtype=torch.float32, device=dev)
+            ops.mip_composite_bwd(c["raw_rgb"], c["raw_d1"], c["noise1"], c["s1"], c["d"], c["near"], c["far"], self.transform_idx,
+                                  c["white"], self.rgb_padding, self.density_bias, c["w1"], c["dist1"], cc(g_rgb1), cc(g_dist1),
+                                  cc(g_acc1), cc(g_w1), d_rgb, d_den)
+            self.nerf.backward(d_rgb, d_den, c["saved1"])
+        if any(t is not None for t in (g_dist0, g_acc0, g_w0)):
+            d_den0 = torch.empty(n * S0, 1, dtype=torch.float32, device=dev)
+            ops.mip_composite_bwd(None, c["raw_d0"], c["noise0"], c["s0"], c["d"], c["near"], c["far"], self.transform_idx,
+                                  c["white"], self.rgb_padding, self.density_bias, c["w0"], c["dist0"], None, cc(g_dist0),
+                                  cc(g_acc0), cc(g_w0), None, d_den0)
+            self.prop.backward(d_den0, c["acts0"])
+
+    def _draws(self, n, randomized, dev):
+        """The reference's three torch RNG draws (mip.py:283, math_ops.py:52, models.py:163-165), taken in its order."""
+        s_rand = torch.rand(n, self.n_samples + 1, device=dev) if randomized else None
+        noise0 = noise1 = None
+        if randomized and self.density_noise > 0:
+            noise0 = self.density_noise * torch.randn(n, self.n_samples, device=dev)
+        if randomized:
+            P1 = self.N_fine
+            s = 1 / P1
+            jit = torch.empty(n, P1, device=dev).uniform_(to=s - EPS32)
+            u = torch.minimum(torch.arange(P1, device=dev) * s + jit, torch.ones_like(jit) - EPS32)
+            if self.density_noise > 0:
+                noise1 = self.density_noise * torch.randn(n, P1 - 1, device=dev)
+        else:
+            u = torch.linspace(0., 1. - EPS32, self.N_fine).to(dev)
+        return s_rand, u, noise0, noise1
+
+    # ---------------------------------------------------------------- public ----
+    def forward(self, rays, randomized, white_bg, viewc=0., s_rand=None, u=None):
+        """-> [[None, distance, acc(, s_vals, weights)], [rgb, distance, acc, None(, s_vals, weights)]]
+        (models.py:178-187).  `s_rand` / `u` override the internal draws (parity tests)."""
+        if white_bg:
+            raise NotImplementedError("white_bg=True crashes the reference at the proposal level (mip.py:188, rgb is None)")
+        self._check_arena()
+        dev = self.arena.flat.device
+        n = rays.origins.shape[0]
+        ds_rand, du, noise0, noise1 = self._draws(n, randomized, dev)
+        if s_rand is None:
+            s_rand = ds_rand
+        if u is None:
+            u = du
+        s_rand = None if s_rand is None else s_rand.to(dev).float().contiguous()
+        u = u.to(dev).float().contiguous()
+        params = self.param_list()
+        keep = torch.is_grad_enabled() and any(p.requires_grad for p in params)   # grad mode is off inside Function.forward
+        outs = _MipFn.apply(self, rays, bool(white_bg), s_rand, u, noise0, noise1, keep, *params)
+        dist0, acc0, s0, w0, rgb1, dist1, acc1, s1, w1 = outs
+        ret = [[None, dist0, acc0], [rgb1, dist1, acc1, None]]
+        if self.proposal_loss:
+            ret[0] += [s0, w0]
+            ret[1] += [s1, w1]
+        return ret
+
+
+class _MipFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, rays, white_bg, s_rand, u, noise0, noise1, keep, *params):
+        outs, c = model._run(rays, keep, white_bg, s_rand, u, noise0, noise1)
+        ctx.model, ctx.c = model, c
+        ctx.mark_non_differentiable(outs[2], outs[7])
+        return outs
+
+    @staticmethod
+    def backward(ctx, g_dist0, g_acc0, g_s0, g_w0, g_rgb1, g_dist1, g_acc1, g_s1, g_w1):
+        if ctx.c is None:
+            raise RuntimeError("MipNerfModel.forward ran without saved activations")
+        m = ctx.model
+        m.arena.grad.zero_()
+        m._backward(ctx.c, g_dist0, g_acc0, g_w0, g_rgb1, g_dist1, g_acc1, g_w1)
+        ctx.c = None
+        grads = tuple(m.arena.g[n].clone() for n in m._pnames)
+        return (None,) * 8 + grads
+
+
+def make_mipnerf(args, device="cuda", compute="bf16"):
+    """models.py:190-197."""
+    return MipNerfModel(no_warp_sample=args.no_warp_sample, disable_integration=args.disable_integration, ray_shape=args.ray_shape,
+                        fn=args.fn, max_deg_point=args.max_degree, radius=args.radius, transform_idx=args.transform_idx,
+                        real=args.real, rgb_layer=args.rgb_layer, hidden_layer=args.hidden_layer, density_noise=args.density_noise,
+                        encode_appearance=args.encode_appearance, n_samples=args.N_samples, proposal_loss=args.proposal_loss,
+                        N_fine=args.N_fine, semantic=args.semantic, semantic_class_num=args.semantic_class_num,
+                        compute=compute, device=device)
+
+
+def render_image(render_fn, rays, rank=0, chunk=8192):
+    """Chunked full-frame inference (models.py:328-360): rays fields [H,W,.] -> (rgb [H,W,3], distance [H,W],
+    acc [H,W], semantic=None).  One process drives one GPU, so the reference's reflect-padding to the
+    DataParallel device count is not needed."""
+    height, width = rays[0].shape[:2]
+    num_rays = height * width
+    flat = Rays(*[r.reshape(num_rays, -1) for r in rays])
+    res = []
+    for i in range(0, num_rays, chunk):
+        out = render_fn(Rays(*[r[i:i + chunk] for r in flat]))[-1]
+        res.append(out[:3])
+    rgb, dist, acc = [torch.cat(r, 0) for r in zip(*res)]
+    return rgb.reshape(height, width, -1), dist.reshape(height, width), acc.reshape(height, width), None

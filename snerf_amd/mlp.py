@@ -1,0 +1,447 @@
+"""Tiny-MLP executors on top of the MFMA GEMM kernels (forward, data- and
+weight-gradient), one class per network of the reference:
+
+  ClassicNeRFNet  -- ``NeRF``        s-nerf/model/run_nerf_helpers.py:74-126
+  MipProposalNet  -- ``proposal``    s-nerf/model/models.py:299-325
+  MipNerfNet      -- ``MLP``         s-nerf/model/models.py:217-296
+
+Design (MI355X-first, not a translation of nn.Linear chains):
+  * parameters live in ONE flat fp32 arena (one Adam launch, one RCCL
+    all-reduce bucket); ``nn.Parameter`` objects of the drop-in modules are
+    views into it, gradients are views into a second flat arena;
+  * every layer's weight is packed once per parameter version into the GEMM
+    operand layout: [N padded to 128, K padded to the 128-byte tile row] in
+    the compute dtype, plus the transposed pack used by the data gradient;
+  * concatenations (skip connections, [bottleneck | view encoding]) are never
+    materialised: producers write into column ranges of one wide buffer;
+  * ReLU is fused into the forward epilogue, its mask and the bias gradient
+    (column sums) into the data-gradient epilogue; weight gradients are
+    accumulated with fp32 atomics straight into the flat gradient arena.
+"""
+import torch
+
+from . import ops
+from .ops import ACT_MASK, ACT_NONE, ACT_RELU, gran, roundup
+
+
+class ParamArena:
+    """Flat fp32 parameter + gradient storage with named views."""
+
+    def __init__(self, shapes, device):
+        self.names = [n for n, _ in shapes]
+        self.shapes = dict(shapes)
+        offs, o = {}, 0
+        for n, s in shapes:
+            numel = 1
+            for d in s:
+                numel *= d
+            offs[n] = (o, numel)
+            o += roundup(numel, 4)  # keep every view 16-byte aligned
+        self.numel = roundup(o, 4)
+        self.epoch = 0
+        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(self.numel, dtype=torch.float32, device=device)
+        self.p = {n: self.flat[a:a + c].view(self.shapes[n]) for n, (a, c) in offs.items()}
+        self.g = {n: self.grad[a:a + c].view(self.shapes[n]) for n, (a, c) in offs.items()}
+
+    def load(self, sd: dict, prefix: str = ""):
+        with torch.no_grad():
+            for n in self.names:
+                self.p[n].copy_(sd[prefix + n].to(self.flat.device, torch.float32))
+
+    def bump(self):
+        """Call after the parameters were modified behind torch's back (fused Adam kernel, RCCL broadcast)."""
+        self.epoch += 1
+
+    def version(self) -> int:
+        return self.flat._version + self.epoch
+
+
+def _w2(t):
+    return t if t.dim() == 2 else t.view(1, -1)
+
+
+class _Net:
+    """Shared machinery: packing, buffer helpers, layer calls."""
+
+    def __init__(self, arena: ParamArena, prefix: str, dt: int, variant: int = 0):
+        self.a, self.pre, self.dt, self.variant = arena, prefix, dt, variant
+        self.g = gran(dt)
+        self.tdt = ops.torch_dtype(dt)
+        self.dev = arena.flat.device
+        self._packed_version = -1
+        self.version_fn = arena.version   # drop-in modules override this with their nn.Parameter versions
+        self.fw, self.fb, self.tw = {}, {}, {}
+
+    # ---- packing -------------------------------------------------------------
+    def W(self, name):
+        return _w2(self.a.p[self.pre + name + ".weight"])
+
+    def B(self, name):
+        return self.a.p[self.pre + name + ".bias"]
+
+    def gW(self, name):
+        return _w2(self.a.g[self.pre + name + ".weight"])
+
+    def gB(self, name):
+        return self.a.g[self.pre + name + ".bias"]
+
+    def _pack_fwd(self, key, name, segs, kbuf):
+        W = self.W(name)
+        N = W.shape[0]
+        out = torch.zeros(roundup(N, 128), kbuf, dtype=self.tdt, device=self.dev)
+        for bc, wc, cnt in segs:
+            out[:N, bc:bc + cnt] = W[:, wc:wc + cnt]
+        b = torch.zeros(roundup(N, 128), dtype=torch.float32, device=self.dev)
+        b[:N] = self.B(name)
+        self.fw[key], self.fb[key] = out, b
+
+    def _pack_dgrad(self, key, parts, wc, cnt):
+        """W^T restricted to weight columns [wc, wc+cnt) for one or more layers that read the same
+        activation: rows = those input columns (padded to 128), cols = concat of each layer's outputs
+        padded to the tile granularity (matches the [dZ_a | dZ_b] gradient buffer)."""
+        cols = sum(roundup(self.W(n).shape[0], self.g) for n in parts)
+        out = torch.zeros(roundup(cnt, 128), cols, dtype=self.tdt, device=self.dev)
+        c = 0
+        for n in parts:
+            W = self.W(n)
+            out[:cnt, c:c + W.shape[0]] = W[:, wc:wc + cnt].t()
+            c += roundup(W.shape[0], self.g)
+        self.tw[key] = out
+
+    def ensure_packed(self, train: bool):
+        v = self.version_fn()
+        if self._packed_version != v or (train and not self.tw):
+            with torch.no_grad():
+                self.pack(train)
+            self._packed_version = v
+
+    # ---- kernels ---------------------------------------------------------------
+    def buf(self, M, cols, f32=False):
+        return torch.empty(M, cols, dtype=torch.float32 if f32 else self.tdt, device=self.dev)
+
+    def fwd(self, key, A, K, Y, n_store, act=ACT_RELU, out_f32=False):
+        ops.linear_fwd(A, self.fw[key], self.fb[key], Y, K, n_store, act, self.dt, out_f32=out_f32, variant=self.variant)
+
+    def dgrad(self, key, dZ, K, dX, n_store, mask=None, colsum=None):
+        ops.linear_fwd(dZ, self.tw[key], None, dX, K, n_store, ACT_MASK if mask is not None else ACT_NONE, self.dt,
+                       aux=mask, colsum=colsum, variant=self.variant)
+
+    def wgrad(self, name, dZ, X, n_valid, k_valid, wcol=0):
+        gw = self.gW(name)
+        ops.linear_wgrad(dZ, X, gw[:, wcol:], n_valid, k_valid, self.dt)
+
+    def head_grad(self, d_raw_f32, C):
+        """fp32 head gradient [M,C] -> compute-dtype buffer padded to the tile granularity."""
+        M = d_raw_f32.shape[0]
+        out = self.buf(M, roundup(C, self.g))
+        ops.cast_pad(d_raw_f32, C, out, out.shape[1], self.dt)
+        return out
+
+
+# =============================================================================
+# classic NeRF (path B)
+# =============================================================================
+class ClassicNeRFNet(_Net):
+    """8 x W trunk, cat([input_pts, h]) after layer `skip`, alpha / feature / views / rgb heads.
+    Buffers: E [M, Pw] embedding (63 + pad); SK [M, Pw + W] = [embedding | layer-skip output];
+    V [M, W + Vw] = [feature | view embedding (27 + pad)]; OUT [M,4] fp32 = [rgb | alpha]."""
+
+    def __init__(self, arena, prefix, dt, D=8, W=256, input_ch=63, input_ch_views=27, skips=(4,), variant=0):
+        super().__init__(arena, prefix, dt, variant)
+        assert len(skips) == 1 and 0 <= skips[0] < D - 1 and W % self.g == 0 and (W // 2) % self.g == 0
+        self.D, self.Wd, self.ic, self.icv, self.skip = D, W, input_ch, input_ch_views, skips[0]
+        self.Pw, self.Vw = roundup(input_ch, self.g), roundup(input_ch_views, self.g)
+
+    @staticmethod
+    def param_shapes(D=8, W=256, input_ch=63, input_ch_views=27, skips=(4,)):
+        out = []
+        for i in range(D):
+            k = input_ch if i == 0 else (W + input_ch if (i - 1) in skips else W)
+            out += [(f"pts_linears.{i}.weight", (W, k)), (f"pts_linears.{i}.bias", (W,))]
+        out += [("views_linears.0.weight", (W // 2, input_ch_views + W)), ("views_linears.0.bias", (W // 2,)),
+                ("feature_linear.weight", (W, W)), ("feature_linear.bias", (W,)),
+                ("alpha_linear.weight", (1, W)), ("alpha_linear.bias", (1,)),
+                ("rgb_linear.weight", (3, W // 2)), ("rgb_linear.bias", (3,))]
+        return out
+
+    def pack(self, train):
+        W, ic, Pw = self.Wd, self.ic, self.Pw
+        for i in range(self.D):
+            n = f"pts_linears.{i}"
+            if i == 0:
+                self._pack_fwd(n, n, [(0, 0, ic)], Pw)
+            elif i == self.skip + 1:
+                self._pack_fwd(n, n, [(0, 0, ic), (Pw, ic, W)], Pw + W)     # param [pts | h] -> buffer [pts pad | h]
+            else:
+                self._pack_fwd(n, n, [(0, 0, W)], W)
+        self._pack_fwd("alpha", "alpha_linear", [(0, 0, W)], W)
+        self._pack_fwd("feature", "feature_linear", [(0, 0, W)], W)
+        self._pack_fwd("views", "views_linears.0", [(0, 0, W + self.icv)], W + self.Vw)
+        self._pack_fwd("rgb", "rgb_linear", [(0, 0, W // 2)], W // 2)
+        if train:
+            self._pack_dgrad("rgb", ["rgb_linear"], 0, W // 2)
+            self._pack_dgrad("views", ["views_linears.0"], 0, W)             # only the feature columns need a gradient
+            self._pack_dgrad("fa", ["feature_linear", "alpha_linear"], 0, W)
+            for i in range(1, self.D):
+                n = f"pts_linears.{i}"
+                self._pack_dgrad(n, [n], ic if i == self.skip + 1 else 0, W)
+
+    def forward(self, pts, viewdirs, S, keep: bool):
+        """pts [M,3] fp32, viewdirs [N,3] -> raw [M,4] fp32 (+ saved activations when keep)."""
+        self.ensure_packed(keep)
+        M, W, Pw = pts.shape[0], self.Wd, self.Pw
+        E = self.buf(M, Pw)
+        SK = self.buf(M, Pw + W)
+        V = self.buf(M, W + self.Vw)
+        ops.classic_embed(pts, viewdirs, S, (self.ic - 3) // 6, (self.icv - 3) // 6, E, SK[:, :Pw], Pw, V[:, W:], self.Vw, self.dt)
+        acts = []
+        x, k = E, Pw
+        pp = [self.buf(M, W), self.buf(M, W)] if not keep else None
+        for i in range(self.D):
+            if i == self.skip:
+                y = SK[:, Pw:]
+            else:
+                y = self.buf(M, W) if keep else pp[i & 1]
+            self.fwd(f"pts_linears.{i}", x, k, y, W)
+            acts.append((x, k, y))
+            if i == self.skip:
+                x, k = SK, Pw + W
+            else:
+                x, k = y, W
+        OUT = self.buf(M, 4, f32=True)
+        self.fwd("alpha", x, W, OUT[:, 3:], 1, ACT_NONE, out_f32=True)
+        self.fwd("feature", x, W, V[:, :W], W, ACT_NONE)
+        HV = self.buf(M, W // 2)
+        self.fwd("views", V, W + self.Vw, HV, W // 2)
+        self.fwd("rgb", HV, W // 2, OUT[:, :3], 3, ACT_NONE, out_f32=True)
+        saved = (acts, V, HV, SK, E) if keep else None
+        return OUT, saved
+
+    def backward(self, d_raw, saved):
+        """d_raw [M,4] fp32 -> accumulates parameter gradients into the arena."""
+        acts, V, HV, SK, E = saved
+        W, Pw, g, M = self.Wd, self.Pw, self.g, d_raw.shape[0]
+        ops.colsum_f32(d_raw, 3, self.gB("rgb_linear"))
+        ops.colsum_f32(d_raw[:, 3:], 1, self.gB("alpha_linear"))
+        dz = self.head_grad(d_raw, 3)
+        self.wgrad("rgb_linear", dz, HV, 3, W // 2)
+        dHV = self.buf(M, W // 2)
+        self.dgrad("rgb", dz, dz.shape[1], dHV, W // 2, mask=HV, colsum=self.gB("views_linears.0"))
+        self.wgrad("views_linears.0", dHV, V, W // 2, W + self.icv)
+        DB = self.buf(M, W + g)                                   # [d feature | d alpha (+pad)]
+        self.dgrad("views", dHV, W // 2, DB, W, colsum=self.gB("feature_linear"))
+        ops.cast_pad(d_raw[:, 3:], 1, DB[:, W:], g, self.dt)
+        x7 = acts[-1][2]
+        self.wgrad("feature_linear", DB[:, :W], x7, W, W)
+        self.wgrad("alpha_linear", DB[:, W:], x7, 1, W)
+        dZ = self.buf(M, W)
+        self.dgrad("fa", DB, W + g, dZ, W, mask=x7, colsum=self.gB(f"pts_linears.{self.D - 1}"))
+        for i in range(self.D - 1, -1, -1):
+            x, k, y = acts[i]
+            n = f"pts_linears.{i}"
+            if i == self.skip + 1:
+                self.wgrad(n, dZ, SK[:, :Pw], W, self.ic, wcol=0)
+                self.wgrad(n, dZ, SK[:, Pw:], W, W, wcol=self.ic)
+            elif i == 0:
+                self.wgrad(n, dZ, E, W, self.ic)
+            else:
+                self.wgrad(n, dZ, x, W, W)
+            if i > 0:
+                xin = acts[i - 1][2]                              # the trunk activation feeding layer i
+                dX = self.buf(M, W)
+                self.dgrad(n, dZ, W, dX, W, mask=xin, colsum=self.gB(f"pts_linears.{i - 1}"))
+                dZ = dX
+
+
+# =============================================================================
+# mip path (path A)
+# =============================================================================
+class MipProposalNet(_Net):
+    """proposal MLP: n_layers x (Linear+ReLU) width H, density head -> [M,1] fp32 (models.py:299-325)."""
+
+    def __init__(self, arena, prefix, dt, hidden=256, n_layers=4, feature_dim=96, variant=0):
+        super().__init__(arena, prefix, dt, variant)
+        assert hidden % self.g == 0
+        self.H, self.L, self.fd, self.Ew = hidden, n_layers, feature_dim, roundup(feature_dim, self.g)
+
+    @staticmethod
+    def param_shapes(hidden=256, n_layers=4, feature_dim=96):
+        out = []
+        for i in range(n_layers):
+            out += [(f"layers.{i}.layers.0.weight", (hidden, feature_dim if i == 0 else hidden)), (f"layers.{i}.layers.0.bias", (hidden,))]
+        return out + [("density_layer.weight", (1, hidden)), ("density_layer.bias", (1,))]
+
+    def pack(self, train):
+        for i in range(self.L):
+            n = f"layers.{i}.layers.0"
+            self._pack_fwd(n, n, [(0, 0, self.fd if i == 0 else self.H)], self.Ew if i == 0 else self.H)
+            if train and i > 0:
+                self._pack_dgrad(n, [n], 0, self.H)
+        self._pack_fwd("density", "density_layer", [(0, 0, self.H)], self.H)
+        if train:
+            self._pack_dgrad("density", ["density_layer"], 0, self.H)
+
+    def forward(self, E, keep: bool):
+        """E [M, Ew] encoded samples (compute dtype) -> raw density [M,1] fp32."""
+        self.ensure_packed(keep)
+        M, H = E.shape[0], self.H
+        acts, x, k = [], E, self.Ew
+        pp = [self.buf(M, H), self.buf(M, H)] if not keep else None
+        for i in range(self.L):
+            y = self.buf(M, H) if keep else pp[i & 1]
+            self.fwd(f"layers.{i}.layers.0", x, k, y, H)
+            acts.append((x, k, y))
+            x, k = y, H
+        out = self.buf(M, 1, f32=True)
+        self.fwd("density", x, H, out, 1, ACT_NONE, out_f32=True)
+        return out, (acts if keep else None)
+
+    def backward(self, d_raw_density, acts):
+        H, M = self.H, d_raw_density.shape[0]
+        ops.colsum_f32(d_raw_density, 1, self.gB("density_layer"))
+        dz = self.head_grad(d_raw_density, 1)
+        xl = acts[-1][2]
+        self.wgrad("density_layer", dz, xl, 1, H)
+        dZ = self.buf(M, H)
+        self.dgrad("density", dz, dz.shape[1], dZ, H, mask=xl, colsum=self.gB(f"layers.{self.L - 1}.layers.0"))
+        for i in range(self.L - 1, -1, -1):
+            x, k, y = acts[i]
+            n = f"layers.{i}.layers.0"
+            self.wgrad(n, dZ, x, H, self.fd if i == 0 else H)
+            if i > 0:
+                dX = self.buf(M, H)
+                self.dgrad(n, dZ, H, dX, H, mask=x, colsum=self.gB(f"layers.{i - 1}.layers.0"))
+                dZ = dX
+
+
+class MipNerfNet(_Net):
+    """NeRF MLP of the mip path (models.py:217-296): 8 DenseBlocks width H with cat([x, inputs]) after
+    layer `skip_layer` (trunk first), density head from the trunk, bottleneck, cat([bottleneck, cond]),
+    `n_cond` cond layers of 128, rgb head.
+    Buffers: SKIP [M, H + Ew] = [layer-4 output | IPE (+pad)] (layer 0 reads the IPE columns in place);
+             CB [M, H + Cw] = [bottleneck | view encoding (+pad)]."""
+
+    def __init__(self, arena, prefix, dt, hidden=1024, n_layers=8, skip_layer=4, feature_dim=96, cond_dim=27,
+                 n_cond=3, cond_units=128, variant=0):
+        super().__init__(arena, prefix, dt, variant)
+        assert hidden % self.g == 0 and cond_units % self.g == 0 and n_layers > skip_layer + 1
+        self.H, self.L, self.skip, self.fd, self.cd, self.nc, self.cu = hidden, n_layers, skip_layer, feature_dim, cond_dim, n_cond, cond_units
+        self.Ew, self.Cw = roundup(feature_dim, self.g), roundup(cond_dim, self.g)
+
+    @staticmethod
+    def param_shapes(hidden=1024, n_layers=8, skip_layer=4, feature_dim=96, cond_dim=27, n_cond=3, cond_units=128):
+        out = []
+        for i in range(n_layers):
+            k = feature_dim if i == 0 else (hidden + feature_dim if ((i - 1) % skip_layer == 0 and i - 1 > 0) else hidden)
+            out += [(f"layers.{i}.layers.0.weight", (hidden, k)), (f"layers.{i}.layers.0.bias", (hidden,))]
+        out += [("density_layer.weight", (1, hidden)), ("density_layer.bias", (1,)),
+                ("bottleneck_layer.layers.0.weight", (hidden, hidden)), ("bottleneck_layer.layers.0.bias", (hidden,))]
+        for j in range(n_cond):
+            out += [(f"cond_layers.{j}.layers.0.weight", (cond_units, hidden + cond_dim if j == 0 else cond_units)),
+                    (f"cond_layers.{j}.layers.0.bias", (cond_units,))]
+        return out + [("rgb_layer.weight", (3, cond_units)), ("rgb_layer.bias", (3,))]
+
+    def _is_skip_in(self, i):  # layer i consumes the concatenated [trunk | enc] buffer
+        return i >= 1 and (i - 1) % self.skip == 0 and (i - 1) > 0
+
+    def _is_skip_out(self, i):  # layer i's output is followed by the concat
+        return i % self.skip == 0 and i > 0
+
+    def pack(self, train):
+        H = self.H
+        for i in range(self.L):
+            n = f"layers.{i}.layers.0"
+            if i == 0:
+                self._pack_fwd(n, n, [(0, 0, self.fd)], self.Ew)
+            elif self._is_skip_in(i):
+                self._pack_fwd(n, n, [(0, 0, H + self.fd)], H + self.Ew)
+            else:
+                self._pack_fwd(n, n, [(0, 0, H)], H)
+            if train and i > 0:
+                self._pack_dgrad(n, [n], 0, H)
+        self._pack_fwd("density", "density_layer", [(0, 0, H)], H)
+        self._pack_fwd("bottleneck", "bottleneck_layer.layers.0", [(0, 0, H)], H)
+        for j in range(self.nc):
+            n = f"cond_layers.{j}.layers.0"
+            self._pack_fwd(n, n, [(0, 0, H + self.cd if j == 0 else self.cu)], H + self.Cw if j == 0 else self.cu)
+            if train:
+                self._pack_dgrad(n, [n], 0, H if j == 0 else self.cu)
+        self._pack_fwd("rgb", "rgb_layer", [(0, 0, self.cu)], self.cu)
+        if train:
+            self._pack_dgrad("rgb", ["rgb_layer"], 0, self.cu)
+            self._pack_dgrad("bd", ["bottleneck_layer.layers.0", "density_layer"], 0, H)
+
+    def alloc_inputs(self, M):
+        """-> (SKIP, CB); the encoders write SKIP[:, H:] and CB[:, H:] in place."""
+        return self.buf(M, self.H + self.Ew), self.buf(M, self.H + self.Cw)
+
+    def forward(self, SKIP, CB, keep: bool):
+        """-> raw_rgb [M,3] fp32, raw_density [M,1] fp32."""
+        self.ensure_packed(keep)
+        M, H = SKIP.shape[0], self.H
+        acts = []
+        x, k = SKIP[:, H:], self.Ew
+        pp = [self.buf(M, H), self.buf(M, H)] if not keep else None
+        for i in range(self.L):
+            if self._is_skip_out(i):
+                y = SKIP[:, :H]
+            else:
+                y = self.buf(M, H) if keep else pp[i & 1]
+            self.fwd(f"layers.{i}.layers.0", x, k, y, H)
+            acts.append((x, k, y))
+            if self._is_skip_out(i):
+                x, k = SKIP, H + self.Ew
+            else:
+                x, k = y, H
+        assert k == H, "a skip concat directly before the heads is not supported"
+        raw_d = self.buf(M, 1, f32=True)
+        self.fwd("density", x, H, raw_d, 1, ACT_NONE, out_f32=True)
+        self.fwd("bottleneck", x, H, CB[:, :H], H)
+        cacts = []
+        cx, ck = CB, H + self.Cw
+        for j in range(self.nc):
+            cy = self.buf(M, self.cu)
+            self.fwd(f"cond_layers.{j}.layers.0", cx, ck, cy, self.cu)
+            cacts.append((cx, ck, cy))
+            cx, ck = cy, self.cu
+        raw_rgb = self.buf(M, 3, f32=True)
+        self.fwd("rgb", cx, self.cu, raw_rgb, 3, ACT_NONE, out_f32=True)
+        return raw_rgb, raw_d, ((acts, cacts, SKIP, CB) if keep else None)
+
+    def backward(self, d_raw_rgb, d_raw_density, saved):
+        acts, cacts, SKIP, CB = saved
+        H, g, cu, M = self.H, self.g, self.cu, d_raw_rgb.shape[0]
+        ops.colsum_f32(d_raw_rgb, 3, self.gB("rgb_layer"))
+        ops.colsum_f32(d_raw_density, 1, self.gB("density_layer"))
+        dz = self.head_grad(d_raw_rgb, 3)
+        clast = cacts[-1][2]
+        self.wgrad("rgb_layer", dz, clast, 3, cu)
+        dC = self.buf(M, cu)
+        self.dgrad("rgb", dz, dz.shape[1], dC, cu, mask=clast, colsum=self.gB(f"cond_layers.{self.nc - 1}.layers.0"))
+        DB = self.buf(M, H + g)                                     # [d bottleneck | d raw density (+pad)]
+        for j in range(self.nc - 1, -1, -1):
+            cx, ck, cy = cacts[j]
+            n = f"cond_layers.{j}.layers.0"
+            self.wgrad(n, dC, cx, cu, H + self.cd if j == 0 else cu)
+            if j > 0:
+                dX = self.buf(M, cu)
+                self.dgrad(n, dC, cu, dX, cu, mask=cx, colsum=self.gB(f"cond_layers.{j - 1}.layers.0"))
+                dC = dX
+            else:
+                self.dgrad(n, dC, cu, DB, H, mask=CB, colsum=self.gB("bottleneck_layer.layers.0"))
+        ops.cast_pad(d_raw_density, 1, DB[:, H:], g, self.dt)
+        xl = acts[-1][2]
+        self.wgrad("bottleneck_layer.layers.0", DB[:, :H], xl, H, H)
+        self.wgrad("density_layer", DB[:, H:], xl, 1, H)
+        dZ = self.buf(M, H)
+        self.dgrad("bd", DB, H + g, dZ, H, mask=xl, colsum=self.gB(f"layers.{self.L - 1}.layers.0"))
+        for i in range(self.L - 1, -1, -1):
+            x, k, y = acts[i]
+            n = f"layers.{i}.layers.0"
+            self.wgrad(n, dZ, x, H, self.fd if i == 0 else (H + self.fd if self._is_skip_in(i) else H))
+            if i > 0:
+                xin = acts[i - 1][2]
+                dX = self.buf(M, H)
+                self.dgrad(n, dZ, H, dX, H, mask=xin, colsum=self.gB(f"layers.{i - 1}.layers.0"))
+                dZ = dX

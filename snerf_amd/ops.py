@@ -1,0 +1,246 @@
+"""Thin torch-tensor -> C-ABI wrappers (device pointers, strides, current HIP stream).
+
+PyTorch is plumbing here: it owns device memory and the stream.  Every
+function launches hand-written HIP kernels from libsnerf_hip.so through
+``_lib.call``; nothing in this file computes on the host or falls back to
+torch ops.
+"""
+import torch
+
+from . import _lib
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_MASK = 0, 1, 2
+_TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16}
+
+
+def torch_dtype(dt: int):
+    return _TORCH_DT[dt]
+
+
+def gran(dt: int) -> int:
+    """reduction-axis granularity of the GEMM tiles: 128-byte LDS rows."""
+    return 32 if dt == F32 else 64
+
+
+def roundup(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _chk2d(t, dt=None):
+    assert t.is_cuda and t.dim() == 2 and t.stride(1) == 1, "expected a row-major 2-D CUDA view"
+    if dt is not None:
+        assert t.dtype == dt, f"dtype {t.dtype} != {dt}"
+    return t
+
+
+def _f32c(t):
+    assert t is None or (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()), "expected contiguous fp32 CUDA tensor"
+    return t
+
+
+_zeros_cache = {}
+
+
+def zero_page(device):
+    z = _zeros_cache.get(device)
+    if z is None:
+        z = torch.zeros(64, dtype=torch.float32, device=device)
+        _zeros_cache[device] = z
+    return z
+
+
+# ------------------------------------------------------------------ GEMMs ----
+def linear_fwd(A, W, bias, Y, K, n_store, act, dt, out_f32=False, aux=None, colsum=None, variant=0):
+    """Y[:, :n_store] = act(A[:, :K] @ W[:, :K]^T + bias); A/W/Y are 2-D views (row stride = ld)."""
+    _chk2d(A, _TORCH_DT[dt]); _chk2d(W, _TORCH_DT[dt]); _chk2d(Y, torch.float32 if out_f32 else _TORCH_DT[dt])
+    M = A.shape[0]
+    assert Y.shape[0] == M and A.shape[1] >= K and W.shape[1] >= K and Y.shape[1] >= n_store
+    if aux is not None:
+        _chk2d(aux, _TORCH_DT[dt])
+    _lib.call("snerf_linear_fwd", _p(A), A.stride(0), _p(W), W.stride(0), _p(bias), _p(Y), Y.stride(0),
+              _p(aux), 0 if aux is None else aux.stride(0), _p(colsum), M, W.shape[0], K, n_store, act, dt,
+              1 if out_f32 else 0, variant, _stream())
+
+
+def linear_wgrad(dZ, X, dW, n_valid, k_valid, dt):
+    """dW[:n_valid, :k_valid] += dZ^T @ X (fp32 atomics).  dZ [M,N], X [M,K] views, dW fp32 view."""
+    _chk2d(dZ, _TORCH_DT[dt]); _chk2d(X, _TORCH_DT[dt]); _chk2d(dW, torch.float32)
+    assert dZ.shape[0] == X.shape[0] and dW.shape[0] >= n_valid and dW.shape[1] >= k_valid
+    _lib.call("snerf_linear_wgrad", _p(dZ), dZ.stride(0), _p(X), X.stride(0), _p(dW), dW.stride(0),
+              _p(zero_page(dZ.device)), dZ.shape[0], dZ.shape[1], X.shape[1], n_valid, k_valid, dt, _stream())
+
+
+# --------------------------------------------------------------- encoders ----
+def classic_embed(pts, viewdirs, S, L, Lv, dst1, dst2, w_pts, dstv, w_views, dt):
+    pts = _f32c(pts); M = pts.shape[0]
+    assert pts.shape[1] == 3
+    if viewdirs is not None:
+        assert viewdirs.dtype == torch.float32 and viewdirs.stride(1) == 1 and viewdirs.shape[1] == 3
+        assert M == viewdirs.shape[0] * S
+    _lib.call("snerf_classic_embed", _p(pts), _p(viewdirs), 0 if viewdirs is None else viewdirs.stride(0), S, M, L, Lv,
+              _p(dst1), dst1.stride(0), _p(dst2), 0 if dst2 is None else dst2.stride(0), w_pts,
+              _p(dstv), 0 if dstv is None else dstv.stride(0), w_views, dt, _stream())
+
+
+def mip_encode(s_vals, origins, directions, radii, near, far, cone, transform_idx, max_deg, dst1, dst2, width, dt,
+               means_out=None, covs_out=None):
+    n, P = s_vals.shape
+    for t in (s_vals, origins, directions, radii, near, far):
+        _f32c(t)
+    _lib.call("snerf_mip_encode", _p(s_vals), _p(origins), _p(directions), _p(radii), _p(near), _p(far), n, P - 1,
+              1 if cone else 0, transform_idx, max_deg, _p(dst1), dst1.stride(0), _p(dst2),
+              0 if dst2 is None else dst2.stride(0), width, _p(_f32c(means_out)), _p(_f32c(covs_out)), dt, _stream())
+
+
+def mip_viewenc(viewdirs, S, deg, dst, width, dt):
+    _f32c(viewdirs)
+    _lib.call("snerf_mip_viewenc", _p(viewdirs), viewdirs.shape[0], S, deg, _p(dst), dst.stride(0), width, dt, _stream())
+
+
+# --------------------------------------------------------------- samplers ----
+def _u_arg(u, n, nf):
+    _f32c(u)
+    if u.dim() == 1:
+        assert u.shape[0] == nf
+        return u, 0
+    assert u.shape == (n, nf)
+    return u, nf
+
+
+def classic_sample_pdf(bins, weights, u, mid_mode, want_inds=False, want_std=False):
+    """mid_mode True: bins = z_vals [N,S], weights [N,S] (the kernel uses mids and weights[:,1:-1]);
+    mid_mode False: bins [N,nb], weights [N,nb-1]."""
+    _f32c(bins); _f32c(weights)
+    n = bins.shape[0]
+    if mid_mode:
+        assert weights.shape == bins.shape
+        nc, wptr = bins.shape[1] - 1, weights.data_ptr() + 4
+    else:
+        assert weights.shape[1] == bins.shape[1] - 1
+        nc, wptr = bins.shape[1], weights.data_ptr()
+    nf = u.shape[-1]
+    u, us = _u_arg(u, n, nf)
+    dev = bins.device
+    out = torch.empty(n, nf, dtype=torch.float32, device=dev)
+    inds = torch.empty(n, nf, dtype=torch.int32, device=dev) if want_inds else None
+    std = torch.empty(n, dtype=torch.float32, device=dev) if want_std else None
+    _lib.call("snerf_classic_sample_pdf", _p(bins), bins.stride(0), 1 if mid_mode else 0, wptr, weights.stride(0), nc,
+              _p(u), us, n, nf, _p(out), _p(inds), _p(std), _stream())
+    return out, inds, std
+
+
+def classic_points(rays, z_vals):
+    assert rays.is_cuda and rays.dtype == torch.float32 and rays.stride(1) == 1
+    _f32c(z_vals)
+    n, S = z_vals.shape
+    pts = torch.empty(n, S, 3, dtype=torch.float32, device=z_vals.device)
+    _lib.call("snerf_classic_points", _p(rays), rays.stride(0), _p(z_vals), n, S, _p(pts), _stream())
+    return pts
+
+
+def classic_merge_sort(a, b):
+    _f32c(a); _f32c(b)
+    n = a.shape[0]
+    out = torch.empty(n, a.shape[1] + b.shape[1], dtype=torch.float32, device=a.device)
+    _lib.call("snerf_classic_merge_sort", _p(a), a.shape[1], _p(b), b.shape[1], n, _p(out), _stream())
+    return out
+
+
+def mip_resample(s_vals, weights, u, resample_padding=0.01, want_idx=False):
+    _f32c(s_vals); _f32c(weights)
+    n, P = s_vals.shape
+    nf = u.shape[-1]
+    u, us = _u_arg(u, n, nf)
+    out = torch.empty(n, nf, dtype=torch.float32, device=s_vals.device)
+    idx = torch.empty(n, nf, dtype=torch.int32, device=s_vals.device) if want_idx else None
+    _lib.call("snerf_mip_resample", _p(s_vals), _p(weights), _p(u), us, n, P - 1, nf, float(resample_padding), _p(out), _p(idx), _stream())
+    return out, idx
+
+
+def stratified(base, rnd, near, far, n, mode, lindisp=False):
+    """mode 0: classic z-values from near/far [N] views (stride in elements); mode 1: mip s-values."""
+    _f32c(base); _f32c(rnd)
+    P = base.shape[0]
+    out = torch.empty(n, P, dtype=torch.float32, device=base.device)
+    nfs = 0
+    if mode == 0:
+        assert near.dtype == torch.float32 and far.dtype == torch.float32 and near.stride(0) == far.stride(0)
+        nfs = near.stride(0)
+    _lib.call("snerf_stratified", _p(base), _p(rnd), _p(near), _p(far), nfs, n, P, mode, 1 if lindisp else 0, _p(out), _stream())
+    return out
+
+
+# ------------------------------------------------------------- compositing ----
+def mip_composite_fwd(raw_rgb, raw_density, noise, s_vals, dirs, near, far, transform_idx, white, rgb_padding, density_bias):
+    n, P = s_vals.shape
+    S = P - 1
+    dev = s_vals.device
+    comp = torch.empty(n, 3, dtype=torch.float32, device=dev) if raw_rgb is not None else None
+    dist = torch.empty(n, dtype=torch.float32, device=dev)
+    acc = torch.empty(n, dtype=torch.float32, device=dev)
+    w = torch.empty(n, S, dtype=torch.float32, device=dev)
+    _lib.call("snerf_mip_composite_fwd", _p(raw_rgb), 0 if raw_rgb is None else raw_rgb.stride(0), _p(raw_density),
+              raw_density.stride(0), _p(_f32c(noise)), _p(_f32c(s_vals)), _p(_f32c(dirs)), _p(_f32c(near)), _p(_f32c(far)), n, S,
+              transform_idx, 1 if white else 0, float(rgb_padding), float(density_bias), _p(comp), _p(dist), _p(acc), _p(w), _stream())
+    return comp, dist, acc, w
+
+
+def mip_composite_bwd(raw_rgb, raw_density, noise, s_vals, dirs, near, far, transform_idx, white, rgb_padding, density_bias,
+                      weights, distance, g_rgb, g_dist, g_acc, g_w, d_raw_rgb, d_raw_density):
+    n, P = s_vals.shape
+    for t in (g_rgb, g_dist, g_acc, g_w, weights, distance):
+        _f32c(t)
+    _lib.call("snerf_mip_composite_bwd", _p(raw_rgb), 0 if raw_rgb is None else raw_rgb.stride(0), _p(raw_density),
+              raw_density.stride(0), _p(noise), _p(s_vals), _p(dirs), _p(near), _p(far), n, P - 1, transform_idx,
+              1 if white else 0, float(rgb_padding), float(density_bias), _p(weights), _p(distance), _p(g_rgb), _p(g_dist),
+              _p(g_acc), _p(g_w), _p(d_raw_rgb), 0 if d_raw_rgb is None else d_raw_rgb.stride(0), _p(d_raw_density),
+              d_raw_density.stride(0), _stream())
+
+
+def classic_composite_fwd(raw, noise, z_vals, rays_d, white):
+    _chk2d(raw, torch.float32); _f32c(z_vals); _f32c(noise)
+    n, S = z_vals.shape
+    dev = z_vals.device
+    assert rays_d.dtype == torch.float32 and rays_d.stride(1) == 1
+    rgb = torch.empty(n, 3, dtype=torch.float32, device=dev)
+    disp, acc, depth = (torch.empty(n, dtype=torch.float32, device=dev) for _ in range(3))
+    w = torch.empty(n, S, dtype=torch.float32, device=dev)
+    _lib.call("snerf_classic_composite_fwd", _p(raw), raw.stride(0), _p(noise), _p(z_vals), _p(rays_d), rays_d.stride(0), n, S,
+              1 if white else 0, _p(rgb), _p(disp), _p(acc), _p(w), _p(depth), _stream())
+    return rgb, disp, acc, w, depth
+
+
+def classic_composite_bwd(raw, noise, z_vals, rays_d, white, weights, acc, depth, g_rgb, g_disp, g_acc, g_depth, g_w, d_raw):
+    n, S = z_vals.shape
+    for t in (weights, acc, depth, g_rgb, g_disp, g_acc, g_depth, g_w):
+        _f32c(t)
+    _lib.call("snerf_classic_composite_bwd", _p(raw), raw.stride(0), _p(noise), _p(z_vals), _p(rays_d), rays_d.stride(0), n, S,
+              1 if white else 0, _p(weights), _p(acc), _p(depth), _p(g_rgb), _p(g_disp), _p(g_acc), _p(g_depth), _p(g_w),
+              _p(d_raw), d_raw.stride(0), _stream())
+
+
+# ------------------------------------------------------------ training tail ----
+def adam_step(p, g, m, v, lr, b1, b2, eps, step, grad_scale=1.0, zero_grad=True):
+    for t in (p, g, m, v):
+        _f32c(t)
+    _lib.call("snerf_adam_step", _p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(b1), float(b2), float(eps), int(step),
+              float(grad_scale), 1 if zero_grad else 0, _stream())
+
+
+def colsum_f32(x, C, out):
+    _chk2d(x, torch.float32)
+    _lib.call("snerf_colsum_f32", _p(x), x.stride(0), x.shape[0], C, _p(out), _stream())
+
+
+def cast_pad(src, C, dst, Cpad, dt):
+    _chk2d(src, torch.float32)
+    _lib.call("snerf_cast_pad", _p(src), src.stride(0), src.shape[0], C, Cpad, _p(dst), dst.stride(0), dt, _stream())

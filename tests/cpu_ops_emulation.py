@@ -1,0 +1,165 @@
+"""TEST INFRASTRUCTURE: a CPU emulation of the `snerf_amd.ops` entry points (same signatures, in-place
+semantics) built from the oracle, so that the HOST logic above the C-ABI -- weight packing, buffer/column
+plumbing, the hand-written backward chains of snerf_amd.mlp, the autograd glue and the trainer -- can be
+exercised by `-m "not gpu"` tests in a container without a GPU.  Never imported by the product."""
+import contextlib
+
+import torch
+
+from oracle import classic as oc
+from oracle import mip as om
+
+
+def linear_fwd(A, W, bias, Y, K, n_store, act, dt, out_f32=False, aux=None, colsum=None, variant=0):
+    assert W.shape[0] % 128 == 0 and K % (32 if dt == 0 else 64) == 0
+    y = A[:, :K].float() @ W[:, :K].float().t()
+    if bias is not None:
+        y = y + bias
+    y = y[:, :n_store]
+    if act == 1:
+        y = torch.relu(y)
+    elif act == 2:
+        y = y * (aux[:, :n_store].float() > 0)
+    Y[:, :n_store] = y.to(Y.dtype)
+    if colsum is not None:
+        colsum[:n_store] += y.sum(0)
+
+
+def linear_wgrad(dZ, X, dW, n_valid, k_valid, dt):
+    dW[:n_valid, :k_valid] += (dZ.float().t() @ X.float())[:n_valid, :k_valid]
+
+
+def classic_embed(pts, viewdirs, S, L, Lv, dst1, dst2, w_pts, dstv, w_views, dt):
+    e = oc.embed(pts, L)
+    pad = torch.zeros(pts.shape[0], w_pts - e.shape[1])
+    v = torch.cat([e, pad], -1)
+    dst1[:, :w_pts] = v.to(dst1.dtype)
+    if dst2 is not None:
+        dst2[:, :w_pts] = v.to(dst2.dtype)
+    if viewdirs is not None:
+        ev = oc.embed(viewdirs[:, None].expand(-1, S, -1).reshape(-1, 3), Lv)
+        dstv[:, :w_views] = torch.cat([ev, torch.zeros(ev.shape[0], w_views - ev.shape[1])], -1).to(dstv.dtype)
+
+
+def mip_encode(s_vals, origins, directions, radii, near, far, cone, transform_idx, max_deg, dst1, dst2, width, dt,
+               means_out=None, covs_out=None):
+    fm, fc = om.sample2enc(s_vals, origins, directions, radii[:, None], near[:, None], far[:, None], "cone" if cone else "cylinder", transform_idx)
+    enc = om.integrated_pos_enc(fm, fc, 0, max_deg).reshape(-1, 6 * max_deg)
+    v = torch.cat([enc, torch.zeros(enc.shape[0], width - enc.shape[1])], -1)
+    dst1[:, :width] = v.to(dst1.dtype)
+    if dst2 is not None:
+        dst2[:, :width] = v.to(dst2.dtype)
+
+
+def mip_viewenc(viewdirs, S, deg, dst, width, dt):
+    e = om.pos_enc(viewdirs, 0, deg, True)[:, None].expand(-1, S, -1).reshape(-1, 3 + 6 * deg)
+    dst[:, :width] = torch.cat([e, torch.zeros(e.shape[0], width - e.shape[1])], -1).to(dst.dtype)
+
+
+def classic_sample_pdf(bins, weights, u, mid_mode, want_inds=False, want_std=False):
+    n = bins.shape[0]
+    uu = u if u.dim() == 2 else u.expand(n, u.shape[0])
+    if mid_mode:
+        s, i = oc.sample_pdf(0.5 * (bins[:, 1:] + bins[:, :-1]), weights[:, 1:-1], uu)
+    else:
+        s, i = oc.sample_pdf(bins, weights, uu)
+    return s, (i.int() if want_inds else None), (torch.std(s, dim=-1, unbiased=False) if want_std else None)
+
+
+def classic_points(rays, z_vals):
+    return rays[:, None, 0:3] + rays[:, None, 3:6] * z_vals[..., None]
+
+
+def classic_merge_sort(a, b):
+    return torch.sort(torch.cat([a, b], -1), -1)[0]
+
+
+def mip_resample(s_vals, weights, u, resample_padding=0.01, want_idx=False):
+    s, i = om.warp_resample_s(s_vals, weights, u, resample_padding)
+    return s, (i if want_idx else None)
+
+
+def stratified(base, rnd, near, far, n, mode, lindisp=False):
+    if mode == 1:
+        return om.warp_sample_s(n, base.shape[0] - 1, rnd).contiguous()
+    return oc.stratified_z(near[:, None], far[:, None], base.shape[0], lindisp, rnd).contiguous()
+
+
+def mip_composite_fwd(raw_rgb, raw_density, noise, s_vals, dirs, near, far, transform_idx, white, rgb_padding, density_bias):
+    n, P = s_vals.shape
+    rd = raw_density.reshape(n, P - 1, 1)
+    if noise is not None:
+        rd = rd + noise.reshape(n, P - 1, 1)
+    rgb, den = om.activate(None if raw_rgb is None else raw_rgb.reshape(n, P - 1, 3), rd, rgb_padding, density_bias)
+    c, d, a, w, _ = om.volumetric_rendering(rgb, den, s_vals, dirs, near[:, None], far[:, None], white, None, transform_idx)
+    return c, d, a, w
+
+
+def mip_composite_bwd(raw_rgb, raw_density, noise, s_vals, dirs, near, far, transform_idx, white, rgb_padding, density_bias,
+                      weights, distance, g_rgb, g_dist, g_acc, g_w, d_raw_rgb, d_raw_density):
+    with torch.enable_grad():
+        rr = None if raw_rgb is None else raw_rgb.detach().clone().requires_grad_(True)
+        rd = raw_density.detach().clone().requires_grad_(True)
+        c, d, a, w = mip_composite_fwd(rr, rd, noise, s_vals, dirs, near, far, transform_idx, white, rgb_padding, density_bias)
+        loss = 0
+        for o, g in ((c, g_rgb), (d, g_dist), (a, g_acc), (w, g_w)):
+            if g is not None and o is not None:
+                loss = loss + (o * g).sum()
+        loss.backward()
+    d_raw_density.copy_(rd.grad)
+    if rr is not None:
+        d_raw_rgb.copy_(rr.grad)
+
+
+def classic_composite_fwd(raw, noise, z_vals, rays_d, white):
+    n, S = z_vals.shape
+    return oc.raw2outputs(raw.reshape(n, S, -1), z_vals, rays_d, noise, white)
+
+
+def classic_composite_bwd(raw, noise, z_vals, rays_d, white, weights, acc, depth, g_rgb, g_disp, g_acc, g_depth, g_w, d_raw):
+    with torch.enable_grad():
+        r = raw.detach().clone().requires_grad_(True)
+        outs = classic_composite_fwd(r, noise, z_vals, rays_d, white)
+        loss = 0
+        for o, g in zip(outs, (g_rgb, g_disp, g_acc, g_w, g_depth)):
+            if g is not None:
+                loss = loss + (o * g).sum()
+        loss.backward()
+    d_raw.copy_(r.grad)
+
+
+def adam_step(p, g, m, v, lr, b1, b2, eps, step, grad_scale=1.0, zero_grad=True):
+    gg = g * grad_scale
+    m.mul_(b1).add_(gg, alpha=1 - b1)
+    v.mul_(b2).addcmul_(gg, gg, value=1 - b2)
+    p.sub_((lr / (1 - b1 ** step)) * m / (v.sqrt() / (1 - b2 ** step) ** 0.5 + eps))
+    if zero_grad:
+        g.zero_()
+
+
+def colsum_f32(x, C, out):
+    out[:C] += x[:, :C].sum(0)
+
+
+def cast_pad(src, C, dst, Cpad, dt):
+    dst[:, :Cpad] = 0
+    dst[:, :C] = src[:, :C].to(dst.dtype)
+
+
+_NAMES = ["linear_fwd", "linear_wgrad", "classic_embed", "mip_encode", "mip_viewenc", "classic_sample_pdf", "classic_points",
+          "classic_merge_sort", "mip_resample", "stratified", "mip_composite_fwd", "mip_composite_bwd", "classic_composite_fwd",
+          "classic_composite_bwd", "adam_step", "colsum_f32", "cast_pad"]
+
+
+@contextlib.contextmanager
+def emulate_ops():
+    """Swap the C-ABI wrappers of snerf_amd.ops for the CPU emulation inside a `with` block."""
+    from snerf_amd import ops
+    saved = {n: getattr(ops, n) for n in _NAMES}
+    try:
+        for n in _NAMES:
+            setattr(ops, n, globals()[n])
+        yield ops
+    finally:
+        for n, f in saved.items():
+            setattr(ops, n, f)

@@ -1,0 +1,47 @@
+"""The C-ABI shared library loads without a GPU and exports every symbol include/snerf_hip.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from snerf_amd import _lib
+
+
+def test_header_parses_and_lists_entry_points():
+    protos = _lib.parse_header()
+    src = open(_lib.HEADER_PATH).read()
+    declared = set(re.findall(r"\bint\s+(snerf_\w+)\s*\(", re.sub(r"/\*.*?\*/", " ", src, flags=re.S)))
+    assert declared == set(protos) and len(protos) >= 18
+    for name in ("snerf_linear_fwd", "snerf_linear_wgrad", "snerf_mip_encode", "snerf_mip_resample", "snerf_classic_sample_pdf",
+                 "snerf_mip_composite_fwd", "snerf_mip_composite_bwd", "snerf_classic_composite_fwd", "snerf_adam_step"):
+        assert name in protos
+    # no torch / C++ types in the signatures: only pointers and plain scalars
+    for sig in protos.values():
+        for ty, _ in sig:
+            assert ty in (ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float)
+
+
+@pytest.mark.skipif(not os.path.exists(_lib.LIB_PATH), reason="libsnerf_hip.so not built (run __graft_entry__.build())")
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    for name in _lib.parse_header():
+        assert getattr(lib, name) is not None
+    assert lib.snerf_version() >= 1
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU/PyTorch fallback"):
+        _lib.load()
+
+
+def test_bad_arguments_are_rejected_without_a_gpu():
+    """argument validation happens before any launch, so it can be exercised on a CPU-only box"""
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("library not built")
+    with pytest.raises(_lib.SnerfHipError, match="bad argument"):
+        _lib.call("snerf_linear_fwd", None, 0, None, 0, None, None, 0, None, 0, None, 16, 100, 64, 1, 0, 1, 0, 0, None)  # N % 128 != 0
+    with pytest.raises(_lib.SnerfHipError, match="bad argument"):
+        _lib.call("snerf_mip_resample", None, None, None, 0, 4, 1, 8, 0.01, None, None, None)  # S < 2

@@ -1,0 +1,322 @@
+"""Stage-isolated parity of every HIP kernel against the CPU oracle (through the C-ABI).
+Integer / index outputs are compared bit-exactly; floating point within the tolerance written at each check."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import classic as oc
+from oracle import common, mip as om
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from snerf_amd import ops as _ops
+    return _ops
+
+
+def dev(t):
+    return t.cuda() if torch.is_tensor(t) else t
+
+
+def close(a, b, rtol, atol, what=""):
+    a = a.detach().double().cpu(); b = b.detach().double().cpu()
+    assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
+    assert torch.equal(torch.isnan(a), torch.isnan(b)), f"{what}: NaN pattern differs"
+    a = torch.nan_to_num(a, nan=0.0); b = torch.nan_to_num(b, nan=0.0)
+    err = (a - b).abs(); tol = atol + rtol * b.abs()
+    bad = err > tol
+    assert not bool(bad.any()), f"{what}: {int(bad.sum())}/{bad.numel()} out of tol, max err {err.max().item():.3e} at {np.unravel_index(int(err.argmax()), err.shape)}"
+
+
+def gen(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+# ------------------------------------------------------------------ GEMM ----
+@pytest.mark.parametrize("dt,M,N,K,variant", [(0, 300, 128, 96, 0), (0, 1000, 256, 1120, 0), (1, 300, 128, 128, 0),
+                                              (1, 1000, 256, 1152, 0), (1, 777, 256, 320, 1), (1, 2048, 1024, 1024, 1)])
+def test_linear_fwd(ops, dt, M, N, K, variant):
+    tdt = ops.torch_dtype(dt)
+    A = gen(M, K + ops.gran(dt), seed=1).to(tdt).cuda()            # wider buffer: lda != K
+    W = (gen(N, K, seed=2) / K ** 0.5).to(tdt).cuda()
+    bias = gen(N, seed=3).cuda()
+    n_store = N - 5
+    ref = torch.relu(A[:, :K].double().cpu() @ W.double().cpu().t() + bias.double().cpu())[:, :n_store]
+    Y = torch.full((M, N), 7.0, dtype=tdt, device="cuda")
+    ops.linear_fwd(A, W, bias, Y, K, n_store, ops.ACT_RELU, dt, variant=variant)
+    tol = 1e-5 if dt == 0 else 1e-2
+    close(Y[:, :n_store], ref, tol, tol, "relu out")
+    assert bool((Y[:, n_store:] == 7.0).all()), "columns >= n_store must not be written"
+    # fp32 output, no activation, column-offset destination
+    Y2 = torch.zeros(M, 4, dtype=torch.float32, device="cuda")
+    ops.linear_fwd(A, W, bias, Y2[:, 3:], K, 1, ops.ACT_NONE, dt, out_f32=True, variant=variant)
+    ref2 = (A[:, :K].double().cpu() @ W.double().cpu().t() + bias.double().cpu())[:, :1]
+    close(Y2[:, 3:], ref2, 1e-5 if dt == 0 else 2e-3, 1e-5 if dt == 0 else 2e-3, "head out")
+    assert bool((Y2[:, :3] == 0).all())
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+def test_linear_dgrad_mask_colsum(ops, dt):
+    tdt = ops.torch_dtype(dt)
+    M, Nred, Kout = 515, 192, 256
+    dZ = gen(M, Nred, seed=4).to(tdt).cuda()
+    Wt = (gen(Kout, Nred, seed=5) / Nred ** 0.5).to(tdt).cuda()
+    act = gen(M, Kout, seed=6).to(tdt).cuda()
+    dX = torch.zeros(M, Kout, dtype=tdt, device="cuda")
+    cs = torch.zeros(Kout, dtype=torch.float32, device="cuda")
+    ops.linear_fwd(dZ, Wt, None, dX, Nred, Kout, ops.ACT_MASK, dt, aux=act, colsum=cs)
+    ref = (dZ.double().cpu() @ Wt.double().cpu().t()) * (act.double().cpu() > 0)
+    tol = 1e-5 if dt == 0 else 1e-2
+    close(dX, ref, tol, tol, "dgrad")
+    close(cs, ref.sum(0), 1e-4 if dt == 0 else 2e-2, 1e-3 if dt == 0 else 5e-2, "colsum")
+
+
+@pytest.mark.parametrize("dt,M,N,K,nv,kv", [(0, 700, 96, 128, 90, 127), (0, 5000, 256, 1120, 256, 1120), (1, 700, 64, 128, 3, 128),
+                                            (1, 5000, 256, 320, 256, 283), (1, 3000, 1024, 1152, 1024, 1120)])
+def test_linear_wgrad(ops, dt, M, N, K, nv, kv):
+    tdt = ops.torch_dtype(dt)
+    dZ = gen(M, N, seed=7).to(tdt).cuda()
+    X = gen(M, K, seed=8).to(tdt).cuda()
+    dW = torch.ones(nv, kv, dtype=torch.float32, device="cuda")   # accumulates on top of existing content
+    ops.linear_wgrad(dZ, X, dW, nv, kv, dt)
+    ref = 1.0 + (dZ.double().cpu().t() @ X.double().cpu())[:nv, :kv]
+    close(dW, ref, 1e-4, 1e-3 * (M / 1000) ** 0.5, "wgrad")
+
+
+# -------------------------------------------------------------- encoders ----
+@pytest.mark.parametrize("dt", [0, 1])
+def test_classic_embed(ops, dt):
+    tdt = ops.torch_dtype(dt)
+    N, S = 7, 5
+    pts = gen(N * S, 3, seed=9, scale=4.0)
+    vd = torch.nn.functional.normalize(gen(N, 3, seed=10), dim=-1)
+    rb = torch.cat([torch.zeros(N, 8), vd], -1).cuda()             # strided viewdirs like ray_batch[:, -3:]
+    g = ops.gran(dt)
+    E = torch.full((N * S, 64), 9.0, dtype=tdt, device="cuda"); SK = torch.full((N * S, 64 + 32), 9.0, dtype=tdt, device="cuda")
+    V = torch.full((N * S, 16 + g), 9.0, dtype=tdt, device="cuda")
+    ops.classic_embed(pts.cuda(), rb[:, -3:], S, 10, 4, E, SK[:, :64], 64, V[:, 16:], g, dt)
+    ref_p = oc.embed(pts, 10); ref_v = oc.embed(vd[:, None].expand(N, S, 3).reshape(-1, 3), 4)
+    tol = 2e-6 if dt == 0 else 4e-3
+    close(E[:, :63], ref_p, 0, tol, "pts embed"); close(SK[:, :63], ref_p, 0, tol, "pts embed copy")
+    close(V[:, 16:16 + 27], ref_v, 0, tol, "view embed")
+    assert bool((E[:, 63] == 0).all()) and bool((V[:, 16 + 27:] == 0).all()) and bool((V[:, :16] == 9).all()) and bool((SK[:, 64:] == 9).all())
+
+
+@pytest.mark.parametrize("shape", ["cone", "cylinder"])
+def test_mip_encode(ops, golden, shape):
+    g = golden("g3_sample2enc")
+    n, P = g["s_vals"].shape
+    S = P - 1
+    args = [dev(g[k]).contiguous() for k in ("s_vals", "origins", "directions")] + [dev(g[k]).reshape(-1).contiguous() for k in ("radii", "near", "far")]
+    out = torch.full((n * S, 128), 5.0, dtype=torch.float32, device="cuda")
+    mo = torch.empty(n * S, 3, device="cuda"); co = torch.empty(n * S, 3, device="cuda")
+    ops.mip_encode(*args, shape == "cone", 0, 16, out[:, 16:], None, 100, ops.F32, means_out=mo, covs_out=co)
+    fm, fc = om.sample2enc(g["s_vals"], g["origins"], g["directions"], g["radii"], g["near"], g["far"], shape, 0)
+    close(mo.reshape(n, S, 3), fm, 2e-6, 2e-6, "contracted means")
+    close(co.reshape(n, S, 3), fc, 5e-5, 1e-9, "warped cov diag")
+    if shape == "cone":  # also pinned directly against the reference's own output
+        close(mo.reshape(n, S, 3), g["f_means"], 2e-6, 2e-6, "means vs reference")
+        close(co.reshape(n, S, 3), torch.diagonal(g["f_covs"], dim1=-2, dim2=-1), 5e-5, 1e-9, "cov vs reference")
+    enc = om.integrated_pos_enc(fm, fc, 0, 16).reshape(n * S, 96)
+    # sin of arguments up to 2^15 |x|: an input ulp (1e-7 relative) moves the phase by up to 2^15 * 2 * 1e-7 ~ 7e-3 rad at the
+    # highest degree; those features are damped by exp(-var/2) but not always to zero -> compare per degree
+    got = out[:, 16:16 + 96].cpu()
+    for deg in range(16):
+        cols = [deg * 3 + d for d in range(3)] + [48 + deg * 3 + d for d in range(3)]
+        close(got[:, cols], enc[:, cols], 0, 3e-6 * 2 ** deg + 1e-6, f"IPE degree {deg}")
+    assert bool((out[:, 16 + 96:16 + 100] == 0).all()) and bool((out[:, :16] == 5).all()) and bool((out[:, 116:] == 5).all())
+
+
+def test_mip_encode_ipe_exact_inputs(ops, golden):
+    """IPE stage alone: feed means/covs that survive the sampler unchanged (|x| < 3 region is x/3 ... not exact), so instead
+    check the bf16 path against the fp32 path of the same kernel."""
+    g = golden("g2_cast")
+    n, P = g["s_vals"].shape
+    S = P - 1
+    args = [dev(g[k]).contiguous() for k in ("s_vals", "origins", "directions")] + [dev(g[k]).reshape(-1).contiguous() for k in ("radii", "near", "far")]
+    a = torch.empty(n * S, 96, dtype=torch.float32, device="cuda"); b = torch.empty(n * S, 128, dtype=torch.bfloat16, device="cuda")
+    ops.mip_encode(*args, True, 0, 16, a, None, 96, ops.F32)
+    ops.mip_encode(*args, True, 0, 16, b, None, 128, ops.BF16)
+    close(b[:, :96].float(), a, 0, 4e-3, "bf16 IPE vs fp32 IPE")
+    assert bool((b[:, 96:] == 0).all())
+
+
+def test_mip_viewenc(ops, golden):
+    x = golden("g1_posenc")["x"]
+    S = 3
+    out = torch.empty(x.shape[0] * S, 32, dtype=torch.float32, device="cuda")
+    ops.mip_viewenc(x.cuda().contiguous(), S, 4, out, 32, ops.F32)
+    ref = om.pos_enc(x, 0, 4, True)[:, None].expand(-1, S, -1).reshape(-1, 27)
+    close(out[:, :27], ref, 0, 2e-6, "view pos_enc")
+    assert bool((out[:, 27:] == 0).all())
+
+
+# -------------------------------------------------------------- samplers ----
+def test_stratified(ops):
+    N, P = 9, 17
+    near = torch.full((N,), 2.0) + gen(N, seed=11) * 0.1
+    far = torch.full((N,), 6.0) + gen(N, seed=12)
+    rb = torch.zeros(N, 11); rb[:, 6] = near; rb[:, 7] = far
+    rb = rb.cuda()
+    base = torch.linspace(0., 1., P)
+    rnd = torch.rand(N, P, generator=torch.Generator().manual_seed(13))
+    for lindisp in (False, True):
+        for r in (None, rnd):
+            z = ops.stratified(base.cuda(), dev(r), rb[:, 6], rb[:, 7], N, 0, lindisp)
+            ref = oc.stratified_z(near[:, None], far[:, None], P, lindisp, r)
+            assert torch.equal(z.cpu(), ref), f"classic stratified lindisp={lindisp} rand={r is not None}"
+    s = ops.stratified(torch.linspace(0., 1., P).cuda(), rnd.cuda(), None, None, N, 1)
+    assert torch.equal(s.cpu(), om.warp_sample_s(N, P - 1, rnd))
+
+
+def test_classic_sample_pdf(ops, golden):
+    g = golden("g9_sample_pdf")
+    bins, w = g["bins"], g["weights"]
+    n = bins.shape[0]
+    for u in (torch.linspace(0., 1., 24), g["u_rand"]):
+        ref_s, ref_i = oc.sample_pdf(bins, w, u if u.dim() == 2 else u.expand(n, 24))
+        s, inds, _ = ops.classic_sample_pdf(bins.cuda(), w.cuda(), u.cuda().contiguous(), False, want_inds=True)
+        assert torch.equal(inds.cpu().long(), ref_i), "sample_pdf indices must be bit-exact"
+        assert torch.equal(s.cpu(), ref_s), "sample_pdf samples must be bit-exact (same op sequence)"
+    # fused z_vals form + z_std, larger random case incl. zero weights
+    N, S, Nf = 200, 64, 128
+    gg = torch.Generator().manual_seed(14)
+    z = torch.sort(torch.rand(N, S, generator=gg) * 4 + 2, -1)[0]
+    ww = torch.rand(N, S, generator=gg) ** 4
+    ww[:5] = 0
+    u = torch.rand(N, Nf, generator=gg)
+    ref_s, ref_i = oc.sample_pdf(0.5 * (z[:, 1:] + z[:, :-1]), ww[:, 1:-1], u)
+    s, inds, std = ops.classic_sample_pdf(z.cuda(), ww.cuda(), u.cuda(), True, want_inds=True, want_std=True)
+    assert torch.equal(inds.cpu().long(), ref_i) and torch.equal(s.cpu(), ref_s)
+    close(std, torch.std(ref_s, dim=-1, unbiased=False), 1e-5, 1e-6, "z_std")
+
+
+def test_merge_sort(ops):
+    gg = torch.Generator().manual_seed(15)
+    a = torch.sort(torch.rand(37, 64, generator=gg), -1)[0]
+    b = torch.rand(37, 128, generator=gg)
+    b[0, :10] = a[0, :10]  # ties
+    out = ops.classic_merge_sort(a.cuda(), b.cuda())
+    assert torch.equal(out.cpu(), torch.sort(torch.cat([a, b], -1), -1)[0])
+
+
+def test_mip_resample(ops, golden):
+    for num in (32, 33):
+        g = golden(f"g5_pdf_{num}")
+        # A14 alone is reached through padding=0 on un-blurrable input; test the fused A13+A14 against the oracle
+        for u in (g["u_det"], om.rand_u(num, g["jitter"])):
+            ref_s, ref_i = om.warp_resample_s(g["bins"], g["weights"], u, 0.01)
+            s, idx = ops.mip_resample(g["bins"].cuda(), g["weights"].cuda(), u.cuda().contiguous(), 0.01, want_idx=True)
+            assert torch.equal(idx.cpu(), ref_i), "resample interval indices must be bit-exact"
+            assert torch.equal(s.cpu(), ref_s), "resample fence posts must be bit-exact"
+    N, S, Nf = 300, 128, 128
+    gg = torch.Generator().manual_seed(16)
+    sv = torch.sort(torch.rand(N, S + 1, generator=gg), -1)[0]
+    w = torch.rand(N, S, generator=gg) ** 6
+    w[:3] = 0; w[3] = 0; w[3, 50] = 1.0
+    u = om.rand_u(Nf, torch.empty(N, Nf).uniform_(0, 1 / Nf - om.EPS32, generator=gg))
+    ref_s, ref_i = om.warp_resample_s(sv, w, u, 0.01)
+    s, idx = ops.mip_resample(sv.cuda(), w.cuda(), u.cuda(), 0.01, want_idx=True)
+    assert torch.equal(idx.cpu(), ref_i) and torch.equal(s.cpu(), ref_s)
+
+
+# ------------------------------------------------------------ compositing ----
+def test_mip_composite_fwd_bwd(ops, golden):
+    for name, white in (("g6_volrend_white0", False), ("g6_volrend_white1", True)):
+        g = golden(name)
+        n, S = g["density"].shape[:2]
+        # invert the activations so the kernel's fused sigmoid/softplus reproduce the golden rgb/density
+        rgb, den = g["rgb"].double(), g["density"].double()
+        raw_rgb = torch.logit(((rgb + 0.001) / 1.002).clamp(1e-6, 1 - 1e-6)).float()
+        den_c = den.clamp(1e-6, 50.0)
+        raw_den = (torch.log(torch.expm1(den_c)) + 1.0).float()
+        rr = raw_rgb.reshape(-1, 3).cuda().contiguous(); rd = raw_den.reshape(-1, 1).cuda().contiguous()
+        sv, d = g["s_vals"].cuda(), g["dirs"].cuda()
+        near, far = g["near"].reshape(-1).cuda(), g["far"].reshape(-1).cuda()
+        comp, dist, acc, w = ops.mip_composite_fwd(rr, rd, None, sv, d, near, far, 0, white, 0.001, -1.0)
+        # oracle on the same raw values (rows 0/1 of the golden use density 0 / 1e4 which the inverse clamps)
+        raw_rgb_t = raw_rgb.clone().requires_grad_(True); raw_den_t = raw_den.clone().requires_grad_(True)
+        rgb_o, den_o = om.activate(raw_rgb_t, raw_den_t)
+        c_o, d_o, a_o, w_o, _ = om.volumetric_rendering(rgb_o, den_o, g["s_vals"], g["dirs"], g["near"], g["far"], white)
+        close(comp, c_o, 1e-5, 1e-6, "comp_rgb"); close(dist, d_o, 1e-5, 1e-5, "distance"); close(acc, a_o, 1e-5, 1e-6, "acc")
+        close(w, w_o, 1e-5, 1e-7, "weights")
+        sel = slice(2, None)  # rows with un-clamped densities also match the reference's own numbers
+        close(comp[sel], g["comp_rgb"][sel], 2e-5, 2e-6, "comp_rgb vs reference"); close(w[sel], g["weights"][sel], 2e-5, 1e-6, "w vs reference")
+        # backward against autograd of the oracle
+        gg = torch.Generator().manual_seed(17)
+        g_rgb, g_dist, g_acc, g_w = torch.randn(n, 3, generator=gg), torch.randn(n, generator=gg), torch.randn(n, generator=gg), torch.randn(n, S, generator=gg)
+        loss = (c_o * g_rgb).sum() + (d_o * g_dist).sum() + (a_o * g_acc).sum() + (w_o * g_w).sum()
+        loss.backward()
+        d_rgb = torch.empty(n * S, 3, device="cuda"); d_den = torch.empty(n * S, 1, device="cuda")
+        ops.mip_composite_bwd(rr, rd, None, sv, d, near, far, 0, white, 0.001, -1.0, w, dist, g_rgb.cuda(), g_dist.cuda(), g_acc.cuda(),
+                              g_w.cuda(), d_rgb, d_den)
+        close(d_rgb.reshape(n, S, 3), raw_rgb_t.grad, 1e-4, 1e-6, "d raw_rgb")
+        close(d_den.reshape(n, S, 1), raw_den_t.grad, 2e-4, 2e-5, "d raw_density")
+    g = golden("g6_volrend_norgb")
+    den_c = g["density"].double().clamp(1e-6, 50.0)
+    rd = (torch.log(torch.expm1(den_c)) + 1.0).float().reshape(-1, 1).cuda()
+    comp, dist, acc, w = ops.mip_composite_fwd(None, rd, None, g["s_vals"].cuda(), g["dirs"].cuda(), g["near"].reshape(-1).cuda(),
+                                               g["far"].reshape(-1).cuda(), 0, False, 0.001, -1.0)
+    assert comp is None
+    close(w[2:], g["weights"][2:], 2e-5, 1e-6, "proposal weights vs reference"); close(dist[2:], g["distance"][2:], 2e-5, 1e-5, "distance")
+    # sigma == 0 row: distance is clipped up to t_0 (nan/zero path of mip.py:185-186)
+    rd0 = torch.full((g["density"].shape[0] * g["density"].shape[1], 1), -80.0, device="cuda")
+    _, dist0, acc0, _ = ops.mip_composite_fwd(None, rd0, None, g["s_vals"].cuda(), g["dirs"].cuda(), g["near"].reshape(-1).cuda(),
+                                              g["far"].reshape(-1).cuda(), 0, False, 0.001, -1.0)
+    t0 = om.transform(g["s_vals"][:, :1], g["near"], g["far"], 0)[:, 0]
+    close(dist0, t0, 1e-6, 1e-6, "zero-density distance == t_0"); assert float(acc0.abs().max()) < 1e-30
+
+
+def test_classic_composite_fwd_bwd(ops, golden):
+    for name, white in (("g9_raw2outputs_white0", False), ("g9_raw2outputs_white1", True)):
+        g = golden(name)
+        raw, z, rd = g["raw"], g["z_vals"], g["rays_d"]
+        n, S = z.shape
+        out = ops.classic_composite_fwd(raw.reshape(-1, 4).cuda().contiguous(), None, z.cuda(), rd.cuda(), white)
+        for got, key in zip(out, ("rgb_map", "disp_map", "acc_map", "weights", "depth_map")):
+            close(got, g[key], 2e-5, 2e-6, key + " vs reference")
+        raw_t = raw.clone().requires_grad_(True)
+        o = oc.raw2outputs(raw_t, z, rd, None, white)
+        gg = torch.Generator().manual_seed(18)
+        gs = [torch.randn(n, 3, generator=gg), torch.randn(n, generator=gg) * 0.1, torch.randn(n, generator=gg),
+              torch.randn(n, S, generator=gg), torch.randn(n, generator=gg)]
+        sum((a * b).sum() for a, b in zip(o, gs)).backward()
+        d_raw = torch.zeros(n * S, 4, device="cuda")
+        ops.classic_composite_bwd(raw.reshape(-1, 4).cuda().contiguous(), None, z.cuda(), rd.cuda(), white, out[3], out[2], out[4],
+                                  gs[0].cuda(), gs[1].cuda(), gs[2].cuda(), gs[4].cuda(), gs[3].cuda(), d_raw)
+        close(d_raw.reshape(n, S, 4), raw_t.grad, 2e-4, 2e-5, "d raw")
+    # many-segment case (S = 192 > 2 wave segments) with noise
+    gg = torch.Generator().manual_seed(19)
+    n, S = 33, 192
+    raw = torch.randn(n, S, 4, generator=gg); z = torch.sort(torch.rand(n, S, generator=gg) * 4 + 2, -1)[0]; rd = torch.randn(n, 3, generator=gg)
+    noise = torch.randn(n, S, generator=gg)
+    out = ops.classic_composite_fwd(raw.reshape(-1, 4).cuda().contiguous(), noise.cuda(), z.cuda(), rd.cuda(), False)
+    ref = oc.raw2outputs(raw, z, rd, noise, False)
+    for got, want, key in zip(out, ref, ("rgb_map", "disp_map", "acc_map", "weights", "depth_map")):
+        close(got, want, 2e-5, 2e-6, key + " S=192")
+
+
+# ------------------------------------------------------------ training tail ----
+def test_adam_and_small_ops(ops):
+    n = 10007
+    p = gen(n, seed=20); gr = gen(n, seed=21)
+    pt = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pt], lr=5e-4, betas=(0.9, 0.999), eps=1e-8)
+    pc, gc, m, v = p.cuda().clone(), gr.cuda().clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    for step in range(1, 4):
+        pt.grad = gr.clone() * step
+        opt.step()
+        gc.copy_((gr * step).cuda() * 2.0)            # grad_scale 0.5 undoes the 2x
+        ops.adam_step(pc, gc, m, v, 5e-4, 0.9, 0.999, 1e-8, step, grad_scale=0.5, zero_grad=True)
+        assert float(gc.abs().max()) == 0.0
+    close(pc, pt.detach(), 1e-5, 1e-6, "adam params")
+    x = gen(1234, 4, seed=22).cuda()
+    out = torch.ones(3, device="cuda")
+    ops.colsum_f32(x, 3, out)
+    close(out, 1 + x[:, :3].double().sum(0).cpu(), 1e-5, 1e-4, "colsum")
+    dst = torch.full((1234, 64), 3.0, dtype=torch.bfloat16, device="cuda")
+    ops.cast_pad(x[:, 3:], 1, dst[:, 32:], 32, ops.BF16)
+    close(dst[:, 32].float(), x[:, 3].bfloat16().float(), 0, 0, "cast"); assert bool((dst[:, 33:] == 0).all()) and bool((dst[:, :32] == 3).all())

@@ -1,0 +1,110 @@
+"""Stage-isolated forward / backward parity of the three tiny-MLP executors (snerf_amd.mlp) against torch autograd of
+the oracle's MLPs on IDENTICAL inputs.  "hip": real MFMA kernels (GPU box); "emulated": host logic only (CPU)."""
+import pytest
+import torch
+
+from cpu_ops_emulation import emulate_ops
+from oracle import classic as oc
+from oracle import mip as om
+
+DEV = "cuda"
+
+
+@pytest.fixture(params=[pytest.param("hip", marks=pytest.mark.gpu), "emulated"])
+def backend(request):
+    global DEV
+    if request.param == "hip":
+        DEV = "cuda"
+        yield "hip"
+    else:
+        DEV = "cpu"
+        with emulate_ops():
+            yield "emulated"
+    DEV = "cuda"
+
+
+def rnd_params(shapes, seed):
+    g = torch.Generator().manual_seed(seed)
+    return {k: (torch.randn(s, generator=g) * (1.4 / s[1] ** 0.5) if len(s) == 2 else torch.randn(s, generator=g) * 0.1) for k, s in shapes}
+
+
+def rel(a, b):
+    a = a.detach().float().cpu(); b = b.detach().float().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-20)).item()
+
+
+def q(t, dt):
+    """round to the compute dtype like the encoders do when they write the MLP input"""
+    return t.bfloat16().float() if dt == 1 else t
+
+
+@pytest.mark.parametrize("dt,hidden,M,tol", [(0, 64, 333, 2e-5), (1, 128, 333, 2e-2), (0, 1024, 700, 2e-5), (1, 1024, 700, 2e-2)])
+def test_mip_nets(backend, dt, hidden, M, tol):
+    from snerf_amd import ops
+    from snerf_amd.mlp import MipNerfNet, MipProposalNet, ParamArena
+    shapes = [("mlp." + n, s) for n, s in MipNerfNet.param_shapes(hidden, 8, 4, 96, 27, 3, 128)]
+    shapes += [("proposal." + n, s) for n, s in MipProposalNet.param_shapes(256 if hidden == 1024 else hidden, 4, 96)]
+    sd = rnd_params(shapes, 3)
+    arena = ParamArena(shapes, torch.device(DEV))
+    arena.load(sd)
+    nerf = MipNerfNet(arena, "mlp.", dt, hidden)
+    prop = MipProposalNet(arena, "proposal.", dt, 256 if hidden == 1024 else hidden)
+    g = torch.Generator().manual_seed(4)
+    n, S = M // 9 + 1, 9
+    M = n * S
+    enc = q(torch.rand(n, S, 96, generator=g) * 2 - 1, dt)
+    cond = q(torch.rand(n, 27, generator=g) * 2 - 1, dt)
+    d_rgb, d_den, d_den0 = torch.randn(M, 3, generator=g), torch.randn(M, 1, generator=g), torch.randn(M, 1, generator=g)
+    # oracle + autograd
+    pr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    rr, rd, _ = om.nerf_mlp(pr, enc, cond)
+    pd = om.proposal_mlp(pr, enc)
+    ((rr.reshape(M, 3) * d_rgb).sum() + (rd.reshape(M, 1) * d_den).sum() + (pd.reshape(M, 1) * d_den0).sum()).backward()
+    # HIP / emulated path
+    tdt = ops.torch_dtype(dt)
+    SKIP, CB = nerf.alloc_inputs(M)
+    SKIP[:, hidden:] = 0; CB[:, hidden:] = 0
+    SKIP[:, hidden:hidden + 96] = enc.reshape(M, 96).to(DEV, tdt)
+    CB[:, hidden:hidden + 27] = cond[:, None].expand(n, S, 27).reshape(M, 27).to(DEV, tdt)
+    E0 = torch.zeros(M, prop.Ew, dtype=tdt, device=DEV); E0[:, :96] = enc.reshape(M, 96).to(DEV, tdt)
+    raw_rgb, raw_d, saved = nerf.forward(SKIP, CB, True)
+    raw_d0, acts0 = prop.forward(E0, True)
+    assert rel(raw_rgb, rr.reshape(M, 3)) < tol and rel(raw_d, rd.reshape(M, 1)) < tol and rel(raw_d0, pd.reshape(M, 1)) < tol, \
+        (rel(raw_rgb, rr.reshape(M, 3)), rel(raw_d, rd.reshape(M, 1)), rel(raw_d0, pd.reshape(M, 1)))
+    # inference mode (ping-pong buffers) must give the same numbers
+    raw_rgb_i, raw_d_i, _ = nerf.forward(SKIP.clone(), CB.clone(), False)
+    assert torch.equal(raw_rgb_i, raw_rgb) and torch.equal(raw_d_i, raw_d)
+    arena.grad.zero_()
+    nerf.backward(d_rgb.to(DEV), d_den.to(DEV), saved)
+    prop.backward(d_den0.to(DEV), acts0)
+    worst = max((rel(arena.g[k], pr[k].grad), k) for k in sd)
+    assert worst[0] < (5e-3 if dt == 0 else 0.25), f"worst gradient: {worst}"  # bf16: 8-bit mantissa through 12+ layers each way
+
+
+@pytest.mark.parametrize("dt,W,tol", [(0, 64, 2e-5), (1, 128, 2e-2), (0, 256, 2e-5), (1, 256, 2e-2)])
+def test_classic_net(backend, dt, W, tol):
+    from snerf_amd import ops
+    from snerf_amd.mlp import ClassicNeRFNet, ParamArena
+    shapes = ClassicNeRFNet.param_shapes(8, W, 63, 27, (4,))
+    sd = rnd_params(shapes, 5)
+    arena = ParamArena(shapes, torch.device(DEV))
+    arena.load(sd)
+    net = ClassicNeRFNet(arena, "", dt, 8, W)
+    g = torch.Generator().manual_seed(6)
+    n, S = 41, 7
+    M = n * S
+    pts = torch.rand(M, 3, generator=g) * 2 - 1
+    vd = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1)
+    d_raw = torch.randn(M, 4, generator=g)
+    pr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    e = torch.cat([q(oc.embed(pts, 10), dt), q(oc.embed(vd[:, None].expand(n, S, 3).reshape(M, 3), 4), dt)], -1)
+    ref = oc.nerf_mlp(pr, e)
+    (ref * d_raw).sum().backward()
+    raw, saved = net.forward(pts.to(DEV), vd.to(DEV), S, True)
+    assert rel(raw, ref) < tol, rel(raw, ref)
+    raw_i, _ = net.forward(pts.to(DEV), vd.to(DEV), S, False)
+    assert torch.equal(raw_i, raw)
+    arena.grad.zero_()
+    net.backward(d_raw.to(DEV), saved)
+    worst = max((rel(arena.g[k], pr[k].grad), k) for k in sd)
+    assert worst[0] < (5e-3 if dt == 0 else 0.25), f"worst gradient: {worst}"  # bf16: 8-bit mantissa through 12+ layers each way
