@@ -37,11 +37,12 @@ int snerf_version(void);
  * W is the packed weight [N (multiple of 128), K] in `dtype`; K a multiple of 64 (bf16) / 32 (fp32)
  * with zero padding; lda/ldw multiples of 8/4; Y is `dtype` or fp32 (out_f32).  With W := W^T the
  * same entry computes the data gradient; ACT_MASK applies the ReLU mask from `aux` and `colsum`
- * (fp32 [n_store], accumulated atomically) receives the column sums = bias gradient of the layer below.
- * variant: 0 = 128x128 tile, 1 = 256x256 tile (bf16, N % 256 == 0). */
+ * (fp32 [n_store], accumulated) receives the column sums = bias gradient of the layer below; `colsum_ws`
+ * (fp32 [2*ceil(M/128), N], contents irrelevant) lets that reduction run without atomics.
+ * variant: low nibble 0 = 128x128 tile, 1 = 256x256 tile (bf16, N % 256 == 0); higher bits = ablation switches. */
 int snerf_linear_fwd(const void* A, long lda, const void* W, long ldw, const float* bias, void* Y, long ldy,
-                     const void* aux, long ldaux, float* colsum, int M, int N, int K, int n_store, int act,
-                     int dtype, int out_f32, int variant, void* stream);
+                     const void* aux, long ldaux, float* colsum, float* colsum_ws, int M, int N, int K, int n_store,
+                     int act, int dtype, int out_f32, int variant, void* stream);
 
 /* dW[n_valid, k_valid] (fp32, ldw) += dZ[M,N]^T . X[M,K]  -- weight gradient of the same layers
  * (autograd of nn.Linear in the reference; train.py:213 loss.backward()).  `zeros` = >=16 bytes of

@@ -46,6 +46,16 @@ __device__ __forceinline__ float wave_incl_scan_add(float v, int lane) {
   return v;
 }
 
+// inclusive suffix sum: lane i gets sum over lanes >= i
+__device__ __forceinline__ float wave_incl_rscan_add(float v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    float t = __shfl_down(v, o, 64);
+    if (lane + o < 64) v += t;
+  }
+  return v;
+}
+
 __device__ __forceinline__ float wave_incl_scan_mul(float v, int lane) {
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {

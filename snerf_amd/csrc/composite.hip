@@ -10,6 +10,8 @@
 // raw network outputs are fp32 [M, ld] (the MLP heads store fp32).
 #include "common.h"
 
+#define MAXSEG 8   // backward kernels keep per-64-sample-segment partial sums in registers: S <= 512
+
 __device__ __forceinline__ float transform_s(float s, float near, float far, int idx) {
   if (idx == 0) return near * expf(s * logf(far / near));
   if (idx == 1) return 1.f / ((1.f - s) / near + s / far);
@@ -106,37 +108,48 @@ __global__ __launch_bounds__(256) void mip_composite_bwd_kernel(MipComp a) {
   if (a.g_rgb != nullptr) { grgb[0] = a.g_rgb[ray * 3]; grgb[1] = a.g_rgb[ray * 3 + 1]; grgb[2] = a.g_rgb[ray * 3 + 2]; }
   float gacc = a.g_acc != nullptr ? a.g_acc[ray] : 0.f;
   if (a.white && a.raw_rgb != nullptr) gacc -= grgb[0] + grgb[1] + grgb[2];
-  float gdist = 0.f;
-  if (a.g_dist != nullptr) {
-    // clip passes the gradient only strictly inside [t0, tS] (torch.clip semantics: boundary counts as inside)
-    const float d = a.distance[ray];
-    const float tlo = transform_s(sv[0], near, far, a.transform_idx), thi = transform_s(sv[S], near, far, a.transform_idx);
-    gdist = (d >= tlo && d <= thi) ? a.g_dist[ray] : 0.f;
-  }
   const int nseg = (S + 63) / 64;
-  // pass 1 (front to back): total of g_k w_k, needed to turn prefix sums into suffix sums
-  float total_gw = 0.f;
-  for (int seg = 0; seg < nseg; ++seg) {
+  // pass 1: per-segment sums of g_k w_k (split into the part without the distance gradient and sum w_k tmid_k).
+  // sum_k w_k tmid_k is the UNclipped distance, which decides whether clip() passes the distance gradient
+  // (torch.clip backward looks at its input).  Per-segment totals let pass 2 build suffix sums by direct
+  // summation (reverse scan) instead of total - prefix, which would cancel catastrophically near the far end.
+  float segA[MAXSEG], segB[MAXSEG];
+#pragma unroll
+  for (int seg = 0; seg < MAXSEG; ++seg) {
+    float pa = 0.f, pb = 0.f;
     const int i = seg * 64 + lane;
-    float gw = 0.f;
-    if (i < S) {
+    if (seg < nseg && i < S) {
       const float w = a.weights[ray * S + i];
       const float t0 = transform_s(sv[i], near, far, a.transform_idx), t1 = transform_s(sv[i + 1], near, far, a.transform_idx);
-      float g = gacc + gdist * (0.5f * (t0 + t1));
+      float g = gacc;
       if (a.g_w != nullptr) g += a.g_w[ray * S + i];
       if (a.raw_rgb != nullptr) {
         const float* rr = a.raw_rgb + (ray * S + i) * a.ld_rgb;
 #pragma unroll
         for (int c = 0; c < 3; ++c) g += grgb[c] * (sigmoid_f(rr[c]) * (1.f + 2.f * a.rgb_padding) - a.rgb_padding);
       }
-      gw = g * w;
+      pa = g * w;
+      pb = w * (0.5f * (t0 + t1));
     }
-    total_gw += gw;
+    segA[seg] = seg < nseg ? wave_sum(pa) : 0.f;
+    segB[seg] = seg < nseg ? wave_sum(pb) : 0.f;
   }
-  total_gw = wave_sum(total_gw);
+  float raw_dist = 0.f;
+#pragma unroll
+  for (int seg = 0; seg < MAXSEG; ++seg) raw_dist += segB[seg];
+  float gdist = 0.f;
+  if (a.g_dist != nullptr) {
+    const float tlo = transform_s(sv[0], near, far, a.transform_idx), thi = transform_s(sv[S], near, far, a.transform_idx);
+    gdist = (raw_dist >= tlo && raw_dist <= thi) ? a.g_dist[ray] : 0.f;   // false for NaN as well (nan -> inf -> clipped)
+  }
   // pass 2: per sample gradient
-  float carry_dd = 0.f, carry_gw = 0.f;
-  for (int seg = 0; seg < nseg; ++seg) {
+  float carry_dd = 0.f;
+#pragma unroll
+  for (int seg = 0; seg < MAXSEG; ++seg) {
+    if (seg >= nseg) break;
+    float later = 0.f;                                             // sum of g_k w_k over all later segments
+#pragma unroll
+    for (int s2 = 0; s2 < MAXSEG; ++s2) later += s2 > seg ? segA[s2] + gdist * segB[s2] : 0.f;
     const int i = seg * 64 + lane;
     const bool ok = i < S;
     float dd = 0.f, delta = 0.f, g = 0.f, w = 0.f, sp_grad = 0.f;
@@ -164,12 +177,10 @@ __global__ __launch_bounds__(256) void mip_composite_bwd_kernel(MipComp a) {
     }
     const float gw = g * w;
     const float incl_dd = wave_incl_scan_add(dd, lane);
-    const float incl_gw = wave_incl_scan_add(gw, lane);
     const float t_next = expf(-(carry_dd + incl_dd));              // T_{i+1}
-    const float suffix = total_gw - (carry_gw + incl_gw);          // sum_{k>i} g_k w_k
+    const float suffix = later + (wave_incl_rscan_add(gw, lane) - gw);   // sum_{k>i} g_k w_k
     if (ok) a.d_raw_density[(ray * S + i) * a.ld_dden] = (g * t_next - suffix) * delta * sp_grad;
     carry_dd += __shfl(incl_dd, 63, 64);
-    carry_gw += __shfl(incl_gw, 63, 64);
   }
 }
 
@@ -203,7 +214,7 @@ extern "C" int snerf_mip_composite_bwd(const float* raw_rgb, long ld_rgb, const 
                                        const float* g_w, float* d_raw_rgb, long ld_drgb, float* d_raw_density, long ld_dden,
                                        void* stream) {
   if (N <= 0) return SNERF_OK;
-  if (S <= 0 || raw_density == nullptr || weights == nullptr || d_raw_density == nullptr) return SNERF_ERR_ARG;
+  if (S <= 0 || S > 64 * MAXSEG || raw_density == nullptr || weights == nullptr || d_raw_density == nullptr) return SNERF_ERR_ARG;
   if (raw_rgb != nullptr && d_raw_rgb == nullptr) return SNERF_ERR_ARG;
   if (g_dist != nullptr && distance == nullptr) return SNERF_ERR_ARG;
   MipComp a = make_mip(raw_rgb, ld_rgb, raw_density, ld_den, noise, s_vals, dirs, near, far, N, S, transform_idx, white, rgb_padding, density_bias);
@@ -304,21 +315,28 @@ __global__ __launch_bounds__(256) void classic_composite_bwd_kernel(ClassicComp 
     }
   }
   const int nseg = (S + 63) / 64;
-  float total_gw = 0.f;
-  for (int seg = 0; seg < nseg; ++seg) {
+  float segG[MAXSEG];                                               // per-segment sums of g_k w_k
+#pragma unroll
+  for (int seg = 0; seg < MAXSEG; ++seg) {
+    float pg = 0.f;
     const int i = seg * 64 + lane;
-    if (i < S) {
+    if (seg < nseg && i < S) {
       const float* rr = a.raw + (ray * S + i) * a.ld;
       float g = gacc + gdepth * z[i];
       if (a.g_w != nullptr) g += a.g_w[ray * S + i];
 #pragma unroll
       for (int c = 0; c < 3; ++c) g += grgb[c] * sigmoid_f(rr[c]);
-      total_gw += g * a.weights[ray * S + i];
+      pg = g * a.weights[ray * S + i];
     }
+    segG[seg] = seg < nseg ? wave_sum(pg) : 0.f;
   }
-  total_gw = wave_sum(total_gw);
-  float carry_p = 1.f, carry_gw = 0.f;
-  for (int seg = 0; seg < nseg; ++seg) {
+  float carry_p = 1.f;
+#pragma unroll
+  for (int seg = 0; seg < MAXSEG; ++seg) {
+    if (seg >= nseg) break;
+    float later = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < MAXSEG; ++s2) later += s2 > seg ? segG[s2] : 0.f;
     const int i = seg * 64 + lane;
     const bool ok = i < S;
     float q = 1.f, g = 0.f, w = 0.f, dist = 0.f, sg = 0.f;
@@ -336,9 +354,9 @@ __global__ __launch_bounds__(256) void classic_composite_bwd_kernel(ClassicComp 
       float* dr = a.d_raw + (ray * S + i) * a.ld_draw;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        const float s = sigmoid_f(rr[c]);
-        g += grgb[c] * s;
-        dr[c] = w * grgb[c] * s * (1.f - s);
+        const float sgm = sigmoid_f(rr[c]);
+        g += grgb[c] * sgm;
+        dr[c] = w * grgb[c] * sgm * (1.f - sgm);
       }
     }
     const float gw = g * w;
@@ -346,15 +364,13 @@ __global__ __launch_bounds__(256) void classic_composite_bwd_kernel(ClassicComp 
     float excl_q = __shfl_up(incl_q, 1, 64);
     if (lane == 0) excl_q = 1.f;
     const float P = carry_p * excl_q;
-    const float incl_gw = wave_incl_scan_add(gw, lane);
-    const float suffix = total_gw - (carry_gw + incl_gw);
+    const float suffix = later + (wave_incl_rscan_add(gw, lane) - gw);
     if (ok) {
       const float dalpha = g * P - suffix / q;
       // alpha = 1 - exp(-relu(sg) dist): d alpha / d sg = dist * exp(-sg dist) for sg > 0
       a.d_raw[(ray * S + i) * a.ld_draw + 3] = sg > 0.f ? dalpha * dist * expf(-sg * dist) : 0.f;
     }
     carry_p *= __shfl(incl_q, 63, 64);
-    carry_gw += __shfl(incl_gw, 63, 64);
   }
 }
 
@@ -377,7 +393,7 @@ extern "C" int snerf_classic_composite_bwd(const float* raw, long ld, const floa
                                            const float* depth_map, const float* g_rgb, const float* g_disp, const float* g_acc,
                                            const float* g_depth, const float* g_w, float* d_raw, long ld_draw, void* stream) {
   if (N <= 0) return SNERF_OK;
-  if (S <= 0 || ld < 4 || ld_draw < 4 || raw == nullptr || weights == nullptr || d_raw == nullptr) return SNERF_ERR_ARG;
+  if (S <= 0 || S > 64 * MAXSEG || ld < 4 || ld_draw < 4 || raw == nullptr || weights == nullptr || d_raw == nullptr) return SNERF_ERR_ARG;
   if (g_disp != nullptr && (acc_map == nullptr || depth_map == nullptr)) return SNERF_ERR_ARG;
   ClassicComp a{};
   a.raw = raw; a.ld = ld; a.noise = noise; a.z_vals = z_vals; a.rays_d = rays_d; a.rd_stride = rd_stride; a.N = N; a.S = S; a.white = white;

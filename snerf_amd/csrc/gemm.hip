@@ -30,7 +30,9 @@ struct GemmNT {
   void* Y; long ldy;
   const void* aux; long ldaux;
   float* colsum;
-  int M, N, K, n_store, act, out_f32;
+  int M, N, K, n_store, act, out_f32, vec_store;
+  float* colsum_ws; int fast_epi;
+  int dbg;  // ablation bits (tools/gemm_probe.py): 1 = no staging loads after tile 0, 2 = no LDS fragment reads, 4 = no stores
 };
 
 template <typename T> struct Frag;
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmNT p) {
   for (int kt = 0; kt < KT; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (kt + 1 < KT) issue(kt + 1, (kt + 1) & 1);
+    if (kt + 1 < KT && !(p.dbg & 1)) issue(kt + 1, (kt + 1) & 1);
     const char* sA = smem + (kt & 1) * STAGE;
     const char* sB = sA + BM * 128;
 #pragma unroll
@@ -134,44 +136,197 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmNT p) {
       frag_t a[TM], b[TN];
       const int c = 2 * ks + chalf;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = *(const frag_t*)(sA + ra[i] * 128 + ((c ^ ((ra[i] >> 1) & 7)) << 4));
+      for (int i = 0; i < TM; ++i) a[i] = *(const frag_t*)((p.dbg & 2) ? smem + lane * 16 : sA + ra[i] * 128 + ((c ^ ((ra[i] >> 1) & 7)) << 4));
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = *(const frag_t*)(sB + rb[j] * 128 + ((c ^ ((rb[j] >> 1) & 7)) << 4));
+      for (int j = 0; j < TN; ++j) b[j] = *(const frag_t*)((p.dbg & 2) ? smem + lane * 16 + 1024 : sB + rb[j] * 128 + ((c ^ ((rb[j] >> 1) & 7)) << 4));
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) mma32(acc[i][j], a[i], b[j]);
+        for (int j = 0; j < TN; ++j) mma32(acc[i][j], b[j], a[i]);   // D = W-tile . X-tile^T: lanes own rows m
     }
   }
 
-  // epilogue: D[i][j], j = lane&31 (n), i = (r&3) + 8*(r>>2) + 4*(lane>>5) (m)
-  const T* __restrict__ aux = (const T*)p.aux;
+  // epilogue: MFMA "A" operand = weights, "B" operand = activations, so D[i'][j'] has j' = lane&31 = local m and
+  // i' = (r&3) + 8*(r>>2) + 4*(lane>>5) = local n: every lane owns ONE output row and, per register quad, FOUR consecutive
+  // output columns.
+  //
+  // Fast path: 32-row x 128-byte slabs of the wave's tile are transposed through LDS (bias + activation + cast on the way
+  // in) and leave as full 128-byte row segments, 16 bytes per lane (the same shape as the staging loads); the ReLU mask of
+  // the data gradient is applied on the way out with 16-byte loads of the saved activation, and the bias gradient
+  // (column sums) is reduced in registers + 3 shuffles and written, without atomics, to a [row-slab, N] workspace that a
+  // second tiny kernel folds.
+  if (p.fast_epi) {
+    constexpr int CG = 128 / (int)sizeof(T);          // columns per 128-byte group
+    constexpr int NCG = WTN / CG;                     // groups per wave tile (1 for bf16, 2 for fp32 at WTN = 64)
+    constexpr int JPG = CG / 32;                      // 32-column MFMA tiles per group
+    constexpr int PITCH = 144;                        // 128 + 16: keeps 16-byte alignment, staggers banks
+    __syncthreads();                                  // every wave is done with the staging buffers
+    char* my = smem + wave * (32 * PITCH);
+    const T* __restrict__ auxp = (const T*)p.aux;
+    const int prow = lane >> 3, pch = lane & 7;
+    float cs[NCG][EPC];
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + wn * WTN + j * 32 + (lane & 31);
-    const bool nok = n < p.n_store;
-    const float bv = (p.bias != nullptr && nok) ? p.bias[n] : 0.f;
-    float csum = 0.f;
+    for (int g = 0; g < NCG; ++g)
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) cs[g][e] = 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        float v = acc[i][j][r] + bv;
-        if (p.act == ACT_RELU) v = v > 0.f ? v : 0.f;
-        if (m < p.M && nok) {
-          if (p.act == ACT_MASK) v = to_f32(aux[(long)m * p.ldaux + n]) > 0.f ? v : 0.f;
-          if (p.out_f32) ((float*)p.Y)[(long)m * p.ldy + n] = v;
-          else ((T*)p.Y)[(long)m * p.ldy + n] = from_f32<T>(v);
-          csum += v;
+      for (int g = 0; g < NCG; ++g) {
+        // phase 1: registers -> LDS slab [32 rows][CG columns]
+#pragma unroll
+        for (int jj = 0; jj < JPG; ++jj) {
+          const int j = g * JPG + jj;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int cl = jj * 32 + 8 * q + 4 * (lane >> 5);                    // column inside the group
+            float v[4];
+            f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias != nullptr) b4 = *(const f32x4*)(p.bias + n0 + wn * WTN + g * CG + cl);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[e] = acc[i][j][4 * q + e] + b4[e];
+              if (p.act == ACT_RELU) v[e] = v[e] > 0.f ? v[e] : 0.f;
+            }
+            char* dst = my + (lane & 31) * PITCH + cl * (int)sizeof(T);
+            if constexpr (sizeof(T) == 2) {
+              bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+              *(bf16x4*)dst = o;
+            } else {
+              f32x4 o = {v[0], v[1], v[2], v[3]};
+              *(f32x4*)dst = o;
+            }
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // phase 2: LDS -> global, 8 lanes per 128-byte row segment
+        const int ncol = n0 + wn * WTN + g * CG + pch * EPC;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int row = it * 8 + prow;
+          const int m = m0 + wm * WTM + i * 32 + row;
+          frag_t val = *(const frag_t*)(my + row * PITCH + pch * 16);
+          if (m < p.M && ncol < p.n_store && !(p.dbg & 4)) {
+            if (p.act == ACT_MASK) {
+              const frag_t a8 = *(const frag_t*)(auxp + (long)m * p.ldaux + ncol);
+#pragma unroll
+              for (int e = 0; e < EPC; ++e) if (!((float)a8[e] > 0.f)) val[e] = (T)0.f;
+            }
+            *(frag_t*)((T*)p.Y + (long)m * p.ldy + ncol) = val;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) cs[g][e] += (float)val[e];
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+    }
+    if (p.colsum_ws != nullptr) {
+      const int slab = (m0 / BM) * WM + wm;                                       // row of the workspace
+#pragma unroll
+      for (int g = 0; g < NCG; ++g) {
+        const int ncol = n0 + wn * WTN + g * CG + pch * EPC;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          float c = cs[g][e];
+          c += __shfl_xor(c, 8, 64); c += __shfl_xor(c, 16, 64); c += __shfl_xor(c, 32, 64);
+          if (lane < 8 && ncol + e < p.n_store) p.colsum_ws[(long)slab * p.N + ncol + e] = c;
         }
       }
     }
+    return;
+  }
+  const T* __restrict__ aux = (const T*)p.aux;
+  const bool vec_ok = p.vec_store != 0;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    float csum[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) csum[q][e] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int nb = n0 + wn * WTN + j * 32 + 8 * q + 4 * (lane >> 5);
+      float bv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias != nullptr) {
+        const f32x4 b4 = *(const f32x4*)(p.bias + nb);      // bias is padded to N (multiple of 128)
+        bv[0] = b4[0]; bv[1] = b4[1]; bv[2] = b4[2]; bv[3] = b4[3];
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * WTM + i * 32 + (lane & 31);
+        if (m >= p.M || nb >= p.n_store || (p.dbg & 4)) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = acc[i][j][4 * q + e] + bv[e];
+          if (p.act == ACT_RELU) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        }
+        const bool full = nb + 3 < p.n_store;
+        if (p.act == ACT_MASK) {
+          const T* ap = aux + (long)m * p.ldaux + nb;
+          if (full && vec_ok) {
+            if constexpr (sizeof(T) == 2) {
+              const bf16x4 a4 = *(const bf16x4*)ap;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = (float)a4[e] > 0.f ? v[e] : 0.f;
+            } else {
+              const f32x4 a4 = *(const f32x4*)ap;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = a4[e] > 0.f ? v[e] : 0.f;
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (nb + e < p.n_store) v[e] = to_f32(ap[e]) > 0.f ? v[e] : 0.f;
+          }
+        }
+        if (full && vec_ok) {
+          if (p.out_f32 || sizeof(T) == 4) {
+            f32x4 o = {v[0], v[1], v[2], v[3]};
+            *(f32x4*)((float*)p.Y + (long)m * p.ldy + nb) = o;
+          } else {
+            bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+            *(bf16x4*)((__bf16*)p.Y + (long)m * p.ldy + nb) = o;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (nb + e < p.n_store) {
+              if (p.out_f32) ((float*)p.Y)[(long)m * p.ldy + nb + e] = v[e];
+              else ((T*)p.Y)[(long)m * p.ldy + nb + e] = from_f32<T>(v[e]);
+            }
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) csum[q][e] += (nb + e < p.n_store) ? v[e] : 0.f;
+      }
+    }
     if (p.colsum != nullptr) {
-      csum += __shfl_xor(csum, 32, 64);
-      if (lane < 32 && nok) atomicAdd(p.colsum + n, csum);
+      // column sums over this wave's rows: reduce across the 32 lanes of each half-wave (lanes = rows)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float c = csum[q][e];
+#pragma unroll
+          for (int o = 16; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+          const int n = n0 + wn * WTN + j * 32 + 8 * q + 4 * (lane >> 5) + e;
+          if ((lane & 31) == 0 && n < p.n_store) atomicAdd(p.colsum + n, c);
+        }
     }
   }
+}
+
+// out[n] += sum_r ws[r, n]  (bias gradient from the per-slab column sums of the data-gradient epilogue)
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ ws, int rows, int N, int n_store, float* __restrict__ out) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= n_store) return;
+  const int chunk = (rows + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * chunk, r1 = min(rows, r0 + chunk);
+  float acc = 0.f;
+  for (int r = r0; r < r1; ++r) acc += ws[(long)r * N + n];
+  atomicAdd(out + n, acc);
 }
 
 template <typename T, int BM, int BN, int WM, int WN>
@@ -182,27 +337,43 @@ static int launch_nt(const GemmNT& p, hipStream_t stream) {
     hipFuncSetAttribute((const void*)gemm_nt_kernel<T, BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
-  const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int tiles = tiles_m * (p.N / BN);
   hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, WM, WN>), dim3(tiles), dim3(64 * WM * WN), LDS, stream, p);
+  if (p.fast_epi && p.colsum_ws != nullptr) {
+    const int rows = tiles_m * WM;
+    int ychunks = rows / 64;
+    ychunks = ychunks < 1 ? 1 : (ychunks > 64 ? 64 : ychunks);
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((p.n_store + 255) / 256, ychunks), dim3(256), 0, stream, p.colsum_ws, rows, p.N, p.n_store, p.colsum);
+  }
   return snerf_check_launch();
 }
 
 extern "C" int snerf_linear_fwd(const void* A, long lda, const void* W, long ldw, const float* bias, void* Y, long ldy,
-                                const void* aux, long ldaux, float* colsum, int M, int N, int K, int n_store, int act,
-                                int dtype, int out_f32, int variant, void* stream) {
+                                const void* aux, long ldaux, float* colsum, float* colsum_ws, int M, int N, int K, int n_store,
+                                int act, int dtype, int out_f32, int variant, void* stream) {
   if (M <= 0) return SNERF_OK;
   if (N <= 0 || (N % 128) != 0 || K <= 0 || n_store <= 0 || n_store > N) return SNERF_ERR_ARG;
+  if (dtype != SNERF_DT_F32 && dtype != SNERF_DT_BF16) return SNERF_ERR_ARG;
   const int bke = dtype == SNERF_DT_F32 ? 32 : 64;
   if (K % bke != 0 || lda % (bke / 8) != 0 || ldw % (bke / 8) != 0) return SNERF_ERR_ARG;
   if (act == ACT_MASK && aux == nullptr) return SNERF_ERR_ARG;
-  GemmNT p{A, lda, W, ldw, bias, Y, ldy, aux, ldaux, colsum, M, N, K, n_store, act, out_f32};
+  // vector epilogue stores need 4-element alignment of the destination (and of the mask source)
+  const long esz = (out_f32 || dtype == SNERF_DT_F32) ? 4 : 2;
+  int vec = (ldy % 4 == 0) && (((uintptr_t)Y) % (4 * esz) == 0);
+  if (act == ACT_MASK) vec = vec && (ldaux % 4 == 0) && (((uintptr_t)aux) % (dtype == SNERF_DT_F32 ? 16 : 8) == 0);
+  // fast (LDS-transposed, 16-byte) epilogue: output in the compute dtype, 16-byte aligned row segments, whole chunks
+  const int epc = dtype == SNERF_DT_F32 ? 4 : 8;
+  int fast = !(out_f32 && dtype == SNERF_DT_BF16) && (ldy % epc == 0) && (((uintptr_t)Y) % 16 == 0) && (n_store % epc == 0);
+  if (act == ACT_MASK) fast = fast && (ldaux % epc == 0) && (((uintptr_t)aux) % 16 == 0);
+  if (colsum != nullptr && colsum_ws == nullptr) fast = 0;   // without a workspace the bias gradient uses the atomic path
+  if ((variant >> 4) & 8) fast = 0;                          // ablation: force the direct-store epilogue
+  GemmNT p{A, lda, W, ldw, bias, Y, ldy, aux, ldaux, colsum, M, N, K, n_store, act, out_f32, vec, colsum_ws, fast, (variant >> 4) & 7};
+  variant &= 15;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == SNERF_DT_F32) return launch_nt<float, 128, 128, 2, 2>(p, s);
-  if (dtype == SNERF_DT_BF16) {
-    if (variant == 1 && N % 256 == 0) return launch_nt<__bf16, 256, 256, 2, 4>(p, s);
-    return launch_nt<__bf16, 128, 128, 2, 2>(p, s);
-  }
-  return SNERF_ERR_ARG;
+  if (variant == 1 && N % 256 == 0) return launch_nt<__bf16, 256, 256, 2, 4>(p, s);
+  return launch_nt<__bf16, 128, 128, 2, 2>(p, s);
 }
 
 // ---------------------------------------------------------------------------

@@ -66,8 +66,11 @@ def linear_fwd(A, W, bias, Y, K, n_store, act, dt, out_f32=False, aux=None, cols
     assert Y.shape[0] == M and A.shape[1] >= K and W.shape[1] >= K and Y.shape[1] >= n_store
     if aux is not None:
         _chk2d(aux, _TORCH_DT[dt])
+    ws = None
+    if colsum is not None:  # per-row-slab partial column sums (no atomics); folded into `colsum` by a second kernel
+        ws = torch.empty(2 * ((M + 127) // 128), W.shape[0], dtype=torch.float32, device=A.device)
     _lib.call("snerf_linear_fwd", _p(A), A.stride(0), _p(W), W.stride(0), _p(bias), _p(Y), Y.stride(0),
-              _p(aux), 0 if aux is None else aux.stride(0), _p(colsum), M, W.shape[0], K, n_store, act, dt,
+              _p(aux), 0 if aux is None else aux.stride(0), _p(colsum), _p(ws), M, W.shape[0], K, n_store, act, dt,
               1 if out_f32 else 0, variant, _stream())
 
 

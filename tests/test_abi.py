@@ -42,6 +42,6 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     if not os.path.exists(_lib.LIB_PATH):
         pytest.skip("library not built")
     with pytest.raises(_lib.SnerfHipError, match="bad argument"):
-        _lib.call("snerf_linear_fwd", None, 0, None, 0, None, None, 0, None, 0, None, 16, 100, 64, 1, 0, 1, 0, 0, None)  # N % 128 != 0
+        _lib.call("snerf_linear_fwd", None, 0, None, 0, None, None, 0, None, 0, None, None, 16, 100, 64, 1, 0, 1, 0, 0, None)  # N % 128 != 0
     with pytest.raises(_lib.SnerfHipError, match="bad argument"):
         _lib.call("snerf_mip_resample", None, None, None, 0, 4, 1, 8, 0.01, None, None, None)  # S < 2

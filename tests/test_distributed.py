@@ -1,0 +1,78 @@
+"""N > 1 path on CPU: two gloo ranks, ray batch sharded across them, ONE all-reduce of the flat gradient arena, fused
+Adam with the 1/world mean folded in.  After two steps the parameters must equal a single-process run on the whole
+batch (host logic; kernels emulated -- tests/cpu_ops_emulation.py)."""
+import os
+import sys
+import tempfile
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+
+
+def _build(n_samples=8, n_fine=9, hidden=64):
+    from snerf_amd.mipnerf import MipNerfModel
+    torch.manual_seed(0)
+    return MipNerfModel(n_samples=n_samples, N_fine=n_fine, no_warp_sample=0, ray_shape="cone", fn=1, radius=3., transform_idx=0,
+                        real=True, rgb_layer=3, hidden_layer=hidden, density_noise=0., max_deg_point=16, proposal_hidden_layer=64,
+                        proposal_loss=True, compute="f32", device="cpu")
+
+
+def _data(n):
+    from oracle import common
+    from snerf_amd.mipnerf import Rays
+    rays = Rays(**common.synthetic_rays(n, seed=9))
+    tgt = torch.rand(n, 3, generator=torch.Generator().manual_seed(10))
+    return rays, tgt
+
+
+def _worker(rank, world, init_file, n, out_file):
+    from cpu_ops_emulation import emulate_ops
+    from snerf_amd.trainer import MipTrainer, shard_rays
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    with emulate_ops():
+        model = _build()
+        if rank != 0:
+            with torch.no_grad():
+                model.arena.flat.add_(1.0)          # deliberately different: broadcast must fix it
+        tr = MipTrainer(model, lr=1e-2)
+        tr.broadcast_parameters(0)
+        rays, tgt = _data(n)
+        my = shard_rays(rays, rank, world)
+        per = n // world
+        for _ in range(2):
+            tr.step(my, tgt[rank * per:(rank + 1) * per], randomized=False)
+        flat = model.arena.flat.clone()
+        gathered = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        if rank == 0:
+            torch.save(gathered, out_file)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_ray_sharded_data_parallel_matches_single_process():
+    from cpu_ops_emulation import emulate_ops
+    from snerf_amd.trainer import MipTrainer
+    n, world = 24, 2
+    with tempfile.TemporaryDirectory() as td:
+        init_file, out_file = os.path.join(td, "init"), os.path.join(td, "out.pt")
+        mp.spawn(_worker, args=(world, init_file, n, out_file), nprocs=world, join=True)
+        gathered = torch.load(out_file)
+    assert torch.equal(gathered[0], gathered[1]), "ranks diverged"
+    with emulate_ops():
+        model = _build()
+        tr = MipTrainer(model, lr=1e-2)
+        rays, tgt = _data(n)
+        for _ in range(2):
+            tr.step(rays, tgt, randomized=False)
+    ref = model.arena.flat
+    err = (gathered[0] - ref).abs().max().item()
+    assert err < 2e-5, f"data-parallel parameters differ from the single-process run by {err:.3e}"
+    assert (ref - _build().arena.flat).abs().max().item() > 1e-3, "the optimiser did not move the parameters"

@@ -99,9 +99,9 @@ def test_classic_embed(ops, dt):
     V = torch.full((N * S, 16 + g), 9.0, dtype=tdt, device="cuda")
     ops.classic_embed(pts.cuda(), rb[:, -3:], S, 10, 4, E, SK[:, :64], 64, V[:, 16:], g, dt)
     ref_p = oc.embed(pts, 10); ref_v = oc.embed(vd[:, None].expand(N, S, 3).reshape(-1, 3), 4)
-    tol = 2e-6 if dt == 0 else 4e-3
-    close(E[:, :63], ref_p, 0, tol, "pts embed"); close(SK[:, :63], ref_p, 0, tol, "pts embed copy")
-    close(V[:, 16:16 + 27], ref_v, 0, tol, "view embed")
+    rt, at = (0, 2e-6) if dt == 0 else (8e-3, 1e-5)   # bf16: one rounding of the fp32 value (2^-8 relative)
+    close(E[:, :63], ref_p, rt, at, "pts embed"); close(SK[:, :63], ref_p, rt, at, "pts embed copy")
+    close(V[:, 16:16 + 27], ref_v, rt, at, "view embed")
     assert bool((E[:, 63] == 0).all()) and bool((V[:, 16 + 27:] == 0).all()) and bool((V[:, :16] == 9).all()) and bool((SK[:, 64:] == 9).all())
 
 
@@ -140,7 +140,7 @@ def test_mip_encode_ipe_exact_inputs(ops, golden):
     a = torch.empty(n * S, 96, dtype=torch.float32, device="cuda"); b = torch.empty(n * S, 128, dtype=torch.bfloat16, device="cuda")
     ops.mip_encode(*args, True, 0, 16, a, None, 96, ops.F32)
     ops.mip_encode(*args, True, 0, 16, b, None, 128, ops.BF16)
-    close(b[:, :96].float(), a, 0, 4e-3, "bf16 IPE vs fp32 IPE")
+    close(b[:, :96].float(), a, 8e-3, 1e-6, "bf16 IPE vs fp32 IPE")
     assert bool((b[:, 96:] == 0).all())
 
 
