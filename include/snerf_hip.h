@@ -24,6 +24,7 @@ extern "C" {
 
 #define SNERF_DT_F32 0
 #define SNERF_DT_BF16 1
+#define SNERF_DT_F16 2 /* hash-grid tables only */
 #define SNERF_ACT_NONE 0
 #define SNERF_ACT_RELU 1
 #define SNERF_ACT_MASK 2 /* y = aux > 0 ? y : 0 : ReLU backward fused into the data-gradient GEMM */
@@ -114,6 +115,26 @@ int snerf_classic_composite_bwd(const float* raw, long ld, const float* noise, c
                                 int rd_stride, long N, int S, int white, const float* weights, const float* acc_map,
                                 const float* depth_map, const float* g_rgb, const float* g_disp, const float* g_acc,
                                 const float* g_depth, const float* g_w, float* d_raw, long ld_draw, void* stream);
+
+/* ---- multiresolution hash-grid encoder (S-NeRF++ / zipnerf) ------------------------------------------------------
+ * Same entry points and argument order as the reference's pybind module (s-nerfpp/zipnerf/gridencoder/src/bindings.cpp:5-9,
+ * src/gridencoder.h:12-15; kernels src/gridencoder.cu:87-245, :248-340, :343-369, :506-610):
+ *   grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx?, gridtype, align_corners, interp)
+ *   grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx?, grad_inputs?, ...)
+ *   grad_total_variation(inputs, embeddings, grad, offsets, weight, B, D, C, L, S, H, gridtype, align_corners)
+ * plus `dtype` of the table / outputs / gradients (SNERF_DT_F32 or SNERF_DT_F16; the reference dispatches on the tensor
+ * dtype), the strides (elements) of the level and point axes of `outputs` / `grad` (reference layout [L,B,C]:
+ * stride_l = B*C, stride_b = C; [B, L*C] directly: stride_l = C, stride_b = L*C) and the stream (the reference always
+ * uses the legacy default stream).  inputs fp32 [B,D] in [0,1] (out-of-bound points -> zeros); D in {2,3}; C in {1,2,4,8};
+ * gridtype 0 hash / 1 tiled; interp 0 linear / 1 smoothstep.  grad_embeddings / grad_inputs must arrive zeroed. */
+int snerf_grid_encode_fwd(const float* inputs, const void* embeddings, const int* offsets, void* outputs, int B, int D, int C,
+                          int L, float S, int H, void* dy_dx, int gridtype, int align_corners, int interp, int dtype,
+                          long out_stride_l, long out_stride_b, void* stream);
+int snerf_grid_encode_bwd(const void* grad, const float* inputs, const void* embeddings, const int* offsets, void* grad_embeddings,
+                          int B, int D, int C, int L, float S, int H, const void* dy_dx, void* grad_inputs, int gridtype,
+                          int align_corners, int interp, int dtype, long grad_stride_l, long grad_stride_b, void* stream);
+int snerf_grid_tv_grad(const float* inputs, const void* embeddings, void* grad, const int* offsets, float weight, int B, int D,
+                       int C, int L, float S, int H, int gridtype, int align_corners, int dtype, void* stream);
 
 /* ---- training tail ------------------------------------------------------------------------------
  * torch.optim.Adam step over a flat fp32 arena (model_utils.py:23-34 builds Adam); grad_scale folds the

@@ -1,0 +1,119 @@
+"""Drop-in ``GridEncoder`` of S-NeRF++ / zipnerf backed by the HIP kernels of libsnerf_hip.so.
+
+Mirrors s-nerfpp/zipnerf/gridencoder/grid.py: ``_grid_encode`` (:24-89), ``grid_encode`` (:93), ``GridEncoder``
+(:96-201) -- same constructor keywords, attributes (``num_levels``, ``output_dim``, ``offsets``, ``idx``,
+``grid_sizes``, ``embeddings``, ``per_level_scale`` ...), forward signature and ``state_dict`` keys.
+
+Differences (MI355X-first, documented in DESIGN.md): the kernels write ``[B, L*C]`` directly (no ``[L,B,C]`` buffer +
+permute, grid.py:47,57 / :74), take the current stream, and under autocast the table is cast to fp16 exactly like the
+reference (even C only).  There is no fallback: without the library every call raises.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from . import ops
+
+_gridtype_to_id = {'hash': 0, 'tiled': 1}
+_interp_to_id = {'linear': 0, 'smoothstep': 1}
+
+
+class _grid_encode(Function):
+    @staticmethod
+    def forward(ctx, inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False, gridtype=0,
+                align_corners=False, interpolation=0):
+        inputs = inputs.contiguous().float()
+        L = offsets.shape[0] - 1
+        S = np.log2(per_level_scale)
+        H = base_resolution
+        C = embeddings.shape[1]
+        table = embeddings
+        if torch.is_autocast_enabled() and C % 2 == 0:   # grid.py:41-44
+            table = embeddings.to(torch.half)
+        table = table.contiguous()
+        outputs, dy_dx = ops.grid_encode_fwd(inputs, table, offsets, L, S, H, gridtype, align_corners, interpolation, calc_grad_inputs)
+        ctx.save_for_backward(inputs, table, offsets, dy_dx if dy_dx is not None else torch.empty(0, device=inputs.device))
+        ctx.dims = [L, S, H, gridtype, interpolation, dy_dx is not None, embeddings.dtype]
+        ctx.align_corners = align_corners
+        return outputs
+
+    @staticmethod
+    def backward(ctx, grad):
+        inputs, table, offsets, dy_dx = ctx.saved_tensors
+        L, S, H, gridtype, interpolation, has_dd, emb_dtype = ctx.dims
+        grad = grad.contiguous().to(table.dtype)
+        g_emb, g_in = ops.grid_encode_bwd(grad, inputs, table, offsets, L, S, H, gridtype, ctx.align_corners, interpolation,
+                                          dy_dx if has_dd else None)
+        if g_in is not None:
+            g_in = g_in.to(inputs.dtype)
+        return g_in, g_emb.to(emb_dtype), None, None, None, None, None, None, None
+
+
+grid_encode = _grid_encode.apply
+
+
+class GridEncoder(nn.Module):
+    def __init__(self, input_dim=3, num_levels=16, level_dim=2, per_level_scale=2, base_resolution=16, log2_hashmap_size=19,
+                 desired_resolution=None, gridtype='hash', align_corners=False, interpolation='linear', init_std=1e-4,
+                 device="cuda"):
+        super().__init__()
+        if desired_resolution is not None:
+            per_level_scale = np.exp2(np.log2(desired_resolution / base_resolution) / (num_levels - 1))
+        if input_dim not in (2, 3) or level_dim not in (1, 2, 4, 8):
+            raise NotImplementedError("accelerated GridEncoder: input_dim in {2,3}, level_dim in {1,2,4,8}")
+        self.input_dim, self.num_levels, self.level_dim = input_dim, num_levels, level_dim
+        self.per_level_scale, self.log2_hashmap_size, self.base_resolution = per_level_scale, log2_hashmap_size, base_resolution
+        self.output_dim = num_levels * level_dim
+        self.gridtype, self.gridtype_id = gridtype, _gridtype_to_id[gridtype]
+        self.interpolation, self.interp_id = interpolation, _interp_to_id[interpolation]
+        self.align_corners, self.init_std = align_corners, init_std
+        resolutions, offsets, offset = [], [], 0
+        self.max_params = 2 ** log2_hashmap_size
+        for i in range(num_levels):       # level sizing: grid.py:122-141
+            resolution = int(np.ceil(base_resolution * per_level_scale ** i))
+            resolution = resolution if align_corners else resolution + 1
+            params_in_level = min(self.max_params, resolution ** input_dim)
+            params_in_level = int(np.ceil(params_in_level / 8) * 8)
+            resolutions.append(resolution)
+            offsets.append(offset)
+            offset += params_in_level
+        offsets.append(offset)
+        offsets = torch.from_numpy(np.array(offsets, dtype=np.int32)).to(device)
+        self.register_buffer('offsets', offsets)
+        idx = torch.empty(offset, dtype=torch.long, device=device)
+        for i in range(num_levels):
+            idx[offsets[i]:offsets[i + 1]] = i
+        self.register_buffer('idx', idx)
+        self.register_buffer('grid_sizes', torch.from_numpy(np.array(resolutions, dtype=np.int32)).to(device))
+        self.n_params = offsets[-1] * level_dim
+        self.embeddings = nn.Parameter(torch.empty(offset, level_dim, device=device))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self.embeddings.data.uniform_(-self.init_std, self.init_std)
+
+    def __repr__(self):
+        return (f"GridEncoder: input_dim={self.input_dim} num_levels={self.num_levels} level_dim={self.level_dim} "
+                f"resolution={self.base_resolution} -> {int(round(self.base_resolution * self.per_level_scale ** (self.num_levels - 1)))} "
+                f"per_level_scale={self.per_level_scale:.4f} params={tuple(self.embeddings.shape)} gridtype={self.gridtype} "
+                f"align_corners={self.align_corners} interpolation={self.interpolation}")
+
+    def forward(self, inputs, bound=1, cal_input_grad=False):
+        inputs = (inputs + bound) / (2 * bound)
+        prefix_shape = list(inputs.shape[:-1])
+        inputs = inputs.view(-1, self.input_dim)
+        outputs = grid_encode(inputs, self.embeddings, self.offsets, self.per_level_scale, self.base_resolution,
+                              inputs.requires_grad, self.gridtype_id, self.align_corners, self.interp_id)
+        return outputs.view(prefix_shape + [self.output_dim])
+
+    @torch.no_grad()
+    def grad_total_variation(self, weight=1e-7, inputs=None, bound=1, B=1000000):
+        if inputs is None:
+            inputs = torch.rand(B, self.input_dim, device=self.embeddings.device)
+        else:
+            inputs = ((inputs + bound) / (2 * bound)).view(-1, self.input_dim)
+        if self.embeddings.grad is None:
+            raise ValueError('grad is None, should be called after loss.backward() and before optimizer.step()!')
+        ops.grid_tv_grad(inputs.contiguous().float(), self.embeddings.data.contiguous(), self.embeddings.grad, self.offsets, weight,
+                         self.num_levels, np.log2(self.per_level_scale), self.base_resolution, self.gridtype_id, self.align_corners)

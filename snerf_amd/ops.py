@@ -9,9 +9,9 @@ import torch
 
 from . import _lib
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_MASK = 0, 1, 2
-_TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16}
+_TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
 
 
 def torch_dtype(dt: int):
@@ -247,3 +247,47 @@ def colsum_f32(x, C, out):
 def cast_pad(src, C, dst, Cpad, dt):
     _chk2d(src, torch.float32)
     _lib.call("snerf_cast_pad", _p(src), src.stride(0), src.shape[0], C, Cpad, _p(dst), dst.stride(0), dt, _stream())
+
+
+# ------------------------------------------------------------ hash grid ----
+def grid_encode_fwd(inputs, embeddings, offsets, L, S, H, gridtype, align_corners, interp, want_dy_dx=False, level_major=False):
+    """inputs fp32 [B,D] in [0,1]; embeddings [sO,C] fp32/fp16 -> outputs [B, L*C] (or [L,B,C] if level_major) in the
+    table dtype (+ dy_dx [B, L*D*C])."""
+    _f32c(inputs)
+    assert embeddings.is_cuda and embeddings.is_contiguous() and embeddings.dtype in (torch.float32, torch.float16)
+    assert offsets.dtype == torch.int32 and offsets.is_cuda
+    B, D = inputs.shape
+    C = embeddings.shape[1]
+    dt = F32 if embeddings.dtype == torch.float32 else F16
+    if level_major:
+        out = torch.empty(L, B, C, dtype=embeddings.dtype, device=inputs.device); sl, sb = B * C, C
+    else:
+        out = torch.empty(B, L * C, dtype=embeddings.dtype, device=inputs.device); sl, sb = C, L * C
+    dy_dx = torch.empty(B, L * D * C, dtype=embeddings.dtype, device=inputs.device) if want_dy_dx else None
+    _lib.call("snerf_grid_encode_fwd", _p(inputs), _p(embeddings), _p(offsets), _p(out), B, D, C, L, float(S), int(H), _p(dy_dx),
+              int(gridtype), 1 if align_corners else 0, int(interp), dt, sl, sb, _stream())
+    return out, dy_dx
+
+
+def grid_encode_bwd(grad, inputs, embeddings, offsets, L, S, H, gridtype, align_corners, interp, dy_dx=None, level_major=False):
+    """grad [B, L*C] (or [L,B,C]) in the table dtype -> (grad_embeddings like embeddings, grad_inputs [B,D] or None)."""
+    _f32c(inputs)
+    assert grad.is_contiguous() and grad.dtype == embeddings.dtype
+    B, D = inputs.shape
+    C = embeddings.shape[1]
+    dt = F32 if embeddings.dtype == torch.float32 else F16
+    sl, sb = (B * C, C) if level_major else (C, L * C)
+    g_emb = torch.zeros_like(embeddings)
+    g_in = torch.zeros(B, D, dtype=embeddings.dtype, device=inputs.device) if dy_dx is not None else None
+    _lib.call("snerf_grid_encode_bwd", _p(grad), _p(inputs), _p(embeddings), _p(offsets), _p(g_emb), B, D, C, L, float(S), int(H),
+              _p(dy_dx), _p(g_in), int(gridtype), 1 if align_corners else 0, int(interp), dt, sl, sb, _stream())
+    return g_emb, g_in
+
+
+def grid_tv_grad(inputs, embeddings, grad, offsets, weight, L, S, H, gridtype, align_corners):
+    _f32c(inputs)
+    assert grad.dtype == embeddings.dtype and grad.is_contiguous() and embeddings.is_contiguous()
+    B, D = inputs.shape
+    dt = F32 if embeddings.dtype == torch.float32 else F16
+    _lib.call("snerf_grid_tv_grad", _p(inputs), _p(embeddings), _p(grad), _p(offsets), float(weight), B, D, embeddings.shape[1], L,
+              float(S), int(H), int(gridtype), 1 if align_corners else 0, dt, _stream())

@@ -1,0 +1,105 @@
+"""HIP hash-grid encoder vs oracle/grid.py through the C-ABI (forward, dy_dx, table gradient, input gradient, TV, fp16 tables,
+GridEncoder module + autograd + autocast)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import grid as og
+
+pytestmark = pytest.mark.gpu
+
+
+def setup(L, C, scale, H, log2T, B, seed, desired=None):
+    off, res, s = og.level_layout(3, L, C, scale, H, log2T, desired, False)
+    rng = np.random.default_rng(seed)
+    E = (rng.standard_normal((int(off[-1]), C)) * 0.5).astype(np.float32)
+    x = rng.random((B, 3)).astype(np.float32)
+    x[0] = [-0.2, 0.5, 0.5]; x[1] = [0.5, 0.5, 1.5]; x[2] = [0.0, 1.0, 0.0]      # 2 out of bounds, 1 on the boundary
+    return off, res, float(np.log2(s)), E, x
+
+
+@pytest.mark.parametrize("C,interp,gridtype", [(1, 0, 0), (2, 0, 0), (4, 0, 0), (4, 1, 0), (8, 0, 0), (2, 0, 1)])
+def test_grid_forward_backward_fp32(C, interp, gridtype):
+    from snerf_amd import ops
+    L, H = 6, 4
+    off, res, S, E, x = setup(L, C, 1.7, H, 11, 3000, C + interp)               # 2^11-entry levels: levels >= 2 are hashed / tiled
+    ref, ref_dd = og.grid_encode_forward(x, E, off, S, H, gridtype, False, interp, want_dy_dx=True)
+    xt, Et, offt = torch.from_numpy(x).cuda(), torch.from_numpy(E).cuda(), torch.from_numpy(off).cuda()
+    out, dd = ops.grid_encode_fwd(xt, Et, offt, L, S, H, gridtype, False, interp, want_dy_dx=True)
+    np.testing.assert_allclose(out.cpu().numpy().reshape(-1, L, C), ref.transpose(1, 0, 2), rtol=1e-4, atol=2e-5)  # fma contraction in the kernel vs separate fp32 ops in the oracle
+    np.testing.assert_allclose(dd.cpu().numpy(), ref_dd, rtol=1e-4, atol=1e-4)
+    out_lm, _ = ops.grid_encode_fwd(xt, Et, offt, L, S, H, gridtype, False, interp, level_major=True)   # the reference's [L,B,C] layout
+    assert torch.equal(out_lm.permute(1, 0, 2).reshape(-1, L * C), out)
+    assert float(out[:2].abs().max()) == 0.0, "out-of-bound points must encode to zero"
+    # backward
+    rng = np.random.default_rng(7)
+    G = rng.standard_normal((L, x.shape[0], C)).astype(np.float32)
+    gE_ref, gx_ref = og.grid_encode_backward(G, x, off, E.shape[0], S, H, gridtype, False, interp, dy_dx=ref_dd)
+    Gt = torch.from_numpy(np.ascontiguousarray(G.transpose(1, 0, 2).reshape(-1, L * C))).cuda()
+    gE, gx = ops.grid_encode_bwd(Gt, xt, Et, offt, L, S, H, gridtype, False, interp, dy_dx=dd)
+    np.testing.assert_allclose(gE.cpu().numpy(), gE_ref, rtol=1e-4, atol=2e-4)   # fp32 atomics: order-dependent last bits
+    np.testing.assert_allclose(gx.cpu().numpy(), gx_ref, rtol=1e-3, atol=1e-3)
+    # adjointness on the device results themselves
+    lhs = float((out.double() * Gt.double()).sum()); rhs = float((Et.double() * gE.double()).sum())
+    assert abs(lhs - rhs) < 1e-3 * max(1.0, abs(lhs))
+
+
+def test_grid_shipped_layout_fp16_and_tv():
+    from snerf_amd import ops
+    # zipnerf NeRF grid: L=10, C=4, H=16, desired 8192, T=2^21 (internal/models.py:381-386): 14 995 560 rows
+    L, C, H = 10, 4, 16
+    off, res, s = og.level_layout(3, L, C, 2.0, H, 21, 8192, False)
+    assert int(off[-1]) == 14995560
+    S = float(np.log2(s))
+    g = torch.Generator().manual_seed(0)
+    E = (torch.randn(int(off[-1]), C, generator=g) * 0.1)
+    x = torch.rand(20000, 3, generator=g)
+    offt = torch.from_numpy(off).cuda()
+    out32, _ = ops.grid_encode_fwd(x.cuda(), E.cuda(), offt, L, S, H, 0, False, 0)
+    sub = slice(0, 512)
+    ref = og.grid_encode_forward(x[sub].numpy(), E.numpy(), off, S, H, 0, False, 0)
+    np.testing.assert_allclose(out32[sub].cpu().numpy().reshape(-1, L, C), ref.transpose(1, 0, 2), rtol=1e-4, atol=2e-5)  # fma contraction in the kernel vs separate fp32 ops in the oracle
+    out16, _ = ops.grid_encode_fwd(x.cuda(), E.cuda().half(), offt, L, S, H, 0, False, 0)
+    assert out16.dtype == torch.float16
+    assert float((out16.float() - out32).abs().max()) < 1e-3, "fp16 table vs fp32 table"
+    # fp16 gradient table (packed-half atomics) vs fp32
+    G = torch.randn(20000, L * C, generator=g).cuda() * 0.01
+    g32, _ = ops.grid_encode_bwd(G, x.cuda(), E.cuda(), offt, L, S, H, 0, False, 0)
+    g16, _ = ops.grid_encode_bwd(G.half(), x.cuda(), E.cuda().half(), offt, L, S, H, 0, False, 0)
+    rel = float((g16.float() - g32).norm() / g32.norm())
+    assert rel < 2e-2, rel
+    # total variation on a small grid vs the oracle
+    off2, res2, s2 = og.level_layout(3, 3, 2, 2.0, 4, 9, None, False)
+    rng = np.random.default_rng(3)
+    E2 = rng.standard_normal((int(off2[-1]), 2)).astype(np.float32); x2 = rng.random((500, 3)).astype(np.float32)
+    want = og.grad_total_variation(x2, E2, off2, 0.3, 1.0, 4, 0, False)
+    grad = torch.zeros(E2.shape, device="cuda")
+    ops.grid_tv_grad(torch.from_numpy(x2).cuda(), torch.from_numpy(E2).cuda(), grad, torch.from_numpy(off2).cuda(), 0.3, 3, 1.0, 4, 0, False)
+    np.testing.assert_allclose(grad.cpu().numpy(), want, rtol=1e-3, atol=1e-5)
+
+
+def test_gridencoder_module_autograd_and_autocast():
+    from snerf_amd.gridencoder import GridEncoder
+    enc = GridEncoder(input_dim=3, num_levels=6, level_dim=4, base_resolution=16, log2_hashmap_size=15, desired_resolution=512)
+    assert list(enc.state_dict().keys()) == ["embeddings", "offsets", "idx", "grid_sizes"]
+    with torch.no_grad():
+        enc.embeddings.normal_(0, 0.2)
+    g = torch.Generator().manual_seed(1)
+    x = (torch.rand(777, 3, generator=g) * 2 - 1).cuda().requires_grad_(True)
+    y = enc(x, bound=1)
+    assert y.shape == (777, 24)
+    off, S = enc.offsets.cpu().numpy(), float(np.log2(enc.per_level_scale))
+    ref, dd = og.grid_encode_forward(((x.detach().cpu().numpy() + 1) / 2).astype(np.float32), enc.embeddings.detach().cpu().numpy(), off, S, 16, 0, False, 0,
+                                     want_dy_dx=True)
+    np.testing.assert_allclose(y.detach().cpu().numpy().reshape(-1, 6, 4), ref.transpose(1, 0, 2), rtol=1e-4, atol=2e-5)  # fma contraction in the kernel vs separate fp32 ops in the oracle
+    w = torch.randn(777, 24, generator=g).cuda()
+    (y * w).sum().backward()
+    G = w.cpu().numpy().reshape(-1, 6, 4).transpose(1, 0, 2)
+    gE, gx = og.grid_encode_backward(np.ascontiguousarray(G), ((x.detach().cpu().numpy() + 1) / 2).astype(np.float32), off, enc.embeddings.shape[0], S, 16,
+                                     0, False, 0, dy_dx=dd)
+    np.testing.assert_allclose(enc.embeddings.grad.cpu().numpy(), gE, rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), gx * 0.5, rtol=1e-3, atol=1e-3)     # d/dx of (x + 1) / 2
+    enc.grad_total_variation(weight=1e-3, B=1000)                                        # smoke: adds into .grad
+    with torch.autocast("cuda", dtype=torch.float16):
+        y16 = enc(x.detach())
+    assert y16.dtype == torch.float16 and float((y16.float() - y.detach()).abs().max()) < 2e-3
