@@ -47,9 +47,9 @@ int snerf_linear_fwd(const void* A, long lda, const void* W, long ldw, const flo
 
 /* dW[n_valid, k_valid] (fp32, ldw) += dZ[M,N]^T . X[M,K]  -- weight gradient of the same layers
  * (autograd of nn.Linear in the reference; train.py:213 loss.backward()).  `zeros` = >=16 bytes of
- * device zeros (source for rows past M). */
+ * device zeros (source for rows past M).  variant 1 (bf16, N and K multiples of 128): transposing LDS reads. */
 int snerf_linear_wgrad(const void* Z, long ldz, const void* X, long ldx, float* dW, long ldw, const void* zeros,
-                       int M, int N, int K, int n_valid, int k_valid, int dtype, void* stream);
+                       int M, int N, int K, int n_valid, int k_valid, int dtype, int variant, void* stream);
 
 /* ---- encoders ---------------------------------------------------------------------------------
  * Classic positional encoding written straight into MLP operand buffers.

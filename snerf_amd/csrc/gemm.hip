@@ -18,6 +18,7 @@
 // 157 TF/s peak); dtype bf16 uses v_mfma_f32_32x32x16_bf16 (2.5 PF/s peak),
 // fp32 accumulate in both.
 #include "common.h"
+#include <type_traits>
 
 #define ACT_NONE 0
 #define ACT_RELU 1
@@ -57,7 +58,7 @@ __device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
 // ---------------------------------------------------------------------------
 // NT kernel: BM x BN output tile, WM x WN waves, each wave (BM/WM) x (BN/WN).
 // ---------------------------------------------------------------------------
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, bool INTERLEAVE>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmNT p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef typename Frag<T>::type frag_t;
@@ -124,26 +125,96 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmNT p) {
   for (int j = 0; j < TN; ++j) rb[j] = wn * WTN + j * 32 + (lane & 31);
   const int chalf = lane >> 5;
 
+  // one staging piece (1 KiB per wave-instruction) of tile kt: pieces [0, LA) belong to A, [LA, LA+LB) to W
+  auto issue_piece = [&](int kt, int stage, int pc) {
+    char* sA = smem + stage * STAGE;
+    char* sB = sA + BM * 128;
+    const long k0 = (long)kt * BKE;
+#pragma unroll
+    for (int i = 0; i < LA; ++i) if (pc == i) glds16(A + a_off[i] + k0, sA + (wave * LA + i) * 1024);
+#pragma unroll
+    for (int i = 0; i < LB; ++i) if (pc == LA + i) glds16(W + b_off[i] + k0, sB + (wave * LB + i) * 1024);
+  };
+  auto read_frags = [&](const char* sA, const char* sB, int ks, frag_t* a, frag_t* b) {
+    const int c = 2 * ks + chalf;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a[i] = *(const frag_t*)((p.dbg & 2) ? smem + lane * 16 : sA + ra[i] * 128 + ((c ^ ((ra[i] >> 1) & 7)) << 4));
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b[j] = *(const frag_t*)((p.dbg & 2) ? smem + lane * 16 + 1024 : sB + rb[j] * 128 + ((c ^ ((rb[j] >> 1) & 7)) << 4));
+  };
+
   issue(0, 0);
-  for (int kt = 0; kt < KT; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < KT && !(p.dbg & 1)) issue(kt + 1, (kt + 1) & 1);
-    const char* sA = smem + (kt & 1) * STAGE;
-    const char* sB = sA + BM * 128;
+  if constexpr (!INTERLEAVE) {
+    for (int kt = 0; kt < KT; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (kt + 1 < KT && !(p.dbg & 1)) issue(kt + 1, (kt + 1) & 1);
+      const char* sA = smem + (kt & 1) * STAGE;
+      const char* sB = sA + BM * 128;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      frag_t a[TM], b[TN];
-      const int c = 2 * ks + chalf;
+      for (int ks = 0; ks < 4; ++ks) {
+        frag_t a[TM], b[TN];
+        read_frags(sA, sB, ks, a, b);
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = *(const frag_t*)((p.dbg & 2) ? smem + lane * 16 : sA + ra[i] * 128 + ((c ^ ((ra[i] >> 1) & 7)) << 4));
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = *(const frag_t*)((p.dbg & 2) ? smem + lane * 16 + 1024 : sB + rb[j] * 128 + ((c ^ ((rb[j] >> 1) & 7)) << 4));
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) mma32(acc[i][j], b[j], a[i]);   // D = W-tile . X-tile^T: lanes own rows m
+          for (int j = 0; j < TN; ++j) mma32(acc[i][j], b[j], a[i]);   // D = W-tile . X-tile^T: lanes own rows m
+      }
     }
+  } else {
+    // Same double buffer, but the (LA+LB) staging instructions of the NEXT tile are spread between the MFMAs of this one
+    // (an LDS-DMA piece costs ~60-100 issue cycles; issued as one block after the barrier they leave the matrix pipe
+    // idle on every SIMD at once, since all waves of the workgroup are in the same phase), and the fragments of sub-step
+    // ks+1 are fetched while the MFMAs of ks run.
+    constexpr int NP = LA + LB, PPK = NP / 4;       // staging pieces per k sub-step
+    static_assert(NP % 4 == 0, "pieces must split over the 4 k sub-steps");
+    constexpr int NM = TM * TN;
+    auto tile = [&](int kt, auto more_tag) {
+      constexpr bool MORE = decltype(more_tag)::value;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      const char* sA = smem + (kt & 1) * STAGE;
+      const char* sB = sA + BM * 128;
+      const int c0 = chalf;
+      frag_t a[2][TM], b[2][TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[0][i] = *(const frag_t*)(sA + ra[i] * 128 + ((c0 ^ ((ra[i] >> 1) & 7)) << 4));
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[0][j] = *(const frag_t*)(sB + rb[j] * 128 + ((c0 ^ ((rb[j] >> 1) & 7)) << 4));
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if (ks < 3) {
+          const int c = 2 * (ks + 1) + chalf;
+#pragma unroll
+          for (int i = 0; i < TM; ++i) a[(ks + 1) & 1][i] = *(const frag_t*)(sA + ra[i] * 128 + ((c ^ ((ra[i] >> 1) & 7)) << 4));
+#pragma unroll
+          for (int j = 0; j < TN; ++j) b[(ks + 1) & 1][j] = *(const frag_t*)(sB + rb[j] * 128 + ((c ^ ((rb[j] >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int t = 0; t < NM; ++t) {
+          const int i = t / TN, j = t % TN;
+          mma32(acc[i][j], b[ks & 1][j], a[ks & 1][i]);
+          // after every (NM/PPK)-th MFMA issue one staging piece of the next tile
+          if constexpr (MORE) {
+            if (((t + 1) % (NM / PPK)) == 0) issue_piece(kt + 1, (kt + 1) & 1, ks * PPK + (t + 1) / (NM / PPK) - 1);
+          }
+        }
+      }
+      // pin the software pipeline: fragments of sub-step ks+1 are fetched BEFORE the MFMAs of ks issue, staging pieces
+      // sit between MFMA groups (masks: 0x008 MFMA, 0x010 VMEM, 0x100 DS read)
+      __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if (ks < 3) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+#pragma unroll
+        for (int g = 0; g < PPK; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, NM / PPK, 0);
+          if constexpr (MORE) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        }
+      }
+    };
+    for (int kt = 0; kt < KT - 1; ++kt) tile(kt, std::true_type{});
+    tile(KT - 1, std::false_type{});
   }
 
   // epilogue: MFMA "A" operand = weights, "B" operand = activations, so D[i'][j'] has j' = lane&31 = local m and
@@ -329,17 +400,17 @@ __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restr
   atomicAdd(out + n, acc);
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, bool IL>
 static int launch_nt(const GemmNT& p, hipStream_t stream) {
   constexpr int LDS = 2 * (BM + BN) * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_nt_kernel<T, BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipFuncSetAttribute((const void*)gemm_nt_kernel<T, BM, BN, WM, WN, IL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
   const int tiles_m = (p.M + BM - 1) / BM;
   const int tiles = tiles_m * (p.N / BN);
-  hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, WM, WN>), dim3(tiles), dim3(64 * WM * WN), LDS, stream, p);
+  hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, WM, WN, IL>), dim3(tiles), dim3(64 * WM * WN), LDS, stream, p);
   if (p.fast_epi && p.colsum_ws != nullptr) {
     const int rows = tiles_m * WM;
     int ychunks = rows / 64;
@@ -371,9 +442,10 @@ extern "C" int snerf_linear_fwd(const void* A, long lda, const void* W, long ldw
   GemmNT p{A, lda, W, ldw, bias, Y, ldy, aux, ldaux, colsum, M, N, K, n_store, act, out_f32, vec, colsum_ws, fast, (variant >> 4) & 7};
   variant &= 15;
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == SNERF_DT_F32) return launch_nt<float, 128, 128, 2, 2>(p, s);
-  if (variant == 1 && N % 256 == 0) return launch_nt<__bf16, 256, 256, 2, 4>(p, s);
-  return launch_nt<__bf16, 128, 128, 2, 2>(p, s);
+  // variant: 0 = 128x128 block-issue, 1 = 256x256 block-issue, 2 = 128x128 interleaved, 3 = 256x256 interleaved
+  if (dtype == SNERF_DT_F32) return (variant & 2) ? launch_nt<float, 128, 128, 2, 2, true>(p, s) : launch_nt<float, 128, 128, 2, 2, false>(p, s);
+  if ((variant & 1) && N % 256 == 0) return (variant & 2) ? launch_nt<__bf16, 256, 256, 2, 4, true>(p, s) : launch_nt<__bf16, 256, 256, 2, 4, false>(p, s);
+  return (variant & 2) ? launch_nt<__bf16, 128, 128, 2, 2, true>(p, s) : launch_nt<__bf16, 128, 128, 2, 2, false>(p, s);
 }
 
 // ---------------------------------------------------------------------------
@@ -393,7 +465,7 @@ struct GemmTN {
   int M, N, K, n_valid, k_valid, m_chunk;
 };
 
-template <typename T>
+template <typename T, bool TR>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int EPC = 16 / (int)sizeof(T);
@@ -417,8 +489,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
   constexpr int CPR = ROWB / 16;                     // chunks per row (32 fp32 / 16 bf16)
   const int lrow = lane / CPR, lch = lane % CPR;
   // clamp the column chunk so that partial tiles (N or K not a multiple of 128) stay in bounds
-  int zc = n0 + lch * EPC; zc = zc < p.N ? zc : p.N - EPC;
-  int xc = k0 + lch * EPC; xc = xc < p.K ? xc : p.K - EPC;
+  // TR (bf16): the 16-byte chunk c of tile row r is stored at chunk position c ^ (4 * (r & 3)) so that the four rows a
+  // transposing read touches fall into disjoint 64-byte bank spans; the permutation is applied to the SOURCE address
+  const int sch = TR ? (lch ^ (4 * (lrow & 3))) : lch;
+  int zc = n0 + sch * EPC; zc = zc < p.N ? zc : p.N - EPC;
+  int xc = k0 + sch * EPC; xc = xc < p.K ? xc : p.K - EPC;
 
   auto issue = [&](int st, int stage) {
     char* sZ = smem + stage * 2 * TILEB;
@@ -464,6 +539,34 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
 #pragma unroll
           for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
       }
+    } else if constexpr (TR) {
+      // ds_read_b64_tr_b16: per 16-lane group, lane p supplies the address of 4 consecutive bf16 of row (p>>2) and receives
+      // column p of the 4x16 block -> 4 consecutive reduction indices for its own output row/column: two reads per fragment
+      typedef __attribute__((address_space(3))) bf16x4* lds_b4;
+      const int g = lane >> 4, pl = lane & 15;
+      const int prow = pl >> 2;                                  // row inside the 4-row block == (row & 3)
+#pragma unroll
+      for (int ks = 0; ks < MT / 16; ++ks) {
+        const int row0 = ks * 16 + 8 * (g >> 1) + prow;
+        bf16x8 a[2], b[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int ca = (wn * 64 + t * 32 + 16 * (g & 1)) / 8 + ((pl & 3) >> 1);     // logical 16-byte chunk
+          const int cb = (wk * 64 + t * 32 + 16 * (g & 1)) / 8 + ((pl & 3) >> 1);
+          const int oa = ((ca ^ (4 * prow)) << 4) + ((pl & 1) << 3);
+          const int ob = ((cb ^ (4 * prow)) << 4) + ((pl & 1) << 3);
+          const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(sZ + row0 * ROWB + oa));
+          const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(sZ + (row0 + 4) * ROWB + oa));
+          const bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(sX + row0 * ROWB + ob));
+          const bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(sX + (row0 + 4) * ROWB + ob));
+          a[t] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+          b[t] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
     } else {
 #pragma unroll
       for (int ks = 0; ks < MT / 16; ++ks) {
@@ -500,7 +603,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
 }
 
 extern "C" int snerf_linear_wgrad(const void* Z, long ldz, const void* X, long ldx, float* dW, long ldw, const void* zeros,
-                                  int M, int N, int K, int n_valid, int k_valid, int dtype, void* stream) {
+                                  int M, int N, int K, int n_valid, int k_valid, int dtype, int variant, void* stream) {
   if (M <= 0) return SNERF_OK;
   const int epc = dtype == SNERF_DT_F32 ? 4 : 8;
   if (N < epc || K < epc || N % epc || K % epc || ldz % epc || ldx % epc || zeros == nullptr) return SNERF_ERR_ARG;
@@ -514,8 +617,12 @@ extern "C" int snerf_linear_wgrad(const void* Z, long ldz, const void* X, long l
   GemmTN p{Z, ldz, X, ldx, dW, ldw, zeros, M, N, K, n_valid, k_valid, m_chunk};
   const int lds = 2 * 2 * 8192;
   dim3 grid(tiles, chunks);
-  if (dtype == SNERF_DT_F32) hipLaunchKernelGGL(gemm_tn_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, p);
-  else if (dtype == SNERF_DT_BF16) hipLaunchKernelGGL(gemm_tn_kernel<__bf16>, grid, dim3(256), lds, (hipStream_t)stream, p);
+  // variant 1 (bf16): operands via ds_read_b64_tr_b16 (needs whole 128-column tiles: the source swizzle permutes chunks
+  // inside a 256-byte row); variant 0: 16-bit LDS gathers
+  const bool tr = (variant & 1) && dtype == SNERF_DT_BF16 && (N % 128 == 0) && (K % 128 == 0);
+  if (dtype == SNERF_DT_F32) hipLaunchKernelGGL((gemm_tn_kernel<float, false>), grid, dim3(256), lds, (hipStream_t)stream, p);
+  else if (dtype == SNERF_DT_BF16 && tr) hipLaunchKernelGGL((gemm_tn_kernel<__bf16, true>), grid, dim3(256), lds, (hipStream_t)stream, p);
+  else if (dtype == SNERF_DT_BF16) hipLaunchKernelGGL((gemm_tn_kernel<__bf16, false>), grid, dim3(256), lds, (hipStream_t)stream, p);
   else return SNERF_ERR_ARG;
   return snerf_check_launch();
 }

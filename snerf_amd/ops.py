@@ -74,12 +74,12 @@ def linear_fwd(A, W, bias, Y, K, n_store, act, dt, out_f32=False, aux=None, cols
               1 if out_f32 else 0, variant, _stream())
 
 
-def linear_wgrad(dZ, X, dW, n_valid, k_valid, dt):
+def linear_wgrad(dZ, X, dW, n_valid, k_valid, dt, variant=0):
     """dW[:n_valid, :k_valid] += dZ^T @ X (fp32 atomics).  dZ [M,N], X [M,K] views, dW fp32 view."""
     _chk2d(dZ, _TORCH_DT[dt]); _chk2d(X, _TORCH_DT[dt]); _chk2d(dW, torch.float32)
     assert dZ.shape[0] == X.shape[0] and dW.shape[0] >= n_valid and dW.shape[1] >= k_valid
     _lib.call("snerf_linear_wgrad", _p(dZ), dZ.stride(0), _p(X), X.stride(0), _p(dW), dW.stride(0),
-              _p(zero_page(dZ.device)), dZ.shape[0], dZ.shape[1], X.shape[1], n_valid, k_valid, dt, _stream())
+              _p(zero_page(dZ.device)), dZ.shape[0], dZ.shape[1], X.shape[1], n_valid, k_valid, dt, variant, _stream())
 
 
 # --------------------------------------------------------------- encoders ----

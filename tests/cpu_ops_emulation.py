@@ -25,7 +25,7 @@ def linear_fwd(A, W, bias, Y, K, n_store, act, dt, out_f32=False, aux=None, cols
         colsum[:n_store] += y.sum(0)
 
 
-def linear_wgrad(dZ, X, dW, n_valid, k_valid, dt):
+def linear_wgrad(dZ, X, dW, n_valid, k_valid, dt, variant=0):
     dW[:n_valid, :k_valid] += (dZ.float().t() @ X.float())[:n_valid, :k_valid]
 
 

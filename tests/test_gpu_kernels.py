@@ -75,15 +75,16 @@ def test_linear_dgrad_mask_colsum(ops, dt):
 
 
 @pytest.mark.parametrize("dt,M,N,K,nv,kv", [(0, 700, 96, 128, 90, 127), (0, 5000, 256, 1120, 256, 1120), (1, 700, 64, 128, 3, 128),
-                                            (1, 5000, 256, 320, 256, 283), (1, 3000, 1024, 1152, 1024, 1120)])
+                                            (1, 5000, 256, 320, 256, 283), (1, 3000, 1024, 1152, 1024, 1120), (1, 4100, 256, 128, 256, 96), (1, 2077, 128, 1024, 128, 1024)])
 def test_linear_wgrad(ops, dt, M, N, K, nv, kv):
     tdt = ops.torch_dtype(dt)
     dZ = gen(M, N, seed=7).to(tdt).cuda()
     X = gen(M, K, seed=8).to(tdt).cuda()
-    dW = torch.ones(nv, kv, dtype=torch.float32, device="cuda")   # accumulates on top of existing content
-    ops.linear_wgrad(dZ, X, dW, nv, kv, dt)
     ref = 1.0 + (dZ.double().cpu().t() @ X.double().cpu())[:nv, :kv]
-    close(dW, ref, 1e-4, 1e-3 * (M / 1000) ** 0.5, "wgrad")
+    for variant in (0, 1):                                          # 1 = transposing LDS reads (bf16, whole 128-column tiles)
+        dW = torch.ones(nv, kv, dtype=torch.float32, device="cuda")   # accumulates on top of existing content
+        ops.linear_wgrad(dZ, X, dW, nv, kv, dt, variant=variant)
+        close(dW, ref, 1e-4, 1e-3 * (M / 1000) ** 0.5, f"wgrad variant {variant}")
 
 
 # -------------------------------------------------------------- encoders ----
