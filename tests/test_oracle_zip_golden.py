@@ -1,0 +1,68 @@
+"""Pin oracle/zip.py (path C around the hash grid) against vectors captured from the imported reference
+(oracle/gen_golden_zip.py).  CPU only."""
+import numpy as np
+import torch
+
+from oracle import zip as oz
+
+
+def close(a, b, rtol=1e-6, atol=1e-6, what=""):
+    a = a.double(); b = b.double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = (a - b).abs(); tol = atol + rtol * b.abs()
+    assert bool((err <= tol).all()), f"{what}: max err {err.max().item():.3e}"
+
+
+def test_g10_stages(golden):
+    g = golden("g10_warp")
+    close(oz.s_to_t(g["s"], g["near"], g["far"], -1.5), g["t"], 1e-6, 1e-7, "s_to_t")
+    g = golden("g10_dilate")
+    td, wd = oz.max_dilate_weights(g["t"], g["w"], float(g["dilation"]), (0.0, 1.0))
+    close(td, g["t_dilate"], 0, 0, "t_dilate"); close(wd, g["w_dilate"], 1e-6, 1e-8, "w_dilate")
+    g = golden("g10_sample_intervals")
+    sd, _ = oz.sample_intervals(g["t"], g["logits"], oz.det_centers_u(16))
+    close(sd, g["sdist_det"], 1e-6, 1e-7, "sample_intervals det")
+    sd, _ = oz.sample_intervals(g["t"], g["logits"], oz.rand_u(16, g["jitter"]))
+    close(sd, g["sdist_rand"], 1e-6, 1e-7, "sample_intervals rand")
+    g = golden("g10_cast_rays")
+    b = {k[2:]: v for k, v in g.items() if k.startswith("b_")}
+    m, s = oz.cast_rays(g["tdist"], b["origins"], b["directions"], b["radii"], b["base_x"], b["base_y"], None)
+    close(m, g["means_det"], 1e-6, 1e-6, "cast means"); close(s, g["stds_det"], 1e-6, 1e-9, "cast stds")
+    m, s = oz.cast_rays(g["tdist"], b["origins"], b["directions"], b["radii"], b["base_x"], b["base_y"], g["deg_jitter"])
+    close(m, g["means_rand"], 1e-6, 1e-6, "cast means rand")
+    g = golden("g10_contract")
+    z, so = oz.contract_mean_std(g["x"], g["std"])
+    close(z, g["z"], 1e-6, 1e-7, "contract z"); close(so, g["std_out"], 1e-6, 1e-9, "contract std")
+    g = golden("g10_render")
+    w = oz.compute_alpha_weights(g["density"], g["tdist"], g["dirs"], True)
+    close(w, g["weights"], 1e-6, 1e-7, "alpha weights")
+    close(oz.compute_alpha_weights(g["density"], g["tdist"], g["dirs"], False), g["weights_noopaque"], 1e-6, 1e-7, "alpha weights (not opaque)")
+    r = oz.volumetric_rendering(g["rgbs"], g["weights"], g["tdist"], 1.0)
+    close(r["rgb"], g["rgb"], 1e-6, 1e-6, "rgb"); close(r["depth"], g["depth"], 1e-6, 1e-6, "depth")
+    r = oz.volumetric_rendering(g["rgbs"], g["weights_noopaque"], g["tdist"], 0.5)
+    close(r["rgb"], g["rgb_noopaque"], 1e-6, 1e-6, "rgb (bg 0.5)"); close(r["depth"], g["depth_noopaque"], 1e-6, 1e-6, "depth (not opaque)")
+
+
+def zip_setup():
+    import importlib.util, os, sys
+    spec = importlib.util.spec_from_file_location("gen_golden_zip", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "gen_golden_zip.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    specs = m.small_specs()
+    return specs, m.formula_params(oz.param_shapes(specs))
+
+
+def test_g11_model_forward(golden):
+    g = golden("g11_zip_model")
+    specs, p = zip_setup()
+    batch = {k[2:]: v for k, v in g.items() if k.startswith("b_")}
+    rend, hist = oz.model_forward(p, specs, batch, train_frac=1.0)
+    for lvl in range(3):
+        close(hist[lvl]["sdist"], g[f"det_sdist{lvl}"], 1e-5, 1e-6, f"det sdist {lvl}")
+        close(hist[lvl]["weights"], g[f"det_weights{lvl}"], 1e-4, 1e-6, f"det weights {lvl}")
+    close(rend[-1]["rgb"], g["det_rgb"], 1e-5, 1e-5, "det rgb"); close(rend[-1]["depth"], g["det_depth"], 1e-5, 1e-5, "det depth")
+    close(rend[0]["depth"], g["det_depth0"], 1e-5, 1e-5, "det depth level 0")
+    rend, hist = oz.model_forward(p, specs, batch, train_frac=float(g["rand_train_frac"]), jitters=[g[f"jitter{i}"] for i in range(3)],
+                                  deg_jitters=[g[f"deg_jitter{i}"] for i in range(3)])
+    for lvl in range(3):
+        close(hist[lvl]["sdist"], g[f"rand_sdist{lvl}"], 1e-5, 1e-6, f"rand sdist {lvl}")
+    close(rend[-1]["rgb"], g["rand_rgb"], 1e-5, 1e-5, "rand rgb"); close(rend[-1]["depth"], g["rand_depth"], 1e-5, 1e-5, "rand depth")
