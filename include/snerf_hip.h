@@ -136,6 +136,42 @@ int snerf_grid_encode_bwd(const void* grad, const float* inputs, const void* emb
 int snerf_grid_tv_grad(const float* inputs, const void* embeddings, void* grad, const int* offsets, float weight, int B, int D,
                        int C, int L, float S, int H, int gridtype, int align_corners, int dtype, void* stream);
 
+/* ---- S-NeRF++ / zipnerf background model (s-nerfpp/zipnerf/internal) --------------------------------------------------
+ * One launch per sampling level: stepfun.max_dilate_weights (stepfun.py:75-105; dilate = 0 skips it, level 0) with the
+ * caller's [1:-1] trim (models.py:187-188), the annealed logits (models.py:196-203), stepfun.sample_intervals
+ * (stepfun.py:251-294 -> 175-218 -> 154-161 -> 108-128, math.sorted_interp math.py:88-107) at the centres `u` [R,n]
+ * (rows u_stride apart, 0 = shared) and the power-transformation ray warp s -> t (coord.py:103-162, lam).  sdist [R,S0+1],
+ * weights [R,S0] -> sdist_out / tdist_out [R,n+1]. */
+int snerf_zip_resample(const float* sdist, const float* weights, int S0, const float* u, long u_stride, int n,
+                       const float* near, const float* far, long R, float dilation, int dilate, float anneal,
+                       float resample_padding, float lam, float dom0, float dom1, float* sdist_out, float* tdist_out,
+                       void* stream);
+/* render.cast_rays (render.py:129-168; n multisamples on an m-turn helix, deg_jitter [R,S,n] or NULL) + coord.contract_mean_std
+ * (coord.py:51-63) + /2 + GridEncoder forward (gridencoder.cu:87-245, hash type, linear) + erf down-weighting and mean over
+ * the multisamples (models.py:488-497) -> feat [R*S, ld] (columns level*C + c; feat_dtype fp32/bf16).  table fp32 or fp16
+ * (SNERF_DT_F16); grid_sizes = GridEncoder.grid_sizes; Sl = log2(per_level_scale). */
+int snerf_zip_encode_fwd(const float* tdist, const float* origins, const float* directions, const float* radii,
+                         const float* base_x, const float* base_y, const float* deg_jitter, const void* table,
+                         const int* offsets, const int* grid_sizes, void* feat, long ld, long R, int S, int L, int C, int n,
+                         int m, float Sl, int H, float std_scale, int table_dtype, int feat_dtype, void* stream);
+/* matching scatter-add of grad_feat [R*S, ld] into the fp32 table gradient (gridencoder.cu:248-340 composed with the mean /
+ * erf weights); grad_table accumulates (fp32 atomics). */
+int snerf_zip_encode_bwd(const float* tdist, const float* origins, const float* directions, const float* radii,
+                         const float* base_x, const float* base_y, const float* deg_jitter, const int* offsets,
+                         const int* grid_sizes, const void* grad_feat, long ld, float* grad_table, long R, int S, int L, int C,
+                         int n, int m, float Sl, int H, float std_scale, int feat_dtype, void* stream);
+/* render.compute_alpha_weights (render.py:170-189, opaque_background) + volumetric_rendering (render.py:192-233: rgb with
+ * clamped background weight, depth = clip(exp(E_w[log t_mid]))) fused with density = softplus(raw + bias) (models.py:586)
+ * and rgb = sigmoid(raw)(1 + 2 pad) - pad (models.py:689-703).  raw_rgb NULL = proposal level (rgb = 0). */
+int snerf_zip_composite_fwd(const float* raw_rgb, long ld_rgb, const float* raw_density, long ld_den, const float* tdist,
+                            const float* dirs, long R, int S, int opaque, float bg, float rgb_padding, float density_bias,
+                            float* rgb, float* depth, float* acc, float* weights, void* stream);
+int snerf_zip_composite_bwd(const float* raw_rgb, long ld_rgb, const float* raw_density, long ld_den, const float* tdist,
+                            const float* dirs, long R, int S, int opaque, float bg, float rgb_padding, float density_bias,
+                            const float* weights, const float* acc, const float* depth, const float* g_rgb, const float* g_depth,
+                            const float* g_acc, const float* g_w, float* d_raw_rgb, long ld_drgb, float* d_raw_density,
+                            long ld_dden, void* stream);
+
 /* ---- training tail ------------------------------------------------------------------------------
  * torch.optim.Adam step over a flat fp32 arena (model_utils.py:23-34 builds Adam); grad_scale folds the
  * data-parallel 1/world_size; zero_grad clears g for the next step. */

@@ -242,6 +242,7 @@ def model_forward(p, specs, batch, num_prop_samples=(64, 64), num_nerf_samples=3
         logits = resample_logits(sdist, weights, anneal, 0.0)
         u = det_centers_u(ns) if jitters is None else rand_u(ns, jitters[lvl])
         sdist, _ = sample_intervals(sdist, logits, u, (0.0, 1.0))
+        sdist = sdist.detach()                      # stop_level_grad, models.py:215-218
         tdist = s_to_t(sdist, near, far, power_lambda)
         means, stds = cast_rays(tdist, batch["origins"], batch["directions"], batch["radii"], batch["base_x"], batch["base_y"],
                                 None if deg_jitters is None else deg_jitters[lvl], std_scale=std_scale)

@@ -1,0 +1,502 @@
+// S-NeRF++ / zipnerf background model: sampling and the fused multisample hash-grid featurisation (gfx950).
+//
+//   snerf_zip_resample    stepfun.max_dilate_weights (stepfun.py:75-105) + the annealed logits of Model.forward
+//                         (models.py:196-203) + stepfun.sample_intervals (stepfun.py:251-294, 175-218, 154-161, 108-128;
+//                         math.sorted_interp math.py:88-107) + the s -> t ray warp (coord.py:103-162), one launch per level.
+//                         The reference materialises [R, 3S+2, S] and [R, S+1, n] masks; here one lane walks one ray.
+//   snerf_zip_encode_fwd  render.cast_rays (render.py:129-168: 7 multisamples on a 3-turn helix) + coord.contract_mean_std
+//                         (coord.py:51-63) + /2 + GridEncoder forward (gridencoder.cu:87-245) + the erf down-weighting and
+//                         the mean over the multisamples of MLP.predict_density (models.py:488-497), written straight into
+//                         the density MLP's operand buffer.  The [R,S,7,3] means and the [R*S*7, L*C] per-multisample
+//                         features never exist in memory.
+//   snerf_zip_encode_bwd  the matching scatter-add into the fp32 table gradient (gridencoder.cu:248-340 composed with the
+//                         mean / erf weights).
+//   snerf_zip_composite_* render.compute_alpha_weights + volumetric_rendering (render.py:170-233) fused with the density /
+//                         colour activations of MLP.forward (models.py:586, 689-703).
+#include "common.h"
+#include <hip/hip_fp16.h>
+
+#define ZIP_LANES 64
+
+// ------------------------------------------------------------------------------------------------------------------
+// resample (lane per ray)
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float zip_pow_t(float x, float lam) {            // coord.py:103-108
+  const float l1 = fabsf(lam - 1.f);
+  return l1 / lam * (powf(x / l1 + 1.f, lam) - 1.f);
+}
+__device__ __forceinline__ float zip_inv_pow_t(float x, float lam) {        // coord.py:111-118
+  const float l1 = fabsf(lam - 1.f);
+  return (powf(x * lam / l1 + 1.f + 1.1920929e-07f, 1.f / lam) - 1.f) * l1;
+}
+
+struct ZipResample {
+  const float* sdist; const float* weights; int S0;      // input step function: S0 intervals, S0+1 posts
+  const float* u; long u_stride; int n;                  // n centres -> n+1 output posts
+  const float* near; const float* far;
+  long R; float dilation; int dilate; float anneal, pad, lam, dom0, dom1;
+  float* sdist_out; float* tdist_out;
+};
+
+__global__ __launch_bounds__(ZIP_LANES) void zip_resample_kernel(ZipResample a) {
+  extern __shared__ float lds[];
+  const int cap = 3 * a.S0 + 2;
+  const int stride = cap | 1;
+  float* T = lds + (size_t)threadIdx.x * 2 * stride;     // posts
+  float* W = T + stride;                                 // weights -> cdf
+  const long ray = (long)blockIdx.x * ZIP_LANES + threadIdx.x;
+  if (ray >= a.R) return;
+  const float* t = a.sdist + ray * (a.S0 + 1);
+  const float* w = a.weights + ray * a.S0;
+  const float eps = 1.1920929e-07f;
+  int S;                                                  // intervals of the step function that gets sampled
+  if (a.dilate) {
+    // merged, clipped posts of the three sorted sequences t, t - d (t0), t + d (t1)
+    const int S0 = a.S0, NP = 3 * S0 + 1;
+    int ia = 0, ib = 0, ic = 0;
+    for (int k = 0; k < NP; ++k) {
+      const float va = ia <= S0 ? t[ia] : INFINITY;
+      const float vb = ib < S0 ? t[ib] - a.dilation : INFINITY;
+      const float vc = ic < S0 ? t[ic + 1] + a.dilation : INFINITY;
+      float v;
+      if (vb <= va && vb <= vc) { v = vb; ++ib; } else if (va <= vc) { v = va; ++ia; } else { v = vc; ++ic; }
+      T[k] = fminf(fmaxf(v, a.dom0), a.dom1);
+    }
+    // dilated pdf = max over the intervals i with t0_i <= T_k < t1_i (a contiguous, monotonically moving range)
+    int lo = 0, hi = -1;
+    float sum = 0.f;
+    for (int k = 0; k < NP - 1; ++k) {
+      const float tk = T[k];
+      while (lo < S0 && !(t[lo + 1] + a.dilation > tk)) ++lo;
+      while (hi + 1 < S0 && t[hi + 1] - a.dilation <= tk) ++hi;
+      float p = 0.f;
+      for (int i = lo; i <= hi; ++i) {
+        const float pi = w[i] / fmaxf(t[i + 1] - t[i], eps);
+        if (t[i] - a.dilation <= tk && t[i + 1] + a.dilation > tk) p = fmaxf(p, pi);
+      }
+      const float wd = p * (T[k + 1] - tk);
+      W[k] = wd;
+      sum += wd;
+    }
+    sum = fmaxf(sum, eps);
+    // caller trims [1:-1] (models.py:187-188): posts 1 .. NP-2, intervals 1 .. NP-3
+    S = NP - 3;
+    for (int k = 0; k < S; ++k) W[k] = W[k + 1] / sum;
+    for (int k = 0; k <= S; ++k) T[k] = T[k + 1];
+  } else {
+    S = a.S0;
+    for (int k = 0; k <= S; ++k) T[k] = t[k];
+    for (int k = 0; k < S; ++k) W[k] = w[k];
+  }
+  // annealed logits + softmax (models.py:196-203, stepfun.py:157)
+  float mx = -INFINITY;
+  for (int k = 0; k < S; ++k) {
+    const float l = T[k + 1] > T[k] ? a.anneal * logf(W[k] + a.pad) : -INFINITY;
+    W[k] = l;
+    mx = fmaxf(mx, l);
+  }
+  double acc = 0.0;
+  for (int k = 0; k < S; ++k) { const float e = expf(W[k] - mx); W[k] = e; acc += (double)e; }
+  const float esum = (float)acc;
+  // cdf in place: C[0] = 0, C[k+1] = min(1, cumsum), C[S] = 1 (stepfun.py:108-128); stored shifted by one in W via a carry
+  acc = 0.0;
+  float prev = 0.f;                                      // C[k]
+  for (int k = 0; k < S; ++k) {
+    const float wk = W[k] / esum;
+    W[k] = prev;                                         // W[k] now holds C[k]
+    acc += (double)wk;
+    prev = k == S - 1 ? 1.f : fminf(1.f, (float)acc);
+  }
+  W[S] = 1.f;
+  // invert the cdf at the n centres, build the n+1 fence posts and warp them to metric distances
+  const float* ur = a.u + ray * a.u_stride;
+  const float nr = a.near[ray], fr = a.far[ray];
+  const float s_near = zip_pow_t(nr * 2.f, a.lam), s_far = zip_pow_t(fr * 2.f, a.lam);
+  float* so = a.sdist_out + ray * (a.n + 1);
+  float* to = a.tdist_out + ray * (a.n + 1);
+  auto warp = [&](float s) { return zip_inv_pow_t(s * s_far + (1.f - s) * s_near, a.lam) / 2.f; };
+  float c_prev = 0.f, c0 = 0.f, mid_last = 0.f;
+  for (int j = 0; j < a.n; ++j) {
+    const float uj = ur[j];
+    int lo = 0, hi = S + 1;
+    while (lo < hi) { const int m = (lo + hi) >> 1; if (W[m] <= uj) lo = m + 1; else hi = m; }
+    int i0 = lo - 1; i0 = i0 < 0 ? 0 : (i0 > S ? S : i0);
+    const int i1 = i0 + 1 > S ? S : i0 + 1;
+    float off = (uj - W[i0]) / (W[i1] - W[i0]);
+    if (off != off) off = 0.f;
+    off = fminf(fmaxf(off, 0.f), 1.f);
+    const float c = T[i0] + off * (T[i1] - T[i0]);
+    if (j == 0) c0 = c;
+    else {
+      const float mid = (c + c_prev) / 2.f;
+      if (j == 1) { const float first = fmaxf(2.f * c0 - mid, a.dom0); so[0] = first; to[0] = warp(first); }
+      so[j] = mid; to[j] = warp(mid);
+      mid_last = mid;
+    }
+    c_prev = c;
+  }
+  const float last = fminf(2.f * c_prev - mid_last, a.dom1);
+  so[a.n] = last; to[a.n] = warp(last);
+}
+
+extern "C" int snerf_zip_resample(const float* sdist, const float* weights, int S0, const float* u, long u_stride, int n,
+                                  const float* near, const float* far, long R, float dilation, int dilate, float anneal,
+                                  float resample_padding, float lam, float dom0, float dom1, float* sdist_out, float* tdist_out,
+                                  void* stream) {
+  if (R <= 0) return SNERF_OK;
+  if (S0 < 1 || n < 2 || (dilate && S0 < 2)) return SNERF_ERR_ARG;
+  const int stride = (3 * S0 + 2) | 1;
+  const size_t lds = (size_t)ZIP_LANES * 2 * stride * sizeof(float);
+  if (lds > 160 * 1024) return SNERF_ERR_ARG;
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)zip_resample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  ZipResample a{sdist, weights, S0, u, u_stride, n, near, far, R, dilation, dilate, anneal, resample_padding, lam, dom0, dom1, sdist_out, tdist_out};
+  hipLaunchKernelGGL(zip_resample_kernel, dim3((unsigned)((R + ZIP_LANES - 1) / ZIP_LANES)), dim3(ZIP_LANES), lds, (hipStream_t)stream, a);
+  return snerf_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// fused multisample featurisation
+// ------------------------------------------------------------------------------------------------------------------
+struct ZipEnc {
+  const float* tdist; const float* origins; const float* directions; const float* radii; const float* base_x; const float* base_y;
+  const float* deg_jitter;            // [R,S,n] or null
+  const void* table; const int* offsets; const int* grid_sizes;   // grid_sizes[l] = GridEncoder.grid_sizes (resolution + 1)
+  void* feat; long ld;                // forward: output [P, ld]; backward: gradient input
+  float* grad_table;                  // backward only (fp32)
+  long R; int S, L, n, m; float Sl; int H; float std_scale;
+};
+
+__device__ __forceinline__ uint32_t zip_hash3(const uint32_t* p) { return p[0] ^ (p[1] * 2654435761u) ^ (p[2] * 805459861u); }
+
+__device__ __forceinline__ uint32_t zip_grid_index(uint32_t hs, uint32_t res, const uint32_t* pg) {   // gridencoder.cu:66-84, D = 3, hash type
+  uint32_t stride = 1, index = 0;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    if (stride <= hs) { index += pg[d] * stride; stride *= (res + 1); }
+  }
+  if (stride > hs) index = zip_hash3(pg);
+  return index % hs;
+}
+
+template <typename TT, int C> struct alignas(sizeof(TT) * C) ZVec { TT v[C]; };
+
+// position, contracted + halved, and its erf weight for one multisample
+__device__ __forceinline__ void zip_sample_point(const ZipEnc& a, long ray, int i, int j, float t0, float t1, const float* o, const float* d,
+                                                 const float* bx, const float* by, float rad, float* x01, float* sd) {
+  const float t = t0 + (t1 - t0) * ((float)j + 0.5f) / (float)a.n;
+  float deg = 2.f * 3.14159265358979f * (float)a.m * (float)j / (float)a.n;
+  if (a.deg_jitter != nullptr) deg += a.deg_jitter[(ray * a.S + i) * a.n + j] * 3.14159265358979f * 2.f;
+  float sn, cs;
+  sincosf(deg, &sn, &cs);
+  const float lx = rad * t * cs / 2.f, ly = rad * t * sn / 2.f;
+  float x[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) x[k] = lx * bx[k] + ly * by[k] + t * d[k] + o[k];
+  float std = a.std_scale * rad * t;
+  const float msq = fmaxf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2], 1.1920929e-07f);   // coord.py:51-63
+  if (!(msq <= 1.f)) {
+    const float mag = sqrtf(msq);
+    const float sc = (2.f * mag - 1.f) / msq;
+    const float q = 2.f / mag - 1.f / msq;
+    const float det = (1.f / msq) * (q * q);
+    std = cbrtf(det) * std;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) x[k] = sc * x[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) x01[k] = (x[k] / 2.f + 1.f) / 2.f;   // /2 (models.py:488-490), then (x + bound) / (2 bound) (grid.py:162)
+  *sd = std / 2.f;
+}
+
+template <typename TT, typename OT, int C, bool BWD>
+__global__ __launch_bounds__(256) void zip_encode_kernel(ZipEnc a) {
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  const long P = a.R * a.S;
+  if (p >= P) return;
+  const int level = blockIdx.y;
+  const long ray = p / a.S;
+  const int i = (int)(p - ray * a.S);
+  const float t0 = a.tdist[ray * (a.S + 1) + i], t1 = a.tdist[ray * (a.S + 1) + i + 1];
+  float o[3], d[3], bx[3], by[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { o[k] = a.origins[ray * 3 + k]; d[k] = a.directions[ray * 3 + k]; bx[k] = a.base_x[ray * 3 + k]; by[k] = a.base_y[ray * 3 + k]; }
+  const float rad = a.radii[ray];
+  const uint32_t hs = a.offsets[level + 1] - a.offsets[level];
+  const float scale = exp2f(level * a.Sl) * a.H - 1.0f;
+  const uint32_t res = (uint32_t)ceilf(scale) + 1;
+  const TT* tab = (const TT*)a.table + (long)a.offsets[level] * C;
+  float acc[C], g[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) acc[c] = 0.f;
+  if (BWD) {
+    const OT* gi = (const OT*)a.feat + p * a.ld + level * C;
+#pragma unroll
+    for (int c = 0; c < C; ++c) g[c] = (float)gi[c] / (float)a.n;
+  }
+  for (int j = 0; j < a.n; ++j) {
+    float x01[3], sd;
+    zip_sample_point(a, ray, i, j, t0, t1, o, d, bx, by, rad, x01, &sd);
+    if (x01[0] < 0.f || x01[0] > 1.f || x01[1] < 0.f || x01[1] > 1.f || x01[2] < 0.f || x01[2] > 1.f) continue;   // encoder returns zeros
+    // erf(1 / sqrt(8 std^2 gs^2)) with gs = GridEncoder.grid_sizes[level] (models.py:494)
+    const float gs = (float)a.grid_sizes[level];
+    const float we = erff(1.f / sqrtf(8.f * sd * sd * gs * gs));
+    float fr[3];
+    uint32_t pg[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float ps = x01[k] * scale + 0.5f;
+      const float fl = floorf(ps);
+      pg[k] = (uint32_t)fl;
+      fr[k] = ps - fl;
+    }
+#pragma unroll
+    for (int idx = 0; idx < 8; ++idx) {
+      float w = 1.f;
+      uint32_t pl[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        if (idx & (1 << k)) { w *= fr[k]; pl[k] = pg[k] + 1; } else { w *= 1.f - fr[k]; pl[k] = pg[k]; }
+      }
+      const long row = zip_grid_index(hs, res, pl);
+      if (!BWD) {
+        const ZVec<TT, C> r = *reinterpret_cast<const ZVec<TT, C>*>(tab + row * C);
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] += (w * we) * (float)r.v[c];
+      } else {
+        float* dst = a.grad_table + ((long)a.offsets[level] + row) * C;
+#pragma unroll
+        for (int c = 0; c < C; ++c) atomicAdd(dst + c, (w * we) * g[c]);
+      }
+    }
+  }
+  if (!BWD) {
+    OT* out = (OT*)a.feat + p * a.ld + level * C;
+#pragma unroll
+    for (int c = 0; c < C; ++c) out[c] = (OT)(acc[c] / (float)a.n);
+  }
+}
+
+template <typename TT, typename OT, bool BWD>
+static int zip_enc_launch(const ZipEnc& a, int C, hipStream_t s) {
+  const dim3 grid((unsigned)((a.R * a.S + 255) / 256), a.L), blk(256);
+  switch (C) {
+    case 1: hipLaunchKernelGGL((zip_encode_kernel<TT, OT, 1, BWD>), grid, blk, 0, s, a); break;
+    case 2: hipLaunchKernelGGL((zip_encode_kernel<TT, OT, 2, BWD>), grid, blk, 0, s, a); break;
+    case 4: hipLaunchKernelGGL((zip_encode_kernel<TT, OT, 4, BWD>), grid, blk, 0, s, a); break;
+    case 8: hipLaunchKernelGGL((zip_encode_kernel<TT, OT, 8, BWD>), grid, blk, 0, s, a); break;
+    default: return SNERF_ERR_ARG;
+  }
+  return snerf_check_launch();
+}
+
+template <bool BWD>
+static int zip_enc_dispatch(const ZipEnc& a, int C, int table_dtype, int feat_dtype, hipStream_t s) {
+  if (table_dtype == SNERF_DT_F32 && feat_dtype == SNERF_DT_F32) return zip_enc_launch<float, float, BWD>(a, C, s);
+  if (table_dtype == SNERF_DT_F32 && feat_dtype == SNERF_DT_BF16) return zip_enc_launch<float, __bf16, BWD>(a, C, s);
+  if (table_dtype == 2 && feat_dtype == SNERF_DT_F32) return zip_enc_launch<__half, float, BWD>(a, C, s);
+  if (table_dtype == 2 && feat_dtype == SNERF_DT_BF16) return zip_enc_launch<__half, __bf16, BWD>(a, C, s);
+  return SNERF_ERR_ARG;
+}
+
+extern "C" int snerf_zip_encode_fwd(const float* tdist, const float* origins, const float* directions, const float* radii,
+                                    const float* base_x, const float* base_y, const float* deg_jitter, const void* table,
+                                    const int* offsets, const int* grid_sizes, void* feat, long ld, long R, int S, int L, int C, int n,
+                                    int m, float Sl, int H, float std_scale, int table_dtype, int feat_dtype, void* stream) {
+  if (R <= 0) return SNERF_OK;
+  if (S <= 0 || L <= 0 || n <= 0 || ld < (long)L * C || table == nullptr || feat == nullptr || grid_sizes == nullptr) return SNERF_ERR_ARG;
+  ZipEnc a{tdist, origins, directions, radii, base_x, base_y, deg_jitter, table, offsets, grid_sizes, feat, ld, nullptr, R, S, L, n, m, Sl, H, std_scale};
+  return zip_enc_dispatch<false>(a, C, table_dtype, feat_dtype, (hipStream_t)stream);
+}
+
+extern "C" int snerf_zip_encode_bwd(const float* tdist, const float* origins, const float* directions, const float* radii,
+                                    const float* base_x, const float* base_y, const float* deg_jitter, const int* offsets,
+                                    const int* grid_sizes, const void* grad_feat, long ld, float* grad_table, long R, int S, int L, int C,
+                                    int n, int m, float Sl, int H, float std_scale, int feat_dtype, void* stream) {
+  if (R <= 0) return SNERF_OK;
+  if (S <= 0 || L <= 0 || n <= 0 || ld < (long)L * C || grad_feat == nullptr || grad_table == nullptr || grid_sizes == nullptr) return SNERF_ERR_ARG;
+  ZipEnc a{tdist, origins, directions, radii, base_x, base_y, deg_jitter, nullptr, offsets, grid_sizes, (void*)grad_feat, ld, grad_table, R, S, L, n, m, Sl, H, std_scale};
+  return zip_enc_dispatch<true>(a, C, SNERF_DT_F32, feat_dtype, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// compositing (wave per ray)
+// ------------------------------------------------------------------------------------------------------------------
+#define ZMAXSEG 8
+__device__ __forceinline__ float z_softplus(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float z_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+
+struct ZipComp {
+  const float* raw_rgb; long ld_rgb;        // [P,3] fp32 or null (proposal level: rgb = 0)
+  const float* raw_density; long ld_den;    // [P] fp32 (strided)
+  const float* tdist; const float* dirs;
+  long R; int S; int opaque; float bg, rgb_padding, density_bias;
+  float* rgb; float* depth; float* acc; float* weights;
+  const float* g_rgb; const float* g_depth; const float* g_acc; const float* g_w;
+  float* d_raw_rgb; long ld_drgb; float* d_raw_density; long ld_dden;
+};
+
+__global__ __launch_bounds__(256) void zip_composite_fwd_kernel(ZipComp a) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long ray = (long)blockIdx.x * 4 + wave;
+  if (ray >= a.R) return;
+  const int S = a.S;
+  const float* d = a.dirs + ray * 3;
+  const float dnorm = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  const float* td = a.tdist + ray * (S + 1);
+  float carry = 0.f, s_rgb[3] = {0.f, 0.f, 0.f}, s_acc = 0.f, s_log = 0.f;
+  for (int base = 0; base < S; base += 64) {
+    const int i = base + lane;
+    const bool ok = i < S;
+    float dd = 0.f, lt = 0.f;
+    bool inf_last = false;
+    if (ok) {
+      const float t0 = td[i], t1 = td[i + 1];
+      lt = logf(0.5f * (t0 + t1));
+      dd = z_softplus(a.raw_density[(ray * S + i) * a.ld_den] + a.density_bias) * ((t1 - t0) * dnorm);
+      inf_last = a.opaque && i == S - 1;
+    }
+    const float incl = wave_incl_scan_add(inf_last ? 0.f : dd, lane);
+    const float excl = carry + (incl - (inf_last ? 0.f : dd));
+    const float alpha = inf_last ? 1.f : 1.f - expf(-dd);
+    const float w = ok ? alpha * expf(-excl) : 0.f;
+    if (ok) a.weights[ray * S + i] = w;
+    s_acc += w;
+    s_log += w * lt;
+    if (a.raw_rgb != nullptr && ok) {
+      const float* rr = a.raw_rgb + (ray * S + i) * a.ld_rgb;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) s_rgb[c] += w * (z_sigmoid(rr[c]) * (1.f + 2.f * a.rgb_padding) - a.rgb_padding);
+    }
+    carry += __shfl(incl, 63, 64);
+  }
+  s_acc = wave_sum(s_acc); s_log = wave_sum(s_log);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) s_rgb[c] = wave_sum(s_rgb[c]);
+  if (lane == 0) {
+    a.acc[ray] = s_acc;
+    const float bgw = fmaxf(1.f - s_acc, 0.f);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) a.rgb[ray * 3 + c] = s_rgb[c] + bgw * a.bg;
+    float dep = expf(s_log / fmaxf(s_acc, 1.1920929e-07f));
+    if (dep != dep) dep = INFINITY;
+    a.depth[ray] = fminf(fmaxf(dep, td[0]), td[S]);
+  }
+}
+
+// dL/d(dd_i) = g_i T_{i+1} - sum_{k>i} g_k w_k, g_i = dL/dw_i (see composite.hip); the opaque last interval has alpha == 1
+// independent of its density (no gradient to it).
+__global__ __launch_bounds__(256) void zip_composite_bwd_kernel(ZipComp a) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long ray = (long)blockIdx.x * 4 + wave;
+  if (ray >= a.R) return;
+  const int S = a.S;
+  const float* d = a.dirs + ray * 3;
+  const float dnorm = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  const float* td = a.tdist + ray * (S + 1);
+  float grgb[3] = {0.f, 0.f, 0.f};
+  if (a.g_rgb != nullptr) { grgb[0] = a.g_rgb[ray * 3]; grgb[1] = a.g_rgb[ray * 3 + 1]; grgb[2] = a.g_rgb[ray * 3 + 2]; }
+  const float acc = a.acc[ray];
+  float gacc = a.g_acc != nullptr ? a.g_acc[ray] : 0.f;
+  if (1.f - acc > 0.f) gacc -= a.bg * (grgb[0] + grgb[1] + grgb[2]);          // bg_w = clamp_min(1 - acc, 0)
+  // depth = clip(exp(E)), E = sum w log tmid / max(acc, eps): dE/dw_i = (log tmid_i - E) / acc for acc > eps
+  float gdep = 0.f, E = 0.f, inv_acc = 0.f;
+  if (a.g_depth != nullptr) {
+    const float dep = a.depth[ray];
+    float s_log = 0.f;
+    for (int base = 0; base < S; base += 64) {
+      const int i = base + lane;
+      if (i < S) s_log += a.weights[ray * S + i] * logf(0.5f * (td[i] + td[i + 1]));
+    }
+    s_log = wave_sum(s_log);
+    const float den = fmaxf(acc, 1.1920929e-07f);
+    E = s_log / den;
+    const float raw = expf(E);
+    if (raw >= td[0] && raw <= td[S]) { gdep = a.g_depth[ray] * raw; inv_acc = 1.f / den; }
+    if (!(acc > 1.1920929e-07f)) E = 0.f;   // clamp active: denominator constant
+    (void)dep;
+  }
+  const int nseg = (S + 63) / 64;
+  float segG[ZMAXSEG];
+  auto gval = [&](int i) {
+    float g = gacc;
+    if (gdep != 0.f) g += gdep * (logf(0.5f * (td[i] + td[i + 1])) - E) * inv_acc;
+    if (a.g_w != nullptr) g += a.g_w[ray * S + i];
+    if (a.raw_rgb != nullptr) {
+      const float* rr = a.raw_rgb + (ray * S + i) * a.ld_rgb;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) g += grgb[c] * (z_sigmoid(rr[c]) * (1.f + 2.f * a.rgb_padding) - a.rgb_padding);
+    }
+    return g;
+  };
+#pragma unroll
+  for (int seg = 0; seg < ZMAXSEG; ++seg) {
+    float pg = 0.f;
+    const int i = seg * 64 + lane;
+    if (seg < nseg && i < S) pg = gval(i) * a.weights[ray * S + i];
+    segG[seg] = seg < nseg ? wave_sum(pg) : 0.f;
+  }
+  float carry_dd = 0.f;
+#pragma unroll
+  for (int seg = 0; seg < ZMAXSEG; ++seg) {
+    if (seg >= nseg) break;
+    float later = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < ZMAXSEG; ++s2) later += s2 > seg ? segG[s2] : 0.f;
+    const int i = seg * 64 + lane;
+    const bool ok = i < S;
+    float dd = 0.f, delta = 0.f, g = 0.f, w = 0.f, spg = 0.f;
+    bool inf_last = false;
+    if (ok) {
+      delta = (td[i + 1] - td[i]) * dnorm;
+      const float x = a.raw_density[(ray * S + i) * a.ld_den] + a.density_bias;
+      dd = z_softplus(x) * delta;
+      spg = x > 20.f ? 1.f : z_sigmoid(x);
+      w = a.weights[ray * S + i];
+      g = gval(i);
+      inf_last = a.opaque && i == S - 1;
+      if (a.raw_rgb != nullptr) {
+        const float* rr = a.raw_rgb + (ray * S + i) * a.ld_rgb;
+        float* dr = a.d_raw_rgb + (ray * S + i) * a.ld_drgb;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { const float sg = z_sigmoid(rr[c]); dr[c] = w * grgb[c] * (1.f + 2.f * a.rgb_padding) * sg * (1.f - sg); }
+      }
+    }
+    const float gw = g * w;
+    const float incl_dd = wave_incl_scan_add(inf_last ? 0.f : dd, lane);
+    const float t_next = expf(-(carry_dd + incl_dd));
+    const float suffix = later + (wave_incl_rscan_add(gw, lane) - gw);
+    if (ok) a.d_raw_density[(ray * S + i) * a.ld_dden] = inf_last ? 0.f : (g * t_next - suffix) * delta * spg;
+    carry_dd += __shfl(incl_dd, 63, 64);
+  }
+}
+
+extern "C" int snerf_zip_composite_fwd(const float* raw_rgb, long ld_rgb, const float* raw_density, long ld_den, const float* tdist,
+                                       const float* dirs, long R, int S, int opaque, float bg, float rgb_padding, float density_bias,
+                                       float* rgb, float* depth, float* acc, float* weights, void* stream) {
+  if (R <= 0) return SNERF_OK;
+  if (S <= 0 || raw_density == nullptr || rgb == nullptr || depth == nullptr || acc == nullptr || weights == nullptr) return SNERF_ERR_ARG;
+  ZipComp a{};
+  a.raw_rgb = raw_rgb; a.ld_rgb = ld_rgb; a.raw_density = raw_density; a.ld_den = ld_den; a.tdist = tdist; a.dirs = dirs; a.R = R; a.S = S;
+  a.opaque = opaque; a.bg = bg; a.rgb_padding = rgb_padding; a.density_bias = density_bias; a.rgb = rgb; a.depth = depth; a.acc = acc; a.weights = weights;
+  hipLaunchKernelGGL(zip_composite_fwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+  return snerf_check_launch();
+}
+
+extern "C" int snerf_zip_composite_bwd(const float* raw_rgb, long ld_rgb, const float* raw_density, long ld_den, const float* tdist,
+                                       const float* dirs, long R, int S, int opaque, float bg, float rgb_padding, float density_bias,
+                                       const float* weights, const float* acc, const float* depth, const float* g_rgb, const float* g_depth,
+                                       const float* g_acc, const float* g_w, float* d_raw_rgb, long ld_drgb, float* d_raw_density,
+                                       long ld_dden, void* stream) {
+  if (R <= 0) return SNERF_OK;
+  if (S <= 0 || S > 64 * ZMAXSEG || raw_density == nullptr || weights == nullptr || acc == nullptr || d_raw_density == nullptr) return SNERF_ERR_ARG;
+  if ((raw_rgb != nullptr && d_raw_rgb == nullptr) || (g_depth != nullptr && depth == nullptr)) return SNERF_ERR_ARG;
+  ZipComp a{};
+  a.raw_rgb = raw_rgb; a.ld_rgb = ld_rgb; a.raw_density = raw_density; a.ld_den = ld_den; a.tdist = tdist; a.dirs = dirs; a.R = R; a.S = S;
+  a.opaque = opaque; a.bg = bg; a.rgb_padding = rgb_padding; a.density_bias = density_bias;
+  a.weights = (float*)weights; a.acc = (float*)acc; a.depth = (float*)depth;
+  a.g_rgb = g_rgb; a.g_depth = g_depth; a.g_acc = g_acc; a.g_w = g_w;
+  a.d_raw_rgb = d_raw_rgb; a.ld_drgb = ld_drgb; a.d_raw_density = d_raw_density; a.ld_dden = ld_dden;
+  hipLaunchKernelGGL(zip_composite_bwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+  return snerf_check_launch();
+}

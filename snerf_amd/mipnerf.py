@@ -104,8 +104,10 @@ class MipNerfModel(_ArenaModule):
                                                       self.rgb_padding, self.density_bias)
         ctx = None
         if keep:
-            ctx = dict(d=d, near=near, far=far, s0=s0, s1=s1, raw_d0=raw_d0, acts0=acts0, w0=w0, dist0=dist0, raw_rgb=raw_rgb,
-                       raw_d1=raw_d1, saved1=saved1, w1=w1, dist1=dist1, noise0=noise0, noise1=noise1, white=white_bg)
+            # detached aliases of the output tensors: the originals become outputs of the autograd Function
+            ctx = dict(d=d, near=near, far=far, s0=s0.detach(), s1=s1.detach(), raw_d0=raw_d0, acts0=acts0, w0=w0.detach(), dist0=dist0.detach(),
+                       raw_rgb=raw_rgb, raw_d1=raw_d1, saved1=saved1, w1=w1.detach(), dist1=dist1.detach(), noise0=noise0, noise1=noise1,
+                       white=white_bg)
         return (dist0, acc0, s0, w0, rgb1, dist1, acc1, s1, w1), ctx
 
     def _backward(self, ctx, g_dist0, g_acc0, g_w0, g_rgb1, g_dist1, g_acc1, g_w1):
@@ -176,6 +178,7 @@ class MipNerfModel(_ArenaModule):
 class _MipFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, rays, white_bg, s_rand, u, noise0, noise1, keep, *params):
+        ctx.set_materialize_grads(False)
         outs, c = model._run(rays, keep, white_bg, s_rand, u, noise0, noise1)
         ctx.model, ctx.c = model, c
         ctx.mark_non_differentiable(outs[2], outs[7])

@@ -445,3 +445,140 @@ class MipNerfNet(_Net):
                 dX = self.buf(M, H)
                 self.dgrad(n, dZ, H, dX, H, mask=xin, colsum=self.gB(f"layers.{i - 1}.layers.0"))
                 dZ = dX
+
+
+# =============================================================================
+# zipnerf path (path C): small MLPs behind the fused multisample hash-grid featurisation
+# =============================================================================
+class ZipPropNet(_Net):
+    """PropMLP on the waymo.gin branch (internal/models.py:425-427, 481-519 with disable_rgb): features [P, L*C (+pad)]
+    -> Linear 64 + ReLU -> Linear 1 = raw density [P,1] fp32."""
+
+    def __init__(self, arena, prefix, dt, feat_dim, hidden=64, variant=1):
+        super().__init__(arena, prefix, dt, variant)
+        assert hidden % self.g == 0
+        self.fd, self.H, self.Fw = feat_dim, hidden, roundup(feat_dim, self.g)
+
+    @staticmethod
+    def param_shapes(feat_dim, hidden=64):
+        return [("density_layer.0.weight", (hidden, feat_dim)), ("density_layer.0.bias", (hidden,)),
+                ("density_layer.2.weight", (1, hidden)), ("density_layer.2.bias", (1,))]
+
+    def pack(self, train):
+        self._pack_fwd("d0", "density_layer.0", [(0, 0, self.fd)], self.Fw)
+        self._pack_fwd("d2", "density_layer.2", [(0, 0, self.H)], self.H)
+        if train:
+            self._pack_dgrad("d2", ["density_layer.2"], 0, self.H)
+            self._pack_dgrad("d0", ["density_layer.0"], 0, self.fd)
+
+    def forward(self, Fb, keep):
+        self.ensure_packed(keep)
+        M = Fb.shape[0]
+        H1 = self.buf(M, self.H)
+        self.fwd("d0", Fb, self.Fw, H1, self.H)
+        raw = self.buf(M, 1, f32=True)
+        self.fwd("d2", H1, self.H, raw, 1, ACT_NONE, out_f32=True)
+        return raw, ((Fb, H1) if keep else None)
+
+    def backward(self, d_raw, saved):
+        """-> dF [P, Fw] (gradient w.r.t. the grid features, compute dtype)"""
+        Fb, H1 = saved
+        M = d_raw.shape[0]
+        ops.colsum_f32(d_raw, 1, self.gB("density_layer.2"))
+        dz = self.head_grad(d_raw, 1)
+        self.wgrad("density_layer.2", dz, H1, 1, self.H)
+        dH1 = self.buf(M, self.H)
+        self.dgrad("d2", dz, dz.shape[1], dH1, self.H, mask=H1, colsum=self.gB("density_layer.0"))
+        self.wgrad("density_layer.0", dH1, Fb, self.H, self.fd)
+        dF = self.buf(M, self.Fw)
+        self.dgrad("d0", dH1, self.H, dF, self.Fw)
+        return dF
+
+
+class ZipNerfNet(_Net):
+    """NerfMLP on the waymo.gin branch (internal/models.py:425-427, 462-479, 481-519, 586-703; deg_view = 1, no GLO):
+    features 40 -> 64 ReLU -> 256 (x: channel 0 = raw density, all 256 = bottleneck); [x | dir_enc 9] -> 256 ReLU,
+    cat([., x, dir_enc]) (skip_layer_dir = 0) -> 256 ReLU -> rgb 3.
+    Buffer SB [P, 256 + 256 + Dw] = [lin0 output | x | dir_enc (+pad)]: lin0 reads columns 256.. in place, lin1 the whole row."""
+
+    def __init__(self, arena, prefix, dt, feat_dim=40, hidden=64, bottleneck=256, width=256, dir_dim=9, variant=1):
+        super().__init__(arena, prefix, dt, variant)
+        assert hidden % self.g == 0 and bottleneck % self.g == 0 and width % self.g == 0
+        self.fd, self.H, self.Bw, self.Wd, self.dd = feat_dim, hidden, bottleneck, width, dir_dim
+        self.Fw, self.Dw = roundup(feat_dim, self.g), roundup(dir_dim, self.g)
+
+    @staticmethod
+    def param_shapes(feat_dim=40, hidden=64, bottleneck=256, width=256, dir_dim=9):
+        return [("density_layer.0.weight", (hidden, feat_dim)), ("density_layer.0.bias", (hidden,)),
+                ("density_layer.2.weight", (bottleneck, hidden)), ("density_layer.2.bias", (bottleneck,)),
+                ("lin_second_stage_0.weight", (width, bottleneck + dir_dim)), ("lin_second_stage_0.bias", (width,)),
+                ("lin_second_stage_1.weight", (width, width + bottleneck + dir_dim)), ("lin_second_stage_1.bias", (width,)),
+                ("rgb_layer.weight", (3, width)), ("rgb_layer.bias", (3,))]
+
+    def pack(self, train):
+        B, Wd, dd = self.Bw, self.Wd, self.dd
+        self._pack_fwd("d0", "density_layer.0", [(0, 0, self.fd)], self.Fw)
+        self._pack_fwd("d2", "density_layer.2", [(0, 0, self.H)], self.H)
+        # fp32 density head = row 0 of the second density layer (raw_density = x[..., 0], models.py:511)
+        w2, b2 = self.W("density_layer.2"), self.B("density_layer.2")
+        hw = torch.zeros(128, self.H, dtype=self.tdt, device=self.dev); hw[0] = w2[0]
+        hb = torch.zeros(128, dtype=torch.float32, device=self.dev); hb[0] = b2[0]
+        self.fw["dhead"], self.fb["dhead"] = hw, hb
+        self._pack_fwd("lin0", "lin_second_stage_0", [(0, 0, B + dd)], B + self.Dw)
+        self._pack_fwd("lin1", "lin_second_stage_1", [(0, 0, Wd + B + dd)], Wd + B + self.Dw)
+        self._pack_fwd("rgb", "rgb_layer", [(0, 0, Wd)], Wd)
+        if train:
+            self._pack_dgrad("rgb", ["rgb_layer"], 0, Wd)
+            self._pack_dgrad("lin1a", ["lin_second_stage_1"], 0, Wd)          # columns that multiply lin0's output
+            self._pack_dgrad("d2", ["density_layer.2"], 0, self.H)
+            self._pack_dgrad("d0", ["density_layer.0"], 0, self.fd)
+            # d x = [dZ_lin0 | dZ_lin1 | d raw_density] . [W0[:, x]; W1[:, x]; e_0]
+            g = self.g
+            W0, W1 = self.W("lin_second_stage_0"), self.W("lin_second_stage_1")
+            out = torch.zeros(roundup(B, 128), 2 * Wd + g, dtype=self.tdt, device=self.dev)
+            out[:B, :Wd] = W0[:, :B].t()
+            out[:B, Wd:2 * Wd] = W1[:, Wd:Wd + B].t()
+            out[0, 2 * Wd] = 1.0
+            self.tw["xcat"] = out
+
+    def alloc(self, M):
+        """-> (F, SB): the featurisation kernel writes F[:, :feat_dim] (F arrives zeroed), the view encoder SB[:, Wd+B:]."""
+        return torch.zeros(M, self.Fw, dtype=self.tdt, device=self.dev), self.buf(M, self.Wd + self.Bw + self.Dw)
+
+    def forward(self, Fb, SB, keep):
+        self.ensure_packed(keep)
+        M, B, Wd = Fb.shape[0], self.Bw, self.Wd
+        H1 = self.buf(M, self.H)
+        self.fwd("d0", Fb, self.Fw, H1, self.H)
+        self.fwd("d2", H1, self.H, SB[:, Wd:Wd + B], B, ACT_NONE)
+        raw_d = self.buf(M, 1, f32=True)
+        self.fwd("dhead", H1, self.H, raw_d, 1, ACT_NONE, out_f32=True)
+        self.fwd("lin0", SB[:, Wd:], B + self.Dw, SB[:, :Wd], Wd)
+        H3 = self.buf(M, Wd)
+        self.fwd("lin1", SB, Wd + B + self.Dw, H3, Wd)
+        raw_rgb = self.buf(M, 3, f32=True)
+        self.fwd("rgb", H3, Wd, raw_rgb, 3, ACT_NONE, out_f32=True)
+        return raw_rgb, raw_d, ((Fb, H1, SB, H3) if keep else None)
+
+    def backward(self, d_raw_rgb, d_raw_density, saved):
+        """-> dF [P, Fw]"""
+        Fb, H1, SB, H3 = saved
+        M, B, Wd, g = d_raw_rgb.shape[0], self.Bw, self.Wd, self.g
+        ops.colsum_f32(d_raw_rgb, 3, self.gB("rgb_layer"))
+        dz = self.head_grad(d_raw_rgb, 3)
+        self.wgrad("rgb_layer", dz, H3, 3, Wd)
+        DZ = self.buf(M, 2 * Wd + g)                                         # [dZ_lin0 | dZ_lin1 | d raw_density (+pad)]
+        self.dgrad("rgb", dz, dz.shape[1], DZ[:, Wd:2 * Wd], Wd, mask=H3, colsum=self.gB("lin_second_stage_1"))
+        self.wgrad("lin_second_stage_1", DZ[:, Wd:2 * Wd], SB, Wd, Wd + B + self.dd)
+        self.dgrad("lin1a", DZ[:, Wd:2 * Wd], Wd, DZ[:, :Wd], Wd, mask=SB[:, :Wd], colsum=self.gB("lin_second_stage_0"))
+        self.wgrad("lin_second_stage_0", DZ[:, :Wd], SB[:, Wd:], Wd, B + self.dd)
+        ops.cast_pad(d_raw_density, 1, DZ[:, 2 * Wd:], g, self.dt)
+        dx = self.buf(M, B)
+        self.dgrad("xcat", DZ, 2 * Wd + g, dx, B, colsum=self.gB("density_layer.2"))
+        self.wgrad("density_layer.2", dx, H1, B, self.H)
+        dH1 = self.buf(M, self.H)
+        self.dgrad("d2", dx, B, dH1, self.H, mask=H1, colsum=self.gB("density_layer.0"))
+        self.wgrad("density_layer.0", dH1, Fb, self.H, self.fd)
+        dF = self.buf(M, self.Fw)
+        self.dgrad("d0", dH1, self.H, dF, self.Fw)
+        return dF

@@ -291,3 +291,62 @@ def grid_tv_grad(inputs, embeddings, grad, offsets, weight, L, S, H, gridtype, a
     dt = F32 if embeddings.dtype == torch.float32 else F16
     _lib.call("snerf_grid_tv_grad", _p(inputs), _p(embeddings), _p(grad), _p(offsets), float(weight), B, D, embeddings.shape[1], L,
               float(S), int(H), int(gridtype), 1 if align_corners else 0, dt, _stream())
+
+
+# ------------------------------------------------------------ zipnerf path ----
+def zip_resample(sdist, weights, u, n, near, far, dilation, dilate, anneal, resample_padding=0.0, lam=-1.5, dom=(0.0, 1.0)):
+    _f32c(sdist); _f32c(weights); _f32c(near); _f32c(far)
+    R, P0 = sdist.shape
+    u, us = _u_arg(u, R, n)
+    so = torch.empty(R, n + 1, dtype=torch.float32, device=sdist.device)
+    to = torch.empty_like(so)
+    _lib.call("snerf_zip_resample", _p(sdist), _p(weights), P0 - 1, _p(u), us, n, _p(near), _p(far), R, float(dilation), 1 if dilate else 0,
+              float(anneal), float(resample_padding), float(lam), float(dom[0]), float(dom[1]), _p(so), _p(to), _stream())
+    return so, to
+
+
+def _zip_dt(t):
+    return {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}[t.dtype]
+
+
+def zip_encode_fwd(tdist, origins, directions, radii, base_x, base_y, deg_jitter, table, offsets, grid_sizes, feat, L, C, n, m, Sl, H, std_scale):
+    for t in (tdist, origins, directions, radii, base_x, base_y, deg_jitter):
+        _f32c(t)
+    R, P = tdist.shape
+    assert table.is_contiguous() and offsets.dtype == torch.int32 and grid_sizes.dtype == torch.int32
+    _lib.call("snerf_zip_encode_fwd", _p(tdist), _p(origins), _p(directions), _p(radii), _p(base_x), _p(base_y), _p(deg_jitter), _p(table),
+              _p(offsets), _p(grid_sizes), _p(feat), feat.stride(0), R, P - 1, L, C, n, m, float(Sl), int(H), float(std_scale), _zip_dt(table),
+              _zip_dt(feat), _stream())
+
+
+def zip_encode_bwd(tdist, origins, directions, radii, base_x, base_y, deg_jitter, offsets, grid_sizes, grad_feat, grad_table, L, C, n, m, Sl, H,
+                   std_scale):
+    R, P = tdist.shape
+    assert grad_table.dtype == torch.float32 and grad_table.is_contiguous()
+    _lib.call("snerf_zip_encode_bwd", _p(tdist), _p(origins), _p(directions), _p(radii), _p(base_x), _p(base_y), _p(deg_jitter), _p(offsets),
+              _p(grid_sizes), _p(grad_feat), grad_feat.stride(0), _p(grad_table), R, P - 1, L, C, n, m, float(Sl), int(H), float(std_scale),
+              _zip_dt(grad_feat), _stream())
+
+
+def zip_composite_fwd(raw_rgb, raw_density, tdist, dirs, opaque, bg, rgb_padding, density_bias):
+    _f32c(tdist); _f32c(dirs)
+    R, P = tdist.shape
+    dev = tdist.device
+    rgb = torch.empty(R, 3, dtype=torch.float32, device=dev)
+    depth, acc = torch.empty(R, dtype=torch.float32, device=dev), torch.empty(R, dtype=torch.float32, device=dev)
+    w = torch.empty(R, P - 1, dtype=torch.float32, device=dev)
+    _lib.call("snerf_zip_composite_fwd", _p(raw_rgb), 0 if raw_rgb is None else raw_rgb.stride(0), _p(raw_density), raw_density.stride(0),
+              _p(tdist), _p(dirs), R, P - 1, 1 if opaque else 0, float(bg), float(rgb_padding), float(density_bias), _p(rgb), _p(depth), _p(acc),
+              _p(w), _stream())
+    return rgb, depth, acc, w
+
+
+def zip_composite_bwd(raw_rgb, raw_density, tdist, dirs, opaque, bg, rgb_padding, density_bias, weights, acc, depth, g_rgb, g_depth, g_acc, g_w,
+                      d_raw_rgb, d_raw_density):
+    R, P = tdist.shape
+    for t in (g_rgb, g_depth, g_acc, g_w, weights, acc, depth):
+        _f32c(t)
+    _lib.call("snerf_zip_composite_bwd", _p(raw_rgb), 0 if raw_rgb is None else raw_rgb.stride(0), _p(raw_density), raw_density.stride(0),
+              _p(tdist), _p(dirs), R, P - 1, 1 if opaque else 0, float(bg), float(rgb_padding), float(density_bias), _p(weights), _p(acc),
+              _p(depth), _p(g_rgb), _p(g_depth), _p(g_acc), _p(g_w), _p(d_raw_rgb), 0 if d_raw_rgb is None else d_raw_rgb.stride(0),
+              _p(d_raw_density), d_raw_density.stride(0), _stream())

@@ -1,0 +1,273 @@
+"""Drop-in zipnerf ``Model`` (S-NeRF++ background, path C) backed by libsnerf_hip.so.
+
+Mirrors s-nerfpp/zipnerf/internal/models.py: ``Model`` (:28-349) with the same class attributes, the same
+``forward(rand, batch, train_frac, compute_extras, zero_glo, sample_n, sample_m, step, max_step, cal_input_grad)``
+signature, the same ``(renderings, ray_history)`` return layout (keys ``rgb``/``depth``/``acc`` and
+``sdist``/``weights``/``tdist``/``density``/``rgb``) and the same ``state_dict`` keys / shapes (``nerf_mlp.encoder.embeddings``,
+``nerf_mlp.density_layer.0.weight``, ``nerf_mlp.lin_second_stage_1.weight``, ``prop_mlp_0.encoder.offsets`` ...).
+
+Accelerated branch = what ``configs/waymo.gin`` + class defaults run: ``raydist_fn='power_transformation'``, distinct proposal
+MLPs with C = 1 grids (desired resolution 512 / 2048), NeRF grid C = 4 (8192), ``disable_density_normals``, ``deg_view = 1``,
+no GLO / exposure / semantic head, ``single_jitter``.  Everything else raises NotImplementedError (no eager fallback).
+
+Per level: ONE resample launch (dilation + annealed logits + inverse-CDF intervals + s->t warp), ONE fused featurisation launch
+(7-multisample cone casting + contraction + hash-grid gather + erf down-weighting + mean, written into the MLP operand buffer),
+the small MLPs on the MFMA GEMMs, ONE compositing launch.  The reference's ``[R,S,7,3]`` means, ``[R*S*7, L*C]`` features and
+the ``[R,3S+2,S]`` / ``[R,S+1,n]`` sampling masks never exist.
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from . import ops
+from .classic import _ArenaModule, _dt
+from .mlp import ZipNerfNet, ZipPropNet
+
+EPS32 = float(torch.finfo(torch.float32).eps)
+
+
+def _level_layout(num_levels, base_resolution, desired_resolution, log2_hashmap_size):
+    """gridencoder/grid.py:104-141 (input_dim 3, align_corners False)"""
+    scale = np.exp2(np.log2(desired_resolution / base_resolution) / (num_levels - 1))
+    offsets, res, off = [], [], 0
+    for i in range(num_levels):
+        r = int(np.ceil(base_resolution * scale ** i)) + 1
+        n = int(np.ceil(min(2 ** log2_hashmap_size, r ** 3) / 8) * 8)
+        res.append(r); offsets.append(off); off += n
+    offsets.append(off)
+    return np.array(offsets, dtype=np.int32), np.array(res, dtype=np.int32), float(scale)
+
+
+class _Encoder:
+    def __init__(self, level_dim, desired_resolution, base_resolution=16, log2_hashmap_size=21, level_interval=2):
+        self.L = int(np.log(desired_resolution / base_resolution) / np.log(level_interval)) + 1      # models.py:413
+        self.C, self.H = level_dim, base_resolution
+        self.offsets, self.res, self.scale = _level_layout(self.L, base_resolution, desired_resolution, log2_hashmap_size)
+        self.Sl = float(np.log2(self.scale))
+        self.rows = int(self.offsets[-1])
+
+
+class Model(_ArenaModule):
+    num_prop_samples = (64, 64)
+    num_nerf_samples: int = 32
+    num_levels: int = 3
+    bg_intensity_range = (1., 1.)
+    anneal_slope: float = 10
+    stop_level_grad: bool = True
+    use_viewdirs: bool = True
+    raydist_fn = 'contract'
+    single_jitter: bool = True
+    dilation_multiplier: float = 0.5
+    dilation_bias: float = 0.0025
+    num_glo_features: int = 0
+    near_anneal_rate = None
+    resample_padding: float = 0.0
+    opaque_background: bool = False
+    power_lambda: float = -1.5
+    std_scale: float = 0.35
+    prop_desired_grid_size = [512, 2048]
+    distinct_prop: bool = True
+    single_mlp: bool = False
+
+    def __init__(self, config=None, compute: str = "bf16", table_dtype: str = "f16", device="cuda", grid_log2_hashmap_size: int = 21,
+                 nerf_desired_resolution: int = 8192, init_std: float = 1e-4, **kwargs):
+        super().__init__()
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+        self.config = config
+        if self.raydist_fn != 'power_transformation':
+            raise NotImplementedError("accelerated zipnerf Model: raydist_fn='power_transformation' (configs/waymo.gin)")
+        if (self.num_levels != 3 or len(self.num_prop_samples) != 2 or self.num_glo_features or not self.distinct_prop or self.single_mlp
+                or self.near_anneal_rate is not None or not self.stop_level_grad or not self.use_viewdirs
+                or self.bg_intensity_range[0] != self.bg_intensity_range[1] or (config is not None and getattr(config, "use_semantic", False))):
+            raise NotImplementedError("accelerated zipnerf Model: 2 distinct proposal MLPs + NeRF MLP, no GLO/semantic/near annealing")
+        dev = torch.device(device)
+        self.encs = [_Encoder(1, self.prop_desired_grid_size[0], 16, grid_log2_hashmap_size),
+                     _Encoder(1, self.prop_desired_grid_size[1], 16, grid_log2_hashmap_size),
+                     _Encoder(4, nerf_desired_resolution, 16, grid_log2_hashmap_size)]
+        self.names = ["prop_mlp_0.", "prop_mlp_1.", "nerf_mlp."]
+        shapes = [("nerf_mlp.encoder.embeddings", (self.encs[2].rows, 4))]
+        shapes += [("nerf_mlp." + n, s) for n, s in ZipNerfNet.param_shapes(self.encs[2].L * 4)]
+        for i in range(2):
+            shapes += [(f"prop_mlp_{i}.encoder.embeddings", (self.encs[i].rows, 1))]
+            shapes += [(f"prop_mlp_{i}." + n, s) for n, s in ZipPropNet.param_shapes(self.encs[i].L)]
+        self._setup_arena(shapes, dev)
+        self.dt = _dt(compute)
+        self.compute = compute
+        self.table_half = {"f16": True, "fp16": True, "f32": False, "fp32": False}[table_dtype]
+        self.nets = [ZipPropNet(self.arena, "prop_mlp_0.", self.dt, self.encs[0].L), ZipPropNet(self.arena, "prop_mlp_1.", self.dt, self.encs[1].L),
+                     ZipNerfNet(self.arena, "nerf_mlp.", self.dt, self.encs[2].L * 4)]
+        for n in self.nets:
+            n.version_fn = self._param_version
+        self._tables, self._tables_version = [None] * 3, -1
+        self.dev_offsets, self.dev_sizes = [], []
+        for i, pre in enumerate(self.names):
+            e = self.encs[i]
+            enc_mod = self._modules[pre[:-1]]._modules["encoder"]
+            off = torch.from_numpy(e.offsets).to(dev)
+            enc_mod.register_buffer("offsets", off)
+            idx = torch.empty(e.rows, dtype=torch.long, device=dev)
+            for l in range(e.L):
+                idx[e.offsets[l]:e.offsets[l + 1]] = l
+            enc_mod.register_buffer("idx", idx)
+            enc_mod.register_buffer("grid_sizes", torch.from_numpy(e.res).to(dev))
+            self.dev_offsets.append(off); self.dev_sizes.append(enc_mod.grid_sizes)
+        with torch.no_grad():
+            for n in self.arena.names:
+                p = self.arena.p[n]
+                if n.endswith("embeddings"):
+                    p.uniform_(-init_std, init_std)                                  # grid.py:151-153
+                elif n.endswith(".weight"):
+                    if "lin_second_stage" in n:
+                        nn.init.kaiming_uniform_(p)                                  # models.py:464
+                    else:
+                        nn.init.kaiming_uniform_(p if p.dim() == 2 else p.view(1, -1), a=5 ** 0.5)
+                else:
+                    fan_in = self.arena.p[n[:-4] + "weight"].shape[-1]
+                    nn.init.uniform_(p, -1.0 / fan_in ** 0.5, 1.0 / fan_in ** 0.5)
+
+    # --------------------------------------------------------------------------------------------------------------
+    def _table(self, lvl):
+        """the gather table: fp16 copy of the fp32 master embeddings (like the reference under autocast, grid.py:41-44; C = 1
+        tables stay fp32 there -- here every table may be halved, the gradient always accumulates in fp32)"""
+        v = self._param_version()
+        if v != self._tables_version:
+            self._tables, self._tables_version = [None] * 3, v
+        if self._tables[lvl] is None:
+            emb = self.arena.p[self.names[lvl] + "encoder.embeddings"]
+            self._tables[lvl] = emb.detach().half().contiguous() if self.table_half else emb.detach()
+        return self._tables[lvl]
+
+    def _anneal(self, train_frac):
+        if self.anneal_slope > 0:
+            return (self.anneal_slope * train_frac) / ((self.anneal_slope - 1) * train_frac + 1)   # Schlick bias, models.py:191-194
+        return 1.0
+
+    def _run(self, batch, keep, train_frac, draws, sample_n, sample_m):
+        dev = self.arena.flat.device
+        f = lambda t: t.detach().to(dev, torch.float32).contiguous()
+        o, d, vd = f(batch['origins']), f(batch['directions']), f(batch['viewdirs'])
+        bx, by = f(batch['base_x']), f(batch['base_y'])
+        radii, near, far = f(batch['radii']).reshape(-1), f(batch['near']).reshape(-1), f(batch['far']).reshape(-1)
+        R = o.shape[0]
+        sdist = torch.cat([torch.zeros(R, 1, device=dev), torch.ones(R, 1, device=dev)], -1)
+        weights = torch.ones(R, 1, device=dev)
+        anneal = self._anneal(train_frac)
+        bg = float(self.bg_intensity_range[0])
+        prod = 1
+        levels = []
+        for lvl in range(3):
+            is_prop = lvl < 2
+            ns = self.num_prop_samples[lvl] if is_prop else self.num_nerf_samples
+            dilation = self.dilation_bias + self.dilation_multiplier * 1.0 / prod
+            prod *= ns
+            use_dilation = (self.dilation_bias > 0 or self.dilation_multiplier > 0) and lvl > 0
+            u, degj = draws[lvl]
+            sdist, tdist = ops.zip_resample(sdist, weights.detach(), u, ns, near, far, dilation, use_dilation, anneal, self.resample_padding,
+                                            self.power_lambda)
+            e, net = self.encs[lvl], self.nets[lvl]
+            P = R * ns
+            if is_prop:
+                Fb = torch.zeros(P, net.Fw, dtype=net.tdt, device=dev); SB = None
+            else:
+                Fb, SB = net.alloc(P)
+            ops.zip_encode_fwd(tdist, o, d, radii, bx, by, degj, self._table(lvl), self.dev_offsets[lvl], self.dev_sizes[lvl], Fb, e.L, e.C,
+                               sample_n, sample_m, e.Sl, e.H, self.std_scale)
+            if is_prop:
+                raw_d, saved = net.forward(Fb, keep)
+                raw_rgb = None
+            else:
+                ops.mip_viewenc(vd, ns, 1, SB[:, net.Wd + net.Bw:], net.Dw, self.dt)
+                raw_rgb, raw_d, saved = net.forward(Fb, SB, keep)
+            rgb, depth, acc, weights = ops.zip_composite_fwd(raw_rgb, raw_d, tdist, d, self.opaque_background, bg, 0.001, -1.0)
+            levels.append(dict(sdist=sdist, tdist=tdist, weights=weights, rgb=rgb, depth=depth, acc=acc, raw_rgb=raw_rgb, raw_d=raw_d, saved=saved,
+                               degj=degj, ns=ns))
+        ctx = None
+        if keep:   # detached aliases: the originals become outputs of the autograd Function (no graph / reference cycle through ctx)
+            det = [{k: (v.detach() if torch.is_tensor(v) else v) for k, v in L.items()} for L in levels]
+            ctx = dict(o=o, d=d, radii=radii, bx=bx, by=by, levels=det, bg=bg, n=sample_n, m=sample_m)
+        return levels, ctx
+
+    def _backward(self, ctx, grads):
+        """grads[lvl] = (g_rgb, g_depth, g_acc, g_w); accumulates parameter gradients into the arena."""
+        dev = ctx["o"].device
+        cc = lambda t: None if t is None else t.contiguous().float()
+        for lvl in (2, 1, 0):
+            g_rgb, g_depth, g_acc, g_w = grads[lvl]
+            if all(t is None for t in (g_rgb, g_depth, g_acc, g_w)):
+                continue
+            L = ctx["levels"][lvl]
+            e, net = self.encs[lvl], self.nets[lvl]
+            P = L["weights"].numel()
+            d_den = torch.empty(P, 1, dtype=torch.float32, device=dev)
+            d_rgb = torch.empty(P, 3, dtype=torch.float32, device=dev) if L["raw_rgb"] is not None else None
+            ops.zip_composite_bwd(L["raw_rgb"], L["raw_d"], L["tdist"], ctx["d"], self.opaque_background, ctx["bg"], 0.001, -1.0, L["weights"],
+                                  L["acc"], L["depth"], cc(g_rgb), cc(g_depth), cc(g_acc), cc(g_w), d_rgb, d_den)
+            dF = net.backward(d_den, L["saved"]) if lvl < 2 else net.backward(d_rgb, d_den, L["saved"])
+            ops.zip_encode_bwd(L["tdist"], ctx["o"], ctx["d"], ctx["radii"], ctx["bx"], ctx["by"], L["degj"], self.dev_offsets[lvl],
+                               self.dev_sizes[lvl], dF, self.arena.g[self.names[lvl] + "encoder.embeddings"], e.L, e.C, ctx["n"], ctx["m"], e.Sl,
+                               e.H, self.std_scale)
+
+    def _draws(self, R, rand, dev, sample_n):
+        """the reference's RNG draws in its order: per level one single-jitter draw (stepfun.py:216) then the helix phase
+        jitter (render.py:152)"""
+        out = []
+        for lvl in range(3):
+            ns = self.num_prop_samples[lvl] if lvl < 2 else self.num_nerf_samples
+            if not rand:
+                pad = 1 / (2 * ns)
+                out.append((torch.linspace(pad, 1. - pad - EPS32, ns).to(dev), None))
+            else:
+                u_max = EPS32 + (1 - EPS32) / ns
+                max_jitter = (1 - u_max) / (ns - 1) - EPS32
+                jit = torch.rand(R, 1 if self.single_jitter else ns, device=dev)
+                u = (torch.linspace(0, 1 - u_max, ns).to(dev) + jit * max_jitter).contiguous()
+                out.append((u, torch.rand(R, ns, sample_n, device=dev)))
+        return out
+
+    def forward(self, rand, batch, train_frac, compute_extras, zero_glo=True, sample_n=7, sample_m=3, step=0, max_step=25000,
+                cal_input_grad=False, draws=None):
+        """-> (renderings, ray_history) like models.py:98-349.  `draws` = [(u, deg_jitter)] * 3 overrides the RNG (parity tests)."""
+        if cal_input_grad:
+            raise NotImplementedError("pose refinement through the hash grid (cal_input_grad) is not on the accelerated path")
+        if compute_extras:
+            raise NotImplementedError("compute_extras (distance percentiles, visualisation rays) is not on the accelerated path")
+        self._check_arena()
+        dev = self.arena.flat.device
+        R = batch['origins'].shape[0]
+        if draws is None:
+            draws = self._draws(R, rand, dev, sample_n)
+        params = self.param_list()
+        keep = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        outs = _ZipFn.apply(self, batch, keep, float(train_frac), draws, sample_n, sample_m, *params)
+        renderings, history = [], []
+        for lvl in range(3):
+            rgb, depth, acc, w, sd, td = outs[6 * lvl:6 * lvl + 6]
+            renderings.append(dict(rgb=rgb, depth=depth, acc=acc))
+            history.append(dict(sdist=sd, weights=w, tdist=td))
+        return renderings, history
+
+
+class _ZipFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, batch, keep, train_frac, draws, sample_n, sample_m, *params):
+        ctx.set_materialize_grads(False)
+        levels, c = model._run(batch, keep, train_frac, draws, sample_n, sample_m)
+        ctx.model, ctx.c = model, c
+        outs, nondiff = [], []
+        for L in levels:
+            outs += [L["rgb"], L["depth"], L["acc"], L["weights"], L["sdist"], L["tdist"]]
+            nondiff += [L["sdist"], L["tdist"]]
+        ctx.mark_non_differentiable(*nondiff)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *g):
+        if ctx.c is None:
+            raise RuntimeError("zipnerf Model.forward ran without saved activations")
+        m = ctx.model
+        m.arena.grad.zero_()
+        grads = [(g[6 * l], g[6 * l + 1], g[6 * l + 2], g[6 * l + 3]) for l in range(3)]
+        m._backward(ctx.c, grads)
+        ctx.c = None
+        return (None,) * 7 + tuple(m.arena.g[n].clone() for n in m._pnames)

@@ -146,7 +146,75 @@ def cast_pad(src, C, dst, Cpad, dt):
     dst[:, :C] = src[:, :C].to(dst.dtype)
 
 
-_NAMES = ["linear_fwd", "linear_wgrad", "classic_embed", "mip_encode", "mip_viewenc", "classic_sample_pdf", "classic_points",
+# ---------------------------------------------------------------- zipnerf path ----
+def zip_resample(sdist, weights, u, n, near, far, dilation, dilate, anneal, resample_padding=0.0, lam=-1.5, dom=(0.0, 1.0)):
+    from oracle import zip as oz
+    t, w = sdist, weights
+    if dilate:
+        t, w = oz.max_dilate_weights(t, w, dilation, dom)
+        t, w = t[..., 1:-1], w[..., 1:-1]
+    logits = oz.resample_logits(t, w, anneal, resample_padding)
+    sd, _ = oz.sample_intervals(t, logits, u, dom)
+    return sd.contiguous(), oz.s_to_t(sd, near[:, None], far[:, None], lam).contiguous()
+
+
+def _zip_points(tdist, origins, directions, radii, base_x, base_y, deg_jitter, n, m, std_scale):
+    from oracle import zip as oz
+    means, stds = oz.cast_rays(tdist, origins, directions, radii[:, None], base_x, base_y, deg_jitter, n, m, std_scale)
+    pre = means.shape[:-1]
+    z, s = oz.contract_mean_std(means.reshape(-1, 3), stds.reshape(-1))
+    return (z.reshape(*pre, 3) / 2 + 1) / 2, s.reshape(*pre) / 2
+
+
+def zip_encode_fwd(tdist, origins, directions, radii, base_x, base_y, deg_jitter, table, offsets, grid_sizes, feat, L, C, n, m, Sl, H, std_scale):
+    from oracle import grid as og
+    x01, s = _zip_points(tdist, origins, directions, radii, base_x, base_y, deg_jitter, n, m, std_scale)
+    out = og.grid_encode_forward(x01.reshape(-1, 3).numpy().astype("float32"), table.float().numpy(), offsets.numpy(), Sl, H, 0, False, 0)
+    f = torch.from_numpy(out).permute(1, 0, 2).reshape(list(x01.shape[:-1]) + [L, C])
+    w = torch.erf(1 / torch.sqrt(8 * s[..., None] ** 2 * grid_sizes.float() ** 2))
+    f = (f * w[..., None]).mean(dim=-3).flatten(-2, -1)
+    feat[:, :L * C] = f.reshape(-1, L * C).to(feat.dtype)
+
+
+def zip_encode_bwd(tdist, origins, directions, radii, base_x, base_y, deg_jitter, offsets, grid_sizes, grad_feat, grad_table, L, C, n, m, Sl, H,
+                   std_scale):
+    from oracle import grid as og
+    x01, s = _zip_points(tdist, origins, directions, radii, base_x, base_y, deg_jitter, n, m, std_scale)
+    w = torch.erf(1 / torch.sqrt(8 * s[..., None] ** 2 * grid_sizes.float() ** 2))             # [R,S,n,L]
+    g = grad_feat[:, :L * C].float().reshape(list(x01.shape[:-2]) + [1, L, C]) * w[..., None] / n  # [R,S,n,L,C]
+    G = g.reshape(-1, L, C).permute(1, 0, 2).contiguous().numpy()
+    gE, _ = og.grid_encode_backward(G, x01.reshape(-1, 3).numpy().astype("float32"), offsets.numpy(), grad_table.shape[0], Sl, H, 0, False, 0)
+    grad_table += torch.from_numpy(gE)
+
+
+def zip_composite_fwd(raw_rgb, raw_density, tdist, dirs, opaque, bg, rgb_padding, density_bias):
+    from oracle import zip as oz
+    R, P = tdist.shape
+    dens = torch.nn.functional.softplus(raw_density.reshape(R, P - 1) + density_bias)
+    w = oz.compute_alpha_weights(dens, tdist, dirs, opaque)
+    rgbs = torch.zeros(R, P - 1, 3) if raw_rgb is None else torch.sigmoid(raw_rgb.reshape(R, P - 1, 3)) * (1 + 2 * rgb_padding) - rgb_padding
+    r = oz.volumetric_rendering(rgbs, w, tdist, bg)
+    return r["rgb"], r["depth"], r["acc"], w
+
+
+def zip_composite_bwd(raw_rgb, raw_density, tdist, dirs, opaque, bg, rgb_padding, density_bias, weights, acc, depth, g_rgb, g_depth, g_acc, g_w,
+                      d_raw_rgb, d_raw_density):
+    with torch.enable_grad():
+        rr = None if raw_rgb is None else raw_rgb.detach().clone().requires_grad_(True)
+        rd = raw_density.detach().clone().requires_grad_(True)
+        outs = zip_composite_fwd(rr, rd, tdist, dirs, opaque, bg, rgb_padding, density_bias)
+        loss = 0
+        for o, g in zip(outs, (g_rgb, g_depth, g_acc, g_w)):
+            if g is not None:
+                loss = loss + (o * g).sum()
+        loss.backward()
+    d_raw_density.copy_(rd.grad)
+    if rr is not None:
+        d_raw_rgb.copy_(rr.grad if rr.grad is not None else torch.zeros_like(rr))
+
+
+_NAMES = ["zip_resample", "zip_encode_fwd", "zip_encode_bwd", "zip_composite_fwd", "zip_composite_bwd",
+          "linear_fwd", "linear_wgrad", "classic_embed", "mip_encode", "mip_viewenc", "classic_sample_pdf", "classic_points",
           "classic_merge_sort", "mip_resample", "stratified", "mip_composite_fwd", "mip_composite_bwd", "classic_composite_fwd",
           "classic_composite_bwd", "adam_step", "colsum_f32", "cast_pad"]
 

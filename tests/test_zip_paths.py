@@ -1,0 +1,141 @@
+"""zipnerf Model (path C) end to end: the drop-in module vs the reference's own Model.forward outputs (golden G11, captured
+with the oracle grid encoder injected) and vs the oracle, forward and backward.  "hip" = real kernels, "emulated" = host logic."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from cpu_ops_emulation import emulate_ops
+from oracle import zip as oz
+
+DEV = "cuda"
+
+
+@pytest.fixture(params=[pytest.param("hip", marks=pytest.mark.gpu), "emulated"])
+def backend(request):
+    global DEV
+    if request.param == "hip":
+        DEV = "cuda"
+        yield "hip"
+    else:
+        DEV = "cpu"
+        with emulate_ops():
+            yield "emulated"
+    DEV = "cuda"
+
+
+def close(a, b, rtol, atol, what=""):
+    a = a.detach().double().cpu(); b = b.detach().double().cpu()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = (a - b).abs(); tol = atol + rtol * b.abs()
+    bad = err > tol
+    assert not bool(bad.any()), f"{what}: {int(bad.sum())}/{bad.numel()} out of tol, max err {err.max().item():.3e}"
+
+
+def zip_setup():
+    spec = importlib.util.spec_from_file_location("gen_golden_zip", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "gen_golden_zip.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    specs = m.small_specs()
+    return specs, m.formula_params(oz.param_shapes(specs))
+
+
+def make_model(compute, table, p):
+    from snerf_amd import zipnerf
+    m = zipnerf.Model(config=None, raydist_fn='power_transformation', opaque_background=True, compute=compute, table_dtype=table, device=DEV,
+                      grid_log2_hashmap_size=14)
+    sd = m.state_dict()
+    for k, v in p.items():
+        assert k in sd and tuple(sd[k].shape) == tuple(v.shape), k
+    for k in ("nerf_mlp.encoder.offsets", "nerf_mlp.encoder.idx", "nerf_mlp.encoder.grid_sizes", "prop_mlp_1.encoder.offsets"):
+        assert k in sd
+    m.load_state_dict(p, strict=False)
+    return m
+
+
+@pytest.mark.parametrize("compute,table,tol", [("f32", "f32", 2e-4), ("bf16", "f16", 5e-2)])
+def test_zip_model_vs_reference_golden(backend, golden, compute, table, tol):
+    g = golden("g11_zip_model")
+    specs, p = zip_setup()
+    batch = {k[2:]: v.to(DEV) for k, v in g.items() if k.startswith("b_")}
+    m = make_model(compute, table, p)
+    with torch.no_grad():
+        rend, hist = m(None, batch, 1.0, False)
+    assert set(rend[-1]) >= {"rgb", "depth", "acc"} and set(hist[-1]) >= {"sdist", "weights", "tdist"}
+    close(hist[0]["sdist"], g["det_sdist0"], 1e-5, 1e-6, "sdist level 0 (no network upstream)")
+    if compute == "f32":
+        for lvl in range(3):
+            close(hist[lvl]["sdist"], g[f"det_sdist{lvl}"], tol, tol, f"sdist {lvl}")
+            close(hist[lvl]["weights"], g[f"det_weights{lvl}"], 10 * tol, tol, f"weights {lvl}")
+        close(rend[0]["depth"], g["det_depth0"], tol, tol, "depth level 0")
+    close(rend[-1]["rgb"], g["det_rgb"], tol, tol, "rgb"); close(rend[-1]["depth"], g["det_depth"], tol, 10 * tol, "depth")
+    if compute == "f32":
+        draws = [(oz.rand_u(ns, g[f"jitter{i}"]).to(DEV).contiguous(), g[f"deg_jitter{i}"].to(DEV).contiguous()) for i, ns in enumerate((64, 64, 32))]
+        with torch.no_grad():
+            rend, hist = m(True, batch, float(g["rand_train_frac"]), False, draws=draws)
+        for lvl in range(3):
+            close(hist[lvl]["sdist"], g[f"rand_sdist{lvl}"], tol, tol, f"rand sdist {lvl}")
+        close(rend[-1]["rgb"], g["rand_rgb"], tol, tol, "rand rgb"); close(rend[-1]["depth"], g["rand_depth"], tol, tol, "rand depth")
+
+
+def test_zip_model_backward_vs_oracle_autograd(backend):
+    """fp32 gradients of every parameter incl. the three hash tables vs torch autograd through the oracle (the oracle's grid
+    lookup is made differentiable with an explicit transpose-gather: features are linear in the table)."""
+    specs, p = zip_setup()
+    R = 12
+    g = torch.Generator().manual_seed(5)
+    d = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1)
+    rv = torch.randn(R, 3, generator=g)
+    bx = torch.nn.functional.normalize(torch.cross(d, rv, dim=-1), dim=-1)
+    batch = dict(origins=torch.randn(R, 3, generator=g) * 0.1, directions=d, viewdirs=d, radii=2e-3 + 2e-3 * torch.rand(R, 1, generator=g),
+                 near=torch.full((R, 1), 0.1), far=torch.full((R, 1), 10.0), base_x=bx, base_y=torch.nn.functional.normalize(torch.cross(d, bx, dim=-1), dim=-1))
+    target = torch.rand(R, 3, generator=g)
+    m = make_model("f32", "f32", p)
+    rend, hist = m(None, {k: v.to(DEV) for k, v in batch.items()}, 1.0, False)
+    wts = [h["weights"] for h in hist]
+    loss = ((rend[-1]["rgb"] - target.to(DEV)) ** 2).mean() + 0.1 * rend[-1]["depth"].mean() + 0.05 * sum((w ** 2).sum() for w in wts)
+    loss.backward()
+    # oracle: same forward with torch-differentiable table lookups
+    pr = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    import oracle.zip as ozm
+    orig = ozm.grid_features
+
+    def grid_features_diff(spec, emb, means):
+        from oracle import grid as og
+        x = ((means.reshape(-1, 3) + 1) / 2).detach().numpy().astype(np.float32)
+        B = x.shape[0]
+        outs = []
+        for l in range(spec.L):                         # features = sum_corners w * emb[row]: build rows/weights with the oracle's own index math
+            hs, scale, res = og._level_setup(l, spec.S, spec.H, spec.offsets)
+            pg, frac, _ = og._positions(x, scale, False, 0)
+            acc = 0
+            for idx in range(8):
+                w = np.ones(B, dtype=np.float32); pl = pg.copy()
+                for dd in range(3):
+                    if idx & (1 << dd):
+                        w = w * frac[:, dd]; pl[:, dd] = pg[:, dd] + 1
+                    else:
+                        w = w * (1 - frac[:, dd])
+                rows = og.grid_index(0, False, hs, res, pl) + int(spec.offsets[l])
+                acc = acc + torch.from_numpy(w)[:, None] * emb[torch.from_numpy(rows)]
+            outs.append(acc)
+        return torch.stack(outs, 1).reshape(list(means.shape[:-1]) + [spec.L, spec.C])
+    ozm.grid_features = grid_features_diff
+    try:
+        rend_o, hist_o = oz.model_forward(pr, specs, batch, train_frac=1.0)
+    finally:
+        ozm.grid_features = orig
+    loss_o = ((rend_o[-1]["rgb"] - target) ** 2).mean() + 0.1 * rend_o[-1]["depth"].mean() + 0.05 * sum((h["weights"] ** 2).sum() for h in hist_o)
+    loss_o.backward()
+    close(loss, loss_o, 1e-4, 1e-5, "loss")
+    named = dict(m.named_parameters())
+    bad = []
+    for k in p:
+        gref = pr[k].grad
+        assert gref is not None, k
+        got = named[k].grad.detach().cpu()
+        rel = ((got - gref).norm() / (gref.norm() + 1e-20)).item()
+        print(f"grad {k}: rel {rel:.3e} |ref| {gref.norm().item():.3e} |got| {got.norm().item():.3e}")
+        bad = bad + [k] if rel >= 5e-3 else bad
+    assert not bad, bad
