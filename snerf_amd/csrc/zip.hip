@@ -165,6 +165,9 @@ struct ZipEnc {
   void* feat; long ld;                // forward: output [P, ld]; backward: gradient input
   float* grad_table;                  // backward only (fp32)
   long R; int S, L, n, m; float Sl; int H; float std_scale;
+  int level_begin;                    // first level handled by the generic kernel
+  long slab_row0, slab_rows;          // LDS-privatised backward: the row range this workgroup accumulates
+  const int* lds_slab_level; int lds_nslab;   // slab s covers level lds_slab_level[2s], rows from lds_slab_level[2s+1]
 };
 
 __device__ __forceinline__ uint32_t zip_hash3(const uint32_t* p) { return p[0] ^ (p[1] * 2654435761u) ^ (p[2] * 805459861u); }
@@ -209,12 +212,12 @@ __device__ __forceinline__ void zip_sample_point(const ZipEnc& a, long ray, int 
   *sd = std / 2.f;
 }
 
-template <typename TT, typename OT, int C, bool BWD>
-__global__ __launch_bounds__(256) void zip_encode_kernel(ZipEnc a) {
-  const long p = (long)blockIdx.x * 256 + threadIdx.x;
-  const long P = a.R * a.S;
-  if (p >= P) return;
-  const int level = blockIdx.y;
+// MODE 0: forward gather.  MODE 1: backward, fp32 atomics straight into the table gradient.  MODE 2: backward for SMALL DENSE
+// levels: the whole level's gradient table is privatised in LDS (ds_add_f32), a few hundred persistent workgroups stride over
+// the points and flush once -- at resolution 17..33 every cell receives thousands of contributions per step, and same-address
+// global atomics serialise (measured: level 0 alone cost 63 ms of a 107 ms backward before this path).
+template <typename TT, typename OT, int C, int MODE>
+__device__ __forceinline__ void zip_point_level(const ZipEnc& a, long p, int level, float* lds_tab) {
   const long ray = p / a.S;
   const int i = (int)(p - ray * a.S);
   const float t0 = a.tdist[ray * (a.S + 1) + i], t1 = a.tdist[ray * (a.S + 1) + i + 1];
@@ -228,12 +231,39 @@ __global__ __launch_bounds__(256) void zip_encode_kernel(ZipEnc a) {
   const TT* tab = (const TT*)a.table + (long)a.offsets[level] * C;
   float acc[C], g[C];
 #pragma unroll
-  for (int c = 0; c < C; ++c) acc[c] = 0.f;
-  if (BWD) {
+  for (int c = 0; c < C; ++c) { acc[c] = 0.f; g[c] = 0.f; }
+  if (MODE != 0) {
     const OT* gi = (const OT*)a.feat + p * a.ld + level * C;
 #pragma unroll
     for (int c = 0; c < C; ++c) g[c] = (float)gi[c] / (float)a.n;
   }
+  // backward: contributions of consecutive multisamples that fall into the same cell are merged in registers first
+  uint32_t cur[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
+  float wsum[8];
+#pragma unroll
+  for (int idx = 0; idx < 8; ++idx) wsum[idx] = 0.f;
+  auto flush = [&]() {
+    if (cur[0] == 0xffffffffu) return;
+#pragma unroll
+    for (int idx = 0; idx < 8; ++idx) {
+      uint32_t pl[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) pl[k] = cur[k] + ((idx >> k) & 1);
+      const long row = zip_grid_index(hs, res, pl);
+      if (MODE == 2) {
+        const long lr = row - a.slab_row0;                 // this workgroup owns rows [slab_row0, slab_row0 + slab_rows)
+        if (lr >= 0 && lr < a.slab_rows) {
+#pragma unroll
+          for (int c = 0; c < C; ++c) atomicAdd(lds_tab + lr * C + c, wsum[idx] * g[c]);
+        }
+      } else {
+        float* dst = a.grad_table + ((long)a.offsets[level] + row) * C;
+#pragma unroll
+        for (int c = 0; c < C; ++c) atomicAdd(dst + c, wsum[idx] * g[c]);
+      }
+      wsum[idx] = 0.f;
+    }
+  };
   for (int j = 0; j < a.n; ++j) {
     float x01[3], sd;
     zip_sample_point(a, ray, i, j, t0, t1, o, d, bx, by, rad, x01, &sd);
@@ -250,6 +280,10 @@ __global__ __launch_bounds__(256) void zip_encode_kernel(ZipEnc a) {
       pg[k] = (uint32_t)fl;
       fr[k] = ps - fl;
     }
+    if (MODE != 0 && (pg[0] != cur[0] || pg[1] != cur[1] || pg[2] != cur[2])) {
+      flush();
+      cur[0] = pg[0]; cur[1] = pg[1]; cur[2] = pg[2];
+    }
 #pragma unroll
     for (int idx = 0; idx < 8; ++idx) {
       float w = 1.f;
@@ -258,44 +292,98 @@ __global__ __launch_bounds__(256) void zip_encode_kernel(ZipEnc a) {
       for (int k = 0; k < 3; ++k) {
         if (idx & (1 << k)) { w *= fr[k]; pl[k] = pg[k] + 1; } else { w *= 1.f - fr[k]; pl[k] = pg[k]; }
       }
-      const long row = zip_grid_index(hs, res, pl);
-      if (!BWD) {
+      if (MODE == 0) {
+        const long row = zip_grid_index(hs, res, pl);
         const ZVec<TT, C> r = *reinterpret_cast<const ZVec<TT, C>*>(tab + row * C);
 #pragma unroll
         for (int c = 0; c < C; ++c) acc[c] += (w * we) * (float)r.v[c];
       } else {
-        float* dst = a.grad_table + ((long)a.offsets[level] + row) * C;
-#pragma unroll
-        for (int c = 0; c < C; ++c) atomicAdd(dst + c, (w * we) * g[c]);
+        wsum[idx] += w * we;
       }
     }
   }
-  if (!BWD) {
+  if (MODE == 0) {
     OT* out = (OT*)a.feat + p * a.ld + level * C;
 #pragma unroll
     for (int c = 0; c < C; ++c) out[c] = (OT)(acc[c] / (float)a.n);
+  } else {
+    flush();
+  }
+}
+
+template <typename TT, typename OT, int C, bool BWD>
+__global__ __launch_bounds__(256) void zip_encode_kernel(ZipEnc a) {
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= a.R * a.S) return;
+  zip_point_level<TT, OT, C, BWD ? 1 : 0>(a, p, blockIdx.y + a.level_begin, nullptr);
+}
+
+template <typename OT, int C>
+__global__ __launch_bounds__(256) void zip_encode_bwd_lds_kernel(ZipEnc a, int lds_rows) {
+  extern __shared__ float lds_tab[];
+  // blockIdx.y enumerates (level, slab) pairs of the LDS-privatised levels: slab s of a level covers rows [s*lds_rows, ...)
+  int level = 0, slab = blockIdx.y;
+  for (;; ++level) {
+    const int rows = a.offsets[level + 1] - a.offsets[level];
+    const int ns = (rows + lds_rows - 1) / lds_rows;
+    if (slab < ns) break;
+    slab -= ns;
+  }
+  const int rows = a.offsets[level + 1] - a.offsets[level];
+  a.slab_row0 = (long)slab * lds_rows;
+  a.slab_rows = min((long)lds_rows, rows - a.slab_row0);
+  const int cells = (int)a.slab_rows * C;
+  for (int k = threadIdx.x; k < cells; k += 256) lds_tab[k] = 0.f;
+  __syncthreads();
+  const long P = a.R * a.S;
+  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < P; p += (long)gridDim.x * 256) zip_point_level<float, OT, C, 2>(a, p, level, lds_tab);
+  __syncthreads();
+  float* dst = a.grad_table + ((long)a.offsets[level] + a.slab_row0) * C;
+  for (int k = threadIdx.x; k < cells; k += 256) {
+    const float v = lds_tab[k];
+    if (v != 0.f) atomicAdd(dst + k, v);
   }
 }
 
 template <typename TT, typename OT, bool BWD>
-static int zip_enc_launch(const ZipEnc& a, int C, hipStream_t s) {
-  const dim3 grid((unsigned)((a.R * a.S + 255) / 256), a.L), blk(256);
-  switch (C) {
-    case 1: hipLaunchKernelGGL((zip_encode_kernel<TT, OT, 1, BWD>), grid, blk, 0, s, a); break;
-    case 2: hipLaunchKernelGGL((zip_encode_kernel<TT, OT, 2, BWD>), grid, blk, 0, s, a); break;
-    case 4: hipLaunchKernelGGL((zip_encode_kernel<TT, OT, 4, BWD>), grid, blk, 0, s, a); break;
-    case 8: hipLaunchKernelGGL((zip_encode_kernel<TT, OT, 8, BWD>), grid, blk, 0, s, a); break;
-    default: return SNERF_ERR_ARG;
+static int zip_enc_launch(ZipEnc a, int C, int lds_levels, size_t lds_bytes, int lds_slabs, hipStream_t s) {
+  const dim3 blk(256);
+  const int lds_rows = (int)(lds_bytes / (C * 4));
+  if (BWD && lds_levels > 0) {
+    const dim3 grid(256, lds_slabs);
+    switch (C) {
+      case 1: (void)hipFuncSetAttribute((const void*)zip_encode_bwd_lds_kernel<OT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+              hipLaunchKernelGGL((zip_encode_bwd_lds_kernel<OT, 1>), grid, blk, lds_bytes, s, a, lds_rows); break;
+      case 2: (void)hipFuncSetAttribute((const void*)zip_encode_bwd_lds_kernel<OT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+              hipLaunchKernelGGL((zip_encode_bwd_lds_kernel<OT, 2>), grid, blk, lds_bytes, s, a, lds_rows); break;
+      case 4: (void)hipFuncSetAttribute((const void*)zip_encode_bwd_lds_kernel<OT, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+              hipLaunchKernelGGL((zip_encode_bwd_lds_kernel<OT, 4>), grid, blk, lds_bytes, s, a, lds_rows); break;
+      case 8: (void)hipFuncSetAttribute((const void*)zip_encode_bwd_lds_kernel<OT, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+              hipLaunchKernelGGL((zip_encode_bwd_lds_kernel<OT, 8>), grid, blk, lds_bytes, s, a, lds_rows); break;
+      default: return SNERF_ERR_ARG;
+    }
+  }
+  a.level_begin = BWD ? lds_levels : 0;
+  const int nl = a.L - a.level_begin;
+  if (nl > 0) {
+    const dim3 grid((unsigned)((a.R * a.S + 255) / 256), nl);
+    switch (C) {
+      case 1: hipLaunchKernelGGL((zip_encode_kernel<TT, OT, 1, BWD>), grid, blk, 0, s, a); break;
+      case 2: hipLaunchKernelGGL((zip_encode_kernel<TT, OT, 2, BWD>), grid, blk, 0, s, a); break;
+      case 4: hipLaunchKernelGGL((zip_encode_kernel<TT, OT, 4, BWD>), grid, blk, 0, s, a); break;
+      case 8: hipLaunchKernelGGL((zip_encode_kernel<TT, OT, 8, BWD>), grid, blk, 0, s, a); break;
+      default: return SNERF_ERR_ARG;
+    }
   }
   return snerf_check_launch();
 }
 
 template <bool BWD>
-static int zip_enc_dispatch(const ZipEnc& a, int C, int table_dtype, int feat_dtype, hipStream_t s) {
-  if (table_dtype == SNERF_DT_F32 && feat_dtype == SNERF_DT_F32) return zip_enc_launch<float, float, BWD>(a, C, s);
-  if (table_dtype == SNERF_DT_F32 && feat_dtype == SNERF_DT_BF16) return zip_enc_launch<float, __bf16, BWD>(a, C, s);
-  if (table_dtype == 2 && feat_dtype == SNERF_DT_F32) return zip_enc_launch<__half, float, BWD>(a, C, s);
-  if (table_dtype == 2 && feat_dtype == SNERF_DT_BF16) return zip_enc_launch<__half, __bf16, BWD>(a, C, s);
+static int zip_enc_dispatch(const ZipEnc& a, int C, int table_dtype, int feat_dtype, int lds_levels, size_t lds_bytes, int lds_slabs, hipStream_t s) {
+  if (table_dtype == SNERF_DT_F32 && feat_dtype == SNERF_DT_F32) return zip_enc_launch<float, float, BWD>(a, C, lds_levels, lds_bytes, lds_slabs, s);
+  if (table_dtype == SNERF_DT_F32 && feat_dtype == SNERF_DT_BF16) return zip_enc_launch<float, __bf16, BWD>(a, C, lds_levels, lds_bytes, lds_slabs, s);
+  if (table_dtype == 2 && feat_dtype == SNERF_DT_F32) return zip_enc_launch<__half, float, BWD>(a, C, lds_levels, lds_bytes, lds_slabs, s);
+  if (table_dtype == 2 && feat_dtype == SNERF_DT_BF16) return zip_enc_launch<__half, __bf16, BWD>(a, C, lds_levels, lds_bytes, lds_slabs, s);
   return SNERF_ERR_ARG;
 }
 
@@ -306,17 +394,21 @@ extern "C" int snerf_zip_encode_fwd(const float* tdist, const float* origins, co
   if (R <= 0) return SNERF_OK;
   if (S <= 0 || L <= 0 || n <= 0 || ld < (long)L * C || table == nullptr || feat == nullptr || grid_sizes == nullptr) return SNERF_ERR_ARG;
   ZipEnc a{tdist, origins, directions, radii, base_x, base_y, deg_jitter, table, offsets, grid_sizes, feat, ld, nullptr, R, S, L, n, m, Sl, H, std_scale};
-  return zip_enc_dispatch<false>(a, C, table_dtype, feat_dtype, (hipStream_t)stream);
+  return zip_enc_dispatch<false>(a, C, table_dtype, feat_dtype, 0, 0, 0, (hipStream_t)stream);
 }
 
 extern "C" int snerf_zip_encode_bwd(const float* tdist, const float* origins, const float* directions, const float* radii,
                                     const float* base_x, const float* base_y, const float* deg_jitter, const int* offsets,
                                     const int* grid_sizes, const void* grad_feat, long ld, float* grad_table, long R, int S, int L, int C,
-                                    int n, int m, float Sl, int H, float std_scale, int feat_dtype, void* stream) {
+                                    int n, int m, float Sl, int H, float std_scale, int feat_dtype, int lds_levels, long lds_cells,
+                                    int lds_slabs, void* stream) {
   if (R <= 0) return SNERF_OK;
   if (S <= 0 || L <= 0 || n <= 0 || ld < (long)L * C || grad_feat == nullptr || grad_table == nullptr || grid_sizes == nullptr) return SNERF_ERR_ARG;
   ZipEnc a{tdist, origins, directions, radii, base_x, base_y, deg_jitter, nullptr, offsets, grid_sizes, (void*)grad_feat, ld, grad_table, R, S, L, n, m, Sl, H, std_scale};
-  return zip_enc_dispatch<true>(a, C, SNERF_DT_F32, feat_dtype, (hipStream_t)stream);
+  // the first lds_levels levels take the LDS-privatised path in slabs of lds_cells rows (lds_cells * C * 4 bytes <= 160 KB);
+  // lds_slabs = sum over those levels of ceil(rows / lds_cells) (the host knows the level sizes)
+  if (lds_levels < 0 || lds_levels > L || (lds_levels > 0 && (lds_cells <= 0 || lds_cells * C * 4 > 160 * 1024 || lds_slabs < lds_levels))) return SNERF_ERR_ARG;
+  return zip_enc_dispatch<true>(a, C, SNERF_DT_F32, feat_dtype, lds_levels, (size_t)lds_cells * C * 4, lds_slabs, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

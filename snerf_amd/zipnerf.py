@@ -45,6 +45,14 @@ class _Encoder:
         self.offsets, self.res, self.scale = _level_layout(self.L, base_resolution, desired_resolution, log2_hashmap_size)
         self.Sl = float(np.log2(self.scale))
         self.rows = int(self.offsets[-1])
+        # leading (small, dense, heavily contended) levels take the LDS-privatised backward, in slabs of <= 36 K cells
+        # (144 KB fp32); a level qualifies while it needs at most 8 slabs (each slab re-walks all points)
+        sizes = np.diff(self.offsets)
+        self.lds_cells = (144 * 1024) // (4 * level_dim)
+        self.lds_levels, self.lds_slabs = 0, 0
+        while self.lds_levels < self.L and -(-int(sizes[self.lds_levels]) // self.lds_cells) <= 8:
+            self.lds_slabs += -(-int(sizes[self.lds_levels]) // self.lds_cells)
+            self.lds_levels += 1
 
 
 class Model(_ArenaModule):
@@ -206,7 +214,7 @@ class Model(_ArenaModule):
             dF = net.backward(d_den, L["saved"]) if lvl < 2 else net.backward(d_rgb, d_den, L["saved"])
             ops.zip_encode_bwd(L["tdist"], ctx["o"], ctx["d"], ctx["radii"], ctx["bx"], ctx["by"], L["degj"], self.dev_offsets[lvl],
                                self.dev_sizes[lvl], dF, self.arena.g[self.names[lvl] + "encoder.embeddings"], e.L, e.C, ctx["n"], ctx["m"], e.Sl,
-                               e.H, self.std_scale)
+                               e.H, self.std_scale, e.lds_levels, e.lds_cells, e.lds_slabs)
 
     def _draws(self, R, rand, dev, sample_n):
         """the reference's RNG draws in its order: per level one single-jitter draw (stepfun.py:216) then the helix phase

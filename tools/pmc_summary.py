@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc counter_collection CSVs (one directory per pass) for one kernel-name substring."""
+import csv, glob, os, sys
+root, pat = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "gemm")
+tot = {}
+for f in sorted(glob.glob(os.path.join(root, "*", "*counter_collection.csv"))):
+    rows = list(csv.DictReader(open(f)))
+    per = {}
+    for r in rows:
+        if pat not in r["Kernel_Name"]:
+            continue
+        per.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    for k, v in per.items():
+        v = v[1:] if len(v) > 1 else v            # drop the first (cold) dispatch
+        tot[k] = sum(v) / len(v)
+dur = []
+for f in glob.glob(os.path.join(root, "*", "*kernel_trace.csv")):
+    for r in csv.DictReader(open(f)):
+        if pat in r["Kernel_Name"]:
+            dur.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+print(f"# {root}  kernel~'{pat}'  avg duration under profiling {sum(dur) / max(1, len(dur)) / 1e3:.1f} us over {len(dur)} dispatches")
+for k in sorted(tot):
+    print(f"{k:32s} {tot[k]:18.1f}")
+g = tot.get
+if g("SQ_WAVE_CYCLES"):
+    wc = g("SQ_WAVE_CYCLES")
+    print(f"wait_any/wave_cycles      {g('SQ_WAIT_ANY', 0) / wc:.3f}   (s_waitcnt / barrier)")
+    print(f"wait_inst_any/wave_cycles {g('SQ_WAIT_INST_ANY', 0) / wc:.3f}   (issue stalls)")
+    print(f"active_inst_any/wave_cyc  {g('SQ_ACTIVE_INST_ANY', 0) / wc:.3f}")
+if g("SQ_VALU_MFMA_BUSY_CYCLES") and g("SQ_BUSY_CYCLES"):
+    print(f"mfma_busy/(busy_cycles)   {g('SQ_VALU_MFMA_BUSY_CYCLES') / g('SQ_BUSY_CYCLES'):.3f}  (units differ per SE/XCD: see MI355X_MICROARCH.md)")
+if g("SQ_LDS_IDX_ACTIVE"):
+    print(f"lds_bank_conflict/idx_act {g('SQ_LDS_BANK_CONFLICT', 0) / g('SQ_LDS_IDX_ACTIVE'):.3f}")
+if g("TCC_HIT_sum") is not None and g("TCC_MISS_sum") is not None:
+    print(f"L2 hit rate               {g('TCC_HIT_sum') / (g('TCC_HIT_sum') + g('TCC_MISS_sum')):.3f}")
+if g("FETCH_SIZE") is not None:
+    print(f"FETCH_SIZE x2 (gfx950 correction, KB->bytes): {2 * g('FETCH_SIZE') * 1024 / 1e9:.3f} GB per launch")
+if g("WRITE_SIZE") is not None:
+    print(f"WRITE_SIZE (KB->bytes): {g('WRITE_SIZE') * 1024 / 1e9:.3f} GB per launch")
