@@ -56,166 +56,16 @@ __device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
 }
 
 // ---------------------------------------------------------------------------
-// NT kernel: BM x BN output tile, WM x WN waves, each wave (BM/WM) x (BN/WN).
+// NT epilogue shared by the NT kernels.  acc[i][j] is the 32 x 32 MFMA tile at rows
+// m0 + wm*WTM + 32 i, columns n0 + wn*WTN + 32 j of the block tile.
 // ---------------------------------------------------------------------------
-template <typename T, int BM, int BN, int WM, int WN, bool INTERLEAVE>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmNT p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+template <typename T, int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], char* smem,
+                                            const int m0, const int n0, const int wave, const int lane) {
   typedef typename Frag<T>::type frag_t;
-  constexpr int NW = WM * WN;
-  constexpr int EPC = 16 / (int)sizeof(T);   // elements per 16-byte chunk
-  constexpr int BKE = 128 / (int)sizeof(T);  // reduction elements per tile row
-  constexpr int STAGE = (BM + BN) * 128;
+  constexpr int EPC = 16 / (int)sizeof(T);
   constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
-  constexpr int LA = BM / 8 / NW, LB = BN / 8 / NW;  // glds instructions per wave per tile
-  static_assert(LA >= 1 && LB >= 1, "tile too small for the wave count");
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
-  const int tiles_n = p.N / BN;
-  const int tiles_m = (p.M + BM - 1) / BM;
-  const int logical = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-  const int m0 = (logical / tiles_n) * BM, n0 = (logical % tiles_n) * BN;
-  const T* __restrict__ A = (const T*)p.A;
-  const T* __restrict__ W = (const T*)p.W;
-  const int KT = p.K / BKE;
-
-  // per-lane source coordinates of the staging loads (constant over k)
-  const int lrow = lane >> 3, lsc = lane & 7;
-  long a_off[LA], b_off[LB];
-#pragma unroll
-  for (int i = 0; i < LA; ++i) {
-    const int row = (wave * LA + i) * 8 + lrow;
-    const int c = lsc ^ ((row >> 1) & 7);
-    int gr = m0 + row;
-    gr = gr < p.M ? gr : p.M - 1;
-    a_off[i] = (long)gr * p.lda + c * EPC;
-  }
-#pragma unroll
-  for (int i = 0; i < LB; ++i) {
-    const int row = (wave * LB + i) * 8 + lrow;
-    const int c = lsc ^ ((row >> 1) & 7);
-    b_off[i] = (long)(n0 + row) * p.ldw + c * EPC;
-  }
-
-  auto issue = [&](int kt, int stage) {
-    char* sA = smem + stage * STAGE;
-    char* sB = sA + BM * 128;
-    const long k0 = (long)kt * BKE;
-#pragma unroll
-    for (int i = 0; i < LA; ++i) glds16(A + a_off[i] + k0, sA + (wave * LA + i) * 1024);
-#pragma unroll
-    for (int i = 0; i < LB; ++i) glds16(W + b_off[i] + k0, sB + (wave * LB + i) * 1024);
-  };
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // fragment read offsets (bytes inside a tile), constant over k except the chunk index
-  int ra[TM], rb[TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i) ra[i] = wm * WTM + i * 32 + (lane & 31);
-#pragma unroll
-  for (int j = 0; j < TN; ++j) rb[j] = wn * WTN + j * 32 + (lane & 31);
-  const int chalf = lane >> 5;
-
-  // one staging piece (1 KiB per wave-instruction) of tile kt: pieces [0, LA) belong to A, [LA, LA+LB) to W
-  auto issue_piece = [&](int kt, int stage, int pc) {
-    char* sA = smem + stage * STAGE;
-    char* sB = sA + BM * 128;
-    const long k0 = (long)kt * BKE;
-#pragma unroll
-    for (int i = 0; i < LA; ++i) if (pc == i) glds16(A + a_off[i] + k0, sA + (wave * LA + i) * 1024);
-#pragma unroll
-    for (int i = 0; i < LB; ++i) if (pc == LA + i) glds16(W + b_off[i] + k0, sB + (wave * LB + i) * 1024);
-  };
-  auto read_frags = [&](const char* sA, const char* sB, int ks, frag_t* a, frag_t* b) {
-    const int c = 2 * ks + chalf;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) a[i] = *(const frag_t*)((p.dbg & 2) ? smem + lane * 16 : sA + ra[i] * 128 + ((c ^ ((ra[i] >> 1) & 7)) << 4));
-#pragma unroll
-    for (int j = 0; j < TN; ++j) b[j] = *(const frag_t*)((p.dbg & 2) ? smem + lane * 16 + 1024 : sB + rb[j] * 128 + ((c ^ ((rb[j] >> 1) & 7)) << 4));
-  };
-
-  issue(0, 0);
-  if constexpr (!INTERLEAVE) {
-    for (int kt = 0; kt < KT; ++kt) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (kt + 1 < KT && !(p.dbg & 1)) issue(kt + 1, (kt + 1) & 1);
-      const char* sA = smem + (kt & 1) * STAGE;
-      const char* sB = sA + BM * 128;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        frag_t a[TM], b[TN];
-        read_frags(sA, sB, ks, a, b);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) mma32(acc[i][j], b[j], a[i]);   // D = W-tile . X-tile^T: lanes own rows m
-      }
-    }
-  } else {
-    // Same double buffer, but the (LA+LB) staging instructions of the NEXT tile are spread between the MFMAs of this one
-    // (an LDS-DMA piece costs ~60-100 issue cycles; issued as one block after the barrier they leave the matrix pipe
-    // idle on every SIMD at once, since all waves of the workgroup are in the same phase), and the fragments of sub-step
-    // ks+1 are fetched while the MFMAs of ks run.
-    constexpr int NP = LA + LB, PPK = NP / 4;       // staging pieces per k sub-step
-    static_assert(NP % 4 == 0, "pieces must split over the 4 k sub-steps");
-    constexpr int NM = TM * TN;
-    auto tile = [&](int kt, auto more_tag) {
-      constexpr bool MORE = decltype(more_tag)::value;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      const char* sA = smem + (kt & 1) * STAGE;
-      const char* sB = sA + BM * 128;
-      const int c0 = chalf;
-      frag_t a[2][TM], b[2][TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) a[0][i] = *(const frag_t*)(sA + ra[i] * 128 + ((c0 ^ ((ra[i] >> 1) & 7)) << 4));
-#pragma unroll
-      for (int j = 0; j < TN; ++j) b[0][j] = *(const frag_t*)(sB + rb[j] * 128 + ((c0 ^ ((rb[j] >> 1) & 7)) << 4));
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        if (ks < 3) {
-          const int c = 2 * (ks + 1) + chalf;
-#pragma unroll
-          for (int i = 0; i < TM; ++i) a[(ks + 1) & 1][i] = *(const frag_t*)(sA + ra[i] * 128 + ((c ^ ((ra[i] >> 1) & 7)) << 4));
-#pragma unroll
-          for (int j = 0; j < TN; ++j) b[(ks + 1) & 1][j] = *(const frag_t*)(sB + rb[j] * 128 + ((c ^ ((rb[j] >> 1) & 7)) << 4));
-        }
-#pragma unroll
-        for (int t = 0; t < NM; ++t) {
-          const int i = t / TN, j = t % TN;
-          mma32(acc[i][j], b[ks & 1][j], a[ks & 1][i]);
-          // after every (NM/PPK)-th MFMA issue one staging piece of the next tile
-          if constexpr (MORE) {
-            if (((t + 1) % (NM / PPK)) == 0) issue_piece(kt + 1, (kt + 1) & 1, ks * PPK + (t + 1) / (NM / PPK) - 1);
-          }
-        }
-      }
-      // pin the software pipeline: fragments of sub-step ks+1 are fetched BEFORE the MFMAs of ks issue, staging pieces
-      // sit between MFMA groups (masks: 0x008 MFMA, 0x010 VMEM, 0x100 DS read)
-      __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        if (ks < 3) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
-#pragma unroll
-        for (int g = 0; g < PPK; ++g) {
-          __builtin_amdgcn_sched_group_barrier(0x008, NM / PPK, 0);
-          if constexpr (MORE) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-        }
-      }
-    };
-    for (int kt = 0; kt < KT - 1; ++kt) tile(kt, std::true_type{});
-    tile(KT - 1, std::false_type{});
-  }
 
   // epilogue: MFMA "A" operand = weights, "B" operand = activations, so D[i'][j'] has j' = lane&31 = local m and
   // i' = (r&3) + 8*(r>>2) + 4*(lane>>5) = local n: every lane owns ONE output row and, per register quad, FOUR consecutive
@@ -389,6 +239,668 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmNT p) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// NT kernel: BM x BN output tile, WM x WN waves, each wave (BM/WM) x (BN/WN).
+// ---------------------------------------------------------------------------
+template <typename T, int BM, int BN, int WM, int WN, bool INTERLEAVE>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmNT p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef typename Frag<T>::type frag_t;
+  constexpr int NW = WM * WN;
+  constexpr int EPC = 16 / (int)sizeof(T);   // elements per 16-byte chunk
+  constexpr int BKE = 128 / (int)sizeof(T);  // reduction elements per tile row
+  constexpr int STAGE = (BM + BN) * 128;
+  constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
+  constexpr int LA = BM / 8 / NW, LB = BN / 8 / NW;  // glds instructions per wave per tile
+  static_assert(LA >= 1 && LB >= 1, "tile too small for the wave count");
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int tiles_n = p.N / BN;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int logical = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int m0 = (logical / tiles_n) * BM, n0 = (logical % tiles_n) * BN;
+  const T* __restrict__ A = (const T*)p.A;
+  const T* __restrict__ W = (const T*)p.W;
+  const int KT = p.K / BKE;
+
+  // per-lane source coordinates of the staging loads (constant over k)
+  const int lrow = lane >> 3, lsc = lane & 7;
+  long a_off[LA], b_off[LB];
+#pragma unroll
+  for (int i = 0; i < LA; ++i) {
+    const int row = (wave * LA + i) * 8 + lrow;
+    const int c = lsc ^ ((row >> 1) & 7);
+    int gr = m0 + row;
+    gr = gr < p.M ? gr : p.M - 1;
+    a_off[i] = (long)gr * p.lda + c * EPC;
+  }
+#pragma unroll
+  for (int i = 0; i < LB; ++i) {
+    const int row = (wave * LB + i) * 8 + lrow;
+    const int c = lsc ^ ((row >> 1) & 7);
+    b_off[i] = (long)(n0 + row) * p.ldw + c * EPC;
+  }
+
+  auto issue = [&](int kt, int stage) {
+    char* sA = smem + stage * STAGE;
+    char* sB = sA + BM * 128;
+    const long k0 = (long)kt * BKE;
+#pragma unroll
+    for (int i = 0; i < LA; ++i) glds16(A + a_off[i] + k0, sA + (wave * LA + i) * 1024);
+#pragma unroll
+    for (int i = 0; i < LB; ++i) glds16(W + b_off[i] + k0, sB + (wave * LB + i) * 1024);
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment read offsets (bytes inside a tile), constant over k except the chunk index
+  int ra[TM], rb[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) ra[i] = wm * WTM + i * 32 + (lane & 31);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) rb[j] = wn * WTN + j * 32 + (lane & 31);
+  const int chalf = lane >> 5;
+
+  // one staging piece (1 KiB per wave-instruction) of tile kt: pieces [0, LA) belong to A, [LA, LA+LB) to W
+  auto issue_piece = [&](int kt, int stage, int pc) {
+    char* sA = smem + stage * STAGE;
+    char* sB = sA + BM * 128;
+    const long k0 = (long)kt * BKE;
+#pragma unroll
+    for (int i = 0; i < LA; ++i) if (pc == i) glds16(A + a_off[i] + k0, sA + (wave * LA + i) * 1024);
+#pragma unroll
+    for (int i = 0; i < LB; ++i) if (pc == LA + i) glds16(W + b_off[i] + k0, sB + (wave * LB + i) * 1024);
+  };
+  auto read_frags = [&](const char* sA, const char* sB, int ks, frag_t* a, frag_t* b) {
+    const int c = 2 * ks + chalf;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a[i] = *(const frag_t*)((p.dbg & 2) ? smem + lane * 16 : sA + ra[i] * 128 + ((c ^ ((ra[i] >> 1) & 7)) << 4));
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b[j] = *(const frag_t*)((p.dbg & 2) ? smem + lane * 16 + 1024 : sB + rb[j] * 128 + ((c ^ ((rb[j] >> 1) & 7)) << 4));
+  };
+
+  issue(0, 0);
+  if constexpr (!INTERLEAVE) {
+    for (int kt = 0; kt < KT; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (kt + 1 < KT && !(p.dbg & 1)) issue(kt + 1, (kt + 1) & 1);
+      const char* sA = smem + (kt & 1) * STAGE;
+      const char* sB = sA + BM * 128;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        frag_t a[TM], b[TN];
+        read_frags(sA, sB, ks, a, b);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) mma32(acc[i][j], b[j], a[i]);   // D = W-tile . X-tile^T: lanes own rows m
+      }
+    }
+  } else {
+    // Same double buffer, but the (LA+LB) staging instructions of the NEXT tile are spread between the MFMAs of this one
+    // (an LDS-DMA piece costs ~60-100 issue cycles; issued as one block after the barrier they leave the matrix pipe
+    // idle on every SIMD at once, since all waves of the workgroup are in the same phase), and the fragments of sub-step
+    // ks+1 are fetched while the MFMAs of ks run.
+    constexpr int NP = LA + LB, PPK = NP / 4;       // staging pieces per k sub-step
+    static_assert(NP % 4 == 0, "pieces must split over the 4 k sub-steps");
+    constexpr int NM = TM * TN;
+    auto tile = [&](int kt, auto more_tag) {
+      constexpr bool MORE = decltype(more_tag)::value;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      const char* sA = smem + (kt & 1) * STAGE;
+      const char* sB = sA + BM * 128;
+      const int c0 = chalf;
+      frag_t a[2][TM], b[2][TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[0][i] = *(const frag_t*)(sA + ra[i] * 128 + ((c0 ^ ((ra[i] >> 1) & 7)) << 4));
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[0][j] = *(const frag_t*)(sB + rb[j] * 128 + ((c0 ^ ((rb[j] >> 1) & 7)) << 4));
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if (ks < 3) {
+          const int c = 2 * (ks + 1) + chalf;
+#pragma unroll
+          for (int i = 0; i < TM; ++i) a[(ks + 1) & 1][i] = *(const frag_t*)(sA + ra[i] * 128 + ((c ^ ((ra[i] >> 1) & 7)) << 4));
+#pragma unroll
+          for (int j = 0; j < TN; ++j) b[(ks + 1) & 1][j] = *(const frag_t*)(sB + rb[j] * 128 + ((c ^ ((rb[j] >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int t = 0; t < NM; ++t) {
+          const int i = t / TN, j = t % TN;
+          mma32(acc[i][j], b[ks & 1][j], a[ks & 1][i]);
+          // after every (NM/PPK)-th MFMA issue one staging piece of the next tile
+          if constexpr (MORE) {
+            if (((t + 1) % (NM / PPK)) == 0) issue_piece(kt + 1, (kt + 1) & 1, ks * PPK + (t + 1) / (NM / PPK) - 1);
+          }
+        }
+      }
+      // pin the software pipeline: fragments of sub-step ks+1 are fetched BEFORE the MFMAs of ks issue, staging pieces
+      // sit between MFMA groups (masks: 0x008 MFMA, 0x010 VMEM, 0x100 DS read)
+      __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if (ks < 3) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+#pragma unroll
+        for (int g = 0; g < PPK; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, NM / PPK, 0);
+          if constexpr (MORE) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        }
+      }
+    };
+    for (int kt = 0; kt < KT - 1; ++kt) tile(kt, std::true_type{});
+    tile(KT - 1, std::false_type{});
+  }
+
+  nt_epilogue<T, BM, BN, WM, WN>(p, acc, smem, m0, n0, wave, lane);
+}
+
+// ---------------------------------------------------------------------------
+// NT kernel, 256 x 256 tile, bf16, 8 waves (2 x 4), BK = 64: the "8-phase" schedule.
+//
+// The block tile is staged as four HALF-tiles per k-tile (A0, A1, B0, B1: 128 rows x 128 B each, 16 KiB), double
+// buffered (128 KiB).  The halves are interleaved over the waves so that every wave needs rows of every half and
+// still owns a CONTIGUOUS 128 x 64 output tile (the epilogue is the common one):
+//     A half h, local row lr  <->  tile row (lr>>6)*128 + h*64 + (lr&63)      (wave row wr = lr>>6)
+//     B half g, local row lr  <->  tile col (lr>>5)*64  + g*32 + (lr&31)      (wave col wc = lr>>5)
+// A k-tile is four phases, one 64 x 32 output quadrant (A half x B half, 8 MFMAs 32x32x16) each:
+//     P1 A0.B0   P2 A0.B1   P3 A1.B1   P4 A1.B0
+// and every phase stages ONE half-tile ahead (2 LDS-DMA pieces per wave):
+//     P1 A1(t+1)   P2 A0(t+2)   P3 B0(t+2)   P4 B1(t+2), then s_waitcnt vmcnt(6)
+// so three half-tiles are always in flight and the only VMEM wait of the loop (P4) retires everything tile t+1 needs.
+// The two wave rows run half a phase apart (wr = 1 takes one extra barrier up front): while one wave of a SIMD issues
+// its 8 MFMAs the other one fetches fragments and stages, and the two barriers per phase keep that alternation.
+//
+// Ordering rules (MI355X_MICROARCH.md, LDS-DMA): a staged half is read one phase (two barriers) after the vmcnt that
+// retired it; a half is restaged at the earliest in the phase after its last fragment read, and every phase retires its
+// fragment reads (lgkmcnt(0)) BEFORE its first barrier, so the restaging wave group cannot overtake them.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmNT p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __bf16 T;
+  constexpr int BM = 256, BN = 256, WM = 2, WN = 4;
+  constexpr int HALF = 128 * 128;                     // bytes per half-tile
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int tiles_n = p.N / BN;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int logical = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int m0 = (logical / tiles_n) * BM, n0 = (logical % tiles_n) * BN;
+  const T* __restrict__ A = (const T*)p.A;
+  const T* __restrict__ W = (const T*)p.W;
+  const int KT = p.K / 64;
+
+  // staging sources: wave w owns pieces 2w, 2w+1 (8 rows x 128 B each) of every half-tile
+  const int lrow = lane >> 3, lsc = lane & 7;
+  long a_off[2][2], b_off[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int lr = (wave * 2 + i) * 8 + lrow;
+    const int c = lsc ^ ((lr >> 1) & 7);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int gr = m0 + (lr >> 6) * 128 + h * 64 + (lr & 63);
+      gr = gr < p.M ? gr : p.M - 1;
+      a_off[h][i] = (long)gr * p.lda + c * 8;
+      b_off[h][i] = (long)(n0 + (lr >> 5) * 64 + h * 32 + (lr & 31)) * p.ldw + c * 8;
+    }
+  }
+  char* const my_piece = smem + wave * 2048;
+  // which: 0 = A0, 1 = A1, 2 = B0, 3 = B1
+  auto stage = [&](int kt, int db, int which) {
+    char* dst = my_piece + (db * 4 + which) * HALF;
+    const long k0 = (long)kt * 64;
+    if (which < 2) {
+      glds16(A + a_off[which][0] + k0, dst);
+      glds16(A + a_off[which][1] + k0, dst + 1024);
+    } else {
+      glds16(W + b_off[which - 2][0] + k0, dst);
+      glds16(W + b_off[which - 2][1] + k0, dst + 1024);
+    }
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment addresses inside a half-tile: row (wave part + lane&31), chunk (2 ks + lane>>5) ^ swizzle
+  const int sw = ((lane & 31) >> 1) & 7;
+  int cof[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) cof[ks] = ((2 * ks + (lane >> 5)) ^ sw) << 4;
+  const int fa = (wr * 64 + (lane & 31)) * 128;       // + i2 * 32 * 128
+  const int fb = (wc * 32 + (lane & 31)) * 128;
+
+  bf16x8 a[2][4], b0[4], b1[4];
+  auto read_a = [&](int db, int h) {
+    const char* s = smem + (db * 4 + h) * HALF + fa;
+#pragma unroll
+    for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) a[i2][ks] = *(const bf16x8*)(s + i2 * 4096 + cof[ks]);
+  };
+  auto read_b = [&](int db, int g, bf16x8* b) {
+    const char* s = smem + (db * 4 + 2 + g) * HALF + fb;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) b[ks] = *(const bf16x8*)(s + cof[ks]);
+  };
+  auto quadrant = [&](int h, int g, const bf16x8* b) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int i2 = 0; i2 < 2; ++i2) mma32(acc[2 * h + i2][g], b[ks], a[i2][ks]);   // lanes own rows m
+  };
+  // end of a phase's load section / end of its MFMA section
+  auto sync_loads = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto sync_mfma = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  if ((p.dbg & 2) && blockIdx.x < 256) {
+    // ablation: de-phase the CUs (first resident set of workgroups starts up to 7/8 of a tile time late)
+    const int steps = ((blockIdx.x >> 3) & 7) * (p.K >> 3);
+    for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(8);
+  }
+  // prologue: all of tile 0, three halves of tile 1
+  stage(0, 0, 0); stage(0, 0, 2); stage(0, 0, 3); stage(0, 0, 1);
+  if (KT > 1) {
+    stage(1, 1, 0); stage(1, 1, 2); stage(1, 1, 3);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();          // run half a phase behind wave row 0
+
+  auto tile = [&](int t, auto db_tag) {
+    constexpr int db = decltype(db_tag)::value;
+    const bool more1 = t + 1 < KT && !(p.dbg & 1), more2 = t + 2 < KT && !(p.dbg & 1);
+    // P1
+    read_b(db, 0, b0);
+    read_a(db, 0);
+    if (more1) stage(t + 1, db ^ 1, 1);
+    sync_loads();
+    quadrant(0, 0, b0);
+    sync_mfma();
+    // P2
+    read_b(db, 1, b1);
+    if (more2) stage(t + 2, db, 0);
+    sync_loads();
+    quadrant(0, 1, b1);
+    sync_mfma();
+    // P3
+    read_a(db, 1);
+    if (more2) stage(t + 2, db, 2);
+    sync_loads();
+    quadrant(1, 1, b1);
+    sync_mfma();
+    // P4
+    if (more2) {
+      stage(t + 2, db, 3);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    sync_loads();
+    quadrant(1, 0, b0);
+    sync_mfma();
+  };
+  for (int t = 0; t < KT; t += 2) {
+    tile(t, std::integral_constant<int, 0>{});
+    if (t + 1 < KT) tile(t + 1, std::integral_constant<int, 1>{});
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();          // matches the extra barrier of wave row 1
+
+  nt_epilogue<T, BM, BN, WM, WN>(p, acc, smem, m0, n0, wave, lane);
+}
+
+// ---------------------------------------------------------------------------
+// NT kernel, persistent 8-phase schedule ("variant 8"): 256 x 256 tiles, bf16, 8 waves, one workgroup per CU that walks
+// its output tiles back to back.
+//
+// Same half-tile geometry and quadrant phases as gemm_nt8_kernel, with three changes aimed at what limited it
+// (profiles/r1_f: the load section of a phase was longer than the 8-MFMA section it alternates with, and every output
+// tile paid an exposed prologue and epilogue because only one workgroup fits a CU):
+//  * fragments are PREFETCHED while the wave issues its MFMAs: the second B half during P1, A1 during P2 (each A0 fragment
+//    is replaced in place right after its last MFMA), the first B half of t+1 during P3, A0(t+1) during P4; a load
+//    section then holds only the staging DMA;
+//  * the staging stream is continuous over (tile, k-tile): half-tiles are staged two k-tiles (8 halves) ahead in
+//    consumption order Bfirst, A0, Bsecond, A1 and every phase ends with vmcnt(10) = five halves in flight; the next
+//    tile's first k-tiles are therefore in LDS before the current tile is finished (no prologue after the first tile);
+//  * the epilogue is cut into four 32-row units that ride in load sections: rows 0..63 of the wave tile are final after
+//    P2 of the last k-tile and leave in its P3/P4, rows 64..127 leave in P1/P2 of the next tile's first k-tile, each
+//    unit re-zeroing its accumulators.  The bias vector of the NEXT tile is DMA'd to LDS one tile ahead.
+// The B half that is used first alternates with k-tile parity (even: B0, odd: B1) so that the two B register sets rotate.
+// Ordering (MI355X_MICROARCH.md, LDS-DMA): a half retired by the vmcnt of load section p-1 is first read in MFMA section
+// p (two barriers later for either wave row); a half last read in MFMA section p is restaged in load section p+2 at the
+// earliest, after the lgkmcnt(0) of load section p+1 and its barrier.  Load sections of the two wave rows never overlap
+// in time, so wave w and wave w+4 share one 4 KiB transposition slab.
+// Requires N % 256 == 0, K >= 128, the fast (bf16, 16-byte aligned) epilogue.
+// ---------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <int ACT, bool COLSUM>
+__global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __bf16 T;
+  constexpr int HALF = 128 * 128;                      // bytes per half-tile
+  constexpr int SCRATCH = 8 * HALF;                    // 4 x 4 KiB transposition slabs
+  constexpr int BIAS = SCRATCH + 4 * 4096;             // 2 x 1 KiB bias vectors (tile parity)
+  constexpr int BB = 2;                                // bias quads fetched per batch in the epilogue units
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int tiles_n = p.N >> 8;
+  const int tiles_m = (p.M + 255) >> 8;
+  const int total = tiles_m * tiles_n;
+  const int G = gridDim.x;
+  const int n_my = (total - (int)blockIdx.x + G - 1) / G;      // >= 1 (the launch uses G <= total)
+  const int KT = p.K >> 6;
+  const long NT = (long)n_my * KT;
+  const T* __restrict__ A = (const T*)p.A;
+  const T* __restrict__ W = (const T*)p.W;
+
+  auto origin = [&](int i, int& m0, int& n0) __attribute__((always_inline)) {
+    const int logical = xcd_remap((int)blockIdx.x + i * G, total);
+    m0 = (logical / tiles_n) << 8;
+    n0 = (logical % tiles_n) << 8;
+  };
+
+  // ---- staging stream -------------------------------------------------------------------------------------------
+  const int lrow = lane >> 3, lsc = lane & 7;
+  int arel[2], brel[2];                                // byte offsets of this lane's 16 bytes inside the tile's rows
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int lr = (wave * 2 + i) * 8 + lrow;
+    const int c = lsc ^ ((lr >> 1) & 7);
+    arel[i] = (((lr >> 6) * 128 + (lr & 63)) * (int)p.lda + c * 8) * 2;
+    brel[i] = (((lr >> 5) * 64 + (lr & 31)) * (int)p.ldw + c * 8) * 2;
+  }
+  const int a_half = 64 * (int)p.lda * 2, b_half = 32 * (int)p.ldw * 2;
+  __amdgpu_buffer_rsrc_t rA, rB;
+  int s_i = 0, s_kt = 0;
+  auto stream_tile = [&](int i) __attribute__((always_inline)) {
+    int m0, n0;
+    origin(i < n_my ? i : n_my - 1, m0, n0);           // past the end: restage the last tile (never read)
+    const int rows = min(p.M - m0, 256);
+    rA = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (long)m0 * p.lda), 0, rows * (int)p.lda * 2, 0x00020000);
+    rB = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (long)n0 * p.ldw), 0, 256 * (int)p.ldw * 2, 0x00020000);
+  };
+  auto stream_next = [&]() __attribute__((always_inline)) {
+    if (++s_kt == KT) { s_kt = 0; stream_tile(++s_i); }
+  };
+  // which: 0 = A0, 1 = A1, 2 = B0, 3 = B1 of the stream's k-tile; rows beyond M read as zeros (buffer bounds)
+  auto stage = [&](int db, int which) __attribute__((always_inline)) {
+    char* dst = smem + (db * 4 + which) * HALF + wave * 2048;
+    const int soff = s_kt * 128;
+    if (which < 2) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)dst, 16, arel[0] + which * a_half, soff, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)(dst + 1024), 16, arel[1] + which * a_half, soff, 0, 0);
+    } else {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_ptr_t)dst, 16, brel[0] + (which - 2) * b_half, soff, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_ptr_t)(dst + 1024), 16, brel[1] + (which - 2) * b_half, soff, 0, 0);
+    }
+  };
+  // bias of tile i -> LDS (one 1 KiB DMA by wave 0), double buffered on tile parity
+  auto stage_bias = [&](int i) __attribute__((always_inline)) {
+    if (wave == 0 && p.bias != nullptr && i < n_my) {
+      int m0, n0;
+      origin(i, m0, n0);
+      const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bias + n0), 0, 1024, 0x00020000);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)(smem + BIAS + (i & 1) * 1024), 16, lane * 16, 0, 0, 0);
+    }
+  };
+
+  // ---- fragments ------------------------------------------------------------------------------------------------
+  const int sw = ((lane & 31) >> 1) & 7;
+  int cof[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) cof[ks] = (lane & 31) * 128 + (((2 * ks + (lane >> 5)) ^ sw) << 4);
+  const int fa = wr * 64 * 128, fb = wc * 32 * 128;
+  bf16x8 aF[2][4], bS[2][4];                          // one A register set (replaced in place), two B sets
+  auto lds_a = [&](int db, int h, int i2, int ks) __attribute__((always_inline)) {
+    return *(const bf16x8*)(smem + (db * 4 + h) * HALF + fa + i2 * 4096 + cof[ks]);
+  };
+  auto lds_b = [&](int db, int g, int ks) __attribute__((always_inline)) {
+    return *(const bf16x8*)(smem + (db * 4 + 2 + g) * HALF + fb + cof[ks]);
+  };
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // ---- epilogue units --------------------------------------------------------------------------------------------
+  char* const slab = smem + SCRATCH + (wave & 3) * 4096;
+  const T* __restrict__ auxp = (const T*)p.aux;
+  const int prow = lane >> 3, pch = lane & 7;
+  float cs[COLSUM ? 8 : 1];
+#pragma unroll
+  for (int e = 0; e < (COLSUM ? 8 : 1); ++e) cs[e] = 0.f;
+  // unit u = rows [32u, 32u+32) of the wave tile of the tile at (em0, en0), bias buffer `par`
+  auto unit = [&](int u, int em0, int en0, int par) __attribute__((always_inline)) {
+    const char* bl = smem + BIAS + par * 1024 + wc * 256 + (lane >> 5) * 16;
+    const int row1 = lane & 31;
+#pragma unroll
+    for (int cb = 0; cb < 8; cb += BB) {
+      f32x4 b4[BB];
+#pragma unroll
+      for (int c = 0; c < BB; ++c) b4[c] = *(const f32x4*)(bl + (cb + c) * 32);   // columns 8c + 4 (lane>>5) .. +3 (zeros without a bias)
+#pragma unroll
+      for (int cc = 0; cc < BB; ++cc) {
+        const int c = cb + cc, jj = c >> 2, q = c & 3;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = acc[u][jj][4 * q + e] + b4[cc][e];
+          if (ACT == ACT_RELU) v[e] = v[e] > 0.f ? v[e] : 0.f;
+          acc[u][jj][4 * q + e] = 0.f;
+        }
+        const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+        *(bf16x4*)(slab + row1 * 128 + ((c ^ (row1 & 7)) << 4) + 8 * (lane >> 5)) = o;
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);                 // lgkmcnt(0)
+    const int ncol = en0 + wc * 64 + pch * 8;
+    const bool col_ok = ncol < p.n_store && !(p.dbg & 4);
+#pragma unroll
+    for (int it2 = 0; it2 < 2; ++it2) {                 // two rows in flight (mask loads, slab reads)
+      bf16x8 val[2], a8[2];
+      bool ok[2];
+      T* dst[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int row = (it2 * 2 + k) * 8 + prow;
+        const int m = em0 + wr * 128 + u * 32 + row;
+        ok[k] = col_ok && m < p.M;
+        dst[k] = (T*)p.Y + (long)m * p.ldy + ncol;
+        if (ACT == ACT_MASK) { if (ok[k]) a8[k] = *(const bf16x8*)(auxp + (long)m * p.ldaux + ncol); }
+        val[k] = *(const bf16x8*)(slab + row * 128 + ((pch ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        if (ok[k]) {
+          if (ACT == ACT_MASK) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (!((float)a8[k][e] > 0.f)) val[k][e] = (T)0.f;
+          }
+          *(bf16x8*)dst[k] = val[k];
+          if constexpr (COLSUM) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) cs[e] += (float)val[k][e];
+          }
+        }
+      }
+    }
+  };
+  auto flush_colsum = [&](int em0, int en0) __attribute__((always_inline)) {
+    if constexpr (!COLSUM) return;
+    const int ncol = en0 + wc * 64 + pch * 8;
+    const long srow = (long)((em0 >> 8) * 2 + wr) * p.N;
+#pragma unroll
+    for (int e = 0; e < (COLSUM ? 8 : 0); ++e) {
+      float c = cs[e];
+      c += __shfl_xor(c, 8, 64); c += __shfl_xor(c, 16, 64); c += __shfl_xor(c, 32, 64);
+      if (lane < 8 && ncol + e < p.n_store) p.colsum_ws[srow + ncol + e] = c;
+      cs[e] = 0.f;
+    }
+  };
+
+  // end of a load section (retire the DMA five halves back and this wave's LDS traffic) / of an MFMA section
+  auto end_load = [&]() __attribute__((always_inline)) {
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto end_mfma = [&]() __attribute__((always_inline)) {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- prologue: k-tiles 0 and 1 of the stream, bias of tiles 0 and 1 --------------------------------------------
+  if (p.bias == nullptr && tid < 128) *(f32x4*)(smem + BIAS + tid * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+  stream_tile(0);
+  stage_bias(0);
+  stage(0, 2); stage(0, 0); stage(0, 3); stage(0, 1);
+  stream_next();
+  stage(1, 3); stage(1, 0); stage(1, 2); stage(1, 1);
+  stream_next();
+  asm volatile("s_waitcnt vmcnt(10)" ::: "memory");     // B0, A0, B1 of k-tile 0 (and the bias) have landed
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    aF[0][ks] = lds_a(0, 0, 0, ks);
+    aF[1][ks] = lds_a(0, 0, 1, ks);
+    bS[0][ks] = lds_b(0, 0, ks);
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();            // wave row 1 runs half a phase behind wave row 0
+
+  int c_i = 0, c_kt = 0, m0, n0;
+  origin(0, m0, n0);
+  int em0 = 0, en0 = 0, epar = 0;
+  bool pending = false;
+
+  auto ktile = [&](auto db_tag) __attribute__((always_inline)) {
+    constexpr int db = decltype(db_tag)::value;
+    constexpr int F = db, S = 1 - db;                   // B half used first / second in this k-tile
+    const bool last = c_kt == KT - 1;
+    // P1: A0 x B_F; fetch B_S of this k-tile
+    stage(db, 2 + F);
+    if (pending) unit(2, em0, en0, epar);
+    end_load();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) bS[S][ks] = lds_b(db, S, ks);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      mma32(acc[0][F], bS[F][ks], aF[0][ks]);
+      mma32(acc[1][F], bS[F][ks], aF[1][ks]);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+    }
+    end_mfma();
+    // P2: A0 x B_S; every A0 fragment is replaced by the A1 fragment of the same position right after its last use
+    stage(db, 0);
+    if (pending) { unit(3, em0, en0, epar); flush_colsum(em0, en0); pending = false; }
+    end_load();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int i2 = 0; i2 < 2; ++i2) {
+        mma32(acc[i2][S], bS[S][ks], aF[i2][ks]);
+        aF[i2][ks] = lds_a(db, 1, i2, ks);
+      }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    end_mfma();
+    // P3: A1 x B_S; B_S is replaced by the first B half of the next k-tile
+    stage(db, 2 + S);
+    if (last) unit(0, m0, n0, c_i & 1);
+    end_load();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      mma32(acc[2][S], bS[S][ks], aF[0][ks]);
+      mma32(acc[3][S], bS[S][ks], aF[1][ks]);
+      bS[S][ks] = lds_b(db ^ 1, S, ks);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    end_mfma();
+    // P4: A1 x B_F; A1 is replaced by A0 of the next k-tile
+    stage(db, 1);
+    stream_next();
+    if (last) unit(1, m0, n0, c_i & 1);
+    if (c_kt == 0) stage_bias(c_i + 1);                 // its buffer was last read by units 2, 3 of tile c_i - 1 (P1, P2)
+    end_load();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int i2 = 0; i2 < 2; ++i2) {
+        mma32(acc[2 + i2][F], bS[F][ks], aF[i2][ks]);
+        aF[i2][ks] = lds_a(db ^ 1, 0, i2, ks);
+      }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    end_mfma();
+    if (last) {
+      pending = true; em0 = m0; en0 = n0; epar = c_i & 1;
+      c_kt = 0; ++c_i;
+      origin(c_i < n_my ? c_i : n_my - 1, m0, n0);
+    } else {
+      ++c_kt;
+    }
+  };
+  for (long t = 0; t < NT; t += 2) {
+    ktile(std::integral_constant<int, 0>{});
+    if (t + 1 < NT) ktile(std::integral_constant<int, 1>{});
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();            // matches the extra barrier of wave row 1
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the read-ahead of the stream before the LDS is released
+  // rows 64..127 of the last tile (wave rows take turns on the shared slabs)
+  if (wr == 0) { unit(2, em0, en0, epar); unit(3, em0, en0, epar); flush_colsum(em0, en0); __builtin_amdgcn_s_waitcnt(0xC07F); }
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) { unit(2, em0, en0, epar); unit(3, em0, en0, epar); flush_colsum(em0, en0); }
+}
+
 // out[n] += sum_r ws[r, n]  (bias gradient from the per-slab column sums of the data-gradient epilogue)
 __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ ws, int rows, int N, int n_store, float* __restrict__ out) {
   const int n = blockIdx.x * 256 + threadIdx.x;
@@ -420,6 +932,66 @@ static int launch_nt(const GemmNT& p, hipStream_t stream) {
   return snerf_check_launch();
 }
 
+static int launch_nt8(const GemmNT& p, hipStream_t stream) {
+  constexpr int LDS = 8 * 128 * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)gemm_nt8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  const int tiles_m = (p.M + 255) / 256;
+  const int tiles = tiles_m * (p.N / 256);
+  hipLaunchKernelGGL(gemm_nt8_kernel, dim3(tiles), dim3(512), LDS, stream, p);
+  if (p.fast_epi && p.colsum_ws != nullptr) {
+    const int rows = tiles_m * 2;
+    int ychunks = rows / 64;
+    ychunks = ychunks < 1 ? 1 : (ychunks > 64 ? 64 : ychunks);
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((p.n_store + 255) / 256, ychunks), dim3(256), 0, stream, p.colsum_ws, rows, p.N, p.n_store, p.colsum);
+  }
+  return snerf_check_launch();
+}
+
+static int launch_nt8p(const GemmNT& p, hipStream_t stream) {
+  constexpr int LDS = 8 * 128 * 128 + 4 * 4096 + 2048;
+  static bool attr_set = false;
+  static int n_cu = 256;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)gemm_nt8p_kernel<ACT_NONE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipFuncSetAttribute((const void*)gemm_nt8p_kernel<ACT_RELU, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipFuncSetAttribute((const void*)gemm_nt8p_kernel<ACT_NONE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipFuncSetAttribute((const void*)gemm_nt8p_kernel<ACT_MASK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipFuncSetAttribute((const void*)gemm_nt8p_kernel<ACT_MASK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      n_cu = prop.multiProcessorCount;
+    attr_set = true;
+  }
+  const int tiles_m = (p.M + 255) / 256;
+  const int tiles = tiles_m * (p.N / 256);
+  const int grid = tiles < n_cu ? tiles : n_cu;
+  const bool cs = p.colsum_ws != nullptr;
+  const dim3 g(grid), b(512);
+  if (p.act == ACT_MASK) {
+    if (cs) hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_MASK, true>), g, b, LDS, stream, p);
+    else hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_MASK, false>), g, b, LDS, stream, p);
+  } else if (cs) {
+    if (p.act != ACT_NONE) return SNERF_ERR_ARG;
+    hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_NONE, true>), g, b, LDS, stream, p);
+  } else if (p.act == ACT_RELU) {
+    hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_RELU, false>), g, b, LDS, stream, p);
+  } else {
+    hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_NONE, false>), g, b, LDS, stream, p);
+  }
+  if (p.colsum_ws != nullptr) {
+    const int rows = tiles_m * 2;
+    int ychunks = rows / 64;
+    ychunks = ychunks < 1 ? 1 : (ychunks > 64 ? 64 : ychunks);
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((p.n_store + 255) / 256, ychunks), dim3(256), 0, stream, p.colsum_ws, rows, p.N, p.n_store, p.colsum);
+  }
+  return snerf_check_launch();
+}
+
 extern "C" int snerf_linear_fwd(const void* A, long lda, const void* W, long ldw, const float* bias, void* Y, long ldy,
                                 const void* aux, long ldaux, float* colsum, float* colsum_ws, int M, int N, int K, int n_store,
                                 int act, int dtype, int out_f32, int variant, void* stream) {
@@ -442,7 +1014,12 @@ extern "C" int snerf_linear_fwd(const void* A, long lda, const void* W, long ldw
   GemmNT p{A, lda, W, ldw, bias, Y, ldy, aux, ldaux, colsum, M, N, K, n_store, act, out_f32, vec, colsum_ws, fast, (variant >> 4) & 7};
   variant &= 15;
   hipStream_t s = (hipStream_t)stream;
-  // variant: 0 = 128x128 block-issue, 1 = 256x256 block-issue, 2 = 128x128 interleaved, 3 = 256x256 interleaved
+  // variant: 0 = 128x128 block-issue, 1 = 256x256 block-issue, 2 = 128x128 interleaved, 3 = 256x256 interleaved,
+  //          4 = 256x256 8-phase (bf16, N % 256 == 0; other shapes take the 128x128 kernel)
+  //          8 = 256x256 persistent 8-phase (bf16, N % 256 == 0, K >= 128, 16-byte epilogue; else as variant 4)
+  if (dtype == SNERF_DT_BF16 && (variant & 8) && N % 256 == 0 && K >= 128 && fast && !(colsum != nullptr && act == ACT_RELU) && (lda * 2 * 256 < (1L << 31)) && (ldw * 2 * 256 < (1L << 31)))
+    return launch_nt8p(p, s);
+  if (dtype == SNERF_DT_BF16 && (variant & 12) && N % 256 == 0) return launch_nt8(p, s);
   if (dtype == SNERF_DT_F32) return (variant & 2) ? launch_nt<float, 128, 128, 2, 2, true>(p, s) : launch_nt<float, 128, 128, 2, 2, false>(p, s);
   if ((variant & 1) && N % 256 == 0) return (variant & 2) ? launch_nt<__bf16, 256, 256, 2, 4, true>(p, s) : launch_nt<__bf16, 256, 256, 2, 4, false>(p, s);
   return (variant & 2) ? launch_nt<__bf16, 128, 128, 2, 2, true>(p, s) : launch_nt<__bf16, 128, 128, 2, 2, false>(p, s);
