@@ -107,7 +107,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--rays", type=int, default=4096, help="rays per GPU per step")
     ap.add_argument("--compute", default="bf16", choices=["bf16", "f32"])
-    ap.add_argument("--variant", type=int, default=1, help="GEMM tile variant: 1 = 256x256 (default), 0 = 128x128")
+    ap.add_argument("--variant", type=int, default=8, help="NT GEMM variant: 8 = persistent 8-phase 256x256 (default), 4 = 8-phase, 1 = 256x256 block-issue, 0 = 128x128")
     ap.add_argument("--no-frame", action="store_true", help="skip the 1600x900 frame render")
     ap.add_argument("--no-cpu", action="store_true", help="skip the host-CPU baseline")
     ap.add_argument("--cpu-rays", type=int, default=192)
@@ -170,7 +170,7 @@ def main():
         skipenc = 2.0 * (P1 - 1) * 96 * HIDDEN + 2.0 * (P1 - 1) * 27 * 128       # d/d(encoding) columns of the concat layers
         alg_nt = n * (fwd + fwd - first - skipenc)                               # fwd + dgrad through gemm_nt, per step
         achieved = alg_nt / (gemm_ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": ("gemm_nt_kernel<bf16,256,256,2,4>" if args.variant == 1 else "gemm_nt_kernel<bf16,128,128,2,2>") if args.compute == "bf16" else "gemm_nt_kernel<f32,128,128,2,2>",
+        roofline = {"bound": "mfma", "kernel": {8: "gemm_nt8p_kernel (bf16, 256x256 persistent 8-phase)", 4: "gemm_nt8_kernel (bf16, 256x256 8-phase)", 1: "gemm_nt_kernel<bf16,256,256,2,4>"}.get(args.variant, "gemm_nt_kernel<bf16,128,128,2,2>") if args.compute == "bf16" else "gemm_nt_kernel<f32,128,128,2,2>",
                     "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS if args.compute == "bf16" else 157.3, "unit": "TFLOP/s",
                     "frac": round(achieved / (PEAK_BF16_TFLOPS if args.compute == "bf16" else 157.3), 4), "traffic": None,
                     "launches_per_step": launches, "avg_launch_ms": round(gemm_ms / launches, 4), "kernel_ms_per_step": round(gemm_ms, 3),

@@ -607,7 +607,7 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
   constexpr int HALF = 128 * 128;                      // bytes per half-tile
   constexpr int SCRATCH = 8 * HALF;                    // 4 x 4 KiB transposition slabs
   constexpr int BIAS = SCRATCH + 4 * 4096;             // 2 x 1 KiB bias vectors (tile parity)
-  constexpr int BB = 2;                                // bias quads fetched per batch in the epilogue units
+  constexpr int BB = (ACT == ACT_MASK && COLSUM) ? 1 : 2;   // bias quads fetched per batch in the epilogue units (register budget)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
@@ -692,22 +692,40 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  int c_i = 0, c_kt = 0;                              // tile / k-tile the MFMAs are working on
   // ---- epilogue units --------------------------------------------------------------------------------------------
   char* const slab = smem + SCRATCH + (wave & 3) * 4096;
   const T* __restrict__ auxp = (const T*)p.aux;
-  const int prow = lane >> 3, pch = lane & 7;
   float cs[COLSUM ? 8 : 1];
 #pragma unroll
   for (int e = 0; e < (COLSUM ? 8 : 1); ++e) cs[e] = 0.f;
   // unit u = rows [32u, 32u+32) of the wave tile of the tile at (em0, en0), bias buffer `par`
   auto unit = [&](int u, int em0, int en0, int par) __attribute__((always_inline)) {
-    const char* bl = smem + BIAS + par * 1024 + wc * 256 + (lane >> 5) * 16;
-    const int row1 = lane & 31;
+    // everything lane-dependent is derived from a loop-variant spelling of the lane id, so that none of the unit's address
+    // arithmetic is hoisted into (and kept alive across) the k-loop, where every register is spoken for
+    int zero;
+    asm volatile("s_lshr_b32 %0, %1, 30" : "=s"(zero) : "s"(c_kt));
+    const int ln = lane | zero;
+    const int hi = ln >> 5, row1 = ln & 31, prow = ln >> 3, pch = ln & 7;
+    const int ncol = en0 + wc * 64 + pch * 8;
+    const bool col_ok = ncol < p.n_store && !(p.dbg & 4);
+    const int mbase = em0 + wr * 128 + u * 32 + prow;
+    // the ReLU mask source first: these loads sit behind the staging DMA in the (in-order) vmcnt queue
+    bf16x8 a8[4];
+    if (ACT == ACT_MASK) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        int m = mbase + it * 8;
+        m = m < p.M ? m : p.M - 1;
+        a8[it] = *(const bf16x8*)(auxp + (long)m * p.ldaux + (col_ok ? ncol : 0));
+      }
+    }
+    const char* bl = smem + BIAS + par * 1024 + wc * 256 + hi * 16;
 #pragma unroll
     for (int cb = 0; cb < 8; cb += BB) {
       f32x4 b4[BB];
 #pragma unroll
-      for (int c = 0; c < BB; ++c) b4[c] = *(const f32x4*)(bl + (cb + c) * 32);   // columns 8c + 4 (lane>>5) .. +3 (zeros without a bias)
+      for (int c = 0; c < BB; ++c) b4[c] = *(const f32x4*)(bl + (cb + c) * 32);   // columns 8c + 4 hi .. +3 (zeros without a bias)
 #pragma unroll
       for (int cc = 0; cc < BB; ++cc) {
         const int c = cb + cc, jj = c >> 2, q = c & 3;
@@ -719,51 +737,41 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
           acc[u][jj][4 * q + e] = 0.f;
         }
         const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-        *(bf16x4*)(slab + row1 * 128 + ((c ^ (row1 & 7)) << 4) + 8 * (lane >> 5)) = o;
+        *(bf16x4*)(slab + row1 * 128 + ((c ^ (row1 & 7)) << 4) + 8 * hi) = o;
       }
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);                 // lgkmcnt(0)
-    const int ncol = en0 + wc * 64 + pch * 8;
-    const bool col_ok = ncol < p.n_store && !(p.dbg & 4);
 #pragma unroll
-    for (int it2 = 0; it2 < 2; ++it2) {                 // two rows in flight (mask loads, slab reads)
-      bf16x8 val[2], a8[2];
-      bool ok[2];
-      T* dst[2];
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 8 + prow;
+      const int m = mbase + it * 8;
+      bf16x8 val = *(const bf16x8*)(slab + row * 128 + ((pch ^ (row & 7)) << 4));
+      if (ACT == ACT_MASK) {
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int row = (it2 * 2 + k) * 8 + prow;
-        const int m = em0 + wr * 128 + u * 32 + row;
-        ok[k] = col_ok && m < p.M;
-        dst[k] = (T*)p.Y + (long)m * p.ldy + ncol;
-        if (ACT == ACT_MASK) { if (ok[k]) a8[k] = *(const bf16x8*)(auxp + (long)m * p.ldaux + ncol); }
-        val[k] = *(const bf16x8*)(slab + row * 128 + ((pch ^ (row & 7)) << 4));
+        for (int e = 0; e < 8; ++e) if (!((float)a8[it][e] > 0.f)) val[e] = (T)0.f;
       }
+      if (col_ok && m < p.M) {
+        *(bf16x8*)((T*)p.Y + (long)m * p.ldy + ncol) = val;
+        if constexpr (COLSUM) {
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        if (ok[k]) {
-          if (ACT == ACT_MASK) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) if (!((float)a8[k][e] > 0.f)) val[k][e] = (T)0.f;
-          }
-          *(bf16x8*)dst[k] = val[k];
-          if constexpr (COLSUM) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) cs[e] += (float)val[k][e];
-          }
+          for (int e = 0; e < 8; ++e) cs[e] += (float)val[e];
         }
       }
     }
   };
   auto flush_colsum = [&](int em0, int en0) __attribute__((always_inline)) {
     if constexpr (!COLSUM) return;
+    int zero;
+    asm volatile("s_lshr_b32 %0, %1, 30" : "=s"(zero) : "s"(c_kt));
+    const int ln = lane | zero;
+    const int pch = ln & 7;
     const int ncol = en0 + wc * 64 + pch * 8;
     const long srow = (long)((em0 >> 8) * 2 + wr) * p.N;
 #pragma unroll
     for (int e = 0; e < (COLSUM ? 8 : 0); ++e) {
       float c = cs[e];
       c += __shfl_xor(c, 8, 64); c += __shfl_xor(c, 16, 64); c += __shfl_xor(c, 32, 64);
-      if (lane < 8 && ncol + e < p.n_store) p.colsum_ws[srow + ncol + e] = c;
+      if (ln < 8 && ncol + e < p.n_store) p.colsum_ws[srow + ncol + e] = c;
       cs[e] = 0.f;
     }
   };
@@ -803,7 +811,7 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();            // wave row 1 runs half a phase behind wave row 0
 
-  int c_i = 0, c_kt = 0, m0, n0;
+  int m0, n0;
   origin(0, m0, n0);
   int em0 = 0, en0 = 0, epar = 0;
   bool pending = false;

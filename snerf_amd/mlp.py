@@ -64,7 +64,7 @@ def _w2(t):
 class _Net:
     """Shared machinery: packing, buffer helpers, layer calls."""
 
-    def __init__(self, arena: ParamArena, prefix: str, dt: int, variant: int = 1):
+    def __init__(self, arena: ParamArena, prefix: str, dt: int, variant: int = 8):
         self.a, self.pre, self.dt, self.variant = arena, prefix, dt, variant
         self.g = gran(dt)
         self.tdt = ops.torch_dtype(dt)
@@ -147,7 +147,7 @@ class ClassicNeRFNet(_Net):
     Buffers: E [M, Pw] embedding (63 + pad); SK [M, Pw + W] = [embedding | layer-skip output];
     V [M, W + Vw] = [feature | view embedding (27 + pad)]; OUT [M,4] fp32 = [rgb | alpha]."""
 
-    def __init__(self, arena, prefix, dt, D=8, W=256, input_ch=63, input_ch_views=27, skips=(4,), variant=1):
+    def __init__(self, arena, prefix, dt, D=8, W=256, input_ch=63, input_ch_views=27, skips=(4,), variant=8):
         super().__init__(arena, prefix, dt, variant)
         assert len(skips) == 1 and 0 <= skips[0] < D - 1 and W % self.g == 0 and (W // 2) % self.g == 0
         self.D, self.Wd, self.ic, self.icv, self.skip = D, W, input_ch, input_ch_views, skips[0]
@@ -260,7 +260,7 @@ class ClassicNeRFNet(_Net):
 class MipProposalNet(_Net):
     """proposal MLP: n_layers x (Linear+ReLU) width H, density head -> [M,1] fp32 (models.py:299-325)."""
 
-    def __init__(self, arena, prefix, dt, hidden=256, n_layers=4, feature_dim=96, variant=1):
+    def __init__(self, arena, prefix, dt, hidden=256, n_layers=4, feature_dim=96, variant=8):
         super().__init__(arena, prefix, dt, variant)
         assert hidden % self.g == 0
         self.H, self.L, self.fd, self.Ew = hidden, n_layers, feature_dim, roundup(feature_dim, self.g)
@@ -323,7 +323,7 @@ class MipNerfNet(_Net):
              CB [M, H + Cw] = [bottleneck | view encoding (+pad)]."""
 
     def __init__(self, arena, prefix, dt, hidden=1024, n_layers=8, skip_layer=4, feature_dim=96, cond_dim=27,
-                 n_cond=3, cond_units=128, variant=1):
+                 n_cond=3, cond_units=128, variant=8):
         super().__init__(arena, prefix, dt, variant)
         assert hidden % self.g == 0 and cond_units % self.g == 0 and n_layers > skip_layer + 1
         self.H, self.L, self.skip, self.fd, self.cd, self.nc, self.cu = hidden, n_layers, skip_layer, feature_dim, cond_dim, n_cond, cond_units
@@ -454,7 +454,7 @@ class ZipPropNet(_Net):
     """PropMLP on the waymo.gin branch (internal/models.py:425-427, 481-519 with disable_rgb): features [P, L*C (+pad)]
     -> Linear 64 + ReLU -> Linear 1 = raw density [P,1] fp32."""
 
-    def __init__(self, arena, prefix, dt, feat_dim, hidden=64, variant=1):
+    def __init__(self, arena, prefix, dt, feat_dim, hidden=64, variant=8):
         super().__init__(arena, prefix, dt, variant)
         assert hidden % self.g == 0
         self.fd, self.H, self.Fw = feat_dim, hidden, roundup(feat_dim, self.g)
@@ -501,7 +501,7 @@ class ZipNerfNet(_Net):
     cat([., x, dir_enc]) (skip_layer_dir = 0) -> 256 ReLU -> rgb 3.
     Buffer SB [P, 256 + 256 + Dw] = [lin0 output | x | dir_enc (+pad)]: lin0 reads columns 256.. in place, lin1 the whole row."""
 
-    def __init__(self, arena, prefix, dt, feat_dim=40, hidden=64, bottleneck=256, width=256, dir_dim=9, variant=1):
+    def __init__(self, arena, prefix, dt, feat_dim=40, hidden=64, bottleneck=256, width=256, dir_dim=9, variant=8):
         super().__init__(arena, prefix, dt, variant)
         assert hidden % self.g == 0 and bottleneck % self.g == 0 and width % self.g == 0
         self.fd, self.H, self.Bw, self.Wd, self.dd = feat_dim, hidden, bottleneck, width, dir_dim
