@@ -1187,6 +1187,207 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// TN kernel, 8-phase schedule (bf16): dW[n0:n0+256, k0:k0+256] += dZ[mbeg:mend, n-tile]^T . X[mbeg:mend, k-tile]
+//
+// Same machinery as gemm_nt8p_kernel (half-tiles, quadrant phases, fragments prefetched in place during the MFMA
+// sections, staging two k-tiles ahead with five halves in flight, two wave rows half a phase apart), with the
+// reduction axis on the ROWS of both operands: a k-tile is 64 rows of dZ and of X; a half-tile is 64 rows x 128 columns
+// (256-byte LDS rows, 16-byte chunk c of row r at position c ^ 4 (r & 3)); MFMA fragments come from
+// ds_read_b64_tr_b16 (two per fragment).  One workgroup owns one 256 x 256 tile of dW for one slice of M and adds it
+// with fp32 atomics at the end; rows past the slice read as zeros through the buffer descriptor.
+//     dZ half h, local column lc  <->  tile column (lc>>6)*128 + h*64 + (lc&63)     (wave row wr = lc>>6)
+//     X  half g, local column lc  <->  tile column (lc>>5)*64  + g*32 + (lc&31)     (wave col wc = lc>>5)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void gemm_tn8_kernel(GemmTN p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __bf16 T;
+  typedef __attribute__((address_space(3))) bf16x4* lds_b4;
+  constexpr int HALF = 64 * 256;                       // bytes per half-tile
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int tiles_k = (p.K + 255) >> 8, tiles_n = (p.N + 255) >> 8;
+  const int ntile = tiles_k * tiles_n;
+  const int id = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int tile = id % ntile, chunk = id / ntile;     // workgroups of one M slice are neighbours on an XCD
+  const int n0 = (tile / tiles_k) << 8, k0 = (tile % tiles_k) << 8;
+  const int mbeg = chunk * p.m_chunk;
+  const int rows = min(p.M, mbeg + p.m_chunk) - mbeg;
+  const int KT = (rows + 63) >> 6;
+  const T* __restrict__ Z = (const T*)p.Z + (long)mbeg * p.ldz + n0;
+  const T* __restrict__ X = (const T*)p.X + (long)mbeg * p.ldx + k0;
+  const int zbytes = rows * (int)p.ldz * 2 - n0 * 2, xbytes = rows * (int)p.ldx * 2 - k0 * 2;   // to the end of the slice's last row
+  const int zstep = 64 * (int)p.ldz * 2, xstep = 64 * (int)p.ldx * 2;
+
+  // ---- staging stream: wave w owns pieces 2w, 2w+1 (4 rows x 256 B) of every half-tile -------------------------------
+  const int lrow = lane >> 4, lch = lane & 15;
+  const int lc = (lch ^ (4 * lrow)) * 8;               // logical column of this lane's 16 bytes inside the half
+  const int zcol = ((lc >> 6) * 128 + (lc & 63)) * 2, xcol = ((lc >> 5) * 64 + (lc & 31)) * 2;
+  int zrel[2], xrel[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = (wave * 2 + i) * 4 + lrow;
+    zrel[i] = r * (int)p.ldz * 2 + zcol;
+    xrel[i] = r * (int)p.ldx * 2 + xcol;
+  }
+  int s_kt = 0;
+  // which: 0 = Z0, 1 = Z1, 2 = X0, 3 = X1 of the stream's k-tile
+  auto stage = [&](int db, int which) __attribute__((always_inline)) {
+    char* dst = smem + (db * 4 + which) * HALF + wave * 2048;
+    if (which < 2) {
+      const int off = s_kt * zstep;
+      const int left = zbytes - off;
+      const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)Z + off), 0, left > 0 ? left : 0, 0x00020000);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)dst, 16, zrel[0] + which * 128, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)(dst + 1024), 16, zrel[1] + which * 128, 0, 0, 0);
+    } else {
+      const int off = s_kt * xstep;
+      const int left = xbytes - off;
+      const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)X + off), 0, left > 0 ? left : 0, 0x00020000);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)dst, 16, xrel[0] + (which - 2) * 64, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)(dst + 1024), 16, xrel[1] + (which - 2) * 64, 0, 0, 0);
+    }
+  };
+
+  // ---- fragments: per 16-lane group, lane pl supplies the address of 4 consecutive bf16 of row (pl>>2) of a 4-row block and
+  // receives column pl of that 4 x 16 block; two reads (rows +0..3, +4..7) make the 8 reduction indices of an MFMA operand
+  const int g4 = lane >> 4, pl = lane & 15, prow = pl >> 2;
+  const int frow = (8 * (g4 >> 1) + prow) * 256;       // + ks * 16 * 256 (+ 4 * 256 for the second read)
+  const int fsub = ((pl & 1) << 3);
+  int zc[2], xc1;                                      // swizzled chunk byte offsets of the wave's 32-column blocks
+#pragma unroll
+  for (int i2 = 0; i2 < 2; ++i2) zc[i2] = ((((wr * 64 + i2 * 32 + 16 * (g4 & 1)) >> 3) + ((pl & 3) >> 1)) ^ (4 * prow)) << 4;
+  xc1 = ((((wc * 32 + 16 * (g4 & 1)) >> 3) + ((pl & 3) >> 1)) ^ (4 * prow)) << 4;
+  bf16x8 aF[2][4], bS[2][4];
+  // The transposing reads are issued as inline asm: hipcc orders the builtin behind ALL outstanding LDS-DMA (vmcnt(0) in
+  // every phase, which empties the staging pipeline).  Their results are first used after the lgkmcnt(0) + sched_barrier
+  // that ends the NEXT load section; hardware returns LDS data in order.
+  const unsigned lds0 = (unsigned)(size_t)smem;
+  auto lds_frag = [&](unsigned addr) __attribute__((always_inline)) {
+    bf16x4 lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:1024" : "=&v"(lo), "=&v"(hi) : "v"(addr));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+  const unsigned za[2] = {lds0 + frow + zc[0] + fsub, lds0 + frow + zc[1] + fsub};
+  const unsigned xa = lds0 + frow + xc1 + fsub;
+  auto lds_a = [&](int db, int h, int i2, int ks) __attribute__((always_inline)) {
+    return lds_frag(za[i2] + (db * 4 + h) * HALF + ks * 4096);
+  };
+  auto lds_b = [&](int db, int g, int ks) __attribute__((always_inline)) {
+    return lds_frag(xa + (db * 4 + 2 + g) * HALF + ks * 4096);
+  };
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto end_load = [&]() __attribute__((always_inline)) {
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto end_mfma = [&]() __attribute__((always_inline)) {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- prologue: k-tiles 0 and 1 (tiles past the slice read zeros) ------------------------------------------------------
+  stage(0, 2); stage(0, 0); stage(0, 3); stage(0, 1);
+  ++s_kt;
+  stage(1, 3); stage(1, 0); stage(1, 2); stage(1, 1);
+  ++s_kt;
+  asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    aF[0][ks] = lds_a(0, 0, 0, ks);
+    aF[1][ks] = lds_a(0, 0, 1, ks);
+    bS[0][ks] = lds_b(0, 0, ks);
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();
+
+  auto ktile = [&](auto db_tag) __attribute__((always_inline)) {
+    constexpr int db = decltype(db_tag)::value;
+    constexpr int F = db, S = 1 - db;
+    // P1: Z0 x X_F; fetch X_S
+    stage(db, 2 + F);
+    end_load();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bS[S][ks] = lds_b(db, S, ks);
+      mma32(acc[0][F], aF[0][ks], bS[F][ks]);
+      mma32(acc[1][F], aF[1][ks], bS[F][ks]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    end_mfma();
+    // P2: Z0 x X_S; Z0 fragments replaced by Z1 in place
+    stage(db, 0);
+    end_load();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int i2 = 0; i2 < 2; ++i2) {
+        mma32(acc[i2][S], aF[i2][ks], bS[S][ks]);
+        aF[i2][ks] = lds_a(db, 1, i2, ks);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    end_mfma();
+    // P3: Z1 x X_S; X_S replaced by the first X half of the next k-tile
+    stage(db, 2 + S);
+    end_load();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      mma32(acc[2][S], aF[0][ks], bS[S][ks]);
+      mma32(acc[3][S], aF[1][ks], bS[S][ks]);
+      bS[S][ks] = lds_b(db ^ 1, S, ks);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    end_mfma();
+    // P4: Z1 x X_F; Z1 replaced by Z0 of the next k-tile
+    stage(db, 1);
+    ++s_kt;
+    end_load();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int i2 = 0; i2 < 2; ++i2) {
+        mma32(acc[2 + i2][F], aF[i2][ks], bS[F][ks]);
+        aF[i2][ks] = lds_a(db ^ 1, 0, i2, ks);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    end_mfma();
+  };
+  for (int t = 0; t < KT; t += 2) {
+    ktile(std::integral_constant<int, 0>{});
+    if (t + 1 < KT) ktile(std::integral_constant<int, 1>{});
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // D[i' = n][j' = k]: j' = lane&31, i' = (r&3) + 8*(r>>2) + 4*(lane>>5); acc[i][j]: n block i, k block j of the wave tile
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = k0 + wc * 64 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (n < p.n_valid && k < p.k_valid) atomicAdd(p.dW + (long)n * p.ldw + k, acc[i][j][r]);
+      }
+    }
+}
+
 extern "C" int snerf_linear_wgrad(const void* Z, long ldz, const void* X, long ldx, float* dW, long ldw, const void* zeros,
                                   int M, int N, int K, int n_valid, int k_valid, int dtype, int variant, void* stream) {
   if (M <= 0) return SNERF_OK;
@@ -1199,6 +1400,30 @@ extern "C" int snerf_linear_wgrad(const void* Z, long ldz, const void* X, long l
   m_chunk = ((m_chunk + 255) / 256) * 256;
   if (m_chunk < 1024) m_chunk = 1024;
   chunks = (M + m_chunk - 1) / m_chunk;
+  // variant 2 (bf16): 256 x 256 tiles, 8-phase schedule; M is cut into as many slices as keep every CU busy
+  if ((variant & 2) && dtype == SNERF_DT_BF16 && N % 256 == 0 && K >= 256 && M >= 4096 && ldz * 2 * 65 < (1L << 31) && ldx * 2 * 65 < (1L << 31)) {
+    static bool attr_set = false;
+    static int n_cu = 256;
+    if (!attr_set) {
+      hipFuncSetAttribute((const void*)gemm_tn8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 64 * 256);
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+        n_cu = prop.multiProcessorCount;
+      attr_set = true;
+    }
+    const int t8 = (N / 256) * ((K + 255) / 256);
+    int ch = n_cu / t8;
+    ch = ch < 1 ? 1 : ch;
+    long mc = ((long)M + ch - 1) / ch;
+    mc = ((mc + 127) / 128) * 128;                    // whole k-tile pairs
+    const long lim = (1L << 30) / ((ldz > ldx ? ldz : ldx) * 2);   // slice bytes stay inside 32-bit buffer offsets
+    if (mc > lim) mc = lim / 128 * 128;
+    ch = (int)((M + mc - 1) / mc);
+    GemmTN p8{Z, ldz, X, ldx, dW, ldw, zeros, M, N, K, n_valid, k_valid, (int)mc};
+    hipLaunchKernelGGL(gemm_tn8_kernel, dim3(t8 * ch), dim3(512), 8 * 64 * 256, (hipStream_t)stream, p8);
+    return snerf_check_launch();
+  }
   GemmTN p{Z, ldz, X, ldx, dW, ldw, zeros, M, N, K, n_valid, k_valid, m_chunk};
   const int lds = 2 * 2 * 8192;
   dim3 grid(tiles, chunks);

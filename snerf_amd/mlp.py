@@ -129,7 +129,7 @@ class _Net:
 
     def wgrad(self, name, dZ, X, n_valid, k_valid, wcol=0):
         gw = self.gW(name)
-        ops.linear_wgrad(dZ, X, gw[:, wcol:], n_valid, k_valid, self.dt, variant=1)   # 1: transposing LDS reads where tiles are whole
+        ops.linear_wgrad(dZ, X, gw[:, wcol:], n_valid, k_valid, self.dt, variant=3)   # 2: 8-phase 256x256 tiles where they fit, else 1: transposing LDS reads
 
     def head_grad(self, d_raw_f32, C):
         """fp32 head gradient [M,C] -> compute-dtype buffer padded to the tile granularity."""

@@ -77,13 +77,14 @@ def test_linear_dgrad_mask_colsum(ops, dt, variant, M):
 
 
 @pytest.mark.parametrize("dt,M,N,K,nv,kv", [(0, 700, 96, 128, 90, 127), (0, 5000, 256, 1120, 256, 1120), (1, 700, 64, 128, 3, 128),
-                                            (1, 5000, 256, 320, 256, 283), (1, 3000, 1024, 1152, 1024, 1120), (1, 4100, 256, 128, 256, 96), (1, 2077, 128, 1024, 128, 1024)])
+                                            (1, 5000, 256, 320, 256, 283), (1, 3000, 1024, 1152, 1024, 1120), (1, 4100, 256, 128, 256, 96), (1, 2077, 128, 1024, 128, 1024),
+                                            (1, 70001, 1024, 1152, 1024, 1120), (1, 9000, 256, 320, 256, 283), (1, 33000, 512, 256, 500, 256)])
 def test_linear_wgrad(ops, dt, M, N, K, nv, kv):
     tdt = ops.torch_dtype(dt)
     dZ = gen(M, N, seed=7).to(tdt).cuda()
     X = gen(M, K, seed=8).to(tdt).cuda()
     ref = 1.0 + (dZ.double().cpu().t() @ X.double().cpu())[:nv, :kv]
-    for variant in (0, 1):                                          # 1 = transposing LDS reads (bf16, whole 128-column tiles)
+    for variant in (0, 1, 2):                                       # 1 = transposing LDS reads (bf16, whole 128-column tiles), 2 = 8-phase 256x256
         dW = torch.ones(nv, kv, dtype=torch.float32, device="cuda")   # accumulates on top of existing content
         ops.linear_wgrad(dZ, X, dW, nv, kv, dt, variant=variant)
         close(dW, ref, 1e-4, 1e-3 * (M / 1000) ** 0.5, f"wgrad variant {variant}")

@@ -49,5 +49,27 @@ def main():
         print(f"NT fwd K=1152 variant={v:3d}: {ms:7.3f} ms {2.0 * M * N * 1152 / ms / 1e9:8.1f} TF/s", flush=True)
 
 
+def wgrad():
+    dt = ops.BF16
+    for (M, N, K) in ((524288, 1024, 1024), (524288, 1024, 1152), (262144, 256, 256), (528384, 1024, 1088)):
+        dZ = (torch.rand(M, N, device="cuda") * 2 - 1).to(torch.bfloat16)
+        X = (torch.rand(M, K, device="cuda") * 2 - 1).to(torch.bfloat16)
+        ref = None
+        for v in (1, 2):
+            dW = torch.zeros(N, K, device="cuda")
+            ops.linear_wgrad(dZ, X, dW, N, K, dt, variant=v)
+            torch.cuda.synchronize()
+            if ref is None:
+                ref = dW.clone()
+            else:
+                err = float((dW - ref).abs().max() / ref.abs().max())
+                print(f"TN M={M} N={N} K={K}: variant 2 vs 1 max rel diff {err:.2e}", flush=True)
+            ms = timeit(lambda: ops.linear_wgrad(dZ, X, dW, N, K, dt, variant=v), reps=10)
+            print(f"TN M={M} N={N} K={K} variant={v}: {ms:7.3f} ms {2.0 * M * N * K / ms / 1e9:8.1f} TF/s", flush=True)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "wgrad":
+        wgrad()
+        sys.exit(0)
     main()
