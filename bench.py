@@ -100,6 +100,62 @@ def cpu_baseline(n_rays, model_sd, rays, seed=0):
     return n_rays / dt_s, dt_s, ret[1][0].detach(), ret[1][1].detach()
 
 
+def eager_baseline(model_sd, rays, n_rays, steps, bf16):
+    """The same train step as plain PyTorch-ROCm eager ops on the SAME GPU (the oracle's torch restatement of the reference
+    model moved to cuda; its numpy resampler replaced by the equivalent torch ops), autograd backward + torch.optim.Adam.
+    A reported baseline for BASELINE.json's ">= 2x over the PyTorch-ROCm eager path" target, never part of the product."""
+    from oracle import mip as om
+    dev = rays.origins.device
+
+    def resample_torch(s_vals, weights, u, resample_padding=0.01):
+        w = weights.detach()
+        wp = torch.cat([w[..., :1], w, w[..., -1:]], -1)
+        wmax = torch.maximum(wp[..., :-1], wp[..., 1:])
+        w = 0.5 * (wmax[..., :-1] + wmax[..., 1:]) + resample_padding
+        wsum = w.sum(-1, keepdim=True)
+        pad = torch.clamp(1e-5 - wsum, min=0)
+        w = w + pad / w.shape[-1]
+        wsum = wsum + pad
+        cdf = torch.clamp(torch.cumsum((w / wsum)[..., :-1], -1), max=1.0)
+        cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf, torch.ones_like(cdf[..., :1])], -1)
+        uu = u.to(dev).expand(s_vals.shape[0], -1).contiguous()
+        idx = torch.searchsorted(cdf, uu, right=True) - 1
+        idx = idx.clamp(0, cdf.shape[-1] - 2)
+        b0, b1 = torch.gather(s_vals, -1, idx), torch.gather(s_vals, -1, idx + 1)
+        c0, c1 = torch.gather(cdf, -1, idx), torch.gather(cdf, -1, idx + 1)
+        t = torch.clip(torch.nan_to_num((uu - c0) / (c1 - c0), 0.0), 0, 1)
+        return b0 + t * (b1 - b0), idx
+
+    saved, om.warp_resample_s = om.warp_resample_s, resample_torch
+    prev = torch.get_default_device() if hasattr(torch, "get_default_device") else None
+    torch.set_default_device(dev)
+    try:
+        pr = {k: v.detach().float().clone().requires_grad_(True) for k, v in model_sd.items()}
+        rc = {k: getattr(rays, k)[:n_rays].detach().float() for k in rays._fields}
+        tgt = torch.rand(n_rays, 3, device=dev)
+        opt = torch.optim.Adam(list(pr.values()), lr=5e-4)
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
+                ret = om.mipnerf_forward(pr, rc, S0, P1)
+            loss = ((ret[1][0].float() - tgt) ** 2).mean() + 0.2 * (1.0 / ret[1][1]).mean() + 0.04 * (1.0 / ret[0][1]).mean()
+            loss.backward()
+            opt.step()
+
+        step(); step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dt_s = (time.perf_counter() - t0) / steps
+    finally:
+        om.warp_resample_s = saved
+        torch.set_default_device(prev if prev is not None else "cpu")
+    return n_rays / dt_s, dt_s * 1e3
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -111,6 +167,7 @@ def main():
     ap.add_argument("--no-frame", action="store_true", help="skip the 1600x900 frame render")
     ap.add_argument("--no-cpu", action="store_true", help="skip the host-CPU baseline")
     ap.add_argument("--cpu-rays", type=int, default=192)
+    ap.add_argument("--eager", action="store_true", help="also time the plain PyTorch-ROCm eager train step on this GPU (fp32 and bf16 autocast)")
     ap.add_argument("--frame-chunk", type=int, default=32768)
     args = ap.parse_args()
 
@@ -237,6 +294,14 @@ def main():
                          "f32_kernels_vs_cpu_oracle_max_rel_err_depth": float(((r32[1][1].cpu() - dist_ref).abs() / dist_ref.abs()).max()),
                          "psnr_f32_kernels_vs_cpu_oracle_db": psnr(r32[1][0].cpu(), rgb_ref),
                          "psnr_bf16_kernels_vs_cpu_oracle_db": psnr(rb[1][0].cpu(), rgb_ref)}
+    if rank == 0 and world == 1 and args.eager:
+        sd = {k: v.clone() for k, v in model.state_dict().items()}
+        e32, ms32 = eager_baseline(sd, rays, n, 3, False)
+        e16, ms16 = eager_baseline(sd, rays, n, 3, True)
+        out["eager_baseline"] = {"unit": "rays/s", "fp32": round(e32, 1), "fp32_ms_per_step": round(ms32, 2), "bf16_autocast": round(e16, 1),
+                                 "bf16_autocast_ms_per_step": round(ms16, 2), "rays_per_step": n,
+                                 "kind": "plain PyTorch-ROCm eager ops (torch restatement of the reference model), autograd + torch.optim.Adam, same GPU",
+                                 "speedup_vs_fp32": round(out["value"] / e32, 2), "speedup_vs_bf16_autocast": round(out["value"] / e16, 2)}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
