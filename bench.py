@@ -229,7 +229,11 @@ def main():
         achieved = alg_nt / (gemm_ms * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": {8: "gemm_nt8p_kernel (bf16, 256x256 persistent 8-phase)", 4: "gemm_nt8_kernel (bf16, 256x256 8-phase)", 1: "gemm_nt_kernel<bf16,256,256,2,4>"}.get(args.variant, "gemm_nt_kernel<bf16,128,128,2,2>") if args.compute == "bf16" else "gemm_nt_kernel<f32,128,128,2,2>",
                     "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS if args.compute == "bf16" else 157.3, "unit": "TFLOP/s",
-                    "frac": round(achieved / (PEAK_BF16_TFLOPS if args.compute == "bf16" else 157.3), 4), "traffic": None,
+                    "frac": round(achieved / (PEAK_BF16_TFLOPS if args.compute == "bf16" else 157.3), 4),
+                    # HBM bytes of ONE launch of the largest layer shape (M = 524288, N = K = 1024: algorithmic 1.07 GB in + 1.07 GB out),
+                    # from separate rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE): tools/pmc_gemm.sh
+                    "traffic": (1.618e9 + 1.074e9) if (args.compute == "bf16" and args.variant == 8) else None,
+                    "traffic_source": "profiles/r1_k_gemm_nt8p_pmc.txt (per launch at M=524288 N=K=1024; algorithmic 2.15e9 B)",
                     "launches_per_step": launches, "avg_launch_ms": round(gemm_ms / launches, 4), "kernel_ms_per_step": round(gemm_ms, 3),
                     "algorithmic_flops_per_step": alg_nt, "padded_flops_per_step": padded_flops}
         out = {"metric": "rays/sec (train step)", "value": round(rays_per_s, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps,
