@@ -216,12 +216,14 @@ def main():
         elapsed = te.item()
     final_loss = float(loss)
 
+    # ---- roofline of the dominant kernel (NT MFMA GEMM: all forward + data-gradient layers); the instrumented step contains
+    # the gradient all-reduce, so EVERY rank runs it
+    launches, gemm_ms, padded_flops = measure_gemm_kernel(trainer, rays, tgt, depth, conf)
+    barrier()
     out = None
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         rays_per_s = world * n * args.steps / elapsed
-        # ---- roofline of the dominant kernel (NT MFMA GEMM: all forward + data-gradient layers)
-        launches, gemm_ms, padded_flops = measure_gemm_kernel(trainer, rays, tgt, depth, conf)
         fwd = 2.0 * (S0 * MAC_PROP + (P1 - 1) * MAC_NERF)                        # 2.269 GFLOP / ray
         first = 2.0 * (S0 * 96 * 256 + (P1 - 1) * 96 * HIDDEN)                   # first layers have no data gradient
         skipenc = 2.0 * (P1 - 1) * 96 * HIDDEN + 2.0 * (P1 - 1) * 27 * 128       # d/d(encoding) columns of the concat layers
@@ -248,8 +250,8 @@ def main():
     # ---- full-frame inference (forward only): 1600 x 900 rays, rows sharded across ranks
     if not args.no_frame:
         H, W = 900, 1600
-        rows = H // world
-        pix = np.arange(rank * rows * W, (rank + 1) * rows * W if rank < world - 1 else H * W)
+        rows = (H + world - 1) // world                                               # row blocks; the last rank may own fewer rows
+        pix = np.arange(min(rank * rows, H) * W, min((rank + 1) * rows, H) * W)
         with torch.no_grad():
             chunk = args.frame_chunk
             fr = rays_from_pixels(pix[:chunk], np.zeros((min(chunk, len(pix)), 3)), device)
@@ -262,10 +264,11 @@ def main():
                 ret = model(fr, False, False, 0.)
                 outs.append(torch.cat([ret[1][0], ret[1][1][:, None]], -1))
             img = torch.cat(outs, 0)
-            if world > 1:
-                parts = [torch.empty_like(img) for _ in range(world)] if img.shape[0] * world == H * W else None
-                if parts is not None:
-                    dist.all_gather(parts, img)
+            if world > 1:                                                              # one all-gather of rgb+depth per frame
+                pad = torch.zeros(rows * W, 4, device=device, dtype=img.dtype)
+                pad[:img.shape[0]] = img
+                parts = [torch.empty_like(pad) for _ in range(world)]
+                dist.all_gather(parts, pad)
             barrier()
             t_frame = time.perf_counter() - t0
         if world > 1:
