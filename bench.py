@@ -167,9 +167,15 @@ def main():
     ap.add_argument("--no-frame", action="store_true", help="skip the 1600x900 frame render")
     ap.add_argument("--no-cpu", action="store_true", help="skip the host-CPU baseline")
     ap.add_argument("--cpu-rays", type=int, default=192)
+    ap.add_argument("--shape", default="baseline", choices=["baseline", "shipped"],
+                    help="baseline = BASELINE.json's 64 proposal + 128 fine evals/ray (192 spp); shipped = the reference config's "
+                         "128 proposal + 127 fine intervals (configs/nuScenes_depth_6cams)")
     ap.add_argument("--eager", action="store_true", help="also time the plain PyTorch-ROCm eager train step on this GPU (fp32 and bf16 autocast)")
     ap.add_argument("--frame-chunk", type=int, default=32768)
     args = ap.parse_args()
+    global S0, P1
+    if args.shape == "shipped":
+        S0, P1 = 128, 128
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -241,8 +247,8 @@ def main():
         out = {"metric": "rays/sec (train step)", "value": round(rays_per_s, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": args.compute, "data": "synthetic",
-               "config": {"workload": "S-NeRF path A (MipNerfModel) train step, nuScenes-like 1600x900 rays, 64 proposal + 128 fine evals/ray (192 spp), "
-                                      "hidden 1024, rgb_layer 3, cone + contraction + IPE-96",
+               "config": {"workload": f"S-NeRF path A (MipNerfModel) train step, nuScenes-like 1600x900 rays, {S0} proposal + {P1 - 1} fine evals/ray "
+                                      f"({S0 + P1 - 1} spp), hidden 1024, rgb_layer 3, cone + contraction + IPE-96",
                           "rays_per_gpu_per_step": n, "global_rays_per_step": n * world, "parallelism": f"dp{world} (ray-sharded, one flat RCCL all-reduce)",
                           "train_flops_per_ray": 3 * fwd},
                "roofline": roofline, "final_loss": final_loss}
@@ -277,7 +283,7 @@ def main():
             t_frame = te.item()
         if rank == 0:
             out["ms_per_frame"] = round(t_frame * 1e3, 1)
-            out["frame"] = {"resolution": "1600x900", "rays": H * W, "spp": 192, "chunk": chunk, "rays_per_s": round(H * W / t_frame, 1),
+            out["frame"] = {"resolution": "1600x900", "rays": H * W, "spp": S0 + P1 - 1, "chunk": chunk, "rays_per_s": round(H * W / t_frame, 1),
                             "includes": "host ray generation + H2D per chunk, render, all-gather of rgb+depth"}
 
     # ---- parity read-out + host-CPU baseline (rank 0, N = 1 only)

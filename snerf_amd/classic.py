@@ -97,7 +97,7 @@ class NeRF(_ArenaModule):
     is the accelerated configuration)."""
 
     def __init__(self, D=8, W=256, input_ch=3, input_ch_views=3, output_ch=4, skips=[4], use_viewdirs=False,
-                 compute: str = "bf16", device="cuda", variant: int = 1):
+                 compute: str = "bf16", device="cuda", variant: int = 8):
         super().__init__()
         if not use_viewdirs:
             raise NotImplementedError("the accelerated NeRF requires use_viewdirs=True (the S-NeRF configuration)")

@@ -1217,7 +1217,9 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(GemmTN p) {
   const int KT = (rows + 63) >> 6;
   const T* __restrict__ Z = (const T*)p.Z + (long)mbeg * p.ldz + n0;
   const T* __restrict__ X = (const T*)p.X + (long)mbeg * p.ldx + k0;
-  const int zbytes = rows * (int)p.ldz * 2 - n0 * 2, xbytes = rows * (int)p.ldx * 2 - k0 * 2;   // to the end of the slice's last row
+  // readable bytes from the tile's first element: up to the last VALID column of the slice's last row (the operands may be
+  // column ranges of wider buffers, so nothing past that is known to be mapped)
+  const int zbytes = (rows - 1) * (int)p.ldz * 2 + (p.N - n0) * 2, xbytes = (rows - 1) * (int)p.ldx * 2 + (p.K - k0) * 2;
   const int zstep = 64 * (int)p.ldz * 2, xstep = 64 * (int)p.ldx * 2;
 
   // ---- staging stream: wave w owns pieces 2w, 2w+1 (4 rows x 256 B) of every half-tile -------------------------------

@@ -38,7 +38,7 @@ class MipNerfModel(_ArenaModule):
                  rgb_padding: float = 0.001, disable_integration: bool = False, no_warp_sample=True, fn=None, radius=None,
                  real=False, transform_idx=0, rgb_layer=1, hidden_layer=256, encode_appearance=False, N_vocab=100,
                  proposal_hidden_layer=256, proposal_loss=False, N_fine=128, semantic=False, semantic_class_num=0,
-                 compute: str = "bf16", device="cuda", variant: int = 1):
+                 compute: str = "bf16", device="cuda", variant: int = 8):
         super().__init__()
         if no_warp_sample:
             raise NotImplementedError("no_warp_sample=1 is broken in the reference itself (models.py:82 vs :178); only the warp branch exists")

@@ -90,6 +90,29 @@ def test_linear_wgrad(ops, dt, M, N, K, nv, kv):
         close(dW, ref, 1e-4, 1e-3 * (M / 1000) ** 0.5, f"wgrad variant {variant}")
 
 
+def test_gemm_operands_as_column_ranges(ops):
+    """Operands are column ranges of wider buffers (concat-by-columns layout); whatever surrounds them must not leak in."""
+    dt, M, N, K = 1, 9000, 256, 320
+    big = torch.full((M, 64 + K + 64), float("nan"), dtype=torch.bfloat16, device="cuda")
+    X = big[:, 64:64 + K]
+    X.copy_(gen(M, K, seed=11).to(torch.bfloat16))
+    bigz = torch.full((M, 32 + N), float("nan"), dtype=torch.bfloat16, device="cuda")
+    dZ = bigz[:, 32:]
+    dZ.copy_(gen(M, N, seed=12).to(torch.bfloat16))
+    ref = dZ.double().cpu().t() @ X.double().cpu()
+    for variant in (1, 3):
+        dW = torch.zeros(N, K, dtype=torch.float32, device="cuda")
+        ops.linear_wgrad(dZ, X, dW, N, K, dt, variant=variant)
+        close(dW, ref, 1e-4, 3e-3, f"wgrad on column ranges, variant {variant}")
+    W = (gen(N, K, seed=13) / K ** 0.5).to(torch.bfloat16).cuda()
+    refy = torch.relu(X.double().cpu() @ W.double().cpu().t())
+    for variant in (1, 4, 8):
+        ybig = torch.full((M, N + 64), 5.0, dtype=torch.bfloat16, device="cuda")
+        ops.linear_fwd(X, W, None, ybig[:, 64:], K, N, ops.ACT_RELU, dt, variant=variant)
+        close(ybig[:, 64:], refy, 1e-2, 1e-2, f"fwd on column ranges, variant {variant}")
+        assert bool((ybig[:, :64] == 5.0).all())
+
+
 # -------------------------------------------------------------- encoders ----
 @pytest.mark.parametrize("dt", [0, 1])
 def test_classic_embed(ops, dt):
