@@ -141,3 +141,37 @@ def test_zip_model_backward_vs_oracle_autograd(backend):
         # trilinear weights, hence the wider bound for the tables on the device
         bad = bad + [(k, rel)] if rel >= (3e-2 if k.endswith('embeddings') else 5e-3) else bad
     assert not bad, bad
+
+
+@pytest.mark.gpu
+def test_zip_train_step_at_scale():
+    """The production-size model (waymo.gin grids, 2^21 hash entries) on enough rays that every GEMM takes its large-M kernels
+    (persistent 8-phase NT, 8-phase wgrad with operands that are column ranges of wider buffers): runs, finite, and the bf16
+    step agrees with the fp32-parity step on the rendered colour."""
+    from snerf_amd import ops, zipnerf
+    R = 4096
+    g = torch.Generator().manual_seed(3)
+    pix = torch.randint(0, 1920 * 1280, (R,), generator=g)
+    i, j = (pix % 1920).float(), (pix // 1920).float()
+    d = torch.stack([(i - 960 + 0.5) / 2050, -(j - 640 + 0.5) / 2050, -torch.ones(R)], -1)
+    vd = torch.nn.functional.normalize(d, dim=-1)
+    bx = torch.nn.functional.normalize(torch.cross(vd, torch.tensor([0.0, 1.0, 0.0]).expand(R, 3), dim=-1), dim=-1)
+    by = torch.nn.functional.normalize(torch.cross(vd, bx, dim=-1), dim=-1)
+    batch = {k: v.cuda() for k, v in dict(origins=torch.randn(R, 3, generator=g) * 0.05, directions=d, viewdirs=vd,
+                                          radii=torch.full((R, 1), 2.0 / 2050 / 12 ** 0.5), near=torch.full((R, 1), 0.1),
+                                          far=torch.full((R, 1), 10.0), base_x=bx, base_y=by).items()}
+    tgt = torch.rand(R, 3, generator=g).cuda()
+    rgbs = {}
+    for compute, table in (("bf16", "f16"), ("f32", "f32")):
+        torch.manual_seed(0)
+        m = zipnerf.Model(config=None, raydist_fn='power_transformation', opaque_background=True, compute=compute, table_dtype=table,
+                          grid_log2_hashmap_size=21, init_std=0.1)
+        draws = m._draws(R, False, m.arena.flat.device, 7)
+        ren, _ = m(False, batch, 1.0, False, draws=draws)
+        rgb = ren[2]["rgb"]
+        loss = ((rgb - tgt) ** 2).mean()
+        loss.backward()
+        gr = torch.cat([p.grad.flatten() for p in m.param_list() if p.grad is not None])
+        assert bool(torch.isfinite(rgb).all()) and bool(torch.isfinite(gr).all()) and float(gr.abs().max()) > 0
+        rgbs[compute] = rgb.detach().float()
+    assert float((rgbs["bf16"] - rgbs["f32"]).abs().max()) < 3e-2
