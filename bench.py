@@ -51,6 +51,18 @@ def rays_from_pixels(pix, origins, device, H=900, W=1600, focal=1266.0, near=1.8
     return Rays(t(origins), t(d), t(d / np.linalg.norm(d, axis=-1, keepdims=True)), t(radii), t(ones), t(ones * near), t(ones * far), t(ones * 0))
 
 
+def frame_rays(first, n, device, H=900, W=1600, focal=1266.0, near=1.8, far=110.0):
+    """Rays of n consecutive pixels of the frame, generated on the device (snerf_pinhole_rays: the reference's
+    get_rays_single_img, sample_utils.py:286-345) -- same camera as rays_from_pixels."""
+    from snerf_amd import ops
+    from snerf_amd.mipnerf import Rays
+    th = 0.3
+    pose = np.array([[math.cos(th), 0.0, math.sin(th), 0.0], [0.0, 1.0, 0.0, 0.0], [-math.sin(th), 0.0, math.cos(th), 0.0]], dtype=np.float32)
+    o, d, v, r, nr, fr = ops.pinhole_rays(None, first, n, W, H, pose, W * 0.5, H * 0.5, focal, focal, False, near, far, device)
+    ones = torch.ones_like(r)
+    return Rays(o, d, v, r, ones, nr, fr, ones * 0)
+
+
 def build_model(compute, device, seed=0):
     from snerf_amd.mipnerf import MipNerfModel
     torch.manual_seed(seed)
@@ -260,13 +272,13 @@ def main():
         pix = np.arange(min(rank * rows, H) * W, min((rank + 1) * rows, H) * W)
         with torch.no_grad():
             chunk = args.frame_chunk
-            fr = rays_from_pixels(pix[:chunk], np.zeros((min(chunk, len(pix)), 3)), device)
+            fr = frame_rays(int(pix[0]), min(chunk, len(pix)), device)
             model(fr, False, False, 0.)                                            # warm-up chunk (packing, allocator)
             barrier()
             t0 = time.perf_counter()
             outs = []
             for i in range(0, len(pix), chunk):
-                fr = rays_from_pixels(pix[i:i + chunk], np.zeros((len(pix[i:i + chunk]), 3)), device)
+                fr = frame_rays(int(pix[i]), len(pix[i:i + chunk]), device)           # ray generation on the device, per chunk
                 ret = model(fr, False, False, 0.)
                 outs.append(torch.cat([ret[1][0], ret[1][1][:, None]], -1))
             img = torch.cat(outs, 0)
@@ -284,7 +296,7 @@ def main():
         if rank == 0:
             out["ms_per_frame"] = round(t_frame * 1e3, 1)
             out["frame"] = {"resolution": "1600x900", "rays": H * W, "spp": S0 + P1 - 1, "chunk": chunk, "rays_per_s": round(H * W / t_frame, 1),
-                            "includes": "host ray generation + H2D per chunk, render, all-gather of rgb+depth"}
+                            "includes": "on-device ray generation per chunk, render, all-gather of rgb+depth"}
 
     # ---- parity read-out + host-CPU baseline (rank 0, N = 1 only)
     if rank == 0 and world == 1 and not args.no_cpu:

@@ -183,6 +183,28 @@ int snerf_adam_step(float* p, float* g, float* m, float* v, long n, float lr, fl
 int snerf_colsum_f32(const float* x, long ld, long M, int C, float* out, void* stream);
 int snerf_cast_pad(const float* src, long ld_src, long M, int C, int Cpad, void* dst, long ld_dst, int dtype, void* stream);
 
+/* ---- the callers either side of the path --------------------------------------------------------
+ * Ray generation: s-nerf/utils/sample_utils.py:286-345 get_rays_single_img (training = 0: whole frame / any pixels, half-pixel
+ * centres) and :92-211 sample_single_img (training = 1: directions by run_nerf_helpers.get_rays_by_coord :300-312 without the
+ * half-pixel offset, radii from the half-pixel grid), no-NDC branch.  coords int32 [N,2] = (row, col), or NULL for the N pixels
+ * first_pixel.. in row-major order.  pose_host: HOST pointer to the [3,4] camera-to-world matrix (12 floats, passed by value
+ * to the kernel).  near / far are the caller's bounds (the reference scales them by 0.9 / 1.1 before).  Outputs are the Rays
+ * fields of sample_utils.py:11-13 (lossmult = 1 and app = 0 are the caller's constants). */
+int snerf_pinhole_rays(const int* coords, long first_pixel, int W, int H, const float* pose_host, float cx, float cy, float fx,
+                       float fy, int training, float near, float far, long N, float* origins, float* directions, float* viewdirs,
+                       float* radii, float* near_out, float* far_out, void* stream);
+/* Per-ray loss tail of s-nerf/train.py:150-208, value and gradients w.r.t. the renderer outputs in one pass: RgbLoss
+ * (model/loss_factory.py:5-11) on rgb/tgt [N,3]; calc_depth_loss (model/confidence.py:209-224) = DepthLoss
+ * (loss_factory.py:26-37; disparity 1: |1/p - 1/t|) on dist1 (fine) + coarse_mult * dist0 (coarse), rays with tdepth == 0 masked
+ * out, times conf [N] (nullable), mean over the valid rays, times depth_lambda (tdepth NULL = no depth loss); ProposalLoss
+ * (loss_factory.py:59-74) of the detached fine histogram (s_f [N,Pf], w_f [N,Pf-1]) against the coarse one (s_c [N,Sc+1],
+ * w_c [N,Sc]) times prop_lambda (s_c NULL = off).  out[4] = {#valid depth rays, rgb loss, depth loss, proposal loss};
+ * g_rgb [N,3], g_dist1 / g_dist0 [N], g_wc [N,Sc] = d(total loss)/d(input). */
+int snerf_mip_loss_tail(const float* rgb, const float* tgt, const float* dist1, const float* dist0, const float* tdepth,
+                        const float* conf, const float* s_f, const float* w_f, const float* s_c, const float* w_c, long N, int Pf,
+                        int Sc, int disparity, float depth_lambda, float coarse_mult, float prop_lambda, float* out, float* g_rgb,
+                        float* g_dist1, float* g_dist0, float* g_wc, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -350,3 +350,39 @@ def zip_composite_bwd(raw_rgb, raw_density, tdist, dirs, opaque, bg, rgb_padding
               _p(tdist), _p(dirs), R, P - 1, 1 if opaque else 0, float(bg), float(rgb_padding), float(density_bias), _p(weights), _p(acc),
               _p(depth), _p(g_rgb), _p(g_depth), _p(g_acc), _p(g_w), _p(d_raw_rgb), 0 if d_raw_rgb is None else d_raw_rgb.stride(0),
               _p(d_raw_density), d_raw_density.stride(0), _stream())
+
+
+# ------------------------------------------------- callers ----
+def pinhole_rays(coords, first_pixel, n, W, H, pose, cx, cy, fx, fy, training, near, far, device):
+    """Rays of n pixels of a pinhole camera (coords int32 [n,2] = (row, col) on `device`, or None = pixels first_pixel.. row-major).
+    `pose`: host [3,4] (or [4,4]) camera-to-world.  -> origins, directions, viewdirs [n,3], radii, near, far [n,1]."""
+    import numpy as np
+    p = np.ascontiguousarray(np.asarray(pose, dtype=np.float32)[:3, :4])
+    if coords is not None:
+        assert coords.dtype == torch.int32 and coords.is_contiguous() and coords.shape == (n, 2)
+    o, d, v = (torch.empty(n, 3, dtype=torch.float32, device=device) for _ in range(3))
+    r, nr, fr = (torch.empty(n, 1, dtype=torch.float32, device=device) for _ in range(3))
+    _lib.call("snerf_pinhole_rays", _p(coords), int(first_pixel), int(W), int(H), p.ctypes.data, float(cx), float(cy), float(fx), float(fy),
+              int(bool(training)), float(near), float(far), int(n), _p(o), _p(d), _p(v), _p(r), _p(nr), _p(fr), _stream())
+    return o, d, v, r, nr, fr
+
+
+def mip_loss_tail(rgb, tgt, dist1, dist0, tdepth, conf, s_f, w_f, s_c, w_c, disparity, depth_lambda, coarse_mult, prop_lambda):
+    """-> (out[4] = {#valid, rgb, depth, proposal loss}, g_rgb, g_dist1, g_dist0, g_wc); absent terms return None gradients."""
+    n = rgb.shape[0]
+    dev = rgb.device
+    out = torch.empty(4, dtype=torch.float32, device=dev)
+    g_rgb = torch.empty(n, 3, dtype=torch.float32, device=dev)
+    g1 = g0 = gw = None
+    if tdepth is not None:
+        g1, g0 = torch.empty(n, dtype=torch.float32, device=dev), torch.empty(n, dtype=torch.float32, device=dev)
+    Pf = Sc = 0
+    if s_c is not None:
+        Pf, Sc = s_f.shape[1], w_c.shape[1]
+        assert w_f.shape[1] == Pf - 1 and s_c.shape[1] == Sc + 1
+        gw = torch.empty(n, Sc, dtype=torch.float32, device=dev)
+    c = lambda t: None if t is None else _f32c(t)
+    _lib.call("snerf_mip_loss_tail", _p(c(rgb)), _p(c(tgt)), _p(c(dist1)), _p(c(dist0)), _p(c(tdepth)), _p(c(conf)), _p(c(s_f)), _p(c(w_f)),
+              _p(c(s_c)), _p(c(w_c)), n, Pf, Sc, int(bool(disparity)), float(depth_lambda), float(coarse_mult), float(prop_lambda), _p(out),
+              _p(g_rgb), _p(g1), _p(g0), _p(gw), _stream())
+    return out, g_rgb, g1, g0, gw

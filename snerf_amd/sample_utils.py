@@ -1,0 +1,73 @@
+"""Ray generation on the device: host-side mirror of s-nerf/utils/sample_utils.py (the step immediately before the render
+path).  Same function names and argument meaning as the reference; the per-pixel arithmetic runs in
+`snerf_pinhole_rays` (no [H, W, 3] direction grid is materialised to pick 4096 pixels).  `args` needs `no_ndc=True` (the
+S-NeRF street-scene configuration); NDC rays raise NotImplementedError."""
+import collections
+
+import numpy as np
+import torch
+
+from . import ops
+
+Rays = collections.namedtuple('Rays', ('origins', 'directions', 'viewdirs', 'radii', 'lossmult', 'near', 'far', 'app'))
+
+
+def _intr(intrinsic):
+    K = np.asarray(intrinsic.detach().cpu() if torch.is_tensor(intrinsic) else intrinsic, dtype=np.float32)
+    return float(K[0, 2]), float(K[1, 2]), float(K[0, 0]), float(K[1, 1])
+
+
+def _pose(pose):
+    return np.asarray(pose.detach().cpu() if torch.is_tensor(pose) else pose, dtype=np.float32)
+
+
+def _check(args):
+    if not getattr(args, "no_ndc", True):
+        raise NotImplementedError("NDC rays (no_ndc=False) are outside the accelerated path")
+
+
+def get_rays_single_img(args, image, depth_gt, pose, intrinsic, near=0., far=1., factor=4, device=None):
+    """sample_utils.py:286-345: rays of the whole (H//factor x W//factor) frame -> Rays with [H, W, .] fields."""
+    _check(args)
+    H, W = image.shape[0] // factor, image.shape[1] // factor
+    device = device if device is not None else (image.device if torch.is_tensor(image) and image.is_cuda else torch.device("cuda"))
+    cx, cy, fx, fy = (v / factor for v in _intr(intrinsic))
+    # float32 arithmetic of `intrinsic / factor` (sample_utils.py:290)
+    cx, cy, fx, fy = (float(np.float32(v)) for v in (cx, cy, fx, fy))
+    o, d, v, r, nr, fr = ops.pinhole_rays(None, 0, H * W, W, H, _pose(pose), cx, cy, fx, fy, False, near * 0.9, far * 1.1, device)
+    ones = torch.ones(H, W, 1, dtype=torch.float32, device=device)
+    sh = lambda t: t.view(H, W, -1)
+    return Rays(sh(o), sh(d), sh(v), sh(r), ones, sh(nr), sh(fr), ones * 0.)
+
+
+def rays_of_pixels(coords, pose, intrinsic, H, W, near, far, training=False, device="cuda"):
+    """Rays of selected pixels; coords [N,2] = (row, col) (any integer tensor / array)."""
+    c = torch.as_tensor(coords).to(device=device, dtype=torch.int32).contiguous()
+    cx, cy, fx, fy = _intr(intrinsic)
+    o, d, v, r, nr, fr = ops.pinhole_rays(c, 0, c.shape[0], W, H, _pose(pose), cx, cy, fx, fy, training, near, far, device)
+    ones = torch.ones_like(r)
+    return Rays(o, d, v, r, ones, nr, fr, ones * 0.)
+
+
+def sample_single_img(args, image, depth_gt, pose, intrinsic, near=0., far=1., near_far=False, batch_n=None, app=0.):
+    """sample_utils.py:92-211: a random pixel batch of one image -> (Rays, target_rgb, target_depth, sel_coords, sel_inds).
+    The pixel choice uses numpy's global RNG exactly like the reference (np.random.choice without replacement)."""
+    _check(args)
+    if getattr(args, "smooth_loss", False):
+        raise NotImplementedError("smooth-loss patches are outside the accelerated path")
+    H, W = image.shape[:2]
+    n = batch_n if batch_n is not None else args.N_rgb
+    sel = np.random.choice(H * W, size=[n], replace=False)
+    coords = np.stack([sel // W, sel % W], -1)
+    if not near_far:
+        near, far = near * 0.9, far * 1.1
+    else:
+        nz = depth_gt[depth_gt != 0]
+        near, far = float(nz.min()) * 0.9, float(nz.max()) * 1.1
+    dev = image.device if torch.is_tensor(image) and image.is_cuda else torch.device("cuda")
+    rays = rays_of_pixels(coords, pose, intrinsic, H, W, near, far, training=True, device=dev)
+    rays = rays._replace(app=rays.lossmult * float(app))
+    ct = torch.as_tensor(coords, device=image.device if torch.is_tensor(image) else "cpu").long()
+    target_rgb = image[ct[:, 0], ct[:, 1]]
+    target_dep = depth_gt[ct[:, 0], ct[:, 1]]
+    return rays, target_rgb, target_dep, ct, sel

@@ -3,9 +3,9 @@ gradient exchange and fused Adam on the flat arenas.
 
 Reference counterpart: the hot loop of s-nerf/train.py:110-221 (model forward :112-115, RGB MSE
 loss_factory.py:5-11, disparity-L1 depth loss with per-ray confidence loss_factory.py:26-37 /
-confidence.py:209-224, loss.backward() :213, optimizer.step() :217-221).  The losses themselves belong to
-the caller (SURVEY.md section 8f "next"); here they are a handful of [N]-sized torch expressions that only
-produce dL/d(rgb, distance) -- everything per-sample runs in the HIP kernels.
+confidence.py:209-224, ProposalLoss loss_factory.py:59-74, loss.backward() :213, optimizer.step() :217-221).
+The per-ray loss tail is one kernel that returns the loss terms and
+dL/d(rgb, distance, coarse weights) -- no [N]-sized torch expressions, no device->host sync in the step.
 
 Multi-GPU: one process per GPU, every rank renders its own shard of the ray batch; the only exchange is ONE
 RCCL all-reduce of the flat fp32 gradient arena (35.9 MB for the shipped model) before the Adam kernel, which
@@ -19,10 +19,11 @@ from . import ops
 
 class MipTrainer:
     def __init__(self, model, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, depth_lambda=0.2, coarse_depth_mult=0.2,
-                 process_group=None):
+                 proposal_loss=False, proposal_lambda=0.05, disparity_depth=True, process_group=None):
         self.model = model
         self.lr, self.betas, self.eps = lr, betas, eps
         self.depth_lambda, self.coarse_depth_mult = depth_lambda, coarse_depth_mult
+        self.proposal_loss, self.proposal_lambda, self.disparity_depth = proposal_loss, proposal_lambda, disparity_depth
         a = model.arena
         self.m = torch.zeros_like(a.flat)
         self.v = torch.zeros_like(a.flat)
@@ -37,27 +38,17 @@ class MipTrainer:
             self.model.arena.bump()
 
     def loss_and_grads(self, outs, target_rgb, target_depth, conf):
-        """RGB MSE + confidence-weighted disparity L1 on both levels; returns (loss, output gradients)."""
+        """The reference's per-ray loss tail (train.py:150-208) in ONE kernel, `snerf_mip_loss_tail`: RGB MSE, the
+        confidence-weighted (disparity) depth loss on both levels masked to rays with a LiDAR target, and -- with
+        `proposal_loss` -- ProposalLoss on the two histograms.  Returns (loss [device scalar], output gradients)."""
         dist0, acc0, s0, w0, rgb1, dist1, acc1, s1, w1 = outs
-        n = rgb1.shape[0]
-        diff = rgb1 - target_rgb
-        loss = (diff * diff).mean()
-        g_rgb1 = diff * (2.0 / (3 * n))
-        g_dist0 = g_dist1 = None
-        if target_depth is not None:
-            mask = (target_depth > 0).float() * (conf if conf is not None else 1.0)
-            nv = mask.sum().clamp_min(1.0)
-            inv_t = torch.where(target_depth > 0, 1.0 / target_depth.clamp_min(1e-6), torch.zeros_like(target_depth))
-
-            def dl(d, mult):
-                e = 1.0 / d - inv_t
-                l = (e.abs() * mask).sum() / nv * (self.depth_lambda * mult)
-                g = torch.sign(e) * (-1.0 / (d * d)) * mask * (self.depth_lambda * mult) / nv
-                return l, g
-            l1, g_dist1 = dl(dist1, 1.0)
-            l0, g_dist0 = dl(dist0, self.coarse_depth_mult)
-            loss = loss + l1 + l0
-        return loss, (g_dist0, None, None, g_rgb1, g_dist1, None, None)
+        prop = self.proposal_loss
+        out, g_rgb1, g_dist1, g_dist0, g_w0 = ops.mip_loss_tail(
+            rgb1, target_rgb, dist1 if target_depth is not None else None, dist0 if target_depth is not None else None,
+            target_depth, conf, s1 if prop else None, w1 if prop else None, s0 if prop else None, w0 if prop else None,
+            self.disparity_depth, self.depth_lambda, self.coarse_depth_mult, self.proposal_lambda)
+        self.last_losses = out                                   # {#valid depth rays, rgb, depth, proposal}: stays on the device
+        return out[1:].sum(), (g_dist0, None, g_w0, g_rgb1, g_dist1, None, None)
 
     def step(self, rays, target_rgb, target_depth=None, conf=None, randomized=True, s_rand=None, u=None):
         m = self.model

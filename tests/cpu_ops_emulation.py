@@ -4,6 +4,8 @@ plumbing, the hand-written backward chains of snerf_amd.mlp, the autograd glue a
 exercised by `-m "not gpu"` tests in a container without a GPU.  Never imported by the product."""
 import contextlib
 
+import numpy as np
+
 import torch
 
 from oracle import classic as oc
@@ -213,10 +215,55 @@ def zip_composite_bwd(raw_rgb, raw_density, tdist, dirs, opaque, bg, rgb_padding
         d_raw_rgb.copy_(rr.grad if rr.grad is not None else torch.zeros_like(rr))
 
 
+def pinhole_rays(coords, first_pixel, n, W, H, pose, cx, cy, fx, fy, training, near, far, device):
+    from oracle import callers as oc
+    if coords is None:
+        pix = torch.arange(first_pixel, first_pixel + n)
+        coords = torch.stack([pix // W, pix % W], -1)
+    K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1]], dtype=np.float32)
+    r = oc.pinhole_rays(coords.cpu().long(), np.asarray(pose, dtype=np.float32), K, H, near, far, training=bool(training), W=W)
+    return tuple(r[k].to(device) for k in ("origins", "directions", "viewdirs", "radii", "near", "far"))
+
+
+def mip_loss_tail(rgb, tgt, dist1, dist0, tdepth, conf, s_f, w_f, s_c, w_c, disparity, depth_lambda, coarse_mult, prop_lambda):
+    from oracle import callers as oc
+    dev = rgb.device
+    rg = rgb.detach().cpu().clone().requires_grad_(True)
+    out = torch.zeros(4)
+    loss = oc.rgb_loss(rg, tgt.cpu())
+    out[1] = loss.detach()
+    leaves, g1 = [rg], None
+    if tdepth is not None:
+        d1, d0 = dist1.detach().cpu().clone().requires_grad_(True), dist0.detach().cpu().clone().requires_grad_(True)
+        td = tdepth.cpu()
+        out[0] = float((td != 0).sum())
+        if out[0] > 0:
+            ld = oc.depth_loss(d1, d0, td, None if conf is None else conf.cpu(), coarse_mult, bool(disparity)) * depth_lambda
+            out[2] = ld.detach()
+            loss = loss + ld
+        leaves += [d1, d0]
+    if s_c is not None:
+        wc = w_c.detach().cpu().clone().requires_grad_(True)
+        lp = oc.proposal_loss(s_f.cpu(), w_f.cpu(), s_c.cpu(), wc, prop_lambda)
+        out[3] = lp.detach()
+        loss = loss + lp
+        leaves.append(wc)
+    gs = torch.autograd.grad(loss, leaves, allow_unused=True)
+    gs = [torch.zeros_like(l) if g is None else g for g, l in zip(gs, leaves)]
+    it = iter(gs)
+    g_rgb = next(it).to(dev)
+    gd1 = gd0 = gw = None
+    if tdepth is not None:
+        gd1, gd0 = next(it).to(dev), next(it).to(dev)
+    if s_c is not None:
+        gw = next(it).to(dev)
+    return out.to(dev), g_rgb, gd1, gd0, gw
+
+
 _NAMES = ["zip_resample", "zip_encode_fwd", "zip_encode_bwd", "zip_composite_fwd", "zip_composite_bwd",
           "linear_fwd", "linear_wgrad", "classic_embed", "mip_encode", "mip_viewenc", "classic_sample_pdf", "classic_points",
           "classic_merge_sort", "mip_resample", "stratified", "mip_composite_fwd", "mip_composite_bwd", "classic_composite_fwd",
-          "classic_composite_bwd", "adam_step", "colsum_f32", "cast_pad"]
+          "classic_composite_bwd", "adam_step", "colsum_f32", "cast_pad", "pinhole_rays", "mip_loss_tail"]
 
 
 @contextlib.contextmanager
