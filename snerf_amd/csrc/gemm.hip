@@ -1191,7 +1191,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
 // TN kernel, 8-phase schedule (bf16): dW[n0:n0+256, k0:k0+256] += dZ[mbeg:mend, n-tile]^T . X[mbeg:mend, k-tile]
 //
 // Same machinery as gemm_nt8p_kernel (half-tiles, quadrant phases, fragments prefetched in place during the MFMA
-// sections, staging two k-tiles ahead with five halves in flight, two wave rows half a phase apart), with the
+// sections, staging two k-tiles ahead with five halves in flight, two wave rows in opposite section order), with the
 // reduction axis on the ROWS of both operands: a k-tile is 64 rows of dZ and of X; a half-tile is 64 rows x 128 columns
 // (256-byte LDS rows, 16-byte chunk c of row r at position c ^ 4 (r & 3)); MFMA fragments come from
 // ds_read_b64_tr_b16 (two per fragment).  One workgroup owns one 256 x 256 tile of dW for one slice of M and adds it
@@ -1287,14 +1287,19 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(GemmTN p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  auto end_load = [&]() __attribute__((always_inline)) {
+  // One barrier per phase.  Wave row 1 runs [load section, MFMA section], wave row 0 [MFMA section, load section] between two
+  // barriers, so on every SIMD one wave stages while the other multiplies, and they swap roles mid-interval without meeting.
+  // A load section = stage this phase's half, vmcnt(10) (five halves in flight), lgkmcnt(0).  Ordering: a half retired in the
+  // load section of phase j (by the end of interval j for both rows) is first read in MFMA section j+1; a half last read in
+  // MFMA section p is restaged in load section p+2: row 1's reads (end of interval p) are retired by its lgkmcnt(0) at the
+  // start of interval p+1, row 0's (start of interval p) by its lgkmcnt(0) at the end of interval p -- a barrier lies between
+  // either and every DMA of phase p+2.
+  auto wait_load = [&]() __attribute__((always_inline)) {
     asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
   };
-  auto end_mfma = [&]() __attribute__((always_inline)) {
+  auto end_phase = [&]() __attribute__((always_inline)) {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -1316,14 +1321,12 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(GemmTN p) {
   __builtin_amdgcn_s_waitcnt(0xC07F);
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_s_barrier();
-  if (wr == 1) __builtin_amdgcn_s_barrier();
 
   auto ktile = [&](auto db_tag) __attribute__((always_inline)) {
     constexpr int db = decltype(db_tag)::value;
     constexpr int F = db, S = 1 - db;
     // P1: Z0 x X_F; fetch X_S
-    stage(db, 2 + F);
-    end_load();
+    if (wr == 1) { stage(db, 2 + F); wait_load(); }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       bS[S][ks] = lds_b(db, S, ks);
@@ -1331,10 +1334,10 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(GemmTN p) {
       mma32(acc[1][F], aF[1][ks], bS[F][ks]);
       __builtin_amdgcn_sched_barrier(0);
     }
-    end_mfma();
+    if (wr == 0) { stage(db, 2 + F); wait_load(); }
+    end_phase();
     // P2: Z0 x X_S; Z0 fragments replaced by Z1 in place
-    stage(db, 0);
-    end_load();
+    if (wr == 1) { stage(db, 0); wait_load(); }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -1343,10 +1346,10 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(GemmTN p) {
         aF[i2][ks] = lds_a(db, 1, i2, ks);
         __builtin_amdgcn_sched_barrier(0);
       }
-    end_mfma();
+    if (wr == 0) { stage(db, 0); wait_load(); }
+    end_phase();
     // P3: Z1 x X_S; X_S replaced by the first X half of the next k-tile
-    stage(db, 2 + S);
-    end_load();
+    if (wr == 1) { stage(db, 2 + S); wait_load(); }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       mma32(acc[2][S], aF[0][ks], bS[S][ks]);
@@ -1354,11 +1357,10 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(GemmTN p) {
       bS[S][ks] = lds_b(db ^ 1, S, ks);
       __builtin_amdgcn_sched_barrier(0);
     }
-    end_mfma();
+    if (wr == 0) { stage(db, 2 + S); wait_load(); }
+    end_phase();
     // P4: Z1 x X_F; Z1 replaced by Z0 of the next k-tile
-    stage(db, 1);
-    ++s_kt;
-    end_load();
+    if (wr == 1) { stage(db, 1); ++s_kt; wait_load(); }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -1367,13 +1369,13 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(GemmTN p) {
         aF[i2][ks] = lds_a(db ^ 1, 0, i2, ks);
         __builtin_amdgcn_sched_barrier(0);
       }
-    end_mfma();
+    if (wr == 0) { stage(db, 1); ++s_kt; wait_load(); }
+    end_phase();
   };
   for (int t = 0; t < KT; t += 2) {
     ktile(std::integral_constant<int, 0>{});
     if (t + 1 < KT) ktile(std::integral_constant<int, 1>{});
   }
-  if (wr == 0) __builtin_amdgcn_s_barrier();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // D[i' = n][j' = k]: j' = lane&31, i' = (r&3) + 8*(r>>2) + 4*(lane>>5); acc[i][j]: n block i, k block j of the wave tile
