@@ -23,6 +23,10 @@
 #define ACT_NONE 0
 #define ACT_RELU 1
 #define ACT_MASK 2  // y = (aux > 0) ? y : 0   (ReLU backward fused into dgrad)
+#define ACT_RELU_BITS 3  // ReLU, and `aux` (uint32, OUTPUT) receives one bit per element: y > 0      (persistent kernel only)
+#define ACT_MASK_BITS 4  // as ACT_MASK with `aux` = the bit mask an ACT_RELU_BITS launch of the same [M, N] wrote
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct GemmNT {
   const void* A; long lda;
@@ -607,6 +611,7 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
   constexpr int HALF = 128 * 128;                      // bytes per half-tile
   constexpr int SCRATCH = 8 * HALF;                    // 4 x 4 KiB transposition slabs
   constexpr int BIAS = SCRATCH + 4 * 4096;             // 2 x 1 KiB bias vectors (tile parity)
+  constexpr int MASKB = BIAS + 2048;                   // 8 waves x 4 units x 64 lanes x 4 B: ReLU bit masks of the current tile
   constexpr int BB = (ACT == ACT_MASK && COLSUM) ? 1 : 2;   // bias quads fetched per batch in the epilogue units (register budget)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -672,6 +677,23 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
     }
   };
 
+  // ReLU bit masks (ACT_MASK_BITS): word `lane` of block (32-row block rb, 64-column group cg) holds, in byte it, the bits of
+  // row 8 it + (lane >> 3), columns 8 (lane & 7) + e -- exactly what this lane masks in unit rb.  Each wave DMAs the four
+  // words per lane it will need for tile i (wave-private, so its own vmcnt retirement is all the ordering there is).
+  const int ncg = p.N >> 6;
+  auto stage_mask = [&](int i) __attribute__((always_inline)) {
+    if (ACT != ACT_MASK_BITS || i >= n_my) return;
+    int m0, n0;
+    origin(i, m0, n0);
+    const long words = (long)(((p.M + 255) >> 8) * 8) * ncg * 64;
+    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void*)p.aux, 0, (int)(words * 4), 0x00020000);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int rb = (m0 >> 5) + wr * 4 + u, cg = (n0 >> 6) + wc;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rm, (lds_ptr_t)(smem + MASKB + (wave * 4 + u) * 256), 4, lane * 4, (rb * ncg + cg) * 256, 0, 0);
+    }
+  };
+
   // ---- fragments ------------------------------------------------------------------------------------------------
   const int sw = ((lane & 31) >> 1) & 7;
   int cof[4];
@@ -710,8 +732,10 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
     const int ncol = en0 + wc * 64 + pch * 8;
     const bool col_ok = ncol < p.n_store && !(p.dbg & 4);
     const int mbase = em0 + wr * 128 + u * 32 + prow;
+    unsigned mw = 0;                                     // ACT_MASK_BITS: this lane's 32 mask bits; ACT_RELU_BITS: the bits it produces
+    if (ACT == ACT_MASK_BITS) mw = *(const unsigned*)(smem + MASKB + ((wave * 4 + u) * 64 + ln) * 4);
     // the ReLU mask source first: these loads sit behind the staging DMA in the (in-order) vmcnt queue
-    bf16x8 a8[4];
+    bf16x8 a8[ACT == ACT_MASK ? 4 : 1];
     if (ACT == ACT_MASK) {
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
@@ -733,7 +757,7 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           v[e] = acc[u][jj][4 * q + e] + b4[cc][e];
-          if (ACT == ACT_RELU) v[e] = v[e] > 0.f ? v[e] : 0.f;
+          if (ACT == ACT_RELU || ACT == ACT_RELU_BITS) v[e] = v[e] > 0.f ? v[e] : 0.f;
           acc[u][jj][4 * q + e] = 0.f;
         }
         const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
@@ -750,13 +774,30 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) if (!((float)a8[it][e] > 0.f)) val[e] = (T)0.f;
       }
+      if (ACT == ACT_MASK_BITS) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) if (!((mw >> (8 * it + e)) & 1u)) val[e] = (T)0.f;
+      }
       if (col_ok && m < p.M) {
         *(bf16x8*)((T*)p.Y + (long)m * p.ldy + ncol) = val;
+        if (ACT == ACT_RELU_BITS) {
+          // bf16 > 0  <=>  sign bit clear and not zero (the value is a ReLU output: never NaN-signed)
+          const u32x4 raw = __builtin_bit_cast(u32x4, val);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const unsigned h = (raw[e >> 1] >> (16 * (e & 1))) & 0xffffu;
+            mw |= (h != 0u && h < 0x8000u ? 1u : 0u) << (8 * it + e);
+          }
+        }
         if constexpr (COLSUM) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) cs[e] += (float)val[e];
         }
       }
+    }
+    if (ACT == ACT_RELU_BITS) {
+      const long blk = (long)((em0 >> 5) + wr * 4 + u) * ncg + ((en0 >> 6) + wc);
+      ((unsigned*)p.aux)[blk * 64 + ln] = mw;            // 256 contiguous bytes per wave
     }
   };
   auto flush_colsum = [&](int em0, int en0) __attribute__((always_inline)) {
@@ -794,6 +835,7 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
   if (p.bias == nullptr && tid < 128) *(f32x4*)(smem + BIAS + tid * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
   stream_tile(0);
   stage_bias(0);
+  stage_mask(0);
   stage(0, 2); stage(0, 0); stage(0, 3); stage(0, 1);
   stream_next();
   stage(1, 3); stage(1, 0); stage(1, 2); stage(1, 1);
@@ -814,7 +856,7 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
   int m0, n0;
   origin(0, m0, n0);
   int em0 = 0, en0 = 0, epar = 0;
-  bool pending = false;
+  bool pending = false, pending_mask = false;
 
   auto ktile = [&](auto db_tag) __attribute__((always_inline)) {
     constexpr int db = decltype(db_tag)::value;
@@ -857,6 +899,7 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
     // P3: A1 x B_S; B_S is replaced by the first B half of the next k-tile
     stage(db, 2 + S);
     if (last) unit(0, m0, n0, c_i & 1);
+    if (pending_mask) { stage_mask(c_i); pending_mask = false; }   // its buffer was last read by units 2, 3 of the previous tile (P1, P2)
     end_load();
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -890,7 +933,7 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
     }
     end_mfma();
     if (last) {
-      pending = true; em0 = m0; en0 = n0; epar = c_i & 1;
+      pending = true; pending_mask = true; em0 = m0; en0 = n0; epar = c_i & 1;
       c_kt = 0; ++c_i;
       origin(c_i < n_my ? c_i : n_my - 1, m0, n0);
     } else {
@@ -960,7 +1003,7 @@ static int launch_nt8(const GemmNT& p, hipStream_t stream) {
 }
 
 static int launch_nt8p(const GemmNT& p, hipStream_t stream) {
-  constexpr int LDS = 8 * 128 * 128 + 4 * 4096 + 2048;
+  constexpr int LDS = 8 * 128 * 128 + 4 * 4096 + 2048 + 8192;
   static bool attr_set = false;
   static int n_cu = 256;
   if (!attr_set) {
@@ -969,6 +1012,9 @@ static int launch_nt8p(const GemmNT& p, hipStream_t stream) {
     hipFuncSetAttribute((const void*)gemm_nt8p_kernel<ACT_NONE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     hipFuncSetAttribute((const void*)gemm_nt8p_kernel<ACT_MASK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     hipFuncSetAttribute((const void*)gemm_nt8p_kernel<ACT_MASK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipFuncSetAttribute((const void*)gemm_nt8p_kernel<ACT_RELU_BITS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipFuncSetAttribute((const void*)gemm_nt8p_kernel<ACT_MASK_BITS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipFuncSetAttribute((const void*)gemm_nt8p_kernel<ACT_MASK_BITS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
@@ -983,6 +1029,12 @@ static int launch_nt8p(const GemmNT& p, hipStream_t stream) {
   if (p.act == ACT_MASK) {
     if (cs) hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_MASK, true>), g, b, LDS, stream, p);
     else hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_MASK, false>), g, b, LDS, stream, p);
+  } else if (p.act == ACT_MASK_BITS) {
+    if (cs) hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_MASK_BITS, true>), g, b, LDS, stream, p);
+    else hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_MASK_BITS, false>), g, b, LDS, stream, p);
+  } else if (p.act == ACT_RELU_BITS) {
+    if (cs) return SNERF_ERR_ARG;
+    hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_RELU_BITS, false>), g, b, LDS, stream, p);
   } else if (cs) {
     if (p.act != ACT_NONE) return SNERF_ERR_ARG;
     hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_NONE, true>), g, b, LDS, stream, p);
@@ -1008,11 +1060,13 @@ extern "C" int snerf_linear_fwd(const void* A, long lda, const void* W, long ldw
   if (dtype != SNERF_DT_F32 && dtype != SNERF_DT_BF16) return SNERF_ERR_ARG;
   const int bke = dtype == SNERF_DT_F32 ? 32 : 64;
   if (K % bke != 0 || lda % (bke / 8) != 0 || ldw % (bke / 8) != 0) return SNERF_ERR_ARG;
-  if (act == ACT_MASK && aux == nullptr) return SNERF_ERR_ARG;
+  if ((act == ACT_MASK || act == ACT_RELU_BITS || act == ACT_MASK_BITS) && aux == nullptr) return SNERF_ERR_ARG;
+  if (act < ACT_NONE || act > ACT_MASK_BITS) return SNERF_ERR_ARG;
   // vector epilogue stores need 4-element alignment of the destination (and of the mask source)
   const long esz = (out_f32 || dtype == SNERF_DT_F32) ? 4 : 2;
   int vec = (ldy % 4 == 0) && (((uintptr_t)Y) % (4 * esz) == 0);
   if (act == ACT_MASK) vec = vec && (ldaux % 4 == 0) && (((uintptr_t)aux) % (dtype == SNERF_DT_F32 ? 16 : 8) == 0);
+  if (act >= ACT_RELU_BITS && (((uintptr_t)aux) % 4 != 0)) return SNERF_ERR_ARG;
   // fast (LDS-transposed, 16-byte) epilogue: output in the compute dtype, 16-byte aligned row segments, whole chunks
   const int epc = dtype == SNERF_DT_F32 ? 4 : 8;
   int fast = !(out_f32 && dtype == SNERF_DT_BF16) && (ldy % epc == 0) && (((uintptr_t)Y) % 16 == 0) && (n_store % epc == 0);
@@ -1025,6 +1079,12 @@ extern "C" int snerf_linear_fwd(const void* A, long lda, const void* W, long ldw
   // variant: 0 = 128x128 block-issue, 1 = 256x256 block-issue, 2 = 128x128 interleaved, 3 = 256x256 interleaved,
   //          4 = 256x256 8-phase (bf16, N % 256 == 0; other shapes take the 128x128 kernel)
   //          8 = 256x256 persistent 8-phase (bf16, N % 256 == 0, K >= 128, 16-byte epilogue; else as variant 4)
+  // the bit-mask activations exist only in the persistent kernel (the mask layout is its unit geometry); the mask DMA of a
+  // tile must retire before the tile's last k-tile, which takes K >= 256
+  const bool p8 = dtype == SNERF_DT_BF16 && (variant & 8) && N % 256 == 0 && K >= 128 && fast && !(colsum != nullptr && act == ACT_RELU) &&
+                  (lda * 2 * 256 < (1L << 31)) && (ldw * 2 * 256 < (1L << 31));
+  if (act >= ACT_RELU_BITS && !(p8 && (act == ACT_RELU_BITS || K >= 256) && (long)((M + 255) / 256) * 8 * (N / 64) * 256 < (1L << 31)))
+    return SNERF_ERR_ARG;
   if (dtype == SNERF_DT_BF16 && (variant & 8) && N % 256 == 0 && K >= 128 && fast && !(colsum != nullptr && act == ACT_RELU) && (lda * 2 * 256 < (1L << 31)) && (ldw * 2 * 256 < (1L << 31)))
     return launch_nt8p(p, s);
   if (dtype == SNERF_DT_BF16 && (variant & 12) && N % 256 == 0) return launch_nt8(p, s);

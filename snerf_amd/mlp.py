@@ -110,6 +110,8 @@ class _Net:
         self.tw[key] = out
 
     def ensure_packed(self, train: bool):
+        # ReLU bit masks written by this forward's layers (keyed by the activation view), read by the data-gradient GEMMs
+        self._bits = {} if train else None
         v = self.version_fn()
         if self._packed_version != v or (train and not self.tw):
             with torch.no_grad():
@@ -121,10 +123,25 @@ class _Net:
         return torch.empty(M, cols, dtype=torch.float32 if f32 else self.tdt, device=self.dev)
 
     def fwd(self, key, A, K, Y, n_store, act=ACT_RELU, out_f32=False):
-        ops.linear_fwd(A, self.fw[key], self.fb[key], Y, K, n_store, act, self.dt, out_f32=out_f32, variant=self.variant)
+        W = self.fw[key]
+        bits = getattr(self, "_bits", None)
+        if act == ACT_RELU and bits is not None and not out_f32 and ops.relu_bits_ok(A, W, Y, K, n_store, self.dt, self.variant):
+            # training: the ReLU also leaves a 1-bit mask (1/16 of the activation bytes) for the data gradient of the next layer
+            words = torch.empty(ops.mask_bits_words(A.shape[0], W.shape[0]), dtype=torch.int32, device=A.device)
+            ops.linear_fwd(A, W, self.fb[key], Y, K, n_store, ops.ACT_RELU_BITS, self.dt, aux=words, variant=self.variant)
+            bits[(Y.data_ptr(), Y.shape[0])] = (words, W.shape[0])
+            return
+        ops.linear_fwd(A, W, self.fb[key], Y, K, n_store, act, self.dt, out_f32=out_f32, variant=self.variant)
 
     def dgrad(self, key, dZ, K, dX, n_store, mask=None, colsum=None):
-        ops.linear_fwd(dZ, self.tw[key], None, dX, K, n_store, ACT_MASK if mask is not None else ACT_NONE, self.dt,
+        W = self.tw[key]
+        bits = getattr(self, "_bits", None)
+        if mask is not None and bits:
+            ent = bits.get((mask.data_ptr(), mask.shape[0]))
+            if ent is not None and ent[1] == W.shape[0] and ops.relu_bits_ok(dZ, W, dX, K, n_store, self.dt, self.variant, consumer=True):
+                ops.linear_fwd(dZ, W, None, dX, K, n_store, ops.ACT_MASK_BITS, self.dt, aux=ent[0], colsum=colsum, variant=self.variant)
+                return
+        ops.linear_fwd(dZ, W, None, dX, K, n_store, ACT_MASK if mask is not None else ACT_NONE, self.dt,
                        aux=mask, colsum=colsum, variant=self.variant)
 
     def wgrad(self, name, dZ, X, n_valid, k_valid, wcol=0):

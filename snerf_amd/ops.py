@@ -11,6 +11,8 @@ from . import _lib
 
 F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_MASK = 0, 1, 2
+ACT_RELU_BITS, ACT_MASK_BITS = 3, 4        # ReLU that also writes a 1-bit-per-element mask / ReLU backward from that mask
+ACT_RELU_BITS, ACT_MASK_BITS = 3, 4        # ReLU that also writes a 1-bit-per-element mask / ReLU backward from that mask
 _TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
 
 
@@ -64,14 +66,30 @@ def linear_fwd(A, W, bias, Y, K, n_store, act, dt, out_f32=False, aux=None, cols
     _chk2d(A, _TORCH_DT[dt]); _chk2d(W, _TORCH_DT[dt]); _chk2d(Y, torch.float32 if out_f32 else _TORCH_DT[dt])
     M = A.shape[0]
     assert Y.shape[0] == M and A.shape[1] >= K and W.shape[1] >= K and Y.shape[1] >= n_store
-    if aux is not None:
+    if aux is not None and act < ACT_RELU_BITS:
         _chk2d(aux, _TORCH_DT[dt])
+    if act >= ACT_RELU_BITS:
+        assert aux is not None and aux.dtype == torch.int32 and aux.is_contiguous() and aux.numel() >= mask_bits_words(M, W.shape[0])
     ws = None
     if colsum is not None:  # per-row-slab partial column sums (no atomics); folded into `colsum` by a second kernel
         ws = torch.empty(2 * ((M + 127) // 128), W.shape[0], dtype=torch.float32, device=A.device)
     _lib.call("snerf_linear_fwd", _p(A), A.stride(0), _p(W), W.stride(0), _p(bias), _p(Y), Y.stride(0),
-              _p(aux), 0 if aux is None else aux.stride(0), _p(colsum), _p(ws), M, W.shape[0], K, n_store, act, dt,
+              _p(aux), 0 if (aux is None or act >= ACT_RELU_BITS) else aux.stride(0), _p(colsum), _p(ws), M, W.shape[0], K, n_store, act, dt,
               1 if out_f32 else 0, variant, _stream())
+
+
+def mask_bits_words(M, N):
+    """int32 words of the ReLU bit mask of an [M, N] activation (N % 64 == 0): one 64-word block per (32 rows, 64 columns)."""
+    return 8 * ((M + 255) // 256) * (N // 64) * 64
+
+
+def relu_bits_ok(A, W, Y, K, n_store, dt, variant, consumer=False):
+    """Whether snerf_linear_fwd accepts ACT_RELU_BITS (producer) / ACT_MASK_BITS (consumer) for this launch: the persistent
+    8-phase kernel's conditions (mirrors the dispatch in gemm.hip)."""
+    N = W.shape[0]
+    return (dt == BF16 and (variant & 8) and N % 256 == 0 and K >= (256 if consumer else 128) and Y.dtype == torch.bfloat16
+            and Y.stride(0) % 8 == 0 and Y.data_ptr() % 16 == 0 and n_store % 8 == 0
+            and A.stride(0) * 512 < (1 << 31) and W.stride(0) * 512 < (1 << 31) and mask_bits_words(A.shape[0], N) * 4 < (1 << 31))
 
 
 def linear_wgrad(dZ, X, dW, n_valid, k_valid, dt, variant=0):

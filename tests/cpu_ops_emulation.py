@@ -12,6 +12,9 @@ from oracle import classic as oc
 from oracle import mip as om
 
 
+_BITS = {}
+
+
 def linear_fwd(A, W, bias, Y, K, n_store, act, dt, out_f32=False, aux=None, colsum=None, variant=0):
     assert W.shape[0] % 128 == 0 and K % (32 if dt == 0 else 64) == 0
     y = A[:, :K].float() @ W[:, :K].float().t()
@@ -22,6 +25,11 @@ def linear_fwd(A, W, bias, Y, K, n_store, act, dt, out_f32=False, aux=None, cols
         y = torch.relu(y)
     elif act == 2:
         y = y * (aux[:, :n_store].float() > 0)
+    elif act == 3:                                              # ReLU + bit mask (opaque buffer: keep the mask beside it)
+        y = torch.relu(y)
+        _BITS[aux.data_ptr()] = y.to(Y.dtype).float() > 0
+    elif act == 4:
+        y = y * _BITS[aux.data_ptr()][:, :n_store]
     Y[:, :n_store] = y.to(Y.dtype)
     if colsum is not None:
         colsum[:n_store] += y.sum(0)

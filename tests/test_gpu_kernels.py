@@ -90,6 +90,39 @@ def test_linear_wgrad(ops, dt, M, N, K, nv, kv):
         close(dW, ref, 1e-4, 1e-3 * (M / 1000) ** 0.5, f"wgrad variant {variant}")
 
 
+@pytest.mark.parametrize("M,N,K", [(1000, 256, 256), (70001, 512, 320), (4096, 1024, 1024)])
+def test_relu_bit_mask_roundtrip(ops, M, N, K):
+    """ACT_RELU_BITS writes the activation AND a 1-bit mask; ACT_MASK_BITS must reproduce ACT_MASK on that activation exactly."""
+    dt = 1
+    A = gen(M, K, seed=21).to(torch.bfloat16).cuda()
+    W = (gen(N, K, seed=22) / K ** 0.5).to(torch.bfloat16).cuda()
+    bias = gen(N, seed=23).cuda()
+    h_ref = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    ops.linear_fwd(A, W, bias, h_ref, K, N, ops.ACT_RELU, dt, variant=8)
+    h = torch.empty_like(h_ref)
+    bits = torch.zeros(ops.mask_bits_words(M, N), dtype=torch.int32, device="cuda")
+    assert ops.relu_bits_ok(A, W, h, K, N, dt, 8)
+    ops.linear_fwd(A, W, bias, h, K, N, ops.ACT_RELU_BITS, dt, aux=bits, variant=8)
+    assert torch.equal(h, h_ref)
+    frac = float((h_ref > 0).float().mean())
+    assert 0.2 < frac < 0.8
+    # data gradient of the next layer: dX[M, N] = dZ[M, K2] . Wt[N, K2]^T masked by h > 0
+    K2 = 256
+    dZ = gen(M, K2, seed=24).to(torch.bfloat16).cuda()
+    Wt = (gen(N, K2, seed=25) / K2 ** 0.5).to(torch.bfloat16).cuda()
+    for with_cs in (True, False):
+        cs1 = torch.zeros(N, device="cuda") if with_cs else None
+        cs2 = torch.zeros(N, device="cuda") if with_cs else None
+        d1 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        d2 = torch.full((M, N), 3.0, dtype=torch.bfloat16, device="cuda")
+        ops.linear_fwd(dZ, Wt, None, d1, K2, N, ops.ACT_MASK, dt, aux=h_ref, colsum=cs1, variant=8)
+        assert ops.relu_bits_ok(dZ, Wt, d2, K2, N, dt, 8, consumer=True)
+        ops.linear_fwd(dZ, Wt, None, d2, K2, N, ops.ACT_MASK_BITS, dt, aux=bits, colsum=cs2, variant=8)
+        assert torch.equal(d1, d2)
+        if with_cs:
+            assert torch.allclose(cs1, cs2, rtol=1e-5, atol=1e-3)
+
+
 def test_gemm_operands_as_column_ranges(ops):
     """Operands are column ranges of wider buffers (concat-by-columns layout); whatever surrounds them must not leak in."""
     dt, M, N, K = 1, 9000, 256, 320

@@ -39,6 +39,11 @@ def main():
         for v in (1, 4, 8, 8 + 64):
             ms = timeit(lambda: ops.linear_fwd(A, W, b, Y, K, N, ops.ACT_RELU, dt, variant=v), reps=10)
             print(f"NT fwd   variant={v:3d}: {ms:7.3f} ms {2.0 * M * N * K / ms / 1e9:8.1f} TF/s", flush=True)
+        bits = torch.zeros(ops.mask_bits_words(M, N), dtype=torch.int32, device="cuda")
+        ms = timeit(lambda: ops.linear_fwd(A, W, b, Y, K, N, ops.ACT_RELU_BITS, dt, aux=bits, variant=8), reps=10)
+        print(f"NT fwd+bits  variant=  8: {ms:7.3f} ms {2.0 * M * N * K / ms / 1e9:8.1f} TF/s", flush=True)
+        ms = timeit(lambda: ops.linear_fwd(A, W, None, Y, K, N, ops.ACT_MASK_BITS, dt, aux=bits, colsum=cs, variant=8), reps=10)
+        print(f"NT dgrad bits variant=  8: {ms:7.3f} ms {2.0 * M * N * K / ms / 1e9:8.1f} TF/s", flush=True)
         for v in (1, 4, 8):
             ms = timeit(lambda: ops.linear_fwd(A, W, None, Y, K, N, ops.ACT_MASK, dt, aux=A, colsum=cs, variant=v), reps=10)
             print(f"NT dgrad variant={v:3d}: {ms:7.3f} ms {2.0 * M * N * K / ms / 1e9:8.1f} TF/s", flush=True)
