@@ -28,6 +28,8 @@ extern "C" {
 #define SNERF_ACT_NONE 0
 #define SNERF_ACT_RELU 1
 #define SNERF_ACT_MASK 2 /* y = aux > 0 ? y : 0 : ReLU backward fused into the data-gradient GEMM */
+#define SNERF_ACT_RELU_BITS 3 /* ReLU; `aux` (uint32 words, OUTPUT) also receives one bit per element (y > 0) */
+#define SNERF_ACT_MASK_BITS 4 /* as SNERF_ACT_MASK with `aux` = the words an ACT_RELU_BITS launch of the same [M, N] wrote */
 
 int snerf_version(void);
 
@@ -40,7 +42,12 @@ int snerf_version(void);
  * same entry computes the data gradient; ACT_MASK applies the ReLU mask from `aux` and `colsum`
  * (fp32 [n_store], accumulated) receives the column sums = bias gradient of the layer below; `colsum_ws`
  * (fp32 [2*ceil(M/128), N], contents irrelevant) lets that reduction run without atomics.
- * variant: low nibble 0 = 128x128 tile, 1 = 256x256 tile (bf16, N % 256 == 0); higher bits = ablation switches. */
+ * The two *_BITS activations carry the ReLU mask of a training step as 1 bit per element (8*ceil(M/256) * N/64 blocks of 64
+ * words; word l of block (32-row block, 64-column group) = rows 8*it + l/8, columns 8*(l%8) + e at bit 8*it + e): 1/16 of the
+ * bytes of the activation and DMA-able ahead of use.  Only the persistent kernel implements them (bf16, variant 8,
+ * N % 256 == 0, K >= 128 to write / K >= 256 to read, 16-byte aligned Y rows); other launches return SNERF_ERR_ARG.
+ * variant (low nibble): 0 = 128x128 tile, 1 = 256x256 tile, 4 = 256x256 8-phase, 8 = 256x256 persistent 8-phase (bf16,
+ * N % 256 == 0, K >= 128, 16-byte epilogue; other shapes fall back to 4, then 0); higher bits = ablation switches. */
 int snerf_linear_fwd(const void* A, long lda, const void* W, long ldw, const float* bias, void* Y, long ldy,
                      const void* aux, long ldaux, float* colsum, float* colsum_ws, int M, int N, int K, int n_store,
                      int act, int dtype, int out_f32, int variant, void* stream);
