@@ -42,6 +42,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch ships its own libamdhip64: import it FIRST so that the dynamic linker binds libsnerf_hip.so to that already
+    # loaded runtime (same SONAME).  Loading this library before torch would bring the system runtime into the process as a
+    # second HIP instance, and kernels registered with one runtime cannot be launched on the other's streams.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"libsnerf_hip.so not found at {LIB_PATH}: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
