@@ -182,6 +182,8 @@ def main():
     ap.add_argument("--shape", default="baseline", choices=["baseline", "shipped"],
                     help="baseline = BASELINE.json's 64 proposal + 128 fine evals/ray (192 spp); shipped = the reference config's "
                          "128 proposal + 127 fine intervals (configs/nuScenes_depth_6cams)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for functional tests)")
+    ap.add_argument("--same-device", action="store_true", help="functional test of the N > 1 control flow on a 1-GPU box: every rank uses cuda:0")
     ap.add_argument("--eager", action="store_true", help="also time the plain PyTorch-ROCm eager train step on this GPU (fp32 and bf16 autocast)")
     ap.add_argument("--frame-chunk", type=int, default=32768)
     args = ap.parse_args()
@@ -192,10 +194,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.same_device:
+        local = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend)
     else:
         torch.cuda.set_device(0)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
