@@ -45,7 +45,7 @@ int snerf_version(void);
  * The two *_BITS activations carry the ReLU mask of a training step as 1 bit per element (8*ceil(M/256) * N/64 blocks of 64
  * words; word l of block (32-row block, 64-column group) = rows 8*it + l/8, columns 8*(l%8) + e at bit 8*it + e): 1/16 of the
  * bytes of the activation and DMA-able ahead of use.  Only the persistent kernel implements them (bf16, variant 8,
- * N % 256 == 0, K >= 128 to write / K >= 256 to read, 16-byte aligned Y rows); other launches return SNERF_ERR_ARG.
+ * N % 256 == 0, K >= 128, 16-byte aligned Y rows); other launches return SNERF_ERR_ARG.
  * variant (low nibble): 0 = 128x128 tile, 1 = 256x256 tile, 4 = 256x256 8-phase, 8 = 256x256 persistent 8-phase (bf16,
  * N % 256 == 0, K >= 128, 16-byte epilogue; other shapes fall back to 4, then 0); higher bits = ablation switches. */
 int snerf_linear_fwd(const void* A, long lda, const void* W, long ldw, const float* bias, void* Y, long ldy,

@@ -733,7 +733,12 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
     const bool col_ok = ncol < p.n_store && !(p.dbg & 4);
     const int mbase = em0 + wr * 128 + u * 32 + prow;
     unsigned mw = 0;                                     // ACT_MASK_BITS: this lane's 32 mask bits; ACT_RELU_BITS: the bits it produces
-    if (ACT == ACT_MASK_BITS) mw = *(const unsigned*)(smem + MASKB + ((wave * 4 + u) * 64 + ln) * 4);
+    if (ACT == ACT_MASK_BITS) {
+      // the mask DMA was issued in P3 of the tile's first k-tile; with fewer than four k-tiles the vmcnt(10) of the load
+      // sections in between has not necessarily retired it (wave-private data: this wave's own wait is all it takes)
+      if (KT < 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      mw = *(const unsigned*)(smem + MASKB + ((wave * 4 + u) * 64 + ln) * 4);
+    }
     // the ReLU mask source first: these loads sit behind the staging DMA in the (in-order) vmcnt queue
     bf16x8 a8[ACT == ACT_MASK ? 4 : 1];
     if (ACT == ACT_MASK) {
@@ -1079,11 +1084,10 @@ extern "C" int snerf_linear_fwd(const void* A, long lda, const void* W, long ldw
   // variant: 0 = 128x128 block-issue, 1 = 256x256 block-issue, 2 = 128x128 interleaved, 3 = 256x256 interleaved,
   //          4 = 256x256 8-phase (bf16, N % 256 == 0; other shapes take the 128x128 kernel)
   //          8 = 256x256 persistent 8-phase (bf16, N % 256 == 0, K >= 128, 16-byte epilogue; else as variant 4)
-  // the bit-mask activations exist only in the persistent kernel (the mask layout is its unit geometry); the mask DMA of a
-  // tile must retire before the tile's last k-tile, which takes K >= 256
+  // the bit-mask activations exist only in the persistent kernel (the mask layout is its unit geometry)
   const bool p8 = dtype == SNERF_DT_BF16 && (variant & 8) && N % 256 == 0 && K >= 128 && fast && !(colsum != nullptr && act == ACT_RELU) &&
                   (lda * 2 * 256 < (1L << 31)) && (ldw * 2 * 256 < (1L << 31));
-  if (act >= ACT_RELU_BITS && !(p8 && (act == ACT_RELU_BITS || K >= 256) && (long)((M + 255) / 256) * 8 * (N / 64) * 256 < (1L << 31)))
+  if (act >= ACT_RELU_BITS && !(p8 && (long)((M + 255) / 256) * 8 * (N / 64) * 256 < (1L << 31)))
     return SNERF_ERR_ARG;
   if (dtype == SNERF_DT_BF16 && (variant & 8) && N % 256 == 0 && K >= 128 && fast && !(colsum != nullptr && act == ACT_RELU) && (lda * 2 * 256 < (1L << 31)) && (ldw * 2 * 256 < (1L << 31)))
     return launch_nt8p(p, s);

@@ -87,7 +87,7 @@ def relu_bits_ok(A, W, Y, K, n_store, dt, variant, consumer=False):
     """Whether snerf_linear_fwd accepts ACT_RELU_BITS (producer) / ACT_MASK_BITS (consumer) for this launch: the persistent
     8-phase kernel's conditions (mirrors the dispatch in gemm.hip)."""
     N = W.shape[0]
-    return (dt == BF16 and (variant & 8) and N % 256 == 0 and K >= (256 if consumer else 128) and Y.dtype == torch.bfloat16
+    return (dt == BF16 and (variant & 8) and N % 256 == 0 and K >= 128 and Y.dtype == torch.bfloat16
             and Y.stride(0) % 8 == 0 and Y.data_ptr() % 16 == 0 and n_store % 8 == 0
             and A.stride(0) * 512 < (1 << 31) and W.stride(0) * 512 < (1 << 31) and mask_bits_words(A.shape[0], N) * 4 < (1 << 31))
 

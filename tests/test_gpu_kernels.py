@@ -107,7 +107,7 @@ def test_relu_bit_mask_roundtrip(ops, M, N, K):
     frac = float((h_ref > 0).float().mean())
     assert 0.2 < frac < 0.8
     # data gradient of the next layer: dX[M, N] = dZ[M, K2] . Wt[N, K2]^T masked by h > 0
-    K2 = 256
+    K2 = 256 if M != 70001 else 128                              # 128: two k-tiles, the mask DMA is drained explicitly
     dZ = gen(M, K2, seed=24).to(torch.bfloat16).cuda()
     Wt = (gen(N, K2, seed=25) / K2 ** 0.5).to(torch.bfloat16).cuda()
     for with_cs in (True, False):
