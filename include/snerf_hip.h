@@ -164,12 +164,15 @@ int snerf_zip_encode_fwd(const float* tdist, const float* origins, const float* 
 /* matching scatter-add of grad_feat [R*S, ld] into the fp32 table gradient (gridencoder.cu:248-340 composed with the mean /
  * erf weights); grad_table accumulates (fp32 atomics).  The first `lds_levels` levels (small dense tables) are accumulated
  * in LDS by persistent workgroups, in slabs of `lds_cells` rows (lds_cells*C*4 <= 160 KB; lds_slabs = sum of
- * ceil(rows_l / lds_cells) over those levels), and flushed once. */
+ * ceil(rows_l / lds_cells) over those levels), and flushed once.  grad_table_bf16 (nullable, C even): a bf16 [entries, C]
+ * buffer that receives the contributions of the remaining (hashed) levels as packed bf16-pair atomics instead -- half the
+ * atomic operations (what the reference does with __half2 under autocast, gridencoder.cu:300-330); the caller adds it to the
+ * fp32 gradient afterwards. */
 int snerf_zip_encode_bwd(const float* tdist, const float* origins, const float* directions, const float* radii,
                          const float* base_x, const float* base_y, const float* deg_jitter, const int* offsets,
                          const int* grid_sizes, const void* grad_feat, long ld, float* grad_table, long R, int S, int L, int C,
                          int n, int m, float Sl, int H, float std_scale, int feat_dtype, int lds_levels, long lds_cells,
-                         int lds_slabs, void* stream);
+                         int lds_slabs, void* grad_table_bf16, void* stream);
 /* render.compute_alpha_weights (render.py:170-189, opaque_background) + volumetric_rendering (render.py:192-233: rgb with
  * clamped background weight, depth = clip(exp(E_w[log t_mid]))) fused with density = softplus(raw + bias) (models.py:586)
  * and rgb = sigmoid(raw)(1 + 2 pad) - pad (models.py:689-703).  raw_rgb NULL = proposal level (rgb = 0). */

@@ -164,6 +164,7 @@ struct ZipEnc {
   const void* table; const int* offsets; const int* grid_sizes;   // grid_sizes[l] = GridEncoder.grid_sizes (resolution + 1)
   void* feat; long ld;                // forward: output [P, ld]; backward: gradient input
   float* grad_table;                  // backward only (fp32)
+  void* grad_table16;                 // backward, optional: bf16 [entries, C] for the levels that scatter with global atomics (C even)
   long R; int S, L, n, m; float Sl; int H; float std_scale;
   int level_begin;                    // first level handled by the generic kernel
   long slab_row0, slab_rows;          // LDS-privatised backward: the row range this workgroup accumulates
@@ -255,6 +256,16 @@ __device__ __forceinline__ void zip_point_level(const ZipEnc& a, long p, int lev
         if (lr >= 0 && lr < a.slab_rows) {
 #pragma unroll
           for (int c = 0; c < C; ++c) atomicAdd(lds_tab + lr * C + c, wsum[idx] * g[c]);
+        }
+      } else if (C % 2 == 0 && a.grad_table16 != nullptr) {
+        // the fp32 atomic rate is a hardware constant (profiles/r1_q): a packed bf16 pair halves the number of atomics
+        typedef short s16x2 __attribute__((ext_vector_type(2)));
+        typedef __bf16 b16x2 __attribute__((ext_vector_type(2)));
+        short* dst = (short*)a.grad_table16 + ((long)a.offsets[level] + row) * C;
+#pragma unroll
+        for (int c = 0; c < C; c += 2) {
+          const b16x2 v = {(__bf16)(wsum[idx] * g[c]), (__bf16)(wsum[idx] * g[c + 1])};
+          __builtin_amdgcn_global_atomic_fadd_v2bf16((__attribute__((address_space(1))) s16x2*)(dst + c), __builtin_bit_cast(s16x2, v));
         }
       } else {
         float* dst = a.grad_table + ((long)a.offsets[level] + row) * C;
@@ -393,7 +404,7 @@ extern "C" int snerf_zip_encode_fwd(const float* tdist, const float* origins, co
                                     int m, float Sl, int H, float std_scale, int table_dtype, int feat_dtype, void* stream) {
   if (R <= 0) return SNERF_OK;
   if (S <= 0 || L <= 0 || n <= 0 || ld < (long)L * C || table == nullptr || feat == nullptr || grid_sizes == nullptr) return SNERF_ERR_ARG;
-  ZipEnc a{tdist, origins, directions, radii, base_x, base_y, deg_jitter, table, offsets, grid_sizes, feat, ld, nullptr, R, S, L, n, m, Sl, H, std_scale};
+  ZipEnc a{tdist, origins, directions, radii, base_x, base_y, deg_jitter, table, offsets, grid_sizes, feat, ld, nullptr, nullptr, R, S, L, n, m, Sl, H, std_scale};
   return zip_enc_dispatch<false>(a, C, table_dtype, feat_dtype, 0, 0, 0, (hipStream_t)stream);
 }
 
@@ -401,10 +412,11 @@ extern "C" int snerf_zip_encode_bwd(const float* tdist, const float* origins, co
                                     const float* base_x, const float* base_y, const float* deg_jitter, const int* offsets,
                                     const int* grid_sizes, const void* grad_feat, long ld, float* grad_table, long R, int S, int L, int C,
                                     int n, int m, float Sl, int H, float std_scale, int feat_dtype, int lds_levels, long lds_cells,
-                                    int lds_slabs, void* stream) {
+                                    int lds_slabs, void* grad_table_bf16, void* stream) {
   if (R <= 0) return SNERF_OK;
   if (S <= 0 || L <= 0 || n <= 0 || ld < (long)L * C || grad_feat == nullptr || grad_table == nullptr || grid_sizes == nullptr) return SNERF_ERR_ARG;
-  ZipEnc a{tdist, origins, directions, radii, base_x, base_y, deg_jitter, nullptr, offsets, grid_sizes, (void*)grad_feat, ld, grad_table, R, S, L, n, m, Sl, H, std_scale};
+  if (grad_table_bf16 != nullptr && (C % 2 != 0 || ((uintptr_t)grad_table_bf16) % 4 != 0)) return SNERF_ERR_ARG;
+  ZipEnc a{tdist, origins, directions, radii, base_x, base_y, deg_jitter, nullptr, offsets, grid_sizes, (void*)grad_feat, ld, grad_table, grad_table_bf16, R, S, L, n, m, Sl, H, std_scale};
   // the first lds_levels levels take the LDS-privatised path in slabs of lds_cells rows (lds_cells * C * 4 bytes <= 160 KB);
   // lds_slabs = sum over those levels of ceil(rows / lds_cells) (the host knows the level sizes)
   if (lds_levels < 0 || lds_levels > L || (lds_levels > 0 && (lds_cells <= 0 || lds_cells * C * 4 > 160 * 1024 || lds_slabs < lds_levels))) return SNERF_ERR_ARG;

@@ -338,12 +338,14 @@ def zip_encode_fwd(tdist, origins, directions, radii, base_x, base_y, deg_jitter
 
 
 def zip_encode_bwd(tdist, origins, directions, radii, base_x, base_y, deg_jitter, offsets, grid_sizes, grad_feat, grad_table, L, C, n, m, Sl, H,
-                   std_scale, lds_levels=0, lds_cells=0, lds_slabs=0):
+                   std_scale, lds_levels=0, lds_cells=0, lds_slabs=0, grad_table_bf16=None):
     R, P = tdist.shape
     assert grad_table.dtype == torch.float32 and grad_table.is_contiguous()
+    if grad_table_bf16 is not None:
+        assert grad_table_bf16.dtype == torch.bfloat16 and grad_table_bf16.is_contiguous() and grad_table_bf16.numel() == grad_table.numel()
     _lib.call("snerf_zip_encode_bwd", _p(tdist), _p(origins), _p(directions), _p(radii), _p(base_x), _p(base_y), _p(deg_jitter), _p(offsets),
               _p(grid_sizes), _p(grad_feat), grad_feat.stride(0), _p(grad_table), R, P - 1, L, C, n, m, float(Sl), int(H), float(std_scale),
-              _zip_dt(grad_feat), int(lds_levels), int(lds_cells), int(lds_slabs), _stream())
+              _zip_dt(grad_feat), int(lds_levels), int(lds_cells), int(lds_slabs), _p(grad_table_bf16), _stream())
 
 
 def zip_composite_fwd(raw_rgb, raw_density, tdist, dirs, opaque, bg, rgb_padding, density_bias):

@@ -78,7 +78,7 @@ class Model(_ArenaModule):
     single_mlp: bool = False
 
     def __init__(self, config=None, compute: str = "bf16", table_dtype: str = "f16", device="cuda", grid_log2_hashmap_size: int = 21,
-                 nerf_desired_resolution: int = 8192, init_std: float = 1e-4, **kwargs):
+                 nerf_desired_resolution: int = 8192, init_std: float = 1e-4, table_grad_dtype: str = "f32", **kwargs):
         super().__init__()
         for k, v in kwargs.items():
             setattr(self, k, v)
@@ -103,6 +103,9 @@ class Model(_ArenaModule):
         self.dt = _dt(compute)
         self.compute = compute
         self.table_half = {"f16": True, "fp16": True, "f32": False, "fp32": False}[table_dtype]
+        # "bf16": the hashed levels' table gradient is scattered as packed bf16 pairs (the reference's autocast path scatters
+        # __half2, gridencoder.cu:300-330); "f32" (default) keeps every contribution in fp32
+        self.table_grad_bf16 = {"f32": False, "fp32": False, "bf16": True}[table_grad_dtype]
         self.nets = [ZipPropNet(self.arena, "prop_mlp_0.", self.dt, self.encs[0].L), ZipPropNet(self.arena, "prop_mlp_1.", self.dt, self.encs[1].L),
                      ZipNerfNet(self.arena, "nerf_mlp.", self.dt, self.encs[2].L * 4)]
         for n in self.nets:
@@ -212,9 +215,16 @@ class Model(_ArenaModule):
             ops.zip_composite_bwd(L["raw_rgb"], L["raw_d"], L["tdist"], ctx["d"], self.opaque_background, ctx["bg"], 0.001, -1.0, L["weights"],
                                   L["acc"], L["depth"], cc(g_rgb), cc(g_depth), cc(g_acc), cc(g_w), d_rgb, d_den)
             dF = net.backward(d_den, L["saved"]) if lvl < 2 else net.backward(d_rgb, d_den, L["saved"])
+            gtab = self.arena.g[self.names[lvl] + "encoder.embeddings"]
+            g16 = None
+            if self.table_grad_bf16 and e.C % 2 == 0:
+                # hashed levels scatter packed bf16 pairs (half the atomics); folded into the fp32 gradient right after
+                g16 = torch.zeros(gtab.shape, dtype=torch.bfloat16, device=dev)
             ops.zip_encode_bwd(L["tdist"], ctx["o"], ctx["d"], ctx["radii"], ctx["bx"], ctx["by"], L["degj"], self.dev_offsets[lvl],
-                               self.dev_sizes[lvl], dF, self.arena.g[self.names[lvl] + "encoder.embeddings"], e.L, e.C, ctx["n"], ctx["m"], e.Sl,
-                               e.H, self.std_scale, e.lds_levels, e.lds_cells, e.lds_slabs)
+                               self.dev_sizes[lvl], dF, gtab, e.L, e.C, ctx["n"], ctx["m"], e.Sl,
+                               e.H, self.std_scale, e.lds_levels, e.lds_cells, e.lds_slabs, grad_table_bf16=g16)
+            if g16 is not None:
+                gtab.add_(g16)
 
     def _draws(self, R, rand, dev, sample_n):
         """the reference's RNG draws in its order: per level one single-jitter draw (stepfun.py:216) then the helix phase

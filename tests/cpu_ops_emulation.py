@@ -187,7 +187,7 @@ def zip_encode_fwd(tdist, origins, directions, radii, base_x, base_y, deg_jitter
 
 
 def zip_encode_bwd(tdist, origins, directions, radii, base_x, base_y, deg_jitter, offsets, grid_sizes, grad_feat, grad_table, L, C, n, m, Sl, H,
-                   std_scale, lds_levels=0, lds_cells=0, lds_slabs=0):
+                   std_scale, lds_levels=0, lds_cells=0, lds_slabs=0, grad_table_bf16=None):
     from oracle import grid as og
     x01, s = _zip_points(tdist, origins, directions, radii, base_x, base_y, deg_jitter, n, m, std_scale)
     w = torch.erf(1 / torch.sqrt(8 * s[..., None] ** 2 * grid_sizes.float() ** 2))             # [R,S,n,L]

@@ -175,3 +175,31 @@ def test_zip_train_step_at_scale():
         assert bool(torch.isfinite(rgb).all()) and bool(torch.isfinite(gr).all()) and float(gr.abs().max()) > 0
         rgbs[compute] = rgb.detach().float()
     assert float((rgbs["bf16"] - rgbs["f32"]).abs().max()) < 3e-2
+
+
+@pytest.mark.gpu
+def test_zip_table_gradient_bf16_pairs_match_fp32():
+    """table_grad_dtype="bf16" (half the atomics on the hashed levels) against the fp32 scatter on the same step."""
+    from snerf_amd import zipnerf
+    R = 2048
+    g = torch.Generator().manual_seed(4)
+    d = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1)
+    bx = torch.nn.functional.normalize(torch.cross(d, torch.tensor([0.0, 1.0, 0.0]).expand(R, 3), dim=-1), dim=-1)
+    by = torch.nn.functional.normalize(torch.cross(d, bx, dim=-1), dim=-1)
+    batch = {k: v.cuda() for k, v in dict(origins=torch.randn(R, 3, generator=g) * 0.05, directions=d, viewdirs=d, radii=torch.full((R, 1), 5e-4),
+                                          near=torch.full((R, 1), 0.1), far=torch.full((R, 1), 10.0), base_x=bx, base_y=by).items()}
+    tgt = torch.rand(R, 3, generator=g).cuda()
+    grads = {}
+    for mode in ("f32", "bf16"):
+        torch.manual_seed(0)
+        m = zipnerf.Model(config=None, raydist_fn='power_transformation', opaque_background=True, compute="bf16", table_dtype="f16",
+                          grid_log2_hashmap_size=19, init_std=0.1, table_grad_dtype=mode)
+        draws = m._draws(R, False, m.arena.flat.device, 7)
+        ren, _ = m(False, batch, 1.0, False, draws=draws)
+        ((ren[2]["rgb"] - tgt) ** 2).mean().backward()
+        grads[mode] = dict(m.named_parameters())["nerf_mlp.encoder.embeddings"].grad.float().flatten().clone()
+    a, b = grads["f32"], grads["bf16"]
+    assert float(a.abs().max()) > 0
+    cos = float((a * b).sum() / (a.norm() * b.norm()))
+    assert cos > 0.9995, cos
+    assert float((a - b).norm() / a.norm()) < 3e-2

@@ -16,11 +16,12 @@ def main():
     ap.add_argument("--compute", default="bf16")
     ap.add_argument("--table", default="f16")
     ap.add_argument("--log2T", type=int, default=21)
+    ap.add_argument("--table-grad", default="f32", choices=["f32", "bf16"])
     args = ap.parse_args()
     from snerf_amd import ops, zipnerf
     torch.manual_seed(0)
     m = zipnerf.Model(config=None, raydist_fn='power_transformation', opaque_background=True, compute=args.compute, table_dtype=args.table,
-                      grid_log2_hashmap_size=args.log2T, init_std=0.1)
+                      grid_log2_hashmap_size=args.log2T, init_std=0.1, table_grad_dtype=args.table_grad)
     R = args.rays
     g = torch.Generator().manual_seed(1)
     # Waymo-like pinhole rays (1920x1280, focal 2050), scene rescaled so that near = 0.1, far = 10 (configs/waymo.gin)
@@ -76,7 +77,7 @@ def main():
     enc_ms = [e0.elapsed_time(e1) for e0, e1 in rec]
     tb = 2 if args.table == "f16" else 4
     bytes_lvl = [R * 7 * 64 * 6 * 8 * 1 * tb, R * 7 * 64 * 8 * 8 * 1 * tb, R * 7 * 32 * 10 * 8 * 4 * tb]
-    out = {"path": "C (zipnerf Model, waymo.gin shape: 64+64+32 intervals x 7 multisamples, grids L=6/8/10)", "rays": R, "compute": args.compute,
+    out = {"path": "C (zipnerf Model, waymo.gin shape: 64+64+32 intervals x 7 multisamples, grids L=6/8/10)", "rays": R, "compute": args.compute, "table_grad": args.table_grad,
            "table": args.table, "train_ms": round(dt_train * 1e3, 3), "train_rays_per_s": round(R / dt_train, 1), "fwd_ms": round(dt_fwd * 1e3, 3),
            "fwd_rays_per_s": round(R / dt_fwd, 1), "encode_fwd_ms_per_level": [round(x, 3) for x in enc_ms],
            "encode_fwd_gather_GBps_per_level": [round(b / (ms * 1e-3) / 1e9, 1) for b, ms in zip(bytes_lvl, enc_ms)],
