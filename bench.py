@@ -184,6 +184,9 @@ def main():
                          "128 proposal + 127 fine intervals (configs/nuScenes_depth_6cams)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for functional tests)")
     ap.add_argument("--same-device", action="store_true", help="functional test of the N > 1 control flow on a 1-GPU box: every rank uses cuda:0")
+    ap.add_argument("--ert", type=float, nargs=2, default=None, metavar=("EPS_T", "EPS_W"),
+                    help="also render the frame with early ray termination + sample compaction (inference extension, not the reference's "
+                         "algorithm): skip fine samples whose proposal-predicted transmittance <= EPS_T or weight <= EPS_W")
     ap.add_argument("--eager", action="store_true", help="also time the plain PyTorch-ROCm eager train step on this GPU (fp32 and bf16 autocast)")
     ap.add_argument("--frame-chunk", type=int, default=32768)
     args = ap.parse_args()
@@ -300,6 +303,26 @@ def main():
             te = torch.tensor([t_frame], device=device, dtype=torch.float64)
             dist.all_reduce(te, op=dist.ReduceOp.MAX)
             t_frame = te.item()
+        if args.ert is not None:
+            with torch.no_grad():
+                barrier()
+                t1 = time.perf_counter()
+                kept = tot = 0
+                outs_e = []
+                for i in range(0, len(pix), chunk):
+                    fr = frame_rays(int(pix[i]), len(pix[i:i + chunk]), device)
+                    ret = model(fr, False, False, 0., ert=tuple(args.ert))
+                    kept += model.last_ert_rows[0]; tot += model.last_ert_rows[1]
+                    outs_e.append(torch.cat([ret[1][0], ret[1][1][:, None]], -1))
+                barrier()
+                t_ert = time.perf_counter() - t1
+                img_e = torch.cat(outs_e, 0)
+                mse = float(((img_e[:, :3] - img[:, :3]) ** 2).mean())
+            if rank == 0:
+                out["frame_ert"] = {"eps_t": args.ert[0], "eps_w": args.ert[1], "ms_per_frame": round(t_ert * 1e3, 1),
+                                    "fine_samples_evaluated": round(kept / max(tot, 1), 4),
+                                    "psnr_vs_full_db": (float("inf") if mse == 0 else round(-10.0 * math.log10(mse), 2)),
+                                    "note": "inference extension (csrc/ert.hip), not the reference's algorithm; rank-0 shard"}
         if rank == 0:
             out["ms_per_frame"] = round(t_frame * 1e3, 1)
             out["frame"] = {"resolution": "1600x900", "rays": H * W, "spp": S0 + P1 - 1, "chunk": chunk, "rays_per_s": round(H * W / t_frame, 1),

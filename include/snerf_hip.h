@@ -75,11 +75,11 @@ int snerf_classic_embed(const float* pts, const float* viewdirs, int vd_stride, 
 int snerf_mip_encode(const float* s_vals, const float* origins, const float* directions, const float* radii,
                      const float* near, const float* far, long n_rays, int S, int cone, int transform_idx, int max_deg,
                      void* dst1, long ld1, void* dst2, long ld2, int width, float* means_out, float* covs_out,
-                     int dtype, void* stream);
+                     int dtype, const int* sample_id, long n_rows, void* stream);
 
 /* mip.py:12-21 pos_enc(viewdirs, 0, deg, append_identity) tiled per sample (models.py:285-287). */
 int snerf_mip_viewenc(const float* viewdirs, long n_rays, int S, int deg, void* dst, long ld, int width, int dtype,
-                      void* stream);
+                      const int* sample_id, long n_rows, void* stream);
 
 /* ---- samplers (bit-exact interval indices; fp64 sequential accumulation per ray) -----------------
  * run_nerf_helpers.py:336-379 sample_pdf.  nc = number of bins = cdf entries, nc-1 weights (rows ld_w apart).
@@ -107,7 +107,7 @@ int snerf_stratified(const float* base, const float* rnd, const float* near, con
 int snerf_mip_composite_fwd(const float* raw_rgb, long ld_rgb, const float* raw_density, long ld_den, const float* noise,
                             const float* s_vals, const float* dirs, const float* near, const float* far, long N, int S,
                             int transform_idx, int white, float rgb_padding, float density_bias, float* comp_rgb,
-                            float* distance, float* acc, float* weights, void* stream);
+                            float* distance, float* acc, float* weights, const int* row_index, void* stream);
 int snerf_mip_composite_bwd(const float* raw_rgb, long ld_rgb, const float* raw_density, long ld_den, const float* noise,
                             const float* s_vals, const float* dirs, const float* near, const float* far, long N, int S,
                             int transform_idx, int white, float rgb_padding, float density_bias, const float* weights,
@@ -192,6 +192,16 @@ int snerf_adam_step(float* p, float* g, float* m, float* v, long n, float lr, fl
                     float grad_scale, int zero_grad, void* stream);
 int snerf_colsum_f32(const float* x, long ld, long M, int C, float* out, void* stream);
 int snerf_cast_pad(const float* src, long ld_src, long M, int C, int Cpad, void* dst, long ld_dst, int dtype, void* stream);
+
+/* ---- early ray termination + sample compaction (inference; NOT in the reference: opt-in, error bounded by the proposal) -----
+ * From the proposal histogram (s0 [N,S0+1], w0 [N,S0]) and the resampled fence posts s1 [N,S1+1]: W = cumulative proposal
+ * weight (piecewise linear), T_i = 1 - W(s1[i]), m_i = W(s1[i+1]) - W(s1[i]); fine interval i is kept iff T_i > eps_t and
+ * m_i > eps_w.  Outputs: row_index [N,S1] (row of the kept sample in the compacted arrays, -1 = skipped), sample_id [rows]
+ * (= ray * S1 + i of every row, rows in ray-major order) and *total = number of rows (device).  masks (8*N*ceil(S1/64) bytes)
+ * and counts (int32 [N]) are scratch.  snerf_mip_encode / snerf_mip_viewenc take `sample_id, n_rows` (NULL = all samples) and
+ * snerf_mip_composite_fwd takes `row_index` (NULL = dense rows) to run the fine level on the compacted rows. */
+int snerf_ert_compact(const float* s0, const float* w0, const float* s1, long N, int S0, int S1, float eps_t, float eps_w,
+                      void* masks, int* counts, int* row_index, int* sample_id, long* total, void* stream);
 
 /* ---- the callers either side of the path --------------------------------------------------------
  * Ray generation: s-nerf/utils/sample_utils.py:286-345 get_rays_single_img (training = 0: whole frame / any pixels, half-pixel

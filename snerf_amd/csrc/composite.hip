@@ -32,6 +32,7 @@ struct MipComp {
   // backward inputs / outputs
   const float* g_rgb; const float* g_dist; const float* g_acc; const float* g_w;   // [N,3],[N],[N],[N,S] (nullable)
   float* d_raw_rgb; long ld_drgb; float* d_raw_density; long ld_dden;
+  const int* row_index;                    // forward, optional [N,S]: row of sample (ray, i) in the compacted raw arrays, -1 = not evaluated (empty)
 };
 
 // ---- forward -------------------------------------------------------------
@@ -50,13 +51,17 @@ __global__ __launch_bounds__(256) void mip_composite_fwd_kernel(MipComp a) {
     const int i = base + lane;
     const bool ok = i < S;
     float dd = 0.f, tmid = 0.f;
+    long row = -1;
     if (ok) {
       const float t0 = transform_s(sv[i], near, far, a.transform_idx);
       const float t1 = transform_s(sv[i + 1], near, far, a.transform_idx);
       tmid = 0.5f * (t0 + t1);
-      float rd = a.raw_density[(ray * S + i) * a.ld_den];
-      if (a.noise != nullptr) rd += a.noise[ray * S + i];
-      dd = softplus_f(rd + a.density_bias) * ((t1 - t0) * dnorm);
+      row = a.row_index != nullptr ? (long)a.row_index[ray * S + i] : ray * S + i;
+      if (row >= 0) {
+        float rd = a.raw_density[row * a.ld_den];
+        if (a.noise != nullptr) rd += a.noise[ray * S + i];
+        dd = softplus_f(rd + a.density_bias) * ((t1 - t0) * dnorm);
+      }
     }
     const float incl = wave_incl_scan_add(dd, lane);
     const float excl = carry + (incl - dd);
@@ -65,8 +70,8 @@ __global__ __launch_bounds__(256) void mip_composite_fwd_kernel(MipComp a) {
     if (ok) a.weights[ray * S + i] = w;
     s_acc += w;
     s_dist += w * tmid;
-    if (a.raw_rgb != nullptr && ok) {
-      const float* rr = a.raw_rgb + (ray * S + i) * a.ld_rgb;
+    if (a.raw_rgb != nullptr && ok && row >= 0) {
+      const float* rr = a.raw_rgb + row * a.ld_rgb;
 #pragma unroll
       for (int c = 0; c < 3; ++c) s_rgb[c] += w * (sigmoid_f(rr[c]) * (1.f + 2.f * a.rgb_padding) - a.rgb_padding);
     }
@@ -197,12 +202,12 @@ static MipComp make_mip(const float* raw_rgb, long ld_rgb, const float* raw_dens
 extern "C" int snerf_mip_composite_fwd(const float* raw_rgb, long ld_rgb, const float* raw_density, long ld_den, const float* noise,
                                        const float* s_vals, const float* dirs, const float* near, const float* far, long N, int S,
                                        int transform_idx, int white, float rgb_padding, float density_bias, float* comp_rgb,
-                                       float* distance, float* acc, float* weights, void* stream) {
+                                       float* distance, float* acc, float* weights, const int* row_index, void* stream) {
   if (N <= 0) return SNERF_OK;
   if (S <= 0 || raw_density == nullptr || weights == nullptr || distance == nullptr || acc == nullptr) return SNERF_ERR_ARG;
   if (raw_rgb != nullptr && comp_rgb == nullptr) return SNERF_ERR_ARG;
   MipComp a = make_mip(raw_rgb, ld_rgb, raw_density, ld_den, noise, s_vals, dirs, near, far, N, S, transform_idx, white, rgb_padding, density_bias);
-  a.comp_rgb = comp_rgb; a.distance = distance; a.acc = acc; a.weights = weights;
+  a.comp_rgb = comp_rgb; a.distance = distance; a.acc = acc; a.weights = weights; a.row_index = row_index;
   hipLaunchKernelGGL(mip_composite_fwd_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
   return snerf_check_launch();
 }

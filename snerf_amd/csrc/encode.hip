@@ -91,6 +91,7 @@ struct MipEncArgs {
   int cone, transform_idx, max_deg;
   void* dst1; long ld1; void* dst2; long ld2; int width;  // width >= 6*max_deg, zero padded
   float* means_out; float* covs_out;                       // optional [M,3] debug/parity outputs
+  const int* sample_id;                                    // optional [M]: row j encodes sample sample_id[j] = ray * S + i (compacted rows)
 };
 
 template <typename T>
@@ -99,8 +100,9 @@ __global__ __launch_bounds__(256) void mip_encode_kernel(MipEncArgs a) {
   const long mbase = (long)blockIdx.x * 256;
   const long m = mbase + threadIdx.x;
   if (m < a.M) {
-    const long ray = m / a.S;
-    const int i = (int)(m - ray * a.S);
+    const long src = a.sample_id != nullptr ? (long)a.sample_id[m] : m;
+    const long ray = src / a.S;
+    const int i = (int)(src - ray * a.S);
     const float near = a.near[ray], far = a.far[ray];
     const float t0 = mip_transform(a.s_vals[ray * (a.S + 1) + i], near, far, a.transform_idx);
     const float t1 = mip_transform(a.s_vals[ray * (a.S + 1) + i + 1], near, far, a.transform_idx);
@@ -186,11 +188,12 @@ __global__ __launch_bounds__(256) void mip_encode_kernel(MipEncArgs a) {
 extern "C" int snerf_mip_encode(const float* s_vals, const float* origins, const float* directions, const float* radii,
                                 const float* near, const float* far, long n_rays, int S, int cone, int transform_idx, int max_deg,
                                 void* dst1, long ld1, void* dst2, long ld2, int width, float* means_out, float* covs_out,
-                                int dtype, void* stream) {
-  if (n_rays <= 0) return SNERF_OK;
+                                int dtype, const int* sample_id, long n_rows, void* stream) {
+  if (n_rays <= 0 || (sample_id != nullptr && n_rows <= 0)) return SNERF_OK;
   if (S <= 0 || width < 6 * max_deg || max_deg > 30 || dst1 == nullptr) return SNERF_ERR_ARG;
-  MipEncArgs a{s_vals, origins, directions, radii, near, far, S, n_rays * (long)S, cone, transform_idx, max_deg,
-               dst1, ld1, dst2, ld2, width, means_out, covs_out};
+  if (sample_id != nullptr && n_rows > n_rays * (long)S) return SNERF_ERR_ARG;
+  MipEncArgs a{s_vals, origins, directions, radii, near, far, S, sample_id != nullptr ? n_rows : n_rays * (long)S, cone, transform_idx, max_deg,
+               dst1, ld1, dst2, ld2, width, means_out, covs_out, sample_id};
   const int blocks = (int)((a.M + 255) / 256);
   if (dtype == SNERF_DT_F32) hipLaunchKernelGGL(mip_encode_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(mip_encode_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
@@ -199,14 +202,14 @@ extern "C" int snerf_mip_encode(const float* s_vals, const float* origins, const
 
 template <typename T>
 __global__ __launch_bounds__(256) void mip_viewenc_kernel(const float* __restrict__ viewdirs, int S, long M, int deg, T* dst, long ld,
-                                                          int width) {
+                                                          int width, const int* __restrict__ sample_id) {
   // [x, sin(2^i x) deg-major, sin(2^i x + pi/2)] per ray, replicated for each of the ray's S samples
   const long total = M * width;
   const int n3 = 3 * deg;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
     const long m = e / width;
     const int col = (int)(e - m * width);
-    const float* x = viewdirs + (m / S) * 3;
+    const float* x = viewdirs + ((sample_id != nullptr ? (long)sample_id[m] : m) / S) * 3;
     float v = 0.f;
     if (col < 3) v = x[col];
     else if (col < 3 + 2 * n3) {
@@ -222,14 +225,14 @@ __global__ __launch_bounds__(256) void mip_viewenc_kernel(const float* __restric
 }
 
 extern "C" int snerf_mip_viewenc(const float* viewdirs, long n_rays, int S, int deg, void* dst, long ld, int width, int dtype,
-                                 void* stream) {
-  if (n_rays <= 0) return SNERF_OK;
+                                 const int* sample_id, long n_rows, void* stream) {
+  if (n_rays <= 0 || (sample_id != nullptr && n_rows <= 0)) return SNERF_OK;
   if (width < 3 + 6 * deg || S <= 0) return SNERF_ERR_ARG;
-  const long M = n_rays * (long)S, total = M * width;
+  const long M = sample_id != nullptr ? n_rows : n_rays * (long)S, total = M * width;
   const int blocks = (int)((total + 255) / 256 < 262144 ? (total + 255) / 256 : 262144);
   if (dtype == SNERF_DT_F32)
-    hipLaunchKernelGGL(mip_viewenc_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, viewdirs, S, M, deg, (float*)dst, ld, width);
+    hipLaunchKernelGGL(mip_viewenc_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, viewdirs, S, M, deg, (float*)dst, ld, width, sample_id);
   else
-    hipLaunchKernelGGL(mip_viewenc_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, viewdirs, S, M, deg, (__bf16*)dst, ld, width);
+    hipLaunchKernelGGL(mip_viewenc_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, viewdirs, S, M, deg, (__bf16*)dst, ld, width, sample_id);
   return snerf_check_launch();
 }

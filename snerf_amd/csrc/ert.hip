@@ -1,0 +1,130 @@
+// Early ray termination + sample compaction for inference (north star: "wavefront ballot / prefix-sum for early ray
+// termination and sample compaction").  NOT part of the reference: an opt-in mode of the mip path whose error is bounded by the
+// proposal histogram.  After the proposal level, every fine interval i of a ray has a predicted transmittance at its start,
+// T_i = 1 - W(s1[i]), and a predicted weight m_i = W(s1[i+1]) - W(s1[i]), where W is the cumulative proposal weight
+// (piecewise linear inside the proposal's intervals).  Intervals with T_i <= eps_t (behind the surface) or m_i <= eps_w (empty
+// space) are not evaluated: the NeRF MLP runs on the compacted rows only and the compositing kernel treats the others as empty.
+//   select  : wave per ray; wave scans build W, one ballot per 64 intervals gives the keep mask, popcount the row count
+//   scan    : exclusive prefix sum of the per-ray counts (single workgroup)
+//   assign  : wave per ray; row = offset[ray] + popcount(mask below the lane) -> row_index [N,S1] (-1 = skipped), sample_id [rows]
+#include "common.h"
+
+#define ERT_MAXP 512   // fence posts per level held in LDS per wave
+
+struct ErtArgs {
+  const float* s0; const float* w0; const float* s1;
+  long N; int S0, S1; float eps_t, eps_w;
+  unsigned long long* masks;   // [N, ceil(S1/64)]
+  int* counts;                 // [N] -> exclusive offsets after the scan
+  int* row_index; int* sample_id; long* total;
+};
+
+__global__ __launch_bounds__(256) void ert_select_kernel(ErtArgs a) {
+  __shared__ float sp[4][ERT_MAXP + 1], cum[4][ERT_MAXP + 1], wc[4][ERT_MAXP + 1];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long ray = (long)blockIdx.x * 4 + wave;
+  if (ray >= a.N) return;
+  const int S0 = a.S0, S1 = a.S1;
+  const float* s0 = a.s0 + ray * (S0 + 1);
+  const float* w0 = a.w0 + ray * S0;
+  const float* s1 = a.s1 + ray * (S1 + 1);
+  // cumulative proposal weight at the proposal's fence posts
+  float carry = 0.f;
+  if (lane == 0) cum[wave][0] = 0.f;
+  for (int base = 0; base < S0; base += 64) {
+    const int k = base + lane;
+    const float w = k < S0 ? w0[k] : 0.f;
+    const float incl = wave_incl_scan_add(w, lane);
+    if (k < S0) cum[wave][k + 1] = carry + incl;
+    carry += __shfl(incl, 63, 64);
+  }
+  for (int k = lane; k <= S0; k += 64) sp[wave][k] = s0[k];
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_wave_barrier();
+  // W at the fine fence posts
+  for (int p = lane; p <= S1; p += 64) {
+    const float s = s1[p];
+    int lo = 0, hi = S0;                         // largest k in [0, S0-1] with sp[k] <= s
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (sp[wave][mid] <= s) lo = mid; else hi = mid;
+    }
+    const float a0 = sp[wave][lo], a1 = sp[wave][lo + 1];
+    float fr = a1 > a0 ? (s - a0) / (a1 - a0) : 0.f;
+    fr = fminf(fmaxf(fr, 0.f), 1.f);
+    wc[wave][p] = cum[wave][lo] + fr * (cum[wave][lo + 1] - cum[wave][lo]);
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_wave_barrier();
+  int count = 0;
+  const int nchunk = (S1 + 63) >> 6;
+  for (int c = 0; c < nchunk; ++c) {
+    const int i = c * 64 + lane;
+    bool keep = false;
+    if (i < S1) {
+      const float t = 1.f - wc[wave][i], m = wc[wave][i + 1] - wc[wave][i];
+      keep = t > a.eps_t && m > a.eps_w;
+    }
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(keep);
+    if (lane == 0) a.masks[ray * nchunk + c] = mask;
+    count += __builtin_popcountll(mask);
+  }
+  if (lane == 0) a.counts[ray] = count;
+}
+
+__global__ __launch_bounds__(1024) void ert_scan_kernel(int* counts, long N, long* total) {
+  __shared__ long wsum[16];
+  __shared__ long carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (long base = 0; base < N; base += 1024) {
+    const long r = base + threadIdx.x;
+    const int v = r < N ? counts[r] : 0;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    long before = carry_s;
+    for (int w = 0; w < wave; ++w) before += wsum[w];
+    if (r < N) counts[r] = (int)(before + incl - v);        // exclusive offset
+    __syncthreads();
+    if (threadIdx.x == 1023) carry_s = before + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = carry_s;
+}
+
+__global__ __launch_bounds__(256) void ert_assign_kernel(ErtArgs a) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long ray = (long)blockIdx.x * 4 + wave;
+  if (ray >= a.N) return;
+  const int S1 = a.S1, nchunk = (S1 + 63) >> 6;
+  int row = a.counts[ray];
+  for (int c = 0; c < nchunk; ++c) {
+    const unsigned long long mask = a.masks[ray * nchunk + c];
+    const int i = c * 64 + lane;
+    if (i < S1) {
+      const bool keep = (mask >> lane) & 1ull;
+      const int r = row + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+      a.row_index[ray * S1 + i] = keep ? r : -1;
+      if (keep) a.sample_id[r] = (int)(ray * S1 + i);
+    }
+    row += __builtin_popcountll(mask);
+  }
+}
+
+extern "C" int snerf_ert_compact(const float* s0, const float* w0, const float* s1, long N, int S0, int S1, float eps_t, float eps_w,
+                                 void* masks, int* counts, int* row_index, int* sample_id, long* total, void* stream) {
+  if (N <= 0) return SNERF_OK;
+  if (S0 < 1 || S1 < 1 || S0 > ERT_MAXP || S1 > ERT_MAXP || N * (long)S1 >= (1L << 31)) return SNERF_ERR_ARG;
+  if (s0 == nullptr || w0 == nullptr || s1 == nullptr || masks == nullptr || counts == nullptr || row_index == nullptr || sample_id == nullptr || total == nullptr)
+    return SNERF_ERR_ARG;
+  ErtArgs a{s0, w0, s1, N, S0, S1, eps_t, eps_w, (unsigned long long*)masks, counts, row_index, sample_id, total};
+  const dim3 grid((unsigned)((N + 3) / 4));
+  hipLaunchKernelGGL(ert_select_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(ert_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, counts, N, total);
+  hipLaunchKernelGGL(ert_assign_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+  return snerf_check_launch();
+}

@@ -95,13 +95,27 @@ class MipNerfModel(_ArenaModule):
                                                    self.rgb_padding, self.density_bias)
         # ---- level 1: resample (no gradient: stop_level_grad), encode, NeRF MLP, composite
         s1, _ = ops.mip_resample(s0, w0, u, self.resample_padding)
-        SKIP, CB = self.nerf.alloc_inputs(n * S1)
         H = self.nerf.H
-        ops.mip_encode(s1, o, d, radii, near, far, cone, self.transform_idx, self.max_deg_point, SKIP[:, H:], None, self.nerf.Ew, self.dt)
-        ops.mip_viewenc(vd, S1, self.deg_view, CB[:, H:], self.nerf.Cw, self.dt)
+        ert = getattr(self, "_ert", None)
+        row_index = sample_id = None
+        if ert is not None and not keep:
+            # wave ballot + prefix sums over the proposal histogram pick the fine samples worth evaluating (csrc/ert.hip)
+            row_index, sample_id = ops.ert_compact(s0, w0, s1, ert[0], ert[1])
+            self.last_ert_rows = (int(sample_id.shape[0]), n * S1)
+        rows = n * S1 if sample_id is None else max(int(sample_id.shape[0]), 1)
+        SKIP, CB = self.nerf.alloc_inputs(rows)
+        if sample_id is not None and sample_id.shape[0] == 0:
+            SKIP.zero_(); CB.zero_()                       # nothing survives: one dummy row nobody reads
+            sample_id = None
+            enc_ids = torch.zeros(1, dtype=torch.int32, device=dev)
+        else:
+            enc_ids = sample_id
+        ops.mip_encode(s1, o, d, radii, near, far, cone, self.transform_idx, self.max_deg_point, SKIP[:, H:], None, self.nerf.Ew, self.dt,
+                       sample_id=enc_ids)
+        ops.mip_viewenc(vd, S1, self.deg_view, CB[:, H:], self.nerf.Cw, self.dt, sample_id=enc_ids)
         raw_rgb, raw_d1, saved1 = self.nerf.forward(SKIP, CB, keep)
         rgb1, dist1, acc1, w1 = ops.mip_composite_fwd(raw_rgb, raw_d1, noise1, s1, d, near, far, self.transform_idx, white_bg,
-                                                      self.rgb_padding, self.density_bias)
+                                                      self.rgb_padding, self.density_bias, row_index=row_index)
         ctx = None
         if keep:
             # detached aliases of the output tensors: the originals become outputs of the autograd Function
@@ -149,9 +163,11 @@ class MipNerfModel(_ArenaModule):
         return s_rand, u, noise0, noise1
 
     # ---------------------------------------------------------------- public ----
-    def forward(self, rays, randomized, white_bg, viewc=0., s_rand=None, u=None):
+    def forward(self, rays, randomized, white_bg, viewc=0., s_rand=None, u=None, ert=None):
         """-> [[None, distance, acc(, s_vals, weights)], [rgb, distance, acc, None(, s_vals, weights)]]
-        (models.py:178-187).  `s_rand` / `u` override the internal draws (parity tests)."""
+        (models.py:178-187).  `s_rand` / `u` override the internal draws (parity tests).
+        `ert=(eps_t, eps_w)` (inference only; NOT in the reference): early ray termination + sample compaction -- fine samples whose
+        proposal-predicted transmittance is <= eps_t or whose proposal-predicted weight is <= eps_w are not evaluated."""
         if white_bg:
             raise NotImplementedError("white_bg=True crashes the reference at the proposal level (mip.py:188, rgb is None)")
         self._check_arena()
@@ -166,7 +182,11 @@ class MipNerfModel(_ArenaModule):
         u = u.to(dev).float().contiguous()
         params = self.param_list()
         keep = torch.is_grad_enabled() and any(p.requires_grad for p in params)   # grad mode is off inside Function.forward
+        if ert is not None and keep:
+            raise NotImplementedError("ert (sample compaction) is an inference mode: call under torch.no_grad()")
+        self._ert = None if ert is None else (float(ert[0]), float(ert[1]))
         outs = _MipFn.apply(self, rays, bool(white_bg), s_rand, u, noise0, noise1, keep, *params)
+        self._ert = None
         dist0, acc0, s0, w0, rgb1, dist1, acc1, s1, w1 = outs
         ret = [[None, dist0, acc0], [rgb1, dist1, acc1, None]]
         if self.proposal_loss:

@@ -112,19 +112,46 @@ def classic_embed(pts, viewdirs, S, L, Lv, dst1, dst2, w_pts, dstv, w_views, dt)
               _p(dstv), 0 if dstv is None else dstv.stride(0), w_views, dt, _stream())
 
 
+def _ids(sample_id):
+    if sample_id is None:
+        return None, 0
+    assert sample_id.dtype == torch.int32 and sample_id.is_contiguous() and sample_id.is_cuda
+    return sample_id, sample_id.shape[0]
+
+
 def mip_encode(s_vals, origins, directions, radii, near, far, cone, transform_idx, max_deg, dst1, dst2, width, dt,
-               means_out=None, covs_out=None):
+               means_out=None, covs_out=None, sample_id=None):
+    """sample_id (int32 [rows], optional): encode only the samples ray * S + i listed there, row j of dst <- sample_id[j]."""
     n, P = s_vals.shape
     for t in (s_vals, origins, directions, radii, near, far):
         _f32c(t)
+    ids, rows = _ids(sample_id)
     _lib.call("snerf_mip_encode", _p(s_vals), _p(origins), _p(directions), _p(radii), _p(near), _p(far), n, P - 1,
               1 if cone else 0, transform_idx, max_deg, _p(dst1), dst1.stride(0), _p(dst2),
-              0 if dst2 is None else dst2.stride(0), width, _p(_f32c(means_out)), _p(_f32c(covs_out)), dt, _stream())
+              0 if dst2 is None else dst2.stride(0), width, _p(_f32c(means_out)), _p(_f32c(covs_out)), dt, _p(ids), rows, _stream())
 
 
-def mip_viewenc(viewdirs, S, deg, dst, width, dt):
+def mip_viewenc(viewdirs, S, deg, dst, width, dt, sample_id=None):
     _f32c(viewdirs)
-    _lib.call("snerf_mip_viewenc", _p(viewdirs), viewdirs.shape[0], S, deg, _p(dst), dst.stride(0), width, dt, _stream())
+    ids, rows = _ids(sample_id)
+    _lib.call("snerf_mip_viewenc", _p(viewdirs), viewdirs.shape[0], S, deg, _p(dst), dst.stride(0), width, dt, _p(ids), rows, _stream())
+
+
+def ert_compact(s0, w0, s1, eps_t, eps_w):
+    """Early ray termination + sample compaction from the proposal histogram (inference): -> (row_index int32 [N,S1] with -1 for
+    skipped samples, sample_id int32 [rows] of the kept samples in ray-major order).  One device->host sync for the row count."""
+    n, S0, S1 = s0.shape[0], s0.shape[1] - 1, s1.shape[1] - 1
+    dev = s0.device
+    for t in (s0, w0, s1):
+        _f32c(t)
+    masks = torch.empty(n, (S1 + 63) // 64, dtype=torch.int64, device=dev)
+    counts = torch.empty(n, dtype=torch.int32, device=dev)
+    row_index = torch.empty(n, S1, dtype=torch.int32, device=dev)
+    sample_id = torch.empty(n * S1, dtype=torch.int32, device=dev)
+    total = torch.zeros(1, dtype=torch.int64, device=dev)
+    _lib.call("snerf_ert_compact", _p(s0), _p(w0), _p(s1), n, S0, S1, float(eps_t), float(eps_w), _p(masks), _p(counts), _p(row_index),
+              _p(sample_id), _p(total), _stream())
+    return row_index, sample_id[:int(total.item())]
 
 
 # --------------------------------------------------------------- samplers ----
@@ -201,7 +228,9 @@ def stratified(base, rnd, near, far, n, mode, lindisp=False):
 
 
 # ------------------------------------------------------------- compositing ----
-def mip_composite_fwd(raw_rgb, raw_density, noise, s_vals, dirs, near, far, transform_idx, white, rgb_padding, density_bias):
+def mip_composite_fwd(raw_rgb, raw_density, noise, s_vals, dirs, near, far, transform_idx, white, rgb_padding, density_bias,
+                      row_index=None):
+    """row_index (int32 [n,S], optional): raw_* hold compacted rows; sample (ray, i) reads row row_index[ray, i], -1 = empty."""
     n, P = s_vals.shape
     S = P - 1
     dev = s_vals.device
@@ -211,7 +240,8 @@ def mip_composite_fwd(raw_rgb, raw_density, noise, s_vals, dirs, near, far, tran
     w = torch.empty(n, S, dtype=torch.float32, device=dev)
     _lib.call("snerf_mip_composite_fwd", _p(raw_rgb), 0 if raw_rgb is None else raw_rgb.stride(0), _p(raw_density),
               raw_density.stride(0), _p(_f32c(noise)), _p(_f32c(s_vals)), _p(_f32c(dirs)), _p(_f32c(near)), _p(_f32c(far)), n, S,
-              transform_idx, 1 if white else 0, float(rgb_padding), float(density_bias), _p(comp), _p(dist), _p(acc), _p(w), _stream())
+              transform_idx, 1 if white else 0, float(rgb_padding), float(density_bias), _p(comp), _p(dist), _p(acc), _p(w),
+              _p(row_index), _stream())
     return comp, dist, acc, w
 
 

@@ -52,7 +52,8 @@ def classic_embed(pts, viewdirs, S, L, Lv, dst1, dst2, w_pts, dstv, w_views, dt)
 
 
 def mip_encode(s_vals, origins, directions, radii, near, far, cone, transform_idx, max_deg, dst1, dst2, width, dt,
-               means_out=None, covs_out=None):
+               means_out=None, covs_out=None, sample_id=None):
+    assert sample_id is None, "compacted rows are an inference-only GPU mode"
     fm, fc = om.sample2enc(s_vals, origins, directions, radii[:, None], near[:, None], far[:, None], "cone" if cone else "cylinder", transform_idx)
     enc = om.integrated_pos_enc(fm, fc, 0, max_deg).reshape(-1, 6 * max_deg)
     v = torch.cat([enc, torch.zeros(enc.shape[0], width - enc.shape[1])], -1)
@@ -61,7 +62,8 @@ def mip_encode(s_vals, origins, directions, radii, near, far, cone, transform_id
         dst2[:, :width] = v.to(dst2.dtype)
 
 
-def mip_viewenc(viewdirs, S, deg, dst, width, dt):
+def mip_viewenc(viewdirs, S, deg, dst, width, dt, sample_id=None):
+    assert sample_id is None
     e = om.pos_enc(viewdirs, 0, deg, True)[:, None].expand(-1, S, -1).reshape(-1, 3 + 6 * deg)
     dst[:, :width] = torch.cat([e, torch.zeros(e.shape[0], width - e.shape[1])], -1).to(dst.dtype)
 
@@ -95,7 +97,8 @@ def stratified(base, rnd, near, far, n, mode, lindisp=False):
     return oc.stratified_z(near[:, None], far[:, None], base.shape[0], lindisp, rnd).contiguous()
 
 
-def mip_composite_fwd(raw_rgb, raw_density, noise, s_vals, dirs, near, far, transform_idx, white, rgb_padding, density_bias):
+def mip_composite_fwd(raw_rgb, raw_density, noise, s_vals, dirs, near, far, transform_idx, white, rgb_padding, density_bias, row_index=None):
+    assert row_index is None
     n, P = s_vals.shape
     rd = raw_density.reshape(n, P - 1, 1)
     if noise is not None:

@@ -1,0 +1,83 @@
+"""Early ray termination + sample compaction (inference extension, csrc/ert.hip): selection rule against a plain restatement,
+index maps, exactness when nothing is skipped, and the error bound when samples are skipped.  pytest -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _hist(N, S0, S1, seed):
+    g = torch.Generator().manual_seed(seed)
+    s0 = torch.sort(torch.rand(N, S0 + 1, generator=g), -1).values
+    s0[:, 0], s0[:, -1] = 0.0, 1.0
+    s1 = torch.sort(torch.rand(N, S1 + 1, generator=g), -1).values
+    w0 = torch.rand(N, S0, generator=g) ** 6
+    w0 = w0 / w0.sum(-1, keepdim=True) * torch.rand(N, 1, generator=g)
+    w0[0] = 0.0                                             # an empty ray
+    w0[1] = 0.0; w0[1, 3] = 0.999                           # one opaque interval
+    return s0, w0, s1
+
+
+def _select_ref(s0, w0, s1, eps_t, eps_w):
+    """W = cumulative proposal weight, piecewise linear; keep iff 1 - W(s1[i]) > eps_t and W(s1[i+1]) - W(s1[i]) > eps_w."""
+    s0, w0, s1 = s0.double(), w0.double(), s1.double()
+    cum = torch.cat([torch.zeros_like(w0[:, :1]), torch.cumsum(w0, -1)], -1)
+    k = (torch.searchsorted(s0.contiguous(), s1.contiguous(), right=True) - 1).clamp(0, s0.shape[1] - 2)
+    a0, a1 = torch.gather(s0, 1, k), torch.gather(s0, 1, k + 1)
+    fr = torch.where(a1 > a0, (s1 - a0) / (a1 - a0), torch.zeros_like(s1)).clamp(0, 1)
+    W = torch.gather(cum, 1, k) + fr * (torch.gather(cum, 1, k + 1) - torch.gather(cum, 1, k))
+    T, m = 1 - W[:, :-1], W[:, 1:] - W[:, :-1]
+    return T, m, (T > eps_t) & (m > eps_w)
+
+
+@pytest.mark.parametrize("N,S0,S1", [(37, 64, 128), (1000, 128, 127), (5, 7, 200)])
+def test_ert_compact_selection_and_index_maps(N, S0, S1):
+    from snerf_amd import ops
+    s0, w0, s1 = _hist(N, S0, S1, N)
+    eps_t, eps_w = 1e-2, 1e-4
+    row_index, sample_id = ops.ert_compact(s0.cuda(), w0.cuda(), s1.cuda(), eps_t, eps_w)
+    T, m, keep = _select_ref(s0, w0, s1, eps_t, eps_w)
+    got = (row_index >= 0).cpu()
+    clear = ((T - eps_t).abs() > 1e-5) & ((m - eps_w).abs() > 1e-6)          # away from the thresholds the decision is exact
+    assert bool((got == keep)[clear].all()), int((got != keep)[clear].sum())
+    assert float(clear.float().mean()) > 0.99
+    # index maps: rows are the kept samples in ray-major order, each exactly once
+    ri, sid = row_index.cpu().long(), sample_id.cpu().long()
+    assert sid.shape[0] == int(got.sum())
+    assert torch.equal(sid, torch.nonzero(got.reshape(-1)).flatten())
+    assert torch.equal(ri.reshape(-1)[sid], torch.arange(sid.shape[0]))
+    assert int(got[0].sum()) == 0                                           # the empty ray evaluates nothing
+
+
+def _model():
+    from snerf_amd.mipnerf import MipNerfModel
+    torch.manual_seed(0)
+    return MipNerfModel(n_samples=64, N_fine=129, no_warp_sample=0, ray_shape="cone", fn=1, radius=3., transform_idx=0, real=True,
+                        rgb_layer=3, hidden_layer=256, density_noise=0., max_deg_point=16, proposal_hidden_layer=256,
+                        proposal_loss=True, compute="f32", device="cuda")
+
+
+def test_ert_render_is_exact_without_skips_and_bounded_with_skips():
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    m = _model()
+    rays = bench.synth_rays(1024, 7, torch.device("cuda"))
+    with torch.no_grad():
+        full = m(rays, False, False, 0.)
+        same = m(rays, False, False, 0., ert=(-1.0, -1.0))                  # thresholds below every T and m: all samples kept
+        fast = m(rays, False, False, 0., ert=(1e-2, 1e-4))
+    kept, total = m.last_ert_rows
+    for a, b in zip(full[1], same[1]):
+        if a is not None:
+            assert torch.equal(a, b)                                         # compaction itself changes nothing
+    assert 0 < kept < total
+    # the skipped samples' true weights bound the error of every output
+    w_full, w_fast = full[1][5], fast[1][5]
+    skipped = w_fast == 0
+    lost = (w_full * skipped).sum(-1)
+    assert float((fast[1][0] - full[1][0]).abs().max()) <= float(lost.max()) * 1.05 + 1e-5
+    assert float(lost.max()) < 0.2
+    with pytest.raises(NotImplementedError):
+        m(rays, False, False, 0., ert=(1e-2, 1e-4))                         # training mode (grad enabled)
