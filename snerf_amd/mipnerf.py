@@ -171,6 +171,9 @@ class MipNerfModel(_ArenaModule):
         if white_bg:
             raise NotImplementedError("white_bg=True crashes the reference at the proposal level (mip.py:188, rgb is None)")
         self._check_arena()
+        if torch.is_grad_enabled() and any(torch.is_tensor(r) and r.requires_grad for r in rays):
+            raise NotImplementedError("gradients w.r.t. the rays (pose refinement, sample_utils.py:421-425) are not propagated by the "
+                                      "accelerated path: detach the rays or disable pose_refine")
         dev = self.arena.flat.device
         n = rays.origins.shape[0]
         ds_rand, du, noise0, noise1 = self._draws(n, randomized, dev)
