@@ -246,7 +246,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x16 (&acc)[BM / 
 // ---------------------------------------------------------------------------
 // NT kernel: BM x BN output tile, WM x WN waves, each wave (BM/WM) x (BN/WN).
 // ---------------------------------------------------------------------------
-template <typename T, int BM, int BN, int WM, int WN, bool INTERLEAVE>
+template <typename T, int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmNT p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef typename Frag<T>::type frag_t;
@@ -313,16 +313,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmNT p) {
   for (int j = 0; j < TN; ++j) rb[j] = wn * WTN + j * 32 + (lane & 31);
   const int chalf = lane >> 5;
 
-  // one staging piece (1 KiB per wave-instruction) of tile kt: pieces [0, LA) belong to A, [LA, LA+LB) to W
-  auto issue_piece = [&](int kt, int stage, int pc) {
-    char* sA = smem + stage * STAGE;
-    char* sB = sA + BM * 128;
-    const long k0 = (long)kt * BKE;
-#pragma unroll
-    for (int i = 0; i < LA; ++i) if (pc == i) glds16(A + a_off[i] + k0, sA + (wave * LA + i) * 1024);
-#pragma unroll
-    for (int i = 0; i < LB; ++i) if (pc == LA + i) glds16(W + b_off[i] + k0, sB + (wave * LB + i) * 1024);
-  };
   auto read_frags = [&](const char* sA, const char* sB, int ks, frag_t* a, frag_t* b) {
     const int c = 2 * ks + chalf;
 #pragma unroll
@@ -332,79 +322,22 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmNT p) {
   };
 
   issue(0, 0);
-  if constexpr (!INTERLEAVE) {
-    for (int kt = 0; kt < KT; ++kt) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (kt + 1 < KT && !(p.dbg & 1)) issue(kt + 1, (kt + 1) & 1);
-      const char* sA = smem + (kt & 1) * STAGE;
-      const char* sB = sA + BM * 128;
+  for (int kt = 0; kt < KT; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < KT && !(p.dbg & 1)) issue(kt + 1, (kt + 1) & 1);
+    const char* sA = smem + (kt & 1) * STAGE;
+    const char* sB = sA + BM * 128;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        frag_t a[TM], b[TN];
-        read_frags(sA, sB, ks, a, b);
+    for (int ks = 0; ks < 4; ++ks) {
+      frag_t a[TM], b[TN];
+      read_frags(sA, sB, ks, a, b);
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) mma32(acc[i][j], b[j], a[i]);   // D = W-tile . X-tile^T: lanes own rows m
-      }
+        for (int j = 0; j < TN; ++j) mma32(acc[i][j], b[j], a[i]);   // D = W-tile . X-tile^T: lanes own rows m
     }
-  } else {
-    // Same double buffer, but the (LA+LB) staging instructions of the NEXT tile are spread between the MFMAs of this one
-    // (an LDS-DMA piece costs ~60-100 issue cycles; issued as one block after the barrier they leave the matrix pipe
-    // idle on every SIMD at once, since all waves of the workgroup are in the same phase), and the fragments of sub-step
-    // ks+1 are fetched while the MFMAs of ks run.
-    constexpr int NP = LA + LB, PPK = NP / 4;       // staging pieces per k sub-step
-    static_assert(NP % 4 == 0, "pieces must split over the 4 k sub-steps");
-    constexpr int NM = TM * TN;
-    auto tile = [&](int kt, auto more_tag) {
-      constexpr bool MORE = decltype(more_tag)::value;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      const char* sA = smem + (kt & 1) * STAGE;
-      const char* sB = sA + BM * 128;
-      const int c0 = chalf;
-      frag_t a[2][TM], b[2][TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) a[0][i] = *(const frag_t*)(sA + ra[i] * 128 + ((c0 ^ ((ra[i] >> 1) & 7)) << 4));
-#pragma unroll
-      for (int j = 0; j < TN; ++j) b[0][j] = *(const frag_t*)(sB + rb[j] * 128 + ((c0 ^ ((rb[j] >> 1) & 7)) << 4));
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        if (ks < 3) {
-          const int c = 2 * (ks + 1) + chalf;
-#pragma unroll
-          for (int i = 0; i < TM; ++i) a[(ks + 1) & 1][i] = *(const frag_t*)(sA + ra[i] * 128 + ((c ^ ((ra[i] >> 1) & 7)) << 4));
-#pragma unroll
-          for (int j = 0; j < TN; ++j) b[(ks + 1) & 1][j] = *(const frag_t*)(sB + rb[j] * 128 + ((c ^ ((rb[j] >> 1) & 7)) << 4));
-        }
-#pragma unroll
-        for (int t = 0; t < NM; ++t) {
-          const int i = t / TN, j = t % TN;
-          mma32(acc[i][j], b[ks & 1][j], a[ks & 1][i]);
-          // after every (NM/PPK)-th MFMA issue one staging piece of the next tile
-          if constexpr (MORE) {
-            if (((t + 1) % (NM / PPK)) == 0) issue_piece(kt + 1, (kt + 1) & 1, ks * PPK + (t + 1) / (NM / PPK) - 1);
-          }
-        }
-      }
-      // pin the software pipeline: fragments of sub-step ks+1 are fetched BEFORE the MFMAs of ks issue, staging pieces
-      // sit between MFMA groups (masks: 0x008 MFMA, 0x010 VMEM, 0x100 DS read)
-      __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        if (ks < 3) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
-#pragma unroll
-        for (int g = 0; g < PPK; ++g) {
-          __builtin_amdgcn_sched_group_barrier(0x008, NM / PPK, 0);
-          if constexpr (MORE) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-        }
-      }
-    };
-    for (int kt = 0; kt < KT - 1; ++kt) tile(kt, std::true_type{});
-    tile(KT - 1, std::false_type{});
   }
-
   nt_epilogue<T, BM, BN, WM, WN>(p, acc, smem, m0, n0, wave, lane);
 }
 
@@ -968,17 +901,17 @@ __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restr
   atomicAdd(out + n, acc);
 }
 
-template <typename T, int BM, int BN, int WM, int WN, bool IL>
+template <typename T, int BM, int BN, int WM, int WN>
 static int launch_nt(const GemmNT& p, hipStream_t stream) {
   constexpr int LDS = 2 * (BM + BN) * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_nt_kernel<T, BM, BN, WM, WN, IL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipFuncSetAttribute((const void*)gemm_nt_kernel<T, BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
   const int tiles_m = (p.M + BM - 1) / BM;
   const int tiles = tiles_m * (p.N / BN);
-  hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, WM, WN, IL>), dim3(tiles), dim3(64 * WM * WN), LDS, stream, p);
+  hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, WM, WN>), dim3(tiles), dim3(64 * WM * WN), LDS, stream, p);
   if (p.fast_epi && p.colsum_ws != nullptr) {
     const int rows = tiles_m * WM;
     int ychunks = rows / 64;
@@ -1081,7 +1014,7 @@ extern "C" int snerf_linear_fwd(const void* A, long lda, const void* W, long ldw
   GemmNT p{A, lda, W, ldw, bias, Y, ldy, aux, ldaux, colsum, M, N, K, n_store, act, out_f32, vec, colsum_ws, fast, (variant >> 4) & 7};
   variant &= 15;
   hipStream_t s = (hipStream_t)stream;
-  // variant: 0 = 128x128 block-issue, 1 = 256x256 block-issue, 2 = 128x128 interleaved, 3 = 256x256 interleaved,
+  // variant: 0 = 128x128 block-issue, 1 = 256x256 block-issue,
   //          4 = 256x256 8-phase (bf16, N % 256 == 0; other shapes take the 128x128 kernel)
   //          8 = 256x256 persistent 8-phase (bf16, N % 256 == 0, K >= 128, 16-byte epilogue; else as variant 4)
   // the bit-mask activations exist only in the persistent kernel (the mask layout is its unit geometry)
@@ -1092,9 +1025,9 @@ extern "C" int snerf_linear_fwd(const void* A, long lda, const void* W, long ldw
   if (dtype == SNERF_DT_BF16 && (variant & 8) && N % 256 == 0 && K >= 128 && fast && !(colsum != nullptr && act == ACT_RELU) && (lda * 2 * 256 < (1L << 31)) && (ldw * 2 * 256 < (1L << 31)))
     return launch_nt8p(p, s);
   if (dtype == SNERF_DT_BF16 && (variant & 12) && N % 256 == 0) return launch_nt8(p, s);
-  if (dtype == SNERF_DT_F32) return (variant & 2) ? launch_nt<float, 128, 128, 2, 2, true>(p, s) : launch_nt<float, 128, 128, 2, 2, false>(p, s);
-  if ((variant & 1) && N % 256 == 0) return (variant & 2) ? launch_nt<__bf16, 256, 256, 2, 4, true>(p, s) : launch_nt<__bf16, 256, 256, 2, 4, false>(p, s);
-  return (variant & 2) ? launch_nt<__bf16, 128, 128, 2, 2, true>(p, s) : launch_nt<__bf16, 128, 128, 2, 2, false>(p, s);
+  if (dtype == SNERF_DT_F32) return launch_nt<float, 128, 128, 2, 2>(p, s);
+  if ((variant & 1) && N % 256 == 0) return launch_nt<__bf16, 256, 256, 2, 4>(p, s);
+  return launch_nt<__bf16, 128, 128, 2, 2>(p, s);
 }
 
 // ---------------------------------------------------------------------------
