@@ -178,7 +178,7 @@ def main():
     ap.add_argument("--variant", type=int, default=8, help="NT GEMM variant: 8 = persistent 8-phase 256x256 (default), 4 = 8-phase, 1 = 256x256 block-issue, 0 = 128x128")
     ap.add_argument("--no-frame", action="store_true", help="skip the 1600x900 frame render")
     ap.add_argument("--no-cpu", action="store_true", help="skip the host-CPU baseline")
-    ap.add_argument("--cpu-rays", type=int, default=192)
+    ap.add_argument("--cpu-rays", type=int, default=512, help="rays of the bounded host-CPU baseline sample (about 15 s on the GPU box)")
     ap.add_argument("--shape", default="baseline", choices=["baseline", "shipped"],
                     help="baseline = BASELINE.json's 64 proposal + 128 fine evals/ray (192 spp); shipped = the reference config's "
                          "128 proposal + 127 fine intervals (configs/nuScenes_depth_6cams)")
