@@ -74,3 +74,57 @@ def shard_rays(rays, rank: int, world: int):
     n = rays[0].shape[0]
     per = n // world
     return type(rays)(*[r[rank * per:(rank + 1) * per] for r in rays])
+
+
+class ZipTrainer:
+    """Train step of the S-NeRF++ / zipnerf background model (s-nerfpp/zipnerf/train.py hot loop: Model.forward,
+    train_utils.compute_data_loss :62-90 -- the Charbonnier term on the final level --, loss.backward(), optimizer.step()) on the
+    flat arenas: forward, per-ray loss tail, backward through the fused kernels, ONE RCCL all-reduce of the flat gradient arena
+    (MLPs + the 3 hash tables, ~310 MB for waymo.gin) and one fused Adam launch with the 1/world mean folded in.
+
+    The proposal levels are supervised through `aux_loss_fn(ray_history) -> scalar` (the caller's interlevel / distortion losses,
+    train_utils.py:132-164, stepfun.py:297-307): it is evaluated with torch autograd on detached leaf copies of every level's
+    `weights`, and the resulting d(loss)/d(weights) enters the renderer's hand-written backward."""
+
+    def __init__(self, model, lr=1e-2, betas=(0.9, 0.99), eps=1e-15, charb_padding=0.001, process_group=None):
+        self.model, self.lr, self.betas, self.eps, self.charb = model, lr, betas, eps, charb_padding
+        a = model.arena
+        self.m, self.v, self.t = torch.zeros_like(a.flat), torch.zeros_like(a.flat), 0
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        a.grad.zero_()
+
+    def broadcast_parameters(self, src=0):
+        if self.world > 1:
+            dist.broadcast(self.model.arena.flat, src=src, group=self.pg)
+            self.model.arena.bump()
+
+    def step(self, batch, target_rgb, train_frac=1.0, rand=True, aux_loss_fn=None, draws=None, sample_n=7, sample_m=3):
+        m = self.model
+        dev = m.arena.flat.device
+        R = batch['origins'].shape[0]
+        if draws is None:
+            draws = m._draws(R, rand, dev, sample_n)
+        levels, ctx = m._run(batch, True, float(train_frac), draws, sample_n, sample_m)
+        rgb = levels[2]["rgb"]
+        diff = rgb - target_rgb
+        root = torch.sqrt(diff * diff + self.charb ** 2)               # Charbonnier (train_utils.py:76)
+        loss = root.mean()
+        g_rgb = diff / root * (1.0 / diff.numel())
+        g_w = [None, None, None]
+        if aux_loss_fn is not None:
+            with torch.enable_grad():
+                leaves = [levels[l]["weights"].detach().requires_grad_(True) for l in range(3)]
+                hist = [dict(sdist=levels[l]["sdist"].detach(), tdist=levels[l]["tdist"].detach(), weights=leaves[l]) for l in range(3)]
+                aux = aux_loss_fn(hist)
+                gs = torch.autograd.grad(aux, leaves, allow_unused=True)
+            g_w = list(gs)
+            loss = loss + aux.detach()
+        m._backward(ctx, [(None, None, None, g_w[0]), (None, None, None, g_w[1]), (g_rgb, None, None, g_w[2])])
+        if self.world > 1:
+            dist.all_reduce(m.arena.grad, op=dist.ReduceOp.SUM, group=self.pg)
+        self.t += 1
+        ops.adam_step(m.arena.flat, m.arena.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.t,
+                      grad_scale=1.0 / self.world, zero_grad=True)
+        m.arena.bump()
+        return loss, levels

@@ -76,3 +76,74 @@ def test_ray_sharded_data_parallel_matches_single_process():
     err = (gathered[0] - ref).abs().max().item()
     assert err < 2e-5, f"data-parallel parameters differ from the single-process run by {err:.3e}"
     assert (ref - _build().arena.flat).abs().max().item() > 1e-3, "the optimiser did not move the parameters"
+
+
+# ---------------------------------------------------------------------------- path C (zipnerf) ----
+def _zip_build():
+    from snerf_amd import zipnerf
+    torch.manual_seed(0)
+    return zipnerf.Model(config=None, raydist_fn='power_transformation', opaque_background=True, compute="f32", table_dtype="f32", device="cpu",
+                         grid_log2_hashmap_size=12, init_std=0.1)
+
+
+def _zip_data(n):
+    g = torch.Generator().manual_seed(3)
+    d = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1)
+    bx = torch.nn.functional.normalize(torch.cross(d, torch.tensor([0.0, 1.0, 0.0]).expand(n, 3), dim=-1), dim=-1)
+    by = torch.nn.functional.normalize(torch.cross(d, bx, dim=-1), dim=-1)
+    batch = dict(origins=torch.randn(n, 3, generator=g) * 0.05, directions=d, viewdirs=d, radii=torch.full((n, 1), 5e-4),
+                 near=torch.full((n, 1), 0.1), far=torch.full((n, 1), 10.0), base_x=bx, base_y=by)
+    return batch, torch.rand(n, 3, generator=g)
+
+
+def _zip_aux(hist):
+    # stand-in for the caller's interlevel loss: any differentiable function of the levels' weights
+    return sum((h["weights"] ** 2).sum() for h in hist) * 1e-3
+
+
+def _zip_worker(rank, world, init_file, n, out_file):
+    from cpu_ops_emulation import emulate_ops
+    from snerf_amd.trainer import ZipTrainer
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    with emulate_ops():
+        model = _zip_build()
+        if rank != 0:
+            with torch.no_grad():
+                model.arena.flat.add_(0.5)
+        tr = ZipTrainer(model, lr=1e-2, eps=1e-4)    # a large eps: with the reference's 1e-15 Adam is a sign function of rounding noise on near-zero gradients
+        tr.broadcast_parameters(0)
+        batch, tgt = _zip_data(n)
+        per = n // world
+        mine = {k: v[rank * per:(rank + 1) * per] for k, v in batch.items()}
+        for _ in range(2):
+            # the per-rank aux loss is a SUM over its rays: scale by world so that the all-reduced mean equals the full-batch sum
+            tr.step(mine, tgt[rank * per:(rank + 1) * per], rand=False, aux_loss_fn=lambda h: _zip_aux(h) * world)
+        flat = model.arena.flat.clone()
+        gathered = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        if rank == 0:
+            torch.save(gathered, out_file)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_zip_ray_sharded_data_parallel_matches_single_process():
+    from cpu_ops_emulation import emulate_ops
+    from snerf_amd.trainer import ZipTrainer
+    n, world = 8, 2
+    with tempfile.TemporaryDirectory() as td:
+        init_file, out_file = os.path.join(td, "init"), os.path.join(td, "out.pt")
+        mp.spawn(_zip_worker, args=(world, init_file, n, out_file), nprocs=world, join=True)
+        gathered = torch.load(out_file)
+    assert torch.equal(gathered[0], gathered[1]), "ranks diverged"
+    with emulate_ops():
+        model = _zip_build()
+        start = model.arena.flat.clone()
+        tr = ZipTrainer(model, lr=1e-2, eps=1e-4)    # a large eps: with the reference's 1e-15 Adam is a sign function of rounding noise on near-zero gradients
+        batch, tgt = _zip_data(n)
+        for _ in range(2):
+            tr.step(batch, tgt, rand=False, aux_loss_fn=_zip_aux)
+    err = (gathered[0] - model.arena.flat).abs().max().item()
+    assert err < 5e-5, f"data-parallel parameters differ from the single-process run by {err:.3e}"
+    assert (model.arena.flat - start).abs().max().item() > 1e-3

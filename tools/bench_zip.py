@@ -11,19 +11,37 @@ import torch
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--rays", type=int, default=16384)
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--rays", type=int, default=16384, help="rays per GPU per step (weak scaling)")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--compute", default="bf16")
     ap.add_argument("--table", default="f16")
     ap.add_argument("--log2T", type=int, default=21)
     ap.add_argument("--table-grad", default="f32", choices=["f32", "bf16"])
+    ap.add_argument("--backend", default="nccl")
+    ap.add_argument("--same-device", action="store_true", help="functional test of the N > 1 flow on a 1-GPU box")
     args = ap.parse_args()
+    import torch.distributed as dist
+    world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    if args.same_device:
+        local = 0
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend)
     from snerf_amd import ops, zipnerf
+    from snerf_amd.trainer import ZipTrainer
     torch.manual_seed(0)
     m = zipnerf.Model(config=None, raydist_fn='power_transformation', opaque_background=True, compute=args.compute, table_dtype=args.table,
-                      grid_log2_hashmap_size=args.log2T, init_std=0.1, table_grad_dtype=args.table_grad)
+                      grid_log2_hashmap_size=args.log2T, init_std=0.1, table_grad_dtype=args.table_grad, device=torch.device("cuda", local))
+    tr = ZipTrainer(m, lr=1e-2)
+    tr.broadcast_parameters(0)
     R = args.rays
-    g = torch.Generator().manual_seed(1)
+    g = torch.Generator().manual_seed(1 + rank)
     # Waymo-like pinhole rays (1920x1280, focal 2050), scene rescaled so that near = 0.1, far = 10 (configs/waymo.gin)
     pix = torch.randint(0, 1920 * 1280, (R,), generator=g)
     i, j = (pix % 1920).float(), (pix // 1920).float()
@@ -32,38 +50,40 @@ def main():
     up = torch.tensor([0.0, 1.0, 0.0]).expand(R, 3)
     bx = torch.nn.functional.normalize(torch.cross(vd, up, dim=-1), dim=-1)
     by = torch.nn.functional.normalize(torch.cross(vd, bx, dim=-1), dim=-1)
-    batch = {k: v.cuda() for k, v in dict(origins=torch.randn(R, 3, generator=g) * 0.05, directions=d, viewdirs=vd, radii=torch.full((R, 1), 2.0 / 2050 / 12 ** 0.5),
-                                          near=torch.full((R, 1), 0.1), far=torch.full((R, 1), 10.0), base_x=bx, base_y=by).items()}
-    tgt = torch.rand(R, 3, generator=g).cuda()
+    dev = torch.device("cuda", local)
+    batch = {k: v.to(dev) for k, v in dict(origins=torch.randn(R, 3, generator=g) * 0.05, directions=d, viewdirs=vd, radii=torch.full((R, 1), 2.0 / 2050 / 12 ** 0.5),
+                                           near=torch.full((R, 1), 0.1), far=torch.full((R, 1), 10.0), base_x=bx, base_y=by).items()}
+    tgt = torch.rand(R, 3, generator=g).to(dev)
     a = m.arena
-    mm, vv = torch.zeros_like(a.flat), torch.zeros_like(a.flat)
-    a.grad.zero_()
+    # proposal supervision stand-in with the cost profile of the interlevel loss: a gradient on every level's weights
+    aux = lambda hist: sum((h["weights"] * h["weights"].detach()).sum() for h in hist) * (0.5e-3 / R)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
 
     def train_step(t):
-        draws = m._draws(R, True, a.flat.device, 7)
-        levels, ctx = m._run(batch, True, 0.5, draws, 7, 3)
-        rgb = levels[2]["rgb"]
-        g_rgb = (rgb - tgt) * (2.0 / (3 * R))
-        # data loss on the final rgb + a proposal-supervision stand-in (gradient on every level's weights, like the interlevel loss)
-        grads = [(None, None, None, levels[l]["weights"] * (1e-3 / R)) for l in range(2)] + [(g_rgb, None, None, levels[2]["weights"] * (1e-3 / R))]
-        m._backward(ctx, grads)
-        ops.adam_step(a.flat, a.grad, mm, vv, 1e-2, 0.9, 0.99, 1e-15, t, 1.0, True)
-        a.bump()
+        tr.step(batch, tgt, train_frac=0.5, rand=True, aux_loss_fn=aux)
 
     def fwd_only():
         with torch.no_grad():
             m(None, batch, 1.0, False)
 
-    for t in range(1, 4):
+    for t in range(3):
         train_step(t)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for t in range(4, 4 + args.steps):
+    barrier(); t0 = time.perf_counter()
+    for t in range(args.steps):
         train_step(t)
-    torch.cuda.synchronize(); dt_train = (time.perf_counter() - t0) / args.steps
-    fwd_only(); torch.cuda.synchronize(); t0 = time.perf_counter()
+    barrier(); dt_train = (time.perf_counter() - t0) / args.steps
+    if world > 1:
+        te = torch.tensor([dt_train], device=dev, dtype=torch.float64)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        dt_train = te.item()
+    fwd_only(); barrier(); t0 = time.perf_counter()
     for _ in range(args.steps):
         fwd_only()
-    torch.cuda.synchronize(); dt_fwd = (time.perf_counter() - t0) / args.steps
+    barrier(); dt_fwd = (time.perf_counter() - t0) / args.steps
     # dominant kernel: the fused featurisation (forward), timed with events around its three launches
     rec = []
     orig = ops.zip_encode_fwd
@@ -77,15 +97,20 @@ def main():
     enc_ms = [e0.elapsed_time(e1) for e0, e1 in rec]
     tb = 2 if args.table == "f16" else 4
     bytes_lvl = [R * 7 * 64 * 6 * 8 * 1 * tb, R * 7 * 64 * 8 * 8 * 1 * tb, R * 7 * 32 * 10 * 8 * 4 * tb]
-    out = {"path": "C (zipnerf Model, waymo.gin shape: 64+64+32 intervals x 7 multisamples, grids L=6/8/10)", "rays": R, "compute": args.compute, "table_grad": args.table_grad,
-           "table": args.table, "train_ms": round(dt_train * 1e3, 3), "train_rays_per_s": round(R / dt_train, 1), "fwd_ms": round(dt_fwd * 1e3, 3),
-           "fwd_rays_per_s": round(R / dt_fwd, 1), "encode_fwd_ms_per_level": [round(x, 3) for x in enc_ms],
+    out = {"path": "C (zipnerf Model, waymo.gin shape: 64+64+32 intervals x 7 multisamples, grids L=6/8/10)", "n_gpus": world, "rays_per_gpu": R,
+           "compute": args.compute, "table_grad": args.table_grad,
+           "table": args.table, "train_ms": round(dt_train * 1e3, 3), "train_rays_per_s": round(world * R / dt_train, 1), "fwd_ms": round(dt_fwd * 1e3, 3),
+           "fwd_rays_per_s": round(R / dt_fwd, 1), "frame_1920x1280_s_one_gpu": round(1920 * 1280 / (R / dt_fwd), 3), "encode_fwd_ms_per_level": [round(x, 3) for x in enc_ms],
            "encode_fwd_gather_GBps_per_level": [round(b / (ms * 1e-3) / 1e9, 1) for b, ms in zip(bytes_lvl, enc_ms)],
            "roofline": {"bound": "hbm", "kernel": "zip_encode_kernel (nerf level)", "achieved": round(bytes_lvl[2] / (enc_ms[2] * 1e-3) / 1e9, 1),
                         "peak": 8000.0, "unit": "GB/s", "frac": round(bytes_lvl[2] / (enc_ms[2] * 1e-3) / 1e9 / 8000.0, 4),
                         "note": "algorithmic (useful) gather bytes; table is Infinity-Cache resident when it fits 256 MB"},
            "params": int(a.numel)}
-    print(json.dumps(out))
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
