@@ -181,6 +181,13 @@ def main():
         d[f"jitter{lvl}"] = jit[lvl]; d[f"deg_jitter{lvl}"] = degj[lvl]
     d.update(det_rgb=rend[-1]["rgb"], det_depth=rend[-1]["depth"], rand_rgb=rend_r[-1]["rgb"], rand_depth=rend_r[-1]["depth"],
              det_depth0=rend[0]["depth"], rand_train_frac=np.float32(0.37))
+    # the same model with the semantic head enabled (Config.use_semantic / NerfMLP.use_semantic: models.py:297-305, 594-597)
+    cfg.use_semantic = True
+    model.config = cfg
+    model.nerf_mlp.use_semantic = True
+    with torch.no_grad():
+        rend_s, _ = model(None, dict(batch), train_frac=1.0, compute_extras=False)
+    d.update(sem_rgb=rend_s[-1]["rgb"], sem_semantic=rend_s[-1]["semantic"])
     G["g11_zip_model"] = d
     os.makedirs(OUT, exist_ok=True)
     for name, dd in G.items():

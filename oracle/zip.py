@@ -176,12 +176,14 @@ def pos_enc(x, min_deg, max_deg, append_identity=True):
 
 
 def mlp_forward(p, prefix, spec, means, stds, viewdirs, disable_rgb, deg_view=1, density_bias=-1.0, rgb_padding=0.001,
-                net_depth_viewdirs=2, skip_layer_dir=0):
-    """MLP.forward (models.py:521-714) on the waymo.gin branch.  Returns dict(density, rgb)."""
+                net_depth_viewdirs=2, skip_layer_dir=0, use_semantic=False, class_num=19):
+    """MLP.forward (models.py:521-714) on the waymo.gin branch.  Returns dict(density, rgb, semantic); with `use_semantic`
+    semantic = softmax(x[..., 1:1+class_num]) of the density network's output (models.py:594-597), else None."""
     raw_density, x = predict_density(p, prefix, spec, means, stds)
     density = F.softplus(raw_density + density_bias)
     if disable_rgb:
-        return dict(density=density, rgb=torch.zeros(density.shape + (3,)))
+        return dict(density=density, rgb=torch.zeros(density.shape + (3,)), semantic=None)
+    sem = torch.softmax(x[..., 1:1 + class_num], -1) if use_semantic else None
     dir_enc = pos_enc(viewdirs, 0, deg_view, True)
     dir_enc = torch.broadcast_to(dir_enc[..., None, :], x.shape[:-1] + (dir_enc.shape[-1],))
     h = torch.cat([x, dir_enc], dim=-1)
@@ -191,7 +193,7 @@ def mlp_forward(p, prefix, spec, means, stds, viewdirs, disable_rgb, deg_view=1,
         if i == skip_layer_dir:
             h = torch.cat([h, inputs], dim=-1)
     rgb = torch.sigmoid(F.linear(h, p[prefix + "rgb_layer.weight"], p[prefix + "rgb_layer.bias"]))
-    return dict(density=density, rgb=rgb * (1 + 2 * rgb_padding) - rgb_padding)
+    return dict(density=density, rgb=rgb * (1 + 2 * rgb_padding) - rgb_padding, semantic=sem)
 
 
 # ------------------------------------------------------------------ C9 ----
@@ -206,22 +208,27 @@ def compute_alpha_weights(density, tdist, dirs, opaque_background=True):
     return alpha * trans
 
 
-def volumetric_rendering(rgbs, weights, tdist, bg_rgbs=1.0):
-    """render.py:192-233 (compute_extras=False): rgb = sum w c + max(0, 1 - acc) bg; depth = clip(exp(sum w log t_mid / acc))."""
+def volumetric_rendering(rgbs, weights, tdist, bg_rgbs=1.0, semantic=None):
+    """render.py:192-233 (compute_extras=False): rgb = sum w c + max(0, 1 - acc) bg; depth = clip(exp(sum w log t_mid / acc));
+    semantic = sum detach(w) semantic (:237-241: "no influences to density")."""
     acc = weights.sum(dim=-1)
     bg_w = (1 - acc[..., None]).clamp_min(0.)
     rgb = (weights[..., None] * rgbs).sum(dim=-2) + bg_w * bg_rgbs
     t_mids = 0.5 * (tdist[..., :-1] + tdist[..., 1:])
     expect = (weights * torch.log(t_mids)).sum(dim=-1) / acc.clamp_min(EPS32)
     depth = torch.clip(torch.nan_to_num(torch.exp(expect), float("inf")), tdist[..., 0], tdist[..., -1])
-    return dict(rgb=rgb, depth=depth, acc=acc)
+    out = dict(rgb=rgb, depth=depth, acc=acc)
+    if semantic is not None:
+        out["semantic"] = (weights.detach()[..., None] * semantic).sum(dim=-2)
+    return out
 
 
 # ------------------------------------------------------------------ C11 ---
 def model_forward(p, specs, batch, num_prop_samples=(64, 64), num_nerf_samples=32, train_frac=1.0, anneal_slope=10.0,
                   dilation_multiplier=0.5, dilation_bias=0.0025, power_lambda=-1.5, std_scale=0.35, jitters=None,
-                  deg_jitters=None, bg=1.0):
-    """Model.forward (models.py:98-349) with rand=None (jitters None) or explicit draws.  `specs` = [prop0, prop1, nerf]
+                  deg_jitters=None, bg=1.0, use_semantic=False):
+    """Model.forward (models.py:98-349) with rand=None (jitters None) or explicit draws; `use_semantic`: the final level also
+    renders the 19-class semantic distribution (models.py:297-305).  `specs` = [prop0, prop1, nerf]
     GridSpec; parameter names follow the reference's state_dict (`prop_mlp_0.encoder.embeddings`, `nerf_mlp.rgb_layer.weight`...).
     Returns (renderings, ray_history) with the reference's keys (rgb, depth / sdist, weights, tdist)."""
     near, far = batch["near"], batch["far"]
@@ -247,9 +254,9 @@ def model_forward(p, specs, batch, num_prop_samples=(64, 64), num_nerf_samples=3
         means, stds = cast_rays(tdist, batch["origins"], batch["directions"], batch["radii"], batch["base_x"], batch["base_y"],
                                 None if deg_jitters is None else deg_jitters[lvl], std_scale=std_scale)
         prefix = f"prop_mlp_{lvl}." if is_prop else "nerf_mlp."
-        res = mlp_forward(p, prefix, specs[lvl], means, stds, batch["viewdirs"], disable_rgb=is_prop)
+        res = mlp_forward(p, prefix, specs[lvl], means, stds, batch["viewdirs"], disable_rgb=is_prop, use_semantic=use_semantic and not is_prop)
         weights = compute_alpha_weights(res["density"], tdist, batch["directions"], True)
-        renderings.append(volumetric_rendering(res["rgb"], weights, tdist, bg))
+        renderings.append(volumetric_rendering(res["rgb"], weights, tdist, bg, semantic=res["semantic"]))
         history.append(dict(sdist=sdist.clone(), weights=weights.clone(), tdist=tdist.clone(), density=res["density"], rgb=res["rgb"]))
     return renderings, history
 

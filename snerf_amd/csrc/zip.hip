@@ -604,3 +604,76 @@ extern "C" int snerf_zip_composite_bwd(const float* raw_rgb, long ld_rgb, const 
   hipLaunchKernelGGL(zip_composite_bwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
   return snerf_check_launch();
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// semantic head (models.py:594-597 + render.py:237-241): semantic[r, c] = sum_i detach(w[r, i]) softmax(logits[r, i, :])[c];
+// logits are columns of the density network's output x (x[..., 1:1+C]).  Wave per ray, one sample per lane and pass.
+// Backward: d logits[i, c] = w_i p_c (g_c - sum_k p_k g_k); the weights receive no gradient ("no influences to density").
+// ------------------------------------------------------------------------------------------------------------------
+#define ZSEM_MAXC 32
+
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void zip_semantic_kernel(const float* __restrict__ weights, const T* __restrict__ logits, long ld, long R, int S,
+                                                           int C, float* __restrict__ sem, const float* __restrict__ g_sem,
+                                                           float* __restrict__ d_logits, long ld_d) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long ray = (long)blockIdx.x * 4 + wave;
+  if (ray >= R) return;
+  float acc[ZSEM_MAXC], g[ZSEM_MAXC];
+#pragma unroll
+  for (int c = 0; c < ZSEM_MAXC; ++c) { acc[c] = 0.f; g[c] = (BWD && c < C) ? g_sem[ray * C + c] : 0.f; }
+  for (int base = 0; base < S; base += 64) {
+    const int i = base + lane;
+    if (i >= S) continue;
+    const long p = ray * S + i;
+    const float w = weights[p];
+    const T* lg = logits + p * ld;
+    float v[ZSEM_MAXC], mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < ZSEM_MAXC; ++c) { v[c] = c < C ? (float)lg[c] : -INFINITY; mx = fmaxf(mx, v[c]); }
+    float den = 0.f;
+#pragma unroll
+    for (int c = 0; c < ZSEM_MAXC; ++c) { v[c] = c < C ? expf(v[c] - mx) : 0.f; den += v[c]; }
+    const float inv = 1.f / den;
+    if (BWD) {
+      float dot = 0.f;
+#pragma unroll
+      for (int c = 0; c < ZSEM_MAXC; ++c) dot += (v[c] * inv) * g[c];
+#pragma unroll
+      for (int c = 0; c < ZSEM_MAXC; ++c)
+        if (c < C) d_logits[p * ld_d + c] = w * (v[c] * inv) * (g[c] - dot);
+    } else {
+#pragma unroll
+      for (int c = 0; c < ZSEM_MAXC; ++c) acc[c] += w * (v[c] * inv);
+    }
+  }
+  if (!BWD) {
+#pragma unroll
+    for (int c = 0; c < ZSEM_MAXC; ++c) {
+      const float t = wave_sum(acc[c]);
+      if (lane == 0 && c < C) sem[ray * C + c] = t;
+    }
+  }
+}
+
+extern "C" int snerf_zip_semantic_fwd(const float* weights, const void* logits, long ld, int dtype, long R, int S, int C, float* sem,
+                                      void* stream) {
+  if (R <= 0) return SNERF_OK;
+  if (S <= 0 || C <= 0 || C > ZSEM_MAXC || weights == nullptr || logits == nullptr || sem == nullptr) return SNERF_ERR_ARG;
+  const dim3 grid((unsigned)((R + 3) / 4));
+  if (dtype == SNERF_DT_F32) hipLaunchKernelGGL((zip_semantic_kernel<float, false>), grid, dim3(256), 0, (hipStream_t)stream, weights, (const float*)logits, ld, R, S, C, sem, nullptr, nullptr, 0);
+  else if (dtype == SNERF_DT_BF16) hipLaunchKernelGGL((zip_semantic_kernel<__bf16, false>), grid, dim3(256), 0, (hipStream_t)stream, weights, (const __bf16*)logits, ld, R, S, C, sem, nullptr, nullptr, 0);
+  else return SNERF_ERR_ARG;
+  return snerf_check_launch();
+}
+
+extern "C" int snerf_zip_semantic_bwd(const float* weights, const void* logits, long ld, int dtype, const float* g_sem, long R, int S, int C,
+                                      float* d_logits, long ld_d, void* stream) {
+  if (R <= 0) return SNERF_OK;
+  if (S <= 0 || C <= 0 || C > ZSEM_MAXC || weights == nullptr || logits == nullptr || g_sem == nullptr || d_logits == nullptr || ld_d < C) return SNERF_ERR_ARG;
+  const dim3 grid((unsigned)((R + 3) / 4));
+  if (dtype == SNERF_DT_F32) hipLaunchKernelGGL((zip_semantic_kernel<float, true>), grid, dim3(256), 0, (hipStream_t)stream, weights, (const float*)logits, ld, R, S, C, nullptr, g_sem, d_logits, ld_d);
+  else if (dtype == SNERF_DT_BF16) hipLaunchKernelGGL((zip_semantic_kernel<__bf16, true>), grid, dim3(256), 0, (hipStream_t)stream, weights, (const __bf16*)logits, ld, R, S, C, nullptr, g_sem, d_logits, ld_d);
+  else return SNERF_ERR_ARG;
+  return snerf_check_launch();
+}

@@ -555,7 +555,10 @@ class ZipNerfNet(_Net):
             out = torch.zeros(roundup(B, 128), 2 * Wd + g, dtype=self.tdt, device=self.dev)
             out[:B, :Wd] = W0[:, :B].t()
             out[:B, Wd:2 * Wd] = W1[:, Wd:Wd + B].t()
-            out[0, 2 * Wd] = 1.0
+            # identity rows: column 0 of the trailing block carries d raw_density, columns 1.. the semantic-logit gradients
+            # (x[..., 1:1+C] feeds the softmax of the semantic head, models.py:594-597)
+            for c in range(min(g, B)):
+                out[c, 2 * Wd + c] = 1.0
             self.tw["xcat"] = out
 
     def alloc(self, M):
@@ -578,7 +581,7 @@ class ZipNerfNet(_Net):
         return raw_rgb, raw_d, ((Fb, H1, SB, H3) if keep else None)
 
     def backward(self, d_raw_rgb, d_raw_density, saved):
-        """-> dF [P, Fw]"""
+        """-> dF [P, Fw].  d_raw_density [P, 1] or [P, 1 + C]: column 0 = d raw density, columns 1.. = d semantic logits."""
         Fb, H1, SB, H3 = saved
         M, B, Wd, g = d_raw_rgb.shape[0], self.Bw, self.Wd, self.g
         ops.colsum_f32(d_raw_rgb, 3, self.gB("rgb_layer"))
@@ -589,7 +592,8 @@ class ZipNerfNet(_Net):
         self.wgrad("lin_second_stage_1", DZ[:, Wd:2 * Wd], SB, Wd, Wd + B + self.dd)
         self.dgrad("lin1a", DZ[:, Wd:2 * Wd], Wd, DZ[:, :Wd], Wd, mask=SB[:, :Wd], colsum=self.gB("lin_second_stage_0"))
         self.wgrad("lin_second_stage_0", DZ[:, :Wd], SB[:, Wd:], Wd, B + self.dd)
-        ops.cast_pad(d_raw_density, 1, DZ[:, 2 * Wd:], g, self.dt)
+        assert d_raw_density.shape[1] <= g
+        ops.cast_pad(d_raw_density, d_raw_density.shape[1], DZ[:, 2 * Wd:], g, self.dt)
         dx = self.buf(M, B)
         self.dgrad("xcat", DZ, 2 * Wd + g, dx, B, colsum=self.gB("density_layer.2"))
         self.wgrad("density_layer.2", dx, H1, B, self.H)

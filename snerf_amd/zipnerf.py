@@ -78,7 +78,8 @@ class Model(_ArenaModule):
     single_mlp: bool = False
 
     def __init__(self, config=None, compute: str = "bf16", table_dtype: str = "f16", device="cuda", grid_log2_hashmap_size: int = 21,
-                 nerf_desired_resolution: int = 8192, init_std: float = 1e-4, table_grad_dtype: str = "f32", **kwargs):
+                 nerf_desired_resolution: int = 8192, init_std: float = 1e-4, table_grad_dtype: str = "f32", use_semantic: bool = False,
+                 class_num: int = 19, **kwargs):
         super().__init__()
         for k, v in kwargs.items():
             setattr(self, k, v)
@@ -87,8 +88,11 @@ class Model(_ArenaModule):
             raise NotImplementedError("accelerated zipnerf Model: raydist_fn='power_transformation' (configs/waymo.gin)")
         if (self.num_levels != 3 or len(self.num_prop_samples) != 2 or self.num_glo_features or not self.distinct_prop or self.single_mlp
                 or self.near_anneal_rate is not None or not self.stop_level_grad or not self.use_viewdirs
-                or self.bg_intensity_range[0] != self.bg_intensity_range[1] or (config is not None and getattr(config, "use_semantic", False))):
-            raise NotImplementedError("accelerated zipnerf Model: 2 distinct proposal MLPs + NeRF MLP, no GLO/semantic/near annealing")
+                or self.bg_intensity_range[0] != self.bg_intensity_range[1]):
+            raise NotImplementedError("accelerated zipnerf Model: 2 distinct proposal MLPs + NeRF MLP, no GLO / near annealing")
+        # semantic head (Config.use_semantic -> NerfMLP.use_semantic, models.py:66,297-305,594-597): 19-class softmax of x[..., 1:20]
+        self.use_semantic = bool(use_semantic or (config is not None and getattr(config, "use_semantic", False)))
+        self.class_num = int(class_num)
         dev = torch.device(device)
         self.encs = [_Encoder(1, self.prop_desired_grid_size[0], 16, grid_log2_hashmap_size),
                      _Encoder(1, self.prop_desired_grid_size[1], 16, grid_log2_hashmap_size),
@@ -191,8 +195,12 @@ class Model(_ArenaModule):
                 ops.mip_viewenc(vd, ns, 1, SB[:, net.Wd + net.Bw:], net.Dw, self.dt)
                 raw_rgb, raw_d, saved = net.forward(Fb, SB, keep)
             rgb, depth, acc, weights = ops.zip_composite_fwd(raw_rgb, raw_d, tdist, d, self.opaque_background, bg, 0.001, -1.0)
+            sem = logits = None
+            if self.use_semantic and not is_prop:
+                logits = SB[:, net.Wd + 1:net.Wd + 1 + self.class_num]            # x[..., 1:1+C] of the density network's output
+                sem = ops.zip_semantic_fwd(weights, logits, self.class_num)
             levels.append(dict(sdist=sdist, tdist=tdist, weights=weights, rgb=rgb, depth=depth, acc=acc, raw_rgb=raw_rgb, raw_d=raw_d, saved=saved,
-                               degj=degj, ns=ns))
+                               degj=degj, ns=ns, semantic=sem, logits=logits))
         ctx = None
         if keep:   # detached aliases: the originals become outputs of the autograd Function (no graph / reference cycle through ctx)
             det = [{k: (v.detach() if torch.is_tensor(v) else v) for k, v in L.items()} for L in levels]
@@ -204,16 +212,28 @@ class Model(_ArenaModule):
         dev = ctx["o"].device
         cc = lambda t: None if t is None else t.contiguous().float()
         for lvl in (2, 1, 0):
-            g_rgb, g_depth, g_acc, g_w = grads[lvl]
-            if all(t is None for t in (g_rgb, g_depth, g_acc, g_w)):
+            g_rgb, g_depth, g_acc, g_w = grads[lvl][:4]
+            g_sem = grads[lvl][4] if len(grads[lvl]) > 4 else None
+            if all(t is None for t in (g_rgb, g_depth, g_acc, g_w, g_sem)):
                 continue
             L = ctx["levels"][lvl]
             e, net = self.encs[lvl], self.nets[lvl]
             P = L["weights"].numel()
-            d_den = torch.empty(P, 1, dtype=torch.float32, device=dev)
+            sem_on = g_sem is not None and L.get("logits") is not None
+            # [d raw density | d semantic logits]: the semantic head shares the density network's output (one row of gradients)
+            d_dl = torch.zeros(P, 1 + self.class_num, dtype=torch.float32, device=dev) if sem_on else torch.empty(P, 1, dtype=torch.float32, device=dev)
+            d_den = d_dl[:, :1]
             d_rgb = torch.empty(P, 3, dtype=torch.float32, device=dev) if L["raw_rgb"] is not None else None
-            ops.zip_composite_bwd(L["raw_rgb"], L["raw_d"], L["tdist"], ctx["d"], self.opaque_background, ctx["bg"], 0.001, -1.0, L["weights"],
-                                  L["acc"], L["depth"], cc(g_rgb), cc(g_depth), cc(g_acc), cc(g_w), d_rgb, d_den)
+            if all(t is None for t in (g_rgb, g_depth, g_acc, g_w)):
+                d_den.zero_()
+                if d_rgb is not None:
+                    d_rgb.zero_()
+            else:
+                ops.zip_composite_bwd(L["raw_rgb"], L["raw_d"], L["tdist"], ctx["d"], self.opaque_background, ctx["bg"], 0.001, -1.0, L["weights"],
+                                      L["acc"], L["depth"], cc(g_rgb), cc(g_depth), cc(g_acc), cc(g_w), d_rgb, d_den)
+            if sem_on:
+                ops.zip_semantic_bwd(L["weights"], L["logits"], cc(g_sem), self.class_num, d_dl[:, 1:])
+            d_den = d_dl if sem_on else d_den
             dF = net.backward(d_den, L["saved"]) if lvl < 2 else net.backward(d_rgb, d_den, L["saved"])
             gtab = self.arena.g[self.names[lvl] + "encoder.embeddings"]
             g16 = None
@@ -263,6 +283,8 @@ class Model(_ArenaModule):
             rgb, depth, acc, w, sd, td = outs[6 * lvl:6 * lvl + 6]
             renderings.append(dict(rgb=rgb, depth=depth, acc=acc))
             history.append(dict(sdist=sd, weights=w, tdist=td))
+        if self.use_semantic:
+            renderings[-1]["semantic"] = outs[18]
         return renderings, history
 
 
@@ -277,6 +299,8 @@ class _ZipFn(torch.autograd.Function):
             outs += [L["rgb"], L["depth"], L["acc"], L["weights"], L["sdist"], L["tdist"]]
             nondiff += [L["sdist"], L["tdist"]]
         ctx.mark_non_differentiable(*nondiff)
+        if model.use_semantic:
+            outs.append(levels[2]["semantic"])
         return tuple(outs)
 
     @staticmethod
@@ -286,6 +310,8 @@ class _ZipFn(torch.autograd.Function):
         m = ctx.model
         m.arena.grad.zero_()
         grads = [(g[6 * l], g[6 * l + 1], g[6 * l + 2], g[6 * l + 3]) for l in range(3)]
+        if m.use_semantic:
+            grads[2] = grads[2] + (g[18],)
         m._backward(ctx.c, grads)
         ctx.c = None
         return (None,) * 7 + tuple(m.arena.g[n].clone() for n in m._pnames)

@@ -66,3 +66,15 @@ def test_g11_model_forward(golden):
     for lvl in range(3):
         close(hist[lvl]["sdist"], g[f"rand_sdist{lvl}"], 1e-5, 1e-6, f"rand sdist {lvl}")
     close(rend[-1]["rgb"], g["rand_rgb"], 1e-5, 1e-5, "rand rgb"); close(rend[-1]["depth"], g["rand_depth"], 1e-5, 1e-5, "rand depth")
+
+
+def test_g11_model_forward_with_semantic_head(golden):
+    """use_semantic: softmax(x[..., 1:20]) of the density network, composited with the detached weights (models.py:594-597,
+    render.py:237-241) -- against the reference Model run with the semantic head enabled."""
+    g = golden("g11_zip_model")
+    specs, p = zip_setup()
+    batch = {k[2:]: v for k, v in g.items() if k.startswith("b_")}
+    rend, _ = oz.model_forward(p, specs, batch, train_frac=1.0, use_semantic=True)
+    close(rend[-1]["rgb"], g["sem_rgb"], 1e-5, 1e-5, "rgb with the semantic head on")
+    close(rend[-1]["semantic"], g["sem_semantic"], 1e-5, 1e-6, "semantic")
+    assert "semantic" not in rend[0] and "semantic" not in rend[1]

@@ -41,10 +41,10 @@ def zip_setup():
     return specs, m.formula_params(oz.param_shapes(specs))
 
 
-def make_model(compute, table, p):
+def make_model(compute, table, p, use_semantic=False):
     from snerf_amd import zipnerf
     m = zipnerf.Model(config=None, raydist_fn='power_transformation', opaque_background=True, compute=compute, table_dtype=table, device=DEV,
-                      grid_log2_hashmap_size=14)
+                      grid_log2_hashmap_size=14, use_semantic=use_semantic)
     sd = m.state_dict()
     for k, v in p.items():
         assert k in sd and tuple(sd[k].shape) == tuple(v.shape), k
@@ -79,9 +79,27 @@ def test_zip_model_vs_reference_golden(backend, golden, compute, table, tol):
         close(rend[-1]["rgb"], g["rand_rgb"], tol, tol, "rand rgb"); close(rend[-1]["depth"], g["rand_depth"], tol, tol, "rand depth")
 
 
-def test_zip_model_backward_vs_oracle_autograd(backend):
+@pytest.mark.parametrize("compute,table,tol", [("f32", "f32", 2e-4), ("bf16", "f16", 3e-2)])
+def test_zip_semantic_head_vs_reference_golden(backend, golden, compute, table, tol):
+    """Config.use_semantic: the 19-class distribution rendered by the reference Model (golden) and the unchanged colour."""
+    g = golden("g11_zip_model")
+    specs, p = zip_setup()
+    batch = {k[2:]: v.to(DEV) for k, v in g.items() if k.startswith("b_")}
+    m = make_model(compute, table, p, use_semantic=True)
+    with torch.no_grad():
+        rend, _ = m(None, batch, 1.0, False)
+    assert rend[-1]["semantic"].shape == (20, 19) and "semantic" not in rend[0]
+    close(rend[-1]["semantic"], g["sem_semantic"], tol, tol, "semantic")
+    close(rend[-1]["rgb"], g["sem_rgb"], max(tol, 2e-4), max(tol, 2e-4), "rgb")
+    close(rend[-1]["semantic"].sum(-1), torch.ones(20), 1e-3 if compute == "bf16" else 1e-5, 1e-3 if compute == "bf16" else 1e-5, "class probabilities sum to acc = 1")
+
+
+@pytest.mark.parametrize("use_semantic", [False, True])
+def test_zip_model_backward_vs_oracle_autograd(backend, use_semantic):
     """fp32 gradients of every parameter incl. the three hash tables vs torch autograd through the oracle (the oracle's grid
-    lookup is made differentiable with an explicit transpose-gather: features are linear in the table)."""
+    lookup is made differentiable with an explicit transpose-gather: features are linear in the table).  With the semantic head
+    a class-weighted term on the rendered distribution is added to the loss (its gradient reaches the density network only
+    through the logits: the compositing weights are detached, render.py:237-241)."""
     specs, p = zip_setup()
     R = 12
     g = torch.Generator().manual_seed(5)
@@ -91,10 +109,13 @@ def test_zip_model_backward_vs_oracle_autograd(backend):
     batch = dict(origins=torch.randn(R, 3, generator=g) * 0.1, directions=d, viewdirs=d, radii=2e-3 + 2e-3 * torch.rand(R, 1, generator=g),
                  near=torch.full((R, 1), 0.1), far=torch.full((R, 1), 10.0), base_x=bx, base_y=torch.nn.functional.normalize(torch.cross(d, bx, dim=-1), dim=-1))
     target = torch.rand(R, 3, generator=g)
-    m = make_model("f32", "f32", p)
+    semw = torch.randn(R, 19, generator=g)
+    m = make_model("f32", "f32", p, use_semantic=use_semantic)
     rend, hist = m(None, {k: v.to(DEV) for k, v in batch.items()}, 1.0, False)
     wts = [h["weights"] for h in hist]
     loss = ((rend[-1]["rgb"] - target.to(DEV)) ** 2).mean() + 0.1 * rend[-1]["depth"].mean() + 0.05 * sum((w ** 2).sum() for w in wts)
+    if use_semantic:
+        loss = loss + 0.3 * (rend[-1]["semantic"] * semw.to(DEV)).sum() / R
     loss.backward()
     # oracle: same forward with torch-differentiable table lookups
     pr = {k: v.clone().requires_grad_(True) for k, v in p.items()}
@@ -123,10 +144,12 @@ def test_zip_model_backward_vs_oracle_autograd(backend):
         return torch.stack(outs, 1).reshape(list(means.shape[:-1]) + [spec.L, spec.C])
     ozm.grid_features = grid_features_diff
     try:
-        rend_o, hist_o = oz.model_forward(pr, specs, batch, train_frac=1.0)
+        rend_o, hist_o = oz.model_forward(pr, specs, batch, train_frac=1.0, use_semantic=use_semantic)
     finally:
         ozm.grid_features = orig
     loss_o = ((rend_o[-1]["rgb"] - target) ** 2).mean() + 0.1 * rend_o[-1]["depth"].mean() + 0.05 * sum((h["weights"] ** 2).sum() for h in hist_o)
+    if use_semantic:
+        loss_o = loss_o + 0.3 * (rend_o[-1]["semantic"] * semw).sum() / R
     loss_o.backward()
     close(loss, loss_o, 1e-4, 1e-5, "loss")
     named = dict(m.named_parameters())
