@@ -193,12 +193,15 @@ int snerf_adam_step(float* p, float* g, float* m, float* v, long n, float lr, fl
 int snerf_colsum_f32(const float* x, long ld, long M, int C, float* out, void* stream);
 int snerf_cast_pad(const float* src, long ld_src, long M, int C, int Cpad, void* dst, long ld_dst, int dtype, void* stream);
 
-/* Semantic head of the zipnerf NerfMLP (internal/models.py:594-597) + its compositing (internal/render.py:237-241):
- * semantic [R,C] = sum_i detach(weights [R,S]) softmax(logits [R*S, ld][:, :C]); logits = columns 1..C of the density network's
- * output x (fp32 or bf16).  Backward: d_logits [R*S, ld_d][:, :C] (fp32) from g_sem [R,C]; weights get no gradient. */
-int snerf_zip_semantic_fwd(const float* weights, const void* logits, long ld, int dtype, long R, int S, int C, float* sem, void* stream);
-int snerf_zip_semantic_bwd(const float* weights, const void* logits, long ld, int dtype, const float* g_sem, long R, int S, int C,
-                           float* d_logits, long ld_d, void* stream);
+/* Semantic compositing, both flavours of the reference.  softmax = 1: zipnerf NerfMLP (internal/models.py:594-597) +
+ * internal/render.py:237-241: semantic [R,C] = sum_i detach(weights [R,S]) softmax(logits [R*S, ld][:, :C]) (logits = columns
+ * 1..C of the density network's output x); backward: d_logits only (g_w_out, if given, is zeroed).  softmax = 0: live mip path
+ * (s-nerf/model/mip.py:175-176): semantic = sum_i weights raw_semantic; backward: d_logits [R*S, ld_d][:, :C] = w g and
+ * g_w_out [R,S] = sum_c g_c raw (the weights are part of the graph there).  logits fp32 or bf16; gradients fp32. */
+int snerf_semantic_composite_fwd(const float* weights, const void* logits, long ld, int dtype, long R, int S, int C, int softmax,
+                                 float* sem, void* stream);
+int snerf_semantic_composite_bwd(const float* weights, const void* logits, long ld, int dtype, const float* g_sem, long R, int S, int C,
+                                 int softmax, float* d_logits, long ld_d, float* g_w_out, void* stream);
 
 /* ---- early ray termination + sample compaction (inference; NOT in the reference: opt-in, error bounded by the proposal) -----
  * From the proposal histogram (s0 [N,S0+1], w0 [N,S0]) and the resampled fence posts s1 [N,S1+1]: W = cumulative proposal

@@ -333,9 +333,11 @@ def mipnerf_forward(p: dict, rays: dict, n_samples: int, n_fine: int, s_rand=Non
 
 def mipnerf_param_shapes(hidden: int = 1024, rgb_layers: int = 3, prop_hidden: int = 256, feature_dim: int = 96,
                          cond_dim: int = 27, n_layers: int = 8, n_prop_layers: int = 4, cond_units: int = 128,
-                         skip_layer: int = 4):
+                         skip_layer: int = 4, semantic_class_num: int = 0):
     """Ordered (name, shape) list of ``MipNerfModel.state_dict()`` for the
-    shipped config (models.py:55-68, 232-255, 307-315)."""
+    shipped config (models.py:55-68, 232-255, 307-315); with ``semantic_class_num`` > 0 the
+    semantic head Sequential(DenseBlock(hidden, hidden // 2), Linear(hidden // 2, C)) (models.py:258-260) is registered after
+    the rgb head."""
     out = []
     for i in range(n_layers):
         k = feature_dim if i == 0 else (hidden + feature_dim if ((i - 1) % skip_layer == 0 and (i - 1) > 0) else hidden)
@@ -346,6 +348,9 @@ def mipnerf_param_shapes(hidden: int = 1024, rgb_layers: int = 3, prop_hidden: i
         k = hidden + cond_dim if j == 0 else cond_units
         out += [(f"mlp.cond_layers.{j}.layers.0.weight", (cond_units, k)), (f"mlp.cond_layers.{j}.layers.0.bias", (cond_units,))]
     out += [("mlp.rgb_layer.weight", (3, cond_units)), ("mlp.rgb_layer.bias", (3,))]
+    if semantic_class_num > 0:
+        out += [("mlp.semantic_layer.0.layers.0.weight", (hidden // 2, hidden)), ("mlp.semantic_layer.0.layers.0.bias", (hidden // 2,)),
+                ("mlp.semantic_layer.1.weight", (semantic_class_num, hidden // 2)), ("mlp.semantic_layer.1.bias", (semantic_class_num,))]
     for i in range(n_prop_layers):
         k = feature_dim if i == 0 else prop_hidden
         out += [(f"proposal.layers.{i}.layers.0.weight", (prop_hidden, k)), (f"proposal.layers.{i}.layers.0.bias", (prop_hidden,))]

@@ -606,16 +606,19 @@ extern "C" int snerf_zip_composite_bwd(const float* raw_rgb, long ld_rgb, const 
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// semantic head (models.py:594-597 + render.py:237-241): semantic[r, c] = sum_i detach(w[r, i]) softmax(logits[r, i, :])[c];
-// logits are columns of the density network's output x (x[..., 1:1+C]).  Wave per ray, one sample per lane and pass.
-// Backward: d logits[i, c] = w_i p_c (g_c - sum_k p_k g_k); the weights receive no gradient ("no influences to density").
+// semantic compositing, both flavours of the reference.  Wave per ray, one sample per lane and pass.
+//   softmax = 1 (zipnerf: internal/models.py:594-597 + internal/render.py:237-241): semantic[r, c] = sum_i detach(w[r, i])
+//       softmax(logits[r, i, :])[c]; backward d logits[i, c] = w_i p_c (g_c - sum_k p_k g_k), no gradient to the weights;
+//   softmax = 0 (live mip path: s-nerf/model/mip.py:175-176): semantic[r, c] = sum_i w[r, i] raw[r, i, c]; backward
+//       d raw[i, c] = w_i g_c and d w_i = sum_c g_c raw[i, c] (written to g_w_out, the weights are part of the graph).
 // ------------------------------------------------------------------------------------------------------------------
 #define ZSEM_MAXC 32
 
 template <typename T, bool BWD>
-__global__ __launch_bounds__(256) void zip_semantic_kernel(const float* __restrict__ weights, const T* __restrict__ logits, long ld, long R, int S,
-                                                           int C, float* __restrict__ sem, const float* __restrict__ g_sem,
-                                                           float* __restrict__ d_logits, long ld_d) {
+__global__ __launch_bounds__(256) void semantic_composite_kernel(const float* __restrict__ weights, const T* __restrict__ logits, long ld, long R,
+                                                                 int S, int C, int softmax, float* __restrict__ sem,
+                                                                 const float* __restrict__ g_sem, float* __restrict__ d_logits, long ld_d,
+                                                                 float* __restrict__ g_w_out) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const long ray = (long)blockIdx.x * 4 + wave;
   if (ray >= R) return;
@@ -628,23 +631,32 @@ __global__ __launch_bounds__(256) void zip_semantic_kernel(const float* __restri
     const long p = ray * S + i;
     const float w = weights[p];
     const T* lg = logits + p * ld;
-    float v[ZSEM_MAXC], mx = -INFINITY;
+    float v[ZSEM_MAXC];
+    if (softmax) {
+      float mx = -INFINITY;
 #pragma unroll
-    for (int c = 0; c < ZSEM_MAXC; ++c) { v[c] = c < C ? (float)lg[c] : -INFINITY; mx = fmaxf(mx, v[c]); }
-    float den = 0.f;
+      for (int c = 0; c < ZSEM_MAXC; ++c) { v[c] = c < C ? (float)lg[c] : -INFINITY; mx = fmaxf(mx, v[c]); }
+      float den = 0.f;
 #pragma unroll
-    for (int c = 0; c < ZSEM_MAXC; ++c) { v[c] = c < C ? expf(v[c] - mx) : 0.f; den += v[c]; }
-    const float inv = 1.f / den;
+      for (int c = 0; c < ZSEM_MAXC; ++c) { v[c] = c < C ? expf(v[c] - mx) : 0.f; den += v[c]; }
+      const float inv = 1.f / den;
+#pragma unroll
+      for (int c = 0; c < ZSEM_MAXC; ++c) v[c] *= inv;
+    } else {
+#pragma unroll
+      for (int c = 0; c < ZSEM_MAXC; ++c) v[c] = c < C ? (float)lg[c] : 0.f;
+    }
     if (BWD) {
       float dot = 0.f;
 #pragma unroll
-      for (int c = 0; c < ZSEM_MAXC; ++c) dot += (v[c] * inv) * g[c];
+      for (int c = 0; c < ZSEM_MAXC; ++c) dot += v[c] * g[c];
 #pragma unroll
       for (int c = 0; c < ZSEM_MAXC; ++c)
-        if (c < C) d_logits[p * ld_d + c] = w * (v[c] * inv) * (g[c] - dot);
+        if (c < C) d_logits[p * ld_d + c] = softmax ? w * v[c] * (g[c] - dot) : w * g[c];
+      if (g_w_out != nullptr) g_w_out[p] = softmax ? 0.f : dot;
     } else {
 #pragma unroll
-      for (int c = 0; c < ZSEM_MAXC; ++c) acc[c] += w * (v[c] * inv);
+      for (int c = 0; c < ZSEM_MAXC; ++c) acc[c] += w * v[c];
     }
   }
   if (!BWD) {
@@ -656,24 +668,24 @@ __global__ __launch_bounds__(256) void zip_semantic_kernel(const float* __restri
   }
 }
 
-extern "C" int snerf_zip_semantic_fwd(const float* weights, const void* logits, long ld, int dtype, long R, int S, int C, float* sem,
-                                      void* stream) {
+extern "C" int snerf_semantic_composite_fwd(const float* weights, const void* logits, long ld, int dtype, long R, int S, int C, int softmax,
+                                            float* sem, void* stream) {
   if (R <= 0) return SNERF_OK;
   if (S <= 0 || C <= 0 || C > ZSEM_MAXC || weights == nullptr || logits == nullptr || sem == nullptr) return SNERF_ERR_ARG;
   const dim3 grid((unsigned)((R + 3) / 4));
-  if (dtype == SNERF_DT_F32) hipLaunchKernelGGL((zip_semantic_kernel<float, false>), grid, dim3(256), 0, (hipStream_t)stream, weights, (const float*)logits, ld, R, S, C, sem, nullptr, nullptr, 0);
-  else if (dtype == SNERF_DT_BF16) hipLaunchKernelGGL((zip_semantic_kernel<__bf16, false>), grid, dim3(256), 0, (hipStream_t)stream, weights, (const __bf16*)logits, ld, R, S, C, sem, nullptr, nullptr, 0);
+  if (dtype == SNERF_DT_F32) hipLaunchKernelGGL((semantic_composite_kernel<float, false>), grid, dim3(256), 0, (hipStream_t)stream, weights, (const float*)logits, ld, R, S, C, softmax, sem, nullptr, nullptr, 0, nullptr);
+  else if (dtype == SNERF_DT_BF16) hipLaunchKernelGGL((semantic_composite_kernel<__bf16, false>), grid, dim3(256), 0, (hipStream_t)stream, weights, (const __bf16*)logits, ld, R, S, C, softmax, sem, nullptr, nullptr, 0, nullptr);
   else return SNERF_ERR_ARG;
   return snerf_check_launch();
 }
 
-extern "C" int snerf_zip_semantic_bwd(const float* weights, const void* logits, long ld, int dtype, const float* g_sem, long R, int S, int C,
-                                      float* d_logits, long ld_d, void* stream) {
+extern "C" int snerf_semantic_composite_bwd(const float* weights, const void* logits, long ld, int dtype, const float* g_sem, long R, int S,
+                                            int C, int softmax, float* d_logits, long ld_d, float* g_w_out, void* stream) {
   if (R <= 0) return SNERF_OK;
   if (S <= 0 || C <= 0 || C > ZSEM_MAXC || weights == nullptr || logits == nullptr || g_sem == nullptr || d_logits == nullptr || ld_d < C) return SNERF_ERR_ARG;
   const dim3 grid((unsigned)((R + 3) / 4));
-  if (dtype == SNERF_DT_F32) hipLaunchKernelGGL((zip_semantic_kernel<float, true>), grid, dim3(256), 0, (hipStream_t)stream, weights, (const float*)logits, ld, R, S, C, nullptr, g_sem, d_logits, ld_d);
-  else if (dtype == SNERF_DT_BF16) hipLaunchKernelGGL((zip_semantic_kernel<__bf16, true>), grid, dim3(256), 0, (hipStream_t)stream, weights, (const __bf16*)logits, ld, R, S, C, nullptr, g_sem, d_logits, ld_d);
+  if (dtype == SNERF_DT_F32) hipLaunchKernelGGL((semantic_composite_kernel<float, true>), grid, dim3(256), 0, (hipStream_t)stream, weights, (const float*)logits, ld, R, S, C, softmax, nullptr, g_sem, d_logits, ld_d, g_w_out);
+  else if (dtype == SNERF_DT_BF16) hipLaunchKernelGGL((semantic_composite_kernel<__bf16, true>), grid, dim3(256), 0, (hipStream_t)stream, weights, (const __bf16*)logits, ld, R, S, C, softmax, nullptr, g_sem, d_logits, ld_d, g_w_out);
   else return SNERF_ERR_ARG;
   return snerf_check_launch();
 }

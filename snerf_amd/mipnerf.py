@@ -42,24 +42,27 @@ class MipNerfModel(_ArenaModule):
         super().__init__()
         if no_warp_sample:
             raise NotImplementedError("no_warp_sample=1 is broken in the reference itself (models.py:82 vs :178); only the warp branch exists")
-        if n_levels != 2 or not use_viewdirs or encode_appearance or semantic or disable_integration or min_deg_point != 0 or not stop_level_grad:
-            raise NotImplementedError("accelerated MipNerfModel: n_levels=2, use_viewdirs, stop_level_grad, no appearance/semantic heads")
+        if n_levels != 2 or not use_viewdirs or encode_appearance or disable_integration or min_deg_point != 0 or not stop_level_grad:
+            raise NotImplementedError("accelerated MipNerfModel: n_levels=2, use_viewdirs, stop_level_grad, no appearance embedding")
+        if semantic and not (0 < semantic_class_num <= 32):
+            raise NotImplementedError("semantic head: 1..32 classes")
         if fn != 1:
             raise NotImplementedError("only the contraction warp fn=1 (the shipped nuScenes config) is accelerated")
         self.n_levels, self.n_samples, self.N_fine = n_levels, n_samples, N_fine
         self.resample_padding, self.ray_shape, self.max_deg_point, self.deg_view = resample_padding, ray_shape, max_deg_point, deg_view
         self.density_noise, self.density_bias, self.rgb_padding = density_noise, density_bias, rgb_padding
         self.transform_idx, self.proposal_loss, self.lindisp = int(transform_idx), proposal_loss, lindisp
-        self.radius, self.fn, self.real, self.semantic, self.no_warp_sample, self.use_viewdirs = radius, fn, real, False, 0, True
+        self.radius, self.fn, self.real, self.semantic, self.no_warp_sample, self.use_viewdirs = radius, fn, real, bool(semantic), 0, True
+        self.sem_classes = int(semantic_class_num) if semantic else 0
         self.compute = compute
         fd = max_deg_point * 6
         cd = 3 + 6 * deg_view
-        shapes = [("mlp." + n, s) for n, s in MipNerfNet.param_shapes(hidden_layer, 8, 4, fd, cd, rgb_layer, 128)]
+        shapes = [("mlp." + n, s) for n, s in MipNerfNet.param_shapes(hidden_layer, 8, 4, fd, cd, rgb_layer, 128, self.sem_classes)]
         shapes += [("proposal." + n, s) for n, s in MipProposalNet.param_shapes(proposal_hidden_layer, 4, fd)]
         self._setup_arena(shapes, torch.device(device))
         dt = _dt(compute)
         self.dt = dt
-        self.nerf = MipNerfNet(self.arena, "mlp.", dt, hidden_layer, 8, 4, fd, cd, rgb_layer, 128, variant)
+        self.nerf = MipNerfNet(self.arena, "mlp.", dt, hidden_layer, 8, 4, fd, cd, rgb_layer, 128, variant, semantic_classes=self.sem_classes)
         self.prop = MipProposalNet(self.arena, "proposal.", dt, proposal_hidden_layer, 4, fd, variant)
         self.nerf.version_fn = self._param_version
         self.prop.version_fn = self._param_version
@@ -116,28 +119,40 @@ class MipNerfModel(_ArenaModule):
         raw_rgb, raw_d1, saved1 = self.nerf.forward(SKIP, CB, keep)
         rgb1, dist1, acc1, w1 = ops.mip_composite_fwd(raw_rgb, raw_d1, noise1, s1, d, near, far, self.transform_idx, white_bg,
                                                       self.rgb_padding, self.density_bias, row_index=row_index)
+        sem1 = raw_sem = None
+        if self.semantic:
+            if row_index is not None:
+                raise NotImplementedError("semantic rendering on compacted rows (ert) is not implemented")
+            raw_sem = self.nerf.raw_sem                                  # [n * S1, C] fp32: semantic = sum_i w_i raw_semantic_i (mip.py:175-176)
+            sem1 = ops.semantic_composite_fwd(w1, raw_sem, self.sem_classes, False)
         ctx = None
         if keep:
             # detached aliases of the output tensors: the originals become outputs of the autograd Function
             ctx = dict(d=d, near=near, far=far, s0=s0.detach(), s1=s1.detach(), raw_d0=raw_d0, acts0=acts0, w0=w0.detach(), dist0=dist0.detach(),
                        raw_rgb=raw_rgb, raw_d1=raw_d1, saved1=saved1, w1=w1.detach(), dist1=dist1.detach(), noise0=noise0, noise1=noise1,
-                       white=white_bg)
-        return (dist0, acc0, s0, w0, rgb1, dist1, acc1, s1, w1), ctx
+                       white=white_bg, raw_sem=raw_sem)
+        return (dist0, acc0, s0, w0, rgb1, dist1, acc1, s1, w1) + ((sem1,) if self.semantic else ()), ctx
 
-    def _backward(self, ctx, g_dist0, g_acc0, g_w0, g_rgb1, g_dist1, g_acc1, g_w1):
+    def _backward(self, ctx, g_dist0, g_acc0, g_w0, g_rgb1, g_dist1, g_acc1, g_w1, g_sem1=None):
         """Accumulates parameter gradients into the arena."""
         c = ctx
         n = c["s0"].shape[0]
         S0, S1 = c["s0"].shape[1] - 1, c["s1"].shape[1] - 1
         dev = c["s0"].device
         cc = lambda t: None if t is None else t.contiguous().float()
+        d_raw_sem = None
+        if g_sem1 is not None and c.get("raw_sem") is not None:
+            # semantic = sum_i w_i raw_i: d raw = w g, and the weights get sum_c g_c raw_ic on top of their other gradients
+            d_raw_sem = torch.empty_like(c["raw_sem"])
+            gw_sem = ops.semantic_composite_bwd(c["w1"], c["raw_sem"], cc(g_sem1), self.sem_classes, False, d_raw_sem, want_g_w=True)
+            g_w1 = gw_sem if g_w1 is None else cc(g_w1) + gw_sem
         if any(t is not None for t in (g_rgb1, g_dist1, g_acc1, g_w1)):
             d_rgb = torch.empty(n * S1, 3, dtype=torch.float32, device=dev)
             d_den = torch.empty(n * S1, 1, dtype=torch.float32, device=dev)
             ops.mip_composite_bwd(c["raw_rgb"], c["raw_d1"], c["noise1"], c["s1"], c["d"], c["near"], c["far"], self.transform_idx,
                                   c["white"], self.rgb_padding, self.density_bias, c["w1"], c["dist1"], cc(g_rgb1), cc(g_dist1),
                                   cc(g_acc1), cc(g_w1), d_rgb, d_den)
-            self.nerf.backward(d_rgb, d_den, c["saved1"])
+            self.nerf.backward(d_rgb, d_den, c["saved1"], d_raw_sem)
         if any(t is not None for t in (g_dist0, g_acc0, g_w0)):
             d_den0 = torch.empty(n * S0, 1, dtype=torch.float32, device=dev)
             ops.mip_composite_bwd(None, c["raw_d0"], c["noise0"], c["s0"], c["d"], c["near"], c["far"], self.transform_idx,
@@ -190,8 +205,8 @@ class MipNerfModel(_ArenaModule):
         self._ert = None if ert is None else (float(ert[0]), float(ert[1]))
         outs = _MipFn.apply(self, rays, bool(white_bg), s_rand, u, noise0, noise1, keep, *params)
         self._ert = None
-        dist0, acc0, s0, w0, rgb1, dist1, acc1, s1, w1 = outs
-        ret = [[None, dist0, acc0], [rgb1, dist1, acc1, None]]
+        dist0, acc0, s0, w0, rgb1, dist1, acc1, s1, w1 = outs[:9]
+        ret = [[None, dist0, acc0], [rgb1, dist1, acc1, outs[9] if self.semantic else None]]
         if self.proposal_loss:
             ret[0] += [s0, w0]
             ret[1] += [s1, w1]
@@ -208,12 +223,12 @@ class _MipFn(torch.autograd.Function):
         return outs
 
     @staticmethod
-    def backward(ctx, g_dist0, g_acc0, g_s0, g_w0, g_rgb1, g_dist1, g_acc1, g_s1, g_w1):
+    def backward(ctx, g_dist0, g_acc0, g_s0, g_w0, g_rgb1, g_dist1, g_acc1, g_s1, g_w1, g_sem1=None):
         if ctx.c is None:
             raise RuntimeError("MipNerfModel.forward ran without saved activations")
         m = ctx.model
         m.arena.grad.zero_()
-        m._backward(ctx.c, g_dist0, g_acc0, g_w0, g_rgb1, g_dist1, g_acc1, g_w1)
+        m._backward(ctx.c, g_dist0, g_acc0, g_w0, g_rgb1, g_dist1, g_acc1, g_w1, g_sem1)
         ctx.c = None
         grads = tuple(m.arena.g[n].clone() for n in m._pnames)
         return (None,) * 8 + grads

@@ -340,14 +340,15 @@ class MipNerfNet(_Net):
              CB [M, H + Cw] = [bottleneck | view encoding (+pad)]."""
 
     def __init__(self, arena, prefix, dt, hidden=1024, n_layers=8, skip_layer=4, feature_dim=96, cond_dim=27,
-                 n_cond=3, cond_units=128, variant=8):
+                 n_cond=3, cond_units=128, variant=8, semantic_classes=0):
         super().__init__(arena, prefix, dt, variant)
+        self.sc, self.Hs = int(semantic_classes), hidden // 2    # optional semantic head: trunk -> H/2 ReLU -> C (models.py:258-260)
         assert hidden % self.g == 0 and cond_units % self.g == 0 and n_layers > skip_layer + 1
         self.H, self.L, self.skip, self.fd, self.cd, self.nc, self.cu = hidden, n_layers, skip_layer, feature_dim, cond_dim, n_cond, cond_units
         self.Ew, self.Cw = roundup(feature_dim, self.g), roundup(cond_dim, self.g)
 
     @staticmethod
-    def param_shapes(hidden=1024, n_layers=8, skip_layer=4, feature_dim=96, cond_dim=27, n_cond=3, cond_units=128):
+    def param_shapes(hidden=1024, n_layers=8, skip_layer=4, feature_dim=96, cond_dim=27, n_cond=3, cond_units=128, semantic_classes=0):
         out = []
         for i in range(n_layers):
             k = feature_dim if i == 0 else (hidden + feature_dim if ((i - 1) % skip_layer == 0 and i - 1 > 0) else hidden)
@@ -357,7 +358,11 @@ class MipNerfNet(_Net):
         for j in range(n_cond):
             out += [(f"cond_layers.{j}.layers.0.weight", (cond_units, hidden + cond_dim if j == 0 else cond_units)),
                     (f"cond_layers.{j}.layers.0.bias", (cond_units,))]
-        return out + [("rgb_layer.weight", (3, cond_units)), ("rgb_layer.bias", (3,))]
+        out += [("rgb_layer.weight", (3, cond_units)), ("rgb_layer.bias", (3,))]
+        if semantic_classes > 0:
+            out += [("semantic_layer.0.layers.0.weight", (hidden // 2, hidden)), ("semantic_layer.0.layers.0.bias", (hidden // 2,)),
+                    ("semantic_layer.1.weight", (semantic_classes, hidden // 2)), ("semantic_layer.1.bias", (semantic_classes,))]
+        return out
 
     def _is_skip_in(self, i):  # layer i consumes the concatenated [trunk | enc] buffer
         return i >= 1 and (i - 1) % self.skip == 0 and (i - 1) > 0
@@ -385,9 +390,15 @@ class MipNerfNet(_Net):
             if train:
                 self._pack_dgrad(n, [n], 0, H if j == 0 else self.cu)
         self._pack_fwd("rgb", "rgb_layer", [(0, 0, self.cu)], self.cu)
+        if self.sc:
+            self._pack_fwd("sem0", "semantic_layer.0.layers.0", [(0, 0, H)], H)
+            self._pack_fwd("sem1", "semantic_layer.1", [(0, 0, self.Hs)], self.Hs)
         if train:
             self._pack_dgrad("rgb", ["rgb_layer"], 0, self.cu)
-            self._pack_dgrad("bd", ["bottleneck_layer.layers.0", "density_layer"], 0, H)
+            # the trunk output feeds the bottleneck, the density head and (optionally) the semantic head: one K-concatenated GEMM
+            self._pack_dgrad("bd", ["bottleneck_layer.layers.0", "density_layer"] + (["semantic_layer.0.layers.0"] if self.sc else []), 0, H)
+            if self.sc:
+                self._pack_dgrad("sem1", ["semantic_layer.1"], 0, self.Hs)
 
     def alloc_inputs(self, M):
         """-> (SKIP, CB); the encoders write SKIP[:, H:] and CB[:, H:] in place."""
@@ -424,10 +435,16 @@ class MipNerfNet(_Net):
             cx, ck = cy, self.cu
         raw_rgb = self.buf(M, 3, f32=True)
         self.fwd("rgb", cx, self.cu, raw_rgb, 3, ACT_NONE, out_f32=True)
-        return raw_rgb, raw_d, ((acts, cacts, SKIP, CB) if keep else None)
+        self.raw_sem, S0 = None, None
+        if self.sc:
+            S0 = self.buf(M, self.Hs)
+            self.fwd("sem0", x, H, S0, self.Hs)
+            self.raw_sem = self.buf(M, self.sc, f32=True)
+            self.fwd("sem1", S0, self.Hs, self.raw_sem, self.sc, ACT_NONE, out_f32=True)
+        return raw_rgb, raw_d, ((acts, cacts, SKIP, CB, S0) if keep else None)
 
-    def backward(self, d_raw_rgb, d_raw_density, saved):
-        acts, cacts, SKIP, CB = saved
+    def backward(self, d_raw_rgb, d_raw_density, saved, d_raw_sem=None):
+        acts, cacts, SKIP, CB, S0 = saved
         H, g, cu, M = self.H, self.g, self.cu, d_raw_rgb.shape[0]
         ops.colsum_f32(d_raw_rgb, 3, self.gB("rgb_layer"))
         ops.colsum_f32(d_raw_density, 1, self.gB("density_layer"))
@@ -436,7 +453,7 @@ class MipNerfNet(_Net):
         self.wgrad("rgb_layer", dz, clast, 3, cu)
         dC = self.buf(M, cu)
         self.dgrad("rgb", dz, dz.shape[1], dC, cu, mask=clast, colsum=self.gB(f"cond_layers.{self.nc - 1}.layers.0"))
-        DB = self.buf(M, H + g)                                     # [d bottleneck | d raw density (+pad)]
+        DB = self.buf(M, H + g + (self.Hs if self.sc else 0))       # [d bottleneck | d raw density (+pad) | d semantic hidden]
         for j in range(self.nc - 1, -1, -1):
             cx, ck, cy = cacts[j]
             n = f"cond_layers.{j}.layers.0"
@@ -447,12 +464,24 @@ class MipNerfNet(_Net):
                 dC = dX
             else:
                 self.dgrad(n, dC, cu, DB, H, mask=CB, colsum=self.gB("bottleneck_layer.layers.0"))
-        ops.cast_pad(d_raw_density, 1, DB[:, H:], g, self.dt)
+        ops.cast_pad(d_raw_density, 1, DB[:, H:H + g], g, self.dt)
         xl = acts[-1][2]
+        kb = H + g
+        if self.sc:
+            dS0 = DB[:, H + g:]
+            if d_raw_sem is None:
+                dS0.zero_()
+            else:
+                ops.colsum_f32(d_raw_sem, self.sc, self.gB("semantic_layer.1"))
+                dzs = self.head_grad(d_raw_sem, self.sc)
+                self.wgrad("semantic_layer.1", dzs, S0, self.sc, self.Hs)
+                self.dgrad("sem1", dzs, dzs.shape[1], dS0, self.Hs, mask=S0, colsum=self.gB("semantic_layer.0.layers.0"))
+                self.wgrad("semantic_layer.0.layers.0", dS0, xl, self.Hs, H)
+            kb += self.Hs
         self.wgrad("bottleneck_layer.layers.0", DB[:, :H], xl, H, H)
-        self.wgrad("density_layer", DB[:, H:], xl, 1, H)
+        self.wgrad("density_layer", DB[:, H:H + g], xl, 1, H)
         dZ = self.buf(M, H)
-        self.dgrad("bd", DB, H + g, dZ, H, mask=xl, colsum=self.gB(f"layers.{self.L - 1}.layers.0"))
+        self.dgrad("bd", DB, kb, dZ, H, mask=xl, colsum=self.gB(f"layers.{self.L - 1}.layers.0"))
         for i in range(self.L - 1, -1, -1):
             x, k, y = acts[i]
             n = f"layers.{i}.layers.0"

@@ -438,18 +438,20 @@ def mip_loss_tail(rgb, tgt, dist1, dist0, tdepth, conf, s_f, w_f, s_c, w_c, disp
     return out, g_rgb, g1, g0, gw
 
 
-def zip_semantic_fwd(weights, logits, C):
-    """semantic [R,C] = sum_i w[r,i] softmax(logits[r*S+i, :C]); logits: 2-D view (fp32 / bf16) of the density network's output."""
+def semantic_composite_fwd(weights, logits, C, softmax):
+    """semantic [R,C] = sum_i w[r,i] f(logits[r*S+i, :C]), f = softmax (zipnerf) or identity (live mip path); logits: 2-D view."""
     R, S = weights.shape
     _f32c(weights); _chk2d(logits)
     sem = torch.empty(R, C, dtype=torch.float32, device=weights.device)
-    _lib.call("snerf_zip_semantic_fwd", _p(weights), _p(logits), logits.stride(0), _zip_dt(logits), R, S, C, _p(sem), _stream())
+    _lib.call("snerf_semantic_composite_fwd", _p(weights), _p(logits), logits.stride(0), _zip_dt(logits), R, S, C, int(bool(softmax)), _p(sem), _stream())
     return sem
 
 
-def zip_semantic_bwd(weights, logits, g_sem, C, d_logits):
-    """d_logits (fp32 2-D view, >= C columns) <- w_i p_c (g_c - sum_k p_k g_k)."""
+def semantic_composite_bwd(weights, logits, g_sem, C, softmax, d_logits, want_g_w=False):
+    """d_logits (fp32 2-D view, >= C columns) <- gradient of the logits; returns d weights [R,S] when `want_g_w` (identity flavour)."""
     R, S = weights.shape
     _f32c(weights); _f32c(g_sem); _chk2d(logits); _chk2d(d_logits, torch.float32)
-    _lib.call("snerf_zip_semantic_bwd", _p(weights), _p(logits), logits.stride(0), _zip_dt(logits), _p(g_sem), R, S, C, _p(d_logits),
-              d_logits.stride(0), _stream())
+    g_w = torch.empty(R, S, dtype=torch.float32, device=weights.device) if want_g_w else None
+    _lib.call("snerf_semantic_composite_bwd", _p(weights), _p(logits), logits.stride(0), _zip_dt(logits), _p(g_sem), R, S, C, int(bool(softmax)),
+              _p(d_logits), d_logits.stride(0), _p(g_w), _stream())
+    return g_w

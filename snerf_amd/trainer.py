@@ -41,7 +41,7 @@ class MipTrainer:
         """The reference's per-ray loss tail (train.py:150-208) in ONE kernel, `snerf_mip_loss_tail`: RGB MSE, the
         confidence-weighted (disparity) depth loss on both levels masked to rays with a LiDAR target, and -- with
         `proposal_loss` -- ProposalLoss on the two histograms.  Returns (loss [device scalar], output gradients)."""
-        dist0, acc0, s0, w0, rgb1, dist1, acc1, s1, w1 = outs
+        dist0, acc0, s0, w0, rgb1, dist1, acc1, s1, w1 = outs[:9]
         prop = self.proposal_loss
         out, g_rgb1, g_dist1, g_dist0, g_w0 = ops.mip_loss_tail(
             rgb1, target_rgb, dist1 if target_depth is not None else None, dist0 if target_depth is not None else None,

@@ -198,7 +198,7 @@ class Model(_ArenaModule):
             sem = logits = None
             if self.use_semantic and not is_prop:
                 logits = SB[:, net.Wd + 1:net.Wd + 1 + self.class_num]            # x[..., 1:1+C] of the density network's output
-                sem = ops.zip_semantic_fwd(weights, logits, self.class_num)
+                sem = ops.semantic_composite_fwd(weights, logits, self.class_num, True)
             levels.append(dict(sdist=sdist, tdist=tdist, weights=weights, rgb=rgb, depth=depth, acc=acc, raw_rgb=raw_rgb, raw_d=raw_d, saved=saved,
                                degj=degj, ns=ns, semantic=sem, logits=logits))
         ctx = None
@@ -232,7 +232,7 @@ class Model(_ArenaModule):
                 ops.zip_composite_bwd(L["raw_rgb"], L["raw_d"], L["tdist"], ctx["d"], self.opaque_background, ctx["bg"], 0.001, -1.0, L["weights"],
                                       L["acc"], L["depth"], cc(g_rgb), cc(g_depth), cc(g_acc), cc(g_w), d_rgb, d_den)
             if sem_on:
-                ops.zip_semantic_bwd(L["weights"], L["logits"], cc(g_sem), self.class_num, d_dl[:, 1:])
+                ops.semantic_composite_bwd(L["weights"], L["logits"], cc(g_sem), self.class_num, True, d_dl[:, 1:])
             d_den = d_dl if sem_on else d_den
             dF = net.backward(d_den, L["saved"]) if lvl < 2 else net.backward(d_rgb, d_den, L["saved"])
             gtab = self.arena.g[self.names[lvl] + "encoder.embeddings"]

@@ -271,19 +271,26 @@ def mip_loss_tail(rgb, tgt, dist1, dist0, tdepth, conf, s_f, w_f, s_c, w_c, disp
     return out.to(dev), g_rgb, gd1, gd0, gw
 
 
-def zip_semantic_fwd(weights, logits, C):
-    p = torch.softmax(logits[:, :C].float().reshape(weights.shape[0], weights.shape[1], C), -1)
-    return (weights[..., None] * p).sum(-2)
+def semantic_composite_fwd(weights, logits, C, softmax):
+    v = logits[:, :C].float().reshape(weights.shape[0], weights.shape[1], C)
+    if softmax:
+        v = torch.softmax(v, -1)
+    return (weights[..., None] * v).sum(-2)
 
 
-def zip_semantic_bwd(weights, logits, g_sem, C, d_logits):
+def semantic_composite_bwd(weights, logits, g_sem, C, softmax, d_logits, want_g_w=False):
     R, S = weights.shape
-    p = torch.softmax(logits[:, :C].float().reshape(R, S, C), -1)
-    dot = (p * g_sem[:, None, :]).sum(-1, keepdim=True)
-    d_logits[:, :C] = (weights[..., None] * p * (g_sem[:, None, :] - dot)).reshape(R * S, C)
+    v = logits[:, :C].float().reshape(R, S, C)
+    if softmax:
+        p = torch.softmax(v, -1)
+        dot = (p * g_sem[:, None, :]).sum(-1, keepdim=True)
+        d_logits[:, :C] = (weights[..., None] * p * (g_sem[:, None, :] - dot)).reshape(R * S, C)
+        return torch.zeros(R, S) if want_g_w else None
+    d_logits[:, :C] = (weights[..., None] * g_sem[:, None, :]).expand(R, S, C).reshape(R * S, C)
+    return (v * g_sem[:, None, :]).sum(-1) if want_g_w else None
 
 
-_NAMES = ["zip_semantic_fwd", "zip_semantic_bwd", "zip_resample", "zip_encode_fwd", "zip_encode_bwd", "zip_composite_fwd", "zip_composite_bwd",
+_NAMES = ["semantic_composite_fwd", "semantic_composite_bwd", "zip_resample", "zip_encode_fwd", "zip_encode_bwd", "zip_composite_fwd", "zip_composite_bwd",
           "linear_fwd", "linear_wgrad", "classic_embed", "mip_encode", "mip_viewenc", "classic_sample_pdf", "classic_points",
           "classic_merge_sort", "mip_resample", "stratified", "mip_composite_fwd", "mip_composite_bwd", "classic_composite_fwd",
           "classic_composite_bwd", "adam_step", "colsum_f32", "cast_pad", "pinhole_rays", "mip_loss_tail"]

@@ -183,3 +183,24 @@ def test_g9_render_rays(golden):
         for k in ("rgb_map", "disp_map", "acc_map", "depth_map", "z_vals_map", "weights", "rgb0", "z_std"):
             close(r2[k], g["pt_" + k], tol, tol)
         close(r2["raw"], g["pt_raw"], 10 * tol, 10 * tol)
+
+
+def test_g14_mipnerf_semantic_head(golden):
+    """The optional semantic head (models.py:256-261,279-282; mip.py:175-176): outputs, loss and every parameter gradient of the
+    reference MipNerfModel(semantic=True) reproduced by the oracle."""
+    g = golden("g14_mipnerf_semantic")
+    names = [str(k) for k in g["param_names"]]
+    shapes = mip.mipnerf_param_shapes(hidden=64, prop_hidden=64, semantic_class_num=7)
+    assert [k for k, _ in shapes] == names
+    sd = common.fill_state_dict_({k: torch.empty(s) for k, s in shapes})
+    pr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    rays = {k[5:]: torch.as_tensor(v) for k, v in g.items() if k.startswith("rays_")}
+    ret = mip.mipnerf_forward(pr, rays, 16, 17)
+    sem = ret[1][3]
+    assert sem is not None and tuple(sem.shape) == (24, 7)
+    loss = ((ret[1][0] - g["target"]) ** 2).mean() + 0.01 * ret[0][1].mean() + 0.2 * (sem * g["semw"]).sum() / 24
+    loss.backward()
+    close(ret[1][0], g["l1_rgb"], 1e-5, 1e-6); close(ret[1][1], g["l1_distance"], 1e-5, 1e-5)
+    close(sem, g["l1_semantic"], 1e-5, 1e-6); close(loss, g["loss"], 1e-6, 1e-7)
+    for k in names:
+        close(pr[k].grad, g["grad." + k], 2e-4, 1e-7)

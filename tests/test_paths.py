@@ -274,3 +274,29 @@ def test_mipnerf_backward_vs_autograd(backend, compute, hidden, tol):
     close(loss, loss_ref, tol, tol, "loss")
     named = dict(m.named_parameters())
     check_grads(named, pr, sd, compute, tol)
+
+
+def test_mipnerf_semantic_head_vs_reference_golden(backend, golden):
+    """MipNerfModel(semantic=True): outputs and EVERY parameter gradient against the reference model's own (g14)."""
+    g = golden("g14_mipnerf_semantic")
+    from snerf_amd import mipnerf
+    m = mipnerf.MipNerfModel(n_samples=16, N_fine=17, no_warp_sample=0, ray_shape="cone", fn=1, radius=3., transform_idx=0, real=True,
+                             rgb_layer=3, hidden_layer=64, density_noise=0., max_deg_point=16, proposal_hidden_layer=64,
+                             proposal_loss=True, semantic=True, semantic_class_num=7, compute="f32", device=DEV)
+    names = [str(k) for k in g["param_names"]]
+    assert list(m.state_dict().keys()) == names
+    sd = common.fill_state_dict_({k: torch.empty(v.shape) for k, v in m.state_dict().items()})
+    m.load_state_dict(sd)
+    rays = mipnerf.Rays(**{k[5:]: torch.as_tensor(v).to(DEV) for k, v in g.items() if k.startswith("rays_")})
+    ret = m(rays, False, False, 0.)
+    sem = ret[1][3]
+    assert sem is not None and tuple(sem.shape) == (24, 7)
+    loss = ((ret[1][0] - g["target"].to(DEV)) ** 2).mean() + 0.01 * ret[0][1].mean() + 0.2 * (sem * g["semw"].to(DEV)).sum() / 24
+    loss.backward()
+    close(ret[1][0], g["l1_rgb"], 1e-4, 1e-5, "rgb"); close(ret[1][1], g["l1_distance"], 1e-4, 1e-4, "distance")
+    close(sem, g["l1_semantic"], 1e-4, 1e-5, "semantic"); close(loss, g["loss"], 1e-4, 1e-6, "loss")
+    named = dict(m.named_parameters())
+    for k in names:
+        got, ref = named[k].grad.detach().cpu(), g["grad." + k]
+        rel = float((got - ref).norm() / (ref.norm() + 1e-20))
+        assert rel < 5e-3, (k, rel)
