@@ -246,7 +246,7 @@ def make_mipnerf(args, device="cuda", compute="bf16"):
 
 def render_image(render_fn, rays, rank=0, chunk=8192):
     """Chunked full-frame inference (models.py:328-360): rays fields [H,W,.] -> (rgb [H,W,3], distance [H,W],
-    acc [H,W], semantic=None).  One process drives one GPU, so the reference's reflect-padding to the
+    acc [H,W], semantic [H,W,C] or None).  One process drives one GPU, so the reference's reflect-padding to the
     DataParallel device count is not needed."""
     height, width = rays[0].shape[:2]
     num_rays = height * width
@@ -254,6 +254,8 @@ def render_image(render_fn, rays, rank=0, chunk=8192):
     res = []
     for i in range(0, num_rays, chunk):
         out = render_fn(Rays(*[r[i:i + chunk] for r in flat]))[-1]
-        res.append(out[:3])
-    rgb, dist, acc = [torch.cat(r, 0) for r in zip(*res)]
-    return rgb.reshape(height, width, -1), dist.reshape(height, width), acc.reshape(height, width), None
+        res.append(out[:4] if len(out) > 3 and out[3] is not None else out[:3])
+    cols = [torch.cat(r, 0) for r in zip(*res)]
+    rgb, dist, acc = cols[:3]
+    sem = cols[3].reshape(height, width, -1) if len(cols) > 3 else None
+    return rgb.reshape(height, width, -1), dist.reshape(height, width), acc.reshape(height, width), sem
