@@ -235,6 +235,31 @@ int snerf_mip_loss_tail(const float* rgb, const float* tgt, const float* dist1, 
                         int Sc, int disparity, float depth_lambda, float coarse_mult, float prop_lambda, float* out, float* g_rgb,
                         float* g_dist1, float* g_dist0, float* g_wc, void* stream);
 
+/* zipnerf (path C) ray generation: s-nerfpp/zipnerf/internal/camera_utils.py:453-563 pixels_to_rays, perspective camera, no
+ * distortion, no NDC.  pix_x / pix_y int32 [N] integer pixel coordinates, cam_idx int32 [N] (NULL = camera 0) into pixtocams
+ * [ncam,3,3] (inverse intrinsics) and camtoworlds [ncam,3,4], all device pointers.  float64 arithmetic like numpy's there, one
+ * rounding per output.  origins / directions / viewdirs / base_x / base_y [N,3], radii [N], imageplane [N,2] (nullable). */
+int snerf_zip_pixels_to_rays(const int* pix_x, const int* pix_y, const int* cam_idx, const float* pixtocams, const float* camtoworlds,
+                             int ncam, long N, float* origins, float* directions, float* viewdirs, float* radii, float* imageplane,
+                             float* base_x, float* base_y, void* stream);
+/* Per-ray loss tail of s-nerfpp/zipnerf/train.py:250-311, value and gradients w.r.t. the renderer outputs in one pass:
+ * data term (internal/train_utils.py:62-90; mse = 0: Charbonnier sqrt(resid^2 + pad^2), 1: resid^2) weighted by lossmult [R]
+ * (nullable = 1) and normalised by its sum; disparity L1 |1/(depth+1e-5) - 1/(1e-5+tdepth)| as a masked mean under dmask [R]
+ * (x depth_lambda, train.py:252-255,277) and cmask [R] (x depth_lambda * com_mult, :260-272), both nullable, empty mask = 0;
+ * semantic NLL -log(sem[r, labels[r]] + 1e-6) as a masked mean under smask (x sem_mult, :294-298; sem NULL = off);
+ * anti_interlevel_loss (train_utils.py:132-164: stepfun.blur_stepfun :425-433 with pulse widths pw0 / pw1, math.sorted_interp_quad
+ * :133-156) of the NeRF histogram (s2 [R,S2+1], w2 [R,S2], detached) against the proposal levels (s0/w0, s1/w1; either NULL = skip)
+ * x inter_mult; lossfun_distortion (stepfun.py:297-307) on the NeRF level x dist_mult (s2 NULL = no regularisers).
+ * out[11]: [0..3] = {3 sum lossmult, sum dmask, sum cmask, sum smask}, [4..10] = {data, mse, depth, d_complete, sem, interlevel,
+ * distortion}, weights applied.  g_rgb [R,3], g_depth [R], g_sem [R,C], g_w0 [R,S0], g_w1 [R,S1] (interlevel), g_w2 [R,S2]
+ * (distortion) = d(sum of the terms)/d(input). */
+int snerf_zip_loss_tail(const float* rgb, const float* tgt, const float* lossmult, const float* depth, const float* tdepth,
+                        const float* dmask, const float* cmask, const float* sem, const int* labels, const float* smask, int C,
+                        const float* s0, const float* w0, int S0, const float* s1, const float* w1, int S1, const float* s2,
+                        const float* w2, int S2, long R, int mse, float pad, float data_mult, float depth_lambda, float com_mult,
+                        float sem_mult, float pw0, float pw1, float inter_mult, float dist_mult, float* out, float* g_rgb,
+                        float* g_depth, float* g_sem, float* g_w0, float* g_w1, float* g_w2, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

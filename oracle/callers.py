@@ -150,9 +150,16 @@ def lossfun_distortion(t, w):
 
 
 def blur_stepfun(x, y, r):
-    """stepfun.py:425-433: convolve the step function (x, y) with a box of half-width r -> piecewise-linear (xr, yr)."""
-    x, y = np.asarray(x, np.float64), np.asarray(y, np.float64)
-    cat = np.concatenate([x - r, x + r], -1)
+    """stepfun.py:425-433: convolve the step function (x, y) with a box of half-width r -> piecewise-linear (xr, yr).
+    The knots x -/+ r are formed in x's own dtype (the reference's fp32 tensors round them to fp32; r becomes an fp32 scalar there),
+    everything after that in float64."""
+    x = np.asarray(x)
+    if x.dtype != np.float32:
+        x = x.astype(np.float64)
+    rr = x.dtype.type(r)
+    y = np.asarray(y, np.float64)
+    cat = np.concatenate([x - rr, x + rr], -1).astype(np.float64)
+    r = float(rr)
     idx = np.argsort(cat, -1, kind="stable")
     xr = np.take_along_axis(cat, idx, -1)
     z = np.zeros_like(y[..., :1])
@@ -184,7 +191,7 @@ def anti_interlevel_loss(sdists, weights, pulse_width=(0.03, 0.003), mult=0.01):
     terms = []
     for i in range(len(sdists) - 1):
         cp, wp = np.asarray(sdists[i], np.float64), np.asarray(weights[i], np.float64)
-        c_, w_ = blur_stepfun(c, wn, pulse_width[i])
+        c_, w_ = blur_stepfun(sdists[-1], wn, pulse_width[i])
         area = 0.5 * (w_[..., 1:] + w_[..., :-1]) * (c_[..., 1:] - c_[..., :-1])
         cdf = np.concatenate([np.zeros_like(area[..., :1]), np.cumsum(area, -1)], -1)
         ws = np.diff(sorted_interp_quad(cp, c_, w_, cdf), axis=-1)
@@ -252,7 +259,7 @@ def zip_loss_tail(rgb, target, lossmult, depth, target_depth, depth_mask, com_ma
         tot = 0.0
         for i in range(len(sdists) - 1):
             cp, wp = f(sdists[i]), f(weights[i])
-            c_, w_ = blur_stepfun(c, wn, pulse_width[i])
+            c_, w_ = blur_stepfun(sdists[-1], wn, pulse_width[i])
             area = 0.5 * (w_[..., 1:] + w_[..., :-1]) * (c_[..., 1:] - c_[..., :-1])
             cdf = np.concatenate([np.zeros_like(area[..., :1]), np.cumsum(area, -1)], -1)
             ws = np.diff(sorted_interp_quad(cp, c_, w_, cdf), axis=-1)

@@ -204,3 +204,298 @@ extern "C" int snerf_mip_loss_tail(const float* rgb, const float* tgt, const flo
   hipLaunchKernelGGL(loss_tail_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, (hipStream_t)stream, a);
   return snerf_check_launch();
 }
+
+// ---------------------------------------------------------------------------
+// zipnerf (path C) ray generation: s-nerfpp/zipnerf/internal/camera_utils.py:453-563 (pixels_to_rays), perspective camera, no
+// distortion, no NDC.  numpy promotes to float64 there (integer pixels + .5); the dataset casts the result to fp32.  One lane
+// per ray, float64 arithmetic, one rounding per emitted value.
+// ---------------------------------------------------------------------------
+struct ZipRayGen {
+  const int *pix_x, *pix_y, *cam_idx;
+  const float *pixtocams, *camtoworlds;          // [ncam,3,3], [ncam,3,4]
+  long N;
+  int ncam;
+  float *origins, *directions, *viewdirs, *radii, *imageplane, *base_x, *base_y;
+};
+
+__device__ __forceinline__ void zip_cast(const double* k, const double* p, double x, double y, double* cam, double* d) {
+  const double px = x + .5, py = y + .5;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) cam[c] = (k[3 * c] * px + k[3 * c + 1] * py) + k[3 * c + 2];
+  cam[1] = -cam[1]; cam[2] = -cam[2];                 // OpenCV -> OpenGL (:527)
+#pragma unroll
+  for (int c = 0; c < 3; ++c) d[c] = (p[4 * c] * cam[0] + p[4 * c + 1] * cam[1]) + p[4 * c + 2] * cam[2];
+}
+
+__global__ __launch_bounds__(256) void zip_rays_kernel(ZipRayGen a) {
+  const long r = (long)blockIdx.x * 256 + threadIdx.x;
+  if (r >= a.N) return;
+  int cam = a.cam_idx != nullptr ? a.cam_idx[r] : 0;
+  cam = min(max(cam, 0), a.ncam - 1);
+  double k[9], p[12];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) k[i] = (double)a.pixtocams[9 * cam + i];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) p[i] = (double)a.camtoworlds[12 * cam + i];
+  const double x = (double)a.pix_x[r], y = (double)a.pix_y[r];
+  double c0[3], cx[3], cy[3], d[3], dx[3], dy[3];
+  zip_cast(k, p, x, y, c0, d);
+  zip_cast(k, p, x + 1.0, y, cx, dx);
+  zip_cast(k, p, x, y + 1.0, cy, dy);
+  double nd = 0, nx = 0, ny = 0;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { dx[c] -= d[c]; dy[c] -= d[c]; nd += d[c] * d[c]; nx += dx[c] * dx[c]; ny += dy[c] * dy[c]; }
+  nd = sqrt(nd); nx = sqrt(nx); ny = sqrt(ny);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    a.origins[3 * r + c] = (float)p[4 * c + 3];
+    a.directions[3 * r + c] = (float)d[c];
+    a.viewdirs[3 * r + c] = (float)(d[c] / nd);
+    a.base_x[3 * r + c] = (float)(dx[c] / nx);
+    a.base_y[3 * r + c] = (float)(dy[c] / ny);
+  }
+  a.radii[r] = (float)((0.5 * (nx + ny)) * 2.0 / 3.4641016151377544);
+  if (a.imageplane != nullptr) { a.imageplane[2 * r] = (float)c0[0]; a.imageplane[2 * r + 1] = (float)c0[1]; }
+}
+
+extern "C" int snerf_zip_pixels_to_rays(const int* pix_x, const int* pix_y, const int* cam_idx, const float* pixtocams, const float* camtoworlds,
+                                        int ncam, long N, float* origins, float* directions, float* viewdirs, float* radii, float* imageplane,
+                                        float* base_x, float* base_y, void* stream) {
+  if (N <= 0) return SNERF_OK;
+  if (pix_x == nullptr || pix_y == nullptr || pixtocams == nullptr || camtoworlds == nullptr || ncam < 1 || origins == nullptr ||
+      directions == nullptr || viewdirs == nullptr || radii == nullptr || base_x == nullptr || base_y == nullptr)
+    return SNERF_ERR_ARG;
+  ZipRayGen a{pix_x, pix_y, cam_idx, pixtocams, camtoworlds, N, ncam, origins, directions, viewdirs, radii, imageplane, base_x, base_y};
+  hipLaunchKernelGGL(zip_rays_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  return snerf_check_launch();
+}
+
+// ---------------------------------------------------------------------------
+// Per-ray loss tail of the zipnerf training step (s-nerfpp/zipnerf/train.py:250-311), value AND gradients w.r.t. the renderer
+// outputs in one pass:
+//   data        train_utils.py:62-90   sum(lossmult * sqrt(resid^2 + pad^2)) / sum(lossmult)   ('charb'; 'mse' = resid^2)
+//   depth       train.py:252-255,277   depth_lambda * masked mean |1/(depth+1e-5) - 1/(1e-5+target)|
+//   d_complete  train.py:260-272       the same under the second mask, x 0.2
+//   sem         train.py:294-298       -sem_mult * masked mean log(semantic[r, label] + 1e-6)
+//   interlevel  train_utils.py:132-164 (anti_interlevel_loss): NeRF histogram blurred by the level's pulse width
+//               (stepfun.py:425-433), integrated to a piecewise-quadratic CDF, resampled on the proposal intervals
+//               (math.py:133-156); mean(clamp(w_s - wp, 0)^2 / (wp + 1e-5)); gradient reaches the proposal weights only
+//   distortion  stepfun.py:297-307     mean_r [sum_ij w_i w_j |u_i - u_j| + sum_i w_i^2 d_i / 3]; gradient w.r.t. the NeRF weights
+// grid = (ceil(R/64), 3): y = 0 per-ray terms + distortion, y = 1, 2 the two proposal levels.  One lane per ray.  The blurred
+// histogram is never materialised: its 2(S+1) knots are the merge of the two sorted lists {c - r} and {c + r}, walked once
+// together with the (sorted) proposal fence posts; prefix sums run in float64 (the reference's fp32 cumsum of the +/- steps
+// carries ~1e-4 relative noise, tests/test_oracle_callers_golden.py) and every emitted value is rounded once.
+// out[0..3] = {3 sum lossmult, sum depth mask, sum complete mask, sum semantic mask};
+// out[4..10] = {data, mse, depth, d_complete, sem, interlevel, distortion} (already multiplied by their weights).
+// ---------------------------------------------------------------------------
+struct ZipLoss {
+  const float *rgb, *tgt, *lossmult;
+  const float *depth, *tdepth, *dmask, *cmask;
+  const float* sem; const int* labels; const float* smask;
+  const float *s0, *w0, *s1, *w1, *s2, *w2;
+  long R;
+  int C, S0, S1, S2, mse;
+  float pad, data_mult, depth_lambda, com_mult, sem_mult, pw0, pw1, inter_mult, dist_mult;
+  float* out;
+  float *g_rgb, *g_depth, *g_sem, *g_w0, *g_w1, *g_w2;
+};
+
+__global__ __launch_bounds__(1024) void zip_loss_prepare_kernel(ZipLoss a) {
+  __shared__ float part[4][16];
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  for (long r = threadIdx.x; r < a.R; r += 1024) {
+    s[0] += a.lossmult != nullptr ? a.lossmult[r] : 1.f;
+    if (a.depth != nullptr && a.dmask != nullptr) s[1] += a.dmask[r];
+    if (a.depth != nullptr && a.cmask != nullptr) s[2] += a.cmask[r];
+    if (a.sem != nullptr) s[3] += a.smask != nullptr ? a.smask[r] : 1.f;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    s[k] = wave_sum(s[k]);
+    if ((threadIdx.x & 63) == 0) part[k][threadIdx.x >> 6] = s[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    float t = 0.f;
+    for (int w = 0; w < 16; ++w) t += part[threadIdx.x][w];
+    a.out[threadIdx.x] = threadIdx.x == 0 ? 3.f * t : t;
+  }
+  if (threadIdx.x >= 4 && threadIdx.x < 11) a.out[threadIdx.x] = 0.f;
+}
+
+// anti-interlevel term of one ray against one proposal level -> sum_j clamp(w_s - wp, 0)^2 / (wp + 1e-5); writes d/d wp
+__device__ __forceinline__ float zip_interlevel_ray(const float* __restrict__ c, const float* __restrict__ w, int S, const float* __restrict__ cp,
+                                                    const float* __restrict__ wp, int Sp, float r, float gscale, float* __restrict__ g) {
+  const int n = S + 1;
+  const double r2 = 2.0 * (double)r;
+  // y1[k] = (wn[k] - wn[k-1]) / (2r) with wn = w / (c[k+1] - c[k]) and zeros outside (stepfun.py:427-428)
+  auto y1 = [&](int k) __attribute__((always_inline)) {
+    const double hi = k < S ? (double)w[k] / ((double)c[k + 1] - (double)c[k]) : 0.0;
+    const double lo = k > 0 ? (double)w[k - 1] / ((double)c[k] - (double)c[k - 1]) : 0.0;
+    return (hi - lo) / r2;
+  };
+  int ia = 0, ib = 0, q = 0;
+  float xa = c[0] - r, xb = c[0] + r;
+  double inner = 0.0, yrun = 0.0, cdf = 0.0;
+  double xprev = 0.0, yprev = 0.0, cprev = 0.0;
+  double ci_prev = 0.0;
+  double loss = 0.0;
+  auto emit = [&](double ci) __attribute__((always_inline)) {
+    if (q > 0) {
+      const double ws = ci - ci_prev;
+      const double p = (double)wp[q - 1];
+      const double over = ws > p ? ws - p : 0.0;
+      const double den = p + 1e-5;
+      loss += over * over / den;
+      g[q - 1] = (float)((double)gscale * (-2.0 * over / den - over * over / (den * den)));
+    }
+    ci_prev = ci;
+    ++q;
+  };
+  float xq = cp[0];
+  for (int k = 0; k < 2 * n; ++k) {
+    double xk, val;
+    if (ib >= n || (ia < n && xa <= xb)) { xk = (double)xa; val = y1(ia); ++ia; xa = ia < n ? c[ia] - r : 0.f; }
+    else { xk = (double)xb; val = -y1(ib); ++ib; xb = ib < n ? c[ib] + r : 0.f; }
+    double yk = 0.0;
+    if (k > 0) {
+      const double dx = xk - xprev;
+      yrun += dx * inner;
+      yk = yrun > 0.0 ? yrun : 0.0;
+      cdf += 0.5 * (yk + yprev) * dx;
+    }
+    // proposal fence posts in [x_{k-1}, x_k): idx = k knots are <= x (math.py:141-148)
+    while (q <= Sp && (double)xq < xk) {
+      double ci = 0.0;
+      if (k > 0) {
+        const double t = (double)xq - xprev;
+        double off = t / (xk - xprev);
+        off = off < 0.0 ? 0.0 : (off > 1.0 ? 1.0 : off);
+        ci = cprev + t * (yprev + yk * off + yprev * (1.0 - off)) / 2.0;
+      }
+      emit(ci);
+      xq = q <= Sp ? cp[q] : 0.f;
+    }
+    xprev = xk; yprev = yk; cprev = cdf;
+    inner += val;
+  }
+  while (q <= Sp) {                                   // at or past the last knot: offset = 1 (or nan -> 0 when equal), both give this
+    emit(cprev + ((double)xq - xprev) * yprev);
+    xq = q <= Sp ? cp[q] : 0.f;
+  }
+  return (float)loss;
+}
+
+__global__ __launch_bounds__(64) void zip_loss_tail_kernel(ZipLoss a) {
+  const long r = (long)blockIdx.x * 64 + threadIdx.x;
+  const int task = blockIdx.y;
+  const bool on = r < a.R;
+  if (task > 0) {
+    if (a.s2 == nullptr || a.inter_mult <= 0.f) return;
+    const int lvl = task - 1;
+    const float* sp = lvl == 0 ? a.s0 : a.s1;
+    if (sp == nullptr) return;
+    const int Sp = lvl == 0 ? a.S0 : a.S1;
+    float l = 0.f;
+    if (on) {
+      const float* wp = (lvl == 0 ? a.w0 : a.w1) + r * Sp;
+      float* g = (lvl == 0 ? a.g_w0 : a.g_w1) + r * Sp;
+      const float sc = a.inter_mult / ((float)a.R * (float)Sp);
+      l = zip_interlevel_ray(a.s2 + r * (a.S2 + 1), a.w2 + r * a.S2, a.S2, sp + r * (Sp + 1), wp, Sp, lvl == 0 ? a.pw0 : a.pw1, sc, g) * sc;
+    }
+    l = wave_sum(l);
+    if (threadIdx.x == 0) atomicAdd(a.out + 9, l);
+    return;
+  }
+  float l_data = 0.f, l_mse = 0.f, l_dep = 0.f, l_com = 0.f, l_sem = 0.f, l_dist = 0.f;
+  if (on) {
+    // ---- data term
+    const float lm = a.lossmult != nullptr ? a.lossmult[r] : 1.f;
+    const float inv = 1.f / a.out[0];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float d = a.rgb[3 * r + c] - a.tgt[3 * r + c];
+      const float r2 = d * d;
+      l_mse += lm * r2;
+      if (a.mse) { l_data += lm * r2; a.g_rgb[3 * r + c] = a.data_mult * lm * 2.f * d * inv; }
+      else {
+        const float root = sqrtf(r2 + a.pad * a.pad);
+        l_data += lm * root;
+        a.g_rgb[3 * r + c] = a.data_mult * lm * (d / root) * inv;
+      }
+    }
+    l_data *= a.data_mult * inv; l_mse *= inv;
+    // ---- disparity L1 under the two masks
+    if (a.depth != nullptr) {
+      const float dp = a.depth[r] + 1e-5f;
+      const float e = 1.f / dp - 1.f / (1e-5f + a.tdepth[r]);
+      const float sg = (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f)) * (-1.f / (dp * dp));
+      float g = 0.f;
+      if (a.dmask != nullptr && a.out[1] > 0.f) { const float k = a.depth_lambda * a.dmask[r] / a.out[1]; l_dep = k * fabsf(e); g += k * sg; }
+      if (a.cmask != nullptr && a.out[2] > 0.f) { const float k = a.depth_lambda * a.com_mult * a.cmask[r] / a.out[2]; l_com = k * fabsf(e); g += k * sg; }
+      a.g_depth[r] = g;
+    }
+    // ---- semantic NLL
+    if (a.sem != nullptr) {
+      const int lab = min(max(a.labels[r], 0), a.C - 1);
+      const float m = a.smask != nullptr ? a.smask[r] : 1.f;
+      const float p = a.sem[r * a.C + lab] + 1e-6f;
+      const float k = a.out[3] > 0.f ? a.sem_mult * m / a.out[3] : 0.f;
+      l_sem = -k * logf(p);
+      for (int c = 0; c < a.C; ++c) a.g_sem[r * a.C + c] = c == lab ? -k / p : 0.f;
+    }
+    // ---- distortion: sum_ij w_i w_j |u_i - u_j| through prefix sums over the sorted midpoints
+    if (a.s2 != nullptr && a.dist_mult > 0.f) {
+      const float* c = a.s2 + r * (a.S2 + 1);
+      const float* w = a.w2 + r * a.S2;
+      float* g = a.g_w2 + r * a.S2;
+      double W = 0.0, WU = 0.0;
+      for (int k = 0; k < a.S2; ++k) { const double u = (double)((c[k + 1] + c[k]) / 2.f); W += (double)w[k]; WU += (double)w[k] * u; }
+      double Wl = 0.0, WUl = 0.0, acc = 0.0;
+      const float sc = a.dist_mult / (float)a.R;
+      for (int k = 0; k < a.S2; ++k) {
+        const double u = (double)((c[k + 1] + c[k]) / 2.f), wk = (double)w[k], dk = (double)(c[k + 1] - c[k]);
+        const double Wg = W - Wl - wk, WUg = WU - WUl - wk * u;
+        const double inner = u * (Wl - Wg) - (WUl - WUg);
+        acc += wk * inner + wk * wk * dk / 3.0;
+        g[k] = sc * (float)(2.0 * inner + 2.0 * wk * dk / 3.0);
+        Wl += wk; WUl += wk * u;
+      }
+      l_dist = sc * (float)acc;
+    }
+  }
+  l_data = wave_sum(l_data); l_mse = wave_sum(l_mse); l_dep = wave_sum(l_dep); l_com = wave_sum(l_com); l_sem = wave_sum(l_sem);
+  l_dist = wave_sum(l_dist);
+  if (threadIdx.x == 0) {
+    atomicAdd(a.out + 4, l_data); atomicAdd(a.out + 5, l_mse);
+    if (a.depth != nullptr) { atomicAdd(a.out + 6, l_dep); atomicAdd(a.out + 7, l_com); }
+    if (a.sem != nullptr) atomicAdd(a.out + 8, l_sem);
+    if (a.s2 != nullptr && a.dist_mult > 0.f) atomicAdd(a.out + 10, l_dist);
+  }
+}
+
+extern "C" int snerf_zip_loss_tail(const float* rgb, const float* tgt, const float* lossmult, const float* depth, const float* tdepth,
+                                   const float* dmask, const float* cmask, const float* sem, const int* labels, const float* smask, int C,
+                                   const float* s0, const float* w0, int S0, const float* s1, const float* w1, int S1, const float* s2,
+                                   const float* w2, int S2, long R, int mse, float pad, float data_mult, float depth_lambda, float com_mult,
+                                   float sem_mult, float pw0, float pw1, float inter_mult, float dist_mult, float* out, float* g_rgb,
+                                   float* g_depth, float* g_sem, float* g_w0, float* g_w1, float* g_w2, void* stream) {
+  if (R <= 0) return SNERF_OK;
+  if (rgb == nullptr || tgt == nullptr || out == nullptr || g_rgb == nullptr) return SNERF_ERR_ARG;
+  if (depth != nullptr && (tdepth == nullptr || g_depth == nullptr)) return SNERF_ERR_ARG;
+  if (sem != nullptr && (labels == nullptr || g_sem == nullptr || C < 1)) return SNERF_ERR_ARG;
+  if (s2 != nullptr) {
+    if (w2 == nullptr || S2 < 1) return SNERF_ERR_ARG;
+    if (dist_mult > 0.f && g_w2 == nullptr) return SNERF_ERR_ARG;
+    if (inter_mult > 0.f) {
+      if (s0 != nullptr && (w0 == nullptr || g_w0 == nullptr || S0 < 1 || !(pw0 > 0.f))) return SNERF_ERR_ARG;
+      if (s1 != nullptr && (w1 == nullptr || g_w1 == nullptr || S1 < 1 || !(pw1 > 0.f))) return SNERF_ERR_ARG;
+    }
+  }
+  ZipLoss a{rgb, tgt, lossmult, depth, tdepth, dmask, cmask, sem, labels, smask, s0, w0, s1, w1, s2, w2, R, C, S0, S1, S2, mse,
+            pad, data_mult, depth_lambda, com_mult, sem_mult, pw0, pw1, inter_mult, dist_mult, out, g_rgb, g_depth, g_sem, g_w0, g_w1, g_w2};
+  hipLaunchKernelGGL(zip_loss_prepare_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
+  const bool inter = s2 != nullptr && inter_mult > 0.f && (s0 != nullptr || s1 != nullptr);
+  hipLaunchKernelGGL(zip_loss_tail_kernel, dim3((unsigned)((R + 63) / 64), inter ? 3 : 1), dim3(64), 0, (hipStream_t)stream, a);
+  return snerf_check_launch();
+}

@@ -438,6 +438,67 @@ def mip_loss_tail(rgb, tgt, dist1, dist0, tdepth, conf, s_f, w_f, s_c, w_c, disp
     return out, g_rgb, g1, g0, gw
 
 
+def zip_pixels_to_rays(pix_x, pix_y, cam_idx, pixtocams, camtoworlds, want_imageplane=False):
+    """camera_utils.pixels_to_rays on device: int32 pixel coordinates [n] (+ int32 camera index [n] or None) and the stacked
+    [ncam,3,3] inverse intrinsics / [ncam,3,4] extrinsics -> dict(origins, directions, viewdirs, radii [n,1], base_x, base_y
+    (, imageplane))."""
+    n, dev = pix_x.shape[0], pix_x.device
+    for t in (pix_x, pix_y) + ((cam_idx,) if cam_idx is not None else ()):
+        assert t.dtype == torch.int32 and t.is_contiguous() and t.shape == (n,)
+    k, c = _f32c(pixtocams.contiguous()).reshape(-1, 3, 3), _f32c(camtoworlds.contiguous())   # (torch.linalg.inv returns column-major)
+    assert c.shape[1:] == (3, 4) and c.shape[0] == k.shape[0]
+    o, d, v, bx, by = (torch.empty(n, 3, dtype=torch.float32, device=dev) for _ in range(5))
+    r = torch.empty(n, 1, dtype=torch.float32, device=dev)
+    ip = torch.empty(n, 2, dtype=torch.float32, device=dev) if want_imageplane else None
+    _lib.call("snerf_zip_pixels_to_rays", _p(pix_x), _p(pix_y), _p(cam_idx), _p(k), _p(c), k.shape[0], n, _p(o), _p(d), _p(v), _p(r), _p(ip),
+              _p(bx), _p(by), _stream())
+    out = dict(origins=o, directions=d, viewdirs=v, radii=r, base_x=bx, base_y=by)
+    if ip is not None:
+        out["imageplane"] = ip
+    return out
+
+
+ZIP_LOSS_NAMES = ("data", "mse", "depth", "d_complete", "sem", "interlevel", "distortion")
+
+
+def zip_loss_tail(rgb, tgt, lossmult=None, depth=None, tdepth=None, dmask=None, cmask=None, sem=None, labels=None, smask=None, hist=None,
+                  mse=False, charb_padding=0.001, data_mult=1.0, depth_lambda=0.5, com_mult=0.2, sem_mult=0.04, pulse_width=(0.03, 0.003),
+                  interlevel_mult=0.01, distortion_mult=0.005):
+    """One launch for the zipnerf loss tail.  `hist` = [(sdist, weights)] * 3 (proposal, proposal, NeRF) or None.
+    -> (out[11] (see include/snerf_hip.h), dict of gradients: rgb, depth, semantic, w0, w1, w2 -- None where the term is off)."""
+    R, dev = rgb.shape[0], rgb.device
+    c = lambda t: None if t is None else _f32c(t)
+    new = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)
+    out, g_rgb = new(11), new(R, 3)
+    g_depth = new(R) if depth is not None else None
+    C = 0
+    g_sem = None
+    if sem is not None:
+        C = sem.shape[1]
+        assert labels.dtype == torch.int32 and labels.is_contiguous() and labels.shape == (R,)
+        g_sem = new(R, C)
+    s = [None] * 3; w = [None] * 3; S = [0] * 3; gw = [None] * 3
+    if hist is not None:
+        for i, (sd, wt) in enumerate(hist):
+            if sd is None:
+                continue
+            s[i], w[i], S[i] = c(sd), c(wt), wt.shape[1]
+            assert sd.shape == (R, S[i] + 1) and wt.shape[0] == R
+        assert s[2] is not None
+        if distortion_mult > 0:
+            gw[2] = new(R, S[2])
+        if interlevel_mult > 0:
+            for i in (0, 1):
+                if s[i] is not None:
+                    gw[i] = new(R, S[i])
+    _lib.call("snerf_zip_loss_tail", _p(c(rgb)), _p(c(tgt)), _p(c(lossmult)), _p(c(depth)), _p(c(tdepth)), _p(c(dmask)), _p(c(cmask)), _p(c(sem)),
+              _p(labels), _p(c(smask)), C, _p(s[0]), _p(w[0]), S[0], _p(s[1]), _p(w[1]), S[1], _p(s[2]), _p(w[2]), S[2], R, int(bool(mse)),
+              float(charb_padding), float(data_mult), float(depth_lambda), float(com_mult), float(sem_mult), float(pulse_width[0]),
+              float(pulse_width[1]), float(interlevel_mult), float(distortion_mult), _p(out), _p(g_rgb), _p(g_depth), _p(g_sem), _p(gw[0]),
+              _p(gw[1]), _p(gw[2]), _stream())
+    return out, dict(rgb=g_rgb, depth=g_depth, semantic=g_sem, w0=gw[0], w1=gw[1], w2=gw[2])
+
+
 def semantic_composite_fwd(weights, logits, C, softmax):
     """semantic [R,C] = sum_i w[r,i] f(logits[r*S+i, :C]), f = softmax (zipnerf) or identity (live mip path); logits: 2-D view."""
     R, S = weights.shape

@@ -77,21 +77,27 @@ def shard_rays(rays, rank: int, world: int):
 
 
 class ZipTrainer:
-    """Train step of the S-NeRF++ / zipnerf background model (s-nerfpp/zipnerf/train.py hot loop: Model.forward,
-    train_utils.compute_data_loss :62-90 -- the Charbonnier term on the final level --, loss.backward(), optimizer.step()) on the
-    flat arenas: forward, per-ray loss tail, backward through the fused kernels, ONE RCCL all-reduce of the flat gradient arena
-    (MLPs + the 3 hash tables, ~310 MB for waymo.gin) and one fused Adam launch with the 1/world mean folded in.
+    """Train step of the S-NeRF++ / zipnerf background model (s-nerfpp/zipnerf/train.py hot loop :218-331: Model.forward, the loss
+    terms, loss.backward(), optimizer.step()) on the flat arenas: forward, ONE fused loss-tail launch (ops.zip_loss_tail: Charbonnier
+    data term, disparity-L1 depth terms, semantic NLL, anti-interlevel and distortion regularisers, with their gradients), backward
+    through the fused kernels, ONE RCCL all-reduce of the flat gradient arena (MLPs + the 3 hash tables, ~310 MB for waymo.gin) and
+    one fused Adam launch with the 1/world mean folded in.  No device->host sync anywhere in the step: the loss terms stay on the
+    device in `last_losses` (ops.ZIP_LOSS_NAMES order).
 
-    The proposal levels are supervised through `aux_loss_fn(ray_history) -> scalar` (the caller's interlevel / distortion losses,
-    train_utils.py:132-164, stepfun.py:297-307): it is evaluated with torch autograd on detached leaf copies of every level's
-    `weights`, and the resulting d(loss)/d(weights) enters the renderer's hand-written backward."""
+    `loss_cfg` overrides the reference defaults (internal/configs.py:60-66,85; train.py:253,272,298): charb_padding 0.001, data_mult
+    1, depth_lambda 0.5, com_mult 0.2, sem_mult 0.04, pulse_width (0.03, 0.003), interlevel_mult 0.01, distortion_mult 0.005, mse False.
+    Further caller-defined terms on the ray histories go through `aux_loss_fn(ray_history) -> scalar` (torch autograd on detached
+    leaf copies of every level's `weights`; its d(loss)/d(weights) is added to the fused tail's)."""
 
-    def __init__(self, model, lr=1e-2, betas=(0.9, 0.99), eps=1e-15, charb_padding=0.001, process_group=None):
-        self.model, self.lr, self.betas, self.eps, self.charb = model, lr, betas, eps, charb_padding
+    def __init__(self, model, lr=1e-2, betas=(0.9, 0.99), eps=1e-15, charb_padding=0.001, process_group=None, loss_cfg=None):
+        self.model, self.lr, self.betas, self.eps = model, lr, betas, eps
+        self.loss_cfg = dict(charb_padding=charb_padding)
+        self.loss_cfg.update(loss_cfg or {})
         a = model.arena
         self.m, self.v, self.t = torch.zeros_like(a.flat), torch.zeros_like(a.flat), 0
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.last_losses = None
         a.grad.zero_()
 
     def broadcast_parameters(self, src=0):
@@ -99,28 +105,36 @@ class ZipTrainer:
             dist.broadcast(self.model.arena.flat, src=src, group=self.pg)
             self.model.arena.bump()
 
-    def step(self, batch, target_rgb, train_frac=1.0, rand=True, aux_loss_fn=None, draws=None, sample_n=7, sample_m=3):
+    def step(self, batch, target_rgb, train_frac=1.0, rand=True, aux_loss_fn=None, draws=None, sample_n=7, sample_m=3, targets=None):
+        """`targets` (all optional, per ray): lossmult [R] (the reference's mask_rgb as 0/1 floats), depth [R] + depth_mask [R]
+        (+ complete_mask [R]), semantic int32 labels [R] + semantic_mask [R]."""
         m = self.model
         dev = m.arena.flat.device
         R = batch['origins'].shape[0]
+        t = targets or {}
         if draws is None:
             draws = m._draws(R, rand, dev, sample_n)
         levels, ctx = m._run(batch, True, float(train_frac), draws, sample_n, sample_m)
-        rgb = levels[2]["rgb"]
-        diff = rgb - target_rgb
-        root = torch.sqrt(diff * diff + self.charb ** 2)               # Charbonnier (train_utils.py:76)
-        loss = root.mean()
-        g_rgb = diff / root * (1.0 / diff.numel())
-        g_w = [None, None, None]
+        fin = levels[2]
+        with_depth = t.get("depth") is not None
+        with_sem = t.get("semantic") is not None and fin.get("semantic") is not None
+        out, G = ops.zip_loss_tail(fin["rgb"], target_rgb, t.get("lossmult"), depth=fin["depth"] if with_depth else None,
+                                   tdepth=t.get("depth"), dmask=t.get("depth_mask"), cmask=t.get("complete_mask"),
+                                   sem=fin["semantic"] if with_sem else None, labels=t.get("semantic") if with_sem else None,
+                                   smask=t.get("semantic_mask"), hist=[(levels[l]["sdist"], levels[l]["weights"]) for l in range(3)],
+                                   **self.loss_cfg)
+        self.last_losses = out[4:]
+        loss = out[4] + out[6:].sum()
+        g_w = [G["w0"], G["w1"], G["w2"]]
         if aux_loss_fn is not None:
             with torch.enable_grad():
                 leaves = [levels[l]["weights"].detach().requires_grad_(True) for l in range(3)]
                 hist = [dict(sdist=levels[l]["sdist"].detach(), tdist=levels[l]["tdist"].detach(), weights=leaves[l]) for l in range(3)]
                 aux = aux_loss_fn(hist)
                 gs = torch.autograd.grad(aux, leaves, allow_unused=True)
-            g_w = list(gs)
+            g_w = [a if b is None else (b if a is None else a + b) for a, b in zip(g_w, gs)]
             loss = loss + aux.detach()
-        m._backward(ctx, [(None, None, None, g_w[0]), (None, None, None, g_w[1]), (g_rgb, None, None, g_w[2])])
+        m._backward(ctx, [(None, None, None, g_w[0]), (None, None, None, g_w[1]), (G["rgb"], G["depth"], None, g_w[2], G["semantic"])])
         if self.world > 1:
             dist.all_reduce(m.arena.grad, op=dist.ReduceOp.SUM, group=self.pg)
         self.t += 1

@@ -290,7 +290,43 @@ def semantic_composite_bwd(weights, logits, g_sem, C, softmax, d_logits, want_g_
     return (v * g_sem[:, None, :]).sum(-1) if want_g_w else None
 
 
-_NAMES = ["semantic_composite_fwd", "semantic_composite_bwd", "zip_resample", "zip_encode_fwd", "zip_encode_bwd", "zip_composite_fwd", "zip_composite_bwd",
+def zip_pixels_to_rays(pix_x, pix_y, cam_idx, pixtocams, camtoworlds, want_imageplane=False):
+    from oracle import callers as oc
+    ci = np.zeros(pix_x.shape[0], np.int64) if cam_idx is None else cam_idx.cpu().numpy().astype(np.int64)
+    r = oc.zip_pixels_to_rays(pix_x.cpu().numpy(), pix_y.cpu().numpy(), ci, pixtocams.cpu().numpy().reshape(-1, 3, 3), camtoworlds.cpu().numpy())
+    out = {k: torch.from_numpy(v).to(pix_x.device) for k, v in r.items()}
+    if not want_imageplane:
+        out.pop("imageplane")
+    return out
+
+
+def zip_loss_tail(rgb, tgt, lossmult=None, depth=None, tdepth=None, dmask=None, cmask=None, sem=None, labels=None, smask=None, hist=None,
+                  mse=False, charb_padding=0.001, data_mult=1.0, depth_lambda=0.5, com_mult=0.2, sem_mult=0.04, pulse_width=(0.03, 0.003),
+                  interlevel_mult=0.01, distortion_mult=0.005):
+    from oracle import callers as oc
+    assert not mse
+    n = lambda t: None if t is None else t.detach().cpu().numpy()
+    R, dev = rgb.shape[0], rgb.device
+    sd = [n(h[0]) for h in hist] if hist is not None else None
+    wt = [n(h[1]) for h in hist] if hist is not None else None
+    if hist is None:   # the oracle always takes histograms: feed a dummy one with both regularisers off
+        sd, wt, interlevel_mult, distortion_mult = [np.array([[0., 1.]])] * 3, [np.array([[1.]])] * 3, 0.0, 0.0
+    sm = smask if smask is not None else (torch.ones(R) if sem is not None else None)
+    L, G = oc.zip_loss_tail(n(rgb), n(tgt), n(lossmult), n(depth), n(tdepth), n(dmask), n(cmask), n(sem), n(labels), n(sm), sd, wt,
+                            charb_padding, data_mult, depth_lambda, com_mult, sem_mult, pulse_width, interlevel_mult, distortion_mult)
+    lm = np.ones(R) if lossmult is None else n(lossmult)
+    out = torch.zeros(11)
+    out[0] = 3 * float(lm.sum())
+    out[1] = 0.0 if dmask is None else float(n(dmask).sum())
+    out[2] = 0.0 if cmask is None else float(n(cmask).sum())
+    out[3] = 0.0 if sem is None else float(n(sm).sum())
+    for i, k in enumerate(("data", "mse", "depth", "d_complete", "sem", "interlevel", "distortion")):
+        out[4 + i] = float(L.get(k, 0.0))
+    t = lambda k: torch.from_numpy(np.asarray(G[k], np.float32)).to(dev) if k in G else None
+    return out.to(dev), dict(rgb=t("rgb"), depth=t("depth"), semantic=t("semantic"), w0=t("w0"), w1=t("w1"), w2=t("w2"))
+
+
+_NAMES = ["zip_pixels_to_rays", "zip_loss_tail", "semantic_composite_fwd", "semantic_composite_bwd", "zip_resample", "zip_encode_fwd", "zip_encode_bwd", "zip_composite_fwd", "zip_composite_bwd",
           "linear_fwd", "linear_wgrad", "classic_embed", "mip_encode", "mip_viewenc", "classic_sample_pdf", "classic_points",
           "classic_merge_sort", "mip_resample", "stratified", "mip_composite_fwd", "mip_composite_bwd", "classic_composite_fwd",
           "classic_composite_bwd", "adam_step", "colsum_f32", "cast_pad", "pinhole_rays", "mip_loss_tail"]

@@ -127,3 +127,151 @@ def test_trainer_loss_tail_host_logic():
     (lr, ld, lp), (g_rgb, g_d1, g_d0, g_wc) = _oracle_tail(x, 0.2, 0.2, 0.05)
     assert abs(float(loss) - float(lr + ld + lp)) < 1e-6
     assert torch.allclose(g[0], g_d0) and g[1] is None and torch.allclose(g[2], g_wc) and torch.allclose(g[3], g_rgb) and torch.allclose(g[4], g_d1)
+
+
+# ---------------------------------------------------------------- zipnerf (path C) callers ----
+def _np(golden, name):
+    return {k: (v.numpy() if torch.is_tensor(v) else v) for k, v in golden(name).items()}
+
+
+@gpu
+def test_zip_pixels_to_rays_vs_reference_golden_and_full_frame(golden):
+    from snerf_amd import ops
+    g = _np(golden, "g15_zip_rays")
+    i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).cuda()
+    f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+    r = ops.zip_pixels_to_rays(i32(g["pix_x"]), i32(g["pix_y"]), i32(g["cam_idx"]), f32(g["pixtocams"]), f32(g["camtoworlds"]), want_imageplane=True)
+    for k in ("origins", "directions", "viewdirs", "radii", "imageplane", "base_x", "base_y"):
+        got = r[k].cpu().numpy()
+        assert got.shape == g[k].shape, (k, got.shape, g[k].shape)
+        np.testing.assert_allclose(got, g[k], rtol=2e-7, atol=1e-9, err_msg=k)     # float64 sums on both sides, one fp32 rounding
+    # the whole 1920 x 1280 frame of camera 1 (BASELINE config 5) against the oracle; cam_idx = None means camera 0
+    W, H = 1920, 1280
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.int32), np.arange(W, dtype=np.int32), indexing="ij")
+    px, py = xx.reshape(-1), yy.reshape(-1)
+    r = ops.zip_pixels_to_rays(i32(px), i32(py), None, f32(g["pixtocams"][1:]), f32(g["camtoworlds"][1:]))
+    ref = oc.zip_pixels_to_rays(px, py, np.zeros(px.size, np.int64), g["pixtocams"][1:], g["camtoworlds"][1:])
+    assert "imageplane" not in r
+    for k in ("origins", "directions", "viewdirs", "radii", "base_x", "base_y"):
+        np.testing.assert_allclose(r[k].cpu().numpy(), ref[k], rtol=2e-7, atol=1e-9, err_msg=k)
+    assert float(r["viewdirs"].norm(dim=-1).sub(1).abs().max()) < 2e-7
+
+
+def _zip_tail_inputs(g):
+    mask = g["mask_rgb"].astype(np.float32)
+    dmask = mask * (g["target_depth"] > 0)
+    return mask, dmask
+
+
+@gpu
+def test_zip_loss_tail_vs_reference_golden(golden):
+    from snerf_amd import ops
+    g = _np(golden, "g16_zip_losses")
+    c = lambda a, dt=np.float32: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).cuda()
+    mask, dmask = _zip_tail_inputs(g)
+    hist = [(c(g[f"s{i}"]), c(g[f"w{i}"])) for i in range(3)]
+    out, G = ops.zip_loss_tail(c(g["rgb"]), c(g["target_rgb"]), c(mask), depth=c(g["depth"]), tdepth=c(g["target_depth"]), dmask=c(dmask),
+                               sem=c(g["semantic"]), labels=c(g["labels"], np.int32), smask=c(mask), hist=hist,
+                               charb_padding=float(g["charb_padding"]), depth_lambda=float(g["depth_lambda"]), sem_mult=float(g["sem_mult"]),
+                               pulse_width=[float(x) for x in g["pulse_width"]], interlevel_mult=float(g["anti_interlevel_mult"]),
+                               distortion_mult=float(g["distortion_mult"]))
+    out = out.cpu().numpy().astype(np.float64)
+    L = dict(zip(ops.ZIP_LOSS_NAMES, out[4:]))
+    assert out[0] == 3 * mask.sum() and out[1] == dmask.sum() and out[2] == 0 and out[3] == mask.sum()
+    # the reference's fp32 run: elementwise terms to fp32 rounding, the two regularisers within the noise of its fp32 cumsums
+    for k, ref, tol in (("data", "loss_data", 2e-6), ("mse", "mse", 2e-6), ("depth", "loss_depth", 2e-6), ("sem", "loss_sem", 2e-6),
+                        ("interlevel", "loss_interlevel", 2e-5), ("distortion", "loss_distortion", 2e-5)):
+        assert abs(L[k] - float(g[ref])) <= tol * abs(float(g[ref])), (k, L[k], float(g[ref]))
+    assert L["d_complete"] == 0
+    for k, ref, tol in (("rgb", "g_rgb", 2e-6), ("depth", "g_depth", 2e-6), ("semantic", "g_sem", 2e-6), ("w0", "g_w0", 3e-5), ("w1", "g_w1", 3e-5),
+                        ("w2", "g_w2", 3e-5)):
+        got = G[k].cpu().numpy()
+        assert np.abs(got - g[ref]).max() <= tol * np.abs(g[ref]).max(), (k, np.abs(got - g[ref]).max(), np.abs(g[ref]).max())
+    # the reference evaluated in float64 (its knots c -/+ r are float64 there, fp32 in the kernel as in the fp32 reference)
+    assert abs(L["interlevel"] - float(g["loss_interlevel_f64"])) <= 1e-5 * L["interlevel"]
+    assert abs(L["distortion"] - float(g["loss_distortion_f64"])) <= 2e-6 * L["distortion"]
+    for k in ("w0", "w1", "w2"):
+        ref = g[f"g_{k}_f64"]
+        assert np.abs(G[k].cpu().numpy() - ref).max() <= 5e-5 * np.abs(ref).max(), k
+
+
+def _rand_hist(rng, R, S, peaky=False, lo=0.0, hi=1.0):
+    s = np.sort(rng.random((R, S + 1)), -1) * (hi - lo) + lo
+    s[:, 0], s[:, -1] = 0.0, 1.0
+    w = rng.random((R, S)) ** (6 if peaky else 2)
+    w = w / w.sum(-1, keepdims=True) * rng.random((R, 1))
+    return s.astype(np.float32), w.astype(np.float32)
+
+
+@gpu
+@pytest.mark.parametrize("R,S0,S1,S2,C", [(4099, 64, 64, 32, 19), (65, 7, 130, 3, 1), (1, 64, 64, 32, 4)])
+def test_zip_loss_tail_vs_oracle(R, S0, S1, S2, C):
+    """waymo.gin level sizes at a non-multiple-of-64 ray count, odd level sizes (a proposal level wider than the blurred NeRF
+    histogram has knots, a 3-interval NeRF level), and a single ray; masks with zeros, both depth masks, duplicated fence posts
+    in the proposal levels and exactly-zero weights."""
+    from snerf_amd import ops
+    rng = np.random.default_rng(R + S1)
+    s0, w0 = _rand_hist(rng, R, S0)
+    s1, w1 = _rand_hist(rng, R, S1)
+    s2, w2 = _rand_hist(rng, R, S2, peaky=True)
+    if S0 > 4:
+        s0[:, 3] = s0[:, 2]                       # zero-width proposal interval
+    w1[:, ::5] = 0.0
+    w2[:, 0] = 0.0
+    rgb, tgt = rng.random((R, 3), dtype=np.float32), rng.random((R, 3), dtype=np.float32)
+    lm = (rng.random(R) < 0.7).astype(np.float32)
+    lm[0] = 1.0
+    depth = (rng.random(R) * 60 + 1).astype(np.float32)
+    td = (rng.random(R) * 60 + 1).astype(np.float32)
+    dm = (lm * (rng.random(R) < 0.5)).astype(np.float32)
+    cm = ((1 - lm) * (rng.random(R) < 0.5)).astype(np.float32)
+    sem = rng.random((R, C), dtype=np.float32)
+    sem = sem / sem.sum(-1, keepdims=True) * rng.random((R, 1), dtype=np.float32)
+    lab = rng.integers(0, C, R).astype(np.int32)
+    kw = dict(charb_padding=0.001, data_mult=1.0, depth_lambda=0.5, com_mult=0.2, sem_mult=0.04, pulse_width=(0.03, 0.003), interlevel_mult=0.01,
+              distortion_mult=0.005)
+    Lr, Gr = oc.zip_loss_tail(rgb, tgt, lm, depth, td, dm, cm, sem, lab, lm, [s0, s1, s2], [w0, w1, w2], *kw.values())
+    c = lambda a: torch.from_numpy(a).cuda()
+    out, G = ops.zip_loss_tail(c(rgb), c(tgt), c(lm), depth=c(depth), tdepth=c(td), dmask=c(dm), cmask=c(cm), sem=c(sem), labels=c(lab), smask=c(lm),
+                               hist=[(c(s0), c(w0)), (c(s1), c(w1)), (c(s2), c(w2))], **kw)
+    out = out.cpu().numpy().astype(np.float64)
+    for i, k in enumerate(ops.ZIP_LOSS_NAMES):
+        ref = float(Lr.get(k, 0.0))
+        assert abs(out[4 + i] - ref) <= 1e-5 * abs(ref) + 1e-9, (k, out[4 + i], ref)
+    for k in ("rgb", "depth", "semantic", "w0", "w1", "w2"):
+        got, ref = G[k].cpu().numpy(), Gr[k]
+        assert np.isfinite(got).all(), k
+        assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max() + 1e-12, (k, np.abs(got - ref).max(), np.abs(ref).max())
+
+
+@gpu
+def test_zip_loss_tail_absent_terms_and_empty_masks():
+    from snerf_amd import ops
+    from snerf_amd._lib import SnerfHipError
+    rng = np.random.default_rng(0)
+    R = 130
+    c = lambda a: torch.from_numpy(a).cuda()
+    rgb, tgt = c(rng.random((R, 3), dtype=np.float32)), c(rng.random((R, 3), dtype=np.float32))
+    out, G = ops.zip_loss_tail(rgb, tgt, mse=True)                                   # the 'mse' data term alone
+    ref = float(((rgb - tgt) ** 2).mean())
+    assert abs(float(out[4]) - ref) < 1e-6 * ref and abs(float(out[5]) - ref) < 1e-6 * ref and float(out[6:].abs().sum()) == 0
+    assert torch.allclose(G["rgb"], 2 * (rgb - tgt) / (3 * R), rtol=1e-5, atol=1e-9)
+    assert all(G[k] is None for k in ("depth", "semantic", "w0", "w1", "w2"))
+    # empty masks: the terms are 0 (the reference's mean over an empty selection is NaN) and so are their gradients
+    z = torch.zeros(R, device="cuda")
+    depth, td = c((rng.random(R) + 1).astype(np.float32)), c((rng.random(R) + 1).astype(np.float32))
+    sem, lab = c(rng.random((R, 5), dtype=np.float32)), c(rng.integers(0, 5, R).astype(np.int32))
+    out, G = ops.zip_loss_tail(rgb, tgt, depth=depth, tdepth=td, dmask=z, cmask=z, sem=sem, labels=lab, smask=z)
+    assert float(out[6]) == 0 and float(out[7]) == 0 and float(out[8]) == 0
+    assert float(G["depth"].abs().max()) == 0 and float(G["semantic"].abs().max()) == 0
+    # only one proposal level, distortion off
+    s0, w0 = _rand_hist(rng, R, 16)
+    s2, w2 = _rand_hist(rng, R, 8)
+    out, G = ops.zip_loss_tail(rgb, tgt, hist=[(c(s0), c(w0)), (None, None), (c(s2), c(w2))], distortion_mult=0.0)
+    Lr, Gr = oc.zip_loss_tail(rgb.cpu().numpy(), tgt.cpu().numpy(), None, None, None, None, None, None, None, None, [s0, s2], [w0, w2],
+                              pulse_width=(0.03,), distortion_mult=0.0)
+    assert abs(float(out[9]) - Lr["interlevel"]) <= 1e-5 * Lr["interlevel"] and float(out[10]) == 0
+    assert G["w1"] is None and G["w2"] is None
+    assert np.abs(G["w0"].cpu().numpy() - Gr["w0"]).max() <= 1e-5 * np.abs(Gr["w0"]).max()
+    with pytest.raises(SnerfHipError):
+        ops.zip_loss_tail(rgb, tgt, hist=[(c(s0), c(w0)), (None, None), (c(s2), c(w2))], pulse_width=(0.0, 0.003))

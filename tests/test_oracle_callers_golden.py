@@ -61,8 +61,9 @@ def test_zip_blur_and_quadratic_cdf_stages(golden):
     c, w = g["s2"].astype(np.float64), g["w2"].astype(np.float64)
     wn = w / (c[:, 1:] - c[:, :-1])
     for i, r in enumerate(g["pulse_width"]):
-        xr, yr = oc.blur_stepfun(c, wn, float(r))
-        np.testing.assert_allclose(xr, g[f"blur_x{i}"], rtol=1e-6, atol=1e-7)
+        xr32, _ = oc.blur_stepfun(g["s2"], wn, float(r))
+        assert np.array_equal(xr32.astype(np.float32), g[f"blur_x{i}"])           # fp32 inputs: the reference's fp32 knots, bit for bit
+        xr, yr = oc.blur_stepfun(c, wn, float(r))                                  # float64 inputs: the float64 evaluation
         scale = np.abs(g[f"blur_y{i}"]).max(-1, keepdims=True)
         np.testing.assert_allclose(yr, g[f"blur_y{i}_f64"], rtol=1e-9, atol=1e-9 * scale.max())   # the reference run in float64
         assert np.all(np.abs(yr - g[f"blur_y{i}"]) <= 5e-4 * scale)      # its fp32 cumsum of +/- steps: ~1e-4 of the row maximum
@@ -77,10 +78,10 @@ def test_zip_loss_tail_values_and_gradients(golden):
     g = _np(golden, "g16_zip_losses")
     mask = g["mask_rgb"].astype(np.float64)
     dmask = mask * (g["target_depth"] > 0)
+    args = (float(g["charb_padding"]), 1.0, float(g["depth_lambda"]), 0.2, float(g["sem_mult"]), [float(x) for x in g["pulse_width"]],
+            float(g["anti_interlevel_mult"]), float(g["distortion_mult"]))
     L, G = oc.zip_loss_tail(g["rgb"], g["target_rgb"], mask, g["depth"], g["target_depth"], dmask, None, g["semantic"], g["labels"], mask,
-                            [g["s0"], g["s1"], g["s2"]], [g["w0"], g["w1"], g["w2"]], float(g["charb_padding"]), 1.0, float(g["depth_lambda"]),
-                            0.2, float(g["sem_mult"]), [float(x) for x in g["pulse_width"]], float(g["anti_interlevel_mult"]),
-                            float(g["distortion_mult"]))
+                            [g["s0"], g["s1"], g["s2"]], [g["w0"], g["w1"], g["w2"]], *args)
     for k, ref in (("data", "loss_data"), ("mse", "mse"), ("depth", "loss_depth"), ("sem", "loss_sem"), ("interlevel", "loss_interlevel"),
                    ("distortion", "loss_distortion")):
         assert abs(L[k] - float(g[ref])) <= 2e-5 * abs(float(g[ref])) + 1e-9, (k, L[k], float(g[ref]))
@@ -89,7 +90,10 @@ def test_zip_loss_tail_values_and_gradients(golden):
         tol = 3e-5 * np.abs(g[ref]).max()
         assert np.abs(G[k] - g[ref]).max() <= tol, (k, np.abs(G[k] - g[ref]).max(), tol)
     assert float(np.abs(g["g_w0"]).max()) > 0 and float(np.abs(g["g_w1"]).max()) > 0
-    # against the reference evaluated in float64: the algorithm itself, to rounding
+    # against the reference evaluated in float64 (float64 inputs -> float64 knots on both sides): the algorithm itself, to rounding
+    d = lambda k: g[k].astype(np.float64)
+    L, G = oc.zip_loss_tail(g["rgb"], g["target_rgb"], mask, None, None, None, None, None, None, None, [d("s0"), d("s1"), d("s2")],
+                            [d("w0"), d("w1"), d("w2")], *args)
     assert abs(L["interlevel"] - float(g["loss_interlevel_f64"])) <= 1e-10 * abs(L["interlevel"])
     assert abs(L["distortion"] - float(g["loss_distortion_f64"])) <= 1e-10 * abs(L["distortion"])
     for k in ("w0", "w1", "w2"):

@@ -226,3 +226,43 @@ def test_zip_table_gradient_bf16_pairs_match_fp32():
     cos = float((a * b).sum() / (a.norm() * b.norm()))
     assert cos > 0.9995, cos
     assert float((a - b).norm() / a.norm()) < 3e-2
+
+
+def test_zip_trainer_fused_loss_tail(backend):
+    """ZipTrainer.step: the loss terms it reports are the oracle's loss tail (s-nerfpp/zipnerf/train.py:250-311) evaluated on the
+    renderer outputs of that step, the step changes the parameters, and repeated steps on a fixed batch reduce the loss."""
+    from oracle import callers as ocl
+    from snerf_amd import ops
+    from snerf_amd.trainer import ZipTrainer
+    specs, p = zip_setup()
+    R = 24
+    g = torch.Generator().manual_seed(9)
+    d = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1)
+    bx = torch.nn.functional.normalize(torch.cross(d, torch.randn(R, 3, generator=g), dim=-1), dim=-1)
+    batch = dict(origins=torch.randn(R, 3, generator=g) * 0.1, directions=d, viewdirs=d, radii=2e-3 + 2e-3 * torch.rand(R, 1, generator=g),
+                 near=torch.full((R, 1), 0.1), far=torch.full((R, 1), 10.0), base_x=bx, base_y=torch.nn.functional.normalize(torch.cross(d, bx, dim=-1), dim=-1))
+    batch = {k: v.to(DEV) for k, v in batch.items()}
+    target = torch.rand(R, 3, generator=g).to(DEV)
+    lm = (torch.rand(R, generator=g) < 0.8).float()
+    td = torch.rand(R, generator=g) * 5 + 0.5
+    tg = dict(lossmult=lm.to(DEV), depth=td.to(DEV), depth_mask=(lm * (torch.rand(R, generator=g) < 0.6)).to(DEV),
+              complete_mask=((1 - lm) * 1.0).to(DEV), semantic=torch.randint(0, 19, (R,), generator=g).int().to(DEV), semantic_mask=lm.to(DEV))
+    m = make_model("f32", "f32", p, use_semantic=True)
+    tr = ZipTrainer(m, lr=2e-3, eps=1e-8)
+    start = m.arena.flat.clone()
+    draws = m._draws(R, False, m.arena.flat.device, 7)
+    loss0, levels = tr.step(batch, target, rand=False, draws=draws, targets=tg)
+    n = lambda t: t.detach().cpu().numpy()
+    fin = levels[2]
+    Lr, _ = ocl.zip_loss_tail(n(fin["rgb"]), n(target), n(tg["lossmult"]), n(fin["depth"]), n(tg["depth"]), n(tg["depth_mask"]), n(tg["complete_mask"]),
+                              n(fin["semantic"]), n(tg["semantic"]), n(tg["semantic_mask"]), [n(levels[l]["sdist"]) for l in range(3)],
+                              [n(levels[l]["weights"]) for l in range(3)])
+    got = dict(zip(ops.ZIP_LOSS_NAMES, tr.last_losses.cpu().tolist()))
+    for k in ops.ZIP_LOSS_NAMES:
+        assert abs(got[k] - Lr[k]) <= 2e-5 * abs(Lr[k]) + 1e-9, (k, got[k], Lr[k])
+    assert abs(float(loss0) - Lr["total"]) <= 2e-5 * Lr["total"]
+    assert all(Lr[k] > 0 for k in ("data", "depth", "d_complete", "sem", "interlevel", "distortion"))
+    assert float((m.arena.flat - start).abs().max()) > 1e-4
+    for _ in range(14):
+        loss, _ = tr.step(batch, target, rand=False, draws=draws, targets=tg)
+    assert float(loss) < 0.9 * float(loss0), (float(loss0), float(loss))

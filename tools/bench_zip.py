@@ -43,20 +43,20 @@ def main():
     R = args.rays
     g = torch.Generator().manual_seed(1 + rank)
     # Waymo-like pinhole rays (1920x1280, focal 2050), scene rescaled so that near = 0.1, far = 10 (configs/waymo.gin)
-    pix = torch.randint(0, 1920 * 1280, (R,), generator=g)
-    i, j = (pix % 1920).float(), (pix // 1920).float()
-    d = torch.stack([(i - 960 + 0.5) / 2050, -(j - 640 + 0.5) / 2050, -torch.ones(R)], -1)
-    vd = torch.nn.functional.normalize(d, dim=-1)
-    up = torch.tensor([0.0, 1.0, 0.0]).expand(R, 3)
-    bx = torch.nn.functional.normalize(torch.cross(vd, up, dim=-1), dim=-1)
-    by = torch.nn.functional.normalize(torch.cross(vd, bx, dim=-1), dim=-1)
     dev = torch.device("cuda", local)
-    batch = {k: v.to(dev) for k, v in dict(origins=torch.randn(R, 3, generator=g) * 0.05, directions=d, viewdirs=vd, radii=torch.full((R, 1), 2.0 / 2050 / 12 ** 0.5),
-                                           near=torch.full((R, 1), 0.1), far=torch.full((R, 1), 10.0), base_x=bx, base_y=by).items()}
+    pix = torch.randint(0, 1920 * 1280, (R,), generator=g)
+    K = torch.tensor([[2050.0, 0.0, 960.0], [0.0, 2050.0, 640.0], [0.0, 0.0, 1.0]])
+    c2w = torch.eye(4)[:3].clone()
+    c2w[:, 3] = torch.tensor([0.02, -0.01, 0.03])
+    rays = ops.zip_pixels_to_rays((pix % 1920).int().to(dev), (pix // 1920).int().to(dev), None, torch.linalg.inv(K)[None].to(dev), c2w[None].to(dev))
+    batch = dict(rays, near=torch.full((R, 1), 0.1, device=dev), far=torch.full((R, 1), 10.0, device=dev))
+    batch["origins"] = batch["origins"] + (torch.randn(R, 3, generator=g) * 0.05).to(dev)
     tgt = torch.rand(R, 3, generator=g).to(dev)
     a = m.arena
-    # proposal supervision stand-in with the cost profile of the interlevel loss: a gradient on every level's weights
-    aux = lambda hist: sum((h["weights"] * h["weights"].detach()).sum() for h in hist) * (0.5e-3 / R)
+    # LiDAR-like depth targets on half of the rays; the proposal levels are supervised by the fused tail's
+    # anti-interlevel term, the NeRF level also by the distortion term (reference defaults)
+    tdepth = (torch.rand(R, generator=g) * 4 + 0.2).to(dev)
+    targets = dict(depth=tdepth, depth_mask=(torch.rand(R, generator=g) < 0.5).float().to(dev))
 
     def barrier():
         if world > 1:
@@ -64,7 +64,7 @@ def main():
         torch.cuda.synchronize()
 
     def train_step(t):
-        tr.step(batch, tgt, train_frac=0.5, rand=True, aux_loss_fn=aux)
+        tr.step(batch, tgt, train_frac=0.5, rand=True, targets=targets)
 
     def fwd_only():
         with torch.no_grad():
@@ -95,6 +95,19 @@ def main():
     fwd_only(); torch.cuda.synchronize()
     ops.zip_encode_fwd = orig
     enc_ms = [e0.elapsed_time(e1) for e0, e1 in rec]
+    # the fused loss tail (data + depth + anti-interlevel + distortion, values and gradients)
+    tail = []
+    orig_tail = ops.zip_loss_tail
+
+    def timed_tail(*x, **k):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); r = orig_tail(*x, **k); e1.record(); tail.append((e0, e1))
+        return r
+    ops.zip_loss_tail = timed_tail
+    train_step(0); train_step(1); torch.cuda.synchronize()
+    ops.zip_loss_tail = orig_tail
+    tail_ms = min(e0.elapsed_time(e1) for e0, e1 in tail)
+    losses = dict(zip(ops.ZIP_LOSS_NAMES, [round(v, 6) for v in tr.last_losses.cpu().tolist()]))
     tb = 2 if args.table == "f16" else 4
     bytes_lvl = [R * 7 * 64 * 6 * 8 * 1 * tb, R * 7 * 64 * 8 * 8 * 1 * tb, R * 7 * 32 * 10 * 8 * 4 * tb]
     out = {"path": "C (zipnerf Model, waymo.gin shape: 64+64+32 intervals x 7 multisamples, grids L=6/8/10)", "n_gpus": world, "rays_per_gpu": R,
@@ -105,7 +118,7 @@ def main():
            "roofline": {"bound": "hbm", "kernel": "zip_encode_kernel (nerf level)", "achieved": round(bytes_lvl[2] / (enc_ms[2] * 1e-3) / 1e9, 1),
                         "peak": 8000.0, "unit": "GB/s", "frac": round(bytes_lvl[2] / (enc_ms[2] * 1e-3) / 1e9 / 8000.0, 4),
                         "note": "algorithmic (useful) gather bytes; table is Infinity-Cache resident when it fits 256 MB"},
-           "params": int(a.numel)}
+           "loss_tail_ms": round(tail_ms, 4), "losses_last_step": losses, "params": int(a.numel)}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
