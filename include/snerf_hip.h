@@ -260,6 +260,12 @@ int snerf_zip_loss_tail(const float* rgb, const float* tgt, const float* lossmul
                         float sem_mult, float pw0, float pw1, float inter_mult, float dist_mult, float* out, float* g_rgb,
                         float* g_depth, float* g_sem, float* g_w0, float* g_w1, float* g_w2, void* stream);
 
+/* Distance percentiles of compute_extras (internal/render.py:255-267 -> stepfun.weighted_percentile :329-339, math.sorted_interp
+ * :88-107): tdist [R,S+1], weights [R,S], t_far [R] (the extra fence post that carries the background weight); ps_host: HOST array of
+ * np <= 8 percentiles in % (the reference uses 5, 50, 95); out [R,np]. */
+int snerf_zip_percentiles(const float* tdist, const float* weights, const float* t_far, long R, int S, const float* ps_host, int np,
+                          float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

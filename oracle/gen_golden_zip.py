@@ -181,6 +181,12 @@ def main():
         d[f"jitter{lvl}"] = jit[lvl]; d[f"deg_jitter{lvl}"] = degj[lvl]
     d.update(det_rgb=rend[-1]["rgb"], det_depth=rend[-1]["depth"], rand_rgb=rend_r[-1]["rgb"], rand_depth=rend_r[-1]["depth"],
              det_depth0=rend[0]["depth"], rand_train_frac=np.float32(0.37))
+    # compute_extras=True (the rendering scripts' mode, random_render_waymo_seq.py:197): acc, distance statistics, visualisation rays
+    with torch.no_grad():
+        rend_x, _ = model(None, dict(batch), train_frac=1.0, compute_extras=True)
+    for lvl in range(3):
+        for k in ("acc", "distance_mean", "distance_percentile_5", "distance_median", "distance_percentile_95", "ray_sdist", "ray_weights", "ray_rgbs"):
+            d[f"x{lvl}_{k}"] = rend_x[lvl][k]
     # the same model with the semantic head enabled (Config.use_semantic / NerfMLP.use_semantic: models.py:297-305, 594-597)
     cfg.use_semantic = True
     model.config = cfg

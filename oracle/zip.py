@@ -208,9 +208,20 @@ def compute_alpha_weights(density, tdist, dirs, opaque_background=True):
     return alpha * trans
 
 
-def volumetric_rendering(rgbs, weights, tdist, bg_rgbs=1.0, semantic=None):
-    """render.py:192-233 (compute_extras=False): rgb = sum w c + max(0, 1 - acc) bg; depth = clip(exp(sum w log t_mid / acc));
-    semantic = sum detach(w) semantic (:237-241: "no influences to density")."""
+def weighted_percentile(t, w, ps):
+    """stepfun.py:329-339: percentiles `ps` (in %) of the step function (t, w), w summing to 1: interpolate t at ps/100 in the
+    integrated weights [0, min(1, cumsum(w[:-1])), 1] (:106-126)."""
+    cw = torch.cumsum(w[..., :-1], dim=-1).clamp_max(1)
+    cw0 = torch.cat([torch.zeros_like(cw[..., :1]), cw, torch.ones_like(cw[..., :1])], dim=-1)
+    x = (torch.tensor(ps, dtype=t.dtype) / 100).expand(t.shape[0], len(ps))
+    return sorted_interp(x, cw0, t)[0]
+
+
+def volumetric_rendering(rgbs, weights, tdist, bg_rgbs=1.0, semantic=None, compute_extras=False, t_far=None):
+    """render.py:192-269: rgb = sum w c + max(0, 1 - acc) bg; depth = clip(exp(sum w log t_mid / acc));
+    semantic = sum detach(w) semantic (:237-241: "no influences to density").  compute_extras (:243-267): acc, distance_mean (the same
+    log-space expectation) and the 5 / 50 / 95 % distance percentiles of the histogram extended by a far-plane fence post that
+    carries the background weight."""
     acc = weights.sum(dim=-1)
     bg_w = (1 - acc[..., None]).clamp_min(0.)
     rgb = (weights[..., None] * rgbs).sum(dim=-2) + bg_w * bg_rgbs
@@ -220,16 +231,22 @@ def volumetric_rendering(rgbs, weights, tdist, bg_rgbs=1.0, semantic=None):
     out = dict(rgb=rgb, depth=depth, acc=acc)
     if semantic is not None:
         out["semantic"] = (weights.detach()[..., None] * semantic).sum(dim=-2)
+    if compute_extras:
+        out["distance_mean"] = depth
+        pct = weighted_percentile(torch.cat([tdist, t_far], dim=-1), torch.cat([weights, bg_w], dim=-1), [5, 50, 95])
+        out["distance_percentile_5"], out["distance_median"], out["distance_percentile_95"] = pct[..., 0], pct[..., 1], pct[..., 2]
     return out
 
 
 # ------------------------------------------------------------------ C11 ---
 def model_forward(p, specs, batch, num_prop_samples=(64, 64), num_nerf_samples=32, train_frac=1.0, anneal_slope=10.0,
                   dilation_multiplier=0.5, dilation_bias=0.0025, power_lambda=-1.5, std_scale=0.35, jitters=None,
-                  deg_jitters=None, bg=1.0, use_semantic=False):
+                  deg_jitters=None, bg=1.0, use_semantic=False, compute_extras=False, vis_num_rays=16):
     """Model.forward (models.py:98-349) with rand=None (jitters None) or explicit draws; `use_semantic`: the final level also
     renders the 19-class semantic distribution (models.py:297-305).  `specs` = [prop0, prop1, nerf]
     GridSpec; parameter names follow the reference's state_dict (`prop_mlp_0.encoder.embeddings`, `nerf_mlp.rgb_layer.weight`...).
+    `compute_extras`: acc / distance_* per level and the first `vis_num_rays` rays' ray_sdist / ray_weights / ray_rgbs, the proposal
+    levels' ray_rgbs replaced by the final level's average colour (models.py:316-346).
     Returns (renderings, ray_history) with the reference's keys (rgb, depth / sdist, weights, tdist)."""
     near, far = batch["near"], batch["far"]
     sdist = torch.cat([torch.zeros_like(near), torch.ones_like(far)], dim=-1)
@@ -256,8 +273,15 @@ def model_forward(p, specs, batch, num_prop_samples=(64, 64), num_nerf_samples=3
         prefix = f"prop_mlp_{lvl}." if is_prop else "nerf_mlp."
         res = mlp_forward(p, prefix, specs[lvl], means, stds, batch["viewdirs"], disable_rgb=is_prop, use_semantic=use_semantic and not is_prop)
         weights = compute_alpha_weights(res["density"], tdist, batch["directions"], True)
-        renderings.append(volumetric_rendering(res["rgb"], weights, tdist, bg, semantic=res["semantic"]))
+        renderings.append(volumetric_rendering(res["rgb"], weights, tdist, bg, semantic=res["semantic"], compute_extras=compute_extras, t_far=far))
+        if compute_extras:
+            n = vis_num_rays
+            renderings[-1].update(ray_sdist=sdist[:n], ray_weights=weights[:n], ray_rgbs=res["rgb"][:n])
         history.append(dict(sdist=sdist.clone(), weights=weights.clone(), tdist=tdist.clone(), density=res["density"], rgb=res["rgb"]))
+    if compute_extras:
+        final = torch.sum(renderings[-1]["ray_rgbs"] * renderings[-1]["ray_weights"][..., None], dim=-2)
+        for r in renderings[:-1]:
+            r["ray_rgbs"] = torch.broadcast_to(final[:, None, :], r["ray_sdist"].shape[:1] + (r["ray_weights"].shape[1], 3))
     return renderings, history
 
 

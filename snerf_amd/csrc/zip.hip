@@ -689,3 +689,55 @@ extern "C" int snerf_semantic_composite_bwd(const float* weights, const void* lo
   else return SNERF_ERR_ARG;
   return snerf_check_launch();
 }
+
+// ---------------------------------------------------------------------------
+// Distance percentiles of compute_extras (render.py:255-267 -> stepfun.weighted_percentile :329-339): the histogram is extended by
+// a fence post at t_far carrying the background weight, integrated to cw0 = [0, min(1, cumsum(w)), 1] (:106-126, the background
+// weight itself never enters the cumsum) and t is interpolated at ps/100 (math.sorted_interp :88-107).  One lane per ray, one walk
+// over the samples for all percentiles; prefix sums in the canonical order (float64, rounded once per emitted value).
+// ---------------------------------------------------------------------------
+#define ZIP_MAX_PCT 8
+struct ZipPct { const float *tdist, *weights, *t_far; long R; int S, np; float x[ZIP_MAX_PCT]; float* out; };
+
+__global__ __launch_bounds__(256) void zip_percentile_kernel(ZipPct a) {
+  const long r = (long)blockIdx.x * 256 + threadIdx.x;
+  if (r >= a.R) return;
+  const float* t = a.tdist + r * (a.S + 1);
+  const float* w = a.weights + r * a.S;
+  float x0[ZIP_MAX_PCT], f0[ZIP_MAX_PCT], res[ZIP_MAX_PCT];
+  unsigned done = 0;
+#pragma unroll
+  for (int j = 0; j < ZIP_MAX_PCT; ++j) { x0[j] = 0.f; f0[j] = t[0]; res[j] = 0.f; }
+  double cum = 0.0;
+  for (int k = 1; k <= a.S + 1; ++k) {
+    float cw, tk;
+    if (k <= a.S) { cum += (double)w[k - 1]; cw = fminf((float)cum, 1.f); tk = t[k]; }
+    else { cw = 1.f; tk = a.t_far[r]; }
+#pragma unroll
+    for (int j = 0; j < ZIP_MAX_PCT; ++j) {
+      if (j >= a.np || (done >> j) & 1u) continue;
+      const float x = a.x[j];
+      if (x >= cw) { x0[j] = cw; f0[j] = tk; }
+      else {
+        float off = (x - x0[j]) / (cw - x0[j]);
+        off = off != off ? 0.f : fminf(fmaxf(off, 0.f), 1.f);
+        res[j] = f0[j] + off * (tk - f0[j]);
+        done |= 1u << j;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < ZIP_MAX_PCT; ++j)
+    if (j < a.np) a.out[r * a.np + j] = (done >> j) & 1u ? res[j] : f0[j];
+}
+
+extern "C" int snerf_zip_percentiles(const float* tdist, const float* weights, const float* t_far, long R, int S, const float* ps_host, int np,
+                                     float* out, void* stream) {
+  if (R <= 0) return SNERF_OK;
+  if (tdist == nullptr || weights == nullptr || t_far == nullptr || ps_host == nullptr || out == nullptr || S < 1 || np < 1 || np > ZIP_MAX_PCT)
+    return SNERF_ERR_ARG;
+  ZipPct a{tdist, weights, t_far, R, S, np, {}, out};
+  for (int j = 0; j < np; ++j) a.x[j] = ps_host[j] / 100.f;
+  hipLaunchKernelGGL(zip_percentile_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  return snerf_check_launch();
+}

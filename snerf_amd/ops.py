@@ -499,6 +499,19 @@ def zip_loss_tail(rgb, tgt, lossmult=None, depth=None, tdepth=None, dmask=None, 
     return out, dict(rgb=g_rgb, depth=g_depth, semantic=g_sem, w0=gw[0], w1=gw[1], w2=gw[2])
 
 
+def zip_percentiles(tdist, weights, t_far, ps=(5, 50, 95)):
+    """weighted percentiles (in %) of the ray histograms extended to t_far -> [R, len(ps)] (render.py:255-267)."""
+    import numpy as np
+    R, S = weights.shape
+    _f32c(tdist); _f32c(weights)
+    tf = _f32c(t_far.reshape(-1).contiguous())
+    assert tdist.shape == (R, S + 1) and tf.shape[0] == R
+    p = np.ascontiguousarray(np.asarray(ps, dtype=np.float32))
+    out = torch.empty(R, len(ps), dtype=torch.float32, device=weights.device)
+    _lib.call("snerf_zip_percentiles", _p(tdist), _p(weights), _p(tf), R, S, p.ctypes.data, len(ps), _p(out), _stream())
+    return out
+
+
 def semantic_composite_fwd(weights, logits, C, softmax):
     """semantic [R,C] = sum_i w[r,i] f(logits[r*S+i, :C]), f = softmax (zipnerf) or identity (live mip path); logits: 2-D view."""
     R, S = weights.shape

@@ -268,13 +268,13 @@ class Model(_ArenaModule):
         """-> (renderings, ray_history) like models.py:98-349.  `draws` = [(u, deg_jitter)] * 3 overrides the RNG (parity tests)."""
         if cal_input_grad:
             raise NotImplementedError("pose refinement through the hash grid (cal_input_grad) is not on the accelerated path")
-        if compute_extras:
-            raise NotImplementedError("compute_extras (distance percentiles, visualisation rays) is not on the accelerated path")
         self._check_arena()
         dev = self.arena.flat.device
         R = batch['origins'].shape[0]
         if draws is None:
             draws = self._draws(R, rand, dev, sample_n)
+        if compute_extras:
+            return self._forward_extras(batch, float(train_frac), draws, sample_n, sample_m)
         params = self.param_list()
         keep = torch.is_grad_enabled() and any(p.requires_grad for p in params)
         outs = _ZipFn.apply(self, batch, keep, float(train_frac), draws, sample_n, sample_m, *params)
@@ -286,6 +286,116 @@ class Model(_ArenaModule):
         if self.use_semantic:
             renderings[-1]["semantic"] = outs[18]
         return renderings, history
+
+
+def _extras(self, batch, train_frac, draws, sample_n, sample_m):
+    """compute_extras=True, the rendering scripts' mode (random_render_waymo_seq.py:197; render.py:243-267, models.py:316-346):
+    besides rgb / depth / acc every level carries distance_mean (the log-space expectation = depth), the 5 / 50 / 95 % distance
+    percentiles, and the first `vis_num_rays` rays' histograms (ray_sdist, ray_weights, ray_rgbs; the proposal levels get the final
+    level's average colour).  Inference only: nothing is saved for backward."""
+    if torch.is_grad_enabled() and any(p.requires_grad for p in self.param_list()):
+        raise NotImplementedError("compute_extras is the inference / rendering mode: call it under torch.no_grad()")
+    n = int(getattr(self.config, "vis_num_rays", 16)) if self.config is not None else 16
+    levels, _ = self._run(batch, False, train_frac, draws, sample_n, sample_m)
+    t_far = batch['far'].detach().to(levels[0]["tdist"].device, torch.float32).reshape(-1).contiguous()
+    renderings, history = [], []
+    for L in levels:
+        pct = ops.zip_percentiles(L["tdist"], L["weights"], t_far)
+        r = dict(rgb=L["rgb"], depth=L["depth"], acc=L["acc"], distance_mean=L["depth"], distance_percentile_5=pct[:, 0],
+                 distance_median=pct[:, 1], distance_percentile_95=pct[:, 2], ray_sdist=L["sdist"][:n], ray_weights=L["weights"][:n])
+        if L["semantic"] is not None:
+            r["semantic"] = L["semantic"]
+        renderings.append(r)
+        history.append(dict(sdist=L["sdist"], weights=L["weights"], tdist=L["tdist"]))
+    fin = levels[2]
+    S = fin["weights"].shape[1]
+    pad = 0.001                                                                     # rgb_padding, models.py:372
+    rgbs = torch.sigmoid(fin["raw_rgb"][:min(n, fin["weights"].shape[0]) * S].float().reshape(-1, S, 3)) * (1 + 2 * pad) - pad
+    renderings[2]["ray_rgbs"] = rgbs
+    final = (rgbs * renderings[2]["ray_weights"][..., None]).sum(-2)
+    for r in renderings[:2]:
+        r["ray_rgbs"] = final[:, None, :].expand(-1, r["ray_weights"].shape[1], -1)
+    return renderings, history
+
+
+Model._forward_extras = _extras
+
+
+def _dist_info(accelerator):
+    """(rank, world, gather) from an accelerate.Accelerator-like object or, when None, from torch.distributed."""
+    import torch.distributed as dist
+    if accelerator is not None:
+        return accelerator.local_process_index, accelerator.num_processes, None
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size(), None
+    return 0, 1, None
+
+
+@torch.no_grad()
+def render_image(render_fn, accelerator, batch, rand, config):
+    """models.py:727-813: render all the pixels of an image (test mode).  `batch` = dict of [H,W,.] ray fields, `render_fn(rand, chunk)
+    -> (renderings, ray_history)`, `config.render_chunk_size` rays per call; returns the final level's 2-D buffers reshaped to
+    [H,W,...] plus, for `ray_*` keys, one tensor per level subsampled to `config.vis_num_rays` rays.
+
+    Sharding: every rank renders ONE contiguous block of ceil(H*W / world) rays in its own chunks, and the frame is
+    assembled with ONE all-gather per output buffer -- instead of the reference's split of every chunk across the processes with a
+    gather per chunk (:761-770).  Rays are independent, so the assembled frame is the same.  `accelerator` may be an
+    accelerate.Accelerator (only its process index / count are read) or None (torch.distributed if initialised, else one process)."""
+    import torch.distributed as dist
+    height, width = batch['origins'].shape[:2]
+    num_rays = height * width
+    flat = {k: v.reshape((num_rays, -1)) for k, v in batch.items() if v is not None}
+    rank, world, _ = _dist_info(accelerator)
+    per = (num_rays + world - 1) // world
+    lo, hi = min(rank * per, num_rays), min((rank + 1) * per, num_rays)
+    chunk = int(config.render_chunk_size)
+    chunks = []
+    for i0 in range(lo, hi, chunk):
+        cb = {k: v[i0:min(i0 + chunk, hi)] for k, v in flat.items()}
+        rend, _ = render_fn(rand, cb)
+        cr = dict(rend[-1])
+        for k in rend[0]:
+            if k.startswith('ray_'):
+                cr[k] = [r[k] for r in rend]
+        chunks.append(cr)
+    keys = list(chunks[0].keys()) if chunks else []
+    if world > 1:      # a rank whose block is empty (more ranks than rays) still has to know the keys
+        obj = [keys if rank == 0 else None]
+        dist.broadcast_object_list(obj, src=0)
+        keys = obj[0]
+    rendering = {}
+    for k in keys:
+        if isinstance(chunks[0][k], list):
+            rendering[k] = [torch.cat([c[k][i] for c in chunks]) for i in range(len(chunks[0][k]))]
+        else:
+            rendering[k] = torch.cat([c[k] for c in chunks])
+    if world > 1:
+        def gather(z, rows):
+            pad = torch.zeros((rows,) + tuple(z.shape[1:]), dtype=z.dtype, device=z.device)
+            pad[:z.shape[0]] = z
+            out = [torch.empty_like(pad) for _ in range(world)]
+            dist.all_gather(out, pad)
+            return out
+        for k in keys:
+            if isinstance(rendering[k], list):
+                nloc = torch.tensor([rendering[k][0].shape[0]], device=rendering[k][0].device)
+                ns = [torch.zeros_like(nloc) for _ in range(world)]
+                dist.all_gather(ns, nloc)
+                mx = int(max(int(x) for x in ns))
+                rendering[k] = [torch.cat([g[:int(c)] for g, c in zip(gather(z, mx), ns)]) for z in rendering[k]]
+            else:
+                parts = gather(rendering[k], per)
+                rendering[k] = torch.cat([parts[r][:max(0, min((r + 1) * per, num_rays) - r * per)] for r in range(world)])
+    for k, z in rendering.items():
+        if not k.startswith('ray_'):
+            rendering[k] = z.reshape((height, width) + tuple(z.shape[1:]))
+    rkeys = [k for k in rendering if k.startswith('ray_')]
+    if rkeys:
+        nr = rendering[rkeys[0]][0].shape[0]
+        idx = torch.randperm(nr)[:int(getattr(config, "vis_num_rays", 16))].to(rendering[rkeys[0]][0].device)
+        for k in rkeys:
+            rendering[k] = [r[idx] for r in rendering[k]]
+    return rendering
 
 
 class _ZipFn(torch.autograd.Function):

@@ -326,7 +326,13 @@ def zip_loss_tail(rgb, tgt, lossmult=None, depth=None, tdepth=None, dmask=None, 
     return out.to(dev), dict(rgb=t("rgb"), depth=t("depth"), semantic=t("semantic"), w0=t("w0"), w1=t("w1"), w2=t("w2"))
 
 
-_NAMES = ["zip_pixels_to_rays", "zip_loss_tail", "semantic_composite_fwd", "semantic_composite_bwd", "zip_resample", "zip_encode_fwd", "zip_encode_bwd", "zip_composite_fwd", "zip_composite_bwd",
+def zip_percentiles(tdist, weights, t_far, ps=(5, 50, 95)):
+    from oracle import zip as oz
+    bg = (1 - weights.sum(-1, keepdim=True)).clamp_min(0.)
+    return oz.weighted_percentile(torch.cat([tdist, t_far.reshape(-1, 1)], -1), torch.cat([weights, bg], -1), list(ps))
+
+
+_NAMES = ["zip_percentiles", "zip_pixels_to_rays", "zip_loss_tail", "semantic_composite_fwd", "semantic_composite_bwd", "zip_resample", "zip_encode_fwd", "zip_encode_bwd", "zip_composite_fwd", "zip_composite_bwd",
           "linear_fwd", "linear_wgrad", "classic_embed", "mip_encode", "mip_viewenc", "classic_sample_pdf", "classic_points",
           "classic_merge_sort", "mip_resample", "stratified", "mip_composite_fwd", "mip_composite_bwd", "classic_composite_fwd",
           "classic_composite_bwd", "adam_step", "colsum_f32", "cast_pad", "pinhole_rays", "mip_loss_tail"]

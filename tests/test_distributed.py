@@ -147,3 +147,47 @@ def test_zip_ray_sharded_data_parallel_matches_single_process():
     err = (gathered[0] - model.arena.flat).abs().max().item()
     assert err < 5e-5, f"data-parallel parameters differ from the single-process run by {err:.3e}"
     assert (model.arena.flat - start).abs().max().item() > 1e-3
+
+
+def _zip_render_worker(rank, world, init_file, H, W, out_file):
+    import types
+    from cpu_ops_emulation import emulate_ops
+    from snerf_amd import zipnerf
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    with emulate_ops():
+        model = _zip_build()
+        batch, _ = _zip_data(H * W)
+        frame = {k: v.reshape(H, W, -1) for k, v in batch.items()}
+        cfg = types.SimpleNamespace(render_chunk_size=4, vis_num_rays=2)
+        model.config = cfg
+        out = zipnerf.render_image(lambda rand, b: model(rand, b, train_frac=1.0, compute_extras=True), None, frame, False, cfg)
+        if rank == 0:
+            torch.save({k: v for k, v in out.items()}, out_file)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_zip_render_image_row_blocks_across_ranks_match_single_process():
+    """render_image on 2 ranks (contiguous ray blocks, one all-gather per buffer; 15 rays -> blocks of 8 and 7, ragged chunks of 4)
+    assembles the same frame as one process."""
+    import types
+    from cpu_ops_emulation import emulate_ops
+    from snerf_amd import zipnerf
+    H, W, world = 3, 5, 2
+    with tempfile.TemporaryDirectory() as td:
+        init_file, out_file = os.path.join(td, "init"), os.path.join(td, "out.pt")
+        mp.spawn(_zip_render_worker, args=(world, init_file, H, W, out_file), nprocs=world, join=True)
+        got = torch.load(out_file)
+    with emulate_ops():
+        model = _zip_build()
+        batch, _ = _zip_data(H * W)
+        cfg = types.SimpleNamespace(render_chunk_size=1 << 20, vis_num_rays=2)
+        model.config = cfg
+        ref = zipnerf.render_image(lambda rand, b: model(rand, b, train_frac=1.0, compute_extras=True), None,
+                                   {k: v.reshape(H, W, -1) for k, v in batch.items()}, False, cfg)
+    assert set(got) == set(ref)
+    for k in ("rgb", "depth", "acc", "distance_mean", "distance_median"):
+        assert got[k].shape == ref[k].shape and got[k].shape[:2] == (H, W)
+        assert torch.allclose(got[k], ref[k], rtol=1e-4, atol=1e-5), (k, float((got[k] - ref[k]).abs().max()))
+    assert len(got["ray_weights"]) == 3 and got["ray_weights"][2].shape == (2, 32)

@@ -78,3 +78,19 @@ def test_g11_model_forward_with_semantic_head(golden):
     close(rend[-1]["rgb"], g["sem_rgb"], 1e-5, 1e-5, "rgb with the semantic head on")
     close(rend[-1]["semantic"], g["sem_semantic"], 1e-5, 1e-6, "semantic")
     assert "semantic" not in rend[0] and "semantic" not in rend[1]
+
+
+EXTRA_KEYS = ("acc", "distance_mean", "distance_percentile_5", "distance_median", "distance_percentile_95", "ray_sdist", "ray_weights", "ray_rgbs")
+
+
+def test_g11_model_forward_compute_extras(golden):
+    """compute_extras=True (render.py:243-267, models.py:316-346): acc, log-space distance mean, 5/50/95 % distance percentiles and
+    the visualisation rays of every level -- against the reference Model run in that mode (vis_num_rays = 8)."""
+    g = golden("g11_zip_model")
+    specs, p = zip_setup()
+    batch = {k[2:]: v for k, v in g.items() if k.startswith("b_")}
+    rend, _ = oz.model_forward(p, specs, batch, train_frac=1.0, compute_extras=True, vis_num_rays=8)
+    for lvl in range(3):
+        for k in EXTRA_KEYS:
+            close(rend[lvl][k], g[f"x{lvl}_{k}"], 2e-5, 2e-6, f"level {lvl} {k}")
+    assert g["x0_ray_sdist"].shape == (8, 65) and g["x2_ray_rgbs"].shape == (8, 32, 3) and g["x1_ray_rgbs"].shape == (8, 64, 3)

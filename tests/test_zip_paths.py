@@ -266,3 +266,70 @@ def test_zip_trainer_fused_loss_tail(backend):
     for _ in range(14):
         loss, _ = tr.step(batch, target, rand=False, draws=draws, targets=tg)
     assert float(loss) < 0.9 * float(loss0), (float(loss0), float(loss))
+
+
+def test_zip_compute_extras_vs_reference_golden(backend, golden):
+    """compute_extras=True (the rendering scripts' mode): acc, distance_mean, 5 / 50 / 95 % distance percentiles and the
+    visualisation rays of all three levels against the reference Model run in that mode (vis_num_rays = 8)."""
+    import types
+    g = golden("g11_zip_model")
+    specs, p = zip_setup()
+    batch = {k[2:]: v.to(DEV) for k, v in g.items() if k.startswith("b_")}
+    m = make_model("f32", "f32", p)
+    m.config = types.SimpleNamespace(vis_num_rays=8)
+    with pytest.raises(NotImplementedError):
+        m(None, batch, 1.0, True)                       # parameters require grad and grad mode is on
+    with torch.no_grad():
+        rend, hist = m(None, batch, 1.0, True)
+    tol = 2e-4
+    for lvl in range(3):
+        for k in ("acc", "distance_mean", "distance_percentile_5", "distance_median", "distance_percentile_95", "ray_sdist", "ray_weights", "ray_rgbs"):
+            close(rend[lvl][k], g[f"x{lvl}_{k}"], 10 * tol if k in ("ray_weights",) else tol, tol, f"level {lvl} {k}")
+        close(hist[lvl]["sdist"], g[f"det_sdist{lvl}"], tol, tol, f"sdist {lvl}")
+    close(rend[-1]["rgb"], g["det_rgb"], tol, tol, "rgb")
+
+
+def test_zip_render_image_chunks_match_one_pass(backend, golden):
+    """models.py:727-813 render_image: a [H,W] frame rendered in ragged chunks equals one forward over all rays; 2-D buffers come
+    back as [H,W,...], ray_* keys as one tensor per level with vis_num_rays rows."""
+    import types
+    from snerf_amd import zipnerf
+    g = golden("g11_zip_model")
+    specs, p = zip_setup()
+    batch = {k[2:]: v.to(DEV) for k, v in g.items() if k.startswith("b_")}           # 20 rays -> a 4 x 5 frame
+    frame = {k: v.reshape(4, 5, -1) for k, v in batch.items()}
+    m = make_model("f32", "f32", p, use_semantic=True)
+    cfg = types.SimpleNamespace(render_chunk_size=7, vis_num_rays=3)
+    m.config = cfg
+    fn = lambda rand, b: m(rand, b, train_frac=1.0, compute_extras=True)
+    out = zipnerf.render_image(fn, None, frame, False, cfg)
+    with torch.no_grad():
+        ref, _ = m(None, batch, 1.0, True)
+    assert out["rgb"].shape == (4, 5, 3) and out["depth"].shape == (4, 5) and out["semantic"].shape == (4, 5, 19)
+    for k in ("rgb", "depth", "acc", "semantic", "distance_median", "distance_percentile_95"):
+        # (a percentile on a flat stretch of the CDF amplifies the last-bit differences of a differently shaped GEMM batch)
+        close(out[k].reshape(ref[-1][k].shape), ref[-1][k], 1e-4 if k.startswith("distance") else 1e-6, 1e-6, k)
+    assert len(out["ray_sdist"]) == 3 and out["ray_sdist"][0].shape == (3, 65) and out["ray_rgbs"][2].shape == (3, 32, 3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,S", [(4099, 32), (3, 1), (257, 64)])
+def test_zip_percentiles_kernel_vs_oracle(R, S):
+    """weighted_percentile through the C-ABI against oracle/zip.py (pinned by the g11 compute_extras vectors): opaque rays
+    (weights summing to 1 -> clamped CDF), empty rays (all weight on the far fence post), zero-weight stretches (tied CDF values)."""
+    from snerf_amd import ops
+    g = torch.Generator().manual_seed(R + S)
+    t = torch.sort(torch.rand(R, S + 1, generator=g) * 9 + 0.1, -1).values
+    w = torch.rand(R, S, generator=g) ** 4
+    w = w / w.sum(-1, keepdim=True) * torch.rand(R, 1, generator=g)
+    w[0] = 0.0
+    if R > 2:
+        w[1] = w[1] / w[1].sum() * 1.0000005
+        w[2, : S // 2] = 0.0
+    far = t[:, -1:] + torch.rand(R, 1, generator=g)
+    ps = [5, 50, 95, 0.5, 99.9]
+    ref = oz.weighted_percentile(torch.cat([t, far], -1), torch.cat([w, (1 - w.sum(-1, keepdim=True)).clamp_min(0)], -1), ps)
+    got = ops.zip_percentiles(t.cuda(), w.cuda(), far.cuda(), ps).cpu()
+    assert got.shape == (R, 5)
+    close(got, ref, 2e-5, 1e-6, "percentiles")
+    assert torch.equal(got[0], far[0].expand(5) * 0 + got[0]) and bool((got[0] >= t[0, -1]).all())      # empty ray: between the last post and t_far

@@ -19,6 +19,8 @@ def main():
     ap.add_argument("--log2T", type=int, default=21)
     ap.add_argument("--table-grad", default="f32", choices=["f32", "bf16"])
     ap.add_argument("--backend", default="nccl")
+    ap.add_argument("--semantic", action="store_true", help="19-class semantic head on (Config.use_semantic): rendered and trained")
+    ap.add_argument("--frame-chunk", type=int, default=65536, help="render_chunk_size of the measured 1920x1280 frame")
     ap.add_argument("--same-device", action="store_true", help="functional test of the N > 1 flow on a 1-GPU box")
     args = ap.parse_args()
     import torch.distributed as dist
@@ -37,7 +39,8 @@ def main():
     from snerf_amd.trainer import ZipTrainer
     torch.manual_seed(0)
     m = zipnerf.Model(config=None, raydist_fn='power_transformation', opaque_background=True, compute=args.compute, table_dtype=args.table,
-                      grid_log2_hashmap_size=args.log2T, init_std=0.1, table_grad_dtype=args.table_grad, device=torch.device("cuda", local))
+                      grid_log2_hashmap_size=args.log2T, init_std=0.1, table_grad_dtype=args.table_grad, device=torch.device("cuda", local),
+                      use_semantic=args.semantic)
     tr = ZipTrainer(m, lr=1e-2)
     tr.broadcast_parameters(0)
     R = args.rays
@@ -57,6 +60,8 @@ def main():
     # anti-interlevel term, the NeRF level also by the distortion term (reference defaults)
     tdepth = (torch.rand(R, generator=g) * 4 + 0.2).to(dev)
     targets = dict(depth=tdepth, depth_mask=(torch.rand(R, generator=g) < 0.5).float().to(dev))
+    if args.semantic:
+        targets.update(semantic=torch.randint(0, 19, (R,), generator=g).int().to(dev))
 
     def barrier():
         if world > 1:
@@ -84,6 +89,22 @@ def main():
     for _ in range(args.steps):
         fwd_only()
     barrier(); dt_fwd = (time.perf_counter() - t0) / args.steps
+    # BASELINE config 5: one whole 1920 x 1280 frame (2 457 600 rays) through render_image (ray generation on device, contiguous ray
+    # blocks per rank, compute_extras like random_render_waymo_seq.py:197, one all-gather per buffer)
+    import types
+    W_, H_ = 1920, 1280
+    pidx = torch.arange(W_ * H_, device=dev)
+    fr = ops.zip_pixels_to_rays((pidx % W_).int(), (pidx // W_).int(), None, torch.linalg.inv(K)[None].to(dev), c2w[None].to(dev))
+    fr.update(near=torch.full((W_ * H_, 1), 0.1, device=dev), far=torch.full((W_ * H_, 1), 10.0, device=dev))
+    frame = {k: v.reshape(H_, W_, -1) for k, v in fr.items()}
+    cfg = types.SimpleNamespace(render_chunk_size=args.frame_chunk, vis_num_rays=16)
+    m.config = cfg
+    rfn = lambda rand, b: m(rand, b, train_frac=1.0, compute_extras=True)
+    zipnerf.render_image(rfn, None, frame, False, cfg)
+    barrier(); t0 = time.perf_counter()
+    img = zipnerf.render_image(rfn, None, frame, False, cfg)
+    barrier(); dt_frame = time.perf_counter() - t0
+    assert img["rgb"].shape == (H_, W_, 3) and bool(torch.isfinite(img["rgb"]).all())
     # dominant kernel: the fused featurisation (forward), timed with events around its three launches
     rec = []
     orig = ops.zip_encode_fwd
@@ -113,7 +134,7 @@ def main():
     out = {"path": "C (zipnerf Model, waymo.gin shape: 64+64+32 intervals x 7 multisamples, grids L=6/8/10)", "n_gpus": world, "rays_per_gpu": R,
            "compute": args.compute, "table_grad": args.table_grad,
            "table": args.table, "train_ms": round(dt_train * 1e3, 3), "train_rays_per_s": round(world * R / dt_train, 1), "fwd_ms": round(dt_fwd * 1e3, 3),
-           "fwd_rays_per_s": round(R / dt_fwd, 1), "frame_1920x1280_s_one_gpu": round(1920 * 1280 / (R / dt_fwd), 3), "encode_fwd_ms_per_level": [round(x, 3) for x in enc_ms],
+           "fwd_rays_per_s": round(R / dt_fwd, 1), "frame_1920x1280_s": round(dt_frame, 3), "frame_outputs": sorted(k for k in img if not k.startswith("ray_")), "encode_fwd_ms_per_level": [round(x, 3) for x in enc_ms],
            "encode_fwd_gather_GBps_per_level": [round(b / (ms * 1e-3) / 1e9, 1) for b, ms in zip(bytes_lvl, enc_ms)],
            "roofline": {"bound": "hbm", "kernel": "zip_encode_kernel (nerf level)", "achieved": round(bytes_lvl[2] / (enc_ms[2] * 1e-3) / 1e9, 1),
                         "peak": 8000.0, "unit": "GB/s", "frac": round(bytes_lvl[2] / (enc_ms[2] * 1e-3) / 1e9 / 8000.0, 4),
