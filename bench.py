@@ -271,7 +271,7 @@ def main():
                "dtype": args.compute, "data": "synthetic",
                "config": {"workload": f"S-NeRF path A (MipNerfModel) train step, nuScenes-like 1600x900 rays, {S0} proposal + {P1 - 1} fine evals/ray "
                                       f"({S0 + P1 - 1} spp), hidden 1024, rgb_layer 3, cone + contraction + IPE-96",
-                          "rays_per_gpu_per_step": n, "global_rays_per_step": n * world, "parallelism": f"dp{world} (ray-sharded, one flat RCCL all-reduce)",
+                          "rays_per_gpu_per_step": n, "global_rays_per_step": n * world, "parallelism": f"dp{world} (ray-sharded, flat-arena RCCL all-reduce overlapped with the backward)",
                           "train_flops_per_ray": 3 * fwd},
                "roofline": roofline, "final_loss": final_loss}
 

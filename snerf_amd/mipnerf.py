@@ -133,8 +133,9 @@ class MipNerfModel(_ArenaModule):
                        white=white_bg, raw_sem=raw_sem)
         return (dist0, acc0, s0, w0, rgb1, dist1, acc1, s1, w1) + ((sem1,) if self.semantic else ()), ctx
 
-    def _backward(self, ctx, g_dist0, g_acc0, g_w0, g_rgb1, g_dist1, g_acc1, g_w1, g_sem1=None):
-        """Accumulates parameter gradients into the arena."""
+    def _backward(self, ctx, g_dist0, g_acc0, g_w0, g_rgb1, g_dist1, g_acc1, g_w1, g_sem1=None, on_done=None):
+        """Accumulates parameter gradients into the arena.  `on_done(prefix)` is called as soon as the gradients of the network whose
+        parameters start with `prefix` are final (the trainer starts that block's all-reduce while the rest of the backward runs)."""
         c = ctx
         n = c["s0"].shape[0]
         S0, S1 = c["s0"].shape[1] - 1, c["s1"].shape[1] - 1
@@ -153,12 +154,16 @@ class MipNerfModel(_ArenaModule):
                                   c["white"], self.rgb_padding, self.density_bias, c["w1"], c["dist1"], cc(g_rgb1), cc(g_dist1),
                                   cc(g_acc1), cc(g_w1), d_rgb, d_den)
             self.nerf.backward(d_rgb, d_den, c["saved1"], d_raw_sem)
+        if on_done is not None:
+            on_done("mlp.")
         if any(t is not None for t in (g_dist0, g_acc0, g_w0)):
             d_den0 = torch.empty(n * S0, 1, dtype=torch.float32, device=dev)
             ops.mip_composite_bwd(None, c["raw_d0"], c["noise0"], c["s0"], c["d"], c["near"], c["far"], self.transform_idx,
                                   c["white"], self.rgb_padding, self.density_bias, c["w0"], c["dist0"], None, cc(g_dist0),
                                   cc(g_acc0), cc(g_w0), None, d_den0)
             self.prop.backward(d_den0, c["acts0"])
+        if on_done is not None:
+            on_done("proposal.")
 
     def _draws(self, n, randomized, dev):
         """The reference's three torch RNG draws (mip.py:283, math_ops.py:52, models.py:163-165), taken in its order."""

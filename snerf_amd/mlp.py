@@ -38,6 +38,7 @@ class ParamArena:
             offs[n] = (o, numel)
             o += roundup(numel, 4)  # keep every view 16-byte aligned
         self.numel = roundup(o, 4)
+        self._offs = offs
         self.epoch = 0
         self.flat = torch.zeros(self.numel, dtype=torch.float32, device=device)
         self.grad = torch.zeros(self.numel, dtype=torch.float32, device=device)
@@ -48,6 +49,15 @@ class ParamArena:
         with torch.no_grad():
             for n in self.names:
                 self.p[n].copy_(sd[prefix + n].to(self.flat.device, torch.float32))
+
+    def span(self, prefix: str):
+        """[start, end) of the flat arena covered by the parameters whose name starts with `prefix` (they are laid out together)."""
+        idx = [i for i, n in enumerate(self.names) if n.startswith(prefix)]
+        if not idx or idx != list(range(idx[0], idx[-1] + 1)):
+            raise ValueError(f"parameters with prefix {prefix!r} are not one contiguous block of the arena")
+        a = self._offs[self.names[idx[0]]][0]
+        b = self._offs[self.names[idx[-1] + 1]][0] if idx[-1] + 1 < len(self.names) else self.numel
+        return a, b
 
     def bump(self):
         """Call after the parameters were modified behind torch's back (fused Adam kernel, RCCL broadcast)."""

@@ -7,14 +7,44 @@ confidence.py:209-224, ProposalLoss loss_factory.py:59-74, loss.backward() :213,
 The per-ray loss tail is one kernel that returns the loss terms and
 dL/d(rgb, distance, coarse weights) -- no [N]-sized torch expressions, no device->host sync in the step.
 
-Multi-GPU: one process per GPU, every rank renders its own shard of the ray batch; the only exchange is ONE
-RCCL all-reduce of the flat fp32 gradient arena (35.9 MB for the shipped model) before the Adam kernel, which
-folds the 1/world_size mean into its pass.
+Multi-GPU: one process per GPU, every rank renders its own shard of the ray batch; the only exchange is the
+RCCL all-reduce of the flat fp32 gradient arena (35.9 MB for the shipped model), issued network by network as
+the backward pass completes each block so that it overlaps with the rest of the backward, before the Adam
+kernel, which folds the 1/world_size mean into its pass.
 """
 import torch
 import torch.distributed as dist
 
 from . import ops
+
+
+class _GradExchange:
+    """Gradient all-reduce overlapped with the backward pass: the arena is laid out network by network, and as soon as one network's
+    gradients are final its block is all-reduced asynchronously (RCCL runs it on its own stream) while the remaining networks'
+    backward kernels keep the compute stream busy.  `finish()` reduces whatever was not announced and waits for everything."""
+
+    def __init__(self, arena, world, group):
+        self.arena, self.world, self.group = arena, world, group
+        self.works, self.done = [], []
+
+    def __call__(self, prefix):
+        if self.world <= 1:
+            return
+        a, b = self.arena.span(prefix)
+        self.done.append((a, b))
+        self.works.append(dist.all_reduce(self.arena.grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        if self.world <= 1:
+            return
+        pos = 0
+        for a, b in sorted(self.done) + [(self.arena.numel, self.arena.numel)]:
+            if a > pos:
+                self.works.append(dist.all_reduce(self.arena.grad[pos:a], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            pos = max(pos, b)
+        for w in self.works:
+            w.wait()
+        self.works, self.done = [], []
 
 
 class MipTrainer:
@@ -59,9 +89,9 @@ class MipTrainer:
         u = du if u is None else u
         outs, ctx = m._run(rays, True, False, s_rand, u.contiguous(), noise0, noise1)
         loss, g = self.loss_and_grads(outs, target_rgb, target_depth, conf)
-        m._backward(ctx, *g)
-        if self.world > 1:
-            dist.all_reduce(m.arena.grad, op=dist.ReduceOp.SUM, group=self.pg)
+        ex = _GradExchange(m.arena, self.world, self.pg)
+        m._backward(ctx, *g, on_done=ex)        # the 35.9 MB MLP block is reduced while the proposal network's backward runs
+        ex.finish()
         self.t += 1
         ops.adam_step(m.arena.flat, m.arena.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.t,
                       grad_scale=1.0 / self.world, zero_grad=True)
@@ -80,8 +110,8 @@ class ZipTrainer:
     """Train step of the S-NeRF++ / zipnerf background model (s-nerfpp/zipnerf/train.py hot loop :218-331: Model.forward, the loss
     terms, loss.backward(), optimizer.step()) on the flat arenas: forward, ONE fused loss-tail launch (ops.zip_loss_tail: Charbonnier
     data term, disparity-L1 depth terms, semantic NLL, anti-interlevel and distortion regularisers, with their gradients), backward
-    through the fused kernels, ONE RCCL all-reduce of the flat gradient arena (MLPs + the 3 hash tables, ~310 MB for waymo.gin) and
-    one fused Adam launch with the 1/world mean folded in.  No device->host sync anywhere in the step: the loss terms stay on the
+    through the fused kernels, the RCCL all-reduce of the flat gradient arena (MLPs + the 3 hash tables, ~310 MB for waymo.gin) issued
+    level by level so that it overlaps with the remaining backward, and one fused Adam launch with the 1/world mean folded in.  No device->host sync anywhere in the step: the loss terms stay on the
     device in `last_losses` (ops.ZIP_LOSS_NAMES order).
 
     `loss_cfg` overrides the reference defaults (internal/configs.py:60-66,85; train.py:253,272,298): charb_padding 0.001, data_mult
@@ -134,9 +164,10 @@ class ZipTrainer:
                 gs = torch.autograd.grad(aux, leaves, allow_unused=True)
             g_w = [a if b is None else (b if a is None else a + b) for a, b in zip(g_w, gs)]
             loss = loss + aux.detach()
-        m._backward(ctx, [(None, None, None, g_w[0]), (None, None, None, g_w[1]), (G["rgb"], G["depth"], None, g_w[2], G["semantic"])])
-        if self.world > 1:
-            dist.all_reduce(m.arena.grad, op=dist.ReduceOp.SUM, group=self.pg)
+        ex = _GradExchange(m.arena, self.world, self.pg)
+        # the NeRF level (its 240 MB table gradient) is reduced while the two proposal levels' backward runs
+        m._backward(ctx, [(None, None, None, g_w[0]), (None, None, None, g_w[1]), (G["rgb"], G["depth"], None, g_w[2], G["semantic"])], on_done=ex)
+        ex.finish()
         self.t += 1
         ops.adam_step(m.arena.flat, m.arena.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.t,
                       grad_scale=1.0 / self.world, zero_grad=True)

@@ -207,14 +207,17 @@ class Model(_ArenaModule):
             ctx = dict(o=o, d=d, radii=radii, bx=bx, by=by, levels=det, bg=bg, n=sample_n, m=sample_m)
         return levels, ctx
 
-    def _backward(self, ctx, grads):
-        """grads[lvl] = (g_rgb, g_depth, g_acc, g_w); accumulates parameter gradients into the arena."""
+    def _backward(self, ctx, grads, on_done=None):
+        """grads[lvl] = (g_rgb, g_depth, g_acc, g_w); accumulates parameter gradients into the arena.  `on_done(prefix)` is called as
+        soon as a level's gradients (MLP + hash table) are final, NeRF level first."""
         dev = ctx["o"].device
         cc = lambda t: None if t is None else t.contiguous().float()
         for lvl in (2, 1, 0):
             g_rgb, g_depth, g_acc, g_w = grads[lvl][:4]
             g_sem = grads[lvl][4] if len(grads[lvl]) > 4 else None
             if all(t is None for t in (g_rgb, g_depth, g_acc, g_w, g_sem)):
+                if on_done is not None:
+                    on_done(self.names[lvl])
                 continue
             L = ctx["levels"][lvl]
             e, net = self.encs[lvl], self.nets[lvl]
@@ -245,6 +248,8 @@ class Model(_ArenaModule):
                                e.H, self.std_scale, e.lds_levels, e.lds_cells, e.lds_slabs, grad_table_bf16=g16)
             if g16 is not None:
                 gtab.add_(g16)
+            if on_done is not None:
+                on_done(self.names[lvl])
 
     def _draws(self, R, rand, dev, sample_n):
         """the reference's RNG draws in its order: per level one single-jitter draw (stepfun.py:216) then the helix phase
