@@ -266,6 +266,13 @@ int snerf_zip_loss_tail(const float* rgb, const float* tgt, const float* lossmul
 int snerf_zip_percentiles(const float* tdist, const float* weights, const float* t_far, long R, int S, const float* ps_host, int np,
                           float* out, void* stream);
 
+/* Frame quantisation for the S-NeRF++ wire format (s-nerfpp/zipnerf/random_render_waymo_seq.py:214-227): rgb [P,3] -> u8 as
+ * internal/utils.py:111-116 save_img_u8 (clip(nan_to_num(x), 0, 1) * 255, truncated); depth [P] -> u16 = depth * 256 / scale_factor
+ * truncated (:218-219); sem [P, ld_sem >= C] -> label u8 = first argmax over the C classes (:222-223) and paint u8 [P,3] =
+ * color_map[label] (color_map: device u8 [C,3]; :225).  Any of rgb / depth / sem may be NULL (skipped); paint_u8 may be NULL. */
+int snerf_frame_quantize(const float* rgb, const float* depth, const float* sem, long ld_sem, int C, const void* color_map, long P,
+                         float scale_factor, void* rgb_u8, void* depth_u16, void* label_u8, void* paint_u8, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -269,3 +269,23 @@ def zip_loss_tail(rgb, target, lossmult, depth, target_depth, depth_mask, com_ma
         L["interlevel"] = interlevel_mult * tot
     L["total"] = sum(v for k, v in L.items() if k != "mse")
     return L, G
+
+
+# ---------------------------------------------------------------- frame writer (row 8f-3) ----
+def frame_quantize(rgb=None, depth=None, semantic=None, color_map=None, scale_factor=1.0):
+    """The quantisation the reference applies before PIL writes the frame (s-nerfpp/zipnerf/random_render_waymo_seq.py:214-227):
+    rgb: internal/utils.py:111-116 `(np.clip(np.nan_to_num(img), 0., 1.) * 255.).astype(np.uint8)`; depth :218-219
+    `(dep * 256 / scale_factor).astype(np.uint16)`; labels :222-223 `np.argmax(semantic, -1).astype(np.uint8)`; paint :225
+    `color_map[labels].astype(np.uint8)`.  The same numpy expressions, so the (platform-defined) float -> integer casts are numpy's."""
+    out = {}
+    with np.errstate(invalid="ignore", over="ignore"):
+        if rgb is not None:
+            out["rgb"] = (np.clip(np.nan_to_num(np.asarray(rgb, np.float32)), 0., 1.) * 255.).astype(np.uint8)
+        if depth is not None:
+            out["depth"] = (np.asarray(depth, np.float32) * 256 / scale_factor).astype(np.uint16)
+        if semantic is not None:
+            labels = np.argmax(np.asarray(semantic, np.float32), axis=-1)
+            out["semantic"] = labels.astype(np.uint8)
+            if color_map is not None:
+                out["paint"] = np.asarray(color_map)[labels].astype(np.uint8)
+    return out

@@ -12,9 +12,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _REPO = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "lib", "libsnerf_hip.so")
 HEADER_PATH = os.path.join(_REPO, "include", "snerf_hip.h")
+IO_LIB_PATH = os.path.join(_HERE, "lib", "libsnerf_io.so")
+IO_HEADER_PATH = os.path.join(_REPO, "include", "snerf_io.h")
 
 _CTYPE = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float}
 _lib = None
+_iolib = None
 
 
 def parse_header(path: str = HEADER_PATH):
@@ -22,7 +25,7 @@ def parse_header(path: str = HEADER_PATH):
     src = open(path).read()
     src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
     protos = {}
-    for m in re.finditer(r"\bint\s+(snerf_\w+)\s*\(([^)]*)\)\s*;", src):
+    for m in re.finditer(r"\b(?:int|long)\s+(snerf_\w+)\s*\(([^)]*)\)\s*;", src):
         name, args = m.group(1), m.group(2).strip()
         sig = []
         if args and args != "void":
@@ -56,6 +59,22 @@ def load():
         fn.argtypes = [t for t, _ in sig]
         fn.restype = ctypes.c_int
     _lib = lib
+    return lib
+
+
+def load_io():
+    """libsnerf_io.so (include/snerf_io.h): the host-side PNG writer of the frame writer.  Host-only, no GPU runtime."""
+    global _iolib
+    if _iolib is not None:
+        return _iolib
+    if not os.path.exists(IO_LIB_PATH):
+        raise RuntimeError(f"libsnerf_io.so not found at {IO_LIB_PATH}: build it with `make -C snerf_amd/csrc`")
+    lib = ctypes.CDLL(IO_LIB_PATH)
+    for name, sig in parse_header(IO_HEADER_PATH).items():
+        fn = getattr(lib, name)
+        fn.argtypes = [t for t, _ in sig]
+        fn.restype = ctypes.c_long if name == "snerf_png_encode" else ctypes.c_int
+    _iolib = lib
     return lib
 
 

@@ -499,3 +499,66 @@ extern "C" int snerf_zip_loss_tail(const float* rgb, const float* tgt, const flo
   hipLaunchKernelGGL(zip_loss_tail_kernel, dim3((unsigned)((R + 63) / 64), inter ? 3 : 1), dim3(64), 0, (hipStream_t)stream, a);
   return snerf_check_launch();
 }
+
+// ---------------------------------------------------------------------------
+// Frame quantisation for the S-NeRF++ wire format (s-nerfpp/zipnerf/random_render_waymo_seq.py:214-227):
+//   rgb    u8  = trunc(clip(nan_to_num(rgb), 0, 1) * 255)                       internal/utils.py:111-116 (save_img_u8)
+//   depth  u16 = (depth * 256 / scale_factor).astype(uint16)                    :218-219 (float32 product and quotient, truncation;
+//                                                                                values past 65535 wrap like the x86 int32 cast numpy emits)
+//   label  u8  = argmax_c semantic[., c] (first maximum)                        :222-223
+//   paint  u8x3 = color_map[label]                                              :225
+// One pass over the rendered buffers on the device: the host copy shrinks from (3 + 1 + C) floats to 9 bytes per pixel.
+// ---------------------------------------------------------------------------
+struct FrameQ {
+  const float *rgb, *depth, *sem; long ld_sem; int C; const unsigned char* cmap; long P; float scale_factor;
+  unsigned char* rgb8; unsigned short* depth16; unsigned char* label8; unsigned char* paint8;
+};
+
+__global__ __launch_bounds__(256) void frame_quantize_kernel(FrameQ a) {
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= a.P) return;
+  if (a.rgb != nullptr) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float v = a.rgb[3 * p + c];
+      v = v != v ? 0.f : v;                                   // nan_to_num: nan -> 0, +/-inf -> +/-max (then clipped)
+      v = fminf(fmaxf(v, 0.f), 1.f) * 255.f;
+      a.rgb8[3 * p + c] = (unsigned char)(int)v;
+    }
+  }
+  if (a.depth != nullptr) {
+    const float v = a.depth[p] * 256.f / a.scale_factor;
+    int q;
+    if (!(v == v)) q = (int)0x80000000;                       // cvttss2si's "integer indefinite" for nan / out-of-range
+    else if (v >= 2147483648.f || v < -2147483648.f) q = (int)0x80000000;
+    else q = (int)v;
+    a.depth16[p] = (unsigned short)(q & 0xFFFF);
+  }
+  if (a.sem != nullptr) {
+    const float* s = a.sem + p * a.ld_sem;
+    int best = 0;
+    float bv = s[0];
+    for (int c = 1; c < a.C; ++c) {
+      const float v = s[c];
+      if (v > bv || (v != v && bv == bv)) { bv = v; best = c; }   // np.argmax: first maximum; a nan is a maximum
+    }
+    a.label8[p] = (unsigned char)best;
+    if (a.paint8 != nullptr) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) a.paint8[3 * p + c] = a.cmap[3 * best + c];
+    }
+  }
+}
+
+extern "C" int snerf_frame_quantize(const float* rgb, const float* depth, const float* sem, long ld_sem, int C, const void* color_map, long P,
+                                    float scale_factor, void* rgb_u8, void* depth_u16, void* label_u8, void* paint_u8, void* stream) {
+  if (P <= 0) return SNERF_OK;
+  if (rgb != nullptr && rgb_u8 == nullptr) return SNERF_ERR_ARG;
+  if (depth != nullptr && (depth_u16 == nullptr || !(scale_factor != 0.f))) return SNERF_ERR_ARG;
+  if (sem != nullptr && (label_u8 == nullptr || C < 1 || C > 256 || ld_sem < C)) return SNERF_ERR_ARG;
+  if (sem != nullptr && paint_u8 != nullptr && color_map == nullptr) return SNERF_ERR_ARG;
+  FrameQ a{rgb, depth, sem, ld_sem, C, (const unsigned char*)color_map, P, scale_factor, (unsigned char*)rgb_u8, (unsigned short*)depth_u16,
+           (unsigned char*)label_u8, (unsigned char*)paint_u8};
+  hipLaunchKernelGGL(frame_quantize_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  return snerf_check_launch();
+}

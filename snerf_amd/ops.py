@@ -512,6 +512,37 @@ def zip_percentiles(tdist, weights, t_far, ps=(5, 50, 95)):
     return out
 
 
+def frame_quantize(rgb=None, depth=None, semantic=None, color_map=None, scale_factor=1.0):
+    """Quantise rendered frame buffers for the S-NeRF++ wire format in one launch (random_render_waymo_seq.py:214-227):
+    rgb [..,3] -> uint8, depth [..] -> uint16 (= depth * 256 / scale_factor), semantic [..,C] -> argmax label uint8 (+ paint uint8 [..,3]
+    through `color_map` uint8 [C,3]).  -> dict with the keys of the inputs given ('rgb', 'depth', 'semantic', 'paint'), device tensors."""
+    ref = rgb if rgb is not None else (depth if depth is not None else semantic)
+    dev = ref.device
+    out = {}
+    P = (rgb.numel() // 3) if rgb is not None else (depth.numel() if depth is not None else semantic.numel() // semantic.shape[-1])
+    r = d = s = cm = r8 = d16 = l8 = p8 = None
+    C, ld = 0, 0
+    if rgb is not None:
+        r = _f32c(rgb.contiguous())
+        assert r.shape[-1] == 3 and r.numel() == 3 * P
+        r8 = out["rgb"] = torch.empty(r.shape, dtype=torch.uint8, device=dev)
+    if depth is not None:
+        d = _f32c(depth.contiguous())
+        assert d.numel() == P
+        d16 = out["depth"] = torch.empty(d.shape, dtype=torch.uint16, device=dev)
+    if semantic is not None:
+        s = _f32c(semantic.contiguous())
+        C = ld = s.shape[-1]
+        assert s.numel() == C * P and C <= 256
+        l8 = out["semantic"] = torch.empty(s.shape[:-1], dtype=torch.uint8, device=dev)
+        if color_map is not None:
+            cm = color_map.contiguous()
+            assert cm.dtype == torch.uint8 and cm.is_cuda and tuple(cm.shape) == (C, 3)
+            p8 = out["paint"] = torch.empty(tuple(s.shape[:-1]) + (3,), dtype=torch.uint8, device=dev)
+    _lib.call("snerf_frame_quantize", _p(r), _p(d), _p(s), ld, C, _p(cm), P, float(scale_factor), _p(r8), _p(d16), _p(l8), _p(p8), _stream())
+    return out
+
+
 def semantic_composite_fwd(weights, logits, C, softmax):
     """semantic [R,C] = sum_i w[r,i] f(logits[r*S+i, :C]), f = softmax (zipnerf) or identity (live mip path); logits: 2-D view."""
     R, S = weights.shape
