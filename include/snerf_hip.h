@@ -273,6 +273,25 @@ int snerf_zip_percentiles(const float* tdist, const float* weights, const float*
 int snerf_frame_quantize(const float* rgb, const float* depth, const float* sem, long ld_sem, int C, const void* color_map, long P,
                          float scale_factor, void* rgb_u8, void* depth_u16, void* label_u8, void* paint_u8, void* stream);
 
+/* ---- image-space foreground composite of S-NeRF++ stage 1 (s-nerfpp/stage1_code/) -----------------------
+ * All images are device uint8 [H,W,3] (masks / bands hold 0 or 255, tested as > 0), depth float [H,W] (the uint16 depth PNG / 256,
+ * exactly representable), semantic uint8 [H,W]; P = H*W.
+ * snerf_fg_paste: utils_render.py:826-1005 handle_occlusion_paste given fg_depth [P] = the mesh depth along each pixel's ray (what the
+ * reference's ray tracer returns, :913-947; ignored with person = 1, where the reference uses -1 :940-941).  In place: a pixel with
+ * mask[...,0] > 0 takes the foreground colour, fg depth and class_id when fg_depth < depth or the background class is 0, 1 or 8;
+ * otherwise its mask is cleared.  counters (device int[2]) <- {#masked, #pasted}: occlusion = 1 - pasted / (masked + 1) (:1002-1003). */
+int snerf_fg_paste(void* bg_im, const void* fg_im, void* mask_im, float* depth, void* semantic, const float* fg_depth, long P,
+                   int class_id, int person, int* counters, void* stream);
+/* utils_render.py:306-324 get_bound_im: band = cv2.dilate(mask[...,0]) XOR cv2.erode(mask[...,0]) with the r x r rect kernel (default
+ * anchor r/2, border never wins), written to all 3 channels of bound_im as 0 / 255; mask_out (nullable, must not alias mask_im)
+ * <- ip_utils.py:10-19 set_diff(mask_im, bound_im) as the caller does next (generate_images.py:152-153). */
+int snerf_fg_bound(const void* mask_im, int H, int W, int r, void* bound_im, void* mask_out, void* stream);
+/* In place over nbytes bytes: total_bound <- utils_render.py:338-361 fuse_bound(total_mask, total_bound, bound, mask), then
+ * total_mask <- (mask | total_mask) * 255 (generate_images.py:160-161). */
+int snerf_fg_accumulate(void* total_mask, void* total_bound, const void* bound, const void* mask, long nbytes, void* stream);
+/* utils_render.py:327-335 fuse_bound_and_im: im[bound > 0] = 0, per byte, in place. */
+int snerf_fg_blank(void* im, const void* bound, long nbytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
