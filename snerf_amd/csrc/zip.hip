@@ -39,75 +39,93 @@ struct ZipResample {
 };
 
 __global__ __launch_bounds__(ZIP_LANES) void zip_resample_kernel(ZipResample a) {
+  // LDS, all arrays element-major ([k][lane]: conflict-free for a lane-per-ray walk): the input posts t and pdf p staged with
+  // coalesced loads, then the working posts T and weights / cdf W.  The serial per-ray walks below touch LDS only.
   extern __shared__ float lds[];
   const int cap = 3 * a.S0 + 2;
-  const int stride = cap | 1;
-  float* T = lds + (size_t)threadIdx.x * 2 * stride;     // posts
-  float* W = T + stride;                                 // weights -> cdf
-  const long ray = (long)blockIdx.x * ZIP_LANES + threadIdx.x;
-  if (ray >= a.R) return;
-  const float* t = a.sdist + ray * (a.S0 + 1);
-  const float* w = a.weights + ray * a.S0;
+  const int lane = threadIdx.x;
+  float* t = lds;                                        // [(S0+1)][LANES]
+  float* w = t + (size_t)(a.S0 + 1) * ZIP_LANES;         // [S0][LANES]: pdf of the input step function when dilating, else weights
+  float* T = w + (size_t)a.S0 * ZIP_LANES;               // [cap][LANES] posts
+  float* W = T + (size_t)cap * ZIP_LANES;                // [cap][LANES] weights -> cdf
+  const long ray0 = (long)blockIdx.x * ZIP_LANES;
+  const long nray = min((long)ZIP_LANES, a.R - ray0);
   const float eps = 1.1920929e-07f;
+  {
+    const float* gt = a.sdist + ray0 * (a.S0 + 1);
+    const long nt = nray * (a.S0 + 1);
+    for (long i = lane; i < nt; i += ZIP_LANES) { const int r = (int)(i / (a.S0 + 1)), k = (int)(i - (long)r * (a.S0 + 1)); t[k * ZIP_LANES + r] = gt[i]; }
+    const float* gw = a.weights + ray0 * a.S0;
+    const long nw = nray * a.S0;
+    for (long i = lane; i < nw; i += ZIP_LANES) { const int r = (int)(i / a.S0), k = (int)(i - (long)r * a.S0); w[k * ZIP_LANES + r] = gw[i]; }
+  }
+  __syncthreads();
+  const long ray = ray0 + lane;
+  if (ray >= a.R) return;
+#define Tt(k) t[(k) * ZIP_LANES + lane]
+#define Ww(k) w[(k) * ZIP_LANES + lane]
+#define TT(k) T[(k) * ZIP_LANES + lane]
+#define WW(k) W[(k) * ZIP_LANES + lane]
   int S;                                                  // intervals of the step function that gets sampled
   if (a.dilate) {
     // merged, clipped posts of the three sorted sequences t, t - d (t0), t + d (t1)
     const int S0 = a.S0, NP = 3 * S0 + 1;
     int ia = 0, ib = 0, ic = 0;
+    float va = Tt(0), vb = Tt(0) - a.dilation, vc = Tt(1) + a.dilation;
     for (int k = 0; k < NP; ++k) {
-      const float va = ia <= S0 ? t[ia] : INFINITY;
-      const float vb = ib < S0 ? t[ib] - a.dilation : INFINITY;
-      const float vc = ic < S0 ? t[ic + 1] + a.dilation : INFINITY;
       float v;
-      if (vb <= va && vb <= vc) { v = vb; ++ib; } else if (va <= vc) { v = va; ++ia; } else { v = vc; ++ic; }
-      T[k] = fminf(fmaxf(v, a.dom0), a.dom1);
+      if (vb <= va && vb <= vc) { v = vb; ++ib; vb = ib < S0 ? Tt(ib) - a.dilation : INFINITY; }
+      else if (va <= vc) { v = va; ++ia; va = ia <= S0 ? Tt(ia) : INFINITY; }
+      else { v = vc; ++ic; vc = ic < S0 ? Tt(ic + 1) + a.dilation : INFINITY; }
+      TT(k) = fminf(fmaxf(v, a.dom0), a.dom1);
     }
+    for (int i = 0; i < S0; ++i) Ww(i) = Ww(i) / fmaxf(Tt(i + 1) - Tt(i), eps);      // pdf of the input intervals
     // dilated pdf = max over the intervals i with t0_i <= T_k < t1_i (a contiguous, monotonically moving range)
     int lo = 0, hi = -1;
     float sum = 0.f;
+    float tk = TT(0);
     for (int k = 0; k < NP - 1; ++k) {
-      const float tk = T[k];
-      while (lo < S0 && !(t[lo + 1] + a.dilation > tk)) ++lo;
-      while (hi + 1 < S0 && t[hi + 1] - a.dilation <= tk) ++hi;
+      while (lo < S0 && !(Tt(lo + 1) + a.dilation > tk)) ++lo;
+      while (hi + 1 < S0 && Tt(hi + 1) - a.dilation <= tk) ++hi;
       float p = 0.f;
-      for (int i = lo; i <= hi; ++i) {
-        const float pi = w[i] / fmaxf(t[i + 1] - t[i], eps);
-        if (t[i] - a.dilation <= tk && t[i + 1] + a.dilation > tk) p = fmaxf(p, pi);
-      }
-      const float wd = p * (T[k + 1] - tk);
-      W[k] = wd;
+      for (int i = lo; i <= hi; ++i)
+        if (Tt(i) - a.dilation <= tk && Tt(i + 1) + a.dilation > tk) p = fmaxf(p, Ww(i));
+      const float tn = TT(k + 1);
+      const float wd = p * (tn - tk);
+      WW(k) = wd;
       sum += wd;
+      tk = tn;
     }
     sum = fmaxf(sum, eps);
     // caller trims [1:-1] (models.py:187-188): posts 1 .. NP-2, intervals 1 .. NP-3
     S = NP - 3;
-    for (int k = 0; k < S; ++k) W[k] = W[k + 1] / sum;
-    for (int k = 0; k <= S; ++k) T[k] = T[k + 1];
+    for (int k = 0; k < S; ++k) WW(k) = WW(k + 1) / sum;
+    for (int k = 0; k <= S; ++k) TT(k) = TT(k + 1);
   } else {
     S = a.S0;
-    for (int k = 0; k <= S; ++k) T[k] = t[k];
-    for (int k = 0; k < S; ++k) W[k] = w[k];
+    for (int k = 0; k <= S; ++k) TT(k) = Tt(k);
+    for (int k = 0; k < S; ++k) WW(k) = Ww(k);
   }
   // annealed logits + softmax (models.py:196-203, stepfun.py:157)
   float mx = -INFINITY;
   for (int k = 0; k < S; ++k) {
-    const float l = T[k + 1] > T[k] ? a.anneal * logf(W[k] + a.pad) : -INFINITY;
-    W[k] = l;
+    const float l = TT(k + 1) > TT(k) ? a.anneal * logf(WW(k) + a.pad) : -INFINITY;
+    WW(k) = l;
     mx = fmaxf(mx, l);
   }
   double acc = 0.0;
-  for (int k = 0; k < S; ++k) { const float e = expf(W[k] - mx); W[k] = e; acc += (double)e; }
+  for (int k = 0; k < S; ++k) { const float e = expf(WW(k) - mx); WW(k) = e; acc += (double)e; }
   const float esum = (float)acc;
   // cdf in place: C[0] = 0, C[k+1] = min(1, cumsum), C[S] = 1 (stepfun.py:108-128); stored shifted by one in W via a carry
   acc = 0.0;
   float prev = 0.f;                                      // C[k]
   for (int k = 0; k < S; ++k) {
-    const float wk = W[k] / esum;
-    W[k] = prev;                                         // W[k] now holds C[k]
+    const float wk = WW(k) / esum;
+    WW(k) = prev;                                        // now holds C[k]
     acc += (double)wk;
     prev = k == S - 1 ? 1.f : fminf(1.f, (float)acc);
   }
-  W[S] = 1.f;
+  WW(S) = 1.f;
   // invert the cdf at the n centres, build the n+1 fence posts and warp them to metric distances
   const float* ur = a.u + ray * a.u_stride;
   const float nr = a.near[ray], fr = a.far[ray];
@@ -119,13 +137,13 @@ __global__ __launch_bounds__(ZIP_LANES) void zip_resample_kernel(ZipResample a) 
   for (int j = 0; j < a.n; ++j) {
     const float uj = ur[j];
     int lo = 0, hi = S + 1;
-    while (lo < hi) { const int m = (lo + hi) >> 1; if (W[m] <= uj) lo = m + 1; else hi = m; }
+    while (lo < hi) { const int m = (lo + hi) >> 1; if (WW(m) <= uj) lo = m + 1; else hi = m; }
     int i0 = lo - 1; i0 = i0 < 0 ? 0 : (i0 > S ? S : i0);
     const int i1 = i0 + 1 > S ? S : i0 + 1;
-    float off = (uj - W[i0]) / (W[i1] - W[i0]);
+    float off = (uj - WW(i0)) / (WW(i1) - WW(i0));
     if (off != off) off = 0.f;
     off = fminf(fmaxf(off, 0.f), 1.f);
-    const float c = T[i0] + off * (T[i1] - T[i0]);
+    const float c = TT(i0) + off * (TT(i1) - TT(i0));
     if (j == 0) c0 = c;
     else {
       const float mid = (c + c_prev) / 2.f;
@@ -137,6 +155,10 @@ __global__ __launch_bounds__(ZIP_LANES) void zip_resample_kernel(ZipResample a) 
   }
   const float last = fminf(2.f * c_prev - mid_last, a.dom1);
   so[a.n] = last; to[a.n] = warp(last);
+#undef Tt
+#undef Ww
+#undef TT
+#undef WW
 }
 
 extern "C" int snerf_zip_resample(const float* sdist, const float* weights, int S0, const float* u, long u_stride, int n,
@@ -145,8 +167,7 @@ extern "C" int snerf_zip_resample(const float* sdist, const float* weights, int 
                                   void* stream) {
   if (R <= 0) return SNERF_OK;
   if (S0 < 1 || n < 2 || (dilate && S0 < 2)) return SNERF_ERR_ARG;
-  const int stride = (3 * S0 + 2) | 1;
-  const size_t lds = (size_t)ZIP_LANES * 2 * stride * sizeof(float);
+  const size_t lds = (size_t)ZIP_LANES * (2 * (3 * S0 + 2) + 2 * S0 + 1) * sizeof(float);
   if (lds > 160 * 1024) return SNERF_ERR_ARG;
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)zip_resample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }

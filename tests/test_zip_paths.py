@@ -333,3 +333,54 @@ def test_zip_percentiles_kernel_vs_oracle(R, S):
     assert got.shape == (R, 5)
     close(got, ref, 2e-5, 1e-6, "percentiles")
     assert torch.equal(got[0], far[0].expand(5) * 0 + got[0]) and bool((got[0] >= t[0, -1]).all())      # empty ray: between the last post and t_far
+
+
+def _resample_case(R, S0, n, seed, dilate):
+    g = torch.Generator().manual_seed(seed)
+    if S0 == 1:
+        sd = torch.cat([torch.zeros(R, 1), torch.ones(R, 1)], -1)
+        w = torch.ones(R, 1)
+    else:
+        sd = torch.sort(torch.rand(R, S0 + 1, generator=g), -1).values
+        sd[:, 0], sd[:, -1] = 0.0, 1.0
+        w = torch.rand(R, S0, generator=g) ** 5
+        w = w / w.sum(-1, keepdim=True) * torch.rand(R, 1, generator=g)
+        w[0] = 0.0                                              # an empty ray: uniform after the padding
+        w[1, : S0 // 2] = 0.0                                   # a dead stretch
+        if S0 > 8:
+            sd[2, 5] = sd[2, 4]                                 # a zero-width interval (logit -inf)
+        if S0 > 8 and R > 3:
+            sd[3, 1:4] = sd[3, 1]                               # three coincident posts
+    pad = 1 / (2 * n)
+    u_det = torch.linspace(pad, 1. - pad - 1.1920929e-07, n)
+    u_max = 1.1920929e-07 + (1 - 1.1920929e-07) / n
+    u_rnd = (torch.linspace(0, 1 - u_max, n) + torch.rand(R, 1, generator=g) * ((1 - u_max) / (n - 1) - 1.1920929e-07)).contiguous()
+    near, far = torch.rand(R, generator=g) * 0.3 + 0.05, torch.rand(R, generator=g) * 20 + 5
+    return sd, w, u_det, u_rnd, near, far
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,S0,n,dilate,dilation", [(777, 1, 64, False, 0.0), (1031, 64, 64, True, 0.0025 + 0.5 / 64), (515, 64, 32, True, 0.0025 + 0.5 / 4096),
+                                                      (70, 7, 5, True, 0.05), (64, 33, 64, False, 0.0), (3, 64, 64, True, 0.4)])
+def test_zip_resample_kernel_vs_oracle(R, S0, n, dilate, dilation):
+    """Stage-isolated C2 + C3 (max_dilate_weights, annealed softmax, inverse-CDF sampling, fence posts, power warp) through the C-ABI
+    against oracle/zip.py (pinned by G10): the three level shapes of waymo.gin, odd sizes, a dilation wider than the intervals, with
+    empty rays, dead stretches, zero-width intervals and coincident posts; deterministic centres and per-ray jitter."""
+    from snerf_amd import ops
+    import cpu_ops_emulation as emu
+    sd, w, u_det, u_rnd, near, far = _resample_case(R, S0, n, R + S0, dilate)
+    for u in (u_det, u_rnd):
+        for anneal, pad in ((1.0, 0.0), (0.37, 0.01)):
+            ref_s, ref_t = emu.zip_resample(sd, w, u, n, near, far, dilation, dilate, anneal, pad, -1.5)
+            got_s, got_t = ops.zip_resample(sd.cuda(), w.cuda(), u.cuda(), n, near.cuda(), far.cuda(), dilation, dilate, anneal, pad, -1.5)
+            got_s, got_t = got_s.cpu(), got_t.cpu()
+            assert bool(torch.isfinite(got_s).all()) and bool((got_s[:, 1:] >= got_s[:, :-1]).all()) and bool((got_s >= 0).all()) and bool((got_s <= 1).all())
+            if pad > 0:
+                close(got_s, ref_s, 2e-5, 2e-6, "sdist")
+                close(got_t, ref_t, 2e-4, 1e-5, "tdist")
+            else:
+                # without the padding the inverse CDF is ill-conditioned where the histogram is empty: a centre that falls on a
+                # stretch with ~1e-15 of the mass divides two rounding errors ((u - c0) / (c1 - c0)), and an all-zero ray (row 0)
+                # has no defined answer in the reference either (softmax of all -inf).  Everything else must agree.
+                ok = ((got_s - ref_s).abs() <= 2e-6 + 2e-5 * ref_s.abs())[1:] if S0 > 1 else ((got_s - ref_s).abs() <= 2e-6 + 2e-5 * ref_s.abs())
+                assert float(ok.float().mean()) > 0.998, float(ok.float().mean())
