@@ -38,127 +38,153 @@ struct ZipResample {
   float* sdist_out; float* tdist_out;
 };
 
-__global__ __launch_bounds__(ZIP_LANES) void zip_resample_kernel(ZipResample a) {
-  // LDS, all arrays element-major ([k][lane]: conflict-free for a lane-per-ray walk): the input posts t and pdf p staged with
-  // coalesced loads, then the working posts T and weights / cdf W.  The serial per-ray walks below touch LDS only.
+#define ZR_WAVES 4
+__device__ __forceinline__ double zr_wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double zr_wave_scan(double v, int lane) {     // inclusive prefix sum over the 64 lanes
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const double u = __shfl_up(v, o, 64); if (lane >= o) v += u; }
+  return v;
+}
+
+// One wave per ray, four rays per workgroup: every stage of C2 + C3 is a data-parallel pass over the <= 3*S0+1 posts, staged in a
+// per-wave LDS region (2.3 KB at S0 = n = 64, so the LDS no longer limits the occupancy as it did for the lane-per-ray walk):
+//   merge of the three sorted post lists {t}, {t - d}, {t + d}  -> rank of every element by binary searches (ties: t - d, t, t + d,
+//                                                                   the order of the sequential merge)
+//   dilated pdf (max over the intervals whose dilated support covers the post) -> the covering range by two binary searches
+//   normalisation / softmax / cdf                                 -> float64 wave reductions and scans, one rounding per value
+//   inverse cdf at the n centres, fence posts, power warp          -> one lane per centre, coalesced stores
+__global__ __launch_bounds__(64 * ZR_WAVES) void zip_resample_kernel(ZipResample a) {
   extern __shared__ float lds[];
-  const int cap = 3 * a.S0 + 2;
-  const int lane = threadIdx.x;
-  float* t = lds;                                        // [(S0+1)][LANES]
-  float* w = t + (size_t)(a.S0 + 1) * ZIP_LANES;         // [S0][LANES]: pdf of the input step function when dilating, else weights
-  float* T = w + (size_t)a.S0 * ZIP_LANES;               // [cap][LANES] posts
-  float* W = T + (size_t)cap * ZIP_LANES;                // [cap][LANES] weights -> cdf
-  const long ray0 = (long)blockIdx.x * ZIP_LANES;
-  const long nray = min((long)ZIP_LANES, a.R - ray0);
-  const float eps = 1.1920929e-07f;
-  {
-    const float* gt = a.sdist + ray0 * (a.S0 + 1);
-    const long nt = nray * (a.S0 + 1);
-    for (long i = lane; i < nt; i += ZIP_LANES) { const int r = (int)(i / (a.S0 + 1)), k = (int)(i - (long)r * (a.S0 + 1)); t[k * ZIP_LANES + r] = gt[i]; }
-    const float* gw = a.weights + ray0 * a.S0;
-    const long nw = nray * a.S0;
-    for (long i = lane; i < nw; i += ZIP_LANES) { const int r = (int)(i / a.S0), k = (int)(i - (long)r * a.S0); w[k * ZIP_LANES + r] = gw[i]; }
-  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int S0 = a.S0, NPmax = 3 * S0 + 2;
+  const int per_wave = (S0 + 1) + S0 + 2 * NPmax + a.n;
+  float* t = lds + (size_t)wv * per_wave;               // [S0+1] input posts
+  float* pdf = t + (S0 + 1);                            // [S0]   input weights (-> pdf when dilating)
+  float* Tm = pdf + S0;                                 // [NPmax] merged posts
+  float* Wm = Tm + NPmax;                               // [NPmax] dilated weights -> cdf
+  float* cb = Wm + NPmax;                               // [n]    sampled centres
+  long ray = (long)blockIdx.x * ZR_WAVES + wv;
+  const bool live = ray < a.R;
+  if (!live) ray = a.R - 1;                             // keeps the barriers uniform; nothing is stored
+  const float eps = 1.1920929e-07f, d = a.dilation;
+  const float* gt = a.sdist + ray * (S0 + 1);
+  const float* gw = a.weights + ray * S0;
+  for (int k = lane; k <= S0; k += 64) t[k] = gt[k];
+  for (int k = lane; k < S0; k += 64) pdf[k] = gw[k];
   __syncthreads();
-  const long ray = ray0 + lane;
-  if (ray >= a.R) return;
-#define Tt(k) t[(k) * ZIP_LANES + lane]
-#define Ww(k) w[(k) * ZIP_LANES + lane]
-#define TT(k) T[(k) * ZIP_LANES + lane]
-#define WW(k) W[(k) * ZIP_LANES + lane]
-  int S;                                                  // intervals of the step function that gets sampled
+  const float* T;                                       // posts of the step function that gets sampled
+  float* W;                                             // its weights, later its cdf
+  int S;
   if (a.dilate) {
-    // merged, clipped posts of the three sorted sequences t, t - d (t0), t + d (t1)
-    const int S0 = a.S0, NP = 3 * S0 + 1;
-    int ia = 0, ib = 0, ic = 0;
-    float va = Tt(0), vb = Tt(0) - a.dilation, vc = Tt(1) + a.dilation;
-    for (int k = 0; k < NP; ++k) {
-      float v;
-      if (vb <= va && vb <= vc) { v = vb; ++ib; vb = ib < S0 ? Tt(ib) - a.dilation : INFINITY; }
-      else if (va <= vc) { v = va; ++ia; va = ia <= S0 ? Tt(ia) : INFINITY; }
-      else { v = vc; ++ic; vc = ic < S0 ? Tt(ic + 1) + a.dilation : INFINITY; }
-      TT(k) = fminf(fmaxf(v, a.dom0), a.dom1);
+    const int NP = 3 * S0 + 1;
+    // #{j : list_j (<= | <) x} for the three monotone lists A = t (S0+1 entries), B = t[:-1] - d, C = t[1:] + d (S0 entries each)
+    auto cntA = [&](float x, bool le) __attribute__((always_inline)) { int lo = 0, hi = S0 + 1; while (lo < hi) { const int m = (lo + hi) >> 1; const float v = t[m]; if (le ? v <= x : v < x) lo = m + 1; else hi = m; } return lo; };
+    auto cntB = [&](float x, bool le) __attribute__((always_inline)) { int lo = 0, hi = S0; while (lo < hi) { const int m = (lo + hi) >> 1; const float v = t[m] - d; if (le ? v <= x : v < x) lo = m + 1; else hi = m; } return lo; };
+    auto cntC = [&](float x, bool le) __attribute__((always_inline)) { int lo = 0, hi = S0; while (lo < hi) { const int m = (lo + hi) >> 1; const float v = t[m + 1] + d; if (le ? v <= x : v < x) lo = m + 1; else hi = m; } return lo; };
+    for (int e = lane; e < NP; e += 64) {
+      float v; int rank;
+      if (e <= S0) { v = t[e]; rank = e + cntB(v, true) + cntC(v, false); }
+      else if (e <= 2 * S0) { const int i = e - S0 - 1; v = t[i] - d; rank = i + cntA(v, false) + cntC(v, false); }
+      else { const int i = e - 2 * S0 - 1; v = t[i + 1] + d; rank = i + cntA(v, true) + cntB(v, true); }
+      Tm[rank] = fminf(fmaxf(v, a.dom0), a.dom1);
     }
-    for (int i = 0; i < S0; ++i) Ww(i) = Ww(i) / fmaxf(Tt(i + 1) - Tt(i), eps);      // pdf of the input intervals
-    // dilated pdf = max over the intervals i with t0_i <= T_k < t1_i (a contiguous, monotonically moving range)
-    int lo = 0, hi = -1;
-    float sum = 0.f;
-    float tk = TT(0);
-    for (int k = 0; k < NP - 1; ++k) {
-      while (lo < S0 && !(Tt(lo + 1) + a.dilation > tk)) ++lo;
-      while (hi + 1 < S0 && Tt(hi + 1) - a.dilation <= tk) ++hi;
+    __syncthreads();
+    float wkeep[4];                                      // this lane's w / pdf values stay in registers across the in-place update
+    {
+      int c = 0;
+      for (int k = lane; k < S0; k += 64) wkeep[c++ & 3] = pdf[k] / fmaxf(t[k + 1] - t[k], eps);
+      __syncthreads();
+      c = 0;
+      for (int k = lane; k < S0; k += 64) pdf[k] = wkeep[c++ & 3];
+    }
+    __syncthreads();
+    double part = 0.0;
+    for (int k = lane; k < NP - 1; k += 64) {
+      const float tk = Tm[k];
+      const int lo = cntC(tk, true), hi = cntB(tk, true) - 1;
       float p = 0.f;
       for (int i = lo; i <= hi; ++i)
-        if (Tt(i) - a.dilation <= tk && Tt(i + 1) + a.dilation > tk) p = fmaxf(p, Ww(i));
-      const float tn = TT(k + 1);
-      const float wd = p * (tn - tk);
-      WW(k) = wd;
-      sum += wd;
-      tk = tn;
+        if (t[i] - d <= tk && t[i + 1] + d > tk) p = fmaxf(p, pdf[i]);
+      const float wd = p * (Tm[k + 1] - tk);
+      Wm[k] = wd;
+      part += (double)wd;
     }
-    sum = fmaxf(sum, eps);
+    const float sum = fmaxf((float)zr_wave_sum(part), eps);
+    __syncthreads();
     // caller trims [1:-1] (models.py:187-188): posts 1 .. NP-2, intervals 1 .. NP-3
     S = NP - 3;
-    for (int k = 0; k < S; ++k) WW(k) = WW(k + 1) / sum;
-    for (int k = 0; k <= S; ++k) TT(k) = TT(k + 1);
+    T = Tm + 1;
+    W = Wm + 1;
+    for (int k = lane; k < S; k += 64) W[k] = W[k] / sum;
+    __syncthreads();
   } else {
-    S = a.S0;
-    for (int k = 0; k <= S; ++k) TT(k) = Tt(k);
-    for (int k = 0; k < S; ++k) WW(k) = Ww(k);
+    S = S0;
+    T = t;
+    W = pdf;
   }
-  // annealed logits + softmax (models.py:196-203, stepfun.py:157)
+  // annealed logits + softmax (models.py:196-203, stepfun.py:157); S <= 4 * 64
+  float lg[4];
   float mx = -INFINITY;
-  for (int k = 0; k < S; ++k) {
-    const float l = TT(k + 1) > TT(k) ? a.anneal * logf(WW(k) + a.pad) : -INFINITY;
-    WW(k) = l;
-    mx = fmaxf(mx, l);
+  {
+    int c = 0;
+    for (int k = lane; k < S; k += 64) { const float l = T[k + 1] > T[k] ? a.anneal * logf(W[k] + a.pad) : -INFINITY; lg[c++ & 3] = l; mx = fmaxf(mx, l); }
   }
-  double acc = 0.0;
-  for (int k = 0; k < S; ++k) { const float e = expf(WW(k) - mx); WW(k) = e; acc += (double)e; }
-  const float esum = (float)acc;
-  // cdf in place: C[0] = 0, C[k+1] = min(1, cumsum), C[S] = 1 (stepfun.py:108-128); stored shifted by one in W via a carry
-  acc = 0.0;
-  float prev = 0.f;                                      // C[k]
-  for (int k = 0; k < S; ++k) {
-    const float wk = WW(k) / esum;
-    WW(k) = prev;                                        // now holds C[k]
-    acc += (double)wk;
-    prev = k == S - 1 ? 1.f : fminf(1.f, (float)acc);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  double part = 0.0;
+  {
+    int c = 0;
+    for (int k = lane; k < S; k += 64) { const float e = expf(lg[c & 3] - mx); lg[c++ & 3] = e; part += (double)e; }
   }
-  WW(S) = 1.f;
-  // invert the cdf at the n centres, build the n+1 fence posts and warp them to metric distances
+  const float esum = (float)zr_wave_sum(part);
+  __syncthreads();
+  // cdf in place: C[0] = 0, C[k+1] = min(1, cumsum), C[S] = 1 (stepfun.py:108-128), stored as W[k] = C[k], k = 0 .. S
+  {
+    double carry = 0.0;
+    int c = 0;
+    for (int k0 = 0; k0 < S; k0 += 64) {
+      const int k = k0 + lane;
+      const double v = k < S ? (double)(lg[c++ & 3] / esum) : 0.0;
+      const double inc = zr_wave_scan(v, lane) + carry;
+      if (k < S) W[k + 1] = k == S - 1 ? 1.f : fminf(1.f, (float)inc);
+      carry = __shfl(inc, 63, 64);
+    }
+    if (lane == 0) W[0] = 0.f;
+  }
+  __syncthreads();
+  // invert the cdf at the n centres
   const float* ur = a.u + ray * a.u_stride;
-  const float nr = a.near[ray], fr = a.far[ray];
-  const float s_near = zip_pow_t(nr * 2.f, a.lam), s_far = zip_pow_t(fr * 2.f, a.lam);
-  float* so = a.sdist_out + ray * (a.n + 1);
-  float* to = a.tdist_out + ray * (a.n + 1);
-  auto warp = [&](float s) { return zip_inv_pow_t(s * s_far + (1.f - s) * s_near, a.lam) / 2.f; };
-  float c_prev = 0.f, c0 = 0.f, mid_last = 0.f;
-  for (int j = 0; j < a.n; ++j) {
+  for (int j = lane; j < a.n; j += 64) {
     const float uj = ur[j];
     int lo = 0, hi = S + 1;
-    while (lo < hi) { const int m = (lo + hi) >> 1; if (WW(m) <= uj) lo = m + 1; else hi = m; }
+    while (lo < hi) { const int m = (lo + hi) >> 1; if (W[m] <= uj) lo = m + 1; else hi = m; }
     int i0 = lo - 1; i0 = i0 < 0 ? 0 : (i0 > S ? S : i0);
     const int i1 = i0 + 1 > S ? S : i0 + 1;
-    float off = (uj - WW(i0)) / (WW(i1) - WW(i0));
+    float off = (uj - W[i0]) / (W[i1] - W[i0]);
     if (off != off) off = 0.f;
     off = fminf(fmaxf(off, 0.f), 1.f);
-    const float c = TT(i0) + off * (TT(i1) - TT(i0));
-    if (j == 0) c0 = c;
-    else {
-      const float mid = (c + c_prev) / 2.f;
-      if (j == 1) { const float first = fmaxf(2.f * c0 - mid, a.dom0); so[0] = first; to[0] = warp(first); }
-      so[j] = mid; to[j] = warp(mid);
-      mid_last = mid;
-    }
-    c_prev = c;
+    cb[j] = T[i0] + off * (T[i1] - T[i0]);
   }
-  const float last = fminf(2.f * c_prev - mid_last, a.dom1);
-  so[a.n] = last; to[a.n] = warp(last);
-#undef Tt
-#undef Ww
-#undef TT
-#undef WW
+  __syncthreads();
+  // fence posts = midpoints, end posts reflected and clamped (stepfun.py:281-294), warped to metric distances
+  if (live) {
+    const float nr = a.near[ray], fr = a.far[ray];
+    const float s_near = zip_pow_t(nr * 2.f, a.lam), s_far = zip_pow_t(fr * 2.f, a.lam);
+    float* so = a.sdist_out + ray * (a.n + 1);
+    float* to = a.tdist_out + ray * (a.n + 1);
+    for (int j = lane; j <= a.n; j += 64) {
+      float s;
+      if (j == 0) s = fmaxf(2.f * cb[0] - (cb[1] + cb[0]) / 2.f, a.dom0);
+      else if (j == a.n) s = fminf(2.f * cb[a.n - 1] - (cb[a.n - 1] + cb[a.n - 2]) / 2.f, a.dom1);
+      else s = (cb[j] + cb[j - 1]) / 2.f;
+      so[j] = s;
+      to[j] = zip_inv_pow_t(s * s_far + (1.f - s) * s_near, a.lam) / 2.f;
+    }
+  }
 }
 
 extern "C" int snerf_zip_resample(const float* sdist, const float* weights, int S0, const float* u, long u_stride, int n,
@@ -167,12 +193,11 @@ extern "C" int snerf_zip_resample(const float* sdist, const float* weights, int 
                                   void* stream) {
   if (R <= 0) return SNERF_OK;
   if (S0 < 1 || n < 2 || (dilate && S0 < 2)) return SNERF_ERR_ARG;
-  const size_t lds = (size_t)ZIP_LANES * (2 * (3 * S0 + 2) + 2 * S0 + 1) * sizeof(float);
-  if (lds > 160 * 1024) return SNERF_ERR_ARG;
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)zip_resample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  if ((dilate ? 3 * S0 - 2 : S0) > 256) return SNERF_ERR_ARG;                 // per-lane register slots: 4 x 64 intervals
+  const size_t lds = (size_t)ZR_WAVES * ((S0 + 1) + S0 + 2 * (3 * S0 + 2) + n) * sizeof(float);
+  if (lds > 64 * 1024) return SNERF_ERR_ARG;
   ZipResample a{sdist, weights, S0, u, u_stride, n, near, far, R, dilation, dilate, anneal, resample_padding, lam, dom0, dom1, sdist_out, tdist_out};
-  hipLaunchKernelGGL(zip_resample_kernel, dim3((unsigned)((R + ZIP_LANES - 1) / ZIP_LANES)), dim3(ZIP_LANES), lds, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(zip_resample_kernel, dim3((unsigned)((R + ZR_WAVES - 1) / ZR_WAVES)), dim3(64 * ZR_WAVES), lds, (hipStream_t)stream, a);
   return snerf_check_launch();
 }
 
