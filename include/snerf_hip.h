@@ -156,11 +156,13 @@ int snerf_zip_resample(const float* sdist, const float* weights, int S0, const f
 /* render.cast_rays (render.py:129-168; n multisamples on an m-turn helix, deg_jitter [R,S,n] or NULL) + coord.contract_mean_std
  * (coord.py:51-63) + /2 + GridEncoder forward (gridencoder.cu:87-245, hash type, linear) + erf down-weighting and mean over
  * the multisamples (models.py:488-497) -> feat [R*S, ld] (columns level*C + c; feat_dtype fp32/bf16).  table fp32 or fp16
- * (SNERF_DT_F16); grid_sizes = GridEncoder.grid_sizes; Sl = log2(per_level_scale). */
+ * (SNERF_DT_F16); grid_sizes = GridEncoder.grid_sizes; Sl = log2(per_level_scale).  levels_per_thread: 0 / 1 = one thread per
+ * (interval, level) (best for scattered training rays: most gathers in flight); L = one thread per interval evaluates its multisamples
+ * once for all levels (best for the coherent rays of a frame); values in between group the levels.  Same results. */
 int snerf_zip_encode_fwd(const float* tdist, const float* origins, const float* directions, const float* radii,
                          const float* base_x, const float* base_y, const float* deg_jitter, const void* table,
                          const int* offsets, const int* grid_sizes, void* feat, long ld, long R, int S, int L, int C, int n,
-                         int m, float Sl, int H, float std_scale, int table_dtype, int feat_dtype, void* stream);
+                         int m, float Sl, int H, float std_scale, int table_dtype, int feat_dtype, int levels_per_thread, void* stream);
 /* matching scatter-add of grad_feat [R*S, ld] into the fp32 table gradient (gridencoder.cu:248-340 composed with the mean /
  * erf weights); grad_table accumulates (fp32 atomics).  The first `lds_levels` levels (small dense tables) are accumulated
  * in LDS by persistent workgroups, in slabs of `lds_cells` rows (lds_cells*C*4 <= 160 KB; lds_slabs = sum of

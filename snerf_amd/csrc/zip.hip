@@ -321,6 +321,7 @@ __device__ __forceinline__ void zip_point_level(const ZipEnc& a, long p, int lev
       wsum[idx] = 0.f;
     }
   };
+  float pair_acc[8];
   for (int j = 0; j < a.n; ++j) {
     float x01[3], sd;
     zip_sample_point(a, ray, i, j, t0, t1, o, d, bx, by, rad, x01, &sd);
@@ -341,6 +342,40 @@ __device__ __forceinline__ void zip_point_level(const ZipEnc& a, long p, int lev
       flush();
       cur[0] = pg[0]; cur[1] = pg[1]; cur[2] = pg[2];
     }
+    if constexpr (MODE == 0 && C == 1 && sizeof(TT) == 2) {
+      // single-channel 2-byte tables (the proposal grids): the two x-neighbours of a corner pair are adjacent entries whenever their
+      // rows differ only in bit 0 -- always for an even row of a dense level, and for every even x of a hashed level (the hash
+      // multiplies x by 1, so x ^ 1 flips bit 0 of the row and nothing else) -- and then ONE aligned 32-bit load serves both.
+      // The gathers are request-bound, not byte-bound: a quarter fewer requests.
+#pragma unroll
+      for (int yz = 0; yz < 4; ++yz) {
+        uint32_t pl[3] = {pg[0], pg[1] + (yz & 1), pg[2] + (yz >> 1)};
+        const float wyz = ((yz & 1) ? fr[1] : 1.f - fr[1]) * ((yz >> 1) ? fr[2] : 1.f - fr[2]);
+        const long r0 = zip_grid_index(hs, res, pl);
+        pl[0] = pg[0] + 1;
+        const long r1 = zip_grid_index(hs, res, pl);
+        float v0, v1;
+        if ((r0 ^ r1) == 1) {
+          const uint32_t word = *reinterpret_cast<const uint32_t*>(tab + (r0 & ~1L));
+          const uint16_t lo16 = (uint16_t)(word & 0xffffu), hi16 = (uint16_t)(word >> 16);
+          const uint16_t b0 = (r0 & 1) ? hi16 : lo16, b1 = (r0 & 1) ? lo16 : hi16;
+          v0 = (float)__builtin_bit_cast(TT, b0);
+          v1 = (float)__builtin_bit_cast(TT, b1);
+        } else {
+          v0 = (float)tab[r0];
+          v1 = (float)tab[r1];
+        }
+        // same products, same order as the generic loop below (corner index = x + 2 y + 4 z)
+        float wa = 1.f - fr[0], wb = fr[0];
+        wa *= (yz & 1) ? fr[1] : 1.f - fr[1]; wb *= (yz & 1) ? fr[1] : 1.f - fr[1];
+        wa *= (yz >> 1) ? fr[2] : 1.f - fr[2]; wb *= (yz >> 1) ? fr[2] : 1.f - fr[2];
+        (void)wyz;
+        pair_acc[2 * yz] = (wa * we) * v0;
+        pair_acc[2 * yz + 1] = (wb * we) * v1;
+      }
+#pragma unroll
+      for (int idx = 0; idx < 8; ++idx) acc[0] += pair_acc[idx];
+    } else {
 #pragma unroll
     for (int idx = 0; idx < 8; ++idx) {
       float w = 1.f;
@@ -358,6 +393,7 @@ __device__ __forceinline__ void zip_point_level(const ZipEnc& a, long p, int lev
         wsum[idx] += w * we;
       }
     }
+    }
   }
   if (MODE == 0) {
     OT* out = (OT*)a.feat + p * a.ld + level * C;
@@ -373,6 +409,104 @@ __global__ __launch_bounds__(256) void zip_encode_kernel(ZipEnc a) {
   const long p = (long)blockIdx.x * 256 + threadIdx.x;
   if (p >= a.R * a.S) return;
   zip_point_level<TT, OT, C, BWD ? 1 : 0>(a, p, blockIdx.y + a.level_begin, nullptr);
+}
+
+// Forward featurisation, one thread per interval for ALL levels: the n <= 8 helix multisamples (sincos, contraction, cbrt) are
+// evaluated once and kept in registers instead of once per (interval, level) as in the per-level grid above -- for the
+// single-channel proposal grids that arithmetic, not the gathers, was the larger half of the kernel.
+template <typename TT, typename OT, int C>
+__global__ __launch_bounds__(256) void zip_encode_fwd_all_kernel(ZipEnc a) {
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= a.R * a.S) return;
+  const long ray = p / a.S;
+  const int i = (int)(p - ray * a.S);
+  const float t0 = a.tdist[ray * (a.S + 1) + i], t1 = a.tdist[ray * (a.S + 1) + i + 1];
+  float o[3], d[3], bx[3], by[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { o[k] = a.origins[ray * 3 + k]; d[k] = a.directions[ray * 3 + k]; bx[k] = a.base_x[ray * 3 + k]; by[k] = a.base_y[ray * 3 + k]; }
+  const float rad = a.radii[ray];
+  float X[8][3], SDI[8];                                 // positions in [0,1]^3 and 1 / (sqrt(8) std) per multisample
+  unsigned inb = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (j < a.n) {
+      float sd;
+      zip_sample_point(a, ray, i, j, t0, t1, o, d, bx, by, rad, X[j], &sd);
+      SDI[j] = sd;
+      if (!(X[j][0] < 0.f || X[j][0] > 1.f || X[j][1] < 0.f || X[j][1] > 1.f || X[j][2] < 0.f || X[j][2] > 1.f)) inb |= 1u << j;
+    }
+  }
+  OT* out = (OT*)a.feat + p * a.ld;
+  const int lend = min(a.L, (int)(blockIdx.y + 1) * a.level_begin);       // level_begin = levels per thread in this kernel
+  for (int level = blockIdx.y * a.level_begin; level < lend; ++level) {
+    const uint32_t hs = a.offsets[level + 1] - a.offsets[level];
+    const float scale = exp2f(level * a.Sl) * a.H - 1.0f;
+    const uint32_t res = (uint32_t)ceilf(scale) + 1;
+    const TT* tab = (const TT*)a.table + (long)a.offsets[level] * C;
+    const float gs = (float)a.grid_sizes[level];
+    float acc[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j >= a.n || !((inb >> j) & 1u)) continue;     // outside [0,1]^3 the encoder returns zeros
+      const float sd = SDI[j];
+      const float we = erff(1.f / sqrtf(8.f * sd * sd * gs * gs));
+      float fr[3];
+      uint32_t pg[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float ps = X[j][k] * scale + 0.5f;
+        const float fl = floorf(ps);
+        pg[k] = (uint32_t)fl;
+        fr[k] = ps - fl;
+      }
+      if constexpr (C == 1 && sizeof(TT) == 2) {
+        float pa[8];
+#pragma unroll
+        for (int yz = 0; yz < 4; ++yz) {
+          uint32_t pl[3] = {pg[0], pg[1] + (yz & 1), pg[2] + (yz >> 1)};
+          const long r0 = zip_grid_index(hs, res, pl);
+          pl[0] = pg[0] + 1;
+          const long r1 = zip_grid_index(hs, res, pl);
+          float v0, v1;
+          if ((r0 ^ r1) == 1) {                           // adjacent entries of one aligned 32-bit word (see zip_point_level)
+            const uint32_t word = *reinterpret_cast<const uint32_t*>(tab + (r0 & ~1L));
+            const uint16_t lo16 = (uint16_t)(word & 0xffffu), hi16 = (uint16_t)(word >> 16);
+            const uint16_t b0 = (r0 & 1) ? hi16 : lo16, b1 = (r0 & 1) ? lo16 : hi16;
+            v0 = (float)__builtin_bit_cast(TT, b0);
+            v1 = (float)__builtin_bit_cast(TT, b1);
+          } else {
+            v0 = (float)tab[r0];
+            v1 = (float)tab[r1];
+          }
+          float wa = 1.f - fr[0], wb = fr[0];
+          wa *= (yz & 1) ? fr[1] : 1.f - fr[1]; wb *= (yz & 1) ? fr[1] : 1.f - fr[1];
+          wa *= (yz >> 1) ? fr[2] : 1.f - fr[2]; wb *= (yz >> 1) ? fr[2] : 1.f - fr[2];
+          pa[2 * yz] = (wa * we) * v0;
+          pa[2 * yz + 1] = (wb * we) * v1;
+        }
+#pragma unroll
+        for (int idx = 0; idx < 8; ++idx) acc[0] += pa[idx];
+      } else {
+#pragma unroll
+        for (int idx = 0; idx < 8; ++idx) {
+          float w = 1.f;
+          uint32_t pl[3];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            if (idx & (1 << k)) { w *= fr[k]; pl[k] = pg[k] + 1; } else { w *= 1.f - fr[k]; pl[k] = pg[k]; }
+          }
+          const long row = zip_grid_index(hs, res, pl);
+          const ZVec<TT, C> r = *reinterpret_cast<const ZVec<TT, C>*>(tab + row * C);
+#pragma unroll
+          for (int c = 0; c < C; ++c) acc[c] += (w * we) * (float)r.v[c];
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) out[level * C + c] = (OT)(acc[c] / (float)a.n);
+  }
 }
 
 template <typename OT, int C>
@@ -420,6 +554,19 @@ static int zip_enc_launch(ZipEnc a, int C, int lds_levels, size_t lds_bytes, int
       default: return SNERF_ERR_ARG;
     }
   }
+  if (!BWD && a.n <= 8) {
+    const int lpt = a.level_begin > 0 ? min(a.level_begin, a.L) : 1;        // levels per thread (the caller's locality hint)
+    a.level_begin = lpt;
+    const dim3 grid((unsigned)((a.R * a.S + 255) / 256), (a.L + lpt - 1) / lpt);
+    switch (C) {
+      case 1: hipLaunchKernelGGL((zip_encode_fwd_all_kernel<TT, OT, 1>), grid, blk, 0, s, a); break;
+      case 2: hipLaunchKernelGGL((zip_encode_fwd_all_kernel<TT, OT, 2>), grid, blk, 0, s, a); break;
+      case 4: hipLaunchKernelGGL((zip_encode_fwd_all_kernel<TT, OT, 4>), grid, blk, 0, s, a); break;
+      case 8: hipLaunchKernelGGL((zip_encode_fwd_all_kernel<TT, OT, 8>), grid, blk, 0, s, a); break;
+      default: return SNERF_ERR_ARG;
+    }
+    return snerf_check_launch();
+  }
   a.level_begin = BWD ? lds_levels : 0;
   const int nl = a.L - a.level_begin;
   if (nl > 0) {
@@ -447,10 +594,11 @@ static int zip_enc_dispatch(const ZipEnc& a, int C, int table_dtype, int feat_dt
 extern "C" int snerf_zip_encode_fwd(const float* tdist, const float* origins, const float* directions, const float* radii,
                                     const float* base_x, const float* base_y, const float* deg_jitter, const void* table,
                                     const int* offsets, const int* grid_sizes, void* feat, long ld, long R, int S, int L, int C, int n,
-                                    int m, float Sl, int H, float std_scale, int table_dtype, int feat_dtype, void* stream) {
+                                    int m, float Sl, int H, float std_scale, int table_dtype, int feat_dtype, int levels_per_thread, void* stream) {
   if (R <= 0) return SNERF_OK;
-  if (S <= 0 || L <= 0 || n <= 0 || ld < (long)L * C || table == nullptr || feat == nullptr || grid_sizes == nullptr) return SNERF_ERR_ARG;
+  if (S <= 0 || L <= 0 || n <= 0 || ld < (long)L * C || table == nullptr || feat == nullptr || grid_sizes == nullptr || levels_per_thread < 0) return SNERF_ERR_ARG;
   ZipEnc a{tdist, origins, directions, radii, base_x, base_y, deg_jitter, table, offsets, grid_sizes, feat, ld, nullptr, nullptr, R, S, L, n, m, Sl, H, std_scale};
+  a.level_begin = levels_per_thread;
   return zip_enc_dispatch<false>(a, C, table_dtype, feat_dtype, 0, 0, 0, (hipStream_t)stream);
 }
 

@@ -357,14 +357,15 @@ def _zip_dt(t):
     return {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}[t.dtype]
 
 
-def zip_encode_fwd(tdist, origins, directions, radii, base_x, base_y, deg_jitter, table, offsets, grid_sizes, feat, L, C, n, m, Sl, H, std_scale):
+def zip_encode_fwd(tdist, origins, directions, radii, base_x, base_y, deg_jitter, table, offsets, grid_sizes, feat, L, C, n, m, Sl, H, std_scale,
+                   levels_per_thread=0):
     for t in (tdist, origins, directions, radii, base_x, base_y, deg_jitter):
         _f32c(t)
     R, P = tdist.shape
     assert table.is_contiguous() and offsets.dtype == torch.int32 and grid_sizes.dtype == torch.int32
     _lib.call("snerf_zip_encode_fwd", _p(tdist), _p(origins), _p(directions), _p(radii), _p(base_x), _p(base_y), _p(deg_jitter), _p(table),
               _p(offsets), _p(grid_sizes), _p(feat), feat.stride(0), R, P - 1, L, C, n, m, float(Sl), int(H), float(std_scale), _zip_dt(table),
-              _zip_dt(feat), _stream())
+              _zip_dt(feat), int(levels_per_thread), _stream())
 
 
 def zip_encode_bwd(tdist, origins, directions, radii, base_x, base_y, deg_jitter, offsets, grid_sizes, grad_feat, grad_table, L, C, n, m, Sl, H,

@@ -91,6 +91,7 @@ class Model(_ArenaModule):
                 or self.bg_intensity_range[0] != self.bg_intensity_range[1]):
             raise NotImplementedError("accelerated zipnerf Model: 2 distinct proposal MLPs + NeRF MLP, no GLO / near annealing")
         # semantic head (Config.use_semantic -> NerfMLP.use_semantic, models.py:66,297-305,594-597): 19-class softmax of x[..., 1:20]
+        self.scattered_rays = False      # set True when inference batches are random pixels rather than image rows (a locality hint only)
         self.use_semantic = bool(use_semantic or (config is not None and getattr(config, "use_semantic", False)))
         self.class_num = int(class_num)
         dev = torch.device(device)
@@ -186,8 +187,11 @@ class Model(_ArenaModule):
                 Fb = torch.zeros(P, net.Fw, dtype=net.tdt, device=dev); SB = None
             else:
                 Fb, SB = net.alloc(P)
+            # inference renders frames (coherent rays: evaluate the multisamples once per interval for all levels); training draws
+            # scattered pixels (one thread per level keeps the most gathers in flight)
             ops.zip_encode_fwd(tdist, o, d, radii, bx, by, degj, self._table(lvl), self.dev_offsets[lvl], self.dev_sizes[lvl], Fb, e.L, e.C,
-                               sample_n, sample_m, e.Sl, e.H, self.std_scale)
+                               sample_n, sample_m, e.Sl, e.H, self.std_scale,
+                               levels_per_thread=1 if (keep or self.scattered_rays) else e.L)
             if is_prop:
                 raw_d, saved = net.forward(Fb, keep)
                 raw_rgb = None

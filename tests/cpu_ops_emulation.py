@@ -179,7 +179,8 @@ def _zip_points(tdist, origins, directions, radii, base_x, base_y, deg_jitter, n
     return (z.reshape(*pre, 3) / 2 + 1) / 2, s.reshape(*pre) / 2
 
 
-def zip_encode_fwd(tdist, origins, directions, radii, base_x, base_y, deg_jitter, table, offsets, grid_sizes, feat, L, C, n, m, Sl, H, std_scale):
+def zip_encode_fwd(tdist, origins, directions, radii, base_x, base_y, deg_jitter, table, offsets, grid_sizes, feat, L, C, n, m, Sl, H, std_scale,
+                   levels_per_thread=0):
     from oracle import grid as og
     x01, s = _zip_points(tdist, origins, directions, radii, base_x, base_y, deg_jitter, n, m, std_scale)
     out = og.grid_encode_forward(x01.reshape(-1, 3).numpy().astype("float32"), table.float().numpy(), offsets.numpy(), Sl, H, 0, False, 0)

@@ -384,3 +384,21 @@ def test_zip_resample_kernel_vs_oracle(R, S0, n, dilate, dilation):
                 # has no defined answer in the reference either (softmax of all -inf).  Everything else must agree.
                 ok = ((got_s - ref_s).abs() <= 2e-6 + 2e-5 * ref_s.abs())[1:] if S0 > 1 else ((got_s - ref_s).abs() <= 2e-6 + 2e-5 * ref_s.abs())
                 assert float(ok.float().mean()) > 0.998, float(ok.float().mean())
+
+
+@pytest.mark.gpu
+def test_zip_encode_thread_mappings_agree(golden):
+    """The featurisation kernel's two thread mappings (one thread per (interval, level) for training, one thread per interval over
+    all levels for inference) and the paired 32-bit loads of the single-channel half tables: identical arithmetic, identical bits."""
+    g = golden("g11_zip_model")
+    specs, p = zip_setup()
+    batch = {k[2:]: v.cuda() for k, v in g.items() if k.startswith("b_")}
+    for compute, table in (("f32", "f32"), ("bf16", "f16")):
+        m = make_model(compute, table, p)
+        with torch.no_grad():
+            r_inf, h_inf = m(None, batch, 1.0, False)           # keep = False -> all levels per thread
+        r_trn, h_trn = m(None, batch, 1.0, False)               # parameters require grad -> one level per thread
+        assert r_trn[-1]["rgb"].requires_grad
+        for lvl in range(3):
+            assert torch.equal(h_inf[lvl]["weights"], h_trn[lvl]["weights"].detach()), (compute, lvl)
+        assert torch.equal(r_inf[-1]["rgb"], r_trn[-1]["rgb"].detach())

@@ -72,8 +72,10 @@ def main():
         tr.step(batch, tgt, train_frac=0.5, rand=True, targets=targets)
 
     def fwd_only():
+        m.scattered_rays = True                          # the bench batch is random pixels, not image rows
         with torch.no_grad():
             m(None, batch, 1.0, False)
+        m.scattered_rays = False
 
     for t in range(3):
         train_step(t)
@@ -109,9 +111,9 @@ def main():
     rec = []
     orig = ops.zip_encode_fwd
 
-    def timed(*x):
+    def timed(*x, **k):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); orig(*x); e1.record(); rec.append((e0, e1))
+        e0.record(); orig(*x, **k); e1.record(); rec.append((e0, e1))
     ops.zip_encode_fwd = timed
     fwd_only(); torch.cuda.synchronize()
     ops.zip_encode_fwd = orig
