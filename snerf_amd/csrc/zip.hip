@@ -291,6 +291,35 @@ __device__ __forceinline__ void zip_point_level(const ZipEnc& a, long p, int lev
   for (int idx = 0; idx < 8; ++idx) wsum[idx] = 0.f;
   auto flush = [&]() {
     if (cur[0] == 0xffffffffu) return;
+    if constexpr (C == 1 && MODE == 1) {
+      // single-channel grids with the bf16 gradient table: on the hashed levels the two x-neighbours of a corner pair share one
+      // aligned 32-bit word whenever x is even (see the forward), so ONE packed bf16 atomic carries both; an unpaired corner still
+      // costs one atomic (its value next to a zero).  Dense levels stay in fp32: their cells collect hundreds of addends each.
+      if (a.grad_table16 != nullptr && (uint64_t)(res + 1) * (res + 1) * (res + 1) > (uint64_t)hs) {
+        typedef short s16x2 __attribute__((ext_vector_type(2)));
+        typedef __bf16 b16x2 __attribute__((ext_vector_type(2)));
+        short* dst = (short*)a.grad_table16 + (long)a.offsets[level];
+        auto add2 = [&](long base, float lo, float hi) __attribute__((always_inline)) {
+          const b16x2 v = {(__bf16)lo, (__bf16)hi};
+          __builtin_amdgcn_global_atomic_fadd_v2bf16((__attribute__((address_space(1))) s16x2*)(dst + base), __builtin_bit_cast(s16x2, v));
+        };
+#pragma unroll
+        for (int yz = 0; yz < 4; ++yz) {
+          uint32_t pl[3] = {cur[0], cur[1] + (yz & 1), cur[2] + (yz >> 1)};
+          const long r0 = zip_grid_index(hs, res, pl);
+          pl[0] = cur[0] + 1;
+          const long r1 = zip_grid_index(hs, res, pl);
+          const float v0 = wsum[2 * yz] * g[0], v1 = wsum[2 * yz + 1] * g[0];
+          if ((r0 ^ r1) == 1) add2(r0 & ~1L, (r0 & 1) ? v1 : v0, (r0 & 1) ? v0 : v1);
+          else {
+            add2(r0 & ~1L, (r0 & 1) ? 0.f : v0, (r0 & 1) ? v0 : 0.f);
+            add2(r1 & ~1L, (r1 & 1) ? 0.f : v1, (r1 & 1) ? v1 : 0.f);
+          }
+          wsum[2 * yz] = 0.f; wsum[2 * yz + 1] = 0.f;
+        }
+        return;
+      }
+    }
 #pragma unroll
     for (int idx = 0; idx < 8; ++idx) {
       uint32_t pl[3];
@@ -609,7 +638,7 @@ extern "C" int snerf_zip_encode_bwd(const float* tdist, const float* origins, co
                                     int lds_slabs, void* grad_table_bf16, void* stream) {
   if (R <= 0) return SNERF_OK;
   if (S <= 0 || L <= 0 || n <= 0 || ld < (long)L * C || grad_feat == nullptr || grad_table == nullptr || grid_sizes == nullptr) return SNERF_ERR_ARG;
-  if (grad_table_bf16 != nullptr && (C % 2 != 0 || ((uintptr_t)grad_table_bf16) % 4 != 0)) return SNERF_ERR_ARG;
+  if (grad_table_bf16 != nullptr && ((C % 2 != 0 && C != 1) || ((uintptr_t)grad_table_bf16) % 4 != 0)) return SNERF_ERR_ARG;
   ZipEnc a{tdist, origins, directions, radii, base_x, base_y, deg_jitter, nullptr, offsets, grid_sizes, (void*)grad_feat, ld, grad_table, grad_table_bf16, R, S, L, n, m, Sl, H, std_scale};
   // the first lds_levels levels take the LDS-privatised path in slabs of lds_cells rows (lds_cells * C * 4 bytes <= 160 KB);
   // lds_slabs = sum over those levels of ceil(rows / lds_cells) (the host knows the level sizes)

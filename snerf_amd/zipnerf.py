@@ -244,8 +244,9 @@ class Model(_ArenaModule):
             dF = net.backward(d_den, L["saved"]) if lvl < 2 else net.backward(d_rgb, d_den, L["saved"])
             gtab = self.arena.g[self.names[lvl] + "encoder.embeddings"]
             g16 = None
-            if self.table_grad_bf16 and e.C % 2 == 0:
-                # hashed levels scatter packed bf16 pairs (half the atomics); folded into the fp32 gradient right after
+            if self.table_grad_bf16 and (e.C % 2 == 0 or e.C == 1):
+                # hashed levels scatter packed bf16 pairs (C = 4: half the atomics; C = 1: x-neighbour corners of even cells share one
+                # atomic, a quarter fewer); folded into the fp32 gradient right after
                 g16 = torch.zeros(gtab.shape, dtype=torch.bfloat16, device=dev)
             ops.zip_encode_bwd(L["tdist"], ctx["o"], ctx["d"], ctx["radii"], ctx["bx"], ctx["by"], L["degj"], self.dev_offsets[lvl],
                                self.dev_sizes[lvl], dF, gtab, e.L, e.C, ctx["n"], ctx["m"], e.Sl,
