@@ -294,6 +294,11 @@ int snerf_fg_accumulate(void* total_mask, void* total_bound, const void* bound, 
 /* utils_render.py:327-335 fuse_bound_and_im: im[bound > 0] = 0, per byte, in place. */
 int snerf_fg_blank(void* im, const void* bound, long nbytes, void* stream);
 
+/* Hash-grid weight decay (s-nerfpp/zipnerf/internal/train_utils.py:184-203 hash_decay_loss; torch_scatter.segment_coo(param**2, idx,
+ * reduce='mean').mean() per encoder): table / grad fp32 [rows, C] (grad accumulated: += 2 mult p / (rows_l L C)), offsets device int32
+ * [L+1]; *loss (device, nullable) += mult * mean over (l, c) of the per-level mean of table^2. */
+int snerf_hash_decay(const float* table, float* grad, const int* offsets, int L, int C, float mult, float* loss, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

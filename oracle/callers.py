@@ -200,12 +200,17 @@ def anti_interlevel_loss(sdists, weights, pulse_width=(0.03, 0.003), mult=0.01):
 
 
 def hash_decay_loss(table, offsets, mult=0.1):
-    """train_utils.py:184-203 for one encoder: segment-mean of param^2 per level (idx = level of each row), then the mean over
-    [L, C]; times `mult`."""
+    """train_utils.py:184-203 for one encoder: torch_scatter.segment_coo(param ** 2, idx, out=zeros(L, C), reduce='mean') -- the mean of
+    param^2 over the rows of each level (idx = level of each row, gridencoder/grid.py:128-141) -- then .mean() over [L, C]; times `mult`.
+    torch_scatter (pinned 2.1.1, s-nerfpp/requirements.txt:39) is not installed: its documented reduction is restated here, so this term
+    is PARITY-UNPINNED by the reference.  -> (loss, d loss / d table)."""
     t = np.asarray(table, np.float64)
     L = len(offsets) - 1
     per = np.stack([(t[offsets[l]:offsets[l + 1]] ** 2).mean(0) for l in range(L)])
-    return mult * per.mean()
+    grad = np.zeros_like(t)
+    for l in range(L):
+        grad[offsets[l]:offsets[l + 1]] = 2 * mult * t[offsets[l]:offsets[l + 1]] / ((offsets[l + 1] - offsets[l]) * L * t.shape[1])
+    return mult * per.mean(), grad
 
 
 def zip_loss_tail(rgb, target, lossmult, depth, target_depth, depth_mask, com_mask, semantic, labels, sem_mask, sdists, weights,

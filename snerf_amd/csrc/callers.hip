@@ -562,3 +562,34 @@ extern "C" int snerf_frame_quantize(const float* rgb, const float* depth, const 
   hipLaunchKernelGGL(frame_quantize_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   return snerf_check_launch();
 }
+
+// ---------------------------------------------------------------------------
+// Hash-grid weight decay of the zipnerf training step (s-nerfpp/zipnerf/internal/train_utils.py:184-203, hash_decay_loss, on by default:
+// configs.py:74 hash_decay_mults = 0.1): per encoder, mult * mean_{l,c}( mean over the rows of level l of table[row, c]^2 ) -- the
+// reference computes the per-level means with torch_scatter.segment_coo(param ** 2, idx, reduce='mean').  Value and gradient
+// (grad += 2 mult p / (rows_l L C)) in one pass over the table; grid.y = level.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hash_decay_kernel(const float* __restrict__ table, float* __restrict__ grad, const int* __restrict__ offsets,
+                                                         int L, int C, float mult, float* __restrict__ loss) {
+  const int level = blockIdx.y;
+  const long b = (long)offsets[level] * C, e = (long)offsets[level + 1] * C;
+  const float k = mult / ((float)(offsets[level + 1] - offsets[level]) * (float)L * (float)C);
+  float part = 0.f;
+  for (long i = b + (long)blockIdx.x * 256 + threadIdx.x; i < e; i += (long)gridDim.x * 256) {
+    const float p = table[i];
+    part += p * p;
+    grad[i] += 2.f * k * p;
+  }
+  part = wave_sum(part);
+  __shared__ float ws[4];
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = part;
+  __syncthreads();
+  if (threadIdx.x == 0 && loss != nullptr) atomicAdd(loss, k * (ws[0] + ws[1] + ws[2] + ws[3]));
+}
+
+extern "C" int snerf_hash_decay(const float* table, float* grad, const int* offsets, int L, int C, float mult, float* loss, void* stream) {
+  if (L <= 0 || mult == 0.f) return SNERF_OK;
+  if (table == nullptr || grad == nullptr || offsets == nullptr || C < 1) return SNERF_ERR_ARG;
+  hipLaunchKernelGGL(hash_decay_kernel, dim3(512, L), dim3(256), 0, (hipStream_t)stream, table, grad, offsets, L, C, mult, loss);
+  return snerf_check_launch();
+}

@@ -544,6 +544,14 @@ def frame_quantize(rgb=None, depth=None, semantic=None, color_map=None, scale_fa
     return out
 
 
+def hash_decay(table, grad, offsets, L, C, mult, loss=None):
+    """grad += d/d table of mult * mean_{level, channel}(mean over the level's rows of table^2) (train_utils.py:184-203); `loss`
+    (1-element fp32 device tensor, optional) accumulates the value."""
+    _f32c(table); _f32c(grad)
+    assert offsets.dtype == torch.int32 and offsets.is_cuda and table.shape == grad.shape
+    _lib.call("snerf_hash_decay", _p(table), _p(grad), _p(offsets), int(L), int(C), float(mult), _p(loss), _stream())
+
+
 def semantic_composite_fwd(weights, logits, C, softmax):
     """semantic [R,C] = sum_i w[r,i] f(logits[r*S+i, :C]), f = softmax (zipnerf) or identity (live mip path); logits: 2-D view."""
     R, S = weights.shape

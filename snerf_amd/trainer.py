@@ -115,7 +115,8 @@ class ZipTrainer:
     device in `last_losses` (ops.ZIP_LOSS_NAMES order).
 
     `loss_cfg` overrides the reference defaults (internal/configs.py:60-66,85; train.py:253,272,298): charb_padding 0.001, data_mult
-    1, depth_lambda 0.5, com_mult 0.2, sem_mult 0.04, pulse_width (0.03, 0.003), interlevel_mult 0.01, distortion_mult 0.005, mse False.
+    1, depth_lambda 0.5, com_mult 0.2, sem_mult 0.04, pulse_width (0.03, 0.003), interlevel_mult 0.01, distortion_mult 0.005, mse False,
+    hash_decay_mult 0.1 (`snerf_hash_decay`, one pass over the three tables, value appended to `last_losses`).
     Further caller-defined terms on the ray histories go through `aux_loss_fn(ray_history) -> scalar` (torch autograd on detached
     leaf copies of every level's `weights`; its d(loss)/d(weights) is added to the fused tail's)."""
 
@@ -123,6 +124,8 @@ class ZipTrainer:
         self.model, self.lr, self.betas, self.eps = model, lr, betas, eps
         self.loss_cfg = dict(charb_padding=charb_padding)
         self.loss_cfg.update(loss_cfg or {})
+        # hash-grid weight decay (train_utils.py:184-203; configs.py:74): a term on the parameters, not on the rays
+        self.hash_decay_mult = float(self.loss_cfg.pop("hash_decay_mult", 0.1))
         a = model.arena
         self.m, self.v, self.t = torch.zeros_like(a.flat), torch.zeros_like(a.flat), 0
         self.pg = process_group
@@ -153,8 +156,14 @@ class ZipTrainer:
                                    sem=fin["semantic"] if with_sem else None, labels=t.get("semantic") if with_sem else None,
                                    smask=t.get("semantic_mask"), hist=[(levels[l]["sdist"], levels[l]["weights"]) for l in range(3)],
                                    **self.loss_cfg)
-        self.last_losses = out[4:]
-        loss = out[4] + out[6:].sum()
+        decay = torch.zeros(1, dtype=torch.float32, device=dev)
+        if self.hash_decay_mult > 0:
+            for lvl, pre in enumerate(m.names):            # identical on every rank: the all-reduced mean leaves it unchanged
+                e = m.encs[lvl]
+                ops.hash_decay(m.arena.p[pre + "encoder.embeddings"], m.arena.g[pre + "encoder.embeddings"], m.dev_offsets[lvl], e.L, e.C,
+                               self.hash_decay_mult, decay)
+        self.last_losses = torch.cat([out[4:], decay])     # ops.ZIP_LOSS_NAMES + ("hash_decay",)
+        loss = out[4] + out[6:].sum() + decay[0]
         g_w = [G["w0"], G["w1"], G["w2"]]
         if aux_loss_fn is not None:
             with torch.enable_grad():

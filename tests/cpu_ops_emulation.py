@@ -333,7 +333,17 @@ def zip_percentiles(tdist, weights, t_far, ps=(5, 50, 95)):
     return oz.weighted_percentile(torch.cat([tdist, t_far.reshape(-1, 1)], -1), torch.cat([weights, bg], -1), list(ps))
 
 
-_NAMES = ["zip_percentiles", "zip_pixels_to_rays", "zip_loss_tail", "semantic_composite_fwd", "semantic_composite_bwd", "zip_resample", "zip_encode_fwd", "zip_encode_bwd", "zip_composite_fwd", "zip_composite_bwd",
+def hash_decay(table, grad, offsets, L, C, mult, loss=None):
+    off = offsets.cpu().numpy()
+    for l in range(L):
+        rows = int(off[l + 1] - off[l])
+        k = mult / (rows * L * C)
+        grad[off[l]:off[l + 1]] += 2 * k * table[off[l]:off[l + 1]]
+        if loss is not None:
+            loss += k * (table[off[l]:off[l + 1]].double() ** 2).sum().float()
+
+
+_NAMES = ["hash_decay", "zip_percentiles", "zip_pixels_to_rays", "zip_loss_tail", "semantic_composite_fwd", "semantic_composite_bwd", "zip_resample", "zip_encode_fwd", "zip_encode_bwd", "zip_composite_fwd", "zip_composite_bwd",
           "linear_fwd", "linear_wgrad", "classic_embed", "mip_encode", "mip_viewenc", "classic_sample_pdf", "classic_points",
           "classic_merge_sort", "mip_resample", "stratified", "mip_composite_fwd", "mip_composite_bwd", "classic_composite_fwd",
           "classic_composite_bwd", "adam_step", "colsum_f32", "cast_pad", "pinhole_rays", "mip_loss_tail"]

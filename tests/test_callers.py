@@ -275,3 +275,22 @@ def test_zip_loss_tail_absent_terms_and_empty_masks():
     assert np.abs(G["w0"].cpu().numpy() - Gr["w0"]).max() <= 1e-5 * np.abs(Gr["w0"]).max()
     with pytest.raises(SnerfHipError):
         ops.zip_loss_tail(rgb, tgt, hist=[(c(s0), c(w0)), (None, None), (c(s2), c(w2))], pulse_width=(0.0, 0.003))
+
+
+@gpu
+@pytest.mark.parametrize("C", [1, 4])
+def test_hash_decay_vs_oracle(C):
+    """train_utils.py:184-203 through the C-ABI: value and accumulated gradient on a 3-level table with unequal level sizes."""
+    from snerf_amd import ops
+    rng = np.random.default_rng(C)
+    off = np.array([0, 4920, 40864, 40864 + 2 ** 16], np.int32)
+    tab = (rng.standard_normal((int(off[-1]), C)) * 0.1).astype(np.float32)
+    g0 = rng.standard_normal(tab.shape).astype(np.float32) * 1e-3
+    ref_l, ref_g = oc.hash_decay_loss(tab, off, 0.1)
+    t, g = torch.from_numpy(tab).cuda(), torch.from_numpy(g0.copy()).cuda()
+    loss = torch.zeros(1, device="cuda")
+    ops.hash_decay(t, g, torch.from_numpy(off).cuda(), 3, C, 0.1, loss)
+    assert abs(float(loss) - ref_l) <= 1e-5 * ref_l
+    np.testing.assert_allclose(g.cpu().numpy() - g0, ref_g, rtol=1e-4, atol=1e-9)
+    ops.hash_decay(t, g, torch.from_numpy(off).cuda(), 3, C, 0.0, loss)             # mult 0: nothing happens
+    assert abs(float(loss) - ref_l) <= 1e-5 * ref_l

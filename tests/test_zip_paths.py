@@ -259,10 +259,12 @@ def test_zip_trainer_fused_loss_tail(backend):
     Lr, _ = ocl.zip_loss_tail(n(fin["rgb"]), n(target), n(tg["lossmult"]), n(fin["depth"]), n(tg["depth"]), n(tg["depth_mask"]), n(tg["complete_mask"]),
                               n(fin["semantic"]), n(tg["semantic"]), n(tg["semantic_mask"]), [n(levels[l]["sdist"]) for l in range(3)],
                               [n(levels[l]["weights"]) for l in range(3)])
-    got = dict(zip(ops.ZIP_LOSS_NAMES, tr.last_losses.cpu().tolist()))
+    got = dict(zip(ops.ZIP_LOSS_NAMES + ("hash_decay",), tr.last_losses.cpu().tolist()))
     for k in ops.ZIP_LOSS_NAMES:
         assert abs(got[k] - Lr[k]) <= 2e-5 * abs(Lr[k]) + 1e-9, (k, got[k], Lr[k])
-    assert abs(float(loss0) - Lr["total"]) <= 2e-5 * Lr["total"]
+    decay = sum(ocl.hash_decay_loss(p[pre + "encoder.embeddings"].numpy(), m.encs[i].offsets, 0.1)[0] for i, pre in enumerate(m.names))
+    assert abs(got["hash_decay"] - decay) <= 1e-4 * decay and decay > 0
+    assert abs(float(loss0) - (Lr["total"] + decay)) <= 2e-5 * (Lr["total"] + decay)
     assert all(Lr[k] > 0 for k in ("data", "depth", "d_complete", "sem", "interlevel", "distortion"))
     assert float((m.arena.flat - start).abs().max()) > 1e-4
     for _ in range(14):

@@ -130,7 +130,7 @@ def main():
     train_step(0); train_step(1); torch.cuda.synchronize()
     ops.zip_loss_tail = orig_tail
     tail_ms = min(e0.elapsed_time(e1) for e0, e1 in tail)
-    losses = dict(zip(ops.ZIP_LOSS_NAMES, [round(v, 6) for v in tr.last_losses.cpu().tolist()]))
+    losses = dict(zip(ops.ZIP_LOSS_NAMES + ("hash_decay",), [round(v, 6) for v in tr.last_losses.cpu().tolist()]))
     tb = 2 if args.table == "f16" else 4
     bytes_lvl = [R * 7 * 64 * 6 * 8 * 1 * tb, R * 7 * 64 * 8 * 8 * 1 * tb, R * 7 * 32 * 10 * 8 * 4 * tb]
     out = {"path": "C (zipnerf Model, waymo.gin shape: 64+64+32 intervals x 7 multisamples, grids L=6/8/10)", "n_gpus": world, "rays_per_gpu": R,
