@@ -103,7 +103,8 @@ int snerf_stratified(const float* base, const float* rnd, const float* near, con
                      int P, int mode, int lindisp, float* out, void* stream);
 
 /* ---- compositing --------------------------------------------------------------------------------
- * models.py:166-175 activations + mip.py:151-189 real_volumetric_rendering.  raw_rgb NULL = proposal level. */
+ * models.py:166-175 activations + mip.py:151-189 real_volumetric_rendering.  raw_rgb NULL = proposal level. 
+ * g_dirs (nullable) [N,3] <- d loss / d directions through delta = (t1 - t0) * |d| (mip.py:160-161; the reference's pose refinement). */
 int snerf_mip_composite_fwd(const float* raw_rgb, long ld_rgb, const float* raw_density, long ld_den, const float* noise,
                             const float* s_vals, const float* dirs, const float* near, const float* far, long N, int S,
                             int transform_idx, int white, float rgb_padding, float density_bias, float* comp_rgb,
@@ -113,7 +114,7 @@ int snerf_mip_composite_bwd(const float* raw_rgb, long ld_rgb, const float* raw_
                             int transform_idx, int white, float rgb_padding, float density_bias, const float* weights,
                             const float* distance, const float* g_rgb, const float* g_dist, const float* g_acc,
                             const float* g_w, float* d_raw_rgb, long ld_drgb, float* d_raw_density, long ld_dden,
-                            void* stream);
+                            float* g_dirs, void* stream);
 /* run_nerf_helpers.py:381-424 raw2outputs */
 int snerf_classic_composite_fwd(const float* raw, long ld, const float* noise, const float* z_vals, const float* rays_d,
                                 int rd_stride, long N, int S, int white, float* rgb_map, float* disp_map, float* acc_map,
@@ -298,6 +299,16 @@ int snerf_fg_blank(void* im, const void* bound, long nbytes, void* stream);
  * reduce='mean').mean() per encoder): table / grad fp32 [rows, C] (grad accumulated: += 2 mult p / (rows_l L C)), offsets device int32
  * [L+1]; *loss (device, nullable) += mult * mean over (l, c) of the per-level mean of table^2. */
 int snerf_hash_decay(const float* table, float* grad, const int* offsets, int L, int C, float mult, float* loss, void* stream);
+
+/* Gradients of the encoders w.r.t. the rays (pose refinement, s-nerf/utils/sample_utils.py:410-435: autograd through
+ * integrated_pos_enc mip.py:105-118, sample2enc / Jacobi_g / fn2 mip.py:343-395 and cast_rays / lift_gaussian mip.py:31-91).
+ * dE fp32 [n_rays*S, ld >= 6*max_deg] = d loss / d IPE features; g_origins / g_directions [n_rays,3] are WRITTEN (one wave per ray,
+ * deterministic).  Fence posts carry no ray gradient (level 0 constants; level 1 detached, mip.py:318). */
+int snerf_mip_encode_bwd(const float* s_vals, const float* origins, const float* directions, const float* radii, const float* near,
+                         const float* far, long n_rays, int S, int cone, int transform_idx, int max_deg, const float* dE, long ld,
+                         float* g_origins, float* g_directions, void* stream);
+/* dV fp32 [n_rays*S, ld >= 3 + 6*deg] = d loss / d view-direction encoding (mip.py:12-21) -> g_viewdirs [n_rays,3] (written). */
+int snerf_mip_viewenc_bwd(const float* viewdirs, long n_rays, int S, int deg, const float* dV, long ld, float* g_viewdirs, void* stream);
 
 #ifdef __cplusplus
 }

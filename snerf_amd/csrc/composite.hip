@@ -33,6 +33,7 @@ struct MipComp {
   const float* g_rgb; const float* g_dist; const float* g_acc; const float* g_w;   // [N,3],[N],[N],[N,S] (nullable)
   float* d_raw_rgb; long ld_drgb; float* d_raw_density; long ld_dden;
   const int* row_index;                    // forward, optional [N,S]: row of sample (ray, i) in the compacted raw arrays, -1 = not evaluated (empty)
+  float* g_dirs;                           // backward, optional [N,3]: d loss / d directions through delta = (t1 - t0) |d| (mip.py:160-161)
 };
 
 // ---- forward -------------------------------------------------------------
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(256) void mip_composite_bwd_kernel(MipComp a) {
     gdist = (raw_dist >= tlo && raw_dist <= thi) ? a.g_dist[ray] : 0.f;   // false for NaN as well (nan -> inf -> clipped)
   }
   // pass 2: per sample gradient
-  float carry_dd = 0.f;
+  float carry_dd = 0.f, g_norm = 0.f;
 #pragma unroll
   for (int seg = 0; seg < MAXSEG; ++seg) {
     if (seg >= nseg) break;
@@ -184,8 +185,17 @@ __global__ __launch_bounds__(256) void mip_composite_bwd_kernel(MipComp a) {
     const float incl_dd = wave_incl_scan_add(dd, lane);
     const float t_next = expf(-(carry_dd + incl_dd));              // T_{i+1}
     const float suffix = later + (wave_incl_rscan_add(gw, lane) - gw);   // sum_{k>i} g_k w_k
-    if (ok) a.d_raw_density[(ray * S + i) * a.ld_dden] = (g * t_next - suffix) * delta * sp_grad;
+    const float g_dd = g * t_next - suffix;                         // d loss / d (density * delta)
+    if (ok) a.d_raw_density[(ray * S + i) * a.ld_dden] = g_dd * delta * sp_grad;
+    if (ok) g_norm += g_dd * dd;                                    // d(dd)/d|d| = dd / |d|
     carry_dd += __shfl(incl_dd, 63, 64);
+  }
+  if (a.g_dirs != nullptr) {
+    g_norm = wave_sum(g_norm);
+    if (lane == 0) {
+      const float k = dnorm > 0.f ? g_norm / (dnorm * dnorm) : 0.f;   // d|d|/dd_k = d_k / |d|
+      a.g_dirs[ray * 3] = k * dx; a.g_dirs[ray * 3 + 1] = k * dy; a.g_dirs[ray * 3 + 2] = k * dz;
+    }
   }
 }
 
@@ -217,7 +227,7 @@ extern "C" int snerf_mip_composite_bwd(const float* raw_rgb, long ld_rgb, const 
                                        int transform_idx, int white, float rgb_padding, float density_bias, const float* weights,
                                        const float* distance, const float* g_rgb, const float* g_dist, const float* g_acc,
                                        const float* g_w, float* d_raw_rgb, long ld_drgb, float* d_raw_density, long ld_dden,
-                                       void* stream) {
+                                       float* g_dirs, void* stream) {
   if (N <= 0) return SNERF_OK;
   if (S <= 0 || S > 64 * MAXSEG || raw_density == nullptr || weights == nullptr || d_raw_density == nullptr) return SNERF_ERR_ARG;
   if (raw_rgb != nullptr && d_raw_rgb == nullptr) return SNERF_ERR_ARG;
@@ -226,6 +236,7 @@ extern "C" int snerf_mip_composite_bwd(const float* raw_rgb, long ld_rgb, const 
   a.weights = (float*)weights; a.distance = (float*)distance;
   a.g_rgb = g_rgb; a.g_dist = g_dist; a.g_acc = g_acc; a.g_w = g_w;
   a.d_raw_rgb = d_raw_rgb; a.ld_drgb = ld_drgb; a.d_raw_density = d_raw_density; a.ld_dden = ld_dden;
+  a.g_dirs = g_dirs;
   hipLaunchKernelGGL(mip_composite_bwd_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
   return snerf_check_launch();
 }

@@ -236,3 +236,203 @@ extern "C" int snerf_mip_viewenc(const float* viewdirs, long n_rays, int S, int 
     hipLaunchKernelGGL(mip_viewenc_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, viewdirs, S, M, deg, (__bf16*)dst, ld, width, sample_id);
   return snerf_check_launch();
 }
+
+// ---------------------------------------------------------------------------
+// Gradient of the encoders w.r.t. the RAYS (the reference's pose refinement, s-nerf/utils/sample_utils.py:410-435: origins,
+// directions and viewdirs are functions of the learnable camera pose and autograd carries the loss back through
+// integrated_pos_enc (mip.py:105-118), sample2enc (contraction + Jacobian, mip.py:343-395) and cast_rays / lift_gaussian
+// (mip.py:31-91)).  dE [M, ld] fp32 = d loss / d IPE features of every sample (the data gradient of the first MLP layer and of the
+// skip layer, summed).  One wave per ray: its S samples are walked 64 at a time, every lane rebuilds its sample's Gaussian exactly as
+// the forward does and chains the 6*max_deg feature gradients down to d origin / d direction; one wave reduction, one plain store per
+// ray -- deterministic, no atomics.  The fence posts carry no ray gradient (level 0: constants; level 1: detached, mip.py:318).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float safe_cos(float x) {            // d/dx of safe_sin: the remainder has unit slope
+  const float t = 314.15927f;
+  if (!(fabsf(x) < t)) {
+    float r = fmodf(x, t);
+    if (r != 0.f && r < 0.f) r += t;
+    x = r;
+  }
+  return cosf(x);
+}
+
+struct MipEncBwd {
+  const float* s_vals; const float* origins; const float* directions; const float* radii; const float* near; const float* far;
+  long N; int S, cone, transform_idx, max_deg;
+  const float* dE; long ld;
+  float* g_origins; float* g_directions;
+};
+
+__global__ __launch_bounds__(256) void mip_encode_bwd_kernel(MipEncBwd a) {
+  const int lane = threadIdx.x & 63;
+  const long ray = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= a.N) return;
+  const float near = a.near[ray], far = a.far[ray], rad = a.radii[ray];
+  float d[3], o[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { d[k] = a.directions[ray * 3 + k]; o[k] = a.origins[ray * 3 + k]; }
+  const float dsq = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+  const float dmag = fmaxf(1e-10f, dsq);
+  float go[3] = {0.f, 0.f, 0.f}, gd[3] = {0.f, 0.f, 0.f};
+  const int half = 3 * a.max_deg;
+  for (int i = lane; i < a.S; i += 64) {
+    const float t0 = mip_transform(a.s_vals[ray * (a.S + 1) + i], near, far, a.transform_idx);
+    const float t1 = mip_transform(a.s_vals[ray * (a.S + 1) + i + 1], near, far, a.transform_idx);
+    float t_mean, t_var, r_var;
+    if (a.cone) {
+      const float mu = (t0 + t1) / 2.f, hw = (t1 - t0) / 2.f;
+      const float mu2 = mu * mu, hw2 = hw * hw, hw4 = hw2 * hw2;
+      const float den = 3.f * mu2 + hw2;
+      t_mean = mu + (2.f * mu * hw2) / den;
+      t_var = hw2 / 3.f - (4.f / 15.f) * ((hw4 * (12.f * mu2 - hw2)) / (den * den));
+      r_var = (rad * rad) * (mu2 / 4.f + (5.f / 12.f) * hw2 - (4.f / 15.f) * hw4 / den);
+    } else {
+      t_mean = (t0 + t1) / 2.f;
+      r_var = rad * rad / 4.f;
+      t_var = (t1 - t0) * (t1 - t0) / 12.f;
+    }
+    float x[3], c[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      x[k] = d[k] * t_mean + o[k];
+      const float dd = d[k] * d[k];
+      c[k] = t_var * dd + r_var * (1.f - dd / dmag);
+    }
+    const float nrm = sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+    const float l = nrm + 1e-8f, lj = nrm + 1e-5f;
+    float fm[3], fc[3], J[3][3];
+    const bool far_c = l > 3.f, far_j = lj >= 3.f;
+    const float sl = far_c ? (2.f - 3.f / l) / l : 1.f / 3.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) fm[k] = far_c ? (2.f - 3.f / l) * x[k] / l : x[k] / 3.f;
+    float ln = 0.f, p1 = 1.f / 3.f, p2 = 0.f;
+    if (far_j) { ln = 1.f / lj; const float ln2 = ln * ln; p1 = -3.f * ln2 + 2.f * ln; p2 = 6.f * (ln2 * ln2) - 2.f * (ln2 * ln); }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { J[r][k] = (r == k ? p1 : 0.f) + p2 * (x[r] * x[k]); acc += (J[r][k] * J[r][k]) * c[k]; }
+      fc[r] = acc;
+    }
+    // ---- feature gradients -> d fm, d fc
+    const float* ge = a.dE + (ray * a.S + i) * a.ld;
+    float gfm[3] = {0.f, 0.f, 0.f}, gfc[3] = {0.f, 0.f, 0.f};
+    for (int deg = 0; deg < a.max_deg; ++deg) {
+      const float sc = (float)(1 << deg);
+#pragma unroll
+      for (int dim = 0; dim < 3; ++dim) {
+        const float y = fm[dim] * sc, yv = (fc[dim] * sc) * sc;
+        const float e = expf(-0.5f * yv);
+        const float gs = ge[deg * 3 + dim], gc = ge[half + deg * 3 + dim];
+        const float y2 = y + 1.5707964f;
+        gfm[dim] += sc * e * (safe_cos(y) * gs + safe_cos(y2) * gc);
+        gfc[dim] += (-0.5f * sc * sc) * e * (safe_sin(y) * gs + safe_sin(y2) * gc);
+      }
+    }
+    // ---- contraction and its Jacobian -> d x, d c
+    float gx[3] = {0.f, 0.f, 0.f}, gcv[3] = {0.f, 0.f, 0.f};
+    const float inv_n = nrm > 0.f ? 1.f / nrm : 0.f;                 // d|x|/dx = x / |x| (0 at the origin, as torch.norm's backward)
+    if (far_c) {
+      const float dsl = -2.f / (l * l) + 6.f / (l * l * l);
+      const float dot = gfm[0] * x[0] + gfm[1] * x[1] + gfm[2] * x[2];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) gx[k] += sl * gfm[k] + dot * dsl * x[k] * inv_n;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) gx[k] += gfm[k] / 3.f;
+    }
+    if (far_j) {
+      float gp1 = 0.f, gp2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          gcv[k] += (J[r][k] * J[r][k]) * gfc[r];
+          const float gJ = 2.f * J[r][k] * c[k] * gfc[r];
+          if (r == k) gp1 += gJ;
+          gp2 += gJ * (x[r] * x[k]);
+          gx[r] += gJ * p2 * x[k];
+          gx[k] += gJ * p2 * x[r];
+        }
+      }
+      const float ln2 = ln * ln;
+      const float gln = gp1 * (-6.f * ln + 2.f) + gp2 * (24.f * ln2 * ln - 6.f * ln2);
+      const float glj = -ln2 * gln;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) gx[k] += glj * x[k] * inv_n;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) gcv[k] += gfc[k] / 9.f;
+    }
+    // ---- lift_gaussian -> d origin, d direction
+    float gdm = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      go[k] += gx[k];
+      gd[k] += gx[k] * t_mean + gcv[k] * (2.f * t_var * d[k] - r_var * 2.f * d[k] / dmag);
+      gdm += gcv[k] * r_var * (d[k] * d[k]) / (dmag * dmag);
+    }
+    if (dsq > 1e-10f) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) gd[k] += gdm * 2.f * d[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { go[k] = wave_sum(go[k]); gd[k] = wave_sum(gd[k]); }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { a.g_origins[ray * 3 + k] = go[k]; a.g_directions[ray * 3 + k] = gd[k]; }
+  }
+}
+
+extern "C" int snerf_mip_encode_bwd(const float* s_vals, const float* origins, const float* directions, const float* radii, const float* near,
+                                    const float* far, long n_rays, int S, int cone, int transform_idx, int max_deg, const float* dE, long ld,
+                                    float* g_origins, float* g_directions, void* stream) {
+  if (n_rays <= 0) return SNERF_OK;
+  if (S <= 0 || max_deg < 1 || max_deg > 30 || dE == nullptr || ld < 6 * max_deg || g_origins == nullptr || g_directions == nullptr) return SNERF_ERR_ARG;
+  MipEncBwd a{s_vals, origins, directions, radii, near, far, n_rays, S, cone, transform_idx, max_deg, dE, ld, g_origins, g_directions};
+  hipLaunchKernelGGL(mip_encode_bwd_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+  return snerf_check_launch();
+}
+
+// view-direction encoding [x, sin(2^i x), sin(2^i x + pi/2)] (mip.py:12-21) is shared by the S samples of a ray: sum its feature
+// gradients over the samples, then chain through the sines.  One wave per ray.
+__global__ __launch_bounds__(256) void mip_viewenc_bwd_kernel(const float* __restrict__ viewdirs, long N, int S, int deg, const float* __restrict__ dV,
+                                                              long ld, float* __restrict__ g_viewdirs) {
+  const int lane = threadIdx.x & 63;
+  const long ray = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= N) return;
+  const int n3 = 3 * deg, width = 3 + 2 * n3;
+  float g[3] = {0.f, 0.f, 0.f};
+  const float x[3] = {viewdirs[ray * 3], viewdirs[ray * 3 + 1], viewdirs[ray * 3 + 2]};
+  for (int i = lane; i < S; i += 64) {
+    const float* gv = dV + (ray * S + i) * ld;
+    for (int col = 0; col < width; ++col) {
+      const float v = gv[col];
+      if (col < 3) g[col] += v;
+      else {
+        int j = col - 3;
+        const int ph = j >= n3;
+        if (ph) j -= n3;
+        const float sc = (float)(1 << (j / 3));
+        float y = x[j % 3] * sc;
+        if (ph) y = y + 1.5707964f;
+        g[j % 3] += v * sc * cosf(y);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) g[k] = wave_sum(g[k]);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) g_viewdirs[ray * 3 + k] = g[k];
+  }
+}
+
+extern "C" int snerf_mip_viewenc_bwd(const float* viewdirs, long n_rays, int S, int deg, const float* dV, long ld, float* g_viewdirs, void* stream) {
+  if (n_rays <= 0) return SNERF_OK;
+  if (S <= 0 || deg < 0 || deg > 16 || dV == nullptr || ld < 3 + 6 * deg || g_viewdirs == nullptr) return SNERF_ERR_ARG;
+  hipLaunchKernelGGL(mip_viewenc_bwd_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, (hipStream_t)stream, viewdirs, n_rays, S, deg, dV, ld,
+                     g_viewdirs);
+  return snerf_check_launch();
+}

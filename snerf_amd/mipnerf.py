@@ -128,15 +128,22 @@ class MipNerfModel(_ArenaModule):
         ctx = None
         if keep:
             # detached aliases of the output tensors: the originals become outputs of the autograd Function
-            ctx = dict(d=d, near=near, far=far, s0=s0.detach(), s1=s1.detach(), raw_d0=raw_d0, acts0=acts0, w0=w0.detach(), dist0=dist0.detach(),
+            ctx = dict(o=o, vd=vd, radii=radii, cone=cone, d=d, near=near, far=far, s0=s0.detach(), s1=s1.detach(), raw_d0=raw_d0, acts0=acts0, w0=w0.detach(), dist0=dist0.detach(),
                        raw_rgb=raw_rgb, raw_d1=raw_d1, saved1=saved1, w1=w1.detach(), dist1=dist1.detach(), noise0=noise0, noise1=noise1,
                        white=white_bg, raw_sem=raw_sem)
         return (dist0, acc0, s0, w0, rgb1, dist1, acc1, s1, w1) + ((sem1,) if self.semantic else ()), ctx
 
-    def _backward(self, ctx, g_dist0, g_acc0, g_w0, g_rgb1, g_dist1, g_acc1, g_w1, g_sem1=None, on_done=None):
+    def _backward(self, ctx, g_dist0, g_acc0, g_w0, g_rgb1, g_dist1, g_acc1, g_w1, g_sem1=None, on_done=None, ray_grads=False):
         """Accumulates parameter gradients into the arena.  `on_done(prefix)` is called as soon as the gradients of the network whose
-        parameters start with `prefix` are final (the trainer starts that block's all-reduce while the rest of the backward runs)."""
+        parameters start with `prefix` are final (the trainer starts that block's all-reduce while the rest of the backward runs).
+        `ray_grads`: also return d loss / d (origins, directions, viewdirs) [n,3] each -- the reference's pose refinement
+        (utils/sample_utils.py:410-435) back-propagates through the encoders into the camera pose: the data gradient is carried one GEMM
+        further to the IPE / view encodings, then through integrated_pos_enc, the contraction and its Jacobian, lift_gaussian and the
+        interval lengths (t1 - t0)|d| of the compositing.  Fence posts carry no ray gradient (level 1 is detached, mip.py:318)."""
         c = ctx
+        g_o = g_d = g_vd = None
+        if ray_grads:
+            g_o, g_d, g_vd = (torch.zeros_like(c["o"]) for _ in range(3))
         n = c["s0"].shape[0]
         S0, S1 = c["s0"].shape[1] - 1, c["s1"].shape[1] - 1
         dev = c["s0"].device
@@ -150,20 +157,31 @@ class MipNerfModel(_ArenaModule):
         if any(t is not None for t in (g_rgb1, g_dist1, g_acc1, g_w1)):
             d_rgb = torch.empty(n * S1, 3, dtype=torch.float32, device=dev)
             d_den = torch.empty(n * S1, 1, dtype=torch.float32, device=dev)
+            gdir = torch.empty_like(c["d"]) if ray_grads else None
             ops.mip_composite_bwd(c["raw_rgb"], c["raw_d1"], c["noise1"], c["s1"], c["d"], c["near"], c["far"], self.transform_idx,
                                   c["white"], self.rgb_padding, self.density_bias, c["w1"], c["dist1"], cc(g_rgb1), cc(g_dist1),
-                                  cc(g_acc1), cc(g_w1), d_rgb, d_den)
-            self.nerf.backward(d_rgb, d_den, c["saved1"], d_raw_sem)
+                                  cc(g_acc1), cc(g_w1), d_rgb, d_den, g_dirs=gdir)
+            ig = self.nerf.backward(d_rgb, d_den, c["saved1"], d_raw_sem, want_input_grad=ray_grads)
+            if ray_grads:
+                dE, dV = ig
+                eo, ed = ops.mip_encode_bwd(c["s1"], c["o"], c["d"], c["radii"], c["near"], c["far"], c["cone"], self.transform_idx, self.max_deg_point, dE)
+                g_o += eo; g_d += ed + gdir
+                g_vd += ops.mip_viewenc_bwd(c["vd"], S1, self.deg_view, dV)
         if on_done is not None:
             on_done("mlp.")
         if any(t is not None for t in (g_dist0, g_acc0, g_w0)):
             d_den0 = torch.empty(n * S0, 1, dtype=torch.float32, device=dev)
+            gdir = torch.empty_like(c["d"]) if ray_grads else None
             ops.mip_composite_bwd(None, c["raw_d0"], c["noise0"], c["s0"], c["d"], c["near"], c["far"], self.transform_idx,
                                   c["white"], self.rgb_padding, self.density_bias, c["w0"], c["dist0"], None, cc(g_dist0),
-                                  cc(g_acc0), cc(g_w0), None, d_den0)
-            self.prop.backward(d_den0, c["acts0"])
+                                  cc(g_acc0), cc(g_w0), None, d_den0, g_dirs=gdir)
+            dE0 = self.prop.backward(d_den0, c["acts0"], want_input_grad=ray_grads)
+            if ray_grads:
+                eo, ed = ops.mip_encode_bwd(c["s0"], c["o"], c["d"], c["radii"], c["near"], c["far"], c["cone"], self.transform_idx, self.max_deg_point, dE0)
+                g_o += eo; g_d += ed + gdir
         if on_done is not None:
             on_done("proposal.")
+        return (g_o, g_d, g_vd) if ray_grads else None
 
     def _draws(self, n, randomized, dev):
         """The reference's three torch RNG draws (mip.py:283, math_ops.py:52, models.py:163-165), taken in its order."""
@@ -191,9 +209,10 @@ class MipNerfModel(_ArenaModule):
         if white_bg:
             raise NotImplementedError("white_bg=True crashes the reference at the proposal level (mip.py:188, rgb is None)")
         self._check_arena()
-        if torch.is_grad_enabled() and any(torch.is_tensor(r) and r.requires_grad for r in rays):
-            raise NotImplementedError("gradients w.r.t. the rays (pose refinement, sample_utils.py:421-425) are not propagated by the "
-                                      "accelerated path: detach the rays or disable pose_refine")
+        # pose refinement (sample_utils.py:410-435): origins / directions / viewdirs may carry gradients back to a camera pose
+        ray_grad = torch.is_grad_enabled() and any(torch.is_tensor(r) and r.requires_grad for r in (rays.origins, rays.directions, rays.viewdirs))
+        if torch.is_grad_enabled() and any(torch.is_tensor(r) and r.requires_grad for r in (rays.radii, rays.near, rays.far)):
+            raise NotImplementedError("gradients w.r.t. radii / near / far are not propagated (the reference's pose refinement leaves them constant)")
         dev = self.arena.flat.device
         n = rays.origins.shape[0]
         ds_rand, du, noise0, noise1 = self._draws(n, randomized, dev)
@@ -204,11 +223,12 @@ class MipNerfModel(_ArenaModule):
         s_rand = None if s_rand is None else s_rand.to(dev).float().contiguous()
         u = u.to(dev).float().contiguous()
         params = self.param_list()
-        keep = torch.is_grad_enabled() and any(p.requires_grad for p in params)   # grad mode is off inside Function.forward
+        keep = torch.is_grad_enabled() and (ray_grad or any(p.requires_grad for p in params))   # grad mode is off inside Function.forward
         if ert is not None and keep:
             raise NotImplementedError("ert (sample compaction) is an inference mode: call under torch.no_grad()")
         self._ert = None if ert is None else (float(ert[0]), float(ert[1]))
-        outs = _MipFn.apply(self, rays, bool(white_bg), s_rand, u, noise0, noise1, keep, *params)
+        rt = (rays.origins, rays.directions, rays.viewdirs) if ray_grad else (None, None, None)
+        outs = _MipFn.apply(self, rays, bool(white_bg), s_rand, u, noise0, noise1, keep, *rt, *params)
         self._ert = None
         dist0, acc0, s0, w0, rgb1, dist1, acc1, s1, w1 = outs[:9]
         ret = [[None, dist0, acc0], [rgb1, dist1, acc1, outs[9] if self.semantic else None]]
@@ -220,10 +240,11 @@ class MipNerfModel(_ArenaModule):
 
 class _MipFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, model, rays, white_bg, s_rand, u, noise0, noise1, keep, *params):
+    def forward(ctx, model, rays, white_bg, s_rand, u, noise0, noise1, keep, ray_o, ray_d, ray_vd, *params):
         ctx.set_materialize_grads(False)
         outs, c = model._run(rays, keep, white_bg, s_rand, u, noise0, noise1)
         ctx.model, ctx.c = model, c
+        ctx.ray_meta = None if ray_o is None else [(t.shape, t.dtype, t.device) for t in (ray_o, ray_d, ray_vd)]
         ctx.mark_non_differentiable(outs[2], outs[7])
         return outs
 
@@ -233,10 +254,13 @@ class _MipFn(torch.autograd.Function):
             raise RuntimeError("MipNerfModel.forward ran without saved activations")
         m = ctx.model
         m.arena.grad.zero_()
-        m._backward(ctx.c, g_dist0, g_acc0, g_w0, g_rgb1, g_dist1, g_acc1, g_w1, g_sem1)
+        rg = m._backward(ctx.c, g_dist0, g_acc0, g_w0, g_rgb1, g_dist1, g_acc1, g_w1, g_sem1, ray_grads=ctx.ray_meta is not None)
         ctx.c = None
         grads = tuple(m.arena.g[n].clone() for n in m._pnames)
-        return (None,) * 8 + grads
+        if rg is None:
+            return (None,) * 11 + grads
+        rays_g = tuple(g.reshape(sh).to(device=dev, dtype=dt) for g, (sh, dt, dev) in zip(rg, ctx.ray_meta))
+        return (None,) * 8 + rays_g + grads
 
 
 def make_mipnerf(args, device="cuda", compute="bf16"):

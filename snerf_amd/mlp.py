@@ -119,6 +119,24 @@ class _Net:
             c += roundup(W.shape[0], self.g)
         self.tw[key] = out
 
+    def _pack_dgrad_cols(self, key, parts, cnt):
+        """like _pack_dgrad with a weight-column offset per layer: parts = [(layer, first weight column)]; used for the gradient
+        w.r.t. an INPUT encoding that several layers read at different column positions (rows = the encoding's columns)."""
+        cols = sum(roundup(self.W(n).shape[0], self.g) for n, _ in parts)
+        out = torch.zeros(roundup(cnt, 128), cols, dtype=self.tdt, device=self.dev)
+        c = 0
+        for n, wc in parts:
+            W = self.W(n)
+            out[:cnt, c:c + W.shape[0]] = W[:, wc:wc + cnt].t()
+            c += roundup(W.shape[0], self.g)
+        self.tw[key] = out
+
+    def input_grad(self, key, dZ, K, width):
+        """fp32 [M, width] = dZ[:, :K] @ tw[key]^T: the data gradient that reaches an input encoding (pose refinement only)."""
+        out = self.buf(dZ.shape[0], width, f32=True)
+        ops.linear_fwd(dZ, self.tw[key], None, out, K, width, ACT_NONE, self.dt, out_f32=True, variant=self.variant)
+        return out
+
     def ensure_packed(self, train: bool):
         # ReLU bit masks written by this forward's layers (keyed by the activation view), read by the data-gradient GEMMs
         self._bits = {} if train else None
@@ -308,6 +326,7 @@ class MipProposalNet(_Net):
         self._pack_fwd("density", "density_layer", [(0, 0, self.H)], self.H)
         if train:
             self._pack_dgrad("density", ["density_layer"], 0, self.H)
+            self._pack_dgrad_cols("enc", [("layers.0.layers.0", 0)], self.fd)
 
     def forward(self, E, keep: bool):
         """E [M, Ew] encoded samples (compute dtype) -> raw density [M,1] fp32."""
@@ -324,7 +343,8 @@ class MipProposalNet(_Net):
         self.fwd("density", x, H, out, 1, ACT_NONE, out_f32=True)
         return out, (acts if keep else None)
 
-    def backward(self, d_raw_density, acts):
+    def backward(self, d_raw_density, acts, want_input_grad=False):
+        """-> None, or with `want_input_grad` the fp32 gradient [M, Ew] w.r.t. the encoded samples."""
         H, M = self.H, d_raw_density.shape[0]
         ops.colsum_f32(d_raw_density, 1, self.gB("density_layer"))
         dz = self.head_grad(d_raw_density, 1)
@@ -340,6 +360,7 @@ class MipProposalNet(_Net):
                 dX = self.buf(M, H)
                 self.dgrad(n, dZ, H, dX, H, mask=x, colsum=self.gB(f"layers.{i - 1}.layers.0"))
                 dZ = dX
+        return self.input_grad("enc", dZ, H, self.Ew) if want_input_grad else None
 
 
 class MipNerfNet(_Net):
@@ -409,6 +430,11 @@ class MipNerfNet(_Net):
             self._pack_dgrad("bd", ["bottleneck_layer.layers.0", "density_layer"] + (["semantic_layer.0.layers.0"] if self.sc else []), 0, H)
             if self.sc:
                 self._pack_dgrad("sem1", ["semantic_layer.1"], 0, self.Hs)
+            # gradient w.r.t. the input encodings (pose refinement): IPE columns of layer 0 and of every skip layer, one K-concatenated
+            # GEMM over [dZ_0 | dZ_skip]; view encoding columns of the first cond layer
+            self.enc_layers = [0] + [i for i in range(self.L) if self._is_skip_in(i)]
+            self._pack_dgrad_cols("enc", [(f"layers.{i}.layers.0", 0 if i == 0 else H) for i in self.enc_layers], self.fd)
+            self._pack_dgrad_cols("cenc", [("cond_layers.0.layers.0", H)], self.cd)
 
     def alloc_inputs(self, M):
         """-> (SKIP, CB); the encoders write SKIP[:, H:] and CB[:, H:] in place."""
@@ -453,9 +479,12 @@ class MipNerfNet(_Net):
             self.fwd("sem1", S0, self.Hs, self.raw_sem, self.sc, ACT_NONE, out_f32=True)
         return raw_rgb, raw_d, ((acts, cacts, SKIP, CB, S0) if keep else None)
 
-    def backward(self, d_raw_rgb, d_raw_density, saved, d_raw_sem=None):
+    def backward(self, d_raw_rgb, d_raw_density, saved, d_raw_sem=None, want_input_grad=False):
+        """-> None, or with `want_input_grad` (dE fp32 [M, Ew], dV fp32 [M, Cw]): the gradients w.r.t. the IPE and view encodings."""
         acts, cacts, SKIP, CB, S0 = saved
         H, g, cu, M = self.H, self.g, self.cu, d_raw_rgb.shape[0]
+        dV = None
+        DZE = self.buf(M, H * len(self.enc_layers)) if want_input_grad else None
         ops.colsum_f32(d_raw_rgb, 3, self.gB("rgb_layer"))
         ops.colsum_f32(d_raw_density, 1, self.gB("density_layer"))
         dz = self.head_grad(d_raw_rgb, 3)
@@ -474,6 +503,8 @@ class MipNerfNet(_Net):
                 dC = dX
             else:
                 self.dgrad(n, dC, cu, DB, H, mask=CB, colsum=self.gB("bottleneck_layer.layers.0"))
+                if want_input_grad:
+                    dV = self.input_grad("cenc", dC, cu, self.Cw)
         ops.cast_pad(d_raw_density, 1, DB[:, H:H + g], g, self.dt)
         xl = acts[-1][2]
         kb = H + g
@@ -498,9 +529,16 @@ class MipNerfNet(_Net):
             self.wgrad(n, dZ, x, H, self.fd if i == 0 else (H + self.fd if self._is_skip_in(i) else H))
             if i > 0:
                 xin = acts[i - 1][2]
-                dX = self.buf(M, H)
+                if want_input_grad and (i - 1) in self.enc_layers:      # lands in its column block of the K-concatenated operand
+                    k = self.enc_layers.index(i - 1)
+                    dX = DZE[:, k * H:(k + 1) * H]
+                else:
+                    dX = self.buf(M, H)
                 self.dgrad(n, dZ, H, dX, H, mask=xin, colsum=self.gB(f"layers.{i - 1}.layers.0"))
                 dZ = dX
+        if want_input_grad:
+            return self.input_grad("enc", DZE, DZE.shape[1], self.Ew), dV
+        return None
 
 
 # =============================================================================

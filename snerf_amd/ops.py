@@ -246,15 +246,38 @@ def mip_composite_fwd(raw_rgb, raw_density, noise, s_vals, dirs, near, far, tran
 
 
 def mip_composite_bwd(raw_rgb, raw_density, noise, s_vals, dirs, near, far, transform_idx, white, rgb_padding, density_bias,
-                      weights, distance, g_rgb, g_dist, g_acc, g_w, d_raw_rgb, d_raw_density):
+                      weights, distance, g_rgb, g_dist, g_acc, g_w, d_raw_rgb, d_raw_density, g_dirs=None):
+    """`g_dirs` (optional fp32 [n,3], written): d loss / d directions through the interval lengths (t1 - t0) * |d|."""
     n, P = s_vals.shape
-    for t in (g_rgb, g_dist, g_acc, g_w, weights, distance):
+    for t in (g_rgb, g_dist, g_acc, g_w, weights, distance, g_dirs):
         _f32c(t)
     _lib.call("snerf_mip_composite_bwd", _p(raw_rgb), 0 if raw_rgb is None else raw_rgb.stride(0), _p(raw_density),
               raw_density.stride(0), _p(noise), _p(s_vals), _p(dirs), _p(near), _p(far), n, P - 1, transform_idx,
               1 if white else 0, float(rgb_padding), float(density_bias), _p(weights), _p(distance), _p(g_rgb), _p(g_dist),
               _p(g_acc), _p(g_w), _p(d_raw_rgb), 0 if d_raw_rgb is None else d_raw_rgb.stride(0), _p(d_raw_density),
-              d_raw_density.stride(0), _stream())
+              d_raw_density.stride(0), _p(g_dirs), _stream())
+
+
+def mip_encode_bwd(s_vals, origins, directions, radii, near, far, cone, transform_idx, max_deg, dE):
+    """d loss / d (origins, directions) from the IPE feature gradients dE fp32 [n*S, >= 6*max_deg] (pose refinement)."""
+    n, P = s_vals.shape
+    _f32c(s_vals); _chk2d(dE, torch.float32)
+    assert dE.shape[0] == n * (P - 1)
+    g_o = torch.empty(n, 3, dtype=torch.float32, device=s_vals.device)
+    g_d = torch.empty_like(g_o)
+    _lib.call("snerf_mip_encode_bwd", _p(s_vals), _p(origins), _p(directions), _p(radii), _p(near), _p(far), n, P - 1, 1 if cone else 0,
+              int(transform_idx), int(max_deg), _p(dE), dE.stride(0), _p(g_o), _p(g_d), _stream())
+    return g_o, g_d
+
+
+def mip_viewenc_bwd(viewdirs, S, deg, dV):
+    """d loss / d viewdirs from the view-encoding feature gradients dV fp32 [n*S, >= 3 + 6*deg]."""
+    n = viewdirs.shape[0]
+    _f32c(viewdirs); _chk2d(dV, torch.float32)
+    assert dV.shape[0] == n * S
+    g = torch.empty(n, 3, dtype=torch.float32, device=viewdirs.device)
+    _lib.call("snerf_mip_viewenc_bwd", _p(viewdirs), n, int(S), int(deg), _p(dV), dV.stride(0), _p(g), _stream())
+    return g
 
 
 def classic_composite_fwd(raw, noise, z_vals, rays_d, white):

@@ -80,7 +80,9 @@ class MipTrainer:
         self.last_losses = out                                   # {#valid depth rays, rgb, depth, proposal}: stays on the device
         return out[1:].sum(), (g_dist0, None, g_w0, g_rgb1, g_dist1, None, None)
 
-    def step(self, rays, target_rgb, target_depth=None, conf=None, randomized=True, s_rand=None, u=None):
+    def step(self, rays, target_rgb, target_depth=None, conf=None, randomized=True, s_rand=None, u=None, ray_grads=False):
+        """`ray_grads=True` (pose refinement, configs: pose_refine = True): `last_ray_grads` = d loss / d (origins, directions, viewdirs)
+        of this rank's rays, for the caller's pose optimiser (`rays.origins.backward(g_o)` etc. chains them into the pose parameters)."""
         m = self.model
         dev = m.arena.flat.device
         n = rays.origins.shape[0]
@@ -90,7 +92,8 @@ class MipTrainer:
         outs, ctx = m._run(rays, True, False, s_rand, u.contiguous(), noise0, noise1)
         loss, g = self.loss_and_grads(outs, target_rgb, target_depth, conf)
         ex = _GradExchange(m.arena, self.world, self.pg)
-        m._backward(ctx, *g, on_done=ex)        # the 35.9 MB MLP block is reduced while the proposal network's backward runs
+        # the 35.9 MB MLP block is reduced while the proposal network's backward runs
+        self.last_ray_grads = m._backward(ctx, *g, on_done=ex, ray_grads=ray_grads)
         ex.finish()
         self.t += 1
         ops.adam_step(m.arena.flat, m.arena.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.t,

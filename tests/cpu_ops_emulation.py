@@ -109,11 +109,12 @@ def mip_composite_fwd(raw_rgb, raw_density, noise, s_vals, dirs, near, far, tran
 
 
 def mip_composite_bwd(raw_rgb, raw_density, noise, s_vals, dirs, near, far, transform_idx, white, rgb_padding, density_bias,
-                      weights, distance, g_rgb, g_dist, g_acc, g_w, d_raw_rgb, d_raw_density):
+                      weights, distance, g_rgb, g_dist, g_acc, g_w, d_raw_rgb, d_raw_density, g_dirs=None):
     with torch.enable_grad():
         rr = None if raw_rgb is None else raw_rgb.detach().clone().requires_grad_(True)
         rd = raw_density.detach().clone().requires_grad_(True)
-        c, d, a, w = mip_composite_fwd(rr, rd, noise, s_vals, dirs, near, far, transform_idx, white, rgb_padding, density_bias)
+        dd = dirs.detach().clone().requires_grad_(True)
+        c, d, a, w = mip_composite_fwd(rr, rd, noise, s_vals, dd, near, far, transform_idx, white, rgb_padding, density_bias)
         loss = 0
         for o, g in ((c, g_rgb), (d, g_dist), (a, g_acc), (w, g_w)):
             if g is not None and o is not None:
@@ -122,6 +123,25 @@ def mip_composite_bwd(raw_rgb, raw_density, noise, s_vals, dirs, near, far, tran
     d_raw_density.copy_(rd.grad)
     if rr is not None:
         d_raw_rgb.copy_(rr.grad)
+    if g_dirs is not None:
+        g_dirs.copy_(dd.grad if dd.grad is not None else torch.zeros_like(dd))
+
+
+def mip_encode_bwd(s_vals, origins, directions, radii, near, far, cone, transform_idx, max_deg, dE):
+    with torch.enable_grad():
+        o, d = origins.detach().clone().requires_grad_(True), directions.detach().clone().requires_grad_(True)
+        fm, fc = om.sample2enc(s_vals, o, d, radii[:, None], near[:, None], far[:, None], "cone" if cone else "cylinder", transform_idx)
+        enc = om.integrated_pos_enc(fm, fc, 0, max_deg).reshape(-1, 6 * max_deg)
+        (enc * dE[:, :6 * max_deg]).sum().backward()
+    return o.grad, d.grad
+
+
+def mip_viewenc_bwd(viewdirs, S, deg, dV):
+    with torch.enable_grad():
+        v = viewdirs.detach().clone().requires_grad_(True)
+        e = om.pos_enc(v, 0, deg, True)[:, None].expand(-1, S, -1).reshape(-1, 3 + 6 * deg)
+        (e * dV[:, :3 + 6 * deg]).sum().backward()
+    return v.grad
 
 
 def classic_composite_fwd(raw, noise, z_vals, rays_d, white):
@@ -343,7 +363,7 @@ def hash_decay(table, grad, offsets, L, C, mult, loss=None):
             loss += k * (table[off[l]:off[l + 1]].double() ** 2).sum().float()
 
 
-_NAMES = ["hash_decay", "zip_percentiles", "zip_pixels_to_rays", "zip_loss_tail", "semantic_composite_fwd", "semantic_composite_bwd", "zip_resample", "zip_encode_fwd", "zip_encode_bwd", "zip_composite_fwd", "zip_composite_bwd",
+_NAMES = ["mip_encode_bwd", "mip_viewenc_bwd", "hash_decay", "zip_percentiles", "zip_pixels_to_rays", "zip_loss_tail", "semantic_composite_fwd", "semantic_composite_bwd", "zip_resample", "zip_encode_fwd", "zip_encode_bwd", "zip_composite_fwd", "zip_composite_bwd",
           "linear_fwd", "linear_wgrad", "classic_embed", "mip_encode", "mip_viewenc", "classic_sample_pdf", "classic_points",
           "classic_merge_sort", "mip_resample", "stratified", "mip_composite_fwd", "mip_composite_bwd", "classic_composite_fwd",
           "classic_composite_bwd", "adam_step", "colsum_f32", "cast_pad", "pinhole_rays", "mip_loss_tail"]

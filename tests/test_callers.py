@@ -294,3 +294,36 @@ def test_hash_decay_vs_oracle(C):
     np.testing.assert_allclose(g.cpu().numpy() - g0, ref_g, rtol=1e-4, atol=1e-9)
     ops.hash_decay(t, g, torch.from_numpy(off).cuda(), 3, C, 0.0, loss)             # mult 0: nothing happens
     assert abs(float(loss) - ref_l) <= 1e-5 * ref_l
+
+
+def test_trainer_ray_gradients_for_pose_refinement():
+    """MipTrainer.step(ray_grads=True): the fused step also hands back d loss / d rays, equal to what autograd through
+    MipNerfModel.forward gives for the same loss (host logic on the CPU emulation)."""
+    from cpu_ops_emulation import emulate_ops
+    from oracle import common
+    from snerf_amd import mipnerf
+    from snerf_amd.trainer import MipTrainer
+    with emulate_ops():
+        torch.manual_seed(0)
+        m = mipnerf.MipNerfModel(n_samples=8, N_fine=9, no_warp_sample=0, ray_shape="cone", fn=1, radius=3., transform_idx=0, real=True, rgb_layer=3,
+                                 hidden_layer=64, density_noise=0., max_deg_point=16, proposal_hidden_layer=64, proposal_loss=True, compute="f32",
+                                 device="cpu")
+        n = 12
+        rc = common.synthetic_rays(n, seed=2)
+        g = torch.Generator().manual_seed(3)
+        tgt, td, conf = torch.rand(n, 3, generator=g), torch.rand(n, generator=g) * 20 + 2, torch.rand(n, generator=g)
+        leaves = {k: rc[k].clone().requires_grad_(True) for k in ("origins", "directions", "viewdirs")}
+        ret = m(mipnerf.Rays(**{**rc, **leaves}), False, False, 0.)
+        tr = MipTrainer(m, lr=0.0, depth_lambda=0.2, coarse_depth_mult=0.2, proposal_loss=True, proposal_lambda=0.05)
+        outs = (ret[0][1], ret[0][2], ret[0][3], ret[0][4], ret[1][0], ret[1][1], ret[1][2], ret[1][4], ret[1][5])
+        # the same loss through autograd: dL/d outputs from the fused tail, applied to the differentiable outputs
+        loss, gouts = tr.loss_and_grads(tuple(o.detach() for o in outs), tgt, td, conf)
+        g_dist0, _, g_w0, g_rgb1, g_dist1, _, _ = gouts
+        torch.autograd.backward([ret[0][1], ret[0][4], ret[1][0], ret[1][1]], [g_dist0, g_w0, g_rgb1, g_dist1])
+        tr.step(mipnerf.Rays(**rc), tgt, td, conf, randomized=False, ray_grads=True)
+        assert tr.last_ray_grads is not None
+        for k, got in zip(("origins", "directions", "viewdirs"), tr.last_ray_grads):
+            ref = leaves[k].grad
+            assert float(ref.abs().max()) > 0 and float((got - ref).abs().max()) <= 1e-4 * float(ref.abs().max()), k
+        tr.step(mipnerf.Rays(**rc), tgt, td, conf, randomized=False)
+        assert tr.last_ray_grads is None

@@ -204,3 +204,25 @@ def test_g14_mipnerf_semantic_head(golden):
     close(sem, g["l1_semantic"], 1e-5, 1e-6); close(loss, g["loss"], 1e-6, 1e-7)
     for k in names:
         close(pr[k].grad, g["grad." + k], 2e-4, 1e-7)
+
+
+def test_g19_ray_gradients_of_the_reference(golden):
+    """d loss / d (origins, directions, viewdirs) from the reference MipNerfModel's own autograd (pose refinement path) are reproduced
+    by autograd through the oracle: pins the differentiable structure (which terms carry gradient: Jacobian, |d| of the intervals;
+    which do not: the detached fine fence posts) that the ray-gradient kernels are tested against."""
+    g = golden("g19_mipnerf_raygrad")
+    hidden = 64
+    sd = common.fill_state_dict_({k: torch.empty(s) for k, s in mip.mipnerf_param_shapes(hidden=hidden, prop_hidden=64)})
+    rays = {k[5:]: v for k, v in g.items() if k.startswith("rays_")}
+    leaves = {k: rays[k].clone().requires_grad_(True) for k in ("origins", "directions", "viewdirs")}
+    ref = mip.mipnerf_forward(sd, {**rays, **leaves}, 16, 17)
+    target, td = g["target"], g["target_depth"]
+    loss = (((ref[1][0] - target) ** 2).mean() + 0.2 * ((1 / ref[1][1] - 1 / td).abs()).mean() + 0.04 * ((1 / ref[0][1] - 1 / td).abs()).mean()
+            + 0.01 * (ref[0][4] ** 2).sum() + 0.01 * ref[1][2].mean())
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    for k in ("origins", "directions", "viewdirs"):
+        ref_g = g["grad_" + k]
+        err = float((leaves[k].grad - ref_g).abs().max())
+        # both sides are fp32 autograd of an ill-conditioned sum (2^15-scaled sines): 1e-3 of the largest component is their common noise
+        assert err <= 3e-3 * float(ref_g.abs().max()), (k, err, float(ref_g.abs().max()))

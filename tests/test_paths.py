@@ -300,3 +300,83 @@ def test_mipnerf_semantic_head_vs_reference_golden(backend, golden):
         got, ref = named[k].grad.detach().cpu(), g["grad." + k]
         rel = float((got - ref).norm() / (ref.norm() + 1e-20))
         assert rel < 5e-3, (k, rel)
+
+
+def test_mipnerf_ray_gradients_vs_autograd(backend):
+    """Pose refinement (configs/nuScenes_depth_6cams: pose_refine = True; utils/sample_utils.py:410-435): origins, directions and
+    viewdirs are functions of a learnable camera pose.  d loss / d rays through both levels (encoders, contraction + Jacobian, lifted
+    Gaussians, interval lengths, view encoding) against torch autograd through the oracle, fp32 kernels; the parameter gradients of the
+    same backward are unchanged; a 6-dof pose in front of the rays receives the chained gradient."""
+    from snerf_amd import mipnerf
+    S0, P1, n, hidden = 24, 25, 36, 64
+    sd = mip_params(hidden, 64)
+    rays_c = common.synthetic_rays(n, seed=11)
+    rays_c["near"], rays_c["far"] = torch.full_like(rays_c["near"], 0.5), torch.full_like(rays_c["far"], 30.0)   # samples on both sides of |x| = 3
+    gg = torch.Generator().manual_seed(12)
+    target, tdepth = torch.rand(n, 3, generator=gg), torch.rand(n, generator=gg) * 20 + 2
+
+    def loss_fn(ret, tgt, td):
+        l = ((ret[1][0] - tgt) ** 2).mean()
+        l = l + 0.2 * ((1 / ret[1][1] - 1 / td).abs()).mean() + 0.04 * ((1 / ret[0][1] - 1 / td).abs()).mean()
+        return l + 0.01 * (ret[0][4] ** 2).sum() + 0.01 * ret[1][2].mean()
+
+    def posed(rays, rot, trans):         # sample_rays: directions / viewdirs rotated, origins shifted by the refined pose
+        R = torch.eye(3, device=rot.device) + torch.stack([torch.stack([rot[0] * 0, -rot[2], rot[1]]), torch.stack([rot[2], rot[0] * 0, -rot[0]]),
+                                                           torch.stack([-rot[1], rot[0], rot[0] * 0])])
+        out = dict(rays)
+        out["directions"] = (rays["directions"][:, None, :] * R).sum(-1)
+        out["viewdirs"] = (rays["viewdirs"][:, None, :] * R).sum(-1)
+        out["origins"] = rays["origins"] + trans
+        return out
+    # oracle
+    pr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    rot_r, tr_r = torch.tensor([0.01, -0.02, 0.015], requires_grad=True), torch.tensor([0.05, -0.03, 0.02], requires_grad=True)
+    rr = posed(rays_c, rot_r, tr_r)
+    for k in ("origins", "directions", "viewdirs"):
+        rr[k].retain_grad()
+    ref = om.mipnerf_forward(pr, rr, S0, P1)
+    loss_ref = loss_fn([[None, ref[0][1], ref[0][2], ref[0][3], ref[0][4]], [ref[1][0], ref[1][1], ref[1][2], None, ref[1][4], ref[1][5]]], target, tdepth)
+    loss_ref.backward()
+    # build
+    m = make_mip(hidden, 64, S0, P1, "f32", sd)
+    rot, tr = torch.tensor([0.01, -0.02, 0.015], device=DEV, requires_grad=True), torch.tensor([0.05, -0.03, 0.02], device=DEV, requires_grad=True)
+    rb = posed({k: v.to(DEV) for k, v in rays_c.items()}, rot, tr)
+    for k in ("origins", "directions", "viewdirs"):
+        rb[k].retain_grad()
+    ret = m(mipnerf.Rays(**rb), False, False, 0.)
+    loss = loss_fn(ret, target.to(DEV), tdepth.to(DEV))
+    loss.backward()
+    close(loss, loss_ref, 3e-4, 3e-4, "loss")
+    for k in ("origins", "directions", "viewdirs"):
+        g, gr = rb[k].grad.cpu(), rr[k].grad
+        assert float(gr.abs().max()) > 0
+        err = (g - gr).abs().max().item()
+        assert err <= 2e-3 * gr.abs().max().item(), (k, err, gr.abs().max().item())
+    for g, gr, what in ((rot.grad.cpu(), rot_r.grad, "rotation"), (tr.grad.cpu(), tr_r.grad, "translation")):
+        assert (g - gr).abs().max().item() <= 2e-3 * gr.abs().max().item(), (what, g, gr)
+    check_grads(dict(m.named_parameters()), pr, sd, "f32", 3e-4)
+    with pytest.raises(NotImplementedError):
+        bad = dict(rb); bad["radii"] = rb["radii"].detach().clone().requires_grad_(True)
+        m(mipnerf.Rays(**{k: (v.detach() if k != "radii" else v) for k, v in bad.items()}), False, False, 0.)
+
+
+def test_mipnerf_ray_gradients_vs_reference_golden(backend, golden):
+    """The same backward against the reference's own autograd (G19: reference MipNerfModel, rays requiring grad)."""
+    from snerf_amd import mipnerf
+    g = golden("g19_mipnerf_raygrad")
+    sd = mip_params(64, 64)
+    rays = {k[5:]: v.to(DEV) for k, v in g.items() if k.startswith("rays_")}
+    for k in ("origins", "directions", "viewdirs"):
+        rays[k] = rays[k].clone().requires_grad_(True)
+    m = make_mip(64, 64, 16, 17, "f32", sd)
+    ret = m(mipnerf.Rays(**rays), False, False, 0.)
+    target, td = g["target"].to(DEV), g["target_depth"].to(DEV)
+    loss = (((ret[1][0] - target) ** 2).mean() + 0.2 * ((1 / ret[1][1] - 1 / td).abs()).mean() + 0.04 * ((1 / ret[0][1] - 1 / td).abs()).mean()
+            + 0.01 * (ret[0][4] ** 2).sum() + 0.01 * ret[1][2].mean())
+    loss.backward()
+    close(loss, g["loss"], 1e-4, 1e-5, "loss")
+    close(ret[1][0], g["l1_rgb"], 1e-4, 1e-5, "rgb")
+    for k in ("origins", "directions", "viewdirs"):
+        ref_g = g["grad_" + k]
+        err = float((rays[k].grad.cpu() - ref_g).abs().max())
+        assert err <= 3e-3 * float(ref_g.abs().max()), (k, err, float(ref_g.abs().max()))
