@@ -273,6 +273,35 @@ class Model(_ArenaModule):
                 out.append((u, torch.rand(R, ns, sample_n, device=dev)))
         return out
 
+    def _forward_extras(self, batch, train_frac, draws, sample_n, sample_m):
+        """compute_extras=True, the rendering scripts' mode (random_render_waymo_seq.py:197; render.py:243-267, models.py:316-346):
+        besides rgb / depth / acc every level carries distance_mean (the log-space expectation = depth), the 5 / 50 / 95 % distance
+        percentiles, and the first `vis_num_rays` rays' histograms (ray_sdist, ray_weights, ray_rgbs; the proposal levels get the final
+        level's average colour).  Inference only: nothing is saved for backward."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.param_list()):
+            raise NotImplementedError("compute_extras is the inference / rendering mode: call it under torch.no_grad()")
+        n = int(getattr(self.config, "vis_num_rays", 16)) if self.config is not None else 16
+        levels, _ = self._run(batch, False, train_frac, draws, sample_n, sample_m)
+        t_far = batch['far'].detach().to(levels[0]["tdist"].device, torch.float32).reshape(-1).contiguous()
+        renderings, history = [], []
+        for L in levels:
+            pct = ops.zip_percentiles(L["tdist"], L["weights"], t_far)
+            r = dict(rgb=L["rgb"], depth=L["depth"], acc=L["acc"], distance_mean=L["depth"], distance_percentile_5=pct[:, 0],
+                     distance_median=pct[:, 1], distance_percentile_95=pct[:, 2], ray_sdist=L["sdist"][:n], ray_weights=L["weights"][:n])
+            if L["semantic"] is not None:
+                r["semantic"] = L["semantic"]
+            renderings.append(r)
+            history.append(dict(sdist=L["sdist"], weights=L["weights"], tdist=L["tdist"]))
+        fin = levels[2]
+        S = fin["weights"].shape[1]
+        pad = 0.001                                                                     # rgb_padding, models.py:372
+        rgbs = torch.sigmoid(fin["raw_rgb"][:min(n, fin["weights"].shape[0]) * S].float().reshape(-1, S, 3)) * (1 + 2 * pad) - pad
+        renderings[2]["ray_rgbs"] = rgbs
+        final = (rgbs * renderings[2]["ray_weights"][..., None]).sum(-2)
+        for r in renderings[:2]:
+            r["ray_rgbs"] = final[:, None, :].expand(-1, r["ray_weights"].shape[1], -1)
+        return renderings, history
+
     def forward(self, rand, batch, train_frac, compute_extras, zero_glo=True, sample_n=7, sample_m=3, step=0, max_step=25000,
                 cal_input_grad=False, draws=None):
         """-> (renderings, ray_history) like models.py:98-349.  `draws` = [(u, deg_jitter)] * 3 overrides the RNG (parity tests)."""
@@ -298,37 +327,6 @@ class Model(_ArenaModule):
         return renderings, history
 
 
-def _extras(self, batch, train_frac, draws, sample_n, sample_m):
-    """compute_extras=True, the rendering scripts' mode (random_render_waymo_seq.py:197; render.py:243-267, models.py:316-346):
-    besides rgb / depth / acc every level carries distance_mean (the log-space expectation = depth), the 5 / 50 / 95 % distance
-    percentiles, and the first `vis_num_rays` rays' histograms (ray_sdist, ray_weights, ray_rgbs; the proposal levels get the final
-    level's average colour).  Inference only: nothing is saved for backward."""
-    if torch.is_grad_enabled() and any(p.requires_grad for p in self.param_list()):
-        raise NotImplementedError("compute_extras is the inference / rendering mode: call it under torch.no_grad()")
-    n = int(getattr(self.config, "vis_num_rays", 16)) if self.config is not None else 16
-    levels, _ = self._run(batch, False, train_frac, draws, sample_n, sample_m)
-    t_far = batch['far'].detach().to(levels[0]["tdist"].device, torch.float32).reshape(-1).contiguous()
-    renderings, history = [], []
-    for L in levels:
-        pct = ops.zip_percentiles(L["tdist"], L["weights"], t_far)
-        r = dict(rgb=L["rgb"], depth=L["depth"], acc=L["acc"], distance_mean=L["depth"], distance_percentile_5=pct[:, 0],
-                 distance_median=pct[:, 1], distance_percentile_95=pct[:, 2], ray_sdist=L["sdist"][:n], ray_weights=L["weights"][:n])
-        if L["semantic"] is not None:
-            r["semantic"] = L["semantic"]
-        renderings.append(r)
-        history.append(dict(sdist=L["sdist"], weights=L["weights"], tdist=L["tdist"]))
-    fin = levels[2]
-    S = fin["weights"].shape[1]
-    pad = 0.001                                                                     # rgb_padding, models.py:372
-    rgbs = torch.sigmoid(fin["raw_rgb"][:min(n, fin["weights"].shape[0]) * S].float().reshape(-1, S, 3)) * (1 + 2 * pad) - pad
-    renderings[2]["ray_rgbs"] = rgbs
-    final = (rgbs * renderings[2]["ray_weights"][..., None]).sum(-2)
-    for r in renderings[:2]:
-        r["ray_rgbs"] = final[:, None, :].expand(-1, r["ray_weights"].shape[1], -1)
-    return renderings, history
-
-
-Model._forward_extras = _extras
 
 
 def _dist_info(accelerator):
