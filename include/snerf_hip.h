@@ -41,7 +41,8 @@ int snerf_version(void);
  * with zero padding; lda/ldw multiples of 8/4; Y is `dtype` or fp32 (out_f32).  With W := W^T the
  * same entry computes the data gradient; ACT_MASK applies the ReLU mask from `aux` and `colsum`
  * (fp32 [n_store], accumulated) receives the column sums = bias gradient of the layer below; `colsum_ws`
- * (fp32 [2*ceil(M/128), N], contents irrelevant) lets that reduction run without atomics.
+ * (fp32 [max(2*ceil(M/128), 2*min(ceil(M/256)*(N/256), 1024)), N], contents irrelevant) lets that reduction run without atomics:
+ * one partial row per 128-row slab, or -- persistent kernel -- one per (workgroup, wave row), kept in registers across its tiles.
  * The two *_BITS activations carry the ReLU mask of a training step as 1 bit per element (8*ceil(M/256) * N/64 blocks of 64
  * words; word l of block (32-row block, 64-column group) = rows 8*it + l/8, columns 8*(l%8) + e at bit 8*it + e): 1/16 of the
  * bytes of the activation and DMA-able ahead of use.  Only the persistent kernel implements them (bf16, variant 8,

@@ -738,19 +738,23 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
       ((unsigned*)p.aux)[blk * 64 + ln] = mw;            // 256 contiguous bytes per wave
     }
   };
+  // The column sums stay in registers across this workgroup's tiles: its tiles normally all lie in ONE column block (tile index
+  // stride G is a multiple of tiles_n for the shapes of the step), so the partial sums are flushed once per workgroup -- row
+  // (blockIdx.x, wave row) of the zero-initialised workspace -- instead of once per tile.  A change of column block flushes early.
   auto flush_colsum = [&](int em0, int en0) __attribute__((always_inline)) {
     if constexpr (!COLSUM) return;
+    (void)em0;
     int zero;
     asm volatile("s_lshr_b32 %0, %1, 30" : "=s"(zero) : "s"(c_kt));
     const int ln = lane | zero;
     const int pch = ln & 7;
     const int ncol = en0 + wc * 64 + pch * 8;
-    const long srow = (long)((em0 >> 8) * 2 + wr) * p.N;
+    const long srow = (long)((int)blockIdx.x * 2 + wr) * p.N;
 #pragma unroll
     for (int e = 0; e < (COLSUM ? 8 : 0); ++e) {
       float c = cs[e];
       c += __shfl_xor(c, 8, 64); c += __shfl_xor(c, 16, 64); c += __shfl_xor(c, 32, 64);
-      if (ln < 8 && ncol + e < p.n_store) p.colsum_ws[srow + ncol + e] = c;
+      if (ln < 8 && ncol + e < p.n_store) p.colsum_ws[srow + ncol + e] += c;
       cs[e] = 0.f;
     }
   };
@@ -819,7 +823,7 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
     end_mfma();
     // P2: A0 x B_S; every A0 fragment is replaced by the A1 fragment of the same position right after its last use
     stage(db, 0);
-    if (pending) { unit(3, em0, en0, epar); flush_colsum(em0, en0); pending = false; }
+    if (pending) { unit(3, em0, en0, epar); if (en0 != n0) flush_colsum(em0, en0); pending = false; }
     end_load();
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
@@ -963,6 +967,7 @@ static int launch_nt8p(const GemmNT& p, hipStream_t stream) {
   const int tiles = tiles_m * (p.N / 256);
   const int grid = tiles < n_cu ? tiles : n_cu;
   const bool cs = p.colsum_ws != nullptr;
+  if (cs) (void)hipMemsetAsync(p.colsum_ws, 0, (size_t)grid * 2 * p.N * sizeof(float), stream);   // the workgroups accumulate into it
   const dim3 g(grid), b(512);
   if (p.act == ACT_MASK) {
     if (cs) hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_MASK, true>), g, b, LDS, stream, p);
@@ -982,7 +987,7 @@ static int launch_nt8p(const GemmNT& p, hipStream_t stream) {
     hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_NONE, false>), g, b, LDS, stream, p);
   }
   if (p.colsum_ws != nullptr) {
-    const int rows = tiles_m * 2;
+    const int rows = grid * 2;                            // one partial row per (workgroup, wave row)
     int ychunks = rows / 64;
     ychunks = ychunks < 1 ? 1 : (ychunks > 64 ? 64 : ychunks);
     hipLaunchKernelGGL(colsum_reduce_kernel, dim3((p.n_store + 255) / 256, ychunks), dim3(256), 0, stream, p.colsum_ws, rows, p.N, p.n_store, p.colsum);

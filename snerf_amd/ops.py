@@ -71,8 +71,9 @@ def linear_fwd(A, W, bias, Y, K, n_store, act, dt, out_f32=False, aux=None, cols
     if act >= ACT_RELU_BITS:
         assert aux is not None and aux.dtype == torch.int32 and aux.is_contiguous() and aux.numel() >= mask_bits_words(M, W.shape[0])
     ws = None
-    if colsum is not None:  # per-row-slab partial column sums (no atomics); folded into `colsum` by a second kernel
-        ws = torch.empty(2 * ((M + 127) // 128), W.shape[0], dtype=torch.float32, device=A.device)
+    if colsum is not None:  # partial column sums (no atomics), one row per row slab or per (workgroup, wave row); folded into `colsum` by a second kernel
+        tiles = ((M + 255) // 256) * max(W.shape[0] // 256, 1)
+        ws = torch.empty(max(2 * ((M + 127) // 128), 2 * min(tiles, 1024)), W.shape[0], dtype=torch.float32, device=A.device)
     _lib.call("snerf_linear_fwd", _p(A), A.stride(0), _p(W), W.stride(0), _p(bias), _p(Y), Y.stride(0),
               _p(aux), 0 if (aux is None or act >= ACT_RELU_BITS) else aux.stride(0), _p(colsum), _p(ws), M, W.shape[0], K, n_store, act, dt,
               1 if out_f32 else 0, variant, _stream())

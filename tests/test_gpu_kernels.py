@@ -455,3 +455,27 @@ def test_mip_viewenc_bwd_and_composite_direction_gradient_vs_oracle_autograd():
                           cu(g_acc), cu(g_w), d_rgb, d_den, g_dirs=g_dirs)
     err = (g_dirs.cpu() - d.grad).abs().max()
     assert float(err) <= 2e-4 * float(d.grad.abs().max()), (float(err), float(d.grad.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(70001, 768, 256), (131072, 1024, 128), (300, 1024, 128), (66000, 256, 192)])
+def test_persistent_kernel_colsum_across_tiles(M, N, K):
+    """The persistent kernel keeps the column sums in registers across a workgroup's tiles and flushes once per workgroup (or when the
+    column block changes: N = 768 gives 3 column blocks against a tile stride of 256 workgroups, so consecutive tiles of a workgroup do
+    change block).  Plain and masked data gradients, fewer tiles than compute units (M = 300), ragged last row tile; twice in a row into
+    the same accumulator (the workspace is re-zeroed per launch)."""
+    from snerf_amd import ops as O
+    dZ = (gen(M, K, seed=1) * 0.5).bfloat16().cuda()
+    Wt = (gen(N, K, seed=2) / K ** 0.5).bfloat16().cuda()
+    act = gen(M, N, seed=3).bfloat16().cuda()
+    ref_full = dZ.double().cpu() @ Wt.double().cpu().t()
+    for mode, aux in ((O.ACT_NONE, None), (O.ACT_MASK, act)):
+        dX = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+        cs = torch.zeros(N, dtype=torch.float32, device="cuda")
+        for _ in range(2):
+            O.linear_fwd(dZ, Wt, None, dX, K, N, mode, O.BF16, aux=aux, colsum=cs, variant=8)
+        ref = ref_full * (act.double().cpu() > 0) if aux is not None else ref_full
+        # the kernel sums the bf16-rounded outputs: compare against the column sums of what it stored, and of the exact product
+        stored = dX.double().cpu().sum(0)
+        close(cs / 2, stored, 2e-4, 2e-3 * max(1.0, (M / 515) ** 0.5), f"colsum of the stored values, act {mode}")
+        close(cs / 2, ref.sum(0), 2e-2, 5e-2 * max(1.0, (M / 515) ** 0.5), f"colsum, act {mode}")
