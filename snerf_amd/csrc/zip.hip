@@ -556,7 +556,36 @@ __global__ __launch_bounds__(256) void zip_encode_bwd_lds_kernel(ZipEnc a, int l
   for (int k = threadIdx.x; k < cells; k += 256) lds_tab[k] = 0.f;
   __syncthreads();
   const long P = a.R * a.S;
-  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < P; p += (long)gridDim.x * 256) zip_point_level<float, OT, C, 2>(a, p, level, lds_tab);
+  // A slab of a dense level is a range of z-layers (row = x + y (res+1) + z (res+1)^2).  When the level needs several slabs every
+  // slab pass walks all intervals, so an interval is first tested against the slab with ONE contracted point: its 7 multisamples lie
+  // within rho = |d| (t1 - t0) / 2 + radius * t1 / 2 of the axis midpoint, the contraction is 1-Lipschitz and the [0,1]^3 mapping
+  // scales by 1/4, so their z-cells lie in a known interval; intervals that cannot touch the slab (+ one layer of margin) skip the
+  // full featurisation (sincos / cbrt / erf per multisample).
+  const float scale = exp2f(level * a.Sl) * a.H - 1.0f;
+  const uint32_t res = (uint32_t)ceilf(scale) + 1;
+  const long layer = (long)(res + 1) * (res + 1);
+  const bool dense = layer * (res + 1) <= (long)rows;            // hashed levels small enough for the LDS path have no z-order
+  const bool whole = !dense || (a.slab_row0 == 0 && a.slab_rows >= rows);
+  const long z_lo = a.slab_row0 / layer, z_hi = (a.slab_row0 + a.slab_rows - 1) / layer;
+  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < P; p += (long)gridDim.x * 256) {
+    if (!whole) {
+      const long ray = p / a.S;
+      const int i = (int)(p - ray * a.S);
+      const float t0 = a.tdist[ray * (a.S + 1) + i], t1 = a.tdist[ray * (a.S + 1) + i + 1];
+      const float tm = 0.5f * (t0 + t1);
+      float x[3], dn = 0.f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { const float dk = a.directions[ray * 3 + k]; x[k] = a.origins[ray * 3 + k] + dk * tm; dn += dk * dk; }
+      const float rho = sqrtf(dn) * 0.5f * fabsf(t1 - t0) + a.radii[ray] * fmaxf(fabsf(t0), fabsf(t1)) * 0.5f;
+      const float msq = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
+      float zc = x[2];
+      if (msq > 1.f) { const float mag = sqrtf(msq); zc = (2.f * mag - 1.f) / msq * x[2]; }
+      const float z01 = (zc / 2.f + 1.f) / 2.f, r01 = rho * 0.25f * 1.0001f + 1e-6f;
+      const float c_lo = floorf((z01 - r01) * scale + 0.5f) - 1.f, c_hi = floorf((z01 + r01) * scale + 0.5f) + 2.f;   // corner layers, +-1 margin
+      if (c_hi < (float)z_lo || c_lo > (float)z_hi) continue;
+    }
+    zip_point_level<float, OT, C, 2>(a, p, level, lds_tab);
+  }
   __syncthreads();
   float* dst = a.grad_table + ((long)a.offsets[level] + a.slab_row0) * C;
   for (int k = threadIdx.x; k < cells; k += 256) {

@@ -406,3 +406,37 @@ def test_zip_encode_thread_mappings_agree(golden):
         for lvl in range(3):
             assert torch.equal(h_inf[lvl]["weights"], h_trn[lvl]["weights"].detach()), (compute, lvl)
         assert torch.equal(r_inf[-1]["rgb"], r_trn[-1]["rgb"].detach())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lvl,radius", [(0, 2.0 / 2050 / 12 ** 0.5), (0, 0.05), (2, 2.0 / 2050 / 12 ** 0.5), (2, 0.02)])
+def test_zip_encode_bwd_lds_slabs_match_global_atomics(lvl, radius):
+    """The LDS-privatised backward of the dense low levels (several z-slabs per level, intervals rejected per slab by a conservative
+    bound on their multisamples' z-cells) against the plain global-atomic scatter of the same levels: production grids (2^21 rows),
+    scattered rays, thin and very wide cones (wide cones make the bound loose: nothing may be dropped)."""
+    from snerf_amd import ops, zipnerf
+    m = zipnerf.Model(config=None, raydist_fn='power_transformation', opaque_background=True, compute="bf16", table_dtype="f16", init_std=0.1)
+    e = m.encs[lvl]
+    assert e.lds_levels >= 2 and e.lds_slabs > e.lds_levels          # at least one level takes several slabs
+    R, S = 2048, 16
+    g = torch.Generator().manual_seed(7 + lvl)
+    d = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1)
+    up = torch.tensor([0.0, 1.0, 0.0]).expand(R, 3)
+    bx = torch.nn.functional.normalize(torch.cross(d, up, dim=-1), dim=-1)
+    by = torch.nn.functional.normalize(torch.cross(d, bx, dim=-1), dim=-1)
+    o = torch.randn(R, 3, generator=g) * 0.3
+    t = torch.sort(torch.rand(R, S + 1, generator=g) ** 2 * 12 + 0.05, -1).values.contiguous()      # inside and far outside the unit ball
+    args = [t.cuda(), o.cuda(), d.cuda(), torch.full((R,), radius).cuda(), bx.cuda(), by.cuda(), None]
+    k = e.lds_levels                                                   # only the levels the LDS path owns
+    dF = (torch.randn(R * S, 64, generator=g) * 0.01).bfloat16().cuda()
+    slabs = sum(-(-int(x) // e.lds_cells) for x in (e.offsets[1:k + 1] - e.offsets[:k]))
+    g_lds = torch.zeros(e.rows, e.C, device="cuda")
+    ops.zip_encode_bwd(*args, m.dev_offsets[lvl], m.dev_sizes[lvl], dF, g_lds, k, e.C, 7, 3, e.Sl, e.H, 0.35, k, e.lds_cells, slabs)
+    g_glb = torch.zeros(e.rows, e.C, device="cuda")
+    ops.zip_encode_bwd(*args, m.dev_offsets[lvl], m.dev_sizes[lvl], dF, g_glb, k, e.C, 7, 3, e.Sl, e.H, 0.35, 0, e.lds_cells, 0)
+    rows = int(e.offsets[k])
+    a, b = g_lds[:rows], g_glb[:rows]
+    assert float(b.abs().max()) > 0 and float((b != 0).float().mean()) > 0.05
+    err = float((a - b).abs().max())
+    assert err <= 2e-5 * float(b.abs().max()), (err, float(b.abs().max()))       # summation order only
+    assert float(g_lds[rows:].abs().max()) == 0 and float(g_glb[rows:].abs().max()) == 0
