@@ -45,13 +45,19 @@ class _Encoder:
         self.offsets, self.res, self.scale = _level_layout(self.L, base_resolution, desired_resolution, log2_hashmap_size)
         self.Sl = float(np.log2(self.scale))
         self.rows = int(self.offsets[-1])
-        # leading (small, dense, heavily contended) levels take the LDS-privatised backward, in slabs of <= 36 K cells
-        # (144 KB fp32); a level qualifies while it needs at most 8 slabs (each slab re-walks all points)
+        # leading (small, heavily contended) levels take the LDS-privatised backward, in slabs of <= 36 K cells (144 KB fp32).  Every
+        # slab pass walks all intervals; on a DENSE level a slab is a range of z-layers and the walk rejects an interval with one
+        # contracted point, so such a level qualifies up to 32 slabs, a hashed one (no spatial order in its rows) up to 8
         sizes = np.diff(self.offsets)
         self.lds_cells = (144 * 1024) // (4 * level_dim)
         self.lds_levels, self.lds_slabs = 0, 0
-        while self.lds_levels < self.L and -(-int(sizes[self.lds_levels]) // self.lds_cells) <= 8:
-            self.lds_slabs += -(-int(sizes[self.lds_levels]) // self.lds_cells)
+        while self.lds_levels < self.L:
+            l = self.lds_levels
+            slabs = -(-int(sizes[l]) // self.lds_cells)
+            dense = int(self.res[l]) ** 3 <= int(sizes[l])
+            if slabs > (32 if dense else 8):
+                break
+            self.lds_slabs += slabs
             self.lds_levels += 1
 
 
