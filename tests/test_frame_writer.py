@@ -124,3 +124,13 @@ def test_frame_writer_end_to_end(tmp_path, golden):
             im = np.array(Image.open(str(tmp_path / k / f"{idx:05d}.png")))
             assert np.array_equal(im, g["png_" + k]), (idx, k)
     assert os.path.exists(str(tmp_path / "rgb" / "00007.png")) and not os.path.exists(str(tmp_path / "depth" / "00007.png"))
+    # utils.save_img_u8 drop-in on a device tensor (quantised on the GPU) = the same file content as the host route
+    fw.save_img_u8(c(g["rgb"]), str(tmp_path / "dev.png"))
+    assert np.array_equal(np.array(Image.open(str(tmp_path / "dev.png"))), g["png_rgb"])
+    # a writer error (directory removed under it) surfaces at close()
+    import shutil
+    w = fw.FrameWriter(str(tmp_path / "gone"), threads=2)
+    shutil.rmtree(str(tmp_path / "gone"))
+    w.write(0, dict(rgb=c(g["rgb"])))
+    with pytest.raises(OSError):
+        w.close()

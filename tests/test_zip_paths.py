@@ -314,6 +314,10 @@ def test_zip_render_image_chunks_match_one_pass(backend, golden):
         # (a percentile on a flat stretch of the CDF amplifies the last-bit differences of a differently shaped GEMM batch)
         close(out[k].reshape(ref[-1][k].shape), ref[-1][k], 1e-4 if k.startswith("distance") else 1e-6, 1e-6, k)
     assert len(out["ray_sdist"]) == 3 and out["ray_sdist"][0].shape == (3, 65) and out["ray_rgbs"][2].shape == (3, 32, 3)
+    # the caller's accelerate.Accelerator is accepted as it is (only its process index / count are read)
+    acc = types.SimpleNamespace(local_process_index=0, num_processes=1, is_local_main_process=True)
+    out2 = zipnerf.render_image(fn, acc, frame, False, cfg)
+    assert torch.equal(out2["rgb"], out["rgb"]) and torch.equal(out2["depth"], out["depth"])
 
 
 @pytest.mark.gpu
