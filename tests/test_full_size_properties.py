@@ -112,3 +112,44 @@ def test_path_b_properties_at_full_size():
     assert float(full["acc_map"].max()) <= 1.0 + 1e-4 and float(full["acc_map"].min()) >= 0.0
     assert bool(torch.isfinite(full["rgb_map"]).all()) and float(full["rgb_map"].min()) >= 0.0 and float(full["rgb_map"].max()) <= 1.0 + 1e-5
     assert bool((full["depth_map"] >= 0).all()) and bool((full["depth_map"] <= 6.0 + 1e-3).all())
+
+
+def test_path_c_properties_at_full_size():
+    """BASELINE config 4 shape: 65 536 rays through the production zipnerf model (2^21-row hash grids, 64 + 64 + 32 intervals x 7
+    multisamples, semantic head).  Rays are independent (a sub-batch renders to the same values), fence posts are sorted inside
+    [0, 1] on every level, the weights of an opaque-background ray sum to 1, class probabilities sum to the accumulated weight,
+    the run is deterministic, and the fp32-parity kernels agree with the bf16 / fp16-table kernels."""
+    from snerf_amd import ops, zipnerf
+    R = 65536
+    dev = "cuda"
+    g = torch.Generator().manual_seed(5)
+    pix = torch.randint(0, 1920 * 1280, (R,), generator=g)
+    K = torch.tensor([[2050.0, 0.0, 960.0], [0.0, 2050.0, 640.0], [0.0, 0.0, 1.0]])
+    c2w = torch.eye(4)[:3].clone()
+    rays = ops.zip_pixels_to_rays((pix % 1920).int().to(dev), (pix // 1920).int().to(dev), None, torch.linalg.inv(K)[None].to(dev), c2w[None].to(dev))
+    batch = dict(rays, near=torch.full((R, 1), 0.1, device=dev), far=torch.full((R, 1), 10.0, device=dev))
+    batch["origins"] = batch["origins"] + (torch.randn(R, 3, generator=g) * 0.05).to(dev)
+    outs = {}
+    for compute, table in (("f32", "f32"), ("bf16", "f16")):
+        torch.manual_seed(0)
+        m = zipnerf.Model(config=None, raydist_fn='power_transformation', opaque_background=True, compute=compute, table_dtype=table, init_std=0.1,
+                          use_semantic=True)
+        m.scattered_rays = True
+        with torch.no_grad():
+            rend, hist = m(None, batch, 1.0, False)
+            rend2, _ = m(None, batch, 1.0, False)
+            sub = {k: v[1000:5000] for k, v in batch.items()}
+            rend_s, hist_s = m(None, sub, 1.0, False)
+        assert torch.equal(rend[-1]["rgb"], rend2[-1]["rgb"]) and torch.equal(rend[-1]["depth"], rend2[-1]["depth"]), "not deterministic"
+        tol = 1e-5 if compute == "f32" else 2e-2      # a different batch shape reaches the GEMMs' row tiling (bf16 rounding), nothing else
+        assert float((rend_s[-1]["rgb"] - rend[-1]["rgb"][1000:5000]).abs().max()) <= tol
+        assert torch.equal(hist_s[0]["sdist"], hist[0]["sdist"][1000:5000])          # level 0 has no network upstream: bit-identical
+        for lvl in range(3):
+            sd, w = hist[lvl]["sdist"], hist[lvl]["weights"]
+            assert bool((sd[:, 1:] >= sd[:, :-1]).all()) and float(sd.min()) >= 0 and float(sd.max()) <= 1
+            assert bool((w >= 0).all()) and float((w.sum(-1) - 1).abs().max()) < (1e-4 if compute == "f32" else 2e-2)
+        sem = rend[-1]["semantic"]
+        assert float((sem.sum(-1) - rend[-1]["acc"]).abs().max()) < (1e-4 if compute == "f32" else 2e-2)
+        assert bool(torch.isfinite(rend[-1]["rgb"]).all()) and bool(torch.isfinite(rend[-1]["depth"]).all())
+        outs[compute] = rend[-1]["rgb"].float()
+    assert float((outs["bf16"] - outs["f32"]).abs().max()) < 3e-2
