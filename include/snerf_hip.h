@@ -311,6 +311,17 @@ int snerf_mip_encode_bwd(const float* s_vals, const float* origins, const float*
 /* dV fp32 [n_rays*S, ld >= 3 + 6*deg] = d loss / d view-direction encoding (mip.py:12-21) -> g_viewdirs [n_rays,3] (written). */
 int snerf_mip_viewenc_bwd(const float* viewdirs, long n_rays, int S, int deg, const float* dV, long ld, float* g_viewdirs, void* stream);
 
+/* Inference of one zipnerf PROPOSAL level in a single launch: snerf_zip_encode_fwd for the single-channel grid (C = 1) followed by the
+ * proposal MLP on the features still in registers -- density_layer = Linear(L, hidden) + ReLU + Linear(hidden, 1)
+ * (internal/models.py:425-427, 481-519 with disable_rgb).  w1 [hidden, L], b1 [hidden], w2 [hidden], b2 [1]: fp32 device pointers (the
+ * state_dict tensors prop_mlp_i.density_layer.{0,2}.{weight,bias}); round_bf16 = 1 reproduces the bf16 GEMM path's roundings
+ * (features, weights, hidden layer), 0 = fp32 throughout.  raw_density [R*S] fp32. */
+int snerf_zip_encode_prop_fwd(const float* tdist, const float* origins, const float* directions, const float* radii, const float* base_x,
+                              const float* base_y, const float* deg_jitter, const void* table, const int* offsets, const int* grid_sizes,
+                              long R, int S, int L, int n, int m, float Sl, int H, float std_scale, int table_dtype, const float* w1,
+                              const float* b1, const float* w2, const float* b2, int hidden, int round_bf16, float* raw_density,
+                              void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -538,6 +538,130 @@ __global__ __launch_bounds__(256) void zip_encode_fwd_all_kernel(ZipEnc a) {
   }
 }
 
+// Inference of a proposal level in ONE kernel: featurisation of the single-channel grid (all levels per thread, as above) followed by
+// the proposal MLP itself -- Linear(L -> hidden) + ReLU + Linear(hidden -> 1) = 448 MACs per interval at L = 6 (internal/models.py:425-427,
+// 481-519 with disable_rgb) -- on the features still in registers.  Replaces feature store + two HBM-bound GEMM launches (M = 4.2 M
+// rows, N = 64 / 1) per level and chunk.  `rnd` reproduces the bf16 GEMM path's roundings (features, weights and the hidden layer
+// in bf16, fp32 accumulation); without it everything is fp32 (parity mode).  Weights live in LDS and are read as broadcasts.
+struct ZipPropMlp { const float *w1, *b1, *w2, *b2; int hidden, rnd; float* raw_density; };
+
+__device__ __forceinline__ float zip_rbf(float v, int rnd) { return rnd ? (float)(__bf16)v : v; }
+
+template <typename TT>
+__global__ __launch_bounds__(256) void zip_encode_prop_kernel(ZipEnc a, ZipPropMlp w) {
+  extern __shared__ float lw[];                          // [hidden][L] | b1[hidden] | w2[hidden] | b2
+  const int nw1 = w.hidden * a.L;
+  for (int k = threadIdx.x; k < nw1; k += 256) lw[k] = zip_rbf(w.w1[k], w.rnd);
+  for (int k = threadIdx.x; k < w.hidden; k += 256) { lw[nw1 + k] = w.b1[k]; lw[nw1 + w.hidden + k] = zip_rbf(w.w2[k], w.rnd); }
+  if (threadIdx.x == 0) lw[nw1 + 2 * w.hidden] = w.b2[0];
+  __syncthreads();
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= a.R * a.S) return;
+  const long ray = p / a.S;
+  const int i = (int)(p - ray * a.S);
+  const float t0 = a.tdist[ray * (a.S + 1) + i], t1 = a.tdist[ray * (a.S + 1) + i + 1];
+  float o[3], d[3], bx[3], by[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { o[k] = a.origins[ray * 3 + k]; d[k] = a.directions[ray * 3 + k]; bx[k] = a.base_x[ray * 3 + k]; by[k] = a.base_y[ray * 3 + k]; }
+  const float rad = a.radii[ray];
+  float X[8][3], SDI[8];
+  unsigned inb = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (j < a.n) {
+      float sd;
+      zip_sample_point(a, ray, i, j, t0, t1, o, d, bx, by, rad, X[j], &sd);
+      SDI[j] = sd;
+      if (!(X[j][0] < 0.f || X[j][0] > 1.f || X[j][1] < 0.f || X[j][1] > 1.f || X[j][2] < 0.f || X[j][2] > 1.f)) inb |= 1u << j;
+    }
+  }
+  float feat[16];
+#pragma unroll
+  for (int level = 0; level < 16; ++level) {
+    feat[level] = 0.f;
+    if (level >= a.L) continue;
+    const uint32_t hs = a.offsets[level + 1] - a.offsets[level];
+    const float scale = exp2f(level * a.Sl) * a.H - 1.0f;
+    const uint32_t res = (uint32_t)ceilf(scale) + 1;
+    const TT* tab = (const TT*)a.table + (long)a.offsets[level];
+    const float gs = (float)a.grid_sizes[level];
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j >= a.n || !((inb >> j) & 1u)) continue;
+      const float sd = SDI[j];
+      const float we = erff(1.f / sqrtf(8.f * sd * sd * gs * gs));
+      float fr[3];
+      uint32_t pg[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float ps = X[j][k] * scale + 0.5f;
+        const float fl = floorf(ps);
+        pg[k] = (uint32_t)fl;
+        fr[k] = ps - fl;
+      }
+      float pa[8];
+#pragma unroll
+      for (int yz = 0; yz < 4; ++yz) {
+        uint32_t pl[3] = {pg[0], pg[1] + (yz & 1), pg[2] + (yz >> 1)};
+        const long r0 = zip_grid_index(hs, res, pl);
+        pl[0] = pg[0] + 1;
+        const long r1 = zip_grid_index(hs, res, pl);
+        float v0, v1;
+        if (sizeof(TT) == 2 && (r0 ^ r1) == 1) {
+          const uint32_t word = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(tab) + (r0 & ~1L));
+          const uint16_t lo16 = (uint16_t)(word & 0xffffu), hi16 = (uint16_t)(word >> 16);
+          const uint16_t b0 = (r0 & 1) ? hi16 : lo16, b1 = (r0 & 1) ? lo16 : hi16;
+          if constexpr (sizeof(TT) == 2) { v0 = (float)__builtin_bit_cast(TT, b0); v1 = (float)__builtin_bit_cast(TT, b1); } else { v0 = v1 = 0.f; }
+        } else {
+          v0 = (float)tab[r0];
+          v1 = (float)tab[r1];
+        }
+        float wa = 1.f - fr[0], wb = fr[0];
+        wa *= (yz & 1) ? fr[1] : 1.f - fr[1]; wb *= (yz & 1) ? fr[1] : 1.f - fr[1];
+        wa *= (yz >> 1) ? fr[2] : 1.f - fr[2]; wb *= (yz >> 1) ? fr[2] : 1.f - fr[2];
+        pa[2 * yz] = (wa * we) * v0;
+        pa[2 * yz + 1] = (wb * we) * v1;
+      }
+#pragma unroll
+      for (int idx = 0; idx < 8; ++idx) acc += pa[idx];
+    }
+    feat[level] = zip_rbf(acc / (float)a.n, w.rnd);
+  }
+  // ---- proposal MLP on the registers
+  const float* b1 = lw + nw1;
+  const float* w2 = b1 + w.hidden;
+  float out = 0.f;
+  for (int h = 0; h < w.hidden; ++h) {
+    const float* wr = lw + h * a.L;
+    float acc = 0.f;
+#pragma unroll
+    for (int l = 0; l < 16; ++l) acc += l < a.L ? feat[l] * wr[l] : 0.f;
+    acc += b1[h];
+    out += zip_rbf(fmaxf(acc, 0.f), w.rnd) * w2[h];
+  }
+  w.raw_density[p] = out + lw[nw1 + 2 * w.hidden];
+}
+
+extern "C" int snerf_zip_encode_prop_fwd(const float* tdist, const float* origins, const float* directions, const float* radii, const float* base_x,
+                                         const float* base_y, const float* deg_jitter, const void* table, const int* offsets, const int* grid_sizes,
+                                         long R, int S, int L, int n, int m, float Sl, int H, float std_scale, int table_dtype, const float* w1,
+                                         const float* b1, const float* w2, const float* b2, int hidden, int round_bf16, float* raw_density,
+                                         void* stream) {
+  if (R <= 0) return SNERF_OK;
+  if (S <= 0 || L <= 0 || L > 16 || n <= 0 || n > 8 || hidden <= 0 || hidden > 1024 || table == nullptr || grid_sizes == nullptr || w1 == nullptr ||
+      b1 == nullptr || w2 == nullptr || b2 == nullptr || raw_density == nullptr)
+    return SNERF_ERR_ARG;
+  ZipEnc a{tdist, origins, directions, radii, base_x, base_y, deg_jitter, table, offsets, grid_sizes, nullptr, 0, nullptr, nullptr, R, S, L, n, m, Sl, H, std_scale};
+  ZipPropMlp w{w1, b1, w2, b2, hidden, round_bf16, raw_density};
+  const dim3 grid((unsigned)((R * S + 255) / 256)), blk(256);
+  const size_t lds = (size_t)(hidden * L + 2 * hidden + 1) * sizeof(float);
+  if (table_dtype == SNERF_DT_F32) hipLaunchKernelGGL(zip_encode_prop_kernel<float>, grid, blk, lds, (hipStream_t)stream, a, w);
+  else if (table_dtype == 2) hipLaunchKernelGGL(zip_encode_prop_kernel<__half>, grid, blk, lds, (hipStream_t)stream, a, w);
+  else return SNERF_ERR_ARG;
+  return snerf_check_launch();
+}
+
 template <typename OT, int C>
 __global__ __launch_bounds__(256) void zip_encode_bwd_lds_kernel(ZipEnc a, int lds_rows) {
   extern __shared__ float lds_tab[];

@@ -392,6 +392,21 @@ def zip_encode_fwd(tdist, origins, directions, radii, base_x, base_y, deg_jitter
               _zip_dt(feat), int(levels_per_thread), _stream())
 
 
+def zip_encode_prop_fwd(tdist, origins, directions, radii, base_x, base_y, deg_jitter, table, offsets, grid_sizes, L, n, m, Sl, H, std_scale,
+                        w1, b1, w2, b2, round_bf16):
+    """Fused featurisation + proposal MLP of one proposal level (inference) -> raw density [R*S, 1] fp32."""
+    for t in (tdist, origins, directions, radii, base_x, base_y, deg_jitter, w1, b1, w2, b2):
+        _f32c(t)
+    R, P = tdist.shape
+    hidden = b1.numel()
+    assert table.is_contiguous() and table.shape[-1] == 1 and w1.numel() == hidden * L and w2.numel() == hidden and b2.numel() == 1
+    out = torch.empty(R * (P - 1), 1, dtype=torch.float32, device=tdist.device)
+    _lib.call("snerf_zip_encode_prop_fwd", _p(tdist), _p(origins), _p(directions), _p(radii), _p(base_x), _p(base_y), _p(deg_jitter), _p(table),
+              _p(offsets), _p(grid_sizes), R, P - 1, L, n, m, float(Sl), int(H), float(std_scale), _zip_dt(table), _p(w1), _p(b1), _p(w2), _p(b2),
+              hidden, int(bool(round_bf16)), _p(out), _stream())
+    return out
+
+
 def zip_encode_bwd(tdist, origins, directions, radii, base_x, base_y, deg_jitter, offsets, grid_sizes, grad_feat, grad_table, L, C, n, m, Sl, H,
                    std_scale, lds_levels=0, lds_cells=0, lds_slabs=0, grad_table_bf16=None):
     R, P = tdist.shape

@@ -189,6 +189,17 @@ class Model(_ArenaModule):
                                             self.power_lambda)
             e, net = self.encs[lvl], self.nets[lvl]
             P = R * ns
+            if is_prop and not keep and sample_n <= 8 and e.L <= 16:
+                # inference: featurisation and the proposal MLP in one kernel (no feature buffer, no HBM-bound N = 64 / N = 1 GEMMs)
+                pre = self.names[lvl]
+                raw_d = ops.zip_encode_prop_fwd(tdist, o, d, radii, bx, by, degj, self._table(lvl), self.dev_offsets[lvl], self.dev_sizes[lvl], e.L,
+                                                sample_n, sample_m, e.Sl, e.H, self.std_scale, self.arena.p[pre + "density_layer.0.weight"],
+                                                self.arena.p[pre + "density_layer.0.bias"], self.arena.p[pre + "density_layer.2.weight"],
+                                                self.arena.p[pre + "density_layer.2.bias"], self.dt == ops.BF16)
+                rgb, depth, acc, weights = ops.zip_composite_fwd(None, raw_d, tdist, d, self.opaque_background, bg, 0.001, -1.0)
+                levels.append(dict(sdist=sdist, tdist=tdist, weights=weights, rgb=rgb, depth=depth, acc=acc, raw_rgb=None, raw_d=raw_d, saved=None,
+                                   degj=degj, ns=ns, semantic=None, logits=None))
+                continue
             if is_prop:
                 Fb = torch.zeros(P, net.Fw, dtype=net.tdt, device=dev); SB = None
             else:

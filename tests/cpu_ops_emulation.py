@@ -363,7 +363,17 @@ def hash_decay(table, grad, offsets, L, C, mult, loss=None):
             loss += k * (table[off[l]:off[l + 1]].double() ** 2).sum().float()
 
 
-_NAMES = ["mip_encode_bwd", "mip_viewenc_bwd", "hash_decay", "zip_percentiles", "zip_pixels_to_rays", "zip_loss_tail", "semantic_composite_fwd", "semantic_composite_bwd", "zip_resample", "zip_encode_fwd", "zip_encode_bwd", "zip_composite_fwd", "zip_composite_bwd",
+def zip_encode_prop_fwd(tdist, origins, directions, radii, base_x, base_y, deg_jitter, table, offsets, grid_sizes, L, n, m, Sl, H, std_scale,
+                        w1, b1, w2, b2, round_bf16):
+    P = tdist.shape[0] * (tdist.shape[1] - 1)
+    rb = (lambda t: t.to(torch.bfloat16).float()) if round_bf16 else (lambda t: t)
+    feat = torch.zeros(P, L)
+    zip_encode_fwd(tdist, origins, directions, radii, base_x, base_y, deg_jitter, table, offsets, grid_sizes, feat, L, 1, n, m, Sl, H, std_scale)
+    h = rb(torch.relu(rb(feat) @ rb(w1.reshape(-1, L)).t() + b1))
+    return h @ rb(w2.reshape(-1, 1)) + b2
+
+
+_NAMES = ["zip_encode_prop_fwd", "mip_encode_bwd", "mip_viewenc_bwd", "hash_decay", "zip_percentiles", "zip_pixels_to_rays", "zip_loss_tail", "semantic_composite_fwd", "semantic_composite_bwd", "zip_resample", "zip_encode_fwd", "zip_encode_bwd", "zip_composite_fwd", "zip_composite_bwd",
           "linear_fwd", "linear_wgrad", "classic_embed", "mip_encode", "mip_viewenc", "classic_sample_pdf", "classic_points",
           "classic_merge_sort", "mip_resample", "stratified", "mip_composite_fwd", "mip_composite_bwd", "classic_composite_fwd",
           "classic_composite_bwd", "adam_step", "colsum_f32", "cast_pad", "pinhole_rays", "mip_loss_tail"]

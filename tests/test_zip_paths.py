@@ -396,8 +396,8 @@ def test_zip_resample_kernel_vs_oracle(R, S0, n, dilate, dilation):
 
 @pytest.mark.gpu
 def test_zip_encode_thread_mappings_agree(golden):
-    """The featurisation kernel's two thread mappings (one thread per (interval, level) for training, one thread per interval over
-    all levels for inference) and the paired 32-bit loads of the single-channel half tables: identical arithmetic, identical bits."""
+    """Training and inference take different kernels for the same arithmetic: one thread per (interval, level) + GEMM-kernel MLPs when
+    activations are kept, one thread per interval over all levels (and, on the proposal levels, the MLP fused behind it) otherwise."""
     g = golden("g11_zip_model")
     specs, p = zip_setup()
     batch = {k[2:]: v.cuda() for k, v in g.items() if k.startswith("b_")}
@@ -407,9 +407,13 @@ def test_zip_encode_thread_mappings_agree(golden):
             r_inf, h_inf = m(None, batch, 1.0, False)           # keep = False -> all levels per thread
         r_trn, h_trn = m(None, batch, 1.0, False)               # parameters require grad -> one level per thread
         assert r_trn[-1]["rgb"].requires_grad
+        # level 0 fence posts have no network upstream: bit-identical.  The proposal levels' densities come from the fused
+        # featurisation + MLP kernel at inference and from the GEMM kernels in training: same roundings, different summation order
+        assert torch.equal(h_inf[0]["sdist"], h_trn[0]["sdist"])
+        tol = 2e-5 if compute == "f32" else 2e-2
         for lvl in range(3):
-            assert torch.equal(h_inf[lvl]["weights"], h_trn[lvl]["weights"].detach()), (compute, lvl)
-        assert torch.equal(r_inf[-1]["rgb"], r_trn[-1]["rgb"].detach())
+            close(h_inf[lvl]["weights"], h_trn[lvl]["weights"].detach(), tol, tol, f"{compute} weights {lvl}")
+        close(r_inf[-1]["rgb"], r_trn[-1]["rgb"].detach(), tol, tol, f"{compute} rgb")
 
 
 @pytest.mark.gpu
