@@ -224,10 +224,45 @@ __global__ __launch_bounds__(256) void mip_viewenc_kernel(const float* __restric
   }
 }
 
+// dense rows (no sample_id): the encoding depends on the ray only, so one wave evaluates its ray's `width` values once (lane = column)
+// and replicates them over the ray's S rows with row-contiguous stores -- instead of one sinf per output element.
+template <typename T>
+__global__ __launch_bounds__(256) void mip_viewenc_rays_kernel(const float* __restrict__ viewdirs, long N, int S, int deg, T* dst, long ld, int width) {
+  const int lane = threadIdx.x & 63;
+  const long ray = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= N) return;
+  const int n3 = 3 * deg;
+  const float* x = viewdirs + ray * 3;
+  for (int c0 = 0; c0 < width; c0 += 64) {
+    const int col = c0 + lane;
+    float v = 0.f;
+    if (col < 3) v = x[col];
+    else if (col < 3 + 2 * n3) {
+      int j = col - 3;
+      const int ph = j >= n3;
+      if (ph) j -= n3;
+      float y = x[j % 3] * (float)(1 << (j / 3));
+      if (ph) y = y + 1.5707964f;
+      v = sinf(y);
+    }
+    if (col < width) {
+      const T o = from_f32<T>(v);
+      T* row = dst + (ray * S) * ld + col;
+      for (int i = 0; i < S; ++i) row[(long)i * ld] = o;
+    }
+  }
+}
+
 extern "C" int snerf_mip_viewenc(const float* viewdirs, long n_rays, int S, int deg, void* dst, long ld, int width, int dtype,
                                  const int* sample_id, long n_rows, void* stream) {
   if (n_rays <= 0 || (sample_id != nullptr && n_rows <= 0)) return SNERF_OK;
   if (width < 3 + 6 * deg || S <= 0) return SNERF_ERR_ARG;
+  if (sample_id == nullptr) {
+    const dim3 g((unsigned)((n_rays + 3) / 4)), b(256);
+    if (dtype == SNERF_DT_F32) hipLaunchKernelGGL(mip_viewenc_rays_kernel<float>, g, b, 0, (hipStream_t)stream, viewdirs, n_rays, S, deg, (float*)dst, ld, width);
+    else hipLaunchKernelGGL(mip_viewenc_rays_kernel<__bf16>, g, b, 0, (hipStream_t)stream, viewdirs, n_rays, S, deg, (__bf16*)dst, ld, width);
+    return snerf_check_launch();
+  }
   const long M = sample_id != nullptr ? n_rows : n_rays * (long)S, total = M * width;
   const int blocks = (int)((total + 255) / 256 < 262144 ? (total + 255) / 256 : 262144);
   if (dtype == SNERF_DT_F32)
