@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--table-grad", default="f32", choices=["f32", "bf16"])
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--semantic", action="store_true", help="19-class semantic head on (Config.use_semantic): rendered and trained")
+    ap.add_argument("--frame-only", action="store_true", help="skip the training / forward timing loops (profiling the frame)")
     ap.add_argument("--frame-chunk", type=int, default=65536, help="render_chunk_size of the measured 1920x1280 frame")
     ap.add_argument("--same-device", action="store_true", help="functional test of the N > 1 flow on a 1-GPU box")
     args = ap.parse_args()
@@ -77,7 +78,9 @@ def main():
             m(None, batch, 1.0, False)
         m.scattered_rays = False
 
-    for t in range(3):
+    if args.frame_only:
+        args.steps = 1
+    for t in range(0 if args.frame_only else 3):
         train_step(t)
     barrier(); t0 = time.perf_counter()
     for t in range(args.steps):
