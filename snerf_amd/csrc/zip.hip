@@ -61,10 +61,10 @@ __global__ __launch_bounds__(64 * ZR_WAVES) void zip_resample_kernel(ZipResample
   extern __shared__ float lds[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int S0 = a.S0, NPmax = 3 * S0 + 2;
-  const int per_wave = (S0 + 1) + S0 + 2 * NPmax + a.n;
+  const int per_wave = 2 * (S0 + 1) + 2 * NPmax + a.n;
   float* t = lds + (size_t)wv * per_wave;               // [S0+1] input posts
-  float* pdf = t + (S0 + 1);                            // [S0]   input weights (-> pdf when dilating)
-  float* Tm = pdf + S0;                                 // [NPmax] merged posts
+  float* pdf = t + (S0 + 1);                            // [S0+1] input weights (-> pdf when dilating; -> the S0+1 cdf values when not)
+  float* Tm = pdf + (S0 + 1);                           // [NPmax] merged posts
   float* Wm = Tm + NPmax;                               // [NPmax] dilated weights -> cdf
   float* cb = Wm + NPmax;                               // [n]    sampled centres
   long ray = (long)blockIdx.x * ZR_WAVES + wv;
@@ -194,7 +194,7 @@ extern "C" int snerf_zip_resample(const float* sdist, const float* weights, int 
   if (R <= 0) return SNERF_OK;
   if (S0 < 1 || n < 2 || (dilate && S0 < 2)) return SNERF_ERR_ARG;
   if ((dilate ? 3 * S0 - 2 : S0) > 256) return SNERF_ERR_ARG;                 // per-lane register slots: 4 x 64 intervals
-  const size_t lds = (size_t)ZR_WAVES * ((S0 + 1) + S0 + 2 * (3 * S0 + 2) + n) * sizeof(float);
+  const size_t lds = (size_t)ZR_WAVES * (2 * (S0 + 1) + 2 * (3 * S0 + 2) + n) * sizeof(float);
   if (lds > 64 * 1024) return SNERF_ERR_ARG;
   ZipResample a{sdist, weights, S0, u, u_stride, n, near, far, R, dilation, dilate, anneal, resample_padding, lam, dom0, dom1, sdist_out, tdist_out};
   hipLaunchKernelGGL(zip_resample_kernel, dim3((unsigned)((R + ZR_WAVES - 1) / ZR_WAVES)), dim3(64 * ZR_WAVES), lds, (hipStream_t)stream, a);
