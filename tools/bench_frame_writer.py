@@ -11,7 +11,6 @@ from PIL import Image
 
 def main():
     from snerf_amd import frame_writer as fw, ops
-    from oracle import callers as oc
     H, W, C = 1280, 1920, 19
     dev = torch.device("cuda", 0)
     yy, xx = torch.meshgrid(torch.arange(H, device=dev), torch.arange(W, device=dev), indexing="ij")
@@ -42,7 +41,10 @@ def main():
         torch.cuda.synchronize(); t0 = time.perf_counter()
         r = {k: v.detach().cpu().numpy() for k, v in dict(rgb=rgb, depth=depth, semantic=sem).items()}
         t_copy = time.perf_counter() - t0
-        q = oc.frame_quantize(r["rgb"], r["depth"], r["semantic"], cmap, 0.5)
+        # the reference's expressions (random_render_waymo_seq.py:214-227, internal/utils.py:111-116)
+        labels = np.argmax(r["semantic"], axis=-1)
+        q = dict(rgb=(np.clip(np.nan_to_num(r["rgb"]), 0., 1.) * 255.).astype(np.uint8), depth=(r["depth"] * 256 / 0.5).astype(np.uint16),
+                 semantic=labels.astype(np.uint8), paint=cmap[labels].astype(np.uint8))
         for k, a in q.items():
             Image.fromarray(a).save(os.path.join(td, k + ".png"))
         res["reference_route_ms_per_frame"] = round((time.perf_counter() - t0) * 1e3, 1)
