@@ -479,3 +479,44 @@ def test_persistent_kernel_colsum_across_tiles(M, N, K):
         stored = dX.double().cpu().sum(0)
         close(cs / 2, stored, 2e-4, 2e-3 * max(1.0, (M / 515) ** 0.5), f"colsum of the stored values, act {mode}")
         close(cs / 2, ref.sum(0), 2e-2, 5e-2 * max(1.0, (M / 515) ** 0.5), f"colsum, act {mode}")
+
+
+@pytest.mark.gpu
+def test_linear_kernels_random_shapes_sweep():
+    """A seeded sweep over launch shapes of the two GEMM entry points (every dispatch branch: 128x128, 256x256 block-issue, 8-phase,
+    persistent; ragged M, every K granule, column-range operands, fp32 heads, the weight-gradient kernels with padded / partial
+    outputs) against float64 matmul.  40 + 25 launches, each with its own tolerance from the reduction length."""
+    from snerf_amd import ops as O
+    rng = np.random.default_rng(2024)
+    for it in range(40):
+        N = int(rng.choice([128, 256, 384, 512, 1024]))
+        K = int(rng.choice([64, 128, 192, 256, 320, 1024, 1088, 1152]))
+        M = int(rng.choice([1, 63, 300, 4097, 33000, int(rng.integers(1, 70000))]))
+        variant = int(rng.choice([0, 1, 4, 8]))
+        act = int(rng.choice([O.ACT_NONE, O.ACT_RELU]))
+        out_f32 = bool(rng.integers(0, 2)) and N == 128
+        pad = int(rng.choice([0, 64]))                                  # operands as column ranges of wider buffers
+        A = gen(M, K + pad, seed=it).bfloat16().cuda()[:, pad:]
+        W = (gen(N, K, seed=100 + it) / K ** 0.5).bfloat16().cuda()
+        b = gen(N, seed=200 + it).cuda()
+        n_store = N if not out_f32 else int(rng.integers(1, 8))
+        Y = torch.zeros(M, N, dtype=torch.float32 if out_f32 else torch.bfloat16, device="cuda")
+        O.linear_fwd(A, W, b, Y, K, n_store, act, O.BF16, out_f32=out_f32, variant=variant)
+        ref = A.double().cpu() @ W.double().cpu().t() + b.double().cpu()
+        if act == O.ACT_RELU:
+            ref = ref.clamp_min(0)
+        tol = 2e-3 if out_f32 else 1.2e-2
+        close(Y[:, :n_store], ref[:, :n_store], tol, tol, f"linear_fwd #{it} M={M} N={N} K={K} v={variant} act={act} f32={out_f32} pad={pad}")
+    for it in range(25):
+        N = int(rng.choice([64, 128, 256, 1024]))
+        K = int(rng.choice([64, 128, 256, 1024, 1152]))
+        M = int(rng.choice([64, 515, 4096, 20000, int(rng.integers(64, 40000))]))
+        nv, kv = int(rng.integers(1, N + 1)), int(rng.integers(1, K + 1))
+        variant = int(rng.choice([0, 1, 2, 3]))
+        dZ = (gen(M, N, seed=300 + it) * (gen(M, N, seed=400 + it) > 0)).bfloat16().cuda()
+        X = gen(M, K, seed=500 + it).clamp_min(0).bfloat16().cuda()
+        dW = torch.zeros(N, K, device="cuda")
+        O.linear_wgrad(dZ, X, dW, nv, kv, O.BF16, variant=variant)
+        ref = dZ.double().cpu().t() @ X.double().cpu()
+        close(dW[:nv, :kv], ref[:nv, :kv], 2e-3, 2e-3 * max(1.0, (M / 512) ** 0.5), f"linear_wgrad #{it} M={M} N={N} K={K} nv={nv} kv={kv} v={variant}")
+        assert float(dW[nv:].abs().max() if nv < N else 0) == 0 and float(dW[:, kv:].abs().max() if kv < K else 0) == 0, f"wgrad #{it} wrote outside the valid block"
