@@ -520,3 +520,54 @@ def test_linear_kernels_random_shapes_sweep():
         ref = dZ.double().cpu().t() @ X.double().cpu()
         close(dW[:nv, :kv], ref[:nv, :kv], 2e-3, 2e-3 * max(1.0, (M / 512) ** 0.5), f"linear_wgrad #{it} M={M} N={N} K={K} nv={nv} kv={kv} v={variant}")
         assert float(dW[nv:].abs().max() if nv < N else 0) == 0 and float(dW[:, kv:].abs().max() if kv < K else 0) == 0, f"wgrad #{it} wrote outside the valid block"
+
+
+@pytest.mark.gpu
+def test_per_ray_kernels_random_sizes_sweep():
+    """Seeded sweep over ray counts and interval counts (not multiples of the wave size, single intervals, more than 64 / 128 / 192
+    intervals) for the wave-per-ray and lane-per-ray kernels, against the oracle-backed emulation: mip / zip compositing forward and
+    backward, the mip resampler (bit-exact), the classic sample_pdf (bit-exact)."""
+    from snerf_amd import ops as O
+    import cpu_ops_emulation as E
+    rng = np.random.default_rng(77)
+    cu = lambda t: None if t is None else t.cuda().contiguous()
+    for it in range(14):
+        n = int(rng.choice([1, 3, 65, 130, int(rng.integers(1, 400))]))
+        S = int(rng.choice([1, 2, 31, 64, 65, 127, 128, 200, int(rng.integers(1, 250))]))
+        g = torch.Generator().manual_seed(1000 + it)
+        s = torch.sort(torch.rand(n, S + 1, generator=g), -1).values.contiguous()
+        dirs = torch.randn(n, 3, generator=g)
+        near, far = torch.rand(n, generator=g) + 0.5, torch.rand(n, generator=g) * 50 + 5
+        raw_rgb, raw_d = torch.randn(n * S, 3, generator=g), torch.randn(n * S, 1, generator=g) * 3
+        noise = torch.randn(n, S, generator=g) * 0.1 if it % 2 else None
+        ref = E.mip_composite_fwd(raw_rgb, raw_d, noise, s, dirs, near, far, 0, False, 0.001, -1.0)
+        got = O.mip_composite_fwd(cu(raw_rgb), cu(raw_d), cu(noise), cu(s), cu(dirs), cu(near), cu(far), 0, False, 0.001, -1.0)
+        for a, b, what in zip(got, ref, ("rgb", "distance", "acc", "weights")):
+            close(a, b, 1e-4, 5e-6, f"mip composite fwd #{it} n={n} S={S} {what}")     # t1 - t0 of close posts: both sides round it differently
+        gs = [torch.randn(n, 3, generator=g), torch.randn(n, generator=g) * 0.05, torch.randn(n, generator=g), torch.randn(n, S, generator=g)]
+        dr_ref, dd_ref = torch.empty(n * S, 3), torch.empty(n * S, 1)
+        E.mip_composite_bwd(raw_rgb, raw_d, noise, s, dirs, near, far, 0, False, 0.001, -1.0, ref[3], ref[1], *gs, dr_ref, dd_ref)
+        dr, dd = torch.empty(n * S, 3, device="cuda"), torch.empty(n * S, 1, device="cuda")
+        O.mip_composite_bwd(cu(raw_rgb), cu(raw_d), cu(noise), cu(s), cu(dirs), cu(near), cu(far), 0, False, 0.001, -1.0, got[3], got[1], *[cu(x) for x in gs], dr, dd)
+        close(dr, dr_ref, 5e-4, 1e-5 * float(dr_ref.abs().max() + 1), f"mip composite bwd #{it} n={n} S={S} d_rgb")
+        close(dd, dd_ref, 5e-4, 1e-4 * float(dd_ref.abs().max() + 1), f"mip composite bwd #{it} n={n} S={S} d_density")
+        # zipnerf compositing on metric fence posts
+        td = (s * (far - near)[:, None] + near[:, None]).contiguous()
+        zr = E.zip_composite_fwd(raw_rgb, raw_d, td, dirs, True, 1.0, 0.001, -1.0)
+        zg = O.zip_composite_fwd(cu(raw_rgb), cu(raw_d), cu(td), cu(dirs), True, 1.0, 0.001, -1.0)
+        for a, b, what in zip(zg, zr, ("rgb", "depth", "acc", "weights")):
+            close(a, b, 1e-4, 5e-6, f"zip composite fwd #{it} n={n} S={S} {what}")
+        # samplers: indices and values bit-exact
+        if S >= 2:
+            w = torch.rand(n, S, generator=g) ** 3
+            P1 = int(rng.choice([2, 17, 64, 129]))
+            u = torch.rand(n, P1, generator=g).sort(-1).values.clamp_max(1 - 1.2e-7).contiguous()
+            rs, ri = E.mip_resample(s, w, u, 0.01, want_idx=True)
+            gs_, gi = O.mip_resample(cu(s), cu(w), cu(u), 0.01, want_idx=True)
+            assert torch.equal(gi.cpu().long(), ri.long()) and torch.equal(gs_.cpu(), rs), f"mip_resample #{it} n={n} S={S} P1={P1}"
+            bins = (s * 10).contiguous()
+            uu = torch.rand(n, P1, generator=g).contiguous()
+            wc = torch.rand(n, S, generator=g)
+            cs, ci, _ = E.classic_sample_pdf(bins, wc, uu, False, want_inds=True)
+            ks, ki, _ = O.classic_sample_pdf(cu(bins), cu(wc), cu(uu), False, want_inds=True)
+            assert torch.equal(ki.cpu().long(), ci.long()) and torch.equal(ks.cpu(), cs), f"classic_sample_pdf #{it} n={n} S={S} P1={P1}"
