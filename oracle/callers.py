@@ -2,7 +2,11 @@
 ray generation (the step before) and the per-ray loss tail (the step after).  Only tests/, __graft_entry__.smoke()
 and bench.py's baseline legs may import this package.
 
-Pinned against the imported reference by oracle/gen_golden_callers.py -> tests/golden/g12_rays.npz, g13_losses.npz.
+Pinned against the imported reference by oracle/gen_golden_callers.py -> tests/golden/g12_rays.npz, g13_losses.npz (mip path),
+oracle/gen_golden_zip_callers.py -> g15_zip_rays.npz, g16_zip_losses.npz (zipnerf path; the two regularisers also against the reference
+evaluated in float64) and oracle/gen_golden_frame.py -> g17_frame_writer.npz (pixels decoded from the files the reference's save path
+wrote).  PARITY UNPINNED: `hash_decay_loss` only -- it rests on torch_scatter.segment_coo (pinned 2.1.1, not installed), whose
+documented segment mean is restated.
 Citations are relative to /root/reference/.
 """
 import numpy as np
