@@ -125,7 +125,7 @@ def test_trainer_loss_tail_host_logic():
         outs = (x["d0"], None, x["s_c"], x["w_c"], x["rgb"], x["d1"], None, x["s_f"], x["w_f"])
         loss, g = tr.loss_and_grads(outs, x["tgt"], x["td"], x["conf"])
     (lr, ld, lp), (g_rgb, g_d1, g_d0, g_wc) = _oracle_tail(x, 0.2, 0.2, 0.05)
-    assert abs(float(loss) - float(lr + ld + lp)) < 1e-6
+    assert abs(float(loss) - float((lr + ld + lp).detach())) < 1e-6
     assert torch.allclose(g[0], g_d0) and g[1] is None and torch.allclose(g[2], g_wc) and torch.allclose(g[3], g_rgb) and torch.allclose(g[4], g_d1)
 
 
