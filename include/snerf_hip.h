@@ -322,6 +322,11 @@ int snerf_zip_encode_prop_fwd(const float* tdist, const float* origins, const fl
                               const float* b1, const float* w2, const float* b2, int hidden, int round_bf16, float* raw_density,
                               void* stream);
 
+/* snerf_adam_step with the step count t in DEVICE memory: *step_dev is incremented, then used for the bias corrections -- no launch
+ * argument depends on host state, so a whole training step can be captured in a hipGraph and replayed. */
+int snerf_adam_step_dev(float* p, float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, int* step_dev,
+                        float grad_scale, int zero_grad, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,6 +46,51 @@ extern "C" int snerf_adam_step(float* p, float* g, float* m, float* v, long n, f
   return snerf_check_launch();
 }
 
+// The same update with the step count in device memory (incremented here): nothing in the launch depends on host state, so a whole
+// training step can be captured in a hipGraph and replayed (trainer.MipTrainer.capture).
+__global__ void adam_tick_kernel(int* step) { *step += 1; }
+
+__global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
+                                                       float lr, float b1, float b2, float eps, const int* __restrict__ step, float grad_scale,
+                                                       int zero_grad) {
+  const float t = (float)*step;
+  const float bc1 = 1.f - powf(b1, t), bc2_sqrt = sqrtf(1.f - powf(b2, t));
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    float4 pp = ((float4*)p)[i], gg = ((float4*)g)[i], mm = ((float4*)m)[i], vv = ((float4*)v)[i];
+    float* pa = (float*)&pp; float* ga = (float*)&gg; float* ma = (float*)&mm; float* va = (float*)&vv;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gk = ga[k] * grad_scale;
+      ma[k] = b1 * ma[k] + (1.f - b1) * gk;
+      va[k] = b2 * va[k] + (1.f - b2) * gk * gk;
+      pa[k] -= (lr / bc1) * ma[k] / (sqrtf(va[k]) / bc2_sqrt + eps);
+    }
+    ((float4*)p)[i] = pp; ((float4*)m)[i] = mm; ((float4*)v)[i] = vv;
+    if (zero_grad) ((float4*)g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const long i = (n4 << 2) + threadIdx.x;
+    const float gk = g[i] * grad_scale;
+    m[i] = b1 * m[i] + (1.f - b1) * gk;
+    v[i] = b2 * v[i] + (1.f - b2) * gk * gk;
+    p[i] -= (lr / bc1) * m[i] / (sqrtf(v[i]) / bc2_sqrt + eps);
+    if (zero_grad) g[i] = 0.f;
+  }
+}
+
+extern "C" int snerf_adam_step_dev(float* p, float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, int* step_dev,
+                                   float grad_scale, int zero_grad, void* stream) {
+  if (n <= 0) return SNERF_OK;
+  if (step_dev == nullptr || (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15)) return SNERF_ERR_ARG;
+  const long n4 = n >> 2;
+  int blocks = (int)((n4 + 255) / 256);
+  blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev);
+  hipLaunchKernelGGL(adam_dev_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, b1, b2, eps, step_dev, grad_scale, zero_grad);
+  return snerf_check_launch();
+}
+
 // out[c] += sum_m x[m, c] for a narrow fp32 matrix (head gradients: 3 + 1 columns)
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long ld, long M, int C, float* __restrict__ out) {
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};

@@ -75,6 +75,15 @@ class MipNerfModel(_ArenaModule):
                     fan_in = self.arena.p[n[:-4] + "weight"].shape[-1]
                     nn.init.uniform_(p, -1.0 / fan_in ** 0.5, 1.0 / fan_in ** 0.5)
 
+    def _const(self, key, make, dev):
+        """host-computed constants (torch.linspace on the CPU, as the reference and the oracle evaluate it), uploaded once: no
+        host->device copy inside the step (which also keeps the step capturable in a hipGraph)"""
+        c = self.__dict__.setdefault("_consts", {})
+        k = (key, str(dev), self.n_samples, self.N_fine)
+        if k not in c:
+            c[k] = make().to(dev)
+        return c[k]
+
     # ------------------------------------------------------------------ core ----
     def _run(self, rays: Rays, keep: bool, white_bg: bool, s_rand, u, noise0, noise1):
         """Both levels.  Returns (outs, ctx) with outs = (dist0, acc0, s0, w0, rgb1, dist1, acc1, s1, w1)."""
@@ -89,7 +98,7 @@ class MipNerfModel(_ArenaModule):
         if self.ray_shape not in ("cone", "cylinder"):
             raise ValueError(self.ray_shape)
         # ---- level 0: stratified s, encode, proposal MLP, composite
-        base = torch.linspace(0., 1., S0 + 1).to(dev)
+        base = self._const("base", lambda: torch.linspace(0., 1., S0 + 1), dev)
         s0 = ops.stratified(base, s_rand, None, None, n, 1)
         E0 = self.prop.buf(n * S0, self.prop.Ew)
         ops.mip_encode(s0, o, d, radii, near, far, cone, self.transform_idx, self.max_deg_point, E0, None, self.prop.Ew, self.dt)
@@ -197,7 +206,7 @@ class MipNerfModel(_ArenaModule):
             if self.density_noise > 0:
                 noise1 = self.density_noise * torch.randn(n, P1 - 1, device=dev)
         else:
-            u = torch.linspace(0., 1. - EPS32, self.N_fine).to(dev)
+            u = self._const("u_det", lambda: torch.linspace(0., 1. - EPS32, self.N_fine), dev)
         return s_rand, u, noise0, noise1
 
     # ---------------------------------------------------------------- public ----

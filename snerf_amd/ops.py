@@ -311,6 +311,15 @@ def adam_step(p, g, m, v, lr, b1, b2, eps, step, grad_scale=1.0, zero_grad=True)
               float(grad_scale), 1 if zero_grad else 0, _stream())
 
 
+def adam_step_dev(p, g, m, v, lr, b1, b2, eps, step_dev, grad_scale=1.0, zero_grad=True):
+    """adam_step with the step counter in device memory (int32 [1], incremented by the launch): graph-capturable."""
+    for t in (p, g, m, v):
+        _f32c(t)
+    assert step_dev.dtype == torch.int32 and step_dev.is_cuda and step_dev.numel() == 1
+    _lib.call("snerf_adam_step_dev", _p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(b1), float(b2), float(eps), _p(step_dev),
+              float(grad_scale), 1 if zero_grad else 0, _stream())
+
+
 def colsum_f32(x, C, out):
     _chk2d(x, torch.float32)
     _lib.call("snerf_colsum_f32", _p(x), x.stride(0), x.shape[0], C, _p(out), _stream())

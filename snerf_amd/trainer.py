@@ -60,6 +60,7 @@ class MipTrainer:
         self.t = 0
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self._step_dev = self._graph = None
         a.grad.zero_()
 
     def broadcast_parameters(self, src=0):
@@ -96,10 +97,45 @@ class MipTrainer:
         self.last_ray_grads = m._backward(ctx, *g, on_done=ex, ray_grads=ray_grads)
         ex.finish()
         self.t += 1
-        ops.adam_step(m.arena.flat, m.arena.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.t,
-                      grad_scale=1.0 / self.world, zero_grad=True)
+        if self._step_dev is not None:                    # graph mode: the step count lives on the device (capture / replay below)
+            ops.adam_step_dev(m.arena.flat, m.arena.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self._step_dev,
+                              grad_scale=1.0 / self.world, zero_grad=True)
+        else:
+            ops.adam_step(m.arena.flat, m.arena.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.t,
+                          grad_scale=1.0 / self.world, zero_grad=True)
         m.arena.bump()
         return loss, outs
+
+    # ---- hipGraph capture of the whole step --------------------------------------------------------------------------------------
+    def capture(self, rays, target_rgb, target_depth=None, conf=None, randomized=True, warmup=3):
+        """Capture one full training step (draws, forward, loss tail, backward, Adam: ~130 launches) in a hipGraph over the GIVEN tensors;
+        afterwards `replay()` runs a step with one graph launch -- the caller refreshes the batch by copying into those tensors
+        (`rays.origins.copy_(...)` etc.).  Worth it when the step is launch-bound: at 512 rays per GPU (the 8-GPU split of the
+        reference's 4096-ray batch) the kernels are 10-50 us each.  The packed-weight refresh, the torch RNG draws (graph-safe Philox
+        offsets) and the Adam bias corrections (step count in device memory) are all inside the graph.  Single process only (the RCCL
+        exchange is not captured)."""
+        if self.world != 1:
+            raise NotImplementedError("graph capture covers the single-process step")
+        dev = self.model.arena.flat.device
+        self._step_dev = torch.tensor([self.t], dtype=torch.int32, device=dev)
+        args = (rays, target_rgb, target_depth, conf)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                    # warm-up on a side stream: one-time kernel attributes, allocator pools
+            for _ in range(warmup):
+                self.step(*args, randomized=randomized)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._graph_loss, self._graph_outs = self.step(*args, randomized=randomized)
+        self.t -= 1                                      # capturing records the step, it does not run it
+        return self._graph_loss
+
+    def replay(self):
+        """One captured step.  -> (loss, outs): the same device tensors every time, overwritten by each replay."""
+        self._graph.replay()
+        self.t += 1
+        return self._graph_loss, self._graph_outs
 
 
 def shard_rays(rays, rank: int, world: int):

@@ -373,7 +373,12 @@ def zip_encode_prop_fwd(tdist, origins, directions, radii, base_x, base_y, deg_j
     return h @ rb(w2.reshape(-1, 1)) + b2
 
 
-_NAMES = ["zip_encode_prop_fwd", "mip_encode_bwd", "mip_viewenc_bwd", "hash_decay", "zip_percentiles", "zip_pixels_to_rays", "zip_loss_tail", "semantic_composite_fwd", "semantic_composite_bwd", "zip_resample", "zip_encode_fwd", "zip_encode_bwd", "zip_composite_fwd", "zip_composite_bwd",
+def adam_step_dev(p, g, m, v, lr, b1, b2, eps, step_dev, grad_scale=1.0, zero_grad=True):
+    step_dev += 1
+    adam_step(p, g, m, v, lr, b1, b2, eps, int(step_dev), grad_scale, zero_grad)
+
+
+_NAMES = ["adam_step_dev", "zip_encode_prop_fwd", "mip_encode_bwd", "mip_viewenc_bwd", "hash_decay", "zip_percentiles", "zip_pixels_to_rays", "zip_loss_tail", "semantic_composite_fwd", "semantic_composite_bwd", "zip_resample", "zip_encode_fwd", "zip_encode_bwd", "zip_composite_fwd", "zip_composite_bwd",
           "linear_fwd", "linear_wgrad", "classic_embed", "mip_encode", "mip_viewenc", "classic_sample_pdf", "classic_points",
           "classic_merge_sort", "mip_resample", "stratified", "mip_composite_fwd", "mip_composite_bwd", "classic_composite_fwd",
           "classic_composite_bwd", "adam_step", "colsum_f32", "cast_pad", "pinhole_rays", "mip_loss_tail"]

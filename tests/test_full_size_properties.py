@@ -2,6 +2,7 @@
 minutes per case there) through size-independent properties of the path: rays are independent, fence posts stay sorted inside
 [0, 1], weights form a sub-probability, the fp32-parity and bf16 modes agree, and the samplers are deterministic.
 All through the C-ABI (pytest -m gpu)."""
+import numpy as np
 import pytest
 import torch
 
@@ -153,3 +154,49 @@ def test_path_c_properties_at_full_size():
         assert bool(torch.isfinite(rend[-1]["rgb"]).all()) and bool(torch.isfinite(rend[-1]["depth"]).all())
         outs[compute] = rend[-1]["rgb"].float()
     assert float((outs["bf16"] - outs["f32"]).abs().max()) < 3e-2
+
+
+def test_captured_train_step_replays_like_the_eager_step():
+    """MipTrainer.capture / replay: the whole step as one hipGraph (packed-weight refresh, forward, loss tail, backward, Adam with the
+    step count on the device).  Five replays from a given state land on the parameters of five eager steps, and a refreshed batch
+    (copied into the captured tensors) is picked up."""
+    from oracle import common
+    from snerf_amd import mipnerf
+    from snerf_amd.trainer import MipTrainer
+    n = 512
+
+    def fresh():
+        torch.manual_seed(0)
+        m = mipnerf.MipNerfModel(n_samples=S0, N_fine=P1, no_warp_sample=0, ray_shape="cone", fn=1, radius=3., transform_idx=0, real=True, rgb_layer=3,
+                                 hidden_layer=256, density_noise=0., max_deg_point=16, proposal_loss=True, compute="bf16")
+        return m, MipTrainer(m, lr=5e-4)
+    rc = common.synthetic_rays(n, seed=3)
+    g = torch.Generator().manual_seed(4)
+    tgt, td = torch.rand(n, 3, generator=g).cuda(), (torch.rand(n, generator=g) * 50 + 2).cuda()
+    tgt2 = torch.rand(n, 3, generator=g).cuda()
+    rays = mipnerf.Rays(**{k: v.cuda() for k, v in rc.items()})
+    def eager():
+        m, t = fresh()
+        init = m.arena.flat.clone()
+        for i in range(5):
+            t.step(rays, tgt if i < 3 else tgt2, td, None, randomized=False)
+        return m, init
+    m1, init = eager()
+    m1b, _ = eager()                                                  # the weight-gradient atomics make two eager runs differ as well
+    m2, t2 = fresh()
+    tg = tgt.clone()
+    t2.capture(rays, tg, td, None, randomized=False, warmup=2)        # 2 warm-up steps run eagerly inside capture()
+    losses = []
+    for i in range(2, 5):
+        if i == 3:
+            tg.copy_(tgt2)                                            # new batch: copy into the captured tensor
+        loss, _ = t2.replay()
+        losses.append(float(loss))
+    assert t2.t == 5 and int(t2._step_dev) == 5
+    a, b, a2 = m1.arena.flat, m2.arena.flat, m1b.arena.flat
+    moved = float((a - init).norm())
+    noise = float((a - a2).norm()) / moved                            # Adam turns rounding noise of near-zero gradients into +-lr steps
+    diff = float((a - b).norm()) / moved
+    assert moved > 0 and diff <= 2 * noise + 1e-3, (diff, noise)
+    assert float((a - b).abs().max()) <= 2 * 5 * 5e-4 + 1e-6          # never more than the 5 steps' worth of sign flips
+    assert all(np.isfinite(losses)) and losses[1] != losses[0]
