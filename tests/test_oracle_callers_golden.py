@@ -34,11 +34,11 @@ def test_loss_tail(golden):
     rgb = _t(g, "rgb").requires_grad_(True)
     rl = oc.rgb_loss(rgb, _t(g, "tgt"))
     gr, = torch.autograd.grad(rl, rgb)
-    assert float(rl) == float(g["rgb_loss"]) and torch.equal(gr, _t(g, "g_rgb"))
+    assert float(rl.detach()) == float(g["rgb_loss"]) and torch.equal(gr, _t(g, "g_rgb"))
     d1, d0 = _t(g, "d1").requires_grad_(True), _t(g, "d0").requires_grad_(True)
     dl = oc.depth_loss(d1, d0, _t(g, "td"), _t(g, "conf"), float(g["coarse_depth_mult"]), True)
     g1, g0 = torch.autograd.grad(dl, [d1, d0])
-    assert abs(float(dl) - float(g["depth_loss"])) <= 1e-7
+    assert abs(float(dl.detach()) - float(g["depth_loss"])) <= 1e-7
     assert torch.allclose(g1, _t(g, "g_d1"), rtol=1e-6, atol=0) and torch.allclose(g0, _t(g, "g_d0"), rtol=1e-6, atol=0)
 
 
