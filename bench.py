@@ -106,10 +106,11 @@ def cpu_baseline(n_rays, model_sd, rays, seed=0):
     pr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     t0 = time.perf_counter()
     ret = om.mipnerf_forward(pr, rc, S0, P1)
+    dt_fwd = time.perf_counter() - t0
     loss = ((ret[1][0] - tgt) ** 2).mean() + 0.2 * (1.0 / ret[1][1]).mean() + 0.04 * (1.0 / ret[0][1]).mean()
     loss.backward()
     dt_s = time.perf_counter() - t0
-    return n_rays / dt_s, dt_s, ret[1][0].detach(), ret[1][1].detach()
+    return n_rays / dt_s, dt_s, ret[1][0].detach(), ret[1][1].detach(), n_rays / dt_fwd
 
 
 def eager_baseline(model_sd, rays, n_rays, steps, bf16):
@@ -332,7 +333,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu:
         ncpu = args.cpu_rays
         sd = {k: v.clone() for k, v in model.state_dict().items()}
-        cpu_rps, cpu_s, rgb_ref, dist_ref = cpu_baseline(ncpu, sd, rays)
+        cpu_rps, cpu_s, rgb_ref, dist_ref, cpu_fwd_rps = cpu_baseline(ncpu, sd, rays)
         from snerf_amd.mipnerf import Rays
         sub = Rays(*[r[:ncpu] for r in rays])
         with torch.no_grad():
@@ -343,7 +344,8 @@ def main():
         mse = lambda a, b: float(((a.double() - b.double()) ** 2).mean())
         psnr = lambda a, b: (float("inf") if mse(a, b) == 0 else -10.0 * math.log10(mse(a, b)))
         out["cpu_baseline"] = {"value": round(cpu_rps, 2), "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
-                               "sample": f"{ncpu} rays forward+backward, same network/shape, oracle (torch-CPU restatement of the reference), {cpu_s:.1f} s"}
+                               "sample": f"{ncpu} rays forward+backward, same network/shape, oracle (torch-CPU restatement of the reference), {cpu_s:.1f} s",
+                               "forward_only_value": round(cpu_fwd_rps, 2)}
         out["parity"] = {"rays": ncpu,
                          "f32_kernels_vs_cpu_oracle_max_rel_err_rgb": float(((r32[1][0].cpu() - rgb_ref).abs() / (rgb_ref.abs() + 1e-3)).max()),
                          "f32_kernels_vs_cpu_oracle_max_rel_err_depth": float(((r32[1][1].cpu() - dist_ref).abs() / dist_ref.abs()).max()),
