@@ -150,7 +150,8 @@ int snerf_grid_tv_grad(const float* inputs, const void* embeddings, void* grad, 
  * caller's [1:-1] trim (models.py:187-188), the annealed logits (models.py:196-203), stepfun.sample_intervals
  * (stepfun.py:251-294 -> 175-218 -> 154-161 -> 108-128, math.sorted_interp math.py:88-107) at the centres `u` [R,n]
  * (rows u_stride apart, 0 = shared) and the power-transformation ray warp s -> t (coord.py:103-162, lam).  sdist [R,S0+1],
- * weights [R,S0] -> sdist_out / tdist_out [R,n+1]. */
+ * weights [R,S0] -> sdist_out / tdist_out [R,n+1].  One wave per ray; at most 256 intervals after the dilation (3*S0 - 2 <= 256,
+ * i.e. S0 <= 86; undilated S0 <= 256), SNERF_ERR_ARG beyond. */
 int snerf_zip_resample(const float* sdist, const float* weights, int S0, const float* u, long u_stride, int n,
                        const float* near, const float* far, long R, float dilation, int dilate, float anneal,
                        float resample_padding, float lam, float dom0, float dom1, float* sdist_out, float* tdist_out,
