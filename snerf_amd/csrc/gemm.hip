@@ -719,12 +719,12 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
       if (col_ok && m < p.M) {
         *(bf16x8*)((T*)p.Y + (long)m * p.ldy + ncol) = val;
         if (ACT == ACT_RELU_BITS) {
-          // bf16 > 0  <=>  sign bit clear and not zero (the value is a ReLU output: never NaN-signed)
+          // the value is a ReLU output (max(v, +0) rounded to bf16: never negative, never -0): > 0  <=>  its 16 bits are not all zero
           const u32x4 raw = __builtin_bit_cast(u32x4, val);
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            const unsigned h = (raw[e >> 1] >> (16 * (e & 1))) & 0xffffu;
-            mw |= (h != 0u && h < 0x8000u ? 1u : 0u) << (8 * it + e);
+            const unsigned h = e & 1 ? (raw[e >> 1] >> 16) : (raw[e >> 1] & 0xffffu);
+            mw |= (h != 0u ? 1u : 0u) << (8 * it + e);
           }
         }
         if constexpr (COLSUM) {
