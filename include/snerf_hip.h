@@ -328,6 +328,19 @@ int snerf_zip_encode_prop_fwd(const float* tdist, const float* origins, const fl
 int snerf_adam_step_dev(float* p, float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, int* step_dev,
                         float grad_scale, int zero_grad, void* stream);
 
+/* The Adam step with the gradient hygiene of s-nerfpp/zipnerf/internal/train_utils.py:234-243 (clip_gradients, called every step at
+ * zipnerf/train.py:336) folded into the same pass over the arena, in the reference's order: global-norm clip (clip_coef: device
+ * scalar from snerf_grad_clip_coef, or NULL), value clip (grad_max_val > 0, torch.clamp semantics: NaN stays NaN), then `nonfinite`:
+ * 0 = keep, 1 = NaN / +-Inf -> 0 (a poisoned gradient never reaches m, v or the parameters), 2 = torch.nan_to_num_ exactly (NaN -> 0,
+ * +-Inf -> +-FLT_MAX).  step_dev != NULL: step count in device memory (incremented first); lr_dev != NULL: learning rate read from
+ * device memory (a captured hipGraph then follows an lr schedule). */
+int snerf_adam_step_ex(float* p, float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, int step,
+                       int* step_dev, const float* lr_dev, float grad_scale, int zero_grad, int nonfinite, float grad_max_val,
+                       const float* clip_coef, void* stream);
+/* torch.nn.utils.clip_grad_norm_ coefficient over a flat gradient arena: out[0] = min(1, max_norm / (|grad_scale| * ||g||_2 + 1e-6)),
+ * out[1] = the norm.  ws: >= 1024 doubles of device scratch.  Fixed reduction order (deterministic). */
+int snerf_grad_clip_coef(const float* g, long n, float grad_scale, float max_norm, void* ws, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

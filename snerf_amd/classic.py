@@ -140,6 +140,7 @@ class _RunNetworkFn(torch.autograd.Function):
         m.net.backward(d_raw.contiguous(), ctx.saved)
         ctx.saved = None
         grads = tuple(m.arena.g[n].clone() for n in m._pnames)
+        m.arena.grad.zero_()      # leave the arena clean for whoever accumulates into it next
         return (None, None, None, None, None) + grads
 
 

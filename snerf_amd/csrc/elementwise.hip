@@ -6,88 +6,125 @@
 // torch.optim.Adam over the model parameters): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
 // p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps).  grad_scale folds the 1/world_size
 // of the data-parallel mean into the same pass; grads are zeroed for the next step.
+//
+// Gradient hygiene of the zipnerf training loop (s-nerfpp/zipnerf/internal/train_utils.py:234-243, train.py:336), folded into
+// the same pass: optional global-norm clip (`clip_coef`: device scalar written by snerf_grad_clip_coef), optional value clip
+// (`grad_max_val` > 0: clip_grad_value_), then the non-finite policy `nonfinite`:
+//   0 = keep (plain torch.optim.Adam),  1 = NaN / +-Inf -> 0 (one poisoned gradient cannot reach m, v or the parameters),
+//   2 = torch.Tensor.nan_to_num_() exactly as the reference calls it (NaN -> 0, +-Inf -> +-FLT_MAX).
+struct AdamArgs {
+  float lr, b1, b2, eps, grad_scale, grad_max_val;
+  int zero_grad, nonfinite;
+  const int* step_dev;        // bias-correction step count in device memory (graph capture), or nullptr: `step`
+  const float* lr_dev;        // learning rate in device memory (graph capture with a schedule), or nullptr: `lr`
+  const float* clip_coef;     // global-norm clip coefficient in device memory, or nullptr
+  int step;
+};
+
+__device__ __forceinline__ float adam_clean_grad(float g, const AdamArgs& a, float coef) {
+  g *= a.grad_scale * coef;
+  if (a.grad_max_val > 0.f && g == g) g = fminf(fmaxf(g, -a.grad_max_val), a.grad_max_val);   // torch.clamp keeps a NaN (fminf/fmaxf would not)
+  if (a.nonfinite == 1) g = (fabsf(g) <= 3.402823466e+38f) ? g : 0.f;                          // false for NaN and Inf
+  else if (a.nonfinite == 2) g = (g != g) ? 0.f : fminf(fmaxf(g, -3.402823466e+38f), 3.402823466e+38f);
+  return g;
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
-                                                   float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
-                                                   float bc1, float bc2_sqrt, float grad_scale, int zero_grad) {
+                                                   float* __restrict__ v, long n, AdamArgs a) {
+  const float t = (float)(a.step_dev != nullptr ? *a.step_dev : a.step);
+  const float lr = a.lr_dev != nullptr ? *a.lr_dev : a.lr;
+  const float bc1 = 1.f - powf(a.b1, t), bc2_sqrt = sqrtf(1.f - powf(a.b2, t));
+  const float coef = a.clip_coef != nullptr ? *a.clip_coef : 1.f;
+  const float b1 = a.b1, b2 = a.b2, eps = a.eps;
   const long n4 = n >> 2;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
     float4 pp = ((float4*)p)[i], gg = ((float4*)g)[i], mm = ((float4*)m)[i], vv = ((float4*)v)[i];
     float* pa = (float*)&pp; float* ga = (float*)&gg; float* ma = (float*)&mm; float* va = (float*)&vv;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float gk = ga[k] * grad_scale;
+      const float gk = adam_clean_grad(ga[k], a, coef);
       ma[k] = b1 * ma[k] + (1.f - b1) * gk;
       va[k] = b2 * va[k] + (1.f - b2) * gk * gk;
       pa[k] -= (lr / bc1) * ma[k] / (sqrtf(va[k]) / bc2_sqrt + eps);
     }
     ((float4*)p)[i] = pp; ((float4*)m)[i] = mm; ((float4*)v)[i] = vv;
-    if (zero_grad) ((float4*)g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.zero_grad) ((float4*)g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     const long i = (n4 << 2) + threadIdx.x;
-    const float gk = g[i] * grad_scale;
+    const float gk = adam_clean_grad(g[i], a, coef);
     m[i] = b1 * m[i] + (1.f - b1) * gk;
     v[i] = b2 * v[i] + (1.f - b2) * gk * gk;
     p[i] -= (lr / bc1) * m[i] / (sqrtf(v[i]) / bc2_sqrt + eps);
-    if (zero_grad) g[i] = 0.f;
+    if (a.zero_grad) g[i] = 0.f;
   }
+}
+
+static int adam_launch(float* p, float* g, float* m, float* v, long n, const AdamArgs& a, void* stream) {
+  if (n <= 0) return SNERF_OK;
+  if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) || a.nonfinite < 0 || a.nonfinite > 2) return SNERF_ERR_ARG;
+  const long n4 = n >> 2;
+  int blocks = (int)((n4 + 255) / 256);
+  blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, a);
+  return snerf_check_launch();
 }
 
 extern "C" int snerf_adam_step(float* p, float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, int step,
                                float grad_scale, int zero_grad, void* stream) {
-  if (n <= 0) return SNERF_OK;
-  if (step < 1 || (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15)) return SNERF_ERR_ARG;
-  const float bc1 = 1.f - powf(b1, (float)step), bc2s = sqrtf(1.f - powf(b2, (float)step));
-  const long n4 = n >> 2;
-  int blocks = (int)((n4 + 255) / 256);
-  blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
-  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, b1, b2, eps, bc1, bc2s,
-                     grad_scale, zero_grad);
-  return snerf_check_launch();
+  if (step < 1) return SNERF_ERR_ARG;
+  return adam_launch(p, g, m, v, n, AdamArgs{lr, b1, b2, eps, grad_scale, 0.f, zero_grad, 0, nullptr, nullptr, nullptr, step}, stream);
 }
 
 // The same update with the step count in device memory (incremented here): nothing in the launch depends on host state, so a whole
 // training step can be captured in a hipGraph and replayed (trainer.MipTrainer.capture).
 __global__ void adam_tick_kernel(int* step) { *step += 1; }
 
-__global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
-                                                       float lr, float b1, float b2, float eps, const int* __restrict__ step, float grad_scale,
-                                                       int zero_grad) {
-  const float t = (float)*step;
-  const float bc1 = 1.f - powf(b1, t), bc2_sqrt = sqrtf(1.f - powf(b2, t));
-  const long n4 = n >> 2;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-    float4 pp = ((float4*)p)[i], gg = ((float4*)g)[i], mm = ((float4*)m)[i], vv = ((float4*)v)[i];
-    float* pa = (float*)&pp; float* ga = (float*)&gg; float* ma = (float*)&mm; float* va = (float*)&vv;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float gk = ga[k] * grad_scale;
-      ma[k] = b1 * ma[k] + (1.f - b1) * gk;
-      va[k] = b2 * va[k] + (1.f - b2) * gk * gk;
-      pa[k] -= (lr / bc1) * ma[k] / (sqrtf(va[k]) / bc2_sqrt + eps);
-    }
-    ((float4*)p)[i] = pp; ((float4*)m)[i] = mm; ((float4*)v)[i] = vv;
-    if (zero_grad) ((float4*)g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
-    const long i = (n4 << 2) + threadIdx.x;
-    const float gk = g[i] * grad_scale;
-    m[i] = b1 * m[i] + (1.f - b1) * gk;
-    v[i] = b2 * v[i] + (1.f - b2) * gk * gk;
-    p[i] -= (lr / bc1) * m[i] / (sqrtf(v[i]) / bc2_sqrt + eps);
-    if (zero_grad) g[i] = 0.f;
-  }
-}
-
 extern "C" int snerf_adam_step_dev(float* p, float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, int* step_dev,
                                    float grad_scale, int zero_grad, void* stream) {
   if (n <= 0) return SNERF_OK;
-  if (step_dev == nullptr || (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15)) return SNERF_ERR_ARG;
-  const long n4 = n >> 2;
-  int blocks = (int)((n4 + 255) / 256);
-  blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+  if (step_dev == nullptr) return SNERF_ERR_ARG;
   hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev);
-  hipLaunchKernelGGL(adam_dev_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, b1, b2, eps, step_dev, grad_scale, zero_grad);
+  return adam_launch(p, g, m, v, n, AdamArgs{lr, b1, b2, eps, grad_scale, 0.f, zero_grad, 0, step_dev, nullptr, nullptr, 0}, stream);
+}
+
+extern "C" int snerf_adam_step_ex(float* p, float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, int step,
+                                  int* step_dev, const float* lr_dev, float grad_scale, int zero_grad, int nonfinite,
+                                  float grad_max_val, const float* clip_coef, void* stream) {
+  if (n <= 0) return SNERF_OK;
+  if (step_dev == nullptr && step < 1) return SNERF_ERR_ARG;
+  if (step_dev != nullptr) hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev);
+  return adam_launch(p, g, m, v, n, AdamArgs{lr, b1, b2, eps, grad_scale, grad_max_val, zero_grad, nonfinite, step_dev, lr_dev, clip_coef, step}, stream);
+}
+
+// Global-norm clip coefficient of torch.nn.utils.clip_grad_norm_ (accelerator.clip_grad_norm_, train_utils.py:236-237):
+// coef = min(1, max_norm / (||grad_scale * g||_2 + 1e-6)) over the flat gradient arena, NaN-poisoned like torch's.  Two launches:
+// per-block partial sums of squares in a fixed order (deterministic), then one block folds them.
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, long n, double* __restrict__ part) {
+  __shared__ double red[4];
+  double acc = 0.0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) acc += (double)g[i] * (double)g[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void clip_coef_kernel(const double* __restrict__ part, int nb, float grad_scale, float max_norm, float* __restrict__ out) {
+  double s = 0.0;
+  for (int i = 0; i < nb; ++i) s += part[i];
+  const float norm = fabsf(grad_scale) * (float)sqrt(s);
+  out[0] = fminf(max_norm / (norm + 1e-6f), 1.f);
+  out[1] = norm;
+}
+
+// ws: >= 1024 doubles of device scratch; out: float[2] = {coef, norm}
+extern "C" int snerf_grad_clip_coef(const float* g, long n, float grad_scale, float max_norm, void* ws, float* out, void* stream) {
+  if (n <= 0 || ws == nullptr || out == nullptr || max_norm <= 0.f) return SNERF_ERR_ARG;
+  int blocks = (int)((n + 255) / 256);
+  blocks = blocks > 1024 ? 1024 : blocks;
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, n, (double*)ws);
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (const double*)ws, blocks, grad_scale, max_norm, out);
   return snerf_check_launch();
 }
 

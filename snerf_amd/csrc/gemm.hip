@@ -37,8 +37,12 @@ struct GemmNT {
   float* colsum;
   int M, N, K, n_store, act, out_f32, vec_store;
   float* colsum_ws; int fast_epi;
-  int dbg;  // ablation bits (tools/gemm_probe.py): 1 = no staging loads after tile 0, 2 = no LDS fragment reads, 4 = no stores
+  int dbg;  // ablation bits, honoured only by a `make PROBE=1` build (tools/gemm_probe.py): 1 = no staging loads after tile 0, 2 = no LDS fragment reads, 4 = no stores
 };
+#ifndef SNERF_PROBE
+#define SNERF_PROBE 0   // the shipped library compiles the ablation branches out
+#endif
+#define DBG(p, bit) (SNERF_PROBE && ((p).dbg & (bit)))
 
 template <typename T> struct Frag;
 template <> struct Frag<float> { typedef f32x4 type; };
@@ -131,7 +135,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x16 (&acc)[BM / 
           const int row = it * 8 + prow;
           const int m = m0 + wm * WTM + i * 32 + row;
           frag_t val = *(const frag_t*)(my + row * PITCH + pch * 16);
-          if (m < p.M && ncol < p.n_store && !(p.dbg & 4)) {
+          if (m < p.M && ncol < p.n_store && !DBG(p, 4)) {
             if (p.act == ACT_MASK) {
               const frag_t a8 = *(const frag_t*)(auxp + (long)m * p.ldaux + ncol);
 #pragma unroll
@@ -180,7 +184,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x16 (&acc)[BM / 
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int m = m0 + wm * WTM + i * 32 + (lane & 31);
-        if (m >= p.M || nb >= p.n_store || (p.dbg & 4)) continue;
+        if (m >= p.M || nb >= p.n_store || DBG(p, 4)) continue;
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -316,16 +320,16 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmNT p) {
   auto read_frags = [&](const char* sA, const char* sB, int ks, frag_t* a, frag_t* b) {
     const int c = 2 * ks + chalf;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) a[i] = *(const frag_t*)((p.dbg & 2) ? smem + lane * 16 : sA + ra[i] * 128 + ((c ^ ((ra[i] >> 1) & 7)) << 4));
+    for (int i = 0; i < TM; ++i) a[i] = *(const frag_t*)(DBG(p, 2) ? smem + lane * 16 : sA + ra[i] * 128 + ((c ^ ((ra[i] >> 1) & 7)) << 4));
 #pragma unroll
-    for (int j = 0; j < TN; ++j) b[j] = *(const frag_t*)((p.dbg & 2) ? smem + lane * 16 + 1024 : sB + rb[j] * 128 + ((c ^ ((rb[j] >> 1) & 7)) << 4));
+    for (int j = 0; j < TN; ++j) b[j] = *(const frag_t*)(DBG(p, 2) ? smem + lane * 16 + 1024 : sB + rb[j] * 128 + ((c ^ ((rb[j] >> 1) & 7)) << 4));
   };
 
   issue(0, 0);
   for (int kt = 0; kt < KT; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (kt + 1 < KT && !(p.dbg & 1)) issue(kt + 1, (kt + 1) & 1);
+    if (kt + 1 < KT && !DBG(p, 1)) issue(kt + 1, (kt + 1) & 1);
     const char* sA = smem + (kt & 1) * STAGE;
     const char* sB = sA + BM * 128;
 #pragma unroll
@@ -454,7 +458,7 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmNT p) {
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  if ((p.dbg & 2) && blockIdx.x < 256) {
+  if (DBG(p, 2) && blockIdx.x < 256) {
     // ablation: de-phase the CUs (first resident set of workgroups starts up to 7/8 of a tile time late)
     const int steps = ((blockIdx.x >> 3) & 7) * (p.K >> 3);
     for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(8);
@@ -472,7 +476,7 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmNT p) {
 
   auto tile = [&](int t, auto db_tag) {
     constexpr int db = decltype(db_tag)::value;
-    const bool more1 = t + 1 < KT && !(p.dbg & 1), more2 = t + 2 < KT && !(p.dbg & 1);
+    const bool more1 = t + 1 < KT && !DBG(p, 1), more2 = t + 2 < KT && !DBG(p, 1);
     // P1
     read_b(db, 0, b0);
     read_a(db, 0);
@@ -663,7 +667,7 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
     const int ln = lane | zero;
     const int hi = ln >> 5, row1 = ln & 31, prow = ln >> 3, pch = ln & 7;
     const int ncol = en0 + wc * 64 + pch * 8;
-    const bool col_ok = ncol < p.n_store && !(p.dbg & 4);
+    const bool col_ok = ncol < p.n_store && !DBG(p, 4);
     const int mbase = em0 + wr * 128 + u * 32 + prow;
     unsigned mw = 0;                                     // ACT_MASK_BITS: this lane's 32 mask bits; ACT_RELU_BITS: the bits it produces
     if (ACT == ACT_MASK_BITS) {

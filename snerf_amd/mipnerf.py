@@ -266,6 +266,7 @@ class _MipFn(torch.autograd.Function):
         rg = m._backward(ctx.c, g_dist0, g_acc0, g_w0, g_rgb1, g_dist1, g_acc1, g_w1, g_sem1, ray_grads=ctx.ray_meta is not None)
         ctx.c = None
         grads = tuple(m.arena.g[n].clone() for n in m._pnames)
+        m.arena.grad.zero_()      # the trainers accumulate into the arena and expect it clean at step start
         if rg is None:
             return (None,) * 11 + grads
         rays_g = tuple(g.reshape(sh).to(device=dev, dtype=dt) for g, (sh, dt, dev) in zip(rg, ctx.ray_meta))

@@ -12,7 +12,6 @@ from . import _lib
 F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_MASK = 0, 1, 2
 ACT_RELU_BITS, ACT_MASK_BITS = 3, 4        # ReLU that also writes a 1-bit-per-element mask / ReLU backward from that mask
-ACT_RELU_BITS, ACT_MASK_BITS = 3, 4        # ReLU that also writes a 1-bit-per-element mask / ReLU backward from that mask
 _TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
 
 
@@ -304,20 +303,41 @@ def classic_composite_bwd(raw, noise, z_vals, rays_d, white, weights, acc, depth
 
 
 # ------------------------------------------------------------ training tail ----
-def adam_step(p, g, m, v, lr, b1, b2, eps, step, grad_scale=1.0, zero_grad=True):
-    for t in (p, g, m, v):
-        _f32c(t)
-    _lib.call("snerf_adam_step", _p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(b1), float(b2), float(eps), int(step),
-              float(grad_scale), 1 if zero_grad else 0, _stream())
+NONFINITE = {"keep": 0, "zero": 1, "nan_to_num": 2}
 
 
-def adam_step_dev(p, g, m, v, lr, b1, b2, eps, step_dev, grad_scale=1.0, zero_grad=True):
-    """adam_step with the step counter in device memory (int32 [1], incremented by the launch): graph-capturable."""
+def adam_step(p, g, m, v, lr, b1, b2, eps, step, grad_scale=1.0, zero_grad=True, nonfinite="zero", grad_max_val=0.0, clip_coef=None,
+              step_dev=None, lr_dev=None):
+    """Fused Adam over a flat arena (snerf_adam_step_ex).  Gradient hygiene in the reference's order (train_utils.py:234-243):
+    `clip_coef` (device float, see grad_clip_coef) -> value clip `grad_max_val` -> `nonfinite` policy ("zero": NaN/Inf gradients are
+    dropped so that they can never poison m, v or the parameters; "nan_to_num": torch's nan_to_num_ exactly; "keep": plain Adam).
+    `step_dev` (int32 [1] on the device, incremented by the launch) / `lr_dev` (fp32 [1]) replace the host scalars: graph-capturable."""
     for t in (p, g, m, v):
         _f32c(t)
-    assert step_dev.dtype == torch.int32 and step_dev.is_cuda and step_dev.numel() == 1
-    _lib.call("snerf_adam_step_dev", _p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(b1), float(b2), float(eps), _p(step_dev),
-              float(grad_scale), 1 if zero_grad else 0, _stream())
+    if step_dev is not None:
+        assert step_dev.dtype == torch.int32 and step_dev.is_cuda and step_dev.numel() == 1
+    if lr_dev is not None:
+        assert lr_dev.dtype == torch.float32 and lr_dev.is_cuda and lr_dev.numel() == 1
+    if clip_coef is not None:
+        assert clip_coef.dtype == torch.float32 and clip_coef.is_cuda
+    _lib.call("snerf_adam_step_ex", _p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(b1), float(b2), float(eps), int(step),
+              _p(step_dev), _p(lr_dev), float(grad_scale), 1 if zero_grad else 0, NONFINITE[nonfinite], float(grad_max_val), _p(clip_coef),
+              _stream())
+
+
+def adam_step_dev(p, g, m, v, lr, b1, b2, eps, step_dev, grad_scale=1.0, zero_grad=True, **kw):
+    """adam_step with the step counter in device memory (int32 [1], incremented by the launch): graph-capturable.  (The C-ABI also keeps
+    the plain entries snerf_adam_step / snerf_adam_step_dev = snerf_adam_step_ex without the hygiene options.)"""
+    adam_step(p, g, m, v, lr, b1, b2, eps, 0, grad_scale, zero_grad, step_dev=step_dev, **kw)
+
+
+def grad_clip_coef(g, grad_scale, max_norm):
+    """-> fp32 [2] on the device = (min(1, max_norm / (|grad_scale| ||g|| + 1e-6)), the norm): clip_grad_norm_'s coefficient for adam_step."""
+    _f32c(g)
+    ws = torch.empty(1024, dtype=torch.float64, device=g.device)
+    out = torch.empty(2, dtype=torch.float32, device=g.device)
+    _lib.call("snerf_grad_clip_coef", _p(g), g.numel(), float(grad_scale), float(max_norm), _p(ws), _p(out), _stream())
+    return out
 
 
 def colsum_f32(x, C, out):

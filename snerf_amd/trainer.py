@@ -49,9 +49,14 @@ class _GradExchange:
 
 class MipTrainer:
     def __init__(self, model, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, depth_lambda=0.2, coarse_depth_mult=0.2,
-                 proposal_loss=False, proposal_lambda=0.05, disparity_depth=True, process_group=None):
+                 proposal_loss=False, proposal_lambda=0.05, disparity_depth=True, process_group=None,
+                 nonfinite="zero", grad_max_val=0.0, grad_max_norm=0.0):
+        """`nonfinite` / `grad_max_val` / `grad_max_norm`: gradient hygiene folded into the Adam launch (ops.adam_step).  The s-nerf
+        reference has none (train.py:212-215 drops into pdb on a failing backward); the default "zero" keeps one NaN / Inf gradient
+        (1/(depth + eps), a bf16 overflow) from poisoning m, v and the parameters of the whole arena on every rank.  "keep" = plain Adam."""
         self.model = model
         self.lr, self.betas, self.eps = lr, betas, eps
+        self.nonfinite, self.grad_max_val, self.grad_max_norm = nonfinite, float(grad_max_val), float(grad_max_norm)
         self.depth_lambda, self.coarse_depth_mult = depth_lambda, coarse_depth_mult
         self.proposal_loss, self.proposal_lambda, self.disparity_depth = proposal_loss, proposal_lambda, disparity_depth
         a = model.arena
@@ -60,13 +65,22 @@ class MipTrainer:
         self.t = 0
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
-        self._step_dev = self._graph = None
+        self._step_dev = self._lr_dev = self._graph = None
         a.grad.zero_()
 
     def broadcast_parameters(self, src=0):
         if self.world > 1:
             dist.broadcast(self.model.arena.flat, src=src, group=self.pg)
             self.model.arena.bump()
+
+    def _adam(self):
+        """One fused Adam launch over the flat arena; folds the data-parallel mean, the gradient hygiene and zero_grad."""
+        a = self.model.arena
+        coef = ops.grad_clip_coef(a.grad, 1.0 / self.world, self.grad_max_norm) if self.grad_max_norm > 0 else None
+        ops.adam_step(a.flat, a.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.t, grad_scale=1.0 / self.world,
+                      zero_grad=True, nonfinite=self.nonfinite, grad_max_val=self.grad_max_val, clip_coef=coef,
+                      step_dev=self._step_dev, lr_dev=self._lr_dev)
+        a.bump()
 
     def loss_and_grads(self, outs, target_rgb, target_depth, conf):
         """The reference's per-ray loss tail (train.py:150-208) in ONE kernel, `snerf_mip_loss_tail`: RGB MSE, the
@@ -97,13 +111,7 @@ class MipTrainer:
         self.last_ray_grads = m._backward(ctx, *g, on_done=ex, ray_grads=ray_grads)
         ex.finish()
         self.t += 1
-        if self._step_dev is not None:                    # graph mode: the step count lives on the device (capture / replay below)
-            ops.adam_step_dev(m.arena.flat, m.arena.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self._step_dev,
-                              grad_scale=1.0 / self.world, zero_grad=True)
-        else:
-            ops.adam_step(m.arena.flat, m.arena.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.t,
-                          grad_scale=1.0 / self.world, zero_grad=True)
-        m.arena.bump()
+        self._adam()                                      # graph mode: step count and lr live on the device (capture / replay below)
         return loss, outs
 
     # ---- hipGraph capture of the whole step --------------------------------------------------------------------------------------
@@ -112,19 +120,32 @@ class MipTrainer:
         afterwards `replay()` runs a step with one graph launch -- the caller refreshes the batch by copying into those tensors
         (`rays.origins.copy_(...)` etc.).  Worth it when the step is launch-bound: at 512 rays per GPU (the 8-GPU split of the
         reference's 4096-ray batch) the kernels are 10-50 us each.  The packed-weight refresh, the torch RNG draws (graph-safe Philox
-        offsets) and the Adam bias corrections (step count in device memory) are all inside the graph.  Single process only (the RCCL
-        exchange is not captured)."""
+        offsets), the Adam bias corrections (step count in device memory) and the learning rate (device scalar, refreshed from
+        `self.lr` by every `replay()`, so an lr schedule keeps working) are all inside the graph.
+
+        The `warmup` steps (one-time kernel attributes, allocator pools) are REAL steps on the capture batch, so parameters, Adam
+        moments and the step count are snapshotted before and restored after them: capturing does not train.  (The torch RNG does
+        advance.)  Single process only (the RCCL exchange is not captured)."""
         if self.world != 1:
             raise NotImplementedError("graph capture covers the single-process step")
-        dev = self.model.arena.flat.device
+        a = self.model.arena
+        dev = a.flat.device
+        snap = (a.flat.clone(), self.m.clone(), self.v.clone(), self.t)
         self._step_dev = torch.tensor([self.t], dtype=torch.int32, device=dev)
+        self._lr_dev = torch.tensor([self.lr], dtype=torch.float32, device=dev)
         args = (rays, target_rgb, target_depth, conf)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):                    # warm-up on a side stream: one-time kernel attributes, allocator pools
+        with torch.cuda.stream(side):                    # warm-up on a side stream
             for _ in range(warmup):
                 self.step(*args, randomized=randomized)
         torch.cuda.current_stream(dev).wait_stream(side)
+        with torch.no_grad():
+            a.flat.copy_(snap[0]); self.m.copy_(snap[1]); self.v.copy_(snap[2])
+            self.t = snap[3]
+            self._step_dev.fill_(self.t)
+            a.grad.zero_()
+        a.bump()
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
             self._graph_loss, self._graph_outs = self.step(*args, randomized=randomized)
@@ -133,16 +154,33 @@ class MipTrainer:
 
     def replay(self):
         """One captured step.  -> (loss, outs): the same device tensors every time, overwritten by each replay."""
+        self._lr_dev.fill_(self.lr)                      # the graph reads the learning rate from the device
         self._graph.replay()
         self.t += 1
         return self._graph_loss, self._graph_outs
 
 
+def shard_bounds(n: int, rank: int, world: int):
+    """[start, end) of rank's contiguous share of n rays; the first n % world ranks take one extra ray, nothing is dropped."""
+    per, rem = divmod(n, world)
+    start = rank * per + min(rank, rem)
+    return start, start + per + (1 if rank < rem else 0)
+
+
 def shard_rays(rays, rank: int, world: int):
-    """Contiguous, equal split of a ray batch (namedtuple of [N,.] tensors) across ranks."""
-    n = rays[0].shape[0]
-    per = n // world
-    return type(rays)(*[r[rank * per:(rank + 1) * per] for r in rays])
+    """Contiguous split of a ray batch (namedtuple of [N,.] tensors) across ranks; see shard_bounds."""
+    a, b = shard_bounds(rays[0].shape[0], rank, world)
+    return type(rays)(*[r[a:b] for r in rays])
+
+
+def shard_batch(rays, rank: int, world: int, *per_ray):
+    """shard_rays for the rays AND every per-ray target (target_rgb, target_depth, conf, ...; None passes through) with the same
+    bounds, so that a caller cannot slice them inconsistently.  -> (rays_shard, *target_shards)"""
+    a, b = shard_bounds(rays[0].shape[0], rank, world)
+    for t in per_ray:
+        if t is not None and t.shape[0] != rays[0].shape[0]:
+            raise ValueError("per-ray tensor does not match the ray batch")
+    return (type(rays)(*[r[a:b] for r in rays]),) + tuple(None if t is None else t[a:b] for t in per_ray)
 
 
 class ZipTrainer:
@@ -159,8 +197,14 @@ class ZipTrainer:
     Further caller-defined terms on the ray histories go through `aux_loss_fn(ray_history) -> scalar` (torch autograd on detached
     leaf copies of every level's `weights`; its d(loss)/d(weights) is added to the fused tail's)."""
 
-    def __init__(self, model, lr=1e-2, betas=(0.9, 0.99), eps=1e-15, charb_padding=0.001, process_group=None, loss_cfg=None):
+    def __init__(self, model, lr=1e-2, betas=(0.9, 0.99), eps=1e-15, charb_padding=0.001, process_group=None, loss_cfg=None,
+                 nonfinite="zero", grad_max_val=0.0, grad_max_norm=0.0):
+        """`nonfinite`, `grad_max_val`, `grad_max_norm` = train_utils.clip_gradients (train_utils.py:234-243, run every step at
+        zipnerf/train.py:336; configs.py:83-84 defaults 0 = off), folded into the Adam launch.  The reference always ends with
+        param.grad.nan_to_num_(); "zero" (default) also drops +-Inf instead of mapping it to +-FLT_MAX (which would leave v = inf,
+        i.e. that parameter frozen for good); "nan_to_num" reproduces the reference exactly."""
         self.model, self.lr, self.betas, self.eps = model, lr, betas, eps
+        self.nonfinite, self.grad_max_val, self.grad_max_norm = nonfinite, float(grad_max_val), float(grad_max_norm)
         self.loss_cfg = dict(charb_padding=charb_padding)
         self.loss_cfg.update(loss_cfg or {})
         # hash-grid weight decay (train_utils.py:184-203; configs.py:74): a term on the parameters, not on the rays
@@ -217,7 +261,8 @@ class ZipTrainer:
         m._backward(ctx, [(None, None, None, g_w[0]), (None, None, None, g_w[1]), (G["rgb"], G["depth"], None, g_w[2], G["semantic"])], on_done=ex)
         ex.finish()
         self.t += 1
+        coef = ops.grad_clip_coef(m.arena.grad, 1.0 / self.world, self.grad_max_norm) if self.grad_max_norm > 0 else None
         ops.adam_step(m.arena.flat, m.arena.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.t,
-                      grad_scale=1.0 / self.world, zero_grad=True)
+                      grad_scale=1.0 / self.world, zero_grad=True, nonfinite=self.nonfinite, grad_max_val=self.grad_max_val, clip_coef=coef)
         m.arena.bump()
         return loss, levels

@@ -449,4 +449,6 @@ class _ZipFn(torch.autograd.Function):
             grads[2] = grads[2] + (g[18],)
         m._backward(ctx.c, grads)
         ctx.c = None
-        return (None,) * 7 + tuple(m.arena.g[n].clone() for n in m._pnames)
+        grads = tuple(m.arena.g[n].clone() for n in m._pnames)
+        m.arena.grad.zero_()      # the trainers accumulate into the arena and expect it clean at step start
+        return (None,) * 7 + grads

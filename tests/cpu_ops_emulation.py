@@ -161,13 +161,30 @@ def classic_composite_bwd(raw, noise, z_vals, rays_d, white, weights, acc, depth
     d_raw.copy_(r.grad)
 
 
-def adam_step(p, g, m, v, lr, b1, b2, eps, step, grad_scale=1.0, zero_grad=True):
-    gg = g * grad_scale
+def adam_step(p, g, m, v, lr, b1, b2, eps, step, grad_scale=1.0, zero_grad=True, nonfinite="zero", grad_max_val=0.0, clip_coef=None,
+              step_dev=None, lr_dev=None):
+    if step_dev is not None:
+        step_dev += 1
+        step = int(step_dev)
+    if lr_dev is not None:
+        lr = float(lr_dev)
+    gg = g * grad_scale * (1.0 if clip_coef is None else float(clip_coef[0]))
+    if grad_max_val > 0:
+        gg = torch.clamp(gg, -grad_max_val, grad_max_val)
+    if nonfinite == "zero":
+        gg = torch.where(torch.isfinite(gg), gg, torch.zeros_like(gg))
+    elif nonfinite == "nan_to_num":
+        gg = torch.nan_to_num(gg)
     m.mul_(b1).add_(gg, alpha=1 - b1)
     v.mul_(b2).addcmul_(gg, gg, value=1 - b2)
     p.sub_((lr / (1 - b1 ** step)) * m / (v.sqrt() / (1 - b2 ** step) ** 0.5 + eps))
     if zero_grad:
         g.zero_()
+
+
+def grad_clip_coef(g, grad_scale, max_norm):
+    norm = abs(grad_scale) * float(g.double().pow(2).sum().sqrt())
+    return torch.tensor([min(max_norm / (norm + 1e-6), 1.0), norm], dtype=torch.float32)
 
 
 def colsum_f32(x, C, out):
@@ -373,12 +390,11 @@ def zip_encode_prop_fwd(tdist, origins, directions, radii, base_x, base_y, deg_j
     return h @ rb(w2.reshape(-1, 1)) + b2
 
 
-def adam_step_dev(p, g, m, v, lr, b1, b2, eps, step_dev, grad_scale=1.0, zero_grad=True):
-    step_dev += 1
-    adam_step(p, g, m, v, lr, b1, b2, eps, int(step_dev), grad_scale, zero_grad)
+def adam_step_dev(p, g, m, v, lr, b1, b2, eps, step_dev, grad_scale=1.0, zero_grad=True, **kw):
+    adam_step(p, g, m, v, lr, b1, b2, eps, 0, grad_scale, zero_grad, step_dev=step_dev, **kw)
 
 
-_NAMES = ["adam_step_dev", "zip_encode_prop_fwd", "mip_encode_bwd", "mip_viewenc_bwd", "hash_decay", "zip_percentiles", "zip_pixels_to_rays", "zip_loss_tail", "semantic_composite_fwd", "semantic_composite_bwd", "zip_resample", "zip_encode_fwd", "zip_encode_bwd", "zip_composite_fwd", "zip_composite_bwd",
+_NAMES = ["adam_step_dev", "grad_clip_coef", "zip_encode_prop_fwd", "mip_encode_bwd", "mip_viewenc_bwd", "hash_decay", "zip_percentiles", "zip_pixels_to_rays", "zip_loss_tail", "semantic_composite_fwd", "semantic_composite_bwd", "zip_resample", "zip_encode_fwd", "zip_encode_bwd", "zip_composite_fwd", "zip_composite_bwd",
           "linear_fwd", "linear_wgrad", "classic_embed", "mip_encode", "mip_viewenc", "classic_sample_pdf", "classic_points",
           "classic_merge_sort", "mip_resample", "stratified", "mip_composite_fwd", "mip_composite_bwd", "classic_composite_fwd",
           "classic_composite_bwd", "adam_step", "colsum_f32", "cast_pad", "pinhole_rays", "mip_loss_tail"]
