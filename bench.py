@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the S-NeRF background hot path on MI355X (contract: see DESIGN.md "Measurement").
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        (N > 1 without a launcher: re-executes itself under torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" is one training step of the live S-NeRF renderer (path A, MipNerfModel) on one batch of synthetic
@@ -49,6 +49,20 @@ def rays_from_pixels(pix, origins, device, H=900, W=1600, focal=1266.0, near=1.8
     ones = np.ones((len(pix), 1))
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)
     return Rays(t(origins), t(d), t(d / np.linalg.norm(d, axis=-1, keepdims=True)), t(radii), t(ones), t(ones * near), t(ones * far), t(ones * 0))
+
+
+def relaunch_under_torchrun(n):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks ourselves (one process per GPU over RCCL)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def frame_rays(first, n, device, H=900, W=1600, focal=1266.0, near=1.8, far=110.0):
@@ -174,11 +188,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--rays", type=int, default=4096, help="rays per GPU per step")
+    ap.add_argument("--rays", type=int, default=4096, help="rays per GPU per step (weak scaling) / global rays per step (--scaling strong)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --rays per GPU whatever N (default); strong: the reference's --rays-ray batch split across the N GPUs")
     ap.add_argument("--compute", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--variant", type=int, default=8, help="NT GEMM variant: 8 = persistent 8-phase 256x256 (default), 4 = 8-phase, 1 = 256x256 block-issue, 0 = 128x128")
     ap.add_argument("--no-frame", action="store_true", help="skip the 1600x900 frame render")
     ap.add_argument("--no-cpu", action="store_true", help="skip the host-CPU baseline")
+    ap.add_argument("--no-eager", action="store_true", help="skip the PyTorch-ROCm eager baseline (3 steps each of fp32 and bf16 autocast on this GPU)")
+    ap.add_argument("--no-f32", action="store_true", help="skip the fp32-parity-mode leg (3 train steps with exact-fp32 MFMA)")
+    ap.add_argument("--eager", action="store_true", help="(kept for compatibility: the eager baseline is on by default)")
     ap.add_argument("--cpu-rays", type=int, default=512, help="rays of the bounded host-CPU baseline sample (about 15 s on the GPU box)")
     ap.add_argument("--shape", default="baseline", choices=["baseline", "shipped"],
                     help="baseline = BASELINE.json's 64 proposal + 128 fine evals/ray (192 spp); shipped = the reference config's "
@@ -188,18 +207,21 @@ def main():
     ap.add_argument("--ert", type=float, nargs=2, default=None, metavar=("EPS_T", "EPS_W"),
                     help="also render the frame with early ray termination + sample compaction (inference extension, not the reference's "
                          "algorithm): skip fine samples whose proposal-predicted transmittance <= EPS_T or weight <= EPS_W")
-    ap.add_argument("--eager", action="store_true", help="also time the plain PyTorch-ROCm eager train step on this GPU (fp32 and bf16 autocast)")
     ap.add_argument("--frame-chunk", type=int, default=32768)
     args = ap.parse_args()
     global S0, P1
     if args.shape == "shipped":
         S0, P1 = 128, 128
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(relaunch_under_torchrun(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.same_device:
         local = 0
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
@@ -209,17 +231,17 @@ def main():
             dist.init_process_group(args.backend)
     else:
         torch.cuda.set_device(0)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     device = torch.device("cuda", local if world > 1 else 0)
 
     from snerf_amd import ops
+    from snerf_amd.mipnerf import Rays, render_image
     from snerf_amd.trainer import MipTrainer
     model = build_model(args.compute, device)
     model.nerf.variant = model.prop.variant = args.variant
     trainer = MipTrainer(model, lr=5e-4)
     trainer.broadcast_parameters(0)
 
-    n = args.rays
+    n = args.rays if args.scaling == "weak" else max(args.rays // world, 1)
     rays = synth_rays(n, 1000 + rank, device)
     g = torch.Generator(device="cpu").manual_seed(2000 + rank)
     tgt = torch.rand(n, 3, generator=g).to(device)
@@ -234,9 +256,12 @@ def main():
     for _ in range(args.warmup):
         trainer.step(rays, tgt, depth, conf)
     barrier()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    ev[0].record()
+    for i in range(args.steps):
         loss, _ = trainer.step(rays, tgt, depth, conf)
+        ev[i + 1].record()                                   # per-step device timestamps (no sync inside the timed region)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -244,60 +269,70 @@ def main():
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = te.item()
     final_loss = float(loss)
+    per_step = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps))
+    ms_median = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2])
 
     # ---- roofline of the dominant kernel (NT MFMA GEMM: all forward + data-gradient layers); the instrumented step contains
     # the gradient all-reduce, so EVERY rank runs it
     launches, gemm_ms, padded_flops = measure_gemm_kernel(trainer, rays, tgt, depth, conf)
     barrier()
+    comm = None
+    if world > 1:                                            # the step's one exchange, timed alone: all-reduce of the flat gradient arena
+        buf = torch.zeros_like(model.arena.grad)
+        for _ in range(2):
+            dist.all_reduce(buf)
+        barrier()
+        tc = time.perf_counter()
+        for _ in range(5):
+            dist.all_reduce(buf)
+        barrier()
+        comm = {"collective": "all-reduce(sum) of the flat fp32 gradient arena, one per step, overlapped with the proposal backward",
+                "backend": "rccl" if args.backend == "nccl" else args.backend, "ranks": world, "bytes": buf.numel() * 4,
+                "allreduce_ms_alone": round((time.perf_counter() - tc) / 5 * 1e3, 3)}
+        del buf
+    fwd = 2.0 * (S0 * MAC_PROP + (P1 - 1) * MAC_NERF)                        # 2.269 GFLOP / ray
+    first = 2.0 * (S0 * 96 * 256 + (P1 - 1) * 96 * HIDDEN)                   # first layers have no data gradient
+    skipenc = 2.0 * (P1 - 1) * 96 * HIDDEN + 2.0 * (P1 - 1) * 27 * 128       # d/d(encoding) columns of the concat layers
     out = None
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         rays_per_s = world * n * args.steps / elapsed
-        fwd = 2.0 * (S0 * MAC_PROP + (P1 - 1) * MAC_NERF)                        # 2.269 GFLOP / ray
-        first = 2.0 * (S0 * 96 * 256 + (P1 - 1) * 96 * HIDDEN)                   # first layers have no data gradient
-        skipenc = 2.0 * (P1 - 1) * 96 * HIDDEN + 2.0 * (P1 - 1) * 27 * 128       # d/d(encoding) columns of the concat layers
         alg_nt = n * (fwd + fwd - first - skipenc)                               # fwd + dgrad through gemm_nt, per step
         achieved = alg_nt / (gemm_ms * 1e-3) / 1e12
+        peak = PEAK_BF16_TFLOPS if args.compute == "bf16" else 157.3
         roofline = {"bound": "mfma", "kernel": {8: "gemm_nt8p_kernel (bf16, 256x256 persistent 8-phase)", 4: "gemm_nt8_kernel (bf16, 256x256 8-phase)", 1: "gemm_nt_kernel<bf16,256,256,2,4>"}.get(args.variant, "gemm_nt_kernel<bf16,128,128,2,2>") if args.compute == "bf16" else "gemm_nt_kernel<f32,128,128,2,2>",
-                    "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS if args.compute == "bf16" else 157.3, "unit": "TFLOP/s",
-                    "frac": round(achieved / (PEAK_BF16_TFLOPS if args.compute == "bf16" else 157.3), 4),
+                    "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                     # HBM bytes of ONE launch of the largest layer shape (M = 524288, N = K = 1024: algorithmic 1.07 GB in + 1.07 GB out),
                     # from separate rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE): tools/pmc_gemm.sh
                     "traffic": (1.618e9 + 1.074e9) if (args.compute == "bf16" and args.variant == 8) else None,
                     "traffic_source": "profiles/r1_x_gemm_nt8p_traffic.txt (per launch at M=524288 N=K=1024; algorithmic 2.15e9 B)",
                     "launches_per_step": launches, "avg_launch_ms": round(gemm_ms / launches, 4), "kernel_ms_per_step": round(gemm_ms, 3),
-                    "algorithmic_flops_per_step": alg_nt, "padded_flops_per_step": padded_flops}
+                    "algorithmic_flops_per_step": alg_nt, "padded_flops_per_step": padded_flops,
+                    "whole_step_tflops": round(3 * fwd * n / (ms_step * 1e-3) / 1e12, 1)}
         out = {"metric": "rays/sec (train step)", "value": round(rays_per_s, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps,
-               "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
                "dtype": args.compute, "data": "synthetic",
                "config": {"workload": f"S-NeRF path A (MipNerfModel) train step, nuScenes-like 1600x900 rays, {S0} proposal + {P1 - 1} fine evals/ray "
                                       f"({S0 + P1 - 1} spp), hidden 1024, rgb_layer 3, cone + contraction + IPE-96",
                           "rays_per_gpu_per_step": n, "global_rays_per_step": n * world, "parallelism": f"dp{world} (ray-sharded, flat-arena RCCL all-reduce overlapped with the backward)",
                           "train_flops_per_ray": 3 * fwd},
-               "roofline": roofline, "final_loss": final_loss}
+               "roofline": roofline, "final_loss": final_loss, "ms_per_step_median": round(ms_median, 3)}
+        if comm is not None:
+            out["comm"] = comm
 
-    # ---- full-frame inference (forward only): 1600 x 900 rays, rows sharded across ranks
+    # ---- full-frame inference (forward only): 1600 x 900 rays through the drop-in render_image (models.py:328-360; eval.py:146),
+    # one contiguous block of the frame per rank + one all-gather per output buffer
     if not args.no_frame:
         H, W = 900, 1600
-        rows = (H + world - 1) // world                                               # row blocks; the last rank may own fewer rows
-        pix = np.arange(min(rank * rows, H) * W, min((rank + 1) * rows, H) * W)
+        chunk = args.frame_chunk
+        render_fn = lambda r: model(r, False, False, 0.)
         with torch.no_grad():
-            chunk = args.frame_chunk
-            fr = frame_rays(int(pix[0]), min(chunk, len(pix)), device)
-            model(fr, False, False, 0.)                                            # warm-up chunk (packing, allocator)
+            render_fn(frame_rays(0, min(chunk, H * W), device))                      # warm-up chunk (packing, allocator)
             barrier()
             t0 = time.perf_counter()
-            outs = []
-            for i in range(0, len(pix), chunk):
-                fr = frame_rays(int(pix[i]), len(pix[i:i + chunk]), device)           # ray generation on the device, per chunk
-                ret = model(fr, False, False, 0.)
-                outs.append(torch.cat([ret[1][0], ret[1][1][:, None]], -1))
-            img = torch.cat(outs, 0)
-            if world > 1:                                                              # one all-gather of rgb+depth per frame
-                pad = torch.zeros(rows * W, 4, device=device, dtype=img.dtype)
-                pad[:img.shape[0]] = img
-                parts = [torch.empty_like(pad) for _ in range(world)]
-                dist.all_gather(parts, pad)
+            fr = frame_rays(0, H * W, device)                                         # ray generation on the device (80 MB), inside the timed region
+            grid = Rays(*[r.reshape(H, W, -1) for r in fr])
+            rgb_f, dist_f, acc_f, _ = render_image(render_fn, grid, rank, chunk=chunk, world=world)
             barrier()
             t_frame = time.perf_counter() - t0
         if world > 1:
@@ -309,32 +344,54 @@ def main():
                 barrier()
                 t1 = time.perf_counter()
                 kept = tot = 0
-                outs_e = []
-                for i in range(0, len(pix), chunk):
-                    fr = frame_rays(int(pix[i]), len(pix[i:i + chunk]), device)
-                    ret = model(fr, False, False, 0., ert=tuple(args.ert))
+
+                def render_ert(r):
+                    nonlocal kept, tot
+                    ret = model(r, False, False, 0., ert=tuple(args.ert))
                     kept += model.last_ert_rows[0]; tot += model.last_ert_rows[1]
-                    outs_e.append(torch.cat([ret[1][0], ret[1][1][:, None]], -1))
+                    return ret
+                rgb_e, _, _, _ = render_image(render_ert, grid, rank, chunk=chunk, world=world)
                 barrier()
                 t_ert = time.perf_counter() - t1
-                img_e = torch.cat(outs_e, 0)
-                mse = float(((img_e[:, :3] - img[:, :3]) ** 2).mean())
+                mse = float(((rgb_e - rgb_f) ** 2).mean())
             if rank == 0:
                 out["frame_ert"] = {"eps_t": args.ert[0], "eps_w": args.ert[1], "ms_per_frame": round(t_ert * 1e3, 1),
                                     "fine_samples_evaluated": round(kept / max(tot, 1), 4),
                                     "psnr_vs_full_db": (float("inf") if mse == 0 else round(-10.0 * math.log10(mse), 2)),
-                                    "note": "inference extension (csrc/ert.hip), not the reference's algorithm; rank-0 shard"}
+                                    "note": "inference extension (csrc/ert.hip), not the reference's algorithm; sample count of the rank-0 block"}
         if rank == 0:
             out["ms_per_frame"] = round(t_frame * 1e3, 1)
             out["frame"] = {"resolution": "1600x900", "rays": H * W, "spp": S0 + P1 - 1, "chunk": chunk, "rays_per_s": round(H * W / t_frame, 1),
-                            "includes": "on-device ray generation per chunk, render, all-gather of rgb+depth"}
+                            "tflops": round(fwd * H * W / t_frame / 1e12, 1),
+                            "includes": "on-device ray generation, snerf_amd.mipnerf.render_image (chunk loop), all-gather of rgb / distance / acc"}
+        del rgb_f, dist_f, acc_f, grid, fr
+
+    # ---- the fp32-parity mode's speed (north_star's 1e-4-relative contract holds in compute="f32": exact-fp32 MFMA 32x32x2, 157.3 TF peak)
+    if rank == 0 and world == 1 and not args.no_f32 and args.compute == "bf16":
+        m32 = build_model("f32", device)
+        m32.load_state_dict({k: v.clone() for k, v in model.state_dict().items()})
+        t32 = MipTrainer(m32, lr=5e-4)
+        t32.step(rays, tgt, depth, conf)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            t32.step(rays, tgt, depth, conf)
+        torch.cuda.synchronize()
+        dt32 = (time.perf_counter() - t0) / 3
+        l32, g32, _ = measure_gemm_kernel(t32, rays, tgt, depth, conf)
+        a32 = n * (fwd + fwd - first - skipenc) / (g32 * 1e-3) / 1e12
+        out["f32_mode"] = {"rays_per_s": round(n / dt32, 1), "ms_per_step": round(dt32 * 1e3, 2), "steps": 3,
+                           "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel<f32,128,128,2,2> (v_mfma_f32_32x32x2_f32: exact fp32 FMA chain)",
+                                        "achieved": round(a32, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(a32 / 157.3, 4), "launches_per_step": l32},
+                           "note": "the mode in which rgb / depth match the reference within 1e-4 relative (parity read-out below)"}
+        del t32, m32
+        torch.cuda.empty_cache()
 
     # ---- parity read-out + host-CPU baseline (rank 0, N = 1 only)
     if rank == 0 and world == 1 and not args.no_cpu:
-        ncpu = args.cpu_rays
+        ncpu = min(args.cpu_rays, n)
         sd = {k: v.clone() for k, v in model.state_dict().items()}
         cpu_rps, cpu_s, rgb_ref, dist_ref, cpu_fwd_rps = cpu_baseline(ncpu, sd, rays)
-        from snerf_amd.mipnerf import Rays
         sub = Rays(*[r[:ncpu] for r in rays])
         with torch.no_grad():
             rb = model(sub, False, False, 0.)
@@ -351,12 +408,13 @@ def main():
                          "f32_kernels_vs_cpu_oracle_max_rel_err_depth": float(((r32[1][1].cpu() - dist_ref).abs() / dist_ref.abs()).max()),
                          "psnr_f32_kernels_vs_cpu_oracle_db": psnr(r32[1][0].cpu(), rgb_ref),
                          "psnr_bf16_kernels_vs_cpu_oracle_db": psnr(rb[1][0].cpu(), rgb_ref)}
-    if rank == 0 and world == 1 and args.eager:
+        del m32
+    if rank == 0 and world == 1 and not args.no_eager:
         sd = {k: v.clone() for k, v in model.state_dict().items()}
         e32, ms32 = eager_baseline(sd, rays, n, 3, False)
         e16, ms16 = eager_baseline(sd, rays, n, 3, True)
         out["eager_baseline"] = {"unit": "rays/s", "fp32": round(e32, 1), "fp32_ms_per_step": round(ms32, 2), "bf16_autocast": round(e16, 1),
-                                 "bf16_autocast_ms_per_step": round(ms16, 2), "rays_per_step": n,
+                                 "bf16_autocast_ms_per_step": round(ms16, 2), "rays_per_step": n, "steps": 3,
                                  "kind": "plain PyTorch-ROCm eager ops (torch restatement of the reference model), autograd + torch.optim.Adam, same GPU",
                                  "speedup_vs_fp32": round(out["value"] / e32, 2), "speedup_vs_bf16_autocast": round(out["value"] / e16, 2)}
     if rank == 0:

@@ -323,6 +323,21 @@ int snerf_zip_encode_prop_fwd(const float* tdist, const float* origins, const fl
                               const float* b1, const float* w2, const float* b2, int hidden, int round_bf16, float* raw_density,
                               void* stream);
 
+/* ---- classic-path ray front end ---------------------------------------------------------------------
+ * snerf_classic_get_rays  = get_rays (s-nerf/model/run_nerf_helpers.py:247-258): pinhole rays of an H x W frame, pixel centres at
+ *   +0.5, principal point (cx, cy) = `ori_points` (default W/2, H/2); c2w_host: HOST pointer to the [3,4] camera-to-world matrix.
+ * snerf_classic_ndc_rays  = ndc_rays (:314-332).
+ * snerf_classic_ray_batch = the front half of render() (s-nerf/model/render.py:50-77) in one launch: rays from c2w_host (whole
+ *   frame, n = H*W) or the given rays_o / rays_d [n,3]; unit view directions from the pre-NDC directions; c2w_static_host
+ *   (c2w_staticcam) replaces the rays but not the view directions; NDC warp with near = 1; rows [n, ld] =
+ *   [o3, d3, near, far, (depth), (viewdir3)] exactly as render_rays reads them (render.py:326-329). */
+int snerf_classic_get_rays(int H, int W, double focal, double cx, double cy, const float* c2w_host, float* rays_o, float* rays_d, void* stream);
+int snerf_classic_ndc_rays(int H, int W, double focal, float near, const float* rays_o, const float* rays_d, long n, float* o_out,
+                           float* d_out, void* stream);
+int snerf_classic_ray_batch(int H, int W, double focal, double cx, double cy, const float* c2w_host, const float* c2w_static_host,
+                            const float* rays_o, const float* rays_d, long n, int ndc, float near, float far, const float* depths,
+                            int use_viewdirs, float* rows, int ld, void* stream);
+
 /* snerf_adam_step with the step count t in DEVICE memory: *step_dev is incremented, then used for the bias corrections -- no launch
  * argument depends on host state, so a whole training step can be captured in a hipGraph and replayed. */
 int snerf_adam_step_dev(float* p, float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, int* step_dev,

@@ -206,3 +206,96 @@ def nerf_param_shapes(D=8, W=256, input_ch=63, input_ch_views=27, skips=(4,)):
             ("alpha_linear.weight", (1, W)), ("alpha_linear.bias", (1,)),
             ("rgb_linear.weight", (3, W // 2)), ("rgb_linear.bias", (3,))]
     return out
+
+
+# --------------------------------------------------------------------------
+# B4'  NeRF_RGB -- run_nerf_helpers.py:157-212
+# --------------------------------------------------------------------------
+def nerf_rgb_mlp(p: dict, p_alpha: dict, x: torch.Tensor, input_ch: int = 63, input_ch_views: int = 27,
+                 D: int = 8, skips=(4,)) -> torch.Tensor:
+    """The colour network of the two-stage variant: same trunk / feature / views / rgb layers as ``NeRF`` but NO alpha head;
+    the density column comes from a frozen, separately trained ``alpha_model`` evaluated on the same embedded input under
+    no_grad (run_nerf_helpers.py:188-212).  ``p`` holds the NeRF_RGB parameters without the ``alpha_model.`` entries."""
+    F = torch.nn.functional
+    pts, views = x[..., :input_ch], x[..., input_ch:input_ch + input_ch_views]
+    h = pts
+    for i in range(D):
+        h = F.relu(F.linear(h, p[f"pts_linears.{i}.weight"], p[f"pts_linears.{i}.bias"]))
+        if i in skips:
+            h = torch.cat([pts, h], -1)
+    with torch.no_grad():
+        alpha = nerf_mlp(p_alpha, x, input_ch, input_ch_views, D, skips)[..., 3:4]
+    feat = F.linear(h, p["feature_linear.weight"], p["feature_linear.bias"])
+    h = F.relu(F.linear(torch.cat([feat, views], -1), p["views_linears.0.weight"], p["views_linears.0.bias"]))
+    return torch.cat([F.linear(h, p["rgb_linear.weight"], p["rgb_linear.bias"]), alpha], -1)
+
+
+# --------------------------------------------------------------------------
+# B7  get_rays / ndc_rays / render -- run_nerf_helpers.py:247-258, 314-332; render.py:22-91
+# --------------------------------------------------------------------------
+def get_rays(H: int, W: int, focal: float, c2w: torch.Tensor, ori_points=None):
+    """Pinhole rays of the whole frame, pixel centres at +0.5 (run_nerf_helpers.py:247-258): dirs = [((i + .5) - cx) / f,
+    -((j + .5) - cy) / f, -1], rays_d = sum_k dirs[k] c2w[:, k] (left to right), rays_o = c2w[:, 3].  -> ([H,W,3], [H,W,3])"""
+    cx, cy = (W * 0.5, H * 0.5) if not ori_points else ori_points
+    j, i = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    c0 = ((i + 0.5) - cx) / focal
+    c1 = -((j + 0.5) - cy) / focal
+    c2w = c2w.float()
+    rays_d = torch.stack([(c0 * c2w[r, 0] + c1 * c2w[r, 1]) + (-1.0) * c2w[r, 2] for r in range(3)], -1)
+    return c2w[:3, -1].expand(rays_d.shape), rays_d
+
+
+def ndc_rays(H: int, W: int, focal: float, near: float, rays_o: torch.Tensor, rays_d: torch.Tensor):
+    """Shift the origins to the near plane and project into NDC (run_nerf_helpers.py:314-332)."""
+    t = -(near + rays_o[..., 2]) / rays_d[..., 2]
+    rays_o = rays_o + t[..., None] * rays_d
+    cw, ch = -1.0 / (W / (2.0 * focal)), -1.0 / (H / (2.0 * focal))
+    o0 = cw * rays_o[..., 0] / rays_o[..., 2]
+    o1 = ch * rays_o[..., 1] / rays_o[..., 2]
+    o2 = 1.0 + 2.0 * near / rays_o[..., 2]
+    d0 = cw * (rays_d[..., 0] / rays_d[..., 2] - rays_o[..., 0] / rays_o[..., 2])
+    d1 = ch * (rays_d[..., 1] / rays_d[..., 2] - rays_o[..., 1] / rays_o[..., 2])
+    d2 = -2.0 * near / rays_o[..., 2]
+    return torch.stack([o0, o1, o2], -1), torch.stack([d0, d1, d2], -1)
+
+
+def ray_batch(H, W, focal, rays=None, c2w=None, ndc=True, near=0.0, far=1.0, use_viewdirs=False, c2w_staticcam=None,
+              depths=None, ori_points=None):
+    """The ray-batch assembly of render() (render.py:50-77): -> (rows [N, 8 (+1) (+3)], sh = shape of rays_d)."""
+    if c2w is not None:
+        rays_o, rays_d = get_rays(H, W, focal, c2w, ori_points)
+    else:
+        rays_o, rays_d = rays
+    viewdirs = None
+    if use_viewdirs:
+        viewdirs = rays_d
+        if c2w_staticcam is not None:
+            rays_o, rays_d = get_rays(H, W, focal, c2w_staticcam)
+        viewdirs = viewdirs / torch.norm(viewdirs, dim=-1, keepdim=True)
+        viewdirs = viewdirs.reshape(-1, 3).float()
+    sh = rays_d.shape
+    if ndc:
+        rays_o, rays_d = ndc_rays(H, W, focal, 1.0, rays_o, rays_d)
+    rays_o, rays_d = rays_o.reshape(-1, 3).float(), rays_d.reshape(-1, 3).float()
+    cols = [rays_o, rays_d, near * torch.ones_like(rays_d[..., :1]), far * torch.ones_like(rays_d[..., :1])]
+    if depths is not None:
+        cols.append(depths.reshape(-1, 1))
+    if use_viewdirs:
+        cols.append(viewdirs)
+    return torch.cat(cols, -1), sh
+
+
+def render(H, W, focal, p_coarse, p_fine=None, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0.0, far=1.0,
+           use_viewdirs=False, c2w_staticcam=None, depths=None, ori_points=None, **render_rays_kw):
+    """render() (render.py:22-91) on top of this module's render_rays: chunk loop, reshape to the ray grid's shape,
+    -> [rgb_map, disp_map, acc_map, depth_map, extras]."""
+    rows, sh = ray_batch(H, W, focal, rays, c2w, ndc, near, far, use_viewdirs, c2w_staticcam, depths, ori_points)
+    parts = {}
+    for i in range(0, rows.shape[0], chunk):
+        ret = render_rays(rows[i:i + chunk], p_coarse, p_fine, **render_rays_kw)
+        for k, v in ret.items():
+            parts.setdefault(k, []).append(v)
+    all_ret = {k: torch.cat(v, 0) for k, v in parts.items()}
+    all_ret = {k: v.reshape(list(sh[:-1]) + list(v.shape[1:])) for k, v in all_ret.items()}
+    main = ["rgb_map", "disp_map", "acc_map", "depth_map"]
+    return [all_ret[k] for k in main] + [{k: v for k, v in all_ret.items() if k not in main}]

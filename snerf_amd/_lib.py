@@ -15,7 +15,7 @@ HEADER_PATH = os.path.join(_REPO, "include", "snerf_hip.h")
 IO_LIB_PATH = os.path.join(_HERE, "lib", "libsnerf_io.so")
 IO_HEADER_PATH = os.path.join(_REPO, "include", "snerf_io.h")
 
-_CTYPE = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float}
+_CTYPE = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double}
 _lib = None
 _iolib = None
 

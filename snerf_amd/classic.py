@@ -7,8 +7,14 @@ Mirrors, with the same names, argument meaning and return layout:
   run_network    s-nerf/model/run_nerf_helpers.py:460-474
   raw2outputs    s-nerf/model/run_nerf_helpers.py:381-424
   sample_pdf     s-nerf/model/run_nerf_helpers.py:336-379
+  NeRF_RGB       s-nerf/model/run_nerf_helpers.py:157-212  (colour network over a frozen alpha model)
   render_rays    s-nerf/model/render.py:281-409
   batchify_rays  s-nerf/model/render.py:8-19
+  get_rays       s-nerf/model/run_nerf_helpers.py:247-258
+  ndc_rays       s-nerf/model/run_nerf_helpers.py:314-332
+  render         s-nerf/model/render.py:22-91
+  render_path    s-nerf/model/render.py:94-135
+  create_nerf    s-nerf/model/render.py:165-278
 
 Differences that are deliberate and documented in DESIGN.md:
   * tensors must live on the GPU; there is no CPU path (the library raises);
@@ -19,6 +25,7 @@ Differences that are deliberate and documented in DESIGN.md:
   * ``pytest=True`` (numpy-seeded draws) is honoured the same way the
     reference does it.
 """
+import os
 from typing import Optional
 
 import numpy as np
@@ -78,6 +85,13 @@ class _ArenaModule(nn.Module):
         d = dict(self.named_parameters())
         return [d[n] for n in self._pnames]
 
+    def load_state_dict(self, state_dict, strict=True, assign=False):
+        """Also accepts the ``module.``-prefixed keys of a checkpoint saved from an nn.DataParallel / DDP wrapper (the reference
+        saves the wrapped model: s-nerf/train.py:268, utils/device_utils.py:33,38, eval.py:72-74)."""
+        if assign:
+            raise ValueError("assign=True would detach the parameters from the flat arena")
+        return super().load_state_dict(strip_module_prefix(state_dict), strict=strict)
+
     def _param_version(self):
         return sum(p._version for p in self.param_list()) + self.arena.epoch
 
@@ -95,6 +109,7 @@ def _dt(compute: str) -> int:
 class NeRF(_ArenaModule):
     """Same constructor signature and parameter names as the reference's ``NeRF`` (use_viewdirs=True
     is the accelerated configuration)."""
+    _alpha_head = True
 
     def __init__(self, D=8, W=256, input_ch=3, input_ch_views=3, output_ch=4, skips=[4], use_viewdirs=False,
                  compute: str = "bf16", device="cuda", variant: int = 8):
@@ -103,14 +118,15 @@ class NeRF(_ArenaModule):
             raise NotImplementedError("the accelerated NeRF requires use_viewdirs=True (the S-NeRF configuration)")
         self.D, self.W, self.input_ch, self.input_ch_views, self.skips, self.use_viewdirs = D, W, input_ch, input_ch_views, list(skips), True
         self.compute = compute
-        shapes = ClassicNeRFNet.param_shapes(D, W, input_ch, input_ch_views, tuple(skips))
+        shapes = ClassicNeRFNet.param_shapes(D, W, input_ch, input_ch_views, tuple(skips), alpha_head=self._alpha_head)
         self._setup_arena(shapes, torch.device(device))
-        self.net = ClassicNeRFNet(self.arena, "", _dt(compute), D, W, input_ch, input_ch_views, tuple(skips), variant)
+        self.net = ClassicNeRFNet(self.arena, "", _dt(compute), D, W, input_ch, input_ch_views, tuple(skips), variant,
+                                  alpha_head=self._alpha_head)
         self.net.version_fn = self._param_version
         with torch.no_grad():  # nn.Linear default init, like the reference module
             for i in range(D):
                 self._init_linear(f"pts_linears.{i}")
-            for n in ("views_linears.0", "feature_linear", "alpha_linear", "rgb_linear"):
+            for n in ("views_linears.0", "feature_linear", "rgb_linear") + (("alpha_linear",) if self._alpha_head else ()):
                 self._init_linear(n)
 
     def _init_linear(self, name):
@@ -124,10 +140,32 @@ class NeRF(_ArenaModule):
                                   "with the first layer, pre-embedded inputs never exist on this path")
 
 
+class NeRF_RGB(NeRF):
+    """``NeRF_RGB`` (run_nerf_helpers.py:157-212): the colour network of the two-stage variant -- same trunk / feature / views / rgb
+    layers, NO alpha head; the density column of the output is the frozen ``alpha_model``'s (a ``NeRF``), evaluated under no_grad
+    (:198-199).  ``alpha_model`` is a registered sub-module like in the reference, so ``state_dict()`` carries its parameters under
+    ``alpha_model.`` and ``parameters()`` lists them (they never receive a gradient)."""
+    _alpha_head = False
+
+    def __init__(self, D=8, W=256, input_ch=3, input_ch_views=3, output_ch=4, skips=[4], use_viewdirs=False, alpha_model=None,
+                 compute: str = "bf16", device="cuda", variant: int = 8):
+        super().__init__(D, W, input_ch, input_ch_views, output_ch, skips, use_viewdirs, compute, device, variant)
+        if alpha_model is not None and not (isinstance(alpha_model, NeRF) and alpha_model._alpha_head):
+            raise TypeError("NeRF_RGB: alpha_model must be a snerf_amd.classic.NeRF")
+        self.alpha_model = alpha_model
+
+
 class _RunNetworkFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model: NeRF, pts, viewdirs, S, keep, *params):
         raw, saved = model.net.forward(pts, viewdirs, S, keep)
+        if not model._alpha_head:
+            # NeRF_RGB: column 3 is the frozen alpha model's density (run_nerf_helpers.py:198-199, under no_grad)
+            if model.alpha_model is None:
+                raise RuntimeError("NeRF_RGB without an alpha_model cannot be evaluated (the reference raises TypeError here)")
+            model.alpha_model._check_arena()
+            raw_a, _ = model.alpha_model.net.forward(pts, viewdirs, S, False)
+            raw[:, 3] = raw_a[:, 3]
         ctx.model, ctx.saved, ctx.keep = model, saved, keep
         return raw
 
@@ -250,9 +288,12 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
             t_rand = torch.rand(N_rays, N_samples, device=dev)
     z_vals = ops.stratified(base, None if t_rand is None else t_rand.contiguous().float(), rb[:, 6], rb[:, 7], N_rays, 0, lindisp)
     pts = ops.classic_points(rb, z_vals)
-    if network_fn is None:
-        raise NotImplementedError("alpha_model variants (network_fn=None) are outside the accelerated path")
-    raw = network_query_fn(pts, viewdirs, network_fn)
+    if network_fn is not None:
+        raw = network_query_fn(pts, viewdirs, network_fn)
+    elif getattr(network_fine, "alpha_model", None) is not None:
+        raw = network_query_fn(pts, viewdirs, network_fine.alpha_model)        # render.py:364-366: coarse pass by the alpha model
+    else:
+        raw = network_query_fn(pts, viewdirs, network_fine)                    # render.py:368-369
     rgb_map, disp_map, acc_map, weights, depth_map = raw2outputs(raw, z_vals, rays_d, raw_noise_std, white_bkgd, pytest=pytest)
     inds = None
     if N_importance > 0:
@@ -293,3 +334,157 @@ def make_network_query_fn(embed_fn, embeddirs_fn, netchunk=1024 * 64):
     """The lambda create_nerf builds (render.py:215-218)."""
     return lambda inputs, viewdirs, network_fn: run_network(inputs, viewdirs, network_fn, embed_fn=embed_fn,
                                                             embeddirs_fn=embeddirs_fn, netchunk=netchunk)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Driver functions of the classic path (SURVEY.md row B7)
+# ------------------------------------------------------------------------------------------------------------------
+def _device_of(*ts):
+    """device of the first tensor argument; host inputs (numpy poses) land on the current GPU"""
+    for t in ts:
+        if torch.is_tensor(t):
+            return t.device
+    return torch.device("cuda")
+
+
+def get_rays(H, W, focal, c2w, ori_points=None):
+    """Pinhole rays of an H x W frame (run_nerf_helpers.py:247-258) -> rays_o, rays_d [H,W,3] on the GPU.  `c2w` [3,4] (or
+    [4,4]): tensor (any device) or array; `ori_points` = principal point (x, y), default the image centre."""
+    cx, cy = (W * 0.5, H * 0.5) if not ori_points else (ori_points[0], ori_points[1])
+    return ops.classic_get_rays(H, W, float(focal), c2w, float(cx), float(cy), _device_of(c2w))
+
+
+def ndc_rays(H, W, focal, near, rays_o, rays_d):
+    """NDC warp of forward-facing rays (run_nerf_helpers.py:314-332)."""
+    sh = rays_d.shape
+    o, d = ops.classic_ndc_rays(H, W, float(focal), float(near), rays_o.float().expand(sh).reshape(-1, 3).contiguous(),
+                                rays_d.float().reshape(-1, 3).contiguous())
+    return o.reshape(sh), d.reshape(sh)
+
+
+def render(H, W, focal, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far=1., use_viewdirs=False, c2w_staticcam=None,
+           depths=None, ori_points=None, **kwargs):
+    """render() of the reference (render.py:22-91): build the ray batch -- from `c2w` (whole frame) or the given `rays` =
+    (rays_o, rays_d) -- and render it in chunks.  -> [rgb_map, disp_map, acc_map, depth_map, extras] shaped like the ray grid.
+    The batch assembly (pinhole rays, unit view directions, static camera, NDC warp, row layout) is one kernel launch."""
+    if c2w is not None:
+        n, sh = H * W, (H, W, 3)
+        cx, cy = (W * 0.5, H * 0.5) if not ori_points else (ori_points[0], ori_points[1])
+        ro = rd = None
+        dev = _device_of(c2w, depths)
+    else:
+        rays_o, rays_d = rays
+        sh = tuple(rays_d.shape)
+        dev = _device_of(rays_d, rays_o)
+        rd = rays_d.to(dev, torch.float32).reshape(-1, 3).contiguous()
+        ro = rays_o.to(dev, torch.float32).expand(sh).reshape(-1, 3).contiguous()
+        n, cx, cy = rd.shape[0], W * 0.5, H * 0.5
+        if c2w_staticcam is not None and n != H * W:
+            raise ValueError("c2w_staticcam needs the rays of the whole H x W frame")
+    if near is not None and (torch.is_tensor(near) or torch.is_tensor(far)):
+        raise NotImplementedError("per-ray near / far tensors: pass scalars (every caller of the reference does)")
+    dep = None if depths is None else depths.to(dev, torch.float32).reshape(-1).contiguous()
+    rows = ops.classic_ray_batch(H, W, float(focal), float(cx), float(cy), c2w, c2w_staticcam if use_viewdirs else None, ro, rd, n,
+                                 bool(ndc), float(near), float(far), dep, bool(use_viewdirs), dev)
+    all_ret = batchify_rays(rows, chunk, **kwargs)
+    for k in all_ret:
+        all_ret[k] = torch.reshape(all_ret[k], list(sh[:-1]) + list(all_ret[k].shape[1:]))
+    k_extract = ['rgb_map', 'disp_map', 'acc_map', 'depth_map']
+    return [all_ret[k] for k in k_extract] + [{k: all_ret[k] for k in all_ret if k not in k_extract}]
+
+
+to8b = lambda x: (255 * np.clip(x, 0, 1)).astype(np.uint8)
+
+
+def render_path(render_poses, hwf, chunk, render_kwargs, gt_imgs=None, savedir=None, render_factor=0, ori_points=None, render_masks=None):
+    """Render a camera path (render.py:94-135) -> (rgbs [P,H,W,3], disps [P,H,W]) as numpy arrays."""
+    H, W, focal = hwf
+    H, W = int(H), int(W)
+    focal = float(np.array(focal).mean())
+    if render_factor != 0:
+        H, W, focal = H // render_factor, W // render_factor, focal / render_factor
+    rgbs, disps = [], []
+    for i, c2w in enumerate(render_poses):
+        extra = dict(ori_points=ori_points[i]) if ori_points else {}
+        rgb, disp, acc, depth, extras = render(H, W, focal, chunk=chunk, c2w=c2w[:3, :4], retraw=True, **extra, **render_kwargs)
+        if render_masks:
+            rgb[render_masks[i]] = 0
+        rgbs.append(rgb.cpu().numpy())
+        disps.append(disp.cpu().numpy())
+        if savedir is not None:                         # the reference converts here and writes nothing (render.py:129-132)
+            rgb8 = to8b(rgbs[-1])
+            rgb8[np.isnan(rgb8)] = 0
+    return np.stack(rgbs, 0), np.stack(disps, 0)
+
+
+def create_nerf(args, compute: str = "bf16", device="cuda"):
+    """Instantiate the classic models, their optimiser and the render kwargs (render.py:165-278); `args` carries the reference's
+    flags (multires, multires_views, i_embed, use_viewdirs, N_importance, netdepth(_fine), netwidth(_fine), alpha_model_path,
+    no_coarse, weighted_loss, netchunk, lrate, basedir, expname, ft_path, no_reload, perturb, N_samples, white_bkgd, raw_noise_std,
+    dataset_type, no_ndc, lindisp).  -> (render_kwargs_train, render_kwargs_test, start, grad_vars, optimizer, model_confidence)"""
+    embed_fn, input_ch = get_embedder(args.multires, args.i_embed)
+    input_ch_views, embeddirs_fn, model_confidence = 0, None, None
+    if args.use_viewdirs:
+        embeddirs_fn, input_ch_views = get_embedder(args.multires_views, args.i_embed)
+    output_ch = 5 if args.N_importance > 0 else 4
+    skips = [4]
+    mk = lambda cls, D, W, **kw: cls(D=D, W=W, input_ch=input_ch, output_ch=output_ch, skips=skips, input_ch_views=input_ch_views,
+                                     use_viewdirs=args.use_viewdirs, compute=compute, device=device, **kw)
+    alpha_model = None
+    if getattr(args, "alpha_model_path", None) is None:
+        model = mk(NeRF, args.netdepth, args.netwidth)
+        grad_vars = list(model.parameters())
+    else:
+        alpha_model = mk(NeRF, args.netdepth_fine, args.netwidth_fine)
+        ckpt = torch.load(args.alpha_model_path, map_location="cpu")
+        alpha_model.load_state_dict(strip_module_prefix(ckpt['network_fine_state_dict']))
+        if not args.no_coarse:
+            model = mk(NeRF_RGB, args.netdepth, args.netwidth, alpha_model=alpha_model)
+            grad_vars = list(model.parameters())
+        else:
+            model, grad_vars = None, []
+    model_fine = None
+    if args.N_importance > 0:
+        if alpha_model is None:
+            model_fine = mk(NeRF, args.netdepth_fine, args.netwidth_fine)
+        else:
+            model_fine = mk(NeRF_RGB, args.netdepth_fine, args.netwidth_fine, alpha_model=alpha_model)
+        grad_vars += list(model_fine.parameters())
+    if getattr(args, "weighted_loss", False):
+        raise NotImplementedError("weighted_loss: the reference instantiates DepthConfNet here, a class it never defines (NameError, render.py:207)")
+    network_query_fn = make_network_query_fn(embed_fn, embeddirs_fn, args.netchunk)
+    optimizer = torch.optim.Adam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999))
+    start = 0
+    if getattr(args, "ft_path", None) is not None and args.ft_path != 'None':
+        ckpts = [args.ft_path]
+    else:
+        exp = os.path.join(args.basedir, args.expname)
+        ckpts = [os.path.join(exp, f) for f in sorted(os.listdir(exp)) if 'tar' in f] if os.path.isdir(exp) else []
+    if len(ckpts) > 0 and not args.no_reload:
+        ckpt = torch.load(ckpts[-1], map_location="cpu")
+        start = ckpt['global_step']
+        optimizer.load_state_dict(ckpt['optimizer_state_dict'])
+        model.load_state_dict(strip_module_prefix(ckpt['network_fn_state_dict']))
+        if model_fine is not None:
+            model_fine.load_state_dict(strip_module_prefix(ckpt['network_fine_state_dict']))
+    render_kwargs_train = {'network_query_fn': network_query_fn, 'perturb': args.perturb, 'N_importance': args.N_importance,
+                           'network_fine': model_fine, 'N_samples': args.N_samples, 'network_fn': model,
+                           'use_viewdirs': args.use_viewdirs, 'white_bkgd': args.white_bkgd, 'raw_noise_std': args.raw_noise_std}
+    if args.dataset_type != 'llff' or args.no_ndc:          # NDC only for LLFF-style forward-facing data
+        render_kwargs_train['ndc'] = False
+        render_kwargs_train['lindisp'] = args.lindisp
+    else:
+        render_kwargs_train['ndc'] = True
+    render_kwargs_test = dict(render_kwargs_train)
+    render_kwargs_test['perturb'] = False
+    render_kwargs_test['raw_noise_std'] = 0.
+    return render_kwargs_train, render_kwargs_test, start, grad_vars, optimizer, model_confidence
+
+
+def strip_module_prefix(state_dict):
+    """Checkpoints saved from an nn.DataParallel / DistributedDataParallel wrapper carry a ``module.`` prefix on every key
+    (s-nerf/utils/device_utils.py:33,38; s-nerf/eval.py:72-74 loads them into a wrapped model).  One process drives one GPU here, so
+    the modules are never wrapped: accept both spellings."""
+    if state_dict and all(k.startswith("module.") for k in state_dict):
+        return type(state_dict)((k[len("module."):], v) for k, v in state_dict.items())
+    return state_dict

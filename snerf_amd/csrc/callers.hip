@@ -72,6 +72,125 @@ extern "C" int snerf_pinhole_rays(const int* coords, long first_pixel, int W, in
 }
 
 // ---------------------------------------------------------------------------
+// Classic-path ray front end: get_rays (s-nerf/model/run_nerf_helpers.py:247-258), ndc_rays (:314-332) and the
+// ray-batch assembly of render() (s-nerf/model/render.py:50-77) -- pinhole directions or given rays, unit view directions from
+// the PRE-NDC directions, the optional static camera that replaces the rays but not the view directions, the NDC warp, and the
+// row layout [o3, d3, near, far, (depth), (viewdir3)] -- as ONE lane-per-ray launch writing the [N, ld] rows render_rays reads.
+// Every operation rounds like the reference's separate fp32 torch ops (-ffp-contract=off, explicit association).
+// ---------------------------------------------------------------------------
+struct ClassicRays {
+  const float *rays_o, *rays_d;   // given rays [n,3] (contiguous) or null: pinhole rays of the H x W frame from c2w
+  long n;
+  int H, W;
+  float focal, cx, cy;            // fp32 roundings of the reference's python scalars
+  float c2w[12], c2w_static[12];  // [3,4] row-major
+  int has_c2w, has_static, ndc, use_viewdirs;
+  float ndc_near, near, far;
+  float ndc_cw, ndc_ch;           // -1/(W/(2 focal)), -1/(H/(2 focal)) computed in double on the host like the python scalars
+  const float* depths;            // optional extra column
+  float* rows; int ld;            // ray batch rows, or null
+  float *o_out, *d_out;           // separate [n,3] outputs (get_rays / ndc_rays), or null
+};
+
+__device__ __forceinline__ void classic_pinhole(const float* c2w, int row, int col, float focal, float cx, float cy, float* o, float* d) {
+  // dirs = [((i + 0.5) - cx) / focal, -((j + 0.5) - cy) / focal, -1];  rays_d = sum(dirs[None, :] * c2w[:3, :3], -1)
+  const float c0 = (((float)col + 0.5f) - cx) / focal, c1 = -((((float)row + 0.5f) - cy) / focal), c2 = -1.f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    d[c] = (c0 * c2w[4 * c + 0] + c1 * c2w[4 * c + 1]) + c2 * c2w[4 * c + 2];
+    o[c] = c2w[4 * c + 3];
+  }
+}
+
+__device__ __forceinline__ void classic_ndc(const ClassicRays& a, float* o, float* d) {
+  const float t = -(a.ndc_near + o[2]) / d[2];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) o[c] = o[c] + t * d[c];
+  const float o0 = a.ndc_cw * o[0] / o[2], o1 = a.ndc_ch * o[1] / o[2], o2 = 1.f + (2.f * a.ndc_near) / o[2];
+  const float d0 = a.ndc_cw * (d[0] / d[2] - o[0] / o[2]), d1 = a.ndc_ch * (d[1] / d[2] - o[1] / o[2]), d2 = (-2.f * a.ndc_near) / o[2];
+  o[0] = o0; o[1] = o1; o[2] = o2;
+  d[0] = d0; d[1] = d1; d[2] = d2;
+}
+
+__global__ __launch_bounds__(256) void classic_rays_kernel(ClassicRays a) {
+  const long r = (long)blockIdx.x * 256 + threadIdx.x;
+  if (r >= a.n) return;
+  const int row = (int)(r / a.W), col = (int)(r - (long)row * a.W);
+  float o[3], d[3], v[3];
+  if (a.has_c2w) classic_pinhole(a.c2w, row, col, a.focal, a.cx, a.cy, o, d);
+  else {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { o[c] = a.rays_o[3 * r + c]; d[c] = a.rays_d[3 * r + c]; }
+  }
+  if (a.use_viewdirs) {
+    const float nrm = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c] = d[c] / nrm;
+    // c2w_staticcam: the rays come from the static camera (principal point at the image centre: render.py:59 passes no
+    // ori_points), the view directions stay those of c2w
+    if (a.has_static) classic_pinhole(a.c2w_static, row, col, a.focal, (float)(a.W * 0.5), (float)(a.H * 0.5), o, d);
+  }
+  if (a.ndc) classic_ndc(a, o, d);
+  if (a.o_out != nullptr) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { a.o_out[3 * r + c] = o[c]; a.d_out[3 * r + c] = d[c]; }
+  }
+  if (a.rows != nullptr) {
+    float* q = a.rows + r * a.ld;
+    q[0] = o[0]; q[1] = o[1]; q[2] = o[2]; q[3] = d[0]; q[4] = d[1]; q[5] = d[2];
+    q[6] = a.near; q[7] = a.far;                       // near * ones_like(d[..., :1]): exact
+    int k = 8;
+    if (a.depths != nullptr) q[k++] = a.depths[r];
+    if (a.use_viewdirs) { q[k] = v[0]; q[k + 1] = v[1]; q[k + 2] = v[2]; }
+  }
+}
+
+static int classic_rays_launch(ClassicRays& a, void* stream) {
+  if (a.n <= 0) return SNERF_OK;
+  hipLaunchKernelGGL(classic_rays_kernel, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  return snerf_check_launch();
+}
+
+extern "C" int snerf_classic_get_rays(int H, int W, double focal, double cx, double cy, const float* c2w_host, float* rays_o, float* rays_d,
+                                      void* stream) {
+  if (H <= 0 || W <= 0 || c2w_host == nullptr || rays_o == nullptr || rays_d == nullptr) return SNERF_ERR_ARG;
+  ClassicRays a{};
+  a.n = (long)H * W; a.H = H; a.W = W; a.focal = (float)focal; a.cx = (float)cx; a.cy = (float)cy; a.has_c2w = 1;
+  for (int k = 0; k < 12; ++k) a.c2w[k] = c2w_host[k];
+  a.o_out = rays_o; a.d_out = rays_d;
+  return classic_rays_launch(a, stream);
+}
+
+extern "C" int snerf_classic_ndc_rays(int H, int W, double focal, float near, const float* rays_o, const float* rays_d, long n, float* o_out,
+                                      float* d_out, void* stream) {
+  if (H <= 0 || W <= 0 || rays_o == nullptr || rays_d == nullptr || o_out == nullptr || d_out == nullptr) return SNERF_ERR_ARG;
+  ClassicRays a{};
+  a.n = n; a.H = H; a.W = W; a.rays_o = rays_o; a.rays_d = rays_d; a.ndc = 1; a.ndc_near = near;
+  a.ndc_cw = (float)(-1.0 / ((double)W / (2.0 * focal))); a.ndc_ch = (float)(-1.0 / ((double)H / (2.0 * focal)));
+  a.o_out = o_out; a.d_out = d_out;
+  return classic_rays_launch(a, stream);
+}
+
+extern "C" int snerf_classic_ray_batch(int H, int W, double focal, double cx, double cy, const float* c2w_host, const float* c2w_static_host,
+                                       const float* rays_o, const float* rays_d, long n, int ndc, float near, float far,
+                                       const float* depths, int use_viewdirs, float* rows, int ld, void* stream) {
+  const int need = 8 + (depths != nullptr ? 1 : 0) + (use_viewdirs ? 3 : 0);
+  if (H <= 0 || W <= 0 || rows == nullptr || ld < need) return SNERF_ERR_ARG;
+  if (c2w_host == nullptr && (rays_o == nullptr || rays_d == nullptr)) return SNERF_ERR_ARG;
+  if (c2w_host != nullptr && n != (long)H * W) return SNERF_ERR_ARG;
+  if (c2w_static_host != nullptr && n != (long)H * W) return SNERF_ERR_ARG;
+  ClassicRays a{};
+  a.n = n; a.H = H; a.W = W; a.focal = (float)focal; a.cx = (float)cx; a.cy = (float)cy;
+  a.rays_o = rays_o; a.rays_d = rays_d;
+  if (c2w_host != nullptr) { a.has_c2w = 1; for (int k = 0; k < 12; ++k) a.c2w[k] = c2w_host[k]; }
+  if (c2w_static_host != nullptr) { a.has_static = 1; for (int k = 0; k < 12; ++k) a.c2w_static[k] = c2w_static_host[k]; }
+  a.ndc = ndc; a.ndc_near = 1.f;                       // render.py:66 passes near = 1. to ndc_rays
+  a.ndc_cw = (float)(-1.0 / ((double)W / (2.0 * focal))); a.ndc_ch = (float)(-1.0 / ((double)H / (2.0 * focal)));
+  a.near = near; a.far = far; a.depths = depths; a.use_viewdirs = use_viewdirs; a.rows = rows; a.ld = ld;
+  return classic_rays_launch(a, stream);
+}
+
+// ---------------------------------------------------------------------------
 // Per-ray loss tail of the mip path (s-nerf/train.py:150-208): RgbLoss (loss_factory.py:5-11), calc_depth_loss with DepthLoss
 // and per-ray confidence (confidence.py:209-224, loss_factory.py:26-37) and ProposalLoss (loss_factory.py:59-74), forward
 // value AND the gradients w.r.t. the renderer outputs in one pass.  One lane per ray; prefix sums in the canonical order

@@ -283,18 +283,35 @@ def make_mipnerf(args, device="cuda", compute="bf16"):
                         compute=compute, device=device)
 
 
-def render_image(render_fn, rays, rank=0, chunk=8192):
-    """Chunked full-frame inference (models.py:328-360): rays fields [H,W,.] -> (rgb [H,W,3], distance [H,W],
-    acc [H,W], semantic [H,W,C] or None).  One process drives one GPU, so the reference's reflect-padding to the
-    DataParallel device count is not needed."""
+def render_image(render_fn, rays, rank=0, chunk=8192, world=1, group=None):
+    """Chunked full-frame inference (models.py:328-360; eval.py:146): rays fields [H,W,.] -> (rgb [H,W,3], distance [H,W],
+    acc [H,W], semantic [H,W,C] or None).  One process drives one GPU, so the reference's reflect-padding of a chunk to the
+    DataParallel device count is not needed.  `world` > 1 (one process per GPU, torch.distributed initialised): rank `rank`
+    renders one contiguous block of the frame's rays and ONE all-gather per output buffer assembles the frame on every rank
+     -- instead of scattering every chunk across the devices as nn.DataParallel does."""
     height, width = rays[0].shape[:2]
     num_rays = height * width
     flat = Rays(*[r.reshape(num_rays, -1) for r in rays])
+    per, rem = divmod(num_rays, world)
+    lo = rank * per + min(rank, rem)
+    hi = lo + per + (1 if rank < rem else 0)
     res = []
-    for i in range(0, num_rays, chunk):
-        out = render_fn(Rays(*[r[i:i + chunk] for r in flat]))[-1]
+    for i in range(lo, hi, chunk):
+        out = render_fn(Rays(*[r[i:min(i + chunk, hi)] for r in flat]))[-1]
         res.append(out[:4] if len(out) > 3 and out[3] is not None else out[:3])
     cols = [torch.cat(r, 0) for r in zip(*res)]
-    rgb, dist, acc = cols[:3]
+    if world > 1:
+        import torch.distributed as dist
+        block = per + (1 if rem else 0)                      # every rank contributes a block of the same size (the tail is padding)
+        full = []
+        for c in cols:
+            c2 = c.reshape(c.shape[0], -1)
+            pad = torch.zeros(block, c2.shape[1], dtype=c2.dtype, device=c2.device)
+            pad[:c2.shape[0]] = c2
+            parts = [torch.empty_like(pad) for _ in range(world)]
+            dist.all_gather(parts, pad, group=group)
+            full.append(torch.cat([p[:per + (1 if r < rem else 0)] for r, p in enumerate(parts)], 0))
+        cols = full
+    rgb, dist_, acc = cols[:3]
     sem = cols[3].reshape(height, width, -1) if len(cols) > 3 else None
-    return rgb.reshape(height, width, -1), dist.reshape(height, width), acc.reshape(height, width), sem
+    return rgb.reshape(height, width, -1), dist_.reshape(height, width), acc.reshape(height, width), sem

@@ -192,22 +192,26 @@ class ClassicNeRFNet(_Net):
     Buffers: E [M, Pw] embedding (63 + pad); SK [M, Pw + W] = [embedding | layer-skip output];
     V [M, W + Vw] = [feature | view embedding (27 + pad)]; OUT [M,4] fp32 = [rgb | alpha]."""
 
-    def __init__(self, arena, prefix, dt, D=8, W=256, input_ch=63, input_ch_views=27, skips=(4,), variant=8):
+    def __init__(self, arena, prefix, dt, D=8, W=256, input_ch=63, input_ch_views=27, skips=(4,), variant=8, alpha_head=True):
+        """`alpha_head=False`: the ``NeRF_RGB`` variant (run_nerf_helpers.py:157-212) -- no alpha_linear; column 3 of the output is left
+        for the caller (the frozen alpha model's density)."""
         super().__init__(arena, prefix, dt, variant)
         assert len(skips) == 1 and 0 <= skips[0] < D - 1 and W % self.g == 0 and (W // 2) % self.g == 0
         self.D, self.Wd, self.ic, self.icv, self.skip = D, W, input_ch, input_ch_views, skips[0]
         self.Pw, self.Vw = roundup(input_ch, self.g), roundup(input_ch_views, self.g)
+        self.alpha_head = bool(alpha_head)
 
     @staticmethod
-    def param_shapes(D=8, W=256, input_ch=63, input_ch_views=27, skips=(4,)):
+    def param_shapes(D=8, W=256, input_ch=63, input_ch_views=27, skips=(4,), alpha_head=True):
         out = []
         for i in range(D):
             k = input_ch if i == 0 else (W + input_ch if (i - 1) in skips else W)
             out += [(f"pts_linears.{i}.weight", (W, k)), (f"pts_linears.{i}.bias", (W,))]
         out += [("views_linears.0.weight", (W // 2, input_ch_views + W)), ("views_linears.0.bias", (W // 2,)),
-                ("feature_linear.weight", (W, W)), ("feature_linear.bias", (W,)),
-                ("alpha_linear.weight", (1, W)), ("alpha_linear.bias", (1,)),
-                ("rgb_linear.weight", (3, W // 2)), ("rgb_linear.bias", (3,))]
+                ("feature_linear.weight", (W, W)), ("feature_linear.bias", (W,))]
+        if alpha_head:
+            out += [("alpha_linear.weight", (1, W)), ("alpha_linear.bias", (1,))]
+        out += [("rgb_linear.weight", (3, W // 2)), ("rgb_linear.bias", (3,))]
         return out
 
     def pack(self, train):
@@ -220,14 +224,15 @@ class ClassicNeRFNet(_Net):
                 self._pack_fwd(n, n, [(0, 0, ic), (Pw, ic, W)], Pw + W)     # param [pts | h] -> buffer [pts pad | h]
             else:
                 self._pack_fwd(n, n, [(0, 0, W)], W)
-        self._pack_fwd("alpha", "alpha_linear", [(0, 0, W)], W)
+        if self.alpha_head:
+            self._pack_fwd("alpha", "alpha_linear", [(0, 0, W)], W)
         self._pack_fwd("feature", "feature_linear", [(0, 0, W)], W)
         self._pack_fwd("views", "views_linears.0", [(0, 0, W + self.icv)], W + self.Vw)
         self._pack_fwd("rgb", "rgb_linear", [(0, 0, W // 2)], W // 2)
         if train:
             self._pack_dgrad("rgb", ["rgb_linear"], 0, W // 2)
             self._pack_dgrad("views", ["views_linears.0"], 0, W)             # only the feature columns need a gradient
-            self._pack_dgrad("fa", ["feature_linear", "alpha_linear"], 0, W)
+            self._pack_dgrad("fa", ["feature_linear"] + (["alpha_linear"] if self.alpha_head else []), 0, W)
             for i in range(1, self.D):
                 n = f"pts_linears.{i}"
                 self._pack_dgrad(n, [n], ic if i == self.skip + 1 else 0, W)
@@ -255,7 +260,8 @@ class ClassicNeRFNet(_Net):
             else:
                 x, k = y, W
         OUT = self.buf(M, 4, f32=True)
-        self.fwd("alpha", x, W, OUT[:, 3:], 1, ACT_NONE, out_f32=True)
+        if self.alpha_head:
+            self.fwd("alpha", x, W, OUT[:, 3:], 1, ACT_NONE, out_f32=True)
         self.fwd("feature", x, W, V[:, :W], W, ACT_NONE)
         HV = self.buf(M, W // 2)
         self.fwd("views", V, W + self.Vw, HV, W // 2)
@@ -267,21 +273,24 @@ class ClassicNeRFNet(_Net):
         """d_raw [M,4] fp32 -> accumulates parameter gradients into the arena."""
         acts, V, HV, SK, E = saved
         W, Pw, g, M = self.Wd, self.Pw, self.g, d_raw.shape[0]
+        ah = self.alpha_head
         ops.colsum_f32(d_raw, 3, self.gB("rgb_linear"))
-        ops.colsum_f32(d_raw[:, 3:], 1, self.gB("alpha_linear"))
+        if ah:
+            ops.colsum_f32(d_raw[:, 3:], 1, self.gB("alpha_linear"))
         dz = self.head_grad(d_raw, 3)
         self.wgrad("rgb_linear", dz, HV, 3, W // 2)
         dHV = self.buf(M, W // 2)
         self.dgrad("rgb", dz, dz.shape[1], dHV, W // 2, mask=HV, colsum=self.gB("views_linears.0"))
         self.wgrad("views_linears.0", dHV, V, W // 2, W + self.icv)
-        DB = self.buf(M, W + g)                                   # [d feature | d alpha (+pad)]
+        DB = self.buf(M, W + (g if ah else 0))                    # [d feature | d alpha (+pad)]
         self.dgrad("views", dHV, W // 2, DB, W, colsum=self.gB("feature_linear"))
-        ops.cast_pad(d_raw[:, 3:], 1, DB[:, W:], g, self.dt)
         x7 = acts[-1][2]
         self.wgrad("feature_linear", DB[:, :W], x7, W, W)
-        self.wgrad("alpha_linear", DB[:, W:], x7, 1, W)
+        if ah:
+            ops.cast_pad(d_raw[:, 3:], 1, DB[:, W:], g, self.dt)
+            self.wgrad("alpha_linear", DB[:, W:], x7, 1, W)
         dZ = self.buf(M, W)
-        self.dgrad("fa", DB, W + g, dZ, W, mask=x7, colsum=self.gB(f"pts_linears.{self.D - 1}"))
+        self.dgrad("fa", DB, DB.shape[1], dZ, W, mask=x7, colsum=self.gB(f"pts_linears.{self.D - 1}"))
         for i in range(self.D - 1, -1, -1):
             x, k, y = acts[i]
             n = f"pts_linears.{i}"

@@ -486,6 +486,49 @@ def pinhole_rays(coords, first_pixel, n, W, H, pose, cx, cy, fx, fy, training, n
     return o, d, v, r, nr, fr
 
 
+def _host12(c2w):
+    """[3,4] (or [4,4]) camera-to-world matrix -> contiguous host float32 [12] (one device->host copy per frame if it lives on the GPU)"""
+    import numpy as np
+    if c2w is None:
+        return None
+    a = c2w.detach().float().cpu().numpy() if torch.is_tensor(c2w) else np.asarray(c2w, dtype=np.float32)
+    return np.ascontiguousarray(a[:3, :4], dtype=np.float32)
+
+
+def classic_get_rays(H, W, focal, c2w, cx, cy, device):
+    """get_rays (run_nerf_helpers.py:247-258) -> rays_o, rays_d [H,W,3] on `device`."""
+    p = _host12(c2w)
+    o = torch.empty(H, W, 3, dtype=torch.float32, device=device)
+    d = torch.empty_like(o)
+    _lib.call("snerf_classic_get_rays", int(H), int(W), float(focal), float(cx), float(cy), p.ctypes.data, _p(o), _p(d), _stream())
+    return o, d
+
+
+def classic_ndc_rays(H, W, focal, near, rays_o, rays_d):
+    """ndc_rays (run_nerf_helpers.py:314-332) on [...,3] fp32 tensors."""
+    o, d = _f32c(rays_o.contiguous()), _f32c(rays_d.contiguous())
+    oo, dd = torch.empty_like(o), torch.empty_like(d)
+    _lib.call("snerf_classic_ndc_rays", int(H), int(W), float(focal), float(near), _p(o), _p(d), o.numel() // 3, _p(oo), _p(dd), _stream())
+    return oo, dd
+
+
+def classic_ray_batch(H, W, focal, cx, cy, c2w, c2w_static, rays_o, rays_d, n, ndc, near, far, depths, use_viewdirs, device):
+    """The ray-batch assembly of render() (render.py:50-77) in one launch -> rows [n, 8 (+1) (+3)] fp32."""
+    p, ps = _host12(c2w), _host12(c2w_static)
+    ld = 8 + (1 if depths is not None else 0) + (3 if use_viewdirs else 0)
+    rows = torch.empty(n, ld, dtype=torch.float32, device=device)
+    if rays_o is not None:
+        rays_o, rays_d = _f32c(rays_o), _f32c(rays_d)
+        assert rays_o.shape == (n, 3) and rays_d.shape == (n, 3)
+    if depths is not None:
+        _f32c(depths)
+        assert depths.numel() == n
+    _lib.call("snerf_classic_ray_batch", int(H), int(W), float(focal), float(cx), float(cy), None if p is None else p.ctypes.data,
+              None if ps is None else ps.ctypes.data, _p(rays_o), _p(rays_d), int(n), 1 if ndc else 0, float(near), float(far), _p(depths),
+              1 if use_viewdirs else 0, _p(rows), ld, _stream())
+    return rows
+
+
 def mip_loss_tail(rgb, tgt, dist1, dist0, tdepth, conf, s_f, w_f, s_c, w_c, disparity, depth_lambda, coarse_mult, prop_lambda):
     """-> (out[4] = {#valid, rgb, depth, proposal loss}, g_rgb, g_dist1, g_dist0, g_wc); absent terms return None gradients."""
     n = rgb.shape[0]

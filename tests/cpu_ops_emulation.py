@@ -390,11 +390,27 @@ def zip_encode_prop_fwd(tdist, origins, directions, radii, base_x, base_y, deg_j
     return h @ rb(w2.reshape(-1, 1)) + b2
 
 
+def classic_get_rays(H, W, focal, c2w, cx, cy, device):
+    o, d = oc.get_rays(H, W, focal, torch.as_tensor(c2w).float().cpu(), [cx, cy])
+    return o.contiguous(), d.contiguous()
+
+
+def classic_ndc_rays(H, W, focal, near, rays_o, rays_d):
+    return oc.ndc_rays(H, W, focal, near, rays_o, rays_d)
+
+
+def classic_ray_batch(H, W, focal, cx, cy, c2w, c2w_static, rays_o, rays_d, n, ndc, near, far, depths, use_viewdirs, device):
+    cpu = lambda t: None if t is None else torch.as_tensor(t).float().cpu()
+    rows, _ = oc.ray_batch(H, W, focal, rays=None if rays_o is None else (rays_o, rays_d), c2w=cpu(c2w), ndc=ndc, near=near, far=far,
+                           use_viewdirs=use_viewdirs, c2w_staticcam=cpu(c2w_static), depths=depths, ori_points=[cx, cy])
+    return rows.contiguous()
+
+
 def adam_step_dev(p, g, m, v, lr, b1, b2, eps, step_dev, grad_scale=1.0, zero_grad=True, **kw):
     adam_step(p, g, m, v, lr, b1, b2, eps, 0, grad_scale, zero_grad, step_dev=step_dev, **kw)
 
 
-_NAMES = ["adam_step_dev", "grad_clip_coef", "zip_encode_prop_fwd", "mip_encode_bwd", "mip_viewenc_bwd", "hash_decay", "zip_percentiles", "zip_pixels_to_rays", "zip_loss_tail", "semantic_composite_fwd", "semantic_composite_bwd", "zip_resample", "zip_encode_fwd", "zip_encode_bwd", "zip_composite_fwd", "zip_composite_bwd",
+_NAMES = ["adam_step_dev", "grad_clip_coef", "classic_get_rays", "classic_ndc_rays", "classic_ray_batch", "zip_encode_prop_fwd", "mip_encode_bwd", "mip_viewenc_bwd", "hash_decay", "zip_percentiles", "zip_pixels_to_rays", "zip_loss_tail", "semantic_composite_fwd", "semantic_composite_bwd", "zip_resample", "zip_encode_fwd", "zip_encode_bwd", "zip_composite_fwd", "zip_composite_bwd",
           "linear_fwd", "linear_wgrad", "classic_embed", "mip_encode", "mip_viewenc", "classic_sample_pdf", "classic_points",
           "classic_merge_sort", "mip_resample", "stratified", "mip_composite_fwd", "mip_composite_bwd", "classic_composite_fwd",
           "classic_composite_bwd", "adam_step", "colsum_f32", "cast_pad", "pinhole_rays", "mip_loss_tail"]

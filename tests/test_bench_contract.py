@@ -39,3 +39,49 @@ def test_bench_source_keeps_the_driver_flags_and_defaults():
         assert flag in src, flag
     for key in ('"roofline"', '"cpu_baseline"', '"vs_baseline"', '"higher_is_better"', '"scaling"', '"workload"'):
         assert key in src, key
+
+
+def test_bench_relaunches_itself_for_multi_gpu_without_a_launcher(monkeypatch):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment must start N ranks under torch.distributed.run (127.0.0.1
+    rendezvous) with its own arguments instead of refusing to run."""
+    import importlib
+    import subprocess
+    import sys
+    sys.path.insert(0, REPO)
+    bench = importlib.import_module("bench")
+    seen = {}
+    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: seen.update(cmd=cmd, env=env) or 0)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    try:
+        bench.main()
+    except SystemExit as e:
+        assert e.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    assert os.path.basename(cmd[cmd.index("--master-port") + 2]) == "bench.py"
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_on_one_gpu_without_a_launcher():
+    """The N > 1 control flow end to end on the 1-GPU box: self-launch, gloo rendezvous, both ranks on cuda:0, sharded frame render,
+    strong scaling split -- rank 0 prints one JSON line with the contract fields."""
+    import subprocess
+    import sys
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--backend", "gloo", "--same-device", "--steps", "2", "--warmup", "1",
+           "--rays", "512", "--scaling", "strong", "--no-cpu", "--no-eager", "--no-f32", "--frame-chunk", "16384"]
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=850, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["rays_per_gpu_per_step"] == 256 and d["config"]["global_rays_per_step"] == 512
+    assert d["comm"]["ranks"] == 2 and d["comm"]["bytes"] > 3.5e7 and d["ms_per_frame"] > 0 and "roofline" in d

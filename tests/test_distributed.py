@@ -191,3 +191,37 @@ def test_zip_render_image_row_blocks_across_ranks_match_single_process():
         assert got[k].shape == ref[k].shape and got[k].shape[:2] == (H, W)
         assert torch.allclose(got[k], ref[k], rtol=1e-4, atol=1e-5), (k, float((got[k] - ref[k]).abs().max()))
     assert len(got["ray_weights"]) == 3 and got["ray_weights"][2].shape == (2, 32)
+
+
+def _render_worker(rank, world, init_file, out_file):
+    from cpu_ops_emulation import emulate_ops
+    from snerf_amd import mipnerf
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    with emulate_ops(), torch.no_grad():
+        model = _build()
+        rays, _ = _data(35)                               # 5 x 7 frame: 35 rays do not divide by 2 (17 + 18)
+        grid = mipnerf.Rays(*[r.reshape(5, 7, -1) for r in rays])
+        out = mipnerf.render_image(lambda r: model(r, False, False, 0.), grid, rank, chunk=4, world=world)
+        if rank == 1:                                     # every rank holds the whole frame after the all-gather
+            torch.save([o for o in out[:3]], out_file)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_mip_render_image_sharded_across_ranks():
+    """SURVEY.md section 8e, inference: the frame's rays are split into one contiguous block per rank (uneven split), one all-gather
+    per output buffer; the assembled frame equals the single-process render."""
+    from cpu_ops_emulation import emulate_ops
+    from snerf_amd import mipnerf
+    with tempfile.TemporaryDirectory() as td:
+        init_file, out_file = os.path.join(td, "init"), os.path.join(td, "out.pt")
+        mp.spawn(_render_worker, args=(2, init_file, out_file), nprocs=2, join=True)
+        got = torch.load(out_file)
+    with emulate_ops(), torch.no_grad():
+        model = _build()
+        rays, _ = _data(35)
+        grid = mipnerf.Rays(*[r.reshape(5, 7, -1) for r in rays])
+        ref = mipnerf.render_image(lambda r: model(r, False, False, 0.), grid, 0, chunk=35)
+    for a, b in zip(got, ref[:3]):                        # (CPU BLAS blocks differently for different chunk sizes: last-bit differences)
+        assert a.shape == b.shape and float((a - b).abs().max()) < 1e-5 * (1 + float(b.abs().max()))

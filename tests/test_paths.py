@@ -380,3 +380,37 @@ def test_mipnerf_ray_gradients_vs_reference_golden(backend, golden):
         ref_g = g["grad_" + k]
         err = float((rays[k].grad.cpu() - ref_g).abs().max())
         assert err <= 3e-3 * float(ref_g.abs().max()), (k, err, float(ref_g.abs().max()))
+
+
+def test_render_image_vs_reference_golden(backend, golden):
+    """chunked full-frame inference, ragged last chunk (35 rays in chunks of 8), against the reference's own
+    render_image (models.py:328-360; g21) -- and against ONE forward over all rays (chunking must not change a value)."""
+    from snerf_amd import mipnerf
+    g = golden("g21_render_image")
+    H, W, chunk = int(g["H"]), int(g["W"]), int(g["chunk"])
+    m = mipnerf.MipNerfModel(n_samples=16, N_fine=17, no_warp_sample=0, ray_shape="cone", fn=1, radius=3., transform_idx=0, real=True,
+                             rgb_layer=3, hidden_layer=64, density_noise=0., max_deg_point=16, proposal_hidden_layer=64,
+                             proposal_loss=False, semantic=True, semantic_class_num=7, compute="f32", device=DEV)
+    assert list(m.state_dict().keys()) == [str(k) for k in g["param_names"]]
+    m.load_state_dict(common.fill_state_dict_({k: torch.empty(v.shape) for k, v in m.state_dict().items()}))
+    flat = {k[5:]: torch.as_tensor(v).to(DEV) for k, v in g.items() if k.startswith("rays_")}
+    rays = mipnerf.Rays(**{k: v.reshape(H, W, -1) for k, v in flat.items()})
+    with torch.no_grad():
+        rgb, dist, acc, sem = mipnerf.render_image(lambda r: m(r, False, False, 0.), rays, 0, chunk=chunk)
+        one = m(mipnerf.Rays(**flat), False, False, 0.)[-1]
+    assert rgb.shape == (H, W, 3) and dist.shape == (H, W) and acc.shape == (H, W) and sem.shape == (H, W, 7)
+    close(rgb, g["rgb"], 1e-4, 1e-5, "render_image rgb"); close(dist, g["distance"], 1e-4, 1e-4, "render_image distance")
+    close(acc, g["acc"], 1e-4, 1e-5, "render_image acc"); close(sem, g["semantic"], 1e-4, 1e-5, "render_image semantic")
+    for got, want, k in zip((rgb, dist, acc, sem), one[:4], ("rgb", "distance", "acc", "semantic")):
+        if backend == "hip":      # the HIP GEMMs reduce every row in a fixed order whatever the batch size; CPU BLAS (emulation) does not
+            assert torch.equal(got.reshape(want.shape), want), f"chunking changed {k}"
+        else:
+            close(got.reshape(want.shape), want, 1e-5, 1e-6, f"chunked vs one forward: {k}")
+    # without a semantic head (and with the proposal-loss extras in the level outputs) the fourth output is None
+    m2 = make_mip(64, 64, 16, 17, "f32", mip_params(64, 64))
+    with torch.no_grad():
+        out = mipnerf.render_image(lambda r: m2(r, False, False, 0.), rays, 0, chunk=13)
+        ref = om.mipnerf_forward(mip_params(64, 64), {k: v.cpu() for k, v in flat.items()}, 16, 17)
+    assert out[3] is None and out[0].shape == (H, W, 3)
+    close(out[0].reshape(-1, 3), ref[1][0], 1e-4, 1e-5, "render_image rgb vs oracle")
+    close(out[1].reshape(-1), ref[1][1], 1e-4, 1e-4, "render_image distance vs oracle")
