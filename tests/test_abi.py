@@ -19,7 +19,7 @@ def test_header_parses_and_lists_entry_points():
     # no torch / C++ types in the signatures: only pointers and plain scalars
     for sig in protos.values():
         for ty, _ in sig:
-            assert ty in (ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float)
+            assert ty in (ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_double)
 
 
 @pytest.mark.skipif(not os.path.exists(_lib.LIB_PATH), reason="libsnerf_hip.so not built (run __graft_entry__.build())")
