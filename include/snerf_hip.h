@@ -323,6 +323,16 @@ int snerf_zip_encode_prop_fwd(const float* tdist, const float* origins, const fl
                               const float* b1, const float* w2, const float* b2, int hidden, int round_bf16, float* raw_density,
                               void* stream);
 
+/* ---- deterministic mode ("deterministic mode for parity tests") ------------------------------------------
+ * The weight gradient normally lands in dW by fp32 atomics from the M slices (order varies run to run).  snerf_linear_wgrad_det makes
+ * every slice store its partial tile into `ws` (snerf_linear_wgrad_ws_floats(...) floats) and folds them in slice order: bit-identical
+ * gradients run to run.  snerf_colsum_f32_det is the single-workgroup form of snerf_colsum_f32; snerf_linear_fwd takes variant bit 8
+ * (| 256) to fold its bias-gradient partials in a fixed order. */
+long snerf_linear_wgrad_ws_floats(int M, int N, int K, long ldz, long ldx, int dtype, int variant);
+int snerf_linear_wgrad_det(const void* Z, long ldz, const void* X, long ldx, float* dW, long ldw, const void* zeros, int M, int N, int K,
+                           int n_valid, int k_valid, int dtype, int variant, float* ws, long ws_floats, void* stream);
+int snerf_colsum_f32_det(const float* x, long ld, long M, int C, float* out, void* stream);
+
 /* ---- classic-path ray front end ---------------------------------------------------------------------
  * snerf_classic_get_rays  = get_rays (s-nerf/model/run_nerf_helpers.py:247-258): pinhole rays of an H x W frame, pixel centres at
  *   +0.5, principal point (cx, cy) = `ori_points` (default W/2, H/2); c2w_host: HOST pointer to the [3,4] camera-to-world matrix.

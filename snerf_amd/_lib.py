@@ -16,6 +16,7 @@ IO_LIB_PATH = os.path.join(_HERE, "lib", "libsnerf_io.so")
 IO_HEADER_PATH = os.path.join(_REPO, "include", "snerf_io.h")
 
 _CTYPE = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double}
+RESTYPE = {}          # name -> ctypes return type (int status for the entry points, long for the size queries)
 _lib = None
 _iolib = None
 
@@ -25,8 +26,9 @@ def parse_header(path: str = HEADER_PATH):
     src = open(path).read()
     src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
     protos = {}
-    for m in re.finditer(r"\b(?:int|long)\s+(snerf_\w+)\s*\(([^)]*)\)\s*;", src):
-        name, args = m.group(1), m.group(2).strip()
+    for m in re.finditer(r"\b(int|long)\s+(snerf_\w+)\s*\(([^)]*)\)\s*;", src):
+        name, args = m.group(2), m.group(3).strip()
+        RESTYPE[name] = _CTYPE[m.group(1)]
         sig = []
         if args and args != "void":
             for a in args.split(","):
@@ -57,7 +59,7 @@ def load():
     for name, sig in parse_header().items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.argtypes = [t for t, _ in sig]
-        fn.restype = ctypes.c_int
+        fn.restype = RESTYPE[name]
     _lib = lib
     return lib
 
@@ -83,6 +85,11 @@ class SnerfHipError(RuntimeError):
 
 
 _STATUS = {1: "bad argument", 2: "kernel launch failure"}
+
+
+def query(name: str, *args):
+    """value-returning entries (workspace size queries): no status to check"""
+    return getattr(load(), name)(*args)
 
 
 def call(name: str, *args):

@@ -92,6 +92,15 @@ class _ArenaModule(nn.Module):
             raise ValueError("assign=True would detach the parameters from the flat arena")
         return super().load_state_dict(strip_module_prefix(state_dict), strict=strict)
 
+    def set_deterministic(self, flag: bool = True):
+        """Bit-reproducible parameter gradients for parity runs: the MLP executors fold weight- and bias-gradient
+        partials in a fixed order instead of adding them with fp32 atomics.  Costs a workspace round trip per weight gradient."""
+        for v in vars(self).values():
+            for net in (v if isinstance(v, (list, tuple)) else [v]):
+                if hasattr(net, "deterministic") and hasattr(net, "ensure_packed"):
+                    net.deterministic = bool(flag)
+        return self
+
     def _param_version(self):
         return sum(p._version for p in self.param_list()) + self.arena.epoch
 

@@ -139,6 +139,31 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   }
 }
 
+// the same sums by ONE workgroup in a fixed order (deterministic mode: no atomics between workgroups)
+__global__ __launch_bounds__(1024) void colsum_det_kernel(const float* __restrict__ x, long ld, long M, int C, float* __restrict__ out) {
+  __shared__ float red[16][8];
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (long m = threadIdx.x; m < M; m += 1024)
+    for (int c = 0; c < C; ++c) acc[c] += x[m * ld + c];
+  for (int c = 0; c < C; ++c) {
+    const float s = wave_sum(acc[c]);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][c] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < C) {
+    float s = 0.f;
+    for (int w = 0; w < 16; ++w) s += red[w][threadIdx.x];
+    out[threadIdx.x] += s;
+  }
+}
+
+extern "C" int snerf_colsum_f32_det(const float* x, long ld, long M, int C, float* out, void* stream) {
+  if (M <= 0) return SNERF_OK;
+  if (C < 1 || C > 8) return SNERF_ERR_ARG;
+  hipLaunchKernelGGL(colsum_det_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, ld, M, C, out);
+  return snerf_check_launch();
+}
+
 extern "C" int snerf_colsum_f32(const float* x, long ld, long M, int C, float* out, void* stream) {
   if (M <= 0) return SNERF_OK;
   if (C < 1 || C > 8) return SNERF_ERR_ARG;

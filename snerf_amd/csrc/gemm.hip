@@ -37,6 +37,7 @@ struct GemmNT {
   float* colsum;
   int M, N, K, n_store, act, out_f32, vec_store;
   float* colsum_ws; int fast_epi;
+  int det;  // deterministic bias gradient: the per-slab column sums are folded by ONE thread per column (fixed order)
   int dbg;  // ablation bits, honoured only by a `make PROBE=1` build (tools/gemm_probe.py): 1 = no staging loads after tile 0, 2 = no LDS fragment reads, 4 = no stores
 };
 #ifndef SNERF_PROBE
@@ -923,7 +924,7 @@ static int launch_nt(const GemmNT& p, hipStream_t stream) {
   if (p.fast_epi && p.colsum_ws != nullptr) {
     const int rows = tiles_m * WM;
     int ychunks = rows / 64;
-    ychunks = ychunks < 1 ? 1 : (ychunks > 64 ? 64 : ychunks);
+    ychunks = (ychunks < 1 || p.det) ? 1 : (ychunks > 64 ? 64 : ychunks);
     hipLaunchKernelGGL(colsum_reduce_kernel, dim3((p.n_store + 255) / 256, ychunks), dim3(256), 0, stream, p.colsum_ws, rows, p.N, p.n_store, p.colsum);
   }
   return snerf_check_launch();
@@ -942,7 +943,7 @@ static int launch_nt8(const GemmNT& p, hipStream_t stream) {
   if (p.fast_epi && p.colsum_ws != nullptr) {
     const int rows = tiles_m * 2;
     int ychunks = rows / 64;
-    ychunks = ychunks < 1 ? 1 : (ychunks > 64 ? 64 : ychunks);
+    ychunks = (ychunks < 1 || p.det) ? 1 : (ychunks > 64 ? 64 : ychunks);
     hipLaunchKernelGGL(colsum_reduce_kernel, dim3((p.n_store + 255) / 256, ychunks), dim3(256), 0, stream, p.colsum_ws, rows, p.N, p.n_store, p.colsum);
   }
   return snerf_check_launch();
@@ -993,7 +994,7 @@ static int launch_nt8p(const GemmNT& p, hipStream_t stream) {
   if (p.colsum_ws != nullptr) {
     const int rows = grid * 2;                            // one partial row per (workgroup, wave row)
     int ychunks = rows / 64;
-    ychunks = ychunks < 1 ? 1 : (ychunks > 64 ? 64 : ychunks);
+    ychunks = (ychunks < 1 || p.det) ? 1 : (ychunks > 64 ? 64 : ychunks);
     hipLaunchKernelGGL(colsum_reduce_kernel, dim3((p.n_store + 255) / 256, ychunks), dim3(256), 0, stream, p.colsum_ws, rows, p.N, p.n_store, p.colsum);
   }
   return snerf_check_launch();
@@ -1020,7 +1021,9 @@ extern "C" int snerf_linear_fwd(const void* A, long lda, const void* W, long ldw
   if (act == ACT_MASK) fast = fast && (ldaux % epc == 0) && (((uintptr_t)aux) % 16 == 0);
   if (colsum != nullptr && colsum_ws == nullptr) fast = 0;   // without a workspace the bias gradient uses the atomic path
   if ((variant >> 4) & 8) fast = 0;                          // ablation: force the direct-store epilogue
-  GemmNT p{A, lda, W, ldw, bias, Y, ldy, aux, ldaux, colsum, M, N, K, n_store, act, out_f32, vec, colsum_ws, fast, (variant >> 4) & 7};
+  const int det = (variant >> 8) & 1;                        // variant bit 8: deterministic fold of the bias-gradient partials
+  if (det && colsum != nullptr && !fast) return SNERF_ERR_ARG;   // the direct-store epilogue adds its column sums with atomics
+  GemmNT p{A, lda, W, ldw, bias, Y, ldy, aux, ldaux, colsum, M, N, K, n_store, act, out_f32, vec, colsum_ws, fast, det, (variant >> 4) & 7};
   variant &= 15;
   hipStream_t s = (hipStream_t)stream;
   // variant: 0 = 128x128 block-issue, 1 = 256x256 block-issue,
@@ -1054,6 +1057,9 @@ struct GemmTN {
   float* dW; long ldw;
   const void* zeros;  // >= 16 bytes of zeros in device memory
   int M, N, K, n_valid, k_valid, m_chunk;
+  float* part;        // deterministic mode: every (tile, M slice) stores its partial tile at part + slice * part_stride + n * part_ld + k
+  long part_stride;   // (no atomics); tn_fold_kernel adds the slices in a fixed order.  nullptr: fp32 atomics straight into dW
+  int part_ld;
 };
 
 template <typename T, bool TR>
@@ -1188,7 +1194,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (n < p.n_valid && k < p.k_valid) atomicAdd(p.dW + (long)n * p.ldw + k, acc[i][j][r]);
+        if (n < p.n_valid && k < p.k_valid) {
+          if (p.part != nullptr) p.part[(long)blockIdx.y * p.part_stride + (long)n * p.part_ld + k] = acc[i][j][r];
+          else atomicAdd(p.dW + (long)n * p.ldw + k, acc[i][j][r]);
+        }
       }
     }
 }
@@ -1393,35 +1402,45 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(GemmTN p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = n0 + wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (n < p.n_valid && k < p.k_valid) atomicAdd(p.dW + (long)n * p.ldw + k, acc[i][j][r]);
+        if (n < p.n_valid && k < p.k_valid) {
+          if (p.part != nullptr) p.part[(long)chunk * p.part_stride + (long)n * p.part_ld + k] = acc[i][j][r];
+          else atomicAdd(p.dW + (long)n * p.ldw + k, acc[i][j][r]);
+        }
       }
     }
 }
 
-extern "C" int snerf_linear_wgrad(const void* Z, long ldz, const void* X, long ldx, float* dW, long ldw, const void* zeros,
-                                  int M, int N, int K, int n_valid, int k_valid, int dtype, int variant, void* stream) {
-  if (M <= 0) return SNERF_OK;
-  const int epc = dtype == SNERF_DT_F32 ? 4 : 8;
-  if (N < epc || K < epc || N % epc || K % epc || ldz % epc || ldx % epc || zeros == nullptr) return SNERF_ERR_ARG;
-  // split M so that the grid has a few thousand blocks but each block still amortises its atomics
-  const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
-  int chunks = (4096 + tiles - 1) / tiles;
-  int m_chunk = (M + chunks - 1) / chunks;
-  m_chunk = ((m_chunk + 255) / 256) * 256;
-  if (m_chunk < 1024) m_chunk = 1024;
-  chunks = (M + m_chunk - 1) / m_chunk;
+// dW[n, k] += sum over the M slices, in slice order, of the partial tiles (deterministic weight gradient)
+__global__ __launch_bounds__(256) void tn_fold_kernel(const float* __restrict__ part, long part_stride, int part_ld, int slices, int n_valid,
+                                                      int k_valid, float* __restrict__ dW, long ldw) {
+  const int k = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
+  if (k >= k_valid || n >= n_valid) return;
+  const float* src = part + (long)n * part_ld + k;
+  float s = 0.f;
+  for (int c = 0; c < slices; ++c) s += src[(long)c * part_stride];
+  dW[(long)n * ldw + k] += s;
+}
+
+struct TnPlan {
+  bool use8;          // 256 x 256 8-phase kernel, else 128 x 128
+  int slices;         // M slices (workgroups per output tile)
+  int m_chunk;        // rows per slice
+  int part_ld;        // row length of a partial tile image (K rounded up to the tile)
+  long part_stride;   // floats per slice in the deterministic workspace
+};
+
+static TnPlan tn_plan(int M, int N, int K, long ldz, long ldx, int dtype, int variant) {
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    n_cu = 256;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      n_cu = prop.multiProcessorCount;
+  }
+  TnPlan pl{};
   // variant 2 (bf16): 256 x 256 tiles, 8-phase schedule; M is cut into as many slices as keep every CU busy
   if ((variant & 2) && dtype == SNERF_DT_BF16 && N % 256 == 0 && K >= 256 && M >= 4096 && ldz * 2 * 65 < (1L << 31) && ldx * 2 * 65 < (1L << 31)) {
-    static bool attr_set = false;
-    static int n_cu = 256;
-    if (!attr_set) {
-      hipFuncSetAttribute((const void*)gemm_tn8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 64 * 256);
-      int dev = 0;
-      hipDeviceProp_t prop;
-      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-        n_cu = prop.multiProcessorCount;
-      attr_set = true;
-    }
     const int t8 = (N / 256) * ((K + 255) / 256);
     int ch = n_cu / t8;
     ch = ch < 1 ? 1 : ch;
@@ -1429,20 +1448,70 @@ extern "C" int snerf_linear_wgrad(const void* Z, long ldz, const void* X, long l
     mc = ((mc + 127) / 128) * 128;                    // whole k-tile pairs
     const long lim = (1L << 30) / ((ldz > ldx ? ldz : ldx) * 2);   // slice bytes stay inside 32-bit buffer offsets
     if (mc > lim) mc = lim / 128 * 128;
-    ch = (int)((M + mc - 1) / mc);
-    GemmTN p8{Z, ldz, X, ldx, dW, ldw, zeros, M, N, K, n_valid, k_valid, (int)mc};
-    hipLaunchKernelGGL(gemm_tn8_kernel, dim3(t8 * ch), dim3(512), 8 * 64 * 256, (hipStream_t)stream, p8);
-    return snerf_check_launch();
+    pl.use8 = true; pl.m_chunk = (int)mc; pl.slices = (int)((M + mc - 1) / mc);
+    pl.part_ld = ((K + 255) / 256) * 256; pl.part_stride = (long)N * pl.part_ld;
+    return pl;
   }
-  GemmTN p{Z, ldz, X, ldx, dW, ldw, zeros, M, N, K, n_valid, k_valid, m_chunk};
-  const int lds = 2 * 2 * 8192;
-  dim3 grid(tiles, chunks);
-  // variant 1 (bf16): operands via ds_read_b64_tr_b16 (needs whole 128-column tiles: the source swizzle permutes chunks
-  // inside a 256-byte row); variant 0: 16-bit LDS gathers
-  const bool tr = (variant & 1) && dtype == SNERF_DT_BF16 && (N % 128 == 0) && (K % 128 == 0);
-  if (dtype == SNERF_DT_F32) hipLaunchKernelGGL((gemm_tn_kernel<float, false>), grid, dim3(256), lds, (hipStream_t)stream, p);
-  else if (dtype == SNERF_DT_BF16 && tr) hipLaunchKernelGGL((gemm_tn_kernel<__bf16, true>), grid, dim3(256), lds, (hipStream_t)stream, p);
-  else if (dtype == SNERF_DT_BF16) hipLaunchKernelGGL((gemm_tn_kernel<__bf16, false>), grid, dim3(256), lds, (hipStream_t)stream, p);
-  else return SNERF_ERR_ARG;
+  // split M so that the grid has a few thousand blocks but each block still amortises its atomics
+  const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
+  int chunks = (4096 + tiles - 1) / tiles;
+  int m_chunk = (M + chunks - 1) / chunks;
+  m_chunk = ((m_chunk + 255) / 256) * 256;
+  if (m_chunk < 1024) m_chunk = 1024;
+  pl.use8 = false; pl.m_chunk = m_chunk; pl.slices = (M + m_chunk - 1) / m_chunk;
+  pl.part_ld = ((K + 127) / 128) * 128; pl.part_stride = (long)(((N + 127) / 128) * 128) * pl.part_ld;
+  return pl;
+}
+
+static int wgrad_launch(const void* Z, long ldz, const void* X, long ldx, float* dW, long ldw, const void* zeros, int M, int N, int K,
+                        int n_valid, int k_valid, int dtype, int variant, float* ws, long ws_floats, void* stream) {
+  if (M <= 0) return SNERF_OK;
+  const int epc = dtype == SNERF_DT_F32 ? 4 : 8;
+  if (N < epc || K < epc || N % epc || K % epc || ldz % epc || ldx % epc || zeros == nullptr) return SNERF_ERR_ARG;
+  const TnPlan pl = tn_plan(M, N, K, ldz, ldx, dtype, variant);
+  if (ws != nullptr && ws_floats < pl.part_stride * pl.slices) return SNERF_ERR_ARG;
+  GemmTN p{Z, ldz, X, ldx, dW, ldw, zeros, M, N, K, n_valid, k_valid, pl.m_chunk, ws, pl.part_stride, pl.part_ld};
+  if (pl.use8) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipFuncSetAttribute((const void*)gemm_tn8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 64 * 256);
+      attr_set = true;
+    }
+    const int t8 = (N / 256) * ((K + 255) / 256);
+    hipLaunchKernelGGL(gemm_tn8_kernel, dim3(t8 * pl.slices), dim3(512), 8 * 64 * 256, (hipStream_t)stream, p);
+  } else {
+    const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
+    const int lds = 2 * 2 * 8192;
+    dim3 grid(tiles, pl.slices);
+    // variant 1 (bf16): operands via ds_read_b64_tr_b16 (needs whole 128-column tiles: the source swizzle permutes chunks
+    // inside a 256-byte row); variant 0: 16-bit LDS gathers
+    const bool tr = (variant & 1) && dtype == SNERF_DT_BF16 && (N % 128 == 0) && (K % 128 == 0);
+    if (dtype == SNERF_DT_F32) hipLaunchKernelGGL((gemm_tn_kernel<float, false>), grid, dim3(256), lds, (hipStream_t)stream, p);
+    else if (dtype == SNERF_DT_BF16 && tr) hipLaunchKernelGGL((gemm_tn_kernel<__bf16, true>), grid, dim3(256), lds, (hipStream_t)stream, p);
+    else if (dtype == SNERF_DT_BF16) hipLaunchKernelGGL((gemm_tn_kernel<__bf16, false>), grid, dim3(256), lds, (hipStream_t)stream, p);
+    else return SNERF_ERR_ARG;
+  }
+  if (ws != nullptr)
+    hipLaunchKernelGGL(tn_fold_kernel, dim3((k_valid + 255) / 256, n_valid), dim3(256), 0, (hipStream_t)stream, ws, pl.part_stride, pl.part_ld,
+                       pl.slices, n_valid, k_valid, dW, ldw);
   return snerf_check_launch();
+}
+
+extern "C" int snerf_linear_wgrad(const void* Z, long ldz, const void* X, long ldx, float* dW, long ldw, const void* zeros,
+                                  int M, int N, int K, int n_valid, int k_valid, int dtype, int variant, void* stream) {
+  return wgrad_launch(Z, ldz, X, ldx, dW, ldw, zeros, M, N, K, n_valid, k_valid, dtype, variant, nullptr, 0, stream);
+}
+
+// Deterministic weight gradient: the M slices store partial tiles into `ws` (snerf_linear_wgrad_ws_floats floats) and a second
+// kernel folds them in slice order -- bit-reproducible run to run, no atomics ("deterministic mode").
+extern "C" long snerf_linear_wgrad_ws_floats(int M, int N, int K, long ldz, long ldx, int dtype, int variant) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const TnPlan pl = tn_plan(M, N, K, ldz, ldx, dtype, variant);
+  return pl.part_stride * pl.slices;
+}
+
+extern "C" int snerf_linear_wgrad_det(const void* Z, long ldz, const void* X, long ldx, float* dW, long ldw, const void* zeros, int M, int N,
+                                      int K, int n_valid, int k_valid, int dtype, int variant, float* ws, long ws_floats, void* stream) {
+  if (ws == nullptr) return SNERF_ERR_ARG;
+  return wgrad_launch(Z, ldz, X, ldx, dW, ldw, zeros, M, N, K, n_valid, k_valid, dtype, variant, ws, ws_floats, stream);
 }

@@ -80,6 +80,7 @@ class _Net:
         self.tdt = ops.torch_dtype(dt)
         self.dev = arena.flat.device
         self._packed_version = -1
+        self.deterministic = False        # bit-reproducible gradients: partial tiles folded in a fixed order instead of fp32 atomics
         self.version_fn = arena.version   # drop-in modules override this with their nn.Parameter versions
         self.fw, self.fb, self.tw = {}, {}, {}
 
@@ -137,6 +138,9 @@ class _Net:
         ops.linear_fwd(dZ, self.tw[key], None, out, K, width, ACT_NONE, self.dt, out_f32=True, variant=self.variant)
         return out
 
+    def colsum(self, x, C, out):
+        ops.colsum_f32(x, C, out, deterministic=self.deterministic)
+
     def ensure_packed(self, train: bool):
         # ReLU bit masks written by this forward's layers (keyed by the activation view), read by the data-gradient GEMMs
         self._bits = {} if train else None
@@ -167,14 +171,16 @@ class _Net:
         if mask is not None and bits:
             ent = bits.get((mask.data_ptr(), mask.shape[0]))
             if ent is not None and ent[1] == W.shape[0] and ops.relu_bits_ok(dZ, W, dX, K, n_store, self.dt, self.variant, consumer=True):
-                ops.linear_fwd(dZ, W, None, dX, K, n_store, ops.ACT_MASK_BITS, self.dt, aux=ent[0], colsum=colsum, variant=self.variant)
+                ops.linear_fwd(dZ, W, None, dX, K, n_store, ops.ACT_MASK_BITS, self.dt, aux=ent[0], colsum=colsum, variant=self.variant,
+                               deterministic=self.deterministic)
                 return
         ops.linear_fwd(dZ, W, None, dX, K, n_store, ACT_MASK if mask is not None else ACT_NONE, self.dt,
-                       aux=mask, colsum=colsum, variant=self.variant)
+                       aux=mask, colsum=colsum, variant=self.variant, deterministic=self.deterministic)
 
     def wgrad(self, name, dZ, X, n_valid, k_valid, wcol=0):
         gw = self.gW(name)
-        ops.linear_wgrad(dZ, X, gw[:, wcol:], n_valid, k_valid, self.dt, variant=3)   # 2: 8-phase 256x256 tiles where they fit, else 1: transposing LDS reads
+        ops.linear_wgrad(dZ, X, gw[:, wcol:], n_valid, k_valid, self.dt, variant=3,   # 2: 8-phase 256x256 tiles where they fit, else 1: transposing LDS reads
+                         deterministic=self.deterministic)
 
     def head_grad(self, d_raw_f32, C):
         """fp32 head gradient [M,C] -> compute-dtype buffer padded to the tile granularity."""
@@ -274,9 +280,9 @@ class ClassicNeRFNet(_Net):
         acts, V, HV, SK, E = saved
         W, Pw, g, M = self.Wd, self.Pw, self.g, d_raw.shape[0]
         ah = self.alpha_head
-        ops.colsum_f32(d_raw, 3, self.gB("rgb_linear"))
+        self.colsum(d_raw, 3, self.gB("rgb_linear"))
         if ah:
-            ops.colsum_f32(d_raw[:, 3:], 1, self.gB("alpha_linear"))
+            self.colsum(d_raw[:, 3:], 1, self.gB("alpha_linear"))
         dz = self.head_grad(d_raw, 3)
         self.wgrad("rgb_linear", dz, HV, 3, W // 2)
         dHV = self.buf(M, W // 2)
@@ -355,7 +361,7 @@ class MipProposalNet(_Net):
     def backward(self, d_raw_density, acts, want_input_grad=False):
         """-> None, or with `want_input_grad` the fp32 gradient [M, Ew] w.r.t. the encoded samples."""
         H, M = self.H, d_raw_density.shape[0]
-        ops.colsum_f32(d_raw_density, 1, self.gB("density_layer"))
+        self.colsum(d_raw_density, 1, self.gB("density_layer"))
         dz = self.head_grad(d_raw_density, 1)
         xl = acts[-1][2]
         self.wgrad("density_layer", dz, xl, 1, H)
@@ -494,8 +500,8 @@ class MipNerfNet(_Net):
         H, g, cu, M = self.H, self.g, self.cu, d_raw_rgb.shape[0]
         dV = None
         DZE = self.buf(M, H * len(self.enc_layers)) if want_input_grad else None
-        ops.colsum_f32(d_raw_rgb, 3, self.gB("rgb_layer"))
-        ops.colsum_f32(d_raw_density, 1, self.gB("density_layer"))
+        self.colsum(d_raw_rgb, 3, self.gB("rgb_layer"))
+        self.colsum(d_raw_density, 1, self.gB("density_layer"))
         dz = self.head_grad(d_raw_rgb, 3)
         clast = cacts[-1][2]
         self.wgrad("rgb_layer", dz, clast, 3, cu)
@@ -522,7 +528,7 @@ class MipNerfNet(_Net):
             if d_raw_sem is None:
                 dS0.zero_()
             else:
-                ops.colsum_f32(d_raw_sem, self.sc, self.gB("semantic_layer.1"))
+                self.colsum(d_raw_sem, self.sc, self.gB("semantic_layer.1"))
                 dzs = self.head_grad(d_raw_sem, self.sc)
                 self.wgrad("semantic_layer.1", dzs, S0, self.sc, self.Hs)
                 self.dgrad("sem1", dzs, dzs.shape[1], dS0, self.Hs, mask=S0, colsum=self.gB("semantic_layer.0.layers.0"))
@@ -587,7 +593,7 @@ class ZipPropNet(_Net):
         """-> dF [P, Fw] (gradient w.r.t. the grid features, compute dtype)"""
         Fb, H1 = saved
         M = d_raw.shape[0]
-        ops.colsum_f32(d_raw, 1, self.gB("density_layer.2"))
+        self.colsum(d_raw, 1, self.gB("density_layer.2"))
         dz = self.head_grad(d_raw, 1)
         self.wgrad("density_layer.2", dz, H1, 1, self.H)
         dH1 = self.buf(M, self.H)
@@ -670,7 +676,7 @@ class ZipNerfNet(_Net):
         """-> dF [P, Fw].  d_raw_density [P, 1] or [P, 1 + C]: column 0 = d raw density, columns 1.. = d semantic logits."""
         Fb, H1, SB, H3 = saved
         M, B, Wd, g = d_raw_rgb.shape[0], self.Bw, self.Wd, self.g
-        ops.colsum_f32(d_raw_rgb, 3, self.gB("rgb_layer"))
+        self.colsum(d_raw_rgb, 3, self.gB("rgb_layer"))
         dz = self.head_grad(d_raw_rgb, 3)
         self.wgrad("rgb_layer", dz, H3, 3, Wd)
         DZ = self.buf(M, 2 * Wd + g)                                         # [dZ_lin0 | dZ_lin1 | d raw_density (+pad)]

@@ -60,8 +60,11 @@ def zero_page(device):
 
 
 # ------------------------------------------------------------------ GEMMs ----
-def linear_fwd(A, W, bias, Y, K, n_store, act, dt, out_f32=False, aux=None, colsum=None, variant=0):
-    """Y[:, :n_store] = act(A[:, :K] @ W[:, :K]^T + bias); A/W/Y are 2-D views (row stride = ld)."""
+def linear_fwd(A, W, bias, Y, K, n_store, act, dt, out_f32=False, aux=None, colsum=None, variant=0, deterministic=False):
+    """Y[:, :n_store] = act(A[:, :K] @ W[:, :K]^T + bias); A/W/Y are 2-D views (row stride = ld).  `deterministic`: the bias-gradient
+    partials (`colsum`) are folded in a fixed order."""
+    if deterministic:
+        variant |= 256
     _chk2d(A, _TORCH_DT[dt]); _chk2d(W, _TORCH_DT[dt]); _chk2d(Y, torch.float32 if out_f32 else _TORCH_DT[dt])
     M = A.shape[0]
     assert Y.shape[0] == M and A.shape[1] >= K and W.shape[1] >= K and Y.shape[1] >= n_store
@@ -92,10 +95,17 @@ def relu_bits_ok(A, W, Y, K, n_store, dt, variant, consumer=False):
             and A.stride(0) * 512 < (1 << 31) and W.stride(0) * 512 < (1 << 31) and mask_bits_words(A.shape[0], N) * 4 < (1 << 31))
 
 
-def linear_wgrad(dZ, X, dW, n_valid, k_valid, dt, variant=0):
-    """dW[:n_valid, :k_valid] += dZ^T @ X (fp32 atomics).  dZ [M,N], X [M,K] views, dW fp32 view."""
+def linear_wgrad(dZ, X, dW, n_valid, k_valid, dt, variant=0, deterministic=False):
+    """dW[:n_valid, :k_valid] += dZ^T @ X.  dZ [M,N], X [M,K] views, dW fp32 view.  Default: the M slices add with fp32 atomics (order
+    varies run to run); `deterministic`: they store partial tiles into a workspace that is folded in slice order (bit-reproducible)."""
     _chk2d(dZ, _TORCH_DT[dt]); _chk2d(X, _TORCH_DT[dt]); _chk2d(dW, torch.float32)
     assert dZ.shape[0] == X.shape[0] and dW.shape[0] >= n_valid and dW.shape[1] >= k_valid
+    if deterministic:
+        nws = _lib.query("snerf_linear_wgrad_ws_floats", dZ.shape[0], dZ.shape[1], X.shape[1], dZ.stride(0), X.stride(0), dt, variant)
+        ws = torch.empty(max(int(nws), 1), dtype=torch.float32, device=dZ.device)
+        _lib.call("snerf_linear_wgrad_det", _p(dZ), dZ.stride(0), _p(X), X.stride(0), _p(dW), dW.stride(0), _p(zero_page(dZ.device)),
+                  dZ.shape[0], dZ.shape[1], X.shape[1], n_valid, k_valid, dt, variant, _p(ws), ws.numel(), _stream())
+        return
     _lib.call("snerf_linear_wgrad", _p(dZ), dZ.stride(0), _p(X), X.stride(0), _p(dW), dW.stride(0),
               _p(zero_page(dZ.device)), dZ.shape[0], dZ.shape[1], X.shape[1], n_valid, k_valid, dt, variant, _stream())
 
@@ -340,9 +350,9 @@ def grad_clip_coef(g, grad_scale, max_norm):
     return out
 
 
-def colsum_f32(x, C, out):
+def colsum_f32(x, C, out, deterministic=False):
     _chk2d(x, torch.float32)
-    _lib.call("snerf_colsum_f32", _p(x), x.stride(0), x.shape[0], C, _p(out), _stream())
+    _lib.call("snerf_colsum_f32_det" if deterministic else "snerf_colsum_f32", _p(x), x.stride(0), x.shape[0], C, _p(out), _stream())
 
 
 def cast_pad(src, C, dst, Cpad, dt):

@@ -15,7 +15,7 @@ from oracle import mip as om
 _BITS = {}
 
 
-def linear_fwd(A, W, bias, Y, K, n_store, act, dt, out_f32=False, aux=None, colsum=None, variant=0):
+def linear_fwd(A, W, bias, Y, K, n_store, act, dt, out_f32=False, aux=None, colsum=None, variant=0, deterministic=False):
     assert W.shape[0] % 128 == 0 and K % (32 if dt == 0 else 64) == 0
     y = A[:, :K].float() @ W[:, :K].float().t()
     if bias is not None:
@@ -35,7 +35,7 @@ def linear_fwd(A, W, bias, Y, K, n_store, act, dt, out_f32=False, aux=None, cols
         colsum[:n_store] += y.sum(0)
 
 
-def linear_wgrad(dZ, X, dW, n_valid, k_valid, dt, variant=0):
+def linear_wgrad(dZ, X, dW, n_valid, k_valid, dt, variant=0, deterministic=False):
     dW[:n_valid, :k_valid] += (dZ.float().t() @ X.float())[:n_valid, :k_valid]
 
 
@@ -187,7 +187,7 @@ def grad_clip_coef(g, grad_scale, max_norm):
     return torch.tensor([min(max_norm / (norm + 1e-6), 1.0), norm], dtype=torch.float32)
 
 
-def colsum_f32(x, C, out):
+def colsum_f32(x, C, out, deterministic=False):
     out[:C] += x[:, :C].sum(0)
 
 

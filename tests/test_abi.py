@@ -11,7 +11,7 @@ from snerf_amd import _lib
 def test_header_parses_and_lists_entry_points():
     protos = _lib.parse_header()
     src = open(_lib.HEADER_PATH).read()
-    declared = set(re.findall(r"\bint\s+(snerf_\w+)\s*\(", re.sub(r"/\*.*?\*/", " ", src, flags=re.S)))
+    declared = set(re.findall(r"\b(?:int|long)\s+(snerf_\w+)\s*\(", re.sub(r"/\*.*?\*/", " ", src, flags=re.S)))
     assert declared == set(protos) and len(protos) >= 18
     for name in ("snerf_linear_fwd", "snerf_linear_wgrad", "snerf_mip_encode", "snerf_mip_resample", "snerf_classic_sample_pdf",
                  "snerf_mip_composite_fwd", "snerf_mip_composite_bwd", "snerf_classic_composite_fwd", "snerf_adam_step"):

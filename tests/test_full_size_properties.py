@@ -66,8 +66,11 @@ def test_path_a_properties_at_full_size():
     with torch.no_grad():
         ref = m32(rays, False, False, 0.)
     mse = float(((ref[1][0] - rgb1) ** 2).mean())
+    rel_d = (ref[1][1] - dist1).abs() / ref[1][1].abs()
+    print(f"MEASURED full-size bf16 vs f32: mse {mse:.3e} ({-10 * np.log10(mse):.1f} dB), depth rel err median {float(rel_d.median()):.3e} "
+          f"p99 {float(rel_d.quantile(0.99)):.3e} max {float(rel_d.max()):.3e}, rgb max abs {float((ref[1][0] - rgb1).abs().max()):.3e}")
     assert mse < 1e-6, mse                                        # > 60 dB
-    assert float(((ref[1][1] - dist1).abs() / ref[1][1].abs()).median()) < 2e-2
+    assert float(rel_d.median()) < 2e-2
 
 
 def test_train_step_at_full_size_is_finite_and_reduces_the_loss():
@@ -185,9 +188,11 @@ def test_captured_train_step_replays_like_the_eager_step():
     m1b, _ = eager()                                                  # the weight-gradient atomics make two eager runs differ as well
     m2, t2 = fresh()
     tg = tgt.clone()
-    t2.capture(rays, tg, td, None, randomized=False, warmup=2)        # 2 warm-up steps run eagerly inside capture()
+    t2.capture(rays, tg, td, None, randomized=False, warmup=2)        # the warm-up steps inside capture() must not train
+    assert t2.t == 0 and int(t2._step_dev) == 0 and torch.equal(m2.arena.flat, init), "capture() moved the parameters / the step count"
+    assert float(t2.m.abs().max()) == 0.0 and float(t2.v.abs().max()) == 0.0 and float(m2.arena.grad.abs().max()) == 0.0
     losses = []
-    for i in range(2, 5):
+    for i in range(5):
         if i == 3:
             tg.copy_(tgt2)                                            # new batch: copy into the captured tensor
         loss, _ = t2.replay()
@@ -199,4 +204,9 @@ def test_captured_train_step_replays_like_the_eager_step():
     diff = float((a - b).norm()) / moved
     assert moved > 0 and diff <= 2 * noise + 1e-3, (diff, noise)
     assert float((a - b).abs().max()) <= 2 * 5 * 5e-4 + 1e-6          # never more than the 5 steps' worth of sign flips
-    assert all(np.isfinite(losses)) and losses[1] != losses[0]
+    assert all(np.isfinite(losses)) and losses[3] != losses[2]
+    # the captured graph reads the learning rate from the device: a schedule keeps working after capture
+    before = m2.arena.flat.clone()
+    t2.lr = 0.0
+    t2.replay()
+    assert torch.equal(m2.arena.flat, before), "replay() ignored the updated learning rate"

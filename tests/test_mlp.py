@@ -108,3 +108,31 @@ def test_classic_net(backend, dt, W, tol):
     net.backward(d_raw.to(DEV), saved)
     worst = max((rel(arena.g[k], pr[k].grad), k) for k in sd)
     assert worst[0] < (5e-3 if dt == 0 else 0.25), f"worst gradient: {worst}"  # bf16: 8-bit mantissa through 12+ layers each way
+
+
+@pytest.mark.gpu
+def test_deterministic_mode_gives_bit_identical_gradients():
+    """weight / bias gradients normally land through fp32 atomics (order varies run to run); with
+    set_deterministic() the M slices' partial tiles are folded in a fixed order -- two backward passes agree bit for bit, and agree
+    with the atomic path to rounding."""
+    from snerf_amd import mipnerf
+    from oracle import common
+    torch.manual_seed(0)
+    m = mipnerf.MipNerfModel(n_samples=32, N_fine=33, no_warp_sample=0, ray_shape="cone", fn=1, radius=3., transform_idx=0, real=True, rgb_layer=3,
+                             hidden_layer=512, density_noise=0., max_deg_point=16, proposal_loss=True, compute="bf16")
+    rays = mipnerf.Rays(**{k: v.cuda() for k, v in common.synthetic_rays(2048, seed=3).items()})
+    tgt = torch.rand(2048, 3, device="cuda")
+
+    def grads():
+        for p in m.parameters():
+            p.grad = None
+        ret = m(rays, False, False, 0.)
+        (((ret[1][0] - tgt) ** 2).mean() + 0.05 * (1 / ret[0][1]).mean()).backward()
+        return torch.cat([p.grad.reshape(-1) for p in m.parameters()])
+    m.set_deterministic(True)
+    a, b = grads(), grads()
+    assert torch.equal(a, b), "deterministic mode must be bit-reproducible"
+    m.set_deterministic(False)
+    c = grads()
+    rel = float((a - c).norm() / c.norm())
+    assert float(c.norm()) > 0 and rel < 1e-5, rel
