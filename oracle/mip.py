@@ -293,7 +293,7 @@ def warp_resample_s(s_vals, weights, u, resample_padding: float = 0.01):
 def mipnerf_forward(p: dict, rays: dict, n_samples: int, n_fine: int, s_rand=None, u=None,
                     white_bg: bool = False, ray_shape: str = "cone", transform_idx: int = 0,
                     max_deg_point: int = 16, deg_view: int = 4, resample_padding: float = 0.01,
-                    density_noise0=None, density_noise1=None, return_aux: bool = False):
+                    density_noise0=None, density_noise1=None, return_aux: bool = False, s1_override=None):
     """MipNerfModel.forward, models.py:72-187 (warp branch, use_viewdirs, no
     appearance embedding).  ``u`` [N,n_fine] or [n_fine]; None = det_u(n_fine).
     Returns [[None, distance, acc, s_vals, weights], [rgb, distance, acc, semantic, s_vals, weights]]
@@ -316,6 +316,10 @@ def mipnerf_forward(p: dict, rays: dict, n_samples: int, n_fine: int, s_rand=Non
     if u is None:
         u = det_u(n_fine)
     s1, idx = warp_resample_s(s0, w0, u, resample_padding)
+    if s1_override is not None:
+        # teacher forcing for conditioning-aware gradient checks (tests only): level 1 evaluated at GIVEN fence posts -- those a
+        # reduced-precision run resampled -- so that both sides see identical sample positions (the posts carry no gradient)
+        s1 = s1_override
     m1, c1 = sample2enc(s1, o, d, r, near, far, ray_shape, transform_idx)
     enc1 = integrated_pos_enc(m1, c1, 0, max_deg_point)
     cond = pos_enc(rays["viewdirs"], 0, deg_view, True)
@@ -356,3 +360,22 @@ def mipnerf_param_shapes(hidden: int = 1024, rgb_layers: int = 3, prop_hidden: i
         out += [(f"proposal.layers.{i}.layers.0.weight", (prop_hidden, k)), (f"proposal.layers.{i}.layers.0.bias", (prop_hidden,))]
     out += [("proposal.density_layer.weight", (1, prop_hidden)), ("proposal.density_layer.bias", (1,))]
     return out
+
+
+# --------------------------------------------------------------------------
+# A16  render_image -- models.py:328-360 (eval.py:146)
+# --------------------------------------------------------------------------
+def render_image(p: dict, rays: dict, H: int, W: int, chunk: int, n_samples: int, n_fine: int, **kw):
+    """Chunked full-frame inference: the [H,W,.] ray grid is flattened, rendered in chunks of `chunk` rays (the last one ragged)
+    and the last level's (rgb, distance, acc) are concatenated and reshaped to the image (models.py:328-360; the reference's
+    reflect-padding of a chunk to a multiple of the device count is the identity for one device).
+    -> (rgb [H,W,3], distance [H,W], acc [H,W])"""
+    n = H * W
+    flat = {k: v.reshape(n, -1) for k, v in rays.items()}
+    cols = [[], [], []]
+    for i in range(0, n, chunk):
+        out = mipnerf_forward(p, {k: v[i:i + chunk] for k, v in flat.items()}, n_samples, n_fine, **kw)[-1]
+        for c, o in zip(cols, out[:3]):
+            c.append(o)
+    rgb, dist, acc = (torch.cat(c, 0) for c in cols)
+    return rgb.reshape(H, W, -1), dist.reshape(H, W), acc.reshape(H, W)

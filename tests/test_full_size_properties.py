@@ -69,8 +69,11 @@ def test_path_a_properties_at_full_size():
     rel_d = (ref[1][1] - dist1).abs() / ref[1][1].abs()
     print(f"MEASURED full-size bf16 vs f32: mse {mse:.3e} ({-10 * np.log10(mse):.1f} dB), depth rel err median {float(rel_d.median()):.3e} "
           f"p99 {float(rel_d.quantile(0.99)):.3e} max {float(rel_d.max()):.3e}, rgb max abs {float((ref[1][0] - rgb1).abs().max()):.3e}")
-    assert mse < 1e-6, mse                                        # > 60 dB
-    assert float(rel_d.median()) < 2e-2
+    # measured on MI355X (profiles/r2_a_bf16_bounds.txt): mse 4.2e-9 (83.7 dB), depth rel err median 2.0e-5 / p99 7.8e-5 / max 1.4e-4,
+    # rgb max abs 2.1e-4 -- the bounds below sit within 10 dB / 3x of the measurement
+    assert mse < 4.2e-8, mse                                      # > 73.7 dB
+    assert float(rel_d.median()) < 6e-5 and float(rel_d.quantile(0.99)) < 2.5e-4 and float(rel_d.max()) < 5e-4
+    assert float((ref[1][0] - rgb1).abs().max()) < 7e-4
 
 
 def test_train_step_at_full_size_is_finite_and_reduces_the_loss():

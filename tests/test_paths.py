@@ -56,8 +56,6 @@ def check_grads(named, ref_params, keys, compute, tol):
         else:
             rel = ((got - gref).norm() / (gref.norm() + 1e-12)).item()
             print(f"MEASURED bf16 grad {k}: rel L2 {rel:.3e}")
-            if k.startswith("mlp."):
-                continue  # level 1 sees bf16-perturbed resampled positions; its bf16 gradients are checked stage-isolated in tests/test_mlp.py
             assert rel < 2 * tol, f"grad {k}: relative L2 error {rel:.3e}"
 
 
@@ -249,19 +247,35 @@ def test_mipnerf_forward_vs_oracle(backend, compute, hidden, S0, P1, n, tol):
         print(f"MEASURED bf16 forward vs oracle: PSNR {psnr:.1f} dB, rgb max abs {float((ret[1][0].cpu() - ref[1][0]).abs().max()):.3e}, "
               f"acc max abs {float((ret[1][2].cpu() - ref[1][2]).abs().max()):.3e}, "
               f"distance rel max {float(((ret[1][1].cpu() - ref[1][1]).abs() / ref[1][1].abs()).max()):.3e}, w0 max abs {float((ret[0][4].cpu() - ref[0][4]).abs().max()):.3e}")
-        assert psnr > 35.0, f"bf16 PSNR vs fp32 oracle {psnr:.1f} dB"
+        # measured on MI355X (profiles/r2_a_bf16_bounds.txt): PSNR 95.2 dB, rgb max abs 3.8e-5, acc 4.2e-7, distance rel 2.5e-5, w0 8.3e-6;
+        # the bounds sit within 10 dB / 3-5x of that, so a regression of the bf16 path cannot hide behind them
+        if backend == "hip":
+            assert psnr > 85.0, f"bf16 PSNR vs fp32 oracle {psnr:.1f} dB"
+            assert float((ret[1][0].cpu() - ref[1][0]).abs().max()) < 2e-4 and float((ret[1][2].cpu() - ref[1][2]).abs().max()) < 3e-6
+            assert float(((ret[1][1].cpu() - ref[1][1]).abs() / ref[1][1].abs()).max()) < 1.5e-4 and float((ret[0][4].cpu() - ref[0][4]).abs().max()) < 5e-5
+        else:
+            assert psnr > 35.0, f"bf16 PSNR vs fp32 oracle {psnr:.1f} dB (emulated kernels: torch bf16 matmul roundings)"
 
 
 @pytest.mark.parametrize("compute,hidden,tol", [("f32", 64, 3e-4), ("bf16", 128, 8e-2)])
 def test_mipnerf_backward_vs_autograd(backend, compute, hidden, tol):
     from snerf_amd import mipnerf
     S0, P1, n = 24, 25, 36
-    sd = mip_params(hidden, 64)
+    # seeded N(0, 1.4^2 / fan_in) weights: the formula weights of the goldens are rank 2 (sin(a i + b j + c)), which makes every
+    # back-propagated signal a near-cancelling sum and amplifies bf16 rounding to O(1) relative errors in the early layers
+    sd = random_params(om.mipnerf_param_shapes(hidden=hidden, prop_hidden=64), 21, ("mlp.density_layer.bias", "proposal.density_layer.bias"))
     rays_c = common.synthetic_rays(n, seed=7)
     gg = torch.Generator().manual_seed(8)
     target, tdepth = torch.rand(n, 3, generator=gg), torch.rand(n, generator=gg) * 50 + 5
     pr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    ref = om.mipnerf_forward(pr, rays_c, S0, P1)
+    m = make_mip(hidden, 64, S0, P1, compute, sd)
+    rays = mipnerf.Rays(**{k: v.to(DEV) for k, v in rays_c.items()})
+    ret = m(rays, False, False, 0.)
+    # bf16: a bf16 rounding of a proposal weight moves a resampled fence post, which re-phases the 2^10..2^15 bands of the level-1
+    # encoding -- a conditioning property of the algorithm that would drown every level-1 gradient comparison.  The oracle is
+    # therefore evaluated AT the fence posts the bf16 run resampled (they carry no gradient: stop_level_grad), and then EVERY
+    # parameter gradient, the level-1 network's included, is held to the norm-wise bf16 bound.
+    ref = om.mipnerf_forward(pr, rays_c, S0, P1, s1_override=None if compute == "f32" else ret[1][4].detach().cpu())
 
     def loss_fn(ret, tgt, td):  # RGB MSE + disparity-L1 depth on both levels (loss_factory.py:5-11, 26-37) + a weights term
         l = ((ret[1][0] - tgt) ** 2).mean()
@@ -269,9 +283,6 @@ def test_mipnerf_backward_vs_autograd(backend, compute, hidden, tol):
         return l + 0.01 * (ret[0][4] ** 2).sum() + 0.01 * ret[1][2].mean()
     loss_ref = loss_fn([[None, ref[0][1], ref[0][2], ref[0][3], ref[0][4]], [ref[1][0], ref[1][1], ref[1][2], None, ref[1][4], ref[1][5]]], target, tdepth)
     loss_ref.backward()
-    m = make_mip(hidden, 64, S0, P1, compute, sd)
-    rays = mipnerf.Rays(**{k: v.to(DEV) for k, v in rays_c.items()})
-    ret = m(rays, False, False, 0.)
     loss = loss_fn(ret, target.to(DEV), tdepth.to(DEV))
     loss.backward()
     close(loss, loss_ref, tol, tol, "loss")
