@@ -323,6 +323,21 @@ int snerf_zip_encode_prop_fwd(const float* tdist, const float* origins, const fl
                               const float* b1, const float* w2, const float* b2, int hidden, int round_bf16, float* raw_density,
                               void* stream);
 
+/* ---- fused register-resident MLPs (csrc/fmlp.hip) ----------------------------------------------------------------------------
+ * One launch for a whole 256-wide network; activations stay in registers from the first layer to the heads, the weights stream
+ * through LDS as MFMA fragments.  wstream: n_frags x 1 KiB fragments in the kernel's consumption order, bias: n_blocks x 32 floats
+ * (both built by snerf_amd.mlp.fmlp_pack from the reference's state_dict tensors; layout in the kernel header).  bf16 operands,
+ * fp32 accumulation.
+ * snerf_fmlp_classic_fwd  = NeRF.forward behind run_network (s-nerf/model/run_nerf_helpers.py:103-126, 460-474) for D = 8, W = 256,
+ *   skips = [4], use_viewdirs: E [M, ldE] = embedded points (63 values, zero padded to 64), VE [M, ldVE] = embedded view directions
+ *   (27 -> 32) -> raw [M,4] = (rgb, sigma).  n_frags = 1184, n_blocks = 78.
+ * snerf_fmlp_proposal_fwd = proposal.forward (s-nerf/model/models.py:316-325), 4 x 256: E [M, ldE] = IPE (96) -> raw_density [M].
+ *   n_frags = 448, n_blocks = 33. */
+int snerf_fmlp_classic_fwd(const void* E, long ldE, const void* VE, long ldVE, const void* wstream, long n_frags, const float* bias,
+                           int n_blocks, float* raw, long M, void* stream);
+int snerf_fmlp_proposal_fwd(const void* E, long ldE, const void* wstream, long n_frags, const float* bias, int n_blocks,
+                            float* raw_density, long M, void* stream);
+
 /* ---- deterministic mode ("deterministic mode for parity tests") ------------------------------------------
  * The weight gradient normally lands in dW by fp32 atomics from the M slices (order varies run to run).  snerf_linear_wgrad_det makes
  * every slice store its partial tile into `ws` (snerf_linear_wgrad_ws_floats(...) floats) and folds them in slice order: bit-identical

@@ -1,0 +1,302 @@
+// Fused multi-layer MLP for the 256-wide networks of the path (gfx950 / CDNA4): the whole network in ONE kernel, activations
+// resident in REGISTERS from the first layer to the heads.
+//
+//   snerf_fmlp_classic_fwd  : NeRF 8 x 256 of the classic path (s-nerf/model/run_nerf_helpers.py:74-126 via run_network :460-474):
+//                             pts embedding (63) -> 8 x [Linear 256 + ReLU], cat([pts, h]) after layer 4 -> alpha, feature,
+//                             [feature | view embedding (27)] -> 128 ReLU -> rgb.  593 408 MAC per sample, 12 values out.
+//   snerf_fmlp_proposal_fwd : proposal MLP of the live mip path (s-nerf/model/models.py:299-325): IPE (96) -> 4 x [256 + ReLU] -> 1.
+//
+// Why: as separate GEMM launches these layers are HBM-bound (K = N = 256: 128 FLOP per byte of activation traffic; measured
+// 0.16 of the MFMA peak).  Here nothing but the encoded input (128 - 192 B) and the raw outputs (4 - 16 B) of a
+// sample ever touches HBM.
+//
+// How (MI355X-first, not a chain of tiled GEMMs):
+//  * a wave owns 32 samples (rows).  The MFMA runs "weights x activations": A operand = a 32 (outputs n) x 16 (k) block of W,
+//    B operand = 16 (k) x 32 (rows) of the activations, D[n][row] accumulates in 16 VGPRs per 32 outputs.  Lane (row = lane & 31,
+//    half = lane >> 5) then holds, for ITS row, outputs n = (r & 3) + 8 (r >> 2) + 4 half, r = 0..15 -- and the B operand of the
+//    next layer wants, from that same lane, 8 reduction indices of that same row.  So after bias + ReLU + bf16 rounding the
+//    accumulator registers r = 0..7 / 8..15 ARE the next layer's B fragments for two 16-wide k-steps; the only cost is that the
+//    k-step's 16 reduction indices appear in the order {0-3, 8-11 | 4-7, 12-15} (lane halves), which the host bakes into the
+//    packing of W (fmlp_perm in snerf_amd/mlp.py).  No LDS round trip, no transposition, no shuffles between layers.
+//  * the weights are shared by the 8 waves of a workgroup (256 samples per tile): they stream through LDS as 1 KiB MFMA fragments
+//    in exactly the order the code consumes them (packed once per parameter version on the host), 16 fragments per chunk, a ring
+//    of chunks filled by `global_load_lds` (LDS-DMA) several chunks ahead; one s_barrier per chunk (16 MFMAs per wave) is the only
+//    synchronisation.  A fragment is 64 lanes x 16 B contiguous: the DMA image is lane-linear and the ds_read_b128 of it is
+//    conflict free without any swizzle.  The stream is continuous over the tiles a (persistent) workgroup walks.
+//  * biases live in LDS for the whole kernel; an accumulator is INITIALISED with its bias by four broadcast ds_read_b128.
+//  * per sample-tile the HBM traffic is the input fragments (16 B loads straight into the B-operand registers) and the raw head
+//    outputs; the 1.2 MB weight stream of a tile comes from L2.
+//
+// Bound: MFMA (2.5 PFLOP/s dense bf16).  Algorithmic work: classic 1 186 816 FLOP / sample, proposal 442 880 FLOP / sample; the
+// padded work the kernel executes is 1 212 416 / 458 752 (K and N rounded up to the 16 / 32 of the MFMA shape).
+#include "common.h"
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+#define FM_CHUNK 16                 // fragments per ring slot
+#define FM_SLOT (FM_CHUNK * 1024)   // bytes per ring slot
+#define FM_RING 6                   // ring slots (96 KiB): five chunks in flight ahead of the one being consumed
+#define FM_BIAS_MAX 128             // n-blocks of 32 outputs whose biases fit the LDS table (16 KiB)
+#define FM_LOOK 4                   // weight fragments fetched from LDS ahead of the MFMA that uses them (a register queue)
+
+struct FmlpArgs {
+  const __bf16* E;  long ldE;       // encoded input rows [M, ldE] (pts embedding 63 -> 64, or IPE 96)
+  const __bf16* VE; long ldVE;      // view-direction embedding rows [M, ldVE] (27 -> 32), classic network only
+  const char* wstream;              // n_chunks x 16 KiB of MFMA fragments in consumption order
+  const float* bias;                // n_blocks x 32 floats in consumption order
+  float* out;                       // classic: raw [M,4] = (rgb, sigma); proposal: raw density [M]
+  long M;
+  int tiles, n_chunks, n_blocks;
+};
+
+// ---- the weight stream ---------------------------------------------------------------------------------------------------------
+// g = chunks consumed so far by this workgroup (all tiles); chunk g of the stream lives in ring slot g % FM_RING and holds stream
+// chunk g % n_chunks.  Every wave DMAs 2 of the 16 fragments of a chunk.
+struct WStream {
+  const char* src;          // this lane's source pointer inside chunk 0 (piece 2 * wave, + lane * 16)
+  unsigned ring;            // LDS byte address of the ring
+  unsigned my_piece;        // wave * 2048
+  unsigned slot_off;        // byte offset of the slot being consumed
+  int fill_slot, fill_chunk;  // ring slot / stream chunk of the next DMA
+  int n_chunks;
+};
+
+__device__ __forceinline__ void ws_issue(WStream& w, char* smem) {
+  const char* g = w.src + (long)w.fill_chunk * FM_SLOT;
+  char* dst = smem + w.fill_slot * FM_SLOT + w.my_piece;
+  __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)dst, 16, 0, 0);
+  __builtin_amdgcn_global_load_lds((gbl_ptr_t)(g + 1024), (lds_ptr_t)(dst + 1024), 16, 0, 0);
+  w.fill_slot = w.fill_slot + 1 == FM_RING ? 0 : w.fill_slot + 1;
+  w.fill_chunk = w.fill_chunk + 1 == w.n_chunks ? 0 : w.fill_chunk + 1;
+}
+
+// chunk boundary: the chunk about to be read has landed for every wave, the chunk just finished is free for the DMA.
+// vmcnt(2 (FM_RING - 2)): of this wave's pieces only those of the FM_RING - 2 youngest chunks may still be in flight, i.e. the
+// pieces of the chunk we are about to read are in LDS (loads retire in order; other loads / stores in flight only make the wait
+// stricter).  lgkmcnt(0): this wave's fragment reads of the finished chunk have returned.  The barrier then (a) extends the first
+// fact to the other waves' pieces and (b) the second to the other waves' reads of the slot that is refilled right after it.
+// One volatile asm with a memory clobber: no LDS access of the compiler's may move across it.
+__device__ __forceinline__ void ws_advance(WStream& w, char* smem) {
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(2 * (FM_RING - 2)) : "memory");
+  ws_issue(w, smem);                                    // chunk g + FM_RING - 1 into the slot chunk g - 1 occupied
+  w.slot_off = w.slot_off + FM_SLOT == FM_RING * FM_SLOT ? 0 : w.slot_off + FM_SLOT;
+}
+
+// ---- building blocks -----------------------------------------------------------------------------------------------------------
+struct Ctx {
+  char* smem;
+  WStream ws;
+  const char* frag_base;   // ring + lane * 16
+  const char* bias_lds;    // bias table + (lane >> 5) * 16
+  int f;                   // fragments consumed in this tile (compile-time after unrolling)
+  int nb;                  // n-blocks consumed in this tile
+  bf16x8 q[FM_LOOK];       // fragments f .. f + FM_LOOK - 1, already on their way from LDS
+};
+
+// Next weight fragment (A operand: 32 outputs x 16 reduction indices).  The ds_read of fragment f + FM_LOOK is issued when
+// fragment f is handed out, so FM_LOOK - 1 MFMAs (and the partner wave's) cover the LDS latency; the queue runs across blocks,
+// layers and tiles (the stream is one sequence).  The chunk boundary is taken when the READ-AHEAD crosses it.
+__device__ __forceinline__ bf16x8 next_frag(Ctx& c) {
+  const bf16x8 w = c.q[c.f % FM_LOOK];
+  const int g = c.f + FM_LOOK;
+  if ((g & (FM_CHUNK - 1)) == 0) ws_advance(c.ws, c.smem);
+  c.q[c.f % FM_LOOK] = *(const bf16x8*)(c.frag_base + c.ws.slot_off + (g & (FM_CHUNK - 1)) * 1024);
+  ++c.f;
+  return w;
+}
+
+// accumulator of one 32-output block, initialised with its bias: lane (row, half) owns outputs 8 q + 4 half + e
+__device__ __forceinline__ f32x16 acc_init(Ctx& c) {
+  f32x16 acc;
+  const char* a = c.bias_lds + c.nb * 128;
+  ++c.nb;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 b = *(const f32x4*)(a + q * 32);
+    acc[4 * q + 0] = b[0]; acc[4 * q + 1] = b[1]; acc[4 * q + 2] = b[2]; acc[4 * q + 3] = b[3];
+  }
+  return acc;
+}
+
+template <int NK>
+__device__ __forceinline__ void mac(Ctx& c, f32x16& acc, const bf16x8 (&in)[NK]) {
+#pragma unroll
+  for (int s = 0; s < NK; ++s) {
+    const bf16x8 w = next_frag(c);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, in[s], acc, 0, 0, 0);
+  }
+}
+
+// accumulator -> the two B fragments (k-steps 2 j, 2 j + 1) of the next layer
+typedef unsigned fm_u32x4 __attribute__((ext_vector_type(4)));
+template <bool RELU>
+__device__ __forceinline__ void to_frags(const f32x16& acc, bf16x8& lo, bf16x8& hi) {
+  typedef __attribute__((ext_vector_type(8))) float f32x8;
+  const f32x8 a = {acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6], acc[7]};
+  const f32x8 b = {acc[8], acc[9], acc[10], acc[11], acc[12], acc[13], acc[14], acc[15]};
+  lo = __builtin_convertvector(a, bf16x8);               // v_cvt_pk_bf16_f32: two values per instruction
+  hi = __builtin_convertvector(b, bf16x8);
+  if (RELU) {
+    // ReLU on the rounded value (rounding is monotone and keeps the sign, so round-then-clamp == clamp-then-round): a bf16 is
+    // negative iff its 16 bits are a negative int16, so a packed signed max with 0 clamps two values per instruction (-0 -> +0).
+    // Written as asm on the packed dwords: expressed as a vector max of the bit-cast, hipcc converts every value separately
+    // and re-packs them with v_perm_b32 (2.5x the instructions).
+    fm_u32x4 ul = __builtin_bit_cast(fm_u32x4, lo), uh = __builtin_bit_cast(fm_u32x4, hi);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      asm("v_pk_max_i16 %0, %1, 0" : "=v"(ul[i]) : "v"(ul[i]));
+      asm("v_pk_max_i16 %0, %1, 0" : "=v"(uh[i]) : "v"(uh[i]));
+    }
+    lo = __builtin_bit_cast(bf16x8, ul);
+    hi = __builtin_bit_cast(bf16x8, uh);
+  }
+}
+
+// out[32 NB] = act(W . in + b): NB blocks of 32 outputs, one input segment
+template <int NK, int NB, bool RELU>
+__device__ __forceinline__ void dense(Ctx& c, const bf16x8 (&in)[NK], bf16x8 (&out)[2 * NB]) {
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    f32x16 acc = acc_init(c);
+    mac<NK>(c, acc, in);
+    to_frags<RELU>(acc, out[2 * j], out[2 * j + 1]);
+  }
+}
+
+// two input segments (skip connections / concatenations: the cat is never formed)
+template <int NK0, int NK1, int NB, bool RELU>
+__device__ __forceinline__ void dense2(Ctx& c, const bf16x8 (&in0)[NK0], const bf16x8 (&in1)[NK1], bf16x8 (&out)[2 * NB]) {
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    f32x16 acc = acc_init(c);
+    mac<NK0>(c, acc, in0);
+    mac<NK1>(c, acc, in1);
+    to_frags<RELU>(acc, out[2 * j], out[2 * j + 1]);
+  }
+}
+
+// input fragments straight from HBM: lane (row, half) reads the 16 bytes [16 s + 8 half, +8) of its row (natural k order)
+template <int NK>
+__device__ __forceinline__ void load_rows(const __bf16* p, long ld, long row, int half, bf16x8 (&out)[NK]) {
+  const __bf16* q = p + row * ld + half * 8;
+#pragma unroll
+  for (int s = 0; s < NK; ++s) out[s] = *(const bf16x8*)(q + 16 * s);
+}
+
+#define FMLP_CLASSIC 0
+#define FMLP_PROPOSAL 1
+
+template <int NET>
+__global__ __launch_bounds__(512) void fmlp_kernel(FmlpArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5;
+  float* bias_tab = (float*)(smem + FM_RING * FM_SLOT);
+
+  Ctx c;
+  c.smem = smem;
+  c.ws.src = a.wstream + wave * 2048 + lane * 16;
+  c.ws.ring = (unsigned)(size_t)smem;
+  c.ws.my_piece = wave * 2048;
+  c.ws.slot_off = (FM_RING - 1) * FM_SLOT;              // "chunk -1": the first boundary advances to slot 0
+  c.ws.fill_slot = 0;
+  c.ws.fill_chunk = 0;
+  c.ws.n_chunks = a.n_chunks;
+  c.frag_base = smem + lane * 16;
+  c.bias_lds = (const char*)bias_tab + half * 16;
+
+  // prologue: biases into LDS (plain stores), the first FM_RING - 1 chunks of the stream into the ring
+  for (int i = tid; i < a.n_blocks * 32; i += 512) bias_tab[i] = a.bias[i];
+#pragma unroll
+  for (int i = 0; i < FM_RING - 1; ++i) ws_issue(c.ws, smem);
+  // first boundary: chunk 0 has landed for everybody (and the bias stores are visible); start the fragment queue
+  ws_advance(c.ws, smem);
+#pragma unroll
+  for (int i = 0; i < FM_LOOK; ++i) c.q[i] = *(const bf16x8*)(c.frag_base + c.ws.slot_off + i * 1024);
+
+  for (int tile = blockIdx.x; tile < a.tiles; tile += gridDim.x) {
+    c.f = 0;
+    c.nb = 0;
+    long row = (long)tile * 256 + wave * 32 + (lane & 31);
+    const bool row_ok = row < a.M;
+    row = row_ok ? row : a.M - 1;                       // tail rows: compute on a valid row, store nothing
+
+    if constexpr (NET == FMLP_CLASSIC) {
+      bf16x8 e[4], ve[2], p[16], q[16];
+      load_rows<4>(a.E, a.ldE, row, half, e);
+      load_rows<2>(a.VE, a.ldVE, row, half, ve);
+      dense<4, 8, true>(c, e, p);                       // pts_linears.0
+      dense<16, 8, true>(c, p, q);                      // .1
+      dense<16, 8, true>(c, q, p);                      // .2
+      dense<16, 8, true>(c, p, q);                      // .3
+      dense<16, 8, true>(c, q, p);                      // .4  (skip: the next layer reads cat([pts, h]))
+      dense2<4, 16, 8, true>(c, e, p, q);               // .5
+      dense<16, 8, true>(c, q, p);                      // .6
+      dense<16, 8, true>(c, p, q);                      // .7
+      f32x16 alpha = acc_init(c);                       // alpha_linear: output 0 of one block
+      mac<16>(c, alpha, q);
+      const float sigma = alpha[0];
+      dense<16, 8, false>(c, q, p);                     // feature_linear (no activation)
+      bf16x8 hv[8];
+      dense2<16, 2, 4, true>(c, p, ve, hv);             // views_linears.0 on cat([feature, views])
+      f32x16 rgb = acc_init(c);                         // rgb_linear: outputs 0..2
+      mac<8>(c, rgb, hv);
+      if (row_ok && half == 0) {
+        const f32x4 o = {rgb[0], rgb[1], rgb[2], sigma};
+        *(f32x4*)(a.out + row * 4) = o;
+      }
+    } else {
+      bf16x8 e[6], p[16], q[16];
+      load_rows<6>(a.E, a.ldE, row, half, e);
+      dense<6, 8, true>(c, e, p);                       // layers.0
+      dense<16, 8, true>(c, p, q);
+      dense<16, 8, true>(c, q, p);
+      dense<16, 8, true>(c, p, q);
+      f32x16 d = acc_init(c);                           // density_layer
+      mac<16>(c, d, q);
+      if (row_ok && half == 0) a.out[row] = d[0];
+    }
+    // the fragment count of a network pass is a whole number of chunks (the host pads the stream), so the next tile starts on a
+    // chunk boundary again -- and the queue already holds its first FM_LOOK fragments
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the read-ahead before the LDS is released
+}
+
+template <int NET>
+static int fmlp_launch(const FmlpArgs& a, int expect_frags, int expect_blocks, long n_frags, void* stream) {
+  if (a.M <= 0) return SNERF_OK;
+  if (n_frags != expect_frags || a.n_blocks != expect_blocks || a.n_blocks > FM_BIAS_MAX || (n_frags % FM_CHUNK) != 0) return SNERF_ERR_ARG;
+  if (a.E == nullptr || a.wstream == nullptr || a.bias == nullptr || a.out == nullptr) return SNERF_ERR_ARG;
+  if ((a.ldE % 8) != 0 || (((uintptr_t)a.E) & 15) || (((uintptr_t)a.wstream) & 15)) return SNERF_ERR_ARG;
+  constexpr int LDS = FM_RING * FM_SLOT + FM_BIAS_MAX * 128;
+  static bool attr_set = false;
+  static int n_cu = 256;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)fmlp_kernel<NET>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      n_cu = prop.multiProcessorCount;
+    attr_set = true;
+  }
+  const int grid = a.tiles < n_cu ? a.tiles : n_cu;
+  hipLaunchKernelGGL(fmlp_kernel<NET>, dim3(grid), dim3(512), LDS, (hipStream_t)stream, a);
+  return snerf_check_launch();
+}
+
+extern "C" int snerf_fmlp_classic_fwd(const void* E, long ldE, const void* VE, long ldVE, const void* wstream, long n_frags, const float* bias,
+                                      int n_blocks, float* raw, long M, void* stream) {
+  if (VE == nullptr || (ldVE % 8) != 0 || (((uintptr_t)VE) & 15) || (((uintptr_t)raw) & 15)) return M <= 0 ? SNERF_OK : SNERF_ERR_ARG;
+  FmlpArgs a{(const __bf16*)E, ldE, (const __bf16*)VE, ldVE, (const char*)wstream, bias, raw, M, (int)((M + 255) / 256), (int)(n_frags / FM_CHUNK), n_blocks};
+  // 8 x 4 + 4 x 128 + 160 + 2 x 128 (trunk) + 16 (alpha) + 128 (feature) + 72 (views) + 8 (rgb) fragments; 64 + 1 + 8 + 4 + 1 blocks
+  return fmlp_launch<FMLP_CLASSIC>(a, 1184, 78, n_frags, stream);
+}
+
+extern "C" int snerf_fmlp_proposal_fwd(const void* E, long ldE, const void* wstream, long n_frags, const float* bias, int n_blocks,
+                                       float* raw_density, long M, void* stream) {
+  FmlpArgs a{(const __bf16*)E, ldE, nullptr, 0, (const char*)wstream, bias, raw_density, M, (int)((M + 255) / 256), (int)(n_frags / FM_CHUNK), n_blocks};
+  // 8 x 6 + 3 x 128 + 16 fragments; 32 + 1 blocks
+  return fmlp_launch<FMLP_PROPOSAL>(a, 448, 33, n_frags, stream);
+}

@@ -71,6 +71,50 @@ def _w2(t):
     return t if t.dim() == 2 else t.view(1, -1)
 
 
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Weight stream of the fused register-resident MLP kernels (csrc/fmlp.hip)
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Order in which the 16 reduction indices of a k-step sit in the lanes when the B operand of an MFMA is the previous layer's
+# accumulator (lane half 0 holds outputs {0-3, 8-11}, lane half 1 {4-7, 12-15} of every 16): position p of the fragment carries
+# logical index FMLP_PERM[p].  Layers fed from memory keep the natural order.
+FMLP_PERM = (0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15)
+FMLP_CHUNK = 16
+
+
+def fmlp_pack(layers, device):
+    """layers = [(W fp32 [N,K], bias fp32 [N] or None, segments)] in the order the kernel consumes them, segments =
+    [(first weight column, columns, from_accumulator)] in the order of the kernel's input segments.
+    -> (stream bf16 [n_frags, 512]: 1 KiB MFMA A-operand fragments -- lane (n = lane & 31, half = lane >> 5) holds the 8 reduction
+    positions 8 half .. 8 half + 7 of output n of its 32-output block -- block by block, k-step by k-step, padded to whole chunks;
+    bias fp32 [n_blocks * 32])."""
+    perm = torch.tensor(FMLP_PERM, device=device)
+    frags, biases = [], []
+    for W, b, segs in layers:
+        W = _w2(W).detach().to(device, torch.float32)
+        N = W.shape[0]
+        NB = (N + 31) // 32
+        per_seg = []
+        for c0, cnt, from_acc in segs:
+            ks = (cnt + 15) // 16
+            Ws = torch.zeros(NB * 32, ks * 16, dtype=torch.float32, device=device)
+            Ws[:N, :cnt] = W[:, c0:c0 + cnt]
+            Ws = Ws.view(NB * 32, ks, 16)
+            if from_acc:
+                Ws = Ws[:, :, perm]
+            # [NB, 32 n, ks, 2 halves, 8] -> [NB, ks, half, n, 8]: one fragment = 64 lanes x 8 values, lane = half * 32 + n
+            per_seg.append(Ws.reshape(NB, 32, ks, 2, 8).permute(0, 2, 3, 1, 4).reshape(NB, ks, 512))
+        frags.append(torch.cat(per_seg, 1).reshape(-1, 512))
+        bb = torch.zeros(NB * 32, dtype=torch.float32, device=device)
+        if b is not None:
+            bb[:N] = b.detach().to(device, torch.float32).reshape(-1)
+        biases.append(bb)
+    stream = torch.cat(frags, 0)
+    pad = (-stream.shape[0]) % FMLP_CHUNK
+    if pad:
+        stream = torch.cat([stream, torch.zeros(pad, 512, device=device)], 0)
+    return stream.to(torch.bfloat16).contiguous(), torch.cat(biases).contiguous()
+
+
 class _Net:
     """Shared machinery: packing, buffer helpers, layer calls."""
 
@@ -206,6 +250,7 @@ class ClassicNeRFNet(_Net):
         self.D, self.Wd, self.ic, self.icv, self.skip = D, W, input_ch, input_ch_views, skips[0]
         self.Pw, self.Vw = roundup(input_ch, self.g), roundup(input_ch_views, self.g)
         self.alpha_head = bool(alpha_head)
+        self.fused = True                 # inference through the fused register-resident kernel where it applies (fused_ok)
 
     @staticmethod
     def param_shapes(D=8, W=256, input_ch=63, input_ch_views=27, skips=(4,), alpha_head=True):
@@ -243,8 +288,48 @@ class ClassicNeRFNet(_Net):
                 n = f"pts_linears.{i}"
                 self._pack_dgrad(n, [n], ic if i == self.skip + 1 else 0, W)
 
+    def fused_ok(self):
+        """the register-resident fused kernel (csrc/fmlp.hip) covers the S-NeRF configuration: bf16, 8 x 256, skip after layer 4,
+        63 + 27 input channels, alpha head"""
+        return (self.fused and self.dt == ops.BF16 and self.D == 8 and self.Wd == 256 and self.skip == 4 and self.ic == 63 and self.icv == 27
+                and self.alpha_head)
+
+    def _pack_fused(self):
+        W, ic = self.Wd, self.ic
+        L = []
+        for i in range(self.D):
+            n = f"pts_linears.{i}"
+            if i == 0:
+                segs = [(0, ic, False)]
+            elif i == self.skip + 1:
+                segs = [(0, ic, False), (ic, W, True)]               # cat([input_pts, h]): pts from memory, h from the accumulators
+            else:
+                segs = [(0, W, True)]
+            L.append((self.W(n), self.B(n), segs))
+        L.append((self.W("alpha_linear"), self.B("alpha_linear"), [(0, W, True)]))
+        L.append((self.W("feature_linear"), self.B("feature_linear"), [(0, W, True)]))
+        L.append((self.W("views_linears.0"), self.B("views_linears.0"), [(0, W, True), (W, self.icv, False)]))
+        L.append((self.W("rgb_linear"), self.B("rgb_linear"), [(0, W // 2, True)]))
+        self.fstream, self.fbias = fmlp_pack(L, self.dev)
+
+    def forward_fused(self, pts, viewdirs, S):
+        """Inference: embedding kernel + ONE fused kernel for the whole network (activations never leave the registers)."""
+        v = self.version_fn()
+        if getattr(self, "_fused_version", None) != v:
+            with torch.no_grad():
+                self._pack_fused()
+            self._fused_version = v
+        M = pts.shape[0]
+        E, VE = self.buf(M, 64), self.buf(M, 64)
+        ops.classic_embed(pts, viewdirs, S, (self.ic - 3) // 6, (self.icv - 3) // 6, E, None, 64, VE, 64, self.dt)
+        OUT = self.buf(M, 4, f32=True)
+        ops.fmlp_classic_fwd(E, VE, self.fstream, self.fbias, OUT)
+        return OUT
+
     def forward(self, pts, viewdirs, S, keep: bool):
         """pts [M,3] fp32, viewdirs [N,3] -> raw [M,4] fp32 (+ saved activations when keep)."""
+        if not keep and self.fused_ok():
+            return self.forward_fused(pts, viewdirs, S), None
         self.ensure_packed(keep)
         M, W, Pw = pts.shape[0], self.Wd, self.Pw
         E = self.buf(M, Pw)
@@ -324,6 +409,7 @@ class MipProposalNet(_Net):
         super().__init__(arena, prefix, dt, variant)
         assert hidden % self.g == 0
         self.H, self.L, self.fd, self.Ew = hidden, n_layers, feature_dim, roundup(feature_dim, self.g)
+        self.fused = True                 # inference through the fused register-resident kernel where it applies (fused_ok)
 
     @staticmethod
     def param_shapes(hidden=256, n_layers=4, feature_dim=96):
@@ -343,8 +429,26 @@ class MipProposalNet(_Net):
             self._pack_dgrad("density", ["density_layer"], 0, self.H)
             self._pack_dgrad_cols("enc", [("layers.0.layers.0", 0)], self.fd)
 
+    def fused_ok(self):
+        return self.fused and self.dt == ops.BF16 and self.H == 256 and self.L == 4 and self.fd == 96
+
+    def forward_fused(self, E):
+        v = self.version_fn()
+        if getattr(self, "_fused_version", None) != v:
+            with torch.no_grad():
+                L = [(self.W(f"layers.{i}.layers.0"), self.B(f"layers.{i}.layers.0"), [(0, self.fd if i == 0 else self.H, i > 0)])
+                     for i in range(self.L)]
+                L.append((self.W("density_layer"), self.B("density_layer"), [(0, self.H, True)]))
+                self.fstream, self.fbias = fmlp_pack(L, self.dev)
+            self._fused_version = v
+        out = self.buf(E.shape[0], 1, f32=True)
+        ops.fmlp_proposal_fwd(E, self.fstream, self.fbias, out)
+        return out
+
     def forward(self, E, keep: bool):
         """E [M, Ew] encoded samples (compute dtype) -> raw density [M,1] fp32."""
+        if not keep and self.fused_ok():
+            return self.forward_fused(E), None
         self.ensure_packed(keep)
         M, H = E.shape[0], self.H
         acts, x, k = [], E, self.Ew

@@ -110,6 +110,26 @@ def linear_wgrad(dZ, X, dW, n_valid, k_valid, dt, variant=0, deterministic=False
               _p(zero_page(dZ.device)), dZ.shape[0], dZ.shape[1], X.shape[1], n_valid, k_valid, dt, variant, _stream())
 
 
+# ------------------------------------------------------------ fused MLPs ----
+def fmlp_classic_fwd(E, VE, stream, bias, raw):
+    """The whole classic NeRF 8 x 256 network in one launch (csrc/fmlp.hip): E [M,>=64] / VE [M,>=32] bf16 embeddings, `stream` /
+    `bias` from mlp.fmlp_pack -> raw [M,4] fp32."""
+    _chk2d(E, torch.bfloat16); _chk2d(VE, torch.bfloat16); _chk2d(raw, torch.float32)
+    assert stream.dtype == torch.bfloat16 and stream.is_contiguous() and bias.dtype == torch.float32 and raw.is_contiguous() and raw.shape[1] == 4
+    assert E.shape[1] >= 64 and VE.shape[1] >= 32 and VE.shape[0] == E.shape[0] == raw.shape[0]
+    _lib.call("snerf_fmlp_classic_fwd", _p(E), E.stride(0), _p(VE), VE.stride(0), _p(stream), stream.shape[0], _p(bias), bias.numel() // 32,
+              _p(raw), E.shape[0], _stream())
+
+
+def fmlp_proposal_fwd(E, stream, bias, raw_density):
+    """The proposal MLP 96 -> 4 x 256 -> 1 in one launch: E [M,>=96] bf16 IPE rows -> raw density [M,1] fp32."""
+    _chk2d(E, torch.bfloat16)
+    assert stream.dtype == torch.bfloat16 and stream.is_contiguous() and bias.dtype == torch.float32 and E.shape[1] >= 96
+    assert raw_density.dtype == torch.float32 and raw_density.is_contiguous() and raw_density.numel() == E.shape[0]
+    _lib.call("snerf_fmlp_proposal_fwd", _p(E), E.stride(0), _p(stream), stream.shape[0], _p(bias), bias.numel() // 32, _p(raw_density),
+              E.shape[0], _stream())
+
+
 # --------------------------------------------------------------- encoders ----
 def classic_embed(pts, viewdirs, S, L, Lv, dst1, dst2, w_pts, dstv, w_views, dt):
     pts = _f32c(pts); M = pts.shape[0]

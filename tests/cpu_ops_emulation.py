@@ -406,11 +406,80 @@ def classic_ray_batch(H, W, focal, cx, cy, c2w, c2w_static, rays_o, rays_d, n, n
     return rows.contiguous()
 
 
+# ---- fused register-resident MLPs (csrc/fmlp.hip): a model of the kernel's fragment data flow ---------------------------------
+# An activation is a list of k-steps [M, 16] whose 16 positions are the MFMA's reduction slots (lane half h, element e -> 8 h + e).
+# Inputs loaded from memory fill them in natural order; a layer's accumulator block (32 outputs, natural order n) becomes two
+# k-steps whose position p carries output P[p] / 16 + P[p] -- exactly what the lanes hold (see the kernel header).
+_P = torch.tensor([0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15])
+
+
+class _FStream:
+    def __init__(self, stream, bias):
+        self.s, self.b, self.f, self.nb = stream.float(), bias, 0, 0
+
+    def frag(self):                                  # [32 n, 16 positions]: lane = half * 32 + n holds positions 8 half .. +7
+        w = self.s[self.f].view(2, 32, 8).permute(1, 0, 2).reshape(32, 16)
+        self.f += 1
+        return w
+
+    def block(self, segs, relu, to_frags=True):
+        acc = self.b[self.nb * 32:(self.nb + 1) * 32].clone()[None, :].expand(segs[0][0].shape[0], 32).clone()
+        self.nb += 1
+        for seg in segs:
+            for x in seg:
+                acc = acc + x @ self.frag().t()
+        if not to_frags:
+            return acc
+        y = acc.to(torch.bfloat16).float()
+        if relu:
+            y = torch.relu(y)
+        return [y[:, _P], y[:, 16 + _P]]
+
+    def dense(self, segs, nblocks, relu):
+        out = []
+        for _ in range(nblocks):
+            out += self.block(segs, relu)
+        return out
+
+
+def _rows_to_ksteps(X, nk):
+    return [X[:, 16 * s:16 * s + 16].float() for s in range(nk)]
+
+
+def fmlp_classic_fwd(E, VE, stream, bias, raw):
+    assert stream.shape[0] == 1184 and bias.numel() == 78 * 32
+    st = _FStream(stream, bias)
+    e, ve = _rows_to_ksteps(E, 4), _rows_to_ksteps(VE, 2)
+    p = st.dense([e], 8, True)
+    for _ in range(4):
+        p = st.dense([p], 8, True)
+    p = st.dense([e, p], 8, True)
+    p = st.dense([p], 8, True)
+    q = st.dense([p], 8, True)
+    sigma = st.block([q], False, to_frags=False)[:, 0]
+    feat = st.dense([q], 8, False)
+    hv = st.dense([feat, ve], 4, True)
+    rgb = st.block([hv], False, to_frags=False)[:, :3]
+    assert st.f == 1184 and st.nb == 78
+    raw[:, :3] = rgb
+    raw[:, 3] = sigma
+
+
+def fmlp_proposal_fwd(E, stream, bias, raw_density):
+    assert stream.shape[0] == 448 and bias.numel() == 33 * 32
+    st = _FStream(stream, bias)
+    p = st.dense([_rows_to_ksteps(E, 6)], 8, True)
+    for _ in range(3):
+        p = st.dense([p], 8, True)
+    raw_density.view(-1)[:] = st.block([p], False, to_frags=False)[:, 0]
+    assert st.f == 448 and st.nb == 33
+
+
 def adam_step_dev(p, g, m, v, lr, b1, b2, eps, step_dev, grad_scale=1.0, zero_grad=True, **kw):
     adam_step(p, g, m, v, lr, b1, b2, eps, 0, grad_scale, zero_grad, step_dev=step_dev, **kw)
 
 
-_NAMES = ["adam_step_dev", "grad_clip_coef", "classic_get_rays", "classic_ndc_rays", "classic_ray_batch", "zip_encode_prop_fwd", "mip_encode_bwd", "mip_viewenc_bwd", "hash_decay", "zip_percentiles", "zip_pixels_to_rays", "zip_loss_tail", "semantic_composite_fwd", "semantic_composite_bwd", "zip_resample", "zip_encode_fwd", "zip_encode_bwd", "zip_composite_fwd", "zip_composite_bwd",
+_NAMES = ["adam_step_dev", "grad_clip_coef", "fmlp_classic_fwd", "fmlp_proposal_fwd", "classic_get_rays", "classic_ndc_rays", "classic_ray_batch", "zip_encode_prop_fwd", "mip_encode_bwd", "mip_viewenc_bwd", "hash_decay", "zip_percentiles", "zip_pixels_to_rays", "zip_loss_tail", "semantic_composite_fwd", "semantic_composite_bwd", "zip_resample", "zip_encode_fwd", "zip_encode_bwd", "zip_composite_fwd", "zip_composite_bwd",
           "linear_fwd", "linear_wgrad", "classic_embed", "mip_encode", "mip_viewenc", "classic_sample_pdf", "classic_points",
           "classic_merge_sort", "mip_resample", "stratified", "mip_composite_fwd", "mip_composite_bwd", "classic_composite_fwd",
           "classic_composite_bwd", "adam_step", "colsum_f32", "cast_pad", "pinhole_rays", "mip_loss_tail"]

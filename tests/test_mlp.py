@@ -136,3 +136,66 @@ def test_deterministic_mode_gives_bit_identical_gradients():
     c = grads()
     rel = float((a - c).norm() / c.norm())
     assert float(c.norm()) > 0 and rel < 1e-5, rel
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# fused register-resident MLP kernels (csrc/fmlp.hip)
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _rand_sd(shapes, seed):
+    g = torch.Generator().manual_seed(seed)
+    return {k: (torch.randn(s, generator=g) * (1.4 / s[-1] ** 0.5) if len(s) == 2 else torch.randn(s, generator=g) * 0.1) for k, s in shapes}
+
+
+@pytest.mark.parametrize("M", [1000, 256 * 3])
+def test_fused_classic_network_matches_per_layer_kernels_and_oracle(backend, M):
+    """The one-launch NeRF 8 x 256 (activations in registers, weights as an MFMA-fragment stream) against (a) the fp32 oracle MLP
+    on identical inputs and (b) the per-layer GEMM path -- both bf16 evaluations of the same network, so they agree to bf16
+    rounding.  M = 1000: ragged last tile."""
+    from snerf_amd import classic
+    sd = _rand_sd(oc.nerf_param_shapes(W=256), 31)
+    net = classic.NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=4, skips=[4], use_viewdirs=True, compute="bf16", device=DEV)
+    net.load_state_dict(sd)
+    assert net.net.fused_ok()
+    g = torch.Generator().manual_seed(32)
+    S = 8
+    pts = (torch.rand(M // S, S, 3, generator=g) * 4 - 2)
+    vd = torch.nn.functional.normalize(torch.randn(M // S, 3, generator=g), dim=-1)
+    e, ev = classic.get_embedder(10, 0)[0], classic.get_embedder(4, 0)[0]
+    with torch.no_grad():
+        fused = classic.run_network(pts.to(DEV), vd.to(DEV), net, e, ev).cpu()
+        net.net.fused = False
+        layered = classic.run_network(pts.to(DEV), vd.to(DEV), net, e, ev).cpu()
+        net.net.fused = True
+    ref = oc.run_network(pts, vd, sd)
+    scale = float(ref.abs().max())
+    err_f, err_l = float((fused - ref).abs().max()) / scale, float((layered - ref).abs().max()) / scale
+    print(f"MEASURED fused classic MLP vs fp32 oracle: max err / max |ref| fused {err_f:.3e}, per-layer {err_l:.3e}, "
+          f"fused vs per-layer {float((fused - layered).abs().max()) / scale:.3e}")
+    assert err_f < 2e-2 and err_f < 2.0 * err_l + 1e-3
+    assert float((fused - layered).norm() / layered.norm()) < 5e-3
+
+
+def test_fused_proposal_network_matches_per_layer_kernels_and_oracle(backend):
+    from snerf_amd import mlp, ops
+    from snerf_amd.mlp import ParamArena
+    shapes = mlp.MipProposalNet.param_shapes(256, 4, 96)
+    arena = ParamArena(shapes, torch.device(DEV))
+    sd = _rand_sd(shapes, 33)
+    arena.load(sd)
+    net = mlp.MipProposalNet(arena, "", ops.BF16, 256, 4, 96)
+    assert net.fused_ok()
+    M = 700
+    g = torch.Generator().manual_seed(34)
+    enc = torch.randn(M, 96, generator=g) * 0.5
+    E = torch.zeros(M, net.Ew, dtype=torch.bfloat16, device=DEV)
+    E[:, :96] = enc.to(DEV)
+    with torch.no_grad():
+        fused, _ = net.forward(E, False)
+        net.fused = False
+        layered, _ = net.forward(E, False)
+    ref = om.proposal_mlp({"proposal." + k: v for k, v in sd.items()}, E[:, :96].float().cpu()[None]).reshape(-1)
+    scale = float(ref.abs().max())
+    err = float((fused.cpu().reshape(-1) - ref).abs().max()) / scale
+    print(f"MEASURED fused proposal MLP vs fp32 oracle: {err:.3e}; per-layer {float((layered.cpu().reshape(-1) - ref).abs().max()) / scale:.3e}")
+    assert err < 2e-2
+    assert float((fused - layered).norm() / layered.norm()) < 5e-3

@@ -48,14 +48,29 @@ def main():
         return (time.perf_counter() - t0) / args.steps
 
     dt_train = timeit(train)
+    flops = 2.0 * 593408 * (64 + 192)
     with torch.no_grad():
         dt_fwd = timeit(fwd)
-    flops = 2.0 * 593408 * (64 + 192)
+        # A/B of the inference MLP: the fused register-resident kernel (csrc/fmlp.hip) vs one GEMM launch per layer, the network alone
+        M = N * 192
+        pts = torch.randn(N, 192, 3, device=dev)
+        vd = torch.nn.functional.normalize(torch.randn(N, 3, device=dev), dim=-1)
+        mlp_only = {}
+        for name, flag in (("fused", True), ("per_layer", False)):
+            fine.net.fused = coarse.net.fused = flag
+            dt = timeit(lambda: classic.run_network(pts, vd, fine, embed_fn, embeddirs_fn))
+            mlp_only[name] = {"ms": round(dt * 1e3, 3), "TFLOPs": round(M * 2.0 * 593408 / dt / 1e12, 1)}
+            if not flag:
+                dt_fwd_layered = timeit(fwd)
+        fine.net.fused = coarse.net.fused = True
     print(json.dumps({"path": "B (classic render_rays, 64 coarse + 192 fine evals/ray, NeRF 8x256 x2)", "rays": N, "compute": args.compute,
                       "train_ms": round(dt_train * 1e3, 3), "train_rays_per_s": round(N / dt_train, 1), "fwd_ms": round(dt_fwd * 1e3, 3),
                       "fwd_rays_per_s": round(N / dt_fwd, 1), "fwd_mlp_TFLOPs": round(N * flops / dt_fwd / 1e12, 1),
                       "train_mlp_TFLOPs": round(3 * N * flops / dt_train / 1e12, 1),
-                      "frame_1600x900_s": round(1440000 / (N / dt_fwd), 3)}))
+                      "frame_1600x900_s": round(1440000 / (N / dt_fwd), 3),
+                      "fwd_per_layer_ms": round(dt_fwd_layered * 1e3, 3), "fwd_per_layer_mlp_TFLOPs": round(N * flops / dt_fwd_layered / 1e12, 1),
+                      "run_network_only": {"rows": M, **mlp_only,
+                                           "note": "embedding kernel + NeRF 8x256 on N x 192 samples; TFLOPs = algorithmic 2 x 593 408 FLOP per sample"}}))
 
 
 if __name__ == "__main__":
