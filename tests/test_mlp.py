@@ -103,6 +103,12 @@ def test_classic_net(backend, dt, W, tol):
     raw, saved = net.forward(pts.to(DEV), vd.to(DEV), S, True)
     assert rel(raw, ref) < tol, rel(raw, ref)
     raw_i, _ = net.forward(pts.to(DEV), vd.to(DEV), S, False)
+    if net.fused_ok():
+        # inference takes the fused register-resident kernel: the same bf16 network with another fp32 summation order
+        assert rel(raw_i, raw) < 5e-3, rel(raw_i, raw)
+        net.fused = False
+        raw_i, _ = net.forward(pts.to(DEV), vd.to(DEV), S, False)
+        net.fused = True
     assert torch.equal(raw_i, raw)
     arena.grad.zero_()
     net.backward(d_raw.to(DEV), saved)

@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""The fused classic-network kernel alone (csrc/fmlp.hip), a few launches -- target for rocprofv3 --kernel-trace / --pmc passes.
+Prints its own HIP-event timing too."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from snerf_amd import classic, ops
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 32768 * 192
+torch.manual_seed(0)
+net = classic.NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=4, skips=[4], use_viewdirs=True, compute="bf16")
+net.net._pack_fused()
+E = (torch.rand(M, 64, device="cuda") * 2 - 1).bfloat16()
+VE = (torch.rand(M, 64, device="cuda") * 2 - 1).bfloat16()
+out = torch.empty(M, 4, device="cuda")
+for _ in range(2):
+    ops.fmlp_classic_fwd(E, VE, net.net.fstream, net.net.fbias, out)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(5):
+    ops.fmlp_classic_fwd(E, VE, net.net.fstream, net.net.fbias, out)
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 5
+print(f"fmlp_classic M={M}: {ms:.3f} ms  {M * 2 * 593408 / ms / 1e9:.1f} TFLOP/s algorithmic ({M * 1212416 / ms / 1e9:.1f} executed)")
