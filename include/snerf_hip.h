@@ -337,6 +337,12 @@ int snerf_fmlp_classic_fwd(const void* E, long ldE, const void* VE, long ldVE, c
                            int n_blocks, float* raw, long M, void* stream);
 int snerf_fmlp_proposal_fwd(const void* E, long ldE, const void* wstream, long n_frags, const float* bias, int n_blocks,
                             float* raw_density, long M, void* stream);
+/* snerf_fmlp_classic_fwd with the two positional encodings (Embedder, run_nerf_helpers.py:22-52) computed inside the kernel: the whole
+ * run_network (:460-474) is this ONE launch.  pts [M,3] fp32 sample positions (row = ray * S + sample), viewdirs [M / S, ldvd] fp32.
+ * sin / cos are evaluated in revolutions (two-term exact-product reduction + v_sin_f32, abs. error a few 1e-7) and rounded to bf16
+ * like the output of snerf_classic_embed, which remains the bit-exact fp32 statement of the encoding.  M < 2^31. */
+int snerf_fmlp_classic_pts_fwd(const float* pts, const float* viewdirs, long ldvd, int S, const void* wstream, long n_frags,
+                               const float* bias, int n_blocks, float* raw, long M, void* stream);
 
 /* ---- deterministic mode ("deterministic mode for parity tests") ------------------------------------------
  * The weight gradient normally lands in dW by fp32 atomics from the M slices (order varies run to run).  snerf_linear_wgrad_det makes

@@ -30,6 +30,7 @@
 // Bound: MFMA (2.5 PFLOP/s dense bf16).  Algorithmic work: classic 1 186 816 FLOP / sample, proposal 442 880 FLOP / sample; the
 // padded work the kernel executes is 1 212 416 / 458 752 (K and N rounded up to the 16 / 32 of the MFMA shape).
 #include "common.h"
+#include <utility>
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
@@ -43,6 +44,9 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 struct FmlpArgs {
   const __bf16* E;  long ldE;       // encoded input rows [M, ldE] (pts embedding 63 -> 64, or IPE 96)
   const __bf16* VE; long ldVE;      // view-direction embedding rows [M, ldVE] (27 -> 32), classic network only
+  const float* pts;                 // classic network, in-kernel embedding: sample positions [M,3] ...
+  const float* viewdirs; long ldvd; // ... and per-ray view directions [M / S, ldvd]
+  int S;                            // samples per ray
   const char* wstream;              // n_chunks x 16 KiB of MFMA fragments in consumption order
   const float* bias;                // n_blocks x 32 floats in consumption order
   float* out;                       // classic: raw [M,4] = (rgb, sigma); proposal: raw density [M]
@@ -89,28 +93,28 @@ struct Ctx {
   WStream ws;
   const char* frag_base;   // ring + lane * 16
   const char* bias_lds;    // bias table + (lane >> 5) * 16
-  int f;                   // fragments consumed in this tile (compile-time after unrolling)
-  int nb;                  // n-blocks consumed in this tile
-  bf16x8 q[FM_LOOK];       // fragments f .. f + FM_LOOK - 1, already on their way from LDS
+  bf16x8 q[FM_LOOK];       // the next FM_LOOK fragments, already on their way from LDS
 };
 
-// Next weight fragment (A operand: 32 outputs x 16 reduction indices).  The ds_read of fragment f + FM_LOOK is issued when
-// fragment f is handed out, so FM_LOOK - 1 MFMAs (and the partner wave's) cover the LDS latency; the queue runs across blocks,
-// layers and tiles (the stream is one sequence).  The chunk boundary is taken when the READ-AHEAD crosses it.
+// Next weight fragment (A operand: 32 outputs x 16 reduction indices).  The ds_read of fragment F + FM_LOOK is issued when fragment
+// F is handed out, so FM_LOOK - 1 MFMAs (and the partner wave's) cover the LDS latency; the queue runs across blocks, layers and
+// tiles (the stream is one sequence).  The chunk boundary is taken when the READ-AHEAD crosses it.  F (the fragment's position in
+// the network pass) and every index derived from it are template arguments: nothing here depends on the optimiser proving a
+// counter constant.
+template <int F>
 __device__ __forceinline__ bf16x8 next_frag(Ctx& c) {
-  const bf16x8 w = c.q[c.f % FM_LOOK];
-  const int g = c.f + FM_LOOK;
-  if ((g & (FM_CHUNK - 1)) == 0) ws_advance(c.ws, c.smem);
-  c.q[c.f % FM_LOOK] = *(const bf16x8*)(c.frag_base + c.ws.slot_off + (g & (FM_CHUNK - 1)) * 1024);
-  ++c.f;
+  const bf16x8 w = c.q[F % FM_LOOK];
+  constexpr int G = F + FM_LOOK;
+  if constexpr ((G % FM_CHUNK) == 0) ws_advance(c.ws, c.smem);
+  c.q[F % FM_LOOK] = *(const bf16x8*)(c.frag_base + c.ws.slot_off + (G % FM_CHUNK) * 1024);
   return w;
 }
 
-// accumulator of one 32-output block, initialised with its bias: lane (row, half) owns outputs 8 q + 4 half + e
-__device__ __forceinline__ f32x16 acc_init(Ctx& c) {
+// accumulator of the 32-output block B of the pass, initialised with its bias: lane (row, half) owns outputs 8 q + 4 half + e
+template <int B>
+__device__ __forceinline__ f32x16 acc_init(const Ctx& c) {
   f32x16 acc;
-  const char* a = c.bias_lds + c.nb * 128;
-  ++c.nb;
+  const char* a = c.bias_lds + B * 128;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const f32x4 b = *(const f32x4*)(a + q * 32);
@@ -119,13 +123,13 @@ __device__ __forceinline__ f32x16 acc_init(Ctx& c) {
   return acc;
 }
 
-template <int NK>
+template <int F, int NK, int... I>
+__device__ __forceinline__ void mac_seq(Ctx& c, f32x16& acc, const bf16x8 (&in)[NK], std::integer_sequence<int, I...>) {
+  ((acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(next_frag<F + I>(c), in[I], acc, 0, 0, 0)), ...);
+}
+template <int F, int NK>
 __device__ __forceinline__ void mac(Ctx& c, f32x16& acc, const bf16x8 (&in)[NK]) {
-#pragma unroll
-  for (int s = 0; s < NK; ++s) {
-    const bf16x8 w = next_frag(c);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, in[s], acc, 0, 0, 0);
-  }
+  mac_seq<F, NK>(c, acc, in, std::make_integer_sequence<int, NK>{});
 }
 
 // accumulator -> the two B fragments (k-steps 2 j, 2 j + 1) of the next layer
@@ -153,27 +157,28 @@ __device__ __forceinline__ void to_frags(const f32x16& acc, bf16x8& lo, bf16x8& 
   }
 }
 
-// out[32 NB] = act(W . in + b): NB blocks of 32 outputs, one input segment
-template <int NK, int NB, bool RELU>
-__device__ __forceinline__ void dense(Ctx& c, const bf16x8 (&in)[NK], bf16x8 (&out)[2 * NB]) {
-#pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    f32x16 acc = acc_init(c);
-    mac<NK>(c, acc, in);
-    to_frags<RELU>(acc, out[2 * j], out[2 * j + 1]);
-  }
+// One layer: out[32 NB] = act(W . [in0 | in1] + b) -- NB blocks of 32 outputs over one or two input segments (skip connections and
+// concatenations are never formed).  F = first fragment, B = first bias block of the layer within the pass.
+template <int F, int B, int NK0, int NK1, bool RELU>
+__device__ __forceinline__ void dense_block(Ctx& c, const bf16x8 (&in0)[NK0], const bf16x8 (&in1)[NK1 > 0 ? NK1 : 1], bf16x8& lo, bf16x8& hi) {
+  f32x16 acc = acc_init<B>(c);
+  mac<F, NK0>(c, acc, in0);
+  if constexpr (NK1 > 0) mac<F + NK0, NK1>(c, acc, in1);
+  to_frags<RELU>(acc, lo, hi);
 }
-
-// two input segments (skip connections / concatenations: the cat is never formed)
-template <int NK0, int NK1, int NB, bool RELU>
+template <int F, int B, int NK0, int NK1, int NB, bool RELU, int... J>
+__device__ __forceinline__ void dense_seq(Ctx& c, const bf16x8 (&in0)[NK0], const bf16x8 (&in1)[NK1 > 0 ? NK1 : 1], bf16x8 (&out)[2 * NB],
+                                          std::integer_sequence<int, J...>) {
+  (dense_block<F + J * (NK0 + NK1), B + J, NK0, NK1, RELU>(c, in0, in1, out[2 * J], out[2 * J + 1]), ...);
+}
+template <int F, int B, int NK, int NB, bool RELU>
+__device__ __forceinline__ void dense(Ctx& c, const bf16x8 (&in)[NK], bf16x8 (&out)[2 * NB]) {
+  const bf16x8 none[1] = {};
+  dense_seq<F, B, NK, 0, NB, RELU>(c, in, none, out, std::make_integer_sequence<int, NB>{});
+}
+template <int F, int B, int NK0, int NK1, int NB, bool RELU>
 __device__ __forceinline__ void dense2(Ctx& c, const bf16x8 (&in0)[NK0], const bf16x8 (&in1)[NK1], bf16x8 (&out)[2 * NB]) {
-#pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    f32x16 acc = acc_init(c);
-    mac<NK0>(c, acc, in0);
-    mac<NK1>(c, acc, in1);
-    to_frags<RELU>(acc, out[2 * j], out[2 * j + 1]);
-  }
+  dense_seq<F, B, NK0, NK1, NB, RELU>(c, in0, in1, out, std::make_integer_sequence<int, NB>{});
 }
 
 // input fragments straight from HBM: lane (row, half) reads the 16 bytes [16 s + 8 half, +8) of its row (natural k order)
@@ -184,10 +189,83 @@ __device__ __forceinline__ void load_rows(const __bf16* p, long ld, long row, in
   for (int s = 0; s < NK; ++s) out[s] = *(const bf16x8*)(q + 16 * s);
 }
 
+// ---- in-kernel positional encoding (run_nerf_helpers.py:22-52: [x, sin(2^0 x), cos(2^0 x), sin(2^1 x), cos(2^1 x), ...]) -------------
+// Fragment s of the embedding in natural order: lane half h supplies features k = 16 s + 8 h + e, e = 0..7.  Which (frequency band,
+// sin / cos, component) a feature is, is a compile-time fact per (s, e, half); the lane picks its half's constants with v_cndmask.
+// sin(2^b x) is evaluated in REVOLUTIONS: 2^b x / (2 pi) as an exact-product two-term reduction (p = x * fl(2^b / 2pi), its rounding
+// error recovered by an fma, plus the low word of 1 / 2pi), v_fract_f32, then the hardware's v_sin_f32 (cos = sin(. + 1/4)).  The
+// absolute error is a few 1e-7, far below the half-ulp of the bf16 rounding the feature undergoes next (2e-3 at 1); a fraction of
+// a per cent of the features land on the other side of a bf16 rounding boundary compared with the separate embedding kernel's
+// sinf / cosf (that kernel stays the bit-exact fp32 reference, tests/test_gpu_kernels.py).
+__device__ __forceinline__ constexpr int fe_comp(int k) { return k < 3 ? k : (k - 3) % 3; }
+__device__ __forceinline__ constexpr int fe_band(int k) { return k < 3 ? 0 : (k - 3) / 6; }
+__device__ __forceinline__ constexpr bool fe_cos(int k) { return k >= 3 && ((k - 3) % 6) >= 3; }
+
+template <int K, int WIDTH>
+__device__ __forceinline__ constexpr float fe_scale_hi() {   // fl(2^band / 2pi); 0 for padding features
+  return K >= WIDTH ? 0.f : 0.15915494f * (float)(1 << fe_band(K));
+}
+template <int K, int WIDTH>
+__device__ __forceinline__ constexpr float fe_scale_lo() {   // 2^band * (1/2pi - fl(1/2pi))
+  return K >= WIDTH ? 0.f : 6.4206383e-9f * (float)(1 << fe_band(K));
+}
+
+struct Vec3 { float c0, c1, c2; };                              // scalars, not an array: a select between two array elements
+template <int C>                                               // would become a dynamically indexed (scratch) access
+__device__ __forceinline__ float pick(const Vec3& x) { return C == 0 ? x.c0 : (C == 1 ? x.c1 : x.c2); }
+
+template <int K0, int WIDTH>
+__device__ __forceinline__ float embed_feature(const Vec3& x, bool hi_half) {
+  constexpr int K1 = K0 + 8;
+  const float xs = hi_half ? pick<fe_comp(K1)>(x) : pick<fe_comp(K0)>(x);
+  const float sh = hi_half ? fe_scale_hi<K1, WIDTH>() : fe_scale_hi<K0, WIDTH>();
+  const float sl = hi_half ? fe_scale_lo<K1, WIDTH>() : fe_scale_lo<K0, WIDTH>();
+  const float q = hi_half ? (fe_cos(K1) ? 0.25f : 0.f) : (fe_cos(K0) ? 0.25f : 0.f);
+  const float p = xs * sh;
+  const float err = __builtin_fmaf(xs, sh, -p);                 // exact rounding error of the product
+  const float t = __builtin_amdgcn_fractf(p) + (__builtin_fmaf(xs, sl, err) + q);
+  float v = __builtin_amdgcn_sinf(t);
+  if (K0 < 3) v = hi_half ? v : pick<K0 < 3 ? K0 : 0>(x);       // identity features (half 0 of k-step 0 only)
+  if (K1 >= WIDTH) v = hi_half ? 0.f : v;                       // zero padding (the packed weights are zero there too)
+  if (K0 >= WIDTH) v = 0.f;
+  return v;
+}
+
+template <int S, int WIDTH>
+__device__ __forceinline__ bf16x8 embed_frag(const Vec3& x, bool hi_half) {
+  typedef __attribute__((ext_vector_type(8))) float f32x8;
+  const f32x8 v = {embed_feature<16 * S + 0, WIDTH>(x, hi_half), embed_feature<16 * S + 1, WIDTH>(x, hi_half),
+                   embed_feature<16 * S + 2, WIDTH>(x, hi_half), embed_feature<16 * S + 3, WIDTH>(x, hi_half),
+                   embed_feature<16 * S + 4, WIDTH>(x, hi_half), embed_feature<16 * S + 5, WIDTH>(x, hi_half),
+                   embed_feature<16 * S + 6, WIDTH>(x, hi_half), embed_feature<16 * S + 7, WIDTH>(x, hi_half)};
+  return __builtin_convertvector(v, bf16x8);
+}
+
+template <int NK, int WIDTH>
+__device__ __forceinline__ void embed_frags(const Vec3& x, bool hi_half, bf16x8 (&out)[NK]) {
+  out[0] = embed_frag<0, WIDTH>(x, hi_half);
+  if constexpr (NK > 1) out[1] = embed_frag<1, WIDTH>(x, hi_half);
+  if constexpr (NK > 2) out[2] = embed_frag<2, WIDTH>(x, hi_half);
+  if constexpr (NK > 3) out[3] = embed_frag<3, WIDTH>(x, hi_half);
+  static_assert(NK <= 4, "embedding wider than 64 features");
+}
+
+struct ClassicInputs { bf16x8 e[4], ve[2]; };
+__device__ __forceinline__ ClassicInputs classic_embed_inputs(const float* pp, const float* vp, bool hi_half) {
+  const Vec3 x{pp[0], pp[1], pp[2]}, v{vp[0], vp[1], vp[2]};
+  ClassicInputs r;
+  embed_frags<4, 63>(x, hi_half, r.e);                    // get_embedder(10): 63 features (+ 1 zero)
+  embed_frags<2, 27>(v, hi_half, r.ve);                   // get_embedder(4): 27 features (+ 5 zeros)
+  return r;
+}
+
+// 8 x 4 + 4 x 128 + 160 + 2 x 128 (trunk) + 16 (alpha) + 128 (feature) + 72 (views) + 8 (rgb) fragments; 64 + 1 + 8 + 4 + 1 blocks
+#define FMLP_CLASSIC_FRAGS 1184
+#define FMLP_CLASSIC_BLOCKS 78
 #define FMLP_CLASSIC 0
 #define FMLP_PROPOSAL 1
 
-template <int NET>
+template <int NET, bool EMBED>
 __global__ __launch_bounds__(512) void fmlp_kernel(FmlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -217,32 +295,41 @@ __global__ __launch_bounds__(512) void fmlp_kernel(FmlpArgs a) {
   for (int i = 0; i < FM_LOOK; ++i) c.q[i] = *(const bf16x8*)(c.frag_base + c.ws.slot_off + i * 1024);
 
   for (int tile = blockIdx.x; tile < a.tiles; tile += gridDim.x) {
-    c.f = 0;
-    c.nb = 0;
     long row = (long)tile * 256 + wave * 32 + (lane & 31);
     const bool row_ok = row < a.M;
     row = row_ok ? row : a.M - 1;                       // tail rows: compute on a valid row, store nothing
 
     if constexpr (NET == FMLP_CLASSIC) {
       bf16x8 e[4], ve[2], p[16], q[16];
-      load_rows<4>(a.E, a.ldE, row, half, e);
-      load_rows<2>(a.VE, a.ldVE, row, half, ve);
-      dense<4, 8, true>(c, e, p);                       // pts_linears.0
-      dense<16, 8, true>(c, p, q);                      // .1
-      dense<16, 8, true>(c, q, p);                      // .2
-      dense<16, 8, true>(c, p, q);                      // .3
-      dense<16, 8, true>(c, q, p);                      // .4  (skip: the next layer reads cat([pts, h]))
-      dense2<4, 16, 8, true>(c, e, p, q);               // .5
-      dense<16, 8, true>(c, q, p);                      // .6
-      dense<16, 8, true>(c, p, q);                      // .7
-      f32x16 alpha = acc_init(c);                       // alpha_linear: output 0 of one block
-      mac<16>(c, alpha, q);
+      if constexpr (EMBED) {
+        const ClassicInputs in = classic_embed_inputs(a.pts + row * 3, a.viewdirs + (long)((unsigned)row / (unsigned)a.S) * a.ldvd, half != 0);   // (M < 2^31 rows, checked by the launcher)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) e[i] = in.e[i];
+        ve[0] = in.ve[0]; ve[1] = in.ve[1];
+      } else {
+        load_rows<4>(a.E, a.ldE, row, half, e);
+        load_rows<2>(a.VE, a.ldVE, row, half, ve);
+      }
+      // fragment / bias-block offsets of the layers inside the pass (8 blocks x k-steps each)
+      constexpr int F1 = 8 * 4, F2 = F1 + 128, F3 = F2 + 128, F4 = F3 + 128, F5 = F4 + 128, F6 = F5 + 8 * 20, F7 = F6 + 128;
+      constexpr int FA = F7 + 128, FF = FA + 16, FV = FF + 128, FR = FV + 4 * 18;
+      static_assert(FR + 8 == FMLP_CLASSIC_FRAGS, "classic network: fragment count");
+      dense<0, 0, 4, 8, true>(c, e, p);                 // pts_linears.0
+      dense<F1, 8, 16, 8, true>(c, p, q);               // .1
+      dense<F2, 16, 16, 8, true>(c, q, p);              // .2
+      dense<F3, 24, 16, 8, true>(c, p, q);              // .3
+      dense<F4, 32, 16, 8, true>(c, q, p);              // .4  (skip: the next layer reads cat([pts, h]))
+      dense2<F5, 40, 4, 16, 8, true>(c, e, p, q);       // .5
+      dense<F6, 48, 16, 8, true>(c, q, p);              // .6
+      dense<F7, 56, 16, 8, true>(c, p, q);              // .7
+      f32x16 alpha = acc_init<64>(c);                   // alpha_linear: output 0 of one block
+      mac<FA, 16>(c, alpha, q);
       const float sigma = alpha[0];
-      dense<16, 8, false>(c, q, p);                     // feature_linear (no activation)
+      dense<FF, 65, 16, 8, false>(c, q, p);             // feature_linear (no activation)
       bf16x8 hv[8];
-      dense2<16, 2, 4, true>(c, p, ve, hv);             // views_linears.0 on cat([feature, views])
-      f32x16 rgb = acc_init(c);                         // rgb_linear: outputs 0..2
-      mac<8>(c, rgb, hv);
+      dense2<FV, 73, 16, 2, 4, true>(c, p, ve, hv);     // views_linears.0 on cat([feature, views])
+      f32x16 rgb = acc_init<77>(c);                     // rgb_linear: outputs 0..2
+      mac<FR, 8>(c, rgb, hv);
       if (row_ok && half == 0) {
         const f32x4 o = {rgb[0], rgb[1], rgb[2], sigma};
         *(f32x4*)(a.out + row * 4) = o;
@@ -250,12 +337,12 @@ __global__ __launch_bounds__(512) void fmlp_kernel(FmlpArgs a) {
     } else {
       bf16x8 e[6], p[16], q[16];
       load_rows<6>(a.E, a.ldE, row, half, e);
-      dense<6, 8, true>(c, e, p);                       // layers.0
-      dense<16, 8, true>(c, p, q);
-      dense<16, 8, true>(c, q, p);
-      dense<16, 8, true>(c, p, q);
-      f32x16 d = acc_init(c);                           // density_layer
-      mac<16>(c, d, q);
+      dense<0, 0, 6, 8, true>(c, e, p);                 // layers.0
+      dense<48, 8, 16, 8, true>(c, p, q);
+      dense<48 + 128, 16, 16, 8, true>(c, q, p);
+      dense<48 + 256, 24, 16, 8, true>(c, p, q);
+      f32x16 d = acc_init<32>(c);                       // density_layer
+      mac<48 + 384, 16>(c, d, q);
       if (row_ok && half == 0) a.out[row] = d[0];
     }
     // the fragment count of a network pass is a whole number of chunks (the host pads the stream), so the next tile starts on a
@@ -264,17 +351,17 @@ __global__ __launch_bounds__(512) void fmlp_kernel(FmlpArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the read-ahead before the LDS is released
 }
 
-template <int NET>
+template <int NET, bool EMBED>
 static int fmlp_launch(const FmlpArgs& a, int expect_frags, int expect_blocks, long n_frags, void* stream) {
   if (a.M <= 0) return SNERF_OK;
   if (n_frags != expect_frags || a.n_blocks != expect_blocks || a.n_blocks > FM_BIAS_MAX || (n_frags % FM_CHUNK) != 0) return SNERF_ERR_ARG;
-  if (a.E == nullptr || a.wstream == nullptr || a.bias == nullptr || a.out == nullptr) return SNERF_ERR_ARG;
-  if ((a.ldE % 8) != 0 || (((uintptr_t)a.E) & 15) || (((uintptr_t)a.wstream) & 15)) return SNERF_ERR_ARG;
+  if (a.wstream == nullptr || a.bias == nullptr || a.out == nullptr || (((uintptr_t)a.wstream) & 15)) return SNERF_ERR_ARG;
+  if (!EMBED && (a.E == nullptr || (a.ldE % 8) != 0 || (((uintptr_t)a.E) & 15))) return SNERF_ERR_ARG;
   constexpr int LDS = FM_RING * FM_SLOT + FM_BIAS_MAX * 128;
   static bool attr_set = false;
   static int n_cu = 256;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)fmlp_kernel<NET>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)fmlp_kernel<NET, EMBED>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
@@ -282,21 +369,33 @@ static int fmlp_launch(const FmlpArgs& a, int expect_frags, int expect_blocks, l
     attr_set = true;
   }
   const int grid = a.tiles < n_cu ? a.tiles : n_cu;
-  hipLaunchKernelGGL(fmlp_kernel<NET>, dim3(grid), dim3(512), LDS, (hipStream_t)stream, a);
+  hipLaunchKernelGGL((fmlp_kernel<NET, EMBED>), dim3(grid), dim3(512), LDS, (hipStream_t)stream, a);
   return snerf_check_launch();
 }
 
 extern "C" int snerf_fmlp_classic_fwd(const void* E, long ldE, const void* VE, long ldVE, const void* wstream, long n_frags, const float* bias,
                                       int n_blocks, float* raw, long M, void* stream) {
-  if (VE == nullptr || (ldVE % 8) != 0 || (((uintptr_t)VE) & 15) || (((uintptr_t)raw) & 15)) return M <= 0 ? SNERF_OK : SNERF_ERR_ARG;
-  FmlpArgs a{(const __bf16*)E, ldE, (const __bf16*)VE, ldVE, (const char*)wstream, bias, raw, M, (int)((M + 255) / 256), (int)(n_frags / FM_CHUNK), n_blocks};
-  // 8 x 4 + 4 x 128 + 160 + 2 x 128 (trunk) + 16 (alpha) + 128 (feature) + 72 (views) + 8 (rgb) fragments; 64 + 1 + 8 + 4 + 1 blocks
-  return fmlp_launch<FMLP_CLASSIC>(a, 1184, 78, n_frags, stream);
+  if (M <= 0) return SNERF_OK;
+  if (VE == nullptr || (ldVE % 8) != 0 || (((uintptr_t)VE) & 15) || (((uintptr_t)raw) & 15)) return SNERF_ERR_ARG;
+  FmlpArgs a{(const __bf16*)E, ldE, (const __bf16*)VE, ldVE, nullptr, nullptr, 0, 1, (const char*)wstream, bias, raw, M, (int)((M + 255) / 256),
+             (int)(n_frags / FM_CHUNK), n_blocks};
+  return fmlp_launch<FMLP_CLASSIC, false>(a, FMLP_CLASSIC_FRAGS, FMLP_CLASSIC_BLOCKS, n_frags, stream);
+}
+
+// the same network with the positional encodings computed in the kernel: pts [M,3] fp32 sample positions, viewdirs [M / S, ldvd]
+extern "C" int snerf_fmlp_classic_pts_fwd(const float* pts, const float* viewdirs, long ldvd, int S, const void* wstream, long n_frags,
+                                          const float* bias, int n_blocks, float* raw, long M, void* stream) {
+  if (M <= 0) return SNERF_OK;
+  if (pts == nullptr || viewdirs == nullptr || S <= 0 || ldvd < 3 || (((uintptr_t)raw) & 15) || M >= (1L << 31)) return SNERF_ERR_ARG;
+  FmlpArgs a{nullptr, 0, nullptr, 0, pts, viewdirs, ldvd, S, (const char*)wstream, bias, raw, M, (int)((M + 255) / 256),
+             (int)(n_frags / FM_CHUNK), n_blocks};
+  return fmlp_launch<FMLP_CLASSIC, true>(a, FMLP_CLASSIC_FRAGS, FMLP_CLASSIC_BLOCKS, n_frags, stream);
 }
 
 extern "C" int snerf_fmlp_proposal_fwd(const void* E, long ldE, const void* wstream, long n_frags, const float* bias, int n_blocks,
                                        float* raw_density, long M, void* stream) {
-  FmlpArgs a{(const __bf16*)E, ldE, nullptr, 0, (const char*)wstream, bias, raw_density, M, (int)((M + 255) / 256), (int)(n_frags / FM_CHUNK), n_blocks};
+  FmlpArgs a{(const __bf16*)E, ldE, nullptr, 0, nullptr, nullptr, 0, 1, (const char*)wstream, bias, raw_density, M, (int)((M + 255) / 256),
+             (int)(n_frags / FM_CHUNK), n_blocks};
   // 8 x 6 + 3 x 128 + 16 fragments; 32 + 1 blocks
-  return fmlp_launch<FMLP_PROPOSAL>(a, 448, 33, n_frags, stream);
+  return fmlp_launch<FMLP_PROPOSAL, false>(a, 448, 33, n_frags, stream);
 }

@@ -251,6 +251,7 @@ class ClassicNeRFNet(_Net):
         self.Pw, self.Vw = roundup(input_ch, self.g), roundup(input_ch_views, self.g)
         self.alpha_head = bool(alpha_head)
         self.fused = True                 # inference through the fused register-resident kernel where it applies (fused_ok)
+        self.fused_embed = True           # ... with the positional encodings computed inside it (False: separate embedding kernel)
 
     @staticmethod
     def param_shapes(D=8, W=256, input_ch=63, input_ch_views=27, skips=(4,), alpha_head=True):
@@ -320,9 +321,12 @@ class ClassicNeRFNet(_Net):
                 self._pack_fused()
             self._fused_version = v
         M = pts.shape[0]
+        OUT = self.buf(M, 4, f32=True)
+        if self.fused_embed and M < (1 << 31):
+            ops.fmlp_classic_pts_fwd(pts, viewdirs, S, self.fstream, self.fbias, OUT)     # run_network = one launch
+            return OUT
         E, VE = self.buf(M, 64), self.buf(M, 64)
         ops.classic_embed(pts, viewdirs, S, (self.ic - 3) // 6, (self.icv - 3) // 6, E, None, 64, VE, 64, self.dt)
-        OUT = self.buf(M, 4, f32=True)
         ops.fmlp_classic_fwd(E, VE, self.fstream, self.fbias, OUT)
         return OUT
 

@@ -121,6 +121,15 @@ def fmlp_classic_fwd(E, VE, stream, bias, raw):
               _p(raw), E.shape[0], _stream())
 
 
+def fmlp_classic_pts_fwd(pts, viewdirs, S, stream, bias, raw):
+    """fmlp_classic_fwd with the embeddings computed in the kernel: pts [M,3] fp32, viewdirs [M/S,3] fp32 -> raw [M,4] fp32."""
+    _f32c(pts); _chk2d(raw, torch.float32)
+    assert viewdirs.dtype == torch.float32 and viewdirs.stride(1) == 1 and viewdirs.shape[1] == 3 and pts.shape[0] == viewdirs.shape[0] * S
+    assert stream.dtype == torch.bfloat16 and stream.is_contiguous() and bias.dtype == torch.float32 and raw.is_contiguous() and raw.shape == (pts.shape[0], 4)
+    _lib.call("snerf_fmlp_classic_pts_fwd", _p(pts), _p(viewdirs), viewdirs.stride(0), int(S), _p(stream), stream.shape[0], _p(bias),
+              bias.numel() // 32, _p(raw), pts.shape[0], _stream())
+
+
 def fmlp_proposal_fwd(E, stream, bias, raw_density):
     """The proposal MLP 96 -> 4 x 256 -> 1 in one launch: E [M,>=96] bf16 IPE rows -> raw density [M,1] fp32."""
     _chk2d(E, torch.bfloat16)

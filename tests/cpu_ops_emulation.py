@@ -465,6 +465,12 @@ def fmlp_classic_fwd(E, VE, stream, bias, raw):
     raw[:, 3] = sigma
 
 
+def fmlp_classic_pts_fwd(pts, viewdirs, S, stream, bias, raw):
+    M = pts.shape[0]
+    pad = lambda t, w: torch.cat([t, torch.zeros(M, w - t.shape[1])], -1).to(torch.bfloat16)
+    fmlp_classic_fwd(pad(oc.embed(pts, 10), 64), pad(oc.embed(viewdirs[:, None].expand(-1, S, -1).reshape(-1, 3), 4), 64), stream, bias, raw)
+
+
 def fmlp_proposal_fwd(E, stream, bias, raw_density):
     assert stream.shape[0] == 448 and bias.numel() == 33 * 32
     st = _FStream(stream, bias)
@@ -479,7 +485,7 @@ def adam_step_dev(p, g, m, v, lr, b1, b2, eps, step_dev, grad_scale=1.0, zero_gr
     adam_step(p, g, m, v, lr, b1, b2, eps, 0, grad_scale, zero_grad, step_dev=step_dev, **kw)
 
 
-_NAMES = ["adam_step_dev", "grad_clip_coef", "fmlp_classic_fwd", "fmlp_proposal_fwd", "classic_get_rays", "classic_ndc_rays", "classic_ray_batch", "zip_encode_prop_fwd", "mip_encode_bwd", "mip_viewenc_bwd", "hash_decay", "zip_percentiles", "zip_pixels_to_rays", "zip_loss_tail", "semantic_composite_fwd", "semantic_composite_bwd", "zip_resample", "zip_encode_fwd", "zip_encode_bwd", "zip_composite_fwd", "zip_composite_bwd",
+_NAMES = ["adam_step_dev", "grad_clip_coef", "fmlp_classic_fwd", "fmlp_classic_pts_fwd", "fmlp_proposal_fwd", "classic_get_rays", "classic_ndc_rays", "classic_ray_batch", "zip_encode_prop_fwd", "mip_encode_bwd", "mip_viewenc_bwd", "hash_decay", "zip_percentiles", "zip_pixels_to_rays", "zip_loss_tail", "semantic_composite_fwd", "semantic_composite_bwd", "zip_resample", "zip_encode_fwd", "zip_encode_bwd", "zip_composite_fwd", "zip_composite_bwd",
           "linear_fwd", "linear_wgrad", "classic_embed", "mip_encode", "mip_viewenc", "classic_sample_pdf", "classic_points",
           "classic_merge_sort", "mip_resample", "stratified", "mip_composite_fwd", "mip_composite_bwd", "classic_composite_fwd",
           "classic_composite_bwd", "adam_step", "colsum_f32", "cast_pad", "pinhole_rays", "mip_loss_tail"]

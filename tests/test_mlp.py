@@ -168,7 +168,12 @@ def test_fused_classic_network_matches_per_layer_kernels_and_oracle(backend, M):
     vd = torch.nn.functional.normalize(torch.randn(M // S, 3, generator=g), dim=-1)
     e, ev = classic.get_embedder(10, 0)[0], classic.get_embedder(4, 0)[0]
     with torch.no_grad():
-        fused = classic.run_network(pts.to(DEV), vd.to(DEV), net, e, ev).cpu()
+        fused = classic.run_network(pts.to(DEV), vd.to(DEV), net, e, ev).cpu()       # embeddings computed in the kernel (one launch)
+        net.net.fused_embed = False
+        fused_e = classic.run_network(pts.to(DEV), vd.to(DEV), net, e, ev).cpu()     # embeddings from the bit-exact embedding kernel
+        net.net.fused_embed = True
+        print(f"MEASURED in-kernel embedding vs embedding kernel: rel L2 {float((fused - fused_e).norm() / fused_e.norm()):.3e}")
+        assert float((fused - fused_e).norm() / fused_e.norm()) < 3e-3
         net.net.fused = False
         layered = classic.run_network(pts.to(DEV), vd.to(DEV), net, e, ev).cpu()
         net.net.fused = True

@@ -22,3 +22,15 @@ e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 5
 print(f"fmlp_classic M={M}: {ms:.3f} ms  {M * 2 * 593408 / ms / 1e9:.1f} TFLOP/s algorithmic ({M * 1212416 / ms / 1e9:.1f} executed)")
+S = 192
+pts = torch.randn(M, 3, device="cuda")
+vd = torch.nn.functional.normalize(torch.randn(M // S, 3, device="cuda"), dim=-1)
+for _ in range(2):
+    ops.fmlp_classic_pts_fwd(pts, vd, S, net.net.fstream, net.net.fbias, out)
+e0.record()
+for _ in range(5):
+    ops.fmlp_classic_pts_fwd(pts, vd, S, net.net.fstream, net.net.fbias, out)
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 5
+print(f"fmlp_classic_pts (in-kernel embedding) M={M}: {ms:.3f} ms  {M * 2 * 593408 / ms / 1e9:.1f} TFLOP/s algorithmic")
