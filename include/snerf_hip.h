@@ -188,7 +188,7 @@ int snerf_zip_composite_bwd(const float* raw_rgb, long ld_rgb, const float* raw_
                             const float* dirs, long R, int S, int opaque, float bg, float rgb_padding, float density_bias,
                             const float* weights, const float* acc, const float* depth, const float* g_rgb, const float* g_depth,
                             const float* g_acc, const float* g_w, float* d_raw_rgb, long ld_drgb, float* d_raw_density,
-                            long ld_dden, void* stream);
+                            long ld_dden, float* g_dirs, void* stream);
 
 /* ---- training tail ------------------------------------------------------------------------------
  * torch.optim.Adam step over a flat fp32 arena (model_utils.py:23-34 builds Adam); grad_scale folds the
@@ -368,6 +368,19 @@ int snerf_classic_ndc_rays(int H, int W, double focal, float near, const float* 
 int snerf_classic_ray_batch(int H, int W, double focal, double cx, double cy, const float* c2w_host, const float* c2w_static_host,
                             const float* rays_o, const float* rays_d, long n, int ndc, float near, float far, const float* depths,
                             int use_viewdirs, float* rows, int ld, void* stream);
+
+/* Featurisation backward to the RAYS -- `cal_input_grad` of the reference (internal/models.py:491 -> gridencoder/grid.py:65-89 ->
+ * gridencoder.cu:199-244, 343-369), needed by the pose refinement of zipnerf/train.py:187-197: d loss / d (origins, directions, base_x,
+ * base_y) [R,3] each (ACCUMULATED: the caller zeroes them) from grad_feat = d loss / d features [R*S, ld] (feat_dtype), through the
+ * trilinear derivative of every level, the erf down-weighting's dependence on the contracted std, the contraction's Jacobian
+ * (coord.py:51-63) and the multisample helix (render.py:129-168).  table: the gather table of snerf_zip_encode_fwd (table_dtype 0 =
+ * fp32, 2 = fp16).  snerf_zip_composite_bwd's `g_dirs` (optional, [R,3], written) is d loss / d directions through the interval
+ * lengths (t1 - t0) |d| (render.py:170-176). */
+int snerf_zip_encode_ray_bwd(const float* tdist, const float* origins, const float* directions, const float* radii, const float* base_x,
+                             const float* base_y, const float* deg_jitter, const void* table, const int* offsets, const int* grid_sizes,
+                             const void* grad_feat, long ld, long R, int S, int L, int C, int n, int m, float Sl, int H, float std_scale,
+                             int table_dtype, int feat_dtype, float* g_origins, float* g_directions, float* g_base_x, float* g_base_y,
+                             void* stream);
 
 /* snerf_adam_step with the step count t in DEVICE memory: *step_dev is incremented, then used for the bias corrections -- no launch
  * argument depends on host state, so a whole training step can be captured in a hipGraph and replayed. */

@@ -241,7 +241,7 @@ def volumetric_rendering(rgbs, weights, tdist, bg_rgbs=1.0, semantic=None, compu
 # ------------------------------------------------------------------ C11 ---
 def model_forward(p, specs, batch, num_prop_samples=(64, 64), num_nerf_samples=32, train_frac=1.0, anneal_slope=10.0,
                   dilation_multiplier=0.5, dilation_bias=0.0025, power_lambda=-1.5, std_scale=0.35, jitters=None,
-                  deg_jitters=None, bg=1.0, use_semantic=False, compute_extras=False, vis_num_rays=16):
+                  deg_jitters=None, bg=1.0, use_semantic=False, compute_extras=False, vis_num_rays=16, sdist_override=None):
     """Model.forward (models.py:98-349) with rand=None (jitters None) or explicit draws; `use_semantic`: the final level also
     renders the 19-class semantic distribution (models.py:297-305).  `specs` = [prop0, prop1, nerf]
     GridSpec; parameter names follow the reference's state_dict (`prop_mlp_0.encoder.embeddings`, `nerf_mlp.rgb_layer.weight`...).
@@ -267,6 +267,10 @@ def model_forward(p, specs, batch, num_prop_samples=(64, 64), num_nerf_samples=3
         u = det_centers_u(ns) if jitters is None else rand_u(ns, jitters[lvl])
         sdist, _ = sample_intervals(sdist, logits, u, (0.0, 1.0))
         sdist = sdist.detach()                      # stop_level_grad, models.py:215-218
+        if sdist_override is not None:
+            # teacher forcing for conditioning-aware gradient checks (tests only): every level evaluated at GIVEN fence posts -- those
+            # another evaluation resampled -- so that both sides see identical sample positions (the posts carry no gradient)
+            sdist = sdist_override[lvl].detach()
         tdist = s_to_t(sdist, near, far, power_lambda)
         means, stds = cast_rays(tdist, batch["origins"], batch["directions"], batch["radii"], batch["base_x"], batch["base_y"],
                                 None if deg_jitters is None else deg_jitters[lvl], std_scale=std_scale)

@@ -800,6 +800,147 @@ extern "C" int snerf_zip_encode_bwd(const float* tdist, const float* origins, co
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Featurisation backward to the RAYS (pose refinement: `cal_input_grad`, internal/models.py:491, gridencoder/grid.py:65-89,
+// gridencoder.cu:199-244 + 343-369 (dy_dx, kernel_input_backward); zipnerf/train.py:187-197 re-poses origins / directions / base_x /
+// base_y with a learnable pose and back-propagates through the whole renderer).  One thread per interval, all levels: for each of
+// the n multisamples the position gradient collects (1) the trilinear derivative of every level's features (dy/dx of the
+// reference's encoder) and (2) the erf down-weighting's dependence on the contracted std -- which depends on the position through
+// det(J)^(1/3) of the contraction (coord.py:51-63) --, is carried through the contraction's Jacobian and the helix construction
+// (render.py:129-168: x = lx base_x + ly base_y + t d + o) and summed per ray.  The table is gathered again (no dy_dx buffer of
+// [P n, L 3 C] values is ever stored).  grad_feat = d loss / d features [P, ld] in OT.
+// ------------------------------------------------------------------------------------------------------------------
+template <typename TT, typename OT, int C>
+__global__ __launch_bounds__(256) void zip_encode_ray_bwd_kernel(ZipEnc a, float* __restrict__ g_o, float* __restrict__ g_d,
+                                                                 float* __restrict__ g_bx, float* __restrict__ g_by) {
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= a.R * a.S) return;
+  const long ray = p / a.S;
+  const int i = (int)(p - ray * a.S);
+  const float t0 = a.tdist[ray * (a.S + 1) + i], t1 = a.tdist[ray * (a.S + 1) + i + 1];
+  float o[3], d[3], bx[3], by[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { o[k] = a.origins[ray * 3 + k]; d[k] = a.directions[ray * 3 + k]; bx[k] = a.base_x[ray * 3 + k]; by[k] = a.base_y[ray * 3 + k]; }
+  const float rad = a.radii[ray];
+  const OT* gi = (const OT*)a.feat + p * a.ld;
+  float go[3] = {0.f, 0.f, 0.f}, gd[3] = {0.f, 0.f, 0.f}, gbx[3] = {0.f, 0.f, 0.f}, gby[3] = {0.f, 0.f, 0.f};
+  for (int j = 0; j < a.n; ++j) {
+    // forward of the multisample, intermediates kept (zip_sample_point)
+    const float t = t0 + (t1 - t0) * ((float)j + 0.5f) / (float)a.n;
+    float deg = 2.f * 3.14159265358979f * (float)a.m * (float)j / (float)a.n;
+    if (a.deg_jitter != nullptr) deg += a.deg_jitter[(ray * a.S + i) * a.n + j] * 3.14159265358979f * 2.f;
+    float sn, cs;
+    sincosf(deg, &sn, &cs);
+    const float lx = rad * t * cs / 2.f, ly = rad * t * sn / 2.f;
+    float x[3], z[3], x01[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) x[k] = lx * bx[k] + ly * by[k] + t * d[k] + o[k];
+    const float std_raw = a.std_scale * rad * t;
+    const float msq_raw = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
+    const float msq = fmaxf(msq_raw, 1.1920929e-07f);
+    const bool contracted = !(msq <= 1.f);
+    float mag = 1.f, sc = 1.f, q = 1.f, det = 1.f, cb = 1.f, sd = std_raw / 2.f;
+    if (contracted) {
+      mag = sqrtf(msq); sc = (2.f * mag - 1.f) / msq; q = 2.f / mag - 1.f / msq; det = (1.f / msq) * (q * q); cb = cbrtf(det);
+      sd = cb * std_raw / 2.f;
+    }
+    bool inb = true;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { z[k] = contracted ? sc * x[k] : x[k]; x01[k] = (z[k] / 2.f + 1.f) / 2.f; inb = inb && x01[k] >= 0.f && x01[k] <= 1.f; }
+    if (!inb) continue;                                     // the encoder returns zeros (and no gradient) outside the grid
+    float gx01[3] = {0.f, 0.f, 0.f}, gsd = 0.f;
+    for (int level = 0; level < a.L; ++level) {
+      const uint32_t hs = a.offsets[level + 1] - a.offsets[level];
+      const float scale = exp2f(level * a.Sl) * a.H - 1.0f;
+      const uint32_t res = (uint32_t)ceilf(scale) + 1;
+      const TT* tab = (const TT*)a.table + (long)a.offsets[level] * C;
+      const float gs = (float)a.grid_sizes[level];
+      const float u = 1.f / sqrtf(8.f * sd * sd * gs * gs);
+      const float we = erff(u);
+      float fr[3];
+      uint32_t pg[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float ps = x01[k] * scale + 0.5f;
+        const float fl = floorf(ps);
+        pg[k] = (uint32_t)fl;
+        fr[k] = ps - fl;
+      }
+      float gl[C];
+#pragma unroll
+      for (int c = 0; c < C; ++c) gl[c] = (float)gi[level * C + c] / (float)a.n;
+      float s_fg = 0.f, dfx[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int idx = 0; idx < 8; ++idx) {
+        uint32_t pl[3];
+        float wk[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const bool hi = idx & (1 << k); pl[k] = pg[k] + (hi ? 1u : 0u); wk[k] = hi ? fr[k] : 1.f - fr[k]; }
+        const long row = zip_grid_index(hs, res, pl);
+        const ZVec<TT, C> r = *reinterpret_cast<const ZVec<TT, C>*>(tab + row * C);
+        float vg = 0.f;                                      // sum_c g_c v[corner][c]
+#pragma unroll
+        for (int c = 0; c < C; ++c) vg += gl[c] * (float)r.v[c];
+        s_fg += (wk[0] * wk[1] * wk[2]) * vg;
+        dfx[0] += ((idx & 1) ? vg : -vg) * (wk[1] * wk[2]);
+        dfx[1] += ((idx & 2) ? vg : -vg) * (wk[0] * wk[2]);
+        dfx[2] += ((idx & 4) ? vg : -vg) * (wk[0] * wk[1]);
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) gx01[k] += we * scale * dfx[k];
+      gsd += s_fg * (1.1283791671f * expf(-u * u) * (-u / sd));   // d erf(u)/d sd, u = 1 / (sqrt(8) sd gs)
+    }
+    float dx[3];
+    if (contracted) {
+      const float dz[3] = {gx01[0] / 4.f, gx01[1] / 4.f, gx01[2] / 4.f};     // x01 = (z / 2 + 1) / 2
+      const float dot = dz[0] * x[0] + dz[1] * x[1] + dz[2] * x[2];
+      const float dsc = (1.f / mag - sc) / msq;                              // d sc / d |x|^2
+      const float dq = -1.f / (mag * msq) + 1.f / (msq * msq);
+      const float ddet = -(q * q) / (msq * msq) + (2.f * q / msq) * dq;
+      const float dsd = std_raw * 0.5f * (cb / (3.f * det)) * ddet;           // d sd / d |x|^2
+      const float coef = msq_raw > 1.1920929e-07f ? 2.f * (dsc * dot + gsd * dsd) : 0.f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) dx[k] = sc * dz[k] + coef * x[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) dx[k] = gx01[k] / 4.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { go[k] += dx[k]; gd[k] += t * dx[k]; gbx[k] += lx * dx[k]; gby[k] += ly * dx[k]; }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    atomicAdd(g_o + ray * 3 + k, go[k]); atomicAdd(g_d + ray * 3 + k, gd[k]);
+    atomicAdd(g_bx + ray * 3 + k, gbx[k]); atomicAdd(g_by + ray * 3 + k, gby[k]);
+  }
+}
+
+extern "C" int snerf_zip_encode_ray_bwd(const float* tdist, const float* origins, const float* directions, const float* radii,
+                                        const float* base_x, const float* base_y, const float* deg_jitter, const void* table,
+                                        const int* offsets, const int* grid_sizes, const void* grad_feat, long ld, long R, int S, int L, int C,
+                                        int n, int m, float Sl, int H, float std_scale, int table_dtype, int feat_dtype, float* g_origins,
+                                        float* g_directions, float* g_base_x, float* g_base_y, void* stream) {
+  if (R <= 0) return SNERF_OK;
+  if (S <= 0 || L <= 0 || n <= 0 || table == nullptr || grad_feat == nullptr || g_origins == nullptr || g_directions == nullptr ||
+      g_base_x == nullptr || g_base_y == nullptr || (C != 1 && C != 4))
+    return SNERF_ERR_ARG;
+  ZipEnc a{};
+  a.tdist = tdist; a.origins = origins; a.directions = directions; a.radii = radii; a.base_x = base_x; a.base_y = base_y;
+  a.deg_jitter = deg_jitter; a.table = table; a.offsets = offsets; a.grid_sizes = grid_sizes; a.feat = (void*)grad_feat; a.ld = ld;
+  a.R = R; a.S = S; a.L = L; a.n = n; a.m = m; a.Sl = Sl; a.H = H; a.std_scale = std_scale;
+  const dim3 grid((unsigned)((R * S + 255) / 256)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  // table: fp32 (0) or fp16 (2); gradient features: fp32 (0) or bf16 (1)
+#define ZRB(TT, OT, CC) hipLaunchKernelGGL((zip_encode_ray_bwd_kernel<TT, OT, CC>), grid, block, 0, s, a, g_origins, g_directions, g_base_x, g_base_y)
+  if (table_dtype == 2 && feat_dtype == SNERF_DT_BF16) { if (C == 4) ZRB(__half, __bf16, 4); else ZRB(__half, __bf16, 1); }
+  else if (table_dtype == 2 && feat_dtype == SNERF_DT_F32) { if (C == 4) ZRB(__half, float, 4); else ZRB(__half, float, 1); }
+  else if (table_dtype == 0 && feat_dtype == SNERF_DT_BF16) { if (C == 4) ZRB(float, __bf16, 4); else ZRB(float, __bf16, 1); }
+  else if (table_dtype == 0 && feat_dtype == SNERF_DT_F32) { if (C == 4) ZRB(float, float, 4); else ZRB(float, float, 1); }
+  else return SNERF_ERR_ARG;
+#undef ZRB
+  return snerf_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // compositing (wave per ray)
 // ------------------------------------------------------------------------------------------------------------------
 #define ZMAXSEG 8
@@ -814,6 +955,7 @@ struct ZipComp {
   float* rgb; float* depth; float* acc; float* weights;
   const float* g_rgb; const float* g_depth; const float* g_acc; const float* g_w;
   float* d_raw_rgb; long ld_drgb; float* d_raw_density; long ld_dden;
+  float* g_dirs;                            // optional [R,3]: d loss / d directions through the interval lengths (t1 - t0) |d|
 };
 
 __global__ __launch_bounds__(256) void zip_composite_fwd_kernel(ZipComp a) {
@@ -916,7 +1058,7 @@ __global__ __launch_bounds__(256) void zip_composite_bwd_kernel(ZipComp a) {
     if (seg < nseg && i < S) pg = gval(i) * a.weights[ray * S + i];
     segG[seg] = seg < nseg ? wave_sum(pg) : 0.f;
   }
-  float carry_dd = 0.f;
+  float carry_dd = 0.f, g_norm = 0.f;
 #pragma unroll
   for (int seg = 0; seg < ZMAXSEG; ++seg) {
     if (seg >= nseg) break;
@@ -947,7 +1089,13 @@ __global__ __launch_bounds__(256) void zip_composite_bwd_kernel(ZipComp a) {
     const float t_next = expf(-(carry_dd + incl_dd));
     const float suffix = later + (wave_incl_rscan_add(gw, lane) - gw);
     if (ok) a.d_raw_density[(ray * S + i) * a.ld_dden] = inf_last ? 0.f : (g * t_next - suffix) * delta * spg;
+    // dd_i = density_i (t1 - t0) |d|: the same dL/d(dd_i) also reaches |d| (pose refinement, render.py:170-176)
+    if (ok && !inf_last) g_norm += (g * t_next - suffix) * (dd / dnorm);
     carry_dd += __shfl(incl_dd, 63, 64);
+  }
+  if (a.g_dirs != nullptr) {
+    g_norm = wave_sum(g_norm);
+    if (lane < 3) a.g_dirs[ray * 3 + lane] = g_norm * d[lane] / dnorm;
   }
 }
 
@@ -967,7 +1115,7 @@ extern "C" int snerf_zip_composite_bwd(const float* raw_rgb, long ld_rgb, const 
                                        const float* dirs, long R, int S, int opaque, float bg, float rgb_padding, float density_bias,
                                        const float* weights, const float* acc, const float* depth, const float* g_rgb, const float* g_depth,
                                        const float* g_acc, const float* g_w, float* d_raw_rgb, long ld_drgb, float* d_raw_density,
-                                       long ld_dden, void* stream) {
+                                       long ld_dden, float* g_dirs, void* stream) {
   if (R <= 0) return SNERF_OK;
   if (S <= 0 || S > 64 * ZMAXSEG || raw_density == nullptr || weights == nullptr || acc == nullptr || d_raw_density == nullptr) return SNERF_ERR_ARG;
   if ((raw_rgb != nullptr && d_raw_rgb == nullptr) || (g_depth != nullptr && depth == nullptr)) return SNERF_ERR_ARG;
@@ -976,7 +1124,7 @@ extern "C" int snerf_zip_composite_bwd(const float* raw_rgb, long ld_rgb, const 
   a.opaque = opaque; a.bg = bg; a.rgb_padding = rgb_padding; a.density_bias = density_bias;
   a.weights = (float*)weights; a.acc = (float*)acc; a.depth = (float*)depth;
   a.g_rgb = g_rgb; a.g_depth = g_depth; a.g_acc = g_acc; a.g_w = g_w;
-  a.d_raw_rgb = d_raw_rgb; a.ld_drgb = ld_drgb; a.d_raw_density = d_raw_density; a.ld_dden = ld_dden;
+  a.d_raw_rgb = d_raw_rgb; a.ld_drgb = ld_drgb; a.d_raw_density = d_raw_density; a.ld_dden = ld_dden; a.g_dirs = g_dirs;
   hipLaunchKernelGGL(zip_composite_bwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
   return snerf_check_launch();
 }

@@ -760,6 +760,8 @@ class ZipNerfNet(_Net):
             for c in range(min(g, B)):
                 out[c, 2 * Wd + c] = 1.0
             self.tw["xcat"] = out
+            # gradient w.r.t. the view-direction encoding (pose refinement): both second-stage layers read it, one K-concatenated GEMM
+            self._pack_dgrad_cols("denc", [("lin_second_stage_0", B), ("lin_second_stage_1", Wd + B)], dd)
 
     def alloc(self, M):
         """-> (F, SB): the featurisation kernel writes F[:, :feat_dim] (F arrives zeroed), the view encoder SB[:, Wd+B:]."""
@@ -780,8 +782,9 @@ class ZipNerfNet(_Net):
         self.fwd("rgb", H3, Wd, raw_rgb, 3, ACT_NONE, out_f32=True)
         return raw_rgb, raw_d, ((Fb, H1, SB, H3) if keep else None)
 
-    def backward(self, d_raw_rgb, d_raw_density, saved):
-        """-> dF [P, Fw].  d_raw_density [P, 1] or [P, 1 + C]: column 0 = d raw density, columns 1.. = d semantic logits."""
+    def backward(self, d_raw_rgb, d_raw_density, saved, want_dir_grad=False):
+        """-> dF [P, Fw] (or (dF, dD fp32 [P, Dw]) with `want_dir_grad`: the gradient w.r.t. the direction encoding).
+        d_raw_density [P, 1] or [P, 1 + C]: column 0 = d raw density, columns 1.. = d semantic logits."""
         Fb, H1, SB, H3 = saved
         M, B, Wd, g = d_raw_rgb.shape[0], self.Bw, self.Wd, self.g
         self.colsum(d_raw_rgb, 3, self.gB("rgb_layer"))
@@ -802,4 +805,6 @@ class ZipNerfNet(_Net):
         self.wgrad("density_layer.0", dH1, Fb, self.H, self.fd)
         dF = self.buf(M, self.Fw)
         self.dgrad("d0", dH1, self.H, dF, self.Fw)
+        if want_dir_grad:
+            return dF, self.input_grad("denc", DZ[:, :2 * Wd], 2 * Wd, self.Dw)
         return dF

@@ -500,14 +500,27 @@ def zip_composite_fwd(raw_rgb, raw_density, tdist, dirs, opaque, bg, rgb_padding
 
 
 def zip_composite_bwd(raw_rgb, raw_density, tdist, dirs, opaque, bg, rgb_padding, density_bias, weights, acc, depth, g_rgb, g_depth, g_acc, g_w,
-                      d_raw_rgb, d_raw_density):
+                      d_raw_rgb, d_raw_density, g_dirs=None):
+    """`g_dirs` (optional fp32 [R,3], written): d loss / d directions through the interval lengths (t1 - t0) |d|."""
     R, P = tdist.shape
-    for t in (g_rgb, g_depth, g_acc, g_w, weights, acc, depth):
+    for t in (g_rgb, g_depth, g_acc, g_w, weights, acc, depth, g_dirs):
         _f32c(t)
     _lib.call("snerf_zip_composite_bwd", _p(raw_rgb), 0 if raw_rgb is None else raw_rgb.stride(0), _p(raw_density), raw_density.stride(0),
               _p(tdist), _p(dirs), R, P - 1, 1 if opaque else 0, float(bg), float(rgb_padding), float(density_bias), _p(weights), _p(acc),
               _p(depth), _p(g_rgb), _p(g_depth), _p(g_acc), _p(g_w), _p(d_raw_rgb), 0 if d_raw_rgb is None else d_raw_rgb.stride(0),
-              _p(d_raw_density), d_raw_density.stride(0), _stream())
+              _p(d_raw_density), d_raw_density.stride(0), _p(g_dirs), _stream())
+
+
+def zip_encode_ray_bwd(tdist, origins, directions, radii, base_x, base_y, deg_jitter, table, offsets, grid_sizes, grad_feat, L, C, n, m, Sl, H,
+                       std_scale, g_o, g_d, g_bx, g_by):
+    """Featurisation backward to the rays (cal_input_grad): accumulates d loss / d (origins, directions, base_x, base_y) [R,3]."""
+    for t in (tdist, origins, directions, radii, base_x, base_y, deg_jitter, g_o, g_d, g_bx, g_by):
+        _f32c(t)
+    R, P = tdist.shape
+    assert table.is_contiguous() and grad_feat.stride(1) == 1
+    _lib.call("snerf_zip_encode_ray_bwd", _p(tdist), _p(origins), _p(directions), _p(radii), _p(base_x), _p(base_y), _p(deg_jitter), _p(table),
+              _p(offsets), _p(grid_sizes), _p(grad_feat), grad_feat.stride(0), R, P - 1, L, C, n, m, float(Sl), int(H), float(std_scale),
+              _zip_dt(table), _zip_dt(grad_feat), _p(g_o), _p(g_d), _p(g_bx), _p(g_by), _stream())
 
 
 # ------------------------------------------------- callers (SURVEY 8f) ----

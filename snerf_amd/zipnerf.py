@@ -6,6 +6,9 @@ signature, the same ``(renderings, ray_history)`` return layout (keys ``rgb``/``
 ``sdist``/``weights``/``tdist``/``density``/``rgb``) and the same ``state_dict`` keys / shapes (``nerf_mlp.encoder.embeddings``,
 ``nerf_mlp.density_layer.0.weight``, ``nerf_mlp.lin_second_stage_1.weight``, ``prop_mlp_0.encoder.offsets`` ...).
 
+``cal_input_grad=True`` (pose refinement, zipnerf/train.py:187-224) back-propagates to ``batch['origins' / 'directions' / 'viewdirs' /
+'base_x' / 'base_y']`` when they require grad.
+
 Accelerated branch = what ``configs/waymo.gin`` + class defaults run: ``raydist_fn='power_transformation'``, distinct proposal
 MLPs with C = 1 grids (desired resolution 512 / 2048), NeRF grid C = 4 (8192), ``disable_density_normals``, ``deg_view = 1``,
 no GLO / exposure / semantic head, ``single_jitter``.  Everything else raises NotImplementedError (no eager fallback).
@@ -225,14 +228,19 @@ class Model(_ArenaModule):
         ctx = None
         if keep:   # detached aliases: the originals become outputs of the autograd Function (no graph / reference cycle through ctx)
             det = [{k: (v.detach() if torch.is_tensor(v) else v) for k, v in L.items()} for L in levels]
-            ctx = dict(o=o, d=d, radii=radii, bx=bx, by=by, levels=det, bg=bg, n=sample_n, m=sample_m)
+            ctx = dict(o=o, d=d, vd=vd, radii=radii, bx=bx, by=by, levels=det, bg=bg, n=sample_n, m=sample_m)
         return levels, ctx
 
-    def _backward(self, ctx, grads, on_done=None):
+    def _backward(self, ctx, grads, on_done=None, ray_grads=False):
         """grads[lvl] = (g_rgb, g_depth, g_acc, g_w); accumulates parameter gradients into the arena.  `on_done(prefix)` is called as
-        soon as a level's gradients (MLP + hash table) are final, NeRF level first."""
+        soon as a level's gradients (MLP + hash table) are final, NeRF level first.
+        `ray_grads` (pose refinement, the reference's `cal_input_grad`: zipnerf/train.py:187-197): also returns d loss / d (origins,
+        directions, viewdirs, base_x, base_y) [R,3] -- through the hash-grid positions and the erf down-weighting of every level
+        (`snerf_zip_encode_ray_bwd`), the view-direction encoding and the interval lengths (t1 - t0)|d| of the compositing.  Fence
+        posts carry no gradient (stop_level_grad)."""
         dev = ctx["o"].device
         cc = lambda t: None if t is None else t.contiguous().float()
+        rg = [torch.zeros_like(ctx["o"]) for _ in range(5)] if ray_grads else None      # o, d, vd, bx, by
         for lvl in (2, 1, 0):
             g_rgb, g_depth, g_acc, g_w = grads[lvl][:4]
             g_sem = grads[lvl][4] if len(grads[lvl]) > 4 else None
@@ -253,12 +261,25 @@ class Model(_ArenaModule):
                 if d_rgb is not None:
                     d_rgb.zero_()
             else:
+                gdir = torch.empty_like(ctx["d"]) if ray_grads else None
                 ops.zip_composite_bwd(L["raw_rgb"], L["raw_d"], L["tdist"], ctx["d"], self.opaque_background, ctx["bg"], 0.001, -1.0, L["weights"],
-                                      L["acc"], L["depth"], cc(g_rgb), cc(g_depth), cc(g_acc), cc(g_w), d_rgb, d_den)
+                                      L["acc"], L["depth"], cc(g_rgb), cc(g_depth), cc(g_acc), cc(g_w), d_rgb, d_den, g_dirs=gdir)
+                if ray_grads:
+                    rg[1] += gdir
             if sem_on:
                 ops.semantic_composite_bwd(L["weights"], L["logits"], cc(g_sem), self.class_num, True, d_dl[:, 1:])
             d_den = d_dl if sem_on else d_den
-            dF = net.backward(d_den, L["saved"]) if lvl < 2 else net.backward(d_rgb, d_den, L["saved"])
+            if lvl < 2:
+                dF = net.backward(d_den, L["saved"])
+            elif ray_grads:
+                dF, dD = net.backward(d_rgb, d_den, L["saved"], want_dir_grad=True)
+                rg[2] += ops.mip_viewenc_bwd(ctx["vd"], L["ns"], 1, dD)                 # dir_enc = pos_enc(viewdirs, 0, deg_view = 1)
+            else:
+                dF = net.backward(d_rgb, d_den, L["saved"])
+            if ray_grads:
+                ops.zip_encode_ray_bwd(L["tdist"], ctx["o"], ctx["d"], ctx["radii"], ctx["bx"], ctx["by"], L["degj"], self._table(lvl),
+                                       self.dev_offsets[lvl], self.dev_sizes[lvl], dF, e.L, e.C, ctx["n"], ctx["m"], e.Sl, e.H, self.std_scale,
+                                       rg[0], rg[1], rg[3], rg[4])
             gtab = self.arena.g[self.names[lvl] + "encoder.embeddings"]
             g16 = None
             if self.table_grad_bf16 and (e.C % 2 == 0 or e.C == 1):
@@ -272,6 +293,7 @@ class Model(_ArenaModule):
                 gtab.add_(g16)
             if on_done is not None:
                 on_done(self.names[lvl])
+        return rg
 
     def _draws(self, R, rand, dev, sample_n):
         """the reference's RNG draws in its order: per level one single-jitter draw (stepfun.py:216) then the helix phase
@@ -322,9 +344,14 @@ class Model(_ArenaModule):
     def forward(self, rand, batch, train_frac, compute_extras, zero_glo=True, sample_n=7, sample_m=3, step=0, max_step=25000,
                 cal_input_grad=False, draws=None):
         """-> (renderings, ray_history) like models.py:98-349.  `draws` = [(u, deg_jitter)] * 3 overrides the RNG (parity tests)."""
-        if cal_input_grad:
-            raise NotImplementedError("pose refinement through the hash grid (cal_input_grad) is not on the accelerated path")
         self._check_arena()
+        rkeys = ('origins', 'directions', 'viewdirs', 'base_x', 'base_y')
+        ray_grad = torch.is_grad_enabled() and any(torch.is_tensor(batch[k]) and batch[k].requires_grad for k in rkeys)
+        if ray_grad and not cal_input_grad:
+            raise NotImplementedError("rays that require grad need cal_input_grad=True (the pose-refinement mode of zipnerf/train.py:187-224); "
+                                      "the partial gradient the reference would form without the encoder's input gradient is not provided")
+        if ray_grad and compute_extras:
+            raise NotImplementedError("compute_extras is the rendering mode: no gradients")
         dev = self.arena.flat.device
         R = batch['origins'].shape[0]
         if draws is None:
@@ -332,8 +359,9 @@ class Model(_ArenaModule):
         if compute_extras:
             return self._forward_extras(batch, float(train_frac), draws, sample_n, sample_m)
         params = self.param_list()
-        keep = torch.is_grad_enabled() and any(p.requires_grad for p in params)
-        outs = _ZipFn.apply(self, batch, keep, float(train_frac), draws, sample_n, sample_m, *params)
+        keep = torch.is_grad_enabled() and (ray_grad or any(p.requires_grad for p in params))
+        rt = tuple(batch[k] for k in rkeys) if ray_grad else (None,) * 5
+        outs = _ZipFn.apply(self, batch, keep, float(train_frac), draws, sample_n, sample_m, *rt, *params)
         renderings, history = [], []
         for lvl in range(3):
             rgb, depth, acc, w, sd, td = outs[6 * lvl:6 * lvl + 6]
@@ -425,10 +453,11 @@ def render_image(render_fn, accelerator, batch, rand, config):
 
 class _ZipFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, model, batch, keep, train_frac, draws, sample_n, sample_m, *params):
+    def forward(ctx, model, batch, keep, train_frac, draws, sample_n, sample_m, ray_o, ray_d, ray_vd, ray_bx, ray_by, *params):
         ctx.set_materialize_grads(False)
         levels, c = model._run(batch, keep, train_frac, draws, sample_n, sample_m)
         ctx.model, ctx.c = model, c
+        ctx.ray_meta = None if ray_o is None else [(t.shape, t.dtype, t.device) for t in (ray_o, ray_d, ray_vd, ray_bx, ray_by)]
         outs, nondiff = [], []
         for L in levels:
             outs += [L["rgb"], L["depth"], L["acc"], L["weights"], L["sdist"], L["tdist"]]
@@ -447,8 +476,11 @@ class _ZipFn(torch.autograd.Function):
         grads = [(g[6 * l], g[6 * l + 1], g[6 * l + 2], g[6 * l + 3]) for l in range(3)]
         if m.use_semantic:
             grads[2] = grads[2] + (g[18],)
-        m._backward(ctx.c, grads)
+        rg = m._backward(ctx.c, grads, ray_grads=ctx.ray_meta is not None)
         ctx.c = None
         grads = tuple(m.arena.g[n].clone() for n in m._pnames)
         m.arena.grad.zero_()      # the trainers accumulate into the arena and expect it clean at step start
-        return (None,) * 7 + grads
+        if rg is None:
+            return (None,) * 12 + grads
+        rays_g = tuple(g.reshape(sh).to(device=dev, dtype=dt) for g, (sh, dt, dev) in zip(rg, ctx.ray_meta))
+        return (None,) * 7 + rays_g + grads

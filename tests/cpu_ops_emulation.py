@@ -248,11 +248,46 @@ def zip_composite_fwd(raw_rgb, raw_density, tdist, dirs, opaque, bg, rgb_padding
     return r["rgb"], r["depth"], r["acc"], w
 
 
+class GridFn(torch.autograd.Function):
+    """Differentiable wrapper of the oracle's hash-grid encoder (oracle/grid.py): features [B, L, C] of positions x01 [B,3] in [0,1];
+    backward = the reference's kernel_grid_backward (table) and kernel_input_backward via dy_dx (positions)."""
+
+    @staticmethod
+    def forward(ctx, x01, table, offsets, Sl, H):
+        from oracle import grid as og
+        x = x01.detach().numpy().astype("float32")
+        out, dy_dx = og.grid_encode_forward(x, table.detach().float().numpy(), offsets, Sl, H, 0, False, 0, want_dy_dx=True)
+        ctx.save = (x, offsets, Sl, H, dy_dx, table.shape)
+        return torch.from_numpy(out).permute(1, 0, 2).contiguous()
+
+    @staticmethod
+    def backward(ctx, g):
+        from oracle import grid as og
+        x, offsets, Sl, H, dy_dx, tshape = ctx.save
+        gE, g_in = og.grid_encode_backward(g.permute(1, 0, 2).contiguous().numpy(), x, offsets, tshape[0], Sl, H, 0, False, 0, dy_dx=dy_dx)
+        return torch.from_numpy(g_in), torch.from_numpy(gE), None, None, None
+
+
+def zip_encode_ray_bwd(tdist, origins, directions, radii, base_x, base_y, deg_jitter, table, offsets, grid_sizes, grad_feat, L, C, n, m, Sl, H,
+                       std_scale, g_o, g_d, g_bx, g_by):
+    with torch.enable_grad():
+        leaves = [t.detach().clone().requires_grad_(True) for t in (origins, directions, base_x, base_y)]
+        x01, s = _zip_points(tdist, leaves[0], leaves[1], radii, leaves[2], leaves[3], deg_jitter, n, m, std_scale)
+        f = GridFn.apply(x01.reshape(-1, 3), table.float(), offsets.numpy(), Sl, H).reshape(list(x01.shape[:-1]) + [L, C])
+        w = torch.erf(1 / torch.sqrt(8 * s[..., None] ** 2 * grid_sizes.float() ** 2))
+        feat = (f * w[..., None]).mean(dim=-3).flatten(-2, -1).reshape(-1, L * C)
+        (feat * grad_feat[:, :L * C].float()).sum().backward()
+    for dst, leaf in zip((g_o, g_d, g_bx, g_by), leaves):
+        dst += leaf.grad
+
+
 def zip_composite_bwd(raw_rgb, raw_density, tdist, dirs, opaque, bg, rgb_padding, density_bias, weights, acc, depth, g_rgb, g_depth, g_acc, g_w,
-                      d_raw_rgb, d_raw_density):
+                      d_raw_rgb, d_raw_density, g_dirs=None):
     with torch.enable_grad():
         rr = None if raw_rgb is None else raw_rgb.detach().clone().requires_grad_(True)
         rd = raw_density.detach().clone().requires_grad_(True)
+        if g_dirs is not None:
+            dirs = dirs.detach().clone().requires_grad_(True)
         outs = zip_composite_fwd(rr, rd, tdist, dirs, opaque, bg, rgb_padding, density_bias)
         loss = 0
         for o, g in zip(outs, (g_rgb, g_depth, g_acc, g_w)):
@@ -262,6 +297,8 @@ def zip_composite_bwd(raw_rgb, raw_density, tdist, dirs, opaque, bg, rgb_padding
     d_raw_density.copy_(rd.grad)
     if rr is not None:
         d_raw_rgb.copy_(rr.grad if rr.grad is not None else torch.zeros_like(rr))
+    if g_dirs is not None:
+        g_dirs.copy_(dirs.grad if dirs.grad is not None else torch.zeros_like(dirs))
 
 
 def pinhole_rays(coords, first_pixel, n, W, H, pose, cx, cy, fx, fy, training, near, far, device):
@@ -485,7 +522,7 @@ def adam_step_dev(p, g, m, v, lr, b1, b2, eps, step_dev, grad_scale=1.0, zero_gr
     adam_step(p, g, m, v, lr, b1, b2, eps, 0, grad_scale, zero_grad, step_dev=step_dev, **kw)
 
 
-_NAMES = ["adam_step_dev", "grad_clip_coef", "fmlp_classic_fwd", "fmlp_classic_pts_fwd", "fmlp_proposal_fwd", "classic_get_rays", "classic_ndc_rays", "classic_ray_batch", "zip_encode_prop_fwd", "mip_encode_bwd", "mip_viewenc_bwd", "hash_decay", "zip_percentiles", "zip_pixels_to_rays", "zip_loss_tail", "semantic_composite_fwd", "semantic_composite_bwd", "zip_resample", "zip_encode_fwd", "zip_encode_bwd", "zip_composite_fwd", "zip_composite_bwd",
+_NAMES = ["adam_step_dev", "grad_clip_coef", "fmlp_classic_fwd", "fmlp_classic_pts_fwd", "fmlp_proposal_fwd", "classic_get_rays", "classic_ndc_rays", "classic_ray_batch", "zip_encode_prop_fwd", "mip_encode_bwd", "mip_viewenc_bwd", "hash_decay", "zip_percentiles", "zip_pixels_to_rays", "zip_loss_tail", "semantic_composite_fwd", "semantic_composite_bwd", "zip_resample", "zip_encode_fwd", "zip_encode_bwd", "zip_encode_ray_bwd", "zip_composite_fwd", "zip_composite_bwd",
           "linear_fwd", "linear_wgrad", "classic_embed", "mip_encode", "mip_viewenc", "classic_sample_pdf", "classic_points",
           "classic_merge_sort", "mip_resample", "stratified", "mip_composite_fwd", "mip_composite_bwd", "classic_composite_fwd",
           "classic_composite_bwd", "adam_step", "colsum_f32", "cast_pad", "pinhole_rays", "mip_loss_tail"]
