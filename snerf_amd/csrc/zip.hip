@@ -800,6 +800,223 @@ extern "C" int snerf_zip_encode_bwd(const float* tdist, const float* origins, co
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Table gradient WITHOUT the atomic wall: bin, then accumulate in LDS ("binned" mode).
+//
+// The scatter of gridencoder.cu:248-340 issues one fp32 atomic per (multisample, corner, channel): 3.3 G per 65 536-ray step for the
+// NeRF grid alone, against a hardware rate of 20.6 G/s that no scope / layout choice moves (profiles/r1_q) -- 79 % of the step, and
+// the order of the additions (hence the low bits of the gradient) changes from run to run.  Here the same contributions are first
+// written out as RECORDS (row inside its bin: 2 bytes, value: C floats), partitioned by destination -- bin = (level, range of 4096 /
+// 16384 table rows (C = 4 / 1), replica) -- and then ONE workgroup per bin adds its records into an LDS image of those rows with
+// 64-bit FIXED-POINT integer atomics (2^-36 resolution): LDS atomics are ~2 orders of magnitude cheaper than L2 atomics, every
+// table row is written back by exactly one workgroup, and integer addition is associative, so the gradient is BIT-IDENTICAL run to
+// run whatever order the records arrive in.  Levels whose rows are few but hot (the dense levels: 4913 rows take 118 M records)
+// are split into K replicas that meet in a small global int64 image (again order-independent).
+//   pass 0  zip_bin_emit_kernel<.., 0>  count the records per bin (per-workgroup LDS histogram, one global atomic per non-empty bin)
+//           (host: exclusive scan of the counts -> bin offsets)
+//   pass 1  zip_bin_emit_kernel<.., 1>  reserve a range per (workgroup, bin), write the records
+//   pass 2  zip_bin_accumulate_kernel   one workgroup per bin: LDS fixed-point accumulation, write-back (+= into the fp32 gradient)
+//   pass 3  zip_bin_finish_kernel       fold the replicated levels' int64 image into the gradient
+// ------------------------------------------------------------------------------------------------------------------
+#define ZB_NBMAX 1024                      // bins per level (row ranges x replicas)
+#define ZB_FIX 68719476736.f               // 2^36
+
+struct ZipBin {
+  int bshift;                              // log2(rows per bin)
+  int* counts;                             // [L, ZB_NBMAX] records per bin
+  long* cursors;                           // [L, ZB_NBMAX] next free record of the bin (starts at the bin's offset)
+  const long* starts;                      // [L, ZB_NBMAX] bin offsets (accumulate pass)
+  int ksplit[16];                          // replicas per row range, per level
+  unsigned short* rec_row; float* rec_val; long capacity;
+  long long* g64; long g64_rows;           // int64 image of table rows [0, g64_rows) for the replicated levels
+};
+
+// the records of one (interval, level): same merging of consecutive multisamples in one cell as the atomic path
+template <typename OT, int C, bool WRITE>
+__device__ __forceinline__ void zip_emit_level(const ZipEnc& a, const ZipBin& b, long p, int level, int* lds_cnt, const long* lds_base) {
+  const long ray = p / a.S;
+  const int i = (int)(p - ray * a.S);
+  const float t0 = a.tdist[ray * (a.S + 1) + i], t1 = a.tdist[ray * (a.S + 1) + i + 1];
+  float o[3], d[3], bx[3], by[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { o[k] = a.origins[ray * 3 + k]; d[k] = a.directions[ray * 3 + k]; bx[k] = a.base_x[ray * 3 + k]; by[k] = a.base_y[ray * 3 + k]; }
+  const float rad = a.radii[ray];
+  const uint32_t hs = a.offsets[level + 1] - a.offsets[level];
+  const float scale = exp2f(level * a.Sl) * a.H - 1.0f;
+  const uint32_t res = (uint32_t)ceilf(scale) + 1;
+  const int K = b.ksplit[level], rep = (int)(blockIdx.x % (unsigned)K);
+  float g[C];
+  const OT* gi = (const OT*)a.feat + p * a.ld + level * C;
+#pragma unroll
+  for (int c = 0; c < C; ++c) g[c] = (float)gi[c] / (float)a.n;
+  uint32_t cur[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
+  float wsum[8];
+#pragma unroll
+  for (int idx = 0; idx < 8; ++idx) wsum[idx] = 0.f;
+  auto flush = [&]() {
+    if (cur[0] == 0xffffffffu) return;
+#pragma unroll
+    for (int idx = 0; idx < 8; ++idx) {
+      uint32_t pl[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) pl[k] = cur[k] + ((idx >> k) & 1);
+      const uint32_t row = zip_grid_index(hs, res, pl);
+      const int bin = (int)(row >> b.bshift) * K + rep;
+      const int slot = atomicAdd(lds_cnt + bin, 1);
+      if (WRITE) {
+        const long r = lds_base[bin] + slot;
+        if (r < b.capacity) {
+          b.rec_row[r] = (unsigned short)(row & ((1u << b.bshift) - 1u));
+#pragma unroll
+          for (int c = 0; c < C; ++c) b.rec_val[r * C + c] = wsum[idx] * g[c];
+        }
+      }
+      wsum[idx] = 0.f;
+    }
+  };
+  for (int j = 0; j < a.n; ++j) {
+    float x01[3], sd;
+    zip_sample_point(a, ray, i, j, t0, t1, o, d, bx, by, rad, x01, &sd);
+    if (x01[0] < 0.f || x01[0] > 1.f || x01[1] < 0.f || x01[1] > 1.f || x01[2] < 0.f || x01[2] > 1.f) continue;
+    const float gs = (float)a.grid_sizes[level];
+    const float we = erff(1.f / sqrtf(8.f * sd * sd * gs * gs));
+    float fr[3];
+    uint32_t pg[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float ps = x01[k] * scale + 0.5f;
+      const float fl = floorf(ps);
+      pg[k] = (uint32_t)fl;
+      fr[k] = ps - fl;
+    }
+    if (pg[0] != cur[0] || pg[1] != cur[1] || pg[2] != cur[2]) {
+      flush();
+      cur[0] = pg[0]; cur[1] = pg[1]; cur[2] = pg[2];
+    }
+#pragma unroll
+    for (int idx = 0; idx < 8; ++idx) {
+      float w = 1.f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) w *= (idx & (1 << k)) ? fr[k] : 1.f - fr[k];
+      wsum[idx] += w * we;
+    }
+  }
+  flush();
+}
+
+template <typename OT, int C, int PASS>
+__global__ __launch_bounds__(256) void zip_bin_emit_kernel(ZipEnc a, ZipBin b) {
+  __shared__ int cnt[ZB_NBMAX];
+  __shared__ long base[ZB_NBMAX];
+  const int level = blockIdx.y;
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  const bool live = p < a.R * a.S;
+  for (int k = threadIdx.x; k < ZB_NBMAX; k += 256) cnt[k] = 0;
+  __syncthreads();
+  if (live) zip_emit_level<OT, C, false>(a, b, p, level, cnt, nullptr);
+  __syncthreads();
+  if (PASS == 0) {
+    for (int k = threadIdx.x; k < ZB_NBMAX; k += 256)
+      if (cnt[k] != 0) atomicAdd(b.counts + level * ZB_NBMAX + k, cnt[k]);
+    return;
+  }
+  for (int k = threadIdx.x; k < ZB_NBMAX; k += 256) {
+    base[k] = cnt[k] != 0 ? (long)atomicAdd((unsigned long long*)(b.cursors + level * ZB_NBMAX + k), (unsigned long long)cnt[k]) : 0;
+    cnt[k] = 0;
+  }
+  __syncthreads();
+  if (live) zip_emit_level<OT, C, true>(a, b, p, level, cnt, base);
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void zip_bin_accumulate_kernel(ZipEnc a, ZipBin b) {
+  extern __shared__ long long zb_acc[];
+  const int level = blockIdx.y, bin = blockIdx.x;
+  const int K = b.ksplit[level];
+  const long rows_l = a.offsets[level + 1] - a.offsets[level];
+  const long row0 = (long)(bin / K) << b.bshift;
+  if (row0 >= rows_l) return;                              // bins past the level's last row range
+  const int n = b.counts[level * ZB_NBMAX + bin];
+  const int cells = (int)min((long)(1 << b.bshift), rows_l - row0) * C;
+  for (int k = threadIdx.x; k < cells; k += 256) zb_acc[k] = 0;
+  __syncthreads();
+  const long s0 = b.starts[level * ZB_NBMAX + bin];
+  for (int r = threadIdx.x; r < n; r += 256) {
+    const long q = s0 + r;
+    const int row = b.rec_row[q];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float v = fminf(fmaxf(b.rec_val[q * C + c], -1.0e8f), 1.0e8f);
+      atomicAdd((unsigned long long*)(zb_acc + row * C + c), (unsigned long long)__float2ll_rn(v * ZB_FIX));
+    }
+  }
+  __syncthreads();
+  const long grow = (long)a.offsets[level] + row0;
+  if (K == 1) {                                             // the only workgroup that owns these rows
+    float* dst = a.grad_table + grow * C;
+    for (int k = threadIdx.x; k < cells; k += 256) {
+      const long long v = zb_acc[k];
+      if (v != 0) dst[k] += (float)((double)v * (1.0 / (double)ZB_FIX));
+    }
+  } else {
+    long long* dst = b.g64 + grow * C;
+    for (int k = threadIdx.x; k < cells; k += 256) {
+      const long long v = zb_acc[k];
+      if (v != 0) atomicAdd((unsigned long long*)(dst + k), (unsigned long long)v);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void zip_bin_finish_kernel(const long long* __restrict__ g64, long n, float* __restrict__ grad) {
+  for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < n; k += (long)gridDim.x * 256) {
+    const long long v = g64[k];
+    if (v != 0) grad[k] += (float)((double)v * (1.0 / (double)ZB_FIX));
+  }
+}
+
+// pass: 0 = count, 1 = write records, 2 = accumulate (+ finish).  The host zeroes counts / g64, scans counts into starts / cursors.
+extern "C" int snerf_zip_encode_bwd_binned(int pass, const float* tdist, const float* origins, const float* directions, const float* radii,
+                                           const float* base_x, const float* base_y, const float* deg_jitter, const int* offsets,
+                                           const int* grid_sizes, const void* grad_feat, long ld, float* grad_table, long R, int S, int L, int C,
+                                           int n, int m, float Sl, int H, float std_scale, int feat_dtype, const int* ksplit_host, int* counts,
+                                           long* cursors, const long* starts, void* rec_row, float* rec_val, long capacity, void* g64,
+                                           long g64_rows, void* stream) {
+  if (R <= 0) return SNERF_OK;
+  if (S <= 0 || L <= 0 || L > 16 || n <= 0 || (C != 1 && C != 4) || ksplit_host == nullptr || counts == nullptr) return SNERF_ERR_ARG;
+  ZipEnc a{tdist, origins, directions, radii, base_x, base_y, deg_jitter, nullptr, offsets, grid_sizes, (void*)grad_feat, ld, grad_table, nullptr, R, S, L, n, m, Sl, H, std_scale};
+  ZipBin b{};
+  b.bshift = C == 4 ? 12 : 14;
+  b.counts = counts; b.cursors = cursors; b.starts = starts;
+  for (int l = 0; l < L; ++l) { b.ksplit[l] = ksplit_host[l]; if (b.ksplit[l] < 1) return SNERF_ERR_ARG; }
+  b.rec_row = (unsigned short*)rec_row; b.rec_val = rec_val; b.capacity = capacity; b.g64 = (long long*)g64; b.g64_rows = g64_rows;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 blk(256);
+  if (pass == 0 || pass == 1) {
+    if (grad_feat == nullptr || (pass == 1 && (cursors == nullptr || rec_row == nullptr || rec_val == nullptr))) return SNERF_ERR_ARG;
+    const dim3 grid((unsigned)((R * S + 255) / 256), L);
+#define ZBE(OT, CC) do { if (pass == 0) hipLaunchKernelGGL((zip_bin_emit_kernel<OT, CC, 0>), grid, blk, 0, s, a, b); \
+                         else hipLaunchKernelGGL((zip_bin_emit_kernel<OT, CC, 1>), grid, blk, 0, s, a, b); } while (0)
+    if (feat_dtype == SNERF_DT_BF16) { if (C == 4) ZBE(__bf16, 4); else ZBE(__bf16, 1); }
+    else if (feat_dtype == SNERF_DT_F32) { if (C == 4) ZBE(float, 4); else ZBE(float, 1); }
+    else return SNERF_ERR_ARG;
+#undef ZBE
+    return snerf_check_launch();
+  }
+  if (pass != 2 || starts == nullptr || rec_row == nullptr || rec_val == nullptr || grad_table == nullptr) return SNERF_ERR_ARG;
+  const size_t lds = (size_t)(1 << b.bshift) * C * 8;
+  const dim3 grid(ZB_NBMAX, L);
+  if (C == 4) {
+    (void)hipFuncSetAttribute((const void*)zip_bin_accumulate_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((zip_bin_accumulate_kernel<4>), grid, blk, lds, s, a, b);
+  } else {
+    (void)hipFuncSetAttribute((const void*)zip_bin_accumulate_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((zip_bin_accumulate_kernel<1>), grid, blk, lds, s, a, b);
+  }
+  if (g64 != nullptr && g64_rows > 0)
+    hipLaunchKernelGGL(zip_bin_finish_kernel, dim3(1024), blk, 0, s, (const long long*)g64, g64_rows * C, grad_table);
+  return snerf_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Featurisation backward to the RAYS (pose refinement: `cal_input_grad`, internal/models.py:491, gridencoder/grid.py:65-89,
 // gridencoder.cu:199-244 + 343-369 (dy_dx, kernel_input_backward); zipnerf/train.py:187-197 re-poses origins / directions / base_x /
 // base_y with a learnable pose and back-propagates through the whole renderer).  One thread per interval, all levels: for each of

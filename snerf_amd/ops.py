@@ -486,6 +486,50 @@ def zip_encode_bwd(tdist, origins, directions, radii, base_x, base_y, deg_jitter
               _zip_dt(grad_feat), int(lds_levels), int(lds_cells), int(lds_slabs), _p(grad_table_bf16), _stream())
 
 
+ZB_NBMAX, ZB_TARGET = 1024, 2_000_000
+
+
+def zip_bin_plan(offsets_host, C, records_per_level):
+    """Host-side plan of the binned table gradient: per level the number of replicas K of every row range (levels with few, hot rows
+    are split so that a bin holds ~ZB_TARGET records) and the number of leading table rows the int64 meeting image must cover."""
+    br = 4096 if C == 4 else 16384
+    ks, g64_rows = [], 0
+    for l in range(len(offsets_host) - 1):
+        rows = int(offsets_host[l + 1] - offsets_host[l])
+        rowbins = max((rows + br - 1) // br, 1)
+        k = max(1, min(-(-int(records_per_level) // (rowbins * ZB_TARGET)), ZB_NBMAX // rowbins))
+        ks.append(k)
+        if k > 1:
+            g64_rows = int(offsets_host[l + 1])
+    return ks, g64_rows
+
+
+def zip_encode_bwd_binned(tdist, origins, directions, radii, base_x, base_y, deg_jitter, offsets, grid_sizes, grad_feat, grad_table, L, C, n, m, Sl, H,
+                          std_scale, ksplit, g64_rows):
+    """The table gradient of zip_encode_bwd without L2 atomics on the hashed levels and bit-reproducible: records binned by destination,
+    accumulated per bin in LDS with fixed-point integer atomics (snerf_zip_encode_bwd_binned: count, scan on the device, write, accumulate)."""
+    import numpy as np
+    R, P = tdist.shape
+    S = P - 1
+    dev = tdist.device
+    assert grad_table.dtype == torch.float32 and grad_table.is_contiguous() and C in (1, 4) and L <= 16
+    ks = np.ascontiguousarray(np.asarray(ksplit, dtype=np.int32))
+    counts = torch.zeros(L, ZB_NBMAX, dtype=torch.int32, device=dev)
+    args = (_p(tdist), _p(origins), _p(directions), _p(radii), _p(base_x), _p(base_y), _p(deg_jitter), _p(offsets), _p(grid_sizes), _p(grad_feat),
+            grad_feat.stride(0), _p(grad_table), R, S, L, C, n, m, float(Sl), int(H), float(std_scale), _zip_dt(grad_feat), ks.ctypes.data)
+    _lib.call("snerf_zip_encode_bwd_binned", 0, *args, _p(counts), None, None, None, None, 0, None, 0, _stream())
+    flat = counts.view(-1).to(torch.int64)
+    starts = (torch.cumsum(flat, 0) - flat).contiguous()
+    cursors = starts.clone()
+    capacity = R * S * n * 8 * L                               # every (interval, level) emits at most n cells x 8 corners: no host sync
+    rec_row = torch.empty(capacity, dtype=torch.int16, device=dev)
+    rec_val = torch.empty(capacity, C, dtype=torch.float32, device=dev)
+    _lib.call("snerf_zip_encode_bwd_binned", 1, *args, _p(counts), _p(cursors), _p(starts), _p(rec_row), _p(rec_val), capacity, None, 0, _stream())
+    g64 = torch.zeros(max(g64_rows, 1) * C, dtype=torch.int64, device=dev) if g64_rows > 0 else None
+    _lib.call("snerf_zip_encode_bwd_binned", 2, *args, _p(counts), _p(cursors), _p(starts), _p(rec_row), _p(rec_val), capacity, _p(g64), int(g64_rows),
+              _stream())
+
+
 def zip_composite_fwd(raw_rgb, raw_density, tdist, dirs, opaque, bg, rgb_padding, density_bias):
     _f32c(tdist); _f32c(dirs)
     R, P = tdist.shape

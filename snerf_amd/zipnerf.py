@@ -88,7 +88,7 @@ class Model(_ArenaModule):
 
     def __init__(self, config=None, compute: str = "bf16", table_dtype: str = "f16", device="cuda", grid_log2_hashmap_size: int = 21,
                  nerf_desired_resolution: int = 8192, init_std: float = 1e-4, table_grad_dtype: str = "f32", use_semantic: bool = False,
-                 class_num: int = 19, **kwargs):
+                 class_num: int = 19, table_grad_mode: str = "binned", **kwargs):
         super().__init__()
         for k, v in kwargs.items():
             setattr(self, k, v)
@@ -120,6 +120,12 @@ class Model(_ArenaModule):
         # "bf16": the hashed levels' table gradient is scattered as packed bf16 pairs (the reference's autocast path scatters
         # __half2, gridencoder.cu:300-330); "f32" (default) keeps every contribution in fp32
         self.table_grad_bf16 = {"f32": False, "fp32": False, "bf16": True}[table_grad_dtype]
+        # "binned" (default): contributions are binned by destination and accumulated per bin in LDS with fixed-point integer atomics --
+        # no L2 atomics on the hashed levels, fp32-exact sums, BIT-REPRODUCIBLE gradients (csrc/zip.hip, snerf_zip_encode_bwd_binned);
+        # "atomic": the reference's scatter (gridencoder.cu:248-340) with fp32 (or packed bf16, table_grad_dtype) global atomics
+        if table_grad_mode not in ("binned", "atomic"):
+            raise ValueError(table_grad_mode)
+        self.table_grad_mode = "atomic" if self.table_grad_bf16 else table_grad_mode
         self.nets = [ZipPropNet(self.arena, "prop_mlp_0.", self.dt, self.encs[0].L), ZipPropNet(self.arena, "prop_mlp_1.", self.dt, self.encs[1].L),
                      ZipNerfNet(self.arena, "nerf_mlp.", self.dt, self.encs[2].L * 4)]
         for n in self.nets:
@@ -281,6 +287,13 @@ class Model(_ArenaModule):
                                        self.dev_offsets[lvl], self.dev_sizes[lvl], dF, e.L, e.C, ctx["n"], ctx["m"], e.Sl, e.H, self.std_scale,
                                        rg[0], rg[1], rg[3], rg[4])
             gtab = self.arena.g[self.names[lvl] + "encoder.embeddings"]
+            if self.table_grad_mode == "binned":
+                ks, g64_rows = ops.zip_bin_plan(e.offsets, e.C, P * ctx["n"] * 8)
+                ops.zip_encode_bwd_binned(L["tdist"], ctx["o"], ctx["d"], ctx["radii"], ctx["bx"], ctx["by"], L["degj"], self.dev_offsets[lvl],
+                                          self.dev_sizes[lvl], dF, gtab, e.L, e.C, ctx["n"], ctx["m"], e.Sl, e.H, self.std_scale, ks, g64_rows)
+                if on_done is not None:
+                    on_done(self.names[lvl])
+                continue
             g16 = None
             if self.table_grad_bf16 and (e.C % 2 == 0 or e.C == 1):
                 # hashed levels scatter packed bf16 pairs (C = 4: half the atomics; C = 1: x-neighbour corners of even cells share one

@@ -18,6 +18,9 @@ def main():
     ap.add_argument("--table", default="f16")
     ap.add_argument("--log2T", type=int, default=21)
     ap.add_argument("--table-grad", default="f32", choices=["f32", "bf16"])
+    ap.add_argument("--table-grad-mode", default="binned", choices=["binned", "atomic"],
+                    help="binned (default): records binned by destination + per-bin LDS fixed-point accumulation (no L2 atomics, bit-reproducible); "
+                         "atomic: the reference's scatter with global atomics")
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--semantic", action="store_true", help="19-class semantic head on (Config.use_semantic): rendered and trained")
     ap.add_argument("--frame-only", action="store_true", help="skip the training / forward timing loops (profiling the frame)")
@@ -40,7 +43,7 @@ def main():
     from snerf_amd.trainer import ZipTrainer
     torch.manual_seed(0)
     m = zipnerf.Model(config=None, raydist_fn='power_transformation', opaque_background=True, compute=args.compute, table_dtype=args.table,
-                      grid_log2_hashmap_size=args.log2T, init_std=0.1, table_grad_dtype=args.table_grad, device=torch.device("cuda", local),
+                      grid_log2_hashmap_size=args.log2T, init_std=0.1, table_grad_dtype=args.table_grad, table_grad_mode=args.table_grad_mode, device=torch.device("cuda", local),
                       use_semantic=args.semantic)
     tr = ZipTrainer(m, lr=1e-2)
     tr.broadcast_parameters(0)
@@ -142,7 +145,7 @@ def main():
     tb = 2 if args.table == "f16" else 4
     bytes_lvl = [R * 7 * 64 * 6 * 8 * 1 * tb, R * 7 * 64 * 8 * 8 * 1 * tb, R * 7 * 32 * 10 * 8 * 4 * tb]
     out = {"path": "C (zipnerf Model, waymo.gin shape: 64+64+32 intervals x 7 multisamples, grids L=6/8/10)", "n_gpus": world, "rays_per_gpu": R,
-           "compute": args.compute, "table_grad": args.table_grad,
+           "compute": args.compute, "table_grad": args.table_grad, "table_grad_mode": model.table_grad_mode,
            "table": args.table, "train_ms": round(dt_train * 1e3, 3), "train_rays_per_s": round(world * R / dt_train, 1), "fwd_ms": round(dt_fwd * 1e3, 3),
            "fwd_rays_per_s": round(R / dt_fwd, 1), "frame_1920x1280_s": round(dt_frame, 3), "frame_outputs": sorted(k for k in img if not k.startswith("ray_")), "encode_fwd_ms_per_level": [round(x, 3) for x in enc_ms], "encode_note": "inference: proposal levels = featurisation + MLP fused",
            "encode_fwd_gather_GBps_per_level": [round(b / (ms * 1e-3) / 1e9, 1) for b, ms in zip(bytes_lvl, enc_ms)],
