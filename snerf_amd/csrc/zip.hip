@@ -517,6 +517,33 @@ __global__ __launch_bounds__(256) void zip_encode_fwd_all_kernel(ZipEnc a) {
         }
 #pragma unroll
         for (int idx = 0; idx < 8; ++idx) acc[0] += pa[idx];
+      } else if constexpr (C == 4 && sizeof(TT) == 2) {
+        // 8-byte entries (the NeRF grid's fp16 table): the two x-neighbours of a corner pair are adjacent entries whenever their rows
+        // differ only in bit 0 (every even x: the hash multiplies x by 1) -- ONE aligned 16-byte load then serves both, half of a 32-byte
+        // sector instead of a quarter.  Same products in the same order as the generic loop (corner index = x + 2 y + 4 z).
+#pragma unroll
+        for (int yz = 0; yz < 4; ++yz) {
+          uint32_t pl[3] = {pg[0], pg[1] + (yz & 1), pg[2] + (yz >> 1)};
+          const long r0 = zip_grid_index(hs, res, pl);
+          pl[0] = pg[0] + 1;
+          const long r1 = zip_grid_index(hs, res, pl);
+          ZVec<TT, 4> e0, e1;
+          if ((r0 ^ r1) == 1) {
+            const ZVec<TT, 8> both = *reinterpret_cast<const ZVec<TT, 8>*>(tab + (r0 & ~1L) * 4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { e0.v[c] = both.v[(r0 & 1) * 4 + c]; e1.v[c] = both.v[(r1 & 1) * 4 + c]; }
+          } else {
+            e0 = *reinterpret_cast<const ZVec<TT, 4>*>(tab + r0 * 4);
+            e1 = *reinterpret_cast<const ZVec<TT, 4>*>(tab + r1 * 4);
+          }
+          float wa = 1.f - fr[0], wb = fr[0];
+          wa *= (yz & 1) ? fr[1] : 1.f - fr[1]; wb *= (yz & 1) ? fr[1] : 1.f - fr[1];
+          wa *= (yz >> 1) ? fr[2] : 1.f - fr[2]; wb *= (yz >> 1) ? fr[2] : 1.f - fr[2];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[c] += (wa * we) * (float)e0.v[c];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[c] += (wb * we) * (float)e1.v[c];
+        }
       } else {
 #pragma unroll
         for (int idx = 0; idx < 8; ++idx) {
@@ -928,7 +955,7 @@ __global__ __launch_bounds__(256) void zip_bin_emit_kernel(ZipEnc a, ZipBin b) {
 }
 
 template <int C>
-__global__ __launch_bounds__(256) void zip_bin_accumulate_kernel(ZipEnc a, ZipBin b) {
+__global__ __launch_bounds__(1024) void zip_bin_accumulate_kernel(ZipEnc a, ZipBin b) {
   extern __shared__ long long zb_acc[];
   const int level = blockIdx.y, bin = blockIdx.x;
   const int K = b.ksplit[level];
@@ -937,10 +964,10 @@ __global__ __launch_bounds__(256) void zip_bin_accumulate_kernel(ZipEnc a, ZipBi
   if (row0 >= rows_l) return;                              // bins past the level's last row range
   const int n = b.counts[level * ZB_NBMAX + bin];
   const int cells = (int)min((long)(1 << b.bshift), rows_l - row0) * C;
-  for (int k = threadIdx.x; k < cells; k += 256) zb_acc[k] = 0;
+  for (int k = threadIdx.x; k < cells; k += 1024) zb_acc[k] = 0;
   __syncthreads();
   const long s0 = b.starts[level * ZB_NBMAX + bin];
-  for (int r = threadIdx.x; r < n; r += 256) {
+  for (int r = threadIdx.x; r < n; r += 1024) {          // 16 waves: the record stream needs the memory-level parallelism
     const long q = s0 + r;
     const int row = b.rec_row[q];
 #pragma unroll
@@ -953,13 +980,13 @@ __global__ __launch_bounds__(256) void zip_bin_accumulate_kernel(ZipEnc a, ZipBi
   const long grow = (long)a.offsets[level] + row0;
   if (K == 1) {                                             // the only workgroup that owns these rows
     float* dst = a.grad_table + grow * C;
-    for (int k = threadIdx.x; k < cells; k += 256) {
+    for (int k = threadIdx.x; k < cells; k += 1024) {
       const long long v = zb_acc[k];
       if (v != 0) dst[k] += (float)((double)v * (1.0 / (double)ZB_FIX));
     }
   } else {
     long long* dst = b.g64 + grow * C;
-    for (int k = threadIdx.x; k < cells; k += 256) {
+    for (int k = threadIdx.x; k < cells; k += 1024) {
       const long long v = zb_acc[k];
       if (v != 0) atomicAdd((unsigned long long*)(dst + k), (unsigned long long)v);
     }
@@ -1006,10 +1033,10 @@ extern "C" int snerf_zip_encode_bwd_binned(int pass, const float* tdist, const f
   const dim3 grid(ZB_NBMAX, L);
   if (C == 4) {
     (void)hipFuncSetAttribute((const void*)zip_bin_accumulate_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((zip_bin_accumulate_kernel<4>), grid, blk, lds, s, a, b);
+    hipLaunchKernelGGL((zip_bin_accumulate_kernel<4>), grid, dim3(1024), lds, s, a, b);
   } else {
     (void)hipFuncSetAttribute((const void*)zip_bin_accumulate_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((zip_bin_accumulate_kernel<1>), grid, blk, lds, s, a, b);
+    hipLaunchKernelGGL((zip_bin_accumulate_kernel<1>), grid, dim3(1024), lds, s, a, b);
   }
   if (g64 != nullptr && g64_rows > 0)
     hipLaunchKernelGGL(zip_bin_finish_kernel, dim3(1024), blk, 0, s, (const long long*)g64, g64_rows * C, grad_table);
