@@ -343,6 +343,19 @@ int snerf_fmlp_proposal_fwd(const void* E, long ldE, const void* wstream, long n
  * like the output of snerf_classic_embed, which remains the bit-exact fp32 statement of the encoding.  M < 2^31. */
 int snerf_fmlp_classic_pts_fwd(const float* pts, const float* viewdirs, long ldvd, int S, const void* wstream, long n_frags,
                                const float* bias, int n_blocks, float* raw, long M, void* stream);
+/* Training forward of the two networks (autograd of NeRF.forward / proposal.forward in the reference): the same launch, which also
+ * stores what the backward pass reads -- the bf16 outputs of the hidden layers and the ReLU bit masks of the 256-wide ones.
+ * acts / act_ld: HOST arrays of device pointers / row strides (elements) -- classic: 10 = pts_linears.0 .. .7 (256 wide),
+ * feature_linear (256), views_linears.0 (128); proposal: 4 = layers.0 .. .3 (256 wide).  Pointers 16-byte aligned, strides multiples
+ * of 8.  bits: HOST array of 8 (classic: pts_linears.i) / 4 (proposal) device pointers to 4 * 8 * ceil(M / 256) * 4 * 64 bytes each,
+ * written in the layout snerf_linear_fwd's act = 4 (mask bits) reads.  The per-layer snerf_linear_fwd (data gradient) /
+ * snerf_linear_wgrad consume all of it unchanged. */
+int snerf_fmlp_classic_train_fwd(const void* E, long ldE, const void* VE, long ldVE, const void* wstream, long n_frags,
+                                 const float* bias, int n_blocks, float* raw, void* const* acts, const long* act_ld,
+                                 void* const* bits, long M, void* stream);
+int snerf_fmlp_proposal_train_fwd(const void* E, long ldE, const void* wstream, long n_frags, const float* bias, int n_blocks,
+                                  float* raw_density, void* const* acts, const long* act_ld, void* const* bits, long M,
+                                  void* stream);
 
 /* ---- deterministic mode ("deterministic mode for parity tests") ------------------------------------------
  * The weight gradient normally lands in dW by fp32 atomics from the M slices (order varies run to run).  snerf_linear_wgrad_det makes

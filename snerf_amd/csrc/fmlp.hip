@@ -47,6 +47,8 @@ struct FmlpArgs {
   const float* pts;                 // classic network, in-kernel embedding: sample positions [M,3] ...
   const float* viewdirs; long ldvd; // ... and per-ray view directions [M / S, ldvd]
   int S;                            // samples per ray
+  __bf16* act[12]; long act_ld[12]; // training forward: where the output of layer i is stored (bf16 [M, >= width], row stride act_ld)
+  unsigned char* bits[8];           // ... and the ReLU bit masks of the 256-wide layers (layout of ACT_RELU_BITS in gemm.hip)
   const char* wstream;              // n_chunks x 16 KiB of MFMA fragments in consumption order
   const float* bias;                // n_blocks x 32 floats in consumption order
   float* out;                       // classic: raw [M,4] = (rgb, sigma); proposal: raw density [M]
@@ -82,7 +84,10 @@ __device__ __forceinline__ void ws_issue(WStream& w, char* smem) {
 // fact to the other waves' pieces and (b) the second to the other waves' reads of the slot that is refilled right after it.
 // One volatile asm with a memory clobber: no LDS access of the compiler's may move across it.
 __device__ __forceinline__ void ws_advance(WStream& w, char* smem) {
-  asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(2 * (FM_RING - 2)) : "memory");
+  #ifndef FM_EXTRA_VM
+#define FM_EXTRA_VM 0
+#endif
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(2 * (FM_RING - 2) + FM_EXTRA_VM) : "memory");
   ws_issue(w, smem);                                    // chunk g + FM_RING - 1 into the slot chunk g - 1 occupied
   w.slot_off = w.slot_off + FM_SLOT == FM_RING * FM_SLOT ? 0 : w.slot_off + FM_SLOT;
 }
@@ -157,28 +162,60 @@ __device__ __forceinline__ void to_frags(const f32x16& acc, bf16x8& lo, bf16x8& 
   }
 }
 
+// Training forward: the block's outputs also go to HBM (the weight gradient reads them, the data gradient takes its ReLU mask from
+// them).  Lane (row, half) holds columns 8g + 4 half .. +3 (g = 0..3) of the block: one v_permlane32_swap per register hands each half
+// the other's neighbouring four, so that half 0 owns columns 0..7 and 16..23, half 1 columns 8..15 and 24..31 -- two 16-byte stores
+// per lane, each instruction writing 32 contiguous bytes per row.
+template <bool BITS>
+__device__ __forceinline__ void store_block(__bf16* y, long ld, unsigned char* bits, long row, int half, bool ok, int j, const bf16x8& lo, const bf16x8& hi) {
+  const fm_u32x4 l = __builtin_bit_cast(fm_u32x4, lo), h = __builtin_bit_cast(fm_u32x4, hi);
+  // registers (l0 l1 | l2 l3) = columns (4 half .. | 8 + 4 half ..): swap the odd half of the first pair with the even half of the second
+  const auto a0 = __builtin_amdgcn_permlane32_swap(l[0], l[2], false, false), a1 = __builtin_amdgcn_permlane32_swap(l[1], l[3], false, false);
+  const auto b0 = __builtin_amdgcn_permlane32_swap(h[0], h[2], false, false), b1 = __builtin_amdgcn_permlane32_swap(h[1], h[3], false, false);
+  if (!ok) return;
+  __bf16* p = y + row * ld + 32 * j + 8 * half;
+  const fm_u32x4 lo8 = {a0[0], a1[0], a0[1], a1[1]}, hi8 = {b0[0], b1[0], b0[1], b1[1]};
+  *(fm_u32x4*)(p) = lo8; *(fm_u32x4*)(p + 16) = hi8;
+  if constexpr (BITS) {
+    // The ReLU mask the data-gradient GEMM of the layer below consumes (ACT_MASK_BITS, gemm.hip): block (row / 32, column / 64) = 64
+    // words, word 8 (row % 8) + (column % 64) / 8, byte (row % 32) / 8, bit column % 8.  A ReLU output is > 0 iff its 16 bits are not 0.
+    unsigned m0 = 0, m1 = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const unsigned v0 = e & 1 ? lo8[e >> 1] >> 16 : lo8[e >> 1] & 0xffffu, v1 = e & 1 ? hi8[e >> 1] >> 16 : hi8[e >> 1] & 0xffffu;
+      m0 |= (v0 != 0u ? 1u : 0u) << e; m1 |= (v1 != 0u ? 1u : 0u) << e;
+    }
+    unsigned char* b = bits + ((row >> 5) * 4 + (j >> 1)) * 256 + (((int)row & 7) * 8 + 4 * (j & 1) + half) * 4 + (((int)row >> 3) & 3);
+    b[0] = (unsigned char)m0; b[8] = (unsigned char)m1;
+  }
+}
+struct StoreTo { __bf16* y; long ld; unsigned char* bits; long row; int half; bool ok; };
+
 // One layer: out[32 NB] = act(W . [in0 | in1] + b) -- NB blocks of 32 outputs over one or two input segments (skip connections and
 // concatenations are never formed).  F = first fragment, B = first bias block of the layer within the pass.
-template <int F, int B, int NK0, int NK1, bool RELU>
-__device__ __forceinline__ void dense_block(Ctx& c, const bf16x8 (&in0)[NK0], const bf16x8 (&in1)[NK1 > 0 ? NK1 : 1], bf16x8& lo, bf16x8& hi) {
+template <int F, int B, int NK0, int NK1, bool RELU, bool STORE, bool BITS>
+__device__ __forceinline__ void dense_block(Ctx& c, const bf16x8 (&in0)[NK0], const bf16x8 (&in1)[NK1 > 0 ? NK1 : 1], bf16x8& lo, bf16x8& hi,
+                                            const StoreTo& st, int j) {
   f32x16 acc = acc_init<B>(c);
   mac<F, NK0>(c, acc, in0);
   if constexpr (NK1 > 0) mac<F + NK0, NK1>(c, acc, in1);
   to_frags<RELU>(acc, lo, hi);
+  if constexpr (STORE) store_block<BITS>(st.y, st.ld, st.bits, st.row, st.half, st.ok, j, lo, hi);
 }
-template <int F, int B, int NK0, int NK1, int NB, bool RELU, int... J>
+template <int F, int B, int NK0, int NK1, int NB, bool RELU, bool STORE, int... J>
 __device__ __forceinline__ void dense_seq(Ctx& c, const bf16x8 (&in0)[NK0], const bf16x8 (&in1)[NK1 > 0 ? NK1 : 1], bf16x8 (&out)[2 * NB],
-                                          std::integer_sequence<int, J...>) {
-  (dense_block<F + J * (NK0 + NK1), B + J, NK0, NK1, RELU>(c, in0, in1, out[2 * J], out[2 * J + 1]), ...);
+                                          const StoreTo& st, std::integer_sequence<int, J...>) {
+  // the bit masks exist for the 256-wide ReLU layers (the mask layout's column groups are those of N = 256)
+  (dense_block<F + J * (NK0 + NK1), B + J, NK0, NK1, RELU, STORE, STORE && RELU && NB == 8>(c, in0, in1, out[2 * J], out[2 * J + 1], st, J), ...);
 }
-template <int F, int B, int NK, int NB, bool RELU>
-__device__ __forceinline__ void dense(Ctx& c, const bf16x8 (&in)[NK], bf16x8 (&out)[2 * NB]) {
+template <int F, int B, int NK, int NB, bool RELU, bool STORE = false>
+__device__ __forceinline__ void dense(Ctx& c, const bf16x8 (&in)[NK], bf16x8 (&out)[2 * NB], const StoreTo& st = StoreTo{}) {
   const bf16x8 none[1] = {};
-  dense_seq<F, B, NK, 0, NB, RELU>(c, in, none, out, std::make_integer_sequence<int, NB>{});
+  dense_seq<F, B, NK, 0, NB, RELU, STORE>(c, in, none, out, st, std::make_integer_sequence<int, NB>{});
 }
-template <int F, int B, int NK0, int NK1, int NB, bool RELU>
-__device__ __forceinline__ void dense2(Ctx& c, const bf16x8 (&in0)[NK0], const bf16x8 (&in1)[NK1], bf16x8 (&out)[2 * NB]) {
-  dense_seq<F, B, NK0, NK1, NB, RELU>(c, in0, in1, out, std::make_integer_sequence<int, NB>{});
+template <int F, int B, int NK0, int NK1, int NB, bool RELU, bool STORE = false>
+__device__ __forceinline__ void dense2(Ctx& c, const bf16x8 (&in0)[NK0], const bf16x8 (&in1)[NK1], bf16x8 (&out)[2 * NB], const StoreTo& st = StoreTo{}) {
+  dense_seq<F, B, NK0, NK1, NB, RELU, STORE>(c, in0, in1, out, st, std::make_integer_sequence<int, NB>{});
 }
 
 // input fragments straight from HBM: lane (row, half) reads the 16 bytes [16 s + 8 half, +8) of its row (natural k order)
@@ -265,7 +302,7 @@ __device__ __forceinline__ ClassicInputs classic_embed_inputs(const float* pp, c
 #define FMLP_CLASSIC 0
 #define FMLP_PROPOSAL 1
 
-template <int NET, bool EMBED>
+template <int NET, bool EMBED, bool STORE>
 __global__ __launch_bounds__(512) void fmlp_kernel(FmlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -314,20 +351,21 @@ __global__ __launch_bounds__(512) void fmlp_kernel(FmlpArgs a) {
       constexpr int F1 = 8 * 4, F2 = F1 + 128, F3 = F2 + 128, F4 = F3 + 128, F5 = F4 + 128, F6 = F5 + 8 * 20, F7 = F6 + 128;
       constexpr int FA = F7 + 128, FF = FA + 16, FV = FF + 128, FR = FV + 4 * 18;
       static_assert(FR + 8 == FMLP_CLASSIC_FRAGS, "classic network: fragment count");
-      dense<0, 0, 4, 8, true>(c, e, p);                 // pts_linears.0
-      dense<F1, 8, 16, 8, true>(c, p, q);               // .1
-      dense<F2, 16, 16, 8, true>(c, q, p);              // .2
-      dense<F3, 24, 16, 8, true>(c, p, q);              // .3
-      dense<F4, 32, 16, 8, true>(c, q, p);              // .4  (skip: the next layer reads cat([pts, h]))
-      dense2<F5, 40, 4, 16, 8, true>(c, e, p, q);       // .5
-      dense<F6, 48, 16, 8, true>(c, q, p);              // .6
-      dense<F7, 56, 16, 8, true>(c, p, q);              // .7
-      f32x16 alpha = acc_init<64>(c);                   // alpha_linear: output 0 of one block
+      auto to = [&](int i) { return StoreTo{a.act[i], a.act_ld[i], a.bits[i < 8 ? i : 0], row, half, row_ok}; };
+      dense<0, 0, 4, 8, true, STORE>(c, e, p, to(0));             // pts_linears.0
+      dense<F1, 8, 16, 8, true, STORE>(c, p, q, to(1));           // .1
+      dense<F2, 16, 16, 8, true, STORE>(c, q, p, to(2));          // .2
+      dense<F3, 24, 16, 8, true, STORE>(c, p, q, to(3));          // .3
+      dense<F4, 32, 16, 8, true, STORE>(c, q, p, to(4));          // .4  (skip: the next layer reads cat([pts, h]))
+      dense2<F5, 40, 4, 16, 8, true, STORE>(c, e, p, q, to(5));   // .5
+      dense<F6, 48, 16, 8, true, STORE>(c, q, p, to(6));          // .6
+      dense<F7, 56, 16, 8, true, STORE>(c, p, q, to(7));          // .7
+      f32x16 alpha = acc_init<64>(c);                             // alpha_linear: output 0 of one block
       mac<FA, 16>(c, alpha, q);
       const float sigma = alpha[0];
-      dense<FF, 65, 16, 8, false>(c, q, p);             // feature_linear (no activation)
+      dense<FF, 65, 16, 8, false, STORE>(c, q, p, to(8));         // feature_linear (no activation)
       bf16x8 hv[8];
-      dense2<FV, 73, 16, 2, 4, true>(c, p, ve, hv);     // views_linears.0 on cat([feature, views])
+      dense2<FV, 73, 16, 2, 4, true, STORE>(c, p, ve, hv, to(9)); // views_linears.0 on cat([feature, views])
       f32x16 rgb = acc_init<77>(c);                     // rgb_linear: outputs 0..2
       mac<FR, 8>(c, rgb, hv);
       if (row_ok && half == 0) {
@@ -337,10 +375,11 @@ __global__ __launch_bounds__(512) void fmlp_kernel(FmlpArgs a) {
     } else {
       bf16x8 e[6], p[16], q[16];
       load_rows<6>(a.E, a.ldE, row, half, e);
-      dense<0, 0, 6, 8, true>(c, e, p);                 // layers.0
-      dense<48, 8, 16, 8, true>(c, p, q);
-      dense<48 + 128, 16, 16, 8, true>(c, q, p);
-      dense<48 + 256, 24, 16, 8, true>(c, p, q);
+      auto to = [&](int i) { return StoreTo{a.act[i], a.act_ld[i], a.bits[i < 8 ? i : 0], row, half, row_ok}; };
+      dense<0, 0, 6, 8, true, STORE>(c, e, p, to(0));             // layers.0
+      dense<48, 8, 16, 8, true, STORE>(c, p, q, to(1));
+      dense<48 + 128, 16, 16, 8, true, STORE>(c, q, p, to(2));
+      dense<48 + 256, 24, 16, 8, true, STORE>(c, p, q, to(3));
       f32x16 d = acc_init<32>(c);                       // density_layer
       mac<48 + 384, 16>(c, d, q);
       if (row_ok && half == 0) a.out[row] = d[0];
@@ -351,7 +390,7 @@ __global__ __launch_bounds__(512) void fmlp_kernel(FmlpArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the read-ahead before the LDS is released
 }
 
-template <int NET, bool EMBED>
+template <int NET, bool EMBED, bool STORE = false>
 static int fmlp_launch(const FmlpArgs& a, int expect_frags, int expect_blocks, long n_frags, void* stream) {
   if (a.M <= 0) return SNERF_OK;
   if (n_frags != expect_frags || a.n_blocks != expect_blocks || a.n_blocks > FM_BIAS_MAX || (n_frags % FM_CHUNK) != 0) return SNERF_ERR_ARG;
@@ -361,7 +400,7 @@ static int fmlp_launch(const FmlpArgs& a, int expect_frags, int expect_blocks, l
   static bool attr_set = false;
   static int n_cu = 256;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)fmlp_kernel<NET, EMBED>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)fmlp_kernel<NET, EMBED, STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
@@ -369,7 +408,7 @@ static int fmlp_launch(const FmlpArgs& a, int expect_frags, int expect_blocks, l
     attr_set = true;
   }
   const int grid = a.tiles < n_cu ? a.tiles : n_cu;
-  hipLaunchKernelGGL((fmlp_kernel<NET, EMBED>), dim3(grid), dim3(512), LDS, (hipStream_t)stream, a);
+  hipLaunchKernelGGL((fmlp_kernel<NET, EMBED, STORE>), dim3(grid), dim3(512), LDS, (hipStream_t)stream, a);
   return snerf_check_launch();
 }
 
@@ -377,9 +416,35 @@ extern "C" int snerf_fmlp_classic_fwd(const void* E, long ldE, const void* VE, l
                                       int n_blocks, float* raw, long M, void* stream) {
   if (M <= 0) return SNERF_OK;
   if (VE == nullptr || (ldVE % 8) != 0 || (((uintptr_t)VE) & 15) || (((uintptr_t)raw) & 15)) return SNERF_ERR_ARG;
-  FmlpArgs a{(const __bf16*)E, ldE, (const __bf16*)VE, ldVE, nullptr, nullptr, 0, 1, (const char*)wstream, bias, raw, M, (int)((M + 255) / 256),
-             (int)(n_frags / FM_CHUNK), n_blocks};
+  FmlpArgs a{};
+  a.E = (const __bf16*)E; a.ldE = ldE; a.VE = (const __bf16*)VE; a.ldVE = ldVE; a.S = 1; a.wstream = (const char*)wstream; a.bias = bias; a.out = raw;
+  a.M = M; a.tiles = (int)((M + 255) / 256); a.n_chunks = (int)(n_frags / FM_CHUNK); a.n_blocks = n_blocks;
   return fmlp_launch<FMLP_CLASSIC, false>(a, FMLP_CLASSIC_FRAGS, FMLP_CLASSIC_BLOCKS, n_frags, stream);
+}
+
+// Training forward of the same network: additionally stores the outputs of the ten hidden layers for the backward pass --
+// acts[i] / act_ld[i] (HOST arrays of 10 device pointers / row strides in elements): pts_linears.0 .. .7 (256 wide), feature_linear
+// (256), views_linears.0 (128); every pointer 16-byte aligned, every stride a multiple of 8 -- and bits[i] (HOST array of 8 device
+// pointers, 4 * 8 * ceil(M / 256) * 4 * 64 bytes each): the ReLU bit masks of pts_linears.i in the layout snerf_linear_fwd's
+// ACT_MASK_BITS reads.
+extern "C" int snerf_fmlp_classic_train_fwd(const void* E, long ldE, const void* VE, long ldVE, const void* wstream, long n_frags,
+                                            const float* bias, int n_blocks, float* raw, void* const* acts, const long* act_ld,
+                                            void* const* bits, long M, void* stream) {
+  if (M <= 0) return SNERF_OK;
+  if (VE == nullptr || (ldVE % 8) != 0 || (((uintptr_t)VE) & 15) || (((uintptr_t)raw) & 15) || acts == nullptr || act_ld == nullptr || bits == nullptr)
+    return SNERF_ERR_ARG;
+  FmlpArgs a{};
+  a.E = (const __bf16*)E; a.ldE = ldE; a.VE = (const __bf16*)VE; a.ldVE = ldVE; a.S = 1; a.wstream = (const char*)wstream; a.bias = bias; a.out = raw;
+  a.M = M; a.tiles = (int)((M + 255) / 256); a.n_chunks = (int)(n_frags / FM_CHUNK); a.n_blocks = n_blocks;
+  for (int i = 0; i < 10; ++i) {
+    if (acts[i] == nullptr || (((uintptr_t)acts[i]) & 15) || (act_ld[i] % 8) != 0) return SNERF_ERR_ARG;
+    a.act[i] = (__bf16*)acts[i]; a.act_ld[i] = act_ld[i];
+    if (i < 8) {
+      if (bits[i] == nullptr) return SNERF_ERR_ARG;
+      a.bits[i] = (unsigned char*)bits[i];
+    }
+  }
+  return fmlp_launch<FMLP_CLASSIC, false, true>(a, FMLP_CLASSIC_FRAGS, FMLP_CLASSIC_BLOCKS, n_frags, stream);
 }
 
 // the same network with the positional encodings computed in the kernel: pts [M,3] fp32 sample positions, viewdirs [M / S, ldvd]
@@ -387,15 +452,34 @@ extern "C" int snerf_fmlp_classic_pts_fwd(const float* pts, const float* viewdir
                                           const float* bias, int n_blocks, float* raw, long M, void* stream) {
   if (M <= 0) return SNERF_OK;
   if (pts == nullptr || viewdirs == nullptr || S <= 0 || ldvd < 3 || (((uintptr_t)raw) & 15) || M >= (1L << 31)) return SNERF_ERR_ARG;
-  FmlpArgs a{nullptr, 0, nullptr, 0, pts, viewdirs, ldvd, S, (const char*)wstream, bias, raw, M, (int)((M + 255) / 256),
-             (int)(n_frags / FM_CHUNK), n_blocks};
+  FmlpArgs a{};
+  a.pts = pts; a.viewdirs = viewdirs; a.ldvd = ldvd; a.S = S; a.wstream = (const char*)wstream; a.bias = bias; a.out = raw;
+  a.M = M; a.tiles = (int)((M + 255) / 256); a.n_chunks = (int)(n_frags / FM_CHUNK); a.n_blocks = n_blocks;
   return fmlp_launch<FMLP_CLASSIC, true>(a, FMLP_CLASSIC_FRAGS, FMLP_CLASSIC_BLOCKS, n_frags, stream);
 }
 
 extern "C" int snerf_fmlp_proposal_fwd(const void* E, long ldE, const void* wstream, long n_frags, const float* bias, int n_blocks,
                                        float* raw_density, long M, void* stream) {
-  FmlpArgs a{(const __bf16*)E, ldE, nullptr, 0, nullptr, nullptr, 0, 1, (const char*)wstream, bias, raw_density, M, (int)((M + 255) / 256),
-             (int)(n_frags / FM_CHUNK), n_blocks};
+  FmlpArgs a{};
+  a.E = (const __bf16*)E; a.ldE = ldE; a.S = 1; a.wstream = (const char*)wstream; a.bias = bias; a.out = raw_density;
+  a.M = M; a.tiles = (int)((M + 255) / 256); a.n_chunks = (int)(n_frags / FM_CHUNK); a.n_blocks = n_blocks;
   // 8 x 6 + 3 x 128 + 16 fragments; 32 + 1 blocks
   return fmlp_launch<FMLP_PROPOSAL, false>(a, 448, 33, n_frags, stream);
+}
+
+// training forward of the proposal MLP: acts[0..3] = outputs of layers.0 .. .3 (256 wide)
+extern "C" int snerf_fmlp_proposal_train_fwd(const void* E, long ldE, const void* wstream, long n_frags, const float* bias, int n_blocks,
+                                             float* raw_density, void* const* acts, const long* act_ld, void* const* bits, long M,
+                                             void* stream) {
+  if (M <= 0) return SNERF_OK;
+  if (acts == nullptr || act_ld == nullptr || bits == nullptr) return SNERF_ERR_ARG;
+  FmlpArgs a{};
+  a.E = (const __bf16*)E; a.ldE = ldE; a.S = 1; a.wstream = (const char*)wstream; a.bias = bias; a.out = raw_density;
+  a.M = M; a.tiles = (int)((M + 255) / 256); a.n_chunks = (int)(n_frags / FM_CHUNK); a.n_blocks = n_blocks;
+  for (int i = 0; i < 4; ++i) {
+    if (acts[i] == nullptr || (((uintptr_t)acts[i]) & 15) || (act_ld[i] % 8) != 0) return SNERF_ERR_ARG;
+    if (bits[i] == nullptr) return SNERF_ERR_ARG;
+    a.act[i] = (__bf16*)acts[i]; a.act_ld[i] = act_ld[i]; a.bits[i] = (unsigned char*)bits[i];
+  }
+  return fmlp_launch<FMLP_PROPOSAL, false, true>(a, 448, 33, n_frags, stream);
 }

@@ -313,13 +313,36 @@ class ClassicNeRFNet(_Net):
         L.append((self.W("rgb_linear"), self.B("rgb_linear"), [(0, W // 2, True)]))
         self.fstream, self.fbias = fmlp_pack(L, self.dev)
 
-    def forward_fused(self, pts, viewdirs, S):
-        """Inference: embedding kernel + ONE fused kernel for the whole network (activations never leave the registers)."""
+    def _fused_ready(self):
         v = self.version_fn()
         if getattr(self, "_fused_version", None) != v:
             with torch.no_grad():
                 self._pack_fused()
             self._fused_version = v
+
+    def forward_fused_train(self, pts, viewdirs, S):
+        """Training forward: the exact embedding kernel + ONE fused kernel that also stores the hidden activations in the buffers the
+        per-layer backward reads (same `saved` structure as the per-layer forward)."""
+        self._fused_ready()
+        self.ensure_packed(True)
+        M, W, Pw = pts.shape[0], self.Wd, self.Pw
+        E, SK, V = self.buf(M, Pw), self.buf(M, Pw + W), self.buf(M, W + self.Vw)
+        ops.classic_embed(pts, viewdirs, S, (self.ic - 3) // 6, (self.icv - 3) // 6, E, SK[:, :Pw], Pw, V[:, W:], self.Vw, self.dt)
+        ys = [SK[:, Pw:] if i == self.skip else self.buf(M, W) for i in range(self.D)]
+        HV, OUT = self.buf(M, W // 2), self.buf(M, 4, f32=True)
+        words = [torch.empty(ops.mask_bits_words(M, W), dtype=torch.int32, device=self.dev) for _ in range(self.D)]
+        ops.fmlp_classic_train_fwd(E, V[:, W:], self.fstream, self.fbias, OUT, ys + [V[:, :W], HV], words)
+        for y, w in zip(ys, words):                                   # the data-gradient GEMMs take their ReLU masks from the bits
+            self._bits[(y.data_ptr(), M)] = (w, W)
+        acts, x, k = [], E, Pw
+        for i in range(self.D):
+            acts.append((x, k, ys[i]))
+            x, k = (SK, Pw + W) if i == self.skip else (ys[i], W)
+        return OUT, (acts, V, HV, SK, E)
+
+    def forward_fused(self, pts, viewdirs, S):
+        """Inference: embedding kernel + ONE fused kernel for the whole network (activations never leave the registers)."""
+        self._fused_ready()
         M = pts.shape[0]
         OUT = self.buf(M, 4, f32=True)
         if self.fused_embed and M < (1 << 31):
@@ -332,8 +355,10 @@ class ClassicNeRFNet(_Net):
 
     def forward(self, pts, viewdirs, S, keep: bool):
         """pts [M,3] fp32, viewdirs [N,3] -> raw [M,4] fp32 (+ saved activations when keep)."""
-        if not keep and self.fused_ok():
-            return self.forward_fused(pts, viewdirs, S), None
+        if self.fused_ok():
+            if not keep:
+                return self.forward_fused(pts, viewdirs, S), None
+            return self.forward_fused_train(pts, viewdirs, S)
         self.ensure_packed(keep)
         M, W, Pw = pts.shape[0], self.Wd, self.Pw
         E = self.buf(M, Pw)
@@ -436,7 +461,7 @@ class MipProposalNet(_Net):
     def fused_ok(self):
         return self.fused and self.dt == ops.BF16 and self.H == 256 and self.L == 4 and self.fd == 96
 
-    def forward_fused(self, E):
+    def _fused_ready(self):
         v = self.version_fn()
         if getattr(self, "_fused_version", None) != v:
             with torch.no_grad():
@@ -445,14 +470,34 @@ class MipProposalNet(_Net):
                 L.append((self.W("density_layer"), self.B("density_layer"), [(0, self.H, True)]))
                 self.fstream, self.fbias = fmlp_pack(L, self.dev)
             self._fused_version = v
+
+    def forward_fused(self, E):
+        self._fused_ready()
         out = self.buf(E.shape[0], 1, f32=True)
         ops.fmlp_proposal_fwd(E, self.fstream, self.fbias, out)
         return out
 
+    def forward_fused_train(self, E):
+        """one launch; the four hidden activations are stored for the per-layer backward"""
+        self._fused_ready()
+        self.ensure_packed(True)
+        M, H = E.shape[0], self.H
+        ys = [self.buf(M, H) for _ in range(self.L)]
+        out = self.buf(M, 1, f32=True)
+        words = [torch.empty(ops.mask_bits_words(M, H), dtype=torch.int32, device=self.dev) for _ in range(self.L)]
+        ops.fmlp_proposal_train_fwd(E, self.fstream, self.fbias, out, ys, words)
+        for y, w in zip(ys, words):
+            self._bits[(y.data_ptr(), M)] = (w, H)
+        acts, x, k = [], E, self.Ew
+        for y in ys:
+            acts.append((x, k, y))
+            x, k = y, H
+        return out, acts
+
     def forward(self, E, keep: bool):
         """E [M, Ew] encoded samples (compute dtype) -> raw density [M,1] fp32."""
-        if not keep and self.fused_ok():
-            return self.forward_fused(E), None
+        if self.fused_ok():
+            return self.forward_fused_train(E) if keep else (self.forward_fused(E), None)
         self.ensure_packed(keep)
         M, H = E.shape[0], self.H
         acts, x, k = [], E, self.Ew

@@ -139,6 +139,44 @@ def fmlp_proposal_fwd(E, stream, bias, raw_density):
               E.shape[0], _stream())
 
 
+def _act_arrays(acts, bits, M, widths):
+    import ctypes
+    assert len(acts) == len(widths)
+    for y, w in zip(acts, widths):
+        assert y.dtype == torch.bfloat16 and y.dim() == 2 and y.stride(1) == 1 and y.shape[0] == M and y.shape[1] >= w
+        assert y.data_ptr() % 16 == 0 and y.stride(0) % 8 == 0
+    for b in bits:
+        assert b.dtype == torch.int32 and b.is_contiguous() and b.numel() >= mask_bits_words(M, 256)
+    ptrs = (ctypes.c_void_p * len(acts))(*[y.data_ptr() for y in acts])
+    lds = (ctypes.c_long * len(acts))(*[y.stride(0) for y in acts])
+    bp = (ctypes.c_void_p * len(bits))(*[b.data_ptr() for b in bits])
+    return ptrs, lds, bp
+
+
+def fmlp_classic_train_fwd(E, VE, stream, bias, raw, acts, bits):
+    """fmlp_classic_fwd that also stores the ten hidden-layer outputs (`acts`: pts_linears.0..7 [M,256], feature [M,256], views
+    [M,128], bf16 row-major views) and the ReLU bit masks of the eight trunk layers (`bits`: int32 [mask_bits_words(M, 256)] each)
+    for the per-layer backward."""
+    import ctypes
+    _chk2d(E, torch.bfloat16); _chk2d(VE, torch.bfloat16); _chk2d(raw, torch.float32)
+    assert stream.dtype == torch.bfloat16 and stream.is_contiguous() and bias.dtype == torch.float32 and raw.is_contiguous() and raw.shape[1] == 4
+    assert E.shape[1] >= 64 and VE.shape[1] >= 32 and VE.shape[0] == E.shape[0] == raw.shape[0] and len(bits) == 8
+    ptrs, lds, bp = _act_arrays(acts, bits, E.shape[0], [256] * 9 + [128])
+    _lib.call("snerf_fmlp_classic_train_fwd", _p(E), E.stride(0), _p(VE), VE.stride(0), _p(stream), stream.shape[0], _p(bias),
+              bias.numel() // 32, _p(raw), ctypes.addressof(ptrs), ctypes.addressof(lds), ctypes.addressof(bp), E.shape[0], _stream())
+
+
+def fmlp_proposal_train_fwd(E, stream, bias, raw_density, acts, bits):
+    """fmlp_proposal_fwd that also stores the four hidden-layer outputs (`acts`: [M,256] bf16 each) and their ReLU bit masks."""
+    import ctypes
+    _chk2d(E, torch.bfloat16)
+    assert stream.dtype == torch.bfloat16 and stream.is_contiguous() and bias.dtype == torch.float32 and E.shape[1] >= 96
+    assert raw_density.dtype == torch.float32 and raw_density.is_contiguous() and raw_density.numel() == E.shape[0] and len(bits) == 4
+    ptrs, lds, bp = _act_arrays(acts, bits, E.shape[0], [256] * 4)
+    _lib.call("snerf_fmlp_proposal_train_fwd", _p(E), E.stride(0), _p(stream), stream.shape[0], _p(bias), bias.numel() // 32,
+              _p(raw_density), ctypes.addressof(ptrs), ctypes.addressof(lds), ctypes.addressof(bp), E.shape[0], _stream())
+
+
 # --------------------------------------------------------------- encoders ----
 def classic_embed(pts, viewdirs, S, L, Lv, dst1, dst2, w_pts, dstv, w_views, dt):
     pts = _f32c(pts); M = pts.shape[0]

@@ -465,7 +465,7 @@ class _FStream:
         self.f += 1
         return w
 
-    def block(self, segs, relu, to_frags=True):
+    def block(self, segs, relu, to_frags=True, store=None, j=0):
         acc = self.b[self.nb * 32:(self.nb + 1) * 32].clone()[None, :].expand(segs[0][0].shape[0], 32).clone()
         self.nb += 1
         for seg in segs:
@@ -476,12 +476,14 @@ class _FStream:
         y = acc.to(torch.bfloat16).float()
         if relu:
             y = torch.relu(y)
+        if store is not None:                        # training forward: the block's 32 outputs in natural order, row-major
+            store[:, 32 * j:32 * j + 32] = y.to(store.dtype)
         return [y[:, _P], y[:, 16 + _P]]
 
-    def dense(self, segs, nblocks, relu):
+    def dense(self, segs, nblocks, relu, store=None):
         out = []
-        for _ in range(nblocks):
-            out += self.block(segs, relu)
+        for j in range(nblocks):
+            out += self.block(segs, relu, store=store, j=j)
         return out
 
 
@@ -489,19 +491,20 @@ def _rows_to_ksteps(X, nk):
     return [X[:, 16 * s:16 * s + 16].float() for s in range(nk)]
 
 
-def fmlp_classic_fwd(E, VE, stream, bias, raw):
+def fmlp_classic_fwd(E, VE, stream, bias, raw, acts=None):
     assert stream.shape[0] == 1184 and bias.numel() == 78 * 32
     st = _FStream(stream, bias)
+    a = acts if acts is not None else [None] * 10
     e, ve = _rows_to_ksteps(E, 4), _rows_to_ksteps(VE, 2)
-    p = st.dense([e], 8, True)
-    for _ in range(4):
-        p = st.dense([p], 8, True)
-    p = st.dense([e, p], 8, True)
-    p = st.dense([p], 8, True)
-    q = st.dense([p], 8, True)
+    p = st.dense([e], 8, True, a[0])
+    for i in range(4):
+        p = st.dense([p], 8, True, a[1 + i])
+    p = st.dense([e, p], 8, True, a[5])
+    p = st.dense([p], 8, True, a[6])
+    q = st.dense([p], 8, True, a[7])
     sigma = st.block([q], False, to_frags=False)[:, 0]
-    feat = st.dense([q], 8, False)
-    hv = st.dense([feat, ve], 4, True)
+    feat = st.dense([q], 8, False, a[8])
+    hv = st.dense([feat, ve], 4, True, a[9])
     rgb = st.block([hv], False, to_frags=False)[:, :3]
     assert st.f == 1184 and st.nb == 78
     raw[:, :3] = rgb
@@ -514,21 +517,36 @@ def fmlp_classic_pts_fwd(pts, viewdirs, S, stream, bias, raw):
     fmlp_classic_fwd(pad(oc.embed(pts, 10), 64), pad(oc.embed(viewdirs[:, None].expand(-1, S, -1).reshape(-1, 3), 4), 64), stream, bias, raw)
 
 
-def fmlp_proposal_fwd(E, stream, bias, raw_density):
+def fmlp_classic_train_fwd(E, VE, stream, bias, raw, acts, bits):
+    assert len(acts) == 10 and len(bits) == 8
+    fmlp_classic_fwd(E, VE, stream, bias, raw, acts)
+    for y, w in zip(acts, bits):                     # what ACT_MASK_BITS consumers look up (see linear_fwd above)
+        _BITS[w.data_ptr()] = y.float() > 0
+
+
+def fmlp_proposal_fwd(E, stream, bias, raw_density, acts=None):
     assert stream.shape[0] == 448 and bias.numel() == 33 * 32
     st = _FStream(stream, bias)
-    p = st.dense([_rows_to_ksteps(E, 6)], 8, True)
-    for _ in range(3):
-        p = st.dense([p], 8, True)
+    a = acts if acts is not None else [None] * 4
+    p = st.dense([_rows_to_ksteps(E, 6)], 8, True, a[0])
+    for i in range(3):
+        p = st.dense([p], 8, True, a[1 + i])
     raw_density.view(-1)[:] = st.block([p], False, to_frags=False)[:, 0]
     assert st.f == 448 and st.nb == 33
+
+
+def fmlp_proposal_train_fwd(E, stream, bias, raw_density, acts, bits):
+    assert len(acts) == 4 and len(bits) == 4
+    fmlp_proposal_fwd(E, stream, bias, raw_density, acts)
+    for y, w in zip(acts, bits):
+        _BITS[w.data_ptr()] = y.float() > 0
 
 
 def adam_step_dev(p, g, m, v, lr, b1, b2, eps, step_dev, grad_scale=1.0, zero_grad=True, **kw):
     adam_step(p, g, m, v, lr, b1, b2, eps, 0, grad_scale, zero_grad, step_dev=step_dev, **kw)
 
 
-_NAMES = ["adam_step_dev", "grad_clip_coef", "fmlp_classic_fwd", "fmlp_classic_pts_fwd", "fmlp_proposal_fwd", "classic_get_rays", "classic_ndc_rays", "classic_ray_batch", "zip_encode_prop_fwd", "mip_encode_bwd", "mip_viewenc_bwd", "hash_decay", "zip_percentiles", "zip_pixels_to_rays", "zip_loss_tail", "semantic_composite_fwd", "semantic_composite_bwd", "zip_resample", "zip_encode_fwd", "zip_encode_bwd", "zip_encode_bwd_binned", "zip_encode_ray_bwd", "zip_composite_fwd", "zip_composite_bwd",
+_NAMES = ["adam_step_dev", "grad_clip_coef", "fmlp_classic_fwd", "fmlp_classic_pts_fwd", "fmlp_proposal_fwd", "fmlp_classic_train_fwd", "fmlp_proposal_train_fwd", "classic_get_rays", "classic_ndc_rays", "classic_ray_batch", "zip_encode_prop_fwd", "mip_encode_bwd", "mip_viewenc_bwd", "hash_decay", "zip_percentiles", "zip_pixels_to_rays", "zip_loss_tail", "semantic_composite_fwd", "semantic_composite_bwd", "zip_resample", "zip_encode_fwd", "zip_encode_bwd", "zip_encode_bwd_binned", "zip_encode_ray_bwd", "zip_composite_fwd", "zip_composite_bwd",
           "linear_fwd", "linear_wgrad", "classic_embed", "mip_encode", "mip_viewenc", "classic_sample_pdf", "classic_points",
           "classic_merge_sort", "mip_resample", "stratified", "mip_composite_fwd", "mip_composite_bwd", "classic_composite_fwd",
           "classic_composite_bwd", "adam_step", "colsum_f32", "cast_pad", "pinhole_rays", "mip_loss_tail"]

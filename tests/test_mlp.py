@@ -1,5 +1,6 @@
 """Stage-isolated forward / backward parity of the three tiny-MLP executors (snerf_amd.mlp) against torch autograd of
 the oracle's MLPs on IDENTICAL inputs.  "hip": real MFMA kernels (GPU box); "emulated": host logic only (CPU)."""
+import numpy as np
 import pytest
 import torch
 
@@ -104,12 +105,19 @@ def test_classic_net(backend, dt, W, tol):
     assert rel(raw, ref) < tol, rel(raw, ref)
     raw_i, _ = net.forward(pts.to(DEV), vd.to(DEV), S, False)
     if net.fused_ok():
-        # inference takes the fused register-resident kernel: the same bf16 network with another fp32 summation order
+        # both take the fused register-resident kernel (inference with the embeddings computed in it): the same bf16 network
         assert rel(raw_i, raw) < 5e-3, rel(raw_i, raw)
         net.fused = False
+        raw_l, saved_l = net.forward(pts.to(DEV), vd.to(DEV), S, True)
         raw_i, _ = net.forward(pts.to(DEV), vd.to(DEV), S, False)
         net.fused = True
-    assert torch.equal(raw_i, raw)
+        assert torch.equal(raw_i, raw_l) and rel(raw, raw_l) < 5e-3
+        # the stored activations are the per-layer kernels' to bf16 rounding (another fp32 summation order)
+        for (xa, ka, ya), (xb, kb, yb) in zip(saved[0], saved_l[0]):
+            assert ka == kb and rel(ya, yb) < 1e-2, rel(ya, yb)
+        assert rel(saved[1], saved_l[1]) < 1e-2 and rel(saved[2], saved_l[2]) < 1e-2 and torch.equal(saved[4], saved_l[4])
+    else:
+        assert torch.equal(raw_i, raw)
     arena.grad.zero_()
     net.backward(d_raw.to(DEV), saved)
     worst = max((rel(arena.g[k], pr[k].grad), k) for k in sd)
@@ -210,3 +218,64 @@ def test_fused_proposal_network_matches_per_layer_kernels_and_oracle(backend):
     print(f"MEASURED fused proposal MLP vs fp32 oracle: {err:.3e}; per-layer {float((layered.cpu().reshape(-1) - ref).abs().max()) / scale:.3e}")
     assert err < 2e-2
     assert float((fused - layered).norm() / layered.norm()) < 5e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [1000, 768])
+def test_fused_training_forward_stores_activations_and_relu_bits(M):
+    """snerf_fmlp_classic_train_fwd / _proposal_train_fwd: the stored hidden activations are those of the per-layer kernels (to bf16
+    rounding of another summation order), and the ReLU bit masks -- decoded here from the documented layout (block (row / 32,
+    column / 64) of 64 words; word 8 (row % 8) + (column % 64) / 8, byte (row % 32) / 8, bit column % 8) -- are exactly y > 0 of the
+    activations the same launch stored.  M = 1000: ragged tile."""
+    from snerf_amd import mlp, ops
+    from snerf_amd.mlp import ClassicNeRFNet, MipProposalNet, ParamArena
+
+    def decode(words, Mr, N):
+        w = words.cpu().numpy().view("uint8").reshape(-1, N // 64, 64, 4)                     # [rb, cg, word, byte]
+        bits = ((w[..., None] >> np.arange(8, dtype="uint8")) & 1).astype(bool)               # [rb, cg, word, byte, e]
+        rb, cg, ln, it, e = np.meshgrid(*[np.arange(n) for n in bits.shape], indexing="ij")
+        out = np.zeros((bits.shape[0] * 32, N), bool)
+        out[rb * 32 + 8 * it + (ln >> 3), cg * 64 + 8 * (ln & 7) + e] = bits
+        return out[:Mr]
+
+    shapes = ClassicNeRFNet.param_shapes(8, 256, 63, 27, (4,))
+    arena = ParamArena(shapes, torch.device(DEV)); arena.load(_rand_sd(shapes, 41))
+    net = ClassicNeRFNet(arena, "", ops.BF16, 8, 256)
+    g = torch.Generator().manual_seed(42)
+    S = 8
+    pts = (torch.rand(M, 3, generator=g) * 4 - 2).to(DEV)
+    vd = torch.nn.functional.normalize(torch.randn(M // S, 3, generator=g), dim=-1).to(DEV)
+    raw, saved = net.forward(pts, vd, S, True)
+    assert len(net._bits) == 8
+    net.fused = False
+    raw_l, saved_l = net.forward(pts, vd, S, True)
+    net.fused = True
+    assert rel(raw, raw_l) < 5e-3
+    for (x, k, y), (_, _, yl) in zip(saved[0], saved_l[0]):
+        assert rel(y, yl) < 1e-2
+        words, N = net._bits[(y.data_ptr(), M)]
+        assert np.array_equal(decode(words, M, N), (y.float() > 0).cpu().numpy())
+    assert rel(saved[1], saved_l[1]) < 1e-2 and rel(saved[2], saved_l[2]) < 1e-2
+    # gradients through the two forward variants agree (same per-layer backward kernels, masks from bits either way)
+    d_raw = torch.randn(M, 4, generator=g).to(DEV)
+    arena.grad.zero_(); net.backward(d_raw, saved); ga = arena.grad.clone()
+    net.fused = False
+    raw_l, saved_l = net.forward(pts, vd, S, True)
+    arena.grad.zero_(); net.backward(d_raw, saved_l); gb = arena.grad.clone()
+    net.fused = True
+    assert rel(ga, gb) < 2e-2, rel(ga, gb)
+
+    shapes = MipProposalNet.param_shapes(256, 4, 96)
+    arena = ParamArena(shapes, torch.device(DEV)); arena.load(_rand_sd(shapes, 43))
+    prop = MipProposalNet(arena, "", ops.BF16, 256, 4, 96)
+    E = torch.zeros(M, prop.Ew, dtype=torch.bfloat16, device=DEV)
+    E[:, :96] = (torch.randn(M, 96, generator=g) * 0.5).to(DEV)
+    out, acts = prop.forward(E, True)
+    prop.fused = False
+    out_l, acts_l = prop.forward(E, True)
+    prop.fused = True
+    assert rel(out, out_l) < 5e-3
+    for (x, k, y), (_, _, yl) in zip(acts, acts_l):
+        assert rel(y, yl) < 1e-2
+        words, N = prop._bits[(y.data_ptr(), M)]
+        assert np.array_equal(decode(words, M, N), (y.float() > 0).cpu().numpy())

@@ -1,0 +1,5 @@
+cd /root/repo
+timeout 600 python -m pytest tests/test_mlp.py -x -q -m gpu 2>&1 | tail -3
+timeout 300 python tools/bench_classic.py --steps 5 2>&1 | tail -1 | tee gpurun_out/r2_f_pathB_train_fused.json.log
+timeout 200 python tools/fmlp_single.py 2>&1 | tail -4
+timeout 700 bash tools/pmc_fmlp_train.sh 2>&1 | tail -40 | tee gpurun_out/r2_f_fmlp_train_pmc.txt

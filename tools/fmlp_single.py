@@ -34,3 +34,24 @@ e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 5
 print(f"fmlp_classic_pts (in-kernel embedding) M={M}: {ms:.3f} ms  {M * 2 * 593408 / ms / 1e9:.1f} TFLOP/s algorithmic")
+# training forward: the same launch + 4864 B / row of activation stores
+acts = [torch.empty(M, 256, device="cuda", dtype=torch.bfloat16) for _ in range(9)] + [torch.empty(M, 128, device="cuda", dtype=torch.bfloat16)]
+bits = [torch.empty(ops.mask_bits_words(M, 256), device="cuda", dtype=torch.int32) for _ in range(8)]
+for _ in range(2):
+    ops.fmlp_classic_train_fwd(E, VE, net.net.fstream, net.net.fbias, out, acts, bits)
+e0.record()
+for _ in range(5):
+    ops.fmlp_classic_train_fwd(E, VE, net.net.fstream, net.net.fbias, out, acts, bits)
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 5
+print(f"fmlp_classic_train M={M}: {ms:.3f} ms  {M * 2 * 593408 / ms / 1e9:.1f} TFLOP/s algorithmic, stores {M * 4864 / ms / 1e9:.2f} TB/s")
+# what the part does with the same bytes as a plain write stream
+e0.record()
+for _ in range(5):
+    for a in acts:
+        a.zero_()
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 5
+print(f"plain fill of the same buffers: {ms:.3f} ms  {M * 4864 / ms / 1e9:.2f} TB/s")
