@@ -23,6 +23,7 @@
 #define ACT_NONE 0
 #define ACT_RELU 1
 #define ACT_MASK 2  // y = (aux > 0) ? y : 0   (ReLU backward fused into dgrad)
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 #define ACT_RELU_BITS 3  // ReLU, and `aux` (uint32, OUTPUT) receives one bit per element: y > 0      (persistent kernel only)
 #define ACT_MASK_BITS 4  // as ACT_MASK with `aux` = the bit mask an ACT_RELU_BITS launch of the same [M, N] wrote
 
@@ -718,19 +719,32 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
         for (int e = 0; e < 8; ++e) if (!((float)a8[it][e] > 0.f)) val[e] = (T)0.f;
       }
       if (ACT == ACT_MASK_BITS) {
+        // byte `it` of the word masks these 8 values: u carries bit i of the byte at positions i and i + 15, so (u >> 2k) & 0x10001
+        // has the bits of elements 2k / 2k + 1 in the low bit of each 16-bit half -- a packed multiply by 0 / 1 applies them
+        const unsigned bt = (mw >> (8 * it)) & 0xffu, u = bt | (bt << 15);
+        u32x4 raw = __builtin_bit_cast(u32x4, val);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) if (!((mw >> (8 * it + e)) & 1u)) val[e] = (T)0.f;
+        for (int k = 0; k < 4; ++k) {
+          // (through named scalars: __builtin_bit_cast applied directly to a vector-element lvalue is miscompiled by this clang)
+          const unsigned sel = (u >> (2 * k)) & 0x00010001u, x = raw[k];
+          raw[k] = __builtin_bit_cast(unsigned, (u16x2)(__builtin_bit_cast(u16x2, x) * __builtin_bit_cast(u16x2, sel)));
+        }
+        val = __builtin_bit_cast(bf16x8, raw);
       }
       if (col_ok && m < p.M) {
         *(bf16x8*)((T*)p.Y + (long)m * p.ldy + ncol) = val;
         if (ACT == ACT_RELU_BITS) {
           // the value is a ReLU output (max(v, +0) rounded to bf16: never negative, never -0): > 0  <=>  its 16 bits are not all zero
+          // min(half, 1) per 16-bit half = "is positive"; z gathers the even elements in bits 0, 2, 4, 6 and the odd ones 16 higher
           const u32x4 raw = __builtin_bit_cast(u32x4, val);
+          const u16x2 one = {1, 1};
+          unsigned z = 0;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const unsigned h = e & 1 ? (raw[e >> 1] >> 16) : (raw[e >> 1] & 0xffffu);
-            mw |= (h != 0u ? 1u : 0u) << (8 * it + e);
+          for (int k = 0; k < 4; ++k) {
+            const unsigned x = raw[k];                      // (named scalar: see the note at ACT_MASK_BITS)
+            z |= __builtin_bit_cast(unsigned, (u16x2)__builtin_elementwise_min(__builtin_bit_cast(u16x2, x), one)) << (2 * k);
           }
+          mw |= ((z | (z >> 15)) & 0xffu) << (8 * it);
         }
         if constexpr (COLSUM) {
 #pragma unroll

@@ -247,17 +247,19 @@ def test_fused_training_forward_stores_activations_and_relu_bits(M):
     vd = torch.nn.functional.normalize(torch.randn(M // S, 3, generator=g), dim=-1).to(DEV)
     raw, saved = net.forward(pts, vd, S, True)
     assert len(net._bits) == 8
+    fbits = dict(net._bits)                                           # (the next training forward starts a new table)
     net.fused = False
     raw_l, saved_l = net.forward(pts, vd, S, True)
     net.fused = True
     assert rel(raw, raw_l) < 5e-3
     for (x, k, y), (_, _, yl) in zip(saved[0], saved_l[0]):
         assert rel(y, yl) < 1e-2
-        words, N = net._bits[(y.data_ptr(), M)]
+        words, N = fbits[(y.data_ptr(), M)]
         assert np.array_equal(decode(words, M, N), (y.float() > 0).cpu().numpy())
     assert rel(saved[1], saved_l[1]) < 1e-2 and rel(saved[2], saved_l[2]) < 1e-2
     # gradients through the two forward variants agree (same per-layer backward kernels, masks from bits either way)
     d_raw = torch.randn(M, 4, generator=g).to(DEV)
+    net._bits = fbits
     arena.grad.zero_(); net.backward(d_raw, saved); ga = arena.grad.clone()
     net.fused = False
     raw_l, saved_l = net.forward(pts, vd, S, True)
@@ -271,11 +273,12 @@ def test_fused_training_forward_stores_activations_and_relu_bits(M):
     E = torch.zeros(M, prop.Ew, dtype=torch.bfloat16, device=DEV)
     E[:, :96] = (torch.randn(M, 96, generator=g) * 0.5).to(DEV)
     out, acts = prop.forward(E, True)
+    fbits = dict(prop._bits)
     prop.fused = False
     out_l, acts_l = prop.forward(E, True)
     prop.fused = True
     assert rel(out, out_l) < 5e-3
     for (x, k, y), (_, _, yl) in zip(acts, acts_l):
         assert rel(y, yl) < 1e-2
-        words, N = prop._bits[(y.data_ptr(), M)]
+        words, N = fbits[(y.data_ptr(), M)]
         assert np.array_equal(decode(words, M, N), (y.float() > 0).cpu().numpy())

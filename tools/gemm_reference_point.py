@@ -36,6 +36,12 @@ def main():
         r["nt_vendor_ms"] = timeit(lambda: torch.mm(A, W.t(), out=Y))
         r["nt_vendor_bias_relu_ms"] = timeit(lambda: torch.relu_(torch.addmm(b.to(torch.bfloat16), A, W.t(), out=Y)))
         r["nt_ours_bias_relu_ms"] = timeit(lambda: ops.linear_fwd(A, W, b, Y, K, N, ops.ACT_RELU, ops.BF16, variant=8))
+        if N % 256 == 0:
+            words = torch.empty(ops.mask_bits_words(M, N), dtype=torch.int32, device=dev)
+            cs = torch.zeros(N, device=dev)
+            r["nt_ours_relu_bits_ms"] = timeit(lambda: ops.linear_fwd(A, W, b, Y, K, N, ops.ACT_RELU_BITS, ops.BF16, aux=words, variant=8))
+            r["nt_ours_mask_bits_colsum_ms"] = timeit(lambda: ops.linear_fwd(dZ, W, None, Y, K, N, ops.ACT_MASK_BITS, ops.BF16, aux=words, colsum=cs, variant=8))
+            r["nt_ours_mask_colsum_ms"] = timeit(lambda: ops.linear_fwd(dZ, W, None, Y, K, N, ops.ACT_MASK, ops.BF16, aux=A, colsum=cs, variant=8))
         dWb = torch.empty(N, K, device=dev, dtype=torch.bfloat16)
         r["tn_vendor_ms"] = timeit(lambda: torch.mm(dZ.t(), A, out=dWb))
         r["tn_ours_ms"] = timeit(lambda: ops.linear_wgrad(dZ, A, dW, N, K, ops.BF16, variant=3))
