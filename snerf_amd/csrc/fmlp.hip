@@ -48,7 +48,7 @@ struct FmlpArgs {
   const float* viewdirs; long ldvd; // ... and per-ray view directions [M / S, ldvd]
   int S;                            // samples per ray
   __bf16* act[12]; long act_ld[12]; // training forward: where the output of layer i is stored (bf16 [M, >= width], row stride act_ld)
-  unsigned char* bits[8];           // ... and the ReLU bit masks of the 256-wide layers (layout of ACT_RELU_BITS in gemm.hip)
+  unsigned* bits[8];                // ... and the ReLU bit masks of the 256-wide layers (layout of ACT_RELU_BITS in gemm.hip)
   const char* wstream;              // n_chunks x 16 KiB of MFMA fragments in consumption order
   const float* bias;                // n_blocks x 32 floats in consumption order
   float* out;                       // classic: raw [M,4] = (rgb, sigma); proposal: raw density [M]
@@ -162,51 +162,79 @@ __device__ __forceinline__ void to_frags(const f32x16& acc, bf16x8& lo, bf16x8& 
   }
 }
 
-// Training forward: the block's outputs also go to HBM (the weight gradient reads them, the data gradient takes its ReLU mask from
-// them).  Lane (row, half) holds columns 8g + 4 half .. +3 (g = 0..3) of the block: one v_permlane32_swap per register hands each half
-// the other's neighbouring four, so that half 0 owns columns 0..7 and 16..23, half 1 columns 8..15 and 24..31 -- two 16-byte stores
-// per lane, each instruction writing 32 contiguous bytes per row.
-template <bool BITS>
-__device__ __forceinline__ void store_block(__bf16* y, long ld, unsigned char* bits, long row, int half, bool ok, int j, const bf16x8& lo, const bf16x8& hi) {
+// Training forward: the layer outputs also go to HBM (the weight gradient reads them, the data gradient takes its ReLU mask from
+// them).  A lane holds 4 x 4 columns of ITS row of a block -- stored from there, an instruction would write 16..32-byte pieces of 32
+// rows (measured: the 8 x 256 network at 2.2..2.8 TB/s of stores, twice the time of the launch without them).  Instead every PAIR of
+// blocks (64 columns) is transposed through a 4 KiB per-wave LDS slab, the way the GEMM epilogue does it: lane (r, half) writes its
+// four 8-byte groups of both blocks (16-byte chunks XOR-swizzled by the row), then lane l reads the chunks (row 8 it + l / 8,
+// chunk l % 8), it = 0..3 -- each store instruction covers 8 full 128-byte row segments.  In that layout the lane's four chunks are
+// exactly word l of the ReLU bit-mask block ACT_MASK_BITS consumes (gemm.hip: block (row / 32, column / 64) of 64 words; byte `it` of
+// word l = row 8 it + l / 8, columns 8 (l % 8) .. + 7), so the masks cost one 4-byte store per lane and pair.
+// The slab is wave-private: LDS operations of a wave execute in order, no barrier is involved.
+struct StoreTo {
+  __bf16* y; long ld;        // output buffer of the layer, row stride
+  unsigned* bits;            // its ReLU bit mask words (nullptr for the layers without one)
+  long row0, M;              // first row of this wave's 32-row block (wave-uniform), rows of the launch
+  char* slab;                // this wave's 4 KiB of LDS
+  int lane;
+};
+
+template <bool BITS, int J>
+__device__ __forceinline__ void store_block(const StoreTo& st, const bf16x8& lo, const bf16x8& hi) {
+  const int r = st.lane & 31, half = st.lane >> 5;
+  char* w = st.slab + r * 128 + 8 * half;
   const fm_u32x4 l = __builtin_bit_cast(fm_u32x4, lo), h = __builtin_bit_cast(fm_u32x4, hi);
-  // registers (l0 l1 | l2 l3) = columns (4 half .. | 8 + 4 half ..): swap the odd half of the first pair with the even half of the second
-  const auto a0 = __builtin_amdgcn_permlane32_swap(l[0], l[2], false, false), a1 = __builtin_amdgcn_permlane32_swap(l[1], l[3], false, false);
-  const auto b0 = __builtin_amdgcn_permlane32_swap(h[0], h[2], false, false), b1 = __builtin_amdgcn_permlane32_swap(h[1], h[3], false, false);
-  if (!ok) return;
-  __bf16* p = y + row * ld + 32 * j + 8 * half;
-  const fm_u32x4 lo8 = {a0[0], a1[0], a0[1], a1[1]}, hi8 = {b0[0], b1[0], b0[1], b1[1]};
-  *(fm_u32x4*)(p) = lo8; *(fm_u32x4*)(p + 16) = hi8;
-  if constexpr (BITS) {
-    // The ReLU mask the data-gradient GEMM of the layer below consumes (ACT_MASK_BITS, gemm.hip): block (row / 32, column / 64) = 64
-    // words, word 8 (row % 8) + (column % 64) / 8, byte (row % 32) / 8, bit column % 8.  A ReLU output is > 0 iff its 16 bits are not 0.
-    unsigned m0 = 0, m1 = 0;
+  typedef unsigned fm_u32x2 __attribute__((ext_vector_type(2)));
+  constexpr int C0 = 4 * (J & 1);                                        // first 16-byte chunk of this block inside the 64-column pair
+  *(fm_u32x2*)(w + (((C0 + 0) ^ (r & 7)) << 4)) = fm_u32x2{l[0], l[1]};
+  *(fm_u32x2*)(w + (((C0 + 1) ^ (r & 7)) << 4)) = fm_u32x2{l[2], l[3]};
+  *(fm_u32x2*)(w + (((C0 + 2) ^ (r & 7)) << 4)) = fm_u32x2{h[0], h[1]};
+  *(fm_u32x2*)(w + (((C0 + 3) ^ (r & 7)) << 4)) = fm_u32x2{h[2], h[3]};
+  if constexpr ((J & 1) == 1) {
+    const int prow = st.lane >> 3, pch = st.lane & 7;
+    __bf16* dst = st.y + (st.row0 + prow) * st.ld + 64 * (J >> 1) + 8 * pch;
+    unsigned mw = 0;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const unsigned v0 = e & 1 ? lo8[e >> 1] >> 16 : lo8[e >> 1] & 0xffffu, v1 = e & 1 ? hi8[e >> 1] >> 16 : hi8[e >> 1] & 0xffffu;
-      m0 |= (v0 != 0u ? 1u : 0u) << e; m1 |= (v1 != 0u ? 1u : 0u) << e;
+    for (int it = 0; it < 4; ++it) {
+      const int row = 8 * it + prow;
+      const fm_u32x4 v = *(const fm_u32x4*)(st.slab + row * 128 + ((pch ^ (row & 7)) << 4));
+      if (st.row0 + row < st.M) {
+        *(fm_u32x4*)(dst + (long)(8 * it) * st.ld) = v;
+        if constexpr (BITS) {
+          // a ReLU output is > 0 iff its 16 bits are not 0: min(half word, 1), even elements gathered in bits 0, 2, 4, 6, odd ones 16 higher
+          typedef unsigned short fm_u16x2 __attribute__((ext_vector_type(2)));
+          const fm_u16x2 one = {1, 1};
+          unsigned z = 0;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const unsigned x = v[k];                   // (named scalar: __builtin_bit_cast of a vector-element lvalue is miscompiled)
+            z |= __builtin_bit_cast(unsigned, (fm_u16x2)__builtin_elementwise_min(__builtin_bit_cast(fm_u16x2, x), one)) << (2 * k);
+          }
+          mw |= ((z | (z >> 15)) & 0xffu) << (8 * it);
+        }
+      }
     }
-    unsigned char* b = bits + ((row >> 5) * 4 + (j >> 1)) * 256 + (((int)row & 7) * 8 + 4 * (j & 1) + half) * 4 + (((int)row >> 3) & 3);
-    b[0] = (unsigned char)m0; b[8] = (unsigned char)m1;
+    if constexpr (BITS) st.bits[((st.row0 >> 5) * 4 + (J >> 1)) * 64 + st.lane] = mw;   // 256 contiguous bytes per wave; rows >= M: zeros
   }
 }
-struct StoreTo { __bf16* y; long ld; unsigned char* bits; long row; int half; bool ok; };
 
 // One layer: out[32 NB] = act(W . [in0 | in1] + b) -- NB blocks of 32 outputs over one or two input segments (skip connections and
 // concatenations are never formed).  F = first fragment, B = first bias block of the layer within the pass.
-template <int F, int B, int NK0, int NK1, bool RELU, bool STORE, bool BITS>
+template <int F, int B, int NK0, int NK1, bool RELU, bool STORE, bool BITS, int J>
 __device__ __forceinline__ void dense_block(Ctx& c, const bf16x8 (&in0)[NK0], const bf16x8 (&in1)[NK1 > 0 ? NK1 : 1], bf16x8& lo, bf16x8& hi,
-                                            const StoreTo& st, int j) {
+                                            const StoreTo& st) {
   f32x16 acc = acc_init<B>(c);
   mac<F, NK0>(c, acc, in0);
   if constexpr (NK1 > 0) mac<F + NK0, NK1>(c, acc, in1);
   to_frags<RELU>(acc, lo, hi);
-  if constexpr (STORE) store_block<BITS>(st.y, st.ld, st.bits, st.row, st.half, st.ok, j, lo, hi);
+  if constexpr (STORE) store_block<BITS, J>(st, lo, hi);
 }
 template <int F, int B, int NK0, int NK1, int NB, bool RELU, bool STORE, int... J>
 __device__ __forceinline__ void dense_seq(Ctx& c, const bf16x8 (&in0)[NK0], const bf16x8 (&in1)[NK1 > 0 ? NK1 : 1], bf16x8 (&out)[2 * NB],
                                           const StoreTo& st, std::integer_sequence<int, J...>) {
+  static_assert(NB % 2 == 0, "the training stores work on pairs of blocks");
   // the bit masks exist for the 256-wide ReLU layers (the mask layout's column groups are those of N = 256)
-  (dense_block<F + J * (NK0 + NK1), B + J, NK0, NK1, RELU, STORE, STORE && RELU && NB == 8>(c, in0, in1, out[2 * J], out[2 * J + 1], st, J), ...);
+  (dense_block<F + J * (NK0 + NK1), B + J, NK0, NK1, RELU, STORE, STORE && RELU && NB == 8, J>(c, in0, in1, out[2 * J], out[2 * J + 1], st), ...);
 }
 template <int F, int B, int NK, int NB, bool RELU, bool STORE = false>
 __device__ __forceinline__ void dense(Ctx& c, const bf16x8 (&in)[NK], bf16x8 (&out)[2 * NB], const StoreTo& st = StoreTo{}) {
@@ -351,7 +379,7 @@ __global__ __launch_bounds__(512) void fmlp_kernel(FmlpArgs a) {
       constexpr int F1 = 8 * 4, F2 = F1 + 128, F3 = F2 + 128, F4 = F3 + 128, F5 = F4 + 128, F6 = F5 + 8 * 20, F7 = F6 + 128;
       constexpr int FA = F7 + 128, FF = FA + 16, FV = FF + 128, FR = FV + 4 * 18;
       static_assert(FR + 8 == FMLP_CLASSIC_FRAGS, "classic network: fragment count");
-      auto to = [&](int i) { return StoreTo{a.act[i], a.act_ld[i], a.bits[i < 8 ? i : 0], row, half, row_ok}; };
+      auto to = [&](int i) { return StoreTo{a.act[i], a.act_ld[i], i < 8 ? a.bits[i] : nullptr, (long)tile * 256 + wave * 32, a.M, smem + FM_RING * FM_SLOT + FM_BIAS_MAX * 128 + wave * 4096, lane}; };
       dense<0, 0, 4, 8, true, STORE>(c, e, p, to(0));             // pts_linears.0
       dense<F1, 8, 16, 8, true, STORE>(c, p, q, to(1));           // .1
       dense<F2, 16, 16, 8, true, STORE>(c, q, p, to(2));          // .2
@@ -375,7 +403,7 @@ __global__ __launch_bounds__(512) void fmlp_kernel(FmlpArgs a) {
     } else {
       bf16x8 e[6], p[16], q[16];
       load_rows<6>(a.E, a.ldE, row, half, e);
-      auto to = [&](int i) { return StoreTo{a.act[i], a.act_ld[i], a.bits[i < 8 ? i : 0], row, half, row_ok}; };
+      auto to = [&](int i) { return StoreTo{a.act[i], a.act_ld[i], i < 8 ? a.bits[i] : nullptr, (long)tile * 256 + wave * 32, a.M, smem + FM_RING * FM_SLOT + FM_BIAS_MAX * 128 + wave * 4096, lane}; };
       dense<0, 0, 6, 8, true, STORE>(c, e, p, to(0));             // layers.0
       dense<48, 8, 16, 8, true, STORE>(c, p, q, to(1));
       dense<48 + 128, 16, 16, 8, true, STORE>(c, q, p, to(2));
@@ -396,7 +424,7 @@ static int fmlp_launch(const FmlpArgs& a, int expect_frags, int expect_blocks, l
   if (n_frags != expect_frags || a.n_blocks != expect_blocks || a.n_blocks > FM_BIAS_MAX || (n_frags % FM_CHUNK) != 0) return SNERF_ERR_ARG;
   if (a.wstream == nullptr || a.bias == nullptr || a.out == nullptr || (((uintptr_t)a.wstream) & 15)) return SNERF_ERR_ARG;
   if (!EMBED && (a.E == nullptr || (a.ldE % 8) != 0 || (((uintptr_t)a.E) & 15))) return SNERF_ERR_ARG;
-  constexpr int LDS = FM_RING * FM_SLOT + FM_BIAS_MAX * 128;
+  constexpr int LDS = FM_RING * FM_SLOT + FM_BIAS_MAX * 128 + (STORE ? 8 * 4096 : 0);   // + the transposition slabs of the training stores
   static bool attr_set = false;
   static int n_cu = 256;
   if (!attr_set) {
@@ -441,7 +469,7 @@ extern "C" int snerf_fmlp_classic_train_fwd(const void* E, long ldE, const void*
     a.act[i] = (__bf16*)acts[i]; a.act_ld[i] = act_ld[i];
     if (i < 8) {
       if (bits[i] == nullptr) return SNERF_ERR_ARG;
-      a.bits[i] = (unsigned char*)bits[i];
+      a.bits[i] = (unsigned*)bits[i];
     }
   }
   return fmlp_launch<FMLP_CLASSIC, false, true>(a, FMLP_CLASSIC_FRAGS, FMLP_CLASSIC_BLOCKS, n_frags, stream);
@@ -479,7 +507,7 @@ extern "C" int snerf_fmlp_proposal_train_fwd(const void* E, long ldE, const void
   for (int i = 0; i < 4; ++i) {
     if (acts[i] == nullptr || (((uintptr_t)acts[i]) & 15) || (act_ld[i] % 8) != 0) return SNERF_ERR_ARG;
     if (bits[i] == nullptr) return SNERF_ERR_ARG;
-    a.act[i] = (__bf16*)acts[i]; a.act_ld[i] = act_ld[i]; a.bits[i] = (unsigned char*)bits[i];
+    a.act[i] = (__bf16*)acts[i]; a.act_ld[i] = act_ld[i]; a.bits[i] = (unsigned*)bits[i];
   }
   return fmlp_launch<FMLP_PROPOSAL, false, true>(a, 448, 33, n_frags, stream);
 }
