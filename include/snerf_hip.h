@@ -197,6 +197,11 @@ int snerf_adam_step(float* p, float* g, float* m, float* v, long n, float lr, fl
                     float grad_scale, int zero_grad, void* stream);
 int snerf_colsum_f32(const float* x, long ld, long M, int C, float* out, void* stream);
 int snerf_cast_pad(const float* src, long ld_src, long M, int C, int Cpad, void* dst, long ld_dst, int dtype, void* stream);
+/* Refresh of the packed GEMM / fused-MLP operands after an optimiser step (the reference has no counterpart: torch.nn.Linear reads its
+ * weights in place): dst[i] = flat[idx[i]] rounded to `dtype` (0 = fp32, 1 = bf16); idx -1 -> 0 (padding), -2 -> 1 (identity rows).  flat =
+ * the fp32 parameter arena; idx (16-byte aligned) is built once per network by the host from the same slicing code that defines the
+ * layouts (snerf_amd/mlp.py: _Net._build_plan). */
+int snerf_gather_pack(const float* flat, const int* idx, long n, void* dst, int dtype, void* stream);
 
 /* Semantic compositing, both flavours of the reference.  softmax = 1: zipnerf NerfMLP (internal/models.py:594-597) +
  * internal/render.py:237-241: semantic [R,C] = sum_i detach(weights [R,S]) softmax(logits [R*S, ld][:, :C]) (logits = columns

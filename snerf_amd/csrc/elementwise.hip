@@ -195,4 +195,36 @@ extern "C" int snerf_cast_pad(const float* src, long ld_src, long M, int C, int 
   return snerf_check_launch();
 }
 
+// Weight packing as ONE gather: dst[i] = idx[i] >= 0 ? flat[idx[i]] : (idx[i] == -2 ? 1 : 0), rounded to dst's type.  The index image
+// of every packed operand (padded / transposed / K-concatenated / MFMA-fragment-ordered copies of the parameters) depends only on the
+// network's structure, so the host builds it once and refreshes all operands of a network with this launch after every optimiser step
+// instead of ~60 slice copies.
+template <typename T>
+__global__ __launch_bounds__(256) void gather_pack_kernel(const float* __restrict__ flat, const int* __restrict__ idx, long n, T* __restrict__ dst) {
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
+    if (i + 4 <= n) {
+      const int4 k = *(const int4*)(idx + i);
+      const int kk[4] = {k.x, k.y, k.z, k.w};
+      T o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = from_f32<T>(kk[e] >= 0 ? flat[kk[e]] : (kk[e] == -2 ? 1.f : 0.f));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dst[i + e] = o[e];
+    } else {
+      for (long j = i; j < n; ++j) dst[j] = from_f32<T>(idx[j] >= 0 ? flat[idx[j]] : (idx[j] == -2 ? 1.f : 0.f));
+    }
+  }
+}
+
+extern "C" int snerf_gather_pack(const float* flat, const int* idx, long n, void* dst, int dtype, void* stream) {
+  if (n <= 0) return SNERF_OK;
+  if (flat == nullptr || idx == nullptr || dst == nullptr || (((uintptr_t)idx) & 15)) return SNERF_ERR_ARG;
+  const long want = (n + 1023) / 1024;
+  const int blocks = (int)(want < 4096 ? want : 4096);
+  if (dtype == SNERF_DT_F32) hipLaunchKernelGGL(gather_pack_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, flat, idx, n, (float*)dst);
+  else if (dtype == SNERF_DT_BF16) hipLaunchKernelGGL(gather_pack_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, flat, idx, n, (__bf16*)dst);
+  else return SNERF_ERR_ARG;
+  return snerf_check_launch();
+}
+
 extern "C" int snerf_version() { return 1; }

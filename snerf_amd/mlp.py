@@ -59,6 +59,12 @@ class ParamArena:
         b = self._offs[self.names[idx[-1] + 1]][0] if idx[-1] + 1 < len(self.names) else self.numel
         return a, b
 
+    def index_image(self, name):
+        """float64 tensor of the parameter's shape holding (flat arena position + 2) of every element: what the packing code slices,
+        transposes and concatenates once to learn where each element of a packed operand comes from (0 = padding, 1 = constant one)."""
+        a, c = self._offs[name]
+        return (torch.arange(a, a + c, dtype=torch.float64, device=self.flat.device) + 2.0).view(self.shapes[name])
+
     def bump(self):
         """Call after the parameters were modified behind torch's back (fused Adam kernel, RCCL broadcast)."""
         self.epoch += 1
@@ -89,14 +95,15 @@ def fmlp_pack(layers, device):
     bias fp32 [n_blocks * 32])."""
     perm = torch.tensor(FMLP_PERM, device=device)
     frags, biases = [], []
+    dt = layers[0][0].dtype if layers[0][0].dtype == torch.float64 else torch.float32   # float64: index images (_Net._build_plan)
     for W, b, segs in layers:
-        W = _w2(W).detach().to(device, torch.float32)
+        W = _w2(W).detach().to(device, dt)
         N = W.shape[0]
         NB = (N + 31) // 32
         per_seg = []
         for c0, cnt, from_acc in segs:
             ks = (cnt + 15) // 16
-            Ws = torch.zeros(NB * 32, ks * 16, dtype=torch.float32, device=device)
+            Ws = torch.zeros(NB * 32, ks * 16, dtype=dt, device=device)
             Ws[:N, :cnt] = W[:, c0:c0 + cnt]
             Ws = Ws.view(NB * 32, ks, 16)
             if from_acc:
@@ -104,15 +111,58 @@ def fmlp_pack(layers, device):
             # [NB, 32 n, ks, 2 halves, 8] -> [NB, ks, half, n, 8]: one fragment = 64 lanes x 8 values, lane = half * 32 + n
             per_seg.append(Ws.reshape(NB, 32, ks, 2, 8).permute(0, 2, 3, 1, 4).reshape(NB, ks, 512))
         frags.append(torch.cat(per_seg, 1).reshape(-1, 512))
-        bb = torch.zeros(NB * 32, dtype=torch.float32, device=device)
+        bb = torch.zeros(NB * 32, dtype=dt, device=device)
         if b is not None:
-            bb[:N] = b.detach().to(device, torch.float32).reshape(-1)
+            bb[:N] = b.detach().to(device, dt).reshape(-1)
         biases.append(bb)
     stream = torch.cat(frags, 0)
     pad = (-stream.shape[0]) % FMLP_CHUNK
     if pad:
-        stream = torch.cat([stream, torch.zeros(pad, 512, device=device)], 0)
+        stream = torch.cat([stream, torch.zeros(pad, 512, dtype=dt, device=device)], 0)
+    if dt == torch.float64:
+        return stream.contiguous(), torch.cat(biases).contiguous()
     return stream.to(torch.bfloat16).contiguous(), torch.cat(biases).contiguous()
+
+
+class _PackPlan:
+    """Persistent packed operands of one network + the gather map that refreshes them from the parameter arena."""
+
+    def __init__(self, flat):
+        self.flat = flat
+        self.items = {}                    # dtype -> [(index image, offset)]
+        self.size = {}
+
+    def add(self, img, dtype):
+        off = self.size.get(dtype, 0)
+        self.items.setdefault(dtype, []).append((img, off))
+        self.size[dtype] = off + roundup(img.numel(), 128)        # every operand 256-byte aligned inside its pool
+        return (dtype, off, tuple(img.shape))
+
+    def finish(self):
+        self.pools, self.maps = {}, {}
+        for dtype, items in self.items.items():
+            n = self.size[dtype]
+            idx = torch.full((n,), -1, dtype=torch.int32, device=self.flat.device)
+            for img, off in items:
+                v = img.reshape(-1)
+                assert bool(((v == v.round()) & (v >= 0)).all()), "pack() may only copy parameters, zeros and ones"
+                k = (v - 2.0).to(torch.int32)                      # image value = arena position + 2; 0 = padding, 1 = constant one
+                minus1, minus2 = torch.full_like(k, -1), torch.full_like(k, -2)
+                idx[off:off + v.numel()] = torch.where(v == 0, minus1, torch.where(v == 1, minus2, k))
+            self.pools[dtype] = torch.zeros(n, dtype=dtype, device=self.flat.device)
+            self.maps[dtype] = idx
+        self.items = None
+
+    def view(self, handle):
+        dtype, off, shape = handle
+        n = 1
+        for d in shape:
+            n *= d
+        return self.pools[dtype][off:off + n].view(shape)
+
+    def refresh(self):
+        for dtype, idx in self.maps.items():
+            ops.gather_pack(self.flat, idx, self.pools[dtype])
 
 
 class _Net:
@@ -127,13 +177,54 @@ class _Net:
         self.deterministic = False        # bit-reproducible gradients: partial tiles folded in a fixed order instead of fp32 atomics
         self.version_fn = arena.version   # drop-in modules override this with their nn.Parameter versions
         self.fw, self.fb, self.tw = {}, {}, {}
+        self._rec = None                  # while a plan is being recorded: [(index image, dtype of the operand)]
+        self._plans = {}                  # what was packed -> _PackPlan
 
     # ---- packing -------------------------------------------------------------
+    # The pack() methods below DESCRIBE the operand layouts with ordinary slicing code.  They run once per network (and per train
+    # flag) on index images of the parameters (ParamArena.index_image); the result is one int32 gather map per network, and every
+    # later refresh (the parameters change each optimiser step) is ONE snerf_gather_pack launch per dtype into persistent buffers.
     def W(self, name):
+        if self._rec is not None:
+            return _w2(self.a.index_image(self.pre + name + ".weight"))
         return _w2(self.a.p[self.pre + name + ".weight"])
 
     def B(self, name):
+        if self._rec is not None:
+            return self.a.index_image(self.pre + name + ".bias")
         return self.a.p[self.pre + name + ".bias"]
+
+    def _zeros(self, *shape, f32=False):
+        """operand buffer of a pack() method (recorded: its content becomes part of the network's gather map)"""
+        assert self._rec is not None, "pack() runs only while a plan is recorded"
+        t = torch.zeros(*shape, dtype=torch.float64, device=self.dev)
+        self._rec.append((t, torch.float32 if f32 else self.tdt))
+        return t
+
+    def _build_plan(self, fill):
+        """Run `fill()` (a pack method writing operands obtained from _zeros / returned as extra (image, dtype) pairs) on index images
+        and turn every recorded operand into a view of a persistent pool + its slice of the gather map."""
+        assert self.a.numel < (1 << 31) - 2
+        self._rec = []
+        try:
+            extra = fill() or []
+            rec = self._rec + list(extra)
+        finally:
+            self._rec = None
+        plan = _PackPlan(self.a.flat)
+        handles = [(id(img), plan.add(img, dtype)) for img, dtype in rec]
+        plan.finish()
+        real = {i: plan.view(h) for i, h in handles}
+
+        def swap(v):
+            if isinstance(v, torch.Tensor):
+                return real.get(id(v), v)
+            if isinstance(v, dict):
+                return {k: swap(x) for k, x in v.items()}
+            if isinstance(v, tuple):
+                return tuple(swap(x) for x in v)
+            return v
+        return plan, swap
 
     def gW(self, name):
         return _w2(self.a.g[self.pre + name + ".weight"])
@@ -141,13 +232,26 @@ class _Net:
     def gB(self, name):
         return self.a.g[self.pre + name + ".bias"]
 
+    def _refresh_fused(self, pack_fused):
+        """weight stream / bias table of the fused kernels (fmlp_pack's layout), refreshed by the same gather"""
+        if "fused" not in self._plans:
+            def fill():
+                st, bi = pack_fused()                      # index images (float64) in record mode
+                self._fimg = (st, bi)
+                return [(st, torch.bfloat16), (bi, torch.float32)]
+            plan, swap = self._build_plan(fill)
+            self._plans["fused"] = (plan, swap(self._fimg))
+            del self._fimg
+        plan, (self.fstream, self.fbias) = self._plans["fused"]
+        plan.refresh()
+
     def _pack_fwd(self, key, name, segs, kbuf):
         W = self.W(name)
         N = W.shape[0]
-        out = torch.zeros(roundup(N, 128), kbuf, dtype=self.tdt, device=self.dev)
+        out = self._zeros(roundup(N, 128), kbuf)
         for bc, wc, cnt in segs:
             out[:N, bc:bc + cnt] = W[:, wc:wc + cnt]
-        b = torch.zeros(roundup(N, 128), dtype=torch.float32, device=self.dev)
+        b = self._zeros(roundup(N, 128), f32=True)
         b[:N] = self.B(name)
         self.fw[key], self.fb[key] = out, b
 
@@ -156,7 +260,7 @@ class _Net:
         activation: rows = those input columns (padded to 128), cols = concat of each layer's outputs
         padded to the tile granularity (matches the [dZ_a | dZ_b] gradient buffer)."""
         cols = sum(roundup(self.W(n).shape[0], self.g) for n in parts)
-        out = torch.zeros(roundup(cnt, 128), cols, dtype=self.tdt, device=self.dev)
+        out = self._zeros(roundup(cnt, 128), cols)
         c = 0
         for n in parts:
             W = self.W(n)
@@ -168,7 +272,7 @@ class _Net:
         """like _pack_dgrad with a weight-column offset per layer: parts = [(layer, first weight column)]; used for the gradient
         w.r.t. an INPUT encoding that several layers read at different column positions (rows = the encoding's columns)."""
         cols = sum(roundup(self.W(n).shape[0], self.g) for n, _ in parts)
-        out = torch.zeros(roundup(cnt, 128), cols, dtype=self.tdt, device=self.dev)
+        out = self._zeros(roundup(cnt, 128), cols)
         c = 0
         for n, wc in parts:
             W = self.W(n)
@@ -189,10 +293,16 @@ class _Net:
         # ReLU bit masks written by this forward's layers (keyed by the activation view), read by the data-gradient GEMMs
         self._bits = {} if train else None
         v = self.version_fn()
-        if self._packed_version != v or (train and not self.tw):
+        key = "train" if train else "infer"
+        if self._packed_version != (v, key) and not (key == "infer" and self._packed_version == (v, "train")):
             with torch.no_grad():
-                self.pack(train)
-            self._packed_version = v
+                if key not in self._plans:
+                    self.fw, self.fb, self.tw = {}, {}, {}
+                    plan, swap = self._build_plan(lambda: self.pack(train))
+                    self._plans[key] = (plan, swap(self.fw), swap(self.fb), swap(self.tw))
+                plan, self.fw, self.fb, self.tw = self._plans[key]
+                plan.refresh()
+            self._packed_version = (v, key)
 
     # ---- kernels ---------------------------------------------------------------
     def buf(self, M, cols, f32=False):
@@ -311,13 +421,13 @@ class ClassicNeRFNet(_Net):
         L.append((self.W("feature_linear"), self.B("feature_linear"), [(0, W, True)]))
         L.append((self.W("views_linears.0"), self.B("views_linears.0"), [(0, W, True), (W, self.icv, False)]))
         L.append((self.W("rgb_linear"), self.B("rgb_linear"), [(0, W // 2, True)]))
-        self.fstream, self.fbias = fmlp_pack(L, self.dev)
+        return fmlp_pack(L, self.dev)
 
     def _fused_ready(self):
         v = self.version_fn()
         if getattr(self, "_fused_version", None) != v:
             with torch.no_grad():
-                self._pack_fused()
+                self._refresh_fused(self._pack_fused)
             self._fused_version = v
 
     def forward_fused_train(self, pts, viewdirs, S):
@@ -461,14 +571,17 @@ class MipProposalNet(_Net):
     def fused_ok(self):
         return self.fused and self.dt == ops.BF16 and self.H == 256 and self.L == 4 and self.fd == 96
 
+    def _pack_fused(self):
+        L = [(self.W(f"layers.{i}.layers.0"), self.B(f"layers.{i}.layers.0"), [(0, self.fd if i == 0 else self.H, i > 0)])
+             for i in range(self.L)]
+        L.append((self.W("density_layer"), self.B("density_layer"), [(0, self.H, True)]))
+        return fmlp_pack(L, self.dev)
+
     def _fused_ready(self):
         v = self.version_fn()
         if getattr(self, "_fused_version", None) != v:
             with torch.no_grad():
-                L = [(self.W(f"layers.{i}.layers.0"), self.B(f"layers.{i}.layers.0"), [(0, self.fd if i == 0 else self.H, i > 0)])
-                     for i in range(self.L)]
-                L.append((self.W("density_layer"), self.B("density_layer"), [(0, self.H, True)]))
-                self.fstream, self.fbias = fmlp_pack(L, self.dev)
+                self._refresh_fused(self._pack_fused)
             self._fused_version = v
 
     def forward_fused(self, E):
@@ -783,8 +896,8 @@ class ZipNerfNet(_Net):
         self._pack_fwd("d2", "density_layer.2", [(0, 0, self.H)], self.H)
         # fp32 density head = row 0 of the second density layer (raw_density = x[..., 0], models.py:511)
         w2, b2 = self.W("density_layer.2"), self.B("density_layer.2")
-        hw = torch.zeros(128, self.H, dtype=self.tdt, device=self.dev); hw[0] = w2[0]
-        hb = torch.zeros(128, dtype=torch.float32, device=self.dev); hb[0] = b2[0]
+        hw = self._zeros(128, self.H); hw[0] = w2[0]
+        hb = self._zeros(128, f32=True); hb[0] = b2[0]
         self.fw["dhead"], self.fb["dhead"] = hw, hb
         self._pack_fwd("lin0", "lin_second_stage_0", [(0, 0, B + dd)], B + self.Dw)
         self._pack_fwd("lin1", "lin_second_stage_1", [(0, 0, Wd + B + dd)], Wd + B + self.Dw)
@@ -797,7 +910,7 @@ class ZipNerfNet(_Net):
             # d x = [dZ_lin0 | dZ_lin1 | d raw_density] . [W0[:, x]; W1[:, x]; e_0]
             g = self.g
             W0, W1 = self.W("lin_second_stage_0"), self.W("lin_second_stage_1")
-            out = torch.zeros(roundup(B, 128), 2 * Wd + g, dtype=self.tdt, device=self.dev)
+            out = self._zeros(roundup(B, 128), 2 * Wd + g)
             out[:B, :Wd] = W0[:, :B].t()
             out[:B, Wd:2 * Wd] = W1[:, Wd:Wd + B].t()
             # identity rows: column 0 of the trailing block carries d raw_density, columns 1.. the semantic-logit gradients

@@ -427,6 +427,13 @@ def cast_pad(src, C, dst, Cpad, dt):
     _lib.call("snerf_cast_pad", _p(src), src.stride(0), src.shape[0], C, Cpad, _p(dst), dst.stride(0), dt, _stream())
 
 
+def gather_pack(flat, idx, dst):
+    """dst[i] = flat[idx[i]] (idx -1 -> 0, -2 -> 1) rounded to dst's dtype: all packed operands of a network in one launch."""
+    assert flat.dtype == torch.float32 and flat.is_contiguous() and idx.dtype == torch.int32 and idx.is_contiguous() and dst.is_contiguous()
+    assert dst.numel() == idx.numel() and dst.dtype in (torch.float32, torch.bfloat16)
+    _lib.call("snerf_gather_pack", _p(flat), _p(idx), idx.numel(), _p(dst), F32 if dst.dtype == torch.float32 else BF16, _stream())
+
+
 # ------------------------------------------------------------ hash grid ----
 def grid_encode_fwd(inputs, embeddings, offsets, L, S, H, gridtype, align_corners, interp, want_dy_dx=False, level_major=False):
     """inputs fp32 [B,D] in [0,1]; embeddings [sO,C] fp32/fp16 -> outputs [B, L*C] (or [L,B,C] if level_major) in the

@@ -1,4 +1,4 @@
 cd /root/repo
-timeout 600 python -m pytest tests/test_mlp.py -x -q -m gpu 2>&1 | grep -v "^Extension" | tail -3
-timeout 200 python tools/fmlp_single.py 2>&1 | tail -4
-timeout 300 python tools/bench_classic.py --steps 5 2>&1 | tail -1 | tee gpurun_out/r2_f_pathB_train_fused.json.log
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | grep -v "^Extension" | tail -4
+timeout 400 python bench.py --no-cpu --no-eager --no-f32 2>&1 | tail -1 | cut -c1-1500
+timeout 300 python bench.py --no-cpu --no-eager --no-f32 --no-frame --rays 512 2>&1 | tail -1 | cut -c1-300

@@ -8,7 +8,7 @@ from snerf_amd import classic, ops
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 32768 * 192
 torch.manual_seed(0)
 net = classic.NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=4, skips=[4], use_viewdirs=True, compute="bf16")
-net.net._pack_fused()
+net.net._fused_ready()
 E = (torch.rand(M, 64, device="cuda") * 2 - 1).bfloat16()
 VE = (torch.rand(M, 64, device="cuda") * 2 - 1).bfloat16()
 out = torch.empty(M, 4, device="cuda")

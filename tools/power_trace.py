@@ -22,7 +22,7 @@ if kind == "gemm":
     flop = 2.0 * M * N * K
 elif kind == "fmlp":
     M = 32768 * 192
-    net = classic.NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=4, skips=[4], use_viewdirs=True, compute="bf16"); net.net._pack_fused()
+    net = classic.NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=4, skips=[4], use_viewdirs=True, compute="bf16"); net.net._fused_ready()
     pts = torch.randn(M, 3, device="cuda"); vd = torch.nn.functional.normalize(torch.randn(M // 192, 3, device="cuda"), dim=-1)
     out = torch.empty(M, 4, device="cuda")
     fn = lambda: ops.fmlp_classic_pts_fwd(pts, vd, 192, net.net.fstream, net.net.fbias, out)
