@@ -920,7 +920,12 @@ __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restr
   const int chunk = (rows + gridDim.y - 1) / gridDim.y;
   const int r0 = blockIdx.y * chunk, r1 = min(rows, r0 + chunk);
   float acc = 0.f;
-  for (int r = r0; r < r1; ++r) acc += ws[(long)r * N + n];
+  int r = r0;
+  for (; r + 4 <= r1; r += 4) {                            // four loads in flight; the order of the additions stays r0, r0 + 1, ...
+    const float a = ws[(long)r * N + n], b = ws[(long)(r + 1) * N + n], c = ws[(long)(r + 2) * N + n], d = ws[(long)(r + 3) * N + n];
+    acc += a; acc += b; acc += c; acc += d;
+  }
+  for (; r < r1; ++r) acc += ws[(long)r * N + n];
   atomicAdd(out + n, acc);
 }
 
@@ -937,7 +942,7 @@ static int launch_nt(const GemmNT& p, hipStream_t stream) {
   hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, WM, WN>), dim3(tiles), dim3(64 * WM * WN), LDS, stream, p);
   if (p.fast_epi && p.colsum_ws != nullptr) {
     const int rows = tiles_m * WM;
-    int ychunks = rows / 64;
+    int ychunks = rows / 8;
     ychunks = (ychunks < 1 || p.det) ? 1 : (ychunks > 64 ? 64 : ychunks);
     hipLaunchKernelGGL(colsum_reduce_kernel, dim3((p.n_store + 255) / 256, ychunks), dim3(256), 0, stream, p.colsum_ws, rows, p.N, p.n_store, p.colsum);
   }
@@ -956,7 +961,7 @@ static int launch_nt8(const GemmNT& p, hipStream_t stream) {
   hipLaunchKernelGGL(gemm_nt8_kernel, dim3(tiles), dim3(512), LDS, stream, p);
   if (p.fast_epi && p.colsum_ws != nullptr) {
     const int rows = tiles_m * 2;
-    int ychunks = rows / 64;
+    int ychunks = rows / 8;
     ychunks = (ychunks < 1 || p.det) ? 1 : (ychunks > 64 ? 64 : ychunks);
     hipLaunchKernelGGL(colsum_reduce_kernel, dim3((p.n_store + 255) / 256, ychunks), dim3(256), 0, stream, p.colsum_ws, rows, p.N, p.n_store, p.colsum);
   }
@@ -1007,7 +1012,7 @@ static int launch_nt8p(const GemmNT& p, hipStream_t stream) {
   }
   if (p.colsum_ws != nullptr) {
     const int rows = grid * 2;                            // one partial row per (workgroup, wave row)
-    int ychunks = rows / 64;
+    int ychunks = rows / 8;
     ychunks = (ychunks < 1 || p.det) ? 1 : (ychunks > 64 ? 64 : ychunks);
     hipLaunchKernelGGL(colsum_reduce_kernel, dim3((p.n_store + 255) / 256, ychunks), dim3(256), 0, stream, p.colsum_ws, rows, p.N, p.n_store, p.colsum);
   }
