@@ -25,6 +25,7 @@ extern "C" {
 #define SNERF_DT_F32 0
 #define SNERF_DT_BF16 1
 #define SNERF_DT_F16 2 /* hash-grid tables only */
+#define SNERF_DT_F64 3 /* stand-alone GridEncoder operator only (the reference dispatches float / double / half) */
 #define SNERF_ACT_NONE 0
 #define SNERF_ACT_RELU 1
 #define SNERF_ACT_MASK 2 /* y = aux > 0 ? y : 0 : ReLU backward fused into the data-gradient GEMM */
@@ -131,10 +132,10 @@ int snerf_classic_composite_bwd(const float* raw, long ld, const float* noise, c
  *   grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx?, gridtype, align_corners, interp)
  *   grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx?, grad_inputs?, ...)
  *   grad_total_variation(inputs, embeddings, grad, offsets, weight, B, D, C, L, S, H, gridtype, align_corners)
- * plus `dtype` of the table / outputs / gradients (SNERF_DT_F32 or SNERF_DT_F16; the reference dispatches on the tensor
- * dtype), the strides (elements) of the level and point axes of `outputs` / `grad` (reference layout [L,B,C]:
+ * plus `dtype` of the table / outputs / gradients (SNERF_DT_F32, SNERF_DT_F16 or SNERF_DT_F64; the reference dispatches on the
+ * tensor dtype, AT_DISPATCH_FLOATING_TYPES_AND_HALF gridencoder.cu:469), the strides (elements) of the level and point axes of `outputs` / `grad` (reference layout [L,B,C]:
  * stride_l = B*C, stride_b = C; [B, L*C] directly: stride_l = C, stride_b = L*C) and the stream (the reference always
- * uses the legacy default stream).  inputs fp32 [B,D] in [0,1] (out-of-bound points -> zeros); D in {2,3}; C in {1,2,4,8};
+ * uses the legacy default stream).  inputs fp32 [B,D] in [0,1] (out-of-bound points -> zeros); D in {2,3,4,5} (gridencoder.cu:376-399); C in {1,2,4,8};
  * gridtype 0 hash / 1 tiled; interp 0 linear / 1 smoothstep.  grad_embeddings / grad_inputs must arrive zeroed. */
 int snerf_grid_encode_fwd(const float* inputs, const void* embeddings, const int* offsets, void* outputs, int B, int D, int C,
                           int L, float S, int H, void* dy_dx, int gridtype, int align_corners, int interp, int dtype,

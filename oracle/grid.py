@@ -82,22 +82,26 @@ def _positions(x, scale, align_corners, interp):
     return pg.astype(np.uint32), frac, deriv
 
 
-def grid_encode_forward(inputs, embeddings, offsets, S, H, gridtype=0, align_corners=False, interp=0, want_dy_dx=False):
+def grid_encode_forward(inputs, embeddings, offsets, S, H, gridtype=0, align_corners=False, interp=0, want_dy_dx=False, vt=None):
     """kernel_grid, gridencoder.cu:87-245.  inputs [B,D] fp32 in [0,1]; embeddings [sO,C]; -> outputs [L,B,C] fp32
-    (+ dy_dx [B, L*D*C]).  Out-of-bound points give zeros."""
+    (+ dy_dx [B, L*D*C]).  Out-of-bound points give zeros.  vt = scalar type of the table values and their accumulation (the
+    kernel's scalar_t, :137-147; positions and weights are float whatever the table type): default fp32, np.float64 for the
+    double instantiation (:469 AT_DISPATCH_FLOATING_TYPES_AND_HALF)."""
+    F = np.float32
+    V = F if vt is None else vt
     x = np.asarray(inputs, dtype=F)
-    E = np.asarray(embeddings).astype(F)
+    E = np.asarray(embeddings).astype(V)
     B, D = x.shape
     C = E.shape[1]
     L = len(offsets) - 1
-    out = np.zeros((L, B, C), dtype=F)
-    dy_dx = np.zeros((B, L, D, C), dtype=F) if want_dy_dx else None
+    out = np.zeros((L, B, C), dtype=V)
+    dy_dx = np.zeros((B, L, D, C), dtype=V) if want_dy_dx else None
     oob = ((x < 0) | (x > 1)).any(-1)
     for l in range(L):
         hs, scale, res = _level_setup(l, S, H, offsets)
         tab = E[offsets[l]:offsets[l + 1]]
         pg, frac, deriv = _positions(x, scale, align_corners, interp)
-        acc = np.zeros((B, C), dtype=F)
+        acc = np.zeros((B, C), dtype=V)
         for idx in range(1 << D):
             w = np.ones(B, dtype=F)
             pl = pg.copy()
@@ -107,12 +111,12 @@ def grid_encode_forward(inputs, embeddings, offsets, S, H, gridtype=0, align_cor
                 else:
                     w = (w * (F(1) - frac[:, d])).astype(F)
             gi = grid_index(gridtype, align_corners, hs, res, pl)
-            acc = (acc + w[:, None] * tab[gi]).astype(F)
+            acc = (acc + w[:, None] * tab[gi]).astype(V)
         acc[oob] = 0
         out[l] = acc
         if want_dy_dx:
             for gd in range(D):
-                g = np.zeros((B, C), dtype=F)
+                g = np.zeros((B, C), dtype=V)
                 others = [d for d in range(D) if d != gd]
                 for idx in range(1 << (D - 1)):
                     w = np.full(B, scale, dtype=F)
@@ -126,17 +130,19 @@ def grid_encode_forward(inputs, embeddings, offsets, S, H, gridtype=0, align_cor
                     il = grid_index(gridtype, align_corners, hs, res, pl)
                     pl[:, gd] = pg[:, gd] + 1
                     ir = grid_index(gridtype, align_corners, hs, res, pl)
-                    g = (g + (w[:, None] * (tab[ir] - tab[il])) * deriv[:, gd:gd + 1]).astype(F)
+                    g = (g + (w[:, None] * (tab[ir] - tab[il])) * deriv[:, gd:gd + 1]).astype(V)
                 g[oob] = 0
                 dy_dx[:, l, gd] = g
     return (out, dy_dx.reshape(B, L * D * C)) if want_dy_dx else out
 
 
-def grid_encode_backward(grad, inputs, offsets, table_rows, S, H, gridtype=0, align_corners=False, interp=0, dy_dx=None):
+def grid_encode_backward(grad, inputs, offsets, table_rows, S, H, gridtype=0, align_corners=False, interp=0, dy_dx=None, vt=None):
     """kernel_grid_backward (gridencoder.cu:248-340): scatter-add of w * grad into the table (exact fp64 accumulation
-    here; the kernels use atomics, order-dependent in the last bits) and kernel_input_backward (:343-369)."""
+    here; the kernels use atomics, order-dependent in the last bits) and kernel_input_backward (:343-369).  vt: see the forward."""
+    F = np.float32
+    V = F if vt is None else vt
     x = np.asarray(inputs, dtype=F)
-    G = np.asarray(grad).astype(F)            # [L,B,C]
+    G = np.asarray(grad).astype(V)            # [L,B,C]
     L, B, C = G.shape
     D = x.shape[1]
     gE = np.zeros((table_rows, C), dtype=np.float64)
@@ -153,14 +159,14 @@ def grid_encode_backward(grad, inputs, offsets, table_rows, S, H, gridtype=0, al
                 else:
                     w = (w * (F(1) - frac[:, d])).astype(F)
             gi = grid_index(gridtype, align_corners, hs, res, pl) + int(offsets[l])
-            contrib = (w[:, None] * G[l]).astype(F)
+            contrib = (w[:, None] * G[l]).astype(V)
             contrib[oob] = 0
             np.add.at(gE, gi, contrib.astype(np.float64))
     g_in = None
     if dy_dx is not None:
-        dd = np.asarray(dy_dx).astype(F).reshape(B, L, D, C)
-        g_in = np.einsum("lbc,bldc->bd", G.astype(np.float64), dd.astype(np.float64)).astype(F)
-    return gE.astype(F), g_in
+        dd = np.asarray(dy_dx).astype(V).reshape(B, L, D, C)
+        g_in = np.einsum("lbc,bldc->bd", G.astype(np.float64), dd.astype(np.float64)).astype(V)
+    return gE.astype(V), g_in
 
 
 def grad_total_variation(inputs, embeddings, offsets, weight, S, H, gridtype=0, align_corners=False):

@@ -41,12 +41,17 @@ __device__ __forceinline__ uint32_t grid_index(int gridtype, bool align, uint32_
 
 template <typename T, int C> struct alignas(sizeof(T) * C) VecC { T v[C]; };
 
+// arithmetic type of the channel values: the reference accumulates in the table's scalar type (results[ch] += w * grid[...] with a
+// float weight, gridencoder.cu:137-147); half tables are accumulated in fp32 here (a superset of its precision), double stays double
+template <typename T> struct Acc { typedef float type; };
+template <> struct Acc<double> { typedef double type; };
+
 template <typename T, int C>
-__device__ __forceinline__ void load_c(const T* p, float* out) {
+__device__ __forceinline__ void load_c(const T* p, typename Acc<T>::type* out) {
   // one aligned vector load of the C channels of a table row (rows are C * sizeof(T) aligned)
   VecC<T, C> r = *reinterpret_cast<const VecC<T, C>*>(p);
 #pragma unroll
-  for (int c = 0; c < C; ++c) out[c] = (float)r.v[c];
+  for (int c = 0; c < C; ++c) out[c] = (typename Acc<T>::type)r.v[c];
 }
 
 struct GridArgs {
@@ -87,7 +92,8 @@ __global__ __launch_bounds__(256) void grid_fwd_kernel(GridArgs a) {
     if (a.interp == 1) { pder[d] = 6.f * p * (1.f - p); p = p * p * (3.f - 2.f * p); } else pder[d] = 1.f;
     pos[d] = p;
   }
-  float acc[C];
+  typedef typename Acc<T>::type A;
+  A acc[C];
 #pragma unroll
   for (int c = 0; c < C; ++c) acc[c] = 0.f;
 #pragma unroll
@@ -98,7 +104,7 @@ __global__ __launch_bounds__(256) void grid_fwd_kernel(GridArgs a) {
     for (int d = 0; d < D; ++d) {
       if (idx & (1 << d)) { w *= pos[d]; pl[d] = pg[d] + 1; } else { w *= 1.f - pos[d]; pl[d] = pg[d]; }
     }
-    float v[C];
+    A v[C];
     load_c<T, C>(tab + (long)grid_index<D>(a.gridtype, a.align, hs, res, pl) * C, v);
 #pragma unroll
     for (int c = 0; c < C; ++c) acc[c] += w * v[c];
@@ -114,7 +120,7 @@ __global__ __launch_bounds__(256) void grid_fwd_kernel(GridArgs a) {
   if (dd) {
 #pragma unroll
     for (int gd = 0; gd < D; ++gd) {
-      float g[C];
+      A g[C];
 #pragma unroll
       for (int c = 0; c < C; ++c) g[c] = 0.f;
 #pragma unroll
@@ -126,7 +132,7 @@ __global__ __launch_bounds__(256) void grid_fwd_kernel(GridArgs a) {
           const int d = nd >= gd ? nd + 1 : nd;
           if (idx & (1 << nd)) { w *= pos[d]; pl[d] = pg[d] + 1; } else { w *= 1.f - pos[d]; pl[d] = pg[d]; }
         }
-        float vl[C], vr[C];
+        A vl[C], vr[C];
         pl[gd] = pg[gd];
         load_c<T, C>(tab + (long)grid_index<D>(a.gridtype, a.align, hs, res, pl) * C, vl);
         pl[gd] = pg[gd] + 1;
@@ -148,6 +154,7 @@ struct GridBwdArgs {
 };
 
 __device__ __forceinline__ void atomic_add_T(float* p, float v) { atomicAdd(p, v); }
+__device__ __forceinline__ void atomic_add_T(double* p, double v) { atomicAdd(p, v); }
 __device__ __forceinline__ void atomic_add_T(__half* p, float v) {
   // single fp16 atomic (only C == 1 reaches here; even C uses the packed form below)
   unsigned int* base = (unsigned int*)((uintptr_t)p & ~(uintptr_t)3);
@@ -189,9 +196,9 @@ __global__ __launch_bounds__(256) void grid_bwd_kernel(GridBwdArgs a) {
     if (a.interp == 1) p = p * p * (3.f - 2.f * p);
     pos[d] = p;
   }
-  float g[C];
+  typename Acc<T>::type g[C];
 #pragma unroll
-  for (int c = 0; c < C; ++c) g[c] = (float)gin[c];
+  for (int c = 0; c < C; ++c) g[c] = (typename Acc<T>::type)gin[c];
 #pragma unroll
   for (int idx = 0; idx < (1 << D); ++idx) {
     float w = 1.f;
@@ -219,9 +226,10 @@ __global__ __launch_bounds__(256) void grid_input_bwd_kernel(const T* __restrict
   const long b = t / D;
   const int d = (int)(t - b * D);
   const T* dd = dy_dx + b * L * D * C;
-  float r = 0.f;
+  typedef typename Acc<T>::type A;
+  A r = 0.f;
   for (int l = 0; l < L; ++l)
-    for (int c = 0; c < C; ++c) r += (float)grad[l * sg_l + b * sg_b + c] * (float)dd[(l * D + d) * C + c];
+    for (int c = 0; c < C; ++c) r += (A)grad[l * sg_l + b * sg_b + c] * (A)dd[(l * D + d) * C + c];
   grad_inputs[t] = (T)r;
 }
 
@@ -248,7 +256,8 @@ __global__ __launch_bounds__(256) void grid_tv_kernel(const float* __restrict__ 
 #pragma unroll
   for (int d = 0; d < D; ++d) pg[d] = (uint32_t)floorf(x[d] * scale + (align ? 0.f : 0.5f));
   const uint32_t index = grid_index<D>(gridtype, align, hs, res, pg);
-  float v0[C], results[C], idelta[C];
+  typedef typename Acc<T>::type A;
+  A v0[C], results[C], idelta[C];
   load_c<T, C>(tab + (long)index * C, v0);
 #pragma unroll
   for (int c = 0; c < C; ++c) { results[c] = 0.f; idelta[c] = 0.f; }
@@ -256,23 +265,26 @@ __global__ __launch_bounds__(256) void grid_tv_kernel(const float* __restrict__ 
 #pragma unroll
   for (int d = 0; d < D; ++d) {
     const uint32_t cur = pg[d];
-    float vn[C];
+    A vn[C];
     if (cur < res) {
       pg[d] = cur + 1;
       load_c<T, C>(tab + (long)grid_index<D>(gridtype, align, hs, res, pg) * C, vn);
 #pragma unroll
-      for (int c = 0; c < C; ++c) { const float gv = v0[c] - vn[c]; results[c] += gv; idelta[c] += gv * gv; }
+      for (int c = 0; c < C; ++c) { const A gv = v0[c] - vn[c]; results[c] += gv; idelta[c] += gv * gv; }
     }
     if (cur > 0) {
       pg[d] = cur - 1;
       load_c<T, C>(tab + (long)grid_index<D>(gridtype, align, hs, res, pg) * C, vn);
 #pragma unroll
-      for (int c = 0; c < C; ++c) { const float gv = v0[c] - vn[c]; results[c] += gv; idelta[c] += gv * gv; }
+      for (int c = 0; c < C; ++c) { const A gv = v0[c] - vn[c]; results[c] += gv; idelta[c] += gv * gv; }
     }
     pg[d] = cur;
   }
 #pragma unroll
-  for (int c = 0; c < C; ++c) atomic_add_T(gt + (long)index * C + c, w * results[c] * rsqrtf(idelta[c] + 1e-9f));
+  for (int c = 0; c < C; ++c) {
+    if constexpr (sizeof(T) == 8) atomic_add_T(gt + (long)index * C + c, (double)w * results[c] * rsqrt(idelta[c] + 1e-9));
+    else atomic_add_T(gt + (long)index * C + c, w * results[c] * rsqrtf(idelta[c] + 1e-9f));
+  }
 }
 
 // ---- dispatch ---------------------------------------------------------------------------------------------------
@@ -284,16 +296,20 @@ __global__ __launch_bounds__(256) void grid_tv_kernel(const float* __restrict__ 
     case 8: FN<T, D, 8> __VA_ARGS__; break;                                 \
     default: return SNERF_ERR_ARG;                                          \
   }
+#define GRID_DISPATCH_D(T, FN, ...)                                         \
+  switch (D) {                                                              \
+    case 2: { GRID_DISPATCH_C(T, 2, FN, __VA_ARGS__) } break;               \
+    case 3: { GRID_DISPATCH_C(T, 3, FN, __VA_ARGS__) } break;               \
+    case 4: { GRID_DISPATCH_C(T, 4, FN, __VA_ARGS__) } break;               \
+    case 5: { GRID_DISPATCH_C(T, 5, FN, __VA_ARGS__) } break;               \
+    default: return SNERF_ERR_ARG;                                          \
+  }
+// D = 2..5 and float / double / half: the instantiations of the reference (gridencoder.cu:376-399, AT_DISPATCH_FLOATING_TYPES_AND_HALF)
 #define GRID_DISPATCH(FN, ...)                                              \
-  if (dtype == SNERF_DT_F32) {                                              \
-    if (D == 3) { GRID_DISPATCH_C(float, 3, FN, __VA_ARGS__) }              \
-    else if (D == 2) { GRID_DISPATCH_C(float, 2, FN, __VA_ARGS__) }         \
-    else return SNERF_ERR_ARG;                                              \
-  } else if (dtype == SNERF_DT_F16) {                                       \
-    if (D == 3) { GRID_DISPATCH_C(__half, 3, FN, __VA_ARGS__) }             \
-    else if (D == 2) { GRID_DISPATCH_C(__half, 2, FN, __VA_ARGS__) }        \
-    else return SNERF_ERR_ARG;                                              \
-  } else return SNERF_ERR_ARG;
+  if (dtype == SNERF_DT_F32) { GRID_DISPATCH_D(float, FN, __VA_ARGS__) }    \
+  else if (dtype == SNERF_DT_F16) { GRID_DISPATCH_D(__half, FN, __VA_ARGS__) } \
+  else if (dtype == SNERF_DT_F64) { GRID_DISPATCH_D(double, FN, __VA_ARGS__) } \
+  else return SNERF_ERR_ARG;
 
 template <typename T, int D, int C> static void launch_fwd(const GridArgs& a, hipStream_t s) {
   hipLaunchKernelGGL((grid_fwd_kernel<T, D, C>), dim3((a.B + 255) / 256, a.L), dim3(256), 0, s, a);
@@ -329,6 +345,9 @@ extern "C" int snerf_grid_encode_bwd(const void* grad, const float* inputs, cons
     if (dtype == SNERF_DT_F32)
       hipLaunchKernelGGL(grid_input_bwd_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)grad,
                          grad_stride_l, grad_stride_b, (const float*)dy_dx, (float*)grad_inputs, B, D, C, L);
+    else if (dtype == SNERF_DT_F64)
+      hipLaunchKernelGGL(grid_input_bwd_kernel<double>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const double*)grad,
+                         grad_stride_l, grad_stride_b, (const double*)dy_dx, (double*)grad_inputs, B, D, C, L);
     else
       hipLaunchKernelGGL(grid_input_bwd_kernel<__half>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const __half*)grad,
                          grad_stride_l, grad_stride_b, (const __half*)dy_dx, (__half*)grad_inputs, B, D, C, L);

@@ -60,8 +60,8 @@ class GridEncoder(nn.Module):
         super().__init__()
         if desired_resolution is not None:
             per_level_scale = np.exp2(np.log2(desired_resolution / base_resolution) / (num_levels - 1))
-        if input_dim not in (2, 3) or level_dim not in (1, 2, 4, 8):
-            raise NotImplementedError("accelerated GridEncoder: input_dim in {2,3}, level_dim in {1,2,4,8}")
+        if input_dim not in (2, 3, 4, 5) or level_dim not in (1, 2, 4, 8):
+            raise NotImplementedError("GridEncoder: input_dim in {2,3,4,5}, level_dim in {1,2,4,8} (the reference's instantiations, gridencoder.cu:376-399)")
         self.input_dim, self.num_levels, self.level_dim = input_dim, num_levels, level_dim
         self.per_level_scale, self.log2_hashmap_size, self.base_resolution = per_level_scale, log2_hashmap_size, base_resolution
         self.output_dim = num_levels * level_dim

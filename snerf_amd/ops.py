@@ -9,7 +9,7 @@ import torch
 
 from . import _lib
 
-F32, BF16, F16 = 0, 1, 2
+F32, BF16, F16, F64 = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_MASK = 0, 1, 2
 ACT_RELU_BITS, ACT_MASK_BITS = 3, 4        # ReLU that also writes a 1-bit-per-element mask / ReLU backward from that mask
 _TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
@@ -435,15 +435,18 @@ def gather_pack(flat, idx, dst):
 
 
 # ------------------------------------------------------------ hash grid ----
+_GRID_DT = {torch.float32: F32, torch.float16: F16, torch.float64: F64}    # the reference's three instantiations (gridencoder.cu:469)
+
+
 def grid_encode_fwd(inputs, embeddings, offsets, L, S, H, gridtype, align_corners, interp, want_dy_dx=False, level_major=False):
     """inputs fp32 [B,D] in [0,1]; embeddings [sO,C] fp32/fp16 -> outputs [B, L*C] (or [L,B,C] if level_major) in the
     table dtype (+ dy_dx [B, L*D*C])."""
     _f32c(inputs)
-    assert embeddings.is_cuda and embeddings.is_contiguous() and embeddings.dtype in (torch.float32, torch.float16)
+    assert embeddings.is_cuda and embeddings.is_contiguous() and embeddings.dtype in _GRID_DT
     assert offsets.dtype == torch.int32 and offsets.is_cuda
     B, D = inputs.shape
     C = embeddings.shape[1]
-    dt = F32 if embeddings.dtype == torch.float32 else F16
+    dt = _GRID_DT[embeddings.dtype]
     if level_major:
         out = torch.empty(L, B, C, dtype=embeddings.dtype, device=inputs.device); sl, sb = B * C, C
     else:
@@ -460,7 +463,7 @@ def grid_encode_bwd(grad, inputs, embeddings, offsets, L, S, H, gridtype, align_
     assert grad.is_contiguous() and grad.dtype == embeddings.dtype
     B, D = inputs.shape
     C = embeddings.shape[1]
-    dt = F32 if embeddings.dtype == torch.float32 else F16
+    dt = _GRID_DT[embeddings.dtype]
     sl, sb = (B * C, C) if level_major else (C, L * C)
     g_emb = torch.zeros_like(embeddings)
     g_in = torch.zeros(B, D, dtype=embeddings.dtype, device=inputs.device) if dy_dx is not None else None
@@ -473,7 +476,7 @@ def grid_tv_grad(inputs, embeddings, grad, offsets, weight, L, S, H, gridtype, a
     _f32c(inputs)
     assert grad.dtype == embeddings.dtype and grad.is_contiguous() and embeddings.is_contiguous()
     B, D = inputs.shape
-    dt = F32 if embeddings.dtype == torch.float32 else F16
+    dt = _GRID_DT[embeddings.dtype]
     _lib.call("snerf_grid_tv_grad", _p(inputs), _p(embeddings), _p(grad), _p(offsets), float(weight), B, D, embeddings.shape[1], L,
               float(S), int(H), int(gridtype), 1 if align_corners else 0, dt, _stream())
 

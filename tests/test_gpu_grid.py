@@ -104,3 +104,67 @@ def test_gridencoder_module_autograd_and_autocast():
     with torch.autocast("cuda", dtype=torch.float16):
         y16 = enc(x.detach())
     assert y16.dtype == torch.float16 and float((y16.float() - y.detach()).abs().max()) < 2e-3
+
+
+@pytest.mark.parametrize("D,C,gridtype", [(2, 2, 0), (4, 2, 0), (5, 1, 0), (4, 4, 1)])
+def test_grid_other_input_dims(D, C, gridtype):
+    """The reference instantiates D = 2..5 (gridencoder.cu:376-399); the hash uses one prime per dimension (:50-63)."""
+    from snerf_amd import ops
+    L, H = 4, 3
+    off, res, s = og.level_layout(D, L, C, 1.6, H, 10, None, False)
+    S = float(np.log2(s))
+    rng = np.random.default_rng(10 * D + C)
+    E = (rng.standard_normal((int(off[-1]), C)) * 0.5).astype(np.float32)
+    x = rng.random((700, D)).astype(np.float32)
+    x[0, 0] = -0.1; x[1, D - 1] = 1.2; x[2] = 0.0; x[3] = 1.0
+    ref, ref_dd = og.grid_encode_forward(x, E, off, S, H, gridtype, False, 0, want_dy_dx=True)
+    xt, Et, offt = torch.from_numpy(x).cuda(), torch.from_numpy(E).cuda(), torch.from_numpy(off).cuda()
+    out, dd = ops.grid_encode_fwd(xt, Et, offt, L, S, H, gridtype, False, 0, want_dy_dx=True)
+    np.testing.assert_allclose(out.cpu().numpy().reshape(-1, L, C), ref.transpose(1, 0, 2), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(dd.cpu().numpy(), ref_dd, rtol=5e-3, atol=2e-3)
+    assert float(out[:2].abs().max()) == 0.0
+    G = rng.standard_normal((L, x.shape[0], C)).astype(np.float32)
+    gE_ref, gx_ref = og.grid_encode_backward(G, x, off, E.shape[0], S, H, gridtype, False, 0, dy_dx=ref_dd)
+    Gt = torch.from_numpy(np.ascontiguousarray(G.transpose(1, 0, 2).reshape(-1, L * C))).cuda()
+    gE, gx = ops.grid_encode_bwd(Gt, xt, Et, offt, L, S, H, gridtype, False, 0, dy_dx=dd)
+    np.testing.assert_allclose(gE.cpu().numpy(), gE_ref, rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(gx.cpu().numpy(), gx_ref, rtol=1e-3, atol=1e-3)
+    # the module accepts the dimension
+    from snerf_amd.gridencoder import GridEncoder
+    enc = GridEncoder(input_dim=D, num_levels=L, level_dim=C, per_level_scale=1.6, base_resolution=H, log2_hashmap_size=10, gridtype="hash" if gridtype == 0 else "tiled")
+    assert enc(torch.rand(33, D, device="cuda"), bound=1).shape == (33, L * C)
+
+
+def test_grid_double_tables():
+    """the double instantiation (AT_DISPATCH_FLOATING_TYPES_AND_HALF, gridencoder.cu:469): float positions / weights, table values and
+    their accumulation in double"""
+    from snerf_amd import ops
+    L, C, H = 5, 2, 4
+    off, res, S, E, x = setup(L, C, 1.7, H, 11, 2000, 3)
+    E64 = E.astype(np.float64) + 1e-9 * np.random.default_rng(4).standard_normal(E.shape)      # values that do not fit fp32
+    ref, ref_dd = og.grid_encode_forward(x, E64, off, S, H, 0, False, 1, want_dy_dx=True, vt=np.float64)
+    xt, Et, offt = torch.from_numpy(x).cuda(), torch.from_numpy(E64).cuda(), torch.from_numpy(off).cuda()
+    out, dd = ops.grid_encode_fwd(xt, Et, offt, L, S, H, 0, False, 1, want_dy_dx=True)
+    assert out.dtype == torch.float64 and dd.dtype == torch.float64
+    # positions and weights are fp32 in every instantiation (and the kernel may contract x * scale + 0.5 into one fma): agreement with
+    # the oracle is limited by fp32 weight rounding ...
+    np.testing.assert_allclose(out.cpu().numpy().reshape(-1, L, C), ref.transpose(1, 0, 2), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(dd.cpu().numpy(), ref_dd, rtol=5e-3, atol=2e-3)
+    # ... but the VALUES are carried in double: the encoding is linear in the table, and a 1e-9 perturbation of the entries (invisible
+    # to an fp32 accumulation of O(1) values) comes out resolved to 1e-4 of itself
+    E32t = torch.from_numpy(E.astype(np.float64)).cuda()
+    out32, _ = ops.grid_encode_fwd(xt, E32t, offt, L, S, H, 0, False, 1)
+    d_ref = og.grid_encode_forward(x, E64 - E.astype(np.float64), off, S, H, 0, False, 1, vt=np.float64)
+    d = (out - out32).cpu().numpy().reshape(-1, L, C)
+    assert float(np.abs(d_ref).max()) > 1e-10
+    np.testing.assert_allclose(d, d_ref.transpose(1, 0, 2), rtol=1e-5, atol=1e-13)   # (an fp32 accumulation would be off by 1e-7)
+    G = np.random.default_rng(5).standard_normal((L, x.shape[0], C))
+    gE_ref, gx_ref = og.grid_encode_backward(G, x, off, E.shape[0], S, H, 0, False, 1, dy_dx=ref_dd, vt=np.float64)
+    Gt = torch.from_numpy(np.ascontiguousarray(G.transpose(1, 0, 2).reshape(-1, L * C))).cuda()
+    gE, gx = ops.grid_encode_bwd(Gt, xt, Et, offt, L, S, H, 0, False, 1, dy_dx=dd)
+    assert gE.dtype == torch.float64 and gx.dtype == torch.float64
+    np.testing.assert_allclose(gE.cpu().numpy(), gE_ref, rtol=1e-4, atol=2e-4)                  # fp32 weights, see above
+    np.testing.assert_allclose(gx.cpu().numpy(), gx_ref, rtol=1e-3, atol=1e-3)
+    # adjointness holds to double precision on the device results themselves (same weights on both sides)
+    lhs = float((out * Gt).sum()); rhs = float((Et * gE).sum())
+    assert abs(lhs - rhs) < 1e-10 * max(1.0, abs(lhs))

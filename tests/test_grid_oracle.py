@@ -2,6 +2,7 @@
 cannot be built or run here -- SURVEY.md section 8c): level sizing, hash values, affine reproduction, out-of-bound
 handling, adjointness of backward, dy_dx vs finite differences, TV gradient vs a dense restatement."""
 import numpy as np
+import pytest
 
 from oracle import grid as og
 
@@ -108,3 +109,35 @@ def test_tv_gradient_dense_restatement():
                         gv = v0 - T[n[2], n[1], n[0]]; tot += gv; sq += gv * gv
             want[off[l] + c[0] + c[1] * r + c[2] * r * r, 0] += 0.5 / 6 * tot / np.sqrt(sq + 1e-9)
     np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("D", [2, 4, 5])
+def test_other_input_dims_known_answers(D):
+    """D = 2, 4, 5 (gridencoder.cu:376-399): the hash takes one prime per dimension (:50-63), dense levels index with stride (res)^d
+    (:66-84; the level size rule adds 1 to the resolution when corners are not aligned), and multilinear interpolation reproduces an
+    affine field of the cell coordinates exactly -- in double as well as in fp32 tables."""
+    primes = [1, 2654435761, 805459861, 3674653429, 2097192037]
+    p = np.array([[3, 5, 7, 11, 13][:D]], dtype=np.uint32)
+    want = 0
+    for d in range(D):
+        want ^= (int(p[0, d]) * primes[d]) & 0xFFFFFFFF
+    assert int(og.fast_hash(p)[0]) == want
+    off, res, s = og.level_layout(D, 2, 1, 1.5, 3, 19, None, False)        # both levels dense
+    S = np.log2(s)
+    coef = np.array([0.5, 0.25, -0.125, 0.0625, 0.75, -0.375][:D + 1])
+    tab = np.zeros((int(off[-1]), 1), dtype=np.float64)
+    for l in range(2):
+        r = int(res[l])
+        i = np.arange(r ** D)
+        cell = np.stack([(i // r ** d) % r for d in range(D)], -1)
+        tab[off[l] + i, 0] = coef[0] + cell @ coef[1:]
+    rng = np.random.default_rng(D)
+    x = rng.random((50, D)).astype(np.float32)
+    for vt, tol in ((None, 2e-5), (np.float64, 2e-7)):      # double values, but the weights are fp32 products in every instantiation
+        out = og.grid_encode_forward(x, tab, off, S, 3, 0, False, 0, vt=vt)
+        for l in range(2):
+            scale = np.float32(np.exp2(np.float32(l) * np.float32(S)) * 3 - 1)
+            pos = (x * scale + np.float32(0.5)).astype(np.float32)
+            # the oracle (like the kernel) forms frac = pos - floor(pos) in fp32: evaluate the affine field at floor + frac
+            cellpos = np.floor(pos).astype(np.float64) + (pos - np.floor(pos)).astype(np.float64)
+            np.testing.assert_allclose(out[l, :, 0], coef[0] + cellpos @ coef[1:], rtol=tol, atol=tol)

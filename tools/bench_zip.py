@@ -145,7 +145,10 @@ def main():
     tb = 2 if args.table == "f16" else 4
     bytes_lvl = [R * 7 * 64 * 6 * 8 * 1 * tb, R * 7 * 64 * 8 * 8 * 1 * tb, R * 7 * 32 * 10 * 8 * 4 * tb]
     out = {"path": "C (zipnerf Model, waymo.gin shape: 64+64+32 intervals x 7 multisamples, grids L=6/8/10)", "n_gpus": world, "rays_per_gpu": R,
-           "compute": args.compute, "table_grad": args.table_grad, "table_grad_mode": m.table_grad_mode,
+           "compute": args.compute,
+           "compute_note": "BASELINE config 4 names an fp16 MLP (torch autocast); this build evaluates the MLPs in bf16 (same MFMA rate, fp32 "
+                           "accumulate, no loss scaling needed) and keeps the hash tables in fp16 as the reference does",
+           "table_grad": args.table_grad, "table_grad_mode": m.table_grad_mode,
            "table": args.table, "train_ms": round(dt_train * 1e3, 3), "train_rays_per_s": round(world * R / dt_train, 1), "fwd_ms": round(dt_fwd * 1e3, 3),
            "fwd_rays_per_s": round(R / dt_fwd, 1), "frame_1920x1280_s": round(dt_frame, 3), "frame_outputs": sorted(k for k in img if not k.startswith("ray_")), "encode_fwd_ms_per_level": [round(x, 3) for x in enc_ms], "encode_note": "inference: proposal levels = featurisation + MLP fused",
            "encode_fwd_gather_GBps_per_level": [round(b / (ms * 1e-3) / 1e9, 1) for b, ms in zip(bytes_lvl, enc_ms)],
