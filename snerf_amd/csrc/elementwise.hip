@@ -130,13 +130,17 @@ extern "C" int snerf_grad_clip_coef(const float* g, long n, float grad_scale, fl
 
 // out[c] += sum_m x[m, c] for a narrow fp32 matrix (head gradients: 3 + 1 columns)
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long ld, long M, int C, float* __restrict__ out) {
+  __shared__ float red[4][8];
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (long m = (long)blockIdx.x * 256 + threadIdx.x; m < M; m += (long)gridDim.x * 256)
     for (int c = 0; c < C; ++c) acc[c] += x[m * ld + c];
   for (int c = 0; c < C; ++c) {
     const float s = wave_sum(acc[c]);
-    if ((threadIdx.x & 63) == 0) atomicAdd(out + c, s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][c] = s;
   }
+  __syncthreads();
+  // one atomic per workgroup and column (thousands of same-address atomics were the cost of this kernel, not its 6 MB of reads)
+  if (threadIdx.x < C) atomicAdd(out + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 // the same sums by ONE workgroup in a fixed order (deterministic mode: no atomics between workgroups)
@@ -167,8 +171,8 @@ extern "C" int snerf_colsum_f32_det(const float* x, long ld, long M, int C, floa
 extern "C" int snerf_colsum_f32(const float* x, long ld, long M, int C, float* out, void* stream) {
   if (M <= 0) return SNERF_OK;
   if (C < 1 || C > 8) return SNERF_ERR_ARG;
-  int blocks = (int)((M + 255) / 256);
-  blocks = blocks > 1024 ? 1024 : blocks;
+  int blocks = (int)((M + 2047) / 2048);                  // >= 8 rows per thread
+  blocks = blocks > 512 ? 512 : (blocks < 1 ? 1 : blocks);
   hipLaunchKernelGGL(colsum_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ld, M, C, out);
   return snerf_check_launch();
 }
@@ -185,9 +189,29 @@ __global__ __launch_bounds__(256) void cast_pad_kernel(const float* __restrict__
   }
 }
 
+// bf16, Cpad % 8 == 0, 16-byte aligned rows: one thread per 8 consecutive outputs of a row (one 16-byte store)
+__global__ __launch_bounds__(256) void cast_pad8_kernel(const float* __restrict__ src, long ld_src, long M, int C, int G, __bf16* __restrict__ dst,
+                                                        long ld_dst) {
+  const long total = M * G;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long m = e / G;
+    const int c0 = (int)(e - m * G) * 8;
+    bf16x8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (__bf16)(c0 + k < C ? src[m * ld_src + c0 + k] : 0.f);
+    *(bf16x8*)(dst + m * ld_dst + c0) = o;
+  }
+}
+
 extern "C" int snerf_cast_pad(const float* src, long ld_src, long M, int C, int Cpad, void* dst, long ld_dst, int dtype, void* stream) {
   if (M <= 0) return SNERF_OK;
   if (C < 0 || Cpad < C) return SNERF_ERR_ARG;
+  if (dtype == SNERF_DT_BF16 && (Cpad % 8) == 0 && (ld_dst % 8) == 0 && (((uintptr_t)dst) & 15) == 0) {
+    const long total8 = M * (Cpad / 8);
+    const int blocks8 = (int)((total8 + 255) / 256 < 16384 ? (total8 + 255) / 256 : 16384);
+    hipLaunchKernelGGL(cast_pad8_kernel, dim3(blocks8), dim3(256), 0, (hipStream_t)stream, src, ld_src, M, C, Cpad / 8, (__bf16*)dst, ld_dst);
+    return snerf_check_launch();
+  }
   const long total = M * Cpad;
   const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
   if (dtype == SNERF_DT_F32) hipLaunchKernelGGL(cast_pad_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, ld_src, M, C, Cpad, (float*)dst, ld_dst);

@@ -23,19 +23,21 @@ class _GradExchange:
     gradients are final its block is all-reduced asynchronously (RCCL runs it on its own stream) while the remaining networks'
     backward kernels keep the compute stream busy.  `finish()` reduces whatever was not announced and waits for everything."""
 
-    def __init__(self, arena, world, group):
+    def __init__(self, arena, world, group, single_rank=False):
+        """`single_rank`: run the collectives even in a process group of one rank (diagnostics: exercises the RCCL path on a 1-GPU box)"""
         self.arena, self.world, self.group = arena, world, group
+        self.active = world > 1 or single_rank
         self.works, self.done = [], []
 
     def __call__(self, prefix):
-        if self.world <= 1:
+        if not self.active:
             return
         a, b = self.arena.span(prefix)
         self.done.append((a, b))
         self.works.append(dist.all_reduce(self.arena.grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
-        if self.world <= 1:
+        if not self.active:
             return
         pos = 0
         for a, b in sorted(self.done) + [(self.arena.numel, self.arena.numel)]:
@@ -50,7 +52,7 @@ class _GradExchange:
 class MipTrainer:
     def __init__(self, model, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, depth_lambda=0.2, coarse_depth_mult=0.2,
                  proposal_loss=False, proposal_lambda=0.05, disparity_depth=True, process_group=None,
-                 nonfinite="zero", grad_max_val=0.0, grad_max_norm=0.0):
+                 nonfinite="zero", grad_max_val=0.0, grad_max_norm=0.0, exchange_when_single=False):
         """`nonfinite` / `grad_max_val` / `grad_max_norm`: gradient hygiene folded into the Adam launch (ops.adam_step).  The s-nerf
         reference has none (train.py:212-215 drops into pdb on a failing backward); the default "zero" keeps one NaN / Inf gradient
         (1/(depth + eps), a bf16 overflow) from poisoning m, v and the parameters of the whole arena on every rank.  "keep" = plain Adam."""
@@ -65,6 +67,7 @@ class MipTrainer:
         self.t = 0
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.single_rank_exchange = bool(exchange_when_single) and dist.is_available() and dist.is_initialized()
         self._step_dev = self._lr_dev = self._graph = None
         a.grad.zero_()
 
@@ -106,7 +109,7 @@ class MipTrainer:
         u = du if u is None else u
         outs, ctx = m._run(rays, True, False, s_rand, u.contiguous(), noise0, noise1)
         loss, g = self.loss_and_grads(outs, target_rgb, target_depth, conf)
-        ex = _GradExchange(m.arena, self.world, self.pg)
+        ex = _GradExchange(m.arena, self.world, self.pg, self.single_rank_exchange)
         # the 35.9 MB MLP block is reduced while the proposal network's backward runs
         self.last_ray_grads = m._backward(ctx, *g, on_done=ex, ray_grads=ray_grads)
         ex.finish()

@@ -10,6 +10,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.dirname(HERE))
@@ -225,3 +227,57 @@ def test_mip_render_image_sharded_across_ranks():
         ref = mipnerf.render_image(lambda r: model(r, False, False, 0.), grid, 0, chunk=35)
     for a, b in zip(got, ref[:3]):                        # (CPU BLAS blocks differently for different chunk sizes: last-bit differences)
         assert a.shape == b.shape and float((a - b).abs().max()) < 1e-5 * (1 + float(b.abs().max()))
+
+
+_RCCL_ONE_RANK = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["SNERF_REPO"])
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ["SNERF_PORT"], RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+from snerf_amd import mipnerf
+from snerf_amd.trainer import MipTrainer
+from oracle import common
+
+def run(single):
+    torch.manual_seed(0)
+    m = mipnerf.MipNerfModel(n_samples=32, N_fine=33, no_warp_sample=0, ray_shape="cone", fn=1, radius=3., transform_idx=0, real=True, rgb_layer=3,
+                             hidden_layer=256, density_noise=0., max_deg_point=16, proposal_loss=True, compute="bf16")
+    m.set_deterministic(True)      # weight gradients folded in a fixed order: the two runs can be compared exactly
+    tr = MipTrainer(m, lr=1e-3, proposal_loss=True, exchange_when_single=single)
+    tr.broadcast_parameters()
+    rays = mipnerf.Rays(**{k: v.cuda() for k, v in common.synthetic_rays(1024, seed=3).items()})
+    tgt = torch.rand(1024, 3, generator=torch.Generator().manual_seed(1)).cuda()
+    out = []
+    for _ in range(3):
+        loss, _ = tr.step(rays, tgt, randomized=False)
+        out.append(float(loss))
+    return out, m.arena.flat.clone()
+
+la, pa = run(True)          # gradients go through RCCL all_reduce (async, per network block) on this GPU
+lb, pb = run(False)         # no collective
+assert max(abs(a - b) for a, b in zip(la, lb)) < 1e-6 and float((pa - pb).norm() / pb.norm()) < 1e-6, (la, lb, float((pa - pb).norm() / pb.norm()))
+x = torch.arange(8, device="cuda", dtype=torch.float32)
+parts = [torch.empty_like(x)]
+dist.all_gather(parts, x)
+assert torch.equal(parts[0], x)
+dist.barrier(); torch.cuda.synchronize()
+dist.destroy_process_group()
+print("RCCL_ONE_RANK_OK", la)
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_rccl_collectives_run_on_the_gpu_with_one_rank(tmp_path):
+    """The N > 1 tests above run gloo on CPU tensors; the 1-GPU box cannot host two RCCL ranks (duplicate device).  What it can do is
+    put the SAME code path -- nccl backend (= RCCL), asynchronous per-block all_reduce of the gradient arena from the backward's
+    callbacks, wait before Adam, all_gather -- on real device memory with a communicator of one rank, and check that the training
+    trajectory is the one of the run without collectives."""
+    import subprocess
+    import sys
+    script = tmp_path / "rccl_one_rank.py"
+    script.write_text(_RCCL_ONE_RANK)
+    env = dict(os.environ, SNERF_REPO=REPO, SNERF_PORT=str(29650 + os.getpid() % 200))
+    p = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=550, env=env)
+    assert p.returncode == 0 and "RCCL_ONE_RANK_OK" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])

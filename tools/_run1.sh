@@ -1,2 +1,3 @@
 cd /root/repo
-timeout 900 python -m pytest tests/test_gpu_grid.py -x -q -m gpu -k double 2>&1 | grep -E "^E|^tests.*Error|assert_allclose|passed|failed" | head -30
+SNERF_REPO=/root/repo SNERF_PORT=29651 timeout 300 python tools/_rccl1.py > /tmp/o.txt 2> /tmp/e.txt; echo rc=$?
+tail -5 /tmp/o.txt; grep -v "^$" /tmp/e.txt | tail -30 | cut -c1-300
