@@ -71,3 +71,14 @@ def sample_single_img(args, image, depth_gt, pose, intrinsic, near=0., far=1., n
     target_rgb = image[ct[:, 0], ct[:, 1]]
     target_dep = depth_gt[ct[:, 0], ct[:, 1]]
     return rays, target_rgb, target_dep, ct, sel
+
+
+def apply_pose_transform(rays, pose):
+    """The pose-refinement half of `sample_rays` (sample_utils.py:421-435): rotate directions / viewdirs by pose[:3, :3] and shift the
+    origins by pose[:3, 3], in torch, so that autograd links the rays to a learnable pose (`pose = pose_param_net(img_i,
+    transform_only=True)`).  The rays this module generates are detached from any pose tensor (the per-pixel arithmetic runs in a
+    kernel); with `pose.requires_grad` the returned origins / directions / viewdirs require grad, `MipNerfModel` / zipnerf `Model`
+    deliver d loss / d rays for them, and `loss.backward()` reaches the pose parameters as in the reference."""
+    R, t = pose[:3, :3], pose[:3, 3]
+    rot = lambda v: (v[..., None, :] * R).sum(-1)
+    return rays._replace(origins=rays.origins + t, directions=rot(rays.directions), viewdirs=rot(rays.viewdirs))

@@ -327,3 +327,21 @@ def test_trainer_ray_gradients_for_pose_refinement():
             assert float(ref.abs().max()) > 0 and float((got - ref).abs().max()) <= 1e-4 * float(ref.abs().max()), k
         tr.step(mipnerf.Rays(**rc), tgt, td, conf, randomized=False)
         assert tr.last_ray_grads is None
+
+
+def test_apply_pose_transform_is_sample_rays_pose_branch_and_is_differentiable():
+    """sample_utils.py:421-435: directions / viewdirs rotated by pose[:3,:3] (as a row-vector product), origins shifted by pose[:3,3];
+    autograd reaches the pose (what `pose_refine = True` trains)."""
+    from snerf_amd import sample_utils
+    g = torch.Generator().manual_seed(0)
+    n = 17
+    mk = lambda *s: torch.randn(*s, generator=g)
+    rays = sample_utils.Rays(mk(n, 3), mk(n, 3), mk(n, 3), mk(n, 1), torch.ones(n, 1), torch.ones(n, 1), torch.ones(n, 1) * 9, torch.zeros(n, 1))
+    pose = torch.eye(4) + 0.05 * mk(4, 4)
+    pose.requires_grad_(True)
+    out = sample_utils.apply_pose_transform(rays, pose)
+    assert torch.allclose(out.directions, (rays.directions[:, None, :] * pose[:3, :3]).sum(axis=-1))
+    assert torch.allclose(out.viewdirs, rays.viewdirs @ pose[:3, :3].t()) and torch.allclose(out.origins, rays.origins + pose[:3, 3])
+    assert out.radii is rays.radii and out.near is rays.near
+    (out.origins.sum() + (out.directions ** 2).sum() + out.viewdirs[:, 0].sum()).backward()
+    assert pose.grad is not None and float(pose.grad[:3, :].abs().min()) > 0 and float(pose.grad[3].abs().max()) == 0
