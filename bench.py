@@ -298,6 +298,8 @@ def main():
         ms_step = elapsed / args.steps * 1e3
         rays_per_s = world * n * args.steps / elapsed
         alg_nt = n * (fwd + fwd - first - skipenc)                               # fwd + dgrad through gemm_nt, per step
+        if getattr(model.prop, "fused_ok", lambda: False)():
+            alg_nt -= n * 2.0 * S0 * MAC_PROP                                    # the proposal MLP's forward is one fmlp_kernel launch, not NT GEMMs
         achieved = alg_nt / (gemm_ms * 1e-3) / 1e12
         peak = PEAK_BF16_TFLOPS if args.compute == "bf16" else 157.3
         roofline = {"bound": "mfma", "kernel": {8: "gemm_nt8p_kernel (bf16, 256x256 persistent 8-phase)", 4: "gemm_nt8_kernel (bf16, 256x256 8-phase)", 1: "gemm_nt_kernel<bf16,256,256,2,4>"}.get(args.variant, "gemm_nt_kernel<bf16,128,128,2,2>") if args.compute == "bf16" else "gemm_nt_kernel<f32,128,128,2,2>",
