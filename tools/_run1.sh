@@ -1,3 +1,5 @@
 cd /root/repo
-SNERF_REPO=/root/repo SNERF_PORT=29651 timeout 300 python tools/_rccl1.py > /tmp/o.txt 2> /tmp/e.txt; echo rc=$?
-tail -5 /tmp/o.txt; grep -v "^$" /tmp/e.txt | tail -30 | cut -c1-300
+for v in base prio base prio; do
+  cp snerf_amd/lib/_$v.so snerf_amd/lib/libsnerf_hip.so
+  echo "== $v"; timeout 300 python tools/gemm_reference_point.py 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); [print(k, {a:b for a,b in v.items() if 'ours' in a and 'TFLOPs' in a or a=='nt_vendor_TFLOPs'}) for k,v in d.items()]"
+done
