@@ -1,4 +1,4 @@
-"""The one-line JSON contract of bench.py, checked on the last line the GPU box produced (profiles/r1_z_bench_default.json.log) and on
+"""The one-line JSON contract of bench.py, checked on the last line the GPU box produced (profiles/r2_z_bench_default.json.log) and on
 bench.py's own source (the fields are literal keys there): metric / value / unit / n_gpus / steps / warmup / ms_per_step /
 higher_is_better / scaling / vs_baseline / dtype / data / config.workload + roofline{bound, achieved, peak, unit, frac, traffic} +
 cpu_baseline{value, unit, cores, kind, sample}."""
@@ -9,7 +9,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _last_line():
-    with open(os.path.join(REPO, "profiles", "r1_z_bench_default.json.log")) as f:
+    with open(os.path.join(REPO, "profiles", "r2_z_bench_default.json.log")) as f:
         lines = [l for l in f.read().splitlines() if l.startswith("{")]
     return json.loads(lines[-1])
 
@@ -29,6 +29,13 @@ def test_bench_line_has_the_contract_fields():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["peak"] == 2500.0 and r["traffic"] > 2.0e9
     c = d["cpu_baseline"]
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(c) and c["kind"] in ("port", "reference") and c["unit"] == d["unit"]
+    # round-2 fields of the default line: eager PyTorch-ROCm baselines on the same GPU, the fp32-parity mode's own throughput / roofline
+    e, f = d["eager_baseline"], d["f32_mode"]
+    assert e["fp32"] > 0 and e["bf16_autocast"] > 0 and abs(e["speedup_vs_bf16_autocast"] - d["value"] / e["bf16_autocast"]) < 0.02
+    assert f["roofline"]["peak"] == 157.3 and abs(f["roofline"]["frac"] - f["roofline"]["achieved"] / 157.3) < 1e-3
+    assert d["ms_per_step_median"] > 0 and d["frame"]["rays"] == 1440000
+    # kernel time within the step, whole-step rate below the peak
+    assert r["kernel_ms_per_step"] < d["ms_per_step"] and r["whole_step_tflops"] < r["peak"]
     if isinstance(base, dict) and "metric" in base:
         assert str(base["metric"]).split()[0].lower() in d["metric"].lower() or "ray" in d["metric"].lower()
 
