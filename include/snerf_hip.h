@@ -394,7 +394,8 @@ int snerf_classic_ray_batch(int H, int W, double focal, double cx, double cy, co
  * atomics on the hashed levels, and a gradient that is BIT-IDENTICAL run to run (integer addition is order-independent).
  * Three calls: pass 0 counts (counts [L,1024] int32, zeroed by the caller); the caller scans the counts into `starts` / `cursors`
  * ([L,1024] int64, exclusive prefix sums over the flattened bins); pass 1 writes the records (rec_row uint16 [capacity], rec_val fp32
- * [capacity, C]; capacity >= R*S*n*8*L is always enough); pass 2 accumulates into grad_table (fp32, +=).  ksplit_host: HOST int[L],
+ * [capacity, max(C, 2)] -- for C = 1 a record is one 8-byte {row, value} pair in rec_val and rec_row is not touched; capacity >=
+ * R*S*n*8*L is always enough); pass 2 accumulates into grad_table (fp32, +=).  ksplit_host: HOST int[L],
  * replicas per row range (> 1 for levels with few, hot rows: they meet in g64, an int64 image of table rows [0, g64_rows) zeroed by
  * the caller). */
 int snerf_zip_encode_bwd_binned(int pass, const float* tdist, const float* origins, const float* directions, const float* radii,

@@ -853,7 +853,7 @@ struct ZipBin {
   long* cursors;                           // [L, ZB_NBMAX] next free record of the bin (starts at the bin's offset)
   const long* starts;                      // [L, ZB_NBMAX] bin offsets (accumulate pass)
   int ksplit[16];                          // replicas per row range, per level
-  unsigned short* rec_row; float* rec_val; long capacity;
+  unsigned short* rec_row; float* rec_val; long capacity;   // records: C = 1: rec_val holds {row, value} pairs (8 B); else row + C floats
   long long* g64; long g64_rows;           // int64 image of table rows [0, g64_rows) for the replicated levels
 };
 
@@ -892,9 +892,19 @@ __device__ __forceinline__ void zip_emit_level(const ZipEnc& a, const ZipBin& b,
       if (WRITE) {
         const long r = lds_base[bin] + slot;
         if (r < b.capacity) {
-          b.rec_row[r] = (unsigned short)(row & ((1u << b.bshift) - 1u));
+          const unsigned lrow = row & ((1u << b.bshift) - 1u);
+          if constexpr (C == 1) {                      // one 8-byte record {row in bin, value}: one store instead of a 2- and a 4-byte one
+            const uint2 rv = {lrow, __float_as_uint(wsum[idx] * g[0])};
+            *(uint2*)(b.rec_val + r * 2) = rv;
+          } else if constexpr (C == 4) {               // the four channels as one 16-byte store
+            b.rec_row[r] = (unsigned short)lrow;
+            const f32x4 v4 = {wsum[idx] * g[0], wsum[idx] * g[1], wsum[idx] * g[2], wsum[idx] * g[3]};
+            *(f32x4*)(b.rec_val + r * 4) = v4;
+          } else {
+            b.rec_row[r] = (unsigned short)lrow;
 #pragma unroll
-          for (int c = 0; c < C; ++c) b.rec_val[r * C + c] = wsum[idx] * g[c];
+            for (int c = 0; c < C; ++c) b.rec_val[r * C + c] = wsum[idx] * g[c];
+          }
         }
       }
       wsum[idx] = 0.f;
@@ -967,13 +977,39 @@ __global__ __launch_bounds__(1024) void zip_bin_accumulate_kernel(ZipEnc a, ZipB
   for (int k = threadIdx.x; k < cells; k += 1024) zb_acc[k] = 0;
   __syncthreads();
   const long s0 = b.starts[level * ZB_NBMAX + bin];
-  for (int r = threadIdx.x; r < n; r += 1024) {          // 16 waves: the record stream needs the memory-level parallelism
-    const long q = s0 + r;
-    const int row = b.rec_row[q];
+  // 16 waves x 4 records per thread in flight: the record stream is latency-bound (one record per thread and trip took a bin of
+  // 2 M records 4 ms whatever the LDS did)
+  constexpr int U = 4;
+  for (int r0 = threadIdx.x; r0 < n; r0 += 1024 * U) {
+    int row[U];
+    float val[U][C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) {
-      const float v = fminf(fmaxf(b.rec_val[q * C + c], -1.0e8f), 1.0e8f);
-      atomicAdd((unsigned long long*)(zb_acc + row * C + c), (unsigned long long)__float2ll_rn(v * ZB_FIX));
+    for (int u = 0; u < U; ++u) {
+      const int r = r0 + u * 1024;
+      const long q = s0 + (r < n ? r : r0);
+      if constexpr (C == 1) {
+        const uint2 rv = *(const uint2*)(b.rec_val + q * 2);
+        row[u] = r < n ? (int)rv.x : -1;
+        val[u][0] = __uint_as_float(rv.y);
+        continue;
+      }
+      row[u] = r < n ? (int)b.rec_row[q] : -1;
+      if constexpr (C == 4) {
+        const f32x4 v4 = *(const f32x4*)(b.rec_val + q * 4);
+        val[u][0] = v4[0]; val[u][1] = v4[1]; val[u][2] = v4[2]; val[u][3] = v4[3];
+      } else {
+#pragma unroll
+        for (int c = 0; c < C; ++c) val[u][c] = b.rec_val[q * C + c];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (row[u] < 0) continue;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const float v = fminf(fmaxf(val[u][c], -1.0e8f), 1.0e8f);
+        atomicAdd((unsigned long long*)(zb_acc + row[u] * C + c), (unsigned long long)__float2ll_rn(v * ZB_FIX));
+      }
     }
   }
   __syncthreads();

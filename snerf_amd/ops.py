@@ -571,7 +571,7 @@ def zip_encode_bwd_binned(tdist, origins, directions, radii, base_x, base_y, deg
     cursors = starts.clone()
     capacity = R * S * n * 8 * L                               # every (interval, level) emits at most n cells x 8 corners: no host sync
     rec_row = torch.empty(capacity, dtype=torch.int16, device=dev)
-    rec_val = torch.empty(capacity, C, dtype=torch.float32, device=dev)
+    rec_val = torch.empty(capacity, max(C, 2), dtype=torch.float32, device=dev)       # C = 1: {row, value} pairs in one 8-byte record
     _lib.call("snerf_zip_encode_bwd_binned", 1, *args, _p(counts), _p(cursors), _p(starts), _p(rec_row), _p(rec_val), capacity, None, 0, _stream())
     g64 = torch.zeros(max(g64_rows, 1) * C, dtype=torch.int64, device=dev) if g64_rows > 0 else None
     _lib.call("snerf_zip_encode_bwd_binned", 2, *args, _p(counts), _p(cursors), _p(starts), _p(rec_row), _p(rec_val), capacity, _p(g64), int(g64_rows),

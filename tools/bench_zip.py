@@ -23,6 +23,7 @@ def main():
                          "atomic: the reference's scatter with global atomics")
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--semantic", action="store_true", help="19-class semantic head on (Config.use_semantic): rendered and trained")
+    ap.add_argument("--train-only", action="store_true", help="time the training loop and exit (profiling the train step)")
     ap.add_argument("--frame-only", action="store_true", help="skip the training / forward timing loops (profiling the frame)")
     ap.add_argument("--frame-chunk", type=int, default=65536, help="render_chunk_size of the measured 1920x1280 frame")
     ap.add_argument("--same-device", action="store_true", help="functional test of the N > 1 flow on a 1-GPU box")
@@ -93,6 +94,10 @@ def main():
         te = torch.tensor([dt_train], device=dev, dtype=torch.float64)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         dt_train = te.item()
+    if args.train_only:
+        if rank == 0:
+            print(json.dumps({"path": "C train step only", "rays_per_gpu": R, "train_ms": round(dt_train * 1e3, 3), "table_grad_mode": m.table_grad_mode}))
+        return
     fwd_only(); barrier(); t0 = time.perf_counter()
     for _ in range(args.steps):
         fwd_only()
