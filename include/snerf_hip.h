@@ -392,7 +392,8 @@ int snerf_classic_ray_batch(int H, int W, double focal, double cx, double cy, co
  * out as records partitioned by destination (level, range of 4096 (C = 4) / 16384 (C = 1) table rows, replica), then one workgroup per
  * bin accumulates its records in LDS with 64-bit fixed-point integer atomics (resolution 2^-36) and writes its rows back: no L2
  * atomics on the hashed levels, and a gradient that is BIT-IDENTICAL run to run (integer addition is order-independent).
- * Three calls: pass 0 counts (counts [L,1024] int32, zeroed by the caller); the caller scans the counts into `starts` / `cursors`
+ * Three calls: pass 0 counts (counts [L,1024] int32, zeroed by the caller) and reserves every workgroup's range inside the bins it
+ * touches (wg_offsets: uint32 [L, ceil(R*S/256), 1024], need not be initialised); the caller scans the counts into `starts`
  * ([L,1024] int64, exclusive prefix sums over the flattened bins); pass 1 writes the records (rec_row uint16 [capacity], rec_val fp32
  * [capacity, max(C, 2)] -- for C = 1 a record is one 8-byte {row, value} pair in rec_val and rec_row is not touched; capacity >=
  * R*S*n*8*L is always enough); pass 2 accumulates into grad_table (fp32, +=).  ksplit_host: HOST int[L],
@@ -401,7 +402,7 @@ int snerf_classic_ray_batch(int H, int W, double focal, double cx, double cy, co
 int snerf_zip_encode_bwd_binned(int pass, const float* tdist, const float* origins, const float* directions, const float* radii,
                                 const float* base_x, const float* base_y, const float* deg_jitter, const int* offsets,
                                 const int* grid_sizes, const void* grad_feat, long ld, float* grad_table, long R, int S, int L, int C, int n,
-                                int m, float Sl, int H, float std_scale, int feat_dtype, const int* ksplit_host, int* counts, long* cursors,
+                                int m, float Sl, int H, float std_scale, int feat_dtype, const int* ksplit_host, int* counts, void* wg_offsets,
                                 const long* starts, void* rec_row, float* rec_val, long capacity, void* g64, long g64_rows, void* stream);
 
 /* Featurisation backward to the RAYS -- `cal_input_grad` of the reference (internal/models.py:491 -> gridencoder/grid.py:65-89 ->

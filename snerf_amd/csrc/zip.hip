@@ -838,9 +838,10 @@ extern "C" int snerf_zip_encode_bwd(const float* tdist, const float* origins, co
 // table row is written back by exactly one workgroup, and integer addition is associative, so the gradient is BIT-IDENTICAL run to
 // run whatever order the records arrive in.  Levels whose rows are few but hot (the dense levels: 4913 rows take 118 M records)
 // are split into K replicas that meet in a small global int64 image (again order-independent).
-//   pass 0  zip_bin_emit_kernel<.., 0>  count the records per bin (per-workgroup LDS histogram, one global atomic per non-empty bin)
+//   pass 0  zip_bin_emit_kernel<.., 0>  count the records per bin (per-workgroup LDS histogram, one global atomic per non-empty bin,
+//           whose return value reserves the workgroup's range inside the bin)
 //           (host: exclusive scan of the counts -> bin offsets)
-//   pass 1  zip_bin_emit_kernel<.., 1>  reserve a range per (workgroup, bin), write the records
+//   pass 1  zip_bin_emit_kernel<.., 1>  write the records into the ranges pass 0 reserved per (workgroup, bin)
 //   pass 2  zip_bin_accumulate_kernel   one workgroup per bin: LDS fixed-point accumulation, write-back (+= into the fp32 gradient)
 //   pass 3  zip_bin_finish_kernel       fold the replicated levels' int64 image into the gradient
 // ------------------------------------------------------------------------------------------------------------------
@@ -850,7 +851,7 @@ extern "C" int snerf_zip_encode_bwd(const float* tdist, const float* origins, co
 struct ZipBin {
   int bshift;                              // log2(rows per bin)
   int* counts;                             // [L, ZB_NBMAX] records per bin
-  long* cursors;                           // [L, ZB_NBMAX] next free record of the bin (starts at the bin's offset)
+  unsigned* wg_offsets;                    // [L, workgroups, ZB_NBMAX] offset of a workgroup's record range inside a bin (pass 0 -> pass 1)
   const long* starts;                      // [L, ZB_NBMAX] bin offsets (accumulate pass)
   int ksplit[16];                          // replicas per row range, per level
   unsigned short* rec_row; float* rec_val; long capacity;   // records: C = 1: rec_val holds {row, value} pairs (8 B); else row + C floats
@@ -948,20 +949,26 @@ __global__ __launch_bounds__(256) void zip_bin_emit_kernel(ZipEnc a, ZipBin b) {
   const long p = (long)blockIdx.x * 256 + threadIdx.x;
   const bool live = p < a.R * a.S;
   for (int k = threadIdx.x; k < ZB_NBMAX; k += 256) cnt[k] = 0;
+  if (PASS == 1) {
+    // ranges reserved by pass 0 (entries of bins this workgroup does not touch are never read)
+    const unsigned* wgo1 = b.wg_offsets + ((long)level * gridDim.x + blockIdx.x) * ZB_NBMAX;
+    for (int k = threadIdx.x; k < ZB_NBMAX; k += 256) base[k] = b.starts[level * ZB_NBMAX + k] + (long)wgo1[k];
+    __syncthreads();
+    if (live) zip_emit_level<OT, C, true>(a, b, p, level, cnt, base);
+    return;
+  }
   __syncthreads();
   if (live) zip_emit_level<OT, C, false>(a, b, p, level, cnt, nullptr);
   __syncthreads();
+  // PASS 0 above (shared code): the workgroup's histogram.  It reserves the workgroup's range inside every bin it touches right away --
+  // the bin's running count IS the offset of the range relative to the bin's start (known only after the host's scan) -- and leaves
+  // it in wg_offsets[level, workgroup, bin]; pass 1 then needs no second count sweep.
+  unsigned* wgo = b.wg_offsets + ((long)level * gridDim.x + blockIdx.x) * ZB_NBMAX;
   if (PASS == 0) {
     for (int k = threadIdx.x; k < ZB_NBMAX; k += 256)
-      if (cnt[k] != 0) atomicAdd(b.counts + level * ZB_NBMAX + k, cnt[k]);
+      if (cnt[k] != 0) wgo[k] = (unsigned)atomicAdd(b.counts + level * ZB_NBMAX + k, cnt[k]);
     return;
   }
-  for (int k = threadIdx.x; k < ZB_NBMAX; k += 256) {
-    base[k] = cnt[k] != 0 ? (long)atomicAdd((unsigned long long*)(b.cursors + level * ZB_NBMAX + k), (unsigned long long)cnt[k]) : 0;
-    cnt[k] = 0;
-  }
-  __syncthreads();
-  if (live) zip_emit_level<OT, C, true>(a, b, p, level, cnt, base);
 }
 
 template <int C>
@@ -1036,25 +1043,26 @@ __global__ __launch_bounds__(256) void zip_bin_finish_kernel(const long long* __
   }
 }
 
-// pass: 0 = count, 1 = write records, 2 = accumulate (+ finish).  The host zeroes counts / g64, scans counts into starts / cursors.
+// pass: 0 = count (+ reserve), 1 = write records, 2 = accumulate (+ finish).  The host zeroes counts / g64 and scans counts into starts.
 extern "C" int snerf_zip_encode_bwd_binned(int pass, const float* tdist, const float* origins, const float* directions, const float* radii,
                                            const float* base_x, const float* base_y, const float* deg_jitter, const int* offsets,
                                            const int* grid_sizes, const void* grad_feat, long ld, float* grad_table, long R, int S, int L, int C,
                                            int n, int m, float Sl, int H, float std_scale, int feat_dtype, const int* ksplit_host, int* counts,
-                                           long* cursors, const long* starts, void* rec_row, float* rec_val, long capacity, void* g64,
+                                           void* wg_offsets, const long* starts, void* rec_row, float* rec_val, long capacity, void* g64,
                                            long g64_rows, void* stream) {
   if (R <= 0) return SNERF_OK;
   if (S <= 0 || L <= 0 || L > 16 || n <= 0 || (C != 1 && C != 4) || ksplit_host == nullptr || counts == nullptr) return SNERF_ERR_ARG;
   ZipEnc a{tdist, origins, directions, radii, base_x, base_y, deg_jitter, nullptr, offsets, grid_sizes, (void*)grad_feat, ld, grad_table, nullptr, R, S, L, n, m, Sl, H, std_scale};
   ZipBin b{};
   b.bshift = C == 4 ? 12 : 14;
-  b.counts = counts; b.cursors = cursors; b.starts = starts;
+  b.counts = counts; b.wg_offsets = (unsigned*)wg_offsets; b.starts = starts;
   for (int l = 0; l < L; ++l) { b.ksplit[l] = ksplit_host[l]; if (b.ksplit[l] < 1) return SNERF_ERR_ARG; }
   b.rec_row = (unsigned short*)rec_row; b.rec_val = rec_val; b.capacity = capacity; b.g64 = (long long*)g64; b.g64_rows = g64_rows;
   hipStream_t s = (hipStream_t)stream;
   const dim3 blk(256);
   if (pass == 0 || pass == 1) {
-    if (grad_feat == nullptr || (pass == 1 && (cursors == nullptr || rec_row == nullptr || rec_val == nullptr))) return SNERF_ERR_ARG;
+    if (grad_feat == nullptr || wg_offsets == nullptr || (pass == 1 && (starts == nullptr || rec_row == nullptr || rec_val == nullptr)))
+      return SNERF_ERR_ARG;
     const dim3 grid((unsigned)((R * S + 255) / 256), L);
 #define ZBE(OT, CC) do { if (pass == 0) hipLaunchKernelGGL((zip_bin_emit_kernel<OT, CC, 0>), grid, blk, 0, s, a, b); \
                          else hipLaunchKernelGGL((zip_bin_emit_kernel<OT, CC, 1>), grid, blk, 0, s, a, b); } while (0)

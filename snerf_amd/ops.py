@@ -565,16 +565,17 @@ def zip_encode_bwd_binned(tdist, origins, directions, radii, base_x, base_y, deg
     counts = torch.zeros(L, ZB_NBMAX, dtype=torch.int32, device=dev)
     args = (_p(tdist), _p(origins), _p(directions), _p(radii), _p(base_x), _p(base_y), _p(deg_jitter), _p(offsets), _p(grid_sizes), _p(grad_feat),
             grad_feat.stride(0), _p(grad_table), R, S, L, C, n, m, float(Sl), int(H), float(std_scale), _zip_dt(grad_feat), ks.ctypes.data)
-    _lib.call("snerf_zip_encode_bwd_binned", 0, *args, _p(counts), None, None, None, None, 0, None, 0, _stream())
+    # pass 0 also reserves each workgroup's record range inside the bins it touches (offsets relative to the bin's start)
+    wgo = torch.empty(L * ((R * S + 255) // 256) * ZB_NBMAX, dtype=torch.int32, device=dev)
+    _lib.call("snerf_zip_encode_bwd_binned", 0, *args, _p(counts), _p(wgo), None, None, None, 0, None, 0, _stream())
     flat = counts.view(-1).to(torch.int64)
     starts = (torch.cumsum(flat, 0) - flat).contiguous()
-    cursors = starts.clone()
     capacity = R * S * n * 8 * L                               # every (interval, level) emits at most n cells x 8 corners: no host sync
     rec_row = torch.empty(capacity, dtype=torch.int16, device=dev)
     rec_val = torch.empty(capacity, max(C, 2), dtype=torch.float32, device=dev)       # C = 1: {row, value} pairs in one 8-byte record
-    _lib.call("snerf_zip_encode_bwd_binned", 1, *args, _p(counts), _p(cursors), _p(starts), _p(rec_row), _p(rec_val), capacity, None, 0, _stream())
+    _lib.call("snerf_zip_encode_bwd_binned", 1, *args, _p(counts), _p(wgo), _p(starts), _p(rec_row), _p(rec_val), capacity, None, 0, _stream())
     g64 = torch.zeros(max(g64_rows, 1) * C, dtype=torch.int64, device=dev) if g64_rows > 0 else None
-    _lib.call("snerf_zip_encode_bwd_binned", 2, *args, _p(counts), _p(cursors), _p(starts), _p(rec_row), _p(rec_val), capacity, _p(g64), int(g64_rows),
+    _lib.call("snerf_zip_encode_bwd_binned", 2, *args, _p(counts), _p(wgo), _p(starts), _p(rec_row), _p(rec_val), capacity, _p(g64), int(g64_rows),
               _stream())
 
 
