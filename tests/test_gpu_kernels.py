@@ -571,3 +571,36 @@ def test_per_ray_kernels_random_sizes_sweep():
             cs, ci, _ = E.classic_sample_pdf(bins, wc, uu, False, want_inds=True)
             ks, ki, _ = O.classic_sample_pdf(cu(bins), cu(wc), cu(uu), False, want_inds=True)
             assert torch.equal(ki.cpu().long(), ci.long()) and torch.equal(ks.cpu(), cs), f"classic_sample_pdf #{it} n={n} S={S} P1={P1}"
+
+
+def test_gather_pack_refreshes_operands():
+    """snerf_gather_pack: dst[i] = flat[idx[i]] rounded to dst's type, idx -1 -> 0 (padding), -2 -> 1 (identity rows); sizes that are
+    not multiples of the 4-wide inner step; and the plan built by mlp._Net from its own packing code reproduces that code's result."""
+    from snerf_amd import ops
+    g = torch.Generator().manual_seed(5)
+    flat = torch.randn(10007, generator=g).cuda()
+    for n in (1, 3, 4, 1001, 4096 + 2):
+        idx = torch.randint(-2, flat.numel(), (n,), generator=g, dtype=torch.int32)
+        idx_d = torch.zeros(((n + 3) // 4) * 4, dtype=torch.int32, device="cuda")[:n]          # 16-byte aligned base
+        idx_d.copy_(idx)
+        want = torch.where(idx >= 0, flat.cpu()[idx.clamp(min=0).long()], (idx == -2).float())
+        for dt in (torch.float32, torch.bfloat16):
+            dst = torch.full((n,), 7.0, dtype=dt, device="cuda")
+            ops.gather_pack(flat, idx_d, dst)
+            assert torch.equal(dst.cpu(), want.to(dt)), (n, dt)
+    # end to end: a packed operand equals the slicing code applied to the parameters
+    from snerf_amd.mlp import ClassicNeRFNet, ParamArena
+    shapes = ClassicNeRFNet.param_shapes(8, 128, 63, 27, (4,))
+    arena = ParamArena(shapes, torch.device("cuda"))
+    arena.load({k: torch.randn(s, generator=g) for k, s in shapes})
+    net = ClassicNeRFNet(arena, "", ops.BF16, 8, 128)
+    net.ensure_packed(True)
+    W5 = arena.p["pts_linears.5.weight"]
+    fw = net.fw["pts_linears.5"]
+    assert torch.equal(fw[:128, :63], W5[:, :63].to(torch.bfloat16)) and torch.equal(fw[:128, net.Pw:net.Pw + 128], W5[:, 63:].to(torch.bfloat16))
+    assert float(fw[:, 63:net.Pw].abs().max()) == 0.0
+    tw = net.tw["pts_linears.5"]                          # data-gradient pack: W^T of the trunk columns
+    assert torch.equal(tw[:128, :128], W5[:, 63:].t().to(torch.bfloat16))
+    arena.p["pts_linears.5.weight"].mul_(2.0); arena.bump()
+    net.ensure_packed(True)
+    assert torch.equal(net.fw["pts_linears.5"][:128, :63], (W5[:, :63]).to(torch.bfloat16)) and net.fw["pts_linears.5"].data_ptr() == fw.data_ptr()
