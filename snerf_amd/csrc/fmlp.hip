@@ -149,16 +149,17 @@ __device__ __forceinline__ void to_frags(const f32x16& acc, bf16x8& lo, bf16x8& 
   if (RELU) {
     // ReLU on the rounded value (rounding is monotone and keeps the sign, so round-then-clamp == clamp-then-round): a bf16 is
     // negative iff its 16 bits are a negative int16, so a packed signed max with 0 clamps two values per instruction (-0 -> +0).
-    // Written as asm on the packed dwords: expressed as a vector max of the bit-cast, hipcc converts every value separately
-    // and re-packs them with v_perm_b32 (2.5x the instructions).
+    // The max must be an instruction the COMPILER emits: its result is an MFMA operand, and a VALU write needs wait states before an
+    // MFMA reads the register (tools/probes/mfma_war_probe.hip: zero gap = 100 % wrong results).  hipcc counts them for its own
+    // instructions but put a single `s_nop 0` behind an inline-asm v_pk_max_i16 -- in the one instantiation whose schedule placed an
+    // MFMA right there that was a rare, timing-dependent wrong fragment (round 2, tools/stress_fmlp_variants.py).  The EMPTY asm
+    // only hides the conversion's provenance: without it hipcc converts every value separately and re-packs them with v_perm_b32.
+    typedef short fm_s16x8 __attribute__((ext_vector_type(8)));
+    const fm_s16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
     fm_u32x4 ul = __builtin_bit_cast(fm_u32x4, lo), uh = __builtin_bit_cast(fm_u32x4, hi);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      asm("v_pk_max_i16 %0, %1, 0" : "=v"(ul[i]) : "v"(ul[i]));
-      asm("v_pk_max_i16 %0, %1, 0" : "=v"(uh[i]) : "v"(uh[i]));
-    }
-    lo = __builtin_bit_cast(bf16x8, ul);
-    hi = __builtin_bit_cast(bf16x8, uh);
+    asm("" : "+v"(ul), "+v"(uh));
+    lo = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(fm_s16x8, ul), zero));
+    hi = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(fm_s16x8, uh), zero));
   }
 }
 
@@ -354,6 +355,11 @@ __global__ __launch_bounds__(512) void fmlp_kernel(FmlpArgs a) {
   for (int i = tid; i < a.n_blocks * 32; i += 512) bias_tab[i] = a.bias[i];
 #pragma unroll
   for (int i = 0; i < FM_RING - 1; ++i) ws_issue(c.ws, smem);
+#ifdef FMLP_LOCKSTEP_START
+  // debug builds (tools/stress_fmlp_variants.py): every DMA of the prologue landed and all eight waves leave it in the same cycle --
+  // the start that exposed the timing-dependent operand hazard described at to_frags within a handful of launches
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
   // first boundary: chunk 0 has landed for everybody (and the bias stores are visible); start the fragment queue
   ws_advance(c.ws, smem);
 #pragma unroll

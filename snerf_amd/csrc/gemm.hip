@@ -28,6 +28,7 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 #define ACT_MASK_BITS 4  // as ACT_MASK with `aux` = the bit mask an ACT_RELU_BITS launch of the same [M, N] wrote
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 struct GemmNT {
   const void* A; long lda;
@@ -551,7 +552,7 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
   constexpr int SCRATCH = 8 * HALF;                    // 4 x 4 KiB transposition slabs
   constexpr int BIAS = SCRATCH + 4 * 4096;             // 2 x 1 KiB bias vectors (tile parity)
   constexpr int MASKB = BIAS + 2048;                   // 8 waves x 4 units x 64 lanes x 4 B: ReLU bit masks of the current tile
-  constexpr int BB = (ACT == ACT_MASK && COLSUM) ? 1 : 2;   // bias quads fetched per batch in the epilogue units (register budget)
+  constexpr int BB = ACT == ACT_MASK ? 1 : 2;            // bias quads fetched per batch in the epilogue units (register budget)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
@@ -688,24 +689,32 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
         a8[it] = *(const bf16x8*)(auxp + (long)m * p.ldaux + (col_ok ? ncol : 0));
       }
     }
-    const char* bl = smem + BIAS + par * 1024 + wc * 256 + hi * 16;
+    // The accumulators were INITIALISED with the tile's bias (prologue / the previous tile's units), so a value leaves as it is: two
+    // packed fp32 -> bf16 conversions per four values, ReLU as a packed signed 16-bit max on the rounded pair (a bf16 is negative iff
+    // its bits are a negative int16; -0 -> +0), and the registers are re-initialised with the bias of the NEXT tile of this workgroup
+    // (its buffer, the other parity, was staged at the start of the current tile; zeros without a bias; never used after the last tile).
+    // (the data-gradient flavours -- mask in -- never carry a bias, the launcher checks it: their accumulators restart from zero)
+    constexpr bool NOBIAS = ACT == ACT_MASK || ACT == ACT_MASK_BITS;
+    const char* bl = smem + BIAS + (par ^ 1) * 1024 + wc * 256 + hi * 16;
 #pragma unroll
     for (int cb = 0; cb < 8; cb += BB) {
       f32x4 b4[BB];
 #pragma unroll
-      for (int c = 0; c < BB; ++c) b4[c] = *(const f32x4*)(bl + (cb + c) * 32);   // columns 8c + 4 hi .. +3 (zeros without a bias)
+      for (int c = 0; c < BB; ++c) b4[c] = NOBIAS ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(bl + (cb + c) * 32);   // columns 8c + 4 hi .. +3 of the next tile's bias
 #pragma unroll
       for (int cc = 0; cc < BB; ++cc) {
         const int c = cb + cc, jj = c >> 2, q = c & 3;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[e] = acc[u][jj][4 * q + e] + b4[cc][e];
-          if (ACT == ACT_RELU || ACT == ACT_RELU_BITS) v[e] = v[e] > 0.f ? v[e] : 0.f;
-          acc[u][jj][4 * q + e] = 0.f;
+        const f32x4 v = {acc[u][jj][4 * q + 0], acc[u][jj][4 * q + 1], acc[u][jj][4 * q + 2], acc[u][jj][4 * q + 3]};
+        u32x2 o = __builtin_bit_cast(u32x2, __builtin_convertvector(v, bf16x4));
+        if (ACT == ACT_RELU || ACT == ACT_RELU_BITS) {
+          // (the empty asm keeps the packed conversion; the max itself stays a compiler-visible instruction: see fmlp.hip to_frags)
+          typedef short s16x4 __attribute__((ext_vector_type(4)));
+          asm("" : "+v"(o));
+          o = __builtin_bit_cast(u32x2, __builtin_elementwise_max(__builtin_bit_cast(s16x4, o), s16x4{0, 0, 0, 0}));
         }
-        const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-        *(bf16x4*)(slab + row1 * 128 + ((c ^ (row1 & 7)) << 4) + 8 * hi) = o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[u][jj][4 * q + e] = b4[cc][e];
+        *(u32x2*)(slab + row1 * 128 + ((c ^ (row1 & 7)) << 4) + 8 * hi) = o;
       }
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);                 // lgkmcnt(0)
@@ -808,6 +817,17 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
     aF[0][ks] = lds_a(0, 0, 0, ks);
     aF[1][ks] = lds_a(0, 0, 1, ks);
     bS[0][ks] = lds_b(0, 0, ks);
+  }
+  {                                                      // accumulators start from the bias of tile 0 (see the epilogue units)
+    const char* bl0 = smem + BIAS + wc * 256 + (lane >> 5) * 16;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const f32x4 b = *(const f32x4*)(bl0 + c * 32);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][c >> 2][4 * (c & 3) + e] = b[e];
+    }
   }
   __builtin_amdgcn_s_waitcnt(0xC07F);
   __builtin_amdgcn_sched_barrier(0);
@@ -1028,6 +1048,7 @@ extern "C" int snerf_linear_fwd(const void* A, long lda, const void* W, long ldw
   const int bke = dtype == SNERF_DT_F32 ? 32 : 64;
   if (K % bke != 0 || lda % (bke / 8) != 0 || ldw % (bke / 8) != 0) return SNERF_ERR_ARG;
   if ((act == ACT_MASK || act == ACT_RELU_BITS || act == ACT_MASK_BITS) && aux == nullptr) return SNERF_ERR_ARG;
+  if ((act == ACT_MASK || act == ACT_MASK_BITS) && bias != nullptr) return SNERF_ERR_ARG;   // the masked flavours are data gradients: no bias
   if (act < ACT_NONE || act > ACT_MASK_BITS) return SNERF_ERR_ARG;
   // vector epilogue stores need 4-element alignment of the destination (and of the mask source)
   const long esz = (out_f32 || dtype == SNERF_DT_F32) ? 4 : 2;

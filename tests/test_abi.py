@@ -45,3 +45,23 @@ def test_bad_arguments_are_rejected_without_a_gpu():
         _lib.call("snerf_linear_fwd", None, 0, None, 0, None, None, 0, None, 0, None, None, 16, 100, 64, 1, 0, 1, 0, 0, None)  # N % 128 != 0
     with pytest.raises(_lib.SnerfHipError, match="bad argument"):
         _lib.call("snerf_mip_resample", None, None, None, 0, 4, 1, 8, 0.01, None, None, None)  # S < 2
+
+
+def test_no_vector_alu_instruction_hides_in_inline_asm():
+    """A VALU result needs wait states before an MFMA reads it; hipcc counts them for the instructions it emits itself but not for the
+    text of an inline asm (round 2: an inline `v_pk_max_i16` in front of an MFMA gave rare, timing-dependent wrong results in one
+    instantiation of the fused MLP kernel; tools/probes/mfma_war_probe.hip shows the hazard in isolation).  Inline asm in the kernels is
+    therefore limited to waits, barriers, scalar / debug register reads, the transposing LDS read (waited for by hand) and empty
+    optimisation fences."""
+    import glob
+    import re
+    allowed = ("s_waitcnt", "s_barrier", "s_lshr_b32", "s_getreg_b32", "ds_read_b64_tr_b16", "s_nop", "s_sleep", ";")
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "snerf_amd", "csrc")
+    for path in sorted(glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.h"))):
+        src = open(path).read()
+        for m in re.finditer(r'\basm\s*(?:volatile)?\s*\(\s*((?:"[^"]*"\s*)+)', src):
+            text = "".join(re.findall(r'"([^"]*)"', m.group(1)))
+            for ins in re.split(r"\\n\\t|\\n|\\t", text):
+                ins = ins.strip()
+                if ins:
+                    assert ins.startswith(allowed), f"{os.path.basename(path)}: inline asm instruction {ins!r}"

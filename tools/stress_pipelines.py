@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Determinism screen of the real call sequences around the fused MLP kernels (producer kernel -> fused kernel), with a vendor GEMM
+interleaved: repeated evaluation on identical inputs must be bit-identical."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from snerf_amd import classic, mipnerf, ops
+from oracle import common
+
+ITERS = int(os.environ.get("ITERS", "2000"))
+torch.manual_seed(0)
+big = torch.randn(4096, 4096, device="cuda").bfloat16()
+total = 0
+
+def screen(name, fn):
+    global total
+    ref, bad = None, 0
+    for it in range(ITERS):
+        out = [t.clone() for t in fn()]
+        if it % 3 == 0:
+            torch.mm(big, big)
+        if ref is None:
+            ref = out
+        elif not all(torch.equal(a, b) for a, b in zip(out, ref)):
+            bad += 1
+    print(f"{name:58s} {bad} of {ITERS - 1} repeats differ", flush=True)
+    total += bad
+
+net = classic.NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=4, skips=[4], use_viewdirs=True, compute="bf16", device="cuda")
+M, S = 4096, 8
+pts = torch.rand(M, 3, device="cuda") * 4 - 2
+vd = torch.nn.functional.normalize(torch.randn(M // S, 3, device="cuda"), dim=-1)
+n = net.net
+def classic_train_fwd():
+    raw, saved = n.forward(pts, vd, S, True)                       # classic_embed -> fmlp_classic_train_fwd
+    return [raw] + [y for _, _, y in saved[0]] + [saved[1], saved[2]]
+def classic_infer_embed_kernel():
+    n.fused_embed = False
+    r = n.forward(pts, vd, S, False)[0]
+    n.fused_embed = True
+    return [r]
+def classic_infer_pts():
+    return [n.forward(pts, vd, S, False)[0]]
+with torch.no_grad():
+    screen("classic inference, in-kernel embedding (default)", classic_infer_pts)
+    screen("classic inference, embedding kernel -> fused kernel", classic_infer_embed_kernel)
+    screen("classic training forward (embed -> fused + stores)", classic_train_fwd)
+
+m = mipnerf.MipNerfModel(n_samples=64, N_fine=129, no_warp_sample=0, ray_shape="cone", fn=1, radius=3., transform_idx=0, real=True, rgb_layer=3,
+                         hidden_layer=256, density_noise=0., max_deg_point=16, proposal_loss=True, compute="bf16")
+rays = mipnerf.Rays(**{k: v.cuda() for k, v in common.synthetic_rays(1024, seed=3).items()})
+def mip_infer():
+    with torch.no_grad():
+        ret = m(rays, False, False, 0.)
+    return [ret[1][0], ret[1][1], ret[0][1]]
+screen("path A inference (mip_encode -> fused proposal MLP -> ...)", mip_infer)
+m.set_deterministic(True)
+tgt = torch.rand(1024, 3, device="cuda")
+def mip_train():
+    for p in m.parameters():
+        p.grad = None
+    ret = m(rays, False, False, 0.)
+    (((ret[1][0] - tgt) ** 2).mean() + 0.05 * (1 / ret[0][1]).mean()).backward()
+    return [ret[1][0].detach(), torch.cat([p.grad.reshape(-1) for p in m.parameters()])]
+ITERS = max(ITERS // 4, 100)
+screen("path A train forward + backward (deterministic mode)", mip_train)
+sys.exit(0 if total == 0 else 1)
