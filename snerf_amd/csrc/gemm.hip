@@ -552,7 +552,6 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
   constexpr int SCRATCH = 8 * HALF;                    // 4 x 4 KiB transposition slabs
   constexpr int BIAS = SCRATCH + 4 * 4096;             // 2 x 1 KiB bias vectors (tile parity)
   constexpr int MASKB = BIAS + 2048;                   // 8 waves x 4 units x 64 lanes x 4 B: ReLU bit masks of the current tile
-  constexpr int BB = ACT == ACT_MASK ? 1 : 2;            // bias quads fetched per batch in the epilogue units (register budget)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
@@ -693,31 +692,33 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
     // packed fp32 -> bf16 conversions per four values, ReLU as a packed signed 16-bit max on the rounded pair (a bf16 is negative iff
     // its bits are a negative int16; -0 -> +0), and the registers are re-initialised with the bias of the NEXT tile of this workgroup
     // (its buffer, the other parity, was staged at the start of the current tile; zeros without a bias; never used after the last tile).
-    // (the data-gradient flavours -- mask in -- never carry a bias, the launcher checks it: their accumulators restart from zero)
-    constexpr bool NOBIAS = ACT == ACT_MASK || ACT == ACT_MASK_BITS;
+    // Pass 1 reads the accumulators (pairs straight into v_cvt_pk_bf16_f32, no staging copies), pass 2 loads the next bias from LDS
+    // INTO the accumulator registers (a ds_read_b128 per quad: no vector-ALU moves; without a bias the buffer holds zeros).
     const char* bl = smem + BIAS + (par ^ 1) * 1024 + wc * 256 + hi * 16;
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 #pragma unroll
-    for (int cb = 0; cb < 8; cb += BB) {
-      f32x4 b4[BB];
-#pragma unroll
-      for (int c = 0; c < BB; ++c) b4[c] = NOBIAS ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(bl + (cb + c) * 32);   // columns 8c + 4 hi .. +3 of the next tile's bias
-#pragma unroll
-      for (int cc = 0; cc < BB; ++cc) {
-        const int c = cb + cc, jj = c >> 2, q = c & 3;
-        const f32x4 v = {acc[u][jj][4 * q + 0], acc[u][jj][4 * q + 1], acc[u][jj][4 * q + 2], acc[u][jj][4 * q + 3]};
-        u32x2 o = __builtin_bit_cast(u32x2, __builtin_convertvector(v, bf16x4));
-        if (ACT == ACT_RELU || ACT == ACT_RELU_BITS) {
-          // (the empty asm keeps the packed conversion; the max itself stays a compiler-visible instruction: see fmlp.hip to_frags)
-          typedef short s16x4 __attribute__((ext_vector_type(4)));
-          asm("" : "+v"(o));
-          o = __builtin_bit_cast(u32x2, __builtin_elementwise_max(__builtin_bit_cast(s16x4, o), s16x4{0, 0, 0, 0}));
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[u][jj][4 * q + e] = b4[cc][e];
-        *(u32x2*)(slab + row1 * 128 + ((c ^ (row1 & 7)) << 4) + 8 * hi) = o;
+    for (int c = 0; c < 8; ++c) {
+      const int jj = c >> 2, q = c & 3;
+      const f32x2 v01 = {acc[u][jj][4 * q + 0], acc[u][jj][4 * q + 1]}, v23 = {acc[u][jj][4 * q + 2], acc[u][jj][4 * q + 3]};
+      u32x2 o = {__builtin_bit_cast(unsigned, __builtin_convertvector(v01, bf16x2)), __builtin_bit_cast(unsigned, __builtin_convertvector(v23, bf16x2))};
+      if (ACT == ACT_RELU || ACT == ACT_RELU_BITS) {
+        // (the empty asm keeps the packed conversion; the max itself stays a compiler-visible instruction: see fmlp.hip to_frags)
+        typedef short s16x4 __attribute__((ext_vector_type(4)));
+        asm("" : "+v"(o));
+        o = __builtin_bit_cast(u32x2, __builtin_elementwise_max(__builtin_bit_cast(s16x4, o), s16x4{0, 0, 0, 0}));
       }
+      *(u32x2*)(slab + row1 * 128 + ((c ^ (row1 & 7)) << 4) + 8 * hi) = o;
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const f32x4 b = *(const f32x4*)(bl + c * 32);           // columns 8c + 4 hi .. +3 of the next tile's bias
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[u][c >> 2][4 * (c & 3) + e] = b[e];
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);                 // lgkmcnt(0)
+    T* const yrow = (T*)p.Y + (long)mbase * p.ldy + ncol;      // one 64-bit address; the four row groups are 8 ldy apart
+    const long ystep = 8 * p.ldy;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int row = it * 8 + prow;
@@ -741,12 +742,16 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
         val = __builtin_bit_cast(bf16x8, raw);
       }
       if (col_ok && m < p.M) {
-        *(bf16x8*)((T*)p.Y + (long)m * p.ldy + ncol) = val;
+        *(bf16x8*)(yrow + it * ystep) = val;
         if (ACT == ACT_RELU_BITS) {
           // the value is a ReLU output (max(v, +0) rounded to bf16: never negative, never -0): > 0  <=>  its 16 bits are not all zero
           // min(half, 1) per 16-bit half = "is positive"; z gathers the even elements in bits 0, 2, 4, 6 and the odd ones 16 higher
           const u32x4 raw = __builtin_bit_cast(u32x4, val);
-          const u16x2 one = {1, 1};
+          // (the constant goes through an empty asm: knowing that it is 1, hipcc rewrites min(x, 1) as x != 0 and emits 16-bit
+          // compares, selects and byte permutes -- 112 instead of 48 vector-ALU instructions per unit)
+          unsigned one_bits = 0x00010001u;
+          asm("" : "+v"(one_bits));
+          const u16x2 one = __builtin_bit_cast(u16x2, one_bits);
           unsigned z = 0;
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
