@@ -208,9 +208,11 @@ int snerf_gather_pack(const float* flat, const int* idx, long n, void* dst, int 
  * internal/render.py:237-241: semantic [R,C] = sum_i detach(weights [R,S]) softmax(logits [R*S, ld][:, :C]) (logits = columns
  * 1..C of the density network's output x); backward: d_logits only (g_w_out, if given, is zeroed).  softmax = 0: live mip path
  * (s-nerf/model/mip.py:175-176): semantic = sum_i weights raw_semantic; backward: d_logits [R*S, ld_d][:, :C] = w g and
- * g_w_out [R,S] = sum_c g_c raw (the weights are part of the graph there).  logits fp32 or bf16; gradients fp32. */
+ * g_w_out [R,S] = sum_c g_c raw (the weights are part of the graph there).  logits fp32 or bf16; gradients fp32.  row_index
+ * (forward, may be NULL): int32 [R,S] from snerf_ert_compact -- the logits of sample (r, i) are row row_index[r, i] of `logits`, -1 =
+ * sample not evaluated (contributes nothing): semantic rendering on compacted rows (inference extension, not in the reference). */
 int snerf_semantic_composite_fwd(const float* weights, const void* logits, long ld, int dtype, long R, int S, int C, int softmax,
-                                 float* sem, void* stream);
+                                 const int* row_index, float* sem, void* stream);
 int snerf_semantic_composite_bwd(const float* weights, const void* logits, long ld, int dtype, const float* g_sem, long R, int S, int C,
                                  int softmax, float* d_logits, long ld_d, float* g_w_out, void* stream);
 

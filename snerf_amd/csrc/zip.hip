@@ -1430,7 +1430,7 @@ template <typename T, bool BWD>
 __global__ __launch_bounds__(256) void semantic_composite_kernel(const float* __restrict__ weights, const T* __restrict__ logits, long ld, long R,
                                                                  int S, int C, int softmax, float* __restrict__ sem,
                                                                  const float* __restrict__ g_sem, float* __restrict__ d_logits, long ld_d,
-                                                                 float* __restrict__ g_w_out) {
+                                                                 float* __restrict__ g_w_out, const int* __restrict__ row_index) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const long ray = (long)blockIdx.x * 4 + wave;
   if (ray >= R) return;
@@ -1442,7 +1442,10 @@ __global__ __launch_bounds__(256) void semantic_composite_kernel(const float* __
     if (i >= S) continue;
     const long p = ray * S + i;
     const float w = weights[p];
-    const T* lg = logits + p * ld;
+    // sample compaction (inference, csrc/ert.hip): the logits of sample p live in row row_index[p]; skipped samples (-1) carry no weight
+    const long lrow = (!BWD && row_index != nullptr) ? (long)row_index[p] : p;
+    if (lrow < 0) continue;
+    const T* lg = logits + lrow * ld;
     float v[ZSEM_MAXC];
     if (softmax) {
       float mx = -INFINITY;
@@ -1481,12 +1484,12 @@ __global__ __launch_bounds__(256) void semantic_composite_kernel(const float* __
 }
 
 extern "C" int snerf_semantic_composite_fwd(const float* weights, const void* logits, long ld, int dtype, long R, int S, int C, int softmax,
-                                            float* sem, void* stream) {
+                                            const int* row_index, float* sem, void* stream) {
   if (R <= 0) return SNERF_OK;
   if (S <= 0 || C <= 0 || C > ZSEM_MAXC || weights == nullptr || logits == nullptr || sem == nullptr) return SNERF_ERR_ARG;
   const dim3 grid((unsigned)((R + 3) / 4));
-  if (dtype == SNERF_DT_F32) hipLaunchKernelGGL((semantic_composite_kernel<float, false>), grid, dim3(256), 0, (hipStream_t)stream, weights, (const float*)logits, ld, R, S, C, softmax, sem, nullptr, nullptr, 0, nullptr);
-  else if (dtype == SNERF_DT_BF16) hipLaunchKernelGGL((semantic_composite_kernel<__bf16, false>), grid, dim3(256), 0, (hipStream_t)stream, weights, (const __bf16*)logits, ld, R, S, C, softmax, sem, nullptr, nullptr, 0, nullptr);
+  if (dtype == SNERF_DT_F32) hipLaunchKernelGGL((semantic_composite_kernel<float, false>), grid, dim3(256), 0, (hipStream_t)stream, weights, (const float*)logits, ld, R, S, C, softmax, sem, nullptr, nullptr, 0, nullptr, row_index);
+  else if (dtype == SNERF_DT_BF16) hipLaunchKernelGGL((semantic_composite_kernel<__bf16, false>), grid, dim3(256), 0, (hipStream_t)stream, weights, (const __bf16*)logits, ld, R, S, C, softmax, sem, nullptr, nullptr, 0, nullptr, row_index);
   else return SNERF_ERR_ARG;
   return snerf_check_launch();
 }
@@ -1496,8 +1499,8 @@ extern "C" int snerf_semantic_composite_bwd(const float* weights, const void* lo
   if (R <= 0) return SNERF_OK;
   if (S <= 0 || C <= 0 || C > ZSEM_MAXC || weights == nullptr || logits == nullptr || g_sem == nullptr || d_logits == nullptr || ld_d < C) return SNERF_ERR_ARG;
   const dim3 grid((unsigned)((R + 3) / 4));
-  if (dtype == SNERF_DT_F32) hipLaunchKernelGGL((semantic_composite_kernel<float, true>), grid, dim3(256), 0, (hipStream_t)stream, weights, (const float*)logits, ld, R, S, C, softmax, nullptr, g_sem, d_logits, ld_d, g_w_out);
-  else if (dtype == SNERF_DT_BF16) hipLaunchKernelGGL((semantic_composite_kernel<__bf16, true>), grid, dim3(256), 0, (hipStream_t)stream, weights, (const __bf16*)logits, ld, R, S, C, softmax, nullptr, g_sem, d_logits, ld_d, g_w_out);
+  if (dtype == SNERF_DT_F32) hipLaunchKernelGGL((semantic_composite_kernel<float, true>), grid, dim3(256), 0, (hipStream_t)stream, weights, (const float*)logits, ld, R, S, C, softmax, nullptr, g_sem, d_logits, ld_d, g_w_out, nullptr);
+  else if (dtype == SNERF_DT_BF16) hipLaunchKernelGGL((semantic_composite_kernel<__bf16, true>), grid, dim3(256), 0, (hipStream_t)stream, weights, (const __bf16*)logits, ld, R, S, C, softmax, nullptr, g_sem, d_logits, ld_d, g_w_out, nullptr);
   else return SNERF_ERR_ARG;
   return snerf_check_launch();
 }

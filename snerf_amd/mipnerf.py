@@ -130,10 +130,8 @@ class MipNerfModel(_ArenaModule):
                                                       self.rgb_padding, self.density_bias, row_index=row_index)
         sem1 = raw_sem = None
         if self.semantic:
-            if row_index is not None:
-                raise NotImplementedError("semantic rendering on compacted rows (ert) is not implemented")
-            raw_sem = self.nerf.raw_sem                                  # [n * S1, C] fp32: semantic = sum_i w_i raw_semantic_i (mip.py:175-176)
-            sem1 = ops.semantic_composite_fwd(w1, raw_sem, self.sem_classes, False)
+            raw_sem = self.nerf.raw_sem                                  # [rows, C] fp32: semantic = sum_i w_i raw_semantic_i (mip.py:175-176)
+            sem1 = ops.semantic_composite_fwd(w1, raw_sem, self.sem_classes, False, row_index=row_index)   # compacted rows under ert
         ctx = None
         if keep:
             # detached aliases of the output tensors: the originals become outputs of the autograd Function

@@ -808,12 +808,16 @@ def hash_decay(table, grad, offsets, L, C, mult, loss=None):
     _lib.call("snerf_hash_decay", _p(table), _p(grad), _p(offsets), int(L), int(C), float(mult), _p(loss), _stream())
 
 
-def semantic_composite_fwd(weights, logits, C, softmax):
-    """semantic [R,C] = sum_i w[r,i] f(logits[r*S+i, :C]), f = softmax (zipnerf) or identity (live mip path); logits: 2-D view."""
+def semantic_composite_fwd(weights, logits, C, softmax, row_index=None):
+    """semantic [R,C] = sum_i w[r,i] f(logits[r*S+i, :C]), f = softmax (zipnerf) or identity (live mip path); logits: 2-D view.
+    `row_index` (int32 [R,S], -1 = skipped): the logits are the rows of a compacted evaluation (ert_compact)."""
     R, S = weights.shape
     _f32c(weights); _chk2d(logits)
+    if row_index is not None:
+        assert row_index.dtype == torch.int32 and row_index.is_contiguous() and row_index.numel() == R * S
     sem = torch.empty(R, C, dtype=torch.float32, device=weights.device)
-    _lib.call("snerf_semantic_composite_fwd", _p(weights), _p(logits), logits.stride(0), _zip_dt(logits), R, S, C, int(bool(softmax)), _p(sem), _stream())
+    _lib.call("snerf_semantic_composite_fwd", _p(weights), _p(logits), logits.stride(0), _zip_dt(logits), R, S, C, int(bool(softmax)),
+              _p(row_index), _p(sem), _stream())
     return sem
 
 

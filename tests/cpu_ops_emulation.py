@@ -352,7 +352,11 @@ def mip_loss_tail(rgb, tgt, dist1, dist0, tdepth, conf, s_f, w_f, s_c, w_c, disp
     return out.to(dev), g_rgb, gd1, gd0, gw
 
 
-def semantic_composite_fwd(weights, logits, C, softmax):
+def semantic_composite_fwd(weights, logits, C, softmax, row_index=None):
+    if row_index is not None:
+        ri = row_index.reshape(-1).long()
+        logits = torch.where((ri >= 0)[:, None], logits[ri.clamp(min=0), :C].float(), torch.zeros(1, C))
+        weights = weights * (ri >= 0).reshape(weights.shape)
     v = logits[:, :C].float().reshape(weights.shape[0], weights.shape[1], C)
     if softmax:
         v = torch.softmax(v, -1)
