@@ -21,7 +21,8 @@ def screen(name, fn):
             torch.mm(big, big)
         if ref is None:
             ref = out
-        elif not all(torch.equal(a, b) for a, b in zip(out, ref)):
+        elif not all(torch.equal(a.view(torch.int32) if a.dtype == torch.float32 else a, b.view(torch.int32) if b.dtype == torch.float32 else b)
+                     for a, b in zip(out, ref)):                       # bit patterns: NaNs (disp_map of an empty ray, as in the reference) compare equal
             bad += 1
     print(f"{name:58s} {bad} of {ITERS - 1} repeats differ", flush=True)
     total += bad
@@ -62,6 +63,47 @@ def mip_train():
     ret = m(rays, False, False, 0.)
     (((ret[1][0] - tgt) ** 2).mean() + 0.05 * (1 / ret[0][1]).mean()).backward()
     return [ret[1][0].detach(), torch.cat([p.grad.reshape(-1) for p in m.parameters()])]
+ITERS_SAVE = ITERS
 ITERS = max(ITERS // 4, 100)
 screen("path A train forward + backward (deterministic mode)", mip_train)
+
+# path B: the whole classic render_rays (stratified -> NeRF -> composite -> sample_pdf -> sort -> NeRF -> composite), inference
+ITERS = max(ITERS_SAVE // 4, 100)
+coarse = classic.NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=4, skips=[4], use_viewdirs=True, compute="bf16", device="cuda")
+fine = classic.NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=4, skips=[4], use_viewdirs=True, compute="bf16", device="cuda")
+e_fn, _ = classic.get_embedder(10, 0); ev_fn, _ = classic.get_embedder(4, 0)
+q = classic.make_network_query_fn(e_fn, ev_fn, netchunk=1 << 30)
+N = 2048
+g = torch.Generator().manual_seed(1)
+dd = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1)
+oo = torch.randn(N, 3, generator=g) * 0.1 + torch.tensor([0.0, 0.0, 4.0])
+rays_b = torch.cat([oo, -dd, torch.full((N, 1), 2.0), torch.full((N, 1), 6.0), -dd], -1).cuda()
+def classic_render():
+    with torch.no_grad():
+        r = classic.render_rays(rays_b, coarse, q, 64, perturb=0.0, N_importance=128, network_fine=fine, white_bkgd=False, raw_noise_std=0.0)
+    return [r["rgb_map"], r["disp_map"], r["acc_map"], r["rgb0"]]
+screen("path B inference (render_rays, 64 + 192 evaluations)", classic_render)
+
+# path C: zipnerf Model forward (three levels, hash-grid featurisation) and the binned table gradient
+from snerf_amd import zipnerf
+zm = zipnerf.Model(config=None, raydist_fn="power_transformation", opaque_background=True)
+R = 2048
+zb = ops.zip_pixels_to_rays(torch.arange(R, device="cuda").int() % 64, torch.arange(R, device="cuda").int() // 64, None,
+                            torch.linalg.inv(torch.tensor([[60.0, 0, 32], [0, 60.0, 16], [0, 0, 1]]))[None].cuda(), torch.eye(4)[None, :3].cuda())
+zb.update(near=torch.full((R, 1), 0.1, device="cuda"), far=torch.full((R, 1), 10.0, device="cuda"))
+def zip_infer():
+    with torch.no_grad():
+        ren, _ = zm(None, zb, train_frac=1.0, compute_extras=False)
+    return [ren[-1]["rgb"], ren[-1]["depth"], ren[0]["depth"]]
+screen("path C inference (Model.forward, 64 + 64 + 32 intervals)", zip_infer)
+tgt_c = torch.rand(R, 3, device="cuda")
+zm.set_deterministic(True) if hasattr(zm, "set_deterministic") else None
+def zip_train():
+    for p_ in zm.parameters():
+        p_.grad = None
+    ren, _ = zm(None, zb, train_frac=0.5, compute_extras=False)
+    ((ren[-1]["rgb"] - tgt_c) ** 2).mean().backward()
+    return [ren[-1]["rgb"].detach(), zm.encoder.embeddings.grad if hasattr(zm, "encoder") else ren[-1]["rgb"].detach()]
+ITERS = max(ITERS_SAVE // 10, 50)
+screen("path C train forward + backward (binned table gradient; MLP grads via atomics unless deterministic)", zip_train)
 sys.exit(0 if total == 0 else 1)
