@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Per-launch durations of every GEMM of one path-A train step (HIP events around snerf_linear_fwd / snerf_linear_wgrad), by shape."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from snerf_amd import ops
+from snerf_amd.trainer import MipTrainer
+
+dev = torch.device("cuda")
+model = bench.build_model("bf16", dev)
+rays = bench.synth_rays(4096, 0, dev)
+tgt = torch.rand(4096, 3, device=dev); depth = torch.rand(4096, device=dev) * 20 + 2; conf = torch.ones(4096, device=dev)
+tr = MipTrainer(model, lr=5e-4, proposal_loss=True)
+for _ in range(3):
+    tr.step(rays, tgt, depth, conf)
+rec = []
+of, ow = ops.linear_fwd, ops.linear_wgrad
+def tf(A, W, bias, Y, K, n_store, act, dt, **kw):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); of(A, W, bias, Y, K, n_store, act, dt, **kw); e1.record()
+    rec.append(("NT act=%d%s" % (act, " +colsum" if kw.get("colsum") is not None else ""), A.shape[0], W.shape[0], K, e0, e1))
+def tw(dZ, X, dW, n_valid, k_valid, dt, **kw):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); ow(dZ, X, dW, n_valid, k_valid, dt, **kw); e1.record()
+    rec.append(("TN", dZ.shape[0], n_valid, k_valid, e0, e1))
+ops.linear_fwd, ops.linear_wgrad = tf, tw
+tr.step(rays, tgt, depth, conf)
+torch.cuda.synchronize()
+ops.linear_fwd, ops.linear_wgrad = of, ow
+rows = [(k, M, N, K, e0.elapsed_time(e1)) for k, M, N, K, e0, e1 in rec]
+tot = sum(r[4] for r in rows)
+print(f"{len(rows)} GEMM launches, {tot:.2f} ms")
+for k, M, N, K, ms in sorted(rows, key=lambda r: -r[4]):
+    print(f"{k:18s} M={M:7d} N={N:5d} K={K:5d}  {ms * 1e3:8.1f} us  {2.0 * M * N * K / ms / 1e9:7.1f} TFLOP/s")
