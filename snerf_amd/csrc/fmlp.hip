@@ -195,10 +195,20 @@ __device__ __forceinline__ void store_block(const StoreTo& st, const bf16x8& lo,
     const int prow = st.lane >> 3, pch = st.lane & 7;
     __bf16* dst = st.y + (st.row0 + prow) * st.ld + 64 * (J >> 1) + 8 * pch;
     unsigned mw = 0;
+    // the four read-backs queue right behind the writes (the LDS executes one wave's instructions in order: no wait in between) and
+    // are pinned ahead of the row-bound branches, so that their latencies overlap instead of being paid one by one inside the branches
+    fm_u32x4 vs[4];
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int row = 8 * it + prow;
-      const fm_u32x4 v = *(const fm_u32x4*)(st.slab + row * 128 + ((pch ^ (row & 7)) << 4));
+      vs[it] = *(const fm_u32x4*)(st.slab + row * 128 + ((pch ^ (row & 7)) << 4));
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) asm volatile("" : "+v"(vs[it]));
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = 8 * it + prow;
+      const fm_u32x4 v = vs[it];
       if (st.row0 + row < st.M) {
         *(fm_u32x4*)(dst + (long)(8 * it) * st.ld) = v;
         if constexpr (BITS) {

@@ -716,14 +716,30 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[u][c >> 2][4 * (c & 3) + e] = b[e];
     }
-    __builtin_amdgcn_s_waitcnt(0xC07F);                 // lgkmcnt(0)
+    // No wait between the slab writes and the read-back: the LDS executes one wave's instructions in order, so the four reads below
+    // queue right behind the writes (and behind the bias reads) and their latencies overlap -- one exposed LDS round trip per unit
+    // instead of five (the unit's length is what the other wave row's 8-MFMA section has to cover).  The empty asm pins the four
+    // reads here: left alone, hipcc sinks each one into the store's branch, where it is waited for on its own.
     T* const yrow = (T*)p.Y + (long)mbase * p.ldy + ncol;      // one 64-bit address; the four row groups are 8 ldy apart
     const long ystep = 8 * p.ldy;
+    constexpr bool AHEAD = ACT != ACT_MASK;             // (the bf16-mask flavour has no registers to spare for this)
+    u32x4 vals[AHEAD ? 4 : 1];
+    if constexpr (AHEAD) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + prow;
+        vals[it] = *(const u32x4*)(slab + row * 128 + ((pch ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) asm volatile("" : "+v"(vals[it]));
+    }
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int row = it * 8 + prow;
       const int m = mbase + it * 8;
-      bf16x8 val = *(const bf16x8*)(slab + row * 128 + ((pch ^ (row & 7)) << 4));
+      bf16x8 val;
+      if constexpr (AHEAD) val = __builtin_bit_cast(bf16x8, vals[it]);
+      else val = *(const bf16x8*)(slab + row * 128 + ((pch ^ (row & 7)) << 4));
       if (ACT == ACT_MASK) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) if (!((float)a8[it][e] > 0.f)) val[e] = (T)0.f;
@@ -761,6 +777,9 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
           mw |= ((z | (z >> 15)) & 0xffu) << (8 * it);
         }
         if constexpr (COLSUM) {
+          // (not v_dot2c_f32_bf16 against (1, 0) / (0, 1), which would halve these instructions: tools/probes/dot2_probe.hip -- its
+          // accumulate is not correctly rounded, inf x 0 poisons the neighbouring column, and hipcc 7.2 encodes the packed constant
+          // (1, 0) as the inline constant 1.0, which the instruction reads as (0, 1))
 #pragma unroll
           for (int e = 0; e < 8; ++e) cs[e] += (float)val[e];
         }
