@@ -41,5 +41,42 @@ for (M, N, K) in ((768, 256, 256), (768, 256, 320), (1000, 256, 256), (768, 1024
                 print(f"MISMATCH M={M} N={N} K={K} act={act} it={it}: {int((d > 0).sum())} elements, max {float(d.max()):.3e}, nan {int(torch.isnan(Y.float()).sum())}", flush=True)
                 if bad > 10:
                     sys.exit(1)
+# the training flavours: forward that also writes the ReLU bit mask, then the data gradient that consumes it (+ column sums, folded in
+# a fixed order): activations, bit words, masked gradient and bias gradient must all repeat bit for bit
+for (M, N, K) in ((768, 256, 256), (1000, 1024, 128), (4096, 1024, 1024), (700, 1024, 1152)):
+    A = torch.randn(M, K, device="cuda").bfloat16()
+    W = (torch.randn(N, K, device="cuda") / K ** 0.5).bfloat16()
+    b = torch.randn(N, device="cuda")
+    G = torch.randn(M, N, device="cuda").bfloat16()                       # upstream gradient of the next layer (N x N weights)
+    W2 = (torch.randn(N, N, device="cuda") / N ** 0.5).bfloat16()
+    big = torch.randn(4096, 4096, device="cuda").bfloat16()
+    ref = None
+    for it in range(300):
+        Y = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+        bits = torch.full((ops.mask_bits_words(M, N),), -1, device="cuda", dtype=torch.int32)
+        D = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+        db = torch.zeros(N, device="cuda")
+        if poison is not None and it % 2 == 1:
+            poison(0x7FC00000 if it % 4 == 1 else 0xFFFFFFFF, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        ops.linear_fwd(A, W, b, Y, K, N, ops.ACT_RELU_BITS, ops.BF16, aux=bits, variant=8)
+        if it % 3 == 0:
+            torch.mm(big, big)
+        ops.linear_fwd(G, W2, None, D, N, N, ops.ACT_MASK_BITS, ops.BF16, aux=bits, colsum=db, variant=8, deterministic=True)
+        out = (Y, bits[:8 * ((M + 255) // 256) * (N // 64) * 64], D, db)
+        if ref is None:
+            ref = [t.clone() for t in out]
+            want = torch.relu(A.float() @ W.float().t() + b)
+            assert float((Y.float() - want).abs().max() / want.abs().max()) < 2e-2
+            wantD = (G.float() @ W2.float().t()) * (Y.float() > 0)
+            assert float((D.float() - wantD).abs().max() / wantD.abs().max()) < 2e-2, (M, N, K)
+            assert float((db - D.float().sum(0)).abs().max() / (D.float().sum(0).abs().max() + 1e-6)) < 1e-3, (M, N, K)
+        else:
+            # rows >= M of the last 32-row block of the bit words are never written by design: compare the rows that exist
+            same = torch.equal(out[0], ref[0]) and torch.equal(out[2], ref[2]) and torch.equal(out[3].view(torch.int32), ref[3].view(torch.int32))
+            if not same:
+                bad += 1
+                print(f"MISMATCH (training flavours) M={M} N={N} K={K} it={it}", flush=True)
+                if bad > 10:
+                    sys.exit(1)
 print("stress_small_gemm:", "OK (all repeats bit-identical)" if bad == 0 else f"{bad} mismatching launches")
 sys.exit(0 if bad == 0 else 1)
