@@ -282,6 +282,8 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
     reference's dict (render.py:394-401).  Extra keyword-only inputs `t_rand` [N,S] / `u` [N,Nimp]
     replace the internal torch.rand draws (parity tests)."""
     N_rays = ray_batch.shape[0]
+    if N_rays == 0:   # as the reference (run_network's torch.cat of no chunks): an error, not an empty dict
+        raise ValueError("render_rays: empty ray batch")
     dev = ray_batch.device
     rb = ray_batch.float()
     if rb.stride(-1) != 1:

@@ -1516,9 +1516,13 @@ static TnPlan tn_plan(int M, int N, int K, long ldz, long ldx, int dtype, int va
     pl.part_ld = ((K + 255) / 256) * 256; pl.part_stride = (long)N * pl.part_ld;
     return pl;
   }
-  // split M so that the grid has a few thousand blocks but each block still amortises its atomics
+  // split M so that every CU has work but each block still amortises its atomics
   const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
-  int chunks = (4096 + tiles - 1) / tiles;
+  // about two workgroups per CU: every slice ends with one fp32 atomic per output element, and on the long-M launches of the step
+  // 512 workgroups beat the few thousand of round 1 by 8-23 % (tools/gemm_tn_slices_probe.py; variant bits 16 / 32 / 64 select
+  // 1024 / 2048 / 4096 for that probe)
+  const int target = (variant & 64) ? 4096 : (variant & 32) ? 2048 : (variant & 16) ? 1024 : 512;
+  int chunks = (target + tiles - 1) / tiles;
   int m_chunk = (M + chunks - 1) / chunks;
   m_chunk = ((m_chunk + 255) / 256) * 256;
   if (m_chunk < 1024) m_chunk = 1024;

@@ -222,6 +222,8 @@ class MipNerfModel(_ArenaModule):
             raise NotImplementedError("gradients w.r.t. radii / near / far are not propagated (the reference's pose refinement leaves them constant)")
         dev = self.arena.flat.device
         n = rays.origins.shape[0]
+        if n == 0:    # the reference raises on an empty batch too (models.py: reshape of 0 elements with an inferred dimension)
+            raise RuntimeError("MipNerfModel.forward: empty ray batch")
         ds_rand, du, noise0, noise1 = self._draws(n, randomized, dev)
         if s_rand is None:
             s_rand = ds_rand
