@@ -9,4 +9,5 @@ run wr2 WRITE_SIZE
 run wr3 FETCH_SIZE
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS
 run sq2 SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD TCP_PENDING_STALL_CYCLES_sum TCP_TCC_WRITE_REQ_sum TCC_TAG_STALL_sum
+run sq3 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_LDS SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_MFMA
 python $ROOT/tools/pmc_summary.py $ROOT/gpurun_out/pmc_fmlp_train "fmlp_kernel<0, false, true>"
