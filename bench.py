@@ -307,7 +307,7 @@ def main():
                     # HBM bytes of ONE launch of the largest layer shape (M = 524288, N = K = 1024: algorithmic 1.07 GB in + 1.07 GB out),
                     # from separate rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE): tools/pmc_gemm.sh
                     "traffic": (1.618e9 + 1.074e9) if (args.compute == "bf16" and args.variant == 8) else None,
-                    "traffic_source": "profiles/r1_x_gemm_nt8p_traffic.txt (per launch at M=524288 N=K=1024; algorithmic 2.15e9 B)",
+                    "traffic_source": "profiles/r2_m_gemm_nt8p_traffic.txt (per launch at M=524288 N=K=1024; algorithmic 2.15e9 B)",
                     "launches_per_step": launches, "avg_launch_ms": round(gemm_ms / launches, 4), "kernel_ms_per_step": round(gemm_ms, 3),
                     "algorithmic_flops_per_step": alg_nt, "padded_flops_per_step": padded_flops,
                     "whole_step_tflops": round(3 * fwd * n / (ms_step * 1e-3) / 1e12, 1)}
