@@ -35,9 +35,18 @@
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
-#define FM_CHUNK 16                 // fragments per ring slot
+// Waves per workgroup: 8 (one workgroup per CU: ships) or 4 (two workgroups per CU, each with its own ring of half-size chunks, so that
+// the two waves of a SIMD belong to different workgroups and do not reach their block ends together).  Measured (round 2, MI355X,
+// 6.3 M rows): 4 waves 6.03 ms inference / 10.0 ms training forward, 8 waves 5.50 / 9.31 -- twice the L2 -> LDS weight traffic, half
+// the read-ahead time and twice the barriers cost more than the desynchronisation gives.
+#ifndef FM_WAVES
+#define FM_WAVES 8
+#endif
+#define FM_CHUNK (2 * FM_WAVES)     // fragments per ring slot: every wave DMAs two of them
 #define FM_SLOT (FM_CHUNK * 1024)   // bytes per ring slot
-#define FM_RING 6                   // ring slots (96 KiB): five chunks in flight ahead of the one being consumed
+#define FM_RING 6                   // ring slots: five chunks in flight ahead of the one being consumed
+#define FM_TILE_ROWS (32 * FM_WAVES)          // samples per workgroup tile
+#define FM_WG_PER_CU (FM_WAVES == 4 ? 2 : 1)  // either way two waves per SIMD, 256 VGPRs each
 #define FM_BIAS_MAX 128             // n-blocks of 32 outputs whose biases fit the LDS table (16 KiB)
 #define FM_LOOK 4                   // weight fragments fetched from LDS ahead of the MFMA that uses them (a register queue)
 
@@ -342,7 +351,7 @@ __device__ __forceinline__ ClassicInputs classic_embed_inputs(const float* pp, c
 #define FMLP_PROPOSAL 1
 
 template <int NET, bool EMBED, bool STORE>
-__global__ __launch_bounds__(512) void fmlp_kernel(FmlpArgs a) {
+__global__ __launch_bounds__(64 * FM_WAVES, 2) void fmlp_kernel(FmlpArgs a) {   // (second argument: waves per SIMD -> at most 256 VGPRs)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -362,7 +371,7 @@ __global__ __launch_bounds__(512) void fmlp_kernel(FmlpArgs a) {
   c.bias_lds = (const char*)bias_tab + half * 16;
 
   // prologue: biases into LDS (plain stores), the first FM_RING - 1 chunks of the stream into the ring
-  for (int i = tid; i < a.n_blocks * 32; i += 512) bias_tab[i] = a.bias[i];
+  for (int i = tid; i < a.n_blocks * 32; i += 64 * FM_WAVES) bias_tab[i] = a.bias[i];
 #pragma unroll
   for (int i = 0; i < FM_RING - 1; ++i) ws_issue(c.ws, smem);
 #ifdef FMLP_LOCKSTEP_START
@@ -376,7 +385,7 @@ __global__ __launch_bounds__(512) void fmlp_kernel(FmlpArgs a) {
   for (int i = 0; i < FM_LOOK; ++i) c.q[i] = *(const bf16x8*)(c.frag_base + c.ws.slot_off + i * 1024);
 
   for (int tile = blockIdx.x; tile < a.tiles; tile += gridDim.x) {
-    long row = (long)tile * 256 + wave * 32 + (lane & 31);
+    long row = (long)tile * FM_TILE_ROWS + wave * 32 + (lane & 31);
     const bool row_ok = row < a.M;
     row = row_ok ? row : a.M - 1;                       // tail rows: compute on a valid row, store nothing
 
@@ -395,7 +404,7 @@ __global__ __launch_bounds__(512) void fmlp_kernel(FmlpArgs a) {
       constexpr int F1 = 8 * 4, F2 = F1 + 128, F3 = F2 + 128, F4 = F3 + 128, F5 = F4 + 128, F6 = F5 + 8 * 20, F7 = F6 + 128;
       constexpr int FA = F7 + 128, FF = FA + 16, FV = FF + 128, FR = FV + 4 * 18;
       static_assert(FR + 8 == FMLP_CLASSIC_FRAGS, "classic network: fragment count");
-      auto to = [&](int i) { return StoreTo{a.act[i], a.act_ld[i], i < 8 ? a.bits[i] : nullptr, (long)tile * 256 + wave * 32, a.M, smem + FM_RING * FM_SLOT + FM_BIAS_MAX * 128 + wave * 4096, lane}; };
+      auto to = [&](int i) { return StoreTo{a.act[i], a.act_ld[i], i < 8 ? a.bits[i] : nullptr, (long)tile * FM_TILE_ROWS + wave * 32, a.M, smem + FM_RING * FM_SLOT + FM_BIAS_MAX * 128 + wave * 4096, lane}; };
       dense<0, 0, 4, 8, true, STORE>(c, e, p, to(0));             // pts_linears.0
       dense<F1, 8, 16, 8, true, STORE>(c, p, q, to(1));           // .1
       dense<F2, 16, 16, 8, true, STORE>(c, q, p, to(2));          // .2
@@ -419,7 +428,7 @@ __global__ __launch_bounds__(512) void fmlp_kernel(FmlpArgs a) {
     } else {
       bf16x8 e[6], p[16], q[16];
       load_rows<6>(a.E, a.ldE, row, half, e);
-      auto to = [&](int i) { return StoreTo{a.act[i], a.act_ld[i], i < 8 ? a.bits[i] : nullptr, (long)tile * 256 + wave * 32, a.M, smem + FM_RING * FM_SLOT + FM_BIAS_MAX * 128 + wave * 4096, lane}; };
+      auto to = [&](int i) { return StoreTo{a.act[i], a.act_ld[i], i < 8 ? a.bits[i] : nullptr, (long)tile * FM_TILE_ROWS + wave * 32, a.M, smem + FM_RING * FM_SLOT + FM_BIAS_MAX * 128 + wave * 4096, lane}; };
       dense<0, 0, 6, 8, true, STORE>(c, e, p, to(0));             // layers.0
       dense<48, 8, 16, 8, true, STORE>(c, p, q, to(1));
       dense<48 + 128, 16, 16, 8, true, STORE>(c, q, p, to(2));
@@ -440,7 +449,7 @@ static int fmlp_launch(const FmlpArgs& a, int expect_frags, int expect_blocks, l
   if (n_frags != expect_frags || a.n_blocks != expect_blocks || a.n_blocks > FM_BIAS_MAX || (n_frags % FM_CHUNK) != 0) return SNERF_ERR_ARG;
   if (a.wstream == nullptr || a.bias == nullptr || a.out == nullptr || (((uintptr_t)a.wstream) & 15)) return SNERF_ERR_ARG;
   if (!EMBED && (a.E == nullptr || (a.ldE % 8) != 0 || (((uintptr_t)a.E) & 15))) return SNERF_ERR_ARG;
-  constexpr int LDS = FM_RING * FM_SLOT + FM_BIAS_MAX * 128 + (STORE ? 8 * 4096 : 0);   // + the transposition slabs of the training stores
+  constexpr int LDS = FM_RING * FM_SLOT + FM_BIAS_MAX * 128 + (STORE ? FM_WAVES * 4096 : 0);   // + the transposition slabs of the training stores
   static bool attr_set = false;
   static int n_cu = 256;
   if (!attr_set) {
@@ -451,8 +460,8 @@ static int fmlp_launch(const FmlpArgs& a, int expect_frags, int expect_blocks, l
       n_cu = prop.multiProcessorCount;
     attr_set = true;
   }
-  const int grid = a.tiles < n_cu ? a.tiles : n_cu;
-  hipLaunchKernelGGL((fmlp_kernel<NET, EMBED, STORE>), dim3(grid), dim3(512), LDS, (hipStream_t)stream, a);
+  const int grid = a.tiles < n_cu * FM_WG_PER_CU ? a.tiles : n_cu * FM_WG_PER_CU;
+  hipLaunchKernelGGL((fmlp_kernel<NET, EMBED, STORE>), dim3(grid), dim3(64 * FM_WAVES), LDS, (hipStream_t)stream, a);
   return snerf_check_launch();
 }
 
@@ -462,7 +471,7 @@ extern "C" int snerf_fmlp_classic_fwd(const void* E, long ldE, const void* VE, l
   if (VE == nullptr || (ldVE % 8) != 0 || (((uintptr_t)VE) & 15) || (((uintptr_t)raw) & 15)) return SNERF_ERR_ARG;
   FmlpArgs a{};
   a.E = (const __bf16*)E; a.ldE = ldE; a.VE = (const __bf16*)VE; a.ldVE = ldVE; a.S = 1; a.wstream = (const char*)wstream; a.bias = bias; a.out = raw;
-  a.M = M; a.tiles = (int)((M + 255) / 256); a.n_chunks = (int)(n_frags / FM_CHUNK); a.n_blocks = n_blocks;
+  a.M = M; a.tiles = (int)((M + FM_TILE_ROWS - 1) / FM_TILE_ROWS); a.n_chunks = (int)(n_frags / FM_CHUNK); a.n_blocks = n_blocks;
   return fmlp_launch<FMLP_CLASSIC, false>(a, FMLP_CLASSIC_FRAGS, FMLP_CLASSIC_BLOCKS, n_frags, stream);
 }
 
@@ -479,7 +488,7 @@ extern "C" int snerf_fmlp_classic_train_fwd(const void* E, long ldE, const void*
     return SNERF_ERR_ARG;
   FmlpArgs a{};
   a.E = (const __bf16*)E; a.ldE = ldE; a.VE = (const __bf16*)VE; a.ldVE = ldVE; a.S = 1; a.wstream = (const char*)wstream; a.bias = bias; a.out = raw;
-  a.M = M; a.tiles = (int)((M + 255) / 256); a.n_chunks = (int)(n_frags / FM_CHUNK); a.n_blocks = n_blocks;
+  a.M = M; a.tiles = (int)((M + FM_TILE_ROWS - 1) / FM_TILE_ROWS); a.n_chunks = (int)(n_frags / FM_CHUNK); a.n_blocks = n_blocks;
   for (int i = 0; i < 10; ++i) {
     if (acts[i] == nullptr || (((uintptr_t)acts[i]) & 15) || (act_ld[i] % 8) != 0) return SNERF_ERR_ARG;
     a.act[i] = (__bf16*)acts[i]; a.act_ld[i] = act_ld[i];
@@ -498,7 +507,7 @@ extern "C" int snerf_fmlp_classic_pts_fwd(const float* pts, const float* viewdir
   if (pts == nullptr || viewdirs == nullptr || S <= 0 || ldvd < 3 || (((uintptr_t)raw) & 15) || M >= (1L << 31)) return SNERF_ERR_ARG;
   FmlpArgs a{};
   a.pts = pts; a.viewdirs = viewdirs; a.ldvd = ldvd; a.S = S; a.wstream = (const char*)wstream; a.bias = bias; a.out = raw;
-  a.M = M; a.tiles = (int)((M + 255) / 256); a.n_chunks = (int)(n_frags / FM_CHUNK); a.n_blocks = n_blocks;
+  a.M = M; a.tiles = (int)((M + FM_TILE_ROWS - 1) / FM_TILE_ROWS); a.n_chunks = (int)(n_frags / FM_CHUNK); a.n_blocks = n_blocks;
   return fmlp_launch<FMLP_CLASSIC, true>(a, FMLP_CLASSIC_FRAGS, FMLP_CLASSIC_BLOCKS, n_frags, stream);
 }
 
@@ -506,7 +515,7 @@ extern "C" int snerf_fmlp_proposal_fwd(const void* E, long ldE, const void* wstr
                                        float* raw_density, long M, void* stream) {
   FmlpArgs a{};
   a.E = (const __bf16*)E; a.ldE = ldE; a.S = 1; a.wstream = (const char*)wstream; a.bias = bias; a.out = raw_density;
-  a.M = M; a.tiles = (int)((M + 255) / 256); a.n_chunks = (int)(n_frags / FM_CHUNK); a.n_blocks = n_blocks;
+  a.M = M; a.tiles = (int)((M + FM_TILE_ROWS - 1) / FM_TILE_ROWS); a.n_chunks = (int)(n_frags / FM_CHUNK); a.n_blocks = n_blocks;
   // 8 x 6 + 3 x 128 + 16 fragments; 32 + 1 blocks
   return fmlp_launch<FMLP_PROPOSAL, false>(a, 448, 33, n_frags, stream);
 }
@@ -519,7 +528,7 @@ extern "C" int snerf_fmlp_proposal_train_fwd(const void* E, long ldE, const void
   if (acts == nullptr || act_ld == nullptr || bits == nullptr) return SNERF_ERR_ARG;
   FmlpArgs a{};
   a.E = (const __bf16*)E; a.ldE = ldE; a.S = 1; a.wstream = (const char*)wstream; a.bias = bias; a.out = raw_density;
-  a.M = M; a.tiles = (int)((M + 255) / 256); a.n_chunks = (int)(n_frags / FM_CHUNK); a.n_blocks = n_blocks;
+  a.M = M; a.tiles = (int)((M + FM_TILE_ROWS - 1) / FM_TILE_ROWS); a.n_chunks = (int)(n_frags / FM_CHUNK); a.n_blocks = n_blocks;
   for (int i = 0; i < 4; ++i) {
     if (acts[i] == nullptr || (((uintptr_t)acts[i]) & 15) || (act_ld[i] % 8) != 0) return SNERF_ERR_ARG;
     if (bits[i] == nullptr) return SNERF_ERR_ARG;
