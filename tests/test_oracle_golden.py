@@ -226,3 +226,19 @@ def test_g19_ray_gradients_of_the_reference(golden):
         err = float((leaves[k].grad - ref_g).abs().max())
         # both sides are fp32 autograd of an ill-conditioned sum (2^15-scaled sines): 1e-3 of the largest component is their common noise
         assert err <= 3e-3 * float(ref_g.abs().max()), (k, err, float(ref_g.abs().max()))
+
+
+def test_oracle_fuzz_vs_reference_log_and_live_run():
+    """oracle/fuzz_vs_reference.py: the committed 25-seed summary reports no violation; where the reference is present (the build
+    container) two fresh seeds are replayed live -- random inputs AND random weights, every stage of paths A and B."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    log = open(os.path.join(root, "oracle", "fuzz_vs_reference.log")).read()
+    assert "# total violations: 0" in log and log.count("\n") > 40
+    assert all(line.rstrip().endswith("| 0") for line in log.splitlines() if line and not line.startswith("#"))
+    if not os.path.isdir("/root/reference/s-nerf"):
+        return
+    r = subprocess.run([sys.executable, os.path.join(root, "oracle", "fuzz_vs_reference.py"), "--seeds", "2"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "# total violations: 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
