@@ -229,16 +229,18 @@ def test_g19_ray_gradients_of_the_reference(golden):
 
 
 def test_oracle_fuzz_vs_reference_log_and_live_run():
-    """oracle/fuzz_vs_reference.py: the committed 25-seed summary reports no violation; where the reference is present (the build
-    container) two fresh seeds are replayed live -- random inputs AND random weights, every stage of paths A and B."""
+    """oracle/fuzz_vs_reference.py (paths A, B: 25 seeds) and oracle/fuzz_zip_vs_reference.py (path C around the grid: 12 seeds): the
+    committed summaries report no violation; where the reference is present (the build container) two seeds of each are replayed
+    live -- random inputs AND random weights / hash tables, every stage."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    log = open(os.path.join(root, "oracle", "fuzz_vs_reference.log")).read()
-    assert "# total violations: 0" in log and log.count("\n") > 40
-    assert all(line.rstrip().endswith("| 0") for line in log.splitlines() if line and not line.startswith("#"))
-    if not os.path.isdir("/root/reference/s-nerf"):
-        return
-    r = subprocess.run([sys.executable, os.path.join(root, "oracle", "fuzz_vs_reference.py"), "--seeds", "2"], capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and "# total violations: 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    for name, min_lines, ref_dir in (("fuzz_vs_reference", 40, "/root/reference/s-nerf"), ("fuzz_zip_vs_reference", 20, "/root/reference/s-nerfpp/zipnerf")):
+        log = open(os.path.join(root, "oracle", name + ".log")).read()
+        assert "# total violations: 0" in log and log.count("\n") > min_lines, name
+        assert all(line.rstrip().endswith("| 0") for line in log.splitlines() if line and not line.startswith("#")), name
+        if not os.path.isdir(ref_dir):
+            continue
+        r = subprocess.run([sys.executable, os.path.join(root, "oracle", name + ".py"), "--seeds", "2"], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and "# total violations: 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
