@@ -100,3 +100,51 @@ def test_zip_tiny_ray_batches_match_rows_of_the_full_batch(backend, golden, n):
     for lvl in range(3):
         close(hist[lvl]["sdist"], g[f"det_sdist{lvl}"][:n], 2e-4, 2e-4, f"sdist {lvl}")
     tz.DEV = "cuda"
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_shapes_and_weights_vs_oracle(backend, seed):
+    """Seeded fuzz of the two torch-facing paths at random ray counts, sample counts and network weights (fp32 mode; the fixed cases of
+    test_paths use round numbers): MipNerfModel.forward (deterministic and with the draws passed in) and render_rays vs the oracle."""
+    from snerf_amd import classic, mipnerf
+    g = torch.Generator().manual_seed(777 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    # ---- path A
+    n, S0, P1 = ri(1, 150), ri(4, 40), ri(5, 41)
+    shapes = om.mipnerf_param_shapes(hidden=64, prop_hidden=64)
+    sd = tp.random_params(shapes, 100 + seed, ("mlp.density_layer.bias", "proposal.density_layer.bias"))
+    rays_c = common.synthetic_rays(n, seed=300 + seed)
+    s_rand = torch.rand(n, S0 + 1, generator=g)
+    u = om.rand_u(P1, torch.empty(n, P1).uniform_(0, 1 / P1 - om.EPS32, generator=g))
+    m = tp.make_mip(64, 64, S0, P1, "f32", sd)
+    rays = mipnerf.Rays(**{k: v.to(tp.DEV) for k, v in rays_c.items()})
+    for kw_o, kw_m, rnd in ((dict(), dict(), False), (dict(s_rand=s_rand, u=u), dict(s_rand=s_rand.to(tp.DEV), u=u.to(tp.DEV)), True)):
+        ref = om.mipnerf_forward(sd, rays_c, S0, P1, **kw_o)
+        with torch.no_grad():
+            ret = m(rays, rnd, False, 0., **kw_m)
+        what = f"seed {seed} n {n} S0 {S0} P1 {P1} rand {rnd}: "
+        assert torch.equal(ret[0][3].cpu(), ref[0][3]), what + "level-0 fence posts must be bit-exact"
+        close(ret[0][4], ref[0][4], 1e-4, 1e-6, what + "w0"); close(ret[1][4], ref[1][4], 1e-4, 1e-5, what + "s1")
+        close(ret[1][0], ref[1][0], 1e-4, 1e-4, what + "rgb"); close(ret[1][1], ref[1][1], 1e-4, 1e-4, what + "distance")
+        close(ret[1][2], ref[1][2], 1e-4, 1e-5, what + "acc")
+    # ---- path B (coarse only: the hierarchical pass is conditioned on u == cdf ties, see test_paths)
+    n, S = ri(1, 120), ri(2, 70)
+    pc = tp.random_params(oc.nerf_param_shapes(W=64), 200 + seed, ("alpha_linear.bias",))
+    coarse = tp.make_nerf(64, "f32", pc)
+    embed_fn, _ = classic.get_embedder(10, 0); embeddirs_fn, _ = classic.get_embedder(4, 0)
+    nq = classic.make_network_query_fn(embed_fn, embeddirs_fn)
+    ro = torch.randn(n, 3, generator=g) * 0.2
+    rd = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1) * (1 + 0.2 * torch.rand(n, 1, generator=g))
+    rb = torch.cat([ro, rd, torch.full((n, 1), 2.0), torch.full((n, 1), 6.0), torch.nn.functional.normalize(rd, dim=-1)], -1)
+    t_rand = torch.rand(n, S, generator=g)
+    lindisp = bool(seed % 2)
+    ref = oc.render_rays(rb, pc, None, S, 0, lindisp=lindisp, t_rand=t_rand, retraw=True, white_bkgd=bool(seed % 3 == 0))
+    with torch.no_grad():
+        out = classic.render_rays(rb.to(tp.DEV), coarse, nq, N_samples=S, retraw=True, lindisp=lindisp, perturb=1., N_importance=0,
+                                  white_bkgd=bool(seed % 3 == 0), t_rand=t_rand.to(tp.DEV))
+    what = f"seed {seed} n {n} S {S} lindisp {lindisp}: "
+    assert torch.equal(out["z_vals_map"].cpu(), ref["z_vals_map"]), what + "stratified z must be bit-exact"
+    close(out["raw"], ref["raw"], 1e-4, 1e-4, what + "raw")
+    ok = ref["raw"][:, -1, 3].abs() > 1e-3
+    for k in ("rgb_map", "acc_map", "weights", "depth_map"):
+        close(out[k][ok], ref[k][ok], 1e-4, 1e-4, what + k)
