@@ -56,7 +56,9 @@ int snerf_linear_fwd(const void* A, long lda, const void* W, long ldw, const flo
 
 /* dW[n_valid, k_valid] (fp32, ldw) += dZ[M,N]^T . X[M,K]  -- weight gradient of the same layers
  * (autograd of nn.Linear in the reference; train.py:213 loss.backward()).  `zeros` = >=16 bytes of
- * device zeros (source for rows past M).  variant 1 (bf16, N and K multiples of 128): transposing LDS reads. */
+ * device zeros (source for rows past M).  variant bit 1 (bf16, N and K multiples of 128): transposing LDS reads; bit 2 (bf16,
+ * N % 256 == 0, K >= 256): the 256 x 256 8-phase kernel; bits 16 / 32 / 64: probe only -- 1024 / 2048 / 4096 M-slices for the
+ * 128 x 128 kernel instead of its default of about 512 (tools/gemm_tn_slices_probe.py). */
 int snerf_linear_wgrad(const void* Z, long ldz, const void* X, long ldx, float* dW, long ldw, const void* zeros,
                        int M, int N, int K, int n_valid, int k_valid, int dtype, int variant, void* stream);
 
