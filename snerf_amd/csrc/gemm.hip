@@ -41,6 +41,7 @@ struct GemmNT {
   float* colsum_ws; int fast_epi;
   int det;  // deterministic bias gradient: the per-slab column sums are folded by ONE thread per column (fixed order)
   int dbg;  // ablation bits, honoured only by a `make PROBE=1` build (tools/gemm_probe.py): 1 = no staging loads after tile 0, 2 = no LDS fragment reads, 4 = no stores
+  int stagger;  // persistent kernel: workgroup start offsets, in units of KT x 64 clocks per slot (0 = all start together)
 };
 #ifndef SNERF_PROBE
 #define SNERF_PROBE 0   // the shipped library compiles the ablation branches out
@@ -758,7 +759,7 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
         val = __builtin_bit_cast(bf16x8, raw);
       }
       if (col_ok && m < p.M) {
-        *(bf16x8*)(yrow + it * ystep) = val;
+        *(bf16x8*)(yrow + it * ystep) = val;          // (non-temporal stores measure the same: profiles/r2_n)
         if (ACT == ACT_RELU_BITS) {
           // the value is a ReLU output (max(v, +0) rounded to bf16: never negative, never -0): > 0  <=>  its 16 bits are not all zero
           // min(half, 1) per 16-bit half = "is positive"; z gathers the even elements in bits 0, 2, 4, 6 and the odd ones 16 higher
@@ -825,6 +826,12 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
     __builtin_amdgcn_sched_barrier(0);
   };
 
+  // ---- staggered start (see launch_nt8p): equal work per workgroup keeps the tile boundaries of all CUs in step, so the chip's row
+  // stores arrive in bursts that the write path acknowledges late; the workgroups of an XCD start up to 7/8 of a tile apart instead
+  if (p.stagger) {
+    const int n = (((int)blockIdx.x >> 3) & 7) * KT * p.stagger;
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
+  }
   // ---- prologue: k-tiles 0 and 1 of the stream, bias of tiles 0 and 1 --------------------------------------------
   if (p.bias == nullptr && tid < 128) *(f32x4*)(smem + BIAS + tid * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
   stream_tile(0);
@@ -1087,7 +1094,8 @@ extern "C" int snerf_linear_fwd(const void* A, long lda, const void* W, long ldw
   if ((variant >> 4) & 8) fast = 0;                          // ablation: force the direct-store epilogue
   const int det = (variant >> 8) & 1;                        // variant bit 8: deterministic fold of the bias-gradient partials
   if (det && colsum != nullptr && !fast) return SNERF_ERR_ARG;   // the direct-store epilogue adds its column sums with atomics
-  GemmNT p{A, lda, W, ldw, bias, Y, ldy, aux, ldaux, colsum, M, N, K, n_store, act, out_f32, vec, colsum_ws, fast, det, (variant >> 4) & 7};
+  GemmNT p{A, lda, W, ldw, bias, Y, ldy, aux, ldaux, colsum, M, N, K, n_store, act, out_f32, vec, colsum_ws, fast, det, (variant >> 4) & 7,
+           (variant >> 9) & 15};
   variant &= 15;
   hipStream_t s = (hipStream_t)stream;
   // variant: 0 = 128x128 block-issue, 1 = 256x256 block-issue,
