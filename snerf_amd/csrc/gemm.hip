@@ -759,7 +759,8 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
         val = __builtin_bit_cast(bf16x8, raw);
       }
       if (col_ok && m < p.M) {
-        *(bf16x8*)(yrow + it * ystep) = val;          // (non-temporal stores measure the same: profiles/r2_n)
+        if (!DBG(p, 8)) *(bf16x8*)(yrow + it * ystep) = val;          // (non-temporal stores measure the same: profiles/r2_n)
+        else asm volatile("" ::"v"(val));               // PROBE build, bit 8: everything but the store instruction itself
         if (ACT == ACT_RELU_BITS) {
           // the value is a ReLU output (max(v, +0) rounded to bf16: never negative, never -0): > 0  <=>  its 16 bits are not all zero
           // min(half, 1) per 16-bit half = "is positive"; z gathers the even elements in bits 0, 2, 4, 6 and the odd ones 16 higher
@@ -1094,8 +1095,8 @@ extern "C" int snerf_linear_fwd(const void* A, long lda, const void* W, long ldw
   if ((variant >> 4) & 8) fast = 0;                          // ablation: force the direct-store epilogue
   const int det = (variant >> 8) & 1;                        // variant bit 8: deterministic fold of the bias-gradient partials
   if (det && colsum != nullptr && !fast) return SNERF_ERR_ARG;   // the direct-store epilogue adds its column sums with atomics
-  GemmNT p{A, lda, W, ldw, bias, Y, ldy, aux, ldaux, colsum, M, N, K, n_store, act, out_f32, vec, colsum_ws, fast, det, (variant >> 4) & 7,
-           (variant >> 9) & 15};
+  GemmNT p{A, lda, W, ldw, bias, Y, ldy, aux, ldaux, colsum, M, N, K, n_store, act, out_f32, vec, colsum_ws, fast, det, ((variant >> 4) & 7) | ((variant >> 10) & 8),
+           (variant >> 9) & 15};                                 // (PROBE builds: variant bit 13 = ablation bit 8; bits 9..12 = stagger)
   variant &= 15;
   hipStream_t s = (hipStream_t)stream;
   // variant: 0 = 128x128 block-issue, 1 = 256x256 block-issue,
