@@ -38,6 +38,35 @@ def test_pinhole_rays_vs_reference_golden(golden):
 
 
 @gpu
+@pytest.mark.parametrize("seed", range(5))
+def test_pinhole_rays_random_cameras_vs_oracle(seed):
+    """Seeded fuzz: random image sizes, intrinsics (principal point off-centre, fx != fy), rotations and pixel subsets -- the kernel
+    against oracle/callers.py, which oracle/fuzz_callers_vs_reference.py pins bit for bit to the reference on the same kind of input."""
+    from snerf_amd import sample_utils as su
+    g = torch.Generator().manual_seed(4000 + seed)
+    R = lambda *s: torch.rand(*s, generator=g)
+    H, W = 20 + int(R(1) * 200), 24 + int(R(1) * 300)
+    th, ph = float(R(1)) * 2 - 1, float(R(1)) * 0.4 - 0.2
+    rot = torch.tensor([[np.cos(th), 0.0, np.sin(th)], [0.0, 1.0, 0.0], [-np.sin(th), 0.0, np.cos(th)]], dtype=torch.float64) @ \
+        torch.tensor([[1.0, 0.0, 0.0], [0.0, np.cos(ph), -np.sin(ph)], [0.0, np.sin(ph), np.cos(ph)]], dtype=torch.float64)
+    pose = torch.cat([rot, torch.rand(3, 1, generator=g, dtype=torch.float64) * 4 - 2], 1).float().numpy()
+    K = np.array([[40 + 600 * float(R(1)), 0.0, W * (0.4 + 0.2 * float(R(1)))], [0.0, 40 + 600 * float(R(1)), H * (0.4 + 0.2 * float(R(1)))], [0.0, 0.0, 1.0]], dtype=np.float32)
+    n = 1 + int(R(1) * 500)
+    sel = torch.stack([torch.randint(0, H, (n,), generator=g), torch.randint(0, W, (n,), generator=g)], -1)
+    sel[0] = torch.tensor([H - 1, W - 1]); sel[-1] = torch.tensor([0, 0])             # the last row / column conventions of the reference
+    near, far = 0.5 + float(R(1)) * 2, 50 + float(R(1)) * 100
+    for training in (True, False):
+        want = oc.pinhole_rays(sel, pose, K, H, near, far, training=training, W=W)
+        got = su.rays_of_pixels(sel, pose, K, H, W, near, far, training=training)
+        for k in ("origins", "directions", "lossmult", "near", "far"):
+            a = getattr(got, k).reshape(n, -1).cpu()
+            assert torch.equal(a, want[k].reshape(n, -1)), (seed, training, k, float((a - want[k].reshape(n, -1)).abs().max()))
+        for k in ("viewdirs", "radii"):       # norms / 3-term sums: see test_pinhole_rays_vs_reference_golden
+            a = getattr(got, k).reshape(n, -1).cpu()
+            assert torch.allclose(a, want[k].reshape(n, -1), rtol=3e-7, atol=0), (seed, training, k)
+
+
+@gpu
 def test_sample_single_img_mirror(golden):
     """Same numpy RNG state -> same pixels, rays, targets as the reference's sample_single_img."""
     from snerf_amd import sample_utils as su
