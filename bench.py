@@ -18,6 +18,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # this host's driver only supports dmabuf IPC (RCCL across processes needs it); before torch loads the runtime
+
 import numpy as np
 import torch
 import torch.distributed as dist
