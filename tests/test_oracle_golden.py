@@ -230,7 +230,7 @@ def test_g19_ray_gradients_of_the_reference(golden):
 
 def test_oracle_fuzz_vs_reference_log_and_live_run():
     """oracle/fuzz_vs_reference.py (paths A, B: 25 seeds), oracle/fuzz_zip_vs_reference.py (path C around the grid: 12 seeds) and
-    oracle/fuzz_callers_vs_reference.py (S-NeRF ray generation and loss modules: 20 seeds): the
+    oracle/fuzz_callers_vs_reference.py / fuzz_zip_callers_vs_reference.py (ray generation and loss tails of both code bases: 20 / 12 seeds): the
     committed summaries report no violation; where the reference is present (the build container) two seeds of each are replayed
     live -- random inputs AND random weights / hash tables, every stage."""
     import os
@@ -238,7 +238,8 @@ def test_oracle_fuzz_vs_reference_log_and_live_run():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for name, min_lines, ref_dir in (("fuzz_vs_reference", 40, "/root/reference/s-nerf"), ("fuzz_zip_vs_reference", 20, "/root/reference/s-nerfpp/zipnerf"),
-                                     ("fuzz_callers_vs_reference", 18, "/root/reference/s-nerf")):
+                                     ("fuzz_callers_vs_reference", 18, "/root/reference/s-nerf"),
+                                     ("fuzz_zip_callers_vs_reference", 20, "/root/reference/s-nerfpp/zipnerf")):
         log = open(os.path.join(root, "oracle", name + ".log")).read()
         assert "# total violations: 0" in log and log.count("\n") > min_lines, name
         assert all(line.rstrip().endswith("| 0") for line in log.splitlines() if line and not line.startswith("#")), name
