@@ -827,8 +827,9 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  // ---- staggered start (see launch_nt8p): equal work per workgroup keeps the tile boundaries of all CUs in step, so the chip's row
-  // stores arrive in bursts that the write path acknowledges late; the workgroups of an XCD start up to 7/8 of a tile apart instead
+  // ---- staggered start, a probe (variant bits 9..12, off by default; tools/gemm_stagger_probe.py): equal work per workgroup keeps the
+  // tile boundaries of all CUs in step, so the chip's row stores arrive in bursts -- starting the workgroups of an XCD up to 7/8 of a
+  // tile apart changed nothing on any shape (profiles/r2_n), i.e. the bursts are not what the stores cost
   if (p.stagger) {
     const int n = (((int)blockIdx.x >> 3) & 7) * KT * p.stagger;
     for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
