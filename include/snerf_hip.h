@@ -367,6 +367,24 @@ int snerf_fmlp_proposal_train_fwd(const void* E, long ldE, const void* wstream, 
                                   float* raw_density, void* const* acts, const long* act_ld, void* const* bits, long M,
                                   void* stream);
 
+/* Colour head of the live mip path's NeRF MLP, fused (s-nerf/model/models.py:283-296: cat([bottleneck, view encoding]) ->
+ * cond_layers.0 .. .2 (Linear 128 + ReLU) -> rgb_layer; hidden 1024, 27 view-encoding columns).  Replaces four snerf_linear_fwd
+ * launches forward and the four data-gradient launches backward.
+ * snerf_fcolour_fwd: CB [M, ldCB] bf16 = [bottleneck 1024 | view encoding 27 | zeros up to column 1056] -> raw_rgb [M,3] fp32.
+ *   wstream (336 fragments; cond_layers.0 in k-major order) / bias (13 blocks) from snerf_amd.mlp.fmlp_pack.  acts / act_ld / bits:
+ *   HOST arrays of 3 (or all NULL for inference): the three hidden activations ([M, >= 128] bf16) and their ReLU bit masks
+ *   (8 * ceil(M / 256) * 2 * 64 words each, snerf_linear_fwd's mask-bit layout for N = 128), stored for the backward pass.
+ * snerf_fcolour_bwd: d_raw_rgb [M,3] fp32 -> dC[0..2] = d pre-activation of cond_layers.2, .1, .0 ([M, >= 128] bf16; the weight-
+ *   gradient GEMMs read them) and dB = d pre-activation of the bottleneck layer [M, >= 1024] bf16.  bits[0..3] = the bit masks of
+ *   cond_layers.2, .1, .0 and of the bottleneck (N = 1024); wstream (336 fragments) = fmlp_pack of the TRANSPOSED weights; the four
+ *   layers' bias gradients are ADDED to g_bias[0..3] (128, 128, 128, 1024 floats) in a fixed order (bit-reproducible).
+ *   ws: snerf_fcolour_bwd_ws_floats(M) floats. */
+int snerf_fcolour_fwd(const void* CB, long ldCB, const void* wstream, long n_frags, const float* bias, int n_blocks, float* raw_rgb,
+                      void* const* acts, const long* act_ld, void* const* bits, long M, void* stream);
+long snerf_fcolour_bwd_ws_floats(long M);
+int snerf_fcolour_bwd(const float* d_raw_rgb, const void* wstream, long n_frags, void* const* bits, void* const* dC, const long* dC_ld,
+                      void* dB, long dB_ld, float* const* g_bias, float* ws, long ws_floats, long M, void* stream);
+
 /* ---- deterministic mode ("deterministic mode for parity tests") ------------------------------------------
  * The weight gradient normally lands in dW by fp32 atomics from the M slices (order varies run to run).  snerf_linear_wgrad_det makes
  * every slice store its partial tile into `ws` (snerf_linear_wgrad_ws_floats(...) floats) and folds them in slice order: bit-identical

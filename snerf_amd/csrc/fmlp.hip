@@ -77,56 +77,61 @@ struct WStream {
   int n_chunks;
 };
 
+template <int RING>
 __device__ __forceinline__ void ws_issue(WStream& w, char* smem) {
   const char* g = w.src + (long)w.fill_chunk * FM_SLOT;
   char* dst = smem + w.fill_slot * FM_SLOT + w.my_piece;
   __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)dst, 16, 0, 0);
   __builtin_amdgcn_global_load_lds((gbl_ptr_t)(g + 1024), (lds_ptr_t)(dst + 1024), 16, 0, 0);
-  w.fill_slot = w.fill_slot + 1 == FM_RING ? 0 : w.fill_slot + 1;
+  w.fill_slot = w.fill_slot + 1 == RING ? 0 : w.fill_slot + 1;
   w.fill_chunk = w.fill_chunk + 1 == w.n_chunks ? 0 : w.fill_chunk + 1;
 }
 
 // chunk boundary: the chunk about to be read has landed for every wave, the chunk just finished is free for the DMA.
-// vmcnt(2 (FM_RING - 2)): of this wave's pieces only those of the FM_RING - 2 youngest chunks may still be in flight, i.e. the
+// vmcnt(2 (RING - 2)): of this wave's pieces only those of the RING - 2 youngest chunks may still be in flight, i.e. the
 // pieces of the chunk we are about to read are in LDS (loads retire in order; other loads / stores in flight only make the wait
 // stricter).  lgkmcnt(0): this wave's fragment reads of the finished chunk have returned.  The barrier then (a) extends the first
 // fact to the other waves' pieces and (b) the second to the other waves' reads of the slot that is refilled right after it.
 // One volatile asm with a memory clobber: no LDS access of the compiler's may move across it.
-__device__ __forceinline__ void ws_advance(WStream& w, char* smem) {
-  #ifndef FM_EXTRA_VM
+#ifndef FM_EXTRA_VM
 #define FM_EXTRA_VM 0
 #endif
-  asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(2 * (FM_RING - 2) + FM_EXTRA_VM) : "memory");
-  ws_issue(w, smem);                                    // chunk g + FM_RING - 1 into the slot chunk g - 1 occupied
-  w.slot_off = w.slot_off + FM_SLOT == FM_RING * FM_SLOT ? 0 : w.slot_off + FM_SLOT;
+template <int RING>
+__device__ __forceinline__ void ws_advance(WStream& w, char* smem) {
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(2 * (RING - 2) + FM_EXTRA_VM) : "memory");
+  ws_issue<RING>(w, smem);                              // chunk g + RING - 1 into the slot chunk g - 1 occupied
+  w.slot_off = w.slot_off + FM_SLOT == RING * FM_SLOT ? 0 : w.slot_off + FM_SLOT;
 }
 
 // ---- building blocks -----------------------------------------------------------------------------------------------------------
-struct Ctx {
+template <int RING>
+struct CtxT {
+  static constexpr int ring = RING;   // slots of the weight ring: FM_RING for the 256-wide networks, fewer where the LDS is needed elsewhere
   char* smem;
   WStream ws;
   const char* frag_base;   // ring + lane * 16
   const char* bias_lds;    // bias table + (lane >> 5) * 16
   bf16x8 q[FM_LOOK];       // the next FM_LOOK fragments, already on their way from LDS
 };
+typedef CtxT<FM_RING> Ctx;
 
 // Next weight fragment (A operand: 32 outputs x 16 reduction indices).  The ds_read of fragment F + FM_LOOK is issued when fragment
 // F is handed out, so FM_LOOK - 1 MFMAs (and the partner wave's) cover the LDS latency; the queue runs across blocks, layers and
 // tiles (the stream is one sequence).  The chunk boundary is taken when the READ-AHEAD crosses it.  F (the fragment's position in
 // the network pass) and every index derived from it are template arguments: nothing here depends on the optimiser proving a
 // counter constant.
-template <int F>
-__device__ __forceinline__ bf16x8 next_frag(Ctx& c) {
+template <int F, typename C>
+__device__ __forceinline__ bf16x8 next_frag(C& c) {
   const bf16x8 w = c.q[F % FM_LOOK];
   constexpr int G = F + FM_LOOK;
-  if constexpr ((G % FM_CHUNK) == 0) ws_advance(c.ws, c.smem);
+  if constexpr ((G % FM_CHUNK) == 0) ws_advance<C::ring>(c.ws, c.smem);
   c.q[F % FM_LOOK] = *(const bf16x8*)(c.frag_base + c.ws.slot_off + (G % FM_CHUNK) * 1024);
   return w;
 }
 
 // accumulator of the 32-output block B of the pass, initialised with its bias: lane (row, half) owns outputs 8 q + 4 half + e
-template <int B>
-__device__ __forceinline__ f32x16 acc_init(const Ctx& c) {
+template <int B, typename C>
+__device__ __forceinline__ f32x16 acc_init(const C& c) {
   f32x16 acc;
   const char* a = c.bias_lds + B * 128;
 #pragma unroll
@@ -137,12 +142,12 @@ __device__ __forceinline__ f32x16 acc_init(const Ctx& c) {
   return acc;
 }
 
-template <int F, int NK, int... I>
-__device__ __forceinline__ void mac_seq(Ctx& c, f32x16& acc, const bf16x8 (&in)[NK], std::integer_sequence<int, I...>) {
+template <int F, int NK, int... I, typename C>
+__device__ __forceinline__ void mac_seq(C& c, f32x16& acc, const bf16x8 (&in)[NK], std::integer_sequence<int, I...>) {
   ((acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(next_frag<F + I>(c), in[I], acc, 0, 0, 0)), ...);
 }
-template <int F, int NK>
-__device__ __forceinline__ void mac(Ctx& c, f32x16& acc, const bf16x8 (&in)[NK]) {
+template <int F, int NK, typename C>
+__device__ __forceinline__ void mac(C& c, f32x16& acc, const bf16x8 (&in)[NK]) {
   mac_seq<F, NK>(c, acc, in, std::make_integer_sequence<int, NK>{});
 }
 
@@ -187,6 +192,7 @@ struct StoreTo {
   long row0, M;              // first row of this wave's 32-row block (wave-uniform), rows of the launch
   char* slab;                // this wave's 4 KiB of LDS
   int lane;
+  int ncg;                   // 64-column groups of the layer (its width / 64): row length of the bit-mask block grid
 };
 
 template <bool BITS, int J>
@@ -234,14 +240,14 @@ __device__ __forceinline__ void store_block(const StoreTo& st, const bf16x8& lo,
         }
       }
     }
-    if constexpr (BITS) st.bits[((st.row0 >> 5) * 4 + (J >> 1)) * 64 + st.lane] = mw;   // 256 contiguous bytes per wave; rows >= M: zeros
+    if constexpr (BITS) st.bits[((st.row0 >> 5) * st.ncg + (J >> 1)) * 64 + st.lane] = mw;   // 256 contiguous bytes per wave; rows >= M: zeros
   }
 }
 
 // One layer: out[32 NB] = act(W . [in0 | in1] + b) -- NB blocks of 32 outputs over one or two input segments (skip connections and
 // concatenations are never formed).  F = first fragment, B = first bias block of the layer within the pass.
-template <int F, int B, int NK0, int NK1, bool RELU, bool STORE, bool BITS, int J, bool MORE>
-__device__ __forceinline__ void dense_block(Ctx& c, f32x16& acc, const bf16x8 (&in0)[NK0], const bf16x8 (&in1)[NK1 > 0 ? NK1 : 1], bf16x8& lo,
+template <int F, int B, int NK0, int NK1, bool RELU, bool STORE, bool BITS, int J, bool MORE, typename C>
+__device__ __forceinline__ void dense_block(C& c, f32x16& acc, const bf16x8 (&in0)[NK0], const bf16x8 (&in1)[NK1 > 0 ? NK1 : 1], bf16x8& lo,
                                             bf16x8& hi, const StoreTo& st) {
   mac<F, NK0>(c, acc, in0);
   if constexpr (NK1 > 0) mac<F + NK0, NK1>(c, acc, in1);
@@ -251,22 +257,22 @@ __device__ __forceinline__ void dense_block(Ctx& c, f32x16& acc, const bf16x8 (&
   // accumulator registers are then live across the store path of a kernel that already sits at the 256-register limit)
   if constexpr (MORE) acc = acc_init<B + 1>(c);
 }
-template <int F, int B, int NK0, int NK1, int NB, bool RELU, bool STORE, int... J>
-__device__ __forceinline__ void dense_seq(Ctx& c, const bf16x8 (&in0)[NK0], const bf16x8 (&in1)[NK1 > 0 ? NK1 : 1], bf16x8 (&out)[2 * NB],
+template <int F, int B, int NK0, int NK1, int NB, bool RELU, bool STORE, bool BITS, int... J, typename C>
+__device__ __forceinline__ void dense_seq(C& c, const bf16x8 (&in0)[NK0], const bf16x8 (&in1)[NK1 > 0 ? NK1 : 1], bf16x8 (&out)[2 * NB],
                                           const StoreTo& st, std::integer_sequence<int, J...>) {
   static_assert(NB % 2 == 0, "the training stores work on pairs of blocks");
-  // the bit masks exist for the 256-wide ReLU layers (the mask layout's column groups are those of N = 256)
   f32x16 acc = acc_init<B>(c);
-  (dense_block<F + J * (NK0 + NK1), B + J, NK0, NK1, RELU, STORE, STORE && RELU && NB == 8, J, (J + 1 < NB)>(c, acc, in0, in1, out[2 * J], out[2 * J + 1], st), ...);
+  (dense_block<F + J * (NK0 + NK1), B + J, NK0, NK1, RELU, STORE, BITS, J, (J + 1 < NB)>(c, acc, in0, in1, out[2 * J], out[2 * J + 1], st), ...);
 }
-template <int F, int B, int NK, int NB, bool RELU, bool STORE = false>
-__device__ __forceinline__ void dense(Ctx& c, const bf16x8 (&in)[NK], bf16x8 (&out)[2 * NB], const StoreTo& st = StoreTo{}) {
+// BITS (training stores): the ReLU bit masks; by default for the 256-wide ReLU layers (st.ncg = 4), explicitly for the colour head's
+template <int F, int B, int NK, int NB, bool RELU, bool STORE = false, bool BITS = (STORE && RELU && NB == 8), typename C>
+__device__ __forceinline__ void dense(C& c, const bf16x8 (&in)[NK], bf16x8 (&out)[2 * NB], const StoreTo& st = StoreTo{}) {
   const bf16x8 none[1] = {};
-  dense_seq<F, B, NK, 0, NB, RELU, STORE>(c, in, none, out, st, std::make_integer_sequence<int, NB>{});
+  dense_seq<F, B, NK, 0, NB, RELU, STORE, BITS>(c, in, none, out, st, std::make_integer_sequence<int, NB>{});
 }
-template <int F, int B, int NK0, int NK1, int NB, bool RELU, bool STORE = false>
-__device__ __forceinline__ void dense2(Ctx& c, const bf16x8 (&in0)[NK0], const bf16x8 (&in1)[NK1], bf16x8 (&out)[2 * NB], const StoreTo& st = StoreTo{}) {
-  dense_seq<F, B, NK0, NK1, NB, RELU, STORE>(c, in0, in1, out, st, std::make_integer_sequence<int, NB>{});
+template <int F, int B, int NK0, int NK1, int NB, bool RELU, bool STORE = false, bool BITS = (STORE && RELU && NB == 8), typename C>
+__device__ __forceinline__ void dense2(C& c, const bf16x8 (&in0)[NK0], const bf16x8 (&in1)[NK1], bf16x8 (&out)[2 * NB], const StoreTo& st = StoreTo{}) {
+  dense_seq<F, B, NK0, NK1, NB, RELU, STORE, BITS>(c, in0, in1, out, st, std::make_integer_sequence<int, NB>{});
 }
 
 // input fragments straight from HBM: lane (row, half) reads the 16 bytes [16 s + 8 half, +8) of its row (natural k order)
@@ -347,6 +353,38 @@ __device__ __forceinline__ ClassicInputs classic_embed_inputs(const float* pp, c
   return r;
 }
 
+// kernel prologue shared by the fused kernels: stream state, biases into LDS, the first chunks into the ring, the fragment queue
+template <typename C>
+__device__ __forceinline__ void ctx_start(C& c, char* smem, const char* wstream, int n_chunks, const float* bias, int n_blocks, int tid,
+                                          int wave, int lane) {
+  constexpr int RING = C::ring;
+  float* bias_tab = (float*)(smem + RING * FM_SLOT);
+  c.smem = smem;
+  c.ws.src = wstream + wave * 2048 + lane * 16;
+  c.ws.ring = (unsigned)(size_t)smem;
+  c.ws.my_piece = wave * 2048;
+  c.ws.slot_off = (RING - 1) * FM_SLOT;                 // "chunk -1": the first boundary advances to slot 0
+  c.ws.fill_slot = 0;
+  c.ws.fill_chunk = 0;
+  c.ws.n_chunks = n_chunks;
+  c.frag_base = smem + lane * 16;
+  c.bias_lds = (const char*)bias_tab + (lane >> 5) * 16;
+
+  // prologue: biases into LDS (plain stores), the first RING - 1 chunks of the stream into the ring
+  for (int i = tid; i < n_blocks * 32; i += 64 * FM_WAVES) bias_tab[i] = bias[i];
+#pragma unroll
+  for (int i = 0; i < RING - 1; ++i) ws_issue<RING>(c.ws, smem);
+#ifdef FMLP_LOCKSTEP_START
+  // debug builds (tools/stress_fmlp_variants.py): every DMA of the prologue landed and all eight waves leave it in the same cycle --
+  // the start that exposed the timing-dependent operand hazard described at to_frags within a handful of launches
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+  // first boundary: chunk 0 has landed for everybody (and the bias stores are visible); start the fragment queue
+  ws_advance<RING>(c.ws, smem);
+#pragma unroll
+  for (int i = 0; i < FM_LOOK; ++i) c.q[i] = *(const bf16x8*)(c.frag_base + c.ws.slot_off + i * 1024);
+}
+
 // 8 x 4 + 4 x 128 + 160 + 2 x 128 (trunk) + 16 (alpha) + 128 (feature) + 72 (views) + 8 (rgb) fragments; 64 + 1 + 8 + 4 + 1 blocks
 #define FMLP_CLASSIC_FRAGS 1184
 #define FMLP_CLASSIC_BLOCKS 78
@@ -359,33 +397,9 @@ __global__ __launch_bounds__(64 * FM_WAVES, 2) void fmlp_kernel(FmlpArgs a) {   
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5;
-  float* bias_tab = (float*)(smem + FM_RING * FM_SLOT);
 
   Ctx c;
-  c.smem = smem;
-  c.ws.src = a.wstream + wave * 2048 + lane * 16;
-  c.ws.ring = (unsigned)(size_t)smem;
-  c.ws.my_piece = wave * 2048;
-  c.ws.slot_off = (FM_RING - 1) * FM_SLOT;              // "chunk -1": the first boundary advances to slot 0
-  c.ws.fill_slot = 0;
-  c.ws.fill_chunk = 0;
-  c.ws.n_chunks = a.n_chunks;
-  c.frag_base = smem + lane * 16;
-  c.bias_lds = (const char*)bias_tab + half * 16;
-
-  // prologue: biases into LDS (plain stores), the first FM_RING - 1 chunks of the stream into the ring
-  for (int i = tid; i < a.n_blocks * 32; i += 64 * FM_WAVES) bias_tab[i] = a.bias[i];
-#pragma unroll
-  for (int i = 0; i < FM_RING - 1; ++i) ws_issue(c.ws, smem);
-#ifdef FMLP_LOCKSTEP_START
-  // debug builds (tools/stress_fmlp_variants.py): every DMA of the prologue landed and all eight waves leave it in the same cycle --
-  // the start that exposed the timing-dependent operand hazard described at to_frags within a handful of launches
-  asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
-  // first boundary: chunk 0 has landed for everybody (and the bias stores are visible); start the fragment queue
-  ws_advance(c.ws, smem);
-#pragma unroll
-  for (int i = 0; i < FM_LOOK; ++i) c.q[i] = *(const bf16x8*)(c.frag_base + c.ws.slot_off + i * 1024);
+  ctx_start(c, smem, a.wstream, a.n_chunks, a.bias, a.n_blocks, tid, wave, lane);
 
   for (int tile = blockIdx.x; tile < a.tiles; tile += gridDim.x) {
     long row = (long)tile * FM_TILE_ROWS + wave * 32 + (lane & 31);
@@ -407,7 +421,7 @@ __global__ __launch_bounds__(64 * FM_WAVES, 2) void fmlp_kernel(FmlpArgs a) {   
       constexpr int F1 = 8 * 4, F2 = F1 + 128, F3 = F2 + 128, F4 = F3 + 128, F5 = F4 + 128, F6 = F5 + 8 * 20, F7 = F6 + 128;
       constexpr int FA = F7 + 128, FF = FA + 16, FV = FF + 128, FR = FV + 4 * 18;
       static_assert(FR + 8 == FMLP_CLASSIC_FRAGS, "classic network: fragment count");
-      auto to = [&](int i) { return StoreTo{a.act[i], a.act_ld[i], i < 8 ? a.bits[i] : nullptr, (long)tile * FM_TILE_ROWS + wave * 32, a.M, smem + FM_RING * FM_SLOT + FM_BIAS_MAX * 128 + wave * 4096, lane}; };
+      auto to = [&](int i) { return StoreTo{a.act[i], a.act_ld[i], i < 8 ? a.bits[i] : nullptr, (long)tile * FM_TILE_ROWS + wave * 32, a.M, smem + FM_RING * FM_SLOT + FM_BIAS_MAX * 128 + wave * 4096, lane, 4}; };
       dense<0, 0, 4, 8, true, STORE>(c, e, p, to(0));             // pts_linears.0
       dense<F1, 8, 16, 8, true, STORE>(c, p, q, to(1));           // .1
       dense<F2, 16, 16, 8, true, STORE>(c, q, p, to(2));          // .2
@@ -431,7 +445,7 @@ __global__ __launch_bounds__(64 * FM_WAVES, 2) void fmlp_kernel(FmlpArgs a) {   
     } else {
       bf16x8 e[6], p[16], q[16];
       load_rows<6>(a.E, a.ldE, row, half, e);
-      auto to = [&](int i) { return StoreTo{a.act[i], a.act_ld[i], i < 8 ? a.bits[i] : nullptr, (long)tile * FM_TILE_ROWS + wave * 32, a.M, smem + FM_RING * FM_SLOT + FM_BIAS_MAX * 128 + wave * 4096, lane}; };
+      auto to = [&](int i) { return StoreTo{a.act[i], a.act_ld[i], i < 8 ? a.bits[i] : nullptr, (long)tile * FM_TILE_ROWS + wave * 32, a.M, smem + FM_RING * FM_SLOT + FM_BIAS_MAX * 128 + wave * 4096, lane, 4}; };
       dense<0, 0, 6, 8, true, STORE>(c, e, p, to(0));             // layers.0
       dense<48, 8, 16, 8, true, STORE>(c, p, q, to(1));
       dense<48 + 128, 16, 16, 8, true, STORE>(c, q, p, to(2));
@@ -444,6 +458,308 @@ __global__ __launch_bounds__(64 * FM_WAVES, 2) void fmlp_kernel(FmlpArgs a) {   
     // chunk boundary again -- and the queue already holds its first FM_LOOK fragments
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the read-ahead before the LDS is released
+}
+
+// =================================================================================================================================
+// Colour head of the live mip path's NeRF MLP (s-nerf/model/models.py:283-296): cat([bottleneck, view encoding]) (1024 + 27) ->
+// 3 x [Linear 128 + ReLU] -> Linear 3.  As four GEMM launches forward and eight backward these 128-wide layers are HBM- or
+// epilogue-bound (round 2: 0.48 ms forward, 0.81 ms data gradients per 524 288 rows).  Fused:
+//   * forward (fcolour_fwd_kernel): the first layer runs K-MAJOR -- four accumulators (128 outputs) live, the [bottleneck | view
+//     encoding] row streamed ONCE from HBM as B fragments (16 bytes per lane and k-step, fetched four k-steps = one 128-byte line per
+//     row at a time, two to three lines ahead), its weights streamed in (k-step, block) order; the two 128 x 128 layers and the rgb
+//     head continue from the accumulator registers like every other fused layer.  Training stores the three hidden activations and
+//     their ReLU bit masks (standard block layout, 2 column groups).
+//   * backward (fcolour_bwd_kernel): d raw_rgb -> dC2 -> dC1 -> dC0 -> d bottleneck, the "weights x activations" chain on the
+//     TRANSPOSED weights, every ReLU mask applied from the bit masks (sign-extended 1-bit fields ANDed onto the fp32 accumulators),
+//     the four bias gradients reduced over the 32 rows of a wave by a register butterfly (DPP mirrors / quad permutes inside the
+//     16-lane rows, one ds_swizzle across them: 47 instructions per 32 columns) and carried in one register per block across the tiles of a
+//     workgroup; dC2, dC1, dC0 (the weight-gradient GEMMs read them) and d bottleneck leave through the transposition slabs.
+// Bound: HBM (forward reads the 2176-byte rows once: 1.14 GB per 524 288 rows; backward writes 1.07 GB + 0.4 GB).
+#define FC_NK0 66                                   // k-steps of cond_layers.0: 1024 bottleneck columns + 32 (27 view-encoding columns + zeros)
+#define FC_FWD_FRAGS (4 * FC_NK0 + 32 + 32 + 8)     // 336 = 21 chunks
+#define FC_FWD_BLOCKS 13                            // 4 + 4 + 4 + 1 bias blocks
+#define FC_QD 12                                    // input fragments in flight (three 128-byte lines per row)
+#define FC_BWD_FRAGS 336                            // 4 (rgb^T) + 32 + 32 + 256 (cond_layers.0^T, bottleneck columns) + 12 padding
+#define FC_BWD_COLS 1408                            // 3 x 128 + 1024 bias-gradient columns
+
+struct ColourFwdArgs {
+  const __bf16* CB; long ldCB;        // [M, >= 1056] = [bottleneck 1024 | view encoding 27 | zeros]
+  const char* wstream; const float* bias;
+  float* raw_rgb;                     // [M, 3]
+  __bf16* act[3]; long act_ld[3];     // training: outputs of cond_layers.0 .. .2 ([M, >= 128] bf16)
+  unsigned* bits[3];                  // ... and their ReLU bit masks
+  long M;
+  int tiles, n_chunks, n_blocks;
+};
+
+template <int F, int NB, int S, int... J, typename C>
+__device__ __forceinline__ void kmajor_mfma(C& c, f32x16 (&acc)[NB], const bf16x8& in, std::integer_sequence<int, J...>) {
+  ((acc[J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(next_frag<F + S * NB + J>(c), in, acc[J], 0, 0, 0)), ...);
+}
+// The input fragments are fetched by inline-asm loads the compiler does not track, and waited for with counted s_waitcnt: with the
+// weight stream's `global_load_lds` pending, hipcc answers any vector-memory dependency of its own with s_waitcnt vmcnt(0) (an LDS-DMA is
+// a FLAT operation that touches both memories; on gfx9 a pending one forces every wait to zero) -- measured on the first version of this
+// kernel: one full drain of the input read-ahead AND of the weight stream every third line.
+template <int NK, int QD, int K>
+__device__ __forceinline__ void kmajor_fetch(bf16x8 (&q)[QD], const __bf16* src) {
+  if constexpr (K < NK) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(q[K % QD]) : "v"(src), "n"(32 * K) : "memory");
+}
+__device__ __forceinline__ constexpr int kmajor_cnt(int a, int b, int nk) { return (b < nk ? b : nk) - (a < nk ? a : nk); }
+// vector-memory operations issued after the loads of line L (k-steps 4 L .. 4 L + 3) and before its first use at k-step 4 L: the two
+// lines fetched after it, and two DMA pieces per chunk boundary in between (a boundary falls in front of every k-step S = 3 mod 4 of
+// a 4-block k-major layer that starts on a chunk boundary: fragment 4 S + FM_LOOK is a multiple of FM_CHUNK).  "At most that many
+// outstanding" therefore means line L has landed (loads retire in order).
+__device__ __forceinline__ constexpr int kmajor_younger(int L, int nk) {
+  return kmajor_cnt(4 * L + 4, 4 * L + 8, nk) + kmajor_cnt(4 * L + 8, 4 * L + 12, nk) + 2 * (L < 2 ? L : 2);
+}
+template <int F, int NB, int NK, int QD, int S, typename C>
+__device__ __forceinline__ void kmajor_one(C& c, f32x16 (&acc)[NB], bf16x8 (&q)[QD], const __bf16* src) {
+  static_assert(NB == 4 && QD == 12 && FM_LOOK == 4 && FM_CHUNK == 16 && F % FM_CHUNK == 0, "the wait counts below assume this geometry");
+  if constexpr (S % 4 == 0) {
+    if constexpr (S >= 4) {                             // the line consumed last (k-steps S - 4 .. S - 1) is free: fetch the line QD - 4 ahead
+      kmajor_fetch<NK, QD, S + QD - 4>(q, src); kmajor_fetch<NK, QD, S + QD - 3>(q, src);
+      kmajor_fetch<NK, QD, S + QD - 2>(q, src); kmajor_fetch<NK, QD, S + QD - 1>(q, src);
+    }
+    // (the four registers are operands of the wait, so that no use of them can be scheduled in front of it)
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(q[S % QD]), "+v"(q[S % QD + 1]), "+v"(q[S % QD + 2]), "+v"(q[S % QD + 3]) : "n"(kmajor_younger(S / 4, NK)));
+  }
+  kmajor_mfma<F, NB, S>(c, acc, q[S % QD], std::make_integer_sequence<int, NB>{});
+}
+template <int F, int NB, int NK, int QD, typename C, int... S>
+__device__ __forceinline__ void kmajor_seq(C& c, f32x16 (&acc)[NB], bf16x8 (&q)[QD], const __bf16* src, std::integer_sequence<int, S...>) {
+  (kmajor_one<F, NB, NK, QD, S>(c, acc, q, src), ...);
+}
+template <int NK, int QD, int... K>
+__device__ __forceinline__ void kmajor_prefetch(bf16x8 (&q)[QD], const __bf16* src, std::integer_sequence<int, K...>) {
+  (kmajor_fetch<NK, QD, K>(q, src), ...);
+}
+
+template <bool STORE>
+__global__ __launch_bounds__(64 * FM_WAVES, 2) void fcolour_fwd_kernel(ColourFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5;
+  Ctx c;
+  ctx_start(c, smem, a.wstream, a.n_chunks, a.bias, a.n_blocks, tid, wave, lane);
+  char* const slab = smem + FM_RING * FM_SLOT + FM_BIAS_MAX * 128 + wave * 4096;
+
+  for (int tile = blockIdx.x; tile < a.tiles; tile += gridDim.x) {
+    long row = (long)tile * FM_TILE_ROWS + wave * 32 + (lane & 31);
+    const bool row_ok = row < a.M;
+    row = row_ok ? row : a.M - 1;                       // tail rows: compute on a valid row, store nothing
+    const __bf16* src = a.CB + row * a.ldCB + half * 8;
+    bf16x8 qin[FC_QD];
+    kmajor_prefetch<FC_NK0, FC_QD>(qin, src, std::make_integer_sequence<int, FC_QD>{});
+    f32x16 acc[4] = {acc_init<0>(c), acc_init<1>(c), acc_init<2>(c), acc_init<3>(c)};
+    kmajor_seq<0, 4, FC_NK0, FC_QD>(c, acc, qin, src, std::make_integer_sequence<int, FC_NK0>{});
+    auto to = [&](int i) { return StoreTo{a.act[i], a.act_ld[i], a.bits[i], (long)tile * FM_TILE_ROWS + wave * 32, a.M, slab, lane, 2}; };
+    bf16x8 p[8], q[8];
+    to_frags<true>(acc[0], p[0], p[1]);
+    if constexpr (STORE) store_block<true, 0>(to(0), p[0], p[1]);
+    to_frags<true>(acc[1], p[2], p[3]);
+    if constexpr (STORE) store_block<true, 1>(to(0), p[2], p[3]);
+    to_frags<true>(acc[2], p[4], p[5]);
+    if constexpr (STORE) store_block<true, 2>(to(0), p[4], p[5]);
+    to_frags<true>(acc[3], p[6], p[7]);
+    if constexpr (STORE) store_block<true, 3>(to(0), p[6], p[7]);
+    constexpr int F1 = 4 * FC_NK0, F2 = F1 + 32, FR = F2 + 32;
+    static_assert(FR + 8 == FC_FWD_FRAGS, "colour head: fragment count");
+    dense<F1, 4, 8, 4, true, STORE, STORE>(c, p, q, to(1));        // cond_layers.1
+    dense<F2, 8, 8, 4, true, STORE, STORE>(c, q, p, to(2));        // cond_layers.2
+    f32x16 rgb = acc_init<12>(c);                                  // rgb_layer: outputs 0..2
+    mac<FR, 8>(c, rgb, p);
+    if (row_ok && half == 0) {
+      float* o = a.raw_rgb + row * 3;
+      o[0] = rgb[0]; o[1] = rgb[1]; o[2] = rgb[2];
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the read-ahead before the LDS is released
+}
+
+struct ColourBwdArgs {
+  const float* d_rgb;                 // [M, 3] fp32: d loss / d raw_rgb
+  const char* wstream;                // transposed weights: rgb_layer^T, cond_layers.2^T, .1^T, .0^T (bottleneck columns)
+  const unsigned* bits[4];            // ReLU bit masks of cond_layers.2, .1, .0 (2 column groups) and of the bottleneck (16)
+  __bf16* dC[3]; long dC_ld[3];       // d pre-activation of cond_layers.2, .1, .0 ([M, >= 128] bf16), read by the weight-gradient GEMMs
+  __bf16* dB; long dB_ld;             // d pre-activation of the bottleneck layer [M, >= 1024]
+  float* colsum_ws;                   // [gridDim.x * FM_WAVES, FC_BWD_COLS]: per-wave bias-gradient partials
+  long M;
+  int tiles, n_chunks;
+};
+
+// sum over the 32 rows (lanes 0..31 / 32..63 separately) of a 32 x 32 accumulator block; lane L ends up with the sum of register
+// r = L & 15, i.e. of output column (r & 3) + 8 (r >> 2) + 4 (L >> 5) of the block (lanes L and L ^ 16 hold the same sum).  A reduce-
+// scatter butterfly inside the 16-lane rows -- every step halves the registers a lane still carries: it keeps the half its lane bit
+// selects and adds the partner's copy of that half (DPP row_mirror / row_half_mirror / quad permutes: 45 instructions) -- and one
+// ds_swizzle (lane ^ 16) for the two rows.  (v_permlane16_swap would take the row bit first at half the cost, but hipcc 7.2 returns
+// the first result of __builtin_amdgcn_permlane16_swap for BOTH members of its result pair: tools/probes/rows_sum_probe.hip.)
+#define FC_DPP_ADD(keep, send, ctrl) ((keep) + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (send)), (ctrl), 0xf, 0xf, true)))
+// one reduce-scatter exchange: the lane keeps x (bit clear) or y (bit set) and adds the partner's copy of the same register
+#define FC_RS(x, y, bit, ctrl) FC_DPP_ADD((bit) ? (y) : (x), (bit) ? (x) : (y), ctrl)
+__device__ __forceinline__ float rows_sum(const f32x16& a, int lane) {
+  const bool k3 = (lane & 8) != 0, k2 = (lane & 4) != 0, k1 = (lane & 2) != 0, k0 = (lane & 1) != 0;
+  // (literal register indices: with a loop index hipcc expands every vector element access into a 16-way select chain)
+  const float b0 = FC_RS(a[0], a[8], k3, 0x140), b1 = FC_RS(a[1], a[9], k3, 0x140), b2 = FC_RS(a[2], a[10], k3, 0x140), b3 = FC_RS(a[3], a[11], k3, 0x140);   // lane bit 3:
+  const float b4 = FC_RS(a[4], a[12], k3, 0x140), b5 = FC_RS(a[5], a[13], k3, 0x140), b6 = FC_RS(a[6], a[14], k3, 0x140), b7 = FC_RS(a[7], a[15], k3, 0x140); // row_mirror (15 - p)
+  const float c0 = FC_RS(b0, b4, k2, 0x141), c1 = FC_RS(b1, b5, k2, 0x141), c2 = FC_RS(b2, b6, k2, 0x141), c3 = FC_RS(b3, b7, k2, 0x141);   // lane bit 2: row_half_mirror (7 - p)
+  const float d0 = FC_RS(c0, c2, k1, 0x4E), d1 = FC_RS(c1, c3, k1, 0x4E);                  // lane bit 1: quad_perm [2,3,0,1]
+  const float e = FC_RS(d0, d1, k0, 0xB1);                                                // lane bit 0: quad_perm [1,0,3,2]
+  // the other 16-lane row of this half: ds_swizzle, bit mode (and 0x1f, or 0, xor 0x10)
+  return e + __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, e), 0x401F));
+}
+
+// one 32-output block of a backward layer: acc = W^T-block . in, ReLU mask from the wave's LDS copy of the layer's bit-mask blocks
+// (`mk`: [64-column group][64 words]), bias-gradient partial, bf16 fragments, store through the slab (pairs of blocks)
+template <int F, int NK, int J, int CS, typename C>
+__device__ __forceinline__ void bwd_block(C& c, const bf16x8 (&in)[NK], const char* mk, int lane, int sh, bool row_ok,
+                                          float (&cs)[FC_BWD_COLS / 64], bf16x8& lo, bf16x8& hi, const StoreTo& st) {
+  // this lane's 16 mask bits: words (row & 7) * 8 + 4 (J & 1) + q, q = 0..3, of column group J >> 1; byte row >> 3, nibble lane >> 5
+  const fm_u32x4 w = *(const fm_u32x4*)(mk + ((J >> 1) * 64 + (lane & 7) * 8 + 4 * (J & 1)) * 4);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  mac<F, NK>(c, acc, in);
+  // (literal register indices, as in rows_sum)
+#define FC_MASK1(R, NQ, E) { const float v = acc[R]; acc[R] = __builtin_bit_cast(float, __builtin_bit_cast(int, v) & __builtin_amdgcn_sbfe(NQ, E, 1)); }
+#define FC_MASK4(Q) { const unsigned wq = w[Q]; const int nq = row_ok ? (int)(wq >> sh) : 0;   /* rows past the end contribute nothing */ \
+                      FC_MASK1(4 * Q + 0, nq, 0) FC_MASK1(4 * Q + 1, nq, 1) FC_MASK1(4 * Q + 2, nq, 2) FC_MASK1(4 * Q + 3, nq, 3) }
+  FC_MASK4(0) FC_MASK4(1) FC_MASK4(2) FC_MASK4(3)
+  // lanes L and L ^ 16 hold the same sum: the 16-lane rows of a half take turns (even blocks: row 0, odd blocks: row 1), so that one
+  // register carries TWO blocks' partials across the tiles (44 registers would not fit beside the fragments)
+  const float rs = rows_sum(acc, lane);
+  cs[CS >> 1] += (((lane >> 4) & 1) == (CS & 1)) ? rs : 0.f;
+  to_frags<false>(acc, lo, hi);
+  store_block<false, J>(st, lo, hi);
+}
+template <int F, int NK, int CS0, int NB, typename C, int... J>
+__device__ __forceinline__ void bwd_layer_seq(C& c, const bf16x8 (&in)[NK], const char* mk, int lane, int sh, bool row_ok,
+                                              float (&cs)[FC_BWD_COLS / 64], bf16x8 (&out)[2 * NB], const StoreTo& st, std::integer_sequence<int, J...>) {
+  (bwd_block<F + J * NK, NK, J, CS0 + J>(c, in, mk, lane, sh, row_ok, cs, out[2 * J], out[2 * J + 1], st), ...);
+}
+template <int F, int NK, int CS0, int NB, typename C>
+__device__ __forceinline__ void bwd_layer(C& c, const bf16x8 (&in)[NK], const char* mk, int lane, int sh, bool row_ok,
+                                          float (&cs)[FC_BWD_COLS / 64], bf16x8 (&out)[2 * NB], const StoreTo& st) {
+  bwd_layer_seq<F, NK, CS0, NB>(c, in, mk, lane, sh, row_ok, cs, out, st, std::make_integer_sequence<int, NB>{});
+}
+// the wide last layer: the fragments are not needed again
+template <int F, int NK, int CS0, typename C, int... J>
+__device__ __forceinline__ void bwd_last_seq(C& c, const bf16x8 (&in)[NK], const char* mk, int lane, int sh, bool row_ok,
+                                             float (&cs)[FC_BWD_COLS / 64], const StoreTo& st, std::integer_sequence<int, J...>) {
+  bf16x8 lo, hi;
+  (bwd_block<F + J * NK, NK, J, CS0 + J>(c, in, mk, lane, sh, row_ok, cs, lo, hi, st), ...);
+}
+template <int F, int N, typename C, int... I>
+__device__ __forceinline__ void skip_frags(C& c, std::integer_sequence<int, I...>) {
+  ((void)next_frag<F + I>(c), ...);
+}
+
+// LDS of the backward kernel: [weight ring, FC_BWD_RING slots][8 transposition slabs][8 x FC_MASK_BYTES: per wave the bottleneck's
+// bit masks of its 32 rows (4 KiB), those of cond_layers.2 / .1 / .0 (512 B each) and its 32 rows of d raw_rgb (384 B)].
+// Everything a tile reads from memory arrives by LDS-DMA one tile ahead, so that the loop holds NO vector-memory load the compiler
+// tracks: with the weight stream's `global_load_lds` pending, hipcc answers any such dependency with s_waitcnt vmcnt(0) -- a full
+// drain that also waits for the acknowledgement of every row store just issued (first version of this kernel, one drain per pair of
+// blocks: 620-675 us per 524 288 rows).
+#define FC_BWD_RING 5
+#define FC_MASK_BYTES 6144
+#define FC_BWD_LDS (FC_BWD_RING * FM_SLOT + FM_WAVES * 4096 + FM_WAVES * FC_MASK_BYTES)
+
+__global__ __launch_bounds__(64 * FM_WAVES, 2) void fcolour_bwd_kernel(ColourBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5;
+  char* const slab = smem + FC_BWD_RING * FM_SLOT + wave * 4096;
+  char* const mk = smem + FC_BWD_RING * FM_SLOT + FM_WAVES * 4096 + wave * FC_MASK_BYTES;
+  const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)a.d_rgb, 0, (int)(a.M * 12), 0x00020000);   // rows >= M read as zeros
+  // the bottleneck's masks of the wave's 32 rows: 16 column groups x 256 B, contiguous
+  auto dma_wide = [&](long row0, int lane) __attribute__((always_inline)) {
+    const char* g = (const char*)(a.bits[3] + (row0 >> 5) * (16 * 64)) + lane * 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) __builtin_amdgcn_global_load_lds((gbl_ptr_t)(g + i * 1024), (lds_ptr_t)(mk + i * 1024), 16, 0, 0);
+  };
+  // the three narrow layers' masks (2 column groups = 512 B each: lanes 0..31) and d raw_rgb (32 rows x 12 B: lanes 0..23)
+  auto dma_narrow = [&](long row0, int lane) __attribute__((always_inline)) {
+    if (lane < 32) {
+#pragma unroll
+      for (int l = 0; l < 3; ++l)
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)((const char*)(a.bits[l] + (row0 >> 5) * (2 * 64)) + lane * 16), (lds_ptr_t)(mk + 4096 + l * 512), 16, 0, 0);
+    }
+    if (lane < 24) __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_ptr_t)(mk + 5632), 16, lane * 16, (int)(row0 * 12), 0, 0);
+  };
+  {
+    const long row0 = (long)blockIdx.x * FM_TILE_ROWS + wave * 32;    // (the launch has gridDim.x <= tiles)
+    dma_wide(row0, lane);
+    dma_narrow(row0, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  CtxT<FC_BWD_RING> c;
+  ctx_start(c, smem, a.wstream, a.n_chunks, nullptr, 0, tid, wave, lane);
+  const int sh = 8 * ((lane & 31) >> 3) + 4 * half;     // this lane's nibble inside a mask word
+  float cs[FC_BWD_COLS / 64];                            // bias-gradient partials: register i = blocks 2 i (lanes with bit 4 clear) / 2 i + 1
+#pragma unroll
+  for (int i = 0; i < FC_BWD_COLS / 64; ++i) cs[i] = 0.f;
+
+  for (int tile = blockIdx.x; tile < a.tiles; tile += gridDim.x) {
+    const long row0 = (long)tile * FM_TILE_ROWS + wave * 32;
+    const bool row_ok = row0 + (lane & 31) < a.M;
+    const bool more = tile + (int)gridDim.x < a.tiles;
+    // every global address of the tile is derived from a loop-variant spelling of the lane id: hoisted out of the loop, the 64-bit
+    // store / DMA addresses are spilled (the kernel sits at the 256-register limit) and every reload is a scratch load, i.e. one more
+    // s_waitcnt vmcnt(0) drain per use
+    int zero;
+    asm volatile("s_lshr_b32 %0, %1, 31" : "=s"(zero) : "s"(tile));
+    const int ln = lane | zero;
+    const long next0 = row0 + (long)gridDim.x * FM_TILE_ROWS;
+    // d raw_rgb as the B fragment of one k-step: lane half 0 supplies reduction indices 0..7 = (r, g, b, 0, ...), half 1 zeros
+    bf16x8 g[1];
+    {
+      const float* dp = (const float*)(mk + 5632) + (lane & 31) * 3;
+      const float x0 = dp[0], x1 = dp[1], x2 = dp[2];
+      typedef __attribute__((ext_vector_type(8))) float f32x8;
+      const f32x8 v = {half == 0 ? x0 : 0.f, half == 0 ? x1 : 0.f, half == 0 ? x2 : 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      g[0] = __builtin_convertvector(v, bf16x8);
+    }
+    auto to = [&](int i) { return StoreTo{a.dC[i], a.dC_ld[i], nullptr, row0, a.M, slab, ln, 2}; };
+    bf16x8 p[8], q[8];
+    bwd_layer<0, 1, 0, 4>(c, g, mk + 4096, lane, sh, row_ok, cs, p, to(0));           // dC2 = mask2 . (W_rgb^T d raw_rgb)
+    bwd_layer<4, 8, 4, 4>(c, p, mk + 4608, lane, sh, row_ok, cs, q, to(1));           // dC1 = mask1 . (W_c2^T dC2)
+    bwd_layer<36, 8, 8, 4>(c, q, mk + 5120, lane, sh, row_ok, cs, p, to(2));          // dC0 = mask0 . (W_c1^T dC1)
+    // The bottleneck masks of THIS tile were DMA'd at the end of the previous one; since then the four chunk boundaries of fragments
+    // 0..67 issued eight younger DMA operations, so "at most eight outstanding" means they have landed (loads retire in order;
+    // stores in flight only make the wait stricter).  The narrow masks and d raw_rgb of this tile are consumed: fetch the next tile's.
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (more) dma_narrow(next0, ln);
+    const StoreTo tb{a.dB, a.dB_ld, nullptr, row0, a.M, slab, ln, 16};
+    bwd_last_seq<68, 8, 12>(c, p, mk, lane, sh, row_ok, cs, tb, std::make_integer_sequence<int, 32>{});   // d bottleneck
+    skip_frags<324, 12>(c, std::make_integer_sequence<int, 12>{});                           // the stream's padding to whole chunks
+    static_assert(324 + 12 == FC_BWD_FRAGS && FM_CHUNK == 16 && FM_LOOK == 4, "colour head backward: fragment count / boundary positions");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of the bottleneck masks have returned: refill
+    if (more) dma_wide(next0, ln);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  {
+    const int r = lane & 15;
+    float* dst = a.colsum_ws + (long)((int)blockIdx.x * FM_WAVES + wave) * FC_BWD_COLS + 32 * ((lane >> 4) & 1) + (r & 3) + 8 * (r >> 2) + 4 * half;
+#pragma unroll
+    for (int i = 0; i < FC_BWD_COLS / 64; ++i) dst[64 * i] = cs[i];
+  }
+}
+
+// bias gradients += the per-wave partials, summed in a fixed order (bit-reproducible): 64 columns x 4 row groups per workgroup
+__global__ __launch_bounds__(256) void fcolour_colsum_fold_kernel(const float* __restrict__ ws, int rows, float* g2, float* g1, float* g0, float* gb) {
+  __shared__ float part[4][64];
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cl;
+  float s = 0.f;
+  for (int r = rg; r < rows; r += 4) s += ws[(long)r * FC_BWD_COLS + col];
+  part[rg][cl] = s;
+  __syncthreads();
+  if (rg == 0) {
+    const float t = ((part[0][cl] + part[1][cl]) + part[2][cl]) + part[3][cl];
+    float* dst = col < 128 ? g2 + col : col < 256 ? g1 + (col - 128) : col < 384 ? g0 + (col - 256) : gb + (col - 384);
+    *dst += t;
+  }
 }
 
 template <int NET, bool EMBED, bool STORE = false>
@@ -538,4 +854,93 @@ extern "C" int snerf_fmlp_proposal_train_fwd(const void* E, long ldE, const void
     a.act[i] = (__bf16*)acts[i]; a.act_ld[i] = act_ld[i]; a.bits[i] = (unsigned*)bits[i];
   }
   return fmlp_launch<FMLP_PROPOSAL, false, true>(a, 448, 33, n_frags, stream);
+}
+
+// ---- colour head (cond_layers.0..2 + rgb_layer of the mip path's NeRF MLP, hidden 1024) -------------------------------------------
+static int fcolour_grid(int tiles) {
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    n_cu = 256;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      n_cu = prop.multiProcessorCount;
+  }
+  return tiles < n_cu ? tiles : n_cu;
+}
+
+// raw_rgb [M,3] fp32 = rgb_layer(cond_layers.2(cond_layers.1(cond_layers.0(CB[:, :1051])))) (models.py:283-296).  CB [M, ldCB] bf16 =
+// [bottleneck 1024 | view encoding 27 | zeros up to column 1056]; wstream / bias from mlp.fmlp_pack (cond_layers.0 k-major).
+// acts / act_ld / bits (HOST arrays of 3; all nullptr for inference): where the three hidden activations ([M, >= 128] bf16) and their
+// ReLU bit masks (snerf_linear_fwd's ACT_RELU_BITS layout for N = 128) are stored for the backward pass.
+extern "C" int snerf_fcolour_fwd(const void* CB, long ldCB, const void* wstream, long n_frags, const float* bias, int n_blocks, float* raw_rgb,
+                                 void* const* acts, const long* act_ld, void* const* bits, long M, void* stream) {
+  if (M <= 0) return SNERF_OK;
+  if (CB == nullptr || wstream == nullptr || bias == nullptr || raw_rgb == nullptr || (((uintptr_t)CB) & 15) || (((uintptr_t)wstream) & 15) ||
+      (ldCB % 8) != 0 || ldCB < 16 * FC_NK0 || n_frags != FC_FWD_FRAGS || n_blocks != FC_FWD_BLOCKS)
+    return SNERF_ERR_ARG;
+  ColourFwdArgs a{};
+  a.CB = (const __bf16*)CB; a.ldCB = ldCB; a.wstream = (const char*)wstream; a.bias = bias; a.raw_rgb = raw_rgb; a.M = M;
+  a.tiles = (int)((M + FM_TILE_ROWS - 1) / FM_TILE_ROWS); a.n_chunks = (int)(n_frags / FM_CHUNK); a.n_blocks = n_blocks;
+  const bool store = acts != nullptr;
+  if (store) {
+    if (act_ld == nullptr || bits == nullptr) return SNERF_ERR_ARG;
+    for (int i = 0; i < 3; ++i) {
+      if (acts[i] == nullptr || bits[i] == nullptr || (((uintptr_t)acts[i]) & 15) || (act_ld[i] % 8) != 0 || act_ld[i] < 128) return SNERF_ERR_ARG;
+      a.act[i] = (__bf16*)acts[i]; a.act_ld[i] = act_ld[i]; a.bits[i] = (unsigned*)bits[i];
+    }
+  }
+  const int lds = FM_RING * FM_SLOT + FM_BIAS_MAX * 128 + FM_WAVES * 4096;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)fcolour_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)fcolour_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  const int grid = fcolour_grid(a.tiles);
+  if (store) hipLaunchKernelGGL(fcolour_fwd_kernel<true>, dim3(grid), dim3(64 * FM_WAVES), lds, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(fcolour_fwd_kernel<false>, dim3(grid), dim3(64 * FM_WAVES), lds, (hipStream_t)stream, a);
+  return snerf_check_launch();
+}
+
+// workspace floats snerf_fcolour_bwd needs for M rows
+extern "C" long snerf_fcolour_bwd_ws_floats(long M) {
+  if (M <= 0) return 0;
+  return (long)fcolour_grid((int)((M + FM_TILE_ROWS - 1) / FM_TILE_ROWS)) * FM_WAVES * FC_BWD_COLS;
+}
+
+// Data-gradient chain of the colour head: d_raw_rgb [M,3] fp32 -> dC[0..2] = d pre-activation of cond_layers.2, .1, .0 ([M, >= 128]
+// bf16 each) and dB = d pre-activation of the bottleneck layer ([M, >= 1024] bf16); bits[0..3] = ReLU bit masks of cond_layers.2, .1,
+// .0 (N = 128) and of the bottleneck (N = 1024); wstream from mlp.fmlp_pack of the transposed weights; the bias gradients of the four
+// layers are ADDED to g_bias[0..3] (cond_layers.2, .1, .0: 128 floats, bottleneck: 1024) in a fixed order.  ws: snerf_fcolour_bwd_ws_floats(M).
+extern "C" int snerf_fcolour_bwd(const float* d_raw_rgb, const void* wstream, long n_frags, void* const* bits, void* const* dC, const long* dC_ld,
+                                 void* dB, long dB_ld, float* const* g_bias, float* ws, long ws_floats, long M, void* stream) {
+  if (M <= 0) return SNERF_OK;
+  if (d_raw_rgb == nullptr || wstream == nullptr || bits == nullptr || dC == nullptr || dC_ld == nullptr || dB == nullptr || g_bias == nullptr ||
+      ws == nullptr || n_frags != FC_BWD_FRAGS || (((uintptr_t)wstream) & 15) || (((uintptr_t)dB) & 15) || (dB_ld % 8) != 0 || dB_ld < 1024 ||
+      ws_floats < snerf_fcolour_bwd_ws_floats(M))
+    return SNERF_ERR_ARG;
+  ColourBwdArgs a{};
+  a.d_rgb = d_raw_rgb; a.wstream = (const char*)wstream; a.dB = (__bf16*)dB; a.dB_ld = dB_ld; a.colsum_ws = ws; a.M = M;
+  a.tiles = (int)((M + FM_TILE_ROWS - 1) / FM_TILE_ROWS); a.n_chunks = (int)(n_frags / FM_CHUNK);
+  for (int i = 0; i < 4; ++i) {
+    if (bits[i] == nullptr || (((uintptr_t)bits[i]) & 15) || g_bias[i] == nullptr) return SNERF_ERR_ARG;
+    a.bits[i] = (const unsigned*)bits[i];
+  }
+  for (int i = 0; i < 3; ++i) {
+    if (dC[i] == nullptr || (((uintptr_t)dC[i]) & 15) || (dC_ld[i] % 8) != 0 || dC_ld[i] < 128) return SNERF_ERR_ARG;
+    a.dC[i] = (__bf16*)dC[i]; a.dC_ld[i] = dC_ld[i];
+  }
+  if (M * 12 >= (1L << 31) || (((uintptr_t)d_raw_rgb) & 15)) return SNERF_ERR_ARG;      // d raw_rgb goes through a 32-bit buffer descriptor
+  const int lds = FC_BWD_LDS;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)fcolour_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  const int grid = fcolour_grid(a.tiles);
+  hipLaunchKernelGGL(fcolour_bwd_kernel, dim3(grid), dim3(64 * FM_WAVES), lds, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(fcolour_colsum_fold_kernel, dim3(FC_BWD_COLS / 64), dim3(256), 0, (hipStream_t)stream, ws, grid * FM_WAVES, g_bias[0], g_bias[1],
+                     g_bias[2], g_bias[3]);
+  return snerf_check_launch();
 }

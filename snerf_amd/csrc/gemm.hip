@@ -1131,12 +1131,14 @@ struct GemmTN {
   float* dW; long ldw;
   const void* zeros;  // >= 16 bytes of zeros in device memory
   int M, N, K, n_valid, k_valid, m_chunk;
+  int tiles, slices;  // 128 x 128 kernel: output tiles and M slices of the launch (1-D grid, XCD-aware placement)
   float* part;        // deterministic mode: every (tile, M slice) stores its partial tile at part + slice * part_stride + n * part_ld + k
   long part_stride;   // (no atomics); tn_fold_kernel adds the slices in a fixed order.  nullptr: fp32 atomics straight into dW
   int part_ld;
 };
 
-template <typename T, bool TR>
+// TN_STAGES: slots of the staging ring of the 128 x 128 weight-gradient kernel (16 KiB per slot)
+template <typename T, bool TR, int TN_STAGES>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int EPC = 16 / (int)sizeof(T);
@@ -1149,8 +1151,22 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave >> 1, wk = wave & 1;
   const int tiles_k = (p.K + 127) / 128;
-  const int n0 = (blockIdx.x / tiles_k) * 128, k0 = (blockIdx.x % tiles_k) * 128;
-  const int mbeg = blockIdx.y * p.m_chunk;
+  // 1-D grid of tiles x slices workgroups.  Workgroup b runs on XCD b % 8: ALL tiles of an M slice go to one XCD (consecutive
+  // positions on it), so that the slice's rows of dZ and X -- which every tile of the slice re-reads -- are fetched into one L2
+  // instead of eight (round 2: the N = 128, K = 1051 launch moved 2.4 GB through the fabric for 1.3 GB of operands).
+  const int ntile = p.tiles;
+  int slice, tile;
+  {
+    const int b = (int)blockIdx.x, xcd = b & 7, idx = b >> 3;
+    const int full = p.slices >> 3;                     // slices every XCD owns; the first (slices & 7) XCDs own one more
+    const int extra = p.slices & 7;
+    const int mine = full + (xcd < extra ? 1 : 0);      // slices of this XCD
+    if (idx >= mine * ntile) return;                    // (the grid is padded to 8 x the largest share)
+    slice = (idx / ntile) * 8 + xcd;
+    tile = idx % ntile;
+  }
+  const int n0 = (tile / tiles_k) * 128, k0 = (tile % tiles_k) * 128;
+  const int mbeg = slice * p.m_chunk;
   const int mend = min(p.M, mbeg + p.m_chunk);
   const T* __restrict__ Z = (const T*)p.Z;
   const T* __restrict__ X = (const T*)p.X;
@@ -1188,12 +1204,20 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  if (steps > 0) issue(0, 0);
+  // Ring of TN_STAGES slots, TN_STAGES - 1 stages in flight: these narrow launches are bound by HBM latency, not by their few MFMAs
+  // (one 16 KiB stage in flight per workgroup = 32 KiB per CU: round 2 measured 2.5 TB/s on the N = 128, K = 1051 launch).
+  // Stage st + TN_STAGES - 1 is issued after the barrier of iteration st into the slot stage st - 1 occupied (every wave finished
+  // reading it before that barrier).  vmcnt(2 LI (TN_STAGES - 2)): the 2 LI loads per wave of each younger stage may stay in
+  // flight; the last iterations, with fewer stages behind them, simply wait for everything.
+#pragma unroll
+  for (int s = 0; s < TN_STAGES - 1; ++s)
+    if (s < steps) issue(s, s);
   for (int st = 0; st < steps; ++st) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (st + TN_STAGES - 2 < steps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LI * (TN_STAGES - 2)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (st + 1 < steps) issue(st + 1, (st + 1) & 1);
-    const char* sZ = smem + (st & 1) * 2 * TILEB;
+    if (st + TN_STAGES - 1 < steps) issue(st + TN_STAGES - 1, (st + TN_STAGES - 1) % TN_STAGES);
+    const char* sZ = smem + (st % TN_STAGES) * 2 * TILEB;
     const char* sX = sZ + TILEB;
     if constexpr (sizeof(T) == 4) {
 #pragma unroll
@@ -1269,7 +1293,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
       for (int r = 0; r < 16; ++r) {
         const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (n < p.n_valid && k < p.k_valid) {
-          if (p.part != nullptr) p.part[(long)blockIdx.y * p.part_stride + (long)n * p.part_ld + k] = acc[i][j][r];
+          if (p.part != nullptr) p.part[(long)slice * p.part_stride + (long)n * p.part_ld + k] = acc[i][j][r];
           else atomicAdd(p.dW + (long)n * p.ldw + k, acc[i][j][r]);
         }
       }
@@ -1531,7 +1555,9 @@ static TnPlan tn_plan(int M, int N, int K, long ldz, long ldx, int dtype, int va
   // about two workgroups per CU: every slice ends with one fp32 atomic per output element, and on the long-M launches of the step
   // 512 workgroups beat the few thousand of round 1 by 8-23 % (tools/gemm_tn_slices_probe.py; variant bits 16 / 32 / 64 select
   // 1024 / 2048 / 4096 for that probe)
-  const int target = (variant & 64) ? 4096 : (variant & 32) ? 2048 : (variant & 16) ? 1024 : 512;
+  // round 3, with all tiles of an M slice placed on one XCD: 1024 workgroups beat 512 on the two longest launches (N = 1024, K = 96:
+  // 247 vs 322 us; N = 1, K = 1024: 246 vs 295) and tie elsewhere (tools/gemm_tn_narrow_probe.py; variant bit 16 now selects 512)
+  const int target = (variant & 64) ? 4096 : (variant & 32) ? 2048 : (variant & 16) ? 512 : 1024;
   int chunks = (target + tiles - 1) / tiles;
   int m_chunk = (M + chunks - 1) / chunks;
   m_chunk = ((m_chunk + 255) / 256) * 256;
@@ -1548,7 +1574,7 @@ static int wgrad_launch(const void* Z, long ldz, const void* X, long ldx, float*
   if (N < epc || K < epc || N % epc || K % epc || ldz % epc || ldx % epc || zeros == nullptr) return SNERF_ERR_ARG;
   const TnPlan pl = tn_plan(M, N, K, ldz, ldx, dtype, variant);
   if (ws != nullptr && ws_floats < pl.part_stride * pl.slices) return SNERF_ERR_ARG;
-  GemmTN p{Z, ldz, X, ldx, dW, ldw, zeros, M, N, K, n_valid, k_valid, pl.m_chunk, ws, pl.part_stride, pl.part_ld};
+  GemmTN p{Z, ldz, X, ldx, dW, ldw, zeros, M, N, K, n_valid, k_valid, pl.m_chunk, 0, pl.slices, ws, pl.part_stride, pl.part_ld};
   if (pl.use8) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -1559,15 +1585,34 @@ static int wgrad_launch(const void* Z, long ldz, const void* X, long ldx, float*
     hipLaunchKernelGGL(gemm_tn8_kernel, dim3(t8 * pl.slices), dim3(512), 8 * 64 * 256, (hipStream_t)stream, p);
   } else {
     const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
-    const int lds = 2 * 2 * 8192;
-    dim3 grid(tiles, pl.slices);
+    p.tiles = tiles;
+    // variant bit 128: a ring of four staging slots (three stages in flight) instead of the double buffer.  Measured with the XCD-aware
+    // placement (round 3, tools/gemm_tn_narrow_probe.py): the ring LOSES (64 KiB of LDS per workgroup halve the residency: N = 128,
+    // K = 1051: 472 vs 325 us; N = 1: 341 vs 295), so the double buffer stays the default and the ring is the probe's alternative.
+    const bool deep = (variant & 128) != 0;
+    const int lds = (deep ? 4 : 2) * 2 * 8192;
+    static bool tn_attr_set = false;
+    if (!tn_attr_set) {
+      hipFuncSetAttribute((const void*)gemm_tn_kernel<float, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 8192);
+      hipFuncSetAttribute((const void*)gemm_tn_kernel<__bf16, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 8192);
+      hipFuncSetAttribute((const void*)gemm_tn_kernel<__bf16, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 8192);
+      tn_attr_set = true;
+    }
+    dim3 grid(8 * ((pl.slices + 7) / 8) * tiles);        // every XCD gets room for the largest share of slices
     // variant 1 (bf16): operands via ds_read_b64_tr_b16 (needs whole 128-column tiles: the source swizzle permutes chunks
     // inside a 256-byte row); variant 0: 16-bit LDS gathers
     const bool tr = (variant & 1) && dtype == SNERF_DT_BF16 && (N % 128 == 0) && (K % 128 == 0);
-    if (dtype == SNERF_DT_F32) hipLaunchKernelGGL((gemm_tn_kernel<float, false>), grid, dim3(256), lds, (hipStream_t)stream, p);
-    else if (dtype == SNERF_DT_BF16 && tr) hipLaunchKernelGGL((gemm_tn_kernel<__bf16, true>), grid, dim3(256), lds, (hipStream_t)stream, p);
-    else if (dtype == SNERF_DT_BF16) hipLaunchKernelGGL((gemm_tn_kernel<__bf16, false>), grid, dim3(256), lds, (hipStream_t)stream, p);
-    else return SNERF_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SNERF_DT_F32) {
+      if (deep) hipLaunchKernelGGL((gemm_tn_kernel<float, false, 4>), grid, dim3(256), lds, st, p);
+      else hipLaunchKernelGGL((gemm_tn_kernel<float, false, 2>), grid, dim3(256), lds, st, p);
+    } else if (dtype == SNERF_DT_BF16 && tr) {
+      if (deep) hipLaunchKernelGGL((gemm_tn_kernel<__bf16, true, 4>), grid, dim3(256), lds, st, p);
+      else hipLaunchKernelGGL((gemm_tn_kernel<__bf16, true, 2>), grid, dim3(256), lds, st, p);
+    } else if (dtype == SNERF_DT_BF16) {
+      if (deep) hipLaunchKernelGGL((gemm_tn_kernel<__bf16, false, 4>), grid, dim3(256), lds, st, p);
+      else hipLaunchKernelGGL((gemm_tn_kernel<__bf16, false, 2>), grid, dim3(256), lds, st, p);
+    } else return SNERF_ERR_ARG;
   }
   if (ws != nullptr)
     hipLaunchKernelGGL(tn_fold_kernel, dim3((k_valid + 255) / 256, n_valid), dim3(256), 0, (hipStream_t)stream, ws, pl.part_stride, pl.part_ld,

@@ -88,15 +88,18 @@ FMLP_CHUNK = 16
 
 
 def fmlp_pack(layers, device):
-    """layers = [(W fp32 [N,K], bias fp32 [N] or None, segments)] in the order the kernel consumes them, segments =
-    [(first weight column, columns, from_accumulator)] in the order of the kernel's input segments.
+    """layers = [(W fp32 [N,K], bias fp32 [N] or None, segments[, k_major])] in the order the kernel consumes them, segments =
+    [(first weight column, columns, from_accumulator)] in the order of the kernel's input segments; `k_major`: the layer's fragments
+    are consumed k-step by k-step over ALL its blocks (the colour head's wide first layer keeps its four accumulators live and
+    streams the input row once) instead of block by block.
     -> (stream bf16 [n_frags, 512]: 1 KiB MFMA A-operand fragments -- lane (n = lane & 31, half = lane >> 5) holds the 8 reduction
     positions 8 half .. 8 half + 7 of output n of its 32-output block -- block by block, k-step by k-step, padded to whole chunks;
     bias fp32 [n_blocks * 32])."""
     perm = torch.tensor(FMLP_PERM, device=device)
     frags, biases = [], []
     dt = layers[0][0].dtype if layers[0][0].dtype == torch.float64 else torch.float32   # float64: index images (_Net._build_plan)
-    for W, b, segs in layers:
+    for W, b, segs, *opt in layers:
+        kmajor = bool(opt and opt[0])
         W = _w2(W).detach().to(device, dt)
         N = W.shape[0]
         NB = (N + 31) // 32
@@ -110,7 +113,8 @@ def fmlp_pack(layers, device):
                 Ws = Ws[:, :, perm]
             # [NB, 32 n, ks, 2 halves, 8] -> [NB, ks, half, n, 8]: one fragment = 64 lanes x 8 values, lane = half * 32 + n
             per_seg.append(Ws.reshape(NB, 32, ks, 2, 8).permute(0, 2, 3, 1, 4).reshape(NB, ks, 512))
-        frags.append(torch.cat(per_seg, 1).reshape(-1, 512))
+        fr = torch.cat(per_seg, 1)                                     # [NB, k-steps, 512]
+        frags.append((fr.permute(1, 0, 2) if kmajor else fr).reshape(-1, 512))
         bb = torch.zeros(NB * 32, dtype=dt, device=device)
         if b is not None:
             bb[:N] = b.detach().to(device, dt).reshape(-1)
@@ -232,18 +236,21 @@ class _Net:
     def gB(self, name):
         return self.a.g[self.pre + name + ".bias"]
 
-    def _refresh_fused(self, pack_fused):
-        """weight stream / bias table of the fused kernels (fmlp_pack's layout), refreshed by the same gather"""
-        if "fused" not in self._plans:
+    def _refresh_fused(self, pack_fused, key="fused"):
+        """weight stream / bias table of a fused kernel (fmlp_pack's layout), refreshed by the same gather.  -> (stream, bias)"""
+        if key not in self._plans:
             def fill():
                 st, bi = pack_fused()                      # index images (float64) in record mode
                 self._fimg = (st, bi)
                 return [(st, torch.bfloat16), (bi, torch.float32)]
             plan, swap = self._build_plan(fill)
-            self._plans["fused"] = (plan, swap(self._fimg))
+            self._plans[key] = (plan, swap(self._fimg))
             del self._fimg
-        plan, (self.fstream, self.fbias) = self._plans["fused"]
+        plan, sb = self._plans[key]
         plan.refresh()
+        if key == "fused":
+            self.fstream, self.fbias = sb
+        return sb
 
     def _pack_fwd(self, key, name, segs, kbuf):
         W = self.W(name)
@@ -717,6 +724,39 @@ class MipNerfNet(_Net):
             self._pack_dgrad_cols("enc", [(f"layers.{i}.layers.0", 0 if i == 0 else H) for i in self.enc_layers], self.fd)
             self._pack_dgrad_cols("cenc", [("cond_layers.0.layers.0", H)], self.cd)
 
+    # ---- fused colour head (csrc/fmlp.hip: fcolour_fwd_kernel / fcolour_bwd_kernel) ------------------------------------------------
+    def colour_fused_ok(self):
+        """cat([bottleneck, view encoding]) -> 3 x 128 -> rgb in ONE launch each way: the shipped configuration (hidden 1024, 27
+        view-encoding columns, rgb_layer 3 x 128, bf16)"""
+        return (getattr(self, "fused_colour", True) and self.dt == ops.BF16 and self.H == 1024 and self.cd == 27 and self.nc == 3 and self.cu == 128
+                and self.Cw >= 32)
+
+    def _pack_colour_fwd(self):
+        H, cu = self.H, self.cu
+        L = [(self.W("cond_layers.0.layers.0"), self.B("cond_layers.0.layers.0"), [(0, H, False), (H, self.cd, False)], True),
+             (self.W("cond_layers.1.layers.0"), self.B("cond_layers.1.layers.0"), [(0, cu, True)]),
+             (self.W("cond_layers.2.layers.0"), self.B("cond_layers.2.layers.0"), [(0, cu, True)]),
+             (self.W("rgb_layer"), self.B("rgb_layer"), [(0, cu, True)])]
+        return fmlp_pack(L, self.dev)
+
+    def _pack_colour_bwd(self):
+        """transposed weights in the order the data-gradient chain consumes them (no biases)"""
+        H, cu = self.H, self.cu
+        L = [(self.W("rgb_layer").t(), None, [(0, 3, False)]),                    # d raw_rgb (3 values from memory) -> dC2
+             (self.W("cond_layers.2.layers.0").t(), None, [(0, cu, True)]),       # dC2 -> dC1
+             (self.W("cond_layers.1.layers.0").t(), None, [(0, cu, True)]),       # dC1 -> dC0
+             (self.W("cond_layers.0.layers.0")[:, :H].t(), None, [(0, cu, True)])]  # dC0 -> d bottleneck (the view-encoding columns: input_grad)
+        return fmlp_pack(L, self.dev)
+
+    def _colour_streams(self, train):
+        v = self.version_fn()
+        if getattr(self, "_colour_version", None) != (v, train) and not (not train and getattr(self, "_colour_version", None) == (v, True)):
+            with torch.no_grad():
+                self._cfwd = self._refresh_fused(self._pack_colour_fwd, "colour_fwd")
+                if train:
+                    self._cbwd = self._refresh_fused(self._pack_colour_bwd, "colour_bwd")
+            self._colour_version = (v, train)
+
     def alloc_inputs(self, M):
         """-> (SKIP, CB); the encoders write SKIP[:, H:] and CB[:, H:] in place."""
         return self.buf(M, self.H + self.Ew), self.buf(M, self.H + self.Cw)
@@ -744,14 +784,30 @@ class MipNerfNet(_Net):
         self.fwd("density", x, H, raw_d, 1, ACT_NONE, out_f32=True)
         self.fwd("bottleneck", x, H, CB[:, :H], H)
         cacts = []
-        cx, ck = CB, H + self.Cw
-        for j in range(self.nc):
-            cy = self.buf(M, self.cu)
-            self.fwd(f"cond_layers.{j}.layers.0", cx, ck, cy, self.cu)
-            cacts.append((cx, ck, cy))
-            cx, ck = cy, self.cu
         raw_rgb = self.buf(M, 3, f32=True)
-        self.fwd("rgb", cx, self.cu, raw_rgb, 3, ACT_NONE, out_f32=True)
+        bbits = self._bits.get((CB.data_ptr(), M)) if keep else None
+        if self.colour_fused_ok() and (not keep or (bbits is not None and bbits[1] == H)):
+            # ONE launch for cond_layers.0..2 + rgb_layer; training also stores the three hidden activations + their ReLU bit masks
+            self._colour_streams(keep)
+            cys = cbits = None
+            if keep:
+                cys = [self.buf(M, self.cu) for _ in range(self.nc)]
+                cbits = [torch.empty(ops.mask_bits_words(M, self.cu), dtype=torch.int32, device=self.dev) for _ in range(self.nc)]
+            ops.fcolour_fwd(CB, self._cfwd[0], self._cfwd[1], raw_rgb, cys, cbits)
+            if keep:
+                cx, ck = CB, H + self.Cw
+                for cy in cys:
+                    cacts.append((cx, ck, cy))
+                    cx, ck = cy, self.cu
+                cacts.append(("fused", cbits, bbits[0]))
+        else:
+            cx, ck = CB, H + self.Cw
+            for j in range(self.nc):
+                cy = self.buf(M, self.cu)
+                self.fwd(f"cond_layers.{j}.layers.0", cx, ck, cy, self.cu)
+                cacts.append((cx, ck, cy))
+                cx, ck = cy, self.cu
+            self.fwd("rgb", cx, self.cu, raw_rgb, 3, ACT_NONE, out_f32=True)
         self.raw_sem, S0 = None, None
         if self.sc:
             S0 = self.buf(M, self.Hs)
@@ -769,23 +825,39 @@ class MipNerfNet(_Net):
         self.colsum(d_raw_rgb, 3, self.gB("rgb_layer"))
         self.colsum(d_raw_density, 1, self.gB("density_layer"))
         dz = self.head_grad(d_raw_rgb, 3)
+        fused = cacts[-1] if (len(cacts) == self.nc + 1 and cacts[-1][0] == "fused") else None
+        if fused is not None:
+            cacts = cacts[:-1]
         clast = cacts[-1][2]
         self.wgrad("rgb_layer", dz, clast, 3, cu)
-        dC = self.buf(M, cu)
-        self.dgrad("rgb", dz, dz.shape[1], dC, cu, mask=clast, colsum=self.gB(f"cond_layers.{self.nc - 1}.layers.0"))
         DB = self.buf(M, H + g + (self.Hs if self.sc else 0))       # [d bottleneck | d raw density (+pad) | d semantic hidden]
-        for j in range(self.nc - 1, -1, -1):
-            cx, ck, cy = cacts[j]
-            n = f"cond_layers.{j}.layers.0"
-            self.wgrad(n, dC, cx, cu, H + self.cd if j == 0 else cu)
-            if j > 0:
-                dX = self.buf(M, cu)
-                self.dgrad(n, dC, cu, dX, cu, mask=cx, colsum=self.gB(f"cond_layers.{j - 1}.layers.0"))
-                dC = dX
-            else:
-                self.dgrad(n, dC, cu, DB, H, mask=CB, colsum=self.gB("bottleneck_layer.layers.0"))
-                if want_input_grad:
-                    dV = self.input_grad("cenc", dC, cu, self.Cw)
+        if fused is not None:
+            # the whole data-gradient chain d raw_rgb -> dC2 -> dC1 -> dC0 -> d bottleneck, masks and the four bias gradients: one launch
+            _, cbits, bbits = fused
+            dCs = [self.buf(M, cu) for _ in range(self.nc)]                       # [dC2, dC1, dC0]
+            ops.fcolour_bwd(d_raw_rgb, self._cbwd[0], [cbits[2], cbits[1], cbits[0], bbits], dCs, DB[:, :H],
+                            [self.gB("cond_layers.2.layers.0"), self.gB("cond_layers.1.layers.0"), self.gB("cond_layers.0.layers.0"),
+                             self.gB("bottleneck_layer.layers.0")])
+            for j in range(self.nc - 1, -1, -1):
+                cx, ck, cy = cacts[j]
+                self.wgrad(f"cond_layers.{j}.layers.0", dCs[self.nc - 1 - j], cx, cu, H + self.cd if j == 0 else cu)
+            if want_input_grad:
+                dV = self.input_grad("cenc", dCs[-1], cu, self.Cw)
+        else:
+            dC = self.buf(M, cu)
+            self.dgrad("rgb", dz, dz.shape[1], dC, cu, mask=clast, colsum=self.gB(f"cond_layers.{self.nc - 1}.layers.0"))
+            for j in range(self.nc - 1, -1, -1):
+                cx, ck, cy = cacts[j]
+                n = f"cond_layers.{j}.layers.0"
+                self.wgrad(n, dC, cx, cu, H + self.cd if j == 0 else cu)
+                if j > 0:
+                    dX = self.buf(M, cu)
+                    self.dgrad(n, dC, cu, dX, cu, mask=cx, colsum=self.gB(f"cond_layers.{j - 1}.layers.0"))
+                    dC = dX
+                else:
+                    self.dgrad(n, dC, cu, DB, H, mask=CB, colsum=self.gB("bottleneck_layer.layers.0"))
+                    if want_input_grad:
+                        dV = self.input_grad("cenc", dC, cu, self.Cw)
         ops.cast_pad(d_raw_density, 1, DB[:, H:H + g], g, self.dt)
         xl = acts[-1][2]
         kb = H + g

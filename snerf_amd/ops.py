@@ -177,6 +177,54 @@ def fmlp_proposal_train_fwd(E, stream, bias, raw_density, acts, bits):
               _p(raw_density), ctypes.addressof(ptrs), ctypes.addressof(lds), ctypes.addressof(bp), E.shape[0], _stream())
 
 
+def fcolour_fwd(CB, stream, bias, raw_rgb, acts=None, bits=None):
+    """Fused colour head of the mip path's NeRF MLP (csrc/fmlp.hip): CB [M, >= 1056] bf16 = [bottleneck 1024 | view encoding 27 | 0]
+    -> raw_rgb [M,3] fp32 in ONE launch.  Training: `acts` = 3 x [M, >= 128] bf16 (outputs of cond_layers.0..2), `bits` = 3 x int32
+    [mask_bits_words(M, 128)] (their ReLU bit masks), stored for fcolour_bwd and the weight-gradient GEMMs."""
+    import ctypes
+    _chk2d(CB, torch.bfloat16); _chk2d(raw_rgb, torch.float32)
+    M = CB.shape[0]
+    assert stream.dtype == torch.bfloat16 and stream.is_contiguous() and bias.dtype == torch.float32 and CB.shape[1] >= 1056
+    assert raw_rgb.is_contiguous() and raw_rgb.shape == (M, 3)
+    pa = pl = pb = None
+    if acts is not None:
+        assert len(acts) == 3 and len(bits) == 3
+        for y, b in zip(acts, bits):
+            assert y.dtype == torch.bfloat16 and y.dim() == 2 and y.stride(1) == 1 and y.shape[0] == M and y.shape[1] >= 128
+            assert b.dtype == torch.int32 and b.is_contiguous() and b.numel() >= mask_bits_words(M, 128)
+        pa = (ctypes.c_void_p * 3)(*[y.data_ptr() for y in acts])
+        pl = (ctypes.c_long * 3)(*[y.stride(0) for y in acts])
+        pb = (ctypes.c_void_p * 3)(*[b.data_ptr() for b in bits])
+    _lib.call("snerf_fcolour_fwd", _p(CB), CB.stride(0), _p(stream), stream.shape[0], _p(bias), bias.numel() // 32, _p(raw_rgb),
+              None if pa is None else ctypes.addressof(pa), None if pl is None else ctypes.addressof(pl),
+              None if pb is None else ctypes.addressof(pb), M, _stream())
+
+
+def fcolour_bwd(d_raw_rgb, stream, bits, dC, dB, g_bias):
+    """Fused data-gradient chain of the colour head: d_raw_rgb [M,3] fp32 -> dC = [dC2, dC1, dC0] ([M, >= 128] bf16 each) and dB
+    ([M, >= 1024] bf16 view); bits = ReLU bit masks of [cond_layers.2, .1, .0, bottleneck]; the bias gradients are added to
+    g_bias = [cond_layers.2, .1, .0, bottleneck] (fp32 views of the gradient arena)."""
+    import ctypes
+    _f32c(d_raw_rgb); _chk2d(dB, torch.bfloat16)
+    M = d_raw_rgb.shape[0]
+    assert d_raw_rgb.shape[1] == 3 and stream.dtype == torch.bfloat16 and stream.is_contiguous() and len(bits) == 4 and len(dC) == 3 and len(g_bias) == 4
+    assert dB.shape[0] == M and dB.shape[1] >= 1024
+    for b, n in zip(bits, (128, 128, 128, 1024)):
+        assert b.dtype == torch.int32 and b.is_contiguous() and b.numel() >= mask_bits_words(M, n)
+    for y in dC:
+        assert y.dtype == torch.bfloat16 and y.dim() == 2 and y.stride(1) == 1 and y.shape[0] == M and y.shape[1] >= 128
+    for gb, n in zip(g_bias, (128, 128, 128, 1024)):
+        assert gb.dtype == torch.float32 and gb.is_contiguous() and gb.numel() == n
+    nws = _lib.query("snerf_fcolour_bwd_ws_floats", M)
+    ws = torch.empty(max(int(nws), 1), dtype=torch.float32, device=dB.device)
+    pb = (ctypes.c_void_p * 4)(*[b.data_ptr() for b in bits])
+    pc = (ctypes.c_void_p * 3)(*[y.data_ptr() for y in dC])
+    pl = (ctypes.c_long * 3)(*[y.stride(0) for y in dC])
+    pg = (ctypes.c_void_p * 4)(*[g.data_ptr() for g in g_bias])
+    _lib.call("snerf_fcolour_bwd", _p(d_raw_rgb), _p(stream), stream.shape[0], ctypes.addressof(pb), ctypes.addressof(pc), ctypes.addressof(pl),
+              _p(dB), dB.stride(0), ctypes.addressof(pg), _p(ws), ws.numel(), M, _stream())
+
+
 # --------------------------------------------------------------- encoders ----
 def classic_embed(pts, viewdirs, S, L, Lv, dst1, dst2, w_pts, dstv, w_views, dt):
     pts = _f32c(pts); M = pts.shape[0]

@@ -546,6 +546,57 @@ def fmlp_proposal_train_fwd(E, stream, bias, raw_density, acts, bits):
         _BITS[w.data_ptr()] = y.float() > 0
 
 
+def fcolour_fwd(CB, stream, bias, raw_rgb, acts=None, bits=None):
+    """model of fcolour_fwd_kernel: cond_layers.0 K-MAJOR (66 k-steps x 4 blocks), then two 128-wide layers and the rgb head"""
+    assert stream.shape[0] == 336 and bias.numel() == 13 * 32
+    st = _FStream(stream, bias)
+    M = CB.shape[0]
+    acc = [bias[32 * j:32 * j + 32].clone()[None, :].expand(M, 32).clone() for j in range(4)]
+    st.nb = 4
+    for x in _rows_to_ksteps(CB, 66):
+        for j in range(4):
+            acc[j] = acc[j] + x @ st.frag().t()
+    p = []
+    for j in range(4):
+        y = torch.relu(acc[j].to(torch.bfloat16).float())
+        if acts is not None:
+            acts[0][:, 32 * j:32 * j + 32] = y.to(acts[0].dtype)
+        p += [y[:, _P], y[:, 16 + _P]]
+    q = st.dense([p], 4, True, None if acts is None else acts[1])
+    p = st.dense([q], 4, True, None if acts is None else acts[2])
+    raw_rgb[:, :3] = st.block([p], False, to_frags=False)[:, :3]
+    assert st.f == 336 and st.nb == 13
+    if acts is not None:
+        for y, w in zip(acts, bits):
+            _BITS[w.data_ptr()] = y[:, :128].float() > 0
+
+
+def fcolour_bwd(d_raw_rgb, stream, bits, dC, dB, g_bias):
+    """model of fcolour_bwd_kernel: the data-gradient chain on the transposed weights; masks, bias gradients (of the masked fp32
+    accumulators), bf16 stores"""
+    assert stream.shape[0] == 336
+    st = _FStream(stream, torch.zeros(44 * 32))
+    M = d_raw_rgb.shape[0]
+    g = torch.zeros(M, 16)
+    g[:, :3] = d_raw_rgb.to(torch.bfloat16).float()
+
+    def layer(inp, nblocks, mask, out, gb):
+        frs = []
+        for j in range(nblocks):
+            a = st.block([inp], False, to_frags=False) * mask[:, 32 * j:32 * j + 32]
+            gb[32 * j:32 * j + 32] += a.sum(0)
+            y = a.to(torch.bfloat16).float()
+            out[:, 32 * j:32 * j + 32] = y.to(out.dtype)
+            frs += [y[:, _P], y[:, 16 + _P]]
+        return frs
+    m = [_BITS[b.data_ptr()].float() for b in bits]
+    p = layer([g], 4, m[0], dC[0], g_bias[0])
+    p = layer(p, 4, m[1], dC[1], g_bias[1])
+    p = layer(p, 4, m[2], dC[2], g_bias[2])
+    layer(p, 32, m[3], dB, g_bias[3])
+    assert st.f == 324
+
+
 def gather_pack(flat, idx, dst):
     k = idx.long()
     v = torch.where(k >= 0, flat[k.clamp(min=0)], torch.where(k == -2, torch.ones_like(flat[:1]), torch.zeros_like(flat[:1])).expand_as(k))
@@ -556,7 +607,7 @@ def adam_step_dev(p, g, m, v, lr, b1, b2, eps, step_dev, grad_scale=1.0, zero_gr
     adam_step(p, g, m, v, lr, b1, b2, eps, 0, grad_scale, zero_grad, step_dev=step_dev, **kw)
 
 
-_NAMES = ["gather_pack", "adam_step_dev", "grad_clip_coef", "fmlp_classic_fwd", "fmlp_classic_pts_fwd", "fmlp_proposal_fwd", "fmlp_classic_train_fwd", "fmlp_proposal_train_fwd", "classic_get_rays", "classic_ndc_rays", "classic_ray_batch", "zip_encode_prop_fwd", "mip_encode_bwd", "mip_viewenc_bwd", "hash_decay", "zip_percentiles", "zip_pixels_to_rays", "zip_loss_tail", "semantic_composite_fwd", "semantic_composite_bwd", "zip_resample", "zip_encode_fwd", "zip_encode_bwd", "zip_encode_bwd_binned", "zip_encode_ray_bwd", "zip_composite_fwd", "zip_composite_bwd",
+_NAMES = ["fcolour_fwd", "fcolour_bwd", "gather_pack", "adam_step_dev", "grad_clip_coef", "fmlp_classic_fwd", "fmlp_classic_pts_fwd", "fmlp_proposal_fwd", "fmlp_classic_train_fwd", "fmlp_proposal_train_fwd", "classic_get_rays", "classic_ndc_rays", "classic_ray_batch", "zip_encode_prop_fwd", "mip_encode_bwd", "mip_viewenc_bwd", "hash_decay", "zip_percentiles", "zip_pixels_to_rays", "zip_loss_tail", "semantic_composite_fwd", "semantic_composite_bwd", "zip_resample", "zip_encode_fwd", "zip_encode_bwd", "zip_encode_bwd_binned", "zip_encode_ray_bwd", "zip_composite_fwd", "zip_composite_bwd",
           "linear_fwd", "linear_wgrad", "classic_embed", "mip_encode", "mip_viewenc", "classic_sample_pdf", "classic_points",
           "classic_merge_sort", "mip_resample", "stratified", "mip_composite_fwd", "mip_composite_bwd", "classic_composite_fwd",
           "classic_composite_bwd", "adam_step", "colsum_f32", "cast_pad", "pinhole_rays", "mip_loss_tail"]

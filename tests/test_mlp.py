@@ -220,6 +220,57 @@ def test_fused_proposal_network_matches_per_layer_kernels_and_oracle(backend):
     assert float((fused - layered).norm() / layered.norm()) < 5e-3
 
 
+@pytest.mark.parametrize("M", [700, 1024])
+def test_fused_colour_head_matches_per_layer_kernels_and_oracle(backend, M):
+    """snerf_fcolour_fwd / snerf_fcolour_bwd (cond_layers.0..2 + rgb_layer of the mip path's NeRF MLP, models.py:283-296) against the
+    per-layer GEMM kernels (same bf16 network, another fp32 summation order) and torch autograd of the oracle: raw_rgb, the stored
+    hidden activations, every parameter gradient.  M = 700: ragged 256-row tile."""
+    from snerf_amd import mlp, ops
+    from snerf_amd.mlp import MipNerfNet, ParamArena
+    H = 1024
+    shapes = [("mlp." + n, s) for n, s in MipNerfNet.param_shapes(H, 8, 4, 96, 27, 3, 128)]
+    sd = rnd_params(shapes, 51)
+    g = torch.Generator().manual_seed(52)
+    enc = q(torch.rand(M, 96, generator=g) * 2 - 1, 1)
+    cond = q(torch.rand(M, 27, generator=g) * 2 - 1, 1)
+    d_rgb, d_den = torch.randn(M, 3, generator=g), torch.randn(M, 1, generator=g)
+    pr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    rr, rd, _ = om.nerf_mlp(pr, enc[:, None], cond)               # one "ray" per row: every row carries its own view encoding
+    ((rr.reshape(M, 3) * d_rgb).sum() + (rd.reshape(M, 1) * d_den).sum()).backward()
+
+    def run(fused):
+        arena = ParamArena(shapes, torch.device(DEV))
+        arena.load(sd)
+        net = MipNerfNet(arena, "mlp.", ops.BF16, H)
+        net.fused_colour = fused
+        assert net.colour_fused_ok() == fused
+        SKIP, CB = net.alloc_inputs(M)
+        SKIP[:, H:] = 0; CB[:, H:] = 0
+        SKIP[:, H:H + 96] = enc.to(DEV, torch.bfloat16)
+        CB[:, H:H + 27] = cond.to(DEV, torch.bfloat16)
+        raw_rgb, raw_d, saved = net.forward(SKIP, CB, True)
+        with torch.no_grad():
+            raw_i, _, _ = net.forward(SKIP.clone(), CB.clone(), False)
+        arena.grad.zero_()
+        net.backward(d_rgb.to(DEV), d_den.to(DEV), saved)
+        return raw_rgb, raw_i, saved, {k: arena.g[k].clone() for k in sd}
+    rgb_f, rgb_fi, saved_f, g_f = run(True)
+    rgb_l, _, saved_l, g_l = run(False)
+    assert saved_f[1][-1][0] == "fused" and len(saved_l[1]) == 3
+    ref = rr.reshape(M, 3)
+    assert rel(rgb_f, ref) < 2e-2 and rel(rgb_l, ref) < 2e-2, (rel(rgb_f, ref), rel(rgb_l, ref))
+    assert rel(rgb_f, rgb_l) < 5e-3, rel(rgb_f, rgb_l)
+    assert torch.equal(rgb_fi, rgb_f), "inference launch (no stores) must reproduce the training launch"
+    for j in range(3):
+        assert rel(saved_f[1][j][2], saved_l[1][j][2]) < 1e-2, (j, rel(saved_f[1][j][2], saved_l[1][j][2]))
+    for k in sd:
+        e_f, e_l = rel(g_f[k], pr[k].grad), rel(g_l[k], pr[k].grad)
+        assert e_f < 0.25 and e_f < 2.0 * e_l + 2e-2, (k, e_f, e_l)
+    for k in ("mlp.cond_layers.0.layers.0.weight", "mlp.cond_layers.1.layers.0.bias", "mlp.cond_layers.2.layers.0.bias", "mlp.bottleneck_layer.layers.0.bias",
+              "mlp.bottleneck_layer.layers.0.weight", "mlp.layers.3.layers.0.weight"):
+        assert rel(g_f[k], g_l[k]) < 3e-2, (k, rel(g_f[k], g_l[k]))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("M", [1000, 768])
 def test_fused_training_forward_stores_activations_and_relu_bits(M):

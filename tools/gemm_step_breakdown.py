@@ -25,9 +25,28 @@ def tw(dZ, X, dW, n_valid, k_valid, dt, **kw):
     e0.record(); ow(dZ, X, dW, n_valid, k_valid, dt, **kw); e1.record()
     rec.append(("TN", dZ.shape[0], n_valid, k_valid, e0, e1))
 ops.linear_fwd, ops.linear_wgrad = tf, tw
+fused = []                                           # the fused launches of the step (not GEMM launches): timed beside them
+def wrap(name):
+    orig = getattr(ops, name)
+    def timed(*a, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); r = orig(*a, **kw); e1.record()
+        fused.append((name, e0, e1))
+        return r
+    setattr(ops, name, timed)
+    return orig
+saved = {n: wrap(n) for n in ("fcolour_fwd", "fcolour_bwd", "fmlp_proposal_train_fwd", "mip_encode", "mip_composite_fwd", "mip_composite_bwd", "mip_resample", "adam_step")}
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+ev[0].record()
 tr.step(rays, tgt, depth, conf)
+ev[1].record()
 torch.cuda.synchronize()
 ops.linear_fwd, ops.linear_wgrad = of, ow
+for n, f in saved.items():
+    setattr(ops, n, f)
+print(f"instrumented step {ev[0].elapsed_time(ev[1]):.2f} ms")
+for n, e0, e1 in fused:
+    print(f"fused/other {n:28s} {e0.elapsed_time(e1) * 1e3:8.1f} us")
 rows = [(k, M, N, K, e0.elapsed_time(e1)) for k, M, N, K, e0, e1 in rec]
 tot = sum(r[4] for r in rows)
 print(f"{len(rows)} GEMM launches, {tot:.2f} ms")
