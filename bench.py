@@ -87,6 +87,23 @@ def build_model(compute, device, seed=0):
                         proposal_loss=True, compute=compute, device=device)
 
 
+def roofline_traffic(compute, variant):
+    """HBM bytes of ONE launch of the dominant kernel at its largest layer shape, from the committed PMC measurement
+    (profiles/roofline_traffic.json: FETCH_SIZE x2 + WRITE_SIZE of separate rocprofv3 --pmc passes) -- reported only while the kernel's
+    source still hashes to what was measured (tools/kernel_hash.py), so an edit of the tile walk cannot leave a stale number in the line."""
+    if compute != "bf16" or variant != 8:
+        return None, "no PMC measurement for this kernel selection"
+    try:
+        sys.path.insert(0, os.path.join(REPO, "tools"))
+        from kernel_hash import kernel_hash
+        d = json.load(open(os.path.join(REPO, "profiles", "roofline_traffic.json")))
+        if d["kernel_sha256"] != kernel_hash(d["kernel"]):
+            return None, f"STALE: {d['kernel']} changed since {d['source']} was measured; rerun tools/pmc_gemm_traffic.sh and tools/kernel_hash.py --update"
+        return d["fetch_bytes"] + d["write_bytes"], f"{d['source']} (per launch at {d['launch']}; algorithmic {d['algorithmic_bytes']:.3g} B; kernel sha256 {d['kernel_sha256'][:12]})"
+    except (OSError, KeyError, ValueError) as e:
+        return None, f"unavailable: {e}"
+
+
 def measure_gemm_kernel(trainer, rays, tgt, depth, conf):
     """One instrumented step: HIP events around every launch of the dominant kernel (the NT MFMA GEMM used by all forward
     and data-gradient layers), on the stream the kernels run on (torch's current stream)."""
@@ -185,6 +202,37 @@ def eager_baseline(model_sd, rays, n_rays, steps, bf16):
     return n_rays / dt_s, dt_s * 1e3
 
 
+def dropin_autograd_leg(model_sd, rays, tgt, depth, conf, device, steps):
+    """What an UNMODIFIED s-nerf/train.py executes per step with the drop-in module (train.py:112-115, 150-221): `model(rays)` through
+    the autograd Function, the losses as torch expressions (RgbLoss loss_factory.py:5-11, the confidence-weighted disparity DepthLoss on
+    both levels :26-37 / confidence.py:209-224), `loss.backward()`, `torch.optim.Adam.step()` -- no fused loss tail, no fused Adam, no
+    flat-arena shortcuts.  The product path only; timed like the headline."""
+    m = build_model("bf16", device)
+    m.load_state_dict({k: v.clone() for k, v in model_sd.items()})
+    opt = torch.optim.Adam(m.parameters(), lr=5e-4)
+    mask = depth > 0
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        ret = m(rays, True, False, 0.)
+        loss = ((ret[1][0] - tgt) ** 2).mean()
+        for lvl, mult in ((1, 1.0), (0, 0.2)):
+            d = (1.0 / ret[lvl][1] - 1.0 / depth.clamp(min=1e-6)).abs() * conf
+            loss = loss + 0.2 * mult * torch.where(mask, d, torch.zeros_like(d)).sum() / mask.sum().clamp(min=1)
+        loss.backward()
+        opt.step()
+        return loss
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return dt, float(loss)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -200,6 +248,7 @@ def main():
     ap.add_argument("--no-eager", action="store_true", help="skip the PyTorch-ROCm eager baseline (3 steps each of fp32 and bf16 autocast on this GPU)")
     ap.add_argument("--no-f32", action="store_true", help="skip the fp32-parity-mode leg (3 train steps with exact-fp32 MFMA)")
     ap.add_argument("--eager", action="store_true", help="(kept for compatibility: the eager baseline is on by default)")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the drop-in-autograd and pose-refinement legs (5 steps each)")
     ap.add_argument("--cpu-rays", type=int, default=512, help="rays of the bounded host-CPU baseline sample (about 15 s on the GPU box)")
     ap.add_argument("--shape", default="baseline", choices=["baseline", "shipped"],
                     help="baseline = BASELINE.json's 64 proposal + 128 fine evals/ray (192 spp); shipped = the reference config's "
@@ -304,12 +353,10 @@ def main():
             alg_nt -= n * 2.0 * S0 * MAC_PROP                                    # the proposal MLP's forward is one fmlp_kernel launch, not NT GEMMs
         achieved = alg_nt / (gemm_ms * 1e-3) / 1e12
         peak = PEAK_BF16_TFLOPS if args.compute == "bf16" else 157.3
+        traffic, traffic_src = roofline_traffic(args.compute, args.variant)
         roofline = {"bound": "mfma", "kernel": {8: "gemm_nt8p_kernel (bf16, 256x256 persistent 8-phase)", 4: "gemm_nt8_kernel (bf16, 256x256 8-phase)", 1: "gemm_nt_kernel<bf16,256,256,2,4>"}.get(args.variant, "gemm_nt_kernel<bf16,128,128,2,2>") if args.compute == "bf16" else "gemm_nt_kernel<f32,128,128,2,2>",
                     "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                    # HBM bytes of ONE launch of the largest layer shape (M = 524288, N = K = 1024: algorithmic 1.07 GB in + 1.07 GB out),
-                    # from separate rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE): tools/pmc_gemm.sh
-                    "traffic": (1.618e9 + 1.074e9) if (args.compute == "bf16" and args.variant == 8) else None,
-                    "traffic_source": "profiles/r2_m_gemm_nt8p_traffic.txt (per launch at M=524288 N=K=1024; algorithmic 2.15e9 B)",
+                    "traffic": traffic, "traffic_source": traffic_src,
                     "launches_per_step": launches, "avg_launch_ms": round(gemm_ms / launches, 4), "kernel_ms_per_step": round(gemm_ms, 3),
                     "algorithmic_flops_per_step": alg_nt, "padded_flops_per_step": padded_flops,
                     "whole_step_tflops": round(3 * fwd * n / (ms_step * 1e-3) / 1e12, 1)}
@@ -369,6 +416,27 @@ def main():
                             "tflops": round(fwd * H * W / t_frame / 1e12, 1),
                             "includes": "on-device ray generation, snerf_amd.mipnerf.render_image (chunk loop), all-gather of rgb / distance / acc"}
         del rgb_f, dist_f, acc_f, grid, fr
+
+    # ---- the two routes a user of the reference takes besides MipTrainer.step: the unmodified train.py loop (autograd + torch losses +
+    # torch.optim.Adam) and the shipped config's pose_refine = True (configs/nuScenes_depth_6cams:31: the step also back-propagates to
+    # the rays, MipTrainer.step(..., ray_grads=True))
+    if rank == 0 and world == 1 and not args.no_dropin and args.compute == "bf16":
+        sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+        dt_d, loss_d = dropin_autograd_leg(sd0, rays, tgt, depth, conf, device, 5)
+        out["dropin_autograd"] = {"rays_per_s": round(n / dt_d, 1), "ms_per_step": round(dt_d * 1e3, 3), "steps": 5, "final_loss": loss_d,
+                                  "vs_headline": round((n / dt_d) / out["value"], 4),
+                                  "what": "model(rays) -> torch losses -> loss.backward() -> torch.optim.Adam.step(): the loop of s-nerf/train.py:112-221 unmodified"}
+        for _ in range(2):
+            trainer.step(rays, tgt, depth, conf, ray_grads=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            trainer.step(rays, tgt, depth, conf, ray_grads=True)
+        torch.cuda.synchronize()
+        dt_p = (time.perf_counter() - t0) / 5
+        out["pose_refine"] = {"rays_per_s": round(n / dt_p, 1), "ms_per_step": round(dt_p * 1e3, 3), "steps": 5, "vs_headline": round((n / dt_p) / out["value"], 4),
+                              "what": "MipTrainer.step(..., ray_grads=True): the train step + d loss / d (origins, directions, viewdirs) for the pose optimiser"}
+        torch.cuda.empty_cache()
 
     # ---- the fp32-parity mode's speed (north_star's 1e-4-relative contract holds in compute="f32": exact-fp32 MFMA 32x32x2, 157.3 TF peak)
     if rank == 0 and world == 1 and not args.no_f32 and args.compute == "bf16":

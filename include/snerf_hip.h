@@ -374,13 +374,14 @@ int snerf_fmlp_proposal_train_fwd(const void* E, long ldE, const void* wstream, 
  *   wstream (336 fragments; cond_layers.0 in k-major order) / bias (13 blocks) from snerf_amd.mlp.fmlp_pack.  acts / act_ld / bits:
  *   HOST arrays of 3 (or all NULL for inference): the three hidden activations ([M, >= 128] bf16) and their ReLU bit masks
  *   (8 * ceil(M / 256) * 2 * 64 words each, snerf_linear_fwd's mask-bit layout for N = 128), stored for the backward pass.
+ *   variant: 0; bit 0 selects the alternative input read-ahead depth (tools/fcolour_probe.py).
  * snerf_fcolour_bwd: d_raw_rgb [M,3] fp32 -> dC[0..2] = d pre-activation of cond_layers.2, .1, .0 ([M, >= 128] bf16; the weight-
  *   gradient GEMMs read them) and dB = d pre-activation of the bottleneck layer [M, >= 1024] bf16.  bits[0..3] = the bit masks of
  *   cond_layers.2, .1, .0 and of the bottleneck (N = 1024); wstream (336 fragments) = fmlp_pack of the TRANSPOSED weights; the four
  *   layers' bias gradients are ADDED to g_bias[0..3] (128, 128, 128, 1024 floats) in a fixed order (bit-reproducible).
  *   ws: snerf_fcolour_bwd_ws_floats(M) floats. */
 int snerf_fcolour_fwd(const void* CB, long ldCB, const void* wstream, long n_frags, const float* bias, int n_blocks, float* raw_rgb,
-                      void* const* acts, const long* act_ld, void* const* bits, long M, void* stream);
+                      void* const* acts, const long* act_ld, void* const* bits, long M, int variant, void* stream);
 long snerf_fcolour_bwd_ws_floats(long M);
 int snerf_fcolour_bwd(const float* d_raw_rgb, const void* wstream, long n_frags, void* const* bits, void* const* dC, const long* dC_ld,
                       void* dB, long dB_ld, float* const* g_bias, float* ws, long ws_floats, long M, void* stream);
@@ -412,7 +413,7 @@ int snerf_classic_ray_batch(int H, int W, double focal, double cx, double cy, co
 
 /* snerf_zip_encode_bwd without the atomic wall ("binned" table gradient): the contributions of gridencoder.cu:248-340 are written
  * out as records partitioned by destination (level, range of 4096 (C = 4) / 16384 (C = 1) table rows, replica), then one workgroup per
- * bin accumulates its records in LDS with 64-bit fixed-point integer atomics (resolution 2^-36) and writes its rows back: no L2
+ * bin accumulates its records in LDS with 64-bit fixed-point integer atomics (scale from snerf_zip_bin_scale) and writes its rows back: no L2
  * atomics on the hashed levels, and a gradient that is BIT-IDENTICAL run to run (integer addition is order-independent).
  * Three calls: pass 0 counts (counts [L,1024] int32, zeroed by the caller) and reserves every workgroup's range inside the bins it
  * touches (wg_offsets: uint32 [L, ceil(R*S/256), 1024], need not be initialised); the caller scans the counts into `starts`
@@ -420,12 +421,18 @@ int snerf_classic_ray_batch(int H, int W, double focal, double cx, double cy, co
  * [capacity, max(C, 2)] -- for C = 1 a record is one 8-byte {row, value} pair in rec_val and rec_row is not touched; capacity >=
  * R*S*n*8*L is always enough); pass 2 accumulates into grad_table (fp32, +=).  ksplit_host: HOST int[L],
  * replicas per row range (> 1 for levels with few, hot rows: they meet in g64, an int64 image of table rows [0, g64_rows) zeroed by
- * the caller). */
+ * the caller); level_rows_host: HOST int[L], table rows per level -- a level needs ceil(rows / 4096 or 16384) * ksplit <= 1024 bins,
+ * anything larger is refused with a bad-argument status (use snerf_zip_encode_bwd, the atomic scatter). */
 int snerf_zip_encode_bwd_binned(int pass, const float* tdist, const float* origins, const float* directions, const float* radii,
                                 const float* base_x, const float* base_y, const float* deg_jitter, const int* offsets,
                                 const int* grid_sizes, const void* grad_feat, long ld, float* grad_table, long R, int S, int L, int C, int n,
-                                int m, float Sl, int H, float std_scale, int feat_dtype, const int* ksplit_host, int* counts, void* wg_offsets,
-                                const long* starts, void* rec_row, float* rec_val, long capacity, void* g64, long g64_rows, void* stream);
+                                int m, float Sl, int H, float std_scale, int feat_dtype, const int* ksplit_host, const int* level_rows_host,
+                                int* counts, void* wg_offsets, const long* starts, void* rec_row, float* rec_val, long capacity, void* g64,
+                                long g64_rows, const int* scale_exp, void* stream);
+/* The fixed-point scale of one binned launch: scale_exp (device int[2]) [0] = e such that 2^e * max |grad_feat[:rows, :cols]| lies in
+ * [2^33, 2^34) -- the accumulation grid follows the magnitude of the gradient (a loss-scaled 1e-12 gradient keeps 34 bits below its
+ * largest entry); pass 2 reads it. */
+int snerf_zip_bin_scale(const void* grad_feat, long ld, long rows, int cols, int feat_dtype, int* scale_exp, void* stream);
 
 /* Featurisation backward to the RAYS -- `cal_input_grad` of the reference (internal/models.py:491 -> gridencoder/grid.py:65-89 ->
  * gridencoder.cu:199-244, 343-369), needed by the pose refinement of zipnerf/train.py:187-197: d loss / d (origins, directions, base_x,

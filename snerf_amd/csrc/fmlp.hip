@@ -479,6 +479,7 @@ __global__ __launch_bounds__(64 * FM_WAVES, 2) void fmlp_kernel(FmlpArgs a) {   
 #define FC_FWD_FRAGS (4 * FC_NK0 + 32 + 32 + 8)     // 336 = 21 chunks
 #define FC_FWD_BLOCKS 13                            // 4 + 4 + 4 + 1 bias blocks
 #define FC_QD 12                                    // input fragments in flight (three 128-byte lines per row)
+#define FC_QD_ALT 20                                // (variant bit 0 of snerf_fcolour_fwd: five lines)
 #define FC_BWD_FRAGS 336                            // 4 (rgb^T) + 32 + 32 + 256 (cond_layers.0^T, bottleneck columns) + 12 padding
 #define FC_BWD_COLS 1408                            // 3 x 128 + 1024 bias-gradient columns
 
@@ -505,23 +506,27 @@ __device__ __forceinline__ void kmajor_fetch(bf16x8 (&q)[QD], const __bf16* src)
   if constexpr (K < NK) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(q[K % QD]) : "v"(src), "n"(32 * K) : "memory");
 }
 __device__ __forceinline__ constexpr int kmajor_cnt(int a, int b, int nk) { return (b < nk ? b : nk) - (a < nk ? a : nk); }
-// vector-memory operations issued after the loads of line L (k-steps 4 L .. 4 L + 3) and before its first use at k-step 4 L: the two
-// lines fetched after it, and two DMA pieces per chunk boundary in between (a boundary falls in front of every k-step S = 3 mod 4 of
-// a 4-block k-major layer that starts on a chunk boundary: fragment 4 S + FM_LOOK is a multiple of FM_CHUNK).  "At most that many
-// outstanding" therefore means line L has landed (loads retire in order).
-__device__ __forceinline__ constexpr int kmajor_younger(int L, int nk) {
-  return kmajor_cnt(4 * L + 4, 4 * L + 8, nk) + kmajor_cnt(4 * L + 8, 4 * L + 12, nk) + 2 * (L < 2 ? L : 2);
+// vector-memory operations issued after the loads of line L (k-steps 4 L .. 4 L + 3) and before its first use at k-step 4 L, with
+// A = QD / 4 - 1 lines of read-ahead: the A lines fetched after it, and two DMA pieces per chunk boundary in between (a boundary falls
+// in front of every k-step S = 3 mod 4 of a 4-block k-major layer that starts on a chunk boundary: fragment 4 S + FM_LOOK is a
+// multiple of FM_CHUNK; line L > A is fetched at k-step 4 (L - A), the first A + 1 lines at the start of the tile).  "At most that
+// many outstanding" therefore means line L has landed (loads retire in order).
+__device__ __forceinline__ constexpr int kmajor_younger(int L, int nk, int qd) {
+  const int A = qd / 4 - 1;
+  int n = 2 * (L < A ? L : A);
+  for (int i = 1; i <= A; ++i) n += kmajor_cnt(4 * (L + i), 4 * (L + i) + 4, nk);
+  return n;
 }
 template <int F, int NB, int NK, int QD, int S, typename C>
 __device__ __forceinline__ void kmajor_one(C& c, f32x16 (&acc)[NB], bf16x8 (&q)[QD], const __bf16* src) {
-  static_assert(NB == 4 && QD == 12 && FM_LOOK == 4 && FM_CHUNK == 16 && F % FM_CHUNK == 0, "the wait counts below assume this geometry");
+  static_assert(NB == 4 && QD % 4 == 0 && QD >= 8 && FM_LOOK == 4 && FM_CHUNK == 16 && F % FM_CHUNK == 0, "the wait counts assume this geometry");
   if constexpr (S % 4 == 0) {
     if constexpr (S >= 4) {                             // the line consumed last (k-steps S - 4 .. S - 1) is free: fetch the line QD - 4 ahead
       kmajor_fetch<NK, QD, S + QD - 4>(q, src); kmajor_fetch<NK, QD, S + QD - 3>(q, src);
       kmajor_fetch<NK, QD, S + QD - 2>(q, src); kmajor_fetch<NK, QD, S + QD - 1>(q, src);
     }
     // (the four registers are operands of the wait, so that no use of them can be scheduled in front of it)
-    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(q[S % QD]), "+v"(q[S % QD + 1]), "+v"(q[S % QD + 2]), "+v"(q[S % QD + 3]) : "n"(kmajor_younger(S / 4, NK)));
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(q[S % QD]), "+v"(q[S % QD + 1]), "+v"(q[S % QD + 2]), "+v"(q[S % QD + 3]) : "n"(kmajor_younger(S / 4, NK, QD)));
   }
   kmajor_mfma<F, NB, S>(c, acc, q[S % QD], std::make_integer_sequence<int, NB>{});
 }
@@ -534,7 +539,7 @@ __device__ __forceinline__ void kmajor_prefetch(bf16x8 (&q)[QD], const __bf16* s
   (kmajor_fetch<NK, QD, K>(q, src), ...);
 }
 
-template <bool STORE>
+template <bool STORE, int QD>
 __global__ __launch_bounds__(64 * FM_WAVES, 2) void fcolour_fwd_kernel(ColourFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -549,10 +554,10 @@ __global__ __launch_bounds__(64 * FM_WAVES, 2) void fcolour_fwd_kernel(ColourFwd
     const bool row_ok = row < a.M;
     row = row_ok ? row : a.M - 1;                       // tail rows: compute on a valid row, store nothing
     const __bf16* src = a.CB + row * a.ldCB + half * 8;
-    bf16x8 qin[FC_QD];
-    kmajor_prefetch<FC_NK0, FC_QD>(qin, src, std::make_integer_sequence<int, FC_QD>{});
+    bf16x8 qin[QD];
+    kmajor_prefetch<FC_NK0, QD>(qin, src, std::make_integer_sequence<int, QD>{});
     f32x16 acc[4] = {acc_init<0>(c), acc_init<1>(c), acc_init<2>(c), acc_init<3>(c)};
-    kmajor_seq<0, 4, FC_NK0, FC_QD>(c, acc, qin, src, std::make_integer_sequence<int, FC_NK0>{});
+    kmajor_seq<0, 4, FC_NK0, QD>(c, acc, qin, src, std::make_integer_sequence<int, FC_NK0>{});
     auto to = [&](int i) { return StoreTo{a.act[i], a.act_ld[i], a.bits[i], (long)tile * FM_TILE_ROWS + wave * 32, a.M, slab, lane, 2}; };
     bf16x8 p[8], q[8];
     to_frags<true>(acc[0], p[0], p[1]);
@@ -583,7 +588,7 @@ struct ColourBwdArgs {
   const unsigned* bits[4];            // ReLU bit masks of cond_layers.2, .1, .0 (2 column groups) and of the bottleneck (16)
   __bf16* dC[3]; long dC_ld[3];       // d pre-activation of cond_layers.2, .1, .0 ([M, >= 128] bf16), read by the weight-gradient GEMMs
   __bf16* dB; long dB_ld;             // d pre-activation of the bottleneck layer [M, >= 1024]
-  float* colsum_ws;                   // [gridDim.x * FM_WAVES, FC_BWD_COLS]: per-wave bias-gradient partials
+  float* colsum_ws;                   // [gridDim.x, FC_BWD_COLS]: per-workgroup bias-gradient partials
   long M;
   int tiles, n_chunks;
 };
@@ -737,16 +742,26 @@ __global__ __launch_bounds__(64 * FM_WAVES, 2) void fcolour_bwd_kernel(ColourBwd
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of the bottleneck masks have returned: refill
     if (more) dma_wide(next0, ln);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // the workgroup's eight waves fold their partials in LDS (wave order: fixed) and leave ONE row of the workspace
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's read-ahead of the stream has landed: the ring can be reused
+  __syncthreads();
+  float* red = (float*)smem;                            // [FM_WAVES][FC_BWD_COLS]
   {
     const int r = lane & 15;
-    float* dst = a.colsum_ws + (long)((int)blockIdx.x * FM_WAVES + wave) * FC_BWD_COLS + 32 * ((lane >> 4) & 1) + (r & 3) + 8 * (r >> 2) + 4 * half;
+    float* dst = red + wave * FC_BWD_COLS + 32 * ((lane >> 4) & 1) + (r & 3) + 8 * (r >> 2) + 4 * half;
 #pragma unroll
     for (int i = 0; i < FC_BWD_COLS / 64; ++i) dst[64 * i] = cs[i];
   }
+  __syncthreads();
+  for (int col = tid; col < FC_BWD_COLS; col += 64 * FM_WAVES) {
+    float t = red[col];
+#pragma unroll
+    for (int w = 1; w < FM_WAVES; ++w) t += red[w * FC_BWD_COLS + col];
+    a.colsum_ws[(long)blockIdx.x * FC_BWD_COLS + col] = t;
+  }
 }
 
-// bias gradients += the per-wave partials, summed in a fixed order (bit-reproducible): 64 columns x 4 row groups per workgroup
+// bias gradients += the per-workgroup partials, summed in a fixed order (bit-reproducible): 64 columns x 4 row groups per workgroup
 __global__ __launch_bounds__(256) void fcolour_colsum_fold_kernel(const float* __restrict__ ws, int rows, float* g2, float* g1, float* g0, float* gb) {
   __shared__ float part[4][64];
   const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
@@ -874,7 +889,7 @@ static int fcolour_grid(int tiles) {
 // acts / act_ld / bits (HOST arrays of 3; all nullptr for inference): where the three hidden activations ([M, >= 128] bf16) and their
 // ReLU bit masks (snerf_linear_fwd's ACT_RELU_BITS layout for N = 128) are stored for the backward pass.
 extern "C" int snerf_fcolour_fwd(const void* CB, long ldCB, const void* wstream, long n_frags, const float* bias, int n_blocks, float* raw_rgb,
-                                 void* const* acts, const long* act_ld, void* const* bits, long M, void* stream) {
+                                 void* const* acts, const long* act_ld, void* const* bits, long M, int variant, void* stream) {
   if (M <= 0) return SNERF_OK;
   if (CB == nullptr || wstream == nullptr || bias == nullptr || raw_rgb == nullptr || (((uintptr_t)CB) & 15) || (((uintptr_t)wstream) & 15) ||
       (ldCB % 8) != 0 || ldCB < 16 * FC_NK0 || n_frags != FC_FWD_FRAGS || n_blocks != FC_FWD_BLOCKS)
@@ -893,20 +908,29 @@ extern "C" int snerf_fcolour_fwd(const void* CB, long ldCB, const void* wstream,
   const int lds = FM_RING * FM_SLOT + FM_BIAS_MAX * 128 + FM_WAVES * 4096;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)fcolour_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute((const void*)fcolour_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)fcolour_fwd_kernel<false, FC_QD>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)fcolour_fwd_kernel<true, FC_QD>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)fcolour_fwd_kernel<false, FC_QD_ALT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)fcolour_fwd_kernel<true, FC_QD_ALT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
   const int grid = fcolour_grid(a.tiles);
-  if (store) hipLaunchKernelGGL(fcolour_fwd_kernel<true>, dim3(grid), dim3(64 * FM_WAVES), lds, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(fcolour_fwd_kernel<false>, dim3(grid), dim3(64 * FM_WAVES), lds, (hipStream_t)stream, a);
+  const dim3 g(grid), b(64 * FM_WAVES);
+  hipStream_t st = (hipStream_t)stream;
+  if (variant & 1) {                                    // tools/fcolour_probe.py: the alternative read-ahead depth
+    if (store) hipLaunchKernelGGL((fcolour_fwd_kernel<true, FC_QD_ALT>), g, b, lds, st, a);
+    else hipLaunchKernelGGL((fcolour_fwd_kernel<false, FC_QD_ALT>), g, b, lds, st, a);
+  } else {
+    if (store) hipLaunchKernelGGL((fcolour_fwd_kernel<true, FC_QD>), g, b, lds, st, a);
+    else hipLaunchKernelGGL((fcolour_fwd_kernel<false, FC_QD>), g, b, lds, st, a);
+  }
   return snerf_check_launch();
 }
 
 // workspace floats snerf_fcolour_bwd needs for M rows
 extern "C" long snerf_fcolour_bwd_ws_floats(long M) {
   if (M <= 0) return 0;
-  return (long)fcolour_grid((int)((M + FM_TILE_ROWS - 1) / FM_TILE_ROWS)) * FM_WAVES * FC_BWD_COLS;
+  return (long)fcolour_grid((int)((M + FM_TILE_ROWS - 1) / FM_TILE_ROWS)) * FC_BWD_COLS;
 }
 
 // Data-gradient chain of the colour head: d_raw_rgb [M,3] fp32 -> dC[0..2] = d pre-activation of cond_layers.2, .1, .0 ([M, >= 128]
@@ -940,7 +964,7 @@ extern "C" int snerf_fcolour_bwd(const float* d_raw_rgb, const void* wstream, lo
   }
   const int grid = fcolour_grid(a.tiles);
   hipLaunchKernelGGL(fcolour_bwd_kernel, dim3(grid), dim3(64 * FM_WAVES), lds, (hipStream_t)stream, a);
-  hipLaunchKernelGGL(fcolour_colsum_fold_kernel, dim3(FC_BWD_COLS / 64), dim3(256), 0, (hipStream_t)stream, ws, grid * FM_WAVES, g_bias[0], g_bias[1],
+  hipLaunchKernelGGL(fcolour_colsum_fold_kernel, dim3(FC_BWD_COLS / 64), dim3(256), 0, (hipStream_t)stream, ws, grid, g_bias[0], g_bias[1],
                      g_bias[2], g_bias[3]);
   return snerf_check_launch();
 }

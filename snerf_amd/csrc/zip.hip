@@ -834,7 +834,9 @@ extern "C" int snerf_zip_encode_bwd(const float* tdist, const float* origins, co
 // the order of the additions (hence the low bits of the gradient) changes from run to run.  Here the same contributions are first
 // written out as RECORDS (row inside its bin: 2 bytes, value: C floats), partitioned by destination -- bin = (level, range of 4096 /
 // 16384 table rows (C = 4 / 1), replica) -- and then ONE workgroup per bin adds its records into an LDS image of those rows with
-// 64-bit FIXED-POINT integer atomics (2^-36 resolution): LDS atomics are ~2 orders of magnitude cheaper than L2 atomics, every
+// 64-bit FIXED-POINT integer atomics (scale 2^e chosen per launch from max |grad_feat| so that the largest contribution maps to
+// < 2^34: a relative resolution of 2^-34 of the largest entry whatever the loss scale -- round 2's fixed 2^36 turned every
+// contribution below 7e-12 into zero; rounding to that grid is the only difference to exact real-number sums): LDS atomics are ~2 orders of magnitude cheaper than L2 atomics, every
 // table row is written back by exactly one workgroup, and integer addition is associative, so the gradient is BIT-IDENTICAL run to
 // run whatever order the records arrive in.  Levels whose rows are few but hot (the dense levels: 4913 rows take 118 M records)
 // are split into K replicas that meet in a small global int64 image (again order-independent).
@@ -846,7 +848,7 @@ extern "C" int snerf_zip_encode_bwd(const float* tdist, const float* origins, co
 //   pass 3  zip_bin_finish_kernel       fold the replicated levels' int64 image into the gradient
 // ------------------------------------------------------------------------------------------------------------------
 #define ZB_NBMAX 1024                      // bins per level (row ranges x replicas)
-#define ZB_FIX 68719476736.f               // 2^36
+#define ZB_HEAD 34                         // the largest |grad_feat| entry maps below 2^ZB_HEAD: 2^27 records cannot overflow 63 bits
 
 struct ZipBin {
   int bshift;                              // log2(rows per bin)
@@ -856,6 +858,7 @@ struct ZipBin {
   int ksplit[16];                          // replicas per row range, per level
   unsigned short* rec_row; float* rec_val; long capacity;   // records: C = 1: rec_val holds {row, value} pairs (8 B); else row + C floats
   long long* g64; long g64_rows;           // int64 image of table rows [0, g64_rows) for the replicated levels
+  const int* scale_exp;                    // device: the launch's fixed-point scale is 2^scale_exp[0] (snerf_zip_bin_scale)
 };
 
 // the records of one (interval, level): same merging of consecutive multisamples in one cell as the atomic path
@@ -980,6 +983,9 @@ __global__ __launch_bounds__(1024) void zip_bin_accumulate_kernel(ZipEnc a, ZipB
   const long row0 = (long)(bin / K) << b.bshift;
   if (row0 >= rows_l) return;                              // bins past the level's last row range
   const int n = b.counts[level * ZB_NBMAX + bin];
+  const int se = b.scale_exp[0];
+  const float fix = exp2f((float)se), lim = exp2f((float)(ZB_HEAD + 1 - se));
+  const double unfix = exp2((double)-se);
   const int cells = (int)min((long)(1 << b.bshift), rows_l - row0) * C;
   for (int k = threadIdx.x; k < cells; k += 1024) zb_acc[k] = 0;
   __syncthreads();
@@ -1014,8 +1020,8 @@ __global__ __launch_bounds__(1024) void zip_bin_accumulate_kernel(ZipEnc a, ZipB
       if (row[u] < 0) continue;
 #pragma unroll
       for (int c = 0; c < C; ++c) {
-        const float v = fminf(fmaxf(val[u][c], -1.0e8f), 1.0e8f);
-        atomicAdd((unsigned long long*)(zb_acc + row[u] * C + c), (unsigned long long)__float2ll_rn(v * ZB_FIX));
+        const float v = fminf(fmaxf(val[u][c], -lim), lim);   // (a record is at most max |grad_feat| in magnitude: the clamp only stops non-finite values)
+        atomicAdd((unsigned long long*)(zb_acc + row[u] * C + c), (unsigned long long)__float2ll_rn(v * fix));
       }
     }
   }
@@ -1025,7 +1031,7 @@ __global__ __launch_bounds__(1024) void zip_bin_accumulate_kernel(ZipEnc a, ZipB
     float* dst = a.grad_table + grow * C;
     for (int k = threadIdx.x; k < cells; k += 1024) {
       const long long v = zb_acc[k];
-      if (v != 0) dst[k] += (float)((double)v * (1.0 / (double)ZB_FIX));
+      if (v != 0) dst[k] += (float)((double)v * unfix);
     }
   } else {
     long long* dst = b.g64 + grow * C;
@@ -1036,28 +1042,79 @@ __global__ __launch_bounds__(1024) void zip_bin_accumulate_kernel(ZipEnc a, ZipB
   }
 }
 
-__global__ __launch_bounds__(256) void zip_bin_finish_kernel(const long long* __restrict__ g64, long n, float* __restrict__ grad) {
+__global__ __launch_bounds__(256) void zip_bin_finish_kernel(const long long* __restrict__ g64, long n, float* __restrict__ grad, const int* __restrict__ scale_exp) {
+  const double unfix = exp2((double)-scale_exp[0]);
   for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < n; k += (long)gridDim.x * 256) {
     const long long v = g64[k];
-    if (v != 0) grad[k] += (float)((double)v * (1.0 / (double)ZB_FIX));
+    if (v != 0) grad[k] += (float)((double)v * unfix);
   }
+}
+
+// scale_exp[0] = e with 2^e * max |grad_feat| in [2^(ZB_HEAD - 1), 2^ZB_HEAD) (clamped to the normal range of a float; 36, round 2's
+// constant, when the gradient is all zeros or not finite); scale_exp[1]: scratch (bits of the running maximum)
+template <typename OT>
+__global__ __launch_bounds__(256) void zip_bin_absmax_kernel(const OT* __restrict__ g, long ld, long rows, int cols, unsigned* __restrict__ mx) {
+  float m = 0.f;
+  const long total = rows * cols;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long r = e / cols;
+    m = fmaxf(m, fabsf((float)g[r * ld + (e - r * cols)]));
+  }
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(mx, __float_as_uint(m));      // (non-negative floats order like their bit patterns)
+}
+__global__ void zip_bin_scale_kernel(int* scale_exp) {
+  const unsigned bits = (unsigned)scale_exp[1];
+  int e = 36;
+  if (bits != 0 && bits < 0x7f800000u) {
+    const int ex = (int)(bits >> 23) - 127;                  // max < 2^(ex + 1) (a denormal maximum counts as 2^-127)
+    e = ZB_HEAD - (ex + 1);
+    e = e > 127 ? 127 : (e < -100 ? -100 : e);
+  }
+  scale_exp[0] = e;
+}
+
+extern "C" int snerf_zip_bin_scale(const void* grad_feat, long ld, long rows, int cols, int feat_dtype, int* scale_exp, void* stream) {
+  if (scale_exp == nullptr || (rows > 0 && (grad_feat == nullptr || cols <= 0 || ld < cols))) return SNERF_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  (void)hipMemsetAsync(scale_exp, 0, 2 * sizeof(int), s);
+  if (rows > 0) {
+    const long total = rows * cols;
+    const int grid = (int)(total / 256 / 8 + 1 < 2048 ? total / 256 / 8 + 1 : 2048);
+    if (feat_dtype == SNERF_DT_BF16) hipLaunchKernelGGL(zip_bin_absmax_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)grad_feat, ld, rows, cols, (unsigned*)(scale_exp + 1));
+    else if (feat_dtype == SNERF_DT_F32) hipLaunchKernelGGL(zip_bin_absmax_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)grad_feat, ld, rows, cols, (unsigned*)(scale_exp + 1));
+    else return SNERF_ERR_ARG;
+  }
+  hipLaunchKernelGGL(zip_bin_scale_kernel, dim3(1), dim3(1), 0, s, scale_exp);
+  return snerf_check_launch();
 }
 
 // pass: 0 = count (+ reserve), 1 = write records, 2 = accumulate (+ finish).  The host zeroes counts / g64 and scans counts into starts.
 extern "C" int snerf_zip_encode_bwd_binned(int pass, const float* tdist, const float* origins, const float* directions, const float* radii,
                                            const float* base_x, const float* base_y, const float* deg_jitter, const int* offsets,
                                            const int* grid_sizes, const void* grad_feat, long ld, float* grad_table, long R, int S, int L, int C,
-                                           int n, int m, float Sl, int H, float std_scale, int feat_dtype, const int* ksplit_host, int* counts,
-                                           void* wg_offsets, const long* starts, void* rec_row, float* rec_val, long capacity, void* g64,
-                                           long g64_rows, void* stream) {
+                                           int n, int m, float Sl, int H, float std_scale, int feat_dtype, const int* ksplit_host,
+                                           const int* level_rows_host, int* counts, void* wg_offsets, const long* starts, void* rec_row,
+                                           float* rec_val, long capacity, void* g64, long g64_rows, const int* scale_exp, void* stream) {
   if (R <= 0) return SNERF_OK;
-  if (S <= 0 || L <= 0 || L > 16 || n <= 0 || (C != 1 && C != 4) || ksplit_host == nullptr || counts == nullptr) return SNERF_ERR_ARG;
+  if (S <= 0 || L <= 0 || L > 16 || n <= 0 || (C != 1 && C != 4) || ksplit_host == nullptr || level_rows_host == nullptr || counts == nullptr)
+    return SNERF_ERR_ARG;
+  // a level's bins = row ranges x replicas must fit the ZB_NBMAX-entry histograms of the kernels (LDS cnt / base, counts [L, ZB_NBMAX],
+  // the accumulate grid): a table past 2^22 (C = 4) / 2^24 (C = 1) rows per level has more row ranges than that -- refuse it here
+  // instead of corrupting LDS and dropping gradients (the caller falls back to the atomic scatter)
+  for (int l = 0; l < L; ++l) {
+    const long rowbins = ((long)level_rows_host[l] + (1L << (C == 4 ? 12 : 14)) - 1) >> (C == 4 ? 12 : 14);
+    if (level_rows_host[l] <= 0 || ksplit_host[l] < 1 || rowbins * ksplit_host[l] > ZB_NBMAX) return SNERF_ERR_ARG;
+  }
   ZipEnc a{tdist, origins, directions, radii, base_x, base_y, deg_jitter, nullptr, offsets, grid_sizes, (void*)grad_feat, ld, grad_table, nullptr, R, S, L, n, m, Sl, H, std_scale};
   ZipBin b{};
   b.bshift = C == 4 ? 12 : 14;
   b.counts = counts; b.wg_offsets = (unsigned*)wg_offsets; b.starts = starts;
   for (int l = 0; l < L; ++l) { b.ksplit[l] = ksplit_host[l]; if (b.ksplit[l] < 1) return SNERF_ERR_ARG; }
   b.rec_row = (unsigned short*)rec_row; b.rec_val = rec_val; b.capacity = capacity; b.g64 = (long long*)g64; b.g64_rows = g64_rows;
+  b.scale_exp = scale_exp;
   hipStream_t s = (hipStream_t)stream;
   const dim3 blk(256);
   if (pass == 0 || pass == 1) {
@@ -1072,7 +1129,7 @@ extern "C" int snerf_zip_encode_bwd_binned(int pass, const float* tdist, const f
 #undef ZBE
     return snerf_check_launch();
   }
-  if (pass != 2 || starts == nullptr || rec_row == nullptr || rec_val == nullptr || grad_table == nullptr) return SNERF_ERR_ARG;
+  if (pass != 2 || starts == nullptr || rec_row == nullptr || rec_val == nullptr || grad_table == nullptr || scale_exp == nullptr) return SNERF_ERR_ARG;
   const size_t lds = (size_t)(1 << b.bshift) * C * 8;
   const dim3 grid(ZB_NBMAX, L);
   if (C == 4) {
@@ -1083,7 +1140,7 @@ extern "C" int snerf_zip_encode_bwd_binned(int pass, const float* tdist, const f
     hipLaunchKernelGGL((zip_bin_accumulate_kernel<1>), grid, dim3(1024), lds, s, a, b);
   }
   if (g64 != nullptr && g64_rows > 0)
-    hipLaunchKernelGGL(zip_bin_finish_kernel, dim3(1024), blk, 0, s, (const long long*)g64, g64_rows * C, grad_table);
+    hipLaunchKernelGGL(zip_bin_finish_kernel, dim3(1024), blk, 0, s, (const long long*)g64, g64_rows * C, grad_table, scale_exp);
   return snerf_check_launch();
 }
 

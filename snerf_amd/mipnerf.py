@@ -292,6 +292,9 @@ def render_image(render_fn, rays, rank=0, chunk=8192, world=1, group=None):
     height, width = rays[0].shape[:2]
     num_rays = height * width
     flat = Rays(*[r.reshape(num_rays, -1) for r in rays])
+    if world > 1 and num_rays < world:
+        # a rank with an empty block would skip the all-gathers the others enter (and would not even know the number of output columns)
+        raise ValueError(f"render_image: {num_rays} rays cannot be sharded over {world} ranks")
     per, rem = divmod(num_rays, world)
     lo = rank * per + min(rank, rem)
     hi = lo + per + (1 if rank < rem else 0)

@@ -335,7 +335,15 @@ class _Net:
                 ops.linear_fwd(dZ, W, None, dX, K, n_store, ops.ACT_MASK_BITS, self.dt, aux=ent[0], colsum=colsum, variant=self.variant,
                                deterministic=self.deterministic)
                 return
-        ops.linear_fwd(dZ, W, None, dX, K, n_store, ACT_MASK if mask is not None else ACT_NONE, self.dt,
+        act = ACT_MASK if mask is not None else ACT_NONE
+        if self.deterministic and colsum is not None and not ops.fast_epilogue_ok(dX, n_store, self.dt, aux=mask, act=act):
+            # deterministic mode and a destination the 16-byte epilogue does not cover (an unaligned view, n_store % 8 != 0): the
+            # direct-store epilogue could only add its column sums with atomics (snerf_linear_fwd refuses the combination), so the
+            # bias gradient comes from a fixed-order column sum of the stored data gradient instead
+            ops.linear_fwd(dZ, W, None, dX, K, n_store, act, self.dt, aux=mask, variant=self.variant)
+            ops.colsum_f32(dX[:, :n_store].float().contiguous(), n_store, colsum[:n_store], deterministic=True)
+            return
+        ops.linear_fwd(dZ, W, None, dX, K, n_store, act, self.dt,
                        aux=mask, colsum=colsum, variant=self.variant, deterministic=self.deterministic)
 
     def wgrad(self, name, dZ, X, n_valid, k_valid, wcol=0):

@@ -81,6 +81,16 @@ def linear_fwd(A, W, bias, Y, K, n_store, act, dt, out_f32=False, aux=None, cols
               1 if out_f32 else 0, variant, _stream())
 
 
+def fast_epilogue_ok(Y, n_store, dt, out_f32=False, aux=None, act=ACT_NONE):
+    """Whether snerf_linear_fwd takes its LDS-transposed 16-byte epilogue for this launch (mirrors the dispatch in gemm.hip): the only
+    epilogue whose bias-gradient column sums can be folded deterministically (the direct-store epilogue adds them with atomics)."""
+    epc = 4 if dt == F32 else 8
+    ok = not (out_f32 and dt == BF16) and Y.stride(0) % epc == 0 and Y.data_ptr() % 16 == 0 and n_store % epc == 0
+    if act == ACT_MASK and aux is not None:
+        ok = ok and aux.stride(0) % epc == 0 and aux.data_ptr() % 16 == 0
+    return ok
+
+
 def mask_bits_words(M, N):
     """int32 words of the ReLU bit mask of an [M, N] activation (N % 64 == 0): one 64-word block per (32 rows, 64 columns)."""
     return 8 * ((M + 255) // 256) * (N // 64) * 64
@@ -177,7 +187,7 @@ def fmlp_proposal_train_fwd(E, stream, bias, raw_density, acts, bits):
               _p(raw_density), ctypes.addressof(ptrs), ctypes.addressof(lds), ctypes.addressof(bp), E.shape[0], _stream())
 
 
-def fcolour_fwd(CB, stream, bias, raw_rgb, acts=None, bits=None):
+def fcolour_fwd(CB, stream, bias, raw_rgb, acts=None, bits=None, variant=0):
     """Fused colour head of the mip path's NeRF MLP (csrc/fmlp.hip): CB [M, >= 1056] bf16 = [bottleneck 1024 | view encoding 27 | 0]
     -> raw_rgb [M,3] fp32 in ONE launch.  Training: `acts` = 3 x [M, >= 128] bf16 (outputs of cond_layers.0..2), `bits` = 3 x int32
     [mask_bits_words(M, 128)] (their ReLU bit masks), stored for fcolour_bwd and the weight-gradient GEMMs."""
@@ -197,7 +207,7 @@ def fcolour_fwd(CB, stream, bias, raw_rgb, acts=None, bits=None):
         pb = (ctypes.c_void_p * 3)(*[b.data_ptr() for b in bits])
     _lib.call("snerf_fcolour_fwd", _p(CB), CB.stride(0), _p(stream), stream.shape[0], _p(bias), bias.numel() // 32, _p(raw_rgb),
               None if pa is None else ctypes.addressof(pa), None if pl is None else ctypes.addressof(pl),
-              None if pb is None else ctypes.addressof(pb), M, _stream())
+              None if pb is None else ctypes.addressof(pb), M, int(variant), _stream())
 
 
 def fcolour_bwd(d_raw_rgb, stream, bits, dC, dB, g_bias):
@@ -589,42 +599,65 @@ def zip_bin_plan(offsets_host, C, records_per_level):
     """Host-side plan of the binned table gradient: per level the number of replicas K of every row range (levels with few, hot rows
     are split so that a bin holds ~ZB_TARGET records) and the number of leading table rows the int64 meeting image must cover."""
     br = 4096 if C == 4 else 16384
-    ks, g64_rows = [], 0
+    ks, g64_rows, level_rows = [], 0, []
     for l in range(len(offsets_host) - 1):
         rows = int(offsets_host[l + 1] - offsets_host[l])
         rowbins = max((rows + br - 1) // br, 1)
+        if rowbins > ZB_NBMAX:
+            raise ValueError(f"binned table gradient: level {l} has {rows} rows = {rowbins} row ranges of {br}, more than the {ZB_NBMAX} bins per "
+                             "level of the kernels; use table_grad_mode='atomic' for tables this large")
         k = max(1, min(-(-int(records_per_level) // (rowbins * ZB_TARGET)), ZB_NBMAX // rowbins))
         ks.append(k)
+        level_rows.append(rows)
         if k > 1:
             g64_rows = int(offsets_host[l + 1])
-    return ks, g64_rows
+    return ks, g64_rows, level_rows
+
+
+_zb_ws = {}
+
+
+def _zb_workspace(dev, key, numel, dtype):
+    """the binned backward's worst-case buffers, kept across calls (one stream: a call's kernels finish before the next call reuses
+    them); grown, never shrunk"""
+    t = _zb_ws.get((dev, key))
+    if t is None or t.numel() < numel or t.dtype != dtype:
+        t = torch.empty(numel, dtype=dtype, device=dev)
+        _zb_ws[(dev, key)] = t
+    return t
 
 
 def zip_encode_bwd_binned(tdist, origins, directions, radii, base_x, base_y, deg_jitter, offsets, grid_sizes, grad_feat, grad_table, L, C, n, m, Sl, H,
-                          std_scale, ksplit, g64_rows):
+                          std_scale, ksplit, g64_rows, level_rows):
     """The table gradient of zip_encode_bwd without L2 atomics on the hashed levels and bit-reproducible: records binned by destination,
-    accumulated per bin in LDS with fixed-point integer atomics (snerf_zip_encode_bwd_binned: count, scan on the device, write, accumulate)."""
+    accumulated per bin in LDS with fixed-point integer atomics (snerf_zip_encode_bwd_binned: count, scan on the device, write, accumulate).
+    The fixed-point grid follows the gradient's magnitude (snerf_zip_bin_scale: 34 bits below max |grad_feat|)."""
     import numpy as np
     R, P = tdist.shape
     S = P - 1
     dev = tdist.device
     assert grad_table.dtype == torch.float32 and grad_table.is_contiguous() and C in (1, 4) and L <= 16
     ks = np.ascontiguousarray(np.asarray(ksplit, dtype=np.int32))
+    lr = np.ascontiguousarray(np.asarray(level_rows, dtype=np.int32))
+    assert ks.shape == (L,) and lr.shape == (L,)
     counts = torch.zeros(L, ZB_NBMAX, dtype=torch.int32, device=dev)
+    scale = torch.empty(2, dtype=torch.int32, device=dev)
+    _lib.call("snerf_zip_bin_scale", _p(grad_feat), grad_feat.stride(0), R * S, L * C, _zip_dt(grad_feat), _p(scale), _stream())
     args = (_p(tdist), _p(origins), _p(directions), _p(radii), _p(base_x), _p(base_y), _p(deg_jitter), _p(offsets), _p(grid_sizes), _p(grad_feat),
-            grad_feat.stride(0), _p(grad_table), R, S, L, C, n, m, float(Sl), int(H), float(std_scale), _zip_dt(grad_feat), ks.ctypes.data)
+            grad_feat.stride(0), _p(grad_table), R, S, L, C, n, m, float(Sl), int(H), float(std_scale), _zip_dt(grad_feat), ks.ctypes.data,
+            lr.ctypes.data)
     # pass 0 also reserves each workgroup's record range inside the bins it touches (offsets relative to the bin's start)
-    wgo = torch.empty(L * ((R * S + 255) // 256) * ZB_NBMAX, dtype=torch.int32, device=dev)
-    _lib.call("snerf_zip_encode_bwd_binned", 0, *args, _p(counts), _p(wgo), None, None, None, 0, None, 0, _stream())
+    wgo = _zb_workspace(dev, "wgo", L * ((R * S + 255) // 256) * ZB_NBMAX, torch.int32)
+    _lib.call("snerf_zip_encode_bwd_binned", 0, *args, _p(counts), _p(wgo), None, None, None, 0, None, 0, None, _stream())
     flat = counts.view(-1).to(torch.int64)
     starts = (torch.cumsum(flat, 0) - flat).contiguous()
     capacity = R * S * n * 8 * L                               # every (interval, level) emits at most n cells x 8 corners: no host sync
-    rec_row = torch.empty(capacity, dtype=torch.int16, device=dev)
-    rec_val = torch.empty(capacity, max(C, 2), dtype=torch.float32, device=dev)       # C = 1: {row, value} pairs in one 8-byte record
-    _lib.call("snerf_zip_encode_bwd_binned", 1, *args, _p(counts), _p(wgo), _p(starts), _p(rec_row), _p(rec_val), capacity, None, 0, _stream())
+    rec_row = _zb_workspace(dev, "row", capacity, torch.int16)
+    rec_val = _zb_workspace(dev, "val", capacity * max(C, 2), torch.float32)       # C = 1: {row, value} pairs in one 8-byte record
+    _lib.call("snerf_zip_encode_bwd_binned", 1, *args, _p(counts), _p(wgo), _p(starts), _p(rec_row), _p(rec_val), capacity, None, 0, None, _stream())
     g64 = torch.zeros(max(g64_rows, 1) * C, dtype=torch.int64, device=dev) if g64_rows > 0 else None
     _lib.call("snerf_zip_encode_bwd_binned", 2, *args, _p(counts), _p(wgo), _p(starts), _p(rec_row), _p(rec_val), capacity, _p(g64), int(g64_rows),
-              _stream())
+              _p(scale), _stream())
 
 
 def zip_composite_fwd(raw_rgb, raw_density, tdist, dirs, opaque, bg, rgb_padding, density_bias):

@@ -86,7 +86,7 @@ class Model(_ArenaModule):
     distinct_prop: bool = True
     single_mlp: bool = False
 
-    def __init__(self, config=None, compute: str = "bf16", table_dtype: str = "f16", device="cuda", grid_log2_hashmap_size: int = 21,
+    def __init__(self, config=None, compute: str = "bf16", table_dtype: str = "ref", device="cuda", grid_log2_hashmap_size: int = 21,
                  nerf_desired_resolution: int = 8192, init_std: float = 1e-4, table_grad_dtype: str = "f32", use_semantic: bool = False,
                  class_num: int = 19, table_grad_mode: str = "binned", **kwargs):
         super().__init__()
@@ -116,7 +116,11 @@ class Model(_ArenaModule):
         self._setup_arena(shapes, dev)
         self.dt = _dt(compute)
         self.compute = compute
-        self.table_half = {"f16": True, "fp16": True, "f32": False, "fp32": False}[table_dtype]
+        # gather tables: "ref" (default) = what the reference does under autocast (gridencoder/grid.py:41-44): embeddings are halved only
+        # when C is even, i.e. the C = 4 NeRF table in fp16 and the two C = 1 proposal tables in fp32; "f16" halves all three (narrower
+        # storage than the reference's on the proposal levels: an extension, benchmarked separately); "f32" none
+        self.table_mode = {"ref": "ref", "f16": "f16", "fp16": "f16", "f32": "f32", "fp32": "f32"}[table_dtype]
+        self.table_half = self.table_mode != "f32"        # (any table halved)
         # "bf16": the hashed levels' table gradient is scattered as packed bf16 pairs (the reference's autocast path scatters
         # __half2, gridencoder.cu:300-330); "f32" (default) keeps every contribution in fp32
         self.table_grad_bf16 = {"f32": False, "fp32": False, "bf16": True}[table_grad_dtype]
@@ -126,6 +130,12 @@ class Model(_ArenaModule):
         if table_grad_mode not in ("binned", "atomic"):
             raise ValueError(table_grad_mode)
         self.table_grad_mode = "atomic" if self.table_grad_bf16 else table_grad_mode
+        if self.table_grad_mode == "binned":
+            # the binned kernels hold ZB_NBMAX bins per level: a table whose level has more row ranges (2^22 rows at C = 4, 2^24 at
+            # C = 1, i.e. grid_log2_hashmap_size >= 23 / 25) does not fit them -- the plan raises, and construction fails HERE rather
+            # than in the middle of the first backward pass
+            for e in self.encs:
+                ops.zip_bin_plan(e.offsets, e.C, 1)
         self.nets = [ZipPropNet(self.arena, "prop_mlp_0.", self.dt, self.encs[0].L), ZipPropNet(self.arena, "prop_mlp_1.", self.dt, self.encs[1].L),
                      ZipNerfNet(self.arena, "nerf_mlp.", self.dt, self.encs[2].L * 4)]
         for n in self.nets:
@@ -159,14 +169,15 @@ class Model(_ArenaModule):
 
     # --------------------------------------------------------------------------------------------------------------
     def _table(self, lvl):
-        """the gather table: fp16 copy of the fp32 master embeddings (like the reference under autocast, grid.py:41-44; C = 1
-        tables stay fp32 there -- here every table may be halved, the gradient always accumulates in fp32)"""
+        """the gather table: fp16 copy of the fp32 master embeddings where `table_dtype` says so (default: like the reference under
+        autocast, grid.py:41-44 -- C = 4 halved, the C = 1 tables stay fp32); the gradient always accumulates in fp32"""
         v = self._param_version()
         if v != self._tables_version:
             self._tables, self._tables_version = [None] * 3, v
         if self._tables[lvl] is None:
             emb = self.arena.p[self.names[lvl] + "encoder.embeddings"]
-            self._tables[lvl] = emb.detach().half().contiguous() if self.table_half else emb.detach()
+            half = self.table_mode == "f16" or (self.table_mode == "ref" and self.encs[lvl].C % 2 == 0)
+            self._tables[lvl] = emb.detach().half().contiguous() if half else emb.detach()
         return self._tables[lvl]
 
     def _anneal(self, train_frac):
@@ -288,9 +299,9 @@ class Model(_ArenaModule):
                                        rg[0], rg[1], rg[3], rg[4])
             gtab = self.arena.g[self.names[lvl] + "encoder.embeddings"]
             if self.table_grad_mode == "binned":
-                ks, g64_rows = ops.zip_bin_plan(e.offsets, e.C, P * ctx["n"] * 8)
+                ks, g64_rows, lrows = ops.zip_bin_plan(e.offsets, e.C, P * ctx["n"] * 8)
                 ops.zip_encode_bwd_binned(L["tdist"], ctx["o"], ctx["d"], ctx["radii"], ctx["bx"], ctx["by"], L["degj"], self.dev_offsets[lvl],
-                                          self.dev_sizes[lvl], dF, gtab, e.L, e.C, ctx["n"], ctx["m"], e.Sl, e.H, self.std_scale, ks, g64_rows)
+                                          self.dev_sizes[lvl], dF, gtab, e.L, e.C, ctx["n"], ctx["m"], e.Sl, e.H, self.std_scale, ks, g64_rows, lrows)
                 if on_done is not None:
                     on_done(self.names[lvl])
                 continue

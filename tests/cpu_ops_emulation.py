@@ -239,8 +239,8 @@ def zip_encode_bwd(tdist, origins, directions, radii, base_x, base_y, deg_jitter
 
 
 def zip_encode_bwd_binned(tdist, origins, directions, radii, base_x, base_y, deg_jitter, offsets, grid_sizes, grad_feat, grad_table, L, C, n, m, Sl, H,
-                          std_scale, ksplit, g64_rows):
-    assert len(ksplit) == L and all(k >= 1 for k in ksplit)
+                          std_scale, ksplit, g64_rows, level_rows):
+    assert len(ksplit) == L and all(k >= 1 for k in ksplit) and len(level_rows) == L
     zip_encode_bwd(tdist, origins, directions, radii, base_x, base_y, deg_jitter, offsets, grid_sizes, grad_feat, grad_table, L, C, n, m, Sl, H, std_scale)
 
 
@@ -546,7 +546,7 @@ def fmlp_proposal_train_fwd(E, stream, bias, raw_density, acts, bits):
         _BITS[w.data_ptr()] = y.float() > 0
 
 
-def fcolour_fwd(CB, stream, bias, raw_rgb, acts=None, bits=None):
+def fcolour_fwd(CB, stream, bias, raw_rgb, acts=None, bits=None, variant=0):
     """model of fcolour_fwd_kernel: cond_layers.0 K-MAJOR (66 k-steps x 4 blocks), then two 128-wide layers and the rgb head"""
     assert stream.shape[0] == 336 and bias.numel() == 13 * 32
     st = _FStream(stream, bias)

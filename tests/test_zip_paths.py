@@ -547,11 +547,13 @@ def test_zip_encode_ray_bwd_kernel_vs_oracle(lvl, half):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("lvl", [0, 2])
-def test_zip_table_gradient_binned_is_exact_and_bit_reproducible(lvl, monkeypatch):
+@pytest.mark.parametrize("lvl,gscale", [(0, 1e-3), (2, 1e-3), (2, 1e-11), (0, 3e3)])
+def test_zip_table_gradient_binned_is_exact_and_bit_reproducible(lvl, gscale, monkeypatch):
     """The "binned" table gradient (records partitioned by destination, per-bin LDS accumulation in 64-bit fixed point) against the
     atomic scatter on identical inputs at the production grid sizes (2^21-row hashed levels, several row ranges and -- with a lowered
-    records-per-bin target -- replicated dense levels): equal to fp32 rounding, and bit-identical run to run."""
+    records-per-bin target -- replicated dense levels): equal to fp32 rounding, and bit-identical run to run.  `gscale`: magnitude of
+    d loss / d features -- the fixed-point grid follows it (snerf_zip_bin_scale), so a loss-scaled 1e-11 gradient (mean over 65 536
+    rays x sample weight x 1 / n: what the fine levels of a real step see) is as exact as a 1e-3 one."""
     from snerf_amd import ops, zipnerf
     m = zipnerf.Model(config=None, raydist_fn='power_transformation', opaque_background=True, compute="bf16", table_dtype="f16")
     e = m.encs[lvl]
@@ -566,18 +568,18 @@ def test_zip_table_gradient_binned_is_exact_and_bit_reproducible(lvl, monkeypatc
     degj = c(torch.rand(R, S, n, generator=g))
     d, bx, by = c(d), c(bx), c(by)
     Fw = m.nets[lvl].Fw
-    dF = c(torch.randn(R * S, Fw, generator=g) * 1e-3).bfloat16()
+    dF = c(torch.randn(R * S, Fw, generator=g) * gscale).bfloat16()
     common = (tdist, o, d, radii, bx, by, degj, m.dev_offsets[lvl], m.dev_sizes[lvl], dF)
     tail = (e.L, e.C, n, 3, e.Sl, e.H, m.std_scale)
     ref = torch.zeros(e.rows, e.C, device="cuda")
     ops.zip_encode_bwd(*common, ref, *tail, 0, 0, 0)                                   # fp32 global atomics, every level
     monkeypatch.setattr(ops, "ZB_TARGET", 40_000)                                      # forces replicas (K > 1) on the dense levels
-    ks, g64_rows = ops.zip_bin_plan(e.offsets, e.C, R * S * n * 8)
+    ks, g64_rows, lrows = ops.zip_bin_plan(e.offsets, e.C, R * S * n * 8)
     assert max(ks) > 1 and g64_rows > 0
     outs = []
     for _ in range(2):
         gt = torch.zeros(e.rows, e.C, device="cuda")
-        ops.zip_encode_bwd_binned(*common, gt, *tail, ks, g64_rows)
+        ops.zip_encode_bwd_binned(*common, gt, *tail, ks, g64_rows, lrows)
         outs.append(gt)
     assert torch.equal(outs[0], outs[1]), "binned table gradient must be bit-reproducible"
     rel = float((outs[0] - ref).norm() / ref.norm())
@@ -585,3 +587,20 @@ def test_zip_table_gradient_binned_is_exact_and_bit_reproducible(lvl, monkeypatc
     assert float(ref.norm()) > 0 and rel < 2e-6, rel
     nz = ref != 0
     assert float(((outs[0] - ref).abs()[nz] / ref.abs()[nz]).median()) < 1e-6
+
+
+def test_binned_table_gradient_refuses_tables_with_more_row_ranges_than_bins():
+    """at grid_log2_hashmap_size >= 23 (C = 4) / 25 (C = 1) a level has more than ZB_NBMAX = 1024 row ranges; the kernels'
+    1024-entry histograms would be overrun.  The plan raises, and the C entry returns a bad-argument status before launching anything."""
+    import numpy as np
+    from snerf_amd import _lib, ops
+    offs = np.array([0, 4913, 4913 + (1 << 23)], dtype=np.int64)
+    with pytest.raises(ValueError, match="row ranges"):
+        ops.zip_bin_plan(offs, 4, 1 << 20)
+    ks, g64, rows = ops.zip_bin_plan(np.array([0, 4913, 4913 + (1 << 21)]), 4, 1 << 20)
+    assert rows == [4913, 1 << 21] and all(((r + 4095) // 4096) * k <= ops.ZB_NBMAX for r, k in zip(rows, ks))
+    k2 = np.array([1, 1], dtype=np.int32)
+    big = np.array([4913, 1 << 23], dtype=np.int32)
+    with pytest.raises(_lib.SnerfHipError, match="bad argument"):
+        _lib.call("snerf_zip_encode_bwd_binned", 0, None, None, None, None, None, None, None, None, None, None, 8, None, 16, 4, 2, 4, 7, 3, 0.5, 16, 0.35,
+                  1, k2.ctypes.data, big.ctypes.data, 1, 1, None, None, None, 0, None, 0, None, None)
