@@ -422,9 +422,7 @@ def render_path(render_poses, hwf, chunk, render_kwargs, gt_imgs=None, savedir=N
             rgb[render_masks[i]] = 0
         rgbs.append(rgb.cpu().numpy())
         disps.append(disp.cpu().numpy())
-        if savedir is not None:                         # the reference converts here and writes nothing (render.py:129-132)
-            rgb8 = to8b(rgbs[-1])
-            rgb8[np.isnan(rgb8)] = 0
+        # (`savedir`: the reference converts the frame to 8 bits here and writes nothing, render.py:129-132 -- its imageio call is commented out)
     return np.stack(rgbs, 0), np.stack(disps, 0)
 
 
