@@ -458,6 +458,27 @@ def main():
                            "note": "the mode in which rgb / depth match the reference within 1e-4 relative (parity read-out below)"}
         del t32, m32
         torch.cuda.empty_cache()
+        # the same contract at bf16 MFMA rates: split-bf16 operands (hi = bf16(x), lo = bf16(x - hi); hi.hi + lo.hi + hi.lo, fp32 accumulate)
+        mx3 = build_model("bf16x3", device)
+        mx3.load_state_dict({k: v.clone() for k, v in model.state_dict().items()})
+        tx3 = MipTrainer(mx3, lr=5e-4)
+        for _ in range(2):
+            tx3.step(rays, tgt, depth, conf)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            tx3.step(rays, tgt, depth, conf)
+        torch.cuda.synchronize()
+        dtx3 = (time.perf_counter() - t0) / 5
+        lx3, gx3, _ = measure_gemm_kernel(tx3, rays, tgt, depth, conf)
+        ax3 = 3.0 * n * (fwd + fwd - first - skipenc) / (gx3 * 1e-3) / 1e12          # three bf16 MFMA passes per algorithmic product
+        out["split_bf16_mode"] = {"rays_per_s": round(n / dtx3, 1), "ms_per_step": round(dtx3 * 1e3, 2), "steps": 5,
+                                  "roofline": {"bound": "mfma", "kernel": "gemm_nt8p_kernel<.., SPLIT> (three v_mfma_f32_32x32x16_bf16 passes per product)",
+                                               "achieved": round(ax3, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s (executed bf16 MFMA work)",
+                                               "frac": round(ax3 / PEAK_BF16_TFLOPS, 4), "launches_per_step": lx3},
+                                  "note": "compute='bf16x3': 16-bit mantissas through every GEMM; held to the same 1e-4 rgb / depth bounds as the exact-fp32 mode (parity read-out below)"}
+        del tx3, mx3
+        torch.cuda.empty_cache()
 
     # ---- parity read-out + host-CPU baseline (rank 0, N = 1 only)
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -470,6 +491,10 @@ def main():
             m32 = build_model("f32", device)
             m32.load_state_dict(sd)
             r32 = m32(sub, False, False, 0.)
+            mx3 = build_model("bf16x3", device)
+            mx3.load_state_dict(sd)
+            rx3 = mx3(sub, False, False, 0.)
+            del mx3
         mse = lambda a, b: float(((a.double() - b.double()) ** 2).mean())
         psnr = lambda a, b: (float("inf") if mse(a, b) == 0 else -10.0 * math.log10(mse(a, b)))
         out["cpu_baseline"] = {"value": round(cpu_rps, 2), "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
@@ -478,6 +503,9 @@ def main():
         out["parity"] = {"rays": ncpu,
                          "f32_kernels_vs_cpu_oracle_max_rel_err_rgb": float(((r32[1][0].cpu() - rgb_ref).abs() / (rgb_ref.abs() + 1e-3)).max()),
                          "f32_kernels_vs_cpu_oracle_max_rel_err_depth": float(((r32[1][1].cpu() - dist_ref).abs() / dist_ref.abs()).max()),
+                         "split_bf16_kernels_vs_cpu_oracle_max_rel_err_rgb": float(((rx3[1][0].cpu() - rgb_ref).abs() / (rgb_ref.abs() + 1e-3)).max()),
+                         "split_bf16_kernels_vs_cpu_oracle_max_rel_err_depth": float(((rx3[1][1].cpu() - dist_ref).abs() / dist_ref.abs()).max()),
+                         "psnr_split_bf16_kernels_vs_cpu_oracle_db": psnr(rx3[1][0].cpu(), rgb_ref),
                          "psnr_f32_kernels_vs_cpu_oracle_db": psnr(r32[1][0].cpu(), rgb_ref),
                          "psnr_bf16_kernels_vs_cpu_oracle_db": psnr(rb[1][0].cpu(), rgb_ref)}
         del m32

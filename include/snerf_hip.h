@@ -26,6 +26,7 @@ extern "C" {
 #define SNERF_DT_BF16 1
 #define SNERF_DT_F16 2 /* hash-grid tables only */
 #define SNERF_DT_F64 3 /* stand-alone GridEncoder operator only (the reference dispatches float / double / half) */
+#define SNERF_DT_BF16X3 4 /* snerf_linear_fwd / snerf_linear_wgrad only: split-bf16 operands (the fp32-parity mode at bf16 MFMA rates) */
 #define SNERF_ACT_NONE 0
 #define SNERF_ACT_RELU 1
 #define SNERF_ACT_MASK 2 /* y = aux > 0 ? y : 0 : ReLU backward fused into the data-gradient GEMM */
@@ -198,6 +199,17 @@ int snerf_zip_composite_bwd(const float* raw_rgb, long ld_rgb, const float* raw_
  * data-parallel 1/world_size; zero_grad clears g for the next step. */
 int snerf_adam_step(float* p, float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, int step,
                     float grad_scale, int zero_grad, void* stream);
+/* Split-bf16 operands (dtype SNERF_DT_BF16X3 of snerf_linear_fwd / snerf_linear_wgrad): a value x is carried as hi = bf16(x) and
+ * lo = bf16(x - hi) (16 mantissa bits) and a product evaluated as hi.hi + lo.hi + hi.lo on the bf16 MFMA path with fp32 accumulation
+ * -- the arithmetic of the reference (fp32, s-nerf/model/models.py) to ~2^-16 relative per product at 1/3 of the bf16 rate instead
+ * of 1/16 (the exact-fp32 MFMA).  Layout: activations [M, 2 K] with logical columns [64 j, 64 j + 64) at physical columns
+ * [128 j, 128 j + 64) (hi) and [128 j + 64, 128 j + 128) (lo); weights [N, 3 K] = [hi_j | hi_j | lo_j] per 64 columns (built by
+ * snerf_gather_pack: index bit 30 = the lo part).  snerf_linear_fwd then takes the LOGICAL K, writes bf16 outputs in the interleaved
+ * layout (fp32 outputs plainly), sums hi + lo into the bias gradient; snerf_linear_wgrad takes the PHYSICAL N = dZ columns and
+ * K = X columns (n_valid / k_valid logical) and maps its output indices back.  snerf_split_cast converts fp32 rows ([M, C], zero
+ * padded to Cpad % 64 == 0 logical columns) into that layout. */
+int snerf_split_cast(const float* src, long ld_src, long M, int C, int Cpad, void* dst, long ld_dst, void* stream);
+
 int snerf_colsum_f32(const float* x, long ld, long M, int C, float* out, void* stream);
 int snerf_cast_pad(const float* src, long ld_src, long M, int C, int Cpad, void* dst, long ld_dst, int dtype, void* stream);
 /* Refresh of the packed GEMM / fused-MLP operands after an optimiser step (the reference has no counterpart: torch.nn.Linear reads its

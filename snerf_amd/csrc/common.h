@@ -15,6 +15,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define SNERF_DT_F32 0
 #define SNERF_DT_BF16 1
 #define SNERF_DT_F64 3   // hash-grid tables of the stand-alone GridEncoder operator only
+#define SNERF_DT_BF16X3 4  // GEMM entries only: split-bf16 operands (hi = bf16(x), lo = bf16(x - hi); three MFMA passes), gemm.hip
 
 static inline int snerf_check_launch() {
   hipError_t e = hipGetLastError();

@@ -219,10 +219,50 @@ extern "C" int snerf_cast_pad(const float* src, long ld_src, long M, int C, int 
   return snerf_check_launch();
 }
 
-// Weight packing as ONE gather: dst[i] = idx[i] >= 0 ? flat[idx[i]] : (idx[i] == -2 ? 1 : 0), rounded to dst's type.  The index image
+// fp32 rows -> split-bf16 rows in the GEMMs' interleaved layout (gemm.hip, GemmNT::split): logical columns [64 j, 64 j + 64) of
+// hi = bf16(v) at physical columns [128 j, 128 j + 64), lo = bf16(v - hi) at [128 j + 64, 128 j + 128); columns C .. Cpad - 1 zero.
+// One thread per 8 consecutive logical columns: two 16-byte stores.
+__global__ __launch_bounds__(256) void split_cast_kernel(const float* __restrict__ src, long ld_src, long M, int C, int G, __bf16* __restrict__ dst,
+                                                         long ld_dst) {
+  const long total = M * G;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long m = e / G;
+    const int c0 = (int)(e - m * G) * 8;
+    bf16x8 h, l;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float v = c0 + k < C ? src[m * ld_src + c0 + k] : 0.f;
+      h[k] = (__bf16)v;
+      l[k] = (__bf16)(v - (float)h[k]);
+    }
+    __bf16* d = dst + m * ld_dst + ((c0 >> 6) << 7) + (c0 & 63);
+    *(bf16x8*)d = h;
+    *(bf16x8*)(d + 64) = l;
+  }
+}
+
+extern "C" int snerf_split_cast(const float* src, long ld_src, long M, int C, int Cpad, void* dst, long ld_dst, void* stream) {
+  if (M <= 0) return SNERF_OK;
+  if (src == nullptr || dst == nullptr || C < 0 || Cpad < C || (Cpad % 64) != 0 || (ld_dst % 8) != 0 || ld_dst < 2 * Cpad || (((uintptr_t)dst) & 15))
+    return SNERF_ERR_ARG;
+  const long total8 = M * (Cpad / 8);
+  const int blocks8 = (int)((total8 + 255) / 256 < 16384 ? (total8 + 255) / 256 : 16384);
+  hipLaunchKernelGGL(split_cast_kernel, dim3(blocks8), dim3(256), 0, (hipStream_t)stream, src, ld_src, M, C, Cpad / 8, (__bf16*)dst, ld_dst);
+  return snerf_check_launch();
+}
+
+// Weight packing as ONE gather: dst[i] = idx[i] >= 0 ? flat[idx[i]] : (idx[i] == -2 ? 1 : 0), rounded to dst's type.  An index with
+// bit 30 set selects the LOW part of the split-bf16 pair of flat[idx & 0x3fffffff]: bf16(x - bf16(x)) (bf16 destinations).  The index image
 // of every packed operand (padded / transposed / K-concatenated / MFMA-fragment-ordered copies of the parameters) depends only on the
 // network's structure, so the host builds it once and refreshes all operands of a network with this launch after every optimiser step
 // instead of ~60 slice copies.
+template <typename T>
+__device__ __forceinline__ T gather_one(const float* __restrict__ flat, int k) {
+  if (k < 0) return from_f32<T>(k == -2 ? 1.f : 0.f);
+  const float v = flat[k & 0x3fffffff];
+  if (k & 0x40000000) return from_f32<T>(v - (float)(__bf16)v);
+  return from_f32<T>(v);
+}
 template <typename T>
 __global__ __launch_bounds__(256) void gather_pack_kernel(const float* __restrict__ flat, const int* __restrict__ idx, long n, T* __restrict__ dst) {
   for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
@@ -231,11 +271,11 @@ __global__ __launch_bounds__(256) void gather_pack_kernel(const float* __restric
       const int kk[4] = {k.x, k.y, k.z, k.w};
       T o[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = from_f32<T>(kk[e] >= 0 ? flat[kk[e]] : (kk[e] == -2 ? 1.f : 0.f));
+      for (int e = 0; e < 4; ++e) o[e] = gather_one<T>(flat, kk[e]);
 #pragma unroll
       for (int e = 0; e < 4; ++e) dst[i + e] = o[e];
     } else {
-      for (long j = i; j < n; ++j) dst[j] = from_f32<T>(idx[j] >= 0 ? flat[idx[j]] : (idx[j] == -2 ? 1.f : 0.f));
+      for (long j = i; j < n; ++j) dst[j] = gather_one<T>(flat, idx[j]);
     }
   }
 }

@@ -42,7 +42,16 @@ struct GemmNT {
   int det;  // deterministic bias gradient: the per-slab column sums are folded by ONE thread per column (fixed order)
   int dbg;  // ablation bits, honoured only by a `make PROBE=1` build (tools/gemm_probe.py): 1 = no staging loads after tile 0, 2 = no LDS fragment reads, 4 = no stores
   int stagger;  // persistent kernel: workgroup start offsets, in units of KT x 64 clocks per slot (0 = all start together)
+  // Split-bf16 mode (dtype SNERF_DT_BF16X3: the fp32-parity mode at MFMA-bf16 rates).  Every operand value x is the pair hi = bf16(x),
+  // lo = bf16(x - hi) (16 mantissa bits), and a product is hi.hi + lo.hi + hi.lo (three bf16 MFMA passes, fp32 accumulation; lo.lo,
+  // 2^-16 of 2^-16, is dropped).  Activations are stored k-tile interleaved -- logical columns [64 j, 64 j + 64) live at physical
+  // columns [128 j, 128 j + 64) (hi) and [128 j + 64, 128 j + 128) (lo), so a logical column range at a multiple of 64 is a
+  // contiguous physical range of twice the width -- and the weights as [hi_j | hi_j | lo_j] per k-tile, so that the reduction loop
+  // simply walks 3 K / 64 VIRTUAL k-tiles: tile v reads W's physical tile v and A's physical tile 2 (v / 3) + (v % 3 == 1).
+  // K in this struct is the virtual reduction length (3 x the logical one).
+  int split;
 };
+__device__ __forceinline__ int split_a_tile(int v) { return 2 * (v / 3) + (v % 3 == 1 ? 1 : 0); }
 #ifndef SNERF_PROBE
 #define SNERF_PROBE 0   // the shipped library compiles the ablation branches out
 #endif
@@ -102,10 +111,14 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x16 (&acc)[BM / 
     for (int g = 0; g < NCG; ++g)
 #pragma unroll
       for (int e = 0; e < EPC; ++e) cs[g][e] = 0.f;
+    // split-bf16 mode (bf16 only): two passes per slab -- hi = bf16(v), then lo = bf16(v - hi) -- to the two halves of the
+    // 128-column physical group of these 64 logical columns; the mask source is the hi half of the saved activation
+    const int parts = (sizeof(T) == 2 && p.split) ? 2 : 1;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int g = 0; g < NCG; ++g) {
+        for (int part = 0; part < parts; ++part) {
         // phase 1: registers -> LDS slab [32 rows][CG columns]
 #pragma unroll
         for (int jj = 0; jj < JPG; ++jj) {
@@ -124,6 +137,10 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x16 (&acc)[BM / 
             char* dst = my + (lane & 31) * PITCH + cl * (int)sizeof(T);
             if constexpr (sizeof(T) == 2) {
               bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+              if (part == 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (__bf16)(v[e] - (float)o[e]);
+              }
               *(bf16x4*)dst = o;
             } else {
               f32x4 o = {v[0], v[1], v[2], v[3]};
@@ -134,6 +151,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x16 (&acc)[BM / 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // phase 2: LDS -> global, 8 lanes per 128-byte row segment
         const int ncol = n0 + wn * WTN + g * CG + pch * EPC;
+        const int pcol = parts == 2 ? ((ncol >> 6) << 7) + (ncol & 63) : ncol;     // physical column (hi half) of the logical column
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
           const int row = it * 8 + prow;
@@ -141,16 +159,17 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x16 (&acc)[BM / 
           frag_t val = *(const frag_t*)(my + row * PITCH + pch * 16);
           if (m < p.M && ncol < p.n_store && !DBG(p, 4)) {
             if (p.act == ACT_MASK) {
-              const frag_t a8 = *(const frag_t*)(auxp + (long)m * p.ldaux + ncol);
+              const frag_t a8 = *(const frag_t*)(auxp + (long)m * p.ldaux + pcol);
 #pragma unroll
               for (int e = 0; e < EPC; ++e) if (!((float)a8[e] > 0.f)) val[e] = (T)0.f;
             }
-            *(frag_t*)((T*)p.Y + (long)m * p.ldy + ncol) = val;
+            *(frag_t*)((T*)p.Y + (long)m * p.ldy + pcol + 64 * part) = val;
 #pragma unroll
             for (int e = 0; e < EPC; ++e) cs[g][e] += (float)val[e];
           }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
       }
     }
     if (p.colsum_ws != nullptr) {
@@ -299,8 +318,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmNT p) {
     char* sA = smem + stage * STAGE;
     char* sB = sA + BM * 128;
     const long k0 = (long)kt * BKE;
+    const long ka = p.split ? (long)split_a_tile(kt) * BKE : k0;
 #pragma unroll
-    for (int i = 0; i < LA; ++i) glds16(A + a_off[i] + k0, sA + (wave * LA + i) * 1024);
+    for (int i = 0; i < LA; ++i) glds16(A + a_off[i] + ka, sA + (wave * LA + i) * 1024);
 #pragma unroll
     for (int i = 0; i < LB; ++i) glds16(W + b_off[i] + k0, sB + (wave * LB + i) * 1024);
   };
@@ -406,8 +426,9 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmNT p) {
     char* dst = my_piece + (db * 4 + which) * HALF;
     const long k0 = (long)kt * 64;
     if (which < 2) {
-      glds16(A + a_off[which][0] + k0, dst);
-      glds16(A + a_off[which][1] + k0, dst + 1024);
+      const long ka = p.split ? (long)split_a_tile(kt) * 64 : k0;
+      glds16(A + a_off[which][0] + ka, dst);
+      glds16(A + a_off[which][1] + ka, dst + 1024);
     } else {
       glds16(W + b_off[which - 2][0] + k0, dst);
       glds16(W + b_off[which - 2][1] + k0, dst + 1024);
@@ -545,8 +566,9 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmNT p) {
 // ---------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-template <int ACT, bool COLSUM>
+template <int ACT, bool COLSUM, bool SPLIT = false>
 __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
+  static_assert(!(SPLIT && ACT == ACT_MASK), "split-bf16 data gradients take their ReLU masks from the bit masks");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __bf16 T;
   constexpr int HALF = 128 * 128;                      // bytes per half-tile
@@ -582,9 +604,12 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
     arel[i] = (((lr >> 6) * 128 + (lr & 63)) * (int)p.lda + c * 8) * 2;
     brel[i] = (((lr >> 5) * 64 + (lr & 31)) * (int)p.ldw + c * 8) * 2;
   }
+  // pieces 2 w and 2 w + 1 are 8 rows apart inside one 16-row group: same row block, swizzled chunk c ^ 4 (64 bytes up or down)
+  const int rel_dc = ((lsc ^ ((((wave * 2) * 8 + lrow) >> 1) & 7)) & 4) ? -64 : 64;
   const int a_half = 64 * (int)p.lda * 2, b_half = 32 * (int)p.ldw * 2;
   __amdgpu_buffer_rsrc_t rA, rB;
   int s_i = 0, s_kt = 0;
+  int s_ao = 0, s_m3 = 0;                              // SPLIT: byte offset of the A k-tile (hi, lo, hi of logical tile j = s_kt / 3), s_kt % 3
   auto stream_tile = [&](int i) __attribute__((always_inline)) {
     int m0, n0;
     origin(i < n_my ? i : n_my - 1, m0, n0);           // past the end: restage the last tile (never read)
@@ -593,18 +618,27 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
     rB = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (long)n0 * p.ldw), 0, 256 * (int)p.ldw * 2, 0x00020000);
   };
   auto stream_next = [&]() __attribute__((always_inline)) {
-    if (++s_kt == KT) { s_kt = 0; stream_tile(++s_i); }
+    if (++s_kt == KT) { s_kt = 0; s_ao = 0; s_m3 = 0; stream_tile(++s_i); }
+    else if (SPLIT) {                                    // virtual tile v -> A's physical tile 2 (v / 3) + (v % 3 == 1): +1, -1, +2 tiles
+      s_ao += s_m3 == 0 ? 128 : (s_m3 == 1 ? -128 : 256);
+      s_m3 = s_m3 == 2 ? 0 : s_m3 + 1;
+    }
   };
   // which: 0 = A0, 1 = A1, 2 = B0, 3 = B1 of the stream's k-tile; rows beyond M read as zeros (buffer bounds)
   auto stage = [&](int db, int which) __attribute__((always_inline)) {
     char* dst = smem + (db * 4 + which) * HALF + wave * 2048;
     const int soff = s_kt * 128;
     if (which < 2) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)dst, 16, arel[0] + which * a_half, soff, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)(dst + 1024), 16, arel[1] + which * a_half, soff, 0, 0);
+      const int aoff = SPLIT ? s_ao : soff;
+      // SPLIT (at the register limit): the second piece's offset is derived from the first -- 8 rows further, 16-byte chunk c ^ 4 --
+      // instead of being kept in a register of its own
+      const int a1 = SPLIT ? arel[0] + 16 * (int)p.lda + rel_dc : arel[1];
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)dst, 16, arel[0] + which * a_half, aoff, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)(dst + 1024), 16, a1 + which * a_half, aoff, 0, 0);
     } else {
+      const int b1 = SPLIT ? brel[0] + 16 * (int)p.ldw + rel_dc : brel[1];
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_ptr_t)dst, 16, brel[0] + (which - 2) * b_half, soff, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_ptr_t)(dst + 1024), 16, brel[1] + (which - 2) * b_half, soff, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_ptr_t)(dst + 1024), 16, b1 + (which - 2) * b_half, soff, 0, 0);
     }
   };
   // bias of tile i -> LDS (one 1 KiB DMA by wave 0), double buffered on tile parity
@@ -676,8 +710,11 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
     if (ACT == ACT_MASK_BITS) {
       // the mask DMA was issued in P3 of the tile's first k-tile; with fewer than four k-tiles the vmcnt(10) of the load
       // sections in between has not necessarily retired it (wave-private data: this wave's own wait is all it takes)
-      if (KT < 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      mw = *(const unsigned*)(smem + MASKB + ((wave * 4 + u) * 64 + ln) * 4);
+      if (!SPLIT && KT < 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (split: K >= 128 logical columns = 6 virtual k-tiles)
+      // read by inline asm: hipcc answers a ds_read of memory an LDS-DMA may have written with s_waitcnt vmcnt(0) -- a drain of the
+      // whole staging stream per unit (13 per tile pass in the plain flavour; the split flavour's two passes re-materialised the read
+      // into 43 of them: 9.2 ms instead of 2.7 per launch).  The word is waited for below, right before its first use.
+      if (!SPLIT) asm volatile("ds_read_b32 %0, %1" : "=v"(mw) : "v"((unsigned)(size_t)(smem + MASKB + ((wave * 4 + u) * 64 + ln) * 4)));
     }
     // the ReLU mask source first: these loads sit behind the staging DMA in the (in-order) vmcnt queue
     bf16x8 a8[ACT == ACT_MASK ? 4 : 1];
@@ -698,32 +735,58 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
     const char* bl = smem + BIAS + (par ^ 1) * 1024 + wc * 256 + hi * 16;
     typedef __attribute__((ext_vector_type(2))) float f32x2;
     typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    // SPLIT: the unit runs twice over its accumulators -- part 0 emits hi = bf16(v), part 1 lo = bf16(v - hi) (zero where the ReLU
+    // clamped v) -- to the two 64-column halves of the 128-column physical group of the wave's 64 logical columns; the accumulators
+    // are re-initialised after the second pass.  The two slab round trips are serial (no registers to hold the lo values across the
+    // first one), which the three-times-longer k-loop of this mode pays for.
+    // physical column of this lane's 8 values (split: group g of 64 logical columns = physical columns [128 g, 128 g + 128))
+    const int pcol = SPLIT ? 2 * (en0 + wc * 64) + pch * 8 : ncol;
+    T* const yrow = (T*)p.Y + (long)mbase * p.ldy + pcol;      // one 64-bit address; the four row groups are 8 ldy apart
+    const long ystep = 8 * p.ldy;
+    constexpr bool AHEAD = ACT != ACT_MASK && !SPLIT;   // (the bf16-mask flavour and the split flavours have no registers to spare for this)
+#pragma unroll
+    for (int part = 0; part < (SPLIT ? 2 : 1); ++part) {
+    if (SPLIT && part == 1) __builtin_amdgcn_sched_barrier(0);   // nothing of the second pass may be scheduled into the first (its values would be live across it)
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const int jj = c >> 2, q = c & 3;
       const f32x2 v01 = {acc[u][jj][4 * q + 0], acc[u][jj][4 * q + 1]}, v23 = {acc[u][jj][4 * q + 2], acc[u][jj][4 * q + 3]};
       u32x2 o = {__builtin_bit_cast(unsigned, __builtin_convertvector(v01, bf16x2)), __builtin_bit_cast(unsigned, __builtin_convertvector(v23, bf16x2))};
-      if (ACT == ACT_RELU || ACT == ACT_RELU_BITS) {
+      if ((ACT == ACT_RELU || ACT == ACT_RELU_BITS) && part == 0) {
         // (the empty asm keeps the packed conversion; the max itself stays a compiler-visible instruction: see fmlp.hip to_frags)
         typedef short s16x4 __attribute__((ext_vector_type(4)));
         asm("" : "+v"(o));
         o = __builtin_bit_cast(u32x2, __builtin_elementwise_max(__builtin_bit_cast(s16x4, o), s16x4{0, 0, 0, 0}));
       }
+      if (SPLIT && part == 0) {
+        // the accumulators keep the RESIDUAL of the rounded (and clamped) value for the second pass -- hi's two bf16 are the high
+        // halves of fp32 words; zero where the ReLU clamped -- so that pass costs no registers beyond the first one's
+        const unsigned o0 = o[0], o1 = o[1];              // (named scalars: see the note at ACT_MASK_BITS)
+        float r0 = v01[0] - __builtin_bit_cast(float, o0 << 16), r1 = v01[1] - __builtin_bit_cast(float, o0 & 0xffff0000u);
+        float r2 = v23[0] - __builtin_bit_cast(float, o1 << 16), r3 = v23[1] - __builtin_bit_cast(float, o1 & 0xffff0000u);
+        if (ACT == ACT_RELU || ACT == ACT_RELU_BITS) {
+          r0 = v01[0] > 0.f ? r0 : 0.f; r1 = v01[1] > 0.f ? r1 : 0.f;
+          r2 = v23[0] > 0.f ? r2 : 0.f; r3 = v23[1] > 0.f ? r3 : 0.f;
+        }
+        acc[u][jj][4 * q + 0] = r0; acc[u][jj][4 * q + 1] = r1; acc[u][jj][4 * q + 2] = r2; acc[u][jj][4 * q + 3] = r3;
+      }
       *(u32x2*)(slab + row1 * 128 + ((c ^ (row1 & 7)) << 4) + 8 * hi) = o;
     }
+    if (part == (SPLIT ? 1 : 0)) {
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const f32x4 b = *(const f32x4*)(bl + c * 32);           // columns 8c + 4 hi .. +3 of the next tile's bias
+      for (int c = 0; c < 8; ++c) {
+        const f32x4 b = *(const f32x4*)(bl + c * 32);           // columns 8c + 4 hi .. +3 of the next tile's bias
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc[u][c >> 2][4 * (c & 3) + e] = b[e];
+        for (int e = 0; e < 4; ++e) acc[u][c >> 2][4 * (c & 3) + e] = b[e];
+      }
     }
     // No wait between the slab writes and the read-back: the LDS executes one wave's instructions in order, so the four reads below
     // queue right behind the writes (and behind the bias reads) and their latencies overlap -- one exposed LDS round trip per unit
     // instead of five (the unit's length is what the other wave row's 8-MFMA section has to cover).  The empty asm pins the four
     // reads here: left alone, hipcc sinks each one into the store's branch, where it is waited for on its own.
-    T* const yrow = (T*)p.Y + (long)mbase * p.ldy + ncol;      // one 64-bit address; the four row groups are 8 ldy apart
-    const long ystep = 8 * p.ldy;
-    constexpr bool AHEAD = ACT != ACT_MASK;             // (the bf16-mask flavour has no registers to spare for this)
+    // (the split flavours fetch the word again in each pass instead of carrying it across the first one: they are at the register limit)
+    if (ACT == ACT_MASK_BITS && SPLIT) asm volatile("ds_read_b32 %0, %1" : "=v"(mw) : "v"((unsigned)(size_t)(smem + MASKB + ((wave * 4 + u) * 64 + ln) * 4)));
+    if (ACT == ACT_MASK_BITS && (SPLIT || part == 0)) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(mw));   // (LDS returns in order: the mask word is older than the slab read-backs)
     u32x4 vals[AHEAD ? 4 : 1];
     if constexpr (AHEAD) {
 #pragma unroll
@@ -759,9 +822,9 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
         val = __builtin_bit_cast(bf16x8, raw);
       }
       if (col_ok && m < p.M) {
-        if (!DBG(p, 8)) *(bf16x8*)(yrow + it * ystep) = val;          // (non-temporal stores measure the same: profiles/r2_n)
+        if (!DBG(p, 8)) *(bf16x8*)(yrow + it * ystep + (SPLIT ? 64 * part : 0)) = val;          // (non-temporal stores measure the same: profiles/r2_n)
         else asm volatile("" ::"v"(val));               // PROBE build, bit 8: everything but the store instruction itself
-        if (ACT == ACT_RELU_BITS) {
+        if (ACT == ACT_RELU_BITS && part == 0) {
           // the value is a ReLU output (max(v, +0) rounded to bf16: never negative, never -0): > 0  <=>  its 16 bits are not all zero
           // min(half, 1) per 16-bit half = "is positive"; z gathers the even elements in bits 0, 2, 4, 6 and the odd ones 16 higher
           const u32x4 raw = __builtin_bit_cast(u32x4, val);
@@ -786,6 +849,7 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
           for (int e = 0; e < 8; ++e) cs[e] += (float)val[e];
         }
       }
+    }
     }
     if (ACT == ACT_RELU_BITS) {
       const long blk = (long)((em0 >> 5) + wr * 4 + u) * ncg + ((en0 >> 6) + wc);
@@ -982,6 +1046,30 @@ __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restr
   atomicAdd(out + n, acc);
 }
 
+// out[n] += sum_m (hi + lo)[m, n] of a split-bf16 matrix Y [M, 2 N] (interleaved layout): the bias gradient of the split data-gradient
+// launches of the persistent kernel, whose mask + column-sum flavour does not fit the register file next to the two-pass epilogue
+// (13 spilled registers = scratch traffic in the k-loop; measured 14 ms per launch instead of 3).  One thread per 8 logical columns
+// (two 16-byte loads per row), 256-row chunks per workgroup, one fp32 atomic per column and chunk.
+__global__ __launch_bounds__(256) void colsum_split_kernel(const __bf16* __restrict__ Y, long ldy, int M, int n_store, float* __restrict__ out) {
+  const int g8 = (n_store + 7) >> 3;                       // column groups of 8
+  const int gw = g8 < 256 ? g8 : 256;                      // column groups per workgroup
+  const int per = 256 / gw;                                // rows handled side by side by one workgroup
+  const int cg = threadIdx.x % gw + blockIdx.y * 256, rsub = threadIdx.x / gw;
+  if (cg >= g8 || rsub >= per) return;
+  const int c0 = cg * 8;
+  const __bf16* src = Y + ((c0 >> 6) << 7) + (c0 & 63);
+  const int r0 = blockIdx.x * 1024, r1 = min(M, r0 + 1024);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int r = r0 + rsub; r < r1; r += per) {
+    const bf16x8 h = *(const bf16x8*)(src + (long)r * ldy), l = *(const bf16x8*)(src + (long)r * ldy + 64);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += (float)h[e] + (float)l[e];
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+    if (c0 + e < n_store) atomicAdd(out + c0 + e, acc[e]);
+}
+
 template <typename T, int BM, int BN, int WM, int WN>
 static int launch_nt(const GemmNT& p, hipStream_t stream) {
   constexpr int LDS = 2 * (BM + BN) * 128;
@@ -1046,6 +1134,32 @@ static int launch_nt8p(const GemmNT& p, hipStream_t stream) {
   const bool cs = p.colsum_ws != nullptr;
   if (cs) (void)hipMemsetAsync(p.colsum_ws, 0, (size_t)grid * 2 * p.N * sizeof(float), stream);   // the workgroups accumulate into it
   const dim3 g(grid), b(512);
+  if (p.split) {                                         // split-bf16 flavours (no bf16-aux mask: the data gradients use the bit masks)
+    static bool sattr = false;
+    if (!sattr) {
+      hipFuncSetAttribute((const void*)gemm_nt8p_kernel<ACT_NONE, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      hipFuncSetAttribute((const void*)gemm_nt8p_kernel<ACT_NONE, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      hipFuncSetAttribute((const void*)gemm_nt8p_kernel<ACT_RELU, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      hipFuncSetAttribute((const void*)gemm_nt8p_kernel<ACT_RELU_BITS, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      hipFuncSetAttribute((const void*)gemm_nt8p_kernel<ACT_MASK_BITS, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      sattr = true;
+    }
+    if (p.act == ACT_MASK_BITS) {
+      // (with a bias gradient: the plain flavour, then colsum_split_kernel over the output -- see there)
+      GemmNT q = p;
+      q.colsum_ws = nullptr;
+      hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_MASK_BITS, false, true>), g, b, LDS, stream, q);
+      if (cs) {
+        const int g8 = (p.n_store + 7) / 8;
+        hipLaunchKernelGGL(colsum_split_kernel, dim3((p.M + 1023) / 1024, (g8 + 255) / 256), dim3(256), 0, stream, (const __bf16*)p.Y, p.ldy, p.M, p.n_store, p.colsum);
+      }
+      return snerf_check_launch();
+    } else if (p.act == ACT_RELU_BITS && !cs) hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_RELU_BITS, false, true>), g, b, LDS, stream, p);
+    else if (p.act == ACT_RELU && !cs) hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_RELU, false, true>), g, b, LDS, stream, p);
+    else if (p.act == ACT_NONE && cs) hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_NONE, true, true>), g, b, LDS, stream, p);
+    else if (p.act == ACT_NONE) hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_NONE, false, true>), g, b, LDS, stream, p);
+    else return SNERF_ERR_ARG;
+  } else
   if (p.act == ACT_MASK) {
     if (cs) hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_MASK, true>), g, b, LDS, stream, p);
     else hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_MASK, false>), g, b, LDS, stream, p);
@@ -1077,6 +1191,15 @@ extern "C" int snerf_linear_fwd(const void* A, long lda, const void* W, long ldw
                                 int act, int dtype, int out_f32, int variant, void* stream) {
   if (M <= 0) return SNERF_OK;
   if (N <= 0 || (N % 128) != 0 || K <= 0 || n_store <= 0 || n_store > N) return SNERF_ERR_ARG;
+  // SNERF_DT_BF16X3: split-bf16 operands (see GemmNT::split).  A is [M, >= 2 K] (hi / lo interleaved per 64 columns), W [N, >= 3 K]
+  // ([hi | hi | lo] per 64 columns), K the LOGICAL reduction length; a bf16 output is written in the interleaved layout (ldy >= 2 x
+  // the logical width), an fp32 output (out_f32) plainly.
+  const int split = dtype == SNERF_DT_BF16X3;
+  if (split) {
+    if (K % 64 != 0) return SNERF_ERR_ARG;
+    dtype = SNERF_DT_BF16;
+    K *= 3;
+  }
   if (dtype != SNERF_DT_F32 && dtype != SNERF_DT_BF16) return SNERF_ERR_ARG;
   const int bke = dtype == SNERF_DT_F32 ? 32 : 64;
   if (K % bke != 0 || lda % (bke / 8) != 0 || ldw % (bke / 8) != 0) return SNERF_ERR_ARG;
@@ -1096,8 +1219,10 @@ extern "C" int snerf_linear_fwd(const void* A, long lda, const void* W, long ldw
   if ((variant >> 4) & 8) fast = 0;                          // ablation: force the direct-store epilogue
   const int det = (variant >> 8) & 1;                        // variant bit 8: deterministic fold of the bias-gradient partials
   if (det && colsum != nullptr && !fast) return SNERF_ERR_ARG;   // the direct-store epilogue adds its column sums with atomics
+  if (split && !fast && !out_f32) return SNERF_ERR_ARG;          // the interleaved output exists only in the 16-byte epilogues
+  if (split && out_f32 && (act == ACT_MASK || colsum != nullptr)) return SNERF_ERR_ARG;
   GemmNT p{A, lda, W, ldw, bias, Y, ldy, aux, ldaux, colsum, M, N, K, n_store, act, out_f32, vec, colsum_ws, fast, det, ((variant >> 4) & 7) | ((variant >> 10) & 8),
-           (variant >> 9) & 15};                                 // (PROBE builds: variant bit 13 = ablation bit 8; bits 9..12 = stagger)
+           (variant >> 9) & 15, split};                          // (PROBE builds: variant bit 13 = ablation bit 8; bits 9..12 = stagger)
   variant &= 15;
   hipStream_t s = (hipStream_t)stream;
   // variant: 0 = 128x128 block-issue, 1 = 256x256 block-issue,
@@ -1105,11 +1230,10 @@ extern "C" int snerf_linear_fwd(const void* A, long lda, const void* W, long ldw
   //          8 = 256x256 persistent 8-phase (bf16, N % 256 == 0, K >= 128, 16-byte epilogue; else as variant 4)
   // the bit-mask activations exist only in the persistent kernel (the mask layout is its unit geometry)
   const bool p8 = dtype == SNERF_DT_BF16 && (variant & 8) && N % 256 == 0 && K >= 128 && fast && !(colsum != nullptr && act == ACT_RELU) &&
-                  (lda * 2 * 256 < (1L << 31)) && (ldw * 2 * 256 < (1L << 31));
+                  (lda * 2 * 256 < (1L << 31)) && (ldw * 2 * 256 < (1L << 31)) && !(split && (act == ACT_MASK || (colsum != nullptr && act == ACT_RELU_BITS)));
   if (act >= ACT_RELU_BITS && !(p8 && (long)((M + 255) / 256) * 8 * (N / 64) * 256 < (1L << 31)))
     return SNERF_ERR_ARG;
-  if (dtype == SNERF_DT_BF16 && (variant & 8) && N % 256 == 0 && K >= 128 && fast && !(colsum != nullptr && act == ACT_RELU) && (lda * 2 * 256 < (1L << 31)) && (ldw * 2 * 256 < (1L << 31)))
-    return launch_nt8p(p, s);
+  if (p8) return launch_nt8p(p, s);
   if (dtype == SNERF_DT_BF16 && (variant & 12) && N % 256 == 0) return launch_nt8(p, s);
   if (dtype == SNERF_DT_F32) return launch_nt<float, 128, 128, 2, 2>(p, s);
   if ((variant & 1) && N % 256 == 0) return launch_nt<__bf16, 256, 256, 2, 4>(p, s);
@@ -1132,6 +1256,10 @@ struct GemmTN {
   const void* zeros;  // >= 16 bytes of zeros in device memory
   int M, N, K, n_valid, k_valid, m_chunk;
   int tiles, slices;  // 128 x 128 kernel: output tiles and M slices of the launch (1-D grid, XCD-aware placement)
+  // split-bf16 operands (SNERF_DT_BF16X3): dZ [M, 2 N] and X [M, 2 K] in the hi / lo interleaved layout; the kernels multiply the
+  // PHYSICAL matrices (all four hi / lo combinations of every 64 x 64 block; lo.lo is noise-level and harmless) and the output index
+  // maps the physical (n', k') back to the logical (n, k) = ((n' >> 7) << 6 | n' & 63, ...): the atomics add the combinations up.
+  int split;
   float* part;        // deterministic mode: every (tile, M slice) stores its partial tile at part + slice * part_stride + n * part_ld + k
   long part_stride;   // (no atomics); tn_fold_kernel adds the slices in a fixed order.  nullptr: fp32 atomics straight into dW
   int part_ld;
@@ -1288,10 +1416,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int k = k0 + wk * 64 + j * 32 + (lane & 31);
+      int k = k0 + wk * 64 + j * 32 + (lane & 31);
+      if (p.split) k = ((k >> 7) << 6) | (k & 63);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (p.split) n = ((n >> 7) << 6) | (n & 63);
         if (n < p.n_valid && k < p.k_valid) {
           if (p.part != nullptr) p.part[(long)slice * p.part_stride + (long)n * p.part_ld + k] = acc[i][j][r];
           else atomicAdd(p.dW + (long)n * p.ldw + k, acc[i][j][r]);
@@ -1496,10 +1626,12 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(GemmTN p) {
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int k = k0 + wc * 64 + j * 32 + (lane & 31);
+      int k = k0 + wc * 64 + j * 32 + (lane & 31);
+      if (p.split) k = ((k >> 7) << 6) | (k & 63);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int n = n0 + wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        int n = n0 + wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (p.split) n = ((n >> 7) << 6) | (n & 63);
         if (n < p.n_valid && k < p.k_valid) {
           if (p.part != nullptr) p.part[(long)chunk * p.part_stride + (long)n * p.part_ld + k] = acc[i][j][r];
           else atomicAdd(p.dW + (long)n * p.ldw + k, acc[i][j][r]);
@@ -1570,11 +1702,17 @@ static TnPlan tn_plan(int M, int N, int K, long ldz, long ldx, int dtype, int va
 static int wgrad_launch(const void* Z, long ldz, const void* X, long ldx, float* dW, long ldw, const void* zeros, int M, int N, int K,
                         int n_valid, int k_valid, int dtype, int variant, float* ws, long ws_floats, void* stream) {
   if (M <= 0) return SNERF_OK;
+  // SNERF_DT_BF16X3: N, K are the PHYSICAL widths of the interleaved operands (2 x the logical ones), n_valid / k_valid logical
+  const int split = dtype == SNERF_DT_BF16X3;
+  if (split) {
+    if (N % 128 != 0 || K % 128 != 0 || ws != nullptr) return SNERF_ERR_ARG;        // (no deterministic fold in this mode)
+    dtype = SNERF_DT_BF16;
+  }
   const int epc = dtype == SNERF_DT_F32 ? 4 : 8;
   if (N < epc || K < epc || N % epc || K % epc || ldz % epc || ldx % epc || zeros == nullptr) return SNERF_ERR_ARG;
   const TnPlan pl = tn_plan(M, N, K, ldz, ldx, dtype, variant);
   if (ws != nullptr && ws_floats < pl.part_stride * pl.slices) return SNERF_ERR_ARG;
-  GemmTN p{Z, ldz, X, ldx, dW, ldw, zeros, M, N, K, n_valid, k_valid, pl.m_chunk, 0, pl.slices, ws, pl.part_stride, pl.part_ld};
+  GemmTN p{Z, ldz, X, ldx, dW, ldw, zeros, M, N, K, n_valid, k_valid, pl.m_chunk, 0, pl.slices, split, ws, pl.part_stride, pl.part_ld};
   if (pl.use8) {
     static bool attr_set = false;
     if (!attr_set) {

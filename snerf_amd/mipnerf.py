@@ -122,9 +122,9 @@ class MipNerfModel(_ArenaModule):
             enc_ids = torch.zeros(1, dtype=torch.int32, device=dev)
         else:
             enc_ids = sample_id
-        ops.mip_encode(s1, o, d, radii, near, far, cone, self.transform_idx, self.max_deg_point, SKIP[:, H:], None, self.nerf.Ew, self.dt,
+        ops.mip_encode(s1, o, d, radii, near, far, cone, self.transform_idx, self.max_deg_point, self.nerf.cs(SKIP, H), None, self.nerf.Ew, self.dt,
                        sample_id=enc_ids)
-        ops.mip_viewenc(vd, S1, self.deg_view, CB[:, H:], self.nerf.Cw, self.dt, sample_id=enc_ids)
+        ops.mip_viewenc(vd, S1, self.deg_view, self.nerf.cs(CB, H), self.nerf.Cw, self.dt, sample_id=enc_ids)
         raw_rgb, raw_d1, saved1 = self.nerf.forward(SKIP, CB, keep)
         rgb1, dist1, acc1, w1 = ops.mip_composite_fwd(raw_rgb, raw_d1, noise1, s1, d, near, far, self.transform_idx, white_bg,
                                                       self.rgb_padding, self.density_bias, row_index=row_index)

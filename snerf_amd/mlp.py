@@ -128,6 +128,18 @@ def fmlp_pack(layers, device):
     return stream.to(torch.bfloat16).contiguous(), torch.cat(biases).contiguous()
 
 
+LO_FLAG = float(1 << 40)      # added to an index-image entry: "the low part of the split-bf16 pair of this parameter" (see split_w_image)
+
+
+def split_w_image(img):
+    """index image of a GEMM weight operand [N, K] (K % 64 == 0) -> image of its split-bf16 form [N, 3 K]: per 64 columns
+    [hi | hi | lo] (csrc/gemm.hip, GemmNT::split); padding stays padding, a constant one has no low part"""
+    N, K = img.shape
+    t = img.reshape(N, K // 64, 1, 64)
+    lo = torch.where(t > 1.5, t + LO_FLAG, torch.zeros_like(t))
+    return torch.cat([t, t, lo], 2).reshape(N, 3 * K).contiguous()
+
+
 class _PackPlan:
     """Persistent packed operands of one network + the gather map that refreshes them from the parameter arena."""
 
@@ -150,7 +162,10 @@ class _PackPlan:
             for img, off in items:
                 v = img.reshape(-1)
                 assert bool(((v == v.round()) & (v >= 0)).all()), "pack() may only copy parameters, zeros and ones"
+                lo = v >= LO_FLAG                                  # split-bf16 operands: the low part bf16(x - bf16(x)) of parameter x
+                v = torch.where(lo, v - LO_FLAG, v)
                 k = (v - 2.0).to(torch.int32)                      # image value = arena position + 2; 0 = padding, 1 = constant one
+                k = torch.where(lo, k | (1 << 30), k)
                 minus1, minus2 = torch.full_like(k, -1), torch.full_like(k, -2)
                 idx[off:off + v.numel()] = torch.where(v == 0, minus1, torch.where(v == 1, minus2, k))
             self.pools[dtype] = torch.zeros(n, dtype=dtype, device=self.flat.device)
@@ -175,6 +190,7 @@ class _Net:
     def __init__(self, arena: ParamArena, prefix: str, dt: int, variant: int = 8):
         self.a, self.pre, self.dt, self.variant = arena, prefix, dt, variant
         self.g = gran(dt)
+        self.km = 2 if dt == ops.BF16X3 else 1           # physical columns per logical column of an activation buffer (split-bf16: hi / lo interleaved)
         self.tdt = ops.torch_dtype(dt)
         self.dev = arena.flat.device
         self._packed_version = -1
@@ -216,7 +232,10 @@ class _Net:
         finally:
             self._rec = None
         plan = _PackPlan(self.a.flat)
-        handles = [(id(img), plan.add(img, dtype)) for img, dtype in rec]
+        if self.km == 2:          # every compute-dtype operand of the per-layer plans is a GEMM weight [N, K]: its [hi | hi | lo] form
+            handles = [(id(img), plan.add(split_w_image(img) if dtype == self.tdt and img.dim() == 2 else img, dtype)) for img, dtype in rec]
+        else:
+            handles = [(id(img), plan.add(img, dtype)) for img, dtype in rec]
         plan.finish()
         real = {i: plan.view(h) for i, h in handles}
 
@@ -313,7 +332,13 @@ class _Net:
 
     # ---- kernels ---------------------------------------------------------------
     def buf(self, M, cols, f32=False):
-        return torch.empty(M, cols, dtype=torch.float32 if f32 else self.tdt, device=self.dev)
+        """activation buffer of `cols` LOGICAL columns (split-bf16: twice as many physical ones)"""
+        return torch.empty(M, cols if f32 else cols * self.km, dtype=torch.float32 if f32 else self.tdt, device=self.dev)
+
+    def cs(self, t, a, b=None):
+        """logical column range [a, b) of an activation buffer (multiples of the tile granularity): a plain slice, of twice the width in
+        the split-bf16 layout (64 logical columns = one 128-column physical group)"""
+        return t[:, a * self.km:(None if b is None else b * self.km)]
 
     def fwd(self, key, A, K, Y, n_store, act=ACT_RELU, out_f32=False):
         W = self.fw[key]
@@ -355,7 +380,7 @@ class _Net:
         """fp32 head gradient [M,C] -> compute-dtype buffer padded to the tile granularity."""
         M = d_raw_f32.shape[0]
         out = self.buf(M, roundup(C, self.g))
-        ops.cast_pad(d_raw_f32, C, out, out.shape[1], self.dt)
+        ops.cast_pad(d_raw_f32, C, out, roundup(C, self.g), self.dt)
         return out
 
 
@@ -371,6 +396,7 @@ class ClassicNeRFNet(_Net):
         """`alpha_head=False`: the ``NeRF_RGB`` variant (run_nerf_helpers.py:157-212) -- no alpha_linear; column 3 of the output is left
         for the caller (the frozen alpha model's density)."""
         super().__init__(arena, prefix, dt, variant)
+        assert self.km == 1, "split-bf16 (compute='bf16x3') is built for the mip path's networks"
         assert len(skips) == 1 and 0 <= skips[0] < D - 1 and W % self.g == 0 and (W // 2) % self.g == 0
         self.D, self.Wd, self.ic, self.icv, self.skip = D, W, input_ch, input_ch_views, skips[0]
         self.Pw, self.Vw = roundup(input_ch, self.g), roundup(input_ch_views, self.g)
@@ -647,7 +673,7 @@ class MipProposalNet(_Net):
         xl = acts[-1][2]
         self.wgrad("density_layer", dz, xl, 1, H)
         dZ = self.buf(M, H)
-        self.dgrad("density", dz, dz.shape[1], dZ, H, mask=xl, colsum=self.gB(f"layers.{self.L - 1}.layers.0"))
+        self.dgrad("density", dz, self.g, dZ, H, mask=xl, colsum=self.gB(f"layers.{self.L - 1}.layers.0"))
         for i in range(self.L - 1, -1, -1):
             x, k, y = acts[i]
             n = f"layers.{i}.layers.0"
@@ -774,11 +800,11 @@ class MipNerfNet(_Net):
         self.ensure_packed(keep)
         M, H = SKIP.shape[0], self.H
         acts = []
-        x, k = SKIP[:, H:], self.Ew
+        x, k = self.cs(SKIP, H), self.Ew
         pp = [self.buf(M, H), self.buf(M, H)] if not keep else None
         for i in range(self.L):
             if self._is_skip_out(i):
-                y = SKIP[:, :H]
+                y = self.cs(SKIP, 0, H)
             else:
                 y = self.buf(M, H) if keep else pp[i & 1]
             self.fwd(f"layers.{i}.layers.0", x, k, y, H)
@@ -790,7 +816,7 @@ class MipNerfNet(_Net):
         assert k == H, "a skip concat directly before the heads is not supported"
         raw_d = self.buf(M, 1, f32=True)
         self.fwd("density", x, H, raw_d, 1, ACT_NONE, out_f32=True)
-        self.fwd("bottleneck", x, H, CB[:, :H], H)
+        self.fwd("bottleneck", x, H, self.cs(CB, 0, H), H)
         cacts = []
         raw_rgb = self.buf(M, 3, f32=True)
         bbits = self._bits.get((CB.data_ptr(), M)) if keep else None
@@ -843,7 +869,7 @@ class MipNerfNet(_Net):
             # the whole data-gradient chain d raw_rgb -> dC2 -> dC1 -> dC0 -> d bottleneck, masks and the four bias gradients: one launch
             _, cbits, bbits = fused
             dCs = [self.buf(M, cu) for _ in range(self.nc)]                       # [dC2, dC1, dC0]
-            ops.fcolour_bwd(d_raw_rgb, self._cbwd[0], [cbits[2], cbits[1], cbits[0], bbits], dCs, DB[:, :H],
+            ops.fcolour_bwd(d_raw_rgb, self._cbwd[0], [cbits[2], cbits[1], cbits[0], bbits], dCs, self.cs(DB, 0, H),
                             [self.gB("cond_layers.2.layers.0"), self.gB("cond_layers.1.layers.0"), self.gB("cond_layers.0.layers.0"),
                              self.gB("bottleneck_layer.layers.0")])
             for j in range(self.nc - 1, -1, -1):
@@ -853,7 +879,7 @@ class MipNerfNet(_Net):
                 dV = self.input_grad("cenc", dCs[-1], cu, self.Cw)
         else:
             dC = self.buf(M, cu)
-            self.dgrad("rgb", dz, dz.shape[1], dC, cu, mask=clast, colsum=self.gB(f"cond_layers.{self.nc - 1}.layers.0"))
+            self.dgrad("rgb", dz, g, dC, cu, mask=clast, colsum=self.gB(f"cond_layers.{self.nc - 1}.layers.0"))
             for j in range(self.nc - 1, -1, -1):
                 cx, ck, cy = cacts[j]
                 n = f"cond_layers.{j}.layers.0"
@@ -866,22 +892,22 @@ class MipNerfNet(_Net):
                     self.dgrad(n, dC, cu, DB, H, mask=CB, colsum=self.gB("bottleneck_layer.layers.0"))
                     if want_input_grad:
                         dV = self.input_grad("cenc", dC, cu, self.Cw)
-        ops.cast_pad(d_raw_density, 1, DB[:, H:H + g], g, self.dt)
+        ops.cast_pad(d_raw_density, 1, self.cs(DB, H, H + g), g, self.dt)
         xl = acts[-1][2]
         kb = H + g
         if self.sc:
-            dS0 = DB[:, H + g:]
+            dS0 = self.cs(DB, H + g)
             if d_raw_sem is None:
                 dS0.zero_()
             else:
                 self.colsum(d_raw_sem, self.sc, self.gB("semantic_layer.1"))
                 dzs = self.head_grad(d_raw_sem, self.sc)
                 self.wgrad("semantic_layer.1", dzs, S0, self.sc, self.Hs)
-                self.dgrad("sem1", dzs, dzs.shape[1], dS0, self.Hs, mask=S0, colsum=self.gB("semantic_layer.0.layers.0"))
+                self.dgrad("sem1", dzs, roundup(self.sc, g), dS0, self.Hs, mask=S0, colsum=self.gB("semantic_layer.0.layers.0"))
                 self.wgrad("semantic_layer.0.layers.0", dS0, xl, self.Hs, H)
             kb += self.Hs
-        self.wgrad("bottleneck_layer.layers.0", DB[:, :H], xl, H, H)
-        self.wgrad("density_layer", DB[:, H:H + g], xl, 1, H)
+        self.wgrad("bottleneck_layer.layers.0", self.cs(DB, 0, H), xl, H, H)
+        self.wgrad("density_layer", self.cs(DB, H, H + g), xl, 1, H)
         dZ = self.buf(M, H)
         self.dgrad("bd", DB, kb, dZ, H, mask=xl, colsum=self.gB(f"layers.{self.L - 1}.layers.0"))
         for i in range(self.L - 1, -1, -1):
@@ -892,13 +918,13 @@ class MipNerfNet(_Net):
                 xin = acts[i - 1][2]
                 if want_input_grad and (i - 1) in self.enc_layers:      # lands in its column block of the K-concatenated operand
                     k = self.enc_layers.index(i - 1)
-                    dX = DZE[:, k * H:(k + 1) * H]
+                    dX = self.cs(DZE, k * H, (k + 1) * H)
                 else:
                     dX = self.buf(M, H)
                 self.dgrad(n, dZ, H, dX, H, mask=xin, colsum=self.gB(f"layers.{i - 1}.layers.0"))
                 dZ = dX
         if want_input_grad:
-            return self.input_grad("enc", DZE, DZE.shape[1], self.Ew), dV
+            return self.input_grad("enc", DZE, H * len(self.enc_layers), self.Ew), dV
         return None
 
 
@@ -911,6 +937,7 @@ class ZipPropNet(_Net):
 
     def __init__(self, arena, prefix, dt, feat_dim, hidden=64, variant=8):
         super().__init__(arena, prefix, dt, variant)
+        assert self.km == 1, "split-bf16 (compute='bf16x3') is built for the mip path's networks"
         assert hidden % self.g == 0
         self.fd, self.H, self.Fw = feat_dim, hidden, roundup(feat_dim, self.g)
 
@@ -958,6 +985,7 @@ class ZipNerfNet(_Net):
 
     def __init__(self, arena, prefix, dt, feat_dim=40, hidden=64, bottleneck=256, width=256, dir_dim=9, variant=8):
         super().__init__(arena, prefix, dt, variant)
+        assert self.km == 1, "split-bf16 (compute='bf16x3') is built for the mip path's networks"
         assert hidden % self.g == 0 and bottleneck % self.g == 0 and width % self.g == 0
         self.fd, self.H, self.Bw, self.Wd, self.dd = feat_dim, hidden, bottleneck, width, dir_dim
         self.Fw, self.Dw = roundup(feat_dim, self.g), roundup(dir_dim, self.g)

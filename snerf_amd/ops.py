@@ -10,9 +10,10 @@ import torch
 from . import _lib
 
 F32, BF16, F16, F64 = 0, 1, 2, 3
+BF16X3 = 4                                 # GEMMs only: split-bf16 operands, the fp32-parity mode at bf16 MFMA rates (csrc/gemm.hip, GemmNT::split)
 ACT_NONE, ACT_RELU, ACT_MASK = 0, 1, 2
 ACT_RELU_BITS, ACT_MASK_BITS = 3, 4        # ReLU that also writes a 1-bit-per-element mask / ReLU backward from that mask
-_TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
+_TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16, BF16X3: torch.bfloat16}
 
 
 def torch_dtype(dt: int):
@@ -21,7 +22,7 @@ def torch_dtype(dt: int):
 
 def gran(dt: int) -> int:
     """reduction-axis granularity of the GEMM tiles: 128-byte LDS rows."""
-    return 32 if dt == F32 else 64
+    return 32 if dt == F32 else 64                    # (BF16X3: 64 LOGICAL columns = one 128-column physical group)
 
 
 def roundup(x: int, m: int) -> int:
@@ -67,7 +68,9 @@ def linear_fwd(A, W, bias, Y, K, n_store, act, dt, out_f32=False, aux=None, cols
         variant |= 256
     _chk2d(A, _TORCH_DT[dt]); _chk2d(W, _TORCH_DT[dt]); _chk2d(Y, torch.float32 if out_f32 else _TORCH_DT[dt])
     M = A.shape[0]
-    assert Y.shape[0] == M and A.shape[1] >= K and W.shape[1] >= K and Y.shape[1] >= n_store
+    sp = dt == BF16X3                                     # split-bf16: A [M, 2 K], W [N, 3 K], a bf16 Y [M, 2 n_store] (interleaved layout)
+    assert Y.shape[0] == M and A.shape[1] >= K * (2 if sp else 1) and W.shape[1] >= K * (3 if sp else 1)
+    assert Y.shape[1] >= n_store * (2 if sp and not out_f32 else 1) or (sp and not out_f32 and Y.shape[1] >= 2 * roundup(n_store, 64) - 64)
     if aux is not None and act < ACT_RELU_BITS:
         _chk2d(aux, _TORCH_DT[dt])
     if act >= ACT_RELU_BITS:
@@ -100,7 +103,7 @@ def relu_bits_ok(A, W, Y, K, n_store, dt, variant, consumer=False):
     """Whether snerf_linear_fwd accepts ACT_RELU_BITS (producer) / ACT_MASK_BITS (consumer) for this launch: the persistent
     8-phase kernel's conditions (mirrors the dispatch in gemm.hip)."""
     N = W.shape[0]
-    return (dt == BF16 and (variant & 8) and N % 256 == 0 and K >= 128 and Y.dtype == torch.bfloat16
+    return (dt in (BF16, BF16X3) and (variant & 8) and N % 256 == 0 and K * (3 if dt == BF16X3 else 1) >= 128 and Y.dtype == torch.bfloat16
             and Y.stride(0) % 8 == 0 and Y.data_ptr() % 16 == 0 and n_store % 8 == 0
             and A.stride(0) * 512 < (1 << 31) and W.stride(0) * 512 < (1 << 31) and mask_bits_words(A.shape[0], N) * 4 < (1 << 31))
 
@@ -110,6 +113,10 @@ def linear_wgrad(dZ, X, dW, n_valid, k_valid, dt, variant=0, deterministic=False
     varies run to run); `deterministic`: they store partial tiles into a workspace that is folded in slice order (bit-reproducible)."""
     _chk2d(dZ, _TORCH_DT[dt]); _chk2d(X, _TORCH_DT[dt]); _chk2d(dW, torch.float32)
     assert dZ.shape[0] == X.shape[0] and dW.shape[0] >= n_valid and dW.shape[1] >= k_valid
+    if dt == BF16X3:
+        # dZ / X are the interleaved split operands (physical widths, multiples of 128); the kernels fold the hi / lo combinations
+        assert not deterministic, "the split-bf16 weight gradient has no deterministic fold"
+        assert dZ.shape[1] % 128 == 0 and X.shape[1] % 128 == 0
     if deterministic:
         nws = _lib.query("snerf_linear_wgrad_ws_floats", dZ.shape[0], dZ.shape[1], X.shape[1], dZ.stride(0), X.stride(0), dt, variant)
         ws = torch.empty(max(int(nws), 1), dtype=torch.float32, device=dZ.device)
@@ -261,6 +268,12 @@ def mip_encode(s_vals, origins, directions, radii, near, far, cone, transform_id
     for t in (s_vals, origins, directions, radii, near, far):
         _f32c(t)
     ids, rows = _ids(sample_id)
+    if dt == BF16X3:
+        # the exact fp32 encoding, then the hi / lo split into the GEMM operand layout
+        assert dst2 is None
+        tmp = torch.empty(dst1.shape[0], width, dtype=torch.float32, device=dst1.device)
+        mip_encode(s_vals, origins, directions, radii, near, far, cone, transform_idx, max_deg, tmp, None, width, F32, means_out, covs_out, sample_id)
+        return split_cast(tmp, width, dst1, width)
     _lib.call("snerf_mip_encode", _p(s_vals), _p(origins), _p(directions), _p(radii), _p(near), _p(far), n, P - 1,
               1 if cone else 0, transform_idx, max_deg, _p(dst1), dst1.stride(0), _p(dst2),
               0 if dst2 is None else dst2.stride(0), width, _p(_f32c(means_out)), _p(_f32c(covs_out)), dt, _p(ids), rows, _stream())
@@ -269,6 +282,10 @@ def mip_encode(s_vals, origins, directions, radii, near, far, cone, transform_id
 def mip_viewenc(viewdirs, S, deg, dst, width, dt, sample_id=None):
     _f32c(viewdirs)
     ids, rows = _ids(sample_id)
+    if dt == BF16X3:
+        tmp = torch.empty(dst.shape[0], width, dtype=torch.float32, device=dst.device)
+        mip_viewenc(viewdirs, S, deg, tmp, width, F32, sample_id)
+        return split_cast(tmp, width, dst, width)
     _lib.call("snerf_mip_viewenc", _p(viewdirs), viewdirs.shape[0], S, deg, _p(dst), dst.stride(0), width, dt, _p(ids), rows, _stream())
 
 
@@ -480,7 +497,17 @@ def colsum_f32(x, C, out, deterministic=False):
     _lib.call("snerf_colsum_f32_det" if deterministic else "snerf_colsum_f32", _p(x), x.stride(0), x.shape[0], C, _p(out), _stream())
 
 
+def split_cast(src, C, dst, Cpad):
+    """fp32 [M, >= C] -> split-bf16 rows in the GEMMs' interleaved layout: dst [M, >= 2 Cpad] bf16, Cpad % 64 == 0 logical columns
+    (hi at physical [128 j, 128 j + 64), lo at [128 j + 64, 128 j + 128) of logical columns [64 j, 64 j + 64); columns >= C zero)."""
+    _chk2d(src, torch.float32); _chk2d(dst, torch.bfloat16)
+    assert dst.shape[0] == src.shape[0] and dst.shape[1] >= 2 * Cpad and src.shape[1] >= C
+    _lib.call("snerf_split_cast", _p(src), src.stride(0), src.shape[0], C, Cpad, _p(dst), dst.stride(0), _stream())
+
+
 def cast_pad(src, C, dst, Cpad, dt):
+    if dt == BF16X3:
+        return split_cast(src, C, dst, Cpad)
     _chk2d(src, torch.float32)
     _lib.call("snerf_cast_pad", _p(src), src.stride(0), src.shape[0], C, Cpad, _p(dst), dst.stride(0), dt, _stream())
 

@@ -15,8 +15,55 @@ from oracle import mip as om
 _BITS = {}
 
 
+def _split_unpack(T, K):
+    """split-bf16 activation [M, >= 2 K] (hi / lo interleaved per 64 logical columns) -> (hi [M, K], lo [M, K]) as fp32"""
+    t = T[:, :2 * K].float().reshape(T.shape[0], K // 64, 2, 64)
+    return t[:, :, 0].reshape(T.shape[0], K), t[:, :, 1].reshape(T.shape[0], K)
+
+
+def _split_pack(y, Y, n):
+    """fp32 [M, n] -> the interleaved split-bf16 layout in Y[:, :2 * roundup(n, 64)] (columns n .. are left alone where a group is partial)"""
+    hi = y.to(torch.bfloat16)
+    lo = (y - hi.float()).to(torch.bfloat16)
+    for j in range((n + 63) // 64):
+        w = min(64, n - 64 * j)
+        Y[:, 128 * j:128 * j + w] = hi[:, 64 * j:64 * j + w]
+        Y[:, 128 * j + 64:128 * j + 64 + w] = lo[:, 64 * j:64 * j + w]
+
+
+def split_cast(src, C, dst, Cpad):
+    y = torch.zeros(src.shape[0], Cpad)
+    y[:, :C] = src[:, :C]
+    _split_pack(y, dst, Cpad)
+
+
 def linear_fwd(A, W, bias, Y, K, n_store, act, dt, out_f32=False, aux=None, colsum=None, variant=0, deterministic=False):
     assert W.shape[0] % 128 == 0 and K % (32 if dt == 0 else 64) == 0
+    if dt == 4:                                                 # split-bf16: hi.hi + lo.hi + hi.lo, fp32 accumulation (csrc/gemm.hip)
+        ah, al = _split_unpack(A, K)
+        w = W[:, :3 * K].float().reshape(W.shape[0], K // 64, 3, 64)
+        assert torch.equal(w[:, :, 0], w[:, :, 1]), "weights of the split mode are [hi | hi | lo] per 64 columns"
+        wh, wl = w[:, :, 0].reshape(W.shape[0], K), w[:, :, 2].reshape(W.shape[0], K)
+        y = ah @ wh.t() + al @ wh.t() + ah @ wl.t()
+        if bias is not None:
+            y = y + bias
+        y = y[:, :n_store]
+        if act in (1, 3):
+            y = torch.relu(y)
+        if act == 2:
+            y = y * (_split_unpack(aux, 64 * ((n_store + 63) // 64))[0][:, :n_store] > 0)
+        if act == 3:
+            _BITS[aux.data_ptr()] = y.to(torch.bfloat16).float() > 0
+        if act == 4:
+            y = y * _BITS[aux.data_ptr()][:, :n_store]
+        if out_f32:
+            Y[:, :n_store] = y
+        else:
+            _split_pack(y, Y, n_store)
+            if colsum is not None:
+                hi = y.to(torch.bfloat16).float()
+                colsum[:n_store] += (hi + (y - hi).to(torch.bfloat16).float()).sum(0)
+        return
     y = A[:, :K].float() @ W[:, :K].float().t()
     if bias is not None:
         y = y + bias
@@ -36,6 +83,11 @@ def linear_fwd(A, W, bias, Y, K, n_store, act, dt, out_f32=False, aux=None, cols
 
 
 def linear_wgrad(dZ, X, dW, n_valid, k_valid, dt, variant=0, deterministic=False):
+    if dt == 4:                                                 # the kernels multiply the physical matrices: all four hi / lo combinations
+        zh, zl = _split_unpack(dZ, dZ.shape[1] // 2)
+        xh, xl = _split_unpack(X, X.shape[1] // 2)
+        dW[:n_valid, :k_valid] += ((zh + zl).t() @ (xh + xl))[:n_valid, :k_valid]
+        return
     dW[:n_valid, :k_valid] += (dZ.float().t() @ X.float())[:n_valid, :k_valid]
 
 
@@ -57,6 +109,8 @@ def mip_encode(s_vals, origins, directions, radii, near, far, cone, transform_id
     fm, fc = om.sample2enc(s_vals, origins, directions, radii[:, None], near[:, None], far[:, None], "cone" if cone else "cylinder", transform_idx)
     enc = om.integrated_pos_enc(fm, fc, 0, max_deg).reshape(-1, 6 * max_deg)
     v = torch.cat([enc, torch.zeros(enc.shape[0], width - enc.shape[1])], -1)
+    if dt == 4:
+        return split_cast(v, width, dst1, width)
     dst1[:, :width] = v.to(dst1.dtype)
     if dst2 is not None:
         dst2[:, :width] = v.to(dst2.dtype)
@@ -65,6 +119,8 @@ def mip_encode(s_vals, origins, directions, radii, near, far, cone, transform_id
 def mip_viewenc(viewdirs, S, deg, dst, width, dt, sample_id=None):
     assert sample_id is None
     e = om.pos_enc(viewdirs, 0, deg, True)[:, None].expand(-1, S, -1).reshape(-1, 3 + 6 * deg)
+    if dt == 4:
+        return split_cast(torch.cat([e, torch.zeros(e.shape[0], width - e.shape[1])], -1), width, dst, width)
     dst[:, :width] = torch.cat([e, torch.zeros(e.shape[0], width - e.shape[1])], -1).to(dst.dtype)
 
 
@@ -192,6 +248,8 @@ def colsum_f32(x, C, out, deterministic=False):
 
 
 def cast_pad(src, C, dst, Cpad, dt):
+    if dt == 4:
+        return split_cast(src, C, dst, Cpad)
     dst[:, :Cpad] = 0
     dst[:, :C] = src[:, :C].to(dst.dtype)
 
@@ -599,7 +657,10 @@ def fcolour_bwd(d_raw_rgb, stream, bits, dC, dB, g_bias):
 
 def gather_pack(flat, idx, dst):
     k = idx.long()
-    v = torch.where(k >= 0, flat[k.clamp(min=0)], torch.where(k == -2, torch.ones_like(flat[:1]), torch.zeros_like(flat[:1])).expand_as(k))
+    lo = (k >= 0) & ((k & (1 << 30)) != 0)                     # split-bf16 weights: the low part bf16(x - bf16(x))
+    x = flat[torch.where(k >= 0, k & 0x3fffffff, torch.zeros_like(k))]
+    x = torch.where(lo, x - x.to(torch.bfloat16).float(), x)
+    v = torch.where(k >= 0, x, torch.where(k == -2, torch.ones_like(flat[:1]), torch.zeros_like(flat[:1])).expand_as(k))
     dst.view(-1)[:] = v.to(dst.dtype)
 
 
@@ -607,7 +668,7 @@ def adam_step_dev(p, g, m, v, lr, b1, b2, eps, step_dev, grad_scale=1.0, zero_gr
     adam_step(p, g, m, v, lr, b1, b2, eps, 0, grad_scale, zero_grad, step_dev=step_dev, **kw)
 
 
-_NAMES = ["fcolour_fwd", "fcolour_bwd", "gather_pack", "adam_step_dev", "grad_clip_coef", "fmlp_classic_fwd", "fmlp_classic_pts_fwd", "fmlp_proposal_fwd", "fmlp_classic_train_fwd", "fmlp_proposal_train_fwd", "classic_get_rays", "classic_ndc_rays", "classic_ray_batch", "zip_encode_prop_fwd", "mip_encode_bwd", "mip_viewenc_bwd", "hash_decay", "zip_percentiles", "zip_pixels_to_rays", "zip_loss_tail", "semantic_composite_fwd", "semantic_composite_bwd", "zip_resample", "zip_encode_fwd", "zip_encode_bwd", "zip_encode_bwd_binned", "zip_encode_ray_bwd", "zip_composite_fwd", "zip_composite_bwd",
+_NAMES = ["split_cast", "fcolour_fwd", "fcolour_bwd", "gather_pack", "adam_step_dev", "grad_clip_coef", "fmlp_classic_fwd", "fmlp_classic_pts_fwd", "fmlp_proposal_fwd", "fmlp_classic_train_fwd", "fmlp_proposal_train_fwd", "classic_get_rays", "classic_ndc_rays", "classic_ray_batch", "zip_encode_prop_fwd", "mip_encode_bwd", "mip_viewenc_bwd", "hash_decay", "zip_percentiles", "zip_pixels_to_rays", "zip_loss_tail", "semantic_composite_fwd", "semantic_composite_bwd", "zip_resample", "zip_encode_fwd", "zip_encode_bwd", "zip_encode_bwd_binned", "zip_encode_ray_bwd", "zip_composite_fwd", "zip_composite_bwd",
           "linear_fwd", "linear_wgrad", "classic_embed", "mip_encode", "mip_viewenc", "classic_sample_pdf", "classic_points",
           "classic_merge_sort", "mip_resample", "stratified", "mip_composite_fwd", "mip_composite_bwd", "classic_composite_fwd",
           "classic_composite_bwd", "adam_step", "colsum_f32", "cast_pad", "pinhole_rays", "mip_loss_tail"]

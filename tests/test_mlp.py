@@ -35,11 +35,15 @@ def rel(a, b):
 
 
 def q(t, dt):
-    """round to the compute dtype like the encoders do when they write the MLP input"""
+    """round to the compute dtype like the encoders do when they write the MLP input (split-bf16: hi + lo = 16 mantissa bits)"""
+    if dt == 4:
+        h = t.bfloat16().float()
+        return h + (t - h).bfloat16().float()
     return t.bfloat16().float() if dt == 1 else t
 
 
-@pytest.mark.parametrize("dt,hidden,M,tol", [(0, 64, 333, 2e-5), (1, 128, 333, 2e-2), (0, 1024, 700, 2e-5), (1, 1024, 700, 2e-2)])
+@pytest.mark.parametrize("dt,hidden,M,tol", [(0, 64, 333, 2e-5), (1, 128, 333, 2e-2), (0, 1024, 700, 2e-5), (1, 1024, 700, 2e-2),
+                                             (4, 64, 333, 1e-4), (4, 1024, 700, 1e-4)])      # 4 = split-bf16 (the fp32-parity mode at MFMA-bf16 rates)
 def test_mip_nets(backend, dt, hidden, M, tol):
     from snerf_amd import ops
     from snerf_amd.mlp import MipNerfNet, MipProposalNet, ParamArena
@@ -64,10 +68,16 @@ def test_mip_nets(backend, dt, hidden, M, tol):
     # HIP / emulated path
     tdt = ops.torch_dtype(dt)
     SKIP, CB = nerf.alloc_inputs(M)
-    SKIP[:, hidden:] = 0; CB[:, hidden:] = 0
-    SKIP[:, hidden:hidden + 96] = enc.reshape(M, 96).to(DEV, tdt)
-    CB[:, hidden:hidden + 27] = cond[:, None].expand(n, S, 27).reshape(M, 27).to(DEV, tdt)
-    E0 = torch.zeros(M, prop.Ew, dtype=tdt, device=DEV); E0[:, :96] = enc.reshape(M, 96).to(DEV, tdt)
+    E0 = prop.buf(M, prop.Ew)
+    if dt == 4:      # the encoders' route in this mode: fp32 rows -> hi / lo interleaved operand columns
+        ops.split_cast(enc.reshape(M, 96).to(DEV), 96, nerf.cs(SKIP, hidden), nerf.Ew)
+        ops.split_cast(cond[:, None].expand(n, S, 27).reshape(M, 27).contiguous().to(DEV), 27, nerf.cs(CB, hidden), nerf.Cw)
+        ops.split_cast(enc.reshape(M, 96).to(DEV), 96, E0, prop.Ew)
+    else:
+        SKIP[:, hidden:] = 0; CB[:, hidden:] = 0
+        SKIP[:, hidden:hidden + 96] = enc.reshape(M, 96).to(DEV, tdt)
+        CB[:, hidden:hidden + 27] = cond[:, None].expand(n, S, 27).reshape(M, 27).to(DEV, tdt)
+        E0.zero_(); E0[:, :96] = enc.reshape(M, 96).to(DEV, tdt)
     raw_rgb, raw_d, saved = nerf.forward(SKIP, CB, True)
     raw_d0, acts0 = prop.forward(E0, True)
     assert rel(raw_rgb, rr.reshape(M, 3)) < tol and rel(raw_d, rd.reshape(M, 1)) < tol and rel(raw_d0, pd.reshape(M, 1)) < tol, \
@@ -79,7 +89,10 @@ def test_mip_nets(backend, dt, hidden, M, tol):
     nerf.backward(d_rgb.to(DEV), d_den.to(DEV), saved)
     prop.backward(d_den0.to(DEV), acts0)
     worst = max((rel(arena.g[k], pr[k].grad), k) for k in sd)
-    assert worst[0] < (5e-3 if dt == 0 else 0.25), f"worst gradient: {worst}"  # bf16: 8-bit mantissa through 12+ layers each way
+    # bf16: 8-bit mantissa through 12+ layers each way.  split-bf16 (dt 4): the arithmetic is good to ~1e-5 (forward bound above), but a
+    # pre-activation within that distance of zero flips its ReLU mask, and at these few hundred rows ONE flipped element is 0.1-0.3 % of
+    # a layer's gradient norm (a discontinuity of the function, not an arithmetic error; ~1e-5 of the elements: a handful here)
+    assert worst[0] < {0: 5e-3, 4: 2e-2}.get(dt, 0.25), f"worst gradient: {worst}"
 
 
 @pytest.mark.parametrize("dt,W,tol", [(0, 64, 2e-5), (1, 128, 2e-2), (0, 256, 2e-5), (1, 256, 2e-2)])

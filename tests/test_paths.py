@@ -53,6 +53,12 @@ def check_grads(named, ref_params, keys, compute, tol):
         if compute == "f32":
             scale = gref.abs().max().item() + 1e-12
             close(got / scale, gref / scale, 0, tol * 5, "grad " + k)
+        elif compute == "bf16x3":
+            # the arithmetic is fp32-class (loss / outputs held to the fp32 bounds), but a pre-activation within ~1e-5 of zero flips its
+            # ReLU mask -- one element of these few hundred rows is O(1e-3) of a gradient's norm: norm-wise bound, 25x below bf16's
+            rel = ((got - gref).norm() / (gref.norm() + 1e-12)).item()
+            print(f"MEASURED split-bf16 grad {k}: rel L2 {rel:.3e}")
+            assert rel < 6e-3, f"grad {k}: relative L2 error {rel:.3e}"
         else:
             rel = ((got - gref).norm() / (gref.norm() + 1e-12)).item()
             print(f"MEASURED bf16 grad {k}: rel L2 {rel:.3e}")
@@ -220,7 +226,9 @@ def test_mipnerf_forward_vs_reference_golden(backend, golden):
 
 
 @pytest.mark.parametrize("compute,hidden,S0,P1,n,tol", [("f32", 1024, 64, 129, 96, 1e-4), ("bf16", 1024, 64, 129, 96, 4e-2),
-                                                       ("f32", 128, 128, 128, 70, 1e-4)])
+                                                       ("f32", 128, 128, 128, 70, 1e-4),
+                                                       # split-bf16 (three bf16 MFMA passes per product): the SAME 1e-4 bounds as exact fp32
+                                                       ("bf16x3", 1024, 64, 129, 96, 1e-4), ("bf16x3", 128, 128, 128, 70, 1e-4)])
 def test_mipnerf_forward_vs_oracle(backend, compute, hidden, S0, P1, n, tol):
     """Full-width network at the BASELINE shape (64 proposal + 128 fine intervals) and the shipped 128+127 shape."""
     from snerf_amd import mipnerf
@@ -236,7 +244,7 @@ def test_mipnerf_forward_vs_oracle(backend, compute, hidden, S0, P1, n, tol):
         ret = m(rays, True, False, 0., s_rand=s_rand.to(DEV), u=u.to(DEV))
     assert torch.equal(ret[0][3].cpu(), ref[0][3]), "level-0 fence posts must be bit-exact"
     close(ret[0][4], ref[0][4], tol, tol * 1e-2, "w0"); close(ret[0][1], ref[0][1], tol, tol, "dist0")
-    if compute == "f32":
+    if compute in ("f32", "bf16x3"):
         close(ret[1][4], ref[1][4], 1e-4, 1e-5, "s1")
         close(ret[1][0], ref[1][0], tol, tol, "rgb"); close(ret[1][1], ref[1][1], tol, tol, "distance"); close(ret[1][2], ref[1][2], tol, tol, "acc")
         psnr = common.psnr(ret[1][0].cpu(), ref[1][0])
@@ -257,7 +265,7 @@ def test_mipnerf_forward_vs_oracle(backend, compute, hidden, S0, P1, n, tol):
             assert psnr > 35.0, f"bf16 PSNR vs fp32 oracle {psnr:.1f} dB (emulated kernels: torch bf16 matmul roundings)"
 
 
-@pytest.mark.parametrize("compute,hidden,tol", [("f32", 64, 3e-4), ("bf16", 128, 8e-2)])
+@pytest.mark.parametrize("compute,hidden,tol", [("f32", 64, 3e-4), ("bf16", 128, 8e-2), ("bf16x3", 64, 3e-4)])
 def test_mipnerf_backward_vs_autograd(backend, compute, hidden, tol):
     from snerf_amd import mipnerf
     S0, P1, n = 24, 25, 36
@@ -275,7 +283,7 @@ def test_mipnerf_backward_vs_autograd(backend, compute, hidden, tol):
     # encoding -- a conditioning property of the algorithm that would drown every level-1 gradient comparison.  The oracle is
     # therefore evaluated AT the fence posts the bf16 run resampled (they carry no gradient: stop_level_grad), and then EVERY
     # parameter gradient, the level-1 network's included, is held to the norm-wise bf16 bound.
-    ref = om.mipnerf_forward(pr, rays_c, S0, P1, s1_override=None if compute == "f32" else ret[1][4].detach().cpu())
+    ref = om.mipnerf_forward(pr, rays_c, S0, P1, s1_override=None if compute in ("f32", "bf16x3") else ret[1][4].detach().cpu())
 
     def loss_fn(ret, tgt, td):  # RGB MSE + disparity-L1 depth on both levels (loss_factory.py:5-11, 26-37) + a weights term
         l = ((ret[1][0] - tgt) ** 2).mean()

@@ -8,7 +8,7 @@ from snerf_amd import ops
 from snerf_amd.trainer import MipTrainer
 
 dev = torch.device("cuda")
-model = bench.build_model("bf16", dev)
+model = bench.build_model(sys.argv[1] if len(sys.argv) > 1 else "bf16", dev)      # bf16 (default) | bf16x3 | f32
 rays = bench.synth_rays(4096, 0, dev)
 tgt = torch.rand(4096, 3, device=dev); depth = torch.rand(4096, device=dev) * 20 + 2; conf = torch.ones(4096, device=dev)
 tr = MipTrainer(model, lr=5e-4, proposal_loss=True)
