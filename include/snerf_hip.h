@@ -199,6 +199,15 @@ int snerf_zip_composite_bwd(const float* raw_rgb, long ld_rgb, const float* raw_
  * data-parallel 1/world_size; zero_grad clears g for the next step. */
 int snerf_adam_step(float* p, float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, int step,
                     float grad_scale, int zero_grad, void* stream);
+/* Appearance embedding (--encode_appearance; s-nerf/model/models.py:63-64, 153-159: condition = cat([view encoding, emb(rays.app)])):
+ * snerf_app_embed writes emb[(int)app[ray], :dim] (fp32 table [n_vocab, dim], dim = 48 in the reference) into columns [0, dim) of dst
+ * rows ray * S + i (dst: the condition block right of the 27 view-encoding columns; dtype fp32 / bf16; sample_id / rows as in
+ * snerf_mip_viewenc); indices are clamped to the table.  snerf_app_embed_bwd accumulates d loss / d emb.weight (+=) from the fp32
+ * gradient of those columns, dV [n_rays * S, ld]. */
+int snerf_app_embed(const float* emb, const float* app, int n_vocab, long n_rays, int S, int dim, void* dst, long ld, int dtype,
+                    const int* sample_id, long rows, void* stream);
+int snerf_app_embed_bwd(const float* dV, long ld, const float* app, int n_vocab, long n_rays, int S, int dim, float* g_emb, void* stream);
+
 /* Split-bf16 operands (dtype SNERF_DT_BF16X3 of snerf_linear_fwd / snerf_linear_wgrad): a value x is carried as hi = bf16(x) and
  * lo = bf16(x - hi) (16 mantissa bits) and a product evaluated as hi.hi + lo.hi + hi.lo on the bf16 MFMA path with fp32 accumulation
  * -- the arithmetic of the reference (fp32, s-nerf/model/models.py) to ~2^-16 relative per product at 1/3 of the bf16 rate instead

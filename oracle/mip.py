@@ -294,8 +294,8 @@ def mipnerf_forward(p: dict, rays: dict, n_samples: int, n_fine: int, s_rand=Non
                     white_bg: bool = False, ray_shape: str = "cone", transform_idx: int = 0,
                     max_deg_point: int = 16, deg_view: int = 4, resample_padding: float = 0.01,
                     density_noise0=None, density_noise1=None, return_aux: bool = False, s1_override=None):
-    """MipNerfModel.forward, models.py:72-187 (warp branch, use_viewdirs, no
-    appearance embedding).  ``u`` [N,n_fine] or [n_fine]; None = det_u(n_fine).
+    """MipNerfModel.forward, models.py:72-187 (warp branch, use_viewdirs; the appearance
+    embedding of encode_appearance when `p` holds "emb.weight").  ``u`` [N,n_fine] or [n_fine]; None = det_u(n_fine).
     Returns [[None, distance, acc, s_vals, weights], [rgb, distance, acc, semantic, s_vals, weights]]
     (the proposal_loss=True layout, models.py:180-185) and, if ``return_aux``,
     a dict with the resample indices and raw network outputs."""
@@ -323,6 +323,9 @@ def mipnerf_forward(p: dict, rays: dict, n_samples: int, n_fine: int, s_rand=Non
     m1, c1 = sample2enc(s1, o, d, r, near, far, ray_shape, transform_idx)
     enc1 = integrated_pos_enc(m1, c1, 0, max_deg_point)
     cond = pos_enc(rays["viewdirs"], 0, deg_view, True)
+    if "emb.weight" in p:
+        # encode_appearance (models.py:63-64,153-159): the per-image embedding row rays.app selects, appended to the view condition
+        cond = torch.cat([cond, p["emb.weight"][rays["app"].long().reshape(-1)]], dim=1)
     raw_rgb, raw_d1, raw_sem = nerf_mlp(p, enc1, cond)
     if density_noise1 is not None:
         raw_d1 = raw_d1 + density_noise1
@@ -337,11 +340,12 @@ def mipnerf_forward(p: dict, rays: dict, n_samples: int, n_fine: int, s_rand=Non
 
 def mipnerf_param_shapes(hidden: int = 1024, rgb_layers: int = 3, prop_hidden: int = 256, feature_dim: int = 96,
                          cond_dim: int = 27, n_layers: int = 8, n_prop_layers: int = 4, cond_units: int = 128,
-                         skip_layer: int = 4, semantic_class_num: int = 0):
+                         skip_layer: int = 4, semantic_class_num: int = 0, n_vocab: int = 0):
     """Ordered (name, shape) list of ``MipNerfModel.state_dict()`` for the
     shipped config (models.py:55-68, 232-255, 307-315); with ``semantic_class_num`` > 0 the
     semantic head Sequential(DenseBlock(hidden, hidden // 2), Linear(hidden // 2, C)) (models.py:258-260) is registered after
-    the rgb head."""
+    the rgb head; with ``n_vocab`` > 0 (encode_appearance, models.py:57,63-64) cond_dim must be 27 + 48 and the embedding table
+    ``emb.weight`` [n_vocab, 48] sits between the NeRF MLP and the proposal MLP."""
     out = []
     for i in range(n_layers):
         k = feature_dim if i == 0 else (hidden + feature_dim if ((i - 1) % skip_layer == 0 and (i - 1) > 0) else hidden)
@@ -355,6 +359,8 @@ def mipnerf_param_shapes(hidden: int = 1024, rgb_layers: int = 3, prop_hidden: i
     if semantic_class_num > 0:
         out += [("mlp.semantic_layer.0.layers.0.weight", (hidden // 2, hidden)), ("mlp.semantic_layer.0.layers.0.bias", (hidden // 2,)),
                 ("mlp.semantic_layer.1.weight", (semantic_class_num, hidden // 2)), ("mlp.semantic_layer.1.bias", (semantic_class_num,))]
+    if n_vocab > 0:
+        out += [("emb.weight", (n_vocab, 48))]
     for i in range(n_prop_layers):
         k = feature_dim if i == 0 else prop_hidden
         out += [(f"proposal.layers.{i}.layers.0.weight", (prop_hidden, k)), (f"proposal.layers.{i}.layers.0.bias", (prop_hidden,))]

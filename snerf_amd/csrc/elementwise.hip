@@ -219,6 +219,58 @@ extern "C" int snerf_cast_pad(const float* src, long ld_src, long M, int C, int 
   return snerf_check_launch();
 }
 
+// Appearance embedding of the live mip path (s-nerf/model/models.py:63-64 `emb = Embedding(N_vocab, 48)`, :153-159: condition =
+// cat([view encoding, emb(rays.app.long())]), tiled per sample like the view encoding, models.py:285-287): row m of the condition block
+// gets the embedding row of its ray's image index.  One thread per output element; sample_id as in snerf_mip_viewenc.
+template <typename T>
+__global__ __launch_bounds__(256) void app_embed_kernel(const float* __restrict__ emb, const float* __restrict__ app, int V, long rows, int S, int dim,
+                                                        T* __restrict__ dst, long ld, const int* __restrict__ sample_id) {
+  const long total = rows * dim;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long m = e / dim;
+    const int c = (int)(e - m * dim);
+    const long ray = (sample_id != nullptr ? (long)sample_id[m] : m) / S;
+    int v = (int)app[ray];                                  // rays.app.long(): truncation
+    v = v < 0 ? 0 : (v >= V ? V - 1 : v);
+    dst[m * ld + c] = from_f32<T>(emb[(long)v * dim + c]);
+  }
+}
+// d loss / d emb.weight: one wave per ray sums the condition-block gradient of the ray's S samples (lane = embedding column), then one
+// atomic per (ray, column) into the row of the ray's image
+__global__ __launch_bounds__(256) void app_embed_bwd_kernel(const float* __restrict__ dV, long ld, const float* __restrict__ app, int V, long n_rays, int S,
+                                                            int dim, float* __restrict__ g_emb) {
+  const int lane = threadIdx.x & 63;
+  const long ray = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= n_rays) return;
+  int v = (int)app[ray];
+  v = v < 0 ? 0 : (v >= V ? V - 1 : v);
+  for (int c = lane; c < dim; c += 64) {
+    float s = 0.f;
+    for (int i = 0; i < S; ++i) s += dV[(ray * S + i) * ld + c];
+    atomicAdd(g_emb + (long)v * dim + c, s);
+  }
+}
+
+extern "C" int snerf_app_embed(const float* emb, const float* app, int n_vocab, long n_rays, int S, int dim, void* dst, long ld, int dtype,
+                               const int* sample_id, long rows, void* stream) {
+  const long M = sample_id != nullptr ? rows : n_rays * S;
+  if (M <= 0) return SNERF_OK;
+  if (emb == nullptr || app == nullptr || dst == nullptr || n_vocab <= 0 || S <= 0 || dim <= 0 || ld < dim) return SNERF_ERR_ARG;
+  const long total = M * dim;
+  const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+  if (dtype == SNERF_DT_F32) hipLaunchKernelGGL(app_embed_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, emb, app, n_vocab, M, S, dim, (float*)dst, ld, sample_id);
+  else if (dtype == SNERF_DT_BF16) hipLaunchKernelGGL(app_embed_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, emb, app, n_vocab, M, S, dim, (__bf16*)dst, ld, sample_id);
+  else return SNERF_ERR_ARG;
+  return snerf_check_launch();
+}
+
+extern "C" int snerf_app_embed_bwd(const float* dV, long ld, const float* app, int n_vocab, long n_rays, int S, int dim, float* g_emb, void* stream) {
+  if (n_rays <= 0) return SNERF_OK;
+  if (dV == nullptr || app == nullptr || g_emb == nullptr || n_vocab <= 0 || S <= 0 || dim <= 0 || ld < dim) return SNERF_ERR_ARG;
+  hipLaunchKernelGGL(app_embed_bwd_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dV, ld, app, n_vocab, n_rays, S, dim, g_emb);
+  return snerf_check_launch();
+}
+
 // fp32 rows -> split-bf16 rows in the GEMMs' interleaved layout (gemm.hip, GemmNT::split): logical columns [64 j, 64 j + 64) of
 // hi = bf16(v) at physical columns [128 j, 128 j + 64), lo = bf16(v - hi) at [128 j + 64, 128 j + 128); columns C .. Cpad - 1 zero.
 // One thread per 8 consecutive logical columns: two 16-byte stores.

@@ -11,7 +11,7 @@ Mirrors s-nerf/model/models.py:
 Only the configuration the reference can actually run is accelerated (SURVEY.md
 section 0): warp sampling (``no_warp_sample=0``; the other branch raises NameError
 in the reference, models.py:82/178), contraction ``fn=1`` with radius 3, two levels,
-view directions on, no appearance embedding, no semantic head.  Anything else
+view directions on (optionally with the per-image appearance embedding and the semantic head).  Anything else
 raises NotImplementedError -- there is no eager fallback.
 
 Per level the whole chain  sample -> encode -> MLP -> activations -> composite  runs
@@ -42,8 +42,8 @@ class MipNerfModel(_ArenaModule):
         super().__init__()
         if no_warp_sample:
             raise NotImplementedError("no_warp_sample=1 is broken in the reference itself (models.py:82 vs :178); only the warp branch exists")
-        if n_levels != 2 or not use_viewdirs or encode_appearance or disable_integration or min_deg_point != 0 or not stop_level_grad:
-            raise NotImplementedError("accelerated MipNerfModel: n_levels=2, use_viewdirs, stop_level_grad, no appearance embedding")
+        if n_levels != 2 or not use_viewdirs or disable_integration or min_deg_point != 0 or not stop_level_grad:
+            raise NotImplementedError("accelerated MipNerfModel: n_levels=2, use_viewdirs, stop_level_grad")
         if semantic and not (0 < semantic_class_num <= 32):
             raise NotImplementedError("semantic head: 1..32 classes")
         if fn != 1:
@@ -56,8 +56,14 @@ class MipNerfModel(_ArenaModule):
         self.sem_classes = int(semantic_class_num) if semantic else 0
         self.compute = compute
         fd = max_deg_point * 6
-        cd = 3 + 6 * deg_view
+        # --encode_appearance (models.py:57,63-64,153-159): a per-image embedding row (48 values, selected by rays.app) appended to the
+        # view condition; the table is the parameter `emb.weight`, registered between the two MLPs as in the reference
+        self.encode_appearance, self.N_vocab, self.app_dim = bool(encode_appearance), int(N_vocab), 48
+        self.view_dim = 3 + 6 * deg_view
+        cd = self.view_dim + (self.app_dim if self.encode_appearance else 0)
         shapes = [("mlp." + n, s) for n, s in MipNerfNet.param_shapes(hidden_layer, 8, 4, fd, cd, rgb_layer, 128, self.sem_classes)]
+        if self.encode_appearance:
+            shapes += [("emb.weight", (self.N_vocab, self.app_dim))]
         shapes += [("proposal." + n, s) for n, s in MipProposalNet.param_shapes(proposal_hidden_layer, 4, fd)]
         self._setup_arena(shapes, torch.device(device))
         dt = _dt(compute)
@@ -69,7 +75,9 @@ class MipNerfModel(_ArenaModule):
         with torch.no_grad():  # DenseBlock / heads: xavier-uniform weights (models.py:208,256-257), default-Linear biases
             for n in self.arena.names:
                 p = self.arena.p[n]
-                if n.endswith(".weight"):
+                if n == "emb.weight":
+                    nn.init.normal_(p)                    # torch.nn.Embedding's default
+                elif n.endswith(".weight"):
                     nn.init.xavier_uniform_(p if p.dim() == 2 else p.view(1, -1))
                 else:
                     fan_in = self.arena.p[n[:-4] + "weight"].shape[-1]
@@ -124,7 +132,19 @@ class MipNerfModel(_ArenaModule):
             enc_ids = sample_id
         ops.mip_encode(s1, o, d, radii, near, far, cone, self.transform_idx, self.max_deg_point, self.nerf.cs(SKIP, H), None, self.nerf.Ew, self.dt,
                        sample_id=enc_ids)
-        ops.mip_viewenc(vd, S1, self.deg_view, self.nerf.cs(CB, H), self.nerf.Cw, self.dt, sample_id=enc_ids)
+        app = None
+        if self.encode_appearance:
+            app = f(rays.app).reshape(-1)
+            if self.dt == ops.BF16X3:        # the split layout is written from an fp32 image of the whole condition block
+                cond = torch.empty(rows, self.nerf.Cw, dtype=torch.float32, device=dev)
+                ops.mip_viewenc(vd, S1, self.deg_view, cond, self.nerf.Cw, ops.F32, sample_id=enc_ids)
+                ops.app_embed(self.arena.p["emb.weight"], app, S1, cond[:, self.view_dim:], ops.F32, sample_id=enc_ids)
+                ops.split_cast(cond, self.nerf.Cw, self.nerf.cs(CB, H), self.nerf.Cw)
+            else:
+                ops.mip_viewenc(vd, S1, self.deg_view, CB[:, H:], self.nerf.Cw, self.dt, sample_id=enc_ids)
+                ops.app_embed(self.arena.p["emb.weight"], app, S1, CB[:, H + self.view_dim:], self.dt, sample_id=enc_ids)
+        else:
+            ops.mip_viewenc(vd, S1, self.deg_view, self.nerf.cs(CB, H), self.nerf.Cw, self.dt, sample_id=enc_ids)
         raw_rgb, raw_d1, saved1 = self.nerf.forward(SKIP, CB, keep)
         rgb1, dist1, acc1, w1 = ops.mip_composite_fwd(raw_rgb, raw_d1, noise1, s1, d, near, far, self.transform_idx, white_bg,
                                                       self.rgb_padding, self.density_bias, row_index=row_index)
@@ -137,7 +157,7 @@ class MipNerfModel(_ArenaModule):
             # detached aliases of the output tensors: the originals become outputs of the autograd Function
             ctx = dict(o=o, vd=vd, radii=radii, cone=cone, d=d, near=near, far=far, s0=s0.detach(), s1=s1.detach(), raw_d0=raw_d0, acts0=acts0, w0=w0.detach(), dist0=dist0.detach(),
                        raw_rgb=raw_rgb, raw_d1=raw_d1, saved1=saved1, w1=w1.detach(), dist1=dist1.detach(), noise0=noise0, noise1=noise1,
-                       white=white_bg, raw_sem=raw_sem)
+                       white=white_bg, raw_sem=raw_sem, app=app)
         return (dist0, acc0, s0, w0, rgb1, dist1, acc1, s1, w1) + ((sem1,) if self.semantic else ()), ctx
 
     def _backward(self, ctx, g_dist0, g_acc0, g_w0, g_rgb1, g_dist1, g_acc1, g_w1, g_sem1=None, on_done=None, ray_grads=False):
@@ -168,7 +188,10 @@ class MipNerfModel(_ArenaModule):
             ops.mip_composite_bwd(c["raw_rgb"], c["raw_d1"], c["noise1"], c["s1"], c["d"], c["near"], c["far"], self.transform_idx,
                                   c["white"], self.rgb_padding, self.density_bias, c["w1"], c["dist1"], cc(g_rgb1), cc(g_dist1),
                                   cc(g_acc1), cc(g_w1), d_rgb, d_den, g_dirs=gdir)
-            ig = self.nerf.backward(d_rgb, d_den, c["saved1"], d_raw_sem, want_input_grad=ray_grads)
+            ig = self.nerf.backward(d_rgb, d_den, c["saved1"], d_raw_sem, want_input_grad=ray_grads, want_cond_grad=self.encode_appearance)
+            if self.encode_appearance:     # d loss / d emb.weight from the condition block's gradient (its columns right of the view encoding)
+                dVc = ig[1] if ray_grads else ig
+                ops.app_embed_bwd(dVc[:, self.view_dim:], c["app"], S1, self.arena.g["emb.weight"])
             if ray_grads:
                 dE, dV = ig
                 eo, ed = ops.mip_encode_bwd(c["s1"], c["o"], c["d"], c["radii"], c["near"], c["far"], c["cone"], self.transform_idx, self.max_deg_point, dE)

@@ -850,8 +850,9 @@ class MipNerfNet(_Net):
             self.fwd("sem1", S0, self.Hs, self.raw_sem, self.sc, ACT_NONE, out_f32=True)
         return raw_rgb, raw_d, ((acts, cacts, SKIP, CB, S0) if keep else None)
 
-    def backward(self, d_raw_rgb, d_raw_density, saved, d_raw_sem=None, want_input_grad=False):
-        """-> None, or with `want_input_grad` (dE fp32 [M, Ew], dV fp32 [M, Cw]): the gradients w.r.t. the IPE and view encodings."""
+    def backward(self, d_raw_rgb, d_raw_density, saved, d_raw_sem=None, want_input_grad=False, want_cond_grad=False):
+        """-> None, or with `want_input_grad` (dE fp32 [M, Ew], dV fp32 [M, Cw]): the gradients w.r.t. the IPE and view encodings;
+        with `want_cond_grad` alone: dV (the appearance embedding's columns of the condition block need it in every training step)."""
         acts, cacts, SKIP, CB, S0 = saved
         H, g, cu, M = self.H, self.g, self.cu, d_raw_rgb.shape[0]
         dV = None
@@ -875,7 +876,7 @@ class MipNerfNet(_Net):
             for j in range(self.nc - 1, -1, -1):
                 cx, ck, cy = cacts[j]
                 self.wgrad(f"cond_layers.{j}.layers.0", dCs[self.nc - 1 - j], cx, cu, H + self.cd if j == 0 else cu)
-            if want_input_grad:
+            if want_input_grad or want_cond_grad:
                 dV = self.input_grad("cenc", dCs[-1], cu, self.Cw)
         else:
             dC = self.buf(M, cu)
@@ -890,7 +891,7 @@ class MipNerfNet(_Net):
                     dC = dX
                 else:
                     self.dgrad(n, dC, cu, DB, H, mask=CB, colsum=self.gB("bottleneck_layer.layers.0"))
-                    if want_input_grad:
+                    if want_input_grad or want_cond_grad:
                         dV = self.input_grad("cenc", dC, cu, self.Cw)
         ops.cast_pad(d_raw_density, 1, self.cs(DB, H, H + g), g, self.dt)
         xl = acts[-1][2]
@@ -925,7 +926,7 @@ class MipNerfNet(_Net):
                 dZ = dX
         if want_input_grad:
             return self.input_grad("enc", DZE, H * len(self.enc_layers), self.Ew), dV
-        return None
+        return dV if want_cond_grad else None
 
 
 # =============================================================================

@@ -289,6 +289,20 @@ def mip_viewenc(viewdirs, S, deg, dst, width, dt, sample_id=None):
     _lib.call("snerf_mip_viewenc", _p(viewdirs), viewdirs.shape[0], S, deg, _p(dst), dst.stride(0), width, dt, _p(ids), rows, _stream())
 
 
+def app_embed(emb, app, S, dst, dt, sample_id=None):
+    """appearance embedding rows into the condition block: dst[ray * S + i, :dim] = emb[int(app[ray])] (models.py:153-159)"""
+    _f32c(emb); _f32c(app)
+    ids, rows = _ids(sample_id)
+    _lib.call("snerf_app_embed", _p(emb), _p(app), emb.shape[0], app.numel(), int(S), emb.shape[1], _p(dst), dst.stride(0), dt, _p(ids), rows, _stream())
+
+
+def app_embed_bwd(dV, app, S, g_emb):
+    """g_emb[int(app[ray])] += sum over the ray's S samples of dV[ray * S + i, :dim] (fp32)"""
+    _chk2d(dV, torch.float32); _f32c(app); _f32c(g_emb)
+    assert dV.shape[0] == app.numel() * S and dV.shape[1] >= g_emb.shape[1]
+    _lib.call("snerf_app_embed_bwd", _p(dV), dV.stride(0), _p(app), g_emb.shape[0], app.numel(), int(S), g_emb.shape[1], _p(g_emb), _stream())
+
+
 def ert_compact(s0, w0, s1, eps_t, eps_w):
     """Early ray termination + sample compaction from the proposal histogram (inference): -> (row_index int32 [N,S1] with -1 for
     skipped samples, sample_id int32 [rows] of the kept samples in ray-major order).  One device->host sync for the row count."""
