@@ -259,6 +259,9 @@ def main():
                     help="also render the frame with early ray termination + sample compaction (inference extension, not the reference's "
                          "algorithm): skip fine samples whose proposal-predicted transmittance <= EPS_T or weight <= EPS_W")
     ap.add_argument("--frame-chunk", type=int, default=32768)
+    ap.add_argument("--graph", action="store_true",
+                    help="time the hipGraph-captured step (MipTrainer.capture / replay: forward + loss tail + backward as one graph launch; "
+                         "N > 1: the all-reduce and Adam follow outside the graph) -- the small-batch / strong-scaling step")
     args = ap.parse_args()
     global S0, P1
     if args.shape == "shipped":
@@ -304,14 +307,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.graph:
+        trainer.capture(rays, tgt, depth, conf, warmup=max(args.warmup, 1))
+        step_fn = trainer.replay
+    else:
+        step_fn = lambda: trainer.step(rays, tgt, depth, conf)
     for _ in range(args.warmup):
-        trainer.step(rays, tgt, depth, conf)
+        step_fn()
     barrier()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     ev[0].record()
     for i in range(args.steps):
-        loss, _ = trainer.step(rays, tgt, depth, conf)
+        loss, _ = step_fn()
         ev[i + 1].record()                                   # per-step device timestamps (no sync inside the timed region)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -368,6 +376,8 @@ def main():
                           "rays_per_gpu_per_step": n, "global_rays_per_step": n * world, "parallelism": f"dp{world} (ray-sharded, flat-arena RCCL all-reduce overlapped with the backward)",
                           "train_flops_per_ray": 3 * fwd},
                "roofline": roofline, "final_loss": final_loss, "ms_per_step_median": round(ms_median, 3)}
+        if args.graph:
+            out["config"]["step"] = "hipGraph-captured (MipTrainer.capture / replay)"
         if comm is not None:
             out["comm"] = comm
 

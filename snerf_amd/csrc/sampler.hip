@@ -130,60 +130,82 @@ extern "C" int snerf_classic_merge_sort(const float* a, int na, const float* b, 
 // ---------------------------------------------------------------------------
 // mip resample: s_vals [N,S+1], weights [N,S] -> new fence posts [N,Nf] + idx
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(LPR_THREADS) void mip_resample_kernel(const float* __restrict__ s_vals, const float* __restrict__ weights,
+#define MRS_RAYS 64        // rays per workgroup
+#define MRS_THREADS 256    // 4 waves: wave 0 owns the serial prefix sums (lane per ray), all four the lookups (lane per output sample)
+__global__ __launch_bounds__(MRS_THREADS) void mip_resample_kernel(const float* __restrict__ s_vals, const float* __restrict__ weights,
                                                                    const float* __restrict__ u, long u_stride, long N, int S, int Nf,
                                                                    float padding_c, float* __restrict__ out, int* __restrict__ idx_out) {
   extern __shared__ float lds[];
   const int stride = (S + 1) | 1;
-  float* cdf = lds + threadIdx.x * stride;   // S+1 entries; slot j+1 first holds the blurred weight j
-  const long ray = (long)blockIdx.x * LPR_THREADS + threadIdx.x;
-  if (ray >= N) return;
-  const float* w = weights + ray * S;
-  const float* bins = s_vals + ray * (S + 1);
-  // blur-pool (mip.py:296-306): wmax[i] = max(wp[i], wp[i+1]) with wp = [w0, w0..wS-1, wS-1];
-  // blur[j] = 0.5 * (wmax[j] + wmax[j+1]) + padding
-  double acc = 0.0;
-  float wprev = w[0], wcur = w[0];
-  float mx_lo = fmaxf(wprev, wcur);          // wmax[0] = max(wp[0], wp[1]) = w0
-  for (int j = 0; j < S; ++j) {
-    const float wnext = j + 1 < S ? w[j + 1] : w[S - 1];
-    const float mx_hi = fmaxf(wcur, wnext);  // wmax[j+1]
-    const float blur = 0.5f * (mx_lo + mx_hi) + padding_c;
-    cdf[j + 1] = blur;
-    acc += (double)blur;
-    mx_lo = mx_hi; wcur = wnext;
-  }
-  // sorted_piecewise_constant_pdf (math_ops.py:31-46)
-  float wsum = (float)acc;
-  const float padding = fmaxf(0.f, 1e-5f - wsum);
-  const float padw = padding / (float)S;
-  wsum = wsum + padding;
-  acc = 0.0;
-  cdf[0] = 0.f;
-  for (int j = 0; j < S - 1; ++j) {
-    const float pdf = (cdf[j + 1] + padw) / wsum;
-    acc += (double)pdf;
-    cdf[j + 1] = fminf(1.f, (float)acc);
-  }
-  cdf[S] = 1.f;
-  const float* ur = u + ray * u_stride;
-  for (int k = 0; k < Nf; ++k) {
-    const float uk = ur[k];
-    int lo = 0, hi = S + 1;                  // #(cdf <= u) over S+1 sorted entries
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if (cdf[mid] <= uk) lo = mid + 1; else hi = mid;
+  float* const cdf_all = lds;                                  // [MRS_RAYS][stride]: weights, then blurred weights, then the CDF
+  float* const bins_all = lds + MRS_RAYS * stride;             // [MRS_RAYS][S + 1] fence posts
+  float* const u_all = bins_all + MRS_RAYS * (S + 1);          // [MRS_RAYS or 1][Nf]
+  const long ray0 = (long)blockIdx.x * MRS_RAYS;
+  const int nr = (int)min((long)MRS_RAYS, N - ray0);
+  // stage the workgroup's rows with coalesced loads (round 2 read them lane-per-ray: a different row per lane)
+  for (int e = threadIdx.x; e < nr * S; e += MRS_THREADS) cdf_all[(e / S) * stride + (e % S)] = weights[ray0 * S + e];
+  for (int e = threadIdx.x; e < nr * (S + 1); e += MRS_THREADS) bins_all[e] = s_vals[ray0 * (S + 1) + e];
+  if (u_stride == Nf) { for (int e = threadIdx.x; e < nr * Nf; e += MRS_THREADS) u_all[e] = u[ray0 * Nf + e]; }
+  else if (u_stride == 0) { for (int e = threadIdx.x; e < Nf; e += MRS_THREADS) u_all[e] = u[e]; }
+  __syncthreads();
+  if ((int)threadIdx.x < nr) {
+    float* cdf = cdf_all + threadIdx.x * stride;   // S+1 entries; slot j holds weight j until slot j is overwritten by the blurred weight j - 1
+    // blur-pool (mip.py:296-306): wmax[i] = max(wp[i], wp[i+1]) with wp = [w0, w0..wS-1, wS-1];
+    // blur[j] = 0.5 * (wmax[j] + wmax[j+1]) + padding
+    double acc = 0.0;
+    float wprev = cdf[0], wcur = cdf[0];
+    float mx_lo = fmaxf(wprev, wcur);          // wmax[0] = max(wp[0], wp[1]) = w0
+    for (int j = 0; j < S; ++j) {
+      const float wnext = j + 1 < S ? cdf[j + 1] : wcur;   // (w[S - 1] = the current weight when j = S - 1)
+      const float mx_hi = fmaxf(wcur, wnext);  // wmax[j+1]
+      const float blur = 0.5f * (mx_lo + mx_hi) + padding_c;
+      cdf[j + 1] = blur;                       // (weight j + 1 is already in `wnext`)
+      acc += (double)blur;
+      mx_lo = mx_hi; wcur = wnext;
     }
-    int i0 = lo - 1;
-    if (i0 < 0) i0 = 0;
-    if (i0 > S - 1) i0 = S - 1;              // unreachable for u < 1; keeps loads in bounds
-    const float c0 = cdf[i0], c1 = cdf[i0 + 1];
-    const float b0 = bins[i0], b1 = bins[i0 + 1];
-    float t = (uk - c0) / (c1 - c0);
-    if (t != t) t = 0.f;                     // nan_to_num(., 0)
-    t = fminf(fmaxf(t, 0.f), 1.f);           // clip also maps +-inf like nan_to_num + clip
-    out[ray * Nf + k] = b0 + t * (b1 - b0);
-    if (idx_out != nullptr) idx_out[ray * Nf + k] = i0;
+    // sorted_piecewise_constant_pdf (math_ops.py:31-46)
+    float wsum = (float)acc;
+    const float padding = fmaxf(0.f, 1e-5f - wsum);
+    const float padw = padding / (float)S;
+    wsum = wsum + padding;
+    acc = 0.0;
+    cdf[0] = 0.f;
+    for (int j = 0; j < S - 1; ++j) {
+      const float pdf = (cdf[j + 1] + padw) / wsum;
+      acc += (double)pdf;
+      cdf[j + 1] = fminf(1.f, (float)acc);
+    }
+    cdf[S] = 1.f;
+  }
+  __syncthreads();
+  // lookups, lane per OUTPUT sample: wave w walks rays w, w + 4, ... with its 64 lanes searching that ray's CDF at once; everything it
+  // reads is in LDS, the outputs leave row-contiguously.  (Round 2 kept the lane-per-ray mapping here too: ~1000 dependent steps per
+  // lane, 110-125 us whatever the batch size.)
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const bool u_lds = u_stride == Nf || u_stride == 0;
+  for (int r = wave; r < nr; r += MRS_THREADS / 64) {
+    const float* cdf_r = cdf_all + r * stride;
+    const float* bins_r = bins_all + r * (S + 1);
+    const long ray_r = ray0 + r;
+    const float* ur = u_lds ? u_all + (u_stride == 0 ? 0 : r * Nf) : u + ray_r * u_stride;
+    for (int k = lane; k < Nf; k += 64) {
+      const float uk = ur[k];
+      int lo = 0, hi = S + 1;                // #(cdf <= u) over S+1 sorted entries
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (cdf_r[mid] <= uk) lo = mid + 1; else hi = mid;
+      }
+      int i0 = lo - 1;
+      if (i0 < 0) i0 = 0;
+      if (i0 > S - 1) i0 = S - 1;            // unreachable for u < 1; keeps loads in bounds
+      const float c0 = cdf_r[i0], c1 = cdf_r[i0 + 1];
+      const float b0 = bins_r[i0], b1 = bins_r[i0 + 1];
+      float t = (uk - c0) / (c1 - c0);
+      if (t != t) t = 0.f;                   // nan_to_num(., 0)
+      t = fminf(fmaxf(t, 0.f), 1.f);         // clip also maps +-inf like nan_to_num + clip
+      out[ray_r * Nf + k] = b0 + t * (b1 - b0);
+      if (idx_out != nullptr) idx_out[ray_r * Nf + k] = i0;
+    }
   }
 }
 
@@ -192,12 +214,12 @@ extern "C" int snerf_mip_resample(const float* s_vals, const float* weights, con
   if (N <= 0) return SNERF_OK;
   if (S < 2 || Nf <= 0) return SNERF_ERR_ARG;
   const int stride = (S + 1) | 1;
-  const size_t lds = (size_t)LPR_THREADS * stride * sizeof(float);
+  const size_t lds = (size_t)MRS_RAYS * (stride + (S + 1) + Nf) * sizeof(float);
   if (lds > 160 * 1024) return SNERF_ERR_ARG;
   static bool attr = false;
   if (!attr) { hipFuncSetAttribute((const void*)mip_resample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-  const int blocks = (int)((N + LPR_THREADS - 1) / LPR_THREADS);
-  hipLaunchKernelGGL(mip_resample_kernel, dim3(blocks), dim3(LPR_THREADS), lds, (hipStream_t)stream, s_vals, weights, u, u_stride, N, S,
+  const int blocks = (int)((N + MRS_RAYS - 1) / MRS_RAYS);
+  hipLaunchKernelGGL(mip_resample_kernel, dim3(blocks), dim3(MRS_THREADS), lds, (hipStream_t)stream, s_vals, weights, u, u_stride, N, S,
                      Nf, resample_padding, out, idx_out);
   return snerf_check_launch();
 }

@@ -161,8 +161,9 @@ class MipNerfModel(_ArenaModule):
         return (dist0, acc0, s0, w0, rgb1, dist1, acc1, s1, w1) + ((sem1,) if self.semantic else ()), ctx
 
     def _backward(self, ctx, g_dist0, g_acc0, g_w0, g_rgb1, g_dist1, g_acc1, g_w1, g_sem1=None, on_done=None, ray_grads=False):
-        """Accumulates parameter gradients into the arena.  `on_done(prefix)` is called as soon as the gradients of the network whose
-        parameters start with `prefix` are final (the trainer starts that block's all-reduce while the rest of the backward runs).
+        """Accumulates parameter gradients into the arena.  `on_done(prefix or [prefixes])` is called as soon as the gradients of the
+        parameters whose names start with a prefix are final -- the NeRF MLP's heads, then each of its trunk layers as the backward
+        reaches it, then the proposal network -- and the trainer starts that block's all-reduce while the rest of the backward runs.
         `ray_grads`: also return d loss / d (origins, directions, viewdirs) [n,3] each -- the reference's pose refinement
         (utils/sample_utils.py:410-435) back-propagates through the encoders into the camera pose: the data gradient is carried one GEMM
         further to the IPE / view encodings, then through integrated_pos_enc, the contraction and its Jacobian, lift_gaussian and the
@@ -188,7 +189,9 @@ class MipNerfModel(_ArenaModule):
             ops.mip_composite_bwd(c["raw_rgb"], c["raw_d1"], c["noise1"], c["s1"], c["d"], c["near"], c["far"], self.transform_idx,
                                   c["white"], self.rgb_padding, self.density_bias, c["w1"], c["dist1"], cc(g_rgb1), cc(g_dist1),
                                   cc(g_acc1), cc(g_w1), d_rgb, d_den, g_dirs=gdir)
-            ig = self.nerf.backward(d_rgb, d_den, c["saved1"], d_raw_sem, want_input_grad=ray_grads, want_cond_grad=self.encode_appearance)
+            layer_done = None if on_done is None else (lambda names: on_done(["mlp." + n for n in names]))
+            ig = self.nerf.backward(d_rgb, d_den, c["saved1"], d_raw_sem, want_input_grad=ray_grads, want_cond_grad=self.encode_appearance,
+                                    on_done=layer_done)
             if self.encode_appearance:     # d loss / d emb.weight from the condition block's gradient (its columns right of the view encoding)
                 dVc = ig[1] if ray_grads else ig
                 ops.app_embed_bwd(dVc[:, self.view_dim:], c["app"], S1, self.arena.g["emb.weight"])
@@ -198,7 +201,7 @@ class MipNerfModel(_ArenaModule):
                 g_o += eo; g_d += ed + gdir
                 g_vd += ops.mip_viewenc_bwd(c["vd"], S1, self.deg_view, dV)
         if on_done is not None:
-            on_done("mlp.")
+            on_done("mlp.")           # (whatever of the block was not announced layer by layer; a no-op otherwise)
         if any(t is not None for t in (g_dist0, g_acc0, g_w0)):
             d_den0 = torch.empty(n * S0, 1, dtype=torch.float32, device=dev)
             gdir = torch.empty_like(c["d"]) if ray_grads else None

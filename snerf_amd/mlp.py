@@ -850,9 +850,12 @@ class MipNerfNet(_Net):
             self.fwd("sem1", S0, self.Hs, self.raw_sem, self.sc, ACT_NONE, out_f32=True)
         return raw_rgb, raw_d, ((acts, cacts, SKIP, CB, S0) if keep else None)
 
-    def backward(self, d_raw_rgb, d_raw_density, saved, d_raw_sem=None, want_input_grad=False, want_cond_grad=False):
+    def backward(self, d_raw_rgb, d_raw_density, saved, d_raw_sem=None, want_input_grad=False, want_cond_grad=False, on_done=None):
         """-> None, or with `want_input_grad` (dE fp32 [M, Ew], dV fp32 [M, Cw]): the gradients w.r.t. the IPE and view encodings;
-        with `want_cond_grad` alone: dV (the appearance embedding's columns of the condition block need it in every training step)."""
+        with `want_cond_grad` alone: dV (the appearance embedding's columns of the condition block need it in every training step).
+        `on_done(names)`: called with a list of parameter-name prefixes (relative to this network) as soon as their gradients are final --
+        the heads first, then every trunk layer right after its weight gradient -- so that a data-parallel trainer can put each block
+        on the wire while the rest of the backward pass still runs (the trunk is back-propagated last layer first)."""
         acts, cacts, SKIP, CB, S0 = saved
         H, g, cu, M = self.H, self.g, self.cu, d_raw_rgb.shape[0]
         dV = None
@@ -911,10 +914,14 @@ class MipNerfNet(_Net):
         self.wgrad("density_layer", self.cs(DB, H, H + g), xl, 1, H)
         dZ = self.buf(M, H)
         self.dgrad("bd", DB, kb, dZ, H, mask=xl, colsum=self.gB(f"layers.{self.L - 1}.layers.0"))
+        if on_done is not None:      # everything behind the trunk in the arena: density head, bottleneck, colour head (, semantic head)
+            on_done(["density_layer", "bottleneck_layer", "cond_layers", "rgb_layer"] + (["semantic_layer"] if self.sc else []))
         for i in range(self.L - 1, -1, -1):
             x, k, y = acts[i]
             n = f"layers.{i}.layers.0"
             self.wgrad(n, dZ, x, H, self.fd if i == 0 else (H + self.fd if self._is_skip_in(i) else H))
+            if on_done is not None:  # weight: just now; bias: the column sums of the data gradient that produced dZ
+                on_done([f"layers.{i}."])
             if i > 0:
                 xin = acts[i - 1][2]
                 if want_input_grad and (i - 1) in self.enc_layers:      # lands in its column block of the K-concatenated operand

@@ -19,9 +19,11 @@ from . import ops
 
 
 class _GradExchange:
-    """Gradient all-reduce overlapped with the backward pass: the arena is laid out network by network, and as soon as one network's
-    gradients are final its block is all-reduced asynchronously (RCCL runs it on its own stream) while the remaining networks'
-    backward kernels keep the compute stream busy.  `finish()` reduces whatever was not announced and waits for everything."""
+    """Gradient all-reduce overlapped with the backward pass: the arena is laid out network by network and layer by layer, and as soon
+    as a block's gradients are final -- the NeRF MLP's heads, then each 4 MB trunk layer as the backward reaches it, then the proposal
+    network -- it is all-reduced asynchronously (RCCL runs it on its own stream) while the remaining backward kernels keep the compute
+    stream busy: only the last trunk layer's bucket (~0.4 MB) is left exposed in front of Adam.  `finish()` reduces whatever was not
+    announced and waits for everything."""
 
     def __init__(self, arena, world, group, single_rank=False):
         """`single_rank`: run the collectives even in a process group of one rank (diagnostics: exercises the RCCL path on a 1-GPU box)"""
@@ -30,11 +32,32 @@ class _GradExchange:
         self.works, self.done = [], []
 
     def __call__(self, prefix):
+        """`prefix`: a parameter-name prefix or a list of them; neighbouring spans go out as ONE collective, and what an earlier call
+        already covered is not sent twice (the backward announces the NeRF MLP layer by layer and then once more as a whole)."""
         if not self.active:
             return
-        a, b = self.arena.span(prefix)
-        self.done.append((a, b))
-        self.works.append(dist.all_reduce(self.arena.grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        spans = sorted(self.arena.span(p) for p in ([prefix] if isinstance(prefix, str) else prefix))
+        merged = []
+        for a, b in spans:
+            if merged and a <= merged[-1][1]:
+                merged[-1][1] = max(merged[-1][1], b)
+            else:
+                merged.append([a, b])
+        for a, b in merged:
+            for c, d in sorted(self.done):                      # cut away what is already on the wire
+                if c <= a < d:
+                    a = min(d, b)
+                if c < b <= d:
+                    b = max(c, a)
+            inner = [(c, d) for c, d in self.done if a < c and d < b]
+            pieces, pos = [], a
+            for c, d in sorted(inner):
+                pieces.append((pos, c)); pos = d
+            pieces.append((pos, b))
+            for x, y in pieces:
+                if y > x:
+                    self.done.append((x, y))
+                    self.works.append(dist.all_reduce(self.arena.grad[x:y], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
         if not self.active:
@@ -101,6 +124,17 @@ class MipTrainer:
     def step(self, rays, target_rgb, target_depth=None, conf=None, randomized=True, s_rand=None, u=None, ray_grads=False):
         """`ray_grads=True` (pose refinement, configs: pose_refine = True): `last_ray_grads` = d loss / d (origins, directions, viewdirs)
         of this rank's rays, for the caller's pose optimiser (`rays.origins.backward(g_o)` etc. chains them into the pose parameters)."""
+        ex = _GradExchange(self.model.arena, self.world, self.pg, self.single_rank_exchange)
+        # every block of the gradient arena goes on the wire as soon as the backward pass has finished it (heads, then trunk layer by
+        # trunk layer, then the proposal network): the collectives run under the remaining backward kernels
+        loss, outs = self._forward_backward(rays, target_rgb, target_depth, conf, randomized, s_rand, u, ray_grads, ex)
+        ex.finish()
+        self.t += 1
+        self._adam()                                      # graph mode: step count and lr live on the device (capture / replay below)
+        return loss, outs
+
+    def _forward_backward(self, rays, target_rgb, target_depth, conf, randomized, s_rand, u, ray_grads, on_done):
+        """draws, both levels forward, the fused loss tail, the backward pass into the gradient arena (no exchange, no optimiser)"""
         m = self.model
         dev = m.arena.flat.device
         n = rays.origins.shape[0]
@@ -109,12 +143,7 @@ class MipTrainer:
         u = du if u is None else u
         outs, ctx = m._run(rays, True, False, s_rand, u.contiguous(), noise0, noise1)
         loss, g = self.loss_and_grads(outs, target_rgb, target_depth, conf)
-        ex = _GradExchange(m.arena, self.world, self.pg, self.single_rank_exchange)
-        # the 35.9 MB MLP block is reduced while the proposal network's backward runs
-        self.last_ray_grads = m._backward(ctx, *g, on_done=ex, ray_grads=ray_grads)
-        ex.finish()
-        self.t += 1
-        self._adam()                                      # graph mode: step count and lr live on the device (capture / replay below)
+        self.last_ray_grads = m._backward(ctx, *g, on_done=on_done, ray_grads=ray_grads)
         return loss, outs
 
     # ---- hipGraph capture of the whole step --------------------------------------------------------------------------------------
@@ -128,14 +157,18 @@ class MipTrainer:
 
         The `warmup` steps (one-time kernel attributes, allocator pools) are REAL steps on the capture batch, so parameters, Adam
         moments and the step count are snapshotted before and restored after them: capturing does not train.  (The torch RNG does
-        advance.)  Single process only (the RCCL exchange is not captured)."""
-        if self.world != 1:
-            raise NotImplementedError("graph capture covers the single-process step")
+        advance.)
+
+        Data parallel (world > 1; every rank calls capture / replay together): the graph holds forward + loss tail + backward -- the
+        launch-bound part -- and `replay()` follows it with the gradient all-reduce and the Adam launch OUTSIDE the graph (one
+        collective over the whole arena: nothing is left to overlap it with once the backward is a single graph launch; the
+        collective stays out of the graph so that any backend works, gloo on the 1-GPU box included)."""
         a = self.model.arena
         dev = a.flat.device
         snap = (a.flat.clone(), self.m.clone(), self.v.clone(), self.t)
-        self._step_dev = torch.tensor([self.t], dtype=torch.int32, device=dev)
-        self._lr_dev = torch.tensor([self.lr], dtype=torch.float32, device=dev)
+        if self.world == 1:
+            self._step_dev = torch.tensor([self.t], dtype=torch.int32, device=dev)
+            self._lr_dev = torch.tensor([self.lr], dtype=torch.float32, device=dev)
         args = (rays, target_rgb, target_depth, conf)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -146,20 +179,32 @@ class MipTrainer:
         with torch.no_grad():
             a.flat.copy_(snap[0]); self.m.copy_(snap[1]); self.v.copy_(snap[2])
             self.t = snap[3]
-            self._step_dev.fill_(self.t)
+            if self._step_dev is not None:
+                self._step_dev.fill_(self.t)
             a.grad.zero_()
         a.bump()
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
-            self._graph_loss, self._graph_outs = self.step(*args, randomized=randomized)
-        self.t -= 1                                      # capturing records the step, it does not run it
+            if self.world == 1:
+                self._graph_loss, self._graph_outs = self.step(*args, randomized=randomized)
+            else:
+                self._graph_loss, self._graph_outs = self._forward_backward(*args, randomized, None, None, False, None)
+        if self.world == 1:
+            self.t -= 1                                  # capturing records the step, it does not run it
         return self._graph_loss
 
     def replay(self):
         """One captured step.  -> (loss, outs): the same device tensors every time, overwritten by each replay."""
-        self._lr_dev.fill_(self.lr)                      # the graph reads the learning rate from the device
-        self._graph.replay()
+        if self.world == 1:
+            self._lr_dev.fill_(self.lr)                  # the graph reads the learning rate from the device
+            self._graph.replay()
+            self.t += 1
+            return self._graph_loss, self._graph_outs
+        self._graph.replay()                             # forward + loss tail + backward of this rank's shard
+        ex = _GradExchange(self.model.arena, self.world, self.pg)
+        ex.finish()                                      # one all-reduce of the flat gradient arena
         self.t += 1
+        self._adam()
         return self._graph_loss, self._graph_outs
 
 

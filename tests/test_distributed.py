@@ -281,3 +281,71 @@ def test_rccl_collectives_run_on_the_gpu_with_one_rank(tmp_path):
     env = dict(os.environ, SNERF_REPO=REPO, SNERF_PORT=str(29650 + os.getpid() % 200))
     p = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=550, env=env)
     assert p.returncode == 0 and "RCCL_ONE_RANK_OK" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])
+
+
+_CAPTURED_TWO_RANKS = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["SNERF_REPO"])
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + os.environ["SNERF_PORT"], rank=rank, world_size=world)
+torch.cuda.set_device(0)
+import bench
+from snerf_amd.trainer import MipTrainer, shard_batch
+
+def build():
+    torch.manual_seed(0)
+    from snerf_amd.mipnerf import MipNerfModel
+    return MipNerfModel(n_samples=16, N_fine=17, no_warp_sample=0, ray_shape="cone", fn=1, radius=3., transform_idx=0, real=True, rgb_layer=3,
+                        hidden_layer=256, density_noise=0., max_deg_point=16, proposal_hidden_layer=256, proposal_loss=True, compute="bf16", device="cuda")
+n = 256
+rays = bench.synth_rays(n, 5, "cuda")
+g = torch.Generator().manual_seed(6)
+tgt = torch.rand(n, 3, generator=g).cuda()
+depth = (torch.rand(n, generator=g) * 50 + 2).cuda()
+conf = torch.rand(n, generator=g).cuda()
+my, mt, md, mc = shard_batch(rays, rank, world, tgt, depth, conf)
+
+def run(captured):
+    m = build()
+    tr = MipTrainer(m, lr=1e-3)
+    tr.broadcast_parameters(0)
+    losses = []
+    if captured:
+        tr.capture(my, mt, md, mc, randomized=False, warmup=2)
+        for _ in range(3):
+            losses.append(float(tr.replay()[0]))
+    else:
+        for _ in range(3):
+            losses.append(float(tr.step(my, mt, md, mc, randomized=False)[0]))
+    return losses, m.arena.flat.clone(), tr.t
+le, pe, te = run(False)       # eager: per-layer buckets overlapped with the backward
+lc, pc, tc = run(True)        # captured forward + backward, exchange + Adam outside the graph
+rel = float((pe - pc).norm() / pe.norm())
+assert te == tc == 3 and max(abs(a - b) for a, b in zip(le, lc)) < 2e-3 * max(abs(x) for x in le) and rel < 2e-3, (le, lc, rel)
+other = [torch.empty_like(pc) for _ in range(world)]
+dist.all_gather(other, pc)
+assert torch.equal(other[0], other[1]), "ranks diverged"
+dist.barrier(); torch.cuda.synchronize()
+dist.destroy_process_group()
+if rank == 0:
+    print("CAPTURED_TWO_RANKS_OK", le, lc, rel)
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_graph_captured_step_with_the_exchange_outside_the_graph_two_ranks(tmp_path):
+    """Strong-scaling step: forward + loss tail + backward of a rank's shard as ONE hipGraph launch, the gradient
+    all-reduce and Adam outside it.  Two ranks (gloo; both on cuda:0 -- the 1-GPU box cannot host two RCCL ranks) against the eager
+    data-parallel step with its per-layer buckets: same trajectory (bf16 atomics order aside), identical parameters on both ranks."""
+    import subprocess
+    import sys
+    script = tmp_path / "captured_two_ranks.py"
+    script.write_text(_CAPTURED_TWO_RANKS)
+    port = str(29850 + os.getpid() % 100)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, SNERF_REPO=REPO, SNERF_PORT=port, RANK=str(r), WORLD_SIZE="2")
+        procs.append(subprocess.Popen([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
+    outs = [p.communicate(timeout=800) for p in procs]
+    assert all(p.returncode == 0 for p in procs) and "CAPTURED_TWO_RANKS_OK" in outs[0][0], [(o[0][-800:], o[1][-2500:]) for o in outs]
