@@ -1049,7 +1049,7 @@ __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restr
 // out[n] += sum_m (hi + lo)[m, n] of a split-bf16 matrix Y [M, 2 N] (interleaved layout): the bias gradient of the split data-gradient
 // launches of the persistent kernel, whose mask + column-sum flavour does not fit the register file next to the two-pass epilogue
 // (13 spilled registers = scratch traffic in the k-loop; measured 14 ms per launch instead of 3).  One thread per 8 logical columns
-// (two 16-byte loads per row), 256-row chunks per workgroup, one fp32 atomic per column and chunk.
+// (two 16-byte loads per row, four rows in flight), 256-row chunks per workgroup, one fp32 atomic per column and chunk.
 __global__ __launch_bounds__(256) void colsum_split_kernel(const __bf16* __restrict__ Y, long ldy, int M, int n_store, float* __restrict__ out) {
   const int g8 = (n_store + 7) >> 3;                       // column groups of 8
   const int gw = g8 < 256 ? g8 : 256;                      // column groups per workgroup
@@ -1058,9 +1058,19 @@ __global__ __launch_bounds__(256) void colsum_split_kernel(const __bf16* __restr
   if (cg >= g8 || rsub >= per) return;
   const int c0 = cg * 8;
   const __bf16* src = Y + ((c0 >> 6) << 7) + (c0 & 63);
-  const int r0 = blockIdx.x * 1024, r1 = min(M, r0 + 1024);
+  const int r0 = blockIdx.x * 256, r1 = min(M, r0 + 256);
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int r = r0 + rsub; r < r1; r += per) {
+  int r = r0 + rsub;
+  for (; r + 3 * per < r1; r += 4 * per) {                 // eight 16-byte loads in flight per thread
+    bf16x8 h[4], l[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { h[q] = *(const bf16x8*)(src + (long)(r + q * per) * ldy); l[q] = *(const bf16x8*)(src + (long)(r + q * per) * ldy + 64); }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += (float)h[q][e] + (float)l[q][e];
+  }
+  for (; r < r1; r += per) {
     const bf16x8 h = *(const bf16x8*)(src + (long)r * ldy), l = *(const bf16x8*)(src + (long)r * ldy + 64);
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] += (float)h[e] + (float)l[e];
@@ -1151,7 +1161,7 @@ static int launch_nt8p(const GemmNT& p, hipStream_t stream) {
       hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_MASK_BITS, false, true>), g, b, LDS, stream, q);
       if (cs) {
         const int g8 = (p.n_store + 7) / 8;
-        hipLaunchKernelGGL(colsum_split_kernel, dim3((p.M + 1023) / 1024, (g8 + 255) / 256), dim3(256), 0, stream, (const __bf16*)p.Y, p.ldy, p.M, p.n_store, p.colsum);
+        hipLaunchKernelGGL(colsum_split_kernel, dim3((p.M + 255) / 256, (g8 + 255) / 256), dim3(256), 0, stream, (const __bf16*)p.Y, p.ldy, p.M, p.n_store, p.colsum);
       }
       return snerf_check_launch();
     } else if (p.act == ACT_RELU_BITS && !cs) hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_RELU_BITS, false, true>), g, b, LDS, stream, p);
@@ -1257,7 +1267,8 @@ struct GemmTN {
   int M, N, K, n_valid, k_valid, m_chunk;
   int tiles, slices;  // 128 x 128 kernel: output tiles and M slices of the launch (1-D grid, XCD-aware placement)
   // split-bf16 operands (SNERF_DT_BF16X3): dZ [M, 2 N] and X [M, 2 K] in the hi / lo interleaved layout; the kernels multiply the
-  // PHYSICAL matrices (all four hi / lo combinations of every 64 x 64 block; lo.lo is noise-level and harmless) and the output index
+  // PHYSICAL matrices (the 128 x 128 kernel: all four hi / lo combinations of every 64 x 64 block, lo.lo is noise-level and harmless; the
+  // 8-phase kernel deals X's blocks so that the lo.lo quadrant is the same phase for every wave and skips it) and the output index
   // maps the physical (n', k') back to the logical (n, k) = ((n' >> 7) << 6 | n' & 63, ...): the atomics add the combinations up.
   int split;
   float* part;        // deterministic mode: every (tile, M slice) stores its partial tile at part + slice * part_stride + n * part_ld + k
@@ -1442,6 +1453,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
 //     dZ half h, local column lc  <->  tile column (lc>>6)*128 + h*64 + (lc&63)     (wave row wr = lc>>6)
 //     X  half g, local column lc  <->  tile column (lc>>5)*64  + g*32 + (lc&31)     (wave col wc = lc>>5)
 // ---------------------------------------------------------------------------
+template <bool SPLIT>
 __global__ __launch_bounds__(512) void gemm_tn8_kernel(GemmTN p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __bf16 T;
@@ -1468,7 +1480,13 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(GemmTN p) {
   // ---- staging stream: wave w owns pieces 2w, 2w+1 (4 rows x 256 B) of every half-tile -------------------------------
   const int lrow = lane >> 4, lch = lane & 15;
   const int lc = (lch ^ (4 * lrow)) * 8;               // logical column of this lane's 16 bytes inside the half
-  const int zcol = ((lc >> 6) * 128 + (lc & 63)) * 2, xcol = ((lc >> 5) * 64 + (lc & 31)) * 2;
+  // split-bf16 operands ([hi 64 | lo 64] per 128 physical columns): X's 32-column blocks are dealt so that EVERY wave column gets one hi
+  // block (half 0) and the lo block of the same logical columns (half 1) -- tile column (wc, g, c) <-> physical column
+  // (wc >> 1) * 128 + g * 64 + (wc & 1) * 32 + c -- while dZ's halves are hi / lo by themselves (half h = 64 columns).  The quadrant
+  // dZ half 1 x X half 1 is then lo . lo for every wave and is skipped: 3/4 of the MFMAs instead of 4/4.
+  constexpr int xhalf = SPLIT ? 128 : 64;              // byte offset of X half 1
+  const int zcol = ((lc >> 6) * 128 + (lc & 63)) * 2;
+  const int xcol = SPLIT ? (((lc >> 6) * 128) + ((lc >> 5) & 1) * 32 + (lc & 31)) * 2 : ((lc >> 5) * 64 + (lc & 31)) * 2;
   int zrel[2], xrel[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -1490,8 +1508,8 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(GemmTN p) {
       const int off = s_kt * xstep;
       const int left = xbytes - off;
       const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)X + off), 0, left > 0 ? left : 0, 0x00020000);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)dst, 16, xrel[0] + (which - 2) * 64, 0, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)(dst + 1024), 16, xrel[1] + (which - 2) * 64, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)dst, 16, xrel[0] + (which - 2) * xhalf, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)(dst + 1024), 16, xrel[1] + (which - 2) * xhalf, 0, 0, 0);
     }
   };
 
@@ -1591,12 +1609,15 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(GemmTN p) {
       }
     if (wr == 0) { stage(db, 0); wait_load(); }
     end_phase();
-    // P3: Z1 x X_S; X_S replaced by the first X half of the next k-tile
+    // P3: Z1 x X_S; X_S replaced by the first X half of the next k-tile  (split operands: lo . lo when S = 1 -- skipped)
     if (wr == 1) { stage(db, 2 + S); wait_load(); }
+    constexpr bool skip3 = S == 1 && SPLIT, skip4 = F == 1 && SPLIT;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      mma32(acc[2][S], aF[0][ks], bS[S][ks]);
-      mma32(acc[3][S], aF[1][ks], bS[S][ks]);
+      if constexpr (!skip3) {
+        mma32(acc[2][S], aF[0][ks], bS[S][ks]);
+        mma32(acc[3][S], aF[1][ks], bS[S][ks]);
+      }
       bS[S][ks] = lds_b(db ^ 1, S, ks);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -1608,7 +1629,7 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(GemmTN p) {
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
       for (int i2 = 0; i2 < 2; ++i2) {
-        mma32(acc[2 + i2][F], aF[i2][ks], bS[F][ks]);
+        if constexpr (!skip4) mma32(acc[2 + i2][F], aF[i2][ks], bS[F][ks]);
         aF[i2][ks] = lds_a(db ^ 1, 0, i2, ks);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -1627,11 +1648,15 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(GemmTN p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       int k = k0 + wc * 64 + j * 32 + (lane & 31);
-      if (p.split) k = ((k >> 7) << 6) | (k & 63);
+      if constexpr (SPLIT) {                              // X's dealt 32-column blocks (see the staging): back to the physical, then the logical column
+        if (i >= 2 && j == 1) continue;                   // the skipped lo . lo quadrant
+        k = k0 + (wc >> 1) * 128 + j * 64 + (wc & 1) * 32 + (lane & 31);
+        k = ((k >> 7) << 6) | (k & 63);
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         int n = n0 + wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (p.split) n = ((n >> 7) << 6) | (n & 63);
+        if constexpr (SPLIT) n = ((n >> 7) << 6) | (n & 63);
         if (n < p.n_valid && k < p.k_valid) {
           if (p.part != nullptr) p.part[(long)chunk * p.part_stride + (long)n * p.part_ld + k] = acc[i][j][r];
           else atomicAdd(p.dW + (long)n * p.ldw + k, acc[i][j][r]);
@@ -1716,11 +1741,13 @@ static int wgrad_launch(const void* Z, long ldz, const void* X, long ldx, float*
   if (pl.use8) {
     static bool attr_set = false;
     if (!attr_set) {
-      hipFuncSetAttribute((const void*)gemm_tn8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 64 * 256);
+      hipFuncSetAttribute((const void*)gemm_tn8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 64 * 256);
+      hipFuncSetAttribute((const void*)gemm_tn8_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 64 * 256);
       attr_set = true;
     }
     const int t8 = (N / 256) * ((K + 255) / 256);
-    hipLaunchKernelGGL(gemm_tn8_kernel, dim3(t8 * pl.slices), dim3(512), 8 * 64 * 256, (hipStream_t)stream, p);
+    if (split) hipLaunchKernelGGL(gemm_tn8_kernel<true>, dim3(t8 * pl.slices), dim3(512), 8 * 64 * 256, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(gemm_tn8_kernel<false>, dim3(t8 * pl.slices), dim3(512), 8 * 64 * 256, (hipStream_t)stream, p);
   } else {
     const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
     p.tiles = tiles;
