@@ -378,8 +378,9 @@ int snerf_fmlp_classic_pts_fwd(const float* pts, const float* viewdirs, long ldv
  * stores what the backward pass reads -- the bf16 outputs of the hidden layers and the ReLU bit masks of the 256-wide ones.
  * acts / act_ld: HOST arrays of device pointers / row strides (elements) -- classic: 10 = pts_linears.0 .. .7 (256 wide),
  * feature_linear (256), views_linears.0 (128); proposal: 4 = layers.0 .. .3 (256 wide).  Pointers 16-byte aligned, strides multiples
- * of 8.  bits: HOST array of 8 (classic: pts_linears.i) / 4 (proposal) device pointers to 4 * 8 * ceil(M / 256) * 4 * 64 bytes each,
- * written in the layout snerf_linear_fwd's act = 4 (mask bits) reads.  The per-layer snerf_linear_fwd (data gradient) /
+ * of 8.  bits: HOST array of 9 (classic: pts_linears.0 .. .7, then views_linears.0) / 4 (proposal) device pointers to
+ * 4 * 8 * ceil(M / 256) * 4 * 64 bytes each (views_linears.0: half that), written in the layout snerf_linear_fwd's act = 4 (mask
+ * bits) reads.  The per-layer snerf_linear_fwd (data gradient) /
  * snerf_linear_wgrad consume all of it unchanged. */
 int snerf_fmlp_classic_train_fwd(const void* E, long ldE, const void* VE, long ldVE, const void* wstream, long n_frags,
                                  const float* bias, int n_blocks, float* raw, void* const* acts, const long* act_ld,
@@ -406,6 +407,19 @@ int snerf_fcolour_fwd(const void* CB, long ldCB, const void* wstream, long n_fra
 long snerf_fcolour_bwd_ws_floats(long M);
 int snerf_fcolour_bwd(const float* d_raw_rgb, const void* wstream, long n_frags, void* const* bits, void* const* dC, const long* dC_ld,
                       void* dB, long dB_ld, float* const* g_bias, float* ws, long ws_floats, long M, void* stream);
+
+/* Data-gradient chains of the two 256-wide networks, fused (autograd of NeRF.forward, run_nerf_helpers.py:83-139, and of the mip
+ * path's proposal MLP, s-nerf/model/models.py:237-262): d raw -> d pre-activation of every layer in ONE launch; replaces ten
+ * (classic) / four (proposal) snerf_linear_fwd data-gradient launches.  Every step's output is stored for snerf_linear_wgrad.
+ * net 0 (classic): d_raw [M,4] fp32 (d rgb, d alpha); dz[0] = d views_linears.0 ([M, >= 128] bf16), dz[1] = d feature_linear output
+ *   ([M, >= 256]), dz[2..9] = d pts_linears.7 .. .0; bits[0..7] = masks of pts_linears.0 .. .7, bits[8] = of views_linears.0;
+ *   wstream: 1104 fragments.  net 1 (proposal): d_raw [M] (d raw density); dz[0..3] = d layers.3 .. .0; bits[0..3] = masks of
+ *   layers.0 .. .3; wstream: 400 fragments.  wstream = snerf_amd.mlp.fmlp_pack of the transposed weights in chain order.
+ * The bias gradient of step i is ADDED to g_bias[i] (width of dz[i] floats); the partial sums meet in LDS atomics, so the result is
+ * NOT bit-reproducible run to run (the deterministic mode keeps the per-layer launches).  ws: snerf_fchain_bwd_ws_floats(net, M). */
+long snerf_fchain_bwd_ws_floats(int net, long M);
+int snerf_fchain_bwd(int net, const float* d_raw, const void* wstream, long n_frags, void* const* bits, void* const* dz, const long* dz_ld,
+                     float* const* g_bias, float* ws, long ws_floats, long M, void* stream);
 
 /* ---- deterministic mode ("deterministic mode for parity tests") ------------------------------------------
  * The weight gradient normally lands in dW by fp32 atomics from the M slices (order varies run to run).  snerf_linear_wgrad_det makes

@@ -57,7 +57,7 @@ struct FmlpArgs {
   const float* viewdirs; long ldvd; // ... and per-ray view directions [M / S, ldvd]
   int S;                            // samples per ray
   __bf16* act[12]; long act_ld[12]; // training forward: where the output of layer i is stored (bf16 [M, >= width], row stride act_ld)
-  unsigned* bits[8];                // ... and the ReLU bit masks of the 256-wide layers (layout of ACT_RELU_BITS in gemm.hip)
+  unsigned* bits[9];                // ... and the ReLU bit masks of the 256-wide layers (layout of ACT_RELU_BITS in gemm.hip); classic: [8] = views_linears.0 (128 wide)
   const char* wstream;              // n_chunks x 16 KiB of MFMA fragments in consumption order
   const float* bias;                // n_blocks x 32 floats in consumption order
   float* out;                       // classic: raw [M,4] = (rgb, sigma); proposal: raw density [M]
@@ -435,7 +435,8 @@ __global__ __launch_bounds__(64 * FM_WAVES, 2) void fmlp_kernel(FmlpArgs a) {   
       const float sigma = alpha[0];
       dense<FF, 65, 16, 8, false, STORE>(c, q, p, to(8));         // feature_linear (no activation)
       bf16x8 hv[8];
-      dense2<FV, 73, 16, 2, 4, true, STORE>(c, p, ve, hv, to(9)); // views_linears.0 on cat([feature, views])
+      const StoreTo to_hv{a.act[9], a.act_ld[9], a.bits[8], (long)tile * FM_TILE_ROWS + wave * 32, a.M, smem + FM_RING * FM_SLOT + FM_BIAS_MAX * 128 + wave * 4096, lane, 2};
+      dense2<FV, 73, 16, 2, 4, true, STORE, STORE>(c, p, ve, hv, to_hv); // views_linears.0 on cat([feature, views]) (masks: 2 column groups)
       f32x16 rgb = acc_init<77>(c);                     // rgb_linear: outputs 0..2
       mac<FR, 8>(c, rgb, hv);
       if (row_ok && half == 0) {
@@ -761,6 +762,292 @@ __global__ __launch_bounds__(64 * FM_WAVES, 2) void fcolour_bwd_kernel(ColourBwd
   }
 }
 
+// =================================================================================================================================
+// Fused DATA-GRADIENT CHAINS of the 256-wide networks (classic NeRF 8 x 256 of path B, proposal MLP 4 x 256 of path A): d raw -> ...
+// -> d pre-activation of every layer in ONE launch, the mirror image of fmlp_kernel -- "weights x activations" on the transposed
+// weights, the gradient of a layer being the next layer's B fragments as it leaves the accumulators.  Every layer's gradient is stored
+// (bf16, through the transposition slabs) for the weight-gradient GEMMs, its ReLU mask comes from the bit masks the training forward
+// wrote, its bias gradient is reduced over the wave's 32 rows by the register butterfly (rows_sum) and added to a workgroup-wide LDS
+// table (ds_add_f32: the order of the eight waves' additions is not fixed: the deterministic mode keeps the per-layer kernels).
+// As separate GEMM launches these layers ran at 0.18 of the MFMA peak (256 x 256 tiles, one activation row read per 256 outputs).
+// Everything a tile reads arrives by LDS-DMA (no vector-memory load the compiler tracks: see fcolour_bwd_kernel): the bit masks of
+// the masked steps alternate between two 1 KiB buffers per wave, each fetched one step ahead; d raw and the first mask of the NEXT
+// tile are fetched while the current one runs.
+#define FCH_RING 5
+#define FCH_WAVE_BYTES 3072                      // per wave: two 1 KiB mask buffers + 1 KiB (narrow mask 512 B, d raw 512 B)
+struct ChainArgs {
+  const float* d_raw; int d_cols;                // [M, d_cols] fp32: classic (rgb, alpha) = 4, proposal = 1
+  const char* wstream;
+  const unsigned* bits[9];                       // classic: pts_linears.0..7, views_linears.0; proposal: layers.0..3
+  __bf16* dz[10]; long dz_ld[10];                // the steps' outputs, in chain order
+  float* colsum_ws;                              // [gridDim.x, n_cols]
+  long M;
+  int tiles, n_chunks, n_cols;
+};
+
+// ALTERNATIVE bias-gradient path (FCH_COLSUM_MFMA = 1; not shipped): after a pair of blocks sits in the wave's slab (32 rows x 64
+// columns, bf16, row-major), the transposing LDS read hands it back as MFMA B operands whose reduction index is the ROW, and A =
+// "ones in row g, zeros elsewhere" (g = the block's number modulo 32) adds its 32 column sums into row g of ONE accumulator shared by
+// 32 blocks, added to the workgroup's LDS table after every 32nd block.  Two reads and two MFMAs per block instead of the 47-
+// instruction register butterfly: 35 % fewer instructions (16 845 -> 10 957 per tile), and SLOWER -- classic chain, 6.3 M rows:
+// butterfly 10.65 ms, this 11.68 ms, with the four MFMAs deferred into the next block's MFMA run 11.85 ms, no bias gradient at all
+// 8.42 ms (gpurun_out/r3n, tools/fchain_probe.py).  The kernel is not instruction-bound: every MFMA already pulls its 1 KiB weight
+// fragment through the LDS (8 waves x 1100 fragments x 8 clocks = the MFMA time of a tile), and the extra transposing reads land on
+// that same port.
+typedef __attribute__((ext_vector_type(4))) __bf16 fm_bf16x4;
+struct ColsumCtx {
+  f32x16 acc;
+  fm_bf16x4 f[8];             // the pending pair's transposed fragments: issued at the pair's end, multiplied inside the NEXT block's MFMA run
+  unsigned a0, a1;            // LDS addresses of this lane's first transposing read: rows 0-3 / (chunk ^ 4) of the slab
+  unsigned tab;               // ... and of its entry (row 4 * half, column lane & 31) of the table
+  unsigned tab0;              // butterfly path: this lane's column of block 0 in the table (lanes with bit 4 clear: r = lane & 15)
+};
+__device__ __forceinline__ void colsum_start(ColsumCtx& k, const char* slab, const float* cs, int lane) {
+  const int g = lane >> 4, pl = lane & 15, prow = pl >> 2;
+  const int row = 8 * (g >> 1) + prow;                                   // (row & 7 == prow; rows + 4: the chunk swizzle flips bit 2)
+  const int c = 2 * (g & 1) + ((pl & 3) >> 1);
+  k.a0 = (unsigned)(size_t)(slab + row * 128 + ((c ^ prow) << 4) + ((pl & 1) << 3));
+  k.a1 = k.a0 ^ 64u;
+  k.tab = (unsigned)(size_t)(cs + 32 * 4 * (lane >> 5) + (lane & 31));
+  k.tab0 = (unsigned)(size_t)(cs + ((lane & 15) & 3) + 8 * ((lane & 15) >> 2) + 4 * (lane >> 5));
+#pragma unroll
+  for (int r = 0; r < 16; ++r) k.acc[r] = 0.f;
+}
+// the pair just written to the slab: (ks, t) = (0, 0), (0, 1), (1, 0), (1, 1) -- rows 16 ks .. + 15 of block t; first read of each:
+// rows + 0..3 of the lane's 8-row half, second: rows + 4..7 (chunk swizzle bit 2 flipped).  No wait here: colsum_wait comes much later.
+__device__ __forceinline__ void colsum_issue(ColsumCtx& k) {
+  asm volatile("ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %9 offset:512\n\t"
+               "ds_read_b64_tr_b16 %2, %9\n\tds_read_b64_tr_b16 %3, %8 offset:512\n\t"
+               "ds_read_b64_tr_b16 %4, %8 offset:2048\n\tds_read_b64_tr_b16 %5, %9 offset:2560\n\t"
+               "ds_read_b64_tr_b16 %6, %9 offset:2048\n\tds_read_b64_tr_b16 %7, %8 offset:2560"
+               : "=&v"(k.f[0]), "=&v"(k.f[1]), "=&v"(k.f[2]), "=&v"(k.f[3]), "=&v"(k.f[4]), "=&v"(k.f[5]), "=&v"(k.f[6]), "=&v"(k.f[7])
+               : "v"(k.a0), "v"(k.a1) : "memory");
+}
+__device__ __forceinline__ void colsum_wait(ColsumCtx& k) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(k.f[0]), "+v"(k.f[1]), "+v"(k.f[2]), "+v"(k.f[3]), "+v"(k.f[4]), "+v"(k.f[5]), "+v"(k.f[6]), "+v"(k.f[7])::"memory");
+}
+// MFMA I (0..3) of the pending pair whose second block is number G
+template <int G, int I>
+__device__ __forceinline__ void colsum_mfma(ColsumCtx& k, int lane) {
+  int row = lane & 31;
+  asm volatile("" : "+v"(row));                   // (opaque: or the compiler keeps the selectors of blocks G and G + 32 alive in between and spills)
+  const unsigned o = row == ((G - 1 + (I & 1)) & 31) ? 0x3F803F80u : 0u;
+  const bf16x8 one = __builtin_bit_cast(bf16x8, fm_u32x4{o, o, o, o});
+  k.acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(one, __builtin_shufflevector(k.f[2 * I], k.f[2 * I + 1], 0, 1, 2, 3, 4, 5, 6, 7), k.acc, 0, 0, 0);
+}
+// acc += W-block . in with the pending pair's four column-sum MFMAs spread over the run (independent accumulators: no stall)
+template <int F, int NK, int PG, typename C, int... I>
+__device__ __forceinline__ void mac_colsum_seq(C& c, f32x16& acc, const bf16x8 (&in)[NK], ColsumCtx& k, int lane, std::integer_sequence<int, I...>) {
+  constexpr int Q = NK >= 4 ? NK / 4 : 1;
+  (((acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(next_frag<F + I>(c), in[I], acc, 0, 0, 0)),
+    ((I % Q == Q - 1 && I / Q == 0) ? colsum_wait(k) : (void)0),
+    ((I % Q == Q - 1 && I / Q == 0) ? colsum_mfma<PG, 0>(k, lane) : (void)0), ((I % Q == Q - 1 && I / Q == 1) ? colsum_mfma<PG, 1>(k, lane) : (void)0),
+    ((I % Q == Q - 1 && I / Q == 2) ? colsum_mfma<PG, 2>(k, lane) : (void)0), ((I % Q == Q - 1 && I / Q == 3) ? colsum_mfma<PG, 3>(k, lane) : (void)0)), ...);
+}
+// table[32 (G0 + m) + n] += acc[m][n], m = (r & 3) + 8 (r >> 2) + 4 half: by hand (an LDS atomic the compiler emits itself waits for
+// vmcnt(0) while an LDS-DMA is in flight -- it may alias -- and the weight stream always has some in flight; the table is disjoint
+// from every DMA target.  Completion: lgkmcnt(0) at the tile's end)
+template <int G0>
+__device__ __forceinline__ void colsum_flush(ColsumCtx& k) {
+#define FCH_FLUSH1(R) asm volatile("ds_add_f32 %0, %1 offset:%2" ::"v"(k.tab), "v"(k.acc[R]), "n"((32 * G0 + 32 * (((R) & 3) + 8 * ((R) >> 2))) * 4) : "memory");
+  FCH_FLUSH1(0) FCH_FLUSH1(1) FCH_FLUSH1(2) FCH_FLUSH1(3) FCH_FLUSH1(4) FCH_FLUSH1(5) FCH_FLUSH1(6) FCH_FLUSH1(7)
+  FCH_FLUSH1(8) FCH_FLUSH1(9) FCH_FLUSH1(10) FCH_FLUSH1(11) FCH_FLUSH1(12) FCH_FLUSH1(13) FCH_FLUSH1(14) FCH_FLUSH1(15)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) k.acc[r] = 0.f;
+}
+
+// one 32-output block of a chain step: acc = W^T-block . [in | extra], optional ReLU mask from `mk`, bf16 fragments, store through
+// the slab, bias-gradient partial (pairs of blocks); G = the block's number in the chain, LAST: the chain's last block
+#ifndef FCH_SKIP
+#define FCH_SKIP 0                // (probe builds: 1 no bias gradients, 2 no masks)
+#endif
+#ifndef FCH_COLSUM_MFMA
+#define FCH_COLSUM_MFMA 0
+#endif
+template <int F, int NK, bool EXTRA, bool MASKED, int J, int G, bool LAST, typename C>
+__device__ __forceinline__ void chain_block(C& c, const bf16x8 (&in)[NK], const bf16x8& extra, const char* mk, int lane, int sh, bool row_ok,
+                                            ColsumCtx& k, bf16x8& lo, bf16x8& hi, const StoreTo& st) {
+  fm_u32x4 w = {0u, 0u, 0u, 0u};
+  if constexpr (MASKED) w = *(const fm_u32x4*)(mk + ((J >> 1) * 64 + (lane & 7) * 8 + 4 * (J & 1)) * 4);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  constexpr bool PENDING = FCH_COLSUM_MFMA && (J & 1) == 0 && G > 0 && !(FCH_SKIP & 1);       // the previous pair's column sums ride along
+  if constexpr (PENDING) {
+    if constexpr (NK >= 4) {
+      mac_colsum_seq<F, NK, G - 1>(c, acc, in, k, lane, std::make_integer_sequence<int, NK>{});
+    } else {                                      // (the one-k-step head layers)
+      mac<F, NK>(c, acc, in);
+      colsum_wait(k);
+      colsum_mfma<G - 1, 0>(k, lane); colsum_mfma<G - 1, 1>(k, lane); colsum_mfma<G - 1, 2>(k, lane); colsum_mfma<G - 1, 3>(k, lane);
+    }
+    if constexpr (((G - 1) & 31) == 31) colsum_flush<((G - 1) & ~31)>(k);
+  } else {
+    mac<F, NK>(c, acc, in);
+  }
+  if constexpr (EXTRA) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(next_frag<F + NK>(c), extra, acc, 0, 0, 0);
+#define FCH_MASK1(R, NQ, E) { const float v = acc[R]; acc[R] = __builtin_bit_cast(float, __builtin_bit_cast(int, v) & __builtin_amdgcn_sbfe(NQ, E, 1)); }
+#define FCH_MASK4(Q) { const unsigned wq = w[Q]; const int nq = MASKED ? (row_ok ? (int)(wq >> sh) : 0) : (row_ok ? -1 : 0); \
+                       FCH_MASK1(4 * Q + 0, nq, MASKED ? 0 : 0) FCH_MASK1(4 * Q + 1, nq, MASKED ? 1 : 0) FCH_MASK1(4 * Q + 2, nq, MASKED ? 2 : 0) FCH_MASK1(4 * Q + 3, nq, MASKED ? 3 : 0) }
+  if (!(FCH_SKIP & 2)) { FCH_MASK4(0) FCH_MASK4(1) FCH_MASK4(2) FCH_MASK4(3) }
+  if constexpr (!FCH_COLSUM_MFMA && !(FCH_SKIP & 1)) {
+    // register butterfly over the wave's 32 rows, then one LDS atomic per column into the workgroup's table -- by hand: an LDS atomic
+    // the compiler emits itself waits for vmcnt(0) while an LDS-DMA is in flight (it may alias) and the weight stream always has some
+    // in flight; the table is disjoint from every DMA target.  Completion: lgkmcnt(0) at the tile's end
+    const float rs = rows_sum(acc, lane);
+    if ((lane & 16) == 0) {
+      asm volatile("ds_add_f32 %0, %1 offset:%2" ::"v"(k.tab0), "v"(rs), "n"(32 * G * 4) : "memory");
+    }
+  }
+  to_frags<false>(acc, lo, hi);
+  store_block<false, J>(st, lo, hi);
+  if constexpr (FCH_COLSUM_MFMA && (J & 1) == 1 && !(FCH_SKIP & 1)) {
+    static_assert((G & 1) == 1, "pairs of blocks start on even block numbers");
+    colsum_issue(k);
+    if constexpr (LAST) {                         // nothing follows inside this tile
+      colsum_wait(k);
+      colsum_mfma<G, 0>(k, lane); colsum_mfma<G, 1>(k, lane); colsum_mfma<G, 2>(k, lane); colsum_mfma<G, 3>(k, lane);
+      colsum_flush<(G & ~31)>(k);
+    }
+  }
+}
+template <int F, int NK, bool EXTRA, bool MASKED, int NB, int G0, bool LAST, typename C, int... J>
+__device__ __forceinline__ void chain_step_seq(C& c, const bf16x8 (&in)[NK], const bf16x8& extra, const char* mk, int lane, int sh, bool row_ok,
+                                               ColsumCtx& k, bf16x8 (&out)[2 * NB], const StoreTo& st, std::integer_sequence<int, J...>) {
+  (chain_block<F + J * (NK + (EXTRA ? 1 : 0)), NK, EXTRA, MASKED, J, G0 + J, (LAST && J == NB - 1)>(c, in, extra, mk, lane, sh, row_ok, k, out[2 * J], out[2 * J + 1], st), ...);
+}
+// G0 = number of the step's first block in the chain (its bias gradients: columns 32 G0 .. of the table)
+template <int F, int NK, bool EXTRA, bool MASKED, int NB, int G0, bool LAST = false, typename C>
+__device__ __forceinline__ void chain_step(C& c, const bf16x8 (&in)[NK], const bf16x8& extra, const char* mk, int lane, int sh, bool row_ok,
+                                           ColsumCtx& k, bf16x8 (&out)[2 * NB], const StoreTo& st) {
+  chain_step_seq<F, NK, EXTRA, MASKED, NB, G0, LAST>(c, in, extra, mk, lane, sh, row_ok, k, out, st, std::make_integer_sequence<int, NB>{});
+}
+
+#define FCH_CLASSIC_FRAGS 1104                   // 4 + 64 + 8 x 17 + 7 x 128 = 1100, padded to whole chunks
+#define FCH_CLASSIC_COLS (128 + 256 + 8 * 256)   // bias gradients: views_linears.0, feature_linear, pts_linears.7 .. .0
+#define FCH_TAB(NCOLS) (((NCOLS) + 1023) / 1024 * 1024)      // the LDS table: whole groups of 32 blocks
+#define FCH_PROPOSAL_FRAGS 400                   // 8 + 3 x 128 = 392, padded
+#define FCH_PROPOSAL_COLS (4 * 256)              // layers.3 .. .0
+
+template <int NET>
+__global__ __launch_bounds__(64 * FM_WAVES, 2) void fchain_bwd_kernel(ChainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5;
+  char* const slab = smem + FCH_RING * FM_SLOT + wave * 4096;
+  char* const mk = smem + FCH_RING * FM_SLOT + FM_WAVES * 4096 + wave * FCH_WAVE_BYTES;      // [mask A 1 KiB][mask B 1 KiB][narrow mask 512][d raw 512]
+  float* const cs = (float*)(smem + FCH_RING * FM_SLOT + FM_WAVES * 4096 + FM_WAVES * FCH_WAVE_BYTES);
+  constexpr int NCOLS = NET == FMLP_CLASSIC ? FCH_CLASSIC_COLS : FCH_PROPOSAL_COLS;
+  constexpr int DC = NET == FMLP_CLASSIC ? 4 : 1;             // columns of d raw
+  const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)a.d_raw, 0, (int)(a.M * DC * 4), 0x00020000);   // rows >= M read as zeros
+  // the 256-wide layer l's masks of the wave's 32 rows: 4 column groups x 256 B, contiguous; one DMA (64 lanes x 16 B)
+  auto dma_mask = [&](int l, int buf, long row0, int lane) __attribute__((always_inline)) {
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)((const char*)(a.bits[l] + (row0 >> 5) * (4 * 64)) + lane * 16), (lds_ptr_t)(mk + buf * 1024), 16, 0, 0);
+  };
+  // d raw of the wave's 32 rows (+ classic: the 128-wide views layer's masks, 2 column groups = 512 B)
+  auto dma_small = [&](long row0, int lane) __attribute__((always_inline)) {
+    if (NET == FMLP_CLASSIC && lane < 32)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)((const char*)(a.bits[8] + (row0 >> 5) * (2 * 64)) + lane * 16), (lds_ptr_t)(mk + 2048), 16, 0, 0);
+    if (lane < 8 * DC) __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_ptr_t)(mk + 2560), 16, lane * 16, (int)(row0 * DC * 4), 0, 0);
+  };
+  {
+    const long row0 = (long)blockIdx.x * FM_TILE_ROWS + wave * 32;    // (the launch has gridDim.x <= tiles)
+    dma_small(row0, lane);
+    if (NET == FMLP_PROPOSAL) dma_mask(3, 0, row0, lane);
+    for (int i = tid; i < FCH_TAB(NCOLS); i += 64 * FM_WAVES) cs[i] = 0.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  ColsumCtx k;
+  colsum_start(k, slab, cs, lane);
+  CtxT<FCH_RING> c;
+  ctx_start(c, smem, a.wstream, a.n_chunks, nullptr, 0, tid, wave, lane);        // (ends with a barrier: the zeroed table is visible)
+  const int sh = 8 * ((lane & 31) >> 3) + 4 * half;     // this lane's nibble inside a mask word
+
+  for (int tile = blockIdx.x; tile < a.tiles; tile += gridDim.x) {
+    const long row0 = (long)tile * FM_TILE_ROWS + wave * 32;
+    const bool row_ok = row0 + (lane & 31) < a.M;
+    const bool more = tile + (int)gridDim.x < a.tiles;
+    const long next0 = row0 + (long)gridDim.x * FM_TILE_ROWS;
+    int zero;                                            // (addresses from a loop-variant lane id: see fcolour_bwd_kernel)
+    asm volatile("s_lshr_b32 %0, %1, 31" : "=s"(zero) : "s"(tile));
+    const int ln = lane | zero;
+    auto to = [&](int i, int ncg) { return StoreTo{a.dz[i], a.dz_ld[i], nullptr, row0, a.M, slab, ln, ncg}; };
+    typedef __attribute__((ext_vector_type(8))) float f32x8;
+    const bf16x8 none = {};
+    bf16x8 p[16], q[16];
+    // "at most eight outstanding": the mask fetched one step ago has landed (a step of >= 64 fragments issues >= 8 younger DMA
+    // pieces at its chunk boundaries; stores in flight only make the wait stricter)
+#define FCH_WAIT() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
+    FCH_WAIT();                                          // what the previous tile fetched for this one (first tile: waited for above)
+    if constexpr (NET == FMLP_CLASSIC) {
+      const f32x4 dr = *(const f32x4*)(mk + 2560 + (ln & 31) * 16);
+      const f32x8 v0 = {half == 0 ? dr[0] : 0.f, half == 0 ? dr[1] : 0.f, half == 0 ? dr[2] : 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      const f32x8 v1 = {half == 0 ? dr[3] : 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      bf16x8 g[1] = {__builtin_convertvector(v0, bf16x8)};
+      const bf16x8 ga = __builtin_convertvector(v1, bf16x8);
+      bf16x8 hv[8];
+      chain_step<0, 1, false, true, 4, 0>(c, g, none, mk + 2048, ln, sh, row_ok, k, hv, to(0, 2));                       // d views_linears.0 (masked by its output)
+      dma_mask(7, 0, row0, ln);                                                                                      // -> A: pts_linears.7's masks
+      chain_step<4, 8, false, false, 8, 4>(c, hv, none, nullptr, ln, sh, row_ok, k, p, to(1, 4));                 // d feature_linear (no activation)
+      FCH_WAIT();
+      dma_mask(6, 1, row0, ln);
+      if (more) dma_small(next0, ln);                    // d raw and the views masks of the next tile (this tile's are consumed)
+      chain_step<68, 16, true, true, 8, 12>(c, p, ga, mk, ln, sh, row_ok, k, q, to(2, 4));                        // d pts_linears.7 = mask . ([W_f | w_a]^T [dF; da])
+      FCH_WAIT(); dma_mask(5, 0, row0, ln);
+      chain_step<204, 16, false, true, 8, 20>(c, q, none, mk + 1024, ln, sh, row_ok, k, p, to(3, 4));             // .6
+      FCH_WAIT(); dma_mask(4, 1, row0, ln);
+      chain_step<332, 16, false, true, 8, 28>(c, p, none, mk, ln, sh, row_ok, k, q, to(4, 4));                    // .5
+      FCH_WAIT(); dma_mask(3, 0, row0, ln);
+      chain_step<460, 16, false, true, 8, 36>(c, q, none, mk + 1024, ln, sh, row_ok, k, p, to(5, 4));            // .4
+      FCH_WAIT(); dma_mask(2, 1, row0, ln);
+      chain_step<588, 16, false, true, 8, 44>(c, p, none, mk, ln, sh, row_ok, k, q, to(6, 4));                   // .3
+      FCH_WAIT(); dma_mask(1, 0, row0, ln);
+      chain_step<716, 16, false, true, 8, 52>(c, q, none, mk + 1024, ln, sh, row_ok, k, p, to(7, 4));            // .2
+      FCH_WAIT(); dma_mask(0, 1, row0, ln);
+      chain_step<844, 16, false, true, 8, 60>(c, p, none, mk, ln, sh, row_ok, k, q, to(8, 4));                   // .1
+      FCH_WAIT();
+      chain_step<972, 16, false, true, 8, 68, true>(c, q, none, mk + 1024, ln, sh, row_ok, k, p, to(9, 4));            // .0
+      skip_frags<1100, 4>(c, std::make_integer_sequence<int, 4>{});
+      static_assert(1100 + 4 == FCH_CLASSIC_FRAGS, "classic chain: fragment count");
+    } else {
+      const float dr = *(const float*)(mk + 2560 + (ln & 31) * 4);
+      const f32x8 v0 = {half == 0 ? dr : 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      bf16x8 g[1] = {__builtin_convertvector(v0, bf16x8)};
+      dma_mask(2, 1, row0, ln);                          // -> B: layers.2's masks (A holds layers.3's, fetched during the previous tile)
+      chain_step<0, 1, false, true, 8, 0>(c, g, none, mk, ln, sh, row_ok, k, p, to(0, 4));                              // d layers.3
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the first step is 8 fragments long: too short for the counted wait)
+      dma_mask(1, 0, row0, ln);
+      if (more) dma_small(next0, ln);
+      chain_step<8, 16, false, true, 8, 8>(c, p, none, mk + 1024, ln, sh, row_ok, k, q, to(1, 4));                // .2
+      FCH_WAIT(); dma_mask(0, 1, row0, ln);
+      chain_step<136, 16, false, true, 8, 16>(c, q, none, mk, ln, sh, row_ok, k, p, to(2, 4));                     // .1
+      FCH_WAIT();
+      if (more) dma_mask(3, 0, next0, ln);               // A is free: the next tile's first masks
+      chain_step<264, 16, false, true, 8, 24, true>(c, p, none, mk + 1024, ln, sh, row_ok, k, q, to(3, 4));              // .0
+      skip_frags<392, 8>(c, std::make_integer_sequence<int, 8>{});
+      static_assert(392 + 8 == FCH_PROPOSAL_FRAGS, "proposal chain: fragment count");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int i = tid; i < NCOLS; i += 64 * FM_WAVES) a.colsum_ws[(long)blockIdx.x * NCOLS + i] = cs[i];
+}
+
+// out[c] += sum over the workgroups' partial rows (fixed order)
+struct ChainFoldTab { float* dst[10]; int first[10]; };
+__global__ __launch_bounds__(256) void fchain_colsum_fold_kernel(const float* __restrict__ ws, int rows, int ncols, ChainFoldTab tab) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= ncols) return;
+  float s = 0.f;
+  for (int r = 0; r < rows; ++r) s += ws[(long)r * ncols + col];
+  int t = 0;
+#pragma unroll
+  for (int i = 1; i < 10; ++i) t += tab.first[i] <= col ? 1 : 0;
+  tab.dst[t][col - tab.first[t]] += s;
+}
+
 // bias gradients += the per-workgroup partials, summed in a fixed order (bit-reproducible): 64 columns x 4 row groups per workgroup
 __global__ __launch_bounds__(256) void fcolour_colsum_fold_kernel(const float* __restrict__ ws, int rows, float* g2, float* g1, float* g0, float* gb) {
   __shared__ float part[4][64];
@@ -811,9 +1098,9 @@ extern "C" int snerf_fmlp_classic_fwd(const void* E, long ldE, const void* VE, l
 
 // Training forward of the same network: additionally stores the outputs of the ten hidden layers for the backward pass --
 // acts[i] / act_ld[i] (HOST arrays of 10 device pointers / row strides in elements): pts_linears.0 .. .7 (256 wide), feature_linear
-// (256), views_linears.0 (128); every pointer 16-byte aligned, every stride a multiple of 8 -- and bits[i] (HOST array of 8 device
-// pointers, 4 * 8 * ceil(M / 256) * 4 * 64 bytes each): the ReLU bit masks of pts_linears.i in the layout snerf_linear_fwd's
-// ACT_MASK_BITS reads.
+// (256), views_linears.0 (128); every pointer 16-byte aligned, every stride a multiple of 8 -- and bits[i] (HOST array of 9 device
+// pointers): the ReLU bit masks of pts_linears.i (i < 8: 4 * 8 * ceil(M / 256) * 4 * 64 bytes each) and of views_linears.0 (i = 8:
+// half that) in the layout snerf_linear_fwd's ACT_MASK_BITS reads.
 extern "C" int snerf_fmlp_classic_train_fwd(const void* E, long ldE, const void* VE, long ldVE, const void* wstream, long n_frags,
                                             const float* bias, int n_blocks, float* raw, void* const* acts, const long* act_ld,
                                             void* const* bits, long M, void* stream) {
@@ -826,8 +1113,8 @@ extern "C" int snerf_fmlp_classic_train_fwd(const void* E, long ldE, const void*
   for (int i = 0; i < 10; ++i) {
     if (acts[i] == nullptr || (((uintptr_t)acts[i]) & 15) || (act_ld[i] % 8) != 0) return SNERF_ERR_ARG;
     a.act[i] = (__bf16*)acts[i]; a.act_ld[i] = act_ld[i];
-    if (i < 8) {
-      if (bits[i] == nullptr) return SNERF_ERR_ARG;
+    if (i < 9) {
+      if (bits[i] == nullptr || (((uintptr_t)bits[i]) & 15)) return SNERF_ERR_ARG;
       a.bits[i] = (unsigned*)bits[i];
     }
   }
@@ -966,5 +1253,64 @@ extern "C" int snerf_fcolour_bwd(const float* d_raw_rgb, const void* wstream, lo
   hipLaunchKernelGGL(fcolour_bwd_kernel, dim3(grid), dim3(64 * FM_WAVES), lds, (hipStream_t)stream, a);
   hipLaunchKernelGGL(fcolour_colsum_fold_kernel, dim3(FC_BWD_COLS / 64), dim3(256), 0, (hipStream_t)stream, ws, grid, g_bias[0], g_bias[1],
                      g_bias[2], g_bias[3]);
+  return snerf_check_launch();
+}
+
+// ---- fused data-gradient chains of the 256-wide networks --------------------------------------------------------------------------
+#define FCH_LDS(NCOLS) (FCH_RING * FM_SLOT + FM_WAVES * 4096 + FM_WAVES * FCH_WAVE_BYTES + FCH_TAB(NCOLS) * 4)
+extern "C" long snerf_fchain_bwd_ws_floats(int net, long M) {
+  if (M <= 0 || (net != FMLP_CLASSIC && net != FMLP_PROPOSAL)) return 0;
+  const int ncols = net == FMLP_CLASSIC ? FCH_CLASSIC_COLS : FCH_PROPOSAL_COLS;
+  return (long)fcolour_grid((int)((M + FM_TILE_ROWS - 1) / FM_TILE_ROWS)) * ncols + 64;       // + the fold's two small tables
+}
+
+// net 0 (classic NeRF, run_nerf_helpers.py:83-139): d_raw [M,4] fp32 (d rgb, d alpha) -> dz[0] = d pre-activation of views_linears.0
+// ([M, >= 128] bf16), dz[1] = d feature_linear output ([M, >= 256]), dz[2..9] = d pre-activation of pts_linears.7 .. .0; bits[0..7] =
+// the ReLU bit masks of pts_linears.0 .. .7, bits[8] = of views_linears.0 (snerf_fmlp_classic_train_fwd wrote them); n_steps = 10.
+// net 1 (proposal MLP of the mip path, s-nerf/model/models.py:237-262 with the proposal widths): d_raw [M,1] (d raw density) -> dz[0..3]
+// = d pre-activation of layers.3 .. .0; bits[0..3] of layers.0 .. .3; n_steps = 4.
+// wstream: mlp.fmlp_pack of the transposed weights in chain order.  The bias gradient of step i is ADDED to g_bias[i] (the workgroups'
+// partial sums are reduced in LDS in arrival order: NOT bit-reproducible -- the deterministic mode uses the per-layer kernels).
+extern "C" int snerf_fchain_bwd(int net, const float* d_raw, const void* wstream, long n_frags, void* const* bits, void* const* dz, const long* dz_ld,
+                                float* const* g_bias, float* ws, long ws_floats, long M, void* stream) {
+  if (M <= 0) return SNERF_OK;
+  if (net != FMLP_CLASSIC && net != FMLP_PROPOSAL) return SNERF_ERR_ARG;
+  const bool classic = net == FMLP_CLASSIC;
+  const int n_steps = classic ? 10 : 4, n_bits = classic ? 9 : 4, ncols = classic ? FCH_CLASSIC_COLS : FCH_PROPOSAL_COLS, dc = classic ? 4 : 1;
+  if (d_raw == nullptr || wstream == nullptr || bits == nullptr || dz == nullptr || dz_ld == nullptr || g_bias == nullptr || ws == nullptr ||
+      n_frags != (classic ? FCH_CLASSIC_FRAGS : FCH_PROPOSAL_FRAGS) || (((uintptr_t)wstream) & 15) || (((uintptr_t)d_raw) & 15) ||
+      ws_floats < snerf_fchain_bwd_ws_floats(net, M) || M * dc * 4 >= (1L << 31))
+    return SNERF_ERR_ARG;
+  ChainArgs a{};
+  a.d_raw = d_raw; a.d_cols = dc; a.wstream = (const char*)wstream; a.colsum_ws = ws; a.M = M; a.n_cols = ncols;
+  a.tiles = (int)((M + FM_TILE_ROWS - 1) / FM_TILE_ROWS); a.n_chunks = (int)(n_frags / FM_CHUNK);
+  for (int i = 0; i < n_bits; ++i) {
+    if (bits[i] == nullptr || (((uintptr_t)bits[i]) & 15)) return SNERF_ERR_ARG;
+    a.bits[i] = (const unsigned*)bits[i];
+  }
+  ChainFoldTab tab{};
+  int col = 0;
+  for (int i = 0; i < 10; ++i) {
+    if (i < n_steps) {
+      const int width = (classic && i == 0) ? 128 : 256;
+      if (dz[i] == nullptr || (((uintptr_t)dz[i]) & 15) || (dz_ld[i] % 8) != 0 || dz_ld[i] < width || g_bias[i] == nullptr) return SNERF_ERR_ARG;
+      a.dz[i] = (__bf16*)dz[i]; a.dz_ld[i] = dz_ld[i];
+      tab.dst[i] = g_bias[i]; tab.first[i] = col; col += width;
+    } else {
+      tab.dst[i] = nullptr; tab.first[i] = 1 << 30;
+    }
+  }
+  const int grid = fcolour_grid(a.tiles);
+  const int lds = FCH_LDS(ncols);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)fchain_bwd_kernel<FMLP_CLASSIC>, hipFuncAttributeMaxDynamicSharedMemorySize, FCH_LDS(FCH_CLASSIC_COLS));
+    (void)hipFuncSetAttribute((const void*)fchain_bwd_kernel<FMLP_PROPOSAL>, hipFuncAttributeMaxDynamicSharedMemorySize, FCH_LDS(FCH_PROPOSAL_COLS));
+    attr_set = true;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (classic) hipLaunchKernelGGL(fchain_bwd_kernel<FMLP_CLASSIC>, dim3(grid), dim3(64 * FM_WAVES), lds, st, a);
+  else hipLaunchKernelGGL(fchain_bwd_kernel<FMLP_PROPOSAL>, dim3(grid), dim3(64 * FM_WAVES), lds, st, a);
+  hipLaunchKernelGGL(fchain_colsum_fold_kernel, dim3((ncols + 255) / 256), dim3(256), 0, st, (const float*)ws, grid, ncols, tab);
   return snerf_check_launch();
 }

@@ -471,6 +471,30 @@ class ClassicNeRFNet(_Net):
                 self._refresh_fused(self._pack_fused)
             self._fused_version = v
 
+    def chain_ok(self):
+        """the data-gradient chain as ONE launch (csrc/fmlp.hip fchain_bwd_kernel); its bias gradients meet in LDS atomics, so the
+        deterministic mode keeps the per-layer kernels"""
+        return self.fused_ok() and getattr(self, "fused_chain", True) and not self.deterministic
+
+    def _pack_chain(self):
+        """transposed weights in the order the data-gradient chain consumes them (no biases)"""
+        W, ic = self.Wd, self.ic
+        L = [(self.W("rgb_linear").t(), None, [(0, 3, False)]),                                      # d rgb -> d views_linears.0
+             (self.W("views_linears.0")[:, :W].t(), None, [(0, W // 2, True)]),                      # -> d feature (the view columns: no gradient)
+             (torch.cat([self.W("feature_linear").t(), self.W("alpha_linear").t()], 1), None, [(0, W, True), (W, 1, False)])]   # [d feature | d alpha] -> d pts_linears.7
+        for i in range(self.D - 1, 0, -1):
+            Wi = self.W(f"pts_linears.{i}")
+            L.append(((Wi[:, ic:] if i == self.skip + 1 else Wi).t(), None, [(0, W, True)]))         # d pts_linears.i -> d pts_linears.(i-1)
+        return fmlp_pack(L, self.dev)
+
+    def _chain_stream(self):
+        v = self.version_fn()
+        if getattr(self, "_chain_version", None) != v:
+            with torch.no_grad():
+                self._chain = self._refresh_fused(self._pack_chain, "chain")
+            self._chain_version = v
+        return self._chain[0]
+
     def forward_fused_train(self, pts, viewdirs, S):
         """Training forward: the exact embedding kernel + ONE fused kernel that also stores the hidden activations in the buffers the
         per-layer backward reads (same `saved` structure as the per-layer forward)."""
@@ -482,6 +506,7 @@ class ClassicNeRFNet(_Net):
         ys = [SK[:, Pw:] if i == self.skip else self.buf(M, W) for i in range(self.D)]
         HV, OUT = self.buf(M, W // 2), self.buf(M, 4, f32=True)
         words = [torch.empty(ops.mask_bits_words(M, W), dtype=torch.int32, device=self.dev) for _ in range(self.D)]
+        words.append(torch.empty(ops.mask_bits_words(M, W // 2), dtype=torch.int32, device=self.dev))     # views_linears.0
         ops.fmlp_classic_train_fwd(E, V[:, W:], self.fstream, self.fbias, OUT, ys + [V[:, :W], HV], words)
         for y, w in zip(ys, words):                                   # the data-gradient GEMMs take their ReLU masks from the bits
             self._bits[(y.data_ptr(), M)] = (w, W)
@@ -489,7 +514,7 @@ class ClassicNeRFNet(_Net):
         for i in range(self.D):
             acts.append((x, k, ys[i]))
             x, k = (SK, Pw + W) if i == self.skip else (ys[i], W)
-        return OUT, (acts, V, HV, SK, E)
+        return OUT, (acts, V, HV, SK, E, words)
 
     def forward_fused(self, pts, viewdirs, S):
         """Inference: embedding kernel + ONE fused kernel for the whole network (activations never leave the registers)."""
@@ -542,7 +567,7 @@ class ClassicNeRFNet(_Net):
 
     def backward(self, d_raw, saved):
         """d_raw [M,4] fp32 -> accumulates parameter gradients into the arena."""
-        acts, V, HV, SK, E = saved
+        acts, V, HV, SK, E = saved[:5]
         W, Pw, g, M = self.Wd, self.Pw, self.g, d_raw.shape[0]
         ah = self.alpha_head
         self.colsum(d_raw, 3, self.gB("rgb_linear"))
@@ -550,6 +575,28 @@ class ClassicNeRFNet(_Net):
             self.colsum(d_raw[:, 3:], 1, self.gB("alpha_linear"))
         dz = self.head_grad(d_raw, 3)
         self.wgrad("rgb_linear", dz, HV, 3, W // 2)
+        if len(saved) > 5 and self.chain_ok():
+            # every data gradient in ONE launch; the weight gradients below read what it stored
+            dHV, DB = self.buf(M, W // 2), self.buf(M, W + g)
+            dZs = [self.buf(M, W) for _ in range(self.D)]                 # d pts_linears.7 .. .0
+            ops.fchain_bwd(ops.CHAIN_CLASSIC, d_raw, self._chain_stream(), saved[5], [dHV, DB] + dZs,
+                           [self.gB("views_linears.0"), self.gB("feature_linear")] + [self.gB(f"pts_linears.{i}") for i in range(self.D - 1, -1, -1)])
+            x7 = acts[-1][2]
+            self.wgrad("views_linears.0", dHV, V, W // 2, W + self.icv)
+            self.wgrad("feature_linear", DB[:, :W], x7, W, W)
+            ops.cast_pad(d_raw[:, 3:], 1, DB[:, W:], g, self.dt)
+            self.wgrad("alpha_linear", DB[:, W:], x7, 1, W)
+            for i in range(self.D - 1, -1, -1):
+                x, k, y = acts[i]
+                n, dZ = f"pts_linears.{i}", dZs[self.D - 1 - i]
+                if i == self.skip + 1:
+                    self.wgrad(n, dZ, SK[:, :Pw], W, self.ic, wcol=0)
+                    self.wgrad(n, dZ, SK[:, Pw:], W, W, wcol=self.ic)
+                elif i == 0:
+                    self.wgrad(n, dZ, E, W, self.ic)
+                else:
+                    self.wgrad(n, dZ, x, W, W)
+            return
         dHV = self.buf(M, W // 2)
         self.dgrad("rgb", dz, dz.shape[1], dHV, W // 2, mask=HV, colsum=self.gB("views_linears.0"))
         self.wgrad("views_linears.0", dHV, V, W // 2, W + self.icv)
@@ -625,6 +672,22 @@ class MipProposalNet(_Net):
                 self._refresh_fused(self._pack_fused)
             self._fused_version = v
 
+    def chain_ok(self):
+        return self.fused_ok() and getattr(self, "fused_chain", True) and not self.deterministic
+
+    def _pack_chain(self):
+        L = [(self.W("density_layer").t(), None, [(0, 1, False)])]
+        L += [(self.W(f"layers.{i}.layers.0").t(), None, [(0, self.H, True)]) for i in range(self.L - 1, 0, -1)]
+        return fmlp_pack(L, self.dev)
+
+    def _chain_stream(self):
+        v = self.version_fn()
+        if getattr(self, "_chain_version", None) != v:
+            with torch.no_grad():
+                self._chain = self._refresh_fused(self._pack_chain, "chain")
+            self._chain_version = v
+        return self._chain[0]
+
     def forward_fused(self, E):
         self._fused_ready()
         out = self.buf(E.shape[0], 1, f32=True)
@@ -646,6 +709,7 @@ class MipProposalNet(_Net):
         for y in ys:
             acts.append((x, k, y))
             x, k = y, H
+        self._chain_bits = (ys[0].data_ptr(), words)        # the fused data-gradient chain reads all four masks
         return out, acts
 
     def forward(self, E, keep: bool):
@@ -672,6 +736,14 @@ class MipProposalNet(_Net):
         dz = self.head_grad(d_raw_density, 1)
         xl = acts[-1][2]
         self.wgrad("density_layer", dz, xl, 1, H)
+        cb = getattr(self, "_chain_bits", None)
+        if cb is not None and cb[0] == acts[0][2].data_ptr() and self.chain_ok():
+            dZs = [self.buf(M, H) for _ in range(self.L)]                 # d layers.3 .. .0 in ONE launch
+            ops.fchain_bwd(ops.CHAIN_PROPOSAL, d_raw_density, self._chain_stream(), cb[1], dZs,
+                           [self.gB(f"layers.{i}.layers.0") for i in range(self.L - 1, -1, -1)])
+            for i in range(self.L - 1, -1, -1):
+                self.wgrad(f"layers.{i}.layers.0", dZs[self.L - 1 - i], acts[i][0], H, self.fd if i == 0 else H)
+            return self.input_grad("enc", dZs[-1], H, self.Ew) if want_input_grad else None
         dZ = self.buf(M, H)
         self.dgrad("density", dz, self.g, dZ, H, mask=xl, colsum=self.gB(f"layers.{self.L - 1}.layers.0"))
         for i in range(self.L - 1, -1, -1):

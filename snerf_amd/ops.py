@@ -162,8 +162,8 @@ def _act_arrays(acts, bits, M, widths):
     for y, w in zip(acts, widths):
         assert y.dtype == torch.bfloat16 and y.dim() == 2 and y.stride(1) == 1 and y.shape[0] == M and y.shape[1] >= w
         assert y.data_ptr() % 16 == 0 and y.stride(0) % 8 == 0
-    for b in bits:
-        assert b.dtype == torch.int32 and b.is_contiguous() and b.numel() >= mask_bits_words(M, 256)
+    for i, b in enumerate(bits):
+        assert b.dtype == torch.int32 and b.is_contiguous() and b.numel() >= mask_bits_words(M, 128 if i == 8 else 256)
     ptrs = (ctypes.c_void_p * len(acts))(*[y.data_ptr() for y in acts])
     lds = (ctypes.c_long * len(acts))(*[y.stride(0) for y in acts])
     bp = (ctypes.c_void_p * len(bits))(*[b.data_ptr() for b in bits])
@@ -172,12 +172,12 @@ def _act_arrays(acts, bits, M, widths):
 
 def fmlp_classic_train_fwd(E, VE, stream, bias, raw, acts, bits):
     """fmlp_classic_fwd that also stores the ten hidden-layer outputs (`acts`: pts_linears.0..7 [M,256], feature [M,256], views
-    [M,128], bf16 row-major views) and the ReLU bit masks of the eight trunk layers (`bits`: int32 [mask_bits_words(M, 256)] each)
-    for the per-layer backward."""
+    [M,128], bf16 row-major views) and the ReLU bit masks of the eight trunk layers (`bits[0..7]`: int32 [mask_bits_words(M, 256)]
+    each) and of views_linears.0 (`bits[8]`: [mask_bits_words(M, 128)]) for the backward pass."""
     import ctypes
     _chk2d(E, torch.bfloat16); _chk2d(VE, torch.bfloat16); _chk2d(raw, torch.float32)
     assert stream.dtype == torch.bfloat16 and stream.is_contiguous() and bias.dtype == torch.float32 and raw.is_contiguous() and raw.shape[1] == 4
-    assert E.shape[1] >= 64 and VE.shape[1] >= 32 and VE.shape[0] == E.shape[0] == raw.shape[0] and len(bits) == 8
+    assert E.shape[1] >= 64 and VE.shape[1] >= 32 and VE.shape[0] == E.shape[0] == raw.shape[0] and len(bits) == 9
     ptrs, lds, bp = _act_arrays(acts, bits, E.shape[0], [256] * 9 + [128])
     _lib.call("snerf_fmlp_classic_train_fwd", _p(E), E.stride(0), _p(VE), VE.stride(0), _p(stream), stream.shape[0], _p(bias),
               bias.numel() // 32, _p(raw), ctypes.addressof(ptrs), ctypes.addressof(lds), ctypes.addressof(bp), E.shape[0], _stream())
@@ -240,6 +240,37 @@ def fcolour_bwd(d_raw_rgb, stream, bits, dC, dB, g_bias):
     pg = (ctypes.c_void_p * 4)(*[g.data_ptr() for g in g_bias])
     _lib.call("snerf_fcolour_bwd", _p(d_raw_rgb), _p(stream), stream.shape[0], ctypes.addressof(pb), ctypes.addressof(pc), ctypes.addressof(pl),
               _p(dB), dB.stride(0), ctypes.addressof(pg), _p(ws), ws.numel(), M, _stream())
+
+
+CHAIN_CLASSIC, CHAIN_PROPOSAL = 0, 1
+
+
+def fchain_bwd(net, d_raw, stream, bits, dz, g_bias):
+    """Fused data-gradient chain of a 256-wide network (csrc/fmlp.hip fchain_bwd_kernel), ONE launch instead of one GEMM per layer.
+    CHAIN_CLASSIC: d_raw [M,4] fp32 -> dz = [d views_linears.0 (128), d feature_linear (256), d pts_linears.7 .. .0 (256)]; bits =
+    masks of pts_linears.0..7 + views_linears.0.  CHAIN_PROPOSAL: d_raw [M] / [M,1] (d raw density) -> dz = [d layers.3 .. .0]; bits =
+    masks of layers.0..3.  The bias gradient of step i is added to g_bias[i] (not bit-reproducible: workgroup-level LDS atomics)."""
+    import ctypes
+    classic = net == CHAIN_CLASSIC
+    d_raw = _f32c(d_raw)
+    M = d_raw.shape[0]
+    widths = ([128] + [256] * 9) if classic else [256] * 4
+    assert d_raw.numel() == M * (4 if classic else 1) and stream.dtype == torch.bfloat16 and stream.is_contiguous()
+    assert len(bits) == (9 if classic else 4) and len(dz) == len(widths) == len(g_bias)
+    for i, b in enumerate(bits):
+        assert b.dtype == torch.int32 and b.is_contiguous() and b.numel() >= mask_bits_words(M, 128 if i == 8 else 256)
+    for y, w in zip(dz, widths):
+        assert y.dtype == torch.bfloat16 and y.dim() == 2 and y.stride(1) == 1 and y.shape[0] == M and y.shape[1] >= w
+    for gb, w in zip(g_bias, widths):
+        assert gb.dtype == torch.float32 and gb.is_contiguous() and gb.numel() == w
+    nws = _lib.query("snerf_fchain_bwd_ws_floats", net, M)
+    ws = torch.empty(max(int(nws), 1), dtype=torch.float32, device=d_raw.device)
+    pb = (ctypes.c_void_p * len(bits))(*[b.data_ptr() for b in bits])
+    pz = (ctypes.c_void_p * len(dz))(*[y.data_ptr() for y in dz])
+    pl = (ctypes.c_long * len(dz))(*[y.stride(0) for y in dz])
+    pg = (ctypes.c_void_p * len(dz))(*[g.data_ptr() for g in g_bias])
+    _lib.call("snerf_fchain_bwd", net, _p(d_raw), _p(stream), stream.shape[0], ctypes.addressof(pb), ctypes.addressof(pz), ctypes.addressof(pl),
+              ctypes.addressof(pg), _p(ws), ws.numel(), M, _stream())
 
 
 # --------------------------------------------------------------- encoders ----

@@ -591,9 +591,9 @@ def fmlp_classic_pts_fwd(pts, viewdirs, S, stream, bias, raw):
 
 
 def fmlp_classic_train_fwd(E, VE, stream, bias, raw, acts, bits):
-    assert len(acts) == 10 and len(bits) == 8
+    assert len(acts) == 10 and len(bits) == 9
     fmlp_classic_fwd(E, VE, stream, bias, raw, acts)
-    for y, w in zip(acts, bits):                     # what ACT_MASK_BITS consumers look up (see linear_fwd above)
+    for y, w in zip(acts[:8] + [acts[9]], bits):     # what ACT_MASK_BITS consumers look up (see linear_fwd above); bits[8]: views_linears.0
         _BITS[w.data_ptr()] = y.float() > 0
 
 
@@ -666,6 +666,46 @@ def fcolour_bwd(d_raw_rgb, stream, bits, dC, dB, g_bias):
     assert st.f == 324
 
 
+def fchain_bwd(net, d_raw, stream, bits, dz, g_bias):
+    """model of fchain_bwd_kernel: the data-gradient chains of the 256-wide networks on the transposed weights (masks, bf16
+    stores, bias gradients = column sums of the stored gradients)"""
+    classic = net == 0
+    assert stream.shape[0] == (1104 if classic else 400)
+    st = _FStream(stream, torch.zeros(80 * 32))
+    M = d_raw.shape[0]
+    d_raw = d_raw.reshape(M, -1)
+
+    def head(cols):
+        g = torch.zeros(M, 16)
+        g[:, :len(cols)] = d_raw[:, cols].to(torch.bfloat16).float()
+        return g
+
+    def layer(segs, nblocks, mask, out, gb):
+        frs = []
+        for j in range(nblocks):
+            a = st.block(segs, False, to_frags=False)
+            if mask is not None:
+                a = a * mask[:, 32 * j:32 * j + 32]
+            y = a.to(torch.bfloat16).float()
+            gb[32 * j:32 * j + 32] += y.sum(0)                    # (the kernel sums the bf16 gradients it stores, on the matrix cores)
+            out[:, 32 * j:32 * j + 32] = y.to(out.dtype)
+            frs += [y[:, _P], y[:, 16 + _P]]
+        return frs
+    m = [_BITS[b.data_ptr()].float() for b in bits]
+    if classic:
+        p = layer([[head([0, 1, 2])]], 4, m[8][:, :128], dz[0], g_bias[0])
+        p = layer([p], 8, None, dz[1], g_bias[1])
+        p = layer([p, [head([3])]], 8, m[7], dz[2], g_bias[2])
+        for i in range(6, -1, -1):
+            p = layer([p], 8, m[i], dz[9 - i], g_bias[9 - i])
+        assert st.f == 1100
+    else:
+        p = layer([[head([0])]], 8, m[3], dz[0], g_bias[0])
+        for i in range(2, -1, -1):
+            p = layer([p], 8, m[i], dz[3 - i], g_bias[3 - i])
+        assert st.f == 392
+
+
 def gather_pack(flat, idx, dst):
     k = idx.long()
     lo = (k >= 0) & ((k & (1 << 30)) != 0)                     # split-bf16 weights: the low part bf16(x - bf16(x))
@@ -679,7 +719,7 @@ def adam_step_dev(p, g, m, v, lr, b1, b2, eps, step_dev, grad_scale=1.0, zero_gr
     adam_step(p, g, m, v, lr, b1, b2, eps, 0, grad_scale, zero_grad, step_dev=step_dev, **kw)
 
 
-_NAMES = ["app_embed", "app_embed_bwd", "split_cast", "fcolour_fwd", "fcolour_bwd", "gather_pack", "adam_step_dev", "grad_clip_coef", "fmlp_classic_fwd", "fmlp_classic_pts_fwd", "fmlp_proposal_fwd", "fmlp_classic_train_fwd", "fmlp_proposal_train_fwd", "classic_get_rays", "classic_ndc_rays", "classic_ray_batch", "zip_encode_prop_fwd", "mip_encode_bwd", "mip_viewenc_bwd", "hash_decay", "zip_percentiles", "zip_pixels_to_rays", "zip_loss_tail", "semantic_composite_fwd", "semantic_composite_bwd", "zip_resample", "zip_encode_fwd", "zip_encode_bwd", "zip_encode_bwd_binned", "zip_encode_ray_bwd", "zip_composite_fwd", "zip_composite_bwd",
+_NAMES = ["fchain_bwd", "app_embed", "app_embed_bwd", "split_cast", "fcolour_fwd", "fcolour_bwd", "gather_pack", "adam_step_dev", "grad_clip_coef", "fmlp_classic_fwd", "fmlp_classic_pts_fwd", "fmlp_proposal_fwd", "fmlp_classic_train_fwd", "fmlp_proposal_train_fwd", "classic_get_rays", "classic_ndc_rays", "classic_ray_batch", "zip_encode_prop_fwd", "mip_encode_bwd", "mip_viewenc_bwd", "hash_decay", "zip_percentiles", "zip_pixels_to_rays", "zip_loss_tail", "semantic_composite_fwd", "semantic_composite_bwd", "zip_resample", "zip_encode_fwd", "zip_encode_bwd", "zip_encode_bwd_binned", "zip_encode_ray_bwd", "zip_composite_fwd", "zip_composite_bwd",
           "linear_fwd", "linear_wgrad", "classic_embed", "mip_encode", "mip_viewenc", "classic_sample_pdf", "classic_points",
           "classic_merge_sort", "mip_resample", "stratified", "mip_composite_fwd", "mip_composite_bwd", "classic_composite_fwd",
           "classic_composite_bwd", "adam_step", "colsum_f32", "cast_pad", "pinhole_rays", "mip_loss_tail"]

@@ -160,9 +160,14 @@ def test_deterministic_mode_gives_bit_identical_gradients():
     a, b = grads(), grads()
     assert torch.equal(a, b), "deterministic mode must be bit-reproducible"
     m.set_deterministic(False)
+    m.prop.fused_chain = False                  # the same per-layer kernels, atomics instead of the fixed-order fold
     c = grads()
     rel = float((a - c).norm() / c.norm())
     assert float(c.norm()) > 0 and rel < 1e-5, rel
+    m.prop.fused_chain = True                   # default: the proposal MLP's data gradients as one fused chain (another fp32 summation
+    d = grads()                                 # order in front of the bf16 roundings of the stored gradients)
+    rel = float((a - d).norm() / d.norm())
+    assert rel < 5e-4, rel
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
@@ -284,6 +289,65 @@ def test_fused_colour_head_matches_per_layer_kernels_and_oracle(backend, M):
         assert rel(g_f[k], g_l[k]) < 3e-2, (k, rel(g_f[k], g_l[k]))
 
 
+@pytest.mark.parametrize("M", [1000, 768])
+def test_fused_gradient_chains_match_per_layer_kernels_and_oracle(backend, M):
+    """snerf_fchain_bwd (the data gradients of the classic 8 x 256 network / the proposal MLP in ONE launch each) against the per-layer
+    data-gradient GEMMs (same bf16 chain, another fp32 summation order; bias gradients from the same masked accumulators) and torch
+    autograd of the oracle (run_nerf_helpers.py:83-139, models.py:299-325): every parameter gradient.  M = 1000: ragged tile."""
+    from snerf_amd import ops
+    from snerf_amd.mlp import ClassicNeRFNet, MipProposalNet, ParamArena
+    g = torch.Generator().manual_seed(61)
+    S = 8
+    shapes = ClassicNeRFNet.param_shapes(8, 256, 63, 27, (4,))
+    sd = rnd_params(shapes, 62)
+    pts = torch.rand(M, 3, generator=g) * 2 - 1
+    vd = torch.nn.functional.normalize(torch.randn(M // S, 3, generator=g), dim=-1)
+    d_raw = torch.randn(M, 4, generator=g)
+    pr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    e = torch.cat([q(oc.embed(pts, 10), 1), q(oc.embed(vd[:, None].expand(M // S, S, 3).reshape(M, 3), 4), 1)], -1)
+    (oc.nerf_mlp(pr, e) * d_raw).sum().backward()
+
+    def run_classic(chain):
+        arena = ParamArena(shapes, torch.device(DEV)); arena.load(sd)
+        net = ClassicNeRFNet(arena, "", ops.BF16, 8, 256)
+        net.fused_chain = chain
+        assert net.fused_ok() and net.chain_ok() == chain
+        raw, saved = net.forward(pts.to(DEV), vd.to(DEV), S, True)
+        arena.grad.zero_()
+        net.backward(d_raw.to(DEV), saved)
+        return {k: arena.g[k].clone() for k in sd}
+    g_c, g_l = run_classic(True), run_classic(False)
+    for k in sd:
+        e_c, e_l = rel(g_c[k], pr[k].grad), rel(g_l[k], pr[k].grad)
+        assert e_c < 0.25 and e_c < 2.0 * e_l + 2e-2, (k, e_c, e_l)
+        assert rel(g_c[k], g_l[k]) < 3e-2, (k, rel(g_c[k], g_l[k]))
+
+    shapes_p = MipProposalNet.param_shapes(256, 4, 96)
+    sd_p = rnd_params(shapes_p, 63)
+    enc = q(torch.rand(M, 96, generator=g) * 2 - 1, 1)
+    d_den = torch.randn(M, 1, generator=g)
+    pp = {"proposal." + k: v.clone().requires_grad_(True) for k, v in sd_p.items()}
+    (om.proposal_mlp(pp, enc[:, None]).reshape(M, 1) * d_den).sum().backward()
+
+    def run_prop(chain):
+        arena = ParamArena(shapes_p, torch.device(DEV)); arena.load(sd_p)
+        net = MipProposalNet(arena, "", ops.BF16, 256, 4, 96)
+        net.fused_chain = chain
+        assert net.fused_ok() and net.chain_ok() == chain
+        E = torch.zeros(M, net.Ew, dtype=torch.bfloat16, device=DEV)
+        E[:, :96] = enc.to(DEV, torch.bfloat16)
+        out, acts = net.forward(E, True)
+        arena.grad.zero_()
+        ig = net.backward(d_den.to(DEV), acts, want_input_grad=True)
+        return {k: arena.g[k].clone() for k in sd_p}, ig
+    (g_c, ig_c), (g_l, ig_l) = run_prop(True), run_prop(False)
+    assert rel(ig_c, ig_l) < 3e-2, rel(ig_c, ig_l)
+    for k in sd_p:
+        e_c, e_l = rel(g_c[k], pp["proposal." + k].grad), rel(g_l[k], pp["proposal." + k].grad)
+        assert e_c < 0.25 and e_c < 2.0 * e_l + 2e-2, (k, e_c, e_l)
+        assert rel(g_c[k], g_l[k]) < 3e-2, (k, rel(g_c[k], g_l[k]))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("M", [1000, 768])
 def test_fused_training_forward_stores_activations_and_relu_bits(M):
@@ -321,7 +385,8 @@ def test_fused_training_forward_stores_activations_and_relu_bits(M):
         words, N = fbits[(y.data_ptr(), M)]
         assert np.array_equal(decode(words, M, N), (y.float() > 0).cpu().numpy())
     assert rel(saved[1], saved_l[1]) < 1e-2 and rel(saved[2], saved_l[2]) < 1e-2
-    # gradients through the two forward variants agree (same per-layer backward kernels, masks from bits either way)
+    assert np.array_equal(decode(saved[5][8], M, 128), (saved[2].float() > 0).cpu().numpy())      # views_linears.0 (2 column groups)
+    # gradients through the two forward variants agree (fused data-gradient chain vs the per-layer kernels)
     d_raw = torch.randn(M, 4, generator=g).to(DEV)
     net._bits = fbits
     arena.grad.zero_(); net.backward(d_raw, saved); ga = arena.grad.clone()

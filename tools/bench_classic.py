@@ -51,6 +51,9 @@ def main():
     fine.net.fused = coarse.net.fused = False         # A/B: the training forward as one GEMM launch per layer
     dt_train_layered = timeit(train)
     fine.net.fused = coarse.net.fused = True
+    fine.net.fused_chain = coarse.net.fused_chain = False     # A/B: the data gradients as one GEMM launch per layer
+    dt_train_dgrad_layered = timeit(train)
+    fine.net.fused_chain = coarse.net.fused_chain = True
     flops = 2.0 * 593408 * (64 + 192)
     with torch.no_grad():
         dt_fwd = timeit(fwd)
@@ -71,6 +74,7 @@ def main():
                       "fwd_rays_per_s": round(N / dt_fwd, 1), "fwd_mlp_TFLOPs": round(N * flops / dt_fwd / 1e12, 1),
                       "train_mlp_TFLOPs": round(3 * N * flops / dt_train / 1e12, 1),
                       "train_per_layer_fwd_ms": round(dt_train_layered * 1e3, 3),
+                      "train_per_layer_dgrad_ms": round(dt_train_dgrad_layered * 1e3, 3),
                       "frame_1600x900_s": round(1440000 / (N / dt_fwd), 3),
                       "fwd_per_layer_ms": round(dt_fwd_layered * 1e3, 3), "fwd_per_layer_mlp_TFLOPs": round(N * flops / dt_fwd_layered / 1e12, 1),
                       "run_network_only": {"rows": M, **mlp_only,

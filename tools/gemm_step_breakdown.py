@@ -35,7 +35,7 @@ def wrap(name):
         return r
     setattr(ops, name, timed)
     return orig
-saved = {n: wrap(n) for n in ("fcolour_fwd", "fcolour_bwd", "fmlp_proposal_train_fwd", "mip_encode", "mip_composite_fwd", "mip_composite_bwd", "mip_resample", "adam_step")}
+saved = {n: wrap(n) for n in ("fcolour_fwd", "fcolour_bwd", "fchain_bwd", "fmlp_proposal_train_fwd", "mip_encode", "mip_composite_fwd", "mip_composite_bwd", "mip_resample", "adam_step")}
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
 ev[0].record()
 tr.step(rays, tgt, depth, conf)
