@@ -82,6 +82,16 @@ int snerf_mip_encode(const float* s_vals, const float* origins, const float* dir
                      void* dst1, long ld1, void* dst2, long ld2, int width, float* means_out, float* covs_out,
                      int dtype, const int* sample_id, long n_rows, void* stream);
 
+/* The same with the warp of sample2enc selected (mip.py:367-378 warp_fn, model argument `fn`): fn_idx 1 = the contraction above,
+ * fn_idx 0 = the view-centred warp fn1 (x - viewc) / sqrt(|x - viewc| far) (mip.py:368-369) with Jacobi_f (mip.py:323-340:
+ * (l I - x x^T) / l^1.5 / sqrt(max far), l = |x| + 1e-5 at the unshifted mean).  (vx, vy, vz) = viewc, the mean camera centre
+ * (train.py:36, eval.py:50); far_max: DEVICE scalar = max over the batch of rays.far (ignored for fn_idx 1). */
+int snerf_mip_encode_warp(const float* s_vals, const float* origins, const float* directions, const float* radii,
+                          const float* near, const float* far, long n_rays, int S, int cone, int transform_idx, int max_deg,
+                          void* dst1, long ld1, void* dst2, long ld2, int width, float* means_out, float* covs_out,
+                          int dtype, const int* sample_id, long n_rows, int fn_idx, float vx, float vy, float vz,
+                          const float* far_max, void* stream);
+
 /* mip.py:12-21 pos_enc(viewdirs, 0, deg, append_identity) tiled per sample (models.py:285-287). */
 int snerf_mip_viewenc(const float* viewdirs, long n_rays, int S, int deg, void* dst, long ld, int width, int dtype,
                       const int* sample_id, long n_rows, void* stream);

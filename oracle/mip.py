@@ -96,16 +96,36 @@ def contract_jacobian(x):
     return torch.where(l >= RADIUS, J1, (1.0 / RADIUS) * eye.expand(J1.shape))
 
 
+def warp_view(x, viewc, far):
+    """warp_fn.fn1 (``fn == 0``), mip.py:368-369: (x - viewc) / sqrt(|x - viewc| * far), far [N,1] per ray."""
+    dx = x - viewc
+    return dx / torch.sqrt((torch.linalg.norm(dx, dim=-1) * far)[..., None])
+
+
+def warp_view_jacobian(x, far):
+    """Jacobi_f, mip.py:323-340: (l I - x x^T) / l^(3/2) / sqrt(max far), l = |x| + 1e-5 -- evaluated at the UNSHIFTED means (the
+    reference does not subtract viewc here) and scaled by the batch-wide maximum of far."""
+    ln = torch.linalg.norm(x, dim=-1) + 1e-5
+    L = x[..., :, None] * x[..., None, :]
+    J = ln[..., None, None] * torch.eye(3)
+    J = (J - L) / (ln ** (3 / 2))[..., None, None]
+    return J / torch.sqrt(far.max())
+
+
 # ------------------------------------------------------------------ A6 ----
 def sample2enc(s_vals, origins, directions, radii, near, far, ray_shape="cone", transform_idx=0,
-               full_cov: bool = False):
-    """mip.py:381-395: s -> t -> Gaussians -> contracted mean + warped covariance
-    J diag(c) J^T.  Returns (f_means [N,S,3], cov) where cov is the diagonal
-    [N,S,3] (default) or the full matrix [N,S,3,3] (golden comparison)."""
+               full_cov: bool = False, fn_idx: int = 1, viewc=0.0):
+    """mip.py:381-395: s -> t -> Gaussians -> warped mean + warped covariance
+    J diag(c) J^T (``fn_idx`` 1: the contraction, 0: the view-centred warp of mip.py:368-369 + Jacobi_f).  Returns
+    (f_means [N,S,3], cov) where cov is the diagonal [N,S,3] (default) or the full matrix [N,S,3,3] (golden comparison)."""
     t = transform(s_vals, near, far, transform_idx)
     means, covs = cast_rays(t, origins, directions, radii, ray_shape)
-    f_means = contract(means)
-    J = contract_jacobian(means)
+    if fn_idx == 0:
+        f_means = warp_view(means, viewc, far)
+        J = warp_view_jacobian(means, far)
+    else:
+        f_means = contract(means)
+        J = contract_jacobian(means)
     if full_cov:
         return f_means, torch.einsum("...ai,...i,...bi->...ab", J, covs, J)
     return f_means, torch.sum(J * J * covs[..., None, :], dim=-1)
@@ -293,7 +313,7 @@ def warp_resample_s(s_vals, weights, u, resample_padding: float = 0.01):
 def mipnerf_forward(p: dict, rays: dict, n_samples: int, n_fine: int, s_rand=None, u=None,
                     white_bg: bool = False, ray_shape: str = "cone", transform_idx: int = 0,
                     max_deg_point: int = 16, deg_view: int = 4, resample_padding: float = 0.01,
-                    density_noise0=None, density_noise1=None, return_aux: bool = False, s1_override=None):
+                    density_noise0=None, density_noise1=None, return_aux: bool = False, s1_override=None, fn_idx: int = 1, viewc=0.0):
     """MipNerfModel.forward, models.py:72-187 (warp branch, use_viewdirs; the appearance
     embedding of encode_appearance when `p` holds "emb.weight").  ``u`` [N,n_fine] or [n_fine]; None = det_u(n_fine).
     Returns [[None, distance, acc, s_vals, weights], [rgb, distance, acc, semantic, s_vals, weights]]
@@ -305,7 +325,7 @@ def mipnerf_forward(p: dict, rays: dict, n_samples: int, n_fine: int, s_rand=Non
     aux = {}
     # level 0: proposal
     s0 = warp_sample_s(n, n_samples, s_rand)
-    m0, c0 = sample2enc(s0, o, d, r, near, far, ray_shape, transform_idx)
+    m0, c0 = sample2enc(s0, o, d, r, near, far, ray_shape, transform_idx, fn_idx=fn_idx, viewc=viewc)
     enc0 = integrated_pos_enc(m0, c0, 0, max_deg_point)
     raw_d0 = proposal_mlp(p, enc0)
     if density_noise0 is not None:
@@ -320,7 +340,7 @@ def mipnerf_forward(p: dict, rays: dict, n_samples: int, n_fine: int, s_rand=Non
         # teacher forcing for conditioning-aware gradient checks (tests only): level 1 evaluated at GIVEN fence posts -- those a
         # reduced-precision run resampled -- so that both sides see identical sample positions (the posts carry no gradient)
         s1 = s1_override
-    m1, c1 = sample2enc(s1, o, d, r, near, far, ray_shape, transform_idx)
+    m1, c1 = sample2enc(s1, o, d, r, near, far, ray_shape, transform_idx, fn_idx=fn_idx, viewc=viewc)
     enc1 = integrated_pos_enc(m1, c1, 0, max_deg_point)
     cond = pos_enc(rays["viewdirs"], 0, deg_view, True)
     if "emb.weight" in p:

@@ -241,7 +241,8 @@ def volumetric_rendering(rgbs, weights, tdist, bg_rgbs=1.0, semantic=None, compu
 # ------------------------------------------------------------------ C11 ---
 def model_forward(p, specs, batch, num_prop_samples=(64, 64), num_nerf_samples=32, train_frac=1.0, anneal_slope=10.0,
                   dilation_multiplier=0.5, dilation_bias=0.0025, power_lambda=-1.5, std_scale=0.35, jitters=None,
-                  deg_jitters=None, bg=1.0, use_semantic=False, compute_extras=False, vis_num_rays=16, sdist_override=None):
+                  deg_jitters=None, bg=1.0, use_semantic=False, compute_extras=False, vis_num_rays=16, sdist_override=None,
+                  near_anneal_rate=None, near_anneal_init=0.95):
     """Model.forward (models.py:98-349) with rand=None (jitters None) or explicit draws; `use_semantic`: the final level also
     renders the 19-class semantic distribution (models.py:297-305).  `specs` = [prop0, prop1, nerf]
     GridSpec; parameter names follow the reference's state_dict (`prop_mlp_0.encoder.embeddings`, `nerf_mlp.rgb_layer.weight`...).
@@ -249,7 +250,9 @@ def model_forward(p, specs, batch, num_prop_samples=(64, 64), num_nerf_samples=3
     levels' ray_rgbs replaced by the final level's average colour (models.py:316-346).
     Returns (renderings, ray_history) with the reference's keys (rgb, depth / sdist, weights, tdist)."""
     near, far = batch["near"], batch["far"]
-    sdist = torch.cat([torch.zeros_like(near), torch.ones_like(far)], dim=-1)
+    # near-bound annealing (models.py:147-158): the first interval starts at clip(1 - train_frac / rate, 0, init) instead of 0
+    s_near = 0.0 if near_anneal_rate is None else float(np.clip(1 - train_frac / near_anneal_rate, 0, near_anneal_init))
+    sdist = torch.cat([torch.full_like(near, s_near), torch.ones_like(far)], dim=-1)
     weights = torch.ones_like(near)
     prod = 1
     renderings, history = [], []
@@ -257,15 +260,15 @@ def model_forward(p, specs, batch, num_prop_samples=(64, 64), num_nerf_samples=3
     for lvl in range(n_levels):
         is_prop = lvl < n_levels - 1
         ns = num_prop_samples[lvl] if is_prop else num_nerf_samples
-        dilation = dilation_bias + dilation_multiplier * 1.0 / prod
+        dilation = dilation_bias + dilation_multiplier * (1.0 - s_near) / prod
         prod *= ns
         if lvl > 0:
-            sdist, weights = max_dilate_weights(sdist, weights, dilation, (0.0, 1.0))
+            sdist, weights = max_dilate_weights(sdist, weights, dilation, (s_near, 1.0))
             sdist, weights = sdist[..., 1:-1], weights[..., 1:-1]
         anneal = (anneal_slope * train_frac) / ((anneal_slope - 1) * train_frac + 1) if anneal_slope > 0 else 1.0
         logits = resample_logits(sdist, weights, anneal, 0.0)
         u = det_centers_u(ns) if jitters is None else rand_u(ns, jitters[lvl])
-        sdist, _ = sample_intervals(sdist, logits, u, (0.0, 1.0))
+        sdist, _ = sample_intervals(sdist, logits, u, (s_near, 1.0))
         sdist = sdist.detach()                      # stop_level_grad, models.py:215-218
         if sdist_override is not None:
             # teacher forcing for conditioning-aware gradient checks (tests only): every level evaluated at GIVEN fence posts -- those

@@ -137,6 +137,8 @@ struct MipEncArgs {
   void* dst1; long ld1; void* dst2; long ld2; int width;  // width >= 6*max_deg, zero padded
   float* means_out; float* covs_out;                       // optional [M,3] debug/parity outputs
   const int* sample_id;                                    // optional [M]: row j encodes sample sample_id[j] = ray * S + i (compacted rows)
+  int fn_idx;                                              // 1: contraction (fn2 + Jacobi_g), 0: view-centred warp (fn1 + Jacobi_f)
+  float viewc[3]; const float* far_max;                    // fn_idx 0: the mean camera centre; device scalar max(far) of the batch
 };
 
 template <typename T>
@@ -175,14 +177,35 @@ __global__ __launch_bounds__(256) void mip_encode_kernel(MipEncArgs a) {
       const float dd = d[k] * d[k];
       c[k] = t_var * dd + r_var * (1.f - dd / dmag);
     }
-    // contraction fn2 (mip.py:371-374) and Jacobian (mip.py:343-364); radius hard-coded 3 (mip.py:386)
     const float nrm = sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+    float fm[3], fc[3];
+    if (a.fn_idx == 0) {
+      // view-centred warp fn1 (mip.py:368-369): (x - viewc) / sqrt(|x - viewc| far), and Jacobi_f (mip.py:323-340): J = (l I - x x^T)
+      // / l^1.5 / sqrt(max far) with l = |x| + 1e-5 at the UNSHIFTED mean, as the reference has it; diag(J diag(c) J) as below
+      float dx[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) dx[k] = x[k] - a.viewc[k];
+      const float den = sqrtf(sqrtf(dx[0] * dx[0] + dx[1] * dx[1] + dx[2] * dx[2]) * far);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) fm[k] = dx[k] / den;
+      const float lj = nrm + 1e-5f;
+      const float l15 = powf(lj, 1.5f), sf = sqrtf(a.far_max[0]);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const float J = (((r == k ? lj : 0.f) - x[r] * x[k]) / l15) / sf;
+          acc += (J * J) * c[k];
+        }
+        fc[r] = acc;
+      }
+    } else {
+    // contraction fn2 (mip.py:371-374) and Jacobian (mip.py:343-364); radius hard-coded 3 (mip.py:386)
     const float l = nrm + 1e-8f;
-    float fm[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) fm[k] = l > 3.f ? (2.f - 3.f / l) * x[k] / l : x[k] / 3.f;
     const float lj = nrm + 1e-5f;
-    float fc[3];
     if (lj >= 3.f) {
       const float ln = 1.f / lj, ln2 = ln * ln;
       const float p1 = -3.f * ln2 + 2.f * ln;
@@ -200,6 +223,7 @@ __global__ __launch_bounds__(256) void mip_encode_kernel(MipEncArgs a) {
     } else {
 #pragma unroll
       for (int r = 0; r < 3; ++r) fc[r] = ((1.f / 3.f) * (1.f / 3.f)) * c[r];
+    }
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) { sm[threadIdx.x][k] = fm[k]; sm[threadIdx.x][3 + k] = fc[k]; }
@@ -256,19 +280,39 @@ __global__ __launch_bounds__(256) void mip_encode_kernel(MipEncArgs a) {
   }
 }
 
-extern "C" int snerf_mip_encode(const float* s_vals, const float* origins, const float* directions, const float* radii,
-                                const float* near, const float* far, long n_rays, int S, int cone, int transform_idx, int max_deg,
-                                void* dst1, long ld1, void* dst2, long ld2, int width, float* means_out, float* covs_out,
-                                int dtype, const int* sample_id, long n_rows, void* stream) {
+static int mip_encode_launch(const float* s_vals, const float* origins, const float* directions, const float* radii, const float* near,
+                             const float* far, long n_rays, int S, int cone, int transform_idx, int max_deg, void* dst1, long ld1, void* dst2,
+                             long ld2, int width, float* means_out, float* covs_out, int dtype, const int* sample_id, long n_rows, int fn_idx,
+                             float vx, float vy, float vz, const float* far_max, void* stream) {
   if (n_rays <= 0 || (sample_id != nullptr && n_rows <= 0)) return SNERF_OK;
   if (S <= 0 || width < 6 * max_deg || max_deg > 30 || dst1 == nullptr) return SNERF_ERR_ARG;
   if (sample_id != nullptr && n_rows > n_rays * (long)S) return SNERF_ERR_ARG;
+  if ((fn_idx != 0 && fn_idx != 1) || (fn_idx == 0 && far_max == nullptr)) return SNERF_ERR_ARG;
   MipEncArgs a{s_vals, origins, directions, radii, near, far, S, sample_id != nullptr ? n_rows : n_rays * (long)S, cone, transform_idx, max_deg,
-               dst1, ld1, dst2, ld2, width, means_out, covs_out, sample_id};
+               dst1, ld1, dst2, ld2, width, means_out, covs_out, sample_id, fn_idx, {vx, vy, vz}, far_max};
   const int blocks = (int)((a.M + 255) / 256);
   if (dtype == SNERF_DT_F32) hipLaunchKernelGGL(mip_encode_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(mip_encode_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
   return snerf_check_launch();
+}
+
+extern "C" int snerf_mip_encode(const float* s_vals, const float* origins, const float* directions, const float* radii,
+                                const float* near, const float* far, long n_rays, int S, int cone, int transform_idx, int max_deg,
+                                void* dst1, long ld1, void* dst2, long ld2, int width, float* means_out, float* covs_out,
+                                int dtype, const int* sample_id, long n_rows, void* stream) {
+  return mip_encode_launch(s_vals, origins, directions, radii, near, far, n_rays, S, cone, transform_idx, max_deg, dst1, ld1, dst2, ld2, width,
+                           means_out, covs_out, dtype, sample_id, n_rows, 1, 0.f, 0.f, 0.f, nullptr, stream);
+}
+
+// the same with the warp selected: fn_idx 1 = the contraction above, 0 = the view-centred warp (mip.py:367-378: fn1 + Jacobi_f) around
+// viewc = (vx, vy, vz); far_max: DEVICE scalar = max over the batch's rays.far (Jacobi_f divides by its square root, mip.py:340)
+extern "C" int snerf_mip_encode_warp(const float* s_vals, const float* origins, const float* directions, const float* radii,
+                                     const float* near, const float* far, long n_rays, int S, int cone, int transform_idx, int max_deg,
+                                     void* dst1, long ld1, void* dst2, long ld2, int width, float* means_out, float* covs_out,
+                                     int dtype, const int* sample_id, long n_rows, int fn_idx, float vx, float vy, float vz,
+                                     const float* far_max, void* stream) {
+  return mip_encode_launch(s_vals, origins, directions, radii, near, far, n_rays, S, cone, transform_idx, max_deg, dst1, ld1, dst2, ld2, width,
+                           means_out, covs_out, dtype, sample_id, n_rows, fn_idx, vx, vy, vz, far_max, stream);
 }
 
 template <typename T>

@@ -46,8 +46,9 @@ class MipNerfModel(_ArenaModule):
             raise NotImplementedError("accelerated MipNerfModel: n_levels=2, use_viewdirs, stop_level_grad")
         if semantic and not (0 < semantic_class_num <= 32):
             raise NotImplementedError("semantic head: 1..32 classes")
-        if fn != 1:
-            raise NotImplementedError("only the contraction warp fn=1 (the shipped nuScenes config) is accelerated")
+        if fn not in (0, 1):
+            raise ValueError("fn: 1 = contraction (the shipped nuScenes config), 0 = view-centred warp (mip.py:367-378)")
+        self._viewc = (0.0, 0.0, 0.0)         # fn = 0: the mean camera centre (forward's `viewc` argument / set_viewc)
         self.n_levels, self.n_samples, self.N_fine = n_levels, n_samples, N_fine
         self.resample_padding, self.ray_shape, self.max_deg_point, self.deg_view = resample_padding, ray_shape, max_deg_point, deg_view
         self.density_noise, self.density_bias, self.rgb_padding = density_noise, density_bias, rgb_padding
@@ -92,6 +93,17 @@ class MipNerfModel(_ArenaModule):
             c[k] = make().to(dev)
         return c[k]
 
+    def set_viewc(self, viewc):
+        """the centre of the fn = 0 warp (train.py:36 / eval.py:50: mean of the camera positions), a number or 3 values; kept as host
+        floats (kernel arguments), converted once per distinct object"""
+        if getattr(self, "_viewc_src", None) is viewc:
+            return
+        v = torch.as_tensor(viewc, dtype=torch.float32).detach().reshape(-1).cpu()
+        v = v.expand(3) if v.numel() == 1 else v
+        if v.numel() != 3:
+            raise ValueError("viewc: a scalar or 3 values")
+        self._viewc, self._viewc_src = tuple(float(x) for x in v), viewc
+
     # ------------------------------------------------------------------ core ----
     def _run(self, rays: Rays, keep: bool, white_bg: bool, s_rand, u, noise0, noise1):
         """Both levels.  Returns (outs, ctx) with outs = (dist0, acc0, s0, w0, rgb1, dist1, acc1, s1, w1)."""
@@ -109,7 +121,9 @@ class MipNerfModel(_ArenaModule):
         base = self._const("base", lambda: torch.linspace(0., 1., S0 + 1), dev)
         s0 = ops.stratified(base, s_rand, None, None, n, 1)
         E0 = self.prop.buf(n * S0, self.prop.Ew)
-        ops.mip_encode(s0, o, d, radii, near, far, cone, self.transform_idx, self.max_deg_point, E0, None, self.prop.Ew, self.dt)
+        # fn = 0: Jacobi_f divides by sqrt(far.max()) of the batch (mip.py:340) -- a device scalar, no host round trip
+        warp = None if self.fn == 1 else (self._viewc, far.max().reshape(1))
+        ops.mip_encode(s0, o, d, radii, near, far, cone, self.transform_idx, self.max_deg_point, E0, None, self.prop.Ew, self.dt, warp=warp)
         raw_d0, acts0 = self.prop.forward(E0, keep)
         _, dist0, acc0, w0 = ops.mip_composite_fwd(None, raw_d0, noise0, s0, d, near, far, self.transform_idx, white_bg,
                                                    self.rgb_padding, self.density_bias)
@@ -131,7 +145,7 @@ class MipNerfModel(_ArenaModule):
         else:
             enc_ids = sample_id
         ops.mip_encode(s1, o, d, radii, near, far, cone, self.transform_idx, self.max_deg_point, self.nerf.cs(SKIP, H), None, self.nerf.Ew, self.dt,
-                       sample_id=enc_ids)
+                       sample_id=enc_ids, warp=warp)
         app = None
         if self.encode_appearance:
             app = f(rays.app).reshape(-1)
@@ -168,6 +182,8 @@ class MipNerfModel(_ArenaModule):
         (utils/sample_utils.py:410-435) back-propagates through the encoders into the camera pose: the data gradient is carried one GEMM
         further to the IPE / view encodings, then through integrated_pos_enc, the contraction and its Jacobian, lift_gaussian and the
         interval lengths (t1 - t0)|d| of the compositing.  Fence posts carry no ray gradient (level 1 is detached, mip.py:318)."""
+        if ray_grads and self.fn == 0:
+            raise NotImplementedError("pose refinement (gradients to the rays) is implemented for the contraction warp fn=1 only")
         c = ctx
         g_o = g_d = g_vd = None
         if ray_grads:
@@ -246,6 +262,10 @@ class MipNerfModel(_ArenaModule):
         ray_grad = torch.is_grad_enabled() and any(torch.is_tensor(r) and r.requires_grad for r in (rays.origins, rays.directions, rays.viewdirs))
         if torch.is_grad_enabled() and any(torch.is_tensor(r) and r.requires_grad for r in (rays.radii, rays.near, rays.far)):
             raise NotImplementedError("gradients w.r.t. radii / near / far are not propagated (the reference's pose refinement leaves them constant)")
+        if self.fn == 0:
+            if ray_grad:
+                raise NotImplementedError("pose refinement (gradients to the rays) is implemented for the contraction warp fn=1 only")
+            self.set_viewc(viewc)
         dev = self.arena.flat.device
         n = rays.origins.shape[0]
         if n == 0:    # the reference raises on an empty batch too (models.py: reshape of 0 elements with an inferred dimension)

@@ -293,8 +293,10 @@ def _ids(sample_id):
 
 
 def mip_encode(s_vals, origins, directions, radii, near, far, cone, transform_idx, max_deg, dst1, dst2, width, dt,
-               means_out=None, covs_out=None, sample_id=None):
-    """sample_id (int32 [rows], optional): encode only the samples ray * S + i listed there, row j of dst <- sample_id[j]."""
+               means_out=None, covs_out=None, sample_id=None, warp=None):
+    """sample_id (int32 [rows], optional): encode only the samples ray * S + i listed there, row j of dst <- sample_id[j].
+    warp: None = the contraction (model argument fn = 1), or (viewc [3] host floats, far_max device scalar) = the view-centred warp
+    fn = 0 (mip.py:367-378)."""
     n, P = s_vals.shape
     for t in (s_vals, origins, directions, radii, near, far):
         _f32c(t)
@@ -303,8 +305,16 @@ def mip_encode(s_vals, origins, directions, radii, near, far, cone, transform_id
         # the exact fp32 encoding, then the hi / lo split into the GEMM operand layout
         assert dst2 is None
         tmp = torch.empty(dst1.shape[0], width, dtype=torch.float32, device=dst1.device)
-        mip_encode(s_vals, origins, directions, radii, near, far, cone, transform_idx, max_deg, tmp, None, width, F32, means_out, covs_out, sample_id)
+        mip_encode(s_vals, origins, directions, radii, near, far, cone, transform_idx, max_deg, tmp, None, width, F32, means_out, covs_out, sample_id, warp)
         return split_cast(tmp, width, dst1, width)
+    if warp is not None:
+        (vx, vy, vz), far_max = warp
+        _f32c(far_max)
+        assert far_max.numel() == 1 and far_max.device == s_vals.device
+        return _lib.call("snerf_mip_encode_warp", _p(s_vals), _p(origins), _p(directions), _p(radii), _p(near), _p(far), n, P - 1,
+                         1 if cone else 0, transform_idx, max_deg, _p(dst1), dst1.stride(0), _p(dst2),
+                         0 if dst2 is None else dst2.stride(0), width, _p(_f32c(means_out)), _p(_f32c(covs_out)), dt, _p(ids), rows,
+                         0, float(vx), float(vy), float(vz), _p(far_max), _stream())
     _lib.call("snerf_mip_encode", _p(s_vals), _p(origins), _p(directions), _p(radii), _p(near), _p(far), n, P - 1,
               1 if cone else 0, transform_idx, max_deg, _p(dst1), dst1.stride(0), _p(dst2),
               0 if dst2 is None else dst2.stride(0), width, _p(_f32c(means_out)), _p(_f32c(covs_out)), dt, _p(ids), rows, _stream())

@@ -78,6 +78,7 @@ class Model(_ArenaModule):
     dilation_bias: float = 0.0025
     num_glo_features: int = 0
     near_anneal_rate = None
+    near_anneal_init: float = 0.95
     resample_padding: float = 0.0
     opaque_background: bool = False
     power_lambda: float = -1.5
@@ -94,11 +95,12 @@ class Model(_ArenaModule):
             setattr(self, k, v)
         self.config = config
         if self.raydist_fn != 'power_transformation':
+            # (the class default 'contract' of the reference, models.py:40, cannot run there either: coord.construct_ray_warps falls
+            # through to `fn.__name__` on the string -- AttributeError; configs/waymo.gin binds 'power_transformation')
             raise NotImplementedError("accelerated zipnerf Model: raydist_fn='power_transformation' (configs/waymo.gin)")
         if (self.num_levels != 3 or len(self.num_prop_samples) != 2 or self.num_glo_features or not self.distinct_prop or self.single_mlp
-                or self.near_anneal_rate is not None or not self.stop_level_grad or not self.use_viewdirs
-                or self.bg_intensity_range[0] != self.bg_intensity_range[1]):
-            raise NotImplementedError("accelerated zipnerf Model: 2 distinct proposal MLPs + NeRF MLP, no GLO / near annealing")
+                or not self.stop_level_grad or not self.use_viewdirs or self.bg_intensity_range[0] != self.bg_intensity_range[1]):
+            raise NotImplementedError("accelerated zipnerf Model: 2 distinct proposal MLPs + NeRF MLP, no GLO")
         # semantic head (Config.use_semantic -> NerfMLP.use_semantic, models.py:66,297-305,594-597): 19-class softmax of x[..., 1:20]
         self.scattered_rays = False      # set True when inference batches are random pixels rather than image rows (a locality hint only)
         self.use_semantic = bool(use_semantic or (config is not None and getattr(config, "use_semantic", False)))
@@ -192,7 +194,10 @@ class Model(_ArenaModule):
         bx, by = f(batch['base_x']), f(batch['base_y'])
         radii, near, far = f(batch['radii']).reshape(-1), f(batch['near']).reshape(-1), f(batch['far']).reshape(-1)
         R = o.shape[0]
-        sdist = torch.cat([torch.zeros(R, 1, device=dev), torch.ones(R, 1, device=dev)], -1)
+        # near-bound annealing (models.py:47-48, 147-158): the first interval is [clip(1 - train_frac / rate, 0, init), 1]; its length
+        # scales the dilation (:170-171) and it is the domain of the dilation / resampling clamps (:182-186, :207-213)
+        s_near = 0.0 if self.near_anneal_rate is None else float(min(max(1.0 - train_frac / self.near_anneal_rate, 0.0), self.near_anneal_init))
+        sdist = torch.cat([torch.full((R, 1), s_near, device=dev), torch.ones(R, 1, device=dev)], -1)
         weights = torch.ones(R, 1, device=dev)
         anneal = self._anneal(train_frac)
         bg = float(self.bg_intensity_range[0])
@@ -201,12 +206,12 @@ class Model(_ArenaModule):
         for lvl in range(3):
             is_prop = lvl < 2
             ns = self.num_prop_samples[lvl] if is_prop else self.num_nerf_samples
-            dilation = self.dilation_bias + self.dilation_multiplier * 1.0 / prod
+            dilation = self.dilation_bias + self.dilation_multiplier * (1.0 - s_near) / prod
             prod *= ns
             use_dilation = (self.dilation_bias > 0 or self.dilation_multiplier > 0) and lvl > 0
             u, degj = draws[lvl]
             sdist, tdist = ops.zip_resample(sdist, weights.detach(), u, ns, near, far, dilation, use_dilation, anneal, self.resample_padding,
-                                            self.power_lambda)
+                                            self.power_lambda, dom=(s_near, 1.0))
             e, net = self.encs[lvl], self.nets[lvl]
             P = R * ns
             if is_prop and not keep and sample_n <= 8 and e.L <= 16:

@@ -104,9 +104,11 @@ def classic_embed(pts, viewdirs, S, L, Lv, dst1, dst2, w_pts, dstv, w_views, dt)
 
 
 def mip_encode(s_vals, origins, directions, radii, near, far, cone, transform_idx, max_deg, dst1, dst2, width, dt,
-               means_out=None, covs_out=None, sample_id=None):
+               means_out=None, covs_out=None, sample_id=None, warp=None):
     assert sample_id is None, "compacted rows are an inference-only GPU mode"
-    fm, fc = om.sample2enc(s_vals, origins, directions, radii[:, None], near[:, None], far[:, None], "cone" if cone else "cylinder", transform_idx)
+    kw = {} if warp is None else dict(fn_idx=0, viewc=torch.tensor(warp[0]))
+    assert warp is None or float(warp[1]) == float(far.max())
+    fm, fc = om.sample2enc(s_vals, origins, directions, radii[:, None], near[:, None], far[:, None], "cone" if cone else "cylinder", transform_idx, **kw)
     enc = om.integrated_pos_enc(fm, fc, 0, max_deg).reshape(-1, 6 * max_deg)
     v = torch.cat([enc, torch.zeros(enc.shape[0], width - enc.shape[1])], -1)
     if dt == 4:

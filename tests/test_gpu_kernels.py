@@ -190,6 +190,29 @@ def test_mip_encode(ops, golden, shape):
     assert bool((out[:, 16 + 96:16 + 100] == 0).all()) and bool((out[:, :16] == 5).all()) and bool((out[:, 116:] == 5).all())
 
 
+@pytest.mark.parametrize("shape", ["cone", "cylinder"])
+def test_mip_encode_view_centred_warp(ops, golden, shape):
+    """snerf_mip_encode_warp, fn_idx = 0 (mip.py:367-378: fn1 + Jacobi_f): warped means / covariance diagonal against the reference's own
+    output (g23) and the IPE features against the oracle."""
+    g = golden("g23_warp0")
+    n, P = g["s_vals"].shape
+    S = P - 1
+    args = [dev(g[k]).contiguous() for k in ("s_vals", "rays_origins", "rays_directions")] + [dev(g[k]).reshape(-1).contiguous() for k in ("rays_radii", "rays_near", "rays_far")]
+    out = torch.full((n * S, 100), 5.0, dtype=torch.float32, device="cuda")
+    mo = torch.empty(n * S, 3, device="cuda"); co = torch.empty(n * S, 3, device="cuda")
+    warp = (tuple(float(v) for v in g["viewc"]), args[5].max().reshape(1))
+    ops.mip_encode(*args, shape == "cone", 0, 16, out, None, 100, ops.F32, means_out=mo, covs_out=co, warp=warp)
+    want_c = torch.diagonal(g[shape + "_f_covs"], dim1=-2, dim2=-1)
+    close(mo.reshape(n, S, 3), g[shape + "_f_means"], 2e-6, 2e-6, "means vs reference")
+    close(co.reshape(n, S, 3), want_c, 5e-5, float(want_c.abs().max()) * 1e-6, "cov diagonal vs reference")
+    enc = om.integrated_pos_enc(g[shape + "_f_means"], want_c, 0, 16).reshape(n * S, 96)
+    got = out[:, :96].cpu()
+    for deg in range(16):
+        cols = [deg * 3 + d for d in range(3)] + [48 + deg * 3 + d for d in range(3)]
+        close(got[:, cols], enc[:, cols], 0, 3e-6 * 2 ** deg + 1e-6, f"IPE degree {deg}")
+    assert bool((out[:, 96:] == 0).all())
+
+
 def test_mip_encode_ipe_exact_inputs(ops, golden):
     """IPE stage alone: feed means/covs that survive the sampler unchanged (|x| < 3 region is x/3 ... not exact), so instead
     check the bf16 path against the fp32 path of the same kernel."""

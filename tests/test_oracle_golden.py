@@ -44,6 +44,25 @@ def test_g3_sample2enc(golden):
     close(mip.contract_jacobian(b["x"]), b["J"], 1e-6, 1e-7)
 
 
+def test_g23_view_centred_warp(golden):
+    """`fn = 0` (mip.py:367-378: fn1 + Jacobi_f around viewc): the restated sample2enc against the reference's means and FULL warped
+    covariances for both ray shapes, and mipnerf_forward(fn_idx=0) against the reference model's outputs."""
+    g = golden("g23_warp0")
+    rays = {k[len("rays_"):]: v for k, v in g.items() if k.startswith("rays_")}
+    for shape in ("cone", "cylinder"):
+        fm, fc = mip.sample2enc(g["s_vals"], rays["origins"], rays["directions"], rays["radii"], rays["near"], rays["far"], shape, 0,
+                                full_cov=True, fn_idx=0, viewc=g["viewc"])
+        close(fm, g[shape + "_f_means"], 1e-6, 1e-6)
+        close(fc, g[shape + "_f_covs"], 1e-5, float(g[shape + "_f_covs"].abs().max()) * 1e-6)
+    from oracle import common
+    names = [str(k) for k in g["param_names"]]
+    sd = common.fill_state_dict_({k: torch.empty(tuple(g["grad." + k].shape)) for k in names})
+    ref = mip.mipnerf_forward(sd, rays, 16, 17, fn_idx=0, viewc=g["viewc"])
+    close(ref[1][0], g["l1_rgb"], 1e-5, 1e-6); close(ref[1][1], g["l1_distance"], 1e-5, 1e-5)
+    close(ref[1][2], g["l1_acc"], 1e-5, 1e-6); close(ref[0][1], g["l0_distance"], 1e-5, 1e-5)
+    close(ref[1][4], g["l1_s_vals"], 1e-5, 1e-6)
+
+
 def test_g4_ipe(golden):
     g = golden("g4_ipe")
     e = mip.integrated_pos_enc(g["means"], g["cov_diag"], 0, 16)

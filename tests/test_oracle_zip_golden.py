@@ -68,6 +68,21 @@ def test_g11_model_forward(golden):
     close(rend[-1]["rgb"], g["rand_rgb"], 1e-5, 1e-5, "rand rgb"); close(rend[-1]["depth"], g["rand_depth"], 1e-5, 1e-5, "rand depth")
 
 
+def test_g24_near_bound_annealing(golden):
+    """near_anneal_rate (models.py:47-48, 147-158, 170-171, 182-186, 207-213): first interval [clip(1 - train_frac / rate, 0, init), 1]."""
+    g = golden("g24_zip_near_anneal")
+    specs, p = zip_setup()
+    batch = {k[2:]: v for k, v in g.items() if k.startswith("b_")}
+    for tag, first in (("a", 0.6), ("b", 0.95)):
+        rend, hist = oz.model_forward(p, specs, batch, train_frac=float(g[tag + "_train_frac"]), near_anneal_rate=float(g["near_anneal_rate"]),
+                                      near_anneal_init=float(g["near_anneal_init"]))
+        assert abs(float(hist[0]["sdist"][0, 0]) - first) < 1e-6
+        for lvl in range(3):
+            close(hist[lvl]["sdist"], g[f"{tag}_sdist{lvl}"], 1e-5, 1e-6, f"{tag} sdist {lvl}")
+            close(hist[lvl]["weights"], g[f"{tag}_weights{lvl}"], 1e-4, 1e-6, f"{tag} weights {lvl}")
+        close(rend[-1]["rgb"], g[tag + "_rgb"], 1e-5, 1e-5, tag + " rgb"); close(rend[-1]["depth"], g[tag + "_depth"], 1e-5, 1e-5, tag + " depth")
+
+
 def test_g11_model_forward_with_semantic_head(golden):
     """use_semantic: softmax(x[..., 1:20]) of the density network, composited with the detached weights (models.py:594-597,
     render.py:237-241) -- against the reference Model run with the semantic head enabled."""

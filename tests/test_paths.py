@@ -362,6 +362,38 @@ def test_mipnerf_appearance_embedding_vs_reference_golden(backend, golden, compu
     assert float(g["grad.emb.weight"].abs().sum()) > 0
 
 
+@pytest.mark.parametrize("compute", ["f32", "bf16"])
+def test_mipnerf_view_centred_warp_vs_reference_golden(backend, golden, compute):
+    """MipNerfModel(fn=0): the view-centred warp (mip.py:367-378: fn1 + Jacobi_f, viewc = mean camera centre) instead of the
+    contraction -- outputs and every parameter gradient against the reference model's own (g23); pose refinement is refused."""
+    g = golden("g23_warp0")
+    from snerf_amd import mipnerf
+    m = mipnerf.MipNerfModel(n_samples=16, N_fine=17, no_warp_sample=0, ray_shape="cone", fn=0, radius=3., transform_idx=0, real=True,
+                             rgb_layer=3, hidden_layer=64, density_noise=0., max_deg_point=16, proposal_hidden_layer=64,
+                             proposal_loss=True, compute=compute, device=DEV)
+    names = [str(k) for k in g["param_names"]]
+    assert list(m.state_dict().keys()) == names
+    sd = common.fill_state_dict_({k: torch.empty(tuple(g["grad." + k].shape)) for k in names})
+    m.load_state_dict(sd)
+    rays = mipnerf.Rays(**{k[len("rays_"):]: v.to(DEV) for k, v in g.items() if k.startswith("rays_")})
+    ret = m(rays, False, False, g["viewc"])
+    loss = ((ret[1][0] - g["target"].to(DEV)) ** 2).mean() + 0.01 * ret[0][1].mean() + 0.05 * (1.0 / ret[1][1]).mean()
+    loss.backward()
+    tol = 1e-4 if compute == "f32" else 3e-2
+    close(ret[1][0], g["l1_rgb"], tol, tol * 0.1, "rgb"); close(ret[1][1], g["l1_distance"], tol, tol, "distance")
+    close(ret[1][2], g["l1_acc"], tol, tol * 0.1, "acc"); close(loss, g["loss"], tol, tol * 1e-2, "loss")
+    if compute == "f32":
+        close(ret[1][4], g["l1_s_vals"], 1e-4, 1e-5, "fine fence posts")
+        named = dict(m.named_parameters())
+        for k in names:
+            got, want = named[k].grad.detach().cpu(), g["grad." + k]
+            rel = float((got - want).norm() / (want.norm() + 1e-20))
+            assert rel < 5e-3, (k, rel)
+    o = rays.origins.clone().requires_grad_(True)
+    with pytest.raises(NotImplementedError, match="pose refinement"):
+        m(rays._replace(origins=o), False, False, g["viewc"])
+
+
 def test_mipnerf_ray_gradients_vs_autograd(backend):
     """Pose refinement (configs/nuScenes_depth_6cams: pose_refine = True; utils/sample_utils.py:410-435): origins, directions and
     viewdirs are functions of a learnable camera pose.  d loss / d rays through both levels (encoders, contraction + Jacobian, lifted

@@ -79,6 +79,24 @@ def test_zip_model_vs_reference_golden(backend, golden, compute, table, tol):
         close(rend[-1]["rgb"], g["rand_rgb"], tol, tol, "rand rgb"); close(rend[-1]["depth"], g["rand_depth"], tol, tol, "rand depth")
 
 
+def test_zip_near_bound_annealing_vs_reference_golden(backend, golden):
+    """Model.near_anneal_rate (models.py:47-48, 147-158): the sampling domain starts at clip(1 - train_frac / rate, 0, near_anneal_init)
+    -- fence posts of all three levels, weights, colour and depth against the reference Model's own (g24), fp32."""
+    g = golden("g24_zip_near_anneal")
+    specs, p = zip_setup()
+    batch = {k[2:]: v.to(DEV) for k, v in g.items() if k.startswith("b_")}
+    m = make_model("f32", "f32", p)
+    m.near_anneal_rate, m.near_anneal_init = float(g["near_anneal_rate"]), float(g["near_anneal_init"])
+    for tag in ("a", "b"):
+        with torch.no_grad():
+            rend, hist = m(None, batch, float(g[tag + "_train_frac"]), False)
+        close(hist[0]["sdist"], g[tag + "_sdist0"], 1e-5, 1e-6, tag + " sdist level 0")
+        for lvl in (1, 2):
+            close(hist[lvl]["sdist"], g[f"{tag}_sdist{lvl}"], 2e-4, 2e-5, f"{tag} sdist level {lvl}")
+        close(hist[2]["weights"], g[tag + "_weights2"], 2e-3, 2e-5, tag + " weights")
+        close(rend[-1]["rgb"], g[tag + "_rgb"], 2e-4, 2e-4, tag + " rgb"); close(rend[-1]["depth"], g[tag + "_depth"], 2e-4, 2e-4, tag + " depth")
+
+
 @pytest.mark.parametrize("compute,table,tol", [("f32", "f32", 2e-4), ("bf16", "f16", 3e-2)])
 def test_zip_semantic_head_vs_reference_golden(backend, golden, compute, table, tol):
     """Config.use_semantic: the 19-class distribution rendered by the reference Model (golden) and the unchanged colour."""
