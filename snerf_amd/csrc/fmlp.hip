@@ -96,11 +96,29 @@ __device__ __forceinline__ void ws_issue(WStream& w, char* smem) {
 #ifndef FM_EXTRA_VM
 #define FM_EXTRA_VM 0
 #endif
+// FM_SKEW = 1: the second wave of every SIMD (waves FM_WAVES / 2 ..) runs HALF A CHUNK behind the first -- it takes the barrier of a
+// chunk boundary when its own read-ahead is in the middle of a chunk -- so that the two waves of a SIMD reach their block ends (the
+// vector-ALU / LDS / store work between two MFMA runs) half a block apart instead of together, one wave's MFMAs covering the other's
+// epilogue.  The barrier count per tile is unchanged; the lagging waves still read the chunk the leaders just finished, so the slot
+// refilled at a boundary is the one TWO chunks back (one chunk less read-ahead).  Measured (round 3, 6.3 M rows, A/B/A/B on one box,
+// gpurun_out/r3r): training forward 10.0 -> 9.7 ms, classic gradient chain 11.1 -> 11.2 ms, inference and the colour head unchanged,
+// the same with waves w / w + 1 as partners -- the epilogues are NOT what the MFMA pipe waits for; the training kernels sit between
+// their compute time (5.7 ms) and the time a plain fill of their 30.6 GB takes (6.5 ms) without overlapping the two well.  Off.
+#ifndef FM_SKEW
+#define FM_SKEW 0
+#endif
+template <int RING>
+__device__ __forceinline__ void ws_sync_issue(WStream& w, char* smem) {
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(2 * (RING - 2 - FM_SKEW) + FM_EXTRA_VM) : "memory");
+  ws_issue<RING>(w, smem);                              // chunk g + RING - 1 (- FM_SKEW) into the slot chunk g - 1 (- FM_SKEW) occupied
+}
+__device__ __forceinline__ void ws_cross(WStream& w, int ring) {
+  w.slot_off = w.slot_off + FM_SLOT == ring * FM_SLOT ? 0 : w.slot_off + FM_SLOT;
+}
 template <int RING>
 __device__ __forceinline__ void ws_advance(WStream& w, char* smem) {
-  asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(2 * (RING - 2) + FM_EXTRA_VM) : "memory");
-  ws_issue<RING>(w, smem);                              // chunk g + RING - 1 into the slot chunk g - 1 occupied
-  w.slot_off = w.slot_off + FM_SLOT == RING * FM_SLOT ? 0 : w.slot_off + FM_SLOT;
+  ws_sync_issue<RING>(w, smem);
+  ws_cross(w, RING);
 }
 
 // ---- building blocks -----------------------------------------------------------------------------------------------------------
@@ -112,6 +130,7 @@ struct CtxT {
   const char* frag_base;   // ring + lane * 16
   const char* bias_lds;    // bias table + (lane >> 5) * 16
   bf16x8 q[FM_LOOK];       // the next FM_LOOK fragments, already on their way from LDS
+  bool lag;                // FM_SKEW: this wave takes the chunk barriers half a chunk late (wave-uniform)
 };
 typedef CtxT<FM_RING> Ctx;
 
@@ -124,7 +143,16 @@ template <int F, typename C>
 __device__ __forceinline__ bf16x8 next_frag(C& c) {
   const bf16x8 w = c.q[F % FM_LOOK];
   constexpr int G = F + FM_LOOK;
-  if constexpr ((G % FM_CHUNK) == 0) ws_advance<C::ring>(c.ws, c.smem);
+  if constexpr (FM_SKEW) {
+    if constexpr ((G % FM_CHUNK) == 0) {
+      if (!c.lag) ws_sync_issue<C::ring>(c.ws, c.smem);
+      ws_cross(c.ws, C::ring);
+    } else if constexpr ((G % FM_CHUNK) == FM_CHUNK / 2) {
+      if (c.lag) ws_sync_issue<C::ring>(c.ws, c.smem);
+    }
+  } else if constexpr ((G % FM_CHUNK) == 0) {
+    ws_advance<C::ring>(c.ws, c.smem);
+  }
   c.q[F % FM_LOOK] = *(const bf16x8*)(c.frag_base + c.ws.slot_off + (G % FM_CHUNK) * 1024);
   return w;
 }
@@ -369,11 +397,15 @@ __device__ __forceinline__ void ctx_start(C& c, char* smem, const char* wstream,
   c.ws.n_chunks = n_chunks;
   c.frag_base = smem + lane * 16;
   c.bias_lds = (const char*)bias_tab + (lane >> 5) * 16;
+#ifndef FM_SKEW_BIT
+#define FM_SKEW_BIT (FM_WAVES / 2)                      // waves w and w + FM_WAVES / 2 share a SIMD (round-robin placement)
+#endif
+  c.lag = FM_SKEW && (wave & FM_SKEW_BIT) != 0;
 
-  // prologue: biases into LDS (plain stores), the first RING - 1 chunks of the stream into the ring
+  // prologue: biases into LDS (plain stores), the first RING - 1 (- FM_SKEW) chunks of the stream into the ring
   for (int i = tid; i < n_blocks * 32; i += 64 * FM_WAVES) bias_tab[i] = bias[i];
 #pragma unroll
-  for (int i = 0; i < RING - 1; ++i) ws_issue<RING>(c.ws, smem);
+  for (int i = 0; i < RING - 1 - FM_SKEW; ++i) ws_issue<RING>(c.ws, smem);
 #ifdef FMLP_LOCKSTEP_START
   // debug builds (tools/stress_fmlp_variants.py): every DMA of the prologue landed and all eight waves leave it in the same cycle --
   // the start that exposed the timing-dependent operand hazard described at to_frags within a handful of launches

@@ -37,6 +37,7 @@ print(f"fmlp_classic_pts (in-kernel embedding) M={M}: {ms:.3f} ms  {M * 2 * 5934
 # training forward: the same launch + 4864 B / row of activation stores
 acts = [torch.empty(M, 256, device="cuda", dtype=torch.bfloat16) for _ in range(9)] + [torch.empty(M, 128, device="cuda", dtype=torch.bfloat16)]
 bits = [torch.empty(ops.mask_bits_words(M, 256), device="cuda", dtype=torch.int32) for _ in range(8)]
+bits.append(torch.empty(ops.mask_bits_words(M, 128), device="cuda", dtype=torch.int32))       # views_linears.0
 for _ in range(2):
     ops.fmlp_classic_train_fwd(E, VE, net.net.fstream, net.net.fbias, out, acts, bits)
 e0.record()
