@@ -345,7 +345,7 @@ def main():
         for _ in range(5):
             dist.all_reduce(buf)
         barrier()
-        comm = {"collective": "all-reduce(sum) of the flat fp32 gradient arena, one per step, overlapped with the proposal backward",
+        comm = {"collective": "all-reduce(sum) of the flat fp32 gradient arena in per-layer buckets, each started as soon as its layer's weight gradient is final (heads, the eight 4 MB trunk layers, the proposal network), overlapped with the rest of the backward",
                 "backend": "rccl" if args.backend == "nccl" else args.backend, "ranks": world, "bytes": buf.numel() * 4,
                 "allreduce_ms_alone": round((time.perf_counter() - tc) / 5 * 1e3, 3)}
         del buf
