@@ -464,7 +464,9 @@ int snerf_classic_ray_batch(int H, int W, double focal, double cx, double cy, co
  * touches (wg_offsets: uint32 [L, ceil(R*S/256), 1024], need not be initialised); the caller scans the counts into `starts`
  * ([L,1024] int64, exclusive prefix sums over the flattened bins); pass 1 writes the records (rec_row uint16 [capacity], rec_val fp32
  * [capacity, max(C, 2)] -- for C = 1 a record is one 8-byte {row, value} pair in rec_val and rec_row is not touched; capacity >=
- * R*S*n*8*L is always enough); pass 2 accumulates into grad_table (fp32, +=).  ksplit_host: HOST int[L],
+ * R*S*n*8*L is always enough) -- staged per workgroup in LDS and written run by run, so that a store instruction covers consecutive
+ * records of ONE (workgroup, bin) range instead of 64 different lines (n <= 8; pass 3 is the same write with every thread storing its
+ * records where they fall: more than 8 multisamples, A/B probes); pass 2 accumulates into grad_table (fp32, +=).  ksplit_host: HOST int[L],
  * replicas per row range (> 1 for levels with few, hot rows: they meet in g64, an int64 image of table rows [0, g64_rows) zeroed by
  * the caller); level_rows_host: HOST int[L], table rows per level -- a level needs ceil(rows / 4096 or 16384) * ksplit <= 1024 bins,
  * anything larger is refused with a bad-argument status (use snerf_zip_encode_bwd, the atomic scatter). */

@@ -974,6 +974,174 @@ __global__ __launch_bounds__(256) void zip_bin_emit_kernel(ZipEnc a, ZipBin b) {
   }
 }
 
+// PASS 1 with the records STAGED IN LDS (round 3).  Written straight from the emitting threads (kernel above), a workgroup's 16- /
+// 8-byte records go to ~hundreds of bins in thread order: every store instruction touches 64 different lines, partially, and the
+// lines are evicted from L2 long before the workgroup's other records of the same bin arrive -- the NeRF level wrote 27.6 GB for
+// 13.4 GB of records at ~2 TB/s (profiles/r2_j).  Here the workgroup evaluates its 256 intervals ONCE (cell, fractions and erf weight of
+// every multisample kept in registers), then runs NSUB = 4 sub-passes over corner pairs: the records of a sub-pass are counted per
+// bin (LDS atomics), the counts prefix-summed, the records formed a second time and placed at offset[bin] + slot (a second round of
+// the same atomics hands out the slots) of a 32 KB staging area as {row-in-bin | bin | thread, weight sum}, and streamed out in that
+// order -- consecutive lanes write consecutive records of ONE (workgroup, bin) run.  The value = weight sum x the interval's feature
+// gradient is formed on the way out from a 4 KB table of the workgroup's gradients.  Same records (bit for bit) in the ranges pass 0
+// reserved; only their order inside a run differs, which the fixed-point accumulation does not see.  53 KB of LDS and 155 registers:
+// three workgroups per CU -- occupancy decides here: measured per NeRF-level launch (65 536 rays, gpurun_out/r3v) direct writer 11.05
+// ms; 4 sub-passes 7.26 ms; 8 sub-passes (121 registers, four workgroups, half the run length) 9.06; 2 sub-passes (85 KB: one
+// workgroup per CU, twice the run length) 10.87; 4 sub-passes with the records kept in registers between count and placement (202
+// registers: two workgroups) 8.37.  What it can buy is bounded by the run length: a hashed level of 2^21 rows has 512 row ranges, a
+// workgroup's 3 584 records of a sub-pass make runs of ~7 records (112 B) -- nine runs per store instruction instead of 64 lines.
+// The single-channel proposal grids (8-byte records, 128 row ranges) are faster with the direct writer (4.5 vs 5.4 ms per level).
+#define ZS_NMAX 8
+__device__ __forceinline__ int zs_wave_incl_scan(int v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int u = __shfl_up(v, o, 64);
+    if (lane >= o) v += u;
+  }
+  return v;
+}
+
+template <typename OT, int C, int NSUB>
+__global__ __launch_bounds__(256, NSUB == 8 ? 4 : 3) void zip_bin_write_staged_kernel(ZipEnc a, ZipBin b) {
+  constexpr int CPS = 8 / NSUB;                       // corners per sub-pass
+  __shared__ int cnt[ZB_NBMAX];
+  __shared__ int off[ZB_NBMAX];
+  __shared__ long base[ZB_NBMAX];
+  __shared__ uint2 stage[256 * ZS_NMAX * CPS];
+  __shared__ float gtab[256 * C];
+  __shared__ int wtot[4];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int level = blockIdx.y;
+  const long p = (long)blockIdx.x * 256 + tid;
+  const bool live = p < a.R * a.S;
+  const unsigned* wgo1 = b.wg_offsets + ((long)level * gridDim.x + blockIdx.x) * ZB_NBMAX;
+  for (int k = tid; k < ZB_NBMAX; k += 256) {      // (entries of bins this workgroup does not touch are garbage and never used)
+    base[k] = b.starts[level * ZB_NBMAX + k] + (long)wgo1[k];
+    cnt[k] = 0;
+  }
+  const uint32_t hs = a.offsets[level + 1] - a.offsets[level];
+  const float scale = exp2f(level * a.Sl) * a.H - 1.0f;
+  const uint32_t res = (uint32_t)ceilf(scale) + 1;
+  const int K = b.ksplit[level], rep = (int)(blockIdx.x % (unsigned)K);
+  const unsigned rmask = (1u << b.bshift) - 1u;
+  // ---- the interval's multisamples, once
+  uint32_t pg[ZS_NMAX][3];
+  float fr[ZS_NMAX][3], we[ZS_NMAX];
+  unsigned inb = 0, ends = 0;                       // bit j: multisample j is inside the grid / is the last of its run of equal cells
+  if (live) {
+    const long ray = p / a.S;
+    const int i = (int)(p - ray * a.S);
+    const float t0 = a.tdist[ray * (a.S + 1) + i], t1 = a.tdist[ray * (a.S + 1) + i + 1];
+    float o[3], d[3], bx[3], by[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { o[k] = a.origins[ray * 3 + k]; d[k] = a.directions[ray * 3 + k]; bx[k] = a.base_x[ray * 3 + k]; by[k] = a.base_y[ray * 3 + k]; }
+    const float rad = a.radii[ray];
+    const OT* gi = (const OT*)a.feat + p * a.ld + level * C;
+#pragma unroll
+    for (int c = 0; c < C; ++c) gtab[tid * C + c] = (float)gi[c] / (float)a.n;
+    const float gs = (float)a.grid_sizes[level];
+    int prev = -1;
+#pragma unroll
+    for (int j = 0; j < ZS_NMAX; ++j) {
+      if (j >= a.n) break;
+      float x01[3], sd;
+      zip_sample_point(a, ray, i, j, t0, t1, o, d, bx, by, rad, x01, &sd);
+      if (x01[0] < 0.f || x01[0] > 1.f || x01[1] < 0.f || x01[1] > 1.f || x01[2] < 0.f || x01[2] > 1.f) continue;
+      inb |= 1u << j;
+      we[j] = erff(1.f / sqrtf(8.f * sd * sd * gs * gs));
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float ps = x01[k] * scale + 0.5f;
+        const float fl = floorf(ps);
+        pg[j][k] = (uint32_t)fl;
+        fr[j][k] = ps - fl;
+      }
+      // the previous in-bounds multisample ends its run here if the cell changes (the merging of zip_emit_level)
+#pragma unroll
+      for (int q = 0; q < ZS_NMAX; ++q)
+        if (q == prev && (pg[q][0] != pg[j][0] || pg[q][1] != pg[j][1] || pg[q][2] != pg[j][2])) ends |= 1u << q;
+      prev = j;
+    }
+    if (prev >= 0) ends |= 1u << prev;
+  } else {
+#pragma unroll
+    for (int c = 0; c < C; ++c) gtab[tid * C + c] = 0.f;
+  }
+  __syncthreads();
+  // one record of the sub-pass: corner (e, y, z) of the run that ends at multisample j, weight sum r
+  auto record = [&](int j, int e, int y, int z, float r, bool place) __attribute__((always_inline)) {
+    const uint32_t pl[3] = {pg[j][0] + (uint32_t)e, pg[j][1] + (uint32_t)y, pg[j][2] + (uint32_t)z};
+    const uint32_t row = zip_grid_index(hs, res, pl);
+    const int bin = (int)(row >> b.bshift) * K + rep;
+    const int slot = atomicAdd(cnt + bin, 1);         // count phase: the count; place phase: the slot inside the bin's run (any order will do)
+    if (place) stage[off[bin] + slot] = uint2{(row & rmask) | ((unsigned)bin << 14) | ((unsigned)tid << 24), __float_as_uint(r)};
+  };
+  // the records of corners [sp CPS, sp CPS + CPS) (corner = x + 2 y + 4 z) of this thread's interval; same products in the same order
+  // as zip_emit_level: w = 1; w *= (x ? fr0 : 1 - fr0); w *= (y ? fr1 : 1 - fr1); w *= (z ? fr2 : 1 - fr2); wsum += w * we
+  auto walk = [&](int sp, bool place) __attribute__((always_inline)) {
+    float r[CPS];
+#pragma unroll
+    for (int q = 0; q < CPS; ++q) r[q] = 0.f;
+#pragma unroll
+    for (int j = 0; j < ZS_NMAX; ++j) {
+      if (!((inb >> j) & 1u)) continue;
+#pragma unroll
+      for (int q = 0; q < CPS; ++q) {
+        const int idx = sp * CPS + q;
+        float w = 1.f;
+        w *= (idx & 1) ? fr[j][0] : 1.f - fr[j][0];
+        w *= (idx & 2) ? fr[j][1] : 1.f - fr[j][1];
+        w *= (idx & 4) ? fr[j][2] : 1.f - fr[j][2];
+        r[q] += w * we[j];
+      }
+      if ((ends >> j) & 1u) {
+#pragma unroll
+        for (int q = 0; q < CPS; ++q) { const int idx = sp * CPS + q; record(j, idx & 1, (idx >> 1) & 1, idx >> 2, r[q], place); r[q] = 0.f; }
+      }
+    }
+  };
+  for (int z = 0; z < NSUB; ++z) {                    // sub-pass z: CPS corners
+    walk(z, false);
+    __syncthreads();
+    // exclusive prefix of the 1024 counts: thread t owns bins 4 t .. 4 t + 3 (and zeroes them for the placement counters)
+    const int c0 = cnt[4 * tid], c1 = cnt[4 * tid + 1], c2 = cnt[4 * tid + 2], c3 = cnt[4 * tid + 3];
+    const int mine = c0 + c1 + c2 + c3;
+    const int incl = zs_wave_incl_scan(mine, lane);
+    if (lane == 63) wtot[wv] = incl;
+    cnt[4 * tid] = 0; cnt[4 * tid + 1] = 0; cnt[4 * tid + 2] = 0; cnt[4 * tid + 3] = 0;
+    __syncthreads();
+    int pre = incl - mine;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) if (q < wv) pre += wtot[q];
+    const int total = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    off[4 * tid] = pre; off[4 * tid + 1] = pre + c0; off[4 * tid + 2] = pre + c0 + c1; off[4 * tid + 3] = pre + c0 + c1 + c2;
+    __syncthreads();
+    walk(z, true);
+    __syncthreads();
+    for (int sidx = tid; sidx < total; sidx += 256) {
+      const uint2 rec = stage[sidx];
+      const int bin = (int)((rec.x >> 14) & 1023u);
+      const long r = base[bin] + (sidx - off[bin]);
+      if (r < b.capacity) {
+        const unsigned lrow = rec.x & 0x3fffu;
+        const float wsum = __uint_as_float(rec.y);
+        const float* g = gtab + (rec.x >> 24) * C;
+        if constexpr (C == 1) {
+          const uint2 rv = {lrow, __float_as_uint(wsum * g[0])};
+          *(uint2*)(b.rec_val + r * 2) = rv;
+        } else {
+          b.rec_row[r] = (unsigned short)lrow;
+          const f32x4 v4 = {wsum * g[0], wsum * g[1], wsum * g[2], wsum * g[3]};
+          *(f32x4*)(b.rec_val + r * 4) = v4;
+        }
+      }
+    }
+    __syncthreads();
+    base[4 * tid] += c0; base[4 * tid + 1] += c1; base[4 * tid + 2] += c2; base[4 * tid + 3] += c3;
+    cnt[4 * tid] = 0; cnt[4 * tid + 1] = 0; cnt[4 * tid + 2] = 0; cnt[4 * tid + 3] = 0;
+    __syncthreads();
+  }
+}
+
 template <int C>
 __global__ __launch_bounds__(1024) void zip_bin_accumulate_kernel(ZipEnc a, ZipBin b) {
   extern __shared__ long long zb_acc[];
@@ -1117,11 +1285,16 @@ extern "C" int snerf_zip_encode_bwd_binned(int pass, const float* tdist, const f
   b.scale_exp = scale_exp;
   hipStream_t s = (hipStream_t)stream;
   const dim3 blk(256);
-  if (pass == 0 || pass == 1) {
-    if (grad_feat == nullptr || wg_offsets == nullptr || (pass == 1 && (starts == nullptr || rec_row == nullptr || rec_val == nullptr)))
+  if (pass == 0 || pass == 1 || pass == 3 || pass == 4) {
+    if (grad_feat == nullptr || wg_offsets == nullptr || (pass != 0 && (starts == nullptr || rec_row == nullptr || rec_val == nullptr)))
       return SNERF_ERR_ARG;
     const dim3 grid((unsigned)((R * S + 255) / 256), L);
+    // pass 1: records staged in LDS and written run by run (zip_bin_write_staged_kernel); pass 3 (A/B probes, or more than 8
+    // multisamples): every thread writes its records where they fall
+    // (C = 1: 8-byte records in 128 row ranges per level -- the direct writer is faster there: 4.6 vs 5.8 ms per proposal level)
+    const bool staged = ((pass == 1 && C == 4) || pass == 4) && n <= ZS_NMAX;     // (pass 4: probe -- staged for C = 1 too)
 #define ZBE(OT, CC) do { if (pass == 0) hipLaunchKernelGGL((zip_bin_emit_kernel<OT, CC, 0>), grid, blk, 0, s, a, b); \
+                         else if (staged) hipLaunchKernelGGL((zip_bin_write_staged_kernel<OT, CC, 4>), grid, blk, 0, s, a, b); \
                          else hipLaunchKernelGGL((zip_bin_emit_kernel<OT, CC, 1>), grid, blk, 0, s, a, b); } while (0)
     if (feat_dtype == SNERF_DT_BF16) { if (C == 4) ZBE(__bf16, 4); else ZBE(__bf16, 1); }
     else if (feat_dtype == SNERF_DT_F32) { if (C == 4) ZBE(float, 4); else ZBE(float, 1); }

@@ -709,6 +709,10 @@ def _zb_workspace(dev, key, numel, dtype):
     return t
 
 
+import os as _os
+ZIP_BIN_STAGED = _os.environ.get("SNERF_ZIP_UNSTAGED", "") == ""      # (the environment switch: A/B runs of tools/bench_zip.py)
+
+
 def zip_encode_bwd_binned(tdist, origins, directions, radii, base_x, base_y, deg_jitter, offsets, grid_sizes, grad_feat, grad_table, L, C, n, m, Sl, H,
                           std_scale, ksplit, g64_rows, level_rows):
     """The table gradient of zip_encode_bwd without L2 atomics on the hashed levels and bit-reproducible: records binned by destination,
@@ -736,7 +740,10 @@ def zip_encode_bwd_binned(tdist, origins, directions, radii, base_x, base_y, deg
     capacity = R * S * n * 8 * L                               # every (interval, level) emits at most n cells x 8 corners: no host sync
     rec_row = _zb_workspace(dev, "row", capacity, torch.int16)
     rec_val = _zb_workspace(dev, "val", capacity * max(C, 2), torch.float32)       # C = 1: {row, value} pairs in one 8-byte record
-    _lib.call("snerf_zip_encode_bwd_binned", 1, *args, _p(counts), _p(wgo), _p(starts), _p(rec_row), _p(rec_val), capacity, None, 0, None, _stream())
+    # pass 1: the records staged in LDS and written run by run; ZIP_BIN_STAGED = False (A/B probes, tests): pass 3, every thread
+    # writes its records where they fall (same records, another order inside a (workgroup, bin) run)
+    _lib.call("snerf_zip_encode_bwd_binned", 1 if ZIP_BIN_STAGED else 3, *args, _p(counts), _p(wgo), _p(starts), _p(rec_row), _p(rec_val), capacity,
+              None, 0, None, _stream())
     g64 = torch.zeros(max(g64_rows, 1) * C, dtype=torch.int64, device=dev) if g64_rows > 0 else None
     _lib.call("snerf_zip_encode_bwd_binned", 2, *args, _p(counts), _p(wgo), _p(starts), _p(rec_row), _p(rec_val), capacity, _p(g64), int(g64_rows),
               _p(scale), _stream())

@@ -600,6 +600,12 @@ def test_zip_table_gradient_binned_is_exact_and_bit_reproducible(lvl, gscale, mo
         ops.zip_encode_bwd_binned(*common, gt, *tail, ks, g64_rows, lrows)
         outs.append(gt)
     assert torch.equal(outs[0], outs[1]), "binned table gradient must be bit-reproducible"
+    # the LDS-staged record writer (default) and the direct one produce the same records in another order: identical sums
+    monkeypatch.setattr(ops, "ZIP_BIN_STAGED", False)
+    gd = torch.zeros(e.rows, e.C, device="cuda")
+    ops.zip_encode_bwd_binned(*common, gd, *tail, ks, g64_rows, lrows)
+    monkeypatch.setattr(ops, "ZIP_BIN_STAGED", True)
+    assert torch.equal(outs[0], gd), "staged and direct record writers must give bit-identical gradients"
     rel = float((outs[0] - ref).norm() / ref.norm())
     print(f"MEASURED binned vs atomic table gradient (grid {lvl}): rel L2 {rel:.3e}, K per level {ks}")
     assert float(ref.norm()) > 0 and rel < 2e-6, rel
