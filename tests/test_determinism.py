@@ -62,3 +62,74 @@ def test_small_persistent_gemm_launches_are_bit_reproducible():
             ops.linear_fwd(A, W, b, Y, K, N, ops.ACT_RELU, ops.BF16, variant=8)
             return [Y]
         assert _repeat(fn, 150, big) == 0, (M, N, K)
+
+
+def test_round3_fused_kernels_are_bit_reproducible():
+    """The fused colour head (forward / data-gradient chain) and the fused gradient chains of the 256-wide networks issue their
+    input loads, bit-mask prefetches and LDS atomics by hand with hand-counted s_waitcnt (the compiler would drain the weight stream in
+    front of each): a miscounted wait shows up as a rare, timing-dependent wrong value.  Everything these launches STORE must be
+    bit-identical run to run, with a vendor GEMM interleaved; only the chains' bias gradients (LDS atomics in arrival order) are exempt
+    and are held to rounding instead."""
+    from snerf_amd import ops
+    from snerf_amd.mlp import ClassicNeRFNet, MipNerfNet, MipProposalNet, ParamArena
+    torch.manual_seed(2)
+    dev = torch.device("cuda")
+    big = torch.randn(2048, 2048, device="cuda").bfloat16()
+
+    def rnd(shapes):
+        return {k: (torch.randn(s) * (1.4 / s[-1] ** 0.5) if len(s) == 2 else torch.randn(s) * 0.1) for k, s in shapes}
+    # ---- colour head (M not a multiple of the 256-row tile)
+    M, H = 5000, 1024
+    shapes = [("mlp." + n, s) for n, s in MipNerfNet.param_shapes(H, 8, 4, 96, 27, 3, 128)]
+    arena = ParamArena(shapes, dev); arena.load(rnd(shapes))
+    net = MipNerfNet(arena, "mlp.", ops.BF16, H)
+    assert net.colour_fused_ok()
+    SKIP, CB = net.alloc_inputs(M)
+    SKIP.zero_(); CB.zero_()
+    SKIP[:, H:H + 96] = (torch.rand(M, 96, device=dev) * 2 - 1).bfloat16()
+    CB[:, H:H + 27] = (torch.rand(M, 27, device=dev) * 2 - 1).bfloat16()
+    d_rgb, d_den = torch.randn(M, 3, device=dev), torch.randn(M, 1, device=dev)
+
+    def colour():
+        raw_rgb, raw_d, saved = net.forward(SKIP, CB, True)
+        arena.grad.zero_()
+        net.backward(d_rgb, d_den, saved)
+        names = ["mlp.cond_layers.0.layers.0.bias", "mlp.cond_layers.1.layers.0.bias", "mlp.cond_layers.2.layers.0.bias", "mlp.bottleneck_layer.layers.0.bias"]
+        return [raw_rgb] + [arena.g[k].clone() for k in names]
+    net.deterministic = True                                       # fixed-order weight-gradient folds: every stored value is reproducible
+    assert _repeat(colour, 150, big) == 0
+    # ---- gradient chains: everything they store (dz of every layer) must repeat exactly
+    for kind in ("classic", "proposal"):
+        M = 3000
+        if kind == "classic":
+            shp = ClassicNeRFNet.param_shapes(8, 256, 63, 27, (4,))
+            ar = ParamArena(shp, dev); ar.load(rnd(shp))
+            nn_ = ClassicNeRFNet(ar, "", ops.BF16, 8, 256)
+            pts = torch.rand(M, 3, device=dev) * 2 - 1
+            vd = torch.nn.functional.normalize(torch.randn(M // 8, 3, device=dev), dim=-1)
+            raw, saved = nn_.forward(pts, vd, 8, True)
+            d_raw = torch.randn(M, 4, device=dev)
+            widths, bits, net_id = [128] + [256] * 9, saved[5], ops.CHAIN_CLASSIC
+        else:
+            shp = MipProposalNet.param_shapes(256, 4, 96)
+            ar = ParamArena(shp, dev); ar.load(rnd(shp))
+            nn_ = MipProposalNet(ar, "", ops.BF16, 256, 4, 96)
+            E = torch.zeros(M, nn_.Ew, dtype=torch.bfloat16, device=dev)
+            E[:, :96] = (torch.rand(M, 96, device=dev) * 2 - 1).bfloat16()
+            out, acts = nn_.forward(E, True)
+            d_raw = torch.randn(M, 1, device=dev)
+            widths, bits, net_id = [256] * 4, nn_._chain_bits[1], ops.CHAIN_PROPOSAL
+        stream = nn_._chain_stream()
+        gb0 = None
+
+        def chain():
+            dz = [torch.empty(M, w, dtype=torch.bfloat16, device=dev) for w in widths]
+            gb = [torch.zeros(w, device=dev) for w in widths]
+            ops.fchain_bwd(net_id, d_raw, stream, bits, dz, gb)
+            nonlocal gb0
+            if gb0 is None:
+                gb0 = [g.clone() for g in gb]
+            for g, g0 in zip(gb, gb0):                             # bias gradients: same sums, arrival order of the LDS atomics varies
+                assert float((g - g0).abs().max()) <= 1e-5 * float(g0.abs().max()) + 1e-12
+            return dz
+        assert _repeat(chain, 200, big) == 0, kind
