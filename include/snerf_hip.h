@@ -476,6 +476,20 @@ int snerf_zip_encode_bwd_binned(int pass, const float* tdist, const float* origi
                                 int m, float Sl, int H, float std_scale, int feat_dtype, const int* ksplit_host, const int* level_rows_host,
                                 int* counts, void* wg_offsets, const long* starts, void* rec_row, float* rec_val, long capacity, void* g64,
                                 long g64_rows, const int* scale_exp, void* stream);
+/* out[c] += sum over the M rows of x[m, c] (fp32, any number of columns C <= ld): the bias gradients behind the per-ray rows of the GLO
+ * branch (snerf_colsum_f32 serves the heads: C <= 8).  deterministic != 0: one fixed summation order. */
+int snerf_colsum_wide_f32(const float* x, long ld, long M, int C, float* out, int deterministic, void* stream);
+/* GLO modulation of the zipnerf NeRF MLP's bottleneck (internal/models.py:620-630; Model.num_glo_features > 0, configs/360_glo*.gin):
+ * out[p, c] = X[p, c] * exp(SS[p / S, c]) + SS[p / S, B + c] for the B bottleneck columns of the R * S samples; SS [R, >= 2 B] fp32 =
+ * (scale | shift) per ray, the output of lin_glo_0 / lin_glo_1 on the ray's GLO vector.  X / out in `dtype` (fp32 or bf16).
+ * _bwd: dXm = d loss / d out -> dX = dXm * exp(scale) + d_head (fp32 [R * S, >= n_head]: gradients that enter columns < n_head of x
+ * directly -- raw density and the semantic logits, models.py:511,594), dSS [R, >= 2 B] = (sum_s dXm * X * exp(scale) | sum_s dXm), and
+ * dxsum [R, >= B] = per-ray column sums of the stored dX (their sum over the rays is the bias gradient of density_layer.2).  One
+ * workgroup per ray, samples in order: deterministic. */
+int snerf_zip_glo_modulate(const void* X, long ldx, const float* SS, long ldss, long R, int S, int B, void* out, long ldo, int dtype, void* stream);
+int snerf_zip_glo_modulate_bwd(const void* dXm, long lddxm, const void* X, long ldx, const float* SS, long ldss, const float* d_head, long ldh,
+                               int n_head, long R, int S, int B, void* dX, long lddx, float* dSS, long lddss, float* dxsum, long ldsum,
+                               int dtype, void* stream);
 /* The fixed-point scale of one binned launch: scale_exp (device int[2]) [0] = e such that 2^e * max |grad_feat[:rows, :cols]| lies in
  * [2^33, 2^34) -- the accumulation grid follows the magnitude of the gradient (a loss-scaled 1e-12 gradient keeps 34 bits below its
  * largest entry); pass 2 reads it. */

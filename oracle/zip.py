@@ -176,14 +176,24 @@ def pos_enc(x, min_deg, max_deg, append_identity=True):
 
 
 def mlp_forward(p, prefix, spec, means, stds, viewdirs, disable_rgb, deg_view=1, density_bias=-1.0, rgb_padding=0.001,
-                net_depth_viewdirs=2, skip_layer_dir=0, use_semantic=False, class_num=19):
+                net_depth_viewdirs=2, skip_layer_dir=0, use_semantic=False, class_num=19, glo_vec=None, net_depth_glo=2):
     """MLP.forward (models.py:521-714) on the waymo.gin branch.  Returns dict(density, rgb, semantic); with `use_semantic`
-    semantic = softmax(x[..., 1:1+class_num]) of the density network's output (models.py:594-597), else None."""
+    semantic = softmax(x[..., 1:1+class_num]) of the density network's output (models.py:594-597), else None.  `glo_vec` [R, F]
+    (num_glo_features > 0, models.py:620-630): the per-ray GLO vector goes through lin_glo_0 (ReLU) .. lin_glo_{depth-1} to a
+    (scale, shift) pair that modulates the bottleneck, bottleneck * exp(scale) + shift, before the view-dependent layers."""
     raw_density, x = predict_density(p, prefix, spec, means, stds)
     density = F.softplus(raw_density + density_bias)
     if disable_rgb:
         return dict(density=density, rgb=torch.zeros(density.shape + (3,)), semantic=None)
     sem = torch.softmax(x[..., 1:1 + class_num], -1) if use_semantic else None
+    if glo_vec is not None:
+        g = glo_vec
+        for i in range(net_depth_glo):
+            g = F.linear(g, p[prefix + f"lin_glo_{i}.weight"], p[prefix + f"lin_glo_{i}.bias"])
+            if i != net_depth_glo - 1:
+                g = F.relu(g)
+        scale, shift = torch.broadcast_to(g[..., None, :], x.shape[:-1] + g.shape[-1:]).chunk(2, dim=-1)
+        x = x * torch.exp(scale) + shift
     dir_enc = pos_enc(viewdirs, 0, deg_view, True)
     dir_enc = torch.broadcast_to(dir_enc[..., None, :], x.shape[:-1] + (dir_enc.shape[-1],))
     h = torch.cat([x, dir_enc], dim=-1)
@@ -242,13 +252,18 @@ def volumetric_rendering(rgbs, weights, tdist, bg_rgbs=1.0, semantic=None, compu
 def model_forward(p, specs, batch, num_prop_samples=(64, 64), num_nerf_samples=32, train_frac=1.0, anneal_slope=10.0,
                   dilation_multiplier=0.5, dilation_bias=0.0025, power_lambda=-1.5, std_scale=0.35, jitters=None,
                   deg_jitters=None, bg=1.0, use_semantic=False, compute_extras=False, vis_num_rays=16, sdist_override=None,
-                  near_anneal_rate=None, near_anneal_init=0.95):
+                  near_anneal_rate=None, near_anneal_init=0.95, num_glo_features=0, zero_glo=True):
     """Model.forward (models.py:98-349) with rand=None (jitters None) or explicit draws; `use_semantic`: the final level also
     renders the 19-class semantic distribution (models.py:297-305).  `specs` = [prop0, prop1, nerf]
     GridSpec; parameter names follow the reference's state_dict (`prop_mlp_0.encoder.embeddings`, `nerf_mlp.rgb_layer.weight`...).
     `compute_extras`: acc / distance_* per level and the first `vis_num_rays` rays' ray_sdist / ray_weights / ray_rgbs, the proposal
     levels' ray_rgbs replaced by the final level's average colour (models.py:316-346).
     Returns (renderings, ray_history) with the reference's keys (rgb, depth / sdist, weights, tdist)."""
+    # GLO (models.py:131-139): the embedding row of every ray's camera, or zeros (`zero_glo`, the default of Model.forward)
+    glo_vec = None
+    if num_glo_features > 0:
+        glo_vec = (torch.zeros(batch["origins"].shape[:-1] + (num_glo_features,)) if zero_glo
+                   else p["glo_vecs.weight"][batch["cam_idx"][..., 0].long()])
     near, far = batch["near"], batch["far"]
     # near-bound annealing (models.py:147-158): the first interval starts at clip(1 - train_frac / rate, 0, init) instead of 0
     s_near = 0.0 if near_anneal_rate is None else float(np.clip(1 - train_frac / near_anneal_rate, 0, near_anneal_init))
@@ -278,7 +293,8 @@ def model_forward(p, specs, batch, num_prop_samples=(64, 64), num_nerf_samples=3
         means, stds = cast_rays(tdist, batch["origins"], batch["directions"], batch["radii"], batch["base_x"], batch["base_y"],
                                 None if deg_jitters is None else deg_jitters[lvl], std_scale=std_scale)
         prefix = f"prop_mlp_{lvl}." if is_prop else "nerf_mlp."
-        res = mlp_forward(p, prefix, specs[lvl], means, stds, batch["viewdirs"], disable_rgb=is_prop, use_semantic=use_semantic and not is_prop)
+        res = mlp_forward(p, prefix, specs[lvl], means, stds, batch["viewdirs"], disable_rgb=is_prop, use_semantic=use_semantic and not is_prop,
+                          glo_vec=None if is_prop else glo_vec)
         weights = compute_alpha_weights(res["density"], tdist, batch["directions"], True)
         renderings.append(volumetric_rendering(res["rgb"], weights, tdist, bg, semantic=res["semantic"], compute_extras=compute_extras, t_far=far))
         if compute_extras:
@@ -292,14 +308,18 @@ def model_forward(p, specs, batch, num_prop_samples=(64, 64), num_nerf_samples=3
     return renderings, history
 
 
-def param_shapes(specs, bottleneck=256, width_view=256, deg_view=1):
+def param_shapes(specs, bottleneck=256, width_view=256, deg_view=1, num_glo_features=0, num_glo_embeddings=1000, net_width_glo=128, zero_glo=True):
     """Ordered (name, shape) of the reference Model's learnable parameters on the waymo.gin branch
-    (models.py:393-479; nerf_mlp registered first, then prop_mlp_0, prop_mlp_1)."""
+    (models.py:393-479; nerf_mlp registered first, then prop_mlp_0, prop_mlp_1; with num_glo_features > 0 the NeRF MLP has lin_glo_0 /
+    lin_glo_1 in front of its second stage (:454-459) and, unless config.zero_glo, the model ends with glo_vecs (:75-77))."""
     dim_dir = 3 + 6 * deg_view
     nerf = specs[2]
+    glo = [] if num_glo_features <= 0 else [
+        ("nerf_mlp.lin_glo_0.weight", (net_width_glo, num_glo_features)), ("nerf_mlp.lin_glo_0.bias", (net_width_glo,)),
+        ("nerf_mlp.lin_glo_1.weight", (2 * bottleneck, net_width_glo)), ("nerf_mlp.lin_glo_1.bias", (2 * bottleneck,))]
     out = [("nerf_mlp.encoder.embeddings", (nerf.rows, nerf.C)),
            ("nerf_mlp.density_layer.0.weight", (64, nerf.L * nerf.C)), ("nerf_mlp.density_layer.0.bias", (64,)),
-           ("nerf_mlp.density_layer.2.weight", (bottleneck, 64)), ("nerf_mlp.density_layer.2.bias", (bottleneck,)),
+           ("nerf_mlp.density_layer.2.weight", (bottleneck, 64)), ("nerf_mlp.density_layer.2.bias", (bottleneck,))] + glo + [
            ("nerf_mlp.lin_second_stage_0.weight", (width_view, bottleneck + dim_dir)), ("nerf_mlp.lin_second_stage_0.bias", (width_view,)),
            ("nerf_mlp.lin_second_stage_1.weight", (width_view, width_view + bottleneck + dim_dir)), ("nerf_mlp.lin_second_stage_1.bias", (width_view,)),
            ("nerf_mlp.rgb_layer.weight", (3, width_view)), ("nerf_mlp.rgb_layer.bias", (3,))]
@@ -308,4 +328,6 @@ def param_shapes(specs, bottleneck=256, width_view=256, deg_view=1):
         out += [(f"prop_mlp_{i}.encoder.embeddings", (s.rows, s.C)),
                 (f"prop_mlp_{i}.density_layer.0.weight", (64, s.L * s.C)), (f"prop_mlp_{i}.density_layer.0.bias", (64,)),
                 (f"prop_mlp_{i}.density_layer.2.weight", (1, 64)), (f"prop_mlp_{i}.density_layer.2.bias", (1,))]
+    if num_glo_features > 0 and not zero_glo:
+        out.append(("glo_vecs.weight", (num_glo_embeddings, num_glo_features)))
     return out

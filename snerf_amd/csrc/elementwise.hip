@@ -177,6 +177,30 @@ extern "C" int snerf_colsum_f32(const float* x, long ld, long M, int C, float* o
   return snerf_check_launch();
 }
 
+// out[c] += sum_m x[m, c] for ANY number of columns (the per-ray gradient rows of the GLO modulation: 256 / 512 columns): a thread per
+// column (coalesced rows), the rows split over blockIdx.y chunks that meet in fp32 atomics; one chunk = a fixed order (deterministic).
+__global__ __launch_bounds__(256) void colsum_wide_kernel(const float* __restrict__ x, long ld, long M, int C, long rows_per_chunk, float* __restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const long r0 = (long)blockIdx.y * rows_per_chunk, r1 = r0 + rows_per_chunk < M ? r0 + rows_per_chunk : M;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  long r = r0;
+  for (; r + 3 < r1; r += 4) { s0 += x[r * ld + c]; s1 += x[(r + 1) * ld + c]; s2 += x[(r + 2) * ld + c]; s3 += x[(r + 3) * ld + c]; }
+  for (; r < r1; ++r) s0 += x[r * ld + c];
+  const float s = (s0 + s1) + (s2 + s3);
+  if (gridDim.y == 1) out[c] += s; else atomicAdd(out + c, s);
+}
+
+extern "C" int snerf_colsum_wide_f32(const float* x, long ld, long M, int C, float* out, int deterministic, void* stream) {
+  if (M <= 0) return SNERF_OK;
+  if (x == nullptr || out == nullptr || C < 1 || ld < C) return SNERF_ERR_ARG;
+  long chunks = deterministic ? 1 : (M + 255) / 256;
+  chunks = chunks > 256 ? 256 : chunks;
+  const long rpc = (M + chunks - 1) / chunks;
+  hipLaunchKernelGGL(colsum_wide_kernel, dim3((C + 255) / 256, (unsigned)chunks), dim3(256), 0, (hipStream_t)stream, x, ld, M, C, rpc, out);
+  return snerf_check_launch();
+}
+
 // dst[m, c] (T, ld_dst) = src[m, c] (fp32, ld_src) for c < C; zero for C <= c < Cpad.
 template <typename T>
 __global__ __launch_bounds__(256) void cast_pad_kernel(const float* __restrict__ src, long ld_src, long M, int C, int Cpad, T* __restrict__ dst,

@@ -1318,6 +1318,84 @@ extern "C" int snerf_zip_encode_bwd_binned(int pass, const float* tdist, const f
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// GLO modulation of the NeRF MLP's bottleneck (internal/models.py:620-630, num_glo_features > 0: configs/360_glo*.gin): the per-ray
+// (scale, shift) pair SS [R, 2 B] -- the output of lin_glo_0 / lin_glo_1 on the ray's GLO vector -- applied to the B bottleneck
+// columns of every sample of the ray: xm = x * exp(scale) + shift.  Backward (one workgroup per ray, a thread per column, the ray's
+// samples in order: deterministic): d x = d xm * exp(scale) + d head (the raw-density / semantic-logit gradients that enter x
+// directly, columns < n_head), d scale = sum_s d xm * x * exp(scale), d shift = sum_s d xm, and the per-ray column sums of d x (the
+// bias gradient of density_layer.2 is their sum over the rays).
+// ------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void zip_glo_modulate_kernel(const T* __restrict__ X, long ldx, const float* __restrict__ SS, long ldss, int S, long P,
+                                                              int B, T* __restrict__ out, long ldo) {
+  const long total = P * B;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long p = e / B;
+    const int c = (int)(e - p * B);
+    const float* ss = SS + (p / S) * ldss;
+    out[p * ldo + c] = from_f32<T>(to_f32(X[p * ldx + c]) * expf(ss[c]) + ss[B + c]);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void zip_glo_modulate_bwd_kernel(const T* __restrict__ dXm, long lddxm, const T* __restrict__ X, long ldx,
+                                                                  const float* __restrict__ SS, long ldss, const float* __restrict__ d_head, long ldh,
+                                                                  int n_head, int S, int B, T* __restrict__ dX, long lddx, float* __restrict__ dSS,
+                                                                  long lddss, float* __restrict__ dxsum, long ldsum) {
+  const long ray = blockIdx.x;
+  for (int c = threadIdx.x; c < B; c += 256) {
+    const float e = expf(SS[ray * ldss + c]);
+    float gs = 0.f, gh = 0.f, gx = 0.f;
+    for (int i = 0; i < S; ++i) {
+      const long p = ray * S + i;
+      const float g = to_f32(dXm[p * lddxm + c]);
+      gs += (g * to_f32(X[p * ldx + c])) * e;
+      gh += g;
+      float dx = g * e;
+      if (c < n_head) dx += d_head[p * ldh + c];
+      const T o = from_f32<T>(dx);
+      dX[p * lddx + c] = o;
+      gx += to_f32(o);
+    }
+    dSS[ray * lddss + c] = gs;
+    dSS[ray * lddss + B + c] = gh;
+    dxsum[ray * ldsum + c] = gx;
+  }
+}
+
+extern "C" int snerf_zip_glo_modulate(const void* X, long ldx, const float* SS, long ldss, long R, int S, int B, void* out, long ldo, int dtype,
+                                      void* stream) {
+  if (R <= 0) return SNERF_OK;
+  if (X == nullptr || SS == nullptr || out == nullptr || S <= 0 || B <= 0 || ldx < B || ldo < B || ldss < 2 * B) return SNERF_ERR_ARG;
+  const long P = R * S;
+  const long blocks = (P * B + 255) / 256;
+  const dim3 grid((unsigned)(blocks < 65536 * 8 ? blocks : 65536 * 8));
+  if (dtype == SNERF_DT_F32) hipLaunchKernelGGL(zip_glo_modulate_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)X, ldx, SS, ldss, S, P, B, (float*)out, ldo);
+  else if (dtype == SNERF_DT_BF16) hipLaunchKernelGGL(zip_glo_modulate_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16*)X, ldx, SS, ldss, S, P, B, (__bf16*)out, ldo);
+  else return SNERF_ERR_ARG;
+  return snerf_check_launch();
+}
+
+extern "C" int snerf_zip_glo_modulate_bwd(const void* dXm, long lddxm, const void* X, long ldx, const float* SS, long ldss, const float* d_head,
+                                          long ldh, int n_head, long R, int S, int B, void* dX, long lddx, float* dSS, long lddss, float* dxsum,
+                                          long ldsum, int dtype, void* stream) {
+  if (R <= 0) return SNERF_OK;
+  if (dXm == nullptr || X == nullptr || SS == nullptr || dX == nullptr || dSS == nullptr || dxsum == nullptr || S <= 0 || B <= 0 || n_head < 0 ||
+      n_head > B || (n_head > 0 && (d_head == nullptr || ldh < n_head)) || lddxm < B || ldx < B || lddx < B || ldss < 2 * B || lddss < 2 * B ||
+      ldsum < B || R >= (1L << 31))
+    return SNERF_ERR_ARG;
+  const dim3 grid((unsigned)R), blk(256);
+  if (dtype == SNERF_DT_F32)
+    hipLaunchKernelGGL(zip_glo_modulate_bwd_kernel<float>, grid, blk, 0, (hipStream_t)stream, (const float*)dXm, lddxm, (const float*)X, ldx, SS, ldss, d_head,
+                       ldh, n_head, S, B, (float*)dX, lddx, dSS, lddss, dxsum, ldsum);
+  else if (dtype == SNERF_DT_BF16)
+    hipLaunchKernelGGL(zip_glo_modulate_bwd_kernel<__bf16>, grid, blk, 0, (hipStream_t)stream, (const __bf16*)dXm, lddxm, (const __bf16*)X, ldx, SS, ldss,
+                       d_head, ldh, n_head, S, B, (__bf16*)dX, lddx, dSS, lddss, dxsum, ldsum);
+  else return SNERF_ERR_ARG;
+  return snerf_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Featurisation backward to the RAYS (pose refinement: `cal_input_grad`, internal/models.py:491, gridencoder/grid.py:65-89,
 // gridencoder.cu:199-244 + 343-369 (dy_dx, kernel_input_backward); zipnerf/train.py:187-197 re-poses origins / directions / base_x /
 // base_y with a learnable pose and back-propagates through the whole renderer).  One thread per interval, all levels: for each of

@@ -1058,22 +1058,29 @@ class ZipPropNet(_Net):
 
 
 class ZipNerfNet(_Net):
-    """NerfMLP on the waymo.gin branch (internal/models.py:425-427, 462-479, 481-519, 586-703; deg_view = 1, no GLO):
+    """NerfMLP on the waymo.gin branch (internal/models.py:425-427, 462-479, 481-519, 586-703; deg_view = 1):
     features 40 -> 64 ReLU -> 256 (x: channel 0 = raw density, all 256 = bottleneck); [x | dir_enc 9] -> 256 ReLU,
     cat([., x, dir_enc]) (skip_layer_dir = 0) -> 256 ReLU -> rgb 3.
-    Buffer SB [P, 256 + 256 + Dw] = [lin0 output | x | dir_enc (+pad)]: lin0 reads columns 256.. in place, lin1 the whole row."""
+    Buffer SB [P, 256 + 256 + Dw] = [lin0 output | x | dir_enc (+pad)]: lin0 reads columns 256.. in place, lin1 the whole row.
+    `glo_dim` > 0 (Model.num_glo_features, models.py:454-459, 620-630): the ray's GLO vector -> lin_glo_0 (ReLU) -> lin_glo_1 -> (scale,
+    shift) and the second stage reads x * exp(scale) + shift: SB's x block then holds the MODULATED bottleneck, the unmodulated x
+    (raw density, semantic logits, the operand of density_layer.2's weight gradient) lives in its own buffer."""
 
-    def __init__(self, arena, prefix, dt, feat_dim=40, hidden=64, bottleneck=256, width=256, dir_dim=9, variant=8):
+    def __init__(self, arena, prefix, dt, feat_dim=40, hidden=64, bottleneck=256, width=256, dir_dim=9, variant=8, glo_dim=0, glo_width=128):
         super().__init__(arena, prefix, dt, variant)
         assert self.km == 1, "split-bf16 (compute='bf16x3') is built for the mip path's networks"
         assert hidden % self.g == 0 and bottleneck % self.g == 0 and width % self.g == 0
         self.fd, self.H, self.Bw, self.Wd, self.dd = feat_dim, hidden, bottleneck, width, dir_dim
         self.Fw, self.Dw = roundup(feat_dim, self.g), roundup(dir_dim, self.g)
+        self.gd, self.Gh, self.Gw = glo_dim, glo_width, roundup(max(glo_dim, 1), self.g)
+        assert glo_dim == 0 or (glo_width % self.g == 0 and (2 * bottleneck) % 128 == 0)
 
     @staticmethod
-    def param_shapes(feat_dim=40, hidden=64, bottleneck=256, width=256, dir_dim=9):
+    def param_shapes(feat_dim=40, hidden=64, bottleneck=256, width=256, dir_dim=9, glo_dim=0, glo_width=128):
+        glo = [] if glo_dim <= 0 else [("lin_glo_0.weight", (glo_width, glo_dim)), ("lin_glo_0.bias", (glo_width,)),
+                                       ("lin_glo_1.weight", (2 * bottleneck, glo_width)), ("lin_glo_1.bias", (2 * bottleneck,))]
         return [("density_layer.0.weight", (hidden, feat_dim)), ("density_layer.0.bias", (hidden,)),
-                ("density_layer.2.weight", (bottleneck, hidden)), ("density_layer.2.bias", (bottleneck,)),
+                ("density_layer.2.weight", (bottleneck, hidden)), ("density_layer.2.bias", (bottleneck,))] + glo + [
                 ("lin_second_stage_0.weight", (width, bottleneck + dir_dim)), ("lin_second_stage_0.bias", (width,)),
                 ("lin_second_stage_1.weight", (width, width + bottleneck + dir_dim)), ("lin_second_stage_1.bias", (width,)),
                 ("rgb_layer.weight", (3, width)), ("rgb_layer.bias", (3,))]
@@ -1090,6 +1097,9 @@ class ZipNerfNet(_Net):
         self._pack_fwd("lin0", "lin_second_stage_0", [(0, 0, B + dd)], B + self.Dw)
         self._pack_fwd("lin1", "lin_second_stage_1", [(0, 0, Wd + B + dd)], Wd + B + self.Dw)
         self._pack_fwd("rgb", "rgb_layer", [(0, 0, Wd)], Wd)
+        if self.gd:
+            self._pack_fwd("glo0", "lin_glo_0", [(0, 0, self.gd)], self.Gw)
+            self._pack_fwd("glo1", "lin_glo_1", [(0, 0, self.Gh)], self.Gh)
         if train:
             self._pack_dgrad("rgb", ["rgb_layer"], 0, Wd)
             self._pack_dgrad("lin1a", ["lin_second_stage_1"], 0, Wd)          # columns that multiply lin0's output
@@ -1108,17 +1118,35 @@ class ZipNerfNet(_Net):
             self.tw["xcat"] = out
             # gradient w.r.t. the view-direction encoding (pose refinement): both second-stage layers read it, one K-concatenated GEMM
             self._pack_dgrad_cols("denc", [("lin_second_stage_0", B), ("lin_second_stage_1", Wd + B)], dd)
+            if self.gd:
+                self._pack_dgrad("glo1", ["lin_glo_1"], 0, self.Gh)
+                self._pack_dgrad_cols("gloin", [("lin_glo_0", 0)], self.gd)       # d loss / d GLO vector (the embedding rows' gradient)
 
     def alloc(self, M):
         """-> (F, SB): the featurisation kernel writes F[:, :feat_dim] (F arrives zeroed), the view encoder SB[:, Wd+B:]."""
         return torch.zeros(M, self.Fw, dtype=self.tdt, device=self.dev), self.buf(M, self.Wd + self.Bw + self.Dw)
 
-    def forward(self, Fb, SB, keep):
+    def forward(self, Fb, SB, keep, glo=None, S=0):
+        """`glo` [R, Gw] (compute dtype, zero padded): the rays' GLO vectors, R = rows / S -- required iff glo_dim > 0.  The returned
+        `x` [M, B] is the density network's (unmodulated) output: column 0 = raw density, columns 1.. = semantic logits."""
         self.ensure_packed(keep)
         M, B, Wd = Fb.shape[0], self.Bw, self.Wd
         H1 = self.buf(M, self.H)
         self.fwd("d0", Fb, self.Fw, H1, self.H)
-        self.fwd("d2", H1, self.H, SB[:, Wd:Wd + B], B, ACT_NONE)
+        glo_saved = None
+        if self.gd:
+            assert glo is not None and S > 0 and glo.shape[0] * S == M and glo.shape[1] == self.Gw
+            X = self.buf(M, B)
+            self.fwd("d2", H1, self.H, X, B, ACT_NONE)
+            G0 = self.buf(glo.shape[0], self.Gh)
+            self.fwd("glo0", glo, self.Gw, G0, self.Gh)
+            SS = self.buf(glo.shape[0], 2 * B, f32=True)
+            self.fwd("glo1", G0, self.Gh, SS, 2 * B, ACT_NONE, out_f32=True)
+            ops.zip_glo_modulate(X, SS, S, SB[:, Wd:Wd + B])
+            glo_saved = (X, glo, G0, SS, S)
+        else:
+            X = SB[:, Wd:Wd + B]
+            self.fwd("d2", H1, self.H, X, B, ACT_NONE)
         raw_d = self.buf(M, 1, f32=True)
         self.fwd("dhead", H1, self.H, raw_d, 1, ACT_NONE, out_f32=True)
         self.fwd("lin0", SB[:, Wd:], B + self.Dw, SB[:, :Wd], Wd)
@@ -1126,12 +1154,14 @@ class ZipNerfNet(_Net):
         self.fwd("lin1", SB, Wd + B + self.Dw, H3, Wd)
         raw_rgb = self.buf(M, 3, f32=True)
         self.fwd("rgb", H3, Wd, raw_rgb, 3, ACT_NONE, out_f32=True)
-        return raw_rgb, raw_d, ((Fb, H1, SB, H3) if keep else None)
+        self.last_x = X
+        return raw_rgb, raw_d, ((Fb, H1, SB, H3, glo_saved) if keep else None)
 
-    def backward(self, d_raw_rgb, d_raw_density, saved, want_dir_grad=False):
-        """-> dF [P, Fw] (or (dF, dD fp32 [P, Dw]) with `want_dir_grad`: the gradient w.r.t. the direction encoding).
+    def backward(self, d_raw_rgb, d_raw_density, saved, want_dir_grad=False, want_glo_grad=False):
+        """-> dF [P, Fw] (or (dF, dD fp32 [P, Dw]) with `want_dir_grad`: the gradient w.r.t. the direction encoding; with
+        `want_glo_grad` additionally d loss / d GLO vectors, fp32 [R, Gw], as the last element).
         d_raw_density [P, 1] or [P, 1 + C]: column 0 = d raw density, columns 1.. = d semantic logits."""
-        Fb, H1, SB, H3 = saved
+        Fb, H1, SB, H3, glo_saved = saved
         M, B, Wd, g = d_raw_rgb.shape[0], self.Bw, self.Wd, self.g
         self.colsum(d_raw_rgb, 3, self.gB("rgb_layer"))
         dz = self.head_grad(d_raw_rgb, 3)
@@ -1142,15 +1172,42 @@ class ZipNerfNet(_Net):
         self.dgrad("lin1a", DZ[:, Wd:2 * Wd], Wd, DZ[:, :Wd], Wd, mask=SB[:, :Wd], colsum=self.gB("lin_second_stage_0"))
         self.wgrad("lin_second_stage_0", DZ[:, :Wd], SB[:, Wd:], Wd, B + self.dd)
         assert d_raw_density.shape[1] <= g
-        ops.cast_pad(d_raw_density, d_raw_density.shape[1], DZ[:, 2 * Wd:], g, self.dt)
         dx = self.buf(M, B)
-        self.dgrad("xcat", DZ, 2 * Wd + g, dx, B, colsum=self.gB("density_layer.2"))
+        d_glo = None
+        if glo_saved is None:
+            ops.cast_pad(d_raw_density, d_raw_density.shape[1], DZ[:, 2 * Wd:], g, self.dt)
+            self.dgrad("xcat", DZ, 2 * Wd + g, dx, B, colsum=self.gB("density_layer.2"))
+        else:
+            # the second stage read the MODULATED bottleneck: d xm first (the same pack without its identity block), then through the
+            # modulation -- d x, d (scale | shift) per ray, and the bias gradient of density_layer.2 from the per-ray column sums
+            X, glo, G0, SS, S = glo_saved
+            DZ[:, 2 * Wd:].zero_()
+            dxm = self.buf(M, B)
+            self.dgrad("xcat", DZ, 2 * Wd + g, dxm, B)
+            dSS, dxsum = ops.zip_glo_modulate_bwd(dxm, X, SS, _f32(d_raw_density), S, dx)
+            ops.colsum_wide_f32(dxsum, B, self.gB("density_layer.2"), deterministic=self.deterministic)
+            R = SS.shape[0]
+            ops.colsum_wide_f32(dSS, 2 * B, self.gB("lin_glo_1"), deterministic=self.deterministic)
+            dS = self.buf(R, 2 * B)
+            ops.cast_pad(dSS, 2 * B, dS, 2 * B, self.dt)
+            self.wgrad("lin_glo_1", dS, G0, 2 * B, self.Gh)
+            dG0 = self.buf(R, self.Gh)
+            self.dgrad("glo1", dS, 2 * B, dG0, self.Gh, mask=G0, colsum=self.gB("lin_glo_0"))
+            self.wgrad("lin_glo_0", dG0, glo, self.Gh, self.gd)
+            if want_glo_grad:
+                d_glo = self.input_grad("gloin", dG0, self.Gh, self.Gw)
+        X = SB[:, Wd:Wd + B] if glo_saved is None else glo_saved[0]
         self.wgrad("density_layer.2", dx, H1, B, self.H)
         dH1 = self.buf(M, self.H)
         self.dgrad("d2", dx, B, dH1, self.H, mask=H1, colsum=self.gB("density_layer.0"))
         self.wgrad("density_layer.0", dH1, Fb, self.H, self.fd)
         dF = self.buf(M, self.Fw)
         self.dgrad("d0", dH1, self.H, dF, self.Fw)
-        if want_dir_grad:
-            return dF, self.input_grad("denc", DZ[:, :2 * Wd], 2 * Wd, self.Dw)
-        return dF
+        out = (dF, self.input_grad("denc", DZ[:, :2 * Wd], 2 * Wd, self.Dw)) if want_dir_grad else (dF,)
+        if want_glo_grad:
+            out = out + (d_glo,)
+        return out[0] if len(out) == 1 else out
+
+
+def _f32(t):
+    return t if t.dtype == torch.float32 else t.float()

@@ -749,6 +749,43 @@ def zip_encode_bwd_binned(tdist, origins, directions, radii, base_x, base_y, deg
               _p(scale), _stream())
 
 
+def colsum_wide_f32(x, C, out, deterministic=False):
+    """out[:C] += x[:, :C].sum(0) for any C (fp32)"""
+    _chk2d(x, torch.float32)
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() >= C and x.shape[1] >= C
+    _lib.call("snerf_colsum_wide_f32", _p(x), x.stride(0), x.shape[0], int(C), _p(out), 1 if deterministic else 0, _stream())
+
+
+def zip_glo_modulate(X, SS, S, out):
+    """out = X * exp(scale) + shift per ray (GLO modulation of the bottleneck, internal/models.py:620-630): X / out [R * S, >= B] in the
+    compute dtype, SS [R, 2 B] fp32 = (scale | shift)"""
+    B = SS.shape[1] // 2
+    _chk2d(X, X.dtype); _chk2d(out, X.dtype); _chk2d(SS, torch.float32)
+    R = SS.shape[0]
+    assert X.shape[0] == R * S == out.shape[0] and X.shape[1] >= B and out.shape[1] >= B and X.dtype in (torch.float32, torch.bfloat16)
+    _lib.call("snerf_zip_glo_modulate", _p(X), X.stride(0), _p(SS), SS.stride(0), R, S, B, _p(out), out.stride(0), F32 if X.dtype == torch.float32 else BF16,
+              _stream())
+
+
+def zip_glo_modulate_bwd(dXm, X, SS, d_head, S, dX):
+    """-> (dSS [R, 2 B] fp32, dxsum [R, B] fp32); writes dX = dXm * exp(scale) (+ d_head in its leading columns)."""
+    B = SS.shape[1] // 2
+    R = SS.shape[0]
+    for t in (dXm, X, dX):
+        _chk2d(t, X.dtype)
+        assert t.shape[0] == R * S and t.shape[1] >= B
+    _chk2d(SS, torch.float32)
+    nh = 0 if d_head is None else d_head.shape[1]
+    if d_head is not None:
+        _chk2d(d_head, torch.float32)
+        assert d_head.shape[0] == R * S and nh <= B
+    dSS = torch.empty(R, 2 * B, dtype=torch.float32, device=X.device)
+    dxsum = torch.empty(R, B, dtype=torch.float32, device=X.device)
+    _lib.call("snerf_zip_glo_modulate_bwd", _p(dXm), dXm.stride(0), _p(X), X.stride(0), _p(SS), SS.stride(0), _p(d_head), 0 if d_head is None else d_head.stride(0),
+              nh, R, S, B, _p(dX), dX.stride(0), _p(dSS), dSS.stride(0), _p(dxsum), dxsum.stride(0), F32 if X.dtype == torch.float32 else BF16, _stream())
+    return dSS, dxsum
+
+
 def zip_composite_fwd(raw_rgb, raw_density, tdist, dirs, opaque, bg, rgb_padding, density_bias):
     _f32c(tdist); _f32c(dirs)
     R, P = tdist.shape

@@ -269,10 +269,12 @@ class ZipTrainer:
             dist.broadcast(self.model.arena.flat, src=src, group=self.pg)
             self.model.arena.bump()
 
-    def step(self, batch, target_rgb, train_frac=1.0, rand=True, aux_loss_fn=None, draws=None, sample_n=7, sample_m=3, targets=None):
+    def step(self, batch, target_rgb, train_frac=1.0, rand=True, aux_loss_fn=None, draws=None, sample_n=7, sample_m=3, targets=None, zero_glo=False):
         """`targets` (all optional, per ray): lossmult [R] (the reference's mask_rgb as 0/1 floats), depth [R] + depth_mask [R]
-        (+ complete_mask [R]), semantic int32 labels [R] + semantic_mask [R]."""
+        (+ complete_mask [R]), semantic int32 labels [R] + semantic_mask [R].  `zero_glo` (models with GLO vectors): train with zero
+        vectors instead of the rows batch['cam_idx'] selects (zipnerf/train.py:235 passes zero_glo=False)."""
         m = self.model
+        m._zero_glo = bool(zero_glo)
         dev = m.arena.flat.device
         R = batch['origins'].shape[0]
         t = targets or {}

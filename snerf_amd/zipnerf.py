@@ -11,7 +11,7 @@ signature, the same ``(renderings, ray_history)`` return layout (keys ``rgb``/``
 
 Accelerated branch = what ``configs/waymo.gin`` + class defaults run: ``raydist_fn='power_transformation'``, distinct proposal
 MLPs with C = 1 grids (desired resolution 512 / 2048), NeRF grid C = 4 (8192), ``disable_density_normals``, ``deg_view = 1``,
-no GLO / exposure / semantic head, ``single_jitter``.  Everything else raises NotImplementedError (no eager fallback).
+optional GLO vectors and semantic head, no exposure scaling, ``single_jitter``.  Everything else raises NotImplementedError (no eager fallback).
 
 Per level: ONE resample launch (dilation + annealed logits + inverse-CDF intervals + s->t warp), ONE fused featurisation launch
 (7-multisample cone casting + contraction + hash-grid gather + erf down-weighting + mean, written into the MLP operand buffer),
@@ -77,6 +77,7 @@ class Model(_ArenaModule):
     dilation_multiplier: float = 0.5
     dilation_bias: float = 0.0025
     num_glo_features: int = 0
+    num_glo_embeddings: int = 1000
     near_anneal_rate = None
     near_anneal_init: float = 0.95
     resample_padding: float = 0.0
@@ -98,9 +99,15 @@ class Model(_ArenaModule):
             # (the class default 'contract' of the reference, models.py:40, cannot run there either: coord.construct_ray_warps falls
             # through to `fn.__name__` on the string -- AttributeError; configs/waymo.gin binds 'power_transformation')
             raise NotImplementedError("accelerated zipnerf Model: raydist_fn='power_transformation' (configs/waymo.gin)")
-        if (self.num_levels != 3 or len(self.num_prop_samples) != 2 or self.num_glo_features or not self.distinct_prop or self.single_mlp
+        if (self.num_levels != 3 or len(self.num_prop_samples) != 2 or not self.distinct_prop or self.single_mlp
                 or not self.stop_level_grad or not self.use_viewdirs or self.bg_intensity_range[0] != self.bg_intensity_range[1]):
-            raise NotImplementedError("accelerated zipnerf Model: 2 distinct proposal MLPs + NeRF MLP, no GLO")
+            raise NotImplementedError("accelerated zipnerf Model: 2 distinct proposal MLPs + NeRF MLP")
+        if getattr(self, "learned_exposure_scaling", False):
+            raise NotImplementedError("learned exposure scaling (RawNeRF, configs/llff_raw.gin) is not built")
+        # GLO (models.py:44-45, 75-77, 131-139; configs/360_glo*.gin): a learned vector per training image modulates the NeRF MLP's
+        # bottleneck; the embedding table exists unless config.zero_glo (then the MLP always sees zeros)
+        self.num_glo_features = int(self.num_glo_features)
+        self.glo_embedding = self.num_glo_features > 0 and not (config is not None and getattr(config, "zero_glo", False))
         # semantic head (Config.use_semantic -> NerfMLP.use_semantic, models.py:66,297-305,594-597): 19-class softmax of x[..., 1:20]
         self.scattered_rays = False      # set True when inference batches are random pixels rather than image rows (a locality hint only)
         self.use_semantic = bool(use_semantic or (config is not None and getattr(config, "use_semantic", False)))
@@ -111,10 +118,12 @@ class Model(_ArenaModule):
                      _Encoder(4, nerf_desired_resolution, 16, grid_log2_hashmap_size)]
         self.names = ["prop_mlp_0.", "prop_mlp_1.", "nerf_mlp."]
         shapes = [("nerf_mlp.encoder.embeddings", (self.encs[2].rows, 4))]
-        shapes += [("nerf_mlp." + n, s) for n, s in ZipNerfNet.param_shapes(self.encs[2].L * 4)]
+        shapes += [("nerf_mlp." + n, s) for n, s in ZipNerfNet.param_shapes(self.encs[2].L * 4, glo_dim=self.num_glo_features)]
         for i in range(2):
             shapes += [(f"prop_mlp_{i}.encoder.embeddings", (self.encs[i].rows, 1))]
             shapes += [(f"prop_mlp_{i}." + n, s) for n, s in ZipPropNet.param_shapes(self.encs[i].L)]
+        if self.glo_embedding:
+            shapes += [("glo_vecs.weight", (int(self.num_glo_embeddings), self.num_glo_features))]      # registered last, as in the reference
         self._setup_arena(shapes, dev)
         self.dt = _dt(compute)
         self.compute = compute
@@ -139,7 +148,7 @@ class Model(_ArenaModule):
             for e in self.encs:
                 ops.zip_bin_plan(e.offsets, e.C, 1)
         self.nets = [ZipPropNet(self.arena, "prop_mlp_0.", self.dt, self.encs[0].L), ZipPropNet(self.arena, "prop_mlp_1.", self.dt, self.encs[1].L),
-                     ZipNerfNet(self.arena, "nerf_mlp.", self.dt, self.encs[2].L * 4)]
+                     ZipNerfNet(self.arena, "nerf_mlp.", self.dt, self.encs[2].L * 4, glo_dim=self.num_glo_features)]
         for n in self.nets:
             n.version_fn = self._param_version
         self._tables, self._tables_version = [None] * 3, -1
@@ -160,6 +169,8 @@ class Model(_ArenaModule):
                 p = self.arena.p[n]
                 if n.endswith("embeddings"):
                     p.uniform_(-init_std, init_std)                                  # grid.py:151-153
+                elif n == "glo_vecs.weight":
+                    p.normal_()                                                      # nn.Embedding
                 elif n.endswith(".weight"):
                     if "lin_second_stage" in n:
                         nn.init.kaiming_uniform_(p)                                  # models.py:464
@@ -239,14 +250,21 @@ class Model(_ArenaModule):
                 raw_rgb = None
             else:
                 ops.mip_viewenc(vd, ns, 1, SB[:, net.Wd + net.Bw:], net.Dw, self.dt)
-                raw_rgb, raw_d, saved = net.forward(Fb, SB, keep)
+                glo = cam = None
+                if self.num_glo_features:
+                    # the rays' GLO vectors: the embedding row of the ray's camera, or zeros (`zero_glo`, Model.forward's default)
+                    glo = torch.zeros(R, net.Gw, dtype=net.tdt, device=dev)
+                    if self.glo_embedding and not getattr(self, "_zero_glo", True):
+                        cam = batch['cam_idx'].detach().to(dev, torch.float32).reshape(R, -1)[:, 0].contiguous()
+                        ops.app_embed(self.arena.p["glo_vecs.weight"], cam, 1, glo, self.dt)
+                raw_rgb, raw_d, saved = net.forward(Fb, SB, keep, glo=glo, S=ns)
             rgb, depth, acc, weights = ops.zip_composite_fwd(raw_rgb, raw_d, tdist, d, self.opaque_background, bg, 0.001, -1.0)
             sem = logits = None
             if self.use_semantic and not is_prop:
-                logits = SB[:, net.Wd + 1:net.Wd + 1 + self.class_num]            # x[..., 1:1+C] of the density network's output
+                logits = net.last_x[:, 1:1 + self.class_num]                       # x[..., 1:1+C] of the density network's output
                 sem = ops.semantic_composite_fwd(weights, logits, self.class_num, True)
             levels.append(dict(sdist=sdist, tdist=tdist, weights=weights, rgb=rgb, depth=depth, acc=acc, raw_rgb=raw_rgb, raw_d=raw_d, saved=saved,
-                               degj=degj, ns=ns, semantic=sem, logits=logits))
+                               degj=degj, ns=ns, semantic=sem, logits=logits, cam=None if is_prop else cam))
         ctx = None
         if keep:   # detached aliases: the originals become outputs of the autograd Function (no graph / reference cycle through ctx)
             det = [{k: (v.detach() if torch.is_tensor(v) else v) for k, v in L.items()} for L in levels]
@@ -293,11 +311,15 @@ class Model(_ArenaModule):
             d_den = d_dl if sem_on else d_den
             if lvl < 2:
                 dF = net.backward(d_den, L["saved"])
-            elif ray_grads:
-                dF, dD = net.backward(d_rgb, d_den, L["saved"], want_dir_grad=True)
-                rg[2] += ops.mip_viewenc_bwd(ctx["vd"], L["ns"], 1, dD)                 # dir_enc = pos_enc(viewdirs, 0, deg_view = 1)
             else:
-                dF = net.backward(d_rgb, d_den, L["saved"])
+                want_glo = L.get("cam") is not None                                     # the embedding rows were looked up: they get a gradient
+                res = net.backward(d_rgb, d_den, L["saved"], want_dir_grad=ray_grads, want_glo_grad=want_glo)
+                res = res if isinstance(res, tuple) else (res,)
+                dF = res[0]
+                if ray_grads:
+                    rg[2] += ops.mip_viewenc_bwd(ctx["vd"], L["ns"], 1, res[1])         # dir_enc = pos_enc(viewdirs, 0, deg_view = 1)
+                if want_glo:
+                    ops.app_embed_bwd(res[-1], L["cam"], 1, self.arena.g["glo_vecs.weight"])
             if ray_grads:
                 ops.zip_encode_ray_bwd(L["tdist"], ctx["o"], ctx["d"], ctx["radii"], ctx["bx"], ctx["by"], L["degj"], self._table(lvl),
                                        self.dev_offsets[lvl], self.dev_sizes[lvl], dF, e.L, e.C, ctx["n"], ctx["m"], e.Sl, e.H, self.std_scale,
@@ -381,6 +403,9 @@ class Model(_ArenaModule):
                                       "the partial gradient the reference would form without the encoder's input gradient is not provided")
         if ray_grad and compute_extras:
             raise NotImplementedError("compute_extras is the rendering mode: no gradients")
+        self._zero_glo = bool(zero_glo)          # (models.py:104,131-139: Model.forward defaults to zeros instead of the embedding rows)
+        if self.num_glo_features and self.glo_embedding and not zero_glo and 'cam_idx' not in batch:
+            raise KeyError("zero_glo=False needs batch['cam_idx']")
         dev = self.arena.flat.device
         R = batch['origins'].shape[0]
         if draws is None:

@@ -315,6 +315,29 @@ def zip_encode_bwd_binned(tdist, origins, directions, radii, base_x, base_y, deg
     zip_encode_bwd(tdist, origins, directions, radii, base_x, base_y, deg_jitter, offsets, grid_sizes, grad_feat, grad_table, L, C, n, m, Sl, H, std_scale)
 
 
+def colsum_wide_f32(x, C, out, deterministic=False):
+    out[:C] += x[:, :C].sum(0)
+
+
+def zip_glo_modulate(X, SS, S, out):
+    B = SS.shape[1] // 2
+    ss = SS.repeat_interleave(S, 0)
+    out[:, :B] = (X[:, :B].float() * torch.exp(ss[:, :B]) + ss[:, B:]).to(out.dtype)
+
+
+def zip_glo_modulate_bwd(dXm, X, SS, d_head, S, dX):
+    B = SS.shape[1] // 2
+    R = SS.shape[0]
+    e = torch.exp(SS[:, :B]).repeat_interleave(S, 0)
+    g = dXm[:, :B].float()
+    dx = g * e
+    if d_head is not None:
+        dx[:, :d_head.shape[1]] += d_head
+    dX[:, :B] = dx.to(dX.dtype)
+    dSS = torch.cat([((g * X[:, :B].float()) * e).view(R, S, B).sum(1), g.view(R, S, B).sum(1)], 1)
+    return dSS, dX[:, :B].float().view(R, S, B).sum(1)
+
+
 def zip_composite_fwd(raw_rgb, raw_density, tdist, dirs, opaque, bg, rgb_padding, density_bias):
     from oracle import zip as oz
     R, P = tdist.shape
@@ -721,7 +744,7 @@ def adam_step_dev(p, g, m, v, lr, b1, b2, eps, step_dev, grad_scale=1.0, zero_gr
     adam_step(p, g, m, v, lr, b1, b2, eps, 0, grad_scale, zero_grad, step_dev=step_dev, **kw)
 
 
-_NAMES = ["fchain_bwd", "app_embed", "app_embed_bwd", "split_cast", "fcolour_fwd", "fcolour_bwd", "gather_pack", "adam_step_dev", "grad_clip_coef", "fmlp_classic_fwd", "fmlp_classic_pts_fwd", "fmlp_proposal_fwd", "fmlp_classic_train_fwd", "fmlp_proposal_train_fwd", "classic_get_rays", "classic_ndc_rays", "classic_ray_batch", "zip_encode_prop_fwd", "mip_encode_bwd", "mip_viewenc_bwd", "hash_decay", "zip_percentiles", "zip_pixels_to_rays", "zip_loss_tail", "semantic_composite_fwd", "semantic_composite_bwd", "zip_resample", "zip_encode_fwd", "zip_encode_bwd", "zip_encode_bwd_binned", "zip_encode_ray_bwd", "zip_composite_fwd", "zip_composite_bwd",
+_NAMES = ["colsum_wide_f32", "zip_glo_modulate", "zip_glo_modulate_bwd", "fchain_bwd", "app_embed", "app_embed_bwd", "split_cast", "fcolour_fwd", "fcolour_bwd", "gather_pack", "adam_step_dev", "grad_clip_coef", "fmlp_classic_fwd", "fmlp_classic_pts_fwd", "fmlp_proposal_fwd", "fmlp_classic_train_fwd", "fmlp_proposal_train_fwd", "classic_get_rays", "classic_ndc_rays", "classic_ray_batch", "zip_encode_prop_fwd", "mip_encode_bwd", "mip_viewenc_bwd", "hash_decay", "zip_percentiles", "zip_pixels_to_rays", "zip_loss_tail", "semantic_composite_fwd", "semantic_composite_bwd", "zip_resample", "zip_encode_fwd", "zip_encode_bwd", "zip_encode_bwd_binned", "zip_encode_ray_bwd", "zip_composite_fwd", "zip_composite_bwd",
           "linear_fwd", "linear_wgrad", "classic_embed", "mip_encode", "mip_viewenc", "classic_sample_pdf", "classic_points",
           "classic_merge_sort", "mip_resample", "stratified", "mip_composite_fwd", "mip_composite_bwd", "classic_composite_fwd",
           "classic_composite_bwd", "adam_step", "colsum_f32", "cast_pad", "pinhole_rays", "mip_loss_tail"]

@@ -83,6 +83,33 @@ def test_g24_near_bound_annealing(golden):
         close(rend[-1]["rgb"], g[tag + "_rgb"], 1e-5, 1e-5, tag + " rgb"); close(rend[-1]["depth"], g[tag + "_depth"], 1e-5, 1e-5, tag + " depth")
 
 
+def test_g25_glo_vectors(golden):
+    """num_glo_features > 0 (models.py:44-45, 75-77, 131-139, 454-459, 620-630): the restated GLO branch -- forward with the embedding rows
+    and with zero_glo, and torch autograd through the oracle against the reference's own parameter gradients (the GLO MLP, the
+    embedding table, the layers around the modulation)."""
+    g = golden("g25_zip_glo")
+    specs, _ = zip_setup()
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("gen_golden_zip", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "gen_golden_zip.py"))
+    gz = importlib.util.module_from_spec(spec); spec.loader.exec_module(gz)
+    Fg, E = int(g["num_glo_features"]), int(g["num_glo_embeddings"])
+    p = gz.formula_params(oz.param_shapes(specs, num_glo_features=Fg, num_glo_embeddings=E, zero_glo=False))
+    p["glo_vecs.weight"], p["nerf_mlp.lin_glo_0.weight"], p["nerf_mlp.lin_glo_1.weight"] = g["glo_vecs"], g["lin_glo_0_weight"], g["lin_glo_1_weight"]
+    batch = {k[2:]: v for k, v in g.items() if k.startswith("b_")}
+    for tag, zero in (("emb", False), ("zero", True)):
+        pp = {k: v.clone().requires_grad_(not k.endswith("embeddings")) for k, v in p.items()}
+        rend, hist = oz.model_forward(pp, specs, batch, train_frac=1.0, num_glo_features=Fg, zero_glo=zero)
+        loss = ((rend[-1]["rgb"] - g["target"]) ** 2).mean() + 0.01 * rend[-1]["depth"].mean()
+        loss.backward()
+        close(rend[-1]["rgb"], g[tag + "_rgb"], 1e-5, 1e-6, tag + " rgb"); close(rend[-1]["depth"], g[tag + "_depth"], 1e-5, 1e-5, tag + " depth")
+        for k in g:
+            if k.startswith(tag + "_grad."):
+                n = k[len(tag) + 6:]
+                got, want = pp[n].grad, g[k]
+                assert float((got - want).norm() / (want.norm() + 1e-30)) < 1e-5, (tag, n)
+    assert float((g["emb_rgb"] - g["zero_rgb"]).abs().max()) > 1e-3          # the embedding rows matter
+
+
 def test_g11_model_forward_with_semantic_head(golden):
     """use_semantic: softmax(x[..., 1:20]) of the density network, composited with the detached weights (models.py:594-597,
     render.py:237-241) -- against the reference Model run with the semantic head enabled."""

@@ -97,6 +97,53 @@ def test_zip_near_bound_annealing_vs_reference_golden(backend, golden):
         close(rend[-1]["rgb"], g[tag + "_rgb"], 2e-4, 2e-4, tag + " rgb"); close(rend[-1]["depth"], g[tag + "_depth"], 2e-4, 2e-4, tag + " depth")
 
 
+@pytest.mark.parametrize("compute", ["f32", "bf16"])
+def test_zip_glo_vectors_vs_reference_golden(backend, golden, compute):
+    """Model(num_glo_features=4) (models.py:44-45, 75-77, 131-139, 454-459, 620-630; configs/360_glo4.gin): per-image GLO vectors ->
+    lin_glo_0 / lin_glo_1 -> (scale, shift) modulation of the NeRF MLP's bottleneck.  Forward with the embedding rows and with zero_glo,
+    state_dict layout, and the parameter gradients the reference's own autograd produced (g25) -- the GLO MLP, the embedding table
+    (only the looked-up rows), the layers on both sides of the modulation."""
+    g = golden("g25_zip_glo")
+    from snerf_amd import zipnerf
+    Fg, E = int(g["num_glo_features"]), int(g["num_glo_embeddings"])
+    specs, _ = zip_setup()
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("gen_golden_zip", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "gen_golden_zip.py"))
+    gz = importlib.util.module_from_spec(spec); spec.loader.exec_module(gz)
+    shapes = oz.param_shapes(specs, num_glo_features=Fg, num_glo_embeddings=E, zero_glo=False)
+    p = gz.formula_params(shapes)
+    p["glo_vecs.weight"], p["nerf_mlp.lin_glo_0.weight"], p["nerf_mlp.lin_glo_1.weight"] = g["glo_vecs"], g["lin_glo_0_weight"], g["lin_glo_1_weight"]
+    m = zipnerf.Model(config=None, raydist_fn='power_transformation', opaque_background=True, compute=compute, table_dtype="f32", device=DEV,
+                      grid_log2_hashmap_size=14, num_glo_features=Fg, num_glo_embeddings=E)
+    keys = [k for k in m.state_dict().keys() if k.endswith(("weight", "bias", "embeddings"))]
+    assert keys == [k for k, _ in shapes], keys                                    # lin_glo_* in front of the second stage, glo_vecs last
+    m.load_state_dict(p, strict=False)
+    batch = {k[2:]: v.to(DEV) for k, v in g.items() if k.startswith("b_")}
+    tol = 2e-4 if compute == "f32" else 3e-2
+    named = dict(m.named_parameters())
+    for tag, zero in (("emb", False), ("zero", True)):
+        for q in m.parameters():
+            q.grad = None
+        rend, hist = m(None, batch, 1.0, False, zero_glo=zero)
+        loss = ((rend[-1]["rgb"] - g["target"].to(DEV)) ** 2).mean() + 0.01 * rend[-1]["depth"].mean()
+        loss.backward()
+        close(rend[-1]["rgb"], g[tag + "_rgb"], tol, tol, tag + " rgb"); close(rend[-1]["depth"], g[tag + "_depth"], tol, tol, tag + " depth")
+        for k in g:
+            if k.startswith(tag + "_grad."):
+                n = k[len(tag) + 6:]
+                got, want = named[n].grad, g[k]
+                if tag == "zero" and n == "glo_vecs.weight":
+                    continue
+                if compute == "bf16" and "glo" not in n:      # (formula weights are rank 2 and amplify bf16 rounding to O(1): fp32 only;
+                    continue                                  #  the GLO layers carry full-rank random weights and are held in bf16 too)
+                assert got is not None, n
+                rel = float((got.detach().cpu() - want).norm() / (want.norm() + 1e-30))
+                assert rel < (2e-3 if compute == "f32" else 0.25), (tag, n, rel)
+        if zero:
+            gv = named["glo_vecs.weight"].grad
+            assert gv is None or float(gv.abs().max()) == 0.0                      # zeros went in: the table gets no gradient
+
+
 @pytest.mark.parametrize("compute,table,tol", [("f32", "f32", 2e-4), ("bf16", "f16", 3e-2)])
 def test_zip_semantic_head_vs_reference_golden(backend, golden, compute, table, tol):
     """Config.use_semantic: the 19-class distribution rendered by the reference Model (golden) and the unchanged colour."""
