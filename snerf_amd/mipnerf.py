@@ -96,13 +96,14 @@ class MipNerfModel(_ArenaModule):
     def set_viewc(self, viewc):
         """the centre of the fn = 0 warp (train.py:36 / eval.py:50: mean of the camera positions), a number or 3 values; kept as host
         floats (kernel arguments), converted once per distinct object"""
-        if getattr(self, "_viewc_src", None) is viewc:
+        ver = viewc._version if torch.is_tensor(viewc) else None              # (an in-place update of the tensor is a new value)
+        if getattr(self, "_viewc_src", None) is viewc and getattr(self, "_viewc_ver", None) == ver and torch.is_tensor(viewc):
             return
         v = torch.as_tensor(viewc, dtype=torch.float32).detach().reshape(-1).cpu()
         v = v.expand(3) if v.numel() == 1 else v
         if v.numel() != 3:
             raise ValueError("viewc: a scalar or 3 values")
-        self._viewc, self._viewc_src = tuple(float(x) for x in v), viewc
+        self._viewc, self._viewc_src, self._viewc_ver = tuple(float(x) for x in v), viewc, ver
 
     # ------------------------------------------------------------------ core ----
     def _run(self, rays: Rays, keep: bool, white_bg: bool, s_rand, u, noise0, noise1):
