@@ -166,6 +166,39 @@ def test_two_workgroups_per_cu_nt_kernel_matches_fp64(ops, act):
     assert float((Y.double() - ref).abs().max() / ref.abs().max()) < 6e-3
 
 
+@pytest.mark.parametrize("dt", [0, 1])
+def test_zip_glo_modulation_kernels(ops, dt):
+    """snerf_zip_glo_modulate / _bwd (internal/models.py:620-630: bottleneck * exp(scale) + shift per ray) and snerf_colsum_wide_f32 against
+    torch: forward, d x (incl. the head gradients that enter its leading columns), d (scale | shift) per ray and the per-ray column sums."""
+    tdt = ops.torch_dtype(dt)
+    R, S, B, nh = 37, 5, 256, 20
+    g = torch.Generator().manual_seed(21)
+    X = (torch.randn(R * S, B + 16, generator=g)).to(tdt).cuda()
+    SS = (torch.randn(R, 2 * B, generator=g) * 0.3).cuda()
+    out = torch.zeros(R * S, B + 8, dtype=tdt, device="cuda")
+    ops.zip_glo_modulate(X, SS, S, out)
+    ss = SS.repeat_interleave(S, 0)
+    ref = X[:, :B].float() * torch.exp(ss[:, :B]) + ss[:, B:]
+    rt = 2e-6 if dt == 0 else 8e-3
+    close(out[:, :B].float(), ref, rt, 1e-6, "modulated bottleneck")
+    assert bool((out[:, B:] == 0).all())
+    dXm = (torch.randn(R * S, B, generator=g)).to(tdt).cuda()
+    dh = torch.randn(R * S, nh, generator=g).cuda()
+    dX = torch.empty(R * S, B, dtype=tdt, device="cuda")
+    dSS, dxsum = ops.zip_glo_modulate_bwd(dXm, X, SS, dh, S, dX)
+    e = torch.exp(ss[:, :B])
+    dx_ref = dXm.float() * e
+    dx_ref[:, :nh] += dh
+    close(dX.float(), dx_ref, rt, 1e-6, "d x")
+    close(dSS[:, :B], ((dXm.float() * X[:, :B].float()) * e).view(R, S, B).sum(1), 2e-5, 1e-5, "d scale")
+    close(dSS[:, B:], dXm.float().view(R, S, B).sum(1), 2e-5, 1e-5, "d shift")
+    close(dxsum, dX.float().view(R, S, B).sum(1), 2e-5, 1e-5, "per-ray column sums of the stored d x")
+    for det in (False, True):
+        acc = torch.ones(2 * B, device="cuda")
+        ops.colsum_wide_f32(dSS, 2 * B, acc, deterministic=det)
+        close(acc, 1 + dSS.double().sum(0).float(), 2e-5, 1e-4, "wide column sum")
+
+
 # -------------------------------------------------------------- encoders ----
 @pytest.mark.parametrize("dt", [0, 1])
 def test_classic_embed(ops, dt):
