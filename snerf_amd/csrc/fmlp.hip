@@ -139,9 +139,20 @@ typedef CtxT<FM_RING> Ctx;
 // tiles (the stream is one sequence).  The chunk boundary is taken when the READ-AHEAD crosses it.  F (the fragment's position in
 // the network pass) and every index derived from it are template arguments: nothing here depends on the optimiser proving a
 // counter constant.
+// The reads are issued BY HAND with a hand-counted wait (FM_ASM_FRAGS, round 3): while an LDS-DMA is pending -- always, here -- every
+// lgkmcnt wait the compiler inserts is lgkmcnt(0), and with plain loads the queue collapsed into "two reads, wait for
+// everything, two MFMAs": a full LDS round trip per pair of MFMAs.  LDS operations return in order, so "at most FM_LOOK - 1
+// outstanding" means the read issued FM_LOOK fragments ago has returned whatever else (bias reads, slab traffic, scalar loads) is in
+// flight: other operations only make the wait stricter.  Measured (gpurun_out/r3aa, 6.3 M rows, all tests green): inference 5.58 -> 5.53 ms,
+// training forward 9.58 -> 9.37, classic gradient chain 10.65 -> 10.43, colour head unchanged -- two waves per SIMD were already hiding
+// most of that latency.  Off by default: 2 % does not pay for another hand-counted wait in every fused kernel.
+#ifndef FM_ASM_FRAGS
+#define FM_ASM_FRAGS 0
+#endif
 template <int F, typename C>
 __device__ __forceinline__ bf16x8 next_frag(C& c) {
-  const bf16x8 w = c.q[F % FM_LOOK];
+  bf16x8 w = c.q[F % FM_LOOK];
+  if constexpr (FM_ASM_FRAGS) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(w) : "n"(FM_LOOK - 1));
   constexpr int G = F + FM_LOOK;
   if constexpr (FM_SKEW) {
     if constexpr ((G % FM_CHUNK) == 0) {
@@ -153,7 +164,11 @@ __device__ __forceinline__ bf16x8 next_frag(C& c) {
   } else if constexpr ((G % FM_CHUNK) == 0) {
     ws_advance<C::ring>(c.ws, c.smem);
   }
-  c.q[F % FM_LOOK] = *(const bf16x8*)(c.frag_base + c.ws.slot_off + (G % FM_CHUNK) * 1024);
+  if constexpr (FM_ASM_FRAGS) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(c.q[F % FM_LOOK]) : "v"((unsigned)(size_t)c.frag_base + c.ws.slot_off), "n"((G % FM_CHUNK) * 1024));
+  } else {
+    c.q[F % FM_LOOK] = *(const bf16x8*)(c.frag_base + c.ws.slot_off + (G % FM_CHUNK) * 1024);
+  }
   return w;
 }
 
