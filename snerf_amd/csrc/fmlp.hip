@@ -185,10 +185,23 @@ __device__ __forceinline__ f32x16 acc_init(const C& c) {
   return acc;
 }
 
+#ifdef FM_PROBE_DOUBLE
+// PROBE (tools: -DFM_PROBE_DOUBLE): every weight fragment feeds TWO MFMAs (the second into a dummy accumulator): twice the matrix work
+// for the same LDS traffic -- if the launch takes much less than twice as long, the kernel is bound by the LDS port, not the MFMA pipe
+__device__ f32x16 fm_probe_sink;
+template <int F, int NK, int... I, typename C>
+__device__ __forceinline__ void mac_seq(C& c, f32x16& acc, const bf16x8 (&in)[NK], std::integer_sequence<int, I...>) {
+  f32x16 acc2 = acc;
+  (([&] { const bf16x8 w = next_frag<F + I>(c); acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, in[I], acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, in[(I + 1) % NK], acc2, 0, 0, 0); }()), ...);
+  if (acc2[0] == 123456.789f) fm_probe_sink = acc2;       // (keeps the second chain alive)
+}
+#else
 template <int F, int NK, int... I, typename C>
 __device__ __forceinline__ void mac_seq(C& c, f32x16& acc, const bf16x8 (&in)[NK], std::integer_sequence<int, I...>) {
   ((acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(next_frag<F + I>(c), in[I], acc, 0, 0, 0)), ...);
 }
+#endif
 template <int F, int NK, typename C>
 __device__ __forceinline__ void mac(C& c, f32x16& acc, const bf16x8 (&in)[NK]) {
   mac_seq<F, NK>(c, acc, in, std::make_integer_sequence<int, NK>{});

@@ -12,6 +12,7 @@ def main():
     ap.add_argument("--rays", type=int, default=32768)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--compute", default="bf16")
+    ap.add_argument("--train-only", action="store_true", help="just the fused training step (rocprofv3 target)")
     args = ap.parse_args()
     from snerf_amd import classic
     torch.manual_seed(0)
@@ -48,6 +49,9 @@ def main():
         return (time.perf_counter() - t0) / args.steps
 
     dt_train = timeit(train)
+    if args.train_only:
+        print(json.dumps({"train_ms": round(dt_train * 1e3, 3)}))
+        return
     fine.net.fused = coarse.net.fused = False         # A/B: the training forward as one GEMM launch per layer
     dt_train_layered = timeit(train)
     fine.net.fused = coarse.net.fused = True
