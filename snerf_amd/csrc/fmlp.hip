@@ -251,6 +251,13 @@ struct StoreTo {
   int ncg;                   // 64-column groups of the layer (its width / 64): row length of the bit-mask block grid
 };
 
+// FM_NT_STORES: the row stores as streaming (nt) stores -- nothing of a launch reads them again, and without the hint the 1.2 KB per row
+// that pass through an XCD's L2 evict the weight stream every workgroup re-reads per tile (gemm.hip, the epilogue units' stores).
+// Measured (round 3, A/B/A on one box): training forward 9.56 -> 9.31 ms per 6.3 M rows, classic gradient chain 10.4-10.9 -> 10.3 ms,
+// path-B train step 47.9 / 48.2 -> 46.8 ms.
+#ifndef FM_NT_STORES
+#define FM_NT_STORES 1
+#endif
 template <bool BITS, int J>
 __device__ __forceinline__ void store_block(const StoreTo& st, const bf16x8& lo, const bf16x8& hi) {
   const int r = st.lane & 31, half = st.lane >> 5;
@@ -281,7 +288,8 @@ __device__ __forceinline__ void store_block(const StoreTo& st, const bf16x8& lo,
       const int row = 8 * it + prow;
       const fm_u32x4 v = vs[it];
       if (st.row0 + row < st.M) {
-        *(fm_u32x4*)(dst + (long)(8 * it) * st.ld) = v;
+        if constexpr (FM_NT_STORES) __builtin_nontemporal_store(v, (fm_u32x4*)(dst + (long)(8 * it) * st.ld));
+        else *(fm_u32x4*)(dst + (long)(8 * it) * st.ld) = v;
         if constexpr (BITS) {
           // a ReLU output is > 0 iff its 16 bits are not 0: min(half word, 1), even elements gathered in bits 0, 2, 4, 6, odd ones 16 higher
           typedef unsigned short fm_u16x2 __attribute__((ext_vector_type(2)));
