@@ -51,19 +51,8 @@ struct GemmNT {
   // simply walks 3 K / 64 VIRTUAL k-tiles: tile v reads W's physical tile v and A's physical tile 2 (v / 3) + (v % 3 == 1).
   // K in this struct is the virtual reduction length (3 x the logical one).
   int split;
-  // persistent kernel: walk the row panels from the LAST to the first (variant bit 15).  Alternating the direction between consecutive
-  // layers lets a launch start on the rows its producer wrote last -- the part of its input that is still in the Infinity Cache.
-  int reverse;
 };
 __device__ __forceinline__ int split_a_tile(int v) { return 2 * (v / 3) + (v % 3 == 1 ? 1 : 0); }
-// Cache policy of the persistent NT kernel's streams (compile-time, for A/B builds: tools/gemm_policy_ab.sh): the output rows as
-// streaming (nt) stores, the activation rows as streaming (nt = aux bit 1) DMA loads
-#ifndef GEMM_NT_STORES
-#define GEMM_NT_STORES 0
-#endif
-#ifndef GEMM_NT_ALOADS
-#define GEMM_NT_ALOADS 0
-#endif
 #ifndef SNERF_PROBE
 #define SNERF_PROBE 0   // the shipped library compiles the ablation branches out
 #endif
@@ -719,8 +708,7 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
 
   auto origin = [&](int i, int& m0, int& n0) __attribute__((always_inline)) {
     const int logical = xcd_remap((int)blockIdx.x + i * G, total);
-    const int row = logical / tiles_n;
-    m0 = (p.reverse ? tiles_m - 1 - row : row) << 8;
+    m0 = (logical / tiles_n) << 8;
     n0 = (logical % tiles_n) << 8;
   };
 
@@ -763,8 +751,8 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
       // SPLIT (at the register limit): the second piece's offset is derived from the first -- 8 rows further, 16-byte chunk c ^ 4 --
       // instead of being kept in a register of its own
       const int a1 = SPLIT ? arel[0] + 16 * (int)p.lda + rel_dc : arel[1];
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)dst, 16, arel[0] + which * a_half, aoff, 0, GEMM_NT_ALOADS ? 2 : 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)(dst + 1024), 16, a1 + which * a_half, aoff, 0, GEMM_NT_ALOADS ? 2 : 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)dst, 16, arel[0] + which * a_half, aoff, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)(dst + 1024), 16, a1 + which * a_half, aoff, 0, 0);
     } else {
       const int b1 = SPLIT ? brel[0] + 16 * (int)p.ldw + rel_dc : brel[1];
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_ptr_t)dst, 16, brel[0] + (which - 2) * b_half, soff, 0, 0);
@@ -952,11 +940,8 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
         val = __builtin_bit_cast(bf16x8, raw);
       }
       if (col_ok && m < p.M) {
-        if (!DBG(p, 8)) {
-          bf16x8* const dst = (bf16x8*)(yrow + it * ystep + (SPLIT ? 64 * part : 0));
-          if constexpr (GEMM_NT_STORES) __builtin_nontemporal_store(val, dst);
-          else *dst = val;
-        } else asm volatile("" ::"v"(val));               // PROBE build, bit 8: everything but the store instruction itself
+        if (!DBG(p, 8)) *(bf16x8*)(yrow + it * ystep + (SPLIT ? 64 * part : 0)) = val;          // (non-temporal stores measure the same: profiles/r2_n)
+        else asm volatile("" ::"v"(val));               // PROBE build, bit 8: everything but the store instruction itself
         if (ACT == ACT_RELU_BITS && part == 0) {
           // the value is a ReLU output (max(v, +0) rounded to bf16: never negative, never -0): > 0  <=>  its 16 bits are not all zero
           // min(half, 1) per 16-bit half = "is positive"; z gathers the even elements in bits 0, 2, 4, 6 and the odd ones 16 higher
@@ -1371,7 +1356,7 @@ extern "C" int snerf_linear_fwd(const void* A, long lda, const void* W, long ldw
   if (split && !fast && !out_f32) return SNERF_ERR_ARG;          // the interleaved output exists only in the 16-byte epilogues
   if (split && out_f32 && (act == ACT_MASK || colsum != nullptr)) return SNERF_ERR_ARG;
   GemmNT p{A, lda, W, ldw, bias, Y, ldy, aux, ldaux, colsum, M, N, K, n_store, act, out_f32, vec, colsum_ws, fast, det, ((variant >> 4) & 7) | ((variant >> 10) & 8),
-           (variant >> 9) & 15, split, (variant >> 15) & 1};                          // (PROBE builds: variant bit 13 = ablation bit 8; bits 9..12 = stagger)
+           (variant >> 9) & 15, split};                          // (PROBE builds: variant bit 13 = ablation bit 8; bits 9..12 = stagger)
   // variant bit 14: the two-workgroups-per-CU kernel (bf16, N % 256 == 0, 16-byte epilogue, plain / ReLU / bf16-mask activations)
   const bool nt4 = ((variant >> 14) & 1) && dtype == SNERF_DT_BF16 && !split && N % 256 == 0 && fast && act <= ACT_MASK && (K % 32) == 0 && colsum == nullptr;
   variant &= 15;
@@ -1423,7 +1408,6 @@ struct GemmTN {
   float* part;        // deterministic mode: every (tile, M slice) stores its partial tile at part + slice * part_stride + n * part_ld + k
   long part_stride;   // (no atomics); tn_fold_kernel adds the slices in a fixed order.  nullptr: fp32 atomics straight into dW
   int part_ld;
-  int dbg;            // PROBE builds (SNERF_TN8_DBG): cache-policy bits of the 8-phase kernel's staging loads, tools/gemm_tn_policy_probe.py
 };
 
 // TN_STAGES: slots of the staging ring of the 128 x 128 weight-gradient kernel (16 KiB per slot)
@@ -1652,19 +1636,8 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(GemmTN p) {
       const int off = s_kt * zstep;
       const int left = zbytes - off;
       const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)Z + off), 0, left > 0 ? left : 0, 0x00020000);
-      if (DBG(p, 1)) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)dst, 16, zrel[0] + which * 128, 0, 0, 2);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)(dst + 1024), 16, zrel[1] + which * 128, 0, 0, 2);
-      } else {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)dst, 16, zrel[0] + which * 128, 0, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)(dst + 1024), 16, zrel[1] + which * 128, 0, 0, 0);
-      }
-    } else if (DBG(p, 2)) {
-      const int off = s_kt * xstep;
-      const int left = xbytes - off;
-      const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)X + off), 0, left > 0 ? left : 0, 0x00020000);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)dst, 16, xrel[0] + (which - 2) * xhalf, 0, 0, 2);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)(dst + 1024), 16, xrel[1] + (which - 2) * xhalf, 0, 0, 2);
     } else {
       const int off = s_kt * xstep;
       const int left = xbytes - off;
@@ -1898,10 +1871,7 @@ static int wgrad_launch(const void* Z, long ldz, const void* X, long ldx, float*
   if (N < epc || K < epc || N % epc || K % epc || ldz % epc || ldx % epc || zeros == nullptr) return SNERF_ERR_ARG;
   const TnPlan pl = tn_plan(M, N, K, ldz, ldx, dtype, variant);
   if (ws != nullptr && ws_floats < pl.part_stride * pl.slices) return SNERF_ERR_ARG;
-  GemmTN p{Z, ldz, X, ldx, dW, ldw, zeros, M, N, K, n_valid, k_valid, pl.m_chunk, 0, pl.slices, split, ws, pl.part_stride, pl.part_ld, 0};
-#if SNERF_PROBE
-  if (const char* e = getenv("SNERF_TN8_DBG")) p.dbg = atoi(e);
-#endif
+  GemmTN p{Z, ldz, X, ldx, dW, ldw, zeros, M, N, K, n_valid, k_valid, pl.m_chunk, 0, pl.slices, split, ws, pl.part_stride, pl.part_ld};
   if (pl.use8) {
     static bool attr_set = false;
     if (!attr_set) {
