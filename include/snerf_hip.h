@@ -180,6 +180,16 @@ int snerf_zip_encode_fwd(const float* tdist, const float* origins, const float* 
                          const float* base_x, const float* base_y, const float* deg_jitter, const void* table,
                          const int* offsets, const int* grid_sizes, void* feat, long ld, long R, int S, int L, int C, int n,
                          int m, float Sl, int H, float std_scale, int table_dtype, int feat_dtype, int levels_per_thread, void* stream);
+/* snerf_zip_encode_fwd for a training step whose table gradient is the binned reduction (snerf_zip_encode_bwd_binned): one thread per
+ * (interval, level), and the same sweep also IS that gradient's pass 0 -- it has the 8 rows of every multisample's cell in hand for its
+ * gathers and counts the records the backward will emit per bin (counts [L, 1024], zeroed by the caller) and reserves each workgroup's
+ * ranges (wg_offsets [L, ceil(R S / 256), 1024]); ksplit_host / level_rows_host as for snerf_zip_encode_bwd_binned.  The backward then
+ * starts at its record pass (1 / 3) with these two buffers.  C = 1 or 4, n <= 8 multisamples. */
+int snerf_zip_encode_fwd_count(const float* tdist, const float* origins, const float* directions, const float* radii,
+                               const float* base_x, const float* base_y, const float* deg_jitter, const void* table,
+                               const int* offsets, const int* grid_sizes, void* feat, long ld, long R, int S, int L, int C, int n,
+                               int m, float Sl, int H, float std_scale, int table_dtype, int feat_dtype, const int* ksplit_host,
+                               const int* level_rows_host, int* counts, void* wg_offsets, void* stream);
 /* matching scatter-add of grad_feat [R*S, ld] into the fp32 table gradient (gridencoder.cu:248-340 composed with the mean /
  * erf weights); grad_table accumulates (fp32 atomics).  The first `lds_levels` levels (small dense tables) are accumulated
  * in LDS by persistent workgroups, in slabs of `lds_cells` rows (lds_cells*C*4 <= 160 KB; lds_slabs = sum of

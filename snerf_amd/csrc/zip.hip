@@ -440,13 +440,31 @@ __global__ __launch_bounds__(256) void zip_encode_kernel(ZipEnc a) {
   zip_point_level<TT, OT, C, BWD ? 1 : 0>(a, p, blockIdx.y + a.level_begin, nullptr);
 }
 
+// (bins of the binned table gradient, described further down: the training forward below can already count the records per bin)
+#define ZB_NBMAX 1024                      // bins per level (row ranges x replicas)
+#define ZB_HEAD 34                         // the largest |grad_feat| entry maps below 2^ZB_HEAD: 2^27 records cannot overflow 63 bits
+
+struct ZipBin {
+  int bshift;                              // log2(rows per bin)
+  int* counts;                             // [L, ZB_NBMAX] records per bin
+  unsigned* wg_offsets;                    // [L, workgroups, ZB_NBMAX] offset of a workgroup's record range inside a bin (pass 0 -> pass 1)
+  const long* starts;                      // [L, ZB_NBMAX] bin offsets (accumulate pass)
+  int ksplit[16];                          // replicas per row range, per level
+  unsigned short* rec_row; float* rec_val; long capacity;   // records: C = 1: rec_val holds {row, value} pairs (8 B); else row + C floats
+  long long* g64; long g64_rows;           // int64 image of table rows [0, g64_rows) for the replicated levels
+  const int* scale_exp;                    // device: the launch's fixed-point scale is 2^scale_exp[0] (snerf_zip_bin_scale)
+};
+
 // Forward featurisation, one thread per interval for ALL levels: the n <= 8 helix multisamples (sincos, contraction, cbrt) are
 // evaluated once and kept in registers instead of once per (interval, level) as in the per-level grid above -- for the
 // single-channel proposal grids that arithmetic, not the gathers, was the larger half of the kernel.
-template <typename TT, typename OT, int C>
-__global__ __launch_bounds__(256) void zip_encode_fwd_all_kernel(ZipEnc a) {
-  const long p = (long)blockIdx.x * 256 + threadIdx.x;
-  if (p >= a.R * a.S) return;
+// COUNT (training with the binned table gradient, one level per thread): the kernel is also PASS 0 of that gradient -- it has the 8 rows
+// of every cell in hand for its gathers, so it counts the records the backward will emit (8 per run of consecutive in-bounds
+// multisamples in one cell, exactly zip_emit_level's merging) in the workgroup's LDS histogram and reserves the workgroup's ranges like
+// zip_bin_emit_kernel<.., 0> does; its grid (intervals / 256, levels) is the grid of the backward's record pass.  Saves the separate
+// count sweep (the multisamples' sincos / contraction / cbrt once more per level).
+template <typename TT, typename OT, int C, bool COUNT>
+__device__ __forceinline__ void zip_fwd_all_body(const ZipEnc& a, const ZipBin& b, const long p, int* cnt) {
   const long ray = p / a.S;
   const int i = (int)(p - ray * a.S);
   const float t0 = a.tdist[ray * (a.S + 1) + i], t1 = a.tdist[ray * (a.S + 1) + i + 1];
@@ -476,6 +494,8 @@ __global__ __launch_bounds__(256) void zip_encode_fwd_all_kernel(ZipEnc a) {
     float acc[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) acc[c] = 0.f;
+    uint32_t cur[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};     // COUNT: cell of the current run of multisamples
+    const int K = COUNT ? b.ksplit[level] : 1, rep = COUNT ? (int)(blockIdx.x % (unsigned)K) : 0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       if (j >= a.n || !((inb >> j) & 1u)) continue;     // outside [0,1]^3 the encoder returns zeros
@@ -490,6 +510,14 @@ __global__ __launch_bounds__(256) void zip_encode_fwd_all_kernel(ZipEnc a) {
         pg[k] = (uint32_t)fl;
         fr[k] = ps - fl;
       }
+      bool newcell = false;
+      if constexpr (COUNT) {
+        newcell = pg[0] != cur[0] || pg[1] != cur[1] || pg[2] != cur[2];
+        cur[0] = pg[0]; cur[1] = pg[1]; cur[2] = pg[2];
+      }
+      auto tally = [&](long row) __attribute__((always_inline)) {
+        if constexpr (COUNT) { if (newcell) atomicAdd(cnt + (int)((uint32_t)row >> b.bshift) * K + rep, 1); }
+      };
       if constexpr (C == 1 && sizeof(TT) == 2) {
         float pa[8];
 #pragma unroll
@@ -498,6 +526,7 @@ __global__ __launch_bounds__(256) void zip_encode_fwd_all_kernel(ZipEnc a) {
           const long r0 = zip_grid_index(hs, res, pl);
           pl[0] = pg[0] + 1;
           const long r1 = zip_grid_index(hs, res, pl);
+          tally(r0); tally(r1);
           float v0, v1;
           if ((r0 ^ r1) == 1) {                           // adjacent entries of one aligned 32-bit word (see zip_point_level)
             const uint32_t word = *reinterpret_cast<const uint32_t*>(tab + (r0 & ~1L));
@@ -527,6 +556,7 @@ __global__ __launch_bounds__(256) void zip_encode_fwd_all_kernel(ZipEnc a) {
           const long r0 = zip_grid_index(hs, res, pl);
           pl[0] = pg[0] + 1;
           const long r1 = zip_grid_index(hs, res, pl);
+          tally(r0); tally(r1);
           ZVec<TT, 4> e0, e1;
           if ((r0 ^ r1) == 1) {
             const ZVec<TT, 8> both = *reinterpret_cast<const ZVec<TT, 8>*>(tab + (r0 & ~1L) * 4);
@@ -554,6 +584,7 @@ __global__ __launch_bounds__(256) void zip_encode_fwd_all_kernel(ZipEnc a) {
             if (idx & (1 << k)) { w *= fr[k]; pl[k] = pg[k] + 1; } else { w *= 1.f - fr[k]; pl[k] = pg[k]; }
           }
           const long row = zip_grid_index(hs, res, pl);
+          tally(row);
           const ZVec<TT, C> r = *reinterpret_cast<const ZVec<TT, C>*>(tab + row * C);
 #pragma unroll
           for (int c = 0; c < C; ++c) acc[c] += (w * we) * (float)r.v[c];
@@ -562,6 +593,25 @@ __global__ __launch_bounds__(256) void zip_encode_fwd_all_kernel(ZipEnc a) {
     }
 #pragma unroll
     for (int c = 0; c < C; ++c) out[level * C + c] = (OT)(acc[c] / (float)a.n);
+  }
+}
+
+template <typename TT, typename OT, int C, bool COUNT = false>
+__global__ __launch_bounds__(256) void zip_encode_fwd_all_kernel(ZipEnc a, ZipBin b) {
+  __shared__ int cnt[COUNT ? ZB_NBMAX : 1];
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  const bool live = p < a.R * a.S;
+  if constexpr (COUNT) {
+    for (int k = threadIdx.x; k < ZB_NBMAX; k += 256) cnt[k] = 0;
+    __syncthreads();
+  }
+  if (live) zip_fwd_all_body<TT, OT, C, COUNT>(a, b, p, cnt);
+  if constexpr (COUNT) {
+    __syncthreads();
+    const int level = blockIdx.y;                       // (one level per thread in this mode)
+    unsigned* wgo = b.wg_offsets + ((long)level * gridDim.x + blockIdx.x) * ZB_NBMAX;
+    for (int k = threadIdx.x; k < ZB_NBMAX; k += 256)
+      if (cnt[k] != 0) wgo[k] = (unsigned)atomicAdd(b.counts + level * ZB_NBMAX + k, cnt[k]);
   }
 }
 
@@ -768,10 +818,10 @@ static int zip_enc_launch(ZipEnc a, int C, int lds_levels, size_t lds_bytes, int
     a.level_begin = lpt;
     const dim3 grid((unsigned)((a.R * a.S + 255) / 256), (a.L + lpt - 1) / lpt);
     switch (C) {
-      case 1: hipLaunchKernelGGL((zip_encode_fwd_all_kernel<TT, OT, 1>), grid, blk, 0, s, a); break;
-      case 2: hipLaunchKernelGGL((zip_encode_fwd_all_kernel<TT, OT, 2>), grid, blk, 0, s, a); break;
-      case 4: hipLaunchKernelGGL((zip_encode_fwd_all_kernel<TT, OT, 4>), grid, blk, 0, s, a); break;
-      case 8: hipLaunchKernelGGL((zip_encode_fwd_all_kernel<TT, OT, 8>), grid, blk, 0, s, a); break;
+      case 1: hipLaunchKernelGGL((zip_encode_fwd_all_kernel<TT, OT, 1>), grid, blk, 0, s, a, ZipBin{}); break;
+      case 2: hipLaunchKernelGGL((zip_encode_fwd_all_kernel<TT, OT, 2>), grid, blk, 0, s, a, ZipBin{}); break;
+      case 4: hipLaunchKernelGGL((zip_encode_fwd_all_kernel<TT, OT, 4>), grid, blk, 0, s, a, ZipBin{}); break;
+      case 8: hipLaunchKernelGGL((zip_encode_fwd_all_kernel<TT, OT, 8>), grid, blk, 0, s, a, ZipBin{}); break;
       default: return SNERF_ERR_ARG;
     }
     return snerf_check_launch();
@@ -811,6 +861,41 @@ extern "C" int snerf_zip_encode_fwd(const float* tdist, const float* origins, co
   return zip_enc_dispatch<false>(a, C, table_dtype, feat_dtype, 0, 0, 0, (hipStream_t)stream);
 }
 
+// The training forward of the binned table gradient: snerf_zip_encode_fwd with one level per thread + pass 0 of
+// snerf_zip_encode_bwd_binned in the same sweep (counts [L, 1024] zeroed by the caller, wg_offsets [L, workgroups, 1024]); the backward
+// then starts at its record pass.
+extern "C" int snerf_zip_encode_fwd_count(const float* tdist, const float* origins, const float* directions, const float* radii,
+                                          const float* base_x, const float* base_y, const float* deg_jitter, const void* table,
+                                          const int* offsets, const int* grid_sizes, void* feat, long ld, long R, int S, int L, int C, int n,
+                                          int m, float Sl, int H, float std_scale, int table_dtype, int feat_dtype, const int* ksplit_host,
+                                          const int* level_rows_host, int* counts, void* wg_offsets, void* stream) {
+  if (R <= 0) return SNERF_OK;
+  if (S <= 0 || L <= 0 || L > 16 || n <= 0 || n > 8 || (C != 1 && C != 4) || ld < (long)L * C || table == nullptr || feat == nullptr ||
+      grid_sizes == nullptr || ksplit_host == nullptr || level_rows_host == nullptr || counts == nullptr || wg_offsets == nullptr)
+    return SNERF_ERR_ARG;
+  ZipBin b{};
+  b.bshift = C == 4 ? 12 : 14;
+  for (int l = 0; l < L; ++l) {                         // (the same bound as snerf_zip_encode_bwd_binned)
+    const long rowbins = ((long)level_rows_host[l] + (1L << b.bshift) - 1) >> b.bshift;
+    if (level_rows_host[l] <= 0 || ksplit_host[l] < 1 || rowbins * ksplit_host[l] > ZB_NBMAX) return SNERF_ERR_ARG;
+    b.ksplit[l] = ksplit_host[l];
+  }
+  b.counts = counts; b.wg_offsets = (unsigned*)wg_offsets;
+  ZipEnc a{tdist, origins, directions, radii, base_x, base_y, deg_jitter, table, offsets, grid_sizes, feat, ld, nullptr, nullptr, R, S, L, n, m, Sl, H, std_scale};
+  a.level_begin = 1;
+  const dim3 grid((unsigned)((R * S + 255) / 256), L), blk(256);
+  hipStream_t s = (hipStream_t)stream;
+#define ZFC(TT, OT) do { if (C == 4) hipLaunchKernelGGL((zip_encode_fwd_all_kernel<TT, OT, 4, true>), grid, blk, 0, s, a, b); \
+                         else hipLaunchKernelGGL((zip_encode_fwd_all_kernel<TT, OT, 1, true>), grid, blk, 0, s, a, b); } while (0)
+  if (table_dtype == SNERF_DT_F32 && feat_dtype == SNERF_DT_F32) ZFC(float, float);
+  else if (table_dtype == SNERF_DT_F32 && feat_dtype == SNERF_DT_BF16) ZFC(float, __bf16);
+  else if (table_dtype == 2 && feat_dtype == SNERF_DT_F32) ZFC(__half, float);
+  else if (table_dtype == 2 && feat_dtype == SNERF_DT_BF16) ZFC(__half, __bf16);
+  else return SNERF_ERR_ARG;
+#undef ZFC
+  return snerf_check_launch();
+}
+
 extern "C" int snerf_zip_encode_bwd(const float* tdist, const float* origins, const float* directions, const float* radii,
                                     const float* base_x, const float* base_y, const float* deg_jitter, const int* offsets,
                                     const int* grid_sizes, const void* grad_feat, long ld, float* grad_table, long R, int S, int L, int C,
@@ -847,20 +932,6 @@ extern "C" int snerf_zip_encode_bwd(const float* tdist, const float* origins, co
 //   pass 2  zip_bin_accumulate_kernel   one workgroup per bin: LDS fixed-point accumulation, write-back (+= into the fp32 gradient)
 //   pass 3  zip_bin_finish_kernel       fold the replicated levels' int64 image into the gradient
 // ------------------------------------------------------------------------------------------------------------------
-#define ZB_NBMAX 1024                      // bins per level (row ranges x replicas)
-#define ZB_HEAD 34                         // the largest |grad_feat| entry maps below 2^ZB_HEAD: 2^27 records cannot overflow 63 bits
-
-struct ZipBin {
-  int bshift;                              // log2(rows per bin)
-  int* counts;                             // [L, ZB_NBMAX] records per bin
-  unsigned* wg_offsets;                    // [L, workgroups, ZB_NBMAX] offset of a workgroup's record range inside a bin (pass 0 -> pass 1)
-  const long* starts;                      // [L, ZB_NBMAX] bin offsets (accumulate pass)
-  int ksplit[16];                          // replicas per row range, per level
-  unsigned short* rec_row; float* rec_val; long capacity;   // records: C = 1: rec_val holds {row, value} pairs (8 B); else row + C floats
-  long long* g64; long g64_rows;           // int64 image of table rows [0, g64_rows) for the replicated levels
-  const int* scale_exp;                    // device: the launch's fixed-point scale is 2^scale_exp[0] (snerf_zip_bin_scale)
-};
-
 // the records of one (interval, level): same merging of consecutive multisamples in one cell as the atomic path
 template <typename OT, int C, bool WRITE>
 __device__ __forceinline__ void zip_emit_level(const ZipEnc& a, const ZipBin& b, long p, int level, int* lds_cnt, const long* lds_base) {

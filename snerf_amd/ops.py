@@ -648,6 +648,28 @@ def zip_encode_fwd(tdist, origins, directions, radii, base_x, base_y, deg_jitter
               _zip_dt(feat), int(levels_per_thread), _stream())
 
 
+def zip_encode_fwd_count(tdist, origins, directions, radii, base_x, base_y, deg_jitter, table, offsets, grid_sizes, feat, L, C, n, m, Sl, H, std_scale,
+                         ksplit, level_rows):
+    """zip_encode_fwd (one thread per (interval, level)) that also counts the records of the binned table gradient and reserves the
+    workgroups' ranges: pass 0 of zip_encode_bwd_binned in the forward's sweep.  -> (counts, wg_offsets) to hand to zip_encode_bwd_binned
+    as `precounted`.  wg_offsets is a buffer of its own per call: it lives until the backward."""
+    import numpy as np
+    for t in (tdist, origins, directions, radii, base_x, base_y, deg_jitter):
+        _f32c(t)
+    R, P = tdist.shape
+    S = P - 1
+    assert table.is_contiguous() and offsets.dtype == torch.int32 and grid_sizes.dtype == torch.int32 and C in (1, 4) and n <= 8 and L <= 16
+    ks = np.ascontiguousarray(np.asarray(ksplit, dtype=np.int32))
+    lr = np.ascontiguousarray(np.asarray(level_rows, dtype=np.int32))
+    assert ks.shape == (L,) and lr.shape == (L,)
+    counts = torch.zeros(L, ZB_NBMAX, dtype=torch.int32, device=tdist.device)
+    wgo = torch.empty(L * ((R * S + 255) // 256) * ZB_NBMAX, dtype=torch.int32, device=tdist.device)
+    _lib.call("snerf_zip_encode_fwd_count", _p(tdist), _p(origins), _p(directions), _p(radii), _p(base_x), _p(base_y), _p(deg_jitter), _p(table),
+              _p(offsets), _p(grid_sizes), _p(feat), feat.stride(0), R, S, L, C, n, m, float(Sl), int(H), float(std_scale), _zip_dt(table),
+              _zip_dt(feat), ks.ctypes.data, lr.ctypes.data, _p(counts), _p(wgo), _stream())
+    return counts, wgo
+
+
 def zip_encode_prop_fwd(tdist, origins, directions, radii, base_x, base_y, deg_jitter, table, offsets, grid_sizes, L, n, m, Sl, H, std_scale,
                         w1, b1, w2, b2, round_bf16):
     """Fused featurisation + proposal MLP of one proposal level (inference) -> raw density [R*S, 1] fp32."""
@@ -714,7 +736,7 @@ ZIP_BIN_STAGED = _os.environ.get("SNERF_ZIP_UNSTAGED", "") == ""      # (the env
 
 
 def zip_encode_bwd_binned(tdist, origins, directions, radii, base_x, base_y, deg_jitter, offsets, grid_sizes, grad_feat, grad_table, L, C, n, m, Sl, H,
-                          std_scale, ksplit, g64_rows, level_rows):
+                          std_scale, ksplit, g64_rows, level_rows, precounted=None):
     """The table gradient of zip_encode_bwd without L2 atomics on the hashed levels and bit-reproducible: records binned by destination,
     accumulated per bin in LDS with fixed-point integer atomics (snerf_zip_encode_bwd_binned: count, scan on the device, write, accumulate).
     The fixed-point grid follows the gradient's magnitude (snerf_zip_bin_scale: 34 bits below max |grad_feat|)."""
@@ -726,15 +748,20 @@ def zip_encode_bwd_binned(tdist, origins, directions, radii, base_x, base_y, deg
     ks = np.ascontiguousarray(np.asarray(ksplit, dtype=np.int32))
     lr = np.ascontiguousarray(np.asarray(level_rows, dtype=np.int32))
     assert ks.shape == (L,) and lr.shape == (L,)
-    counts = torch.zeros(L, ZB_NBMAX, dtype=torch.int32, device=dev)
     scale = torch.empty(2, dtype=torch.int32, device=dev)
     _lib.call("snerf_zip_bin_scale", _p(grad_feat), grad_feat.stride(0), R * S, L * C, _zip_dt(grad_feat), _p(scale), _stream())
     args = (_p(tdist), _p(origins), _p(directions), _p(radii), _p(base_x), _p(base_y), _p(deg_jitter), _p(offsets), _p(grid_sizes), _p(grad_feat),
             grad_feat.stride(0), _p(grad_table), R, S, L, C, n, m, float(Sl), int(H), float(std_scale), _zip_dt(grad_feat), ks.ctypes.data,
             lr.ctypes.data)
-    # pass 0 also reserves each workgroup's record range inside the bins it touches (offsets relative to the bin's start)
-    wgo = _zb_workspace(dev, "wgo", L * ((R * S + 255) // 256) * ZB_NBMAX, torch.int32)
-    _lib.call("snerf_zip_encode_bwd_binned", 0, *args, _p(counts), _p(wgo), None, None, None, 0, None, 0, None, _stream())
+    if precounted is not None:
+        # the training forward (zip_encode_fwd_count) already counted the records and reserved the workgroups' ranges
+        counts, wgo = precounted
+        assert counts.shape == (L, ZB_NBMAX) and wgo.numel() >= L * ((R * S + 255) // 256) * ZB_NBMAX
+    else:
+        # pass 0 also reserves each workgroup's record range inside the bins it touches (offsets relative to the bin's start)
+        counts = torch.zeros(L, ZB_NBMAX, dtype=torch.int32, device=dev)
+        wgo = _zb_workspace(dev, "wgo", L * ((R * S + 255) // 256) * ZB_NBMAX, torch.int32)
+        _lib.call("snerf_zip_encode_bwd_binned", 0, *args, _p(counts), _p(wgo), None, None, None, 0, None, 0, None, _stream())
     flat = counts.view(-1).to(torch.int64)
     starts = (torch.cumsum(flat, 0) - flat).contiguous()
     capacity = R * S * n * 8 * L                               # every (interval, level) emits at most n cells x 8 corners: no host sync

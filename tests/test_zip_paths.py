@@ -653,6 +653,32 @@ def test_zip_table_gradient_binned_is_exact_and_bit_reproducible(lvl, gscale, mo
     ops.zip_encode_bwd_binned(*common, gd, *tail, ks, g64_rows, lrows)
     monkeypatch.setattr(ops, "ZIP_BIN_STAGED", True)
     assert torch.equal(outs[0], gd), "staged and direct record writers must give bit-identical gradients"
+    # round 3: the training forward counts the records itself (snerf_zip_encode_fwd_count = featurisation + pass 0): same features as
+    # the plain forward, same per-bin counts as the backward's own count pass, same gradient bit for bit
+    tab = m._table(lvl)
+    f0 = torch.zeros(R * S, Fw, device="cuda", dtype=dF.dtype)
+    f1 = torch.zeros_like(f0)
+    enc_args = (tdist, o, d, radii, bx, by, degj, tab, m.dev_offsets[lvl], m.dev_sizes[lvl])
+    ops.zip_encode_fwd(*enc_args, f0, *tail, levels_per_thread=1)
+    counts, wgo = ops.zip_encode_fwd_count(*enc_args, f1, *tail, ks, lrows)
+    assert torch.equal(f0, f1), "the counting forward must produce the plain forward's features"
+    from snerf_amd import _lib
+    import numpy as np
+    c0 = torch.zeros_like(counts)
+    w0 = torch.empty_like(wgo)
+    ksa, lra = np.asarray(ks, dtype=np.int32), np.asarray(lrows, dtype=np.int32)
+    p_ = lambda t: t.data_ptr()
+    _lib.call("snerf_zip_encode_bwd_binned", 0, p_(tdist), p_(o), p_(d), p_(radii), p_(bx), p_(by), p_(degj), p_(m.dev_offsets[lvl]), p_(m.dev_sizes[lvl]),
+              p_(dF), dF.stride(0), None, R, S, e.L, e.C, n, 3, float(e.Sl), int(e.H), float(m.std_scale), ops._zip_dt(dF), ksa.ctypes.data, lra.ctypes.data,
+              p_(c0), p_(w0), None, None, None, 0, None, 0, None, torch.cuda.current_stream().cuda_stream)
+    assert torch.equal(counts, c0), "forward-side record counts differ from the backward's count pass"
+    assert int(counts.sum()) > 0
+    f2 = torch.zeros(R * S, Fw, device="cuda", dtype=dF.dtype)                          # fp32 table: the kernel's generic gather branch
+    c32, _ = ops.zip_encode_fwd_count(tdist, o, d, radii, bx, by, degj, tab.float().contiguous(), m.dev_offsets[lvl], m.dev_sizes[lvl], f2, *tail, ks, lrows)
+    assert torch.equal(c32, c0)
+    gp = torch.zeros(e.rows, e.C, device="cuda")
+    ops.zip_encode_bwd_binned(*common, gp, *tail, ks, g64_rows, lrows, precounted=(counts, wgo))
+    assert torch.equal(outs[0], gp), "gradient with the forward's counts must equal the gradient with the backward's own count pass"
     rel = float((outs[0] - ref).norm() / ref.norm())
     print(f"MEASURED binned vs atomic table gradient (grid {lvl}): rel L2 {rel:.3e}, K per level {ks}")
     assert float(ref.norm()) > 0 and rel < 2e-6, rel
