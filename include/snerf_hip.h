@@ -190,6 +190,20 @@ int snerf_zip_encode_fwd_count(const float* tdist, const float* origins, const f
                                const int* offsets, const int* grid_sizes, void* feat, long ld, long R, int S, int L, int C, int n,
                                int m, float Sl, int H, float std_scale, int table_dtype, int feat_dtype, const int* ksplit_host,
                                const int* level_rows_host, int* counts, void* wg_offsets, void* stream);
+/* The proposal MLP of a zipnerf TRAINING step (internal/models.py:425-427, 481-519 with disable_rgb: Linear(L -> hidden) + ReLU +
+ * Linear(hidden -> 1) on the grid features) as one launch each way instead of per-layer GEMMs over 64-column padded buffers: F [P, ldf]
+ * (feat_dtype fp32 / bf16, L <= 16 feature columns, ldf >= L -- a compact buffer), parameters fp32 in the reference's layouts
+ * (density_layer.0.weight [hidden, L], .bias [hidden], density_layer.2.weight [1, hidden], .bias [1]; hidden <= 64), raw [P] fp32.
+ * round_bf16: the rounding points of the bf16 GEMM route (bf16 weights and stored activations, fp32 accumulation).  The backward
+ * recomputes the hidden activations from F, writes dF [P, lddf] (columns L .. lddf - 1 zero; lddf <= 64) and adds the parameter
+ * gradients into g_* (fp32, same layouts) by per-workgroup partial sums folded in a fixed order (bit-reproducible);
+ * ws: snerf_zip_prop_mlp_ws_floats(L, hidden, P) floats of scratch. */
+int snerf_zip_prop_mlp_ws_floats(int L, int hidden, long P);
+int snerf_zip_prop_mlp_fwd(const void* F, long ldf, long P, int L, const float* w1, const float* b1, const float* w2, const float* b2,
+                           int hidden, int round_bf16, int feat_dtype, float* raw, void* stream);
+int snerf_zip_prop_mlp_bwd(const void* F, long ldf, const float* d_raw, long P, int L, const float* w1, const float* b1,
+                           const float* w2, const float* b2, int hidden, int round_bf16, int feat_dtype, void* dF, long lddf,
+                           float* g_w1, float* g_b1, float* g_w2, float* g_b2, float* ws, long ws_floats, void* stream);
 /* matching scatter-add of grad_feat [R*S, ld] into the fp32 table gradient (gridencoder.cu:248-340 composed with the mean /
  * erf weights); grad_table accumulates (fp32 atomics).  The first `lds_levels` levels (small dense tables) are accumulated
  * in LDS by persistent workgroups, in slabs of `lds_cells` rows (lds_cells*C*4 <= 160 KB; lds_slabs = sum of

@@ -463,6 +463,9 @@ struct ZipBin {
 // multisamples in one cell, exactly zip_emit_level's merging) in the workgroup's LDS histogram and reserves the workgroup's ranges like
 // zip_bin_emit_kernel<.., 0> does; its grid (intervals / 256, levels) is the grid of the backward's record pass.  Saves the separate
 // count sweep (the multisamples' sincos / contraction / cbrt once more per level).
+#ifndef ZIP_PAIR_F32
+#define ZIP_PAIR_F32 1
+#endif
 template <typename TT, typename OT, int C, bool COUNT>
 __device__ __forceinline__ void zip_fwd_all_body(const ZipEnc& a, const ZipBin& b, const long p, int* cnt) {
   const long ray = p / a.S;
@@ -518,7 +521,36 @@ __device__ __forceinline__ void zip_fwd_all_body(const ZipEnc& a, const ZipBin& 
       auto tally = [&](long row) __attribute__((always_inline)) {
         if constexpr (COUNT) { if (newcell) atomicAdd(cnt + (int)((uint32_t)row >> b.bshift) * K + rep, 1); }
       };
-      if constexpr (C == 1 && sizeof(TT) == 2) {
+      if constexpr (C == 1 && sizeof(TT) == 4 && ZIP_PAIR_F32) {
+        // fp32 single-channel table (the proposal grids under the reference's table policy): the two x-neighbours of a corner pair are
+        // adjacent entries whenever their rows differ only in bit 0 -- one aligned 8-byte load instead of two 4-byte ones (same
+        // products, same order as the generic loop: corner index = x + 2 y + 4 z)
+        float pa[8];
+#pragma unroll
+        for (int yz = 0; yz < 4; ++yz) {
+          uint32_t pl[3] = {pg[0], pg[1] + (yz & 1), pg[2] + (yz >> 1)};
+          const long r0 = zip_grid_index(hs, res, pl);
+          pl[0] = pg[0] + 1;
+          const long r1 = zip_grid_index(hs, res, pl);
+          tally(r0); tally(r1);
+          float v0, v1;
+          if ((r0 ^ r1) == 1) {
+            const float2 both = *reinterpret_cast<const float2*>(tab + (r0 & ~1L));
+            v0 = (r0 & 1) ? both.y : both.x;
+            v1 = (r0 & 1) ? both.x : both.y;
+          } else {
+            v0 = (float)tab[r0];
+            v1 = (float)tab[r1];
+          }
+          float wa = 1.f - fr[0], wb = fr[0];
+          wa *= (yz & 1) ? fr[1] : 1.f - fr[1]; wb *= (yz & 1) ? fr[1] : 1.f - fr[1];
+          wa *= (yz >> 1) ? fr[2] : 1.f - fr[2]; wb *= (yz >> 1) ? fr[2] : 1.f - fr[2];
+          pa[2 * yz] = (wa * we) * v0;
+          pa[2 * yz + 1] = (wb * we) * v1;
+        }
+#pragma unroll
+        for (int idx = 0; idx < 8; ++idx) acc[0] += pa[idx];
+      } else if constexpr (C == 1 && sizeof(TT) == 2) {
         float pa[8];
 #pragma unroll
         for (int yz = 0; yz < 4; ++yz) {
@@ -859,6 +891,222 @@ extern "C" int snerf_zip_encode_fwd(const float* tdist, const float* origins, co
   ZipEnc a{tdist, origins, directions, radii, base_x, base_y, deg_jitter, table, offsets, grid_sizes, feat, ld, nullptr, nullptr, R, S, L, n, m, Sl, H, std_scale};
   a.level_begin = levels_per_thread;
   return zip_enc_dispatch<false>(a, C, table_dtype, feat_dtype, 0, 0, 0, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Proposal MLP of a TRAINING step as two launches (round 3): Linear(L -> hidden <= 64) + ReLU + Linear(hidden -> 1) on the grid
+// features (internal/models.py:425-427, 481-519 with disable_rgb) -- 1.2 kFLOP per interval, which the per-layer GEMM route turned into
+// eight HBM-bound launches over [P, 64]-wide padded buffers per level and step (features, hidden activations and both their
+// gradients: ~4 GB).  Here the features live in a compact [P, ld >= L] buffer, a thread owns an interval, the weights sit in LDS
+// (read as broadcasts), and the hidden activations never leave the registers: the backward recomputes them from the features.
+//   forward:  raw[p] = b2 + sum_h rb(relu(b1[h] + sum_l F[p, l] rb(W1[h, l]))) rb(w2[h])          (rb = bf16 rounding in bf16 mode:
+//             the same rounding points as the GEMM route -- bf16 weights, bf16 stored activations, fp32 accumulation)
+//   backward: g = rb(d raw[p]);  dh[h] = H[h] > 0 ? rb(g rb(w2[h])) : 0;  dF[p, l] = rb(sum_h dh[h] rb(W1[h, l]));
+//             dW1[h, l] = sum_p dh[h] F[p, l];  db1[h] = sum_p dh[h];  dw2[h] = sum_p g H[h];  db2 = sum_p d raw[p]
+// The weight-gradient sums: a workgroup walks tiles of 256 intervals; per tile the threads leave dh / H / F / g in LDS, then thread
+// (h = tid & 63, q = tid >> 6) adds the 64 intervals of quarter q into its register sums (the interval's F and g are broadcast reads);
+// at the end the four quarters meet in LDS and the workgroup stores ONE partial row; zip_prop_fold_kernel adds the rows in workgroup
+// order: bit-reproducible, no atomics.
+// ------------------------------------------------------------------------------------------------------------------
+#define ZPM_H 64                                         // hidden units the kernels are laid out for (fewer: idle lanes)
+#define ZPM_L 16                                         // features per interval at most
+struct ZipPropTrain {
+  const void* F; long ldf;                               // features [P, ldf] (T)
+  const float *w1, *b1, *w2, *b2;                        // parameters, fp32 (density_layer.0 / .2)
+  int L, hidden, rnd;
+  long P;
+  float* raw;                                            // forward: [P] fp32
+  const float* d_raw;                                    // backward: [P] fp32
+  void* dF; long lddf;                                   // backward: [P, lddf] (T); columns >= L are written as zeros up to lddf
+  float* ws;                                             // backward: [workgroups, hidden (L + 2) + 1] partial sums
+};
+
+__device__ __forceinline__ void zpm_load_weights(const ZipPropTrain& w, float* lw) {
+  const int nw1 = w.hidden * w.L;
+  for (int k = threadIdx.x; k < nw1; k += 256) lw[k] = zip_rbf(w.w1[k], w.rnd);
+  for (int k = threadIdx.x; k < w.hidden; k += 256) { lw[nw1 + k] = w.b1[k]; lw[nw1 + w.hidden + k] = zip_rbf(w.w2[k], w.rnd); }
+  if (threadIdx.x == 0) lw[nw1 + 2 * w.hidden] = w.b2[0];
+}
+
+template <typename T, int LM>
+__global__ __launch_bounds__(256) void zip_prop_mlp_fwd_kernel(ZipPropTrain w) {
+  __shared__ float lw[ZPM_H * ZPM_L + 2 * ZPM_H + 1];
+  zpm_load_weights(w, lw);
+  __syncthreads();
+  const int nw1 = w.hidden * w.L;
+  const float* b1 = lw + nw1;
+  const float* w2 = b1 + w.hidden;
+  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < w.P; p += (long)gridDim.x * 256) {
+    const T* f = (const T*)w.F + p * w.ldf;
+    float feat[LM];
+#pragma unroll
+    for (int l = 0; l < LM; ++l) feat[l] = l < w.L ? to_f32(f[l]) : 0.f;
+    float out = 0.f;
+    for (int h = 0; h < w.hidden; ++h) {
+      const float* wr = lw + h * w.L;
+      float acc = 0.f;
+#pragma unroll
+      for (int l = 0; l < LM; ++l) acc += l < w.L ? feat[l] * wr[l] : 0.f;
+      acc += b1[h];
+      out += zip_rbf(fmaxf(acc, 0.f), w.rnd) * w2[h];
+    }
+    w.raw[p] = out + lw[nw1 + 2 * w.hidden];
+  }
+}
+
+// LM: feature slots per interval (8 or 16 >= L).  The tile arrays hold T: in bf16 mode every value in them is a rounded bf16 already
+// (80 KB: two workgroups per CU); the fp32 mode keeps floats (one workgroup per CU).
+template <typename T, int LM>
+__global__ __launch_bounds__(256) void zip_prop_mlp_bwd_kernel(ZipPropTrain w) {
+  constexpr int HP = ZPM_H + (sizeof(T) == 2 ? 2 : 1);   // row pitch of the tile arrays (written row-wise, read column-wise)
+  __shared__ float lw[ZPM_H * ZPM_L + 2 * ZPM_H + 1];
+  __shared__ __attribute__((aligned(16))) T s_dh[256 * HP];
+  __shared__ __attribute__((aligned(16))) T s_h[256 * HP];
+  __shared__ __attribute__((aligned(16))) T s_f[256 * LM];
+  __shared__ float s_g[256];
+  static_assert(sizeof(T) * 256 * HP >= sizeof(float) * 4 * 64 * (LM + 2), "s_dh doubles as the quarter-reduction buffer");
+  zpm_load_weights(w, lw);
+  const int nw1 = w.hidden * w.L;
+  const float* b1 = lw + nw1;
+  const float* w2 = b1 + w.hidden;
+  const int tid = threadIdx.x, hh = tid & 63, q = tid >> 6;
+  float aw1[LM], ab1 = 0.f, aw2 = 0.f, ab2 = 0.f;
+#pragma unroll
+  for (int l = 0; l < LM; ++l) aw1[l] = 0.f;
+  const long tiles = (w.P + 255) >> 8;
+  for (long t = blockIdx.x; t < tiles; t += gridDim.x) {
+    __syncthreads();                                     // (weights loaded / the previous tile's sums done)
+    const long p = (t << 8) + tid;
+    const bool live = p < w.P;
+    float feat[LM];
+    const T* f = (const T*)w.F + (live ? p : 0) * w.ldf;
+#pragma unroll
+    for (int l = 0; l < LM; ++l) feat[l] = (live && l < w.L) ? to_f32(f[l]) : 0.f;
+    const float draw = live ? w.d_raw[p] : 0.f;
+    const float g = zip_rbf(draw, w.rnd);
+    ab2 += draw;
+    float df[LM];
+#pragma unroll
+    for (int l = 0; l < LM; ++l) df[l] = 0.f;
+    for (int h = 0; h < ZPM_H; ++h) {
+      float hr = 0.f, dh = 0.f;
+      if (h < w.hidden) {
+        const float* wr = lw + h * w.L;
+        float acc = 0.f;
+#pragma unroll
+        for (int l = 0; l < LM; ++l) acc += l < w.L ? feat[l] * wr[l] : 0.f;
+        acc += b1[h];
+        hr = zip_rbf(fmaxf(acc, 0.f), w.rnd);
+        dh = hr > 0.f ? zip_rbf(g * w2[h], w.rnd) : 0.f;
+#pragma unroll
+        for (int l = 0; l < LM; ++l) df[l] += l < w.L ? dh * wr[l] : 0.f;
+      }
+      s_dh[tid * HP + h] = from_f32<T>(dh);
+      s_h[tid * HP + h] = from_f32<T>(hr);
+    }
+#pragma unroll
+    for (int l = 0; l < LM; ++l) s_f[tid * LM + l] = from_f32<T>(feat[l]);
+    s_g[tid] = g;
+    if (live) {
+      T* o = (T*)w.dF + p * w.lddf;
+#pragma unroll
+      for (int l = 0; l < LM; ++l) if (l < (int)w.lddf) o[l] = from_f32<T>(l < w.L ? df[l] : 0.f);
+      for (int l = LM; l < (int)w.lddf; ++l) o[l] = from_f32<T>(0.f);
+    }
+    __syncthreads();
+    for (int r = q * 64; r < q * 64 + 64; ++r) {
+      const float dh = to_f32(s_dh[r * HP + hh]);
+      ab1 += dh;
+      aw2 += s_g[r] * to_f32(s_h[r * HP + hh]);
+#pragma unroll
+      for (int l = 0; l < LM; ++l) aw1[l] += dh * to_f32(s_f[r * LM + l]);
+    }
+  }
+  // the four quarters of every hidden unit meet in LDS (s_dh reused), in quarter order; one partial row per workgroup
+  __syncthreads();
+  float* red = (float*)s_dh;                             // [4][64][LM + 2]
+  {
+    float* mine = red + (q * 64 + hh) * (LM + 2);
+#pragma unroll
+    for (int l = 0; l < LM; ++l) mine[l] = aw1[l];
+    mine[LM] = ab1; mine[LM + 1] = aw2;
+  }
+  // d b2: wave sums, then the four waves in order
+  float s = ab2;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (hh == 0) s_g[q] = s;
+  __syncthreads();
+  float* row = w.ws + (long)blockIdx.x * (w.hidden * (w.L + 2) + 1);
+  for (int e = tid; e < w.hidden * (w.L + 2); e += 256) {
+    const int h = e / (w.L + 2), c = e - h * (w.L + 2);
+    const int src = c < w.L ? c : LM + (c - w.L);        // (W1 row | b1 | w2) of hidden unit h
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v += red[(k * 64 + h) * (LM + 2) + src];
+    row[e] = v;
+  }
+  if (tid == 0) row[w.hidden * (w.L + 2)] = ((s_g[0] + s_g[1]) + s_g[2]) + s_g[3];
+}
+
+// g_w1 [hidden, L], g_b1 [hidden], g_w2 [hidden], g_b2 [1] += the workgroups' partial rows, in workgroup order
+__global__ __launch_bounds__(256) void zip_prop_fold_kernel(const float* __restrict__ ws, int rows, int hidden, int L, float* __restrict__ g_w1,
+                                                            float* __restrict__ g_b1, float* __restrict__ g_w2, float* __restrict__ g_b2) {
+  const int n = hidden * (L + 2) + 1;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  float s = 0.f;
+  for (int r = 0; r < rows; ++r) s += ws[(long)r * n + e];
+  if (e == n - 1) { g_b2[0] += s; return; }
+  const int h = e / (L + 2), c = e - h * (L + 2);
+  if (c < L) g_w1[h * L + c] += s;
+  else if (c == L) g_b1[h] += s;
+  else g_w2[h] += s;
+}
+
+extern "C" int snerf_zip_prop_mlp_ws_floats(int L, int hidden, long P) {
+  const long tiles = (P + 255) / 256;
+  const long wgs = tiles < 1024 ? (tiles < 1 ? 1 : tiles) : 1024;
+  return (int)(wgs * (hidden * (L + 2) + 1));
+}
+
+extern "C" int snerf_zip_prop_mlp_fwd(const void* F, long ldf, long P, int L, const float* w1, const float* b1, const float* w2, const float* b2,
+                                      int hidden, int round_bf16, int feat_dtype, float* raw, void* stream) {
+  if (P <= 0) return SNERF_OK;
+  if (F == nullptr || L <= 0 || L > ZPM_L || ldf < L || hidden <= 0 || hidden > ZPM_H || w1 == nullptr || b1 == nullptr || w2 == nullptr ||
+      b2 == nullptr || raw == nullptr)
+    return SNERF_ERR_ARG;
+  ZipPropTrain w{F, ldf, w1, b1, w2, b2, L, hidden, round_bf16, P, raw, nullptr, nullptr, 0, nullptr};
+  const long blocks = (P + 255) / 256;
+  const dim3 grid((unsigned)(blocks < 8192 ? blocks : 8192)), blk(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (feat_dtype == SNERF_DT_BF16) { if (L <= 8) hipLaunchKernelGGL((zip_prop_mlp_fwd_kernel<__bf16, 8>), grid, blk, 0, s, w); else hipLaunchKernelGGL((zip_prop_mlp_fwd_kernel<__bf16, 16>), grid, blk, 0, s, w); }
+  else if (feat_dtype == SNERF_DT_F32) { if (L <= 8) hipLaunchKernelGGL((zip_prop_mlp_fwd_kernel<float, 8>), grid, blk, 0, s, w); else hipLaunchKernelGGL((zip_prop_mlp_fwd_kernel<float, 16>), grid, blk, 0, s, w); }
+  else return SNERF_ERR_ARG;
+  return snerf_check_launch();
+}
+
+// backward of snerf_zip_prop_mlp_fwd: dF [P, lddf] (columns L .. lddf - 1 zero) and g_* += the parameter gradients (fp32, the
+// layouts of the parameters); ws: snerf_zip_prop_mlp_ws_floats(L, hidden, P) floats of scratch
+extern "C" int snerf_zip_prop_mlp_bwd(const void* F, long ldf, const float* d_raw, long P, int L, const float* w1, const float* b1,
+                                      const float* w2, const float* b2, int hidden, int round_bf16, int feat_dtype, void* dF, long lddf,
+                                      float* g_w1, float* g_b1, float* g_w2, float* g_b2, float* ws, long ws_floats, void* stream) {
+  if (P <= 0) return SNERF_OK;
+  if (F == nullptr || d_raw == nullptr || L <= 0 || L > ZPM_L || ldf < L || lddf < L || lddf > 64 || hidden <= 0 || hidden > ZPM_H || w1 == nullptr ||
+      b1 == nullptr || w2 == nullptr || b2 == nullptr || dF == nullptr || g_w1 == nullptr || g_b1 == nullptr || g_w2 == nullptr || g_b2 == nullptr ||
+      ws == nullptr || ws_floats < snerf_zip_prop_mlp_ws_floats(L, hidden, P))
+    return SNERF_ERR_ARG;
+  ZipPropTrain w{F, ldf, w1, b1, w2, b2, L, hidden, round_bf16, P, nullptr, d_raw, dF, lddf, ws};
+  const long tiles = (P + 255) / 256;
+  const int wgs = (int)(tiles < 1024 ? tiles : 1024);
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(wgs), blk(256);
+  if (feat_dtype == SNERF_DT_BF16) { if (L <= 8) hipLaunchKernelGGL((zip_prop_mlp_bwd_kernel<__bf16, 8>), grid, blk, 0, s, w); else hipLaunchKernelGGL((zip_prop_mlp_bwd_kernel<__bf16, 16>), grid, blk, 0, s, w); }
+  else if (feat_dtype == SNERF_DT_F32) { if (L <= 8) hipLaunchKernelGGL((zip_prop_mlp_bwd_kernel<float, 8>), grid, blk, 0, s, w); else hipLaunchKernelGGL((zip_prop_mlp_bwd_kernel<float, 16>), grid, blk, 0, s, w); }
+  else return SNERF_ERR_ARG;
+  const int n = hidden * (L + 2) + 1;
+  hipLaunchKernelGGL(zip_prop_fold_kernel, dim3((n + 255) / 256), dim3(256), 0, s, ws, wgs, hidden, L, g_w1, g_b1, g_w2, g_b2);
+  return snerf_check_launch();
 }
 
 // The training forward of the binned table gradient: snerf_zip_encode_fwd with one level per thread + pass 0 of
@@ -1231,7 +1479,15 @@ __global__ __launch_bounds__(1024) void zip_bin_accumulate_kernel(ZipEnc a, ZipB
   const long s0 = b.starts[level * ZB_NBMAX + bin];
   // 16 waves x 4 records per thread in flight: the record stream is latency-bound (one record per thread and trip took a bin of
   // 2 M records 4 ms whatever the LDS did)
-  constexpr int U = 4;
+  // (round 3: 16 per thread for both record sizes -- train step 52.3-52.9 ms at 4, 51.5-52.2 at 8 / 16, 51.3-51.6 at 16 / 16;
+  // 16 waves per CU leave 128 registers per thread)
+#ifndef ZB_ACC_U4
+#define ZB_ACC_U4 16
+#endif
+#ifndef ZB_ACC_U1
+#define ZB_ACC_U1 16
+#endif
+  constexpr int U = C == 1 ? ZB_ACC_U1 : ZB_ACC_U4;
   for (int r0 = threadIdx.x; r0 < n; r0 += 1024 * U) {
     int row[U];
     float val[U][C];

@@ -1019,7 +1019,24 @@ class ZipPropNet(_Net):
         super().__init__(arena, prefix, dt, variant)
         assert self.km == 1, "split-bf16 (compute='bf16x3') is built for the mip path's networks"
         assert hidden % self.g == 0
-        self.fd, self.H, self.Fw = feat_dim, hidden, roundup(feat_dim, self.g)
+        # fused route (csrc/zip.hip, snerf_zip_prop_mlp_fwd / _bwd): the whole network in one launch each way on a COMPACT feature
+        # buffer (8 or 16 columns instead of the GEMM route's 64): applies to hidden <= 64, feat_dim <= 16; `fused = False` before
+        # the first forward selects the per-layer GEMM route (A/B runs, tests)
+        import os
+        self.fused = hidden <= 64 and feat_dim <= 16 and os.environ.get("SNERF_ZIP_PROP_GEMM", "") == ""     # (the variable: A/B runs of tools/bench_zip.py)
+        self.fd, self.H = feat_dim, hidden
+        self._Fw_gemm = roundup(feat_dim, self.g)
+
+    @property
+    def Fw(self):
+        """columns of the feature buffer the caller allocates"""
+        return roundup(self.fd, 8) if self.fused else self._Fw_gemm
+
+    def _P(self, name):
+        return self.a.p[self.pre + name]
+
+    def _G(self, name):
+        return self.a.g[self.pre + name]
 
     @staticmethod
     def param_shapes(feat_dim, hidden=64):
@@ -1034,6 +1051,10 @@ class ZipPropNet(_Net):
             self._pack_dgrad("d0", ["density_layer.0"], 0, self.fd)
 
     def forward(self, Fb, keep):
+        if self.fused:
+            raw = ops.zip_prop_mlp_fwd(Fb, self.fd, self._P("density_layer.0.weight"), self._P("density_layer.0.bias"),
+                                       self._P("density_layer.2.weight"), self._P("density_layer.2.bias"), self.dt == ops.BF16)
+            return raw, ((Fb,) if keep else None)
         self.ensure_packed(keep)
         M = Fb.shape[0]
         H1 = self.buf(M, self.H)
@@ -1044,6 +1065,11 @@ class ZipPropNet(_Net):
 
     def backward(self, d_raw, saved):
         """-> dF [P, Fw] (gradient w.r.t. the grid features, compute dtype)"""
+        if len(saved) == 1:                   # fused route: the hidden activations are recomputed from the features
+            return ops.zip_prop_mlp_bwd(saved[0], d_raw.reshape(-1), self.fd, self._P("density_layer.0.weight"), self._P("density_layer.0.bias"),
+                                        self._P("density_layer.2.weight"), self._P("density_layer.2.bias"), self.dt == ops.BF16,
+                                        self._G("density_layer.0.weight"), self._G("density_layer.0.bias"), self._G("density_layer.2.weight"),
+                                        self._G("density_layer.2.bias"))
         Fb, H1 = saved
         M = d_raw.shape[0]
         self.colsum(d_raw, 1, self.gB("density_layer.2"))

@@ -670,6 +670,36 @@ def zip_encode_fwd_count(tdist, origins, directions, radii, base_x, base_y, deg_
     return counts, wgo
 
 
+def zip_prop_mlp_fwd(F, L, w1, b1, w2, b2, round_bf16):
+    """Proposal MLP of a training step in one launch: F [P, >= L] (fp32 / bf16, compact) -> raw density [P, 1] fp32."""
+    _chk2d(F, F.dtype)
+    for t in (w1, b1, w2, b2):
+        _f32c(t)
+    P, hidden = F.shape[0], b1.numel()
+    assert F.dtype in (torch.float32, torch.bfloat16) and w1.numel() == hidden * L and w2.numel() == hidden and b2.numel() == 1 and hidden <= 64 and L <= 16
+    raw = torch.empty(P, 1, dtype=torch.float32, device=F.device)
+    _lib.call("snerf_zip_prop_mlp_fwd", _p(F), F.stride(0), P, int(L), _p(w1), _p(b1), _p(w2), _p(b2), hidden, 1 if round_bf16 else 0, _zip_dt(F),
+              _p(raw), _stream())
+    return raw
+
+
+def zip_prop_mlp_bwd(F, d_raw, L, w1, b1, w2, b2, round_bf16, g_w1, g_b1, g_w2, g_b2):
+    """Backward of zip_prop_mlp_fwd: -> dF (F's shape and dtype); the parameter gradients are ADDED into g_* (fp32 views of the
+    parameters' shapes), bit-reproducibly."""
+    _chk2d(F, F.dtype)
+    for t in (w1, b1, w2, b2, g_w1, g_b1, g_w2, g_b2):
+        _f32c(t)
+    P, hidden = F.shape[0], b1.numel()
+    assert d_raw.dtype == torch.float32 and d_raw.is_contiguous() and d_raw.numel() == P and F.shape[1] <= 64
+    assert g_w1.numel() == hidden * L and g_b1.numel() == hidden and g_w2.numel() == hidden and g_b2.numel() == 1
+    dF = torch.empty(P, F.shape[1], dtype=F.dtype, device=F.device)
+    nws = _lib.query("snerf_zip_prop_mlp_ws_floats", int(L), hidden, P)
+    ws = torch.empty(max(int(nws), 1), dtype=torch.float32, device=F.device)
+    _lib.call("snerf_zip_prop_mlp_bwd", _p(F), F.stride(0), _p(d_raw), P, int(L), _p(w1), _p(b1), _p(w2), _p(b2), hidden, 1 if round_bf16 else 0,
+              _zip_dt(F), _p(dF), dF.stride(0), _p(g_w1), _p(g_b1), _p(g_w2), _p(g_b2), _p(ws), ws.numel(), _stream())
+    return dF
+
+
 def zip_encode_prop_fwd(tdist, origins, directions, radii, base_x, base_y, deg_jitter, table, offsets, grid_sizes, L, n, m, Sl, H, std_scale,
                         w1, b1, w2, b2, round_bf16):
     """Fused featurisation + proposal MLP of one proposal level (inference) -> raw density [R*S, 1] fp32."""

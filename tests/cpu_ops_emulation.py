@@ -305,6 +305,34 @@ def zip_encode_fwd_count(tdist, origins, directions, radii, base_x, base_y, deg_
     return ("precounted", tuple(ksplit))                # (what the emulated backward checks it was handed back)
 
 
+def _zpm_rb(t, rnd):
+    return t.bfloat16().float() if rnd else t
+
+
+def _zpm_hidden(F, L, w1, b1, rnd):
+    f = F[:, :L].float()
+    return _zpm_rb(torch.relu(f @ _zpm_rb(w1.reshape(-1, L), rnd).T + b1), rnd), f
+
+
+def zip_prop_mlp_fwd(F, L, w1, b1, w2, b2, round_bf16):
+    H, _ = _zpm_hidden(F, L, w1, b1, round_bf16)
+    return (H @ _zpm_rb(w2.reshape(-1), round_bf16) + b2).reshape(-1, 1)
+
+
+def zip_prop_mlp_bwd(F, d_raw, L, w1, b1, w2, b2, round_bf16, g_w1, g_b1, g_w2, g_b2):
+    rnd = round_bf16
+    H, f = _zpm_hidden(F, L, w1, b1, rnd)
+    g = _zpm_rb(d_raw.reshape(-1, 1).float(), rnd)
+    dh = torch.where(H > 0, _zpm_rb(g * _zpm_rb(w2.reshape(1, -1), rnd), rnd), torch.zeros_like(H))
+    dF = torch.zeros(F.shape, dtype=F.dtype)
+    dF[:, :L] = (dh @ _zpm_rb(w1.reshape(-1, L), rnd)).to(F.dtype)
+    g_w1 += (dh.T @ f).reshape(g_w1.shape)
+    g_b1 += dh.sum(0)
+    g_w2 += (g * H).sum(0).reshape(g_w2.shape)
+    g_b2 += d_raw.sum()
+    return dF
+
+
 def zip_encode_bwd(tdist, origins, directions, radii, base_x, base_y, deg_jitter, offsets, grid_sizes, grad_feat, grad_table, L, C, n, m, Sl, H,
                    std_scale, lds_levels=0, lds_cells=0, lds_slabs=0, grad_table_bf16=None):
     from oracle import grid as og
@@ -752,7 +780,7 @@ def adam_step_dev(p, g, m, v, lr, b1, b2, eps, step_dev, grad_scale=1.0, zero_gr
     adam_step(p, g, m, v, lr, b1, b2, eps, 0, grad_scale, zero_grad, step_dev=step_dev, **kw)
 
 
-_NAMES = ["colsum_wide_f32", "zip_glo_modulate", "zip_glo_modulate_bwd", "fchain_bwd", "app_embed", "app_embed_bwd", "split_cast", "fcolour_fwd", "fcolour_bwd", "gather_pack", "adam_step_dev", "grad_clip_coef", "fmlp_classic_fwd", "fmlp_classic_pts_fwd", "fmlp_proposal_fwd", "fmlp_classic_train_fwd", "fmlp_proposal_train_fwd", "classic_get_rays", "classic_ndc_rays", "classic_ray_batch", "zip_encode_prop_fwd", "mip_encode_bwd", "mip_viewenc_bwd", "hash_decay", "zip_percentiles", "zip_pixels_to_rays", "zip_loss_tail", "semantic_composite_fwd", "semantic_composite_bwd", "zip_resample", "zip_encode_fwd", "zip_encode_fwd_count", "zip_encode_bwd", "zip_encode_bwd_binned", "zip_encode_ray_bwd", "zip_composite_fwd", "zip_composite_bwd",
+_NAMES = ["zip_prop_mlp_fwd", "zip_prop_mlp_bwd", "colsum_wide_f32", "zip_glo_modulate", "zip_glo_modulate_bwd", "fchain_bwd", "app_embed", "app_embed_bwd", "split_cast", "fcolour_fwd", "fcolour_bwd", "gather_pack", "adam_step_dev", "grad_clip_coef", "fmlp_classic_fwd", "fmlp_classic_pts_fwd", "fmlp_proposal_fwd", "fmlp_classic_train_fwd", "fmlp_proposal_train_fwd", "classic_get_rays", "classic_ndc_rays", "classic_ray_batch", "zip_encode_prop_fwd", "mip_encode_bwd", "mip_viewenc_bwd", "hash_decay", "zip_percentiles", "zip_pixels_to_rays", "zip_loss_tail", "semantic_composite_fwd", "semantic_composite_bwd", "zip_resample", "zip_encode_fwd", "zip_encode_fwd_count", "zip_encode_bwd", "zip_encode_bwd_binned", "zip_encode_ray_bwd", "zip_composite_fwd", "zip_composite_bwd",
           "linear_fwd", "linear_wgrad", "classic_embed", "mip_encode", "mip_viewenc", "classic_sample_pdf", "classic_points",
           "classic_merge_sort", "mip_resample", "stratified", "mip_composite_fwd", "mip_composite_bwd", "classic_composite_fwd",
           "classic_composite_bwd", "adam_step", "colsum_f32", "cast_pad", "pinhole_rays", "mip_loss_tail"]

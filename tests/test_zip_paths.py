@@ -701,3 +701,48 @@ def test_binned_table_gradient_refuses_tables_with_more_row_ranges_than_bins():
     with pytest.raises(_lib.SnerfHipError, match="bad argument"):
         _lib.call("snerf_zip_encode_bwd_binned", 0, None, None, None, None, None, None, None, None, None, None, 8, None, 16, 4, 2, 4, 7, 3, 0.5, 16, 0.35,
                   1, k2.ctypes.data, big.ctypes.data, 1, 1, None, None, None, 0, None, 0, None, None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("L,hidden,P,dt", [(6, 64, 70001, "bf16"), (8, 64, 4096, "bf16"), (8, 64, 33333, "f32"), (12, 32, 1000, "bf16"), (16, 64, 777, "f32")])
+def test_fused_proposal_mlp_train_kernels(L, hidden, P, dt):
+    """snerf_zip_prop_mlp_fwd / _bwd (the proposal MLP of a training step in one launch each way, hidden activations recomputed in the
+    backward) against the torch restatement with the GEMM route's rounding points (tests/cpu_ops_emulation.py); ragged interval counts,
+    L <= 8 and L <= 16 instantiations, fewer than 64 hidden units; parameter gradients accumulate and are bit-reproducible."""
+    from snerf_amd import ops
+    import cpu_ops_emulation as E
+    g = torch.Generator().manual_seed(L * 1000 + hidden)
+    tdt = torch.bfloat16 if dt == "bf16" else torch.float32
+    rnd = dt == "bf16"
+    Fw = (L + 7) // 8 * 8
+    F = torch.zeros(P, Fw)
+    F[:, :L] = torch.randn(P, L, generator=g) * 0.5
+    F = F.to(tdt)
+    w1 = torch.randn(hidden, L, generator=g) * 0.4
+    b1 = torch.randn(hidden, generator=g) * 0.2
+    w2 = torch.randn(1, hidden, generator=g) * 0.3
+    b2 = torch.randn(1, generator=g)
+    d_raw = torch.randn(P, generator=g) * 1e-3
+    ref_raw = E.zip_prop_mlp_fwd(F, L, w1, b1, w2, b2, rnd)
+    gref = [torch.full_like(t, 0.5) for t in (w1, b1, w2, b2)]                       # (the gradients ACCUMULATE)
+    ref_dF = E.zip_prop_mlp_bwd(F, d_raw, L, w1, b1, w2, b2, rnd, *gref)
+    c = lambda t: t.cuda().contiguous()
+    Fc, pc, dc = c(F), [c(t) for t in (w1, b1, w2, b2)], c(d_raw)
+    raw = ops.zip_prop_mlp_fwd(Fc, L, *pc, rnd)
+    err = float((raw.cpu() - ref_raw).abs().max() / ref_raw.abs().max())
+    print(f"MEASURED fused proposal MLP L={L} hidden={hidden} {dt}: forward max rel err {err:.2e}")
+    assert err < (2e-3 if rnd else 1e-5), err                                       # bf16: a hidden activation may round the other way (fp32 sum order)
+    outs = []
+    for _ in range(2):
+        gg = [torch.full_like(t, 0.5).cuda() for t in (w1, b1, w2, b2)]
+        dF = ops.zip_prop_mlp_bwd(Fc, dc, L, *pc, rnd, *gg)
+        outs.append((dF, gg))
+    assert torch.equal(outs[0][0], outs[1][0]) and all(torch.equal(a, b) for a, b in zip(outs[0][1], outs[1][1])), "must be bit-reproducible"
+    dF, gg = outs[0]
+    assert dF.dtype == tdt and dF.shape == (P, Fw) and float(dF[:, L:].float().abs().max() if Fw > L else 0.0) == 0.0
+    e_df = float((dF.float().cpu() - ref_dF.float()).norm() / ref_dF.float().norm())
+    assert e_df < (1e-2 if rnd else 1e-5), e_df
+    for name, a, b in zip(("w1", "b1", "w2", "b2"), gg, gref):
+        e = float((a.cpu() - b).norm() / (b - 0.5).norm().clamp_min(1e-12))
+        print(f"MEASURED fused proposal MLP d {name}: rel L2 {e:.2e}")
+        assert e < (1e-2 if rnd else 2e-5), (name, e)
