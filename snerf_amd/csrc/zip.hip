@@ -921,105 +921,153 @@ struct ZipPropTrain {
   float* ws;                                             // backward: [workgroups, hidden (L + 2) + 1] partial sums
 };
 
+typedef float zpm_f2 __attribute__((ext_vector_type(2)));
+template <bool RND> __device__ __forceinline__ float zpm_rb(float v) { if constexpr (RND) return (float)(__bf16)v; else return v; }
+// weights in LDS, ZERO-PADDED to ZPM_H hidden units x LM feature slots: [h][LM] W1 | b1[ZPM_H] | w2[ZPM_H] | b2 -- a padded unit has
+// b1 = w2 = 0 (its activation and gradient are 0), a padded feature slot multiplies zeros: the kernels' loops have fixed trip counts
+// and no L / hidden predicates
+template <int LM, bool RND>
 __device__ __forceinline__ void zpm_load_weights(const ZipPropTrain& w, float* lw) {
-  const int nw1 = w.hidden * w.L;
-  for (int k = threadIdx.x; k < nw1; k += 256) lw[k] = zip_rbf(w.w1[k], w.rnd);
-  for (int k = threadIdx.x; k < w.hidden; k += 256) { lw[nw1 + k] = w.b1[k]; lw[nw1 + w.hidden + k] = zip_rbf(w.w2[k], w.rnd); }
-  if (threadIdx.x == 0) lw[nw1 + 2 * w.hidden] = w.b2[0];
+  for (int k = threadIdx.x; k < ZPM_H * LM; k += 256) {
+    const int h = k / LM, l = k - h * LM;
+    lw[k] = (h < w.hidden && l < w.L) ? zpm_rb<RND>(w.w1[h * w.L + l]) : 0.f;
+  }
+  for (int k = threadIdx.x; k < ZPM_H; k += 256) {
+    lw[ZPM_H * LM + k] = k < w.hidden ? w.b1[k] : 0.f;
+    lw[ZPM_H * LM + ZPM_H + k] = k < w.hidden ? zpm_rb<RND>(w.w2[k]) : 0.f;
+  }
+  if (threadIdx.x == 0) lw[ZPM_H * LM + 2 * ZPM_H] = w.b2[0];
 }
 
+// an interval's features: one 16- / 32-byte load per 8 bf16 / fp32 when the buffer allows it (`vec`: ld a multiple of 8 and >= LM,
+// 16-byte aligned base; columns >= L of such a buffer are zeros or hit zero weights), element-wise otherwise
 template <typename T, int LM>
-__global__ __launch_bounds__(256) void zip_prop_mlp_fwd_kernel(ZipPropTrain w) {
-  __shared__ float lw[ZPM_H * ZPM_L + 2 * ZPM_H + 1];
-  zpm_load_weights(w, lw);
-  __syncthreads();
-  const int nw1 = w.hidden * w.L;
-  const float* b1 = lw + nw1;
-  const float* w2 = b1 + w.hidden;
-  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < w.P; p += (long)gridDim.x * 256) {
-    const T* f = (const T*)w.F + p * w.ldf;
-    float feat[LM];
+__device__ __forceinline__ void zpm_load_row(const T* f, int L, bool vec, float* feat) {
+  if (vec) {
 #pragma unroll
-    for (int l = 0; l < LM; ++l) feat[l] = l < w.L ? to_f32(f[l]) : 0.f;
-    float out = 0.f;
-    for (int h = 0; h < w.hidden; ++h) {
-      const float* wr = lw + h * w.L;
-      float acc = 0.f;
+    for (int c = 0; c < LM; c += 8) {
+      if constexpr (sizeof(T) == 2) {
+        const bf16x8 v = *(const bf16x8*)(f + c);
 #pragma unroll
-      for (int l = 0; l < LM; ++l) acc += l < w.L ? feat[l] * wr[l] : 0.f;
-      acc += b1[h];
-      out += zip_rbf(fmaxf(acc, 0.f), w.rnd) * w2[h];
+        for (int e = 0; e < 8; ++e) feat[c + e] = (float)v[e];
+      } else {
+        const f32x4 v0 = *(const f32x4*)(f + c), v1 = *(const f32x4*)(f + c + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { feat[c + e] = v0[e]; feat[c + 4 + e] = v1[e]; }
+      }
     }
-    w.raw[p] = out + lw[nw1 + 2 * w.hidden];
+  } else {
+#pragma unroll
+    for (int l = 0; l < LM; ++l) feat[l] = l < L ? to_f32(f[l]) : 0.f;
+  }
+}
+
+template <typename T, int LM, bool RND>
+__global__ __launch_bounds__(256) void zip_prop_mlp_fwd_kernel(ZipPropTrain w) {
+  __shared__ __attribute__((aligned(16))) float lw[ZPM_H * LM + 2 * ZPM_H + 1];
+  zpm_load_weights<LM, RND>(w, lw);
+  __syncthreads();
+  const float* b1 = lw + ZPM_H * LM;
+  const float* w2 = b1 + ZPM_H;
+  const bool vec = (w.ldf % 8 == 0) && w.ldf >= LM && ((uintptr_t)w.F % 16 == 0);
+  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < w.P; p += (long)gridDim.x * 256) {
+    float feat[LM];
+    zpm_load_row<T, LM>((const T*)w.F + p * w.ldf, w.L, vec, feat);
+    zpm_f2 f2[LM / 2];
+#pragma unroll
+    for (int k = 0; k < LM / 2; ++k) f2[k] = zpm_f2{feat[2 * k], feat[2 * k + 1]};
+    float out = 0.f;
+#pragma unroll 4
+    for (int h = 0; h < ZPM_H; ++h) {
+      const zpm_f2* wr = (const zpm_f2*)(lw + h * LM);
+      zpm_f2 a2 = {b1[h], 0.f};
+#pragma unroll
+      for (int k = 0; k < LM / 2; ++k) a2 = __builtin_elementwise_fma(f2[k], wr[k], a2);      // (packed fp32 FMA: two slots per instruction)
+      out = __builtin_fmaf(zpm_rb<RND>(fmaxf(a2[0] + a2[1], 0.f)), w2[h], out);
+    }
+    w.raw[p] = out + lw[ZPM_H * LM + 2 * ZPM_H];
   }
 }
 
 // LM: feature slots per interval (8 or 16 >= L).  The tile arrays hold T: in bf16 mode every value in them is a rounded bf16 already
-// (80 KB: two workgroups per CU); the fp32 mode keeps floats (one workgroup per CU).
-template <typename T, int LM>
+// (two workgroups per CU); the fp32 mode keeps floats (one workgroup per CU).
+template <typename T, int LM, bool RND>
 __global__ __launch_bounds__(256) void zip_prop_mlp_bwd_kernel(ZipPropTrain w) {
   constexpr int HP = ZPM_H + (sizeof(T) == 2 ? 2 : 1);   // row pitch of the tile arrays (written row-wise, read column-wise)
-  __shared__ float lw[ZPM_H * ZPM_L + 2 * ZPM_H + 1];
+  __shared__ __attribute__((aligned(16))) float lw[ZPM_H * LM + 2 * ZPM_H + 1];
   __shared__ __attribute__((aligned(16))) T s_dh[256 * HP];
   __shared__ __attribute__((aligned(16))) T s_h[256 * HP];
-  __shared__ __attribute__((aligned(16))) T s_f[256 * LM];
+  __shared__ __attribute__((aligned(16))) float s_f[256 * LM];
   __shared__ float s_g[256];
   static_assert(sizeof(T) * 256 * HP >= sizeof(float) * 4 * 64 * (LM + 2), "s_dh doubles as the quarter-reduction buffer");
-  zpm_load_weights(w, lw);
-  const int nw1 = w.hidden * w.L;
-  const float* b1 = lw + nw1;
-  const float* w2 = b1 + w.hidden;
+  zpm_load_weights<LM, RND>(w, lw);
+  const float* b1 = lw + ZPM_H * LM;
+  const float* w2 = b1 + ZPM_H;
   const int tid = threadIdx.x, hh = tid & 63, q = tid >> 6;
-  float aw1[LM], ab1 = 0.f, aw2 = 0.f, ab2 = 0.f;
+  const bool vec = (w.ldf % 8 == 0) && w.ldf >= LM && ((uintptr_t)w.F % 16 == 0);
+  const bool vec_out = sizeof(T) == 2 && w.lddf == LM && LM == 8 && ((uintptr_t)w.dF % 16 == 0);
+  zpm_f2 aw1[LM / 2];
+  float ab1 = 0.f, aw2 = 0.f, ab2 = 0.f;
 #pragma unroll
-  for (int l = 0; l < LM; ++l) aw1[l] = 0.f;
+  for (int k = 0; k < LM / 2; ++k) aw1[k] = zpm_f2{0.f, 0.f};
   const long tiles = (w.P + 255) >> 8;
   for (long t = blockIdx.x; t < tiles; t += gridDim.x) {
     __syncthreads();                                     // (weights loaded / the previous tile's sums done)
     const long p = (t << 8) + tid;
     const bool live = p < w.P;
     float feat[LM];
-    const T* f = (const T*)w.F + (live ? p : 0) * w.ldf;
-#pragma unroll
-    for (int l = 0; l < LM; ++l) feat[l] = (live && l < w.L) ? to_f32(f[l]) : 0.f;
+    zpm_load_row<T, LM>((const T*)w.F + (live ? p : 0) * w.ldf, w.L, vec, feat);
     const float draw = live ? w.d_raw[p] : 0.f;
-    const float g = zip_rbf(draw, w.rnd);
+    const float g = live ? zpm_rb<RND>(draw) : 0.f;
     ab2 += draw;
-    float df[LM];
+    zpm_f2 f2[LM / 2], df2[LM / 2];
 #pragma unroll
-    for (int l = 0; l < LM; ++l) df[l] = 0.f;
+    for (int k = 0; k < LM / 2; ++k) { f2[k] = zpm_f2{feat[2 * k], feat[2 * k + 1]}; df2[k] = zpm_f2{0.f, 0.f}; }
+#pragma unroll 4
     for (int h = 0; h < ZPM_H; ++h) {
-      float hr = 0.f, dh = 0.f;
-      if (h < w.hidden) {
-        const float* wr = lw + h * w.L;
-        float acc = 0.f;
+      const zpm_f2* wr = (const zpm_f2*)(lw + h * LM);
+      zpm_f2 a2 = {b1[h], 0.f};
 #pragma unroll
-        for (int l = 0; l < LM; ++l) acc += l < w.L ? feat[l] * wr[l] : 0.f;
-        acc += b1[h];
-        hr = zip_rbf(fmaxf(acc, 0.f), w.rnd);
-        dh = hr > 0.f ? zip_rbf(g * w2[h], w.rnd) : 0.f;
+      for (int k = 0; k < LM / 2; ++k) a2 = __builtin_elementwise_fma(f2[k], wr[k], a2);
+      const float hr = zpm_rb<RND>(fmaxf(a2[0] + a2[1], 0.f));
+      const float dh = zpm_rb<RND>(g * w2[h]) * (hr > 0.f ? 1.f : 0.f);          // (a select, not a branch around the LDS read)
+      const zpm_f2 dh2 = {dh, dh};
 #pragma unroll
-        for (int l = 0; l < LM; ++l) df[l] += l < w.L ? dh * wr[l] : 0.f;
-      }
+      for (int k = 0; k < LM / 2; ++k) df2[k] = __builtin_elementwise_fma(dh2, wr[k], df2[k]);
       s_dh[tid * HP + h] = from_f32<T>(dh);
       s_h[tid * HP + h] = from_f32<T>(hr);
     }
+    float df[LM];
 #pragma unroll
-    for (int l = 0; l < LM; ++l) s_f[tid * LM + l] = from_f32<T>(feat[l]);
+    for (int k = 0; k < LM / 2; ++k) { df[2 * k] = df2[k][0]; df[2 * k + 1] = df2[k][1]; }
+#pragma unroll
+    for (int l = 0; l < LM; ++l) s_f[tid * LM + l] = (live && l < w.L) ? feat[l] : 0.f;
     s_g[tid] = g;
     if (live) {
       T* o = (T*)w.dF + p * w.lddf;
+      if (vec_out) {
+        if constexpr (sizeof(T) == 2 && LM == 8) {
+          bf16x8 v;
 #pragma unroll
-      for (int l = 0; l < LM; ++l) if (l < (int)w.lddf) o[l] = from_f32<T>(l < w.L ? df[l] : 0.f);
-      for (int l = LM; l < (int)w.lddf; ++l) o[l] = from_f32<T>(0.f);
+          for (int e = 0; e < 8; ++e) v[e] = (__bf16)df[e];
+          *(bf16x8*)o = v;                               // (columns >= L: sums over zero weights = the zeros the layout asks for)
+        }
+      } else {
+#pragma unroll
+        for (int l = 0; l < LM; ++l) if (l < (int)w.lddf) o[l] = from_f32<T>(l < w.L ? df[l] : 0.f);
+        for (int l = LM; l < (int)w.lddf; ++l) o[l] = from_f32<T>(0.f);
+      }
     }
     __syncthreads();
+#pragma unroll 4
     for (int r = q * 64; r < q * 64 + 64; ++r) {
       const float dh = to_f32(s_dh[r * HP + hh]);
       ab1 += dh;
-      aw2 += s_g[r] * to_f32(s_h[r * HP + hh]);
+      aw2 = __builtin_fmaf(s_g[r], to_f32(s_h[r * HP + hh]), aw2);
+      const zpm_f2 dh2 = {dh, dh};
+      const zpm_f2* fr = (const zpm_f2*)(s_f + r * LM);
 #pragma unroll
-      for (int l = 0; l < LM; ++l) aw1[l] += dh * to_f32(s_f[r * LM + l]);
+      for (int k = 0; k < LM / 2; ++k) aw1[k] = __builtin_elementwise_fma(dh2, fr[k], aw1[k]);
     }
   }
   // the four quarters of every hidden unit meet in LDS (s_dh reused), in quarter order; one partial row per workgroup
@@ -1028,7 +1076,7 @@ __global__ __launch_bounds__(256) void zip_prop_mlp_bwd_kernel(ZipPropTrain w) {
   {
     float* mine = red + (q * 64 + hh) * (LM + 2);
 #pragma unroll
-    for (int l = 0; l < LM; ++l) mine[l] = aw1[l];
+    for (int k = 0; k < LM / 2; ++k) { mine[2 * k] = aw1[k][0]; mine[2 * k + 1] = aw1[k][1]; }
     mine[LM] = ab1; mine[LM + 1] = aw2;
   }
   // d b2: wave sums, then the four waves in order
@@ -1049,14 +1097,18 @@ __global__ __launch_bounds__(256) void zip_prop_mlp_bwd_kernel(ZipPropTrain w) {
   if (tid == 0) row[w.hidden * (w.L + 2)] = ((s_g[0] + s_g[1]) + s_g[2]) + s_g[3];
 }
 
-// g_w1 [hidden, L], g_b1 [hidden], g_w2 [hidden], g_b2 [1] += the workgroups' partial rows, in workgroup order
+// g_w1 [hidden, L], g_b1 [hidden], g_w2 [hidden], g_b2 [1] += the workgroups' partial rows: one wave per element, lane i adds rows i,
+// i + 64, ... in order, then the fixed butterfly over the lanes -- the same sum whatever the schedule
 __global__ __launch_bounds__(256) void zip_prop_fold_kernel(const float* __restrict__ ws, int rows, int hidden, int L, float* __restrict__ g_w1,
                                                             float* __restrict__ g_b1, float* __restrict__ g_w2, float* __restrict__ g_b2) {
   const int n = hidden * (L + 2) + 1;
-  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (e >= n) return;
   float s = 0.f;
-  for (int r = 0; r < rows; ++r) s += ws[(long)r * n + e];
+  for (int r = lane; r < rows; r += 64) s += ws[(long)r * n + e];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane != 0) return;
   if (e == n - 1) { g_b2[0] += s; return; }
   const int h = e / (L + 2), c = e - h * (L + 2);
   if (c < L) g_w1[h * L + c] += s;
@@ -1080,9 +1132,12 @@ extern "C" int snerf_zip_prop_mlp_fwd(const void* F, long ldf, long P, int L, co
   const long blocks = (P + 255) / 256;
   const dim3 grid((unsigned)(blocks < 8192 ? blocks : 8192)), blk(256);
   hipStream_t s = (hipStream_t)stream;
-  if (feat_dtype == SNERF_DT_BF16) { if (L <= 8) hipLaunchKernelGGL((zip_prop_mlp_fwd_kernel<__bf16, 8>), grid, blk, 0, s, w); else hipLaunchKernelGGL((zip_prop_mlp_fwd_kernel<__bf16, 16>), grid, blk, 0, s, w); }
-  else if (feat_dtype == SNERF_DT_F32) { if (L <= 8) hipLaunchKernelGGL((zip_prop_mlp_fwd_kernel<float, 8>), grid, blk, 0, s, w); else hipLaunchKernelGGL((zip_prop_mlp_fwd_kernel<float, 16>), grid, blk, 0, s, w); }
+#define ZPM_F(T, RN) do { if (L <= 8) hipLaunchKernelGGL((zip_prop_mlp_fwd_kernel<T, 8, RN>), grid, blk, 0, s, w); \
+                          else hipLaunchKernelGGL((zip_prop_mlp_fwd_kernel<T, 16, RN>), grid, blk, 0, s, w); } while (0)
+  if (feat_dtype == SNERF_DT_BF16) { if (round_bf16) ZPM_F(__bf16, true); else ZPM_F(__bf16, false); }
+  else if (feat_dtype == SNERF_DT_F32) { if (round_bf16) ZPM_F(float, true); else ZPM_F(float, false); }
   else return SNERF_ERR_ARG;
+#undef ZPM_F
   return snerf_check_launch();
 }
 
@@ -1101,11 +1156,14 @@ extern "C" int snerf_zip_prop_mlp_bwd(const void* F, long ldf, const float* d_ra
   const int wgs = (int)(tiles < 1024 ? tiles : 1024);
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(wgs), blk(256);
-  if (feat_dtype == SNERF_DT_BF16) { if (L <= 8) hipLaunchKernelGGL((zip_prop_mlp_bwd_kernel<__bf16, 8>), grid, blk, 0, s, w); else hipLaunchKernelGGL((zip_prop_mlp_bwd_kernel<__bf16, 16>), grid, blk, 0, s, w); }
-  else if (feat_dtype == SNERF_DT_F32) { if (L <= 8) hipLaunchKernelGGL((zip_prop_mlp_bwd_kernel<float, 8>), grid, blk, 0, s, w); else hipLaunchKernelGGL((zip_prop_mlp_bwd_kernel<float, 16>), grid, blk, 0, s, w); }
+#define ZPM_B(T, RN) do { if (L <= 8) hipLaunchKernelGGL((zip_prop_mlp_bwd_kernel<T, 8, RN>), grid, blk, 0, s, w); \
+                          else hipLaunchKernelGGL((zip_prop_mlp_bwd_kernel<T, 16, RN>), grid, blk, 0, s, w); } while (0)
+  if (feat_dtype == SNERF_DT_BF16) { if (round_bf16) ZPM_B(__bf16, true); else ZPM_B(__bf16, false); }
+  else if (feat_dtype == SNERF_DT_F32) { if (round_bf16) ZPM_B(float, true); else ZPM_B(float, false); }
   else return SNERF_ERR_ARG;
+#undef ZPM_B
   const int n = hidden * (L + 2) + 1;
-  hipLaunchKernelGGL(zip_prop_fold_kernel, dim3((n + 255) / 256), dim3(256), 0, s, ws, wgs, hidden, L, g_w1, g_b1, g_w2, g_b2);
+  hipLaunchKernelGGL(zip_prop_fold_kernel, dim3((n + 3) / 4), dim3(256), 0, s, ws, wgs, hidden, L, g_w1, g_b1, g_w2, g_b2);
   return snerf_check_launch();
 }
 
