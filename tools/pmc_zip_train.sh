@@ -7,6 +7,6 @@ run() { tag=$1; shift; timeout 200 rocprofv3 --kernel-trace --pmc "$@" --output-
 run tcc2 FETCH_SIZE
 run tcc3 WRITE_SIZE
 run tcc1 TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum
-for k in "zip_bin_write_staged_kernelIDF16bLi4" "zip_bin_emit_kernelIDF16bLi4ELi1" "E, 1>" "zip_bin_accumulate_kernel<4>" "zip_bin_accumulate_kernel<1>" "zip_encode_fwd_all"; do
+for k in "zip_bin_write_staged_kernelIDF16bLi4" "E, 1>" "zip_bin_accumulate_kernel<4>" "zip_bin_accumulate_kernel<1>" "zip_encode_fwd_all_kernelI6__half" "E, true>" "zip_prop_mlp_bwd" "zip_prop_mlp_fwd"; do
   python $ROOT/tools/pmc_summary.py $ROOT/gpurun_out/pmc_zip_train "$k" | grep -v "^SQ\|wave_cyc" | head -12
 done
