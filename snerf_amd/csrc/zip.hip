@@ -958,6 +958,9 @@ __device__ __forceinline__ void zpm_load_row(const T* f, int L, bool vec, float*
         for (int e = 0; e < 4; ++e) { feat[c + e] = v0[e]; feat[c + 4 + e] = v1[e]; }
       }
     }
+    // (padding columns are never trusted: a NaN there would survive the zero weights)
+#pragma unroll
+    for (int l = 0; l < LM; ++l) feat[l] = l < L ? feat[l] : 0.f;
   } else {
 #pragma unroll
     for (int l = 0; l < LM; ++l) feat[l] = l < L ? to_f32(f[l]) : 0.f;

@@ -728,6 +728,8 @@ def test_fused_proposal_mlp_train_kernels(L, hidden, P, dt):
     ref_dF = E.zip_prop_mlp_bwd(F, d_raw, L, w1, b1, w2, b2, rnd, *gref)
     c = lambda t: t.cuda().contiguous()
     Fc, pc, dc = c(F), [c(t) for t in (w1, b1, w2, b2)], c(d_raw)
+    if Fw > L:
+        Fc[:, L:] = float("nan")                                                     # padding columns are not read as data
     raw = ops.zip_prop_mlp_fwd(Fc, L, *pc, rnd)
     err = float((raw.cpu() - ref_raw).abs().max() / ref_raw.abs().max())
     print(f"MEASURED fused proposal MLP L={L} hidden={hidden} {dt}: forward max rel err {err:.2e}")
