@@ -255,6 +255,12 @@ struct StoreTo {
 // that pass through an XCD's L2 evict the weight stream every workgroup re-reads per tile (gemm.hip, the epilogue units' stores).
 // Measured (round 3, A/B/A on one box): training forward 9.56 -> 9.31 ms per 6.3 M rows, classic gradient chain 10.4-10.9 -> 10.3 ms,
 // path-B train step 47.9 / 48.2 -> 46.8 ms.
+#ifndef FM_STAGGER
+#define FM_STAGGER 0
+#endif
+#ifndef FM_ABLATE
+#define FM_ABLATE 0       // PROBE builds: 1 = no row-store / mask-store instructions (everything else of the store path stays)
+#endif
 #ifndef FM_NT_STORES
 #define FM_NT_STORES 1
 #endif
@@ -288,8 +294,12 @@ __device__ __forceinline__ void store_block(const StoreTo& st, const bf16x8& lo,
       const int row = 8 * it + prow;
       const fm_u32x4 v = vs[it];
       if (st.row0 + row < st.M) {
+#if FM_ABLATE == 1
+        asm volatile("" ::"v"(v));                       // PROBE (-DFM_ABLATE=1): the whole store path but the row-store instruction itself
+#else
         if constexpr (FM_NT_STORES) __builtin_nontemporal_store(v, (fm_u32x4*)(dst + (long)(8 * it) * st.ld));
         else *(fm_u32x4*)(dst + (long)(8 * it) * st.ld) = v;
+#endif
         if constexpr (BITS) {
           // a ReLU output is > 0 iff its 16 bits are not 0: min(half word, 1), even elements gathered in bits 0, 2, 4, 6, odd ones 16 higher
           typedef unsigned short fm_u16x2 __attribute__((ext_vector_type(2)));
@@ -304,19 +314,120 @@ __device__ __forceinline__ void store_block(const StoreTo& st, const bf16x8& lo,
         }
       }
     }
+#if FM_ABLATE == 1
+    if constexpr (BITS) asm volatile("" ::"v"(mw));
+#else
     if constexpr (BITS) st.bits[((st.row0 >> 5) * st.ncg + (J >> 1)) * 64 + st.lane] = mw;   // 256 contiguous bytes per wave; rows >= M: zeros
+#endif
   }
 }
 
+// EXPERIMENT, off: the same store path cut into PIECES that ride between the MFMAs of the NEXT block (FM_DEFER_STORES, round 3).  Measured on the
+// training forward (6.3 M rows): 5.6 ms without any store path, 7.2 ms with everything but the store instructions, 9.5 ms with them --
+// the eight waves reach their block ends together (chunk barriers), so the CU's vector-memory path sees 32 store instructions at once
+// and every wave waits at issue with its MFMAs behind it.  A block's outputs stay live as the next layer's operands anyway, so its
+// store work needs no extra registers to be postponed: piece 0 (the slab writes) and, for the second block of a pair, pieces 1..4 (one
+// read-back + row store + mask bits each) and 5 (the mask word) are issued a few MFMAs apart inside the following block.
+// Result: correct (all tests), 4 % SLOWER -- every piece ends in the full LDS drain hipcc puts before a use of LDS data while an LDS-DMA
+// is pending, which empties the fragment queue four more times per block; the two waves of a SIMD pass the same pieces at
+// the same MFMA positions, so the pipe is not kept busier either.
+template <bool BITS, int J, int P>
+__device__ __forceinline__ void store_piece(const StoreTo& st, const bf16x8& lo, const bf16x8& hi, unsigned& mw) {
+  const int r = st.lane & 31, half = st.lane >> 5;
+  typedef unsigned fm_u32x2 __attribute__((ext_vector_type(2)));
+  if constexpr (P == 0) {
+    char* w = st.slab + r * 128 + 8 * half;
+    const fm_u32x4 l = __builtin_bit_cast(fm_u32x4, lo), h = __builtin_bit_cast(fm_u32x4, hi);
+    constexpr int C0 = 4 * (J & 1);
+    *(fm_u32x2*)(w + (((C0 + 0) ^ (r & 7)) << 4)) = fm_u32x2{l[0], l[1]};
+    *(fm_u32x2*)(w + (((C0 + 1) ^ (r & 7)) << 4)) = fm_u32x2{l[2], l[3]};
+    *(fm_u32x2*)(w + (((C0 + 2) ^ (r & 7)) << 4)) = fm_u32x2{h[0], h[1]};
+    *(fm_u32x2*)(w + (((C0 + 3) ^ (r & 7)) << 4)) = fm_u32x2{h[2], h[3]};
+    if constexpr ((J & 1) == 1) mw = 0;
+  } else if constexpr ((J & 1) == 1 && P >= 1 && P <= 4) {
+    constexpr int it = P - 1;
+    // (the lane id through an opaque zero: otherwise hipcc hoists the row addresses of every (layer, piece) -- forty 64-bit values --
+    // out of the tile loop and spills them; a scratch reload then costs a vmcnt(0) in every block)
+    int zero;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
+    const int ln = st.lane | zero;
+    const int prow = ln >> 3, pch = ln & 7;
+    const int row = 8 * it + prow;
+    fm_u32x4 v = *(const fm_u32x4*)(st.slab + row * 128 + ((pch ^ (row & 7)) << 4));
+    asm volatile("" : "+v"(v));                          // (the read-back stays ahead of the row-bound branch)
+    if (st.row0 + row < st.M) {
+      __bf16* dst = st.y + (st.row0 + prow) * st.ld + 64 * (J >> 1) + 8 * pch;
+      if constexpr (FM_NT_STORES) __builtin_nontemporal_store(v, (fm_u32x4*)(dst + (long)(8 * it) * st.ld));
+      else *(fm_u32x4*)(dst + (long)(8 * it) * st.ld) = v;
+      if constexpr (BITS) {
+        typedef unsigned short fm_u16x2 __attribute__((ext_vector_type(2)));
+        const fm_u16x2 one = {1, 1};
+        unsigned z = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const unsigned x = v[k];
+          z |= __builtin_bit_cast(unsigned, (fm_u16x2)__builtin_elementwise_min(__builtin_bit_cast(fm_u16x2, x), one)) << (2 * k);
+        }
+        mw |= ((z | (z >> 15)) & 0xffu) << (8 * it);
+      }
+    }
+  } else if constexpr ((J & 1) == 1 && P == 5) {
+    int zero;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
+    if constexpr (BITS) st.bits[((st.row0 >> 5) * st.ncg + (J >> 1)) * 64 + (st.lane | zero)] = mw;
+  }
+}
+#ifndef FM_DEFER_STORES
+#define FM_DEFER_STORES 0   // measured (round 3, 6.3 M rows, A/B on one box): training forward 9.45 ms without, 9.86 pinned, 9.84 left to the scheduler
+#endif
+#ifndef FM_DEFER_PIN
+#define FM_DEFER_PIN 1
+#endif
+
 // One layer: out[32 NB] = act(W . [in0 | in1] + b) -- NB blocks of 32 outputs over one or two input segments (skip connections and
 // concatenations are never formed).  F = first fragment, B = first bias block of the layer within the pass.
-template <int F, int B, int NK0, int NK1, bool RELU, bool STORE, bool BITS, int J, bool MORE, typename C>
-__device__ __forceinline__ void dense_block(C& c, f32x16& acc, const bf16x8 (&in0)[NK0], const bf16x8 (&in1)[NK1 > 0 ? NK1 : 1], bf16x8& lo,
-                                            bf16x8& hi, const StoreTo& st) {
-  mac<F, NK0>(c, acc, in0);
-  if constexpr (NK1 > 0) mac<F + NK0, NK1>(c, acc, in1);
+// MFMAs I of a block with a hook after each (the deferred store pieces of the previous block)
+template <int F, int NK, typename Hook, int... I, typename C>
+__device__ __forceinline__ void mac_seq_hooked(C& c, f32x16& acc, const bf16x8 (&in)[NK], Hook&& hook, std::integer_sequence<int, I...>) {
+  ((acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(next_frag<F + I>(c), in[I], acc, 0, 0, 0), hook(std::integral_constant<int, I>{})), ...);
+}
+
+template <int F, int B, int NK0, int NK1, bool RELU, bool STORE, bool BITS, int J, bool MORE, int NOUT, typename C>
+__device__ __forceinline__ void dense_block(C& c, f32x16& acc, const bf16x8 (&in0)[NK0], const bf16x8 (&in1)[NK1 > 0 ? NK1 : 1], bf16x8 (&out)[NOUT],
+                                            const StoreTo& st, unsigned& mw) {
+  bf16x8& lo = out[2 * J];
+  bf16x8& hi = out[2 * J + 1];
+  constexpr int NKT = NK0 + NK1;
+  // the previous block's store pieces ride in this block: after MFMA T of the block's NKT (segment boundaries do not matter)
+  constexpr bool DEFER = STORE && FM_DEFER_STORES && J > 0 && NKT >= 12;
+  auto hook = [&](auto seg0, auto idx) __attribute__((always_inline)) {
+    if constexpr (DEFER) {
+      constexpr int T = (decltype(seg0)::value ? 0 : NK0) + decltype(idx)::value;       // position among the block's NKT MFMAs
+      constexpr int S = NKT / 6;                                                        // spacing of the pieces
+      const bf16x8& plo = out[2 * (J - 1)];
+      const bf16x8& phi = out[2 * (J - 1) + 1];
+      constexpr int P = T == 0 ? 0 : T == S ? 1 : T == 2 * S ? 2 : T == 3 * S ? 3 : T == 4 * S ? 4 : T == 4 * S + 1 ? 5 : -1;
+      if constexpr (P >= 0 && (P == 0 || ((J - 1) & 1) == 1)) {
+        // (pinned: left to the scheduler, the pieces' read-backs are hoisted to the block's start and their values live across it)
+        if constexpr (FM_DEFER_PIN) __builtin_amdgcn_sched_barrier(0);
+        store_piece<BITS, J - 1, P>(st, plo, phi, mw);
+        if constexpr (FM_DEFER_PIN) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+  mac_seq_hooked<F, NK0>(c, acc, in0, [&](auto i) __attribute__((always_inline)) { hook(std::true_type{}, i); }, std::make_integer_sequence<int, NK0>{});
+  if constexpr (NK1 > 0)
+    mac_seq_hooked<F + NK0, NK1>(c, acc, in1, [&](auto i) __attribute__((always_inline)) { hook(std::false_type{}, i); }, std::make_integer_sequence<int, NK1>{});
   to_frags<RELU>(acc, lo, hi);
-  if constexpr (STORE) store_block<BITS, J>(st, lo, hi);
+  if constexpr (STORE && !(FM_DEFER_STORES && NKT >= 12)) store_block<BITS, J>(st, lo, hi);
+  else if constexpr (STORE && !MORE) {                   // last block of the layer: nothing follows it here -- its pieces go out at once
+    store_piece<BITS, J, 0>(st, lo, hi, mw);
+    store_piece<BITS, J, 1>(st, lo, hi, mw);
+    store_piece<BITS, J, 2>(st, lo, hi, mw);
+    store_piece<BITS, J, 3>(st, lo, hi, mw);
+    store_piece<BITS, J, 4>(st, lo, hi, mw);
+    store_piece<BITS, J, 5>(st, lo, hi, mw);
+  }
   // (issuing these bias reads BEFORE the stores, so that their LDS latency runs under them, measured 9.53 vs 9.43 ms: the sixteen
   // accumulator registers are then live across the store path of a kernel that already sits at the 256-register limit)
   if constexpr (MORE) acc = acc_init<B + 1>(c);
@@ -326,7 +437,8 @@ __device__ __forceinline__ void dense_seq(C& c, const bf16x8 (&in0)[NK0], const 
                                           const StoreTo& st, std::integer_sequence<int, J...>) {
   static_assert(NB % 2 == 0, "the training stores work on pairs of blocks");
   f32x16 acc = acc_init<B>(c);
-  (dense_block<F + J * (NK0 + NK1), B + J, NK0, NK1, RELU, STORE, BITS, J, (J + 1 < NB)>(c, acc, in0, in1, out[2 * J], out[2 * J + 1], st), ...);
+  unsigned mw = 0;                                       // mask word of the pair whose store pieces are under way
+  (dense_block<F + J * (NK0 + NK1), B + J, NK0, NK1, RELU, STORE, BITS, J, (J + 1 < NB)>(c, acc, in0, in1, out, st, mw), ...);
 }
 // BITS (training stores): the ReLU bit masks; by default for the 256-wide ReLU layers (st.ncg = 4), explicitly for the colour head's
 template <int F, int B, int NK, int NB, bool RELU, bool STORE = false, bool BITS = (STORE && RELU && NB == 8), typename C>
@@ -468,6 +580,10 @@ __global__ __launch_bounds__(64 * FM_WAVES, 2) void fmlp_kernel(FmlpArgs a) {   
 
   Ctx c;
   ctx_start(c, smem, a.wstream, a.n_chunks, a.bias, a.n_blocks, tid, wave, lane);
+#if FM_STAGGER
+  // PROBE (-DFM_STAGGER=n): the workgroups of an XCD start up to 15 x 64 n clocks apart -- do the CUs' store bursts line up chip-wide?
+  for (int i = 0; i < (int)((blockIdx.x >> 3) & 15); ++i) __builtin_amdgcn_s_sleep(FM_STAGGER);
+#endif
 
   for (int tile = blockIdx.x; tile < a.tiles; tile += gridDim.x) {
     long row = (long)tile * FM_TILE_ROWS + wave * 32 + (lane & 31);
