@@ -349,7 +349,7 @@ __device__ __forceinline__ void store_piece(const StoreTo& st, const bf16x8& lo,
     // (the lane id through an opaque zero: otherwise hipcc hoists the row addresses of every (layer, piece) -- forty 64-bit values --
     // out of the tile loop and spills them; a scratch reload then costs a vmcnt(0) in every block)
     int zero;
-    asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
+    asm volatile("s_lshr_b32 %0, %1, 30" : "=s"(zero) : "s"(st.ncg));   // (0: ncg is a handful)
     const int ln = st.lane | zero;
     const int prow = ln >> 3, pch = ln & 7;
     const int row = 8 * it + prow;
@@ -373,7 +373,7 @@ __device__ __forceinline__ void store_piece(const StoreTo& st, const bf16x8& lo,
     }
   } else if constexpr ((J & 1) == 1 && P == 5) {
     int zero;
-    asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
+    asm volatile("s_lshr_b32 %0, %1, 30" : "=s"(zero) : "s"(st.ncg));   // (0: ncg is a handful)
     if constexpr (BITS) st.bits[((st.row0 >> 5) * st.ncg + (J >> 1)) * 64 + (st.lane | zero)] = mw;
   }
 }
