@@ -332,7 +332,7 @@ __device__ __forceinline__ void store_block(const StoreTo& st, const bf16x8& lo,
 // is pending, which empties the fragment queue four more times per block; the two waves of a SIMD pass the same pieces at
 // the same MFMA positions, so the pipe is not kept busier either.
 template <bool BITS, int J, int P>
-__device__ __forceinline__ void store_piece(const StoreTo& st, const bf16x8& lo, const bf16x8& hi, unsigned& mw) {
+__device__ __forceinline__ void store_piece(const StoreTo& st, const bf16x8& lo, const bf16x8& hi, unsigned& mw, fm_u32x4 (&vs)[4]) {
   const int r = st.lane & 31, half = st.lane >> 5;
   typedef unsigned fm_u32x2 __attribute__((ext_vector_type(2)));
   if constexpr (P == 0) {
@@ -343,7 +343,16 @@ __device__ __forceinline__ void store_piece(const StoreTo& st, const bf16x8& lo,
     *(fm_u32x2*)(w + (((C0 + 1) ^ (r & 7)) << 4)) = fm_u32x2{l[2], l[3]};
     *(fm_u32x2*)(w + (((C0 + 2) ^ (r & 7)) << 4)) = fm_u32x2{h[0], h[1]};
     *(fm_u32x2*)(w + (((C0 + 3) ^ (r & 7)) << 4)) = fm_u32x2{h[2], h[3]};
-    if constexpr ((J & 1) == 1) mw = 0;
+    if constexpr ((J & 1) == 1) {
+      mw = 0;
+      // all four read-backs now (they queue behind the writes): ONE LDS drain for the pair, at the first piece that uses them
+      const int prow0 = st.lane >> 3, pch0 = st.lane & 7;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = 8 * it + prow0;
+        vs[it] = *(const fm_u32x4*)(st.slab + row * 128 + ((pch0 ^ (row & 7)) << 4));
+      }
+    }
   } else if constexpr ((J & 1) == 1 && P >= 1 && P <= 4) {
     constexpr int it = P - 1;
     // (the lane id through an opaque zero: otherwise hipcc hoists the row addresses of every (layer, piece) -- forty 64-bit values --
@@ -353,8 +362,11 @@ __device__ __forceinline__ void store_piece(const StoreTo& st, const bf16x8& lo,
     const int ln = st.lane | zero;
     const int prow = ln >> 3, pch = ln & 7;
     const int row = 8 * it + prow;
-    fm_u32x4 v = *(const fm_u32x4*)(st.slab + row * 128 + ((pch ^ (row & 7)) << 4));
-    asm volatile("" : "+v"(v));                          // (the read-back stays ahead of the row-bound branch)
+    if constexpr (it == 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(vs[k]));      // (the one wait for all four, here)
+    }
+    const fm_u32x4 v = vs[it];
     if (st.row0 + row < st.M) {
       __bf16* dst = st.y + (st.row0 + prow) * st.ld + 64 * (J >> 1) + 8 * pch;
       if constexpr (FM_NT_STORES) __builtin_nontemporal_store(v, (fm_u32x4*)(dst + (long)(8 * it) * st.ld));
@@ -378,7 +390,8 @@ __device__ __forceinline__ void store_piece(const StoreTo& st, const bf16x8& lo,
   }
 }
 #ifndef FM_DEFER_STORES
-#define FM_DEFER_STORES 0   // measured (round 3, 6.3 M rows, A/B on one box): training forward 9.45 ms without, 9.86 pinned, 9.84 left to the scheduler
+#define FM_DEFER_STORES 0   // measured (round 3, 6.3 M rows, A/B on one box): training forward 9.45-9.55 ms without; one read-back per piece: 9.86 pinned, 9.84 left to the
+                            // scheduler; all four read-backs with the slab writes (one LDS drain per pair, 225 VGPRs): 9.84 pinned, 9.58 unpinned
 #endif
 #ifndef FM_DEFER_PIN
 #define FM_DEFER_PIN 1
@@ -394,7 +407,7 @@ __device__ __forceinline__ void mac_seq_hooked(C& c, f32x16& acc, const bf16x8 (
 
 template <int F, int B, int NK0, int NK1, bool RELU, bool STORE, bool BITS, int J, bool MORE, int NOUT, typename C>
 __device__ __forceinline__ void dense_block(C& c, f32x16& acc, const bf16x8 (&in0)[NK0], const bf16x8 (&in1)[NK1 > 0 ? NK1 : 1], bf16x8 (&out)[NOUT],
-                                            const StoreTo& st, unsigned& mw) {
+                                            const StoreTo& st, unsigned& mw, fm_u32x4 (&vs)[4]) {
   bf16x8& lo = out[2 * J];
   bf16x8& hi = out[2 * J + 1];
   constexpr int NKT = NK0 + NK1;
@@ -410,7 +423,7 @@ __device__ __forceinline__ void dense_block(C& c, f32x16& acc, const bf16x8 (&in
       if constexpr (P >= 0 && (P == 0 || ((J - 1) & 1) == 1)) {
         // (pinned: left to the scheduler, the pieces' read-backs are hoisted to the block's start and their values live across it)
         if constexpr (FM_DEFER_PIN) __builtin_amdgcn_sched_barrier(0);
-        store_piece<BITS, J - 1, P>(st, plo, phi, mw);
+        store_piece<BITS, J - 1, P>(st, plo, phi, mw, vs);
         if constexpr (FM_DEFER_PIN) __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -421,12 +434,12 @@ __device__ __forceinline__ void dense_block(C& c, f32x16& acc, const bf16x8 (&in
   to_frags<RELU>(acc, lo, hi);
   if constexpr (STORE && !(FM_DEFER_STORES && NKT >= 12)) store_block<BITS, J>(st, lo, hi);
   else if constexpr (STORE && !MORE) {                   // last block of the layer: nothing follows it here -- its pieces go out at once
-    store_piece<BITS, J, 0>(st, lo, hi, mw);
-    store_piece<BITS, J, 1>(st, lo, hi, mw);
-    store_piece<BITS, J, 2>(st, lo, hi, mw);
-    store_piece<BITS, J, 3>(st, lo, hi, mw);
-    store_piece<BITS, J, 4>(st, lo, hi, mw);
-    store_piece<BITS, J, 5>(st, lo, hi, mw);
+    store_piece<BITS, J, 0>(st, lo, hi, mw, vs);
+    store_piece<BITS, J, 1>(st, lo, hi, mw, vs);
+    store_piece<BITS, J, 2>(st, lo, hi, mw, vs);
+    store_piece<BITS, J, 3>(st, lo, hi, mw, vs);
+    store_piece<BITS, J, 4>(st, lo, hi, mw, vs);
+    store_piece<BITS, J, 5>(st, lo, hi, mw, vs);
   }
   // (issuing these bias reads BEFORE the stores, so that their LDS latency runs under them, measured 9.53 vs 9.43 ms: the sixteen
   // accumulator registers are then live across the store path of a kernel that already sits at the 256-register limit)
@@ -437,8 +450,9 @@ __device__ __forceinline__ void dense_seq(C& c, const bf16x8 (&in0)[NK0], const 
                                           const StoreTo& st, std::integer_sequence<int, J...>) {
   static_assert(NB % 2 == 0, "the training stores work on pairs of blocks");
   f32x16 acc = acc_init<B>(c);
-  unsigned mw = 0;                                       // mask word of the pair whose store pieces are under way
-  (dense_block<F + J * (NK0 + NK1), B + J, NK0, NK1, RELU, STORE, BITS, J, (J + 1 < NB)>(c, acc, in0, in1, out, st, mw), ...);
+  unsigned mw = 0;                                       // mask word / read-back rows of the pair whose store pieces are under way
+  fm_u32x4 vs[4];
+  (dense_block<F + J * (NK0 + NK1), B + J, NK0, NK1, RELU, STORE, BITS, J, (J + 1 < NB)>(c, acc, in0, in1, out, st, mw, vs), ...);
 }
 // BITS (training stores): the ReLU bit masks; by default for the 256-wide ReLU layers (st.ncg = 4), explicitly for the colour head's
 template <int F, int B, int NK, int NB, bool RELU, bool STORE = false, bool BITS = (STORE && RELU && NB == 8), typename C>
