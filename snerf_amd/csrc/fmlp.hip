@@ -1235,11 +1235,25 @@ __global__ __launch_bounds__(64 * FM_WAVES, 2) void fchain_bwd_kernel(ChainArgs 
 
 // out[c] += sum over the workgroups' partial rows (fixed order)
 struct ChainFoldTab { float* dst[10]; int first[10]; };
+// (64 columns x 4 row groups per workgroup, four rows of a group in flight: a thread walking all 256 partial rows of its column alone
+// took 65 us of load latency per launch)
 __global__ __launch_bounds__(256) void fchain_colsum_fold_kernel(const float* __restrict__ ws, int rows, int ncols, ChainFoldTab tab) {
-  const int col = blockIdx.x * 256 + threadIdx.x;
-  if (col >= ncols) return;
-  float s = 0.f;
-  for (int r = 0; r < rows; ++r) s += ws[(long)r * ncols + col];
+  __shared__ float part[4][64];
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cl;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (col < ncols) {
+    int r = rg;
+    for (; r + 12 < rows; r += 16) {
+      s0 += ws[(long)r * ncols + col]; s1 += ws[(long)(r + 4) * ncols + col];
+      s2 += ws[(long)(r + 8) * ncols + col]; s3 += ws[(long)(r + 12) * ncols + col];
+    }
+    for (; r < rows; r += 4) s0 += ws[(long)r * ncols + col];
+  }
+  part[rg][cl] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (rg != 0 || col >= ncols) return;
+  const float s = ((part[0][cl] + part[1][cl]) + part[2][cl]) + part[3][cl];
   int t = 0;
 #pragma unroll
   for (int i = 1; i < 10; ++i) t += tab.first[i] <= col ? 1 : 0;
@@ -1509,6 +1523,6 @@ extern "C" int snerf_fchain_bwd(int net, const float* d_raw, const void* wstream
   hipStream_t st = (hipStream_t)stream;
   if (classic) hipLaunchKernelGGL(fchain_bwd_kernel<FMLP_CLASSIC>, dim3(grid), dim3(64 * FM_WAVES), lds, st, a);
   else hipLaunchKernelGGL(fchain_bwd_kernel<FMLP_PROPOSAL>, dim3(grid), dim3(64 * FM_WAVES), lds, st, a);
-  hipLaunchKernelGGL(fchain_colsum_fold_kernel, dim3((ncols + 255) / 256), dim3(256), 0, st, (const float*)ws, grid, ncols, tab);
+  hipLaunchKernelGGL(fchain_colsum_fold_kernel, dim3((ncols + 63) / 64), dim3(256), 0, st, (const float*)ws, grid, ncols, tab);
   return snerf_check_launch();
 }
