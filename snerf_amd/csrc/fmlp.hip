@@ -1265,9 +1265,14 @@ __global__ __launch_bounds__(256) void fcolour_colsum_fold_kernel(const float* _
   __shared__ float part[4][64];
   const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + cl;
-  float s = 0.f;
-  for (int r = rg; r < rows; r += 4) s += ws[(long)r * FC_BWD_COLS + col];
-  part[rg][cl] = s;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;           // (four rows in flight)
+  int r = rg;
+  for (; r + 12 < rows; r += 16) {
+    s0 += ws[(long)r * FC_BWD_COLS + col]; s1 += ws[(long)(r + 4) * FC_BWD_COLS + col];
+    s2 += ws[(long)(r + 8) * FC_BWD_COLS + col]; s3 += ws[(long)(r + 12) * FC_BWD_COLS + col];
+  }
+  for (; r < rows; r += 4) s0 += ws[(long)r * FC_BWD_COLS + col];
+  part[rg][cl] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (rg == 0) {
     const float t = ((part[0][cl] + part[1][cl]) + part[2][cl]) + part[3][cl];
