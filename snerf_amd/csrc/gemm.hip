@@ -940,11 +940,7 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
         val = __builtin_bit_cast(bf16x8, raw);
       }
       if (col_ok && m < p.M) {
-#ifdef GEMM_STORE_POLICY
-        if (!DBG(p, 8)) asm volatile("global_store_dwordx4 %0, %1, off " GEMM_STORE_POLICY ::"v"((bf16x8*)(yrow + it * ystep + (SPLIT ? 64 * part : 0))), "v"(val) : "memory");
-#else
         if (!DBG(p, 8)) *(bf16x8*)(yrow + it * ystep + (SPLIT ? 64 * part : 0)) = val;          // (non-temporal stores measure the same: profiles/r2_n)
-#endif
         else asm volatile("" ::"v"(val));               // PROBE build, bit 8: everything but the store instruction itself
         if (ACT == ACT_RELU_BITS && part == 0) {
           // the value is a ReLU output (max(v, +0) rounded to bf16: never negative, never -0): > 0  <=>  its 16 bits are not all zero
