@@ -56,7 +56,7 @@ def test_no_vector_alu_instruction_hides_in_inline_asm():
     atomic add of the fused gradient chains' bias-gradient table and empty optimisation fences."""
     import glob
     import re
-    allowed = ("s_waitcnt", "s_barrier", "s_lshr_b32", "s_getreg_b32", "ds_read_b64_tr_b16", "ds_read_b32", "ds_read_b128", "ds_add_f32", "global_load_dwordx4", "s_nop", "s_sleep", ";")
+    allowed = ("s_waitcnt", "s_barrier", "s_lshr_b32", "s_getreg_b32", "ds_read_b64_tr_b16", "ds_read_b32", "ds_read_b128", "ds_add_f32", "ds_add_u32", "global_load_dwordx4", "s_nop", "s_sleep", ";")
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "snerf_amd", "csrc")
     for path in sorted(glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.h"))):
         src = open(path).read()
