@@ -622,7 +622,7 @@ def test_zip_table_gradient_binned_is_exact_and_bit_reproducible(lvl, gscale, mo
     from snerf_amd import ops, zipnerf
     m = zipnerf.Model(config=None, raydist_fn='power_transformation', opaque_background=True, compute="bf16", table_dtype="f16")
     e = m.encs[lvl]
-    R, S, n = 1536, (64 if lvl < 2 else 32), 7
+    R, S, n = 1536 + (5 if gscale > 1 else 0), (64 if lvl < 2 else 32), 7          # (one case with a ragged last workgroup)
     g = torch.Generator().manual_seed(7)
     d = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1)
     bx = torch.nn.functional.normalize(torch.cross(d, torch.randn(R, 3, generator=g), dim=-1), dim=-1)
