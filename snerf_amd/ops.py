@@ -769,7 +769,8 @@ def zip_encode_bwd_binned(tdist, origins, directions, radii, base_x, base_y, deg
                           std_scale, ksplit, g64_rows, level_rows, precounted=None):
     """The table gradient of zip_encode_bwd without L2 atomics on the hashed levels and bit-reproducible: records binned by destination,
     accumulated per bin in LDS with fixed-point integer atomics (snerf_zip_encode_bwd_binned: count, scan on the device, write, accumulate).
-    The fixed-point grid follows the gradient's magnitude (snerf_zip_bin_scale: 34 bits below max |grad_feat|)."""
+    The fixed-point grid follows the gradient's magnitude (snerf_zip_bin_scale: 34 bits below max |grad_feat|).  `precounted` = the
+    (counts, wg_offsets) pair zip_encode_fwd_count returned for the same intervals and bin plan: the count pass is then skipped."""
     import numpy as np
     R, P = tdist.shape
     S = P - 1
