@@ -60,9 +60,11 @@ def check_grads(named, ref_params, keys, compute, tol):
             print(f"MEASURED split-bf16 grad {k}: rel L2 {rel:.3e}")
             assert rel < 6e-3, f"grad {k}: relative L2 error {rel:.3e}"
         else:
+            # measured (rounds 2-3, GPU kernels and the CPU emulation alike): <= 8.7e-2 on the worst parameter (first-layer weights);
+            # the bound is 1.3x that, not the 2x of the loss tolerance it used to be ("would pass a 2x regression")
             rel = ((got - gref).norm() / (gref.norm() + 1e-12)).item()
             print(f"MEASURED bf16 grad {k}: rel L2 {rel:.3e}")
-            assert rel < 2 * tol, f"grad {k}: relative L2 error {rel:.3e}"
+            assert rel < min(2 * tol, 0.113), f"grad {k}: relative L2 error {rel:.3e}"
 
 
 def nerf_params(W, flip=False):
