@@ -241,6 +241,11 @@ int snerf_adam_step(float* p, float* g, float* m, float* v, long n, float lr, fl
 int snerf_app_embed(const float* emb, const float* app, int n_vocab, long n_rays, int S, int dim, void* dst, long ld, int dtype,
                     const int* sample_id, long rows, void* stream);
 int snerf_app_embed_bwd(const float* dV, long ld, const float* app, int n_vocab, long n_rays, int S, int dim, float* g_emb, void* stream);
+/* the same accumulation in a fixed order (one workgroup per table row, rays in order; no atomics): bit-reproducible run to run */
+int snerf_app_embed_bwd_det(const float* dV, long ld, const float* app, int n_vocab, long n_rays, int S, int dim, float* g_emb, void* stream);
+/* bad[0] += number of entries of the float index vector idx [n] that torch.nn.Embedding(n_rows, .) would refuse after .long() (outside
+ * [0, n_rows) or not finite); the kernels themselves clamp.  The host polls the counter later and raises (no sync inside the step). */
+int snerf_index_check(const float* idx, long n, int n_rows, int* bad, void* stream);
 
 /* Split-bf16 operands (dtype SNERF_DT_BF16X3 of snerf_linear_fwd / snerf_linear_wgrad): a value x is carried as hi = bf16(x) and
  * lo = bf16(x - hi) (16 mantissa bits) and a product evaluated as hi.hi + lo.hi + hi.lo on the bf16 MFMA path with fp32 accumulation

@@ -99,6 +99,7 @@ class _ArenaModule(nn.Module):
             for net in (v if isinstance(v, (list, tuple)) else [v]):
                 if hasattr(net, "deterministic") and hasattr(net, "ensure_packed"):
                     net.deterministic = bool(flag)
+        self._deterministic = bool(flag)                 # (embedding-table gradients: fixed-order accumulation, ops.app_embed_bwd)
         return self
 
     def _param_version(self):

@@ -254,7 +254,8 @@ __global__ __launch_bounds__(256) void app_embed_kernel(const float* __restrict_
     const long m = e / dim;
     const int c = (int)(e - m * dim);
     const long ray = (sample_id != nullptr ? (long)sample_id[m] : m) / S;
-    int v = (int)app[ray];                                  // rays.app.long(): truncation
+    const float av = app[ray];
+    int v = av == av ? (int)av : 0;                         // rays.app.long(): truncation (NaN: row 0; snerf_index_check reports it)
     v = v < 0 ? 0 : (v >= V ? V - 1 : v);
     dst[m * ld + c] = from_f32<T>(emb[(long)v * dim + c]);
   }
@@ -266,13 +267,41 @@ __global__ __launch_bounds__(256) void app_embed_bwd_kernel(const float* __restr
   const int lane = threadIdx.x & 63;
   const long ray = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (ray >= n_rays) return;
-  int v = (int)app[ray];
+  const float av = app[ray];
+  int v = av == av ? (int)av : 0;
   v = v < 0 ? 0 : (v >= V ? V - 1 : v);
   for (int c = lane; c < dim; c += 64) {
     float s = 0.f;
     for (int i = 0; i < S; ++i) s += dV[(ray * S + i) * ld + c];
     atomicAdd(g_emb + (long)v * dim + c, s);
   }
+}
+// the same sums in a FIXED order (deterministic mode): one workgroup per table row walks the rays in order and adds the per-ray sums of
+// the rays that select its row -- no atomics, bit-reproducible; V x n_rays index reads (a few hundred microseconds at 100 x 4096)
+__global__ __launch_bounds__(64) void app_embed_bwd_det_kernel(const float* __restrict__ dV, long ld, const float* __restrict__ app, int V, long n_rays,
+                                                               int S, int dim, float* __restrict__ g_emb) {
+  const int row = blockIdx.x, lane = threadIdx.x;
+  for (int c = lane; c < dim; c += 64) {
+    float acc = 0.f;
+    for (long ray = 0; ray < n_rays; ++ray) {
+      const float av = app[ray];
+      int v = av == av ? (int)av : 0;
+      v = v < 0 ? 0 : (v >= V ? V - 1 : v);
+      if (v != row) continue;
+      float s = 0.f;
+      for (int i = 0; i < S; ++i) s += dV[(ray * S + i) * ld + c];
+      acc += s;
+    }
+    if (acc != 0.f) g_emb[(long)row * dim + c] += acc;
+  }
+}
+// indices that nn.Embedding would refuse (models.py:153-159 rays.app.long(); zipnerf models.py:131-139 cam_idx): counts entries of a float
+// index vector outside [0, n) or not finite into bad[0] -- the host reads the counter later (no sync in the step) and raises
+__global__ __launch_bounds__(256) void index_check_kernel(const float* __restrict__ idx, long n, int hi, int* __restrict__ bad) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  const float v = idx[e];
+  if (!(v == v) || v <= -1.f || v >= (float)hi) atomicAdd(bad, 1);      // (truncation: (-1, 0) maps to row 0 like .long())
 }
 
 extern "C" int snerf_app_embed(const float* emb, const float* app, int n_vocab, long n_rays, int S, int dim, void* dst, long ld, int dtype,
@@ -292,6 +321,20 @@ extern "C" int snerf_app_embed_bwd(const float* dV, long ld, const float* app, i
   if (n_rays <= 0) return SNERF_OK;
   if (dV == nullptr || app == nullptr || g_emb == nullptr || n_vocab <= 0 || S <= 0 || dim <= 0 || ld < dim) return SNERF_ERR_ARG;
   hipLaunchKernelGGL(app_embed_bwd_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dV, ld, app, n_vocab, n_rays, S, dim, g_emb);
+  return snerf_check_launch();
+}
+
+extern "C" int snerf_app_embed_bwd_det(const float* dV, long ld, const float* app, int n_vocab, long n_rays, int S, int dim, float* g_emb, void* stream) {
+  if (n_rays <= 0) return SNERF_OK;
+  if (dV == nullptr || app == nullptr || g_emb == nullptr || n_vocab <= 0 || S <= 0 || dim <= 0 || ld < dim) return SNERF_ERR_ARG;
+  hipLaunchKernelGGL(app_embed_bwd_det_kernel, dim3((unsigned)n_vocab), dim3(64), 0, (hipStream_t)stream, dV, ld, app, n_vocab, n_rays, S, dim, g_emb);
+  return snerf_check_launch();
+}
+
+extern "C" int snerf_index_check(const float* idx, long n, int n_rows, int* bad, void* stream) {
+  if (n <= 0) return SNERF_OK;
+  if (idx == nullptr || bad == nullptr || n_rows <= 0) return SNERF_ERR_ARG;
+  hipLaunchKernelGGL(index_check_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, idx, n, n_rows, bad);
   return snerf_check_launch();
 }
 

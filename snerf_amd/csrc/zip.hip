@@ -231,9 +231,22 @@ __device__ __forceinline__ uint32_t zip_grid_index(uint32_t hs, uint32_t res, co
 
 template <typename TT, int C> struct alignas(sizeof(TT) * C) ZVec { TT v[C]; };
 
+// Grid position of one coordinate on a level: ps = x * scale + 0.5 (gridencoder.cu:148), its cell and fraction.  The forward's count
+// pass and the backward's record writers evaluate this in DIFFERENT kernels and must land in the same cell (a record more or less than
+// counted would overrun a reserved range), so the product and the sum are rounded separately whatever the surrounding code is
+// contracted into -- as the CPU oracle's separate fp32 ops do.
+__device__ __forceinline__ void zip_cell(float x01, float scale, uint32_t* pg, float* fr) {
+#pragma clang fp contract(off)
+  const float ps = x01 * scale + 0.5f;
+  const float fl = floorf(ps);
+  *pg = (uint32_t)fl;
+  *fr = ps - fl;
+}
+
 // position, contracted + halved, and its erf weight for one multisample
 __device__ __forceinline__ void zip_sample_point(const ZipEnc& a, long ray, int i, int j, float t0, float t1, const float* o, const float* d,
                                                  const float* bx, const float* by, float rad, float* x01, float* sd) {
+#pragma clang fp contract(off)        // (same positions in every kernel that calls this: see zip_cell)
   const float t = t0 + (t1 - t0) * ((float)j + 0.5f) / (float)a.n;
   float deg = 2.f * 3.14159265358979f * (float)a.m * (float)j / (float)a.n;
   if (a.deg_jitter != nullptr) deg += a.deg_jitter[(ray * a.S + i) * a.n + j] * 3.14159265358979f * 2.f;
@@ -362,10 +375,7 @@ __device__ __forceinline__ void zip_point_level(const ZipEnc& a, long p, int lev
     uint32_t pg[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const float ps = x01[k] * scale + 0.5f;
-      const float fl = floorf(ps);
-      pg[k] = (uint32_t)fl;
-      fr[k] = ps - fl;
+      zip_cell(x01[k], scale, &pg[k], &fr[k]);
     }
     if (MODE != 0 && (pg[0] != cur[0] || pg[1] != cur[1] || pg[2] != cur[2])) {
       flush();
@@ -508,10 +518,7 @@ __device__ __forceinline__ void zip_fwd_all_body(const ZipEnc& a, const ZipBin& 
       uint32_t pg[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        const float ps = X[j][k] * scale + 0.5f;
-        const float fl = floorf(ps);
-        pg[k] = (uint32_t)fl;
-        fr[k] = ps - fl;
+        zip_cell(X[j][k], scale, &pg[k], &fr[k]);
       }
       bool newcell = false;
       if constexpr (COUNT) {
@@ -704,10 +711,7 @@ __global__ __launch_bounds__(256) void zip_encode_prop_kernel(ZipEnc a, ZipPropM
       uint32_t pg[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        const float ps = X[j][k] * scale + 0.5f;
-        const float fl = floorf(ps);
-        pg[k] = (uint32_t)fl;
-        fr[k] = ps - fl;
+        zip_cell(X[j][k], scale, &pg[k], &fr[k]);
       }
       float pa[8];
 #pragma unroll
@@ -1306,10 +1310,7 @@ __device__ __forceinline__ void zip_emit_level(const ZipEnc& a, const ZipBin& b,
     uint32_t pg[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const float ps = x01[k] * scale + 0.5f;
-      const float fl = floorf(ps);
-      pg[k] = (uint32_t)fl;
-      fr[k] = ps - fl;
+      zip_cell(x01[k], scale, &pg[k], &fr[k]);
     }
     if (pg[0] != cur[0] || pg[1] != cur[1] || pg[2] != cur[2]) {
       flush();
@@ -1432,10 +1433,7 @@ __global__ __launch_bounds__(256, NSUB == 8 ? 4 : 3) void zip_bin_write_staged_k
       we[j] = erff(1.f / sqrtf(8.f * sd * sd * gs * gs));
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        const float ps = x01[k] * scale + 0.5f;
-        const float fl = floorf(ps);
-        pg[j][k] = (uint32_t)fl;
-        fr[j][k] = ps - fl;
+        zip_cell(x01[k], scale, &pg[j][k], &fr[j][k]);
       }
       // the previous in-bounds multisample ends its run here if the cell changes (the merging of zip_emit_level)
 #pragma unroll
@@ -1846,10 +1844,7 @@ __global__ __launch_bounds__(256) void zip_encode_ray_bwd_kernel(ZipEnc a, float
       uint32_t pg[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        const float ps = x01[k] * scale + 0.5f;
-        const float fl = floorf(ps);
-        pg[k] = (uint32_t)fl;
-        fr[k] = ps - fl;
+        zip_cell(x01[k], scale, &pg[k], &fr[k]);
       }
       float gl[C];
 #pragma unroll

@@ -54,50 +54,40 @@ grid_encode = _grid_encode.apply
 
 
 class GridEncoder(nn.Module):
+    """Attribute names, buffer names (`offsets`, `idx`, `grid_sizes`) and the `embeddings` parameter are the reference module's: callers
+    read them (internal/models.py:413-421, 494; train_utils.py:184-203) and checkpoints store them."""
+
     def __init__(self, input_dim=3, num_levels=16, level_dim=2, per_level_scale=2, base_resolution=16, log2_hashmap_size=19,
                  desired_resolution=None, gridtype='hash', align_corners=False, interpolation='linear', init_std=1e-4,
                  device="cuda"):
         super().__init__()
-        if desired_resolution is not None:
-            per_level_scale = np.exp2(np.log2(desired_resolution / base_resolution) / (num_levels - 1))
         if input_dim not in (2, 3, 4, 5) or level_dim not in (1, 2, 4, 8):
             raise NotImplementedError("GridEncoder: input_dim in {2,3,4,5}, level_dim in {1,2,4,8} (the reference's instantiations, gridencoder.cu:376-399)")
-        self.input_dim, self.num_levels, self.level_dim = input_dim, num_levels, level_dim
-        self.per_level_scale, self.log2_hashmap_size, self.base_resolution = per_level_scale, log2_hashmap_size, base_resolution
-        self.output_dim = num_levels * level_dim
-        self.gridtype, self.gridtype_id = gridtype, _gridtype_to_id[gridtype]
-        self.interpolation, self.interp_id = interpolation, _interp_to_id[interpolation]
-        self.align_corners, self.init_std = align_corners, init_std
-        resolutions, offsets, offset = [], [], 0
-        self.max_params = 2 ** log2_hashmap_size
-        for i in range(num_levels):       # level sizing: grid.py:122-141
-            resolution = int(np.ceil(base_resolution * per_level_scale ** i))
-            resolution = resolution if align_corners else resolution + 1
-            params_in_level = min(self.max_params, resolution ** input_dim)
-            params_in_level = int(np.ceil(params_in_level / 8) * 8)
-            resolutions.append(resolution)
-            offsets.append(offset)
-            offset += params_in_level
-        offsets.append(offset)
-        offsets = torch.from_numpy(np.array(offsets, dtype=np.int32)).to(device)
-        self.register_buffer('offsets', offsets)
-        idx = torch.empty(offset, dtype=torch.long, device=device)
-        for i in range(num_levels):
-            idx[offsets[i]:offsets[i + 1]] = i
-        self.register_buffer('idx', idx)
-        self.register_buffer('grid_sizes', torch.from_numpy(np.array(resolutions, dtype=np.int32)).to(device))
-        self.n_params = offsets[-1] * level_dim
-        self.embeddings = nn.Parameter(torch.empty(offset, level_dim, device=device))
+        if desired_resolution is not None:               # the finest level lands on desired_resolution (grid.py:104-106)
+            per_level_scale = ops.grid_per_level_scale(base_resolution, desired_resolution, num_levels)
+        offsets, sizes = ops.grid_level_layout(input_dim, num_levels, per_level_scale, base_resolution, log2_hashmap_size, align_corners)
+        vars(self).update(input_dim=input_dim, num_levels=num_levels, level_dim=level_dim, per_level_scale=per_level_scale,
+                          log2_hashmap_size=log2_hashmap_size, base_resolution=base_resolution, output_dim=num_levels * level_dim,
+                          gridtype=gridtype, gridtype_id=_gridtype_to_id[gridtype], interpolation=interpolation,
+                          interp_id=_interp_to_id[interpolation], align_corners=align_corners, init_std=init_std,
+                          max_params=2 ** log2_hashmap_size)
+        rows = int(offsets[-1])
+        self.register_buffer('offsets', torch.from_numpy(offsets).to(device))
+        # level of every table row (the hash-decay loss segments the table with it, train_utils.py:207-211)
+        self.register_buffer('idx', torch.repeat_interleave(torch.arange(num_levels), torch.from_numpy(np.diff(offsets).astype(np.int64))).to(device))
+        self.register_buffer('grid_sizes', torch.from_numpy(sizes).to(device))
+        self.n_params = rows * level_dim
+        self.embeddings = nn.Parameter(torch.empty(rows, level_dim, device=device))
         self.reset_parameters()
 
     def reset_parameters(self):
         self.embeddings.data.uniform_(-self.init_std, self.init_std)
 
-    def __repr__(self):
-        return (f"GridEncoder: input_dim={self.input_dim} num_levels={self.num_levels} level_dim={self.level_dim} "
-                f"resolution={self.base_resolution} -> {int(round(self.base_resolution * self.per_level_scale ** (self.num_levels - 1)))} "
-                f"per_level_scale={self.per_level_scale:.4f} params={tuple(self.embeddings.shape)} gridtype={self.gridtype} "
-                f"align_corners={self.align_corners} interpolation={self.interpolation}")
+    def extra_repr(self):
+        finest = int(self.grid_sizes[-1]) - (0 if self.align_corners else 1)
+        return (f"D={self.input_dim}, L={self.num_levels}, C={self.level_dim}, base {self.base_resolution} -> {finest} "
+                f"(x{self.per_level_scale:.4f} per level), table {tuple(self.embeddings.shape)}, {self.gridtype}/{self.interpolation}"
+                f"{', align_corners' if self.align_corners else ''}")
 
     def forward(self, inputs, bound=1, cal_input_grad=False):
         inputs = (inputs + bound) / (2 * bound)

@@ -104,6 +104,7 @@ class MipNerfModel(_ArenaModule):
         if v.numel() != 3:
             raise ValueError("viewc: a scalar or 3 values")
         self._viewc, self._viewc_src, self._viewc_ver = tuple(float(x) for x in v), viewc, ver
+        self._viewc_given = True
 
     # ------------------------------------------------------------------ core ----
     def _run(self, rays: Rays, keep: bool, white_bg: bool, s_rand, u, noise0, noise1):
@@ -211,7 +212,7 @@ class MipNerfModel(_ArenaModule):
                                     on_done=layer_done)
             if self.encode_appearance:     # d loss / d emb.weight from the condition block's gradient (its columns right of the view encoding)
                 dVc = ig[1] if ray_grads else ig
-                ops.app_embed_bwd(dVc[:, self.view_dim:], c["app"], S1, self.arena.g["emb.weight"])
+                ops.app_embed_bwd(dVc[:, self.view_dim:], c["app"], S1, self.arena.g["emb.weight"], deterministic=getattr(self, "_deterministic", False))
             if ray_grads:
                 dE, dV = ig
                 eo, ed = ops.mip_encode_bwd(c["s1"], c["o"], c["d"], c["radii"], c["near"], c["far"], c["cone"], self.transform_idx, self.max_deg_point, dE)

@@ -366,7 +366,7 @@ class _Net:
             # direct-store epilogue could only add its column sums with atomics (snerf_linear_fwd refuses the combination), so the
             # bias gradient comes from a fixed-order column sum of the stored data gradient instead
             ops.linear_fwd(dZ, W, None, dX, K, n_store, act, self.dt, aux=mask, variant=self.variant)
-            ops.colsum_f32(dX[:, :n_store].float().contiguous(), n_store, colsum[:n_store], deterministic=True)
+            ops.colsum_wide_f32(dX[:, :n_store].float(), n_store, colsum, deterministic=True)     # (any width; colsum_f32_det stops at 8 columns)
             return
         ops.linear_fwd(dZ, W, None, dX, K, n_store, act, self.dt,
                        aux=mask, colsum=colsum, variant=self.variant, deterministic=self.deterministic)

@@ -330,18 +330,53 @@ def mip_viewenc(viewdirs, S, deg, dst, width, dt, sample_id=None):
     _lib.call("snerf_mip_viewenc", _p(viewdirs), viewdirs.shape[0], S, deg, _p(dst), dst.stride(0), width, dt, _p(ids), rows, _stream())
 
 
-def app_embed(emb, app, S, dst, dt, sample_id=None):
-    """appearance embedding rows into the condition block: dst[ray * S + i, :dim] = emb[int(app[ray])] (models.py:153-159)"""
+_index_checks = []          # [(device counter, message)] of launched index checks whose result has not been read yet
+
+
+def poll_index_checks(block=False):
+    """Raise IndexError for an embedding index outside its table seen by an EARLIER launch (torch.nn.Embedding raises on one; the
+    kernels clamp).  Without `block` only counters whose kernel has certainly finished are read: the step never waits for the check."""
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        return
+    keep = []
+    for ev, cnt, msg in _index_checks:
+        if block or ev.query():
+            if int(cnt.item()) != 0:
+                _index_checks.clear()
+                raise IndexError(msg)
+        else:
+            keep.append((ev, cnt, msg))
+    _index_checks[:] = keep
+
+
+def index_check(idx, n_rows, what):
+    """asynchronous range check of a float index vector against a table of n_rows rows; reported by a later poll_index_checks()"""
+    poll_index_checks()
+    if torch.cuda.is_current_stream_capturing():
+        return                                           # (a captured step replays with fresh data nobody checks: validate before capturing)
+    cnt = torch.zeros(1, dtype=torch.int32, device=idx.device)
+    _lib.call("snerf_index_check", _p(idx), idx.numel(), int(n_rows), _p(cnt), _stream())
+    ev = torch.cuda.Event()
+    ev.record()
+    _index_checks.append((ev, cnt, f"{what}: index out of range for a table of {n_rows} rows (torch.nn.Embedding raises here; the kernel clamped)"))
+
+
+def app_embed(emb, app, S, dst, dt, sample_id=None, check=True):
+    """appearance embedding rows into the condition block: dst[ray * S + i, :dim] = emb[int(app[ray])] (models.py:153-159).  `check`:
+    indices outside the table are reported (IndexError, as nn.Embedding would) by a later call of this module -- see index_check."""
     _f32c(emb); _f32c(app)
+    if check:
+        index_check(app, emb.shape[0], "embedding lookup")
     ids, rows = _ids(sample_id)
     _lib.call("snerf_app_embed", _p(emb), _p(app), emb.shape[0], app.numel(), int(S), emb.shape[1], _p(dst), dst.stride(0), dt, _p(ids), rows, _stream())
 
 
-def app_embed_bwd(dV, app, S, g_emb):
-    """g_emb[int(app[ray])] += sum over the ray's S samples of dV[ray * S + i, :dim] (fp32)"""
+def app_embed_bwd(dV, app, S, g_emb, deterministic=False):
+    """g_emb[int(app[ray])] += sum over the ray's S samples of dV[ray * S + i, :dim] (fp32); `deterministic`: in a fixed order (no atomics)"""
     _chk2d(dV, torch.float32); _f32c(app); _f32c(g_emb)
     assert dV.shape[0] == app.numel() * S and dV.shape[1] >= g_emb.shape[1]
-    _lib.call("snerf_app_embed_bwd", _p(dV), dV.stride(0), _p(app), g_emb.shape[0], app.numel(), int(S), g_emb.shape[1], _p(g_emb), _stream())
+    _lib.call("snerf_app_embed_bwd_det" if deterministic else "snerf_app_embed_bwd", _p(dV), dV.stride(0), _p(app), g_emb.shape[0], app.numel(), int(S),
+              g_emb.shape[1], _p(g_emb), _stream())
 
 
 def ert_compact(s0, w0, s1, eps_t, eps_w):
@@ -575,6 +610,27 @@ def gather_pack(flat, idx, dst):
 
 
 # ------------------------------------------------------------ hash grid ----
+def grid_per_level_scale(base_resolution, desired_resolution, num_levels):
+    """growth factor that puts level num_levels - 1 at desired_resolution (gridencoder/grid.py:104-106)"""
+    import numpy as np
+    return float(np.exp2(np.log2(desired_resolution / base_resolution) / (num_levels - 1)))
+
+
+def grid_level_layout(input_dim, num_levels, per_level_scale, base_resolution, log2_hashmap_size, align_corners=False):
+    """Row layout of a multiresolution hash table (gridencoder/grid.py:122-141), all levels at once: level l has
+    ceil(base * scale^l) (+ 1 unless align_corners) grid points per axis and min(2^log2T, points^D) rows rounded up to a multiple of 8.
+    -> (offsets int32 [L + 1], grid_sizes int32 [L]); shared by the drop-in GridEncoder and the zipnerf Model's fused encoders."""
+    import numpy as np
+    lv = np.arange(num_levels, dtype=np.float64)
+    sizes = np.ceil(base_resolution * np.asarray(per_level_scale, dtype=np.float64) ** lv).astype(np.int64) + (0 if align_corners else 1)
+    dense = np.array([int(r) ** input_dim for r in sizes], dtype=object)             # (python ints: 8193^5 does not fit int64)
+    rows = np.array([-(-min(int(d), 2 ** log2_hashmap_size) // 8) * 8 for d in dense], dtype=np.int64)
+    offsets = np.concatenate([[0], np.cumsum(rows)])
+    if offsets[-1] >= 2 ** 31:
+        raise ValueError("hash table rows exceed int32 offsets")
+    return offsets.astype(np.int32), sizes.astype(np.int32)
+
+
 _GRID_DT = {torch.float32: F32, torch.float16: F16, torch.float64: F64}    # the reference's three instantiations (gridencoder.cu:469)
 
 

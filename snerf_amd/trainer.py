@@ -44,20 +44,22 @@ class _GradExchange:
             else:
                 merged.append([a, b])
         for a, b in merged:
-            for c, d in sorted(self.done):                      # cut away what is already on the wire
-                if c <= a < d:
-                    a = min(d, b)
-                if c < b <= d:
-                    b = max(c, a)
-            inner = [(c, d) for c, d in self.done if a < c and d < b]
-            pieces, pos = [], a
-            for c, d in sorted(inner):
-                pieces.append((pos, c)); pos = d
-            pieces.append((pos, b))
-            for x, y in pieces:
-                if y > x:
-                    self.done.append((x, y))
-                    self.works.append(dist.all_reduce(self.arena.grad[x:y], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            # [a, b) minus the union of what is already on the wire, in one sweep over the sent spans in ascending order
+            pos = a
+            for c, d in sorted(self.done):
+                if d <= pos:
+                    continue
+                if c >= b:
+                    break
+                if c > pos:
+                    self._send(pos, c)
+                pos = max(pos, d)
+            if pos < b:
+                self._send(pos, b)
+
+    def _send(self, x, y):
+        self.done.append((x, y))
+        self.works.append(dist.all_reduce(self.arena.grad[x:y], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
         if not self.active:
@@ -121,9 +123,12 @@ class MipTrainer:
         self.last_losses = out                                   # {#valid depth rays, rgb, depth, proposal}: stays on the device
         return out[1:].sum(), (g_dist0, None, g_w0, g_rgb1, g_dist1, None, None)
 
-    def step(self, rays, target_rgb, target_depth=None, conf=None, randomized=True, s_rand=None, u=None, ray_grads=False):
+    def step(self, rays, target_rgb, target_depth=None, conf=None, randomized=True, s_rand=None, u=None, ray_grads=False, viewc=None):
         """`ray_grads=True` (pose refinement, configs: pose_refine = True): `last_ray_grads` = d loss / d (origins, directions, viewdirs)
-        of this rank's rays, for the caller's pose optimiser (`rays.origins.backward(g_o)` etc. chains them into the pose parameters)."""
+        of this rank's rays, for the caller's pose optimiser (`rays.origins.backward(g_o)` etc. chains them into the pose parameters).
+        `viewc` (fn = 0 models, the view-centred warp): the warp centre the reference passes to every forward (train.py:36,112); a model
+        built with fn = 0 refuses to step until a centre has been given here or through `model.set_viewc`."""
+        self._set_viewc(viewc)
         ex = _GradExchange(self.model.arena, self.world, self.pg, self.single_rank_exchange)
         # every block of the gradient arena goes on the wire as soon as the backward pass has finished it (heads, then trunk layer by
         # trunk layer, then the proposal network): the collectives run under the remaining backward kernels
@@ -132,6 +137,13 @@ class MipTrainer:
         self.t += 1
         self._adam()                                      # graph mode: step count and lr live on the device (capture / replay below)
         return loss, outs
+
+    def _set_viewc(self, viewc):
+        m = self.model
+        if viewc is not None:
+            m.set_viewc(viewc)
+        elif m.fn == 0 and not getattr(m, "_viewc_given", False):
+            raise ValueError("MipTrainer: the model warps around a view centre (fn = 0): pass viewc= (train.py:36,112) or call model.set_viewc first")
 
     def _forward_backward(self, rays, target_rgb, target_depth, conf, randomized, s_rand, u, ray_grads, on_done):
         """draws, both levels forward, the fused loss tail, the backward pass into the gradient arena (no exchange, no optimiser)"""
@@ -147,7 +159,7 @@ class MipTrainer:
         return loss, outs
 
     # ---- hipGraph capture of the whole step --------------------------------------------------------------------------------------
-    def capture(self, rays, target_rgb, target_depth=None, conf=None, randomized=True, warmup=3):
+    def capture(self, rays, target_rgb, target_depth=None, conf=None, randomized=True, warmup=3, viewc=None):
         """Capture one full training step (draws, forward, loss tail, backward, Adam: ~130 launches) in a hipGraph over the GIVEN tensors;
         afterwards `replay()` runs a step with one graph launch -- the caller refreshes the batch by copying into those tensors
         (`rays.origins.copy_(...)` etc.).  Worth it when the step is launch-bound: at 512 rays per GPU (the 8-GPU split of the
@@ -163,6 +175,7 @@ class MipTrainer:
         launch-bound part -- and `replay()` follows it with the gradient all-reduce and the Adam launch OUTSIDE the graph (one
         collective over the whole arena: nothing is left to overlap it with once the backward is a single graph launch; the
         collective stays out of the graph so that any backend works, gloo on the 1-GPU box included)."""
+        self._set_viewc(viewc)                           # (fn = 0: the centre is a kernel argument, i.e. a constant of the captured graph)
         a = self.model.arena
         dev = a.flat.device
         snap = (a.flat.clone(), self.m.clone(), self.v.clone(), self.t)

@@ -30,15 +30,10 @@ EPS32 = float(torch.finfo(torch.float32).eps)
 
 
 def _level_layout(num_levels, base_resolution, desired_resolution, log2_hashmap_size):
-    """gridencoder/grid.py:104-141 (input_dim 3, align_corners False)"""
-    scale = np.exp2(np.log2(desired_resolution / base_resolution) / (num_levels - 1))
-    offsets, res, off = [], [], 0
-    for i in range(num_levels):
-        r = int(np.ceil(base_resolution * scale ** i)) + 1
-        n = int(np.ceil(min(2 ** log2_hashmap_size, r ** 3) / 8) * 8)
-        res.append(r); offsets.append(off); off += n
-    offsets.append(off)
-    return np.array(offsets, dtype=np.int32), np.array(res, dtype=np.int32), float(scale)
+    """gridencoder/grid.py:104-141 (input_dim 3, align_corners False) -> (offsets, grid sizes, per-level scale)"""
+    scale = ops.grid_per_level_scale(base_resolution, desired_resolution, num_levels)
+    offsets, res = ops.grid_level_layout(3, num_levels, scale, base_resolution, log2_hashmap_size, False)
+    return offsets, res, scale
 
 
 class _Encoder:
@@ -330,7 +325,7 @@ class Model(_ArenaModule):
                 if ray_grads:
                     rg[2] += ops.mip_viewenc_bwd(ctx["vd"], L["ns"], 1, res[1])         # dir_enc = pos_enc(viewdirs, 0, deg_view = 1)
                 if want_glo:
-                    ops.app_embed_bwd(res[-1], L["cam"], 1, self.arena.g["glo_vecs.weight"])
+                    ops.app_embed_bwd(res[-1], L["cam"], 1, self.arena.g["glo_vecs.weight"], deterministic=getattr(self, "_deterministic", False))
             if ray_grads:
                 ops.zip_encode_ray_bwd(L["tdist"], ctx["o"], ctx["d"], ctx["radii"], ctx["bx"], ctx["by"], L["degj"], self._table(lvl),
                                        self.dev_offsets[lvl], self.dev_sizes[lvl], dF, e.L, e.C, ctx["n"], ctx["m"], e.Sl, e.H, self.std_scale,

@@ -126,13 +126,13 @@ def mip_viewenc(viewdirs, S, deg, dst, width, dt, sample_id=None):
     dst[:, :width] = torch.cat([e, torch.zeros(e.shape[0], width - e.shape[1])], -1).to(dst.dtype)
 
 
-def app_embed(emb, app, S, dst, dt, sample_id=None):
+def app_embed(emb, app, S, dst, dt, sample_id=None, check=True):
     assert sample_id is None
     rows = emb[app.reshape(-1).long().clamp(0, emb.shape[0] - 1)]
     dst[:, :emb.shape[1]] = rows[:, None].expand(-1, S, -1).reshape(-1, emb.shape[1]).to(dst.dtype)
 
 
-def app_embed_bwd(dV, app, S, g_emb):
+def app_embed_bwd(dV, app, S, g_emb, deterministic=False):
     idx = app.reshape(-1).long().clamp(0, g_emb.shape[0] - 1)
     g_emb.index_add_(0, idx, dV[:, :g_emb.shape[1]].reshape(idx.numel(), S, -1).sum(1))
 

@@ -349,3 +349,36 @@ def test_graph_captured_step_with_the_exchange_outside_the_graph_two_ranks(tmp_p
         procs.append(subprocess.Popen([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
     outs = [p.communicate(timeout=800) for p in procs]
     assert all(p.returncode == 0 for p in procs) and "CAPTURED_TWO_RANKS_OK" in outs[0][0], [(o[0][-800:], o[1][-2500:]) for o in outs]
+
+
+def test_grad_exchange_sends_every_element_exactly_once(monkeypatch):
+    """_GradExchange with queries that only partly overlap what is already on the wire: the pieces that go out are the
+    interval difference [a, b) minus the union of the sent spans, so no element of the gradient arena is all-reduced (summed) twice and
+    finish() covers the rest -- every element exactly once whatever the order of the announcements."""
+    import types
+    from snerf_amd import trainer
+
+    class _Work:
+        def wait(self):
+            pass
+
+    sent = []
+
+    def fake_all_reduce(t, op=None, group=None, async_op=False):
+        sent.append((t.storage_offset(), t.storage_offset() + t.numel()))
+        return _Work()
+    monkeypatch.setattr(trainer.dist, "all_reduce", fake_all_reduce)
+    numel = 120
+    spans = {"a": (80, 100), "b": (60, 80), "c": (40, 60), "all": (0, 100), "mid": (50, 90), "tail": (95, 120), "x": (10, 20)}
+    arena = types.SimpleNamespace(grad=torch.zeros(numel), numel=numel, span=lambda p: spans[p])
+    for order in (["a", "b", "c", "all"], ["x", "mid", "all", "tail"], [["a", "c"], "mid", "x"], ["all", "all", "tail"], []):
+        sent.clear()
+        ex = trainer._GradExchange(arena, 2, None)
+        for q in order:
+            ex(q)
+        ex.finish()
+        cover = torch.zeros(numel, dtype=torch.int32)
+        for x, y in sent:
+            assert y > x
+            cover[x:y] += 1
+        assert bool((cover == 1).all()), (order, sent)

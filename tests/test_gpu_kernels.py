@@ -680,3 +680,37 @@ def test_gather_pack_refreshes_operands():
     arena.p["pts_linears.5.weight"].mul_(2.0); arena.bump()
     net.ensure_packed(True)
     assert torch.equal(net.fw["pts_linears.5"][:128, :63], (W5[:, :63]).to(torch.bfloat16)) and net.fw["pts_linears.5"].data_ptr() == fw.data_ptr()
+
+
+def test_embedding_index_range_is_reported_and_gradient_is_reproducible(ops):
+    """rays.app / cam_idx outside the embedding table -- nn.Embedding raises (models.py:153-159); the kernels clamp, and the
+    asynchronous range check reports the launch at the next poll (no sync inside the step).  The deterministic accumulation of the
+    table gradient (one workgroup per row, rays in order) is bit-reproducible and equals index_add."""
+    V, dim, n, S = 7, 48, 300, 5
+    g = torch.Generator().manual_seed(5)
+    emb = torch.randn(V, dim, generator=g).to("cuda")
+    app = torch.randint(0, V, (n,), generator=g).float().to("cuda")
+    dst = torch.zeros(n * S, 64, device="cuda")
+    ops.app_embed(emb, app, S, dst, ops.F32)
+    ops.poll_index_checks(block=True)                         # in range: nothing raised
+    assert torch.equal(dst[:, :dim], emb[app.long()].repeat_interleave(S, 0))
+    bad = app.clone(); bad[17] = float(V)
+    ops.app_embed(emb, bad, S, dst, ops.F32)
+    with pytest.raises(IndexError, match="out of range"):
+        ops.poll_index_checks(block=True)
+    bad[17] = float("nan")
+    ops.app_embed(emb, bad, S, dst, ops.F32)
+    with pytest.raises(IndexError):
+        ops.poll_index_checks(block=True)
+    dV = torch.randn(n * S, 64, generator=g).to("cuda")
+    outs = []
+    for _ in range(2):
+        ge = torch.zeros(V, dim, device="cuda")
+        ops.app_embed_bwd(dV, app, S, ge, deterministic=True)
+        outs.append(ge)
+    assert torch.equal(outs[0], outs[1])
+    want = torch.zeros(V, dim, device="cuda").index_add_(0, app.long(), dV[:, :dim].reshape(n, S, dim).sum(1))
+    close(outs[0], want.cpu(), 1e-5, 1e-5, "deterministic embedding gradient")
+    ga = torch.zeros(V, dim, device="cuda")
+    ops.app_embed_bwd(dV, app, S, ga)
+    close(ga, want.cpu(), 1e-5, 1e-5, "atomic embedding gradient")

@@ -170,6 +170,33 @@ def test_deterministic_mode_gives_bit_identical_gradients():
     assert rel < 5e-4, rel
 
 
+@pytest.mark.gpu
+def test_deterministic_dgrad_with_an_unaligned_destination_folds_wide_bias_gradients():
+    """_Net.dgrad in deterministic mode when the 16-byte epilogue does not cover the destination (here: a view that starts 2 columns
+    into its buffer): the bias gradient is a fixed-order column sum of the stored data gradient -- for ANY width (the
+    first version called the 8-column head kernel and failed for every real hidden width)."""
+    import types
+    from snerf_amd import mlp, ops
+    torch.manual_seed(0)
+    M, K, N = 1024, 256, 256
+    dZ = (torch.randn(M, K, device=DEV) * 0.1).bfloat16()
+    Wt = (torch.randn(N, K, device=DEV) * 0.05).bfloat16()
+    me = types.SimpleNamespace(tw={"k": Wt}, dt=ops.BF16, variant=8, deterministic=True, _bits=None)
+    outs = []
+    for _ in range(2):
+        buf = torch.zeros(M, N + 8, dtype=torch.bfloat16, device=DEV)
+        dX = buf[:, 2:2 + N]                                  # rows start 4 bytes off a 16-byte boundary
+        assert not ops.fast_epilogue_ok(dX, N, ops.BF16)
+        cs = torch.zeros(N, dtype=torch.float32, device=DEV)
+        mlp._Net.dgrad(me, "k", dZ, K, dX, N, mask=None, colsum=cs)
+        outs.append((dX.clone(), cs))
+    want = dZ.float() @ Wt.float().t()
+    assert float((outs[0][0].float() - want).abs().max()) < 2e-2 * float(want.abs().max())
+    assert torch.equal(outs[0][1], outs[1][1]), "deterministic mode: the bias gradient must be bit-reproducible"
+    ref = outs[0][0].float().sum(0)
+    assert float((outs[0][1] - ref).abs().max()) < 1e-3 * float(ref.abs().max() + 1e-6)
+
+
 # ---------------------------------------------------------------------------------------------------------------------------------
 # fused register-resident MLP kernels (csrc/fmlp.hip)
 # ---------------------------------------------------------------------------------------------------------------------------------

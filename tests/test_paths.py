@@ -396,6 +396,30 @@ def test_mipnerf_view_centred_warp_vs_reference_golden(backend, golden, compute)
         m(rays._replace(origins=o), False, False, g["viewc"])
 
 
+def test_mip_trainer_passes_the_view_centre_of_the_fn0_warp(backend, golden):
+    """MipTrainer on an fn = 0 model: the trainer calls model._run directly, so the warp centre the reference hands to every
+    forward (train.py:36,112) has to come through step(viewc=...) / capture(viewc=...).  Without one the step refuses to run instead of
+    warping around (0, 0, 0); with the golden's centre the trainer's forward reproduces the reference model's outputs (g23)."""
+    g = golden("g23_warp0")
+    from snerf_amd import mipnerf
+    from snerf_amd.trainer import MipTrainer
+    m = mipnerf.MipNerfModel(n_samples=16, N_fine=17, no_warp_sample=0, ray_shape="cone", fn=0, radius=3., transform_idx=0, real=True,
+                             rgb_layer=3, hidden_layer=64, density_noise=0., max_deg_point=16, proposal_hidden_layer=64,
+                             proposal_loss=True, compute="f32", device=DEV)
+    names = [str(k) for k in g["param_names"]]
+    m.load_state_dict(common.fill_state_dict_({k: torch.empty(tuple(g["grad." + k].shape)) for k in names}))
+    rays = mipnerf.Rays(**{k[len("rays_"):]: v.to(DEV) for k, v in g.items() if k.startswith("rays_")})
+    tr = MipTrainer(m, lr=0.0)
+    tgt = g["target"].to(DEV)
+    with pytest.raises(ValueError, match="view centre"):
+        tr.step(rays, tgt, randomized=False)
+    _, outs = tr.step(rays, tgt, randomized=False, viewc=g["viewc"])
+    close(outs[4], g["l1_rgb"], 1e-4, 1e-5, "rgb through the trainer")
+    close(outs[5], g["l1_distance"], 1e-4, 1e-4, "distance through the trainer")
+    _, outs2 = tr.step(rays, tgt, randomized=False)              # the centre stays set
+    assert torch.equal(outs2[4], outs[4])
+
+
 def test_mipnerf_ray_gradients_vs_autograd(backend):
     """Pose refinement (configs/nuScenes_depth_6cams: pose_refine = True; utils/sample_utils.py:410-435): origins, directions and
     viewdirs are functions of a learnable camera pose.  d loss / d rays through both levels (encoders, contraction + Jacobian, lifted
