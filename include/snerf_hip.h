@@ -34,6 +34,8 @@ extern "C" {
 #define SNERF_ACT_MASK_BITS 4 /* as SNERF_ACT_MASK with `aux` = the words an ACT_RELU_BITS launch of the same [M, N] wrote */
 
 int snerf_version(void);
+/* the hipError_t (as int) that the most recent "kernel launch failure" status (2) of any entry stood for; 0 if there was none */
+int snerf_last_hip_error(void);
 
 /* ---- tiny-MLP layers (MFMA GEMMs) ------------------------------------------------------------
  * Y[M, n_store] = act(A[M,K] . W[N,K]^T + bias).  Replaces nn.Linear(+ReLU):

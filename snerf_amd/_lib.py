@@ -95,4 +95,5 @@ def query(name: str, *args):
 def call(name: str, *args):
     rc = getattr(load(), name)(*args)
     if rc != 0:
-        raise SnerfHipError(f"{name} failed: status {rc} ({_STATUS.get(rc, 'unknown')})")
+        extra = f", hipError_t {load().snerf_last_hip_error()}" if rc == 2 else ""
+        raise SnerfHipError(f"{name} failed: status {rc} ({_STATUS.get(rc, 'unknown')}{extra})")

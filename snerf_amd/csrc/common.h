@@ -17,8 +17,10 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define SNERF_DT_F64 3   // hash-grid tables of the stand-alone GridEncoder operator only
 #define SNERF_DT_BF16X3 4  // GEMM entries only: split-bf16 operands (hi = bf16(x), lo = bf16(x - hi); three MFMA passes), gemm.hip
 
+extern int g_snerf_last_hip_error;   // (elementwise.hip) the hipError_t behind the most recent SNERF_ERR_LAUNCH: snerf_last_hip_error()
 static inline int snerf_check_launch() {
   hipError_t e = hipGetLastError();
+  if (e != hipSuccess) g_snerf_last_hip_error = (int)e;
   return e == hipSuccess ? SNERF_OK : SNERF_ERR_LAUNCH;
 }
 

@@ -411,3 +411,5 @@ extern "C" int snerf_gather_pack(const float* flat, const int* idx, long n, void
 }
 
 extern "C" int snerf_version() { return 1; }
+int g_snerf_last_hip_error = 0;
+extern "C" int snerf_last_hip_error() { return g_snerf_last_hip_error; }

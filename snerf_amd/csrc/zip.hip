@@ -1563,52 +1563,58 @@ __global__ __launch_bounds__(256, NSUB == 8 ? 4 : 3) void zip_bin_write_staged_k
 // writer; only the order inside a bin differs, which the integer accumulation does not see.  A buffer that overflows between two flushes
 // (a dense level whose samples pile into one z-slab) sends the record straight to the bin (LDS cursor, one 8-byte store): correct, slower.
 #define ZW_CH 16
-#define ZW_CAP 48
+#define ZW_CAP 48                                     // ring of three chunks per bin
 template <typename OT>
 __global__ __launch_bounds__(256) void zip_bin_write_wc_kernel(ZipEnc a, ZipBin b, long ntiles) {
-  extern __shared__ uint2 zw_buf[];                   // [wc_nb][ZW_CAP] records, then base [wc_nb] (long), fill [wc_nb], done [wc_nb]
+  extern __shared__ uint2 zw_buf[];                   // [wc_nb][ZW_CAP] record rings, then base [wc_nb] (long), head / tail / done [wc_nb]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int level = blockIdx.y;
   const uint32_t hs = a.offsets[level + 1] - a.offsets[level];
   const int K = b.ksplit[level];
   const int nb = (int)(((hs + (1u << b.bshift) - 1u) >> b.bshift) * (unsigned)K);      // bins of this level (<= wc_nb: checked on the host)
   long* base = (long*)(zw_buf + (size_t)b.wc_nb * ZW_CAP);
-  int* fill = (int*)(base + b.wc_nb);
-  int* done = fill + b.wc_nb;                         // records of the bin already in global memory (this workgroup's range)
+  int* head = (int*)(base + b.wc_nb);                 // ring: records [head, tail) of the bin's stream are buffered (head % ZW_CH == 0)
+  int* tail = head + b.wc_nb;
+  int* done = tail + b.wc_nb;                         // records of the bin already in global memory (this workgroup's range)
   const long* ws = b.wstart + ((long)level * b.wc_nb) * b.wc_gw + blockIdx.x;
-  for (int k = tid; k < nb; k += 256) { base[k] = ws[(long)k * b.wc_gw]; fill[k] = 0; done[k] = 0; }
+  for (int k = tid; k < nb; k += 256) { base[k] = ws[(long)k * b.wc_gw]; head[k] = 0; tail[k] = 0; done[k] = 0; }
   const float scale = exp2f(level * a.Sl) * a.H - 1.0f;
   const uint32_t res = (uint32_t)ceilf(scale) + 1;
   const unsigned rmask = (1u << b.bshift) - 1u;
   const float gs = (float)a.grid_sizes[level];
   uint2* __restrict__ rec = (uint2*)b.rec_val;
   // sub-steps per multisample: a level with few bins takes its 8 corners in two halves so that the arrivals between two flushes stay
-  // near the chunk size (2048 records per step over < 96 bins would overrun the buffers' slack)
+  // near the chunk size (2048 records per step over < 96 bins would overrun the rings' slack)
   const int nh = nb < 96 ? 2 : 1, cps = 8 / nh;
   __syncthreads();
-  // the owning wave of a bin (bin % 4) moves whole chunks out; `all`: the final flush also moves the partial chunk
+  // Wave w owns the bins == w (mod 4) and moves their complete chunks out; `all`: the last flush also moves the partial chunk.  Lane l
+  // decides for bin w + 4 l (+ 256 per pass); the copies run 4 bins per instruction, 16 lanes (= one 128-byte chunk) per bin.
   auto flush = [&](bool all) __attribute__((always_inline)) {
-    for (int b0 = wv; b0 < nb; b0 += 256) {            // lane l looks at bin b0 + 4 l
+    for (int b0 = wv; b0 < nb; b0 += 256) {
       const int mybin = b0 + 4 * lane;
-      int n = 0, nfl = 0, pos = 0;
+      int h = 0, nrec = 0, pos = 0;
       if (mybin < nb) {
-        n = min(fill[mybin], ZW_CAP);
-        nfl = all ? n : (n & ~(ZW_CH - 1));
-        if (nfl > 0) { pos = done[mybin]; done[mybin] = pos + nfl; }      // (only this lane touches done / fill of its bin in this phase)
+        h = head[mybin];
+        const int t = min(tail[mybin], h + ZW_CAP);    // (slots past the ring went straight to the bin)
+        nrec = all ? t - h : ((t - h) & ~(ZW_CH - 1));
+        if (nrec > 0) { pos = done[mybin]; done[mybin] = pos + nrec; }
+        head[mybin] = h + (all ? 0 : nrec);            // (after the last flush nothing is appended any more)
+        tail[mybin] = all ? h : t;
       }
-      unsigned long long m = __ballot(nfl > 0);
-      while (m) {
-        const int l = __ffsll((long long)m) - 1;
-        m &= m - 1;
-        const int bn = b0 + 4 * l;
-        const int cnt = __shfl(nfl, l, 64), ps = __shfl(pos, l, 64), tot = __shfl(n, l, 64);
-        const uint2* src = zw_buf + (size_t)bn * ZW_CAP;
-        if (lane < cnt) rec[base[bn] + ps + lane] = src[lane];
-        const int rem = tot - cnt;                     // < ZW_CH records stay: move them to the front
-        uint2 t = uint2{0u, 0u};
-        if (lane < rem) t = src[cnt + lane];
-        if (lane < rem) zw_buf[(size_t)bn * ZW_CAP + lane] = t;
-        if (lane == 0) fill[bn] = rem;
+      const int nchunk = (nrec + ZW_CH - 1) / ZW_CH;
+#pragma unroll
+      for (int c = 0; c < ZW_CAP / ZW_CH; ++c) {
+        if (!__ballot(nchunk > c)) break;
+#pragma unroll 4
+        for (int g4 = 0; g4 < 16; ++g4) {              // bins b0 + 4 (4 g4 + q), q = lane / 16
+          const int src_lane = 4 * g4 + (lane >> 4);
+          const int n_ = __shfl(nrec, src_lane, 64), h_ = __shfl(h, src_lane, 64), p_ = __shfl(pos, src_lane, 64);
+          const int r = c * ZW_CH + (lane & 15);
+          const bool on = r < n_;
+          if (!__ballot(on)) continue;
+          const int bn = b0 + 4 * src_lane;
+          if (on) rec[base[bn] + p_ + r] = zw_buf[(size_t)bn * ZW_CAP + (unsigned)(h_ + r) % ZW_CAP];
+        }
       }
     }
   };
@@ -1665,18 +1671,18 @@ __global__ __launch_bounds__(256) void zip_bin_write_wc_kernel(ZipEnc a, ZipBin 
         }
       }
       if (!__syncthreads_or((int)end)) continue;       // nobody's run of equal cells ends at this multisample (coarse levels: only the last)
-      for (int h = 0; h < nh; ++h) {
+      for (int hh = 0; hh < nh; ++hh) {
         if (end) {
 #pragma unroll
           for (int idx = 0; idx < 8; ++idx) {
-            if (idx / cps != h) continue;
+            if (idx / cps != hh) continue;
             const uint32_t pl[3] = {pg[j][0] + (uint32_t)(idx & 1), pg[j][1] + (uint32_t)((idx >> 1) & 1), pg[j][2] + (uint32_t)(idx >> 2)};
             const uint32_t row = zip_grid_index(hs, res, pl);
             const int bin = (int)(row >> b.bshift) * K + rep;
             const uint2 rv = {row & rmask, __float_as_uint(r[idx] * g)};
-            const int slot = atomicAdd(fill + bin, 1);
-            if (slot < ZW_CAP) zw_buf[(size_t)bin * ZW_CAP + slot] = rv;
-            else rec[base[bin] + atomicAdd(done + bin, 1)] = rv;          // buffer full until the next flush: straight to the bin
+            const int slot = atomicAdd(tail + bin, 1);
+            if (slot - head[bin] < ZW_CAP) zw_buf[(size_t)bin * ZW_CAP + (unsigned)slot % ZW_CAP] = rv;
+            else rec[base[bin] + atomicAdd(done + bin, 1)] = rv;          // ring full until the next flush: straight to the bin
           }
         }
         __syncthreads();
@@ -1860,16 +1866,16 @@ extern "C" int snerf_zip_encode_bwd_binned(int pass, const float* tdist, const f
     // records through per-bin chunk buffers of persistent workgroups (zip_bin_write_wc_kernel); grid x = the writer workgroups the count
     // pass tallied for (tile t belongs to workgroup t % wc_gw)
     const long ntiles = (R * S + 255) / 256;
-    const size_t lds = (size_t)wc_nb * (ZW_CAP * sizeof(uint2) + sizeof(long) + 2 * sizeof(int));
+    const size_t lds = (size_t)wc_nb * (ZW_CAP * sizeof(uint2) + sizeof(long) + 3 * sizeof(int));
     if (lds > 160 * 1024) return SNERF_ERR_ARG;
     const dim3 grid((unsigned)wc_gw, L);
-    if (feat_dtype == SNERF_DT_BF16) {
-      (void)hipFuncSetAttribute((const void*)zip_bin_write_wc_kernel<__bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      hipLaunchKernelGGL((zip_bin_write_wc_kernel<__bf16>), grid, blk, lds, s, a, b, ntiles);
-    } else if (feat_dtype == SNERF_DT_F32) {
-      (void)hipFuncSetAttribute((const void*)zip_bin_write_wc_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      hipLaunchKernelGGL((zip_bin_write_wc_kernel<float>), grid, blk, lds, s, a, b, ntiles);
-    } else return SNERF_ERR_ARG;
+    (void)hipGetLastError();                          // (an error some earlier runtime call of this thread left behind is not this launch's)
+    const void* fn = feat_dtype == SNERF_DT_BF16 ? (const void*)zip_bin_write_wc_kernel<__bf16> : (const void*)zip_bin_write_wc_kernel<float>;
+    if (feat_dtype != SNERF_DT_BF16 && feat_dtype != SNERF_DT_F32) return SNERF_ERR_ARG;
+    // (the kernel also has a few hundred bytes of static LDS: ask for what this launch needs, not for the whole 160 KB)
+    if (lds > 48 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return snerf_check_launch() ? SNERF_ERR_LAUNCH : SNERF_ERR_LAUNCH;
+    if (feat_dtype == SNERF_DT_BF16) hipLaunchKernelGGL((zip_bin_write_wc_kernel<__bf16>), grid, blk, lds, s, a, b, ntiles);
+    else hipLaunchKernelGGL((zip_bin_write_wc_kernel<float>), grid, blk, lds, s, a, b, ntiles);
     return snerf_check_launch();
   }
   if (pass == 0 || pass == 1 || pass == 3 || pass == 4) {
