@@ -193,7 +193,14 @@ int snerf_zip_encode_fwd_count(const float* tdist, const float* origins, const f
                                const float* base_x, const float* base_y, const float* deg_jitter, const void* table,
                                const int* offsets, const int* grid_sizes, void* feat, long ld, long R, int S, int L, int C, int n,
                                int m, float Sl, int H, float std_scale, int table_dtype, int feat_dtype, const int* ksplit_host,
-                               const int* level_rows_host, int* counts, void* wg_offsets, int* wc_counts, int wc_gw, int wc_nb, void* stream);
+                               const int* level_rows_host, int* counts, void* wg_offsets, int* wc_counts, int wc_gw, int wc_nb, const float* pts,
+                               void* stream);
+/* The n multisamples of every interval, evaluated once (render.cast_rays :129-168 + coord.contract_mean_std :51-63 + the halving of
+ * models.py:488-490): pts fp32 [n, R*S, 4] = (position in [0,1]^3, std / 2), 16-byte aligned.  Optional input (`pts`, NULL = evaluate in
+ * the kernel) of snerf_zip_encode_fwd_count and snerf_zip_encode_bwd_binned, which run one thread per (interval, level): the helix sincos,
+ * the contraction and the cbrt of a multisample do not depend on the level. */
+int snerf_zip_points(const float* tdist, const float* origins, const float* directions, const float* radii, const float* base_x,
+                     const float* base_y, const float* deg_jitter, long R, int S, int n, int m, float std_scale, float* pts, void* stream);
 /* The proposal MLP of a zipnerf TRAINING step (internal/models.py:425-427, 481-519 with disable_rgb: Linear(L -> hidden) + ReLU +
  * Linear(hidden -> 1) on the grid features) as one launch each way instead of per-layer GEMMs over 64-column padded buffers: F [P, ldf]
  * (feat_dtype fp32 / bf16, L <= 16 feature columns, ldf >= L -- a compact buffer), parameters fp32 in the reference's layouts
@@ -515,7 +522,7 @@ int snerf_zip_encode_bwd_binned(int pass, const float* tdist, const float* origi
                                 int m, float Sl, int H, float std_scale, int feat_dtype, const int* ksplit_host, const int* level_rows_host,
                                 int* counts, void* wg_offsets, const long* starts, void* rec_row, float* rec_val, long capacity, void* g64,
                                 long g64_rows, const int* scale_exp, int* wc_counts, const long* wc_starts, int wc_gw, int wc_nb, int* wc_err,
-                                void* stream);
+                                const float* pts, void* stream);
 /* out[c] += sum over the M rows of x[m, c] (fp32, any number of columns C <= ld): the bias gradients behind the per-ray rows of the GLO
  * branch (snerf_colsum_f32 serves the heads: C <= 8).  deterministic != 0: one fixed summation order. */
 int snerf_colsum_wide_f32(const float* x, long ld, long M, int C, float* out, int deterministic, void* stream);

@@ -215,6 +215,7 @@ struct ZipEnc {
   int level_begin;                    // first level handled by the generic kernel
   long slab_row0, slab_rows;          // LDS-privatised backward: the row range this workgroup accumulates
   const int* lds_slab_level; int lds_nslab;   // slab s covers level lds_slab_level[2s], rows from lds_slab_level[2s+1]
+  const float4* pts;                  // optional [n, R*S]: the multisamples' (x, y, z in [0,1]^3, std / 2) from snerf_zip_points (see zip_sample_point)
 };
 
 __device__ __forceinline__ uint32_t zip_hash3(const uint32_t* p) { return p[0] ^ (p[1] * 2654435761u) ^ (p[2] * 805459861u); }
@@ -225,8 +226,13 @@ __device__ __forceinline__ uint32_t zip_grid_index(uint32_t hs, uint32_t res, co
   for (int d = 0; d < 3; ++d) {
     if (stride <= hs) { index += pg[d] * stride; stride *= (res + 1); }
   }
-  if (stride > hs) index = zip_hash3(pg);
-  return index % hs;
+  // a dense level's index is below its row count by construction; a hashed level has 2^log2T rows (grid.py:122-141): the reference's
+  // `% hashmap_size` is a mask there (the general remainder stays for any other layout)
+  if (stride > hs) {
+    index = zip_hash3(pg);
+    return (hs & (hs - 1u)) == 0u ? index & (hs - 1u) : index % hs;
+  }
+  return index < hs ? index : index % hs;
 }
 
 template <typename TT, int C> struct alignas(sizeof(TT) * C) ZVec { TT v[C]; };
@@ -247,6 +253,15 @@ __device__ __forceinline__ void zip_cell(float x01, float scale, uint32_t* pg, f
 __device__ __forceinline__ void zip_sample_point(const ZipEnc& a, long ray, int i, int j, float t0, float t1, const float* o, const float* d,
                                                  const float* bx, const float* by, float rad, float* x01, float* sd) {
 #pragma clang fp contract(off)        // (same positions in every kernel that calls this: see zip_cell)
+  if (a.pts != nullptr) {
+    // training: the kernels run one thread per (interval, LEVEL) and the table gradient's passes visit every level again -- the helix
+    // position (sincos), the contraction (sqrt, divisions) and the std scale (cbrt) of a multisample do not depend on the level, and
+    // re-evaluating them per level was the larger half of those kernels' instructions.  snerf_zip_points evaluates them once per
+    // interval (this very function, pts == nullptr) and every later pass reads 16 bytes per multisample instead.
+    const float4 v = a.pts[(long)j * (a.R * a.S) + ray * a.S + i];
+    x01[0] = v.x; x01[1] = v.y; x01[2] = v.z; *sd = v.w;
+    return;
+  }
   const float t = t0 + (t1 - t0) * ((float)j + 0.5f) / (float)a.n;
   float deg = 2.f * 3.14159265358979f * (float)a.m * (float)j / (float)a.n;
   if (a.deg_jitter != nullptr) deg += a.deg_jitter[(ray * a.S + i) * a.n + j] * 3.14159265358979f * 2.f;
@@ -270,6 +285,35 @@ __device__ __forceinline__ void zip_sample_point(const ZipEnc& a, long ray, int 
 #pragma unroll
   for (int k = 0; k < 3; ++k) x01[k] = (x[k] / 2.f + 1.f) / 2.f;   // /2 (models.py:488-490), then (x + bound) / (2 bound) (grid.py:162)
   *sd = std / 2.f;
+}
+
+// the multisamples of every interval, once: pts[j, p] = (x01, std / 2) of multisample j of interval p = ray * S + i (coalesced 16-byte stores)
+__global__ __launch_bounds__(256) void zip_points_kernel(ZipEnc a, float4* __restrict__ out) {
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= a.R * a.S) return;
+  const long ray = p / a.S;
+  const int i = (int)(p - ray * a.S);
+  const float t0 = a.tdist[ray * (a.S + 1) + i], t1 = a.tdist[ray * (a.S + 1) + i + 1];
+  float o[3], d[3], bx[3], by[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { o[k] = a.origins[ray * 3 + k]; d[k] = a.directions[ray * 3 + k]; bx[k] = a.base_x[ray * 3 + k]; by[k] = a.base_y[ray * 3 + k]; }
+  const float rad = a.radii[ray];
+  for (int j = 0; j < a.n; ++j) {
+    float x01[3], sd;
+    zip_sample_point(a, ray, i, j, t0, t1, o, d, bx, by, rad, x01, &sd);
+    out[(long)j * (a.R * a.S) + p] = float4{x01[0], x01[1], x01[2], sd};
+  }
+}
+
+extern "C" int snerf_zip_points(const float* tdist, const float* origins, const float* directions, const float* radii, const float* base_x,
+                                const float* base_y, const float* deg_jitter, long R, int S, int n, int m, float std_scale, float* pts, void* stream) {
+  if (R <= 0) return SNERF_OK;
+  if (S <= 0 || n <= 0 || pts == nullptr || tdist == nullptr || origins == nullptr || directions == nullptr || radii == nullptr || base_x == nullptr ||
+      base_y == nullptr || (((uintptr_t)pts) & 15) != 0)
+    return SNERF_ERR_ARG;
+  ZipEnc a{tdist, origins, directions, radii, base_x, base_y, deg_jitter, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, R, S, 0, n, m, 0.f, 0, std_scale};
+  hipLaunchKernelGGL(zip_points_kernel, dim3((unsigned)((R * S + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, (float4*)pts);
+  return snerf_check_launch();
 }
 
 // MODE 0: forward gather.  MODE 1: backward, fp32 atomics straight into the table gradient.  MODE 2: backward for SMALL DENSE
@@ -1202,7 +1246,7 @@ extern "C" int snerf_zip_encode_fwd_count(const float* tdist, const float* origi
                                           const int* offsets, const int* grid_sizes, void* feat, long ld, long R, int S, int L, int C, int n,
                                           int m, float Sl, int H, float std_scale, int table_dtype, int feat_dtype, const int* ksplit_host,
                                           const int* level_rows_host, int* counts, void* wg_offsets, int* wc_counts, int wc_gw, int wc_nb,
-                                          void* stream) {
+                                          const float* pts, void* stream) {
   if (R <= 0) return SNERF_OK;
   if (S <= 0 || L <= 0 || L > 16 || n <= 0 || n > 8 || (C != 1 && C != 4) || ld < (long)L * C || table == nullptr || feat == nullptr ||
       grid_sizes == nullptr || ksplit_host == nullptr || level_rows_host == nullptr)
@@ -1221,6 +1265,7 @@ extern "C" int snerf_zip_encode_fwd_count(const float* tdist, const float* origi
   b.wcnt = wc_counts; b.wc_gw = wc_gw; b.wc_nb = wc_nb;
   ZipEnc a{tdist, origins, directions, radii, base_x, base_y, deg_jitter, table, offsets, grid_sizes, feat, ld, nullptr, nullptr, R, S, L, n, m, Sl, H, std_scale};
   a.level_begin = 1;
+  a.pts = (const float4*)pts;
   const dim3 grid((unsigned)((R * S + 255) / 256), L), blk(256);
   hipStream_t s = (hipStream_t)stream;
 #define ZFC(TT, OT) do { if (C == 4) hipLaunchKernelGGL((zip_encode_fwd_all_kernel<TT, OT, 4, true>), grid, blk, 0, s, a, b); \
@@ -1837,7 +1882,7 @@ extern "C" int snerf_zip_encode_bwd_binned(int pass, const float* tdist, const f
                                            int n, int m, float Sl, int H, float std_scale, int feat_dtype, const int* ksplit_host,
                                            const int* level_rows_host, int* counts, void* wg_offsets, const long* starts, void* rec_row,
                                            float* rec_val, long capacity, void* g64, long g64_rows, const int* scale_exp, int* wc_counts,
-                                           const long* wc_starts, int wc_gw, int wc_nb, int* wc_err, void* stream) {
+                                           const long* wc_starts, int wc_gw, int wc_nb, int* wc_err, const float* pts, void* stream) {
   if (R <= 0) return SNERF_OK;
   if (S <= 0 || L <= 0 || L > 16 || n <= 0 || (C != 1 && C != 4) || ksplit_host == nullptr || level_rows_host == nullptr) return SNERF_ERR_ARG;
   const bool wc = wc_counts != nullptr;               // passes 0 / 5 with the write-combining writer's bookkeeping (C = 1)
@@ -1856,6 +1901,7 @@ extern "C" int snerf_zip_encode_bwd_binned(int pass, const float* tdist, const f
   ZipBin b{};
   b.bshift = C == 4 ? 12 : 14;
   b.wcnt = wc_counts; b.wstart = wc_starts; b.wc_gw = wc_gw; b.wc_nb = wc_nb; b.err = wc_err;
+  a.pts = (const float4*)pts;
   b.counts = counts; b.wg_offsets = (unsigned*)wg_offsets; b.starts = starts;
   for (int l = 0; l < L; ++l) { b.ksplit[l] = ksplit_host[l]; if (b.ksplit[l] < 1) return SNERF_ERR_ARG; }
   b.rec_row = (unsigned short*)rec_row; b.rec_val = rec_val; b.capacity = capacity; b.g64 = (long long*)g64; b.g64_rows = g64_rows;

@@ -704,8 +704,21 @@ def zip_encode_fwd(tdist, origins, directions, radii, base_x, base_y, deg_jitter
               _zip_dt(feat), int(levels_per_thread), _stream())
 
 
+def zip_points(tdist, origins, directions, radii, base_x, base_y, deg_jitter, n, m, std_scale):
+    """The n multisamples of every interval, evaluated once: -> pts fp32 [n, R*S, 4] = (position in [0,1]^3, std / 2).  Input of
+    zip_encode_fwd_count / zip_encode_bwd_binned (`pts=`): their one-thread-per-(interval, level) kernels then read 16 bytes per
+    multisample instead of re-evaluating sincos / contraction / cbrt for every level."""
+    for t in (tdist, origins, directions, radii, base_x, base_y, deg_jitter):
+        _f32c(t)
+    R, P = tdist.shape
+    pts = torch.empty(n, R * (P - 1), 4, dtype=torch.float32, device=tdist.device)
+    _lib.call("snerf_zip_points", _p(tdist), _p(origins), _p(directions), _p(radii), _p(base_x), _p(base_y), _p(deg_jitter), R, P - 1, int(n), int(m),
+              float(std_scale), _p(pts), _stream())
+    return pts
+
+
 def zip_encode_fwd_count(tdist, origins, directions, radii, base_x, base_y, deg_jitter, table, offsets, grid_sizes, feat, L, C, n, m, Sl, H, std_scale,
-                         ksplit, level_rows):
+                         ksplit, level_rows, pts=None):
     """zip_encode_fwd (one thread per (interval, level)) that also counts the records of the binned table gradient and reserves the
     workgroups' ranges: pass 0 of zip_encode_bwd_binned in the forward's sweep.  -> (counts, wg_offsets) to hand to zip_encode_bwd_binned
     as `precounted`.  wg_offsets is a buffer of its own per call: it lives until the backward."""
@@ -715,6 +728,7 @@ def zip_encode_fwd_count(tdist, origins, directions, radii, base_x, base_y, deg_
     R, P = tdist.shape
     S = P - 1
     assert table.is_contiguous() and offsets.dtype == torch.int32 and grid_sizes.dtype == torch.int32 and C in (1, 4) and n <= 8 and L <= 16
+    assert pts is None or (pts.dtype == torch.float32 and pts.is_contiguous() and pts.shape == (n, R * S, 4))
     ks = np.ascontiguousarray(np.asarray(ksplit, dtype=np.int32))
     lr = np.ascontiguousarray(np.asarray(level_rows, dtype=np.int32))
     assert ks.shape == (L,) and lr.shape == (L,)
@@ -724,13 +738,13 @@ def zip_encode_fwd_count(tdist, origins, directions, radii, base_x, base_y, deg_
         wcnt = torch.zeros(L, wc_nb, ZW_GW, dtype=torch.int32, device=tdist.device)
         _lib.call("snerf_zip_encode_fwd_count", _p(tdist), _p(origins), _p(directions), _p(radii), _p(base_x), _p(base_y), _p(deg_jitter), _p(table),
                   _p(offsets), _p(grid_sizes), _p(feat), feat.stride(0), R, S, L, C, n, m, float(Sl), int(H), float(std_scale), _zip_dt(table),
-                  _zip_dt(feat), ks.ctypes.data, lr.ctypes.data, None, None, _p(wcnt), ZW_GW, wc_nb, _stream())
+                  _zip_dt(feat), ks.ctypes.data, lr.ctypes.data, None, None, _p(wcnt), ZW_GW, wc_nb, _p(pts), _stream())
         return "wc", wcnt
     counts = torch.zeros(L, ZB_NBMAX, dtype=torch.int32, device=tdist.device)
     wgo = torch.empty(L * ((R * S + 255) // 256) * ZB_NBMAX, dtype=torch.int32, device=tdist.device)
     _lib.call("snerf_zip_encode_fwd_count", _p(tdist), _p(origins), _p(directions), _p(radii), _p(base_x), _p(base_y), _p(deg_jitter), _p(table),
               _p(offsets), _p(grid_sizes), _p(feat), feat.stride(0), R, S, L, C, n, m, float(Sl), int(H), float(std_scale), _zip_dt(table),
-              _zip_dt(feat), ks.ctypes.data, lr.ctypes.data, _p(counts), _p(wgo), None, 0, 0, _stream())
+              _zip_dt(feat), ks.ctypes.data, lr.ctypes.data, _p(counts), _p(wgo), None, 0, 0, _p(pts), _stream())
     return counts, wgo
 
 
@@ -852,7 +866,7 @@ zip_wc_errors = None                                                    # device
 
 
 def zip_encode_bwd_binned(tdist, origins, directions, radii, base_x, base_y, deg_jitter, offsets, grid_sizes, grad_feat, grad_table, L, C, n, m, Sl, H,
-                          std_scale, ksplit, g64_rows, level_rows, precounted=None):
+                          std_scale, ksplit, g64_rows, level_rows, precounted=None, pts=None):
     """The table gradient of zip_encode_bwd without L2 atomics on the hashed levels and bit-reproducible: records binned by destination,
     accumulated per bin in LDS with fixed-point integer atomics (snerf_zip_encode_bwd_binned: count, scan on the device, write, accumulate).
     The fixed-point grid follows the gradient's magnitude (snerf_zip_bin_scale: 34 bits below max |grad_feat|).  `precounted` = the
@@ -871,7 +885,8 @@ def zip_encode_bwd_binned(tdist, origins, directions, radii, base_x, base_y, deg
             grad_feat.stride(0), _p(grad_table), R, S, L, C, n, m, float(Sl), int(H), float(std_scale), _zip_dt(grad_feat), ks.ctypes.data,
             lr.ctypes.data)
     global zip_wc_errors
-    none5 = (None, None, 0, 0, None)
+    assert pts is None or (pts.dtype == torch.float32 and pts.is_contiguous() and pts.shape == (n, R * S, 4))
+    none5 = (None, None, 0, 0, None, _p(pts))
     wc_nb = zip_wc_bins(ks, lr) if (C == 1 and ZIP_BIN_WC and n <= 8) else 0
     if precounted is not None and isinstance(precounted[0], str):
         assert wc_nb and precounted[1].shape == (L, wc_nb, ZW_GW), "the forward counted for the write-combining writer"
@@ -887,7 +902,7 @@ def zip_encode_bwd_binned(tdist, origins, directions, radii, base_x, base_y, deg
             wcnt = precounted[1]
         else:
             wcnt = torch.zeros(L, wc_nb, ZW_GW, dtype=torch.int32, device=dev)
-            _lib.call("snerf_zip_encode_bwd_binned", 0, *args, None, None, None, None, None, 0, None, 0, None, _p(wcnt), None, ZW_GW, wc_nb, None, _stream())
+            _lib.call("snerf_zip_encode_bwd_binned", 0, *args, None, None, None, None, None, 0, None, 0, None, _p(wcnt), None, ZW_GW, wc_nb, None, _p(pts), _stream())
         flat = wcnt.view(-1).to(torch.int64)
         wstart = (torch.cumsum(flat, 0) - flat).view(L, wc_nb, ZW_GW)
         counts = torch.zeros(L, ZB_NBMAX, dtype=torch.int32, device=dev)
@@ -897,7 +912,7 @@ def zip_encode_bwd_binned(tdist, origins, directions, radii, base_x, base_y, deg
         if zip_wc_errors is None or zip_wc_errors.device != dev:
             zip_wc_errors = torch.zeros(1, dtype=torch.int32, device=dev)
         _lib.call("snerf_zip_encode_bwd_binned", 5, *args, None, None, None, _p(rec_row), _p(rec_val), capacity, None, 0, None, _p(wcnt), _p(wstart),
-                  ZW_GW, wc_nb, _p(zip_wc_errors), _stream())
+                  ZW_GW, wc_nb, _p(zip_wc_errors), _p(pts), _stream())
         wgo = None
     else:
         if precounted is not None:

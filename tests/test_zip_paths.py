@@ -651,7 +651,7 @@ def test_zip_table_gradient_binned_is_exact_and_bit_reproducible(lvl, gscale, mo
     import numpy as np
     ksa, lra = np.asarray(ks, dtype=np.int32), np.asarray(lrows, dtype=np.int32)
     p_ = lambda t: t.data_ptr()
-    none5 = (None, None, 0, 0, None)
+    none5 = (None, None, 0, 0, None, None)                                                # (no write-combining bookkeeping, no shared points)
     tab = m._table(lvl)
     f0 = torch.zeros(R * S, Fw, device="cuda", dtype=dF.dtype)
     f1 = torch.zeros_like(f0)
@@ -676,7 +676,7 @@ def test_zip_table_gradient_binned_is_exact_and_bit_reproducible(lvl, gscale, mo
         tag, wcnt = ops.zip_encode_fwd_count(*enc_args, f1, *tail, ks, lrows)
         assert tag == "wc" and torch.equal(f0, f1), "the counting forward must produce the plain forward's features"
         w0 = torch.zeros_like(wcnt)
-        _lib.call(*bwd0, None, None, None, None, None, 0, None, 0, None, p_(w0), None, ops.ZW_GW, wcnt.shape[1], None, torch.cuda.current_stream().cuda_stream)
+        _lib.call(*bwd0, None, None, None, None, None, 0, None, 0, None, p_(w0), None, ops.ZW_GW, wcnt.shape[1], None, None, torch.cuda.current_stream().cuda_stream)
         assert torch.equal(wcnt, w0) and int(wcnt.sum()) > 0, "forward-side record counts differ from the backward's count pass"
         f2 = torch.zeros(R * S, Fw, device="cuda", dtype=dF.dtype)                      # half table: the kernel's paired 4-byte gather branch
         _, w16 = ops.zip_encode_fwd_count(tdist, o, d, radii, bx, by, degj, tab.half().contiguous(), m.dev_offsets[lvl], m.dev_sizes[lvl], f2, *tail, ks, lrows)
@@ -707,6 +707,21 @@ def test_zip_table_gradient_binned_is_exact_and_bit_reproducible(lvl, gscale, mo
         gp = torch.zeros(e.rows, e.C, device="cuda")
         ops.zip_encode_bwd_binned(*common, gp, *tail, ks, g64_rows, lrows, precounted=(counts, wgo))
         assert torch.equal(outs[0], gp), "gradient with the forward's counts must equal the gradient with the backward's own count pass"
+    # round 4: the multisamples evaluated once per interval (snerf_zip_points) and read by the per-level kernels: same positions bit for
+    # bit, hence the same features, counts and gradient
+    pts = ops.zip_points(tdist, o, d, radii, bx, by, degj, n, 3, m.std_scale)
+    assert pts.shape == (n, R * S, 4)
+    f3 = torch.zeros_like(f0)
+    pre = ops.zip_encode_fwd_count(*enc_args, f3, *tail, ks, lrows, pts=pts)
+    assert torch.equal(f0, f3), "features from the shared multisamples must equal the in-kernel evaluation"
+    g3 = torch.zeros(e.rows, e.C, device="cuda")
+    ops.zip_encode_bwd_binned(*common, g3, *tail, ks, g64_rows, lrows, precounted=pre, pts=pts)
+    assert torch.equal(outs[0], g3), "gradient from the shared multisamples must equal the in-kernel evaluation"
+    g4 = torch.zeros(e.rows, e.C, device="cuda")
+    ops.zip_encode_bwd_binned(*common, g4, *tail, ks, g64_rows, lrows, pts=pts)            # (the backward's own count pass reads them too)
+    assert torch.equal(outs[0], g4)
+    if e.C == 1:
+        assert int(ops.zip_wc_errors.item()) == 0
     rel = float((outs[0] - ref).norm() / ref.norm())
     print(f"MEASURED binned vs atomic table gradient (grid {lvl}): rel L2 {rel:.3e}, K per level {ks}")
     assert float(ref.norm()) > 0 and rel < 2e-6, rel
@@ -728,7 +743,7 @@ def test_binned_table_gradient_refuses_tables_with_more_row_ranges_than_bins():
     big = np.array([4913, 1 << 23], dtype=np.int32)
     with pytest.raises(_lib.SnerfHipError, match="bad argument"):
         _lib.call("snerf_zip_encode_bwd_binned", 0, None, None, None, None, None, None, None, None, None, None, 8, None, 16, 4, 2, 4, 7, 3, 0.5, 16, 0.35,
-                  1, k2.ctypes.data, big.ctypes.data, 1, 1, None, None, None, 0, None, 0, None, None, None, 0, 0, None, None)
+                  1, k2.ctypes.data, big.ctypes.data, 1, 1, None, None, None, 0, None, 0, None, None, None, 0, 0, None, None, None)
 
 
 @pytest.mark.gpu
