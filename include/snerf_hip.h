@@ -186,21 +186,12 @@ int snerf_zip_encode_fwd(const float* tdist, const float* origins, const float* 
  * (interval, level), and the same sweep also IS that gradient's pass 0 -- it has the 8 rows of every multisample's cell in hand for its
  * gathers and counts the records the backward will emit per bin (counts [L, 1024], zeroed by the caller) and reserves each workgroup's
  * ranges (wg_offsets [L, ceil(R S / 256), 1024]); ksplit_host / level_rows_host as for snerf_zip_encode_bwd_binned.  The backward then
- * starts at its record pass (1 / 3) with these two buffers.  C = 1 or 4, n <= 8 multisamples.
- * wc_counts != NULL (C = 1): the counts go to the write-combining writer's layout instead -- int32 [L, wc_nb, wc_gw], zeroed by the caller,
- * records per (level, bin, writer workgroup = tile % wc_gw) -- and counts / wg_offsets are not touched (pass 5 of the backward). */
+ * starts at its record pass (1 / 3) with these two buffers.  C = 1 or 4, n <= 8 multisamples. */
 int snerf_zip_encode_fwd_count(const float* tdist, const float* origins, const float* directions, const float* radii,
                                const float* base_x, const float* base_y, const float* deg_jitter, const void* table,
                                const int* offsets, const int* grid_sizes, void* feat, long ld, long R, int S, int L, int C, int n,
                                int m, float Sl, int H, float std_scale, int table_dtype, int feat_dtype, const int* ksplit_host,
-                               const int* level_rows_host, int* counts, void* wg_offsets, int* wc_counts, int wc_gw, int wc_nb, const float* pts,
-                               void* stream);
-/* The n multisamples of every interval, evaluated once (render.cast_rays :129-168 + coord.contract_mean_std :51-63 + the halving of
- * models.py:488-490): pts fp32 [n, R*S, 4] = (position in [0,1]^3, std / 2), 16-byte aligned.  Optional input (`pts`, NULL = evaluate in
- * the kernel) of snerf_zip_encode_fwd_count and snerf_zip_encode_bwd_binned, which run one thread per (interval, level): the helix sincos,
- * the contraction and the cbrt of a multisample do not depend on the level. */
-int snerf_zip_points(const float* tdist, const float* origins, const float* directions, const float* radii, const float* base_x,
-                     const float* base_y, const float* deg_jitter, long R, int S, int n, int m, float std_scale, float* pts, void* stream);
+                               const int* level_rows_host, int* counts, void* wg_offsets, void* stream);
 /* The proposal MLP of a zipnerf TRAINING step (internal/models.py:425-427, 481-519 with disable_rgb: Linear(L -> hidden) + ReLU +
  * Linear(hidden -> 1) on the grid features) as one launch each way instead of per-layer GEMMs over 64-column padded buffers: F [P, ldf]
  * (feat_dtype fp32 / bf16, L <= 16 feature columns, ldf >= L -- a compact buffer), parameters fp32 in the reference's layouts
@@ -509,20 +500,13 @@ int snerf_classic_ray_batch(int H, int W, double focal, double cx, double cy, co
  * records where they fall: more than 8 multisamples, A/B probes); pass 2 accumulates into grad_table (fp32, +=).  ksplit_host: HOST int[L],
  * replicas per row range (> 1 for levels with few, hot rows: they meet in g64, an int64 image of table rows [0, g64_rows) zeroed by
  * the caller); level_rows_host: HOST int[L], table rows per level -- a level needs ceil(rows / 4096 or 16384) * ksplit <= 1024 bins,
- * anything larger is refused with a bad-argument status (use snerf_zip_encode_bwd, the atomic scatter).
- * Single-channel grids (C = 1; every ksplit a power of two): pass 5 is the WRITE-COMBINING record writer -- wc_gw persistent workgroups
- * per level keep a 16-record chunk buffer per bin in LDS and store whole 128-byte chunks (one L2 request per 16 records instead of one per
- * record).  It needs the counts per (level, bin, writer workgroup): wc_counts int32 [L, wc_nb, wc_gw] (pass 0 with wc_counts != NULL, or
- * snerf_zip_encode_fwd_count), every level's bins <= wc_nb <= 1024, and wc_starts int64 of the same shape = the exclusive prefix sums of
- * wc_counts flattened (the caller's scan), i.e. the record range each workgroup owns in each bin; counts / starts ([L,1024]) for pass 2 are
- * the per-bin sums / first prefixes.  wc_err (optional int32[1]): incremented when a workgroup's records do not fill its ranges exactly. */
+ * anything larger is refused with a bad-argument status (use snerf_zip_encode_bwd, the atomic scatter). */
 int snerf_zip_encode_bwd_binned(int pass, const float* tdist, const float* origins, const float* directions, const float* radii,
                                 const float* base_x, const float* base_y, const float* deg_jitter, const int* offsets,
                                 const int* grid_sizes, const void* grad_feat, long ld, float* grad_table, long R, int S, int L, int C, int n,
                                 int m, float Sl, int H, float std_scale, int feat_dtype, const int* ksplit_host, const int* level_rows_host,
                                 int* counts, void* wg_offsets, const long* starts, void* rec_row, float* rec_val, long capacity, void* g64,
-                                long g64_rows, const int* scale_exp, int* wc_counts, const long* wc_starts, int wc_gw, int wc_nb, int* wc_err,
-                                const float* pts, void* stream);
+                                long g64_rows, const int* scale_exp, void* stream);
 /* out[c] += sum over the M rows of x[m, c] (fp32, any number of columns C <= ld): the bias gradients behind the per-ray rows of the GLO
  * branch (snerf_colsum_f32 serves the heads: C <= 8).  deterministic != 0: one fixed summation order. */
 int snerf_colsum_wide_f32(const float* x, long ld, long M, int C, float* out, int deterministic, void* stream);

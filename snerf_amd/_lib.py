@@ -10,7 +10,7 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _REPO = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_HERE, "lib", "libsnerf_hip.so")
+LIB_PATH = os.environ.get("SNERF_HIP_LIB") or os.path.join(_HERE, "lib", "libsnerf_hip.so")   # (the override: A/B builds of tools/probes)
 HEADER_PATH = os.path.join(_REPO, "include", "snerf_hip.h")
 IO_LIB_PATH = os.path.join(_HERE, "lib", "libsnerf_io.so")
 IO_HEADER_PATH = os.path.join(_REPO, "include", "snerf_io.h")

@@ -215,7 +215,6 @@ struct ZipEnc {
   int level_begin;                    // first level handled by the generic kernel
   long slab_row0, slab_rows;          // LDS-privatised backward: the row range this workgroup accumulates
   const int* lds_slab_level; int lds_nslab;   // slab s covers level lds_slab_level[2s], rows from lds_slab_level[2s+1]
-  const float4* pts;                  // optional [n, R*S]: the multisamples' (x, y, z in [0,1]^3, std / 2) from snerf_zip_points (see zip_sample_point)
 };
 
 __device__ __forceinline__ uint32_t zip_hash3(const uint32_t* p) { return p[0] ^ (p[1] * 2654435761u) ^ (p[2] * 805459861u); }
@@ -226,13 +225,8 @@ __device__ __forceinline__ uint32_t zip_grid_index(uint32_t hs, uint32_t res, co
   for (int d = 0; d < 3; ++d) {
     if (stride <= hs) { index += pg[d] * stride; stride *= (res + 1); }
   }
-  // a dense level's index is below its row count by construction; a hashed level has 2^log2T rows (grid.py:122-141): the reference's
-  // `% hashmap_size` is a mask there (the general remainder stays for any other layout)
-  if (stride > hs) {
-    index = zip_hash3(pg);
-    return (hs & (hs - 1u)) == 0u ? index & (hs - 1u) : index % hs;
-  }
-  return index < hs ? index : index % hs;
+  if (stride > hs) index = zip_hash3(pg);
+  return index % hs;
 }
 
 template <typename TT, int C> struct alignas(sizeof(TT) * C) ZVec { TT v[C]; };
@@ -253,15 +247,6 @@ __device__ __forceinline__ void zip_cell(float x01, float scale, uint32_t* pg, f
 __device__ __forceinline__ void zip_sample_point(const ZipEnc& a, long ray, int i, int j, float t0, float t1, const float* o, const float* d,
                                                  const float* bx, const float* by, float rad, float* x01, float* sd) {
 #pragma clang fp contract(off)        // (same positions in every kernel that calls this: see zip_cell)
-  if (a.pts != nullptr) {
-    // training: the kernels run one thread per (interval, LEVEL) and the table gradient's passes visit every level again -- the helix
-    // position (sincos), the contraction (sqrt, divisions) and the std scale (cbrt) of a multisample do not depend on the level, and
-    // re-evaluating them per level was the larger half of those kernels' instructions.  snerf_zip_points evaluates them once per
-    // interval (this very function, pts == nullptr) and every later pass reads 16 bytes per multisample instead.
-    const float4 v = a.pts[(long)j * (a.R * a.S) + ray * a.S + i];
-    x01[0] = v.x; x01[1] = v.y; x01[2] = v.z; *sd = v.w;
-    return;
-  }
   const float t = t0 + (t1 - t0) * ((float)j + 0.5f) / (float)a.n;
   float deg = 2.f * 3.14159265358979f * (float)a.m * (float)j / (float)a.n;
   if (a.deg_jitter != nullptr) deg += a.deg_jitter[(ray * a.S + i) * a.n + j] * 3.14159265358979f * 2.f;
@@ -285,35 +270,6 @@ __device__ __forceinline__ void zip_sample_point(const ZipEnc& a, long ray, int 
 #pragma unroll
   for (int k = 0; k < 3; ++k) x01[k] = (x[k] / 2.f + 1.f) / 2.f;   // /2 (models.py:488-490), then (x + bound) / (2 bound) (grid.py:162)
   *sd = std / 2.f;
-}
-
-// the multisamples of every interval, once: pts[j, p] = (x01, std / 2) of multisample j of interval p = ray * S + i (coalesced 16-byte stores)
-__global__ __launch_bounds__(256) void zip_points_kernel(ZipEnc a, float4* __restrict__ out) {
-  const long p = (long)blockIdx.x * 256 + threadIdx.x;
-  if (p >= a.R * a.S) return;
-  const long ray = p / a.S;
-  const int i = (int)(p - ray * a.S);
-  const float t0 = a.tdist[ray * (a.S + 1) + i], t1 = a.tdist[ray * (a.S + 1) + i + 1];
-  float o[3], d[3], bx[3], by[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) { o[k] = a.origins[ray * 3 + k]; d[k] = a.directions[ray * 3 + k]; bx[k] = a.base_x[ray * 3 + k]; by[k] = a.base_y[ray * 3 + k]; }
-  const float rad = a.radii[ray];
-  for (int j = 0; j < a.n; ++j) {
-    float x01[3], sd;
-    zip_sample_point(a, ray, i, j, t0, t1, o, d, bx, by, rad, x01, &sd);
-    out[(long)j * (a.R * a.S) + p] = float4{x01[0], x01[1], x01[2], sd};
-  }
-}
-
-extern "C" int snerf_zip_points(const float* tdist, const float* origins, const float* directions, const float* radii, const float* base_x,
-                                const float* base_y, const float* deg_jitter, long R, int S, int n, int m, float std_scale, float* pts, void* stream) {
-  if (R <= 0) return SNERF_OK;
-  if (S <= 0 || n <= 0 || pts == nullptr || tdist == nullptr || origins == nullptr || directions == nullptr || radii == nullptr || base_x == nullptr ||
-      base_y == nullptr || (((uintptr_t)pts) & 15) != 0)
-    return SNERF_ERR_ARG;
-  ZipEnc a{tdist, origins, directions, radii, base_x, base_y, deg_jitter, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, R, S, 0, n, m, 0.f, 0, std_scale};
-  hipLaunchKernelGGL(zip_points_kernel, dim3((unsigned)((R * S + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, (float4*)pts);
-  return snerf_check_launch();
 }
 
 // MODE 0: forward gather.  MODE 1: backward, fp32 atomics straight into the table gradient.  MODE 2: backward for SMALL DENSE
@@ -507,19 +463,7 @@ struct ZipBin {
   unsigned short* rec_row; float* rec_val; long capacity;   // records: C = 1: rec_val holds {row, value} pairs (8 B); else row + C floats
   long long* g64; long g64_rows;           // int64 image of table rows [0, g64_rows) for the replicated levels
   const int* scale_exp;                    // device: the launch's fixed-point scale is 2^scale_exp[0] (snerf_zip_bin_scale)
-  // write-combining record writer (C = 1, zip_bin_write_wc_kernel): records per (level, bin, writer workgroup) counted by the count pass
-  // [L, wc_nb, wc_gw] and their exclusive prefix in that order (= the exact range every writer workgroup owns inside every bin)
-  int* wcnt; const long* wstart; int wc_gw, wc_nb;
-  int* err;                                // debug counter: a writer workgroup whose records did not fill its reserved ranges exactly
 };
-
-// Replica of a record's row range.  C = 4: the replica of the emitting 256-interval tile (a tile's records of a hot dense level go to ONE
-// replica: the staged writer's runs stay long).  C = 1 (write-combining writer): K is a power of two and consecutive intervals take
-// consecutive replicas, so a dense level's few row ranges are spread over K x ranges chunk buffers of every writer workgroup.
-template <int C> __device__ __forceinline__ int zip_rep(long p, int K) {
-  if constexpr (C == 1) return (int)(p & (long)(K - 1));
-  else return (int)((p >> 8) % K);
-}
 
 // Forward featurisation, one thread per interval for ALL levels: the n <= 8 helix multisamples (sincos, contraction, cbrt) are
 // evaluated once and kept in registers instead of once per (interval, level) as in the per-level grid above -- for the
@@ -564,7 +508,7 @@ __device__ __forceinline__ void zip_fwd_all_body(const ZipEnc& a, const ZipBin& 
 #pragma unroll
     for (int c = 0; c < C; ++c) acc[c] = 0.f;
     uint32_t cur[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};     // COUNT: cell of the current run of multisamples
-    const int K = COUNT ? b.ksplit[level] : 1, rep = COUNT ? zip_rep<C>(p, K) : 0;
+    const int K = COUNT ? b.ksplit[level] : 1, rep = COUNT ? (int)(blockIdx.x % (unsigned)K) : 0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       if (j >= a.n || !((inb >> j) & 1u)) continue;     // outside [0,1]^3 the encoder returns zeros
@@ -704,12 +648,6 @@ __global__ __launch_bounds__(256) void zip_encode_fwd_all_kernel(ZipEnc a, ZipBi
   if constexpr (COUNT) {
     __syncthreads();
     const int level = blockIdx.y;                       // (one level per thread in this mode)
-    if (b.wcnt != nullptr) {                            // write-combining writer: records per (bin, writer workgroup of this tile)
-      int* wc = b.wcnt + (long)level * b.wc_nb * b.wc_gw + (blockIdx.x % (unsigned)b.wc_gw);
-      for (int k = threadIdx.x; k < b.wc_nb; k += 256)
-        if (cnt[k] != 0) atomicAdd(wc + (long)k * b.wc_gw, cnt[k]);
-      return;
-    }
     unsigned* wgo = b.wg_offsets + ((long)level * gridDim.x + blockIdx.x) * ZB_NBMAX;
     for (int k = threadIdx.x; k < ZB_NBMAX; k += 256)
       if (cnt[k] != 0) wgo[k] = (unsigned)atomicAdd(b.counts + level * ZB_NBMAX + k, cnt[k]);
@@ -1245,27 +1183,21 @@ extern "C" int snerf_zip_encode_fwd_count(const float* tdist, const float* origi
                                           const float* base_x, const float* base_y, const float* deg_jitter, const void* table,
                                           const int* offsets, const int* grid_sizes, void* feat, long ld, long R, int S, int L, int C, int n,
                                           int m, float Sl, int H, float std_scale, int table_dtype, int feat_dtype, const int* ksplit_host,
-                                          const int* level_rows_host, int* counts, void* wg_offsets, int* wc_counts, int wc_gw, int wc_nb,
-                                          const float* pts, void* stream) {
+                                          const int* level_rows_host, int* counts, void* wg_offsets, void* stream) {
   if (R <= 0) return SNERF_OK;
   if (S <= 0 || L <= 0 || L > 16 || n <= 0 || n > 8 || (C != 1 && C != 4) || ld < (long)L * C || table == nullptr || feat == nullptr ||
-      grid_sizes == nullptr || ksplit_host == nullptr || level_rows_host == nullptr)
+      grid_sizes == nullptr || ksplit_host == nullptr || level_rows_host == nullptr || counts == nullptr || wg_offsets == nullptr)
     return SNERF_ERR_ARG;
-  const bool wc = wc_counts != nullptr;               // counts in the write-combining writer's layout [L, wc_nb, wc_gw] (C = 1 only)
-  if (wc ? (C != 1 || wc_gw < 1 || wc_nb < 1 || wc_nb > ZB_NBMAX) : (counts == nullptr || wg_offsets == nullptr)) return SNERF_ERR_ARG;
   ZipBin b{};
   b.bshift = C == 4 ? 12 : 14;
   for (int l = 0; l < L; ++l) {                         // (the same bound as snerf_zip_encode_bwd_binned)
     const long rowbins = ((long)level_rows_host[l] + (1L << b.bshift) - 1) >> b.bshift;
-    if (level_rows_host[l] <= 0 || ksplit_host[l] < 1 || rowbins * ksplit_host[l] > (wc ? wc_nb : ZB_NBMAX)) return SNERF_ERR_ARG;
-    if (C == 1 && (ksplit_host[l] & (ksplit_host[l] - 1)) != 0) return SNERF_ERR_ARG;      // zip_rep<1>: a power of two
+    if (level_rows_host[l] <= 0 || ksplit_host[l] < 1 || rowbins * ksplit_host[l] > ZB_NBMAX) return SNERF_ERR_ARG;
     b.ksplit[l] = ksplit_host[l];
   }
   b.counts = counts; b.wg_offsets = (unsigned*)wg_offsets;
-  b.wcnt = wc_counts; b.wc_gw = wc_gw; b.wc_nb = wc_nb;
   ZipEnc a{tdist, origins, directions, radii, base_x, base_y, deg_jitter, table, offsets, grid_sizes, feat, ld, nullptr, nullptr, R, S, L, n, m, Sl, H, std_scale};
   a.level_begin = 1;
-  a.pts = (const float4*)pts;
   const dim3 grid((unsigned)((R * S + 255) / 256), L), blk(256);
   hipStream_t s = (hipStream_t)stream;
 #define ZFC(TT, OT) do { if (C == 4) hipLaunchKernelGGL((zip_encode_fwd_all_kernel<TT, OT, 4, true>), grid, blk, 0, s, a, b); \
@@ -1328,7 +1260,7 @@ __device__ __forceinline__ void zip_emit_level(const ZipEnc& a, const ZipBin& b,
   const uint32_t hs = a.offsets[level + 1] - a.offsets[level];
   const float scale = exp2f(level * a.Sl) * a.H - 1.0f;
   const uint32_t res = (uint32_t)ceilf(scale) + 1;
-  const int K = b.ksplit[level], rep = zip_rep<C>(p, K);
+  const int K = b.ksplit[level], rep = (int)(blockIdx.x % (unsigned)K);
   float g[C];
   const OT* gi = (const OT*)a.feat + p * a.ld + level * C;
 #pragma unroll
@@ -1417,14 +1349,8 @@ __global__ __launch_bounds__(256) void zip_bin_emit_kernel(ZipEnc a, ZipBin b) {
   // PASS 0 above (shared code): the workgroup's histogram.  It reserves the workgroup's range inside every bin it touches right away --
   // the bin's running count IS the offset of the range relative to the bin's start (known only after the host's scan) -- and leaves
   // it in wg_offsets[level, workgroup, bin]; pass 1 then needs no second count sweep.
+  unsigned* wgo = b.wg_offsets + ((long)level * gridDim.x + blockIdx.x) * ZB_NBMAX;
   if (PASS == 0) {
-    if (b.wcnt != nullptr) {                              // (as in the counting forward: the write-combining writer's layout)
-      int* wc = b.wcnt + (long)level * b.wc_nb * b.wc_gw + (blockIdx.x % (unsigned)b.wc_gw);
-      for (int k = threadIdx.x; k < b.wc_nb; k += 256)
-        if (cnt[k] != 0) atomicAdd(wc + (long)k * b.wc_gw, cnt[k]);
-      return;
-    }
-    unsigned* wgo = b.wg_offsets + ((long)level * gridDim.x + blockIdx.x) * ZB_NBMAX;
     for (int k = threadIdx.x; k < ZB_NBMAX; k += 256)
       if (cnt[k] != 0) wgo[k] = (unsigned)atomicAdd(b.counts + level * ZB_NBMAX + k, cnt[k]);
     return;
@@ -1478,7 +1404,7 @@ __global__ __launch_bounds__(256, NSUB == 8 ? 4 : 3) void zip_bin_write_staged_k
   const uint32_t hs = a.offsets[level + 1] - a.offsets[level];
   const float scale = exp2f(level * a.Sl) * a.H - 1.0f;
   const uint32_t res = (uint32_t)ceilf(scale) + 1;
-  const int K = b.ksplit[level], rep = zip_rep<C>(p, K);
+  const int K = b.ksplit[level], rep = (int)(blockIdx.x % (unsigned)K);
   const unsigned rmask = (1u << b.bshift) - 1u;
   // ---- the interval's multisamples, once
   uint32_t pg[ZS_NMAX][3];
@@ -1593,160 +1519,6 @@ __global__ __launch_bounds__(256, NSUB == 8 ? 4 : 3) void zip_bin_write_staged_k
     base[4 * tid] += c0; base[4 * tid + 1] += c1; base[4 * tid + 2] += c2; base[4 * tid + 3] += c3;
     cnt[4 * tid] = 0; cnt[4 * tid + 1] = 0; cnt[4 * tid + 2] = 0; cnt[4 * tid + 3] = 0;
     __syncthreads();
-  }
-}
-
-// PASS 1 for the single-channel grids as a WRITE-COMBINING partition (round 4).  The direct writer above issues one 8-byte store per
-// record, each to another line: 913 M records per proposal level = 238 G L2 write requests per second, i.e. ~one request per clock and L2
-// channel (128 channels) -- the L2 request rate, not bytes, bounds it (3.8 ms per level for 7.3 GB).  Here a PERSISTENT workgroup keeps
-// one small chunk buffer per bin in LDS across all its 256-interval tiles (bins per level <= wc_nb: 128 row ranges of a 2^21-row hashed
-// level; a dense level's few ranges times K replicas, zip_rep<1>): a record costs one LDS atomic (its slot) and one 8-byte LDS write, and
-// whenever a buffer holds ZW_CH = 16 records or more the owning wave streams whole 128-byte chunks to the bin -- 16 records per L2
-// request instead of one, and no global atomics: the count pass tallied the records per (bin, writer workgroup) (b.wcnt, same tile ->
-// workgroup map: tile % wc_gw), the host's exclusive prefix over (level, bin, workgroup) is the exact range each workgroup owns in each
-// bin (b.wstart), and a workgroup fills its ranges front to back.  Records, values and the fixed-point sums are those of the direct
-// writer; only the order inside a bin differs, which the integer accumulation does not see.  A buffer that overflows between two flushes
-// (a dense level whose samples pile into one z-slab) sends the record straight to the bin (LDS cursor, one 8-byte store): correct, slower.
-#define ZW_CH 16
-#define ZW_CAP 48                                     // ring of three chunks per bin
-template <typename OT>
-__global__ __launch_bounds__(256) void zip_bin_write_wc_kernel(ZipEnc a, ZipBin b, long ntiles) {
-  extern __shared__ uint2 zw_buf[];                   // [wc_nb][ZW_CAP] record rings, then base [wc_nb] (long), head / tail / done [wc_nb]
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int level = blockIdx.y;
-  const uint32_t hs = a.offsets[level + 1] - a.offsets[level];
-  const int K = b.ksplit[level];
-  const int nb = (int)(((hs + (1u << b.bshift) - 1u) >> b.bshift) * (unsigned)K);      // bins of this level (<= wc_nb: checked on the host)
-  long* base = (long*)(zw_buf + (size_t)b.wc_nb * ZW_CAP);
-  int* head = (int*)(base + b.wc_nb);                 // ring: records [head, tail) of the bin's stream are buffered (head % ZW_CH == 0)
-  int* tail = head + b.wc_nb;
-  int* done = tail + b.wc_nb;                         // records of the bin already in global memory (this workgroup's range)
-  const long* ws = b.wstart + ((long)level * b.wc_nb) * b.wc_gw + blockIdx.x;
-  for (int k = tid; k < nb; k += 256) { base[k] = ws[(long)k * b.wc_gw]; head[k] = 0; tail[k] = 0; done[k] = 0; }
-  const float scale = exp2f(level * a.Sl) * a.H - 1.0f;
-  const uint32_t res = (uint32_t)ceilf(scale) + 1;
-  const unsigned rmask = (1u << b.bshift) - 1u;
-  const float gs = (float)a.grid_sizes[level];
-  uint2* __restrict__ rec = (uint2*)b.rec_val;
-  // sub-steps per multisample: a level with few bins takes its 8 corners in two halves so that the arrivals between two flushes stay
-  // near the chunk size (2048 records per step over < 96 bins would overrun the rings' slack)
-  const int nh = nb < 96 ? 2 : 1, cps = 8 / nh;
-  __syncthreads();
-  // Wave w owns the bins == w (mod 4) and moves their complete chunks out; `all`: the last flush also moves the partial chunk.  Lane l
-  // decides for bin w + 4 l (+ 256 per pass); the copies run 4 bins per instruction, 16 lanes (= one 128-byte chunk) per bin.
-  auto flush = [&](bool all) __attribute__((always_inline)) {
-    for (int b0 = wv; b0 < nb; b0 += 256) {
-      const int mybin = b0 + 4 * lane;
-      int h = 0, nrec = 0, pos = 0;
-      if (mybin < nb) {
-        h = head[mybin];
-        const int t = min(tail[mybin], h + ZW_CAP);    // (slots past the ring went straight to the bin)
-        nrec = all ? t - h : ((t - h) & ~(ZW_CH - 1));
-        if (nrec > 0) { pos = done[mybin]; done[mybin] = pos + nrec; }
-        head[mybin] = h + (all ? 0 : nrec);            // (after the last flush nothing is appended any more)
-        tail[mybin] = all ? h : t;
-      }
-      const int nchunk = (nrec + ZW_CH - 1) / ZW_CH;
-#pragma unroll
-      for (int c = 0; c < ZW_CAP / ZW_CH; ++c) {
-        if (!__ballot(nchunk > c)) break;
-#pragma unroll 4
-        for (int g4 = 0; g4 < 16; ++g4) {              // bins b0 + 4 (4 g4 + q), q = lane / 16
-          const int src_lane = 4 * g4 + (lane >> 4);
-          const int n_ = __shfl(nrec, src_lane, 64), h_ = __shfl(h, src_lane, 64), p_ = __shfl(pos, src_lane, 64);
-          const int r = c * ZW_CH + (lane & 15);
-          const bool on = r < n_;
-          if (!__ballot(on)) continue;
-          const int bn = b0 + 4 * src_lane;
-          if (on) rec[base[bn] + p_ + r] = zw_buf[(size_t)bn * ZW_CAP + (unsigned)(h_ + r) % ZW_CAP];
-        }
-      }
-    }
-  };
-  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const long p = tile * 256 + tid;
-    const bool live = p < a.R * a.S;
-    uint32_t pg[ZS_NMAX][3];
-    float fr[ZS_NMAX][3], we[ZS_NMAX];
-    unsigned inb = 0, ends = 0;
-    float g = 0.f;
-    if (live) {
-      const long ray = p / a.S;
-      const int i = (int)(p - ray * a.S);
-      const float t0 = a.tdist[ray * (a.S + 1) + i], t1 = a.tdist[ray * (a.S + 1) + i + 1];
-      float o[3], d[3], bx[3], by[3];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) { o[k] = a.origins[ray * 3 + k]; d[k] = a.directions[ray * 3 + k]; bx[k] = a.base_x[ray * 3 + k]; by[k] = a.base_y[ray * 3 + k]; }
-      const float rad = a.radii[ray];
-      g = (float)((const OT*)a.feat)[p * a.ld + level] / (float)a.n;
-      int prev = -1;
-#pragma unroll
-      for (int j = 0; j < ZS_NMAX; ++j) {
-        if (j >= a.n) break;
-        float x01[3], sd;
-        zip_sample_point(a, ray, i, j, t0, t1, o, d, bx, by, rad, x01, &sd);
-        if (x01[0] < 0.f || x01[0] > 1.f || x01[1] < 0.f || x01[1] > 1.f || x01[2] < 0.f || x01[2] > 1.f) continue;
-        inb |= 1u << j;
-        we[j] = erff(1.f / sqrtf(8.f * sd * sd * gs * gs));
-#pragma unroll
-        for (int k = 0; k < 3; ++k) zip_cell(x01[k], scale, &pg[j][k], &fr[j][k]);
-#pragma unroll
-        for (int q = 0; q < ZS_NMAX; ++q)
-          if (q == prev && (pg[q][0] != pg[j][0] || pg[q][1] != pg[j][1] || pg[q][2] != pg[j][2])) ends |= 1u << q;
-        prev = j;
-      }
-      if (prev >= 0) ends |= 1u << prev;
-    }
-    const int rep = zip_rep<1>(p, K);
-    float r[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) r[q] = 0.f;
-#pragma unroll
-    for (int j = 0; j < ZS_NMAX; ++j) {
-      if (j >= a.n) break;
-      const bool in = (inb >> j) & 1u, end = (ends >> j) & 1u;
-      if (in) {
-#pragma unroll
-        for (int idx = 0; idx < 8; ++idx) {            // same products in the same order as zip_emit_level
-          float w = 1.f;
-          w *= (idx & 1) ? fr[j][0] : 1.f - fr[j][0];
-          w *= (idx & 2) ? fr[j][1] : 1.f - fr[j][1];
-          w *= (idx & 4) ? fr[j][2] : 1.f - fr[j][2];
-          r[idx] += w * we[j];
-        }
-      }
-      if (!__syncthreads_or((int)end)) continue;       // nobody's run of equal cells ends at this multisample (coarse levels: only the last)
-      for (int hh = 0; hh < nh; ++hh) {
-        if (end) {
-#pragma unroll
-          for (int idx = 0; idx < 8; ++idx) {
-            if (idx / cps != hh) continue;
-            const uint32_t pl[3] = {pg[j][0] + (uint32_t)(idx & 1), pg[j][1] + (uint32_t)((idx >> 1) & 1), pg[j][2] + (uint32_t)(idx >> 2)};
-            const uint32_t row = zip_grid_index(hs, res, pl);
-            const int bin = (int)(row >> b.bshift) * K + rep;
-            const uint2 rv = {row & rmask, __float_as_uint(r[idx] * g)};
-            const int slot = atomicAdd(tail + bin, 1);
-            if (slot - head[bin] < ZW_CAP) zw_buf[(size_t)bin * ZW_CAP + (unsigned)slot % ZW_CAP] = rv;
-            else rec[base[bin] + atomicAdd(done + bin, 1)] = rv;          // ring full until the next flush: straight to the bin
-          }
-        }
-        __syncthreads();
-        flush(false);
-        __syncthreads();
-      }
-      if (end) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) r[q] = 0.f;
-      }
-    }
-  }
-  flush(true);
-  __syncthreads();
-  // every reserved range must be filled exactly (the count pass and this pass form the same records): a mismatch is counted, never silent
-  if (b.err != nullptr) {
-    const int* wc = b.wcnt + (long)level * b.wc_nb * b.wc_gw + blockIdx.x;
-    for (int k = tid; k < nb; k += 256)
-      if (done[k] != wc[(long)k * b.wc_gw]) atomicAdd(b.err, 1);
   }
 }
 
@@ -1881,51 +1653,28 @@ extern "C" int snerf_zip_encode_bwd_binned(int pass, const float* tdist, const f
                                            const int* grid_sizes, const void* grad_feat, long ld, float* grad_table, long R, int S, int L, int C,
                                            int n, int m, float Sl, int H, float std_scale, int feat_dtype, const int* ksplit_host,
                                            const int* level_rows_host, int* counts, void* wg_offsets, const long* starts, void* rec_row,
-                                           float* rec_val, long capacity, void* g64, long g64_rows, const int* scale_exp, int* wc_counts,
-                                           const long* wc_starts, int wc_gw, int wc_nb, int* wc_err, const float* pts, void* stream) {
+                                           float* rec_val, long capacity, void* g64, long g64_rows, const int* scale_exp, void* stream) {
   if (R <= 0) return SNERF_OK;
-  if (S <= 0 || L <= 0 || L > 16 || n <= 0 || (C != 1 && C != 4) || ksplit_host == nullptr || level_rows_host == nullptr) return SNERF_ERR_ARG;
-  const bool wc = wc_counts != nullptr;               // passes 0 / 5 with the write-combining writer's bookkeeping (C = 1)
-  if (wc ? (C != 1 || wc_gw < 1 || wc_nb < 1 || wc_nb > ZB_NBMAX || n > ZS_NMAX) : (counts == nullptr && pass != 2)) return SNERF_ERR_ARG;
-  if (pass == 2 && counts == nullptr) return SNERF_ERR_ARG;
-  if (pass == 5 && (!wc || wc_starts == nullptr || rec_val == nullptr || grad_feat == nullptr)) return SNERF_ERR_ARG;
+  if (S <= 0 || L <= 0 || L > 16 || n <= 0 || (C != 1 && C != 4) || ksplit_host == nullptr || level_rows_host == nullptr || counts == nullptr)
+    return SNERF_ERR_ARG;
   // a level's bins = row ranges x replicas must fit the ZB_NBMAX-entry histograms of the kernels (LDS cnt / base, counts [L, ZB_NBMAX],
   // the accumulate grid): a table past 2^22 (C = 4) / 2^24 (C = 1) rows per level has more row ranges than that -- refuse it here
   // instead of corrupting LDS and dropping gradients (the caller falls back to the atomic scatter)
   for (int l = 0; l < L; ++l) {
     const long rowbins = ((long)level_rows_host[l] + (1L << (C == 4 ? 12 : 14)) - 1) >> (C == 4 ? 12 : 14);
-    if (level_rows_host[l] <= 0 || ksplit_host[l] < 1 || rowbins * ksplit_host[l] > ((wc && pass != 2) ? wc_nb : ZB_NBMAX)) return SNERF_ERR_ARG;
-    if (C == 1 && (ksplit_host[l] & (ksplit_host[l] - 1)) != 0) return SNERF_ERR_ARG;      // zip_rep<1>: a power of two
+    if (level_rows_host[l] <= 0 || ksplit_host[l] < 1 || rowbins * ksplit_host[l] > ZB_NBMAX) return SNERF_ERR_ARG;
   }
   ZipEnc a{tdist, origins, directions, radii, base_x, base_y, deg_jitter, nullptr, offsets, grid_sizes, (void*)grad_feat, ld, grad_table, nullptr, R, S, L, n, m, Sl, H, std_scale};
   ZipBin b{};
   b.bshift = C == 4 ? 12 : 14;
-  b.wcnt = wc_counts; b.wstart = wc_starts; b.wc_gw = wc_gw; b.wc_nb = wc_nb; b.err = wc_err;
-  a.pts = (const float4*)pts;
   b.counts = counts; b.wg_offsets = (unsigned*)wg_offsets; b.starts = starts;
   for (int l = 0; l < L; ++l) { b.ksplit[l] = ksplit_host[l]; if (b.ksplit[l] < 1) return SNERF_ERR_ARG; }
   b.rec_row = (unsigned short*)rec_row; b.rec_val = rec_val; b.capacity = capacity; b.g64 = (long long*)g64; b.g64_rows = g64_rows;
   b.scale_exp = scale_exp;
   hipStream_t s = (hipStream_t)stream;
   const dim3 blk(256);
-  if (pass == 5) {
-    // records through per-bin chunk buffers of persistent workgroups (zip_bin_write_wc_kernel); grid x = the writer workgroups the count
-    // pass tallied for (tile t belongs to workgroup t % wc_gw)
-    const long ntiles = (R * S + 255) / 256;
-    const size_t lds = (size_t)wc_nb * (ZW_CAP * sizeof(uint2) + sizeof(long) + 3 * sizeof(int));
-    if (lds > 160 * 1024) return SNERF_ERR_ARG;
-    const dim3 grid((unsigned)wc_gw, L);
-    (void)hipGetLastError();                          // (an error some earlier runtime call of this thread left behind is not this launch's)
-    const void* fn = feat_dtype == SNERF_DT_BF16 ? (const void*)zip_bin_write_wc_kernel<__bf16> : (const void*)zip_bin_write_wc_kernel<float>;
-    if (feat_dtype != SNERF_DT_BF16 && feat_dtype != SNERF_DT_F32) return SNERF_ERR_ARG;
-    // (the kernel also has a few hundred bytes of static LDS: ask for what this launch needs, not for the whole 160 KB)
-    if (lds > 48 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return snerf_check_launch() ? SNERF_ERR_LAUNCH : SNERF_ERR_LAUNCH;
-    if (feat_dtype == SNERF_DT_BF16) hipLaunchKernelGGL((zip_bin_write_wc_kernel<__bf16>), grid, blk, lds, s, a, b, ntiles);
-    else hipLaunchKernelGGL((zip_bin_write_wc_kernel<float>), grid, blk, lds, s, a, b, ntiles);
-    return snerf_check_launch();
-  }
   if (pass == 0 || pass == 1 || pass == 3 || pass == 4) {
-    if (grad_feat == nullptr || (wg_offsets == nullptr && !(wc && pass == 0)) || (pass != 0 && (starts == nullptr || rec_row == nullptr || rec_val == nullptr)))
+    if (grad_feat == nullptr || wg_offsets == nullptr || (pass != 0 && (starts == nullptr || rec_row == nullptr || rec_val == nullptr)))
       return SNERF_ERR_ARG;
     const dim3 grid((unsigned)((R * S + 255) / 256), L);
     // pass 1: records staged in LDS and written run by run (zip_bin_write_staged_kernel); pass 3 (A/B probes, or more than 8

@@ -704,21 +704,8 @@ def zip_encode_fwd(tdist, origins, directions, radii, base_x, base_y, deg_jitter
               _zip_dt(feat), int(levels_per_thread), _stream())
 
 
-def zip_points(tdist, origins, directions, radii, base_x, base_y, deg_jitter, n, m, std_scale):
-    """The n multisamples of every interval, evaluated once: -> pts fp32 [n, R*S, 4] = (position in [0,1]^3, std / 2).  Input of
-    zip_encode_fwd_count / zip_encode_bwd_binned (`pts=`): their one-thread-per-(interval, level) kernels then read 16 bytes per
-    multisample instead of re-evaluating sincos / contraction / cbrt for every level."""
-    for t in (tdist, origins, directions, radii, base_x, base_y, deg_jitter):
-        _f32c(t)
-    R, P = tdist.shape
-    pts = torch.empty(n, R * (P - 1), 4, dtype=torch.float32, device=tdist.device)
-    _lib.call("snerf_zip_points", _p(tdist), _p(origins), _p(directions), _p(radii), _p(base_x), _p(base_y), _p(deg_jitter), R, P - 1, int(n), int(m),
-              float(std_scale), _p(pts), _stream())
-    return pts
-
-
 def zip_encode_fwd_count(tdist, origins, directions, radii, base_x, base_y, deg_jitter, table, offsets, grid_sizes, feat, L, C, n, m, Sl, H, std_scale,
-                         ksplit, level_rows, pts=None):
+                         ksplit, level_rows):
     """zip_encode_fwd (one thread per (interval, level)) that also counts the records of the binned table gradient and reserves the
     workgroups' ranges: pass 0 of zip_encode_bwd_binned in the forward's sweep.  -> (counts, wg_offsets) to hand to zip_encode_bwd_binned
     as `precounted`.  wg_offsets is a buffer of its own per call: it lives until the backward."""
@@ -728,23 +715,14 @@ def zip_encode_fwd_count(tdist, origins, directions, radii, base_x, base_y, deg_
     R, P = tdist.shape
     S = P - 1
     assert table.is_contiguous() and offsets.dtype == torch.int32 and grid_sizes.dtype == torch.int32 and C in (1, 4) and n <= 8 and L <= 16
-    assert pts is None or (pts.dtype == torch.float32 and pts.is_contiguous() and pts.shape == (n, R * S, 4))
     ks = np.ascontiguousarray(np.asarray(ksplit, dtype=np.int32))
     lr = np.ascontiguousarray(np.asarray(level_rows, dtype=np.int32))
     assert ks.shape == (L,) and lr.shape == (L,)
-    wc_nb = zip_wc_bins(ks, lr) if (C == 1 and ZIP_BIN_WC) else 0
-    if wc_nb:
-        # single-channel grid: the counts the write-combining record writer needs, per (level, bin, writer workgroup)
-        wcnt = torch.zeros(L, wc_nb, ZW_GW, dtype=torch.int32, device=tdist.device)
-        _lib.call("snerf_zip_encode_fwd_count", _p(tdist), _p(origins), _p(directions), _p(radii), _p(base_x), _p(base_y), _p(deg_jitter), _p(table),
-                  _p(offsets), _p(grid_sizes), _p(feat), feat.stride(0), R, S, L, C, n, m, float(Sl), int(H), float(std_scale), _zip_dt(table),
-                  _zip_dt(feat), ks.ctypes.data, lr.ctypes.data, None, None, _p(wcnt), ZW_GW, wc_nb, _p(pts), _stream())
-        return "wc", wcnt
     counts = torch.zeros(L, ZB_NBMAX, dtype=torch.int32, device=tdist.device)
     wgo = torch.empty(L * ((R * S + 255) // 256) * ZB_NBMAX, dtype=torch.int32, device=tdist.device)
     _lib.call("snerf_zip_encode_fwd_count", _p(tdist), _p(origins), _p(directions), _p(radii), _p(base_x), _p(base_y), _p(deg_jitter), _p(table),
               _p(offsets), _p(grid_sizes), _p(feat), feat.stride(0), R, S, L, C, n, m, float(Sl), int(H), float(std_scale), _zip_dt(table),
-              _zip_dt(feat), ks.ctypes.data, lr.ctypes.data, _p(counts), _p(wgo), None, 0, 0, _p(pts), _stream())
+              _zip_dt(feat), ks.ctypes.data, lr.ctypes.data, _p(counts), _p(wgo), _stream())
     return counts, wgo
 
 
@@ -807,14 +785,9 @@ def zip_encode_bwd(tdist, origins, directions, radii, base_x, base_y, deg_jitter
 ZB_NBMAX, ZB_TARGET = 1024, 2_000_000
 
 
-ZW_GW, ZW_NBMAX = 768, 256        # write-combining writer (C = 1): persistent workgroups per level (3 per CU), bins per level it can buffer
-
-
 def zip_bin_plan(offsets_host, C, records_per_level):
     """Host-side plan of the binned table gradient: per level the number of replicas K of every row range (levels with few, hot rows
-    are split so that a bin holds ~ZB_TARGET records) and the number of leading table rows the int64 meeting image must cover.
-    C = 1 (write-combining record writer): K is a power of two, and a level with few row ranges gets enough replicas for ~64-128 bins
-    whatever its record count -- its records are then spread over that many chunk buffers of a writer workgroup (csrc/zip.hip, zip_rep)."""
+    are split so that a bin holds ~ZB_TARGET records) and the number of leading table rows the int64 meeting image must cover."""
     br = 4096 if C == 4 else 16384
     ks, g64_rows, level_rows = [], 0, []
     for l in range(len(offsets_host) - 1):
@@ -824,26 +797,11 @@ def zip_bin_plan(offsets_host, C, records_per_level):
             raise ValueError(f"binned table gradient: level {l} has {rows} rows = {rowbins} row ranges of {br}, more than the {ZB_NBMAX} bins per "
                              "level of the kernels; use table_grad_mode='atomic' for tables this large")
         k = max(1, min(-(-int(records_per_level) // (rowbins * ZB_TARGET)), ZB_NBMAX // rowbins))
-        if C == 1:
-            k = 1 << (k - 1).bit_length()                              # next power of two
-            while rowbins * k < 64:                                     # spread a small level over >= 64 chunk buffers
-                k *= 2
-            while k > 1 and rowbins * k > (128 if rowbins <= 128 else ZB_NBMAX):
-                k //= 2
         ks.append(k)
         level_rows.append(rows)
         if k > 1:
             g64_rows = int(offsets_host[l + 1])
     return ks, g64_rows, level_rows
-
-
-def zip_wc_bins(ksplit, level_rows):
-    """bins per level the write-combining writer must buffer (a power of two >= 128), or 0 when a level has more than it can (the
-    direct record writer serves such a table)"""
-    nb = max(((r + 16383) // 16384) * k for k, r in zip(ksplit, level_rows))
-    if nb > ZW_NBMAX:
-        return 0
-    return 128 if nb <= 128 else 256
 
 
 _zb_ws = {}
@@ -861,12 +819,10 @@ def _zb_workspace(dev, key, numel, dtype):
 
 import os as _os
 ZIP_BIN_STAGED = _os.environ.get("SNERF_ZIP_UNSTAGED", "") == ""      # (the environment switch: A/B runs of tools/bench_zip.py)
-ZIP_BIN_WC = _os.environ.get("SNERF_ZIP_NO_WC", "") == ""              # single-channel grids: write-combining record writer (A/B: the direct writer)
-zip_wc_errors = None                                                    # device int32[1]: writer workgroups whose records missed their reserved ranges (must stay 0)
 
 
 def zip_encode_bwd_binned(tdist, origins, directions, radii, base_x, base_y, deg_jitter, offsets, grid_sizes, grad_feat, grad_table, L, C, n, m, Sl, H,
-                          std_scale, ksplit, g64_rows, level_rows, precounted=None, pts=None):
+                          std_scale, ksplit, g64_rows, level_rows, precounted=None):
     """The table gradient of zip_encode_bwd without L2 atomics on the hashed levels and bit-reproducible: records binned by destination,
     accumulated per bin in LDS with fixed-point integer atomics (snerf_zip_encode_bwd_binned: count, scan on the device, write, accumulate).
     The fixed-point grid follows the gradient's magnitude (snerf_zip_bin_scale: 34 bits below max |grad_feat|).  `precounted` = the
@@ -884,55 +840,27 @@ def zip_encode_bwd_binned(tdist, origins, directions, radii, base_x, base_y, deg
     args = (_p(tdist), _p(origins), _p(directions), _p(radii), _p(base_x), _p(base_y), _p(deg_jitter), _p(offsets), _p(grid_sizes), _p(grad_feat),
             grad_feat.stride(0), _p(grad_table), R, S, L, C, n, m, float(Sl), int(H), float(std_scale), _zip_dt(grad_feat), ks.ctypes.data,
             lr.ctypes.data)
-    global zip_wc_errors
-    assert pts is None or (pts.dtype == torch.float32 and pts.is_contiguous() and pts.shape == (n, R * S, 4))
-    none5 = (None, None, 0, 0, None, _p(pts))
-    wc_nb = zip_wc_bins(ks, lr) if (C == 1 and ZIP_BIN_WC and n <= 8) else 0
-    if precounted is not None and isinstance(precounted[0], str):
-        assert wc_nb and precounted[1].shape == (L, wc_nb, ZW_GW), "the forward counted for the write-combining writer"
-    elif precounted is not None:
-        wc_nb = 0                                               # counted for the direct / staged writers
+    if precounted is not None:
+        # the training forward (zip_encode_fwd_count) already counted the records and reserved the workgroups' ranges
+        counts, wgo = precounted
+        assert counts.shape == (L, ZB_NBMAX) and wgo.numel() >= L * ((R * S + 255) // 256) * ZB_NBMAX
+    else:
+        # pass 0 also reserves each workgroup's record range inside the bins it touches (offsets relative to the bin's start)
+        counts = torch.zeros(L, ZB_NBMAX, dtype=torch.int32, device=dev)
+        wgo = _zb_workspace(dev, "wgo", L * ((R * S + 255) // 256) * ZB_NBMAX, torch.int32)
+        _lib.call("snerf_zip_encode_bwd_binned", 0, *args, _p(counts), _p(wgo), None, None, None, 0, None, 0, None, _stream())
+    flat = counts.view(-1).to(torch.int64)
+    starts = (torch.cumsum(flat, 0) - flat).contiguous()
     capacity = R * S * n * 8 * L                               # every (interval, level) emits at most n cells x 8 corners: no host sync
     rec_row = _zb_workspace(dev, "row", capacity, torch.int16)
     rec_val = _zb_workspace(dev, "val", capacity * max(C, 2), torch.float32)       # C = 1: {row, value} pairs in one 8-byte record
-    if wc_nb:
-        # single-channel grid: counts per (level, bin, writer workgroup); their exclusive prefix in that order is the range every writer
-        # workgroup owns inside every bin, so the writer needs neither atomics nor a second count
-        if precounted is not None:
-            wcnt = precounted[1]
-        else:
-            wcnt = torch.zeros(L, wc_nb, ZW_GW, dtype=torch.int32, device=dev)
-            _lib.call("snerf_zip_encode_bwd_binned", 0, *args, None, None, None, None, None, 0, None, 0, None, _p(wcnt), None, ZW_GW, wc_nb, None, _p(pts), _stream())
-        flat = wcnt.view(-1).to(torch.int64)
-        wstart = (torch.cumsum(flat, 0) - flat).view(L, wc_nb, ZW_GW)
-        counts = torch.zeros(L, ZB_NBMAX, dtype=torch.int32, device=dev)
-        counts[:, :wc_nb] = wcnt.sum(-1)
-        starts = torch.zeros(L, ZB_NBMAX, dtype=torch.int64, device=dev)
-        starts[:, :wc_nb] = wstart[:, :, 0]
-        if zip_wc_errors is None or zip_wc_errors.device != dev:
-            zip_wc_errors = torch.zeros(1, dtype=torch.int32, device=dev)
-        _lib.call("snerf_zip_encode_bwd_binned", 5, *args, None, None, None, _p(rec_row), _p(rec_val), capacity, None, 0, None, _p(wcnt), _p(wstart),
-                  ZW_GW, wc_nb, _p(zip_wc_errors), _p(pts), _stream())
-        wgo = None
-    else:
-        if precounted is not None:
-            # the training forward (zip_encode_fwd_count) already counted the records and reserved the workgroups' ranges
-            counts, wgo = precounted
-            assert counts.shape == (L, ZB_NBMAX) and wgo.numel() >= L * ((R * S + 255) // 256) * ZB_NBMAX
-        else:
-            # pass 0 also reserves each workgroup's record range inside the bins it touches (offsets relative to the bin's start)
-            counts = torch.zeros(L, ZB_NBMAX, dtype=torch.int32, device=dev)
-            wgo = _zb_workspace(dev, "wgo", L * ((R * S + 255) // 256) * ZB_NBMAX, torch.int32)
-            _lib.call("snerf_zip_encode_bwd_binned", 0, *args, _p(counts), _p(wgo), None, None, None, 0, None, 0, None, *none5, _stream())
-        flat = counts.view(-1).to(torch.int64)
-        starts = (torch.cumsum(flat, 0) - flat).contiguous()
-        # pass 1: the records staged in LDS and written run by run; ZIP_BIN_STAGED = False (A/B probes, tests): pass 3, every thread
-        # writes its records where they fall (same records, another order inside a (workgroup, bin) run)
-        _lib.call("snerf_zip_encode_bwd_binned", 1 if ZIP_BIN_STAGED else 3, *args, _p(counts), _p(wgo), _p(starts), _p(rec_row), _p(rec_val), capacity,
-                  None, 0, None, *none5, _stream())
+    # pass 1: the records staged in LDS and written run by run; ZIP_BIN_STAGED = False (A/B probes, tests): pass 3, every thread
+    # writes its records where they fall (same records, another order inside a (workgroup, bin) run)
+    _lib.call("snerf_zip_encode_bwd_binned", 1 if ZIP_BIN_STAGED else 3, *args, _p(counts), _p(wgo), _p(starts), _p(rec_row), _p(rec_val), capacity,
+              None, 0, None, _stream())
     g64 = torch.zeros(max(g64_rows, 1) * C, dtype=torch.int64, device=dev) if g64_rows > 0 else None
     _lib.call("snerf_zip_encode_bwd_binned", 2, *args, _p(counts), _p(wgo), _p(starts), _p(rec_row), _p(rec_val), capacity, _p(g64), int(g64_rows),
-              _p(scale), *none5, _stream())
+              _p(scale), _stream())
 
 
 def colsum_wide_f32(x, C, out, deterministic=False):

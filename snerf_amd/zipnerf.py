@@ -140,7 +140,6 @@ class Model(_ArenaModule):
         # of a separate count sweep in the backward; False (or SNERF_ZIP_COUNT_IN_BWD=1, for A/B runs) keeps the round-2 order
         import os
         self.count_in_forward = os.environ.get("SNERF_ZIP_COUNT_IN_BWD", "") == ""
-        self.share_points = os.environ.get("SNERF_ZIP_NO_SHARED_POINTS", "") == ""      # (A/B switch: multisamples evaluated once per interval)
         if self.table_grad_mode == "binned":
             # the binned kernels hold ZB_NBMAX bins per level: a table whose level has more row ranges (2^22 rows at C = 4, 2^24 at
             # C = 1, i.e. grid_log2_hashmap_size >= 23 / 25) does not fit them -- the plan raises, and construction fails HERE rather
@@ -242,15 +241,12 @@ class Model(_ArenaModule):
                 Fb, SB = net.alloc(P)
             # inference renders frames (coherent rays: evaluate the multisamples once per interval for all levels); training draws
             # scattered pixels (one thread per level keeps the most gathers in flight)
-            precount = pts = None
+            precount = None
             if keep and self.table_grad_mode == "binned" and self.count_in_forward and sample_n <= 8 and e.C in (1, 4):
                 # training with the binned table gradient: the featurisation sweep is also that gradient's count pass
                 ks, _, lrows = ops.zip_bin_plan(e.offsets, e.C, P * sample_n * 8)
-                # the multisamples once per interval (position + std): the featurisation and the table gradient's passes run one thread per
-                # (interval, level) and would otherwise re-evaluate them per level
-                pts = ops.zip_points(tdist, o, d, radii, bx, by, degj, sample_n, sample_m, self.std_scale) if self.share_points else None
                 precount = ops.zip_encode_fwd_count(tdist, o, d, radii, bx, by, degj, self._table(lvl), self.dev_offsets[lvl], self.dev_sizes[lvl], Fb,
-                                                    e.L, e.C, sample_n, sample_m, e.Sl, e.H, self.std_scale, ks, lrows, pts=pts)
+                                                    e.L, e.C, sample_n, sample_m, e.Sl, e.H, self.std_scale, ks, lrows)
             else:
                 ops.zip_encode_fwd(tdist, o, d, radii, bx, by, degj, self._table(lvl), self.dev_offsets[lvl], self.dev_sizes[lvl], Fb, e.L, e.C,
                                    sample_n, sample_m, e.Sl, e.H, self.std_scale,
@@ -274,7 +270,7 @@ class Model(_ArenaModule):
                 logits = net.last_x[:, 1:1 + self.class_num]                       # x[..., 1:1+C] of the density network's output
                 sem = ops.semantic_composite_fwd(weights, logits, self.class_num, True)
             levels.append(dict(sdist=sdist, tdist=tdist, weights=weights, rgb=rgb, depth=depth, acc=acc, raw_rgb=raw_rgb, raw_d=raw_d, saved=saved,
-                               degj=degj, ns=ns, semantic=sem, logits=logits, cam=None if is_prop else cam, precount=precount, pts=pts))
+                               degj=degj, ns=ns, semantic=sem, logits=logits, cam=None if is_prop else cam, precount=precount))
         ctx = None
         if keep:   # detached aliases: the originals become outputs of the autograd Function (no graph / reference cycle through ctx)
             det = [{k: (v.detach() if torch.is_tensor(v) else v) for k, v in L.items()} for L in levels]
@@ -339,8 +335,8 @@ class Model(_ArenaModule):
                 ks, g64_rows, lrows = ops.zip_bin_plan(e.offsets, e.C, P * ctx["n"] * 8)
                 ops.zip_encode_bwd_binned(L["tdist"], ctx["o"], ctx["d"], ctx["radii"], ctx["bx"], ctx["by"], L["degj"], self.dev_offsets[lvl],
                                           self.dev_sizes[lvl], dF, gtab, e.L, e.C, ctx["n"], ctx["m"], e.Sl, e.H, self.std_scale, ks, g64_rows, lrows,
-                                          precounted=L.get("precount"), pts=L.get("pts"))
-                L["precount"] = L["pts"] = None                                        # (large buffers: release them now)
+                                          precounted=L.get("precount"))
+                L["precount"] = None                                                   # (its workgroup-offset buffer is large: release it now)
                 if on_done is not None:
                     on_done(self.names[lvl])
                 continue

@@ -298,15 +298,9 @@ def zip_encode_fwd(tdist, origins, directions, radii, base_x, base_y, deg_jitter
     feat[:, :L * C] = f.reshape(-1, L * C).to(feat.dtype)
 
 
-def zip_points(tdist, origins, directions, radii, base_x, base_y, deg_jitter, n, m, std_scale):
-    x01, s = _zip_points(tdist, origins, directions, radii, base_x, base_y, deg_jitter, n, m, std_scale)          # [R,S,n,3], [R,S,n]
-    return torch.cat([x01, s[..., None]], -1).reshape(-1, n, 4).permute(1, 0, 2).contiguous()
-
-
 def zip_encode_fwd_count(tdist, origins, directions, radii, base_x, base_y, deg_jitter, table, offsets, grid_sizes, feat, L, C, n, m, Sl, H, std_scale,
-                         ksplit, level_rows, pts=None):
+                         ksplit, level_rows):
     assert len(ksplit) == L and all(k >= 1 for k in ksplit) and len(level_rows) == L and n <= 8 and C in (1, 4)
-    assert pts is None or pts.shape == (n, tdist.shape[0] * (tdist.shape[1] - 1), 4)
     zip_encode_fwd(tdist, origins, directions, radii, base_x, base_y, deg_jitter, table, offsets, grid_sizes, feat, L, C, n, m, Sl, H, std_scale, 1)
     return ("precounted", tuple(ksplit))                # (what the emulated backward checks it was handed back)
 
@@ -351,7 +345,7 @@ def zip_encode_bwd(tdist, origins, directions, radii, base_x, base_y, deg_jitter
 
 
 def zip_encode_bwd_binned(tdist, origins, directions, radii, base_x, base_y, deg_jitter, offsets, grid_sizes, grad_feat, grad_table, L, C, n, m, Sl, H,
-                          std_scale, ksplit, g64_rows, level_rows, precounted=None, pts=None):
+                          std_scale, ksplit, g64_rows, level_rows, precounted=None):
     assert len(ksplit) == L and all(k >= 1 for k in ksplit) and len(level_rows) == L
     assert precounted is None or precounted == ("precounted", tuple(ksplit)), "the forward's counts belong to another bin plan"
     zip_encode_bwd(tdist, origins, directions, radii, base_x, base_y, deg_jitter, offsets, grid_sizes, grad_feat, grad_table, L, C, n, m, Sl, H, std_scale)
@@ -786,7 +780,7 @@ def adam_step_dev(p, g, m, v, lr, b1, b2, eps, step_dev, grad_scale=1.0, zero_gr
     adam_step(p, g, m, v, lr, b1, b2, eps, 0, grad_scale, zero_grad, step_dev=step_dev, **kw)
 
 
-_NAMES = ["zip_points", "zip_prop_mlp_fwd", "zip_prop_mlp_bwd", "colsum_wide_f32", "zip_glo_modulate", "zip_glo_modulate_bwd", "fchain_bwd", "app_embed", "app_embed_bwd", "split_cast", "fcolour_fwd", "fcolour_bwd", "gather_pack", "adam_step_dev", "grad_clip_coef", "fmlp_classic_fwd", "fmlp_classic_pts_fwd", "fmlp_proposal_fwd", "fmlp_classic_train_fwd", "fmlp_proposal_train_fwd", "classic_get_rays", "classic_ndc_rays", "classic_ray_batch", "zip_encode_prop_fwd", "mip_encode_bwd", "mip_viewenc_bwd", "hash_decay", "zip_percentiles", "zip_pixels_to_rays", "zip_loss_tail", "semantic_composite_fwd", "semantic_composite_bwd", "zip_resample", "zip_encode_fwd", "zip_encode_fwd_count", "zip_encode_bwd", "zip_encode_bwd_binned", "zip_encode_ray_bwd", "zip_composite_fwd", "zip_composite_bwd",
+_NAMES = ["zip_prop_mlp_fwd", "zip_prop_mlp_bwd", "colsum_wide_f32", "zip_glo_modulate", "zip_glo_modulate_bwd", "fchain_bwd", "app_embed", "app_embed_bwd", "split_cast", "fcolour_fwd", "fcolour_bwd", "gather_pack", "adam_step_dev", "grad_clip_coef", "fmlp_classic_fwd", "fmlp_classic_pts_fwd", "fmlp_proposal_fwd", "fmlp_classic_train_fwd", "fmlp_proposal_train_fwd", "classic_get_rays", "classic_ndc_rays", "classic_ray_batch", "zip_encode_prop_fwd", "mip_encode_bwd", "mip_viewenc_bwd", "hash_decay", "zip_percentiles", "zip_pixels_to_rays", "zip_loss_tail", "semantic_composite_fwd", "semantic_composite_bwd", "zip_resample", "zip_encode_fwd", "zip_encode_fwd_count", "zip_encode_bwd", "zip_encode_bwd_binned", "zip_encode_ray_bwd", "zip_composite_fwd", "zip_composite_bwd",
           "linear_fwd", "linear_wgrad", "classic_embed", "mip_encode", "mip_viewenc", "classic_sample_pdf", "classic_points",
           "classic_merge_sort", "mip_resample", "stratified", "mip_composite_fwd", "mip_composite_bwd", "classic_composite_fwd",
           "classic_composite_bwd", "adam_step", "colsum_f32", "cast_pad", "pinhole_rays", "mip_loss_tail"]

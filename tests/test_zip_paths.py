@@ -647,81 +647,38 @@ def test_zip_table_gradient_binned_is_exact_and_bit_reproducible(lvl, gscale, mo
         ops.zip_encode_bwd_binned(*common, gt, *tail, ks, g64_rows, lrows)
         outs.append(gt)
     assert torch.equal(outs[0], outs[1]), "binned table gradient must be bit-reproducible"
-    from snerf_amd import _lib
-    import numpy as np
-    ksa, lra = np.asarray(ks, dtype=np.int32), np.asarray(lrows, dtype=np.int32)
-    p_ = lambda t: t.data_ptr()
-    none5 = (None, None, 0, 0, None, None)                                                # (no write-combining bookkeeping, no shared points)
+    # the LDS-staged record writer (default) and the direct one produce the same records in another order: identical sums
+    monkeypatch.setattr(ops, "ZIP_BIN_STAGED", False)
+    gd = torch.zeros(e.rows, e.C, device="cuda")
+    ops.zip_encode_bwd_binned(*common, gd, *tail, ks, g64_rows, lrows)
+    monkeypatch.setattr(ops, "ZIP_BIN_STAGED", True)
+    assert torch.equal(outs[0], gd), "staged and direct record writers must give bit-identical gradients"
+    # round 3: the training forward counts the records itself (snerf_zip_encode_fwd_count = featurisation + pass 0): same features as
+    # the plain forward, same per-bin counts as the backward's own count pass, same gradient bit for bit
     tab = m._table(lvl)
     f0 = torch.zeros(R * S, Fw, device="cuda", dtype=dF.dtype)
     f1 = torch.zeros_like(f0)
     enc_args = (tdist, o, d, radii, bx, by, degj, tab, m.dev_offsets[lvl], m.dev_sizes[lvl])
     ops.zip_encode_fwd(*enc_args, f0, *tail, levels_per_thread=1)
-    bwd0 = ("snerf_zip_encode_bwd_binned", 0, p_(tdist), p_(o), p_(d), p_(radii), p_(bx), p_(by), p_(degj), p_(m.dev_offsets[lvl]), p_(m.dev_sizes[lvl]),
-            p_(dF), dF.stride(0), None, R, S, e.L, e.C, n, 3, float(e.Sl), int(e.H), float(m.std_scale), ops._zip_dt(dF), ksa.ctypes.data, lra.ctypes.data)
-    if e.C == 1:
-        # single-channel grid (round 4): the write-combining record writer (default) against the direct one -- same records in another
-        # order, identical fixed-point sums -- and its bookkeeping: every writer workgroup filled its reserved ranges exactly
-        assert all(k & (k - 1) == 0 for k in ks) and ops.zip_wc_bins(ks, lrows) in (128, 256)
-        assert int(ops.zip_wc_errors.item()) == 0, "a write-combining writer workgroup missed its reserved record ranges"
-        monkeypatch.setattr(ops, "ZIP_BIN_WC", False)
-        for staged in (False, True):
-            monkeypatch.setattr(ops, "ZIP_BIN_STAGED", staged)
-            gd = torch.zeros(e.rows, e.C, device="cuda")
-            ops.zip_encode_bwd_binned(*common, gd, *tail, ks, g64_rows, lrows)
-            assert torch.equal(outs[0], gd), "write-combining and direct record writers must give bit-identical gradients"
-        monkeypatch.setattr(ops, "ZIP_BIN_WC", True)
-        # the training forward counts the records itself, per (level, bin, writer workgroup): same features as the plain forward, same
-        # counts as the backward's own count pass, same gradient bit for bit
-        tag, wcnt = ops.zip_encode_fwd_count(*enc_args, f1, *tail, ks, lrows)
-        assert tag == "wc" and torch.equal(f0, f1), "the counting forward must produce the plain forward's features"
-        w0 = torch.zeros_like(wcnt)
-        _lib.call(*bwd0, None, None, None, None, None, 0, None, 0, None, p_(w0), None, ops.ZW_GW, wcnt.shape[1], None, None, torch.cuda.current_stream().cuda_stream)
-        assert torch.equal(wcnt, w0) and int(wcnt.sum()) > 0, "forward-side record counts differ from the backward's count pass"
-        f2 = torch.zeros(R * S, Fw, device="cuda", dtype=dF.dtype)                      # half table: the kernel's paired 4-byte gather branch
-        _, w16 = ops.zip_encode_fwd_count(tdist, o, d, radii, bx, by, degj, tab.half().contiguous(), m.dev_offsets[lvl], m.dev_sizes[lvl], f2, *tail, ks, lrows)
-        assert torch.equal(w16, w0)
-        gp = torch.zeros(e.rows, e.C, device="cuda")
-        ops.zip_encode_bwd_binned(*common, gp, *tail, ks, g64_rows, lrows, precounted=(tag, wcnt))
-        assert torch.equal(outs[0], gp), "gradient with the forward's counts must equal the gradient with the backward's own count pass"
-        assert int(ops.zip_wc_errors.item()) == 0
-    else:
-        # the LDS-staged record writer (default) and the direct one produce the same records in another order: identical sums
-        monkeypatch.setattr(ops, "ZIP_BIN_STAGED", False)
-        gd = torch.zeros(e.rows, e.C, device="cuda")
-        ops.zip_encode_bwd_binned(*common, gd, *tail, ks, g64_rows, lrows)
-        monkeypatch.setattr(ops, "ZIP_BIN_STAGED", True)
-        assert torch.equal(outs[0], gd), "staged and direct record writers must give bit-identical gradients"
-        # round 3: the training forward counts the records itself (snerf_zip_encode_fwd_count = featurisation + pass 0): same features as
-        # the plain forward, same per-bin counts as the backward's own count pass, same gradient bit for bit
-        counts, wgo = ops.zip_encode_fwd_count(*enc_args, f1, *tail, ks, lrows)
-        assert torch.equal(f0, f1), "the counting forward must produce the plain forward's features"
-        c0 = torch.zeros_like(counts)
-        w0 = torch.empty_like(wgo)
-        _lib.call(*bwd0, p_(c0), p_(w0), None, None, None, 0, None, 0, None, *none5, torch.cuda.current_stream().cuda_stream)
-        assert torch.equal(counts, c0), "forward-side record counts differ from the backward's count pass"
-        assert int(counts.sum()) > 0
-        f2 = torch.zeros(R * S, Fw, device="cuda", dtype=dF.dtype)                          # fp32 table: the kernel's generic gather branch
-        c32, _ = ops.zip_encode_fwd_count(tdist, o, d, radii, bx, by, degj, tab.float().contiguous(), m.dev_offsets[lvl], m.dev_sizes[lvl], f2, *tail, ks, lrows)
-        assert torch.equal(c32, c0)
-        gp = torch.zeros(e.rows, e.C, device="cuda")
-        ops.zip_encode_bwd_binned(*common, gp, *tail, ks, g64_rows, lrows, precounted=(counts, wgo))
-        assert torch.equal(outs[0], gp), "gradient with the forward's counts must equal the gradient with the backward's own count pass"
-    # round 4: the multisamples evaluated once per interval (snerf_zip_points) and read by the per-level kernels: same positions bit for
-    # bit, hence the same features, counts and gradient
-    pts = ops.zip_points(tdist, o, d, radii, bx, by, degj, n, 3, m.std_scale)
-    assert pts.shape == (n, R * S, 4)
-    f3 = torch.zeros_like(f0)
-    pre = ops.zip_encode_fwd_count(*enc_args, f3, *tail, ks, lrows, pts=pts)
-    assert torch.equal(f0, f3), "features from the shared multisamples must equal the in-kernel evaluation"
-    g3 = torch.zeros(e.rows, e.C, device="cuda")
-    ops.zip_encode_bwd_binned(*common, g3, *tail, ks, g64_rows, lrows, precounted=pre, pts=pts)
-    assert torch.equal(outs[0], g3), "gradient from the shared multisamples must equal the in-kernel evaluation"
-    g4 = torch.zeros(e.rows, e.C, device="cuda")
-    ops.zip_encode_bwd_binned(*common, g4, *tail, ks, g64_rows, lrows, pts=pts)            # (the backward's own count pass reads them too)
-    assert torch.equal(outs[0], g4)
-    if e.C == 1:
-        assert int(ops.zip_wc_errors.item()) == 0
+    counts, wgo = ops.zip_encode_fwd_count(*enc_args, f1, *tail, ks, lrows)
+    assert torch.equal(f0, f1), "the counting forward must produce the plain forward's features"
+    from snerf_amd import _lib
+    import numpy as np
+    c0 = torch.zeros_like(counts)
+    w0 = torch.empty_like(wgo)
+    ksa, lra = np.asarray(ks, dtype=np.int32), np.asarray(lrows, dtype=np.int32)
+    p_ = lambda t: t.data_ptr()
+    _lib.call("snerf_zip_encode_bwd_binned", 0, p_(tdist), p_(o), p_(d), p_(radii), p_(bx), p_(by), p_(degj), p_(m.dev_offsets[lvl]), p_(m.dev_sizes[lvl]),
+              p_(dF), dF.stride(0), None, R, S, e.L, e.C, n, 3, float(e.Sl), int(e.H), float(m.std_scale), ops._zip_dt(dF), ksa.ctypes.data, lra.ctypes.data,
+              p_(c0), p_(w0), None, None, None, 0, None, 0, None, torch.cuda.current_stream().cuda_stream)
+    assert torch.equal(counts, c0), "forward-side record counts differ from the backward's count pass"
+    assert int(counts.sum()) > 0
+    f2 = torch.zeros(R * S, Fw, device="cuda", dtype=dF.dtype)                          # fp32 table: the kernel's generic gather branch
+    c32, _ = ops.zip_encode_fwd_count(tdist, o, d, radii, bx, by, degj, tab.float().contiguous(), m.dev_offsets[lvl], m.dev_sizes[lvl], f2, *tail, ks, lrows)
+    assert torch.equal(c32, c0)
+    gp = torch.zeros(e.rows, e.C, device="cuda")
+    ops.zip_encode_bwd_binned(*common, gp, *tail, ks, g64_rows, lrows, precounted=(counts, wgo))
+    assert torch.equal(outs[0], gp), "gradient with the forward's counts must equal the gradient with the backward's own count pass"
     rel = float((outs[0] - ref).norm() / ref.norm())
     print(f"MEASURED binned vs atomic table gradient (grid {lvl}): rel L2 {rel:.3e}, K per level {ks}")
     assert float(ref.norm()) > 0 and rel < 2e-6, rel
@@ -743,7 +700,7 @@ def test_binned_table_gradient_refuses_tables_with_more_row_ranges_than_bins():
     big = np.array([4913, 1 << 23], dtype=np.int32)
     with pytest.raises(_lib.SnerfHipError, match="bad argument"):
         _lib.call("snerf_zip_encode_bwd_binned", 0, None, None, None, None, None, None, None, None, None, None, 8, None, 16, 4, 2, 4, 7, 3, 0.5, 16, 0.35,
-                  1, k2.ctypes.data, big.ctypes.data, 1, 1, None, None, None, 0, None, 0, None, None, None, 0, 0, None, None, None)
+                  1, k2.ctypes.data, big.ctypes.data, 1, 1, None, None, None, 0, None, 0, None, None)
 
 
 @pytest.mark.gpu
