@@ -427,6 +427,7 @@ def main():
     ap.add_argument("--no-eager", action="store_true", help="skip the PyTorch-ROCm eager baseline (3 steps each of fp32 and bf16 autocast on this GPU)")
     ap.add_argument("--no-f32", action="store_true", help="skip the fp32-parity-mode leg (3 train steps with exact-fp32 MFMA)")
     ap.add_argument("--eager", action="store_true", help="(kept for compatibility: the eager baseline is on by default)")
+    ap.add_argument("--no-ert-scene", action="store_true", help="skip the early-ray-termination leg (200 fit steps on an analytic scene + two frames)")
     ap.add_argument("--no-paths", action="store_true", help="skip the path-C (zipnerf, 65 536 rays) and path-B (classic render_rays, 32 768 rays) legs")
     ap.add_argument("--no-dropin", action="store_true", help="skip the drop-in-autograd and pose-refinement legs (5 steps each)")
     ap.add_argument("--cpu-rays", type=int, default=512, help="rays of the bounded host-CPU baseline sample (about 15 s on the GPU box)")
@@ -612,6 +613,19 @@ def main():
         t0 = time.perf_counter()
         out["path_b"] = path_b_leg(device)
         out["path_b"]["leg_wall_s"] = round(time.perf_counter() - t0, 1)
+
+    # ---- early ray termination on a scene with real opacity (north_star: "early ray termination and sample compaction"):
+    # a fresh model fitted for 200 steps to an analytic street scene (tools/ert_scene.py), its 1600 x 900 frame rendered plain and with
+    # the front-to-back termination inside north_star's tolerance (eps_t = 1e-4: an exact bound on acc / rgb).  A labelled extra: the
+    # headline frame above stays un-skipped.
+    if rank == 0 and world == 1 and not args.no_ert_scene and not args.no_frame and args.compute == "bf16":
+        sys.path.insert(0, os.path.join(REPO, "tools"))
+        import ert_scene
+        torch.cuda.empty_cache()
+        t0 = time.perf_counter()
+        out["ert_scene"] = ert_scene.fit_and_render(build_model("bf16", device, seed=1), steps=200, eps=(1e-4, 0.0), group=16)
+        out["ert_scene"]["leg_wall_s"] = round(time.perf_counter() - t0, 1)
+        torch.cuda.empty_cache()
 
     # ---- the two routes a user of the reference takes besides MipTrainer.step: the unmodified train.py loop (autograd + torch losses +
     # torch.optim.Adam) and the shipped config's pose_refine = True (configs/nuScenes_depth_6cams:31: the step also back-propagates to

@@ -289,6 +289,16 @@ int snerf_semantic_composite_bwd(const float* weights, const void* logits, long 
  * snerf_mip_composite_fwd takes `row_index` (NULL = dense rows) to run the fine level on the compacted rows. */
 int snerf_ert_compact(const float* s0, const float* w0, const float* s1, long N, int S0, int S1, float eps_t, float eps_w,
                       void* masks, int* counts, int* row_index, int* sample_id, long* total, void* stream);
+/* Front-to-back early ray termination on the fine network's OWN densities (inference; exact bound): the fine level is evaluated in groups
+ * of consecutive samples.  One call = after group [g0, g0 + G) was evaluated (prev_raw_d: its raw densities, row r of it = row_index -
+ * prev_base; G = 0 / NULL for the first call), add its optical depth sum softplus(raw + density_bias) (t1 - t0) |d| to tau [N] (in/out,
+ * zeroed by the caller), flag the rays with exp(-tau) > eps_t (flags [N]), and assign the next group [next_g0, next_g0 + next_G):
+ * row_index [N, S1] (row_base + running row, or -1 for the rays that left) and sample_id [rows]; counts [N] scratch; total[0] = rows.
+ * The samples never assigned keep the -1 the caller initialised row_index with; their weights sum to at most eps_t per ray. */
+int snerf_ert_f2b_step(const float* prev_raw_d, long ld_den, long prev_base, const float* s1, const float* dirs, const float* near,
+                       const float* far, long N, int S1, int g0, int G, int next_g0, int next_G, int transform_idx, float density_bias,
+                       float eps_t, float* tau, int* flags, int* counts, int* row_index, int* sample_id, long row_base, long* total,
+                       void* stream);
 
 /* ---- the callers either side of the path --------------------------------------------------------
  * Ray generation: s-nerf/utils/sample_utils.py:286-345 get_rays_single_img (training = 0: whole frame / any pixels, half-pixel

@@ -128,3 +128,87 @@ extern "C" int snerf_ert_compact(const float* s0, const float* w0, const float* 
   hipLaunchKernelGGL(ert_assign_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
   return snerf_check_launch();
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Front-to-back early ray termination on the FINE network's own densities (round 4).  The selection above trusts the proposal
+// histogram, and on a fitted scene it finds little to skip: the fine samples are importance-sampled FROM that histogram, so almost
+// all of them sit where it predicts weight (profiles/r4_i_ert_scene.txt: 94-95 % kept at eps = 1e-4).  What a converged scene does
+// offer is opacity: once a ray's transmittance has fallen below eps_t, everything behind contributes at most eps_t to acc and rgb.
+// The fine level is therefore evaluated in groups of G consecutive samples, front to back; after a group, one wave per ray adds the
+// group's optical depth  sum softplus(raw + bias) (t1 - t0) |d|  (the compositing kernel's terms) to the ray's running tau, and rays
+// with exp(-tau) <= eps_t leave: ballot-free here (one flag per ray), compaction by the same scan + popcount-free assign as above,
+// since a surviving ray contributes a whole group of rows.  The bound is exact: the skipped samples' weights sum to <= exp(-tau).
+//   step(prev group evaluated, next group to assign): update tau from the previous group's raw densities, flag the survivors,
+//   exclusive scan of their row counts, write row_index / sample_id of the next group.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float ert_transform_s(float s, float near, float far, int idx) {       // composite.hip transform_s
+  if (idx == 0) return near * expf(s * logf(far / near));
+  if (idx == 1) return 1.f / ((1.f - s) / near + s / far);
+  return near * (1.f - s) + far * s;
+}
+struct ErtF2B {
+  const float* raw_d; long ld_den; long prev_base;       // raw densities of the previous group's rows (row_index - prev_base), or null
+  const float* s1; const float* dirs; const float* near; const float* far;
+  long N; int S1, g0, G, next_g0, next_G, tidx; float density_bias, eps_t;
+  float* tau; int* flags; int* counts; int* row_index; int* sample_id; long row_base;
+};
+__global__ __launch_bounds__(256) void ert_f2b_update_kernel(ErtF2B a) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long ray = (long)blockIdx.x * 4 + wave;
+  if (ray >= a.N) return;
+  float tau = a.tau[ray];
+  if (a.raw_d != nullptr && a.G > 0) {
+    const float near = a.near[ray], far = a.far[ray];
+    const float dx = a.dirs[ray * 3], dy = a.dirs[ray * 3 + 1], dz = a.dirs[ray * 3 + 2];
+    const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float* sv = a.s1 + ray * (a.S1 + 1);
+    float part = 0.f;
+    for (int k = lane; k < a.G; k += 64) {
+      const int i = a.g0 + k;
+      const int row = a.row_index[ray * a.S1 + i];
+      if (row >= 0) {
+        const float t0 = ert_transform_s(sv[i], near, far, a.tidx), t1 = ert_transform_s(sv[i + 1], near, far, a.tidx);
+        const float x = a.raw_d[(row - a.prev_base) * a.ld_den] + a.density_bias;
+        part += (x > 20.f ? x : log1pf(expf(x))) * ((t1 - t0) * dnorm);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+    tau += part;
+    if (lane == 0) a.tau[ray] = tau;
+  }
+  if (lane == 0) {
+    const int alive = expf(-tau) > a.eps_t ? 1 : 0;
+    a.flags[ray] = alive;
+    a.counts[ray] = alive ? a.next_G : 0;
+  }
+}
+__global__ __launch_bounds__(256) void ert_f2b_assign_kernel(ErtF2B a) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long ray = (long)blockIdx.x * 4 + wave;
+  if (ray >= a.N) return;
+  const int alive = a.flags[ray], off = a.counts[ray];     // (exclusive offset after the scan)
+  for (int k = lane; k < a.next_G; k += 64) {
+    const int i = a.next_g0 + k;
+    a.row_index[ray * a.S1 + i] = alive ? (int)(a.row_base + off + k) : -1;
+    if (alive) a.sample_id[off + k] = (int)(ray * a.S1 + i);
+  }
+}
+
+extern "C" int snerf_ert_f2b_step(const float* prev_raw_d, long ld_den, long prev_base, const float* s1, const float* dirs, const float* near,
+                                  const float* far, long N, int S1, int g0, int G, int next_g0, int next_G, int transform_idx, float density_bias,
+                                  float eps_t, float* tau, int* flags, int* counts, int* row_index, int* sample_id, long row_base, long* total,
+                                  void* stream) {
+  if (N <= 0) return SNERF_OK;
+  if (S1 < 1 || G < 0 || next_G < 1 || g0 < 0 || g0 + G > S1 || next_g0 < 0 || next_g0 + next_G > S1 || N * (long)S1 >= (1L << 31)) return SNERF_ERR_ARG;
+  if (s1 == nullptr || dirs == nullptr || near == nullptr || far == nullptr || tau == nullptr || flags == nullptr || counts == nullptr ||
+      row_index == nullptr || sample_id == nullptr || total == nullptr || (G > 0 && prev_raw_d == nullptr))
+    return SNERF_ERR_ARG;
+  ErtF2B a{prev_raw_d, ld_den, prev_base, s1, dirs, near, far, N, S1, g0, G, next_g0, next_G, transform_idx, density_bias, eps_t,
+           tau, flags, counts, row_index, sample_id, row_base};
+  const dim3 grid((unsigned)((N + 3) / 4));
+  hipLaunchKernelGGL(ert_f2b_update_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(ert_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, counts, N, total);
+  hipLaunchKernelGGL(ert_f2b_assign_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+  return snerf_check_launch();
+}

@@ -131,28 +131,68 @@ class MipNerfModel(_ArenaModule):
                                                    self.rgb_padding, self.density_bias)
         # ---- level 1: resample (no gradient: stop_level_grad), encode, NeRF MLP, composite
         s1, _ = ops.mip_resample(s0, w0, u, self.resample_padding)
-        H = self.nerf.H
         ert = getattr(self, "_ert", None)
         row_index = sample_id = None
-        if ert is not None and not keep:
-            # wave ballot + prefix sums over the proposal histogram pick the fine samples worth evaluating (csrc/ert.hip)
-            row_index, sample_id = ops.ert_compact(s0, w0, s1, ert[0], ert[1])
-            self.last_ert_rows = (int(sample_id.shape[0]), n * S1)
-        rows = n * S1 if sample_id is None else max(int(sample_id.shape[0]), 1)
-        SKIP, CB = self.nerf.alloc_inputs(rows)
+        app = f(rays.app).reshape(-1) if self.encode_appearance else None
+        if ert is not None and not keep and ert[2] > 0:
+            # front-to-back termination on the fine network's own densities (csrc/ert.hip, snerf_ert_f2b_step): groups of ert[2]
+            # consecutive samples; after every group the rays whose transmittance fell below eps_t leave
+            G = int(ert[2])
+            state = ops.ert_f2b_state(n, S1, G, dev)
+            row_index = state[3]
+            parts, prev_d, prev_base, base, g0, Gp, evaluated = [], None, 0, 0, 0, 0, 0
+            for n0 in range(0, S1, G):
+                Gn = min(G, S1 - n0)
+                ids = ops.ert_f2b_step(prev_d, prev_base, s1, d, near, far, g0, Gp, n0, Gn, self.transform_idx, self.density_bias, ert[0], state, base)
+                if ids.shape[0] == 0:
+                    break
+                rr, rd, rs = self._eval_fine(ids.shape[0], ids, s1, o, d, vd, radii, near, far, cone, app, warp, S1, False)[:3]
+                parts.append((rr, rd, rs))
+                prev_d, prev_base, g0, Gp = rd, base, n0, Gn
+                base += ids.shape[0]
+                evaluated += ids.shape[0]
+            self.last_ert_rows = (evaluated, n * S1)
+            raw_rgb = torch.cat([p_[0] for p_ in parts], 0)
+            raw_d1 = torch.cat([p_[1] for p_ in parts], 0)
+            raw_sem_rows = torch.cat([p_[2] for p_ in parts], 0) if self.semantic else None
+            saved1 = None
+        else:
+            if ert is not None and not keep:
+                # wave ballot + prefix sums over the proposal histogram pick the fine samples worth evaluating (csrc/ert.hip)
+                row_index, sample_id = ops.ert_compact(s0, w0, s1, ert[0], ert[1])
+                self.last_ert_rows = (int(sample_id.shape[0]), n * S1)
+            rows = n * S1 if sample_id is None else max(int(sample_id.shape[0]), 1)
+            raw_rgb, raw_d1, raw_sem_rows, saved1 = self._eval_fine(rows, sample_id, s1, o, d, vd, radii, near, far, cone, app, warp, S1, keep)
+        rgb1, dist1, acc1, w1 = ops.mip_composite_fwd(raw_rgb, raw_d1, noise1, s1, d, near, far, self.transform_idx, white_bg,
+                                                      self.rgb_padding, self.density_bias, row_index=row_index)
+        sem1 = raw_sem = None
+        if self.semantic:
+            raw_sem = raw_sem_rows                                       # [rows, C] fp32: semantic = sum_i w_i raw_semantic_i (mip.py:175-176)
+            sem1 = ops.semantic_composite_fwd(w1, raw_sem, self.sem_classes, False, row_index=row_index)   # compacted rows under ert
+        ctx = None
+        if keep:
+            # detached aliases of the output tensors: the originals become outputs of the autograd Function
+            ctx = dict(o=o, vd=vd, radii=radii, cone=cone, d=d, near=near, far=far, s0=s0.detach(), s1=s1.detach(), raw_d0=raw_d0, acts0=acts0, w0=w0.detach(), dist0=dist0.detach(),
+                       raw_rgb=raw_rgb, raw_d1=raw_d1, saved1=saved1, w1=w1.detach(), dist1=dist1.detach(), noise0=noise0, noise1=noise1,
+                       white=white_bg, raw_sem=raw_sem, app=app)
+        return (dist0, acc0, s0, w0, rgb1, dist1, acc1, s1, w1) + ((sem1,) if self.semantic else ()), ctx
+
+    def _eval_fine(self, rows, sample_id, s1, o, d, vd, radii, near, far, cone, app, warp, S1, keep):
+        """IPE + view / appearance condition + NeRF MLP on `rows` fine samples (all n * S1 of them, or the compacted list `sample_id`).
+        -> (raw_rgb, raw_density, raw_semantic or None, saved activations)"""
+        dev = self.arena.flat.device
+        H = self.nerf.H
+        SKIP, CB = self.nerf.alloc_inputs(max(rows, 1))
         if sample_id is not None and sample_id.shape[0] == 0:
             SKIP.zero_(); CB.zero_()                       # nothing survives: one dummy row nobody reads
-            sample_id = None
             enc_ids = torch.zeros(1, dtype=torch.int32, device=dev)
         else:
             enc_ids = sample_id
         ops.mip_encode(s1, o, d, radii, near, far, cone, self.transform_idx, self.max_deg_point, self.nerf.cs(SKIP, H), None, self.nerf.Ew, self.dt,
                        sample_id=enc_ids, warp=warp)
-        app = None
         if self.encode_appearance:
-            app = f(rays.app).reshape(-1)
             if self.dt == ops.BF16X3:        # the split layout is written from an fp32 image of the whole condition block
-                cond = torch.empty(rows, self.nerf.Cw, dtype=torch.float32, device=dev)
+                cond = torch.empty(max(rows, 1), self.nerf.Cw, dtype=torch.float32, device=dev)
                 ops.mip_viewenc(vd, S1, self.deg_view, cond, self.nerf.Cw, ops.F32, sample_id=enc_ids)
                 ops.app_embed(self.arena.p["emb.weight"], app, S1, cond[:, self.view_dim:], ops.F32, sample_id=enc_ids)
                 ops.split_cast(cond, self.nerf.Cw, self.nerf.cs(CB, H), self.nerf.Cw)
@@ -162,19 +202,7 @@ class MipNerfModel(_ArenaModule):
         else:
             ops.mip_viewenc(vd, S1, self.deg_view, self.nerf.cs(CB, H), self.nerf.Cw, self.dt, sample_id=enc_ids)
         raw_rgb, raw_d1, saved1 = self.nerf.forward(SKIP, CB, keep)
-        rgb1, dist1, acc1, w1 = ops.mip_composite_fwd(raw_rgb, raw_d1, noise1, s1, d, near, far, self.transform_idx, white_bg,
-                                                      self.rgb_padding, self.density_bias, row_index=row_index)
-        sem1 = raw_sem = None
-        if self.semantic:
-            raw_sem = self.nerf.raw_sem                                  # [rows, C] fp32: semantic = sum_i w_i raw_semantic_i (mip.py:175-176)
-            sem1 = ops.semantic_composite_fwd(w1, raw_sem, self.sem_classes, False, row_index=row_index)   # compacted rows under ert
-        ctx = None
-        if keep:
-            # detached aliases of the output tensors: the originals become outputs of the autograd Function
-            ctx = dict(o=o, vd=vd, radii=radii, cone=cone, d=d, near=near, far=far, s0=s0.detach(), s1=s1.detach(), raw_d0=raw_d0, acts0=acts0, w0=w0.detach(), dist0=dist0.detach(),
-                       raw_rgb=raw_rgb, raw_d1=raw_d1, saved1=saved1, w1=w1.detach(), dist1=dist1.detach(), noise0=noise0, noise1=noise1,
-                       white=white_bg, raw_sem=raw_sem, app=app)
-        return (dist0, acc0, s0, w0, rgb1, dist1, acc1, s1, w1) + ((sem1,) if self.semantic else ()), ctx
+        return raw_rgb, raw_d1, (self.nerf.raw_sem if self.semantic else None), saved1
 
     def _backward(self, ctx, g_dist0, g_acc0, g_w0, g_rgb1, g_dist1, g_acc1, g_w1, g_sem1=None, on_done=None, ray_grads=False):
         """Accumulates parameter gradients into the arena.  `on_done(prefix or [prefixes])` is called as soon as the gradients of the
@@ -256,7 +284,9 @@ class MipNerfModel(_ArenaModule):
         """-> [[None, distance, acc(, s_vals, weights)], [rgb, distance, acc, None(, s_vals, weights)]]
         (models.py:178-187).  `s_rand` / `u` override the internal draws (parity tests).
         `ert=(eps_t, eps_w)` (inference only; NOT in the reference): early ray termination + sample compaction -- fine samples whose
-        proposal-predicted transmittance is <= eps_t or whose proposal-predicted weight is <= eps_w are not evaluated."""
+        proposal-predicted transmittance is <= eps_t or whose proposal-predicted weight is <= eps_w are not evaluated.
+        `ert=(eps_t, eps_w, G)`: the fine level front to back in groups of G samples; a ray stops once its transmittance, from the fine
+        network's own densities, is <= eps_t -- the skipped samples' weights then sum to <= eps_t (an exact bound on acc / rgb)."""
         if white_bg:
             raise NotImplementedError("white_bg=True crashes the reference at the proposal level (mip.py:188, rgb is None)")
         self._check_arena()
@@ -283,7 +313,9 @@ class MipNerfModel(_ArenaModule):
         keep = torch.is_grad_enabled() and (ray_grad or any(p.requires_grad for p in params))   # grad mode is off inside Function.forward
         if ert is not None and keep:
             raise NotImplementedError("ert (sample compaction) is an inference mode: call under torch.no_grad()")
-        self._ert = None if ert is None else (float(ert[0]), float(ert[1]))
+        # ert = (eps_t, eps_w): selection from the proposal histogram; ert = (eps_t, eps_w, G): front to back in groups of G fine samples,
+        # rays leave when their transmittance (the fine network's own densities) falls to eps_t (eps_w unused: the bound is exact)
+        self._ert = None if ert is None else (float(ert[0]), float(ert[1]), int(ert[2]) if len(ert) > 2 else 0)
         rt = (rays.origins, rays.directions, rays.viewdirs) if ray_grad else (None, None, None)
         outs = _MipFn.apply(self, rays, bool(white_bg), s_rand, u, noise0, noise1, keep, *rt, *params)
         self._ert = None

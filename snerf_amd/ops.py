@@ -995,6 +995,24 @@ def classic_ray_batch(H, W, focal, cx, cy, c2w, c2w_static, rays_o, rays_d, n, n
     return rows
 
 
+def ert_f2b_step(prev_raw_d, prev_base, s1, dirs, near, far, g0, G, next_g0, next_G, transform_idx, density_bias, eps_t, state, row_base):
+    """One step of the front-to-back early ray termination (snerf_ert_f2b_step): fold the evaluated group [g0, g0 + G) into the rays'
+    optical depth and assign the next group to the rays still above eps_t.  `state` = (tau, flags, counts, row_index, sample_id, total)
+    from ert_f2b_state.  -> sample_id[:rows] of the next group (one device->host sync for the row count)."""
+    tau, flags, counts, row_index, sample_id, total = state
+    n, S1 = row_index.shape
+    _lib.call("snerf_ert_f2b_step", _p(prev_raw_d), 0 if prev_raw_d is None else prev_raw_d.stride(0), int(prev_base), _p(s1), _p(dirs), _p(near), _p(far),
+              n, S1, int(g0), int(G), int(next_g0), int(next_G), int(transform_idx), float(density_bias), float(eps_t), _p(tau), _p(flags), _p(counts),
+              _p(row_index), _p(sample_id), int(row_base), _p(total), _stream())
+    return sample_id[:int(total.item())]
+
+
+def ert_f2b_state(n, S1, group, device):
+    return (torch.zeros(n, dtype=torch.float32, device=device), torch.empty(n, dtype=torch.int32, device=device),
+            torch.empty(n, dtype=torch.int32, device=device), torch.full((n, S1), -1, dtype=torch.int32, device=device),
+            torch.empty(n * group, dtype=torch.int32, device=device), torch.zeros(1, dtype=torch.int64, device=device))
+
+
 def mip_loss_tail(rgb, tgt, dist1, dist0, tdepth, conf, s_f, w_f, s_c, w_c, disparity, depth_lambda, coarse_mult, prop_lambda):
     """-> (out[4] = {#valid, rgb, depth, proposal loss}, g_rgb, g_dist1, g_dist0, g_wc); absent terms return None gradients."""
     n = rgb.shape[0]

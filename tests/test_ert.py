@@ -108,3 +108,43 @@ def test_ert_with_the_semantic_head():
     lost = (w_full * (w_fast == 0)).sum(-1)
     bound = float(lost.max()) * float(raw_sem.abs().max()) * 1.05 + 1e-5
     assert float((sem_fast - sem_full).abs().max()) <= bound
+
+
+def test_front_to_back_ert_is_exact_without_termination_and_bounded_by_eps():
+    """ert=(eps_t, eps_w, G): the fine level in groups of G samples, rays leave once the FINE network's transmittance is <= eps_t
+    (snerf_ert_f2b_step).  With eps_t = 0 nothing leaves and the render equals the plain one bit for bit (grouping changes nothing);
+    on an opaque medium rays stop early and every output is off by at most the exact bound: acc and rgb by eps_t (x the colour range),
+    distance by eps_t x t_far."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    m = _model()
+    rays = bench.synth_rays(1024, 7, torch.device("cuda"))
+    with torch.no_grad():
+        full = m(rays, False, False, 0.)
+        same = m(rays, False, False, 0., ert=(0.0, 0.0, 32))
+        assert m.last_ert_rows[0] == m.last_ert_rows[1]
+        same48 = m(rays, False, False, 0., ert=(0.0, 0.0, 48))              # a ragged last group (128 = 48 + 48 + 32)
+    for a, b, c in zip(full[1], same[1], same48[1]):
+        if a is not None:
+            assert torch.equal(a, b) and torch.equal(a, c)
+    with torch.no_grad():                                                   # make the medium opaque: rays now end inside the sampled range
+        p = dict(m.named_parameters())
+        p["proposal.density_layer.bias"] += 6.0
+        p["mlp.density_layer.bias"] += 6.0
+    m.arena.bump()
+    eps = 1e-3
+    with torch.no_grad():
+        full = m(rays, False, False, 0.)
+        fast = m(rays, False, False, 0., ert=(eps, 0.0, 16))
+    kept, total = m.last_ert_rows
+    assert 0 < kept < 0.8 * total, (kept, total)
+    assert float((fast[1][2] - full[1][2]).abs().max()) <= eps * 1.01 + 1e-6                    # acc
+    assert float((fast[1][0] - full[1][0]).abs().max()) <= eps * 1.002 * 1.01 + 1e-6            # rgb in [-0.001, 1.001]
+    far = float(rays.far.max())
+    assert float((fast[1][1] - full[1][1]).abs().max()) <= eps * far * 1.01 + 1e-4              # distance = sum w t_mid
+    # the evaluated samples' weights are the full render's; the others are exactly zero
+    w_full, w_fast = full[1][5], fast[1][5]
+    ev = w_fast != 0
+    assert float((w_full[ev] - w_fast[ev]).abs().max()) < 1e-6
+    assert float((w_full * (~ev)).sum(-1).max()) <= eps * 1.01 + 1e-6
