@@ -244,6 +244,60 @@ def shard_batch(rays, rank: int, world: int, *per_ray):
     return (type(rays)(*[r[a:b] for r in rays]),) + tuple(None if t is None else t[a:b] for t in per_ray)
 
 
+class _TableShards:
+    """Hash-table gradients without the dense all-reduce (the reference all-reduces the dense ~310 MB through DDP,
+    zipnerf/train.py:334).  Touched-rows-only exchange does not apply at the reference's batch sizes -- a rank's 8 192 rays put 14.7 M
+    multisample cells on every 2^21-row level: every row is touched -- so the table spans go the ZeRO-1 way instead: REDUCE-SCATTER of
+    the gradient span (each rank receives the sum of its 1 / world slice), Adam on that slice only (its m / v slices; 1 / world of the
+    optimiser pass), ALL-GATHER of the updated parameter slices.  Same bytes on the wire as the all-reduce it replaces (a ring all-reduce
+    is exactly these two phases) with the optimiser work of the tables sharded; the MLP parameters keep the bucketed all-reduce.
+    Level sizes are multiples of 8 rows (grid.py:130), so the spans divide evenly for world sizes 2 / 4 / 8; other world sizes, and
+    global-norm clipping (which needs the norm of the whole reduced gradient), use the all-reduce path."""
+
+    def __init__(self, arena, names, world, group):
+        self.arena, self.world, self.group = arena, world, group
+        self.rank = dist.get_rank(group)
+        self.spans = {}
+        for n in names:
+            a, b = arena.span(n)
+            if (b - a) % world != 0:
+                raise ValueError("table span does not divide by the world size")
+            self.spans[n] = (a, b, (b - a) // world)
+        self.nccl = dist.get_backend(group) == "nccl"
+        self.pending = []
+
+    def reduce_scatter(self, name):
+        """start the reduce-scatter of one table's gradient span; -> nothing (finish() waits)"""
+        a, b, per = self.spans[name]
+        g = self.arena.grad[a:b]
+        mine = g[self.rank * per:(self.rank + 1) * per]
+        if self.nccl:
+            out = torch.empty_like(mine)
+            w = dist.reduce_scatter_tensor(out, g, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self.pending.append((name, out, [w]))
+        else:       # (gloo has no reduce-scatter: one reduce per destination rank; functional tests only)
+            ws = [dist.reduce(g[r * per:(r + 1) * per], dst=dist.get_global_rank(self.group, r) if self.group is not None else r,
+                              op=dist.ReduceOp.SUM, group=self.group, async_op=True) for r in range(self.world)]
+            self.pending.append((name, mine, ws))
+
+    def finish(self):
+        """-> [(name, flat slice [lo, hi) of this rank, reduced gradient slice)]"""
+        out = []
+        for name, gshard, ws in self.pending:
+            for w in ws:
+                w.wait()
+            a, b, per = self.spans[name]
+            out.append((name, a + self.rank * per, a + (self.rank + 1) * per, gshard.clone() if not self.nccl else gshard))
+        self.pending = []
+        return out
+
+    def all_gather_params(self, name):
+        a, b, per = self.spans[name]
+        full = self.arena.flat[a:b]
+        mine = full[self.rank * per:(self.rank + 1) * per]
+        dist.all_gather_into_tensor(full, mine if self.nccl else mine.clone(), group=self.group)
+
+
 class ZipTrainer:
     """Train step of the S-NeRF++ / zipnerf background model (s-nerfpp/zipnerf/train.py hot loop :218-331: Model.forward, the loss
     terms, loss.backward(), optimizer.step()) on the flat arenas: forward, ONE fused loss-tail launch (ops.zip_loss_tail: Charbonnier
@@ -259,7 +313,7 @@ class ZipTrainer:
     leaf copies of every level's `weights`; its d(loss)/d(weights) is added to the fused tail's)."""
 
     def __init__(self, model, lr=1e-2, betas=(0.9, 0.99), eps=1e-15, charb_padding=0.001, process_group=None, loss_cfg=None,
-                 nonfinite="zero", grad_max_val=0.0, grad_max_norm=0.0):
+                 nonfinite="zero", grad_max_val=0.0, grad_max_norm=0.0, table_exchange="sharded"):
         """`nonfinite`, `grad_max_val`, `grad_max_norm` = train_utils.clip_gradients (train_utils.py:234-243, run every step at
         zipnerf/train.py:336; configs.py:83-84 defaults 0 = off), folded into the Adam launch.  The reference always ends with
         param.grad.nan_to_num_(); "zero" (default) also drops +-Inf instead of mapping it to +-FLT_MAX (which would leave v = inf,
@@ -276,6 +330,15 @@ class ZipTrainer:
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.last_losses = None
         a.grad.zero_()
+        # the hash tables' gradients: "sharded" (default for N > 1) = reduce-scatter + Adam on the rank's slice + all-gather of the updated
+        # parameters (_TableShards); "allreduce" = part of the bucketed all-reduce like the MLP parameters (the reference's DDP behaviour)
+        if table_exchange not in ("sharded", "allreduce"):
+            raise ValueError(table_exchange)
+        self.tables = [n + "encoder.embeddings" for n in model.names]
+        self.shards = None
+        if table_exchange == "sharded" and self.world > 1 and self.grad_max_norm <= 0 and \
+                all((a.span(n)[1] - a.span(n)[0]) % self.world == 0 for n in self.tables):
+            self.shards = _TableShards(a, self.tables, self.world, process_group)
 
     def broadcast_parameters(self, src=0):
         if self.world > 1:
@@ -320,12 +383,41 @@ class ZipTrainer:
             g_w = [a if b is None else (b if a is None else a + b) for a, b in zip(g_w, gs)]
             loss = loss + aux.detach()
         ex = _GradExchange(m.arena, self.world, self.pg)
-        # the NeRF level (its 240 MB table gradient) is reduced while the two proposal levels' backward runs
-        m._backward(ctx, [(None, None, None, g_w[0]), (None, None, None, g_w[1]), (G["rgb"], G["depth"], None, g_w[2], G["semantic"])], on_done=ex)
+        sh = self.shards
+        if sh is not None:
+            for n in self.tables:                      # the table spans do not ride in the all-reduce buckets
+                ex.done.append(m.arena.span(n))
+
+        def level_done(prefix):
+            # a level's gradients are final: its table starts its reduce-scatter, its MLP parameters their all-reduce -- the NeRF level
+            # (240 MB of table gradient) is on the wire while the two proposal levels' backward runs
+            if sh is not None and isinstance(prefix, str) and prefix + "encoder.embeddings" in sh.spans:
+                sh.reduce_scatter(prefix + "encoder.embeddings")
+            ex(prefix)
+        m._backward(ctx, [(None, None, None, g_w[0]), (None, None, None, g_w[1]), (G["rgb"], G["depth"], None, g_w[2], G["semantic"])], on_done=level_done)
         ex.finish()
         self.t += 1
-        coef = ops.grad_clip_coef(m.arena.grad, 1.0 / self.world, self.grad_max_norm) if self.grad_max_norm > 0 else None
-        ops.adam_step(m.arena.flat, m.arena.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.t,
-                      grad_scale=1.0 / self.world, zero_grad=True, nonfinite=self.nonfinite, grad_max_val=self.grad_max_val, clip_coef=coef)
+        a = m.arena
+        adam = lambda lo, hi, g=None: ops.adam_step(a.flat[lo:hi], a.grad[lo:hi] if g is None else g, self.m[lo:hi], self.v[lo:hi], self.lr, self.betas[0],
+                                                    self.betas[1], self.eps, self.t, grad_scale=1.0 / self.world, zero_grad=True,
+                                                    nonfinite=self.nonfinite, grad_max_val=self.grad_max_val)
+        if sh is None:
+            coef = ops.grad_clip_coef(a.grad, 1.0 / self.world, self.grad_max_norm) if self.grad_max_norm > 0 else None
+            ops.adam_step(a.flat, a.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.t,
+                          grad_scale=1.0 / self.world, zero_grad=True, nonfinite=self.nonfinite, grad_max_val=self.grad_max_val, clip_coef=coef)
+        else:
+            # tables: this rank's slice only, then the updated slices are gathered; everything between the table spans: the usual pass
+            mine = sh.finish()
+            for name, lo, hi, gshard in mine:
+                adam(lo, hi, gshard)
+            pos = 0
+            for ta, tb in sorted(a.span(n) for n in self.tables) + [(a.numel, a.numel)]:
+                if ta > pos:
+                    adam(pos, ta)
+                if tb > ta:
+                    a.grad[ta:tb].zero_()
+                pos = max(pos, tb)
+            for name in self.tables:
+                sh.all_gather_params(name)
         m.arena.bump()
         return loss, levels

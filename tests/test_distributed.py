@@ -103,7 +103,7 @@ def _zip_aux(hist):
     return sum((h["weights"] ** 2).sum() for h in hist) * 1e-3
 
 
-def _zip_worker(rank, world, init_file, n, out_file):
+def _zip_worker(rank, world, init_file, n, out_file, table_exchange="sharded"):
     from cpu_ops_emulation import emulate_ops
     from snerf_amd.trainer import ZipTrainer
     dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
@@ -113,7 +113,8 @@ def _zip_worker(rank, world, init_file, n, out_file):
         if rank != 0:
             with torch.no_grad():
                 model.arena.flat.add_(0.5)
-        tr = ZipTrainer(model, lr=1e-2, eps=1e-4)    # a large eps: with the reference's 1e-15 Adam is a sign function of rounding noise on near-zero gradients
+        tr = ZipTrainer(model, lr=1e-2, eps=1e-4, table_exchange=table_exchange)    # a large eps: with the reference's 1e-15 Adam is a sign function of rounding noise on near-zero gradients
+        assert (tr.shards is not None) == (table_exchange == "sharded")
         tr.broadcast_parameters(0)
         batch, tgt = _zip_data(n)
         per = n // world
@@ -138,7 +139,13 @@ def test_zip_ray_sharded_data_parallel_matches_single_process():
         init_file, out_file = os.path.join(td, "init"), os.path.join(td, "out.pt")
         mp.spawn(_zip_worker, args=(world, init_file, n, out_file), nprocs=world, join=True)
         gathered = torch.load(out_file)
+        # the hash tables through reduce-scatter + sharded Adam + all-gather (default) and through the dense all-reduce: the same sums
+        # (two addends commute), the same optimiser arithmetic on every element -- identical parameters
+        init2, out2 = os.path.join(td, "init2"), os.path.join(td, "out2.pt")
+        mp.spawn(_zip_worker, args=(world, init2, n, out2, "allreduce"), nprocs=world, join=True)
+        dense = torch.load(out2)
     assert torch.equal(gathered[0], gathered[1]), "ranks diverged"
+    assert torch.equal(gathered[0], dense[0]) and torch.equal(dense[0], dense[1]), "sharded and all-reduced table updates differ"
     with emulate_ops():
         model = _zip_build()
         start = model.arena.flat.clone()

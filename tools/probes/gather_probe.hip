@@ -3,6 +3,9 @@
 //   scattered  every lane of a wave reads its own pseudo-random row (one distinct line per lane: the hashed levels)
 //   clustered  the 64 lanes of a wave read 64 CONSECUTIVE rows at one pseudo-random base (one or a few lines per wave: the upper bound a
 //              perfectly coherent gather could reach)
+//   windowed   scattered, but every workgroup stays inside ONE 16 MB window of the table (a 2^21-row level of 8-byte entries: what a
+//              workgroup of the training featurisation, one level per workgroup, touches) -- separates the address-translation reach
+//              from the line-request rate
 // Prints rows/s and useful GB/s per case from HIP events.  Run it under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` (and TCC_EA0_RDREQ_sum /
 // TCC_HIT_sum TCC_MISS_sum in separate passes): FETCH_SIZE per launch / the known number of gathered rows = the bytes the counter books
 // per row for THIS access width, which is the scale factor tools/pmc_summary.py applies to the gather kernels (the guide's x2 is stated
@@ -19,11 +22,14 @@ template <> struct Acc<uint2> { static __device__ unsigned f(uint2 v) { return v
 template <> struct Acc<uint4> { static __device__ unsigned f(uint4 v) { return v.x ^ v.y ^ v.z ^ v.w; } };
 
 // every thread gathers `per_thread` rows, 8 independent loads in flight (the featurisation has 8 corners in flight per multisample)
-template <typename T, bool CLUSTER>
+template <typename T, int MODE>       // 0 scattered, 1 clustered, 2 windowed
 __global__ __launch_bounds__(256) void gather(const T* __restrict__ tab, unsigned rows, int per_thread, unsigned seed, unsigned* __restrict__ out) {
+  constexpr bool CLUSTER = MODE == 1;
   const unsigned tid = blockIdx.x * 256 + threadIdx.x;
   const unsigned lane = threadIdx.x & 63, wave = tid >> 6;
   unsigned s = seed ^ ((CLUSTER ? wave : tid) * 2654435761u + 12345u);
+  const unsigned wrows = (16u << 20) / sizeof(T), nwin = rows / wrows > 0 ? rows / wrows : 1;
+  const unsigned wbase = MODE == 2 ? (blockIdx.x % nwin) * wrows : 0u, wspan = MODE == 2 ? (wrows < rows ? wrows : rows) : rows;
   unsigned acc = 0;
   for (int k = 0; k < per_thread; k += 8) {
     unsigned idx[8];
@@ -31,7 +37,7 @@ __global__ __launch_bounds__(256) void gather(const T* __restrict__ tab, unsigne
     for (int q = 0; q < 8; ++q) {
       s = s * 1664525u + 1013904223u;
       const unsigned r = (s >> 3) ^ (s << 11);
-      idx[q] = CLUSTER ? ((r % (rows - 64u)) & ~63u) + lane : r % rows;
+      idx[q] = CLUSTER ? ((r % (rows - 64u)) & ~63u) + lane : wbase + r % wspan;
     }
     T v[8];
 #pragma unroll
@@ -46,7 +52,7 @@ __global__ void fill(uint32_t* p, size_t n) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = (uint32_t)(i * 2654435761u);
 }
 
-template <typename T, bool CLUSTER>
+template <typename T, int CLUSTER>
 void run(const char* pat, const void* tab, size_t bytes, unsigned* out) {
   const unsigned rows = (unsigned)(bytes / sizeof(T));
   const int blocks = 256 * 32, per_thread = 128;
@@ -73,12 +79,15 @@ int main() {
   fill<<<4096, 256>>>((uint32_t*)tab, sizes[2] / 4);
   hipDeviceSynchronize();
   for (int t = 0; t < 3; ++t) {
-    run<uint32_t, false>("scattered", tab, sizes[t], out);
-    run<uint2, false>("scattered", tab, sizes[t], out);
-    run<uint4, false>("scattered", tab, sizes[t], out);
-    run<uint32_t, true>("clustered", tab, sizes[t], out);
-    run<uint2, true>("clustered", tab, sizes[t], out);
-    run<uint4, true>("clustered", tab, sizes[t], out);
+    run<uint32_t, 0>("scattered", tab, sizes[t], out);
+    run<uint2, 0>("scattered", tab, sizes[t], out);
+    run<uint4, 0>("scattered", tab, sizes[t], out);
+    run<uint32_t, 1>("clustered", tab, sizes[t], out);
+    run<uint2, 1>("clustered", tab, sizes[t], out);
+    run<uint4, 1>("clustered", tab, sizes[t], out);
+    run<uint32_t, 2>("windowed", tab, sizes[t], out);
+    run<uint2, 2>("windowed", tab, sizes[t], out);
+    run<uint4, 2>("windowed", tab, sizes[t], out);
   }
   hipFree(tab); hipFree(out);
   return 0;
