@@ -75,8 +75,6 @@ struct WStream {
   unsigned slot_off;        // byte offset of the slot being consumed
   int fill_slot, fill_chunk;  // ring slot / stream chunk of the next DMA
   int n_chunks;
-  unsigned cnt_lds;         // FM_FLAGS: LDS byte address of the four arrival counters
-  unsigned bnd;             // FM_FLAGS: index of the next chunk boundary of this wave
 };
 
 template <int RING>
@@ -95,76 +93,31 @@ __device__ __forceinline__ void ws_issue(WStream& w, char* smem) {
 // stricter).  lgkmcnt(0): this wave's fragment reads of the finished chunk have returned.  The barrier then (a) extends the first
 // fact to the other waves' pieces and (b) the second to the other waves' reads of the slot that is refilled right after it.
 // One volatile asm with a memory clobber: no LDS access of the compiler's may move across it.
-#ifndef FM_EXTRA_VM
-#define FM_EXTRA_VM 0
-#endif
-// FM_SKEW = 1: the second wave of every SIMD (waves FM_WAVES / 2 ..) runs HALF A CHUNK behind the first -- it takes the barrier of a
-// chunk boundary when its own read-ahead is in the middle of a chunk -- so that the two waves of a SIMD reach their block ends (the
-// vector-ALU / LDS / store work between two MFMA runs) half a block apart instead of together, one wave's MFMAs covering the other's
-// epilogue.  The barrier count per tile is unchanged; the lagging waves still read the chunk the leaders just finished, so the slot
-// refilled at a boundary is the one TWO chunks back (one chunk less read-ahead).  Measured (round 3, 6.3 M rows, A/B/A/B on one box,
-// gpurun_out/r3r): training forward 10.0 -> 9.7 ms, classic gradient chain 11.1 -> 11.2 ms, inference and the colour head unchanged,
-// the same with waves w / w + 1 as partners -- the epilogues are NOT what the MFMA pipe waits for; the training kernels sit between
-// their compute time (5.7 ms) and the time a plain fill of their 30.6 GB takes (6.5 ms) without overlapping the two well.  Off.
-#ifndef FM_SKEW
-#define FM_SKEW 0
-#endif
-// FM_FLAGS (round 3, experiment): the chunk boundary WITHOUT a workgroup barrier.  A wave ARRIVES at boundary b when its own pieces of
-// the chunks up to b + 1 have landed (vmcnt) and its reads of chunk b - 1 have returned (lgkmcnt), and says so by adding one to the
-// boundary's arrival counter (four counters in LDS, used round robin, cumulative); it may CROSS the boundary when all eight waves
-// have arrived at boundary b - 1 -- then chunk b is complete in LDS and chunk b - 2 is read by nobody any more, so its slot takes
-// chunk b + RING - 2.  A wave can therefore run up to one chunk (one 32-output block at K = 256) ahead of the slowest one instead of
-// meeting it at every block: the eight waves need not reach their store paths in the same cycle.  One chunk less read-ahead than
-// the barrier protocol (the slot refilled at a boundary is the one TWO chunks back).
-// Measured (6.3 M rows, A/B/A/B on one box, all tests green): training forward 9.45-9.48 -> 9.48-9.51 ms, inference 5.65 -> 5.84 ms.  The
-// lockstep of the eight waves is NOT what the store path costs.  Off.
-#ifndef FM_FLAGS
-#define FM_FLAGS 0
-#endif
-template <int RING, bool FLAGS = false>
+// (Withdrawn variants of this boundary -- a wave pair running half a chunk apart, arrival counters instead of the workgroup barrier, an
+// extra vmcnt slack -- are kept with their measurements in tools/probes/fmlp_experiments.hip; DESIGN.md section 6b lists them.)
+template <int RING>
 __device__ __forceinline__ void ws_sync_issue(WStream& w, char* smem) {
-  if constexpr (FLAGS) {
-    static_assert(RING >= 5, "the flag protocol keeps RING - 4 chunks in flight behind the two that must have landed");
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(2 * (RING - 4)) : "memory");
-    const unsigned b = w.bnd;
-    const unsigned mine = w.cnt_lds + (b & 3u) * 4u, theirs = w.cnt_lds + ((b - 1u) & 3u) * 4u;
-    const unsigned target = FM_WAVES * (((b - 1u) >> 2) + 1u);
-    if ((threadIdx.x & 63) == 0) {
-      const unsigned one = 1u;
-      asm volatile("ds_add_u32 %0, %1" ::"v"(mine), "v"(one) : "memory");
-    }
-    unsigned seen;
-    do {
-      asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen) : "v"(theirs) : "memory");
-      seen = (unsigned)__builtin_amdgcn_readfirstlane((int)seen);
-    } while (seen < target);
-    w.bnd = b + 1u;
-    ws_issue<RING>(w, smem);                            // chunk b + RING - 2 into the slot chunk b - 2 occupied
-  } else {
-  asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(2 * (RING - 2 - FM_SKEW) + FM_EXTRA_VM) : "memory");
-  ws_issue<RING>(w, smem);                              // chunk g + RING - 1 (- FM_SKEW) into the slot chunk g - 1 (- FM_SKEW) occupied
-  }
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(2 * (RING - 2)) : "memory");
+  ws_issue<RING>(w, smem);                              // chunk g + RING - 1 into the slot chunk g - 1 occupied
 }
 __device__ __forceinline__ void ws_cross(WStream& w, int ring) {
   w.slot_off = w.slot_off + FM_SLOT == ring * FM_SLOT ? 0 : w.slot_off + FM_SLOT;
 }
-template <int RING, bool FLAGS = false>
+template <int RING>
 __device__ __forceinline__ void ws_advance(WStream& w, char* smem) {
-  ws_sync_issue<RING, FLAGS>(w, smem);
+  ws_sync_issue<RING>(w, smem);
   ws_cross(w, RING);
 }
 
 // ---- building blocks -----------------------------------------------------------------------------------------------------------
-template <int RING, bool FLAGS = false>
+template <int RING>
 struct CtxT {
   static constexpr int ring = RING;   // slots of the weight ring: FM_RING for the 256-wide networks, fewer where the LDS is needed elsewhere
-  static constexpr bool flags = FLAGS;   // chunk boundaries by arrival counters instead of workgroup barriers (ws_sync_issue)
   char* smem;
   WStream ws;
   const char* frag_base;   // ring + lane * 16
   const char* bias_lds;    // bias table + (lane >> 5) * 16
   bf16x8 q[FM_LOOK];       // the next FM_LOOK fragments, already on their way from LDS
-  bool lag;                // FM_SKEW: this wave takes the chunk barriers half a chunk late (wave-uniform)
 };
 typedef CtxT<FM_RING> Ctx;
 
@@ -173,36 +126,13 @@ typedef CtxT<FM_RING> Ctx;
 // tiles (the stream is one sequence).  The chunk boundary is taken when the READ-AHEAD crosses it.  F (the fragment's position in
 // the network pass) and every index derived from it are template arguments: nothing here depends on the optimiser proving a
 // counter constant.
-// The reads are issued BY HAND with a hand-counted wait (FM_ASM_FRAGS, round 3): while an LDS-DMA is pending -- always, here -- every
-// lgkmcnt wait the compiler inserts is lgkmcnt(0), and with plain loads the queue collapsed into "two reads, wait for
-// everything, two MFMAs": a full LDS round trip per pair of MFMAs.  LDS operations return in order, so "at most FM_LOOK - 1
-// outstanding" means the read issued FM_LOOK fragments ago has returned whatever else (bias reads, slab traffic, scalar loads) is in
-// flight: other operations only make the wait stricter.  Measured (gpurun_out/r3aa, 6.3 M rows, all tests green): inference 5.58 -> 5.53 ms,
-// training forward 9.58 -> 9.37, classic gradient chain 10.65 -> 10.43, colour head unchanged -- two waves per SIMD were already hiding
-// most of that latency.  Off by default: 2 % does not pay for another hand-counted wait in every fused kernel.
-#ifndef FM_ASM_FRAGS
-#define FM_ASM_FRAGS 0
-#endif
+// (Issuing these reads by hand with a hand-counted lgkmcnt gained 2 %: withdrawn, tools/probes/fmlp_experiments.hip.)
 template <int F, typename C>
 __device__ __forceinline__ bf16x8 next_frag(C& c) {
   bf16x8 w = c.q[F % FM_LOOK];
-  if constexpr (FM_ASM_FRAGS) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(w) : "n"(FM_LOOK - 1));
   constexpr int G = F + FM_LOOK;
-  if constexpr (FM_SKEW) {
-    if constexpr ((G % FM_CHUNK) == 0) {
-      if (!c.lag) ws_sync_issue<C::ring>(c.ws, c.smem);
-      ws_cross(c.ws, C::ring);
-    } else if constexpr ((G % FM_CHUNK) == FM_CHUNK / 2) {
-      if (c.lag) ws_sync_issue<C::ring>(c.ws, c.smem);
-    }
-  } else if constexpr ((G % FM_CHUNK) == 0) {
-    ws_advance<C::ring, C::flags>(c.ws, c.smem);
-  }
-  if constexpr (FM_ASM_FRAGS) {
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(c.q[F % FM_LOOK]) : "v"((unsigned)(size_t)c.frag_base + c.ws.slot_off), "n"((G % FM_CHUNK) * 1024));
-  } else {
-    c.q[F % FM_LOOK] = *(const bf16x8*)(c.frag_base + c.ws.slot_off + (G % FM_CHUNK) * 1024);
-  }
+  if constexpr ((G % FM_CHUNK) == 0) ws_advance<C::ring>(c.ws, c.smem);
+  c.q[F % FM_LOOK] = *(const bf16x8*)(c.frag_base + c.ws.slot_off + (G % FM_CHUNK) * 1024);
   return w;
 }
 
@@ -219,23 +149,10 @@ __device__ __forceinline__ f32x16 acc_init(const C& c) {
   return acc;
 }
 
-#ifdef FM_PROBE_DOUBLE
-// PROBE (tools: -DFM_PROBE_DOUBLE): every weight fragment feeds TWO MFMAs (the second into a dummy accumulator): twice the matrix work
-// for the same LDS traffic -- if the launch takes much less than twice as long, the kernel is bound by the LDS port, not the MFMA pipe
-__device__ f32x16 fm_probe_sink;
-template <int F, int NK, int... I, typename C>
-__device__ __forceinline__ void mac_seq(C& c, f32x16& acc, const bf16x8 (&in)[NK], std::integer_sequence<int, I...>) {
-  f32x16 acc2 = acc;
-  (([&] { const bf16x8 w = next_frag<F + I>(c); acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, in[I], acc, 0, 0, 0);
-          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, in[(I + 1) % NK], acc2, 0, 0, 0); }()), ...);
-  if (acc2[0] == 123456.789f) fm_probe_sink = acc2;       // (keeps the second chain alive)
-}
-#else
 template <int F, int NK, int... I, typename C>
 __device__ __forceinline__ void mac_seq(C& c, f32x16& acc, const bf16x8 (&in)[NK], std::integer_sequence<int, I...>) {
   ((acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(next_frag<F + I>(c), in[I], acc, 0, 0, 0)), ...);
 }
-#endif
 template <int F, int NK, typename C>
 __device__ __forceinline__ void mac(C& c, f32x16& acc, const bf16x8 (&in)[NK]) {
   mac_seq<F, NK>(c, acc, in, std::make_integer_sequence<int, NK>{});
@@ -285,19 +202,10 @@ struct StoreTo {
   int ncg;                   // 64-column groups of the layer (its width / 64): row length of the bit-mask block grid
 };
 
-// FM_NT_STORES: the row stores as streaming (nt) stores -- nothing of a launch reads them again, and without the hint the 1.2 KB per row
+// The row stores are streaming (nt) stores -- nothing of a launch reads them again, and without the hint the 1.2 KB per row
 // that pass through an XCD's L2 evict the weight stream every workgroup re-reads per tile (gemm.hip, the epilogue units' stores).
 // Measured (round 3, A/B/A on one box): training forward 9.56 -> 9.31 ms per 6.3 M rows, classic gradient chain 10.4-10.9 -> 10.3 ms,
 // path-B train step 47.9 / 48.2 -> 46.8 ms.
-#ifndef FM_STAGGER
-#define FM_STAGGER 0
-#endif
-#ifndef FM_ABLATE
-#define FM_ABLATE 0       // PROBE builds: 1 = no row-store / mask-store instructions (everything else of the store path stays)
-#endif
-#ifndef FM_NT_STORES
-#define FM_NT_STORES 1
-#endif
 template <bool BITS, int J>
 __device__ __forceinline__ void store_block(const StoreTo& st, const bf16x8& lo, const bf16x8& hi) {
   const int r = st.lane & 31, half = st.lane >> 5;
@@ -328,12 +236,7 @@ __device__ __forceinline__ void store_block(const StoreTo& st, const bf16x8& lo,
       const int row = 8 * it + prow;
       const fm_u32x4 v = vs[it];
       if (st.row0 + row < st.M) {
-#if FM_ABLATE == 1
-        asm volatile("" ::"v"(v));                       // PROBE (-DFM_ABLATE=1): the whole store path but the row-store instruction itself
-#else
-        if constexpr (FM_NT_STORES) __builtin_nontemporal_store(v, (fm_u32x4*)(dst + (long)(8 * it) * st.ld));
-        else *(fm_u32x4*)(dst + (long)(8 * it) * st.ld) = v;
-#endif
+        __builtin_nontemporal_store(v, (fm_u32x4*)(dst + (long)(8 * it) * st.ld));
         if constexpr (BITS) {
           // a ReLU output is > 0 iff its 16 bits are not 0: min(half word, 1), even elements gathered in bits 0, 2, 4, 6, odd ones 16 higher
           typedef unsigned short fm_u16x2 __attribute__((ext_vector_type(2)));
@@ -348,133 +251,24 @@ __device__ __forceinline__ void store_block(const StoreTo& st, const bf16x8& lo,
         }
       }
     }
-#if FM_ABLATE == 1
-    if constexpr (BITS) asm volatile("" ::"v"(mw));
-#else
     if constexpr (BITS) st.bits[((st.row0 >> 5) * st.ncg + (J >> 1)) * 64 + st.lane] = mw;   // 256 contiguous bytes per wave; rows >= M: zeros
-#endif
   }
 }
 
-// EXPERIMENT, off: the same store path cut into PIECES that ride between the MFMAs of the NEXT block (FM_DEFER_STORES, round 3).  Measured on the
-// training forward (6.3 M rows): 5.6 ms without any store path, 7.2 ms with everything but the store instructions, 9.5 ms with them --
-// the eight waves reach their block ends together (chunk barriers), so the CU's vector-memory path sees 32 store instructions at once
-// and every wave waits at issue with its MFMAs behind it.  A block's outputs stay live as the next layer's operands anyway, so its
-// store work needs no extra registers to be postponed: piece 0 (the slab writes) and, for the second block of a pair, pieces 1..4 (one
-// read-back + row store + mask bits each) and 5 (the mask word) are issued a few MFMAs apart inside the following block.
-// Result: correct (all tests), 4 % SLOWER -- every piece ends in the full LDS drain hipcc puts before a use of LDS data while an LDS-DMA
-// is pending, which empties the fragment queue four more times per block; the two waves of a SIMD pass the same pieces at
-// the same MFMA positions, so the pipe is not kept busier either.
-template <bool BITS, int J, int P>
-__device__ __forceinline__ void store_piece(const StoreTo& st, const bf16x8& lo, const bf16x8& hi, unsigned& mw, fm_u32x4 (&vs)[4]) {
-  const int r = st.lane & 31, half = st.lane >> 5;
-  typedef unsigned fm_u32x2 __attribute__((ext_vector_type(2)));
-  if constexpr (P == 0) {
-    char* w = st.slab + r * 128 + 8 * half;
-    const fm_u32x4 l = __builtin_bit_cast(fm_u32x4, lo), h = __builtin_bit_cast(fm_u32x4, hi);
-    constexpr int C0 = 4 * (J & 1);
-    *(fm_u32x2*)(w + (((C0 + 0) ^ (r & 7)) << 4)) = fm_u32x2{l[0], l[1]};
-    *(fm_u32x2*)(w + (((C0 + 1) ^ (r & 7)) << 4)) = fm_u32x2{l[2], l[3]};
-    *(fm_u32x2*)(w + (((C0 + 2) ^ (r & 7)) << 4)) = fm_u32x2{h[0], h[1]};
-    *(fm_u32x2*)(w + (((C0 + 3) ^ (r & 7)) << 4)) = fm_u32x2{h[2], h[3]};
-    if constexpr ((J & 1) == 1) {
-      mw = 0;
-      // all four read-backs now (they queue behind the writes): ONE LDS drain for the pair, at the first piece that uses them
-      const int prow0 = st.lane >> 3, pch0 = st.lane & 7;
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int row = 8 * it + prow0;
-        vs[it] = *(const fm_u32x4*)(st.slab + row * 128 + ((pch0 ^ (row & 7)) << 4));
-      }
-    }
-  } else if constexpr ((J & 1) == 1 && P >= 1 && P <= 4) {
-    constexpr int it = P - 1;
-    // (the lane id through an opaque zero: otherwise hipcc hoists the row addresses of every (layer, piece) -- forty 64-bit values --
-    // out of the tile loop and spills them; a scratch reload then costs a vmcnt(0) in every block)
-    int zero;
-    asm volatile("s_lshr_b32 %0, %1, 30" : "=s"(zero) : "s"(st.ncg));   // (0: ncg is a handful)
-    const int ln = st.lane | zero;
-    const int prow = ln >> 3, pch = ln & 7;
-    const int row = 8 * it + prow;
-    if constexpr (it == 0) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(vs[k]));      // (the one wait for all four, here)
-    }
-    const fm_u32x4 v = vs[it];
-    if (st.row0 + row < st.M) {
-      __bf16* dst = st.y + (st.row0 + prow) * st.ld + 64 * (J >> 1) + 8 * pch;
-      if constexpr (FM_NT_STORES) __builtin_nontemporal_store(v, (fm_u32x4*)(dst + (long)(8 * it) * st.ld));
-      else *(fm_u32x4*)(dst + (long)(8 * it) * st.ld) = v;
-      if constexpr (BITS) {
-        typedef unsigned short fm_u16x2 __attribute__((ext_vector_type(2)));
-        const fm_u16x2 one = {1, 1};
-        unsigned z = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const unsigned x = v[k];
-          z |= __builtin_bit_cast(unsigned, (fm_u16x2)__builtin_elementwise_min(__builtin_bit_cast(fm_u16x2, x), one)) << (2 * k);
-        }
-        mw |= ((z | (z >> 15)) & 0xffu) << (8 * it);
-      }
-    }
-  } else if constexpr ((J & 1) == 1 && P == 5) {
-    int zero;
-    asm volatile("s_lshr_b32 %0, %1, 30" : "=s"(zero) : "s"(st.ncg));   // (0: ncg is a handful)
-    if constexpr (BITS) st.bits[((st.row0 >> 5) * st.ncg + (J >> 1)) * 64 + (st.lane | zero)] = mw;
-  }
-}
-#ifndef FM_DEFER_STORES
-#define FM_DEFER_STORES 0   // measured (round 3, 6.3 M rows, A/B on one box): training forward 9.45-9.55 ms without; one read-back per piece: 9.86 pinned, 9.84 left to the
-                            // scheduler; all four read-backs with the slab writes (one LDS drain per pair, 225 VGPRs): 9.84 pinned, 9.58 unpinned
-#endif
-#ifndef FM_DEFER_PIN
-#define FM_DEFER_PIN 1
-#endif
+// (Cutting this store path into pieces that ride between the next block's MFMAs was built and measured 4 % slower: withdrawn,
+// tools/probes/fmlp_experiments.hip.)
 
 // One layer: out[32 NB] = act(W . [in0 | in1] + b) -- NB blocks of 32 outputs over one or two input segments (skip connections and
 // concatenations are never formed).  F = first fragment, B = first bias block of the layer within the pass.
-// MFMAs I of a block with a hook after each (the deferred store pieces of the previous block)
-template <int F, int NK, typename Hook, int... I, typename C>
-__device__ __forceinline__ void mac_seq_hooked(C& c, f32x16& acc, const bf16x8 (&in)[NK], Hook&& hook, std::integer_sequence<int, I...>) {
-  ((acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(next_frag<F + I>(c), in[I], acc, 0, 0, 0), hook(std::integral_constant<int, I>{})), ...);
-}
-
 template <int F, int B, int NK0, int NK1, bool RELU, bool STORE, bool BITS, int J, bool MORE, int NOUT, typename C>
 __device__ __forceinline__ void dense_block(C& c, f32x16& acc, const bf16x8 (&in0)[NK0], const bf16x8 (&in1)[NK1 > 0 ? NK1 : 1], bf16x8 (&out)[NOUT],
-                                            const StoreTo& st, unsigned& mw, fm_u32x4 (&vs)[4]) {
+                                            const StoreTo& st) {
   bf16x8& lo = out[2 * J];
   bf16x8& hi = out[2 * J + 1];
-  constexpr int NKT = NK0 + NK1;
-  // the previous block's store pieces ride in this block: after MFMA T of the block's NKT (segment boundaries do not matter)
-  constexpr bool DEFER = STORE && FM_DEFER_STORES && J > 0 && NKT >= 12;
-  auto hook = [&](auto seg0, auto idx) __attribute__((always_inline)) {
-    if constexpr (DEFER) {
-      constexpr int T = (decltype(seg0)::value ? 0 : NK0) + decltype(idx)::value;       // position among the block's NKT MFMAs
-      constexpr int S = NKT / 6;                                                        // spacing of the pieces
-      const bf16x8& plo = out[2 * (J - 1)];
-      const bf16x8& phi = out[2 * (J - 1) + 1];
-      constexpr int P = T == 0 ? 0 : T == S ? 1 : T == 2 * S ? 2 : T == 3 * S ? 3 : T == 4 * S ? 4 : T == 4 * S + 1 ? 5 : -1;
-      if constexpr (P >= 0 && (P == 0 || ((J - 1) & 1) == 1)) {
-        // (pinned: left to the scheduler, the pieces' read-backs are hoisted to the block's start and their values live across it)
-        if constexpr (FM_DEFER_PIN) __builtin_amdgcn_sched_barrier(0);
-        store_piece<BITS, J - 1, P>(st, plo, phi, mw, vs);
-        if constexpr (FM_DEFER_PIN) __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-  };
-  mac_seq_hooked<F, NK0>(c, acc, in0, [&](auto i) __attribute__((always_inline)) { hook(std::true_type{}, i); }, std::make_integer_sequence<int, NK0>{});
-  if constexpr (NK1 > 0)
-    mac_seq_hooked<F + NK0, NK1>(c, acc, in1, [&](auto i) __attribute__((always_inline)) { hook(std::false_type{}, i); }, std::make_integer_sequence<int, NK1>{});
+  mac<F, NK0>(c, acc, in0);
+  if constexpr (NK1 > 0) mac<F + NK0, NK1>(c, acc, in1);
   to_frags<RELU>(acc, lo, hi);
-  if constexpr (STORE && !(FM_DEFER_STORES && NKT >= 12)) store_block<BITS, J>(st, lo, hi);
-  else if constexpr (STORE && !MORE) {                   // last block of the layer: nothing follows it here -- its pieces go out at once
-    store_piece<BITS, J, 0>(st, lo, hi, mw, vs);
-    store_piece<BITS, J, 1>(st, lo, hi, mw, vs);
-    store_piece<BITS, J, 2>(st, lo, hi, mw, vs);
-    store_piece<BITS, J, 3>(st, lo, hi, mw, vs);
-    store_piece<BITS, J, 4>(st, lo, hi, mw, vs);
-    store_piece<BITS, J, 5>(st, lo, hi, mw, vs);
-  }
+  if constexpr (STORE) store_block<BITS, J>(st, lo, hi);
   // (issuing these bias reads BEFORE the stores, so that their LDS latency runs under them, measured 9.53 vs 9.43 ms: the sixteen
   // accumulator registers are then live across the store path of a kernel that already sits at the 256-register limit)
   if constexpr (MORE) acc = acc_init<B + 1>(c);
@@ -484,9 +278,7 @@ __device__ __forceinline__ void dense_seq(C& c, const bf16x8 (&in0)[NK0], const 
                                           const StoreTo& st, std::integer_sequence<int, J...>) {
   static_assert(NB % 2 == 0, "the training stores work on pairs of blocks");
   f32x16 acc = acc_init<B>(c);
-  unsigned mw = 0;                                       // mask word / read-back rows of the pair whose store pieces are under way
-  fm_u32x4 vs[4];
-  (dense_block<F + J * (NK0 + NK1), B + J, NK0, NK1, RELU, STORE, BITS, J, (J + 1 < NB)>(c, acc, in0, in1, out, st, mw, vs), ...);
+  (dense_block<F + J * (NK0 + NK1), B + J, NK0, NK1, RELU, STORE, BITS, J, (J + 1 < NB)>(c, acc, in0, in1, out, st), ...);
 }
 // BITS (training stores): the ReLU bit masks; by default for the 256-wide ReLU layers (st.ncg = 4), explicitly for the colour head's
 template <int F, int B, int NK, int NB, bool RELU, bool STORE = false, bool BITS = (STORE && RELU && NB == 8), typename C>
@@ -593,36 +385,11 @@ __device__ __forceinline__ void ctx_start(C& c, char* smem, const char* wstream,
   c.ws.n_chunks = n_chunks;
   c.frag_base = smem + lane * 16;
   c.bias_lds = (const char*)bias_tab + (lane >> 5) * 16;
-#ifndef FM_SKEW_BIT
-#define FM_SKEW_BIT (FM_WAVES / 2)                      // waves w and w + FM_WAVES / 2 share a SIMD (round-robin placement)
-#endif
-  c.lag = FM_SKEW && (wave & FM_SKEW_BIT) != 0;
 
-  // prologue: biases into LDS (plain stores), the first RING - 1 (- FM_SKEW) chunks of the stream into the ring
+  // prologue: biases into LDS (plain stores), the first RING - 1 chunks of the stream into the ring
   for (int i = tid; i < n_blocks * 32; i += 64 * FM_WAVES) bias_tab[i] = bias[i];
-  if constexpr (C::flags) {
-    // flag protocol: chunks 0 .. RING - 3; the arrival counters live in the last 16 bytes of the bias table (n_blocks < FM_BIAS_MAX);
-    // boundary 0 counts as reached by everybody.  ONE barrier, here: chunks 0 and 1 have landed for all waves.
-    unsigned* cnt = (unsigned*)(bias_tab + FM_BIAS_MAX * 32 - 4);
-    c.ws.cnt_lds = (unsigned)(size_t)cnt;
-    c.ws.bnd = 1u;
-    if (tid < 4) cnt[tid] = tid == 0 ? FM_WAVES : 0u;
 #pragma unroll
-    for (int i = 0; i < RING - 2; ++i) ws_issue<RING>(c.ws, smem);
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(2 * (RING - 4)) : "memory");
-    ws_issue<RING>(c.ws, smem);                         // chunk RING - 2
-    ws_cross(c.ws, RING);
-#pragma unroll
-    for (int i = 0; i < FM_LOOK; ++i) c.q[i] = *(const bf16x8*)(c.frag_base + c.ws.slot_off + i * 1024);
-    return;
-  }
-#pragma unroll
-  for (int i = 0; i < RING - 1 - FM_SKEW; ++i) ws_issue<RING>(c.ws, smem);
-#ifdef FMLP_LOCKSTEP_START
-  // debug builds (tools/stress_fmlp_variants.py): every DMA of the prologue landed and all eight waves leave it in the same cycle --
-  // the start that exposed the timing-dependent operand hazard described at to_frags within a handful of launches
-  asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
+  for (int i = 0; i < RING - 1; ++i) ws_issue<RING>(c.ws, smem);
   // first boundary: chunk 0 has landed for everybody (and the bias stores are visible); start the fragment queue
   ws_advance<RING>(c.ws, smem);
 #pragma unroll
@@ -642,12 +409,8 @@ __global__ __launch_bounds__(64 * FM_WAVES, 2) void fmlp_kernel(FmlpArgs a) {   
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5;
 
-  CtxT<FM_RING, (FM_FLAGS != 0)> c;
+  CtxT<FM_RING> c;
   ctx_start(c, smem, a.wstream, a.n_chunks, a.bias, a.n_blocks, tid, wave, lane);
-#if FM_STAGGER
-  // PROBE (-DFM_STAGGER=n): the workgroups of an XCD start up to 15 x 64 n clocks apart -- do the CUs' store bursts line up chip-wide?
-  for (int i = 0; i < (int)((blockIdx.x >> 3) & 15); ++i) __builtin_amdgcn_s_sleep(FM_STAGGER);
-#endif
 
   for (int tile = blockIdx.x; tile < a.tiles; tile += gridDim.x) {
     long row = (long)tile * FM_TILE_ROWS + wave * 32 + (lane & 31);
@@ -1033,85 +796,19 @@ struct ChainArgs {
   int tiles, n_chunks, n_cols;
 };
 
-// ALTERNATIVE bias-gradient path (FCH_COLSUM_MFMA = 1; not shipped): after a pair of blocks sits in the wave's slab (32 rows x 64
-// columns, bf16, row-major), the transposing LDS read hands it back as MFMA B operands whose reduction index is the ROW, and A =
-// "ones in row g, zeros elsewhere" (g = the block's number modulo 32) adds its 32 column sums into row g of ONE accumulator shared by
-// 32 blocks, added to the workgroup's LDS table after every 32nd block.  Two reads and two MFMAs per block instead of the 47-
-// instruction register butterfly: 35 % fewer instructions (16 845 -> 10 957 per tile), and SLOWER -- classic chain, 6.3 M rows:
-// butterfly 10.65 ms, this 11.68 ms, with the four MFMAs deferred into the next block's MFMA run 11.85 ms, no bias gradient at all
-// 8.42 ms (gpurun_out/r3n, tools/fchain_probe.py).  The kernel is not instruction-bound: every MFMA already pulls its 1 KiB weight
-// fragment through the LDS (8 waves x 1100 fragments x 8 clocks = the MFMA time of a tile), and the extra transposing reads land on
-// that same port.
-typedef __attribute__((ext_vector_type(4))) __bf16 fm_bf16x4;
+// Bias gradients: a register butterfly over the wave's 32 rows and one LDS atomic per column into the workgroup's table (chain_block).
+// (The alternative -- column sums by two transposing LDS reads + two MFMAs per block on the slab -- has 35 % fewer instructions and is 10 %
+// slower: withdrawn, tools/probes/fmlp_experiments.hip, profiles/r3_n_fchain_probe_mfma_colsum.txt.)
 struct ColsumCtx {
-  f32x16 acc;
-  fm_bf16x4 f[8];             // the pending pair's transposed fragments: issued at the pair's end, multiplied inside the NEXT block's MFMA run
-  unsigned a0, a1;            // LDS addresses of this lane's first transposing read: rows 0-3 / (chunk ^ 4) of the slab
-  unsigned tab;               // ... and of its entry (row 4 * half, column lane & 31) of the table
-  unsigned tab0;              // butterfly path: this lane's column of block 0 in the table (lanes with bit 4 clear: r = lane & 15)
+  unsigned tab0;              // this lane's column of block 0 in the table (lanes with bit 4 clear: r = lane & 15)
 };
 __device__ __forceinline__ void colsum_start(ColsumCtx& k, const char* slab, const float* cs, int lane) {
-  const int g = lane >> 4, pl = lane & 15, prow = pl >> 2;
-  const int row = 8 * (g >> 1) + prow;                                   // (row & 7 == prow; rows + 4: the chunk swizzle flips bit 2)
-  const int c = 2 * (g & 1) + ((pl & 3) >> 1);
-  k.a0 = (unsigned)(size_t)(slab + row * 128 + ((c ^ prow) << 4) + ((pl & 1) << 3));
-  k.a1 = k.a0 ^ 64u;
-  k.tab = (unsigned)(size_t)(cs + 32 * 4 * (lane >> 5) + (lane & 31));
+  (void)slab;
   k.tab0 = (unsigned)(size_t)(cs + ((lane & 15) & 3) + 8 * ((lane & 15) >> 2) + 4 * (lane >> 5));
-#pragma unroll
-  for (int r = 0; r < 16; ++r) k.acc[r] = 0.f;
-}
-// the pair just written to the slab: (ks, t) = (0, 0), (0, 1), (1, 0), (1, 1) -- rows 16 ks .. + 15 of block t; first read of each:
-// rows + 0..3 of the lane's 8-row half, second: rows + 4..7 (chunk swizzle bit 2 flipped).  No wait here: colsum_wait comes much later.
-__device__ __forceinline__ void colsum_issue(ColsumCtx& k) {
-  asm volatile("ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %9 offset:512\n\t"
-               "ds_read_b64_tr_b16 %2, %9\n\tds_read_b64_tr_b16 %3, %8 offset:512\n\t"
-               "ds_read_b64_tr_b16 %4, %8 offset:2048\n\tds_read_b64_tr_b16 %5, %9 offset:2560\n\t"
-               "ds_read_b64_tr_b16 %6, %9 offset:2048\n\tds_read_b64_tr_b16 %7, %8 offset:2560"
-               : "=&v"(k.f[0]), "=&v"(k.f[1]), "=&v"(k.f[2]), "=&v"(k.f[3]), "=&v"(k.f[4]), "=&v"(k.f[5]), "=&v"(k.f[6]), "=&v"(k.f[7])
-               : "v"(k.a0), "v"(k.a1) : "memory");
-}
-__device__ __forceinline__ void colsum_wait(ColsumCtx& k) {
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(k.f[0]), "+v"(k.f[1]), "+v"(k.f[2]), "+v"(k.f[3]), "+v"(k.f[4]), "+v"(k.f[5]), "+v"(k.f[6]), "+v"(k.f[7])::"memory");
-}
-// MFMA I (0..3) of the pending pair whose second block is number G
-template <int G, int I>
-__device__ __forceinline__ void colsum_mfma(ColsumCtx& k, int lane) {
-  int row = lane & 31;
-  asm volatile("" : "+v"(row));                   // (opaque: or the compiler keeps the selectors of blocks G and G + 32 alive in between and spills)
-  const unsigned o = row == ((G - 1 + (I & 1)) & 31) ? 0x3F803F80u : 0u;
-  const bf16x8 one = __builtin_bit_cast(bf16x8, fm_u32x4{o, o, o, o});
-  k.acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(one, __builtin_shufflevector(k.f[2 * I], k.f[2 * I + 1], 0, 1, 2, 3, 4, 5, 6, 7), k.acc, 0, 0, 0);
-}
-// acc += W-block . in with the pending pair's four column-sum MFMAs spread over the run (independent accumulators: no stall)
-template <int F, int NK, int PG, typename C, int... I>
-__device__ __forceinline__ void mac_colsum_seq(C& c, f32x16& acc, const bf16x8 (&in)[NK], ColsumCtx& k, int lane, std::integer_sequence<int, I...>) {
-  constexpr int Q = NK >= 4 ? NK / 4 : 1;
-  (((acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(next_frag<F + I>(c), in[I], acc, 0, 0, 0)),
-    ((I % Q == Q - 1 && I / Q == 0) ? colsum_wait(k) : (void)0),
-    ((I % Q == Q - 1 && I / Q == 0) ? colsum_mfma<PG, 0>(k, lane) : (void)0), ((I % Q == Q - 1 && I / Q == 1) ? colsum_mfma<PG, 1>(k, lane) : (void)0),
-    ((I % Q == Q - 1 && I / Q == 2) ? colsum_mfma<PG, 2>(k, lane) : (void)0), ((I % Q == Q - 1 && I / Q == 3) ? colsum_mfma<PG, 3>(k, lane) : (void)0)), ...);
-}
-// table[32 (G0 + m) + n] += acc[m][n], m = (r & 3) + 8 (r >> 2) + 4 half: by hand (an LDS atomic the compiler emits itself waits for
-// vmcnt(0) while an LDS-DMA is in flight -- it may alias -- and the weight stream always has some in flight; the table is disjoint
-// from every DMA target.  Completion: lgkmcnt(0) at the tile's end)
-template <int G0>
-__device__ __forceinline__ void colsum_flush(ColsumCtx& k) {
-#define FCH_FLUSH1(R) asm volatile("ds_add_f32 %0, %1 offset:%2" ::"v"(k.tab), "v"(k.acc[R]), "n"((32 * G0 + 32 * (((R) & 3) + 8 * ((R) >> 2))) * 4) : "memory");
-  FCH_FLUSH1(0) FCH_FLUSH1(1) FCH_FLUSH1(2) FCH_FLUSH1(3) FCH_FLUSH1(4) FCH_FLUSH1(5) FCH_FLUSH1(6) FCH_FLUSH1(7)
-  FCH_FLUSH1(8) FCH_FLUSH1(9) FCH_FLUSH1(10) FCH_FLUSH1(11) FCH_FLUSH1(12) FCH_FLUSH1(13) FCH_FLUSH1(14) FCH_FLUSH1(15)
-#pragma unroll
-  for (int r = 0; r < 16; ++r) k.acc[r] = 0.f;
 }
 
 // one 32-output block of a chain step: acc = W^T-block . [in | extra], optional ReLU mask from `mk`, bf16 fragments, store through
 // the slab, bias-gradient partial (pairs of blocks); G = the block's number in the chain, LAST: the chain's last block
-#ifndef FCH_SKIP
-#define FCH_SKIP 0                // (probe builds: 1 no bias gradients, 2 no masks)
-#endif
-#ifndef FCH_COLSUM_MFMA
-#define FCH_COLSUM_MFMA 0
-#endif
 template <int F, int NK, bool EXTRA, bool MASKED, int J, int G, bool LAST, typename C>
 __device__ __forceinline__ void chain_block(C& c, const bf16x8 (&in)[NK], const bf16x8& extra, const char* mk, int lane, int sh, bool row_ok,
                                             ColsumCtx& k, bf16x8& lo, bf16x8& hi, const StoreTo& st) {
@@ -1120,25 +817,13 @@ __device__ __forceinline__ void chain_block(C& c, const bf16x8 (&in)[NK], const 
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  constexpr bool PENDING = FCH_COLSUM_MFMA && (J & 1) == 0 && G > 0 && !(FCH_SKIP & 1);       // the previous pair's column sums ride along
-  if constexpr (PENDING) {
-    if constexpr (NK >= 4) {
-      mac_colsum_seq<F, NK, G - 1>(c, acc, in, k, lane, std::make_integer_sequence<int, NK>{});
-    } else {                                      // (the one-k-step head layers)
-      mac<F, NK>(c, acc, in);
-      colsum_wait(k);
-      colsum_mfma<G - 1, 0>(k, lane); colsum_mfma<G - 1, 1>(k, lane); colsum_mfma<G - 1, 2>(k, lane); colsum_mfma<G - 1, 3>(k, lane);
-    }
-    if constexpr (((G - 1) & 31) == 31) colsum_flush<((G - 1) & ~31)>(k);
-  } else {
-    mac<F, NK>(c, acc, in);
-  }
+  mac<F, NK>(c, acc, in);
   if constexpr (EXTRA) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(next_frag<F + NK>(c), extra, acc, 0, 0, 0);
 #define FCH_MASK1(R, NQ, E) { const float v = acc[R]; acc[R] = __builtin_bit_cast(float, __builtin_bit_cast(int, v) & __builtin_amdgcn_sbfe(NQ, E, 1)); }
 #define FCH_MASK4(Q) { const unsigned wq = w[Q]; const int nq = MASKED ? (row_ok ? (int)(wq >> sh) : 0) : (row_ok ? -1 : 0); \
                        FCH_MASK1(4 * Q + 0, nq, MASKED ? 0 : 0) FCH_MASK1(4 * Q + 1, nq, MASKED ? 1 : 0) FCH_MASK1(4 * Q + 2, nq, MASKED ? 2 : 0) FCH_MASK1(4 * Q + 3, nq, MASKED ? 3 : 0) }
-  if (!(FCH_SKIP & 2)) { FCH_MASK4(0) FCH_MASK4(1) FCH_MASK4(2) FCH_MASK4(3) }
-  if constexpr (!FCH_COLSUM_MFMA && !(FCH_SKIP & 1)) {
+  FCH_MASK4(0) FCH_MASK4(1) FCH_MASK4(2) FCH_MASK4(3)
+  {
     // register butterfly over the wave's 32 rows, then one LDS atomic per column into the workgroup's table -- by hand: an LDS atomic
     // the compiler emits itself waits for vmcnt(0) while an LDS-DMA is in flight (it may alias) and the weight stream always has some
     // in flight; the table is disjoint from every DMA target.  Completion: lgkmcnt(0) at the tile's end
@@ -1149,15 +834,6 @@ __device__ __forceinline__ void chain_block(C& c, const bf16x8 (&in)[NK], const 
   }
   to_frags<false>(acc, lo, hi);
   store_block<false, J>(st, lo, hi);
-  if constexpr (FCH_COLSUM_MFMA && (J & 1) == 1 && !(FCH_SKIP & 1)) {
-    static_assert((G & 1) == 1, "pairs of blocks start on even block numbers");
-    colsum_issue(k);
-    if constexpr (LAST) {                         // nothing follows inside this tile
-      colsum_wait(k);
-      colsum_mfma<G, 0>(k, lane); colsum_mfma<G, 1>(k, lane); colsum_mfma<G, 2>(k, lane); colsum_mfma<G, 3>(k, lane);
-      colsum_flush<(G & ~31)>(k);
-    }
-  }
 }
 template <int F, int NK, bool EXTRA, bool MASKED, int NB, int G0, bool LAST, typename C, int... J>
 __device__ __forceinline__ void chain_step_seq(C& c, const bf16x8 (&in)[NK], const bf16x8& extra, const char* mk, int lane, int sh, bool row_ok,

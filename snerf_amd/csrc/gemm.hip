@@ -371,123 +371,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmNT p) {
 }
 
 // ---------------------------------------------------------------------------
-// NT kernel, TWO independent 4-wave workgroups per CU (DESIGN r2 section 7.0b; variant bit 14 of snerf_linear_fwd): 128 x 256 tile,
-// bf16, wave w owns all 128 rows x columns [64 w, 64 w + 64) (128 accumulator registers, 768 B of LDS fragments per MFMA as in the
-// 8-phase kernels), BK = 32 so that a stage is 24 KiB and a ring of three fits twice into the 160 KiB of a CU (the epilogue's
-// transposition slabs reuse the ring).  One tile per workgroup, one barrier per k-tile (16 MFMAs per wave); the latencies a
-// workgroup cannot hide -- the ring's DMA two k-tiles ahead, the fragment reads, above all its epilogue's store drain -- are to be
-// covered by the OTHER workgroup of the CU, whose waves share the SIMDs but none of the barriers.
-// MEASURED (round 3, tools/gemm_nt4_probe.py, profiles/r3_w_*): correct (same result as the shipped kernel), and 0.69 of its speed --
-// M = 524 288, N = K = 1024: 1390 us = 790 TFLOP/s against 950-1090 us = 1007-1162; K = 1152: 1524 vs 1062 us; M = 65 536: 168 vs 117 us.
-// PMC against the shipped kernel: 1.65 x the issue cycles (ring bookkeeping and 64-bit DMA addresses per 16 instead of 32 MFMAs), 1.45 x
-// the wait cycles, FETCH 2.09 vs 1.62 GB (W re-read per 128 instead of 256 rows), LDS bank conflicts 10 % of LDS-active cycles.  The
-// structural part: 160 KiB per CU hold 2 x 48 KiB of operands in flight for a demand of 47 B per clock and CU = 2000 clocks of latency
-// cover, where the 8-phase kernel holds 96 KiB for 32 B per clock = 3000 clocks -- the second workgroup pays for its independence with
-// the prefetch depth.  Kept as an experiment (forward flavours only, no bias gradient); nothing ships through it.
-// LDS layout of a stage: rows of 64 bytes, two per 128-byte line; 16-byte chunk c of tile row r sits in line r >> 1 at chunk position
-// ((4 (r & 1) + c) ^ ((r >> 2) & 3)): the 16 lanes of a ds_read_b128 pass (16 consecutive rows, one k-chunk) hit 16 different
-// 16-byte bank groups.  The DMA writes lane i of a 1 KiB piece to line i >> 3, position i & 7, so the swizzle is applied to the
-// SOURCE address: that position holds row 2 line + (x >> 2), chunk x & 3 with x = (i & 7) ^ ((line >> 1) & 3).
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void gemm_nt4_kernel(GemmNT p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  typedef __bf16 T;
-  constexpr int BM = 128, BN = 256, STAGE = (BM + BN) * 64;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tiles_n = p.N / BN;
-  const int tiles_m = (p.M + BM - 1) / BM;
-  const int logical = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-  const int m0 = (logical / tiles_n) * BM, n0 = (logical % tiles_n) * BN;
-  const T* __restrict__ A = (const T*)p.A;
-  const T* __restrict__ W = (const T*)p.W;
-  const int KT = p.K / 32;
-  // staging sources: A = pieces 0..7 (16 rows each), B = pieces 0..15; wave w takes A pieces 2 w, 2 w + 1 and B pieces 4 w .. 4 w + 3
-  long a_off[2], b_off[4];
-  {
-    const int line = lane >> 3, pos = lane & 7;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int L = (wave * 2 + i) * 8 + line;                  // line of the A part of the stage = tile row >> 1
-      const int x = pos ^ ((L >> 1) & 3);
-      int gr = m0 + 2 * L + (x >> 2);
-      gr = gr < p.M ? gr : p.M - 1;
-      a_off[i] = (long)gr * p.lda + (x & 3) * 8;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int L = (wave * 4 + i) * 8 + line;
-      const int x = pos ^ ((L >> 1) & 3);
-      b_off[i] = (long)(n0 + 2 * L + (x >> 2)) * p.ldw + (x & 3) * 8;
-    }
-  }
-  auto issue = [&](int kt, int stage) __attribute__((always_inline)) {
-    char* sA = smem + stage * STAGE;
-    char* sB = sA + BM * 64;
-    const long k0 = (long)kt * 32;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) glds16(A + a_off[i] + k0, sA + (wave * 2 + i) * 1024);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(W + b_off[i] + k0, sB + (wave * 4 + i) * 1024);
-  };
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  // fragment addresses inside a stage for k-step 0 (k-step 1: chunk + 2, i.e. position ^ 2)
-  int fa[4], fb[2];
-  {
-    const int chalf = lane >> 5;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = i * 32 + (lane & 31);
-      fa[i] = (r >> 1) * 128 + ((((r & 1) << 2 | chalf) ^ ((r >> 2) & 3)) << 4);
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int r = wave * 64 + j * 32 + (lane & 31);
-      fb[j] = BM * 64 + (r >> 1) * 128 + ((((r & 1) << 2 | chalf) ^ ((r >> 2) & 3)) << 4);
-    }
-  }
-  bf16x8 a0[4], b0[2], a1[4], b1[2];
-  auto read = [&](int stage, int ks, bf16x8 (&a)[4], bf16x8 (&b)[2]) __attribute__((always_inline)) {
-    const char* base = smem + stage * STAGE;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) a[i] = *(const bf16x8*)(base + (fa[i] ^ (ks << 5)));
-#pragma unroll
-    for (int j = 0; j < 2; ++j) b[j] = *(const bf16x8*)(base + (fb[j] ^ (ks << 5)));
-  };
-  auto mfma8 = [&](const bf16x8 (&a)[4], const bf16x8 (&b)[2]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) mma32(acc[i][j], b[j], a[i]);   // D = W-tile . X-tile^T: lanes own rows m
-  };
-  issue(0, 0);
-  if (KT > 1) issue(1, 1);
-  if (KT > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  read(0, 0, a0, b0);
-  int st = 0;                                                   // stage of k-tile kt
-  for (int kt = 0; kt < KT; ++kt) {
-    const int st1 = st == 2 ? 0 : st + 1, st2 = st1 == 2 ? 0 : st1 + 1;
-    if (kt + 2 < KT) issue(kt + 2, st2);                        // (its previous content, k-tile kt - 1, was last read before the barrier below of the previous iteration)
-    read(st, 1, a1, b1);
-    mfma8(a0, b0);
-    if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // k-tile kt + 1 has landed (this wave's pieces)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (kt + 1 < KT) read(st1, 0, a0, b0);
-    mfma8(a1, b1);
-    st = st1;
-  }
-  nt_epilogue<T, BM, BN, 1, 4>(p, acc, smem, m0, n0, wave, lane);
-}
-
-// ---------------------------------------------------------------------------
 // NT kernel, 256 x 256 tile, bf16, 8 waves (2 x 4), BK = 64: the "8-phase" schedule.
 //
 // The block tile is staged as four HALF-tiles per k-tile (A0, A1, B0, B1: 128 rows x 128 B each, 16 KiB), double
@@ -1357,8 +1240,6 @@ extern "C" int snerf_linear_fwd(const void* A, long lda, const void* W, long ldw
   if (split && out_f32 && (act == ACT_MASK || colsum != nullptr)) return SNERF_ERR_ARG;
   GemmNT p{A, lda, W, ldw, bias, Y, ldy, aux, ldaux, colsum, M, N, K, n_store, act, out_f32, vec, colsum_ws, fast, det, ((variant >> 4) & 7) | ((variant >> 10) & 8),
            (variant >> 9) & 15, split};                          // (PROBE builds: variant bit 13 = ablation bit 8; bits 9..12 = stagger)
-  // variant bit 14: the two-workgroups-per-CU kernel (bf16, N % 256 == 0, 16-byte epilogue, plain / ReLU / bf16-mask activations)
-  const bool nt4 = ((variant >> 14) & 1) && dtype == SNERF_DT_BF16 && !split && N % 256 == 0 && fast && act <= ACT_MASK && (K % 32) == 0 && colsum == nullptr;
   variant &= 15;
   hipStream_t s = (hipStream_t)stream;
   // variant: 0 = 128x128 block-issue, 1 = 256x256 block-issue,
@@ -1369,14 +1250,6 @@ extern "C" int snerf_linear_fwd(const void* A, long lda, const void* W, long ldw
                   (lda * 2 * 256 < (1L << 31)) && (ldw * 2 * 256 < (1L << 31)) && !(split && (act == ACT_MASK || (colsum != nullptr && act == ACT_RELU_BITS)));
   if (act >= ACT_RELU_BITS && !(p8 && (long)((M + 255) / 256) * 8 * (N / 64) * 256 < (1L << 31)))
     return SNERF_ERR_ARG;
-  if (nt4) {                                                    // (experiment: two 4-wave workgroups per CU on 128 x 256 tiles)
-    static bool attr4 = false;
-    if (!attr4) { (void)hipFuncSetAttribute((const void*)gemm_nt4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 384 * 64); attr4 = true; }
-    const int tiles = ((M + 127) / 128) * (N / 256);
-    p.colsum_ws = nullptr;
-    hipLaunchKernelGGL(gemm_nt4_kernel, dim3(tiles), dim3(256), 3 * 384 * 64, s, p);
-    return snerf_check_launch();
-  }
   if (p8) return launch_nt8p(p, s);
   if (dtype == SNERF_DT_BF16 && (variant & 12) && N % 256 == 0) return launch_nt8(p, s);
   if (dtype == SNERF_DT_F32) return launch_nt<float, 128, 128, 2, 2>(p, s);

@@ -146,26 +146,6 @@ def test_gemm_operands_as_column_ranges(ops):
         assert bool((ybig[:, :64] == 5.0).all())
 
 
-@pytest.mark.parametrize("act", [0, 1, 2])
-def test_two_workgroups_per_cu_nt_kernel_matches_fp64(ops, act):
-    """gemm_nt4_kernel (variant bit 14: 128 x 256 tiles, 4 waves, BK = 32, two workgroups per CU -- the experiment of DESIGN 6b) on a
-    ragged shape: plain, bias + ReLU, and the bf16-mask data-gradient flavour against an fp64 matmul."""
-    M, N, K = 1000, 512, 1152
-    g = torch.Generator().manual_seed(3)
-    A = (torch.rand(M, K, generator=g) * 2 - 1).bfloat16().cuda()
-    W = ((torch.rand(N, K, generator=g) * 2 - 1) / K ** 0.5).bfloat16().cuda()
-    b = None if act == 2 else torch.rand(N, generator=g).cuda()
-    aux = (torch.rand(M, N, generator=g) - 0.5).bfloat16().cuda() if act == 2 else None
-    ref = A.double() @ W.double().t() + (0 if b is None else b.double())
-    if act == 1:
-        ref = torch.relu(ref)
-    if act == 2:
-        ref = ref * (aux.double() > 0)
-    Y = torch.full((M, N), 7.0, dtype=torch.bfloat16, device="cuda")
-    ops.linear_fwd(A, W, b, Y, K, N, act, ops.BF16, aux=aux, variant=8 | (1 << 14))
-    assert float((Y.double() - ref).abs().max() / ref.abs().max()) < 6e-3
-
-
 @pytest.mark.parametrize("dt", [0, 1])
 def test_zip_glo_modulation_kernels(ops, dt):
     """snerf_zip_glo_modulate / _bwd (internal/models.py:620-630: bottleneck * exp(scale) + shift per ray) and snerf_colsum_wide_f32 against

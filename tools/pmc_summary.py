@@ -33,7 +33,17 @@ if g("SQ_LDS_IDX_ACTIVE"):
     print(f"lds_bank_conflict/idx_act {g('SQ_LDS_BANK_CONFLICT', 0) / g('SQ_LDS_IDX_ACTIVE'):.3f}")
 if g("TCC_HIT_sum") is not None and g("TCC_MISS_sum") is not None:
     print(f"L2 hit rate               {g('TCC_HIT_sum') / (g('TCC_HIT_sum') + g('TCC_MISS_sum')):.3f}")
+# FETCH_SIZE = TCC_EA0_RDREQ x 64 B (KB).  Calibration (tools/probes/gather_probe.hip under --pmc, profiles/r4_a_gather_probe*.txt): a wide
+# COALESCED stream books exactly half of its bytes (128-byte requests tallied at 64: the guide's x2); a SCATTERED gather of 4- / 8- / 16-byte
+# rows books one request = 64 B per row whatever the row width (TCC_REQ = rows, 97 % misses, TCC_EA0_RDREQ_32B = 0).  Whether such a
+# request moves 64 or 128 bytes cannot be told from the counters (the scattered-row rate is the same from a 120 MB and from a 2 GB table:
+# the memory side is not what limits it), so the gather kernels get both: x1 = lower bound, x2 = upper bound.
+GATHER = ("zip_encode", "grid_encode", "zip_bin_emit", "zip_bin_write", "gather<")
 if g("FETCH_SIZE") is not None:
-    print(f"FETCH_SIZE x2 (gfx950 correction, KB->bytes): {2 * g('FETCH_SIZE') * 1024 / 1e9:.3f} GB per launch")
+    if any(k in pat for k in GATHER):
+        print(f"FETCH_SIZE, gather class (KB->bytes): {g('FETCH_SIZE') * 1024 / 1e9:.3f} GB per launch at 64 B per request (lower bound), "
+              f"{2 * g('FETCH_SIZE') * 1024 / 1e9:.3f} GB at 128 B (upper bound)")
+    else:
+        print(f"FETCH_SIZE x2 (gfx950 correction for coalesced streams, KB->bytes): {2 * g('FETCH_SIZE') * 1024 / 1e9:.3f} GB per launch")
 if g("WRITE_SIZE") is not None:
     print(f"WRITE_SIZE (KB->bytes): {g('WRITE_SIZE') * 1024 / 1e9:.3f} GB per launch")

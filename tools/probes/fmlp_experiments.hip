@@ -1,3 +1,8 @@
+// RECORD OF WITHDRAWN EXPERIMENTS: snerf_amd/csrc/fmlp.hip as it stood at the end of round 3, with its build switches FM_EXTRA_VM, FM_SKEW,
+// FM_FLAGS, FM_ASM_FRAGS, FM_PROBE_DOUBLE, FM_STAGGER, FM_ABLATE, FM_DEFER_STORES / FM_DEFER_PIN, FMLP_LOCKSTEP_START, FCH_SKIP, FCH_COLSUM_MFMA (all off by
+// default).  The shipped file is this one with every switch folded at its default (identical ISA for all 14 kernels, checked).  To repeat a
+// measurement: copy it over csrc/fmlp.hip and build with `make CXXFLAGS+=-DFM_...`; logs: profiles/r3_n_*, r3_r_*, r3_y_*, r3_zz_fmlp_*.
+
 // Fused multi-layer MLP for the 256-wide networks of the path (gfx950 / CDNA4): the whole network in ONE kernel, activations
 // resident in REGISTERS from the first layer to the heads.
 //

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B of the two-workgroups-per-CU NT kernel (gemm_nt4_kernel: 128 x 256 tiles, 4 waves, BK = 32; variant bit 14) against the shipped
+"""(WITHDRAWN: the kernel lives in tools/probes/gemm_nt4_kernel.hip since round 4; kept for the record of profiles/r3_w_*)  A/B of the two-workgroups-per-CU NT kernel (gemm_nt4_kernel: 128 x 256 tiles, 4 waves, BK = 32; variant bit 14) against the shipped
 persistent 8-phase kernel on the train step's large forward shapes; checks the result against an fp64 matmul first."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
