@@ -70,6 +70,29 @@ __device__ __forceinline__ void mma32(f32x16& acc, const f32x4& a, const f32x4& 
   for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
 }
 
+// fp16 flavour (dtype SNERF_DT_F16; BASELINE config 4's "fp16 MLP"): the kernels move their 16-bit operands through LDS and registers as opaque
+// bit patterns (typed bf16x8 here), so a build flag F16 only selects the MFMA (v_mfma_f32_32x32x16_f16, same rate) and the fp32 <-> 16-bit
+// conversions; ReLU by a packed signed max and the "is positive" tests on bit patterns hold for both formats.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <bool F16> __device__ __forceinline__ void mma32t(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+  if constexpr (F16) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+  else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+}
+template <bool F16> __device__ __forceinline__ void mma32t(f32x16& acc, const f32x4& a, const f32x4& b) { mma32(acc, a, b); }
+template <bool F16> __device__ __forceinline__ __bf16 cvt16(float v) {          // fp32 -> the launch's 16-bit format (as a bf16-typed bit pattern)
+  if constexpr (F16) return __builtin_bit_cast(__bf16, (_Float16)v);
+  else return (__bf16)v;
+}
+template <bool F16> __device__ __forceinline__ float up16(__bf16 h) {
+  if constexpr (F16) return (float)__builtin_bit_cast(_Float16, h);
+  else return (float)h;
+}
+template <bool F16> __device__ __forceinline__ float up16(float x) { return x; }
+template <typename T, bool F16> __device__ __forceinline__ T down16(float v) {
+  if constexpr (sizeof(T) == 4) return v;
+  else return cvt16<F16>(v);
+}
+
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
@@ -81,7 +104,7 @@ __device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
 // NT epilogue shared by the NT kernels.  acc[i][j] is the 32 x 32 MFMA tile at rows
 // m0 + wm*WTM + 32 i, columns n0 + wn*WTN + 32 j of the block tile.
 // ---------------------------------------------------------------------------
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, bool F16 = false>
 __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], char* smem,
                                             const int m0, const int n0, const int wave, const int lane) {
   typedef typename Frag<T>::type frag_t;
@@ -137,7 +160,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x16 (&acc)[BM / 
             }
             char* dst = my + (lane & 31) * PITCH + cl * (int)sizeof(T);
             if constexpr (sizeof(T) == 2) {
-              bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+              bf16x4 o = {cvt16<F16>(v[0]), cvt16<F16>(v[1]), cvt16<F16>(v[2]), cvt16<F16>(v[3])};
               if (part == 1) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = (__bf16)(v[e] - (float)o[e]);
@@ -162,11 +185,11 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x16 (&acc)[BM / 
             if (p.act == ACT_MASK) {
               const frag_t a8 = *(const frag_t*)(auxp + (long)m * p.ldaux + pcol);
 #pragma unroll
-              for (int e = 0; e < EPC; ++e) if (!((float)a8[e] > 0.f)) val[e] = (T)0.f;
+              for (int e = 0; e < EPC; ++e) if (!(up16<F16>(a8[e]) > 0.f)) val[e] = (T)0.f;
             }
             *(frag_t*)((T*)p.Y + (long)m * p.ldy + pcol + 64 * part) = val;
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) cs[g][e] += (float)val[e];
+            for (int e = 0; e < EPC; ++e) cs[g][e] += up16<F16>(val[e]);
           }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -222,7 +245,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x16 (&acc)[BM / 
             if constexpr (sizeof(T) == 2) {
               const bf16x4 a4 = *(const bf16x4*)ap;
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = (float)a4[e] > 0.f ? v[e] : 0.f;
+              for (int e = 0; e < 4; ++e) v[e] = up16<F16>(a4[e]) > 0.f ? v[e] : 0.f;
             } else {
               const f32x4 a4 = *(const f32x4*)ap;
 #pragma unroll
@@ -231,7 +254,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x16 (&acc)[BM / 
           } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-              if (nb + e < p.n_store) v[e] = to_f32(ap[e]) > 0.f ? v[e] : 0.f;
+              if (nb + e < p.n_store) v[e] = up16<F16>(ap[e]) > 0.f ? v[e] : 0.f;
           }
         }
         if (full && vec_ok) {
@@ -239,7 +262,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x16 (&acc)[BM / 
             f32x4 o = {v[0], v[1], v[2], v[3]};
             *(f32x4*)((float*)p.Y + (long)m * p.ldy + nb) = o;
           } else {
-            bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+            bf16x4 o = {cvt16<F16>(v[0]), cvt16<F16>(v[1]), cvt16<F16>(v[2]), cvt16<F16>(v[3])};
             *(bf16x4*)((__bf16*)p.Y + (long)m * p.ldy + nb) = o;
           }
         } else {
@@ -247,7 +270,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x16 (&acc)[BM / 
           for (int e = 0; e < 4; ++e) {
             if (nb + e < p.n_store) {
               if (p.out_f32) ((float*)p.Y)[(long)m * p.ldy + nb + e] = v[e];
-              else ((T*)p.Y)[(long)m * p.ldy + nb + e] = from_f32<T>(v[e]);
+              else ((T*)p.Y)[(long)m * p.ldy + nb + e] = down16<T, F16>(v[e]);
             }
           }
         }
@@ -274,7 +297,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x16 (&acc)[BM / 
 // ---------------------------------------------------------------------------
 // NT kernel: BM x BN output tile, WM x WN waves, each wave (BM/WM) x (BN/WN).
 // ---------------------------------------------------------------------------
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, bool F16 = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmNT p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef typename Frag<T>::type frag_t;
@@ -364,10 +387,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmNT p) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) mma32(acc[i][j], b[j], a[i]);   // D = W-tile . X-tile^T: lanes own rows m
+        for (int j = 0; j < TN; ++j) mma32t<F16>(acc[i][j], b[j], a[i]);   // D = W-tile . X-tile^T: lanes own rows m
     }
   }
-  nt_epilogue<T, BM, BN, WM, WN>(p, acc, smem, m0, n0, wave, lane);
+  nt_epilogue<T, BM, BN, WM, WN, F16>(p, acc, smem, m0, n0, wave, lane);
 }
 
 // ---------------------------------------------------------------------------
@@ -390,6 +413,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmNT p) {
 // retired it; a half is restaged at the earliest in the phase after its last fragment read, and every phase retires its
 // fragment reads (lgkmcnt(0)) BEFORE its first barrier, so the restaging wave group cannot overtake them.
 // ---------------------------------------------------------------------------
+template <bool F16 = false>
 __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmNT p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __bf16 T;
@@ -469,7 +493,7 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmNT p) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-      for (int i2 = 0; i2 < 2; ++i2) mma32(acc[2 * h + i2][g], b[ks], a[i2][ks]);   // lanes own rows m
+      for (int i2 = 0; i2 < 2; ++i2) mma32t<F16>(acc[2 * h + i2][g], b[ks], a[i2][ks]);   // lanes own rows m
   };
   // end of a phase's load section / end of its MFMA section
   auto sync_loads = [&]() {
@@ -539,7 +563,7 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmNT p) {
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();          // matches the extra barrier of wave row 1
 
-  nt_epilogue<T, BM, BN, WM, WN>(p, acc, smem, m0, n0, wave, lane);
+  nt_epilogue<T, BM, BN, WM, WN, F16>(p, acc, smem, m0, n0, wave, lane);
 }
 
 // ---------------------------------------------------------------------------
@@ -567,9 +591,10 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmNT p) {
 // ---------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-template <int ACT, bool COLSUM, bool SPLIT = false>
+template <int ACT, bool COLSUM, bool SPLIT = false, bool F16 = false>
 __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
   static_assert(!(SPLIT && ACT == ACT_MASK), "split-bf16 data gradients take their ReLU masks from the bit masks");
+  static_assert(!(SPLIT && F16), "the split mode is a bf16 construction");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __bf16 T;
   constexpr int HALF = 128 * 128;                      // bytes per half-tile
@@ -752,7 +777,13 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
     for (int c = 0; c < 8; ++c) {
       const int jj = c >> 2, q = c & 3;
       const f32x2 v01 = {acc[u][jj][4 * q + 0], acc[u][jj][4 * q + 1]}, v23 = {acc[u][jj][4 * q + 2], acc[u][jj][4 * q + 3]};
-      u32x2 o = {__builtin_bit_cast(unsigned, __builtin_convertvector(v01, bf16x2)), __builtin_bit_cast(unsigned, __builtin_convertvector(v23, bf16x2))};
+      u32x2 o;
+      if constexpr (F16) {
+        typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+        o = u32x2{__builtin_bit_cast(unsigned, __builtin_convertvector(v01, f16x2)), __builtin_bit_cast(unsigned, __builtin_convertvector(v23, f16x2))};
+      } else {
+        o = u32x2{__builtin_bit_cast(unsigned, __builtin_convertvector(v01, bf16x2)), __builtin_bit_cast(unsigned, __builtin_convertvector(v23, bf16x2))};
+      }
       if ((ACT == ACT_RELU || ACT == ACT_RELU_BITS) && part == 0) {
         // (the empty asm keeps the packed conversion; the max itself stays a compiler-visible instruction: see fmlp.hip to_frags)
         typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -807,7 +838,7 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
       else val = *(const bf16x8*)(slab + row * 128 + ((pch ^ (row & 7)) << 4));
       if (ACT == ACT_MASK) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) if (!((float)a8[it][e] > 0.f)) val[e] = (T)0.f;
+        for (int e = 0; e < 8; ++e) if (!(up16<F16>(a8[it][e]) > 0.f)) val[e] = (T)0.f;
       }
       if (ACT == ACT_MASK_BITS) {
         // byte `it` of the word masks these 8 values: u carries bit i of the byte at positions i and i + 15, so (u >> 2k) & 0x10001
@@ -847,7 +878,7 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
           // accumulate is not correctly rounded, inf x 0 poisons the neighbouring column, and hipcc 7.2 encodes the packed constant
           // (1, 0) as the inline constant 1.0, which the instruction reads as (0, 1))
 #pragma unroll
-          for (int e = 0; e < 8; ++e) cs[e] += (float)val[e];
+          for (int e = 0; e < 8; ++e) cs[e] += up16<F16>(val[e]);
         }
       }
     }
@@ -949,8 +980,8 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
     for (int ks = 0; ks < 4; ++ks) bS[S][ks] = lds_b(db, S, ks);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      mma32(acc[0][F], bS[F][ks], aF[0][ks]);
-      mma32(acc[1][F], bS[F][ks], aF[1][ks]);
+      mma32t<F16>(acc[0][F], bS[F][ks], aF[0][ks]);
+      mma32t<F16>(acc[1][F], bS[F][ks], aF[1][ks]);
     }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -966,7 +997,7 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
       for (int i2 = 0; i2 < 2; ++i2) {
-        mma32(acc[i2][S], bS[S][ks], aF[i2][ks]);
+        mma32t<F16>(acc[i2][S], bS[S][ks], aF[i2][ks]);
         aF[i2][ks] = lds_a(db, 1, i2, ks);
       }
 #pragma unroll
@@ -982,8 +1013,8 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
     end_load();
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      mma32(acc[2][S], bS[S][ks], aF[0][ks]);
-      mma32(acc[3][S], bS[S][ks], aF[1][ks]);
+      mma32t<F16>(acc[2][S], bS[S][ks], aF[0][ks]);
+      mma32t<F16>(acc[3][S], bS[S][ks], aF[1][ks]);
       bS[S][ks] = lds_b(db ^ 1, S, ks);
     }
 #pragma unroll
@@ -1002,7 +1033,7 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
       for (int i2 = 0; i2 < 2; ++i2) {
-        mma32(acc[2 + i2][F], bS[F][ks], aF[i2][ks]);
+        mma32t<F16>(acc[2 + i2][F], bS[F][ks], aF[i2][ks]);
         aF[i2][ks] = lds_a(db ^ 1, 0, i2, ks);
       }
 #pragma unroll
@@ -1082,17 +1113,17 @@ __global__ __launch_bounds__(256) void colsum_split_kernel(const __bf16* __restr
     if (c0 + e < n_store) atomicAdd(out + c0 + e, acc[e]);
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, bool F16 = false>
 static int launch_nt(const GemmNT& p, hipStream_t stream) {
   constexpr int LDS = 2 * (BM + BN) * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_nt_kernel<T, BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipFuncSetAttribute((const void*)gemm_nt_kernel<T, BM, BN, WM, WN, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
   const int tiles_m = (p.M + BM - 1) / BM;
   const int tiles = tiles_m * (p.N / BN);
-  hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, WM, WN>), dim3(tiles), dim3(64 * WM * WN), LDS, stream, p);
+  hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, WM, WN, F16>), dim3(tiles), dim3(64 * WM * WN), LDS, stream, p);
   if (p.fast_epi && p.colsum_ws != nullptr) {
     const int rows = tiles_m * WM;
     int ychunks = rows / 8;
@@ -1102,16 +1133,17 @@ static int launch_nt(const GemmNT& p, hipStream_t stream) {
   return snerf_check_launch();
 }
 
+template <bool F16 = false>
 static int launch_nt8(const GemmNT& p, hipStream_t stream) {
   constexpr int LDS = 8 * 128 * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_nt8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipFuncSetAttribute((const void*)gemm_nt8_kernel<F16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
   const int tiles_m = (p.M + 255) / 256;
   const int tiles = tiles_m * (p.N / 256);
-  hipLaunchKernelGGL(gemm_nt8_kernel, dim3(tiles), dim3(512), LDS, stream, p);
+  hipLaunchKernelGGL((gemm_nt8_kernel<F16>), dim3(tiles), dim3(512), LDS, stream, p);
   if (p.fast_epi && p.colsum_ws != nullptr) {
     const int rows = tiles_m * 2;
     int ychunks = rows / 8;
@@ -1121,19 +1153,20 @@ static int launch_nt8(const GemmNT& p, hipStream_t stream) {
   return snerf_check_launch();
 }
 
+template <bool F16 = false>
 static int launch_nt8p(const GemmNT& p, hipStream_t stream) {
   constexpr int LDS = 8 * 128 * 128 + 4 * 4096 + 2048 + 8192;
   static bool attr_set = false;
   static int n_cu = 256;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_nt8p_kernel<ACT_NONE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    hipFuncSetAttribute((const void*)gemm_nt8p_kernel<ACT_RELU, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    hipFuncSetAttribute((const void*)gemm_nt8p_kernel<ACT_NONE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    hipFuncSetAttribute((const void*)gemm_nt8p_kernel<ACT_MASK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    hipFuncSetAttribute((const void*)gemm_nt8p_kernel<ACT_MASK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    hipFuncSetAttribute((const void*)gemm_nt8p_kernel<ACT_RELU_BITS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    hipFuncSetAttribute((const void*)gemm_nt8p_kernel<ACT_MASK_BITS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    hipFuncSetAttribute((const void*)gemm_nt8p_kernel<ACT_MASK_BITS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipFuncSetAttribute((const void*)gemm_nt8p_kernel<ACT_NONE, false, false, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipFuncSetAttribute((const void*)gemm_nt8p_kernel<ACT_RELU, false, false, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipFuncSetAttribute((const void*)gemm_nt8p_kernel<ACT_NONE, true, false, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipFuncSetAttribute((const void*)gemm_nt8p_kernel<ACT_MASK, false, false, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipFuncSetAttribute((const void*)gemm_nt8p_kernel<ACT_MASK, true, false, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipFuncSetAttribute((const void*)gemm_nt8p_kernel<ACT_RELU_BITS, false, false, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipFuncSetAttribute((const void*)gemm_nt8p_kernel<ACT_MASK_BITS, false, false, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipFuncSetAttribute((const void*)gemm_nt8p_kernel<ACT_MASK_BITS, true, false, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
@@ -1151,6 +1184,7 @@ static int launch_nt8p(const GemmNT& p, hipStream_t stream) {
   const bool cs = p.colsum_ws != nullptr;
   if (cs) (void)hipMemsetAsync(p.colsum_ws, 0, (size_t)grid * 2 * p.N * sizeof(float), stream);   // the workgroups accumulate into it
   const dim3 g(grid), b(512);
+  if (p.split && F16) return SNERF_ERR_ARG;
   if (p.split) {                                         // split-bf16 flavours (no bf16-aux mask: the data gradients use the bit masks)
     static bool sattr = false;
     if (!sattr) {
@@ -1178,21 +1212,21 @@ static int launch_nt8p(const GemmNT& p, hipStream_t stream) {
     else return SNERF_ERR_ARG;
   } else
   if (p.act == ACT_MASK) {
-    if (cs) hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_MASK, true>), g, b, LDS, stream, p);
-    else hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_MASK, false>), g, b, LDS, stream, p);
+    if (cs) hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_MASK, true, false, F16>), g, b, LDS, stream, p);
+    else hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_MASK, false, false, F16>), g, b, LDS, stream, p);
   } else if (p.act == ACT_MASK_BITS) {
-    if (cs) hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_MASK_BITS, true>), g, b, LDS, stream, p);
-    else hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_MASK_BITS, false>), g, b, LDS, stream, p);
+    if (cs) hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_MASK_BITS, true, false, F16>), g, b, LDS, stream, p);
+    else hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_MASK_BITS, false, false, F16>), g, b, LDS, stream, p);
   } else if (p.act == ACT_RELU_BITS) {
     if (cs) return SNERF_ERR_ARG;
-    hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_RELU_BITS, false>), g, b, LDS, stream, p);
+    hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_RELU_BITS, false, false, F16>), g, b, LDS, stream, p);
   } else if (cs) {
     if (p.act != ACT_NONE) return SNERF_ERR_ARG;
-    hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_NONE, true>), g, b, LDS, stream, p);
+    hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_NONE, true, false, F16>), g, b, LDS, stream, p);
   } else if (p.act == ACT_RELU) {
-    hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_RELU, false>), g, b, LDS, stream, p);
+    hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_RELU, false, false, F16>), g, b, LDS, stream, p);
   } else {
-    hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_NONE, false>), g, b, LDS, stream, p);
+    hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_NONE, false, false, F16>), g, b, LDS, stream, p);
   }
   if (p.colsum_ws != nullptr) {
     const int rows = grid * 2;                            // one partial row per (workgroup, wave row)
@@ -1217,6 +1251,9 @@ extern "C" int snerf_linear_fwd(const void* A, long lda, const void* W, long ldw
     dtype = SNERF_DT_BF16;
     K *= 3;
   }
+  // SNERF_DT_F16: the bf16 kernels with the fp16 MFMA and fp16 conversions (same tiles, same layouts, same rate)
+  const bool f16 = dtype == 2;
+  if (f16) dtype = SNERF_DT_BF16;
   if (dtype != SNERF_DT_F32 && dtype != SNERF_DT_BF16) return SNERF_ERR_ARG;
   const int bke = dtype == SNERF_DT_F32 ? 32 : 64;
   if (K % bke != 0 || lda % (bke / 8) != 0 || ldw % (bke / 8) != 0) return SNERF_ERR_ARG;
@@ -1250,6 +1287,12 @@ extern "C" int snerf_linear_fwd(const void* A, long lda, const void* W, long ldw
                   (lda * 2 * 256 < (1L << 31)) && (ldw * 2 * 256 < (1L << 31)) && !(split && (act == ACT_MASK || (colsum != nullptr && act == ACT_RELU_BITS)));
   if (act >= ACT_RELU_BITS && !(p8 && (long)((M + 255) / 256) * 8 * (N / 64) * 256 < (1L << 31)))
     return SNERF_ERR_ARG;
+  if (f16) {
+    if (p8) return launch_nt8p<true>(p, s);
+    if ((variant & 12) && N % 256 == 0) return launch_nt8<true>(p, s);
+    if ((variant & 1) && N % 256 == 0) return launch_nt<__bf16, 256, 256, 2, 4, true>(p, s);
+    return launch_nt<__bf16, 128, 128, 2, 2, true>(p, s);
+  }
   if (p8) return launch_nt8p(p, s);
   if (dtype == SNERF_DT_BF16 && (variant & 12) && N % 256 == 0) return launch_nt8(p, s);
   if (dtype == SNERF_DT_F32) return launch_nt<float, 128, 128, 2, 2>(p, s);
@@ -1284,7 +1327,7 @@ struct GemmTN {
 };
 
 // TN_STAGES: slots of the staging ring of the 128 x 128 weight-gradient kernel (16 KiB per slot)
-template <typename T, bool TR, int TN_STAGES>
+template <typename T, bool TR, int TN_STAGES, bool F16 = false>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int EPC = 16 / (int)sizeof(T);
@@ -1406,7 +1449,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < 2; ++j) mma32t<F16>(acc[i][j], a[i], b[j]);
       }
     } else {
 #pragma unroll
@@ -1425,7 +1468,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i].v, b[j].v, acc[i][j], 0, 0, 0);
+          for (int j = 0; j < 2; ++j) mma32t<F16>(acc[i][j], a[i].v, b[j].v);
       }
     }
   }
@@ -1460,7 +1503,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
 //     dZ half h, local column lc  <->  tile column (lc>>6)*128 + h*64 + (lc&63)     (wave row wr = lc>>6)
 //     X  half g, local column lc  <->  tile column (lc>>5)*64  + g*32 + (lc&31)     (wave col wc = lc>>5)
 // ---------------------------------------------------------------------------
-template <bool SPLIT>
+template <bool SPLIT, bool F16 = false>
 __global__ __launch_bounds__(512) void gemm_tn8_kernel(GemmTN p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __bf16 T;
@@ -1598,8 +1641,8 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(GemmTN p) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       bS[S][ks] = lds_b(db, S, ks);
-      mma32(acc[0][F], aF[0][ks], bS[F][ks]);
-      mma32(acc[1][F], aF[1][ks], bS[F][ks]);
+      mma32t<F16>(acc[0][F], aF[0][ks], bS[F][ks]);
+      mma32t<F16>(acc[1][F], aF[1][ks], bS[F][ks]);
       __builtin_amdgcn_sched_barrier(0);
     }
     if (wr == 0) { stage(db, 2 + F); wait_load(); }
@@ -1610,7 +1653,7 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(GemmTN p) {
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
       for (int i2 = 0; i2 < 2; ++i2) {
-        mma32(acc[i2][S], aF[i2][ks], bS[S][ks]);
+        mma32t<F16>(acc[i2][S], aF[i2][ks], bS[S][ks]);
         aF[i2][ks] = lds_a(db, 1, i2, ks);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -1622,8 +1665,8 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(GemmTN p) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       if constexpr (!skip3) {
-        mma32(acc[2][S], aF[0][ks], bS[S][ks]);
-        mma32(acc[3][S], aF[1][ks], bS[S][ks]);
+        mma32t<F16>(acc[2][S], aF[0][ks], bS[S][ks]);
+        mma32t<F16>(acc[3][S], aF[1][ks], bS[S][ks]);
       }
       bS[S][ks] = lds_b(db ^ 1, S, ks);
       __builtin_amdgcn_sched_barrier(0);
@@ -1636,7 +1679,7 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(GemmTN p) {
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
       for (int i2 = 0; i2 < 2; ++i2) {
-        if constexpr (!skip4) mma32(acc[2 + i2][F], aF[i2][ks], bS[F][ks]);
+        if constexpr (!skip4) mma32t<F16>(acc[2 + i2][F], aF[i2][ks], bS[F][ks]);
         aF[i2][ks] = lds_a(db ^ 1, 0, i2, ks);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -1740,6 +1783,8 @@ static int wgrad_launch(const void* Z, long ldz, const void* X, long ldx, float*
     if (N % 128 != 0 || K % 128 != 0 || ws != nullptr) return SNERF_ERR_ARG;        // (no deterministic fold in this mode)
     dtype = SNERF_DT_BF16;
   }
+  const bool f16 = dtype == 2;                        // SNERF_DT_F16: the bf16 kernels with the fp16 MFMA
+  if (f16) dtype = SNERF_DT_BF16;
   const int epc = dtype == SNERF_DT_F32 ? 4 : 8;
   if (N < epc || K < epc || N % epc || K % epc || ldz % epc || ldx % epc || zeros == nullptr) return SNERF_ERR_ARG;
   const TnPlan pl = tn_plan(M, N, K, ldz, ldx, dtype, variant);
@@ -1753,7 +1798,11 @@ static int wgrad_launch(const void* Z, long ldz, const void* X, long ldx, float*
       attr_set = true;
     }
     const int t8 = (N / 256) * ((K + 255) / 256);
-    if (split) hipLaunchKernelGGL(gemm_tn8_kernel<true>, dim3(t8 * pl.slices), dim3(512), 8 * 64 * 256, (hipStream_t)stream, p);
+    if (f16) {
+      static bool attr16 = false;
+      if (!attr16) { hipFuncSetAttribute((const void*)gemm_tn8_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 64 * 256); attr16 = true; }
+      hipLaunchKernelGGL((gemm_tn8_kernel<false, true>), dim3(t8 * pl.slices), dim3(512), 8 * 64 * 256, (hipStream_t)stream, p);
+    } else if (split) hipLaunchKernelGGL(gemm_tn8_kernel<true>, dim3(t8 * pl.slices), dim3(512), 8 * 64 * 256, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(gemm_tn8_kernel<false>, dim3(t8 * pl.slices), dim3(512), 8 * 64 * 256, (hipStream_t)stream, p);
   } else {
     const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
@@ -1775,7 +1824,18 @@ static int wgrad_launch(const void* Z, long ldz, const void* X, long ldx, float*
     // inside a 256-byte row); variant 0: 16-bit LDS gathers
     const bool tr = (variant & 1) && dtype == SNERF_DT_BF16 && (N % 128 == 0) && (K % 128 == 0);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == SNERF_DT_F32) {
+    if (f16) {
+      static bool tn16_attr = false;
+      if (!tn16_attr) {
+        hipFuncSetAttribute((const void*)gemm_tn_kernel<__bf16, true, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 8192);
+        hipFuncSetAttribute((const void*)gemm_tn_kernel<__bf16, false, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 8192);
+        tn16_attr = true;
+      }
+      if (tr) { if (deep) hipLaunchKernelGGL((gemm_tn_kernel<__bf16, true, 4, true>), grid, dim3(256), lds, st, p);
+                else hipLaunchKernelGGL((gemm_tn_kernel<__bf16, true, 2, true>), grid, dim3(256), lds, st, p); }
+      else { if (deep) hipLaunchKernelGGL((gemm_tn_kernel<__bf16, false, 4, true>), grid, dim3(256), lds, st, p);
+             else hipLaunchKernelGGL((gemm_tn_kernel<__bf16, false, 2, true>), grid, dim3(256), lds, st, p); }
+    } else if (dtype == SNERF_DT_F32) {
       if (deep) hipLaunchKernelGGL((gemm_tn_kernel<float, false, 4>), grid, dim3(256), lds, st, p);
       else hipLaunchKernelGGL((gemm_tn_kernel<float, false, 2>), grid, dim3(256), lds, st, p);
     } else if (dtype == SNERF_DT_BF16 && tr) {
@@ -1801,6 +1861,7 @@ extern "C" int snerf_linear_wgrad(const void* Z, long ldz, const void* X, long l
 // kernel folds them in slice order -- bit-reproducible run to run, no atomics ("deterministic mode").
 extern "C" long snerf_linear_wgrad_ws_floats(int M, int N, int K, long ldz, long ldx, int dtype, int variant) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
+  if (dtype == 2) dtype = SNERF_DT_BF16;              // (SNERF_DT_F16 runs the bf16 kernels' plan)
   const TnPlan pl = tn_plan(M, N, K, ldz, ldx, dtype, variant);
   return pl.part_stride * pl.slices;
 }

@@ -103,7 +103,7 @@ def relu_bits_ok(A, W, Y, K, n_store, dt, variant, consumer=False):
     """Whether snerf_linear_fwd accepts ACT_RELU_BITS (producer) / ACT_MASK_BITS (consumer) for this launch: the persistent
     8-phase kernel's conditions (mirrors the dispatch in gemm.hip)."""
     N = W.shape[0]
-    return (dt in (BF16, BF16X3) and (variant & 8) and N % 256 == 0 and K * (3 if dt == BF16X3 else 1) >= 128 and Y.dtype == torch.bfloat16
+    return (dt in (BF16, BF16X3, F16) and (variant & 8) and N % 256 == 0 and K * (3 if dt == BF16X3 else 1) >= 128 and Y.dtype == _TORCH_DT[dt]
             and Y.stride(0) % 8 == 0 and Y.data_ptr() % 16 == 0 and n_store % 8 == 0
             and A.stride(0) * 512 < (1 << 31) and W.stride(0) * 512 < (1 << 31) and mask_bits_words(A.shape[0], N) * 4 < (1 << 31))
 

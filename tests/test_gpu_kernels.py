@@ -39,7 +39,10 @@ def gen(*shape, seed=0, scale=1.0):
 @pytest.mark.parametrize("dt,M,N,K,variant", [(0, 300, 128, 96, 0), (0, 1000, 256, 1120, 0), (1, 300, 128, 128, 0),
                                               (1, 1000, 256, 1152, 0), (1, 777, 256, 320, 1), (1, 2048, 1024, 1024, 1),
                                               (1, 777, 256, 320, 4), (1, 2048, 1024, 1024, 4), (1, 1000, 512, 64, 4), (1, 1000, 256, 192, 4),
-                                              (1, 777, 256, 320, 8), (1, 2048, 1024, 1024, 8), (1, 70000, 512, 128, 8), (1, 100000, 256, 192, 8)])
+                                              (1, 777, 256, 320, 8), (1, 2048, 1024, 1024, 8), (1, 70000, 512, 128, 8), (1, 100000, 256, 192, 8),
+                                              # fp16 (dtype 2): the same kernels with the fp16 MFMA and conversions -- 3 more mantissa bits than bf16
+                                              (2, 300, 128, 128, 0), (2, 777, 256, 320, 1), (2, 2048, 1024, 1024, 4), (2, 777, 256, 320, 8),
+                                              (2, 70000, 512, 128, 8), (2, 100000, 256, 192, 8)])
 def test_linear_fwd(ops, dt, M, N, K, variant):
     tdt = ops.torch_dtype(dt)
     A = gen(M, K + ops.gran(dt), seed=1).to(tdt).cuda()            # wider buffer: lda != K
@@ -49,18 +52,19 @@ def test_linear_fwd(ops, dt, M, N, K, variant):
     ref = torch.relu(A[:, :K].double().cpu() @ W.double().cpu().t() + bias.double().cpu())[:, :n_store]
     Y = torch.full((M, N), 7.0, dtype=tdt, device="cuda")
     ops.linear_fwd(A, W, bias, Y, K, n_store, ops.ACT_RELU, dt, variant=variant)
-    tol = 1e-5 if dt == 0 else 1e-2
+    tol = {0: 1e-5, 1: 1e-2, 2: 1.5e-3}[dt]
     close(Y[:, :n_store], ref, tol, tol, "relu out")
     assert bool((Y[:, n_store:] == 7.0).all()), "columns >= n_store must not be written"
     # fp32 output, no activation, column-offset destination
     Y2 = torch.zeros(M, 4, dtype=torch.float32, device="cuda")
     ops.linear_fwd(A, W, bias, Y2[:, 3:], K, 1, ops.ACT_NONE, dt, out_f32=True, variant=variant)
     ref2 = (A[:, :K].double().cpu() @ W.double().cpu().t() + bias.double().cpu())[:, :1]
-    close(Y2[:, 3:], ref2, 1e-5 if dt == 0 else 2e-3, 1e-5 if dt == 0 else 2e-3, "head out")
+    close(Y2[:, 3:], ref2, 1e-5 if dt == 0 else 2e-3, 1e-5 if dt == 0 else 2e-3, "head out")       # (fp32 accumulation of 16-bit products)
     assert bool((Y2[:, :3] == 0).all())
 
 
-@pytest.mark.parametrize("dt,variant,M", [(0, 0, 515), (1, 0, 515), (1, 1, 515), (1, 4, 515), (1, 8, 515), (1, 8, 70001)])
+@pytest.mark.parametrize("dt,variant,M", [(0, 0, 515), (1, 0, 515), (1, 1, 515), (1, 4, 515), (1, 8, 515), (1, 8, 70001), (2, 0, 515), (2, 4, 515),
+                                          (2, 8, 515), (2, 8, 70001)])
 def test_linear_dgrad_mask_colsum(ops, dt, variant, M):
     tdt = ops.torch_dtype(dt)
     Nred, Kout = 192, 256
@@ -71,14 +75,15 @@ def test_linear_dgrad_mask_colsum(ops, dt, variant, M):
     cs = torch.zeros(Kout, dtype=torch.float32, device="cuda")
     ops.linear_fwd(dZ, Wt, None, dX, Nred, Kout, ops.ACT_MASK, dt, aux=act, colsum=cs, variant=variant)
     ref = (dZ.double().cpu() @ Wt.double().cpu().t()) * (act.double().cpu() > 0)
-    tol = 1e-5 if dt == 0 else 1e-2
+    tol = {0: 1e-5, 1: 1e-2, 2: 1.5e-3}[dt]
     close(dX, ref, tol, tol, "dgrad")
     close(cs, ref.sum(0), 1e-4 if dt == 0 else 2e-2, (1e-3 if dt == 0 else 5e-2) * max(1.0, (M / 515) ** 0.5), "colsum")
 
 
 @pytest.mark.parametrize("dt,M,N,K,nv,kv", [(0, 700, 96, 128, 90, 127), (0, 5000, 256, 1120, 256, 1120), (1, 700, 64, 128, 3, 128),
                                             (1, 5000, 256, 320, 256, 283), (1, 3000, 1024, 1152, 1024, 1120), (1, 4100, 256, 128, 256, 96), (1, 2077, 128, 1024, 128, 1024),
-                                            (1, 70001, 1024, 1152, 1024, 1120), (1, 9000, 256, 320, 256, 283), (1, 33000, 512, 256, 500, 256)])
+                                            (1, 70001, 1024, 1152, 1024, 1120), (1, 9000, 256, 320, 256, 283), (1, 33000, 512, 256, 500, 256),
+                                            (2, 700, 64, 128, 3, 128), (2, 5000, 256, 320, 256, 283), (2, 70001, 1024, 1152, 1024, 1120), (2, 33000, 512, 256, 500, 256)])
 def test_linear_wgrad(ops, dt, M, N, K, nv, kv):
     tdt = ops.torch_dtype(dt)
     dZ = gen(M, N, seed=7).to(tdt).cuda()
@@ -90,14 +95,14 @@ def test_linear_wgrad(ops, dt, M, N, K, nv, kv):
         close(dW, ref, 1e-4, 1e-3 * (M / 1000) ** 0.5, f"wgrad variant {variant}")
 
 
-@pytest.mark.parametrize("M,N,K", [(1000, 256, 256), (70001, 512, 320), (4096, 1024, 1024)])
-def test_relu_bit_mask_roundtrip(ops, M, N, K):
-    """ACT_RELU_BITS writes the activation AND a 1-bit mask; ACT_MASK_BITS must reproduce ACT_MASK on that activation exactly."""
-    dt = 1
-    A = gen(M, K, seed=21).to(torch.bfloat16).cuda()
-    W = (gen(N, K, seed=22) / K ** 0.5).to(torch.bfloat16).cuda()
+@pytest.mark.parametrize("M,N,K,dt", [(1000, 256, 256, 1), (70001, 512, 320, 1), (4096, 1024, 1024, 1), (1000, 256, 256, 2), (70001, 512, 320, 2)])
+def test_relu_bit_mask_roundtrip(ops, M, N, K, dt):
+    """ACT_RELU_BITS writes the activation AND a 1-bit mask; ACT_MASK_BITS must reproduce ACT_MASK on that activation exactly (bf16 and fp16)."""
+    h16 = ops.torch_dtype(dt)
+    A = gen(M, K, seed=21).to(h16).cuda()
+    W = (gen(N, K, seed=22) / K ** 0.5).to(h16).cuda()
     bias = gen(N, seed=23).cuda()
-    h_ref = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    h_ref = torch.empty(M, N, dtype=h16, device="cuda")
     ops.linear_fwd(A, W, bias, h_ref, K, N, ops.ACT_RELU, dt, variant=8)
     h = torch.empty_like(h_ref)
     bits = torch.zeros(ops.mask_bits_words(M, N), dtype=torch.int32, device="cuda")
@@ -108,13 +113,13 @@ def test_relu_bit_mask_roundtrip(ops, M, N, K):
     assert 0.2 < frac < 0.8
     # data gradient of the next layer: dX[M, N] = dZ[M, K2] . Wt[N, K2]^T masked by h > 0
     K2 = 256 if M != 70001 else 128                              # 128: two k-tiles, the mask DMA is drained explicitly
-    dZ = gen(M, K2, seed=24).to(torch.bfloat16).cuda()
-    Wt = (gen(N, K2, seed=25) / K2 ** 0.5).to(torch.bfloat16).cuda()
+    dZ = gen(M, K2, seed=24).to(h16).cuda()
+    Wt = (gen(N, K2, seed=25) / K2 ** 0.5).to(h16).cuda()
     for with_cs in (True, False):
         cs1 = torch.zeros(N, device="cuda") if with_cs else None
         cs2 = torch.zeros(N, device="cuda") if with_cs else None
-        d1 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
-        d2 = torch.full((M, N), 3.0, dtype=torch.bfloat16, device="cuda")
+        d1 = torch.empty(M, N, dtype=h16, device="cuda")
+        d2 = torch.full((M, N), 3.0, dtype=h16, device="cuda")
         ops.linear_fwd(dZ, Wt, None, d1, K2, N, ops.ACT_MASK, dt, aux=h_ref, colsum=cs1, variant=8)
         assert ops.relu_bits_ok(dZ, Wt, d2, K2, N, dt, 8, consumer=True)
         ops.linear_fwd(dZ, Wt, None, d2, K2, N, ops.ACT_MASK_BITS, dt, aux=bits, colsum=cs2, variant=8)
