@@ -285,11 +285,13 @@ def counter_bytes(key):
         return None, f"unavailable: {e}"
 
 
-def path_c_leg(device, n_rays=65536, steps=5, compute="bf16"):
+def path_c_leg(device, n_rays=65536, steps=5, compute="fp16", also=("bf16",)):
     """BASELINE configs 4-5 (S-NeRF++ / zipnerf background, waymo.gin shape: 64 + 64 + 32 intervals x 7 multisamples, hash grids
     L = 6 / 8 / 10, T = 2^21): ZipTrainer train step at 65 536 rays (configs.py:29), forward only, and the whole 1920 x 1280 frame through
     zipnerf.render_image (compute_extras like random_render_waymo_seq.py:197).  Roofline of the dominant kernel (hash-grid gather of the
-    NeRF level inside the fused featurisation): useful bytes / its event-timed launch."""
+    NeRF level inside the fused featurisation): useful bytes / its event-timed launch.
+    `compute`: the networks' arithmetic -- "fp16" is what BASELINE configs[3] names ("fp16 MLP": zipnerf/train.py:215 autocast); the train
+    step of every mode in `also` is timed beside it on the same batch."""
     import types
     from snerf_amd import ops, zipnerf
     from snerf_amd.trainer import ZipTrainer
@@ -347,12 +349,13 @@ def path_c_leg(device, n_rays=65536, steps=5, compute="bf16"):
     ok = img["rgb"].shape == (H_, W_, 3) and bool(torch.isfinite(img["rgb"]).all())
     useful = [R * 7 * 64 * 6 * 8 * 4, R * 7 * 64 * 8 * 8 * 4, R * 7 * 32 * 10 * 8 * 4 * 2]       # prop 0 / prop 1 (fp32, C = 1), NeRF (fp16, C = 4)
     cb, cb_src = counter_bytes("zip_encode_fwd_all_nerf_train")
-    rl = {"bound": "hbm", "kernel": "zip_encode_fwd_all_kernel<half, bf16, 4, COUNT> (NeRF-level hash-grid gather of the train step)",
+    rl = {"bound": "hbm", "kernel": "zip_encode_fwd_all_kernel<half, %s, 4, COUNT> (NeRF-level hash-grid gather of the train step)" % {"fp16": "_Float16", "bf16": "bf16", "f32": "float"}[compute],
           "achieved": round(useful[2] / (enc_train[2] * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
           "frac": round(useful[2] / (enc_train[2] * 1e-3) / 1e9 / 8000.0, 4), "useful_bytes_per_launch": useful[2],
           "traffic": cb, "traffic_source": cb_src, "launch_ms": round(enc_train[2], 3)}
     out = {"workload": "BASELINE configs[3] / [4]: zipnerf Model (waymo.gin: 64 + 64 + 32 intervals x 7 multisamples, grids L = 6 / 8 / 10, T = 2^21, "
-                       "NeRF table fp16), ZipTrainer step with depth targets; bf16 MLPs",
+                       "NeRF table fp16), ZipTrainer step with depth targets; %s MLPs%s" % (compute, " (static loss scale %g folded into Adam)" % tr.loss_scale if tr.loss_scale != 1 else ""),
+           "dtype": compute,
            "rays_per_step": R, "steps": steps, "train_ms_per_step": round(dt_train * 1e3, 3), "train_rays_per_s": round(R / dt_train, 1),
            "fwd_ms": round(dt_fwd * 1e3, 3), "fwd_rays_per_s": round(R / dt_fwd, 1),
            "frame_1920x1280_ms": round(dt_frame * 1e3, 1), "frame_ok": ok,
@@ -364,6 +367,14 @@ def path_c_leg(device, n_rays=65536, steps=5, compute="bf16"):
            "roofline": rl, "losses_last_step": [round(v, 6) for v in tr.last_losses.cpu().tolist()]}
     del tr, m, frame, fr, img
     torch.cuda.empty_cache()
+    for other in also:                                   # the same train step in the other reduced-precision mode(s)
+        torch.manual_seed(0)
+        m2 = zipnerf.Model(config=None, raydist_fn='power_transformation', opaque_background=True, compute=other, table_dtype="ref", init_std=0.1, device=device)
+        tr2 = ZipTrainer(m2, lr=1e-2)
+        dt2 = _timeit(lambda: tr2.step(batch, tgt, train_frac=0.5, rand=True, targets=targets), steps, warm=3)
+        out["train_ms_per_step_" + other] = round(dt2 * 1e3, 3)
+        del tr2, m2
+        torch.cuda.empty_cache()
     return out
 
 

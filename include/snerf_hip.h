@@ -24,7 +24,7 @@ extern "C" {
 
 #define SNERF_DT_F32 0
 #define SNERF_DT_BF16 1
-#define SNERF_DT_F16 2 /* hash-grid tables only */
+#define SNERF_DT_F16 2 /* hash-grid tables; the fp16 compute mode of path C (GEMMs: fp16 operands on the f16 MFMA, fp32 accumulation; features, activations, packed weights) */
 #define SNERF_DT_F64 3 /* stand-alone GridEncoder operator only (the reference dispatches float / double / half) */
 #define SNERF_DT_BF16X3 4 /* snerf_linear_fwd / snerf_linear_wgrad only: split-bf16 operands (the fp32-parity mode at bf16 MFMA rates) */
 #define SNERF_ACT_NONE 0
@@ -196,7 +196,8 @@ int snerf_zip_encode_fwd_count(const float* tdist, const float* origins, const f
  * Linear(hidden -> 1) on the grid features) as one launch each way instead of per-layer GEMMs over 64-column padded buffers: F [P, ldf]
  * (feat_dtype fp32 / bf16, L <= 16 feature columns, ldf >= L -- a compact buffer), parameters fp32 in the reference's layouts
  * (density_layer.0.weight [hidden, L], .bias [hidden], density_layer.2.weight [1, hidden], .bias [1]; hidden <= 64), raw [P] fp32.
- * round_bf16: the rounding points of the bf16 GEMM route (bf16 weights and stored activations, fp32 accumulation).  The backward
+ * round_bf16: rounding mode = the rounding points of the GEMM route in that compute dtype (weights and stored activations rounded, fp32
+ * accumulation): 0 none (fp32), 1 bf16, 2 fp16 (requires feat_dtype SNERF_DT_F16).  The backward
  * recomputes the hidden activations from F, writes dF [P, lddf] (columns L .. lddf - 1 zero; lddf <= 64) and adds the parameter
  * gradients into g_* (fp32, same layouts) by per-workgroup partial sums folded in a fixed order (bit-reproducible);
  * ws: snerf_zip_prop_mlp_ws_floats(L, hidden, P) floats of scratch. */
@@ -397,7 +398,7 @@ int snerf_mip_viewenc_bwd(const float* viewdirs, long n_rays, int S, int deg, co
 /* Inference of one zipnerf PROPOSAL level in a single launch: snerf_zip_encode_fwd for the single-channel grid (C = 1) followed by the
  * proposal MLP on the features still in registers -- density_layer = Linear(L, hidden) + ReLU + Linear(hidden, 1)
  * (internal/models.py:425-427, 481-519 with disable_rgb).  w1 [hidden, L], b1 [hidden], w2 [hidden], b2 [1]: fp32 device pointers (the
- * state_dict tensors prop_mlp_i.density_layer.{0,2}.{weight,bias}); round_bf16 = 1 reproduces the bf16 GEMM path's roundings
+ * state_dict tensors prop_mlp_i.density_layer.{0,2}.{weight,bias}); round_bf16 = 1 (bf16) / 2 (fp16) reproduces that GEMM path's roundings
  * (features, weights, hidden layer), 0 = fp32 throughout.  raw_density [R*S] fp32. */
 int snerf_zip_encode_prop_fwd(const float* tdist, const float* origins, const float* directions, const float* radii, const float* base_x,
                               const float* base_y, const float* deg_jitter, const void* table, const int* offsets, const int* grid_sizes,

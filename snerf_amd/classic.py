@@ -113,7 +113,7 @@ class _ArenaModule(nn.Module):
 
 
 def _dt(compute: str) -> int:
-    return {"bf16": ops.BF16, "f32": ops.F32, "fp32": ops.F32, "bf16x3": ops.BF16X3}[compute]
+    return {"bf16": ops.BF16, "f32": ops.F32, "fp32": ops.F32, "bf16x3": ops.BF16X3, "fp16": ops.F16, "f16": ops.F16}[compute]
 
 
 class NeRF(_ArenaModule):

@@ -9,11 +9,13 @@
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 h16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 #define SNERF_DT_F32 0
 #define SNERF_DT_BF16 1
+#define SNERF_DT_F16 2
 #define SNERF_DT_F64 3   // hash-grid tables of the stand-alone GridEncoder operator only
 #define SNERF_DT_BF16X3 4  // GEMM entries only: split-bf16 operands (hi = bf16(x), lo = bf16(x - hi); three MFMA passes), gemm.hip
 
@@ -72,4 +74,5 @@ __device__ __forceinline__ float wave_incl_scan_mul(float v, int lane) {
 template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ __bf16 from_f32<__bf16>(float v) { return (__bf16)v; }
+template <> __device__ __forceinline__ _Float16 from_f32<_Float16>(float v) { return (_Float16)v; }   // (the fp16 compute mode, dtype SNERF_DT_F16)
 template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }

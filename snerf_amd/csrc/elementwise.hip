@@ -213,32 +213,36 @@ __global__ __launch_bounds__(256) void cast_pad_kernel(const float* __restrict__
   }
 }
 
-// bf16, Cpad % 8 == 0, 16-byte aligned rows: one thread per 8 consecutive outputs of a row (one 16-byte store)
-__global__ __launch_bounds__(256) void cast_pad8_kernel(const float* __restrict__ src, long ld_src, long M, int C, int G, __bf16* __restrict__ dst,
+// 16-bit outputs, Cpad % 8 == 0, 16-byte aligned rows: one thread per 8 consecutive outputs of a row (one 16-byte store)
+template <typename T>
+__global__ __launch_bounds__(256) void cast_pad8_kernel(const float* __restrict__ src, long ld_src, long M, int C, int G, T* __restrict__ dst,
                                                         long ld_dst) {
+  typedef __attribute__((ext_vector_type(8))) T vec8;
   const long total = M * G;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
     const long m = e / G;
     const int c0 = (int)(e - m * G) * 8;
-    bf16x8 o;
+    vec8 o;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) o[k] = (__bf16)(c0 + k < C ? src[m * ld_src + c0 + k] : 0.f);
-    *(bf16x8*)(dst + m * ld_dst + c0) = o;
+    for (int k = 0; k < 8; ++k) o[k] = (T)(c0 + k < C ? src[m * ld_src + c0 + k] : 0.f);
+    *(vec8*)(dst + m * ld_dst + c0) = o;
   }
 }
 
 extern "C" int snerf_cast_pad(const float* src, long ld_src, long M, int C, int Cpad, void* dst, long ld_dst, int dtype, void* stream) {
   if (M <= 0) return SNERF_OK;
   if (C < 0 || Cpad < C) return SNERF_ERR_ARG;
-  if (dtype == SNERF_DT_BF16 && (Cpad % 8) == 0 && (ld_dst % 8) == 0 && (((uintptr_t)dst) & 15) == 0) {
+  if ((dtype == SNERF_DT_BF16 || dtype == SNERF_DT_F16) && (Cpad % 8) == 0 && (ld_dst % 8) == 0 && (((uintptr_t)dst) & 15) == 0) {
     const long total8 = M * (Cpad / 8);
     const int blocks8 = (int)((total8 + 255) / 256 < 16384 ? (total8 + 255) / 256 : 16384);
-    hipLaunchKernelGGL(cast_pad8_kernel, dim3(blocks8), dim3(256), 0, (hipStream_t)stream, src, ld_src, M, C, Cpad / 8, (__bf16*)dst, ld_dst);
+    if (dtype == SNERF_DT_BF16) hipLaunchKernelGGL(cast_pad8_kernel<__bf16>, dim3(blocks8), dim3(256), 0, (hipStream_t)stream, src, ld_src, M, C, Cpad / 8, (__bf16*)dst, ld_dst);
+    else hipLaunchKernelGGL(cast_pad8_kernel<_Float16>, dim3(blocks8), dim3(256), 0, (hipStream_t)stream, src, ld_src, M, C, Cpad / 8, (_Float16*)dst, ld_dst);
     return snerf_check_launch();
   }
   const long total = M * Cpad;
   const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
   if (dtype == SNERF_DT_F32) hipLaunchKernelGGL(cast_pad_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, ld_src, M, C, Cpad, (float*)dst, ld_dst);
+  else if (dtype == SNERF_DT_F16) hipLaunchKernelGGL(cast_pad_kernel<_Float16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, ld_src, M, C, Cpad, (_Float16*)dst, ld_dst);
   else hipLaunchKernelGGL(cast_pad_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, ld_src, M, C, Cpad, (__bf16*)dst, ld_dst);
   return snerf_check_launch();
 }
@@ -313,6 +317,7 @@ extern "C" int snerf_app_embed(const float* emb, const float* app, int n_vocab, 
   const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
   if (dtype == SNERF_DT_F32) hipLaunchKernelGGL(app_embed_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, emb, app, n_vocab, M, S, dim, (float*)dst, ld, sample_id);
   else if (dtype == SNERF_DT_BF16) hipLaunchKernelGGL(app_embed_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, emb, app, n_vocab, M, S, dim, (__bf16*)dst, ld, sample_id);
+  else if (dtype == SNERF_DT_F16) hipLaunchKernelGGL(app_embed_kernel<_Float16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, emb, app, n_vocab, M, S, dim, (_Float16*)dst, ld, sample_id);
   else return SNERF_ERR_ARG;
   return snerf_check_launch();
 }
@@ -406,6 +411,7 @@ extern "C" int snerf_gather_pack(const float* flat, const int* idx, long n, void
   const int blocks = (int)(want < 4096 ? want : 4096);
   if (dtype == SNERF_DT_F32) hipLaunchKernelGGL(gather_pack_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, flat, idx, n, (float*)dst);
   else if (dtype == SNERF_DT_BF16) hipLaunchKernelGGL(gather_pack_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, flat, idx, n, (__bf16*)dst);
+  else if (dtype == SNERF_DT_F16) hipLaunchKernelGGL(gather_pack_kernel<_Float16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, flat, idx, n, (_Float16*)dst);
   else return SNERF_ERR_ARG;
   return snerf_check_launch();
 }

@@ -375,6 +375,7 @@ extern "C" int snerf_mip_viewenc(const float* viewdirs, long n_rays, int S, int 
   if (sample_id == nullptr) {
     const dim3 g((unsigned)((n_rays + 3) / 4)), b(256);
     if (dtype == SNERF_DT_F32) hipLaunchKernelGGL(mip_viewenc_rays_kernel<float>, g, b, 0, (hipStream_t)stream, viewdirs, n_rays, S, deg, (float*)dst, ld, width);
+    else if (dtype == SNERF_DT_F16) hipLaunchKernelGGL(mip_viewenc_rays_kernel<_Float16>, g, b, 0, (hipStream_t)stream, viewdirs, n_rays, S, deg, (_Float16*)dst, ld, width);
     else hipLaunchKernelGGL(mip_viewenc_rays_kernel<__bf16>, g, b, 0, (hipStream_t)stream, viewdirs, n_rays, S, deg, (__bf16*)dst, ld, width);
     return snerf_check_launch();
   }
@@ -382,6 +383,8 @@ extern "C" int snerf_mip_viewenc(const float* viewdirs, long n_rays, int S, int 
   const int blocks = (int)((total + 255) / 256 < 262144 ? (total + 255) / 256 : 262144);
   if (dtype == SNERF_DT_F32)
     hipLaunchKernelGGL(mip_viewenc_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, viewdirs, S, M, deg, (float*)dst, ld, width, sample_id);
+  else if (dtype == SNERF_DT_F16)
+    hipLaunchKernelGGL(mip_viewenc_kernel<_Float16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, viewdirs, S, M, deg, (_Float16*)dst, ld, width, sample_id);
   else
     hipLaunchKernelGGL(mip_viewenc_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, viewdirs, S, M, deg, (__bf16*)dst, ld, width, sample_id);
   return snerf_check_launch();

@@ -661,7 +661,7 @@ __global__ __launch_bounds__(256) void zip_encode_fwd_all_kernel(ZipEnc a, ZipBi
 // in bf16, fp32 accumulation); without it everything is fp32 (parity mode).  Weights live in LDS and are read as broadcasts.
 struct ZipPropMlp { const float *w1, *b1, *w2, *b2; int hidden, rnd; float* raw_density; };
 
-__device__ __forceinline__ float zip_rbf(float v, int rnd) { return rnd ? (float)(__bf16)v : v; }
+__device__ __forceinline__ float zip_rbf(float v, int rnd) { return rnd == 1 ? (float)(__bf16)v : (rnd == 2 ? (float)(_Float16)v : v); }   // rounding mode: 0 none, 1 bf16, 2 fp16
 
 template <typename TT>
 __global__ __launch_bounds__(256) void zip_encode_prop_kernel(ZipEnc a, ZipPropMlp w) {
@@ -885,6 +885,8 @@ static int zip_enc_dispatch(const ZipEnc& a, int C, int table_dtype, int feat_dt
   if (table_dtype == SNERF_DT_F32 && feat_dtype == SNERF_DT_BF16) return zip_enc_launch<float, __bf16, BWD>(a, C, lds_levels, lds_bytes, lds_slabs, s);
   if (table_dtype == 2 && feat_dtype == SNERF_DT_F32) return zip_enc_launch<__half, float, BWD>(a, C, lds_levels, lds_bytes, lds_slabs, s);
   if (table_dtype == 2 && feat_dtype == SNERF_DT_BF16) return zip_enc_launch<__half, __bf16, BWD>(a, C, lds_levels, lds_bytes, lds_slabs, s);
+  if (table_dtype == SNERF_DT_F32 && feat_dtype == SNERF_DT_F16) return zip_enc_launch<float, _Float16, BWD>(a, C, lds_levels, lds_bytes, lds_slabs, s);
+  if (table_dtype == 2 && feat_dtype == SNERF_DT_F16) return zip_enc_launch<__half, _Float16, BWD>(a, C, lds_levels, lds_bytes, lds_slabs, s);
   return SNERF_ERR_ARG;
 }
 
@@ -928,11 +930,13 @@ struct ZipPropTrain {
 };
 
 typedef float zpm_f2 __attribute__((ext_vector_type(2)));
-template <bool RND> __device__ __forceinline__ float zpm_rb(float v) { if constexpr (RND) return (float)(__bf16)v; else return v; }
+template <int RND> __device__ __forceinline__ float zpm_rb(float v) {          // rounding mode of the compute dtype: 0 none, 1 bf16, 2 fp16
+  if constexpr (RND == 1) return (float)(__bf16)v; else if constexpr (RND == 2) return (float)(_Float16)v; else return v;
+}
 // weights in LDS, ZERO-PADDED to ZPM_H hidden units x LM feature slots: [h][LM] W1 | b1[ZPM_H] | w2[ZPM_H] | b2 -- a padded unit has
 // b1 = w2 = 0 (its activation and gradient are 0), a padded feature slot multiplies zeros: the kernels' loops have fixed trip counts
 // and no L / hidden predicates
-template <int LM, bool RND>
+template <int LM, int RND>
 __device__ __forceinline__ void zpm_load_weights(const ZipPropTrain& w, float* lw) {
   for (int k = threadIdx.x; k < ZPM_H * LM; k += 256) {
     const int h = k / LM, l = k - h * LM;
@@ -953,7 +957,8 @@ __device__ __forceinline__ void zpm_load_row(const T* f, int L, bool vec, float*
 #pragma unroll
     for (int c = 0; c < LM; c += 8) {
       if constexpr (sizeof(T) == 2) {
-        const bf16x8 v = *(const bf16x8*)(f + c);
+        typedef __attribute__((ext_vector_type(8))) T vec8;
+        const vec8 v = *(const vec8*)(f + c);
 #pragma unroll
         for (int e = 0; e < 8; ++e) feat[c + e] = (float)v[e];
       } else {
@@ -971,7 +976,7 @@ __device__ __forceinline__ void zpm_load_row(const T* f, int L, bool vec, float*
   }
 }
 
-template <typename T, int LM, bool RND>
+template <typename T, int LM, int RND>
 __global__ __launch_bounds__(256) void zip_prop_mlp_fwd_kernel(ZipPropTrain w) {
   __shared__ __attribute__((aligned(16))) float lw[ZPM_H * LM + 2 * ZPM_H + 1];
   zpm_load_weights<LM, RND>(w, lw);
@@ -1000,7 +1005,7 @@ __global__ __launch_bounds__(256) void zip_prop_mlp_fwd_kernel(ZipPropTrain w) {
 
 // LM: feature slots per interval (8 or 16 >= L).  The tile arrays hold T: in bf16 mode every value in them is a rounded bf16 already
 // (two workgroups per CU); the fp32 mode keeps floats (one workgroup per CU).
-template <typename T, int LM, bool RND>
+template <typename T, int LM, int RND>
 __global__ __launch_bounds__(256) void zip_prop_mlp_bwd_kernel(ZipPropTrain w) {
   constexpr int HP = ZPM_H + (sizeof(T) == 2 ? 2 : 1);   // row pitch of the tile arrays (written row-wise, read column-wise)
   __shared__ __attribute__((aligned(16))) float lw[ZPM_H * LM + 2 * ZPM_H + 1];
@@ -1056,10 +1061,11 @@ __global__ __launch_bounds__(256) void zip_prop_mlp_bwd_kernel(ZipPropTrain w) {
       T* o = (T*)w.dF + p * w.lddf;
       if (vec_out) {
         if constexpr (sizeof(T) == 2 && LM == 8) {
-          bf16x8 v;
+          typedef __attribute__((ext_vector_type(8))) T vec8;
+          vec8 v;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = (__bf16)df[e];
-          *(bf16x8*)o = v;                               // (columns >= L: sums over zero weights = the zeros the layout asks for)
+          for (int e = 0; e < 8; ++e) v[e] = (T)df[e];
+          *(vec8*)o = v;                               // (columns >= L: sums over zero weights = the zeros the layout asks for)
         }
       } else {
 #pragma unroll
@@ -1143,8 +1149,9 @@ extern "C" int snerf_zip_prop_mlp_fwd(const void* F, long ldf, long P, int L, co
   hipStream_t s = (hipStream_t)stream;
 #define ZPM_F(T, RN) do { if (L <= 8) hipLaunchKernelGGL((zip_prop_mlp_fwd_kernel<T, 8, RN>), grid, blk, 0, s, w); \
                           else hipLaunchKernelGGL((zip_prop_mlp_fwd_kernel<T, 16, RN>), grid, blk, 0, s, w); } while (0)
-  if (feat_dtype == SNERF_DT_BF16) { if (round_bf16) ZPM_F(__bf16, true); else ZPM_F(__bf16, false); }
-  else if (feat_dtype == SNERF_DT_F32) { if (round_bf16) ZPM_F(float, true); else ZPM_F(float, false); }
+  if (feat_dtype == SNERF_DT_BF16) { if (round_bf16 == 1) ZPM_F(__bf16, 1); else if (round_bf16 == 0) ZPM_F(__bf16, 0); else return SNERF_ERR_ARG; }
+  else if (feat_dtype == SNERF_DT_F16) { if (round_bf16 == 2) ZPM_F(_Float16, 2); else return SNERF_ERR_ARG; }
+  else if (feat_dtype == SNERF_DT_F32) { if (round_bf16 == 1) ZPM_F(float, 1); else if (round_bf16 == 0) ZPM_F(float, 0); else return SNERF_ERR_ARG; }
   else return SNERF_ERR_ARG;
 #undef ZPM_F
   return snerf_check_launch();
@@ -1167,8 +1174,9 @@ extern "C" int snerf_zip_prop_mlp_bwd(const void* F, long ldf, const float* d_ra
   const dim3 grid(wgs), blk(256);
 #define ZPM_B(T, RN) do { if (L <= 8) hipLaunchKernelGGL((zip_prop_mlp_bwd_kernel<T, 8, RN>), grid, blk, 0, s, w); \
                           else hipLaunchKernelGGL((zip_prop_mlp_bwd_kernel<T, 16, RN>), grid, blk, 0, s, w); } while (0)
-  if (feat_dtype == SNERF_DT_BF16) { if (round_bf16) ZPM_B(__bf16, true); else ZPM_B(__bf16, false); }
-  else if (feat_dtype == SNERF_DT_F32) { if (round_bf16) ZPM_B(float, true); else ZPM_B(float, false); }
+  if (feat_dtype == SNERF_DT_BF16) { if (round_bf16 == 1) ZPM_B(__bf16, 1); else if (round_bf16 == 0) ZPM_B(__bf16, 0); else return SNERF_ERR_ARG; }
+  else if (feat_dtype == SNERF_DT_F16) { if (round_bf16 == 2) ZPM_B(_Float16, 2); else return SNERF_ERR_ARG; }
+  else if (feat_dtype == SNERF_DT_F32) { if (round_bf16 == 1) ZPM_B(float, 1); else if (round_bf16 == 0) ZPM_B(float, 0); else return SNERF_ERR_ARG; }
   else return SNERF_ERR_ARG;
 #undef ZPM_B
   const int n = hidden * (L + 2) + 1;
@@ -1206,6 +1214,8 @@ extern "C" int snerf_zip_encode_fwd_count(const float* tdist, const float* origi
   else if (table_dtype == SNERF_DT_F32 && feat_dtype == SNERF_DT_BF16) ZFC(float, __bf16);
   else if (table_dtype == 2 && feat_dtype == SNERF_DT_F32) ZFC(__half, float);
   else if (table_dtype == 2 && feat_dtype == SNERF_DT_BF16) ZFC(__half, __bf16);
+  else if (table_dtype == SNERF_DT_F32 && feat_dtype == SNERF_DT_F16) ZFC(float, _Float16);
+  else if (table_dtype == 2 && feat_dtype == SNERF_DT_F16) ZFC(__half, _Float16);
   else return SNERF_ERR_ARG;
 #undef ZFC
   return snerf_check_launch();
@@ -1640,6 +1650,7 @@ extern "C" int snerf_zip_bin_scale(const void* grad_feat, long ld, long rows, in
     const long total = rows * cols;
     const int grid = (int)(total / 256 / 8 + 1 < 2048 ? total / 256 / 8 + 1 : 2048);
     if (feat_dtype == SNERF_DT_BF16) hipLaunchKernelGGL(zip_bin_absmax_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)grad_feat, ld, rows, cols, (unsigned*)(scale_exp + 1));
+    else if (feat_dtype == SNERF_DT_F16) hipLaunchKernelGGL(zip_bin_absmax_kernel<_Float16>, dim3(grid), dim3(256), 0, s, (const _Float16*)grad_feat, ld, rows, cols, (unsigned*)(scale_exp + 1));
     else if (feat_dtype == SNERF_DT_F32) hipLaunchKernelGGL(zip_bin_absmax_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)grad_feat, ld, rows, cols, (unsigned*)(scale_exp + 1));
     else return SNERF_ERR_ARG;
   }
@@ -1685,6 +1696,7 @@ extern "C" int snerf_zip_encode_bwd_binned(int pass, const float* tdist, const f
                          else if (staged) hipLaunchKernelGGL((zip_bin_write_staged_kernel<OT, CC, 4>), grid, blk, 0, s, a, b); \
                          else hipLaunchKernelGGL((zip_bin_emit_kernel<OT, CC, 1>), grid, blk, 0, s, a, b); } while (0)
     if (feat_dtype == SNERF_DT_BF16) { if (C == 4) ZBE(__bf16, 4); else ZBE(__bf16, 1); }
+    else if (feat_dtype == SNERF_DT_F16) { if (C == 4) ZBE(_Float16, 4); else ZBE(_Float16, 1); }
     else if (feat_dtype == SNERF_DT_F32) { if (C == 4) ZBE(float, 4); else ZBE(float, 1); }
     else return SNERF_ERR_ARG;
 #undef ZBE
@@ -1760,6 +1772,7 @@ extern "C" int snerf_zip_glo_modulate(const void* X, long ldx, const float* SS, 
   const dim3 grid((unsigned)(blocks < 65536 * 8 ? blocks : 65536 * 8));
   if (dtype == SNERF_DT_F32) hipLaunchKernelGGL(zip_glo_modulate_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)X, ldx, SS, ldss, S, P, B, (float*)out, ldo);
   else if (dtype == SNERF_DT_BF16) hipLaunchKernelGGL(zip_glo_modulate_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16*)X, ldx, SS, ldss, S, P, B, (__bf16*)out, ldo);
+  else if (dtype == SNERF_DT_F16) hipLaunchKernelGGL(zip_glo_modulate_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream, (const _Float16*)X, ldx, SS, ldss, S, P, B, (_Float16*)out, ldo);
   else return SNERF_ERR_ARG;
   return snerf_check_launch();
 }
@@ -1779,6 +1792,9 @@ extern "C" int snerf_zip_glo_modulate_bwd(const void* dXm, long lddxm, const voi
   else if (dtype == SNERF_DT_BF16)
     hipLaunchKernelGGL(zip_glo_modulate_bwd_kernel<__bf16>, grid, blk, 0, (hipStream_t)stream, (const __bf16*)dXm, lddxm, (const __bf16*)X, ldx, SS, ldss,
                        d_head, ldh, n_head, S, B, (__bf16*)dX, lddx, dSS, lddss, dxsum, ldsum);
+  else if (dtype == SNERF_DT_F16)
+    hipLaunchKernelGGL(zip_glo_modulate_bwd_kernel<_Float16>, grid, blk, 0, (hipStream_t)stream, (const _Float16*)dXm, lddxm, (const _Float16*)X, ldx, SS, ldss,
+                       d_head, ldh, n_head, S, B, (_Float16*)dX, lddx, dSS, lddss, dxsum, ldsum);
   else return SNERF_ERR_ARG;
   return snerf_check_launch();
 }
@@ -1910,12 +1926,14 @@ extern "C" int snerf_zip_encode_ray_bwd(const float* tdist, const float* origins
   a.R = R; a.S = S; a.L = L; a.n = n; a.m = m; a.Sl = Sl; a.H = H; a.std_scale = std_scale;
   const dim3 grid((unsigned)((R * S + 255) / 256)), block(256);
   hipStream_t s = (hipStream_t)stream;
-  // table: fp32 (0) or fp16 (2); gradient features: fp32 (0) or bf16 (1)
+  // table: fp32 (0) or fp16 (2); gradient features: fp32 (0), bf16 (1) or fp16 (2)
 #define ZRB(TT, OT, CC) hipLaunchKernelGGL((zip_encode_ray_bwd_kernel<TT, OT, CC>), grid, block, 0, s, a, g_origins, g_directions, g_base_x, g_base_y)
   if (table_dtype == 2 && feat_dtype == SNERF_DT_BF16) { if (C == 4) ZRB(__half, __bf16, 4); else ZRB(__half, __bf16, 1); }
   else if (table_dtype == 2 && feat_dtype == SNERF_DT_F32) { if (C == 4) ZRB(__half, float, 4); else ZRB(__half, float, 1); }
   else if (table_dtype == 0 && feat_dtype == SNERF_DT_BF16) { if (C == 4) ZRB(float, __bf16, 4); else ZRB(float, __bf16, 1); }
   else if (table_dtype == 0 && feat_dtype == SNERF_DT_F32) { if (C == 4) ZRB(float, float, 4); else ZRB(float, float, 1); }
+  else if (table_dtype == 2 && feat_dtype == SNERF_DT_F16) { if (C == 4) ZRB(__half, _Float16, 4); else ZRB(__half, _Float16, 1); }
+  else if (table_dtype == 0 && feat_dtype == SNERF_DT_F16) { if (C == 4) ZRB(float, _Float16, 4); else ZRB(float, _Float16, 1); }
   else return SNERF_ERR_ARG;
 #undef ZRB
   return snerf_check_launch();
@@ -2183,6 +2201,7 @@ extern "C" int snerf_semantic_composite_fwd(const float* weights, const void* lo
   const dim3 grid((unsigned)((R + 3) / 4));
   if (dtype == SNERF_DT_F32) hipLaunchKernelGGL((semantic_composite_kernel<float, false>), grid, dim3(256), 0, (hipStream_t)stream, weights, (const float*)logits, ld, R, S, C, softmax, sem, nullptr, nullptr, 0, nullptr, row_index);
   else if (dtype == SNERF_DT_BF16) hipLaunchKernelGGL((semantic_composite_kernel<__bf16, false>), grid, dim3(256), 0, (hipStream_t)stream, weights, (const __bf16*)logits, ld, R, S, C, softmax, sem, nullptr, nullptr, 0, nullptr, row_index);
+  else if (dtype == SNERF_DT_F16) hipLaunchKernelGGL((semantic_composite_kernel<_Float16, false>), grid, dim3(256), 0, (hipStream_t)stream, weights, (const _Float16*)logits, ld, R, S, C, softmax, sem, nullptr, nullptr, 0, nullptr, row_index);
   else return SNERF_ERR_ARG;
   return snerf_check_launch();
 }
@@ -2194,6 +2213,7 @@ extern "C" int snerf_semantic_composite_bwd(const float* weights, const void* lo
   const dim3 grid((unsigned)((R + 3) / 4));
   if (dtype == SNERF_DT_F32) hipLaunchKernelGGL((semantic_composite_kernel<float, true>), grid, dim3(256), 0, (hipStream_t)stream, weights, (const float*)logits, ld, R, S, C, softmax, nullptr, g_sem, d_logits, ld_d, g_w_out, nullptr);
   else if (dtype == SNERF_DT_BF16) hipLaunchKernelGGL((semantic_composite_kernel<__bf16, true>), grid, dim3(256), 0, (hipStream_t)stream, weights, (const __bf16*)logits, ld, R, S, C, softmax, nullptr, g_sem, d_logits, ld_d, g_w_out, nullptr);
+  else if (dtype == SNERF_DT_F16) hipLaunchKernelGGL((semantic_composite_kernel<_Float16, true>), grid, dim3(256), 0, (hipStream_t)stream, weights, (const _Float16*)logits, ld, R, S, C, softmax, nullptr, g_sem, d_logits, ld_d, g_w_out, nullptr);
   else return SNERF_ERR_ARG;
   return snerf_check_launch();
 }

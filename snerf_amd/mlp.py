@@ -1053,7 +1053,7 @@ class ZipPropNet(_Net):
     def forward(self, Fb, keep):
         if self.fused:
             raw = ops.zip_prop_mlp_fwd(Fb, self.fd, self._P("density_layer.0.weight"), self._P("density_layer.0.bias"),
-                                       self._P("density_layer.2.weight"), self._P("density_layer.2.bias"), self.dt == ops.BF16)
+                                       self._P("density_layer.2.weight"), self._P("density_layer.2.bias"), self.dt)
             return raw, ((Fb,) if keep else None)
         self.ensure_packed(keep)
         M = Fb.shape[0]
@@ -1067,7 +1067,7 @@ class ZipPropNet(_Net):
         """-> dF [P, Fw] (gradient w.r.t. the grid features, compute dtype)"""
         if len(saved) == 1:                   # fused route: the hidden activations are recomputed from the features
             return ops.zip_prop_mlp_bwd(saved[0], d_raw.reshape(-1), self.fd, self._P("density_layer.0.weight"), self._P("density_layer.0.bias"),
-                                        self._P("density_layer.2.weight"), self._P("density_layer.2.bias"), self.dt == ops.BF16,
+                                        self._P("density_layer.2.weight"), self._P("density_layer.2.bias"), self.dt,
                                         self._G("density_layer.0.weight"), self._G("density_layer.0.bias"), self._G("density_layer.2.weight"),
                                         self._G("density_layer.2.bias"))
         Fb, H1 = saved

@@ -88,7 +88,7 @@ def fast_epilogue_ok(Y, n_store, dt, out_f32=False, aux=None, act=ACT_NONE):
     """Whether snerf_linear_fwd takes its LDS-transposed 16-byte epilogue for this launch (mirrors the dispatch in gemm.hip): the only
     epilogue whose bias-gradient column sums can be folded deterministically (the direct-store epilogue adds them with atomics)."""
     epc = 4 if dt == F32 else 8
-    ok = not (out_f32 and dt == BF16) and Y.stride(0) % epc == 0 and Y.data_ptr() % 16 == 0 and n_store % epc == 0
+    ok = not (out_f32 and dt in (BF16, F16)) and Y.stride(0) % epc == 0 and Y.data_ptr() % 16 == 0 and n_store % epc == 0
     if act == ACT_MASK and aux is not None:
         ok = ok and aux.stride(0) % epc == 0 and aux.data_ptr() % 16 == 0
     return ok
@@ -605,8 +605,8 @@ def cast_pad(src, C, dst, Cpad, dt):
 def gather_pack(flat, idx, dst):
     """dst[i] = flat[idx[i]] (idx -1 -> 0, -2 -> 1) rounded to dst's dtype: all packed operands of a network in one launch."""
     assert flat.dtype == torch.float32 and flat.is_contiguous() and idx.dtype == torch.int32 and idx.is_contiguous() and dst.is_contiguous()
-    assert dst.numel() == idx.numel() and dst.dtype in (torch.float32, torch.bfloat16)
-    _lib.call("snerf_gather_pack", _p(flat), _p(idx), idx.numel(), _p(dst), F32 if dst.dtype == torch.float32 else BF16, _stream())
+    assert dst.numel() == idx.numel() and dst.dtype in (torch.float32, torch.bfloat16, torch.float16)
+    _lib.call("snerf_gather_pack", _p(flat), _p(idx), idx.numel(), _p(dst), _zip_dt(dst), _stream())
 
 
 # ------------------------------------------------------------ hash grid ----
@@ -693,6 +693,14 @@ def _zip_dt(t):
     return {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}[t.dtype]
 
 
+def round_mode(dt):
+    """rounding mode of the fused proposal networks (their activations are rounded like the GEMM route's buffers of that compute dtype):
+    0 none (fp32), 1 bf16, 2 fp16.  Accepts a compute dtype code or the older bool (True = bf16)."""
+    if isinstance(dt, bool):
+        return 1 if dt else 0
+    return {F32: 0, BF16: 1, F16: 2}[int(dt)]
+
+
 def zip_encode_fwd(tdist, origins, directions, radii, base_x, base_y, deg_jitter, table, offsets, grid_sizes, feat, L, C, n, m, Sl, H, std_scale,
                    levels_per_thread=0):
     for t in (tdist, origins, directions, radii, base_x, base_y, deg_jitter):
@@ -732,9 +740,9 @@ def zip_prop_mlp_fwd(F, L, w1, b1, w2, b2, round_bf16):
     for t in (w1, b1, w2, b2):
         _f32c(t)
     P, hidden = F.shape[0], b1.numel()
-    assert F.dtype in (torch.float32, torch.bfloat16) and w1.numel() == hidden * L and w2.numel() == hidden and b2.numel() == 1 and hidden <= 64 and L <= 16
+    assert F.dtype in (torch.float32, torch.bfloat16, torch.float16) and w1.numel() == hidden * L and w2.numel() == hidden and b2.numel() == 1 and hidden <= 64 and L <= 16
     raw = torch.empty(P, 1, dtype=torch.float32, device=F.device)
-    _lib.call("snerf_zip_prop_mlp_fwd", _p(F), F.stride(0), P, int(L), _p(w1), _p(b1), _p(w2), _p(b2), hidden, 1 if round_bf16 else 0, _zip_dt(F),
+    _lib.call("snerf_zip_prop_mlp_fwd", _p(F), F.stride(0), P, int(L), _p(w1), _p(b1), _p(w2), _p(b2), hidden, round_mode(round_bf16), _zip_dt(F),
               _p(raw), _stream())
     return raw
 
@@ -751,7 +759,7 @@ def zip_prop_mlp_bwd(F, d_raw, L, w1, b1, w2, b2, round_bf16, g_w1, g_b1, g_w2, 
     dF = torch.empty(P, F.shape[1], dtype=F.dtype, device=F.device)
     nws = _lib.query("snerf_zip_prop_mlp_ws_floats", int(L), hidden, P)
     ws = torch.empty(max(int(nws), 1), dtype=torch.float32, device=F.device)
-    _lib.call("snerf_zip_prop_mlp_bwd", _p(F), F.stride(0), _p(d_raw), P, int(L), _p(w1), _p(b1), _p(w2), _p(b2), hidden, 1 if round_bf16 else 0,
+    _lib.call("snerf_zip_prop_mlp_bwd", _p(F), F.stride(0), _p(d_raw), P, int(L), _p(w1), _p(b1), _p(w2), _p(b2), hidden, round_mode(round_bf16),
               _zip_dt(F), _p(dF), dF.stride(0), _p(g_w1), _p(g_b1), _p(g_w2), _p(g_b2), _p(ws), ws.numel(), _stream())
     return dF
 
@@ -767,7 +775,7 @@ def zip_encode_prop_fwd(tdist, origins, directions, radii, base_x, base_y, deg_j
     out = torch.empty(R * (P - 1), 1, dtype=torch.float32, device=tdist.device)
     _lib.call("snerf_zip_encode_prop_fwd", _p(tdist), _p(origins), _p(directions), _p(radii), _p(base_x), _p(base_y), _p(deg_jitter), _p(table),
               _p(offsets), _p(grid_sizes), R, P - 1, L, n, m, float(Sl), int(H), float(std_scale), _zip_dt(table), _p(w1), _p(b1), _p(w2), _p(b2),
-              hidden, int(bool(round_bf16)), _p(out), _stream())
+              hidden, round_mode(round_bf16), _p(out), _stream())
     return out
 
 
@@ -876,8 +884,8 @@ def zip_glo_modulate(X, SS, S, out):
     B = SS.shape[1] // 2
     _chk2d(X, X.dtype); _chk2d(out, X.dtype); _chk2d(SS, torch.float32)
     R = SS.shape[0]
-    assert X.shape[0] == R * S == out.shape[0] and X.shape[1] >= B and out.shape[1] >= B and X.dtype in (torch.float32, torch.bfloat16)
-    _lib.call("snerf_zip_glo_modulate", _p(X), X.stride(0), _p(SS), SS.stride(0), R, S, B, _p(out), out.stride(0), F32 if X.dtype == torch.float32 else BF16,
+    assert X.shape[0] == R * S == out.shape[0] and X.shape[1] >= B and out.shape[1] >= B and X.dtype in (torch.float32, torch.bfloat16, torch.float16)
+    _lib.call("snerf_zip_glo_modulate", _p(X), X.stride(0), _p(SS), SS.stride(0), R, S, B, _p(out), out.stride(0), _zip_dt(X),
               _stream())
 
 
@@ -896,7 +904,7 @@ def zip_glo_modulate_bwd(dXm, X, SS, d_head, S, dX):
     dSS = torch.empty(R, 2 * B, dtype=torch.float32, device=X.device)
     dxsum = torch.empty(R, B, dtype=torch.float32, device=X.device)
     _lib.call("snerf_zip_glo_modulate_bwd", _p(dXm), dXm.stride(0), _p(X), X.stride(0), _p(SS), SS.stride(0), _p(d_head), 0 if d_head is None else d_head.stride(0),
-              nh, R, S, B, _p(dX), dX.stride(0), _p(dSS), dSS.stride(0), _p(dxsum), dxsum.stride(0), F32 if X.dtype == torch.float32 else BF16, _stream())
+              nh, R, S, B, _p(dX), dX.stride(0), _p(dSS), dSS.stride(0), _p(dxsum), dxsum.stride(0), _zip_dt(X), _stream())
     return dSS, dxsum
 
 
@@ -1139,12 +1147,18 @@ def frame_quantize(rgb=None, depth=None, semantic=None, color_map=None, scale_fa
     return out
 
 
-def hash_decay(table, grad, offsets, L, C, mult, loss=None):
-    """grad += d/d table of mult * mean_{level, channel}(mean over the level's rows of table^2) (train_utils.py:184-203); `loss`
-    (1-element fp32 device tensor, optional) accumulates the value."""
+def hash_decay(table, grad, offsets, L, C, mult, loss=None, grad_mult=1.0):
+    """grad += grad_mult * d/d table of mult * mean_{level, channel}(mean over the level's rows of table^2) (train_utils.py:184-203);
+    `loss` (1-element fp32 device tensor, optional) accumulates the value.  `grad_mult`: the trainer's loss scale (the term is linear in
+    `mult`, so the kernel runs with mult * grad_mult and the value is divided back)."""
     _f32c(table); _f32c(grad)
     assert offsets.dtype == torch.int32 and offsets.is_cuda and table.shape == grad.shape
-    _lib.call("snerf_hash_decay", _p(table), _p(grad), _p(offsets), int(L), int(C), float(mult), _p(loss), _stream())
+    if grad_mult != 1.0 and loss is not None:
+        tmp = torch.zeros_like(loss)
+        _lib.call("snerf_hash_decay", _p(table), _p(grad), _p(offsets), int(L), int(C), float(mult) * float(grad_mult), _p(tmp), _stream())
+        loss.add_(tmp, alpha=1.0 / float(grad_mult))
+        return
+    _lib.call("snerf_hash_decay", _p(table), _p(grad), _p(offsets), int(L), int(C), float(mult) * float(grad_mult), _p(loss), _stream())
 
 
 def semantic_composite_fwd(weights, logits, C, softmax, row_index=None):

@@ -313,8 +313,11 @@ class ZipTrainer:
     leaf copies of every level's `weights`; its d(loss)/d(weights) is added to the fused tail's)."""
 
     def __init__(self, model, lr=1e-2, betas=(0.9, 0.99), eps=1e-15, charb_padding=0.001, process_group=None, loss_cfg=None,
-                 nonfinite="zero", grad_max_val=0.0, grad_max_norm=0.0, table_exchange="sharded"):
-        """`nonfinite`, `grad_max_val`, `grad_max_norm` = train_utils.clip_gradients (train_utils.py:234-243, run every step at
+                 nonfinite="zero", grad_max_val=0.0, grad_max_norm=0.0, table_exchange="sharded", loss_scale=None):
+        """`loss_scale` (static; default 4096 when the model computes in fp16, else 1): the gradients of the rendered outputs are multiplied
+        by it before the backward -- so that the fp16 gradient buffers of the networks stay in fp16's normal range -- and the factor is
+        undone inside the Adam launch (grad_scale), before clipping.  Overflowed (non-finite) gradients are dropped by `nonfinite`.
+        `nonfinite`, `grad_max_val`, `grad_max_norm` = train_utils.clip_gradients (train_utils.py:234-243, run every step at
         zipnerf/train.py:336; configs.py:83-84 defaults 0 = off), folded into the Adam launch.  The reference always ends with
         param.grad.nan_to_num_(); "zero" (default) also drops +-Inf instead of mapping it to +-FLT_MAX (which would leave v = inf,
         i.e. that parameter frozen for good); "nan_to_num" reproduces the reference exactly."""
@@ -329,6 +332,7 @@ class ZipTrainer:
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.last_losses = None
+        self.loss_scale = float(loss_scale) if loss_scale is not None else (4096.0 if getattr(model, "dt", None) == ops.F16 else 1.0)
         a.grad.zero_()
         # the hash tables' gradients: "sharded" (default for N > 1) = reduce-scatter + Adam on the rank's slice + all-gather of the updated
         # parameters (_TableShards); "allreduce" = part of the bucketed all-reduce like the MLP parameters (the reference's DDP behaviour)
@@ -366,11 +370,16 @@ class ZipTrainer:
                                    smask=t.get("semantic_mask"), hist=[(levels[l]["sdist"], levels[l]["weights"]) for l in range(3)],
                                    **self.loss_cfg)
         decay = torch.zeros(1, dtype=torch.float32, device=dev)
+        ls = self.loss_scale
+        if ls != 1.0:
+            for g in G.values():
+                if g is not None:
+                    g.mul_(ls)
         if self.hash_decay_mult > 0:
             for lvl, pre in enumerate(m.names):            # identical on every rank: the all-reduced mean leaves it unchanged
                 e = m.encs[lvl]
                 ops.hash_decay(m.arena.p[pre + "encoder.embeddings"], m.arena.g[pre + "encoder.embeddings"], m.dev_offsets[lvl], e.L, e.C,
-                               self.hash_decay_mult, decay)
+                               self.hash_decay_mult, decay, grad_mult=ls)
         self.last_losses = torch.cat([out[4:], decay])     # ops.ZIP_LOSS_NAMES + ("hash_decay",)
         loss = out[4] + out[6:].sum() + decay[0]
         g_w = [G["w0"], G["w1"], G["w2"]]
@@ -380,6 +389,7 @@ class ZipTrainer:
                 hist = [dict(sdist=levels[l]["sdist"].detach(), tdist=levels[l]["tdist"].detach(), weights=leaves[l]) for l in range(3)]
                 aux = aux_loss_fn(hist)
                 gs = torch.autograd.grad(aux, leaves, allow_unused=True)
+            gs = [b if (b is None or ls == 1.0) else b * ls for b in gs]
             g_w = [a if b is None else (b if a is None else a + b) for a, b in zip(g_w, gs)]
             loss = loss + aux.detach()
         ex = _GradExchange(m.arena, self.world, self.pg)
@@ -399,12 +409,12 @@ class ZipTrainer:
         self.t += 1
         a = m.arena
         adam = lambda lo, hi, g=None: ops.adam_step(a.flat[lo:hi], a.grad[lo:hi] if g is None else g, self.m[lo:hi], self.v[lo:hi], self.lr, self.betas[0],
-                                                    self.betas[1], self.eps, self.t, grad_scale=1.0 / self.world, zero_grad=True,
+                                                    self.betas[1], self.eps, self.t, grad_scale=1.0 / (self.world * ls), zero_grad=True,
                                                     nonfinite=self.nonfinite, grad_max_val=self.grad_max_val)
         if sh is None:
-            coef = ops.grad_clip_coef(a.grad, 1.0 / self.world, self.grad_max_norm) if self.grad_max_norm > 0 else None
+            coef = ops.grad_clip_coef(a.grad, 1.0 / (self.world * ls), self.grad_max_norm) if self.grad_max_norm > 0 else None
             ops.adam_step(a.flat, a.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.t,
-                          grad_scale=1.0 / self.world, zero_grad=True, nonfinite=self.nonfinite, grad_max_val=self.grad_max_val, clip_coef=coef)
+                          grad_scale=1.0 / (self.world * ls), zero_grad=True, nonfinite=self.nonfinite, grad_max_val=self.grad_max_val, clip_coef=coef)
         else:
             # tables: this rank's slice only, then the updated slices are gathered; everything between the table spans: the usual pass
             mine = sh.finish()

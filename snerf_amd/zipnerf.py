@@ -122,6 +122,10 @@ class Model(_ArenaModule):
         self._setup_arena(shapes, dev)
         self.dt = _dt(compute)
         self.compute = compute
+        # compute="fp16": fp16 features / activations / gradient buffers and the fp16 MFMA (BASELINE config 4's "fp16 MLP", the tcnn-style
+        # half-precision network); gradients flow through the networks multiplied by a static loss scale (here for loss.backward(), in
+        # ZipTrainer folded into the Adam launch)
+        self.autograd_loss_scale = 4096.0 if self.dt == ops.F16 else 1.0
         # gather tables: "ref" (default) = what the reference does under autocast (gridencoder/grid.py:41-44): embeddings are halved only
         # when C is even, i.e. the C = 4 NeRF table in fp16 and the two C = 1 proposal tables in fp32; "f16" halves all three (narrower
         # storage than the reference's on the proposal levels: an extension, benchmarked separately); "f32" none
@@ -230,7 +234,7 @@ class Model(_ArenaModule):
                 raw_d = ops.zip_encode_prop_fwd(tdist, o, d, radii, bx, by, degj, self._table(lvl), self.dev_offsets[lvl], self.dev_sizes[lvl], e.L,
                                                 sample_n, sample_m, e.Sl, e.H, self.std_scale, self.arena.p[pre + "density_layer.0.weight"],
                                                 self.arena.p[pre + "density_layer.0.bias"], self.arena.p[pre + "density_layer.2.weight"],
-                                                self.arena.p[pre + "density_layer.2.bias"], self.dt == ops.BF16)
+                                                self.arena.p[pre + "density_layer.2.bias"], self.dt)
                 rgb, depth, acc, weights = ops.zip_composite_fwd(None, raw_d, tdist, d, self.opaque_background, bg, 0.001, -1.0)
                 levels.append(dict(sdist=sdist, tdist=tdist, weights=weights, rgb=rgb, depth=depth, acc=acc, raw_rgb=None, raw_d=raw_d, saved=None,
                                    degj=degj, ns=ns, semantic=None, logits=None))
@@ -535,12 +539,17 @@ class _ZipFn(torch.autograd.Function):
             raise RuntimeError("zipnerf Model.forward ran without saved activations")
         m = ctx.model
         m.arena.grad.zero_()
+        ls = m.autograd_loss_scale           # fp16 compute: the backward runs on scaled output gradients (ZipTrainer folds the same factor into Adam)
+        if ls != 1.0:
+            g = tuple(None if t is None else t * ls for t in g)
         grads = [(g[6 * l], g[6 * l + 1], g[6 * l + 2], g[6 * l + 3]) for l in range(3)]
         if m.use_semantic:
             grads[2] = grads[2] + (g[18],)
         rg = m._backward(ctx.c, grads, ray_grads=ctx.ray_meta is not None)
         ctx.c = None
-        grads = tuple(m.arena.g[n].clone() for n in m._pnames)
+        grads = tuple(m.arena.g[n].clone() if ls == 1.0 else m.arena.g[n] * (1.0 / ls) for n in m._pnames)
+        if rg is not None and ls != 1.0:
+            rg = [t * (1.0 / ls) for t in rg]
         m.arena.grad.zero_()      # the trainers accumulate into the arena and expect it clean at step start
         if rg is None:
             return (None,) * 12 + grads

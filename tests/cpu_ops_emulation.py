@@ -306,7 +306,8 @@ def zip_encode_fwd_count(tdist, origins, directions, radii, base_x, base_y, deg_
 
 
 def _zpm_rb(t, rnd):
-    return t.bfloat16().float() if rnd else t
+    """rnd: rounding mode (0 / False none, 1 / True bf16, 2 fp16)"""
+    return t.half().float() if int(rnd) == 2 else (t.bfloat16().float() if rnd else t)
 
 
 def _zpm_hidden(F, L, w1, b1, rnd):
@@ -547,12 +548,12 @@ def zip_percentiles(tdist, weights, t_far, ps=(5, 50, 95)):
     return oz.weighted_percentile(torch.cat([tdist, t_far.reshape(-1, 1)], -1), torch.cat([weights, bg], -1), list(ps))
 
 
-def hash_decay(table, grad, offsets, L, C, mult, loss=None):
+def hash_decay(table, grad, offsets, L, C, mult, loss=None, grad_mult=1.0):
     off = offsets.cpu().numpy()
     for l in range(L):
         rows = int(off[l + 1] - off[l])
         k = mult / (rows * L * C)
-        grad[off[l]:off[l + 1]] += 2 * k * table[off[l]:off[l + 1]]
+        grad[off[l]:off[l + 1]] += 2 * k * grad_mult * table[off[l]:off[l + 1]]
         if loss is not None:
             loss += k * (table[off[l]:off[l + 1]].double() ** 2).sum().float()
 
@@ -560,7 +561,7 @@ def hash_decay(table, grad, offsets, L, C, mult, loss=None):
 def zip_encode_prop_fwd(tdist, origins, directions, radii, base_x, base_y, deg_jitter, table, offsets, grid_sizes, L, n, m, Sl, H, std_scale,
                         w1, b1, w2, b2, round_bf16):
     P = tdist.shape[0] * (tdist.shape[1] - 1)
-    rb = (lambda t: t.to(torch.bfloat16).float()) if round_bf16 else (lambda t: t)
+    rb = lambda t: _zpm_rb(t, round_bf16)
     feat = torch.zeros(P, L)
     zip_encode_fwd(tdist, origins, directions, radii, base_x, base_y, deg_jitter, table, offsets, grid_sizes, feat, L, 1, n, m, Sl, H, std_scale)
     h = rb(torch.relu(rb(feat) @ rb(w1.reshape(-1, L)).t() + b1))

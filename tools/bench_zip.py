@@ -14,7 +14,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--rays", type=int, default=16384, help="rays per GPU per step (weak scaling)")
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--compute", default="bf16")
+    ap.add_argument("--compute", default="fp16", help="fp16 (BASELINE config 4's fp16 MLP; static loss scale), bf16 or f32")
     ap.add_argument("--table", default="ref", choices=["ref", "f16", "f32"],
                     help="gather tables: ref = the reference's autocast policy (C = 4 NeRF table fp16, C = 1 proposal tables fp32, gridencoder/grid.py:41-44); "
                          "f16 = all three halved (narrower than the reference on the proposal levels); f32 = none")
@@ -153,8 +153,10 @@ def main():
     bytes_lvl = [R * 7 * 64 * 6 * 8 * 1 * tbs[0], R * 7 * 64 * 8 * 8 * 1 * tbs[1], R * 7 * 32 * 10 * 8 * 4 * tbs[2]]
     out = {"path": "C (zipnerf Model, waymo.gin shape: 64+64+32 intervals x 7 multisamples, grids L=6/8/10)", "n_gpus": world, "rays_per_gpu": R,
            "compute": args.compute,
-           "compute_note": "BASELINE config 4 names an fp16 MLP (torch autocast); this build evaluates the MLPs in bf16 (same MFMA rate, fp32 "
-                           "accumulate, no loss scaling needed); tables: see `table` (ref = fp16 where the reference halves them, i.e. only the C = 4 NeRF table)",
+           "compute_note": "BASELINE config 4 names an fp16 MLP (torch autocast): compute=fp16 runs the fp16 MFMA with fp32 accumulation and a static loss "
+                           "scale folded into Adam (loss_scale below); bf16 is the same kernels at the same rate without a loss scale; tables: see `table` "
+                           "(ref = fp16 where the reference halves them, i.e. only the C = 4 NeRF table)",
+           "loss_scale": tr.loss_scale,
            "table_grad": args.table_grad, "table_grad_mode": m.table_grad_mode,
            "table": args.table, "train_ms": round(dt_train * 1e3, 3), "train_rays_per_s": round(world * R / dt_train, 1), "fwd_ms": round(dt_fwd * 1e3, 3),
            "fwd_rays_per_s": round(R / dt_fwd, 1), "frame_1920x1280_s": round(dt_frame, 3), "frame_outputs": sorted(k for k in img if not k.startswith("ray_")), "encode_fwd_ms_per_level": [round(x, 3) for x in enc_ms], "encode_note": "inference: proposal levels = featurisation + MLP fused",
