@@ -464,6 +464,15 @@ struct ZipBin {
   long long* g64; long g64_rows;           // int64 image of table rows [0, g64_rows) for the replicated levels
   const int* scale_exp;                    // device: the launch's fixed-point scale is 2^scale_exp[0] (snerf_zip_bin_scale)
 };
+// HALF RECORDS (HREC; passes 5 / 6 / 7): the record's values travel as fp16 of value * 2^(scale_exp - ZB_HALF_SHIFT) -- the largest
+// |grad_feat| entry lands in [2^14, 2^15), fp16's subnormals reach 2^-39 of it, below the 2^-34 fixed-point grid -- 10 instead of 18
+// bytes per record of a four-channel grid ({row u16} + {4 x fp16}), 4 instead of 8 for a single-channel one ({row u16 | fp16} in one
+// word).  Every contribution is rounded to 11 significant bits once (round to nearest: unbiased), the sums stay exact and
+// order-independent.  The reference scatters __half2 atomics into an fp16 table's gradient (gridencoder.cu:302-315: every ADDITION rounds
+// to 11 bits), so for the tables it halves this is tighter than the reference's own gradient; for fp32 tables it is an option.
+#define ZB_HALF_SHIFT (ZB_HEAD - 15)
+typedef _Float16 zb_h4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned zb_half_bits(float v) { return (unsigned)__builtin_bit_cast(unsigned short, (_Float16)v); }
 
 // Forward featurisation, one thread per interval for ALL levels: the n <= 8 helix multisamples (sincos, contraction, cbrt) are
 // evaluated once and kept in registers instead of once per (interval, level) as in the per-level grid above -- for the
@@ -1258,7 +1267,7 @@ extern "C" int snerf_zip_encode_bwd(const float* tdist, const float* origins, co
 //   pass 3  zip_bin_finish_kernel       fold the replicated levels' int64 image into the gradient
 // ------------------------------------------------------------------------------------------------------------------
 // the records of one (interval, level): same merging of consecutive multisamples in one cell as the atomic path
-template <typename OT, int C, bool WRITE>
+template <typename OT, int C, bool WRITE, bool HREC = false>
 __device__ __forceinline__ void zip_emit_level(const ZipEnc& a, const ZipBin& b, long p, int level, int* lds_cnt, const long* lds_base) {
   const long ray = p / a.S;
   const int i = (int)(p - ray * a.S);
@@ -1275,6 +1284,8 @@ __device__ __forceinline__ void zip_emit_level(const ZipEnc& a, const ZipBin& b,
   const OT* gi = (const OT*)a.feat + p * a.ld + level * C;
 #pragma unroll
   for (int c = 0; c < C; ++c) g[c] = (float)gi[c] / (float)a.n;
+  float hmul = 1.f;
+  if constexpr (HREC && WRITE) hmul = exp2f((float)(b.scale_exp[0] - ZB_HALF_SHIFT));
   uint32_t cur[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
   float wsum[8];
 #pragma unroll
@@ -1293,7 +1304,13 @@ __device__ __forceinline__ void zip_emit_level(const ZipEnc& a, const ZipBin& b,
         const long r = lds_base[bin] + slot;
         if (r < b.capacity) {
           const unsigned lrow = row & ((1u << b.bshift) - 1u);
-          if constexpr (C == 1) {                      // one 8-byte record {row in bin, value}: one store instead of a 2- and a 4-byte one
+          if constexpr (HREC && C == 1) {              // one 4-byte record {row in bin | fp16 value}
+            ((unsigned*)b.rec_val)[r] = lrow | (zb_half_bits((wsum[idx] * g[0]) * hmul) << 16);
+          } else if constexpr (HREC && C == 4) {       // row + the four channels as one 8-byte store
+            b.rec_row[r] = (unsigned short)lrow;
+            const zb_h4 v4 = {(_Float16)((wsum[idx] * g[0]) * hmul), (_Float16)((wsum[idx] * g[1]) * hmul), (_Float16)((wsum[idx] * g[2]) * hmul), (_Float16)((wsum[idx] * g[3]) * hmul)};
+            *(zb_h4*)(b.rec_val + r * 2) = v4;
+          } else if constexpr (C == 1) {               // one 8-byte record {row in bin, value}: one store instead of a 2- and a 4-byte one
             const uint2 rv = {lrow, __float_as_uint(wsum[idx] * g[0])};
             *(uint2*)(b.rec_val + r * 2) = rv;
           } else if constexpr (C == 4) {               // the four channels as one 16-byte store
@@ -1337,7 +1354,7 @@ __device__ __forceinline__ void zip_emit_level(const ZipEnc& a, const ZipBin& b,
   flush();
 }
 
-template <typename OT, int C, int PASS>
+template <typename OT, int C, int PASS, bool HREC = false>
 __global__ __launch_bounds__(256) void zip_bin_emit_kernel(ZipEnc a, ZipBin b) {
   __shared__ int cnt[ZB_NBMAX];
   __shared__ long base[ZB_NBMAX];
@@ -1350,7 +1367,7 @@ __global__ __launch_bounds__(256) void zip_bin_emit_kernel(ZipEnc a, ZipBin b) {
     const unsigned* wgo1 = b.wg_offsets + ((long)level * gridDim.x + blockIdx.x) * ZB_NBMAX;
     for (int k = threadIdx.x; k < ZB_NBMAX; k += 256) base[k] = b.starts[level * ZB_NBMAX + k] + (long)wgo1[k];
     __syncthreads();
-    if (live) zip_emit_level<OT, C, true>(a, b, p, level, cnt, base);
+    if (live) zip_emit_level<OT, C, true, HREC>(a, b, p, level, cnt, base);
     return;
   }
   __syncthreads();
@@ -1393,7 +1410,7 @@ __device__ __forceinline__ int zs_wave_incl_scan(int v, int lane) {
   return v;
 }
 
-template <typename OT, int C, int NSUB>
+template <typename OT, int C, int NSUB, bool HREC = false>
 __global__ __launch_bounds__(256, NSUB == 8 ? 4 : 3) void zip_bin_write_staged_kernel(ZipEnc a, ZipBin b) {
   constexpr int CPS = 8 / NSUB;                       // corners per sub-pass
   __shared__ int cnt[ZB_NBMAX];
@@ -1416,6 +1433,8 @@ __global__ __launch_bounds__(256, NSUB == 8 ? 4 : 3) void zip_bin_write_staged_k
   const uint32_t res = (uint32_t)ceilf(scale) + 1;
   const int K = b.ksplit[level], rep = (int)(blockIdx.x % (unsigned)K);
   const unsigned rmask = (1u << b.bshift) - 1u;
+  float hmul = 1.f;
+  if constexpr (HREC) hmul = exp2f((float)(b.scale_exp[0] - ZB_HALF_SHIFT));
   // ---- the interval's multisamples, once
   uint32_t pg[ZS_NMAX][3];
   float fr[ZS_NMAX][3], we[ZS_NMAX];
@@ -1515,7 +1534,13 @@ __global__ __launch_bounds__(256, NSUB == 8 ? 4 : 3) void zip_bin_write_staged_k
         const unsigned lrow = rec.x & 0x3fffu;
         const float wsum = __uint_as_float(rec.y);
         const float* g = gtab + (rec.x >> 24) * C;
-        if constexpr (C == 1) {
+        if constexpr (HREC && C == 1) {
+          ((unsigned*)b.rec_val)[r] = lrow | (zb_half_bits((wsum * g[0]) * hmul) << 16);
+        } else if constexpr (HREC) {
+          b.rec_row[r] = (unsigned short)lrow;
+          const zb_h4 v4 = {(_Float16)((wsum * g[0]) * hmul), (_Float16)((wsum * g[1]) * hmul), (_Float16)((wsum * g[2]) * hmul), (_Float16)((wsum * g[3]) * hmul)};
+          *(zb_h4*)(b.rec_val + r * 2) = v4;
+        } else if constexpr (C == 1) {
           const uint2 rv = {lrow, __float_as_uint(wsum * g[0])};
           *(uint2*)(b.rec_val + r * 2) = rv;
         } else {
@@ -1532,7 +1557,7 @@ __global__ __launch_bounds__(256, NSUB == 8 ? 4 : 3) void zip_bin_write_staged_k
   }
 }
 
-template <int C>
+template <int C, bool HREC = false>
 __global__ __launch_bounds__(1024) void zip_bin_accumulate_kernel(ZipEnc a, ZipBin b) {
   extern __shared__ long long zb_acc[];
   const int level = blockIdx.y, bin = blockIdx.x;
@@ -1566,6 +1591,18 @@ __global__ __launch_bounds__(1024) void zip_bin_accumulate_kernel(ZipEnc a, ZipB
     for (int u = 0; u < U; ++u) {
       const int r = r0 + u * 1024;
       const long q = s0 + (r < n ? r : r0);
+      if constexpr (HREC && C == 1) {
+        const unsigned rv = ((const unsigned*)b.rec_val)[q];
+        row[u] = r < n ? (int)(rv & 0xffffu) : -1;
+        val[u][0] = (float)__builtin_bit_cast(_Float16, (unsigned short)(rv >> 16));
+        continue;
+      }
+      if constexpr (HREC && C == 4) {
+        row[u] = r < n ? (int)b.rec_row[q] : -1;
+        const zb_h4 v4 = *(const zb_h4*)(b.rec_val + q * 2);
+        val[u][0] = (float)v4[0]; val[u][1] = (float)v4[1]; val[u][2] = (float)v4[2]; val[u][3] = (float)v4[3];
+        continue;
+      }
       if constexpr (C == 1) {
         const uint2 rv = *(const uint2*)(b.rec_val + q * 2);
         row[u] = r < n ? (int)rv.x : -1;
@@ -1586,8 +1623,9 @@ __global__ __launch_bounds__(1024) void zip_bin_accumulate_kernel(ZipEnc a, ZipB
       if (row[u] < 0) continue;
 #pragma unroll
       for (int c = 0; c < C; ++c) {
-        const float v = fminf(fmaxf(val[u][c], -lim), lim);   // (a record is at most max |grad_feat| in magnitude: the clamp only stops non-finite values)
-        atomicAdd((unsigned long long*)(zb_acc + row[u] * C + c), (unsigned long long)__float2ll_rn(v * fix));
+        // (a record is at most max |grad_feat| in magnitude: the clamp only stops non-finite values)
+        const float v = HREC ? fminf(fmaxf(val[u][c], -65536.f), 65536.f) * (float)(1 << ZB_HALF_SHIFT) : fminf(fmaxf(val[u][c], -lim), lim) * fix;   // half records carry value * 2^(se - ZB_HALF_SHIFT)
+        atomicAdd((unsigned long long*)(zb_acc + row[u] * C + c), (unsigned long long)__float2ll_rn(v));
       }
     }
   }
@@ -1684,8 +1722,11 @@ extern "C" int snerf_zip_encode_bwd_binned(int pass, const float* tdist, const f
   b.scale_exp = scale_exp;
   hipStream_t s = (hipStream_t)stream;
   const dim3 blk(256);
+  // passes 5 / 6 / 7 = 1 / 3 / 2 with HALF records (see ZB_HALF_SHIFT): the writers then need scale_exp too
+  const bool hrec = pass >= 5 && pass <= 7;
+  if (hrec) pass = pass == 5 ? 1 : (pass == 6 ? 3 : 2);
   if (pass == 0 || pass == 1 || pass == 3 || pass == 4) {
-    if (grad_feat == nullptr || wg_offsets == nullptr || (pass != 0 && (starts == nullptr || rec_row == nullptr || rec_val == nullptr)))
+    if (grad_feat == nullptr || wg_offsets == nullptr || (pass != 0 && (starts == nullptr || rec_row == nullptr || rec_val == nullptr)) || (hrec && scale_exp == nullptr))
       return SNERF_ERR_ARG;
     const dim3 grid((unsigned)((R * S + 255) / 256), L);
     // pass 1: records staged in LDS and written run by run (zip_bin_write_staged_kernel); pass 3 (A/B probes, or more than 8
@@ -1693,7 +1734,9 @@ extern "C" int snerf_zip_encode_bwd_binned(int pass, const float* tdist, const f
     // (C = 1: 8-byte records in 128 row ranges per level -- the direct writer is faster there: 4.6 vs 5.8 ms per proposal level)
     const bool staged = ((pass == 1 && C == 4) || pass == 4) && n <= ZS_NMAX;     // (pass 4: probe -- staged for C = 1 too)
 #define ZBE(OT, CC) do { if (pass == 0) hipLaunchKernelGGL((zip_bin_emit_kernel<OT, CC, 0>), grid, blk, 0, s, a, b); \
+                         else if (staged && hrec) hipLaunchKernelGGL((zip_bin_write_staged_kernel<OT, CC, 4, true>), grid, blk, 0, s, a, b); \
                          else if (staged) hipLaunchKernelGGL((zip_bin_write_staged_kernel<OT, CC, 4>), grid, blk, 0, s, a, b); \
+                         else if (hrec) hipLaunchKernelGGL((zip_bin_emit_kernel<OT, CC, 1, true>), grid, blk, 0, s, a, b); \
                          else hipLaunchKernelGGL((zip_bin_emit_kernel<OT, CC, 1>), grid, blk, 0, s, a, b); } while (0)
     if (feat_dtype == SNERF_DT_BF16) { if (C == 4) ZBE(__bf16, 4); else ZBE(__bf16, 1); }
     else if (feat_dtype == SNERF_DT_F16) { if (C == 4) ZBE(_Float16, 4); else ZBE(_Float16, 1); }
@@ -1705,7 +1748,13 @@ extern "C" int snerf_zip_encode_bwd_binned(int pass, const float* tdist, const f
   if (pass != 2 || starts == nullptr || rec_row == nullptr || rec_val == nullptr || grad_table == nullptr || scale_exp == nullptr) return SNERF_ERR_ARG;
   const size_t lds = (size_t)(1 << b.bshift) * C * 8;
   const dim3 grid(ZB_NBMAX, L);
-  if (C == 4) {
+  if (hrec && C == 4) {
+    (void)hipFuncSetAttribute((const void*)zip_bin_accumulate_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((zip_bin_accumulate_kernel<4, true>), grid, dim3(1024), lds, s, a, b);
+  } else if (hrec) {
+    (void)hipFuncSetAttribute((const void*)zip_bin_accumulate_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((zip_bin_accumulate_kernel<1, true>), grid, dim3(1024), lds, s, a, b);
+  } else if (C == 4) {
     (void)hipFuncSetAttribute((const void*)zip_bin_accumulate_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL((zip_bin_accumulate_kernel<4>), grid, dim3(1024), lds, s, a, b);
   } else {

@@ -830,11 +830,13 @@ ZIP_BIN_STAGED = _os.environ.get("SNERF_ZIP_UNSTAGED", "") == ""      # (the env
 
 
 def zip_encode_bwd_binned(tdist, origins, directions, radii, base_x, base_y, deg_jitter, offsets, grid_sizes, grad_feat, grad_table, L, C, n, m, Sl, H,
-                          std_scale, ksplit, g64_rows, level_rows, precounted=None):
+                          std_scale, ksplit, g64_rows, level_rows, precounted=None, half_records=False):
     """The table gradient of zip_encode_bwd without L2 atomics on the hashed levels and bit-reproducible: records binned by destination,
     accumulated per bin in LDS with fixed-point integer atomics (snerf_zip_encode_bwd_binned: count, scan on the device, write, accumulate).
     The fixed-point grid follows the gradient's magnitude (snerf_zip_bin_scale: 34 bits below max |grad_feat|).  `precounted` = the
-    (counts, wg_offsets) pair zip_encode_fwd_count returned for the same intervals and bin plan: the count pass is then skipped."""
+    (counts, wg_offsets) pair zip_encode_fwd_count returned for the same intervals and bin plan: the count pass is then skipped.
+    `half_records`: the records carry fp16 values scaled by the launch's exponent (10 / 4 instead of 18 / 8 bytes per record at C = 4 / 1):
+    every contribution is rounded to 11 significant bits once, the sums stay exact and order-independent (csrc/zip.hip, ZB_HALF_SHIFT)."""
     import numpy as np
     R, P = tdist.shape
     S = P - 1
@@ -864,10 +866,11 @@ def zip_encode_bwd_binned(tdist, origins, directions, radii, base_x, base_y, deg
     rec_val = _zb_workspace(dev, "val", capacity * max(C, 2), torch.float32)       # C = 1: {row, value} pairs in one 8-byte record
     # pass 1: the records staged in LDS and written run by run; ZIP_BIN_STAGED = False (A/B probes, tests): pass 3, every thread
     # writes its records where they fall (same records, another order inside a (workgroup, bin) run)
-    _lib.call("snerf_zip_encode_bwd_binned", 1 if ZIP_BIN_STAGED else 3, *args, _p(counts), _p(wgo), _p(starts), _p(rec_row), _p(rec_val), capacity,
-              None, 0, None, _stream())
+    wpass = (5 if ZIP_BIN_STAGED else 6) if half_records else (1 if ZIP_BIN_STAGED else 3)
+    _lib.call("snerf_zip_encode_bwd_binned", wpass, *args, _p(counts), _p(wgo), _p(starts), _p(rec_row), _p(rec_val), capacity,
+              None, 0, _p(scale) if half_records else None, _stream())
     g64 = torch.zeros(max(g64_rows, 1) * C, dtype=torch.int64, device=dev) if g64_rows > 0 else None
-    _lib.call("snerf_zip_encode_bwd_binned", 2, *args, _p(counts), _p(wgo), _p(starts), _p(rec_row), _p(rec_val), capacity, _p(g64), int(g64_rows),
+    _lib.call("snerf_zip_encode_bwd_binned", 7 if half_records else 2, *args, _p(counts), _p(wgo), _p(starts), _p(rec_row), _p(rec_val), capacity, _p(g64), int(g64_rows),
               _p(scale), _stream())
 
 

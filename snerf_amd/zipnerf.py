@@ -84,7 +84,7 @@ class Model(_ArenaModule):
     single_mlp: bool = False
 
     def __init__(self, config=None, compute: str = "bf16", table_dtype: str = "ref", device="cuda", grid_log2_hashmap_size: int = 21,
-                 nerf_desired_resolution: int = 8192, init_std: float = 1e-4, table_grad_dtype: str = "f32", use_semantic: bool = False,
+                 nerf_desired_resolution: int = 8192, init_std: float = 1e-4, table_grad_dtype: str = "table", use_semantic: bool = False,
                  class_num: int = 19, table_grad_mode: str = "binned", **kwargs):
         super().__init__()
         for k, v in kwargs.items():
@@ -131,9 +131,15 @@ class Model(_ArenaModule):
         # storage than the reference's on the proposal levels: an extension, benchmarked separately); "f32" none
         self.table_mode = {"ref": "ref", "f16": "f16", "fp16": "f16", "f32": "f32", "fp32": "f32"}[table_dtype]
         self.table_half = self.table_mode != "f32"        # (any table halved)
-        # "bf16": the hashed levels' table gradient is scattered as packed bf16 pairs (the reference's autocast path scatters
-        # __half2, gridencoder.cu:300-330); "f32" (default) keeps every contribution in fp32
-        self.table_grad_bf16 = {"f32": False, "fp32": False, "bf16": True}[table_grad_dtype]
+        # precision of the table gradient's CONTRIBUTIONS (the sums are exact in every binned mode).  "table" (default): like the table's
+        # storage -- the reference scatters __half2 atomics for the tables it halves (gridencoder.cu:300-330) and fp32 atomics otherwise;
+        # here a halved table's records carry fp16 values (10 instead of 18 bytes per record at C = 4), fp32 tables fp32 records;
+        # "f32": fp32 records on every level; "f16": fp16 records on every level (4-byte records at C = 1: narrower than the reference on the
+        # proposal levels); "bf16": the atomic scatter with packed bf16 pairs (round 1, kept for A/B runs)
+        if table_grad_dtype not in ("table", "f32", "fp32", "f16", "fp16", "bf16"):
+            raise ValueError(table_grad_dtype)
+        self.table_grad_bf16 = table_grad_dtype == "bf16"
+        self.table_grad_records = {"table": "table", "f32": "f32", "fp32": "f32", "f16": "f16", "fp16": "f16", "bf16": "f32"}[table_grad_dtype]
         # "binned" (default): contributions are binned by destination and accumulated per bin in LDS with fixed-point integer atomics --
         # no L2 atomics on the hashed levels, fp32-exact sums, BIT-REPRODUCIBLE gradients (csrc/zip.hip, snerf_zip_encode_bwd_binned);
         # "atomic": the reference's scatter (gridencoder.cu:248-340) with fp32 (or packed bf16, table_grad_dtype) global atomics
@@ -281,6 +287,12 @@ class Model(_ArenaModule):
             ctx = dict(o=o, d=d, vd=vd, radii=radii, bx=bx, by=by, levels=det, bg=bg, n=sample_n, m=sample_m)
         return levels, ctx
 
+    def _half_records(self, lvl):
+        """whether level lvl's binned table gradient travels as fp16 records (table_grad_dtype)"""
+        if self.table_grad_records == "table":
+            return self.table_mode == "f16" or (self.table_mode == "ref" and self.encs[lvl].C % 2 == 0)
+        return self.table_grad_records == "f16"
+
     def _backward(self, ctx, grads, on_done=None, ray_grads=False):
         """grads[lvl] = (g_rgb, g_depth, g_acc, g_w); accumulates parameter gradients into the arena.  `on_done(prefix)` is called as
         soon as a level's gradients (MLP + hash table) are final, NeRF level first.
@@ -339,7 +351,7 @@ class Model(_ArenaModule):
                 ks, g64_rows, lrows = ops.zip_bin_plan(e.offsets, e.C, P * ctx["n"] * 8)
                 ops.zip_encode_bwd_binned(L["tdist"], ctx["o"], ctx["d"], ctx["radii"], ctx["bx"], ctx["by"], L["degj"], self.dev_offsets[lvl],
                                           self.dev_sizes[lvl], dF, gtab, e.L, e.C, ctx["n"], ctx["m"], e.Sl, e.H, self.std_scale, ks, g64_rows, lrows,
-                                          precounted=L.get("precount"))
+                                          precounted=L.get("precount"), half_records=self._half_records(lvl))
                 L["precount"] = None                                                   # (its workgroup-offset buffer is large: release it now)
                 if on_done is not None:
                     on_done(self.names[lvl])

@@ -346,7 +346,7 @@ def zip_encode_bwd(tdist, origins, directions, radii, base_x, base_y, deg_jitter
 
 
 def zip_encode_bwd_binned(tdist, origins, directions, radii, base_x, base_y, deg_jitter, offsets, grid_sizes, grad_feat, grad_table, L, C, n, m, Sl, H,
-                          std_scale, ksplit, g64_rows, level_rows, precounted=None):
+                          std_scale, ksplit, g64_rows, level_rows, precounted=None, half_records=False):
     assert len(ksplit) == L and all(k >= 1 for k in ksplit) and len(level_rows) == L
     assert precounted is None or precounted == ("precounted", tuple(ksplit)), "the forward's counts belong to another bin plan"
     zip_encode_bwd(tdist, origins, directions, radii, base_x, base_y, deg_jitter, offsets, grid_sizes, grad_feat, grad_table, L, C, n, m, Sl, H, std_scale)

@@ -799,6 +799,21 @@ def test_zip_table_gradient_binned_is_exact_and_bit_reproducible(lvl, gscale, mo
     assert float(ref.norm()) > 0 and rel < 2e-6, rel
     nz = ref != 0
     assert float(((outs[0] - ref).abs()[nz] / ref.abs()[nz]).median()) < 1e-6
+    # half records (table_grad_dtype="table" on a halved table / "f16"): fp16 values scaled by the launch's exponent, 10 / 4 bytes per record.
+    # Every contribution is rounded to 11 bits once; sums exact: bit-reproducible, staged == direct, and within 2^-11 / sqrt(#addends) of
+    # the fp32 records -- whatever the gradient's magnitude (1e-11 and 3e3 are cases of this test)
+    hs = []
+    for staged in (True, False, True):
+        monkeypatch.setattr(ops, "ZIP_BIN_STAGED", staged)
+        gh = torch.zeros(e.rows, e.C, device="cuda")
+        ops.zip_encode_bwd_binned(*common, gh, *tail, ks, g64_rows, lrows, half_records=True, precounted=(counts, wgo) if len(hs) == 2 else None)
+        hs.append(gh)
+    assert torch.equal(hs[0], hs[1]) and torch.equal(hs[0], hs[2]), "half records: staged / direct / precounted must be bit-identical"
+    relh = float((hs[0] - outs[0]).norm() / outs[0].norm())
+    nzh = outs[0] != 0
+    med = float(((hs[0] - outs[0]).abs()[nzh] / outs[0].abs()[nzh]).median())
+    print(f"MEASURED half-record table gradient vs fp32 records (grid {lvl}, |g| ~ {gscale:g}): rel L2 {relh:.3e}, median entry {med:.3e}")
+    assert relh < 3e-4 and med < 2.0 ** -11, (relh, med)           # one rounding to 11 bits per contribution (<= 2^-12 relative each), and they average
 
 
 def test_binned_table_gradient_refuses_tables_with_more_row_ranges_than_bins():
