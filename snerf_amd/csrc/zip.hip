@@ -516,8 +516,13 @@ __device__ __forceinline__ void zip_fwd_all_body(const ZipEnc& a, const ZipBin& 
     float acc[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) acc[c] = 0.f;
-    uint32_t cur[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};     // COUNT: cell of the current run of multisamples
+    // cell of the current run of multisamples: consecutive multisamples of an interval often sit in ONE cell (always on the coarse
+    // levels), whose 8 corner entries are then kept in registers instead of being gathered again (same rows, same values: identical
+    // features); COUNT tallies a record per corner of every run, exactly zip_emit_level's merging
+    uint32_t cur[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
     const int K = COUNT ? b.ksplit[level] : 1, rep = COUNT ? (int)(blockIdx.x % (unsigned)K) : 0;
+    float cv[(C == 1) ? 8 : 1];                          // C = 1: the cell's corner values (corner = x + 2 y + 4 z)
+    ZVec<TT, C> ce[(C == 1) ? 1 : 8];                    // C > 1: the cell's corner entries
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       if (j >= a.n || !((inb >> j) & 1u)) continue;     // outside [0,1]^3 the encoder returns zeros
@@ -529,11 +534,8 @@ __device__ __forceinline__ void zip_fwd_all_body(const ZipEnc& a, const ZipBin& 
       for (int k = 0; k < 3; ++k) {
         zip_cell(X[j][k], scale, &pg[k], &fr[k]);
       }
-      bool newcell = false;
-      if constexpr (COUNT) {
-        newcell = pg[0] != cur[0] || pg[1] != cur[1] || pg[2] != cur[2];
-        cur[0] = pg[0]; cur[1] = pg[1]; cur[2] = pg[2];
-      }
+      const bool newcell = pg[0] != cur[0] || pg[1] != cur[1] || pg[2] != cur[2];
+      cur[0] = pg[0]; cur[1] = pg[1]; cur[2] = pg[2];
       auto tally = [&](long row) __attribute__((always_inline)) {
         if constexpr (COUNT) { if (newcell) atomicAdd(cnt + (int)((uint32_t)row >> b.bshift) * K + rep, 1); }
       };
@@ -544,20 +546,22 @@ __device__ __forceinline__ void zip_fwd_all_body(const ZipEnc& a, const ZipBin& 
         float pa[8];
 #pragma unroll
         for (int yz = 0; yz < 4; ++yz) {
-          uint32_t pl[3] = {pg[0], pg[1] + (yz & 1), pg[2] + (yz >> 1)};
-          const long r0 = zip_grid_index(hs, res, pl);
-          pl[0] = pg[0] + 1;
-          const long r1 = zip_grid_index(hs, res, pl);
-          tally(r0); tally(r1);
-          float v0, v1;
-          if ((r0 ^ r1) == 1) {
-            const float2 both = *reinterpret_cast<const float2*>(tab + (r0 & ~1L));
-            v0 = (r0 & 1) ? both.y : both.x;
-            v1 = (r0 & 1) ? both.x : both.y;
-          } else {
-            v0 = (float)tab[r0];
-            v1 = (float)tab[r1];
+          if (newcell) {
+            uint32_t pl[3] = {pg[0], pg[1] + (yz & 1), pg[2] + (yz >> 1)};
+            const long r0 = zip_grid_index(hs, res, pl);
+            pl[0] = pg[0] + 1;
+            const long r1 = zip_grid_index(hs, res, pl);
+            tally(r0); tally(r1);
+            if ((r0 ^ r1) == 1) {
+              const float2 both = *reinterpret_cast<const float2*>(tab + (r0 & ~1L));
+              cv[2 * yz] = (r0 & 1) ? both.y : both.x;
+              cv[2 * yz + 1] = (r0 & 1) ? both.x : both.y;
+            } else {
+              cv[2 * yz] = (float)tab[r0];
+              cv[2 * yz + 1] = (float)tab[r1];
+            }
           }
+          const float v0 = cv[2 * yz], v1 = cv[2 * yz + 1];
           float wa = 1.f - fr[0], wb = fr[0];
           wa *= (yz & 1) ? fr[1] : 1.f - fr[1]; wb *= (yz & 1) ? fr[1] : 1.f - fr[1];
           wa *= (yz >> 1) ? fr[2] : 1.f - fr[2]; wb *= (yz >> 1) ? fr[2] : 1.f - fr[2];
@@ -570,22 +574,24 @@ __device__ __forceinline__ void zip_fwd_all_body(const ZipEnc& a, const ZipBin& 
         float pa[8];
 #pragma unroll
         for (int yz = 0; yz < 4; ++yz) {
-          uint32_t pl[3] = {pg[0], pg[1] + (yz & 1), pg[2] + (yz >> 1)};
-          const long r0 = zip_grid_index(hs, res, pl);
-          pl[0] = pg[0] + 1;
-          const long r1 = zip_grid_index(hs, res, pl);
-          tally(r0); tally(r1);
-          float v0, v1;
-          if ((r0 ^ r1) == 1) {                           // adjacent entries of one aligned 32-bit word (see zip_point_level)
-            const uint32_t word = *reinterpret_cast<const uint32_t*>(tab + (r0 & ~1L));
-            const uint16_t lo16 = (uint16_t)(word & 0xffffu), hi16 = (uint16_t)(word >> 16);
-            const uint16_t b0 = (r0 & 1) ? hi16 : lo16, b1 = (r0 & 1) ? lo16 : hi16;
-            v0 = (float)__builtin_bit_cast(TT, b0);
-            v1 = (float)__builtin_bit_cast(TT, b1);
-          } else {
-            v0 = (float)tab[r0];
-            v1 = (float)tab[r1];
+          if (newcell) {
+            uint32_t pl[3] = {pg[0], pg[1] + (yz & 1), pg[2] + (yz >> 1)};
+            const long r0 = zip_grid_index(hs, res, pl);
+            pl[0] = pg[0] + 1;
+            const long r1 = zip_grid_index(hs, res, pl);
+            tally(r0); tally(r1);
+            if ((r0 ^ r1) == 1) {                           // adjacent entries of one aligned 32-bit word (see zip_point_level)
+              const uint32_t word = *reinterpret_cast<const uint32_t*>(tab + (r0 & ~1L));
+              const uint16_t lo16 = (uint16_t)(word & 0xffffu), hi16 = (uint16_t)(word >> 16);
+              const uint16_t b0 = (r0 & 1) ? hi16 : lo16, b1 = (r0 & 1) ? lo16 : hi16;
+              cv[2 * yz] = (float)__builtin_bit_cast(TT, b0);
+              cv[2 * yz + 1] = (float)__builtin_bit_cast(TT, b1);
+            } else {
+              cv[2 * yz] = (float)tab[r0];
+              cv[2 * yz + 1] = (float)tab[r1];
+            }
           }
+          const float v0 = cv[2 * yz], v1 = cv[2 * yz + 1];
           float wa = 1.f - fr[0], wb = fr[0];
           wa *= (yz & 1) ? fr[1] : 1.f - fr[1]; wb *= (yz & 1) ? fr[1] : 1.f - fr[1];
           wa *= (yz >> 1) ? fr[2] : 1.f - fr[2]; wb *= (yz >> 1) ? fr[2] : 1.f - fr[2];
@@ -600,20 +606,22 @@ __device__ __forceinline__ void zip_fwd_all_body(const ZipEnc& a, const ZipBin& 
         // sector instead of a quarter.  Same products in the same order as the generic loop (corner index = x + 2 y + 4 z).
 #pragma unroll
         for (int yz = 0; yz < 4; ++yz) {
-          uint32_t pl[3] = {pg[0], pg[1] + (yz & 1), pg[2] + (yz >> 1)};
-          const long r0 = zip_grid_index(hs, res, pl);
-          pl[0] = pg[0] + 1;
-          const long r1 = zip_grid_index(hs, res, pl);
-          tally(r0); tally(r1);
-          ZVec<TT, 4> e0, e1;
-          if ((r0 ^ r1) == 1) {
-            const ZVec<TT, 8> both = *reinterpret_cast<const ZVec<TT, 8>*>(tab + (r0 & ~1L) * 4);
+          if (newcell) {
+            uint32_t pl[3] = {pg[0], pg[1] + (yz & 1), pg[2] + (yz >> 1)};
+            const long r0 = zip_grid_index(hs, res, pl);
+            pl[0] = pg[0] + 1;
+            const long r1 = zip_grid_index(hs, res, pl);
+            tally(r0); tally(r1);
+            if ((r0 ^ r1) == 1) {
+              const ZVec<TT, 8> both = *reinterpret_cast<const ZVec<TT, 8>*>(tab + (r0 & ~1L) * 4);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { e0.v[c] = both.v[(r0 & 1) * 4 + c]; e1.v[c] = both.v[(r1 & 1) * 4 + c]; }
-          } else {
-            e0 = *reinterpret_cast<const ZVec<TT, 4>*>(tab + r0 * 4);
-            e1 = *reinterpret_cast<const ZVec<TT, 4>*>(tab + r1 * 4);
+              for (int c = 0; c < 4; ++c) { ce[2 * yz].v[c] = both.v[(r0 & 1) * 4 + c]; ce[2 * yz + 1].v[c] = both.v[(r1 & 1) * 4 + c]; }
+            } else {
+              ce[2 * yz] = *reinterpret_cast<const ZVec<TT, 4>*>(tab + r0 * 4);
+              ce[2 * yz + 1] = *reinterpret_cast<const ZVec<TT, 4>*>(tab + r1 * 4);
+            }
           }
+          const ZVec<TT, 4> e0 = ce[2 * yz], e1 = ce[2 * yz + 1];
           float wa = 1.f - fr[0], wb = fr[0];
           wa *= (yz & 1) ? fr[1] : 1.f - fr[1]; wb *= (yz & 1) ? fr[1] : 1.f - fr[1];
           wa *= (yz >> 1) ? fr[2] : 1.f - fr[2]; wb *= (yz >> 1) ? fr[2] : 1.f - fr[2];
@@ -631,11 +639,14 @@ __device__ __forceinline__ void zip_fwd_all_body(const ZipEnc& a, const ZipBin& 
           for (int k = 0; k < 3; ++k) {
             if (idx & (1 << k)) { w *= fr[k]; pl[k] = pg[k] + 1; } else { w *= 1.f - fr[k]; pl[k] = pg[k]; }
           }
-          const long row = zip_grid_index(hs, res, pl);
-          tally(row);
-          const ZVec<TT, C> r = *reinterpret_cast<const ZVec<TT, C>*>(tab + row * C);
+          if (newcell) {
+            const long row = zip_grid_index(hs, res, pl);
+            tally(row);
+            if constexpr (C == 1) cv[idx] = (float)tab[row];
+            else ce[idx] = *reinterpret_cast<const ZVec<TT, C>*>(tab + row * C);
+          }
 #pragma unroll
-          for (int c = 0; c < C; ++c) acc[c] += (w * we) * (float)r.v[c];
+          for (int c = 0; c < C; ++c) acc[c] += (w * we) * (C == 1 ? cv[idx] : (float)ce[C == 1 ? 0 : idx].v[c]);
         }
       }
     }
@@ -1384,6 +1395,111 @@ __global__ __launch_bounds__(256) void zip_bin_emit_kernel(ZipEnc a, ZipBin b) {
   }
 }
 
+// PASS 1, direct writer, ALL LEVELS PER THREAD (round 4; the single-channel grids): the interval's multisample positions (sincos,
+// contraction, cbrt: about half of the per-level writer's arithmetic) are evaluated once and kept in registers while the workgroup walks
+// the levels one after the other -- the per-level ranges pass 0 reserved are reloaded between two barriers per level.  Same records in
+// the same ranges as zip_bin_emit_kernel<.., 1> with grid.y = levels.
+template <typename OT, int C, bool HREC>
+__global__ __launch_bounds__(256) void zip_bin_emit_all_kernel(ZipEnc a, ZipBin b) {
+  __shared__ int cnt[ZB_NBMAX];
+  __shared__ long base[ZB_NBMAX];
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  const bool live = p < a.R * a.S;
+  float X[8][3], SDI[8];
+  unsigned inb = 0;
+  if (live) {
+    const long ray = p / a.S;
+    const int i = (int)(p - ray * a.S);
+    const float t0 = a.tdist[ray * (a.S + 1) + i], t1 = a.tdist[ray * (a.S + 1) + i + 1];
+    float o[3], d[3], bx[3], by[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { o[k] = a.origins[ray * 3 + k]; d[k] = a.directions[ray * 3 + k]; bx[k] = a.base_x[ray * 3 + k]; by[k] = a.base_y[ray * 3 + k]; }
+    const float rad = a.radii[ray];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j < a.n) {
+        zip_sample_point(a, ray, i, j, t0, t1, o, d, bx, by, rad, X[j], &SDI[j]);
+        if (!(X[j][0] < 0.f || X[j][0] > 1.f || X[j][1] < 0.f || X[j][1] > 1.f || X[j][2] < 0.f || X[j][2] > 1.f)) inb |= 1u << j;
+      }
+    }
+  }
+  float hmul = 1.f;
+  if constexpr (HREC) hmul = exp2f((float)(b.scale_exp[0] - ZB_HALF_SHIFT));
+  for (int level = 0; level < a.L; ++level) {
+    __syncthreads();
+    const unsigned* wgo1 = b.wg_offsets + ((long)level * gridDim.x + blockIdx.x) * ZB_NBMAX;
+    for (int k = threadIdx.x; k < ZB_NBMAX; k += 256) { base[k] = b.starts[level * ZB_NBMAX + k] + (long)wgo1[k]; cnt[k] = 0; }
+    __syncthreads();
+    if (!live) continue;
+    const uint32_t hs = a.offsets[level + 1] - a.offsets[level];
+    const float scale = exp2f(level * a.Sl) * a.H - 1.0f;
+    const uint32_t res = (uint32_t)ceilf(scale) + 1;
+    const int K = b.ksplit[level], rep = (int)(blockIdx.x % (unsigned)K);
+    const float gs = (float)a.grid_sizes[level];
+    float g[C];
+    const OT* gi = (const OT*)a.feat + p * a.ld + level * C;
+#pragma unroll
+    for (int c = 0; c < C; ++c) g[c] = (float)gi[c] / (float)a.n;
+    uint32_t cur[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
+    float wsum[8];
+#pragma unroll
+    for (int idx = 0; idx < 8; ++idx) wsum[idx] = 0.f;
+    auto flush = [&]() __attribute__((always_inline)) {
+      if (cur[0] == 0xffffffffu) return;
+#pragma unroll
+      for (int idx = 0; idx < 8; ++idx) {
+        uint32_t pl[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pl[k] = cur[k] + ((idx >> k) & 1);
+        const uint32_t row = zip_grid_index(hs, res, pl);
+        const int bin = (int)(row >> b.bshift) * K + rep;
+        const int slot = atomicAdd(cnt + bin, 1);
+        const long r = base[bin] + slot;
+        if (r < b.capacity) {
+          const unsigned lrow = row & ((1u << b.bshift) - 1u);
+          if constexpr (HREC && C == 1) {
+            ((unsigned*)b.rec_val)[r] = lrow | (zb_half_bits((wsum[idx] * g[0]) * hmul) << 16);
+          } else if constexpr (C == 1) {
+            const uint2 rv = {lrow, __float_as_uint(wsum[idx] * g[0])};
+            *(uint2*)(b.rec_val + r * 2) = rv;
+          } else if constexpr (HREC) {
+            b.rec_row[r] = (unsigned short)lrow;
+            const zb_h4 v4 = {(_Float16)((wsum[idx] * g[0]) * hmul), (_Float16)((wsum[idx] * g[1]) * hmul), (_Float16)((wsum[idx] * g[2]) * hmul), (_Float16)((wsum[idx] * g[3]) * hmul)};
+            *(zb_h4*)(b.rec_val + r * 2) = v4;
+          } else {
+            b.rec_row[r] = (unsigned short)lrow;
+            const f32x4 v4 = {wsum[idx] * g[0], wsum[idx] * g[1], wsum[idx] * g[2], wsum[idx] * g[3]};
+            *(f32x4*)(b.rec_val + r * 4) = v4;
+          }
+        }
+        wsum[idx] = 0.f;
+      }
+    };
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j >= a.n || !((inb >> j) & 1u)) continue;
+      const float sd = SDI[j];
+      const float we = erff(1.f / sqrtf(8.f * sd * sd * gs * gs));
+      float fr[3];
+      uint32_t pg[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) zip_cell(X[j][k], scale, &pg[k], &fr[k]);
+      if (pg[0] != cur[0] || pg[1] != cur[1] || pg[2] != cur[2]) {
+        flush();
+        cur[0] = pg[0]; cur[1] = pg[1]; cur[2] = pg[2];
+      }
+#pragma unroll
+      for (int idx = 0; idx < 8; ++idx) {
+        float w = 1.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) w *= (idx & (1 << k)) ? fr[k] : 1.f - fr[k];
+        wsum[idx] += w * we;
+      }
+    }
+    flush();
+  }
+}
+
 // PASS 1 with the records STAGED IN LDS (round 3).  Written straight from the emitting threads (kernel above), a workgroup's 16- /
 // 8-byte records go to ~hundreds of bins in thread order: every store instruction touches 64 different lines, partially, and the
 // lines are evicted from L2 long before the workgroup's other records of the same bin arrive -- the NeRF level wrote 27.6 GB for
@@ -1723,8 +1839,11 @@ extern "C" int snerf_zip_encode_bwd_binned(int pass, const float* tdist, const f
   hipStream_t s = (hipStream_t)stream;
   const dim3 blk(256);
   // passes 5 / 6 / 7 = 1 / 3 / 2 with HALF records (see ZB_HALF_SHIFT): the writers then need scale_exp too
-  const bool hrec = pass >= 5 && pass <= 7;
-  if (hrec) pass = pass == 5 ? 1 : (pass == 6 ? 3 : 2);
+  // passes 8 / 9 (probes): the all-levels direct writer whatever C, with fp32 / half records
+  const bool hrec = (pass >= 5 && pass <= 7) || pass == 9;
+  const bool force_all = pass == 8 || pass == 9;
+  if (force_all) pass = 1;
+  else if (hrec) pass = pass == 5 ? 1 : (pass == 6 ? 3 : 2);
   if (pass == 0 || pass == 1 || pass == 3 || pass == 4) {
     if (grad_feat == nullptr || wg_offsets == nullptr || (pass != 0 && (starts == nullptr || rec_row == nullptr || rec_val == nullptr)) || (hrec && scale_exp == nullptr))
       return SNERF_ERR_ARG;
@@ -1732,8 +1851,13 @@ extern "C" int snerf_zip_encode_bwd_binned(int pass, const float* tdist, const f
     // pass 1: records staged in LDS and written run by run (zip_bin_write_staged_kernel); pass 3 (A/B probes, or more than 8
     // multisamples): every thread writes its records where they fall
     // (C = 1: 8-byte records in 128 row ranges per level -- the direct writer is faster there: 4.6 vs 5.8 ms per proposal level)
-    const bool staged = ((pass == 1 && C == 4) || pass == 4) && n <= ZS_NMAX;     // (pass 4: probe -- staged for C = 1 too)
+    const bool staged = ((pass == 1 && C == 4 && !force_all) || pass == 4) && n <= ZS_NMAX;     // (pass 4: probe -- staged for C = 1 too)
+    // pass 1 at C = 1: the direct writer with all levels per thread (pass 3 keeps the one-level-per-thread form for A/B runs and tests)
+    const bool all_levels = pass == 1 && (C == 1 || force_all) && n <= 8;
+    const dim3 grid1((unsigned)((R * S + 255) / 256), 1);
 #define ZBE(OT, CC) do { if (pass == 0) hipLaunchKernelGGL((zip_bin_emit_kernel<OT, CC, 0>), grid, blk, 0, s, a, b); \
+                         else if (all_levels && hrec) hipLaunchKernelGGL((zip_bin_emit_all_kernel<OT, CC, true>), grid1, blk, 0, s, a, b); \
+                         else if (all_levels) hipLaunchKernelGGL((zip_bin_emit_all_kernel<OT, CC, false>), grid1, blk, 0, s, a, b); \
                          else if (staged && hrec) hipLaunchKernelGGL((zip_bin_write_staged_kernel<OT, CC, 4, true>), grid, blk, 0, s, a, b); \
                          else if (staged) hipLaunchKernelGGL((zip_bin_write_staged_kernel<OT, CC, 4>), grid, blk, 0, s, a, b); \
                          else if (hrec) hipLaunchKernelGGL((zip_bin_emit_kernel<OT, CC, 1, true>), grid, blk, 0, s, a, b); \

@@ -826,6 +826,7 @@ def _zb_workspace(dev, key, numel, dtype):
 
 
 import os as _os
+ZIP_BIN_ALL_LEVELS = _os.environ.get("SNERF_ZIP_ALL_LEVELS", "") != ""   # probe switch: A/B runs of tools/bench_zip.py
 ZIP_BIN_STAGED = _os.environ.get("SNERF_ZIP_UNSTAGED", "") == ""      # (the environment switch: A/B runs of tools/bench_zip.py)
 
 
@@ -867,6 +868,8 @@ def zip_encode_bwd_binned(tdist, origins, directions, radii, base_x, base_y, deg
     # pass 1: the records staged in LDS and written run by run; ZIP_BIN_STAGED = False (A/B probes, tests): pass 3, every thread
     # writes its records where they fall (same records, another order inside a (workgroup, bin) run)
     wpass = (5 if ZIP_BIN_STAGED else 6) if half_records else (1 if ZIP_BIN_STAGED else 3)
+    if ZIP_BIN_ALL_LEVELS and ZIP_BIN_STAGED:            # (probe: the all-levels direct writer for the four-channel grid too)
+        wpass = 9 if half_records else 8
     _lib.call("snerf_zip_encode_bwd_binned", wpass, *args, _p(counts), _p(wgo), _p(starts), _p(rec_row), _p(rec_val), capacity,
               None, 0, _p(scale) if half_records else None, _stream())
     g64 = torch.zeros(max(g64_rows, 1) * C, dtype=torch.int64, device=dev) if g64_rows > 0 else None

@@ -84,7 +84,7 @@ class Model(_ArenaModule):
     single_mlp: bool = False
 
     def __init__(self, config=None, compute: str = "bf16", table_dtype: str = "ref", device="cuda", grid_log2_hashmap_size: int = 21,
-                 nerf_desired_resolution: int = 8192, init_std: float = 1e-4, table_grad_dtype: str = "table", use_semantic: bool = False,
+                 nerf_desired_resolution: int = 8192, init_std: float = 1e-4, table_grad_dtype: str = "auto", use_semantic: bool = False,
                  class_num: int = 19, table_grad_mode: str = "binned", **kwargs):
         super().__init__()
         for k, v in kwargs.items():
@@ -131,15 +131,17 @@ class Model(_ArenaModule):
         # storage than the reference's on the proposal levels: an extension, benchmarked separately); "f32" none
         self.table_mode = {"ref": "ref", "f16": "f16", "fp16": "f16", "f32": "f32", "fp32": "f32"}[table_dtype]
         self.table_half = self.table_mode != "f32"        # (any table halved)
-        # precision of the table gradient's CONTRIBUTIONS (the sums are exact in every binned mode).  "table" (default): like the table's
-        # storage -- the reference scatters __half2 atomics for the tables it halves (gridencoder.cu:300-330) and fp32 atomics otherwise;
-        # here a halved table's records carry fp16 values (10 instead of 18 bytes per record at C = 4), fp32 tables fp32 records;
-        # "f32": fp32 records on every level; "f16": fp16 records on every level (4-byte records at C = 1: narrower than the reference on the
-        # proposal levels); "bf16": the atomic scatter with packed bf16 pairs (round 1, kept for A/B runs)
-        if table_grad_dtype not in ("table", "f32", "fp32", "f16", "fp16", "bf16"):
+        # precision of the table gradient's CONTRIBUTIONS (the sums are exact in every binned mode).  A contribution is (interpolation
+        # weight) x (d loss / d feature), and the second factor arrives in the compute dtype: with 16-bit compute it carries 8 (bf16) or 11
+        # (fp16) significant bits already.  "auto" (default): fp16 records (10 / 4 instead of 18 / 8 bytes at C = 4 / 1; one rounding to 11
+        # bits per contribution) wherever the table is halved -- the reference scatters __half2 atomics there, gridencoder.cu:300-330, every
+        # ADDITION rounding to 11 bits -- or the networks compute in 16 bits; fp32 records with fp32 compute on an fp32 table (the parity
+        # mode).  "table": by the table's storage only; "f32" / "f16": every level; "bf16": the atomic scatter with packed bf16 pairs
+        # (round 1, kept for A/B runs)
+        if table_grad_dtype not in ("auto", "table", "f32", "fp32", "f16", "fp16", "bf16"):
             raise ValueError(table_grad_dtype)
         self.table_grad_bf16 = table_grad_dtype == "bf16"
-        self.table_grad_records = {"table": "table", "f32": "f32", "fp32": "f32", "f16": "f16", "fp16": "f16", "bf16": "f32"}[table_grad_dtype]
+        self.table_grad_records = {"auto": "auto", "table": "table", "f32": "f32", "fp32": "f32", "f16": "f16", "fp16": "f16", "bf16": "f32"}[table_grad_dtype]
         # "binned" (default): contributions are binned by destination and accumulated per bin in LDS with fixed-point integer atomics --
         # no L2 atomics on the hashed levels, fp32-exact sums, BIT-REPRODUCIBLE gradients (csrc/zip.hip, snerf_zip_encode_bwd_binned);
         # "atomic": the reference's scatter (gridencoder.cu:248-340) with fp32 (or packed bf16, table_grad_dtype) global atomics
@@ -289,8 +291,9 @@ class Model(_ArenaModule):
 
     def _half_records(self, lvl):
         """whether level lvl's binned table gradient travels as fp16 records (table_grad_dtype)"""
-        if self.table_grad_records == "table":
-            return self.table_mode == "f16" or (self.table_mode == "ref" and self.encs[lvl].C % 2 == 0)
+        if self.table_grad_records in ("table", "auto"):
+            halved = self.table_mode == "f16" or (self.table_mode == "ref" and self.encs[lvl].C % 2 == 0)
+            return halved or (self.table_grad_records == "auto" and self.dt in (ops.BF16, ops.F16))
         return self.table_grad_records == "f16"
 
     def _backward(self, ctx, grads, on_done=None, ray_grads=False):

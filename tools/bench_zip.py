@@ -19,7 +19,7 @@ def main():
                     help="gather tables: ref = the reference's autocast policy (C = 4 NeRF table fp16, C = 1 proposal tables fp32, gridencoder/grid.py:41-44); "
                          "f16 = all three halved (narrower than the reference on the proposal levels); f32 = none")
     ap.add_argument("--log2T", type=int, default=21)
-    ap.add_argument("--table-grad", default="table", choices=["table", "f32", "f16", "bf16"])
+    ap.add_argument("--table-grad", default="auto", choices=["auto", "table", "f32", "f16", "bf16"])
     ap.add_argument("--table-grad-mode", default="binned", choices=["binned", "atomic"],
                     help="binned (default): records binned by destination + per-bin LDS fixed-point accumulation (no L2 atomics, bit-reproducible); "
                          "atomic: the reference's scatter with global atomics")
