@@ -722,6 +722,8 @@ __global__ __launch_bounds__(256) void zip_encode_prop_kernel(ZipEnc a, ZipPropM
     const TT* tab = (const TT*)a.table + (long)a.offsets[level];
     const float gs = (float)a.grid_sizes[level];
     float acc = 0.f;
+    uint32_t cur[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};   // the cell whose corner values are in cv (see zip_fwd_all_body)
+    float cv[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       if (j >= a.n || !((inb >> j) & 1u)) continue;
@@ -733,25 +735,29 @@ __global__ __launch_bounds__(256) void zip_encode_prop_kernel(ZipEnc a, ZipPropM
       for (int k = 0; k < 3; ++k) {
         zip_cell(X[j][k], scale, &pg[k], &fr[k]);
       }
+      const bool newcell = pg[0] != cur[0] || pg[1] != cur[1] || pg[2] != cur[2];
+      cur[0] = pg[0]; cur[1] = pg[1]; cur[2] = pg[2];
       float pa[8];
 #pragma unroll
       for (int yz = 0; yz < 4; ++yz) {
-        uint32_t pl[3] = {pg[0], pg[1] + (yz & 1), pg[2] + (yz >> 1)};
-        const long r0 = zip_grid_index(hs, res, pl);
-        pl[0] = pg[0] + 1;
-        const long r1 = zip_grid_index(hs, res, pl);
-        float v0, v1;
-        // (fp32 tables: the aligned-pair 8-byte load that helps the training forward, zip_fwd_all_body, costs this kernel 20 % on the
-        // 8-level proposal grid -- 5.04 -> 6.06 ms per 4.2 M intervals, round 3 -- and stays out)
-        if (sizeof(TT) == 2 && (r0 ^ r1) == 1) {
-          const uint32_t word = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(tab) + (r0 & ~1L));
-          const uint16_t lo16 = (uint16_t)(word & 0xffffu), hi16 = (uint16_t)(word >> 16);
-          const uint16_t b0 = (r0 & 1) ? hi16 : lo16, b1 = (r0 & 1) ? lo16 : hi16;
-          if constexpr (sizeof(TT) == 2) { v0 = (float)__builtin_bit_cast(TT, b0); v1 = (float)__builtin_bit_cast(TT, b1); } else { v0 = v1 = 0.f; }
-        } else {
-          v0 = (float)tab[r0];
-          v1 = (float)tab[r1];
+        if (newcell) {
+          uint32_t pl[3] = {pg[0], pg[1] + (yz & 1), pg[2] + (yz >> 1)};
+          const long r0 = zip_grid_index(hs, res, pl);
+          pl[0] = pg[0] + 1;
+          const long r1 = zip_grid_index(hs, res, pl);
+          // (fp32 tables: the aligned-pair 8-byte load that helps the training forward, zip_fwd_all_body, costs this kernel 20 % on the
+          // 8-level proposal grid -- 5.04 -> 6.06 ms per 4.2 M intervals, round 3 -- and stays out)
+          if (sizeof(TT) == 2 && (r0 ^ r1) == 1) {
+            const uint32_t word = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(tab) + (r0 & ~1L));
+            const uint16_t lo16 = (uint16_t)(word & 0xffffu), hi16 = (uint16_t)(word >> 16);
+            const uint16_t b0 = (r0 & 1) ? hi16 : lo16, b1 = (r0 & 1) ? lo16 : hi16;
+            if constexpr (sizeof(TT) == 2) { cv[2 * yz] = (float)__builtin_bit_cast(TT, b0); cv[2 * yz + 1] = (float)__builtin_bit_cast(TT, b1); }
+          } else {
+            cv[2 * yz] = (float)tab[r0];
+            cv[2 * yz + 1] = (float)tab[r1];
+          }
         }
+        const float v0 = cv[2 * yz], v1 = cv[2 * yz + 1];
         float wa = 1.f - fr[0], wb = fr[0];
         wa *= (yz & 1) ? fr[1] : 1.f - fr[1]; wb *= (yz & 1) ? fr[1] : 1.f - fr[1];
         wa *= (yz >> 1) ? fr[2] : 1.f - fr[2]; wb *= (yz >> 1) ? fr[2] : 1.f - fr[2];

@@ -14,7 +14,8 @@ for spec in "fetch FETCH_SIZE" "write WRITE_SIZE" "req TCC_EA0_RDREQ_sum TCC_EA0
   run classic $tag "$BC" "$@"
 done
 cd $ROOT
-{ for k in "zip_encode_fwd_all_kernelI6__half" "E, true>" "zip_bin_write_staged_kernelIDF16bLi4" "E, 1>" "zip_bin_accumulate_kernel<4>" "zip_bin_accumulate_kernel<1>"; do python tools/pmc_summary.py $O/zip "$k"; done
+# (kernel-name patterns of the fp16 compute mode: NeRF-level / proposal-level training forward, staged writer C = 4, all-levels writer C = 1, accumulate)
+{ for k in "zip_encode_fwd_all_kernelI6__half" "zip_encode_fwd_all_kernelIfDF16_Li1ELb1" "zip_bin_write_staged_kernelIDF16_Li4" "zip_bin_emit_all_kernelIDF16_Li1" "zip_bin_accumulate_kernel<4, true>" "zip_bin_accumulate_kernel<1, true>"; do python tools/pmc_summary.py $O/zip "$k"; done
   for k in "fmlp_kernel<0, false, true>" "fchain_bwd_kernel<0>"; do python tools/pmc_summary.py $O/classic "$k"; done; } > $O/summary.txt 2>&1
 python - <<'PY'
 import json, os, re
@@ -28,11 +29,11 @@ def block(pat):
 out = {}
 f, w = block("zip_encode_fwd_all_kernelI6__half")
 if f is not None and w is not None:
-    out["zip_encode_fwd_all_nerf_train"] = {"bytes": f + w, "bytes_upper": 2 * f + w, "source": "profiles/r4_m_pathC_pathB_pmc.txt",
+    out["zip_encode_fwd_all_nerf_train"] = {"bytes": f + w, "bytes_upper": 2 * f + w, "source": os.environ.get("PMC_SOURCE", "profiles/r4_x_pathC_pathB_pmc.txt"),
         "how": "FETCH_SIZE (one 64-B request per gathered row: lower bound; x2 if the requests are 128 B) + WRITE_SIZE, rocprofv3 --pmc, 65 536 rays"}
 f, w = block("fmlp_kernel<0, false, true>")
 if f is not None and w is not None:
-    out["fmlp_kernel_train_fwd"] = {"bytes": 2 * f + w, "source": "profiles/r4_m_pathC_pathB_pmc.txt",
+    out["fmlp_kernel_train_fwd"] = {"bytes": 2 * f + w, "source": os.environ.get("PMC_SOURCE", "profiles/r4_x_pathC_pathB_pmc.txt"),
         "how": "FETCH_SIZE x 2 (coalesced stream correction) + WRITE_SIZE per launch (average of the coarse and the fine pass), rocprofv3 --pmc, 32 768 rays"}
 json.dump(out, open(os.path.join(root, "gpurun_out/pmc_paths/roofline_traffic_paths.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
