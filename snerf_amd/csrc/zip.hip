@@ -1743,11 +1743,15 @@ __global__ __launch_bounds__(1024) void zip_bin_accumulate_kernel(ZipEnc a, ZipB
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (row[u] < 0) continue;
+      // C = 4: channel c of row r sits in slot c ^ ((r >> 3) & 3) of the row's four 8-byte cells.  Unswizzled, one instruction (a fixed
+      // channel of 64 random rows) can only reach the 8 bank pairs 4 (r mod 8) + c of the 32: an 8-way conflict whatever the rows are;
+      // with the swizzle the 64 lanes spread over all 32 pairs (round 4: the LDS atomics were 2.0 of the kernel's 3.8 ms)
+      const int sw = C == 4 ? (row[u] >> 3) & 3 : 0;
 #pragma unroll
       for (int c = 0; c < C; ++c) {
         // (a record is at most max |grad_feat| in magnitude: the clamp only stops non-finite values)
         const float v = HREC ? fminf(fmaxf(val[u][c], -65536.f), 65536.f) * (float)(1 << ZB_HALF_SHIFT) : fminf(fmaxf(val[u][c], -lim), lim) * fix;   // half records carry value * 2^(se - ZB_HALF_SHIFT)
-        atomicAdd((unsigned long long*)(zb_acc + row[u] * C + c), (unsigned long long)__float2ll_rn(v));
+        atomicAdd((unsigned long long*)(zb_acc + row[u] * C + (c ^ sw)), (unsigned long long)__float2ll_rn(v));
       }
     }
   }
@@ -1757,13 +1761,15 @@ __global__ __launch_bounds__(1024) void zip_bin_accumulate_kernel(ZipEnc a, ZipB
     float* dst = a.grad_table + grow * C;
     for (int k = threadIdx.x; k < cells; k += 1024) {
       const long long v = zb_acc[k];
-      if (v != 0) dst[k] += (float)((double)v * unfix);
+      const int kk = C == 4 ? (k ^ ((k >> 5) & 3)) : k;     // (undo the slot swizzle: row = k >> 2, its (row >> 3) & 3 = (k >> 5) & 3)
+      if (v != 0) dst[kk] += (float)((double)v * unfix);
     }
   } else {
     long long* dst = b.g64 + grow * C;
     for (int k = threadIdx.x; k < cells; k += 1024) {
       const long long v = zb_acc[k];
-      if (v != 0) atomicAdd((unsigned long long*)(dst + k), (unsigned long long)v);
+      const int kk = C == 4 ? (k ^ ((k >> 5) & 3)) : k;
+      if (v != 0) atomicAdd((unsigned long long*)(dst + kk), (unsigned long long)v);
     }
   }
 }
