@@ -591,7 +591,7 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmNT p) {
 // ---------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-template <int ACT, bool COLSUM, bool SPLIT = false, bool F16 = false>
+template <int ACT, bool COLSUM, bool SPLIT = false, bool F16 = false, bool KT2 = false>
 __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
   static_assert(!(SPLIT && ACT == ACT_MASK), "split-bf16 data gradients take their ReLU masks from the bit masks");
   static_assert(!(SPLIT && F16), "the split mode is a bf16 construction");
@@ -974,6 +974,13 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
     const bool last = c_kt == KT - 1;
     // P1: A0 x B_F; fetch B_S of this k-tile
     stage(db, 2 + F);
+    // K = 128 (two k-tiles per tile): the next tile's bias (DMA'd in P4 of k-tile 0) and this tile's mask words (P3 of k-tile 0) are read by
+    // unit 0 in P3 of THIS k-tile, six to nine DMAs later -- fewer than the ten the stream's vmcnt(10) leaves in flight, so nothing orders
+    // them (round 4: about one launch in 200 took a stale bias into one 32 x 64 block when another persistent GEMM had run on the CU
+    // before: tools/probes/gemm_k128_bias_race.py).  Retire everything but the two DMAs just issued; this section's barrier publishes
+    // wave 0's bias to the other waves.  With three or more k-tiles the ordinary waits cover both.  KT2 is a template flag of the K = 128
+    // launches (the wait as a run-time branch in this section cost every other launch 1-2 %: 25.93 -> 26.25 ms per step).
+    if constexpr (KT2) { if (last) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
     if (pending) unit(2, em0, en0, epar);
     end_load();
 #pragma unroll
@@ -1167,6 +1174,15 @@ static int launch_nt8p(const GemmNT& p, hipStream_t stream) {
     hipFuncSetAttribute((const void*)gemm_nt8p_kernel<ACT_RELU_BITS, false, false, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     hipFuncSetAttribute((const void*)gemm_nt8p_kernel<ACT_MASK_BITS, false, false, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     hipFuncSetAttribute((const void*)gemm_nt8p_kernel<ACT_MASK_BITS, true, false, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    // the K = 128 flavours (two k-tiles per tile: see KT2 in the kernel)
+    hipFuncSetAttribute((const void*)gemm_nt8p_kernel<ACT_NONE, false, false, F16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipFuncSetAttribute((const void*)gemm_nt8p_kernel<ACT_RELU, false, false, F16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipFuncSetAttribute((const void*)gemm_nt8p_kernel<ACT_NONE, true, false, F16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipFuncSetAttribute((const void*)gemm_nt8p_kernel<ACT_MASK, false, false, F16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipFuncSetAttribute((const void*)gemm_nt8p_kernel<ACT_MASK, true, false, F16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipFuncSetAttribute((const void*)gemm_nt8p_kernel<ACT_RELU_BITS, false, false, F16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipFuncSetAttribute((const void*)gemm_nt8p_kernel<ACT_MASK_BITS, false, false, F16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipFuncSetAttribute((const void*)gemm_nt8p_kernel<ACT_MASK_BITS, true, false, F16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
@@ -1210,23 +1226,26 @@ static int launch_nt8p(const GemmNT& p, hipStream_t stream) {
     else if (p.act == ACT_NONE && cs) hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_NONE, true, true>), g, b, LDS, stream, p);
     else if (p.act == ACT_NONE) hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_NONE, false, true>), g, b, LDS, stream, p);
     else return SNERF_ERR_ARG;
-  } else
-  if (p.act == ACT_MASK) {
-    if (cs) hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_MASK, true, false, F16>), g, b, LDS, stream, p);
-    else hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_MASK, false, false, F16>), g, b, LDS, stream, p);
-  } else if (p.act == ACT_MASK_BITS) {
-    if (cs) hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_MASK_BITS, true, false, F16>), g, b, LDS, stream, p);
-    else hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_MASK_BITS, false, false, F16>), g, b, LDS, stream, p);
-  } else if (p.act == ACT_RELU_BITS) {
-    if (cs) return SNERF_ERR_ARG;
-    hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_RELU_BITS, false, false, F16>), g, b, LDS, stream, p);
-  } else if (cs) {
-    if (p.act != ACT_NONE) return SNERF_ERR_ARG;
-    hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_NONE, true, false, F16>), g, b, LDS, stream, p);
-  } else if (p.act == ACT_RELU) {
-    hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_RELU, false, false, F16>), g, b, LDS, stream, p);
   } else {
-    hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_NONE, false, false, F16>), g, b, LDS, stream, p);
+    const bool kt2 = (p.K >> 6) == 2;                    // K = 128: the flavour that orders the bias / mask DMAs by hand
+#define NT8P(A_, C_) do { if (kt2) hipLaunchKernelGGL((gemm_nt8p_kernel<A_, C_, false, F16, true>), g, b, LDS, stream, p); \
+                          else hipLaunchKernelGGL((gemm_nt8p_kernel<A_, C_, false, F16, false>), g, b, LDS, stream, p); } while (0)
+    if (p.act == ACT_MASK) {
+      if (cs) NT8P(ACT_MASK, true); else NT8P(ACT_MASK, false);
+    } else if (p.act == ACT_MASK_BITS) {
+      if (cs) NT8P(ACT_MASK_BITS, true); else NT8P(ACT_MASK_BITS, false);
+    } else if (p.act == ACT_RELU_BITS) {
+      if (cs) return SNERF_ERR_ARG;
+      NT8P(ACT_RELU_BITS, false);
+    } else if (cs) {
+      if (p.act != ACT_NONE) return SNERF_ERR_ARG;
+      NT8P(ACT_NONE, true);
+    } else if (p.act == ACT_RELU) {
+      NT8P(ACT_RELU, false);
+    } else {
+      NT8P(ACT_NONE, false);
+    }
+#undef NT8P
   }
   if (p.colsum_ws != nullptr) {
     const int rows = grid * 2;                            // one partial row per (workgroup, wave row)

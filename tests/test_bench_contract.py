@@ -1,4 +1,4 @@
-"""The one-line JSON contract of bench.py, checked on the last line the GPU box produced (profiles/r4_m_bench_default.json.log) and on
+"""The one-line JSON contract of bench.py, checked on the last line the GPU box produced (profiles/r4_x_bench_default.json.log) and on
 bench.py's own source (the fields are literal keys there): metric / value / unit / n_gpus / steps / warmup / ms_per_step /
 higher_is_better / scaling / vs_baseline / dtype / data / config.workload + roofline{bound, achieved, peak, unit, frac, traffic} +
 cpu_baseline{value, unit, cores, kind, sample}."""
@@ -6,7 +6,7 @@ import json
 import os
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BENCH_LOG = "r4_m_bench_default.json.log"          # the default line as the GPU box printed it this round
+BENCH_LOG = "r4_x_bench_default.json.log"          # the default line as the GPU box printed it this round
 
 
 def _last_line():
@@ -49,6 +49,8 @@ def test_bench_line_has_the_contract_fields():
     # early ray termination on the fitted scene: a labelled extra with both frame times, the kept fraction and the errors
     e = d["ert_scene"]
     assert e["eps_t"] == 1e-4 and e["ms_per_frame_full"] > 0 and e["ms_per_frame_ert"] > 0 and 0 < e["fine_samples_evaluated"] <= 1
+    # front-to-back termination: the skipped samples' weights sum to <= eps_t, so acc AND rgb (colours in [-0.001, 1.001]) are inside it.  (Until the
+    # K = 128 race of the persistent GEMM was fixed in round 4, two renders of one model could differ by more in a few 32-row blocks.)
     assert e["max_abs_err_acc"] <= 1.01e-4 and e["max_abs_err_rgb"] <= 1.1e-4
     if isinstance(base, dict) and "metric" in base:
         assert str(base["metric"]).split()[0].lower() in d["metric"].lower() or "ray" in d["metric"].lower()

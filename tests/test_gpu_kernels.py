@@ -699,3 +699,31 @@ def test_embedding_index_range_is_reported_and_gradient_is_reproducible(ops):
     ga = torch.zeros(V, dim, device="cuda")
     ops.app_embed_bwd(dV, app, S, ga)
     close(ga, want.cpu(), 1e-5, 1e-5, "atomic embedding gradient")
+
+
+@pytest.mark.gpu
+def test_persistent_gemm_two_k_tiles_after_another_layer_is_reproducible():
+    """gemm_nt8p_kernel with K = 128 (two k-tiles per output tile: the first layer of the 1024-wide NeRF MLP) launched right after ANOTHER
+    persistent GEMM: the next tile's bias vector and the tile's mask words are DMA'd into LDS six to nine DMAs before the epilogue unit that
+    reads them -- fewer than the ten the stream's vmcnt(10) leaves in flight.  Until round 4 nothing ordered them and about one launch in
+    300 took the previous kernel's bias into one 32 x 64 output block (tools/probes/gemm_k128_bias_race.py: 5-6 events per 2000 launches
+    before the fix, none after).  1500 launches here: a regression shows with > 95 % probability."""
+    from snerf_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(0)
+    rnd = lambda *s: torch.rand(*s, device="cuda", generator=g) * 2 - 1
+    M, H, K = 524288, 1024, 128
+    buf = rnd(M, H + K).bfloat16()
+    A = buf[:, H:]                                                  # a column range of a wider buffer, as in the model
+    W0, b0 = (rnd(H, K) / K ** 0.5).bfloat16(), rnd(H)
+    W1, b1 = (rnd(H, H) / H ** 0.5).bfloat16(), rnd(H)
+    Y, Z = torch.empty(M, H, dtype=torch.bfloat16, device="cuda"), torch.empty(M, H, dtype=torch.bfloat16, device="cuda")
+    bits = torch.empty(ops.mask_bits_words(M, H), dtype=torch.int32, device="cuda")
+    for act, aux, reps in ((ops.ACT_RELU, None, 900), (ops.ACT_RELU_BITS, bits, 600)):
+        ops.linear_fwd(A, W0, b0, Y, K, H, act, ops.BF16, aux=aux, variant=8)
+        ref = Y.clone()
+        want = torch.relu(A.float() @ W0.float().t() + b0)
+        assert float((ref.float() - want).abs().max()) < 0.05
+        for r in range(reps):
+            ops.linear_fwd(Y, W1, b1, Z, H, H, ops.ACT_RELU, ops.BF16, variant=8)        # leaves another layer's bias in the CUs' LDS
+            ops.linear_fwd(A, W0, b0, Y, K, H, act, ops.BF16, aux=aux, variant=8)
+            assert torch.equal(Y, ref), (act, r, int((Y != ref).sum()))
