@@ -36,6 +36,9 @@ extern "C" {
 int snerf_version(void);
 /* the hipError_t (as int) that the most recent "kernel launch failure" status (2) of any entry stood for; 0 if there was none */
 int snerf_last_hip_error(void);
+/* Test utility (tests/test_stale_lds.py): fills the LDS of every CU with a seeded pseudo-random pattern.  LDS content survives from one
+ * kernel to the next; a kernel that reads LDS before its own write / DMA has landed shows up as a result that depends on `seed`. */
+int snerf_debug_lds_scribble(int seed, void* stream);
 
 /* ---- tiny-MLP layers (MFMA GEMMs) ------------------------------------------------------------
  * Y[M, n_store] = act(A[M,K] . W[N,K]^T + bias).  Replaces nn.Linear(+ReLU):

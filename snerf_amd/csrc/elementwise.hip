@@ -419,3 +419,25 @@ extern "C" int snerf_gather_pack(const float* flat, const int* idx, long n, void
 extern "C" int snerf_version() { return 1; }
 int g_snerf_last_hip_error = 0;
 extern "C" int snerf_last_hip_error() { return g_snerf_last_hip_error; }
+
+// Test utility: fill the LDS of every CU with a pseudo-random pattern (seeded).  LDS content survives from one kernel to the next on a CU, so
+// a kernel that reads a location before its own write / DMA into it has landed normally re-reads what its previous launch left there and
+// every reproducibility loop passes.  tests/test_stale_lds.py runs whole steps with this kernel in front of every launch, twice with different
+// seeds: any difference is such a read (a missing initialisation shows every time, a missing ORDERING -- the K = 128 race of gemm_nt8p_kernel,
+// round 4 -- when it fires).
+__global__ __launch_bounds__(1024) void lds_scribble_kernel(unsigned seed, unsigned* sink) {
+  extern __shared__ unsigned scribble[];
+  unsigned h = seed * 2654435761u + blockIdx.x * 40503u + 17u;
+  for (int i = threadIdx.x; i < 160 * 1024 / 4; i += 1024) {
+    h = (h ^ (unsigned)i) * 1664525u + 1013904223u;
+    scribble[i] = (h >> 7) ^ (h << 13);               // any bit pattern: NaNs and infinities included
+  }
+  __syncthreads();
+  if (scribble[(seed + threadIdx.x) % (160 * 1024 / 4)] == 0x5eed5eedu && sink != nullptr) sink[0] = seed;   // (keeps the stores alive)
+}
+extern "C" int snerf_debug_lds_scribble(int seed, void* stream) {
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)lds_scribble_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  hipLaunchKernelGGL(lds_scribble_kernel, dim3(4096), dim3(1024), 160 * 1024, (hipStream_t)stream, (unsigned)seed, (unsigned*)nullptr);
+  return snerf_check_launch();
+}

@@ -52,6 +52,11 @@ def _f32c(t):
 _zeros_cache = {}
 
 
+def lds_scribble(seed):
+    """test utility: fill every CU's LDS with a seeded pattern (tests/test_stale_lds.py)"""
+    _lib.call("snerf_debug_lds_scribble", int(seed), _stream())
+
+
 def zero_page(device):
     z = _zeros_cache.get(device)
     if z is None:
