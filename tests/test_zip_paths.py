@@ -410,6 +410,49 @@ def test_zip_fp16_vs_reference_autocast_golden(backend, golden):
             assert d32 <= ref_dev and d16 <= 1.5 * ref_dev, (n, d16, d32, ref_dev)
 
 
+def test_zip_record_precision_policy_and_loss_scale_plumbing(backend):
+    """Host logic of round 4 (runs on the emulated backend too): which levels' table gradients travel as fp16 records for every
+    (table_dtype, compute, table_grad_dtype) combination, the rounding-mode codes of the fused proposal networks, and ZipTrainer's loss
+    scale: in fp32 compute a step with loss_scale = 1024 must move the parameters like a step with loss_scale = 1 (every gradient source
+    carries the factor -- loss tail, hash decay, an auxiliary loss on the histograms -- and Adam's grad_scale undoes it)."""
+    from snerf_amd import ops, zipnerf
+    from snerf_amd.trainer import ZipTrainer
+    assert [ops.round_mode(x) for x in (False, True, ops.F32, ops.BF16, ops.F16)] == [0, 1, 0, 1, 2]
+    mk = lambda **kw: zipnerf.Model(config=None, raydist_fn='power_transformation', opaque_background=True, device=DEV, grid_log2_hashmap_size=12, **kw)
+    want = {("ref", "bf16", "auto"): [True, True, True], ("ref", "f32", "auto"): [False, False, True], ("f32", "f32", "auto"): [False, False, False],
+            ("f32", "fp16", "auto"): [True, True, True], ("ref", "bf16", "table"): [False, False, True], ("f16", "f32", "table"): [True, True, True],
+            ("ref", "bf16", "f32"): [False, False, False], ("f32", "f32", "f16"): [True, True, True]}
+    for (table, compute, tg), halves in want.items():
+        m = mk(table_dtype=table, compute=compute, table_grad_dtype=tg)
+        assert [m._half_records(l) for l in range(3)] == halves, (table, compute, tg)
+        assert m.autograd_loss_scale == (4096.0 if compute == "fp16" else 1.0)
+    with pytest.raises(ValueError):
+        mk(table_grad_dtype="int8")
+    assert mk(table_grad_dtype="bf16").table_grad_mode == "atomic"
+    specs, p = zip_setup()
+    R = 16
+    g = torch.Generator().manual_seed(5)
+    d = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1)
+    bx = torch.nn.functional.normalize(torch.cross(d, torch.randn(R, 3, generator=g), dim=-1), dim=-1)
+    batch = {k: v.to(DEV) for k, v in dict(origins=torch.randn(R, 3, generator=g) * 0.1, directions=d, viewdirs=d, radii=2e-3 + 2e-3 * torch.rand(R, 1, generator=g),
+                                            near=torch.full((R, 1), 0.1), far=torch.full((R, 1), 10.0), base_x=bx,
+                                            base_y=torch.nn.functional.normalize(torch.cross(d, bx, dim=-1), dim=-1)).items()}
+    target = torch.rand(R, 3, generator=g).to(DEV)
+    aux = lambda hist: 0.01 * sum((h["weights"] ** 2).sum() for h in hist)
+    moved = {}
+    for ls in (1.0, 1024.0):
+        m = make_model("f32", "f32", p)
+        tr = ZipTrainer(m, lr=1e-2, eps=1e-8, loss_scale=ls)
+        assert tr.loss_scale == ls
+        start = m.arena.flat.clone()
+        draws = m._draws(R, False, m.arena.flat.device, 7)
+        loss, _ = tr.step(batch, target, rand=False, draws=draws, aux_loss_fn=aux)
+        moved[ls] = (float(loss), (m.arena.flat - start).clone())
+    assert abs(moved[1.0][0] - moved[1024.0][0]) <= 1e-6 * abs(moved[1.0][0])
+    da, db = moved[1.0][1], moved[1024.0][1]
+    assert float(da.abs().max()) > 1e-4 and float((da - db).abs().max()) <= 2e-3 * 1e-2, float((da - db).abs().max())
+
+
 def test_zip_trainer_fused_loss_tail(backend):
     """ZipTrainer.step: the loss terms it reports are the oracle's loss tail (s-nerfpp/zipnerf/train.py:250-311) evaluated on the
     renderer outputs of that step, the step changes the parameters, and repeated steps on a fixed batch reduce the loss."""
