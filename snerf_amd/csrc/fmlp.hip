@@ -110,9 +110,10 @@ __device__ __forceinline__ void ws_advance(WStream& w, char* smem) {
 }
 
 // ---- building blocks -----------------------------------------------------------------------------------------------------------
-template <int RING>
+template <int RING, bool F16 = false>
 struct CtxT {
   static constexpr int ring = RING;   // slots of the weight ring: FM_RING for the 256-wide networks, fewer where the LDS is needed elsewhere
+  static constexpr bool f16 = F16;    // fp16 flavour (path C's compute="fp16"): the 16-bit operands are fp16 bit patterns, f16 MFMA and conversions
   char* smem;
   WStream ws;
   const char* frag_base;   // ring + lane * 16
@@ -151,6 +152,10 @@ __device__ __forceinline__ f32x16 acc_init(const C& c) {
 
 template <int F, int NK, int... I, typename C>
 __device__ __forceinline__ void mac_seq(C& c, f32x16& acc, const bf16x8 (&in)[NK], std::integer_sequence<int, I...>) {
+  if constexpr (C::f16) {
+    typedef _Float16 fm_f16x8 __attribute__((ext_vector_type(8)));
+    ((acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(fm_f16x8, next_frag<F + I>(c)), __builtin_bit_cast(fm_f16x8, in[I]), acc, 0, 0, 0)), ...);
+  } else
   ((acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(next_frag<F + I>(c), in[I], acc, 0, 0, 0)), ...);
 }
 template <int F, int NK, typename C>
@@ -160,13 +165,19 @@ __device__ __forceinline__ void mac(C& c, f32x16& acc, const bf16x8 (&in)[NK]) {
 
 // accumulator -> the two B fragments (k-steps 2 j, 2 j + 1) of the next layer
 typedef unsigned fm_u32x4 __attribute__((ext_vector_type(4)));
-template <bool RELU>
+template <bool RELU, bool F16 = false>
 __device__ __forceinline__ void to_frags(const f32x16& acc, bf16x8& lo, bf16x8& hi) {
   typedef __attribute__((ext_vector_type(8))) float f32x8;
   const f32x8 a = {acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6], acc[7]};
   const f32x8 b = {acc[8], acc[9], acc[10], acc[11], acc[12], acc[13], acc[14], acc[15]};
+  if constexpr (F16) {                                   // (an fp16 is negative iff its 16 bits are a negative int16 too: the same packed max below)
+    typedef _Float16 fm_f16x8 __attribute__((ext_vector_type(8)));
+    lo = __builtin_bit_cast(bf16x8, __builtin_convertvector(a, fm_f16x8));
+    hi = __builtin_bit_cast(bf16x8, __builtin_convertvector(b, fm_f16x8));
+  } else {
   lo = __builtin_convertvector(a, bf16x8);               // v_cvt_pk_bf16_f32: two values per instruction
   hi = __builtin_convertvector(b, bf16x8);
+  }
   if (RELU) {
     // ReLU on the rounded value (rounding is monotone and keeps the sign, so round-then-clamp == clamp-then-round): a bf16 is
     // negative iff its 16 bits are a negative int16, so a packed signed max with 0 clamps two values per instruction (-0 -> +0).
@@ -267,7 +278,7 @@ __device__ __forceinline__ void dense_block(C& c, f32x16& acc, const bf16x8 (&in
   bf16x8& hi = out[2 * J + 1];
   mac<F, NK0>(c, acc, in0);
   if constexpr (NK1 > 0) mac<F + NK0, NK1>(c, acc, in1);
-  to_frags<RELU>(acc, lo, hi);
+  to_frags<RELU, C::f16>(acc, lo, hi);
   if constexpr (STORE) store_block<BITS, J>(st, lo, hi);
   // (issuing these bias reads BEFORE the stores, so that their LDS latency runs under them, measured 9.53 vs 9.43 ms: the sixteen
   // accumulator registers are then live across the store path of a kernel that already sits at the 256-register limit)
@@ -470,6 +481,82 @@ __global__ __launch_bounds__(64 * FM_WAVES, 2) void fmlp_kernel(FmlpArgs a) {   
     // chunk boundary again -- and the queue already holds its first FM_LOOK fragments
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the read-ahead before the LDS is released
+}
+
+// =================================================================================================================================
+// NeRF MLP of the zipnerf path at inference (s-nerfpp/zipnerf/internal/models.py:462-479, 586-703 on the waymo.gin branch, deg_view = 1, no GLO
+// vectors): grid features (40 -> 64 columns) -> Linear 64 + ReLU -> Linear 256 (x; channel 0 = raw density) -> cat([x, dir_enc 9])
+// -> 256 ReLU -> cat([h, x, dir_enc]) -> 256 ReLU -> Linear 3.  As seven GEMM-shaped launches every layer is bound by the 0.5 - 2.4 GB of
+// activations it moves per 65 536-ray chunk (2.2 ms per chunk of a 1920 x 1280 frame); here a row's 160 bytes of inputs and 16 bytes of
+// outputs are all that touches HBM.  Built from the blocks above; two things are particular:
+//   * the raw density is output 0 of density_layer.2 BEFORE its rounding to the compute dtype (the per-layer path evaluates that row once
+//     more as an fp32 head): one extra 32-output block over the same 4 k-steps;
+//   * the last hidden layer is never held: as soon as a block of 32 of its outputs is rounded, the two k-steps of the rgb layer that
+//     consume it are multiplied into the rgb accumulator (the host interleaves the rgb weights block by block) -- x, the first hidden
+//     layer and the direction encoding (33 fragments) are what a lane keeps while the 264 MFMAs of that layer run.
+// 460 fragments (29 chunks), 35 bias blocks.  F16: fp16 operands (compute="fp16").
+#define FZIP_FRAGS 460
+#define FZIP_BLOCKS 35
+struct FzipArgs {
+  const __bf16* F; long ldF;        // grid features [M, >= 64] (columns 40..63 zero)
+  const __bf16* D; long ldD;        // direction encoding [M, >= 16] (columns 9..15 zero)
+  const char* wstream; const float* bias;
+  float* raw_rgb; long ld_rgb;      // [M, >= 3] fp32
+  float* raw_d; long ld_d;          // [M, >= 1] fp32
+  long M; int tiles, n_chunks, n_blocks;
+};
+
+template <int F, int B, int J, typename C>
+__device__ __forceinline__ void fzip_last_block(C& c, const bf16x8 (&h2)[16], const bf16x8 (&x)[16], const bf16x8 (&dv)[1], f32x16& rgb) {
+  f32x16 acc = acc_init<B + 2 * J>(c);
+  constexpr int F0 = F + J * 35;
+  mac<F0, 16>(c, acc, h2);
+  mac<F0 + 16, 16>(c, acc, x);
+  mac<F0 + 32, 1>(c, acc, dv);
+  bf16x8 lh[2];
+  to_frags<true, C::f16>(acc, lh[0], lh[1]);
+  mac<F0 + 33, 2>(c, rgb, lh);
+}
+template <int F, int B, typename C, int... J>
+__device__ __forceinline__ void fzip_last_seq(C& c, const bf16x8 (&h2)[16], const bf16x8 (&x)[16], const bf16x8 (&dv)[1], f32x16& rgb, std::integer_sequence<int, J...>) {
+  (fzip_last_block<F, B, J>(c, h2, x, dv, rgb), ...);
+}
+
+template <bool F16>
+__global__ __launch_bounds__(64 * FM_WAVES, 2) void fzip_fwd_kernel(FzipArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5;
+  CtxT<FM_RING, F16> c;
+  ctx_start(c, smem, a.wstream, a.n_chunks, a.bias, a.n_blocks, tid, wave, lane);
+  for (int tile = blockIdx.x; tile < a.tiles; tile += gridDim.x) {
+    long row = (long)tile * FM_TILE_ROWS + wave * 32 + (lane & 31);
+    const bool row_ok = row < a.M;
+    row = row_ok ? row : a.M - 1;
+    bf16x8 f[4], dv[1], h1[4], x[16], h2[16];
+    load_rows<4>(a.F, a.ldF, row, half, f);
+    load_rows<1>(a.D, a.ldD, row, half, dv);
+    constexpr int F1 = 2 * 4, FD = F1 + 8 * 4, F2 = FD + 4, F3 = F2 + 8 * 17;
+    static_assert(F3 + 8 * 35 == FZIP_FRAGS, "zipnerf MLP: fragment count");
+    dense<0, 0, 4, 2, true>(c, f, h1);                     // density_layer.0 (+ ReLU)
+    dense<F1, 2, 4, 8, false>(c, h1, x);                   // density_layer.2: x (bottleneck, no activation)
+    f32x16 dh = acc_init<10>(c);                           // ... and its output 0 once more, unrounded: the raw density
+    mac<FD, 4>(c, dh, h1);
+    dense2<F2, 11, 16, 1, 8, true>(c, x, dv, h2);          // lin_second_stage_0 on cat([x, dir_enc]) (+ ReLU)
+    f32x16 rgb = acc_init<20>(c);                          // rgb_layer: its bias sits in the first of the interleaved pieces
+    fzip_last_seq<F3, 19>(c, h2, x, dv, rgb, std::make_integer_sequence<int, 8>{});   // lin_second_stage_1 on cat([h, x, dir_enc]) (+ ReLU) -> rgb
+    // the pass is padded to whole chunks (464 fragments): take the four padding fragments out of the queue so that the next tile starts on
+    // a chunk boundary like every other network's
+    (void)next_frag<FZIP_FRAGS>(c); (void)next_frag<FZIP_FRAGS + 1>(c); (void)next_frag<FZIP_FRAGS + 2>(c); (void)next_frag<FZIP_FRAGS + 3>(c);
+    static_assert((FZIP_FRAGS + 4) % FM_CHUNK == 0, "padding of the zipnerf pass");
+    if (row_ok && half == 0) {
+      a.raw_d[row * a.ld_d] = dh[0];
+      float* o = a.raw_rgb + row * a.ld_rgb;
+      o[0] = rgb[0]; o[1] = rgb[1]; o[2] = rgb[2];
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // =================================================================================================================================
@@ -1102,6 +1189,34 @@ extern "C" int snerf_fmlp_proposal_train_fwd(const void* E, long ldE, const void
 }
 
 // ---- colour head (cond_layers.0..2 + rgb_layer of the mip path's NeRF MLP, hidden 1024) -------------------------------------------
+// NeRF MLP of the zipnerf path, inference (fzip_fwd_kernel).  wstream / bias: ZipNerfNet._pack_fused_infer (snerf_amd/mlp.py) through fmlp_pack;
+// dtype SNERF_DT_BF16 or SNERF_DT_F16 = the type of F, D and of the weight stream.
+extern "C" int snerf_fmlp_zip_fwd(const void* F, long ldF, const void* D, long ldD, const void* wstream, long n_frags, const float* bias, int n_blocks,
+                                  float* raw_rgb, long ld_rgb, float* raw_d, long ld_d, long M, int dtype, void* stream) {
+  if (M <= 0) return SNERF_OK;
+  if (F == nullptr || D == nullptr || wstream == nullptr || bias == nullptr || raw_rgb == nullptr || raw_d == nullptr || ldF < 64 || ldD < 16 || (ldF % 8) ||
+      (ldD % 8) || (((uintptr_t)F) & 15) || (((uintptr_t)D) & 15) || ld_rgb < 3 || ld_d < 1 || M >= (1L << 31) || n_blocks != FZIP_BLOCKS ||
+      n_frags != ((FZIP_FRAGS + FM_CHUNK - 1) / FM_CHUNK) * FM_CHUNK || (dtype != SNERF_DT_BF16 && dtype != SNERF_DT_F16))
+    return SNERF_ERR_ARG;
+  FzipArgs a{(const __bf16*)F, ldF, (const __bf16*)D, ldD, (const char*)wstream, bias, raw_rgb, ld_rgb, raw_d, ld_d, M, 0, (int)(n_frags / FM_CHUNK), n_blocks};
+  a.tiles = (int)((M + FM_TILE_ROWS - 1) / FM_TILE_ROWS);
+  const int lds = FM_RING * FM_SLOT + FM_BIAS_MAX * 128;
+  static bool attr = false;
+  static int n_cu = 256;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)fzip_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)fzip_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
+    attr = true;
+  }
+  const int grid = a.tiles < n_cu * FM_WG_PER_CU ? a.tiles : n_cu * FM_WG_PER_CU;
+  if (dtype == SNERF_DT_F16) hipLaunchKernelGGL(fzip_fwd_kernel<true>, dim3(grid), dim3(64 * FM_WAVES), lds, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(fzip_fwd_kernel<false>, dim3(grid), dim3(64 * FM_WAVES), lds, (hipStream_t)stream, a);
+  return snerf_check_launch();
+}
+
 static int fcolour_grid(int tiles) {
   static int n_cu = 0;
   if (n_cu == 0) {

@@ -255,13 +255,13 @@ class _Net:
     def gB(self, name):
         return self.a.g[self.pre + name + ".bias"]
 
-    def _refresh_fused(self, pack_fused, key="fused"):
+    def _refresh_fused(self, pack_fused, key="fused", dtype=torch.bfloat16):
         """weight stream / bias table of a fused kernel (fmlp_pack's layout), refreshed by the same gather.  -> (stream, bias)"""
         if key not in self._plans:
             def fill():
                 st, bi = pack_fused()                      # index images (float64) in record mode
                 self._fimg = (st, bi)
-                return [(st, torch.bfloat16), (bi, torch.float32)]
+                return [(st, dtype), (bi, torch.float32)]
             plan, swap = self._build_plan(fill)
             self._plans[key] = (plan, swap(self._fimg))
             del self._fimg
@@ -1147,6 +1147,43 @@ class ZipNerfNet(_Net):
             if self.gd:
                 self._pack_dgrad("glo1", ["lin_glo_1"], 0, self.Gh)
                 self._pack_dgrad_cols("gloin", [("lin_glo_0", 0)], self.gd)       # d loss / d GLO vector (the embedding rows' gradient)
+
+    # ---- inference as ONE launch (csrc/fmlp.hip, fzip_fwd_kernel): activations in registers, 160 bytes in and 16 bytes out per sample ----
+    def fused_infer_ok(self):
+        import os
+        on = getattr(self, "fused_infer", os.environ.get("SNERF_ZIP_FUSED_INFER", "1") != "0")      # (the variable: A/B runs of tools/bench_zip.py)
+        return (on and self.gd == 0 and self.dt in (ops.BF16, ops.F16) and self.fd <= 64 and self.H == 64 and self.Bw == 256 and self.Wd == 256
+                and self.dd <= 16)
+
+    def _pack_fused_infer(self):
+        """the layers in the order fzip_fwd_kernel consumes them: density_layer.0, density_layer.2, its row 0 once more (fp32 raw density),
+        lin_second_stage_0 on [x | dir], then lin_second_stage_1 block by block, each block followed by the two k-steps of rgb_layer
+        that consume it"""
+        B, Wd, dd, fd, H = self.Bw, self.Wd, self.dd, self.fd, self.H
+        W0, b0 = self.W("density_layer.0"), self.B("density_layer.0")
+        W2, b2 = self.W("density_layer.2"), self.B("density_layer.2")
+        L0, c0 = self.W("lin_second_stage_0"), self.B("lin_second_stage_0")
+        L1, c1 = self.W("lin_second_stage_1"), self.B("lin_second_stage_1")
+        Wr, br = self.W("rgb_layer"), self.B("rgb_layer")
+        W0p = torch.cat([W0, torch.zeros(H, 64 - fd, dtype=W0.dtype, device=W0.device)], 1) if fd < 64 else W0
+        layers = [(W0p, b0, [(0, 64, False)]), (W2, b2, [(0, H, True)]), (W2[0:1], b2[0:1], [(0, H, True)]),
+                  (L0, c0, [(0, B, True), (B, dd, False)])]
+        for j in range(Wd // 32):
+            layers.append((L1[32 * j:32 * j + 32], c1[32 * j:32 * j + 32], [(0, Wd, True), (Wd, B, True), (Wd + B, dd, False)]))
+            layers.append((Wr[:, 32 * j:32 * j + 32], br if j == 0 else None, [(0, 32, True)]))
+        return fmlp_pack(layers, self.dev)
+
+    def forward_fused(self, Fb, D):
+        """Fb [M, 64] grid features, D [M, 16] direction encoding (compute dtype, zero padded) -> raw_rgb [M,3], raw_density [M,1] fp32"""
+        v = self.version_fn()
+        if getattr(self, "_zinfer_version", None) != v:
+            with torch.no_grad():
+                self._zinfer = self._refresh_fused(self._pack_fused_infer, "zip_infer", dtype=self.tdt)
+            self._zinfer_version = v
+        M = Fb.shape[0]
+        raw_rgb, raw_d = self.buf(M, 3, f32=True), self.buf(M, 1, f32=True)
+        ops.fmlp_zip_fwd(Fb, D, self._zinfer[0], self._zinfer[1], raw_rgb, raw_d)
+        return raw_rgb, raw_d
 
     def alloc(self, M):
         """-> (F, SB): the featurisation kernel writes F[:, :feat_dim] (F arrives zeroed), the view encoder SB[:, Wd+B:]."""

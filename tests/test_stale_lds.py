@@ -115,7 +115,7 @@ def test_path_c_forward_and_backward_do_not_read_stale_lds(scribbled):
     tgt = torch.rand(R, 3, generator=g).cuda()
     for compute, table in (("fp16", "f16"), ("bf16", "ref")):
         m = zipnerf.Model(config=None, raydist_fn='power_transformation', opaque_background=True, compute=compute, table_dtype=table,
-                          grid_log2_hashmap_size=16, init_std=0.1, use_semantic=True)
+                          grid_log2_hashmap_size=16, init_std=0.1, use_semantic=(compute == "fp16"))     # (without the semantic head inference takes the fused NeRF MLP)
         for net in m.nets:
             net.deterministic = True
         draws = m._draws(R, False, m.arena.flat.device, 7)
@@ -123,7 +123,7 @@ def test_path_c_forward_and_backward_do_not_read_stale_lds(scribbled):
         def infer():
             with torch.no_grad():
                 ren, hist = m(False, batch, 1.0, False, draws=draws)
-            return [ren[2]["rgb"], ren[2]["depth"], ren[2]["semantic"], hist[0]["weights"], hist[1]["weights"]]
+            return [ren[2]["rgb"], ren[2]["depth"], hist[0]["weights"], hist[1]["weights"]] + ([ren[2]["semantic"]] if m.use_semantic else [])
 
         def train():
             for p in m.parameters():

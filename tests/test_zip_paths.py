@@ -453,6 +453,56 @@ def test_zip_record_precision_policy_and_loss_scale_plumbing(backend):
     assert float(da.abs().max()) > 1e-4 and float((da - db).abs().max()) <= 2e-3 * 1e-2, float((da - db).abs().max())
 
 
+@pytest.mark.parametrize("compute,tol", [("bf16", 2e-2), ("fp16", 2e-3)])
+def test_zip_fused_inference_mlp_matches_the_per_layer_path(backend, golden, compute, tol):
+    """Inference evaluates the NeRF MLP in ONE launch (csrc/fmlp.hip fzip_fwd_kernel: activations in registers, the last hidden layer
+    consumed by the rgb layer block by block, the raw density taken from the unrounded accumulator); `fused_infer = False` selects the
+    seven per-layer launches of the training forward.  Same rounding points (every stored activation in the compute dtype, fp32
+    accumulation, fp32 heads): the two differ by summation order only.  Also against the reference's golden (g11), and ragged row counts."""
+    from snerf_amd import ops
+    g = golden("g11_zip_model")
+    specs, p = zip_setup()
+    batch = {k[2:]: v.to(DEV) for k, v in g.items() if k.startswith("b_")}
+    m = make_model(compute, "f32", p)
+    net = m.nets[2]
+    assert net.fused_infer_ok()
+    outs = {}
+    for fused in (True, False):
+        net.fused_infer = fused
+        with torch.no_grad():
+            rend, hist = m(None, batch, 1.0, False)
+        outs[fused] = (rend[-1]["rgb"], rend[-1]["depth"], hist[-1]["weights"])
+    net.fused_infer = True
+    for a, b, what in zip(outs[True], outs[False], ("rgb", "depth", "weights")):
+        close(a, b, tol, tol, what + " fused vs per-layer")
+    close(outs[True][0], g["det_rgb"], 5 * tol, 5 * tol, "rgb vs the reference")
+    # the network alone on random features: ragged row counts, full-rank weights
+    gen = torch.Generator().manual_seed(3)
+    for k in list(p):
+        if k.startswith("nerf_mlp.") and k.endswith(".weight") and "encoder" not in k:
+            p[k] = torch.randn(p[k].shape, generator=gen) * (1.2 / p[k].shape[1] ** 0.5)
+    m = make_model(compute, "f32", p)
+    net = m.nets[2]
+    for M in (1, 255, 1000):
+        Fb = torch.zeros(M, 64); Fb[:, :40] = torch.randn(M, 40, generator=gen) * 0.5
+        Dn = torch.zeros(M, 16); Dn[:, :9] = torch.randn(M, 9, generator=gen)
+        Fb, Dn = Fb.to(net.tdt).to(DEV), Dn.to(net.tdt).to(DEV)
+        with torch.no_grad():
+            rgb_f, den_f = net.forward_fused(Fb, Dn)
+            F2, SB = net.alloc(M)
+            F2.copy_(Fb); SB[:, net.Wd + net.Bw:net.Wd + net.Bw + 16] = Dn; SB[:, net.Wd + net.Bw + 16:] = 0
+            rgb_l, den_l, _ = net.forward(F2, SB, False)
+        close(rgb_f, rgb_l, tol, tol, f"raw rgb M={M}"); close(den_f, den_l, tol, tol, f"raw density M={M}")
+        W = {k[9:]: v.double() for k, v in p.items() if k.startswith("nerf_mlp.") and "encoder" not in k}
+        f64, d64 = Fb.double().cpu()[:, :40], Dn.double().cpu()[:, :9]
+        h1 = torch.relu(f64 @ W["density_layer.0.weight"].t() + W["density_layer.0.bias"])
+        x = h1 @ W["density_layer.2.weight"].t() + W["density_layer.2.bias"]
+        h2 = torch.relu(torch.cat([x, d64], -1) @ W["lin_second_stage_0.weight"].t() + W["lin_second_stage_0.bias"])
+        h3 = torch.relu(torch.cat([h2, x, d64], -1) @ W["lin_second_stage_1.weight"].t() + W["lin_second_stage_1.bias"])
+        close(rgb_f, h3 @ W["rgb_layer.weight"].t() + W["rgb_layer.bias"], 5 * tol, 5 * tol, f"raw rgb vs fp64 M={M}")
+        close(den_f, x[:, :1], 5 * tol, 5 * tol, f"raw density vs fp64 M={M}")
+
+
 def test_zip_trainer_fused_loss_tail(backend):
     """ZipTrainer.step: the loss terms it reports are the oracle's loss tail (s-nerfpp/zipnerf/train.py:250-311) evaluated on the
     renderer outputs of that step, the step changes the parameters, and repeated steps on a fixed batch reduce the loss."""
