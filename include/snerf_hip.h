@@ -448,10 +448,11 @@ int snerf_fmlp_proposal_train_fwd(const void* E, long ldE, const void* wstream, 
  * vectors): F [M, ldF >= 64] grid features (columns 40.. zero) and D [M, ldD >= 16] direction encoding (columns 9.. zero) in `dtype`
  * (SNERF_DT_BF16 or SNERF_DT_F16) -> raw_rgb [M, ld_rgb >= 3] and raw_d [M, ld_d >= 1] fp32.  density_layer.0 (+ReLU), density_layer.2 (x;
  * raw density = its output 0 before rounding), lin_second_stage_0 on cat([x, D]) (+ReLU), lin_second_stage_1 on cat([h, x, D]) (+ReLU),
- * rgb_layer -- activations stay in registers.  wstream (464 fragments of 1 KiB) / bias (35 blocks of 32 floats): the packing of
+ * rgb_layer -- activations stay in registers.  x32 (optional, [M, ld_x >= 32] in `dtype`): channels 0..31 of x, of which the semantic head
+ * reads 1..C (models.py:594-597).  wstream (464 fragments of 1 KiB) / bias (35 blocks of 32 floats): the packing of
  * snerf_amd.mlp.ZipNerfNet._pack_fused_infer. */
 int snerf_fmlp_zip_fwd(const void* F, long ldF, const void* D, long ldD, const void* wstream, long n_frags, const float* bias, int n_blocks,
-                       float* raw_rgb, long ld_rgb, float* raw_d, long ld_d, long M, int dtype, void* stream);
+                       float* raw_rgb, long ld_rgb, float* raw_d, long ld_d, void* x32, long ld_x, long M, int dtype, void* stream);
 /* Colour head of the live mip path's NeRF MLP, fused (s-nerf/model/models.py:283-296: cat([bottleneck, view encoding]) ->
  * cond_layers.0 .. .2 (Linear 128 + ReLU) -> rgb_layer; hidden 1024, 27 view-encoding columns).  Replaces four snerf_linear_fwd
  * launches forward and the four data-gradient launches backward.

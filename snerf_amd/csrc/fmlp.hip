@@ -503,6 +503,7 @@ struct FzipArgs {
   const char* wstream; const float* bias;
   float* raw_rgb; long ld_rgb;      // [M, >= 3] fp32
   float* raw_d; long ld_d;          // [M, >= 1] fp32
+  __bf16* X32; long ld_x;           // optional [M, >= 32]: the first 32 channels of x in the compute dtype (the semantic head reads x[:, 1:1+C])
   long M; int tiles, n_chunks, n_blocks;
 };
 
@@ -541,6 +542,17 @@ __global__ __launch_bounds__(64 * FM_WAVES, 2) void fzip_fwd_kernel(FzipArgs a) 
     static_assert(F3 + 8 * 35 == FZIP_FRAGS, "zipnerf MLP: fragment count");
     dense<0, 0, 4, 2, true>(c, f, h1);                     // density_layer.0 (+ ReLU)
     dense<F1, 2, 4, 8, false>(c, h1, x);                   // density_layer.2: x (bottleneck, no activation)
+    if (a.X32 != nullptr && row_ok) {
+      // block 0 of x as the lanes hold it: fragment 0 / 1 = outputs 0..15 / 16..31, lane half h owns {4 h .. 4 h + 3, 8 + 4 h .. 8 + 4 h + 3} of each
+      typedef unsigned fz_u32x2 __attribute__((ext_vector_type(2)));
+      __bf16* xr = a.X32 + row * a.ld_x + 4 * half;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const fm_u32x4 v = __builtin_bit_cast(fm_u32x4, x[s]);
+        *(fz_u32x2*)(xr + 16 * s) = fz_u32x2{v[0], v[1]};
+        *(fz_u32x2*)(xr + 16 * s + 8) = fz_u32x2{v[2], v[3]};
+      }
+    }
     f32x16 dh = acc_init<10>(c);                           // ... and its output 0 once more, unrounded: the raw density
     mac<FD, 4>(c, dh, h1);
     dense2<F2, 11, 16, 1, 8, true>(c, x, dv, h2);          // lin_second_stage_0 on cat([x, dir_enc]) (+ ReLU)
@@ -1192,13 +1204,14 @@ extern "C" int snerf_fmlp_proposal_train_fwd(const void* E, long ldE, const void
 // NeRF MLP of the zipnerf path, inference (fzip_fwd_kernel).  wstream / bias: ZipNerfNet._pack_fused_infer (snerf_amd/mlp.py) through fmlp_pack;
 // dtype SNERF_DT_BF16 or SNERF_DT_F16 = the type of F, D and of the weight stream.
 extern "C" int snerf_fmlp_zip_fwd(const void* F, long ldF, const void* D, long ldD, const void* wstream, long n_frags, const float* bias, int n_blocks,
-                                  float* raw_rgb, long ld_rgb, float* raw_d, long ld_d, long M, int dtype, void* stream) {
+                                  float* raw_rgb, long ld_rgb, float* raw_d, long ld_d, void* x32, long ld_x, long M, int dtype, void* stream) {
   if (M <= 0) return SNERF_OK;
+  if (x32 != nullptr && (ld_x < 32 || (ld_x % 4) || (((uintptr_t)x32) & 7))) return SNERF_ERR_ARG;
   if (F == nullptr || D == nullptr || wstream == nullptr || bias == nullptr || raw_rgb == nullptr || raw_d == nullptr || ldF < 64 || ldD < 16 || (ldF % 8) ||
       (ldD % 8) || (((uintptr_t)F) & 15) || (((uintptr_t)D) & 15) || ld_rgb < 3 || ld_d < 1 || M >= (1L << 31) || n_blocks != FZIP_BLOCKS ||
       n_frags != ((FZIP_FRAGS + FM_CHUNK - 1) / FM_CHUNK) * FM_CHUNK || (dtype != SNERF_DT_BF16 && dtype != SNERF_DT_F16))
     return SNERF_ERR_ARG;
-  FzipArgs a{(const __bf16*)F, ldF, (const __bf16*)D, ldD, (const char*)wstream, bias, raw_rgb, ld_rgb, raw_d, ld_d, M, 0, (int)(n_frags / FM_CHUNK), n_blocks};
+  FzipArgs a{(const __bf16*)F, ldF, (const __bf16*)D, ldD, (const char*)wstream, bias, raw_rgb, ld_rgb, raw_d, ld_d, (__bf16*)x32, ld_x, M, 0, (int)(n_frags / FM_CHUNK), n_blocks};
   a.tiles = (int)((M + FM_TILE_ROWS - 1) / FM_TILE_ROWS);
   const int lds = FM_RING * FM_SLOT + FM_BIAS_MAX * 128;
   static bool attr = false;

@@ -1173,8 +1173,9 @@ class ZipNerfNet(_Net):
             layers.append((Wr[:, 32 * j:32 * j + 32], br if j == 0 else None, [(0, 32, True)]))
         return fmlp_pack(layers, self.dev)
 
-    def forward_fused(self, Fb, D):
-        """Fb [M, 64] grid features, D [M, 16] direction encoding (compute dtype, zero padded) -> raw_rgb [M,3], raw_density [M,1] fp32"""
+    def forward_fused(self, Fb, D, want_x=False):
+        """Fb [M, 64] grid features, D [M, 16] direction encoding (compute dtype, zero padded) -> raw_rgb [M,3], raw_density [M,1] fp32;
+        `want_x`: self.last_x = the first 32 channels of x [M, 32] (the semantic head's logits are its columns 1 .. C)"""
         v = self.version_fn()
         if getattr(self, "_zinfer_version", None) != v:
             with torch.no_grad():
@@ -1182,7 +1183,8 @@ class ZipNerfNet(_Net):
             self._zinfer_version = v
         M = Fb.shape[0]
         raw_rgb, raw_d = self.buf(M, 3, f32=True), self.buf(M, 1, f32=True)
-        ops.fmlp_zip_fwd(Fb, D, self._zinfer[0], self._zinfer[1], raw_rgb, raw_d)
+        self.last_x = self.buf(M, 32) if want_x else None
+        ops.fmlp_zip_fwd(Fb, D, self._zinfer[0], self._zinfer[1], raw_rgb, raw_d, self.last_x)
         return raw_rgb, raw_d
 
     def alloc(self, M):

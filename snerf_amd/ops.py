@@ -199,15 +199,19 @@ def fmlp_proposal_train_fwd(E, stream, bias, raw_density, acts, bits):
               _p(raw_density), ctypes.addressof(ptrs), ctypes.addressof(lds), ctypes.addressof(bp), E.shape[0], _stream())
 
 
-def fmlp_zip_fwd(Fb, D, stream, bias, raw_rgb, raw_d):
+def fmlp_zip_fwd(Fb, D, stream, bias, raw_rgb, raw_d, x32=None):
     """NeRF MLP of the zipnerf path at inference in ONE launch (csrc/fmlp.hip, fzip_fwd_kernel): Fb [M, >= 64] grid features, D [M, >= 16]
-    direction encoding (bf16 or fp16 = the stream's dtype, zero padded) -> raw_rgb [M, 3], raw_d [M, 1] fp32."""
+    direction encoding (bf16 or fp16 = the stream's dtype, zero padded) -> raw_rgb [M, 3], raw_d [M, 1] fp32; x32 (optional [M, >= 32],
+    compute dtype): the first 32 channels of the bottleneck x (the semantic logits are x[:, 1:1+C])."""
     _chk2d(Fb, Fb.dtype); _chk2d(D, Fb.dtype); _chk2d(raw_rgb, torch.float32); _chk2d(raw_d, torch.float32)
     M = Fb.shape[0]
     assert Fb.dtype in (torch.bfloat16, torch.float16) and stream.dtype == Fb.dtype and stream.is_contiguous() and bias.dtype == torch.float32
     assert D.shape[0] == M and raw_rgb.shape[0] == M and raw_d.shape[0] == M and Fb.shape[1] >= 64 and D.shape[1] >= 16 and raw_rgb.shape[1] >= 3
+    if x32 is not None:
+        _chk2d(x32, Fb.dtype)
+        assert x32.shape[0] == M and x32.shape[1] >= 32
     _lib.call("snerf_fmlp_zip_fwd", _p(Fb), Fb.stride(0), _p(D), D.stride(0), _p(stream), stream.shape[0], _p(bias), bias.numel() // 32,
-              _p(raw_rgb), raw_rgb.stride(0), _p(raw_d), raw_d.stride(0), M, _zip_dt(Fb), _stream())
+              _p(raw_rgb), raw_rgb.stride(0), _p(raw_d), raw_d.stride(0), _p(x32), 0 if x32 is None else x32.stride(0), M, _zip_dt(Fb), _stream())
 
 
 def fcolour_fwd(CB, stream, bias, raw_rgb, acts=None, bits=None, variant=0):

@@ -247,7 +247,7 @@ class Model(_ArenaModule):
                 levels.append(dict(sdist=sdist, tdist=tdist, weights=weights, rgb=rgb, depth=depth, acc=acc, raw_rgb=None, raw_d=raw_d, saved=None,
                                    degj=degj, ns=ns, semantic=None, logits=None))
                 continue
-            fused_nerf = (not is_prop) and not keep and not self.use_semantic and not self.num_glo_features and net.fused_infer_ok() and net.Fw == 64
+            fused_nerf = (not is_prop) and not keep and not self.num_glo_features and net.fused_infer_ok() and net.Fw == 64 and self.class_num < 32
             if is_prop or fused_nerf:
                 Fb = torch.zeros(P, net.Fw, dtype=net.tdt, device=dev); SB = None
             else:
@@ -271,7 +271,7 @@ class Model(_ArenaModule):
                 # inference: the whole NeRF MLP in one launch, activations in registers (csrc/fmlp.hip, fzip_fwd_kernel)
                 Dn = torch.empty(P, 16, dtype=net.tdt, device=dev)
                 ops.mip_viewenc(vd, ns, 1, Dn, 16, self.dt)
-                raw_rgb, raw_d = net.forward_fused(Fb, Dn)
+                raw_rgb, raw_d = net.forward_fused(Fb, Dn, want_x=self.use_semantic)
                 saved = cam = None
             else:
                 ops.mip_viewenc(vd, ns, 1, SB[:, net.Wd + net.Bw:], net.Dw, self.dt)

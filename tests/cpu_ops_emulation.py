@@ -647,7 +647,7 @@ def fmlp_classic_fwd(E, VE, stream, bias, raw, acts=None):
     raw[:, 3] = sigma
 
 
-def fmlp_zip_fwd(Fb, D, stream, bias, raw_rgb, raw_d):
+def fmlp_zip_fwd(Fb, D, stream, bias, raw_rgb, raw_d, x32=None):
     """model of fzip_fwd_kernel: density_layer.0 (2 blocks), density_layer.2 (8 blocks: x), its row 0 once more in fp32, lin_second_stage_0
     on [x | dir], then lin_second_stage_1 block by block, each block's two k-steps multiplied into the rgb accumulator right away"""
     assert stream.shape[0] == 464 and bias.numel() == 35 * 32 and stream.dtype == Fb.dtype
@@ -655,6 +655,9 @@ def fmlp_zip_fwd(Fb, D, stream, bias, raw_rgb, raw_d):
     f, dv = _rows_to_ksteps(Fb, 4), _rows_to_ksteps(D, 1)
     h1 = st.dense([f], 2, True)
     x = st.dense([h1], 8, False)
+    if x32 is not None:                                         # block 0 of x back in natural order
+        inv = torch.argsort(_P)
+        x32[:, :16] = x[0][:, inv].to(x32.dtype); x32[:, 16:32] = x[1][:, inv].to(x32.dtype)
     raw_d.view(-1)[:] = st.block([h1], False, to_frags=False)[:, 0]
     h2 = st.dense([x, dv], 8, True)
     rgb = None

@@ -488,11 +488,14 @@ def test_zip_fused_inference_mlp_matches_the_per_layer_path(backend, golden, com
         Dn = torch.zeros(M, 16); Dn[:, :9] = torch.randn(M, 9, generator=gen)
         Fb, Dn = Fb.to(net.tdt).to(DEV), Dn.to(net.tdt).to(DEV)
         with torch.no_grad():
-            rgb_f, den_f = net.forward_fused(Fb, Dn)
+            rgb_f, den_f = net.forward_fused(Fb, Dn, want_x=True)
+            x32 = net.last_x.clone()
             F2, SB = net.alloc(M)
             F2.copy_(Fb); SB[:, net.Wd + net.Bw:net.Wd + net.Bw + 16] = Dn; SB[:, net.Wd + net.Bw + 16:] = 0
             rgb_l, den_l, _ = net.forward(F2, SB, False)
         close(rgb_f, rgb_l, tol, tol, f"raw rgb M={M}"); close(den_f, den_l, tol, tol, f"raw density M={M}")
+        assert x32.shape == (M, 32) and x32.dtype == net.tdt
+        close(x32, net.last_x[:, :32], tol, tol, f"x[:, :32] (semantic logits) M={M}")
         W = {k[9:]: v.double() for k, v in p.items() if k.startswith("nerf_mlp.") and "encoder" not in k}
         f64, d64 = Fb.double().cpu()[:, :40], Dn.double().cpu()[:, :9]
         h1 = torch.relu(f64 @ W["density_layer.0.weight"].t() + W["density_layer.0.bias"])
