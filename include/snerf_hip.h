@@ -453,6 +453,12 @@ int snerf_fmlp_proposal_train_fwd(const void* E, long ldE, const void* wstream, 
  * snerf_amd.mlp.ZipNerfNet._pack_fused_infer. */
 int snerf_fmlp_zip_fwd(const void* F, long ldF, const void* D, long ldD, const void* wstream, long n_frags, const float* bias, int n_blocks,
                        float* raw_rgb, long ld_rgb, float* raw_d, long ld_d, void* x32, long ld_x, long M, int dtype, void* stream);
+/* ... and as the TRAINING forward: the same outputs plus what the backward reads -- acts[0] = H1 [M, >= 64], acts[1] = x, acts[2] = h
+ * (lin_second_stage_0), acts[3] = H3 (lin_second_stage_1) [M, >= 256] each (in `dtype`, row strides act_ld, 16-byte aligned) and bits[0] /
+ * bits[1] = the ReLU bit masks of h / H3 in snerf_linear_fwd's SNERF_ACT_RELU_BITS layout for an [M, 256] activation. */
+int snerf_fmlp_zip_train_fwd(const void* F, long ldF, const void* D, long ldD, const void* wstream, long n_frags, const float* bias, int n_blocks,
+                             float* raw_rgb, long ld_rgb, float* raw_d, long ld_d, void* const* acts, const long* act_ld, void* const* bits,
+                             long M, int dtype, void* stream);
 /* Colour head of the live mip path's NeRF MLP, fused (s-nerf/model/models.py:283-296: cat([bottleneck, view encoding]) ->
  * cond_layers.0 .. .2 (Linear 128 + ReLU) -> rgb_layer; hidden 1024, 27 view-encoding columns).  Replaces four snerf_linear_fwd
  * launches forward and the four data-gradient launches backward.

@@ -505,25 +505,30 @@ struct FzipArgs {
   float* raw_d; long ld_d;          // [M, >= 1] fp32
   __bf16* X32; long ld_x;           // optional [M, >= 32]: the first 32 channels of x in the compute dtype (the semantic head reads x[:, 1:1+C])
   long M; int tiles, n_chunks, n_blocks;
+  // training forward (STORE): the four layer outputs the backward needs -- H1 [M, >= 64], x, h (lin_second_stage_0) and H3 (lin_second_stage_1)
+  // [M, >= 256] each, row strides act_ld -- and the ReLU bit masks of h and H3 (layout of ACT_RELU_BITS in gemm.hip)
+  __bf16* act[4]; long act_ld[4]; unsigned* bits[2];
 };
 
-template <int F, int B, int J, typename C>
-__device__ __forceinline__ void fzip_last_block(C& c, const bf16x8 (&h2)[16], const bf16x8 (&x)[16], const bf16x8 (&dv)[1], f32x16& rgb) {
+template <int F, int B, int J, bool STORE, typename C>
+__device__ __forceinline__ void fzip_last_block(C& c, const bf16x8 (&h2)[16], const bf16x8 (&x)[16], const bf16x8 (&dv)[1], f32x16& rgb, const StoreTo& st, bf16x8 (&lh)[2]) {
   f32x16 acc = acc_init<B + 2 * J>(c);
   constexpr int F0 = F + J * 35;
   mac<F0, 16>(c, acc, h2);
   mac<F0 + 16, 16>(c, acc, x);
   mac<F0 + 32, 1>(c, acc, dv);
-  bf16x8 lh[2];
   to_frags<true, C::f16>(acc, lh[0], lh[1]);
+  if constexpr (STORE) store_block<true, J>(st, lh[0], lh[1]);
   mac<F0 + 33, 2>(c, rgb, lh);
 }
-template <int F, int B, typename C, int... J>
-__device__ __forceinline__ void fzip_last_seq(C& c, const bf16x8 (&h2)[16], const bf16x8 (&x)[16], const bf16x8 (&dv)[1], f32x16& rgb, std::integer_sequence<int, J...>) {
-  (fzip_last_block<F, B, J>(c, h2, x, dv, rgb), ...);
+template <int F, int B, bool STORE, typename C, int... J>
+__device__ __forceinline__ void fzip_last_seq(C& c, const bf16x8 (&h2)[16], const bf16x8 (&x)[16], const bf16x8 (&dv)[1], f32x16& rgb, const StoreTo& st,
+                                              std::integer_sequence<int, J...>) {
+  bf16x8 lh[2];
+  (fzip_last_block<F, B, J, STORE>(c, h2, x, dv, rgb, st, lh), ...);
 }
 
-template <bool F16>
+template <bool F16, bool STORE = false>
 __global__ __launch_bounds__(64 * FM_WAVES, 2) void fzip_fwd_kernel(FzipArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -540,8 +545,10 @@ __global__ __launch_bounds__(64 * FM_WAVES, 2) void fzip_fwd_kernel(FzipArgs a) 
     load_rows<1>(a.D, a.ldD, row, half, dv);
     constexpr int F1 = 2 * 4, FD = F1 + 8 * 4, F2 = FD + 4, F3 = F2 + 8 * 17;
     static_assert(F3 + 8 * 35 == FZIP_FRAGS, "zipnerf MLP: fragment count");
-    dense<0, 0, 4, 2, true>(c, f, h1);                     // density_layer.0 (+ ReLU)
-    dense<F1, 2, 4, 8, false>(c, h1, x);                   // density_layer.2: x (bottleneck, no activation)
+    auto to = [&](int i, int ncg) { return StoreTo{a.act[i], a.act_ld[i], i >= 2 ? a.bits[i - 2] : nullptr, (long)tile * FM_TILE_ROWS + wave * 32, a.M,
+                                                   smem + FM_RING * FM_SLOT + FM_BIAS_MAX * 128 + wave * 4096, lane, ncg}; };
+    dense<0, 0, 4, 2, true, STORE>(c, f, h1, to(0, 1));    // density_layer.0 (+ ReLU)
+    dense<F1, 2, 4, 8, false, STORE>(c, h1, x, to(1, 4));  // density_layer.2: x (bottleneck, no activation)
     if (a.X32 != nullptr && row_ok) {
       // block 0 of x as the lanes hold it: fragment 0 / 1 = outputs 0..15 / 16..31, lane half h owns {4 h .. 4 h + 3, 8 + 4 h .. 8 + 4 h + 3} of each
       typedef unsigned fz_u32x2 __attribute__((ext_vector_type(2)));
@@ -555,9 +562,9 @@ __global__ __launch_bounds__(64 * FM_WAVES, 2) void fzip_fwd_kernel(FzipArgs a) 
     }
     f32x16 dh = acc_init<10>(c);                           // ... and its output 0 once more, unrounded: the raw density
     mac<FD, 4>(c, dh, h1);
-    dense2<F2, 11, 16, 1, 8, true>(c, x, dv, h2);          // lin_second_stage_0 on cat([x, dir_enc]) (+ ReLU)
+    dense2<F2, 11, 16, 1, 8, true, STORE>(c, x, dv, h2, to(2, 4));   // lin_second_stage_0 on cat([x, dir_enc]) (+ ReLU)
     f32x16 rgb = acc_init<20>(c);                          // rgb_layer: its bias sits in the first of the interleaved pieces
-    fzip_last_seq<F3, 19>(c, h2, x, dv, rgb, std::make_integer_sequence<int, 8>{});   // lin_second_stage_1 on cat([h, x, dir_enc]) (+ ReLU) -> rgb
+    fzip_last_seq<F3, 19, STORE>(c, h2, x, dv, rgb, to(3, 4), std::make_integer_sequence<int, 8>{});   // lin_second_stage_1 on cat([h, x, dir_enc]) (+ ReLU) -> rgb
     // the pass is padded to whole chunks (464 fragments): take the four padding fragments out of the queue so that the next tile starts on
     // a chunk boundary like every other network's
     (void)next_frag<FZIP_FRAGS>(c); (void)next_frag<FZIP_FRAGS + 1>(c); (void)next_frag<FZIP_FRAGS + 2>(c); (void)next_frag<FZIP_FRAGS + 3>(c);
@@ -1211,7 +1218,7 @@ extern "C" int snerf_fmlp_zip_fwd(const void* F, long ldF, const void* D, long l
       (ldD % 8) || (((uintptr_t)F) & 15) || (((uintptr_t)D) & 15) || ld_rgb < 3 || ld_d < 1 || M >= (1L << 31) || n_blocks != FZIP_BLOCKS ||
       n_frags != ((FZIP_FRAGS + FM_CHUNK - 1) / FM_CHUNK) * FM_CHUNK || (dtype != SNERF_DT_BF16 && dtype != SNERF_DT_F16))
     return SNERF_ERR_ARG;
-  FzipArgs a{(const __bf16*)F, ldF, (const __bf16*)D, ldD, (const char*)wstream, bias, raw_rgb, ld_rgb, raw_d, ld_d, (__bf16*)x32, ld_x, M, 0, (int)(n_frags / FM_CHUNK), n_blocks};
+  FzipArgs a{(const __bf16*)F, ldF, (const __bf16*)D, ldD, (const char*)wstream, bias, raw_rgb, ld_rgb, raw_d, ld_d, (__bf16*)x32, ld_x, M, 0, (int)(n_frags / FM_CHUNK), n_blocks, {}, {}, {}};
   a.tiles = (int)((M + FM_TILE_ROWS - 1) / FM_TILE_ROWS);
   const int lds = FM_RING * FM_SLOT + FM_BIAS_MAX * 128;
   static bool attr = false;
@@ -1227,6 +1234,47 @@ extern "C" int snerf_fmlp_zip_fwd(const void* F, long ldF, const void* D, long l
   const int grid = a.tiles < n_cu * FM_WG_PER_CU ? a.tiles : n_cu * FM_WG_PER_CU;
   if (dtype == SNERF_DT_F16) hipLaunchKernelGGL(fzip_fwd_kernel<true>, dim3(grid), dim3(64 * FM_WAVES), lds, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(fzip_fwd_kernel<false>, dim3(grid), dim3(64 * FM_WAVES), lds, (hipStream_t)stream, a);
+  return snerf_check_launch();
+}
+
+// ... and the same network as the TRAINING forward of a ZipTrainer step: additionally stores what the backward reads -- acts[0] = H1 [M, >= 64]
+// (density_layer.0), acts[1] = x, acts[2] = h (lin_second_stage_0), acts[3] = H3 (lin_second_stage_1) [M, >= 256] each (compute dtype, row
+// strides act_ld, 16-byte aligned; x and h are normally column ranges of the [h | x | dir] operand of lin_second_stage_1's weight gradient) and
+// bits[0] / bits[1] = the ReLU bit masks of h / H3 (snerf_linear_fwd's ACT_RELU_BITS layout for [M, 256]) -- through the per-wave transposition
+// slabs of the other store-carrying fused kernels.  Replaces seven launches that move 10 GB per 65 536-ray step by one that writes 3.5 GB.
+extern "C" int snerf_fmlp_zip_train_fwd(const void* F, long ldF, const void* D, long ldD, const void* wstream, long n_frags, const float* bias,
+                                        int n_blocks, float* raw_rgb, long ld_rgb, float* raw_d, long ld_d, void* const* acts, const long* act_ld,
+                                        void* const* bits, long M, int dtype, void* stream) {
+  if (M <= 0) return SNERF_OK;
+  if (F == nullptr || D == nullptr || wstream == nullptr || bias == nullptr || raw_rgb == nullptr || raw_d == nullptr || acts == nullptr || act_ld == nullptr ||
+      bits == nullptr || ldF < 64 || ldD < 16 || (ldF % 8) || (ldD % 8) || (((uintptr_t)F) & 15) || (((uintptr_t)D) & 15) || ld_rgb < 3 || ld_d < 1 ||
+      M >= (1L << 31) || n_blocks != FZIP_BLOCKS || n_frags != ((FZIP_FRAGS + FM_CHUNK - 1) / FM_CHUNK) * FM_CHUNK ||
+      (dtype != SNERF_DT_BF16 && dtype != SNERF_DT_F16))
+    return SNERF_ERR_ARG;
+  FzipArgs a{(const __bf16*)F, ldF, (const __bf16*)D, ldD, (const char*)wstream, bias, raw_rgb, ld_rgb, raw_d, ld_d, nullptr, 0, M, 0, (int)(n_frags / FM_CHUNK), n_blocks, {}, {}, {}};
+  for (int i = 0; i < 4; ++i) {
+    if (acts[i] == nullptr || (((uintptr_t)acts[i]) & 15) || (act_ld[i] % 8) != 0 || act_ld[i] < (i == 0 ? 64 : 256)) return SNERF_ERR_ARG;
+    a.act[i] = (__bf16*)acts[i]; a.act_ld[i] = act_ld[i];
+  }
+  for (int i = 0; i < 2; ++i) {
+    if (bits[i] == nullptr || (((uintptr_t)bits[i]) & 15)) return SNERF_ERR_ARG;
+    a.bits[i] = (unsigned*)bits[i];
+  }
+  a.tiles = (int)((M + FM_TILE_ROWS - 1) / FM_TILE_ROWS);
+  const int lds = FM_RING * FM_SLOT + FM_BIAS_MAX * 128 + FM_WAVES * 4096;
+  static bool attr = false;
+  static int n_cu = 256;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)fzip_fwd_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)fzip_fwd_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
+    attr = true;
+  }
+  const int grid = a.tiles < n_cu * FM_WG_PER_CU ? a.tiles : n_cu * FM_WG_PER_CU;
+  if (dtype == SNERF_DT_F16) hipLaunchKernelGGL((fzip_fwd_kernel<true, true>), dim3(grid), dim3(64 * FM_WAVES), lds, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((fzip_fwd_kernel<false, true>), dim3(grid), dim3(64 * FM_WAVES), lds, (hipStream_t)stream, a);
   return snerf_check_launch();
 }
 

@@ -1173,19 +1173,40 @@ class ZipNerfNet(_Net):
             layers.append((Wr[:, 32 * j:32 * j + 32], br if j == 0 else None, [(0, 32, True)]))
         return fmlp_pack(layers, self.dev)
 
-    def forward_fused(self, Fb, D, want_x=False):
-        """Fb [M, 64] grid features, D [M, 16] direction encoding (compute dtype, zero padded) -> raw_rgb [M,3], raw_density [M,1] fp32;
-        `want_x`: self.last_x = the first 32 channels of x [M, 32] (the semantic head's logits are its columns 1 .. C)"""
+    def _zip_streams(self):
         v = self.version_fn()
         if getattr(self, "_zinfer_version", None) != v:
             with torch.no_grad():
                 self._zinfer = self._refresh_fused(self._pack_fused_infer, "zip_infer", dtype=self.tdt)
             self._zinfer_version = v
+        return self._zinfer
+
+    def forward_fused(self, Fb, D, want_x=False):
+        """Fb [M, 64] grid features, D [M, 16] direction encoding (compute dtype, zero padded) -> raw_rgb [M,3], raw_density [M,1] fp32;
+        `want_x`: self.last_x = the first 32 channels of x [M, 32] (the semantic head's logits are its columns 1 .. C)"""
+        st, bi = self._zip_streams()
         M = Fb.shape[0]
         raw_rgb, raw_d = self.buf(M, 3, f32=True), self.buf(M, 1, f32=True)
         self.last_x = self.buf(M, 32) if want_x else None
-        ops.fmlp_zip_fwd(Fb, D, self._zinfer[0], self._zinfer[1], raw_rgb, raw_d, self.last_x)
+        ops.fmlp_zip_fwd(Fb, D, st, bi, raw_rgb, raw_d, self.last_x)
         return raw_rgb, raw_d
+
+    def forward_fused_train(self, Fb, SB):
+        """The training forward as one launch: same `saved` tuple and ReLU bit masks as forward(Fb, SB, keep=True) leaves (the backward does not
+        know which of the two ran).  SB [M, Wd + B + Dw] arrives with the direction encoding in its last block; h and x are written into
+        its first two."""
+        self.ensure_packed(True)                                  # (the backward's operands + the bit-mask registry of this step)
+        st, bi = self._zip_streams()
+        M, B, Wd = Fb.shape[0], self.Bw, self.Wd
+        H1, H3 = self.buf(M, self.H), self.buf(M, Wd)
+        h2, X = SB[:, :Wd], SB[:, Wd:Wd + B]
+        raw_rgb, raw_d = self.buf(M, 3, f32=True), self.buf(M, 1, f32=True)
+        words = [torch.empty(ops.mask_bits_words(M, 256), dtype=torch.int32, device=self.dev) for _ in range(2)]
+        ops.fmlp_zip_train_fwd(Fb, SB[:, Wd + B:], st, bi, raw_rgb, raw_d, [H1, X, h2, H3], words)
+        self._bits[(h2.data_ptr(), M)] = (words[0], Wd)
+        self._bits[(H3.data_ptr(), M)] = (words[1], Wd)
+        self.last_x = X
+        return raw_rgb, raw_d, (Fb, H1, SB, H3, None)
 
     def alloc(self, M):
         """-> (F, SB): the featurisation kernel writes F[:, :feat_dim] (F arrives zeroed), the view encoder SB[:, Wd+B:]."""
@@ -1194,6 +1215,10 @@ class ZipNerfNet(_Net):
     def forward(self, Fb, SB, keep, glo=None, S=0):
         """`glo` [R, Gw] (compute dtype, zero padded): the rays' GLO vectors, R = rows / S -- required iff glo_dim > 0.  The returned
         `x` [M, B] is the density network's (unmodulated) output: column 0 = raw density, columns 1.. = semantic logits."""
+        import os
+        if keep and glo is None and self.fused_infer_ok() and self.Dw >= 16 and ops.mask_bits_words(Fb.shape[0], 256) * 4 < (1 << 31) and \
+                getattr(self, "fused_train", os.environ.get("SNERF_ZIP_FUSED_TRAIN", "1") != "0"):       # (the variable: A/B runs of tools/bench_zip.py)
+            return self.forward_fused_train(Fb, SB)
         self.ensure_packed(keep)
         M, B, Wd = Fb.shape[0], self.Bw, self.Wd
         H1 = self.buf(M, self.H)

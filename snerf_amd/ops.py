@@ -214,6 +214,27 @@ def fmlp_zip_fwd(Fb, D, stream, bias, raw_rgb, raw_d, x32=None):
               _p(raw_rgb), raw_rgb.stride(0), _p(raw_d), raw_d.stride(0), _p(x32), 0 if x32 is None else x32.stride(0), M, _zip_dt(Fb), _stream())
 
 
+def fmlp_zip_train_fwd(Fb, D, stream, bias, raw_rgb, raw_d, acts, bits):
+    """The training forward of the zipnerf NeRF MLP in ONE launch (fzip_fwd_kernel<.., STORE>): as fmlp_zip_fwd, plus acts = [H1 [M, >= 64],
+    x, h, H3 [M, >= 256]] (compute dtype 2-D views, written) and bits = 2 x int32 [mask_bits_words(M, 256)] (ReLU bit masks of h and H3)."""
+    import ctypes
+    _chk2d(Fb, Fb.dtype); _chk2d(D, Fb.dtype); _chk2d(raw_rgb, torch.float32); _chk2d(raw_d, torch.float32)
+    M = Fb.shape[0]
+    assert Fb.dtype in (torch.bfloat16, torch.float16) and stream.dtype == Fb.dtype and stream.is_contiguous() and bias.dtype == torch.float32
+    assert D.shape[0] == M and raw_rgb.shape[0] == M and raw_d.shape[0] == M and Fb.shape[1] >= 64 and D.shape[1] >= 16 and len(acts) == 4 and len(bits) == 2
+    for i, y in enumerate(acts):
+        _chk2d(y, Fb.dtype)
+        assert y.shape[0] == M and y.shape[1] >= (64 if i == 0 else 256)
+    for b in bits:
+        assert b.dtype == torch.int32 and b.is_contiguous() and b.numel() >= mask_bits_words(M, 256)
+    pa = (ctypes.c_void_p * 4)(*[y.data_ptr() for y in acts])
+    pl = (ctypes.c_long * 4)(*[y.stride(0) for y in acts])
+    pb = (ctypes.c_void_p * 2)(*[b.data_ptr() for b in bits])
+    _lib.call("snerf_fmlp_zip_train_fwd", _p(Fb), Fb.stride(0), _p(D), D.stride(0), _p(stream), stream.shape[0], _p(bias), bias.numel() // 32,
+              _p(raw_rgb), raw_rgb.stride(0), _p(raw_d), raw_d.stride(0), ctypes.addressof(pa), ctypes.addressof(pl), ctypes.addressof(pb), M,
+              _zip_dt(Fb), _stream())
+
+
 def fcolour_fwd(CB, stream, bias, raw_rgb, acts=None, bits=None, variant=0):
     """Fused colour head of the mip path's NeRF MLP (csrc/fmlp.hip): CB [M, >= 1056] bf16 = [bottleneck 1024 | view encoding 27 | 0]
     -> raw_rgb [M,3] fp32 in ONE launch.  Training: `acts` = 3 x [M, >= 128] bf16 (outputs of cond_layers.0..2), `bits` = 3 x int32

@@ -647,6 +647,26 @@ def fmlp_classic_fwd(E, VE, stream, bias, raw, acts=None):
     raw[:, 3] = sigma
 
 
+def fmlp_zip_train_fwd(Fb, D, stream, bias, raw_rgb, raw_d, acts, bits):
+    """model of fzip_fwd_kernel<.., STORE>: the same pass, every layer output stored in natural order, ReLU masks of h and H3 registered"""
+    assert stream.shape[0] == 464 and bias.numel() == 35 * 32 and len(acts) == 4 and len(bits) == 2
+    st = _FStream(stream, bias)
+    f, dv = _rows_to_ksteps(Fb, 4), _rows_to_ksteps(D, 1)
+    h1 = st.dense([f], 2, True, acts[0])
+    x = st.dense([h1], 8, False, acts[1])
+    raw_d.view(-1)[:] = st.block([h1], False, to_frags=False)[:, 0]
+    h2 = st.dense([x, dv], 8, True, acts[2])
+    rgb = None
+    for j in range(8):
+        blk = st.block([h2, x, dv], True, store=acts[3], j=j)
+        piece = st.block([blk], False, to_frags=False)
+        rgb = piece if rgb is None else rgb + piece
+    assert st.f == 460 and st.nb == 35
+    raw_rgb[:, :3] = rgb[:, :3]
+    _BITS[bits[0].data_ptr()] = acts[2][:, :256].float() > 0
+    _BITS[bits[1].data_ptr()] = acts[3][:, :256].float() > 0
+
+
 def fmlp_zip_fwd(Fb, D, stream, bias, raw_rgb, raw_d, x32=None):
     """model of fzip_fwd_kernel: density_layer.0 (2 blocks), density_layer.2 (8 blocks: x), its row 0 once more in fp32, lin_second_stage_0
     on [x | dir], then lin_second_stage_1 block by block, each block's two k-steps multiplied into the rgb accumulator right away"""
@@ -804,7 +824,7 @@ def adam_step_dev(p, g, m, v, lr, b1, b2, eps, step_dev, grad_scale=1.0, zero_gr
     adam_step(p, g, m, v, lr, b1, b2, eps, 0, grad_scale, zero_grad, step_dev=step_dev, **kw)
 
 
-_NAMES = ["fmlp_zip_fwd", "zip_prop_mlp_fwd", "zip_prop_mlp_bwd", "colsum_wide_f32", "zip_glo_modulate", "zip_glo_modulate_bwd", "fchain_bwd", "app_embed", "app_embed_bwd", "split_cast", "fcolour_fwd", "fcolour_bwd", "gather_pack", "adam_step_dev", "grad_clip_coef", "fmlp_classic_fwd", "fmlp_classic_pts_fwd", "fmlp_proposal_fwd", "fmlp_classic_train_fwd", "fmlp_proposal_train_fwd", "classic_get_rays", "classic_ndc_rays", "classic_ray_batch", "zip_encode_prop_fwd", "mip_encode_bwd", "mip_viewenc_bwd", "hash_decay", "zip_percentiles", "zip_pixels_to_rays", "zip_loss_tail", "semantic_composite_fwd", "semantic_composite_bwd", "zip_resample", "zip_encode_fwd", "zip_encode_fwd_count", "zip_encode_bwd", "zip_encode_bwd_binned", "zip_encode_ray_bwd", "zip_composite_fwd", "zip_composite_bwd",
+_NAMES = ["fmlp_zip_fwd", "fmlp_zip_train_fwd", "zip_prop_mlp_fwd", "zip_prop_mlp_bwd", "colsum_wide_f32", "zip_glo_modulate", "zip_glo_modulate_bwd", "fchain_bwd", "app_embed", "app_embed_bwd", "split_cast", "fcolour_fwd", "fcolour_bwd", "gather_pack", "adam_step_dev", "grad_clip_coef", "fmlp_classic_fwd", "fmlp_classic_pts_fwd", "fmlp_proposal_fwd", "fmlp_classic_train_fwd", "fmlp_proposal_train_fwd", "classic_get_rays", "classic_ndc_rays", "classic_ray_batch", "zip_encode_prop_fwd", "mip_encode_bwd", "mip_viewenc_bwd", "hash_decay", "zip_percentiles", "zip_pixels_to_rays", "zip_loss_tail", "semantic_composite_fwd", "semantic_composite_bwd", "zip_resample", "zip_encode_fwd", "zip_encode_fwd_count", "zip_encode_bwd", "zip_encode_bwd_binned", "zip_encode_ray_bwd", "zip_composite_fwd", "zip_composite_bwd",
           "linear_fwd", "linear_wgrad", "classic_embed", "mip_encode", "mip_viewenc", "classic_sample_pdf", "classic_points",
           "classic_merge_sort", "mip_resample", "stratified", "mip_composite_fwd", "mip_composite_bwd", "classic_composite_fwd",
           "classic_composite_bwd", "adam_step", "colsum_f32", "cast_pad", "pinhole_rays", "mip_loss_tail"]

@@ -506,6 +506,44 @@ def test_zip_fused_inference_mlp_matches_the_per_layer_path(backend, golden, com
         close(den_f, x[:, :1], 5 * tol, 5 * tol, f"raw density vs fp64 M={M}")
 
 
+@pytest.mark.parametrize("compute,tol", [("bf16", 3e-2), ("fp16", 4e-3)])
+def test_zip_fused_training_forward_matches_the_per_layer_path(backend, golden, compute, tol):
+    """The training forward of the NeRF MLP as one launch (fzip_fwd_kernel<.., STORE>: every layer's output stored through the transposition
+    slabs, ReLU bit masks of the two 256-wide hidden layers in the GEMMs' layout) against the seven per-layer launches (`fused_train =
+    False`): the stored activations, the raw outputs and -- through the unchanged backward, which reads the stored activations and bit masks --
+    every parameter gradient, on rows that are not a multiple of the 256-row tile."""
+    specs, p = zip_setup()
+    gen = torch.Generator().manual_seed(5)
+    for k in list(p):
+        if k.startswith("nerf_mlp.") and k.endswith(".weight") and "encoder" not in k:
+            p[k] = torch.randn(p[k].shape, generator=gen) * (1.2 / p[k].shape[1] ** 0.5)
+    m = make_model(compute, "f32", p, use_semantic=True)
+    net = m.nets[2]
+    M = 1000
+    Fb0 = torch.zeros(M, 64); Fb0[:, :40] = torch.randn(M, 40, generator=gen) * 0.5
+    Dn = torch.zeros(M, 16); Dn[:, :9] = torch.randn(M, 9, generator=gen)
+    d_rgb = (torch.randn(M, 3, generator=gen) * 1e-2).to(DEV)
+    d_den = (torch.randn(M, 1 + 19, generator=gen) * 1e-2).to(DEV)       # raw density + 19 semantic logits
+    res = {}
+    for fused in (True, False):
+        net.fused_train = fused
+        Fb, SB = net.alloc(M)
+        Fb.copy_(Fb0.to(net.tdt)); SB[:, net.Wd + net.Bw:] = 0; SB[:, net.Wd + net.Bw:net.Wd + net.Bw + 16] = Dn.to(net.tdt)
+        raw_rgb, raw_d, saved = net.forward(Fb, SB, True)
+        assert (len(net._bits) == 2) if fused else True
+        m.arena.grad.zero_()
+        dF = net.backward(d_rgb, d_den, saved)
+        res[fused] = dict(raw_rgb=raw_rgb.clone(), raw_d=raw_d.clone(), H1=saved[1].clone(), SB=saved[2][:, :512].clone(), H3=saved[3].clone(), dF=dF.clone(),
+                          x=net.last_x.clone(), grad=m.arena.grad.clone())
+    net.fused_train = True
+    for k in ("raw_rgb", "raw_d", "H1", "SB", "H3", "x"):
+        close(res[True][k], res[False][k], tol, tol, k)
+    for k in ("dF", "grad"):
+        a, b = res[True][k].float(), res[False][k].float()
+        rel = float((a - b).norm() / b.norm())
+        assert float(b.norm()) > 0 and rel < 2 * tol, (k, rel)
+
+
 def test_zip_trainer_fused_loss_tail(backend):
     """ZipTrainer.step: the loss terms it reports are the oracle's loss tail (s-nerfpp/zipnerf/train.py:250-311) evaluated on the
     renderer outputs of that step, the step changes the parameters, and repeated steps on a fixed batch reduce the loss."""
