@@ -454,11 +454,21 @@ int snerf_fmlp_proposal_train_fwd(const void* E, long ldE, const void* wstream, 
 int snerf_fmlp_zip_fwd(const void* F, long ldF, const void* D, long ldD, const void* wstream, long n_frags, const float* bias, int n_blocks,
                        float* raw_rgb, long ld_rgb, float* raw_d, long ld_d, void* x32, long ld_x, long M, int dtype, void* stream);
 /* ... and as the TRAINING forward: the same outputs plus what the backward reads -- acts[0] = H1 [M, >= 64], acts[1] = x, acts[2] = h
- * (lin_second_stage_0), acts[3] = H3 (lin_second_stage_1) [M, >= 256] each (in `dtype`, row strides act_ld, 16-byte aligned) and bits[0] /
- * bits[1] = the ReLU bit masks of h / H3 in snerf_linear_fwd's SNERF_ACT_RELU_BITS layout for an [M, 256] activation. */
+ * (lin_second_stage_0), acts[3] = H3 (lin_second_stage_1) [M, >= 256] each (in `dtype`, row strides act_ld, 16-byte aligned) and bits[0..2] =
+ * the ReLU bit masks of H1 ([M, 64]), h and H3 ([M, 256]) in snerf_linear_fwd's SNERF_ACT_RELU_BITS layout. */
 int snerf_fmlp_zip_train_fwd(const void* F, long ldF, const void* D, long ldD, const void* wstream, long n_frags, const float* bias, int n_blocks,
                              float* raw_rgb, long ld_rgb, float* raw_d, long ld_d, void* const* acts, const long* act_ld, void* const* bits,
                              long M, int dtype, void* stream);
+/* ... and its BACKWARD data-gradient chain in one launch: d_rgb [M, ld_rgb >= 3], d_den [M, ld_den >= den_cols] fp32 (d raw density, then the
+ * gradients of the den_cols - 1 <= 31 semantic logits) -> dz[0] = d pre-activation of lin_second_stage_1, dz[1] = of lin_second_stage_0, dz[2] = d x
+ * ([M, >= 256] each), dz[3] = d pre-activation of density_layer.0, dz[4] = d grid features ([M, >= 64]) in `dtype` -- the operands of the five
+ * weight-gradient GEMMs and of the table gradient; bits[0..2] as written by snerf_fmlp_zip_train_fwd; the bias gradients of lin_second_stage_1,
+ * lin_second_stage_0, density_layer.2, density_layer.0 are ADDED to g_bias[0..3] (not bit-reproducible); ws: snerf_fmlp_zip_chain_ws_floats(M)
+ * floats.  wstream (448 fragments): snerf_amd.mlp.ZipNerfNet._pack_fused_chain. */
+long snerf_fmlp_zip_chain_ws_floats(long M);
+int snerf_fmlp_zip_chain_bwd(const float* d_rgb, long ld_rgb, const float* d_den, long ld_den, int den_cols, const void* wstream, long n_frags,
+                             void* const* bits, void* const* dz, const long* dz_ld, float* const* g_bias, float* ws, long ws_floats, long M,
+                             int dtype, void* stream);
 /* Colour head of the live mip path's NeRF MLP, fused (s-nerf/model/models.py:283-296: cat([bottleneck, view encoding]) ->
  * cond_layers.0 .. .2 (Linear 128 + ReLU) -> rgb_layer; hidden 1024, 27 view-encoding columns).  Replaces four snerf_linear_fwd
  * launches forward and the four data-gradient launches backward.

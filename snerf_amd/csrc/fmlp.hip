@@ -506,8 +506,8 @@ struct FzipArgs {
   __bf16* X32; long ld_x;           // optional [M, >= 32]: the first 32 channels of x in the compute dtype (the semantic head reads x[:, 1:1+C])
   long M; int tiles, n_chunks, n_blocks;
   // training forward (STORE): the four layer outputs the backward needs -- H1 [M, >= 64], x, h (lin_second_stage_0) and H3 (lin_second_stage_1)
-  // [M, >= 256] each, row strides act_ld -- and the ReLU bit masks of h and H3 (layout of ACT_RELU_BITS in gemm.hip)
-  __bf16* act[4]; long act_ld[4]; unsigned* bits[2];
+  // [M, >= 256] each, row strides act_ld -- and the ReLU bit masks of H1 (one 64-column group), h and H3 (layout of ACT_RELU_BITS in gemm.hip)
+  __bf16* act[4]; long act_ld[4]; unsigned* bits[3];
 };
 
 template <int F, int B, int J, bool STORE, typename C>
@@ -545,9 +545,9 @@ __global__ __launch_bounds__(64 * FM_WAVES, 2) void fzip_fwd_kernel(FzipArgs a) 
     load_rows<1>(a.D, a.ldD, row, half, dv);
     constexpr int F1 = 2 * 4, FD = F1 + 8 * 4, F2 = FD + 4, F3 = F2 + 8 * 17;
     static_assert(F3 + 8 * 35 == FZIP_FRAGS, "zipnerf MLP: fragment count");
-    auto to = [&](int i, int ncg) { return StoreTo{a.act[i], a.act_ld[i], i >= 2 ? a.bits[i - 2] : nullptr, (long)tile * FM_TILE_ROWS + wave * 32, a.M,
+    auto to = [&](int i, int ncg) { return StoreTo{a.act[i], a.act_ld[i], i == 0 ? a.bits[0] : (i >= 2 ? a.bits[i - 1] : nullptr), (long)tile * FM_TILE_ROWS + wave * 32, a.M,
                                                    smem + FM_RING * FM_SLOT + FM_BIAS_MAX * 128 + wave * 4096, lane, ncg}; };
-    dense<0, 0, 4, 2, true, STORE>(c, f, h1, to(0, 1));    // density_layer.0 (+ ReLU)
+    dense<0, 0, 4, 2, true, STORE, STORE>(c, f, h1, to(0, 1));    // density_layer.0 (+ ReLU; training: with its bit mask, one column group)
     dense<F1, 2, 4, 8, false, STORE>(c, h1, x, to(1, 4));  // density_layer.2: x (bottleneck, no activation)
     if (a.X32 != nullptr && row_ok) {
       // block 0 of x as the lanes hold it: fragment 0 / 1 = outputs 0..15 / 16..31, lane half h owns {4 h .. 4 h + 3, 8 + 4 h .. 8 + 4 h + 3} of each
@@ -1065,6 +1065,165 @@ __global__ __launch_bounds__(64 * FM_WAVES, 2) void fchain_bwd_kernel(ChainArgs 
   for (int i = tid; i < NCOLS; i += 64 * FM_WAVES) a.colsum_ws[(long)blockIdx.x * NCOLS + i] = cs[i];
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Data-gradient chain of the zipnerf NeRF MLP (round 4; the backward of fzip_fwd_kernel<.., STORE>): d raw_rgb [M,3], d (raw density |
+// semantic logits) [M, <= 32] ->
+//   dH3 = mask(H3) . rgb_layer^T d rgb                               -> dz[0]  (the weight gradient of lin_second_stage_1 reads it)
+//   dh  = mask(h)  . lin_second_stage_1[:, :256]^T dH3               -> dz[1]  (... of lin_second_stage_0)
+//   dx  = lin_second_stage_0[:, :256]^T dh + lin_second_stage_1[:, 256:512]^T dH3 + [d density | d logits | 0]   -> dz[2]
+//   dH1 = mask(H1) . density_layer.2^T dx                            -> dz[3]
+//   dF  = density_layer.0^T dH1                                      -> dz[4]  (the gradient of the grid features: the table gradient's input)
+// on the blocks of fchain_bwd_kernel (transposed weights streamed through the ring, masks from the forward's bit masks, bias gradients
+// by the register butterfly into a workgroup table).  dx is never held: as soon as a block of 32 of its channels is rounded and on its way
+// out, the two k-steps of density_layer.2^T that consume it are multiplied into the two dH1 accumulators (the host interleaves those
+// fragments), so a lane keeps dh, dH3 and the head gradients (34 fragments) while the 272 MFMAs of the dx step run.
+// Mask images per wave and tile: H3 and h 1 KiB each, H1 256 B, by LDS-DMA ONE TILE AHEAD (H3 / h right after the step that consumed them --
+// 19 chunks of weight stream follow before the next tile reads them -- H1 after its step; the first tile's with a full wait).
+// 448 fragments (28 chunks); bias-gradient table 896 columns (256 + 256 + 256 + 64, + 64 unused of the last step).
+#define FZCH_FRAGS 448
+#define FZCH_COLS 896
+#define FZCH_WAVE_BYTES 2560
+#define FZCH_LDS (FCH_RING * FM_SLOT + FM_WAVES * 4096 + FM_WAVES * FZCH_WAVE_BYTES + FCH_TAB(FZCH_COLS) * 4)
+struct ZipChainArgs {
+  const float* d_rgb; long ld_rgb;               // [M, >= 3] fp32
+  const float* d_den; long ld_den; int den_cols;  // [M, den_cols <= 32] fp32: d raw density, then the semantic logits' gradients
+  const char* wstream;
+  const unsigned* bits[3];                       // ReLU bit masks of H1 (64 wide), h, H3 (256 wide)
+  __bf16* dz[5]; long dz_ld[5];
+  float* colsum_ws;                              // [gridDim.x, FZCH_COLS]
+  long M;
+  int tiles, n_chunks;
+};
+
+// what follows the MFMAs of a chain block: ReLU mask from the bit-mask words, bias-gradient partial, rounding, store through the slab
+template <bool MASKED, int J, int G, typename C>
+__device__ __forceinline__ void zc_finish(C& c, f32x16& acc, const char* mk, int lane, int sh, bool row_ok, ColsumCtx& k, bf16x8& lo, bf16x8& hi, const StoreTo& st) {
+  (void)c;
+  fm_u32x4 w = {0u, 0u, 0u, 0u};
+  if constexpr (MASKED) w = *(const fm_u32x4*)(mk + ((J >> 1) * 64 + (lane & 7) * 8 + 4 * (J & 1)) * 4);
+  FCH_MASK4(0) FCH_MASK4(1) FCH_MASK4(2) FCH_MASK4(3)
+  const float rs = rows_sum(acc, lane);
+  if ((lane & 16) == 0) {
+    asm volatile("ds_add_f32 %0, %1 offset:%2" ::"v"(k.tab0), "v"(rs), "n"(32 * G * 4) : "memory");
+  }
+  to_frags<false, C::f16>(acc, lo, hi);
+  store_block<false, J>(st, lo, hi);
+}
+template <int F, int NK, bool MASKED, int J, int G, typename C>
+__device__ __forceinline__ void zc_block(C& c, const bf16x8 (&in)[NK], const char* mk, int lane, int sh, bool row_ok, ColsumCtx& k, bf16x8& lo, bf16x8& hi,
+                                         const StoreTo& st) {
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  mac<F, NK>(c, acc, in);
+  zc_finish<MASKED, J, G>(c, acc, mk, lane, sh, row_ok, k, lo, hi, st);
+}
+template <int F, int NK, bool MASKED, int NB, int G0, typename C, int... J>
+__device__ __forceinline__ void zc_step(C& c, const bf16x8 (&in)[NK], const char* mk, int lane, int sh, bool row_ok, ColsumCtx& k, bf16x8 (&out)[2 * NB],
+                                        const StoreTo& st, std::integer_sequence<int, J...>) {
+  (zc_block<F + J * NK, NK, MASKED, J, G0 + J>(c, in, mk, lane, sh, row_ok, k, out[2 * J], out[2 * J + 1], st), ...);
+}
+// the dx step, block J: 34 k-steps over [dh | dH3 | head gradients], then its two fragments into the two dH1 accumulators
+template <int F, int J, int G0, typename C>
+__device__ __forceinline__ void zc_dx_block(C& c, const bf16x8 (&in)[34], int lane, int sh, bool row_ok, ColsumCtx& k, f32x16& h0, f32x16& h1, const StoreTo& st) {
+  constexpr int F0 = F + J * 38;
+  bf16x8 lh[2];
+  zc_block<F0, 34, false, J, G0 + J>(c, in, nullptr, lane, sh, row_ok, k, lh[0], lh[1], st);
+  mac<F0 + 34, 2>(c, h0, lh);
+  mac<F0 + 36, 2>(c, h1, lh);
+}
+template <int F, int G0, typename C, int... J>
+__device__ __forceinline__ void zc_dx_step(C& c, const bf16x8 (&in)[34], int lane, int sh, bool row_ok, ColsumCtx& k, f32x16& h0, f32x16& h1, const StoreTo& st,
+                                           std::integer_sequence<int, J...>) {
+  (zc_dx_block<F, J, G0>(c, in, lane, sh, row_ok, k, h0, h1, st), ...);
+}
+
+template <bool F16>
+__global__ __launch_bounds__(64 * FM_WAVES, 2) void fzip_chain_bwd_kernel(ZipChainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5;
+  char* const slab = smem + FCH_RING * FM_SLOT + wave * 4096;
+  char* const mk = smem + FCH_RING * FM_SLOT + FM_WAVES * 4096 + wave * FZCH_WAVE_BYTES;      // [H3 masks 1 KiB][h masks 1 KiB][H1 masks 256 B]
+  float* const cs = (float*)(smem + FCH_RING * FM_SLOT + FM_WAVES * 4096 + FM_WAVES * FZCH_WAVE_BYTES);
+  auto dma_wide = [&](int l, int buf, long row0, int ln) __attribute__((always_inline)) {           // a 256-wide layer's masks of the wave's 32 rows
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)((const char*)(a.bits[l] + (row0 >> 5) * (4 * 64)) + ln * 16), (lds_ptr_t)(mk + buf * 1024), 16, 0, 0);
+  };
+  auto dma_h1 = [&](long row0, int ln) __attribute__((always_inline)) {                              // H1's (one column group: 256 B)
+    if (ln < 16) __builtin_amdgcn_global_load_lds((gbl_ptr_t)((const char*)(a.bits[0] + (row0 >> 5) * 64) + ln * 16), (lds_ptr_t)(mk + 2048), 16, 0, 0);
+  };
+  {
+    const long row0 = (long)blockIdx.x * FM_TILE_ROWS + wave * 32;    // (the launch has gridDim.x <= tiles)
+    dma_wide(2, 0, row0, lane); dma_wide(1, 1, row0, lane); dma_h1(row0, lane);
+    for (int i = tid; i < FCH_TAB(FZCH_COLS); i += 64 * FM_WAVES) cs[i] = 0.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  ColsumCtx k;
+  colsum_start(k, slab, cs, lane);
+  CtxT<FCH_RING, F16> c;
+  ctx_start(c, smem, a.wstream, a.n_chunks, nullptr, 0, tid, wave, lane);        // (ends with a barrier: the zeroed table is visible)
+  const int sh = 8 * ((lane & 31) >> 3) + 4 * half;     // this lane's nibble inside a mask word
+
+  for (int tile = blockIdx.x; tile < a.tiles; tile += gridDim.x) {
+    const long row0 = (long)tile * FM_TILE_ROWS + wave * 32;
+    const bool row_ok = row0 + (lane & 31) < a.M;
+    const bool more = tile + (int)gridDim.x < a.tiles;
+    const long next0 = row0 + (long)gridDim.x * FM_TILE_ROWS;
+    int zero;                                            // (addresses from a loop-variant lane id: see fcolour_bwd_kernel)
+    asm volatile("s_lshr_b32 %0, %1, 31" : "=s"(zero) : "s"(tile));
+    const int ln = lane | zero;
+    auto to = [&](int i, int ncg) { return StoreTo{a.dz[i], a.dz_ld[i], nullptr, row0, a.M, slab, ln, ncg}; };
+    typedef __attribute__((ext_vector_type(8))) float f32x8;
+    // the head gradients of this lane's row, as B fragments in natural order: lane half h supplies reduction indices 8 h + e of a k-step
+    const long row = row_ok ? row0 + (ln & 31) : 0;
+    f32x8 vg = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, v0 = vg, v1 = vg;
+    if (row_ok) {
+      if (half == 0) { const float* pr = a.d_rgb + row * a.ld_rgb; vg[0] = pr[0]; vg[1] = pr[1]; vg[2] = pr[2]; }
+      const float* pd = a.d_den + row * a.ld_den;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c0 = 8 * half + e, c1 = 16 + 8 * half + e;
+        v0[e] = c0 < a.den_cols ? pd[c0] : 0.f;
+        v1[e] = c1 < a.den_cols ? pd[c1] : 0.f;
+      }
+    }
+    bf16x8 p[16], q[16], in[34];
+    bf16x8 g[1];
+    if constexpr (F16) {
+      typedef _Float16 fz_f16x8 __attribute__((ext_vector_type(8)));
+      g[0] = __builtin_bit_cast(bf16x8, __builtin_convertvector(vg, fz_f16x8));
+      in[32] = __builtin_bit_cast(bf16x8, __builtin_convertvector(v0, fz_f16x8));
+      in[33] = __builtin_bit_cast(bf16x8, __builtin_convertvector(v1, fz_f16x8));
+    } else {
+      g[0] = __builtin_convertvector(vg, bf16x8);
+      in[32] = __builtin_convertvector(v0, bf16x8);
+      in[33] = __builtin_convertvector(v1, bf16x8);
+    }
+    FCH_WAIT();                                          // the masks fetched during the previous tile have landed (first tile: waited for above)
+    zc_step<0, 1, true, 8, 0>(c, g, mk, ln, sh, row_ok, k, p, to(0, 4), std::make_integer_sequence<int, 8>{});                 // dH3
+    zc_step<8, 16, true, 8, 8>(c, p, mk + 1024, ln, sh, row_ok, k, q, to(1, 4), std::make_integer_sequence<int, 8>{});         // dh
+    if (more) { dma_wide(2, 0, next0, ln); dma_wide(1, 1, next0, ln); }      // both buffers are consumed: the next tile's H3 / h masks
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { in[i] = q[i]; in[16 + i] = p[i]; }
+    f32x16 h0, h1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { h0[r] = 0.f; h1[r] = 0.f; }
+    zc_dx_step<136, 16>(c, in, ln, sh, row_ok, k, h0, h1, to(2, 4), std::make_integer_sequence<int, 8>{});                     // dx (+ dH1's MFMAs)
+    bf16x8 dh1[4];
+    zc_finish<true, 0, 24>(c, h0, mk + 2048, ln, sh, row_ok, k, dh1[0], dh1[1], to(3, 1));                                   // dH1
+    zc_finish<true, 1, 25>(c, h1, mk + 2048, ln, sh, row_ok, k, dh1[2], dh1[3], to(3, 1));
+    if (more) dma_h1(next0, ln);
+    bf16x8 df[4];
+    zc_step<440, 4, false, 2, 26>(c, dh1, nullptr, ln, sh, row_ok, k, df, to(4, 1), std::make_integer_sequence<int, 2>{});     // dF
+    static_assert(440 + 8 == FZCH_FRAGS && FZCH_FRAGS % FM_CHUNK == 0, "zipnerf chain: fragment count");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int i = tid; i < FZCH_COLS; i += 64 * FM_WAVES) a.colsum_ws[(long)blockIdx.x * FZCH_COLS + i] = cs[i];
+}
+
 // out[c] += sum over the workgroups' partial rows (fixed order)
 struct ChainFoldTab { float* dst[10]; int first[10]; };
 // (64 columns x 4 row groups per workgroup, four rows of a group in flight: a thread walking all 256 partial rows of its column alone
@@ -1240,7 +1399,7 @@ extern "C" int snerf_fmlp_zip_fwd(const void* F, long ldF, const void* D, long l
 // ... and the same network as the TRAINING forward of a ZipTrainer step: additionally stores what the backward reads -- acts[0] = H1 [M, >= 64]
 // (density_layer.0), acts[1] = x, acts[2] = h (lin_second_stage_0), acts[3] = H3 (lin_second_stage_1) [M, >= 256] each (compute dtype, row
 // strides act_ld, 16-byte aligned; x and h are normally column ranges of the [h | x | dir] operand of lin_second_stage_1's weight gradient) and
-// bits[0] / bits[1] = the ReLU bit masks of h / H3 (snerf_linear_fwd's ACT_RELU_BITS layout for [M, 256]) -- through the per-wave transposition
+// bits[0] / bits[1] / bits[2] = the ReLU bit masks of H1 ([M, 64]) / h / H3 ([M, 256]; snerf_linear_fwd's ACT_RELU_BITS layout) -- through the per-wave transposition
 // slabs of the other store-carrying fused kernels.  Replaces seven launches that move 10 GB per 65 536-ray step by one that writes 3.5 GB.
 extern "C" int snerf_fmlp_zip_train_fwd(const void* F, long ldF, const void* D, long ldD, const void* wstream, long n_frags, const float* bias,
                                         int n_blocks, float* raw_rgb, long ld_rgb, float* raw_d, long ld_d, void* const* acts, const long* act_ld,
@@ -1256,7 +1415,7 @@ extern "C" int snerf_fmlp_zip_train_fwd(const void* F, long ldF, const void* D, 
     if (acts[i] == nullptr || (((uintptr_t)acts[i]) & 15) || (act_ld[i] % 8) != 0 || act_ld[i] < (i == 0 ? 64 : 256)) return SNERF_ERR_ARG;
     a.act[i] = (__bf16*)acts[i]; a.act_ld[i] = act_ld[i];
   }
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < 3; ++i) {
     if (bits[i] == nullptr || (((uintptr_t)bits[i]) & 15)) return SNERF_ERR_ARG;
     a.bits[i] = (unsigned*)bits[i];
   }
@@ -1431,5 +1590,57 @@ extern "C" int snerf_fchain_bwd(int net, const float* d_raw, const void* wstream
   if (classic) hipLaunchKernelGGL(fchain_bwd_kernel<FMLP_CLASSIC>, dim3(grid), dim3(64 * FM_WAVES), lds, st, a);
   else hipLaunchKernelGGL(fchain_bwd_kernel<FMLP_PROPOSAL>, dim3(grid), dim3(64 * FM_WAVES), lds, st, a);
   hipLaunchKernelGGL(fchain_colsum_fold_kernel, dim3((ncols + 63) / 64), dim3(256), 0, st, (const float*)ws, grid, ncols, tab);
+  return snerf_check_launch();
+}
+
+// Data-gradient chain of the zipnerf NeRF MLP (fzip_chain_bwd_kernel; the backward of snerf_fmlp_zip_train_fwd).  d_rgb [M, ld_rgb >= 3], d_den
+// [M, ld_den >= den_cols], den_cols <= 32 (d raw density, then the semantic logits' gradients) fp32; bits[0..2] = the bit masks of H1, h, H3 the
+// training forward wrote; dz[0] = dH3, dz[1] = dh, dz[2] = dx ([M, >= 256] each), dz[3] = dH1, dz[4] = dF ([M, >= 64]) in `dtype`; the bias
+// gradients of lin_second_stage_1, lin_second_stage_0, density_layer.2, density_layer.0 are ADDED to g_bias[0..3] (arrival-order LDS atomics:
+// not bit-reproducible; the deterministic mode keeps the per-layer kernels).  wstream: ZipNerfNet._pack_fused_chain (448 fragments).
+extern "C" long snerf_fmlp_zip_chain_ws_floats(long M) {
+  if (M <= 0) return 0;
+  return (long)fcolour_grid((int)((M + FM_TILE_ROWS - 1) / FM_TILE_ROWS)) * FZCH_COLS + 64;
+}
+extern "C" int snerf_fmlp_zip_chain_bwd(const float* d_rgb, long ld_rgb, const float* d_den, long ld_den, int den_cols, const void* wstream, long n_frags,
+                                        void* const* bits, void* const* dz, const long* dz_ld, float* const* g_bias, float* ws, long ws_floats, long M,
+                                        int dtype, void* stream) {
+  if (M <= 0) return SNERF_OK;
+  if (d_rgb == nullptr || d_den == nullptr || wstream == nullptr || bits == nullptr || dz == nullptr || dz_ld == nullptr || g_bias == nullptr || ws == nullptr ||
+      ld_rgb < 3 || den_cols < 1 || den_cols > 32 || ld_den < den_cols || n_frags != FZCH_FRAGS || (((uintptr_t)wstream) & 15) ||
+      ws_floats < snerf_fmlp_zip_chain_ws_floats(M) || M >= (1L << 31) || (dtype != SNERF_DT_BF16 && dtype != SNERF_DT_F16))
+    return SNERF_ERR_ARG;
+  ZipChainArgs a{};
+  a.d_rgb = d_rgb; a.ld_rgb = ld_rgb; a.d_den = d_den; a.ld_den = ld_den; a.den_cols = den_cols; a.wstream = (const char*)wstream; a.colsum_ws = ws; a.M = M;
+  a.tiles = (int)((M + FM_TILE_ROWS - 1) / FM_TILE_ROWS); a.n_chunks = (int)(n_frags / FM_CHUNK);
+  for (int i = 0; i < 3; ++i) {
+    if (bits[i] == nullptr || (((uintptr_t)bits[i]) & 15)) return SNERF_ERR_ARG;
+    a.bits[i] = (const unsigned*)bits[i];
+  }
+  const int grid = fcolour_grid(a.tiles);
+  ChainFoldTab tab{};
+  const int widths[5] = {256, 256, 256, 64, 64};
+  int col = 0;
+  for (int i = 0; i < 10; ++i) {
+    if (i < 5) {
+      if (dz[i] == nullptr || (((uintptr_t)dz[i]) & 15) || (dz_ld[i] % 8) != 0 || dz_ld[i] < widths[i] || (i < 4 && g_bias[i] == nullptr)) return SNERF_ERR_ARG;
+      a.dz[i] = (__bf16*)dz[i]; a.dz_ld[i] = dz_ld[i];
+      tab.dst[i] = i < 4 ? g_bias[i] : ws + (long)grid * FZCH_COLS;      // (the last step's column sums are not a bias gradient: into the workspace's tail)
+      tab.first[i] = col; col += widths[i];
+    } else {
+      tab.dst[i] = nullptr; tab.first[i] = 1 << 30;
+    }
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)fzip_chain_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FZCH_LDS);
+    (void)hipFuncSetAttribute((const void*)fzip_chain_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FZCH_LDS);
+    attr_set = true;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  (void)hipMemsetAsync(ws + (long)grid * FZCH_COLS, 0, 64 * sizeof(float), st);
+  if (dtype == SNERF_DT_F16) hipLaunchKernelGGL(fzip_chain_bwd_kernel<true>, dim3(grid), dim3(64 * FM_WAVES), FZCH_LDS, st, a);
+  else hipLaunchKernelGGL(fzip_chain_bwd_kernel<false>, dim3(grid), dim3(64 * FM_WAVES), FZCH_LDS, st, a);
+  hipLaunchKernelGGL(fchain_colsum_fold_kernel, dim3((FZCH_COLS + 63) / 64), dim3(256), 0, st, (const float*)ws, grid, FZCH_COLS, tab);
   return snerf_check_launch();
 }

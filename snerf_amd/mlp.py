@@ -1201,12 +1201,39 @@ class ZipNerfNet(_Net):
         H1, H3 = self.buf(M, self.H), self.buf(M, Wd)
         h2, X = SB[:, :Wd], SB[:, Wd:Wd + B]
         raw_rgb, raw_d = self.buf(M, 3, f32=True), self.buf(M, 1, f32=True)
-        words = [torch.empty(ops.mask_bits_words(M, 256), dtype=torch.int32, device=self.dev) for _ in range(2)]
+        words = [torch.empty(ops.mask_bits_words(M, w), dtype=torch.int32, device=self.dev) for w in (self.H, Wd, Wd)]
         ops.fmlp_zip_train_fwd(Fb, SB[:, Wd + B:], st, bi, raw_rgb, raw_d, [H1, X, h2, H3], words)
-        self._bits[(h2.data_ptr(), M)] = (words[0], Wd)
-        self._bits[(H3.data_ptr(), M)] = (words[1], Wd)
+        self._bits[(h2.data_ptr(), M)] = (words[1], Wd)          # (what the per-layer data gradients look up by their mask operand)
+        self._bits[(H3.data_ptr(), M)] = (words[2], Wd)
+        self._zip_bits = (words, H1.data_ptr(), M)                # ... and all three for the fused gradient chain
         self.last_x = X
         return raw_rgb, raw_d, (Fb, H1, SB, H3, None)
+
+    def _pack_fused_chain(self):
+        """transposed weights in the order fzip_chain_bwd_kernel consumes them: rgb_layer^T, lin_second_stage_1[:, :Wd]^T, then block by block
+        of dx: [lin_second_stage_0[:, :B]^T | lin_second_stage_1[:, Wd:Wd+B]^T | identity on the 32 head-gradient columns] followed by the
+        two k-steps of density_layer.2^T (both 32-output blocks of dH1) that consume the block, and density_layer.0^T"""
+        B, Wd, fd, H = self.Bw, self.Wd, self.fd, self.H
+        W0, W2 = self.W("density_layer.0"), self.W("density_layer.2")
+        L0, L1, Wr = self.W("lin_second_stage_0"), self.W("lin_second_stage_1"), self.W("rgb_layer")
+        eye = torch.zeros(B, 32, dtype=W0.dtype, device=W0.device)
+        eye[:32] = torch.eye(32, dtype=W0.dtype, device=W0.device)                       # (1.0 = "constant one" in an index image as well)
+        Wx = torch.cat([L0[:, :B].t(), L1[:, Wd:Wd + B].t(), eye], 1)                     # [B (x channel), Wd (dh) + Wd (dH3) + 32]
+        layers = [(Wr.t(), None, [(0, 3, False)]), (L1[:, :Wd].t(), None, [(0, Wd, True)])]
+        for j in range(B // 32):
+            layers.append((Wx[32 * j:32 * j + 32], None, [(0, Wd, True), (Wd, Wd, True), (2 * Wd, 32, False)]))
+            for blk in range(H // 32):
+                layers.append((W2[32 * j:32 * j + 32, 32 * blk:32 * blk + 32].t(), None, [(0, 32, True)]))
+        W0t = torch.cat([W0.t(), torch.zeros(64 - fd, H, dtype=W0.dtype, device=W0.device)], 0) if fd < 64 else W0.t()
+        layers.append((W0t, None, [(0, H, True)]))
+        return fmlp_pack(layers, self.dev)
+
+    def fused_chain_ok(self, saved, n_den):
+        import os
+        zb = getattr(self, "_zip_bits", None)
+        on = getattr(self, "fused_chain", os.environ.get("SNERF_ZIP_FUSED_CHAIN", "1") != "0")       # (the variable: A/B runs of tools/bench_zip.py)
+        return (on and zb is not None and saved[4] is None and zb[1] == saved[1].data_ptr() and zb[2] == saved[1].shape[0] and not self.deterministic
+                and self.fused_infer_ok() and n_den <= 32)
 
     def alloc(self, M):
         """-> (F, SB): the featurisation kernel writes F[:, :feat_dim] (F arrives zeroed), the view encoder SB[:, Wd+B:]."""
@@ -1219,6 +1246,7 @@ class ZipNerfNet(_Net):
         if keep and glo is None and self.fused_infer_ok() and self.Dw >= 16 and ops.mask_bits_words(Fb.shape[0], 256) * 4 < (1 << 31) and \
                 getattr(self, "fused_train", os.environ.get("SNERF_ZIP_FUSED_TRAIN", "1") != "0"):       # (the variable: A/B runs of tools/bench_zip.py)
             return self.forward_fused_train(Fb, SB)
+        self._zip_bits = None                                       # (the fused gradient chain needs the masks the fused forward writes)
         self.ensure_packed(keep)
         M, B, Wd = Fb.shape[0], self.Bw, self.Wd
         H1 = self.buf(M, self.H)
@@ -1257,6 +1285,23 @@ class ZipNerfNet(_Net):
         dz = self.head_grad(d_raw_rgb, 3)
         self.wgrad("rgb_layer", dz, H3, 3, Wd)
         DZ = self.buf(M, 2 * Wd + g)                                         # [dZ_lin0 | dZ_lin1 | d raw_density (+pad)]
+        if self.fused_chain_ok(saved, d_raw_density.shape[1]):
+            # the five data gradients as ONE launch (csrc/fmlp.hip, fzip_chain_bwd_kernel) on the bit masks the fused forward wrote; the
+            # weight gradients read its outputs exactly like the per-layer chain's
+            v = self.version_fn()
+            if getattr(self, "_zchain_version", None) != v:
+                with torch.no_grad():
+                    self._zchain = self._refresh_fused(self._pack_fused_chain, "zip_chain", dtype=self.tdt)
+                self._zchain_version = v
+            dx, dH1, dF = self.buf(M, B), self.buf(M, self.H), self.buf(M, self.Fw)
+            ops.fmlp_zip_chain_bwd(_f32(d_raw_rgb), _f32(d_raw_density), self._zchain[0], self._zip_bits[0], [DZ[:, Wd:2 * Wd], DZ[:, :Wd], dx, dH1, dF],
+                                   [self.gB("lin_second_stage_1"), self.gB("lin_second_stage_0"), self.gB("density_layer.2"), self.gB("density_layer.0")])
+            self.wgrad("lin_second_stage_1", DZ[:, Wd:2 * Wd], SB, Wd, Wd + B + self.dd)
+            self.wgrad("lin_second_stage_0", DZ[:, :Wd], SB[:, Wd:], Wd, B + self.dd)
+            self.wgrad("density_layer.2", dx, H1, B, self.H)
+            self.wgrad("density_layer.0", dH1, Fb, self.H, self.fd)
+            out = (dF, self.input_grad("denc", DZ[:, :2 * Wd], 2 * Wd, self.Dw)) if want_dir_grad else (dF,)
+            return out[0] if len(out) == 1 else out
         self.dgrad("rgb", dz, dz.shape[1], DZ[:, Wd:2 * Wd], Wd, mask=H3, colsum=self.gB("lin_second_stage_1"))
         self.wgrad("lin_second_stage_1", DZ[:, Wd:2 * Wd], SB, Wd, Wd + B + self.dd)
         self.dgrad("lin1a", DZ[:, Wd:2 * Wd], Wd, DZ[:, :Wd], Wd, mask=SB[:, :Wd], colsum=self.gB("lin_second_stage_0"))

@@ -216,23 +216,50 @@ def fmlp_zip_fwd(Fb, D, stream, bias, raw_rgb, raw_d, x32=None):
 
 def fmlp_zip_train_fwd(Fb, D, stream, bias, raw_rgb, raw_d, acts, bits):
     """The training forward of the zipnerf NeRF MLP in ONE launch (fzip_fwd_kernel<.., STORE>): as fmlp_zip_fwd, plus acts = [H1 [M, >= 64],
-    x, h, H3 [M, >= 256]] (compute dtype 2-D views, written) and bits = 2 x int32 [mask_bits_words(M, 256)] (ReLU bit masks of h and H3)."""
+    x, h, H3 [M, >= 256]] (compute dtype 2-D views, written) and bits = 3 x int32: the ReLU bit masks of H1 [mask_bits_words(M, 64)], h and H3
+    [mask_bits_words(M, 256)]."""
     import ctypes
     _chk2d(Fb, Fb.dtype); _chk2d(D, Fb.dtype); _chk2d(raw_rgb, torch.float32); _chk2d(raw_d, torch.float32)
     M = Fb.shape[0]
     assert Fb.dtype in (torch.bfloat16, torch.float16) and stream.dtype == Fb.dtype and stream.is_contiguous() and bias.dtype == torch.float32
-    assert D.shape[0] == M and raw_rgb.shape[0] == M and raw_d.shape[0] == M and Fb.shape[1] >= 64 and D.shape[1] >= 16 and len(acts) == 4 and len(bits) == 2
+    assert D.shape[0] == M and raw_rgb.shape[0] == M and raw_d.shape[0] == M and Fb.shape[1] >= 64 and D.shape[1] >= 16 and len(acts) == 4 and len(bits) == 3
     for i, y in enumerate(acts):
         _chk2d(y, Fb.dtype)
         assert y.shape[0] == M and y.shape[1] >= (64 if i == 0 else 256)
-    for b in bits:
-        assert b.dtype == torch.int32 and b.is_contiguous() and b.numel() >= mask_bits_words(M, 256)
+    for i, b in enumerate(bits):
+        assert b.dtype == torch.int32 and b.is_contiguous() and b.numel() >= mask_bits_words(M, 64 if i == 0 else 256)
     pa = (ctypes.c_void_p * 4)(*[y.data_ptr() for y in acts])
     pl = (ctypes.c_long * 4)(*[y.stride(0) for y in acts])
-    pb = (ctypes.c_void_p * 2)(*[b.data_ptr() for b in bits])
+    pb = (ctypes.c_void_p * 3)(*[b.data_ptr() for b in bits])
     _lib.call("snerf_fmlp_zip_train_fwd", _p(Fb), Fb.stride(0), _p(D), D.stride(0), _p(stream), stream.shape[0], _p(bias), bias.numel() // 32,
               _p(raw_rgb), raw_rgb.stride(0), _p(raw_d), raw_d.stride(0), ctypes.addressof(pa), ctypes.addressof(pl), ctypes.addressof(pb), M,
               _zip_dt(Fb), _stream())
+
+
+def fmlp_zip_chain_bwd(d_rgb, d_den, stream, bits, dz, g_bias):
+    """Data-gradient chain of the zipnerf NeRF MLP in ONE launch (fzip_chain_bwd_kernel): d_rgb [M,3], d_den [M, 1 + C <= 32] fp32 -> dz = [dH3, dh,
+    dx ([M, >= 256]), dH1, dF ([M, >= 64])] (compute dtype views, written); bits = the forward's masks of H1, h, H3; the bias gradients of
+    lin_second_stage_1 / _0, density_layer.2 / .0 are added to g_bias[0..3] (not bit-reproducible)."""
+    import ctypes
+    _chk2d(d_rgb, torch.float32); _chk2d(d_den, torch.float32)
+    M = d_rgb.shape[0]
+    assert d_den.shape[0] == M and 1 <= d_den.shape[1] <= 32 and stream.dtype in (torch.bfloat16, torch.float16) and stream.is_contiguous()
+    assert len(bits) == 3 and len(dz) == 5 and len(g_bias) == 4
+    for i, b in enumerate(bits):
+        assert b.dtype == torch.int32 and b.is_contiguous() and b.numel() >= mask_bits_words(M, 64 if i == 0 else 256)
+    for i, y in enumerate(dz):
+        _chk2d(y, stream.dtype)
+        assert y.shape[0] == M and y.shape[1] >= (256 if i < 3 else 64)
+    for gb, w in zip(g_bias, (256, 256, 256, 64)):
+        assert gb.dtype == torch.float32 and gb.is_contiguous() and gb.numel() == w
+    nws = _lib.query("snerf_fmlp_zip_chain_ws_floats", M)
+    ws = torch.empty(max(int(nws), 1), dtype=torch.float32, device=d_rgb.device)
+    pb = (ctypes.c_void_p * 3)(*[b.data_ptr() for b in bits])
+    pz = (ctypes.c_void_p * 5)(*[y.data_ptr() for y in dz])
+    pl = (ctypes.c_long * 5)(*[y.stride(0) for y in dz])
+    pg = (ctypes.c_void_p * 4)(*[g.data_ptr() for g in g_bias])
+    _lib.call("snerf_fmlp_zip_chain_bwd", _p(d_rgb), d_rgb.stride(0), _p(d_den), d_den.stride(0), d_den.shape[1], _p(stream), stream.shape[0],
+              ctypes.addressof(pb), ctypes.addressof(pz), ctypes.addressof(pl), ctypes.addressof(pg), _p(ws), ws.numel(), M, _zip_dt(stream), _stream())
 
 
 def fcolour_fwd(CB, stream, bias, raw_rgb, acts=None, bits=None, variant=0):

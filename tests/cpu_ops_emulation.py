@@ -649,7 +649,7 @@ def fmlp_classic_fwd(E, VE, stream, bias, raw, acts=None):
 
 def fmlp_zip_train_fwd(Fb, D, stream, bias, raw_rgb, raw_d, acts, bits):
     """model of fzip_fwd_kernel<.., STORE>: the same pass, every layer output stored in natural order, ReLU masks of h and H3 registered"""
-    assert stream.shape[0] == 464 and bias.numel() == 35 * 32 and len(acts) == 4 and len(bits) == 2
+    assert stream.shape[0] == 464 and bias.numel() == 35 * 32 and len(acts) == 4 and len(bits) == 3
     st = _FStream(stream, bias)
     f, dv = _rows_to_ksteps(Fb, 4), _rows_to_ksteps(D, 1)
     h1 = st.dense([f], 2, True, acts[0])
@@ -663,8 +663,50 @@ def fmlp_zip_train_fwd(Fb, D, stream, bias, raw_rgb, raw_d, acts, bits):
         rgb = piece if rgb is None else rgb + piece
     assert st.f == 460 and st.nb == 35
     raw_rgb[:, :3] = rgb[:, :3]
-    _BITS[bits[0].data_ptr()] = acts[2][:, :256].float() > 0
-    _BITS[bits[1].data_ptr()] = acts[3][:, :256].float() > 0
+    _BITS[bits[0].data_ptr()] = acts[0][:, :64].float() > 0
+    _BITS[bits[1].data_ptr()] = acts[2][:, :256].float() > 0
+    _BITS[bits[2].data_ptr()] = acts[3][:, :256].float() > 0
+
+
+def fmlp_zip_chain_bwd(d_rgb, d_den, stream, bits, dz, g_bias):
+    """model of fzip_chain_bwd_kernel (no biases in this stream: every block starts from zero): the transposed layers in chain order, masks from
+    the registered bit masks, bias gradients = column sums of the fp32 (masked) pre-rounding values, dx consumed block by block by dH1"""
+    assert stream.shape[0] == 448 and len(bits) == 3 and len(dz) == 5 and len(g_bias) == 4
+    M = d_rgb.shape[0]
+    st = _FStream(stream, torch.zeros(64 * 32))
+    dt = st.dt
+    mH1, mh, mH3 = (_BITS[b.data_ptr()] for b in bits)
+
+    def finish(acc, mask, store, j, gb):
+        if mask is not None:
+            acc = acc * mask[:, 32 * j:32 * j + 32].float()
+        if gb is not None:
+            gb[32 * j:32 * j + 32] += acc.sum(0)
+        y = acc.to(dt).float()
+        store[:, 32 * j:32 * j + 32] = y.to(store.dtype)
+        return [y[:, _P], y[:, 16 + _P]]
+
+    def step(segs, nblocks, mask, store, gb):
+        out = []
+        for j in range(nblocks):
+            out += finish(st.block(segs, False, to_frags=False), mask, store, j, gb)
+        return out
+    g = torch.zeros(M, 16); g[:, :3] = d_rgb[:, :3]
+    g = [g.to(dt).float()]
+    e = torch.zeros(M, 32); e[:, :d_den.shape[1]] = d_den
+    e = e.to(dt).float()
+    e = [e[:, :16], e[:, 16:]]
+    p = step([g], 8, mH3, dz[0], g_bias[0])
+    q = step([p], 8, mh, dz[1], g_bias[1])
+    h0 = h1 = None
+    for j in range(8):
+        lh = finish(st.block([q, p, e], False, to_frags=False), None, dz[2], j, g_bias[2])
+        a0 = st.block([lh], False, to_frags=False); a1 = st.block([lh], False, to_frags=False)
+        h0 = a0 if h0 is None else h0 + a0
+        h1 = a1 if h1 is None else h1 + a1
+    dh1 = finish(h0, mH1, dz[3], 0, g_bias[3]) + finish(h1, mH1, dz[3], 1, g_bias[3])
+    step([dh1], 2, None, dz[4], None)
+    assert st.f == 448
 
 
 def fmlp_zip_fwd(Fb, D, stream, bias, raw_rgb, raw_d, x32=None):
@@ -824,7 +866,7 @@ def adam_step_dev(p, g, m, v, lr, b1, b2, eps, step_dev, grad_scale=1.0, zero_gr
     adam_step(p, g, m, v, lr, b1, b2, eps, 0, grad_scale, zero_grad, step_dev=step_dev, **kw)
 
 
-_NAMES = ["fmlp_zip_fwd", "fmlp_zip_train_fwd", "zip_prop_mlp_fwd", "zip_prop_mlp_bwd", "colsum_wide_f32", "zip_glo_modulate", "zip_glo_modulate_bwd", "fchain_bwd", "app_embed", "app_embed_bwd", "split_cast", "fcolour_fwd", "fcolour_bwd", "gather_pack", "adam_step_dev", "grad_clip_coef", "fmlp_classic_fwd", "fmlp_classic_pts_fwd", "fmlp_proposal_fwd", "fmlp_classic_train_fwd", "fmlp_proposal_train_fwd", "classic_get_rays", "classic_ndc_rays", "classic_ray_batch", "zip_encode_prop_fwd", "mip_encode_bwd", "mip_viewenc_bwd", "hash_decay", "zip_percentiles", "zip_pixels_to_rays", "zip_loss_tail", "semantic_composite_fwd", "semantic_composite_bwd", "zip_resample", "zip_encode_fwd", "zip_encode_fwd_count", "zip_encode_bwd", "zip_encode_bwd_binned", "zip_encode_ray_bwd", "zip_composite_fwd", "zip_composite_bwd",
+_NAMES = ["fmlp_zip_fwd", "fmlp_zip_train_fwd", "fmlp_zip_chain_bwd", "zip_prop_mlp_fwd", "zip_prop_mlp_bwd", "colsum_wide_f32", "zip_glo_modulate", "zip_glo_modulate_bwd", "fchain_bwd", "app_embed", "app_embed_bwd", "split_cast", "fcolour_fwd", "fcolour_bwd", "gather_pack", "adam_step_dev", "grad_clip_coef", "fmlp_classic_fwd", "fmlp_classic_pts_fwd", "fmlp_proposal_fwd", "fmlp_classic_train_fwd", "fmlp_proposal_train_fwd", "classic_get_rays", "classic_ndc_rays", "classic_ray_batch", "zip_encode_prop_fwd", "mip_encode_bwd", "mip_viewenc_bwd", "hash_decay", "zip_percentiles", "zip_pixels_to_rays", "zip_loss_tail", "semantic_composite_fwd", "semantic_composite_bwd", "zip_resample", "zip_encode_fwd", "zip_encode_fwd_count", "zip_encode_bwd", "zip_encode_bwd_binned", "zip_encode_ray_bwd", "zip_composite_fwd", "zip_composite_bwd",
           "linear_fwd", "linear_wgrad", "classic_embed", "mip_encode", "mip_viewenc", "classic_sample_pdf", "classic_points",
           "classic_merge_sort", "mip_resample", "stratified", "mip_composite_fwd", "mip_composite_bwd", "classic_composite_fwd",
           "classic_composite_bwd", "adam_step", "colsum_f32", "cast_pad", "pinhole_rays", "mip_loss_tail"]

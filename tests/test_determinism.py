@@ -136,3 +136,41 @@ def test_round3_fused_kernels_are_bit_reproducible():
                 assert float((g - g0).abs().max()) <= 1e-5 * float(g0.abs().max()) + 1e-12
             return dz
         assert _repeat(chain, 200, big) == 0, kind
+
+
+@pytest.mark.parametrize("compute", ["bf16", "fp16"])
+def test_zip_fused_mlp_forward_and_gradient_chain_are_bit_reproducible(compute):
+    """fzip_fwd_kernel<.., STORE> and fzip_chain_bwd_kernel (round 4) prefetch their mask images by LDS-DMA one tile ahead and count on the
+    weight stream's waits to order them: everything they STORE (activations, bit masks, raw outputs; the five data gradients) must be
+    bit-identical run to run with other kernels and other LDS content in between; only the chain's bias gradients (LDS atomics in arrival
+    order) are exempt and held to rounding.  Rows not a multiple of the 256-row tile, more tiles than workgroups."""
+    from snerf_amd import ops
+    from snerf_amd.mlp import ParamArena, ZipNerfNet
+    torch.manual_seed(3)
+    dev = torch.device("cuda")
+    big = torch.randn(2048, 2048, device="cuda").bfloat16()
+    shapes = [("n." + k, s) for k, s in ZipNerfNet.param_shapes(40)]
+    arena = ParamArena(shapes, dev)
+    arena.load({k: (torch.randn(s) * (1.2 / s[-1] ** 0.5) if len(s) == 2 else torch.randn(s) * 0.1) for k, s in shapes})
+    net = ZipNerfNet(arena, "n.", ops.F16 if compute == "fp16" else ops.BF16, 40)
+    M = 256 * 300 + 77
+    Fb0 = torch.zeros(M, 64, device=dev); Fb0[:, :40] = torch.randn(M, 40, device=dev) * 0.5
+    Dn = torch.zeros(M, 16, device=dev); Dn[:, :9] = torch.randn(M, 9, device=dev)
+    d_rgb = torch.randn(M, 3, device=dev) * 1e-2
+    d_den = torch.randn(M, 20, device=dev) * 1e-2
+    names = ["n.lin_second_stage_1.bias", "n.lin_second_stage_0.bias", "n.density_layer.2.bias", "n.density_layer.0.bias"]
+    bias_grads = []
+
+    def step():
+        Fb, SB = net.alloc(M)
+        Fb.copy_(Fb0.to(net.tdt)); SB[:, 512:] = 0; SB[:, 512:528] = Dn.to(net.tdt)
+        raw_rgb, raw_d, saved = net.forward(Fb, SB, True)
+        assert net._zip_bits is not None
+        arena.grad.zero_()
+        dF = net.backward(d_rgb, d_den, saved)
+        bias_grads.append(torch.cat([arena.g[k].reshape(-1) for k in names]).clone())
+        return [raw_rgb, raw_d, saved[1], saved[2], saved[3], dF] + list(net._zip_bits[0])
+    assert _repeat(step, 60, big) == 0
+    ref = bias_grads[0]
+    assert float(ref.norm()) > 0
+    assert max(float((b - ref).norm() / ref.norm()) for b in bias_grads[1:]) < 1e-5

@@ -114,6 +114,29 @@ def main():
         return [ren[2]["rgb"]] + [p.grad for p in zm.parameters() if p.grad is not None]
     total += screen("path C inference (8192 rays)", c_infer, reps)
     total += screen("path C deterministic train pass", c_train, max(reps // 3, 1))
+    # the fused training forward + gradient chain of path C's NeRF MLP (not used in the deterministic mode above): everything they STORE
+    from snerf_amd.mlp import ParamArena, ZipNerfNet
+    for compute in ("fp16", "bf16"):
+        torch.manual_seed(3)
+        dev = torch.device("cuda")
+        shapes = [("n." + k, sh) for k, sh in ZipNerfNet.param_shapes(40)]
+        arena = ParamArena(shapes, dev)
+        arena.load({k: (torch.randn(sh) * (1.2 / sh[-1] ** 0.5) if len(sh) == 2 else torch.randn(sh) * 0.1) for k, sh in shapes})
+        net2 = ZipNerfNet(arena, "n.", ops.F16 if compute == "fp16" else ops.BF16, 40)
+        M2 = 256 * 1100 + 77
+        Fb0 = torch.zeros(M2, 64, device=dev); Fb0[:, :40] = torch.randn(M2, 40, device=dev) * 0.5
+        Dn = torch.zeros(M2, 16, device=dev); Dn[:, :9] = torch.randn(M2, 9, device=dev)
+        d_rgb = torch.randn(M2, 3, device=dev) * 1e-2
+        d_den = torch.randn(M2, 20, device=dev) * 1e-2
+
+        def fz_step():
+            Fb, SB = net2.alloc(M2)
+            Fb.copy_(Fb0.to(net2.tdt)); SB[:, 512:] = 0; SB[:, 512:528] = Dn.to(net2.tdt)
+            raw_rgb, raw_d, saved = net2.forward(Fb, SB, True)
+            arena.grad.zero_()
+            dF = net2.backward(d_rgb, d_den, saved)
+            return [raw_rgb, raw_d, saved[1], saved[2], saved[3], dF] + list(net2._zip_bits[0])
+        total += screen(f"path C fused MLP forward + gradient chain, {compute} (281 677 rows)", fz_step, reps)
     print("TOTAL differing outputs:", total)
     return 1 if total else 0
 
