@@ -562,7 +562,8 @@ int snerf_zip_glo_modulate_bwd(const void* dXm, long lddxm, const void* X, long 
                                int dtype, void* stream);
 /* The fixed-point scale of one binned launch: scale_exp (device int[2]) [0] = e such that 2^e * max |grad_feat[:rows, :cols]| lies in
  * [2^33, 2^34) -- the accumulation grid follows the magnitude of the gradient (a loss-scaled 1e-12 gradient keeps 34 bits below its
- * largest entry); pass 2 reads it. */
+ * largest entry); pass 2 reads it.  [1] = the bits of that maximum; a NaN / +-Inf in grad_feat (an fp16 overflow) leaves 0x7f800000
+ * there and pass 2 then writes a NaN into grad_table[0]: the launch's records are meaningless and a found-inf check must see it. */
 int snerf_zip_bin_scale(const void* grad_feat, long ld, long rows, int cols, int feat_dtype, int* scale_exp, void* stream);
 
 /* Featurisation backward to the RAYS -- `cal_input_grad` of the reference (internal/models.py:491 -> gridencoder/grid.py:65-89 ->
@@ -595,6 +596,10 @@ int snerf_adam_step_ex(float* p, float* g, float* m, float* v, long n, float lr,
 /* torch.nn.utils.clip_grad_norm_ coefficient over a flat gradient arena: out[0] = min(1, max_norm / (|grad_scale| * ||g||_2 + 1e-6)),
  * out[1] = the norm.  ws: >= 1024 doubles of device scratch.  Fixed reduction order (deterministic). */
 int snerf_grad_clip_coef(const float* g, long n, float grad_scale, float max_norm, void* ws, float* out, void* stream);
+/* The found-inf check of a dynamic loss scaler (torch.cuda.amp.GradScaler, which accelerate wraps around the reference's fp16 training:
+ * s-nerfpp/zipnerf/train.py:44,215,331): *flag |= 1 when any of the n fp32 gradients is NaN or +-Inf.  The caller zeroes *flag
+ * (device int); the binned table gradient marks an overflowed feature gradient by a NaN in its first element (snerf_zip_encode_bwd_binned). */
+int snerf_nonfinite_flag(const float* g, long n, int* flag, void* stream);
 
 #ifdef __cplusplus
 }

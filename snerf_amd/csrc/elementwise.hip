@@ -128,6 +128,35 @@ extern "C" int snerf_grad_clip_coef(const float* g, long n, float grad_scale, fl
   return snerf_check_launch();
 }
 
+// found-inf pass of a dynamic loss scaler (torch.cuda.amp.GradScaler.unscale_'s check; the reference trains its fp16 MLPs under
+// accelerate's scaler: zipnerf/train.py:44,215,331): *flag |= 1 when any element of the fp32 arena is NaN or +-Inf.  One read of the
+// arena (310 MB for waymo.gin: ~60 us); the caller zeroes the flag.
+__global__ __launch_bounds__(256) void nonfinite_flag_kernel(const unsigned* __restrict__ g, long n, int* __restrict__ flag) {
+  bool bad = false;
+  const long head = ((16 - ((size_t)g & 15)) & 15) >> 2;                          // scalar words up to the first 16-byte boundary
+  const long nv = n > head ? (n - head) >> 2 : 0;
+  const uint4* gv = (const uint4*)(g + (n > head ? head : 0));
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
+    const uint4 w = gv[i];
+    bad |= ((w.x & 0x7f800000u) == 0x7f800000u) | ((w.y & 0x7f800000u) == 0x7f800000u) | ((w.z & 0x7f800000u) == 0x7f800000u) |
+           ((w.w & 0x7f800000u) == 0x7f800000u);
+  }
+  if (blockIdx.x == 0) {
+    const long tail0 = n > head ? head + (nv << 2) : 0;
+    for (long i = threadIdx.x; i < (n > head ? head : n); i += 256) bad |= (g[i] & 0x7f800000u) == 0x7f800000u;
+    for (long i = tail0 + threadIdx.x; i < n; i += 256) bad |= (g[i] & 0x7f800000u) == 0x7f800000u;
+  }
+  if (__ballot(bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+extern "C" int snerf_nonfinite_flag(const float* g, long n, int* flag, void* stream) {
+  if (n < 0 || flag == nullptr || (n > 0 && g == nullptr) || ((size_t)g & 3) != 0) return SNERF_ERR_ARG;
+  if (n == 0) return SNERF_OK;
+  long blocks = (n / 4 + 255) / 256;
+  blocks = blocks > 4096 ? 4096 : (blocks < 1 ? 1 : blocks);
+  hipLaunchKernelGGL(nonfinite_flag_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned*)g, n, flag);
+  return snerf_check_launch();
+}
+
 // out[c] += sum_m x[m, c] for a narrow fp32 matrix (head gradients: 3 + 1 columns)
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long ld, long M, int C, float* __restrict__ out) {
   __shared__ float red[4][8];

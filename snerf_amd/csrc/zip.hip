@@ -1790,12 +1790,19 @@ __global__ __launch_bounds__(256) void zip_bin_absmax_kernel(const OT* __restric
   const long total = rows * cols;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
     const long r = e / cols;
-    m = fmaxf(m, fabsf((float)g[r * ld + (e - r * cols)]));
+    const float x = fabsf((float)g[r * ld + (e - r * cols)]);
+    m = fmaxf(m, x != x ? __builtin_inff() : x);                                   // (a NaN counts as an overflow: zip_bin_overflow_mark_kernel)
   }
   m = fmaxf(m, __shfl_xor(m, 32, 64));
 #pragma unroll
   for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
   if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(mx, __float_as_uint(m));      // (non-negative floats order like their bit patterns)
+}
+// an overflowed feature gradient (fp16 compute mode: +-Inf / NaN in grad_feat) cannot be scaled into fixed point: the level's records
+// are meaningless.  Mark the table gradient by a NaN in its first element so that whoever checks the gradients for overflow (a
+// dynamic loss scaler: snerf_nonfinite_flag, or torch's GradScaler.unscale_) skips the step; the static policy drops it in Adam.
+__global__ void zip_bin_overflow_mark_kernel(float* __restrict__ grad, const int* __restrict__ scale_exp) {
+  if ((unsigned)scale_exp[1] >= 0x7f800000u) grad[0] = __builtin_nanf("");
 }
 __global__ void zip_bin_scale_kernel(int* scale_exp) {
   const unsigned bits = (unsigned)scale_exp[1];
@@ -1899,6 +1906,7 @@ extern "C" int snerf_zip_encode_bwd_binned(int pass, const float* tdist, const f
   }
   if (g64 != nullptr && g64_rows > 0)
     hipLaunchKernelGGL(zip_bin_finish_kernel, dim3(1024), blk, 0, s, (const long long*)g64, g64_rows * C, grad_table, scale_exp);
+  hipLaunchKernelGGL(zip_bin_overflow_mark_kernel, dim3(1), dim3(1), 0, s, grad_table, scale_exp);
   return snerf_check_launch();
 }
 

@@ -650,6 +650,14 @@ def grad_clip_coef(g, grad_scale, max_norm):
     return out
 
 
+def nonfinite_flag(g, flag):
+    """flag (int32 [1] on the device, zeroed by the caller) |= 1 when any fp32 element of `g` is NaN / +-Inf: the found-inf pass of a
+    dynamic loss scaler (snerf_nonfinite_flag).  No host sync."""
+    _f32c(g)
+    assert flag.dtype == torch.int32 and flag.is_cuda and flag.numel() >= 1
+    _lib.call("snerf_nonfinite_flag", _p(g), g.numel(), _p(flag), _stream())
+
+
 def colsum_f32(x, C, out, deterministic=False):
     _chk2d(x, torch.float32)
     _lib.call("snerf_colsum_f32_det" if deterministic else "snerf_colsum_f32", _p(x), x.stride(0), x.shape[0], C, _p(out), _stream())

@@ -298,6 +298,39 @@ class _TableShards:
         dist.all_gather_into_tensor(full, mine if self.nccl else mine.clone(), group=self.group)
 
 
+class LossScaler:
+    """The policy of torch.cuda.amp.GradScaler (what accelerate wraps around the reference's fp16 training, zipnerf/train.py:44,215,331) as
+    host state: the scale starts at `init_scale`, a step whose gradients hold a NaN / +-Inf is skipped and multiplies it by
+    `backoff_factor`, `growth_interval` consecutive clean steps multiply it by `growth_factor`.  Same defaults as torch."""
+
+    def __init__(self, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
+        if not (init_scale > 0 and growth_factor > 1.0 and 0.0 < backoff_factor < 1.0 and growth_interval >= 1):
+            raise ValueError("LossScaler: init_scale > 0, growth_factor > 1, 0 < backoff_factor < 1, growth_interval >= 1")
+        self.scale, self.growth_factor, self.backoff_factor = float(init_scale), float(growth_factor), float(backoff_factor)
+        self.growth_interval, self.good_steps, self.skipped_steps = int(growth_interval), 0, 0
+
+    def update(self, found_inf: bool) -> bool:
+        """-> True when the optimizer step has to be skipped"""
+        if found_inf:
+            self.scale *= self.backoff_factor
+            self.good_steps = 0
+            self.skipped_steps += 1
+            return True
+        self.good_steps += 1
+        if self.good_steps >= self.growth_interval:
+            self.scale *= self.growth_factor
+            self.good_steps = 0
+        return False
+
+    def state_dict(self):
+        return dict(scale=self.scale, growth_factor=self.growth_factor, backoff_factor=self.backoff_factor, growth_interval=self.growth_interval,
+                    good_steps=self.good_steps, skipped_steps=self.skipped_steps)
+
+    def load_state_dict(self, d):
+        self.scale, self.growth_factor, self.backoff_factor = float(d["scale"]), float(d["growth_factor"]), float(d["backoff_factor"])
+        self.growth_interval, self.good_steps, self.skipped_steps = int(d["growth_interval"]), int(d["good_steps"]), int(d.get("skipped_steps", 0))
+
+
 class ZipTrainer:
     """Train step of the S-NeRF++ / zipnerf background model (s-nerfpp/zipnerf/train.py hot loop :218-331: Model.forward, the loss
     terms, loss.backward(), optimizer.step()) on the flat arenas: forward, ONE fused loss-tail launch (ops.zip_loss_tail: Charbonnier
@@ -314,9 +347,13 @@ class ZipTrainer:
 
     def __init__(self, model, lr=1e-2, betas=(0.9, 0.99), eps=1e-15, charb_padding=0.001, process_group=None, loss_cfg=None,
                  nonfinite="zero", grad_max_val=0.0, grad_max_norm=0.0, table_exchange="sharded", loss_scale=None):
-        """`loss_scale` (static; default 4096 when the model computes in fp16, else 1): the gradients of the rendered outputs are multiplied
-        by it before the backward -- so that the fp16 gradient buffers of the networks stay in fp16's normal range -- and the factor is
-        undone inside the Adam launch (grad_scale), before clipping.  Overflowed (non-finite) gradients are dropped by `nonfinite`.
+        """`loss_scale` (a number = static; default 4096 when the model computes in fp16, else 1): the gradients of the rendered outputs are
+        multiplied by it before the backward -- so that the fp16 gradient buffers of the networks stay in fp16's normal range -- and the
+        factor is undone inside the Adam launch (grad_scale), before clipping.  Overflowed (non-finite) gradients are dropped by
+        `nonfinite`.  `loss_scale="dynamic"` (or a LossScaler): torch's GradScaler policy -- one pass over the gradient arena after the
+        exchange (snerf_nonfinite_flag, + a 4-byte MAX all-reduce when the tables are sharded), ONE device->host read of the flag per
+        step (as GradScaler.step does), a step with an overflow is skipped whole (parameters, m, v and the step count t untouched,
+        gradients zeroed) and halves the scale; `scaler.skipped_steps` counts them.  The static scale keeps the step free of host syncs.
         `nonfinite`, `grad_max_val`, `grad_max_norm` = train_utils.clip_gradients (train_utils.py:234-243, run every step at
         zipnerf/train.py:336; configs.py:83-84 defaults 0 = off), folded into the Adam launch.  The reference always ends with
         param.grad.nan_to_num_(); "zero" (default) also drops +-Inf instead of mapping it to +-FLT_MAX (which would leave v = inf,
@@ -332,7 +369,14 @@ class ZipTrainer:
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.last_losses = None
-        self.loss_scale = float(loss_scale) if loss_scale is not None else (4096.0 if getattr(model, "dt", None) == ops.F16 else 1.0)
+        self.scaler = LossScaler() if isinstance(loss_scale, str) and loss_scale == "dynamic" else (loss_scale if isinstance(loss_scale, LossScaler) else None)
+        if isinstance(loss_scale, str) and self.scaler is None:
+            raise ValueError(f"loss_scale: a number, 'dynamic' or a LossScaler, not {loss_scale!r}")
+        if self.scaler is not None:
+            self.loss_scale = self.scaler.scale
+            self._found_inf = torch.zeros(1, dtype=torch.int32, device=a.flat.device)
+        else:
+            self.loss_scale = float(loss_scale) if loss_scale is not None else (4096.0 if getattr(model, "dt", None) == ops.F16 else 1.0)
         a.grad.zero_()
         # the hash tables' gradients: "sharded" (default for N > 1) = reduce-scatter + Adam on the rank's slice + all-gather of the updated
         # parameters (_TableShards); "allreduce" = part of the bucketed all-reduce like the MLP parameters (the reference's DDP behaviour)
@@ -348,6 +392,20 @@ class ZipTrainer:
         if self.world > 1:
             dist.broadcast(self.model.arena.flat, src=src, group=self.pg)
             self.model.arena.bump()
+
+    def _overflowed(self, a, shards):
+        """dynamic loss scaling: the found-inf pass over the exchanged gradients and the scaler's update; -> True = the step is skipped
+        (gradients zeroed; parameters, moments and t stay as they were)"""
+        self._found_inf.zero_()
+        ops.nonfinite_flag(a.grad, self._found_inf)
+        if shards is not None:         # sharded tables: each rank sees the reduced gradient of its slices only -> agree on the flag
+            for _, _, _, gshard in shards:
+                ops.nonfinite_flag(gshard, self._found_inf)
+            dist.all_reduce(self._found_inf, op=dist.ReduceOp.MAX, group=self.pg)
+        if not self.scaler.update(bool(int(self._found_inf.item()))):
+            return False
+        a.grad.zero_()
+        return True
 
     def step(self, batch, target_rgb, train_frac=1.0, rand=True, aux_loss_fn=None, draws=None, sample_n=7, sample_m=3, targets=None, zero_glo=False):
         """`targets` (all optional, per ray): lossmult [R] (the reference's mask_rgb as 0/1 floats), depth [R] + depth_mask [R]
@@ -370,6 +428,8 @@ class ZipTrainer:
                                    smask=t.get("semantic_mask"), hist=[(levels[l]["sdist"], levels[l]["weights"]) for l in range(3)],
                                    **self.loss_cfg)
         decay = torch.zeros(1, dtype=torch.float32, device=dev)
+        if self.scaler is not None:
+            self.loss_scale = self.scaler.scale
         ls = self.loss_scale
         if ls != 1.0:
             for g in G.values():
@@ -406,8 +466,11 @@ class ZipTrainer:
             ex(prefix)
         m._backward(ctx, [(None, None, None, g_w[0]), (None, None, None, g_w[1]), (G["rgb"], G["depth"], None, g_w[2], G["semantic"])], on_done=level_done)
         ex.finish()
-        self.t += 1
         a = m.arena
+        mine = sh.finish() if sh is not None else None
+        if self.scaler is not None and self._overflowed(a, mine):
+            return loss, levels
+        self.t += 1
         adam = lambda lo, hi, g=None: ops.adam_step(a.flat[lo:hi], a.grad[lo:hi] if g is None else g, self.m[lo:hi], self.v[lo:hi], self.lr, self.betas[0],
                                                     self.betas[1], self.eps, self.t, grad_scale=1.0 / (self.world * ls), zero_grad=True,
                                                     nonfinite=self.nonfinite, grad_max_val=self.grad_max_val)
@@ -417,7 +480,6 @@ class ZipTrainer:
                           grad_scale=1.0 / (self.world * ls), zero_grad=True, nonfinite=self.nonfinite, grad_max_val=self.grad_max_val, clip_coef=coef)
         else:
             # tables: this rank's slice only, then the updated slices are gathered; everything between the table spans: the usual pass
-            mine = sh.finish()
             for name, lo, hi, gshard in mine:
                 adam(lo, hi, gshard)
             pos = 0

@@ -860,6 +860,141 @@ def test_zip_encode_ray_bwd_kernel_vs_oracle(lvl, half):
         assert rel < 2e-2, (name, rel)        # finest levels: 1e-7 position differences (sincosf / cbrtf vs torch) -> 1e-3 of the derivative
 
 
+def test_loss_scaler_policy_is_gradscalers():
+    """LossScaler = torch.cuda.amp.GradScaler's update rule (what accelerate wraps around the reference's fp16 training, zipnerf/train.py:44):
+    backoff on an overflow (and the step is skipped), growth after `growth_interval` CONSECUTIVE clean steps; checked against torch's own
+    `_amp_update_scale_` on the CPU for a random overflow pattern."""
+    from snerf_amd.trainer import LossScaler
+    sc = LossScaler(init_scale=1024.0, growth_interval=4)
+    scale, tracker = torch.full((1,), 1024.0), torch.zeros(1, dtype=torch.int32)
+    rng = np.random.default_rng(3)
+    skipped = 0
+    for i in range(200):
+        bad = bool(rng.random() < 0.15)
+        assert sc.update(bad) == bad
+        skipped += bad
+        torch._amp_update_scale_(scale, tracker, torch.full((1,), float(bad)), 2.0, 0.5, 4)
+        assert sc.scale == float(scale) and sc.good_steps == int(tracker), i
+    assert sc.skipped_steps == skipped > 0
+    other = LossScaler()
+    other.load_state_dict(sc.state_dict())
+    assert other.state_dict() == sc.state_dict()
+    with pytest.raises(ValueError):
+        LossScaler(backoff_factor=1.5)
+
+
+@pytest.mark.gpu
+def test_nonfinite_flag_and_the_table_gradients_overflow_mark():
+    """snerf_nonfinite_flag (the found-inf pass of the dynamic loss scaler) on unaligned spans with the bad element at the head, in
+    the vector body and in the tail; and the binned table gradient of an overflowed feature gradient (an Inf or a NaN in d features,
+    which fixed-point records cannot carry) marks itself by a NaN in its first element, so that the same pass sees it."""
+    from snerf_amd import ops, zipnerf
+    base = torch.randn(100_003, device="cuda")
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for off in (0, 1, 2, 3):
+        for n in (0, 1, 5, 1027, 100_003 - 3):
+            v = base[off:off + n]
+            flag.zero_()
+            ops.nonfinite_flag(v, flag)
+            assert int(flag) == 0, (off, n)
+            for pos in sorted({0, n // 2, n - 1} - {-1}):
+                if n == 0:
+                    continue
+                for bad in (float("inf"), float("-inf"), float("nan")):
+                    w = v.clone() if off == 0 else base.clone()[off:off + n]
+                    w[pos] = bad
+                    flag.zero_()
+                    ops.nonfinite_flag(w, flag)
+                    assert int(flag) == 1, (off, n, pos, bad)
+    big = torch.full((1 << 22,), 3.0e38, device="cuda")       # large finite values are not flagged
+    flag.zero_()
+    ops.nonfinite_flag(big, flag)
+    assert int(flag) == 0
+    m = zipnerf.Model(config=None, raydist_fn='power_transformation', opaque_background=True, compute="fp16", table_dtype="f16", grid_log2_hashmap_size=16)
+    lvl = 2
+    e = m.encs[lvl]
+    R, S, n = 300, 32, 7
+    g = torch.Generator().manual_seed(11)
+    d = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1)
+    bx = torch.nn.functional.normalize(torch.cross(d, torch.randn(R, 3, generator=g), dim=-1), dim=-1)
+    by = torch.nn.functional.normalize(torch.cross(d, bx, dim=-1), dim=-1)
+    c = lambda t: t.cuda().contiguous()
+    o, radii = c(torch.randn(R, 3, generator=g) * 0.3), c(2e-3 + 2e-3 * torch.rand(R, generator=g))
+    tdist = c(torch.sort(torch.rand(R, S + 1, generator=g) * 6 + 0.05, -1)[0])
+    degj = c(torch.rand(R, S, n, generator=g))
+    d, bx, by = c(d), c(bx), c(by)
+    ks, g64_rows, lrows = ops.zip_bin_plan(e.offsets, e.C, R * S * n * 8)
+    tail = (e.L, e.C, n, 3, e.Sl, e.H, m.std_scale)
+    for bad, half in ((None, True), (float("inf"), True), (float("nan"), True), (float("-inf"), False)):
+        dF = c(torch.randn(R * S, m.nets[lvl].Fw, generator=g) * 1e-2).half()
+        if bad is not None:
+            dF[R * S // 3, 5] = bad
+        gt = torch.zeros(e.rows, e.C, device="cuda")
+        ops.zip_encode_bwd_binned(tdist, o, d, radii, bx, by, degj, m.dev_offsets[lvl], m.dev_sizes[lvl], dF, gt, *tail, ks, g64_rows, lrows, half_records=half)
+        flag.zero_()
+        ops.nonfinite_flag(gt.view(-1), flag)
+        assert int(flag) == (0 if bad is None else 1), (bad, half)
+        if bad is not None:
+            assert bool(torch.isnan(gt.view(-1)[0]))
+
+
+@pytest.mark.gpu
+def test_zip_trainer_dynamic_loss_scale_skips_overflowed_steps():
+    """ZipTrainer(loss_scale="dynamic") on the fp16 compute mode: started from a scale the fp16 gradient buffers cannot hold (2^40),
+    every overflowed step is skipped WHOLE -- parameters, Adam moments and the step count bit-for-bit untouched, gradients zeroed --
+    and halves the scale until the backward fits; from there the steps update and the loss falls.  With a scale that fits from the
+    start the dynamic trainer and the static one are the same arithmetic: identical parameters after 3 steps."""
+    from snerf_amd import zipnerf
+    from snerf_amd.trainer import ZipTrainer, LossScaler
+    R = 1024
+    g = torch.Generator().manual_seed(4)
+    d = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1)
+    bx = torch.nn.functional.normalize(torch.cross(d, torch.tensor([0.0, 1.0, 0.0]).expand(R, 3), dim=-1), dim=-1)
+    by = torch.nn.functional.normalize(torch.cross(d, bx, dim=-1), dim=-1)
+    batch = {k: v.cuda() for k, v in dict(origins=torch.randn(R, 3, generator=g) * 0.05, directions=d, viewdirs=d, radii=torch.full((R, 1), 5e-4),
+                                          near=torch.full((R, 1), 0.1), far=torch.full((R, 1), 10.0), base_x=bx, base_y=by).items()}
+    tgt = torch.rand(R, 3, generator=g).cuda()
+    mk = lambda: zipnerf.Model(config=None, raydist_fn='power_transformation', opaque_background=True, compute="fp16", table_dtype="f16",
+                               grid_log2_hashmap_size=14, init_std=0.1)
+    torch.manual_seed(0)
+    m = mk()
+    tr = ZipTrainer(m, lr=2e-3, eps=1e-8, loss_scale=LossScaler(init_scale=2.0 ** 40, growth_interval=1000))
+    draws = m._draws(R, False, m.arena.flat.device, 7)
+    start, losses, scales = m.arena.flat.clone(), [], []
+    for i in range(40):
+        before, t0, skipped0 = m.arena.flat.clone(), tr.t, tr.scaler.skipped_steps
+        loss, _ = tr.step(batch, tgt, rand=False, draws=draws)
+        scales.append(tr.scaler.scale)
+        if tr.scaler.skipped_steps > skipped0:
+            assert torch.equal(m.arena.flat, before) and tr.t == t0 and not bool(m.arena.grad.any())
+            assert not bool(tr.m.any()) or i > 0
+        else:
+            assert tr.t == t0 + 1
+            losses.append(float(loss))
+    sk = tr.scaler.skipped_steps
+    print(f"MEASURED dynamic loss scale from 2^40: {sk} skipped steps, settled at 2^{int(np.log2(tr.scaler.scale))}; loss {losses[0]:.5f} -> {losses[-1]:.5f} over {len(losses)} steps")
+    assert 5 <= sk < 35 and tr.t == 40 - sk and tr.scaler.scale == 2.0 ** (40 - sk)
+    assert bool(torch.isfinite(m.arena.flat).all()) and bool(torch.isfinite(tr.m).all()) and bool(torch.isfinite(tr.v).all())
+    assert len(losses) >= 5 and losses[-1] < losses[0] and not torch.equal(m.arena.flat, start)
+    # a scale that fits: dynamic == static, bit for bit
+    finals = []
+    for ls in (4096.0, LossScaler(init_scale=4096.0)):
+        torch.manual_seed(0)
+        m = mk()
+        for net in m.nets:
+            net.deterministic = True              # (fixed-order folds instead of fp32 atomics: the two runs are then comparable bit for bit)
+        tr = ZipTrainer(m, lr=2e-3, eps=1e-8, loss_scale=ls)
+        draws = m._draws(R, False, m.arena.flat.device, 7)
+        for _ in range(3):
+            tr.step(batch, tgt, rand=False, draws=draws)
+        finals.append(m.arena.flat.clone())
+        if tr.scaler is not None:
+            assert tr.scaler.skipped_steps == 0 and tr.scaler.good_steps == 3
+    assert torch.equal(finals[0], finals[1])
+    with pytest.raises(ValueError):
+        ZipTrainer(mk(), loss_scale="auto")
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("lvl,gscale", [(0, 1e-3), (2, 1e-3), (2, 1e-11), (0, 3e3)])
 def test_zip_table_gradient_binned_is_exact_and_bit_reproducible(lvl, gscale, monkeypatch):
