@@ -1734,15 +1734,25 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(GemmTN p) {
     }
 }
 
-// dW[n, k] += sum over the M slices, in slice order, of the partial tiles (deterministic weight gradient)
+// dW[n, k] += sum over the M slices, in slice order, of the partial tiles (deterministic weight gradient; also the default for short
+// reductions, ops.linear_wgrad).  VEC: four columns per thread (16-byte loads, the slices' loads of an unrolled group in flight together).
+template <bool VEC>
 __global__ __launch_bounds__(256) void tn_fold_kernel(const float* __restrict__ part, long part_stride, int part_ld, int slices, int n_valid,
                                                       int k_valid, float* __restrict__ dW, long ldw) {
-  const int k = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
+  const int k = (blockIdx.x * 256 + threadIdx.x) * (VEC ? 4 : 1), n = blockIdx.y;
   if (k >= k_valid || n >= n_valid) return;
   const float* src = part + (long)n * part_ld + k;
-  float s = 0.f;
-  for (int c = 0; c < slices; ++c) s += src[(long)c * part_stride];
-  dW[(long)n * ldw + k] += s;
+  if constexpr (VEC) {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+    for (int c = 0; c < slices; ++c) s += *(const f32x4*)(src + (long)c * part_stride);
+    f32x4* dst = (f32x4*)(dW + (long)n * ldw + k);
+    *dst += s;
+  } else {
+    float s = 0.f;
+    for (int c = 0; c < slices; ++c) s += src[(long)c * part_stride];
+    dW[(long)n * ldw + k] += s;
+  }
 }
 
 struct TnPlan {
@@ -1865,9 +1875,16 @@ static int wgrad_launch(const void* Z, long ldz, const void* X, long ldx, float*
       else hipLaunchKernelGGL((gemm_tn_kernel<__bf16, false, 2>), grid, dim3(256), lds, st, p);
     } else return SNERF_ERR_ARG;
   }
-  if (ws != nullptr)
-    hipLaunchKernelGGL(tn_fold_kernel, dim3((k_valid + 255) / 256, n_valid), dim3(256), 0, (hipStream_t)stream, ws, pl.part_stride, pl.part_ld,
-                       pl.slices, n_valid, k_valid, dW, ldw);
+  if (ws != nullptr) {
+    // (the same sums in the same order either way: the vector flavour only needs 16-byte aligned rows)
+    const bool vec = k_valid % 4 == 0 && pl.part_ld % 4 == 0 && pl.part_stride % 4 == 0 && ldw % 4 == 0 && ((size_t)dW & 15) == 0 && ((size_t)ws & 15) == 0;
+    if (vec)
+      hipLaunchKernelGGL(tn_fold_kernel<true>, dim3((k_valid / 4 + 255) / 256, n_valid), dim3(256), 0, (hipStream_t)stream, ws, pl.part_stride,
+                         pl.part_ld, pl.slices, n_valid, k_valid, dW, ldw);
+    else
+      hipLaunchKernelGGL(tn_fold_kernel<false>, dim3((k_valid + 255) / 256, n_valid), dim3(256), 0, (hipStream_t)stream, ws, pl.part_stride,
+                         pl.part_ld, pl.slices, n_valid, k_valid, dW, ldw);
+  }
   return snerf_check_launch();
 }
 

@@ -113,15 +113,26 @@ def relu_bits_ok(A, W, Y, K, n_store, dt, variant, consumer=False):
             and A.stride(0) * 512 < (1 << 31) and W.stride(0) * 512 < (1 << 31) and mask_bits_words(A.shape[0], N) * 4 < (1 << 31))
 
 
+WGRAD_FOLD = __import__("os").environ.get("SNERF_WGRAD_FOLD", "1") != "0"   # (the environment switch: A/B runs, tools/probes/wgrad_fold_ab.sh)
+
+
 def linear_wgrad(dZ, X, dW, n_valid, k_valid, dt, variant=0, deterministic=False):
-    """dW[:n_valid, :k_valid] += dZ^T @ X.  dZ [M,N], X [M,K] views, dW fp32 view.  Default: the M slices add with fp32 atomics (order
-    varies run to run); `deterministic`: they store partial tiles into a workspace that is folded in slice order (bit-reproducible)."""
+    """dW[:n_valid, :k_valid] += dZ^T @ X.  dZ [M,N], X [M,K] views, dW fp32 view.  The M slices of a launch either add with fp32 atomics (order varies
+    run to run) or store partial tiles into a workspace that a second launch folds in slice order (bit-reproducible): `deterministic`
+    forces the fold; it is also the default for the wide layers (below)."""
     _chk2d(dZ, _TORCH_DT[dt]); _chk2d(X, _TORCH_DT[dt]); _chk2d(dW, torch.float32)
     assert dZ.shape[0] == X.shape[0] and dW.shape[0] >= n_valid and dW.shape[1] >= k_valid
     if dt == BF16X3:
         # dZ / X are the interleaved split operands (physical widths, multiples of 128); the kernels fold the hi / lo combinations
         assert not deterministic, "the split-bf16 weight gradient has no deterministic fold"
         assert dZ.shape[1] % 128 == 0 and X.shape[1] % 128 == 0
+    # wide layers on the 256 x 256 kernel (>= 8 output tiles, i.e. <= 32 M slices): the slices store their partial tiles and a second
+    # launch folds them in slice order instead of adding 256 x 256 fp32 atomics per slice -- bit-reproducible, and faster: the atomics
+    # of 16 slices (16.8 M per launch at N = K = 1024, whatever M is) cost 24-71 us, the stores + fold 7-26 (tools/probes/
+    # tn_epilogue_probe.py); 512-ray step 4.55 -> 4.24 ms, 4096-ray step 25.65 -> 25.47 (A/B on one box, tools/probes/wgrad_fold_ab.sh)
+    if not deterministic and WGRAD_FOLD and (variant & 2) and dt in (BF16, F16) and dZ.shape[0] >= 4096 and dZ.shape[1] % 256 == 0 and \
+            X.shape[1] >= 256 and (dZ.shape[1] // 256) * ((X.shape[1] + 255) // 256) >= 8:
+        deterministic = True
     if deterministic:
         nws = _lib.query("snerf_linear_wgrad_ws_floats", dZ.shape[0], dZ.shape[1], X.shape[1], dZ.stride(0), X.stride(0), dt, variant)
         ws = torch.empty(max(int(nws), 1), dtype=torch.float32, device=dZ.device)
