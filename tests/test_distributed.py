@@ -158,6 +158,53 @@ def test_zip_ray_sharded_data_parallel_matches_single_process():
     assert (model.arena.flat - start).abs().max().item() > 1e-3
 
 
+def _zip_dynamic_scale_worker(rank, world, init_file, n, out_file):
+    from cpu_ops_emulation import emulate_ops
+    from snerf_amd.trainer import ZipTrainer, LossScaler
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    with emulate_ops():
+        model = _zip_build()
+        tr = ZipTrainer(model, lr=1e-2, eps=1e-4, loss_scale=LossScaler(init_scale=256.0, growth_interval=2))
+        assert tr.shards is not None
+        tr.broadcast_parameters(0)
+        batch, tgt = _zip_data(n)
+        per = n // world
+        mine = {k: v[rank * per:(rank + 1) * per] for k, v in batch.items()}
+        log = []
+        for i in range(4):
+            # step 1: ONE rank's gradients overflow (its aux term is infinite) -- every rank has to skip
+            mult = float("inf") if (i == 1 and rank == 1) else float(world)
+            before = model.arena.flat.clone()
+            tr.step(mine, tgt[rank * per:(rank + 1) * per], rand=False, aux_loss_fn=lambda h: _zip_aux(h) * mult)
+            log.append((bool(torch.equal(before, model.arena.flat)), tr.t, tr.scaler.scale, tr.scaler.skipped_steps, bool(tr.model.arena.grad.any())))
+        flat = model.arena.flat.clone()
+        gathered = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        logs = [None] * world
+        dist.all_gather_object(logs, log)
+        if rank == 0:
+            torch.save((gathered, logs), out_file)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_zip_dynamic_loss_scale_skips_on_every_rank_when_one_rank_overflows():
+    """ZipTrainer(loss_scale=LossScaler(...)) with sharded table updates on two ranks: an overflow in ONE rank's gradients (step 1) is
+    seen by both (the all-reduced sums are non-finite / the 4-byte MAX all-reduce of the flag) -- both skip the step whole, halve the
+    scale, keep t; the other steps update, the scale grows after 2 clean steps, and the ranks stay bit-identical."""
+    n, world = 8, 2
+    with tempfile.TemporaryDirectory() as td:
+        init_file, out_file = os.path.join(td, "init"), os.path.join(td, "out.pt")
+        mp.spawn(_zip_dynamic_scale_worker, args=(world, init_file, n, out_file), nprocs=world, join=True)
+        gathered, logs = torch.load(out_file, weights_only=False)
+    assert torch.equal(gathered[0], gathered[1]), "ranks diverged"
+    assert bool(torch.isfinite(gathered[0]).all())
+    assert logs[0] == logs[1]
+    #            unchanged, t, scale, skipped, grads left
+    assert logs[0] == [(False, 1, 256.0, 0, False), (True, 1, 128.0, 1, False), (False, 2, 128.0, 1, False), (False, 3, 256.0, 1, False)], logs[0]
+
+
 def _zip_render_worker(rank, world, init_file, H, W, out_file):
     import types
     from cpu_ops_emulation import emulate_ops
