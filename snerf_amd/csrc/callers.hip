@@ -443,16 +443,20 @@ __global__ __launch_bounds__(1024) void zip_loss_prepare_kernel(ZipLoss a) {
 }
 
 // anti-interlevel term of one ray against one proposal level -> sum_j clamp(w_s - wp, 0)^2 / (wp + 1e-5); writes d/d wp
+// (`g` may be `wp` itself: g[j] is written after the last read of wp[j] -- the LDS-staged caller overwrites the weights in place)
 __device__ __forceinline__ float zip_interlevel_ray(const float* __restrict__ c, const float* __restrict__ w, int S, const float* __restrict__ cp,
-                                                    const float* __restrict__ wp, int Sp, float r, float gscale, float* __restrict__ g) {
+                                                    const float* wp, int Sp, float r, float gscale, float* g) {
   const int n = S + 1;
   const double r2 = 2.0 * (double)r;
-  // y1[k] = (wn[k] - wn[k-1]) / (2r) with wn = w / (c[k+1] - c[k]) and zeros outside (stepfun.py:427-428)
-  auto y1 = [&](int k) __attribute__((always_inline)) {
+  // y1[k] = (wn[k] - wn[k-1]) / (2r) with wn = w / (c[k+1] - c[k]) and zeros outside (stepfun.py:427-428); each of the two knot streams
+  // visits k = 0 .. S in order, so wn[k-1] is the value its previous visit computed (`last`): one division per knot
+  auto y1 = [&](int k, double& last) __attribute__((always_inline)) {
     const double hi = k < S ? (double)w[k] / ((double)c[k + 1] - (double)c[k]) : 0.0;
-    const double lo = k > 0 ? (double)w[k - 1] / ((double)c[k] - (double)c[k - 1]) : 0.0;
-    return (hi - lo) / r2;
+    const double v = (hi - last) / r2;
+    last = hi;
+    return v;
   };
+  double wn_a = 0.0, wn_b = 0.0;
   int ia = 0, ib = 0, q = 0;
   float xa = c[0] - r, xb = c[0] + r;
   double inner = 0.0, yrun = 0.0, cdf = 0.0;
@@ -474,8 +478,8 @@ __device__ __forceinline__ float zip_interlevel_ray(const float* __restrict__ c,
   float xq = cp[0];
   for (int k = 0; k < 2 * n; ++k) {
     double xk, val;
-    if (ib >= n || (ia < n && xa <= xb)) { xk = (double)xa; val = y1(ia); ++ia; xa = ia < n ? c[ia] - r : 0.f; }
-    else { xk = (double)xb; val = -y1(ib); ++ib; xb = ib < n ? c[ib] + r : 0.f; }
+    if (ib >= n || (ia < n && xa <= xb)) { xk = (double)xa; val = y1(ia, wn_a); ++ia; xa = ia < n ? c[ia] - r : 0.f; }
+    else { xk = (double)xb; val = -y1(ib, wn_b); ++ib; xb = ib < n ? c[ib] + r : 0.f; }
     double yk = 0.0;
     if (k > 0) {
       const double dx = xk - xprev;
@@ -503,6 +507,44 @@ __device__ __forceinline__ float zip_interlevel_ray(const float* __restrict__ c,
     xq = q <= Sp ? cp[q] : 0.f;
   }
   return (float)loss;
+}
+
+// The anti-interlevel term with a workgroup's 64 rays staged in LDS: the per-lane walks over (c, w, cp, wp) are 130 dependent steps of
+// row-strided reads -- from global memory every one of them is 64 cache lines per wave instruction (573 us for 65 536 rays x 2 levels);
+// staged through coalesced loads into odd-strided LDS rows (conflict-free for lane = ray) they are LDS latency.  The gradient overwrites
+// the staged proposal weights in place and leaves through coalesced stores.  grid = (ceil(R / 64), 2 levels); same arithmetic, same
+// order, same results as the global-memory walk (which stays for interval counts whose rows do not fit 160 KB).
+__global__ __launch_bounds__(64) void zip_interlevel_lds_kernel(ZipLoss a) {
+  extern __shared__ float zil_sm[];
+  const int lvl = blockIdx.y;
+  const float* sp = lvl == 0 ? a.s0 : a.s1;
+  if (sp == nullptr) return;
+  const int Sp = lvl == 0 ? a.S0 : a.S1, S = a.S2;
+  const int stc = (S + 1) | 1, stw = S | 1, stp = (Sp + 1) | 1, stq = Sp | 1;
+  float* sc = zil_sm;
+  float* sw = sc + 64 * stc;
+  float* scp = sw + 64 * stw;
+  float* swp = scp + 64 * stp;
+  const long r0 = (long)blockIdx.x * 64;
+  const int nr = (int)(a.R - r0 < 64 ? a.R - r0 : 64);
+  const int tid = threadIdx.x;
+  auto stage = [&](const float* __restrict__ src, int len, float* dst, int stride) __attribute__((always_inline)) {
+    for (int i = tid; i < nr * len; i += 64) { const int ray = i / len; dst[ray * stride + (i - ray * len)] = src[i]; }
+  };
+  stage(a.s2 + r0 * (S + 1), S + 1, sc, stc);
+  stage(a.w2 + r0 * S, S, sw, stw);
+  stage(sp + r0 * (Sp + 1), Sp + 1, scp, stp);
+  stage((lvl == 0 ? a.w0 : a.w1) + r0 * Sp, Sp, swp, stq);
+  __syncthreads();
+  float l = 0.f;
+  const float scale = a.inter_mult / ((float)a.R * (float)Sp);
+  if (tid < nr)
+    l = zip_interlevel_ray(sc + tid * stc, sw + tid * stw, S, scp + tid * stp, swp + tid * stq, Sp, lvl == 0 ? a.pw0 : a.pw1, scale, swp + tid * stq) * scale;
+  __syncthreads();
+  float* g = (lvl == 0 ? a.g_w0 : a.g_w1) + r0 * Sp;
+  for (int i = tid; i < nr * Sp; i += 64) { const int ray = i / Sp; g[i] = swp[ray * stq + (i - ray * Sp)]; }
+  l = wave_sum(l);
+  if (tid == 0) atomicAdd(a.out + 9, l);
 }
 
 __global__ __launch_bounds__(64) void zip_loss_tail_kernel(ZipLoss a) {
@@ -615,7 +657,15 @@ extern "C" int snerf_zip_loss_tail(const float* rgb, const float* tgt, const flo
             pad, data_mult, depth_lambda, com_mult, sem_mult, pw0, pw1, inter_mult, dist_mult, out, g_rgb, g_depth, g_sem, g_w0, g_w1, g_w2};
   hipLaunchKernelGGL(zip_loss_prepare_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
   const bool inter = s2 != nullptr && inter_mult > 0.f && (s0 != nullptr || s1 != nullptr);
-  hipLaunchKernelGGL(zip_loss_tail_kernel, dim3((unsigned)((R + 63) / 64), inter ? 3 : 1), dim3(64), 0, (hipStream_t)stream, a);
+  // the interlevel walks from LDS when a workgroup's rows fit (the shipped interval counts: 49 KB); else from global memory (y = 1, 2)
+  const int Spm = (s0 != nullptr ? S0 : 0) > (s1 != nullptr ? S1 : 0) ? S0 : S1;
+  const size_t lds = (size_t)64 * 4 * (((S2 + 1) | 1) + (S2 | 1) + ((Spm + 1) | 1) + (Spm | 1));
+  const bool staged = inter && lds <= 160 * 1024;
+  hipLaunchKernelGGL(zip_loss_tail_kernel, dim3((unsigned)((R + 63) / 64), inter && !staged ? 3 : 1), dim3(64), 0, (hipStream_t)stream, a);
+  if (staged) {
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)zip_interlevel_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(zip_interlevel_lds_kernel, dim3((unsigned)((R + 63) / 64), 2), dim3(64), lds, (hipStream_t)stream, a);
+  }
   return snerf_check_launch();
 }
 

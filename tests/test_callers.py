@@ -233,11 +233,12 @@ def _rand_hist(rng, R, S, peaky=False, lo=0.0, hi=1.0):
 
 
 @gpu
-@pytest.mark.parametrize("R,S0,S1,S2,C", [(4099, 64, 64, 32, 19), (65, 7, 130, 3, 1), (1, 64, 64, 32, 4)])
+@pytest.mark.parametrize("R,S0,S1,S2,C", [(4099, 64, 64, 32, 19), (65, 7, 130, 3, 1), (1, 64, 64, 32, 4), (70, 128, 128, 64, 2), (70, 300, 64, 32, 2)])
 def test_zip_loss_tail_vs_oracle(R, S0, S1, S2, C):
     """waymo.gin level sizes at a non-multiple-of-64 ray count, odd level sizes (a proposal level wider than the blurred NeRF
     histogram has knots, a 3-interval NeRF level), and a single ray; masks with zeros, both depth masks, duplicated fence posts
-    in the proposal levels and exactly-zero weights."""
+    in the proposal levels and exactly-zero weights.  The last two cases: a workgroup's staged rows above 64 KB of LDS (the interlevel
+    kernel's opt-in limit) and above 160 KB (the walk falls back to global memory)."""
     from snerf_amd import ops
     rng = np.random.default_rng(R + S1)
     s0, w0 = _rand_hist(rng, R, S0)
