@@ -116,6 +116,11 @@ def relu_bits_ok(A, W, Y, K, n_store, dt, variant, consumer=False):
 WGRAD_FOLD = __import__("os").environ.get("SNERF_WGRAD_FOLD", "1") != "0"   # (the environment switch: A/B runs, tools/probes/wgrad_fold_ab.sh)
 
 
+def wgrad_uses_fold(M, N, K, dt, variant):
+    """the default cross-slice reduction of linear_wgrad: True = partial tiles + fixed-order fold (see there), False = fp32 atomics"""
+    return bool(WGRAD_FOLD and (variant & 2) and dt in (BF16, F16) and M >= 4096 and N % 256 == 0 and K >= 256 and (N // 256) * ((K + 255) // 256) >= 8)
+
+
 def linear_wgrad(dZ, X, dW, n_valid, k_valid, dt, variant=0, deterministic=False):
     """dW[:n_valid, :k_valid] += dZ^T @ X.  dZ [M,N], X [M,K] views, dW fp32 view.  The M slices of a launch either add with fp32 atomics (order varies
     run to run) or store partial tiles into a workspace that a second launch folds in slice order (bit-reproducible): `deterministic`
@@ -130,8 +135,7 @@ def linear_wgrad(dZ, X, dW, n_valid, k_valid, dt, variant=0, deterministic=False
     # launch folds them in slice order instead of adding 256 x 256 fp32 atomics per slice -- bit-reproducible, and faster: the atomics
     # of 16 slices (16.8 M per launch at N = K = 1024, whatever M is) cost 24-71 us, the stores + fold 7-26 (tools/probes/
     # tn_epilogue_probe.py); 512-ray step 4.55 -> 4.24 ms, 4096-ray step 25.65 -> 25.47 (A/B on one box, tools/probes/wgrad_fold_ab.sh)
-    if not deterministic and WGRAD_FOLD and (variant & 2) and dt in (BF16, F16) and dZ.shape[0] >= 4096 and dZ.shape[1] % 256 == 0 and \
-            X.shape[1] >= 256 and (dZ.shape[1] // 256) * ((X.shape[1] + 255) // 256) >= 8:
+    if not deterministic and wgrad_uses_fold(dZ.shape[0], dZ.shape[1], X.shape[1], dt, variant):
         deterministic = True
     if deterministic:
         nws = _lib.query("snerf_linear_wgrad_ws_floats", dZ.shape[0], dZ.shape[1], X.shape[1], dZ.stride(0), X.stride(0), dt, variant)

@@ -74,7 +74,68 @@ class _GradExchange:
         self.works, self.done = [], []
 
 
-class MipTrainer:
+class _AdamState:
+    """Checkpointing of the fused Adam launch's state in torch.optim.Adam's `state_dict()` layout over `model.parameters()` -- what the
+    reference stores next to the weights (s-nerf/train.py:264-273 'optimzer', resumed at utils/model_utils.py:44-63; zipnerf/train.py:432-440
+    'optimizer', internal/checkpoints.py:52-54): a checkpoint written by the reference's training loop resumes here and the other way round
+    (`torch.optim.Adam(model.parameters()).load_state_dict(trainer.state_dict())`)."""
+
+    def _moments(self):
+        return self.m, self.v
+
+    def state_dict(self):
+        a = self.model.arena
+        m, v = self._moments()
+        names = [n for n, _ in self.model.named_parameters()]
+        state = {}
+        for i, n in enumerate(names):
+            lo, cnt = a._offs[n]
+            state[i] = {"step": torch.tensor(float(self.t)), "exp_avg": m[lo:lo + cnt].view(a.shapes[n]).clone(),
+                        "exp_avg_sq": v[lo:lo + cnt].view(a.shapes[n]).clone()}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0, "amsgrad": False, "maximize": False,
+                 "foreach": None, "capturable": False, "differentiable": False, "fused": None, "params": list(range(len(names)))}
+        sd = {"state": state, "param_groups": [group], "param_names": names}
+        if getattr(self, "scaler", None) is not None:
+            sd["loss_scaler"] = self.scaler.state_dict()
+        return sd
+
+    def load_state_dict(self, sd):
+        a = self.model.arena
+        names = [n for n, _ in self.model.named_parameters()]
+        groups = sd["param_groups"]
+        if sum(len(g["params"]) for g in groups) != len(names):
+            raise ValueError(f"optimizer state for {sum(len(g['params']) for g in groups)} parameters, the model has {len(names)}")
+        if "param_names" in sd and list(sd["param_names"]) != names:
+            raise ValueError("optimizer state was saved for other parameter names")
+        order = [i for g in groups for i in g["params"]]
+        steps = set()
+        with torch.no_grad():
+            for pos, n in zip(order, names):
+                lo, cnt = a._offs[n]
+                st = sd["state"].get(pos, sd["state"].get(str(pos)))
+                if st is None:                              # (a parameter the saved optimizer never stepped)
+                    self.m[lo:lo + cnt].zero_(); self.v[lo:lo + cnt].zero_()
+                    continue
+                if tuple(st["exp_avg"].shape) != tuple(a.shapes[n]):
+                    raise ValueError(f"optimizer state of {n}: shape {tuple(st['exp_avg'].shape)}, the parameter has {tuple(a.shapes[n])}")
+                self.m[lo:lo + cnt].copy_(st["exp_avg"].reshape(-1).to(self.m.device, torch.float32))
+                self.v[lo:lo + cnt].copy_(st["exp_avg_sq"].reshape(-1).to(self.v.device, torch.float32))
+                steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError(f"one Adam launch covers the whole arena: the saved parameters disagree on the step count ({sorted(steps)})")
+        self.t = steps.pop() if steps else 0
+        g0 = groups[0]
+        self.lr, self.betas, self.eps = float(g0["lr"]), tuple(float(b) for b in g0["betas"]), float(g0["eps"])
+        if float(g0.get("weight_decay", 0) or 0) != 0 or g0.get("amsgrad", False):
+            raise ValueError("the fused Adam launch has no weight decay / amsgrad")
+        if getattr(self, "_step_dev", None) is not None:
+            self._step_dev.fill_(self.t)
+        if getattr(self, "scaler", None) is not None and "loss_scaler" in sd:
+            self.scaler.load_state_dict(sd["loss_scaler"])
+            self.loss_scale = self.scaler.scale
+
+
+class MipTrainer(_AdamState):
     def __init__(self, model, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, depth_lambda=0.2, coarse_depth_mult=0.2,
                  proposal_loss=False, proposal_lambda=0.05, disparity_depth=True, process_group=None,
                  nonfinite="zero", grad_max_val=0.0, grad_max_norm=0.0, exchange_when_single=False):
@@ -292,8 +353,12 @@ class _TableShards:
         return out
 
     def all_gather_params(self, name):
+        self.all_gather_span(self.arena.flat, name)
+
+    def all_gather_span(self, flat, name):
+        """every rank's slice of the table span of `flat` (the parameters, or an Adam moment of the same layout) to every rank"""
         a, b, per = self.spans[name]
-        full = self.arena.flat[a:b]
+        full = flat[a:b]
         mine = full[self.rank * per:(self.rank + 1) * per]
         dist.all_gather_into_tensor(full, mine if self.nccl else mine.clone(), group=self.group)
 
@@ -331,7 +396,7 @@ class LossScaler:
         self.growth_interval, self.good_steps, self.skipped_steps = int(d["growth_interval"]), int(d["good_steps"]), int(d.get("skipped_steps", 0))
 
 
-class ZipTrainer:
+class ZipTrainer(_AdamState):
     """Train step of the S-NeRF++ / zipnerf background model (s-nerfpp/zipnerf/train.py hot loop :218-331: Model.forward, the loss
     terms, loss.backward(), optimizer.step()) on the flat arenas: forward, ONE fused loss-tail launch (ops.zip_loss_tail: Charbonnier
     data term, disparity-L1 depth terms, semantic NLL, anti-interlevel and distortion regularisers, with their gradients), backward
@@ -392,6 +457,17 @@ class ZipTrainer:
         if self.world > 1:
             dist.broadcast(self.model.arena.flat, src=src, group=self.pg)
             self.model.arena.bump()
+
+    def _moments(self):
+        """sharded table updates keep a rank's Adam moments current on its own slices only: a checkpoint gathers them (collective: every
+        rank has to call state_dict())"""
+        if self.shards is None:
+            return self.m, self.v
+        m, v = self.m.clone(), self.v.clone()
+        for name in self.tables:
+            self.shards.all_gather_span(m, name)
+            self.shards.all_gather_span(v, name)
+        return m, v
 
     def _overflowed(self, a, shards):
         """dynamic loss scaling: the found-inf pass over the exchanged gradients and the scaler's update; -> True = the step is skipped

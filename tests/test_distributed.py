@@ -125,8 +125,12 @@ def _zip_worker(rank, world, init_file, n, out_file, table_exchange="sharded"):
         flat = model.arena.flat.clone()
         gathered = [torch.empty_like(flat) for _ in range(world)]
         dist.all_gather(gathered, flat)
+        sd = tr.state_dict()                        # (collective with sharded tables: the other ranks' moment slices are gathered)
+        moments = torch.cat([torch.cat([st["exp_avg"].reshape(-1), st["exp_avg_sq"].reshape(-1)]) for st in sd["state"].values()])
+        all_m = [torch.empty_like(moments) for _ in range(world)]
+        dist.all_gather(all_m, moments)
         if rank == 0:
-            torch.save(gathered, out_file)
+            torch.save((gathered, all_m), out_file)
     dist.destroy_process_group()
 
 
@@ -138,12 +142,14 @@ def test_zip_ray_sharded_data_parallel_matches_single_process():
     with tempfile.TemporaryDirectory() as td:
         init_file, out_file = os.path.join(td, "init"), os.path.join(td, "out.pt")
         mp.spawn(_zip_worker, args=(world, init_file, n, out_file), nprocs=world, join=True)
-        gathered = torch.load(out_file)
+        gathered, moments = torch.load(out_file)
         # the hash tables through reduce-scatter + sharded Adam + all-gather (default) and through the dense all-reduce: the same sums
         # (two addends commute), the same optimiser arithmetic on every element -- identical parameters
         init2, out2 = os.path.join(td, "init2"), os.path.join(td, "out2.pt")
         mp.spawn(_zip_worker, args=(world, init2, n, out2, "allreduce"), nprocs=world, join=True)
-        dense = torch.load(out2)
+        dense, dense_moments = torch.load(out2)
+    # a checkpoint of the sharded run holds every rank's Adam moments (gathered), the same on both ranks and the same as the dense run's
+    assert torch.equal(moments[0], moments[1]) and torch.equal(moments[0], dense_moments[0]) and float(moments[0].abs().sum()) > 0
     assert torch.equal(gathered[0], gathered[1]), "ranks diverged"
     assert torch.equal(gathered[0], dense[0]) and torch.equal(dense[0], dense[1]), "sharded and all-reduced table updates differ"
     with emulate_ops():
@@ -436,3 +442,72 @@ def test_grad_exchange_sends_every_element_exactly_once(monkeypatch):
             assert y > x
             cover[x:y] += 1
         assert bool((cover == 1).all()), (order, sent)
+
+
+def test_trainer_checkpoints_are_torch_adam_state_dicts():
+    """MipTrainer / ZipTrainer.state_dict() is torch.optim.Adam's layout over model.parameters() -- what the reference saves as 'optimzer'
+    (s-nerf/train.py:269) / 'optimizer' (zipnerf/train.py:437) and resumes from (model_utils.py:53, checkpoints.py:54): it loads into a
+    torch Adam, a torch Adam's state loads into the trainer, and a resumed trainer continues bit for bit."""
+    from cpu_ops_emulation import emulate_ops
+    from snerf_amd.trainer import ZipTrainer, MipTrainer, LossScaler
+    n = 8
+    with emulate_ops():
+        model = _zip_build()
+        tr = ZipTrainer(model, lr=1e-2, eps=1e-4, loss_scale=LossScaler(init_scale=8.0, growth_interval=2))
+        batch, tgt = _zip_data(n)
+        for _ in range(2):
+            tr.step(batch, tgt, rand=False, aux_loss_fn=_zip_aux)
+        sd = tr.state_dict()
+        assert sd["param_names"] == [k for k, _ in model.named_parameters()] and sd["loss_scaler"]["scale"] == 16.0
+        # -> torch.optim.Adam
+        opt = torch.optim.Adam(model.parameters(), lr=1.0)
+        opt.load_state_dict({k: v for k, v in sd.items() if k in ("state", "param_groups")})
+        assert opt.param_groups[0]["lr"] == 1e-2 and tuple(opt.param_groups[0]["betas"]) == (0.9, 0.99)
+        for i, p_ in enumerate(model.parameters()):
+            assert torch.equal(opt.state[p_]["exp_avg"], sd["state"][i]["exp_avg"]) and int(opt.state[p_]["step"]) == 2
+        # resume: a fresh model + trainer loaded from the checkpoint takes the same third step
+        model2 = _zip_build()
+        model2.load_state_dict(model.state_dict())
+        tr2 = ZipTrainer(model2, lr=3e-3, loss_scale="dynamic")
+        tr2.load_state_dict(sd)
+        assert tr2.t == 2 and tr2.lr == 1e-2 and tr2.eps == 1e-4 and tr2.scaler.scale == 16.0 and tr2.scaler.good_steps == 0
+        for t_, m_ in ((tr, model), (tr2, model2)):
+            t_.step(batch, tgt, rand=False, aux_loss_fn=_zip_aux)
+        assert torch.equal(model.arena.flat, model2.arena.flat) and torch.equal(tr.m, tr2.m) and torch.equal(tr.v, tr2.v) and tr2.t == 3
+        # torch.optim.Adam -> trainer
+        model3 = _zip_build()
+        opt3 = torch.optim.Adam(model3.parameters(), lr=5e-3, betas=(0.8, 0.9), eps=1e-6)
+        g = torch.Generator().manual_seed(1)
+        for _ in range(3):
+            for p_ in model3.parameters():
+                p_.grad = torch.randn(p_.shape, generator=g)
+            opt3.step()
+        tr3 = ZipTrainer(model3)
+        tr3.load_state_dict(opt3.state_dict())
+        assert tr3.t == 3 and tr3.lr == 5e-3 and tr3.betas == (0.8, 0.9) and tr3.eps == 1e-6
+        for nme, p_ in model3.named_parameters():
+            lo, cnt = model3.arena._offs[nme]
+            assert torch.equal(tr3.m[lo:lo + cnt].view(p_.shape), opt3.state[p_]["exp_avg"])
+            assert torch.equal(tr3.v[lo:lo + cnt].view(p_.shape), opt3.state[p_]["exp_avg_sq"])
+        bad = opt3.state_dict()
+        bad["param_groups"][0]["params"] = bad["param_groups"][0]["params"][:-1]
+        with pytest.raises(ValueError):
+            tr3.load_state_dict(bad)
+        wd = opt3.state_dict()
+        wd["param_groups"][0]["weight_decay"] = 0.1
+        with pytest.raises(ValueError):
+            tr3.load_state_dict(wd)
+        # path A's trainer: the same layout
+        ma = _build()
+        ta = MipTrainer(ma, lr=1e-3)
+        rays, tgt_a = _data(16)
+        ta.step(rays, tgt_a, randomized=False)
+        sa = ta.state_dict()
+        torch.optim.Adam(ma.parameters()).load_state_dict({k: v for k, v in sa.items() if k in ("state", "param_groups")})
+        mb = _build()
+        mb.load_state_dict(ma.state_dict())
+        tb = MipTrainer(mb, lr=1.0)
+        tb.load_state_dict(sa)
+        for t_ in (ta, tb):
+            t_.step(rays, tgt_a, randomized=False)
+        assert tb.t == 2 and torch.equal(ma.arena.flat, mb.arena.flat)

@@ -438,3 +438,18 @@ def test_fused_training_forward_stores_activations_and_relu_bits(M):
         assert rel(y, yl) < 1e-2
         words, N = fbits[(y.data_ptr(), M)]
         assert np.array_equal(decode(words, M, N), (y.float() > 0).cpu().numpy())
+
+
+def test_wgrad_fold_policy():
+    """ops.wgrad_uses_fold: the wide layers of path A (>= 8 output tiles of the 256 x 256 kernel) reduce their M slices by partial tiles +
+    fold, everything else -- few-tile launches with hundreds of slices (paths B / C), the 128 x 128 kernel's shapes, fp32 and split-bf16
+    operands, short reductions the 8-phase kernel does not take -- keeps the fp32 atomics."""
+    from snerf_amd import ops
+    assert ops.wgrad_uses_fold(786432, 1024, 1024, ops.BF16, 3) and ops.wgrad_uses_fold(32768, 1024, 1024, ops.F16, 2)
+    assert ops.wgrad_uses_fold(262144, 1024, 512, ops.BF16, 3) and ops.wgrad_uses_fold(262144, 512, 1024, ops.BF16, 3)
+    assert not ops.wgrad_uses_fold(6291456, 256, 256, ops.BF16, 3)          # path B: one tile, 256 slices
+    assert not ops.wgrad_uses_fold(786432, 1024, 96, ops.BF16, 3)            # K < 256: the 128 x 128 kernel
+    assert not ops.wgrad_uses_fold(786432, 1024 + 128, 1024, ops.BF16, 3)    # N not a multiple of 256
+    assert not ops.wgrad_uses_fold(2048, 1024, 1024, ops.BF16, 3)            # below the 8-phase kernel's M
+    assert not ops.wgrad_uses_fold(786432, 1024, 1024, ops.F32, 3) and not ops.wgrad_uses_fold(786432, 2048, 2048, ops.BF16X3, 3)
+    assert not ops.wgrad_uses_fold(786432, 1024, 1024, ops.BF16, 1)          # variant without the 8-phase kernel
