@@ -125,6 +125,9 @@ class _AdamState:
             raise ValueError(f"one Adam launch covers the whole arena: the saved parameters disagree on the step count ({sorted(steps)})")
         self.t = steps.pop() if steps else 0
         g0 = groups[0]
+        for g in groups[1:]:                                # one launch, one set of hyper-parameters
+            if (float(g["lr"]), tuple(g["betas"]), float(g["eps"])) != (float(g0["lr"]), tuple(g0["betas"]), float(g0["eps"])):
+                raise ValueError("the fused Adam launch covers the whole arena with one lr / betas / eps: the saved param_groups differ")
         self.lr, self.betas, self.eps = float(g0["lr"]), tuple(float(b) for b in g0["betas"]), float(g0["eps"])
         if float(g0.get("weight_decay", 0) or 0) != 0 or g0.get("amsgrad", False):
             raise ValueError("the fused Adam launch has no weight decay / amsgrad")

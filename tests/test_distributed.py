@@ -497,6 +497,13 @@ def test_trainer_checkpoints_are_torch_adam_state_dicts():
         wd["param_groups"][0]["weight_decay"] = 0.1
         with pytest.raises(ValueError):
             tr3.load_state_dict(wd)
+        ps = list(model3.parameters())
+        two = torch.optim.Adam([{"params": ps[:3], "lr": 1e-3}, {"params": ps[3:], "lr": 1e-4}])
+        with pytest.raises(ValueError):
+            tr3.load_state_dict(two.state_dict())           # two learning rates cannot ride in one launch
+        same = torch.optim.Adam([{"params": ps[:3]}, {"params": ps[3:]}], lr=2e-3)
+        tr3.load_state_dict(same.state_dict())              # (never stepped: empty state -> zero moments, t = 0)
+        assert tr3.t == 0 and tr3.lr == 2e-3 and not bool(tr3.m.any()) and not bool(tr3.v.any())
         # path A's trainer: the same layout
         ma = _build()
         ta = MipTrainer(ma, lr=1e-3)
