@@ -461,7 +461,7 @@ def test_trainer_checkpoints_are_torch_adam_state_dicts():
         assert sd["param_names"] == [k for k, _ in model.named_parameters()] and sd["loss_scaler"]["scale"] == 16.0
         # -> torch.optim.Adam
         opt = torch.optim.Adam(model.parameters(), lr=1.0)
-        opt.load_state_dict({k: v for k, v in sd.items() if k in ("state", "param_groups")})
+        opt.load_state_dict(sd)                                      # (torch ignores the extra top-level entries)
         assert opt.param_groups[0]["lr"] == 1e-2 and tuple(opt.param_groups[0]["betas"]) == (0.9, 0.99)
         for i, p_ in enumerate(model.parameters()):
             assert torch.equal(opt.state[p_]["exp_avg"], sd["state"][i]["exp_avg"]) and int(opt.state[p_]["step"]) == 2
@@ -510,7 +510,7 @@ def test_trainer_checkpoints_are_torch_adam_state_dicts():
         rays, tgt_a = _data(16)
         ta.step(rays, tgt_a, randomized=False)
         sa = ta.state_dict()
-        torch.optim.Adam(ma.parameters()).load_state_dict({k: v for k, v in sa.items() if k in ("state", "param_groups")})
+        torch.optim.Adam(ma.parameters()).load_state_dict(sa)
         mb = _build()
         mb.load_state_dict(ma.state_dict())
         tb = MipTrainer(mb, lr=1.0)
