@@ -21,3 +21,9 @@ python tools/rocprof_summary.py $(find $O/prof_z -name "b_kernel_trace.csv") > $
 bash tools/pmc_gemm_traffic.sh > $O/gemm_nt8p_traffic.txt 2>&1; tail -12 $O/gemm_nt8p_traffic.txt
 bash tools/pmc_paths.sh > $O/pmc_paths.log 2>&1; cp gpurun_out/pmc_paths/summary.txt $O/pathC_pathB_pmc.txt; cp gpurun_out/pmc_paths/roofline_traffic_paths.json $O/; cat $O/roofline_traffic_paths.json
 rm -rf $O/prof_*
+# optional extras (ROUND_END_EXTRAS=1, +4 GPU-minutes): the suite under the LDS scribble, the stale-LDS repetition screen, the 512-ray step
+if [ -n "$ROUND_END_EXTRAS" ]; then
+  SNERF_TEST_SCRIBBLE_LDS=1 timeout 600 python -m pytest tests -x -q -m gpu 2>&1 | grep -v "^Extension" | tail -1 | tee $O/pytest_lds_scribble.txt
+  timeout 300 python tools/stress_stale_lds.py 600 2>&1 | grep "path \|TOTAL" | tee $O/stress_stale_lds.txt
+  bash tools/probes/small_step_profile.sh 2>&1 | head -12 | tee $O/small_step.txt
+fi
