@@ -593,6 +593,12 @@ int snerf_adam_step_dev(float* p, float* g, float* m, float* v, long n, float lr
 int snerf_adam_step_ex(float* p, float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, int step,
                        int* step_dev, const float* lr_dev, float grad_scale, int zero_grad, int nonfinite, float grad_max_val,
                        const float* clip_coef, void* stream);
+/* snerf_adam_step_ex with a counter: *dropped (device uint64, 8-byte aligned, never reset by the launch; NULL = off) += the number of
+ * NaN / +-Inf gradient elements the launch saw, whatever `nonfinite` does with them.  The reference trains fp16 under GradScaler
+ * (zipnerf/train.py:44,331), which skips such a step; with a static loss scale the drop would otherwise be silent. */
+int snerf_adam_step_cnt(float* p, float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, int step,
+                        int* step_dev, const float* lr_dev, float grad_scale, int zero_grad, int nonfinite, float grad_max_val,
+                        const float* clip_coef, void* dropped, void* stream);
 /* torch.nn.utils.clip_grad_norm_ coefficient over a flat gradient arena: out[0] = min(1, max_norm / (|grad_scale| * ||g||_2 + 1e-6)),
  * out[1] = the norm.  ws: >= 1024 doubles of device scratch.  Fixed reduction order (deterministic). */
 int snerf_grad_clip_coef(const float* g, long n, float grad_scale, float max_norm, void* ws, float* out, void* stream);

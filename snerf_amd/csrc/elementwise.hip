@@ -19,6 +19,7 @@ struct AdamArgs {
   const float* lr_dev;        // learning rate in device memory (graph capture with a schedule), or nullptr: `lr`
   const float* clip_coef;     // global-norm clip coefficient in device memory, or nullptr
   int step;
+  unsigned long long* dropped; // += number of NaN / +-Inf gradient elements this launch saw (any `nonfinite` policy), or nullptr
 };
 
 __device__ __forceinline__ float adam_clean_grad(float g, const AdamArgs& a, float coef) {
@@ -29,6 +30,9 @@ __device__ __forceinline__ float adam_clean_grad(float g, const AdamArgs& a, flo
   return g;
 }
 
+// VEC = 4: all four pointers 16-byte aligned (whole arenas, aligned spans); VEC = 1: any alignment -- a rank's 1 / world slice of a
+// single-channel hash table starts at an odd float (6 606 952 / 8 = 825 869 rows per rank), trainer._TableShards.
+template <int VEC>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long n, AdamArgs a) {
   const float t = (float)(a.step_dev != nullptr ? *a.step_dev : a.step);
@@ -36,12 +40,14 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
   const float bc1 = 1.f - powf(a.b1, t), bc2_sqrt = sqrtf(1.f - powf(a.b2, t));
   const float coef = a.clip_coef != nullptr ? *a.clip_coef : 1.f;
   const float b1 = a.b1, b2 = a.b2, eps = a.eps;
-  const long n4 = n >> 2;
+  const long n4 = VEC == 4 ? (n >> 2) : 0;
+  unsigned bad = 0;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
     float4 pp = ((float4*)p)[i], gg = ((float4*)g)[i], mm = ((float4*)m)[i], vv = ((float4*)v)[i];
     float* pa = (float*)&pp; float* ga = (float*)&gg; float* ma = (float*)&mm; float* va = (float*)&vv;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
+      bad += (fabsf(ga[k]) <= 3.402823466e+38f) ? 0u : 1u;
       const float gk = adam_clean_grad(ga[k], a, coef);
       ma[k] = b1 * ma[k] + (1.f - b1) * gk;
       va[k] = b2 * va[k] + (1.f - b2) * gk * gk;
@@ -50,30 +56,39 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     ((float4*)p)[i] = pp; ((float4*)m)[i] = mm; ((float4*)v)[i] = vv;
     if (a.zero_grad) ((float4*)g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
-    const long i = (n4 << 2) + threadIdx.x;
+  // VEC = 4: the n & 3 tail elements (block 0); VEC = 1: every element, one per thread and stride
+  const long t0 = VEC == 4 ? (n4 << 2) + (blockIdx.x == 0 ? (long)threadIdx.x : n) : (long)blockIdx.x * 256 + threadIdx.x;
+  for (long i = t0; i < n; i += (long)gridDim.x * 256) {
+    bad += (fabsf(g[i]) <= 3.402823466e+38f) ? 0u : 1u;
     const float gk = adam_clean_grad(g[i], a, coef);
     m[i] = b1 * m[i] + (1.f - b1) * gk;
     v[i] = b2 * v[i] + (1.f - b2) * gk * gk;
     p[i] -= (lr / bc1) * m[i] / (sqrtf(v[i]) / bc2_sqrt + eps);
     if (a.zero_grad) g[i] = 0.f;
   }
+  if (a.dropped != nullptr && __any(bad != 0)) {        // rare: one atomic per wave that saw a non-finite gradient
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) bad += __shfl_xor(bad, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(a.dropped, (unsigned long long)bad);
+  }
 }
 
 static int adam_launch(float* p, float* g, float* m, float* v, long n, const AdamArgs& a, void* stream) {
   if (n <= 0) return SNERF_OK;
-  if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) || a.nonfinite < 0 || a.nonfinite > 2) return SNERF_ERR_ARG;
-  const long n4 = n >> 2;
-  int blocks = (int)((n4 + 255) / 256);
-  blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
-  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, a);
+  if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 3) || a.nonfinite < 0 || a.nonfinite > 2) return SNERF_ERR_ARG;
+  const bool vec = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
+  const long units = vec ? (n >> 2) : n;
+  int blocks = (int)((units + 255) / 256);
+  blocks = blocks < 1 ? 1 : (blocks > (vec ? 2048 : 8192) ? (vec ? 2048 : 8192) : blocks);
+  if (vec) hipLaunchKernelGGL(adam_kernel<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, a);
+  else hipLaunchKernelGGL(adam_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, a);
   return snerf_check_launch();
 }
 
 extern "C" int snerf_adam_step(float* p, float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, int step,
                                float grad_scale, int zero_grad, void* stream) {
   if (step < 1) return SNERF_ERR_ARG;
-  return adam_launch(p, g, m, v, n, AdamArgs{lr, b1, b2, eps, grad_scale, 0.f, zero_grad, 0, nullptr, nullptr, nullptr, step}, stream);
+  return adam_launch(p, g, m, v, n, AdamArgs{lr, b1, b2, eps, grad_scale, 0.f, zero_grad, 0, nullptr, nullptr, nullptr, step, nullptr}, stream);
 }
 
 // The same update with the step count in device memory (incremented here): nothing in the launch depends on host state, so a whole
@@ -85,7 +100,7 @@ extern "C" int snerf_adam_step_dev(float* p, float* g, float* m, float* v, long 
   if (n <= 0) return SNERF_OK;
   if (step_dev == nullptr) return SNERF_ERR_ARG;
   hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev);
-  return adam_launch(p, g, m, v, n, AdamArgs{lr, b1, b2, eps, grad_scale, 0.f, zero_grad, 0, step_dev, nullptr, nullptr, 0}, stream);
+  return adam_launch(p, g, m, v, n, AdamArgs{lr, b1, b2, eps, grad_scale, 0.f, zero_grad, 0, step_dev, nullptr, nullptr, 0, nullptr}, stream);
 }
 
 extern "C" int snerf_adam_step_ex(float* p, float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, int step,
@@ -94,7 +109,20 @@ extern "C" int snerf_adam_step_ex(float* p, float* g, float* m, float* v, long n
   if (n <= 0) return SNERF_OK;
   if (step_dev == nullptr && step < 1) return SNERF_ERR_ARG;
   if (step_dev != nullptr) hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev);
-  return adam_launch(p, g, m, v, n, AdamArgs{lr, b1, b2, eps, grad_scale, grad_max_val, zero_grad, nonfinite, step_dev, lr_dev, clip_coef, step}, stream);
+  return adam_launch(p, g, m, v, n, AdamArgs{lr, b1, b2, eps, grad_scale, grad_max_val, zero_grad, nonfinite, step_dev, lr_dev, clip_coef, step, nullptr}, stream);
+}
+
+// snerf_adam_step_ex + `dropped` (device uint64, never reset here): += the number of NaN / +-Inf gradient elements of this launch.  An
+// fp16 run with a static loss scale and nonfinite = 1 otherwise drops overflowed gradients silently (GradScaler would skip the step).
+extern "C" int snerf_adam_step_cnt(float* p, float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps, int step,
+                                   int* step_dev, const float* lr_dev, float grad_scale, int zero_grad, int nonfinite,
+                                   float grad_max_val, const float* clip_coef, void* dropped, void* stream) {
+  if (n <= 0) return SNERF_OK;
+  if (step_dev == nullptr && step < 1) return SNERF_ERR_ARG;
+  if (dropped != nullptr && ((uintptr_t)dropped & 7)) return SNERF_ERR_ARG;
+  if (step_dev != nullptr) hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev);
+  return adam_launch(p, g, m, v, n, AdamArgs{lr, b1, b2, eps, grad_scale, grad_max_val, zero_grad, nonfinite, step_dev, lr_dev, clip_coef, step,
+                                             (unsigned long long*)dropped}, stream);
 }
 
 // Global-norm clip coefficient of torch.nn.utils.clip_grad_norm_ (accelerator.clip_grad_norm_, train_utils.py:236-237):

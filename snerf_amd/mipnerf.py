@@ -152,6 +152,8 @@ class MipNerfModel(_ArenaModule):
                 base += ids.shape[0]
                 evaluated += ids.shape[0]
             self.last_ert_rows = (evaluated, n * S1)
+            if not parts:       # (unreachable with eps_t < 1 -- the first group always has every ray -- kept so that the cat below never sees [])
+                parts.append(self._eval_fine(0, torch.zeros(0, dtype=torch.int32, device=dev), s1, o, d, vd, radii, near, far, cone, app, warp, S1, False)[:3])
             raw_rgb = torch.cat([p_[0] for p_ in parts], 0)
             raw_d1 = torch.cat([p_[1] for p_ in parts], 0)
             raw_sem_rows = torch.cat([p_[2] for p_ in parts], 0) if self.semantic else None
@@ -286,7 +288,8 @@ class MipNerfModel(_ArenaModule):
         `ert=(eps_t, eps_w)` (inference only; NOT in the reference): early ray termination + sample compaction -- fine samples whose
         proposal-predicted transmittance is <= eps_t or whose proposal-predicted weight is <= eps_w are not evaluated.
         `ert=(eps_t, eps_w, G)`: the fine level front to back in groups of G samples; a ray stops once its transmittance, from the fine
-        network's own densities, is <= eps_t -- the skipped samples' weights then sum to <= eps_t (an exact bound on acc / rgb)."""
+        network's own densities, is <= eps_t -- the skipped samples' weights then sum to <= eps_t (an exact bound on acc / rgb); eps_w is
+        not used in this mode, and every group costs one device->host read of the survivor count (small G = sync-bound)."""
         if white_bg:
             raise NotImplementedError("white_bg=True crashes the reference at the proposal level (mip.py:188, rgb is None)")
         self._check_arena()
@@ -316,6 +319,9 @@ class MipNerfModel(_ArenaModule):
         # ert = (eps_t, eps_w): selection from the proposal histogram; ert = (eps_t, eps_w, G): front to back in groups of G fine samples,
         # rays leave when their transmittance (the fine network's own densities) falls to eps_t (eps_w unused: the bound is exact)
         self._ert = None if ert is None else (float(ert[0]), float(ert[1]), int(ert[2]) if len(ert) > 2 else 0)
+        if self._ert is not None and not (self._ert[0] < 1.0 and self._ert[2] >= 0):     # (NaN fails the comparison too)
+            self._ert = None
+            raise ValueError("ert: eps_t < 1 (a transmittance; >= 1 would terminate every ray before its first sample; < 0 = never), G >= 0")
         rt = (rays.origins, rays.directions, rays.viewdirs) if ray_grad else (None, None, None)
         outs = _MipFn.apply(self, rays, bool(white_bg), s_rand, u, noise0, noise1, keep, *rt, *params)
         self._ert = None

@@ -413,23 +413,54 @@ def mip_viewenc(viewdirs, S, deg, dst, width, dt, sample_id=None):
     _lib.call("snerf_mip_viewenc", _p(viewdirs), viewdirs.shape[0], S, deg, _p(dst), dst.stride(0), width, dt, _p(ids), rows, _stream())
 
 
-_index_checks = []          # [(device counter, message)] of launched index checks whose result has not been read yet
+class _IndexCheckSlots:
+    """Per-device ring of range-check slots: one int32 device counter, one pinned host mirror and one event per slot, all allocated
+    once.  A check zeroes its counter, runs snerf_index_check, copies the counter into the pinned mirror (non_blocking) and records the
+    event behind the copy; a poll reads the HOST value of slots whose event has completed -- no device synchronisation, no
+    allocation per call (`cnt.item()` was a memcpy + stream sync behind the step's queued kernels)."""
+    SLOTS = 16
+
+    def __init__(self, device):
+        self.dev = torch.zeros(self.SLOTS, dtype=torch.int32, device=device)
+        self.host = torch.zeros(self.SLOTS, dtype=torch.int32).pin_memory()
+        self.events = [torch.cuda.Event() for _ in range(self.SLOTS)]
+        self.msgs = [None] * self.SLOTS            # None = free
+        self.head = 0
+
+    def poll(self, block=False):
+        for k in range(self.SLOTS):
+            if self.msgs[k] is None:
+                continue
+            if block:
+                self.events[k].synchronize()
+            elif not self.events[k].query():
+                continue
+            msg, self.msgs[k] = self.msgs[k], None
+            if int(self.host[k]) != 0:
+                raise IndexError(msg)
+
+    def acquire(self):
+        for _ in range(self.SLOTS):
+            k, self.head = self.head, (self.head + 1) % self.SLOTS
+            if self.msgs[k] is None:
+                return k
+        k = self.head                                # every slot pending (16 checks in flight): wait for the oldest one
+        self.events[k].synchronize()
+        self.poll()
+        return self.acquire()
+
+
+_index_slots = {}            # device index -> _IndexCheckSlots
 
 
 def poll_index_checks(block=False):
     """Raise IndexError for an embedding index outside its table seen by an EARLIER launch (torch.nn.Embedding raises on one; the
-    kernels clamp).  Without `block` only counters whose kernel has certainly finished are read: the step never waits for the check."""
+    kernels clamp).  Without `block` only checks whose result has already arrived in pinned host memory are read: the step never waits
+    for the check and never synchronises the device."""
     if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
         return
-    keep = []
-    for ev, cnt, msg in _index_checks:
-        if block or ev.query():
-            if int(cnt.item()) != 0:
-                _index_checks.clear()
-                raise IndexError(msg)
-        else:
-            keep.append((ev, cnt, msg))
-    _index_checks[:] = keep
+    for slots in _index_slots.values():
+        slots.poll(block)
 
 
 def index_check(idx, n_rows, what):
@@ -437,11 +468,17 @@ def index_check(idx, n_rows, what):
     poll_index_checks()
     if torch.cuda.is_current_stream_capturing():
         return                                           # (a captured step replays with fresh data nobody checks: validate before capturing)
-    cnt = torch.zeros(1, dtype=torch.int32, device=idx.device)
+    di = idx.device.index if idx.device.index is not None else torch.cuda.current_device()
+    slots = _index_slots.get(di)
+    if slots is None:
+        slots = _index_slots[di] = _IndexCheckSlots(idx.device)
+    k = slots.acquire()
+    cnt = slots.dev[k:k + 1]
+    cnt.zero_()
     _lib.call("snerf_index_check", _p(idx), idx.numel(), int(n_rows), _p(cnt), _stream())
-    ev = torch.cuda.Event()
-    ev.record()
-    _index_checks.append((ev, cnt, f"{what}: index out of range for a table of {n_rows} rows (torch.nn.Embedding raises here; the kernel clamped)"))
+    slots.host[k:k + 1].copy_(cnt, non_blocking=True)
+    slots.events[k].record()
+    slots.msgs[k] = f"{what}: index out of range for a table of {n_rows} rows (torch.nn.Embedding raises here; the kernel clamped)"
 
 
 def app_embed(emb, app, S, dst, dt, sample_id=None, check=True):
@@ -632,7 +669,7 @@ NONFINITE = {"keep": 0, "zero": 1, "nan_to_num": 2}
 
 
 def adam_step(p, g, m, v, lr, b1, b2, eps, step, grad_scale=1.0, zero_grad=True, nonfinite="zero", grad_max_val=0.0, clip_coef=None,
-              step_dev=None, lr_dev=None):
+              step_dev=None, lr_dev=None, dropped=None):
     """Fused Adam over a flat arena (snerf_adam_step_ex).  Gradient hygiene in the reference's order (train_utils.py:234-243):
     `clip_coef` (device float, see grad_clip_coef) -> value clip `grad_max_val` -> `nonfinite` policy ("zero": NaN/Inf gradients are
     dropped so that they can never poison m, v or the parameters; "nan_to_num": torch's nan_to_num_ exactly; "keep": plain Adam).
@@ -645,9 +682,11 @@ def adam_step(p, g, m, v, lr, b1, b2, eps, step, grad_scale=1.0, zero_grad=True,
         assert lr_dev.dtype == torch.float32 and lr_dev.is_cuda and lr_dev.numel() == 1
     if clip_coef is not None:
         assert clip_coef.dtype == torch.float32 and clip_coef.is_cuda
-    _lib.call("snerf_adam_step_ex", _p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(b1), float(b2), float(eps), int(step),
+    if dropped is not None:     # int64 [1] on the device: += the number of NaN / +-Inf gradient elements of this launch (never reset here)
+        assert dropped.dtype == torch.int64 and dropped.is_cuda and dropped.numel() == 1
+    _lib.call("snerf_adam_step_cnt", _p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(b1), float(b2), float(eps), int(step),
               _p(step_dev), _p(lr_dev), float(grad_scale), 1 if zero_grad else 0, NONFINITE[nonfinite], float(grad_max_val), _p(clip_coef),
-              _stream())
+              _p(dropped), _stream())
 
 
 def adam_step_dev(p, g, m, v, lr, b1, b2, eps, step_dev, grad_scale=1.0, zero_grad=True, **kw):

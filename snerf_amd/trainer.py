@@ -97,6 +97,8 @@ class _AdamState:
         sd = {"state": state, "param_groups": [group], "param_names": names}
         if getattr(self, "scaler", None) is not None:
             sd["loss_scaler"] = self.scaler.state_dict()
+        elif getattr(self, "loss_scale", None) is not None:
+            sd["static_loss_scale"] = float(self.loss_scale)
         return sd
 
     def load_state_dict(self, sd):
@@ -128,7 +130,11 @@ class _AdamState:
         for g in groups[1:]:                                # one launch, one set of hyper-parameters
             if (float(g["lr"]), tuple(g["betas"]), float(g["eps"])) != (float(g0["lr"]), tuple(g0["betas"]), float(g0["eps"])):
                 raise ValueError("the fused Adam launch covers the whole arena with one lr / betas / eps: the saved param_groups differ")
-        self.lr, self.betas, self.eps = float(g0["lr"]), tuple(float(b) for b in g0["betas"]), float(g0["eps"])
+        new_betas, new_eps = tuple(float(b) for b in g0["betas"]), float(g0["eps"])
+        if getattr(self, "_graph", None) is not None and (new_betas != tuple(float(b) for b in self.betas) or new_eps != float(self.eps)):
+            # betas / eps are host kernel arguments baked into the captured hipGraph (lr and the step count live on the device)
+            raise ValueError("load_state_dict after capture(): the checkpoint's betas / eps differ from the captured step's -- load before capturing")
+        self.lr, self.betas, self.eps = float(g0["lr"]), new_betas, new_eps
         if float(g0.get("weight_decay", 0) or 0) != 0 or g0.get("amsgrad", False):
             raise ValueError("the fused Adam launch has no weight decay / amsgrad")
         if getattr(self, "_step_dev", None) is not None:
@@ -136,6 +142,10 @@ class _AdamState:
         if getattr(self, "scaler", None) is not None and "loss_scaler" in sd:
             self.scaler.load_state_dict(sd["loss_scaler"])
             self.loss_scale = self.scaler.scale
+        elif getattr(self, "scaler", None) is None and "static_loss_scale" in sd and getattr(self, "loss_scale", None) is not None \
+                and float(sd["static_loss_scale"]) != float(self.loss_scale):
+            import warnings
+            warnings.warn(f"resuming with a static loss scale of {self.loss_scale:g}; the checkpoint was trained with {float(sd['static_loss_scale']):g}")
 
 
 class MipTrainer(_AdamState):
@@ -316,7 +326,9 @@ class _TableShards:
     optimiser pass), ALL-GATHER of the updated parameter slices.  Same bytes on the wire as the all-reduce it replaces (a ring all-reduce
     is exactly these two phases) with the optimiser work of the tables sharded; the MLP parameters keep the bucketed all-reduce.
     Level sizes are multiples of 8 rows (grid.py:130), so the spans divide evenly for world sizes 2 / 4 / 8; other world sizes, and
-    global-norm clipping (which needs the norm of the whole reduced gradient), use the all-reduce path."""
+    global-norm clipping (which needs the norm of the whole reduced gradient), use the all-reduce path.  A rank's slice of a
+    single-channel table is NOT a multiple of 4 floats at world 4 / 8 (6 606 952 / 8 = 825 869): ops.adam_step takes its four
+    pointers at any 4-byte alignment (scalar flavour of the kernel; tests/test_gpu_kernels.py::test_adam_on_misaligned_slices...)."""
 
     def __init__(self, arena, names, world, group):
         self.arena, self.world, self.group = arena, world, group
@@ -418,7 +430,8 @@ class ZipTrainer(_AdamState):
         """`loss_scale` (a number = static; default 4096 when the model computes in fp16, else 1): the gradients of the rendered outputs are
         multiplied by it before the backward -- so that the fp16 gradient buffers of the networks stay in fp16's normal range -- and the
         factor is undone inside the Adam launch (grad_scale), before clipping.  Overflowed (non-finite) gradients are dropped by
-        `nonfinite`.  `loss_scale="dynamic"` (or a LossScaler): torch's GradScaler policy -- one pass over the gradient arena after the
+        `nonfinite` and counted in `dropped_nonfinite` (device int64: watch it in fp16 runs -- GradScaler would have skipped those steps).
+        `loss_scale="dynamic"` (or a LossScaler): torch's GradScaler policy -- one pass over the gradient arena after the
         exchange (snerf_nonfinite_flag, + a 4-byte MAX all-reduce when the tables are sharded), ONE device->host read of the flag per
         step (as GradScaler.step does), a step with an overflow is skipped whole (parameters, m, v and the step count t untouched,
         gradients zeroed) and halves the scale; `scaler.skipped_steps` counts them.  The static scale keeps the step free of host syncs.
@@ -437,6 +450,9 @@ class ZipTrainer(_AdamState):
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.last_losses = None
+        # running count of NaN / +-Inf gradient elements the Adam launches met (device int64, no host sync; read it when logging): a
+        # persistently overflowing fp16 run with the static scale looks healthy otherwise -- the `nonfinite` policy drops them silently
+        self.dropped_nonfinite = torch.zeros(1, dtype=torch.int64, device=a.flat.device)
         self.scaler = LossScaler() if isinstance(loss_scale, str) and loss_scale == "dynamic" else (loss_scale if isinstance(loss_scale, LossScaler) else None)
         if isinstance(loss_scale, str) and self.scaler is None:
             raise ValueError(f"loss_scale: a number, 'dynamic' or a LossScaler, not {loss_scale!r}")
@@ -552,11 +568,12 @@ class ZipTrainer(_AdamState):
         self.t += 1
         adam = lambda lo, hi, g=None: ops.adam_step(a.flat[lo:hi], a.grad[lo:hi] if g is None else g, self.m[lo:hi], self.v[lo:hi], self.lr, self.betas[0],
                                                     self.betas[1], self.eps, self.t, grad_scale=1.0 / (self.world * ls), zero_grad=True,
-                                                    nonfinite=self.nonfinite, grad_max_val=self.grad_max_val)
+                                                    nonfinite=self.nonfinite, grad_max_val=self.grad_max_val, dropped=self.dropped_nonfinite)
         if sh is None:
             coef = ops.grad_clip_coef(a.grad, 1.0 / (self.world * ls), self.grad_max_norm) if self.grad_max_norm > 0 else None
             ops.adam_step(a.flat, a.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.t,
-                          grad_scale=1.0 / (self.world * ls), zero_grad=True, nonfinite=self.nonfinite, grad_max_val=self.grad_max_val, clip_coef=coef)
+                          grad_scale=1.0 / (self.world * ls), zero_grad=True, nonfinite=self.nonfinite, grad_max_val=self.grad_max_val, clip_coef=coef,
+                          dropped=self.dropped_nonfinite)
         else:
             # tables: this rank's slice only, then the updated slices are gathered; everything between the table spans: the usual pass
             for name, lo, hi, gshard in mine:

@@ -231,7 +231,9 @@ def classic_composite_bwd(raw, noise, z_vals, rays_d, white, weights, acc, depth
 
 
 def adam_step(p, g, m, v, lr, b1, b2, eps, step, grad_scale=1.0, zero_grad=True, nonfinite="zero", grad_max_val=0.0, clip_coef=None,
-              step_dev=None, lr_dev=None):
+              step_dev=None, lr_dev=None, dropped=None):
+    if dropped is not None:
+        dropped += int((~torch.isfinite(g)).sum())
     if step_dev is not None:
         step_dev += 1
         step = int(step_dev)

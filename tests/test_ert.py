@@ -128,6 +128,8 @@ def test_front_to_back_ert_is_exact_without_termination_and_bounded_by_eps():
     for a, b, c in zip(full[1], same[1], same48[1]):
         if a is not None:
             assert torch.equal(a, b) and torch.equal(a, c)
+    with torch.no_grad(), pytest.raises(ValueError, match="eps_t < 1"):      # eps_t >= 1 used to end in torch.cat([])
+        m(rays, False, False, 0., ert=(1.0, 0.0, 32))
     with torch.no_grad():                                                   # make the medium opaque: rays now end inside the sampled range
         p = dict(m.named_parameters())
         p["proposal.density_layer.bias"] += 6.0

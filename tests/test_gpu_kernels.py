@@ -443,6 +443,38 @@ def test_adam_and_small_ops(ops):
     close(dst[:, 32].float(), x[:, 3].bfloat16().float(), 0, 0, "cast"); assert bool((dst[:, 33:] == 0).all()) and bool((dst[:, :32] == 3).all())
 
 
+@pytest.mark.gpu
+def test_adam_on_misaligned_slices_matches_aligned():
+    """a rank's 1 / world slice of a single-channel hash table starts at an odd float (ZipTrainer's sharded table update at world
+    sizes 4 and 8: 6 606 952 / 8 = 825 869): the launch must take p / g / m / v at any 4-byte alignment, each with its own, and give
+    exactly the update of the aligned launch (trainer._TableShards)"""
+    from snerf_amd import ops
+    n = 825869
+    base = [gen(n + 8, seed=30 + k).cuda() for k in range(4)]
+    base[3].abs_()
+    ref = [b[:n].clone() for b in base]
+    ops.adam_step(*ref, 1e-2, 0.9, 0.99, 1e-15, 3, grad_scale=0.25, zero_grad=True)
+    for offs in ((1, 0, 1, 1), (2, 0, 2, 2), (3, 1, 2, 0), (1, 1, 1, 1)):
+        bufs = [torch.zeros(n + 8, device="cuda") for _ in range(4)]
+        views = [bufs[k][o:o + n] for k, o in enumerate(offs)]
+        for vw, b in zip(views, base):
+            vw.copy_(b[:n])
+        ops.adam_step(*views, 1e-2, 0.9, 0.99, 1e-15, 3, grad_scale=0.25, zero_grad=True)
+        for k in (0, 2, 3):
+            assert torch.equal(views[k], ref[k]), (offs, k)
+            assert float(bufs[k][:offs[k]].abs().max() if offs[k] else 0.0) == 0.0 and float(bufs[k][offs[k] + n:].abs().max()) == 0.0
+        assert float(views[1].abs().max()) == 0.0
+    # the dropped-gradient counter (snerf_adam_step_cnt): NaN / +-Inf elements are counted, whatever the policy does with them
+    p, g, m, v = (b[:4099].clone() for b in base)
+    v.abs_()
+    g[5], g[4097], g[4098] = float("inf"), float("nan"), float("-inf")
+    p0, cnt = p.clone(), torch.zeros(1, dtype=torch.int64, device="cuda")
+    for _ in range(2):
+        g[5], g[4097], g[4098] = float("inf"), float("nan"), float("-inf")
+        ops.adam_step(p, g, m, v, 1e-2, 0.9, 0.99, 1e-15, 1, nonfinite="zero", dropped=cnt)
+    assert int(cnt) == 6 and bool(torch.isfinite(p).all()) and float(p[5]) == float(p0[5]) if float(m[5]) == 0 else True
+
+
 # ---------------------------------------------------------------- ray gradients (pose refinement) ----
 def _pose_rays(n, seed, far_scene=True):
     """rays whose samples straddle the contraction radius (|x| around 3) so that both branches of fn2 / Jacobi_g are exercised"""
