@@ -1,7 +1,7 @@
 """Run-to-run determinism of the kernels that have no atomics on their path: repeated launches on identical inputs must be bit-identical,
 also with a vendor GEMM interleaved (different clocks, cache and register state).  Round 2 found a rare (1e-3 per launch), timing-dependent
 wrong operand in one instantiation of the fused MLP kernel this way -- an inline-asm VALU instruction right in front of an MFMA (see
-csrc/fmlp.hip to_frags, tools/probes/mfma_war_probe.hip); the longer screens are tools/stress_*.py (and a `-DFMLP_LOCKSTEP_START` build of tools/probes/fmlp_experiments.hip in place of
+csrc/fmlp.hip to_frags, tools/probes/mfma_war_probe.hip); the longer screens are tools/stress_*.py (and a `-DFMLP_LOCKSTEP_START` build of the round-3 fmlp.hip (`git show 3a38ce5:tools/probes/fmlp_experiments.hip`) in place of
 fmlp.hip, which turns such a hazard from rare into certain)."""
 import pytest
 import torch
