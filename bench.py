@@ -378,6 +378,72 @@ def path_c_leg(device, n_rays=65536, steps=5, compute="fp16", also=("bf16",)):
     return out
 
 
+def grid_encoder_leg(device, R=65536, S=32, n=7, steps=3):
+    """The reference's only native FFI as a stand-alone operator (gridencoder/grid.py:24-89 -> bindings.cpp:5-9): GridEncoder of the NeRF
+    level (L = 10, C = 4, H = 16 -> 8192, T = 2^21: internal/models.py:381-386) on B = 65 536 x 32 x 7 points under fp16 autocast (half
+    table, half gradients: grid.py:41-44), forward + backward through the module's autograd Function.  Points in the order the
+    reference's callers pass them (the 7 helix multisamples of an interval one after the other, contracted: models.py:488-494).
+    Timed: the corner-cached gather + binned table gradient (default) and, beside it, the one-thread-per-(point, level) gather + atomic
+    scatter of kernel_grid / kernel_grid_backward's restatement (SNERF_GRID_FAST=0), same inputs."""
+    from snerf_amd import ops
+    from snerf_amd.gridencoder import GridEncoder
+    L, C = 10, 4
+    g = torch.Generator(device=device).manual_seed(3)
+    o = torch.randn(R, 1, 1, 3, generator=g, device=device) * 0.05
+    d = torch.nn.functional.normalize(torch.randn(R, 1, 1, 3, generator=g, device=device), dim=-1)
+    edges = torch.exp(torch.linspace(math.log(0.1), math.log(30.0), S + 1, device=device))
+    t0, t1 = edges[:-1].view(1, S, 1, 1), edges[1:].view(1, S, 1, 1)
+    j = (torch.arange(n, device=device, dtype=torch.float32) + 0.5).view(1, 1, n, 1) / n
+    t = t0 + (t1 - t0) * j
+    ang = 2 * math.pi * 3 * j
+    e1 = torch.nn.functional.normalize(torch.cross(d, torch.tensor([0.0, 0.0, 1.0], device=device).expand_as(d), dim=-1), dim=-1)
+    e2 = torch.cross(d, e1, dim=-1)
+    x = o + d * t + 1.5e-3 * t * (torch.cos(ang) * e1 + torch.sin(ang) * e2)
+    mag = x.norm(dim=-1, keepdim=True).clamp(min=1e-6)
+    x = torch.where(mag <= 1, x, (2 - 1 / mag) * x / mag) / 2                       # contraction into the ball of radius 2, halved: [-1, 1]^3
+    x = x.reshape(-1, 3).contiguous()
+    B = x.shape[0]
+    enc = GridEncoder(input_dim=3, num_levels=L, level_dim=C, base_resolution=16, desired_resolution=8192, log2_hashmap_size=21, device=device)
+    with torch.no_grad():
+        enc.embeddings.uniform_(-0.1, 0.1)
+    w = (torch.randn(B, L * C, generator=g, device=device) * 1e-3).half()
+
+    def fwd_bwd():
+        enc.embeddings.grad = None
+        with torch.autocast("cuda", dtype=torch.float16):
+            y = enc(x, bound=1)
+        y.backward(w)
+
+    def fwd_only():
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            enc(x, bound=1)
+    res = {}
+    try:
+        for name, fast, k in (("fast", True, steps), ("reference_form", False, 1)):
+            ops.grid_set_fast_path(fast)
+            f_ms = _timeit(fwd_only, k, warm=1) * 1e3
+            fb_ms = _timeit(fwd_bwd, k, warm=1) * 1e3
+            res[name] = (f_ms, fb_ms - f_ms, enc.embeddings.grad.clone())
+    finally:
+        ops.grid_set_fast_path(True)
+    gf, gs = res["fast"][2], res["reference_form"][2]
+    useful = B * L * 8 * C * 2                                                # 8 corner rows of C halves per (point, level)
+    out = {"workload": f"GridEncoder (L = {L}, C = {C}, T = 2^21, 16 -> 8192; half table under autocast) forward + backward on B = {R} x {S} x {n} = {B} "
+                       "ray-ordered contracted multisample points; autograd through snerf_amd.gridencoder (the drop-in of gridencoder/grid.py)",
+           "points": B, "fwd_ms": round(res["fast"][0], 3), "bwd_ms": round(res["fast"][1], 3),
+           "reference_form_fwd_ms": round(res["reference_form"][0], 3), "reference_form_bwd_ms": round(res["reference_form"][1], 3),
+           "bwd_speedup_vs_atomic_scatter": round(res["reference_form"][1] / res["fast"][1], 2),
+           "fwd_speedup_vs_per_point_gather": round(res["reference_form"][0] / res["fast"][0], 2),
+           "table_gradient_rel_l2_fast_vs_atomic": float((gf - gs).norm() / gs.norm()),
+           "roofline": {"bound": "hbm", "kernel": "g3_fwd_kernel<_Float16, 4> (corner-cached hash-grid gather)", "achieved": round(useful / (res["fast"][0] * 1e-3) / 1e9, 1),
+                        "peak": 8000.0, "unit": "GB/s", "frac": round(useful / (res["fast"][0] * 1e-3) / 1e9 / 8000.0, 4), "useful_bytes_per_launch": useful,
+                        "traffic": None, "note": "useful bytes = 8 corner rows x 8 B per (point, level); the backward moves the same payload as records"},
+           "bwd_useful_GBps": round(useful / (res["fast"][1] * 1e-3) / 1e9, 1)}
+    del enc, x, w, res, gf, gs
+    torch.cuda.empty_cache()
+    return out
+
+
 def path_b_leg(device, n_rays=32768, steps=5, compute="bf16"):
     """The classic render_rays path (path B, behind the signatures north_star names): 64 coarse + 192 fine evaluations per ray through two
     NeRF 8 x 256 networks, autograd through the drop-in operators + torch.optim.Adam (the route of render.py:281-409 callers)."""
@@ -624,6 +690,9 @@ def main():
         t0 = time.perf_counter()
         out["path_b"] = path_b_leg(device)
         out["path_b"]["leg_wall_s"] = round(time.perf_counter() - t0, 1)
+        t0 = time.perf_counter()
+        out["grid_encoder"] = grid_encoder_leg(device)
+        out["grid_encoder"]["leg_wall_s"] = round(time.perf_counter() - t0, 1)
 
     # ---- early ray termination on a scene with real opacity (north_star: "early ray termination and sample compaction"):
     # a fresh model fitted for 200 steps to an analytic street scene (tools/ert_scene.py), its 1600 x 900 frame rendered plain and with

@@ -39,6 +39,17 @@ __device__ __forceinline__ uint32_t grid_index(int gridtype, bool align, uint32_
   return index % hashmap_size;
 }
 
+// grid position of one coordinate on a level (gridencoder.cu:148): product and sum rounded separately -- like the CPU oracle's fp32 ops
+// and like zip.hip's zip_cell, so that the corner-cached forward and the binned table gradient (zip.hip: g3_*) land in the same cell
+// with the same fractions as the kernels of this file
+__device__ __forceinline__ void grid_cell(float x, float scale, float shift, uint32_t* pg, float* fr) {
+#pragma clang fp contract(off)
+  const float ps = x * scale + shift;
+  const float fl = floorf(ps);
+  *pg = (uint32_t)fl;
+  *fr = ps - fl;
+}
+
 template <typename T, int C> struct alignas(sizeof(T) * C) VecC { T v[C]; };
 
 // arithmetic type of the channel values: the reference accumulates in the table's scalar type (results[ch] += w * grid[...] with a
@@ -62,6 +73,7 @@ struct GridArgs {
 
 template <typename T, int D, int C>
 __global__ __launch_bounds__(256) void grid_fwd_kernel(GridArgs a) {
+#pragma clang fp contract(off)        // products and sums rounded one by one, like the CPU oracle and like zip.hip's g3_fwd_kernel (bit-identical outputs)
   const int b = blockIdx.x * 256 + threadIdx.x;
   if (b >= a.B) return;
   const int level = blockIdx.y;
@@ -85,10 +97,8 @@ __global__ __launch_bounds__(256) void grid_fwd_kernel(GridArgs a) {
   uint32_t pg[D];
 #pragma unroll
   for (int d = 0; d < D; ++d) {
-    float p = x[d] * scale + (a.align ? 0.f : 0.5f);
-    const float fl = floorf(p);
-    pg[d] = (uint32_t)fl;
-    p -= fl;
+    float p;
+    grid_cell(x[d], scale, a.align ? 0.f : 0.5f, &pg[d], &p);
     if (a.interp == 1) { pder[d] = 6.f * p * (1.f - p); p = p * p * (3.f - 2.f * p); } else pder[d] = 1.f;
     pos[d] = p;
   }
@@ -189,10 +199,8 @@ __global__ __launch_bounds__(256) void grid_bwd_kernel(GridBwdArgs a) {
   uint32_t pg[D];
 #pragma unroll
   for (int d = 0; d < D; ++d) {
-    float p = x[d] * scale + (a.align ? 0.f : 0.5f);
-    const float fl = floorf(p);
-    pg[d] = (uint32_t)fl;
-    p -= fl;
+    float p;
+    grid_cell(x[d], scale, a.align ? 0.f : 0.5f, &pg[d], &p);
     if (a.interp == 1) p = p * p * (3.f - 2.f * p);
     pos[d] = p;
   }
@@ -254,7 +262,7 @@ __global__ __launch_bounds__(256) void grid_tv_kernel(const float* __restrict__ 
   const uint32_t res = (uint32_t)ceilf(scale) + 1;
   uint32_t pg[D];
 #pragma unroll
-  for (int d = 0; d < D; ++d) pg[d] = (uint32_t)floorf(x[d] * scale + (align ? 0.f : 0.5f));
+  for (int d = 0; d < D; ++d) { float fr_unused; grid_cell(x[d], scale, align ? 0.f : 0.5f, &pg[d], &fr_unused); }
   const uint32_t index = grid_index<D>(gridtype, align, hs, res, pg);
   typedef typename Acc<T>::type A;
   A v0[C], results[C], idelta[C];
@@ -322,11 +330,23 @@ template <typename T, int D, int C> static void launch_tv(const float* in, const
   hipLaunchKernelGGL((grid_tv_kernel<T, D, C>), dim3((B + 255) / 256, L), dim3(256), 0, s, in, (const T*)tab, (T*)grad, off, w, B, S, H, gt, al);
 }
 
+int g3_fwd_launch(const float* inputs, const void* table, const int* offsets, void* outputs, long B, int C, int L, float S, int H, int dtype,
+                  long s_l, long s_b, hipStream_t s);                       // zip.hip
+extern int g3_fwd_group;
+static int g_grid_fast_path = 1;
+// A/B switch of the measurement legs and the parity tests (0: kernel_grid's one-thread-per-(point, level) form for every instantiation;
+// 2 / 4 / 8 (probes): that many consecutive points per thread in the fast gather, a cell's corners kept across them)
+extern "C" int snerf_grid_set_fast_path(int on) { g_grid_fast_path = on != 0; g3_fwd_group = (on == 2 || on == 4 || on == 8) ? on : 1; return SNERF_OK; }
+
 extern "C" int snerf_grid_encode_fwd(const float* inputs, const void* embeddings, const int* offsets, void* outputs, int B, int D, int C,
                                      int L, float S, int H, void* dy_dx, int gridtype, int align_corners, int interp, int dtype,
                                      long out_stride_l, long out_stride_b, void* stream) {
   if (B <= 0) return SNERF_OK;
   if (L <= 0 || inputs == nullptr || embeddings == nullptr || offsets == nullptr || outputs == nullptr) return SNERF_ERR_ARG;
+  // the instantiations zipnerf constructs (D = 3, C = 4 / 1, hash, linear, float / half) without dy_dx: the corner-cached gather of zip.hip
+  if (D == 3 && (C == 1 || C == 4) && gridtype == 0 && !align_corners && interp == 0 && dy_dx == nullptr &&
+      (dtype == SNERF_DT_F32 || dtype == SNERF_DT_F16) && g_grid_fast_path)
+    return g3_fwd_launch(inputs, embeddings, offsets, outputs, B, C, L, S, H, dtype, out_stride_l, out_stride_b, (hipStream_t)stream);
   GridArgs a{inputs, embeddings, offsets, outputs, dy_dx, out_stride_l, out_stride_b, B, L, S, H, gridtype, align_corners, interp};
   GRID_DISPATCH(launch_fwd, (a, (hipStream_t)stream))
   return snerf_check_launch();

@@ -1679,7 +1679,9 @@ __global__ __launch_bounds__(256, NSUB == 8 ? 4 : 3) void zip_bin_write_staged_k
   }
 }
 
-template <int C, bool HREC = false>
+// GT: type of the gradient table the rows are added to (fp32 everywhere but the stand-alone GridEncoder's half tables, whose
+// reference contract is a gradient in the table's dtype)
+template <int C, bool HREC = false, typename GT = float>
 __global__ __launch_bounds__(1024) void zip_bin_accumulate_kernel(ZipEnc a, ZipBin b) {
   extern __shared__ long long zb_acc[];
   const int level = blockIdx.y, bin = blockIdx.x;
@@ -1758,11 +1760,11 @@ __global__ __launch_bounds__(1024) void zip_bin_accumulate_kernel(ZipEnc a, ZipB
   __syncthreads();
   const long grow = (long)a.offsets[level] + row0;
   if (K == 1) {                                             // the only workgroup that owns these rows
-    float* dst = a.grad_table + grow * C;
+    GT* dst = (GT*)a.grad_table + grow * C;
     for (int k = threadIdx.x; k < cells; k += 1024) {
       const long long v = zb_acc[k];
       const int kk = C == 4 ? (k ^ ((k >> 5) & 3)) : k;     // (undo the slot swizzle: row = k >> 2, its (row >> 3) & 3 = (k >> 5) & 3)
-      if (v != 0) dst[kk] += (float)((double)v * unfix);
+      if (v != 0) dst[kk] = (GT)((float)dst[kk] + (float)((double)v * unfix));
     }
   } else {
     long long* dst = b.g64 + grow * C;
@@ -1774,11 +1776,12 @@ __global__ __launch_bounds__(1024) void zip_bin_accumulate_kernel(ZipEnc a, ZipB
   }
 }
 
-__global__ __launch_bounds__(256) void zip_bin_finish_kernel(const long long* __restrict__ g64, long n, float* __restrict__ grad, const int* __restrict__ scale_exp) {
+template <typename GT = float>
+__global__ __launch_bounds__(256) void zip_bin_finish_kernel(const long long* __restrict__ g64, long n, GT* __restrict__ grad, const int* __restrict__ scale_exp) {
   const double unfix = exp2((double)-scale_exp[0]);
   for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < n; k += (long)gridDim.x * 256) {
     const long long v = g64[k];
-    if (v != 0) grad[k] += (float)((double)v * unfix);
+    if (v != 0) grad[k] = (GT)((float)grad[k] + (float)((double)v * unfix));
   }
 }
 
@@ -1801,8 +1804,9 @@ __global__ __launch_bounds__(256) void zip_bin_absmax_kernel(const OT* __restric
 // an overflowed feature gradient (fp16 compute mode: +-Inf / NaN in grad_feat) cannot be scaled into fixed point: the level's records
 // are meaningless.  Mark the table gradient by a NaN in its first element so that whoever checks the gradients for overflow (a
 // dynamic loss scaler: snerf_nonfinite_flag, or torch's GradScaler.unscale_) skips the step; the static policy drops it in Adam.
-__global__ void zip_bin_overflow_mark_kernel(float* __restrict__ grad, const int* __restrict__ scale_exp) {
-  if ((unsigned)scale_exp[1] >= 0x7f800000u) grad[0] = __builtin_nanf("");
+template <typename GT = float>
+__global__ void zip_bin_overflow_mark_kernel(GT* __restrict__ grad, const int* __restrict__ scale_exp) {
+  if ((unsigned)scale_exp[1] >= 0x7f800000u) grad[0] = (GT)__builtin_nanf("");
 }
 __global__ void zip_bin_scale_kernel(int* scale_exp) {
   const unsigned bits = (unsigned)scale_exp[1];
@@ -1828,6 +1832,30 @@ extern "C" int snerf_zip_bin_scale(const void* grad_feat, long ld, long rows, in
     else return SNERF_ERR_ARG;
   }
   hipLaunchKernelGGL(zip_bin_scale_kernel, dim3(1), dim3(1), 0, s, scale_exp);
+  return snerf_check_launch();
+}
+
+// pass 2 of the binned table gradient: one workgroup per bin, the replicated levels' int64 image folded, the overflow mark
+template <typename GT>
+static int zb_accumulate_launch(const ZipEnc& a, const ZipBin& b, int C, int L, bool hrec, hipStream_t s) {
+  const size_t lds = (size_t)(1 << b.bshift) * C * 8;
+  const dim3 grid(ZB_NBMAX, L);
+  if (hrec && C == 4) {
+    (void)hipFuncSetAttribute((const void*)zip_bin_accumulate_kernel<4, true, GT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((zip_bin_accumulate_kernel<4, true, GT>), grid, dim3(1024), lds, s, a, b);
+  } else if (hrec) {
+    (void)hipFuncSetAttribute((const void*)zip_bin_accumulate_kernel<1, true, GT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((zip_bin_accumulate_kernel<1, true, GT>), grid, dim3(1024), lds, s, a, b);
+  } else if (C == 4) {
+    (void)hipFuncSetAttribute((const void*)zip_bin_accumulate_kernel<4, false, GT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((zip_bin_accumulate_kernel<4, false, GT>), grid, dim3(1024), lds, s, a, b);
+  } else {
+    (void)hipFuncSetAttribute((const void*)zip_bin_accumulate_kernel<1, false, GT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((zip_bin_accumulate_kernel<1, false, GT>), grid, dim3(1024), lds, s, a, b);
+  }
+  if (b.g64 != nullptr && b.g64_rows > 0)
+    hipLaunchKernelGGL(zip_bin_finish_kernel<GT>, dim3(1024), dim3(256), 0, s, (const long long*)b.g64, b.g64_rows * C, (GT*)a.grad_table, b.scale_exp);
+  hipLaunchKernelGGL(zip_bin_overflow_mark_kernel<GT>, dim3(1), dim3(1), 0, s, (GT*)a.grad_table, b.scale_exp);
   return snerf_check_launch();
 }
 
@@ -1889,25 +1917,320 @@ extern "C" int snerf_zip_encode_bwd_binned(int pass, const float* tdist, const f
     return snerf_check_launch();
   }
   if (pass != 2 || starts == nullptr || rec_row == nullptr || rec_val == nullptr || grad_table == nullptr || scale_exp == nullptr) return SNERF_ERR_ARG;
-  const size_t lds = (size_t)(1 << b.bshift) * C * 8;
-  const dim3 grid(ZB_NBMAX, L);
-  if (hrec && C == 4) {
-    (void)hipFuncSetAttribute((const void*)zip_bin_accumulate_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((zip_bin_accumulate_kernel<4, true>), grid, dim3(1024), lds, s, a, b);
-  } else if (hrec) {
-    (void)hipFuncSetAttribute((const void*)zip_bin_accumulate_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((zip_bin_accumulate_kernel<1, true>), grid, dim3(1024), lds, s, a, b);
-  } else if (C == 4) {
-    (void)hipFuncSetAttribute((const void*)zip_bin_accumulate_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((zip_bin_accumulate_kernel<4>), grid, dim3(1024), lds, s, a, b);
-  } else {
-    (void)hipFuncSetAttribute((const void*)zip_bin_accumulate_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((zip_bin_accumulate_kernel<1>), grid, dim3(1024), lds, s, a, b);
+  return zb_accumulate_launch<float>(a, b, C, L, hrec, s);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The stand-alone GridEncoder (the reference's only native FFI: gridencoder/src/bindings.cpp:5-9) on the same machinery, for the
+// instantiations zipnerf constructs (internal/models.py:413-421): D = 3, hash grid type, linear interpolation, align_corners = False,
+// C = 4 (NeRF grid) / 1 (proposal grids), float or half table.  Arbitrary points [B, 3] in [0, 1]^3 instead of ray geometry:
+//   forward   g3_fwd_kernel       one thread per (G3 = 8 consecutive points, level): a cell's eight corner entries stay in registers while
+//             consecutive points fall into it (the reference's callers pass the 7 multisamples of an interval one after the other:
+//             always one cell on the coarse levels), x-neighbour corners as ONE 4- / 8- / 16-byte load where their rows are adjacent
+//             -- kernel_grid (gridencoder.cu:87-245) fetches 8 rows per (point, level) whatever the neighbours did;
+//   backward  g3_bin_emit_kernel  the binned table gradient above fed from points: a run of consecutive points in one cell becomes 8
+//             RECORDS (row, sum of w x grad over the run); count -> device scan -> write -> LDS fixed-point accumulation, in ONE
+//             C-ABI call on a caller-provided workspace (no atomics on the table, bit-reproducible) -- kernel_grid_backward
+//             (gridencoder.cu:248-340) issues 8 x C / 2 half2 atomics per (point, level): 20.6 G atomics/s on this part.
+// Everything else (D != 3, C = 2 / 8, tiled, smoothstep, align_corners, double, dy_dx) stays in grid.hip.
+// ------------------------------------------------------------------------------------------------------------------
+#define G3_PTS 8
+struct G3Args {
+  const float* inputs; long B;
+  const void* table; const int* offsets;
+  void* io; long s_l, s_b;                 // forward: outputs; backward: the incoming gradient; strides (elements) of the level / point axes
+  int L; float Sl; int H;
+};
+
+template <typename TT, int C, int G>
+__global__ __launch_bounds__(256) void g3_fwd_kernel(G3Args a) {
+#pragma clang fp contract(off)        // every product and sum rounded on its own: the same bits as grid.hip's grid_fwd_kernel whatever the compiler fuses elsewhere
+  const int level = blockIdx.y;
+  const long p0 = ((long)blockIdx.x * 256 + threadIdx.x) * G;
+  if (p0 >= a.B) return;
+  const uint32_t hs = a.offsets[level + 1] - a.offsets[level];
+  const float scale = exp2f(level * a.Sl) * a.H - 1.0f;
+  const uint32_t res = (uint32_t)ceilf(scale) + 1;
+  const TT* tab = (const TT*)a.table + (long)a.offsets[level] * C;
+  uint32_t cur[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
+  ZVec<TT, C> ce[8];
+#pragma unroll
+  for (int j = 0; j < G; ++j) {
+    const long p = p0 + j;
+    if (p >= a.B) break;
+    TT* out = (TT*)a.io + level * a.s_l + p * a.s_b;
+    float x[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) x[k] = a.inputs[p * 3 + k];
+    if (x[0] < 0.f || x[0] > 1.f || x[1] < 0.f || x[1] > 1.f || x[2] < 0.f || x[2] > 1.f) {   // (a NaN coordinate passes, as in kernel_grid)
+#pragma unroll
+      for (int c = 0; c < C; ++c) out[c] = (TT)0.f;
+      continue;
+    }
+    float fr[3];
+    uint32_t pg[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) zip_cell(x[k], scale, &pg[k], &fr[k]);
+    const bool newcell = G == 1 || pg[0] != cur[0] || pg[1] != cur[1] || pg[2] != cur[2];
+    cur[0] = pg[0]; cur[1] = pg[1]; cur[2] = pg[2];
+    if (newcell) {
+#pragma unroll
+      for (int yz = 0; yz < 4; ++yz) {
+        uint32_t pl[3] = {pg[0], pg[1] + (yz & 1), pg[2] + (yz >> 1)};
+        const long r0 = zip_grid_index(hs, res, pl);
+        pl[0] = pg[0] + 1;
+        const long r1 = zip_grid_index(hs, res, pl);
+        // x-neighbours in adjacent rows (always on dense levels with an even row, every even x of a hashed level: the hash multiplies x
+        // by 1) arrive as ONE aligned load of both entries
+        if ((r0 ^ r1) == 1 && sizeof(TT) * C <= 8) {
+          const ZVec<TT, 2 * C> both = *reinterpret_cast<const ZVec<TT, 2 * C>*>(tab + (r0 & ~1L) * C);
+#pragma unroll
+          for (int c = 0; c < C; ++c) { ce[2 * yz].v[c] = both.v[(r0 & 1) * C + c]; ce[2 * yz + 1].v[c] = both.v[(r1 & 1) * C + c]; }
+        } else {
+          ce[2 * yz] = *reinterpret_cast<const ZVec<TT, C>*>(tab + r0 * C);
+          ce[2 * yz + 1] = *reinterpret_cast<const ZVec<TT, C>*>(tab + r1 * C);
+        }
+      }
+    }
+    float acc[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] = 0.f;
+#pragma unroll
+    for (int idx = 0; idx < 8; ++idx) {          // kernel_grid's order (gridencoder.cu:160-185): corner = x + 2 y + 4 z, w = product over d
+      float w = 1.f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) w *= (idx & (1 << k)) ? fr[k] : 1.f - fr[k];
+#pragma unroll
+      for (int c = 0; c < C; ++c) acc[c] += w * (float)ce[idx].v[c];
+    }
+    ZVec<TT, C> o;
+#pragma unroll
+    for (int c = 0; c < C; ++c) o.v[c] = (TT)acc[c];
+    if ((a.s_b % C) == 0 && (a.s_l % C) == 0) *reinterpret_cast<ZVec<TT, C>*>(out) = o;
+    else {
+#pragma unroll
+      for (int c = 0; c < C; ++c) out[c] = o.v[c];
+    }
   }
-  if (g64 != nullptr && g64_rows > 0)
-    hipLaunchKernelGGL(zip_bin_finish_kernel, dim3(1024), blk, 0, s, (const long long*)g64, g64_rows * C, grad_table, scale_exp);
-  hipLaunchKernelGGL(zip_bin_overflow_mark_kernel, dim3(1), dim3(1), 0, s, grad_table, scale_exp);
+}
+
+// the fast forward for grid.hip's snerf_grid_encode_fwd (D = 3, C = 1 / 4, hash, linear, no align_corners, float / half, no dy_dx)
+int g3_fwd_group = 1;                                                    // points per thread (probe switch: snerf_grid_set_fast_path(2 / 4 / 8))
+int g3_fwd_launch(const float* inputs, const void* table, const int* offsets, void* outputs, long B, int C, int L, float S, int H, int dtype,
+                  long s_l, long s_b, hipStream_t s) {
+  G3Args a{inputs, B, table, offsets, outputs, s_l, s_b, L, S, H};
+  const int G = g3_fwd_group;
+  const dim3 grid((unsigned)((B + 256 * G - 1) / (256 * G)), L), blk(256);
+#define G3F(TT, CC) do { if (G == 1) hipLaunchKernelGGL((g3_fwd_kernel<TT, CC, 1>), grid, blk, 0, s, a); \
+                         else if (G == 2) hipLaunchKernelGGL((g3_fwd_kernel<TT, CC, 2>), grid, blk, 0, s, a); \
+                         else if (G == 4) hipLaunchKernelGGL((g3_fwd_kernel<TT, CC, 4>), grid, blk, 0, s, a); \
+                         else hipLaunchKernelGGL((g3_fwd_kernel<TT, CC, 8>), grid, blk, 0, s, a); } while (0)
+  if (dtype == SNERF_DT_F16) { if (C == 4) G3F(_Float16, 4); else if (C == 1) G3F(_Float16, 1); else return SNERF_ERR_ARG; }
+  else if (dtype == SNERF_DT_F32) { if (C == 4) G3F(float, 4); else if (C == 1) G3F(float, 1); else return SNERF_ERR_ARG; }
+  else return SNERF_ERR_ARG;
+#undef G3F
   return snerf_check_launch();
+}
+
+// records of one (group of G3_PTS points, level): PASS 0 counts (and reserves the workgroup's ranges), PASS 1 writes
+template <typename GT, int C, int PASS, bool HREC>
+__global__ __launch_bounds__(256) void g3_bin_emit_kernel(G3Args a, ZipBin b) {
+  __shared__ int cnt[ZB_NBMAX];
+  __shared__ long base[PASS == 1 ? ZB_NBMAX : 1];
+  const int level = blockIdx.y;
+  for (int k = threadIdx.x; k < ZB_NBMAX; k += 256) cnt[k] = 0;
+  if constexpr (PASS == 1) {
+    const unsigned* wgo1 = b.wg_offsets + ((long)level * gridDim.x + blockIdx.x) * ZB_NBMAX;
+    for (int k = threadIdx.x; k < ZB_NBMAX; k += 256) base[k] = b.starts[level * ZB_NBMAX + k] + (long)wgo1[k];
+  }
+  __syncthreads();
+  const long p0 = ((long)blockIdx.x * 256 + threadIdx.x) * G3_PTS;
+  if (p0 < a.B) {
+    const uint32_t hs = a.offsets[level + 1] - a.offsets[level];
+    const float scale = exp2f(level * a.Sl) * a.H - 1.0f;
+    const uint32_t res = (uint32_t)ceilf(scale) + 1;
+    const int K = b.ksplit[level], rep = (int)(blockIdx.x % (unsigned)K);
+    float hmul = 1.f;
+    if constexpr (HREC && PASS == 1) hmul = exp2f((float)(b.scale_exp[0] - ZB_HALF_SHIFT));
+    uint32_t cur[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
+    float vals[8][C];
+#pragma unroll
+    for (int idx = 0; idx < 8; ++idx)
+#pragma unroll
+      for (int c = 0; c < C; ++c) vals[idx][c] = 0.f;
+    auto flush = [&]() __attribute__((always_inline)) {
+      if (cur[0] == 0xffffffffu) return;
+#pragma unroll
+      for (int idx = 0; idx < 8; ++idx) {
+        uint32_t pl[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pl[k] = cur[k] + ((idx >> k) & 1);
+        const uint32_t row = zip_grid_index(hs, res, pl);
+        const int bin = (int)(row >> b.bshift) * K + rep;
+        const int slot = atomicAdd(cnt + bin, 1);
+        if constexpr (PASS == 1) {
+          const long r = base[bin] + slot;
+          if (r < b.capacity) {
+            const unsigned lrow = row & ((1u << b.bshift) - 1u);
+            if constexpr (HREC && C == 1) {
+              ((unsigned*)b.rec_val)[r] = lrow | (zb_half_bits(vals[idx][0] * hmul) << 16);
+            } else if constexpr (HREC) {
+              b.rec_row[r] = (unsigned short)lrow;
+              const zb_h4 v4 = {(_Float16)(vals[idx][0] * hmul), (_Float16)(vals[idx][1] * hmul), (_Float16)(vals[idx][2] * hmul), (_Float16)(vals[idx][3] * hmul)};
+              *(zb_h4*)(b.rec_val + r * 2) = v4;
+            } else if constexpr (C == 1) {
+              const uint2 rv = {lrow, __float_as_uint(vals[idx][0])};
+              *(uint2*)(b.rec_val + r * 2) = rv;
+            } else {
+              b.rec_row[r] = (unsigned short)lrow;
+              const f32x4 v4 = {vals[idx][0], vals[idx][1], vals[idx][2], vals[idx][3]};
+              *(f32x4*)(b.rec_val + r * 4) = v4;
+            }
+          }
+#pragma unroll
+          for (int c = 0; c < C; ++c) vals[idx][c] = 0.f;
+        }
+      }
+    };
+#pragma unroll
+    for (int j = 0; j < G3_PTS; ++j) {
+      const long p = p0 + j;
+      if (p >= a.B) break;
+      float x[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) x[k] = a.inputs[p * 3 + k];
+      if (x[0] < 0.f || x[0] > 1.f || x[1] < 0.f || x[1] > 1.f || x[2] < 0.f || x[2] > 1.f) continue;
+      float fr[3];
+      uint32_t pg[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) zip_cell(x[k], scale, &pg[k], &fr[k]);
+      if (pg[0] != cur[0] || pg[1] != cur[1] || pg[2] != cur[2]) {
+        flush();
+        cur[0] = pg[0]; cur[1] = pg[1]; cur[2] = pg[2];
+      }
+      if constexpr (PASS == 1) {
+        const GT* gi = (const GT*)a.io + level * a.s_l + p * a.s_b;
+        float g[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) g[c] = (float)gi[c];
+#pragma unroll
+        for (int idx = 0; idx < 8; ++idx) {
+          float w = 1.f;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) w *= (idx & (1 << k)) ? fr[k] : 1.f - fr[k];
+#pragma unroll
+          for (int c = 0; c < C; ++c) vals[idx][c] += w * g[c];
+        }
+      }
+    }
+    flush();
+  }
+  if constexpr (PASS == 0) {
+    __syncthreads();
+    unsigned* wgo = b.wg_offsets + ((long)level * gridDim.x + blockIdx.x) * ZB_NBMAX;
+    for (int k = threadIdx.x; k < ZB_NBMAX; k += 256)
+      if (cnt[k] != 0) wgo[k] = (unsigned)atomicAdd(b.counts + level * ZB_NBMAX + k, cnt[k]);
+  }
+}
+
+// exclusive scan of the [L x ZB_NBMAX] bin counts into record offsets, on the device (the zipnerf trainer does it with torch.cumsum)
+__global__ __launch_bounds__(1024) void g3_scan_kernel(const int* __restrict__ counts, long* __restrict__ starts, int L) {
+  __shared__ long wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  long mine = 0;
+  for (int k = 0; k < L; ++k) mine += counts[tid * L + k];            // thread t owns elements [t L, t L + L) of the flat array
+  long incl = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const long u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
+  if (lane == 63) wsum[wv] = incl;
+  __syncthreads();
+  long pre = incl - mine;
+  for (int q = 0; q < wv; ++q) pre += wsum[q];
+  for (int k = 0; k < L; ++k) { starts[tid * L + k] = pre; pre += counts[tid * L + k]; }
+}
+
+// bin plan of a level layout (ops.zip_bin_plan on the host): replicas per row range, rows the int64 meeting image covers
+static int g3_plan(const int* offsets_host, int L, int C, long B, int* ksplit, int* level_rows, long* g64_rows) {
+  const int bshift = C == 4 ? 12 : 14;
+  const long target = 2000000, per_level = B * 8;
+  *g64_rows = 0;
+  for (int l = 0; l < L; ++l) {
+    const long rows = (long)offsets_host[l + 1] - offsets_host[l];
+    if (rows <= 0) return SNERF_ERR_ARG;
+    const long rowbins = (rows + (1L << bshift) - 1) >> bshift;
+    if (rowbins > ZB_NBMAX) return SNERF_ERR_ARG;
+    long k = (per_level + rowbins * target - 1) / (rowbins * target);
+    k = k < 1 ? 1 : (k > ZB_NBMAX / rowbins ? ZB_NBMAX / rowbins : k);
+    ksplit[l] = (int)k; level_rows[l] = (int)rows;
+    if (k > 1) *g64_rows = offsets_host[l + 1];
+  }
+  return SNERF_OK;
+}
+
+struct G3Ws { size_t counts, starts, scale, wgo, g64, rec_row, rec_val, total; long cap, nwg; };
+static G3Ws g3_ws_layout(long B, int C, int L, long g64_rows, bool hrec) {
+  G3Ws w{};
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  w.nwg = (B + 256 * G3_PTS - 1) / (256 * G3_PTS);
+  w.cap = B * 8 * L;
+  size_t o = 0;
+  w.counts = o; o = al(o + (size_t)L * ZB_NBMAX * 4);
+  w.scale = o; o = al(o + 8);
+  w.g64 = o; o = al(o + (size_t)g64_rows * C * 8);                      // counts .. g64: one memset
+  w.starts = o; o = al(o + (size_t)L * ZB_NBMAX * 8);
+  w.wgo = o; o = al(o + (size_t)L * w.nwg * ZB_NBMAX * 4);
+  w.rec_row = o; o = al(o + (C == 4 ? (size_t)w.cap * 2 : 0));
+  w.rec_val = o; o = al(o + (size_t)w.cap * (hrec ? (C == 4 ? 8 : 4) : (C == 4 ? 16 : 8)));
+  w.total = o;
+  return w;
+}
+
+extern "C" long snerf_grid_encode_bwd_binned_ws_bytes(long B, int C, int L, const int* offsets_host, int half_records) {
+  int ks[16], lr[16]; long g64_rows;
+  if (B <= 0) return 0;
+  if (L <= 0 || L > 16 || (C != 1 && C != 4) || offsets_host == nullptr || g3_plan(offsets_host, L, C, B, ks, lr, &g64_rows) != SNERF_OK) return -1;
+  return (long)g3_ws_layout(B, C, L, g64_rows, half_records != 0).total;
+}
+
+extern "C" int snerf_grid_encode_bwd_binned(const void* grad, const float* inputs, const int* offsets, const int* offsets_host, void* grad_embeddings,
+                                            long B, int C, int L, float S, int H, int grad_dtype, int out_dtype, long grad_stride_l,
+                                            long grad_stride_b, int half_records, void* ws, long ws_bytes, void* stream) {
+  if (B <= 0) return SNERF_OK;
+  int ks[16], lr[16]; long g64_rows;
+  if (L <= 0 || L > 16 || (C != 1 && C != 4) || grad == nullptr || inputs == nullptr || offsets == nullptr || offsets_host == nullptr ||
+      grad_embeddings == nullptr || ws == nullptr || ((uintptr_t)ws & 255) || (grad_dtype != SNERF_DT_F32 && grad_dtype != SNERF_DT_F16) ||
+      (out_dtype != SNERF_DT_F32 && out_dtype != SNERF_DT_F16) || g3_plan(offsets_host, L, C, B, ks, lr, &g64_rows) != SNERF_OK)
+    return SNERF_ERR_ARG;
+  const bool hrec = half_records != 0;
+  const G3Ws w = g3_ws_layout(B, C, L, g64_rows, hrec);
+  if ((long)w.total > ws_bytes) return SNERF_ERR_ARG;
+  // the scale pass reads the gradient as rows of C values: [B, L*C] contiguous (stride_b = L*C, stride_l = C) or [L, B, C] (stride_l = B*C)
+  const bool point_major = grad_stride_l == C && grad_stride_b == (long)L * C, level_major = grad_stride_b == C && grad_stride_l == B * C;
+  if (!point_major && !level_major) return SNERF_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  char* base = (char*)ws;
+  (void)hipMemsetAsync(base + w.counts, 0, w.starts - w.counts, s);
+  int* scale = (int*)(base + w.scale);
+  int rc = snerf_zip_bin_scale(grad, C, B * L, C, grad_dtype, scale, stream);
+  if (rc != SNERF_OK) return rc;
+  G3Args a{inputs, B, nullptr, offsets, (void*)grad, grad_stride_l, grad_stride_b, L, S, H};
+  ZipBin b{};
+  b.bshift = C == 4 ? 12 : 14;
+  b.counts = (int*)(base + w.counts); b.wg_offsets = (unsigned*)(base + w.wgo); b.starts = (const long*)(base + w.starts);
+  for (int l = 0; l < L; ++l) b.ksplit[l] = ks[l];
+  b.rec_row = (unsigned short*)(base + w.rec_row); b.rec_val = (float*)(base + w.rec_val); b.capacity = w.cap;
+  b.g64 = g64_rows > 0 ? (long long*)(base + w.g64) : nullptr; b.g64_rows = g64_rows; b.scale_exp = scale;
+  const dim3 grid((unsigned)w.nwg, L), blk(256);
+#define G3E(GT, CC) do { hipLaunchKernelGGL((g3_bin_emit_kernel<GT, CC, 0, false>), grid, blk, 0, s, a, b); \
+                         hipLaunchKernelGGL(g3_scan_kernel, dim3(1), dim3(1024), 0, s, b.counts, (long*)(base + w.starts), L); \
+                         if (hrec) hipLaunchKernelGGL((g3_bin_emit_kernel<GT, CC, 1, true>), grid, blk, 0, s, a, b); \
+                         else hipLaunchKernelGGL((g3_bin_emit_kernel<GT, CC, 1, false>), grid, blk, 0, s, a, b); } while (0)
+  if (grad_dtype == SNERF_DT_F16) { if (C == 4) G3E(_Float16, 4); else G3E(_Float16, 1); }
+  else { if (C == 4) G3E(float, 4); else G3E(float, 1); }
+#undef G3E
+  ZipEnc za{};
+  za.offsets = offsets; za.grad_table = (float*)grad_embeddings; za.L = L;
+  return out_dtype == SNERF_DT_F16 ? zb_accumulate_launch<_Float16>(za, b, C, L, hrec, s) : zb_accumulate_launch<float>(za, b, C, L, hrec, s);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -35,6 +35,9 @@ class _grid_encode(Function):
         outputs, dy_dx = ops.grid_encode_fwd(inputs, table, offsets, L, S, H, gridtype, align_corners, interpolation, calc_grad_inputs)
         ctx.save_for_backward(inputs, table, offsets, dy_dx if dy_dx is not None else torch.empty(0, device=inputs.device))
         ctx.dims = [L, S, H, gridtype, interpolation, dy_dx is not None, embeddings.dtype]
+        # D = 3 / C in {1, 4} / hash / linear without input gradients (what internal/models.py:413-421 constructs): the forward above ran
+        # the corner-cached gather and the backward takes the binned table gradient (csrc/zip.hip g3_*) instead of the atomic scatter
+        ctx.fast = ops.grid_fast_ok(inputs.shape[1], C, gridtype, align_corners, interpolation, table.dtype, calc_grad_inputs)
         ctx.align_corners = align_corners
         return outputs
 
@@ -43,6 +46,10 @@ class _grid_encode(Function):
         inputs, table, offsets, dy_dx = ctx.saved_tensors
         L, S, H, gridtype, interpolation, has_dd, emb_dtype = ctx.dims
         grad = grad.contiguous().to(table.dtype)
+        if ctx.fast:
+            out_dt = emb_dtype if emb_dtype in (torch.float32, torch.float16) else torch.float32
+            g_emb = ops.grid_encode_bwd_binned(grad, inputs, offsets, table.shape[1], L, S, H, out_dtype=out_dt)
+            return None, g_emb.to(emb_dtype), None, None, None, None, None, None, None
         g_emb, g_in = ops.grid_encode_bwd(grad, inputs, table, offsets, L, S, H, gridtype, ctx.align_corners, interpolation,
                                           dy_dx if has_dd else None)
         if g_in is not None:

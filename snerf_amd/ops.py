@@ -5,6 +5,8 @@ function launches hand-written HIP kernels from libsnerf_hip.so through
 ``_lib.call``; nothing in this file computes on the host or falls back to
 torch ops.
 """
+import os as _os
+
 import torch
 
 from . import _lib
@@ -770,6 +772,8 @@ def grid_encode_fwd(inputs, embeddings, offsets, L, S, H, gridtype, align_corner
     _f32c(inputs)
     assert embeddings.is_cuda and embeddings.is_contiguous() and embeddings.dtype in _GRID_DT
     assert offsets.dtype == torch.int32 and offsets.is_cuda
+    if _grid_fast_sent != GRID_FAST:
+        grid_set_fast_path(GRID_FAST)
     B, D = inputs.shape
     C = embeddings.shape[1]
     dt = _GRID_DT[embeddings.dtype]
@@ -796,6 +800,65 @@ def grid_encode_bwd(grad, inputs, embeddings, offsets, L, S, H, gridtype, align_
     _lib.call("snerf_grid_encode_bwd", _p(grad), _p(inputs), _p(embeddings), _p(offsets), _p(g_emb), B, D, C, L, float(S), int(H),
               _p(dy_dx), _p(g_in), int(gridtype), 1 if align_corners else 0, int(interp), dt, sl, sb, _stream())
     return g_emb, g_in
+
+
+def grid_fast_ok(D, C, gridtype, align_corners, interp, dtype, want_dy_dx=False):
+    """the instantiations that run on the corner-cached gather / binned table gradient (csrc/zip.hip g3_*): what zipnerf constructs
+    (internal/models.py:413-421).  Everything else -- and SNERF_GRID_FAST=0 -- runs the one-thread-per-(point, level) kernels of csrc/grid.hip."""
+    return (GRID_FAST and D == 3 and C in (1, 4) and int(gridtype) == 0 and not align_corners and int(interp) == 0 and not want_dy_dx
+            and dtype in (torch.float32, torch.float16))
+
+
+GRID_FAST = _os.environ.get("SNERF_GRID_FAST", "1") != "0"          # (A/B switch of the grid_encoder measurement leg and the parity tests)
+_grid_fast_sent = None
+
+
+def grid_set_fast_path(on: bool):
+    """flip the A/B switch at run time (bench.py's grid_encoder leg times both forms in one process)"""
+    global GRID_FAST, _grid_fast_sent
+    GRID_FAST = bool(on)
+    _lib.call("snerf_grid_set_fast_path", int(on))          # (2 / 4 / 8: probe values, see csrc/grid.hip)
+    _grid_fast_sent = GRID_FAST
+
+
+_host_offsets = {}
+
+
+def grid_host_offsets(offsets):
+    """host copy (numpy int32) of a GridEncoder's device `offsets` buffer, cached per tensor storage: the bin plan of the binned table
+    gradient is made on the host.  One device->host copy the first time a given buffer is seen."""
+    key = (offsets.data_ptr(), offsets.numel(), offsets._version)
+    h = _host_offsets.get(key)
+    if h is None:
+        import numpy as np
+        h = np.ascontiguousarray(offsets.detach().cpu().numpy().astype(np.int32))
+        if len(_host_offsets) > 64:
+            _host_offsets.clear()
+        _host_offsets[key] = h
+    return h
+
+
+def grid_encode_bwd_binned(grad, inputs, offsets, C, L, S, H, out_dtype=torch.float32, half_records=None, level_major=False, offsets_host=None):
+    """Table gradient of the stand-alone GridEncoder without atomics (snerf_grid_encode_bwd_binned; D = 3, hash, linear, C in {1, 4}):
+    grad [B, L*C] (or [L,B,C]) fp32 / fp16 -> grad_embeddings [rows, C] in `out_dtype`, bit-reproducible.  `half_records` (default:
+    follows the gradient's dtype): contributions travel as fp16 -- the reference adds __half2 atomics into a half table's gradient."""
+    _f32c(inputs)
+    assert grad.is_contiguous() and grad.dtype in (torch.float32, torch.float16) and out_dtype in (torch.float32, torch.float16) and C in (1, 4)
+    B = inputs.shape[0]
+    oh = grid_host_offsets(offsets) if offsets_host is None else offsets_host
+    if half_records is None:
+        half_records = grad.dtype == torch.float16
+    g_emb = torch.zeros(int(oh[-1]), C, dtype=out_dtype, device=inputs.device)
+    if B == 0:
+        return g_emb
+    nb = _lib.query("snerf_grid_encode_bwd_binned_ws_bytes", B, C, L, oh.ctypes.data, 1 if half_records else 0)
+    if nb < 0:
+        raise ValueError("grid_encode_bwd_binned: level layout outside the binned kernels' range (more than 1024 row ranges per level)")
+    ws = _zb_workspace(inputs.device, "g3ws", int(nb), torch.uint8)
+    sl, sb = (B * C, C) if level_major else (C, L * C)
+    _lib.call("snerf_grid_encode_bwd_binned", _p(grad), _p(inputs), _p(offsets), oh.ctypes.data, _p(g_emb), B, C, L, float(S), int(H),
+              _GRID_DT[grad.dtype], _GRID_DT[out_dtype], sl, sb, 1 if half_records else 0, _p(ws), int(nb), _stream())
+    return g_emb
 
 
 def grid_tv_grad(inputs, embeddings, grad, offsets, weight, L, S, H, gridtype, align_corners):
@@ -955,7 +1018,6 @@ def _zb_workspace(dev, key, numel, dtype):
     return t
 
 
-import os as _os
 ZIP_BIN_ALL_LEVELS = _os.environ.get("SNERF_ZIP_ALL_LEVELS", "") != ""   # probe switch: A/B runs of tools/bench_zip.py
 ZIP_BIN_STAGED = _os.environ.get("SNERF_ZIP_UNSTAGED", "") == ""      # (the environment switch: A/B runs of tools/bench_zip.py)
 

@@ -168,3 +168,113 @@ def test_grid_double_tables():
     # adjointness holds to double precision on the device results themselves (same weights on both sides)
     lhs = float((out * Gt).sum()); rhs = float((Et * gE).sum())
     assert abs(lhs - rhs) < 1e-10 * max(1.0, abs(lhs))
+
+
+# ---------------------------------------------------------------- corner-cached gather + binned table gradient (csrc/zip.hip g3_*) ----
+def _clumped_points(B, seed):
+    """points as the reference's callers pass them (internal/models.py:488-494: the 7 multisamples of an interval one after the other):
+    groups of 7 neighbours around a random centre -- one cell on the coarse levels, several on the fine ones -- plus out-of-bounds and
+    boundary points and a ragged tail (B % 8 != 0)"""
+    rng = np.random.default_rng(seed)
+    centres = rng.random(((B + 6) // 7, 1, 3)).astype(np.float32)
+    x = (centres + rng.standard_normal((centres.shape[0], 7, 3)).astype(np.float32) * 2e-3).reshape(-1, 3)[:B]
+    x = np.clip(x, 0.0, 1.0)
+    x[5] = [-0.2, 0.5, 0.5]; x[6] = [0.5, 0.5, 1.5]; x[7] = [0.0, 1.0, 0.0]; x[11] = [1.0, 1.0, 1.0]
+    return np.ascontiguousarray(x)
+
+
+@pytest.mark.parametrize("C,half", [(4, False), (4, True), (1, False), (1, True)])
+def test_grid_fast_forward_is_the_slow_kernel_bit_for_bit(C, half):
+    """snerf_grid_encode_fwd runs the corner-cached, pair-loading gather for D = 3 / hash / linear / C in {1, 4}: the same corner
+    products in the same order as kernel_grid's restatement (grid.hip) -- identical bits, for random and for clumped points, in both
+    output layouts."""
+    from snerf_amd import ops
+    L, H = 8, 16
+    off, res, s = og.level_layout(3, L, C, 2.0, H, 15, 1024, False)
+    S = float(np.log2(s))
+    rng = np.random.default_rng(C)
+    E = torch.from_numpy((rng.standard_normal((int(off[-1]), C)) * 0.5).astype(np.float32)).cuda()
+    E = E.half() if half else E
+    offt = torch.from_numpy(off).cuda()
+    try:
+        for x in (_clumped_points(20003, 1), np.random.default_rng(2).random((4099, 3)).astype(np.float32)):
+            xt = torch.from_numpy(x).cuda()
+            ops.grid_set_fast_path(False)
+            slow, _ = ops.grid_encode_fwd(xt, E, offt, L, S, H, 0, False, 0)
+            slow_lm, _ = ops.grid_encode_fwd(xt, E, offt, L, S, H, 0, False, 0, level_major=True)
+            ops.grid_set_fast_path(True)
+            fast, _ = ops.grid_encode_fwd(xt, E, offt, L, S, H, 0, False, 0)
+            fast_lm, _ = ops.grid_encode_fwd(xt, E, offt, L, S, H, 0, False, 0, level_major=True)
+            assert torch.equal(fast, slow) and torch.equal(fast_lm, slow_lm)
+            assert float(fast.float().abs().max()) > 0
+    finally:
+        ops.grid_set_fast_path(True)
+
+
+@pytest.mark.parametrize("C,B", [(4, 20003), (1, 20003), (4, 300007)])
+def test_grid_binned_backward_vs_oracle_atomic_kernel_and_itself(C, B):
+    """snerf_grid_encode_bwd_binned against oracle/grid.py's kernel_grid_backward restatement, against the atomic kernel, run to run
+    (bit-identical), in both gradient layouts, with fp16 gradients / half records, and (B = 300 007: 2.4 M records per level) with the
+    dense levels split into replicas that meet in the int64 image."""
+    from snerf_amd import ops
+    L, H = 7, 8
+    off, res, s = og.level_layout(3, L, C, 2.0, H, 14, 512, False)
+    S = float(np.log2(s))
+    x = _clumped_points(B, 3)
+    rng = np.random.default_rng(4)
+    G = (rng.standard_normal((B, L * C)) * 0.3).astype(np.float32)
+    xt, Gt, offt = torch.from_numpy(x).cuda(), torch.from_numpy(G).cuda(), torch.from_numpy(off).cuda()
+    E = torch.zeros(int(off[-1]), C, device="cuda")
+    g_at, _ = ops.grid_encode_bwd(Gt, xt, E, offt, L, S, H, 0, False, 0)
+    g_bin = ops.grid_encode_bwd_binned(Gt, xt, offt, C, L, S, H)
+    assert g_bin.dtype == torch.float32 and g_bin.shape == E.shape
+    scale = float(g_at.abs().max())
+    assert float((g_bin - g_at).abs().max()) < 2e-5 * scale          # fp32 atomics: order-dependent last bits; the binned sums are exact
+    if B <= 50000:
+        gE_ref, _ = og.grid_encode_backward(np.ascontiguousarray(G.reshape(B, L, C).transpose(1, 0, 2)), x, off, E.shape[0], S, H, 0, False, 0)
+        np.testing.assert_allclose(g_bin.cpu().numpy(), gE_ref, rtol=1e-4, atol=2e-5 * scale)
+    assert torch.equal(ops.grid_encode_bwd_binned(Gt, xt, offt, C, L, S, H), g_bin), "not bit-reproducible"
+    G_lm = Gt.reshape(B, L, C).permute(1, 0, 2).contiguous()
+    assert torch.equal(ops.grid_encode_bwd_binned(G_lm, xt, offt, C, L, S, H, level_major=True), g_bin)
+    # fp16 gradients (the reference's autocast case): records rounded once to 11 bits, sums exact; half output like the reference's
+    g16 = ops.grid_encode_bwd_binned(Gt.half(), xt, offt, C, L, S, H)
+    rel = float((g16 - g_bin).norm() / g_bin.norm())
+    assert rel < 1e-3, rel
+    g16h = ops.grid_encode_bwd_binned(Gt.half(), xt, offt, C, L, S, H, out_dtype=torch.float16)
+    assert g16h.dtype == torch.float16 and float((g16h.float() - g16).abs().max()) <= 1e-3 * scale + 1e-3
+    # adjointness with the fast forward
+    Et = torch.from_numpy((rng.standard_normal(E.shape) * 0.5).astype(np.float32)).cuda()
+    out, _ = ops.grid_encode_fwd(xt, Et, offt, L, S, H, 0, False, 0)
+    lhs, rhs = float((out.double() * Gt.double()).sum()), float((Et.double() * g_bin.double()).sum())
+    assert abs(lhs - rhs) < 1e-3 * max(1.0, abs(lhs))
+
+
+def test_gridencoder_module_takes_the_fast_path_without_input_gradients():
+    """GridEncoder.forward / backward as zipnerf calls it (no gradient to the positions; fp32 and autocast): corner-cached gather +
+    binned table gradient behind the reference's module API, against the oracle."""
+    from snerf_amd.gridencoder import GridEncoder
+    from snerf_amd import ops
+    assert ops.GRID_FAST
+    for C in (4, 1):
+        enc = GridEncoder(input_dim=3, num_levels=6, level_dim=C, base_resolution=16, log2_hashmap_size=15, desired_resolution=512)
+        torch.manual_seed(11)
+        with torch.no_grad():
+            enc.embeddings.normal_(0, 0.2)
+        x = torch.from_numpy(_clumped_points(7001, 9) * 2 - 1).cuda()
+        g = torch.Generator().manual_seed(1)
+        w = torch.randn(7001, 6 * C, generator=g).cuda()
+        off, S = enc.offsets.cpu().numpy(), float(np.log2(enc.per_level_scale))
+        x01 = ((x.cpu().numpy() + 1) / 2).astype(np.float32)
+        ref = og.grid_encode_forward(x01, enc.embeddings.detach().cpu().numpy(), off, S, 16, 0, False, 0)
+        gE, _ = og.grid_encode_backward(np.ascontiguousarray(w.cpu().numpy().reshape(-1, 6, C).transpose(1, 0, 2)), x01, off, enc.embeddings.shape[0], S, 16, 0, False, 0)
+        y = enc(x, bound=1)
+        np.testing.assert_allclose(y.detach().cpu().numpy().reshape(-1, 6, C), ref.transpose(1, 0, 2), rtol=1e-4, atol=2e-5)
+        (y * w).sum().backward()
+        np.testing.assert_allclose(enc.embeddings.grad.cpu().numpy(), gE, rtol=1e-4, atol=2e-4)
+        enc.embeddings.grad = None
+        with torch.autocast("cuda", dtype=torch.float16):
+            y16 = enc(x)
+        (y16.float() * w).sum().backward()
+        assert y16.dtype == (torch.float16 if C == 4 else torch.float32) and enc.embeddings.grad.dtype == torch.float32   # (odd C: the table is not halved, grid.py:41-44)
+        tol = 2e-2 if C == 4 else 1e-3                          # C = 4: half table and half gradients (grid.py:41-44); C = 1 stays fp32
+        assert float((enc.embeddings.grad - torch.from_numpy(gE).cuda()).norm() / np.linalg.norm(gE)) < tol
