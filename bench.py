@@ -347,6 +347,35 @@ def path_c_leg(device, n_rays=65536, steps=5, compute="fp16", also=("bf16",)):
     img = zipnerf.render_image(rfn, None, frame, False, cfg)
     torch.cuda.synchronize(); dt_frame = time.perf_counter() - t0
     ok = img["rgb"].shape == (H_, W_, 3) and bool(torch.isfinite(img["rgb"]).all())
+    # BASELINE configs[4] (M5): the S-NeRF++ background frame as random_render_waymo_seq.py:197-220 produces it -- the model with its
+    # 19-class semantic head (internal/models.py:586-703), compute_extras, and the frame's files (rgb PNG, 16-bit depth PNG, argmax
+    # semantic PNG + palette) written through FrameWriter (device-side quantisation, PNG encoding on a background thread)
+    import shutil
+    import tempfile
+    from snerf_amd.frame_writer import FrameWriter
+    torch.manual_seed(0)
+    msem = zipnerf.Model(config=None, raydist_fn='power_transformation', opaque_background=True, compute=compute, table_dtype="ref",
+                         init_std=0.1, device=device, use_semantic=True)
+    msem.config = cfg
+    rsem = lambda rand, b: msem(rand, b, train_frac=1.0, compute_extras=True)
+    tmpd = tempfile.mkdtemp(prefix="snerf_frames_")
+    try:
+        with FrameWriter(tmpd, scale_factor=1.0) as fw:
+            fw.write(0, zipnerf.render_image(rsem, None, frame, False, cfg))
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for k in (1, 2):
+                img_s = zipnerf.render_image(rsem, None, frame, False, cfg)
+                fw.write(k, img_s)
+            torch.cuda.synchronize(); dt_sem_render = (time.perf_counter() - t0) / 2
+        dt_sem_total = (time.perf_counter() - t0) / 2               # (the context exit waits for the writer thread)
+        files = sorted(os.path.relpath(os.path.join(d, f), tmpd) for d, _, fs in os.walk(tmpd) for f in fs)
+        sem_ok = img_s["semantic"].shape == (H_, W_, 19) and bool(torch.isfinite(img_s["semantic"]).all()) and len(files) >= 9
+    finally:
+        shutil.rmtree(tmpd, ignore_errors=True)
+    sem_frame = {"what": "Model(use_semantic=True) frame 1920 x 1280 with the 19-class head + compute_extras, written through FrameWriter (rgb / depth16 / semantic / paint PNGs)",
+                 "render_ms": round(dt_sem_render * 1e3, 1), "render_and_files_ms": round(dt_sem_total * 1e3, 1), "frames": 2, "ok": sem_ok, "files_per_frame": len(files) // 3}
+    del msem, img_s
+    torch.cuda.empty_cache()
     useful = [R * 7 * 64 * 6 * 8 * 4, R * 7 * 64 * 8 * 8 * 4, R * 7 * 32 * 10 * 8 * 4 * 2]       # prop 0 / prop 1 (fp32, C = 1), NeRF (fp16, C = 4)
     cb, cb_src = counter_bytes("zip_encode_fwd_all_nerf_train")
     rl = {"bound": "hbm", "kernel": "zip_encode_fwd_all_kernel<half, %s, 4, COUNT> (NeRF-level hash-grid gather of the train step)" % {"fp16": "_Float16", "bf16": "bf16", "f32": "float"}[compute],
@@ -358,13 +387,14 @@ def path_c_leg(device, n_rays=65536, steps=5, compute="fp16", also=("bf16",)):
            "dtype": compute,
            "rays_per_step": R, "steps": steps, "train_ms_per_step": round(dt_train * 1e3, 3), "train_rays_per_s": round(R / dt_train, 1),
            "fwd_ms": round(dt_fwd * 1e3, 3), "fwd_rays_per_s": round(R / dt_fwd, 1),
-           "frame_1920x1280_ms": round(dt_frame * 1e3, 1), "frame_ok": ok,
+           "frame_1920x1280_ms": round(dt_frame * 1e3, 1), "frame_ok": ok, "frame_semantic": sem_frame,
            "encode_train_ms_per_level": [round(x, 3) for x in enc_train], "encode_inference_ms_per_level": [round(x, 3) for x in enc_inf],
            "encode_train_useful_GBps_per_level": [round(b / (ms * 1e-3) / 1e9, 1) for b, ms in zip(useful, enc_train)],
            "table_gradient_ms": {"nerf": round(tgrad[0], 3), "prop1": round(tgrad[1], 3), "prop0": round(tgrad[2], 3)},
            "train_useful_gather_bytes_per_step": 2 * sum(useful),
            "train_step_useful_TBps": round(2 * sum(useful) / dt_train / 1e12, 3),
            "roofline": rl, "losses_last_step": [round(v, 6) for v in tr.last_losses.cpu().tolist()]}
+    sd_c = {k: v.detach().float().cpu().clone() for k, v in m.state_dict().items() if v.is_floating_point()}     # (the encoders' integer buffers stay behind)
     del tr, m, frame, fr, img
     torch.cuda.empty_cache()
     for other in also:                                   # the same train step in the other reduced-precision mode(s)
@@ -374,6 +404,130 @@ def path_c_leg(device, n_rays=65536, steps=5, compute="fp16", also=("bf16",)):
         dt2 = _timeit(lambda: tr2.step(batch, tgt, train_frac=0.5, rand=True, targets=targets), steps, warm=3)
         out["train_ms_per_step_" + other] = round(dt2 * 1e3, 3)
         del tr2, m2
+        torch.cuda.empty_cache()
+    out.update(path_c_baselines(sd_c, batch, tgt, device, R / dt_train))
+    return out
+
+
+def _zip_oracle_step(oz, p, specs, b, tgt, grid_fn):
+    """forward + backward of the reference zipnerf Model's train step as plain torch ops (oracle/zip.py = internal/models.py:98-349):
+    Charbonnier data loss on the final level, autograd backward into every parameter incl. the three hash tables"""
+    saved, oz.grid_features = oz.grid_features, grid_fn
+    try:
+        jit = [torch.rand(b["origins"].shape[0], 1, device=tgt.device) for _ in range(3)]
+        ren, _ = oz.model_forward(p, specs, b, jitters=jit)
+        loss = torch.sqrt((ren[-1]["rgb"] - tgt) ** 2 + 0.001 ** 2).mean()
+        loss.backward()
+    finally:
+        oz.grid_features = saved
+    return loss
+
+
+def path_c_baselines(sd, batch, tgt, device, build_rays_per_s, n_cpu=512, n_eager=16384):
+    """The two baselines SURVEY section 8(d) asks for beside path C's number, on the same synthetic batch and weights:
+    cpu_baseline = the oracle's torch restatement (hash-grid gather as torch ops, oracle/eager.py) forward + backward on the box's host
+    cores, bounded sample; eager_baseline = the same Python on the GPU as the reference would run it on ROCm -- torch eager ops +
+    autograd + torch.optim.Adam, with the hash-grid encoder as its native extension's kernels (the per-(point, level) gather and the
+    atomic scatter of gridencoder.cu, here csrc/grid.hip with the fast path off), fp32 (no autocast: the bf16 / fp16 numbers are the build's)."""
+    from oracle import zip as oz, eager
+    from snerf_amd import ops
+    from snerf_amd.gridencoder import grid_encode
+    specs = [oz.GridSpec(6, 1, 512), oz.GridSpec(8, 1, 2048), oz.GridSpec(10, 4, 8192)]
+    keys = ("origins", "directions", "viewdirs", "radii", "base_x", "base_y", "near", "far")
+    out = {}
+    # ---- host CPU
+    bc = {k: batch[k][:n_cpu].detach().float().cpu() for k in keys}
+    bc["radii"] = bc["radii"].reshape(n_cpu, 1)
+    pc = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    t0 = time.perf_counter()
+    _zip_oracle_step(oz, pc, specs, bc, tgt[:n_cpu].cpu(), eager.grid_features_torch)
+    dt = time.perf_counter() - t0
+    out["cpu_baseline"] = {"value": round(n_cpu / dt, 2), "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+                           "sample": f"{n_cpu} rays forward + backward of the zipnerf Model (oracle/zip.py + oracle/eager.py: torch-CPU restatement of the reference), {dt:.1f} s"}
+    del pc
+    # ---- PyTorch-ROCm eager on this GPU, reference-form grid kernels
+    prev = torch.get_default_device() if hasattr(torch, "get_default_device") else None
+    torch.set_default_device(device)
+    try:
+        ops.grid_set_fast_path(False)
+        pg = {k: v.to(device).requires_grad_(True) for k, v in sd.items()}
+        bg = {k: batch[k][:n_eager].detach().float() for k in keys}
+        bg["radii"] = bg["radii"].reshape(n_eager, 1)
+        tg = tgt[:n_eager]
+        offs = [torch.from_numpy(sp.offsets).to(device) for sp in specs]
+        scale = {id(sp): float(2.0 ** sp.S) for sp in specs}
+        off_of = {id(sp): o for sp, o in zip(specs, offs)}
+
+        def grid_fn(spec, emb, means):
+            y = grid_encode(((means.reshape(-1, 3) + 1) / 2).contiguous(), emb, off_of[id(spec)], scale[id(spec)], spec.H, False, 0, False, 0)
+            return y.reshape(list(means.shape[:-1]) + [spec.L, spec.C])
+        opt = torch.optim.Adam(list(pg.values()), lr=1e-2, eps=1e-15)
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            _zip_oracle_step(oz, pg, specs, bg, tg, grid_fn)
+            opt.step()
+        step()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        dte = (time.perf_counter() - t0) / 2
+        out["eager_baseline"] = {"unit": "rays/s", "fp32": round(n_eager / dte, 1), "fp32_ms_per_step": round(dte * 1e3, 2), "rays_per_step": n_eager, "steps": 2,
+                                 "kind": "the reference's Model as PyTorch-ROCm eager ops (oracle/zip.py on the GPU) + autograd + torch.optim.Adam, its hash-grid "
+                                         "extension as the per-(point, level) gather / atomic-scatter kernels (csrc/grid.hip, fast path off), same GPU",
+                                 "speedup_of_the_build": round(build_rays_per_s / (n_eager / dte), 2)}
+        del pg, opt
+    finally:
+        ops.grid_set_fast_path(True)
+        torch.set_default_device(prev if prev is not None else "cpu")
+        torch.cuda.empty_cache()
+    return out
+
+
+def path_b_baselines(sd_c, sd_f, rays, tgt, device, build_rays_per_s, n_cpu=1024, n_eager=8192):
+    """cpu_baseline (oracle/classic.py = render.py:281-409 + run_nerf_helpers.py on the host cores, forward + backward, bounded sample) and
+    eager_baseline (the same torch ops on this GPU with torch.searchsorted as the reference calls it, autograd + torch.optim.Adam, fp32)
+    for the classic render_rays path."""
+    from oracle import classic as oc, eager
+    out = {}
+
+    def step(pc, pf, r, t, opt=None):
+        if opt is not None:
+            opt.zero_grad(set_to_none=True)
+        n = r.shape[0]
+        ret = oc.render_rays(r, pc, pf, 64, 128, t_rand=torch.rand(n, 64, device=r.device), u=torch.rand(n, 128, device=r.device))
+        loss = ((ret["rgb_map"] - t) ** 2).mean() + ((ret["rgb0"] - t) ** 2).mean()
+        loss.backward()
+        if opt is not None:
+            opt.step()
+    pc = {k: v.clone().requires_grad_(True) for k, v in sd_c.items()}
+    pf = {k: v.clone().requires_grad_(True) for k, v in sd_f.items()}
+    t0 = time.perf_counter()
+    step(pc, pf, rays[:n_cpu].cpu(), tgt[:n_cpu].cpu())
+    dt = time.perf_counter() - t0
+    out["cpu_baseline"] = {"value": round(n_cpu / dt, 2), "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+                           "sample": f"{n_cpu} rays forward + backward of render_rays (64 + 128, two NeRF 8 x 256), oracle/classic.py, {dt:.1f} s"}
+    prev = torch.get_default_device() if hasattr(torch, "get_default_device") else None
+    saved, oc.sample_pdf = oc.sample_pdf, eager.sample_pdf_torch
+    torch.set_default_device(device)
+    try:
+        pc = {k: v.to(device).requires_grad_(True) for k, v in sd_c.items()}
+        pf = {k: v.to(device).requires_grad_(True) for k, v in sd_f.items()}
+        opt = torch.optim.Adam(list(pc.values()) + list(pf.values()), lr=5e-4)
+        r, t = rays[:n_eager], tgt[:n_eager]
+        step(pc, pf, r, t, opt)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(3):
+            step(pc, pf, r, t, opt)
+        torch.cuda.synchronize()
+        dte = (time.perf_counter() - t0) / 3
+        out["eager_baseline"] = {"unit": "rays/s", "fp32": round(n_eager / dte, 1), "fp32_ms_per_step": round(dte * 1e3, 2), "rays_per_step": n_eager, "steps": 3,
+                                 "kind": "plain PyTorch-ROCm eager ops (torch restatement of render_rays / NeRF), autograd + torch.optim.Adam, same GPU",
+                                 "speedup_of_the_build": round(build_rays_per_s / (n_eager / dte), 2)}
+    finally:
+        oc.sample_pdf = saved
+        torch.set_default_device(prev if prev is not None else "cpu")
         torch.cuda.empty_cache()
     return out
 
@@ -473,20 +627,81 @@ def path_b_leg(device, n_rays=32768, steps=5, compute="bf16"):
     dt_train = _timeit(train, steps)
     with torch.no_grad():
         dt_fwd = _timeit(fwd, steps)
+    # the 1600 x 900 frame through the drop-in render() (render.py:22-91: rays from c2w, batchify_rays in chunks, both networks)
+    Hh, Ww, focal = 900, 1600, 1266.0
+    c2w = torch.tensor([[1.0, 0.0, 0.0, 0.0], [0.0, 1.0, 0.0, 0.0], [0.0, 0.0, 1.0, 4.0]], device=device)
+    rk = dict(network_fn=coarse, network_query_fn=q, N_samples=64, perturb=0.0, N_importance=128, network_fine=fine, white_bkgd=False, raw_noise_std=0.0)
+    with torch.no_grad():
+        classic.render(Hh, Ww, focal, chunk=1 << 17, c2w=c2w, ndc=False, near=2.0, far=6.0, use_viewdirs=True, **rk)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        fr = classic.render(Hh, Ww, focal, chunk=1 << 17, c2w=c2w, ndc=False, near=2.0, far=6.0, use_viewdirs=True, **rk)
+        torch.cuda.synchronize(); dt_frame = time.perf_counter() - t0
+    frame_ok = fr[0].shape == (Hh, Ww, 3) and bool(torch.isfinite(fr[0]).all())
+    del fr
     flops = 2.0 * 593408 * (64 + 192)                                  # 303.8 MFLOP / ray forward
     a_tr, a_fw = 3 * N * flops / dt_train / 1e12, N * flops / dt_fwd / 1e12
     cb, cb_src = counter_bytes("fmlp_kernel_train_fwd")
     out = {"workload": "path B: classic render_rays (render.py:281-409), 64 coarse + 128 importance samples (fine net on 192), NeRF 8 x 256 x 2, "
                        "autograd + torch.optim.Adam; bf16 MFMA, fp32 accumulate",
            "rays_per_step": N, "steps": steps, "train_ms_per_step": round(dt_train * 1e3, 3), "train_rays_per_s": round(N / dt_train, 1),
-           "fwd_ms": round(dt_fwd * 1e3, 3), "fwd_rays_per_s": round(N / dt_fwd, 1), "frame_1600x900_ms": round(1440000 / (N / dt_fwd) * 1e3, 1),
+           "fwd_ms": round(dt_fwd * 1e3, 3), "fwd_rays_per_s": round(N / dt_fwd, 1), "frame_1600x900_ms": round(dt_frame * 1e3, 1), "frame_ok": frame_ok,
+           "frame_what": "classic.render(H, W, focal, c2w=...) (render.py:22-91): on-device rays, 11 chunks of 131 072 rays, coarse + fine network; measured",
+           "frame_tflops": round(Hh * Ww * flops / dt_frame / 1e12, 1),
            "roofline": {"bound": "mfma", "kernel": "fmlp_kernel (fused register-resident 8 x 256 MLP) + fchain_bwd + gemm_tn (whole step's MLP work)",
                         "achieved": round(a_tr, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(a_tr / PEAK_BF16_TFLOPS, 4),
                         "forward_only_achieved": round(a_fw, 1), "forward_only_frac": round(a_fw / PEAK_BF16_TFLOPS, 4),
                         "algorithmic_flops_per_ray_forward": flops, "traffic": cb, "traffic_source": cb_src}}
+    sd_c = {k: v.detach().float().cpu().clone() for k, v in coarse.state_dict().items()}
+    sd_f = {k: v.detach().float().cpu().clone() for k, v in fine.state_dict().items()}
     del coarse, fine, opt
     torch.cuda.empty_cache()
+    out.update(path_b_baselines(sd_c, sd_f, rays, tgt, device, N / dt_train))
     return out
+
+
+def small_step_leg(device, n_rays=512, steps=20):
+    """The per-GPU step of the reference's 4096-ray batch split over 8 GPUs (8 x 512 rays): launched kernel by kernel and
+    as a hipGraph replay (MipTrainer.capture).  The strong-scaling ceiling of an 8-GPU node is headline_ms / (8 x this)."""
+    from snerf_amd.trainer import MipTrainer
+    m = build_model("bf16", device)
+    tr = MipTrainer(m, lr=5e-4)
+    rays = synth_rays(n_rays, 77, device)
+    g = torch.Generator(device="cpu").manual_seed(78)
+    tgt = torch.rand(n_rays, 3, generator=g).to(device)
+    depth = torch.where(torch.rand(n_rays, generator=g) < 0.5, torch.rand(n_rays, generator=g) * 78 + 2, torch.zeros(n_rays)).to(device)
+    conf = torch.rand(n_rays, generator=g).to(device)
+    dt_e = _timeit(lambda: tr.step(rays, tgt, depth, conf), steps, warm=5)
+    tr.capture(rays, tgt, depth, conf, warmup=2)
+    dt_g = _timeit(tr.replay, steps, warm=3)
+    del tr, m
+    torch.cuda.empty_cache()
+    return {"rays": n_rays, "steps": steps, "ms": round(min(dt_e, dt_g) * 1e3, 3), "ms_eager_launches": round(dt_e * 1e3, 3), "ms_hipgraph": round(dt_g * 1e3, 3),
+            "what": "path-A train step at 512 rays (1/8 of the 4096-ray batch): draws, forward, loss tail, backward, fused Adam; bf16"}
+
+
+def shipped_shape_leg(device, n_rays=4096, steps=5):
+    """SURVEY 8(d) M2's second shape: the shipped config's 128 proposal + 127 fine intervals (configs/nuScenes_depth_6cams:36; mip.py:308-316)
+    instead of BASELINE's 64 + 128 -- same train step, same kernels."""
+    global S0, P1
+    from snerf_amd.trainer import MipTrainer
+    keep = (S0, P1)
+    S0, P1 = 128, 128
+    try:
+        m = build_model("bf16", device)
+        tr = MipTrainer(m, lr=5e-4)
+        rays = synth_rays(n_rays, 1000, device)
+        g = torch.Generator(device="cpu").manual_seed(2000)
+        tgt = torch.rand(n_rays, 3, generator=g).to(device)
+        depth = torch.where(torch.rand(n_rays, generator=g) < 0.5, torch.rand(n_rays, generator=g) * 78 + 2, torch.zeros(n_rays)).to(device)
+        conf = torch.rand(n_rays, generator=g).to(device)
+        dt = _timeit(lambda: tr.step(rays, tgt, depth, conf), steps, warm=3)
+        fwd = 2.0 * (S0 * MAC_PROP + (P1 - 1) * MAC_NERF)
+        del tr, m
+    finally:
+        S0, P1 = keep
+    torch.cuda.empty_cache()
+    return {"shape": "128 proposal + 127 fine intervals (255 network evaluations per ray), hidden 1024", "rays_per_step": n_rays, "steps": steps,
+            "ms_per_step": round(dt * 1e3, 3), "rays_per_s": round(n_rays / dt, 1), "whole_step_tflops": round(3 * fwd * n_rays / dt / 1e12, 1)}
 
 
 def main():
@@ -607,6 +822,38 @@ def main():
                 "backend": "rccl" if args.backend == "nccl" else args.backend, "ranks": world, "bytes": buf.numel() * 4,
                 "allreduce_ms_alone": round((time.perf_counter() - tc) / 5 * 1e3, 3)}
         del buf
+    # ---- N > 1: the STRONG-scaling step beside the weak-scaling headline (north_star / SURVEY 8e: the reference's 4096-ray batch split
+    # across the ranks, 512 rays per GPU at N = 8) -- a second trainer on the same model, launched per kernel and as a hipGraph
+    strong = None
+    if world > 1 and args.scaling == "weak":
+        ns = max(args.rays // world, 1)
+        rs = synth_rays(ns, 3000 + rank, device)
+        gs = torch.Generator(device="cpu").manual_seed(4000 + rank)
+        tg_s = torch.rand(ns, 3, generator=gs).to(device)
+        dp_s = torch.where(torch.rand(ns, generator=gs) < 0.5, torch.rand(ns, generator=gs) * 78 + 2, torch.zeros(ns)).to(device)
+        cf_s = torch.rand(ns, generator=gs).to(device)
+        strong = {"global_rays_per_step": ns * world, "rays_per_gpu_per_step": ns, "steps": args.steps}
+        for mode in ("launches", "hipgraph"):
+            ts = MipTrainer(model, lr=5e-4)
+            if mode == "hipgraph":
+                ts.capture(rs, tg_s, dp_s, cf_s, warmup=2)
+                fn = ts.replay
+            else:
+                fn = lambda: ts.step(rs, tg_s, dp_s, cf_s)
+            for _ in range(3):
+                fn()
+            barrier()
+            t_s = time.perf_counter()
+            for _ in range(args.steps):
+                fn()
+            barrier()
+            el = time.perf_counter() - t_s
+            te = torch.tensor([el], device=device, dtype=torch.float64)
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            strong["ms_per_step_" + mode] = round(te.item() / args.steps * 1e3, 3)
+            strong["rays_per_s_" + mode] = round(ns * world * args.steps / te.item(), 1)
+            del ts
+        strong["note"] = "scaling: strong -- total work fixed at --rays per step; compare rays_per_s with the N = 1 headline (same 4096-ray batch)"
     fwd = 2.0 * (S0 * MAC_PROP + (P1 - 1) * MAC_NERF)                        # 2.269 GFLOP / ray
     out = None
     if rank == 0:
@@ -633,6 +880,8 @@ def main():
             out["config"]["step"] = "hipGraph-captured (MipTrainer.capture / replay)"
         if comm is not None:
             out["comm"] = comm
+        if strong is not None:
+            out["strong_scaling"] = strong
 
     # ---- full-frame inference (forward only): 1600 x 900 rays through the drop-in render_image (models.py:328-360; eval.py:146),
     # one contiguous block of the frame per rank + one all-gather per output buffer
@@ -703,7 +952,9 @@ def main():
         import ert_scene
         torch.cuda.empty_cache()
         t0 = time.perf_counter()
-        out["ert_scene"] = ert_scene.fit_and_render(build_model("bf16", device, seed=1), steps=200, eps=(1e-4, 0.0), group=16)
+        out["ert_scene"] = ert_scene.fit_and_render(build_model("bf16", device, seed=1), steps=120, eps=(1e-4, 0.0), group=16, rows=96, row0=400,
+                                                    build=lambda mode: build_model(mode, device, seed=1))
+        out["fitted_weights_precision"] = out["ert_scene"].pop("precision_on_fitted_weights")
         out["ert_scene"]["leg_wall_s"] = round(time.perf_counter() - t0, 1)
         torch.cuda.empty_cache()
 
@@ -727,6 +978,11 @@ def main():
         out["pose_refine"] = {"rays_per_s": round(n / dt_p, 1), "ms_per_step": round(dt_p * 1e3, 3), "steps": 5, "vs_headline": round((n / dt_p) / out["value"], 4),
                               "what": "MipTrainer.step(..., ray_grads=True): the train step + d loss / d (origins, directions, viewdirs) for the pose optimiser"}
         torch.cuda.empty_cache()
+
+    if rank == 0 and world == 1 and not args.no_dropin and args.compute == "bf16" and args.shape == "baseline":
+        out["small_step"] = small_step_leg(device)
+        out["small_step"]["strong_scaling_ceiling_at_8_gpus"] = round(out["ms_per_step"] / out["small_step"]["ms"], 2)
+        out["shipped_shape"] = shipped_shape_leg(device)
 
     # ---- the fp32-parity mode's speed (north_star's 1e-4-relative contract holds in compute="f32": exact-fp32 MFMA 32x32x2, 157.3 TF peak)
     if rank == 0 and world == 1 and not args.no_f32 and args.compute == "bf16":

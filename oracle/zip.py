@@ -158,7 +158,7 @@ def predict_density(p, prefix, spec, means, stds):
     m, s = contract_mean_std(means.reshape(-1, 3), stds.reshape(-1))
     m, s = m.reshape(*pre, 3) / 2, s.reshape(*pre) / 2
     feats = grid_features(spec, p[prefix + "encoder.embeddings"], m)
-    grid_sizes = torch.from_numpy(spec.res.astype(np.int32))
+    grid_sizes = torch.from_numpy(spec.res.astype(np.int32)).to(s.device)
     w = torch.erf(1 / torch.sqrt(8 * s[..., None] ** 2 * grid_sizes ** 2))
     feats = (feats * w[..., None]).mean(dim=-3).flatten(-2, -1)
     x = F.linear(F.relu(F.linear(feats, p[prefix + "density_layer.0.weight"], p[prefix + "density_layer.0.bias"])),

@@ -30,6 +30,15 @@ __device__ __forceinline__ float adam_clean_grad(float g, const AdamArgs& a, flo
   return g;
 }
 
+// one element's update: every product and sum rounded on its own, so that the vector and the scalar flavour of the kernel (and any
+// future one) give the same bits -- a sharded table update must equal the dense one whatever alignment its slices have
+__device__ __forceinline__ void adam_update(float& p, float& m, float& v, float gk, float b1, float b2, float step_size, float bc2_sqrt, float eps) {
+#pragma clang fp contract(off)
+  m = b1 * m + (1.f - b1) * gk;
+  v = b2 * v + ((1.f - b2) * gk) * gk;
+  p = p - (step_size * m) / (sqrtf(v) / bc2_sqrt + eps);
+}
+
 // VEC = 4: all four pointers 16-byte aligned (whole arenas, aligned spans); VEC = 1: any alignment -- a rank's 1 / world slice of a
 // single-channel hash table starts at an odd float (6 606 952 / 8 = 825 869 rows per rank), trainer._TableShards.
 template <int VEC>
@@ -49,9 +58,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     for (int k = 0; k < 4; ++k) {
       bad += (fabsf(ga[k]) <= 3.402823466e+38f) ? 0u : 1u;
       const float gk = adam_clean_grad(ga[k], a, coef);
-      ma[k] = b1 * ma[k] + (1.f - b1) * gk;
-      va[k] = b2 * va[k] + (1.f - b2) * gk * gk;
-      pa[k] -= (lr / bc1) * ma[k] / (sqrtf(va[k]) / bc2_sqrt + eps);
+      adam_update(pa[k], ma[k], va[k], gk, b1, b2, lr / bc1, bc2_sqrt, eps);
     }
     ((float4*)p)[i] = pp; ((float4*)m)[i] = mm; ((float4*)v)[i] = vv;
     if (a.zero_grad) ((float4*)g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -61,9 +68,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
   for (long i = t0; i < n; i += (long)gridDim.x * 256) {
     bad += (fabsf(g[i]) <= 3.402823466e+38f) ? 0u : 1u;
     const float gk = adam_clean_grad(g[i], a, coef);
-    m[i] = b1 * m[i] + (1.f - b1) * gk;
-    v[i] = b2 * v[i] + (1.f - b2) * gk * gk;
-    p[i] -= (lr / bc1) * m[i] / (sqrtf(v[i]) / bc2_sqrt + eps);
+    float pi = p[i], mi = m[i], vi = v[i];
+    adam_update(pi, mi, vi, gk, b1, b2, lr / bc1, bc2_sqrt, eps);
+    p[i] = pi; m[i] = mi; v[i] = vi;
     if (a.zero_grad) g[i] = 0.f;
   }
   if (a.dropped != nullptr && __any(bad != 0)) {        // rare: one atomic per wave that saw a non-finite gradient

@@ -1055,7 +1055,7 @@ def zip_encode_bwd_binned(tdist, origins, directions, radii, base_x, base_y, deg
     flat = counts.view(-1).to(torch.int64)
     starts = (torch.cumsum(flat, 0) - flat).contiguous()
     capacity = R * S * n * 8 * L                               # every (interval, level) emits at most n cells x 8 corners: no host sync
-    rec_row = _zb_workspace(dev, "row", capacity, torch.int16)
+    rec_row = _zb_workspace(dev, "row", capacity if C == 4 else 1, torch.int16)          # (C = 1 records carry their row)
     rec_val = _zb_workspace(dev, "val", capacity * max(C, 2), torch.float32)       # C = 1: {row, value} pairs in one 8-byte record
     # pass 1: the records staged in LDS and written run by run; ZIP_BIN_STAGED = False (A/B probes, tests): pass 3, every thread
     # writes its records where they fall (same records, another order inside a (workgroup, bin) run)

@@ -141,3 +141,26 @@ def test_other_input_dims_known_answers(D):
             # the oracle (like the kernel) forms frac = pos - floor(pos) in fp32: evaluate the affine field at floor + frac
             cellpos = np.floor(pos).astype(np.float64) + (pos - np.floor(pos)).astype(np.float64)
             np.testing.assert_allclose(out[l, :, 0], coef[0] + cellpos @ coef[1:], rtol=tol, atol=tol)
+
+
+def test_eager_restatements_match_the_oracle():
+    """oracle/eager.py (the torch-op forms bench.py's baseline legs of paths B / C run on the CPU and on the GPU): GridEncoder forward and
+    table gradient against oracle/grid.py, sample_pdf against oracle/classic.py's canonical-order sampler (same indices)."""
+    import torch
+    from oracle import zip as oz, eager, classic as oc
+    spec = oz.GridSpec(6, 4, 512, 16, 12)                       # levels >= 2 hashed
+    g = torch.Generator().manual_seed(0)
+    emb = torch.randn(spec.rows, 4, generator=g) * 0.3
+    m = torch.rand(300, 7, 3, generator=g) * 2.2 - 1.1           # some points outside [-1, 1]: zeros
+    assert float((oz.grid_features(spec, emb, m) - eager.grid_features_torch(spec, emb, m)).abs().max()) < 1e-6
+    embg = emb.clone().requires_grad_(True)
+    G = torch.randn(300, 7, 6, 4, generator=g)
+    (eager.grid_features_torch(spec, embg, m) * G).sum().backward()
+    x01 = ((m.reshape(-1, 3) + 1) / 2).numpy().astype(np.float32)
+    gE, _ = og.grid_encode_backward(np.ascontiguousarray(G.reshape(-1, 6, 4).permute(1, 0, 2).numpy()), x01, spec.offsets, spec.rows, spec.S, spec.H, 0, False, 0)
+    assert float((embg.grad - torch.from_numpy(gE)).abs().max()) < 1e-5 * float(np.abs(gE).max())
+    bins = torch.sort(torch.rand(50, 63, generator=g), -1).values
+    w, u = torch.rand(50, 62, generator=g), torch.rand(50, 128, generator=g)
+    s1, i1 = oc.sample_pdf(bins, w, u)
+    s2, i2 = eager.sample_pdf_torch(bins, w, u)
+    assert float((s1 - s2).abs().max()) < 1e-5 and int((i1 != i2).sum()) <= 2      # (a tie at fp32 rounding may move an index by one)

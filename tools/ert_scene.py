@@ -71,10 +71,43 @@ def rays_of(coords, first, n, dev):
     return Rays(o, d, v, r, ones, nr, fr, ones * 0)
 
 
-def fit_and_render(model, steps=300, eps=(1e-4, 1e-4), rays_per_step=4096, chunk=32768, lr=1e-3, seed=0, log=None, group=0):
+def precision_on_fitted_weights(model, build, rows=40, row0=430):
+    """bf16 / split-bf16 against exact fp32 on TRAINED weights (the init-time bounds say nothing about a fitted
+    model): `rows` image rows through the scene's boxes and ground, rendered by `model`'s weights in compute = "f32", "bf16x3" and
+    "bf16".  `build(compute)` -> a fresh MipNerfModel of the same shape.  -> dict of PSNR / max errors vs the f32 render."""
+    dev = model.arena.flat.device
+    n = rows * W
+    rays = rays_of(None, row0 * W, n, dev)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    outs = {}
+    with torch.no_grad():
+        for mode in ("f32", "bf16x3", "bf16"):
+            m = model if mode == "bf16" else build(mode)
+            if m is not model:
+                m.load_state_dict(sd)
+            parts = [m(type(rays)(*[r[a:a + 16384] for r in rays]), False, False, 0.) for a in range(0, n, 16384)]
+            outs[mode] = tuple(torch.cat([p[1][k] for p in parts], 0) for k in (0, 1, 2))      # rgb, distance, acc
+            del m
+    torch.cuda.empty_cache()
+    ref = outs["f32"]
+    res = {"rays": n, "what": f"rows {row0}..{row0 + rows - 1} of the 1600 x 900 frame of the FITTED model, each mode vs compute='f32' on the same weights"}
+    for mode in ("bf16x3", "bf16"):
+        rgb, dist, acc = outs[mode]
+        mse = float(((rgb.double() - ref[0].double()) ** 2).mean())
+        res[mode] = {"psnr_db": float("inf") if mse == 0 else round(-10.0 * math.log10(mse), 2),
+                     "max_abs_err_rgb": float((rgb - ref[0]).abs().max()),
+                     "max_rel_err_depth": float(((dist - ref[1]).abs() / ref[1].abs().clamp(min=1e-6)).max()),
+                     "p999_rel_err_depth": float(torch.quantile(((dist - ref[1]).abs() / ref[1].abs().clamp(min=1e-6)).float(), 0.999)),
+                     "max_abs_err_acc": float((acc - ref[2]).abs().max())}
+    return res
+
+
+def fit_and_render(model, steps=300, eps=(1e-4, 1e-4), rays_per_step=4096, chunk=32768, lr=1e-3, seed=0, log=None, group=0, rows=None, row0=0,
+                   build=None):
     """Fit `model` (a MipNerfModel on its device) to the analytic scene, then render the frame plain and with ERT.  -> dict
     `group` > 0: front-to-back termination on the fine network's own densities in groups of that many samples (eps_t is then an exact
-    bound); 0: the selection from the proposal histogram (eps_t, eps_w)."""
+    bound); 0: the selection from the proposal histogram (eps_t, eps_w).  `rows` (+ `row0`): render only that window of image rows (a
+    short leg of bench.py); `build`: also run precision_on_fitted_weights with it."""
     from snerf_amd.mipnerf import Rays, render_image
     from snerf_amd.trainer import MipTrainer
     dev = model.arena.flat.device
@@ -91,8 +124,10 @@ def fit_and_render(model, steps=300, eps=(1e-4, 1e-4), rays_per_step=4096, chunk
         if log is not None and (it % 50 == 0 or it == steps - 1):
             log(f"fit step {it}: loss {float(loss):.5f}")
     torch.cuda.synchronize(); t_fit = time.perf_counter() - t0
-    fr = rays_of(None, 0, H * W, dev)
-    grid = Rays(*[r.reshape(H, W, -1) for r in fr])
+    prec = precision_on_fitted_weights(model, build) if build is not None else None
+    Hw = H if rows is None else rows                                   # (a window is rendered and scored like a frame of `rows` rows)
+    fr = rays_of(None, row0 * W, Hw * W, dev)
+    grid = Rays(*[r.reshape(Hw, W, -1) for r in fr])
     stats = {"kept": 0, "tot": 0}
 
     def render(ert):
@@ -113,10 +148,11 @@ def fit_and_render(model, steps=300, eps=(1e-4, 1e-4), rays_per_step=4096, chunk
     tgt_rgb, tgt_t = analytic_scene(fr.origins, fr.directions)
     mse = lambda a, b: float(((a - b) ** 2).mean())
     psnr = lambda m: float("inf") if m == 0 else -10.0 * math.log10(m)
-    hitm = (tgt_t > 0).reshape(H, W)
-    return {"scene": "4 opaque boxes at 12-60 m + checkered ground plane + sky (tools/ert_scene.py), RGB + depth supervised",
+    hitm = (tgt_t > 0).reshape(Hw, W)
+    window = None if rows is None else f"rows {row0}..{row0 + rows - 1} of {H}"
+    return {"window": window, "precision_on_fitted_weights": prec, "scene": "4 opaque boxes at 12-60 m + checkered ground plane + sky (tools/ert_scene.py), RGB + depth supervised",
             "fit_steps": steps, "fit_s": round(t_fit, 2), "fit_psnr_db": round(psnr(mse(rgb_f.reshape(-1, 3), tgt_rgb)), 2),
-            "fit_depth_median_rel_err": round(float(((dist_f - tgt_t.reshape(H, W)).abs() / tgt_t.reshape(H, W).clamp(min=1))[hitm].median()), 4),
+            "fit_depth_median_rel_err": round(float(((dist_f - tgt_t.reshape(Hw, W)).abs() / tgt_t.reshape(Hw, W).clamp(min=1))[hitm].median()), 4),
             "mode": f"front to back on the fine network's densities, groups of {group} samples (exact bound eps_t)" if group else "selection from the proposal histogram",
             "eps_t": eps[0], "eps_w": eps[1], "ms_per_frame_full": round(t_full * 1e3, 1), "ms_per_frame_ert": round(t_ert * 1e3, 1),
             "speedup": round(t_full / t_ert, 3), "fine_samples_evaluated": round(stats["kept"] / max(stats["tot"], 1), 4),
