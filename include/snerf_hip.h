@@ -409,6 +409,12 @@ int snerf_hash_decay(const float* table, float* grad, const int* offsets, int L,
 int snerf_mip_encode_bwd(const float* s_vals, const float* origins, const float* directions, const float* radii, const float* near,
                          const float* far, long n_rays, int S, int cone, int transform_idx, int max_deg, const float* dE, long ld,
                          float* g_origins, float* g_directions, void* stream);
+/* snerf_mip_encode_bwd with the warp selected, the backward of snerf_mip_encode_warp: fn_idx 1 = the contraction (above), 0 = the
+ * view-centred warp fn1 + Jacobi_f (mip.py:323-341, 367-369) around (vx, vy, vz); far_max = device scalar max(far) of the batch. */
+int snerf_mip_encode_warp_bwd(const float* s_vals, const float* origins, const float* directions, const float* radii, const float* near,
+                              const float* far, long n_rays, int S, int cone, int transform_idx, int max_deg, const float* dE, long ld,
+                              float* g_origins, float* g_directions, int fn_idx, float vx, float vy, float vz, const float* far_max,
+                              void* stream);
 /* dV fp32 [n_rays*S, ld >= 3 + 6*deg] = d loss / d view-direction encoding (mip.py:12-21) -> g_viewdirs [n_rays,3] (written). */
 int snerf_mip_viewenc_bwd(const float* viewdirs, long n_rays, int S, int deg, const float* dV, long ld, float* g_viewdirs, void* stream);
 

@@ -46,6 +46,8 @@ class Embedder:
         self.out_dim = input_dims * (1 + 2 * multires)
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        if self.multires == 0:
+            return x                                     # nn.Identity()
         flat = x.reshape(-1, 3).contiguous().float()
         out = torch.empty(flat.shape[0], self.out_dim, dtype=torch.float32, device=x.device)
         ops.classic_embed(flat, None, 1, self.multires, 0, out, None, self.out_dim, None, 0, ops.F32)
@@ -53,9 +55,9 @@ class Embedder:
 
 
 def get_embedder(multires, i=0):
-    if i == -1:
-        raise NotImplementedError("identity embedding (i_embed=-1) is not on the accelerated path")
-    e = Embedder(multires)
+    """(embedder, out_dim) (run_nerf_helpers.py:55-70).  i = -1: the identity (nn.Identity(), 3 in the reference, :56-57) -- here an
+    Embedder with zero frequencies, whose fused encoding is the input itself."""
+    e = Embedder(0 if i == -1 else multires)
     return e, e.out_dim
 
 
@@ -124,19 +126,24 @@ class NeRF(_ArenaModule):
     def __init__(self, D=8, W=256, input_ch=3, input_ch_views=3, output_ch=4, skips=[4], use_viewdirs=False,
                  compute: str = "bf16", device="cuda", variant: int = 8):
         super().__init__()
-        if not use_viewdirs:
-            raise NotImplementedError("the accelerated NeRF requires use_viewdirs=True (the S-NeRF configuration)")
-        self.D, self.W, self.input_ch, self.input_ch_views, self.skips, self.use_viewdirs = D, W, input_ch, input_ch_views, list(skips), True
+        # use_viewdirs=False (run_nerf_helpers.py:100-101, 122-124; create_nerf passes output_ch = 5 with N_importance > 0, render.py:180-183):
+        # the trunk + output_linear(W -> output_ch) on the per-layer MFMA GEMMs; the fused register-resident kernels cover use_viewdirs=True
+        oc = 0 if use_viewdirs else int(output_ch)
+        if not use_viewdirs and not (self._alpha_head and 4 <= oc <= 16):
+            raise ValueError("NeRF(use_viewdirs=False): output_ch in 4..16 (raw2outputs reads columns 0..3)")
+        self.D, self.W, self.input_ch, self.input_ch_views, self.skips, self.use_viewdirs = D, W, input_ch, input_ch_views, list(skips), bool(use_viewdirs)
+        self.output_ch = int(output_ch)
         self.compute = compute
-        shapes = ClassicNeRFNet.param_shapes(D, W, input_ch, input_ch_views, tuple(skips), alpha_head=self._alpha_head)
+        shapes = ClassicNeRFNet.param_shapes(D, W, input_ch, input_ch_views, tuple(skips), alpha_head=self._alpha_head, output_ch=oc)
         self._setup_arena(shapes, torch.device(device))
         self.net = ClassicNeRFNet(self.arena, "", _dt(compute), D, W, input_ch, input_ch_views, tuple(skips), variant,
-                                  alpha_head=self._alpha_head)
+                                  alpha_head=self._alpha_head, output_ch=oc)
         self.net.version_fn = self._param_version
         with torch.no_grad():  # nn.Linear default init, like the reference module
             for i in range(D):
                 self._init_linear(f"pts_linears.{i}")
-            for n in ("views_linears.0", "feature_linear", "rgb_linear") + (("alpha_linear",) if self._alpha_head else ()):
+            heads = ("views_linears.0", "output_linear") if oc else ("views_linears.0", "feature_linear", "rgb_linear") + (("alpha_linear",) if self._alpha_head else ())
+            for n in heads:
                 self._init_linear(n)
 
     def _init_linear(self, name):
@@ -200,14 +207,20 @@ def run_network(inputs, viewdirs, fn, embed_fn, embeddirs_fn, netchunk=1024 * 64
         raise TypeError("run_network: `fn` must be a snerf_amd.classic.NeRF (no eager fallback for foreign modules)")
     if not isinstance(embed_fn, Embedder) or embed_fn.out_dim != fn.input_ch:
         raise TypeError("run_network: embed_fn must come from snerf_amd.classic.get_embedder and match the model")
-    if viewdirs is None or not isinstance(embeddirs_fn, Embedder) or embeddirs_fn.out_dim != fn.input_ch_views:
-        raise TypeError("run_network: viewdirs + matching embeddirs_fn are required (use_viewdirs=True)")
+    if fn.use_viewdirs:
+        if viewdirs is None or not isinstance(embeddirs_fn, Embedder) or embeddirs_fn.out_dim != fn.input_ch_views:
+            raise TypeError("run_network: viewdirs + matching embeddirs_fn are required (use_viewdirs=True)")
+    elif viewdirs is not None:
+        # (the reference would concatenate the encoded directions and fail in torch.split on a network built without them)
+        raise TypeError("run_network: this network was built with use_viewdirs=False; pass viewdirs=None")
     fn._check_arena()
     N, S = inputs.shape[0], inputs.shape[1]
     pts = inputs.reshape(-1, 3).contiguous().float()
-    vd = viewdirs.float()
-    if vd.stride(-1) != 1:
-        vd = vd.contiguous()
+    vd = None
+    if viewdirs is not None:
+        vd = viewdirs.float()
+        if vd.stride(-1) != 1:
+            vd = vd.contiguous()
     params = fn.param_list()
     keep = torch.is_grad_enabled() and any(p.requires_grad for p in params)   # grad mode is off inside Function.forward
     raw = _RunNetworkFn.apply(fn, pts, vd, S, keep, *params)
@@ -393,11 +406,14 @@ def render(H, W, focal, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0.,
         n, cx, cy = rd.shape[0], W * 0.5, H * 0.5
         if c2w_staticcam is not None and n != H * W:
             raise ValueError("c2w_staticcam needs the rays of the whole H x W frame")
-    if near is not None and (torch.is_tensor(near) or torch.is_tensor(far)):
-        raise NotImplementedError("per-ray near / far tensors: pass scalars (every caller of the reference does)")
     dep = None if depths is None else depths.to(dev, torch.float32).reshape(-1).contiguous()
+    per_ray = torch.is_tensor(near) or torch.is_tensor(far)
     rows = ops.classic_ray_batch(H, W, float(focal), float(cx), float(cy), c2w, c2w_staticcam if use_viewdirs else None, ro, rd, n,
-                                 bool(ndc), float(near), float(far), dep, bool(use_viewdirs), dev)
+                                 bool(ndc), 0.0 if per_ray else float(near), 1.0 if per_ray else float(far), dep, bool(use_viewdirs), dev)
+    if per_ray:      # near * ones_like(rays_d[..., :1]) (render.py:74): anything that broadcasts against [N, 1]
+        ones = torch.ones(n, 1, dtype=torch.float32, device=dev)
+        rows[:, 6:7] = torch.as_tensor(near, dtype=torch.float32, device=dev) * ones
+        rows[:, 7:8] = torch.as_tensor(far, dtype=torch.float32, device=dev) * ones
     all_ret = batchify_rays(rows, chunk, **kwargs)
     for k in all_ret:
         all_ret[k] = torch.reshape(all_ret[k], list(sh[:-1]) + list(all_ret[k].shape[1:]))

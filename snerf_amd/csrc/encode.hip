@@ -414,6 +414,7 @@ struct MipEncBwd {
   long N; int S, cone, transform_idx, max_deg;
   const float* dE; long ld;
   float* g_origins; float* g_directions;
+  int fn_idx; float viewc[3]; const float* far_max;        // fn_idx 0: the view-centred warp (mip.py:367-369 fn1 + Jacobi_f :323-340), as in MipEncArgs
 };
 
 __global__ __launch_bounds__(256) void mip_encode_bwd_kernel(MipEncBwd a) {
@@ -454,11 +455,30 @@ __global__ __launch_bounds__(256) void mip_encode_bwd_kernel(MipEncBwd a) {
     const float nrm = sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
     const float l = nrm + 1e-8f, lj = nrm + 1e-5f;
     float fm[3], fc[3], J[3][3];
-    const bool far_c = l > 3.f, far_j = lj >= 3.f;
+    const bool warp0 = a.fn_idx == 0;
+    const bool far_c = !warp0 && l > 3.f, far_j = !warp0 && lj >= 3.f;
     const float sl = far_c ? (2.f - 3.f / l) / l : 1.f / 3.f;
+    float ln = 0.f, p1 = 1.f / 3.f, p2 = 0.f;
+    float dxv[3] = {0.f, 0.f, 0.f}, rv = 0.f, denv = 1.f, l15 = 1.f, sf = 1.f;      // fn_idx 0
+    if (warp0) {
+      // fm = (x - viewc) / sqrt(|x - viewc| far); J = ((l I - x x^T) / l^1.5) / sqrt(max far), l = |x| + 1e-5 (the forward's arithmetic)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) dxv[k] = x[k] - a.viewc[k];
+      rv = sqrtf(dxv[0] * dxv[0] + dxv[1] * dxv[1] + dxv[2] * dxv[2]);
+      denv = sqrtf(rv * far);
+      l15 = powf(lj, 1.5f); sf = sqrtf(a.far_max[0]);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) fm[k] = dxv[k] / denv;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { J[r][k] = (((r == k ? lj : 0.f) - x[r] * x[k]) / l15) / sf; acc += (J[r][k] * J[r][k]) * c[k]; }
+        fc[r] = acc;
+      }
+    } else {
 #pragma unroll
     for (int k = 0; k < 3; ++k) fm[k] = far_c ? (2.f - 3.f / l) * x[k] / l : x[k] / 3.f;
-    float ln = 0.f, p1 = 1.f / 3.f, p2 = 0.f;
     if (far_j) { ln = 1.f / lj; const float ln2 = ln * ln; p1 = -3.f * ln2 + 2.f * ln; p2 = 6.f * (ln2 * ln2) - 2.f * (ln2 * ln); }
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
@@ -466,6 +486,7 @@ __global__ __launch_bounds__(256) void mip_encode_bwd_kernel(MipEncBwd a) {
 #pragma unroll
       for (int k = 0; k < 3; ++k) { J[r][k] = (r == k ? p1 : 0.f) + p2 * (x[r] * x[k]); acc += (J[r][k] * J[r][k]) * c[k]; }
       fc[r] = acc;
+    }
     }
     // ---- feature gradients -> d fm, d fc
     const float* ge = a.dE + (ray * a.S + i) * a.ld;
@@ -485,6 +506,30 @@ __global__ __launch_bounds__(256) void mip_encode_bwd_kernel(MipEncBwd a) {
     // ---- contraction and its Jacobian -> d x, d c
     float gx[3] = {0.f, 0.f, 0.f}, gcv[3] = {0.f, 0.f, 0.f};
     const float inv_n = nrm > 0.f ? 1.f / nrm : 0.f;                 // d|x|/dx = x / |x| (0 at the origin, as torch.norm's backward)
+    if (warp0) {
+      // d fm_k / d x_j = delta_kj / den - dx_k dx_j / (2 r^2 den)
+      if (rv > 0.f) {
+        const float dot = gfm[0] * dxv[0] + gfm[1] * dxv[1] + gfm[2] * dxv[2];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) gx[k] += gfm[k] / denv - dot * dxv[k] / (2.f * rv * rv * denv);
+      }
+      // J_rk = (delta_rk l - x_r x_k) / (l^1.5 sf): through the outer product and through l = |x| + 1e-5
+      float glj = 0.f;
+      const float inv = 1.f / (l15 * sf);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          gcv[k] += (J[r][k] * J[r][k]) * gfc[r];
+          const float gJ = 2.f * J[r][k] * c[k] * gfc[r];
+          gx[r] -= gJ * x[k] * inv;
+          gx[k] -= gJ * x[r] * inv;
+          glj += gJ * ((r == k ? inv : 0.f) - 1.5f * J[r][k] / lj);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) gx[k] += glj * x[k] * inv_n;
+    } else {
     if (far_c) {
       const float dsl = -2.f / (l * l) + 6.f / (l * l * l);
       const float dot = gfm[0] * x[0] + gfm[1] * x[1] + gfm[2] * x[2];
@@ -517,6 +562,7 @@ __global__ __launch_bounds__(256) void mip_encode_bwd_kernel(MipEncBwd a) {
 #pragma unroll
       for (int k = 0; k < 3; ++k) gcv[k] += gfc[k] / 9.f;
     }
+    }
     // ---- lift_gaussian -> d origin, d direction
     float gdm = 0.f;
 #pragma unroll
@@ -543,7 +589,21 @@ extern "C" int snerf_mip_encode_bwd(const float* s_vals, const float* origins, c
                                     float* g_origins, float* g_directions, void* stream) {
   if (n_rays <= 0) return SNERF_OK;
   if (S <= 0 || max_deg < 1 || max_deg > 30 || dE == nullptr || ld < 6 * max_deg || g_origins == nullptr || g_directions == nullptr) return SNERF_ERR_ARG;
-  MipEncBwd a{s_vals, origins, directions, radii, near, far, n_rays, S, cone, transform_idx, max_deg, dE, ld, g_origins, g_directions};
+  MipEncBwd a{s_vals, origins, directions, radii, near, far, n_rays, S, cone, transform_idx, max_deg, dE, ld, g_origins, g_directions, 1, {0.f, 0.f, 0.f}, nullptr};
+  hipLaunchKernelGGL(mip_encode_bwd_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+  return snerf_check_launch();
+}
+
+// the same with the warp selected (snerf_mip_encode_warp's backward): fn_idx 0 = the view-centred warp around (vx, vy, vz), far_max = the
+// device scalar max(far) of the batch -- pose refinement of a model built with fn = 0 (models.py:35; mip.py:367-378)
+extern "C" int snerf_mip_encode_warp_bwd(const float* s_vals, const float* origins, const float* directions, const float* radii, const float* near,
+                                         const float* far, long n_rays, int S, int cone, int transform_idx, int max_deg, const float* dE, long ld,
+                                         float* g_origins, float* g_directions, int fn_idx, float vx, float vy, float vz, const float* far_max,
+                                         void* stream) {
+  if (n_rays <= 0) return SNERF_OK;
+  if (S <= 0 || max_deg < 1 || max_deg > 30 || dE == nullptr || ld < 6 * max_deg || g_origins == nullptr || g_directions == nullptr ||
+      (fn_idx != 0 && fn_idx != 1) || (fn_idx == 0 && far_max == nullptr)) return SNERF_ERR_ARG;
+  MipEncBwd a{s_vals, origins, directions, radii, near, far, n_rays, S, cone, transform_idx, max_deg, dE, ld, g_origins, g_directions, fn_idx, {vx, vy, vz}, far_max};
   hipLaunchKernelGGL(mip_encode_bwd_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
   return snerf_check_launch();
 }

@@ -214,9 +214,8 @@ class MipNerfModel(_ArenaModule):
         (utils/sample_utils.py:410-435) back-propagates through the encoders into the camera pose: the data gradient is carried one GEMM
         further to the IPE / view encodings, then through integrated_pos_enc, the contraction and its Jacobian, lift_gaussian and the
         interval lengths (t1 - t0)|d| of the compositing.  Fence posts carry no ray gradient (level 1 is detached, mip.py:318)."""
-        if ray_grads and self.fn == 0:
-            raise NotImplementedError("pose refinement (gradients to the rays) is implemented for the contraction warp fn=1 only")
         c = ctx
+        warp = None if self.fn == 1 else (self._viewc, c["far"].max().reshape(1))      # (the forward's warp argument, _run)
         g_o = g_d = g_vd = None
         if ray_grads:
             g_o, g_d, g_vd = (torch.zeros_like(c["o"]) for _ in range(3))
@@ -245,7 +244,7 @@ class MipNerfModel(_ArenaModule):
                 ops.app_embed_bwd(dVc[:, self.view_dim:], c["app"], S1, self.arena.g["emb.weight"], deterministic=getattr(self, "_deterministic", False))
             if ray_grads:
                 dE, dV = ig
-                eo, ed = ops.mip_encode_bwd(c["s1"], c["o"], c["d"], c["radii"], c["near"], c["far"], c["cone"], self.transform_idx, self.max_deg_point, dE)
+                eo, ed = ops.mip_encode_bwd(c["s1"], c["o"], c["d"], c["radii"], c["near"], c["far"], c["cone"], self.transform_idx, self.max_deg_point, dE, warp=warp)
                 g_o += eo; g_d += ed + gdir
                 g_vd += ops.mip_viewenc_bwd(c["vd"], S1, self.deg_view, dV)
         if on_done is not None:
@@ -258,7 +257,7 @@ class MipNerfModel(_ArenaModule):
                                   cc(g_acc0), cc(g_w0), None, d_den0, g_dirs=gdir)
             dE0 = self.prop.backward(d_den0, c["acts0"], want_input_grad=ray_grads)
             if ray_grads:
-                eo, ed = ops.mip_encode_bwd(c["s0"], c["o"], c["d"], c["radii"], c["near"], c["far"], c["cone"], self.transform_idx, self.max_deg_point, dE0)
+                eo, ed = ops.mip_encode_bwd(c["s0"], c["o"], c["d"], c["radii"], c["near"], c["far"], c["cone"], self.transform_idx, self.max_deg_point, dE0, warp=warp)
                 g_o += eo; g_d += ed + gdir
         if on_done is not None:
             on_done("proposal.")
@@ -298,8 +297,6 @@ class MipNerfModel(_ArenaModule):
         if torch.is_grad_enabled() and any(torch.is_tensor(r) and r.requires_grad for r in (rays.radii, rays.near, rays.far)):
             raise NotImplementedError("gradients w.r.t. radii / near / far are not propagated (the reference's pose refinement leaves them constant)")
         if self.fn == 0:
-            if ray_grad:
-                raise NotImplementedError("pose refinement (gradients to the rays) is implemented for the contraction warp fn=1 only")
             self.set_viewc(viewc)
         dev = self.arena.flat.device
         n = rays.origins.shape[0]

@@ -392,10 +392,13 @@ class ClassicNeRFNet(_Net):
     Buffers: E [M, Pw] embedding (63 + pad); SK [M, Pw + W] = [embedding | layer-skip output];
     V [M, W + Vw] = [feature | view embedding (27 + pad)]; OUT [M,4] fp32 = [rgb | alpha]."""
 
-    def __init__(self, arena, prefix, dt, D=8, W=256, input_ch=63, input_ch_views=27, skips=(4,), variant=8, alpha_head=True):
+    def __init__(self, arena, prefix, dt, D=8, W=256, input_ch=63, input_ch_views=27, skips=(4,), variant=8, alpha_head=True, output_ch=0):
         """`alpha_head=False`: the ``NeRF_RGB`` variant (run_nerf_helpers.py:157-212) -- no alpha_linear; column 3 of the output is left
-        for the caller (the frozen alpha model's density)."""
+        for the caller (the frozen alpha model's density).  `output_ch` > 0: the ``use_viewdirs=False`` network (run_nerf_helpers.py:100-101,
+        122-124): the trunk's output goes through ``output_linear`` (W -> output_ch) alone; ``views_linears.0`` exists (the reference
+        constructs it regardless, :90) but is never evaluated."""
         super().__init__(arena, prefix, dt, variant)
+        self.output_ch = int(output_ch)
         assert self.km == 1, "split-bf16 (compute='bf16x3') is built for the mip path's networks"
         assert len(skips) == 1 and 0 <= skips[0] < D - 1 and W % self.g == 0 and (W // 2) % self.g == 0
         self.D, self.Wd, self.ic, self.icv, self.skip = D, W, input_ch, input_ch_views, skips[0]
@@ -405,13 +408,15 @@ class ClassicNeRFNet(_Net):
         self.fused_embed = True           # ... with the positional encodings computed inside it (False: separate embedding kernel)
 
     @staticmethod
-    def param_shapes(D=8, W=256, input_ch=63, input_ch_views=27, skips=(4,), alpha_head=True):
+    def param_shapes(D=8, W=256, input_ch=63, input_ch_views=27, skips=(4,), alpha_head=True, output_ch=0):
         out = []
         for i in range(D):
             k = input_ch if i == 0 else (W + input_ch if (i - 1) in skips else W)
             out += [(f"pts_linears.{i}.weight", (W, k)), (f"pts_linears.{i}.bias", (W,))]
-        out += [("views_linears.0.weight", (W // 2, input_ch_views + W)), ("views_linears.0.bias", (W // 2,)),
-                ("feature_linear.weight", (W, W)), ("feature_linear.bias", (W,))]
+        out += [("views_linears.0.weight", (W // 2, input_ch_views + W)), ("views_linears.0.bias", (W // 2,))]
+        if output_ch > 0:
+            return out + [("output_linear.weight", (output_ch, W)), ("output_linear.bias", (output_ch,))]
+        out += [("feature_linear.weight", (W, W)), ("feature_linear.bias", (W,))]
         if alpha_head:
             out += [("alpha_linear.weight", (1, W)), ("alpha_linear.bias", (1,))]
         out += [("rgb_linear.weight", (3, W // 2)), ("rgb_linear.bias", (3,))]
@@ -427,6 +432,14 @@ class ClassicNeRFNet(_Net):
                 self._pack_fwd(n, n, [(0, 0, ic), (Pw, ic, W)], Pw + W)     # param [pts | h] -> buffer [pts pad | h]
             else:
                 self._pack_fwd(n, n, [(0, 0, W)], W)
+        if self.output_ch > 0:
+            self._pack_fwd("out", "output_linear", [(0, 0, W)], W)
+            if train:
+                self._pack_dgrad("out", ["output_linear"], 0, W)
+                for i in range(1, self.D):
+                    n = f"pts_linears.{i}"
+                    self._pack_dgrad(n, [n], ic if i == self.skip + 1 else 0, W)
+            return
         if self.alpha_head:
             self._pack_fwd("alpha", "alpha_linear", [(0, 0, W)], W)
         self._pack_fwd("feature", "feature_linear", [(0, 0, W)], W)
@@ -444,7 +457,7 @@ class ClassicNeRFNet(_Net):
         """the register-resident fused kernel (csrc/fmlp.hip) covers the S-NeRF configuration: bf16, 8 x 256, skip after layer 4,
         63 + 27 input channels, alpha head"""
         return (self.fused and self.dt == ops.BF16 and self.D == 8 and self.Wd == 256 and self.skip == 4 and self.ic == 63 and self.icv == 27
-                and self.alpha_head)
+                and self.alpha_head and self.output_ch == 0)
 
     def _pack_fused(self):
         W, ic = self.Wd, self.ic
@@ -539,8 +552,12 @@ class ClassicNeRFNet(_Net):
         M, W, Pw = pts.shape[0], self.Wd, self.Pw
         E = self.buf(M, Pw)
         SK = self.buf(M, Pw + W)
-        V = self.buf(M, W + self.Vw)
-        ops.classic_embed(pts, viewdirs, S, (self.ic - 3) // 6, (self.icv - 3) // 6, E, SK[:, :Pw], Pw, V[:, W:], self.Vw, self.dt)
+        noviews = self.output_ch > 0
+        V = None if noviews else self.buf(M, W + self.Vw)
+        if noviews:
+            ops.classic_embed(pts, None, S, (self.ic - 3) // 6, 0, E, SK[:, :Pw], Pw, None, 0, self.dt)
+        else:
+            ops.classic_embed(pts, viewdirs, S, (self.ic - 3) // 6, (self.icv - 3) // 6, E, SK[:, :Pw], Pw, V[:, W:], self.Vw, self.dt)
         acts = []
         x, k = E, Pw
         pp = [self.buf(M, W), self.buf(M, W)] if not keep else None
@@ -555,6 +572,10 @@ class ClassicNeRFNet(_Net):
                 x, k = SK, Pw + W
             else:
                 x, k = y, W
+        if noviews:
+            OUT = self.buf(M, self.output_ch, f32=True)
+            self.fwd("out", x, W, OUT, self.output_ch, ACT_NONE, out_f32=True)
+            return OUT, ((acts, None, None, SK, E) if keep else None)
         OUT = self.buf(M, 4, f32=True)
         if self.alpha_head:
             self.fwd("alpha", x, W, OUT[:, 3:], 1, ACT_NONE, out_f32=True)
@@ -581,6 +602,15 @@ class ClassicNeRFNet(_Net):
         acts, V, HV, SK, E = saved[:5]
         W, Pw, g, M = self.Wd, self.Pw, self.g, d_raw.shape[0]
         ah = self.alpha_head
+        if self.output_ch > 0:
+            oc, x7 = self.output_ch, acts[-1][2]
+            self.colsum(d_raw, oc, self.gB("output_linear"))
+            dz = self.head_grad(d_raw, oc)
+            self.wgrad("output_linear", dz, x7, oc, W)
+            dZ = self.buf(M, W)
+            self.dgrad("out", dz, dz.shape[1], dZ, W, mask=x7, colsum=self.gB(f"pts_linears.{self.D - 1}"))
+            self._trunk_backward(dZ, acts, SK, E)
+            return
         self.colsum(d_raw, 3, self.gB("rgb_linear"))
         if ah:
             self.colsum(d_raw[:, 3:], 1, self.gB("alpha_linear"))
@@ -619,6 +649,12 @@ class ClassicNeRFNet(_Net):
             self.wgrad("alpha_linear", DB[:, W:], x7, 1, W)
         dZ = self.buf(M, W)
         self.dgrad("fa", DB, DB.shape[1], dZ, W, mask=x7, colsum=self.gB(f"pts_linears.{self.D - 1}"))
+        self._trunk_backward(dZ, acts, SK, E)
+
+    def _trunk_backward(self, dZ, acts, SK, E):
+        """weight gradients of pts_linears.{D-1 .. 0} and the data gradients between them, from dZ = d loss / d (pre-activation of the
+        last trunk layer)"""
+        W, M = self.Wd, dZ.shape[0]
         for i in range(self.D - 1, -1, -1):
             x, k, y = acts[i]
             n = f"pts_linears.{i}"

@@ -622,13 +622,20 @@ def mip_composite_bwd(raw_rgb, raw_density, noise, s_vals, dirs, near, far, tran
               d_raw_density.stride(0), _p(g_dirs), _stream())
 
 
-def mip_encode_bwd(s_vals, origins, directions, radii, near, far, cone, transform_idx, max_deg, dE):
-    """d loss / d (origins, directions) from the IPE feature gradients dE fp32 [n*S, >= 6*max_deg] (pose refinement)."""
+def mip_encode_bwd(s_vals, origins, directions, radii, near, far, cone, transform_idx, max_deg, dE, warp=None):
+    """d loss / d (origins, directions) from the IPE feature gradients dE fp32 [n*S, >= 6*max_deg] (pose refinement).  `warp` = the
+    forward's ((vx, vy, vz), far_max): the view-centred warp of an fn = 0 model (snerf_mip_encode_warp_bwd)."""
     n, P = s_vals.shape
     _f32c(s_vals); _chk2d(dE, torch.float32)
     assert dE.shape[0] == n * (P - 1)
     g_o = torch.empty(n, 3, dtype=torch.float32, device=s_vals.device)
     g_d = torch.empty_like(g_o)
+    if warp is not None:
+        (vx, vy, vz), far_max = warp
+        _f32c(far_max)
+        _lib.call("snerf_mip_encode_warp_bwd", _p(s_vals), _p(origins), _p(directions), _p(radii), _p(near), _p(far), n, P - 1, 1 if cone else 0,
+                  int(transform_idx), int(max_deg), _p(dE), dE.stride(0), _p(g_o), _p(g_d), 0, float(vx), float(vy), float(vz), _p(far_max), _stream())
+        return g_o, g_d
     _lib.call("snerf_mip_encode_bwd", _p(s_vals), _p(origins), _p(directions), _p(radii), _p(near), _p(far), n, P - 1, 1 if cone else 0,
               int(transform_idx), int(max_deg), _p(dE), dE.stride(0), _p(g_o), _p(g_d), _stream())
     return g_o, g_d

@@ -196,10 +196,11 @@ def mip_composite_bwd(raw_rgb, raw_density, noise, s_vals, dirs, near, far, tran
         g_dirs.copy_(dd.grad if dd.grad is not None else torch.zeros_like(dd))
 
 
-def mip_encode_bwd(s_vals, origins, directions, radii, near, far, cone, transform_idx, max_deg, dE):
+def mip_encode_bwd(s_vals, origins, directions, radii, near, far, cone, transform_idx, max_deg, dE, warp=None):
+    kw = {} if warp is None else dict(fn_idx=0, viewc=torch.tensor(warp[0]))
     with torch.enable_grad():
         o, d = origins.detach().clone().requires_grad_(True), directions.detach().clone().requires_grad_(True)
-        fm, fc = om.sample2enc(s_vals, o, d, radii[:, None], near[:, None], far[:, None], "cone" if cone else "cylinder", transform_idx)
+        fm, fc = om.sample2enc(s_vals, o, d, radii[:, None], near[:, None], far[:, None], "cone" if cone else "cylinder", transform_idx, **kw)
         enc = om.integrated_pos_enc(fm, fc, 0, max_deg).reshape(-1, 6 * max_deg)
         (enc * dE[:, :6 * max_deg]).sum().backward()
     return o.grad, d.grad

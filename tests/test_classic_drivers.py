@@ -267,3 +267,84 @@ def test_config1_m1_full_size(golden, compute):
         close(pick(acc), g["acc_map"], 3e-2, 3e-2, "M1 acc (bf16)")
     white = 1.0 - acc[..., None]
     assert float((rgb - white).min()) > -1e-3     # white background: rgb >= 1 - acc
+
+
+# ---------------------------------------------------------------- branches beyond the S-NeRF configuration (golden g27 - g29) ----
+def _fill(net, flip=False):
+    sd = common.fill_state_dict_({k: torch.empty_like(v) for k, v in net.state_dict().items()})
+    net.load_state_dict({k: v.flip(0) for k, v in sd.items()} if flip else sd)
+    return net
+
+
+def test_nerf_without_viewdirs_matches_the_reference(backend, golden):
+    """NeRF(use_viewdirs=False, output_ch=5) (run_nerf_helpers.py:100-124; create_nerf's output_ch = 5, render.py:180-183): the
+    reference's state_dict keys (views_linears.0 exists, unused), run_network on viewdirs=None, the parameter gradients, and
+    render_rays on an 8-column ray batch -- against the reference's own outputs (g27)."""
+    from snerf_amd import classic
+    g = golden("g27_no_viewdirs")
+    mk = lambda: classic.NeRF(D=8, W=64, input_ch=63, input_ch_views=0, output_ch=5, skips=[4], use_viewdirs=False, compute="f32", device=DEV)
+    coarse, fine = _fill(mk()), _fill(mk(), True)
+    assert list(coarse.state_dict().keys()) == [str(k) for k in g["param_names"]]
+    embed_fn, ic = classic.get_embedder(10, 0)
+    nq = classic.make_network_query_fn(embed_fn, None)
+    run = classic.run_network(g["pts"].to(DEV), None, coarse, embed_fn, None)
+    assert run.shape == (12, 8, 5)
+    close(run, g["run_network_out"], 1e-4, 1e-4, "run_network (no viewdirs)")
+    ((run - g["target"].to(DEV)) ** 2).sum().backward()
+    named = dict(coarse.named_parameters())
+    for k in named:
+        if "grad_" + k in g:
+            ref = g["grad_" + k]
+            close(named[k].grad / (ref.abs().max() + 1e-12), ref / (ref.abs().max() + 1e-12), 0, 5e-4, "grad " + k)
+        else:
+            assert k.startswith("views_linears.0") and (named[k].grad is None or float(named[k].grad.abs().max()) == 0.0), k
+    with pytest.raises(TypeError, match="use_viewdirs=False"):
+        classic.run_network(g["pts"].to(DEV), g["ray_batch"][:, 3:6].to(DEV), coarse, embed_fn, None)
+    with torch.no_grad():
+        rr = classic.render_rays(g["ray_batch"].to(DEV), coarse, nq, N_samples=16, retraw=True, perturb=0., N_importance=32, network_fine=fine)
+    for k in ("rgb_map", "disp_map", "acc_map", "depth_map", "z_vals_map", "weights", "rgb0", "disp0", "acc0"):
+        close(rr[k], g["rr_" + k], 2e-4, 2e-4, "render_rays " + k)
+    assert rr["raw"].shape == g["rr_raw"].shape
+
+
+def test_identity_embedding_matches_the_reference(backend, golden):
+    """get_embedder(multires, i=-1) = (identity, 3) (run_nerf_helpers.py:55-57): NeRF(input_ch=3, input_ch_views=3) sees the raw points
+    and directions -- run_network, gradients, render_rays against the reference (g28)."""
+    from snerf_amd import classic
+    g = golden("g28_identity_embed")
+    e, ic = classic.get_embedder(10, -1)
+    ed, icv = classic.get_embedder(4, -1)
+    assert ic == 3 and icv == 3
+    x = torch.rand(5, 3)
+    assert e(x) is x
+    mk = lambda: classic.NeRF(D=8, W=64, input_ch=3, input_ch_views=3, output_ch=4, skips=[4], use_viewdirs=True, compute="f32", device=DEV)
+    coarse, fine = _fill(mk()), _fill(mk(), True)
+    nq = classic.make_network_query_fn(e, ed)
+    run = classic.run_network(g["pts"].to(DEV), g["viewdirs"].to(DEV), coarse, e, ed)
+    close(run, g["run_network_out"], 1e-4, 1e-4, "run_network (identity embedding)")
+    ((run - g["target"].to(DEV)) ** 2).sum().backward()
+    for k, p in coarse.named_parameters():
+        ref = g["grad_" + k]
+        close(p.grad / (ref.abs().max() + 1e-12), ref / (ref.abs().max() + 1e-12), 0, 5e-4, "grad " + k)
+    with torch.no_grad():
+        rr = classic.render_rays(g["ray_batch"].to(DEV), coarse, nq, N_samples=16, retraw=True, perturb=0., N_importance=32, network_fine=fine)
+    for k in ("rgb_map", "disp_map", "acc_map", "depth_map", "weights", "rgb0", "disp0", "acc0"):
+        close(rr[k], g["rr_" + k], 2e-4, 2e-4, "render_rays " + k)
+
+
+def test_render_with_per_ray_near_far_tensors(backend, golden):
+    """render(..., near=<[N,1] tensor>, far=<[N,1] tensor>) (render.py:74 broadcasts them against the rays) against the reference (g29)"""
+    from snerf_amd import classic
+    g = golden("g29_near_far")
+    mk = lambda: classic.NeRF(D=8, W=64, input_ch=63, input_ch_views=27, output_ch=4, skips=[4], use_viewdirs=True, compute="f32", device=DEV)
+    coarse, fine = _fill(mk()), _fill(mk(), True)
+    e, _ = classic.get_embedder(10, 0)
+    ed, _ = classic.get_embedder(4, 0)
+    kw = dict(network_fn=coarse, network_query_fn=classic.make_network_query_fn(e, ed), N_samples=16, N_importance=32, network_fine=fine, perturb=0.,
+              white_bkgd=False, raw_noise_std=0.)
+    with torch.no_grad():
+        out = classic.render(6, 8, 7.5, chunk=5, rays=(g["rays_o"].to(DEV), g["rays_d"].to(DEV)), ndc=False, near=g["near"].to(DEV), far=g["far"].to(DEV),
+                             use_viewdirs=True, **kw)
+    for i in range(4):
+        close(out[i], g[str(i)], 2e-4, 2e-4, f"render output {i}")
+    close(out[4]["z_vals_map"], g["x_z_vals_map"], 1e-6, 1e-6, "z_vals")

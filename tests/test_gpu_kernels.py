@@ -520,6 +520,38 @@ def test_mip_encode_bwd_vs_oracle_autograd(n, S, cone, deg):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,S,cone,deg", [(130, 64, True, 16), (37, 127, False, 10)])
+def test_mip_encode_warp_bwd_vs_oracle_autograd(n, S, cone, deg):
+    """the same gradient through the view-centred warp of an fn = 0 model (mip.py:367-369 fn1, :323-340 Jacobi_f): snerf_mip_encode_warp_bwd
+    against float64 / float32 autograd through oracle/mip.py's sample2enc(fn_idx=0)"""
+    from snerf_amd import ops
+    r = _pose_rays(n, 5 + S)
+    g = torch.Generator().manual_seed(S + 1)
+    s = torch.sort(torch.rand(n, S + 1, generator=g), -1).values
+    s[:, 0], s[:, -1] = 0.0, 1.0
+    dE = torch.randn(n * S, 6 * deg + 4, generator=g)
+    viewc = (0.3, -0.2, 0.5)
+    def autograd(dt):
+        o, d = r["origins"].to(dt).clone().requires_grad_(True), r["directions"].to(dt).clone().requires_grad_(True)
+        fm, fc = om.sample2enc(s.to(dt), o, d, r["radii"].to(dt), r["near"].to(dt), r["far"].to(dt), "cone" if cone else "cylinder", 0, fn_idx=0,
+                               viewc=torch.tensor(viewc, dtype=dt))
+        enc = om.integrated_pos_enc(fm, fc, 0, deg).reshape(-1, 6 * deg)
+        (enc * dE[:, :6 * deg].to(dt)).sum().backward()
+        return o.grad, d.grad
+    o32, d32 = autograd(torch.float32)
+    o64, d64 = autograd(torch.float64)
+    c = lambda t: t.detach().cuda().contiguous()
+    far = c(r["far"]).reshape(-1)
+    go, gd = ops.mip_encode_bwd(c(s), c(r["origins"]), c(r["directions"]), c(r["radii"]).reshape(-1), c(r["near"]).reshape(-1), far, cone, 0, deg, c(dE),
+                                warp=(viewc, far.max().reshape(1)))
+    for got, ref32, ref64, what in ((go, o32, o64, "origins"), (gd, d32, d64, "directions")):
+        scale = ref64.abs().max(dim=-1).values
+        err = (got.cpu().double() - ref64).abs().max(dim=-1).values / scale
+        noise = (ref32.double() - ref64).abs().max(dim=-1).values / scale
+        assert float(err.max()) <= 3 * float(noise.max()) + 2e-5 and float(err.median()) <= 3 * float(noise.median()) + 2e-5, (what, float(err.max()), float(noise.max()))
+
+
+@pytest.mark.gpu
 def test_mip_viewenc_bwd_and_composite_direction_gradient_vs_oracle_autograd():
     from snerf_amd import ops
     n, S, deg = 70, 33, 4

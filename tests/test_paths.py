@@ -367,7 +367,7 @@ def test_mipnerf_appearance_embedding_vs_reference_golden(backend, golden, compu
 @pytest.mark.parametrize("compute", ["f32", "bf16"])
 def test_mipnerf_view_centred_warp_vs_reference_golden(backend, golden, compute):
     """MipNerfModel(fn=0): the view-centred warp (mip.py:367-378: fn1 + Jacobi_f, viewc = mean camera centre) instead of the
-    contraction -- outputs and every parameter gradient against the reference model's own (g23); pose refinement is refused."""
+    contraction -- outputs and every parameter gradient against the reference model's own (g23)."""
     g = golden("g23_warp0")
     from snerf_amd import mipnerf
     m = mipnerf.MipNerfModel(n_samples=16, N_fine=17, no_warp_sample=0, ray_shape="cone", fn=0, radius=3., transform_idx=0, real=True,
@@ -391,9 +391,29 @@ def test_mipnerf_view_centred_warp_vs_reference_golden(backend, golden, compute)
             got, want = named[k].grad.detach().cpu(), g["grad." + k]
             rel = float((got - want).norm() / (want.norm() + 1e-20))
             assert rel < 5e-3, (k, rel)
-    o = rays.origins.clone().requires_grad_(True)
-    with pytest.raises(NotImplementedError, match="pose refinement"):
-        m(rays._replace(origins=o), False, False, g["viewc"])
+
+
+def test_mipnerf_pose_refinement_through_the_view_centred_warp(backend, golden):
+    """pose refinement of an fn = 0 model: d loss / d (origins, directions, viewdirs) through fn1 (mip.py:368-369) and Jacobi_f
+    (:323-340) against the reference model's own autograd (g30; snerf_mip_encode_warp_bwd)."""
+    from snerf_amd import mipnerf
+    g = golden("g30_pose_fn0")
+    S0, P1, hidden = int(g["S0"]), int(g["P1"]), int(g["hidden"])
+    m = mipnerf.MipNerfModel(n_samples=S0, N_fine=P1, no_warp_sample=0, ray_shape="cone", fn=0, radius=3., transform_idx=0, real=True,
+                             rgb_layer=3, hidden_layer=hidden, density_noise=0., max_deg_point=16, proposal_hidden_layer=64,
+                             proposal_loss=True, compute="f32", device=DEV)
+    m.load_state_dict(common.fill_state_dict_({k: torch.empty_like(v) for k, v in m.state_dict().items()}))
+    rays = {k: g[k].to(DEV) for k in mipnerf.Rays._fields}
+    for k in ("origins", "directions", "viewdirs"):
+        rays[k] = rays[k].clone().requires_grad_(True)
+    ret = m(mipnerf.Rays(**rays), False, False, g["viewc"])
+    close(ret[1][0], g["rgb"], 1e-4, 1e-5, "rgb"); close(ret[1][1], g["dist1"], 1e-4, 1e-4, "distance")
+    loss = (ret[1][0] * g["w_rgb"].to(DEV)).sum() + 0.05 * (ret[1][1] * g["w_d1"].to(DEV)).sum() + 0.05 * (ret[0][1] * g["w_d0"].to(DEV)).sum()
+    loss.backward()
+    for k in ("origins", "directions", "viewdirs"):
+        ref_g = g["g_" + k]
+        err = float((rays[k].grad.cpu() - ref_g).abs().max())
+        assert float(ref_g.abs().max()) > 0 and err <= 3e-3 * float(ref_g.abs().max()), (k, err, float(ref_g.abs().max()))
 
 
 def test_mip_trainer_passes_the_view_centre_of_the_fn0_warp(backend, golden):
