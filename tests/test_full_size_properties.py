@@ -243,3 +243,33 @@ def test_captured_train_step_replays_like_the_eager_step():
     t2.lr = 0.0
     t2.replay()
     assert torch.equal(m2.arena.flat, before), "replay() ignored the updated learning rate"
+
+
+def test_precision_modes_on_fitted_weights():
+    """the bf16 / split-bf16 bounds above are measured at initialisation-like weights; a FITTED model has sharp
+    densities and larger activations.  The BASELINE-shape model is fitted for 120 steps to the analytic street scene (tools/ert_scene.py)
+    and 40 image rows are rendered from the same weights in compute = f32 / bf16x3 / bf16.  Measured on MI355X
+    (profiles/r5_c_bench_default.json.log, `fitted_weights_precision`): bf16x3 -- rgb 1.1e-5, depth max rel 8.3e-5, 122.7 dB: inside
+    north_star's 1e-4; bf16 -- 66.6 dB, rgb 4.3e-3, depth max rel 7.2e-3 (p99.9 4.1e-3): 50x its init-time error, OUTSIDE 1e-4 by
+    two orders.  The bounds sit 2-3x off the measurement; the point of the test is that the drift of plain bf16 is known and that
+    the split mode does not share it."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import ert_scene
+    from snerf_amd.trainer import MipTrainer
+    m = _model("bf16")
+    tr = MipTrainer(m, lr=1e-3, depth_lambda=0.5, coarse_depth_mult=1.0)
+    g = torch.Generator(device="cpu").manual_seed(0)
+    for it in range(120):
+        pix = torch.randint(0, ert_scene.H * ert_scene.W, (4096,), generator=g)
+        rays = ert_scene.rays_of(torch.stack([pix // ert_scene.W, pix % ert_scene.W], -1).int().cuda(), 0, 4096, torch.device("cuda"))
+        rgb, t_hit = ert_scene.analytic_scene(rays.origins, rays.directions)
+        tr.lr = 1e-3 * (0.1 ** (it / 120))
+        tr.step(rays, rgb, t_hit, torch.ones_like(t_hit))
+    res = ert_scene.precision_on_fitted_weights(m, _model, rows=20)
+    print("MEASURED precision on fitted weights:", res)
+    x3, b = res["bf16x3"], res["bf16"]
+    assert x3["max_abs_err_rgb"] < 5e-5 and x3["max_rel_err_depth"] < 2.5e-4 and x3["psnr_db"] > 110.0, x3
+    assert b["psnr_db"] > 58.0 and b["max_abs_err_rgb"] < 1.5e-2 and b["p999_rel_err_depth"] < 1.5e-2, b
+    assert b["max_abs_err_rgb"] > 10 * x3["max_abs_err_rgb"], "bf16 is expected to drift on fitted weights; the split mode is not"

@@ -10,6 +10,12 @@ from oracle import common, mip as om
 
 from cpu_ops_emulation import emulate_ops
 
+import json
+import os
+
+_BOUNDS_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bf16_grad_bounds.json")
+_BF16_BOUNDS = json.load(open(_BOUNDS_FILE)) if os.path.exists(_BOUNDS_FILE) else {}
+
 
 @pytest.fixture(params=[pytest.param("hip", marks=pytest.mark.gpu), "emulated"])
 def backend(request):
@@ -60,11 +66,23 @@ def check_grads(named, ref_params, keys, compute, tol):
             print(f"MEASURED split-bf16 grad {k}: rel L2 {rel:.3e}")
             assert rel < 6e-3, f"grad {k}: relative L2 error {rel:.3e}"
         else:
-            # measured (rounds 2-3, GPU kernels and the CPU emulation alike): <= 8.7e-2 on the worst parameter (first-layer weights);
-            # the bound is 1.3x that, not the 2x of the loss tolerance it used to be ("would pass a 2x regression")
+            # bf16: held PER PARAMETER to 1.3 x the error measured for it (tests/bf16_grad_bounds.json: per test and backend -- the HIP
+            # kernels on an MI355X, the CPU emulation here), with a floor of 2e-3 for parameters whose error is at the noise level; a
+            # parameter without an entry falls back to the old global bound (the global 0.113 hid a 30 % regression of the
+            # first layer).  SNERF_DUMP_BF16_BOUNDS=<file>: record the measurements instead (tools/measure_bf16_grad_bounds.sh).
             rel = ((got - gref).norm() / (gref.norm() + 1e-12)).item()
             print(f"MEASURED bf16 grad {k}: rel L2 {rel:.3e}")
-            assert rel < min(2 * tol, 0.113), f"grad {k}: relative L2 error {rel:.3e}"
+            test = os.environ.get("PYTEST_CURRENT_TEST", "?").split("::")[-1].split(" ")[0]
+            be = "hip" if DEV == "cuda" else "emulated"
+            dump = os.environ.get("SNERF_DUMP_BF16_BOUNDS")
+            if dump:
+                d = json.load(open(dump)) if os.path.exists(dump) else {}
+                d.setdefault(test, {}).setdefault(be, {})[k] = max(rel, d.get(test, {}).get(be, {}).get(k, 0.0))
+                json.dump(d, open(dump, "w"), indent=1, sort_keys=True)
+                continue
+            measured = _BF16_BOUNDS.get(test, {}).get(be, {}).get(k)
+            bound = min(2 * tol, 0.113) if measured is None else max(1.3 * measured, 2e-3)
+            assert rel < bound, f"grad {k}: relative L2 error {rel:.3e} (bound {bound:.3e}, measured {measured})"
 
 
 def nerf_params(W, flip=False):
