@@ -939,6 +939,23 @@ def main():
         t0 = time.perf_counter()
         out["path_b"] = path_b_leg(device)
         out["path_b"]["leg_wall_s"] = round(time.perf_counter() - t0, 1)
+        if not args.no_ert_scene:
+            # north_star's "early ray termination and sample compaction" where it pays: path B's fine pass re-evaluates the 64
+            # uniform coarse positions (render.py:380-389), a good part of which lies behind the first surface.  Two classic NeRFs fitted for
+            # 300 steps to the analytic street scene, the 1600 x 900 frame plain and with render_rays(ert=(1e-4, 48)) (exact bound on acc / rgb)
+            sys.path.insert(0, os.path.join(REPO, "tools"))
+            import ert_classic_analysis
+            t0 = time.perf_counter()
+            r = ert_classic_analysis.fit_and_measure(steps=300, eps_list=(1e-4,), rows_n=900, groups=(48,), ert_eps=1e-4, dev=device, row0=0)
+            m48 = r["measured"]["eps_0.0001_G48"]
+            out["path_b_ert"] = {"what": "classic render_rays frame 1600 x 900 (64 + 128, two fitted NeRF 8 x 256), plain vs ert=(1e-4, 48): fine pass front to back in "
+                                         "groups of 48 samples, rays leave at fine transmittance <= 1e-4, rows compacted (csrc-free: selection in torch, evaluation by fmlp_kernel)",
+                                 "fit_steps": r["fit_steps"], "fit_psnr_db": r["fit_psnr_db"], "frame_ms_plain": r["window_ms_plain"], "frame_ms_ert": m48["window_ms"],
+                                 "speedup": m48["speedup"], "fine_evaluations_kept": m48["fine_evaluations_kept"],
+                                 "best_case_speedup_at_sample_granularity": r["rules"]["exact_eps_0.0001"]["best_case_frame_speedup"],
+                                 "max_abs_err_rgb": m48["max_abs_err_rgb"], "max_abs_err_acc": m48["max_abs_err_acc"], "max_abs_err_depth": m48["max_abs_err_depth"],
+                                 "leg_wall_s": round(time.perf_counter() - t0, 1)}
+            torch.cuda.empty_cache()
         t0 = time.perf_counter()
         out["grid_encoder"] = grid_encoder_leg(device)
         out["grid_encoder"]["leg_wall_s"] = round(time.perf_counter() - t0, 1)

@@ -289,12 +289,54 @@ def _sample_pdf_z(z_vals, weights, N_samples, det, pytest, u, return_inds):
     return ops.classic_sample_pdf(z_vals, weights.detach().contiguous(), u, True, return_inds, True)
 
 
+ERT_STATS = {"evaluated": 0, "total": 0}          # fine-network evaluations of the ert renders since the caller last reset it
+
+
+def _fine_pass_front_to_back(rb, z_all, viewdirs, run_fn, network_query_fn, eps_t, G):
+    """The fine network front to back in groups of G samples (inference extension, NOT in the reference): after every group the rays
+    whose transmittance -- from the fine network's own densities, raw2outputs' alpha (run_nerf_helpers.py:394-414) -- has fallen to
+    <= eps_t leave, and the rows of the next group are compacted to the survivors.  Unevaluated samples keep raw = 0 (alpha = 0,
+    weight 0): the weights they would have had sum to <= eps_t per ray, which bounds the error of acc_map and (x 1) of rgb_map.
+    The 64 uniform coarse positions the fine pass re-evaluates (render.py:380-389) are what lies behind an opaque hit: measured on a
+    fitted street scene 26 % of the fine evaluations at eps_t = 1e-4 (tools/ert_classic_analysis.py).  -> raw [N, S, C]"""
+    N, S = z_all.shape
+    dev = z_all.device
+    dn = rb[:, 3:6].norm(dim=-1)
+    alive = None                       # None = every ray; else the surviving rays' indices, with their rows / transmittances kept compact
+    rbs, T, dns = rb, torch.ones(N, device=dev), dn
+    raw = None
+    for g0 in range(0, S, G):
+        g1 = min(g0 + G, S)
+        if rbs.shape[0] == 0:
+            break
+        zr = (z_all[:, g0:g1] if alive is None else z_all[alive, g0:g1]).contiguous()
+        pts = ops.classic_points(rbs, zr)                                              # render.py:354 on the surviving rows
+        rg = network_query_fn(pts, None if viewdirs is None else rbs[:, -3:], run_fn)
+        if raw is None:
+            raw = torch.zeros(N, S, rg.shape[-1], dtype=rg.dtype, device=dev)
+        if alive is None:
+            raw[:, g0:g1] = rg
+        else:
+            raw[alive, g0:g1] = rg
+        ERT_STATS["evaluated"] += int(rg.shape[0]) * (g1 - g0)
+        if g1 < S:
+            znext = z_all[:, g0 + 1:g1 + 1] if alive is None else z_all[alive, g0 + 1:g1 + 1]
+            T = T * torch.exp(-(torch.relu(rg[..., 3]) * ((znext - zr) * dns[:, None])).sum(-1))       # x prod (1 - alpha) over the group
+            keep = T > eps_t
+            if int(keep.sum()) < keep.numel():                                         # (the one device->host read per group)
+                alive = torch.nonzero(keep).reshape(-1) if alive is None else alive[keep]
+                rbs, T, dns = rbs[keep], T[keep], dns[keep]
+    ERT_STATS["total"] += N * S
+    return raw
+
+
 def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False, lindisp=False, perturb=0.,
                 N_importance=0, network_fine=None, white_bkgd=False, raw_noise_std=0., verbose=False, pytest=False,
-                t_rand: Optional[torch.Tensor] = None, u: Optional[torch.Tensor] = None, return_inds: bool = False):
+                t_rand: Optional[torch.Tensor] = None, u: Optional[torch.Tensor] = None, return_inds: bool = False, ert=None):
     """Volumetric rendering of a ray batch [N, 8|11] = [o3, d3, near, far, (viewdir3)]; returns the
     reference's dict (render.py:394-401).  Extra keyword-only inputs `t_rand` [N,S] / `u` [N,Nimp]
-    replace the internal torch.rand draws (parity tests)."""
+    replace the internal torch.rand draws (parity tests).  `ert=(eps_t, G)` (inference only, under torch.no_grad(); NOT in the
+    reference): early ray termination + row compaction in the fine pass -- see _fine_pass_front_to_back."""
     N_rays = ray_batch.shape[0]
     if N_rays == 0:   # as the reference (run_network's torch.cat of no chunks): an error, not an empty dict
         raise ValueError("render_rays: empty ray batch")
@@ -325,9 +367,17 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
         rgb_map_0, disp_map_0, acc_map_0 = rgb_map, disp_map, acc_map
         z_samples, inds, z_std = _sample_pdf_z(z_vals, weights, N_importance, perturb == 0., pytest, u, return_inds)
         z_all = ops.classic_merge_sort(z_vals, z_samples)
-        pts = ops.classic_points(rb, z_all)
         run_fn = network_fn if network_fine is None else network_fine
-        raw = network_query_fn(pts, viewdirs, run_fn)
+        if ert is not None:
+            if torch.is_grad_enabled() or raw_noise_std > 0.:
+                raise NotImplementedError("ert is an inference mode: call under torch.no_grad() with raw_noise_std = 0")
+            eps_t, G = float(ert[0]), int(ert[1])
+            if not (eps_t < 1.0 and G >= 1):
+                raise ValueError("ert = (eps_t < 1, G >= 1)")
+            raw = _fine_pass_front_to_back(rb, z_all, viewdirs, run_fn, network_query_fn, eps_t, G)
+        else:
+            pts = ops.classic_points(rb, z_all)
+            raw = network_query_fn(pts, viewdirs, run_fn)
         rgb_map, disp_map, acc_map, weights_, depth_map = raw2outputs(raw, z_all, rays_d, raw_noise_std, white_bkgd, pytest=pytest)
     ret = {'rgb_map': rgb_map, 'disp_map': disp_map, 'acc_map': acc_map, 'depth_map': depth_map, 'z_vals_map': z_vals,
            'weights': weights}

@@ -150,3 +150,47 @@ def test_front_to_back_ert_is_exact_without_termination_and_bounded_by_eps():
     ev = w_fast != 0
     assert float((w_full[ev] - w_fast[ev]).abs().max()) < 1e-6
     assert float((w_full * (~ev)).sum(-1).max()) <= eps * 1.01 + 1e-6
+
+
+def test_classic_fine_pass_front_to_back_ert():
+    """render_rays(..., ert=(eps_t, G)): path B's fine network front to back in groups of G of the 192 sorted samples, rays leave once
+    the fine transmittance is <= eps_t, the next group's rows are compacted to the survivors.  Nothing leaves (eps_t < 0): bit-identical
+    to the plain render whatever the grouping.  Opaque medium: fewer evaluations, acc / rgb / depth inside the exact bound."""
+    from snerf_amd import classic
+    torch.manual_seed(0)
+    mk = lambda: classic.NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=4, skips=[4], use_viewdirs=True, compute="bf16", device="cuda")
+    coarse, fine = mk(), mk()
+    e, _ = classic.get_embedder(10, 0)
+    ed, _ = classic.get_embedder(4, 0)
+    q = classic.make_network_query_fn(e, ed)
+    g = torch.Generator().manual_seed(1)
+    N = 3000
+    d = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1)
+    o = torch.randn(N, 3, generator=g) * 0.1 + torch.tensor([0.0, 0.0, 4.0])
+    rays = torch.cat([o, -d, torch.full((N, 1), 2.0), torch.full((N, 1), 6.0), -d], -1).cuda()
+    kw = dict(network_fn=coarse, network_query_fn=q, N_samples=64, perturb=0.0, N_importance=128, network_fine=fine, retraw=True)
+    with torch.no_grad():
+        full = classic.render_rays(rays, **kw)
+        for G in (32, 50):                                                    # 192 = 6 x 32 = 3 x 50 + 42 (ragged last group)
+            same = classic.render_rays(rays, ert=(-1.0, G), **kw)
+            for k in ("rgb_map", "acc_map", "depth_map", "disp_map", "raw"):
+                assert torch.equal(torch.nan_to_num(full[k], nan=-7.0), torch.nan_to_num(same[k], nan=-7.0)), (G, k)     # (disp = 1 / (depth / acc): 0 / 0 on an empty ray)
+        with pytest.raises(ValueError):
+            classic.render_rays(rays, ert=(1.0, 32), **kw)
+        with torch.no_grad():
+            for net in (coarse, fine):
+                dict(net.named_parameters())["alpha_linear.bias"] += 40.0      # an opaque medium: rays end within the first ~130 of the 192 sorted samples
+                net.arena.bump()
+        full = classic.render_rays(rays, **kw)
+        eps = 1e-3
+        classic.ERT_STATS.update(evaluated=0, total=0)
+        fast = classic.render_rays(rays, ert=(eps, 16), **kw)
+    ev, tot = classic.ERT_STATS["evaluated"], classic.ERT_STATS["total"]
+    assert tot == N * 192 and 0 < ev < 0.85 * tot, (ev, tot)
+    assert float((fast["acc_map"] - full["acc_map"]).abs().max()) <= eps * 1.01 + 1e-6
+    assert float((fast["rgb_map"] - full["rgb_map"]).abs().max()) <= eps * 1.01 + 1e-6          # sigmoid colours in [0, 1]
+    assert float((fast["depth_map"] - full["depth_map"]).abs().max()) <= eps * 6.0 * 1.01 + 1e-5  # sum w z, z <= far = 6
+    evaluated = (fast["raw"] != 0).any(-1)
+    assert torch.equal(fast["raw"][evaluated], full["raw"][evaluated])
+    with pytest.raises(NotImplementedError):
+        classic.render_rays(rays, ert=(eps, 32), **kw)                        # (grad mode on)
