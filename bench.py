@@ -285,7 +285,7 @@ def counter_bytes(key):
         return None, f"unavailable: {e}"
 
 
-def path_c_leg(device, n_rays=65536, steps=5, compute="fp16", also=("bf16",)):
+def path_c_leg(device, n_rays=65536, steps=10, compute="fp16", also=("bf16",), scale_factor=0.01):
     """BASELINE configs 4-5 (S-NeRF++ / zipnerf background, waymo.gin shape: 64 + 64 + 32 intervals x 7 multisamples, hash grids
     L = 6 / 8 / 10, T = 2^21): ZipTrainer train step at 65 536 rays (configs.py:29), forward only, and the whole 1920 x 1280 frame through
     zipnerf.render_image (compute_extras like random_render_waymo_seq.py:197).  Roofline of the dominant kernel (hash-grid gather of the
@@ -307,10 +307,14 @@ def path_c_leg(device, n_rays=65536, steps=5, compute="fp16", also=("bf16",)):
     c2w[:, 3] = torch.tensor([0.02, -0.01, 0.03])
     Kinv, c2wd = torch.linalg.inv(K)[None].to(device), c2w[None].to(device)
     rays = ops.zip_pixels_to_rays((pix % 1920).int().to(device), (pix // 1920).int().to(device), None, Kinv, c2wd)
-    batch = dict(rays, near=torch.full((R, 1), 0.1, device=device), far=torch.full((R, 1), 10.0, device=device))
+    # the WAYMO loader's ray range after its PCA rescale (internal/datasets.py:837-841: near = 2 scale_factor, far = 10000 scale_factor;
+    # scale_factor = 1 / (largest camera distance): 0.01 for a 100 m sequence), not waymo.gin's 0.1 / 10, which that loader overrides
+    t_near, t_far = 2.0 * scale_factor, 10000.0 * scale_factor
+    batch = dict(rays, near=torch.full((R, 1), t_near, device=device), far=torch.full((R, 1), t_far, device=device))
     batch["origins"] = batch["origins"] + (torch.randn(R, 3, generator=g) * 0.05).to(device)
     tgt = torch.rand(R, 3, generator=g).to(device)
-    targets = dict(depth=(torch.rand(R, generator=g) * 4 + 0.2).to(device), depth_mask=(torch.rand(R, generator=g) < 0.5).float().to(device))
+    # (LiDAR returns at 2 .. 80 m in scene units)
+    targets = dict(depth=(torch.rand(R, generator=g) * 0.78 + 0.02).to(device), depth_mask=(torch.rand(R, generator=g) < 0.5).float().to(device))
     train = lambda: tr.step(batch, tgt, train_frac=0.5, rand=True, targets=targets)
 
     def fwd():
@@ -337,7 +341,7 @@ def path_c_leg(device, n_rays=65536, steps=5, compute="fp16", also=("bf16",)):
     W_, H_ = 1920, 1280
     pidx = torch.arange(W_ * H_, device=device)
     fr = ops.zip_pixels_to_rays((pidx % W_).int(), (pidx // W_).int(), None, Kinv, c2wd)
-    fr.update(near=torch.full((W_ * H_, 1), 0.1, device=device), far=torch.full((W_ * H_, 1), 10.0, device=device))
+    fr.update(near=torch.full((W_ * H_, 1), t_near, device=device), far=torch.full((W_ * H_, 1), t_far, device=device))
     frame = {k: v.reshape(H_, W_, -1) for k, v in fr.items()}
     cfg = types.SimpleNamespace(render_chunk_size=65536, vis_num_rays=16)
     m.config = cfg
@@ -383,7 +387,7 @@ def path_c_leg(device, n_rays=65536, steps=5, compute="fp16", also=("bf16",)):
           "frac": round(useful[2] / (enc_train[2] * 1e-3) / 1e9 / 8000.0, 4), "useful_bytes_per_launch": useful[2],
           "traffic": cb, "traffic_source": cb_src, "launch_ms": round(enc_train[2], 3)}
     out = {"workload": "BASELINE configs[3] / [4]: zipnerf Model (waymo.gin: 64 + 64 + 32 intervals x 7 multisamples, grids L = 6 / 8 / 10, T = 2^21, "
-                       "NeRF table fp16), ZipTrainer step with depth targets; %s MLPs%s" % (compute, " (static loss scale %g folded into Adam)" % tr.loss_scale if tr.loss_scale != 1 else ""),
+                       "NeRF table fp16), rays in [2, 10000] x scale_factor 0.01 (datasets.py:837-841), ZipTrainer step with depth targets; %s MLPs%s" % (compute, " (static loss scale %g folded into Adam)" % tr.loss_scale if tr.loss_scale != 1 else ""),
            "dtype": compute,
            "rays_per_step": R, "steps": steps, "train_ms_per_step": round(dt_train * 1e3, 3), "train_rays_per_s": round(R / dt_train, 1),
            "fwd_ms": round(dt_fwd * 1e3, 3), "fwd_rays_per_s": round(R / dt_fwd, 1),

@@ -38,6 +38,7 @@ class _grid_encode(Function):
         # D = 3 / C in {1, 4} / hash / linear without input gradients (what internal/models.py:413-421 constructs): the forward above ran
         # the corner-cached gather and the backward takes the binned table gradient (csrc/zip.hip g3_*) instead of the atomic scatter
         ctx.fast = ops.grid_fast_ok(inputs.shape[1], C, gridtype, align_corners, interpolation, table.dtype, calc_grad_inputs)
+        ctx.offsets_host = ops.grid_host_offsets(offsets) if ctx.fast and ctx.needs_input_grad[1] else None   # (read here: `offsets` is the caller's tensor object)
         ctx.align_corners = align_corners
         return outputs
 
@@ -48,7 +49,7 @@ class _grid_encode(Function):
         grad = grad.contiguous().to(table.dtype)
         if ctx.fast:
             out_dt = emb_dtype if emb_dtype in (torch.float32, torch.float16) else torch.float32
-            g_emb = ops.grid_encode_bwd_binned(grad, inputs, offsets, table.shape[1], L, S, H, out_dtype=out_dt)
+            g_emb = ops.grid_encode_bwd_binned(grad, inputs, offsets, table.shape[1], L, S, H, out_dtype=out_dt, offsets_host=ctx.offsets_host)
             return None, g_emb.to(emb_dtype), None, None, None, None, None, None, None
         g_emb, g_in = ops.grid_encode_bwd(grad, inputs, table, offsets, L, S, H, gridtype, ctx.align_corners, interpolation,
                                           dy_dx if has_dd else None)

@@ -828,20 +828,19 @@ def grid_set_fast_path(on: bool):
     _grid_fast_sent = GRID_FAST
 
 
-_host_offsets = {}
-
-
 def grid_host_offsets(offsets):
-    """host copy (numpy int32) of a GridEncoder's device `offsets` buffer, cached per tensor storage: the bin plan of the binned table
-    gradient is made on the host.  One device->host copy the first time a given buffer is seen."""
-    key = (offsets.data_ptr(), offsets.numel(), offsets._version)
-    h = _host_offsets.get(key)
-    if h is None:
-        import numpy as np
-        h = np.ascontiguousarray(offsets.detach().cpu().numpy().astype(np.int32))
-        if len(_host_offsets) > 64:
-            _host_offsets.clear()
-        _host_offsets[key] = h
+    """host copy (numpy int32) of a GridEncoder's device `offsets` buffer -- the bin plan of the binned table gradient is made on the
+    host.  The copy rides on the tensor OBJECT (with the tensor's version), so a module's buffer is copied once; a foreign or rebuilt
+    tensor costs one device->host copy per call.  (Never keyed by address: a freed buffer's address can come back with other contents.)"""
+    c = getattr(offsets, "_snerf_host_offsets", None)
+    if c is not None and c[0] == offsets._version:
+        return c[1]
+    import numpy as np
+    h = np.ascontiguousarray(offsets.detach().cpu().numpy().astype(np.int32))
+    try:
+        offsets._snerf_host_offsets = (offsets._version, h)
+    except AttributeError:
+        pass
     return h
 
 
