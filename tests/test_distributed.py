@@ -81,11 +81,11 @@ def test_ray_sharded_data_parallel_matches_single_process():
 
 
 # ---------------------------------------------------------------------------- path C (zipnerf) ----
-def _zip_build():
+def _zip_build(log2T=12):
     from snerf_amd import zipnerf
     torch.manual_seed(0)
     return zipnerf.Model(config=None, raydist_fn='power_transformation', opaque_background=True, compute="f32", table_dtype="f32", device="cpu",
-                         grid_log2_hashmap_size=12, init_std=0.1)
+                         grid_log2_hashmap_size=log2T, init_std=0.1)
 
 
 def _zip_data(n):
@@ -103,13 +103,13 @@ def _zip_aux(hist):
     return sum((h["weights"] ** 2).sum() for h in hist) * 1e-3
 
 
-def _zip_worker(rank, world, init_file, n, out_file, table_exchange="sharded"):
+def _zip_worker(rank, world, init_file, n, out_file, table_exchange="sharded", log2T=12):
     from cpu_ops_emulation import emulate_ops
     from snerf_amd.trainer import ZipTrainer
     dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
     torch.set_num_threads(2)
     with emulate_ops():
-        model = _zip_build()
+        model = _zip_build(log2T)
         if rank != 0:
             with torch.no_grad():
                 model.arena.flat.add_(0.5)
@@ -192,6 +192,32 @@ def _zip_dynamic_scale_worker(rank, world, init_file, n, out_file):
         if rank == 0:
             torch.save((gathered, logs), out_file)
     dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_zip_sharded_tables_on_four_ranks_with_slices_off_the_16_byte_grid():
+    """at world 4 / 8 a rank's slice of a single-channel table is not a multiple of 4 floats (the default proposal tables:
+    6 606 952 / 8 = 825 869 rows per rank) -- the sharded update (reduce-scatter, Adam on the slice, all-gather) has to agree with
+    the dense all-reduce there too.  Four gloo ranks on a small model whose C = 1 tables are cut off the 16-byte grid (the HIP Adam
+    kernel takes such slices since round 5: tests/test_gpu_kernels.py::test_adam_on_misaligned_slices_matches_aligned)."""
+    from cpu_ops_emulation import emulate_ops
+    n, world = 8, 4
+    with emulate_ops():
+        m = _zip_build(13)            # 2^13-row levels: the C = 1 tables hold 45 880 / 62 264 rows = 11 470 / 15 566 per rank (2 mod 4)
+        spans = [m.arena.span(nm + "encoder.embeddings") for nm in m.names]
+        per = [(b - a) // world for a, b in spans]
+        assert all((b - a) % world == 0 for a, b in spans) and any(p % 4 != 0 or (a % 4) != 0 for p, (a, b) in zip(per, spans)), (spans, per)
+    with tempfile.TemporaryDirectory() as td:
+        init_file, out_file = os.path.join(td, "init"), os.path.join(td, "out.pt")
+        mp.spawn(_zip_worker, args=(world, init_file, n, out_file, "sharded", 13), nprocs=world, join=True)
+        gathered, moments = torch.load(out_file)
+        init2, out2 = os.path.join(td, "init2"), os.path.join(td, "out2.pt")
+        mp.spawn(_zip_worker, args=(world, init2, n, out2, "allreduce", 13), nprocs=world, join=True)
+        dense, dense_moments = torch.load(out2)
+    for r in range(1, world):
+        assert torch.equal(gathered[0], gathered[r]), "ranks diverged"
+    # four addends: the sharded path sums them in the reduce's order, the dense path in the all-reduce's -- equal up to fp32 rounding
+    assert float((gathered[0] - dense[0]).abs().max()) < 2e-6 and float((moments[0] - dense_moments[0]).abs().max()) < 1e-6
 
 
 @pytest.mark.timeout(600)
