@@ -586,6 +586,7 @@ def grid_encoder_leg(device, R=65536, S=32, n=7, steps=3):
         ops.grid_set_fast_path(True)
     gf, gs = res["fast"][2], res["reference_form"][2]
     useful = B * L * 8 * C * 2                                                # 8 corner rows of C halves per (point, level)
+    cb, cb_src = counter_bytes("grid_encoder_fwd")
     out = {"workload": f"GridEncoder (L = {L}, C = {C}, T = 2^21, 16 -> 8192; half table under autocast) forward + backward on B = {R} x {S} x {n} = {B} "
                        "ray-ordered contracted multisample points; autograd through snerf_amd.gridencoder (the drop-in of gridencoder/grid.py)",
            "points": B, "fwd_ms": round(res["fast"][0], 3), "bwd_ms": round(res["fast"][1], 3),
@@ -595,7 +596,7 @@ def grid_encoder_leg(device, R=65536, S=32, n=7, steps=3):
            "table_gradient_rel_l2_fast_vs_atomic": float((gf - gs).norm() / gs.norm()),
            "roofline": {"bound": "hbm", "kernel": "g3_fwd_kernel<_Float16, 4> (corner-cached hash-grid gather)", "achieved": round(useful / (res["fast"][0] * 1e-3) / 1e9, 1),
                         "peak": 8000.0, "unit": "GB/s", "frac": round(useful / (res["fast"][0] * 1e-3) / 1e9 / 8000.0, 4), "useful_bytes_per_launch": useful,
-                        "traffic": None, "note": "useful bytes = 8 corner rows x 8 B per (point, level); the backward moves the same payload as records"},
+                        "traffic": cb, "traffic_source": cb_src, "note": "useful bytes = 8 corner rows x 8 B per (point, level); the backward moves the same payload as records"},
            "bwd_useful_GBps": round(useful / (res["fast"][1] * 1e-3) / 1e9, 1)}
     del enc, x, w, res, gf, gs
     torch.cuda.empty_cache()
@@ -946,14 +947,14 @@ def main():
         if not args.no_ert_scene:
             # north_star's "early ray termination and sample compaction" where it pays: path B's fine pass re-evaluates the 64
             # uniform coarse positions (render.py:380-389), a good part of which lies behind the first surface.  Two classic NeRFs fitted for
-            # 300 steps to the analytic street scene, the 1600 x 900 frame plain and with render_rays(ert=(1e-4, 48)) (exact bound on acc / rgb)
+            # 500 steps to the analytic street scene, the 1600 x 900 frame plain and with render_rays(ert=(1e-4, (96, 16))) (exact bound on acc / rgb)
             sys.path.insert(0, os.path.join(REPO, "tools"))
             import ert_classic_analysis
             t0 = time.perf_counter()
-            r = ert_classic_analysis.fit_and_measure(steps=300, eps_list=(1e-4,), rows_n=900, groups=(48,), ert_eps=1e-4, dev=device, row0=0)
-            m48 = r["measured"]["eps_0.0001_G48"]
-            out["path_b_ert"] = {"what": "classic render_rays frame 1600 x 900 (64 + 128, two fitted NeRF 8 x 256), plain vs ert=(1e-4, 48): fine pass front to back in "
-                                         "groups of 48 samples, rays leave at fine transmittance <= 1e-4, rows compacted (csrc-free: selection in torch, evaluation by fmlp_kernel)",
+            r = ert_classic_analysis.fit_and_measure(steps=500, eps_list=(1e-4,), rows_n=900, groups=((96, 16),), ert_eps=1e-4, dev=device, row0=0)
+            m48 = r["measured"]["eps_0.0001_G96_16"]
+            out["path_b_ert"] = {"what": "classic render_rays frame 1600 x 900 (64 + 128, two fitted NeRF 8 x 256), plain vs ert=(1e-4, (96, 16)): fine pass front to back -- the "
+                                         "first 96 sorted samples in one piece, then groups of 16 --, rays leave at fine transmittance <= 1e-4, rows compacted (csrc-free: selection in torch, evaluation by fmlp_kernel)",
                                  "fit_steps": r["fit_steps"], "fit_psnr_db": r["fit_psnr_db"], "frame_ms_plain": r["window_ms_plain"], "frame_ms_ert": m48["window_ms"],
                                  "speedup": m48["speedup"], "fine_evaluations_kept": m48["fine_evaluations_kept"],
                                  "best_case_speedup_at_sample_granularity": r["rules"]["exact_eps_0.0001"]["best_case_frame_speedup"],

@@ -305,8 +305,15 @@ def _fine_pass_front_to_back(rb, z_all, viewdirs, run_fn, network_query_fn, eps_
     alive = None                       # None = every ray; else the surviving rays' indices, with their rows / transmittances kept compact
     rbs, T, dns = rb, torch.ones(N, device=dev), dn
     raw = None
-    for g0 in range(0, S, G):
-        g1 = min(g0 + G, S)
+    # G: one group size, or a schedule of sizes (the last one repeats) -- e.g. (96, 16): hardly a ray ends within its first 96 sorted
+    # samples (the coarse positions in front of its first surface + the front half of the 128 importance samples drawn around it), so
+    # those go in one piece and the tail in fine steps (measured on the fitted street scene: 1.23x vs 1.19x for uniform groups of 48)
+    sizes = [int(G)] if isinstance(G, (int, float)) else [int(x) for x in G]
+    bounds, k = [0], 0
+    while bounds[-1] < S:
+        bounds.append(min(S, bounds[-1] + sizes[min(k, len(sizes) - 1)]))
+        k += 1
+    for g0, g1 in zip(bounds[:-1], bounds[1:]):
         if rbs.shape[0] == 0:
             break
         zr = (z_all[:, g0:g1] if alive is None else z_all[alive, g0:g1]).contiguous()
@@ -335,7 +342,7 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
                 t_rand: Optional[torch.Tensor] = None, u: Optional[torch.Tensor] = None, return_inds: bool = False, ert=None):
     """Volumetric rendering of a ray batch [N, 8|11] = [o3, d3, near, far, (viewdir3)]; returns the
     reference's dict (render.py:394-401).  Extra keyword-only inputs `t_rand` [N,S] / `u` [N,Nimp]
-    replace the internal torch.rand draws (parity tests).  `ert=(eps_t, G)` (inference only, under torch.no_grad(); NOT in the
+    replace the internal torch.rand draws (parity tests).  `ert=(eps_t, G | (G0, G1, ...))` (inference only, under torch.no_grad(); NOT in the
     reference): early ray termination + row compaction in the fine pass -- see _fine_pass_front_to_back."""
     N_rays = ray_batch.shape[0]
     if N_rays == 0:   # as the reference (run_network's torch.cat of no chunks): an error, not an empty dict
@@ -371,9 +378,9 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
         if ert is not None:
             if torch.is_grad_enabled() or raw_noise_std > 0.:
                 raise NotImplementedError("ert is an inference mode: call under torch.no_grad() with raw_noise_std = 0")
-            eps_t, G = float(ert[0]), int(ert[1])
-            if not (eps_t < 1.0 and G >= 1):
-                raise ValueError("ert = (eps_t < 1, G >= 1)")
+            eps_t, G = float(ert[0]), ert[1]
+            if not (eps_t < 1.0 and min([G] if isinstance(G, (int, float)) else list(G)) >= 1):
+                raise ValueError("ert = (eps_t < 1, G >= 1 or a schedule of group sizes >= 1)")
             raw = _fine_pass_front_to_back(rb, z_all, viewdirs, run_fn, network_query_fn, eps_t, G)
         else:
             pts = ops.classic_points(rb, z_all)

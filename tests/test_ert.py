@@ -171,7 +171,7 @@ def test_classic_fine_pass_front_to_back_ert():
     kw = dict(network_fn=coarse, network_query_fn=q, N_samples=64, perturb=0.0, N_importance=128, network_fine=fine, retraw=True)
     with torch.no_grad():
         full = classic.render_rays(rays, **kw)
-        for G in (32, 50):                                                    # 192 = 6 x 32 = 3 x 50 + 42 (ragged last group)
+        for G in (32, 50, (128, 16)):                                         # 192 = 6 x 32 = 3 x 50 + 42 (ragged last group) = 128 + 4 x 16 (a schedule)
             same = classic.render_rays(rays, ert=(-1.0, G), **kw)
             for k in ("rgb_map", "acc_map", "depth_map", "disp_map", "raw"):
                 assert torch.equal(torch.nan_to_num(full[k], nan=-7.0), torch.nan_to_num(same[k], nan=-7.0)), (G, k)     # (disp = 1 / (depth / acc): 0 / 0 on an empty ray)

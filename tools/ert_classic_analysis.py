@@ -33,7 +33,7 @@ def rows_of(first, n, dev):
     return torch.cat([r.origins, r.directions, r.near, r.far, r.viewdirs], -1), r
 
 
-def fit_and_measure(steps=400, eps_list=(1e-4, 1e-3, 1e-2), rows_n=96, lindisp=False, groups=(32, 48), ert_eps=1e-4, dev=None, chunk=524288, row0=400):
+def fit_and_measure(steps=400, eps_list=(1e-4, 1e-3, 1e-2), rows_n=96, lindisp=False, groups=(48, (96, 16)), ert_eps=1e-4, dev=None, chunk=524288, row0=400):
     """-> dict: the analysis above + the MEASURED window renders with render_rays(ert=(ert_eps, G)) for G in `groups` against the plain
     render of the same fitted networks (time, evaluated fraction, errors).  bench.py's `path_b_ert` leg calls this with fewer steps."""
     import types
@@ -119,7 +119,7 @@ def fit_and_measure(steps=400, eps_list=(1e-4, 1e-3, 1e-2), rows_n=96, lindisp=F
         render((ert_eps, G))
         classic.ERT_STATS.update(evaluated=0, total=0)
         (rgb_e, acc_e, dep_e), t_e = render((ert_eps, G))
-        res["measured"][f"eps_{ert_eps:g}_G{G}"] = {
+        res["measured"][f"eps_{ert_eps:g}_G{G if isinstance(G, int) else '_'.join(map(str, G))}"] = {
             "window_ms": round(t_e * 1e3, 2), "speedup": round(t_plain / t_e, 3),
             "fine_evaluations_kept": round(classic.ERT_STATS["evaluated"] / max(classic.ERT_STATS["total"], 1), 4),
             "max_abs_err_rgb": float((rgb_e - rgb_p).abs().max()), "max_abs_err_acc": float((acc_e - acc_p).abs().max()),

@@ -38,7 +38,7 @@ if g("TCC_HIT_sum") is not None and g("TCC_MISS_sum") is not None:
 # rows books one request = 64 B per row whatever the row width (TCC_REQ = rows, 97 % misses, TCC_EA0_RDREQ_32B = 0).  Whether such a
 # request moves 64 or 128 bytes cannot be told from the counters (the scattered-row rate is the same from a 120 MB and from a 2 GB table:
 # the memory side is not what limits it), so the gather kernels get both: x1 = lower bound, x2 = upper bound.
-GATHER = ("zip_encode", "grid_encode", "zip_bin_emit", "zip_bin_write", "gather<")
+GATHER = ("zip_encode", "grid_encode", "zip_bin_emit", "zip_bin_write", "gather<", "g3_", "grid_fwd_kernel", "grid_bwd_kernel")
 if g("FETCH_SIZE") is not None:
     if any(k in pat for k in GATHER):
         print(f"FETCH_SIZE, gather class (KB->bytes): {g('FETCH_SIZE') * 1024 / 1e9:.3f} GB per launch at 64 B per request (lower bound), "
