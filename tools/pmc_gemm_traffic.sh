@@ -4,7 +4,7 @@
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
-run() { tag=$1; shift; timeout 120 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $ROOT/gpurun_out/pmc_nt8_traffic/$tag -o p -- python $ROOT/tools/gemm_single.py 8 nt > /dev/null 2>&1 < /dev/null; }
+run() { tag=$1; shift; timeout -k 5 120 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $ROOT/gpurun_out/pmc_nt8_traffic/$tag -o p -- python $ROOT/tools/gemm_single.py 8 nt > /dev/null 2>&1 < /dev/null; }
 run tcc2 FETCH_SIZE
 run tcc3 WRITE_SIZE
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS

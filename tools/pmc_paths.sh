@@ -5,7 +5,7 @@ set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 O=$ROOT/gpurun_out/pmc_paths; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-run() { dir=$1; tag=$2; cmd=$3; shift 3; timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/$dir/$tag -o p -- $cmd > /dev/null 2>&1 < /dev/null; }
+run() { dir=$1; tag=$2; cmd=$3; shift 3; timeout -k 5 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/$dir/$tag -o p -- $cmd > /dev/null 2>&1 < /dev/null; }
 ZC="python $ROOT/tools/bench_zip.py --rays 65536 --steps 2 --train-only"
 BC="python $ROOT/tools/bench_classic.py --rays 32768 --steps 2 --train-only"
 for spec in "fetch FETCH_SIZE" "write WRITE_SIZE" "req TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_REQ_sum"; do
@@ -15,7 +15,7 @@ for spec in "fetch FETCH_SIZE" "write WRITE_SIZE" "req TCC_EA0_RDREQ_sum TCC_EA0
 done
 cd $ROOT
 # (kernel-name patterns of the fp16 compute mode: NeRF-level / proposal-level training forward, staged writer C = 4, all-levels writer C = 1, accumulate)
-{ for k in "zip_encode_fwd_all_kernelI6__half" "zip_encode_fwd_all_kernelIfDF16_Li1ELb1" "zip_bin_write_staged_kernelIDF16_Li4" "zip_bin_emit_all_kernelIDF16_Li1" "zip_bin_accumulate_kernel<4, true>" "zip_bin_accumulate_kernel<1, true>"; do python tools/pmc_summary.py $O/zip "$k"; done
+{ for k in "zip_encode_fwd_all_kernelI6__half" "zip_encode_fwd_all_kernelIfDF16_Li1ELb1" "zip_bin_write_staged_kernelIDF16_Li4" "zip_bin_emit_all_kernelIDF16_Li1" "zip_bin_accumulate_kernel<4, true," "zip_bin_accumulate_kernel<1, true,"; do python tools/pmc_summary.py $O/zip "$k"; done
   for k in "fmlp_kernel<0, false, true>" "fchain_bwd_kernel<0>"; do python tools/pmc_summary.py $O/classic "$k"; done; } > $O/summary.txt 2>&1
 python - <<'PY'
 import json, os, re
