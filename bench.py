@@ -546,6 +546,18 @@ def grid_encoder_leg(device, R=65536, S=32, n=7, steps=3):
     from snerf_amd import ops
     from snerf_amd.gridencoder import GridEncoder
     L, C = 10, 4
+    x = grid_points(device, R, S, n)
+    B = x.shape[0]
+    g = torch.Generator(device=device).manual_seed(4)
+    enc = GridEncoder(input_dim=3, num_levels=L, level_dim=C, base_resolution=16, desired_resolution=8192, log2_hashmap_size=21, device=device)
+    with torch.no_grad():
+        enc.embeddings.uniform_(-0.1, 0.1)
+    w = (torch.randn(B, L * C, generator=g, device=device) * 1e-3).half()
+    return _grid_encoder_measure(enc, x, w, R, S, n, L, C, steps)
+
+
+def grid_points(device, R=65536, S=32, n=7):
+    """R x S x n contracted multisample points in [-1, 1]^3, in the order zipnerf passes them to its encoders (models.py:488-494)"""
     g = torch.Generator(device=device).manual_seed(3)
     o = torch.randn(R, 1, 1, 3, generator=g, device=device) * 0.05
     d = torch.nn.functional.normalize(torch.randn(R, 1, 1, 3, generator=g, device=device), dim=-1)
@@ -559,12 +571,12 @@ def grid_encoder_leg(device, R=65536, S=32, n=7, steps=3):
     x = o + d * t + 1.5e-3 * t * (torch.cos(ang) * e1 + torch.sin(ang) * e2)
     mag = x.norm(dim=-1, keepdim=True).clamp(min=1e-6)
     x = torch.where(mag <= 1, x, (2 - 1 / mag) * x / mag) / 2                       # contraction into the ball of radius 2, halved: [-1, 1]^3
-    x = x.reshape(-1, 3).contiguous()
+    return x.reshape(-1, 3).contiguous()
+
+
+def _grid_encoder_measure(enc, x, w, R, S, n, L, C, steps):
+    from snerf_amd import ops
     B = x.shape[0]
-    enc = GridEncoder(input_dim=3, num_levels=L, level_dim=C, base_resolution=16, desired_resolution=8192, log2_hashmap_size=21, device=device)
-    with torch.no_grad():
-        enc.embeddings.uniform_(-0.1, 0.1)
-    w = (torch.randn(B, L * C, generator=g, device=device) * 1e-3).half()
 
     def fwd_bwd():
         enc.embeddings.grad = None

@@ -335,8 +335,9 @@ int g3_fwd_launch(const float* inputs, const void* table, const int* offsets, vo
 extern int g3_fwd_group;
 static int g_grid_fast_path = 1;
 // A/B switch of the measurement legs and the parity tests (0: kernel_grid's one-thread-per-(point, level) form for every instantiation;
-// 2 / 4 / 8 (probes): that many consecutive points per thread in the fast gather, a cell's corners kept across them)
-extern "C" int snerf_grid_set_fast_path(int on) { g_grid_fast_path = on != 0; g3_fwd_group = (on == 2 || on == 4 || on == 8) ? on : 1; return SNERF_OK; }
+// 2 / 4 / 8 (probes): that many consecutive points per thread in the fast gather, a cell's corners kept across them; 16 (probe): the
+// point-major thread mapping (coalesced [B, L*C] output), 32: the level-major one; 1 = chosen by entry width)
+extern "C" int snerf_grid_set_fast_path(int on) { g_grid_fast_path = on != 0; g3_fwd_group = (on == 2 || on == 4 || on == 8) ? on : (on == 16 ? 0 : (on == 32 ? 1 : -1)); return SNERF_OK; }
 
 extern "C" int snerf_grid_encode_fwd(const float* inputs, const void* embeddings, const int* offsets, void* outputs, int B, int D, int C,
                                      int L, float S, int H, void* dy_dx, int gridtype, int align_corners, int interp, int dtype,

@@ -1945,8 +1945,13 @@ struct G3Args {
 template <typename TT, int C, int G>
 __global__ __launch_bounds__(256) void g3_fwd_kernel(G3Args a) {
 #pragma clang fp contract(off)        // every product and sum rounded on its own: the same bits as grid.hip's grid_fwd_kernel whatever the compiler fuses elsewhere
-  const int level = blockIdx.y;
-  const long p0 = ((long)blockIdx.x * 256 + threadIdx.x) * G;
+  // G >= 1: level-major grid (blockIdx.y = level: the blocks in flight gather from one level's table), G consecutive points per thread.
+  // G == 0: point-major -- thread t = point * L + level, so that a workgroup's outputs are ONE contiguous run of [B, L*C] (the
+  // level-major form writes 8-byte pieces 80 bytes apart: 4x the bytes at the memory side, profiles/r5_x_grid_encoder_pmc.txt)
+  constexpr int GP = G == 0 ? 1 : G;
+  const long t0 = (long)blockIdx.x * 256 + threadIdx.x;
+  const int level = G == 0 ? (int)(t0 % a.L) : (int)blockIdx.y;
+  const long p0 = G == 0 ? t0 / a.L : t0 * GP;
   if (p0 >= a.B) return;
   const uint32_t hs = a.offsets[level + 1] - a.offsets[level];
   const float scale = exp2f(level * a.Sl) * a.H - 1.0f;
@@ -1955,7 +1960,7 @@ __global__ __launch_bounds__(256) void g3_fwd_kernel(G3Args a) {
   uint32_t cur[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
   ZVec<TT, C> ce[8];
 #pragma unroll
-  for (int j = 0; j < G; ++j) {
+  for (int j = 0; j < GP; ++j) {
     const long p = p0 + j;
     if (p >= a.B) break;
     TT* out = (TT*)a.io + level * a.s_l + p * a.s_b;
@@ -1971,7 +1976,7 @@ __global__ __launch_bounds__(256) void g3_fwd_kernel(G3Args a) {
     uint32_t pg[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) zip_cell(x[k], scale, &pg[k], &fr[k]);
-    const bool newcell = G == 1 || pg[0] != cur[0] || pg[1] != cur[1] || pg[2] != cur[2];
+    const bool newcell = GP == 1 || pg[0] != cur[0] || pg[1] != cur[1] || pg[2] != cur[2];
     cur[0] = pg[0]; cur[1] = pg[1]; cur[2] = pg[2];
     if (newcell) {
 #pragma unroll
@@ -2015,13 +2020,17 @@ __global__ __launch_bounds__(256) void g3_fwd_kernel(G3Args a) {
 }
 
 // the fast forward for grid.hip's snerf_grid_encode_fwd (D = 3, C = 1 / 4, hash, linear, no align_corners, float / half, no dy_dx)
-int g3_fwd_group = 1;                                                    // points per thread (probe switch: snerf_grid_set_fast_path(2 / 4 / 8))
+int g3_fwd_group = -1;      // -1: by entry width (below); 0 / 1 / 2 / 4 / 8: probe values of snerf_grid_set_fast_path (point-major; points per thread)
 int g3_fwd_launch(const float* inputs, const void* table, const int* offsets, void* outputs, long B, int C, int L, float S, int H, int dtype,
                   long s_l, long s_b, hipStream_t s) {
   G3Args a{inputs, B, table, offsets, outputs, s_l, s_b, L, S, H};
-  const int G = g3_fwd_group;
-  const dim3 grid((unsigned)((B + 256 * G - 1) / (256 * G)), L), blk(256);
-#define G3F(TT, CC) do { if (G == 1) hipLaunchKernelGGL((g3_fwd_kernel<TT, CC, 1>), grid, blk, 0, s, a); \
+  // measured at 14.7 M points, L = 10 (profiles/r5_y_grid_encoder_mapping_ab.txt): 8-byte entries (C = 4, half) 6.2 ms point-major vs 7.7
+  // level-major on ray-ordered points, equal on random ones; 2- / 4-byte entries (C = 1) are faster level-major (4.2 vs 5.6 ms)
+  const int G = g3_fwd_group >= 0 ? g3_fwd_group : ((size_t)C * (dtype == SNERF_DT_F16 ? 2 : 4) >= 8 ? 0 : 1);
+  const bool pm = G == 0 && s_l == C && s_b == (long)L * C;              // point-major needs the [B, L*C] layout to pay
+  const dim3 grid0((unsigned)((B * L + 255) / 256)), grid((unsigned)((B + 256 * (G < 1 ? 1 : G) - 1) / (256 * (G < 1 ? 1 : G))), L), blk(256);
+#define G3F(TT, CC) do { if (pm) hipLaunchKernelGGL((g3_fwd_kernel<TT, CC, 0>), grid0, blk, 0, s, a); \
+                         else if (G <= 1) hipLaunchKernelGGL((g3_fwd_kernel<TT, CC, 1>), grid, blk, 0, s, a); \
                          else if (G == 2) hipLaunchKernelGGL((g3_fwd_kernel<TT, CC, 2>), grid, blk, 0, s, a); \
                          else if (G == 4) hipLaunchKernelGGL((g3_fwd_kernel<TT, CC, 4>), grid, blk, 0, s, a); \
                          else hipLaunchKernelGGL((g3_fwd_kernel<TT, CC, 8>), grid, blk, 0, s, a); } while (0)
