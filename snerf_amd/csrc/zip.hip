@@ -14,6 +14,7 @@
 //   snerf_zip_composite_* render.compute_alpha_weights + volumetric_rendering (render.py:170-233) fused with the density /
 //                         colour activations of MLP.forward (models.py:586, 689-703).
 #include "common.h"
+#include <stdlib.h>
 #include <hip/hip_fp16.h>
 
 #define ZIP_LANES 64
@@ -215,7 +216,12 @@ struct ZipEnc {
   int level_begin;                    // first level handled by the generic kernel
   long slab_row0, slab_rows;          // LDS-privatised backward: the row range this workgroup accumulates
   const int* lds_slab_level; int lds_nslab;   // slab s covers level lds_slab_level[2s], rows from lds_slab_level[2s+1]
+  int lf;                             // (workgroup, level) grid launched 1-D with the level fastest: the number of level blocks; 0 = 2-D grid (x = workgroup, y = level)
 };
+// logical block coordinates of the (workgroup, level) grids under either launch order
+#define ZIP_BX(a) ((a).lf ? blockIdx.x / (unsigned)(a).lf : blockIdx.x)
+#define ZIP_BY(a) ((a).lf ? blockIdx.x % (unsigned)(a).lf : blockIdx.y)
+#define ZIP_GX(a) ((a).lf ? gridDim.x / (unsigned)(a).lf : gridDim.x)
 
 __device__ __forceinline__ uint32_t zip_hash3(const uint32_t* p) { return p[0] ^ (p[1] * 2654435761u) ^ (p[2] * 805459861u); }
 
@@ -506,8 +512,8 @@ __device__ __forceinline__ void zip_fwd_all_body(const ZipEnc& a, const ZipBin& 
     }
   }
   OT* out = (OT*)a.feat + p * a.ld;
-  const int lend = min(a.L, (int)(blockIdx.y + 1) * a.level_begin);       // level_begin = levels per thread in this kernel
-  for (int level = blockIdx.y * a.level_begin; level < lend; ++level) {
+  const int lend = min(a.L, (int)(ZIP_BY(a) + 1) * a.level_begin);       // level_begin = levels per thread in this kernel
+  for (int level = ZIP_BY(a) * a.level_begin; level < lend; ++level) {
     const uint32_t hs = a.offsets[level + 1] - a.offsets[level];
     const float scale = exp2f(level * a.Sl) * a.H - 1.0f;
     const uint32_t res = (uint32_t)ceilf(scale) + 1;
@@ -520,7 +526,7 @@ __device__ __forceinline__ void zip_fwd_all_body(const ZipEnc& a, const ZipBin& 
     // levels), whose 8 corner entries are then kept in registers instead of being gathered again (same rows, same values: identical
     // features); COUNT tallies a record per corner of every run, exactly zip_emit_level's merging
     uint32_t cur[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
-    const int K = COUNT ? b.ksplit[level] : 1, rep = COUNT ? (int)(blockIdx.x % (unsigned)K) : 0;
+    const int K = COUNT ? b.ksplit[level] : 1, rep = COUNT ? (int)(ZIP_BX(a) % (unsigned)K) : 0;
     float cv[(C == 1) ? 8 : 1];                          // C = 1: the cell's corner values (corner = x + 2 y + 4 z)
     ZVec<TT, C> ce[(C == 1) ? 1 : 8];                    // C > 1: the cell's corner entries
 #pragma unroll
@@ -658,7 +664,7 @@ __device__ __forceinline__ void zip_fwd_all_body(const ZipEnc& a, const ZipBin& 
 template <typename TT, typename OT, int C, bool COUNT = false>
 __global__ __launch_bounds__(256) void zip_encode_fwd_all_kernel(ZipEnc a, ZipBin b) {
   __shared__ int cnt[COUNT ? ZB_NBMAX : 1];
-  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  const long p = (long)ZIP_BX(a) * 256 + threadIdx.x;
   const bool live = p < a.R * a.S;
   if constexpr (COUNT) {
     for (int k = threadIdx.x; k < ZB_NBMAX; k += 256) cnt[k] = 0;
@@ -667,8 +673,8 @@ __global__ __launch_bounds__(256) void zip_encode_fwd_all_kernel(ZipEnc a, ZipBi
   if (live) zip_fwd_all_body<TT, OT, C, COUNT>(a, b, p, cnt);
   if constexpr (COUNT) {
     __syncthreads();
-    const int level = blockIdx.y;                       // (one level per thread in this mode)
-    unsigned* wgo = b.wg_offsets + ((long)level * gridDim.x + blockIdx.x) * ZB_NBMAX;
+    const int level = ZIP_BY(a);                        // (one level per thread in this mode)
+    unsigned* wgo = b.wg_offsets + ((long)level * ZIP_GX(a) + ZIP_BX(a)) * ZB_NBMAX;
     for (int k = threadIdx.x; k < ZB_NBMAX; k += 256)
       if (cnt[k] != 0) wgo[k] = (unsigned)atomicAdd(b.counts + level * ZB_NBMAX + k, cnt[k]);
   }
@@ -1232,6 +1238,8 @@ extern "C" int snerf_zip_encode_fwd_count(const float* tdist, const float* origi
   b.counts = counts; b.wg_offsets = (unsigned*)wg_offsets;
   ZipEnc a{tdist, origins, directions, radii, base_x, base_y, deg_jitter, table, offsets, grid_sizes, feat, ld, nullptr, nullptr, R, S, L, n, m, Sl, H, std_scale};
   a.level_begin = 1;
+  // (2-D grid, level-major launch order: the workgroups in flight gather from ONE level's table.  Launched level-fastest the same kernel
+  // takes 4.3 instead of 3.2 ms per proposal level and 5.5 instead of 4.8 on the NeRF level: profiles/r5_z_pathC_launch_order_ab.txt)
   const dim3 grid((unsigned)((R * S + 255) / 256), L), blk(256);
   hipStream_t s = (hipStream_t)stream;
 #define ZFC(TT, OT) do { if (C == 4) hipLaunchKernelGGL((zip_encode_fwd_all_kernel<TT, OT, 4, true>), grid, blk, 0, s, a, b); \
@@ -1542,10 +1550,10 @@ __global__ __launch_bounds__(256, NSUB == 8 ? 4 : 3) void zip_bin_write_staged_k
   __shared__ float gtab[256 * C];
   __shared__ int wtot[4];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int level = blockIdx.y;
-  const long p = (long)blockIdx.x * 256 + tid;
+  const int level = ZIP_BY(a);
+  const long p = (long)ZIP_BX(a) * 256 + tid;
   const bool live = p < a.R * a.S;
-  const unsigned* wgo1 = b.wg_offsets + ((long)level * gridDim.x + blockIdx.x) * ZB_NBMAX;
+  const unsigned* wgo1 = b.wg_offsets + ((long)level * ZIP_GX(a) + ZIP_BX(a)) * ZB_NBMAX;
   for (int k = tid; k < ZB_NBMAX; k += 256) {      // (entries of bins this workgroup does not touch are garbage and never used)
     base[k] = b.starts[level * ZB_NBMAX + k] + (long)wgo1[k];
     cnt[k] = 0;
@@ -1553,7 +1561,7 @@ __global__ __launch_bounds__(256, NSUB == 8 ? 4 : 3) void zip_bin_write_staged_k
   const uint32_t hs = a.offsets[level + 1] - a.offsets[level];
   const float scale = exp2f(level * a.Sl) * a.H - 1.0f;
   const uint32_t res = (uint32_t)ceilf(scale) + 1;
-  const int K = b.ksplit[level], rep = (int)(blockIdx.x % (unsigned)K);
+  const int K = b.ksplit[level], rep = (int)(ZIP_BX(a) % (unsigned)K);
   const unsigned rmask = (1u << b.bshift) - 1u;
   float hmul = 1.f;
   if constexpr (HREC) hmul = exp2f((float)(b.scale_exp[0] - ZB_HALF_SHIFT));
@@ -1681,7 +1689,9 @@ __global__ __launch_bounds__(256, NSUB == 8 ? 4 : 3) void zip_bin_write_staged_k
 
 // GT: type of the gradient table the rows are added to (fp32 everywhere but the stand-alone GridEncoder's half tables, whose
 // reference contract is a gradient in the table's dtype)
-template <int C, bool HREC = false, typename GT = float>
+// PACK (C = 4, half records; the stand-alone GridEncoder's direct writer): a record is ONE 16-byte word {row, 2 x 2 halves, pad} instead of a
+// 2-byte row and an 8-byte value in two planes -- its writer scatters single records, and every store is a memory request of its own
+template <int C, bool HREC = false, typename GT = float, bool PACK = false>
 __global__ __launch_bounds__(1024) void zip_bin_accumulate_kernel(ZipEnc a, ZipBin b) {
   extern __shared__ long long zb_acc[];
   const int level = blockIdx.y, bin = blockIdx.x;
@@ -1719,6 +1729,14 @@ __global__ __launch_bounds__(1024) void zip_bin_accumulate_kernel(ZipEnc a, ZipB
         const unsigned rv = ((const unsigned*)b.rec_val)[q];
         row[u] = r < n ? (int)(rv & 0xffffu) : -1;
         val[u][0] = (float)__builtin_bit_cast(_Float16, (unsigned short)(rv >> 16));
+        continue;
+      }
+      if constexpr (HREC && C == 4 && PACK) {
+        const uint4 rec = *(const uint4*)(b.rec_val + q * 4);
+        row[u] = r < n ? (int)rec.x : -1;
+        const uint2 hv = {rec.y, rec.z};
+        const zb_h4 v4 = __builtin_bit_cast(zb_h4, hv);
+        val[u][0] = (float)v4[0]; val[u][1] = (float)v4[1]; val[u][2] = (float)v4[2]; val[u][3] = (float)v4[3];
         continue;
       }
       if constexpr (HREC && C == 4) {
@@ -1837,10 +1855,13 @@ extern "C" int snerf_zip_bin_scale(const void* grad_feat, long ld, long rows, in
 
 // pass 2 of the binned table gradient: one workgroup per bin, the replicated levels' int64 image folded, the overflow mark
 template <typename GT>
-static int zb_accumulate_launch(const ZipEnc& a, const ZipBin& b, int C, int L, bool hrec, hipStream_t s) {
+static int zb_accumulate_launch(const ZipEnc& a, const ZipBin& b, int C, int L, bool hrec, hipStream_t s, bool pack = false) {
   const size_t lds = (size_t)(1 << b.bshift) * C * 8;
   const dim3 grid(ZB_NBMAX, L);
-  if (hrec && C == 4) {
+  if (hrec && C == 4 && pack) {
+    (void)hipFuncSetAttribute((const void*)zip_bin_accumulate_kernel<4, true, GT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((zip_bin_accumulate_kernel<4, true, GT, true>), grid, dim3(1024), lds, s, a, b);
+  } else if (hrec && C == 4) {
     (void)hipFuncSetAttribute((const void*)zip_bin_accumulate_kernel<4, true, GT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL((zip_bin_accumulate_kernel<4, true, GT>), grid, dim3(1024), lds, s, a, b);
   } else if (hrec) {
@@ -1902,11 +1923,19 @@ extern "C" int snerf_zip_encode_bwd_binned(int pass, const float* tdist, const f
     // pass 1 at C = 1: the direct writer with all levels per thread (pass 3 keeps the one-level-per-thread form for A/B runs and tests)
     const bool all_levels = pass == 1 && (C == 1 || force_all) && n <= 8;
     const dim3 grid1((unsigned)((R * S + 255) / 256), 1);
+    // the staged writer gathers nothing: it is launched LEVEL-FASTEST (1-D grid), so that the L workgroups of one block of intervals run
+    // together and the feature-gradient rows they all read (8-byte pieces of [P, ld]) and the rays' geometry come from HBM once:
+    // 6.0 -> 5.2 ms per NeRF-level launch (profiles/r5_z_pathC_launch_order_ab.txt)
+    ZipEnc a_st = a;
+    dim3 grid_st = grid;
+    static int lf_on = -1;
+    if (lf_on < 0) { const char* e = getenv("SNERF_ZIP_WRITER_2D"); lf_on = (e != nullptr && e[0] == '1') ? 0 : 1; }   // (A/B switch)
+    if (lf_on) { a_st.lf = L; grid_st = dim3(grid.x * (unsigned)L); }
 #define ZBE(OT, CC) do { if (pass == 0) hipLaunchKernelGGL((zip_bin_emit_kernel<OT, CC, 0>), grid, blk, 0, s, a, b); \
                          else if (all_levels && hrec) hipLaunchKernelGGL((zip_bin_emit_all_kernel<OT, CC, true>), grid1, blk, 0, s, a, b); \
                          else if (all_levels) hipLaunchKernelGGL((zip_bin_emit_all_kernel<OT, CC, false>), grid1, blk, 0, s, a, b); \
-                         else if (staged && hrec) hipLaunchKernelGGL((zip_bin_write_staged_kernel<OT, CC, 4, true>), grid, blk, 0, s, a, b); \
-                         else if (staged) hipLaunchKernelGGL((zip_bin_write_staged_kernel<OT, CC, 4>), grid, blk, 0, s, a, b); \
+                         else if (staged && hrec) hipLaunchKernelGGL((zip_bin_write_staged_kernel<OT, CC, 4, true>), grid_st, blk, 0, s, a_st, b); \
+                         else if (staged) hipLaunchKernelGGL((zip_bin_write_staged_kernel<OT, CC, 4>), grid_st, blk, 0, s, a_st, b); \
                          else if (hrec) hipLaunchKernelGGL((zip_bin_emit_kernel<OT, CC, 1, true>), grid, blk, 0, s, a, b); \
                          else hipLaunchKernelGGL((zip_bin_emit_kernel<OT, CC, 1>), grid, blk, 0, s, a, b); } while (0)
     if (feat_dtype == SNERF_DT_BF16) { if (C == 4) ZBE(__bf16, 4); else ZBE(__bf16, 1); }
@@ -2046,19 +2075,22 @@ template <typename GT, int C, int PASS, bool HREC>
 __global__ __launch_bounds__(256) void g3_bin_emit_kernel(G3Args a, ZipBin b) {
   __shared__ int cnt[ZB_NBMAX];
   __shared__ long base[PASS == 1 ? ZB_NBMAX : 1];
-  const int level = blockIdx.y;
+  // 1-D grid, level fastest: the L workgroups of one range of points run together, so that the positions and the [B, L*C] gradient rows
+  // they all read come from HBM once (level-major launch order fetched 16.6 GB for 1.4 GB: profiles/r5_x_grid_encoder_pmc.txt)
+  const int level = (int)(blockIdx.x % (unsigned)a.L);
+  const unsigned wg = blockIdx.x / (unsigned)a.L, nwg = gridDim.x / (unsigned)a.L;
   for (int k = threadIdx.x; k < ZB_NBMAX; k += 256) cnt[k] = 0;
   if constexpr (PASS == 1) {
-    const unsigned* wgo1 = b.wg_offsets + ((long)level * gridDim.x + blockIdx.x) * ZB_NBMAX;
+    const unsigned* wgo1 = b.wg_offsets + ((long)level * nwg + wg) * ZB_NBMAX;
     for (int k = threadIdx.x; k < ZB_NBMAX; k += 256) base[k] = b.starts[level * ZB_NBMAX + k] + (long)wgo1[k];
   }
   __syncthreads();
-  const long p0 = ((long)blockIdx.x * 256 + threadIdx.x) * G3_PTS;
+  const long p0 = ((long)wg * 256 + threadIdx.x) * G3_PTS;
   if (p0 < a.B) {
     const uint32_t hs = a.offsets[level + 1] - a.offsets[level];
     const float scale = exp2f(level * a.Sl) * a.H - 1.0f;
     const uint32_t res = (uint32_t)ceilf(scale) + 1;
-    const int K = b.ksplit[level], rep = (int)(blockIdx.x % (unsigned)K);
+    const int K = b.ksplit[level], rep = (int)(wg % (unsigned)K);
     float hmul = 1.f;
     if constexpr (HREC && PASS == 1) hmul = exp2f((float)(b.scale_exp[0] - ZB_HALF_SHIFT));
     uint32_t cur[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
@@ -2083,10 +2115,10 @@ __global__ __launch_bounds__(256) void g3_bin_emit_kernel(G3Args a, ZipBin b) {
             const unsigned lrow = row & ((1u << b.bshift) - 1u);
             if constexpr (HREC && C == 1) {
               ((unsigned*)b.rec_val)[r] = lrow | (zb_half_bits(vals[idx][0] * hmul) << 16);
-            } else if constexpr (HREC) {
-              b.rec_row[r] = (unsigned short)lrow;
+            } else if constexpr (HREC) {                 // ONE 16-byte record (PACK form of the accumulate kernel)
               const zb_h4 v4 = {(_Float16)(vals[idx][0] * hmul), (_Float16)(vals[idx][1] * hmul), (_Float16)(vals[idx][2] * hmul), (_Float16)(vals[idx][3] * hmul)};
-              *(zb_h4*)(b.rec_val + r * 2) = v4;
+              const uint2 hv = __builtin_bit_cast(uint2, v4);
+              *(uint4*)(b.rec_val + r * 4) = uint4{lrow, hv.x, hv.y, 0u};
             } else if constexpr (C == 1) {
               const uint2 rv = {lrow, __float_as_uint(vals[idx][0])};
               *(uint2*)(b.rec_val + r * 2) = rv;
@@ -2136,7 +2168,7 @@ __global__ __launch_bounds__(256) void g3_bin_emit_kernel(G3Args a, ZipBin b) {
   }
   if constexpr (PASS == 0) {
     __syncthreads();
-    unsigned* wgo = b.wg_offsets + ((long)level * gridDim.x + blockIdx.x) * ZB_NBMAX;
+    unsigned* wgo = b.wg_offsets + ((long)level * nwg + wg) * ZB_NBMAX;
     for (int k = threadIdx.x; k < ZB_NBMAX; k += 256)
       if (cnt[k] != 0) wgo[k] = (unsigned)atomicAdd(b.counts + level * ZB_NBMAX + k, cnt[k]);
   }
@@ -2188,8 +2220,8 @@ static G3Ws g3_ws_layout(long B, int C, int L, long g64_rows, bool hrec) {
   w.g64 = o; o = al(o + (size_t)g64_rows * C * 8);                      // counts .. g64: one memset
   w.starts = o; o = al(o + (size_t)L * ZB_NBMAX * 8);
   w.wgo = o; o = al(o + (size_t)L * w.nwg * ZB_NBMAX * 4);
-  w.rec_row = o; o = al(o + (C == 4 ? (size_t)w.cap * 2 : 0));
-  w.rec_val = o; o = al(o + (size_t)w.cap * (hrec ? (C == 4 ? 8 : 4) : (C == 4 ? 16 : 8)));
+  w.rec_row = o; o = al(o + (C == 4 && !hrec ? (size_t)w.cap * 2 : 0));
+  w.rec_val = o; o = al(o + (size_t)w.cap * (hrec ? (C == 4 ? 16 : 4) : (C == 4 ? 16 : 8)));     // (half records at C = 4: packed 16-byte words)
   w.total = o;
   return w;
 }
@@ -2229,7 +2261,7 @@ extern "C" int snerf_grid_encode_bwd_binned(const void* grad, const float* input
   for (int l = 0; l < L; ++l) b.ksplit[l] = ks[l];
   b.rec_row = (unsigned short*)(base + w.rec_row); b.rec_val = (float*)(base + w.rec_val); b.capacity = w.cap;
   b.g64 = g64_rows > 0 ? (long long*)(base + w.g64) : nullptr; b.g64_rows = g64_rows; b.scale_exp = scale;
-  const dim3 grid((unsigned)w.nwg, L), blk(256);
+  const dim3 grid((unsigned)(w.nwg * L)), blk(256);
 #define G3E(GT, CC) do { hipLaunchKernelGGL((g3_bin_emit_kernel<GT, CC, 0, false>), grid, blk, 0, s, a, b); \
                          hipLaunchKernelGGL(g3_scan_kernel, dim3(1), dim3(1024), 0, s, b.counts, (long*)(base + w.starts), L); \
                          if (hrec) hipLaunchKernelGGL((g3_bin_emit_kernel<GT, CC, 1, true>), grid, blk, 0, s, a, b); \
@@ -2239,7 +2271,7 @@ extern "C" int snerf_grid_encode_bwd_binned(const void* grad, const float* input
 #undef G3E
   ZipEnc za{};
   za.offsets = offsets; za.grad_table = (float*)grad_embeddings; za.L = L;
-  return out_dtype == SNERF_DT_F16 ? zb_accumulate_launch<_Float16>(za, b, C, L, hrec, s) : zb_accumulate_launch<float>(za, b, C, L, hrec, s);
+  return out_dtype == SNERF_DT_F16 ? zb_accumulate_launch<_Float16>(za, b, C, L, hrec, s, true) : zb_accumulate_launch<float>(za, b, C, L, hrec, s, true);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
