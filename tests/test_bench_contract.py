@@ -129,6 +129,26 @@ def test_bench_two_ranks_on_one_gpu_without_a_launcher():
 
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
+def test_bench_two_ranks_weak_scaling_line_carries_the_strong_scaling_step():
+    """`bench.py --gpus N` as the driver launches it (default --scaling weak): the line also carries `strong_scaling` -- the reference's
+    --rays batch split over the ranks, launched per kernel and as a hipGraph -- beside the weak-scaling headline."""
+    import subprocess
+    import sys
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--backend", "gloo", "--same-device", "--steps", "2", "--warmup", "1",
+           "--rays", "512", "--no-cpu", "--no-eager", "--no-f32", "--no-frame", "--no-dropin", "--no-paths", "--no-ert-scene"]
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=850, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["rays_per_gpu_per_step"] == 512 and d["config"]["global_rays_per_step"] == 1024
+    ss = d["strong_scaling"]
+    assert ss["global_rays_per_step"] == 512 and ss["rays_per_gpu_per_step"] == 256
+    assert ss["ms_per_step_launches"] > 0 and ss["ms_per_step_hipgraph"] > 0 and ss["rays_per_s_hipgraph"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
 def test_bench_eight_ranks_strong_scaling_on_one_gpu():
     """The reference's 4096-ray batch split across EIGHT ranks (512 rays each: BASELINE config 3's `ray batches DDP over 8 x MI355X`,
     s-nerf/train.py:284-296) -- functional run of the 8-rank control flow on the 1-GPU box: gloo rendezvous, every rank on cuda:0, the
