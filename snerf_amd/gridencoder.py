@@ -51,7 +51,10 @@ class _grid_encode(Function):
             out_dt = emb_dtype if emb_dtype in (torch.float32, torch.float16) else torch.float32
             # (a level-major copy of the gradient first, as grid.py:74 makes, would let the record writer read it coalesced: measured 19.4 vs
             # 18.3 ms per backward at 14.7 M points -- the copy costs more than the 8-byte strided reads, profiles/r5_y_grid_encoder_mapping_ab.txt)
-            g_emb = ops.grid_encode_bwd_binned(grad, inputs, offsets, table.shape[1], L, S, H, out_dtype=out_dt, offsets_host=ctx.offsets_host)
+            try:
+                g_emb = ops.grid_encode_bwd_binned(grad, inputs, offsets, table.shape[1], L, S, H, out_dtype=out_dt, offsets_host=ctx.offsets_host)
+            except ValueError:       # a level with more than 1024 row ranges (> 2^22 rows at C = 4, > 2^24 at C = 1): the atomic scatter takes it
+                g_emb = ops.grid_encode_bwd(grad, inputs, table, offsets, L, S, H, gridtype, ctx.align_corners, interpolation, None)[0]
             return None, g_emb.to(emb_dtype), None, None, None, None, None, None, None
         g_emb, g_in = ops.grid_encode_bwd(grad, inputs, table, offsets, L, S, H, gridtype, ctx.align_corners, interpolation,
                                           dy_dx if has_dd else None)

@@ -278,3 +278,27 @@ def test_gridencoder_module_takes_the_fast_path_without_input_gradients():
         assert y16.dtype == (torch.float16 if C == 4 else torch.float32) and enc.embeddings.grad.dtype == torch.float32   # (odd C: the table is not halved, grid.py:41-44)
         tol = 2e-2 if C == 4 else 1e-3                          # C = 4: half table and half gradients (grid.py:41-44); C = 1 stays fp32
         assert float((enc.embeddings.grad - torch.from_numpy(gE).cuda()).norm() / np.linalg.norm(gE)) < tol
+
+
+@pytest.mark.parametrize("B,L,oob", [(1, 3, False), (5, 1, False), (64, 4, True), (2049, 2, False)])
+def test_grid_fast_path_edge_cases(B, L, oob):
+    """one point, one level, every point out of bounds, one point past a workgroup's 2048: forward and binned backward vs the oracle"""
+    from snerf_amd import ops
+    C, H = 4, 8
+    off, res, s = og.level_layout(3, L, C, 2.0, H, 12, None, False)
+    S = float(np.log2(s))
+    rng = np.random.default_rng(B + L)
+    E = (rng.standard_normal((int(off[-1]), C)) * 0.5).astype(np.float32)
+    x = rng.random((B, 3)).astype(np.float32)
+    if oob:
+        x[:, 0] += 1.5
+    G = rng.standard_normal((B, L * C)).astype(np.float32)
+    xt, Et, Gt, offt = (torch.from_numpy(a).cuda() for a in (x, E, G, off))
+    out, _ = ops.grid_encode_fwd(xt, Et, offt, L, S, H, 0, False, 0)
+    ref = og.grid_encode_forward(x, E, off, S, H, 0, False, 0)
+    np.testing.assert_allclose(out.cpu().numpy().reshape(B, L, C), ref.transpose(1, 0, 2), rtol=1e-4, atol=2e-5)
+    gE = ops.grid_encode_bwd_binned(Gt, xt, offt, C, L, S, H)
+    gE_ref, _ = og.grid_encode_backward(np.ascontiguousarray(G.reshape(B, L, C).transpose(1, 0, 2)), x, off, E.shape[0], S, H, 0, False, 0)
+    np.testing.assert_allclose(gE.cpu().numpy(), gE_ref, rtol=1e-4, atol=1e-5)
+    if oob:
+        assert float(out.abs().max()) == 0.0 and float(gE.abs().max()) == 0.0
