@@ -1809,6 +1809,22 @@ template <typename OT>
 __global__ __launch_bounds__(256) void zip_bin_absmax_kernel(const OT* __restrict__ g, long ld, long rows, int cols, unsigned* __restrict__ mx) {
   float m = 0.f;
   const long total = rows * cols;
+  if (ld == cols && (((uintptr_t)g) & 15) == 0) {
+    // contiguous (the stand-alone GridEncoder's [B, L*C] / [L, B, C] gradients): 16-byte loads, no index division -- the strided form
+    // below took 0.75 ms for 1.2 GB
+    constexpr int E = 16 / (int)sizeof(OT);
+    const long nv = total / E;
+    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nv; v += (long)gridDim.x * 256) {
+      const uint4 q = ((const uint4*)g)[v];
+      const OT* e = (const OT*)&q;
+#pragma unroll
+      for (int k = 0; k < E; ++k) { const float x = fabsf((float)e[k]); m = fmaxf(m, x != x ? __builtin_inff() : x); }
+    }
+    for (long e = nv * E + (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+      const float x = fabsf((float)g[e]);
+      m = fmaxf(m, x != x ? __builtin_inff() : x);
+    }
+  } else
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
     const long r = e / cols;
     const float x = fabsf((float)g[r * ld + (e - r * cols)]);
