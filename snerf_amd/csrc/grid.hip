@@ -344,8 +344,8 @@ extern "C" int snerf_grid_encode_fwd(const float* inputs, const void* embeddings
                                      long out_stride_l, long out_stride_b, void* stream) {
   if (B <= 0) return SNERF_OK;
   if (L <= 0 || inputs == nullptr || embeddings == nullptr || offsets == nullptr || outputs == nullptr) return SNERF_ERR_ARG;
-  // the instantiations zipnerf constructs (D = 3, C = 4 / 1, hash, linear, float / half) without dy_dx: the corner-cached gather of zip.hip
-  if (D == 3 && (C == 1 || C == 4) && gridtype == 0 && !align_corners && interp == 0 && dy_dx == nullptr &&
+  // D = 3, hash, linear, float / half, no dy_dx (what zipnerf constructs, at every channel count): the pair-loading gather of zip.hip
+  if (D == 3 && (C == 1 || C == 2 || C == 4 || C == 8) && gridtype == 0 && !align_corners && interp == 0 && dy_dx == nullptr &&
       (dtype == SNERF_DT_F32 || dtype == SNERF_DT_F16) && g_grid_fast_path)
     return g3_fwd_launch(inputs, embeddings, offsets, outputs, B, C, L, S, H, dtype, out_stride_l, out_stride_b, (hipStream_t)stream);
   GridArgs a{inputs, embeddings, offsets, outputs, dy_dx, out_stride_l, out_stride_b, B, L, S, H, gridtype, align_corners, interp};

@@ -2079,8 +2079,8 @@ int g3_fwd_launch(const float* inputs, const void* table, const int* offsets, vo
                          else if (G == 2) hipLaunchKernelGGL((g3_fwd_kernel<TT, CC, 2>), grid, blk, 0, s, a); \
                          else if (G == 4) hipLaunchKernelGGL((g3_fwd_kernel<TT, CC, 4>), grid, blk, 0, s, a); \
                          else hipLaunchKernelGGL((g3_fwd_kernel<TT, CC, 8>), grid, blk, 0, s, a); } while (0)
-  if (dtype == SNERF_DT_F16) { if (C == 4) G3F(_Float16, 4); else if (C == 1) G3F(_Float16, 1); else return SNERF_ERR_ARG; }
-  else if (dtype == SNERF_DT_F32) { if (C == 4) G3F(float, 4); else if (C == 1) G3F(float, 1); else return SNERF_ERR_ARG; }
+  if (dtype == SNERF_DT_F16) { if (C == 4) G3F(_Float16, 4); else if (C == 1) G3F(_Float16, 1); else if (C == 2) G3F(_Float16, 2); else if (C == 8) G3F(_Float16, 8); else return SNERF_ERR_ARG; }
+  else if (dtype == SNERF_DT_F32) { if (C == 4) G3F(float, 4); else if (C == 1) G3F(float, 1); else if (C == 2) G3F(float, 2); else if (C == 8) G3F(float, 8); else return SNERF_ERR_ARG; }
   else return SNERF_ERR_ARG;
 #undef G3F
   return snerf_check_launch();

@@ -183,7 +183,7 @@ def _clumped_points(B, seed):
     return np.ascontiguousarray(x)
 
 
-@pytest.mark.parametrize("C,half", [(4, False), (4, True), (1, False), (1, True)])
+@pytest.mark.parametrize("C,half", [(4, False), (4, True), (1, False), (1, True), (2, True), (2, False), (8, True)])
 def test_grid_fast_forward_is_the_slow_kernel_bit_for_bit(C, half):
     """snerf_grid_encode_fwd runs the corner-cached, pair-loading gather for D = 3 / hash / linear / C in {1, 4}: the same corner
     products in the same order as kernel_grid's restatement (grid.hip) -- identical bits, for random and for clumped points, in both
