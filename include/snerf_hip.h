@@ -164,13 +164,13 @@ int snerf_grid_encode_bwd(const void* grad, const float* inputs, const void* emb
 int snerf_grid_tv_grad(const float* inputs, const void* embeddings, void* grad, const int* offsets, float weight, int B, int D,
                        int C, int L, float S, int H, int gridtype, int align_corners, int dtype, void* stream);
 /* The table gradient of grid_encode_backward (gridencoder.cu:248-340, bindings.cpp:7) WITHOUT atomics on the table, for the instantiations
- * zipnerf constructs (internal/models.py:413-421: D = 3, hash, linear, align_corners = False, C = 4 / 1): runs of consecutive points in one
+ * zipnerf constructs (internal/models.py:413-421: D = 3, hash, linear, align_corners = False; C in {1, 2, 4, 8}): runs of consecutive points in one
  * cell become records (row, sum of w x grad), binned by destination row range, accumulated per bin in LDS in 64-bit fixed point
  * (bit-reproducible; sums exact to 2^-34 of the largest |grad|).  ONE call: count -> device scan -> write -> accumulate, on the
  * caller's workspace `ws` (256-byte aligned, >= snerf_grid_encode_bwd_binned_ws_bytes(...) bytes; -1 = unsupported layout).
  * grad [B, L*C] (stride_l = C, stride_b = L*C) or [L, B, C] (stride_l = B*C, stride_b = C) in grad_dtype (F32 / F16); grad_embeddings
  * [sO, C] in out_dtype (F32 / F16), += like the reference (arrives zeroed); offsets_host = the same int32 [L + 1] offsets in host memory
- * (the bin plan is made on the host); half_records != 0: contributions rounded once to fp16 (the reference adds __half2 atomics there).
+ * (the bin plan is made on the host); half_records != 0 (C = 1 / 4 only): contributions rounded once to fp16 (the reference adds __half2 atomics there).
  * snerf_grid_set_fast_path(0) sends snerf_grid_encode_fwd back to the one-thread-per-(point, level) kernel for every instantiation (A/B). */
 long snerf_grid_encode_bwd_binned_ws_bytes(long B, int C, int L, const int* offsets_host, int half_records);
 int snerf_grid_encode_bwd_binned(const void* grad, const float* inputs, const int* offsets, const int* offsets_host, void* grad_embeddings,

@@ -1717,7 +1717,7 @@ __global__ __launch_bounds__(1024) void zip_bin_accumulate_kernel(ZipEnc a, ZipB
 #ifndef ZB_ACC_U1
 #define ZB_ACC_U1 16
 #endif
-  constexpr int U = C == 1 ? ZB_ACC_U1 : ZB_ACC_U4;
+  constexpr int U = C == 1 ? ZB_ACC_U1 : (C == 8 ? 8 : ZB_ACC_U4);        // (C = 8: 8 records x 8 channels in flight per thread: 128-register budget)
   for (int r0 = threadIdx.x; r0 < n; r0 += 1024 * U) {
     int row[U];
     float val[U][C];
@@ -1886,6 +1886,12 @@ static int zb_accumulate_launch(const ZipEnc& a, const ZipBin& b, int C, int L, 
   } else if (C == 4) {
     (void)hipFuncSetAttribute((const void*)zip_bin_accumulate_kernel<4, false, GT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL((zip_bin_accumulate_kernel<4, false, GT>), grid, dim3(1024), lds, s, a, b);
+  } else if (C == 2) {                                     // (C = 2 / 8: the stand-alone GridEncoder only, fp32 records)
+    (void)hipFuncSetAttribute((const void*)zip_bin_accumulate_kernel<2, false, GT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((zip_bin_accumulate_kernel<2, false, GT>), grid, dim3(1024), lds, s, a, b);
+  } else if (C == 8) {
+    (void)hipFuncSetAttribute((const void*)zip_bin_accumulate_kernel<8, false, GT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((zip_bin_accumulate_kernel<8, false, GT>), grid, dim3(1024), lds, s, a, b);
   } else {
     (void)hipFuncSetAttribute((const void*)zip_bin_accumulate_kernel<1, false, GT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL((zip_bin_accumulate_kernel<1, false, GT>), grid, dim3(1024), lds, s, a, b);
@@ -2131,17 +2137,21 @@ __global__ __launch_bounds__(256) void g3_bin_emit_kernel(G3Args a, ZipBin b) {
             const unsigned lrow = row & ((1u << b.bshift) - 1u);
             if constexpr (HREC && C == 1) {
               ((unsigned*)b.rec_val)[r] = lrow | (zb_half_bits(vals[idx][0] * hmul) << 16);
-            } else if constexpr (HREC) {                 // ONE 16-byte record (PACK form of the accumulate kernel)
+            } else if constexpr (HREC && C == 4) {       // ONE 16-byte record (PACK form of the accumulate kernel)
               const zb_h4 v4 = {(_Float16)(vals[idx][0] * hmul), (_Float16)(vals[idx][1] * hmul), (_Float16)(vals[idx][2] * hmul), (_Float16)(vals[idx][3] * hmul)};
               const uint2 hv = __builtin_bit_cast(uint2, v4);
               *(uint4*)(b.rec_val + r * 4) = uint4{lrow, hv.x, hv.y, 0u};
             } else if constexpr (C == 1) {
               const uint2 rv = {lrow, __float_as_uint(vals[idx][0])};
               *(uint2*)(b.rec_val + r * 2) = rv;
-            } else {
+            } else if constexpr (C == 4) {
               b.rec_row[r] = (unsigned short)lrow;
               const f32x4 v4 = {vals[idx][0], vals[idx][1], vals[idx][2], vals[idx][3]};
               *(f32x4*)(b.rec_val + r * 4) = v4;
+            } else {                                     // C = 2 / 8: row plane + C floats
+              b.rec_row[r] = (unsigned short)lrow;
+#pragma unroll
+              for (int c = 0; c < C; ++c) b.rec_val[r * C + c] = vals[idx][c];
             }
           }
 #pragma unroll
@@ -2208,7 +2218,7 @@ __global__ __launch_bounds__(1024) void g3_scan_kernel(const int* __restrict__ c
 
 // bin plan of a level layout (ops.zip_bin_plan on the host): replicas per row range, rows the int64 meeting image covers
 static int g3_plan(const int* offsets_host, int L, int C, long B, int* ksplit, int* level_rows, long* g64_rows) {
-  const int bshift = C == 4 ? 12 : 14;
+  const int bshift = C == 8 ? 11 : (C == 4 ? 12 : (C == 2 ? 13 : 14));          // 128 KB of 64-bit cells per bin
   const long target = 2000000, per_level = B * 8;
   *g64_rows = 0;
   for (int l = 0; l < L; ++l) {
@@ -2236,8 +2246,8 @@ static G3Ws g3_ws_layout(long B, int C, int L, long g64_rows, bool hrec) {
   w.g64 = o; o = al(o + (size_t)g64_rows * C * 8);                      // counts .. g64: one memset
   w.starts = o; o = al(o + (size_t)L * ZB_NBMAX * 8);
   w.wgo = o; o = al(o + (size_t)L * w.nwg * ZB_NBMAX * 4);
-  w.rec_row = o; o = al(o + (C == 4 && !hrec ? (size_t)w.cap * 2 : 0));
-  w.rec_val = o; o = al(o + (size_t)w.cap * (hrec ? (C == 4 ? 16 : 4) : (C == 4 ? 16 : 8)));     // (half records at C = 4: packed 16-byte words)
+  w.rec_row = o; o = al(o + (C != 1 && !hrec ? (size_t)w.cap * 2 : 0));
+  w.rec_val = o; o = al(o + (size_t)w.cap * (hrec ? (C == 4 ? 16 : 4) : (C == 1 ? 8 : (size_t)C * 4)));     // (half records at C = 4: packed 16-byte words)
   w.total = o;
   return w;
 }
@@ -2245,8 +2255,8 @@ static G3Ws g3_ws_layout(long B, int C, int L, long g64_rows, bool hrec) {
 extern "C" long snerf_grid_encode_bwd_binned_ws_bytes(long B, int C, int L, const int* offsets_host, int half_records) {
   int ks[16], lr[16]; long g64_rows;
   if (B <= 0) return 0;
-  if (L <= 0 || L > 16 || (C != 1 && C != 4) || offsets_host == nullptr || g3_plan(offsets_host, L, C, B, ks, lr, &g64_rows) != SNERF_OK) return -1;
-  return (long)g3_ws_layout(B, C, L, g64_rows, half_records != 0).total;
+  if (L <= 0 || L > 16 || (C != 1 && C != 2 && C != 4 && C != 8) || offsets_host == nullptr || g3_plan(offsets_host, L, C, B, ks, lr, &g64_rows) != SNERF_OK) return -1;
+  return (long)g3_ws_layout(B, C, L, g64_rows, half_records != 0 && (C == 1 || C == 4)).total;
 }
 
 extern "C" int snerf_grid_encode_bwd_binned(const void* grad, const float* inputs, const int* offsets, const int* offsets_host, void* grad_embeddings,
@@ -2254,11 +2264,11 @@ extern "C" int snerf_grid_encode_bwd_binned(const void* grad, const float* input
                                             long grad_stride_b, int half_records, void* ws, long ws_bytes, void* stream) {
   if (B <= 0) return SNERF_OK;
   int ks[16], lr[16]; long g64_rows;
-  if (L <= 0 || L > 16 || (C != 1 && C != 4) || grad == nullptr || inputs == nullptr || offsets == nullptr || offsets_host == nullptr ||
+  if (L <= 0 || L > 16 || (C != 1 && C != 2 && C != 4 && C != 8) || grad == nullptr || inputs == nullptr || offsets == nullptr || offsets_host == nullptr ||
       grad_embeddings == nullptr || ws == nullptr || ((uintptr_t)ws & 255) || (grad_dtype != SNERF_DT_F32 && grad_dtype != SNERF_DT_F16) ||
       (out_dtype != SNERF_DT_F32 && out_dtype != SNERF_DT_F16) || g3_plan(offsets_host, L, C, B, ks, lr, &g64_rows) != SNERF_OK)
     return SNERF_ERR_ARG;
-  const bool hrec = half_records != 0;
+  const bool hrec = half_records != 0 && (C == 1 || C == 4);              // (C = 2 / 8: fp32 records whatever the gradient's dtype)
   const G3Ws w = g3_ws_layout(B, C, L, g64_rows, hrec);
   if ((long)w.total > ws_bytes) return SNERF_ERR_ARG;
   // the scale pass reads the gradient as rows of C values: [B, L*C] contiguous (stride_b = L*C, stride_l = C) or [L, B, C] (stride_l = B*C)
@@ -2272,7 +2282,7 @@ extern "C" int snerf_grid_encode_bwd_binned(const void* grad, const float* input
   if (rc != SNERF_OK) return rc;
   G3Args a{inputs, B, nullptr, offsets, (void*)grad, grad_stride_l, grad_stride_b, L, S, H};
   ZipBin b{};
-  b.bshift = C == 4 ? 12 : 14;
+  b.bshift = C == 8 ? 11 : (C == 4 ? 12 : (C == 2 ? 13 : 14));
   b.counts = (int*)(base + w.counts); b.wg_offsets = (unsigned*)(base + w.wgo); b.starts = (const long*)(base + w.starts);
   for (int l = 0; l < L; ++l) b.ksplit[l] = ks[l];
   b.rec_row = (unsigned short*)(base + w.rec_row); b.rec_val = (float*)(base + w.rec_val); b.capacity = w.cap;
@@ -2282,8 +2292,8 @@ extern "C" int snerf_grid_encode_bwd_binned(const void* grad, const float* input
                          hipLaunchKernelGGL(g3_scan_kernel, dim3(1), dim3(1024), 0, s, b.counts, (long*)(base + w.starts), L); \
                          if (hrec) hipLaunchKernelGGL((g3_bin_emit_kernel<GT, CC, 1, true>), grid, blk, 0, s, a, b); \
                          else hipLaunchKernelGGL((g3_bin_emit_kernel<GT, CC, 1, false>), grid, blk, 0, s, a, b); } while (0)
-  if (grad_dtype == SNERF_DT_F16) { if (C == 4) G3E(_Float16, 4); else G3E(_Float16, 1); }
-  else { if (C == 4) G3E(float, 4); else G3E(float, 1); }
+  if (grad_dtype == SNERF_DT_F16) { if (C == 4) G3E(_Float16, 4); else if (C == 1) G3E(_Float16, 1); else if (C == 2) G3E(_Float16, 2); else G3E(_Float16, 8); }
+  else { if (C == 4) G3E(float, 4); else if (C == 1) G3E(float, 1); else if (C == 2) G3E(float, 2); else G3E(float, 8); }
 #undef G3E
   ZipEnc za{};
   za.offsets = offsets; za.grad_table = (float*)grad_embeddings; za.L = L;

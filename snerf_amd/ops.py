@@ -810,9 +810,9 @@ def grid_encode_bwd(grad, inputs, embeddings, offsets, L, S, H, gridtype, align_
 
 
 def grid_fast_ok(D, C, gridtype, align_corners, interp, dtype, want_dy_dx=False):
-    """the instantiations that run on the corner-cached gather / binned table gradient (csrc/zip.hip g3_*): what zipnerf constructs
-    (internal/models.py:413-421).  Everything else -- and SNERF_GRID_FAST=0 -- runs the one-thread-per-(point, level) kernels of csrc/grid.hip."""
-    return (GRID_FAST and D == 3 and C in (1, 4) and int(gridtype) == 0 and not align_corners and int(interp) == 0 and not want_dy_dx
+    """the instantiations that run on the pair-loading gather / binned table gradient (csrc/zip.hip g3_*): D = 3, hash, linear -- what
+    zipnerf constructs (internal/models.py:413-421: C = 4 / 1), at every channel count.  Everything else -- and SNERF_GRID_FAST=0 -- runs the one-thread-per-(point, level) kernels of csrc/grid.hip."""
+    return (GRID_FAST and D == 3 and C in (1, 2, 4, 8) and int(gridtype) == 0 and not align_corners and int(interp) == 0 and not want_dy_dx
             and dtype in (torch.float32, torch.float16))
 
 
@@ -845,15 +845,15 @@ def grid_host_offsets(offsets):
 
 
 def grid_encode_bwd_binned(grad, inputs, offsets, C, L, S, H, out_dtype=torch.float32, half_records=None, level_major=False, offsets_host=None):
-    """Table gradient of the stand-alone GridEncoder without atomics (snerf_grid_encode_bwd_binned; D = 3, hash, linear, C in {1, 4}):
+    """Table gradient of the stand-alone GridEncoder without atomics (snerf_grid_encode_bwd_binned; D = 3, hash, linear, C in {1, 2, 4, 8}):
     grad [B, L*C] (or [L,B,C]) fp32 / fp16 -> grad_embeddings [rows, C] in `out_dtype`, bit-reproducible.  `half_records` (default:
     follows the gradient's dtype): contributions travel as fp16 -- the reference adds __half2 atomics into a half table's gradient."""
     _f32c(inputs)
-    assert grad.is_contiguous() and grad.dtype in (torch.float32, torch.float16) and out_dtype in (torch.float32, torch.float16) and C in (1, 4)
+    assert grad.is_contiguous() and grad.dtype in (torch.float32, torch.float16) and out_dtype in (torch.float32, torch.float16) and C in (1, 2, 4, 8)
     B = inputs.shape[0]
     oh = grid_host_offsets(offsets) if offsets_host is None else offsets_host
     if half_records is None:
-        half_records = grad.dtype == torch.float16
+        half_records = grad.dtype == torch.float16 and C in (1, 4)        # (C = 2 / 8 travel as fp32 records)
     g_emb = torch.zeros(int(oh[-1]), C, dtype=out_dtype, device=inputs.device)
     if B == 0:
         return g_emb

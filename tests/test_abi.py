@@ -70,7 +70,7 @@ def test_no_vector_alu_instruction_hides_in_inline_asm():
 
 def test_grid_binned_backward_workspace_query_and_its_limits():
     """snerf_grid_encode_bwd_binned_ws_bytes is host-only: a positive size for the layouts zipnerf builds, -1 for what the binned kernels do
-    not cover (C not in {1, 4}, a level with more than 1024 row ranges) -- GridEncoder.backward then falls back to the atomic scatter."""
+    not cover (C not in {1, 2, 4, 8}, a level with more than 1024 row ranges) -- GridEncoder.backward then falls back to the atomic scatter."""
     if not os.path.exists(_lib.LIB_PATH):
         pytest.skip("library not built")
     import numpy as np
@@ -80,6 +80,6 @@ def test_grid_binned_backward_workspace_query_and_its_limits():
     full = q(65536 * 32 * 7, 4, off, 1)
     assert 10e9 < full < 30e9 and q(65536 * 32 * 7, 4, off, 0) > full            # fp32 records need the row plane too
     assert q(1000, 1, off, 1) > 0 and q(0, 4, off, 1) == 0
-    assert q(1000, 2, off, 0) == -1 and q(1000, 8, off, 1) == -1                  # the other channel counts stay with grid.hip
+    assert q(1000, 2, off, 0) > 0 and q(1000, 8, off, 1) > 0 and q(1000, 3, off, 0) == -1
     big = [0, 8, 8 + (1 << 23)]                                                   # 2^23 rows at C = 4: 2048 row ranges of 4096
-    assert q(1000, 4, big, 1) == -1 and q(1000, 1, big, 1) > 0                    # (C = 1: 512 ranges of 16384)
+    assert q(1000, 4, big, 1) == -1 and q(1000, 8, big, 0) == -1 and q(1000, 1, big, 1) > 0    # (C = 1: 512 ranges of 16384)

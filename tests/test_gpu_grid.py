@@ -211,7 +211,7 @@ def test_grid_fast_forward_is_the_slow_kernel_bit_for_bit(C, half):
         ops.grid_set_fast_path(True)
 
 
-@pytest.mark.parametrize("C,B", [(4, 20003), (1, 20003), (4, 300007)])
+@pytest.mark.parametrize("C,B", [(4, 20003), (1, 20003), (4, 300007), (2, 20003), (8, 20003), (2, 300007)])
 def test_grid_binned_backward_vs_oracle_atomic_kernel_and_itself(C, B):
     """snerf_grid_encode_bwd_binned against oracle/grid.py's kernel_grid_backward restatement, against the atomic kernel, run to run
     (bit-identical), in both gradient layouts, with fp16 gradients / half records, and (B = 300 007: 2.4 M records per level) with the
