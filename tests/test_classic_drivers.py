@@ -348,3 +348,43 @@ def test_render_with_per_ray_near_far_tensors(backend, golden):
     for i in range(4):
         close(out[i], g[str(i)], 2e-4, 2e-4, f"render output {i}")
     close(out[4]["z_vals_map"], g["x_z_vals_map"], 1e-6, 1e-6, "z_vals")
+
+
+def test_fine_pass_early_termination_host_logic(backend):
+    """render_rays(ert=(eps_t, G | schedule)) on both backends (the GPU-sized version with the fused kernels is tests/test_ert.py): without
+    termination the grouped fine pass reproduces the plain render exactly; on an opaque medium fewer samples are evaluated and acc / rgb
+    stay inside the exact bound eps_t; the evaluated samples' raw outputs are the plain render's."""
+    from snerf_amd import classic
+    torch.manual_seed(0)
+    mk = lambda: classic.NeRF(D=8, W=64, input_ch=63, input_ch_views=27, output_ch=4, skips=[4], use_viewdirs=True, compute="f32", device=DEV)
+    coarse, fine = mk(), mk()
+    e, _ = classic.get_embedder(10, 0)
+    ed, _ = classic.get_embedder(4, 0)
+    q = classic.make_network_query_fn(e, ed)
+    g = torch.Generator().manual_seed(1)
+    N = 150
+    d = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1)
+    o = torch.randn(N, 3, generator=g) * 0.1 + torch.tensor([0.0, 0.0, 4.0])
+    rays = torch.cat([o, -d, torch.full((N, 1), 2.0), torch.full((N, 1), 6.0), -d], -1).to(DEV)
+    kw = dict(network_fn=coarse, network_query_fn=q, N_samples=64, perturb=0.0, N_importance=128, network_fine=fine, retraw=True)
+    with torch.no_grad():
+        full = classic.render_rays(rays, **kw)
+        for G in (40, (96, 16)):
+            same = classic.render_rays(rays, ert=(-1.0, G), **kw)
+            for k in ("rgb_map", "acc_map", "depth_map", "raw"):
+                assert torch.equal(full[k], same[k]), (G, k)
+        for net in (coarse, fine):
+            dict(net.named_parameters())["alpha_linear.bias"] += 40.0
+            net.arena.bump()
+        full = classic.render_rays(rays, **kw)
+        classic.ERT_STATS.update(evaluated=0, total=0)
+        fast = classic.render_rays(rays, ert=(1e-3, 16), **kw)
+    assert classic.ERT_STATS["total"] == N * 192 and 0 < classic.ERT_STATS["evaluated"] < 0.85 * N * 192
+    assert float((fast["acc_map"] - full["acc_map"]).abs().max()) <= 1e-3 * 1.01 + 1e-6
+    assert float((fast["rgb_map"] - full["rgb_map"]).abs().max()) <= 1e-3 * 1.01 + 1e-6
+    ev = (fast["raw"] != 0).any(-1)
+    assert torch.equal(fast["raw"][ev], full["raw"][ev])
+    with pytest.raises(NotImplementedError):
+        classic.render_rays(rays, ert=(1e-3, 16), **kw)                      # (grad mode on)
+    with torch.no_grad(), pytest.raises(ValueError):
+        classic.render_rays(rays, ert=(1.0, 16), **kw)
