@@ -172,6 +172,9 @@ int snerf_grid_tv_grad(const float* inputs, const void* embeddings, void* grad, 
  * [sO, C] in out_dtype (F32 / F16), += like the reference (arrives zeroed); offsets_host = the same int32 [L + 1] offsets in host memory
  * (the bin plan is made on the host); half_records != 0 (C = 1 / 4 only): contributions rounded once to fp16 (the reference adds __half2 atomics there).
  * snerf_grid_set_fast_path(0) sends snerf_grid_encode_fwd back to the one-thread-per-(point, level) kernel for every instantiation (A/B). */
+/* starts[L, 1024] (int64) = exclusive scan of counts[L, 1024] (int32), flat over levels and bins: the record offsets of the binned table
+ * gradient (between its count and write passes), on the device. */
+int snerf_zip_bin_scan(const int* counts, long* starts, int L, void* stream);
 long snerf_grid_encode_bwd_binned_ws_bytes(long B, int C, int L, const int* offsets_host, int half_records);
 int snerf_grid_encode_bwd_binned(const void* grad, const float* inputs, const int* offsets, const int* offsets_host, void* grad_embeddings,
                                  long B, int C, int L, float S, int H, int grad_dtype, int out_dtype, long grad_stride_l,

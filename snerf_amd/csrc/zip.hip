@@ -1826,6 +1826,7 @@ __global__ __launch_bounds__(256) void zip_bin_absmax_kernel(const OT* __restric
     }
   } else
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    // (rows at a pitch: a wave per row with lanes over 40 two-byte columns was tried and is 2.5x slower than this element-per-thread form)
     const long r = e / cols;
     const float x = fabsf((float)g[r * ld + (e - r * cols)]);
     m = fmaxf(m, x != x ? __builtin_inff() : x);                                   // (a NaN counts as an overflow: zip_bin_overflow_mark_kernel)
@@ -2250,6 +2251,13 @@ static G3Ws g3_ws_layout(long B, int C, int L, long g64_rows, bool hrec) {
   w.rec_val = o; o = al(o + (size_t)w.cap * (hrec ? (C == 4 ? 16 : 4) : (C == 1 ? 8 : (size_t)C * 4)));     // (half records at C = 4: packed 16-byte words)
   w.total = o;
   return w;
+}
+
+// starts = exclusive scan of the [L x ZB_NBMAX] bin counts (int32 -> int64 record offsets): one launch instead of torch's cast + cumsum + subtract
+extern "C" int snerf_zip_bin_scan(const int* counts, long* starts, int L, void* stream) {
+  if (counts == nullptr || starts == nullptr || L <= 0 || L > 16) return SNERF_ERR_ARG;
+  hipLaunchKernelGGL(g3_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, counts, starts, L);
+  return snerf_check_launch();
 }
 
 extern "C" long snerf_grid_encode_bwd_binned_ws_bytes(long B, int C, int L, const int* offsets_host, int half_records) {

@@ -1058,8 +1058,8 @@ def zip_encode_bwd_binned(tdist, origins, directions, radii, base_x, base_y, deg
         counts = torch.zeros(L, ZB_NBMAX, dtype=torch.int32, device=dev)
         wgo = _zb_workspace(dev, "wgo", L * ((R * S + 255) // 256) * ZB_NBMAX, torch.int32)
         _lib.call("snerf_zip_encode_bwd_binned", 0, *args, _p(counts), _p(wgo), None, None, None, 0, None, 0, None, _stream())
-    flat = counts.view(-1).to(torch.int64)
-    starts = (torch.cumsum(flat, 0) - flat).contiguous()
+    starts = torch.empty(L * ZB_NBMAX, dtype=torch.int64, device=dev)
+    _lib.call("snerf_zip_bin_scan", _p(counts), _p(starts), L, _stream())                  # exclusive scan of the bin counts, on the device
     capacity = R * S * n * 8 * L                               # every (interval, level) emits at most n cells x 8 corners: no host sync
     rec_row = _zb_workspace(dev, "row", capacity if C == 4 else 1, torch.int16)          # (C = 1 records carry their row)
     rec_val = _zb_workspace(dev, "val", capacity * max(C, 2), torch.float32)       # C = 1: {row, value} pairs in one 8-byte record
