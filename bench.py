@@ -1007,7 +1007,7 @@ def main():
             r = ert_classic_analysis.fit_and_measure(steps=500, eps_list=(1e-4,), rows_n=900, groups=((96, 16),), ert_eps=1e-4, dev=device, row0=0)
             m48 = r["measured"]["eps_0.0001_G96_16"]
             out["path_b_ert"] = {"what": "classic render_rays frame 1600 x 900 (64 + 128, two fitted NeRF 8 x 256), plain vs ert=(1e-4, (96, 16)): fine pass front to back -- the "
-                                         "first 96 sorted samples in one piece, then groups of 16 --, rays leave at fine transmittance <= 1e-4, rows compacted (csrc-free: selection in torch, evaluation by fmlp_kernel)",
+                                         "first 96 sorted samples in one piece, then groups of 16 --, rays leave at fine transmittance <= 1e-4, rows compacted (per-group scatter + transmittance + compaction: snerf_classic_ert_step, evaluation by fmlp_kernel)",
                                  "fit_steps": r["fit_steps"], "fit_psnr_db": r["fit_psnr_db"], "frame_ms_plain": r["window_ms_plain"], "frame_ms_ert": m48["window_ms"],
                                  "speedup": m48["speedup"], "fine_evaluations_kept": m48["fine_evaluations_kept"],
                                  "best_case_speedup_at_sample_granularity": r["rules"]["exact_eps_0.0001"]["best_case_frame_speedup"],

@@ -320,6 +320,18 @@ int snerf_ert_f2b_step(const float* prev_raw_d, long ld_den, long prev_base, con
                        const float* far, long N, int S1, int g0, int G, int next_g0, int next_G, int transform_idx, float density_bias,
                        float eps_t, float* tau, int* flags, int* counts, int* row_index, int* sample_id, long row_base, long* total,
                        void* stream);
+/* Front-to-back early ray termination of the CLASSIC path's fine pass (render_rays(ert=...), inference extension, not in the reference):
+ * after the fine network evaluated the group [g0, g0 + G) of the rays `alive` (int32 [n], NULL = rays 0 .. n-1; rows of raw_g [n*G, C >= 4]
+ * in that order), scatter the raw outputs into raw_full [N, S, C], multiply the rays' transmittances T [N] by exp(-sum relu(sigma) dz |d|)
+ * (raw2outputs, run_nerf_helpers.py:394-414; rays [N, ld_rays]: o3, d3, ...; z_all [N, S] sorted), and compact the rays with T > eps_t
+ * into alive_next (in order; none when g0 + G == S); *total (device) = their number.  keep / offs: int32 [n] scratch. */
+int snerf_classic_ert_step(const float* raw_g, int C, const int* alive, long n, const float* z_all, int S, const float* rays, long ld_rays,
+                           int g0, int G, float eps_t, float* T, float* raw_full, int* keep, int* offs, int* alive_next, long* total,
+                           void* stream);
+/* pts [n, G, 3] = o + d z (render.py:354) and viewdirs [n, 3] (columns viewdir_col .. +2 of the ray rows; NULL = none) of the rows
+ * (alive[i], g0 + k) -- the compacted rows of the next group. */
+int snerf_classic_ert_points(const float* rays, long ld_rays, const float* z_all, int S, const int* alive, long n, int g0, int G,
+                             float* pts, float* viewdirs, int viewdir_col, void* stream);
 
 /* ---- the callers either side of the path --------------------------------------------------------
  * Ray generation: s-nerf/utils/sample_utils.py:286-345 get_rays_single_img (training = 0: whole frame / any pixels, half-pixel

@@ -313,6 +313,24 @@ def _fine_pass_front_to_back(rb, z_all, viewdirs, run_fn, network_query_fn, eps_
     while bounds[-1] < S:
         bounds.append(min(S, bounds[-1] + sizes[min(k, len(sizes) - 1)]))
         k += 1
+    if z_all.is_cuda:
+        # the HIP form: positions of the compacted rows, then ONE step (scatter + transmittance + compaction, snerf_classic_ert_step) and
+        # one count read-back per group -- no index_select / masked copies of the ray rows
+        z_all = z_all.contiguous()
+        scratch = (torch.empty(N, dtype=torch.int32, device=dev), torch.empty(N, dtype=torch.int32, device=dev),
+                   torch.empty(N, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int64, device=dev))
+        for g0, g1 in zip(bounds[:-1], bounds[1:]):
+            n = N if alive is None else alive.numel()
+            if n == 0:
+                break
+            pts, vd = ops.classic_ert_points(rb, z_all, alive, g0, g1 - g0)
+            rg = network_query_fn(pts, vd if viewdirs is not None else None, run_fn)
+            if raw is None:
+                raw = torch.zeros(N, S, rg.shape[-1], dtype=torch.float32, device=dev)
+            ERT_STATS["evaluated"] += n * (g1 - g0)
+            alive = ops.classic_ert_step(rg.float().contiguous(), alive, z_all, rb, g0, g1 - g0, eps_t, T, raw, scratch)
+        ERT_STATS["total"] += N * S
+        return raw
     for g0, g1 in zip(bounds[:-1], bounds[1:]):
         if rbs.shape[0] == 0:
             break

@@ -212,3 +212,98 @@ extern "C" int snerf_ert_f2b_step(const float* prev_raw_d, long ld_den, long pre
   hipLaunchKernelGGL(ert_f2b_assign_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
   return snerf_check_launch();
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// The same front-to-back termination for the CLASSIC path's fine pass (round 5; snerf_amd/classic.py _fine_pass_front_to_back): the
+// fine network of render_rays evaluates the sorted union of the 64 uniform coarse positions and the 128 importance samples
+// (render.py:380-389) -- the uniform ones behind the first surface are what can be skipped (35 % of the fine evaluations of a fitted
+// street scene at eps 1e-4, tools/ert_classic_analysis.py).  One step after every evaluated group [g0, g0 + G) of the surviving rays:
+//   update  wave per surviving ray: the group's raw outputs go to their places in raw_full [N, S, C] (unevaluated samples keep raw = 0:
+//           alpha 0, weight 0), the group's optical depth  sum relu(sigma) (z[i+1] - z[i]) |d|  (raw2outputs, run_nerf_helpers.py:394-414)
+//           multiplies the ray's transmittance, the ray stays if T > eps_t
+//   scan    exclusive prefix sum of the keep flags (ert_scan_kernel)
+//   assign  the survivors' ray ids, compacted in order -> the rows of the next group
+// and the positions + view directions of a group's rows (classic_ert_points_kernel: render.py:354 on the compacted rows).
+// ------------------------------------------------------------------------------------------------------------------
+struct ClassicErt {
+  const float* raw_g; int C;
+  const int* alive; long n;
+  const float* z; int S;
+  const float* rays; long ld_rays;
+  int g0, G; float eps_t;
+  float* T; float* raw_full;
+  int* keep; int* offs; int* alive_next;
+};
+__global__ __launch_bounds__(256) void classic_ert_update_kernel(ClassicErt a) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long i = (long)blockIdx.x * 4 + wave;
+  if (i >= a.n) return;
+  const long ray = a.alive != nullptr ? (long)a.alive[i] : i;
+  const float* rd = a.rays + ray * a.ld_rays + 3;
+  const float dn = sqrtf(rd[0] * rd[0] + rd[1] * rd[1] + rd[2] * rd[2]);
+  const float* zr = a.z + ray * a.S;
+  float part = 0.f;
+  for (int k = lane; k < a.G; k += 64) {
+    const int s = a.g0 + k;
+    const float* src = a.raw_g + (i * a.G + k) * a.C;
+    float* dst = a.raw_full + (ray * a.S + s) * a.C;
+    for (int c = 0; c < a.C; ++c) dst[c] = src[c];
+    if (s + 1 < a.S) part += fmaxf(src[3], 0.f) * ((zr[s + 1] - zr[s]) * dn);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+  if (lane == 0) {
+    const float T = a.T[ray] * expf(-part);
+    a.T[ray] = T;
+    const int keep = (a.g0 + a.G < a.S && T > a.eps_t) ? 1 : 0;
+    a.keep[i] = keep;
+    a.offs[i] = keep;
+  }
+}
+__global__ __launch_bounds__(256) void classic_ert_assign_kernel(ClassicErt a) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n) return;
+  if (a.keep[i]) a.alive_next[a.offs[i]] = a.alive != nullptr ? a.alive[i] : (int)i;
+}
+extern "C" int snerf_classic_ert_step(const float* raw_g, int C, const int* alive, long n, const float* z_all, int S, const float* rays, long ld_rays,
+                                      int g0, int G, float eps_t, float* T, float* raw_full, int* keep, int* offs, int* alive_next, long* total,
+                                      void* stream) {
+  if (n <= 0) return SNERF_OK;
+  if (raw_g == nullptr || C < 4 || z_all == nullptr || S < 1 || rays == nullptr || ld_rays < 6 || g0 < 0 || G < 1 || g0 + G > S || T == nullptr ||
+      raw_full == nullptr || keep == nullptr || offs == nullptr || alive_next == nullptr || total == nullptr || n >= (1L << 31))
+    return SNERF_ERR_ARG;
+  ClassicErt a{raw_g, C, alive, n, z_all, S, rays, ld_rays, g0, G, eps_t, T, raw_full, keep, offs, alive_next};
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(classic_ert_update_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(ert_scan_kernel, dim3(1), dim3(1024), 0, s, offs, n, total);
+  hipLaunchKernelGGL(classic_ert_assign_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+  return snerf_check_launch();
+}
+
+__global__ __launch_bounds__(256) void classic_ert_points_kernel(const float* __restrict__ rays, long ld_rays, const float* __restrict__ z, int S,
+                                                                 const int* __restrict__ alive, long n, int g0, int G, float* __restrict__ pts,
+                                                                 float* __restrict__ vd, int vd_col) {
+#pragma clang fp contract(off)        // o + d * z with the product rounded on its own, like classic_points_kernel (sampler.hip) and the eager ops
+  const long total = n * G * 3;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long m = e / 3;
+    const int c = (int)(e - m * 3);
+    const long i = m / G;
+    const int k = (int)(m - i * G);
+    const long ray = alive != nullptr ? (long)alive[i] : i;
+    const float prod = rays[ray * ld_rays + 3 + c] * z[ray * S + g0 + k];
+    pts[e] = rays[ray * ld_rays + c] + prod;
+    if (vd != nullptr && k == 0) vd[i * 3 + c] = rays[ray * ld_rays + vd_col + c];
+  }
+}
+extern "C" int snerf_classic_ert_points(const float* rays, long ld_rays, const float* z_all, int S, const int* alive, long n, int g0, int G,
+                                        float* pts, float* viewdirs, int viewdir_col, void* stream) {
+  if (n <= 0) return SNERF_OK;
+  if (rays == nullptr || ld_rays < 6 || z_all == nullptr || S < 1 || g0 < 0 || G < 1 || g0 + G > S || pts == nullptr ||
+      (viewdirs != nullptr && (viewdir_col < 0 || viewdir_col + 3 > ld_rays)))
+    return SNERF_ERR_ARG;
+  const long total = n * G * 3;
+  const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+  hipLaunchKernelGGL(classic_ert_points_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rays, ld_rays, z_all, S, alive, n, g0, G, pts, viewdirs, viewdir_col);
+  return snerf_check_launch();
+}

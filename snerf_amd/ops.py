@@ -1219,6 +1219,32 @@ def ert_f2b_step(prev_raw_d, prev_base, s1, dirs, near, far, g0, G, next_g0, nex
     return sample_id[:int(total.item())]
 
 
+def classic_ert_points(rays, z_all, alive, g0, G):
+    """positions [n, G, 3] and view directions [n, 3] (None for 8-column ray rows) of the rows (alive[i], g0 + k): the next group of the
+    classic path's front-to-back fine pass (snerf_classic_ert_points); alive None = every ray"""
+    assert rays.is_cuda and rays.dtype == torch.float32 and rays.stride(1) == 1
+    _f32c(z_all)
+    N, S = z_all.shape
+    n = N if alive is None else alive.numel()
+    pts = torch.empty(n, G, 3, dtype=torch.float32, device=rays.device)
+    vd = torch.empty(n, 3, dtype=torch.float32, device=rays.device) if rays.shape[1] > 9 else None
+    _lib.call("snerf_classic_ert_points", _p(rays), rays.stride(0), _p(z_all), S, _p(alive), n, int(g0), int(G), _p(pts), _p(vd), rays.shape[1] - 3, _stream())
+    return pts, vd
+
+
+def classic_ert_step(raw_g, alive, z_all, rays, g0, G, eps_t, T, raw_full, scratch):
+    """one step of that pass (snerf_classic_ert_step): scatter the evaluated group, update the transmittances, compact the survivors.
+    `scratch` = (keep, offs, alive_next int32 [N], total int64 [1]).  -> alive_next[:count] (one device->host read of the count)"""
+    N, S = z_all.shape
+    n = N if alive is None else alive.numel()
+    keep, offs, nxt, total = scratch
+    assert raw_g.dtype == torch.float32 and raw_g.is_contiguous() and raw_full.dtype == torch.float32 and raw_full.is_contiguous() and raw_g.numel() == n * G * raw_full.shape[-1]
+    total.zero_()
+    _lib.call("snerf_classic_ert_step", _p(raw_g), raw_full.shape[-1], _p(alive), n, _p(z_all), S, _p(rays), rays.stride(0), int(g0), int(G), float(eps_t),
+              _p(T), _p(raw_full), _p(keep), _p(offs), _p(nxt), _p(total), _stream())
+    return nxt[:int(total.item())].clone()
+
+
 def ert_f2b_state(n, S1, group, device):
     return (torch.zeros(n, dtype=torch.float32, device=device), torch.empty(n, dtype=torch.int32, device=device),
             torch.empty(n, dtype=torch.int32, device=device), torch.full((n, S1), -1, dtype=torch.int32, device=device),

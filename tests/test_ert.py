@@ -194,3 +194,45 @@ def test_classic_fine_pass_front_to_back_ert():
     assert torch.equal(fast["raw"][evaluated], full["raw"][evaluated])
     with pytest.raises(NotImplementedError):
         classic.render_rays(rays, ert=(eps, 32), **kw)                        # (grad mode on)
+
+
+def test_classic_ert_step_kernels_against_torch():
+    """snerf_classic_ert_points / snerf_classic_ert_step on their own: positions bit-equal to o + d z of the compacted rows, raw rows at
+    their places, transmittance = T exp(-sum relu(sigma) dz |d|) (raw2outputs, run_nerf_helpers.py:394-414), survivors compacted in order;
+    the last group (g0 + G == S) keeps no ray and leaves T alone apart from the factor of its own samples."""
+    from snerf_amd import ops
+    g = torch.Generator().manual_seed(3)
+    N, S, C = 1500, 37, 5
+    rays = torch.randn(N, 11, generator=g).cuda()
+    z = torch.sort(torch.rand(N, S, generator=g) * 4 + 2, -1).values.cuda()
+    alive = torch.sort(torch.randperm(N, generator=g)[:900]).values.to(torch.int32).cuda()
+    for al in (None, alive):
+        n = N if al is None else al.numel()
+        idx = torch.arange(N, device="cuda") if al is None else al.long()
+        for g0, G in ((0, 7), (7, 20), (27, 10)):
+            pts, vd = ops.classic_ert_points(rays, z, al, g0, G)
+            ref = rays[idx, None, 0:3] + rays[idx, None, 3:6] * z[idx, g0:g0 + G, None]
+            assert torch.equal(pts, ref) and torch.equal(vd, rays[idx, 8:11])
+            raw_g = torch.randn(n, G, C, generator=g).cuda()
+            T = (torch.rand(N, generator=g) * 0.5 + 0.5).cuda()
+            T0 = T.clone()
+            raw_full = torch.zeros(N, S, C, device="cuda")
+            scratch = (torch.empty(N, dtype=torch.int32, device="cuda"), torch.empty(N, dtype=torch.int32, device="cuda"),
+                       torch.empty(N, dtype=torch.int32, device="cuda"), torch.zeros(1, dtype=torch.int64, device="cuda"))
+            eps = 0.3
+            nxt = ops.classic_ert_step(raw_g, al, z, rays, g0, G, eps, T, raw_full, scratch)
+            want = torch.zeros_like(raw_full)
+            want[idx, g0:g0 + G] = raw_g
+            assert torch.equal(raw_full, want)
+            g1 = min(g0 + G, S - 1)                                             # (the ray's last sample has no successor: no factor)
+            dz = (z[idx, g0 + 1:g1 + 1] - z[idx, g0:g1]) * rays[idx, 3:6].norm(dim=-1)[:, None]
+            Tw = T0.clone()
+            Tw[idx] = T0[idx] * torch.exp(-(torch.relu(raw_g[:, :g1 - g0, 3]) * dz).sum(-1))
+            assert float((T - Tw).abs().max()) < 1e-6
+            if g0 + G == S:
+                assert nxt.numel() == 0
+            else:
+                sure = (Tw[idx] - eps).abs() > 1e-5
+                got = torch.zeros(N, dtype=torch.bool, device="cuda"); got[nxt.long()] = True
+                assert torch.equal(got[idx][sure], (Tw[idx] > eps)[sure])
+                assert torch.equal(nxt, torch.sort(nxt).values) and nxt.dtype == torch.int32

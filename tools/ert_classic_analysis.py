@@ -33,7 +33,7 @@ def rows_of(first, n, dev):
     return torch.cat([r.origins, r.directions, r.near, r.far, r.viewdirs], -1), r
 
 
-def fit_and_measure(steps=400, eps_list=(1e-4, 1e-3, 1e-2), rows_n=96, lindisp=False, groups=(48, (96, 16)), ert_eps=1e-4, dev=None, chunk=524288, row0=400):
+def fit_and_measure(steps=400, eps_list=(1e-4, 1e-3, 1e-2), rows_n=96, lindisp=False, groups=(48, (96, 16)), ert_eps=1e-4, dev=None, chunk=524288, row0=400, stages=False):
     """-> dict: the analysis above + the MEASURED window renders with render_rays(ert=(ert_eps, G)) for G in `groups` against the plain
     render of the same fitted networks (time, evaluated fraction, errors).  bench.py's `path_b_ert` leg calls this with fewer steps."""
     import types
@@ -124,6 +124,32 @@ def fit_and_measure(steps=400, eps_list=(1e-4, 1e-3, 1e-2), rows_n=96, lindisp=F
             "fine_evaluations_kept": round(classic.ERT_STATS["evaluated"] / max(classic.ERT_STATS["total"], 1), 4),
             "max_abs_err_rgb": float((rgb_e - rgb_p).abs().max()), "max_abs_err_acc": float((acc_e - acc_p).abs().max()),
             "max_abs_err_depth": float((dep_e - dep_p).abs().max())}
+    if stages:
+        # where the ERT window's time goes (synchronised timers around the three stages of a group; the syncs cost a little themselves)
+        from snerf_amd import ops
+        acc = {"points": 0.0, "network": 0.0, "step": 0.0}
+        def timed(name, fn):
+            def w(*a, **k):
+                torch.cuda.synchronize(); t = time.perf_counter()
+                r = fn(*a, **k)
+                torch.cuda.synchronize(); acc[name] += time.perf_counter() - t
+                return r
+            return w
+        keep = (ops.classic_ert_points, ops.classic_ert_step)
+        ops.classic_ert_points, ops.classic_ert_step = timed("points", keep[0]), timed("step", keep[1])
+        q0 = q
+        q = timed("network", q0)                      # (coarse pass + every fine group)
+        _, t_all = render((ert_eps, groups[-1]))
+        ert_acc = dict(acc)
+        for k in acc:
+            acc[k] = 0.0
+        _, t_pl = render(None)
+        res["stages_ms_plain"] = {"network": round(acc["network"] * 1e3, 2), "window": round(t_pl * 1e3, 2)}
+        acc.update(ert_acc)
+        ops.classic_ert_points, ops.classic_ert_step = keep
+        q = q0
+        res["stages_ms"] = {k: round(v * 1e3, 2) for k, v in acc.items()}
+        res["stages_ms"]["window"] = round(t_all * 1e3, 2)
     return res
 
 
@@ -135,9 +161,10 @@ def main():
     ap.add_argument("--chunk", type=int, default=524288)
     ap.add_argument("--row0", type=int, default=400)
     ap.add_argument("--lindisp", action="store_true", help="coarse positions uniform in disparity (render_rays(lindisp=True)); default: uniform in depth, the reference's default")
+    ap.add_argument("--stages", action="store_true", help="also time the stages of the front-to-back pass (points / network / step)")
     args = ap.parse_args()
     torch.cuda.set_device(0)
-    print(json.dumps(fit_and_measure(args.steps, args.eps, args.rows, args.lindisp, chunk=args.chunk, row0=args.row0)))
+    print(json.dumps(fit_and_measure(args.steps, args.eps, args.rows, args.lindisp, chunk=args.chunk, row0=args.row0, stages=args.stages)))
 
 
 if __name__ == "__main__":
