@@ -324,7 +324,7 @@ int snerf_ert_f2b_step(const float* prev_raw_d, long ld_den, long prev_base, con
  * after the fine network evaluated the group [g0, g0 + G) of the rays `alive` (int32 [n], NULL = rays 0 .. n-1; rows of raw_g [n*G, C >= 4]
  * in that order), scatter the raw outputs into raw_full [N, S, C], multiply the rays' transmittances T [N] by exp(-sum relu(sigma) dz |d|)
  * (raw2outputs, run_nerf_helpers.py:394-414; rays [N, ld_rays]: o3, d3, ...; z_all [N, S] sorted), and compact the rays with T > eps_t
- * into alive_next (in order; none when g0 + G == S); *total (device) = their number.  keep / offs: int32 [n] scratch. */
+ * into alive_next (in order; none when g0 + G == S); *total (device) = their number.  keep: int32 [n], offs: int32 [ceil(n / 1024)] scratch. */
 int snerf_classic_ert_step(const float* raw_g, int C, const int* alive, long n, const float* z_all, int S, const float* rays, long ld_rays,
                            int g0, int G, float eps_t, float* T, float* raw_full, int* keep, int* offs, int* alive_next, long* total,
                            void* stream);

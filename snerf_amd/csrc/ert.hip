@@ -257,13 +257,39 @@ __global__ __launch_bounds__(256) void classic_ert_update_kernel(ClassicErt a) {
     a.T[ray] = T;
     const int keep = (a.g0 + a.G < a.S && T > a.eps_t) ? 1 : 0;
     a.keep[i] = keep;
-    a.offs[i] = keep;
   }
 }
+// compaction in three small launches instead of one workgroup walking all n flags (0.45 ms at n = 512 k): sums of 1024-flag blocks ->
+// ert_scan_kernel over the <= n / 1024 sums -> block-local scan + ordered write
+__global__ __launch_bounds__(256) void classic_ert_block_sums_kernel(const int* __restrict__ keep, long n, int* __restrict__ partial) {
+  __shared__ int ws[4];
+  const long e0 = (long)blockIdx.x * 1024 + threadIdx.x * 4;
+  int c = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) c += (e0 + k < n) ? keep[e0 + k] : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
 __global__ __launch_bounds__(256) void classic_ert_assign_kernel(ClassicErt a) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= a.n) return;
-  if (a.keep[i]) a.alive_next[a.offs[i]] = a.alive != nullptr ? a.alive[i] : (int)i;
+  __shared__ int ws[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long e0 = (long)blockIdx.x * 1024 + threadIdx.x * 4;
+  int k4[4], c = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { k4[k] = (e0 + k < a.n) ? a.keep[e0 + k] : 0; c += k4[k]; }
+  int incl = c;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+  if (lane == 63) ws[wave] = incl;
+  __syncthreads();
+  int base = a.offs[blockIdx.x] + incl - c;              // (offs: the exclusive scan of the block sums)
+  for (int w = 0; w < wave; ++w) base += ws[w];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (k4[k]) a.alive_next[base++] = a.alive != nullptr ? a.alive[e0 + k] : (int)(e0 + k);
 }
 extern "C" int snerf_classic_ert_step(const float* raw_g, int C, const int* alive, long n, const float* z_all, int S, const float* rays, long ld_rays,
                                       int g0, int G, float eps_t, float* T, float* raw_full, int* keep, int* offs, int* alive_next, long* total,
@@ -275,8 +301,10 @@ extern "C" int snerf_classic_ert_step(const float* raw_g, int C, const int* aliv
   ClassicErt a{raw_g, C, alive, n, z_all, S, rays, ld_rays, g0, G, eps_t, T, raw_full, keep, offs, alive_next};
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(classic_ert_update_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(ert_scan_kernel, dim3(1), dim3(1024), 0, s, offs, n, total);
-  hipLaunchKernelGGL(classic_ert_assign_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+  const long nb = (n + 1023) / 1024;
+  hipLaunchKernelGGL(classic_ert_block_sums_kernel, dim3((unsigned)nb), dim3(256), 0, s, keep, n, offs);
+  hipLaunchKernelGGL(ert_scan_kernel, dim3(1), dim3(1024), 0, s, offs, nb, total);
+  hipLaunchKernelGGL(classic_ert_assign_kernel, dim3((unsigned)nb), dim3(256), 0, s, a);
   return snerf_check_launch();
 }
 

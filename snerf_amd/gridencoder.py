@@ -35,7 +35,7 @@ class _grid_encode(Function):
         outputs, dy_dx = ops.grid_encode_fwd(inputs, table, offsets, L, S, H, gridtype, align_corners, interpolation, calc_grad_inputs)
         ctx.save_for_backward(inputs, table, offsets, dy_dx if dy_dx is not None else torch.empty(0, device=inputs.device))
         ctx.dims = [L, S, H, gridtype, interpolation, dy_dx is not None, embeddings.dtype]
-        # D = 3 / C in {1, 4} / hash / linear without input gradients (what internal/models.py:413-421 constructs): the forward above ran
+        # D = 3 / C in {1, 2, 4, 8} / hash / linear without input gradients (what internal/models.py:413-421 constructs, and the module's default C = 2): the forward above ran
         # the corner-cached gather and the backward takes the binned table gradient (csrc/zip.hip g3_*) instead of the atomic scatter
         ctx.fast = ops.grid_fast_ok(inputs.shape[1], C, gridtype, align_corners, interpolation, table.dtype, calc_grad_inputs)
         ctx.offsets_host = ops.grid_host_offsets(offsets) if ctx.fast and ctx.needs_input_grad[1] else None   # (read here: `offsets` is the caller's tensor object)

@@ -1239,7 +1239,6 @@ def classic_ert_step(raw_g, alive, z_all, rays, g0, G, eps_t, T, raw_full, scrat
     n = N if alive is None else alive.numel()
     keep, offs, nxt, total = scratch
     assert raw_g.dtype == torch.float32 and raw_g.is_contiguous() and raw_full.dtype == torch.float32 and raw_full.is_contiguous() and raw_g.numel() == n * G * raw_full.shape[-1]
-    total.zero_()
     _lib.call("snerf_classic_ert_step", _p(raw_g), raw_full.shape[-1], _p(alive), n, _p(z_all), S, _p(rays), rays.stride(0), int(g0), int(G), float(eps_t),
               _p(T), _p(raw_full), _p(keep), _p(offs), _p(nxt), _p(total), _stream())
     return nxt[:int(total.item())].clone()

@@ -161,10 +161,12 @@ def main():
     ap.add_argument("--chunk", type=int, default=524288)
     ap.add_argument("--row0", type=int, default=400)
     ap.add_argument("--lindisp", action="store_true", help="coarse positions uniform in disparity (render_rays(lindisp=True)); default: uniform in depth, the reference's default")
+    ap.add_argument("--groups", default="48;96,16", help="group schedules to measure, ';'-separated (a schedule: ','-separated sizes, the last repeats)")
     ap.add_argument("--stages", action="store_true", help="also time the stages of the front-to-back pass (points / network / step)")
     args = ap.parse_args()
     torch.cuda.set_device(0)
-    print(json.dumps(fit_and_measure(args.steps, args.eps, args.rows, args.lindisp, chunk=args.chunk, row0=args.row0, stages=args.stages)))
+    print(json.dumps(fit_and_measure(args.steps, args.eps, args.rows, args.lindisp, chunk=args.chunk, row0=args.row0, stages=args.stages,
+                                     groups=tuple((lambda v: v[0] if len(v) == 1 else v)(tuple(int(x) for x in g.split(','))) for g in args.groups.split(';')))))
 
 
 if __name__ == "__main__":
