@@ -464,8 +464,8 @@ def path_c_baselines(sd, batch, tgt, device, build_rays_per_s, n_cpu=512, n_eage
     # ---- PyTorch-ROCm eager on this GPU, reference-form grid kernels
     prev = torch.get_default_device() if hasattr(torch, "get_default_device") else None
     torch.set_default_device(device)
+    prev_fast = ops.grid_set_fast_path(False)
     try:
-        ops.grid_set_fast_path(False)
         pg = {k: v.to(device).requires_grad_(True) for k, v in sd.items()}
         bg = {k: batch[k][:n_eager].detach().float() for k in keys}
         bg["radii"] = bg["radii"].reshape(n_eager, 1)
@@ -509,7 +509,7 @@ def path_c_baselines(sd, batch, tgt, device, build_rays_per_s, n_cpu=512, n_eage
                                  "speedup_of_the_build": round(build_rays_per_s / (n_eager / dte), 2)}
         del pg, opt
     finally:
-        ops.grid_set_fast_path(True)
+        ops.grid_set_fast_path(prev_fast)
         torch.set_default_device(prev if prev is not None else "cpu")
         torch.cuda.empty_cache()
     return out
@@ -611,8 +611,9 @@ def grid_points(device, R=65536, S=32, n=7):
     return x.reshape(-1, 3).contiguous()
 
 
-def _grid_encoder_measure(enc, x, w, R, S, n, L, C, steps):
+def _grid_encoder_measure(enc, x, w, R, S_, n, L, C, steps):
     from snerf_amd import ops
+    import numpy as np
     B = x.shape[0]
 
     def fwd_bwd():
@@ -625,6 +626,7 @@ def _grid_encoder_measure(enc, x, w, R, S, n, L, C, steps):
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
             enc(x, bound=1)
     res = {}
+    prev_fast = ops.GRID_FAST
     try:
         for name, fast, k in (("fast", True, steps), ("reference_form", False, 1)):
             ops.grid_set_fast_path(fast)
@@ -632,21 +634,33 @@ def _grid_encoder_measure(enc, x, w, R, S, n, L, C, steps):
             fb_ms = _timeit(fwd_bwd, k, warm=1) * 1e3
             res[name] = (f_ms, fb_ms - f_ms, enc.embeddings.grad.clone())
     finally:
-        ops.grid_set_fast_path(True)
+        ops.grid_set_fast_path(prev_fast)
     gf, gs = res["fast"][2], res["reference_form"][2]
+    # an fp32-ACCUMULATED gradient of the same half gradients as the yardstick for both (fp32 atomics into an fp32 table gradient: order
+    # noise ~1e-7): which of the two 16-bit forms is off, and by how much, at the full size
+    x01 = ((x + 1) / 2).contiguous()
+    S, H = float(np.log2(enc.per_level_scale)), enc.base_resolution
+    truth, _ = ops.grid_encode_bwd(w.float(), x01, torch.zeros_like(enc.embeddings.data), enc.offsets, L, S, H, 0, False, 0)
+    tn = float(truth.norm())
+    err = lambda g: {"rel_l2": float((g.float() - truth).norm() / tn), "max_abs_over_max": float((g.float() - truth).abs().max() / truth.abs().max())}
+    e_fast, e_atomic = err(gf), err(gs)
+    plan = ops.grid_encode_bwd_binned_plan(B, C, L, enc.offsets.cpu().numpy(), True, torch.float16)
     useful = B * L * 8 * C * 2                                                # 8 corner rows of C halves per (point, level)
     cb, cb_src = counter_bytes("grid_encoder_fwd")
-    out = {"workload": f"GridEncoder (L = {L}, C = {C}, T = 2^21, 16 -> 8192; half table under autocast) forward + backward on B = {R} x {S} x {n} = {B} "
+    out = {"workload": f"GridEncoder (L = {L}, C = {C}, T = 2^21, 16 -> 8192; half table under autocast) forward + backward on B = {R} x {S_} x {n} = {B} "
                        "ray-ordered contracted multisample points; autograd through snerf_amd.gridencoder (the drop-in of gridencoder/grid.py)",
            "points": B, "fwd_ms": round(res["fast"][0], 3), "bwd_ms": round(res["fast"][1], 3),
            "reference_form_fwd_ms": round(res["reference_form"][0], 3), "reference_form_bwd_ms": round(res["reference_form"][1], 3),
            "bwd_speedup_vs_atomic_scatter": round(res["reference_form"][1] / res["fast"][1], 2),
            "fwd_speedup_vs_per_point_gather": round(res["reference_form"][0] / res["fast"][0], 2),
-           "table_gradient_rel_l2_fast_vs_atomic": float((gf - gs).norm() / gs.norm()),
+           "bwd_workspace_bytes": plan["bytes_used"], "bwd_chunks_per_level": plan["chunks"], "bwd_levels_per_transposed_group": plan["levels_per_transposed_group"],
+           "bwd_launches": plan["launches"],
+           "table_gradient_error_vs_fp32_accumulated": {"fast_binned_half_records": e_fast, "atomic_half2_scatter": e_atomic},
            "roofline": {"bound": "hbm", "kernel": "g3_fwd_kernel<_Float16, 4> (corner-cached hash-grid gather)", "achieved": round(useful / (res["fast"][0] * 1e-3) / 1e9, 1),
                         "peak": 8000.0, "unit": "GB/s", "frac": round(useful / (res["fast"][0] * 1e-3) / 1e9 / 8000.0, 4), "useful_bytes_per_launch": useful,
-                        "traffic": cb, "traffic_source": cb_src, "note": "useful bytes = 8 corner rows x 8 B per (point, level); the backward moves the same payload as records"},
+                        "traffic": cb, "traffic_source": cb_src},
            "bwd_useful_GBps": round(useful / (res["fast"][1] * 1e-3) / 1e9, 1)}
+    del truth, x01
     del enc, x, w, res, gf, gs
     torch.cuda.empty_cache()
     return out

@@ -158,6 +158,12 @@ int snerf_classic_composite_bwd(const float* raw, long ld, const float* noise, c
 int snerf_grid_encode_fwd(const float* inputs, const void* embeddings, const int* offsets, void* outputs, int B, int D, int C,
                           int L, float S, int H, void* dy_dx, int gridtype, int align_corners, int interp, int dtype,
                           long out_stride_l, long out_stride_b, void* stream);
+/* snerf_grid_encode_fwd in kernel_grid's own form (one thread per (point, level), eight independent row loads: gridencoder.cu:87-245) for
+ * EVERY instantiation -- the A/B partner of the measurement legs and parity tests.  Same arguments, same results bit for bit.  (A second
+ * entry instead of a process-wide switch: no hidden state in the library.) */
+int snerf_grid_encode_fwd_ref(const float* inputs, const void* embeddings, const int* offsets, void* outputs, int B, int D, int C,
+                              int L, float S, int H, void* dy_dx, int gridtype, int align_corners, int interp, int dtype,
+                              long out_stride_l, long out_stride_b, void* stream);
 int snerf_grid_encode_bwd(const void* grad, const float* inputs, const void* embeddings, const int* offsets, void* grad_embeddings,
                           int B, int D, int C, int L, float S, int H, const void* dy_dx, void* grad_inputs, int gridtype,
                           int align_corners, int interp, int dtype, long grad_stride_l, long grad_stride_b, void* stream);
@@ -165,21 +171,27 @@ int snerf_grid_tv_grad(const float* inputs, const void* embeddings, void* grad, 
                        int C, int L, float S, int H, int gridtype, int align_corners, int dtype, void* stream);
 /* The table gradient of grid_encode_backward (gridencoder.cu:248-340, bindings.cpp:7) WITHOUT atomics on the table, for the instantiations
  * zipnerf constructs (internal/models.py:413-421: D = 3, hash, linear, align_corners = False; C in {1, 2, 4, 8}): runs of consecutive points in one
- * cell become records (row, sum of w x grad), binned by destination row range, accumulated per bin in LDS in 64-bit fixed point
- * (bit-reproducible; sums exact to 2^-34 of the largest |grad|).  ONE call: count -> device scan -> write -> accumulate, on the
- * caller's workspace `ws` (256-byte aligned, >= snerf_grid_encode_bwd_binned_ws_bytes(...) bytes; -1 = unsupported layout).
- * grad [B, L*C] (stride_l = C, stride_b = L*C) or [L, B, C] (stride_l = B*C, stride_b = C) in grad_dtype (F32 / F16); grad_embeddings
- * [sO, C] in out_dtype (F32 / F16), += like the reference (arrives zeroed); offsets_host = the same int32 [L + 1] offsets in host memory
- * (the bin plan is made on the host); half_records != 0 (C = 1 / 4 only): contributions rounded once to fp16 (the reference adds __half2 atomics there).
- * snerf_grid_set_fast_path(0) sends snerf_grid_encode_fwd back to the one-thread-per-(point, level) kernel for every instantiation (A/B). */
+ * cell become records (row, sum of w x grad), binned by destination row range through an LDS stage (full, aligned lines), accumulated per
+ * bin in LDS in 64-bit fixed point (bit-reproducible; sums exact to 2^-31 of the largest |grad|).  ONE call, LEVEL by level and CHUNK of
+ * points by chunk: count -> scan -> staged write -> accumulate into the level's int64 image, so that the workspace is bounded whatever B
+ * is.  `ws`: 256-byte aligned; ANY size from the smallest feasible layout up works -- the call plans its chunks and (for a [B, L*C]
+ * gradient) the number of levels it transposes per sweep from `ws_bytes`; snerf_grid_encode_bwd_binned_ws_bytes(...) returns the
+ * recommended size: everything in one chunk when that takes less than 1 GB, else 1 GB (-1 = unsupported level layout: more than 1024
+ * row ranges per level); snerf_grid_encode_bwd_binned_plan(...) reports what a given size would run (out[6]: chunks per level, points
+ * per chunk, levels per transposed group (0 = none), kernel launches, record capacity of a chunk, bytes used).
+ * grad [B, L*C] (stride_l = C, stride_b = L*C) or [L, B, C] (stride_l = B*C, stride_b = C: the layout the reference's backward builds,
+ * grid.py:74 -- no transposition sweep) in grad_dtype (F32 / F16); grad_embeddings [sO, C] in out_dtype (F32 / F16), += like the reference
+ * (arrives zeroed); offsets_host = the same int32 [L + 1] offsets in host memory (the plan is made on the host); half_records != 0
+ * (C = 1 / 4 only): contributions rounded once to fp16 (the reference adds __half2 atomics there). */
 /* starts[L, 1024] (int64) = exclusive scan of counts[L, 1024] (int32), flat over levels and bins: the record offsets of the binned table
  * gradient (between its count and write passes), on the device. */
 int snerf_zip_bin_scan(const int* counts, long* starts, int L, void* stream);
 long snerf_grid_encode_bwd_binned_ws_bytes(long B, int C, int L, const int* offsets_host, int half_records);
+int snerf_grid_encode_bwd_binned_plan(long B, int C, int L, const int* offsets_host, int half_records, int grad_dtype, int level_major,
+                                      long ws_bytes, long* out);
 int snerf_grid_encode_bwd_binned(const void* grad, const float* inputs, const int* offsets, const int* offsets_host, void* grad_embeddings,
                                  long B, int C, int L, float S, int H, int grad_dtype, int out_dtype, long grad_stride_l,
                                  long grad_stride_b, int half_records, void* ws, long ws_bytes, void* stream);
-int snerf_grid_set_fast_path(int on);
 
 /* ---- S-NeRF++ / zipnerf background model (s-nerfpp/zipnerf/internal) --------------------------------------------------
  * One launch per sampling level: stepfun.max_dilate_weights (stepfun.py:75-105; dilate = 0 skips it, level 0) with the

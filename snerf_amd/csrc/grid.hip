@@ -332,25 +332,32 @@ template <typename T, int D, int C> static void launch_tv(const float* in, const
 
 int g3_fwd_launch(const float* inputs, const void* table, const int* offsets, void* outputs, long B, int C, int L, float S, int H, int dtype,
                   long s_l, long s_b, hipStream_t s);                       // zip.hip
-extern int g3_fwd_group;
-static int g_grid_fast_path = 1;
-// A/B switch of the measurement legs and the parity tests (0: kernel_grid's one-thread-per-(point, level) form for every instantiation;
-// 2 / 4 / 8 (probes): that many consecutive points per thread in the fast gather, a cell's corners kept across them; 16 (probe): the
-// point-major thread mapping (coalesced [B, L*C] output), 32: the level-major one; 1 = chosen by entry width)
-extern "C" int snerf_grid_set_fast_path(int on) { g_grid_fast_path = on != 0; g3_fwd_group = (on == 2 || on == 4 || on == 8) ? on : (on == 16 ? 0 : (on == 32 ? 1 : -1)); return SNERF_OK; }
-
-extern "C" int snerf_grid_encode_fwd(const float* inputs, const void* embeddings, const int* offsets, void* outputs, int B, int D, int C,
-                                     int L, float S, int H, void* dy_dx, int gridtype, int align_corners, int interp, int dtype,
-                                     long out_stride_l, long out_stride_b, void* stream) {
+static int grid_fwd_entry(const float* inputs, const void* embeddings, const int* offsets, void* outputs, int B, int D, int C,
+                          int L, float S, int H, void* dy_dx, int gridtype, int align_corners, int interp, int dtype,
+                          long out_stride_l, long out_stride_b, void* stream, bool fast) {
   if (B <= 0) return SNERF_OK;
   if (L <= 0 || inputs == nullptr || embeddings == nullptr || offsets == nullptr || outputs == nullptr) return SNERF_ERR_ARG;
   // D = 3, hash, linear, float / half, no dy_dx (what zipnerf constructs, at every channel count): the pair-loading gather of zip.hip
-  if (D == 3 && (C == 1 || C == 2 || C == 4 || C == 8) && gridtype == 0 && !align_corners && interp == 0 && dy_dx == nullptr &&
-      (dtype == SNERF_DT_F32 || dtype == SNERF_DT_F16) && g_grid_fast_path)
+  if (fast && D == 3 && (C == 1 || C == 2 || C == 4 || C == 8) && gridtype == 0 && !align_corners && interp == 0 && dy_dx == nullptr &&
+      (dtype == SNERF_DT_F32 || dtype == SNERF_DT_F16))
     return g3_fwd_launch(inputs, embeddings, offsets, outputs, B, C, L, S, H, dtype, out_stride_l, out_stride_b, (hipStream_t)stream);
   GridArgs a{inputs, embeddings, offsets, outputs, dy_dx, out_stride_l, out_stride_b, B, L, S, H, gridtype, align_corners, interp};
   GRID_DISPATCH(launch_fwd, (a, (hipStream_t)stream))
   return snerf_check_launch();
+}
+
+extern "C" int snerf_grid_encode_fwd(const float* inputs, const void* embeddings, const int* offsets, void* outputs, int B, int D, int C,
+                                     int L, float S, int H, void* dy_dx, int gridtype, int align_corners, int interp, int dtype,
+                                     long out_stride_l, long out_stride_b, void* stream) {
+  return grid_fwd_entry(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners, interp, dtype, out_stride_l, out_stride_b, stream, true);
+}
+// the same operator in kernel_grid's own form (one thread per (point, level), eight independent row loads) for EVERY instantiation: the
+// A/B partner of the measurement legs and the parity tests -- a second entry point instead of a process-wide switch, so that two
+// threads comparing the forms never race on library state
+extern "C" int snerf_grid_encode_fwd_ref(const float* inputs, const void* embeddings, const int* offsets, void* outputs, int B, int D, int C,
+                                         int L, float S, int H, void* dy_dx, int gridtype, int align_corners, int interp, int dtype,
+                                         long out_stride_l, long out_stride_b, void* stream) {
+  return grid_fwd_entry(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners, interp, dtype, out_stride_l, out_stride_b, stream, false);
 }
 
 extern "C" int snerf_grid_encode_bwd(const void* grad, const float* inputs, const void* embeddings, const int* offsets, void* grad_embeddings,

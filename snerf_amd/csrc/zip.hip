@@ -1687,26 +1687,13 @@ __global__ __launch_bounds__(256, NSUB == 8 ? 4 : 3) void zip_bin_write_staged_k
   }
 }
 
-// GT: type of the gradient table the rows are added to (fp32 everywhere but the stand-alone GridEncoder's half tables, whose
-// reference contract is a gradient in the table's dtype)
-// PACK (C = 4, half records; the stand-alone GridEncoder's direct writer): a record is ONE 16-byte word {row, 2 x 2 halves, pad} instead of a
-// 2-byte row and an 8-byte value in two planes -- its writer scatters single records, and every store is a memory request of its own
-template <int C, bool HREC = false, typename GT = float, bool PACK = false>
-__global__ __launch_bounds__(1024) void zip_bin_accumulate_kernel(ZipEnc a, ZipBin b) {
-  extern __shared__ long long zb_acc[];
-  const int level = blockIdx.y, bin = blockIdx.x;
-  const int K = b.ksplit[level];
-  const long rows_l = a.offsets[level + 1] - a.offsets[level];
-  const long row0 = (long)(bin / K) << b.bshift;
-  if (row0 >= rows_l) return;                              // bins past the level's last row range
-  const int n = b.counts[level * ZB_NBMAX + bin];
-  const int se = b.scale_exp[0];
-  const float fix = exp2f((float)se), lim = exp2f((float)(ZB_HEAD + 1 - se));
-  const double unfix = exp2((double)-se);
-  const int cells = (int)min((long)(1 << b.bshift), rows_l - row0) * C;
-  for (int k = threadIdx.x; k < cells; k += 1024) zb_acc[k] = 0;
-  __syncthreads();
-  const long s0 = b.starts[level * ZB_NBMAX + bin];
+// the records [s0, s0 + n) of one bin added into the bin's LDS image in 64-bit fixed point (shared by the zipnerf path's accumulate
+// kernel and the stand-alone GridEncoder's chunked one below).  Record formats: HREC C = 1 one word {row | fp16 << 16}; HREC C = 4 a
+// 2-byte row plane + an 8-byte plane of four halves; fp32 C = 1 {row, value} pairs; otherwise a row plane + C floats.
+// SKIPZ: records whose values are all zero are skipped before the conversions (the stand-alone encoder's runs are padded with such records)
+template <int C, bool HREC, bool SKIPZ = false>
+__device__ __forceinline__ void zb_acc_records(long long* zb_acc, const unsigned short* __restrict__ rec_row, const float* __restrict__ rec_val,
+                                               const long s0, const int n, const float fix, const float lim) {
   // 16 waves x 4 records per thread in flight: the record stream is latency-bound (one record per thread and trip took a bin of
   // 2 M records 4 ms whatever the LDS did)
   // (round 3: 16 per thread for both record sizes -- train step 52.3-52.9 ms at 4, 51.5-52.2 at 8 / 16, 51.3-51.6 at 16 / 16;
@@ -1726,55 +1713,73 @@ __global__ __launch_bounds__(1024) void zip_bin_accumulate_kernel(ZipEnc a, ZipB
       const int r = r0 + u * 1024;
       const long q = s0 + (r < n ? r : r0);
       if constexpr (HREC && C == 1) {
-        const unsigned rv = ((const unsigned*)b.rec_val)[q];
+        const unsigned rv = ((const unsigned*)rec_val)[q];
         row[u] = r < n ? (int)(rv & 0xffffu) : -1;
         val[u][0] = (float)__builtin_bit_cast(_Float16, (unsigned short)(rv >> 16));
         continue;
       }
-      if constexpr (HREC && C == 4 && PACK) {
-        const uint4 rec = *(const uint4*)(b.rec_val + q * 4);
-        row[u] = r < n ? (int)rec.x : -1;
-        const uint2 hv = {rec.y, rec.z};
-        const zb_h4 v4 = __builtin_bit_cast(zb_h4, hv);
-        val[u][0] = (float)v4[0]; val[u][1] = (float)v4[1]; val[u][2] = (float)v4[2]; val[u][3] = (float)v4[3];
-        continue;
-      }
       if constexpr (HREC && C == 4) {
-        row[u] = r < n ? (int)b.rec_row[q] : -1;
-        const zb_h4 v4 = *(const zb_h4*)(b.rec_val + q * 2);
+        row[u] = r < n ? (int)rec_row[q] : -1;
+        const zb_h4 v4 = *(const zb_h4*)(rec_val + q * 2);
         val[u][0] = (float)v4[0]; val[u][1] = (float)v4[1]; val[u][2] = (float)v4[2]; val[u][3] = (float)v4[3];
         continue;
       }
       if constexpr (C == 1) {
-        const uint2 rv = *(const uint2*)(b.rec_val + q * 2);
+        const uint2 rv = *(const uint2*)(rec_val + q * 2);
         row[u] = r < n ? (int)rv.x : -1;
         val[u][0] = __uint_as_float(rv.y);
         continue;
       }
-      row[u] = r < n ? (int)b.rec_row[q] : -1;
+      row[u] = r < n ? (int)rec_row[q] : -1;
       if constexpr (C == 4) {
-        const f32x4 v4 = *(const f32x4*)(b.rec_val + q * 4);
+        const f32x4 v4 = *(const f32x4*)(rec_val + q * 4);
         val[u][0] = v4[0]; val[u][1] = v4[1]; val[u][2] = v4[2]; val[u][3] = v4[3];
       } else {
 #pragma unroll
-        for (int c = 0; c < C; ++c) val[u][c] = b.rec_val[q * C + c];
+        for (int c = 0; c < C; ++c) val[u][c] = rec_val[q * C + c];
       }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (row[u] < 0) continue;
+      if constexpr (SKIPZ) {
+        bool nz = false;
+#pragma unroll
+        for (int c = 0; c < C; ++c) nz |= val[u][c] != 0.f;
+        if (!nz) continue;
+      }
       // C = 4: channel c of row r sits in slot c ^ ((r >> 3) & 3) of the row's four 8-byte cells.  Unswizzled, one instruction (a fixed
       // channel of 64 random rows) can only reach the 8 bank pairs 4 (r mod 8) + c of the 32: an 8-way conflict whatever the rows are;
       // with the swizzle the 64 lanes spread over all 32 pairs (round 4: the LDS atomics were 2.0 of the kernel's 3.8 ms)
       const int sw = C == 4 ? (row[u] >> 3) & 3 : 0;
 #pragma unroll
       for (int c = 0; c < C; ++c) {
-        // (a record is at most max |grad_feat| in magnitude: the clamp only stops non-finite values)
+        // (a record is at most max |grad_feat| in magnitude -- 8 x that for the stand-alone encoder's merged runs, whose scale leaves 3
+        // more head bits: the clamp only stops non-finite values)
         const float v = HREC ? fminf(fmaxf(val[u][c], -65536.f), 65536.f) * (float)(1 << ZB_HALF_SHIFT) : fminf(fmaxf(val[u][c], -lim), lim) * fix;   // half records carry value * 2^(se - ZB_HALF_SHIFT)
         atomicAdd((unsigned long long*)(zb_acc + row[u] * C + (c ^ sw)), (unsigned long long)__float2ll_rn(v));
       }
     }
   }
+}
+
+// GT: type of the gradient table the rows are added to (fp32 in the zipnerf path)
+template <int C, bool HREC = false, typename GT = float>
+__global__ __launch_bounds__(1024) void zip_bin_accumulate_kernel(ZipEnc a, ZipBin b) {
+  extern __shared__ long long zb_acc[];
+  const int level = blockIdx.y, bin = blockIdx.x;
+  const int K = b.ksplit[level];
+  const long rows_l = a.offsets[level + 1] - a.offsets[level];
+  const long row0 = (long)(bin / K) << b.bshift;
+  if (row0 >= rows_l) return;                              // bins past the level's last row range
+  const int n = b.counts[level * ZB_NBMAX + bin];
+  const int se = b.scale_exp[0];
+  const float fix = exp2f((float)se), lim = exp2f((float)(ZB_HEAD + 1 - se));
+  const double unfix = exp2((double)-se);
+  const int cells = (int)min((long)(1 << b.bshift), rows_l - row0) * C;
+  for (int k = threadIdx.x; k < cells; k += 1024) zb_acc[k] = 0;
+  __syncthreads();
+  zb_acc_records<C, HREC>(zb_acc, b.rec_row, b.rec_val, b.starts[level * ZB_NBMAX + bin], n, fix, lim);
   __syncthreads();
   const long grow = (long)a.offsets[level] + row0;
   if (K == 1) {                                             // the only workgroup that owns these rows
@@ -1843,12 +1848,13 @@ template <typename GT = float>
 __global__ void zip_bin_overflow_mark_kernel(GT* __restrict__ grad, const int* __restrict__ scale_exp) {
   if ((unsigned)scale_exp[1] >= 0x7f800000u) grad[0] = (GT)__builtin_nanf("");
 }
-__global__ void zip_bin_scale_kernel(int* scale_exp) {
+// head: extra head bits (a record of the stand-alone encoder is the sum of up to 8 merged contributions: 3)
+__global__ void zip_bin_scale_kernel(int* scale_exp, int head) {
   const unsigned bits = (unsigned)scale_exp[1];
-  int e = 36;
+  int e = 36 - head;
   if (bits != 0 && bits < 0x7f800000u) {
     const int ex = (int)(bits >> 23) - 127;                  // max < 2^(ex + 1) (a denormal maximum counts as 2^-127)
-    e = ZB_HEAD - (ex + 1);
+    e = ZB_HEAD - head - (ex + 1);
     e = e > 127 ? 127 : (e < -100 ? -100 : e);
   }
   scale_exp[0] = e;
@@ -1866,40 +1872,25 @@ extern "C" int snerf_zip_bin_scale(const void* grad_feat, long ld, long rows, in
     else if (feat_dtype == SNERF_DT_F32) hipLaunchKernelGGL(zip_bin_absmax_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)grad_feat, ld, rows, cols, (unsigned*)(scale_exp + 1));
     else return SNERF_ERR_ARG;
   }
-  hipLaunchKernelGGL(zip_bin_scale_kernel, dim3(1), dim3(1), 0, s, scale_exp);
+  hipLaunchKernelGGL(zip_bin_scale_kernel, dim3(1), dim3(1), 0, s, scale_exp, 0);
   return snerf_check_launch();
 }
 
 // pass 2 of the binned table gradient: one workgroup per bin, the replicated levels' int64 image folded, the overflow mark
-template <typename GT>
-static int zb_accumulate_launch(const ZipEnc& a, const ZipBin& b, int C, int L, bool hrec, hipStream_t s, bool pack = false) {
+static int zb_accumulate_launch(const ZipEnc& a, const ZipBin& b, int C, int L, bool hrec, hipStream_t s) {
   const size_t lds = (size_t)(1 << b.bshift) * C * 8;
   const dim3 grid(ZB_NBMAX, L);
-  if (hrec && C == 4 && pack) {
-    (void)hipFuncSetAttribute((const void*)zip_bin_accumulate_kernel<4, true, GT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((zip_bin_accumulate_kernel<4, true, GT, true>), grid, dim3(1024), lds, s, a, b);
-  } else if (hrec && C == 4) {
-    (void)hipFuncSetAttribute((const void*)zip_bin_accumulate_kernel<4, true, GT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((zip_bin_accumulate_kernel<4, true, GT>), grid, dim3(1024), lds, s, a, b);
-  } else if (hrec) {
-    (void)hipFuncSetAttribute((const void*)zip_bin_accumulate_kernel<1, true, GT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((zip_bin_accumulate_kernel<1, true, GT>), grid, dim3(1024), lds, s, a, b);
-  } else if (C == 4) {
-    (void)hipFuncSetAttribute((const void*)zip_bin_accumulate_kernel<4, false, GT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((zip_bin_accumulate_kernel<4, false, GT>), grid, dim3(1024), lds, s, a, b);
-  } else if (C == 2) {                                     // (C = 2 / 8: the stand-alone GridEncoder only, fp32 records)
-    (void)hipFuncSetAttribute((const void*)zip_bin_accumulate_kernel<2, false, GT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((zip_bin_accumulate_kernel<2, false, GT>), grid, dim3(1024), lds, s, a, b);
-  } else if (C == 8) {
-    (void)hipFuncSetAttribute((const void*)zip_bin_accumulate_kernel<8, false, GT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((zip_bin_accumulate_kernel<8, false, GT>), grid, dim3(1024), lds, s, a, b);
-  } else {
-    (void)hipFuncSetAttribute((const void*)zip_bin_accumulate_kernel<1, false, GT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((zip_bin_accumulate_kernel<1, false, GT>), grid, dim3(1024), lds, s, a, b);
-  }
+#define ZBA(CC, HH) do { (void)hipFuncSetAttribute((const void*)zip_bin_accumulate_kernel<CC, HH, float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                         hipLaunchKernelGGL((zip_bin_accumulate_kernel<CC, HH, float>), grid, dim3(1024), lds, s, a, b); } while (0)
+  if (hrec && C == 4) ZBA(4, true);
+  else if (hrec && C == 1) ZBA(1, true);
+  else if (C == 4) ZBA(4, false);
+  else if (C == 1) ZBA(1, false);
+  else return SNERF_ERR_ARG;
+#undef ZBA
   if (b.g64 != nullptr && b.g64_rows > 0)
-    hipLaunchKernelGGL(zip_bin_finish_kernel<GT>, dim3(1024), dim3(256), 0, s, (const long long*)b.g64, b.g64_rows * C, (GT*)a.grad_table, b.scale_exp);
-  hipLaunchKernelGGL(zip_bin_overflow_mark_kernel<GT>, dim3(1), dim3(1), 0, s, (GT*)a.grad_table, b.scale_exp);
+    hipLaunchKernelGGL(zip_bin_finish_kernel<float>, dim3(1024), dim3(256), 0, s, (const long long*)b.g64, b.g64_rows * C, a.grad_table, b.scale_exp);
+  hipLaunchKernelGGL(zip_bin_overflow_mark_kernel<float>, dim3(1), dim3(1), 0, s, a.grad_table, b.scale_exp);
   return snerf_check_launch();
 }
 
@@ -1969,24 +1960,23 @@ extern "C" int snerf_zip_encode_bwd_binned(int pass, const float* tdist, const f
     return snerf_check_launch();
   }
   if (pass != 2 || starts == nullptr || rec_row == nullptr || rec_val == nullptr || grad_table == nullptr || scale_exp == nullptr) return SNERF_ERR_ARG;
-  return zb_accumulate_launch<float>(a, b, C, L, hrec, s);
+  return zb_accumulate_launch(a, b, C, L, hrec, s);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
 // The stand-alone GridEncoder (the reference's only native FFI: gridencoder/src/bindings.cpp:5-9) on the same machinery, for the
 // instantiations zipnerf constructs (internal/models.py:413-421): D = 3, hash grid type, linear interpolation, align_corners = False,
 // C = 4 (NeRF grid) / 1 (proposal grids), float or half table.  Arbitrary points [B, 3] in [0, 1]^3 instead of ray geometry:
-//   forward   g3_fwd_kernel       one thread per (G3 = 8 consecutive points, level): a cell's eight corner entries stay in registers while
-//             consecutive points fall into it (the reference's callers pass the 7 multisamples of an interval one after the other:
-//             always one cell on the coarse levels), x-neighbour corners as ONE 4- / 8- / 16-byte load where their rows are adjacent
-//             -- kernel_grid (gridencoder.cu:87-245) fetches 8 rows per (point, level) whatever the neighbours did;
-//   backward  g3_bin_emit_kernel  the binned table gradient above fed from points: a run of consecutive points in one cell becomes 8
-//             RECORDS (row, sum of w x grad over the run); count -> device scan -> write -> LDS fixed-point accumulation, in ONE
-//             C-ABI call on a caller-provided workspace (no atomics on the table, bit-reproducible) -- kernel_grid_backward
-//             (gridencoder.cu:248-340) issues 8 x C / 2 half2 atomics per (point, level): 20.6 G atomics/s on this part.
-// Everything else (D != 3, C = 2 / 8, tiled, smoothstep, align_corners, double, dy_dx) stays in grid.hip.
+//   forward   g3_fwd_kernel       one thread per (point, level), x-neighbour corners as ONE 4- / 8- / 16-byte load where their rows are
+//             adjacent; point-major thread order for 8-byte entries so that [B, L*C] leaves in contiguous runs -- kernel_grid
+//             (gridencoder.cu:87-245) fetches 8 rows per (point, level) whatever the neighbours did;
+//   backward  g3_count / g3_write_staged / g3_accumulate: the binned table gradient above fed from points: a run of consecutive points
+//             in one cell becomes 8 RECORDS (row, sum of w x grad over the run); level by level and chunk by chunk, count -> device scan ->
+//             LDS-staged write -> LDS fixed-point accumulation, in ONE C-ABI call on a caller-provided BOUNDED workspace (no atomics on
+//             the table, bit-reproducible) -- kernel_grid_backward (gridencoder.cu:248-340) issues 8 x C / 2 half2 atomics per
+//             (point, level): 20.6 G atomics/s on this part.
+// Everything else (D != 3, tiled, smoothstep, align_corners, double, dy_dx) stays in grid.hip.
 // ------------------------------------------------------------------------------------------------------------------
-#define G3_PTS 8
 struct G3Args {
   const float* inputs; long B;
   const void* table; const int* offsets;
@@ -2071,21 +2061,17 @@ __global__ __launch_bounds__(256) void g3_fwd_kernel(G3Args a) {
   }
 }
 
-// the fast forward for grid.hip's snerf_grid_encode_fwd (D = 3, C = 1 / 4, hash, linear, no align_corners, float / half, no dy_dx)
-int g3_fwd_group = -1;      // -1: by entry width (below); 0 / 1 / 2 / 4 / 8: probe values of snerf_grid_set_fast_path (point-major; points per thread)
+// the fast forward for grid.hip's snerf_grid_encode_fwd (D = 3, C = 1 / 2 / 4 / 8, hash, linear, no align_corners, float / half, no dy_dx)
 int g3_fwd_launch(const float* inputs, const void* table, const int* offsets, void* outputs, long B, int C, int L, float S, int H, int dtype,
                   long s_l, long s_b, hipStream_t s) {
   G3Args a{inputs, B, table, offsets, outputs, s_l, s_b, L, S, H};
   // measured at 14.7 M points, L = 10 (profiles/r5_y_grid_encoder_mapping_ab.txt): 8-byte entries (C = 4, half) 6.2 ms point-major vs 7.7
-  // level-major on ray-ordered points, equal on random ones; 2- / 4-byte entries (C = 1) are faster level-major (4.2 vs 5.6 ms)
-  const int G = g3_fwd_group >= 0 ? g3_fwd_group : ((size_t)C * (dtype == SNERF_DT_F16 ? 2 : 4) >= 8 ? 0 : 1);
-  const bool pm = G == 0 && s_l == C && s_b == (long)L * C;              // point-major needs the [B, L*C] layout to pay
-  const dim3 grid0((unsigned)((B * L + 255) / 256)), grid((unsigned)((B + 256 * (G < 1 ? 1 : G) - 1) / (256 * (G < 1 ? 1 : G))), L), blk(256);
+  // level-major on ray-ordered points, equal on random ones; 2- / 4-byte entries (C = 1) are faster level-major (4.2 vs 5.6 ms).
+  // (2 / 4 / 8 consecutive points per thread with the cell's corners kept in registers: slower, profiles/r5_a_grid_encoder_leg_and_sweep.txt)
+  const bool pm = (size_t)C * (dtype == SNERF_DT_F16 ? 2 : 4) >= 8 && s_l == C && s_b == (long)L * C;   // point-major needs the [B, L*C] layout to pay
+  const dim3 grid0((unsigned)((B * L + 255) / 256)), grid((unsigned)((B + 255) / 256), L), blk(256);
 #define G3F(TT, CC) do { if (pm) hipLaunchKernelGGL((g3_fwd_kernel<TT, CC, 0>), grid0, blk, 0, s, a); \
-                         else if (G <= 1) hipLaunchKernelGGL((g3_fwd_kernel<TT, CC, 1>), grid, blk, 0, s, a); \
-                         else if (G == 2) hipLaunchKernelGGL((g3_fwd_kernel<TT, CC, 2>), grid, blk, 0, s, a); \
-                         else if (G == 4) hipLaunchKernelGGL((g3_fwd_kernel<TT, CC, 4>), grid, blk, 0, s, a); \
-                         else hipLaunchKernelGGL((g3_fwd_kernel<TT, CC, 8>), grid, blk, 0, s, a); } while (0)
+                         else hipLaunchKernelGGL((g3_fwd_kernel<TT, CC, 1>), grid, blk, 0, s, a); } while (0)
   if (dtype == SNERF_DT_F16) { if (C == 4) G3F(_Float16, 4); else if (C == 1) G3F(_Float16, 1); else if (C == 2) G3F(_Float16, 2); else if (C == 8) G3F(_Float16, 8); else return SNERF_ERR_ARG; }
   else if (dtype == SNERF_DT_F32) { if (C == 4) G3F(float, 4); else if (C == 1) G3F(float, 1); else if (C == 2) G3F(float, 2); else if (C == 8) G3F(float, 8); else return SNERF_ERR_ARG; }
   else return SNERF_ERR_ARG;
@@ -2093,111 +2079,553 @@ int g3_fwd_launch(const float* inputs, const void* table, const int* offsets, vo
   return snerf_check_launch();
 }
 
-// records of one (group of G3_PTS points, level): PASS 0 counts (and reserves the workgroup's ranges), PASS 1 writes
-template <typename GT, int C, int PASS, bool HREC>
-__global__ __launch_bounds__(256) void g3_bin_emit_kernel(G3Args a, ZipBin b) {
-  __shared__ int cnt[ZB_NBMAX];
-  __shared__ long base[PASS == 1 ? ZB_NBMAX : 1];
-  // 1-D grid, level fastest: the L workgroups of one range of points run together, so that the positions and the [B, L*C] gradient rows
-  // they all read come from HBM once (level-major launch order fetched 16.6 GB for 1.4 GB: profiles/r5_x_grid_encoder_pmc.txt)
-  const int level = (int)(blockIdx.x % (unsigned)a.L);
-  const unsigned wg = blockIdx.x / (unsigned)a.L, nwg = gridDim.x / (unsigned)a.L;
-  for (int k = threadIdx.x; k < ZB_NBMAX; k += 256) cnt[k] = 0;
-  if constexpr (PASS == 1) {
-    const unsigned* wgo1 = b.wg_offsets + ((long)level * nwg + wg) * ZB_NBMAX;
-    for (int k = threadIdx.x; k < ZB_NBMAX; k += 256) base[k] = b.starts[level * ZB_NBMAX + k] + (long)wgo1[k];
+// ---- table gradient of the stand-alone encoder (round 6): chunked, LDS-staged, bounded workspace ----------------------------------
+// Same record / bin / LDS-fixed-point scheme as the zipnerf path above, reorganised so that the workspace does not grow with B and every
+// record store is a full, aligned line:
+//   * LEVELS OUTER, POINT CHUNKS INNER.  One level's records of one chunk of Pc points are counted, written and accumulated before the
+//     next chunk reuses the record buffer; the partial sums of a level meet in ONE int64 image of that level (exact: integer sums,
+//     one rounding at the end, bit-reproducible whatever the chunking).  Workspace = records of one (level, chunk) + the image of one
+//     level + the offsets of one level, whatever B is (the round-5 form kept B x 8 x L records: 11-30 GB at 14.7 M points).
+//   * The gradient is read LEVEL-MAJOR ([L, B, C]: the layout the reference's own backward builds, grid.py:74, and its FFI takes);
+//     a point-major [B, L*C] gradient is transposed by g3_transpose_kernel in groups of as many levels as the workspace holds (the
+//     same sweep finds max |grad| for the fixed-point scale), so that a level's pass reads B x C contiguous values instead of 8 bytes of
+//     every 80-byte row.
+//   * STAGED WRITER (g3_write_staged_kernel): a workgroup of WT threads x PPT consecutive points forms its <= WT x PPT x 8 records
+//     (runs of consecutive points in one cell merged, as before), and moves them through an LDS stage SORTED BY BIN in windows of NSW
+//     records: consecutive lanes store consecutive records of one (workgroup, bin) run.  Every run is padded to GR records (zero
+//     records: row 0, value 0) so that runs start and end on 32-byte sectors in both planes -- no partial-sector stores, no
+//     read-for-ownership (the direct writer wrote 18.2 GB and fetched 15.7 GB for 13.3 GB of records, profiles/r5_x_grid_encoder_pmc.txt).
+//     A bin that takes more than a quarter of the stage from one workgroup (dense coarse levels) is written directly: its records
+//     arrive in consecutive slots anyway.  The count pass (g3_count_kernel) leaves {offset, count} per (workgroup, bin), so the writer
+//     starts from its histogram; each (run, corner)'s window is classified once (4 bits) and a window's walk only hashes its own records.
+//   * Merged runs can reach G3 PPT x max |grad|: the scale keeps log2(8) = 3 more head bits (zip_bin_scale_kernel's `head`).
+#define G3_DIRECT 0xffffffffu
+#ifndef G3_WT_
+#define G3_WT_ 1024      // (tools/probes/g3_variants.sh builds the alternatives)
+#define G3_PPT_ 4
+#define G3_WPE_ 4       // waves per SIMD the register budget is set for
+#endif
+template <int C, bool HREC> struct G3Cfg {
+  static constexpr int VW = HREC ? (C == 1 ? 1 : C / 2) : C;            // 32-bit words of a staged value
+  static constexpr int VWG = (C == 1 && !HREC) ? 2 : VW;                // 32-bit words of a record in the global value plane (C = 1: the row rides in it)
+  static constexpr bool ROWPLANE = C != 1;
+  static constexpr int GRLOG = ROWPLANE ? 4 : 3;                        // runs padded to 16 records (2-byte row plane: 32 B) / 8 (4- / 8-byte records)
+  // ONE workgroup of 1024 threads x 4 points per CU: 144 KB of stage (a workgroup's <= 32 768 records pass in 3-4 windows at 12 bytes per
+  // staged record), 128 registers per thread.  Measured alternatives (profiles/r6_a_g3_writer_variants.txt): 512 threads x 8 points with
+  // two workgroups per CU (10 windows, 97 spilled registers); 768 / 512 threads with a thread's keys in registers too; 8 instead of 4
+  // consecutive points per thread would merge 7 % more records on the bench's points.
+  static constexpr int STAGE_BYTES = 147456;
+  static constexpr int NS = (STAGE_BYTES / (4 + 4 * VW)) / 64 * 64;     // stage capacity (records): 18432 / 12288 / 7360 / 4096
+  static constexpr int BIG = NS / 4, NSW = NS - BIG;                    // runs longer than BIG go direct; a window takes the bins that START inside NSW
+  static constexpr int WT = G3_WT_, PPT = G3_PPT_;
+  static constexpr int REC_BYTES = (ROWPLANE ? 2 : 0) + 4 * VWG;
+  static constexpr size_t LDS = 3 * ZB_NBMAX * 4 + (size_t)NS * 4 * (1 + VW) + 256;    // (+ 64 + 64 + 64 bytes of scan / window scalars)
+};
+#define G3_WT G3_WT_
+#define G3_PPT G3_PPT_
+
+struct G3W {
+  const float* inputs; long B; int in_vec;              // points [B, 3]; in_vec: 16-byte loads allowed
+  const void* grad; long g_sb;                          // this level's gradient: value c of point p at grad[p * g_sb + c]
+  const int* offsets; int level; float Sl; int H;
+  unsigned wg0; long wgs_per_chunk;                     // writer: first workgroup of the chunk; count: workgroups per chunk
+  uint2* wgo;                                           // [workgroups of all points][ZB_NBMAX] {offset of the run inside its bin, records}
+  int* counts;                                          // count: [chunks][ZB_NBMAX] padded records per bin
+  const unsigned* starts;                               // writer: [ZB_NBMAX] bin offsets of this (level, chunk)
+  int bshift, K;
+  unsigned short* rec_row; unsigned* rec_val; unsigned cap;
+  const int* scale_exp;
+};
+
+__device__ __forceinline__ uint32_t g3_grid_index(uint32_t hs, uint32_t res, bool pow2, const uint32_t* pg) {   // zip_grid_index with the modulo as a mask where it is one
+  uint32_t stride = 1, index = 0;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    if (stride <= hs) { index += pg[d] * stride; stride *= (res + 1); }
   }
+  if (stride > hs) index = zip_hash3(pg);
+  if (index >= hs) index = pow2 ? (index & (hs - 1u)) : index % hs;
+  return index;
+}
+
+template <int PPT> struct G3Pts { uint32_t pg[PPT][3]; float fr[PPT][3]; unsigned inb, ends; };
+// cells and fractions of PPT consecutive points; bit j of `ends`: point j is the last of its run of in-bounds points in one cell
+template <int PPT>
+__device__ __forceinline__ void g3_decode(const G3W& a, long p0, float scale, G3Pts<PPT>& t) {
+  float xs[PPT * 3];
+  if (PPT * 3 % 4 == 0 && a.in_vec && p0 + PPT <= a.B) {
+    const float4* v = reinterpret_cast<const float4*>(a.inputs + p0 * 3);
+#pragma unroll
+    for (int q = 0; q < PPT * 3 / 4; ++q) { const float4 f = v[q]; xs[4 * q] = f.x; xs[4 * q + 1] = f.y; xs[4 * q + 2] = f.z; xs[4 * q + 3] = f.w; }
+  } else {
+#pragma unroll
+    for (int q = 0; q < PPT * 3; ++q) xs[q] = p0 * 3 + q < a.B * 3 ? a.inputs[p0 * 3 + q] : -1.f;
+  }
+  t.inb = 0; t.ends = 0;
+  int prev = -1;
+  uint32_t pc[3] = {0u, 0u, 0u};
+#pragma unroll
+  for (int j = 0; j < PPT; ++j) {
+    const float* x = xs + 3 * j;
+    if (p0 + j >= a.B || x[0] < 0.f || x[0] > 1.f || x[1] < 0.f || x[1] > 1.f || x[2] < 0.f || x[2] > 1.f) continue;   // (a NaN coordinate passes, as in kernel_grid)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) zip_cell(x[k], scale, &t.pg[j][k], &t.fr[j][k]);
+    if (prev >= 0 && (t.pg[j][0] != pc[0] || t.pg[j][1] != pc[1] || t.pg[j][2] != pc[2])) t.ends |= 1u << prev;
+    pc[0] = t.pg[j][0]; pc[1] = t.pg[j][1]; pc[2] = t.pg[j][2];
+    prev = j;
+    t.inb |= 1u << j;
+  }
+  if (prev >= 0) t.ends |= 1u << prev;
+}
+
+// count pass of one level, all chunks: per-workgroup histogram -> padded reservation inside every touched bin of the workgroup's chunk
+template <int WT, int PPT, int GRLOG>
+__global__ __launch_bounds__(WT) void g3_count_kernel(G3W a) {
+  __shared__ int cnt[ZB_NBMAX];
+  const int tid = threadIdx.x;
+  for (int k = tid; k < ZB_NBMAX; k += WT) cnt[k] = 0;
   __syncthreads();
-  const long p0 = ((long)wg * 256 + threadIdx.x) * G3_PTS;
+  const unsigned wg = blockIdx.x;
+  const long p0 = ((long)wg * WT + tid) * PPT;
+  const uint32_t hs = a.offsets[a.level + 1] - a.offsets[a.level];
+  const float scale = exp2f(a.level * a.Sl) * a.H - 1.0f;
+  const uint32_t res = (uint32_t)ceilf(scale) + 1;
+  const bool pow2 = (hs & (hs - 1u)) == 0u;
+  const int rep = (int)(wg % (unsigned)a.K);
   if (p0 < a.B) {
-    const uint32_t hs = a.offsets[level + 1] - a.offsets[level];
-    const float scale = exp2f(level * a.Sl) * a.H - 1.0f;
-    const uint32_t res = (uint32_t)ceilf(scale) + 1;
-    const int K = b.ksplit[level], rep = (int)(wg % (unsigned)K);
-    float hmul = 1.f;
-    if constexpr (HREC && PASS == 1) hmul = exp2f((float)(b.scale_exp[0] - ZB_HALF_SHIFT));
-    uint32_t cur[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
-    float vals[8][C];
+    G3Pts<PPT> t;
+    g3_decode<PPT>(a, p0, scale, t);
 #pragma unroll
-    for (int idx = 0; idx < 8; ++idx)
-#pragma unroll
-      for (int c = 0; c < C; ++c) vals[idx][c] = 0.f;
-    auto flush = [&]() __attribute__((always_inline)) {
-      if (cur[0] == 0xffffffffu) return;
+    for (int j = 0; j < PPT; ++j) {
+      if (!((t.ends >> j) & 1u)) continue;
 #pragma unroll
       for (int idx = 0; idx < 8; ++idx) {
-        uint32_t pl[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) pl[k] = cur[k] + ((idx >> k) & 1);
-        const uint32_t row = zip_grid_index(hs, res, pl);
-        const int bin = (int)(row >> b.bshift) * K + rep;
-        const int slot = atomicAdd(cnt + bin, 1);
-        if constexpr (PASS == 1) {
-          const long r = base[bin] + slot;
-          if (r < b.capacity) {
-            const unsigned lrow = row & ((1u << b.bshift) - 1u);
-            if constexpr (HREC && C == 1) {
-              ((unsigned*)b.rec_val)[r] = lrow | (zb_half_bits(vals[idx][0] * hmul) << 16);
-            } else if constexpr (HREC && C == 4) {       // ONE 16-byte record (PACK form of the accumulate kernel)
-              const zb_h4 v4 = {(_Float16)(vals[idx][0] * hmul), (_Float16)(vals[idx][1] * hmul), (_Float16)(vals[idx][2] * hmul), (_Float16)(vals[idx][3] * hmul)};
-              const uint2 hv = __builtin_bit_cast(uint2, v4);
-              *(uint4*)(b.rec_val + r * 4) = uint4{lrow, hv.x, hv.y, 0u};
-            } else if constexpr (C == 1) {
-              const uint2 rv = {lrow, __float_as_uint(vals[idx][0])};
-              *(uint2*)(b.rec_val + r * 2) = rv;
-            } else if constexpr (C == 4) {
-              b.rec_row[r] = (unsigned short)lrow;
-              const f32x4 v4 = {vals[idx][0], vals[idx][1], vals[idx][2], vals[idx][3]};
-              *(f32x4*)(b.rec_val + r * 4) = v4;
-            } else {                                     // C = 2 / 8: row plane + C floats
-              b.rec_row[r] = (unsigned short)lrow;
-#pragma unroll
-              for (int c = 0; c < C; ++c) b.rec_val[r * C + c] = vals[idx][c];
-            }
-          }
-#pragma unroll
-          for (int c = 0; c < C; ++c) vals[idx][c] = 0.f;
-        }
-      }
-    };
-#pragma unroll
-    for (int j = 0; j < G3_PTS; ++j) {
-      const long p = p0 + j;
-      if (p >= a.B) break;
-      float x[3];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) x[k] = a.inputs[p * 3 + k];
-      if (x[0] < 0.f || x[0] > 1.f || x[1] < 0.f || x[1] > 1.f || x[2] < 0.f || x[2] > 1.f) continue;
-      float fr[3];
-      uint32_t pg[3];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) zip_cell(x[k], scale, &pg[k], &fr[k]);
-      if (pg[0] != cur[0] || pg[1] != cur[1] || pg[2] != cur[2]) {
-        flush();
-        cur[0] = pg[0]; cur[1] = pg[1]; cur[2] = pg[2];
-      }
-      if constexpr (PASS == 1) {
-        const GT* gi = (const GT*)a.io + level * a.s_l + p * a.s_b;
-        float g[C];
-#pragma unroll
-        for (int c = 0; c < C; ++c) g[c] = (float)gi[c];
-#pragma unroll
-        for (int idx = 0; idx < 8; ++idx) {
-          float w = 1.f;
-#pragma unroll
-          for (int k = 0; k < 3; ++k) w *= (idx & (1 << k)) ? fr[k] : 1.f - fr[k];
-#pragma unroll
-          for (int c = 0; c < C; ++c) vals[idx][c] += w * g[c];
-        }
+        const uint32_t pl[3] = {t.pg[j][0] + (idx & 1), t.pg[j][1] + ((idx >> 1) & 1), t.pg[j][2] + (idx >> 2)};
+        const uint32_t row = g3_grid_index(hs, res, pow2, pl);
+        atomicAdd(cnt + (int)(row >> a.bshift) * a.K + rep, 1);
       }
     }
-    flush();
   }
-  if constexpr (PASS == 0) {
+  __syncthreads();
+  int* counts = a.counts + (long)(wg / (unsigned long)a.wgs_per_chunk) * ZB_NBMAX;
+  uint2* wrow = a.wgo + (long)wg * ZB_NBMAX;
+  for (int k = tid; k < ZB_NBMAX; k += WT) {
+    const int c = cnt[k];
+    unsigned o = 0;
+    if (c != 0) o = (unsigned)atomicAdd(counts + k, (c + (1 << GRLOG) - 1) & ~((1 << GRLOG) - 1));
+    wrow[k] = uint2{o, (unsigned)c};
+  }
+}
+
+// starts[c][bin] = exclusive scan over the bins of counts[c][bin], one block per chunk (32-bit: a chunk holds < 2^32 records)
+__global__ __launch_bounds__(1024) void g3_scan_chunks_kernel(const int* __restrict__ counts, unsigned* __restrict__ starts) {
+  __shared__ unsigned wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const unsigned mine = (unsigned)counts[(long)blockIdx.x * ZB_NBMAX + tid];
+  unsigned incl = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const unsigned u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
+  if (lane == 63) wsum[wv] = incl;
+  __syncthreads();
+  unsigned pre = incl - mine;
+  for (int q = 0; q < wv; ++q) pre += wsum[q];
+  starts[(long)blockIdx.x * ZB_NBMAX + tid] = pre;
+}
+
+template <int C, bool HREC>
+__device__ __forceinline__ void g3_pack(const float* v, float hmul, unsigned* w) {
+  if constexpr (HREC && C == 1) w[0] = zb_half_bits(v[0] * hmul);
+  else if constexpr (HREC) {
+    const zb_h4 v4 = {(_Float16)(v[0] * hmul), (_Float16)(v[1] * hmul), (_Float16)(v[2] * hmul), (_Float16)(v[3] * hmul)};
+    const uint2 hv = __builtin_bit_cast(uint2, v4);
+    w[0] = hv.x; w[1] = hv.y;
+  } else {
+#pragma unroll
+    for (int c = 0; c < C; ++c) w[c] = __float_as_uint(v[c]);
+  }
+}
+template <int C, bool HREC>
+__device__ __forceinline__ void g3_store_one(unsigned short* rec_row, unsigned* rec_val, unsigned r, unsigned lrow, const unsigned* w) {
+  constexpr int VW = G3Cfg<C, HREC>::VW;
+  if constexpr (HREC && C == 1) rec_val[r] = lrow | (w[0] << 16);
+  else if constexpr (C == 1) *reinterpret_cast<uint2*>(rec_val + 2l * r) = uint2{lrow, w[0]};
+  else {
+    rec_row[r] = (unsigned short)lrow;
+    unsigned* d = rec_val + (long)r * VW;
+    if constexpr (VW == 2) *reinterpret_cast<uint2*>(d) = uint2{w[0], w[1]};
+    else {
+#pragma unroll
+      for (int k = 0; k < VW; k += 4) *reinterpret_cast<uint4*>(d + k) = uint4{w[k], w[k + 1], w[k + 2], w[k + 3]};
+    }
+  }
+}
+// records r (even) and r + 1 of one run
+template <int C, bool HREC>
+__device__ __forceinline__ void g3_store_pair(unsigned short* rec_row, unsigned* rec_val, unsigned r, unsigned l0, unsigned l1, const unsigned* w0, const unsigned* w1) {
+  constexpr int VW = G3Cfg<C, HREC>::VW;
+  if constexpr (HREC && C == 1) *reinterpret_cast<uint2*>(rec_val + r) = uint2{l0 | (w0[0] << 16), l1 | (w1[0] << 16)};
+  else if constexpr (C == 1) *reinterpret_cast<uint4*>(rec_val + 2l * r) = uint4{l0, w0[0], l1, w1[0]};
+  else {
+    *reinterpret_cast<unsigned*>(rec_row + r) = l0 | (l1 << 16);
+    unsigned* d = rec_val + (long)r * VW;
+    if constexpr (VW == 2) *reinterpret_cast<uint4*>(d) = uint4{w0[0], w0[1], w1[0], w1[1]};
+    else {
+#pragma unroll
+      for (int k = 0; k < VW; k += 4) *reinterpret_cast<uint4*>(d + k) = uint4{w0[k], w0[k + 1], w0[k + 2], w0[k + 3]};
+#pragma unroll
+      for (int k = 0; k < VW; k += 4) *reinterpret_cast<uint4*>(d + VW + k) = uint4{w1[k], w1[k + 1], w1[k + 2], w1[k + 3]};
+    }
+  }
+}
+
+#ifdef G3_PROF          // probe builds only (tools/probes/g3_prof.sh): cycles per phase of the staged writer, summed over workgroups by thread 0
+__device__ unsigned long long g3_prof_cycles[16];
+extern "C" int snerf_g3_prof_read(unsigned long long* host16, int reset) {
+  if (hipMemcpyFromSymbol(host16, HIP_SYMBOL(g3_prof_cycles), sizeof(unsigned long long) * 16) != hipSuccess) return SNERF_ERR_LAUNCH;
+  if (reset) { unsigned long long z[16] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g3_prof_cycles), z, sizeof(z)); }
+  return SNERF_OK;
+}
+#define G3_TICK(i) do { __builtin_amdgcn_s_waitcnt(0); if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g3_prof_cycles[i], now_ - t_prev_); t_prev_ = now_; } } while (0)
+#define G3_TICK0() unsigned long long t_prev_ = __builtin_amdgcn_s_memtime()
+#else
+#define G3_TICK(i) do { } while (0)
+#define G3_TICK0() do { } while (0)
+#endif
+template <typename GT, int C, bool HREC>
+__global__ __launch_bounds__(G3_WT, G3_WPE_) void g3_write_staged_kernel(G3W a) {
+  using Cfg = G3Cfg<C, HREC>;
+  constexpr int WT = Cfg::WT, PPT = Cfg::PPT, VW = Cfg::VW, NS = Cfg::NS, NSW = Cfg::NSW, BIG = Cfg::BIG, GR = 1 << Cfg::GRLOG;
+  constexpr int BPT = (ZB_NBMAX + WT - 1) / WT, NWV = WT / 64;       // thread t owns bins t, t + WT, ... (the order of the bins in the stage is free)
+  extern __shared__ __attribute__((aligned(16))) unsigned g3_lds[];
+  unsigned* sval = g3_lds;                                   // [NS * VW] staged values (16-byte aligned)
+  unsigned* skey = sval + NS * VW;                           // [NS] staged record: row in bin | bin << 14
+  int* cnt = (int*)(skey + NS);                              // [ZB_NBMAX] placement counters
+  unsigned* off = (unsigned*)cnt + ZB_NBMAX;                 // [ZB_NBMAX] offset of the bin's padded run in the sorted order of the staged bins; G3_DIRECT: written directly
+  unsigned* base = off + ZB_NBMAX;                           // [ZB_NBMAX] record offset of this workgroup's run inside the chunk's record buffer
+  unsigned* wtot = base + ZB_NBMAX;                          // [NWV]
+  unsigned* wend = wtot + 16;                                // [16] end of the staged records of window w (stage positions)
+  unsigned* wbeg = wend + 16;                                // [16] their begin: the bin that straddles the window boundary belongs to the window before
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const unsigned wg = a.wg0 + blockIdx.x;
+  const long p0 = ((long)wg * WT + tid) * PPT;
+  const uint32_t hs = a.offsets[a.level + 1] - a.offsets[a.level];
+  const float scale = exp2f(a.level * a.Sl) * a.H - 1.0f;
+  const uint32_t res = (uint32_t)ceilf(scale) + 1;
+  const bool pow2 = (hs & (hs - 1u)) == 0u;
+  const int rep = (int)(wg % (unsigned)a.K);
+  const unsigned rmask = (1u << a.bshift) - 1u;
+  float hmul = 1.f;
+  if constexpr (HREC) hmul = exp2f((float)(a.scale_exp[0] - ZB_HALF_SHIFT));
+  G3_TICK0();
+  // ---- the thread's points and their gradients
+  G3Pts<PPT> t;
+  t.inb = 0; t.ends = 0;
+  ZVec<GT, C> g[PPT];
+  if (p0 < a.B) {
+    g3_decode<PPT>(a, p0, scale, t);
+#pragma unroll
+    for (int j = 0; j < PPT; ++j)
+      if ((t.inb >> j) & 1u) g[j] = *reinterpret_cast<const ZVec<GT, C>*>((const GT*)a.grad + (p0 + j) * a.g_sb);
+  }
+  // ---- CACHE: every record's VALUE once -- (run, corner) -> packed words in registers (64 at C = 4); the fractions and gradients die here.
+  // (A window that re-walks the points to form its values -- the form kept below for the wide fp32 records -- costs 8.7 instead of 8.3 ms
+  // per backward; keeping the 32 KEYS in registers too needs 96 + registers per thread: at 1024 threads they spill to scratch (19.7 ms
+  // per backward instead of 15.2), at 512 threads x 256 registers the phases of the single resident workgroup stop overlapping (16.7):
+  // profiles/r6_a_g3_writer_variants.txt.)
+  constexpr bool CACHE_ = G3Cfg<C, HREC>::VW <= 2;
+  unsigned rv_[CACHE_ ? PPT * 8 : 1][G3Cfg<C, HREC>::VW];
+  if constexpr (CACHE_) {
+#pragma unroll
+    for (int idx = 0; idx < 8; ++idx) {
+      float acc[C];
+#pragma unroll
+      for (int c = 0; c < C; ++c) acc[c] = 0.f;
+#pragma unroll
+      for (int j = 0; j < PPT; ++j) {
+#pragma unroll
+        for (int k = 0; k < G3Cfg<C, HREC>::VW; ++k) rv_[j * 8 + idx][k] = 0u;
+        if (!((t.inb >> j) & 1u)) continue;
+        float wgt = 1.f;                             // kernel_grid_backward's weight (gridencoder.cu:291-300): product over d in order
+#pragma unroll
+        for (int k = 0; k < 3; ++k) wgt *= (idx & (1 << k)) ? t.fr[j][k] : 1.f - t.fr[j][k];
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] += wgt * (float)g[j].v[c];
+        if (!((t.ends >> j) & 1u)) continue;
+        g3_pack<C, HREC>(acc, hmul, rv_[j * 8 + idx]);
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] = 0.f;
+      }
+    }
+  }
+  G3_TICK(0);
+  // ---- the workgroup's histogram (count pass) -> sorted offsets of the staged bins, windows
+  if (tid < 16) { wend[tid] = 0; wbeg[tid] = 0xffffffffu; }
+  const uint2* wrow = a.wgo + (long)wg * ZB_NBMAX;
+  unsigned cb[BPT], pb[BPT], ob[BPT];
+  unsigned mine = 0;
+#pragma unroll
+  for (int q = 0; q < BPT; ++q) {
+    const int bin = tid + q * WT;
+    cb[q] = 0; pb[q] = 0;
+    if (bin >= ZB_NBMAX) continue;
+    const uint2 e = wrow[bin];
+    cb[q] = e.y;
+    pb[q] = (e.y + GR - 1) & ~(unsigned)(GR - 1);
+    base[bin] = a.starts[bin] + e.x;
+    cnt[bin] = 0;
+    if (pb[q] <= (unsigned)BIG) mine += pb[q];
+  }
+  unsigned incl = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const unsigned u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
+  if (lane == 63) wtot[wv] = incl;
+  __syncthreads();
+  unsigned pre = incl - mine, total = 0;
+#pragma unroll
+  for (int q = 0; q < NWV; ++q) { if (q < wv) pre += wtot[q]; total += wtot[q]; }
+  int nwin = (int)((total + NSW - 1) / NSW);
+  const bool alldirect = nwin > 15;           // (cannot happen with the padded capacity of the shipped configurations; kept correct)
+  if (alldirect) nwin = 0;
+#pragma unroll
+  for (int q = 0; q < BPT; ++q) {
+    const int bin = tid + q * WT;
+    ob[q] = G3_DIRECT;
+    if (bin >= ZB_NBMAX) continue;
+    if (alldirect || pb[q] > (unsigned)BIG) { off[bin] = G3_DIRECT; continue; }
+    ob[q] = pre; off[bin] = pre;
+    if (pb[q] != 0) { atomicMax(wend + pre / NSW, pre % NSW + pb[q]); atomicMin(wbeg + pre / NSW, pre % NSW); }
+    pre += pb[q];
+  }
+  __syncthreads();
+  G3_TICK(1);
+  constexpr bool CACHE = CACHE_;
+  auto& rv = rv_;
+  // ---- window of every (run, corner): 4 bits (15 = direct)
+  unsigned wr[PPT];
+#pragma unroll
+  for (int j = 0; j < PPT; ++j) {
+    wr[j] = 0;
+    if (!((t.ends >> j) & 1u)) continue;
+#pragma unroll
+    for (int idx = 0; idx < 8; ++idx) {
+      const uint32_t pl[3] = {t.pg[j][0] + (idx & 1), t.pg[j][1] + ((idx >> 1) & 1), t.pg[j][2] + (idx >> 2)};
+      const uint32_t row = g3_grid_index(hs, res, pow2, pl);
+      const unsigned o = off[(int)(row >> a.bshift) * a.K + rep];
+      wr[j] |= (o == G3_DIRECT ? 15u : o / NSW) << (4 * idx);
+    }
+  }
+  G3_TICK(2);
+  // ---- windows: place, stream out
+  for (int w = 0; w < (nwin > 0 ? nwin : 1); ++w) {
+    // padding records of the bins of this window (row 0, value 0)
+#pragma unroll
+    for (int q = 0; q < BPT; ++q) {
+      if (ob[q] == G3_DIRECT || pb[q] == cb[q] || (int)(ob[q] / NSW) != w) continue;
+      const unsigned s0 = ob[q] - w * NSW;
+      for (unsigned s = cb[q]; s < pb[q]; ++s) {
+        skey[s0 + s] = (unsigned)(tid + q * WT) << 14;
+#pragma unroll
+        for (int k = 0; k < VW; ++k) sval[(s0 + s) * VW + k] = 0u;
+      }
+    }
+    G3_TICK(5);
+    if constexpr (CACHE) {
+#pragma unroll
+      for (int j = 0; j < PPT; ++j) {
+        if (!((t.ends >> j) & 1u)) continue;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) asm volatile("" : "+v"(t.pg[j][k]));      // (keeps the 32 hashes out of the loop preheader)
+#pragma unroll
+        for (int idx = 0; idx < 8; ++idx) {
+          const unsigned wid = (wr[j] >> (4 * idx)) & 15u;
+          if ((int)wid == w || (wid == 15u && w == 0)) {
+            const uint32_t pl[3] = {t.pg[j][0] + (idx & 1), t.pg[j][1] + ((idx >> 1) & 1), t.pg[j][2] + (idx >> 2)};
+            const uint32_t row = g3_grid_index(hs, res, pow2, pl);
+            const int bin = (int)(row >> a.bshift) * a.K + rep;
+            const unsigned slot = (unsigned)atomicAdd(cnt + bin, 1);
+            if (wid == 15u) {
+              const unsigned r = base[bin] + slot;
+              if (r < a.cap) g3_store_one<C, HREC>(a.rec_row, a.rec_val, r, row & rmask, rv[j * 8 + idx]);
+            } else {
+              const unsigned s_ = off[bin] - w * NSW + slot;
+              skey[s_] = (row & rmask) | ((unsigned)bin << 14);
+#pragma unroll
+              for (int k = 0; k < VW; ++k) sval[s_ * VW + k] = rv[j * 8 + idx][k];
+            }
+          }
+        }
+      }
+    } else {
+    // (the cells and fractions are loop-invariant: without this the compiler hoists all 64 hashes and weights out of the window loop
+    // and spills several hundred registers)
+#pragma unroll
+    for (int j = 0; j < PPT; ++j)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { asm volatile("" : "+v"(t.pg[j][k])); asm volatile("" : "+v"(t.fr[j][k])); }
+    // corner by corner (one accumulator of C values live instead of eight): the run sums of corner idx, each emitted at its run's end
+#pragma unroll
+    for (int idx = 0; idx < 8; ++idx) {
+      float acc[C];
+#pragma unroll
+      for (int c = 0; c < C; ++c) acc[c] = 0.f;
+#pragma unroll
+      for (int j = 0; j < PPT; ++j) {
+        if (!((t.inb >> j) & 1u)) continue;
+        float wgt = 1.f;                             // kernel_grid_backward's weight (gridencoder.cu:291-300): product over d in order
+#pragma unroll
+        for (int k = 0; k < 3; ++k) wgt *= (idx & (1 << k)) ? t.fr[j][k] : 1.f - t.fr[j][k];
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] += wgt * (float)g[j].v[c];
+        if (!((t.ends >> j) & 1u)) continue;
+        const unsigned wid = (wr[j] >> (4 * idx)) & 15u;
+        if ((int)wid == w || (wid == 15u && w == 0)) {
+          const uint32_t pl[3] = {t.pg[j][0] + (idx & 1), t.pg[j][1] + ((idx >> 1) & 1), t.pg[j][2] + (idx >> 2)};
+          const uint32_t row = g3_grid_index(hs, res, pow2, pl);
+          const int bin = (int)(row >> a.bshift) * a.K + rep;
+          const unsigned slot = (unsigned)atomicAdd(cnt + bin, 1);
+          unsigned wv_[VW];
+          g3_pack<C, HREC>(acc, hmul, wv_);
+          if (wid == 15u) {
+            const unsigned r = base[bin] + slot;
+            if (r < a.cap) g3_store_one<C, HREC>(a.rec_row, a.rec_val, r, row & rmask, wv_);
+          } else {
+            const unsigned s = off[bin] - w * NSW + slot;
+            skey[s] = (row & rmask) | ((unsigned)bin << 14);
+#pragma unroll
+            for (int k = 0; k < VW; ++k) sval[s * VW + k] = wv_[k];
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] = 0.f;
+      }
+    }
+    }
+    G3_TICK(6);
     __syncthreads();
-    unsigned* wgo = b.wg_offsets + ((long)level * nwg + wg) * ZB_NBMAX;
-    for (int k = threadIdx.x; k < ZB_NBMAX; k += 256)
-      if (cnt[k] != 0) wgo[k] = (unsigned)atomicAdd(b.counts + level * ZB_NBMAX + k, cnt[k]);
+    G3_TICK(3);
+    const unsigned n = nwin > 0 ? wend[w] : 0u, n0 = nwin > 0 ? wbeg[w] : 0u;   // padded records staged in this window: [n0, n); pairs never straddle a run (GR is even)
+    for (unsigned s = n0 + 2u * tid; s < n; s += 2u * WT) {
+      const unsigned k0 = skey[s], k1 = skey[s + 1];
+      const int bin = (int)(k0 >> 14);
+      const unsigned r = base[bin] + (s - (off[bin] - w * NSW));
+      if (r + 1 < a.cap) g3_store_pair<C, HREC>(a.rec_row, a.rec_val, r, k0 & 0x3fffu, k1 & 0x3fffu, sval + s * VW, sval + (s + 1) * VW);
+    }
+    __syncthreads();
+    G3_TICK(4);
+  }
+  // ---- padding of the directly written runs
+#pragma unroll
+  for (int q = 0; q < BPT; ++q) {
+    if (ob[q] != G3_DIRECT || tid + q * WT >= ZB_NBMAX) continue;
+    const unsigned zero[VW] = {};
+    for (unsigned s = cb[q]; s < pb[q]; ++s) {
+      const unsigned r = base[tid + q * WT] + s;
+      if (r < a.cap) g3_store_one<C, HREC>(a.rec_row, a.rec_val, r, 0u, zero);
+    }
+  }
+}
+
+// one chunk's records of one bin -> the bin's rows: LDS fixed-point sums (+ the level image of the earlier chunks), written as the
+// gradient after the level's last chunk.  K > 1 (replicated row ranges of the hot dense levels): every chunk adds into the zeroed image
+// with integer atomics and zip_bin_finish_kernel converts it after the last one.
+struct G3A {
+  const int* counts; const unsigned* starts; const unsigned short* rec_row; const float* rec_val; unsigned cap;
+  int bshift, K; long rows_l;
+  long long* g64;                            // image of this level's rows (null: single chunk, K = 1)
+  void* out;                                 // this level's rows of grad_embeddings
+  const int* scale_exp; int first, last;
+};
+template <int C, bool HREC, typename GT>
+__global__ __launch_bounds__(1024) void g3_accumulate_kernel(G3A a) {
+  extern __shared__ long long zb_acc[];
+  const int bin = blockIdx.x;
+  const long row0 = (long)(bin / a.K) << a.bshift;
+  if (row0 >= a.rows_l) return;
+  const unsigned s0 = a.starts[bin];
+  int n = a.counts[bin];
+  if (s0 >= a.cap) n = 0; else if ((unsigned)n > a.cap - s0) n = (int)(a.cap - s0);
+  const int se = a.scale_exp[0];
+  const float fix = exp2f((float)se), lim = exp2f((float)(ZB_HEAD + 1 - se));
+  const double unfix = exp2((double)-se);
+  const int cells = (int)min((long)(1 << a.bshift), a.rows_l - row0) * C;
+  for (int k = threadIdx.x; k < cells; k += 1024) zb_acc[k] = 0;
+  __syncthreads();
+  zb_acc_records<C, HREC, true>(zb_acc, a.rec_row, a.rec_val, (long)s0, n, fix, lim);
+  __syncthreads();
+  if (a.K == 1) {
+    GT* dst = (GT*)a.out + row0 * C;
+    long long* img = a.g64 != nullptr ? a.g64 + row0 * C : nullptr;
+    for (int k = threadIdx.x; k < cells; k += 1024) {
+      long long v = zb_acc[k];
+      const int kk = C == 4 ? (k ^ ((k >> 5) & 3)) : k;     // (undo the slot swizzle)
+      if (!a.first) v += img[kk];
+      if (a.last) { if (v != 0) dst[kk] = (GT)((float)dst[kk] + (float)((double)v * unfix)); }
+      else img[kk] = v;
+    }
+  } else {
+    long long* img = a.g64 + row0 * C;
+    for (int k = threadIdx.x; k < cells; k += 1024) {
+      const long long v = zb_acc[k];
+      const int kk = C == 4 ? (k ^ ((k >> 5) & 3)) : k;
+      if (v != 0) atomicAdd((unsigned long long*)(img + kk), (unsigned long long)v);
+    }
+  }
+}
+
+// [B, L*C] -> [nl, B, C] for levels [l0, l0 + nl) through an LDS tile of TP points (rows read whole and coalesced); mx != null: max |grad|
+// over ALL columns on the way (bits of the non-negative maximum; NaN counts as Inf)
+template <typename GT>
+__global__ __launch_bounds__(256) void g3_transpose_kernel(const GT* __restrict__ grad, long B, int LC, int C, int l0, int nl, GT* __restrict__ tg,
+                                                           unsigned* __restrict__ mx, int TP) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char g3_tile[];
+  const int tid = threadIdx.x;
+  const long p0 = (long)blockIdx.x * TP;
+  const int np = (int)min((long)TP, B - p0);
+  const long nbytes = (long)np * LC * (long)sizeof(GT);
+  const unsigned char* src = (const unsigned char*)grad + p0 * LC * (long)sizeof(GT);
+  // max |x| on the BIT patterns (sign cleared, unsigned compare: non-negative floats order like their bits, a NaN sorts above Inf): two
+  // integer ops per 32-bit word (the float form -- convert, fabs, NaN test per element -- made this sweep 2.6 ms instead of 0.3)
+  typedef unsigned short g3_us2 __attribute__((ext_vector_type(2)));
+  unsigned mb = 0u;                                  // fp32: bits of the maximum; fp16: two 16-bit maxima
+  auto upd = [&](unsigned wbits) __attribute__((always_inline)) {
+    if constexpr (sizeof(GT) == 2) mb = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(g3_us2, mb), __builtin_bit_cast(g3_us2, wbits & 0x7fff7fffu)));
+    else { const unsigned v = wbits & 0x7fffffffu; mb = v > mb ? v : mb; }
+  };
+  const long nv = (((uintptr_t)src) & 15) == 0 ? nbytes / 16 : 0;
+  for (long v = tid; v < nv; v += 256) {
+    const uint4 q = reinterpret_cast<const uint4*>(src)[v];
+    reinterpret_cast<uint4*>(g3_tile)[v] = q;
+    if (mx != nullptr) { upd(q.x); upd(q.y); upd(q.z); upd(q.w); }
+  }
+  for (long e = nv * (16 / (long)sizeof(GT)) + tid; e < nbytes / (long)sizeof(GT); e += 256) {
+    const GT gv = ((const GT*)src)[e];
+    ((GT*)g3_tile)[e] = gv;
+    if constexpr (sizeof(GT) == 2) upd((unsigned)__builtin_bit_cast(unsigned short, gv)); else upd(__builtin_bit_cast(unsigned, gv));
+  }
+  if (mx != nullptr) {
+    float m;
+    if constexpr (sizeof(GT) == 2) {
+      const unsigned h = (mb & 0xffffu) > (mb >> 16) ? (mb & 0xffffu) : (mb >> 16);
+      m = h >= 0x7c00u ? __builtin_inff() : (float)__builtin_bit_cast(_Float16, (unsigned short)h);
+    } else m = mb >= 0x7f800000u ? __builtin_inff() : __uint_as_float(mb);
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    // (one same-address atomic per wave of 57 000 workgroups serialises in L2: 2.3 ms; the maximum only grows, so a wave whose value is
+    // not above what it can already see skips it)
+    if ((tid & 63) == 0 && m > 0.f && __float_as_uint(m) > __atomic_load_n(mx, __ATOMIC_RELAXED)) atomicMax(mx, __float_as_uint(m));
+  }
+  __syncthreads();
+  const GT* tile = (const GT*)g3_tile;
+  for (int i = tid; i < nl * np; i += 256) {
+    const int li = i / np, pt = i - li * np;
+    const GT* s = tile + (long)pt * LC + (l0 + li) * C;
+    GT* d = tg + ((long)li * B + p0 + pt) * C;
+    if ((C * (int)sizeof(GT)) % 4 == 0) {
+      for (int k = 0; k < C * (int)sizeof(GT) / 4; ++k) ((unsigned*)d)[k] = ((const unsigned*)s)[k];
+    } else {
+      for (int c = 0; c < C; ++c) d[c] = s[c];
+    }
   }
 }
 
@@ -2217,42 +2645,6 @@ __global__ __launch_bounds__(1024) void g3_scan_kernel(const int* __restrict__ c
   for (int k = 0; k < L; ++k) { starts[tid * L + k] = pre; pre += counts[tid * L + k]; }
 }
 
-// bin plan of a level layout (ops.zip_bin_plan on the host): replicas per row range, rows the int64 meeting image covers
-static int g3_plan(const int* offsets_host, int L, int C, long B, int* ksplit, int* level_rows, long* g64_rows) {
-  const int bshift = C == 8 ? 11 : (C == 4 ? 12 : (C == 2 ? 13 : 14));          // 128 KB of 64-bit cells per bin
-  const long target = 2000000, per_level = B * 8;
-  *g64_rows = 0;
-  for (int l = 0; l < L; ++l) {
-    const long rows = (long)offsets_host[l + 1] - offsets_host[l];
-    if (rows <= 0) return SNERF_ERR_ARG;
-    const long rowbins = (rows + (1L << bshift) - 1) >> bshift;
-    if (rowbins > ZB_NBMAX) return SNERF_ERR_ARG;
-    long k = (per_level + rowbins * target - 1) / (rowbins * target);
-    k = k < 1 ? 1 : (k > ZB_NBMAX / rowbins ? ZB_NBMAX / rowbins : k);
-    ksplit[l] = (int)k; level_rows[l] = (int)rows;
-    if (k > 1) *g64_rows = offsets_host[l + 1];
-  }
-  return SNERF_OK;
-}
-
-struct G3Ws { size_t counts, starts, scale, wgo, g64, rec_row, rec_val, total; long cap, nwg; };
-static G3Ws g3_ws_layout(long B, int C, int L, long g64_rows, bool hrec) {
-  G3Ws w{};
-  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
-  w.nwg = (B + 256 * G3_PTS - 1) / (256 * G3_PTS);
-  w.cap = B * 8 * L;
-  size_t o = 0;
-  w.counts = o; o = al(o + (size_t)L * ZB_NBMAX * 4);
-  w.scale = o; o = al(o + 8);
-  w.g64 = o; o = al(o + (size_t)g64_rows * C * 8);                      // counts .. g64: one memset
-  w.starts = o; o = al(o + (size_t)L * ZB_NBMAX * 8);
-  w.wgo = o; o = al(o + (size_t)L * w.nwg * ZB_NBMAX * 4);
-  w.rec_row = o; o = al(o + (C != 1 && !hrec ? (size_t)w.cap * 2 : 0));
-  w.rec_val = o; o = al(o + (size_t)w.cap * (hrec ? (C == 4 ? 16 : 4) : (C == 1 ? 8 : (size_t)C * 4)));     // (half records at C = 4: packed 16-byte words)
-  w.total = o;
-  return w;
-}
-
 // starts = exclusive scan of the [L x ZB_NBMAX] bin counts (int32 -> int64 record offsets): one launch instead of torch's cast + cumsum + subtract
 extern "C" int snerf_zip_bin_scan(const int* counts, long* starts, int L, void* stream) {
   if (counts == nullptr || starts == nullptr || L <= 0 || L > 16) return SNERF_ERR_ARG;
@@ -2260,52 +2652,236 @@ extern "C" int snerf_zip_bin_scan(const int* counts, long* starts, int L, void* 
   return snerf_check_launch();
 }
 
+// ---- host plan: chunk size, levels per transposed group, workspace layout ----
+struct G3Plan {
+  int wt, ppt, grlog, rec_bytes, vwg, rowplane, bshift;
+  long wgpts, nwg_total, pc, wgs_per_chunk;          // points per workgroup / chunk
+  int nck, lt, groups;                               // chunks per level; levels per transposed group (0: the gradient is level-major already)
+  unsigned cap;                                      // records a chunk's buffer holds (padded upper bound)
+  int ks[16]; long rows[16]; long g64_rows;          // replicas per row range (at the chunk's record count); rows of the level image (0: none)
+  size_t o_scale, o_counts, o_starts, o_wgo, o_g64, o_tg, o_row, o_val, total, zero_bytes;
+};
+static inline size_t g3_al(size_t v) { return (v + 255) & ~(size_t)255; }
+// padded upper bound of the records of pc points of one level: 8 per point + (GR - 1) per non-empty (workgroup, bin) pair
+static long g3_cap(long pc, long wgpts, int grlog, int maxbins) {
+  const long rec = pc * 8, pairs = ((pc + wgpts - 1) / wgpts) * (long)maxbins;
+  return rec + ((1L << grlog) - 1) * (rec < pairs ? rec : pairs) + 64;
+}
+static int g3_make_plan(long B, int C, int L, const int* oh, bool hrec, bool point_major, int gsz, long ws_bytes, G3Plan* pl, long* need_min) {
+  G3Plan p{};
+  const int vw = hrec ? (C == 1 ? 1 : C / 2) : C;
+  p.vwg = (C == 1 && !hrec) ? 2 : vw;
+  p.rowplane = C != 1; p.grlog = p.rowplane ? 4 : 3;
+  p.wt = G3_WT; p.ppt = G3_PPT;
+  p.rec_bytes = (p.rowplane ? 2 : 0) + 4 * p.vwg;
+  p.bshift = C == 8 ? 11 : (C == 4 ? 12 : (C == 2 ? 13 : 14));          // 128 KB of 64-bit cells per bin
+  p.wgpts = (long)p.wt * p.ppt;
+  p.nwg_total = (B + p.wgpts - 1) / p.wgpts;
+  long rowbins[16], max_rows = 0;
+  for (int l = 0; l < L; ++l) {
+    p.rows[l] = (long)oh[l + 1] - oh[l];
+    if (p.rows[l] <= 0) return SNERF_ERR_ARG;
+    rowbins[l] = (p.rows[l] + (1L << p.bshift) - 1) >> p.bshift;
+    if (rowbins[l] > ZB_NBMAX) return SNERF_ERR_ARG;
+    if (p.rows[l] > max_rows) max_rows = p.rows[l];
+  }
+  const long target = 2000000;                                           // records per bin the replicas aim at
+  auto layout = [&](long nwg_chunk, int lt, G3Plan& q) -> bool {        // everything for chunks of nwg_chunk workgroups
+    q.wgs_per_chunk = nwg_chunk; q.pc = nwg_chunk * q.wgpts;
+    q.nck = (int)((q.nwg_total + nwg_chunk - 1) / nwg_chunk);
+    q.lt = lt; q.groups = lt > 0 ? (L + lt - 1) / lt : 1;
+    int maxbins = 1; q.g64_rows = 0;
+    const long pts = q.pc < B ? q.pc : B;
+    for (int l = 0; l < L; ++l) {
+      // replicas per row range: a level's accumulate launch is on its own here (levels outer), so it needs >= ~512 bins to fill the
+      // part -- level 0's 4913 rows are 2 row ranges -- as long as a bin keeps >= 8192 records (below that zeroing and folding its
+      // 128 KB image costs more than its records); never more than `target` records per bin
+      long k = (pts * 8 + rowbins[l] * target - 1) / (rowbins[l] * target);
+      const long kfill = (512 + rowbins[l] - 1) / rowbins[l], kmax = pts * 8 / (rowbins[l] * 8192);
+      if (kfill > k) k = kfill < kmax ? kfill : kmax;
+      k = k < 1 ? 1 : (k > ZB_NBMAX / rowbins[l] ? ZB_NBMAX / rowbins[l] : k);
+      q.ks[l] = (int)k;
+      if (rowbins[l] * k > maxbins) maxbins = (int)(rowbins[l] * k);
+      if ((k > 1 || q.nck > 1) && q.rows[l] > q.g64_rows) q.g64_rows = q.rows[l];
+    }
+    const long cap = g3_cap(pts, q.wgpts, q.grlog, maxbins);
+    if (cap >= (1L << 32) - 64) return false;
+    q.cap = (unsigned)cap;
+    size_t o = 0;
+    q.o_scale = o; o = g3_al(o + 8);
+    q.o_counts = o; o = g3_al(o + (size_t)L * q.nck * ZB_NBMAX * 4);    // scale .. counts: zeroed at the start of a call
+    q.zero_bytes = o;
+    q.o_starts = o; o = g3_al(o + (size_t)q.nck * ZB_NBMAX * 4);
+    q.o_wgo = o; o = g3_al(o + (size_t)q.nwg_total * ZB_NBMAX * 8);
+    q.o_g64 = o; o = g3_al(o + (size_t)q.g64_rows * C * 8);
+    q.o_tg = o; o = g3_al(o + (lt > 0 ? (size_t)lt * B * C * gsz : 0));
+    q.o_row = o; o = g3_al(o + (q.rowplane ? (size_t)cap * 2 : 0));
+    q.o_val = o; o = g3_al(o + (size_t)cap * 4 * q.vwg);
+    q.total = o;
+    return true;
+  };
+  // candidates: levels per transposed group x chunk size; the cheapest estimate that fits (transposition sweeps: the whole gradient read
+  // once per group; chunks: launch gaps + the level image read and written once per extra chunk)
+  double best = 1e30; bool found = false; G3Plan bestp{};
+  long minneed = -1;
+  for (int lt = point_major ? L : 0; lt >= (point_major ? 1 : 0); --lt) {
+    if (point_major && lt > 1 && (L + lt - 1) / lt == (L + lt - 2) / (lt - 1)) continue;      // (lt - 1 makes the same number of sweeps with a smaller copy)
+    G3Plan q = p;
+    const long minwg = 1;                                              // (a workspace too small for more still runs, one workgroup per chunk)
+    if (layout(minwg, lt, q) && (minneed < 0 || (long)q.total < minneed)) minneed = (long)q.total;
+    if (layout(p.nwg_total, lt, q) && (minneed < 0 || (long)q.total < minneed)) minneed = (long)q.total;
+    // the largest chunk that fits: one chunk for the whole level needs no level image (checked first); below that the size is monotone
+    long lo = minwg, hi = p.nwg_total - 1, fit = -1;
+    if (layout(p.nwg_total, lt, q) && (long)q.total <= ws_bytes) fit = p.nwg_total;
+    else {
+      while (lo <= hi) {
+        const long mid = (lo + hi) / 2;
+        if (layout(mid, lt, q) && (long)q.total <= ws_bytes) { fit = mid; lo = mid + 1; } else hi = mid - 1;
+      }
+    }
+    if (fit < 0) { if (lt == 0) break; continue; }
+    // balance the chunks: the same number of chunks with equal sizes
+    const long nck = (p.nwg_total + fit - 1) / fit, even = (p.nwg_total + nck - 1) / nck;
+    layout(even <= fit ? even : fit, lt, q);
+    const double gbytes = (double)B * L * C * gsz;
+    const double cost = (lt > 0 ? q.groups * (gbytes + (double)lt * B * C * gsz) / 4e12 : 0.0) +
+                        (double)L * q.nck * (20e-6 + (q.nck > 1 ? 2.0 * max_rows * C * 8 / 4e12 : 0.0));
+    if (cost < best) { best = cost; bestp = q; found = true; }
+    if (lt == 0) break;
+  }
+  if (need_min != nullptr) *need_min = minneed;
+  if (!found) return SNERF_ERR_ARG;
+  *pl = bestp;
+  return SNERF_OK;
+}
+
+#define G3_WS_DEFAULT 1000000000L
+// recommended workspace: everything in one chunk if that takes less than 1 GB, else 1 GB (or the smallest feasible layout beyond it)
 extern "C" long snerf_grid_encode_bwd_binned_ws_bytes(long B, int C, int L, const int* offsets_host, int half_records) {
-  int ks[16], lr[16]; long g64_rows;
   if (B <= 0) return 0;
-  if (L <= 0 || L > 16 || (C != 1 && C != 2 && C != 4 && C != 8) || offsets_host == nullptr || g3_plan(offsets_host, L, C, B, ks, lr, &g64_rows) != SNERF_OK) return -1;
-  return (long)g3_ws_layout(B, C, L, g64_rows, half_records != 0 && (C == 1 || C == 4)).total;
+  if (L <= 0 || L > 16 || (C != 1 && C != 2 && C != 4 && C != 8) || offsets_host == nullptr) return -1;
+  const bool hrec = half_records != 0 && (C == 1 || C == 4);
+  G3Plan pl; long need_min = -1;
+  // (sized for a point-major fp32 gradient: the worst case of the layouts the call accepts)
+  const int rc = g3_make_plan(B, C, L, offsets_host, hrec, true, 4, G3_WS_DEFAULT, &pl, &need_min);
+  if (rc == SNERF_OK) return (long)pl.total;
+  if (need_min < 0) return -1;
+  return need_min;
+}
+
+// the plan a call with this workspace would run: out[0] = chunks per level, out[1] = points per chunk, out[2] = levels per transposed
+// group (0: none), out[3] = kernel launches, out[4] = record capacity of a chunk, out[5] = bytes used
+extern "C" int snerf_grid_encode_bwd_binned_plan(long B, int C, int L, const int* offsets_host, int half_records, int grad_dtype, int level_major,
+                                                 long ws_bytes, long* out) {
+  if (B <= 0 || L <= 0 || L > 16 || (C != 1 && C != 2 && C != 4 && C != 8) || offsets_host == nullptr || out == nullptr) return SNERF_ERR_ARG;
+  G3Plan pl;
+  const int rc = g3_make_plan(B, C, L, offsets_host, half_records != 0 && (C == 1 || C == 4), level_major == 0, grad_dtype == SNERF_DT_F16 ? 2 : 4, ws_bytes, &pl, nullptr);
+  if (rc != SNERF_OK) return rc;
+  int kx = 0;
+  for (int l = 0; l < L; ++l) kx += pl.ks[l] > 1 ? 1 : 0;
+  out[0] = pl.nck; out[1] = pl.pc; out[2] = pl.lt; out[3] = (pl.lt > 0 ? pl.groups : 1) + 2 + (long)L * (2 + 2 * pl.nck) + kx + 1;
+  out[4] = pl.cap; out[5] = (long)pl.total;
+  return SNERF_OK;
 }
 
 extern "C" int snerf_grid_encode_bwd_binned(const void* grad, const float* inputs, const int* offsets, const int* offsets_host, void* grad_embeddings,
                                             long B, int C, int L, float S, int H, int grad_dtype, int out_dtype, long grad_stride_l,
                                             long grad_stride_b, int half_records, void* ws, long ws_bytes, void* stream) {
   if (B <= 0) return SNERF_OK;
-  int ks[16], lr[16]; long g64_rows;
   if (L <= 0 || L > 16 || (C != 1 && C != 2 && C != 4 && C != 8) || grad == nullptr || inputs == nullptr || offsets == nullptr || offsets_host == nullptr ||
       grad_embeddings == nullptr || ws == nullptr || ((uintptr_t)ws & 255) || (grad_dtype != SNERF_DT_F32 && grad_dtype != SNERF_DT_F16) ||
-      (out_dtype != SNERF_DT_F32 && out_dtype != SNERF_DT_F16) || g3_plan(offsets_host, L, C, B, ks, lr, &g64_rows) != SNERF_OK)
+      (out_dtype != SNERF_DT_F32 && out_dtype != SNERF_DT_F16))
     return SNERF_ERR_ARG;
   const bool hrec = half_records != 0 && (C == 1 || C == 4);              // (C = 2 / 8: fp32 records whatever the gradient's dtype)
-  const G3Ws w = g3_ws_layout(B, C, L, g64_rows, hrec);
-  if ((long)w.total > ws_bytes) return SNERF_ERR_ARG;
-  // the scale pass reads the gradient as rows of C values: [B, L*C] contiguous (stride_b = L*C, stride_l = C) or [L, B, C] (stride_l = B*C)
   const bool point_major = grad_stride_l == C && grad_stride_b == (long)L * C, level_major = grad_stride_b == C && grad_stride_l == B * C;
   if (!point_major && !level_major) return SNERF_ERR_ARG;
+  const int gsz = grad_dtype == SNERF_DT_F16 ? 2 : 4;
+  G3Plan pl;
+  if (g3_make_plan(B, C, L, offsets_host, hrec, !level_major, gsz, ws_bytes, &pl, nullptr) != SNERF_OK) return SNERF_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   char* base = (char*)ws;
-  (void)hipMemsetAsync(base + w.counts, 0, w.starts - w.counts, s);
-  int* scale = (int*)(base + w.scale);
-  int rc = snerf_zip_bin_scale(grad, C, B * L, C, grad_dtype, scale, stream);
-  if (rc != SNERF_OK) return rc;
-  G3Args a{inputs, B, nullptr, offsets, (void*)grad, grad_stride_l, grad_stride_b, L, S, H};
-  ZipBin b{};
-  b.bshift = C == 8 ? 11 : (C == 4 ? 12 : (C == 2 ? 13 : 14));
-  b.counts = (int*)(base + w.counts); b.wg_offsets = (unsigned*)(base + w.wgo); b.starts = (const long*)(base + w.starts);
-  for (int l = 0; l < L; ++l) b.ksplit[l] = ks[l];
-  b.rec_row = (unsigned short*)(base + w.rec_row); b.rec_val = (float*)(base + w.rec_val); b.capacity = w.cap;
-  b.g64 = g64_rows > 0 ? (long long*)(base + w.g64) : nullptr; b.g64_rows = g64_rows; b.scale_exp = scale;
-  const dim3 grid((unsigned)(w.nwg * L)), blk(256);
-#define G3E(GT, CC) do { hipLaunchKernelGGL((g3_bin_emit_kernel<GT, CC, 0, false>), grid, blk, 0, s, a, b); \
-                         hipLaunchKernelGGL(g3_scan_kernel, dim3(1), dim3(1024), 0, s, b.counts, (long*)(base + w.starts), L); \
-                         if (hrec) hipLaunchKernelGGL((g3_bin_emit_kernel<GT, CC, 1, true>), grid, blk, 0, s, a, b); \
-                         else hipLaunchKernelGGL((g3_bin_emit_kernel<GT, CC, 1, false>), grid, blk, 0, s, a, b); } while (0)
-  if (grad_dtype == SNERF_DT_F16) { if (C == 4) G3E(_Float16, 4); else if (C == 1) G3E(_Float16, 1); else if (C == 2) G3E(_Float16, 2); else G3E(_Float16, 8); }
-  else { if (C == 4) G3E(float, 4); else if (C == 1) G3E(float, 1); else if (C == 2) G3E(float, 2); else G3E(float, 8); }
-#undef G3E
-  ZipEnc za{};
-  za.offsets = offsets; za.grad_table = (float*)grad_embeddings; za.L = L;
-  return out_dtype == SNERF_DT_F16 ? zb_accumulate_launch<_Float16>(za, b, C, L, hrec, s, true) : zb_accumulate_launch<float>(za, b, C, L, hrec, s, true);
+  (void)hipMemsetAsync(base + pl.o_scale, 0, pl.zero_bytes, s);
+  int* scale = (int*)(base + pl.o_scale);
+  int* counts = (int*)(base + pl.o_counts);
+  unsigned* starts = (unsigned*)(base + pl.o_starts);
+  long long* g64 = pl.g64_rows > 0 ? (long long*)(base + pl.o_g64) : nullptr;
+  const size_t esz = out_dtype == SNERF_DT_F16 ? 2 : 4;
+  if (level_major) {                                                     // the reference's own layout: max |grad| by the stream kernel
+    if (gsz == 2) hipLaunchKernelGGL(zip_bin_absmax_kernel<_Float16>, dim3(2048), dim3(256), 0, s, (const _Float16*)grad, (long)C, B * L, C, (unsigned*)(scale + 1));
+    else hipLaunchKernelGGL(zip_bin_absmax_kernel<float>, dim3(2048), dim3(256), 0, s, (const float*)grad, (long)C, B * L, C, (unsigned*)(scale + 1));
+    hipLaunchKernelGGL(zip_bin_scale_kernel, dim3(1), dim3(1), 0, s, scale, 3);
+  }
+  const int RB = L * C * gsz;
+  const int TP = RB <= 256 ? 256 : ((65536 / RB) & ~63);
+  G3W a{};
+  a.inputs = inputs; a.B = B; a.in_vec = (((uintptr_t)inputs) & 15) == 0 ? 1 : 0;
+  a.offsets = offsets; a.Sl = S; a.H = H;
+  a.wgo = (uint2*)(base + pl.o_wgo); a.bshift = pl.bshift;
+  a.rec_row = (unsigned short*)(base + pl.o_row); a.rec_val = (unsigned*)(base + pl.o_val); a.cap = pl.cap; a.scale_exp = scale;
+  for (int l = 0; l < L; ++l) {
+    if (!level_major && l % pl.lt == 0) {                                // the next group of levels, transposed (the first sweep also finds max |grad|)
+      const int nl = L - l < pl.lt ? L - l : pl.lt;
+      const dim3 tgrid((unsigned)((B + TP - 1) / TP));
+      const size_t lds = (size_t)TP * RB;
+      if (gsz == 2) hipLaunchKernelGGL(g3_transpose_kernel<_Float16>, tgrid, dim3(256), lds, s, (const _Float16*)grad, B, L * C, C, l, nl, (_Float16*)(base + pl.o_tg), l == 0 ? (unsigned*)(scale + 1) : nullptr, TP);
+      else hipLaunchKernelGGL(g3_transpose_kernel<float>, tgrid, dim3(256), lds, s, (const float*)grad, B, L * C, C, l, nl, (float*)(base + pl.o_tg), l == 0 ? (unsigned*)(scale + 1) : nullptr, TP);
+      if (l == 0) hipLaunchKernelGGL(zip_bin_scale_kernel, dim3(1), dim3(1), 0, s, scale, 3);
+    }
+    a.level = l; a.K = pl.ks[l];
+    a.grad = level_major ? (const void*)((const char*)grad + (size_t)l * B * C * gsz) : (const void*)(base + pl.o_tg + (size_t)(l % pl.lt) * B * C * gsz);
+    a.g_sb = C;
+    int* counts_l = counts + (long)l * pl.nck * ZB_NBMAX;
+    // count (all chunks of the level) -> scan
+    a.counts = counts_l; a.wgs_per_chunk = pl.wgs_per_chunk; a.wg0 = 0;
+    const dim3 cgrid((unsigned)pl.nwg_total);
+    if (pl.grlog == 4) hipLaunchKernelGGL((g3_count_kernel<G3_WT, G3_PPT, 4>), cgrid, dim3(G3_WT), 0, s, a);
+    else hipLaunchKernelGGL((g3_count_kernel<G3_WT, G3_PPT, 3>), cgrid, dim3(G3_WT), 0, s, a);
+    hipLaunchKernelGGL(g3_scan_chunks_kernel, dim3(pl.nck), dim3(1024), 0, s, counts_l, starts);
+    const bool image = pl.ks[l] > 1 || pl.nck > 1;
+    if (pl.ks[l] > 1) (void)hipMemsetAsync(g64, 0, (size_t)pl.rows[l] * C * 8, s);
+    G3A ac{};
+    ac.rec_row = a.rec_row; ac.rec_val = (const float*)a.rec_val; ac.cap = pl.cap; ac.bshift = pl.bshift; ac.K = pl.ks[l]; ac.rows_l = pl.rows[l];
+    ac.g64 = image ? g64 : nullptr; ac.out = (char*)grad_embeddings + (size_t)offsets_host[l] * C * esz; ac.scale_exp = scale;
+    const size_t lds = (size_t)(1 << pl.bshift) * C * 8;
+    for (int c = 0; c < pl.nck; ++c) {
+      a.wg0 = (unsigned)(c * pl.wgs_per_chunk);
+      a.starts = starts + (long)c * ZB_NBMAX;
+      const long nwg_c = pl.nwg_total - (long)c * pl.wgs_per_chunk < pl.wgs_per_chunk ? pl.nwg_total - (long)c * pl.wgs_per_chunk : pl.wgs_per_chunk;
+      const dim3 wgrid((unsigned)nwg_c);
+#define G3WR(GT, CC, HH) do { (void)hipFuncSetAttribute((const void*)g3_write_staged_kernel<GT, CC, HH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G3Cfg<CC, HH>::LDS); \
+                              hipLaunchKernelGGL((g3_write_staged_kernel<GT, CC, HH>), wgrid, dim3(G3_WT), (G3Cfg<CC, HH>::LDS), s, a); } while (0)
+      if (gsz == 2) {
+        if (C == 4) { if (hrec) G3WR(_Float16, 4, true); else G3WR(_Float16, 4, false); }
+        else if (C == 1) { if (hrec) G3WR(_Float16, 1, true); else G3WR(_Float16, 1, false); }
+        else if (C == 2) G3WR(_Float16, 2, false); else G3WR(_Float16, 8, false);
+      } else {
+        if (C == 4) { if (hrec) G3WR(float, 4, true); else G3WR(float, 4, false); }
+        else if (C == 1) { if (hrec) G3WR(float, 1, true); else G3WR(float, 1, false); }
+        else if (C == 2) G3WR(float, 2, false); else G3WR(float, 8, false);
+      }
+#undef G3WR
+      ac.counts = counts_l + (long)c * ZB_NBMAX; ac.starts = a.starts; ac.first = c == 0; ac.last = c == pl.nck - 1;
+#define G3AC(CC, HH, GT) do { (void)hipFuncSetAttribute((const void*)g3_accumulate_kernel<CC, HH, GT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                              hipLaunchKernelGGL((g3_accumulate_kernel<CC, HH, GT>), dim3(ZB_NBMAX), dim3(1024), lds, s, ac); } while (0)
+      if (out_dtype == SNERF_DT_F16) {
+        if (C == 4) { if (hrec) G3AC(4, true, _Float16); else G3AC(4, false, _Float16); }
+        else if (C == 1) { if (hrec) G3AC(1, true, _Float16); else G3AC(1, false, _Float16); }
+        else if (C == 2) G3AC(2, false, _Float16); else G3AC(8, false, _Float16);
+      } else {
+        if (C == 4) { if (hrec) G3AC(4, true, float); else G3AC(4, false, float); }
+        else if (C == 1) { if (hrec) G3AC(1, true, float); else G3AC(1, false, float); }
+        else if (C == 2) G3AC(2, false, float); else G3AC(8, false, float);
+      }
+#undef G3AC
+    }
+    if (pl.ks[l] > 1) {
+      if (out_dtype == SNERF_DT_F16) hipLaunchKernelGGL(zip_bin_finish_kernel<_Float16>, dim3(256), dim3(256), 0, s, (const long long*)g64, pl.rows[l] * C, (_Float16*)ac.out, scale);
+      else hipLaunchKernelGGL(zip_bin_finish_kernel<float>, dim3(256), dim3(256), 0, s, (const long long*)g64, pl.rows[l] * C, (float*)ac.out, scale);
+    }
+  }
+  if (out_dtype == SNERF_DT_F16) hipLaunchKernelGGL(zip_bin_overflow_mark_kernel<_Float16>, dim3(1), dim3(1), 0, s, (_Float16*)grad_embeddings, scale);
+  else hipLaunchKernelGGL(zip_bin_overflow_mark_kernel<float>, dim3(1), dim3(1), 0, s, (float*)grad_embeddings, scale);
+  return snerf_check_launch();
 }
 
 // ------------------------------------------------------------------------------------------------------------------

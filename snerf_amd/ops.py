@@ -773,14 +773,13 @@ def grid_level_layout(input_dim, num_levels, per_level_scale, base_resolution, l
 _GRID_DT = {torch.float32: F32, torch.float16: F16, torch.float64: F64}    # the reference's three instantiations (gridencoder.cu:469)
 
 
-def grid_encode_fwd(inputs, embeddings, offsets, L, S, H, gridtype, align_corners, interp, want_dy_dx=False, level_major=False):
+def grid_encode_fwd(inputs, embeddings, offsets, L, S, H, gridtype, align_corners, interp, want_dy_dx=False, level_major=False, reference_form=None):
     """inputs fp32 [B,D] in [0,1]; embeddings [sO,C] fp32/fp16 -> outputs [B, L*C] (or [L,B,C] if level_major) in the
-    table dtype (+ dy_dx [B, L*D*C])."""
+    table dtype (+ dy_dx [B, L*D*C]).  reference_form (default: not GRID_FAST): kernel_grid's one-thread-per-(point, level) form for every
+    instantiation (snerf_grid_encode_fwd_ref) -- the A/B partner of the measurement legs; same bits."""
     _f32c(inputs)
     assert embeddings.is_cuda and embeddings.is_contiguous() and embeddings.dtype in _GRID_DT
     assert offsets.dtype == torch.int32 and offsets.is_cuda
-    if _grid_fast_sent != GRID_FAST:
-        grid_set_fast_path(GRID_FAST)
     B, D = inputs.shape
     C = embeddings.shape[1]
     dt = _GRID_DT[embeddings.dtype]
@@ -789,7 +788,8 @@ def grid_encode_fwd(inputs, embeddings, offsets, L, S, H, gridtype, align_corner
     else:
         out = torch.empty(B, L * C, dtype=embeddings.dtype, device=inputs.device); sl, sb = C, L * C
     dy_dx = torch.empty(B, L * D * C, dtype=embeddings.dtype, device=inputs.device) if want_dy_dx else None
-    _lib.call("snerf_grid_encode_fwd", _p(inputs), _p(embeddings), _p(offsets), _p(out), B, D, C, L, float(S), int(H), _p(dy_dx),
+    ref = (not GRID_FAST) if reference_form is None else bool(reference_form)
+    _lib.call("snerf_grid_encode_fwd_ref" if ref else "snerf_grid_encode_fwd", _p(inputs), _p(embeddings), _p(offsets), _p(out), B, D, C, L, float(S), int(H), _p(dy_dx),
               int(gridtype), 1 if align_corners else 0, int(interp), dt, sl, sb, _stream())
     return out, dy_dx
 
@@ -816,16 +816,16 @@ def grid_fast_ok(D, C, gridtype, align_corners, interp, dtype, want_dy_dx=False)
             and dtype in (torch.float32, torch.float16))
 
 
-GRID_FAST = _os.environ.get("SNERF_GRID_FAST", "1") != "0"          # (A/B switch of the grid_encoder measurement leg and the parity tests)
-_grid_fast_sent = None
+GRID_FAST = _os.environ.get("SNERF_GRID_FAST", "1") != "0"          # (python-side default of the A/B choice; the library itself holds no switch)
 
 
 def grid_set_fast_path(on: bool):
-    """flip the A/B switch at run time (bench.py's grid_encoder leg times both forms in one process)"""
-    global GRID_FAST, _grid_fast_sent
+    """default form of the stand-alone encoder for callers that do not say (bench.py's grid_encoder leg times both in one process):
+    picks the ENTRY POINT grid_encode_fwd calls and whether GridEncoder.backward takes the binned table gradient.  Returns the previous value."""
+    global GRID_FAST
+    prev = GRID_FAST
     GRID_FAST = bool(on)
-    _lib.call("snerf_grid_set_fast_path", int(on))          # (2 / 4 / 8: probe values, see csrc/grid.hip)
-    _grid_fast_sent = GRID_FAST
+    return prev
 
 
 def grid_host_offsets(offsets):
@@ -844,10 +844,15 @@ def grid_host_offsets(offsets):
     return h
 
 
-def grid_encode_bwd_binned(grad, inputs, offsets, C, L, S, H, out_dtype=torch.float32, half_records=None, level_major=False, offsets_host=None):
+GRID_BWD_WS_BYTES = int(_os.environ.get("SNERF_GRID_BWD_WS", "0"))        # workspace of the binned table gradient; 0: the library's recommendation (<= 1 GiB)
+
+
+def grid_encode_bwd_binned(grad, inputs, offsets, C, L, S, H, out_dtype=torch.float32, half_records=None, level_major=False, offsets_host=None, ws_bytes=None):
     """Table gradient of the stand-alone GridEncoder without atomics (snerf_grid_encode_bwd_binned; D = 3, hash, linear, C in {1, 2, 4, 8}):
     grad [B, L*C] (or [L,B,C]) fp32 / fp16 -> grad_embeddings [rows, C] in `out_dtype`, bit-reproducible.  `half_records` (default:
-    follows the gradient's dtype): contributions travel as fp16 -- the reference adds __half2 atomics into a half table's gradient."""
+    follows the gradient's dtype): contributions travel as fp16 -- the reference adds __half2 atomics into a half table's gradient.
+    `ws_bytes`: size of the workspace the call may use (default: snerf_grid_encode_bwd_binned_ws_bytes, at most 1 GiB at any B); the
+    call chunks the points to fit it."""
     _f32c(inputs)
     assert grad.is_contiguous() and grad.dtype in (torch.float32, torch.float16) and out_dtype in (torch.float32, torch.float16) and C in (1, 2, 4, 8)
     B = inputs.shape[0]
@@ -860,11 +865,27 @@ def grid_encode_bwd_binned(grad, inputs, offsets, C, L, S, H, out_dtype=torch.fl
     nb = _lib.query("snerf_grid_encode_bwd_binned_ws_bytes", B, C, L, oh.ctypes.data, 1 if half_records else 0)
     if nb < 0:
         raise ValueError("grid_encode_bwd_binned: level layout outside the binned kernels' range (more than 1024 row ranges per level)")
-    ws = _zb_workspace(inputs.device, "g3ws", int(nb), torch.uint8)
+    want = int(ws_bytes if ws_bytes is not None else (GRID_BWD_WS_BYTES or nb))
+    ws = _zb_workspace(inputs.device, "g3ws", (want + 255) // 256 * 256, torch.uint8)
     sl, sb = (B * C, C) if level_major else (C, L * C)
     _lib.call("snerf_grid_encode_bwd_binned", _p(grad), _p(inputs), _p(offsets), oh.ctypes.data, _p(g_emb), B, C, L, float(S), int(H),
-              _GRID_DT[grad.dtype], _GRID_DT[out_dtype], sl, sb, 1 if half_records else 0, _p(ws), int(nb), _stream())
+              _GRID_DT[grad.dtype], _GRID_DT[out_dtype], sl, sb, 1 if half_records else 0, _p(ws), want, _stream())
     return g_emb
+
+
+def grid_encode_bwd_binned_plan(B, C, L, offsets_host, half_records, grad_dtype=torch.float16, level_major=False, ws_bytes=None):
+    """what snerf_grid_encode_bwd_binned would run on a workspace of ws_bytes (default: the recommended size): dict(chunks, chunk_points,
+    levels_per_transposed_group, launches, chunk_record_capacity, bytes_used, ws_bytes)"""
+    import ctypes
+    import numpy as np
+    oh = np.ascontiguousarray(np.asarray(offsets_host, dtype=np.int32))
+    if ws_bytes is None:
+        ws_bytes = _lib.query("snerf_grid_encode_bwd_binned_ws_bytes", B, C, L, oh.ctypes.data, 1 if half_records else 0)
+    out = (ctypes.c_long * 6)()
+    _lib.call("snerf_grid_encode_bwd_binned_plan", B, C, L, oh.ctypes.data, 1 if half_records else 0, _GRID_DT[grad_dtype], 1 if level_major else 0,
+              int(ws_bytes), ctypes.addressof(out))
+    return dict(chunks=out[0], chunk_points=out[1], levels_per_transposed_group=out[2], launches=out[3], chunk_record_capacity=out[4], bytes_used=out[5],
+                ws_bytes=int(ws_bytes))
 
 
 def grid_tv_grad(inputs, embeddings, grad, offsets, weight, L, S, H, gridtype, align_corners):

@@ -69,16 +69,28 @@ def test_no_vector_alu_instruction_hides_in_inline_asm():
 
 
 def test_grid_binned_backward_workspace_query_and_its_limits():
-    """snerf_grid_encode_bwd_binned_ws_bytes is host-only: a positive size for the layouts zipnerf builds, -1 for what the binned kernels do
-    not cover (C not in {1, 2, 4, 8}, a level with more than 1024 row ranges) -- GridEncoder.backward then falls back to the atomic scatter."""
+    """snerf_grid_encode_bwd_binned_ws_bytes / _plan are host-only: the recommended workspace is BOUNDED (at most 1 GiB at the bench's 14.7 M
+    points, where the round-5 form needed 11-30 GB: at most 1 GB), smaller workspaces plan more chunks, -1 for what the binned kernels do not cover
+    (C not in {1, 2, 4, 8}, a level with more than 1024 row ranges) -- GridEncoder.backward then falls back to the atomic scatter."""
     if not os.path.exists(_lib.LIB_PATH):
         pytest.skip("library not built")
     import numpy as np
+    import torch
     from snerf_amd import ops
     q = lambda B, C, off, half: _lib.query("snerf_grid_encode_bwd_binned_ws_bytes", B, C, len(off) - 1, np.ascontiguousarray(np.asarray(off, dtype=np.int32)).ctypes.data, half)
     off, _ = ops.grid_level_layout(3, 10, ops.grid_per_level_scale(16, 8192, 10), 16, 21)
-    full = q(65536 * 32 * 7, 4, off, 1)
-    assert 10e9 < full < 30e9 and q(65536 * 32 * 7, 4, off, 0) > full            # fp32 records need the row plane too
+    B = 65536 * 32 * 7
+    full = q(B, 4, off, 1)
+    assert 0.5e9 < full <= 1e9 and q(B, 4, off, 0) <= 1e9
+    plan = ops.grid_encode_bwd_binned_plan(B, 4, 10, off, True, torch.float16)
+    assert plan["bytes_used"] <= full and plan["chunks"] >= 2 and 1 <= plan["levels_per_transposed_group"] <= 10 and plan["launches"] < 400
+    assert plan["chunk_record_capacity"] >= 8 * plan["chunk_points"]
+    lm = ops.grid_encode_bwd_binned_plan(B, 4, 10, off, True, torch.float16, level_major=True)
+    assert lm["levels_per_transposed_group"] == 0 and lm["chunks"] <= plan["chunks"]          # the reference's layout needs no transposed copy
+    small = ops.grid_encode_bwd_binned_plan(B, 4, 10, off, True, torch.float16, ws_bytes=300 << 20)
+    assert small["bytes_used"] <= (300 << 20) and small["chunks"] > plan["chunks"]
+    few = ops.grid_encode_bwd_binned_plan(20000, 4, 10, off, True, torch.float16)
+    assert few["chunks"] == 1 and few["levels_per_transposed_group"] == 10 and few["bytes_used"] < (64 << 20)
     assert q(1000, 1, off, 1) > 0 and q(0, 4, off, 1) == 0
     assert q(1000, 2, off, 0) > 0 and q(1000, 8, off, 1) > 0 and q(1000, 3, off, 0) == -1
     big = [0, 8, 8 + (1 << 23)]                                                   # 2^23 rows at C = 4: 2048 row ranges of 4096

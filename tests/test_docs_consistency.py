@@ -19,9 +19,9 @@ def test_entry_point_count_matches_the_header():
 def test_cited_profiles_exist():
     have = set(os.listdir(os.path.join(REPO, "profiles")))
     for doc in ("DESIGN.md", "profiles/README.md", "README.md", "bench.py"):
-        for name in re.findall(r"profiles/(r[1-5]_[a-z]+_[A-Za-z0-9_.]+?\.(?:txt|log))", read(*doc.split("/"))):
+        for name in re.findall(r"profiles/(r[1-6]_[a-z]+_[A-Za-z0-9_.]+?\.(?:txt|log))", read(*doc.split("/"))):
             assert name in have, (doc, name)
-    for name in re.findall(r"`(r[1-5]_[a-z]+_[A-Za-z0-9_.]+?\.(?:txt|log))`", read("profiles", "README.md")):
+    for name in re.findall(r"`(r[1-6]_[a-z]+_[A-Za-z0-9_.]+?\.(?:txt|log))`", read("profiles", "README.md")):
         assert name in have, name
 
 

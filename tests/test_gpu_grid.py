@@ -196,19 +196,14 @@ def test_grid_fast_forward_is_the_slow_kernel_bit_for_bit(C, half):
     E = torch.from_numpy((rng.standard_normal((int(off[-1]), C)) * 0.5).astype(np.float32)).cuda()
     E = E.half() if half else E
     offt = torch.from_numpy(off).cuda()
-    try:
-        for x in (_clumped_points(20003, 1), np.random.default_rng(2).random((4099, 3)).astype(np.float32)):
-            xt = torch.from_numpy(x).cuda()
-            ops.grid_set_fast_path(False)
-            slow, _ = ops.grid_encode_fwd(xt, E, offt, L, S, H, 0, False, 0)
-            slow_lm, _ = ops.grid_encode_fwd(xt, E, offt, L, S, H, 0, False, 0, level_major=True)
-            ops.grid_set_fast_path(True)
-            fast, _ = ops.grid_encode_fwd(xt, E, offt, L, S, H, 0, False, 0)
-            fast_lm, _ = ops.grid_encode_fwd(xt, E, offt, L, S, H, 0, False, 0, level_major=True)
-            assert torch.equal(fast, slow) and torch.equal(fast_lm, slow_lm)
-            assert float(fast.float().abs().max()) > 0
-    finally:
-        ops.grid_set_fast_path(True)
+    for x in (_clumped_points(20003, 1), np.random.default_rng(2).random((4099, 3)).astype(np.float32)):
+        xt = torch.from_numpy(x).cuda()
+        slow, _ = ops.grid_encode_fwd(xt, E, offt, L, S, H, 0, False, 0, reference_form=True)          # snerf_grid_encode_fwd_ref
+        slow_lm, _ = ops.grid_encode_fwd(xt, E, offt, L, S, H, 0, False, 0, level_major=True, reference_form=True)
+        fast, _ = ops.grid_encode_fwd(xt, E, offt, L, S, H, 0, False, 0, reference_form=False)
+        fast_lm, _ = ops.grid_encode_fwd(xt, E, offt, L, S, H, 0, False, 0, level_major=True, reference_form=False)
+        assert torch.equal(fast, slow) and torch.equal(fast_lm, slow_lm)
+        assert float(fast.float().abs().max()) > 0
 
 
 @pytest.mark.parametrize("C,B", [(4, 20003), (1, 20003), (4, 300007), (2, 20003), (8, 20003), (2, 300007)])
@@ -247,6 +242,91 @@ def test_grid_binned_backward_vs_oracle_atomic_kernel_and_itself(C, B):
     out, _ = ops.grid_encode_fwd(xt, Et, offt, L, S, H, 0, False, 0)
     lhs, rhs = float((out.double() * Gt.double()).sum()), float((Et.double() * g_bin.double()).sum())
     assert abs(lhs - rhs) < 1e-3 * max(1.0, abs(lhs))
+
+
+@pytest.mark.parametrize("C,half", [(4, True), (4, False), (1, True), (1, False), (2, False), (8, False)])
+def test_grid_binned_backward_chunked_is_the_single_pass_bit_for_bit(C, half):
+    """The workspace bounds the chunk size, not the result: with a workspace that forces several chunks per level (the level's int64
+    image carries the partial sums) and one transposed level at a time, the gradient is bit-identical to the one-chunk run, in both
+    gradient layouts; the plan query reports the chunking."""
+    from snerf_amd import ops
+    L, H, B = 6, 8, 70001
+    off, res, s = og.level_layout(3, L, C, 2.0, H, 14, 512, False)
+    S = float(np.log2(s))
+    x = _clumped_points(B, 5)
+    rng = np.random.default_rng(6)
+    G = (rng.standard_normal((B, L * C)) * 0.3).astype(np.float32)
+    xt, offt = torch.from_numpy(x).cuda(), torch.from_numpy(off).cuda()
+    Gt = torch.from_numpy(G).cuda()
+    Gt = Gt.half() if half else Gt
+    one = ops.grid_encode_bwd_binned(Gt, xt, offt, C, L, S, H)
+    p1 = ops.grid_encode_bwd_binned_plan(B, C, L, off, half, Gt.dtype)
+    assert p1["chunks"] == 1 and p1["levels_per_transposed_group"] == L and p1["bytes_used"] <= p1["ws_bytes"]
+    G_lm = Gt.reshape(B, L, C).permute(1, 0, 2).contiguous()
+    seen = set()
+    for frac in (0.7, 0.5, 0.35):
+        ws = int(p1["bytes_used"] * frac)
+        pk = ops.grid_encode_bwd_binned_plan(B, C, L, off, half, Gt.dtype, ws_bytes=ws)
+        assert pk["bytes_used"] <= ws
+        seen.add((pk["chunks"], pk["levels_per_transposed_group"]))
+        assert torch.equal(ops.grid_encode_bwd_binned(Gt, xt, offt, C, L, S, H, ws_bytes=ws), one), pk
+        assert torch.equal(ops.grid_encode_bwd_binned(G_lm, xt, offt, C, L, S, H, level_major=True, ws_bytes=ws), one), pk
+    assert any(c > 1 for c, _ in seen) and any(lt < L for _, lt in seen), seen
+    with pytest.raises(Exception):
+        ops.grid_encode_bwd_binned(Gt, xt, offt, C, L, S, H, ws_bytes=4096)       # below the smallest feasible layout: refused, not overrun
+
+
+@pytest.mark.parametrize("C,half", [(4, True), (4, False), (1, False), (2, False), (8, False)])
+def test_grid_binned_backward_many_bins_several_stage_windows(C, half):
+    """Hashed levels of 2^19 rows (128-1024 row ranges): a workgroup's 32 768 records spread over hundreds of bins and pass through the
+    LDS stage in several windows (the bin that straddles a window boundary, the empty head of the next window), next to dense levels
+    that are written directly -- against the atomic scatter (fp32 atomics) and run to run."""
+    from snerf_amd import ops
+    L, H, B = 5, 16, 40009
+    off, res, s = og.level_layout(3, L, C, 2.6, H, 19, None, False)
+    S = float(np.log2(s))
+    rng = np.random.default_rng(21)
+    x = np.concatenate([rng.random((B - 9000, 3)).astype(np.float32), _clumped_points(9000, 2)])      # scattered points: no merging on the fine levels
+    G = (rng.standard_normal((B, L * C)) * 0.3).astype(np.float32)
+    xt, offt = torch.from_numpy(x).cuda(), torch.from_numpy(off).cuda()
+    Gt = torch.from_numpy(G).cuda()
+    Gt = Gt.half() if half else Gt
+    E = torch.zeros(int(off[-1]), C, device="cuda")
+    g_at, _ = ops.grid_encode_bwd(Gt.float(), xt, E, offt, L, S, H, 0, False, 0)
+    g_bin = ops.grid_encode_bwd_binned(Gt, xt, offt, C, L, S, H)
+    scale = float(g_at.abs().max())
+    tol = 2e-3 if half else 2e-5
+    assert float((g_bin - g_at).abs().max()) <= tol * scale, float((g_bin - g_at).abs().max()) / scale
+    assert torch.equal(ops.grid_encode_bwd_binned(Gt, xt, offt, C, L, S, H), g_bin), "not bit-reproducible"
+
+
+@pytest.mark.parametrize("C", [4, 1])
+def test_grid_binned_backward_merged_runs_do_not_saturate(C):
+    """Eight consecutive identical points with identical same-sign gradients merge into ONE record of 8 x w x grad (the reference's
+    callers pass an interval's multisamples one after the other, and zipnerf mean-pools them: identical gradients): the record must not
+    clamp at the half range / the fixed-point limit -- the scale keeps 3 head bits for the merge.  Against the atomic scatter, half and
+    fp32 gradients, with the largest entries among the merged ones."""
+    from snerf_amd import ops
+    L, H = 4, 8
+    off, res, s = og.level_layout(3, L, C, 2.0, H, 14, 512, False)
+    S = float(np.log2(s))
+    rng = np.random.default_rng(8)
+    base = rng.random((512, 3)).astype(np.float32) * 0.9 + 0.05
+    x = np.repeat(base, 8, axis=0)                                       # 8 identical points in a row: one cell on every level
+    g1 = np.abs(rng.standard_normal((512, L * C))).astype(np.float32) + 0.5
+    g1[:4] *= 40.0                                                        # the launch's max |grad| sits in merged runs
+    G = np.repeat(g1, 8, axis=0)
+    xt, offt = torch.from_numpy(x).cuda(), torch.from_numpy(off).cuda()
+    E = torch.zeros(int(off[-1]), C, device="cuda")
+    for half in (False, True):
+        Gt = torch.from_numpy(G).cuda()
+        Gt = Gt.half() if half else Gt
+        g_at, _ = ops.grid_encode_bwd(Gt.float(), xt, E, offt, L, S, H, 0, False, 0)      # fp32 atomics on the same (rounded) gradients
+        g_bin = ops.grid_encode_bwd_binned(Gt, xt, offt, C, L, S, H)
+        scale = float(g_at.abs().max())
+        assert scale > 8 * 20.0
+        tol = 2e-3 if half else 2e-5                                     # half records: one rounding to 11 bits per contribution
+        assert float((g_bin - g_at).abs().max()) <= tol * scale, (half, float((g_bin - g_at).abs().max()), scale)
 
 
 def test_gridencoder_module_takes_the_fast_path_without_input_gradients():
