@@ -773,6 +773,42 @@ def shipped_shape_leg(device, n_rays=4096, steps=5):
             "ms_per_step": round(dt * 1e3, 3), "rays_per_s": round(n_rays / dt, 1), "whole_step_tflops": round(3 * fwd * n_rays / dt / 1e12, 1)}
 
 
+PROSE_KEYS = ("what", "note", "frame_what", "frame_note", "includes", "traffic_source", "mode", "scene", "window", "kernel", "parallelism", "collective", "step")
+LAST_LEGS = ("path_b_ert", "path_b", "grid_encoder", "path_c")          # the driver keeps the line's 8 KB tail: the other configs' numbers go last
+
+
+def compact_line(out, limit=7900):
+    """The one JSON line without its prose (the strings say what each leg ran: profiles/README.md holds them, keyed by leg; --verbose-json prints them
+    inline), floats at 6 significant digits, the legs of BASELINE configs 4-5 / path B last.  Contract fields (metric .. config.workload, roofline,
+    cpu_baseline{value, unit, cores, kind, sample}) stay."""
+    def strip(v, top=False):
+        if isinstance(v, dict):
+            o = {}
+            for k, x in v.items():
+                if k in PROSE_KEYS or (k == "kind" and isinstance(x, str) and len(x) > 16) or (k == "workload" and not top):
+                    continue
+                if k == "sample" and isinstance(x, str):
+                    x = x[:72]
+                o[k] = strip(x)
+            return o
+        if isinstance(v, list):
+            return [strip(x) for x in v]
+        if isinstance(v, float) and v == v and abs(v) != float("inf"):
+            return float(f"{v:.6g}")
+        return v
+    c = {k: (strip(v) if k != "config" else {kk: (vv if kk == "workload" else strip(vv)) for kk, vv in v.items() if kk not in PROSE_KEYS}) for k, v in out.items()}
+    c["roofline"] = dict(c["roofline"], kernel=out["roofline"]["kernel"].split(" ")[0])
+    ordered = {k: v for k, v in c.items() if k not in LAST_LEGS}
+    for k in LAST_LEGS:
+        if k in c:
+            ordered[k] = c[k]
+    n = len(json.dumps(ordered))
+    ordered_final = dict(ordered)
+    if n > limit:                                          # (never cut a number silently: say so in the line)
+        ordered_final = {"line_bytes_over_limit": n, **ordered}
+    return ordered_final
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -788,7 +824,11 @@ def main():
     ap.add_argument("--no-eager", action="store_true", help="skip the PyTorch-ROCm eager baseline (3 steps each of fp32 and bf16 autocast on this GPU)")
     ap.add_argument("--no-f32", action="store_true", help="skip the fp32-parity-mode leg (3 train steps with exact-fp32 MFMA)")
     ap.add_argument("--eager", action="store_true", help="(kept for compatibility: the eager baseline is on by default)")
-    ap.add_argument("--no-ert-scene", action="store_true", help="skip the early-ray-termination leg (200 fit steps on an analytic scene + two frames)")
+    ap.add_argument("--no-ert-scene", action="store_true", help="skip the path-B early-termination leg and the fitted-weights precision read-out (fit steps on an analytic scene)")
+    ap.add_argument("--ert-scene", action="store_true", help="also run the path-A early-termination leg (retired from the default line in round 6: 0.96x, "
+                                                             "the fine samples of path A sit ON the surface; profiles/README.md)")
+    ap.add_argument("--verbose-json", action="store_true", help="print the line with every leg's prose (what / note / kind / traffic_source strings); the default "
+                                                               "line is compact (< 8 KB: the driver keeps an 8 KB tail) -- the prose is in profiles/README.md, keyed by leg")
     ap.add_argument("--no-paths", action="store_true", help="skip the path-C (zipnerf, 65 536 rays) and path-B (classic render_rays, 32 768 rays) legs")
     ap.add_argument("--no-dropin", action="store_true", help="skip the drop-in-autograd and pose-refinement legs (5 steps each)")
     ap.add_argument("--cpu-rays", type=int, default=512, help="rays of the bounded host-CPU baseline sample (about 15 s on the GPU box)")
@@ -1036,15 +1076,19 @@ def main():
     # a fresh model fitted for 200 steps to an analytic street scene (tools/ert_scene.py), its 1600 x 900 frame rendered plain and with
     # the front-to-back termination inside north_star's tolerance (eps_t = 1e-4: an exact bound on acc / rgb).  A labelled extra: the
     # headline frame above stays un-skipped.
-    if rank == 0 and world == 1 and not args.no_ert_scene and not args.no_frame and args.compute == "bf16":
+    if rank == 0 and world == 1 and not args.no_ert_scene and args.compute == "bf16":
         sys.path.insert(0, os.path.join(REPO, "tools"))
         import ert_scene
         torch.cuda.empty_cache()
         t0 = time.perf_counter()
-        out["ert_scene"] = ert_scene.fit_and_render(build_model("bf16", device, seed=1), steps=120, eps=(1e-4, 0.0), group=16, rows=96, row0=400,
-                                                    build=lambda mode: build_model(mode, device, seed=1))
-        out["fitted_weights_precision"] = out["ert_scene"].pop("precision_on_fitted_weights")
-        out["ert_scene"]["leg_wall_s"] = round(time.perf_counter() - t0, 1)
+        if args.ert_scene and not args.no_frame:
+            out["ert_scene"] = ert_scene.fit_and_render(build_model("bf16", device, seed=1), steps=120, eps=(1e-4, 0.0), group=16, rows=96, row0=400,
+                                                        build=lambda mode: build_model(mode, device, seed=1))
+            out["fitted_weights_precision"] = out["ert_scene"].pop("precision_on_fitted_weights")
+            out["ert_scene"]["leg_wall_s"] = round(time.perf_counter() - t0, 1)
+        else:       # the precision of every compute mode on FITTED weights (120 fit steps), without the two ERT frames
+            out["fitted_weights_precision"] = ert_scene.fit_and_precision(build_model("bf16", device, seed=1), steps=120, build=lambda mode: build_model(mode, device, seed=1))
+            out["fitted_weights_precision"]["leg_wall_s"] = round(time.perf_counter() - t0, 1)
         torch.cuda.empty_cache()
 
     # ---- the two routes a user of the reference takes besides MipTrainer.step: the unmodified train.py loop (autograd + torch losses +
@@ -1159,7 +1203,7 @@ def main():
             out["eager_baseline"]["frame_note"] = ("the build's measured 1600 x 900 frame rate (render_image, ray generation and gathers included) over the eager forward's "
                                                    "rate on a 4096-ray chunk (eval.py's chunk size; a frame is 352 such chunks)")
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out if args.verbose_json else compact_line(out)), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -120,3 +120,49 @@ def synthetic_rays(n: int, seed: int = 0, H: int = 900, W: int = 1600, focal: fl
         "origins": t(o), "directions": t(d), "viewdirs": t(viewdirs), "radii": t(radii),
         "lossmult": t(ones), "near": t(ones * near), "far": t(ones * far), "app": t(ones * 0.0),
     }
+
+
+# ---- golden fixtures: one writer for every oracle/gen_golden*.py, with a verification mode ---------------------------------------------
+_GOLDEN_BAD = []
+
+
+def golden_equal(a: np.ndarray, b: np.ndarray) -> bool:
+    """bit-for-bit equality of a stored and a regenerated array (same dtype and shape; NaNs equal; string arrays compared with ==)"""
+    a, b = np.asarray(a), np.asarray(b)
+    if a.shape != b.shape or a.dtype != b.dtype:
+        return False
+    if a.dtype.kind in "fc":
+        return bool(np.array_equal(a, b, equal_nan=True))
+    return bool(np.array_equal(a, b))
+
+
+def save_golden(path: str, **arrays) -> None:
+    """np.savez_compressed(path, **arrays) -- or, when the generator runs with `--check`, regenerate-and-compare: the arrays are checked
+    against the committed file (keys, dtypes, shapes, every bit) and NOTHING is written; the process prints `check: OK` (exit 0) or the
+    mismatching keys (exit 1) when it ends.  tests/test_oracle_golden.py runs every generator this way when /root/reference exists."""
+    import atexit
+    import os
+    import sys
+    arrays = {k: np.asarray(v) for k, v in arrays.items()}
+    if "--check" not in sys.argv:
+        np.savez_compressed(path, **arrays)
+        return
+    if not _GOLDEN_BAD and not getattr(save_golden, "_hooked", False):
+        def report():
+            bad = [b for b in _GOLDEN_BAD if b is not None]
+            print("check:", "OK" if not bad else f"{len(bad)} mismatches: {bad[:8]}", flush=True)
+            if bad:
+                os._exit(1)
+        atexit.register(report)
+        save_golden._hooked = True
+    _GOLDEN_BAD.append(None)
+    name = os.path.basename(path)
+    if not os.path.exists(path):
+        _GOLDEN_BAD.append(f"{name}: missing")
+        return
+    old = np.load(path, allow_pickle=False)
+    if set(old.files) != set(arrays):
+        _GOLDEN_BAD.append(f"{name}: keys differ ({sorted(set(old.files) ^ set(arrays))[:4]})")
+    for k, v in arrays.items():
+        if k in old.files and not golden_equal(old[k], v):
+            _GOLDEN_BAD.append(f"{name}:{k}")

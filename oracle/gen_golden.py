@@ -269,7 +269,7 @@ def main():
             for k, v in d.items():
                 if v.dtype.kind in "US":
                     continue
-                if not np.array_equal(old[k], v, equal_nan=True):
+                if not common.golden_equal(old[k], v):
                     print("MISMATCH", name, k, float(np.nanmax(np.abs(old[k].astype(np.float64) - v))))
                     bad += 1
         else:

@@ -125,7 +125,7 @@ def main():
         if args.check:
             old = np.load(path, allow_pickle=False)
             for k, v in d.items():
-                if not np.array_equal(old[k], v, equal_nan=True):
+                if not common.golden_equal(old[k], v):
                     print("MISMATCH", name, k)
                     bad += 1
         else:

@@ -12,6 +12,9 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+from oracle import common as _oracle_common  # noqa: E402  (save_golden: writes the fixture, or compares under --check)
 OUT = os.path.join(REPO, "tests", "golden")
 REF = "/root/reference/s-nerf"
 
@@ -53,7 +56,7 @@ def main():
     for k in rays._fields:
         out["sel_" + k] = getattr(rays, k).numpy()
         out["full_" + k] = getattr(full, k).reshape(H * W, -1).numpy()
-    np.savez_compressed(os.path.join(OUT, "g12_rays.npz"), **out)
+    _oracle_common.save_golden(os.path.join(OUT, "g12_rays.npz"), **out)
     # ---- G13: loss tail on seeded renderer outputs (shapes of the shipped config: 128 + 127 intervals, shrunk ray count)
     N, Sc, Pf = 96, 128, 128
     def fence(n, P):
@@ -79,7 +82,7 @@ def main():
     dl = (dl * conf[mask]).mean()
     g_d1, g_d0 = torch.autograd.grad(dl, [d1, d0])
     n = lambda t: t.detach().numpy()
-    np.savez_compressed(os.path.join(OUT, "g13_losses.npz"), s_c=n(s_c), s_f=n(s_f), w_c=n(w_c), w_f=n(w_f), proposal_loss=n(pl), g_wc=n(g_wc),
+    _oracle_common.save_golden(os.path.join(OUT, "g13_losses.npz"), s_c=n(s_c), s_f=n(s_f), w_c=n(w_c), w_f=n(w_f), proposal_loss=n(pl), g_wc=n(g_wc),
                         rgb=n(rgb), tgt=n(tgt), rgb_loss=n(rl), g_rgb=n(g_rgb), d1=n(d1), d0=n(d0), td=n(td), conf=n(conf), depth_loss=n(dl),
                         g_d1=n(g_d1), g_d0=n(g_d0), proposal_lambda=np.float32(0.05), coarse_depth_mult=np.float32(0.2))
     print("wrote g12_rays.npz, g13_losses.npz")

@@ -18,6 +18,9 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+from oracle import common as _oracle_common  # noqa: E402  (save_golden: writes the fixture, or compares under --check)
 OUT = os.path.join(REPO, "tests", "golden")
 REF = "/root/reference/s-nerfpp/stage1_code"
 
@@ -102,7 +105,7 @@ def main():
             out.update({f"paste_{cat}_im": r[0], f"paste_{cat}_depth": r[1], f"paste_{cat}_semantic": r[2], f"paste_{cat}_mask": r[3],
                         f"paste_{cat}_occlusion": np.float64(r[4])})
     out.update(bg_im=bg_im, fg_im=fg_im, depth_u16=depth_u16, semantic=sem, fg_depth=fg_depth)
-    np.savez_compressed(os.path.join(OUT, "g18_foreground.npz"), **out)
+    _oracle_common.save_golden(os.path.join(OUT, "g18_foreground.npz"), **out)
     print("wrote g18_foreground.npz", {k: float(out[k]) for k in out if k.endswith("occlusion")})
 
 

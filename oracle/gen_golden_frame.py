@@ -12,6 +12,9 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+from oracle import common as _oracle_common  # noqa: E402  (save_golden: writes the fixture, or compares under --check)
 OUT = os.path.join(REPO, "tests", "golden")
 sys.path.insert(0, REPO)
 
@@ -53,7 +56,7 @@ def main():
         Image.fromarray(labels.astype(np.uint8)).save(p("semantic.png"))
         Image.fromarray(cmap[labels].astype(np.uint8)).save(p("paint.png"))
         dec = {k: np.array(Image.open(p(k + ".png"))) for k in ("rgb", "depth", "semantic", "paint")}
-    np.savez_compressed(os.path.join(OUT, "g17_frame_writer.npz"), rgb=rgb, depth=depth, semantic=sem, scale_factor=np.float64(scale_factor),
+    _oracle_common.save_golden(os.path.join(OUT, "g17_frame_writer.npz"), rgb=rgb, depth=depth, semantic=sem, scale_factor=np.float64(scale_factor),
                         color_map=cmap.astype(np.uint8), png_rgb=dec["rgb"], png_depth=dec["depth"].astype(np.uint16), png_semantic=dec["semantic"],
                         png_paint=dec["paint"])
     print("wrote g17_frame_writer.npz", {k: (v.shape, v.dtype) for k, v in dec.items()})

@@ -13,6 +13,9 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+from oracle import common as _oracle_common  # noqa: E402  (save_golden: writes the fixture, or compares under --check)
 sys.path.insert(0, REPO)
 from oracle import common  # noqa: E402
 from oracle.gen_golden import _import_reference  # noqa: E402
@@ -40,7 +43,7 @@ def main():
     out = dict(**{f"rays_{k}": v for k, v in rays.items()}, target=target, target_depth=tdepth, loss=loss.detach(), l1_rgb=ret[1][0], l1_distance=ret[1][1],
                l0_distance=ret[0][1], **{"grad_" + k: v.grad for k, v in leaves.items()})
     arr = {k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in out.items()}
-    np.savez_compressed(os.path.join(REPO, "tests", "golden", "g19_mipnerf_raygrad.npz"), **arr)
+    _oracle_common.save_golden(os.path.join(REPO, "tests", "golden", "g19_mipnerf_raygrad.npz"), **arr)
     print("wrote g19_mipnerf_raygrad.npz", {k: float(np.abs(arr["grad_" + k]).max()) for k in leaves})
 
 

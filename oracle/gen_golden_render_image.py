@@ -14,6 +14,9 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+from oracle import common as _oracle_common  # noqa: E402  (save_golden: writes the fixture, or compares under --check)
 sys.path.insert(0, REPO)
 from oracle import common  # noqa: E402
 from oracle.gen_golden import _import_reference  # noqa: E402
@@ -40,7 +43,7 @@ def main():
     out = dict(**{f"rays_{k}": v for k, v in flat.items()}, H=np.int64(H), W=np.int64(W), chunk=np.int64(chunk), rgb=rgb, distance=dist, acc=acc,
                semantic=sem, param_names=np.array(list(sd.keys())))
     arr = {k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in out.items()}
-    np.savez_compressed(os.path.join(REPO, "tests", "golden", "g21_render_image.npz"), **arr)
+    _oracle_common.save_golden(os.path.join(REPO, "tests", "golden", "g21_render_image.npz"), **arr)
     print("wrote g21_render_image.npz", sum(a.nbytes for a in arr.values()), "bytes", tuple(rgb.shape), tuple(dist.shape), tuple(sem.shape))
 
 

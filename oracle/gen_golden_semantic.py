@@ -13,6 +13,9 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+from oracle import common as _oracle_common  # noqa: E402  (save_golden: writes the fixture, or compares under --check)
 sys.path.insert(0, REPO)
 from oracle import common  # noqa: E402
 from oracle.gen_golden import _import_reference  # noqa: E402
@@ -40,7 +43,7 @@ def main():
     for k, v in model.named_parameters():
         out["grad." + k] = v.grad
     arr = {k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in out.items()}
-    np.savez_compressed(os.path.join(REPO, "tests", "golden", "g14_mipnerf_semantic.npz"), **arr)
+    _oracle_common.save_golden(os.path.join(REPO, "tests", "golden", "g14_mipnerf_semantic.npz"), **arr)
     print("wrote g14_mipnerf_semantic.npz", sum(a.nbytes for a in arr.values()), "bytes; semantic params:", [k for k in sd if "semantic" in k])
 
 

@@ -20,6 +20,9 @@ import torch.nn as nn
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+from oracle import common as _oracle_common  # noqa: E402  (save_golden: writes the fixture, or compares under --check)
 OUT = os.path.join(REPO, "tests", "golden")
 REF = "/root/reference/s-nerfpp/zipnerf"
 sys.path.insert(0, REPO)
@@ -198,7 +201,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     for name, dd in G.items():
         arr = {k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in dd.items()}
-        np.savez_compressed(os.path.join(OUT, name + ".npz"), **arr)
+        _oracle_common.save_golden(os.path.join(OUT, name + ".npz"), **arr)
         print("wrote", name, sum(a.nbytes for a in arr.values()), "bytes")
 
 

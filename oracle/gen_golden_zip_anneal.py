@@ -14,6 +14,9 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+from oracle import common as _oracle_common  # noqa: E402  (save_golden: writes the fixture, or compares under --check)
 sys.path.insert(0, REPO)
 from oracle import zip as oz  # noqa: E402
 from oracle import gen_golden_zip as gz  # noqa: E402
@@ -41,7 +44,7 @@ def main():
             d[f"{tag}_sdist{lvl}"] = hist[lvl]["sdist"]; d[f"{tag}_weights{lvl}"] = hist[lvl]["weights"]
         d[tag + "_rgb"], d[tag + "_depth"] = rend[-1]["rgb"], rend[-1]["depth"]
     arr = {k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in d.items()}
-    np.savez_compressed(os.path.join(REPO, "tests", "golden", "g24_zip_near_anneal.npz"), **arr)
+    _oracle_common.save_golden(os.path.join(REPO, "tests", "golden", "g24_zip_near_anneal.npz"), **arr)
     print("wrote g24_zip_near_anneal.npz", sum(a.nbytes for a in arr.values()), "bytes; first posts:", float(d["a_sdist0"][0, 0]), float(d["b_sdist0"][0, 0]))
 
 

@@ -17,6 +17,9 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+from oracle import common as _oracle_common  # noqa: E402  (save_golden: writes the fixture, or compares under --check)
 OUT = os.path.join(REPO, "tests", "golden")
 sys.path.insert(0, REPO)
 
@@ -73,7 +76,7 @@ def main():
     py = rng.integers(0, 1280, n).astype(np.int32)
     o, d, vd, rad, ip, bx, by = cu.pixels_to_rays(px, py, pixtocams[cam_idx], c2w[cam_idx])
     f32 = lambda a: np.asarray(a, np.float32)
-    np.savez_compressed(os.path.join(OUT, "g15_zip_rays.npz"), pixtocams=pixtocams, camtoworlds=c2w, cam_idx=cam_idx.astype(np.int32), pix_x=px, pix_y=py,
+    _oracle_common.save_golden(os.path.join(OUT, "g15_zip_rays.npz"), pixtocams=pixtocams, camtoworlds=c2w, cam_idx=cam_idx.astype(np.int32), pix_x=px, pix_y=py,
                         origins=f32(o), directions=f32(d), viewdirs=f32(vd), radii=f32(rad), imageplane=f32(ip), base_x=f32(bx), base_y=f32(by))
     # ---- G16: loss tail on seeded renderer outputs (waymo.gin level sizes 64 / 64 / 32, shrunk ray count)
     R, C = 80, 19
@@ -134,7 +137,7 @@ def main():
         stage[f"cdf_interp{i}_f64"] = rmath.sorted_interp_quad(dd([s0, s1][i]), c_, w_, cdf).numpy()
     stage.update(loss_interlevel_f64=li64.detach().numpy(), loss_distortion_f64=ld64.detach().numpy(), g_w0_f64=g64[0].numpy(),
                  g_w1_f64=g64[1].numpy(), g_w2_f64=g64[2].numpy())
-    np.savez_compressed(
+    _oracle_common.save_golden(
         os.path.join(OUT, "g16_zip_losses.npz"), s0=s0.numpy(), w0=w0.numpy(), s1=s1.numpy(), w1=w1.numpy(), s2=s2.numpy(), w2=w2.numpy(),
         rgb=rgb.numpy(), target_rgb=tgt.numpy(), mask_rgb=mask_rgb.numpy(), depth=depth.numpy(), target_depth=tdepth.numpy(),
         semantic=sem.numpy(), labels=labels.numpy().astype(np.int32), depth_lambda=np.float64(dep_lam), sem_mult=np.float64(0.04),

@@ -16,6 +16,9 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+from oracle import common as _oracle_common  # noqa: E402  (save_golden: writes the fixture, or compares under --check)
 sys.path.insert(0, REPO)
 from oracle import zip as oz  # noqa: E402
 from oracle import gen_golden_zip as gz  # noqa: E402
@@ -64,7 +67,7 @@ def main():
             if v.grad is not None and not k.endswith("embeddings"):
                 d[f"{tag}_grad.{k}"] = v.grad.float() / SCALE
     arr = {k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in d.items()}
-    np.savez_compressed(os.path.join(REPO, "tests", "golden", "g26_zip_fp16.npz"), **arr)
+    _oracle_common.save_golden(os.path.join(REPO, "tests", "golden", "g26_zip_fp16.npz"), **arr)
     print("wrote g26_zip_fp16.npz", sum(a.nbytes for a in arr.values() if a.dtype.kind != "U"), "bytes")
     print("reference fp16 vs fp32: max |d rgb|", float(np.abs(arr["f16_rgb"] - arr["f32_rgb"]).max()), " max rel d depth",
           float((np.abs(arr["f16_depth"] - arr["f32_depth"]) / np.abs(arr["f32_depth"])).max()), arr["f16_dtypes"])

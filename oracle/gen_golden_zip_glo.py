@@ -14,6 +14,9 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+from oracle import common as _oracle_common  # noqa: E402  (save_golden: writes the fixture, or compares under --check)
 sys.path.insert(0, REPO)
 from oracle import zip as oz  # noqa: E402
 from oracle import gen_golden_zip as gz  # noqa: E402
@@ -61,7 +64,7 @@ def main():
             if v.grad is not None and ("glo" in k or k in KEEP):
                 d[f"{tag}_grad.{k}"] = v.grad.clone()
     arr = {k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in d.items()}
-    np.savez_compressed(os.path.join(REPO, "tests", "golden", "g25_zip_glo.npz"), **arr)
+    _oracle_common.save_golden(os.path.join(REPO, "tests", "golden", "g25_zip_glo.npz"), **arr)
     print("wrote g25_zip_glo.npz", sum(a.nbytes for a in arr.values()), "bytes;", [k for k in arr if "glo" in k and "grad" in k])
 
 

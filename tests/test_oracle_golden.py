@@ -1,5 +1,7 @@
 """Pin the CPU oracle against golden vectors captured from the imported
 reference (oracle/gen_golden.py).  CPU only."""
+import os
+
 import numpy as np
 import torch
 
@@ -266,3 +268,24 @@ def test_oracle_fuzz_vs_reference_log_and_live_run():
             continue
         r = subprocess.run([sys.executable, os.path.join(root, "oracle", name + ".py"), "--seeds", "2"], capture_output=True, text=True, timeout=900)
         assert r.returncode == 0 and "# total violations: 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_every_golden_generator_verifies_against_the_reference():
+    """`python oracle/gen_golden*.py --check` for all 16 generators: each imports the reference's own modules (/root/reference, build
+    container only), regenerates its fixtures in memory and compares them with the committed files bit for bit -- `check: OK`, nothing
+    written.  Skipped where the reference is not mounted (the GPU box)."""
+    import glob
+    import subprocess
+    import sys
+    import pytest
+    if not os.path.isdir("/root/reference/s-nerf"):
+        pytest.skip("/root/reference is not mounted here")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gens = sorted(glob.glob(os.path.join(repo, "oracle", "gen_golden*.py")))
+    assert len(gens) == 16
+    before = {f: os.path.getmtime(os.path.join(repo, "tests", "golden", f)) for f in os.listdir(os.path.join(repo, "tests", "golden"))}
+    procs = [(g, subprocess.Popen([sys.executable, g, "--check"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=repo)) for g in gens]
+    for g, p in procs:
+        out = p.communicate(timeout=900)[0]
+        assert p.returncode == 0 and out.strip().splitlines()[-1] == "check: OK", (os.path.basename(g), out[-400:])
+    assert before == {f: os.path.getmtime(os.path.join(repo, "tests", "golden", f)) for f in before}, "a generator wrote under --check"

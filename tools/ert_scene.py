@@ -102,13 +102,8 @@ def precision_on_fitted_weights(model, build, rows=40, row0=430):
     return res
 
 
-def fit_and_render(model, steps=300, eps=(1e-4, 1e-4), rays_per_step=4096, chunk=32768, lr=1e-3, seed=0, log=None, group=0, rows=None, row0=0,
-                   build=None):
-    """Fit `model` (a MipNerfModel on its device) to the analytic scene, then render the frame plain and with ERT.  -> dict
-    `group` > 0: front-to-back termination on the fine network's own densities in groups of that many samples (eps_t is then an exact
-    bound); 0: the selection from the proposal histogram (eps_t, eps_w).  `rows` (+ `row0`): render only that window of image rows (a
-    short leg of bench.py); `build`: also run precision_on_fitted_weights with it."""
-    from snerf_amd.mipnerf import Rays, render_image
+def fit(model, steps, rays_per_step=4096, lr=1e-3, seed=0, log=None):
+    """`steps` train steps of `model` on the analytic scene (RGB + depth supervised) -> seconds"""
     from snerf_amd.trainer import MipTrainer
     dev = model.arena.flat.device
     tr = MipTrainer(model, lr=lr, depth_lambda=0.5, coarse_depth_mult=1.0)
@@ -123,7 +118,27 @@ def fit_and_render(model, steps=300, eps=(1e-4, 1e-4), rays_per_step=4096, chunk
         loss, _ = tr.step(rays, rgb, t_hit, torch.ones_like(t_hit))
         if log is not None and (it % 50 == 0 or it == steps - 1):
             log(f"fit step {it}: loss {float(loss):.5f}")
-    torch.cuda.synchronize(); t_fit = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+
+def fit_and_precision(model, steps, build):
+    """bench.py's fitted_weights_precision leg: fit, then every compute mode against exact fp32 on the fitted weights"""
+    t_fit = fit(model, steps)
+    res = precision_on_fitted_weights(model, build)
+    res["fit_steps"], res["fit_s"] = steps, round(t_fit, 2)
+    return res
+
+
+def fit_and_render(model, steps=300, eps=(1e-4, 1e-4), rays_per_step=4096, chunk=32768, lr=1e-3, seed=0, log=None, group=0, rows=None, row0=0,
+                   build=None):
+    """Fit `model` (a MipNerfModel on its device) to the analytic scene, then render the frame plain and with ERT.  -> dict
+    `group` > 0: front-to-back termination on the fine network's own densities in groups of that many samples (eps_t is then an exact
+    bound); 0: the selection from the proposal histogram (eps_t, eps_w).  `rows` (+ `row0`): render only that window of image rows (a
+    short leg of bench.py); `build`: also run precision_on_fitted_weights with it."""
+    from snerf_amd.mipnerf import Rays, render_image
+    dev = model.arena.flat.device
+    t_fit = fit(model, steps, rays_per_step, lr, seed, log)
     prec = precision_on_fitted_weights(model, build) if build is not None else None
     Hw = H if rows is None else rows                                   # (a window is rendered and scored like a frame of `rows` rows)
     fr = rays_of(None, row0 * W, Hw * W, dev)
