@@ -163,25 +163,7 @@ def eager_baseline(model_sd, rays, n_rays, steps, bf16):
     from oracle import mip as om
     dev = rays.origins.device
 
-    def resample_torch(s_vals, weights, u, resample_padding=0.01):
-        w = weights.detach()
-        wp = torch.cat([w[..., :1], w, w[..., -1:]], -1)
-        wmax = torch.maximum(wp[..., :-1], wp[..., 1:])
-        w = 0.5 * (wmax[..., :-1] + wmax[..., 1:]) + resample_padding
-        wsum = w.sum(-1, keepdim=True)
-        pad = torch.clamp(1e-5 - wsum, min=0)
-        w = w + pad / w.shape[-1]
-        wsum = wsum + pad
-        cdf = torch.clamp(torch.cumsum((w / wsum)[..., :-1], -1), max=1.0)
-        cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf, torch.ones_like(cdf[..., :1])], -1)
-        uu = u.to(dev).expand(s_vals.shape[0], -1).contiguous()
-        idx = torch.searchsorted(cdf, uu, right=True) - 1
-        idx = idx.clamp(0, cdf.shape[-1] - 2)
-        b0, b1 = torch.gather(s_vals, -1, idx), torch.gather(s_vals, -1, idx + 1)
-        c0, c1 = torch.gather(cdf, -1, idx), torch.gather(cdf, -1, idx + 1)
-        t = torch.clip(torch.nan_to_num((uu - c0) / (c1 - c0), 0.0), 0, 1)
-        return b0 + t * (b1 - b0), idx
-
+    from oracle.eager import mip_resample_torch as resample_torch
     saved, om.warp_resample_s = om.warp_resample_s, resample_torch
     prev = torch.get_default_device() if hasattr(torch, "get_default_device") else None
     torch.set_default_device(dev)

@@ -66,3 +66,27 @@ def sample_pdf_torch(bins, weights, u, sum_mode="torch"):
     denom = c1 - c0
     denom = torch.where(denom < 1e-5, torch.ones_like(denom), denom)
     return b0 + (u - c0) / denom * (b1 - b0), inds
+
+
+def mip_resample_torch(s_vals, weights, u, resample_padding=0.01):
+    """oracle/mip.warp_resample_s (mip.py:294-320, math_ops.py:19-76) as torch ops on the tensors' device -- the numpy restatement with
+    its canonical accumulation order is the parity oracle; this form is what a PyTorch-ROCm eager run of the reference executes.
+    -> (s_vals of the resampled fence posts, interval indices)"""
+    dev = s_vals.device
+    w = weights.detach()
+    wp = torch.cat([w[..., :1], w, w[..., -1:]], -1)
+    wmax = torch.maximum(wp[..., :-1], wp[..., 1:])
+    w = 0.5 * (wmax[..., :-1] + wmax[..., 1:]) + resample_padding
+    wsum = w.sum(-1, keepdim=True)
+    pad = torch.clamp(1e-5 - wsum, min=0)
+    w = w + pad / w.shape[-1]
+    wsum = wsum + pad
+    cdf = torch.clamp(torch.cumsum((w / wsum)[..., :-1], -1), max=1.0)
+    cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf, torch.ones_like(cdf[..., :1])], -1)
+    uu = u.to(dev).expand(s_vals.shape[0], -1).contiguous()
+    idx = torch.searchsorted(cdf, uu, right=True) - 1
+    idx = idx.clamp(0, cdf.shape[-1] - 2)
+    b0, b1 = torch.gather(s_vals, -1, idx), torch.gather(s_vals, -1, idx + 1)
+    c0, c1 = torch.gather(cdf, -1, idx), torch.gather(cdf, -1, idx + 1)
+    t = torch.clip(torch.nan_to_num((uu - c0) / (c1 - c0), 0.0), 0, 1)
+    return b0 + t * (b1 - b0), idx

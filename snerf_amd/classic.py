@@ -289,22 +289,21 @@ def _sample_pdf_z(z_vals, weights, N_samples, det, pytest, u, return_inds):
     return ops.classic_sample_pdf(z_vals, weights.detach().contiguous(), u, True, return_inds, True)
 
 
-ERT_STATS = {"evaluated": 0, "total": 0}          # fine-network evaluations of the ert renders since the caller last reset it
-
-
 def _fine_pass_front_to_back(rb, z_all, viewdirs, run_fn, network_query_fn, eps_t, G):
     """The fine network front to back in groups of G samples (inference extension, NOT in the reference): after every group the rays
     whose transmittance -- from the fine network's own densities, raw2outputs' alpha (run_nerf_helpers.py:394-414) -- has fallen to
     <= eps_t leave, and the rows of the next group are compacted to the survivors.  Unevaluated samples keep raw = 0 (alpha = 0,
     weight 0): the weights they would have had sum to <= eps_t per ray, which bounds the error of acc_map and (x 1) of rgb_map.
     The 64 uniform coarse positions the fine pass re-evaluates (render.py:380-389) are what lies behind an opaque hit: measured on a
-    fitted street scene 26 % of the fine evaluations at eps_t = 1e-4 (tools/ert_classic_analysis.py).  -> raw [N, S, C]"""
+    fitted street scene 26 % of the fine evaluations at eps_t = 1e-4 (tools/ert_classic_analysis.py).
+    -> (raw [N, S, C], fine-network evaluations done): the count is returned per call -- render_rays hands it on as ret['ert_evals'] --,
+    not kept in module state (two models rendering from two threads would race on it)."""
     N, S = z_all.shape
     dev = z_all.device
     dn = rb[:, 3:6].norm(dim=-1)
     alive = None                       # None = every ray; else the surviving rays' indices, with their rows / transmittances kept compact
     rbs, T, dns = rb, torch.ones(N, device=dev), dn
-    raw = None
+    raw, evaluated = None, 0
     # G: one group size, or a schedule of sizes (the last one repeats) -- e.g. (96, 16): hardly a ray ends within its first 96 sorted
     # samples (the coarse positions in front of its first surface + the front half of the 128 importance samples drawn around it), so
     # those go in one piece and the tail in fine steps (measured on the fitted street scene: 1.23x vs 1.19x for uniform groups of 48)
@@ -327,10 +326,9 @@ def _fine_pass_front_to_back(rb, z_all, viewdirs, run_fn, network_query_fn, eps_
             rg = network_query_fn(pts, vd if viewdirs is not None else None, run_fn)
             if raw is None:
                 raw = torch.zeros(N, S, rg.shape[-1], dtype=torch.float32, device=dev)
-            ERT_STATS["evaluated"] += n * (g1 - g0)
+            evaluated += n * (g1 - g0)
             alive = ops.classic_ert_step(rg.float().contiguous(), alive, z_all, rb, g0, g1 - g0, eps_t, T, raw, scratch)
-        ERT_STATS["total"] += N * S
-        return raw
+        return raw, evaluated
     for g0, g1 in zip(bounds[:-1], bounds[1:]):
         if rbs.shape[0] == 0:
             break
@@ -343,7 +341,7 @@ def _fine_pass_front_to_back(rb, z_all, viewdirs, run_fn, network_query_fn, eps_
             raw[:, g0:g1] = rg
         else:
             raw[alive, g0:g1] = rg
-        ERT_STATS["evaluated"] += int(rg.shape[0]) * (g1 - g0)
+        evaluated += int(rg.shape[0]) * (g1 - g0)
         if g1 < S:
             znext = z_all[:, g0 + 1:g1 + 1] if alive is None else z_all[alive, g0 + 1:g1 + 1]
             T = T * torch.exp(-(torch.relu(rg[..., 3]) * ((znext - zr) * dns[:, None])).sum(-1))       # x prod (1 - alpha) over the group
@@ -351,8 +349,7 @@ def _fine_pass_front_to_back(rb, z_all, viewdirs, run_fn, network_query_fn, eps_
             if int(keep.sum()) < keep.numel():                                         # (the one device->host read per group)
                 alive = torch.nonzero(keep).reshape(-1) if alive is None else alive[keep]
                 rbs, T, dns = rbs[keep], T[keep], dns[keep]
-    ERT_STATS["total"] += N * S
-    return raw
+    return raw, evaluated
 
 
 def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False, lindisp=False, perturb=0.,
@@ -365,6 +362,14 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
     N_rays = ray_batch.shape[0]
     if N_rays == 0:   # as the reference (run_network's torch.cat of no chunks): an error, not an empty dict
         raise ValueError("render_rays: empty ray batch")
+    if ert is not None:           # validated at entry, whatever branch runs below
+        if torch.is_grad_enabled() or raw_noise_std > 0.:
+            raise NotImplementedError("ert is an inference mode: call under torch.no_grad() with raw_noise_std = 0")
+        if not (float(ert[0]) < 1.0 and min([ert[1]] if isinstance(ert[1], (int, float)) else list(ert[1])) >= 1):
+            raise ValueError("ert = (eps_t < 1, G >= 1 or a schedule of group sizes >= 1)")
+        if N_importance <= 0:
+            raise ValueError("ert terminates rays in the FINE pass (render.py:380-389): it needs N_importance > 0")
+    ert_evals = None
     dev = ray_batch.device
     rb = ray_batch.float()
     if rb.stride(-1) != 1:
@@ -394,12 +399,7 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
         z_all = ops.classic_merge_sort(z_vals, z_samples)
         run_fn = network_fn if network_fine is None else network_fine
         if ert is not None:
-            if torch.is_grad_enabled() or raw_noise_std > 0.:
-                raise NotImplementedError("ert is an inference mode: call under torch.no_grad() with raw_noise_std = 0")
-            eps_t, G = float(ert[0]), ert[1]
-            if not (eps_t < 1.0 and min([G] if isinstance(G, (int, float)) else list(G)) >= 1):
-                raise ValueError("ert = (eps_t < 1, G >= 1 or a schedule of group sizes >= 1)")
-            raw = _fine_pass_front_to_back(rb, z_all, viewdirs, run_fn, network_query_fn, eps_t, G)
+            raw, ert_evals = _fine_pass_front_to_back(rb, z_all, viewdirs, run_fn, network_query_fn, float(ert[0]), ert[1])
         else:
             pts = ops.classic_points(rb, z_all)
             raw = network_query_fn(pts, viewdirs, run_fn)
@@ -408,6 +408,8 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
            'weights': weights}
     if retraw:
         ret['raw'] = raw
+    if ert_evals is not None:     # [1, 2] = (fine-network evaluations done, evaluations of the plain render); batchify_rays concatenates the chunks' rows
+        ret['ert_evals'] = torch.tensor([[ert_evals, N_rays * int(z_all.shape[1])]], dtype=torch.int64)
     if N_importance > 0:
         ret['rgb0'] = rgb_map_0
         ret['disp0'] = disp_map_0

@@ -377,9 +377,9 @@ def test_fine_pass_early_termination_host_logic(backend):
             dict(net.named_parameters())["alpha_linear.bias"] += 40.0
             net.arena.bump()
         full = classic.render_rays(rays, **kw)
-        classic.ERT_STATS.update(evaluated=0, total=0)
         fast = classic.render_rays(rays, ert=(1e-3, 16), **kw)
-    assert classic.ERT_STATS["total"] == N * 192 and 0 < classic.ERT_STATS["evaluated"] < 0.85 * N * 192
+    ev, tot = (int(v) for v in fast["ert_evals"].sum(0))
+    assert tot == N * 192 and 0 < ev < 0.85 * N * 192
     assert float((fast["acc_map"] - full["acc_map"]).abs().max()) <= 1e-3 * 1.01 + 1e-6
     assert float((fast["rgb_map"] - full["rgb_map"]).abs().max()) <= 1e-3 * 1.01 + 1e-6
     ev = (fast["raw"] != 0).any(-1)

@@ -183,9 +183,10 @@ def test_classic_fine_pass_front_to_back_ert():
                 net.arena.bump()
         full = classic.render_rays(rays, **kw)
         eps = 1e-3
-        classic.ERT_STATS.update(evaluated=0, total=0)
         fast = classic.render_rays(rays, ert=(eps, 16), **kw)
-    ev, tot = classic.ERT_STATS["evaluated"], classic.ERT_STATS["total"]
+        with pytest.raises(ValueError):
+            classic.render_rays(rays, ert=(eps, 16), **dict(kw, N_importance=0))          # no fine pass: refused, not silently ignored
+    ev, tot = (int(v) for v in fast["ert_evals"].sum(0))
     assert tot == N * 192 and 0 < ev < 0.85 * tot, (ev, tot)
     assert float((fast["acc_map"] - full["acc_map"]).abs().max()) <= eps * 1.01 + 1e-6
     assert float((fast["rgb_map"] - full["rgb_map"]).abs().max()) <= eps * 1.01 + 1e-6          # sigmoid colours in [0, 1]

@@ -101,13 +101,18 @@ def fit_and_measure(steps=400, eps_list=(1e-4, 1e-3, 1e-2), rows_n=96, lindisp=F
         res["rules"][f"coarse_eps_{eps:g}"]["max_abs_err_acc_if_skipped"] = float(lost.max())
         res["rules"][f"coarse_eps_{eps:g}"]["p999_abs_err_acc_if_skipped"] = float(torch.quantile(lost, 0.999))
     # ---- measured: the window rendered plain and with the front-to-back termination
+    evals = [0, 0]
+
     def render(ert):
         parts = []
+        evals[0] = evals[1] = 0
         with torch.no_grad():
             torch.cuda.synchronize(); t1 = time.perf_counter()
             for a in range(0, nw, chunk):
                 o = classic.render_rays(rows[a:a + chunk], coarse, q, 64, lindisp=args.lindisp, perturb=0.0, N_importance=128, network_fine=fine, ert=ert)
                 parts.append((o["rgb_map"], o["acc_map"], o["depth_map"]))
+                if "ert_evals" in o:
+                    evals[0] += int(o["ert_evals"][0, 0]); evals[1] += int(o["ert_evals"][0, 1])
             torch.cuda.synchronize()
         return [torch.cat(x, 0) for x in zip(*parts)], time.perf_counter() - t1
     render(None)
@@ -117,11 +122,10 @@ def fit_and_measure(steps=400, eps_list=(1e-4, 1e-3, 1e-2), rows_n=96, lindisp=F
     res["measured"] = {}
     for G in groups:
         render((ert_eps, G))
-        classic.ERT_STATS.update(evaluated=0, total=0)
         (rgb_e, acc_e, dep_e), t_e = render((ert_eps, G))
         res["measured"][f"eps_{ert_eps:g}_G{G if isinstance(G, int) else '_'.join(map(str, G))}"] = {
             "window_ms": round(t_e * 1e3, 2), "speedup": round(t_plain / t_e, 3),
-            "fine_evaluations_kept": round(classic.ERT_STATS["evaluated"] / max(classic.ERT_STATS["total"], 1), 4),
+            "fine_evaluations_kept": round(evals[0] / max(evals[1], 1), 4),
             "max_abs_err_rgb": float((rgb_e - rgb_p).abs().max()), "max_abs_err_acc": float((acc_e - acc_p).abs().max()),
             "max_abs_err_depth": float((dep_e - dep_p).abs().max())}
     if stages:
