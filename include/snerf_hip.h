@@ -81,7 +81,9 @@ int snerf_classic_embed(const float* pts, const float* viewdirs, int vd_stride, 
 /* mip path: s -> t (mip.py:7-9) -> cast_rays cone/cylinder (mip.py:80-91, 56-77, 31-53) -> contraction
  * fn2 + Jacobi_g (mip.py:343-374) -> diagonal of J diag(c) J^T (mip.py:381-395) -> integrated_pos_enc
  * (mip.py:94-118, 24-28; math_ops.py:6-12), `width` >= 6*max_deg columns (zero padded) into dst1 (and dst2).
- * means_out/covs_out: optional fp32 [N*S,3] copies of the contracted mean / covariance diagonal. */
+ * means_out/covs_out: optional fp32 [N*S,3] copies of the contracted mean / covariance diagonal.
+ * `cone`: bit 0 = ray shape (1 cone, 0 cylinder); bit 1 = --disable_integration (models.py:132-133: the covariances are replaced by zeros
+ * before the encoding; the backward entries take the same value). */
 int snerf_mip_encode(const float* s_vals, const float* origins, const float* directions, const float* radii,
                      const float* near, const float* far, long n_rays, int S, int cone, int transform_idx, int max_deg,
                      void* dst1, long ld1, void* dst2, long ld2, int width, float* means_out, float* covs_out,

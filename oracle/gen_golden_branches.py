@@ -9,6 +9,8 @@ item 8), captured from the REFERENCE's own functions:
   g29_near_far       render(..., near=<tensor [N,1]>, far=<tensor [N,1]>) (render.py:74: near * ones_like(rays_d[..., :1]))
   g30_pose_fn0       MipNerfModel(fn=0) forward + gradients w.r.t. origins / directions / viewdirs (mip.py:323-341, 367-378, 381-395:
                      the view-centred warp under pose refinement)
+  g31_no_integration MipNerfModel(disable_integration=1) (arg_parser.py:188 --disable_integration; models.py:132-133: the sample covariances
+                     are replaced by zeros before integrated_pos_enc): outputs of both levels, parameter gradients, ray gradients
 
 Runs only in the build container (needs /root/reference); the .npz files are data.
     python oracle/gen_golden_branches.py [--check]
@@ -111,6 +113,23 @@ def gen_all():
     G["g30_pose_fn0"] = dict(**{k: v for k, v in rays.items()}, viewc=viewc, w_rgb=w_rgb, w_d1=w_d1, w_d0=w_d0, rgb=ret[1][0], dist1=ret[1][1], dist0=ret[0][1],
                              g_origins=leaves["origins"].grad, g_directions=leaves["directions"].grad, g_viewdirs=leaves["viewdirs"].grad,
                              S0=np.int64(S0), P1=np.int64(P1), hidden=np.int64(hidden))
+    # ---- mip path: --disable_integration (contraction warp, pose refinement on)
+    m = models.MipNerfModel(n_samples=S0, N_fine=P1, no_warp_sample=0, disable_integration=1, ray_shape="cone", fn=1, radius=3., transform_idx=0, real=True,
+                            rgb_layer=3, hidden_layer=hidden, density_noise=0., max_deg_point=16, proposal_hidden_layer=64, proposal_loss=True)
+    sd = common.fill_state_dict_(m.state_dict())
+    m.load_state_dict(sd)
+    rays = common.synthetic_rays(n, seed=31)
+    leaves = {k: rays[k].clone().requires_grad_(True) for k in ("origins", "directions", "viewdirs")}
+    rr4 = RT(leaves["origins"], leaves["directions"], leaves["viewdirs"], rays["radii"], rays["lossmult"], rays["near"], rays["far"], rays["app"])
+    ret = m(rr4, False, False, 0.)
+    w_rgb, w_d1, w_d0 = R(n, 3), R(n), R(n)
+    loss = (ret[1][0] * w_rgb).sum() + 0.05 * (ret[1][1] * w_d1).sum() + 0.05 * (ret[0][1] * w_d0).sum()
+    loss.backward()
+    G["g31_no_integration"] = dict(**{k: v for k, v in rays.items()}, w_rgb=w_rgb, w_d1=w_d1, w_d0=w_d0, rgb=ret[1][0], dist1=ret[1][1], acc1=ret[1][2],
+                                   dist0=ret[0][1], s1=ret[1][4], weights1=ret[1][5], loss=loss.detach(),
+                                   g_origins=leaves["origins"].grad, g_directions=leaves["directions"].grad, g_viewdirs=leaves["viewdirs"].grad,
+                                   param_names=np.array(list(sd.keys())), **{"grad." + k: p.grad for k, p in m.named_parameters()},
+                                   S0=np.int64(S0), P1=np.int64(P1), hidden=np.int64(hidden))
     return {k: t2n(v) for k, v in G.items()}
 
 

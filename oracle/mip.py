@@ -313,7 +313,8 @@ def warp_resample_s(s_vals, weights, u, resample_padding: float = 0.01):
 def mipnerf_forward(p: dict, rays: dict, n_samples: int, n_fine: int, s_rand=None, u=None,
                     white_bg: bool = False, ray_shape: str = "cone", transform_idx: int = 0,
                     max_deg_point: int = 16, deg_view: int = 4, resample_padding: float = 0.01,
-                    density_noise0=None, density_noise1=None, return_aux: bool = False, s1_override=None, fn_idx: int = 1, viewc=0.0):
+                    density_noise0=None, density_noise1=None, return_aux: bool = False, s1_override=None, fn_idx: int = 1, viewc=0.0,
+                    disable_integration: bool = False):
     """MipNerfModel.forward, models.py:72-187 (warp branch, use_viewdirs; the appearance
     embedding of encode_appearance when `p` holds "emb.weight").  ``u`` [N,n_fine] or [n_fine]; None = det_u(n_fine).
     Returns [[None, distance, acc, s_vals, weights], [rgb, distance, acc, semantic, s_vals, weights]]
@@ -326,6 +327,8 @@ def mipnerf_forward(p: dict, rays: dict, n_samples: int, n_fine: int, s_rand=Non
     # level 0: proposal
     s0 = warp_sample_s(n, n_samples, s_rand)
     m0, c0 = sample2enc(s0, o, d, r, near, far, ray_shape, transform_idx, fn_idx=fn_idx, viewc=viewc)
+    if disable_integration:            # models.py:132-133: samples = (samples[0], torch.zeros_like(samples[1]))
+        c0 = torch.zeros_like(c0)
     enc0 = integrated_pos_enc(m0, c0, 0, max_deg_point)
     raw_d0 = proposal_mlp(p, enc0)
     if density_noise0 is not None:
@@ -341,6 +344,8 @@ def mipnerf_forward(p: dict, rays: dict, n_samples: int, n_fine: int, s_rand=Non
         # reduced-precision run resampled -- so that both sides see identical sample positions (the posts carry no gradient)
         s1 = s1_override
     m1, c1 = sample2enc(s1, o, d, r, near, far, ray_shape, transform_idx, fn_idx=fn_idx, viewc=viewc)
+    if disable_integration:
+        c1 = torch.zeros_like(c1)
     enc1 = integrated_pos_enc(m1, c1, 0, max_deg_point)
     cond = pos_enc(rays["viewdirs"], 0, deg_view, True)
     if "emb.weight" in p:

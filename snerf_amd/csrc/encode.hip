@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void mip_encode_kernel(MipEncArgs a) {
     const float t1 = mip_transform(a.s_vals[ray * (a.S + 1) + i + 1], near, far, a.transform_idx);
     const float rad = a.radii[ray];
     float t_mean, t_var, r_var;
-    if (a.cone) {  // conical_frustum_to_gaussian, stable form (mip.py:56-64)
+    if (a.cone & 1) {  // conical_frustum_to_gaussian, stable form (mip.py:56-64)
       const float mu = (t0 + t1) / 2.f, hw = (t1 - t0) / 2.f;
       const float mu2 = mu * mu, hw2 = hw * hw, hw4 = hw2 * hw2;
       const float den = 3.f * mu2 + hw2;
@@ -224,6 +224,10 @@ __global__ __launch_bounds__(256) void mip_encode_kernel(MipEncArgs a) {
 #pragma unroll
       for (int r = 0; r < 3; ++r) fc[r] = ((1.f / 3.f) * (1.f / 3.f)) * c[r];
     }
+    }
+    if (a.cone & 2) {   // --disable_integration (models.py:132-133): samples = (means, zeros_like(covs)) -- the encoding loses its exp(-var / 2) factor
+#pragma unroll
+      for (int k = 0; k < 3; ++k) fc[k] = 0.f;
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) { sm[threadIdx.x][k] = fm[k]; sm[threadIdx.x][3 + k] = fc[k]; }
@@ -433,7 +437,7 @@ __global__ __launch_bounds__(256) void mip_encode_bwd_kernel(MipEncBwd a) {
     const float t0 = mip_transform(a.s_vals[ray * (a.S + 1) + i], near, far, a.transform_idx);
     const float t1 = mip_transform(a.s_vals[ray * (a.S + 1) + i + 1], near, far, a.transform_idx);
     float t_mean, t_var, r_var;
-    if (a.cone) {
+    if (a.cone & 1) {
       const float mu = (t0 + t1) / 2.f, hw = (t1 - t0) / 2.f;
       const float mu2 = mu * mu, hw2 = hw * hw, hw4 = hw2 * hw2;
       const float den = 3.f * mu2 + hw2;
@@ -488,6 +492,10 @@ __global__ __launch_bounds__(256) void mip_encode_bwd_kernel(MipEncBwd a) {
       fc[r] = acc;
     }
     }
+    if (a.cone & 2) {   // --disable_integration: the encoder saw zeros_like(covs), a constant -- no exp factor, no gradient through the covariance
+#pragma unroll
+      for (int k = 0; k < 3; ++k) fc[k] = 0.f;
+    }
     // ---- feature gradients -> d fm, d fc
     const float* ge = a.dE + (ray * a.S + i) * a.ld;
     float gfm[3] = {0.f, 0.f, 0.f}, gfc[3] = {0.f, 0.f, 0.f};
@@ -503,6 +511,7 @@ __global__ __launch_bounds__(256) void mip_encode_bwd_kernel(MipEncBwd a) {
         gfc[dim] += (-0.5f * sc * sc) * e * (safe_sin(y) * gs + safe_sin(y2) * gc);
       }
     }
+    if (a.cone & 2) { gfc[0] = 0.f; gfc[1] = 0.f; gfc[2] = 0.f; }
     // ---- contraction and its Jacobian -> d x, d c
     float gx[3] = {0.f, 0.f, 0.f}, gcv[3] = {0.f, 0.f, 0.f};
     const float inv_n = nrm > 0.f ? 1.f / nrm : 0.f;                 // d|x|/dx = x / |x| (0 at the origin, as torch.norm's backward)

@@ -42,14 +42,19 @@ class MipNerfModel(_ArenaModule):
         super().__init__()
         if no_warp_sample:
             raise NotImplementedError("no_warp_sample=1 is broken in the reference itself (models.py:82 vs :178); only the warp branch exists")
-        if n_levels != 2 or not use_viewdirs or disable_integration or min_deg_point != 0 or not stop_level_grad:
-            raise NotImplementedError("accelerated MipNerfModel: n_levels=2, use_viewdirs, stop_level_grad")
+        if not use_viewdirs:
+            raise NotImplementedError("use_viewdirs=False is broken in the reference itself: models.py:164 calls self.mlp(samples_enc) without the `condition` "
+                                      "argument MLP.forward requires (models.py:265) and unpacks its three results into two")
+        if n_levels != 2 or min_deg_point != 0 or not stop_level_grad:
+            raise NotImplementedError("accelerated MipNerfModel: n_levels=2, stop_level_grad, min_deg_point=0 -- the values make_mipnerf (models.py:190-214) "
+                                      "and every shipped config construct it with; constructor defaults nothing sets")
         if semantic and not (0 < semantic_class_num <= 32):
             raise NotImplementedError("semantic head: 1..32 classes")
         if fn not in (0, 1):
             raise ValueError("fn: 1 = contraction (the shipped nuScenes config), 0 = view-centred warp (mip.py:367-378)")
         self._viewc = (0.0, 0.0, 0.0)         # fn = 0: the mean camera centre (forward's `viewc` argument / set_viewc)
         self.n_levels, self.n_samples, self.N_fine = n_levels, n_samples, N_fine
+        self.disable_integration = bool(disable_integration)          # --disable_integration (arg_parser.py:188; models.py:132-133)
         self.resample_padding, self.ray_shape, self.max_deg_point, self.deg_view = resample_padding, ray_shape, max_deg_point, deg_view
         self.density_noise, self.density_bias, self.rgb_padding = density_noise, density_bias, rgb_padding
         self.transform_idx, self.proposal_loss, self.lindisp = int(transform_idx), proposal_loss, lindisp
@@ -116,7 +121,7 @@ class MipNerfModel(_ArenaModule):
         n = o.shape[0]
         S0, P1 = self.n_samples, self.N_fine
         S1 = P1 - 1
-        cone = self.ray_shape == "cone"
+        cone = (1 if self.ray_shape == "cone" else 0) | (2 if self.disable_integration else 0)      # (bit 1: the encoders zero the covariances)
         if self.ray_shape not in ("cone", "cylinder"):
             raise ValueError(self.ray_shape)
         # ---- level 0: stratified s, encode, proposal MLP, composite

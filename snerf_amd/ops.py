@@ -379,7 +379,8 @@ def _ids(sample_id):
 
 def mip_encode(s_vals, origins, directions, radii, near, far, cone, transform_idx, max_deg, dst1, dst2, width, dt,
                means_out=None, covs_out=None, sample_id=None, warp=None):
-    """sample_id (int32 [rows], optional): encode only the samples ray * S + i listed there, row j of dst <- sample_id[j].
+    """cone: ray shape (True / 1 = cone, False / 0 = cylinder); + 2 = --disable_integration (models.py:132-133: the covariances are replaced
+    by zeros before the encoding).  sample_id (int32 [rows], optional): encode only the samples ray * S + i listed there, row j of dst <- sample_id[j].
     warp: None = the contraction (model argument fn = 1), or (viewc [3] host floats, far_max device scalar) = the view-centred warp
     fn = 0 (mip.py:367-378)."""
     n, P = s_vals.shape
@@ -397,11 +398,11 @@ def mip_encode(s_vals, origins, directions, radii, near, far, cone, transform_id
         _f32c(far_max)
         assert far_max.numel() == 1 and far_max.device == s_vals.device
         return _lib.call("snerf_mip_encode_warp", _p(s_vals), _p(origins), _p(directions), _p(radii), _p(near), _p(far), n, P - 1,
-                         1 if cone else 0, transform_idx, max_deg, _p(dst1), dst1.stride(0), _p(dst2),
+                         int(cone), transform_idx, max_deg, _p(dst1), dst1.stride(0), _p(dst2),
                          0 if dst2 is None else dst2.stride(0), width, _p(_f32c(means_out)), _p(_f32c(covs_out)), dt, _p(ids), rows,
                          0, float(vx), float(vy), float(vz), _p(far_max), _stream())
     _lib.call("snerf_mip_encode", _p(s_vals), _p(origins), _p(directions), _p(radii), _p(near), _p(far), n, P - 1,
-              1 if cone else 0, transform_idx, max_deg, _p(dst1), dst1.stride(0), _p(dst2),
+              int(cone), transform_idx, max_deg, _p(dst1), dst1.stride(0), _p(dst2),
               0 if dst2 is None else dst2.stride(0), width, _p(_f32c(means_out)), _p(_f32c(covs_out)), dt, _p(ids), rows, _stream())
 
 
@@ -633,10 +634,10 @@ def mip_encode_bwd(s_vals, origins, directions, radii, near, far, cone, transfor
     if warp is not None:
         (vx, vy, vz), far_max = warp
         _f32c(far_max)
-        _lib.call("snerf_mip_encode_warp_bwd", _p(s_vals), _p(origins), _p(directions), _p(radii), _p(near), _p(far), n, P - 1, 1 if cone else 0,
+        _lib.call("snerf_mip_encode_warp_bwd", _p(s_vals), _p(origins), _p(directions), _p(radii), _p(near), _p(far), n, P - 1, int(cone),
                   int(transform_idx), int(max_deg), _p(dE), dE.stride(0), _p(g_o), _p(g_d), 0, float(vx), float(vy), float(vz), _p(far_max), _stream())
         return g_o, g_d
-    _lib.call("snerf_mip_encode_bwd", _p(s_vals), _p(origins), _p(directions), _p(radii), _p(near), _p(far), n, P - 1, 1 if cone else 0,
+    _lib.call("snerf_mip_encode_bwd", _p(s_vals), _p(origins), _p(directions), _p(radii), _p(near), _p(far), n, P - 1, int(cone),
               int(transform_idx), int(max_deg), _p(dE), dE.stride(0), _p(g_o), _p(g_d), _stream())
     return g_o, g_d
 

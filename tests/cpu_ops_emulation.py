@@ -108,7 +108,9 @@ def mip_encode(s_vals, origins, directions, radii, near, far, cone, transform_id
     assert sample_id is None, "compacted rows are an inference-only GPU mode"
     kw = {} if warp is None else dict(fn_idx=0, viewc=torch.tensor(warp[0]))
     assert warp is None or float(warp[1]) == float(far.max())
-    fm, fc = om.sample2enc(s_vals, origins, directions, radii[:, None], near[:, None], far[:, None], "cone" if cone else "cylinder", transform_idx, **kw)
+    fm, fc = om.sample2enc(s_vals, origins, directions, radii[:, None], near[:, None], far[:, None], "cone" if int(cone) & 1 else "cylinder", transform_idx, **kw)
+    if int(cone) & 2:                      # --disable_integration
+        fc = torch.zeros_like(fc)
     enc = om.integrated_pos_enc(fm, fc, 0, max_deg).reshape(-1, 6 * max_deg)
     v = torch.cat([enc, torch.zeros(enc.shape[0], width - enc.shape[1])], -1)
     if dt == 4:
@@ -200,7 +202,9 @@ def mip_encode_bwd(s_vals, origins, directions, radii, near, far, cone, transfor
     kw = {} if warp is None else dict(fn_idx=0, viewc=torch.tensor(warp[0]))
     with torch.enable_grad():
         o, d = origins.detach().clone().requires_grad_(True), directions.detach().clone().requires_grad_(True)
-        fm, fc = om.sample2enc(s_vals, o, d, radii[:, None], near[:, None], far[:, None], "cone" if cone else "cylinder", transform_idx, **kw)
+        fm, fc = om.sample2enc(s_vals, o, d, radii[:, None], near[:, None], far[:, None], "cone" if int(cone) & 1 else "cylinder", transform_idx, **kw)
+        if int(cone) & 2:
+            fc = torch.zeros_like(fc)
         enc = om.integrated_pos_enc(fm, fc, 0, max_deg).reshape(-1, 6 * max_deg)
         (enc * dE[:, :6 * max_deg]).sum().backward()
     return o.grad, d.grad

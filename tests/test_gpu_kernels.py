@@ -520,6 +520,46 @@ def test_mip_encode_bwd_vs_oracle_autograd(n, S, cone, deg):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,S,cone,deg", [(130, 64, True, 16), (64, 5, False, 10)])
+def test_mip_encode_without_integration_fwd_and_bwd(n, S, cone, deg):
+    """--disable_integration (models.py:132-133; bit 1 of the kernels' `cone` argument): the features are safe_sin of the scaled means with
+    NO exp(-var / 2) factor -- against integrated_pos_enc(means, zeros) evaluated on the KERNEL's own means (the un-damped 2^15 x phase
+    turns one ulp of the mean into 2e-3 rad: a comparison through independently computed means would only test fp32 noise); the covariance
+    output is zero; the ray gradient against float64 / float32 autograd through the oracle with the covariance replaced by a constant."""
+    from snerf_amd import ops
+    r = _pose_rays(n, 11 + S)
+    g = torch.Generator().manual_seed(S + 7)
+    s = torch.sort(torch.rand(n, S + 1, generator=g), -1).values
+    s[:, 0], s[:, -1] = 0.0, 1.0
+    c = lambda t: t.detach().cuda().contiguous()
+    args = [c(s), c(r["origins"]), c(r["directions"]), c(r["radii"]).reshape(-1), c(r["near"]).reshape(-1), c(r["far"]).reshape(-1)]
+    flag = (1 if cone else 0) | 2
+    out = torch.empty(n * S, 6 * deg + 4, device="cuda"); mo = torch.empty(n * S, 3, device="cuda"); co = torch.full((n * S, 3), 7.0, device="cuda")
+    ops.mip_encode(*args, flag, 0, deg, out, None, 6 * deg + 4, ops.F32, means_out=mo, covs_out=co)
+    assert float(co.abs().max()) == 0.0
+    want = om.integrated_pos_enc(mo.cpu().reshape(n, S, 3), torch.zeros(n, S, 3), 0, deg).reshape(n * S, 6 * deg)
+    assert float((out[:, :6 * deg].cpu() - want).abs().max()) <= 2e-6 and bool((out[:, 6 * deg:] == 0).all())
+    plain = torch.empty_like(out)
+    ops.mip_encode(*args, flag & 1, 0, deg, plain, None, 6 * deg + 4, ops.F32)
+    assert float((plain - out).abs().max()) > 0.1                                      # (the damped features differ)
+    dE = torch.randn(n * S, 6 * deg + 4, generator=g)
+
+    def autograd(dt):
+        o, d = r["origins"].to(dt).clone().requires_grad_(True), r["directions"].to(dt).clone().requires_grad_(True)
+        fm, fc = om.sample2enc(s.to(dt), o, d, r["radii"].to(dt), r["near"].to(dt), r["far"].to(dt), "cone" if cone else "cylinder", 0)
+        enc = om.integrated_pos_enc(fm, torch.zeros_like(fc), 0, deg).reshape(-1, 6 * deg)
+        (enc * dE[:, :6 * deg].to(dt)).sum().backward()
+        return o.grad, d.grad
+    (o32, d32), (o64, d64) = autograd(torch.float32), autograd(torch.float64)
+    go, gd = ops.mip_encode_bwd(*args, flag, 0, deg, c(dE))
+    for got, ref32, ref64, what in ((go, o32, o64, "origins"), (gd, d32, d64, "directions")):
+        scale = ref64.abs().max(dim=-1).values
+        err = (got.cpu().double() - ref64).abs().max(dim=-1).values / scale
+        noise = (ref32.double() - ref64).abs().max(dim=-1).values / scale
+        assert float(err.max()) <= 3 * float(noise.max()) + 2e-5 and float(err.median()) <= 3 * float(noise.median()) + 2e-5, (what, float(err.max()), float(noise.max()))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n,S,cone,deg", [(130, 64, True, 16), (37, 127, False, 10)])
 def test_mip_encode_warp_bwd_vs_oracle_autograd(n, S, cone, deg):
     """the same gradient through the view-centred warp of an fn = 0 model (mip.py:367-369 fn1, :323-340 Jacobi_f): snerf_mip_encode_warp_bwd

@@ -434,6 +434,37 @@ def test_mipnerf_pose_refinement_through_the_view_centred_warp(backend, golden):
         assert float(ref_g.abs().max()) > 0 and err <= 3e-3 * float(ref_g.abs().max()), (k, err, float(ref_g.abs().max()))
 
 
+def test_mipnerf_disable_integration(backend, golden):
+    """MipNerfModel(disable_integration=1) -- the encoders zero the covariances (bit 1 of the kernels' `cone` argument), forward and
+    pose-refinement backward -- against the reference model's own outputs, parameter gradients and ray gradients (g31)."""
+    from snerf_amd import mipnerf
+    g = golden("g31_no_integration")
+    S0, P1, hidden = int(g["S0"]), int(g["P1"]), int(g["hidden"])
+    m = mipnerf.MipNerfModel(n_samples=S0, N_fine=P1, no_warp_sample=0, disable_integration=1, ray_shape="cone", fn=1, radius=3., transform_idx=0, real=True,
+                             rgb_layer=3, hidden_layer=hidden, density_noise=0., max_deg_point=16, proposal_hidden_layer=64,
+                             proposal_loss=True, compute="f32", device=DEV)
+    names = [str(k) for k in g["param_names"]]
+    assert list(m.state_dict().keys()) == names
+    m.load_state_dict(common.fill_state_dict_({k: torch.empty(tuple(g["grad." + k].shape)) for k in names}))
+    rays = {k: g[k].to(DEV) for k in mipnerf.Rays._fields}
+    for k in ("origins", "directions", "viewdirs"):
+        rays[k] = rays[k].clone().requires_grad_(True)
+    ret = m(mipnerf.Rays(**rays), False, False, 0.)
+    # (un-damped 2^15 x features: fp32 noise of the means is 1e-4 in the outputs and per cent in the gradients -- see test_g31_disable_integration;
+    # the encoder itself is held to 2e-6 on its own means by test_mip_encode_without_integration_fwd_and_bwd)
+    close(ret[1][0], g["rgb"], 0, 5e-4, "rgb"); close(ret[1][1], g["dist1"], 5e-4, 0, "distance"); close(ret[1][2], g["acc1"], 0, 5e-4, "acc")
+    close(ret[0][1], g["dist0"], 5e-4, 0, "proposal distance"); close(ret[1][4], g["s1"], 0, 5e-4, "fine fence posts")
+    loss = (ret[1][0] * g["w_rgb"].to(DEV)).sum() + 0.05 * (ret[1][1] * g["w_d1"].to(DEV)).sum() + 0.05 * (ret[0][1] * g["w_d0"].to(DEV)).sum()
+    loss.backward()
+    named = dict(m.named_parameters())
+    for k in names:
+        got, want = named[k].grad.detach().cpu(), g["grad." + k]
+        assert float((got - want).norm() / (want.norm() + 1e-20)) < 0.12, k
+    for k in ("origins", "directions", "viewdirs"):
+        ref_g = g["g_" + k]
+        assert float(ref_g.abs().max()) > 0 and float((rays[k].grad.cpu() - ref_g).norm() / ref_g.norm()) < (0.02 if k == "viewdirs" else 0.5), k
+
+
 def test_mip_trainer_passes_the_view_centre_of_the_fn0_warp(backend, golden):
     """MipTrainer on an fn = 0 model: the trainer calls model._run directly, so the warp centre the reference hands to every
     forward (train.py:36,112) has to come through step(viewc=...) / capture(viewc=...).  Without one the step refuses to run instead of

@@ -10,7 +10,9 @@ for spec in "fetch FETCH_SIZE" "write WRITE_SIZE"; do
   timeout -k 5 200 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/g/$tag -o p -- python $ROOT/tools/bench_grid.py --once > /dev/null 2>&1 < /dev/null
 done
 cd $ROOT
-{ for k in "g3_fwd_kernelIDF16_Li4ELi0" "g3_bin_emit_kernelIDF16_Li4ELi1ELb1" "g3_bin_emit_kernelIDF16_Li4ELi0" "zip_bin_accumulate_kernel<4, true, float, true>" "grid_fwd_kernel<__half, 3, 4>" "grid_bwd_kernel<__half, 3, 4>"; do python tools/pmc_summary.py $O/g "$k"; done; } > $O/summary.txt 2>&1
+# (per launch: the backward runs its writer / accumulate once per (level, chunk) -- 30 launches at the default 1 GB workspace -- the count once per level,
+# the transposition once per group of levels: pmc_summary.py prints the AVERAGE launch and the number of dispatches it saw)
+{ for k in "g3_fwd_kernelIDF16_Li4ELi0" "g3_write_staged_kernelIDF16_Li4ELb1" "g3_accumulate_kernel<4, true, float>" "g3_count_kernel" "g3_transpose_kernel" "grid_fwd_kernel<__half, 3, 4>" "grid_bwd_kernel<__half, 3, 4>"; do python tools/pmc_summary.py $O/g "$k"; done; } > $O/summary.txt 2>&1
 python - <<'PY'
 import json, os, re
 root = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
@@ -23,7 +25,7 @@ def block(pat):
 out = {}
 f, w = block("g3_fwd_kernelIDF16_Li4ELi0")
 if f is not None and w is not None:
-    out["grid_encoder_fwd"] = {"bytes": f + w, "bytes_upper": 2 * f + w, "source": os.environ.get("PMC_SOURCE", "profiles/r5_x_grid_encoder_pmc.txt"),
+    out["grid_encoder_fwd"] = {"bytes": f + w, "bytes_upper": 2 * f + w, "source": os.environ.get("PMC_SOURCE", "profiles/r6_x_grid_encoder_pmc.txt"),
         "how": "FETCH_SIZE (one 64-B request per gathered row: lower bound; x2 if the requests are 128 B) + WRITE_SIZE, rocprofv3 --pmc, 14 680 064 points"}
 json.dump(out, open(os.path.join(root, "gpurun_out/pmc_grid/roofline_traffic_grid.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
