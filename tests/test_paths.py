@@ -436,7 +436,12 @@ def test_mipnerf_pose_refinement_through_the_view_centred_warp(backend, golden):
 
 def test_mipnerf_disable_integration(backend, golden):
     """MipNerfModel(disable_integration=1) -- the encoders zero the covariances (bit 1 of the kernels' `cone` argument), forward and
-    pose-refinement backward -- against the reference model's own outputs, parameter gradients and ray gradients (g31)."""
+    pose-refinement backward -- against the reference model's own outputs, parameter gradients and ray gradients (g31).
+    Without the exp(-var / 2) damping the 2^15 x features reach the network at full amplitude: one ulp of a contracted mean moves their phase
+    by 2e-3 rad, and the REFERENCE's fp32 evaluation itself sits 1.5e-3 (distance) from the float64 evaluation of the same formulas.  So the
+    yardstick is the float64 oracle: every output / gradient must be as close to it as the reference's own fp32 result is, within a factor
+    of 5 (measured: 3.7 at most on the GPU -- the fine fence posts --, 1.0 emulated).  The encoder alone is held to 2e-6 on its own means by
+    test_mip_encode_without_integration_fwd_and_bwd; the branch itself differs from the default path by 1e-3 .. 1e-1."""
     from snerf_amd import mipnerf
     g = golden("g31_no_integration")
     S0, P1, hidden = int(g["S0"]), int(g["P1"]), int(g["hidden"])
@@ -445,24 +450,36 @@ def test_mipnerf_disable_integration(backend, golden):
                              proposal_loss=True, compute="f32", device=DEV)
     names = [str(k) for k in g["param_names"]]
     assert list(m.state_dict().keys()) == names
-    m.load_state_dict(common.fill_state_dict_({k: torch.empty(tuple(g["grad." + k].shape)) for k in names}))
+    sd = common.fill_state_dict_({k: torch.empty(tuple(g["grad." + k].shape)) for k in names})
+    m.load_state_dict(sd)
     rays = {k: g[k].to(DEV) for k in mipnerf.Rays._fields}
     for k in ("origins", "directions", "viewdirs"):
         rays[k] = rays[k].clone().requires_grad_(True)
     ret = m(mipnerf.Rays(**rays), False, False, 0.)
-    # (un-damped 2^15 x features: fp32 noise of the means is 1e-4 in the outputs and per cent in the gradients -- see test_g31_disable_integration;
-    # the encoder itself is held to 2e-6 on its own means by test_mip_encode_without_integration_fwd_and_bwd)
-    close(ret[1][0], g["rgb"], 0, 5e-4, "rgb"); close(ret[1][1], g["dist1"], 5e-4, 0, "distance"); close(ret[1][2], g["acc1"], 0, 5e-4, "acc")
-    close(ret[0][1], g["dist0"], 5e-4, 0, "proposal distance"); close(ret[1][4], g["s1"], 0, 5e-4, "fine fence posts")
     loss = (ret[1][0] * g["w_rgb"].to(DEV)).sum() + 0.05 * (ret[1][1] * g["w_d1"].to(DEV)).sum() + 0.05 * (ret[0][1] * g["w_d0"].to(DEV)).sum()
     loss.backward()
+    # the float64 evaluation of the same formulas (oracle/mip.py)
+    p64 = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    r64 = {k: g[k].double() for k in mipnerf.Rays._fields}
+    for k in ("origins", "directions", "viewdirs"):
+        r64[k].requires_grad_(True)
+    ref = om.mipnerf_forward(p64, r64, S0, P1, disable_integration=True)
+    ((ref[1][0] * g["w_rgb"].double()).sum() + 0.05 * (ref[1][1] * g["w_d1"].double()).sum() + 0.05 * (ref[0][1] * g["w_d0"].double()).sum()).backward()
+    rel = lambda a, b: float(((a.detach().double().cpu() - b.detach()).abs() / b.detach().abs().clamp(min=1e-3)).max())
+    for what, got, want64, gold in (("rgb", ret[1][0], ref[1][0], g["rgb"]), ("distance", ret[1][1], ref[1][1], g["dist1"]), ("acc", ret[1][2], ref[1][2], g["acc1"]),
+                                    ("proposal distance", ret[0][1], ref[0][1], g["dist0"]), ("fine fence posts", ret[1][4], ref[1][4], g["s1"])):
+        noise = rel(gold, want64)
+        assert rel(got, want64) <= 5 * noise + 2e-5, (what, rel(got, want64), noise)
+    plain = om.mipnerf_forward(sd, {k: g[k] for k in mipnerf.Rays._fields}, S0, P1)      # the default path: 3 % / 2 % / 4 % away in distance / proposal distance / fence posts
+    assert rel(plain[1][1], ref[1][1]) > 3 * (5 * rel(g["dist1"], ref[1][1]) + 2e-5) and rel(plain[1][4], ref[1][4]) > 1e-2
+    l2 = lambda a, b: float((a.detach().double().cpu() - b.detach()).norm() / (b.detach().norm() + 1e-30))
     named = dict(m.named_parameters())
     for k in names:
-        got, want = named[k].grad.detach().cpu(), g["grad." + k]
-        assert float((got - want).norm() / (want.norm() + 1e-20)) < 0.12, k
+        noise = l2(g["grad." + k], p64[k].grad)
+        assert l2(named[k].grad, p64[k].grad) <= 5 * noise + 2e-3, (k, l2(named[k].grad, p64[k].grad), noise)
     for k in ("origins", "directions", "viewdirs"):
-        ref_g = g["g_" + k]
-        assert float(ref_g.abs().max()) > 0 and float((rays[k].grad.cpu() - ref_g).norm() / ref_g.norm()) < (0.02 if k == "viewdirs" else 0.5), k
+        noise = l2(g["g_" + k], r64[k].grad)
+        assert float(g["g_" + k].abs().max()) > 0 and l2(rays[k].grad, r64[k].grad) <= 5 * noise + 2e-3, (k, l2(rays[k].grad, r64[k].grad), noise)
 
 
 def test_mip_trainer_passes_the_view_centre_of_the_fn0_warp(backend, golden):

@@ -19,8 +19,8 @@ timeout -k 5 400 python tools/bench_zip.py --rays 65536 2>&1 | tail -1 > $O/path
 ( cd /tmp && export TMPDIR=/tmp && timeout -k 5 300 rocprofv3 --kernel-trace --output-format csv -d $ROOT/$O/prof_z -o b -- python $ROOT/tools/bench_zip.py --rays 65536 --steps 8 --train-only > /dev/null 2>&1 < /dev/null )
 python tools/rocprof_summary.py $(find $O/prof_z -name "b_kernel_trace.csv") > $O/pathC_train_kernel_stats.txt; head -12 $O/pathC_train_kernel_stats.txt | cut -c1-160
 bash tools/pmc_gemm_traffic.sh > $O/gemm_nt8p_traffic.txt 2>&1; tail -12 $O/gemm_nt8p_traffic.txt
-PMC_SOURCE=profiles/r5_x_pathC_pathB_pmc.txt bash tools/pmc_paths.sh > $O/pmc_paths.log 2>&1; cp gpurun_out/pmc_paths/summary.txt $O/pathC_pathB_pmc.txt; cp gpurun_out/pmc_paths/roofline_traffic_paths.json $O/; cat $O/roofline_traffic_paths.json
-PMC_SOURCE=profiles/r5_x_grid_encoder_pmc.txt bash tools/pmc_grid.sh > $O/pmc_grid.log 2>&1; cp gpurun_out/pmc_grid/summary.txt $O/grid_encoder_pmc.txt; cat gpurun_out/pmc_grid/roofline_traffic_grid.json
+PMC_SOURCE=profiles/r6_x_pathC_pathB_pmc.txt bash tools/pmc_paths.sh > $O/pmc_paths.log 2>&1; cp gpurun_out/pmc_paths/summary.txt $O/pathC_pathB_pmc.txt; cp gpurun_out/pmc_paths/roofline_traffic_paths.json $O/; cat $O/roofline_traffic_paths.json
+PMC_SOURCE=profiles/r6_x_grid_encoder_pmc.txt bash tools/pmc_grid.sh > $O/pmc_grid.log 2>&1; cp gpurun_out/pmc_grid/summary.txt $O/grid_encoder_pmc.txt; cat gpurun_out/pmc_grid/roofline_traffic_grid.json
 python - <<'PY'
 import json
 a = json.load(open("gpurun_out/final/roofline_traffic_paths.json")); a.update(json.load(open("gpurun_out/pmc_grid/roofline_traffic_grid.json")))
