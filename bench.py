@@ -799,7 +799,7 @@ def main():
     ap.add_argument("--rays", type=int, default=4096, help="rays per GPU per step (weak scaling) / global rays per step (--scaling strong)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --rays per GPU whatever N (default); strong: the reference's --rays-ray batch split across the N GPUs")
-    ap.add_argument("--compute", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--compute", default="bf16", choices=["bf16", "f32", "bf16x3", "bf16x3_fwd"])
     ap.add_argument("--variant", type=int, default=8, help="NT GEMM variant: 8 = persistent 8-phase 256x256 (default), 4 = 8-phase, 1 = 256x256 block-issue, 0 = 128x128")
     ap.add_argument("--no-frame", action="store_true", help="skip the 1600x900 frame render")
     ap.add_argument("--no-cpu", action="store_true", help="skip the host-CPU baseline")
@@ -954,9 +954,9 @@ def main():
         ms_step = elapsed / args.steps * 1e3
         rays_per_s = world * n * args.steps / elapsed
         achieved = alg_nt / (gemm_ms * 1e-3) / 1e12
-        peak = PEAK_BF16_TFLOPS if args.compute == "bf16" else 157.3
+        peak = 157.3 if args.compute == "f32" else PEAK_BF16_TFLOPS
         traffic, traffic_src = roofline_traffic(args.compute, args.variant)
-        roofline = {"bound": "mfma", "kernel": {8: "gemm_nt8p_kernel (bf16, 256x256 persistent 8-phase)", 4: "gemm_nt8_kernel (bf16, 256x256 8-phase)", 1: "gemm_nt_kernel<bf16,256,256,2,4>"}.get(args.variant, "gemm_nt_kernel<bf16,128,128,2,2>") if args.compute == "bf16" else "gemm_nt_kernel<f32,128,128,2,2>",
+        roofline = {"bound": "mfma", "kernel": {8: "gemm_nt8p_kernel (bf16, 256x256 persistent 8-phase)", 4: "gemm_nt8_kernel (bf16, 256x256 8-phase)", 1: "gemm_nt_kernel<bf16,256,256,2,4>"}.get(args.variant, "gemm_nt_kernel<bf16,128,128,2,2>") if args.compute == "bf16" else ("gemm_nt_kernel<f32,128,128,2,2>" if args.compute == "f32" else "gemm_nt8p_kernel<.., SPLIT> (three bf16 MFMA passes per product; executed work)"),
                     "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                     "traffic": traffic, "traffic_source": traffic_src,
                     "launches_per_step": launches, "avg_launch_ms": round(gemm_ms / launches, 4), "kernel_ms_per_step": round(gemm_ms, 3),
@@ -1139,6 +1139,25 @@ def main():
                                                "frac": round(ax3 / PEAK_BF16_TFLOPS, 4), "launches_per_step": lx3},
                                   "note": "compute='bf16x3': 16-bit mantissas through every GEMM; held to the same 1e-4 rgb / depth bounds as the exact-fp32 mode (parity read-out below)"}
         del tx3, mx3
+        torch.cuda.empty_cache()
+        # the same three-pass FORWARD (bit-identical renders and losses) with a ONE-pass bf16 backward: compute="bf16x3_fwd"
+        mxf = build_model("bf16x3_fwd", device)
+        mxf.load_state_dict({k: v.clone() for k, v in model.state_dict().items()})
+        txf = MipTrainer(mxf, lr=5e-4)
+        for _ in range(2):
+            txf.step(rays, tgt, depth, conf)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            txf.step(rays, tgt, depth, conf)
+        torch.cuda.synchronize()
+        dtxf = (time.perf_counter() - t0) / 5
+        out["split_fwd_mode"] = {"rays_per_s": round(n / dtxf, 1), "ms_per_step": round(dtxf * 1e3, 2), "steps": 5,
+                                 "speedup_vs_split_bf16_mode": round(dtx3 / dtxf, 3),
+                                 "note": "compute='bf16x3_fwd': the split-bf16 forward (renders / losses bit-identical to compute='bf16x3', inside the 1e-4 contract) with "
+                                         "single-pass bf16 data and weight gradients (hi halves of the saved activations); gradient error between the two pure modes "
+                                         "(tests/test_paths.py::test_mipnerf_split_forward_plain_backward)"}
+        del txf, mxf
         torch.cuda.empty_cache()
 
     # ---- parity read-out + host-CPU baseline (rank 0, N = 1 only)

@@ -55,7 +55,9 @@ int snerf_debug_lds_scribble(int seed, void* stream);
  * bytes of the activation and DMA-able ahead of use.  Only the persistent kernel implements them (bf16, variant 8,
  * N % 256 == 0, K >= 128, 16-byte aligned Y rows); other launches return SNERF_ERR_ARG.
  * variant (low nibble): 0 = 128x128 tile, 1 = 256x256 tile, 4 = 256x256 8-phase, 8 = 256x256 persistent 8-phase (bf16,
- * N % 256 == 0, K >= 128, 16-byte epilogue; other shapes fall back to 4, then 0); higher bits = ablation switches. */
+ * N % 256 == 0, K >= 128, 16-byte epilogue; other shapes fall back to 4, then 0); higher bits = ablation switches, except
+ * bit 14 (0x4000; dtype bf16, ACT_MASK): `aux` is an activation a split-bf16 (SNERF_DT_BF16X3) forward saved -- interleaved hi / lo per 64
+ * columns -- while A, W and Y are plain bf16: the single-pass data gradient behind a three-pass forward (compute="bf16x3_fwd"). */
 int snerf_linear_fwd(const void* A, long lda, const void* W, long ldw, const float* bias, void* Y, long ldy,
                      const void* aux, long ldaux, float* colsum, float* colsum_ws, int M, int N, int K, int n_store,
                      int act, int dtype, int out_f32, int variant, void* stream);
@@ -64,7 +66,8 @@ int snerf_linear_fwd(const void* A, long lda, const void* W, long ldw, const flo
  * (autograd of nn.Linear in the reference; train.py:213 loss.backward()).  `zeros` = >=16 bytes of
  * device zeros (source for rows past M).  variant bit 1 (bf16, N and K multiples of 128): transposing LDS reads; bit 2 (bf16,
  * N % 256 == 0, K >= 256): the 256 x 256 8-phase kernel; bits 16 / 32 / 64: probe only -- 1024 / 2048 / 4096 M-slices for the
- * 128 x 128 kernel instead of its default of about 512 (tools/gemm_tn_slices_probe.py). */
+ * 128 x 128 kernel instead of its default of about 512 (tools/gemm_tn_slices_probe.py); bit 14 (0x4000; dtype bf16): X is an activation a
+ * split-bf16 forward saved ([M, >= 2 K], hi / lo interleaved per 64 columns) and its hi half is multiplied, K = its LOGICAL width, dZ plain bf16. */
 int snerf_linear_wgrad(const void* Z, long ldz, const void* X, long ldx, float* dW, long ldw, const void* zeros,
                        int M, int N, int K, int n_valid, int k_valid, int dtype, int variant, void* stream);
 

@@ -51,6 +51,9 @@ struct GemmNT {
   // simply walks 3 K / 64 VIRTUAL k-tiles: tile v reads W's physical tile v and A's physical tile 2 (v / 3) + (v % 3 == 1).
   // K in this struct is the virtual reduction length (3 x the logical one).
   int split;
+  // Plain (bf16) data gradient behind a split-bf16 FORWARD (compute="bf16x3_fwd"): the ACT_MASK source `aux` is a saved activation in the
+  // interleaved layout above -- logical column c is read at physical column (c >> 6) * 128 + (c & 63), its hi half.
+  int aux_split;
 };
 __device__ __forceinline__ int split_a_tile(int v) { return 2 * (v / 3) + (v % 3 == 1 ? 1 : 0); }
 #ifndef SNERF_PROBE
@@ -183,7 +186,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x16 (&acc)[BM / 
           frag_t val = *(const frag_t*)(my + row * PITCH + pch * 16);
           if (m < p.M && ncol < p.n_store && !DBG(p, 4)) {
             if (p.act == ACT_MASK) {
-              const frag_t a8 = *(const frag_t*)(auxp + (long)m * p.ldaux + pcol);
+              const frag_t a8 = *(const frag_t*)(auxp + (long)m * p.ldaux + (p.aux_split ? ((ncol >> 6) << 7) + (ncol & 63) : pcol));
 #pragma unroll
               for (int e = 0; e < EPC; ++e) if (!(up16<F16>(a8[e]) > 0.f)) val[e] = (T)0.f;
             }
@@ -240,7 +243,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x16 (&acc)[BM / 
         }
         const bool full = nb + 3 < p.n_store;
         if (p.act == ACT_MASK) {
-          const T* ap = aux + (long)m * p.ldaux + nb;
+          const T* ap = aux + (long)m * p.ldaux + (p.aux_split ? ((nb >> 6) << 7) + (nb & 63) : nb);
           if (full && vec_ok) {
             if constexpr (sizeof(T) == 2) {
               const bf16x4 a4 = *(const bf16x4*)ap;
@@ -1294,8 +1297,11 @@ extern "C" int snerf_linear_fwd(const void* A, long lda, const void* W, long ldw
   if (det && colsum != nullptr && !fast) return SNERF_ERR_ARG;   // the direct-store epilogue adds its column sums with atomics
   if (split && !fast && !out_f32) return SNERF_ERR_ARG;          // the interleaved output exists only in the 16-byte epilogues
   if (split && out_f32 && (act == ACT_MASK || colsum != nullptr)) return SNERF_ERR_ARG;
+  // variant bit 14: `aux` (ACT_MASK) is a split-bf16 activation, the operands are plain bf16 (GemmNT::aux_split)
+  const int aux_split = (variant >> 14) & 1;
+  if (aux_split && (split || f16 || dtype != SNERF_DT_BF16 || act != ACT_MASK)) return SNERF_ERR_ARG;
   GemmNT p{A, lda, W, ldw, bias, Y, ldy, aux, ldaux, colsum, M, N, K, n_store, act, out_f32, vec, colsum_ws, fast, det, ((variant >> 4) & 7) | ((variant >> 10) & 8),
-           (variant >> 9) & 15, split};                          // (PROBE builds: variant bit 13 = ablation bit 8; bits 9..12 = stagger)
+           (variant >> 9) & 15, split, aux_split};               // (PROBE builds: variant bit 13 = ablation bit 8; bits 9..12 = stagger)
   variant &= 15;
   hipStream_t s = (hipStream_t)stream;
   // variant: 0 = 128x128 block-issue, 1 = 256x256 block-issue,
@@ -1303,7 +1309,8 @@ extern "C" int snerf_linear_fwd(const void* A, long lda, const void* W, long ldw
   //          8 = 256x256 persistent 8-phase (bf16, N % 256 == 0, K >= 128, 16-byte epilogue; else as variant 4)
   // the bit-mask activations exist only in the persistent kernel (the mask layout is its unit geometry)
   const bool p8 = dtype == SNERF_DT_BF16 && (variant & 8) && N % 256 == 0 && K >= 128 && fast && !(colsum != nullptr && act == ACT_RELU) &&
-                  (lda * 2 * 256 < (1L << 31)) && (ldw * 2 * 256 < (1L << 31)) && !(split && (act == ACT_MASK || (colsum != nullptr && act == ACT_RELU_BITS)));
+                  (lda * 2 * 256 < (1L << 31)) && (ldw * 2 * 256 < (1L << 31)) && !(split && (act == ACT_MASK || (colsum != nullptr && act == ACT_RELU_BITS))) &&
+                  !aux_split;                                     // (the persistent kernel's own bf16-mask loads know the plain layout only)
   if (act >= ACT_RELU_BITS && !(p8 && (long)((M + 255) / 256) * 8 * (N / 64) * 256 < (1L << 31)))
     return SNERF_ERR_ARG;
   if (f16) {
@@ -1339,7 +1346,9 @@ struct GemmTN {
   // PHYSICAL matrices (the 128 x 128 kernel: all four hi / lo combinations of every 64 x 64 block, lo.lo is noise-level and harmless; the
   // 8-phase kernel deals X's blocks so that the lo.lo quadrant is the same phase for every wave and skips it) and the output index
   // maps the physical (n', k') back to the logical (n, k) = ((n' >> 7) << 6 | n' & 63, ...): the atomics add the combinations up.
-  int split;
+  int split;          // 1: as above; 2: dZ plain bf16, X a split-bf16 activation of which only the hi half is multiplied (the single-pass
+                      //    weight gradient behind a split-bf16 forward, compute="bf16x3_fwd"): K = X's LOGICAL width, logical column c is read at
+                      //    physical column (c >> 6) * 128 + (c & 63); everything else as the plain bf16 launch
   float* part;        // deterministic mode: every (tile, M slice) stores its partial tile at part + slice * part_stride + n * part_ld + k
   long part_stride;   // (no atomics); tn_fold_kernel adds the slices in a fixed order.  nullptr: fp32 atomics straight into dW
   int part_ld;
@@ -1389,6 +1398,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
   const int sch = TR ? (lch ^ (4 * (lrow & 3))) : lch;
   int zc = n0 + sch * EPC; zc = zc < p.N ? zc : p.N - EPC;
   int xc = k0 + sch * EPC; xc = xc < p.K ? xc : p.K - EPC;
+  if (p.split == 2) xc = ((xc >> 6) << 7) | (xc & 63);    // the hi half of a split-bf16 activation
 
   auto issue = [&](int st, int stage) {
     char* sZ = smem + stage * 2 * TILEB;
@@ -1497,11 +1507,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       int k = k0 + wk * 64 + j * 32 + (lane & 31);
-      if (p.split) k = ((k >> 7) << 6) | (k & 63);
+      if (p.split == 1) k = ((k >> 7) << 6) | (k & 63);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (p.split) n = ((n >> 7) << 6) | (n & 63);
+        if (p.split == 1) n = ((n >> 7) << 6) | (n & 63);
         if (n < p.n_valid && k < p.k_valid) {
           if (p.part != nullptr) p.part[(long)slice * p.part_stride + (long)n * p.part_ld + k] = acc[i][j][r];
           else atomicAdd(p.dW + (long)n * p.ldw + k, acc[i][j][r]);
@@ -1540,10 +1550,12 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(GemmTN p) {
   const int rows = min(p.M, mbeg + p.m_chunk) - mbeg;
   const int KT = (rows + 63) >> 6;
   const T* __restrict__ Z = (const T*)p.Z + (long)mbeg * p.ldz + n0;
-  const T* __restrict__ X = (const T*)p.X + (long)mbeg * p.ldx + k0;
+  const bool xhi = !SPLIT && p.split == 2;             // X: the hi half of a split-bf16 activation (logical K; see GemmTN::split)
+  const T* __restrict__ X = (const T*)p.X + (long)mbeg * p.ldx + (xhi ? 2 * k0 : k0);
   // readable bytes from the tile's first element: up to the last VALID column of the slice's last row (the operands may be
   // column ranges of wider buffers, so nothing past that is known to be mapped)
-  const int zbytes = (rows - 1) * (int)p.ldz * 2 + (p.N - n0) * 2, xbytes = (rows - 1) * (int)p.ldx * 2 + (p.K - k0) * 2;
+  const int xcols = xhi ? ((p.K - 1) >> 6) * 128 + ((p.K - 1) & 63) + 1 - 2 * k0 : p.K - k0;    // physical columns from the tile's first one to the last valid one
+  const int zbytes = (rows - 1) * (int)p.ldz * 2 + (p.N - n0) * 2, xbytes = (rows - 1) * (int)p.ldx * 2 + xcols * 2;
   const int zstep = 64 * (int)p.ldz * 2, xstep = 64 * (int)p.ldx * 2;
 
   // ---- staging stream: wave w owns pieces 2w, 2w+1 (4 rows x 256 B) of every half-tile -------------------------------
@@ -1555,7 +1567,7 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(GemmTN p) {
   // dZ half 1 x X half 1 is then lo . lo for every wave and is skipped: 3/4 of the MFMAs instead of 4/4.
   constexpr int xhalf = SPLIT ? 128 : 64;              // byte offset of X half 1
   const int zcol = ((lc >> 6) * 128 + (lc & 63)) * 2;
-  const int xcol = SPLIT ? (((lc >> 6) * 128) + ((lc >> 5) & 1) * 32 + (lc & 31)) * 2 : ((lc >> 5) * 64 + (lc & 31)) * 2;
+  const int xcol = SPLIT ? (((lc >> 6) * 128) + ((lc >> 5) & 1) * 32 + (lc & 31)) * 2 : ((lc >> 5) * (xhi ? 128 : 64) + (lc & 31)) * 2;
   int zrel[2], xrel[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -1812,13 +1824,16 @@ static int wgrad_launch(const void* Z, long ldz, const void* X, long ldx, float*
     if (N % 128 != 0 || K % 128 != 0 || ws != nullptr) return SNERF_ERR_ARG;        // (no deterministic fold in this mode)
     dtype = SNERF_DT_BF16;
   }
+  // variant bit 14 (dtype bf16): X is a split-bf16 activation [M, >= 2 K] of which the hi half is multiplied; K its LOGICAL width (GemmTN::split == 2)
+  const int xhi = (variant >> 14) & 1;
+  if (xhi && (split || dtype != SNERF_DT_BF16)) return SNERF_ERR_ARG;
   const bool f16 = dtype == 2;                        // SNERF_DT_F16: the bf16 kernels with the fp16 MFMA
   if (f16) dtype = SNERF_DT_BF16;
   const int epc = dtype == SNERF_DT_F32 ? 4 : 8;
   if (N < epc || K < epc || N % epc || K % epc || ldz % epc || ldx % epc || zeros == nullptr) return SNERF_ERR_ARG;
   const TnPlan pl = tn_plan(M, N, K, ldz, ldx, dtype, variant);
   if (ws != nullptr && ws_floats < pl.part_stride * pl.slices) return SNERF_ERR_ARG;
-  GemmTN p{Z, ldz, X, ldx, dW, ldw, zeros, M, N, K, n_valid, k_valid, pl.m_chunk, 0, pl.slices, split, ws, pl.part_stride, pl.part_ld};
+  GemmTN p{Z, ldz, X, ldx, dW, ldw, zeros, M, N, K, n_valid, k_valid, pl.m_chunk, 0, pl.slices, split ? 1 : (xhi ? 2 : 0), ws, pl.part_stride, pl.part_ld};
   if (pl.use8) {
     static bool attr_set = false;
     if (!attr_set) {

@@ -74,8 +74,9 @@ class MipNerfModel(_ArenaModule):
         self._setup_arena(shapes, torch.device(device))
         dt = _dt(compute)
         self.dt = dt
-        self.nerf = MipNerfNet(self.arena, "mlp.", dt, hidden_layer, 8, 4, fd, cd, rgb_layer, 128, variant, semantic_classes=self.sem_classes)
-        self.prop = MipProposalNet(self.arena, "proposal.", dt, proposal_hidden_layer, 4, fd, variant)
+        bp = compute == "bf16x3_fwd"          # three-pass split-bf16 forward (renders inside the fp32 contract), one-pass bf16 backward
+        self.nerf = MipNerfNet(self.arena, "mlp.", dt, hidden_layer, 8, 4, fd, cd, rgb_layer, 128, variant, semantic_classes=self.sem_classes, bwd_plain=bp)
+        self.prop = MipProposalNet(self.arena, "proposal.", dt, proposal_hidden_layer, 4, fd, variant, bwd_plain=bp)
         self.nerf.version_fn = self._param_version
         self.prop.version_fn = self._param_version
         with torch.no_grad():  # DenseBlock / heads: xavier-uniform weights (models.py:208,256-257), default-Linear biases

@@ -18,6 +18,8 @@ Design (MI355X-first, not a translation of nn.Linear chains):
     (column sums) into the data-gradient epilogue; weight gradients are
     accumulated with fp32 atomics straight into the flat gradient arena.
 """
+import contextlib
+
 import torch
 
 from . import ops
@@ -187,11 +189,17 @@ class _PackPlan:
 class _Net:
     """Shared machinery: packing, buffer helpers, layer calls."""
 
-    def __init__(self, arena: ParamArena, prefix: str, dt: int, variant: int = 8):
+    def __init__(self, arena: ParamArena, prefix: str, dt: int, variant: int = 8, bwd_plain: bool = False):
         self.a, self.pre, self.dt, self.variant = arena, prefix, dt, variant
         self.g = gran(dt)
         self.km = 2 if dt == ops.BF16X3 else 1           # physical columns per logical column of an activation buffer (split-bf16: hi / lo interleaved)
         self.tdt = ops.torch_dtype(dt)
+        # compute="bf16x3_fwd": the FORWARD in split-bf16 (three MFMA passes: renders inside the fp32 contract), the BACKWARD as ONE plain bf16
+        # pass per product -- data gradients on plain bf16 buffers with plainly packed W^T, weight gradients from the hi half of the saved
+        # split activations (snerf_linear_wgrad variant bit 14), ReLU masks from the forward's bit masks or the saved hi halves (bit 14 of
+        # snerf_linear_fwd).  The gradients then carry the bf16 mode's rounding (of exact forward values), at a third of the split backward.
+        self.bwd_plain = bool(bwd_plain) and dt == ops.BF16X3
+        self._in_plain_bwd = False
         self.dev = arena.flat.device
         self._packed_version = -1
         self.deterministic = False        # bit-reproducible gradients: partial tiles folded in a fixed order instead of fp32 atomics
@@ -214,26 +222,45 @@ class _Net:
             return self.a.index_image(self.pre + name + ".bias")
         return self.a.p[self.pre + name + ".bias"]
 
-    def _zeros(self, *shape, f32=False):
-        """operand buffer of a pack() method (recorded: its content becomes part of the network's gather map)"""
+    def _zeros(self, *shape, f32=False, plain=False):
+        """operand buffer of a pack() method (recorded: its content becomes part of the network's gather map).  `plain`: a compute-dtype
+        operand that stays ONE bf16 value per parameter in a split-bf16 network (the backward's W^T under `bwd_plain`)"""
         assert self._rec is not None, "pack() runs only while a plan is recorded"
         t = torch.zeros(*shape, dtype=torch.float64, device=self.dev)
         self._rec.append((t, torch.float32 if f32 else self.tdt))
+        if plain:
+            self._rec_plain.add(id(t))
         return t
+
+    @contextlib.contextmanager
+    def _bwd(self):
+        """the body of a backward(): under `bwd_plain` every helper below (buf / cs / head_grad / dgrad / wgrad / input_grad) works on plain
+        bf16 buffers while it runs; a no-op otherwise"""
+        if not self.bwd_plain:
+            yield
+            return
+        saved = (self.dt, self.km, self._in_plain_bwd)
+        self.dt, self.km, self._in_plain_bwd = ops.BF16, 1, True
+        try:
+            yield
+        finally:
+            self.dt, self.km, self._in_plain_bwd = saved
 
     def _build_plan(self, fill):
         """Run `fill()` (a pack method writing operands obtained from _zeros / returned as extra (image, dtype) pairs) on index images
         and turn every recorded operand into a view of a persistent pool + its slice of the gather map."""
         assert self.a.numel < (1 << 31) - 2
-        self._rec = []
+        self._rec, self._rec_plain = [], set()
         try:
             extra = fill() or []
             rec = self._rec + list(extra)
+            plain = self._rec_plain
         finally:
             self._rec = None
         plan = _PackPlan(self.a.flat)
         if self.km == 2:          # every compute-dtype operand of the per-layer plans is a GEMM weight [N, K]: its [hi | hi | lo] form
-            handles = [(id(img), plan.add(split_w_image(img) if dtype == self.tdt and img.dim() == 2 else img, dtype)) for img, dtype in rec]
+            handles = [(id(img), plan.add(split_w_image(img) if dtype == self.tdt and img.dim() == 2 and id(img) not in plain else img, dtype))
+                       for img, dtype in rec]
         else:
             handles = [(id(img), plan.add(img, dtype)) for img, dtype in rec]
         plan.finish()
@@ -286,7 +313,7 @@ class _Net:
         activation: rows = those input columns (padded to 128), cols = concat of each layer's outputs
         padded to the tile granularity (matches the [dZ_a | dZ_b] gradient buffer)."""
         cols = sum(roundup(self.W(n).shape[0], self.g) for n in parts)
-        out = self._zeros(roundup(cnt, 128), cols)
+        out = self._zeros(roundup(cnt, 128), cols, plain=self.bwd_plain)
         c = 0
         for n in parts:
             W = self.W(n)
@@ -298,7 +325,7 @@ class _Net:
         """like _pack_dgrad with a weight-column offset per layer: parts = [(layer, first weight column)]; used for the gradient
         w.r.t. an INPUT encoding that several layers read at different column positions (rows = the encoding's columns)."""
         cols = sum(roundup(self.W(n).shape[0], self.g) for n, _ in parts)
-        out = self._zeros(roundup(cnt, 128), cols)
+        out = self._zeros(roundup(cnt, 128), cols, plain=self.bwd_plain)
         c = 0
         for n, wc in parts:
             W = self.W(n)
@@ -365,16 +392,17 @@ class _Net:
             # deterministic mode and a destination the 16-byte epilogue does not cover (an unaligned view, n_store % 8 != 0): the
             # direct-store epilogue could only add its column sums with atomics (snerf_linear_fwd refuses the combination), so the
             # bias gradient comes from a fixed-order column sum of the stored data gradient instead
-            ops.linear_fwd(dZ, W, None, dX, K, n_store, act, self.dt, aux=mask, variant=self.variant)
+            ops.linear_fwd(dZ, W, None, dX, K, n_store, act, self.dt, aux=mask, variant=self.variant, aux_split=self._in_plain_bwd and mask is not None)
             ops.colsum_wide_f32(dX[:, :n_store].float(), n_store, colsum, deterministic=True)     # (any width; colsum_f32_det stops at 8 columns)
             return
         ops.linear_fwd(dZ, W, None, dX, K, n_store, act, self.dt,
-                       aux=mask, colsum=colsum, variant=self.variant, deterministic=self.deterministic)
+                       aux=mask, colsum=colsum, variant=self.variant, deterministic=self.deterministic,
+                       aux_split=self._in_plain_bwd and mask is not None)      # (the mask source is an activation the split forward saved)
 
     def wgrad(self, name, dZ, X, n_valid, k_valid, wcol=0):
         gw = self.gW(name)
         ops.linear_wgrad(dZ, X, gw[:, wcol:], n_valid, k_valid, self.dt, variant=3,   # 2: 8-phase 256x256 tiles where they fit, else 1: transposing LDS reads
-                         deterministic=self.deterministic)
+                         deterministic=self.deterministic, x_split_hi=self._in_plain_bwd)
 
     def head_grad(self, d_raw_f32, C):
         """fp32 head gradient [M,C] -> compute-dtype buffer padded to the tile granularity."""
@@ -677,8 +705,8 @@ class ClassicNeRFNet(_Net):
 class MipProposalNet(_Net):
     """proposal MLP: n_layers x (Linear+ReLU) width H, density head -> [M,1] fp32 (models.py:299-325)."""
 
-    def __init__(self, arena, prefix, dt, hidden=256, n_layers=4, feature_dim=96, variant=8):
-        super().__init__(arena, prefix, dt, variant)
+    def __init__(self, arena, prefix, dt, hidden=256, n_layers=4, feature_dim=96, variant=8, bwd_plain=False):
+        super().__init__(arena, prefix, dt, variant, bwd_plain)
         assert hidden % self.g == 0
         self.H, self.L, self.fd, self.Ew = hidden, n_layers, feature_dim, roundup(feature_dim, self.g)
         self.fused = True                 # inference through the fused register-resident kernel where it applies (fused_ok)
@@ -776,6 +804,10 @@ class MipProposalNet(_Net):
 
     def backward(self, d_raw_density, acts, want_input_grad=False):
         """-> None, or with `want_input_grad` the fp32 gradient [M, Ew] w.r.t. the encoded samples."""
+        with self._bwd():
+            return self._backward(d_raw_density, acts, want_input_grad)
+
+    def _backward(self, d_raw_density, acts, want_input_grad):
         H, M = self.H, d_raw_density.shape[0]
         self.colsum(d_raw_density, 1, self.gB("density_layer"))
         dz = self.head_grad(d_raw_density, 1)
@@ -810,8 +842,8 @@ class MipNerfNet(_Net):
              CB [M, H + Cw] = [bottleneck | view encoding (+pad)]."""
 
     def __init__(self, arena, prefix, dt, hidden=1024, n_layers=8, skip_layer=4, feature_dim=96, cond_dim=27,
-                 n_cond=3, cond_units=128, variant=8, semantic_classes=0):
-        super().__init__(arena, prefix, dt, variant)
+                 n_cond=3, cond_units=128, variant=8, semantic_classes=0, bwd_plain=False):
+        super().__init__(arena, prefix, dt, variant, bwd_plain)
         self.sc, self.Hs = int(semantic_classes), hidden // 2    # optional semantic head: trunk -> H/2 ReLU -> C (models.py:258-260)
         assert hidden % self.g == 0 and cond_units % self.g == 0 and n_layers > skip_layer + 1
         self.H, self.L, self.skip, self.fd, self.cd, self.nc, self.cu = hidden, n_layers, skip_layer, feature_dim, cond_dim, n_cond, cond_units
@@ -967,7 +999,12 @@ class MipNerfNet(_Net):
             self.fwd("sem1", S0, self.Hs, self.raw_sem, self.sc, ACT_NONE, out_f32=True)
         return raw_rgb, raw_d, ((acts, cacts, SKIP, CB, S0) if keep else None)
 
-    def backward(self, d_raw_rgb, d_raw_density, saved, d_raw_sem=None, want_input_grad=False, want_cond_grad=False, on_done=None):
+    def backward(self, *args, **kwargs):
+        """see _backward; under `bwd_plain` (compute="bf16x3_fwd") the whole pass runs as plain bf16 launches (_Net._bwd)"""
+        with self._bwd():
+            return self._backward(*args, **kwargs)
+
+    def _backward(self, d_raw_rgb, d_raw_density, saved, d_raw_sem=None, want_input_grad=False, want_cond_grad=False, on_done=None):
         """-> None, or with `want_input_grad` (dE fp32 [M, Ew], dV fp32 [M, Cw]): the gradients w.r.t. the IPE and view encodings;
         with `want_cond_grad` alone: dV (the appearance embedding's columns of the condition block need it in every training step).
         `on_done(names)`: called with a list of parameter-name prefixes (relative to this network) as soon as their gradients are final --

@@ -68,11 +68,15 @@ def zero_page(device):
 
 
 # ------------------------------------------------------------------ GEMMs ----
-def linear_fwd(A, W, bias, Y, K, n_store, act, dt, out_f32=False, aux=None, colsum=None, variant=0, deterministic=False):
+def linear_fwd(A, W, bias, Y, K, n_store, act, dt, out_f32=False, aux=None, colsum=None, variant=0, deterministic=False, aux_split=False):
     """Y[:, :n_store] = act(A[:, :K] @ W[:, :K]^T + bias); A/W/Y are 2-D views (row stride = ld).  `deterministic`: the bias-gradient
-    partials (`colsum`) are folded in a fixed order."""
+    partials (`colsum`) are folded in a fixed order.  `aux_split` (plain bf16 launch, ACT_MASK): the mask source is an activation a
+    split-bf16 forward saved (interleaved hi / lo; its hi half is tested)."""
     if deterministic:
         variant |= 256
+    if aux_split and act == ACT_MASK:
+        assert dt == BF16 and aux is not None and aux.shape[1] >= 2 * roundup(n_store, 64) - 64
+        variant |= 1 << 14
     _chk2d(A, _TORCH_DT[dt]); _chk2d(W, _TORCH_DT[dt]); _chk2d(Y, torch.float32 if out_f32 else _TORCH_DT[dt])
     M = A.shape[0]
     sp = dt == BF16X3                                     # split-bf16: A [M, 2 K], W [N, 3 K], a bf16 Y [M, 2 n_store] (interleaved layout)
@@ -123,12 +127,18 @@ def wgrad_uses_fold(M, N, K, dt, variant):
     return bool(WGRAD_FOLD and (variant & 2) and dt in (BF16, F16) and M >= 4096 and N % 256 == 0 and K >= 256 and (N // 256) * ((K + 255) // 256) >= 8)
 
 
-def linear_wgrad(dZ, X, dW, n_valid, k_valid, dt, variant=0, deterministic=False):
+def linear_wgrad(dZ, X, dW, n_valid, k_valid, dt, variant=0, deterministic=False, x_split_hi=False):
     """dW[:n_valid, :k_valid] += dZ^T @ X.  dZ [M,N], X [M,K] views, dW fp32 view.  The M slices of a launch either add with fp32 atomics (order varies
     run to run) or store partial tiles into a workspace that a second launch folds in slice order (bit-reproducible): `deterministic`
-    forces the fold; it is also the default for the wide layers (below)."""
+    forces the fold; it is also the default for the wide layers (below).  `x_split_hi` (dt bf16): X is an activation a split-bf16 forward
+    saved ([M, 2 K] interleaved hi / lo) and its hi half is multiplied."""
     _chk2d(dZ, _TORCH_DT[dt]); _chk2d(X, _TORCH_DT[dt]); _chk2d(dW, torch.float32)
     assert dZ.shape[0] == X.shape[0] and dW.shape[0] >= n_valid and dW.shape[1] >= k_valid
+    Kx = X.shape[1]
+    if x_split_hi:
+        assert dt == BF16 and Kx % 128 == 0
+        Kx //= 2
+        variant |= 1 << 14
     if dt == BF16X3:
         # dZ / X are the interleaved split operands (physical widths, multiples of 128); the kernels fold the hi / lo combinations
         assert not deterministic, "the split-bf16 weight gradient has no deterministic fold"
@@ -137,16 +147,16 @@ def linear_wgrad(dZ, X, dW, n_valid, k_valid, dt, variant=0, deterministic=False
     # launch folds them in slice order instead of adding 256 x 256 fp32 atomics per slice -- bit-reproducible, and faster: the atomics
     # of 16 slices (16.8 M per launch at N = K = 1024, whatever M is) cost 24-71 us, the stores + fold 7-26 (tools/probes/
     # tn_epilogue_probe.py); 512-ray step 4.55 -> 4.24 ms, 4096-ray step 25.65 -> 25.47 (A/B on one box, tools/probes/wgrad_fold_ab.sh)
-    if not deterministic and wgrad_uses_fold(dZ.shape[0], dZ.shape[1], X.shape[1], dt, variant):
+    if not deterministic and wgrad_uses_fold(dZ.shape[0], dZ.shape[1], Kx, dt, variant):
         deterministic = True
     if deterministic:
-        nws = _lib.query("snerf_linear_wgrad_ws_floats", dZ.shape[0], dZ.shape[1], X.shape[1], dZ.stride(0), X.stride(0), dt, variant)
+        nws = _lib.query("snerf_linear_wgrad_ws_floats", dZ.shape[0], dZ.shape[1], Kx, dZ.stride(0), X.stride(0), dt, variant)
         ws = torch.empty(max(int(nws), 1), dtype=torch.float32, device=dZ.device)
         _lib.call("snerf_linear_wgrad_det", _p(dZ), dZ.stride(0), _p(X), X.stride(0), _p(dW), dW.stride(0), _p(zero_page(dZ.device)),
-                  dZ.shape[0], dZ.shape[1], X.shape[1], n_valid, k_valid, dt, variant, _p(ws), ws.numel(), _stream())
+                  dZ.shape[0], dZ.shape[1], Kx, n_valid, k_valid, dt, variant, _p(ws), ws.numel(), _stream())
         return
     _lib.call("snerf_linear_wgrad", _p(dZ), dZ.stride(0), _p(X), X.stride(0), _p(dW), dW.stride(0),
-              _p(zero_page(dZ.device)), dZ.shape[0], dZ.shape[1], X.shape[1], n_valid, k_valid, dt, variant, _stream())
+              _p(zero_page(dZ.device)), dZ.shape[0], dZ.shape[1], Kx, n_valid, k_valid, dt, variant, _stream())
 
 
 # ------------------------------------------------------------ fused MLPs ----

@@ -37,8 +37,11 @@ def split_cast(src, C, dst, Cpad):
     _split_pack(y, dst, Cpad)
 
 
-def linear_fwd(A, W, bias, Y, K, n_store, act, dt, out_f32=False, aux=None, colsum=None, variant=0, deterministic=False):
+def linear_fwd(A, W, bias, Y, K, n_store, act, dt, out_f32=False, aux=None, colsum=None, variant=0, deterministic=False, aux_split=False):
     assert W.shape[0] % 128 == 0 and K % (32 if dt == 0 else 64) == 0
+    if aux_split and act == 2:                                   # plain bf16 data gradient, mask = the hi half of a split-bf16 activation
+        assert dt == 1
+        aux = _split_unpack(aux, 64 * ((n_store + 63) // 64))[0]
     if dt == 4:                                                 # split-bf16: hi.hi + lo.hi + hi.lo, fp32 accumulation (csrc/gemm.hip)
         ah, al = _split_unpack(A, K)
         w = W[:, :3 * K].float().reshape(W.shape[0], K // 64, 3, 64)
@@ -82,7 +85,11 @@ def linear_fwd(A, W, bias, Y, K, n_store, act, dt, out_f32=False, aux=None, cols
         colsum[:n_store] += y.sum(0)
 
 
-def linear_wgrad(dZ, X, dW, n_valid, k_valid, dt, variant=0, deterministic=False):
+def linear_wgrad(dZ, X, dW, n_valid, k_valid, dt, variant=0, deterministic=False, x_split_hi=False):
+    if x_split_hi:                                              # plain bf16 dZ x the hi half of a split-bf16 activation
+        assert dt == 1 and X.shape[1] % 128 == 0
+        dW[:n_valid, :k_valid] += (dZ.float().t() @ _split_unpack(X, X.shape[1] // 2)[0])[:n_valid, :k_valid]
+        return
     if dt == 4:                                                 # the kernels multiply the physical matrices: all four hi / lo combinations
         zh, zl = _split_unpack(dZ, dZ.shape[1] // 2)
         xh, xl = _split_unpack(X, X.shape[1] // 2)

@@ -95,6 +95,64 @@ def test_linear_wgrad(ops, dt, M, N, K, nv, kv):
         close(dW, ref, 1e-4, 1e-3 * (M / 1000) ** 0.5, f"wgrad variant {variant}")
 
 
+def _split_layout(x):
+    """fp32 [M, K] (K % 64 == 0) -> the split-bf16 activation layout [M, 2 K]: per 64 logical columns [hi 64 | lo 64]"""
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    M, K = x.shape
+    return torch.stack([hi.reshape(M, K // 64, 64), lo.reshape(M, K // 64, 64)], 2).reshape(M, 2 * K).contiguous()
+
+
+@pytest.mark.parametrize("M,N,K,nv,kv", [(700, 64, 128, 3, 128), (5000, 256, 320, 256, 283), (3000, 1024, 1152, 1024, 1120), (4100, 256, 128, 256, 96),
+                                         (70001, 1024, 1152, 1024, 1120), (9000, 256, 320, 256, 283), (33000, 512, 256, 500, 256), (4500, 64, 1024, 1, 1024)])
+def test_linear_wgrad_hi_half_of_split_activation(ops, M, N, K, nv, kv):
+    """compute="bf16x3_fwd": the single-pass weight gradient reads the hi half of an activation the split-bf16 forward saved (variant bit 14 of
+    snerf_linear_wgrad).  Both kernels (128 x 128 and the 8-phase 256 x 256), atomics and the partial-tile fold, X as a column range of a wider
+    buffer; the result must equal the plain launch on the de-interleaved hi half BIT FOR BIT where the summation order is fixed (fold)."""
+    dZ = gen(M, N, seed=7).to(torch.bfloat16).cuda()
+    Kp = ((K + 63) // 64) * 64
+    x = torch.zeros(M, Kp)
+    x[:, :K] = gen(M, K, seed=8)
+    wide = torch.zeros(M, 2 * Kp + 256, dtype=torch.bfloat16)
+    wide[:, 128:128 + 2 * Kp] = _split_layout(x)
+    wide[:, :128] = 7.0; wide[:, 128 + 2 * Kp:] = -5.0              # neighbours of the column range must not leak in
+    Xs = wide.cuda()[:, 128:128 + 2 * Kp]
+    Xh = x.to(torch.bfloat16).cuda()
+    ref = 1.0 + (dZ.double().cpu().t() @ Xh.double().cpu())[:nv, :kv]
+    for variant in (0, 1, 2, 3):
+        for det in (False, True):
+            dW = torch.ones(nv, kv, dtype=torch.float32, device="cuda")
+            ops.linear_wgrad(dZ, Xs, dW, nv, kv, ops.BF16, variant=variant, deterministic=det, x_split_hi=True)
+            close(dW, ref, 1e-4, 1e-3 * (M / 1000) ** 0.5, f"hi-half wgrad variant {variant} det {det}")
+            if det:
+                dW2 = torch.ones(nv, kv, dtype=torch.float32, device="cuda")
+                ops.linear_wgrad(dZ, Xh, dW2, nv, kv, ops.BF16, variant=variant, deterministic=True)
+                assert torch.equal(dW, dW2), f"variant {variant}: the hi-half launch and the plain launch on the same values differ"
+
+
+@pytest.mark.parametrize("M,Nred,Kout,variant", [(515, 192, 256, 0), (515, 192, 256, 8), (70001, 64, 256, 8), (3000, 128, 128, 8), (3000, 256, 1024, 4)])
+def test_linear_dgrad_mask_from_split_activation(ops, M, Nred, Kout, variant):
+    """compute="bf16x3_fwd": a plain bf16 data gradient whose ReLU mask source is a split-bf16 activation (variant bit 14 of snerf_linear_fwd):
+    identical to the plain launch masked by the de-interleaved hi half."""
+    dZ = gen(M, Nred, seed=4).to(torch.bfloat16).cuda()
+    Wt = (gen(Kout, Nred, seed=5) / Nred ** 0.5).to(torch.bfloat16).cuda()
+    a = gen(M, Kout, seed=6)
+    a = torch.where(a.abs() < 0.3, torch.zeros_like(a), a)        # exact zeros and values whose hi half is zero-adjacent
+    act_s = _split_layout(a).cuda()
+    act_h = a.to(torch.bfloat16).cuda()
+    for n_store in (Kout, Kout - 8):
+        out = []
+        for aux, sp in ((act_s, True), (act_h, False)):
+            dX = torch.full((M, Kout), 3.0, dtype=torch.bfloat16, device="cuda")
+            cs = torch.zeros(Kout, dtype=torch.float32, device="cuda")
+            ops.linear_fwd(dZ, Wt, None, dX, Nred, n_store, ops.ACT_MASK, ops.BF16, aux=aux, colsum=cs, variant=variant, aux_split=sp)
+            out.append((dX, cs))
+        assert torch.equal(out[0][0], out[1][0]), "masked data gradient differs from the plain launch on the hi half"
+        close(out[0][1], out[1][1], 1e-5, 1e-3 * (M / 515) ** 0.5, "bias gradient")
+        ref = (dZ.double().cpu() @ Wt.double().cpu().t()) * (act_h.double().cpu() > 0)
+        close(out[0][0][:, :n_store], ref[:, :n_store], 1e-2, 1e-2, "dgrad")
+
+
 @pytest.mark.parametrize("M,N,K,dt", [(1000, 256, 256, 1), (70001, 512, 320, 1), (4096, 1024, 1024, 1), (1000, 256, 256, 2), (70001, 512, 320, 2)])
 def test_relu_bit_mask_roundtrip(ops, M, N, K, dt):
     """ACT_RELU_BITS writes the activation AND a 1-bit mask; ACT_MASK_BITS must reproduce ACT_MASK on that activation exactly (bf16 and fp16)."""

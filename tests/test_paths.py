@@ -318,6 +318,51 @@ def test_mipnerf_backward_vs_autograd(backend, compute, hidden, tol):
     check_grads(named, pr, sd, compute, tol)
 
 
+def test_mipnerf_split_forward_plain_backward(backend):
+    """compute="bf16x3_fwd": the three-pass split-bf16 FORWARD (renders held to the fp32 contract) with a ONE-pass bf16 BACKWARD.
+    (1) its outputs are bit-identical to compute="bf16x3" (the same forward launches); (2) loss and outputs against the oracle at the
+    fp32 bounds; (3) every parameter gradient against the oracle's autograd norm-wise, and no worse than 1.5 x the plain bf16 mode's
+    error on the same problem (the backward rounds its operands once, like that mode, but from exact forward values).  256-wide
+    networks and 4800 rows: the persistent NT kernel with bit masks, the 8-phase weight gradient on the hi halves (M >= 4096), the
+    128-wide colour head through the bf16-mask epilogue with a split-layout mask source."""
+    from snerf_amd import mipnerf
+    S0, P1, n, hidden = 24, 25, 200, 256
+    sd = random_params(om.mipnerf_param_shapes(hidden=hidden, prop_hidden=256), 21, ("mlp.density_layer.bias", "proposal.density_layer.bias"))
+    rays_c = common.synthetic_rays(n, seed=7)
+    gg = torch.Generator().manual_seed(8)
+    target, tdepth = torch.rand(n, 3, generator=gg), torch.rand(n, generator=gg) * 50 + 5
+    pr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    rays = mipnerf.Rays(**{k: v.to(DEV) for k, v in rays_c.items()})
+
+    def loss_fn(ret, tgt, td):
+        l = ((ret[1][0] - tgt) ** 2).mean()
+        l = l + 0.2 * ((1 / ret[1][1] - 1 / td).abs()).mean() + 0.2 * 0.2 * ((1 / ret[0][1] - 1 / td).abs()).mean()
+        return l + 0.01 * (ret[0][4] ** 2).sum() + 0.01 * ret[1][2].mean()
+    ref = om.mipnerf_forward(pr, rays_c, S0, P1)
+    loss_ref = loss_fn([[None, ref[0][1], ref[0][2], ref[0][3], ref[0][4]], [ref[1][0], ref[1][1], ref[1][2], None, ref[1][4], ref[1][5]]], target, tdepth)
+    loss_ref.backward()
+    rets, errs = {}, {}
+    for compute in ("bf16x3_fwd", "bf16x3", "bf16"):
+        m = make_mip(hidden, 256, S0, P1, compute, sd)
+        ret = m(rays, False, False, 0.)
+        loss = loss_fn(ret, target.to(DEV), tdepth.to(DEV))
+        loss.backward()
+        rets[compute] = (loss.detach().cpu(), [t.detach().cpu() for t in (ret[1][0], ret[1][1], ret[1][2], ret[0][1], ret[0][4])])
+        named = dict(m.named_parameters())
+        errs[compute] = {k: ((named[k].grad.detach().cpu() - pr[k].grad).norm() / (pr[k].grad.norm() + 1e-12)).item() for k in sd}
+    for a, b in zip(rets["bf16x3_fwd"][1], rets["bf16x3"][1]):
+        assert torch.equal(a, b), "the forward of bf16x3_fwd must be the split-bf16 forward, bit for bit"
+    assert torch.equal(rets["bf16x3_fwd"][0], rets["bf16x3"][0])
+    close(rets["bf16x3_fwd"][0], loss_ref, 3e-4, 3e-4, "loss")
+    close(rets["bf16x3_fwd"][1][0], ref[1][0], 1e-4, 1e-4, "rgb"); close(rets["bf16x3_fwd"][1][1], ref[1][1], 1e-4, 1e-4, "distance")
+    worst = {c: max(e.values()) for c, e in errs.items()}
+    print("MEASURED parameter-gradient rel L2 (max over parameters): " + ", ".join(f"{c} {v:.3e}" for c, v in worst.items()))
+    for k in sd:
+        e = errs["bf16x3_fwd"][k]
+        assert e < max(1.5 * errs["bf16"][k], 4e-3), f"grad {k}: rel L2 {e:.3e} vs the plain bf16 mode's {errs['bf16'][k]:.3e}"
+        assert e < 0.113, f"grad {k}: rel L2 {e:.3e}"
+
+
 def test_mipnerf_semantic_head_vs_reference_golden(backend, golden):
     """MipNerfModel(semantic=True): outputs and EVERY parameter gradient against the reference model's own (g14)."""
     g = golden("g14_mipnerf_semantic")

@@ -44,19 +44,58 @@ def main():
     ident = lambda x: x
     variants = {"a16 x w32": (r16, ident), "a32 x w16": (ident, r16), "a16 x w16": (r16, r16), "a16s x w32": (r16s, ident),
                 "abf16 x w32": (rb16, ident), "a32 x wbf16": (ident, rb16), "abf16 x wbf16": (rb16, rb16)}
+    f8 = lambda x: x.to(torch.float8_e4m3fn).float()
+
+    def p2scale(x, top):                       # power of two that brings max |x| of the tensor just under `top`
+        return torch.exp2(torch.floor(math.log2(top) - torch.log2(x.abs().amax().clamp(min=1e-30))))
+
+    def split_lin(rnd):                        # hi = rnd(x), lo = rnd(x - hi); hi.hi + lo.hi + hi.lo (lo.lo dropped): the three-pass form
+        def make(real_linear, wcache):
+            def lin(x, w, b=None):
+                if id(w) not in wcache:
+                    wh = rnd(w)
+                    wcache[id(w)] = (wh, rnd(w - wh))
+                wh, wl = wcache[id(w)]
+                xh = rnd(x)
+                xl = rnd(x - xh)
+                return real_linear(xh, wh, b) + real_linear(xl, wh) + real_linear(xh, wl)
+            return lin
+        return make
+
+    def f16_f8_lin(real_linear, wcache):       # fp16 hi.hi + fp8 corrections: [A_lo | A_hi](e4m3) . [W_hi ; W_lo](e4m3), lo parts scaled by a power of two per tensor
+        def lin(x, w, b=None):
+            if id(w) not in wcache:
+                wh = r16(w)
+                wl = w - wh
+                sw, swl = p2scale(w, 256.0), p2scale(wl, 256.0)
+                wcache[id(w)] = (wh, f8(w * sw) / sw, f8(wl * swl) / swl)
+            wh, w8, wl8 = wcache[id(w)]
+            xh = r16(x)
+            xl = x - xh
+            sx, sxl = p2scale(x, 256.0), p2scale(xl, 256.0)
+            return real_linear(xh, wh, b) + real_linear(f8(xl * sxl) / sxl, w8) + real_linear(f8(x * sx) / sx, wl8)
+        return lin
+
+    def f64_lin(real_linear, wcache):          # the noise floor of the yardstick: fp64 products and sums
+        def lin(x, w, b=None):
+            return real_linear(x.double(), w.double(), None if b is None else b.double()).float()
+        return lin
+    custom = {"f64 linears": f64_lin, "bf16x3 (emulated)": split_lin(rb16), "f16x3 (emulated)": split_lin(r16), "f16 + f8 corr.": f16_f8_lin}
     real_linear = F.linear
     saved, om.warp_resample_s = om.warp_resample_s, eager.mip_resample_torch
     prev = torch.get_default_device() if hasattr(torch, "get_default_device") else None
     torch.set_default_device(dev)
     outs = {}
     try:
-        def run(ra, rw):
+        def run(ra, rw, make=None):
             wcache = {}
 
             def lin(x, w, b=None):
                 if id(w) not in wcache:
                     wcache[id(w)] = rw(w)
                 return real_linear(ra(x), wcache[id(w)], b)
+            if make is not None:
+                lin = make(real_linear, wcache)
             om.F.linear = lin
             try:
                 parts = []
@@ -70,6 +109,8 @@ def main():
         ref = run(ident, ident)
         for name, (ra, rw) in variants.items():
             outs[name] = run(ra, rw)
+        for name, make in custom.items():
+            outs[name] = run(None, None, make)
     finally:
         om.warp_resample_s = saved
         torch.set_default_device(prev if prev is not None else "cpu")
