@@ -799,7 +799,7 @@ def main():
     ap.add_argument("--rays", type=int, default=4096, help="rays per GPU per step (weak scaling) / global rays per step (--scaling strong)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --rays per GPU whatever N (default); strong: the reference's --rays-ray batch split across the N GPUs")
-    ap.add_argument("--compute", default="bf16", choices=["bf16", "f32", "bf16x3", "bf16x3_fwd"])
+    ap.add_argument("--compute", default="bf16", choices=["bf16", "f32", "bf16x3", "bf16x3_fwd", "f16f8"])
     ap.add_argument("--variant", type=int, default=8, help="NT GEMM variant: 8 = persistent 8-phase 256x256 (default), 4 = 8-phase, 1 = 256x256 block-issue, 0 = 128x128")
     ap.add_argument("--no-frame", action="store_true", help="skip the 1600x900 frame render")
     ap.add_argument("--no-cpu", action="store_true", help="skip the host-CPU baseline")
@@ -1172,6 +1172,36 @@ def main():
                                          "(tests/test_paths.py::test_mipnerf_split_forward_plain_backward)"}
         del txf, mxf
         torch.cuda.empty_cache()
+        # the same contract in TWO pass-equivalents: fp16 tiles + e4m3 correction tiles on the block-scaled MFMA (compute="f16f8"), scaled fp16 backward
+        m8 = build_model("f16f8", device)
+        m8.load_state_dict({k: v.clone() for k, v in model.state_dict().items()})
+        t8 = MipTrainer(m8, lr=5e-4)
+        for _ in range(2):
+            t8.step(rays, tgt, depth, conf)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            t8.step(rays, tgt, depth, conf)
+        torch.cuda.synchronize()
+        dt8 = (time.perf_counter() - t0) / 5
+        out["f16f8_mode"] = {"rays_per_s": round(n / dt8, 1), "ms_per_step": round(dt8 * 1e3, 2), "steps": 5, "speedup_vs_split_bf16_mode": round(dtx3 / dt8, 3),
+                             "note": "compute='f16f8': x = fp16(x) + r; hi.hi on the fp16 MFMA + the correction r.w + x.(w - fp16(w)) as OCP e4m3 on v_mfma_scale_f32_32x32x64_f8f6f4 "
+                                     "(twice the 16-bit rate): the forward in two pass-equivalents instead of three; backward = plain fp16 on power-of-two scaled gradients"}
+        if not args.no_frame:
+            with torch.no_grad():
+                fn8 = lambda r: m8(r, False, False, 0.)
+                fn8(frame_rays(0, min(args.frame_chunk, 900 * 1600), device))
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                fr8 = frame_rays(0, 900 * 1600, device)
+                render_image(fn8, Rays(*[r.reshape(900, 1600, -1) for r in fr8]), rank, chunk=args.frame_chunk, world=world)
+                torch.cuda.synchronize()
+                t8f = time.perf_counter() - t0
+                del fr8
+            out["f16f8_mode"]["ms_per_frame"] = round(t8f * 1e3, 1)
+            out["f16f8_mode"]["frame_rays_per_s"] = round(900 * 1600 / t8f, 1)
+        del t8, m8
+        torch.cuda.empty_cache()
 
     # ---- parity read-out + host-CPU baseline (rank 0, N = 1 only)
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -1216,6 +1246,9 @@ def main():
             out["eager_baseline"]["frame_speedup_vs_bf16_autocast"] = round(out["frame"]["rays_per_s"] / f16_fwd, 2)
             if "frame_rays_per_s" in out.get("split_bf16_mode", {}):      # north_star's frame target in the mode that also holds its 1e-4
                 out["eager_baseline"]["split_bf16_frame_speedup_vs_fp32"] = round(out["split_bf16_mode"]["frame_rays_per_s"] / f32_fwd, 2)
+            if "frame_rays_per_s" in out.get("f16f8_mode", {}):
+                out["eager_baseline"]["f16f8_frame_speedup_vs_fp32"] = round(out["f16f8_mode"]["frame_rays_per_s"] / f32_fwd, 2)
+                out["eager_baseline"]["f16f8_frame_speedup_vs_bf16_autocast"] = round(out["f16f8_mode"]["frame_rays_per_s"] / f16_fwd, 2)
             out["eager_baseline"]["frame_note"] = ("the build's measured 1600 x 900 frame rate (render_image, ray generation and gathers included) over the eager forward's "
                                                    "rate on a 4096-ray chunk (eval.py's chunk size; a frame is 352 such chunks)")
     if rank == 0:

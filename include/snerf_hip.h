@@ -298,6 +298,17 @@ int snerf_index_check(const float* idx, long n, int n_rows, int* bad, void* stre
  * padded to Cpad % 64 == 0 logical columns) into that layout. */
 int snerf_split_cast(const float* src, long ld_src, long M, int C, int Cpad, void* dst, long ld_dst, void* stream);
 
+/* fp16 + fp8 split operands (dtype SNERF_DT_F16F8 of snerf_linear_fwd): the same fp32-class contract in TWO pass-equivalents.  x = hi + r,
+ * hi = fp16(x); a product is hi.hi on the fp16 MFMA plus the correction r.w + x.(w - fp16(w)), whose factors need 4 significant bits only and run as
+ * OCP e4m3 on the block-scaled MFMA (v_mfma_scale_f32_32x32x64_f8f6f4, twice the 16-bit rate; its E8M0 scale bytes undo the operands' power-of-two
+ * scales).  Layout per 64 logical columns, 256 bytes: activations [fp16(x) x 64 | e4m3((x - hi) 2^13) x 64 | e4m3(x 2^2) x 64], weights
+ * [fp16(w) x 64 | e4m3(w 2^9) x 64 | e4m3((w - hi) 2^20) x 64] (2-byte element strides, K the LOGICAL reduction length; e4m3 saturates at +-448:
+ * |x| > 112 or |w| > 0.875 lose the clipped part of the correction only).  Forward activations only: ACT_NONE / ACT_RELU / ACT_RELU_BITS, no column
+ * sums; the backward behind it runs on plain fp16 operands (bit 14 of the two GEMM entries' `variant` reads the fp16 halves).  Measured on fitted
+ * weights: profiles/r6_c_two_pass_precision_with_split_schemes.txt.  snerf_split8_cast converts fp32 rows into either layout (weight = 0 / 1). */
+#define SNERF_DT_F16F8 5
+int snerf_split8_cast(const float* src, long ld_src, long M, int C, int Cpad, void* dst, long ld_dst, int weight, void* stream);
+
 int snerf_colsum_f32(const float* x, long ld, long M, int C, float* out, void* stream);
 int snerf_cast_pad(const float* src, long ld_src, long M, int C, int Cpad, void* dst, long ld_dst, int dtype, void* stream);
 /* Refresh of the packed GEMM / fused-MLP operands after an optimiser step (the reference has no counterpart: torch.nn.Linear reads its

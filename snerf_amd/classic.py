@@ -115,8 +115,9 @@ class _ArenaModule(nn.Module):
 
 
 def _dt(compute: str) -> int:
-    """compute mode -> GEMM dtype code.  "bf16x3_fwd" (the mip path): the split-bf16 forward with a single-pass bf16 backward (mlp._Net.bwd_plain)"""
-    return {"bf16": ops.BF16, "f32": ops.F32, "fp32": ops.F32, "bf16x3": ops.BF16X3, "bf16x3_fwd": ops.BF16X3, "fp16": ops.F16, "f16": ops.F16}[compute]
+    """compute mode -> GEMM dtype code.  "bf16x3_fwd" (the mip path): the split-bf16 forward with a single-pass bf16 backward (mlp._Net.bwd_plain);
+    "f16f8" (the mip path): fp16 tiles + e4m3 correction tiles in the forward (two pass-equivalents, the same 1e-4 contract), scaled fp16 backward"""
+    return {"bf16": ops.BF16, "f32": ops.F32, "fp32": ops.F32, "bf16x3": ops.BF16X3, "bf16x3_fwd": ops.BF16X3, "f16f8": ops.F16F8, "fp16": ops.F16, "f16": ops.F16}[compute]
 
 
 class NeRF(_ArenaModule):

@@ -18,6 +18,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define SNERF_DT_F16 2
 #define SNERF_DT_F64 3   // hash-grid tables of the stand-alone GridEncoder operator only
 #define SNERF_DT_BF16X3 4  // GEMM entries only: split-bf16 operands (hi = bf16(x), lo = bf16(x - hi); three MFMA passes), gemm.hip
+#define SNERF_DT_F16F8 5   // snerf_linear_fwd only: fp16 + fp8 split operands (fp16 tiles + e4m3 correction tiles on the block-scaled MFMA: two pass-equivalents), gemm.hip
 
 extern int g_snerf_last_hip_error;   // (elementwise.hip) the hipError_t behind the most recent SNERF_ERR_LAUNCH: snerf_last_hip_error()
 static inline int snerf_check_launch() {

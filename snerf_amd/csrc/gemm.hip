@@ -50,6 +50,14 @@ struct GemmNT {
   // contiguous physical range of twice the width -- and the weights as [hi_j | hi_j | lo_j] per k-tile, so that the reduction loop
   // simply walks 3 K / 64 VIRTUAL k-tiles: tile v reads W's physical tile v and A's physical tile 2 (v / 3) + (v % 3 == 1).
   // K in this struct is the virtual reduction length (3 x the logical one).
+  //
+  // split == 2 (dtype SNERF_DT_F16F8: the same contract in TWO pass-equivalents): x = hi + r with hi = fp16(x) (11 bits); the product is
+  // hi.hi on the fp16 MFMA plus a correction r.w + x.(w - fp16(w)) whose operands need 4 bits only and run as e4m3 on the block-scaled
+  // MFMA at twice the rate: activations [hi16 x 64 | e4m3(r 2^13) x 64 | e4m3(x 2^2) x 64] per 64 logical columns (256 bytes, the footprint
+  // of the bf16 split layout), weights [hi16 x 64 | e4m3(w 2^9) x 64 | e4m3((w - hi) 2^20) x 64], so that virtual tile 2 j is the fp16 tile and
+  // 2 j + 1 the 128-byte e4m3 tile of logical tile j for BOTH operands; the scale bytes of the MFMA take the 2^22 out again.  Values beyond
+  // +-448 / scale saturate (|x| > 112, |w| > 0.875): the correction then loses what was clipped, i.e. the product falls back towards plain
+  // fp16 for that element.  K = 2 x the logical reduction length.  Forward activations only (NONE / RELU / RELU_BITS, no column sums).
   int split;
   // Plain (bf16) data gradient behind a split-bf16 FORWARD (compute="bf16x3_fwd"): the ACT_MASK source `aux` is a saved activation in the
   // interleaved layout above -- logical column c is read at physical column (c >> 6) * 128 + (c & 63), its hi half.
@@ -82,6 +90,25 @@ template <bool F16> __device__ __forceinline__ void mma32t(f32x16& acc, const bf
   else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
 }
 template <bool F16> __device__ __forceinline__ void mma32t(f32x16& acc, const f32x4& a, const f32x4& b) { mma32(acc, a, b); }
+// The CORRECTION tile of the fp16 + fp8 split mode (GemmNT::split == 2): 32 x 32 x 64 e4m3 products per instruction -- two 16-byte fragments
+// per operand, read exactly like two bf16 fragments (the byte -> k map inside a lane is the same for both operands, so it does not matter)
+// -- on the block-scaled MFMA with constant E8M0 scale bytes 116 = 2^-11 on both sides: the operands were scaled by 2^22 in total.
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void mma8(f32x16& acc, const bf16x8& a0, const bf16x8& a1, const bf16x8& b0, const bf16x8& b1) {
+  const i32x8 a = __builtin_bit_cast(i32x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15));
+  const i32x8 b = __builtin_bit_cast(i32x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15));
+  acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc, 0, 0, 0, 0x74747474, 0, 0x74747474);
+}
+// four fp32 -> four e4m3 bytes of x * mul (clamped to the format's +-448)
+__device__ __forceinline__ unsigned pack_e4m3x4(float x0, float x1, float x2, float x3, float mul) {
+  x0 = __builtin_amdgcn_fmed3f(x0 * mul, -448.f, 448.f); x1 = __builtin_amdgcn_fmed3f(x1 * mul, -448.f, 448.f);
+  x2 = __builtin_amdgcn_fmed3f(x2 * mul, -448.f, 448.f); x3 = __builtin_amdgcn_fmed3f(x3 * mul, -448.f, 448.f);
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(x0, x1, 0, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(x2, x3, w, true);
+  return (unsigned)w;
+}
+#define F8_A_LO 8192.f        /* 2^13: activations' residual x - fp16(x) */
+#define F8_A_HI 4.f           /* 2^2 : activations themselves             (13 + 9 = 2 + 20 = 22 = the two scale bytes' 11 + 11) */
 template <bool F16> __device__ __forceinline__ __bf16 cvt16(float v) {          // fp32 -> the launch's 16-bit format (as a bf16-typed bit pattern)
   if constexpr (F16) return __builtin_bit_cast(__bf16, (_Float16)v);
   else return (__bf16)v;
@@ -164,6 +191,13 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x16 (&acc)[BM / 
             char* dst = my + (lane & 31) * PITCH + cl * (int)sizeof(T);
             if constexpr (sizeof(T) == 2) {
               bf16x4 o = {cvt16<F16>(v[0]), cvt16<F16>(v[1]), cvt16<F16>(v[2]), cvt16<F16>(v[3])};
+              if (part == 1 && p.split == 2) {
+                // fp16 + fp8 mode: the group's second 128 bytes = [e4m3(r 2^13) x 64 | e4m3(x 2^2) x 64], one byte per logical column
+                char* d8 = my + (lane & 31) * PITCH + cl;
+                *(unsigned*)d8 = pack_e4m3x4(v[0] - up16<F16>(o[0]), v[1] - up16<F16>(o[1]), v[2] - up16<F16>(o[2]), v[3] - up16<F16>(o[3]), F8_A_LO);
+                *(unsigned*)(d8 + 64) = pack_e4m3x4(v[0], v[1], v[2], v[3], F8_A_HI);
+                continue;
+              }
               if (part == 1) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = (__bf16)(v[e] - (float)o[e]);
@@ -345,7 +379,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmNT p) {
     char* sA = smem + stage * STAGE;
     char* sB = sA + BM * 128;
     const long k0 = (long)kt * BKE;
-    const long ka = p.split ? (long)split_a_tile(kt) * BKE : k0;
+    const long ka = p.split == 1 ? (long)split_a_tile(kt) * BKE : k0;
 #pragma unroll
     for (int i = 0; i < LA; ++i) glds16(A + a_off[i] + ka, sA + (wave * LA + i) * 1024);
 #pragma unroll
@@ -383,6 +417,21 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(GemmNT p) {
     if (kt + 1 < KT && !DBG(p, 1)) issue(kt + 1, (kt + 1) & 1);
     const char* sA = smem + (kt & 1) * STAGE;
     const char* sB = sA + BM * 128;
+    if constexpr (sizeof(T) == 2) {
+      if (p.split == 2 && (kt & 1)) {                   // the e4m3 correction tile of the fp16 + fp8 mode
+#pragma unroll
+        for (int ks = 0; ks < 4; ks += 2) {
+          frag_t a[2][TM], b[2][TN];
+          read_frags(sA, sB, ks, a[0], b[0]);
+          read_frags(sA, sB, ks + 1, a[1], b[1]);
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) mma8(acc[i][j], b[0][j], b[1][j], a[0][i], a[1][i]);
+        }
+        continue;
+      }
+    }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       frag_t a[TM], b[TN];
@@ -454,7 +503,7 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmNT p) {
     char* dst = my_piece + (db * 4 + which) * HALF;
     const long k0 = (long)kt * 64;
     if (which < 2) {
-      const long ka = p.split ? (long)split_a_tile(kt) * 64 : k0;
+      const long ka = p.split == 1 ? (long)split_a_tile(kt) * 64 : k0;
       glds16(A + a_off[which][0] + ka, dst);
       glds16(A + a_off[which][1] + ka, dst + 1024);
     } else {
@@ -594,10 +643,15 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmNT p) {
 // ---------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-template <int ACT, bool COLSUM, bool SPLIT = false, bool F16 = false, bool KT2 = false>
+// SPLIT: 0 = plain operands, 1 = split-bf16 (three bf16 passes), 2 = fp16 + fp8 (GemmNT::split == 2: fp16 tiles and e4m3 correction tiles
+// alternate -- virtual tile v is an fp16 tile for even v and lands in staging buffer v & 1, so the kind of a k-tile is its buffer index,
+// a compile-time constant of each copy of the k-tile body)
+template <int ACT, bool COLSUM, int SPLIT = 0, bool F16 = false, bool KT2 = false>
 __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
   static_assert(!(SPLIT && ACT == ACT_MASK), "split-bf16 data gradients take their ReLU masks from the bit masks");
-  static_assert(!(SPLIT && F16), "the split mode is a bf16 construction");
+  static_assert(SPLIT != 1 || !F16, "the three-pass split mode is a bf16 construction");
+  static_assert(SPLIT != 2 || (F16 && !COLSUM && !KT2 && (ACT == ACT_NONE || ACT == ACT_RELU || ACT == ACT_RELU_BITS)),
+                "fp16 + fp8: forward activations only (its backward runs on plain operands)");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __bf16 T;
   constexpr int HALF = 128 * 128;                      // bytes per half-tile
@@ -648,7 +702,7 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
   };
   auto stream_next = [&]() __attribute__((always_inline)) {
     if (++s_kt == KT) { s_kt = 0; s_ao = 0; s_m3 = 0; stream_tile(++s_i); }
-    else if (SPLIT) {                                    // virtual tile v -> A's physical tile 2 (v / 3) + (v % 3 == 1): +1, -1, +2 tiles
+    else if (SPLIT == 1) {                               // virtual tile v -> A's physical tile 2 (v / 3) + (v % 3 == 1): +1, -1, +2 tiles
       s_ao += s_m3 == 0 ? 128 : (s_m3 == 1 ? -128 : 256);
       s_m3 = s_m3 == 2 ? 0 : s_m3 + 1;
     }
@@ -658,7 +712,7 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
     char* dst = smem + (db * 4 + which) * HALF + wave * 2048;
     const int soff = s_kt * 128;
     if (which < 2) {
-      const int aoff = SPLIT ? s_ao : soff;
+      const int aoff = SPLIT == 1 ? s_ao : soff;            // (fp16 + fp8: A's physical tile IS the virtual tile, like W's)
       // SPLIT (at the register limit): the second piece's offset is derived from the first -- 8 rows further, 16-byte chunk c ^ 4 --
       // instead of being kept in a register of its own
       const int a1 = SPLIT ? arel[0] + 16 * (int)p.lda + rel_dc : arel[1];
@@ -780,6 +834,21 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
     for (int c = 0; c < 8; ++c) {
       const int jj = c >> 2, q = c & 3;
       const f32x2 v01 = {acc[u][jj][4 * q + 0], acc[u][jj][4 * q + 1]}, v23 = {acc[u][jj][4 * q + 2], acc[u][jj][4 * q + 3]};
+      if constexpr (SPLIT == 2) {
+        if (part == 1) {
+          // fp16 + fp8: the second 128 bytes of the group, [e4m3(r 2^13) x 64 | e4m3(x 2^2) x 64], from the untouched accumulators (the values are
+          // rounded and clamped once more: cheaper than carrying the first pass's results in registers this flavour does not have).  This lane's
+          // four values are columns 8 c + 4 hi .. + 3 of the 64: bytes 8 c + 4 hi of either half = chunk c >> 1 (+ 4), offset 8 (c & 1) + 4 hi
+          float x0 = v01[0], x1 = v01[1], x2 = v23[0], x3 = v23[1];
+          if (ACT == ACT_RELU || ACT == ACT_RELU_BITS) { x0 = fmaxf(x0, 0.f); x1 = fmaxf(x1, 0.f); x2 = fmaxf(x2, 0.f); x3 = fmaxf(x3, 0.f); }
+          const unsigned lo8 = pack_e4m3x4(x0 - (float)(_Float16)x0, x1 - (float)(_Float16)x1, x2 - (float)(_Float16)x2, x3 - (float)(_Float16)x3, F8_A_LO);
+          const unsigned hi8 = pack_e4m3x4(x0, x1, x2, x3, F8_A_HI);
+          char* const d8 = slab + row1 * 128 + 8 * (c & 1) + 4 * hi;
+          *(unsigned*)(d8 + (((c >> 1) ^ (row1 & 7)) << 4)) = lo8;
+          *(unsigned*)(d8 + (((4 + (c >> 1)) ^ (row1 & 7)) << 4)) = hi8;
+          continue;
+        }
+      }
       u32x2 o;
       if constexpr (F16) {
         typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
@@ -793,7 +862,7 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
         asm("" : "+v"(o));
         o = __builtin_bit_cast(u32x2, __builtin_elementwise_max(__builtin_bit_cast(s16x4, o), s16x4{0, 0, 0, 0}));
       }
-      if (SPLIT && part == 0) {
+      if (SPLIT == 1 && part == 0) {
         // the accumulators keep the RESIDUAL of the rounded (and clamped) value for the second pass -- hi's two bf16 are the high
         // halves of fp32 words; zero where the ReLU clamped -- so that pass costs no registers beyond the first one's
         const unsigned o0 = o[0], o1 = o[1];              // (named scalars: see the note at ACT_MASK_BITS)
@@ -974,6 +1043,7 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
   auto ktile = [&](auto db_tag) __attribute__((always_inline)) {
     constexpr int db = decltype(db_tag)::value;
     constexpr int F = db, S = 1 - db;                   // B half used first / second in this k-tile
+    constexpr bool F8T = SPLIT == 2 && db == 1;         // fp16 + fp8: the odd virtual tiles are the e4m3 correction tiles
     const bool last = c_kt == KT - 1;
     // P1: A0 x B_F; fetch B_S of this k-tile
     stage(db, 2 + F);
@@ -988,6 +1058,18 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
     end_load();
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) bS[S][ks] = lds_b(db, S, ks);
+    if constexpr (F8T) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ks += 2) {
+        mma8(acc[0][F], bS[F][ks], bS[F][ks + 1], aF[0][ks], aF[0][ks + 1]);
+        mma8(acc[1][F], bS[F][ks], bS[F][ks + 1], aF[1][ks], aF[1][ks + 1]);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      }
+    } else {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       mma32t<F16>(acc[0][F], bS[F][ks], aF[0][ks]);
@@ -998,11 +1080,27 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
     }
+    }
     end_mfma();
     // P2: A0 x B_S; every A0 fragment is replaced by the A1 fragment of the same position right after its last use
     stage(db, 0);
     if (pending) { unit(3, em0, en0, epar); if (en0 != n0) flush_colsum(em0, en0); pending = false; }
     end_load();
+    if constexpr (F8T) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ks += 2)
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2) {
+          mma8(acc[i2][S], bS[S][ks], bS[S][ks + 1], aF[i2][ks], aF[i2][ks + 1]);
+          aF[i2][ks] = lds_a(db, 1, i2, ks);
+          aF[i2][ks + 1] = lds_a(db, 1, i2, ks + 1);
+        }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      }
+    } else {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -1015,12 +1113,27 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
+    }
     end_mfma();
     // P3: A1 x B_S; B_S is replaced by the first B half of the next k-tile
     stage(db, 2 + S);
     if (last) unit(0, m0, n0, c_i & 1);
     if (pending_mask) { stage_mask(c_i); pending_mask = false; }   // its buffer was last read by units 2, 3 of the previous tile (P1, P2)
     end_load();
+    if constexpr (F8T) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ks += 2) {
+        mma8(acc[2][S], bS[S][ks], bS[S][ks + 1], aF[0][ks], aF[0][ks + 1]);
+        mma8(acc[3][S], bS[S][ks], bS[S][ks + 1], aF[1][ks], aF[1][ks + 1]);
+        bS[S][ks] = lds_b(db ^ 1, S, ks);
+        bS[S][ks + 1] = lds_b(db ^ 1, S, ks + 1);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      }
+    } else {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       mma32t<F16>(acc[2][S], bS[S][ks], aF[0][ks]);
@@ -1032,6 +1145,7 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
       __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
+    }
     end_mfma();
     // P4: A1 x B_F; A1 is replaced by A0 of the next k-tile
     stage(db, 1);
@@ -1039,6 +1153,21 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
     if (last) unit(1, m0, n0, c_i & 1);
     if (c_kt == 0) stage_bias(c_i + 1);                 // its buffer was last read by units 2, 3 of tile c_i - 1 (P1, P2)
     end_load();
+    if constexpr (F8T) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ks += 2)
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2) {
+          mma8(acc[2 + i2][F], bS[F][ks], bS[F][ks + 1], aF[i2][ks], aF[i2][ks + 1]);
+          aF[i2][ks] = lds_a(db ^ 1, 0, i2, ks);
+          aF[i2][ks + 1] = lds_a(db ^ 1, 0, i2, ks + 1);
+        }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      }
+    } else {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -1050,6 +1179,7 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
     for (int k = 0; k < 8; ++k) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
     }
     end_mfma();
     if (last) {
@@ -1203,6 +1333,23 @@ static int launch_nt8p(const GemmNT& p, hipStream_t stream) {
   const bool cs = p.colsum_ws != nullptr;
   if (cs) (void)hipMemsetAsync(p.colsum_ws, 0, (size_t)grid * 2 * p.N * sizeof(float), stream);   // the workgroups accumulate into it
   const dim3 g(grid), b(512);
+  if (p.split == 2) {                                    // fp16 + fp8 flavours (forward activations only)
+    if constexpr (F16) {
+      static bool s8attr = false;
+      if (!s8attr) {
+        hipFuncSetAttribute((const void*)gemm_nt8p_kernel<ACT_NONE, false, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipFuncSetAttribute((const void*)gemm_nt8p_kernel<ACT_RELU, false, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipFuncSetAttribute((const void*)gemm_nt8p_kernel<ACT_RELU_BITS, false, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        s8attr = true;
+      }
+      if (cs) return SNERF_ERR_ARG;
+      if (p.act == ACT_RELU_BITS) hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_RELU_BITS, false, 2, true>), g, b, LDS, stream, p);
+      else if (p.act == ACT_RELU) hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_RELU, false, 2, true>), g, b, LDS, stream, p);
+      else if (p.act == ACT_NONE) hipLaunchKernelGGL((gemm_nt8p_kernel<ACT_NONE, false, 2, true>), g, b, LDS, stream, p);
+      else return SNERF_ERR_ARG;
+      return snerf_check_launch();
+    } else return SNERF_ERR_ARG;
+  }
   if (p.split && F16) return SNERF_ERR_ARG;
   if (p.split) {                                         // split-bf16 flavours (no bf16-aux mask: the data gradients use the bit masks)
     static bool sattr = false;
@@ -1267,11 +1414,14 @@ extern "C" int snerf_linear_fwd(const void* A, long lda, const void* W, long ldw
   // SNERF_DT_BF16X3: split-bf16 operands (see GemmNT::split).  A is [M, >= 2 K] (hi / lo interleaved per 64 columns), W [N, >= 3 K]
   // ([hi | hi | lo] per 64 columns), K the LOGICAL reduction length; a bf16 output is written in the interleaved layout (ldy >= 2 x
   // the logical width), an fp32 output (out_f32) plainly.
-  const int split = dtype == SNERF_DT_BF16X3;
+  // SNERF_DT_F16F8: the fp16 + fp8 form of the same contract (GemmNT::split == 2): A and W are [.., >= 2 K] 2-byte elements, K logical
+  int split = dtype == SNERF_DT_BF16X3 ? 1 : (dtype == SNERF_DT_F16F8 ? 2 : 0);
   if (split) {
     if (K % 64 != 0) return SNERF_ERR_ARG;
-    dtype = SNERF_DT_BF16;
-    K *= 3;
+    if (split == 2 && (act == ACT_MASK || act == ACT_MASK_BITS || colsum != nullptr)) return SNERF_ERR_ARG;   // forward activations only
+    if (split == 2 && !out_f32 && n_store % 64 != 0) return SNERF_ERR_ARG;   // (a group's e4m3 bytes are 16 columns per store: whole 64-column groups only)
+    dtype = split == 2 ? 2 : SNERF_DT_BF16;
+    K *= split == 2 ? 2 : 3;
   }
   // SNERF_DT_F16: the bf16 kernels with the fp16 MFMA and fp16 conversions (same tiles, same layouts, same rate)
   const bool f16 = dtype == 2;
@@ -1299,7 +1449,7 @@ extern "C" int snerf_linear_fwd(const void* A, long lda, const void* W, long ldw
   if (split && out_f32 && (act == ACT_MASK || colsum != nullptr)) return SNERF_ERR_ARG;
   // variant bit 14: `aux` (ACT_MASK) is a split-bf16 activation, the operands are plain bf16 (GemmNT::aux_split)
   const int aux_split = (variant >> 14) & 1;
-  if (aux_split && (split || f16 || dtype != SNERF_DT_BF16 || act != ACT_MASK)) return SNERF_ERR_ARG;
+  if (aux_split && (split || dtype != SNERF_DT_BF16 || act != ACT_MASK)) return SNERF_ERR_ARG;     // (bf16, or fp16 behind an fp16 + fp8 forward)
   GemmNT p{A, lda, W, ldw, bias, Y, ldy, aux, ldaux, colsum, M, N, K, n_store, act, out_f32, vec, colsum_ws, fast, det, ((variant >> 4) & 7) | ((variant >> 10) & 8),
            (variant >> 9) & 15, split, aux_split};               // (PROBE builds: variant bit 13 = ablation bit 8; bits 9..12 = stagger)
   variant &= 15;
@@ -1310,11 +1460,13 @@ extern "C" int snerf_linear_fwd(const void* A, long lda, const void* W, long ldw
   // the bit-mask activations exist only in the persistent kernel (the mask layout is its unit geometry)
   const bool p8 = dtype == SNERF_DT_BF16 && (variant & 8) && N % 256 == 0 && K >= 128 && fast && !(colsum != nullptr && act == ACT_RELU) &&
                   (lda * 2 * 256 < (1L << 31)) && (ldw * 2 * 256 < (1L << 31)) && !(split && (act == ACT_MASK || (colsum != nullptr && act == ACT_RELU_BITS))) &&
-                  !aux_split;                                     // (the persistent kernel's own bf16-mask loads know the plain layout only)
+                  !aux_split &&                                   // (the persistent kernel's own bf16-mask loads know the plain layout only)
+                  !(split == 2 && K < 256);                       // (fp16 + fp8: no K = 128 flavour)
   if (act >= ACT_RELU_BITS && !(p8 && (long)((M + 255) / 256) * 8 * (N / 64) * 256 < (1L << 31)))
     return SNERF_ERR_ARG;
   if (f16) {
     if (p8) return launch_nt8p<true>(p, s);
+    if (split == 2) return launch_nt<__bf16, 128, 128, 2, 2, true>(p, s);       // (the other 8-phase kernel has no e4m3 tiles)
     if ((variant & 12) && N % 256 == 0) return launch_nt8<true>(p, s);
     if ((variant & 1) && N % 256 == 0) return launch_nt<__bf16, 256, 256, 2, 4, true>(p, s);
     return launch_nt<__bf16, 128, 128, 2, 2, true>(p, s);
@@ -1826,7 +1978,7 @@ static int wgrad_launch(const void* Z, long ldz, const void* X, long ldx, float*
   }
   // variant bit 14 (dtype bf16): X is a split-bf16 activation [M, >= 2 K] of which the hi half is multiplied; K its LOGICAL width (GemmTN::split == 2)
   const int xhi = (variant >> 14) & 1;
-  if (xhi && (split || dtype != SNERF_DT_BF16)) return SNERF_ERR_ARG;
+  if (xhi && (split || (dtype != SNERF_DT_BF16 && dtype != 2))) return SNERF_ERR_ARG;     // (bf16, or fp16 behind an fp16 + fp8 forward)
   const bool f16 = dtype == 2;                        // SNERF_DT_F16: the bf16 kernels with the fp16 MFMA
   if (f16) dtype = SNERF_DT_BF16;
   const int epc = dtype == SNERF_DT_F32 ? 4 : 8;

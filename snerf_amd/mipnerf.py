@@ -199,11 +199,11 @@ class MipNerfModel(_ArenaModule):
         ops.mip_encode(s1, o, d, radii, near, far, cone, self.transform_idx, self.max_deg_point, self.nerf.cs(SKIP, H), None, self.nerf.Ew, self.dt,
                        sample_id=enc_ids, warp=warp)
         if self.encode_appearance:
-            if self.dt == ops.BF16X3:        # the split layout is written from an fp32 image of the whole condition block
+            if self.dt in ops.SPLIT_DTS:     # the split layout is written from an fp32 image of the whole condition block
                 cond = torch.empty(max(rows, 1), self.nerf.Cw, dtype=torch.float32, device=dev)
                 ops.mip_viewenc(vd, S1, self.deg_view, cond, self.nerf.Cw, ops.F32, sample_id=enc_ids)
                 ops.app_embed(self.arena.p["emb.weight"], app, S1, cond[:, self.view_dim:], ops.F32, sample_id=enc_ids)
-                ops.split_cast(cond, self.nerf.Cw, self.nerf.cs(CB, H), self.nerf.Cw)
+                ops.cast_pad(cond, self.nerf.Cw, self.nerf.cs(CB, H), self.nerf.Cw, self.dt)
             else:
                 ops.mip_viewenc(vd, S1, self.deg_view, CB[:, H:], self.nerf.Cw, self.dt, sample_id=enc_ids)
                 ops.app_embed(self.arena.p["emb.weight"], app, S1, CB[:, H + self.view_dim:], self.dt, sample_id=enc_ids)

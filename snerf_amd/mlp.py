@@ -173,6 +173,7 @@ class _PackPlan:
             self.pools[dtype] = torch.zeros(n, dtype=dtype, device=self.flat.device)
             self.maps[dtype] = idx
         self.items = None
+        self.post = []                     # fp16 + fp8 weights: (fp32 image [N, K] in the fp32 pool, its [N, 2 K] split operand), converted after the gather
 
     def view(self, handle):
         dtype, off, shape = handle
@@ -184,6 +185,8 @@ class _PackPlan:
     def refresh(self):
         for dtype, idx in self.maps.items():
             ops.gather_pack(self.flat, idx, self.pools[dtype])
+        for src, dst in self.post:
+            ops.split8_cast(src, src.shape[1], dst, src.shape[1], weight=True)
 
 
 class _Net:
@@ -192,14 +195,20 @@ class _Net:
     def __init__(self, arena: ParamArena, prefix: str, dt: int, variant: int = 8, bwd_plain: bool = False):
         self.a, self.pre, self.dt, self.variant = arena, prefix, dt, variant
         self.g = gran(dt)
-        self.km = 2 if dt == ops.BF16X3 else 1           # physical columns per logical column of an activation buffer (split-bf16: hi / lo interleaved)
+        self.km = 2 if dt in ops.SPLIT_DTS else 1        # physical columns per logical column of an activation buffer (split-bf16: hi / lo interleaved)
         self.tdt = ops.torch_dtype(dt)
         # compute="bf16x3_fwd": the FORWARD in split-bf16 (three MFMA passes: renders inside the fp32 contract), the BACKWARD as ONE plain bf16
         # pass per product -- data gradients on plain bf16 buffers with plainly packed W^T, weight gradients from the hi half of the saved
         # split activations (snerf_linear_wgrad variant bit 14), ReLU masks from the forward's bit masks or the saved hi halves (bit 14 of
         # snerf_linear_fwd).  The gradients then carry the bf16 mode's rounding (of exact forward values), at a third of the split backward.
-        self.bwd_plain = bool(bwd_plain) and dt == ops.BF16X3
+        # compute="f16f8" (dtype F16F8: fp16 tiles + e4m3 correction tiles, two pass-equivalents) has a forward only: its backward is ALWAYS the
+        # plain one, in fp16 -- on gradients scaled by a power of two chosen per call from their largest entry (fp16 has 5 exponent bits: the
+        # raw gradients of a mean-reduced loss sit in its subnormals), accumulated into a scratch gradient arena and folded into the real one
+        # with the inverse scale (_scaled_backward).
+        self.bwd_plain = (bool(bwd_plain) and dt == ops.BF16X3) or dt == ops.F16F8
+        self.bwd_dt = ops.F16 if dt == ops.F16F8 else ops.BF16
         self._in_plain_bwd = False
+        self._g = arena.g                                 # where gW / gB point: the arena's gradient views, or the scratch ones of a scaled backward
         self.dev = arena.flat.device
         self._packed_version = -1
         self.deterministic = False        # bit-reproducible gradients: partial tiles folded in a fixed order instead of fp32 atomics
@@ -239,12 +248,38 @@ class _Net:
         if not self.bwd_plain:
             yield
             return
-        saved = (self.dt, self.km, self._in_plain_bwd)
-        self.dt, self.km, self._in_plain_bwd = ops.BF16, 1, True
+        saved = (self.dt, self.km, self.tdt, self._in_plain_bwd)
+        self.dt, self.km, self.tdt, self._in_plain_bwd = self.bwd_dt, 1, ops.torch_dtype(self.bwd_dt), True
         try:
             yield
         finally:
-            self.dt, self.km, self._in_plain_bwd = saved
+            self.dt, self.km, self.tdt, self._in_plain_bwd = saved
+
+    def _scaled_backward(self, grads, run, on_done=None):
+        """fp16 backward (behind the fp16 + fp8 forward): `grads` = the fp32 gradients entering the network (None entries allowed), `run(scaled
+        grads)` the backward body.  The gradients are multiplied by S = 2^k with max |g| S in [512, 1024) -- device-side, no read-back --, the body
+        accumulates S x (parameter gradients) into a zeroed scratch copy of this network's span of the gradient arena, which is then added to
+        the real one times 1 / S; tensors `run` returns (gradients w.r.t. the encodings) are scaled back too."""
+        live = [g for g in grads if g is not None]
+        amax = torch.stack([g.abs().amax() for g in live]).amax()
+        S = torch.exp2(torch.floor(torch.log2(1024.0 / amax.clamp(min=1e-30)))).clamp(2.0 ** -24, 2.0 ** 40)
+        a, b = self.a.span(self.pre)
+        if getattr(self, "_gscratch", None) is None:
+            self._gscratch = torch.zeros(b - a, dtype=torch.float32, device=self.dev)
+            self._gs_views = {n: self._gscratch[o - a:o - a + c].view(self.a.shapes[n]) for n, (o, c) in self.a._offs.items() if n.startswith(self.pre)}
+        else:
+            self._gscratch.zero_()
+        self._g = self._gs_views
+        try:
+            out = run([None if g is None else g * S for g in grads])
+        finally:
+            self._g = self.a.g
+        inv = 1.0 / S
+        self.a.grad[a:b].addcmul_(self._gscratch, inv.expand_as(self._gscratch))
+        if on_done is not None:
+            on_done([""])
+        unscale = lambda t: t * inv if torch.is_tensor(t) else t
+        return tuple(unscale(t) for t in out) if isinstance(out, tuple) else unscale(out)
 
     def _build_plan(self, fill):
         """Run `fill()` (a pack method writing operands obtained from _zeros / returned as extra (image, dtype) pairs) on index images
@@ -258,13 +293,27 @@ class _Net:
         finally:
             self._rec = None
         plan = _PackPlan(self.a.flat)
-        if self.km == 2:          # every compute-dtype operand of the per-layer plans is a GEMM weight [N, K]: its [hi | hi | lo] form
+        if self.dt == ops.F16F8:  # GEMM weights [N, K]: gathered as fp32 images, then converted into the fp16 + fp8 operand [N, 2 K] (ops.split8_cast)
+            is_w = lambda img, dtype: dtype == self.tdt and img.dim() == 2 and id(img) not in plain
+            handles = [(id(img), plan.add(img, torch.float32 if is_w(img, dtype) else dtype), is_w(img, dtype)) for img, dtype in rec]
+            plan.finish()
+            real = {}
+            for i, h, w in handles:
+                real[i] = plan.view(h)
+                if w:
+                    assert real[i].shape[1] % 64 == 0
+                    dst = torch.zeros(real[i].shape[0], 2 * real[i].shape[1], dtype=self.tdt, device=self.dev)
+                    plan.post.append((real[i], dst))
+                    real[i] = dst
+            handles = None
+        elif self.km == 2:        # every compute-dtype operand of the per-layer plans is a GEMM weight [N, K]: its [hi | hi | lo] form
             handles = [(id(img), plan.add(split_w_image(img) if dtype == self.tdt and img.dim() == 2 and id(img) not in plain else img, dtype))
                        for img, dtype in rec]
         else:
             handles = [(id(img), plan.add(img, dtype)) for img, dtype in rec]
-        plan.finish()
-        real = {i: plan.view(h) for i, h in handles}
+        if handles is not None:
+            plan.finish()
+            real = {i: plan.view(h) for i, h in handles}
 
         def swap(v):
             if isinstance(v, torch.Tensor):
@@ -277,10 +326,10 @@ class _Net:
         return plan, swap
 
     def gW(self, name):
-        return _w2(self.a.g[self.pre + name + ".weight"])
+        return _w2(self._g[self.pre + name + ".weight"])
 
     def gB(self, name):
-        return self.a.g[self.pre + name + ".bias"]
+        return self._g[self.pre + name + ".bias"]
 
     def _refresh_fused(self, pack_fused, key="fused", dtype=torch.bfloat16):
         """weight stream / bias table of a fused kernel (fmlp_pack's layout), refreshed by the same gather.  -> (stream, bias)"""
@@ -392,12 +441,12 @@ class _Net:
             # deterministic mode and a destination the 16-byte epilogue does not cover (an unaligned view, n_store % 8 != 0): the
             # direct-store epilogue could only add its column sums with atomics (snerf_linear_fwd refuses the combination), so the
             # bias gradient comes from a fixed-order column sum of the stored data gradient instead
-            ops.linear_fwd(dZ, W, None, dX, K, n_store, act, self.dt, aux=mask, variant=self.variant, aux_split=self._in_plain_bwd and mask is not None)
+            ops.linear_fwd(dZ, W, None, dX, K, n_store, act, self.dt, aux=mask, variant=self.variant, aux_split=getattr(self, "_in_plain_bwd", False) and mask is not None)
             ops.colsum_wide_f32(dX[:, :n_store].float(), n_store, colsum, deterministic=True)     # (any width; colsum_f32_det stops at 8 columns)
             return
         ops.linear_fwd(dZ, W, None, dX, K, n_store, act, self.dt,
                        aux=mask, colsum=colsum, variant=self.variant, deterministic=self.deterministic,
-                       aux_split=self._in_plain_bwd and mask is not None)      # (the mask source is an activation the split forward saved)
+                       aux_split=getattr(self, "_in_plain_bwd", False) and mask is not None)      # (the mask source is an activation the split forward saved)
 
     def wgrad(self, name, dZ, X, n_valid, k_valid, wcol=0):
         gw = self.gW(name)
@@ -805,6 +854,8 @@ class MipProposalNet(_Net):
     def backward(self, d_raw_density, acts, want_input_grad=False):
         """-> None, or with `want_input_grad` the fp32 gradient [M, Ew] w.r.t. the encoded samples."""
         with self._bwd():
+            if self.bwd_plain and self.bwd_dt == ops.F16:
+                return self._scaled_backward([d_raw_density], lambda g: self._backward(g[0], acts, want_input_grad))
             return self._backward(d_raw_density, acts, want_input_grad)
 
     def _backward(self, d_raw_density, acts, want_input_grad):
@@ -999,10 +1050,13 @@ class MipNerfNet(_Net):
             self.fwd("sem1", S0, self.Hs, self.raw_sem, self.sc, ACT_NONE, out_f32=True)
         return raw_rgb, raw_d, ((acts, cacts, SKIP, CB, S0) if keep else None)
 
-    def backward(self, *args, **kwargs):
-        """see _backward; under `bwd_plain` (compute="bf16x3_fwd") the whole pass runs as plain bf16 launches (_Net._bwd)"""
+    def backward(self, d_raw_rgb, d_raw_density, saved, d_raw_sem=None, want_input_grad=False, want_cond_grad=False, on_done=None):
+        """see _backward; under `bwd_plain` (compute="bf16x3_fwd" / "f16f8") the whole pass runs as plain bf16 / scaled fp16 launches (_Net._bwd)"""
         with self._bwd():
-            return self._backward(*args, **kwargs)
+            if self.bwd_plain and self.bwd_dt == ops.F16:
+                return self._scaled_backward([d_raw_rgb, d_raw_density, d_raw_sem],
+                                             lambda g: self._backward(g[0], g[1], saved, g[2], want_input_grad, want_cond_grad, None), on_done)
+            return self._backward(d_raw_rgb, d_raw_density, saved, d_raw_sem, want_input_grad, want_cond_grad, on_done)
 
     def _backward(self, d_raw_rgb, d_raw_density, saved, d_raw_sem=None, want_input_grad=False, want_cond_grad=False, on_done=None):
         """-> None, or with `want_input_grad` (dE fp32 [M, Ew], dV fp32 [M, Cw]): the gradients w.r.t. the IPE and view encodings;

@@ -13,9 +13,11 @@ from . import _lib
 
 F32, BF16, F16, F64 = 0, 1, 2, 3
 BF16X3 = 4                                 # GEMMs only: split-bf16 operands, the fp32-parity mode at bf16 MFMA rates (csrc/gemm.hip, GemmNT::split)
+F16F8 = 5                                  # snerf_linear_fwd only: fp16 + fp8 split operands, the same contract in two pass-equivalents (GemmNT::split == 2)
+SPLIT_DTS = (BF16X3, F16F8)                # activation buffers hold 2 physical 2-byte columns per logical column
 ACT_NONE, ACT_RELU, ACT_MASK = 0, 1, 2
 ACT_RELU_BITS, ACT_MASK_BITS = 3, 4        # ReLU that also writes a 1-bit-per-element mask / ReLU backward from that mask
-_TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16, BF16X3: torch.bfloat16}
+_TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16, BF16X3: torch.bfloat16, F16F8: torch.float16}
 
 
 def torch_dtype(dt: int):
@@ -75,12 +77,12 @@ def linear_fwd(A, W, bias, Y, K, n_store, act, dt, out_f32=False, aux=None, cols
     if deterministic:
         variant |= 256
     if aux_split and act == ACT_MASK:
-        assert dt == BF16 and aux is not None and aux.shape[1] >= 2 * roundup(n_store, 64) - 64
+        assert dt in (BF16, F16) and aux is not None and aux.shape[1] >= 2 * roundup(n_store, 64) - 64
         variant |= 1 << 14
     _chk2d(A, _TORCH_DT[dt]); _chk2d(W, _TORCH_DT[dt]); _chk2d(Y, torch.float32 if out_f32 else _TORCH_DT[dt])
     M = A.shape[0]
-    sp = dt == BF16X3                                     # split-bf16: A [M, 2 K], W [N, 3 K], a bf16 Y [M, 2 n_store] (interleaved layout)
-    assert Y.shape[0] == M and A.shape[1] >= K * (2 if sp else 1) and W.shape[1] >= K * (3 if sp else 1)
+    sp = dt in SPLIT_DTS                                  # split-bf16: A [M, 2 K], W [N, 3 K], a bf16 Y [M, 2 n_store] (interleaved layout); fp16 + fp8: W [N, 2 K]
+    assert Y.shape[0] == M and A.shape[1] >= K * (2 if sp else 1) and W.shape[1] >= K * ((3 if dt == BF16X3 else 2) if sp else 1)
     assert Y.shape[1] >= n_store * (2 if sp and not out_f32 else 1) or (sp and not out_f32 and Y.shape[1] >= 2 * roundup(n_store, 64) - 64)
     if aux is not None and act < ACT_RELU_BITS:
         _chk2d(aux, _TORCH_DT[dt])
@@ -114,7 +116,8 @@ def relu_bits_ok(A, W, Y, K, n_store, dt, variant, consumer=False):
     """Whether snerf_linear_fwd accepts ACT_RELU_BITS (producer) / ACT_MASK_BITS (consumer) for this launch: the persistent
     8-phase kernel's conditions (mirrors the dispatch in gemm.hip)."""
     N = W.shape[0]
-    return (dt in (BF16, BF16X3, F16) and (variant & 8) and N % 256 == 0 and K * (3 if dt == BF16X3 else 1) >= 128 and Y.dtype == _TORCH_DT[dt]
+    return (dt in (BF16, BF16X3, F16, F16F8) and (variant & 8) and N % 256 == 0 and K * (3 if dt == BF16X3 else 1) >= 128 and Y.dtype == _TORCH_DT[dt]
+            and not (dt == F16F8 and (consumer or K < 128))
             and Y.stride(0) % 8 == 0 and Y.data_ptr() % 16 == 0 and n_store % 8 == 0
             and A.stride(0) * 512 < (1 << 31) and W.stride(0) * 512 < (1 << 31) and mask_bits_words(A.shape[0], N) * 4 < (1 << 31))
 
@@ -136,7 +139,7 @@ def linear_wgrad(dZ, X, dW, n_valid, k_valid, dt, variant=0, deterministic=False
     assert dZ.shape[0] == X.shape[0] and dW.shape[0] >= n_valid and dW.shape[1] >= k_valid
     Kx = X.shape[1]
     if x_split_hi:
-        assert dt == BF16 and Kx % 128 == 0
+        assert dt in (BF16, F16) and Kx % 128 == 0
         Kx //= 2
         variant |= 1 << 14
     if dt == BF16X3:
@@ -397,12 +400,12 @@ def mip_encode(s_vals, origins, directions, radii, near, far, cone, transform_id
     for t in (s_vals, origins, directions, radii, near, far):
         _f32c(t)
     ids, rows = _ids(sample_id)
-    if dt == BF16X3:
+    if dt in SPLIT_DTS:
         # the exact fp32 encoding, then the hi / lo split into the GEMM operand layout
         assert dst2 is None
         tmp = torch.empty(dst1.shape[0], width, dtype=torch.float32, device=dst1.device)
         mip_encode(s_vals, origins, directions, radii, near, far, cone, transform_idx, max_deg, tmp, None, width, F32, means_out, covs_out, sample_id, warp)
-        return split_cast(tmp, width, dst1, width)
+        return cast_pad(tmp, width, dst1, width, dt)
     if warp is not None:
         (vx, vy, vz), far_max = warp
         _f32c(far_max)
@@ -419,10 +422,10 @@ def mip_encode(s_vals, origins, directions, radii, near, far, cone, transform_id
 def mip_viewenc(viewdirs, S, deg, dst, width, dt, sample_id=None):
     _f32c(viewdirs)
     ids, rows = _ids(sample_id)
-    if dt == BF16X3:
+    if dt in SPLIT_DTS:
         tmp = torch.empty(dst.shape[0], width, dtype=torch.float32, device=dst.device)
         mip_viewenc(viewdirs, S, deg, tmp, width, F32, sample_id)
-        return split_cast(tmp, width, dst, width)
+        return cast_pad(tmp, width, dst, width, dt)
     _lib.call("snerf_mip_viewenc", _p(viewdirs), viewdirs.shape[0], S, deg, _p(dst), dst.stride(0), width, dt, _p(ids), rows, _stream())
 
 
@@ -745,9 +748,20 @@ def split_cast(src, C, dst, Cpad):
     _lib.call("snerf_split_cast", _p(src), src.stride(0), src.shape[0], C, Cpad, _p(dst), dst.stride(0), _stream())
 
 
+def split8_cast(src, C, dst, Cpad, weight=False):
+    """fp32 [M, >= C] -> rows in the fp16 + fp8 split layout (dtype F16F8; csrc/gemm.hip, GemmNT::split == 2): dst [M, >= 2 Cpad] fp16-typed, per 64
+    logical columns [fp16(x) x 64 | 128 e4m3 bytes]: the residual x - fp16(x) scaled by 2^13 and x scaled by 2^2 (activations), or -- `weight` --
+    w scaled by 2^9 and its residual scaled by 2^20; columns >= C zero."""
+    _chk2d(src, torch.float32); _chk2d(dst, torch.float16)
+    assert dst.shape[0] == src.shape[0] and dst.shape[1] >= 2 * Cpad and src.shape[1] >= C
+    _lib.call("snerf_split8_cast", _p(src), src.stride(0), src.shape[0], C, Cpad, _p(dst), dst.stride(0), 1 if weight else 0, _stream())
+
+
 def cast_pad(src, C, dst, Cpad, dt):
     if dt == BF16X3:
         return split_cast(src, C, dst, Cpad)
+    if dt == F16F8:
+        return split8_cast(src, C, dst, Cpad)
     _chk2d(src, torch.float32)
     _lib.call("snerf_cast_pad", _p(src), src.stride(0), src.shape[0], C, Cpad, _p(dst), dst.stride(0), dt, _stream())
 

@@ -31,6 +31,45 @@ def _split_pack(y, Y, n):
         Y[:, 128 * j + 64:128 * j + 64 + w] = lo[:, 64 * j:64 * j + w]
 
 
+_F8 = torch.float8_e4m3fn
+_S8_ACT, _S8_W = (2.0 ** 13, 2.0 ** 2), (2.0 ** 20, 2.0 ** 9)       # (residual scale, value scale) of activations / weights; 13 + 9 = 2 + 20 = 22
+
+
+def _e4m3(x, mul):
+    return (x * mul).clamp(-448.0, 448.0).to(_F8)
+
+
+def _s8_unpack(T, K, weight=False):
+    """fp16 + fp8 split rows [M, >= 2 K] (fp16-typed; per 64 logical columns [fp16 x 64 | 128 e4m3 bytes]) -> (hi, e4m3 residual, e4m3 value) as fp32,
+    the e4m3 parts still carrying their power-of-two scales"""
+    M = T.shape[0]
+    t = T[:, :2 * K].contiguous().view(M, K // 64, 128)
+    hi = t[:, :, :64].float().reshape(M, K)
+    by = t[:, :, 64:].contiguous().view(torch.uint8).reshape(M, K // 64, 128)
+    first, second = by[:, :, :64].contiguous().view(_F8).float().reshape(M, K), by[:, :, 64:].contiguous().view(_F8).float().reshape(M, K)
+    return (hi, second, first) if weight else (hi, first, second)
+
+
+def _s8_pack(y, Y, n, weight=False):
+    mr, mx = _S8_W if weight else _S8_ACT
+    hi = y.to(torch.float16)
+    r8, x8 = _e4m3(y - hi.float(), mr).view(torch.uint8), _e4m3(y, mx).view(torch.uint8)
+    yb = Y.view(torch.uint8).view(Y.shape[0], -1)              # [M, 2 x physical columns] bytes
+    for j in range((n + 63) // 64):
+        w = min(64, n - 64 * j)
+        Y[:, 128 * j:128 * j + w] = hi[:, 64 * j:64 * j + w]
+        b0 = 256 * j + 128
+        first, second = (x8, r8) if weight else (r8, x8)
+        yb[:, b0:b0 + w] = first[:, 64 * j:64 * j + w]
+        yb[:, b0 + 64:b0 + 64 + w] = second[:, 64 * j:64 * j + w]
+
+
+def split8_cast(src, C, dst, Cpad, weight=False):
+    y = torch.zeros(src.shape[0], Cpad)
+    y[:, :C] = src[:, :C]
+    _s8_pack(y, dst, Cpad, weight)
+
+
 def split_cast(src, C, dst, Cpad):
     y = torch.zeros(src.shape[0], Cpad)
     y[:, :C] = src[:, :C]
@@ -39,9 +78,26 @@ def split_cast(src, C, dst, Cpad):
 
 def linear_fwd(A, W, bias, Y, K, n_store, act, dt, out_f32=False, aux=None, colsum=None, variant=0, deterministic=False, aux_split=False):
     assert W.shape[0] % 128 == 0 and K % (32 if dt == 0 else 64) == 0
-    if aux_split and act == 2:                                   # plain bf16 data gradient, mask = the hi half of a split-bf16 activation
-        assert dt == 1
+    if aux_split and act == 2:                                   # plain bf16 / fp16 data gradient, mask = the hi half of a split activation
+        assert dt in (1, 2)
         aux = _split_unpack(aux, 64 * ((n_store + 63) // 64))[0]
+    if dt == 5:                                                 # fp16 + fp8: hi.hi on fp16 + e4m3 corrections r.w + x.(w - hi) (csrc/gemm.hip, GemmNT::split == 2)
+        assert act in (0, 1, 3) and colsum is None
+        ah, ar, ax = _s8_unpack(A, K)
+        wh, wr, wx = _s8_unpack(W, K, weight=True)
+        y = ah @ wh.t() + (ar @ wx.t() + ax @ wr.t()) * 2.0 ** -22
+        if bias is not None:
+            y = y + bias
+        y = y[:, :n_store]
+        if act in (1, 3):
+            y = torch.relu(y)
+        if act == 3:
+            _BITS[aux.data_ptr()] = y.to(torch.float16).float() > 0
+        if out_f32:
+            Y[:, :n_store] = y
+        else:
+            _s8_pack(y, Y, n_store)
+        return
     if dt == 4:                                                 # split-bf16: hi.hi + lo.hi + hi.lo, fp32 accumulation (csrc/gemm.hip)
         ah, al = _split_unpack(A, K)
         w = W[:, :3 * K].float().reshape(W.shape[0], K // 64, 3, 64)
@@ -86,8 +142,8 @@ def linear_fwd(A, W, bias, Y, K, n_store, act, dt, out_f32=False, aux=None, cols
 
 
 def linear_wgrad(dZ, X, dW, n_valid, k_valid, dt, variant=0, deterministic=False, x_split_hi=False):
-    if x_split_hi:                                              # plain bf16 dZ x the hi half of a split-bf16 activation
-        assert dt == 1 and X.shape[1] % 128 == 0
+    if x_split_hi:                                              # plain bf16 / fp16 dZ x the hi half of a split activation
+        assert dt in (1, 2) and X.shape[1] % 128 == 0
         dW[:n_valid, :k_valid] += (dZ.float().t() @ _split_unpack(X, X.shape[1] // 2)[0])[:n_valid, :k_valid]
         return
     if dt == 4:                                                 # the kernels multiply the physical matrices: all four hi / lo combinations
@@ -122,6 +178,8 @@ def mip_encode(s_vals, origins, directions, radii, near, far, cone, transform_id
     v = torch.cat([enc, torch.zeros(enc.shape[0], width - enc.shape[1])], -1)
     if dt == 4:
         return split_cast(v, width, dst1, width)
+    if dt == 5:
+        return split8_cast(v, width, dst1, width)
     dst1[:, :width] = v.to(dst1.dtype)
     if dst2 is not None:
         dst2[:, :width] = v.to(dst2.dtype)
@@ -130,8 +188,8 @@ def mip_encode(s_vals, origins, directions, radii, near, far, cone, transform_id
 def mip_viewenc(viewdirs, S, deg, dst, width, dt, sample_id=None):
     assert sample_id is None
     e = om.pos_enc(viewdirs, 0, deg, True)[:, None].expand(-1, S, -1).reshape(-1, 3 + 6 * deg)
-    if dt == 4:
-        return split_cast(torch.cat([e, torch.zeros(e.shape[0], width - e.shape[1])], -1), width, dst, width)
+    if dt in (4, 5):
+        return (split_cast if dt == 4 else split8_cast)(torch.cat([e, torch.zeros(e.shape[0], width - e.shape[1])], -1), width, dst, width)
     dst[:, :width] = torch.cat([e, torch.zeros(e.shape[0], width - e.shape[1])], -1).to(dst.dtype)
 
 
@@ -282,6 +340,8 @@ def colsum_f32(x, C, out, deterministic=False):
 def cast_pad(src, C, dst, Cpad, dt):
     if dt == 4:
         return split_cast(src, C, dst, Cpad)
+    if dt == 5:
+        return split8_cast(src, C, dst, Cpad)
     dst[:, :Cpad] = 0
     dst[:, :C] = src[:, :C].to(dst.dtype)
 
@@ -885,7 +945,7 @@ def adam_step_dev(p, g, m, v, lr, b1, b2, eps, step_dev, grad_scale=1.0, zero_gr
     adam_step(p, g, m, v, lr, b1, b2, eps, 0, grad_scale, zero_grad, step_dev=step_dev, **kw)
 
 
-_NAMES = ["nonfinite_flag", "fmlp_zip_fwd", "fmlp_zip_train_fwd", "fmlp_zip_chain_bwd", "zip_prop_mlp_fwd", "zip_prop_mlp_bwd", "colsum_wide_f32", "zip_glo_modulate", "zip_glo_modulate_bwd", "fchain_bwd", "app_embed", "app_embed_bwd", "split_cast", "fcolour_fwd", "fcolour_bwd", "gather_pack", "adam_step_dev", "grad_clip_coef", "fmlp_classic_fwd", "fmlp_classic_pts_fwd", "fmlp_proposal_fwd", "fmlp_classic_train_fwd", "fmlp_proposal_train_fwd", "classic_get_rays", "classic_ndc_rays", "classic_ray_batch", "zip_encode_prop_fwd", "mip_encode_bwd", "mip_viewenc_bwd", "hash_decay", "zip_percentiles", "zip_pixels_to_rays", "zip_loss_tail", "semantic_composite_fwd", "semantic_composite_bwd", "zip_resample", "zip_encode_fwd", "zip_encode_fwd_count", "zip_encode_bwd", "zip_encode_bwd_binned", "zip_encode_ray_bwd", "zip_composite_fwd", "zip_composite_bwd",
+_NAMES = ["nonfinite_flag", "fmlp_zip_fwd", "fmlp_zip_train_fwd", "fmlp_zip_chain_bwd", "zip_prop_mlp_fwd", "zip_prop_mlp_bwd", "colsum_wide_f32", "zip_glo_modulate", "zip_glo_modulate_bwd", "fchain_bwd", "app_embed", "app_embed_bwd", "split_cast", "split8_cast", "fcolour_fwd", "fcolour_bwd", "gather_pack", "adam_step_dev", "grad_clip_coef", "fmlp_classic_fwd", "fmlp_classic_pts_fwd", "fmlp_proposal_fwd", "fmlp_classic_train_fwd", "fmlp_proposal_train_fwd", "classic_get_rays", "classic_ndc_rays", "classic_ray_batch", "zip_encode_prop_fwd", "mip_encode_bwd", "mip_viewenc_bwd", "hash_decay", "zip_percentiles", "zip_pixels_to_rays", "zip_loss_tail", "semantic_composite_fwd", "semantic_composite_bwd", "zip_resample", "zip_encode_fwd", "zip_encode_fwd_count", "zip_encode_bwd", "zip_encode_bwd_binned", "zip_encode_ray_bwd", "zip_composite_fwd", "zip_composite_bwd",
           "linear_fwd", "linear_wgrad", "classic_embed", "mip_encode", "mip_viewenc", "classic_sample_pdf", "classic_points",
           "classic_merge_sort", "mip_resample", "stratified", "mip_composite_fwd", "mip_composite_bwd", "classic_composite_fwd",
           "classic_composite_bwd", "adam_step", "colsum_f32", "cast_pad", "pinhole_rays", "mip_loss_tail"]

@@ -269,7 +269,11 @@ def test_precision_modes_on_fitted_weights():
         tr.step(rays, rgb, t_hit, torch.ones_like(t_hit))
     res = ert_scene.precision_on_fitted_weights(m, _model, rows=20)
     print("MEASURED precision on fitted weights:", res)
-    x3, b = res["bf16x3"], res["bf16"]
+    x3, b, f8 = res["bf16x3"], res["bf16"], res["f16f8"]
     assert x3["max_abs_err_rgb"] < 5e-5 and x3["max_rel_err_depth"] < 2.5e-4 and x3["psnr_db"] > 110.0, x3
+    # compute="f16f8" (fp16 tiles + e4m3 correction tiles, two pass-equivalents): the same bounds (emulated before it was built: rgb 1.6e-5, depth
+    # max rel 7.8e-5, 119 dB, profiles/r6_c_two_pass_precision_with_split_schemes.txt -- the fp32 yardstick itself moves by 5e-5 in depth between
+    # fp32 and fp64 accumulation)
+    assert f8["max_abs_err_rgb"] < 5e-5 and f8["max_rel_err_depth"] < 2.5e-4 and f8["psnr_db"] > 108.0, f8
     assert b["psnr_db"] > 58.0 and b["max_abs_err_rgb"] < 1.5e-2 and b["p999_rel_err_depth"] < 1.5e-2, b
     assert b["max_abs_err_rgb"] > 10 * x3["max_abs_err_rgb"], "bf16 is expected to drift on fitted weights; the split mode is not"

@@ -153,6 +153,81 @@ def test_linear_dgrad_mask_from_split_activation(ops, M, Nred, Kout, variant):
         close(out[0][0][:, :n_store], ref[:, :n_store], 1e-2, 1e-2, "dgrad")
 
 
+def _s8_unpack(T, K, weight=False):
+    """rows in the fp16 + fp8 split layout (fp16-typed [M, >= 2 K]) -> (fp16 part, e4m3 residual / 2^s, e4m3 value / 2^s) as float64"""
+    M = T.shape[0]
+    t = T[:, :2 * K].contiguous().cpu().view(M, K // 64, 128)
+    hi = t[:, :, :64].double().reshape(M, K)
+    by = t[:, :, 64:].contiguous().view(torch.uint8).reshape(M, K // 64, 128)
+    f, s = by[:, :, :64].contiguous().view(torch.float8_e4m3fn).double().reshape(M, K), by[:, :, 64:].contiguous().view(torch.float8_e4m3fn).double().reshape(M, K)
+    return (hi, s / 2.0 ** 20, f / 2.0 ** 9) if weight else (hi, f / 2.0 ** 13, s / 2.0 ** 2)
+
+
+@pytest.mark.parametrize("M,N,K,variant", [(300, 128, 128, 0), (1000, 256, 1152, 0), (777, 256, 320, 8), (2048, 1024, 1024, 8), (70000, 512, 128, 8), (100000, 256, 192, 8),
+                                           (515, 256, 64, 8)])
+def test_linear_fwd_f16f8(ops, M, N, K, variant):
+    """dtype F16F8 (fp16 tiles + e4m3 correction tiles on the block-scaled MFMA): (1) ops.split8_cast against a host conversion; (2) the product
+    against the float64 sum of exactly the three terms the kernels multiply (hi.hi + r8.w8 + x8.wr8 from the unpacked operands): 2e-5 of the row
+    scale sum |a||w| -- the block-scaled MFMA sums its 64 e4m3 products with about 6 significant bits of their largest one (measured: 2^-6 of the
+    correction's own magnitude, which is 2^-11 of the product's), fp32 accumulation noise elsewhere; (3) against the TRUE product of the fp32 inputs: 2^-14 of sum |a||w| (bf16 alone: 2^-8); (4) the
+    interleaved fp16 + fp8 output equals split8_cast of the fp32 output of the same launch, ReLU bit masks included."""
+    a32 = gen(M, K, seed=1) * (0.25 + 3.75 * torch.rand(M, 1, generator=torch.Generator().manual_seed(5)))   # (rows of O(1) scale: the e4m3 residual has an ABSOLUTE floor of 2^-23)
+    w32 = gen(N, K, seed=2) / K ** 0.5
+    A = torch.zeros(M, 2 * K + 128, dtype=torch.float16, device="cuda")            # wider buffer: lda != 2 K
+    ops.split8_cast(a32.cuda(), K, A, K)
+    W = torch.zeros(N, 2 * K, dtype=torch.float16, device="cuda")
+    ops.split8_cast(w32.cuda(), K, W, K, weight=True)
+    ah, ar, ax = _s8_unpack(A, K)
+    wh, wr, wx = _s8_unpack(W, K, weight=True)
+    assert torch.equal(ah.float(), a32.half().float()) and torch.equal(wh.float(), w32.half().float())
+    q = lambda x, m: (x * m).clamp(-448, 448).to(torch.float8_e4m3fn).double() / m
+    assert torch.equal(ar, q(a32 - a32.half().float(), 2.0 ** 13)) and torch.equal(ax, q(a32, 4.0)), "activation bytes"
+    assert torch.equal(wr, q(w32 - w32.half().float(), 2.0 ** 20)) and torch.equal(wx, q(w32, 512.0)), "weight bytes"
+    bias = gen(N, seed=3).cuda()
+    terms = ah @ wh.t() + ar @ wx.t() + ax @ wr.t() + bias.double().cpu()
+    true = a32.double() @ w32.double().t() + bias.double().cpu()
+    scale = (a32.double().abs() @ w32.double().abs().t())
+    Y32 = torch.zeros(M, N, dtype=torch.float32, device="cuda")
+    ops.linear_fwd(A, W, bias, Y32, K, N, ops.ACT_NONE, ops.F16F8, out_f32=True, variant=variant)        # (fp32 outputs: the 128 x 128 kernel)
+    e_terms = float(((Y32.double().cpu() - terms).abs() / scale).max())
+    e_true = float(((Y32.double().cpu() - true).abs() / scale).max())
+    print(f"MEASURED f16f8 M {M} N {N} K {K}: vs its own three terms {e_terms:.2e}, vs the true product {e_true:.2e} of sum |a||w|")
+    assert e_terms < 3e-5 and e_true < 2.0 ** -14
+    n_store = N - 64
+    Y = torch.full((M, 2 * N), 7.0, dtype=torch.float16, device="cuda")
+    act = ops.ACT_RELU
+    bits = None
+    if ops.relu_bits_ok(A, W, Y, K, n_store, ops.F16F8, variant):
+        act, bits = ops.ACT_RELU_BITS, torch.zeros(ops.mask_bits_words(M, N), dtype=torch.int32, device="cuda")
+    ops.linear_fwd(A, W, bias, Y, K, n_store, act, ops.F16F8, aux=bits, variant=variant)                  # (variant 8: the persistent kernel)
+    assert bool((Y[:, 2 * n_store:] == 7.0).all()), "columns >= n_store must not be written"
+    yr = torch.relu(Y32).double().cpu()[:, :n_store]
+    yh, yr8, yx8 = (t[:, :n_store] for t in _s8_unpack(Y, N))
+    # the kernels' own fp32 value differs from Y32 by summation order only: hi part within two fp16 ulps, hi + residual within 2^-13 of the value
+    # (+ the residual's absolute floor), the value byte within an e4m3 ulp (2^-3) or its floor
+    atol = 8e-6 * (K / 64) ** 0.5                                  # (what two summation orders of K products differ by)
+    assert bool(((yh - yr).abs() <= 2.0 ** -10 * yr.abs() + atol).all())
+    assert bool(((yh + yr8 - yr).abs() <= 2.0 ** -14 * yr.abs() + atol).all())
+    assert bool(((yx8 - yr).abs() <= 2.0 ** -3 * yr.abs() + 2.0 ** -10).all())
+    assert bool(((yh > 0) == (yr > 0))[(yr.abs() > 1e-3)].all())
+    if variant == 0:                                                 # same kernel as the fp32 launch: the very same accumulators, so the bytes are those of split8_cast
+        exp = _cast_ref(ops, torch.relu(Y32), N)
+        assert torch.equal(Y[:, :2 * n_store], exp[:, :2 * n_store]), "interleaved output != split8_cast(fp32 output)"
+    if bits is not None:                                             # the bit mask reproduces the sign pattern: a plain fp16 data gradient masked by it == masked by the hi halves
+        dZ = gen(M, 256, seed=24).half().cuda()
+        Wt = (gen(N, 256, seed=25) / 16).half().cuda()
+        d1 = torch.zeros(M, N, dtype=torch.float16, device="cuda"); d2 = torch.zeros_like(d1)
+        ops.linear_fwd(dZ, Wt, None, d1, 256, n_store, ops.ACT_MASK_BITS, ops.F16, aux=bits, variant=8)
+        ops.linear_fwd(dZ, Wt, None, d2, 256, n_store, ops.ACT_MASK, ops.F16, aux=Y, variant=0, aux_split=True)
+        assert torch.equal(d1, d2)
+
+
+def _cast_ref(ops, y32, N):
+    out = torch.zeros(y32.shape[0], 2 * N, dtype=torch.float16, device="cuda")
+    ops.split8_cast(y32, N, out, N)
+    return out
+
+
 @pytest.mark.parametrize("M,N,K,dt", [(1000, 256, 256, 1), (70001, 512, 320, 1), (4096, 1024, 1024, 1), (1000, 256, 256, 2), (70001, 512, 320, 2)])
 def test_relu_bit_mask_roundtrip(ops, M, N, K, dt):
     """ACT_RELU_BITS writes the activation AND a 1-bit mask; ACT_MASK_BITS must reproduce ACT_MASK on that activation exactly (bf16 and fp16)."""
