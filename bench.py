@@ -799,7 +799,7 @@ def main():
     ap.add_argument("--rays", type=int, default=4096, help="rays per GPU per step (weak scaling) / global rays per step (--scaling strong)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --rays per GPU whatever N (default); strong: the reference's --rays-ray batch split across the N GPUs")
-    ap.add_argument("--compute", default="bf16", choices=["bf16", "f32", "bf16x3", "bf16x3_fwd", "f16f8"])
+    ap.add_argument("--compute", default="bf16", choices=["bf16", "f32", "bf16x3", "bf16x3_fwd", "f16f8", "fp16"])
     ap.add_argument("--variant", type=int, default=8, help="NT GEMM variant: 8 = persistent 8-phase 256x256 (default), 4 = 8-phase, 1 = 256x256 block-issue, 0 = 128x128")
     ap.add_argument("--no-frame", action="store_true", help="skip the 1600x900 frame render")
     ap.add_argument("--no-cpu", action="store_true", help="skip the host-CPU baseline")
@@ -1171,6 +1171,23 @@ def main():
                                          "single-pass bf16 data and weight gradients (hi halves of the saved activations); gradient error between the two pure modes "
                                          "(tests/test_paths.py::test_mipnerf_split_forward_plain_backward)"}
         del txf, mxf
+        torch.cuda.empty_cache()
+        # one fp16 pass (compute="fp16" on the mip path: 11 significant bits per operand instead of bf16's 8, per-layer launches, scaled fp16 backward)
+        mh = build_model("fp16", device)
+        mh.load_state_dict({k: v.clone() for k, v in model.state_dict().items()})
+        th = MipTrainer(mh, lr=5e-4)
+        for _ in range(2):
+            th.step(rays, tgt, depth, conf)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            th.step(rays, tgt, depth, conf)
+        torch.cuda.synchronize()
+        dth = (time.perf_counter() - t0) / 5
+        out["fp16_mode"] = {"rays_per_s": round(n / dth, 1), "ms_per_step": round(dth * 1e3, 2), "steps": 5,
+                            "note": "compute='fp16': the bf16 step's GEMMs on the f16 MFMA (same rate); the 256- / 128-wide networks per layer (the fused register-resident "
+                                    "kernels are bf16); precision on fitted weights in fitted_weights_precision.fp16"}
+        del th, mh
         torch.cuda.empty_cache()
         # the same contract in TWO pass-equivalents: fp16 tiles + e4m3 correction tiles on the block-scaled MFMA (compute="f16f8"), scaled fp16 backward
         m8 = build_model("f16f8", device)

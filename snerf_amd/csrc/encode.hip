@@ -296,7 +296,9 @@ static int mip_encode_launch(const float* s_vals, const float* origins, const fl
                dst1, ld1, dst2, ld2, width, means_out, covs_out, sample_id, fn_idx, {vx, vy, vz}, far_max};
   const int blocks = (int)((a.M + 255) / 256);
   if (dtype == SNERF_DT_F32) hipLaunchKernelGGL(mip_encode_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(mip_encode_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+  else if (dtype == SNERF_DT_F16) hipLaunchKernelGGL(mip_encode_kernel<_Float16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+  else if (dtype == SNERF_DT_BF16) hipLaunchKernelGGL(mip_encode_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+  else return SNERF_ERR_ARG;
   return snerf_check_launch();
 }
 

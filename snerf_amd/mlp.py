@@ -255,6 +255,10 @@ class _Net:
         finally:
             self.dt, self.km, self.tdt, self._in_plain_bwd = saved
 
+    def _fp16_backward(self):
+        """fp16 gradient GEMMs (behind the fp16 + fp8 forward, or compute="fp16" on the mip path): they run on scaled gradients (_scaled_backward)"""
+        return (self.bwd_plain and self.bwd_dt == ops.F16) or self.dt == ops.F16
+
     def _scaled_backward(self, grads, run, on_done=None):
         """fp16 backward (behind the fp16 + fp8 forward): `grads` = the fp32 gradients entering the network (None entries allowed), `run(scaled
         grads)` the backward body.  The gradients are multiplied by S = 2^k with max |g| S in [512, 1024) -- device-side, no read-back --, the body
@@ -854,7 +858,7 @@ class MipProposalNet(_Net):
     def backward(self, d_raw_density, acts, want_input_grad=False):
         """-> None, or with `want_input_grad` the fp32 gradient [M, Ew] w.r.t. the encoded samples."""
         with self._bwd():
-            if self.bwd_plain and self.bwd_dt == ops.F16:
+            if self._fp16_backward():
                 return self._scaled_backward([d_raw_density], lambda g: self._backward(g[0], acts, want_input_grad))
             return self._backward(d_raw_density, acts, want_input_grad)
 
@@ -1053,7 +1057,7 @@ class MipNerfNet(_Net):
     def backward(self, d_raw_rgb, d_raw_density, saved, d_raw_sem=None, want_input_grad=False, want_cond_grad=False, on_done=None):
         """see _backward; under `bwd_plain` (compute="bf16x3_fwd" / "f16f8") the whole pass runs as plain bf16 / scaled fp16 launches (_Net._bwd)"""
         with self._bwd():
-            if self.bwd_plain and self.bwd_dt == ops.F16:
+            if self._fp16_backward():
                 return self._scaled_backward([d_raw_rgb, d_raw_density, d_raw_sem],
                                              lambda g: self._backward(g[0], g[1], saved, g[2], want_input_grad, want_cond_grad, None), on_done)
             return self._backward(d_raw_rgb, d_raw_density, saved, d_raw_sem, want_input_grad, want_cond_grad, on_done)

@@ -275,5 +275,8 @@ def test_precision_modes_on_fitted_weights():
     # max rel 7.8e-5, 119 dB, profiles/r6_c_two_pass_precision_with_split_schemes.txt -- the fp32 yardstick itself moves by 5e-5 in depth between
     # fp32 and fp64 accumulation)
     assert f8["max_abs_err_rgb"] < 5e-5 and f8["max_rel_err_depth"] < 2.5e-4 and f8["psnr_db"] > 108.0, f8
+    # compute="fp16": one pass like bf16, 11 significant bits instead of 8 (emulated: 81-84 dB, rgb 5e-4, depth 8e-4-1e-3)
+    h = res["fp16"]
+    assert h["psnr_db"] > b["psnr_db"] + 8.0 and h["max_abs_err_rgb"] < 0.25 * b["max_abs_err_rgb"], (h, b)
     assert b["psnr_db"] > 58.0 and b["max_abs_err_rgb"] < 1.5e-2 and b["p999_rel_err_depth"] < 1.5e-2, b
     assert b["max_abs_err_rgb"] > 10 * x3["max_abs_err_rgb"], "bf16 is expected to drift on fitted weights; the split mode is not"

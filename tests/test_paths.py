@@ -248,7 +248,8 @@ def test_mipnerf_forward_vs_reference_golden(backend, golden):
 @pytest.mark.parametrize("compute,hidden,S0,P1,n,tol", [("f32", 1024, 64, 129, 96, 1e-4), ("bf16", 1024, 64, 129, 96, 4e-2),
                                                        ("f32", 128, 128, 128, 70, 1e-4),
                                                        # split-bf16 (three bf16 MFMA passes per product): the SAME 1e-4 bounds as exact fp32
-                                                       ("bf16x3", 1024, 64, 129, 96, 1e-4), ("bf16x3", 128, 128, 128, 70, 1e-4)])
+                                                       ("bf16x3", 1024, 64, 129, 96, 1e-4), ("bf16x3", 128, 128, 128, 70, 1e-4),
+                                                       ("f16f8", 1024, 64, 129, 96, 1e-4), ("fp16", 1024, 64, 129, 96, 1e-2)])
 def test_mipnerf_forward_vs_oracle(backend, compute, hidden, S0, P1, n, tol):
     """Full-width network at the BASELINE shape (64 proposal + 128 fine intervals) and the shipped 128+127 shape."""
     from snerf_amd import mipnerf
@@ -264,7 +265,7 @@ def test_mipnerf_forward_vs_oracle(backend, compute, hidden, S0, P1, n, tol):
         ret = m(rays, True, False, 0., s_rand=s_rand.to(DEV), u=u.to(DEV))
     assert torch.equal(ret[0][3].cpu(), ref[0][3]), "level-0 fence posts must be bit-exact"
     close(ret[0][4], ref[0][4], tol, tol * 1e-2, "w0"); close(ret[0][1], ref[0][1], tol, tol, "dist0")
-    if compute in ("f32", "bf16x3"):
+    if compute in ("f32", "bf16x3", "f16f8"):
         close(ret[1][4], ref[1][4], 1e-4, 1e-5, "s1")
         close(ret[1][0], ref[1][0], tol, tol, "rgb"); close(ret[1][1], ref[1][1], tol, tol, "distance"); close(ret[1][2], ref[1][2], tol, tol, "acc")
         psnr = common.psnr(ret[1][0].cpu(), ref[1][0])
@@ -285,7 +286,10 @@ def test_mipnerf_forward_vs_oracle(backend, compute, hidden, S0, P1, n, tol):
             assert psnr > 35.0, f"bf16 PSNR vs fp32 oracle {psnr:.1f} dB (emulated kernels: torch bf16 matmul roundings)"
 
 
-@pytest.mark.parametrize("compute,hidden,tol", [("f32", 64, 3e-4), ("bf16", 128, 8e-2), ("bf16x3", 64, 3e-4)])
+@pytest.mark.parametrize("compute,hidden,tol", [("f32", 64, 3e-4), ("bf16", 128, 8e-2), ("bf16x3", 64, 3e-4),
+                                                # compute="fp16" on the mip path: fp16 operands on the f16 MFMA (11 bits instead of bf16's 8), the backward on
+                                                # power-of-two scaled gradients (mlp._Net._scaled_backward); held to a quarter of the bf16 bound
+                                                ("fp16", 128, 2e-2)])
 def test_mipnerf_backward_vs_autograd(backend, compute, hidden, tol):
     from snerf_amd import mipnerf
     S0, P1, n = 24, 25, 36

@@ -81,7 +81,7 @@ def precision_on_fitted_weights(model, build, rows=40, row0=430):
     sd = {k: v.clone() for k, v in model.state_dict().items()}
     outs = {}
     with torch.no_grad():
-        for mode in ("f32", "bf16x3", "f16f8", "bf16"):
+        for mode in ("f32", "bf16x3", "f16f8", "fp16", "bf16"):
             m = model if mode == "bf16" else build(mode)
             if m is not model:
                 m.load_state_dict(sd)
@@ -91,7 +91,7 @@ def precision_on_fitted_weights(model, build, rows=40, row0=430):
     torch.cuda.empty_cache()
     ref = outs["f32"]
     res = {"rays": n, "what": f"rows {row0}..{row0 + rows - 1} of the 1600 x 900 frame of the FITTED model, each mode vs compute='f32' on the same weights"}
-    for mode in ("bf16x3", "f16f8", "bf16"):
+    for mode in ("bf16x3", "f16f8", "fp16", "bf16"):
         rgb, dist, acc = outs[mode]
         mse = float(((rgb.double() - ref[0].double()) ** 2).mean())
         res[mode] = {"psnr_db": float("inf") if mse == 0 else round(-10.0 * math.log10(mse), 2),

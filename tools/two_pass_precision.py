@@ -124,7 +124,7 @@ def main():
         return {"psnr_db": round(-10 * math.log10(max(mse, 1e-30)), 2), "max_abs_err_rgb": float((rgb - ref[0]).abs().max()),
                 "max_rel_err_depth": float(rel.max()), "p999_rel_err_depth": float(torch.quantile(rel.float(), 0.999)), "max_abs_err_acc": float((acc - ref[2]).abs().max())}
     res = {"fit_steps": 120, "fit_s": round(t_fit, 1), "rays": n, "tolerance": 1e-4, "emulated_two_pass_bounds": {k: err(v) for k, v in outs.items()},
-           "kernels_vs_their_f32_mode": {k: kern[k] for k in ("bf16x3", "f16f8", "bf16")}}
+           "kernels_vs_their_f32_mode": {k: kern[k] for k in ("bf16x3", "f16f8", "fp16", "bf16")}}
     print(json.dumps(res))
     print(f"\n{'operands':18s} {'PSNR dB':>8s} {'rgb max abs':>12s} {'depth max rel':>14s} {'depth p99.9':>12s} {'acc max abs':>12s}   inside 1e-4?")
     rowsf = list(res["emulated_two_pass_bounds"].items()) + [("kernels: " + k, v) for k, v in res["kernels_vs_their_f32_mode"].items()]
