@@ -755,7 +755,9 @@ def shipped_shape_leg(device, n_rays=4096, steps=5):
             "ms_per_step": round(dt * 1e3, 3), "rays_per_s": round(n_rays / dt, 1), "whole_step_tflops": round(3 * fwd * n_rays / dt / 1e12, 1)}
 
 
-PROSE_KEYS = ("what", "note", "frame_what", "frame_note", "includes", "traffic_source", "mode", "scene", "window", "kernel", "parallelism", "collective", "step")
+PROSE_KEYS = ("what", "note", "frame_what", "frame_note", "includes", "traffic_source", "mode", "scene", "window", "kernel", "parallelism", "collective", "step",
+              # numbers only the verbose line carries (the compact one must stay under the driver's 8 KB tail)
+              "losses_last_step", "leg_wall_s", "p999_rel_err_depth", "max_abs_err_acc")
 LAST_LEGS = ("path_b_ert", "path_b", "grid_encoder", "path_c")          # the driver keeps the line's 8 KB tail: the other configs' numbers go last
 
 

@@ -17,12 +17,12 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.dirname(HERE))
 
 
-def _build(n_samples=8, n_fine=9, hidden=64):
+def _build(n_samples=8, n_fine=9, hidden=64, compute="f32"):
     from snerf_amd.mipnerf import MipNerfModel
     torch.manual_seed(0)
     return MipNerfModel(n_samples=n_samples, N_fine=n_fine, no_warp_sample=0, ray_shape="cone", fn=1, radius=3., transform_idx=0,
                         real=True, rgb_layer=3, hidden_layer=hidden, density_noise=0., max_deg_point=16, proposal_hidden_layer=64,
-                        proposal_loss=True, compute="f32", device="cpu")
+                        proposal_loss=True, compute=compute, device="cpu")
 
 
 def _data(n):
@@ -33,13 +33,13 @@ def _data(n):
     return rays, tgt
 
 
-def _worker(rank, world, init_file, n, out_file):
+def _worker(rank, world, init_file, n, out_file, compute="f32"):
     from cpu_ops_emulation import emulate_ops
     from snerf_amd.trainer import MipTrainer, shard_rays
     dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
     torch.set_num_threads(2)
     with emulate_ops():
-        model = _build()
+        model = _build(compute=compute)
         if rank != 0:
             with torch.no_grad():
                 model.arena.flat.add_(1.0)          # deliberately different: broadcast must fix it
@@ -59,24 +59,27 @@ def _worker(rank, world, init_file, n, out_file):
 
 
 @pytest.mark.timeout(300)
-def test_ray_sharded_data_parallel_matches_single_process():
+@pytest.mark.parametrize("compute,tol", [("f32", 2e-5), ("f16f8", 1e-3), ("bf16x3_fwd", 1e-3)])
+def test_ray_sharded_data_parallel_matches_single_process(compute, tol):
+    """compute="f16f8" / "bf16x3_fwd": the modes whose backward differs from their forward's layout (scaled fp16 / plain bf16 gradients through a
+    scratch arena, one exchange announcement per network): the ranks must still agree bit for bit and follow the single-process run."""
     from cpu_ops_emulation import emulate_ops
     from snerf_amd.trainer import MipTrainer
     n, world = 24, 2
     with tempfile.TemporaryDirectory() as td:
         init_file, out_file = os.path.join(td, "init"), os.path.join(td, "out.pt")
-        mp.spawn(_worker, args=(world, init_file, n, out_file), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, init_file, n, out_file, compute), nprocs=world, join=True)
         gathered = torch.load(out_file)
     assert torch.equal(gathered[0], gathered[1]), "ranks diverged"
     with emulate_ops():
-        model = _build()
+        model = _build(compute=compute)
         tr = MipTrainer(model, lr=1e-2)
         rays, tgt = _data(n)
         for _ in range(2):
             tr.step(rays, tgt, randomized=False)
     ref = model.arena.flat
     err = (gathered[0] - ref).abs().max().item()
-    assert err < 2e-5, f"data-parallel parameters differ from the single-process run by {err:.3e}"
+    assert err < tol, f"data-parallel parameters differ from the single-process run by {err:.3e}"
     assert (ref - _build().arena.flat).abs().max().item() > 1e-3, "the optimiser did not move the parameters"
 
 
