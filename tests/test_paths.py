@@ -371,6 +371,42 @@ def test_mipnerf_split_forward_plain_backward(backend):
             assert e < 0.113, f"{mode} grad {k}: rel L2 {e:.3e}"
 
 
+@pytest.mark.parametrize("compute,tol_out,tol_grad", [("f16f8", 1e-4, 2e-2), ("bf16x3_fwd", 1e-4, 3e-2), ("fp16", 5e-3, 6e-2)])
+def test_mipnerf_new_modes_with_every_optional_branch(backend, compute, tol_out, tol_grad):
+    """The round-6 compute modes through the branches the plain tests do not take: semantic head (its own trunk-side data gradient), appearance
+    embedding (the condition block written from an fp32 image in the split layouts; its table gradient from the scaled backward's returned
+    tensor), pose refinement (gradients w.r.t. origins / directions / viewdirs through input_grad -- scaled back by _scaled_backward).  Against
+    the exact f32 mode of the same model on the same rays: outputs at `tol_out`, every gradient norm-wise at `tol_grad`."""
+    from snerf_amd import mipnerf
+    r = common.synthetic_rays(40, seed=3)
+    r["app"] = torch.randint(0, 5, (40, 1), generator=torch.Generator().manual_seed(1)).float()
+    res = {}
+    for mode in ("f32", compute):
+        torch.manual_seed(0)
+        m = mipnerf.MipNerfModel(n_samples=16, N_fine=17, no_warp_sample=0, ray_shape="cone", fn=1, radius=3., transform_idx=0, real=True, rgb_layer=3,
+                                 hidden_layer=256, density_noise=0., max_deg_point=16, proposal_hidden_layer=128, proposal_loss=True, semantic=True,
+                                 semantic_class_num=7, encode_appearance=True, N_vocab=5, compute=mode, device=DEV)
+        if "sd" in res:
+            m.load_state_dict(res["sd"])
+        else:
+            res["sd"] = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        rays = mipnerf.Rays(**{k: v.to(DEV).clone().requires_grad_(k in ("origins", "directions", "viewdirs")) for k, v in r.items()})
+        ret = m(rays, False, False, 0.)
+        loss = (ret[1][0] ** 2).mean() + 1e-2 * ret[1][1].mean() + (ret[1][3] ** 2).mean() + 1e-2 * ret[0][1].mean()
+        loss.backward()
+        g = {k: p.grad.detach().cpu() for k, p in m.named_parameters()}
+        g.update({"rays." + k: getattr(rays, k).grad.detach().cpu() for k in ("origins", "directions", "viewdirs")})
+        res[mode] = ([t.detach().cpu() for t in (ret[1][0], ret[1][1], ret[1][3])], g)
+    for a, b_, what in zip(res[compute][0], res["f32"][0], ("rgb", "distance", "semantic")):
+        close(a, b_, tol_out, tol_out, f"{compute} {what}")
+    worst = 0.0
+    for k, gref in res["f32"][1].items():
+        e = ((res[compute][1][k] - gref).norm() / (gref.norm() + 1e-12)).item()
+        worst = max(worst, e)
+        assert e < tol_grad, f"{compute} grad {k}: rel L2 {e:.3e}"
+    print(f"MEASURED {compute} with semantic head + appearance embedding + ray gradients: worst gradient rel L2 {worst:.3e}")
+
+
 def test_mipnerf_semantic_head_vs_reference_golden(backend, golden):
     """MipNerfModel(semantic=True): outputs and EVERY parameter gradient against the reference model's own (g14)."""
     g = golden("g14_mipnerf_semantic")
