@@ -1633,8 +1633,30 @@ __global__ __launch_bounds__(256, NSUB == 8 ? 4 : 3) void zip_bin_write_staged_k
         r[q] += w * we[j];
       }
       if ((ends >> j) & 1u) {
+        if constexpr (CPS == 2) {
+          // the sub-pass's two corners are x-neighbours (corner = x + 2 y + 4 z): on a hashed level with even x their rows differ in bit 0 only, on a
+          // dense level they are adjacent -- the same bin either way, so ONE counter update hands out both slots (a lane whose two rows fall into
+          // different bins takes the second update alone).  Same records in the same ranges: the order inside a run is all that changes.
+          const uint32_t pl0[3] = {pg[j][0], pg[j][1] + (uint32_t)(sp & 1), pg[j][2] + (uint32_t)(sp >> 1)};
+          const uint32_t pl1[3] = {pg[j][0] + 1u, pl0[1], pl0[2]};
+          const uint32_t row0 = zip_grid_index(hs, res, pl0), row1 = zip_grid_index(hs, res, pl1);
+          const int bin0 = (int)(row0 >> b.bshift) * K + rep;
+          int bin1 = (int)(row1 >> b.bshift) * K + rep;
+          const bool same = bin0 == bin1;
+          const int slot0 = atomicAdd(cnt + bin0, same ? 2 : 1);
+          int slot1 = slot0 + 1;
+          if (!same) slot1 = atomicAdd(cnt + bin1, 1);
+          if (place) {
+            const int o0 = off[bin0];
+            const int o1 = same ? o0 : off[bin1];
+            stage[o0 + slot0] = uint2{(row0 & rmask) | ((unsigned)bin0 << 14) | ((unsigned)tid << 24), __float_as_uint(r[0])};
+            stage[o1 + slot1] = uint2{(row1 & rmask) | ((unsigned)bin1 << 14) | ((unsigned)tid << 24), __float_as_uint(r[1])};
+          }
+          r[0] = 0.f; r[1] = 0.f;
+        } else {
 #pragma unroll
         for (int q = 0; q < CPS; ++q) { const int idx = sp * CPS + q; record(j, idx & 1, (idx >> 1) & 1, idx >> 2, r[q], place); r[q] = 0.f; }
+        }
       }
     }
   };
