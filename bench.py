@@ -1237,6 +1237,10 @@ def main():
             mx3.load_state_dict(sd)
             rx3 = mx3(sub, False, False, 0.)
             del mx3
+            m8 = build_model("f16f8", device)
+            m8.load_state_dict(sd)
+            r8 = m8(sub, False, False, 0.)
+            del m8
         mse = lambda a, b: float(((a.double() - b.double()) ** 2).mean())
         psnr = lambda a, b: (float("inf") if mse(a, b) == 0 else -10.0 * math.log10(mse(a, b)))
         out["cpu_baseline"] = {"value": round(cpu_rps, 2), "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
@@ -1247,6 +1251,9 @@ def main():
                          "f32_kernels_vs_cpu_oracle_max_rel_err_depth": float(((r32[1][1].cpu() - dist_ref).abs() / dist_ref.abs()).max()),
                          "split_bf16_kernels_vs_cpu_oracle_max_rel_err_rgb": float(((rx3[1][0].cpu() - rgb_ref).abs() / (rgb_ref.abs() + 1e-3)).max()),
                          "split_bf16_kernels_vs_cpu_oracle_max_rel_err_depth": float(((rx3[1][1].cpu() - dist_ref).abs() / dist_ref.abs()).max()),
+                         "f16f8_kernels_vs_cpu_oracle_max_rel_err_rgb": float(((r8[1][0].cpu() - rgb_ref).abs() / (rgb_ref.abs() + 1e-3)).max()),
+                         "f16f8_kernels_vs_cpu_oracle_max_rel_err_depth": float(((r8[1][1].cpu() - dist_ref).abs() / dist_ref.abs()).max()),
+                         "psnr_f16f8_kernels_vs_cpu_oracle_db": psnr(r8[1][0].cpu(), rgb_ref),
                          "psnr_split_bf16_kernels_vs_cpu_oracle_db": psnr(rx3[1][0].cpu(), rgb_ref),
                          "psnr_f32_kernels_vs_cpu_oracle_db": psnr(r32[1][0].cpu(), rgb_ref),
                          "psnr_bf16_kernels_vs_cpu_oracle_db": psnr(rb[1][0].cpu(), rgb_ref)}

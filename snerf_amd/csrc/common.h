@@ -72,6 +72,21 @@ __device__ __forceinline__ float wave_incl_scan_mul(float v, int lane) {
   return v;
 }
 
+// four fp32 -> four OCP e4m3 bytes of x * mul, saturating at the format's +-448 (the fp16 + fp8 split operands of gemm.hip, GemmNT::split == 2)
+__device__ __forceinline__ unsigned snerf_e4m3x4(float x0, float x1, float x2, float x3, float mul) {
+  x0 = __builtin_amdgcn_fmed3f(x0 * mul, -448.f, 448.f); x1 = __builtin_amdgcn_fmed3f(x1 * mul, -448.f, 448.f);
+  x2 = __builtin_amdgcn_fmed3f(x2 * mul, -448.f, 448.f); x3 = __builtin_amdgcn_fmed3f(x3 * mul, -448.f, 448.f);
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(x0, x1, 0, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(x2, x3, w, true);
+  return (unsigned)w;
+}
+// power-of-two scales of those bytes: activations carry e4m3((x - fp16(x)) 2^13) and e4m3(x 2^2), weights e4m3(w 2^9) and e4m3((w - fp16(w)) 2^20);
+// 13 + 9 = 2 + 20 = 22 = what the two E8M0 scale bytes (116 = 2^-11 each) of the block-scaled MFMA take out again
+#define SNERF_F8_ACT_RES 8192.f
+#define SNERF_F8_ACT_VAL 4.f
+#define SNERF_F8_W_VAL 512.f
+#define SNERF_F8_W_RES 1048576.f
+
 template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ __bf16 from_f32<__bf16>(float v) { return (__bf16)v; }

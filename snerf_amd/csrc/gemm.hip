@@ -99,16 +99,6 @@ __device__ __forceinline__ void mma8(f32x16& acc, const bf16x8& a0, const bf16x8
   const i32x8 b = __builtin_bit_cast(i32x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15));
   acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc, 0, 0, 0, 0x74747474, 0, 0x74747474);
 }
-// four fp32 -> four e4m3 bytes of x * mul (clamped to the format's +-448)
-__device__ __forceinline__ unsigned pack_e4m3x4(float x0, float x1, float x2, float x3, float mul) {
-  x0 = __builtin_amdgcn_fmed3f(x0 * mul, -448.f, 448.f); x1 = __builtin_amdgcn_fmed3f(x1 * mul, -448.f, 448.f);
-  x2 = __builtin_amdgcn_fmed3f(x2 * mul, -448.f, 448.f); x3 = __builtin_amdgcn_fmed3f(x3 * mul, -448.f, 448.f);
-  int w = __builtin_amdgcn_cvt_pk_fp8_f32(x0, x1, 0, false);
-  w = __builtin_amdgcn_cvt_pk_fp8_f32(x2, x3, w, true);
-  return (unsigned)w;
-}
-#define F8_A_LO 8192.f        /* 2^13: activations' residual x - fp16(x) */
-#define F8_A_HI 4.f           /* 2^2 : activations themselves             (13 + 9 = 2 + 20 = 22 = the two scale bytes' 11 + 11) */
 template <bool F16> __device__ __forceinline__ __bf16 cvt16(float v) {          // fp32 -> the launch's 16-bit format (as a bf16-typed bit pattern)
   if constexpr (F16) return __builtin_bit_cast(__bf16, (_Float16)v);
   else return (__bf16)v;
@@ -194,8 +184,8 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x16 (&acc)[BM / 
               if (part == 1 && p.split == 2) {
                 // fp16 + fp8 mode: the group's second 128 bytes = [e4m3(r 2^13) x 64 | e4m3(x 2^2) x 64], one byte per logical column
                 char* d8 = my + (lane & 31) * PITCH + cl;
-                *(unsigned*)d8 = pack_e4m3x4(v[0] - up16<F16>(o[0]), v[1] - up16<F16>(o[1]), v[2] - up16<F16>(o[2]), v[3] - up16<F16>(o[3]), F8_A_LO);
-                *(unsigned*)(d8 + 64) = pack_e4m3x4(v[0], v[1], v[2], v[3], F8_A_HI);
+                *(unsigned*)d8 = snerf_e4m3x4(v[0] - up16<F16>(o[0]), v[1] - up16<F16>(o[1]), v[2] - up16<F16>(o[2]), v[3] - up16<F16>(o[3]), SNERF_F8_ACT_RES);
+                *(unsigned*)(d8 + 64) = snerf_e4m3x4(v[0], v[1], v[2], v[3], SNERF_F8_ACT_VAL);
                 continue;
               }
               if (part == 1) {
@@ -841,8 +831,8 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
           // four values are columns 8 c + 4 hi .. + 3 of the 64: bytes 8 c + 4 hi of either half = chunk c >> 1 (+ 4), offset 8 (c & 1) + 4 hi
           float x0 = v01[0], x1 = v01[1], x2 = v23[0], x3 = v23[1];
           if (ACT == ACT_RELU || ACT == ACT_RELU_BITS) { x0 = fmaxf(x0, 0.f); x1 = fmaxf(x1, 0.f); x2 = fmaxf(x2, 0.f); x3 = fmaxf(x3, 0.f); }
-          const unsigned lo8 = pack_e4m3x4(x0 - (float)(_Float16)x0, x1 - (float)(_Float16)x1, x2 - (float)(_Float16)x2, x3 - (float)(_Float16)x3, F8_A_LO);
-          const unsigned hi8 = pack_e4m3x4(x0, x1, x2, x3, F8_A_HI);
+          const unsigned lo8 = snerf_e4m3x4(x0 - (float)(_Float16)x0, x1 - (float)(_Float16)x1, x2 - (float)(_Float16)x2, x3 - (float)(_Float16)x3, SNERF_F8_ACT_RES);
+          const unsigned hi8 = snerf_e4m3x4(x0, x1, x2, x3, SNERF_F8_ACT_VAL);
           char* const d8 = slab + row1 * 128 + 8 * (c & 1) + 4 * hi;
           *(unsigned*)(d8 + (((c >> 1) ^ (row1 & 7)) << 4)) = lo8;
           *(unsigned*)(d8 + (((4 + (c >> 1)) ^ (row1 & 7)) << 4)) = hi8;

@@ -192,7 +192,8 @@ def test_path_c_properties_at_full_size():
     assert float((outs["bf16"] - outs["f32"]).abs().max()) < 3e-2
 
 
-def test_captured_train_step_replays_like_the_eager_step():
+@pytest.mark.parametrize("compute", ["bf16", "f16f8"])
+def test_captured_train_step_replays_like_the_eager_step(compute):
     """MipTrainer.capture / replay: the whole step as one hipGraph (packed-weight refresh, forward, loss tail, backward, Adam with the
     step count on the device).  Five replays from a given state land on the parameters of five eager steps, and a refreshed batch
     (copied into the captured tensors) is picked up."""
@@ -204,8 +205,8 @@ def test_captured_train_step_replays_like_the_eager_step():
     def fresh():
         torch.manual_seed(0)
         m = mipnerf.MipNerfModel(n_samples=S0, N_fine=P1, no_warp_sample=0, ray_shape="cone", fn=1, radius=3., transform_idx=0, real=True, rgb_layer=3,
-                                 hidden_layer=256, density_noise=0., max_deg_point=16, proposal_loss=True, compute="bf16")
-        return m, MipTrainer(m, lr=5e-4)
+                                 hidden_layer=256, density_noise=0., max_deg_point=16, proposal_loss=True, compute=compute)
+        return m, MipTrainer(m, lr=5e-4)          # (f16f8: the scaled fp16 backward picks its power of two on the device -- nothing in it reads back)
     rc = common.synthetic_rays(n, seed=3)
     g = torch.Generator().manual_seed(4)
     tgt, td = torch.rand(n, 3, generator=g).cuda(), (torch.rand(n, generator=g) * 50 + 2).cuda()
