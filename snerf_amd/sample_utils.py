@@ -49,16 +49,55 @@ def rays_of_pixels(coords, pose, intrinsic, H, W, near, far, training=False, dev
     return Rays(o, d, v, r, ones, nr, fr, ones * 0.)
 
 
+def sample_patches(H, W, patch_sz, n_patch):
+    """sample_utils.py:68-89 (sample_patches_pt): `n_patch` centres drawn with np.random.randint among the pixels strictly more than `patch_sz` from
+    every border (row-major order of that window), each giving the (2 (patch_sz // 2))^2 pixels [c - patch_sz // 2, c + patch_sz // 2) around it,
+    rows outer.  -> int64 [n_patch * (2 (patch_sz // 2))^2, 2] of (row, col)."""
+    hr, wc = H - 2 * patch_sz - 1, W - 2 * patch_sz - 1                  # rows / columns r with patch_sz < r < H - patch_sz
+    if hr <= 0 or wc <= 0:
+        raise ValueError("image smaller than the smooth-loss patch margin (the reference's np.random.randint(0) raises here too)")
+    idx = np.random.randint(hr * wc, size=n_patch)
+    cr, cc = patch_sz + 1 + idx // wc, patch_sz + 1 + idx % wc
+    h = patch_sz // 2
+    dr, dc = np.meshgrid(np.arange(-h, h), np.arange(-h, h), indexing="ij")
+    rows = (cr[:, None, None] + dr[None]).reshape(-1)
+    cols = (cc[:, None, None] + dc[None]).reshape(-1)
+    return np.stack([rows, cols], -1).astype(np.int64)
+
+
+def smooth_loss(image, skymask, sel_coords_smooth, pred_distance_smooth, n_patch, patch_sz, weight, use_skymask=True):
+    """loss_factory.py:38-57 (SmoothLoss) on loss.py:14-35 (edge_aware_loss_v2): the edge-aware smoothness of the patches' disparities, in torch
+    ops (autograd carries it to `pred_distance_smooth` = the renderer's distances of the batch's patch rays, train.py:154-177).  A caller-side
+    loss: off in the shipped config (configs/nuScenes_depth_6cams:61), no kernel."""
+    img = torch.as_tensor(image)
+    c = torch.as_tensor(sel_coords_smooth).long().to(img.device)
+    dev = pred_distance_smooth.device
+    rgb = img[c[:, 0], c[:, 1]].to(dev).view(n_patch, patch_sz, patch_sz, -1)
+    disp = (1 / torch.clamp(pred_distance_smooth, min=1e-5)).view(n_patch, patch_sz, patch_sz, -1)
+    disp = disp / (disp.mean(1, True).mean(2, True) + 1e-7)
+    gx = torch.abs(disp[:, :, :-1, :] - disp[:, :, 1:, :]) * torch.exp(-torch.mean(torch.abs(rgb[:, :, :-1, :] - rgb[:, :, 1:, :]), 3, keepdim=True))
+    gy = torch.abs(disp[:, :-1, :, :] - disp[:, 1:, :, :]) * torch.exp(-torch.mean(torch.abs(rgb[:, :-1, :, :] - rgb[:, 1:, :, :]), 3, keepdim=True))
+    if use_skymask:
+        sky = torch.as_tensor(skymask)[c[:, 0].to(torch.as_tensor(skymask).device), c[:, 1].to(torch.as_tensor(skymask).device)].to(dev).view(n_patch, patch_sz, patch_sz, -1)
+        gx = gx + sky[:, :, :-1, :] * gx
+        gy = gy + sky[:, :-1, :, :] * gy
+    return (gx.mean() + gy.mean()) * weight
+
+
 def sample_single_img(args, image, depth_gt, pose, intrinsic, near=0., far=1., near_far=False, batch_n=None, app=0.):
     """sample_utils.py:92-211: a random pixel batch of one image -> (Rays, target_rgb, target_depth, sel_coords, sel_inds).
     The pixel choice uses numpy's global RNG exactly like the reference (np.random.choice without replacement)."""
     _check(args)
-    if getattr(args, "smooth_loss", False):
-        raise NotImplementedError("smooth-loss patches are outside the accelerated path")
     H, W = image.shape[:2]
     n = batch_n if batch_n is not None else args.N_rgb
+    patches = None
+    if getattr(args, "smooth_loss", False):
+        # --smooth_loss (sample_utils.py:102-103, 136-138): N_patch random patches appended BEHIND the random pixels; their centres are drawn first
+        patches = sample_patches(H, W, int(args.patch_sz), int(args.N_patch))
     sel = np.random.choice(H * W, size=[n], replace=False)
     coords = np.stack([sel // W, sel % W], -1)
+    if patches is not None:
+        coords = np.concatenate([coords, patches], 0)
     if not near_far:
         near, far = near * 0.9, far * 1.1
     else:

@@ -80,6 +80,42 @@ def test_sample_single_img_mirror(golden):
     assert torch.equal(rays.directions.cpu(), _t(g, "sel_directions")) and torch.equal(rays.near.cpu(), _t(g, "sel_near"))
 
 
+def test_smooth_loss_patches_and_loss_vs_reference_golden(golden):
+    """--smooth_loss (g32, from the reference's sample_patches_pt / SmoothLoss): same numpy RNG state -> the same patch pixels (drawn BEFORE the random
+    pixel batch), and the caller-side loss with its gradient on the reference's inputs.  Host logic only: runs without a GPU."""
+    from snerf_amd import sample_utils as su
+    g = golden("g32_smooth_patches")
+    H, W, n_rgb, p, npatch = (int(g[k]) for k in ("H", "W", "N_rgb", "patch_sz", "N_patch"))
+    np.random.seed(13)
+    patches = su.sample_patches(H, W, p, npatch)
+    sel = np.random.choice(H * W, size=[n_rgb], replace=False)
+    want = g["sel_coords"].numpy() if torch.is_tensor(g["sel_coords"]) else np.asarray(g["sel_coords"])
+    assert np.array_equal(patches, want[n_rgb:]) and np.array_equal(np.stack([sel // W, sel % W], -1), want[:n_rgb])
+    assert np.array_equal(sel, np.asarray(g["sel_inds"]))
+    dist = _t(g, "patch_distance").clone().requires_grad_(True)
+    loss = su.smooth_loss(_t(g, "image"), _t(g, "skymask"), torch.as_tensor(want[n_rgb:]), dist, npatch, p, float(g["smooth_lambda"]))
+    loss.backward()
+    assert torch.allclose(loss.detach(), _t(g, "smooth_loss"), rtol=1e-6, atol=0), (float(loss), float(_t(g, "smooth_loss")))
+    assert torch.allclose(dist.grad, _t(g, "g_patch_distance"), rtol=1e-5, atol=1e-9)
+    with pytest.raises(ValueError):
+        su.sample_patches(10, 10, 6, 2)
+
+
+@gpu
+def test_sample_single_img_with_smooth_loss_patches(golden):
+    """the whole training batch of the --smooth_loss branch: random pixels + patches -> rays and targets as the reference's (g32)"""
+    from snerf_amd import sample_utils as su
+    g = golden("g32_smooth_patches")
+    args = types.SimpleNamespace(no_ndc=True, smooth_loss=True, N_rgb=int(g["N_rgb"]), patch_sz=int(g["patch_sz"]), N_patch=int(g["N_patch"]))
+    image, depth = _t(g, "image", "cuda"), _t(g, "depth", "cuda")
+    np.random.seed(13)
+    rays, trgb, tdep, sel, inds = su.sample_single_img(args, image, depth, g["pose"], g["intrinsic"], near=2.0, far=100.0, near_far=False)
+    assert torch.equal(sel.cpu(), _t(g, "sel_coords")) and np.array_equal(np.asarray(inds), np.asarray(g["sel_inds"]))
+    assert torch.equal(trgb.cpu(), _t(g, "target_rgb")) and torch.equal(tdep.cpu(), _t(g, "target_depth"))
+    assert torch.equal(rays.directions.cpu(), _t(g, "sel_directions")) and torch.equal(rays.origins.cpu(), _t(g, "sel_origins"))
+    assert torch.allclose(rays.radii.cpu(), _t(g, "sel_radii"), rtol=3e-7, atol=0) and torch.equal(rays.near.cpu(), _t(g, "sel_near"))
+
+
 def _loss_inputs(N, Sc, Pf, seed):
     gen = torch.Generator().manual_seed(seed)
 

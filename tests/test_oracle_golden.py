@@ -302,7 +302,7 @@ def test_oracle_fuzz_vs_reference_log_and_live_run():
 
 
 def test_every_golden_generator_verifies_against_the_reference():
-    """`python oracle/gen_golden*.py --check` for all 16 generators: each imports the reference's own modules (/root/reference, build
+    """`python oracle/gen_golden*.py --check` for all 17 generators: each imports the reference's own modules (/root/reference, build
     container only), regenerates its fixtures in memory and compares them with the committed files bit for bit -- `check: OK`, nothing
     written.  Skipped where the reference is not mounted (the GPU box)."""
     import glob
@@ -313,7 +313,7 @@ def test_every_golden_generator_verifies_against_the_reference():
         pytest.skip("/root/reference is not mounted here")
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     gens = sorted(glob.glob(os.path.join(repo, "oracle", "gen_golden*.py")))
-    assert len(gens) == 16
+    assert len(gens) == 17
     before = {f: os.path.getmtime(os.path.join(repo, "tests", "golden", f)) for f in os.listdir(os.path.join(repo, "tests", "golden"))}
     procs = [(g, subprocess.Popen([sys.executable, g, "--check"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=repo)) for g in gens]
     for g, p in procs:
