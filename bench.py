@@ -705,6 +705,20 @@ def path_b_leg(device, n_rays=32768, steps=5, compute="bf16"):
     sd_f = {k: v.detach().float().cpu().clone() for k, v in fine.state_dict().items()}
     del coarse, fine, opt
     torch.cuda.empty_cache()
+    # the modes whose render_rays outputs stay inside the 1e-4 contract (per-layer launches: the fused kernels are bf16): same step, 3 repetitions
+    inside = {}
+    for mode in ("f16f8", "f32"):
+        compute_keep, compute = compute, mode
+        coarse, fine = mk(), mk()
+        compute = compute_keep
+        opt = torch.optim.Adam(list(coarse.parameters()) + list(fine.parameters()), lr=5e-4)
+        t_tr = _timeit(train, 3, warm=1)
+        with torch.no_grad():
+            t_fw = _timeit(fwd, 3, warm=1)
+        inside[mode] = {"train_ms_per_step": round(t_tr * 1e3, 2), "fwd_ms": round(t_fw * 1e3, 2)}
+        del coarse, fine, opt
+        torch.cuda.empty_cache()
+    out["modes_inside_1e-4"] = inside
     out.update(path_b_baselines(sd_c, sd_f, rays, tgt, device, N / dt_train))
     out["eager_baseline"]["frame_speedup_vs_fp32"] = round((Hh * Ww / dt_frame) / out["eager_baseline"]["forward_only_fp32"], 2)
     return out

@@ -139,7 +139,7 @@ class NeRF(_ArenaModule):
         shapes = ClassicNeRFNet.param_shapes(D, W, input_ch, input_ch_views, tuple(skips), alpha_head=self._alpha_head, output_ch=oc)
         self._setup_arena(shapes, torch.device(device))
         self.net = ClassicNeRFNet(self.arena, "", _dt(compute), D, W, input_ch, input_ch_views, tuple(skips), variant,
-                                  alpha_head=self._alpha_head, output_ch=oc)
+                                  alpha_head=self._alpha_head, output_ch=oc, bwd_plain=compute == "bf16x3_fwd")
         self.net.version_fn = self._param_version
         with torch.no_grad():  # nn.Linear default init, like the reference module
             for i in range(D):

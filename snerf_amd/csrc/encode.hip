@@ -105,8 +105,12 @@ extern "C" int snerf_classic_embed(const float* pts, const float* viewdirs, int 
   hipStream_t s = (hipStream_t)stream;
   if (dtype == SNERF_DT_F32)
     classic_embed_launch<float>(pts, viewdirs, vd_stride, S, M, L, Lv, dst1, ld1, dst2, ld2, w_pts, dstv, ldv, w_views, s);
-  else
+  else if (dtype == SNERF_DT_F16)
+    classic_embed_launch<_Float16>(pts, viewdirs, vd_stride, S, M, L, Lv, dst1, ld1, dst2, ld2, w_pts, dstv, ldv, w_views, s);
+  else if (dtype == SNERF_DT_BF16)
     classic_embed_launch<__bf16>(pts, viewdirs, vd_stride, S, M, L, Lv, dst1, ld1, dst2, ld2, w_pts, dstv, ldv, w_views, s);
+  else
+    return SNERF_ERR_ARG;
   return snerf_check_launch();
 }
 

@@ -473,14 +473,13 @@ class ClassicNeRFNet(_Net):
     Buffers: E [M, Pw] embedding (63 + pad); SK [M, Pw + W] = [embedding | layer-skip output];
     V [M, W + Vw] = [feature | view embedding (27 + pad)]; OUT [M,4] fp32 = [rgb | alpha]."""
 
-    def __init__(self, arena, prefix, dt, D=8, W=256, input_ch=63, input_ch_views=27, skips=(4,), variant=8, alpha_head=True, output_ch=0):
+    def __init__(self, arena, prefix, dt, D=8, W=256, input_ch=63, input_ch_views=27, skips=(4,), variant=8, alpha_head=True, output_ch=0, bwd_plain=False):
         """`alpha_head=False`: the ``NeRF_RGB`` variant (run_nerf_helpers.py:157-212) -- no alpha_linear; column 3 of the output is left
         for the caller (the frozen alpha model's density).  `output_ch` > 0: the ``use_viewdirs=False`` network (run_nerf_helpers.py:100-101,
         122-124): the trunk's output goes through ``output_linear`` (W -> output_ch) alone; ``views_linears.0`` exists (the reference
         constructs it regardless, :90) but is never evaluated."""
-        super().__init__(arena, prefix, dt, variant)
+        super().__init__(arena, prefix, dt, variant, bwd_plain)
         self.output_ch = int(output_ch)
-        assert self.km == 1, "split-bf16 (compute='bf16x3') is built for the mip path's networks"
         assert len(skips) == 1 and 0 <= skips[0] < D - 1 and W % self.g == 0 and (W // 2) % self.g == 0
         self.D, self.Wd, self.ic, self.icv, self.skip = D, W, input_ch, input_ch_views, skips[0]
         self.Pw, self.Vw = roundup(input_ch, self.g), roundup(input_ch_views, self.g)
@@ -635,16 +634,17 @@ class ClassicNeRFNet(_Net):
         SK = self.buf(M, Pw + W)
         noviews = self.output_ch > 0
         V = None if noviews else self.buf(M, W + self.Vw)
+        cs = self.cs                                          # (logical column ranges: twice as wide physically in the split layouts)
         if noviews:
-            ops.classic_embed(pts, None, S, (self.ic - 3) // 6, 0, E, SK[:, :Pw], Pw, None, 0, self.dt)
+            ops.classic_embed(pts, None, S, (self.ic - 3) // 6, 0, E, cs(SK, 0, Pw), Pw, None, 0, self.dt)
         else:
-            ops.classic_embed(pts, viewdirs, S, (self.ic - 3) // 6, (self.icv - 3) // 6, E, SK[:, :Pw], Pw, V[:, W:], self.Vw, self.dt)
+            ops.classic_embed(pts, viewdirs, S, (self.ic - 3) // 6, (self.icv - 3) // 6, E, cs(SK, 0, Pw), Pw, cs(V, W), self.Vw, self.dt)
         acts = []
         x, k = E, Pw
         pp = [self.buf(M, W), self.buf(M, W)] if not keep else None
         for i in range(self.D):
             if i == self.skip:
-                y = SK[:, Pw:]
+                y = cs(SK, Pw)
             else:
                 y = self.buf(M, W) if keep else pp[i & 1]
             self.fwd(f"pts_linears.{i}", x, k, y, W)
@@ -660,7 +660,7 @@ class ClassicNeRFNet(_Net):
         OUT = self.buf(M, 4, f32=True)
         if self.alpha_head:
             self.fwd("alpha", x, W, OUT[:, 3:], 1, ACT_NONE, out_f32=True)
-        self.fwd("feature", x, W, V[:, :W], W, ACT_NONE)
+        self.fwd("feature", x, W, cs(V, 0, W), W, ACT_NONE)
         HV = self.buf(M, W // 2)
         self.fwd("views", V, W + self.Vw, HV, W // 2)
         self.fwd("rgb", HV, W // 2, OUT[:, :3], 3, ACT_NONE, out_f32=True)
@@ -673,13 +673,19 @@ class ClassicNeRFNet(_Net):
         the weight gradient -- instead of one launch per block, each re-reading the [M, W] gradient matrix (3.2 GB at 6.3 M samples)."""
         W, Pw = self.Wd, self.Pw
         tmp = torch.zeros(W, Pw + W, dtype=torch.float32, device=self.dev)
-        ops.linear_wgrad(dZ, SK, tmp, W, Pw + W, self.dt, variant=3, deterministic=self.deterministic)
+        ops.linear_wgrad(dZ, SK, tmp, W, Pw + W, self.dt, variant=3, deterministic=self.deterministic, x_split_hi=self._in_plain_bwd)
         gw = self.gW(n)
         gw[:, :self.ic] += tmp[:, :self.ic]
         gw[:, self.ic:] += tmp[:, Pw:]
 
     def backward(self, d_raw, saved):
-        """d_raw [M,4] fp32 -> accumulates parameter gradients into the arena."""
+        """d_raw [M,4] fp32 -> accumulates parameter gradients into the arena (compute="bf16x3_fwd" / "f16f8" / "fp16": _Net._bwd, _scaled_backward)."""
+        with self._bwd():
+            if self._fp16_backward():
+                return self._scaled_backward([d_raw], lambda g: self._backward(g[0], saved))
+            return self._backward(d_raw, saved)
+
+    def _backward(self, d_raw, saved):
         acts, V, HV, SK, E = saved[:5]
         W, Pw, g, M = self.Wd, self.Pw, self.g, d_raw.shape[0]
         ah = self.alpha_head
@@ -689,7 +695,7 @@ class ClassicNeRFNet(_Net):
             dz = self.head_grad(d_raw, oc)
             self.wgrad("output_linear", dz, x7, oc, W)
             dZ = self.buf(M, W)
-            self.dgrad("out", dz, dz.shape[1], dZ, W, mask=x7, colsum=self.gB(f"pts_linears.{self.D - 1}"))
+            self.dgrad("out", dz, roundup(oc, g), dZ, W, mask=x7, colsum=self.gB(f"pts_linears.{self.D - 1}"))
             self._trunk_backward(dZ, acts, SK, E)
             return
         self.colsum(d_raw, 3, self.gB("rgb_linear"))
@@ -705,9 +711,9 @@ class ClassicNeRFNet(_Net):
                            [self.gB("views_linears.0"), self.gB("feature_linear")] + [self.gB(f"pts_linears.{i}") for i in range(self.D - 1, -1, -1)])
             x7 = acts[-1][2]
             self.wgrad("views_linears.0", dHV, V, W // 2, W + self.icv)
-            self.wgrad("feature_linear", DB[:, :W], x7, W, W)
-            ops.cast_pad(d_raw[:, 3:], 1, DB[:, W:], g, self.dt)
-            self.wgrad("alpha_linear", DB[:, W:], x7, 1, W)
+            self.wgrad("feature_linear", self.cs(DB, 0, W), x7, W, W)
+            ops.cast_pad(d_raw[:, 3:], 1, self.cs(DB, W), g, self.dt)
+            self.wgrad("alpha_linear", self.cs(DB, W), x7, 1, W)
             for i in range(self.D - 1, -1, -1):
                 x, k, y = acts[i]
                 n, dZ = f"pts_linears.{i}", dZs[self.D - 1 - i]
@@ -719,17 +725,17 @@ class ClassicNeRFNet(_Net):
                     self.wgrad(n, dZ, x, W, W)
             return
         dHV = self.buf(M, W // 2)
-        self.dgrad("rgb", dz, dz.shape[1], dHV, W // 2, mask=HV, colsum=self.gB("views_linears.0"))
+        self.dgrad("rgb", dz, g, dHV, W // 2, mask=HV, colsum=self.gB("views_linears.0"))
         self.wgrad("views_linears.0", dHV, V, W // 2, W + self.icv)
         DB = self.buf(M, W + (g if ah else 0))                    # [d feature | d alpha (+pad)]
         self.dgrad("views", dHV, W // 2, DB, W, colsum=self.gB("feature_linear"))
         x7 = acts[-1][2]
-        self.wgrad("feature_linear", DB[:, :W], x7, W, W)
+        self.wgrad("feature_linear", self.cs(DB, 0, W), x7, W, W)
         if ah:
-            ops.cast_pad(d_raw[:, 3:], 1, DB[:, W:], g, self.dt)
-            self.wgrad("alpha_linear", DB[:, W:], x7, 1, W)
+            ops.cast_pad(d_raw[:, 3:], 1, self.cs(DB, W), g, self.dt)
+            self.wgrad("alpha_linear", self.cs(DB, W), x7, 1, W)
         dZ = self.buf(M, W)
-        self.dgrad("fa", DB, DB.shape[1], dZ, W, mask=x7, colsum=self.gB(f"pts_linears.{self.D - 1}"))
+        self.dgrad("fa", DB, W + (g if ah else 0), dZ, W, mask=x7, colsum=self.gB(f"pts_linears.{self.D - 1}"))
         self._trunk_backward(dZ, acts, SK, E)
 
     def _trunk_backward(self, dZ, acts, SK, E):

@@ -375,6 +375,17 @@ def fchain_bwd(net, d_raw, stream, bits, dz, g_bias):
 def classic_embed(pts, viewdirs, S, L, Lv, dst1, dst2, w_pts, dstv, w_views, dt):
     pts = _f32c(pts); M = pts.shape[0]
     assert pts.shape[1] == 3
+    if dt in SPLIT_DTS:
+        # the exact fp32 embeddings, then the hi / lo (fp16 + fp8) split into each destination's GEMM operand layout
+        t1 = torch.empty(M, w_pts, dtype=torch.float32, device=pts.device)
+        tv = None if viewdirs is None else torch.empty(M, w_views, dtype=torch.float32, device=pts.device)
+        classic_embed(pts, viewdirs, S, L, Lv, t1, None, w_pts, tv, w_views, F32)
+        cast_pad(t1, w_pts, dst1, w_pts, dt)
+        if dst2 is not None:
+            cast_pad(t1, w_pts, dst2, w_pts, dt)
+        if tv is not None:
+            cast_pad(tv, w_views, dstv, w_views, dt)
+        return
     if viewdirs is not None:
         assert viewdirs.dtype == torch.float32 and viewdirs.stride(1) == 1 and viewdirs.shape[1] == 3
         assert M == viewdirs.shape[0] * S

@@ -158,6 +158,14 @@ def classic_embed(pts, viewdirs, S, L, Lv, dst1, dst2, w_pts, dstv, w_views, dt)
     e = oc.embed(pts, L)
     pad = torch.zeros(pts.shape[0], w_pts - e.shape[1])
     v = torch.cat([e, pad], -1)
+    if dt in (4, 5):                                            # the split layouts: fp32 images, then the operand layout per destination
+        cast_pad(v, w_pts, dst1, w_pts, dt)
+        if dst2 is not None:
+            cast_pad(v, w_pts, dst2, w_pts, dt)
+        if viewdirs is not None:
+            ev = oc.embed(viewdirs[:, None].expand(-1, S, -1).reshape(-1, 3), Lv)
+            cast_pad(torch.cat([ev, torch.zeros(ev.shape[0], w_views - ev.shape[1])], -1), w_views, dstv, w_views, dt)
+        return
     dst1[:, :w_pts] = v.to(dst1.dtype)
     if dst2 is not None:
         dst2[:, :w_pts] = v.to(dst2.dtype)

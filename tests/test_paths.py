@@ -132,9 +132,12 @@ def test_classic_render_rays_vs_reference_golden(backend, golden):
         close(r2["raw"], g["pt_raw"], 1e-3, 1e-3, "hierarchical raw")
 
 
-@pytest.mark.parametrize("compute,W,tol", [("f32", 256, 1e-4), ("bf16", 256, 3e-2)])
+@pytest.mark.parametrize("compute,W,tol", [("f32", 256, 1e-4), ("bf16", 256, 3e-2),
+                                           # the fp32-class split modes on the classic network: the exact mode's bounds
+                                           ("f16f8", 256, 1e-4), ("bf16x3", 256, 1e-4)])
 def test_classic_render_rays_vs_oracle(backend, compute, W, tol):
     from snerf_amd import classic
+    exact = compute in ("f32", "f16f8", "bf16x3")
     pc = random_params(oc.nerf_param_shapes(W=W), 11, ("alpha_linear.bias",))
     pf = random_params(oc.nerf_param_shapes(W=W), 12, ("alpha_linear.bias",))
     coarse, fine = make_nerf(W, compute, pc), make_nerf(W, compute, pf)
@@ -154,7 +157,7 @@ def test_classic_render_rays_vs_oracle(backend, compute, W, tol):
     # raw2outputs gives the last sample an interval of 1e10, so alpha_last = 1 - exp(-relu(sigma_last) * 1e10) jumps from 0
     # to 1 at sigma_last = 0: rays whose last raw sigma is within rounding noise of 0 are excluded from value checks.
     ref_c = oc.render_rays(rb, pc, None, 64, 0, t_rand=t_rand, retraw=True)
-    ok0 = ref_c["raw"][:, -1, 3].abs() > (1e-3 if compute == "f32" else 5e-2)
+    ok0 = ref_c["raw"][:, -1, 3].abs() > (1e-3 if exact else 5e-2)
     assert ok0.float().mean() > 0.8
     for k in ("rgb0", "acc0", "weights"):
         close(out[k][ok0], ref[k][ok0], tol, tol, k)
@@ -174,19 +177,21 @@ def test_classic_render_rays_vs_oracle(backend, compute, W, tol):
     fin = oc.raw2outputs(raw_ref, z_fine, rb[:, 3:6])
     rtol_raw = tol * 10
     close(out["raw"], raw_ref, rtol_raw, rtol_raw, "fine raw on identical depths")
-    ok1 = raw_ref[:, -1, 3].abs() > (1e-3 if compute == "f32" else 5e-2)
+    ok1 = raw_ref[:, -1, 3].abs() > (1e-3 if exact else 5e-2)
     assert ok1.float().mean() > 0.8
     for got, want, k in zip((out["rgb_map"], out["disp_map"], out["acc_map"], out["depth_map"]), (fin[0], fin[1], fin[2], fin[4]),
                             ("rgb_map", "disp_map", "acc_map", "depth_map")):
-        close(got[ok1], want[ok1], tol, tol if k != "depth_map" or compute == "f32" else 5e-2, k + " on identical depths")
+        close(got[ok1], want[ok1], tol, tol if k != "depth_map" or exact else 5e-2, k + " on identical depths")
     #  (3) and end to end against the all-oracle pipeline with the conditioning-aware tolerance.
-    e2e = 2e-3 if compute == "f32" else 5e-2
-    ok = ok0 & ok1 & (ref["raw"][:, -1, 3].abs() > (1e-3 if compute == "f32" else 5e-2))
+    e2e = 2e-3 if exact else 5e-2
+    ok = ok0 & ok1 & (ref["raw"][:, -1, 3].abs() > (1e-3 if exact else 5e-2))
     close(out["rgb_map"][ok], ref["rgb_map"][ok], e2e, e2e, "rgb_map end to end")
     close(out["z_std"], ref["z_std"], e2e, e2e, "z_std end to end")
 
 
-@pytest.mark.parametrize("compute,W,tol", [("f32", 64, 2e-4), ("bf16", 128, 6e-2)])
+@pytest.mark.parametrize("compute,W,tol", [("f32", 64, 2e-4), ("bf16", 128, 6e-2),
+                                           # the split modes on the classic network (per-layer launches): fp32-class loss, gradients as the mode's backward
+                                           ("bf16x3", 128, 3e-4), ("f16f8", 128, 3e-4), ("bf16x3_fwd", 128, 3e-4), ("fp16", 128, 2e-2)])
 def test_classic_backward_vs_autograd(backend, compute, W, tol):
     from snerf_amd import classic
     pc = random_params(oc.nerf_param_shapes(W=W), 13, ("alpha_linear.bias",))
@@ -208,7 +213,12 @@ def test_classic_backward_vs_autograd(backend, compute, W, tol):
     loss = ((out["rgb_map"] - target.to(DEV)) ** 2).mean() + 0.1 * out["depth_map"].mean() + 0.05 * (out["weights"] ** 2).sum()
     loss.backward()
     close(loss, loss_ref, tol, tol, "loss")
-    check_grads(dict(net.named_parameters()), pr, pc, compute, tol)
+    if compute in ("f16f8", "bf16x3_fwd"):                      # fp32-class forward, 16-bit single-pass backward: norm-wise, well inside the bf16 mode's errors
+        for k in pc:
+            rel = ((dict(net.named_parameters())[k].grad.detach().cpu() - pr[k].grad).norm() / (pr[k].grad.norm() + 1e-12)).item()
+            assert rel < 3e-2, f"{compute} grad {k}: rel L2 {rel:.3e}"
+        return
+    check_grads(dict(net.named_parameters()), pr, pc, compute, 8e-2 if compute == "fp16" else tol)
 
 
 def mip_params(hidden, prop_hidden):
