@@ -14,13 +14,15 @@ import test_paths as tp
 from test_paths import backend, close   # noqa: F401  (fixture)
 
 
+@pytest.mark.parametrize("compute", ["f32", "f16f8", "bf16x3_fwd"])
 @pytest.mark.parametrize("n", [1, 3, 33])
-def test_mipnerf_tiny_ray_batches_vs_oracle(backend, n):
+def test_mipnerf_tiny_ray_batches_vs_oracle(backend, n, compute):
+    """(the 1e-4 modes alike: the split layouts' k-tiles, the e4m3 tiles and the scaled / plain backward on 16- to 561-row operands)"""
     from snerf_amd import mipnerf
     sd = tp.mip_params(64, 64)
     rays_c = common.synthetic_rays(n, seed=9)
     ref = om.mipnerf_forward(sd, rays_c, 16, 17)
-    m = tp.make_mip(64, 64, 16, 17, "f32", sd)
+    m = tp.make_mip(64, 64, 16, 17, compute, sd)
     rays = mipnerf.Rays(**{k: v.to(tp.DEV) for k, v in rays_c.items()})
     with torch.no_grad():
         ret = m(rays, False, False, 0.)
