@@ -114,6 +114,9 @@ int snerf_mip_viewenc(const float* viewdirs, long n_rays, int S, int deg, void* 
 int snerf_classic_sample_pdf(const float* bins, long ld_bins, int mid_mode, const float* weights, long ld_w, int nc,
                              const float* u, long u_stride, long N, int Nf, float* samples, int* inds, float* z_std,
                              void* stream);
+/* math_ops.py:50-54 (randomized branch of sorted_piecewise_constant_pdf): u = min(arange(P) * s + jit, 1 - eps) in place over the
+ * uniform draw jit [N, P] (torch's own RNG launch stays the caller's, so the draws are the reference's); one launch, same roundings. */
+int snerf_jitter_u(float* u, long N, int P, float s, void* stream);
 /* render.py:354/:385  pts = rays_o[...,None,:] + rays_d[...,None,:] * z_vals[...,:,None]; rays rows = [o3,d3,...]. */
 int snerf_classic_points(const float* rays, int ray_stride, const float* z_vals, long N, int S, float* pts, void* stream);
 /* render.py:383 torch.sort(torch.cat([z_vals, z_samples], -1), -1) */
@@ -376,7 +379,7 @@ int snerf_pinhole_rays(const int* coords, long first_pixel, int W, int H, const 
  * (loss_factory.py:26-37; disparity 1: |1/p - 1/t|) on dist1 (fine) + coarse_mult * dist0 (coarse), rays with tdepth == 0 masked
  * out, times conf [N] (nullable), mean over the valid rays, times depth_lambda (tdepth NULL = no depth loss); ProposalLoss
  * (loss_factory.py:59-74) of the detached fine histogram (s_f [N,Pf], w_f [N,Pf-1]) against the coarse one (s_c [N,Sc+1],
- * w_c [N,Sc]) times prop_lambda (s_c NULL = off).  out[4] = {#valid depth rays, rgb loss, depth loss, proposal loss};
+ * w_c [N,Sc]) times prop_lambda (s_c NULL = off).  out[5] = {#valid depth rays, rgb loss, depth loss, proposal loss, their sum};
  * g_rgb [N,3], g_dist1 / g_dist0 [N], g_wc [N,Sc] = d(total loss)/d(input). */
 int snerf_mip_loss_tail(const float* rgb, const float* tgt, const float* dist1, const float* dist0, const float* tdepth,
                         const float* conf, const float* s_f, const float* w_f, const float* s_c, const float* w_c, long N, int Pf,

@@ -219,7 +219,7 @@ __global__ __launch_bounds__(1024) void loss_prepare_kernel(const float* __restr
   if (threadIdx.x == 0) {
     int t = 0;
     for (int w = 0; w < 16; ++w) t += part[w];
-    out[0] = (float)t; out[1] = 0.f; out[2] = 0.f; out[3] = 0.f;
+    out[0] = (float)t; out[1] = 0.f; out[2] = 0.f; out[3] = 0.f; out[4] = 0.f;
   }
 }
 
@@ -306,6 +306,7 @@ __global__ __launch_bounds__(64) void loss_tail_kernel(LossTail a) {
     atomicAdd(a.out + 1, l_rgb);
     if (a.tdepth != nullptr) atomicAdd(a.out + 2, l_dep);
     if (a.s_c != nullptr) atomicAdd(a.out + 3, l_prop);
+    atomicAdd(a.out + 4, (l_rgb + l_dep) + l_prop);     // the total: the step's loss scalar without a fold launch behind the tail
   }
 }
 

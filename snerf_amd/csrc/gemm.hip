@@ -666,6 +666,14 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
     m0 = (logical / tiles_n) << 8;
     n0 = (logical % tiles_n) << 8;
   };
+  if constexpr (COLSUM) {
+    // the column-sum partials accumulate into rows (2 blockIdx.x, 2 blockIdx.x + 1) of the workspace: the workgroup zeroes them itself,
+    // long before its first flush (a whole tile later, behind that tile's barriers) -- instead of a memset launch in front of every
+    // data-gradient GEMM (8 per training step).  The stores are older than every staging load, so the hand-counted vmcnt waits below only
+    // get stricter while they are in flight.
+    float* z = p.colsum_ws + (long)blockIdx.x * 2 * p.N;
+    for (int i = tid; i < 2 * p.N; i += 512) z[i] = 0.f;
+  }
 
   // ---- staging stream -------------------------------------------------------------------------------------------
   const int lrow = lane >> 3, lsc = lane & 7;
@@ -952,7 +960,7 @@ __global__ __launch_bounds__(512) void gemm_nt8p_kernel(GemmNT p) {
   };
   // The column sums stay in registers across this workgroup's tiles: its tiles normally all lie in ONE column block (tile index
   // stride G is a multiple of tiles_n for the shapes of the step), so the partial sums are flushed once per workgroup -- row
-  // (blockIdx.x, wave row) of the zero-initialised workspace -- instead of once per tile.  A change of column block flushes early.
+  // (blockIdx.x, wave row) of the workspace (zeroed by the workgroup at its start) -- instead of once per tile.  A change of column block flushes early.
   auto flush_colsum = [&](int em0, int en0) __attribute__((always_inline)) {
     if constexpr (!COLSUM) return;
     (void)em0;
@@ -1321,7 +1329,6 @@ static int launch_nt8p(const GemmNT& p, hipStream_t stream) {
   if (const char* e = getenv("SNERF_NT8P_GRID")) { const int g = atoi(e); if (g > 0 && g < grid) grid = g; }
 #endif
   const bool cs = p.colsum_ws != nullptr;
-  if (cs) (void)hipMemsetAsync(p.colsum_ws, 0, (size_t)grid * 2 * p.N * sizeof(float), stream);   // the workgroups accumulate into it
   const dim3 g(grid), b(512);
   if (p.split == 2) {                                    // fp16 + fp8 flavours (forward activations only)
     if constexpr (F16) {

@@ -264,6 +264,26 @@ extern "C" int snerf_stratified(const float* base, const float* rnd, const float
   return snerf_check_launch();
 }
 
+// u[n, k] = min(k * s + jit[n, k], 1 - eps)  (math_ops.py:50-54: arange(num_samples) * s + uniform_(to = s - eps), clamped below 1), in
+// place over the uniform draw: the five eager launches of that expression (arange, mul, add, ones_like - eps, minimum) as one.  Same
+// roundings as the eager ops: float(k) * float(s) and the sum are rounded separately (no fma).
+__global__ __launch_bounds__(256) void jitter_u_kernel(float* __restrict__ u, long N, int P, float s) {
+  const long total = N * P;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int k = (int)(e % P);
+    u[e] = fminf(__fadd_rn(__fmul_rn((float)k, s), u[e]), 0.99999988079071044921875f);
+  }
+}
+
+extern "C" int snerf_jitter_u(float* u, long N, int P, float s, void* stream) {
+  if (N <= 0) return SNERF_OK;
+  if (u == nullptr || P <= 0) return SNERF_ERR_ARG;
+  const long total = N * P;
+  const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+  hipLaunchKernelGGL(jitter_u_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, u, N, P, s);
+  return snerf_check_launch();
+}
+
 // pts[n,s,:] = o[n] + d[n] * z[n,s]   (render.py:354, :385) -- separate multiply and add like the eager ops
 __global__ __launch_bounds__(256) void classic_points_kernel(const float* __restrict__ rays, int ray_stride, const float* __restrict__ z,
                                                              long N, int S, float* __restrict__ pts) {

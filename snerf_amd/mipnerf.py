@@ -279,7 +279,7 @@ class MipNerfModel(_ArenaModule):
             P1 = self.N_fine
             s = 1 / P1
             jit = torch.empty(n, P1, device=dev).uniform_(to=s - EPS32)
-            u = torch.minimum(torch.arange(P1, device=dev) * s + jit, torch.ones_like(jit) - EPS32)
+            u = ops.jitter_u(jit, s)               # = torch.minimum(torch.arange(P1) * s + jit, torch.ones_like(jit) - EPS32), bit for bit
             if self.density_noise > 0:
                 noise1 = self.density_noise * torch.randn(n, P1 - 1, device=dev)
         else:

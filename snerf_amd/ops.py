@@ -603,6 +603,13 @@ def mip_resample(s_vals, weights, u, resample_padding=0.01, want_idx=False):
     return out, idx
 
 
+def jitter_u(jit, s):
+    """math_ops.py:50-54: min(arange(P) * s + jit, 1 - eps) IN PLACE over the uniform draw jit [N, P] (one launch, the eager expression's bits)"""
+    _f32c(jit)
+    _lib.call("snerf_jitter_u", _p(jit), jit.shape[0], jit.shape[1], float(s), _stream())
+    return jit
+
+
 def stratified(base, rnd, near, far, n, mode, lindisp=False):
     """mode 0: classic z-values from near/far [N] views (stride in elements); mode 1: mip s-values."""
     _f32c(base); _f32c(rnd)
@@ -1308,10 +1315,10 @@ def ert_f2b_state(n, S1, group, device):
 
 
 def mip_loss_tail(rgb, tgt, dist1, dist0, tdepth, conf, s_f, w_f, s_c, w_c, disparity, depth_lambda, coarse_mult, prop_lambda):
-    """-> (out[4] = {#valid, rgb, depth, proposal loss}, g_rgb, g_dist1, g_dist0, g_wc); absent terms return None gradients."""
+    """-> (out[5] = {#valid, rgb, depth, proposal loss, total}, g_rgb, g_dist1, g_dist0, g_wc); absent terms return None gradients."""
     n = rgb.shape[0]
     dev = rgb.device
-    out = torch.empty(4, dtype=torch.float32, device=dev)
+    out = torch.empty(5, dtype=torch.float32, device=dev)
     g_rgb = torch.empty(n, 3, dtype=torch.float32, device=dev)
     g1 = g0 = gw = None
     if tdepth is not None:

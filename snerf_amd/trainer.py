@@ -194,8 +194,8 @@ class MipTrainer(_AdamState):
             rgb1, target_rgb, dist1 if target_depth is not None else None, dist0 if target_depth is not None else None,
             target_depth, conf, s1 if prop else None, w1 if prop else None, s0 if prop else None, w0 if prop else None,
             self.disparity_depth, self.depth_lambda, self.coarse_depth_mult, self.proposal_lambda)
-        self.last_losses = out                                   # {#valid depth rays, rgb, depth, proposal}: stays on the device
-        return out[1:].sum(), (g_dist0, None, g_w0, g_rgb1, g_dist1, None, None)
+        self.last_losses = out[:4]                               # {#valid depth rays, rgb, depth, proposal}: stays on the device
+        return out[4], (g_dist0, None, g_w0, g_rgb1, g_dist1, None, None)      # out[4]: their sum, formed by the same launch
 
     def step(self, rays, target_rgb, target_depth=None, conf=None, randomized=True, s_rand=None, u=None, ray_grads=False, viewc=None):
         """`ray_grads=True` (pose refinement, configs: pose_refine = True): `last_ray_grads` = d loss / d (origins, directions, viewdirs)

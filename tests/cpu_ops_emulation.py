@@ -241,6 +241,12 @@ def stratified(base, rnd, near, far, n, mode, lindisp=False):
     return oc.stratified_z(near[:, None], far[:, None], base.shape[0], lindisp, rnd).contiguous()
 
 
+def jitter_u(jit, s):
+    eps = float(torch.finfo(torch.float32).eps)
+    jit.copy_(torch.minimum(torch.arange(jit.shape[1], device=jit.device) * s + jit, torch.ones_like(jit) - eps))   # math_ops.py:50-54
+    return jit
+
+
 def mip_composite_fwd(raw_rgb, raw_density, noise, s_vals, dirs, near, far, transform_idx, white, rgb_padding, density_bias, row_index=None):
     assert row_index is None
     n, P = s_vals.shape
@@ -539,7 +545,7 @@ def mip_loss_tail(rgb, tgt, dist1, dist0, tdepth, conf, s_f, w_f, s_c, w_c, disp
     from oracle import callers as oc
     dev = rgb.device
     rg = rgb.detach().cpu().clone().requires_grad_(True)
-    out = torch.zeros(4)
+    out = torch.zeros(5)
     loss = oc.rgb_loss(rg, tgt.cpu())
     out[1] = loss.detach()
     leaves, g1 = [rg], None
@@ -558,6 +564,7 @@ def mip_loss_tail(rgb, tgt, dist1, dist0, tdepth, conf, s_f, w_f, s_c, w_c, disp
         out[3] = lp.detach()
         loss = loss + lp
         leaves.append(wc)
+    out[4] = loss.detach()
     gs = torch.autograd.grad(loss, leaves, allow_unused=True)
     gs = [torch.zeros_like(l) if g is None else g for g, l in zip(gs, leaves)]
     it = iter(gs)
@@ -956,7 +963,7 @@ def adam_step_dev(p, g, m, v, lr, b1, b2, eps, step_dev, grad_scale=1.0, zero_gr
 _NAMES = ["nonfinite_flag", "fmlp_zip_fwd", "fmlp_zip_train_fwd", "fmlp_zip_chain_bwd", "zip_prop_mlp_fwd", "zip_prop_mlp_bwd", "colsum_wide_f32", "zip_glo_modulate", "zip_glo_modulate_bwd", "fchain_bwd", "app_embed", "app_embed_bwd", "split_cast", "split8_cast", "fcolour_fwd", "fcolour_bwd", "gather_pack", "adam_step_dev", "grad_clip_coef", "fmlp_classic_fwd", "fmlp_classic_pts_fwd", "fmlp_proposal_fwd", "fmlp_classic_train_fwd", "fmlp_proposal_train_fwd", "classic_get_rays", "classic_ndc_rays", "classic_ray_batch", "zip_encode_prop_fwd", "mip_encode_bwd", "mip_viewenc_bwd", "hash_decay", "zip_percentiles", "zip_pixels_to_rays", "zip_loss_tail", "semantic_composite_fwd", "semantic_composite_bwd", "zip_resample", "zip_encode_fwd", "zip_encode_fwd_count", "zip_encode_bwd", "zip_encode_bwd_binned", "zip_encode_ray_bwd", "zip_composite_fwd", "zip_composite_bwd",
           "linear_fwd", "linear_wgrad", "classic_embed", "mip_encode", "mip_viewenc", "classic_sample_pdf", "classic_points",
           "classic_merge_sort", "mip_resample", "stratified", "mip_composite_fwd", "mip_composite_bwd", "classic_composite_fwd",
-          "classic_composite_bwd", "adam_step", "colsum_f32", "cast_pad", "pinhole_rays", "mip_loss_tail"]
+          "classic_composite_bwd", "adam_step", "colsum_f32", "cast_pad", "pinhole_rays", "mip_loss_tail", "jitter_u"]
 
 
 @contextlib.contextmanager

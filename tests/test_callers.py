@@ -166,6 +166,7 @@ def test_loss_tail_vs_oracle(golden, N, Sc, Pf):
     assert int(out[0]) == int((x["td"] != 0).sum())
     for got, ref, name in ((out[1], lr, "rgb"), (out[2], ld, "depth"), (out[3], lp, "proposal")):
         assert abs(float(got) - float(ref)) <= 2e-6 * max(abs(float(ref)), 1e-3), (name, float(got), float(ref))
+    assert abs(float(out[4]) - float(lr + ld + lp)) <= 4e-6 * float(lr + ld + lp)      # out[4]: the total, formed by the same launch
     if N == 96:                                                    # the reference's own numbers
         assert abs(float(out[3]) - float(g["proposal_loss"])) <= 2e-6 * float(g["proposal_loss"])
         # entries where +g / -g pairs cancel in the reverse prefix sum carry rounding noise of the row's magnitude
@@ -177,6 +178,7 @@ def test_loss_tail_vs_oracle(golden, N, Sc, Pf):
     # rgb-only call (no depth targets, no proposal loss)
     out2, h2, a, b, cgw = ops.mip_loss_tail(c["rgb"], c["tgt"], None, None, None, None, None, None, None, None, True, 0.2, 0.2, 0.05)
     assert a is None and b is None and cgw is None and torch.equal(h2, h_rgb) and float(out2[2]) == 0.0 and float(out2[3]) == 0.0
+    assert abs(float(out2[4]) - float(out2[1])) <= 4e-6 * float(out2[1])
 
 
 def test_trainer_loss_tail_host_logic():

@@ -457,6 +457,19 @@ def test_merge_sort(ops):
     assert torch.equal(out.cpu(), torch.sort(torch.cat([a, b], -1), -1)[0])
 
 
+@pytest.mark.parametrize("n,P", [(1, 128), (33, 128), (4096, 128), (517, 65)])
+def test_jitter_u_is_the_eager_expression(ops, n, P):
+    """snerf_jitter_u = math_ops.py:50-54 (arange(P) * s + uniform_(to = s - eps), clamped below 1), bit for bit, in one launch"""
+    eps = float(torch.finfo(torch.float32).eps)
+    s = 1 / P
+    torch.manual_seed(5)
+    jit = torch.empty(n, P, device="cuda").uniform_(to=s - eps)
+    jit[0, -1] = s                                     # a draw that must be clamped
+    ref = torch.minimum(torch.arange(P, device="cuda") * s + jit, torch.ones_like(jit) - eps)
+    got = ops.jitter_u(jit.clone(), s)
+    assert torch.equal(got, ref) and float(got.max()) < 1.0
+
+
 def test_mip_resample(ops, golden):
     for num in (32, 33):
         g = golden(f"g5_pdf_{num}")
