@@ -319,6 +319,11 @@ int snerf_cast_pad(const float* src, long ld_src, long M, int C, int Cpad, void*
  * the fp32 parameter arena; idx (16-byte aligned) is built once per network by the host from the same slicing code that defines the
  * layouts (snerf_amd/mlp.py: _Net._build_plan). */
 int snerf_gather_pack(const float* flat, const int* idx, long n, void* dst, int dtype, void* stream);
+/* The same refresh with the transposed images (a packed W^T reads the arena at a stride of one weight row per element: one L2 request per
+ * element in the gather) taken as 16 x 64 destination tiles: tiles int32 [n_tiles, 4] = {dst_off, src_base, src_stride, dst_ld} with
+ * dst[dst_off + i * dst_ld + j] = flat[src_base + j * src_stride + i], i < 16, j < 64; src_base and src_stride multiples of 4, flat and tiles
+ * 16-byte aligned.  The tiles' elements carry idx = -3 (skipped by the gather part of the launch).  One launch. */
+int snerf_gather_pack_tiles(const float* flat, const int* idx, long n, void* dst, int dtype, const int* tiles, int n_tiles, void* stream);
 
 /* Semantic compositing, both flavours of the reference.  softmax = 1: zipnerf NerfMLP (internal/models.py:594-597) +
  * internal/render.py:237-241: semantic [R,C] = sum_i detach(weights [R,S]) softmax(logits [R*S, ld][:, :C]) (logits = columns

@@ -480,6 +480,64 @@ extern "C" int snerf_gather_pack(const float* flat, const int* idx, long n, void
   return snerf_check_launch();
 }
 
+// The same refresh with the TRANSPOSED images taken out of the element-wise gather.  A packed W^T (the data-gradient GEMMs' operand) reads the
+// arena at a stride of one weight row per destination element: 64 lanes x 4 scalar loads = 256 L2 requests per 256 elements, which is what the
+// refresh of a 1024-wide network cost (75 us of the 512-ray step's 4.3 ms).  The host finds the 16 x 64 destination tiles with
+// dst[r0 + i, c0 + j] = flat[base + j * stride + i] (base, stride multiples of 4: 16-byte loads) once per plan; here one wave takes a tile: lane j
+// loads its 16 consecutive source floats (one 64-byte line) and the wave writes 16 rows of 64 consecutive destinations.  The tiles' elements carry
+// idx = -3 in the gather map (skipped there).  Blocks [0, tile_blocks) take four tiles each, the rest run the element-wise gather.
+struct PackTile { int dst_off, src_base, src_stride, dst_ld; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void gather_pack_tiles_kernel(const float* __restrict__ flat, const int* __restrict__ idx, long n, T* __restrict__ dst,
+                                                                const PackTile* __restrict__ tiles, int n_tiles, int tile_blocks) {
+  if ((int)blockIdx.x < tile_blocks) {
+    const int t = (int)blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (t >= n_tiles) return;
+    const PackTile pt = tiles[t];
+    const f32x4* src = (const f32x4*)(flat + pt.src_base + (long)lane * pt.src_stride);
+    f32x4 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = src[q];
+    T* d = dst + pt.dst_off + lane;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d[(long)(q * 4 + e) * pt.dst_ld] = from_f32<T>(v[q][e]);
+    return;
+  }
+  const long b = (long)blockIdx.x - tile_blocks, nb = (long)gridDim.x - tile_blocks;
+  for (long i = (b * 256 + threadIdx.x) * 4; i < n; i += nb * 1024) {
+    if (i + 4 <= n) {
+      const int4 k = *(const int4*)(idx + i);
+      const int kk[4] = {k.x, k.y, k.z, k.w};
+      if (kk[0] == -3 && kk[1] == -3 && kk[2] == -3 && kk[3] == -3) continue;   // (four tile elements: nothing to do)
+      T o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = kk[e] == -3 ? from_f32<T>(0.f) : gather_one<T>(flat, kk[e]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (kk[e] != -3) dst[i + e] = o[e];
+    } else {
+      for (long j = i; j < n; ++j) if (idx[j] != -3) dst[j] = gather_one<T>(flat, idx[j]);
+    }
+  }
+}
+
+extern "C" int snerf_gather_pack_tiles(const float* flat, const int* idx, long n, void* dst, int dtype, const int* tiles, int n_tiles, void* stream) {
+  if (n <= 0) return SNERF_OK;
+  if (flat == nullptr || idx == nullptr || dst == nullptr || (((uintptr_t)idx) & 15) || (((uintptr_t)flat) & 15) || n_tiles < 0 ||
+      (n_tiles > 0 && (tiles == nullptr || (((uintptr_t)tiles) & 15)))) return SNERF_ERR_ARG;
+  const long want = (n + 1023) / 1024;
+  const int gblocks = (int)(want < 4096 ? want : 4096), tblocks = (n_tiles + 3) / 4;
+  const dim3 g((unsigned)(gblocks + tblocks)), b(256);
+  const PackTile* tl = (const PackTile*)tiles;
+  if (dtype == SNERF_DT_F32) hipLaunchKernelGGL(gather_pack_tiles_kernel<float>, g, b, 0, (hipStream_t)stream, flat, idx, n, (float*)dst, tl, n_tiles, tblocks);
+  else if (dtype == SNERF_DT_BF16) hipLaunchKernelGGL(gather_pack_tiles_kernel<__bf16>, g, b, 0, (hipStream_t)stream, flat, idx, n, (__bf16*)dst, tl, n_tiles, tblocks);
+  else if (dtype == SNERF_DT_F16) hipLaunchKernelGGL(gather_pack_tiles_kernel<_Float16>, g, b, 0, (hipStream_t)stream, flat, idx, n, (_Float16*)dst, tl, n_tiles, tblocks);
+  else return SNERF_ERR_ARG;
+  return snerf_check_launch();
+}
+
 extern "C" int snerf_version() { return 1; }
 int g_snerf_last_hip_error = 0;
 extern "C" int snerf_last_hip_error() { return g_snerf_last_hip_error; }

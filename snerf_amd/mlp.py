@@ -156,11 +156,36 @@ class _PackPlan:
         self.size[dtype] = off + roundup(img.numel(), 128)        # every operand 256-byte aligned inside its pool
         return (dtype, off, tuple(img.shape))
 
+    @staticmethod
+    def _transposed_tiles(k2, off):
+        """k2: int64 [R, C] arena positions of one packed operand (negative: padding / ones; bit 30: split-bf16 low parts).  -> (int32 [n, 4] tile
+        descriptors of snerf_gather_pack_tiles, bool [R, C] mask of the covered elements) for the 16 x 64 tiles with
+        k2[r0 + i, c0 + j] = base + j * stride + i, base % 4 == stride % 4 == 0, stride >= 16 -- the transposed weight images."""
+        R, C = k2.shape
+        R16, C64 = R // 16 * 16, C // 64 * 64
+        if R16 == 0 or C64 == 0:
+            return None, None
+        t = k2[:R16, :C64].reshape(R16 // 16, 16, C64 // 64, 64)
+        base = t[:, 0, :, 0]
+        s = t[:, 0, :, 1] - base
+        i = torch.arange(16, device=k2.device).view(1, 16, 1, 1)
+        j = torch.arange(64, device=k2.device).view(1, 1, 1, 64)
+        ok = (t == base[:, None, :, None] + i + j * s[:, None, :, None]).all(3).all(1)
+        ok &= (base >= 0) & (base % 4 == 0) & (s % 4 == 0) & (s >= 16) & (base + 63 * s + 15 < (1 << 30))
+        if not bool(ok.any()):
+            return None, None
+        tr, tc = torch.nonzero(ok, as_tuple=True)
+        tiles = torch.stack([off + tr * 16 * C + tc * 64, base[tr, tc], s[tr, tc], torch.full_like(tr, C)], 1).to(torch.int32)
+        mask = torch.zeros(R, C, dtype=torch.bool, device=k2.device)
+        mask[:R16, :C64] = ok[:, None, :, None].expand(-1, 16, -1, 64).reshape(R16, C64)
+        return tiles, mask
+
     def finish(self):
-        self.pools, self.maps = {}, {}
+        self.pools, self.maps, self.tiles = {}, {}, {}
         for dtype, items in self.items.items():
             n = self.size[dtype]
             idx = torch.full((n,), -1, dtype=torch.int32, device=self.flat.device)
+            tl = []
             for img, off in items:
                 v = img.reshape(-1)
                 assert bool(((v == v.round()) & (v >= 0)).all()), "pack() may only copy parameters, zeros and ones"
@@ -169,9 +194,17 @@ class _PackPlan:
                 k = (v - 2.0).to(torch.int32)                      # image value = arena position + 2; 0 = padding, 1 = constant one
                 k = torch.where(lo, k | (1 << 30), k)
                 minus1, minus2 = torch.full_like(k, -1), torch.full_like(k, -2)
-                idx[off:off + v.numel()] = torch.where(v == 0, minus1, torch.where(v == 1, minus2, k))
+                k = torch.where(v == 0, minus1, torch.where(v == 1, minus2, k))
+                if img.dim() == 2 and dtype in (torch.bfloat16, torch.float16) and n < (1 << 31):
+                    # transposed weight images (W^T of the data-gradient GEMMs) leave the element-wise gather: 16 x 64 tiles, one 64-byte source line per lane
+                    tiles, mask = self._transposed_tiles(k.view(img.shape).long(), off)
+                    if tiles is not None:
+                        tl.append(tiles)
+                        k = torch.where(mask.reshape(-1), torch.full_like(k, -3), k)
+                idx[off:off + v.numel()] = k
             self.pools[dtype] = torch.zeros(n, dtype=dtype, device=self.flat.device)
             self.maps[dtype] = idx
+            self.tiles[dtype] = torch.cat(tl, 0).contiguous() if tl else None
         self.items = None
         self.post = []                     # fp16 + fp8 weights: (fp32 image [N, K] in the fp32 pool, its [N, 2 K] split operand), converted after the gather
 
@@ -184,7 +217,7 @@ class _PackPlan:
 
     def refresh(self):
         for dtype, idx in self.maps.items():
-            ops.gather_pack(self.flat, idx, self.pools[dtype])
+            ops.gather_pack(self.flat, idx, self.pools[dtype], self.tiles[dtype])
         for src, dst in self.post:
             ops.split8_cast(src, src.shape[1], dst, src.shape[1], weight=True)
 

@@ -784,11 +784,16 @@ def cast_pad(src, C, dst, Cpad, dt):
     _lib.call("snerf_cast_pad", _p(src), src.stride(0), src.shape[0], C, Cpad, _p(dst), dst.stride(0), dt, _stream())
 
 
-def gather_pack(flat, idx, dst):
-    """dst[i] = flat[idx[i]] (idx -1 -> 0, -2 -> 1) rounded to dst's dtype: all packed operands of a network in one launch."""
+def gather_pack(flat, idx, dst, tiles=None):
+    """dst[i] = flat[idx[i]] (idx -1 -> 0, -2 -> 1) rounded to dst's dtype: all packed operands of a network in one launch.  `tiles` (int32
+    [n, 4] = dst_off, src_base, src_stride, dst_ld: 16 x 64 transposed tiles, their elements marked idx = -3): snerf_gather_pack_tiles."""
     assert flat.dtype == torch.float32 and flat.is_contiguous() and idx.dtype == torch.int32 and idx.is_contiguous() and dst.is_contiguous()
     assert dst.numel() == idx.numel() and dst.dtype in (torch.float32, torch.bfloat16, torch.float16)
-    _lib.call("snerf_gather_pack", _p(flat), _p(idx), idx.numel(), _p(dst), _zip_dt(dst), _stream())
+    if tiles is None or tiles.numel() == 0:
+        _lib.call("snerf_gather_pack", _p(flat), _p(idx), idx.numel(), _p(dst), _zip_dt(dst), _stream())
+        return
+    assert tiles.dtype == torch.int32 and tiles.is_contiguous() and tiles.dim() == 2 and tiles.shape[1] == 4
+    _lib.call("snerf_gather_pack_tiles", _p(flat), _p(idx), idx.numel(), _p(dst), _zip_dt(dst), _p(tiles), tiles.shape[0], _stream())
 
 
 # ------------------------------------------------------------ hash grid ----

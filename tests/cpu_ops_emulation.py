@@ -947,13 +947,25 @@ def fchain_bwd(net, d_raw, stream, bits, dz, g_bias):
         assert st.f == 392
 
 
-def gather_pack(flat, idx, dst):
+def gather_pack(flat, idx, dst, tiles=None):
+    if tiles is not None and tiles.numel():
+        t = tiles.long()
+        i = torch.arange(16).view(1, 16, 1)
+        j = torch.arange(64).view(1, 1, 64)
+        d = (t[:, 0].view(-1, 1, 1) + i * t[:, 3].view(-1, 1, 1) + j).reshape(-1)
+        s = (t[:, 1].view(-1, 1, 1) + j * t[:, 2].view(-1, 1, 1) + i).reshape(-1)
+        assert bool((idx.long()[d] == -3).all()) and int((idx == -3).sum()) == d.numel()
+        keep = dst.view(-1).clone()
     k = idx.long()
     lo = (k >= 0) & ((k & (1 << 30)) != 0)                     # split-bf16 weights: the low part bf16(x - bf16(x))
     x = flat[torch.where(k >= 0, k & 0x3fffffff, torch.zeros_like(k))]
     x = torch.where(lo, x - x.to(torch.bfloat16).float(), x)
     v = torch.where(k >= 0, x, torch.where(k == -2, torch.ones_like(flat[:1]), torch.zeros_like(flat[:1])).expand_as(k))
     dst.view(-1)[:] = v.to(dst.dtype)
+    if tiles is not None and tiles.numel():
+        skip = idx == -3
+        dst.view(-1)[skip] = keep[skip]
+        dst.view(-1)[d] = flat[s].to(dst.dtype)
 
 
 def adam_step_dev(p, g, m, v, lr, b1, b2, eps, step_dev, grad_scale=1.0, zero_grad=True, **kw):

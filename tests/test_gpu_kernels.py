@@ -915,6 +915,20 @@ def test_gather_pack_refreshes_operands():
     arena.p["pts_linears.5.weight"].mul_(2.0); arena.bump()
     net.ensure_packed(True)
     assert torch.equal(net.fw["pts_linears.5"][:128, :63], (W5[:, :63]).to(torch.bfloat16)) and net.fw["pts_linears.5"].data_ptr() == fw.data_ptr()
+    assert torch.equal(net.tw["pts_linears.5"][:128, :128], W5[:, 63:].t().to(torch.bfloat16))
+    # the transposed images leave the gather as 16 x 64 tiles (snerf_gather_pack_tiles): same bits as the plain gather over the unmarked map
+    plan = net._plans["train"][0]
+    tiles = plan.tiles[torch.bfloat16]
+    assert tiles is not None and tiles.shape[0] >= 7 * 2 * 8                     # at least seven 128 x 128 trunk transposes (8 x 2 tiles each)
+    idx = plan.maps[torch.bfloat16].clone()
+    t = tiles.long()
+    i, j = torch.arange(16, device="cuda").view(1, 16, 1), torch.arange(64, device="cuda").view(1, 1, 64)
+    d = (t[:, 0].view(-1, 1, 1) + i * t[:, 3].view(-1, 1, 1) + j).reshape(-1)
+    assert bool((idx[d] == -3).all()) and int((idx == -3).sum()) == d.numel()
+    idx[d] = (t[:, 1].view(-1, 1, 1) + j * t[:, 2].view(-1, 1, 1) + i).reshape(-1).to(torch.int32)
+    plain = torch.full_like(plan.pools[torch.bfloat16], 3.0)
+    ops.gather_pack(arena.flat, idx, plain)
+    assert torch.equal(plain, plan.pools[torch.bfloat16])
 
 
 def test_embedding_index_range_is_reported_and_gradient_is_reproducible(ops):

@@ -453,3 +453,34 @@ def test_wgrad_fold_policy():
     assert not ops.wgrad_uses_fold(2048, 1024, 1024, ops.BF16, 3)            # below the 8-phase kernel's M
     assert not ops.wgrad_uses_fold(786432, 1024, 1024, ops.F32, 3) and not ops.wgrad_uses_fold(786432, 2048, 2048, ops.BF16X3, 3)
     assert not ops.wgrad_uses_fold(786432, 1024, 1024, ops.BF16, 1)          # variant without the 8-phase kernel
+
+
+def test_pack_plan_takes_the_transposed_weight_images_as_tiles():
+    """_PackPlan.finish: the W^T images of the data-gradient GEMMs leave the element-wise gather map as 16 x 64 tiles (snerf_gather_pack_tiles);
+    the plan refreshed through the CPU emulation (which expands the tiles) equals the slicing code applied to the parameters."""
+    from cpu_ops_emulation import emulate_ops
+    from snerf_amd.mlp import ClassicNeRFNet, ParamArena, _PackPlan
+    g = torch.Generator().manual_seed(3)
+    # detection on a hand-made map: a 32 x 128 transposed block (stride 40) next to padding and an untransposed block
+    k = torch.full((48, 192), -1, dtype=torch.int64)
+    k[:32, :128] = 400 + torch.arange(128).view(1, -1) * 40 + torch.arange(32).view(-1, 1)
+    k[:32, 128:192] = 9000 + torch.arange(32).view(-1, 1) * 64 + torch.arange(64).view(1, -1)
+    tiles, mask = _PackPlan._transposed_tiles(k, 1000)
+    assert tiles.shape == (4, 4) and int(mask.sum()) == 32 * 128 and bool(mask[:32, :128].all())
+    assert sorted(tiles[:, 0].tolist()) == [1000, 1064, 1000 + 16 * 192, 1064 + 16 * 192] and set(tiles[:, 2].tolist()) == {40} and set(tiles[:, 3].tolist()) == {192}
+    k[5, 7] += 1                                             # one element off: its tile stays in the gather
+    tiles, mask = _PackPlan._transposed_tiles(k, 1000)
+    assert tiles.shape == (3, 4) and not bool(mask[:16, :64].any())
+    k[:32, :128] = 402 + torch.arange(128).view(1, -1) * 40 + torch.arange(32).view(-1, 1)      # base not a multiple of 4: no 16-byte loads
+    assert _PackPlan._transposed_tiles(k, 0)[0] is None
+    with emulate_ops() as ops:
+        shapes = ClassicNeRFNet.param_shapes(8, 128, 63, 27, (4,))
+        arena = ParamArena(shapes, torch.device("cpu"))
+        arena.load({n: torch.randn(s, generator=g) for n, s in shapes})
+        net = ClassicNeRFNet(arena, "", ops.BF16, 8, 128)
+        net.ensure_packed(True)
+        plan = net._plans["train"][0]
+        assert plan.tiles[torch.bfloat16] is not None and int((plan.maps[torch.bfloat16] == -3).sum()) == plan.tiles[torch.bfloat16].shape[0] * 1024
+        W5 = arena.p["pts_linears.5.weight"]
+        assert torch.equal(net.tw["pts_linears.5"][:128, :128], W5[:, 63:].t().to(torch.bfloat16))
+        assert torch.equal(net.fw["pts_linears.5"][:128, :63], W5[:, :63].to(torch.bfloat16))
