@@ -130,8 +130,10 @@ extern "C" int snerf_classic_merge_sort(const float* a, int na, const float* b, 
 // ---------------------------------------------------------------------------
 // mip resample: s_vals [N,S+1], weights [N,S] -> new fence posts [N,Nf] + idx
 // ---------------------------------------------------------------------------
-#define MRS_RAYS 64        // rays per workgroup
 #define MRS_THREADS 256    // 4 waves: wave 0 owns the serial prefix sums (lane per ray), all four the lookups (lane per output sample)
+// MRS_RAYS: rays per workgroup.  64 for large batches; 16 up to 16 384 rays (a training batch: 4096 rays are 256 workgroups instead of 64 -- the
+// kernel is a chain of dependent LDS reads, 44 us whatever the batch at 64 rays per workgroup -- and each wave looks up 4 rays instead of 16)
+template <int MRS_RAYS>
 __global__ __launch_bounds__(MRS_THREADS) void mip_resample_kernel(const float* __restrict__ s_vals, const float* __restrict__ weights,
                                                                    const float* __restrict__ u, long u_stride, long N, int S, int Nf,
                                                                    float padding_c, float* __restrict__ out, int* __restrict__ idx_out) {
@@ -214,13 +216,20 @@ extern "C" int snerf_mip_resample(const float* s_vals, const float* weights, con
   if (N <= 0) return SNERF_OK;
   if (S < 2 || Nf <= 0) return SNERF_ERR_ARG;
   const int stride = (S + 1) | 1;
-  const size_t lds = (size_t)MRS_RAYS * (stride + (S + 1) + Nf) * sizeof(float);
-  if (lds > 160 * 1024) return SNERF_ERR_ARG;
+  const int rays = N <= 16384 ? 16 : 64;
+  const size_t lds = (size_t)rays * (stride + (S + 1) + Nf) * sizeof(float);
+  if ((size_t)64 * (stride + (S + 1) + Nf) * sizeof(float) > 160 * 1024) return SNERF_ERR_ARG;       // (one limit for every batch size)
   static bool attr = false;
-  if (!attr) { hipFuncSetAttribute((const void*)mip_resample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-  const int blocks = (int)((N + MRS_RAYS - 1) / MRS_RAYS);
-  hipLaunchKernelGGL(mip_resample_kernel, dim3(blocks), dim3(MRS_THREADS), lds, (hipStream_t)stream, s_vals, weights, u, u_stride, N, S,
-                     Nf, resample_padding, out, idx_out);
+  if (!attr) {
+    hipFuncSetAttribute((const void*)mip_resample_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)mip_resample_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  const int blocks = (int)((N + rays - 1) / rays);
+  if (rays == 16) hipLaunchKernelGGL(mip_resample_kernel<16>, dim3(blocks), dim3(MRS_THREADS), lds, (hipStream_t)stream, s_vals, weights, u, u_stride, N, S,
+                                     Nf, resample_padding, out, idx_out);
+  else hipLaunchKernelGGL(mip_resample_kernel<64>, dim3(blocks), dim3(MRS_THREADS), lds, (hipStream_t)stream, s_vals, weights, u, u_stride, N, S,
+                          Nf, resample_padding, out, idx_out);
   return snerf_check_launch();
 }
 

@@ -488,6 +488,10 @@ def test_mip_resample(ops, golden):
     ref_s, ref_i = om.warp_resample_s(sv, w, u, 0.01)
     s, idx = ops.mip_resample(sv.cuda(), w.cuda(), u.cuda(), 0.01, want_idx=True)
     assert torch.equal(idx.cpu(), ref_i) and torch.equal(s.cpu(), ref_s)
+    # batches above 16 384 rays run 64 rays per workgroup instead of 16: the same rows, the same bits (a frame chunk vs a training batch)
+    rep = 57                                                      # 300 x 57 = 17 100 rays
+    s2, idx2 = ops.mip_resample(sv.cuda().repeat(rep, 1), w.cuda().repeat(rep, 1), u.cuda().repeat(rep, 1), 0.01, want_idx=True)
+    assert torch.equal(s2.view(rep, N, Nf), s.expand(rep, -1, -1)) and torch.equal(idx2.view(rep, N, Nf), idx.expand(rep, -1, -1))
 
 
 # ------------------------------------------------------------ compositing ----
