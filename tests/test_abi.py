@@ -45,6 +45,11 @@ def test_bad_arguments_are_rejected_without_a_gpu():
         _lib.call("snerf_linear_fwd", None, 0, None, 0, None, None, 0, None, 0, None, None, 16, 100, 64, 1, 0, 1, 0, 0, None)  # N % 128 != 0
     with pytest.raises(_lib.SnerfHipError, match="bad argument"):
         _lib.call("snerf_mip_resample", None, None, None, 0, 4, 1, 8, 0.01, None, None, None)  # S < 2
+    with pytest.raises(_lib.SnerfHipError, match="bad argument"):
+        _lib.call("snerf_jitter_u", None, 4, 8, 0.125, None)                                   # no buffer
+    with pytest.raises(_lib.SnerfHipError, match="bad argument"):
+        _lib.call("snerf_gather_pack_tiles", None, None, 16, None, 1, None, 1, None)           # no arena / map / destination
+    assert _lib.call("snerf_jitter_u", None, 0, 8, 0.125, None) is None                        # an empty batch is not an error
 
 
 def test_no_vector_alu_instruction_hides_in_inline_asm():
