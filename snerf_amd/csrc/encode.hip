@@ -145,12 +145,15 @@ struct MipEncArgs {
   float viewc[3]; const float* far_max;                    // fn_idx 0: the mean camera centre; device scalar max(far) of the batch
 };
 
-template <typename T>
+template <typename T, int ROWS>
 __global__ __launch_bounds__(256) void mip_encode_kernel(MipEncArgs a) {
-  __shared__ float sm[256][6];
-  const long mbase = (long)blockIdx.x * 256;
+  // ROWS rows per workgroup of 256 threads: 256 for large batches; 64 for small ones (phase 2 below is a chain of exp / sin evaluations, 64 per
+  // thread at 256 rows: a 512-ray batch is then ONE wave per SIMD with nothing to hide their latency behind -- 47 us per launch whatever the
+  // batch; at 64 rows the same work is four waves per SIMD, 16 evaluations each)
+  __shared__ float sm[ROWS][6];
+  const long mbase = (long)blockIdx.x * ROWS;
   const long m = mbase + threadIdx.x;
-  if (m < a.M) {
+  if ((int)threadIdx.x < ROWS && m < a.M) {
     const long src = a.sample_id != nullptr ? (long)a.sample_id[m] : m;
     const long ray = src / a.S;
     const int i = (int)(src - ray * a.S);
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(256) void mip_encode_kernel(MipEncArgs a) {
   // generic loop below), the rest write the zero padding.  Same fp32 operations per feature as one thread per output element, half the
   // exponentials and no 64-bit index divisions (round 2: 120 + 205 us per step for the two levels).
   const int nfeat = 6 * a.max_deg, half = 3 * a.max_deg;
-  const int rows = (int)(a.M - mbase < 256 ? a.M - mbase : 256);
+  const int rows = (int)(a.M - mbase < ROWS ? a.M - mbase : ROWS);
   T* d1 = (T*)a.dst1; T* d2 = (T*)a.dst2;
   if (half <= 64) {
     for (int e = threadIdx.x; e < rows * 64; e += 256) {
@@ -298,11 +301,15 @@ static int mip_encode_launch(const float* s_vals, const float* origins, const fl
   if ((fn_idx != 0 && fn_idx != 1) || (fn_idx == 0 && far_max == nullptr)) return SNERF_ERR_ARG;
   MipEncArgs a{s_vals, origins, directions, radii, near, far, S, sample_id != nullptr ? n_rows : n_rays * (long)S, cone, transform_idx, max_deg,
                dst1, ld1, dst2, ld2, width, means_out, covs_out, sample_id, fn_idx, {vx, vy, vz}, far_max};
-  const int blocks = (int)((a.M + 255) / 256);
-  if (dtype == SNERF_DT_F32) hipLaunchKernelGGL(mip_encode_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
-  else if (dtype == SNERF_DT_F16) hipLaunchKernelGGL(mip_encode_kernel<_Float16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
-  else if (dtype == SNERF_DT_BF16) hipLaunchKernelGGL(mip_encode_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+  const bool small = a.M <= 131072;                       // (up to two workgroups of 256 rows per CU: take 64-row workgroups instead)
+  const int blocks = (int)(small ? (a.M + 63) / 64 : (a.M + 255) / 256);
+#define MIP_ENC(T_) do { if (small) hipLaunchKernelGGL((mip_encode_kernel<T_, 64>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a); \
+                         else hipLaunchKernelGGL((mip_encode_kernel<T_, 256>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a); } while (0)
+  if (dtype == SNERF_DT_F32) MIP_ENC(float);
+  else if (dtype == SNERF_DT_F16) MIP_ENC(_Float16);
+  else if (dtype == SNERF_DT_BF16) MIP_ENC(__bf16);
   else return SNERF_ERR_ARG;
+#undef MIP_ENC
   return snerf_check_launch();
 }
 

@@ -384,6 +384,27 @@ def test_mip_encode_view_centred_warp(ops, golden, shape):
     assert bool((out[:, 96:] == 0).all())
 
 
+def test_mip_encode_row_block_flavours_agree(ops):
+    """mip_encode_kernel runs 64 rows per workgroup up to 131 072 rows and 256 above (a training batch of 512 rays vs a frame chunk): the same
+    rays in one large launch and in two small ones must give the same bits (bf16 operand and the fp32 image)."""
+    n, S = 1100, 128                                           # 140 800 rows in one launch: the 256-row flavour
+    g = torch.Generator().manual_seed(31)
+    s_vals = torch.sort(torch.rand(n, S + 1, generator=g), -1)[0].cuda()
+    o, d = (torch.randn(n, 3, generator=g) * 2).cuda(), torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).cuda()
+    rad = (torch.rand(n, generator=g) * 1e-3 + 1e-4).cuda()
+    near, far = (torch.rand(n, generator=g) + 0.5).cuda(), (torch.rand(n, generator=g) * 50 + 5).cuda()
+    for dt, tdt in ((ops.BF16, torch.bfloat16), (ops.F32, torch.float32)):
+        big = torch.full((n * S, 128), 7.0, dtype=tdt, device="cuda")
+        ops.mip_encode(s_vals, o, d, rad, near, far, True, 0, 16, big, None, 128, dt)
+        parts = []
+        for a, b in ((0, 600), (600, n)):                      # 76 800 and 64 000 rows: the 64-row flavour
+            out = torch.full(((b - a) * S, 128), 7.0, dtype=tdt, device="cuda")
+            ops.mip_encode(s_vals[a:b].contiguous(), o[a:b].contiguous(), d[a:b].contiguous(), rad[a:b].contiguous(), near[a:b].contiguous(),
+                           far[a:b].contiguous(), True, 0, 16, out, None, 128, dt)
+            parts.append(out)
+        assert torch.equal(big, torch.cat(parts, 0)) and float(big[:, 96:].float().abs().max()) == 0.0
+
+
 def test_mip_encode_ipe_exact_inputs(ops, golden):
     """IPE stage alone: feed means/covs that survive the sampler unchanged (|x| < 3 region is x/3 ... not exact), so instead
     check the bf16 path against the fp32 path of the same kernel."""
