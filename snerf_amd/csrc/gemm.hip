@@ -1916,6 +1916,45 @@ __global__ __launch_bounds__(256) void tn_fold_kernel(const float* __restrict__ 
   }
 }
 
+// The same fold for MANY slices (the 128 x 128 kernel runs ~1024 workgroups per launch: 114 ... 1024 slices per output tile): a workgroup takes 64
+// consecutive (VEC: 4-float) pieces of the valid output region and splits the slices over its G = 16 waves -- wave g adds slices g, g + G, ... in order,
+// wave 0 then adds the 16 partial sums in wave order: a fixed order again (bit-reproducible), with 16 x more loads in flight than one thread per piece.
+template <bool VEC>
+__global__ __launch_bounds__(1024) void tn_fold_many_kernel(const float* __restrict__ part, long part_stride, int part_ld, int slices, int n_valid,
+                                                            int k_valid, float* __restrict__ dW, long ldw) {
+  constexpr int G = 16, W = VEC ? 4 : 1;
+  __shared__ float sm[G][64][W];
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int kq = k_valid / W;                                     // pieces per output row
+  const long e = (long)blockIdx.x * 64 + lane;
+  const bool live = e < (long)n_valid * kq;
+  const int n = live ? (int)(e / kq) : 0, k = live ? (int)(e - (long)n * kq) * W : 0;
+  const float* src = part + (long)n * part_ld + k;
+  float s[W];
+#pragma unroll
+  for (int w = 0; w < W; ++w) s[w] = 0.f;
+  if (live) {
+#pragma unroll 4
+    for (int c = g; c < slices; c += G) {
+      if constexpr (VEC) { const f32x4 v = *(const f32x4*)(src + (long)c * part_stride); s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3]; }
+      else s[0] += src[(long)c * part_stride];
+    }
+  }
+#pragma unroll
+  for (int w = 0; w < W; ++w) sm[g][lane][w] = s[w];
+  __syncthreads();
+  if (g == 0 && live) {
+    float* dst = dW + (long)n * ldw + k;
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+      float t = sm[0][lane][w];
+#pragma unroll
+      for (int q = 1; q < G; ++q) t += sm[q][lane][w];
+      dst[w] += t;
+    }
+  }
+}
+
 struct TnPlan {
   bool use8;          // 256 x 256 8-phase kernel, else 128 x 128
   int slices;         // M slices (workgroups per output tile)
@@ -2042,7 +2081,12 @@ static int wgrad_launch(const void* Z, long ldz, const void* X, long ldx, float*
   if (ws != nullptr) {
     // (the same sums in the same order either way: the vector flavour only needs 16-byte aligned rows)
     const bool vec = k_valid % 4 == 0 && pl.part_ld % 4 == 0 && pl.part_stride % 4 == 0 && ldw % 4 == 0 && ((size_t)dW & 15) == 0 && ((size_t)ws & 15) == 0;
-    if (vec)
+    if (pl.slices > 32) {                                  // (the 128 x 128 kernel's launches; the wide layers run 16 slices)
+      const long pieces = (long)n_valid * (vec ? k_valid / 4 : k_valid);
+      const dim3 fg((unsigned)((pieces + 63) / 64));
+      if (vec) hipLaunchKernelGGL(tn_fold_many_kernel<true>, fg, dim3(1024), 0, (hipStream_t)stream, ws, pl.part_stride, pl.part_ld, pl.slices, n_valid, k_valid, dW, ldw);
+      else hipLaunchKernelGGL(tn_fold_many_kernel<false>, fg, dim3(1024), 0, (hipStream_t)stream, ws, pl.part_stride, pl.part_ld, pl.slices, n_valid, k_valid, dW, ldw);
+    } else if (vec)
       hipLaunchKernelGGL(tn_fold_kernel<true>, dim3((k_valid / 4 + 255) / 256, n_valid), dim3(256), 0, (hipStream_t)stream, ws, pl.part_stride,
                          pl.part_ld, pl.slices, n_valid, k_valid, dW, ldw);
     else

@@ -122,12 +122,27 @@ def relu_bits_ok(A, W, Y, K, n_store, dt, variant, consumer=False):
             and A.stride(0) * 512 < (1 << 31) and W.stride(0) * 512 < (1 << 31) and mask_bits_words(A.shape[0], N) * 4 < (1 << 31))
 
 
-WGRAD_FOLD = __import__("os").environ.get("SNERF_WGRAD_FOLD", "1") != "0"   # (the environment switch: A/B runs, tools/probes/wgrad_fold_ab.sh)
+# the environment switch (A/B runs, tools/probes/wgrad_fold_ab.sh): "0" = fp32 atomics everywhere, "wide" = the fold for the wide layers only (round 5's
+# policy), anything else = the policy below
+WGRAD_FOLD = __import__("os").environ.get("SNERF_WGRAD_FOLD", "1") != "0"
+WGRAD_FOLD_WIDE_ONLY = __import__("os").environ.get("SNERF_WGRAD_FOLD", "1") == "wide"
 
 
-def wgrad_uses_fold(M, N, K, dt, variant):
-    """the default cross-slice reduction of linear_wgrad: True = partial tiles + fixed-order fold (see there), False = fp32 atomics"""
-    return bool(WGRAD_FOLD and (variant & 2) and dt in (BF16, F16) and M >= 4096 and N % 256 == 0 and K >= 256 and (N // 256) * ((K + 255) // 256) >= 8)
+def wgrad_uses_fold(M, N, K, dt, variant, n_valid=None, k_valid=None):
+    """the default cross-slice reduction of linear_wgrad: True = partial tiles + fixed-order fold (see there), False = fp32 atomics.
+    A launch runs ~256 (256 x 256 kernel) or ~1024 (128 x 128 kernel) workgroups whatever M is, and every one of them ends with one fp32 atomic per
+    valid element of its tile: 16.8 M atomics per launch on full tiles, all issued at the same moment -- 25-70 us per launch that the partial tiles +
+    fold replace by 10-25.  So: every launch of the 256 x 256 kernel, and the 128 x 128 kernel's launches with up to four output tiles of >= 8 valid
+    rows (more tiles -- N = 128, K = 1051; N = 1024, K = 96 -- stream enough operand bytes per atomic to hide them: measured neutral; a head's 1-3
+    valid rows issue few atomics).  profiles/r6_z_wgrad_fold_narrow_ab.txt"""
+    if not WGRAD_FOLD or dt not in (BF16, F16) or M < 4096:
+        return False
+    if (variant & 2) and N % 256 == 0 and K >= 256:                   # tn_plan's condition for the 256 x 256 kernel
+        return not WGRAD_FOLD_WIDE_ONLY or (N // 256) * ((K + 255) // 256) >= 8
+    if WGRAD_FOLD_WIDE_ONLY:
+        return False
+    nv = N if n_valid is None else n_valid
+    return nv >= 8 and ((N + 127) // 128) * ((K + 127) // 128) <= 4
 
 
 def linear_wgrad(dZ, X, dW, n_valid, k_valid, dt, variant=0, deterministic=False, x_split_hi=False):
@@ -150,7 +165,7 @@ def linear_wgrad(dZ, X, dW, n_valid, k_valid, dt, variant=0, deterministic=False
     # launch folds them in slice order instead of adding 256 x 256 fp32 atomics per slice -- bit-reproducible, and faster: the atomics
     # of 16 slices (16.8 M per launch at N = K = 1024, whatever M is) cost 24-71 us, the stores + fold 7-26 (tools/probes/
     # tn_epilogue_probe.py); 512-ray step 4.55 -> 4.24 ms, 4096-ray step 25.65 -> 25.47 (A/B on one box, tools/probes/wgrad_fold_ab.sh)
-    if not deterministic and wgrad_uses_fold(dZ.shape[0], dZ.shape[1], Kx, dt, variant):
+    if not deterministic and wgrad_uses_fold(dZ.shape[0], dZ.shape[1], Kx, dt, variant, n_valid, k_valid):
         deterministic = True
     if deterministic:
         nws = _lib.query("snerf_linear_wgrad_ws_floats", dZ.shape[0], dZ.shape[1], Kx, dZ.stride(0), X.stride(0), dt, variant)

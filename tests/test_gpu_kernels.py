@@ -956,6 +956,36 @@ def test_gather_pack_refreshes_operands():
     assert torch.equal(plain, plan.pools[torch.bfloat16])
 
 
+@pytest.mark.parametrize("M,N,K,nv,kv", [(40000, 256, 256, 256, 256), (70000, 128, 128, 128, 128), (50000, 256, 96, 256, 96), (33000, 128, 104, 128, 99),
+                                         (4096, 256, 256, 200, 256)])
+def test_wgrad_many_slice_fold(ops, M, N, K, nv, kv):
+    """The few-tile weight gradients (hundreds of M slices per output tile) through partial tiles + tn_fold_many_kernel -- the default since round 6 --:
+    against a float64 product, bit-identical run to run, accumulating (+=) into dW, untouched outside [:n_valid, :k_valid], and equal to the
+    fp32-atomic form within its rounding."""
+    g = torch.Generator().manual_seed(M + N)
+    dZ = (torch.randn(M, N, generator=g) * 0.1).to(torch.bfloat16).cuda()
+    X = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+    assert ops.wgrad_uses_fold(M, N, K, ops.BF16, 3, nv, kv)
+    ref = dZ.double().t()[:nv] @ X.double()[:, :kv]
+    outs = []
+    for _ in range(2):
+        dW = torch.full((N, K), 0.5, dtype=torch.float32, device="cuda")
+        ops.linear_wgrad(dZ, X, dW, nv, kv, ops.BF16, variant=3)
+        outs.append(dW)
+    assert torch.equal(outs[0], outs[1])
+    got = outs[0].double() - 0.5
+    assert float((got[:nv, :kv] - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-4
+    assert float(got[nv:].abs().max() if nv < N else 0.0) == 0.0 and float(got[:, kv:].abs().max() if kv < K else 0.0) == 0.0
+    saved = ops.WGRAD_FOLD
+    try:
+        ops.WGRAD_FOLD = False
+        dA = torch.full((N, K), 0.5, dtype=torch.float32, device="cuda")
+        ops.linear_wgrad(dZ, X, dA, nv, kv, ops.BF16, variant=3)
+    finally:
+        ops.WGRAD_FOLD = saved
+    assert float((dA - outs[0]).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-4
+
+
 def test_embedding_index_range_is_reported_and_gradient_is_reproducible(ops):
     """rays.app / cam_idx outside the embedding table -- nn.Embedding raises (models.py:153-159); the kernels clamp, and the
     asynchronous range check reports the launch at the next poll (no sync inside the step).  The deterministic accumulation of the
