@@ -324,6 +324,10 @@ int snerf_gather_pack(const float* flat, const int* idx, long n, void* dst, int 
  * dst[dst_off + i * dst_ld + j] = flat[src_base + j * src_stride + i], i < 16, j < 64; src_base and src_stride multiples of 4, flat and tiles
  * 16-byte aligned.  The tiles' elements carry idx = -3 (skipped by the gather part of the launch).  One launch. */
 int snerf_gather_pack_tiles(const float* flat, const int* idx, long n, void* dst, int dtype, const int* tiles, int n_tiles, void* stream);
+/* snerf_gather_pack_tiles of a network's 16-bit operand pool and the plain gather of its (small) fp32 pool -- biases, fused-kernel tables:
+ * dst32[i] = flat[idx32[i]], same index codes -- as ONE launch (tiles / n_tiles may be NULL / 0; n32 = 0: the 16-bit pool alone). */
+int snerf_gather_pack_pair(const float* flat, const int* idx, long n, void* dst, int dtype, const int* tiles, int n_tiles, const int* idx32,
+                           long n32, float* dst32, void* stream);
 
 /* Semantic compositing, both flavours of the reference.  softmax = 1: zipnerf NerfMLP (internal/models.py:594-597) +
  * internal/render.py:237-241: semantic [R,C] = sum_i detach(weights [R,S]) softmax(logits [R*S, ld][:, :C]) (logits = columns

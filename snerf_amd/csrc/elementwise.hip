@@ -488,25 +488,9 @@ extern "C" int snerf_gather_pack(const float* flat, const int* idx, long n, void
 // idx = -3 in the gather map (skipped there).  Blocks [0, tile_blocks) take four tiles each, the rest run the element-wise gather.
 struct PackTile { int dst_off, src_base, src_stride, dst_ld; };
 
+// element-wise part: block b of nb walks the map four elements per thread; idx = -3 marks what the tile part writes
 template <typename T>
-__global__ __launch_bounds__(256) void gather_pack_tiles_kernel(const float* __restrict__ flat, const int* __restrict__ idx, long n, T* __restrict__ dst,
-                                                                const PackTile* __restrict__ tiles, int n_tiles, int tile_blocks) {
-  if ((int)blockIdx.x < tile_blocks) {
-    const int t = (int)blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (t >= n_tiles) return;
-    const PackTile pt = tiles[t];
-    const f32x4* src = (const f32x4*)(flat + pt.src_base + (long)lane * pt.src_stride);
-    f32x4 v[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = src[q];
-    T* d = dst + pt.dst_off + lane;
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) d[(long)(q * 4 + e) * pt.dst_ld] = from_f32<T>(v[q][e]);
-    return;
-  }
-  const long b = (long)blockIdx.x - tile_blocks, nb = (long)gridDim.x - tile_blocks;
+__device__ __forceinline__ void gather_pack_span(const float* __restrict__ flat, const int* __restrict__ idx, long n, T* __restrict__ dst, long b, long nb) {
   for (long i = (b * 256 + threadIdx.x) * 4; i < n; i += nb * 1024) {
     if (i + 4 <= n) {
       const int4 k = *(const int4*)(idx + i);
@@ -523,19 +507,59 @@ __global__ __launch_bounds__(256) void gather_pack_tiles_kernel(const float* __r
   }
 }
 
-extern "C" int snerf_gather_pack_tiles(const float* flat, const int* idx, long n, void* dst, int dtype, const int* tiles, int n_tiles, void* stream) {
-  if (n <= 0) return SNERF_OK;
-  if (flat == nullptr || idx == nullptr || dst == nullptr || (((uintptr_t)idx) & 15) || (((uintptr_t)flat) & 15) || n_tiles < 0 ||
+template <typename T>
+__global__ __launch_bounds__(256) void gather_pack_tiles_kernel(const float* __restrict__ flat, const int* __restrict__ idx, long n, T* __restrict__ dst,
+                                                                const PackTile* __restrict__ tiles, int n_tiles, int tile_blocks, int gather_blocks,
+                                                                const int* __restrict__ idx_b, long n_b, float* __restrict__ dst_b) {
+  if ((int)blockIdx.x < tile_blocks) {
+    const int t = (int)blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (t >= n_tiles) return;
+    const PackTile pt = tiles[t];
+    const f32x4* src = (const f32x4*)(flat + pt.src_base + (long)lane * pt.src_stride);
+    f32x4 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = src[q];
+    T* d = dst + pt.dst_off + lane;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d[(long)(q * 4 + e) * pt.dst_ld] = from_f32<T>(v[q][e]);
+    return;
+  }
+  long b = (long)blockIdx.x - tile_blocks;
+  if (b >= gather_blocks) {
+    // the network's fp32 pool (biases, fused-kernel tables: small) rides in the same launch: blocks past the 16-bit pool's share
+    gather_pack_span<float>(flat, idx_b, n_b, dst_b, b - gather_blocks, (long)gridDim.x - tile_blocks - gather_blocks);
+    return;
+  }
+  gather_pack_span<T>(flat, idx, n, dst, b, gather_blocks);
+}
+
+static int gather_pack_launch(const float* flat, const int* idx, long n, void* dst, int dtype, const int* tiles, int n_tiles, const int* idx_b, long n_b,
+                              float* dst_b, void* stream) {
+  if (n <= 0 && n_b <= 0) return SNERF_OK;
+  if (n <= 0 || flat == nullptr || idx == nullptr || dst == nullptr || (((uintptr_t)idx) & 15) || (((uintptr_t)flat) & 15) || n_tiles < 0 ||
       (n_tiles > 0 && (tiles == nullptr || (((uintptr_t)tiles) & 15)))) return SNERF_ERR_ARG;
-  const long want = (n + 1023) / 1024;
-  const int gblocks = (int)(want < 4096 ? want : 4096), tblocks = (n_tiles + 3) / 4;
-  const dim3 g((unsigned)(gblocks + tblocks)), b(256);
+  if (n_b < 0 || (n_b > 0 && (idx_b == nullptr || dst_b == nullptr || (((uintptr_t)idx_b) & 15)))) return SNERF_ERR_ARG;
+  const long want = (n + 1023) / 1024, want_b = (n_b + 1023) / 1024;
+  const int gblocks = (int)(want < 4096 ? want : 4096), tblocks = (n_tiles + 3) / 4, bblocks = (int)(want_b < 1024 ? want_b : 1024);
+  const dim3 g((unsigned)(gblocks + tblocks + bblocks)), b(256);
   const PackTile* tl = (const PackTile*)tiles;
-  if (dtype == SNERF_DT_F32) hipLaunchKernelGGL(gather_pack_tiles_kernel<float>, g, b, 0, (hipStream_t)stream, flat, idx, n, (float*)dst, tl, n_tiles, tblocks);
-  else if (dtype == SNERF_DT_BF16) hipLaunchKernelGGL(gather_pack_tiles_kernel<__bf16>, g, b, 0, (hipStream_t)stream, flat, idx, n, (__bf16*)dst, tl, n_tiles, tblocks);
-  else if (dtype == SNERF_DT_F16) hipLaunchKernelGGL(gather_pack_tiles_kernel<_Float16>, g, b, 0, (hipStream_t)stream, flat, idx, n, (_Float16*)dst, tl, n_tiles, tblocks);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == SNERF_DT_F32) hipLaunchKernelGGL(gather_pack_tiles_kernel<float>, g, b, 0, s, flat, idx, n, (float*)dst, tl, n_tiles, tblocks, gblocks, idx_b, n_b, dst_b);
+  else if (dtype == SNERF_DT_BF16) hipLaunchKernelGGL(gather_pack_tiles_kernel<__bf16>, g, b, 0, s, flat, idx, n, (__bf16*)dst, tl, n_tiles, tblocks, gblocks, idx_b, n_b, dst_b);
+  else if (dtype == SNERF_DT_F16) hipLaunchKernelGGL(gather_pack_tiles_kernel<_Float16>, g, b, 0, s, flat, idx, n, (_Float16*)dst, tl, n_tiles, tblocks, gblocks, idx_b, n_b, dst_b);
   else return SNERF_ERR_ARG;
   return snerf_check_launch();
+}
+
+extern "C" int snerf_gather_pack_tiles(const float* flat, const int* idx, long n, void* dst, int dtype, const int* tiles, int n_tiles, void* stream) {
+  return gather_pack_launch(flat, idx, n, dst, dtype, tiles, n_tiles, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int snerf_gather_pack_pair(const float* flat, const int* idx, long n, void* dst, int dtype, const int* tiles, int n_tiles, const int* idx32,
+                                      long n32, float* dst32, void* stream) {
+  return gather_pack_launch(flat, idx, n, dst, dtype, tiles, n_tiles, idx32, n32, dst32, stream);
 }
 
 extern "C" int snerf_version() { return 1; }

@@ -216,8 +216,14 @@ class _PackPlan:
         return self.pools[dtype][off:off + n].view(shape)
 
     def refresh(self):
-        for dtype, idx in self.maps.items():
-            ops.gather_pack(self.flat, idx, self.pools[dtype], self.tiles[dtype])
+        half = [d for d in self.maps if d in (torch.bfloat16, torch.float16)]
+        if len(half) == 1 and torch.float32 in self.maps and len(self.maps) == 2:
+            # the usual case -- one 16-bit operand pool + the fp32 pool (biases, fused-kernel tables) -- is ONE launch
+            d = half[0]
+            ops.gather_pack_pair(self.flat, self.maps[d], self.pools[d], self.tiles[d], self.maps[torch.float32], self.pools[torch.float32])
+        else:
+            for dtype, idx in self.maps.items():
+                ops.gather_pack(self.flat, idx, self.pools[dtype], self.tiles[dtype])
         for src, dst in self.post:
             ops.split8_cast(src, src.shape[1], dst, src.shape[1], weight=True)
 

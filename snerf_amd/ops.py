@@ -811,6 +811,16 @@ def gather_pack(flat, idx, dst, tiles=None):
     _lib.call("snerf_gather_pack_tiles", _p(flat), _p(idx), idx.numel(), _p(dst), _zip_dt(dst), _p(tiles), tiles.shape[0], _stream())
 
 
+def gather_pack_pair(flat, idx, dst, tiles, idx32, dst32):
+    """gather_pack of a 16-bit pool (with its transposed tiles, or None) and of the network's fp32 pool in ONE launch (snerf_gather_pack_pair)"""
+    assert flat.dtype == torch.float32 and flat.is_contiguous() and idx.dtype == torch.int32 and idx.is_contiguous() and dst.is_contiguous()
+    assert dst.numel() == idx.numel() and dst.dtype in (torch.bfloat16, torch.float16)
+    assert idx32.dtype == torch.int32 and idx32.is_contiguous() and dst32.dtype == torch.float32 and dst32.is_contiguous() and dst32.numel() == idx32.numel()
+    nt = 0 if tiles is None else tiles.shape[0]
+    assert tiles is None or (tiles.dtype == torch.int32 and tiles.is_contiguous() and tiles.dim() == 2 and tiles.shape[1] == 4)
+    _lib.call("snerf_gather_pack_pair", _p(flat), _p(idx), idx.numel(), _p(dst), _zip_dt(dst), _p(tiles), nt, _p(idx32), idx32.numel(), _p(dst32), _stream())
+
+
 # ------------------------------------------------------------ hash grid ----
 def grid_per_level_scale(base_resolution, desired_resolution, num_levels):
     """growth factor that puts level num_levels - 1 at desired_resolution (gridencoder/grid.py:104-106)"""

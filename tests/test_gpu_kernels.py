@@ -954,6 +954,14 @@ def test_gather_pack_refreshes_operands():
     plain = torch.full_like(plan.pools[torch.bfloat16], 3.0)
     ops.gather_pack(arena.flat, idx, plain)
     assert torch.equal(plain, plan.pools[torch.bfloat16])
+    # ... and the network's fp32 pool rides in the same launch (snerf_gather_pack_pair): the plain gather of its map gives the same pool
+    assert set(plan.maps) == {torch.bfloat16, torch.float32}
+    plain32 = torch.full_like(plan.pools[torch.float32], 3.0)
+    ops.gather_pack(arena.flat, plan.maps[torch.float32], plain32)
+    assert torch.equal(plain32, plan.pools[torch.float32]) and float(plain32.abs().max()) > 0
+    both16, both32 = torch.full_like(plan.pools[torch.bfloat16], 5.0), torch.full_like(plan.pools[torch.float32], 5.0)
+    ops.gather_pack_pair(arena.flat, plan.maps[torch.bfloat16], both16, plan.tiles[torch.bfloat16], plan.maps[torch.float32], both32)
+    assert torch.equal(both16, plan.pools[torch.bfloat16]) and torch.equal(both32, plan.pools[torch.float32])
 
 
 @pytest.mark.parametrize("M,N,K,nv,kv", [(40000, 256, 256, 256, 256), (70000, 128, 128, 128, 128), (50000, 256, 96, 256, 96), (33000, 128, 104, 128, 99),
