@@ -9,8 +9,9 @@ from snerf_amd.trainer import MipTrainer
 
 dev = torch.device("cuda")
 model = bench.build_model(sys.argv[1] if len(sys.argv) > 1 else "bf16", dev)      # bf16 (default) | bf16x3 | f32
-rays = bench.synth_rays(4096, 0, dev)
-tgt = torch.rand(4096, 3, device=dev); depth = torch.rand(4096, device=dev) * 20 + 2; conf = torch.ones(4096, device=dev)
+R = int(os.environ.get("RAYS", "4096"))                                            # RAYS=512: the per-rank batch of an 8-GPU strong-scaling run
+rays = bench.synth_rays(R, 0, dev)
+tgt = torch.rand(R, 3, device=dev); depth = torch.rand(R, device=dev) * 20 + 2; conf = torch.ones(R, device=dev)
 tr = MipTrainer(model, lr=5e-4, proposal_loss=True)
 for _ in range(3):
     tr.step(rays, tgt, depth, conf)
