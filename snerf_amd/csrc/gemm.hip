@@ -1963,7 +1963,11 @@ struct TnPlan {
   long part_stride;   // floats per slice in the deterministic workspace
 };
 
-static TnPlan tn_plan(int M, int N, int K, long ldz, long ldx, int dtype, int variant) {
+// fold: the launch stores partial tiles (deterministic / default fold mode) instead of adding with atomics -- two rules that exist to amortise a
+// workgroup's atomics then do not apply to SMALL M (<= 131 072 rows, where the fixed cost of a launch is what is left of it): the 128 x 128 kernel
+// may cut slices of 256 instead of >= 1024 rows, and a launch the 256 x 256 kernel would cut into slices of fewer than eight k-tiles (one or two output
+// tiles: M = 32 768 -> 256 slices of two k-tiles, a 256 KB partial tile each) goes to the 128 x 128 kernel instead.
+static TnPlan tn_plan(int M, int N, int K, long ldz, long ldx, int dtype, int variant, bool fold = false) {
   static int n_cu = 0;
   if (n_cu == 0) {
     int dev = 0;
@@ -1982,9 +1986,11 @@ static TnPlan tn_plan(int M, int N, int K, long ldz, long ldx, int dtype, int va
     mc = ((mc + 127) / 128) * 128;                    // whole k-tile pairs
     const long lim = (1L << 30) / ((ldz > ldx ? ldz : ldx) * 2);   // slice bytes stay inside 32-bit buffer offsets
     if (mc > lim) mc = lim / 128 * 128;
-    pl.use8 = true; pl.m_chunk = (int)mc; pl.slices = (int)((M + mc - 1) / mc);
-    pl.part_ld = ((K + 255) / 256) * 256; pl.part_stride = (long)N * pl.part_ld;
-    return pl;
+    if (!(fold && M <= 131072 && mc < 512)) {
+      pl.use8 = true; pl.m_chunk = (int)mc; pl.slices = (int)((M + mc - 1) / mc);
+      pl.part_ld = ((K + 255) / 256) * 256; pl.part_stride = (long)N * pl.part_ld;
+      return pl;
+    }
   }
   // split M so that every CU has work but each block still amortises its atomics
   const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
@@ -1997,7 +2003,8 @@ static TnPlan tn_plan(int M, int N, int K, long ldz, long ldx, int dtype, int va
   int chunks = (target + tiles - 1) / tiles;
   int m_chunk = (M + chunks - 1) / chunks;
   m_chunk = ((m_chunk + 255) / 256) * 256;
-  if (m_chunk < 1024) m_chunk = 1024;
+  const int floor_rows = (fold && M <= 131072) ? 256 : 1024;
+  if (m_chunk < floor_rows) m_chunk = floor_rows;
   pl.use8 = false; pl.m_chunk = m_chunk; pl.slices = (M + m_chunk - 1) / m_chunk;
   pl.part_ld = ((K + 127) / 128) * 128; pl.part_stride = (long)(((N + 127) / 128) * 128) * pl.part_ld;
   return pl;
@@ -2019,7 +2026,7 @@ static int wgrad_launch(const void* Z, long ldz, const void* X, long ldx, float*
   if (f16) dtype = SNERF_DT_BF16;
   const int epc = dtype == SNERF_DT_F32 ? 4 : 8;
   if (N < epc || K < epc || N % epc || K % epc || ldz % epc || ldx % epc || zeros == nullptr) return SNERF_ERR_ARG;
-  const TnPlan pl = tn_plan(M, N, K, ldz, ldx, dtype, variant);
+  const TnPlan pl = tn_plan(M, N, K, ldz, ldx, dtype, variant, ws != nullptr);
   if (ws != nullptr && ws_floats < pl.part_stride * pl.slices) return SNERF_ERR_ARG;
   GemmTN p{Z, ldz, X, ldx, dW, ldw, zeros, M, N, K, n_valid, k_valid, pl.m_chunk, 0, pl.slices, split ? 1 : (xhi ? 2 : 0), ws, pl.part_stride, pl.part_ld};
   if (pl.use8) {
@@ -2106,7 +2113,7 @@ extern "C" int snerf_linear_wgrad(const void* Z, long ldz, const void* X, long l
 extern "C" long snerf_linear_wgrad_ws_floats(int M, int N, int K, long ldz, long ldx, int dtype, int variant) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   if (dtype == 2) dtype = SNERF_DT_BF16;              // (SNERF_DT_F16 runs the bf16 kernels' plan)
-  const TnPlan pl = tn_plan(M, N, K, ldz, ldx, dtype, variant);
+  const TnPlan pl = tn_plan(M, N, K, ldz, ldx, dtype, variant, true);
   return pl.part_stride * pl.slices;
 }
 
