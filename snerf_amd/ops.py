@@ -126,6 +126,7 @@ def relu_bits_ok(A, W, Y, K, n_store, dt, variant, consumer=False):
 # policy), anything else = the policy below
 WGRAD_FOLD = __import__("os").environ.get("SNERF_WGRAD_FOLD", "1") != "0"
 WGRAD_FOLD_WIDE_ONLY = __import__("os").environ.get("SNERF_WGRAD_FOLD", "1") == "wide"
+WGRAD_FOLD_SMALL_M = __import__("os").environ.get("SNERF_WGRAD_FOLD_SMALL_M", "1") != "0"      # (A/B switch of the small-M rule below)
 
 
 def wgrad_uses_fold(M, N, K, dt, variant, n_valid=None, k_valid=None):
@@ -142,7 +143,9 @@ def wgrad_uses_fold(M, N, K, dt, variant, n_valid=None, k_valid=None):
     if WGRAD_FOLD_WIDE_ONLY:
         return False
     nv = N if n_valid is None else n_valid
-    return nv >= 8 and ((N + 127) // 128) * ((K + 127) // 128) <= 4
+    tiles = ((N + 127) // 128) * ((K + 127) // 128)
+    # (small M: the 16.8 M atomics are most of a many-tile launch too -- N = 128, K = 1051 and N = 1024, K = 96 of the 512-ray step)
+    return nv >= 8 and (tiles <= 4 or (WGRAD_FOLD_SMALL_M and M <= 131072 and tiles <= 16))
 
 
 def linear_wgrad(dZ, X, dW, n_valid, k_valid, dt, variant=0, deterministic=False, x_split_hi=False):

@@ -453,6 +453,7 @@ def test_wgrad_fold_policy():
     assert not ops.wgrad_uses_fold(524288, 128, 128, ops.BF16, 3, 3, 128)    # a head: 3 valid rows
     assert not ops.wgrad_uses_fold(786432, 1024, 96, ops.BF16, 3)            # K < 256: the 128 x 128 kernel, 8 tiles
     assert not ops.wgrad_uses_fold(524288, 128, 1088, ops.BF16, 3, 128, 1051)   # 9 tiles
+    assert ops.wgrad_uses_fold(65536, 128, 1088, ops.BF16, 3, 128, 1051) and ops.wgrad_uses_fold(65536, 1024, 96, ops.BF16, 3)   # ... but at small M the atomics are most of the launch
     assert not ops.wgrad_uses_fold(786432, 1024 + 128, 1024, ops.BF16, 3)    # N not a multiple of 256
     assert not ops.wgrad_uses_fold(2048, 1024, 1024, ops.BF16, 3)            # below the 8-phase kernel's M
     assert not ops.wgrad_uses_fold(786432, 1024, 1024, ops.F32, 3) and not ops.wgrad_uses_fold(786432, 2048, 2048, ops.BF16X3, 3)
