@@ -133,14 +133,17 @@ def wgrad_uses_fold(M, N, K, dt, variant, n_valid=None, k_valid=None):
     """the default cross-slice reduction of linear_wgrad: True = partial tiles + fixed-order fold (see there), False = fp32 atomics.
     A launch runs ~256 (256 x 256 kernel) or ~1024 (128 x 128 kernel) workgroups whatever M is, and every one of them ends with one fp32 atomic per
     valid element of its tile: 16.8 M atomics per launch on full tiles, all issued at the same moment -- 25-70 us per launch that the partial tiles +
-    fold replace by 10-25.  So: every launch of the 256 x 256 kernel, and the 128 x 128 kernel's launches with up to four output tiles of >= 8 valid
-    rows (more tiles -- N = 128, K = 1051; N = 1024, K = 96 -- stream enough operand bytes per atomic to hide them: measured neutral; a head's 1-3
-    valid rows issue few atomics).  profiles/r6_z_wgrad_fold_narrow_ab.txt"""
+    fold replace by 10-25.  So: the wide layers (>= 8 tiles of the 256 x 256 kernel: any M, round 5) and, up to 2^20 rows, its few-tile launches and
+    the 128 x 128 kernel's launches with up to four output tiles of >= 8 valid rows (more tiles -- N = 128, K = 1051; N = 1024, K = 96 -- stream
+    enough operand bytes per atomic to hide them: measured neutral; a head's 1-3 valid rows issue few atomics).  Beyond 2^20 rows a workgroup's slice
+    is long enough for the bursts to drift apart: path C's 2.1 M-row launches are neutral, path B's 8.4 M-row launches LOSE 0.4 ms per step to the
+    partial tiles + folds (alternating A/B).  profiles/r6_z_wgrad_fold_narrow_ab.txt"""
     if not WGRAD_FOLD or dt not in (BF16, F16) or M < 4096:
         return False
+    few_ok = not WGRAD_FOLD_WIDE_ONLY and M <= (1 << 20)
     if (variant & 2) and N % 256 == 0 and K >= 256:                   # tn_plan's condition for the 256 x 256 kernel
-        return not WGRAD_FOLD_WIDE_ONLY or (N // 256) * ((K + 255) // 256) >= 8
-    if WGRAD_FOLD_WIDE_ONLY:
+        return (N // 256) * ((K + 255) // 256) >= 8 or few_ok
+    if not few_ok:
         return False
     nv = N if n_valid is None else n_valid
     tiles = ((N + 127) // 128) * ((K + 127) // 128)

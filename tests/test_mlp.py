@@ -441,14 +441,14 @@ def test_fused_training_forward_stores_activations_and_relu_bits(M):
 
 
 def test_wgrad_fold_policy():
-    """ops.wgrad_uses_fold: every launch of the 256 x 256 kernel (the wide layers of path A; paths B / C: one tile, 256 slices -- since the many-slice
-    fold kernel of round 6) and the 128 x 128 kernel's launches of up to four output tiles with >= 8 valid rows reduce their M slices by partial
-    tiles + fold; many-tile launches of the 128 x 128 kernel, the heads' 1-3 valid rows, fp32 and split-bf16 operands and short reductions keep the
-    fp32 atomics."""
+    """ops.wgrad_uses_fold: the wide layers of path A (any M) and, up to 2^20 rows, the few-tile launches of both kernels (>= 8 valid rows; since the
+    many-slice fold kernel of round 6) reduce their M slices by partial tiles + fold; the multi-million-row launches of paths B / C, many-tile
+    launches of the 128 x 128 kernel at large M, the heads' 1-3 valid rows, fp32 and split-bf16 operands and short reductions keep the fp32 atomics."""
     from snerf_amd import ops
     assert ops.wgrad_uses_fold(786432, 1024, 1024, ops.BF16, 3) and ops.wgrad_uses_fold(32768, 1024, 1024, ops.F16, 2)
     assert ops.wgrad_uses_fold(262144, 1024, 512, ops.BF16, 3) and ops.wgrad_uses_fold(262144, 512, 1024, ops.BF16, 3)
-    assert ops.wgrad_uses_fold(6291456, 256, 256, ops.BF16, 3)              # path B: one tile of the 256 x 256 kernel, 256 slices
+    assert ops.wgrad_uses_fold(262144, 256, 256, ops.BF16, 3)               # one tile of the 256 x 256 kernel, 256 slices (path A's proposal network)
+    assert not ops.wgrad_uses_fold(6291456, 256, 256, ops.BF16, 3) and not ops.wgrad_uses_fold(2097152, 256, 256, ops.BF16, 3)   # paths B / C: long slices hide the atomics
     assert ops.wgrad_uses_fold(524288, 128, 128, ops.BF16, 3) and ops.wgrad_uses_fold(262144, 256, 96, ops.BF16, 3, 256, 96)   # 128 x 128 kernel, <= 4 tiles
     assert not ops.wgrad_uses_fold(524288, 128, 128, ops.BF16, 3, 3, 128)    # a head: 3 valid rows
     assert not ops.wgrad_uses_fold(786432, 1024, 96, ops.BF16, 3)            # K < 256: the 128 x 128 kernel, 8 tiles
