@@ -226,13 +226,22 @@ struct ZipEnc {
 __device__ __forceinline__ uint32_t zip_hash3(const uint32_t* p) { return p[0] ^ (p[1] * 2654435761u) ^ (p[2] * 805459861u); }
 
 __device__ __forceinline__ uint32_t zip_grid_index(uint32_t hs, uint32_t res, const uint32_t* pg) {   // gridencoder.cu:66-84, D = 3, hash type
-  uint32_t stride = 1, index = 0;
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    if (stride <= hs) { index += pg[d] * stride; stride *= (res + 1); }
+  // The reference walks `if (stride <= hs) { index += pg[d] * stride; stride *= res + 1; }` over d and hashes when the final stride exceeds
+  // hs.  Which of the two a level is depends on (hs, res) only -- the same for every lane wherever a wave works on one level -- so the
+  // decision is taken on those (scalar) values first and each lane evaluates ONE form: the featurisation and record kernels are VALU-issue
+  // bound (profiles/r6_zz_pathC_gather_bound_pmc.txt) and evaluating both forms plus a runtime modulo per corner was a third of their
+  // instructions (u32 multiplies are quarter rate).  Same uint32 arithmetic, same wrap-around, same result for every input.
+  const uint32_t s1 = res + 1u, s2 = s1 * s1;
+  const bool dense = s1 <= hs && s2 <= hs && s2 * s1 <= hs;        // every guard of the walk passes and the final stride does not exceed hs
+  uint32_t index;
+  if (dense) {
+    index = pg[0] + pg[1] * s1 + pg[2] * s2;
+    if (index >= hs) index %= hs;                                  // (coordinates beyond res only)
+  } else {
+    index = zip_hash3(pg);
+    index = (hs & (hs - 1u)) == 0u ? (index & (hs - 1u)) : index % hs;
   }
-  if (stride > hs) index = zip_hash3(pg);
-  return index % hs;
+  return index;
 }
 
 template <typename TT, int C> struct alignas(sizeof(TT) * C) ZVec { TT v[C]; };
