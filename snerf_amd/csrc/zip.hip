@@ -236,7 +236,7 @@ __device__ __forceinline__ uint32_t zip_grid_index(uint32_t hs, uint32_t res, co
   uint32_t index;
   if (dense) {
     index = pg[0] + pg[1] * s1 + pg[2] * s2;
-    if (index >= hs) index %= hs;                                  // (coordinates beyond res only)
+    while (index >= hs) index -= hs;                               // (= index % hs; coordinates beyond res only: a three-instruction loop instead of a modulo expansion per corner -- these kernels are as long as the instruction cache)
   } else {
     index = zip_hash3(pg);
     index = (hs & (hs - 1u)) == 0u ? (index & (hs - 1u)) : index % hs;
@@ -2168,15 +2168,9 @@ struct G3W {
   const int* scale_exp;
 };
 
-__device__ __forceinline__ uint32_t g3_grid_index(uint32_t hs, uint32_t res, bool pow2, const uint32_t* pg) {   // zip_grid_index with the modulo as a mask where it is one
-  uint32_t stride = 1, index = 0;
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    if (stride <= hs) { index += pg[d] * stride; stride *= (res + 1); }
-  }
-  if (stride > hs) index = zip_hash3(pg);
-  if (index >= hs) index = pow2 ? (index & (hs - 1u)) : index % hs;
-  return index;
+__device__ __forceinline__ uint32_t g3_grid_index(uint32_t hs, uint32_t res, bool pow2, const uint32_t* pg) {   // = zip_grid_index: one form per level, the modulo as a mask where it is one
+  (void)pow2;
+  return zip_grid_index(hs, res, pg);
 }
 
 template <int PPT> struct G3Pts { uint32_t pg[PPT][3]; float fr[PPT][3]; unsigned inb, ends; };
