@@ -478,6 +478,9 @@ struct ZipBin {
   unsigned short* rec_row; float* rec_val; long capacity;   // records: C = 1: rec_val holds {row, value} pairs (8 B); else row + C floats
   long long* g64; long g64_rows;           // int64 image of table rows [0, g64_rows) for the replicated levels
   const int* scale_exp;                    // device: the launch's fixed-point scale is 2^scale_exp[0] (snerf_zip_bin_scale)
+  // count-forward of the single-channel grids: blockIdx.y enumerates GROUPS of up to two levels evaluated by one thread on one
+  // evaluation of the interval's multisamples (ngrp = 0: one level per thread, blockIdx.y = level); see snerf_zip_encode_fwd_count
+  int ngrp; signed char grp[16][2];
 };
 // HALF RECORDS (HREC; passes 5 / 6 / 7): the record's values travel as fp16 of value * 2^(scale_exp - ZB_HALF_SHIFT) -- the largest
 // |grad_feat| entry lands in [2^14, 2^15), fp16's subnormals reach 2^-39 of it, below the 2^-34 fixed-point grid -- 10 instead of 18
@@ -521,8 +524,13 @@ __device__ __forceinline__ void zip_fwd_all_body(const ZipEnc& a, const ZipBin& 
     }
   }
   OT* out = (OT*)a.feat + p * a.ld;
-  const int lend = min(a.L, (int)(ZIP_BY(a) + 1) * a.level_begin);       // level_begin = levels per thread in this kernel
-  for (int level = ZIP_BY(a) * a.level_begin; level < lend; ++level) {
+  const bool grouped = COUNT && C == 1 && b.ngrp > 0;    // (groups exist for the single-channel grids only: compile-time false elsewhere)
+  const int lbeg = grouped ? 0 : (int)ZIP_BY(a) * a.level_begin;
+  const int lend = grouped ? 2 : min(a.L, (int)(ZIP_BY(a) + 1) * a.level_begin);       // level_begin = levels per thread in this kernel
+  for (int it = lbeg; it < lend; ++it) {
+    const int level = grouped ? (int)b.grp[ZIP_BY(a)][it] : it;
+    if (level < 0) break;
+    int* cntl = cnt + (grouped ? it * ZB_NBMAX : 0);     // (a group's levels count into their own bins)
     const uint32_t hs = a.offsets[level + 1] - a.offsets[level];
     const float scale = exp2f(level * a.Sl) * a.H - 1.0f;
     const uint32_t res = (uint32_t)ceilf(scale) + 1;
@@ -552,7 +560,7 @@ __device__ __forceinline__ void zip_fwd_all_body(const ZipEnc& a, const ZipBin& 
       const bool newcell = pg[0] != cur[0] || pg[1] != cur[1] || pg[2] != cur[2];
       cur[0] = pg[0]; cur[1] = pg[1]; cur[2] = pg[2];
       auto tally = [&](long row) __attribute__((always_inline)) {
-        if constexpr (COUNT) { if (newcell) atomicAdd(cnt + (int)((uint32_t)row >> b.bshift) * K + rep, 1); }
+        if constexpr (COUNT) { if (newcell) atomicAdd(cntl + (int)((uint32_t)row >> b.bshift) * K + rep, 1); }
       };
       if constexpr (C == 1 && sizeof(TT) == 4 && ZIP_PAIR_F32) {
         // fp32 single-channel table (the proposal grids under the reference's table policy): the two x-neighbours of a corner pair are
@@ -672,20 +680,26 @@ __device__ __forceinline__ void zip_fwd_all_body(const ZipEnc& a, const ZipBin& 
 
 template <typename TT, typename OT, int C, bool COUNT = false>
 __global__ __launch_bounds__(256) void zip_encode_fwd_all_kernel(ZipEnc a, ZipBin b) {
-  __shared__ int cnt[COUNT ? ZB_NBMAX : 1];
+  constexpr int NQ = COUNT && C == 1 ? 2 : 1;            // levels a thread may take (see ZipBin::grp)
+  __shared__ int cnt[COUNT ? NQ * ZB_NBMAX : 1];
   const long p = (long)ZIP_BX(a) * 256 + threadIdx.x;
   const bool live = p < a.R * a.S;
   if constexpr (COUNT) {
-    for (int k = threadIdx.x; k < ZB_NBMAX; k += 256) cnt[k] = 0;
+    for (int k = threadIdx.x; k < NQ * ZB_NBMAX; k += 256) cnt[k] = 0;
     __syncthreads();
   }
   if (live) zip_fwd_all_body<TT, OT, C, COUNT>(a, b, p, cnt);
   if constexpr (COUNT) {
     __syncthreads();
-    const int level = ZIP_BY(a);                        // (one level per thread in this mode)
-    unsigned* wgo = b.wg_offsets + ((long)level * ZIP_GX(a) + ZIP_BX(a)) * ZB_NBMAX;
-    for (int k = threadIdx.x; k < ZB_NBMAX; k += 256)
-      if (cnt[k] != 0) wgo[k] = (unsigned)atomicAdd(b.counts + level * ZB_NBMAX + k, cnt[k]);
+    const bool grouped = NQ == 2 && b.ngrp > 0;
+    for (int q = 0; q < (grouped ? 2 : 1); ++q) {       // (one level per thread, or a group of up to two)
+      const int level = grouped ? (int)b.grp[ZIP_BY(a)][q] : (int)ZIP_BY(a);
+      if (level < 0) break;
+      unsigned* wgo = b.wg_offsets + ((long)level * ZIP_GX(a) + ZIP_BX(a)) * ZB_NBMAX;
+      const int* cq = cnt + q * ZB_NBMAX;
+      for (int k = threadIdx.x; k < ZB_NBMAX; k += 256)
+        if (cq[k] != 0) wgo[k] = (unsigned)atomicAdd(b.counts + level * ZB_NBMAX + k, cq[k]);
+    }
   }
 }
 
@@ -1249,7 +1263,25 @@ extern "C" int snerf_zip_encode_fwd_count(const float* tdist, const float* origi
   a.level_begin = 1;
   // (2-D grid, level-major launch order: the workgroups in flight gather from ONE level's table.  Launched level-fastest the same kernel
   // takes 4.3 instead of 3.2 ms per proposal level and 5.5 instead of 4.8 on the NeRF level: profiles/r5_z_pathC_launch_order_ab.txt)
-  const dim3 grid((unsigned)((R * S + 255) / 256), L), blk(256);
+  int ny = L;
+  if (C == 1 && L >= 2) {
+    // The single-channel kernel is VALU-issue bound and close to half of a thread's instructions are the interval's multisample geometry
+    // (profiles/r6_zz_pathC_gather_bound_pmc.txt): a thread takes a DENSE coarse level (a table of at most a few MB that stays in L2) together
+    // with a HASHED one, so the geometry is evaluated once for both while the blocks in flight still gather from one large table.
+    int dense[16], hashed[16], nd = 0, nh = 0;
+    for (int l = 0; l < L; ++l) {
+      const float scale = exp2f(l * Sl) * H - 1.0f;
+      const uint32_t s1 = (uint32_t)ceilf(scale) + 2u, s2 = s1 * s1, hs = (uint32_t)level_rows_host[l];
+      if (s1 <= hs && s2 <= hs && s2 * s1 <= hs) dense[nd++] = l; else hashed[nh++] = l;    // (zip_grid_index's rule; only the pairing depends on it)
+    }
+    const int np = nd < nh ? nd : nh;
+    int g = 0;
+    for (int i = 0; i < np; ++i, ++g) { b.grp[g][0] = (signed char)dense[i]; b.grp[g][1] = (signed char)hashed[i]; }
+    for (int i = np; i < nd; ++i, ++g) { b.grp[g][0] = (signed char)dense[i]; b.grp[g][1] = -1; }
+    for (int i = np; i < nh; ++i, ++g) { b.grp[g][0] = (signed char)hashed[i]; b.grp[g][1] = -1; }
+    if (np > 0) { b.ngrp = g; ny = g; }
+  }
+  const dim3 grid((unsigned)((R * S + 255) / 256), ny), blk(256);
   hipStream_t s = (hipStream_t)stream;
 #define ZFC(TT, OT) do { if (C == 4) hipLaunchKernelGGL((zip_encode_fwd_all_kernel<TT, OT, 4, true>), grid, blk, 0, s, a, b); \
                          else hipLaunchKernelGGL((zip_encode_fwd_all_kernel<TT, OT, 1, true>), grid, blk, 0, s, a, b); } while (0)
