@@ -467,6 +467,9 @@ __global__ __launch_bounds__(256) void zip_encode_kernel(ZipEnc a) {
 
 // (bins of the binned table gradient, described further down: the training forward below can already count the records per bin)
 #define ZB_NBMAX 1024                      // bins per level (row ranges x replicas)
+// bin of a table row: (row >> bshift) * K + rep.  Row ranges and replicas are both at most ZB_NBMAX, so the 24-bit multiply is exact -- and
+// issues at the full VALU rate where v_mul_lo_u32 takes four slots (these kernels are VALU-issue bound and form 56 bins per thread)
+__device__ __forceinline__ int zb_bin(uint32_t row, int bshift, int K, int rep) { return (int)__umul24(row >> bshift, (unsigned)K) + rep; }
 #define ZB_HEAD 34                         // the largest |grad_feat| entry maps below 2^ZB_HEAD: 2^27 records cannot overflow 63 bits
 
 struct ZipBin {
@@ -560,7 +563,7 @@ __device__ __forceinline__ void zip_fwd_all_body(const ZipEnc& a, const ZipBin& 
       const bool newcell = pg[0] != cur[0] || pg[1] != cur[1] || pg[2] != cur[2];
       cur[0] = pg[0]; cur[1] = pg[1]; cur[2] = pg[2];
       auto tally = [&](long row) __attribute__((always_inline)) {
-        if constexpr (COUNT) { if (newcell) atomicAdd(cntl + (int)((uint32_t)row >> b.bshift) * K + rep, 1); }
+        if constexpr (COUNT) { if (newcell) atomicAdd(cntl + zb_bin((uint32_t)row, b.bshift, K, rep), 1); }
       };
       if constexpr (C == 1 && sizeof(TT) == 4 && ZIP_PAIR_F32) {
         // fp32 single-channel table (the proposal grids under the reference's table policy): the two x-neighbours of a corner pair are
@@ -1364,7 +1367,7 @@ __device__ __forceinline__ void zip_emit_level(const ZipEnc& a, const ZipBin& b,
 #pragma unroll
       for (int k = 0; k < 3; ++k) pl[k] = cur[k] + ((idx >> k) & 1);
       const uint32_t row = zip_grid_index(hs, res, pl);
-      const int bin = (int)(row >> b.bshift) * K + rep;
+      const int bin = zb_bin((uint32_t)row, b.bshift, K, rep);
       const int slot = atomicAdd(lds_cnt + bin, 1);
       if (WRITE) {
         const long r = lds_base[bin] + slot;
@@ -1507,7 +1510,7 @@ __global__ __launch_bounds__(256) void zip_bin_emit_all_kernel(ZipEnc a, ZipBin 
 #pragma unroll
         for (int k = 0; k < 3; ++k) pl[k] = cur[k] + ((idx >> k) & 1);
         const uint32_t row = zip_grid_index(hs, res, pl);
-        const int bin = (int)(row >> b.bshift) * K + rep;
+        const int bin = zb_bin((uint32_t)row, b.bshift, K, rep);
         const int slot = atomicAdd(cnt + bin, 1);
         const long r = base[bin] + slot;
         if (r < b.capacity) {
@@ -1651,7 +1654,7 @@ __global__ __launch_bounds__(256, NSUB == 8 ? 4 : 3) void zip_bin_write_staged_k
   auto record = [&](int j, int e, int y, int z, float r, bool place) __attribute__((always_inline)) {
     const uint32_t pl[3] = {pg[j][0] + (uint32_t)e, pg[j][1] + (uint32_t)y, pg[j][2] + (uint32_t)z};
     const uint32_t row = zip_grid_index(hs, res, pl);
-    const int bin = (int)(row >> b.bshift) * K + rep;
+    const int bin = zb_bin((uint32_t)row, b.bshift, K, rep);
     const int slot = atomicAdd(cnt + bin, 1);         // count phase: the count; place phase: the slot inside the bin's run (any order will do)
     if (place) stage[off[bin] + slot] = uint2{(row & rmask) | ((unsigned)bin << 14) | ((unsigned)tid << 24), __float_as_uint(r)};
   };
@@ -1681,8 +1684,8 @@ __global__ __launch_bounds__(256, NSUB == 8 ? 4 : 3) void zip_bin_write_staged_k
           const uint32_t pl0[3] = {pg[j][0], pg[j][1] + (uint32_t)(sp & 1), pg[j][2] + (uint32_t)(sp >> 1)};
           const uint32_t pl1[3] = {pg[j][0] + 1u, pl0[1], pl0[2]};
           const uint32_t row0 = zip_grid_index(hs, res, pl0), row1 = zip_grid_index(hs, res, pl1);
-          const int bin0 = (int)(row0 >> b.bshift) * K + rep;
-          int bin1 = (int)(row1 >> b.bshift) * K + rep;
+          const int bin0 = zb_bin((uint32_t)row0, b.bshift, K, rep);
+          int bin1 = zb_bin((uint32_t)row1, b.bshift, K, rep);
           const bool same = bin0 == bin1;
           const int slot0 = atomicAdd(cnt + bin0, same ? 2 : 1);
           int slot1 = slot0 + 1;
@@ -2259,7 +2262,7 @@ __global__ __launch_bounds__(WT) void g3_count_kernel(G3W a) {
       for (int idx = 0; idx < 8; ++idx) {
         const uint32_t pl[3] = {t.pg[j][0] + (idx & 1), t.pg[j][1] + ((idx >> 1) & 1), t.pg[j][2] + (idx >> 2)};
         const uint32_t row = g3_grid_index(hs, res, pow2, pl);
-        atomicAdd(cnt + (int)(row >> a.bshift) * a.K + rep, 1);
+        atomicAdd(cnt + zb_bin((uint32_t)row, a.bshift, a.K, rep), 1);
       }
     }
   }
@@ -2467,7 +2470,7 @@ __global__ __launch_bounds__(G3_WT, G3_WPE_) void g3_write_staged_kernel(G3W a) 
     for (int idx = 0; idx < 8; ++idx) {
       const uint32_t pl[3] = {t.pg[j][0] + (idx & 1), t.pg[j][1] + ((idx >> 1) & 1), t.pg[j][2] + (idx >> 2)};
       const uint32_t row = g3_grid_index(hs, res, pow2, pl);
-      const unsigned o = off[(int)(row >> a.bshift) * a.K + rep];
+      const unsigned o = off[zb_bin((uint32_t)row, a.bshift, a.K, rep)];
       wr[j] |= (o == G3_DIRECT ? 15u : o / NSW) << (4 * idx);
     }
   }
@@ -2498,7 +2501,7 @@ __global__ __launch_bounds__(G3_WT, G3_WPE_) void g3_write_staged_kernel(G3W a) 
           if ((int)wid == w || (wid == 15u && w == 0)) {
             const uint32_t pl[3] = {t.pg[j][0] + (idx & 1), t.pg[j][1] + ((idx >> 1) & 1), t.pg[j][2] + (idx >> 2)};
             const uint32_t row = g3_grid_index(hs, res, pow2, pl);
-            const int bin = (int)(row >> a.bshift) * a.K + rep;
+            const int bin = zb_bin((uint32_t)row, a.bshift, a.K, rep);
             const unsigned slot = (unsigned)atomicAdd(cnt + bin, 1);
             if (wid == 15u) {
               const unsigned r = base[bin] + slot;
@@ -2538,7 +2541,7 @@ __global__ __launch_bounds__(G3_WT, G3_WPE_) void g3_write_staged_kernel(G3W a) 
         if ((int)wid == w || (wid == 15u && w == 0)) {
           const uint32_t pl[3] = {t.pg[j][0] + (idx & 1), t.pg[j][1] + ((idx >> 1) & 1), t.pg[j][2] + (idx >> 2)};
           const uint32_t row = g3_grid_index(hs, res, pow2, pl);
-          const int bin = (int)(row >> a.bshift) * a.K + rep;
+          const int bin = zb_bin((uint32_t)row, a.bshift, a.K, rep);
           const unsigned slot = (unsigned)atomicAdd(cnt + bin, 1);
           unsigned wv_[VW];
           g3_pack<C, HREC>(acc, hmul, wv_);
