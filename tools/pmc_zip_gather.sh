@@ -1,6 +1,6 @@
 #!/bin/bash
 # What bounds path C's featurisation forward (zip_encode_fwd_all_kernel, C = 1 proposal levels and the C = 4 NeRF level): address unit (TA),
-# L1 (TCP), translation (UTCL1), L2 (TCC) and issue counters of the train step, separate rocprofv3 --pmc passes (no trace domains beside
+# L1 (TCP), translation (UTCL1), L2 (TCC) and issue counters (the TA_* passes return nothing on this pool and are not run) of the train step, separate rocprofv3 --pmc passes (no trace domains beside
 # --kernel-trace).  Output: gpurun_out/pmc_zip_gather/{pass}/ + summary.txt (one block per kernel, averages per launch; the derived lines
 # at the end relate them to the launch time and to the scattered-row rate of tools/probes/gather_probe.hip, profiles/r4_a_gather_probe.txt).
 set -u
@@ -8,8 +8,6 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/pmc_zip_gather
 cd /tmp && export TMPDIR=/tmp
 run() { tag=$1; shift; timeout 200 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$tag -o p -- python $ROOT/tools/bench_zip.py --rays 65536 --steps 2 --train-only > /dev/null 2>&1 < /dev/null; }
-run ta1 TA_BUSY_avr TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TA_BUFFER_READ_WAVEFRONTS_sum
-run ta2 TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_ADDR_STALLED_BY_TD_CYCLES_sum
 run tcp1 TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum
 run tcp2 TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum
 run tcp3 TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum TCP_TA_TCP_STATE_READ_sum
@@ -47,12 +45,8 @@ print(f"derived: fabric (EA) read requests {g('TCC_EA0_RDREQ_sum') / 1e6:.1f} M 
       f"({g('TCC_EA0_RDREQ_sum') / SCATTER * 1e6 / us:.2f} of the launch)")
 print(f"derived: L2 requests {g('TCC_REQ_sum') / 1e6:.1f} M = {g('TCC_REQ_sum') / (us * 1e-6) / 1e9:.1f} G/s; hit rate {g('TCC_HIT_sum') / (g('TCC_HIT_sum') + g('TCC_MISS_sum')):.3f}; "
       f"tag stall cycles / request {g('TCC_TAG_STALL_sum') / g('TCC_REQ_sum'):.3f}")
-rdw = g('TA_FLAT_READ_WAVEFRONTS_sum') + (g('TA_BUFFER_READ_WAVEFRONTS_sum') if g('TA_BUFFER_READ_WAVEFRONTS_sum') == g('TA_BUFFER_READ_WAVEFRONTS_sum') else 0)
-print(f"derived: read wavefronts at the TA {rdw / 1e6:.2f} M; L1 line accesses (TCP_TOTAL_CACHE_ACCESSES) {g('TCP_TOTAL_CACHE_ACCESSES_sum') / 1e6:.1f} M = "
-      f"{g('TCP_TOTAL_CACHE_ACCESSES_sum') / max(rdw, 1):.1f} per read wavefront; L1 -> L2 read requests {g('TCP_TCC_READ_REQ_sum') / 1e6:.1f} M "
+print(f"derived: L1 line accesses (TCP_TOTAL_CACHE_ACCESSES) {g('TCP_TOTAL_CACHE_ACCESSES_sum') / 1e6:.1f} M; L1 -> L2 read requests {g('TCP_TCC_READ_REQ_sum') / 1e6:.1f} M "
       f"(L1 hit rate {1 - g('TCP_TCC_READ_REQ_sum') / g('TCP_TOTAL_CACHE_ACCESSES_sum'):.3f})")
-print(f"derived: TA busy (avr over instances) {g('TA_BUSY_avr'):.1f} %; TA busy cycles summed / (CUs x launch cycles) {g('TA_TA_BUSY_sum') / (CUS * cyc):.3f}; "
-      f"address stalled by TC {g('TA_ADDR_STALLED_BY_TC_CYCLES_sum') / (CUS * cyc):.3f}, data stalled by TC {g('TA_DATA_STALLED_BY_TC_CYCLES_sum') / (CUS * cyc):.3f} of the CU-cycles")
 print(f"derived: L1 busy (TCP_GATE_EN2 / TCP_GATE_EN1) {g('TCP_GATE_EN2_sum') / g('TCP_GATE_EN1_sum'):.3f}; L1 line accesses per CU-cycle {g('TCP_TOTAL_CACHE_ACCESSES_sum') / (CUS * cyc):.3f} "
       f"(the tag pipe takes one line per cycle); pending-request stall {g('TCP_PENDING_STALL_CYCLES_sum') / (CUS * cyc):.3f}, TCR->TCP stall {g('TCP_TCR_TCP_STALL_CYCLES_sum') / (CUS * cyc):.3f}, "
       f"read tag-conflict stall {g('TCP_READ_TAGCONFLICT_STALL_CYCLES_sum') / (CUS * cyc):.3f} of the CU-cycles")
